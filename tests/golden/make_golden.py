@@ -1,0 +1,231 @@
+"""Generates the committed golden fixtures from the imported reference (build container only).
+
+    python tests/golden/make_golden.py
+
+The reference (/root/reference, PyTorch, networks/MSTr.py::MSTransception) has no golden vectors
+of its own, so the pins are outputs of the reference itself, run here on CPU
+fp32 with the name-seeded weights of transception_amd/seeded_init.py loaded strict=True:
+
+  model_b2.npz     whole model, B=2, train mode: sampled stage activations, sampled logits, the packed
+                   argmax mask, the top-2 margin, loss / ce / dice, sampled parameter gradients,
+                   updated BatchNorm running statistics; eval-mode logits sample as well
+  train_trace.npz  two SGD steps (lr 0.05, m 0.9, wd 1e-4, cosine T_max=100): loss, ce, dice, lr,
+                   grad norm, post-step parameter checksums
+  modules.npz      per-module forward outputs and input gradients for the sub-modules listed in
+                   SURVEY.md section 8(c), driven by seeded inputs / upstream gradients
+
+Fixtures hold data only (inputs are re-derived from seeds; outputs are sampled at seeded positions
+plus float64 checksums), never reference source.
+"""
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+from ref_shim import import_reference  # noqa: E402
+from transception_amd.seeded_init import (seeded_input, seeded_labels, seeded_state_dict,  # noqa: E402
+                                           seeded_tensor, _stream)
+
+NSAMP = 2048
+
+
+def sample_idx(tag: str, numel: int, n: int = NSAMP) -> np.ndarray:
+    g = _stream(f"sample:{tag}", 3)
+    return g.integers(0, numel, size=min(n, numel), dtype=np.int64)
+
+
+def pack(store: dict, tag: str, t: torch.Tensor):
+    a = t.detach().contiguous().float().reshape(-1).numpy()
+    idx = sample_idx(tag, a.size)
+    store[tag + "/shape"] = np.array(t.shape, dtype=np.int64)
+    store[tag + "/samples"] = a[idx].astype(np.float32)
+    store[tag + "/sum"] = np.array([a.astype(np.float64).sum(), np.abs(a.astype(np.float64)).sum()])
+
+
+GRAD_PROBES = [
+    "backbone.patch_embed1.proj.weight",
+    "backbone.block1.0.attn.keys.weight",
+    "backbone.block1.1.mlp.dwconv.dwconv.weight",
+    "backbone.patch_embed_stage2.patch_embeds.0.patch_conv.bn.weight",
+    "backbone.mhca_stage2.mhca_blks.0.cpe.proj.weight",
+    "backbone.mhca_stage2.mhca_blks.1.crpe.conv_list.2.weight",
+    "backbone.mhca_stage3.mhca_blks.2.MHCA_layers.5.factoratt_crpe.qkv.weight",
+    "backbone.mhca_stage3.InvRes.conv2.bn.bias",
+    "backbone.mhca_stage4.aggregate.conv_h.weight",
+    "backbone.mhca_stage4.aggregate.bn1.weight",
+    "bridge.bridge_layer1.attn.q.weight",
+    "bridge.bridge_layer2.attn.scale_reduce.sr1.weight",
+    "bridge.bridge_layer3.attn.kv.weight",
+    "bridge.bridge_layer4.mixffn3.fc2.weight",
+    "decoder_3.layer_up.expand.weight",
+    "decoder_2.concat_linear.weight",
+    "decoder_1.layer_former_2.mlp.norm1.weight",
+    "decoder_0.layer_up.norm.bias",
+    "decoder_0.last_layer.weight",
+    "decoder_0.last_layer.bias",
+]
+
+
+def whole_model(MST, Dice):
+    out = {}
+    sd = seeded_state_dict()
+    ref = MST(num_classes=9)
+    ref.load_state_dict(sd, strict=True)
+    ref.train()
+    x = torch.from_numpy(seeded_input(2))
+    y_lab = torch.from_numpy(seeded_labels(2))
+    taps = {}
+    ref.backbone.patch_embed1.register_forward_hook(lambda m, i, o: taps.update(patch_embed1=o[0]))
+    def enc_hook(m, i, o):
+        for k, t in enumerate(o):
+            taps[f"enc{k}"] = t.permute(0, 2, 3, 1)
+
+    ref.backbone.register_forward_hook(enc_hook)
+    for k in range(4):
+        getattr(ref.bridge, f"bridge_layer{k + 1}").register_forward_hook(
+            lambda m, i, o, k=k: taps.update({f"bridge{k + 1}": o}))
+    ref.decoder_1.register_forward_hook(lambda m, i, o: taps.update(dec1=o))
+    logits = ref(x)
+    for k, v in taps.items():
+        pack(out, "tap/" + k, v)
+    pack(out, "logits", logits)
+    lg = logits.detach()
+    out["argmax"] = lg.argmax(1).numpy().astype(np.uint8)
+    top2 = lg.topk(2, dim=1).values
+    out["margin_f16"] = (top2[:, 0] - top2[:, 1]).numpy().astype(np.float16)
+    ce = torch.nn.functional.cross_entropy(logits, y_lab)
+    dice = Dice(9)(logits, y_lab, softmax=True)
+    loss = 0.4 * ce + 0.6 * dice
+    loss.backward()
+    out["loss"] = np.array([loss.item(), ce.item(), dice.item()], dtype=np.float64)
+    named = dict(ref.named_parameters())
+    sq = 0.0
+    for n, p in named.items():
+        if p.grad is not None:
+            sq += float((p.grad.double() ** 2).sum())
+    out["grad_norm"] = np.array([math.sqrt(sq)])
+    for n in GRAD_PROBES:
+        pack(out, "grad/" + n, named[n].grad)
+    rsd = ref.state_dict()
+    for k in ("backbone.patch_embed_stage2.patch_embeds.0.patch_conv.bn",
+              "backbone.mhca_stage3.InvRes.norm", "backbone.mhca_stage4.aggregate.bn1"):
+        out["bn/" + k + ".running_mean"] = rsd[k + ".running_mean"].numpy()
+        out["bn/" + k + ".running_var"] = rsd[k + ".running_var"].numpy()
+        out["bn/" + k + ".num_batches_tracked"] = rsd[k + ".num_batches_tracked"].numpy()
+    # eval mode, fresh buffers
+    ref2 = MST(num_classes=9)
+    ref2.load_state_dict(sd, strict=True)
+    ref2.eval()
+    with torch.no_grad():
+        le = ref2(x)
+    pack(out, "logits_eval", le)
+    out["argmax_eval"] = le.argmax(1).numpy().astype(np.uint8)
+    t2 = le.topk(2, dim=1).values
+    out["margin_eval_f16"] = (t2[:, 0] - t2[:, 1]).numpy().astype(np.float16)
+    # 3-channel input path
+    x3 = torch.from_numpy(seeded_input(1, in_ch=3))
+    with torch.no_grad():
+        pack(out, "logits_eval_rgb", ref2(x3))
+    np.savez_compressed(os.path.join(HERE, "model_b2.npz"), **out)
+    print("model_b2: loss", out["loss"], "grad_norm", out["grad_norm"])
+
+
+TRACE_PROBES = ["backbone.patch_embed1.proj.weight", "backbone.mhca_stage2.mhca_blks.0.MHCA_layers.0.mlp.fc1.weight",
+                "backbone.mhca_stage3.aggregate.conv1.weight", "bridge.bridge_layer2.attn.q.weight",
+                "bridge.bridge_layer4.mixffn4.fc2.bias", "decoder_2.layer_former_1.attn.values.weight",
+                "decoder_0.last_layer.weight", "backbone.mhca_stage4.InvRes.conv1.bn.weight"]
+
+
+def train_trace(MST, Dice):
+    out = {}
+    ref = MST(num_classes=9)
+    ref.load_state_dict(seeded_state_dict(), strict=True)
+    ref.train()
+    opt = torch.optim.SGD(ref.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=100)
+    dice_fn = Dice(9)
+    rows = []
+    for step in range(2):
+        x = torch.from_numpy(seeded_input(2, seed=7 + step))
+        lab = torch.from_numpy(seeded_labels(2, seed=7 + step))
+        logits = ref(x)
+        ce = torch.nn.functional.cross_entropy(logits, lab)
+        dice = dice_fn(logits, lab, softmax=True)
+        loss = 0.4 * ce + 0.6 * dice
+        opt.zero_grad()
+        loss.backward()
+        gn = math.sqrt(sum(float((p.grad.double() ** 2).sum()) for p in ref.parameters() if p.grad is not None))
+        opt.step()
+        sched.step()
+        rows.append([loss.item(), ce.item(), dice.item(), opt.param_groups[0]["lr"], gn])
+        named = dict(ref.named_parameters())
+        for n in TRACE_PROBES:
+            a = named[n].detach().double()
+            out[f"step{step}/{n}"] = np.array([a.sum().item(), a.abs().sum().item()])
+    out["trace"] = np.array(rows, dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "train_trace.npz"), **out)
+    print("train_trace:\n", out["trace"])
+
+
+def modules(MST):
+    """Per-module goldens: y = m(x); gx = d(sum(y*g))/dx, on seeded x, g (B=2)."""
+    out = {}
+    ref = MST(num_classes=9)
+    ref.load_state_dict(seeded_state_dict(), strict=True)
+    ref.train()
+    bb, br = ref.backbone, ref.bridge
+
+    def run(tag, fn, shapes, scale=1.0):
+        xs = [torch.from_numpy(seeded_tensor(f"{tag}/x{i}", s, scale)).requires_grad_(True) for i, s in enumerate(shapes)]
+        y = fn(*xs)
+        g = torch.from_numpy(seeded_tensor(f"{tag}/g", tuple(y.shape)))
+        (y * g).sum().backward()
+        pack(out, f"{tag}/y", y)
+        for i, xi in enumerate(xs):
+            pack(out, f"{tag}/gx{i}", xi.grad)
+        print(tag, tuple(y.shape))
+
+    B = 2
+    run("patch_embed1", lambda x: bb.patch_embed1(x)[0], [(B, 3, 224, 224)])
+    run("eff_attn_s1", lambda x: bb.block1[0].attn(x), [(B, 64, 56, 56)])
+    run("eff_attn_d2", lambda x: ref.decoder_2.layer_former_1.attn(x), [(B, 320, 14, 14)])
+    run("eff_block_s1", lambda x: bb.block1[1](x, 56, 56), [(B, 3136, 64)])
+    run("mixffn_s2", lambda x: bb.mhca_stage2.mhca_blks[0].MHCA_layers[0].mlp(x, 28, 28), [(B, 784, 64)])
+    run("mixffn_b4", lambda x: br.bridge_layer2.mixffn4(x, 7, 7), [(B, 49, 512)])
+    run("ripm_s2", lambda x: torch.cat(bb.patch_embed_stage2(x), 1), [(B, 64, 56, 56)])
+    run("resblock_s3", lambda x: bb.mhca_stage3.InvRes(x), [(B, 128, 14, 14)])
+    for s, (C, hw) in zip((2, 3, 4), ((64, 28), (128, 14), (320, 7))):
+        st = getattr(bb, f"mhca_stage{s}")
+        run(f"mhca_block_s{s}", lambda x, st=st, hw=hw: st.mhca_blks[1].MHCA_layers[1](x, (hw, hw)), [(B, hw * hw, C)])
+        run(f"factoratt_s{s}", lambda x, st=st, hw=hw: st.mhca_blks[2].MHCA_layers[0].factoratt_crpe(x, (hw, hw)),
+            [(B, hw * hw, C)])
+        run(f"coordatt_s{s}", lambda x, st=st: st.aggregate(x), [(B, 4 * C, hw, hw)])
+    run("chan_att", lambda x: br.bridge_layer1.attn(x), [(B, 6076, 64)])
+    run("scale_reduce", lambda x: br.bridge_layer2.attn.scale_reduce(x), [(B, 6076, 64)])
+    run("self_att", lambda x: br.bridge_layer3.attn(x), [(B, 6076, 64)])
+    run("bridge_layer1", lambda x: br.bridge_layer1(x), [(B, 6076, 64)])
+    run("bridge_layer4", lambda x: br.bridge_layer4(x), [(B, 6076, 64)])
+    run("dec3", lambda x: ref.decoder_3(x), [(B, 49, 512)])
+    run("dec2", lambda a, b: ref.decoder_2(a, b), [(B, 196, 256), (B, 14, 14, 320)])
+    run("dec0", lambda a, b: ref.decoder_0(a, b), [(B, 3136, 64), (B, 56, 56, 64)])
+    np.savez_compressed(os.path.join(HERE, "modules.npz"), **out)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    MST, Dice = import_reference()
+    which = sys.argv[1:] or ["model", "trace", "modules"]
+    if "model" in which:
+        whole_model(MST, Dice)
+    if "trace" in which:
+        train_trace(MST, Dice)
+    if "modules" in which:
+        modules(MST)
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)))
