@@ -1,0 +1,226 @@
+/*
+ * transception_hip.h -- C ABI of libtransception_hip.so (MI355X / gfx950).
+ *
+ * The drop-in boundary for the TransCeption forward/backward hot path.  The reference
+ * (xmindflow/TransCeption) is 100 % Python on PyTorch and has NO native FFI of its own
+ * (SURVEY.md section 2): every arithmetic step of networks/MSTr.py::MSTransception is an ATen
+ * call.  Each entry point below therefore names the reference *call sites* (file:line in
+ * /root/reference) whose ATen arithmetic it replaces.  The Python host
+ * (transception_amd/_lib.py, ctypes) is the binding a reference maintainer would add; see
+ * INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain pointers + sizes only; all pointers are DEVICE pointers owned by the caller;
+ *  - `stream` is a hipStream_t passed as void*; the library never allocates, frees or
+ *    synchronises; every call is asynchronous on `stream` and capturable in a hipGraph;
+ *  - activations are token-major / NHWC: a map [B,H,W,C] is the token matrix [B*H*W, C];
+ *    `ld*` arguments are row strides in ELEMENTS so that ops can read/write column slices;
+ *  - `dtype` selects the storage type of activations/weights: TC_F32 or TC_BF16; statistics,
+ *    accumulators and every `float*` argument are always fp32;
+ *  - return value: TC_OK (0) or a negative TC_ERR_* code; nothing throws across the ABI.
+ */
+#ifndef TRANSCEPTION_HIP_H
+#define TRANSCEPTION_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { TC_OK = 0, TC_ERR_ARG = -1, TC_ERR_LAUNCH = -2, TC_ERR_UNSUPPORTED = -3 };
+enum { TC_F32 = 0, TC_BF16 = 1 };
+enum { TC_ACT_NONE = 0, TC_ACT_HSWISH = 1, TC_ACT_COORD = 2, TC_ACT_SIGMOID = 3, TC_ACT_GELU = 4 };
+
+/* library identity: returns the ABI version (bumped on any signature change) */
+int tc_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM:  C[b] = alpha * op(A[b]) * op(B[b]) (+ bias) (+ R[b]) ; optional sigmoid ; optional C += .
+ *   op(A) is M x K: transA=0 -> A stored [M,K] (row stride lda); transA=1 -> stored [K,M].
+ *   op(B) is K x N: transB=0 -> B stored [K,N] (row stride ldb); transB=1 -> stored [N,K]
+ *   (the nn.Linear / 1x1-conv weight layout).  Two batch levels: z = b1*nb2 + b2, element
+ *   offsets b1*s?1 + b2*s?2.  splitk > 1 requires accumulate=1 (fp32 atomics into C).
+ * Replaces: every nn.Linear / 1x1 nn.Conv2d / torch.bmm / einsum / `@` on the path --
+ *   MSTr.py:109-111,136-137,141 (EfficientAttention), :856,866-871,883 (FactorAtt),
+ *   :892-900 (MixFFN_skip fc1/fc2), :338,1043-1049 (pw / 1x1 convs), :1333,1342-1346 (CoordAtt),
+ *   :2270-2288,2312-2350 (bridge attention), :190,218,276,281 (decoder), and their autograd
+ *   backward (dX = dY*W, dW = dY^T*X).
+ */
+typedef struct TcGemm {
+    const void* A; const void* B; void* C;
+    const void* bias;            /* [N] or NULL */
+    const void* R;               /* residual, same indexing as C with ldr / sR*, or NULL */
+    int M, N, K;
+    int lda, ldb, ldc, ldr;
+    int transA, transB;
+    int nb1, nb2;                /* batch counts (>=1) */
+    long long sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2;
+    float alpha;
+    int accumulate;              /* C += result */
+    int act;                     /* TC_ACT_NONE or TC_ACT_SIGMOID */
+    int splitk;                  /* >=1 */
+    int dtype;
+    int c_f32;                   /* C (and the accumulate read) is fp32 whatever dtype is: weight gradients */
+    int atomic;                  /* accumulate with fp32 atomics (batches that share one C) */
+} TcGemm;
+int tc_gemm(const TcGemm* g, void* stream);
+
+/* out[c] (+)= sum_b sum_r x[b*sb + r*ldx + c]   (bias gradients; fp32 output).  Replaces the bias-gradient
+ * reductions autograd performs for every Linear/Conv on the path (trainer.py:146). */
+int tc_colsum(const void* x, int rows, int cols, int ldx, int nb, long long sb, float* out, int accumulate, int dtype,
+              void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm over the last dim (C <= 4096), optionally followed by exact-erf GELU.
+ * Replaces nn.LayerNorm at MSTr.py:165,170,303,898(norm1 of MixFFN_skip)+894 GELU,:932-933 (eps 1e-6),
+ *   :199,225,1720,2249,2390-2391 and their backward.
+ * mean/rstd: fp32 [rows] saved for backward.
+ */
+int tc_layernorm_fwd(const void* x, int ldx, const void* gamma, const void* beta, void* y, int ldy,
+                     float* mean, float* rstd, int rows, int C, float eps, int act, int dtype, void* stream);
+/* dx = d/dx ; dgamma/dbeta (fp32 [C]) are ACCUMULATED into (caller zeroes or reuses grad buffers).
+ * If dres != NULL its rows (stride ldres) are added to dx (fan-in of a residual branch). */
+int tc_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx, const void* gamma, const void* beta,
+                     const float* mean, const float* rstd, void* dx, int lddx, const void* dres, int ldres,
+                     float* dgamma, float* dbeta, int rows, int C, int act, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Depthwise k x k convolution on NHWC maps, k in {3,5,7}, stride 1 or 2, padding (k-1)/2,
+ * weight in the PyTorch layout [C,1,k,k], optional bias, optional "+ x" (stride 1 only).
+ * x rows (pixels) have stride ldx elements, y rows ldy, so channel slices of wider buffers work.
+ * Replaces: DWConv MSTr.py:21-31 (+ the skip add at :900), ConvPosEnc :744-752, ConvRelPosEnc
+ *   depthwise 3/5/7 convs :785-797,814-816, DWConv2d_BN.dwconv :328-336, ResBlock.dwconv :1005-1013.
+ */
+int tc_dwconv_fwd(const void* x, int ldx, const void* w, const void* bias, void* y, int ldy,
+                  int B, int H, int W, int C, int k, int stride, int add_input, int dtype, void* stream);
+/* accumulate=1: dx += result */
+int tc_dwconv_bwd_input(const void* dy, int lddy, const void* w, void* dx, int lddx,
+                        int B, int H, int W, int C, int k, int stride, int add_input, int accumulate, int dtype,
+                        void* stream);
+/* dw [C,1,k,k] and db [C] (fp32) are ACCUMULATED into. db may be NULL. */
+int tc_dwconv_bwd_weight(const void* dy, int lddy, const void* x, int ldx, float* dw, float* db,
+                         int B, int H, int W, int C, int k, int stride, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * BatchNorm2d over token rows ([rows, C], statistics over rows) fused with its activation and an
+ * optional residual add:  y = act((x-mean)*rstd*gamma+beta) (+ res).
+ * Replaces nn.BatchNorm2d + Hardswish / silu_swish at MSTr.py:339-340,358-360 (RIPM), :376-401,1045-1049
+ *   (ResBlock / Conv2d_BN), :1335-1336 (CoordAtt bn1 + act) and the residual add :1050.
+ * training=1: batch statistics (biased var), running stats updated with momentum 0.1 and the unbiased
+ *   variance, save_mean/save_rstd [C] written for backward.  training=0: running statistics.
+ * `partial` is caller-provided fp32 scratch of at least tc_bn_scratch_floats(rows, C) floats.
+ */
+long long tc_bn_scratch_floats(int rows, int C);
+int tc_bn_fwd(const void* x, int ldx, const void* gamma, const void* beta, float* running_mean,
+              float* running_var, const void* res, int ldres, void* y, int ldy, float* save_mean,
+              float* save_rstd, float* partial, int rows, int C, float eps, float momentum, int training,
+              int act, int dtype, void* stream);
+/* dgamma/dbeta ACCUMULATED into; dx written (or accumulated into when accumulate=1).
+ * (The residual gradient is dy itself.) */
+int tc_bn_bwd(const void* dy, int lddy, const void* x, int ldx, const void* gamma, const void* beta,
+              const float* save_mean, const float* save_rstd, void* dx, int lddx, float* dgamma,
+              float* dbeta, float* partial, int rows, int C, int act, int accumulate, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Softmax over one axis of a batch of [R, Ccols] matrices (row stride ld, batch stride sb).
+ * axis=1: over the contiguous columns; axis=0: over the rows (per column).
+ * Replaces F.softmax / .softmax at MSTr.py:118-128 (EfficientAttention: keys over N, queries over C),
+ *   :865 (FactorAtt k over N), :2322-2332 (channel attention on the flat re-view), :2283 (scores).
+ */
+int tc_softmax_fwd(const void* x, void* y, int nb, long long sbx, long long sby, int R, int Ccols,
+                   int ldx, int ldy, int axis, int dtype, void* stream);
+int tc_softmax_bwd(const void* dy, const void* y, void* dx, int nb, long long sbdy, long long sby,
+                   long long sbdx, int R, int Ccols, int lddy, int ldy, int lddx, int axis, int accumulate,
+                   int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused single-head attention with spatial-reduction K/V (the Dual Transformer Bridge core):
+ *   O[b] = softmax(Q[b] K[b]^T * scale) V[b],  head dim 64, no score matrix in HBM.
+ *   lse[b, q] = log-sum-exp of the scaled scores (fp32), saved for backward.
+ * Replaces MSTr.py:2281-2287 (M_EfficientSelfAtten: q@k^T*scale -> softmax -> @v) and its backward.
+ */
+int tc_attn_fwd(const void* Q, int ldq, long long sq, const void* K, int ldk, const void* V, int ldv,
+                long long skv, void* O, int ldo, long long so, float* lse, int B, int Nq, int Nk,
+                float scale, int dtype, void* stream);
+/* delta: fp32 scratch [B*Nq].  dQ is written; dK/dV (row strides lddk/lddv, batch stride sdkv) are written, or
+ * added to when accumulate_dkv=1 (several query groups sharing one K/V). */
+int tc_attn_bwd(const void* Q, int ldq, long long sq, const void* K, int ldk, const void* V, int ldv,
+                long long skv, const void* O, int ldo, long long so, const void* dO, int lddo, long long sdo,
+                const float* lse, float* delta, void* dQ, int lddq, long long sdq, void* dK, int lddk,
+                void* dV, int lddv, long long sdkv, int accumulate_dkv, int B, int Nq, int Nk, float scale,
+                int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Elementwise / layout kernels.
+ */
+/* out = alpha*a + b*c (rows x cols, each with its own row stride).  FactorAtt merge MSTr.py:877, 821. */
+int tc_fma3_fwd(const void* a, int lda, const void* b, int ldb, const void* c, int ldc, void* out, int ldo,
+                int rows, int cols, float alpha, int dtype, void* stream);
+/* da = alpha*dout ; db (+)= dout*c ; dc = dout*b.  db_accumulate adds into db (q receives two grads). */
+int tc_fma3_bwd(const void* dout, int lddo, const void* b, int ldb, const void* c, int ldc, void* da, int ldda,
+                void* db, int lddb, int db_accumulate, void* dc, int lddc, int rows, int cols, float alpha,
+                int dtype, void* stream);
+/* y = a + b */
+int tc_add(const void* a, int lda, const void* b, int ldb, void* y, int ldy, int rows, int cols, int dtype,
+           void* stream);
+/* dz = dy * s * (1 - s) given s = sigmoid(z) */
+int tc_sigmoid_bwd(const void* dy, const void* s, void* dz, long long n, int dtype, void* stream);
+/* batched strided copy: dst[b, r, c] (+)= src[b, r, c]  (batch strides sb*, row strides ld*, in elements).
+ * The torch.cat / slicing glue of MSTr.py:2231,2237 (raw stage-4 tokens into the K/V source). */
+int tc_copy3d(const void* src, long long sbs, int lds, void* dst, long long sbd, int ldd, int nb, int rows, int cols,
+              int accumulate, int dtype, void* stream);
+/* batched transpose: dst[b, c, r] = src[b, r, c]  (logits NHWC -> NCHW, MSTr.py:281 permute) */
+int tc_transpose(const void* src, void* dst, int nb, int R, int Ccols, int dtype, void* stream);
+
+/* CoordAtt pooling MSTr.py:1327-1332.  pooled/att rows: first B*H rows (b,h) = mean over w, then B*W rows (b,w) = mean over h
+ * (a row permutation of the reference's per-image cat; BatchNorm statistics over rows are unaffected). */
+int tc_coord_pool_fwd(const void* x, void* pooled, int B, int H, int W, int C, int dtype, void* stream);
+int tc_coord_pool_bwd(const void* dpooled, void* dx, int B, int H, int W, int C, int accumulate, int dtype,
+                      void* stream);
+/* CoordAtt gating MSTr.py:1345: y = x * a_w[b,w,:] * a_h[b,h,:]; att rows as for pooling ([B*H] a_h then [B*W] a_w) */
+int tc_coord_gate_fwd(const void* x, const void* att, void* y, int B, int H, int W, int C, int dtype,
+                      void* stream);
+/* dx (+)= dy*a_w*a_h ; datt[b,h] = sum_w dy*x*a_w ; datt[b,H+w] = sum_h dy*x*a_h */
+int tc_coord_gate_bwd(const void* dy, const void* x, const void* att, void* dx, int dx_accumulate,
+                      void* datt, int B, int H, int W, int C, int dtype, void* stream);
+
+/* Pixel shuffle of PatchExpand / FinalPatchExpand_X4, MSTr.py:196-197,222-223:
+ *   fwd: in [B,H,W,p*p*c] -> out [B,H*p,W*p,c] with channel index (p1*p + p2)*c + cc ; inverse=1 undoes it. */
+int tc_pixel_shuffle(const void* in, void* out, int B, int H, int W, int p, int c, int inverse, int dtype,
+                     void* stream);
+/* Non-overlapping patch gather for the k=s patchify convs of Scale_reduce, MSTr.py:2215-2217,2233-2235:
+ *   fwd: map [B,H,W,C] (batch stride sb_map, pixel stride ld_map) -> cols [B*(H/k)*(W/k), k*k*C] ordered (c,ky,kx) = the conv weight's [O, I*k*k] view;
+ *   inverse=1 scatters cols back (the input gradient); inverse=2 adds them onto the map. */
+int tc_patchify(const void* map, long long sb_map, int ld_map, void* cols, int B, int H, int W, int C, int k,
+                int inverse, int dtype, void* stream);
+/* Channel de-interleave of Scale_reduce (Appendix C.4): out[b, g*P+pos, c] = in[b, pos, c*mult+g];
+ *   out rows have stride ldo and batch stride sbo (written straight into the [B,784,64] K/V source buffer). */
+int tc_sr_deinterleave(const void* in, void* out, long long sbo, int ldo, int B, int P, int C, int mult,
+                       int inverse, int dtype, void* stream);
+/* im2col for the 7x7 stride-4 pad-3 stem conv (MSTr.py:296,300) from an NCHW fp32/bf16 image with in_ch
+ * channels (1 => the reference's x.repeat(1,3,1,1), MSTr.py:2828-2829, is folded in):
+ *   cols [B*Ho*Wo, ldc] with column (ci*49 + ky*7 + kx), ci in 0..2, zero padded up to ldc. */
+int tc_stem_im2col(const void* img, void* cols, int ldc, int B, int in_ch, int H, int W, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Training-step kernels (trainer.py:123-153, utils.py:11-47).
+ */
+/* Per-pixel softmax over classes; accumulates into sums[0]=sum CE, sums[1+3c..]=intersect_c, y_sum_c, z_sum_c.
+ * logits NCHW [B,ncls,HW] (storage dtype), labels int64 [B,HW]; prob (fp32 [B,ncls,HW]) saved for backward. */
+int tc_seg_loss_fwd(const void* logits, const long long* labels, float* prob, float* sums, int B, int ncls,
+                    int HW, int dtype, void* stream);
+/* dlogits for loss = w_ce*CE_mean + w_dice*mean_c(1 - (2I+eps)/(Z+Y+eps)); sums are the (all-reduced) forward sums;
+ * n_pix_global = global pixel count for the CE mean. */
+int tc_seg_loss_bwd(const float* prob, const long long* labels, const float* sums, void* dlogits, int B, int ncls,
+                    int HW, float w_ce, float w_dice, float n_pix_global, float gscale, const float* gscale_dev, int dtype,
+                    void* stream);
+/* Fused SGD with momentum and weight decay over flat fp32 buffers (torch.optim.SGD semantics, trainer.py:125):
+ *   g = grad*gscale + wd*p ; buf = first ? g : mom*buf + g ; p -= lr*buf. */
+int tc_sgd_step(float* p, const float* grad, float* buf, long long n, float lr, float momentum, float wd,
+                float gscale, int first, void* stream);
+/* dst(bf16) = src(fp32) and back, for bf16 working copies of fp32 master weights */
+int tc_cast(const void* src, void* dst, long long n, int src_dtype, int dst_dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRANSCEPTION_HIP_H */

@@ -1,0 +1,313 @@
+"""Model-level parity on the MI355X, through the nn.Module surface and the C ABI.
+
+ * per-module: each HIP block (forward + backward) against the committed reference goldens (tests/golden/modules.npz,
+   produced by the reference itself) on the same seeded inputs;
+ * whole model (B=2, 224^2, fp32 path): logits / loss / gradients / BatchNorm buffers against tests/golden/model_b2.npz,
+   and against the CPU oracle run in the same process; eval mode; 3-channel input;
+ * two SGD steps against the reference's train trace (tests/golden/train_trace.npz);
+ * sizes the reference cannot run (384^2) against the CPU oracle; bf16 storage path with its own stated budget.
+Tolerance for the fp32 path: 1e-3 abs on logits is the contract (BASELINE.json); the tests assert 1e-4.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from golden_util import check_packed, load  # noqa: E402
+from transception_amd.seeded_init import seeded_input, seeded_labels, seeded_state_dict, seeded_tensor  # noqa: E402
+
+DEV = "cuda:0"
+SIDES = [56, 28, 14, 7]
+MULT = [1, 2, 5, 8]
+NTOK = [s * s * m for s, m in zip(SIDES, MULT)]
+N6 = sum(NTOK)
+
+
+@pytest.fixture(scope="module")
+def model():
+    from transception_amd import MSTransception
+    m = MSTransception(num_classes=9)
+    m.load_state_dict(seeded_state_dict(), strict=True)
+    m.to(DEV)
+    m.train()
+    return m
+
+
+def _graph(model, record=True):
+    from transception_amd.engine import Graph
+    model._ensure_flat(torch.device(DEV))
+    model._used_views = {}
+    return Graph(torch.float32, torch.device(DEV), training=True, record=record)
+
+
+def _var(t, requires_grad=True):
+    from transception_amd.engine import Var
+    return Var(t.to(DEV).contiguous(), requires_grad=requires_grad)
+
+
+def _stage_major(x_img: torch.Tensor, B: int) -> torch.Tensor:
+    """[B, 6076, 64] (per-image concat of the four scales, the reference layout) -> stage-major [B*6076, 64]."""
+    parts, off = [], 0
+    for n in NTOK:
+        parts.append(x_img[:, off:off + n].reshape(B * n, 64))
+        off += n
+    return torch.cat(parts, 0)
+
+
+def _image_major(x_st: torch.Tensor, B: int) -> torch.Tensor:
+    parts, r = [], 0
+    for n in NTOK:
+        parts.append(x_st[r:r + B * n].reshape(B, n, 64))
+        r += B * n
+    return torch.cat(parts, 1)
+
+
+def _R(B):
+    R = [0]
+    for n in NTOK:
+        R.append(R[-1] + B * n)
+    return R
+
+
+def _tok(x):      # NCHW -> [B*H*W, C]
+    B, C, H, W = x.shape
+    return x.permute(0, 2, 3, 1).reshape(B * H * W, C)
+
+
+def _untok(t, B, H, W):
+    return t.reshape(B, H, W, -1).permute(0, 3, 1, 2)
+
+
+def _finish(G, outs, gys):
+    for o, g in zip(outs, gys):
+        assert o.is_whole
+        r = o.root
+        r.grad_t = g.to(DEV).contiguous().view(r.rows, r.cols)
+        r.whole_written = True
+    G.backward()
+    torch.cuda.synchronize()
+
+
+def test_modules_against_reference_goldens(model):
+    import transception_amd.model as MM
+    gold = load("modules.npz")
+    B = 2
+    bb = "backbone"
+    R = _R(B)
+
+    def run(tag, shapes, to_in, fn, from_out, to_gout, from_gin, atol=3e-5, check_gx=True):
+        xs = [torch.from_numpy(seeded_tensor(f"{tag}/x{i}", s)) for i, s in enumerate(shapes)]
+        G = _graph(model)
+        vs = [_var(to_in[i](x)) for i, x in enumerate(xs)]
+        out = fn(G, *vs)
+        y = from_out(out.data.float().cpu())
+        check_packed(gold, f"{tag}/y", y, atol=atol, rtol=2e-5)
+        g = torch.from_numpy(seeded_tensor(f"{tag}/g", tuple(y.shape)))
+        _finish(G, [out], [to_gout(g)])
+        if check_gx:
+            for i, v in enumerate(vs):
+                check_packed(gold, f"{tag}/gx{i}", from_gin[i](G.grad_of(v).float().cpu()), atol=atol, rtol=3e-4)
+
+    ident = lambda t: t
+    tok3 = lambda t: t.reshape(-1, t.shape[-1])
+    # EfficientAttention / EfficientTransformerBlock / MixFFN
+    run("eff_attn_s1", [(B, 64, 56, 56)], [_tok], lambda G, x: MM._eff_attention(model, G, x, f"{bb}.block1.0.attn", B, 3136),
+        lambda o: _untok(o, B, 56, 56), _tok, [lambda g: _untok(g, B, 56, 56)])
+    run("eff_attn_d2", [(B, 320, 14, 14)], [_tok], lambda G, x: MM._eff_attention(model, G, x, "decoder_2.layer_former_1.attn", B, 196),
+        lambda o: _untok(o, B, 14, 14), _tok, [lambda g: _untok(g, B, 14, 14)])
+    run("eff_block_s1", [(B, 3136, 64)], [tok3], lambda G, x: MM._eff_block(model, G, x, f"{bb}.block1.1", B, 56, 56),
+        lambda o: o.reshape(B, 3136, 64), tok3, [lambda g: g.reshape(B, 3136, 64)])
+    run("mixffn_s2", [(B, 784, 64)], [tok3],
+        lambda G, x: MM._mixffn(model, G, x, f"{bb}.mhca_stage2.mhca_blks.0.MHCA_layers.0.mlp", B, 28, 28, None),
+        lambda o: o.reshape(B, 784, 64), tok3, [lambda g: g.reshape(B, 784, 64)])
+    run("mixffn_b4", [(B, 49, 512)], [tok3], lambda G, x: MM._mixffn(model, G, x, "bridge.bridge_layer2.mixffn4", B, 7, 7, None),
+        lambda o: o.reshape(B, 49, 512), tok3, [lambda g: g.reshape(B, 49, 512)])
+    # ResBlock, MB blocks, IFF
+    run("resblock_s3", [(B, 128, 14, 14)], [_tok],
+        lambda G, x: MM._resblock(model, G, x, f"{bb}.mhca_stage3.InvRes", B, 14, G.new(B * 196, 128)),
+        lambda o: _untok(o, B, 14, 14), _tok, [lambda g: _untok(g, B, 14, 14)], atol=1e-4)
+    for s, (C, hw) in zip((2, 3, 4), ((64, 28), (128, 14), (320, 7))):
+        st = f"{bb}.mhca_stage{s}"
+        run(f"mhca_block_s{s}", [(B, hw * hw, C)], [tok3],
+            lambda G, x, st=st, hw=hw: MM._mhca_block(model, G, x, f"{st}.mhca_blks.1.MHCA_layers.1", f"{st}.mhca_blks.1", B, hw),
+            lambda o, hw=hw, C=C: o.reshape(B, hw * hw, C), tok3, [lambda g, hw=hw, C=C: g.reshape(B, hw * hw, C)])
+        run(f"factoratt_s{s}", [(B, hw * hw, C)], [tok3],
+            lambda G, x, st=st, hw=hw: MM._factor_att(model, G, x, f"{st}.mhca_blks.2.MHCA_layers.0", f"{st}.mhca_blks.2", B, hw),
+            lambda o, hw=hw, C=C: o.reshape(B, hw * hw, C), tok3, [lambda g, hw=hw, C=C: g.reshape(B, hw * hw, C)])
+        run(f"coordatt_s{s}", [(B, 4 * C, hw, hw)], [_tok],
+            lambda G, x, st=st, hw=hw: MM._coord_att(model, G, x, f"{st}.aggregate", B, hw, G.new(B * hw * hw, model._index[
+                f"{st}.aggregate.conv_in_out.weight"][1][0])),
+            lambda o, hw=hw: _untok(o, B, hw, hw), _tok, [lambda g, hw=hw: _untok(g, B, hw, hw)], atol=1e-4)
+    # bridge pieces: inputs are the reference's image-major token matrix, the engine works stage-major
+    sm, im = (lambda t: _stage_major(t, B)), (lambda t: _image_major(t, B))
+    run("chan_att", [(B, N6, 64)], [sm], lambda G, x: MM._channel_att(model, G, x, None, "bridge.bridge_layer1.attn", B, NTOK, R, N6),
+        im, sm, [im], atol=1e-4)
+    run("scale_reduce", [(B, N6, 64)], [sm],
+        lambda G, x: MM._scale_reduce(model, G, x, "bridge.bridge_layer2.attn.scale_reduce", B, SIDES, NTOK, R),
+        lambda o: o.reshape(B, 784, 64), tok3, [im])
+    for fused in (False, True):
+        model.use_fused_attention = fused
+
+        def self_att(G, x):
+            G.use_fused_attention = fused
+            return MM._self_att(model, G, x, None, "bridge.bridge_layer3.attn", B, SIDES, NTOK, R, N6)
+        run("self_att", [(B, N6, 64)], [sm], self_att, im, sm, [im], atol=1e-4)
+    for li in (1, 4):
+        def layer(G, x, li=li):
+            G.use_fused_attention = True
+            return MM._bridge_layer(model, G, x, li, B, SIDES, NTOK, R, N6)
+        run(f"bridge_layer{li}", [(B, N6, 64)], [sm], layer, im, sm, [im], atol=2e-4)
+    # decoder
+    run("dec3", [(B, 49, 512)], [tok3], lambda G, x: MM._patch_expand(model, G, x, "decoder_3.layer_up", B, 7, 2),
+        lambda o: o.reshape(B, 196, 256), tok3, [lambda g: g.reshape(B, 49, 512)])
+    run("dec2", [(B, 196, 256), (B, 14, 14, 320)], [tok3, tok3], lambda G, a, b: MM._decoder(model, G, a, b, "decoder_2", B, 14, False),
+        lambda o: o.reshape(B, 784, 160), tok3, [lambda g: g.reshape(B, 196, 256), lambda g: g.reshape(B, 14, 14, 320)], atol=1e-4)
+    run("dec0", [(B, 3136, 64), (B, 56, 56, 64)], [tok3, tok3], lambda G, a, b: MM._decoder(model, G, a, b, "decoder_0", B, 56, True),
+        lambda o: o.reshape(B, 9, 224, 224), lambda g: g.reshape(B * 9, 224 * 224),
+        [lambda g: g.reshape(B, 3136, 64), lambda g: g.reshape(B, 56, 56, 64)], atol=1e-4)
+
+
+def test_ripm_against_reference_golden(model):
+    import transception_amd.model as MM
+    gold = load("modules.npz")
+    B = 2
+    x = torch.from_numpy(seeded_tensor("ripm_s2/x0", (B, 64, 56, 56)))
+    G = _graph(model)
+    xv = _var(_tok(x))
+    outs, side = MM._ripm(model, G, xv, "backbone.patch_embed_stage2", B, 56)
+    assert side == 28
+    y = torch.cat([_untok(o.data.float().cpu(), B, 28, 28) for o in outs], 1)
+    check_packed(gold, "ripm_s2/y", y, atol=1e-4, rtol=2e-5)
+    g = torch.from_numpy(seeded_tensor("ripm_s2/g", tuple(y.shape)))
+    # all three chained outputs receive an upstream gradient (they are consumed by three MB branches)
+    for i, o in enumerate(outs):
+        gi, acc = G.wgrad(o)
+        assert acc == 0
+        gi.copy_(_tok(g[:, 64 * i:64 * (i + 1)]).to(DEV))
+    G.backward()
+    check_packed(gold, "ripm_s2/gx0", _untok(G.grad_of(xv).float().cpu(), B, 56, 56), atol=1e-4, rtol=3e-4)
+
+
+def test_stem_against_reference_golden(model):
+    gold = load("modules.npz")
+    import transception_amd.model as MM
+    x = torch.from_numpy(seeded_tensor("patch_embed1/x0", (2, 3, 224, 224)))
+    G = _graph(model, record=False)
+    cols = G.stem_im2col(x.to(DEV), 2, 3, 224, 224)
+    W, b = MM._lin(model, G, "backbone.patch_embed1.proj")
+    t = MM._ln(model, G, G.linear(cols.colslice(0, 147), W, b), "backbone.patch_embed1.norm")
+    check_packed(gold, "patch_embed1/y", t.data.float().cpu().reshape(2, 3136, 64), atol=3e-5, rtol=2e-5)
+
+
+def _fresh(dtype=torch.float32):
+    from transception_amd import MSTransception
+    m = MSTransception(num_classes=9)
+    m.load_state_dict(seeded_state_dict(), strict=True)
+    m.to(DEV)
+    m.set_compute_dtype(dtype)
+    return m
+
+
+def test_whole_model_train_step_vs_reference_golden_and_oracle():
+    from oracle.transception_oracle import TransCeptionOracle, ce_dice_loss, load_params
+    from transception_amd.train import SegLoss
+    g = load("model_b2.npz")
+    m = _fresh().train()
+    x = torch.from_numpy(seeded_input(2))
+    lab = torch.from_numpy(seeded_labels(2))
+    logits = m(x.to(DEV))
+    assert logits.dtype == torch.float32 and tuple(logits.shape) == (2, 9, 224, 224)
+    lc = logits.detach().cpu()
+    check_packed(g, "logits", lc, atol=1e-4)                                     # contract: 1e-3
+    safe = g["margin_f16"].astype(np.float32) > 2e-4
+    assert np.array_equal(lc.argmax(1).numpy().astype(np.uint8)[safe], g["argmax"][safe]) and safe.mean() > 0.99
+    loss, ce, dice = SegLoss(9)(logits, lab.to(DEV))
+    np.testing.assert_allclose([loss.item(), ce.item(), dice.item()], g["loss"], rtol=0, atol=2e-5)
+    loss.backward()
+    named = dict(m.named_parameters())
+    gn = math.sqrt(sum(float((p.grad.double() ** 2).sum()) for p in m.parameters() if p.grad is not None))
+    assert abs(gn - g["grad_norm"][0]) <= 2e-4 * g["grad_norm"][0]
+    assert sum(1 for p in m.parameters() if p.grad is None) == 332                  # the reference's grad-less set
+    for key in [k[5:-6] for k in g.files if k.startswith("grad/") and k.endswith("/shape")]:
+        check_packed(g, "grad/" + key, named[key].grad.cpu(), atol=2e-6, rtol=2e-3, sum_rtol=1e-3)
+    sd = m.state_dict()
+    for key in [k[3:] for k in g.files if k.startswith("bn/")]:
+        np.testing.assert_allclose(sd[key].cpu().numpy(), g["bn/" + key], rtol=1e-4, atol=1e-5)
+    # and against the oracle evaluated here on the host CPU (same inputs, same weights)
+    orc = TransCeptionOracle(load_params(seeded_state_dict(), requires_grad=True), 9, training=True)
+    lo = orc(x)
+    assert (lo.detach() - lc).abs().max().item() < 1e-4
+    ol, _, _ = ce_dice_loss(lo, lab, 9)
+    ol.backward()
+    for key in ("bridge.bridge_layer2.attn.kv.weight", "backbone.mhca_stage3.mhca_blks.0.crpe.conv_list.1.weight",
+                "decoder_0.layer_up.expand.weight", "backbone.patch_embed1.proj.bias"):
+        ref = orc.P[key].grad
+        got = named[key].grad.cpu()
+        assert (got - ref).abs().max().item() <= 2e-6 + 2e-3 * ref.abs().max().item(), key
+
+
+def test_whole_model_eval_and_rgb():
+    g = load("model_b2.npz")
+    m = _fresh().eval()
+    with torch.no_grad():
+        le = m(torch.from_numpy(seeded_input(2)).to(DEV)).cpu()
+        check_packed(g, "logits_eval", le, atol=1e-4)
+        safe = g["margin_eval_f16"].astype(np.float32) > 2e-4
+        assert np.array_equal(le.argmax(1).numpy().astype(np.uint8)[safe], g["argmax_eval"][safe])
+        check_packed(g, "logits_eval_rgb", m(torch.from_numpy(seeded_input(1, in_ch=3)).to(DEV)).cpu(), atol=1e-4)
+    sd = m.state_dict()
+    ref = seeded_state_dict()
+    assert list(sd.keys()) == list(ref.keys())
+    for k in ("backbone.mhca_stage2.mhca_blks.0.cpe.proj.weight", "bridge.bridge_layer3.attn.scale_reduce.sr1.weight",
+              "backbone.patch_embed_stage3.patch_embeds.1.patch_conv.bn.running_var"):
+        assert torch.equal(sd[k].cpu(), ref[k])
+
+
+def test_train_trace_two_sgd_steps():
+    from transception_amd.train import FusedSGD, SegLoss, cosine_lr, train_step
+    g = load("train_trace.npz")
+    m = _fresh().train()
+    opt = FusedSGD(m, lr=0.05, momentum=0.9, weight_decay=1e-4)
+    loss_fn = SegLoss(9)
+    for step in range(2):
+        x = torch.from_numpy(seeded_input(2, seed=7 + step)).to(DEV)
+        lab = torch.from_numpy(seeded_labels(2, seed=7 + step)).to(DEV)
+        loss, ce, dice = train_step(m, loss_fn, opt, x, lab)
+        opt.lr = cosine_lr(0.05, step + 1, 100)
+        np.testing.assert_allclose([loss.item(), ce.item(), dice.item(), opt.lr], g["trace"][step][:4], rtol=5e-5, atol=2e-5)
+        named = dict(m.named_parameters())
+        for key in [k.split("/", 1)[1] for k in g.files if k.startswith(f"step{step}/")]:
+            a = named[key].detach().double().cpu()
+            np.testing.assert_allclose([a.sum().item(), a.abs().sum().item()], g[f"step{step}/{key}"], rtol=2e-5, atol=2e-4)
+
+
+def test_size_384_against_oracle():
+    """The reference is hard-wired to 224 (MSTr.py:2228-2231,2394-2397); for other sizes the oracle, pinned at 224, is the check."""
+    from oracle.transception_oracle import TransCeptionOracle, load_params
+    m = _fresh().eval()
+    x = torch.from_numpy(seeded_input(1, in_ch=3, size=384))
+    with torch.no_grad():
+        got = m(x.to(DEV)).cpu()
+        want = TransCeptionOracle(load_params(seeded_state_dict()), 9, training=False)(x)
+    assert tuple(got.shape) == (1, 9, 384, 384)
+    assert (got - want).abs().max().item() < 2e-4
+
+
+def test_bf16_storage_budget():
+    """bf16 storage / fp32 accumulate has no reference; budget: max |dlogit| <= 0.15, >= 98.5 % mask agreement."""
+    g = load("model_b2.npz")
+    m = _fresh(torch.bfloat16).eval()
+    with torch.no_grad():
+        le = m(torch.from_numpy(seeded_input(2)).to(DEV)).cpu()
+    idx_err = np.abs(le.reshape(-1).numpy()[__import__("golden_util").sample_idx("logits_eval", le.numel())] - g["logits_eval/samples"])
+    assert idx_err.max() < 0.15, idx_err.max()
+    assert (le.argmax(1).numpy().astype(np.uint8) == g["argmax_eval"]).mean() > 0.985
+
+
+def test_no_cpu_fallback():
+    from transception_amd import MSTransception
+    with pytest.raises(RuntimeError):
+        MSTransception(9)(torch.zeros(1, 1, 224, 224))

@@ -1,0 +1,357 @@
+"""Per-kernel parity on the MI355X: every C-ABI op (forward + gradient kernels, driven through engine.Graph)
+against a plain fp32 PyTorch-CPU evaluation of the same math on the same seeded inputs.
+
+Tolerances are for the fp32 path: 2e-5 abs + 2e-5 rel on activations, 1e-4 rel on reductions over >1e4 terms.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from transception_amd._lib import ACT_COORD, ACT_GELU, ACT_HSWISH, ACT_NONE, ACT_SIGMOID  # noqa: E402
+from transception_amd.seeded_init import seeded_tensor  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def T(tag, shape, scale=1.0):
+    return torch.from_numpy(seeded_tensor("ops/" + tag, shape, scale))
+
+
+def close(got, want, atol=2e-5, rtol=2e-5, what=""):
+    got = got.detach().float().cpu()
+    want = want.detach().float()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    err = (got - want).abs()
+    tol = atol + rtol * want.abs()
+    assert bool((err <= tol).all()), f"{what}: max err {err.max().item():.3e}, ref max {want.abs().max().item():.3e}"
+
+
+@pytest.fixture()
+def G():
+    from transception_amd.engine import Graph
+    return Graph(torch.float32, torch.device(DEV), training=True, record=True)
+
+
+def mkP(t):
+    from transception_amd.engine import P
+    d = t.to(DEV).contiguous()
+    return P(d, torch.zeros_like(d, dtype=torch.float32))
+
+
+def mkV(G, t, requires_grad=True):
+    from transception_amd.engine import Var
+    return Var(t.to(DEV).contiguous(), requires_grad=requires_grad)
+
+
+def run_bwd(G, out, gy):
+    out.root.grad_t = gy.to(DEV).contiguous().view(out.rows, out.cols)
+    out.root.whole_written = True
+    G.backward()
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("M,N,K,bias,res,act", [(100, 64, 64, True, True, ACT_NONE), (300, 200, 147, True, False, ACT_NONE),
+                                                 (257, 9, 64, True, False, ACT_NONE), (64, 320, 20, True, False, ACT_SIGMOID),
+                                                 (1568, 256, 64, False, False, ACT_NONE), (98, 2048, 512, True, True, ACT_NONE)])
+def test_linear(G, M, N, K, bias, res, act):
+    x, w = T(f"lin.x{M}.{K}", (M, K)), T(f"lin.w{N}.{K}", (N, K), 1 / math.sqrt(K))
+    b = T(f"lin.b{N}", (N,), 0.1) if bias else None
+    r = T(f"lin.r{M}.{N}", (M, N)) if res else None
+    gy = T(f"lin.g{M}.{N}", (M, N))
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    br = b.clone().requires_grad_() if bias else None
+    rr = r.clone().requires_grad_() if res else None
+    y = F.linear(xr, wr, br)
+    if res:
+        y = y + rr
+    if act == ACT_SIGMOID:
+        y = torch.sigmoid(y)
+    y.backward(gy)
+    xv, W = mkV(G, x), mkP(w)
+    Bp = mkP(b) if bias else None
+    rv = mkV(G, r) if res else None
+    out = G.linear(xv, W, Bp, residual=rv, act=act)
+    close(out.data, y, what="y")
+    run_bwd(G, out, gy)
+    close(G.grad_of(xv), xr.grad, 5e-5, 5e-5, "dx")
+    close(W.grad, wr.grad, 1e-4, 1e-4, "dW")
+    if bias:
+        close(Bp.grad, br.grad, 1e-4, 1e-4, "db")
+    if res:
+        close(G.grad_of(rv), rr.grad, what="dres")
+
+
+def test_linear_big_tiles_and_splitk(G):
+    M, N, K = 4096, 256, 64
+    x, w, gy = T("linb.x", (M, K)), T("linb.w", (N, K), 0.125), T("linb.g", (M, N))
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    y = F.linear(xr, wr)
+    y.backward(gy)
+    xv, W = mkV(G, x), mkP(w)
+    out = G.linear(xv, W)
+    close(out.data, y, what="y")
+    run_bwd(G, out, gy)
+    close(G.grad_of(xv), xr.grad, 5e-5, 5e-5, "dx")
+    close(W.grad, wr.grad, 2e-4, 2e-4, "dW")
+
+
+@pytest.mark.parametrize("tA,tB", [(0, 0), (0, 1), (1, 0)])
+def test_bmm_two_level_batches(G, tA, tB):
+    nb1, nb2, M, N, K = 2, 3, 40, 24, 50
+    a = T(f"bmm.a{tA}", (nb1, nb2, K, M) if tA else (nb1, nb2, M, K))
+    b = T(f"bmm.b{tB}", (nb1, nb2, N, K) if tB else (nb1, nb2, K, N))
+    gy = T("bmm.g", (nb1, nb2, M, N))
+    ar, br = a.clone().requires_grad_(), b.clone().requires_grad_()
+    y = 0.5 * ((ar.transpose(-1, -2) if tA else ar) @ (br.transpose(-1, -2) if tB else br))
+    y.backward(gy)
+    av, bv = mkV(G, a.reshape(-1, a.shape[-1])), mkV(G, b.reshape(-1, b.shape[-1]))
+    out = G.new(nb1 * nb2 * M, N)
+    ra, rb = a.shape[-2], b.shape[-2]
+    G.bmm(av, bv, out, M, N, K, tA, tB, nb1=nb1, nb2=nb2, sA=(nb2 * ra * av.cols, ra * av.cols),
+          sB=(nb2 * rb * bv.cols, rb * bv.cols), sC=(nb2 * M * N, M * N), alpha=0.5)
+    close(out.data.view(nb1, nb2, M, N), y, what="y")
+    run_bwd(G, out, gy.reshape(-1, N))
+    close(G.grad_of(av).view(a.shape), ar.grad, 5e-5, 5e-5, "dA")
+    close(G.grad_of(bv).view(b.shape), br.grad, 5e-5, 5e-5, "dB")
+
+
+@pytest.mark.parametrize("rows,C,eps,act", [(50, 64, 1e-5, ACT_NONE), (33, 160, 1e-6, ACT_NONE), (77, 256, 1e-5, ACT_GELU),
+                                            (9, 2048, 1e-5, ACT_GELU), (1000, 320, 1e-5, ACT_NONE)])
+def test_layernorm(G, rows, C, eps, act):
+    x, g, b, gy = T(f"ln.x{rows}", (rows, C), 2.0), T(f"ln.g{C}", (C,)) * 0.2 + 1, T(f"ln.b{C}", (C,), 0.3), T(f"ln.gy{rows}", (rows, C))
+    xr, gr, br = x.clone().requires_grad_(), g.clone().requires_grad_(), b.clone().requires_grad_()
+    y = F.layer_norm(xr, (C,), gr, br, eps)
+    if act == ACT_GELU:
+        y = F.gelu(y)
+    y.backward(gy)
+    xv, gp, bp = mkV(G, x), mkP(g), mkP(b)
+    out = G.layernorm(xv, gp, bp, eps, act)
+    close(out.data, y, what="y")
+    run_bwd(G, out, gy)
+    close(G.grad_of(xv), xr.grad, 5e-5, 5e-5, "dx")
+    close(gp.grad, gr.grad, 2e-4, 2e-4, "dgamma")
+    close(bp.grad, br.grad, 2e-4, 2e-4, "dbeta")
+
+
+@pytest.mark.parametrize("C,H,k,stride,bias,add", [(64, 12, 3, 1, True, True), (64, 12, 3, 2, False, False), (24, 9, 5, 1, True, False),
+                                                    (120, 7, 7, 1, True, False), (256, 14, 3, 1, True, True), (16, 28, 3, 1, True, False)])
+def test_dwconv(G, C, H, k, stride, bias, add):
+    B = 2
+    x = T(f"dw.x{C}.{H}", (B, H, H, C))
+    w = T(f"dw.w{C}.{k}", (C, 1, k, k), 0.3)
+    b = T(f"dw.b{C}", (C,), 0.1) if bias else None
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    br = b.clone().requires_grad_() if bias else None
+    y = F.conv2d(xr.permute(0, 3, 1, 2), wr, br, stride=stride, padding=(k - 1) // 2, groups=C).permute(0, 2, 3, 1)
+    if add:
+        y = y + xr
+    gy = T(f"dw.g{C}.{H}.{stride}", tuple(y.shape))
+    y.backward(gy)
+    xv, wp = mkV(G, x.reshape(-1, C)), mkP(w)
+    bp = mkP(b) if bias else None
+    out = G.dwconv(xv, wp, bp, B, H, H, k, stride, add)
+    close(out.data.view(y.shape), y, what="y")
+    run_bwd(G, out, gy.reshape(-1, C))
+    close(G.grad_of(xv).view(x.shape), xr.grad, 5e-5, 5e-5, "dx")
+    close(wp.grad, wr.grad, 2e-4, 2e-4, "dw")
+    if bias:
+        close(bp.grad, br.grad, 2e-4, 2e-4, "db")
+
+
+@pytest.mark.parametrize("rows,C,act,res", [(392, 64, ACT_HSWISH, False), (1568, 128, ACT_NONE, True), (56, 16, ACT_COORD, False),
+                                            (98, 80, ACT_COORD, False), (5000, 320, ACT_HSWISH, False)])
+def test_batchnorm_train(G, rows, C, act, res):
+    x = T(f"bn.x{rows}.{C}", (rows, C), 1.5) + 0.7
+    g, b = T(f"bn.g{C}", (C,)) * 0.2 + 1, T(f"bn.b{C}", (C,), 0.3)
+    rm, rv = T(f"bn.rm{C}", (C,), 0.1), T(f"bn.rv{C}", (C,)).abs() + 0.5
+    r = T(f"bn.r{rows}.{C}", (rows, C)) if res else None
+    gy = T(f"bn.gy{rows}.{C}", (rows, C))
+    xr, gr, br = x.clone().requires_grad_(), g.clone().requires_grad_(), b.clone().requires_grad_()
+    rmr, rvr = rm.clone(), rv.clone()
+    y = F.batch_norm(xr, rmr, rvr, gr, br, True, 0.1, 1e-5)
+    if act == ACT_HSWISH:
+        y = F.hardswish(y)
+    elif act == ACT_COORD:
+        y = y * torch.clamp(F.silu(y + 3) / 6, max=1.0)
+    if res:
+        rr = r.clone().requires_grad_()
+        y = y + rr
+    y.backward(gy)
+    xv, gp, bp = mkV(G, x), mkP(g), mkP(b)
+    rmd, rvd = rm.to(DEV), rv.to(DEV)
+    resv = mkV(G, r) if res else None
+    out = G.batchnorm(xv, gp, bp, rmd, rvd, act, resv)
+    close(out.data, y, 3e-5, 3e-5, what="y")
+    close(rmd, rmr, 1e-5, 1e-5, "running_mean")
+    close(rvd, rvr, 1e-5, 1e-5, "running_var")
+    run_bwd(G, out, gy)
+    close(G.grad_of(xv), xr.grad, 1e-4, 1e-4, "dx")
+    close(gp.grad, gr.grad, 3e-4, 3e-4, "dgamma")
+    close(bp.grad, br.grad, 3e-4, 3e-4, "dbeta")
+    if res:
+        close(G.grad_of(resv), rr.grad, what="dres")
+
+
+def test_batchnorm_eval():
+    from transception_amd.engine import Graph
+    Ge = Graph(torch.float32, torch.device(DEV), training=False, record=False)
+    rows, C = 100, 64
+    x, g, b = T("bne.x", (rows, C)), T("bne.g", (C,)) * 0.2 + 1, T("bne.b", (C,), 0.3)
+    rm, rv = T("bne.rm", (C,), 0.1), T("bne.rv", (C,)).abs() + 0.5
+    y = F.hardswish(F.batch_norm(x, rm.clone(), rv.clone(), g, b, False, 0.1, 1e-5))
+    out = Ge.batchnorm(mkV(Ge, x), mkP(g), mkP(b), rm.to(DEV), rv.to(DEV), ACT_HSWISH)
+    close(out.data, y, what="y")
+
+
+@pytest.mark.parametrize("nb,R,C,axis", [(3, 50, 64, 1), (2, 64, 6076, 1), (2, 784, 64, 0), (2, 64, 6076, 0), (4, 49, 320, 0),
+                                         (1, 37, 784, 1)])
+def test_softmax(G, nb, R, C, axis):
+    x, gy = T(f"sm.x{nb}.{R}.{C}", (nb, R, C), 2.0), T(f"sm.g{nb}.{R}.{C}", (nb, R, C))
+    xr = x.clone().requires_grad_()
+    y = torch.softmax(xr, dim=2 if axis == 1 else 1)
+    y.backward(gy)
+    xv = mkV(G, x.reshape(nb * R, C))
+    out = G.softmax(xv, nb, axis)
+    close(out.data.view(nb, R, C), y, 1e-6, 2e-5, "y")
+    run_bwd(G, out, gy.reshape(nb * R, C))
+    close(G.grad_of(xv).view(nb, R, C), xr.grad, 2e-6, 5e-5, "dx")
+
+
+def test_softmax_on_column_slice(G):
+    nb, R, C = 2, 196, 128
+    x, gy = T("sms.x", (nb * R, 3 * C)), T("sms.g", (nb * R, C))
+    xr = x.clone().requires_grad_()
+    y = torch.softmax(xr[:, C:2 * C].reshape(nb, R, C), dim=1)
+    y.backward(gy.view(nb, R, C))
+    xv = mkV(G, x)
+    out = G.softmax(xv.colslice(C, 2 * C), nb, 0)
+    close(out.data.view(nb, R, C), y, 1e-6, 2e-5, "y")
+    run_bwd(G, out, gy)
+    close(G.grad_of(xv), xr.grad, 2e-6, 5e-5, "dx (other columns must stay zero)")
+
+
+def test_fma3_coord_pixel_layout(G):
+    rows, C = 300, 64
+    a, b, c, gy = T("f3.a", (rows, C)), T("f3.b", (rows, C)), T("f3.c", (rows, C)), T("f3.g", (rows, C))
+    ar, br, cr = (t.clone().requires_grad_() for t in (a, b, c))
+    y = 0.25 * ar + br * cr
+    y.backward(gy)
+    av, bv, cv = mkV(G, a), mkV(G, b), mkV(G, c)
+    out = G.fma3(av, bv, cv, 0.25)
+    close(out.data, y, what="fma3")
+    run_bwd(G, out, gy)
+    for v, r, n in ((av, ar, "da"), (bv, br, "db"), (cv, cr, "dc")):
+        close(G.grad_of(v), r.grad, what=n)
+
+
+def test_coord_pool_gate(G):
+    B, H, C = 2, 7, 80
+    x, gy = T("cg.x", (B, H, H, C)), T("cg.g", (B, H, H, C))
+    att = torch.sigmoid(T("cg.a", (2 * B * H, C)))
+    xr, ar = x.clone().requires_grad_(), att.clone().requires_grad_()
+    pooled_ref = torch.cat([xr.mean(2).reshape(B * H, C), xr.mean(1).reshape(B * H, C)], 0)
+    a_h, a_w = ar[:B * H].view(B, H, 1, C), ar[B * H:].view(B, 1, H, C)
+    y = xr * a_w * a_h
+    gp = T("cg.gp", (2 * B * H, C))
+    (y * gy).sum().backward(retain_graph=True)
+    gx_gate, ga = xr.grad.clone(), ar.grad.clone()
+    xr.grad = None
+    (pooled_ref * gp).sum().backward()
+    gx_pool = xr.grad.clone()
+    xv, av = mkV(G, x.reshape(-1, C)), mkV(G, att)
+    pooled = G.coord_pool(xv, B, H, H)
+    out = G.coord_gate(xv, av, B, H, H)
+    close(pooled.data, pooled_ref, what="pooled")
+    close(out.data.view(y.shape), y, what="gate")
+    pooled.root.grad_t = gp.to(DEV)
+    pooled.root.whole_written = True
+    run_bwd(G, out, gy.reshape(-1, C))
+    close(G.grad_of(xv).view(x.shape), gx_gate + gx_pool, 5e-5, 5e-5, "dx (two consumers accumulate)")
+    close(G.grad_of(av), ga, 5e-5, 5e-5, "datt")
+
+
+def test_pixel_shuffle_transpose(G):
+    B, H, p, c = 2, 5, 4, 8
+    x, gy = T("ps.x", (B, H, H, p * p * c)), T("ps.g", (B * H * p * H * p, c))
+    xr = x.clone().requires_grad_()
+    y = xr.reshape(B, H, H, p, p, c).permute(0, 1, 3, 2, 4, 5).reshape(-1, c)
+    y.backward(gy)
+    xv = mkV(G, x.reshape(-1, p * p * c))
+    out = G.pixel_shuffle(xv, B, H, H, p)
+    close(out.data, y, 0, 0, "shuffle")
+    run_bwd(G, out, gy)
+    close(G.grad_of(xv).view(x.shape), xr.grad, 0, 0, "dshuffle")
+    t = T("tr.x", (3 * 50, 9))
+    tv = mkV(G, t)
+    o = G.transpose(tv, 3)
+    close(o.data.view(3, 9, 50), t.view(3, 50, 9).transpose(1, 2), 0, 0, "transpose")
+
+
+def test_patchify_deinterleave(G):
+    B, H, C, k = 2, 8, 8, 4
+    buf = T("pf.x", (B * H * H + 10, C))          # map occupies the first B*H*H rows
+    w = T("pf.w", (C, C, k, k), 0.2)
+    br = buf.clone().requires_grad_()
+    ref = F.conv2d(br[:B * H * H].view(B, H, H, C).permute(0, 3, 1, 2), w, stride=k)   # [B, C, 2, 2]
+    bv = mkV(G, buf)
+    cols = G.patchify(bv, 0, H * H * C, B, H, H, C, k)
+    got = cols.data.cpu() @ w.view(C, -1).t()                                          # [B*4, C]
+    close(got.view(B, 2, 2, C).permute(0, 3, 1, 2), ref, 2e-5, 2e-5, "patchify+gemm == conv")
+    gy = T("pf.g", tuple(cols.data.shape))
+    (F.unfold(br[:B * H * H].view(B, H, H, C).permute(0, 3, 1, 2), k, stride=k).transpose(1, 2).reshape(-1, C * k * k) * gy).sum().backward()
+    run_bwd(G, cols, gy)
+    close(G.grad_of(bv), br.grad, 0, 0, "dpatchify")
+    # de-interleave (Scale_reduce quirk)
+    Pn, mult, Cd = 4, 2, 8
+    o = T("di.x", (B * Pn, Cd * mult))
+    want = o.view(B, Pn, Cd, mult).permute(0, 3, 1, 2).reshape(B, mult * Pn, Cd)
+    ov = mkV(G, o)
+    dst = G.new(B * 12, Cd)
+    dst.data.zero_()
+    G.sr_deinterleave(ov, dst, 2 * Cd, 12 * Cd, B, Pn, Cd, mult)
+    close(dst.data.view(B, 12, Cd)[:, 2:2 + mult * Pn], want, 0, 0, "deinterleave")
+
+
+def test_attention_paths_agree_with_reference(G):
+    B, Nq, Nk, d = 2, 200, 98, 64
+    q, kv, gy = T("at.q", (B * Nq, d)), T("at.kv", (B * Nk, 2 * d)), T("at.g", (B * Nq, d))
+    qr, kvr = q.clone().requires_grad_(), kv.clone().requires_grad_()
+    k, v = kvr[:, :d].reshape(B, Nk, d), kvr[:, d:].reshape(B, Nk, d)
+    y = (torch.softmax(qr.view(B, Nq, d) @ k.transpose(1, 2) * 0.125, -1) @ v).reshape(B * Nq, d)
+    y.backward(gy)
+    for fused in (False, True):
+        from transception_amd.engine import Graph
+        Gx = Graph(torch.float32, torch.device(DEV), True, True)
+        Gx.use_fused_attention = fused
+        qv, kvv = mkV(Gx, q), mkV(Gx, kv)
+        out = Gx.attention(qv, kvv.colslice(0, d), kvv.colslice(d, 2 * d), B, Nq, Nk, 0.125)
+        close(out.data, y, 2e-5, 2e-5, f"attention fused={fused}")
+        run_bwd(Gx, out, gy)
+        close(Gx.grad_of(qv), qr.grad, 5e-5, 5e-5, f"dq fused={fused}")
+        close(Gx.grad_of(kvv), kvr.grad, 5e-5, 5e-5, f"dkv fused={fused}")
+
+
+def test_seg_loss_and_sgd():
+    from transception_amd.train import SegLoss
+    B, ncls, H = 2, 9, 32
+    logits = T("sl.x", (B, ncls, H, H), 2.0)
+    lab = torch.from_numpy(np.random.default_rng(5).integers(0, ncls, (B, H, H)))
+    lr_ = logits.clone().requires_grad_()
+    ce = F.cross_entropy(lr_, lab)
+    p = torch.softmax(lr_, 1)
+    oh = F.one_hot(lab, ncls).permute(0, 3, 1, 2).float()
+    inter, ys, zs = (p * oh).sum((0, 2, 3)), oh.sum((0, 2, 3)), (p * p).sum((0, 2, 3))
+    dice = (1 - (2 * inter + 1e-5) / (zs + ys + 1e-5)).mean()
+    loss = 0.4 * ce + 0.6 * dice
+    loss.backward()
+    ld = logits.to(DEV).requires_grad_()
+    out = SegLoss(ncls)(ld, lab.to(DEV))
+    got, gce, gdice = out
+    assert abs(got.item() - loss.item()) < 2e-6 and abs(gce.item() - ce.item()) < 2e-6 and abs(gdice.item() - dice.item()) < 2e-6
+    got.backward()
+    close(ld.grad, lr_.grad, 1e-8, 1e-4, "dlogits")

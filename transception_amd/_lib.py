@@ -1,0 +1,109 @@
+"""ctypes binding of libtransception_hip.so -- the only way the Python host reaches the GPU arithmetic.
+
+There is deliberately NO fallback: if the shared library is missing or a call returns a non-zero
+status the host raises.  (The CPU oracle under oracle/ is test infrastructure and is never imported here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libtransception_hip.so")
+
+TC_F32, TC_BF16 = 0, 1
+ACT_NONE, ACT_HSWISH, ACT_COORD, ACT_SIGMOID, ACT_GELU = 0, 1, 2, 3, 4
+ABI_VERSION = 1
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_longlong, C.c_float
+
+
+class TcGemm(C.Structure):
+    _fields_ = [("A", vp), ("B", vp), ("C", vp), ("bias", vp), ("R", vp),
+                ("M", i32), ("N", i32), ("K", i32),
+                ("lda", i32), ("ldb", i32), ("ldc", i32), ("ldr", i32),
+                ("transA", i32), ("transB", i32), ("nb1", i32), ("nb2", i32),
+                ("sA1", i64), ("sA2", i64), ("sB1", i64), ("sB2", i64),
+                ("sC1", i64), ("sC2", i64), ("sR1", i64), ("sR2", i64),
+                ("alpha", f32), ("accumulate", i32), ("act", i32), ("splitk", i32), ("dtype", i32), ("c_f32", i32), ("atomic", i32)]
+
+
+# name -> argtypes (every function returns int status unless listed in _RET)
+SIGNATURES = {
+    "tc_abi_version": [],
+    "tc_gemm": [C.POINTER(TcGemm), vp],
+    "tc_colsum": [vp, i32, i32, i32, i32, i64, vp, i32, i32, vp],
+    "tc_layernorm_fwd": [vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, f32, i32, i32, vp],
+    "tc_layernorm_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp],
+    "tc_dwconv_fwd": [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "tc_dwconv_bwd_input": [vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "tc_dwconv_bwd_weight": [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "tc_bn_scratch_floats": [i32, i32],
+    "tc_bn_fwd": [vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, f32, f32, i32, i32, i32, vp],
+    "tc_bn_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "tc_softmax_fwd": [vp, vp, i32, i64, i64, i32, i32, i32, i32, i32, i32, vp],
+    "tc_softmax_bwd": [vp, vp, vp, i32, i64, i64, i64, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "tc_attn_fwd": [vp, i32, i64, vp, i32, vp, i32, i64, vp, i32, i64, vp, i32, i32, i32, f32, i32, vp],
+    "tc_attn_bwd": [vp, i32, i64, vp, i32, vp, i32, i64, vp, i32, i64, vp, i32, i64, vp, vp, vp, i32, i64, vp, i32,
+                    vp, i32, i64, i32, i32, i32, i32, f32, i32, vp],
+    "tc_fma3_fwd": [vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, f32, i32, vp],
+    "tc_fma3_bwd": [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, vp, i32, i32, i32, f32, i32, vp],
+    "tc_add": [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp],
+    "tc_sigmoid_bwd": [vp, vp, vp, i64, i32, vp],
+    "tc_copy3d": [vp, i64, i32, vp, i64, i32, i32, i32, i32, i32, i32, vp],
+    "tc_transpose": [vp, vp, i32, i32, i32, i32, vp],
+    "tc_coord_pool_fwd": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "tc_coord_pool_bwd": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "tc_coord_gate_fwd": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "tc_coord_gate_bwd": [vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp],
+    "tc_pixel_shuffle": [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "tc_patchify": [vp, i64, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "tc_sr_deinterleave": [vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp],
+    "tc_stem_im2col": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "tc_seg_loss_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "tc_seg_loss_bwd": [vp, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, vp, i32, vp],
+    "tc_sgd_step": [vp, vp, vp, i64, f32, f32, f32, f32, i32, vp],
+    "tc_cast": [vp, vp, i64, i32, i32, vp],
+}
+_RET = {"tc_bn_scratch_floats": i64}
+_RAW = {"tc_abi_version", "tc_bn_scratch_floats"}     # not status-returning
+
+
+class TcError(RuntimeError):
+    pass
+
+
+class _Lib:
+    def __init__(self, path: str = LIB_PATH):
+        if not os.path.exists(path):
+            raise TcError(f"{path} is missing: build it with `python -m transception_amd.build` "
+                          "(there is no CPU/PyTorch fallback for the TransCeption hot path)")
+        self.path = path
+        self.cdll = C.CDLL(path)
+        for name, args in SIGNATURES.items():
+            fn = getattr(self.cdll, name)          # AttributeError if a declared symbol is not exported
+            fn.argtypes = args
+            fn.restype = _RET.get(name, i32)
+            setattr(self, name, fn if name in _RAW else self._checked(name, fn))
+        v = self.cdll.tc_abi_version()
+        if v != ABI_VERSION:
+            raise TcError(f"ABI mismatch: library {v}, host {ABI_VERSION}")
+
+    @staticmethod
+    def _checked(name, fn):
+        def call(*a):
+            rc = fn(*a)
+            if rc != 0:
+                raise TcError(f"{name} failed with status {rc}")
+        call.__name__ = name
+        return call
+
+
+_lib = None
+
+
+def lib() -> _Lib:
+    global _lib
+    if _lib is None:
+        _lib = _Lib()
+    return _lib

@@ -1,0 +1,162 @@
+// Depthwise k x k convolutions (k = 3/5/7, stride 1/2) on NHWC maps: forward, input gradient, weight/bias gradient.
+// HBM-bound: every thread owns 4 consecutive channels of a pixel (16 lanes = 256 B contiguous per pixel), the
+// filter slice of the block's 64 channels is staged once in LDS in [tap][channel] order (the PyTorch [C,1,k,k]
+// layout is transposed on the way in), and the k*k window re-reads are served by L1/L2.
+#include "tc_common.h"
+
+namespace {
+
+template <typename T, int K, bool BWD>
+__global__ __launch_bounds__(256) void dw_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ w,
+                                                 const T* __restrict__ bias, T* __restrict__ y, int ldy, int B, int H, int W,
+                                                 int Ho, int Wo, int C, int stride, int add_input, int accumulate) {
+    // forward:  x is the [B,H,W] input, y the [B,Ho,Wo] output.
+    // BWD    :  x is dy on [B,Ho,Wo], y is dx on [B,H,W]  (transposed convolution with the same taps).
+    __shared__ float wsm[K * K][64];
+    __shared__ float bsm[64];
+    const int c0 = blockIdx.y * 64;
+    for (int i = threadIdx.x; i < K * K * 64; i += 256) {
+        const int tap = i >> 6, cc = i & 63;
+        wsm[tap][cc] = (c0 + cc < C) ? ldf<T>(w + (long long)(c0 + cc) * K * K + tap) : 0.f;
+    }
+    if (threadIdx.x < 64) bsm[threadIdx.x] = (bias && c0 + threadIdx.x < C) ? ldf<T>(bias + c0 + threadIdx.x) : 0.f;
+    __syncthreads();
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int c = c0 + tx * 4;
+    if (c >= C) return;
+    constexpr int P = (K - 1) / 2;
+    const int OH = BWD ? H : Ho, OW = BWD ? W : Wo;          // extent of the tensor being written
+    const int IH = BWD ? Ho : H, IW = BWD ? Wo : W;          // extent of the tensor being read
+    const long long npix = (long long)B * OH * OW;
+    for (long long pix = (long long)blockIdx.x * 16 + ty; pix < npix; pix += (long long)gridDim.x * 16) {
+        const int ow = (int)(pix % OW);
+        const int oh = (int)((pix / OW) % OH);
+        const int b = (int)(pix / ((long long)OW * OH));
+        float4 acc = BWD ? make_float4(0.f, 0.f, 0.f, 0.f)
+                         : make_float4(bsm[tx * 4], bsm[tx * 4 + 1], bsm[tx * 4 + 2], bsm[tx * 4 + 3]);
+        const T* xb = x + (long long)b * IH * IW * ldx + c;
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            int ih;
+            if (!BWD) ih = oh * stride + ky - P;
+            else { const int t = oh + P - ky; if (t % stride) continue; ih = t / stride; if (t < 0) continue; }
+            if (ih < 0 || ih >= IH) continue;
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                int iw;
+                if (!BWD) iw = ow * stride + kx - P;
+                else { const int t = ow + P - kx; if (t % stride) continue; iw = t / stride; if (t < 0) continue; }
+                if (iw < 0 || iw >= IW) continue;
+                const float4 v = ld4<T>(xb + ((long long)ih * IW + iw) * ldx);
+                const float* wt = &wsm[ky * K + kx][tx * 4];
+                acc.x += v.x * wt[0]; acc.y += v.y * wt[1]; acc.z += v.z * wt[2]; acc.w += v.w * wt[3];
+            }
+        }
+        if (add_input) {   // stride 1: same pixel of the read tensor
+            const float4 v = ld4<T>(xb + ((long long)oh * IW + ow) * ldx);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        if (accumulate) { const float4 o = ld4<T>(y + pix * ldy + c); acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
+        st4<T>(y + pix * ldy + c, acc);
+    }
+}
+
+// dw[c, tap] += sum_pix dy[pix, c] * x[pix shifted by tap, c] ; db[c] += sum_pix dy[pix, c]
+template <typename T, int K>
+__global__ __launch_bounds__(256) void dw_wgrad_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ x, int ldx,
+                                                       float* __restrict__ dw, float* __restrict__ db, int B, int H, int W,
+                                                       int Ho, int Wo, int C, int stride) {
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + tx;
+    constexpr int P = (K - 1) / 2;
+    float acc[K * K];
+    float accb = 0.f;
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) acc[i] = 0.f;
+    const long long npix = (long long)B * Ho * Wo;
+    if (c < C) {
+        for (long long pix = (long long)blockIdx.x * 4 + ty; pix < npix; pix += (long long)gridDim.x * 4) {
+            const int ow = (int)(pix % Wo);
+            const int oh = (int)((pix / Wo) % Ho);
+            const int b = (int)(pix / ((long long)Wo * Ho));
+            const float d = ldf<T>(dy + pix * lddy + c);
+            accb += d;
+            const T* xb = x + (long long)b * H * W * ldx + c;
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky) {
+                const int ih = oh * stride + ky - P;
+                if (ih < 0 || ih >= H) continue;
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    const int iw = ow * stride + kx - P;
+                    if (iw < 0 || iw >= W) continue;
+                    acc[ky * K + kx] += d * ldf<T>(xb + ((long long)ih * W + iw) * ldx);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i <= K * K; ++i) {
+        red[ty][tx] = (i < K * K) ? acc[i < K * K ? i : 0] : accb;
+        __syncthreads();
+        if (ty == 0 && c < C) {
+            const float s = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+            if (i < K * K) atomicAdd(dw + (long long)c * K * K + i, s);
+            else if (db) atomicAdd(db + c, s);
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T, bool BWD>
+int launch_dw(const void* x, int ldx, const void* w, const void* bias, void* y, int ldy, int B, int H, int W, int C, int k,
+              int stride, int add_input, int accumulate, hipStream_t s) {
+    const int P = (k - 1) / 2;
+    const int Ho = (H + 2 * P - k) / stride + 1, Wo = (W + 2 * P - k) / stride + 1;
+    const long long npix = (long long)B * (BWD ? H * W : Ho * Wo);
+    dim3 grid(tc_blocks(npix, 16 * 4, 2048), (C + 63) / 64), block(256);
+#define TC_DW(KK) hipLaunchKernelGGL((dw_kernel<T, KK, BWD>), grid, block, 0, s, (const T*)x, ldx, (const T*)w, (const T*)bias, \
+                                     (T*)y, ldy, B, H, W, Ho, Wo, C, stride, add_input, accumulate)
+    if (k == 3) TC_DW(3); else if (k == 5) TC_DW(5); else TC_DW(7);
+#undef TC_DW
+    return tc_launch_status();
+}
+
+bool dw_args_ok(int B, int H, int W, int C, int k, int stride, int add_input) {
+    return B > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0 && (k == 3 || k == 5 || k == 7) && (stride == 1 || stride == 2) &&
+           !(add_input && stride != 1);
+}
+
+}  // namespace
+
+extern "C" int tc_dwconv_fwd(const void* x, int ldx, const void* w, const void* bias, void* y, int ldy, int B, int H, int W,
+                             int C, int k, int stride, int add_input, int dtype, void* stream) {
+    if (!x || !w || !y || (ldx & 3) || (ldy & 3) || !dw_args_ok(B, H, W, C, k, stride, add_input)) return TC_ERR_ARG;
+    TC_DISPATCH_DTYPE(dtype, return (launch_dw<T, false>(x, ldx, w, bias, y, ldy, B, H, W, C, k, stride, add_input, 0,
+                                                         (hipStream_t)stream)));
+    return TC_ERR_ARG;
+}
+
+extern "C" int tc_dwconv_bwd_input(const void* dy, int lddy, const void* w, void* dx, int lddx, int B, int H, int W, int C,
+                                   int k, int stride, int add_input, int accumulate, int dtype, void* stream) {
+    if (!dy || !w || !dx || (lddy & 3) || (lddx & 3) || !dw_args_ok(B, H, W, C, k, stride, add_input)) return TC_ERR_ARG;
+    TC_DISPATCH_DTYPE(dtype, return (launch_dw<T, true>(dy, lddy, w, nullptr, dx, lddx, B, H, W, C, k, stride, add_input, accumulate,
+                                                        (hipStream_t)stream)));
+    return TC_ERR_ARG;
+}
+
+extern "C" int tc_dwconv_bwd_weight(const void* dy, int lddy, const void* x, int ldx, float* dw, float* db, int B, int H,
+                                    int W, int C, int k, int stride, int dtype, void* stream) {
+    if (!dy || !x || !dw || !dw_args_ok(B, H, W, C, k, stride, 0)) return TC_ERR_ARG;
+    const int P = (k - 1) / 2;
+    const int Ho = (H + 2 * P - k) / stride + 1, Wo = (W + 2 * P - k) / stride + 1;
+    const long long npix = (long long)B * Ho * Wo;
+    dim3 grid(tc_blocks(npix, 4 * 64, 256), (C + 63) / 64), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define TC_DWW(KK) hipLaunchKernelGGL((dw_wgrad_kernel<T, KK>), grid, block, 0, s, (const T*)dy, lddy, (const T*)x, ldx, dw, db, \
+                                      B, H, W, Ho, Wo, C, stride)
+    TC_DISPATCH_DTYPE(dtype, { if (k == 3) TC_DWW(3); else if (k == 5) TC_DWW(5); else TC_DWW(7); });
+#undef TC_DWW
+    return tc_launch_status();
+}

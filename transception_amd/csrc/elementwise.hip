@@ -1,0 +1,345 @@
+// Elementwise and layout kernels of the TransCeption path (all HBM-bound, 4 channels = 8/16 B per lane).
+#include "tc_common.h"
+
+namespace {
+
+#define TC_GRID_STRIDE(i, n) for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long long)gridDim.x * blockDim.x)
+
+template <typename T>
+__global__ void fma3_fwd_kernel(const T* a, int lda, const T* b, int ldb, const T* c, int ldc, T* o, int ldo, int rows, int cq,
+                                float alpha) {
+    TC_GRID_STRIDE(i, (long long)rows * cq) {
+        const long long r = i / cq; const int q = (int)(i % cq) * 4;
+        const float4 va = ld4<T>(a + r * lda + q), vb = ld4<T>(b + r * ldb + q), vc = ld4<T>(c + r * ldc + q);
+        st4<T>(o + r * ldo + q, make_float4(alpha * va.x + vb.x * vc.x, alpha * va.y + vb.y * vc.y, alpha * va.z + vb.z * vc.z,
+                                            alpha * va.w + vb.w * vc.w));
+    }
+}
+
+template <typename T>
+__global__ void fma3_bwd_kernel(const T* d, int ldd, const T* b, int ldb, const T* c, int ldc, T* da, int ldda, T* db, int lddb,
+                                int db_acc, T* dc, int lddc, int rows, int cq, float alpha) {
+    TC_GRID_STRIDE(i, (long long)rows * cq) {
+        const long long r = i / cq; const int q = (int)(i % cq) * 4;
+        const float4 vd = ld4<T>(d + r * ldd + q), vb = ld4<T>(b + r * ldb + q), vc = ld4<T>(c + r * ldc + q);
+        st4<T>(da + r * ldda + q, make_float4(alpha * vd.x, alpha * vd.y, alpha * vd.z, alpha * vd.w));
+        float4 g = make_float4(vd.x * vc.x, vd.y * vc.y, vd.z * vc.z, vd.w * vc.w);
+        if (db_acc) { const float4 o = ld4<T>(db + r * lddb + q); g.x += o.x; g.y += o.y; g.z += o.z; g.w += o.w; }
+        st4<T>(db + r * lddb + q, g);
+        st4<T>(dc + r * lddc + q, make_float4(vd.x * vb.x, vd.y * vb.y, vd.z * vb.z, vd.w * vb.w));
+    }
+}
+
+template <typename T>
+__global__ void add_kernel(const T* a, int lda, const T* b, int ldb, T* y, int ldy, int rows, int cq) {
+    TC_GRID_STRIDE(i, (long long)rows * cq) {
+        const long long r = i / cq; const int q = (int)(i % cq) * 4;
+        const float4 va = ld4<T>(a + r * lda + q), vb = ld4<T>(b + r * ldb + q);
+        st4<T>(y + r * ldy + q, make_float4(va.x + vb.x, va.y + vb.y, va.z + vb.z, va.w + vb.w));
+    }
+}
+
+template <typename T>
+__global__ void sigmoid_bwd_kernel(const T* dy, const T* s, T* dz, long long n) {
+    TC_GRID_STRIDE(i, n) { const float v = ldf<T>(s + i); stf<T>(dz + i, ldf<T>(dy + i) * v * (1.f - v)); }
+}
+
+template <typename T>
+__global__ void copy3d_kernel(const T* src, long long sbs, int lds, T* dst, long long sbd, int ldd, int nb, int rows, int cols, int acc) {
+    TC_GRID_STRIDE(i, (long long)nb * rows * cols) {
+        const int c = (int)(i % cols); const long long t = i / cols; const int r = (int)(t % rows); const long long b = t / rows;
+        T* d = dst + b * sbd + (long long)r * ldd + c;
+        float v = ldf<T>(src + b * sbs + (long long)r * lds + c);
+        if (acc) v += ldf<T>(d);
+        stf<T>(d, v);
+    }
+}
+
+template <typename T>
+__global__ void transpose_kernel(const T* src, T* dst, int R, int Cc) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const T* s = src + (long long)b * R * Cc;
+    T* d = dst + (long long)b * R * Cc;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+    for (int j = ty; j < 32; j += 8) if (r0 + j < R && c0 + tx < Cc) tile[j][tx] = ldf<T>(s + (long long)(r0 + j) * Cc + c0 + tx);
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) if (c0 + j < Cc && r0 + tx < R) stf<T>(d + (long long)(c0 + j) * R + r0 + tx, tile[tx][j]);
+}
+
+// ---------------------------------------------------------------- CoordAtt (IFF) pooling and gating
+template <typename T>
+__global__ void coord_pool_fwd_kernel(const T* x, T* pooled, int B, int H, int W, int C) {
+    const int cq = C >> 2;
+    TC_GRID_STRIDE(i, (long long)B * (H + W) * cq) {
+        const int q = (int)(i % cq) * 4; const int j = (int)((i / cq) % (H + W)); const int b = (int)(i / ((long long)cq * (H + W)));
+        const T* xb = x + (long long)b * H * W * C + q;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < H) { for (int w = 0; w < W; ++w) { const float4 v = ld4<T>(xb + ((long long)j * W + w) * C); s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+                     const float inv = 1.f / W; s.x *= inv; s.y *= inv; s.z *= inv; s.w *= inv; }
+        else { const int w = j - H; for (int h = 0; h < H; ++h) { const float4 v = ld4<T>(xb + ((long long)h * W + w) * C); s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+               const float inv = 1.f / H; s.x *= inv; s.y *= inv; s.z *= inv; s.w *= inv; }
+        st4<T>(pooled + (j < H ? ((long long)b * H + j) : ((long long)B * H + (long long)b * W + (j - H))) * C + q, s);
+    }
+}
+
+template <typename T>
+__global__ void coord_pool_bwd_kernel(const T* dp, T* dx, int B, int H, int W, int C, int acc) {
+    const int cq = C >> 2;
+    TC_GRID_STRIDE(i, (long long)B * H * W * cq) {
+        const int q = (int)(i % cq) * 4; const long long pix = i / cq;
+        const int w = (int)(pix % W), h = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
+        const float4 gh = ld4<T>(dp + ((long long)b * H + h) * C + q), gw = ld4<T>(dp + ((long long)B * H + (long long)b * W + w) * C + q);
+        const float ih = 1.f / W, iw = 1.f / H;
+        float4 g = make_float4(gh.x * ih + gw.x * iw, gh.y * ih + gw.y * iw, gh.z * ih + gw.z * iw, gh.w * ih + gw.w * iw);
+        T* o = dx + pix * C + q;
+        if (acc) { const float4 v = ld4<T>(o); g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w; }
+        st4<T>(o, g);
+    }
+}
+
+template <typename T>
+__global__ void coord_gate_fwd_kernel(const T* x, const T* att, T* y, int B, int H, int W, int C) {
+    const int cq = C >> 2;
+    TC_GRID_STRIDE(i, (long long)B * H * W * cq) {
+        const int q = (int)(i % cq) * 4; const long long pix = i / cq;
+        const int w = (int)(pix % W), h = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
+        const float4 ah = ld4<T>(att + ((long long)b * H + h) * C + q), aw = ld4<T>(att + ((long long)B * H + (long long)b * W + w) * C + q);
+        const float4 v = ld4<T>(x + pix * C + q);
+        st4<T>(y + pix * C + q, make_float4(v.x * aw.x * ah.x, v.y * aw.y * ah.y, v.z * aw.z * ah.z, v.w * aw.w * ah.w));
+    }
+}
+
+// dx = dy*aw*ah (optionally accumulated)
+template <typename T>
+__global__ void coord_gate_bwd_dx_kernel(const T* dy, const T* att, T* dx, int acc, int B, int H, int W, int C) {
+    const int cq = C >> 2;
+    TC_GRID_STRIDE(i, (long long)B * H * W * cq) {
+        const int q = (int)(i % cq) * 4; const long long pix = i / cq;
+        const int w = (int)(pix % W), h = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
+        const float4 ah = ld4<T>(att + ((long long)b * H + h) * C + q), aw = ld4<T>(att + ((long long)B * H + (long long)b * W + w) * C + q);
+        const float4 d = ld4<T>(dy + pix * C + q);
+        float4 g = make_float4(d.x * aw.x * ah.x, d.y * aw.y * ah.y, d.z * aw.z * ah.z, d.w * aw.w * ah.w);
+        T* o = dx + pix * C + q;
+        if (acc) { const float4 v = ld4<T>(o); g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w; }
+        st4<T>(o, g);
+    }
+}
+
+// datt[b,h] = sum_w dy*x*aw ; datt[b,H+w] = sum_h dy*x*ah
+template <typename T>
+__global__ void coord_gate_bwd_att_kernel(const T* dy, const T* x, const T* att, T* datt, int B, int H, int W, int C) {
+    const int cq = C >> 2;
+    TC_GRID_STRIDE(i, (long long)B * (H + W) * cq) {
+        const int q = (int)(i % cq) * 4; const int j = (int)((i / cq) % (H + W)); const int b = (int)(i / ((long long)cq * (H + W)));
+        const T* ah_b = att + (long long)b * H * C + q;
+        const T* aw_b = att + ((long long)B * H + (long long)b * W) * C + q;
+        const long long base = (long long)b * H * W;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < H) {
+            for (int w = 0; w < W; ++w) {
+                const long long pix = base + (long long)j * W + w;
+                const float4 d = ld4<T>(dy + pix * C + q), v = ld4<T>(x + pix * C + q), a = ld4<T>(aw_b + (long long)w * C);
+                s.x += d.x * v.x * a.x; s.y += d.y * v.y * a.y; s.z += d.z * v.z * a.z; s.w += d.w * v.w * a.w;
+            }
+        } else {
+            const int w = j - H;
+            for (int h = 0; h < H; ++h) {
+                const long long pix = base + (long long)h * W + w;
+                const float4 d = ld4<T>(dy + pix * C + q), v = ld4<T>(x + pix * C + q), a = ld4<T>(ah_b + (long long)h * C);
+                s.x += d.x * v.x * a.x; s.y += d.y * v.y * a.y; s.z += d.z * v.z * a.z; s.w += d.w * v.w * a.w;
+            }
+        }
+        st4<T>(datt + (j < H ? ((long long)b * H + j) : ((long long)B * H + (long long)b * W + (j - H))) * C + q, s);
+    }
+}
+
+// ---------------------------------------------------------------- layout permutations
+template <typename T>
+__global__ void pixel_shuffle_kernel(const T* in, T* out, int B, int H, int W, int p, int c, int inverse) {
+    // expanded pixel (b, h*p+p1, w*p+p2), channel cc  <->  coarse pixel (b,h,w), channel (p1*p+p2)*c + cc
+    const int cq = c >> 2;
+    const long long n = (long long)B * H * p * W * p * cq;
+    TC_GRID_STRIDE(i, n) {
+        const int q = (int)(i % cq) * 4; long long t = i / cq;
+        const int ow = (int)(t % (W * p)); t /= (W * p);
+        const int oh = (int)(t % (H * p)); const int b = (int)(t / (H * p));
+        const int h = oh / p, p1 = oh % p, w = ow / p, p2 = ow % p;
+        const long long fine = (((long long)b * H * p + oh) * W * p + ow) * c + q;
+        const long long coarse = (((long long)b * H + h) * W + w) * (long long)(p * p * c) + (p1 * p + p2) * c + q;
+        if (!inverse) st4<T>(out + fine, ld4<T>(in + coarse)); else st4<T>(out + coarse, ld4<T>(in + fine));
+    }
+}
+
+template <typename T>
+__global__ void patchify_kernel(const T* map, long long sb, int ld, T* cols, int B, int H, int W, int C, int k, int inverse) {
+    const int cq = C >> 2, Ho = H / k, Wo = W / k;
+    const long long n = (long long)B * H * W * cq;
+    T* m = const_cast<T*>(map);
+    TC_GRID_STRIDE(i, n) {
+        const int q = (int)(i % cq) * 4; long long t = i / cq;
+        const int w = (int)(t % W); t /= W; const int h = (int)(t % H); const int b = (int)(t / H);
+        const long long src = b * sb + ((long long)h * W + w) * ld + q;
+        const long long row = ((long long)b * Ho + h / k) * Wo + w / k;
+        const int kk = k * k;
+        T* d = cols + row * (long long)(kk * C) + (long long)q * kk + (h % k) * k + (w % k);     // column (c, ky, kx)
+        if (!inverse) {
+            const float4 v = ld4<T>(m + src);
+            stf<T>(d, v.x); stf<T>(d + kk, v.y); stf<T>(d + 2 * kk, v.z); stf<T>(d + 3 * kk, v.w);
+        } else {
+            float4 v = make_float4(ldf<T>(d), ldf<T>(d + kk), ldf<T>(d + 2 * kk), ldf<T>(d + 3 * kk));
+            if (inverse == 2) { const float4 o = ld4<T>(m + src); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            st4<T>(m + src, v);
+        }
+    }
+}
+
+template <typename T>
+__global__ void sr_deinterleave_kernel(const T* in, T* out, long long sbo, int ldo, int B, int P, int C, int mult, int inverse) {
+    // out[b, g*P+pos, c] = in[b, pos, c*mult+g]   (in: [B, P, C*mult] contiguous)
+    const long long n = (long long)B * P * C * mult;
+    T* o = out; T* ii = const_cast<T*>(in);
+    TC_GRID_STRIDE(i, n) {
+        const int c = (int)(i % C); long long t = i / C;
+        const int pos = (int)(t % P); t /= P; const int g = (int)(t % mult); const int b = (int)(t / mult);
+        const long long oi = b * sbo + ((long long)g * P + pos) * ldo + c;
+        const long long si = ((long long)b * P + pos) * (C * mult) + c * mult + g;
+        if (!inverse) o[oi] = ii[si]; else ii[si] = o[oi];
+    }
+}
+
+template <typename T>
+__global__ void stem_im2col_kernel(const T* img, T* cols, int ldc, int B, int in_ch, int H, int W, int Ho, int Wo) {
+    const long long n = (long long)B * Ho * Wo * ldc;
+    TC_GRID_STRIDE(i, n) {
+        const int col = (int)(i % ldc); long long t = i / ldc;
+        const int ow = (int)(t % Wo); t /= Wo; const int oh = (int)(t % Ho); const int b = (int)(t / Ho);
+        float v = 0.f;
+        if (col < 147) {
+            const int ci = col / 49, ky = (col % 49) / 7, kx = col % 7;
+            const int ih = oh * 4 + ky - 3, iw = ow * 4 + kx - 3;
+            if (ih >= 0 && ih < H && iw >= 0 && iw < W)
+                v = ldf<T>(img + (((long long)b * in_ch + (in_ch == 1 ? 0 : ci)) * H + ih) * W + iw);
+        }
+        stf<T>(cols + i, v);
+    }
+}
+
+template <typename TS, typename TD>
+__global__ void cast_kernel(const TS* s, TD* d, long long n) { TC_GRID_STRIDE(i, n) stf<TD>(d + i, ldf<TS>(s + i)); }
+
+inline dim3 g1(long long n) { return dim3(tc_blocks(n, 256, 8192)); }
+
+}  // namespace
+
+#define TC_S ((hipStream_t)stream)
+
+extern "C" int tc_fma3_fwd(const void* a, int lda, const void* b, int ldb, const void* c, int ldc, void* out, int ldo, int rows,
+                           int cols, float alpha, int dtype, void* stream) {
+    if (!a || !b || !c || !out || rows <= 0 || cols <= 0 || ((cols | lda | ldb | ldc | ldo) & 3)) return TC_ERR_ARG;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((fma3_fwd_kernel<T>), g1((long long)rows * cols / 4), dim3(256), 0, TC_S, (const T*)a,
+                                                lda, (const T*)b, ldb, (const T*)c, ldc, (T*)out, ldo, rows, cols / 4, alpha));
+    return tc_launch_status();
+}
+extern "C" int tc_fma3_bwd(const void* dout, int lddo, const void* b, int ldb, const void* c, int ldc, void* da, int ldda, void* db,
+                           int lddb, int db_accumulate, void* dc, int lddc, int rows, int cols, float alpha, int dtype, void* stream) {
+    if (!dout || !b || !c || !da || !db || !dc || rows <= 0 || cols <= 0 || ((cols | lddo | ldb | ldc | ldda | lddb | lddc) & 3))
+        return TC_ERR_ARG;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((fma3_bwd_kernel<T>), g1((long long)rows * cols / 4), dim3(256), 0, TC_S,
+                                                (const T*)dout, lddo, (const T*)b, ldb, (const T*)c, ldc, (T*)da, ldda, (T*)db, lddb,
+                                                db_accumulate, (T*)dc, lddc, rows, cols / 4, alpha));
+    return tc_launch_status();
+}
+extern "C" int tc_add(const void* a, int lda, const void* b, int ldb, void* y, int ldy, int rows, int cols, int dtype, void* stream) {
+    if (!a || !b || !y || rows <= 0 || cols <= 0 || ((cols | lda | ldb | ldy) & 3)) return TC_ERR_ARG;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((add_kernel<T>), g1((long long)rows * cols / 4), dim3(256), 0, TC_S, (const T*)a, lda,
+                                                (const T*)b, ldb, (T*)y, ldy, rows, cols / 4));
+    return tc_launch_status();
+}
+extern "C" int tc_sigmoid_bwd(const void* dy, const void* s, void* dz, long long n, int dtype, void* stream) {
+    if (!dy || !s || !dz || n <= 0) return TC_ERR_ARG;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((sigmoid_bwd_kernel<T>), g1(n), dim3(256), 0, TC_S, (const T*)dy, (const T*)s, (T*)dz, n));
+    return tc_launch_status();
+}
+extern "C" int tc_copy3d(const void* src, long long sbs, int lds, void* dst, long long sbd, int ldd, int nb, int rows, int cols,
+                         int accumulate, int dtype, void* stream) {
+    if (!src || !dst || nb <= 0 || rows <= 0 || cols <= 0) return TC_ERR_ARG;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((copy3d_kernel<T>), g1((long long)nb * rows * cols), dim3(256), 0, TC_S, (const T*)src,
+                                                sbs, lds, (T*)dst, sbd, ldd, nb, rows, cols, accumulate));
+    return tc_launch_status();
+}
+extern "C" int tc_transpose(const void* src, void* dst, int nb, int R, int Cc, int dtype, void* stream) {
+    if (!src || !dst || nb <= 0 || R <= 0 || Cc <= 0 || nb > 65535) return TC_ERR_ARG;
+    dim3 grid((Cc + 31) / 32, (R + 31) / 32, nb);
+    if (grid.y > 65535) return TC_ERR_ARG;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((transpose_kernel<T>), grid, dim3(256), 0, TC_S, (const T*)src, (T*)dst, R, Cc));
+    return tc_launch_status();
+}
+extern "C" int tc_coord_pool_fwd(const void* x, void* pooled, int B, int H, int W, int C, int dtype, void* stream) {
+    if (!x || !pooled || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return TC_ERR_ARG;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((coord_pool_fwd_kernel<T>), g1((long long)B * (H + W) * C / 4), dim3(256), 0, TC_S,
+                                                (const T*)x, (T*)pooled, B, H, W, C));
+    return tc_launch_status();
+}
+extern "C" int tc_coord_pool_bwd(const void* dpooled, void* dx, int B, int H, int W, int C, int accumulate, int dtype, void* stream) {
+    if (!dpooled || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return TC_ERR_ARG;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((coord_pool_bwd_kernel<T>), g1((long long)B * H * W * C / 4), dim3(256), 0, TC_S,
+                                                (const T*)dpooled, (T*)dx, B, H, W, C, accumulate));
+    return tc_launch_status();
+}
+extern "C" int tc_coord_gate_fwd(const void* x, const void* att, void* y, int B, int H, int W, int C, int dtype, void* stream) {
+    if (!x || !att || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return TC_ERR_ARG;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((coord_gate_fwd_kernel<T>), g1((long long)B * H * W * C / 4), dim3(256), 0, TC_S,
+                                                (const T*)x, (const T*)att, (T*)y, B, H, W, C));
+    return tc_launch_status();
+}
+extern "C" int tc_coord_gate_bwd(const void* dy, const void* x, const void* att, void* dx, int dx_accumulate, void* datt, int B, int H,
+                                 int W, int C, int dtype, void* stream) {
+    if (!dy || !x || !att || !dx || !datt || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return TC_ERR_ARG;
+    TC_DISPATCH_DTYPE(dtype, {
+        hipLaunchKernelGGL((coord_gate_bwd_dx_kernel<T>), g1((long long)B * H * W * C / 4), dim3(256), 0, TC_S, (const T*)dy,
+                           (const T*)att, (T*)dx, dx_accumulate, B, H, W, C);
+        hipLaunchKernelGGL((coord_gate_bwd_att_kernel<T>), g1((long long)B * (H + W) * C / 4), dim3(256), 0, TC_S, (const T*)dy,
+                           (const T*)x, (const T*)att, (T*)datt, B, H, W, C);
+    });
+    return tc_launch_status();
+}
+extern "C" int tc_pixel_shuffle(const void* in, void* out, int B, int H, int W, int p, int c, int inverse, int dtype, void* stream) {
+    if (!in || !out || B <= 0 || H <= 0 || W <= 0 || p <= 0 || c <= 0 || (c & 3)) return TC_ERR_ARG;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((pixel_shuffle_kernel<T>), g1((long long)B * H * W * p * p * c / 4), dim3(256), 0, TC_S,
+                                                (const T*)in, (T*)out, B, H, W, p, c, inverse));
+    return tc_launch_status();
+}
+extern "C" int tc_patchify(const void* map, long long sb_map, int ld_map, void* cols, int B, int H, int W, int C, int k, int inverse,
+                           int dtype, void* stream) {
+    if (!map || !cols || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || k <= 0 || H % k || W % k || (ld_map & 3) || (sb_map & 3))
+        return TC_ERR_ARG;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((patchify_kernel<T>), g1((long long)B * H * W * C / 4), dim3(256), 0, TC_S, (const T*)map,
+                                                sb_map, ld_map, (T*)cols, B, H, W, C, k, inverse));
+    return tc_launch_status();
+}
+extern "C" int tc_sr_deinterleave(const void* in, void* out, long long sbo, int ldo, int B, int P, int C, int mult, int inverse, int dtype,
+                                  void* stream) {
+    if (!in || !out || B <= 0 || P <= 0 || C <= 0 || mult <= 0) return TC_ERR_ARG;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((sr_deinterleave_kernel<T>), g1((long long)B * P * C * mult), dim3(256), 0, TC_S,
+                                                (const T*)in, (T*)out, sbo, ldo, B, P, C, mult, inverse));
+    return tc_launch_status();
+}
+extern "C" int tc_stem_im2col(const void* img, void* cols, int ldc, int B, int in_ch, int H, int W, int dtype, void* stream) {
+    if (!img || !cols || B <= 0 || (in_ch != 1 && in_ch != 3) || H <= 0 || W <= 0 || ldc < 147) return TC_ERR_ARG;
+    const int Ho = (H + 6 - 7) / 4 + 1, Wo = (W + 6 - 7) / 4 + 1;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((stem_im2col_kernel<T>), g1((long long)B * Ho * Wo * ldc), dim3(256), 0, TC_S, (const T*)img,
+                                                (T*)cols, ldc, B, in_ch, H, W, Ho, Wo));
+    return tc_launch_status();
+}
+extern "C" int tc_cast(const void* src, void* dst, long long n, int src_dtype, int dst_dtype, void* stream) {
+    if (!src || !dst || n <= 0) return TC_ERR_ARG;
+    if (src_dtype == TC_F32 && dst_dtype == TC_BF16)
+        hipLaunchKernelGGL((cast_kernel<float, bf16_t>), g1(n), dim3(256), 0, TC_S, (const float*)src, (bf16_t*)dst, n);
+    else if (src_dtype == TC_BF16 && dst_dtype == TC_F32)
+        hipLaunchKernelGGL((cast_kernel<bf16_t, float>), g1(n), dim3(256), 0, TC_S, (const bf16_t*)src, (float*)dst, n);
+    else return TC_ERR_ARG;
+    return tc_launch_status();
+}
+extern "C" int tc_abi_version(void) { return 1; }

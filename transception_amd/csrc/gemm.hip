@@ -1,0 +1,228 @@
+// Batched GEMM for gfx950 on the fp32 matrix core (v_mfma_f32_32x32x2_f32): exact fp32 products and
+// accumulation, used for every Linear / 1x1-conv / bmm of the TransCeption path and their gradients.
+//   C[b] = alpha * op(A[b]) op(B[b]) (+bias) (+R) ; optional sigmoid ; optional accumulate / split-K atomics.
+// 256 threads = 4 waves (2 x 2); each wave owns a (BM/2) x (BN/2) sub-tile made of 32x32 MFMA blocks.
+// Operands are staged through LDS "K-inner" (As[BM][BK+1], Bs[BN][BK+1]) whatever their global layout, with a
+// register prefetch of the next K-slab.  Storage type T (fp32 or bf16) is converted on the global<->LDS edge.
+#include "tc_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+struct GemmDev {
+    const void* A; const void* B; void* C; const void* bias; const void* R;
+    int M, N, K, lda, ldb, ldc, ldr;
+    int nb2, splitk, kchunk;
+    long long sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2;
+    float alpha; int accumulate, act;
+    int vecA, vecB, atomic;
+};
+
+// Load a 4-wide strip of an operand tile.  `trans` = the operand is stored [K, X] (X contiguous).
+// Returns values for (x0..x0+3, k) when trans, or (x, k0..k0+3) otherwise.
+template <typename T>
+__device__ __forceinline__ float4 load_strip(const T* base, int ld, int x, int k, int X, int K, bool trans, bool vec) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!trans) {
+        if (x < X) {
+            const T* p = base + (long long)x * ld + k;
+            if (vec && k + 3 < K) v = ld4<T>(p);
+            else {
+                if (k + 0 < K) v.x = ldf<T>(p + 0);
+                if (k + 1 < K) v.y = ldf<T>(p + 1);
+                if (k + 2 < K) v.z = ldf<T>(p + 2);
+                if (k + 3 < K) v.w = ldf<T>(p + 3);
+            }
+        }
+    } else {
+        if (k < K) {
+            const T* p = base + (long long)k * ld + x;
+            if (vec && x + 3 < X) v = ld4<T>(p);
+            else {
+                if (x + 0 < X) v.x = ldf<T>(p + 0);
+                if (x + 1 < X) v.y = ldf<T>(p + 1);
+                if (x + 2 < X) v.z = ldf<T>(p + 2);
+                if (x + 3 < X) v.w = ldf<T>(p + 3);
+            }
+        }
+    }
+    return v;
+}
+
+template <typename T, typename TC, int BM, int BN, bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmDev p) {
+    constexpr int BK = 16, LDT = BK + 1;
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int SA = BM * BK / 4 / 256, SB = BN * BK / 4 / 256;   // strips per thread
+    static_assert(SA >= 1 && SB >= 1, "tile too small");
+    __shared__ float As[BM * LDT];
+    __shared__ float Bs[BN * LDT];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    int z = blockIdx.z;
+    const int ks = z % p.splitk; z /= p.splitk;
+    const int b2 = z % p.nb2, b1 = z / p.nb2;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = ks * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
+
+    const T* A = reinterpret_cast<const T*>(p.A) + b1 * p.sA1 + b2 * p.sA2;
+    const T* B = reinterpret_cast<const T*>(p.B) + b1 * p.sB1 + b2 * p.sB2;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[SA], rb[SB];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < SA; ++i) {
+            const int f = tid + i * 256;
+            if (!TA) { const int row = f / (BK / 4), kq = f % (BK / 4);
+                ra[i] = load_strip<T>(A, p.lda, m0 + row, k0 + kq * 4, p.M, kend, false, p.vecA); }
+            else { const int k = f / (BM / 4), mq = f % (BM / 4);
+                ra[i] = load_strip<T>(A, p.lda, m0 + mq * 4, k0 + k, p.M, kend, true, p.vecA); }
+        }
+#pragma unroll
+        for (int i = 0; i < SB; ++i) {
+            const int f = tid + i * 256;
+            if (TB) { const int row = f / (BK / 4), kq = f % (BK / 4);          // stored [N,K]
+                rb[i] = load_strip<T>(B, p.ldb, n0 + row, k0 + kq * 4, p.N, kend, false, p.vecB); }
+            else { const int k = f / (BN / 4), nq = f % (BN / 4);               // stored [K,N]
+                rb[i] = load_strip<T>(B, p.ldb, n0 + nq * 4, k0 + k, p.N, kend, true, p.vecB); }
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < SA; ++i) {
+            const int f = tid + i * 256;
+            if (!TA) { const int row = f / (BK / 4), kq = f % (BK / 4); float* d = &As[row * LDT + kq * 4];
+                d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w; }
+            else { const int k = f / (BM / 4), mq = f % (BM / 4); float* d = &As[(mq * 4) * LDT + k];
+                d[0] = ra[i].x; d[LDT] = ra[i].y; d[2 * LDT] = ra[i].z; d[3 * LDT] = ra[i].w; }
+        }
+#pragma unroll
+        for (int i = 0; i < SB; ++i) {
+            const int f = tid + i * 256;
+            if (TB) { const int row = f / (BK / 4), kq = f % (BK / 4); float* d = &Bs[row * LDT + kq * 4];
+                d[0] = rb[i].x; d[1] = rb[i].y; d[2] = rb[i].z; d[3] = rb[i].w; }
+            else { const int k = f / (BN / 4), nq = f % (BN / 4); float* d = &Bs[(nq * 4) * LDT + k];
+                d[0] = rb[i].x; d[LDT] = rb[i].y; d[2 * LDT] = rb[i].z; d[3 * LDT] = rb[i].w; }
+        }
+    };
+
+    if (kbeg < kend) fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        stage();
+        __syncthreads();
+        if (k0 + BK < kend) fetch(k0 + BK);
+        const float* ap = &As[(wr * WM + (lane & 31)) * LDT + (lane >> 5)];
+        const float* bp = &Bs[(wc * WN + (lane & 31)) * LDT + (lane >> 5)];
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = ap[i * 32 * LDT + kk];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = bp[j * 32 * LDT + kk];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: acc[r] holds row (r&3) + 8*(r>>2) + 4*(lane>>5), column lane&31 of its 32x32 block
+    TC* C = reinterpret_cast<TC*>(p.C) + b1 * p.sC1 + b2 * p.sC2;
+    const T* R = p.R ? reinterpret_cast<const T*>(p.R) + b1 * p.sR1 + b2 * p.sR2 : nullptr;
+    const T* bias = reinterpret_cast<const T*>(p.bias);
+    const bool first_split = (ks == 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wc * WN + j * 32 + (lane & 31);
+            if (col >= p.N) continue;
+            const float bv = (bias && first_split) ? ldf<T>(bias + col) : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wr * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row >= p.M) continue;
+                float v = p.alpha * acc[i][j][r] + bv;
+                if (R && first_split) v += ldf<T>(R + (long long)row * p.ldr + col);
+                TC* c = C + (long long)row * p.ldc + col;
+                if (p.atomic) {
+                    atomicAdd(reinterpret_cast<float*>(c), v);       // fp32 only (checked on the host)
+                } else {
+                    if (p.act == TC_ACT_SIGMOID) v = sigmoid_f(v);
+                    if (p.accumulate) v += ldf<TC>(c);
+                    stf<TC>(c, v);
+                }
+            }
+        }
+}
+
+template <typename T, typename TC, int BM, int BN>
+int launch(const GemmDev& d, int transA, int transB, dim3 grid, hipStream_t s) {
+    dim3 block(256);
+    if (!transA && transB) hipLaunchKernelGGL((gemm_kernel<T, TC, BM, BN, false, true>), grid, block, 0, s, d);
+    else if (!transA && !transB) hipLaunchKernelGGL((gemm_kernel<T, TC, BM, BN, false, false>), grid, block, 0, s, d);
+    else if (transA && !transB) hipLaunchKernelGGL((gemm_kernel<T, TC, BM, BN, true, false>), grid, block, 0, s, d);
+    else hipLaunchKernelGGL((gemm_kernel<T, TC, BM, BN, true, true>), grid, block, 0, s, d);
+    return tc_launch_status();
+}
+
+template <typename T>
+int gemm_typed(const TcGemm* g, hipStream_t s) {
+    GemmDev d;
+    d.A = g->A; d.B = g->B; d.C = g->C; d.bias = g->bias; d.R = g->R;
+    d.M = g->M; d.N = g->N; d.K = g->K; d.lda = g->lda; d.ldb = g->ldb; d.ldc = g->ldc; d.ldr = g->ldr;
+    d.nb2 = g->nb2; d.splitk = g->splitk;
+    d.sA1 = g->sA1; d.sA2 = g->sA2; d.sB1 = g->sB1; d.sB2 = g->sB2;
+    d.sC1 = g->sC1; d.sC2 = g->sC2; d.sR1 = g->sR1; d.sR2 = g->sR2;
+    d.alpha = g->alpha; d.accumulate = g->accumulate; d.act = g->act;
+    d.atomic = (g->splitk > 1 || g->atomic) ? 1 : 0;
+    const int esz = (int)sizeof(T);
+    auto aligned = [&](const void* ptr, int ld, long long s1, long long s2) {
+        return ((uintptr_t)ptr % (4 * esz) == 0) && (ld % 4 == 0) && (s1 % 4 == 0) && (s2 % 4 == 0);
+    };
+    d.vecA = aligned(g->A, g->lda, g->sA1, g->sA2);
+    d.vecB = aligned(g->B, g->ldb, g->sB1, g->sB2);
+    const int nb = g->nb1 * g->nb2;
+    const long long big = (long long)((g->M + 127) / 128) * ((g->N + 127) / 128) * nb;
+    const bool use128 = big >= 192 && g->M >= 96 && g->N >= 96;
+    const int BM = use128 ? 128 : 64, BN = use128 ? 128 : 64;
+    int kchunk = (g->K + g->splitk - 1) / g->splitk;
+    kchunk = (kchunk + 15) / 16 * 16;
+    d.kchunk = kchunk;
+    d.splitk = (g->K + kchunk - 1) / kchunk;
+    if (d.splitk < 1) d.splitk = 1;
+    dim3 grid((g->N + BN - 1) / BN, (g->M + BM - 1) / BM, nb * d.splitk);
+    if (grid.y > 65535 || grid.z > 65535) return TC_ERR_ARG;
+    if (g->c_f32)
+        return use128 ? launch<T, float, 128, 128>(d, g->transA, g->transB, grid, s)
+                      : launch<T, float, 64, 64>(d, g->transA, g->transB, grid, s);
+    return use128 ? launch<T, T, 128, 128>(d, g->transA, g->transB, grid, s)
+                  : launch<T, T, 64, 64>(d, g->transA, g->transB, grid, s);
+}
+
+}  // namespace
+
+extern "C" int tc_gemm(const TcGemm* g, void* stream) {
+    if (!g || !g->A || !g->B || !g->C || g->M <= 0 || g->N <= 0 || g->K <= 0 || g->nb1 < 1 || g->nb2 < 1 ||
+        g->splitk < 1)
+        return TC_ERR_ARG;
+    if ((g->splitk > 1 || g->atomic) && (!g->accumulate || (g->dtype != TC_F32 && !g->c_f32) || g->act != TC_ACT_NONE)) return TC_ERR_ARG;
+    if (g->act != TC_ACT_NONE && g->act != TC_ACT_SIGMOID) return TC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    TC_DISPATCH_DTYPE(g->dtype, return gemm_typed<T>(g, s));
+    return TC_ERR_ARG;
+}

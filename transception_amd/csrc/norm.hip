@@ -1,0 +1,334 @@
+// LayerNorm (+ exact GELU) and BatchNorm (+ Hardswish / IFF activation / residual) for token-major activations.
+// HBM-bound kernels: one wavefront per LayerNorm row with the row held in registers (two-pass statistics via
+// wave shuffles); BatchNorm statistics as deterministic per-chunk partials that the apply kernel folds itself.
+#include "tc_common.h"
+
+namespace {
+
+constexpr int LN_MAXV = 8;   // vec4 per lane -> C <= 2048
+
+// ---------------------------------------------------------------------------------------------- LayerNorm
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ gamma,
+                                                     const T* __restrict__ beta, T* __restrict__ y, int ldy,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int rows,
+                                                     int C, float eps, int act) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = C >> 2;
+    const T* xr = x + (long long)row * ldx;
+    float4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int q = lane + i * 64;
+        if (q < nv) { v[i] = ld4<T>(xr + q * 4); s += v[i].x + v[i].y + v[i].z + v[i].w; }
+    }
+    const float mu = wave_sum(s) / (float)C;
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int q = lane + i * 64;
+        if (q < nv) {
+            const float a = v[i].x - mu, b = v[i].y - mu, c = v[i].z - mu, d = v[i].w - mu;
+            s2 += a * a + b * b + c * c + d * d;
+        }
+    }
+    const float rs = rsqrtf(wave_sum(s2) / (float)C + eps);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    T* yr = y + (long long)row * ldy;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int q = lane + i * 64;
+        if (q < nv) {
+            const float4 g = ld4<T>(gamma + q * 4), b = ld4<T>(beta + q * 4);
+            float4 o;
+            o.x = (v[i].x - mu) * rs * g.x + b.x; o.y = (v[i].y - mu) * rs * g.y + b.y;
+            o.z = (v[i].z - mu) * rs * g.z + b.z; o.w = (v[i].w - mu) * rs * g.w + b.w;
+            if (act == TC_ACT_GELU) { o.x = gelu_f(o.x); o.y = gelu_f(o.y); o.z = gelu_f(o.z); o.w = gelu_f(o.w); }
+            st4<T>(yr + q * 4, o);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ x, int ldx,
+                                                     const T* __restrict__ gamma, const T* __restrict__ beta,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     T* __restrict__ dx, int lddx, const T* __restrict__ dres, int ldres,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int C,
+                                                     int act) {
+    extern __shared__ float red[];           // [4 waves][2][C]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = C >> 2;
+    float4 g[LN_MAXV], b[LN_MAXV], ag[LN_MAXV], ab[LN_MAXV];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int q = lane + i * 64;
+        ag[i] = ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < nv) { g[i] = ld4<T>(gamma + q * 4); b[i] = ld4<T>(beta + q * 4); }
+    }
+    const float invC = 1.0f / (float)C;
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        const T* xr = x + (long long)row * ldx;
+        const T* dyr = dy + (long long)row * lddy;
+        float4 xh[LN_MAXV], gg[LN_MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int q = lane + i * 64;
+            if (q < nv) {
+                float4 xv = ld4<T>(xr + q * 4), d = ld4<T>(dyr + q * 4);
+                xv.x = (xv.x - mu) * rs; xv.y = (xv.y - mu) * rs; xv.z = (xv.z - mu) * rs; xv.w = (xv.w - mu) * rs;
+                if (act == TC_ACT_GELU) {
+                    d.x *= gelu_grad_f(xv.x * g[i].x + b[i].x); d.y *= gelu_grad_f(xv.y * g[i].y + b[i].y);
+                    d.z *= gelu_grad_f(xv.z * g[i].z + b[i].z); d.w *= gelu_grad_f(xv.w * g[i].w + b[i].w);
+                }
+                ag[i].x += d.x * xv.x; ag[i].y += d.y * xv.y; ag[i].z += d.z * xv.z; ag[i].w += d.w * xv.w;
+                ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
+                d.x *= g[i].x; d.y *= g[i].y; d.z *= g[i].z; d.w *= g[i].w;
+                s1 += d.x + d.y + d.z + d.w;
+                s2 += d.x * xv.x + d.y * xv.y + d.z * xv.z + d.w * xv.w;
+                xh[i] = xv; gg[i] = d;
+            }
+        }
+        s1 = wave_sum(s1) * invC; s2 = wave_sum(s2) * invC;
+        T* dxr = dx + (long long)row * lddx;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int q = lane + i * 64;
+            if (q < nv) {
+                float4 o;
+                o.x = rs * (gg[i].x - s1 - xh[i].x * s2); o.y = rs * (gg[i].y - s1 - xh[i].y * s2);
+                o.z = rs * (gg[i].z - s1 - xh[i].z * s2); o.w = rs * (gg[i].w - s1 - xh[i].w * s2);
+                if (dres) { const float4 r = ld4<T>(dres + (long long)row * ldres + q * 4);
+                    o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
+                st4<T>(dxr + q * 4, o);
+            }
+        }
+    }
+    // cross-wave reduction of the per-lane dgamma/dbeta partials, then one atomic per channel per block
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int q = lane + i * 64;
+        if (q < nv) {
+            float* r0 = red + (wave * 2 + 0) * C + q * 4; float* r1 = red + (wave * 2 + 1) * C + q * 4;
+            r0[0] = ag[i].x; r0[1] = ag[i].y; r0[2] = ag[i].z; r0[3] = ag[i].w;
+            r1[0] = ab[i].x; r1[1] = ab[i].y; r1[2] = ab[i].z; r1[3] = ab[i].w;
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a = 0.f, bb = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { a += red[(w * 2 + 0) * C + c]; bb += red[(w * 2 + 1) * C + c]; }
+        atomicAdd(dgamma + c, a);
+        atomicAdd(dbeta + c, bb);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- BatchNorm
+// scratch layout: shift[C] | S1[nchunk][C] | S2[nchunk][C]
+__host__ __device__ inline int bn_nchunk(int rows) { int n = (rows + 127) / 128; return n < 1 ? 1 : (n > 32 ? 32 : n); }
+
+// mode 0 (forward stats):  S1 = sum(x - shift), S2 = sum((x-shift)^2), shift = x[0, c]
+// mode 1 (backward sums):  S1 = sum(dz), S2 = sum(dz * xhat), dz = dy * act'(z)
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy,
+                                                         const T* __restrict__ gamma, const T* __restrict__ beta,
+                                                         const float* __restrict__ save_mean,
+                                                         const float* __restrict__ save_rstd, float* __restrict__ scratch,
+                                                         int rows, int C, int act) {
+    __shared__ float r1[4][64], r2[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + tx;
+    const int nchunk = gridDim.x, chunk = blockIdx.x;
+    const int per = (rows + nchunk - 1) / nchunk;
+    const int rbeg = chunk * per, rend = min(rows, rbeg + per);
+    float s1 = 0.f, s2 = 0.f;
+    if (c < C) {
+        if (MODE == 0) {
+            const float sh = ldf<T>(x + c);
+            if (chunk == 0 && ty == 0) scratch[c] = sh;
+            for (int r = rbeg + ty; r < rend; r += 4) {
+                const float v = ldf<T>(x + (long long)r * ldx + c) - sh;
+                s1 += v; s2 += v * v;
+            }
+        } else {
+            const float mu = save_mean[c], rs = save_rstd[c];
+            const float g = ldf<T>(gamma + c), b = ldf<T>(beta + c);
+            for (int r = rbeg + ty; r < rend; r += 4) {
+                const float xh = (ldf<T>(x + (long long)r * ldx + c) - mu) * rs;
+                float d = ldf<T>(dy + (long long)r * lddy + c);
+                if (act != TC_ACT_NONE) d *= act_grad(act, xh * g + b);
+                s1 += d; s2 += d * xh;
+            }
+        }
+    }
+    r1[ty][tx] = s1; r2[ty][tx] = s2;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        scratch[C + chunk * C + c] = r1[0][tx] + r1[1][tx] + r1[2][tx] + r1[3][tx];
+        scratch[C + nchunk * C + chunk * C + c] = r2[0][tx] + r2[1][tx] + r2[2][tx] + r2[3][tx];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ gamma,
+                                                       const T* __restrict__ beta, float* __restrict__ running_mean,
+                                                       float* __restrict__ running_var, const T* __restrict__ res, int ldres,
+                                                       T* __restrict__ y, int ldy, float* __restrict__ save_mean,
+                                                       float* __restrict__ save_rstd, const float* __restrict__ scratch,
+                                                       int nchunk, int rows, int C, float eps, float momentum, int training,
+                                                       int act) {
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;       // 16 channel quads x 16 row lanes
+    const int c = blockIdx.y * 64 + tx * 4;
+    if (c >= C) return;
+    float mu[4], rs[4];
+    if (training) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s1 = 0.f, s2 = 0.f;
+            for (int k = 0; k < nchunk; ++k) { s1 += scratch[C + k * C + c + j]; s2 += scratch[C + nchunk * C + k * C + c + j]; }
+            const float m1 = s1 / (float)rows;
+            const float var = fmaxf(s2 / (float)rows - m1 * m1, 0.f);
+            mu[j] = scratch[c + j] + m1;
+            rs[j] = rsqrtf(var + eps);
+            if (blockIdx.x == 0 && ty == 0) {
+                save_mean[c + j] = mu[j]; save_rstd[c + j] = rs[j];
+                const float unbiased = rows > 1 ? var * (float)rows / (float)(rows - 1) : var;
+                running_mean[c + j] = (1.f - momentum) * running_mean[c + j] + momentum * mu[j];
+                running_var[c + j] = (1.f - momentum) * running_var[c + j] + momentum * unbiased;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { mu[j] = running_mean[c + j]; rs[j] = rsqrtf(running_var[c + j] + eps); }
+    }
+    const float4 g = ld4<T>(gamma + c), b = ld4<T>(beta + c);
+    for (int r = blockIdx.x * 16 + ty; r < rows; r += gridDim.x * 16) {
+        float4 v = ld4<T>(x + (long long)r * ldx + c);
+        v.x = (v.x - mu[0]) * rs[0] * g.x + b.x; v.y = (v.y - mu[1]) * rs[1] * g.y + b.y;
+        v.z = (v.z - mu[2]) * rs[2] * g.z + b.z; v.w = (v.w - mu[3]) * rs[3] * g.w + b.w;
+        if (act != TC_ACT_NONE) { v.x = apply_act(act, v.x); v.y = apply_act(act, v.y); v.z = apply_act(act, v.z); v.w = apply_act(act, v.w); }
+        if (res) { const float4 q = ld4<T>(res + (long long)r * ldres + c); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+        st4<T>(y + (long long)r * ldy + c, v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ x, int ldx,
+                                                           const T* __restrict__ gamma, const T* __restrict__ beta,
+                                                           const float* __restrict__ save_mean,
+                                                           const float* __restrict__ save_rstd, T* __restrict__ dx, int lddx,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           const float* __restrict__ scratch, int nchunk, int rows, int C,
+                                                           int act, int accumulate) {
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int c = blockIdx.y * 64 + tx * 4;
+    if (c >= C) return;
+    float mu[4], rs[4], m1[4], m2[4], gam[4], bet[4];
+    const float4 g = ld4<T>(gamma + c), b = ld4<T>(beta + c);
+    gam[0] = g.x; gam[1] = g.y; gam[2] = g.z; gam[3] = g.w;
+    bet[0] = b.x; bet[1] = b.y; bet[2] = b.z; bet[3] = b.w;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int k = 0; k < nchunk; ++k) { s1 += scratch[C + k * C + c + j]; s2 += scratch[C + nchunk * C + k * C + c + j]; }
+        mu[j] = save_mean[c + j]; rs[j] = save_rstd[c + j];
+        m1[j] = s1 / (float)rows; m2[j] = s2 / (float)rows;
+        if (blockIdx.x == 0 && ty == 0) { dgamma[c + j] += s2; dbeta[c + j] += s1; }
+    }
+    for (int r = blockIdx.x * 16 + ty; r < rows; r += gridDim.x * 16) {
+        const float4 xv = ld4<T>(x + (long long)r * ldx + c);
+        const float4 dv = ld4<T>(dy + (long long)r * lddy + c);
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+        const float ds[4] = {dv.x, dv.y, dv.z, dv.w};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xh = (xs[j] - mu[j]) * rs[j];
+            float d = ds[j];
+            if (act != TC_ACT_NONE) d *= act_grad(act, xh * gam[j] + bet[j]);
+            o[j] = gam[j] * rs[j] * (d - m1[j] - xh * m2[j]);
+        }
+        if (accumulate) { const float4 q = ld4<T>(dx + (long long)r * lddx + c); o[0] += q.x; o[1] += q.y; o[2] += q.z; o[3] += q.w; }
+        st4<T>(dx + (long long)r * lddx + c, make_float4(o[0], o[1], o[2], o[3]));
+    }
+}
+
+}  // namespace
+
+extern "C" int tc_layernorm_fwd(const void* x, int ldx, const void* gamma, const void* beta, void* y, int ldy,
+                                float* mean, float* rstd, int rows, int C, float eps, int act, int dtype, void* stream) {
+    if (!x || !y || !gamma || !beta || !mean || !rstd || rows <= 0 || C <= 0 || (C & 3) || C > 256 * LN_MAXV ||
+        (ldx & 3) || (ldy & 3) || (act != TC_ACT_NONE && act != TC_ACT_GELU))
+        return TC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ln_fwd_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, (const T*)x, ldx,
+                                                (const T*)gamma, (const T*)beta, (T*)y, ldy, mean, rstd, rows, C, eps, act));
+    return tc_launch_status();
+}
+
+extern "C" int tc_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx, const void* gamma, const void* beta,
+                                const float* mean, const float* rstd, void* dx, int lddx, const void* dres, int ldres,
+                                float* dgamma, float* dbeta, int rows, int C, int act, int dtype, void* stream) {
+    if (!dy || !x || !gamma || !beta || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0 || C <= 0 || (C & 3) ||
+        C > 256 * LN_MAXV || (ldx & 3) || (lddy & 3) || (lddx & 3) || (dres && (ldres & 3)))
+        return TC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = tc_blocks(rows, 16, 1024);
+    const size_t shm = (size_t)8 * C * sizeof(float);
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T>), dim3(grid), dim3(256), shm, s, (const T*)dy, lddy,
+                                                (const T*)x, ldx, (const T*)gamma, (const T*)beta, mean, rstd, (T*)dx, lddx,
+                                                (const T*)dres, ldres, dgamma, dbeta, rows, C, act));
+    return tc_launch_status();
+}
+
+extern "C" long long tc_bn_scratch_floats(int rows, int C) { return (long long)C * (1 + 2 * bn_nchunk(rows)); }
+
+extern "C" int tc_bn_fwd(const void* x, int ldx, const void* gamma, const void* beta, float* running_mean,
+                         float* running_var, const void* res, int ldres, void* y, int ldy, float* save_mean,
+                         float* save_rstd, float* partial, int rows, int C, float eps, float momentum, int training,
+                         int act, int dtype, void* stream) {
+    if (!x || !gamma || !beta || !running_mean || !running_var || !y || rows <= 0 || C <= 0 || (C & 3) || (ldx & 3) ||
+        (ldy & 3) || (res && (ldres & 3)) || (training && (!save_mean || !save_rstd || !partial)))
+        return TC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int nchunk = bn_nchunk(rows);
+    const int cb = (C + 63) / 64;
+    TC_DISPATCH_DTYPE(dtype, {
+        if (training) {
+            hipLaunchKernelGGL((bn_partial_kernel<T, 0>), dim3(nchunk, cb), dim3(256), 0, s, (const T*)x, ldx, (const T*)nullptr,
+                               0, (const T*)gamma, (const T*)beta, (const float*)nullptr, (const float*)nullptr, partial, rows,
+                               C, act);
+        }
+        const int rb = tc_blocks(rows, 64, 512);
+        hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(rb, cb), dim3(256), 0, s, (const T*)x, ldx, (const T*)gamma,
+                           (const T*)beta, running_mean, running_var, (const T*)res, ldres, (T*)y, ldy, save_mean, save_rstd,
+                           partial, nchunk, rows, C, eps, momentum, training, act);
+    });
+    return tc_launch_status();
+}
+
+extern "C" int tc_bn_bwd(const void* dy, int lddy, const void* x, int ldx, const void* gamma, const void* beta,
+                         const float* save_mean, const float* save_rstd, void* dx, int lddx, float* dgamma, float* dbeta,
+                         float* partial, int rows, int C, int act, int accumulate, int dtype, void* stream) {
+    if (!dy || !x || !gamma || !beta || !save_mean || !save_rstd || !dx || !dgamma || !dbeta || !partial || rows <= 0 ||
+        C <= 0 || (C & 3) || (ldx & 3) || (lddy & 3) || (lddx & 3))
+        return TC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int nchunk = bn_nchunk(rows);
+    const int cb = (C + 63) / 64;
+    TC_DISPATCH_DTYPE(dtype, {
+        hipLaunchKernelGGL((bn_partial_kernel<T, 1>), dim3(nchunk, cb), dim3(256), 0, s, (const T*)x, ldx, (const T*)dy, lddy,
+                           (const T*)gamma, (const T*)beta, save_mean, save_rstd, partial, rows, C, act);
+        const int rb = tc_blocks(rows, 64, 512);
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(rb, cb), dim3(256), 0, s, (const T*)dy, lddy, (const T*)x, ldx,
+                           (const T*)gamma, (const T*)beta, save_mean, save_rstd, (T*)dx, lddx, dgamma, dbeta, partial, nchunk,
+                           rows, C, act, accumulate);
+    });
+    return tc_launch_status();
+}

@@ -1,0 +1,145 @@
+// Softmax along either axis of a batch of row-major [R, Ccols] matrices (forward and backward).
+// axis=1: one wavefront per row, shuffle reductions.  axis=0 (softmax over tokens, per channel): a block owns
+// 64 columns (16 lanes x 4 channels = 256 B per row) and 16 row lanes, reductions through LDS.
+#include "tc_common.h"
+
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_fwd(const T* __restrict__ x, T* __restrict__ y, long long sbx, long long sby,
+                                                        int R, int Cc, int ldx, int ldy, long long nrows) {
+    const int lane = threadIdx.x & 63;
+    const long long gr = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gr >= nrows) return;
+    const int b = (int)(gr / R), r = (int)(gr % R);
+    const T* xr = x + b * sbx + (long long)r * ldx;
+    T* yr = y + b * sby + (long long)r * ldy;
+    float m = -INFINITY;
+    for (int c = lane; c < Cc; c += 64) m = fmaxf(m, ldf<T>(xr + c));
+    m = wave_max(m);
+    float s = 0.f;
+    for (int c = lane; c < Cc; c += 64) s += __expf(ldf<T>(xr + c) - m);
+    s = 1.0f / wave_sum(s);
+    for (int c = lane; c < Cc; c += 64) stf<T>(yr + c, __expf(ldf<T>(xr + c) - m) * s);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_bwd(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx,
+                                                        long long sbdy, long long sby, long long sbdx, int R, int Cc, int lddy,
+                                                        int ldy, int lddx, long long nrows, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const long long gr = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gr >= nrows) return;
+    const int b = (int)(gr / R), r = (int)(gr % R);
+    const T* dyr = dy + b * sbdy + (long long)r * lddy;
+    const T* yr = y + b * sby + (long long)r * ldy;
+    T* dxr = dx + b * sbdx + (long long)r * lddx;
+    float s = 0.f;
+    for (int c = lane; c < Cc; c += 64) s += ldf<T>(dyr + c) * ldf<T>(yr + c);
+    s = wave_sum(s);
+    for (int c = lane; c < Cc; c += 64) {
+        float v = ldf<T>(yr + c) * (ldf<T>(dyr + c) - s);
+        if (accumulate) v += ldf<T>(dxr + c);
+        stf<T>(dxr + c, v);
+    }
+}
+
+__device__ __forceinline__ float4 f4max(float4 a, float4 b) { return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)); }
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+template <bool MAX>
+__device__ __forceinline__ float4 block_reduce16(float4 v, float4 (*sm)[16], int tx, int ty) {
+    sm[ty][tx] = v;
+    __syncthreads();
+    float4 r = sm[0][tx];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) r = MAX ? f4max(r, sm[i][tx]) : f4add(r, sm[i][tx]);
+    __syncthreads();
+    return r;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_cols_fwd(const T* __restrict__ x, T* __restrict__ y, long long sbx, long long sby,
+                                                        int R, int Cc, int ldx, int ldy) {
+    __shared__ float4 sm[16][16];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + tx * 4;
+    const bool ok = c < Cc;
+    const T* xb = x + blockIdx.y * sbx + (ok ? c : 0);
+    T* yb = y + blockIdx.y * sby + (ok ? c : 0);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    if (ok) for (int r = ty; r < R; r += 16) m = f4max(m, ld4<T>(xb + (long long)r * ldx));
+    m = block_reduce16<true>(m, sm, tx, ty);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) for (int r = ty; r < R; r += 16) {
+        const float4 v = ld4<T>(xb + (long long)r * ldx);
+        s.x += __expf(v.x - m.x); s.y += __expf(v.y - m.y); s.z += __expf(v.z - m.z); s.w += __expf(v.w - m.w);
+    }
+    s = block_reduce16<false>(s, sm, tx, ty);
+    if (!ok) return;
+    s.x = 1.f / s.x; s.y = 1.f / s.y; s.z = 1.f / s.z; s.w = 1.f / s.w;
+    for (int r = ty; r < R; r += 16) {
+        float4 v = ld4<T>(xb + (long long)r * ldx);
+        v.x = __expf(v.x - m.x) * s.x; v.y = __expf(v.y - m.y) * s.y; v.z = __expf(v.z - m.z) * s.z; v.w = __expf(v.w - m.w) * s.w;
+        st4<T>(yb + (long long)r * ldy, v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_cols_bwd(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx,
+                                                        long long sbdy, long long sby, long long sbdx, int R, int Cc, int lddy,
+                                                        int ldy, int lddx, int accumulate) {
+    __shared__ float4 sm[16][16];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + tx * 4;
+    const bool ok = c < Cc;
+    const T* dyb = dy + blockIdx.y * sbdy + (ok ? c : 0);
+    const T* yb = y + blockIdx.y * sby + (ok ? c : 0);
+    T* dxb = dx + blockIdx.y * sbdx + (ok ? c : 0);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) for (int r = ty; r < R; r += 16) {
+        const float4 a = ld4<T>(dyb + (long long)r * lddy), p = ld4<T>(yb + (long long)r * ldy);
+        s.x += a.x * p.x; s.y += a.y * p.y; s.z += a.z * p.z; s.w += a.w * p.w;
+    }
+    s = block_reduce16<false>(s, sm, tx, ty);
+    if (!ok) return;
+    for (int r = ty; r < R; r += 16) {
+        const float4 a = ld4<T>(dyb + (long long)r * lddy), p = ld4<T>(yb + (long long)r * ldy);
+        float4 o = make_float4(p.x * (a.x - s.x), p.y * (a.y - s.y), p.z * (a.z - s.z), p.w * (a.w - s.w));
+        if (accumulate) { const float4 q = ld4<T>(dxb + (long long)r * lddx); o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w; }
+        st4<T>(dxb + (long long)r * lddx, o);
+    }
+}
+
+}  // namespace
+
+extern "C" int tc_softmax_fwd(const void* x, void* y, int nb, long long sbx, long long sby, int R, int Cc, int ldx, int ldy,
+                              int axis, int dtype, void* stream) {
+    if (!x || !y || nb <= 0 || R <= 0 || Cc <= 0 || (axis != 0 && axis != 1)) return TC_ERR_ARG;
+    if (axis == 0 && ((Cc & 3) || (ldx & 3) || (ldy & 3) || (sbx & 3) || (sby & 3))) return TC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const long long nrows = (long long)nb * R;
+    TC_DISPATCH_DTYPE(dtype, {
+        if (axis == 1) hipLaunchKernelGGL((softmax_rows_fwd<T>), dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, s, (const T*)x,
+                                          (T*)y, sbx, sby, R, Cc, ldx, ldy, nrows);
+        else hipLaunchKernelGGL((softmax_cols_fwd<T>), dim3((Cc + 63) / 64, nb), dim3(256), 0, s, (const T*)x, (T*)y, sbx, sby, R,
+                                Cc, ldx, ldy);
+    });
+    return tc_launch_status();
+}
+
+extern "C" int tc_softmax_bwd(const void* dy, const void* y, void* dx, int nb, long long sbdy, long long sby, long long sbdx,
+                              int R, int Cc, int lddy, int ldy, int lddx, int axis, int accumulate, int dtype, void* stream) {
+    if (!dy || !y || !dx || nb <= 0 || R <= 0 || Cc <= 0 || (axis != 0 && axis != 1)) return TC_ERR_ARG;
+    if (axis == 0 && ((Cc & 3) || (lddy & 3) || (ldy & 3) || (lddx & 3) || (sbdy & 3) || (sby & 3) || (sbdx & 3)))
+        return TC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const long long nrows = (long long)nb * R;
+    TC_DISPATCH_DTYPE(dtype, {
+        if (axis == 1) hipLaunchKernelGGL((softmax_rows_bwd<T>), dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, s, (const T*)dy,
+                                          (const T*)y, (T*)dx, sbdy, sby, sbdx, R, Cc, lddy, ldy, lddx, nrows, accumulate);
+        else hipLaunchKernelGGL((softmax_cols_bwd<T>), dim3((Cc + 63) / 64, nb), dim3(256), 0, s, (const T*)dy, (const T*)y,
+                                (T*)dx, sbdy, sby, sbdx, R, Cc, lddy, ldy, lddx, accumulate);
+    });
+    return tc_launch_status();
+}

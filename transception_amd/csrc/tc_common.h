@@ -1,0 +1,114 @@
+// Shared device helpers for the TransCeption gfx950 kernels.
+// One storage type parameter T per kernel: float (parity path) or bf16_t (raw 16-bit storage, fp32 math).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/transception_hip.h"
+
+typedef unsigned short bf16_t;
+
+#define TC_WAVE 64
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    unsigned u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);          // round to nearest even (NaN payloads not preserved)
+    return (bf16_t)(u >> 16);
+}
+
+template <typename T> __device__ __forceinline__ float ldf(const T* p);
+template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+template <typename T> __device__ __forceinline__ void stf(T* p, float v);
+template <> __device__ __forceinline__ void stf<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+
+// 4-element vector access (16 B for float, 8 B for bf16); caller guarantees alignment.
+template <typename T> __device__ __forceinline__ float4 ld4(const T* p);
+template <> __device__ __forceinline__ float4 ld4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <> __device__ __forceinline__ float4 ld4<bf16_t>(const bf16_t* p) {
+    uint2 r = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u),
+                       __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
+}
+template <typename T> __device__ __forceinline__ void st4(T* p, float4 v);
+template <> __device__ __forceinline__ void st4<float>(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, float4 v) {
+    uint2 r;
+    r.x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
+    r.y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
+    *reinterpret_cast<uint2*>(p) = r;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float hswish_f(float x) { return x * fminf(fmaxf(x + 3.0f, 0.0f), 6.0f) * (1.0f / 6.0f); }
+__device__ __forceinline__ float hswish_grad_f(float x) {
+    return x <= -3.0f ? 0.0f : (x >= 3.0f ? 1.0f : (2.0f * x + 3.0f) * (1.0f / 6.0f));
+}
+// IFF activation, reference MSTr.py:1270-1286: y * min(silu(y+3)/6, 1)
+__device__ __forceinline__ float coordact_f(float y) {
+    const float u = y + 3.0f;
+    return y * fminf(u * sigmoid_f(u) * (1.0f / 6.0f), 1.0f);
+}
+__device__ __forceinline__ float coordact_grad_f(float y) {
+    const float u = y + 3.0f, s = sigmoid_f(u);
+    const float g = u * s * (1.0f / 6.0f);
+    if (g >= 1.0f) return 1.0f;
+    const float dg = (s + u * s * (1.0f - s)) * (1.0f / 6.0f);
+    return g + y * dg;
+}
+
+// act codes shared by BN-apply / GEMM epilogues
+__device__ __forceinline__ float apply_act(int act, float v) {
+    switch (act) {
+        case TC_ACT_HSWISH: return hswish_f(v);
+        case TC_ACT_COORD: return coordact_f(v);
+        case TC_ACT_SIGMOID: return sigmoid_f(v);
+        case TC_ACT_GELU: return gelu_f(v);
+        default: return v;
+    }
+}
+__device__ __forceinline__ float act_grad(int act, float z) {
+    switch (act) {
+        case TC_ACT_HSWISH: return hswish_grad_f(z);
+        case TC_ACT_COORD: return coordact_grad_f(z);
+        case TC_ACT_SIGMOID: { const float s = sigmoid_f(z); return s * (1.0f - s); }
+        case TC_ACT_GELU: return gelu_grad_f(z);
+        default: return 1.0f;
+    }
+}
+
+static inline int tc_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? TC_OK : TC_ERR_LAUNCH;
+}
+static inline int tc_blocks(long long work, int per_block, int cap = 4096) {
+    long long b = (work + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    return (int)(b > cap ? cap : b);
+}
+
+#define TC_DISPATCH_DTYPE(dtype, ...)                                  \
+    do {                                                               \
+        if ((dtype) == TC_F32) { using T = float; __VA_ARGS__; }       \
+        else if ((dtype) == TC_BF16) { using T = bf16_t; __VA_ARGS__; }\
+        else return TC_ERR_ARG;                                        \
+    } while (0)

@@ -1,0 +1,145 @@
+// Reductions and training-step kernels: bias-gradient column sums, the fused CE + Dice segmentation loss
+// (trainer.py:141-143, utils.py:24-47) and the fused SGD-momentum update (trainer.py:125).
+#include "tc_common.h"
+
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int rows, int cols, int ldx, float* __restrict__ out,
+                                                     int nb, long long sb) {
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + tx;
+    float s = 0.f;
+    if (c < cols)
+        for (long long r = (long long)blockIdx.x * 4 + ty; r < (long long)rows * nb; r += (long long)gridDim.x * 4)
+            s += ldf<T>(x + (r / rows) * sb + (r % rows) * ldx + c);
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < cols) atomicAdd(out + c, red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]);
+}
+
+constexpr int MAXCLS = 16;
+
+template <typename T>
+__global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const T* __restrict__ logits, const long long* __restrict__ labels,
+                                                           float* __restrict__ prob, float* __restrict__ sums, int B, int ncls, int HW) {
+    __shared__ float red[4][1 + 3 * MAXCLS];
+    float ce = 0.f, I[MAXCLS], Y[MAXCLS], Z[MAXCLS];
+#pragma unroll
+    for (int k = 0; k < MAXCLS; ++k) I[k] = Y[k] = Z[k] = 0.f;
+    const long long n = (long long)B * HW;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int b = (int)(i / HW); const int p = (int)(i % HW);
+        const T* lp = logits + (long long)b * ncls * HW + p;
+        float v[MAXCLS], m = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < MAXCLS; ++k) if (k < ncls) { v[k] = ldf<T>(lp + (long long)k * HW); m = fmaxf(m, v[k]); }
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXCLS; ++k) if (k < ncls) { v[k] = expf(v[k] - m); s += v[k]; }
+        const float inv = 1.f / s;
+        const int lab = (int)labels[i];
+        float* pp = prob + (long long)b * ncls * HW + p;
+#pragma unroll
+        for (int k = 0; k < MAXCLS; ++k) if (k < ncls) {
+            const float pk = v[k] * inv;
+            pp[(long long)k * HW] = pk;
+            Z[k] += pk * pk;
+            if (k == lab) { I[k] += pk; Y[k] += 1.f; ce -= logf(fmaxf(pk, 1e-38f)); }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    ce = wave_sum(ce);
+    if (lane == 0) red[wave][0] = ce;
+#pragma unroll
+    for (int k = 0; k < MAXCLS; ++k) if (k < ncls) {
+        const float a = wave_sum(I[k]), b = wave_sum(Y[k]), c = wave_sum(Z[k]);
+        if (lane == 0) { red[wave][1 + 3 * k] = a; red[wave][2 + 3 * k] = b; red[wave][3 + 3 * k] = c; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 1 + 3 * ncls)
+        atomicAdd(sums + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float* __restrict__ prob, const long long* __restrict__ labels,
+                                                           const float* __restrict__ sums, T* __restrict__ dlogits, int B, int ncls,
+                                                           int HW, float w_ce, float w_dice, float n_pix, float gscale, const float* __restrict__ gscale_dev) {
+    if (gscale_dev) gscale *= *gscale_dev;
+    __shared__ float ca[MAXCLS], cb[MAXCLS];          // dDice/dp_c = ca[c]*onehot_c + cb[c]*p_c
+    if (threadIdx.x < ncls) {
+        const float I = sums[1 + 3 * threadIdx.x], Y = sums[2 + 3 * threadIdx.x], Z = sums[3 + 3 * threadIdx.x];
+        const float den = Z + Y + 1e-5f, num = 2.f * I + 1e-5f;
+        ca[threadIdx.x] = -w_dice / (float)ncls * 2.f / den;
+        cb[threadIdx.x] = w_dice / (float)ncls * 2.f * num / (den * den);
+    }
+    __syncthreads();
+    const long long n = (long long)B * HW;
+    const float cew = w_ce / n_pix;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int b = (int)(i / HW); const int p = (int)(i % HW);
+        const float* pp = prob + (long long)b * ncls * HW + p;
+        const int lab = (int)labels[i];
+        float pk[MAXCLS], g[MAXCLS], dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXCLS; ++k) if (k < ncls) {
+            pk[k] = pp[(long long)k * HW];
+            g[k] = (k == lab ? ca[k] : 0.f) + cb[k] * pk[k];
+            dot += g[k] * pk[k];
+        }
+        T* dp = dlogits + (long long)b * ncls * HW + p;
+#pragma unroll
+        for (int k = 0; k < MAXCLS; ++k) if (k < ncls)
+            stf<T>(dp + (long long)k * HW, gscale * (cew * (pk[k] - (k == lab ? 1.f : 0.f)) + pk[k] * (g[k] - dot)));
+    }
+}
+
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, long long n, float lr,
+                           float mom, float wd, float gscale, int first) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float w = p[i];
+        const float d = g[i] * gscale + wd * w;
+        const float b = first ? d : mom * buf[i] + d;
+        buf[i] = b;
+        p[i] = w - lr * b;
+    }
+}
+
+}  // namespace
+
+extern "C" int tc_colsum(const void* x, int rows, int cols, int ldx, int nb, long long sb, float* out, int accumulate, int dtype,
+                         void* stream) {
+    if (!x || !out || rows <= 0 || cols <= 0 || nb <= 0) return TC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (!accumulate && hipMemsetAsync(out, 0, sizeof(float) * cols, s) != hipSuccess) return TC_ERR_LAUNCH;
+    dim3 grid(tc_blocks((long long)rows * nb, 4 * 32, 256), (cols + 63) / 64);
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(256), 0, s, (const T*)x, rows, cols, ldx, out, nb, sb));
+    return tc_launch_status();
+}
+
+extern "C" int tc_seg_loss_fwd(const void* logits, const long long* labels, float* prob, float* sums, int B, int ncls, int HW,
+                               int dtype, void* stream) {
+    if (!logits || !labels || !prob || !sums || B <= 0 || ncls <= 0 || ncls > MAXCLS || HW <= 0) return TC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((seg_loss_fwd_kernel<T>), dim3(tc_blocks((long long)B * HW, 256, 1024)), dim3(256), 0, s,
+                                                (const T*)logits, labels, prob, sums, B, ncls, HW));
+    return tc_launch_status();
+}
+
+extern "C" int tc_seg_loss_bwd(const float* prob, const long long* labels, const float* sums, void* dlogits, int B, int ncls, int HW,
+                               float w_ce, float w_dice, float n_pix_global, float gscale, const float* gscale_dev, int dtype, void* stream) {
+    if (!prob || !labels || !sums || !dlogits || B <= 0 || ncls <= 0 || ncls > MAXCLS || HW <= 0) return TC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((seg_loss_bwd_kernel<T>), dim3(tc_blocks((long long)B * HW, 256, 2048)), dim3(256), 0, s,
+                                                prob, labels, sums, (T*)dlogits, B, ncls, HW, w_ce, w_dice, n_pix_global, gscale, gscale_dev));
+    return tc_launch_status();
+}
+
+extern "C" int tc_sgd_step(float* p, const float* grad, float* buf, long long n, float lr, float momentum, float wd, float gscale,
+                           int first, void* stream) {
+    if (!p || !grad || !buf || n <= 0) return TC_ERR_ARG;
+    hipLaunchKernelGGL(sgd_kernel, dim3(tc_blocks(n, 256 * 4, 4096)), dim3(256), 0, (hipStream_t)stream, p, grad, buf, n, lr, momentum, wd,
+                       gscale, first);
+    return tc_launch_status();
+}

@@ -1,0 +1,554 @@
+"""Host-side execution engine: a reverse-mode tape over raw HIP kernel launches.
+
+Instead of ~16k ATen autograd nodes (what the reference's eager forward builds), one
+training step here is a flat list of C-ABI kernel launches recorded on a tape; backward replays the tape in
+reverse, each entry launching the hand-written gradient kernels.  Gradients of activations live in buffers
+with the same layout as the activations (so column / row slices of a buffer receive their gradients in place,
+residual fan-in is fused as `accumulate` flags or by aliasing), and parameter gradients are accumulated by
+the kernels straight into the model's flat fp32 gradient arena.  Everything is asynchronous on the current
+HIP stream, with static shapes and no host synchronisation, so a whole step can be captured in a hipGraph.
+
+torch is used for device memory (torch.empty) and streams only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+
+from ._lib import (ACT_COORD, ACT_GELU, ACT_HSWISH, ACT_NONE, ACT_SIGMOID, TC_BF16, TC_F32, TcGemm, lib)
+
+_DT = {torch.float32: TC_F32, torch.bfloat16: TC_BF16}
+
+
+class P:
+    """Engine-side handle of one parameter: compute-dtype data + fp32 gradient view (or None when frozen)."""
+    __slots__ = ("data", "grad")
+
+    def __init__(self, data: torch.Tensor, grad: Optional[torch.Tensor]):
+        self.data = data
+        self.grad = grad
+
+
+class Var:
+    """A 2-D activation view [rows, cols] (last dim contiguous, row stride ld) plus its lazily created gradient.
+
+    Children made by cols()/rows()/reshape() share the root's storage *and* the root's gradient buffer."""
+    __slots__ = ("data", "root", "path", "kids", "grad_t", "whole_written", "part_written", "has_grad", "requires_grad")
+
+    def __init__(self, data: torch.Tensor, root: "Var" = None, path=None, requires_grad: bool = True):
+        assert data.dim() == 2 and (data.stride(1) == 1 or data.shape[1] == 1), (data.shape, data.stride())
+        self.data = data
+        self.root = root if root is not None else self
+        self.path = path or ()            # sequence of ('c', a, b) / ('r', a, b) / ('v', rows, cols) from the root
+        self.kids: Dict[tuple, Var] = {}
+        self.grad_t: Optional[torch.Tensor] = None     # root only
+        self.whole_written = False                     # root only
+        self.part_written = False                      # root only
+        self.has_grad = False                          # per slice object
+        self.requires_grad = requires_grad
+
+    rows = property(lambda s: s.data.shape[0])
+    cols = property(lambda s: s.data.shape[1])
+    ld = property(lambda s: s.data.stride(0))
+
+    def _kid(self, key, data):
+        k = self.kids.get(key)
+        if k is None:
+            k = Var(data, self.root, self.path + (key,), self.root.requires_grad)
+            self.kids[key] = k
+        return k
+
+    def colslice(self, a: int, b: int) -> "Var":
+        return self._kid(("c", a, b), self.data[:, a:b])
+
+    def rowslice(self, a: int, b: int) -> "Var":
+        return self._kid(("r", a, b), self.data[a:b])
+
+    def reshape(self, rows: int, cols: int) -> "Var":
+        assert self.data.is_contiguous()
+        return self._kid(("v", rows, cols), self.data.view(rows, cols))
+
+    @property
+    def is_whole(self) -> bool:
+        return all(k[0] == "v" for k in self.path)
+
+    def apply_path(self, t: torch.Tensor) -> torch.Tensor:
+        for k in self.path:
+            if k[0] == "c":
+                t = t[:, k[1]:k[2]]
+            elif k[0] == "r":
+                t = t[k[1]:k[2]]
+            else:
+                t = t.view(k[1], k[2])
+        return t
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+class Graph:
+    def __init__(self, dtype: torch.dtype, device, training: bool, record: bool):
+        self.L = lib()
+        self.dtype = dtype
+        self.dt = _DT[dtype]
+        self.dev = device
+        self.training = training
+        self.record = record
+        self.tape: List[Callable[[], None]] = []
+        self.stream = torch.cuda.current_stream(device).cuda_stream
+        self.n_launch = 0
+
+    # ------------------------------------------------------------------ memory
+    def new(self, rows: int, cols: int, requires_grad: bool = True) -> Var:
+        return Var(torch.empty((rows, cols), dtype=self.dtype, device=self.dev), requires_grad=requires_grad)
+
+    def f32(self, *shape) -> torch.Tensor:
+        return torch.empty(shape, dtype=torch.float32, device=self.dev)
+
+    # ------------------------------------------------------------------ gradient bookkeeping
+    def grad_of(self, v: Var) -> Optional[torch.Tensor]:
+        """Gradient view of v for READING (None if nothing was ever written to it)."""
+        r = v.root
+        if r.grad_t is None:
+            return None
+        if not v.is_whole and not (v.has_grad or r.whole_written):
+            return None
+        return v.apply_path(r.grad_t)
+
+    def wgrad(self, v: Var) -> Tuple[torch.Tensor, int]:
+        """Gradient view of v for WRITING and whether the kernel must accumulate into it."""
+        r = v.root
+        if v.is_whole:
+            acc = r.whole_written or r.part_written
+            if r.grad_t is None:
+                r.grad_t = torch.empty_like(r.data) if r.data.is_contiguous() else torch.empty(
+                    r.data.shape, dtype=r.data.dtype, device=r.data.device)
+                assert r.grad_t.stride() == r.data.stride(), "gradient layout must mirror the data layout"
+            r.whole_written = True
+        else:
+            if r.grad_t is None:
+                assert r.data.is_contiguous()
+                r.grad_t = torch.zeros_like(r.data)        # parts may stay unwritten
+            acc = v.has_grad or r.whole_written
+            v.has_grad = True
+            r.part_written = True
+        return v.apply_path(r.grad_t), int(acc)
+
+    def pass_grad(self, v: Var, src: torch.Tensor):
+        """v.grad (+)= src without a copy when v has no gradient yet (identity / residual branches)."""
+        if not v.requires_grad:
+            return
+        r = v.root
+        if v.is_whole and r.grad_t is None and src.stride() == r.data.stride() and src.shape == r.data.shape:
+            r.grad_t = src                                   # alias: later contributions accumulate in place
+            r.whole_written = True
+            return
+        g, acc = self.wgrad(v)
+        if acc:
+            self.L.tc_add(_ptr(g), g.stride(0), _ptr(src), src.stride(0), _ptr(g), g.stride(0), g.shape[0], g.shape[1],
+                          self.dt, self.stream)
+        else:
+            self.L.tc_copy3d(_ptr(src), 0, src.stride(0), _ptr(g), 0, g.stride(0), 1, g.shape[0], g.shape[1], 0, self.dt,
+                             self.stream)
+
+    def _write_or_add(self, v: Var, fn: Callable[[torch.Tensor], None]):
+        """For kernels without an accumulate mode: write directly, or via a temporary + add."""
+        g, acc = self.wgrad(v)
+        if not acc:
+            fn(g)
+        else:
+            tmp = torch.empty((g.shape[0], g.shape[1]), dtype=g.dtype, device=g.device)
+            fn(tmp)
+            self.L.tc_add(_ptr(g), g.stride(0), _ptr(tmp), tmp.stride(0), _ptr(g), g.stride(0), g.shape[0], g.shape[1],
+                          self.dt, self.stream)
+
+    def backward(self):
+        for fn in reversed(self.tape):
+            fn()
+        self.tape = []
+
+    def _rec(self, fn):
+        if self.record:
+            self.tape.append(fn)
+
+    # ------------------------------------------------------------------ GEMM plumbing
+    def _gemm(self, A, lda, B, ldb, Cm, ldc, M, N, K, tA, tB, bias=None, R=None, ldr=0, alpha=1.0, acc=0, act=ACT_NONE,
+              splitk=1, nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), c_f32=0, atomic=0):
+        g = TcGemm(A, B, Cm, bias, R, M, N, K, lda, ldb, ldc, ldr, tA, tB, nb1, nb2, sA[0], sA[1], sB[0], sB[1], sC[0], sC[1],
+                   sR[0], sR[1], alpha, acc, act, splitk, self.dt, c_f32, atomic)
+        self.n_launch += 1
+        self.L.tc_gemm(C.byref(g), self.stream)
+
+    @staticmethod
+    def _splitk(m_out: int, n_out: int, k_red: int) -> int:
+        tiles = ((m_out + 63) // 64) * ((n_out + 63) // 64)
+        return max(1, min(512 // max(tiles, 1), k_red // 256, 128))
+
+    # ------------------------------------------------------------------ ops
+    def linear(self, x: Var, W: P, b: Optional[P] = None, out: Optional[Var] = None, residual: Optional[Var] = None,
+               act: int = ACT_NONE, wcols: Optional[Tuple[int, int]] = None, accumulate: bool = False,
+               batch: Optional[Tuple[int, int, int, int]] = None) -> Var:
+        """out = act(x @ W[:, wcols]^T + b + residual)  (or out += ... when accumulate).  W is [N, K] (nn.Linear).
+
+        batch=(nb, sx, so, sr): x / out / residual are the views of batch 0 ([M, K] / [M, N]); batch i lives
+        sx / so / sr ELEMENTS further on in the same buffers (used to re-lay-out rows between buffers)."""
+        Wt = W.data if wcols is None else W.data[:, wcols[0]:wcols[1]]
+        N, K = Wt.shape
+        assert x.cols == K, (x.cols, K)
+        M = x.rows
+        if out is None:
+            assert batch is None
+            out = self.new(M, N)
+        assert out.rows == M and out.cols == N
+        nb, sx, so, sr = batch if batch is not None else (1, 0, 0, 0)
+        self._gemm(_ptr(x.data), x.ld, _ptr(Wt), Wt.stride(0), _ptr(out.data), out.ld, M, N, K, 0, 1,
+                   bias=_ptr(b.data) if b is not None else None, R=_ptr(residual.data) if residual is not None else None,
+                   ldr=residual.ld if residual is not None else 0, acc=int(accumulate), act=act, nb1=nb, sA=(sx, 0),
+                   sC=(so, 0), sR=(sr, 0))
+
+        def bwd():
+            dy = self.grad_of(out)
+            if dy is None:
+                return
+            dz = dy
+            if act == ACT_SIGMOID:
+                assert dy.is_contiguous() and out.data.is_contiguous() and nb == 1
+                dz = torch.empty_like(dy)
+                self.L.tc_sigmoid_bwd(_ptr(dy), _ptr(out.data), _ptr(dz), dy.numel(), self.dt, self.stream)
+            if x.requires_grad:
+                gx, acc = self.wgrad(x)
+                self._gemm(_ptr(dz), dz.stride(0), _ptr(Wt), Wt.stride(0), _ptr(gx), gx.stride(0), M, K, N, 0, 0, acc=acc,
+                           nb1=nb, sA=(so, 0), sC=(sx, 0))
+            if W.grad is not None:
+                gW = W.grad if wcols is None else W.grad[:, wcols[0]:wcols[1]]
+                self._gemm(_ptr(dz), dz.stride(0), _ptr(x.data), x.ld, _ptr(gW), gW.stride(0), N, K, M, 1, 0, acc=1,
+                           splitk=self._splitk(N, K, M), c_f32=1, nb1=nb, sA=(so, 0), sB=(sx, 0), atomic=int(nb > 1))
+            if b is not None and b.grad is not None:
+                self.L.tc_colsum(_ptr(dz), M, N, dz.stride(0), nb, so, _ptr(b.grad), 1, self.dt, self.stream)
+            if residual is not None:
+                assert nb == 1 or sr == so
+                self.pass_grad(residual, dy) if nb == 1 else self._pass_grad_batched(residual, dy, nb, M, N, so)
+        self._rec(bwd)
+        return out
+
+    def _pass_grad_batched(self, v: Var, src: torch.Tensor, nb: int, M: int, N: int, sb: int):
+        g, acc = self.wgrad(v)
+        self.L.tc_copy3d(_ptr(src), sb, src.stride(0), _ptr(g), sb, g.stride(0), nb, M, N, acc, self.dt, self.stream)
+
+    def layernorm(self, x: Var, g: P, b: P, eps: float = 1e-5, act: int = ACT_NONE, out: Optional[Var] = None) -> Var:
+        rows, Cc = x.rows, x.cols
+        if out is None:
+            out = self.new(rows, Cc)
+        mean, rstd = self.f32(rows), self.f32(rows)
+        self.L.tc_layernorm_fwd(_ptr(x.data), x.ld, _ptr(g.data), _ptr(b.data), _ptr(out.data), out.ld, _ptr(mean), _ptr(rstd),
+                                rows, Cc, eps, act, self.dt, self.stream)
+
+        def bwd():
+            dy = self.grad_of(out)
+            if dy is None or not x.requires_grad:
+                return
+            gx, acc = self.wgrad(x)
+            self.L.tc_layernorm_bwd(_ptr(dy), dy.stride(0), _ptr(x.data), x.ld, _ptr(g.data), _ptr(b.data), _ptr(mean),
+                                    _ptr(rstd), _ptr(gx), gx.stride(0), _ptr(gx) if acc else None, gx.stride(0),
+                                    _ptr(g.grad), _ptr(b.grad), rows, Cc, act, self.dt, self.stream)
+        self._rec(bwd)
+        return out
+
+    def dwconv(self, x: Var, w: P, b: Optional[P], B: int, H: int, W: int, k: int, stride: int = 1, add_input: bool = False,
+               out: Optional[Var] = None) -> Var:
+        Cc = x.cols
+        assert x.rows == B * H * W
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        if out is None:
+            out = self.new(B * Ho * Wo, Cc)
+        self.L.tc_dwconv_fwd(_ptr(x.data), x.ld, _ptr(w.data), _ptr(b.data) if b is not None else None, _ptr(out.data), out.ld,
+                             B, H, W, Cc, k, stride, int(add_input), self.dt, self.stream)
+
+        def bwd():
+            dy = self.grad_of(out)
+            if dy is None:
+                return
+            if x.requires_grad:
+                gx, acc = self.wgrad(x)
+                self.L.tc_dwconv_bwd_input(_ptr(dy), dy.stride(0), _ptr(w.data), _ptr(gx), gx.stride(0), B, H, W, Cc, k, stride,
+                                           int(add_input), acc, self.dt, self.stream)
+            if w.grad is not None:
+                self.L.tc_dwconv_bwd_weight(_ptr(dy), dy.stride(0), _ptr(x.data), x.ld, _ptr(w.grad),
+                                            _ptr(b.grad) if b is not None else None, B, H, W, Cc, k, stride, self.dt, self.stream)
+        self._rec(bwd)
+        return out
+
+    def batchnorm(self, x: Var, gamma: P, beta: P, running_mean: torch.Tensor, running_var: torch.Tensor, act: int = ACT_NONE,
+                  residual: Optional[Var] = None, out: Optional[Var] = None) -> Var:
+        rows, Cc = x.rows, x.cols
+        if out is None:
+            out = self.new(rows, Cc)
+        if self.record and not self.training:
+            raise NotImplementedError("backward through BatchNorm in eval mode is not part of the reference path")
+        smean = srstd = part = None
+        if self.training:
+            smean, srstd = self.f32(Cc), self.f32(Cc)
+            part = self.f32(int(self.L.tc_bn_scratch_floats(rows, Cc)))
+        self.L.tc_bn_fwd(_ptr(x.data), x.ld, _ptr(gamma.data), _ptr(beta.data), _ptr(running_mean), _ptr(running_var),
+                         _ptr(residual.data) if residual is not None else None, residual.ld if residual is not None else 0,
+                         _ptr(out.data), out.ld, _ptr(smean), _ptr(srstd), _ptr(part), rows, Cc, 1e-5, 0.1, int(self.training),
+                         act, self.dt, self.stream)
+
+        def bwd():
+            dy = self.grad_of(out)
+            if dy is None:
+                return
+            gx, acc = self.wgrad(x)
+            self.L.tc_bn_bwd(_ptr(dy), dy.stride(0), _ptr(x.data), x.ld, _ptr(gamma.data), _ptr(beta.data), _ptr(smean),
+                             _ptr(srstd), _ptr(gx), gx.stride(0), _ptr(gamma.grad), _ptr(beta.grad), _ptr(part), rows, Cc, act,
+                             acc, self.dt, self.stream)
+            if residual is not None:
+                self.pass_grad(residual, dy)
+        self._rec(bwd)
+        return out
+
+    def softmax(self, x: Var, nb: int, axis: int, out: Optional[Var] = None) -> Var:
+        """Softmax over axis (0 = rows, 1 = cols) of each of the nb stacked [rows/nb, cols] matrices."""
+        R, Cc = x.rows // nb, x.cols
+        if out is None:
+            out = self.new(x.rows, Cc)
+        self.L.tc_softmax_fwd(_ptr(x.data), _ptr(out.data), nb, R * x.ld, R * out.ld, R, Cc, x.ld, out.ld, axis, self.dt,
+                              self.stream)
+
+        def bwd():
+            dy = self.grad_of(out)
+            if dy is None:
+                return
+            gx, acc = self.wgrad(x)
+            self.L.tc_softmax_bwd(_ptr(dy), _ptr(out.data), _ptr(gx), nb, R * dy.stride(0), R * out.ld, R * gx.stride(0), R, Cc,
+                                  dy.stride(0), out.ld, gx.stride(0), axis, acc, self.dt, self.stream)
+        self._rec(bwd)
+        return out
+
+    def bmm(self, A: Var, B: Var, out: Var, M: int, N: int, K: int, tA: int, tB: int, nb1: int = 1, nb2: int = 1,
+            sA=(0, 0), sB=(0, 0), sC=(0, 0), alpha: float = 1.0) -> Var:
+        """out[b] = alpha * op(A[b]) op(B[b]); A/B/out are 2-D views whose data pointer is batch (0,0)."""
+        assert not (tA and tB)
+        self._gemm(_ptr(A.data), A.ld, _ptr(B.data), B.ld, _ptr(out.data), out.ld, M, N, K, tA, tB, alpha=alpha, nb1=nb1,
+                   nb2=nb2, sA=sA, sB=sB, sC=sC)
+
+        def bwd():
+            dC = self.grad_of(out)
+            if dC is None:
+                return
+            ldc = dC.stride(0)
+            kw = dict(alpha=alpha, nb1=nb1, nb2=nb2)
+            if A.requires_grad:
+                gA, acc = self.wgrad(A)
+                if not tA and not tB:      # dA[M,K] = dC[M,N] . B[K,N]^T
+                    self._gemm(_ptr(dC), ldc, _ptr(B.data), B.ld, _ptr(gA), gA.stride(0), M, K, N, 0, 1, acc=acc, sA=sC, sB=sB,
+                               sC=sA, **kw)
+                elif not tA and tB:        # B stored [N,K]: dA = dC . B
+                    self._gemm(_ptr(dC), ldc, _ptr(B.data), B.ld, _ptr(gA), gA.stride(0), M, K, N, 0, 0, acc=acc, sA=sC, sB=sB,
+                               sC=sA, **kw)
+                else:                      # A stored [K,M], B stored [K,N]: dA[K,M] = B[K,N] . dC[M,N]^T
+                    self._gemm(_ptr(B.data), B.ld, _ptr(dC), ldc, _ptr(gA), gA.stride(0), K, M, N, 0, 1, acc=acc, sA=sB, sB=sC,
+                               sC=sA, **kw)
+            if B.requires_grad:
+                gB, acc = self.wgrad(B)
+                if not tA and not tB:      # dB[K,N] = A[M,K]^T . dC[M,N]
+                    self._gemm(_ptr(A.data), A.ld, _ptr(dC), ldc, _ptr(gB), gB.stride(0), K, N, M, 1, 0, acc=acc, sA=sA, sB=sC,
+                               sC=sB, **kw)
+                elif not tA and tB:        # dB[N,K] = dC[M,N]^T . A[M,K]
+                    self._gemm(_ptr(dC), ldc, _ptr(A.data), A.ld, _ptr(gB), gB.stride(0), N, K, M, 1, 0, acc=acc, sA=sC, sB=sA,
+                               sC=sB, **kw)
+                else:                      # dB[K,N] = A_stored[K,M] . dC[M,N]
+                    self._gemm(_ptr(A.data), A.ld, _ptr(dC), ldc, _ptr(gB), gB.stride(0), K, N, M, 0, 0, acc=acc, sA=sA, sB=sC,
+                               sC=sB, **kw)
+        self._rec(bwd)
+        return out
+
+    def fma3(self, a: Var, b: Var, c: Var, alpha: float, out: Optional[Var] = None) -> Var:
+        """out = alpha*a + b*c"""
+        rows, Cc = a.rows, a.cols
+        if out is None:
+            out = self.new(rows, Cc)
+        self.L.tc_fma3_fwd(_ptr(a.data), a.ld, _ptr(b.data), b.ld, _ptr(c.data), c.ld, _ptr(out.data), out.ld, rows, Cc, alpha,
+                           self.dt, self.stream)
+
+        def bwd():
+            d = self.grad_of(out)
+            if d is None:
+                return
+            ga, acca = self.wgrad(a)
+            gb, accb = self.wgrad(b)
+            gc, accc = self.wgrad(c)
+            assert not acca and not accc, "fma3: a and c must be single-use"
+            self.L.tc_fma3_bwd(_ptr(d), d.stride(0), _ptr(b.data), b.ld, _ptr(c.data), c.ld, _ptr(ga), ga.stride(0), _ptr(gb),
+                               gb.stride(0), accb, _ptr(gc), gc.stride(0), rows, Cc, alpha, self.dt, self.stream)
+        self._rec(bwd)
+        return out
+
+    def coord_pool(self, x: Var, B: int, H: int, W: int) -> Var:
+        Cc = x.cols
+        assert x.data.is_contiguous()
+        out = self.new(B * (H + W), Cc)
+        self.L.tc_coord_pool_fwd(_ptr(x.data), _ptr(out.data), B, H, W, Cc, self.dt, self.stream)
+
+        def bwd():
+            d = self.grad_of(out)
+            if d is None:
+                return
+            gx, acc = self.wgrad(x)
+            self.L.tc_coord_pool_bwd(_ptr(d), _ptr(gx), B, H, W, Cc, acc, self.dt, self.stream)
+        self._rec(bwd)
+        return out
+
+    def coord_gate(self, x: Var, att: Var, B: int, H: int, W: int) -> Var:
+        Cc = x.cols
+        assert x.data.is_contiguous() and att.data.is_contiguous()
+        out = self.new(x.rows, Cc)
+        self.L.tc_coord_gate_fwd(_ptr(x.data), _ptr(att.data), _ptr(out.data), B, H, W, Cc, self.dt, self.stream)
+
+        def bwd():
+            d = self.grad_of(out)
+            if d is None:
+                return
+            gx, acc = self.wgrad(x)
+            ga, acca = self.wgrad(att)
+            assert not acca
+            self.L.tc_coord_gate_bwd(_ptr(d), _ptr(x.data), _ptr(att.data), _ptr(gx), acc, _ptr(ga), B, H, W, Cc, self.dt,
+                                     self.stream)
+        self._rec(bwd)
+        return out
+
+    def pixel_shuffle(self, x: Var, B: int, H: int, W: int, p: int) -> Var:
+        c = x.cols // (p * p)
+        assert x.data.is_contiguous()
+        out = self.new(B * H * p * W * p, c)
+        self.L.tc_pixel_shuffle(_ptr(x.data), _ptr(out.data), B, H, W, p, c, 0, self.dt, self.stream)
+
+        def bwd():
+            d = self.grad_of(out)
+            if d is None:
+                return
+            assert d.is_contiguous()
+            self._write_or_add(x, lambda g: self.L.tc_pixel_shuffle(_ptr(d), _ptr(g), B, H, W, p, c, 1, self.dt, self.stream))
+        self._rec(bwd)
+        return out
+
+    def patchify(self, buf: Var, off: int, sb: int, B: int, H: int, W: int, Cc: int, k: int) -> Var:
+        """Gather the k x k patches of the [B,H,W,Cc] map that starts `off` elements into each batch of `buf`."""
+        assert buf.data.is_contiguous() and buf.is_whole
+        out = self.new(B * (H // k) * (W // k), k * k * Cc)
+        base = buf.data.data_ptr() + off * buf.data.element_size()
+        self.L.tc_patchify(base, sb, Cc, _ptr(out.data), B, H, W, Cc, k, 0, self.dt, self.stream)
+
+        def bwd():
+            d = self.grad_of(out)
+            if d is None:
+                return
+            r = buf.root
+            first = r.grad_t is None
+            if first:
+                r.grad_t = torch.zeros_like(r.data)
+            r.part_written = True
+            gbase = r.grad_t.data_ptr() + off * r.grad_t.element_size()
+            self.L.tc_patchify(gbase, sb, Cc, _ptr(d), B, H, W, Cc, k, 2, self.dt, self.stream)
+        self._rec(bwd)
+        return out
+
+    def copy_rows(self, src: Var, src_off: int, src_sb: int, dst: Var, dst_off: int, dst_sb: int, nb: int, rows: int, cols: int):
+        """dst[b, r, :] = src[b, r, :] for batch-strided row blocks (offsets/strides in elements of the contiguous roots)."""
+        assert src.data.is_contiguous() and dst.data.is_contiguous() and src.is_whole and dst.is_whole
+        es = src.data.element_size()
+        self.L.tc_copy3d(src.data.data_ptr() + src_off * es, src_sb, src.ld, dst.data.data_ptr() + dst_off * es, dst_sb, dst.ld,
+                         nb, rows, cols, 0, self.dt, self.stream)
+
+        def bwd():
+            dg = self.grad_of(dst)
+            if dg is None:
+                return
+            r = src.root
+            if r.grad_t is None:
+                r.grad_t = torch.zeros_like(r.data)
+            r.part_written = True
+            self.L.tc_copy3d(dg.data_ptr() + dst_off * es, dst_sb, dst.ld, r.grad_t.data_ptr() + src_off * es, src_sb, src.ld,
+                             nb, rows, cols, 1, self.dt, self.stream)
+        self._rec(bwd)
+
+    def sr_deinterleave(self, x: Var, dst: Var, dst_off: int, dst_sb: int, B: int, Pn: int, Cc: int, mult: int):
+        """dst[b, g*Pn+pos, c] = x[b*Pn+pos, c*mult+g] written at element offset dst_off of each dst batch."""
+        assert x.data.is_contiguous() and dst.data.is_contiguous()
+        es = x.data.element_size()
+        self.L.tc_sr_deinterleave(_ptr(x.data), dst.data.data_ptr() + dst_off * es, dst_sb, dst.ld, B, Pn, Cc, mult, 0, self.dt,
+                                  self.stream)
+
+        def bwd():
+            dg = self.grad_of(dst)
+            if dg is None:
+                return
+            self._write_or_add(x, lambda g: self.L.tc_sr_deinterleave(_ptr(g), dg.data_ptr() + dst_off * es, dst_sb, dst.ld, B,
+                                                                      Pn, Cc, mult, 1, self.dt, self.stream))
+        self._rec(bwd)
+
+    def transpose(self, x: Var, nb: int) -> Var:
+        """[nb, R, C] -> [nb, C, R]"""
+        R, Cc = x.rows // nb, x.cols
+        assert x.data.is_contiguous()
+        out = self.new(nb * Cc, R)
+        self.L.tc_transpose(_ptr(x.data), _ptr(out.data), nb, R, Cc, self.dt, self.stream)
+
+        def bwd():
+            d = self.grad_of(out)
+            if d is None:
+                return
+            assert d.is_contiguous()
+            self._write_or_add(x, lambda g: self.L.tc_transpose(_ptr(d), _ptr(g), nb, Cc, R, self.dt, self.stream))
+        self._rec(bwd)
+        return out
+
+    def stem_im2col(self, img: torch.Tensor, B: int, in_ch: int, H: int, W: int) -> Var:
+        """7x7 s4 p3 patches of the NCHW image -> [B*(H/4)*(W/4), 148] (147 real columns); no gradient (network input)."""
+        Ho, Wo = (H - 1) // 4 + 1, (W - 1) // 4 + 1
+        out = self.new(B * Ho * Wo, 148, requires_grad=False)
+        self.L.tc_stem_im2col(_ptr(img), _ptr(out.data), 148, B, in_ch, H, W, self.dt, self.stream)
+        return out
+
+    def attention(self, q: Var, k: Var, v: Var, B: int, Nq: int, Nk: int, scale: float, out: Optional[Var] = None) -> Var:
+        """softmax(q k^T * scale) v per batch (single head, d = q.cols)."""
+        d = q.cols
+        if self.use_fused_attention:
+            return self._attention_fused(q, k, v, B, Nq, Nk, scale, out)
+        S = self.new(B * Nq, Nk)
+        self.bmm(q, k, S, Nq, Nk, d, 0, 1, nb1=B, sA=(Nq * q.ld, 0), sB=(Nk * k.ld, 0), sC=(Nq * Nk, 0), alpha=scale)
+        Pm = self.softmax(S, B, 1)
+        if out is None:
+            out = self.new(B * Nq, d)
+        self.bmm(Pm, v, out, Nq, d, Nk, 0, 0, nb1=B, sA=(Nq * Nk, 0), sB=(Nk * v.ld, 0), sC=(Nq * out.ld, 0))
+        return out
+
+    use_fused_attention = False
+
+    def _attention_fused(self, q: Var, k: Var, v: Var, B: int, Nq: int, Nk: int, scale: float, out: Optional[Var] = None) -> Var:
+        d = q.cols
+        assert d == 64
+        if out is None:
+            out = self.new(B * Nq, d)
+        lse = self.f32(B * Nq)
+        self.L.tc_attn_fwd(_ptr(q.data), q.ld, Nq * q.ld, _ptr(k.data), k.ld, _ptr(v.data), v.ld, Nk * k.ld, _ptr(out.data),
+                           out.ld, Nq * out.ld, _ptr(lse), B, Nq, Nk, scale, self.dt, self.stream)
+
+        def bwd():
+            dO = self.grad_of(out)
+            if dO is None:
+                return
+            gq, aq = self.wgrad(q)
+            gk, ak = self.wgrad(k)
+            gv, av = self.wgrad(v)
+            assert not aq and ak == av, "fused attention: q single-use, k/v written together"
+            delta = self.f32(B * Nq)
+            self.L.tc_attn_bwd(_ptr(q.data), q.ld, Nq * q.ld, _ptr(k.data), k.ld, _ptr(v.data), v.ld, Nk * k.ld, _ptr(out.data),
+                               out.ld, Nq * out.ld, _ptr(dO), dO.stride(0), Nq * dO.stride(0), _ptr(lse), _ptr(delta), _ptr(gq),
+                               gq.stride(0), Nq * gq.stride(0), _ptr(gk), gk.stride(0), _ptr(gv), gv.stride(0),
+                               Nk * gk.stride(0), ak, B, Nq, Nk, scale, self.dt, self.stream)
+        self._rec(bwd)
+        return out

@@ -1,0 +1,666 @@
+"""MSTransception / TransCeption: the reference's nn.Module surface over the MI355X engine.
+
+Drop-in boundary: same constructor signature as the reference's
+``networks/MSTr.py::MSTransception`` (MSTr.py:2760-2761), ``forward(x[B,1|3,H,W]) -> float32 logits
+[B,num_classes,H,W]``, and an identical ``state_dict`` schema (2200 keys, PyTorch-native weight layouts,
+aliases of the shared cpe/crpe modules included), so ``load_state_dict`` of a reference checkpoint is
+strict-clean and ``trainer.py`` / ``test.py`` style loops (``.train()/.eval()``, ``.parameters()``,
+``loss.backward()``, ``torch.no_grad()``) work unchanged.
+
+The sub-modules below are *parameter holders only* (never called); they are created in the reference's
+constructor order with the reference's initialisers so that a model built under the same torch seed has
+the same weights.  All arithmetic runs in ``_run`` as HIP kernel launches through ``engine.Graph``:
+token-major / NHWC activations, the four encoder scales written straight into one stage-major bridge
+buffer (no pack/unpack copies), weights and gradients in flat fp32 arenas.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from ._lib import ACT_COORD, ACT_GELU, ACT_HSWISH, ACT_NONE, ACT_SIGMOID, TC_BF16, TC_F32, lib
+from .engine import Graph, P, Var
+
+DIMS = (64, 128, 320, 512)
+LAYERS = (3, 8, 3)
+HEADS = 8
+CRPE_WINDOW = ((3, 2), (5, 3), (7, 3))
+SR_K = (8, 4, 2)
+MULT = (1, 2, 5, 8)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# parameter holders, built in the reference's construction order (RNG consumption == reference)
+# ----------------------------------------------------------------------------------------------------------
+def _xavier_convs(mod: nn.Module):
+    for m in mod.modules():
+        if isinstance(m, nn.Conv2d):
+            nn.init.xavier_uniform_(m.weight)
+            if m.bias is not None:
+                nn.init.zeros_(m.bias)
+        elif isinstance(m, nn.BatchNorm2d):
+            m.weight.data.fill_(1)
+            m.bias.data.zero_()
+
+
+def _mk_dwconv2d_bn(ch: int, stride: int) -> nn.Module:          # MSTr.py:309-353
+    m = nn.Module()
+    m.dwconv = nn.Conv2d(ch, ch, 3, stride, 1, groups=ch, bias=False)
+    m.pwconv = nn.Conv2d(ch, ch, 1, 1, 0, bias=False)
+    m.bn = nn.BatchNorm2d(ch)
+    _xavier_convs(m)
+    return m
+
+
+def _mk_patch_embed_stage(ch: int) -> nn.Module:                 # MSTr.py:704-722
+    m = nn.Module()
+    pes = []
+    for idx in range(3):
+        pe = nn.Module()
+        pe.patch_conv = _mk_dwconv2d_bn(ch, 2 if idx == 0 else 1)
+        pes.append(pe)
+    m.patch_embeds = nn.ModuleList(pes)
+    return m
+
+
+def _mk_conv2d_bn(cin: int, cout: int) -> nn.Module:             # MSTr.py:364-394
+    m = nn.Module()
+    m.conv = nn.Conv2d(cin, cout, 1, 1, 0, bias=False)
+    m.bn = nn.BatchNorm2d(cout)
+    nn.init.constant_(m.bn.weight, 1)
+    nn.init.constant_(m.bn.bias, 0)
+    nn.init.xavier_uniform_(m.conv.weight)
+    return m
+
+
+def _mk_mixffn_skip(c1: int, c2: int) -> nn.Module:              # MSTr.py:889-898
+    m = nn.Module()
+    m.fc1 = nn.Linear(c1, c2)
+    m.dwconv = nn.Module()
+    m.dwconv.dwconv = nn.Conv2d(c2, c2, 3, 1, 1, groups=c2)
+    m.fc2 = nn.Linear(c2, c1)
+    m.norm1 = nn.LayerNorm(c2)
+    m.norm2 = nn.LayerNorm(c2)      # present in the reference, never used (MSTr.py:897-898)
+    m.norm3 = nn.LayerNorm(c2)
+    return m
+
+
+def _mk_mhca_encoder(dim: int, layers: int) -> nn.Module:        # MSTr.py:949-978
+    m = nn.Module()
+    m.cpe = nn.Module()
+    m.cpe.proj = nn.Conv2d(dim, dim, 3, 1, 1, groups=dim)
+    ch = dim // HEADS
+    m.crpe = nn.Module()
+    m.crpe.conv_list = nn.ModuleList(
+        [nn.Conv2d(nh * ch, nh * ch, k, padding=k // 2, groups=nh * ch) for k, nh in CRPE_WINDOW])
+    blks = []
+    for _ in range(layers):
+        b = nn.Module()
+        b.cpe = m.cpe                       # shared modules -> state_dict aliases (MSTr.py:920-921)
+        b.crpe = m.crpe
+        b.factoratt_crpe = nn.Module()
+        b.factoratt_crpe.qkv = nn.Linear(dim, dim * 3, bias=True)
+        b.factoratt_crpe.proj = nn.Linear(dim, dim)
+        b.factoratt_crpe.crpe = m.crpe
+        b.mlp = _mk_mixffn_skip(dim, dim * 4)
+        b.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        b.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        blks.append(b)
+    m.MHCA_layers = nn.ModuleList(blks)
+    return m
+
+
+def _mk_resblock(ch: int) -> nn.Module:                          # MSTr.py:996-1039
+    m = nn.Module()
+    m.conv1 = _mk_conv2d_bn(ch, ch)
+    m.dwconv = nn.Conv2d(ch, ch, 3, 1, 1, bias=False, groups=ch)
+    m.norm = nn.BatchNorm2d(ch)
+    m.conv2 = _mk_conv2d_bn(ch, ch)
+    _xavier_convs(m)                        # self.apply(_init_weights): conv1.conv, dwconv, conv2.conv in order
+    return m
+
+
+def _mk_coord_att(inp: int, oup: int) -> nn.Module:              # MSTr.py:1304-1320
+    m = nn.Module()
+    mip = max(8, inp // 16)
+    m.conv1 = nn.Conv2d(inp, mip, 1)
+    m.bn1 = nn.BatchNorm2d(mip)
+    m.conv_h = nn.Conv2d(mip, inp, 1)
+    m.conv_w = nn.Conv2d(mip, inp, 1)
+    m.conv_in_out = nn.Conv2d(inp, oup, 1)
+    return m
+
+
+def _mk_mhca_stage(dim: int, out_dim: int, layers: int) -> nn.Module:   # MSTr.py:1350-1403
+    m = nn.Module()
+    m.mhca_blks = nn.ModuleList([_mk_mhca_encoder(dim, layers) for _ in range(3)])
+    m.InvRes = _mk_resblock(dim)
+    m.aggregate = _mk_coord_att(dim * 4, out_dim)
+    return m
+
+
+def _mk_eff_block(dim: int) -> nn.Module:                        # MSTr.py:146-162, 95-103
+    m = nn.Module()
+    m.norm1 = nn.LayerNorm(dim)
+    m.attn = nn.Module()
+    m.attn.keys = nn.Conv2d(dim, dim, 1)
+    m.attn.queries = nn.Conv2d(dim, dim, 1)
+    m.attn.values = nn.Conv2d(dim, dim, 1)
+    m.attn.reprojection = nn.Conv2d(dim, dim, 1)
+    m.norm2 = nn.LayerNorm(dim)
+    m.mlp = _mk_mixffn_skip(dim, dim * 4)
+    return m
+
+
+def _mk_scale_reduce(dim: int) -> nn.Module:                     # MSTr.py:2209-2223
+    m = nn.Module()
+    m.sr0 = nn.Conv2d(dim, dim, 8, 8)
+    m.sr1 = nn.Conv2d(dim * 2, dim * 2, 4, 4)
+    m.sr2 = nn.Conv2d(dim * 5, dim * 5, 2, 2)
+    m.norm = nn.LayerNorm(dim)
+    return m
+
+
+def _mk_bridge_layer(dim: int, ch_att: bool) -> nn.Module:       # MSTr.py:2356-2371
+    m = nn.Module()
+    m.norm1 = nn.LayerNorm(dim)
+    a = nn.Module()
+    if ch_att:
+        a.q = nn.Linear(dim, dim, bias=True)
+        a.k = nn.Linear(dim, dim, bias=True)
+        a.v = nn.Linear(dim, dim, bias=True)
+        a.proj = nn.Linear(dim, dim)
+    else:
+        a.q = nn.Linear(dim, dim, bias=True)
+        a.kv = nn.Linear(dim, dim * 2, bias=True)
+        a.proj = nn.Linear(dim, dim)
+    a.scale_reduce = _mk_scale_reduce(dim)     # unused (grad-less) inside the channel-attention layer
+    m.attn = a
+    m.norm2 = nn.LayerNorm(dim)
+    m.mixffn1 = _mk_mixffn_skip(dim, dim * 4)
+    m.mixffn2 = _mk_mixffn_skip(dim * 2, dim * 8)
+    m.mixffn3 = _mk_mixffn_skip(dim * 5, dim * 20)
+    m.mixffn4 = _mk_mixffn_skip(dim * 8, dim * 32)
+    return m
+
+
+def _mk_decoder_layer(in_out_chan, n_class: int, is_last: bool) -> nn.Module:   # MSTr.py:230-269
+    dims, out_dim = in_out_chan[0], in_out_chan[1]
+    m = nn.Module()
+    m.concat_linear = nn.Linear(dims * (4 if is_last else 2), out_dim)
+    m.layer_up = nn.Module()
+    if not is_last:
+        m.layer_up.expand = nn.Linear(out_dim, 2 * out_dim, bias=False)
+        m.layer_up.norm = nn.LayerNorm(out_dim // 2)
+    else:
+        m.layer_up.expand = nn.Linear(out_dim, 16 * out_dim, bias=False)
+        m.layer_up.norm = nn.LayerNorm(out_dim)
+        m.last_layer = nn.Conv2d(out_dim, n_class, 1)
+    m.layer_former_1 = _mk_eff_block(out_dim)
+    m.layer_former_2 = _mk_eff_block(out_dim)
+    for sub in m.modules():                 # MSTr.py:255-269
+        if isinstance(sub, (nn.Linear, nn.Conv2d)):
+            nn.init.xavier_uniform_(sub.weight)
+            if sub.bias is not None:
+                nn.init.zeros_(sub.bias)
+        elif isinstance(sub, nn.LayerNorm):
+            nn.init.ones_(sub.weight)
+            nn.init.zeros_(sub.bias)
+    return m
+
+
+def _mk_backbone() -> nn.Module:                                 # MSTr.py:1536-1671
+    m = nn.Module()
+    for i, d in enumerate(DIMS):
+        setattr(m, f"conv1_1_s{i + 1}", nn.Conv2d(3 * d, d, 1))     # dead parameters, kept for the schema
+    m.patch_embed_stage2 = _mk_patch_embed_stage(DIMS[0])
+    m.patch_embed_stage3 = _mk_patch_embed_stage(DIMS[1])
+    m.patch_embed_stage4 = _mk_patch_embed_stage(DIMS[2])
+    m.mhca_stage2 = _mk_mhca_stage(DIMS[0], DIMS[1], LAYERS[0])
+    m.mhca_stage3 = _mk_mhca_stage(DIMS[1], DIMS[2], LAYERS[1])
+    m.mhca_stage4 = _mk_mhca_stage(DIMS[2], DIMS[3], LAYERS[2])
+    m.patch_embed1 = nn.Module()
+    m.patch_embed1.proj = nn.Conv2d(3, DIMS[0], 7, 4, 3)
+    m.patch_embed1.norm = nn.LayerNorm(DIMS[0])
+    m.cpe = nn.Module()
+    m.cpe.proj = nn.Conv2d(DIMS[0], DIMS[0], 3, 1, 1, groups=DIMS[0])   # dead
+    m.block1 = nn.ModuleList([_mk_eff_block(DIMS[0]) for _ in range(2)])
+    m.norm1 = nn.LayerNorm(DIMS[0])
+    return m
+
+
+# ----------------------------------------------------------------------------------------------------------
+class _StepFn(torch.autograd.Function):
+    """Connects the engine's tape to loss.backward().  Parameter gradients are accumulated by the kernels into
+    the model's gradient arena (returned grads are None); see MSTransception._attach_grads."""
+
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        logits, G, out_var = model._run(x, record=True)
+        ctx.model, ctx.G, ctx.out_var = model, G, out_var
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        ctx.model._backward(ctx.G, ctx.out_var, dlogits)
+        ctx.G = ctx.out_var = None
+        return (None, None) + (None,) * len(ctx.model._uniq_params)
+
+
+class MSTransception(nn.Module):
+    def __init__(self, num_classes=9, head_count=8, dil_conv=1, token_mlp_mode="mix_skip", MSViT_config=2, concat='coord',
+                 have_bridge='original', use_sa_config=1, sa_ker=7, Stage_3or4=3, inter='res', num_sp=1,
+                 br_ch_att_list=[True, False, False, False]):
+        super().__init__()
+        if (token_mlp_mode != "mix_skip" or concat != "coord" or have_bridge not in ("original",) or Stage_3or4 != 3
+                or list(br_ch_att_list) != [True, False, False, False]):
+            raise NotImplementedError("only the default MSTransception configuration (the one train_MSTransception.py:168 "
+                                      "builds) is implemented; ablation switches are out of scope")
+        self.num_classes = num_classes
+        self.backbone = _mk_backbone()
+        self.bridge = nn.Module()
+        for i, ch in enumerate(br_ch_att_list):
+            setattr(self.bridge, f"bridge_layer{i + 1}", _mk_bridge_layer(64, ch))
+        ioc = [[32, 64, 64, 64], [144, 128, 128, 128], [288, 320, 320, 320], [512, 512, 512, 512]]
+        self.decoder_3 = _mk_decoder_layer(ioc[3], num_classes, False)
+        self.decoder_2 = _mk_decoder_layer(ioc[2], num_classes, False)
+        self.decoder_1 = _mk_decoder_layer(ioc[1], num_classes, False)
+        self.decoder_0 = _mk_decoder_layer(ioc[0], num_classes, True)
+        self.compute_dtype = torch.float32
+        self.use_fused_attention = True
+        self._flat: Optional[torch.Tensor] = None
+        self._gflat: Optional[torch.Tensor] = None
+        self._flat_lp: Optional[torch.Tensor] = None
+        self._index: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
+        self._uniq_params: List[nn.Parameter] = []
+        self._used: set = set()
+        self.last_launches = 0
+
+    # ------------------------------------------------------------------ flat parameter / gradient arenas
+    def set_compute_dtype(self, dtype: torch.dtype):
+        assert dtype in (torch.float32, torch.bfloat16)
+        self.compute_dtype = dtype
+        return self
+
+    def _ensure_flat(self, device):
+        uniq = list(self.parameters())
+        ok = (self._flat is not None and self._flat.device == device and len(uniq) == len(self._uniq_params)
+              and uniq[0].data_ptr() == self._flat.data_ptr() and uniq[-1].device == device)
+        if ok:
+            return
+        offs, total = [], 0
+        for p in uniq:
+            offs.append(total)
+            total += (p.numel() + 7) // 8 * 8
+        flat = torch.zeros(total, dtype=torch.float32, device=device)
+        for p, o in zip(uniq, offs):
+            flat[o:o + p.numel()].copy_(p.data.reshape(-1).to(device=device, dtype=torch.float32))
+            p.data = flat[o:o + p.numel()].view(p.shape)
+            p.grad = None
+        self._flat, self._gflat = flat, torch.zeros_like(flat)
+        self._flat_lp = None
+        self._uniq_params = uniq
+        off_of = {id(p): o for p, o in zip(uniq, offs)}
+        self._index = {n: (off_of[id(p)], tuple(p.shape)) for n, p in self.named_parameters(remove_duplicate=False)}
+        self._pid = {n: id(p) for n, p in self.named_parameters(remove_duplicate=False)}
+
+    def flat_parameters(self) -> torch.Tensor:
+        return self._flat
+
+    def flat_gradients(self) -> torch.Tensor:
+        return self._gflat
+
+    def _attach_grads(self):
+        """Expose arena slices as .grad for the parameters the step touched (the reference leaves 332 tensors None)."""
+        byid = {id(p): p for p in self._uniq_params}
+        for pid, (off, shape) in self._used_views.items():
+            p = byid[pid]
+            if p.grad is None:
+                p.grad = self._gflat[off:off + p.numel()].view(shape)
+
+    # ------------------------------------------------------------------ nn.Module surface
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not x.is_cuda:
+            raise RuntimeError("transception_amd runs on MI355X only: move the input to a HIP device "
+                               "(there is no CPU fallback; the CPU oracle lives under oracle/ for tests)")
+        self._ensure_flat(x.device)
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._uniq_params)
+        if need_grad:
+            return _StepFn.apply(self, x, *self._uniq_params)
+        logits, G, _ = self._run(x, record=False)
+        self.last_launches = G.n_launch
+        return logits
+
+    # ------------------------------------------------------------------ engine plumbing
+    def _P(self, G: Graph, name: str, view: Optional[Tuple[int, ...]] = None) -> P:
+        off, shape = self._index[name]
+        n = math.prod(shape)
+        shp = view or shape
+        src = self._flat if self.compute_dtype == torch.float32 else self._flat_lp
+        data = src[off:off + n].view(shp)
+        grad = None
+        if G.record:
+            grad = self._gflat[off:off + n].view(shp)
+            self._used_views[self._pid[name]] = (off, shape)
+        return P(data, grad)
+
+    def _run(self, x: torch.Tensor, record: bool):
+        dev = x.device
+        L = lib()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        if self.compute_dtype != torch.float32:
+            if self._flat_lp is None:
+                self._flat_lp = torch.empty(self._flat.numel(), dtype=self.compute_dtype, device=dev)
+            L.tc_cast(self._flat.data_ptr(), self._flat_lp.data_ptr(), self._flat.numel(), TC_F32, TC_BF16, stream)
+        if record:
+            self._used_views = {}
+        G = Graph(self.compute_dtype, dev, self.training, record)
+        G.use_fused_attention = self.use_fused_attention
+        B, in_ch, H, W = x.shape
+        if in_ch not in (1, 3) or H != W or H % 32:
+            raise ValueError(f"expected [B, 1|3, S, S] with S a multiple of 32, got {tuple(x.shape)}")
+        xin = x.contiguous().float()
+        if self.compute_dtype != torch.float32:
+            xl = torch.empty(xin.shape, dtype=self.compute_dtype, device=dev)
+            L.tc_cast(xin.data_ptr(), xl.data_ptr(), xin.numel(), TC_F32, TC_BF16, stream)
+            xin = xl
+        out_var = _forward(self, G, xin, B, in_ch, H)
+        logits = out_var.data.view(B, self.num_classes, H, W)
+        if self.compute_dtype != torch.float32:
+            lf = torch.empty(logits.shape, dtype=torch.float32, device=dev)
+            L.tc_cast(logits.data_ptr(), lf.data_ptr(), logits.numel(), TC_BF16, TC_F32, stream)
+            logits = lf
+        if self.training:
+            for m in self.modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    m.num_batches_tracked += 1
+        self.last_launches = G.n_launch
+        return logits, G, out_var
+
+    def _backward(self, G: Graph, out_var: Var, dlogits: torch.Tensor):
+        L = lib()
+        first = next((p for p in self._uniq_params if id(p) in self._used_views), None)
+        if first is not None and first.grad is None:
+            self._gflat.zero_()                     # zero_grad(set_to_none=True) semantics: start from zero
+        d = dlogits.contiguous()
+        if self.compute_dtype != torch.float32:
+            dl = torch.empty(d.shape, dtype=self.compute_dtype, device=d.device)
+            L.tc_cast(d.data_ptr(), dl.data_ptr(), d.numel(), TC_F32, TC_BF16, G.stream)
+            d = dl
+        out_var.root.grad_t = d.view(out_var.rows, out_var.cols)
+        out_var.root.whole_written = True
+        G.backward()
+        self._attach_grads()
+
+
+TransCeption = MSTransception
+
+
+# ----------------------------------------------------------------------------------------------------------
+# the forward pass as engine calls (reference lines cited per block; index-level spec in SURVEY.md Appendix C)
+# ----------------------------------------------------------------------------------------------------------
+def _lin(M: MSTransception, G: Graph, name: str, bias: bool = True):
+    off, shape = M._index[name + ".weight"]
+    W = M._P(G, name + ".weight", (shape[0], math.prod(shape[1:])))
+    b = M._P(G, name + ".bias") if bias else None
+    return W, b
+
+
+def _ln(M, G, x, name, eps=1e-5, act=ACT_NONE, out=None):
+    return G.layernorm(x, M._P(G, name + ".weight"), M._P(G, name + ".bias"), eps, act, out)
+
+
+def _bn(M, G, x, name, act, residual=None, out=None):
+    holder = M.get_submodule(name)
+    return G.batchnorm(x, M._P(G, name + ".weight"), M._P(G, name + ".bias"), holder.running_mean, holder.running_var, act,
+                       residual, out)
+
+
+def _mixffn(M, G, x, name, B, H, W, residual, out=None):
+    """MixFFN_skip, MSTr.py:889-902 (fc1 evaluated once): fc2(GELU(LN(dw3x3(h) + h))) + residual."""
+    h = G.linear(x, *_lin(M, G, name + ".fc1"))
+    d = G.dwconv(h, M._P(G, name + ".dwconv.dwconv.weight"), M._P(G, name + ".dwconv.dwconv.bias"), B, H, W, 3, 1, True)
+    a = _ln(M, G, d, name + ".norm1", act=ACT_GELU)
+    return G.linear(a, *_lin(M, G, name + ".fc2"), out=out, residual=residual)
+
+
+def _eff_attention(M, G, n1: Var, name: str, B: int, N: int, residual: Optional[Var] = None) -> Var:
+    """EfficientAttention with one head, MSTr.py:106-143 (Appendix C.6), + the block's residual add."""
+    C = n1.cols
+    rows = B * N
+    kqv = G.new(rows, 3 * C)
+    k = G.linear(n1, *_lin(M, G, name + ".keys"), out=kqv.colslice(0, C))
+    q = G.linear(n1, *_lin(M, G, name + ".queries"), out=kqv.colslice(C, 2 * C))
+    v = G.linear(n1, *_lin(M, G, name + ".values"), out=kqv.colslice(2 * C, 3 * C))
+    ksm = G.softmax(k, B, 0)                       # over tokens, per channel
+    qsm = G.softmax(q, 1, 1)                       # over channels, per token
+    ctx = G.new(B * C, C)
+    G.bmm(ksm, v, ctx, C, C, N, 1, 0, nb1=B, sA=(N * ksm.ld, 0), sB=(N * v.ld, 0), sC=(C * C, 0))
+    att = G.new(rows, C)
+    G.bmm(qsm, ctx, att, N, C, C, 0, 0, nb1=B, sA=(N * qsm.ld, 0), sB=(C * C, 0), sC=(N * C, 0))
+    return G.linear(att, *_lin(M, G, name + ".reprojection"), residual=residual)
+
+
+def _eff_block(M, G, t: Var, name: str, B: int, H: int, W: int) -> Var:
+    """EfficientTransformerBlock, MSTr.py:164-173."""
+    tx = _eff_attention(M, G, _ln(M, G, t, name + ".norm1"), name + ".attn", B, H * W, residual=t)
+    n2 = _ln(M, G, tx, name + ".norm2")
+    return _mixffn(M, G, n2, name + ".mlp", B, H, W, residual=tx)
+
+
+def _ripm(M, G, m: Var, name: str, B: int, side: int) -> Tuple[List[Var], int]:
+    """Patch_Embed_stage of DWConv2d_BN, MSTr.py:725-732, 355-362."""
+    outs, x = [], m
+    for i in range(3):
+        stride = 2 if i == 0 else 1
+        pre = f"{name}.patch_embeds.{i}.patch_conv"
+        y = G.dwconv(x, M._P(G, pre + ".dwconv.weight"), None, B, side, side, 3, stride)
+        side = (side - 1) // stride + 1
+        z = G.linear(y, *_lin(M, G, pre + ".pwconv", bias=False))
+        x = _bn(M, G, z, pre + ".bn", ACT_HSWISH)
+        outs.append(x)
+    return outs, side
+
+
+def _resblock(M, G, x: Var, name: str, B: int, side: int, out: Var) -> Var:
+    """ResBlock, MSTr.py:1042-1050."""
+    f = _bn(M, G, G.linear(x, *_lin(M, G, name + ".conv1.conv", bias=False)), name + ".conv1.bn", ACT_HSWISH)
+    f = G.dwconv(f, M._P(G, name + ".dwconv.weight"), None, B, side, side, 3, 1)
+    f = _bn(M, G, f, name + ".norm", ACT_HSWISH)
+    f = G.linear(f, *_lin(M, G, name + ".conv2.conv", bias=False))
+    return _bn(M, G, f, name + ".conv2.bn", ACT_NONE, residual=x, out=out)
+
+
+def _factor_att(M, G, n: Var, blk: str, enc: str, B: int, side: int, residual: Optional[Var] = None) -> Var:
+    """FactorAtt_ConvRelPosEnc + ConvRelPosEnc, MSTr.py:852-886, 801-823 (Appendix C.1-2), + residual add."""
+    C, N = n.cols, side * side
+    rows, h, Ch = B * N, HEADS, n.cols // HEADS
+    qkv = G.linear(n, *_lin(M, G, blk + ".factoratt_crpe.qkv"))
+    q, k, v = qkv.colslice(0, C), qkv.colslice(C, 2 * C), qkv.colslice(2 * C, 3 * C)
+    ksm = G.softmax(k, B, 0)
+    ctx = G.new(B * h * Ch, Ch)
+    G.bmm(ksm, v, ctx, Ch, Ch, N, 1, 0, nb1=B, nb2=h, sA=(N * C, Ch), sB=(N * 3 * C, Ch), sC=(h * Ch * Ch, Ch * Ch))
+    fa = G.new(rows, C)
+    G.bmm(q, ctx, fa, N, Ch, Ch, 0, 0, nb1=B, nb2=h, sA=(N * 3 * C, Ch), sB=(h * Ch * Ch, Ch * Ch), sC=(N * C, Ch))
+    convv = G.new(rows, C)
+    c0 = 0
+    for i, (ksz, nh) in enumerate(CRPE_WINDOW):
+        w = nh * Ch
+        G.dwconv(v.colslice(c0, c0 + w), M._P(G, f"{enc}.crpe.conv_list.{i}.weight"), M._P(G, f"{enc}.crpe.conv_list.{i}.bias"),
+                 B, side, side, ksz, 1, False, out=convv.colslice(c0, c0 + w))
+        c0 += w
+    o = G.fma3(fa, q, convv, Ch ** -0.5)
+    return G.linear(o, *_lin(M, G, blk + ".factoratt_crpe.proj"), residual=residual)
+
+
+def _mhca_block(M, G, t: Var, blk: str, enc: str, B: int, side: int, out: Optional[Var] = None) -> Var:
+    """MHCABlock, MSTr.py:935-946: shared cpe (dw3x3 + identity) in every block, LN eps 1e-6."""
+    t1 = G.dwconv(t, M._P(G, enc + ".cpe.proj.weight"), M._P(G, enc + ".cpe.proj.bias"), B, side, side, 3, 1, True)
+    t2 = _factor_att(M, G, _ln(M, G, t1, blk + ".norm1", 1e-6), blk, enc, B, side, residual=t1)
+    n2 = _ln(M, G, t2, blk + ".norm2", 1e-6)
+    return _mixffn(M, G, n2, blk + ".mlp", B, side, side, residual=t2, out=out)
+
+
+def _coord_att(M, G, x: Var, name: str, B: int, side: int, out: Var) -> Var:
+    """CoordAtt (IFF), MSTr.py:1322-1348."""
+    pooled = G.coord_pool(x, B, side, side)
+    y = G.linear(pooled, *_lin(M, G, name + ".conv1"))
+    y = _bn(M, G, y, name + ".bn1", ACT_COORD)
+    att = G.new(2 * B * side, x.cols)
+    half = B * side
+    G.linear(y.rowslice(0, half), *_lin(M, G, name + ".conv_h"), out=att.rowslice(0, half), act=ACT_SIGMOID)
+    G.linear(y.rowslice(half, 2 * half), *_lin(M, G, name + ".conv_w"), out=att.rowslice(half, 2 * half), act=ACT_SIGMOID)
+    gated = G.coord_gate(x, att, B, side, side)
+    return G.linear(gated, *_lin(M, G, name + ".conv_in_out"), out=out)
+
+
+def _mhca_stage(M, G, maps: List[Var], name: str, layers: int, B: int, side: int, out: Var) -> Var:
+    """MHCA_stage, MSTr.py:1412-1441: the four branch outputs are written into one [rows, 4C] buffer (no cat)."""
+    C = maps[0].cols
+    cat = G.new(B * side * side, 4 * C)
+    _resblock(M, G, maps[0], name + ".InvRes", B, side, cat.colslice(0, C))
+    for p in range(3):
+        t, enc = maps[p], f"{name}.mhca_blks.{p}"
+        for l in range(layers):
+            t = _mhca_block(M, G, t, f"{enc}.MHCA_layers.{l}", enc, B, side,
+                            cat.colslice((p + 1) * C, (p + 2) * C) if l == layers - 1 else None)
+    return _coord_att(M, G, cat, name + ".aggregate", B, side, out)
+
+
+def _channel_att(M, G, n: Var, X: Optional[Var], name: str, B: int, ntok: List[int], R: List[int], N6: int) -> Var:
+    """M_EfficientChannelAtten, MSTr.py:2309-2353: needs each image's tokens contiguous (flat [C, N] re-view), so the
+    q/k/v GEMMs scatter their rows from the stage-major buffer into image-major ones, and proj gathers back."""
+    Cd = 64
+    offs = [sum(ntok[:i]) for i in range(4)]
+    imgs = {}
+    for key in ("k", "q", "v"):
+        buf = G.new(B * N6, Cd)
+        Wb = _lin(M, G, f"{name}.{key}")
+        for s in range(4):
+            G.linear(n.rowslice(R[s], R[s] + ntok[s]), *Wb, out=buf.rowslice(offs[s], offs[s] + ntok[s]),
+                     batch=(B, ntok[s] * Cd, N6 * Cd, 0))
+        imgs[key] = buf.reshape(B * Cd, N6)
+    ksm = G.softmax(imgs["k"], 1, 1)
+    qsm = G.softmax(imgs["q"], B, 0)
+    ctx = G.new(B * Cd, Cd)
+    G.bmm(ksm, imgs["v"], ctx, Cd, Cd, N6, 0, 1, nb1=B, sA=(Cd * N6, 0), sB=(Cd * N6, 0), sC=(Cd * Cd, 0))
+    Op = G.new(B * Cd, N6)
+    G.bmm(ctx, qsm, Op, Cd, N6, Cd, 1, 0, nb1=B, sA=(Cd * Cd, 0), sB=(Cd * N6, 0), sC=(Cd * N6, 0))
+    o_img = G.transpose(Op, B)                                  # [B*N6, 64], image-major
+    tx1 = G.new(B * N6, Cd)
+    Wp = _lin(M, G, name + ".proj")
+    for s in range(4):
+        G.linear(o_img.rowslice(offs[s], offs[s] + ntok[s]), *Wp, out=tx1.rowslice(R[s], R[s] + ntok[s]),
+                 residual=X.rowslice(R[s], R[s] + ntok[s]) if X is not None else None,
+                 batch=(B, N6 * Cd, ntok[s] * Cd, ntok[s] * Cd))
+    return tx1
+
+
+def _scale_reduce(M, G, n: Var, name: str, B: int, sides: List[int], ntok: List[int], R: List[int]) -> Var:
+    """Scale_reduce, MSTr.py:2225-2249 (Appendix C.4): k=s patchify convs + channel de-interleave + LN -> [B*Nk, 64]."""
+    Cd = 64
+    Pn = sides[3] * sides[3]
+    Nk = Pn * 8 + ntok[3]
+    red = G.new(B * Nk, Cd)                                     # image-major K/V source
+    roff = 0
+    for s in range(3):
+        Cm = Cd * MULT[s]
+        cols = G.patchify(n, R[s] * Cd, sides[s] * sides[s] * Cm, B, sides[s], sides[s], Cm, SR_K[s])
+        o = G.linear(cols, *_lin(M, G, f"{name}.sr{s}"))
+        G.sr_deinterleave(o, red, roff * Cd, Nk * Cd, B, Pn, Cd, MULT[s])
+        roff += MULT[s] * Pn
+    G.copy_rows(n, R[3] * Cd, ntok[3] * Cd, red, roff * Cd, Nk * Cd, B, ntok[3], Cd)
+    return _ln(M, G, red, name + ".norm")
+
+
+def _self_att(M, G, n: Var, X: Optional[Var], name: str, B: int, sides: List[int], ntok: List[int], R: List[int], N6: int) -> Var:
+    """M_EfficientSelfAtten, MSTr.py:2267-2292: one head, d = 64, keys/values from the reduced token set."""
+    Cd = 64
+    Nk = sides[3] * sides[3] * 8 + ntok[3]
+    q = G.linear(n, *_lin(M, G, name + ".q"))
+    rn = _scale_reduce(M, G, n, name + ".scale_reduce", B, sides, ntok, R)
+    kv = G.linear(rn, *_lin(M, G, name + ".kv"))
+    k, v = kv.colslice(0, Cd), kv.colslice(Cd, 2 * Cd)
+    att = G.new(B * N6, Cd)
+    for s in range(4):
+        G.attention(q.rowslice(R[s], R[s + 1]), k, v, B, ntok[s], Nk, Cd ** -0.5, out=att.rowslice(R[s], R[s + 1]))
+    return G.linear(att, *_lin(M, G, name + ".proj"), residual=X)
+
+
+def _bridge_layer(M, G, X: Var, li: int, B: int, sides, ntok, R, N6) -> Var:
+    """BridgLayer_4, MSTr.py:2373-2409, on the stage-major token buffer [sum_s B*ntok_s, 64]."""
+    name = f"bridge.bridge_layer{li}"
+    n = _ln(M, G, X, name + ".norm1")
+    if li == 1:
+        tx1 = _channel_att(M, G, n, X, name + ".attn", B, ntok, R, N6)
+    else:
+        tx1 = _self_att(M, G, n, X, name + ".attn", B, sides, ntok, R, N6)
+    tx = _ln(M, G, tx1, name + ".norm2")
+    tx2 = G.new(B * N6, 64)
+    for s in range(4):
+        rows, width = B * sides[s] * sides[s], 64 * MULT[s]
+        view = lambda v: v.rowslice(R[s], R[s + 1]).reshape(rows, width)
+        _mixffn(M, G, view(tx), f"{name}.mixffn{s + 1}", B, sides[s], sides[s], residual=view(tx1), out=view(tx2))
+    return tx2
+
+
+def _patch_expand(M, G, t: Var, name: str, B: int, side: int, p: int) -> Var:
+    """PatchExpand / FinalPatchExpand_X4, MSTr.py:184-201, 213-227."""
+    if t.rows != B * side * side:
+        raise AssertionError("input feature has wrong size")
+    y = G.linear(t, *_lin(M, G, name + ".expand", bias=False))
+    return _ln(M, G, G.pixel_shuffle(y, B, side, side, p), name + ".norm")
+
+
+def _decoder(M, G, x1: Var, skip: Var, name: str, B: int, side: int, last: bool) -> Var:
+    """MyDecoderLayer, MSTr.py:271-290; cat([x1, skip]) @ W^T is evaluated as two accumulating GEMMs."""
+    W, b = _lin(M, G, name + ".concat_linear")
+    c1 = x1.cols
+    t = G.linear(x1, W, b, wcols=(0, c1))
+    G.linear(skip, W, None, out=t, wcols=(c1, c1 + skip.cols), accumulate=True)
+    t = _eff_block(M, G, t, name + ".layer_former_1", B, side, side)
+    t = _eff_block(M, G, t, name + ".layer_former_2", B, side, side)
+    if not last:
+        return _patch_expand(M, G, t, name + ".layer_up", B, side, 2)
+    y = _patch_expand(M, G, t, name + ".layer_up", B, side, 4)
+    lg = G.linear(y, *_lin(M, G, name + ".last_layer"))         # [B*16*side^2, classes]
+    return G.transpose(lg, B)                                   # NCHW logits [B*classes, H*W]
+
+
+def _forward(M: MSTransception, G: Graph, x: torch.Tensor, B: int, in_ch: int, S: int) -> Var:
+    """MSTransception.forward, MSTr.py:2826-2852 / MSViT.forward :1709-1744 / BridgeBlock_4 :2422-2442."""
+    sides = [S // 4, S // 8, S // 16, S // 32]
+    ntok = [sides[i] * sides[i] * MULT[i] for i in range(4)]      # 64-wide tokens per image and stage
+    N6 = sum(ntok)
+    R = [0]
+    for nt in ntok:
+        R.append(R[-1] + B * nt)
+    Xb = G.new(B * N6, 64)                                        # stage-major bridge buffer = the encoder outputs
+
+    def stage_map(buf: Var, s: int) -> Var:
+        return buf.rowslice(R[s], R[s + 1]).reshape(B * sides[s] * sides[s], 64 * MULT[s])
+
+    # stage 1 -- OverlapPatchEmbeddings + 2 EfficientTransformerBlocks (MSTr.py:1714-1721)
+    cols = G.stem_im2col(x, B, in_ch, S, S)
+    W, b = _lin(M, G, "backbone.patch_embed1.proj")
+    t = G.linear(cols.colslice(0, 147), W, b)
+    t = _ln(M, G, t, "backbone.patch_embed1.norm")
+    for i in range(2):
+        t = _eff_block(M, G, t, f"backbone.block1.{i}", B, sides[0], sides[0])
+    m = _ln(M, G, t, "backbone.norm1", out=stage_map(Xb, 0))
+    # stages 2-4 -- RIPM + MB transformer + IFF (MSTr.py:1728-1742)
+    for s in (1, 2, 3):
+        maps, side = _ripm(M, G, m, f"backbone.patch_embed_stage{s + 1}", B, sides[s - 1])
+        m = _mhca_stage(M, G, maps, f"backbone.mhca_stage{s + 1}", LAYERS[s - 1], B, side, stage_map(Xb, s))
+    # Dual Transformer Bridge
+    X = Xb
+    for li in range(1, 5):
+        X = _bridge_layer(M, G, X, li, B, sides, ntok, R, N6)
+    # decoder
+    d3 = _patch_expand(M, G, stage_map(X, 3), "decoder_3.layer_up", B, sides[3], 2)
+    d2 = _decoder(M, G, d3, stage_map(X, 2), "decoder_2", B, sides[2], False)
+    d1 = _decoder(M, G, d2, stage_map(X, 1), "decoder_1", B, sides[1], False)
+    return _decoder(M, G, d1, stage_map(X, 0), "decoder_0", B, sides[0], True)

@@ -1,0 +1,143 @@
+"""Training-step harness: the reference's trainer.py semantics on the MI355X engine.
+
+  loss = 0.4 * CrossEntropy + 0.6 * Dice(softmax=True)           trainer.py:141-143, utils.py:11-47
+  SGD(momentum 0.9, weight_decay 1e-4), per-iteration cosine LR   trainer.py:125-127, 151-153
+  batch-dim sharding: one process per GPU, gradients all-reduced over RCCL (the reference uses
+  nn.DataParallel, trainer.py:110-111); the Dice sums are all-reduced so the loss equals the
+  single-process global-batch loss.
+
+Loss and optimiser are HIP kernels too (tc_seg_loss_*, tc_sgd_step); torch provides memory, streams and
+torch.distributed only.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from ._lib import TC_BF16, TC_F32, lib
+
+
+def _dt(t: torch.Tensor) -> int:
+    return TC_F32 if t.dtype == torch.float32 else TC_BF16
+
+
+class _SegLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, ncls, w_ce, w_dice, group):
+        L = lib()
+        logits = logits.contiguous()
+        B, C, H, W = logits.shape
+        assert C == ncls and labels.shape == (B, H, W) and labels.dtype == torch.int64
+        stream = torch.cuda.current_stream(logits.device).cuda_stream
+        prob = torch.empty((B, C, H, W), dtype=torch.float32, device=logits.device)
+        sums = torch.zeros(1 + 3 * ncls, dtype=torch.float32, device=logits.device)
+        labels = labels.contiguous()
+        L.tc_seg_loss_fwd(logits.data_ptr(), labels.data_ptr(), prob.data_ptr(), sums.data_ptr(), B, ncls, H * W, _dt(logits), stream)
+        n_pix = float(B * H * W)
+        world = 1
+        if group is not None and dist.is_initialized() and dist.get_world_size(group) > 1:
+            world = dist.get_world_size(group)
+            dist.all_reduce(sums, group=group)               # C2: 1 + 27 floats (global-batch CE and Dice sums)
+            n_pix *= world
+        s = sums.double()
+        ce = s[0] / n_pix
+        inter, ysum, zsum = s[1::3], s[2::3], s[3::3]
+        dice = (1.0 - (2.0 * inter + 1e-5) / (zsum + ysum + 1e-5)).mean()
+        loss = w_ce * ce + w_dice * dice
+        ctx.save_for_backward(prob, labels, sums)
+        ctx.meta = (ncls, w_ce, w_dice, n_pix, world, logits.dtype)
+        return loss.float(), ce.float(), dice.float()
+
+    @staticmethod
+    def backward(ctx, gloss, gce, gdice):
+        prob, labels, sums = ctx.saved_tensors
+        ncls, w_ce, w_dice, n_pix, world, dtype = ctx.meta
+        B, C, H, W = prob.shape
+        L = lib()
+        stream = torch.cuda.current_stream(prob.device).cuda_stream
+        d = torch.empty((B, C, H, W), dtype=dtype, device=prob.device)
+        # gradients of the *global* loss w.r.t. local logits; the later gradient all-reduce SUMS ranks, so the usual
+        # DDP mean is folded in by the caller (gscale).  gloss is 1 for a plain loss.backward().
+        gl = gloss.detach().float().contiguous()             # upstream d(loss) stays on the device: no host sync
+        L.tc_seg_loss_bwd(prob.data_ptr(), labels.data_ptr(), sums.data_ptr(), d.data_ptr(), B, ncls, H * W, float(w_ce), float(w_dice),
+                          float(n_pix), 1.0, gl.data_ptr(), _dt(d), stream)
+        return d, None, None, None, None, None
+
+
+class SegLoss(torch.nn.Module):
+    """0.4*CE + 0.6*Dice over the (global) batch; returns (loss, ce, dice)."""
+
+    def __init__(self, n_classes: int = 9, w_ce: float = 0.4, w_dice: float = 0.6, group=None):
+        super().__init__()
+        self.n_classes, self.w_ce, self.w_dice, self.group = n_classes, w_ce, w_dice, group
+
+    def forward(self, logits: torch.Tensor, labels: torch.Tensor):
+        return _SegLossFn.apply(logits, labels.long(), self.n_classes, self.w_ce, self.w_dice, self.group)
+
+
+def cosine_lr(base_lr: float, step: int, t_max: int) -> float:
+    """CosineAnnealingLR(eta_min=0) after `step` scheduler.step() calls (trainer.py:126-127,151-153)."""
+    return 0.5 * base_lr * (1.0 + math.cos(math.pi * step / t_max))
+
+
+class FusedSGD:
+    """torch.optim.SGD(momentum, weight_decay) semantics as one kernel over the model's flat arenas.
+
+    Parameters that never receive a gradient (332 tensors in the reference) are left untouched, exactly as
+    torch.optim.SGD skips `p.grad is None`: the update runs over the used segments only."""
+
+    def __init__(self, model, lr: float = 0.05, momentum: float = 0.9, weight_decay: float = 1e-4):
+        self.model, self.lr, self.momentum, self.wd = model, lr, momentum, weight_decay
+        self.buf: Optional[torch.Tensor] = None
+        self.steps = 0
+        self._segments = None
+
+    def _segs(self):
+        if self._segments is None:
+            views = sorted((off, math.prod(shape)) for off, shape in self.model._used_views.values())
+            segs = []
+            for off, n in views:
+                n8 = (n + 7) // 8 * 8
+                if segs and segs[-1][0] + segs[-1][1] == off:
+                    segs[-1][1] += n8
+                else:
+                    segs.append([off, n8])
+            self._segments = [(o, n) for o, n in segs]
+        return self._segments
+
+    def zero_grad(self):
+        self.model._gflat.zero_()
+
+    def step(self, grad_scale: float = 1.0):
+        M = self.model
+        flat, g = M._flat, M._gflat
+        if self.buf is None:
+            self.buf = torch.zeros_like(flat)
+        L = lib()
+        stream = torch.cuda.current_stream(flat.device).cuda_stream
+        es = 4
+        for off, n in self._segs():
+            n = min(n, flat.numel() - off)
+            L.tc_sgd_step(flat.data_ptr() + off * es, g.data_ptr() + off * es, self.buf.data_ptr() + off * es, n, float(self.lr),
+                          float(self.momentum), float(self.wd), float(grad_scale), int(self.steps == 0), stream)
+        self.steps += 1
+
+
+def allreduce_gradients(model, group=None):
+    """C1: one all-reduce(sum) of the flat gradient arena over RCCL/xGMI (gloo in CPU tests)."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(model._gflat, group=group)
+
+
+def train_step(model, loss_fn: SegLoss, opt: FusedSGD, images: torch.Tensor, labels: torch.Tensor, group=None):
+    """One step with trainer.py semantics; returns (loss, ce, dice) tensors (no host sync)."""
+    opt.zero_grad()
+    logits = model(images)
+    loss, ce, dice = loss_fn(logits, labels)
+    loss.backward()
+    allreduce_gradients(model, group)
+    opt.step()
+    return loss, ce, dice
