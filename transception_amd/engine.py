@@ -34,10 +34,12 @@ class P:
 class Var:
     """A 2-D activation view [rows, cols] (last dim contiguous, row stride ld) plus its lazily created gradient.
 
-    Children made by cols()/rows()/reshape() share the root's storage *and* the root's gradient buffer."""
-    __slots__ = ("data", "root", "path", "kids", "grad_t", "whole_written", "part_written", "has_grad", "requires_grad")
+    Children made by colslice()/rowslice()/reshape() share the root's storage *and* the root's gradient buffer;
+    every view knows the rectangle of the root it covers so that gradient writes from overlapping views accumulate."""
+    __slots__ = ("data", "root", "path", "kids", "grad_t", "whole_written", "written", "requires_grad", "region", "reshaped")
 
-    def __init__(self, data: torch.Tensor, root: "Var" = None, path=None, requires_grad: bool = True):
+    def __init__(self, data: torch.Tensor, root: "Var" = None, path=None, requires_grad: bool = True, region=None,
+                 reshaped: bool = False):
         assert data.dim() == 2 and (data.stride(1) == 1 or data.shape[1] == 1), (data.shape, data.stride())
         self.data = data
         self.root = root if root is not None else self
@@ -45,34 +47,40 @@ class Var:
         self.kids: Dict[tuple, Var] = {}
         self.grad_t: Optional[torch.Tensor] = None     # root only
         self.whole_written = False                     # root only
-        self.part_written = False                      # root only
-        self.has_grad = False                          # per slice object
+        self.written: List[tuple] = []                 # root only: rectangles (r0, r1, c0, c1) that received a gradient
         self.requires_grad = requires_grad
+        self.region = region if region is not None else (0, data.shape[0], 0, data.shape[1])   # in root coordinates
+        self.reshaped = reshaped
 
     rows = property(lambda s: s.data.shape[0])
     cols = property(lambda s: s.data.shape[1])
     ld = property(lambda s: s.data.stride(0))
 
-    def _kid(self, key, data):
+    def _kid(self, key, data, region, reshaped=False):
         k = self.kids.get(key)
         if k is None:
-            k = Var(data, self.root, self.path + (key,), self.root.requires_grad)
+            k = Var(data, self.root, self.path + (key,), self.root.requires_grad, region, reshaped)
             self.kids[key] = k
         return k
 
     def colslice(self, a: int, b: int) -> "Var":
-        return self._kid(("c", a, b), self.data[:, a:b])
+        assert not self.reshaped, "slice before reshaping"
+        r0, r1, c0, _ = self.region
+        return self._kid(("c", a, b), self.data[:, a:b], (r0, r1, c0 + a, c0 + b))
 
     def rowslice(self, a: int, b: int) -> "Var":
-        return self._kid(("r", a, b), self.data[a:b])
+        assert not self.reshaped, "slice before reshaping"
+        r0, _, c0, c1 = self.region
+        return self._kid(("r", a, b), self.data[a:b], (r0 + a, r0 + b, c0, c1))
 
     def reshape(self, rows: int, cols: int) -> "Var":
-        assert self.data.is_contiguous()
-        return self._kid(("v", rows, cols), self.data.view(rows, cols))
+        assert self.data.is_contiguous() and self.region[2] == 0 and self.region[3] == self.root.data.shape[1]
+        return self._kid(("v", rows, cols), self.data.view(rows, cols), self.region, True)
 
     @property
     def is_whole(self) -> bool:
-        return all(k[0] == "v" for k in self.path)
+        rt = self.root.data
+        return self.region == (0, rt.shape[0], 0, rt.shape[1])
 
     def apply_path(self, t: torch.Tensor) -> torch.Tensor:
         for k in self.path:
@@ -83,6 +91,10 @@ class Var:
             else:
                 t = t.view(k[1], k[2])
         return t
+
+
+def _overlap(a, b) -> bool:
+    return a[0] < b[1] and b[0] < a[1] and a[2] < b[3] and b[2] < a[3]
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -110,32 +122,43 @@ class Graph:
 
     # ------------------------------------------------------------------ gradient bookkeeping
     def grad_of(self, v: Var) -> Optional[torch.Tensor]:
-        """Gradient view of v for READING (None if nothing was ever written to it)."""
+        """Gradient view of v for READING (None if nothing was ever written to any part of it)."""
         r = v.root
         if r.grad_t is None:
             return None
-        if not v.is_whole and not (v.has_grad or r.whole_written):
+        if not (r.whole_written or any(_overlap(v.region, w) for w in r.written)):
             return None
         return v.apply_path(r.grad_t)
 
-    def wgrad(self, v: Var) -> Tuple[torch.Tensor, int]:
-        """Gradient view of v for WRITING and whether the kernel must accumulate into it."""
+    def wgrad(self, v: Var, ext_rows: int = 0) -> Tuple[torch.Tensor, int]:
+        """Gradient view of v for WRITING and whether the kernel must accumulate into it.  ext_rows: the kernel also
+        writes that many root rows beyond the view (batch-strided launches whose view is batch 0)."""
         r = v.root
-        if v.is_whole:
-            acc = r.whole_written or r.part_written
-            if r.grad_t is None:
-                r.grad_t = torch.empty_like(r.data) if r.data.is_contiguous() else torch.empty(
-                    r.data.shape, dtype=r.data.dtype, device=r.data.device)
+        whole = v.is_whole
+        reg = (v.region[0], v.region[1] + ext_rows, v.region[2], v.region[3])
+        if r.grad_t is None:
+            if whole:
+                r.grad_t = torch.empty_like(r.data)
                 assert r.grad_t.stride() == r.data.stride(), "gradient layout must mirror the data layout"
-            r.whole_written = True
-        else:
-            if r.grad_t is None:
+            else:
                 assert r.data.is_contiguous()
                 r.grad_t = torch.zeros_like(r.data)        # parts may stay unwritten
-            acc = v.has_grad or r.whole_written
-            v.has_grad = True
-            r.part_written = True
+        acc = r.whole_written or any(_overlap(reg, w) for w in r.written)
+        if whole:
+            r.whole_written = True
+        else:
+            r.written.append(reg)
         return v.apply_path(r.grad_t), int(acc)
+
+    def _region_grad(self, root: Var, off: int, nelem: int) -> torch.Tensor:
+        """Mark `nelem` elements starting `off` elements into the (contiguous) root as gradient-carrying (the writer
+        accumulates); returns the root gradient buffer, zero-initialised on first use."""
+        assert root.data.is_contiguous()
+        cols = root.data.shape[1]
+        if root.grad_t is None:
+            root.grad_t = torch.zeros_like(root.data)
+        root.written.append((off // cols, (off + nelem + cols - 1) // cols, 0, cols))
+        return root.grad_t
 
     def pass_grad(self, v: Var, src: torch.Tensor):
         """v.grad (+)= src without a copy when v has no gradient yet (identity / residual branches)."""
@@ -219,7 +242,7 @@ class Graph:
                 dz = torch.empty_like(dy)
                 self.L.tc_sigmoid_bwd(_ptr(dy), _ptr(out.data), _ptr(dz), dy.numel(), self.dt, self.stream)
             if x.requires_grad:
-                gx, acc = self.wgrad(x)
+                gx, acc = self.wgrad(x, (nb - 1) * sx // x.root.cols if nb > 1 else 0)
                 self._gemm(_ptr(dz), dz.stride(0), _ptr(Wt), Wt.stride(0), _ptr(gx), gx.stride(0), M, K, N, 0, 0, acc=acc,
                            nb1=nb, sA=(so, 0), sC=(sx, 0))
             if W.grad is not None:
@@ -235,7 +258,7 @@ class Graph:
         return out
 
     def _pass_grad_batched(self, v: Var, src: torch.Tensor, nb: int, M: int, N: int, sb: int):
-        g, acc = self.wgrad(v)
+        g, acc = self.wgrad(v, (nb - 1) * sb // v.root.cols)
         self.L.tc_copy3d(_ptr(src), sb, src.stride(0), _ptr(g), sb, g.stride(0), nb, M, N, acc, self.dt, self.stream)
 
     def layernorm(self, x: Var, g: P, b: P, eps: float = 1e-5, act: int = ACT_NONE, out: Optional[Var] = None) -> Var:
@@ -446,12 +469,8 @@ class Graph:
             d = self.grad_of(out)
             if d is None:
                 return
-            r = buf.root
-            first = r.grad_t is None
-            if first:
-                r.grad_t = torch.zeros_like(r.data)
-            r.part_written = True
-            gbase = r.grad_t.data_ptr() + off * r.grad_t.element_size()
+            gt = self._region_grad(buf.root, off, B * sb)
+            gbase = gt.data_ptr() + off * gt.element_size()
             self.L.tc_patchify(gbase, sb, Cc, _ptr(d), B, H, W, Cc, k, 2, self.dt, self.stream)
         self._rec(bwd)
         return out
@@ -467,11 +486,8 @@ class Graph:
             dg = self.grad_of(dst)
             if dg is None:
                 return
-            r = src.root
-            if r.grad_t is None:
-                r.grad_t = torch.zeros_like(r.data)
-            r.part_written = True
-            self.L.tc_copy3d(dg.data_ptr() + dst_off * es, dst_sb, dst.ld, r.grad_t.data_ptr() + src_off * es, src_sb, src.ld,
+            gt = self._region_grad(src.root, src_off, nb * src_sb)
+            self.L.tc_copy3d(dg.data_ptr() + dst_off * es, dst_sb, dst.ld, gt.data_ptr() + src_off * es, src_sb, src.ld,
                              nb, rows, cols, 1, self.dt, self.stream)
         self._rec(bwd)
 

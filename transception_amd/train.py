@@ -109,7 +109,8 @@ class FusedSGD:
         return self._segments
 
     def zero_grad(self):
-        self.model._gflat.zero_()
+        if self.model._gflat is not None:
+            self.model._gflat.zero_()
 
     def step(self, grad_scale: float = 1.0):
         M = self.model
