@@ -1,0 +1,166 @@
+#!/usr/bin/env python
+"""bench.py -- images/sec, forward + backward (+ loss + SGD step), TransCeption 224x224, B=16 per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype f32|bf16] [--batch 16] [--size 224] [--no-cpu]
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+One "step" = one pass of the hot path over one batch of synthetic Synapse-shaped input resident in HBM:
+MSTransception forward, 0.4*CE+0.6*Dice loss, backward, (gradient all-reduce over RCCL when N>1), fused SGD update.
+Weak scaling: 16 images per GPU.  Rank 0 prints ONE JSON line (contract in the task description), carrying
+  roofline      the bridge SR-attention forward kernel (the MFMA-bound kernel BASELINE.json's north_star names), timed
+                live with HIP events around every one of its launches inside the timed region;
+  cpu_baseline  the CPU oracle (a port of the reference arithmetic; the reference's Python cannot travel) timed on this
+                box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}        # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+
+
+def synthetic_batch(B: int, size: int, device, seed: int):
+    """Synapse-shaped input: one-channel slice normalised to [-1, 1] (trainer.py:89-92) + integer labels in 0..8."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = (torch.rand(B, 1, size, size, generator=g) - 0.5) / 0.5
+    y = torch.randint(0, 9, (B, size, size), generator=g)
+    return x.to(device), y.to(device)
+
+
+def cpu_baseline(batch: int, size: int, reps: int = 2):
+    """Oracle fwd+bwd+SGD on the host cores, bounded sample: 1 warm-up + `reps` steps of the same B x size^2 workload."""
+    from oracle.transception_oracle import TransCeptionOracle, ce_dice_loss, load_params
+    from transception_amd.seeded_init import seeded_state_dict
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    P = load_params(seeded_state_dict(), requires_grad=True)
+    leaves = list({id(v): v for v in P.values() if v.requires_grad}.values())
+    opt = torch.optim.SGD(leaves, lr=0.05, momentum=0.9, weight_decay=1e-4)
+    orc = TransCeptionOracle(P, 9, training=True)
+    x, y = synthetic_batch(batch, size, "cpu", 1)
+    times = []
+    for i in range(reps + 1):
+        t0 = time.perf_counter()
+        loss, _, _ = ce_dice_loss(orc(x), y, 9)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    t = sorted(times[1:])[len(times[1:]) // 2]
+    return {"value": batch / t, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{reps} timed fwd+bwd+SGD steps (1 warm-up) of B={batch} {size}x{size}, fp32 PyTorch-CPU oracle, median"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-attn-events", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    import torch.distributed as dist
+    group = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        group = dist.group.WORLD
+
+    import transception_amd.engine as engine
+    from transception_amd import MSTransception
+    from transception_amd.seeded_init import seeded_state_dict
+    from transception_amd.train import FusedSGD, SegLoss, cosine_lr, train_step
+
+    model = MSTransception(num_classes=9)
+    model.load_state_dict(seeded_state_dict(), strict=True)      # random-init weights of the architecture (name-seeded)
+    model.to(dev).train()
+    model.set_compute_dtype(torch.float32 if args.dtype == "f32" else torch.bfloat16)
+    model._ensure_flat(dev)
+    if world > 1:
+        dist.broadcast(model.flat_parameters(), src=0)           # C3: identical replicas
+    loss_fn = SegLoss(9, group=group)
+    opt = FusedSGD(model, lr=0.05, momentum=0.9, weight_decay=1e-4)
+    x, y = synthetic_batch(args.batch, args.size, dev, 1234 + rank)
+    t_max = max(args.steps + args.warmup, 1)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        train_step(model, loss_fn, opt, x, y, group)
+        opt.lr = cosine_lr(0.05, i + 1, t_max)
+    sync()
+    if rank == 0 and not args.no_attn_events:
+        engine.PROFILE = {}
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss, ce, dice = train_step(model, loss_fn, opt, x, y, group)
+        opt.lr = cosine_lr(0.05, args.warmup + i + 1, t_max)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    prof, engine.PROFILE = engine.PROFILE, None
+
+    if rank == 0:
+        out = {
+            "metric": "images/sec fwd+bwd at 224x224 B=16 per GPU", "value": world * args.batch * args.steps / elapsed,
+            "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"TransCeption (MSTransception) {args.size}x{args.size} B={args.batch}/GPU fwd+bwd+SGD, "
+                                   "synthetic Synapse slices, name-seeded random-init weights",
+                       "global_batch": world * args.batch, "image_size": args.size, "parallelism": f"dp{world}",
+                       "kernel_launches_fwd": model.last_launches, "final_loss": float(loss.item())},
+        }
+        if prof and prof.get("attn_fwd"):
+            ev = prof["attn_fwd"]
+            ms = sum(a.elapsed_time(b) for a, b, _ in ev)
+            fl = sum(f for _, _, f in ev)
+            peak = PEAK_TFLOPS[args.dtype]
+            ach = fl / (ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": "attn_fwd_kernel (bridge SR-attention forward, QK^T+PV fused)",
+                               "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                               "launches": len(ev), "avg_launch_us": 1e3 * ms / len(ev),
+                               "algorithmic_flops_per_launch": fl / len(ev)}
+            if prof.get("attn_bwd"):
+                evb = prof["attn_bwd"]
+                msb = sum(a.elapsed_time(b) for a, b, _ in evb)
+                flb = sum(f for _, _, f in evb)
+                out["roofline_attn_bwd"] = {"bound": "mfma", "achieved": flb / (msb * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+                                            "frac": flb / (msb * 1e-3) / 1e12 / peak, "launches": len(evb),
+                                            "avg_launch_us": 1e3 * msb / len(evb)}
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(args.batch, args.size)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

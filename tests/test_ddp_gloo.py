@@ -1,0 +1,46 @@
+"""world_size-2 gloo checks of the multi-GPU host logic: the gradient all-reduce over the flat arena
+(C1) and the Dice/CE sums all-reduce (C2) that makes the sharded loss equal the single-process global-batch loss."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle.transception_oracle import ce_dice_loss, dice_loss_sums
+    from transception_amd.train import allreduce_gradients, loss_from_sums, seg_sums_allreduce
+    g = torch.Generator().manual_seed(3)
+    logits = torch.randn(4, 9, 16, 16, generator=g)
+    labels = torch.randint(0, 9, (4, 16, 16), generator=g)
+    full, _, _ = ce_dice_loss(logits, labels, 9)
+    lo, la = logits[2 * rank:2 * rank + 2], labels[2 * rank:2 * rank + 2]
+    prob = torch.softmax(lo, 1)
+    inter, ysum, zsum = dice_loss_sums(prob, la, 9)
+    ce_sum = torch.nn.functional.cross_entropy(lo, la, reduction="sum")
+    sums = torch.zeros(28)
+    sums[0] = ce_sum
+    sums[1::3], sums[2::3], sums[3::3] = inter, ysum, zsum
+    sums, n_pix, w = seg_sums_allreduce(sums, float(lo.shape[0] * 16 * 16))
+    loss, ce, dice = loss_from_sums(sums, n_pix, 0.4, 0.6)
+    ok_loss = abs(loss.item() - full.item()) < 1e-6 and w == 2
+
+    class Fake:
+        _gflat = torch.full((1000,), float(rank + 1))
+    allreduce_gradients(Fake)
+    ok_grad = bool((Fake._gflat == 3.0).all())
+    ret[rank] = (ok_loss, ok_grad)
+    dist.destroy_process_group()
+
+
+def test_two_rank_loss_and_gradient_allreduce():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + (os.getpid() % 500)
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert all(ret[r] == (True, True) for r in range(world)), dict(ret)

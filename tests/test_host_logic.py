@@ -1,0 +1,82 @@
+"""Host-side logic that needs no GPU: state_dict schema, constructor contract, no-CPU-fallback, the engine's
+gradient-region bookkeeping, the fused-SGD segment table and the cosine schedule."""
+import math
+
+import pytest
+import torch
+
+from transception_amd import MSTransception, TransCeption
+from transception_amd.seeded_init import load_manifest, seeded_state_dict
+
+
+@pytest.fixture(scope="module")
+def model():
+    return MSTransception(num_classes=9)
+
+
+def test_state_dict_schema_matches_reference_manifest(model):
+    ents = load_manifest()
+    sd = model.state_dict()
+    assert list(sd.keys()) == [e[0] for e in ents]
+    for k, shape, _ in ents:
+        assert tuple(sd[k].shape) == tuple(shape), k
+    assert sum(p.numel() for p in model.parameters()) == 47_316_553
+    # aliases of the shared cpe / crpe modules share storage
+    a = "backbone.mhca_stage2.mhca_blks.0.cpe.proj.weight"
+    b = "backbone.mhca_stage2.mhca_blks.0.MHCA_layers.2.cpe.proj.weight"
+    assert sd[a].data_ptr() == sd[b].data_ptr()
+
+
+def test_load_seeded_state_strict(model):
+    res = model.load_state_dict(seeded_state_dict(), strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert TransCeption is MSTransception
+
+
+def test_constructor_contract():
+    MSTransception(num_classes=2, head_count=8, dil_conv=1, token_mlp_mode="mix_skip", MSViT_config=2, concat="coord",
+                   have_bridge="original", use_sa_config=1, sa_ker=7, Stage_3or4=3, inter="res", num_sp=1,
+                   br_ch_att_list=[True, False, False, False])
+    for kw in (dict(concat="cbam"), dict(have_bridge="sp"), dict(Stage_3or4=4), dict(token_mlp_mode="mix")):
+        with pytest.raises(NotImplementedError):
+            MSTransception(**kw)
+
+
+def test_no_cpu_fallback(model):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model(torch.zeros(1, 1, 224, 224))
+
+
+def test_engine_gradient_regions():
+    from transception_amd.engine import Graph, Var
+    G = Graph(torch.float32, torch.device("cpu"), training=True, record=True)
+    root = Var(torch.zeros(10, 12))
+    q, v = root.colslice(0, 4), root.colslice(8, 12)
+    g, acc = G.wgrad(v.colslice(0, 2))
+    assert acc == 0 and tuple(g.shape) == (10, 2)
+    g, acc = G.wgrad(v)                       # overlaps the sub-slice written above -> must accumulate
+    assert acc == 1
+    assert G.wgrad(q)[1] == 0 and G.wgrad(q)[1] == 1
+    assert G.grad_of(root.colslice(4, 8)) is None          # untouched columns
+    assert G.wgrad(root)[1] == 1                           # whole write after parts accumulates
+    r2 = Var(torch.zeros(6, 4))
+    assert G.wgrad(r2)[1] == 0 and G.wgrad(r2.rowslice(0, 3))[1] == 1
+    r3 = Var(torch.zeros(8, 4))
+    blk = r3.rowslice(2, 6).reshape(2, 8)
+    assert blk.region == (2, 6, 0, 4) and not blk.is_whole
+    assert G.wgrad(blk)[1] == 0 and G.wgrad(r3.rowslice(4, 8))[1] == 1 and G.wgrad(r3.rowslice(0, 2))[1] == 0
+    src = torch.ones(8, 4)
+    r4 = Var(torch.zeros(8, 4))
+    G.pass_grad(r4, src)                                    # alias, no copy
+    assert G.grad_of(r4).data_ptr() == src.data_ptr()
+
+
+def test_cosine_schedule_matches_torch():
+    from transception_amd.train import cosine_lr
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=0.05)
+    sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=100)
+    for step in range(1, 6):
+        opt.step()
+        sch.step()
+        assert math.isclose(opt.param_groups[0]["lr"], cosine_lr(0.05, step, 100), rel_tol=1e-9)

@@ -21,6 +21,22 @@ from ._lib import (ACT_COORD, ACT_GELU, ACT_HSWISH, ACT_NONE, ACT_SIGMOID, TC_BF
 
 _DT = {torch.float32: TC_F32, torch.bfloat16: TC_BF16}
 
+# bench.py sets this to a dict {kernel name: [(start_event, stop_event, algorithmic_flops), ...]} to time individual
+# launches with HIP events on the launching stream (the events are recorded on torch's current stream, which is the
+# stream every kernel here is launched on).
+PROFILE: Optional[dict] = None
+
+
+def _timed(name: str, flops: float, fn):
+    if PROFILE is None:
+        fn()
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn()
+    e1.record()
+    PROFILE.setdefault(name, []).append((e0, e1, flops))
+
 
 class P:
     """Engine-side handle of one parameter: compute-dtype data + fp32 gradient view (or None when frozen)."""
@@ -110,7 +126,7 @@ class Graph:
         self.training = training
         self.record = record
         self.tape: List[Callable[[], None]] = []
-        self.stream = torch.cuda.current_stream(device).cuda_stream
+        self.stream = torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0
         self.n_launch = 0
 
     # ------------------------------------------------------------------ memory
@@ -550,8 +566,9 @@ class Graph:
         if out is None:
             out = self.new(B * Nq, d)
         lse = self.f32(B * Nq)
-        self.L.tc_attn_fwd(_ptr(q.data), q.ld, Nq * q.ld, _ptr(k.data), k.ld, _ptr(v.data), v.ld, Nk * k.ld, _ptr(out.data),
-                           out.ld, Nq * out.ld, _ptr(lse), B, Nq, Nk, scale, self.dt, self.stream)
+        _timed("attn_fwd", 4.0 * B * Nq * Nk * d, lambda: self.L.tc_attn_fwd(
+            _ptr(q.data), q.ld, Nq * q.ld, _ptr(k.data), k.ld, _ptr(v.data), v.ld, Nk * k.ld, _ptr(out.data), out.ld, Nq * out.ld,
+            _ptr(lse), B, Nq, Nk, scale, self.dt, self.stream))
 
         def bwd():
             dO = self.grad_of(out)
@@ -562,9 +579,10 @@ class Graph:
             gv, av = self.wgrad(v)
             assert not aq and ak == av, "fused attention: q single-use, k/v written together"
             delta = self.f32(B * Nq)
-            self.L.tc_attn_bwd(_ptr(q.data), q.ld, Nq * q.ld, _ptr(k.data), k.ld, _ptr(v.data), v.ld, Nk * k.ld, _ptr(out.data),
-                               out.ld, Nq * out.ld, _ptr(dO), dO.stride(0), Nq * dO.stride(0), _ptr(lse), _ptr(delta), _ptr(gq),
-                               gq.stride(0), Nq * gq.stride(0), _ptr(gk), gk.stride(0), _ptr(gv), gv.stride(0),
-                               Nk * gk.stride(0), ak, B, Nq, Nk, scale, self.dt, self.stream)
+            _timed("attn_bwd", 10.0 * B * Nq * Nk * d, lambda: self.L.tc_attn_bwd(
+                _ptr(q.data), q.ld, Nq * q.ld, _ptr(k.data), k.ld, _ptr(v.data), v.ld, Nk * k.ld, _ptr(out.data), out.ld,
+                Nq * out.ld, _ptr(dO), dO.stride(0), Nq * dO.stride(0), _ptr(lse), _ptr(delta), _ptr(gq), gq.stride(0),
+                Nq * gq.stride(0), _ptr(gk), gk.stride(0), _ptr(gv), gv.stride(0), Nk * gk.stride(0), ak, B, Nq, Nk, scale,
+                self.dt, self.stream))
         self._rec(bwd)
         return out

@@ -24,6 +24,25 @@ def _dt(t: torch.Tensor) -> int:
     return TC_F32 if t.dtype == torch.float32 else TC_BF16
 
 
+def seg_sums_allreduce(sums: torch.Tensor, n_pix: float, group=None):
+    """C2 of SURVEY.md section 8(e): the [1 + 3*classes] vector (sum CE, then intersect/y_sum/z_sum per class) is summed over
+    ranks so that every rank forms the loss of the GLOBAL batch (Dice is not linear in the batch, utils.py:24-32)."""
+    world = 1
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        world = dist.get_world_size(group)
+        dist.all_reduce(sums, group=group)
+    return sums, n_pix * world, world
+
+
+def loss_from_sums(sums: torch.Tensor, n_pix: float, w_ce: float, w_dice: float):
+    """0.4*CE + 0.6*Dice from the (global) sums: trainer.py:141-143, utils.py:34-47 (smooth 1e-5, mean over classes)."""
+    s = sums.double()
+    ce = s[0] / n_pix
+    inter, ysum, zsum = s[1::3], s[2::3], s[3::3]
+    dice = (1.0 - (2.0 * inter + 1e-5) / (zsum + ysum + 1e-5)).mean()
+    return w_ce * ce + w_dice * dice, ce, dice
+
+
 class _SegLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, labels, ncls, w_ce, w_dice, group):
@@ -36,17 +55,8 @@ class _SegLossFn(torch.autograd.Function):
         sums = torch.zeros(1 + 3 * ncls, dtype=torch.float32, device=logits.device)
         labels = labels.contiguous()
         L.tc_seg_loss_fwd(logits.data_ptr(), labels.data_ptr(), prob.data_ptr(), sums.data_ptr(), B, ncls, H * W, _dt(logits), stream)
-        n_pix = float(B * H * W)
-        world = 1
-        if group is not None and dist.is_initialized() and dist.get_world_size(group) > 1:
-            world = dist.get_world_size(group)
-            dist.all_reduce(sums, group=group)               # C2: 1 + 27 floats (global-batch CE and Dice sums)
-            n_pix *= world
-        s = sums.double()
-        ce = s[0] / n_pix
-        inter, ysum, zsum = s[1::3], s[2::3], s[3::3]
-        dice = (1.0 - (2.0 * inter + 1e-5) / (zsum + ysum + 1e-5)).mean()
-        loss = w_ce * ce + w_dice * dice
+        sums, n_pix, world = seg_sums_allreduce(sums, float(B * H * W), group)
+        loss, ce, dice = loss_from_sums(sums, n_pix, w_ce, w_dice)
         ctx.save_for_backward(prob, labels, sums)
         ctx.meta = (ncls, w_ce, w_dice, n_pix, world, logits.dtype)
         return loss.float(), ce.float(), dice.float()
