@@ -61,6 +61,7 @@ typedef struct TcGemm {
     int dtype;
     int c_f32;                   /* C (and the accumulate read) is fp32 whatever dtype is: weight gradients */
     int atomic;                  /* accumulate with fp32 atomics (batches that share one C) */
+    float* rowsum;               /* optional fp32 [M]: rowsum[m] += sum_k op(A)[m,k] (bias gradient of a dW GEMM) */
 } TcGemm;
 int tc_gemm(const TcGemm* g, void* stream);
 

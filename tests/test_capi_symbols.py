@@ -20,7 +20,7 @@ def header_functions():
         args = m.group(2).strip()
         fns[m.group(1)] = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
     nfields = sum(len([x for x in decl.split(",") if x.strip()]) for decl in
-                  re.findall(r"(?:const void\*|void\*|int|long long|float)\s+([^;]+);", struct))
+                  re.findall(r"(?:const void\*|void\*|float\*|int|long long|float)\s+([^;]+);", struct))
     return fns, nfields
 
 

@@ -311,3 +311,22 @@ def test_no_cpu_fallback():
     from transception_amd import MSTransception
     with pytest.raises(RuntimeError):
         MSTransception(9)(torch.zeros(1, 1, 224, 224))
+
+
+def test_bf16_train_step_tracks_fp32():
+    """bf16 storage + bf16 MFMA, fp32 statistics/accumulators/master weights: loss within 1e-2 of the reference's fp32 loss,
+    gradient direction (cosine over all parameters) > 0.99."""
+    from transception_amd.train import SegLoss
+    g = load("model_b2.npz")
+    x = torch.from_numpy(seeded_input(2)).to(DEV)
+    lab = torch.from_numpy(seeded_labels(2)).to(DEV)
+    grads = {}
+    for dt in (torch.float32, torch.bfloat16):
+        m = _fresh(dt).train()
+        loss, _, _ = SegLoss(9)(m(x), lab)
+        loss.backward()
+        grads[dt] = (loss.item(), m.flat_gradients().clone())
+    assert abs(grads[torch.bfloat16][0] - g["loss"][0]) < 1e-2
+    a, b = grads[torch.float32][1].double(), grads[torch.bfloat16][1].double()
+    cos = float((a * b).sum() / (a.norm() * b.norm()))
+    assert cos > 0.99, cos

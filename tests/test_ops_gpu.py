@@ -355,3 +355,98 @@ def test_seg_loss_and_sgd():
     assert abs(got.item() - loss.item()) < 2e-6 and abs(gce.item() - ce.item()) < 2e-6 and abs(gdice.item() - dice.item()) < 2e-6
     got.backward()
     close(ld.grad, lr_.grad, 1e-8, 1e-4, "dlogits")
+
+
+# ------------------------------------------------------------------------------------------------ bf16 storage path
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+def closeb(got, want, rel=1.5e-2, what=""):
+    got, want = got.detach().float().cpu(), want.detach().float()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    err = (got - want).abs().max().item()
+    scale = want.abs().max().item()
+    assert err <= rel * scale + 1e-6, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+@pytest.fixture()
+def Gb():
+    from transception_amd.engine import Graph
+    return Graph(torch.bfloat16, torch.device(DEV), training=True, record=True)
+
+
+def mkPb(t):
+    from transception_amd.engine import P
+    return P(_bf(t).to(DEV).contiguous(), torch.zeros(t.shape, dtype=torch.float32, device=DEV))
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 200, 147), (4096, 256, 64), (98, 2048, 512), (257, 9, 64)])
+def test_linear_bf16(Gb, M, N, K):
+    x, w, b = _bf(T(f"lb.x{M}", (M, K))), _bf(T(f"lb.w{N}", (N, K), 1 / math.sqrt(K))), _bf(T(f"lb.b{N}", (N,), 0.1))
+    r, gy = _bf(T(f"lb.r{M}", (M, N))), _bf(T(f"lb.g{M}", (M, N)))
+    xr, wr, br, rr = (t.float().requires_grad_() for t in (x, w, b, r))
+    y = F.linear(xr, wr, br) + rr
+    y.backward(gy.float())
+    xv, W, Bp, rv = mkV(Gb, x), mkPb(w.float()), mkPb(b.float()), mkV(Gb, r)
+    out = Gb.linear(xv, W, Bp, residual=rv)
+    closeb(out.data, y, what="y")
+    run_bwd(Gb, out, gy)
+    closeb(Gb.grad_of(xv), xr.grad, what="dx")
+    closeb(W.grad, wr.grad, what="dW")
+    closeb(Bp.grad, br.grad, what="db (rides on the dW GEMM)")
+
+
+@pytest.mark.parametrize("tA,tB", [(0, 0), (0, 1), (1, 0)])
+def test_bmm_bf16(Gb, tA, tB):
+    nb1, nb2, M, N, K = 2, 3, 40, 24, 56
+    a = _bf(T(f"bb.a{tA}", (nb1, nb2, K, M) if tA else (nb1, nb2, M, K)))
+    b = _bf(T(f"bb.b{tB}", (nb1, nb2, N, K) if tB else (nb1, nb2, K, N)))
+    gy = _bf(T("bb.g", (nb1, nb2, M, N)))
+    ar, br = a.float().requires_grad_(), b.float().requires_grad_()
+    y = 0.5 * ((ar.transpose(-1, -2) if tA else ar) @ (br.transpose(-1, -2) if tB else br))
+    y.backward(gy.float())
+    av, bv = mkV(Gb, a.reshape(-1, a.shape[-1])), mkV(Gb, b.reshape(-1, b.shape[-1]))
+    out = Gb.new(nb1 * nb2 * M, N)
+    ra, rb = a.shape[-2], b.shape[-2]
+    Gb.bmm(av, bv, out, M, N, K, tA, tB, nb1=nb1, nb2=nb2, sA=(nb2 * ra * av.cols, ra * av.cols),
+           sB=(nb2 * rb * bv.cols, rb * bv.cols), sC=(nb2 * M * N, M * N), alpha=0.5)
+    closeb(out.data.view(nb1, nb2, M, N), y, what="y")
+    run_bwd(Gb, out, gy.reshape(-1, N))
+    closeb(Gb.grad_of(av).view(a.shape), ar.grad, what="dA")
+    closeb(Gb.grad_of(bv).view(b.shape), br.grad, what="dB")
+
+
+@pytest.mark.parametrize("Nq,Nk", [(200, 98), (392, 784), (130, 784)])
+def test_attention_bf16(Nq, Nk):
+    from transception_amd.engine import Graph
+    B, d = 2, 64
+    q, kv, gy = _bf(T(f"ab.q{Nq}", (B * Nq, d))), _bf(T(f"ab.kv{Nk}", (B * Nk, 2 * d))), _bf(T(f"ab.g{Nq}", (B * Nq, d)))
+    qr, kvr = q.float().requires_grad_(), kv.float().requires_grad_()
+    k, v = kvr[:, :d].reshape(B, Nk, d), kvr[:, d:].reshape(B, Nk, d)
+    y = (torch.softmax(qr.view(B, Nq, d) @ k.transpose(1, 2) * 0.125, -1) @ v).reshape(B * Nq, d)
+    y.backward(gy.float())
+    Gx = Graph(torch.bfloat16, torch.device(DEV), True, True)
+    Gx.use_fused_attention = True
+    qv, kvv = mkV(Gx, q), mkV(Gx, kv)
+    out = Gx.attention(qv, kvv.colslice(0, d), kvv.colslice(d, 2 * d), B, Nq, Nk, 0.125)
+    closeb(out.data, y, 2e-2, "attention bf16")
+    run_bwd(Gx, out, gy)
+    closeb(Gx.grad_of(qv), qr.grad, 3e-2, "dq bf16")
+    closeb(Gx.grad_of(kvv), kvr.grad, 3e-2, "dkv bf16")
+
+
+def test_dwconv_layernorm_bf16(Gb):
+    B, H, C = 2, 14, 128
+    x, w, b = _bf(T("db.x", (B, H, H, C))), _bf(T("db.w", (C, 1, 3, 3), 0.3)), _bf(T("db.b", (C,), 0.1))
+    xr, wr, br = (t.float().requires_grad_() for t in (x, w, b))
+    y = F.conv2d(xr.permute(0, 3, 1, 2), wr, br, padding=1, groups=C).permute(0, 2, 3, 1) + xr
+    gy = _bf(T("db.g", tuple(y.shape)))
+    y.backward(gy.float())
+    xv, wp, bp = mkV(Gb, x.reshape(-1, C)), mkPb(w.float()), mkPb(b.float())
+    out = Gb.dwconv(xv, wp, bp, B, H, H, 3, 1, True)
+    closeb(out.data.view(y.shape), y, what="dw y")
+    run_bwd(Gb, out, gy.reshape(-1, C))
+    closeb(Gb.grad_of(xv).view(x.shape), xr.grad, what="dw dx")
+    closeb(wp.grad, wr.grad, what="dw dw")
+    closeb(bp.grad, br.grad, what="dw db")

@@ -25,7 +25,7 @@ class TcGemm(C.Structure):
                 ("transA", i32), ("transB", i32), ("nb1", i32), ("nb2", i32),
                 ("sA1", i64), ("sA2", i64), ("sB1", i64), ("sB2", i64),
                 ("sC1", i64), ("sC2", i64), ("sR1", i64), ("sR2", i64),
-                ("alpha", f32), ("accumulate", i32), ("act", i32), ("splitk", i32), ("dtype", i32), ("c_f32", i32), ("atomic", i32)]
+                ("alpha", f32), ("accumulate", i32), ("act", i32), ("splitk", i32), ("dtype", i32), ("c_f32", i32), ("atomic", i32), ("rowsum", vp)]
 
 
 # name -> argtypes (every function returns int status unless listed in _RET)

@@ -109,6 +109,159 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const T* __restrict__ dy,
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Stride-1 "row strip" kernels: a thread owns CPT consecutive channels of one output row (b, oh) and walks along ow with
+// the K x K input window held in registers (K new loads per output instead of K*K; column slots rotate at compile time).
+//   MODE 0: y = conv(x) (+bias) (+x)          MODE 1: dx = conv^T(dy) (+dy)  [same walk with flipped taps]
+//   MODE 2: dw[c,ky,kx] += sum dy * x ;  db[c] += sum dy   (block-level LDS reduction, then one atomic per block and tap)
+template <typename T, int CPT> __device__ __forceinline__ void ldv(const T* p, float* o);
+template <> __device__ __forceinline__ void ldv<float, 4>(const float* p, float* o) { const float4 v = *reinterpret_cast<const float4*>(p); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+template <> __device__ __forceinline__ void ldv<float, 2>(const float* p, float* o) { const float2 v = *reinterpret_cast<const float2*>(p); o[0] = v.x; o[1] = v.y; }
+template <> __device__ __forceinline__ void ldv<bf16_t, 4>(const bf16_t* p, float* o) { const float4 v = ld4<bf16_t>(p); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+template <> __device__ __forceinline__ void ldv<bf16_t, 2>(const bf16_t* p, float* o) { const unsigned r = *reinterpret_cast<const unsigned*>(p); o[0] = __uint_as_float(r << 16); o[1] = __uint_as_float(r & 0xffff0000u); }
+template <typename T, int CPT> __device__ __forceinline__ void stv(T* p, const float* o);
+template <> __device__ __forceinline__ void stv<float, 4>(float* p, const float* o) { *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]); }
+template <> __device__ __forceinline__ void stv<float, 2>(float* p, const float* o) { *reinterpret_cast<float2*>(p) = make_float2(o[0], o[1]); }
+template <> __device__ __forceinline__ void stv<bf16_t, 4>(bf16_t* p, const float* o) { st4<bf16_t>(p, make_float4(o[0], o[1], o[2], o[3])); }
+template <> __device__ __forceinline__ void stv<bf16_t, 2>(bf16_t* p, const float* o) { *reinterpret_cast<unsigned*>(p) = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16); }
+
+template <typename T, int K, int CPT, int MODE>
+__global__ __launch_bounds__(256) void dw_strip_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ w, const T* __restrict__ bias,
+                                                       const T* __restrict__ dy, int lddy, T* __restrict__ y, int ldy,
+                                                       float* __restrict__ dw, float* __restrict__ db, int B, int H, int W, int C,
+                                                       int add_input, int accumulate) {
+    constexpr int P = (K - 1) / 2, CGB = 64 / CPT, RI = 256 / CGB;
+    const int cgl = threadIdx.x % CGB, ri = threadIdx.x / CGB;
+    const int c = blockIdx.y * 64 + cgl * CPT;
+    const bool cok = c < C;
+    const T* src = (MODE == 1) ? dy : x;              // tensor the window slides over
+    const int lds_ = (MODE == 1) ? lddy : ldx;
+    float wr[(MODE == 2) ? 1 : K * K][CPT];
+    float bs[CPT];
+    float acc[(MODE == 2) ? K * K : 1][CPT];
+    float accb[CPT];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) { bs[i] = 0.f; accb[i] = 0.f; }
+    if (MODE != 2 && cok) {
+#pragma unroll
+        for (int t = 0; t < K * K; ++t)
+#pragma unroll
+            for (int i = 0; i < CPT; ++i)
+                wr[t][i] = ldf<T>(w + (long long)(c + i) * K * K + (MODE == 1 ? (K * K - 1 - t) : t));
+        if (MODE == 0 && bias)
+#pragma unroll
+            for (int i = 0; i < CPT; ++i) bs[i] = ldf<T>(bias + c + i);
+    }
+    if (MODE == 2) {
+#pragma unroll
+        for (int t = 0; t < K * K; ++t)
+#pragma unroll
+            for (int i = 0; i < CPT; ++i) acc[t][i] = 0.f;
+    }
+    const int nrows = B * H;
+    if (cok) {
+        for (int row = blockIdx.x * RI + ri; row < nrows; row += gridDim.x * RI) {
+            const int oh = row % H, b = row / H;
+            const T* sb = src + (long long)b * H * W * lds_ + c;
+            float win[K][K][CPT];                      // win[ky][slot]: slot (j + kx) % K holds column ow - P + kx at step j
+            bool rok[K];
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky) rok[ky] = (oh + ky - P >= 0) && (oh + ky - P < H);
+            // prime: columns -P .. P-1 go to slots 0 .. K-2
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < K - 1; ++kx) {
+                    const int iw = kx - P;
+#pragma unroll
+                    for (int i = 0; i < CPT; ++i) win[ky][kx][i] = 0.f;
+                    if (rok[ky] && iw >= 0 && iw < W) ldv<T, CPT>(sb + ((long long)(oh + ky - P) * W + iw) * lds_, win[ky][kx]);
+                }
+            for (int ow0 = 0; ow0 < W; ow0 += K) {
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const int ow = ow0 + j;
+                    if (ow < W) {
+                        // newest column ow + P enters slot (j + K - 1) % K
+                        const int iw = ow + P;
+#pragma unroll
+                        for (int ky = 0; ky < K; ++ky) {
+#pragma unroll
+                            for (int i = 0; i < CPT; ++i) win[ky][(j + K - 1) % K][i] = 0.f;
+                            if (rok[ky] && iw < W) ldv<T, CPT>(sb + ((long long)(oh + ky - P) * W + iw) * lds_, win[ky][(j + K - 1) % K]);
+                        }
+                        const long long pix = ((long long)b * H + oh) * W + ow;
+                        if (MODE == 2) {
+                            float d[CPT];
+                            ldv<T, CPT>(dy + pix * lddy + c, d);
+#pragma unroll
+                            for (int i = 0; i < CPT; ++i) accb[i] += d[i];
+#pragma unroll
+                            for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+                                for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                                    for (int i = 0; i < CPT; ++i) acc[ky * K + kx][i] += d[i] * win[ky][(j + kx) % K][i];
+                        } else {
+                            float o[CPT];
+#pragma unroll
+                            for (int i = 0; i < CPT; ++i) o[i] = bs[i];
+#pragma unroll
+                            for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+                                for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                                    for (int i = 0; i < CPT; ++i) o[i] += wr[ky * K + kx][i] * win[ky][(j + kx) % K][i];
+                            if (add_input)
+#pragma unroll
+                                for (int i = 0; i < CPT; ++i) o[i] += win[P][(j + P) % K][i];
+                            T* dst = y + pix * ldy + c;
+                            if (accumulate) { float q[CPT]; ldv<T, CPT>(dst, q);
+#pragma unroll
+                                for (int i = 0; i < CPT; ++i) o[i] += q[i]; }
+                            stv<T, CPT>(dst, o);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (MODE == 2) {
+        __shared__ float red[RI][64];
+#pragma unroll
+        for (int t = 0; t <= K * K; ++t) {
+#pragma unroll
+            for (int i = 0; i < CPT; ++i) red[ri][cgl * CPT + i] = (t < K * K) ? acc[t < K * K ? t : 0][i] : accb[i];
+            __syncthreads();
+            if (threadIdx.x < 64 && blockIdx.y * 64 + threadIdx.x < C) {
+                float s_ = 0.f;
+#pragma unroll
+                for (int r = 0; r < RI; ++r) s_ += red[r][threadIdx.x];
+                const int cc = blockIdx.y * 64 + threadIdx.x;
+                if (t < K * K) atomicAdd(dw + (long long)cc * K * K + t, s_);
+                else if (db) atomicAdd(db + cc, s_);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <typename T, int MODE>
+int launch_strip(const void* x, int ldx, const void* w, const void* bias, const void* dy, int lddy, void* y, int ldy, float* dw,
+                 float* db, int B, int H, int W, int C, int k, int add_input, int accumulate, hipStream_t s) {
+    const int nrows = B * H;
+#define TC_STRIP(KK, CPT)                                                                                                       \
+    {                                                                                                                           \
+        constexpr int RI = 256 / (64 / CPT);                                                                                    \
+        dim3 grid(tc_blocks(nrows, RI, MODE == 2 ? 512 : 4096), (C + 63) / 64);                                                  \
+        hipLaunchKernelGGL((dw_strip_kernel<T, KK, CPT, MODE>), grid, dim3(256), 0, s, (const T*)x, ldx, (const T*)w, (const T*)bias, \
+                           (const T*)dy, lddy, (T*)y, ldy, dw, db, B, H, W, C, add_input, accumulate);                          \
+    }
+    if (k == 3) TC_STRIP(3, 4) else if (k == 5) TC_STRIP(5, 2) else TC_STRIP(7, 2)
+#undef TC_STRIP
+    return tc_launch_status();
+}
+
 template <typename T, bool BWD>
 int launch_dw(const void* x, int ldx, const void* w, const void* bias, void* y, int ldy, int B, int H, int W, int C, int k,
               int stride, int add_input, int accumulate, hipStream_t s) {
@@ -133,6 +286,9 @@ bool dw_args_ok(int B, int H, int W, int C, int k, int stride, int add_input) {
 extern "C" int tc_dwconv_fwd(const void* x, int ldx, const void* w, const void* bias, void* y, int ldy, int B, int H, int W,
                              int C, int k, int stride, int add_input, int dtype, void* stream) {
     if (!x || !w || !y || (ldx & 3) || (ldy & 3) || !dw_args_ok(B, H, W, C, k, stride, add_input)) return TC_ERR_ARG;
+    if (stride == 1)
+        TC_DISPATCH_DTYPE(dtype, return (launch_strip<T, 0>(x, ldx, w, bias, nullptr, 0, y, ldy, nullptr, nullptr, B, H, W, C, k,
+                                                            add_input, 0, (hipStream_t)stream)));
     TC_DISPATCH_DTYPE(dtype, return (launch_dw<T, false>(x, ldx, w, bias, y, ldy, B, H, W, C, k, stride, add_input, 0,
                                                          (hipStream_t)stream)));
     return TC_ERR_ARG;
@@ -141,6 +297,9 @@ extern "C" int tc_dwconv_fwd(const void* x, int ldx, const void* w, const void* 
 extern "C" int tc_dwconv_bwd_input(const void* dy, int lddy, const void* w, void* dx, int lddx, int B, int H, int W, int C,
                                    int k, int stride, int add_input, int accumulate, int dtype, void* stream) {
     if (!dy || !w || !dx || (lddy & 3) || (lddx & 3) || !dw_args_ok(B, H, W, C, k, stride, add_input)) return TC_ERR_ARG;
+    if (stride == 1)
+        TC_DISPATCH_DTYPE(dtype, return (launch_strip<T, 1>(nullptr, 0, w, nullptr, dy, lddy, dx, lddx, nullptr, nullptr, B, H, W, C, k,
+                                                            add_input, accumulate, (hipStream_t)stream)));
     TC_DISPATCH_DTYPE(dtype, return (launch_dw<T, true>(dy, lddy, w, nullptr, dx, lddx, B, H, W, C, k, stride, add_input, accumulate,
                                                         (hipStream_t)stream)));
     return TC_ERR_ARG;
@@ -149,6 +308,9 @@ extern "C" int tc_dwconv_bwd_input(const void* dy, int lddy, const void* w, void
 extern "C" int tc_dwconv_bwd_weight(const void* dy, int lddy, const void* x, int ldx, float* dw, float* db, int B, int H,
                                     int W, int C, int k, int stride, int dtype, void* stream) {
     if (!dy || !x || !dw || !dw_args_ok(B, H, W, C, k, stride, 0)) return TC_ERR_ARG;
+    if (stride == 1)
+        TC_DISPATCH_DTYPE(dtype, return (launch_strip<T, 2>(x, ldx, nullptr, nullptr, dy, lddy, nullptr, 0, dw, db, B, H, W, C, k, 0, 0,
+                                                            (hipStream_t)stream)));
     const int P = (k - 1) / 2;
     const int Ho = (H + 2 * P - k) / stride + 1, Wo = (W + 2 * P - k) / stride + 1;
     const long long npix = (long long)B * Ho * Wo;

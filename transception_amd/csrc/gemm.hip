@@ -1,12 +1,17 @@
-// Batched GEMM for gfx950 on the fp32 matrix core (v_mfma_f32_32x32x2_f32): exact fp32 products and
-// accumulation, used for every Linear / 1x1-conv / bmm of the TransCeption path and their gradients.
-//   C[b] = alpha * op(A[b]) op(B[b]) (+bias) (+R) ; optional sigmoid ; optional accumulate / split-K atomics.
-// 256 threads = 4 waves (2 x 2); each wave owns a (BM/2) x (BN/2) sub-tile made of 32x32 MFMA blocks.
-// Operands are staged through LDS "K-inner" (As[BM][BK+1], Bs[BN][BK+1]) whatever their global layout, with a
-// register prefetch of the next K-slab.  Storage type T (fp32 or bf16) is converted on the global<->LDS edge.
+// Batched GEMM for gfx950, used for every Linear / 1x1-conv / bmm of the TransCeption path and their gradients:
+//   C[b] = alpha * op(A[b]) op(B[b]) (+bias) (+R) ; optional sigmoid ; optional accumulate / atomic accumulation.
+// Two matrix-core paths selected by the storage type:
+//   fp32 storage -> v_mfma_f32_32x32x2_f32  (exact fp32 products, the parity path),  K-slab 16
+//   bf16 storage -> v_mfma_f32_32x32x16_bf16 (fp32 accumulate),                       K-slab 32
+// 256 threads = 4 waves (2 x 2); each wave owns a (BM/2) x (BN/2) sub-tile made of 32x32 MFMA blocks.  Operands are
+// staged through LDS "K-inner" (As[BM][BK+pad], Bs[BN][BK+pad]) whatever their global layout (transposed operands are
+// transposed on the LDS write), with a register prefetch of the next K-slab.  C may be fp32 while A/B are bf16
+// (weight gradients accumulate into the fp32 gradient arena); an optional row-sum of op(A) (the bias gradient that
+// belongs to a dW GEMM) is produced by the blocks of the first N-tile.
 #include "tc_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -17,40 +22,73 @@ struct GemmDev {
     long long sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2;
     float alpha; int accumulate, act;
     int vecA, vecB, atomic;
+    float* rowsum;          // optional: rowsum[m] += sum_k op(A)[m][k]  (fp32, atomics)
 };
 
+// ---------------------------------------------------------------------------------------------- shared epilogue
+// acc[r] of a 32x32 block holds row (r&3) + 8*(r>>2) + 4*(lane>>5), column lane&31
+template <typename T, typename TC, int TM, int TN>
+__device__ __forceinline__ void epilogue(const GemmDev& p, f32x16 (&acc)[TM][TN], int b1, int b2, int ks, int mbase, int nbase, int lane) {
+    TC* C = reinterpret_cast<TC*>(p.C) + b1 * p.sC1 + b2 * p.sC2;
+    const T* R = p.R ? reinterpret_cast<const T*>(p.R) + b1 * p.sR1 + b2 * p.sR2 : nullptr;
+    const T* bias = reinterpret_cast<const T*>(p.bias);
+    const bool first_split = (ks == 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = nbase + j * 32 + (lane & 31);
+            if (col >= p.N) continue;
+            const float bv = (bias && first_split) ? ldf<T>(bias + col) : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row >= p.M) continue;
+                float v = p.alpha * acc[i][j][r] + bv;
+                if (R && first_split) v += ldf<T>(R + (long long)row * p.ldr + col);
+                TC* c = C + (long long)row * p.ldc + col;
+                if (p.atomic) {
+                    atomicAdd(reinterpret_cast<float*>(c), v);       // fp32 C only (checked on the host)
+                } else {
+                    if (p.act == TC_ACT_SIGMOID) v = sigmoid_f(v);
+                    if (p.accumulate) v += ldf<TC>(c);
+                    stf<TC>(c, v);
+                }
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------- fp32 path
 // Load a 4-wide strip of an operand tile.  `trans` = the operand is stored [K, X] (X contiguous).
-// Returns values for (x0..x0+3, k) when trans, or (x, k0..k0+3) otherwise.
-template <typename T>
-__device__ __forceinline__ float4 load_strip(const T* base, int ld, int x, int k, int X, int K, bool trans, bool vec) {
+__device__ __forceinline__ float4 load_strip(const float* base, int ld, int x, int k, int X, int K, bool trans, bool vec) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!trans) {
         if (x < X) {
-            const T* p = base + (long long)x * ld + k;
-            if (vec && k + 3 < K) v = ld4<T>(p);
+            const float* p = base + (long long)x * ld + k;
+            if (vec && k + 3 < K) v = *reinterpret_cast<const float4*>(p);
             else {
-                if (k + 0 < K) v.x = ldf<T>(p + 0);
-                if (k + 1 < K) v.y = ldf<T>(p + 1);
-                if (k + 2 < K) v.z = ldf<T>(p + 2);
-                if (k + 3 < K) v.w = ldf<T>(p + 3);
+                if (k + 0 < K) v.x = p[0];
+                if (k + 1 < K) v.y = p[1];
+                if (k + 2 < K) v.z = p[2];
+                if (k + 3 < K) v.w = p[3];
             }
         }
     } else {
         if (k < K) {
-            const T* p = base + (long long)k * ld + x;
-            if (vec && x + 3 < X) v = ld4<T>(p);
+            const float* p = base + (long long)k * ld + x;
+            if (vec && x + 3 < X) v = *reinterpret_cast<const float4*>(p);
             else {
-                if (x + 0 < X) v.x = ldf<T>(p + 0);
-                if (x + 1 < X) v.y = ldf<T>(p + 1);
-                if (x + 2 < X) v.z = ldf<T>(p + 2);
-                if (x + 3 < X) v.w = ldf<T>(p + 3);
+                if (x + 0 < X) v.x = p[0];
+                if (x + 1 < X) v.y = p[1];
+                if (x + 2 < X) v.z = p[2];
+                if (x + 3 < X) v.w = p[3];
             }
         }
     }
     return v;
 }
 
-template <typename T, typename TC, int BM, int BN, bool TA, bool TB>
+template <typename TC, int BM, int BN, bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmDev p) {
     constexpr int BK = 16, LDT = BK + 1;
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
@@ -68,8 +106,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev p) {
     const int kbeg = ks * p.kchunk;
     const int kend = min(p.K, kbeg + p.kchunk);
 
-    const T* A = reinterpret_cast<const T*>(p.A) + b1 * p.sA1 + b2 * p.sA2;
-    const T* B = reinterpret_cast<const T*>(p.B) + b1 * p.sB1 + b2 * p.sB2;
+    const float* A = reinterpret_cast<const float*>(p.A) + b1 * p.sA1 + b2 * p.sA2;
+    const float* B = reinterpret_cast<const float*>(p.B) + b1 * p.sB1 + b2 * p.sB2;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -85,17 +123,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev p) {
         for (int i = 0; i < SA; ++i) {
             const int f = tid + i * 256;
             if (!TA) { const int row = f / (BK / 4), kq = f % (BK / 4);
-                ra[i] = load_strip<T>(A, p.lda, m0 + row, k0 + kq * 4, p.M, kend, false, p.vecA); }
+                ra[i] = load_strip(A, p.lda, m0 + row, k0 + kq * 4, p.M, kend, false, p.vecA); }
             else { const int k = f / (BM / 4), mq = f % (BM / 4);
-                ra[i] = load_strip<T>(A, p.lda, m0 + mq * 4, k0 + k, p.M, kend, true, p.vecA); }
+                ra[i] = load_strip(A, p.lda, m0 + mq * 4, k0 + k, p.M, kend, true, p.vecA); }
         }
 #pragma unroll
         for (int i = 0; i < SB; ++i) {
             const int f = tid + i * 256;
             if (TB) { const int row = f / (BK / 4), kq = f % (BK / 4);          // stored [N,K]
-                rb[i] = load_strip<T>(B, p.ldb, n0 + row, k0 + kq * 4, p.N, kend, false, p.vecB); }
+                rb[i] = load_strip(B, p.ldb, n0 + row, k0 + kq * 4, p.N, kend, false, p.vecB); }
             else { const int k = f / (BN / 4), nq = f % (BN / 4);               // stored [K,N]
-                rb[i] = load_strip<T>(B, p.ldb, n0 + nq * 4, k0 + k, p.N, kend, true, p.vecB); }
+                rb[i] = load_strip(B, p.ldb, n0 + nq * 4, k0 + k, p.N, kend, true, p.vecB); }
         }
     };
     auto stage = [&]() {
@@ -117,11 +155,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev p) {
         }
     };
 
+    float rsum = 0.f;
+    const bool do_rowsum = p.rowsum && blockIdx.x == 0 && tid < BM;
     if (kbeg < kend) fetch(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         stage();
         __syncthreads();
         if (k0 + BK < kend) fetch(k0 + BK);
+        if (do_rowsum) {
+#pragma unroll
+            for (int kk = 0; kk < BK; ++kk) rsum += As[tid * LDT + kk];
+        }
         const float* ap = &As[(wr * WM + (lane & 31)) * LDT + (lane >> 5)];
         const float* bp = &Bs[(wc * WN + (lane & 31)) * LDT + (lane >> 5)];
 #pragma unroll
@@ -139,44 +183,151 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev p) {
         }
         __syncthreads();
     }
+    if (do_rowsum && m0 + tid < p.M) atomicAdd(p.rowsum + m0 + tid, rsum);
+    epilogue<float, TC, TM, TN>(p, acc, b1, b2, ks, m0 + wr * WM, n0 + wc * WN, lane);
+}
 
-    // epilogue: acc[r] holds row (r&3) + 8*(r>>2) + 4*(lane>>5), column lane&31 of its 32x32 block
-    TC* C = reinterpret_cast<TC*>(p.C) + b1 * p.sC1 + b2 * p.sC2;
-    const T* R = p.R ? reinterpret_cast<const T*>(p.R) + b1 * p.sR1 + b2 * p.sR2 : nullptr;
-    const T* bias = reinterpret_cast<const T*>(p.bias);
-    const bool first_split = (ks == 0);
+// ---------------------------------------------------------------------------------------------- bf16 path
+// Load an 8-wide strip (16 B) of an operand tile as raw bf16 bits.
+__device__ __forceinline__ uint4 load_strip8(const bf16_t* base, int ld, int x, int k, int X, int K, bool trans, bool vec) {
+    union { uint4 v; bf16_t e[8]; } u;
+    u.v = make_uint4(0u, 0u, 0u, 0u);
+    if (!trans) {
+        if (x < X) {
+            const bf16_t* p = base + (long long)x * ld + k;
+            if (vec && k + 7 < K) u.v = *reinterpret_cast<const uint4*>(p);
+            else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) if (k + i < K) u.e[i] = p[i];
+            }
+        }
+    } else {
+        if (k < K) {
+            const bf16_t* p = base + (long long)k * ld + x;
+            if (vec && x + 7 < X) u.v = *reinterpret_cast<const uint4*>(p);
+            else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) if (x + i < X) u.e[i] = p[i];
+            }
+        }
+    }
+    return u.v;
+}
+
+template <typename TC, int BM, int BN, bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmDev p) {
+    constexpr int BK = 32, LDT = BK + 8;                       // 80-byte rows: 16-B aligned, conflict-free b128 fragment reads
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int SA = BM * BK / 8 / 256, SB = BN * BK / 8 / 256;   // 8-element strips per thread
+    static_assert(SA >= 1 && SB >= 1, "tile too small");
+    __shared__ __attribute__((aligned(16))) bf16_t As[BM * LDT];
+    __shared__ __attribute__((aligned(16))) bf16_t Bs[BN * LDT];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    int z = blockIdx.z;
+    const int ks = z % p.splitk; z /= p.splitk;
+    const int b2 = z % p.nb2, b1 = z / p.nb2;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = ks * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
+
+    const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + b1 * p.sA1 + b2 * p.sA2;
+    const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B) + b1 * p.sB1 + b2 * p.sB2;
+
+    f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wc * WN + j * 32 + (lane & 31);
-            if (col >= p.N) continue;
-            const float bv = (bias && first_split) ? ldf<T>(bias + col) : 0.f;
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wr * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row >= p.M) continue;
-                float v = p.alpha * acc[i][j][r] + bv;
-                if (R && first_split) v += ldf<T>(R + (long long)row * p.ldr + col);
-                TC* c = C + (long long)row * p.ldc + col;
-                if (p.atomic) {
-                    atomicAdd(reinterpret_cast<float*>(c), v);       // fp32 only (checked on the host)
-                } else {
-                    if (p.act == TC_ACT_SIGMOID) v = sigmoid_f(v);
-                    if (p.accumulate) v += ldf<TC>(c);
-                    stf<TC>(c, v);
-                }
-            }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    uint4 ra[SA], rb[SB];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < SA; ++i) {
+            const int f = tid + i * 256;
+            if (!TA) { const int row = f / (BK / 8), kq = f % (BK / 8);
+                ra[i] = load_strip8(A, p.lda, m0 + row, k0 + kq * 8, p.M, kend, false, p.vecA); }
+            else { const int k = f / (BM / 8), mq = f % (BM / 8);
+                ra[i] = load_strip8(A, p.lda, m0 + mq * 8, k0 + k, p.M, kend, true, p.vecA); }
         }
+#pragma unroll
+        for (int i = 0; i < SB; ++i) {
+            const int f = tid + i * 256;
+            if (TB) { const int row = f / (BK / 8), kq = f % (BK / 8);
+                rb[i] = load_strip8(B, p.ldb, n0 + row, k0 + kq * 8, p.N, kend, false, p.vecB); }
+            else { const int k = f / (BN / 8), nq = f % (BN / 8);
+                rb[i] = load_strip8(B, p.ldb, n0 + nq * 8, k0 + k, p.N, kend, true, p.vecB); }
+        }
+    };
+    auto put_t = [&](bf16_t* base, int x0, int k, uint4 v) {       // transposed write: 8 rows x0.., column k
+        union { uint4 v; bf16_t e[8]; } u;
+        u.v = v;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) base[(x0 + i) * LDT + k] = u.e[i];
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < SA; ++i) {
+            const int f = tid + i * 256;
+            if (!TA) { const int row = f / (BK / 8), kq = f % (BK / 8); *reinterpret_cast<uint4*>(&As[row * LDT + kq * 8]) = ra[i]; }
+            else { const int k = f / (BM / 8), mq = f % (BM / 8); put_t(As, mq * 8, k, ra[i]); }
+        }
+#pragma unroll
+        for (int i = 0; i < SB; ++i) {
+            const int f = tid + i * 256;
+            if (TB) { const int row = f / (BK / 8), kq = f % (BK / 8); *reinterpret_cast<uint4*>(&Bs[row * LDT + kq * 8]) = rb[i]; }
+            else { const int k = f / (BN / 8), nq = f % (BN / 8); put_t(Bs, nq * 8, k, rb[i]); }
+        }
+    };
+
+    float rsum = 0.f;
+    const bool do_rowsum = p.rowsum && blockIdx.x == 0 && tid < BM;
+    if (kbeg < kend) fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        stage();
+        __syncthreads();
+        if (k0 + BK < kend) fetch(k0 + BK);
+        if (do_rowsum) {
+#pragma unroll
+            for (int kk = 0; kk < BK; ++kk) rsum += bf2f(As[tid * LDT + kk]);
+        }
+        const bf16_t* ap = &As[(wr * WM + (lane & 31)) * LDT + 8 * (lane >> 5)];
+        const bf16_t* bp = &Bs[(wc * WN + (lane & 31)) * LDT + 8 * (lane >> 5)];
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 16) {
+            bf16x8 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(ap + i * 32 * LDT + kk);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8*>(bp + j * 32 * LDT + kk);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    if (do_rowsum && m0 + tid < p.M) atomicAdd(p.rowsum + m0 + tid, rsum);
+    epilogue<bf16_t, TC, TM, TN>(p, acc, b1, b2, ks, m0 + wr * WM, n0 + wc * WN, lane);
+}
+
+// ---------------------------------------------------------------------------------------------- host side
+template <typename T, typename TC, int BM, int BN, bool TA, bool TB>
+void launch_one(const GemmDev& d, dim3 grid, hipStream_t s) {
+    if constexpr (sizeof(T) == 4) hipLaunchKernelGGL((gemm_kernel<TC, BM, BN, TA, TB>), grid, dim3(256), 0, s, d);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<TC, BM, BN, TA, TB>), grid, dim3(256), 0, s, d);
 }
 
 template <typename T, typename TC, int BM, int BN>
 int launch(const GemmDev& d, int transA, int transB, dim3 grid, hipStream_t s) {
-    dim3 block(256);
-    if (!transA && transB) hipLaunchKernelGGL((gemm_kernel<T, TC, BM, BN, false, true>), grid, block, 0, s, d);
-    else if (!transA && !transB) hipLaunchKernelGGL((gemm_kernel<T, TC, BM, BN, false, false>), grid, block, 0, s, d);
-    else if (transA && !transB) hipLaunchKernelGGL((gemm_kernel<T, TC, BM, BN, true, false>), grid, block, 0, s, d);
-    else hipLaunchKernelGGL((gemm_kernel<T, TC, BM, BN, true, true>), grid, block, 0, s, d);
+    if (!transA && transB) launch_one<T, TC, BM, BN, false, true>(d, grid, s);
+    else if (!transA && !transB) launch_one<T, TC, BM, BN, false, false>(d, grid, s);
+    else if (transA && !transB) launch_one<T, TC, BM, BN, true, false>(d, grid, s);
+    else launch_one<T, TC, BM, BN, true, true>(d, grid, s);
     return tc_launch_status();
 }
 
@@ -190,9 +341,10 @@ int gemm_typed(const TcGemm* g, hipStream_t s) {
     d.sC1 = g->sC1; d.sC2 = g->sC2; d.sR1 = g->sR1; d.sR2 = g->sR2;
     d.alpha = g->alpha; d.accumulate = g->accumulate; d.act = g->act;
     d.atomic = (g->splitk > 1 || g->atomic) ? 1 : 0;
-    const int esz = (int)sizeof(T);
+    d.rowsum = g->rowsum;
+    constexpr int VEC = 16 / (int)sizeof(T);                         // elements per 16-byte vector
     auto aligned = [&](const void* ptr, int ld, long long s1, long long s2) {
-        return ((uintptr_t)ptr % (4 * esz) == 0) && (ld % 4 == 0) && (s1 % 4 == 0) && (s2 % 4 == 0);
+        return ((uintptr_t)ptr % 16 == 0) && (ld % VEC == 0) && (s1 % VEC == 0) && (s2 % VEC == 0);
     };
     d.vecA = aligned(g->A, g->lda, g->sA1, g->sA2);
     d.vecB = aligned(g->B, g->ldb, g->sB1, g->sB2);
@@ -200,8 +352,9 @@ int gemm_typed(const TcGemm* g, hipStream_t s) {
     const long long big = (long long)((g->M + 127) / 128) * ((g->N + 127) / 128) * nb;
     const bool use128 = big >= 192 && g->M >= 96 && g->N >= 96;
     const int BM = use128 ? 128 : 64, BN = use128 ? 128 : 64;
+    constexpr int BK = sizeof(T) == 4 ? 16 : 32;
     int kchunk = (g->K + g->splitk - 1) / g->splitk;
-    kchunk = (kchunk + 15) / 16 * 16;
+    kchunk = (kchunk + BK - 1) / BK * BK;
     d.kchunk = kchunk;
     d.splitk = (g->K + kchunk - 1) / kchunk;
     if (d.splitk < 1) d.splitk = 1;
@@ -221,6 +374,7 @@ extern "C" int tc_gemm(const TcGemm* g, void* stream) {
         g->splitk < 1)
         return TC_ERR_ARG;
     if ((g->splitk > 1 || g->atomic) && (!g->accumulate || (g->dtype != TC_F32 && !g->c_f32) || g->act != TC_ACT_NONE)) return TC_ERR_ARG;
+    if (g->rowsum && (g->nb1 * g->nb2 > 1 && !g->atomic)) return TC_ERR_ARG;
     if (g->act != TC_ACT_NONE && g->act != TC_ACT_SIGMOID) return TC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     TC_DISPATCH_DTYPE(g->dtype, return gemm_typed<T>(g, s));

@@ -215,9 +215,9 @@ class Graph:
 
     # ------------------------------------------------------------------ GEMM plumbing
     def _gemm(self, A, lda, B, ldb, Cm, ldc, M, N, K, tA, tB, bias=None, R=None, ldr=0, alpha=1.0, acc=0, act=ACT_NONE,
-              splitk=1, nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), c_f32=0, atomic=0):
+              splitk=1, nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), c_f32=0, atomic=0, rowsum=None):
         g = TcGemm(A, B, Cm, bias, R, M, N, K, lda, ldb, ldc, ldr, tA, tB, nb1, nb2, sA[0], sA[1], sB[0], sB[1], sC[0], sC[1],
-                   sR[0], sR[1], alpha, acc, act, splitk, self.dt, c_f32, atomic)
+                   sR[0], sR[1], alpha, acc, act, splitk, self.dt, c_f32, atomic, rowsum)
         self.n_launch += 1
         self.L.tc_gemm(C.byref(g), self.stream)
 
@@ -261,11 +261,13 @@ class Graph:
                 gx, acc = self.wgrad(x, (nb - 1) * sx // x.root.cols if nb > 1 else 0)
                 self._gemm(_ptr(dz), dz.stride(0), _ptr(Wt), Wt.stride(0), _ptr(gx), gx.stride(0), M, K, N, 0, 0, acc=acc,
                            nb1=nb, sA=(so, 0), sC=(sx, 0))
+            want_db = b is not None and b.grad is not None
             if W.grad is not None:
                 gW = W.grad if wcols is None else W.grad[:, wcols[0]:wcols[1]]
                 self._gemm(_ptr(dz), dz.stride(0), _ptr(x.data), x.ld, _ptr(gW), gW.stride(0), N, K, M, 1, 0, acc=1,
-                           splitk=self._splitk(N, K, M), c_f32=1, nb1=nb, sA=(so, 0), sB=(sx, 0), atomic=int(nb > 1))
-            if b is not None and b.grad is not None:
+                           splitk=self._splitk(N, K, M), c_f32=1, nb1=nb, sA=(so, 0), sB=(sx, 0), atomic=int(nb > 1),
+                           rowsum=_ptr(b.grad) if want_db else None)       # db = column sums of dz ride along
+            elif want_db:
                 self.L.tc_colsum(_ptr(dz), M, N, dz.stride(0), nb, so, _ptr(b.grad), 1, self.dt, self.stream)
             if residual is not None:
                 assert nb == 1 or sr == so
