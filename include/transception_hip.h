@@ -215,9 +215,10 @@ int tc_seg_loss_bwd(const float* prob, const long long* labels, const float* sum
                     int HW, float w_ce, float w_dice, float n_pix_global, float gscale, const float* gscale_dev, int dtype,
                     void* stream);
 /* Fused SGD with momentum and weight decay over flat fp32 buffers (torch.optim.SGD semantics, trainer.py:125):
- *   g = grad*gscale + wd*p ; buf = first ? g : mom*buf + g ; p -= lr*buf. */
-int tc_sgd_step(float* p, const float* grad, float* buf, long long n, float lr, float momentum, float wd,
-                float gscale, int first, void* stream);
+ *   g = grad*gscale + wd*p ; buf = first ? g : mom*buf + g ; p -= lr*buf.
+ * lr_dev (optional device scalar) overrides lr, so a hipGraph-captured step can follow a per-iteration schedule. */
+int tc_sgd_step(float* p, const float* grad, float* buf, long long n, float lr, const float* lr_dev, float momentum,
+                float wd, float gscale, int first, void* stream);
 /* dst(bf16) = src(fp32) and back, for bf16 working copies of fp32 master weights */
 int tc_cast(const void* src, void* dst, long long n, int src_dtype, int dst_dtype, void* stream);
 

@@ -62,7 +62,7 @@ SIGNATURES = {
     "tc_stem_im2col": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "tc_seg_loss_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "tc_seg_loss_bwd": [vp, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, vp, i32, vp],
-    "tc_sgd_step": [vp, vp, vp, i64, f32, f32, f32, f32, i32, vp],
+    "tc_sgd_step": [vp, vp, vp, i64, f32, vp, f32, f32, f32, i32, vp],
     "tc_cast": [vp, vp, i64, i32, i32, vp],
 }
 _RET = {"tc_bn_scratch_floats": i64}

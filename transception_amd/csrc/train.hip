@@ -96,7 +96,8 @@ __global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float* __restri
 }
 
 __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, long long n, float lr,
-                           float mom, float wd, float gscale, int first) {
+                           float mom, float wd, float gscale, int first, const float* __restrict__ lr_dev) {
+    if (lr_dev) lr = *lr_dev;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const float w = p[i];
         const float d = g[i] * gscale + wd * w;
@@ -136,10 +137,10 @@ extern "C" int tc_seg_loss_bwd(const float* prob, const long long* labels, const
     return tc_launch_status();
 }
 
-extern "C" int tc_sgd_step(float* p, const float* grad, float* buf, long long n, float lr, float momentum, float wd, float gscale,
-                           int first, void* stream) {
+extern "C" int tc_sgd_step(float* p, const float* grad, float* buf, long long n, float lr, const float* lr_dev, float momentum, float wd,
+                           float gscale, int first, void* stream) {
     if (!p || !grad || !buf || n <= 0) return TC_ERR_ARG;
     hipLaunchKernelGGL(sgd_kernel, dim3(tc_blocks(n, 256 * 4, 4096)), dim3(256), 0, (hipStream_t)stream, p, grad, buf, n, lr, momentum, wd,
-                       gscale, first);
+                       gscale, first, lr_dev);
     return tc_launch_status();
 }

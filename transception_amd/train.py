@@ -104,6 +104,12 @@ class FusedSGD:
         self.buf: Optional[torch.Tensor] = None
         self.steps = 0
         self._segments = None
+        self.lr_dev: Optional[torch.Tensor] = None       # device scalar read by the kernel (hipGraph-friendly schedule)
+
+    def set_lr(self, lr: float):
+        self.lr = lr
+        if self.lr_dev is not None:
+            self.lr_dev.fill_(lr)
 
     def _segs(self):
         if self._segments is None:
@@ -127,13 +133,16 @@ class FusedSGD:
         flat, g = M._flat, M._gflat
         if self.buf is None:
             self.buf = torch.zeros_like(flat)
+        if self.lr_dev is None:
+            self.lr_dev = torch.full((1,), float(self.lr), dtype=torch.float32, device=flat.device)
         L = lib()
         stream = torch.cuda.current_stream(flat.device).cuda_stream
         es = 4
         for off, n in self._segs():
             n = min(n, flat.numel() - off)
             L.tc_sgd_step(flat.data_ptr() + off * es, g.data_ptr() + off * es, self.buf.data_ptr() + off * es, n, float(self.lr),
-                          float(self.momentum), float(self.wd), float(grad_scale), int(self.steps == 0), stream)
+                          self.lr_dev.data_ptr(), float(self.momentum), float(self.wd), float(grad_scale), int(self.steps == 0),
+                          stream)
         self.steps += 1
 
 
@@ -152,3 +161,46 @@ def train_step(model, loss_fn: SegLoss, opt: FusedSGD, images: torch.Tensor, lab
     allreduce_gradients(model, group)
     opt.step()
     return loss, ce, dice
+
+
+class GraphedStep:
+    """A whole training step (forward, loss, backward, SGD) captured once into a hipGraph and replayed: ~3400 kernel
+    launches per step become one graph launch, removing the host from the loop.  Inputs are copied into static buffers;
+    the learning rate is a device scalar (FusedSGD.set_lr).  For world > 1 the gradient all-reduce stays outside the
+    graphs: graph A = forward+loss+backward, RCCL all-reduce on the flat arena, graph B = SGD."""
+
+    def __init__(self, model, loss_fn: SegLoss, opt: FusedSGD, images: torch.Tensor, labels: torch.Tensor, group=None, warmup: int = 3):
+        self.model, self.loss_fn, self.opt, self.group = model, loss_fn, opt, group
+        self.x, self.y = images.clone(), labels.clone()
+        self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                train_step(model, loss_fn, opt, self.x, self.y, group)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.g_main = torch.cuda.CUDAGraph()
+        if not self.distributed:
+            with torch.cuda.graph(self.g_main):
+                self.out = train_step(model, loss_fn, opt, self.x, self.y, None)
+            self.g_opt = None
+        else:
+            with torch.cuda.graph(self.g_main):
+                opt.zero_grad()
+                loss, ce, dice = loss_fn(model(self.x), self.y)     # the 28-float Dice all-reduce is captured (RCCL supports it)
+                loss.backward()
+                self.out = (loss, ce, dice)
+            self.g_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_opt):
+                opt.step()
+
+    def __call__(self, images: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None):
+        if images is not None:
+            self.x.copy_(images, non_blocking=True)
+            self.y.copy_(labels, non_blocking=True)
+        self.g_main.replay()
+        if self.g_opt is not None:
+            allreduce_gradients(self.model, self.group)
+            self.g_opt.replay()
+        return self.out
