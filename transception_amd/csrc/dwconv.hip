@@ -129,7 +129,7 @@ template <typename T, int K, int CPT, int MODE>
 __global__ __launch_bounds__(256) void dw_strip_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ w, const T* __restrict__ bias,
                                                        const T* __restrict__ dy, int lddy, T* __restrict__ y, int ldy,
                                                        float* __restrict__ dw, float* __restrict__ db, int B, int H, int W, int C,
-                                                       int add_input, int accumulate) {
+                                                       int add_input, int accumulate, int nseg) {
     constexpr int P = (K - 1) / 2, CGB = 64 / CPT, RI = 256 / CGB;
     const int cgl = threadIdx.x % CGB, ri = threadIdx.x / CGB;
     const int c = blockIdx.y * 64 + cgl * CPT;
@@ -158,30 +158,33 @@ __global__ __launch_bounds__(256) void dw_strip_kernel(const T* __restrict__ x, 
 #pragma unroll
             for (int i = 0; i < CPT; ++i) acc[t][i] = 0.f;
     }
-    const int nrows = B * H;
+    const int nrows = B * H * nseg;                 // work item = (b, oh, W-segment)
+    const int seglen = (W + nseg - 1) / nseg;
     if (cok) {
-        for (int row = blockIdx.x * RI + ri; row < nrows; row += gridDim.x * RI) {
+        for (int item = blockIdx.x * RI + ri; item < nrows; item += gridDim.x * RI) {
+            const int seg = item % nseg, row = item / nseg;
             const int oh = row % H, b = row / H;
+            const int w0 = seg * seglen, w1 = min(W, w0 + seglen);
             const T* sb = src + (long long)b * H * W * lds_ + c;
             float win[K][K][CPT];                      // win[ky][slot]: slot (j + kx) % K holds column ow - P + kx at step j
             bool rok[K];
 #pragma unroll
             for (int ky = 0; ky < K; ++ky) rok[ky] = (oh + ky - P >= 0) && (oh + ky - P < H);
-            // prime: columns -P .. P-1 go to slots 0 .. K-2
+            // prime: columns w0-P .. w0+P-1 go to slots 0 .. K-2
 #pragma unroll
             for (int ky = 0; ky < K; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < K - 1; ++kx) {
-                    const int iw = kx - P;
+                    const int iw = w0 + kx - P;
 #pragma unroll
                     for (int i = 0; i < CPT; ++i) win[ky][kx][i] = 0.f;
                     if (rok[ky] && iw >= 0 && iw < W) ldv<T, CPT>(sb + ((long long)(oh + ky - P) * W + iw) * lds_, win[ky][kx]);
                 }
-            for (int ow0 = 0; ow0 < W; ow0 += K) {
+            for (int ow0 = w0; ow0 < w1; ow0 += K) {
 #pragma unroll
                 for (int j = 0; j < K; ++j) {
                     const int ow = ow0 + j;
-                    if (ow < W) {
+                    if (ow < w1) {
                         // newest column ow + P enters slot (j + K - 1) % K
                         const int iw = ow + P;
 #pragma unroll
@@ -253,9 +256,13 @@ int launch_strip(const void* x, int ldx, const void* w, const void* bias, const 
 #define TC_STRIP(KK, CPT)                                                                                                       \
     {                                                                                                                           \
         constexpr int RI = 256 / (64 / CPT);                                                                                    \
-        dim3 grid(tc_blocks(nrows, RI, MODE == 2 ? 512 : 4096), (C + 63) / 64);                                                  \
+        /* split rows into W-segments until ~64k threads exist (small maps are otherwise a handful of long serial walks) */  \
+        int nseg = (int)(65536LL / ((long long)nrows * ((C + CPT - 1) / CPT)));                                                 \
+        const int maxseg = W / (KK + 4) > 0 ? W / (KK + 4) : 1;                                                                 \
+        nseg = nseg < 1 ? 1 : (nseg > maxseg ? maxseg : nseg);                                                                  \
+        dim3 grid(tc_blocks((long long)nrows * nseg, RI, MODE == 2 ? 512 : 4096), (C + 63) / 64);                                \
         hipLaunchKernelGGL((dw_strip_kernel<T, KK, CPT, MODE>), grid, dim3(256), 0, s, (const T*)x, ldx, (const T*)w, (const T*)bias, \
-                           (const T*)dy, lddy, (T*)y, ldy, dw, db, B, H, W, C, add_input, accumulate);                          \
+                           (const T*)dy, lddy, (T*)y, ldy, dw, db, B, H, W, C, add_input, accumulate, nseg);                    \
     }
     if (k == 3) TC_STRIP(3, 4) else if (k == 5) TC_STRIP(5, 2) else TC_STRIP(7, 2)
 #undef TC_STRIP

@@ -5,80 +5,98 @@
 
 namespace {
 
-constexpr int LN_MAXV = 8;   // vec4 per lane -> C <= 2048
+constexpr int LN_MAXC = 2048;
 
 // ---------------------------------------------------------------------------------------------- LayerNorm
-template <typename T>
+// A group of GS lanes (16 / 32 / 64) owns one row, each lane NV float4s of it; a 256-thread block therefore works on
+// 256/GS rows at a time (C = 64 rows use 16 lanes: 4 rows per wave instead of 48 idle lanes).  Statistics by xor-shuffles
+// inside the group.  The backward keeps per-lane partial dgamma/dbeta over a grid-stride loop of rows, folds the groups
+// of a block through LDS and issues one atomic per channel per block (grid capped so the atomics do not serialise).
+template <int GS> __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = GS / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <typename T, int GS, int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ gamma,
                                                      const T* __restrict__ beta, T* __restrict__ y, int ldy,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int rows,
                                                      int C, float eps, int act) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    constexpr int RPB = 256 / GS;
+    const int gl = threadIdx.x % GS, gi = threadIdx.x / GS;
     const int nv = C >> 2;
-    const T* xr = x + (long long)row * ldx;
-    float4 v[LN_MAXV];
-    float s = 0.f;
+    const float invC = 1.0f / (float)C;
+    float4 g[NV], b[NV];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int q = lane + i * 64;
-        if (q < nv) { v[i] = ld4<T>(xr + q * 4); s += v[i].x + v[i].y + v[i].z + v[i].w; }
+    for (int i = 0; i < NV; ++i) {
+        const int q = gl + i * GS;
+        if (q < nv) { g[i] = ld4<T>(gamma + q * 4); b[i] = ld4<T>(beta + q * 4); }
     }
-    const float mu = wave_sum(s) / (float)C;
-    float s2 = 0.f;
+    for (int row = blockIdx.x * RPB + gi; row < rows; row += gridDim.x * RPB) {
+        const T* xr = x + (long long)row * ldx;
+        float4 v[NV];
+        float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int q = lane + i * 64;
-        if (q < nv) {
-            const float a = v[i].x - mu, b = v[i].y - mu, c = v[i].z - mu, d = v[i].w - mu;
-            s2 += a * a + b * b + c * c + d * d;
+        for (int i = 0; i < NV; ++i) {
+            const int q = gl + i * GS;
+            if (q < nv) { v[i] = ld4<T>(xr + q * 4); s += v[i].x + v[i].y + v[i].z + v[i].w; }
         }
-    }
-    const float rs = rsqrtf(wave_sum(s2) / (float)C + eps);
-    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
-    T* yr = y + (long long)row * ldy;
+        const float mu = group_sum<GS>(s) * invC;
+        float s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int q = lane + i * 64;
-        if (q < nv) {
-            const float4 g = ld4<T>(gamma + q * 4), b = ld4<T>(beta + q * 4);
-            float4 o;
-            o.x = (v[i].x - mu) * rs * g.x + b.x; o.y = (v[i].y - mu) * rs * g.y + b.y;
-            o.z = (v[i].z - mu) * rs * g.z + b.z; o.w = (v[i].w - mu) * rs * g.w + b.w;
-            if (act == TC_ACT_GELU) { o.x = gelu_f(o.x); o.y = gelu_f(o.y); o.z = gelu_f(o.z); o.w = gelu_f(o.w); }
-            st4<T>(yr + q * 4, o);
+        for (int i = 0; i < NV; ++i) {
+            const int q = gl + i * GS;
+            if (q < nv) {
+                const float a = v[i].x - mu, bb = v[i].y - mu, c = v[i].z - mu, d = v[i].w - mu;
+                s2 += a * a + bb * bb + c * c + d * d;
+            }
+        }
+        const float rs = rsqrtf(group_sum<GS>(s2) * invC + eps);
+        if (gl == 0) { mean[row] = mu; rstd[row] = rs; }
+        T* yr = y + (long long)row * ldy;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int q = gl + i * GS;
+            if (q < nv) {
+                float4 o;
+                o.x = (v[i].x - mu) * rs * g[i].x + b[i].x; o.y = (v[i].y - mu) * rs * g[i].y + b[i].y;
+                o.z = (v[i].z - mu) * rs * g[i].z + b[i].z; o.w = (v[i].w - mu) * rs * g[i].w + b[i].w;
+                if (act == TC_ACT_GELU) { o.x = gelu_f(o.x); o.y = gelu_f(o.y); o.z = gelu_f(o.z); o.w = gelu_f(o.w); }
+                st4<T>(yr + q * 4, o);
+            }
         }
     }
 }
 
-template <typename T>
+template <typename T, int GS, int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ x, int ldx,
                                                      const T* __restrict__ gamma, const T* __restrict__ beta,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      T* __restrict__ dx, int lddx, const T* __restrict__ dres, int ldres,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int C,
                                                      int act) {
-    extern __shared__ float red[];           // [4 waves][2][C]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int RPB = 256 / GS;
+    extern __shared__ float red[];           // [RPB][2][C]
+    const int gl = threadIdx.x % GS, gi = threadIdx.x / GS;
     const int nv = C >> 2;
-    float4 g[LN_MAXV], b[LN_MAXV], ag[LN_MAXV], ab[LN_MAXV];
+    float4 g[NV], b[NV], ag[NV], ab[NV];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int q = lane + i * 64;
+    for (int i = 0; i < NV; ++i) {
+        const int q = gl + i * GS;
         ag[i] = ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (q < nv) { g[i] = ld4<T>(gamma + q * 4); b[i] = ld4<T>(beta + q * 4); }
     }
     const float invC = 1.0f / (float)C;
-    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    for (int row = blockIdx.x * RPB + gi; row < rows; row += gridDim.x * RPB) {
         const float mu = mean[row], rs = rstd[row];
         const T* xr = x + (long long)row * ldx;
         const T* dyr = dy + (long long)row * lddy;
-        float4 xh[LN_MAXV], gg[LN_MAXV];
+        float4 xh[NV], gg[NV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) {
-            const int q = lane + i * 64;
+        for (int i = 0; i < NV; ++i) {
+            const int q = gl + i * GS;
             if (q < nv) {
                 float4 xv = ld4<T>(xr + q * 4), d = ld4<T>(dyr + q * 4);
                 xv.x = (xv.x - mu) * rs; xv.y = (xv.y - mu) * rs; xv.z = (xv.z - mu) * rs; xv.w = (xv.w - mu) * rs;
@@ -94,11 +112,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
                 xh[i] = xv; gg[i] = d;
             }
         }
-        s1 = wave_sum(s1) * invC; s2 = wave_sum(s2) * invC;
+        s1 = group_sum<GS>(s1) * invC; s2 = group_sum<GS>(s2) * invC;
         T* dxr = dx + (long long)row * lddx;
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) {
-            const int q = lane + i * 64;
+        for (int i = 0; i < NV; ++i) {
+            const int q = gl + i * GS;
             if (q < nv) {
                 float4 o;
                 o.x = rs * (gg[i].x - s1 - xh[i].x * s2); o.y = rs * (gg[i].y - s1 - xh[i].y * s2);
@@ -109,12 +127,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
             }
         }
     }
-    // cross-wave reduction of the per-lane dgamma/dbeta partials, then one atomic per channel per block
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int q = lane + i * 64;
+    for (int i = 0; i < NV; ++i) {
+        const int q = gl + i * GS;
         if (q < nv) {
-            float* r0 = red + (wave * 2 + 0) * C + q * 4; float* r1 = red + (wave * 2 + 1) * C + q * 4;
+            float* r0 = red + (gi * 2 + 0) * C + q * 4; float* r1 = red + (gi * 2 + 1) * C + q * 4;
             r0[0] = ag[i].x; r0[1] = ag[i].y; r0[2] = ag[i].z; r0[3] = ag[i].w;
             r1[0] = ab[i].x; r1[1] = ab[i].y; r1[2] = ab[i].z; r1[3] = ab[i].w;
         }
@@ -123,11 +140,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
     for (int c = threadIdx.x; c < C; c += 256) {
         float a = 0.f, bb = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) { a += red[(w * 2 + 0) * C + c]; bb += red[(w * 2 + 1) * C + c]; }
+        for (int w = 0; w < RPB; ++w) { a += red[(w * 2 + 0) * C + c]; bb += red[(w * 2 + 1) * C + c]; }
         atomicAdd(dgamma + c, a);
         atomicAdd(dbeta + c, bb);
     }
 }
+
+// (GS, NV) by row width: quads = C/4
+#define TC_LN_DISPATCH(quads, CALL)                                     \
+    if ((quads) <= 16) { CALL(16, 1); }                                 \
+    else if ((quads) <= 32) { CALL(32, 1); }                            \
+    else if ((quads) <= 64) { CALL(64, 1); }                            \
+    else if ((quads) <= 128) { CALL(64, 2); }                           \
+    else if ((quads) <= 256) { CALL(64, 4); }                           \
+    else if ((quads) <= 320) { CALL(64, 5); }                           \
+    else { CALL(64, 8); }
 
 // ---------------------------------------------------------------------------------------------- BatchNorm
 // scratch layout: shift[C] | S1[nchunk][C] | S2[nchunk][C]
@@ -263,12 +290,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 
 extern "C" int tc_layernorm_fwd(const void* x, int ldx, const void* gamma, const void* beta, void* y, int ldy,
                                 float* mean, float* rstd, int rows, int C, float eps, int act, int dtype, void* stream) {
-    if (!x || !y || !gamma || !beta || !mean || !rstd || rows <= 0 || C <= 0 || (C & 3) || C > 256 * LN_MAXV ||
+    if (!x || !y || !gamma || !beta || !mean || !rstd || rows <= 0 || C <= 0 || (C & 3) || C > LN_MAXC ||
         (ldx & 3) || (ldy & 3) || (act != TC_ACT_NONE && act != TC_ACT_GELU))
         return TC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ln_fwd_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, (const T*)x, ldx,
-                                                (const T*)gamma, (const T*)beta, (T*)y, ldy, mean, rstd, rows, C, eps, act));
+    const int quads = C >> 2;
+#define TC_LNF(GS, NV) hipLaunchKernelGGL((ln_fwd_kernel<T, GS, NV>), dim3(tc_blocks(rows, 256 / GS, 2048)), dim3(256), 0, s, (const T*)x, \
+                                          ldx, (const T*)gamma, (const T*)beta, (T*)y, ldy, mean, rstd, rows, C, eps, act)
+    TC_DISPATCH_DTYPE(dtype, { TC_LN_DISPATCH(quads, TC_LNF) });
+#undef TC_LNF
     return tc_launch_status();
 }
 
@@ -276,14 +306,16 @@ extern "C" int tc_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx
                                 const float* mean, const float* rstd, void* dx, int lddx, const void* dres, int ldres,
                                 float* dgamma, float* dbeta, int rows, int C, int act, int dtype, void* stream) {
     if (!dy || !x || !gamma || !beta || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0 || C <= 0 || (C & 3) ||
-        C > 256 * LN_MAXV || (ldx & 3) || (lddy & 3) || (lddx & 3) || (dres && (ldres & 3)))
+        C > LN_MAXC || (ldx & 3) || (lddy & 3) || (lddx & 3) || (dres && (ldres & 3)))
         return TC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    const int grid = tc_blocks(rows, 16, 1024);
-    const size_t shm = (size_t)8 * C * sizeof(float);
-    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T>), dim3(grid), dim3(256), shm, s, (const T*)dy, lddy,
-                                                (const T*)x, ldx, (const T*)gamma, (const T*)beta, mean, rstd, (T*)dx, lddx,
-                                                (const T*)dres, ldres, dgamma, dbeta, rows, C, act));
+    const int quads = C >> 2;
+#define TC_LNB(GS, NV) hipLaunchKernelGGL((ln_bwd_kernel<T, GS, NV>), dim3(tc_blocks(rows, (256 / GS) * 4, 256)), dim3(256),            \
+                                          (size_t)(256 / GS) * 2 * C * sizeof(float), s, (const T*)dy, lddy, (const T*)x, ldx,            \
+                                          (const T*)gamma, (const T*)beta, mean, rstd, (T*)dx, lddx, (const T*)dres, ldres, dgamma,      \
+                                          dbeta, rows, C, act)
+    TC_DISPATCH_DTYPE(dtype, { TC_LN_DISPATCH(quads, TC_LNB) });
+#undef TC_LNB
     return tc_launch_status();
 }
 

@@ -117,7 +117,68 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
+_SIDE_STREAMS: Dict[str, list] = {}
+
+
+def _side_streams(device, n: int):
+    key = str(device)
+    pool = _SIDE_STREAMS.setdefault(key, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device))
+    return pool[:n]
+
+
+class _Branch:
+    def __init__(self, G, stream):
+        self.G, self.stream, self.ctx, self.prev = G, stream, None, None
+
+    def __enter__(self):
+        G = self.G
+        self.prev = (G.cur, G.stream)
+        G.cur, G.stream = self.stream, self.stream.cuda_stream
+        self.ctx = torch.cuda.stream(self.stream)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        self.ctx.__exit__(*a)
+        self.G.cur, self.G.stream = self.prev
+
+
+class _Parallel:
+    """Fork/join of independent sub-graphs over HIP streams (branch 0 stays on the main stream).  In a captured hipGraph the
+    branches become parallel node chains; the tape replays them in reverse with the fork and join swapped."""
+
+    def __init__(self, G, n: int):
+        self.G, self.n = G, n
+        self.sides = _side_streams(G.dev, n - 1) if (n > 1 and G.use_streams and torch.device(G.dev).type == "cuda") else []
+
+    def __enter__(self):
+        G = self.G
+        for s in self.sides:
+            s.wait_stream(G.cur)
+        if G.record and self.sides:
+            G.tape.append(("join", G.cur, self.sides))          # backward: main waits for the branches
+        return self
+
+    def branch(self, i: int):
+        G = self.G
+        return _Branch(G, self.sides[i - 1] if (i > 0 and self.sides) else G.cur)
+
+    def __exit__(self, *a):
+        G = self.G
+        for s in self.sides:
+            G.cur.wait_stream(s)
+        if G.record and self.sides:
+            G.tape.append(("fork", G.cur, self.sides))          # backward: the branches wait for main
+
+
 class Graph:
+    use_streams = True
+
+    def parallel(self, n: int) -> _Parallel:
+        return _Parallel(self, n)
+
     def __init__(self, dtype: torch.dtype, device, training: bool, record: bool):
         self.L = lib()
         self.dtype = dtype
@@ -126,7 +187,8 @@ class Graph:
         self.training = training
         self.record = record
         self.tape: List[Callable[[], None]] = []
-        self.stream = torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0
+        self.cur = torch.cuda.current_stream(device) if torch.device(device).type == "cuda" else None
+        self.stream = self.cur.cuda_stream if self.cur is not None else 0
         self.n_launch = 0
 
     # ------------------------------------------------------------------ memory
@@ -205,13 +267,27 @@ class Graph:
                           self.dt, self.stream)
 
     def backward(self):
-        for fn in reversed(self.tape):
-            fn()
+        main = (self.cur, self.stream)
+        for entry in reversed(self.tape):
+            if entry[0] == "join":                       # forward fork point: everything the branches produced flows back to main
+                for s in entry[2]:
+                    entry[1].wait_stream(s)
+            elif entry[0] == "fork":                     # forward join point: branch backward starts after main's upstream work
+                for s in entry[2]:
+                    s.wait_stream(entry[1])
+            else:
+                fn, st = entry
+                if st is None or st is self.cur:
+                    fn()
+                else:
+                    with _Branch(self, st):
+                        fn()
+        self.cur, self.stream = main
         self.tape = []
 
     def _rec(self, fn):
         if self.record:
-            self.tape.append(fn)
+            self.tape.append((fn, self.cur))
 
     # ------------------------------------------------------------------ GEMM plumbing
     def _gemm(self, A, lda, B, ldb, Cm, ldc, M, N, K, tA, tB, bias=None, R=None, ldr=0, alpha=1.0, acc=0, act=ACT_NONE,

@@ -521,12 +521,15 @@ def _mhca_stage(M, G, maps: List[Var], name: str, layers: int, B: int, side: int
     """MHCA_stage, MSTr.py:1412-1441: the four branch outputs are written into one [rows, 4C] buffer (no cat)."""
     C = maps[0].cols
     cat = G.new(B * side * side, 4 * C)
-    _resblock(M, G, maps[0], name + ".InvRes", B, side, cat.colslice(0, C))
-    for p in range(3):
-        t, enc = maps[p], f"{name}.mhca_blks.{p}"
-        for l in range(layers):
-            t = _mhca_block(M, G, t, f"{enc}.MHCA_layers.{l}", enc, B, side,
-                            cat.colslice((p + 1) * C, (p + 2) * C) if l == layers - 1 else None)
+    with G.parallel(3) as par:                      # the three MB paths (+ InvRes) are independent: one HIP stream each
+        for p in range(3):
+            with par.branch(p):
+                if p == 0:
+                    _resblock(M, G, maps[0], name + ".InvRes", B, side, cat.colslice(0, C))
+                t, enc = maps[p], f"{name}.mhca_blks.{p}"
+                for l in range(layers):
+                    t = _mhca_block(M, G, t, f"{enc}.MHCA_layers.{l}", enc, B, side,
+                                    cat.colslice((p + 1) * C, (p + 2) * C) if l == layers - 1 else None)
     return _coord_att(M, G, cat, name + ".aggregate", B, side, out)
 
 
@@ -600,10 +603,12 @@ def _bridge_layer(M, G, X: Var, li: int, B: int, sides, ntok, R, N6) -> Var:
         tx1 = _self_att(M, G, n, X, name + ".attn", B, sides, ntok, R, N6)
     tx = _ln(M, G, tx1, name + ".norm2")
     tx2 = G.new(B * N6, 64)
-    for s in range(4):
-        rows, width = B * sides[s] * sides[s], 64 * MULT[s]
-        view = lambda v: v.rowslice(R[s], R[s + 1]).reshape(rows, width)
-        _mixffn(M, G, view(tx), f"{name}.mixffn{s + 1}", B, sides[s], sides[s], residual=view(tx1), out=view(tx2))
+    with G.parallel(4) as par:                      # the four per-scale MixFFNs are independent
+        for s in range(4):
+            with par.branch(s):
+                rows, width = B * sides[s] * sides[s], 64 * MULT[s]
+                view = lambda v: v.rowslice(R[s], R[s + 1]).reshape(rows, width)
+                _mixffn(M, G, view(tx), f"{name}.mixffn{s + 1}", B, sides[s], sides[s], residual=view(tx1), out=view(tx2))
     return tx2
 
 
