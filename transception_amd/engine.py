@@ -13,6 +13,7 @@ torch is used for device memory (torch.empty) and streams only.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
@@ -149,8 +150,9 @@ class _Parallel:
     """Fork/join of independent sub-graphs over HIP streams (branch 0 stays on the main stream).  In a captured hipGraph the
     branches become parallel node chains; the tape replays them in reverse with the fork and join swapped."""
 
-    def __init__(self, G, n: int):
+    def __init__(self, G, n: int, shared=()):
         self.G, self.n = G, n
+        self.shared = [v.root for v in shared]      # buffers several branches write gradient slices of
         self.sides = _side_streams(G.dev, n - 1) if (n > 1 and G.use_streams and torch.device(G.dev).type == "cuda") else []
 
     def __enter__(self):
@@ -170,14 +172,14 @@ class _Parallel:
         for s in self.sides:
             G.cur.wait_stream(s)
         if G.record and self.sides:
-            G.tape.append(("fork", G.cur, self.sides))          # backward: the branches wait for main
+            G.tape.append(("fork", G.cur, self.sides, self.shared))   # backward: the branches wait for main
 
 
 class Graph:
-    use_streams = True
+    use_streams = os.environ.get("TC_NO_STREAMS", "0") != "1"
 
-    def parallel(self, n: int) -> _Parallel:
-        return _Parallel(self, n)
+    def parallel(self, n: int, shared=()) -> _Parallel:
+        return _Parallel(self, n, shared)
 
     def __init__(self, dtype: torch.dtype, device, training: bool, record: bool):
         self.L = lib()
@@ -273,6 +275,9 @@ class Graph:
                 for s in entry[2]:
                     entry[1].wait_stream(s)
             elif entry[0] == "fork":                     # forward join point: branch backward starts after main's upstream work
+                for r in entry[3]:                       # gradient buffers shared by the branches are created (zeroed) on main
+                    if r.grad_t is None:                 # first, so no branch's lazy zero-fill can race another branch's write
+                        r.grad_t = torch.zeros_like(r.data)
                 for s in entry[2]:
                     s.wait_stream(entry[1])
             else:

@@ -603,7 +603,7 @@ def _bridge_layer(M, G, X: Var, li: int, B: int, sides, ntok, R, N6) -> Var:
         tx1 = _self_att(M, G, n, X, name + ".attn", B, sides, ntok, R, N6)
     tx = _ln(M, G, tx1, name + ".norm2")
     tx2 = G.new(B * N6, 64)
-    with G.parallel(4) as par:                      # the four per-scale MixFFNs are independent
+    with G.parallel(4, shared=(tx, tx1)) as par:    # the four per-scale MixFFNs are independent
         for s in range(4):
             with par.branch(s):
                 rows, width = B * sides[s] * sides[s], 64 * MULT[s]
