@@ -150,6 +150,17 @@ int tc_attn_bwd(const void* Q, int ldq, long long sq, const void* K, int ldk, co
                 void* dV, int lddv, long long sdkv, int accumulate_dkv, int B, int Nq, int Nk, float scale,
                 int dtype, void* stream);
 
+/* Segmented form used by the bridge: Q / O / dO / dQ / lse are stage-major row blocks -- segment i holds B images of
+ * nq[i] queries back to back, segments follow each other -- while K/V stay image-major (batch stride skv).  ONE launch
+ * covers all segments (bf16); fp32 storage runs the per-segment kernels above.  nq is a HOST array of nseg (<= 4) ints.
+ * Replaces the same reference lines (MSTr.py:2281-2287) for all 6076 query tokens of every image at once. */
+int tc_attn_fwd_seg(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, long long skv, void* O, int ldo,
+                    float* lse, int B, int nseg, const int* nq, int Nk, float scale, int dtype, void* stream);
+int tc_attn_bwd_seg(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, long long skv, const void* O,
+                    int ldo, const void* dO, int lddo, const float* lse, float* delta, void* dQ, int lddq, void* dK,
+                    int lddk, void* dV, int lddv, long long sdkv, int B, int nseg, const int* nq, int Nk, float scale,
+                    int dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Elementwise / layout kernels.
  */

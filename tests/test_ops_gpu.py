@@ -450,3 +450,37 @@ def test_dwconv_layernorm_bf16(Gb):
     closeb(Gb.grad_of(xv).view(x.shape), xr.grad, what="dw dx")
     closeb(wp.grad, wr.grad, what="dw dw")
     closeb(bp.grad, br.grad, what="dw db")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attention_segmented(dtype):
+    """Stage-major queries (segments of B images each) against image-major K/V: one launch on the bf16 path."""
+    from transception_amd.engine import Graph
+    B, d, Nk, nq = 2, 64, 210, [150, 64, 33]
+    rows = B * sum(nq)
+    cast = (lambda t: t) if dtype == torch.float32 else _bf
+    q, kv, gy = cast(T("as.q", (rows, d))), cast(T("as.kv", (B * Nk, 2 * d))), cast(T("as.g", (rows, d)))
+    qr, kvr = q.float().requires_grad_(), kv.float().requires_grad_()
+    k, v = kvr[:, :d].reshape(B, Nk, d), kvr[:, d:].reshape(B, Nk, d)
+    outs, r0 = [], 0
+    for n in nq:
+        qs = qr[r0:r0 + B * n].view(B, n, d)
+        outs.append((torch.softmax(qs @ k.transpose(1, 2) * 0.125, -1) @ v).reshape(B * n, d))
+        r0 += B * n
+    y = torch.cat(outs, 0)
+    y.backward(gy.float())
+    Gx = Graph(dtype, torch.device(DEV), True, True)
+    qv, kvv = mkV(Gx, q), mkV(Gx, kv)
+    out = Gx.attention_seg(qv, kvv.colslice(0, d), kvv.colslice(d, 2 * d), B, nq, Nk, 0.125)
+    tol = 2e-5 if dtype == torch.float32 else None
+    if tol:
+        close(out.data, y, 2e-5, 2e-5, "seg attention")
+    else:
+        closeb(out.data, y, 2e-2, "seg attention bf16")
+    run_bwd(Gx, out, gy)
+    if tol:
+        close(Gx.grad_of(qv), qr.grad, 5e-5, 5e-5, "dq")
+        close(Gx.grad_of(kvv), kvr.grad, 5e-5, 5e-5, "dkv")
+    else:
+        closeb(Gx.grad_of(qv), qr.grad, 3e-2, "dq bf16")
+        closeb(Gx.grad_of(kvv), kvr.grad, 3e-2, "dkv bf16")

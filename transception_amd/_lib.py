@@ -46,6 +46,9 @@ SIGNATURES = {
     "tc_attn_fwd": [vp, i32, i64, vp, i32, vp, i32, i64, vp, i32, i64, vp, i32, i32, i32, f32, i32, vp],
     "tc_attn_bwd": [vp, i32, i64, vp, i32, vp, i32, i64, vp, i32, i64, vp, i32, i64, vp, vp, vp, i32, i64, vp, i32,
                     vp, i32, i64, i32, i32, i32, i32, f32, i32, vp],
+    "tc_attn_fwd_seg": [vp, i32, vp, i32, vp, i32, i64, vp, i32, vp, i32, i32, C.POINTER(i32), i32, f32, i32, vp],
+    "tc_attn_bwd_seg": [vp, i32, vp, i32, vp, i32, i64, vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, vp, i32, i64, i32, i32,
+                        C.POINTER(i32), i32, f32, i32, vp],
     "tc_fma3_fwd": [vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, f32, i32, vp],
     "tc_fma3_bwd": [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, vp, i32, i32, i32, f32, i32, vp],
     "tc_add": [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp],

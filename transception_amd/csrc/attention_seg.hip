@@ -1,0 +1,458 @@
+// Segmented single-launch bf16 attention for the Dual Transformer Bridge.
+//
+// The bridge's 6076 query tokens per image live in a stage-major buffer (four row segments, one per encoder scale, each
+// holding B images back to back), while the 784 reduced K/V tokens are image-major.  One launch covers every
+// (segment, image, 128-query tile): ~800 workgroups instead of four launches of 50-400, so the chip is filled and the
+// launch boundary is paid once.  Versus attention.hip's first bf16 kernels this version also
+//   * prefetches the next 128-key K/V fill into registers while the current one is being consumed,
+//   * folds the softmax scale into the exp2 argument (one FMA per score), masks keys only in the tail tile,
+//   * rescales the running output lazily (only when some row maximum grew by more than 2^8),
+//   * allows two workgroups per CU (launch bounds) so one wave's softmax VALU overlaps another's MFMA.
+// fp32 storage falls back to the per-segment fp32 kernels of attention.hip (parity path).
+#include "tc_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int D = 64, KB = 128, LDR = D + 8, LDTB = KB + 8;
+#define LOG2E 1.4426950408889634f
+#define LN2 0.6931471805599453f
+#define NEG_BIG (-1.0e30f)
+#define RESCALE_THR 8.0f
+
+struct Segs {
+    int n;
+    int nq[4];        // queries per image in the segment
+    int row0[4];      // first row of the segment in the stage-major buffers
+    int tile0[5];     // prefix sums of B * ceil(nq/128)   (forward / dQ tiling)
+    int t32[5];       // prefix sums of ceil(nq/32)        (dK/dV per-image query tiles)
+};
+
+__device__ __forceinline__ int pi_row(int i) { return 16 * ((i >> 2) & 1) + (i & 3) + 4 * (i >> 3); }
+__device__ __forceinline__ int d_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+__device__ __forceinline__ bf16x8 ld_frag(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ bf16x8 pack8(const f32x16& v, int o) {
+    bf16x8 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = (__bf16)v[o + i];
+    return r;
+}
+__device__ __forceinline__ uint4 ld_row8(const bf16_t* base, int ld, int row, int nrows, int c8) {
+    return row < nrows ? *reinterpret_cast<const uint4*>(base + (long long)row * ld + c8) : make_uint4(0u, 0u, 0u, 0u);
+}
+__device__ __forceinline__ void st_t8(bf16_t* dst, int ldt, int c8, int col, uint4 v) {
+    union { uint4 v; bf16_t e[8]; } u;
+    u.v = v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dst[(c8 + i) * ldt + col] = u.e[i];
+}
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// block -> (segment, image, first query row of the tile, queries valid in the tile's segment-image)
+__device__ __forceinline__ void locate_tile(const Segs& sg, int t, int& row_base, int& q_local0, int& nq, int& b) {
+    int s = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) if (i < sg.n && t >= sg.tile0[i]) s = i;
+    const int local = t - sg.tile0[s];
+    nq = sg.nq[s];
+    const int tiles = (nq + 127) >> 7;
+    b = local / tiles;
+    q_local0 = (local - b * tiles) * 128;
+    row_base = sg.row0[s] + b * nq;
+}
+
+__global__ __launch_bounds__(256, 2) void attn_fwd_seg_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
+                                                              const bf16_t* __restrict__ V, int ldv, long long skv, bf16_t* __restrict__ O,
+                                                              int ldo, float* __restrict__ lse, Segs sg, int Nk, float scale) {
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[KB * LDR];
+    __shared__ __attribute__((aligned(16))) bf16_t Vt[D * LDTB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    int row_base, q0, nq, b;
+    locate_tile(sg, blockIdx.x, row_base, q0, nq, b);
+    const int ql = q0 + wave * 32 + j;                     // query index inside this (segment, image)
+    const bool ok = ql < nq;
+    const long long qrow = (long long)row_base + ql;
+    const bf16_t* Kb = K + b * skv;
+    const bf16_t* Vb = V + b * skv;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const uint4 v = ok ? *reinterpret_cast<const uint4*>(Q + qrow * ldq + 16 * ks + 8 * h) : make_uint4(0u, 0u, 0u, 0u);
+        qf[ks] = *reinterpret_cast<const bf16x8*>(&v);
+    }
+    const float qs = scale * LOG2E;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    float m = NEG_BIG, lsum = 0.f;
+    const int krow = pi_row(j);
+    uint4 kr[4], vr[4];
+    auto fetch = [&](int kb0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = tid + i * 256, r = f >> 3, c8 = (f & 7) * 8;
+            kr[i] = ld_row8(Kb, ldk, kb0 + r, Nk, c8);
+            vr[i] = ld_row8(Vb, ldv, kb0 + r, Nk, c8);
+        }
+    };
+    fetch(0);
+    for (int kb0 = 0; kb0 < Nk; kb0 += KB) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = tid + i * 256, r = f >> 3, c8 = (f & 7) * 8;
+            *reinterpret_cast<uint4*>(&Ks[r * LDR + c8]) = kr[i];
+            st_t8(Vt, LDTB, c8, r, vr[i]);
+        }
+        __syncthreads();
+        if (kb0 + KB < Nk) fetch(kb0 + KB);
+#pragma unroll 1
+        for (int sub = 0; sub < KB / 32; ++sub) {
+            const int kv0 = kb0 + 32 * sub;
+            if (kv0 >= Nk) break;
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            const bf16_t* kp = Ks + (32 * sub + krow) * LDR + 8 * h;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(kp + 16 * ks), qf[ks], s, 0, 0, 0);
+            const bool tail = kv0 + 32 > Nk;                    // wave-uniform
+            if (tail) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) if (kv0 + 16 * h + r >= Nk) s[r] = NEG_BIG;
+            }
+            float mx = s[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * qs;        // scaled maximum of this tile
+            if (__any(mx > m + RESCALE_THR)) {                  // lazy rescale: rare once the running maximum has settled
+                const float mn = fmaxf(m, mx);
+                const float alpha = fast_exp2(m - mn);
+                lsum *= alpha;
+                m = mn;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc0[r] *= alpha; acc1[r] *= alpha; }
+            }
+            float rs = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = fast_exp2(fmaf(s[r], qs, -m)); rs += s[r]; }
+            rs += __shfl_xor(rs, 32, 64);
+            lsum += rs;
+            const bf16_t* vp = Vt + j * LDTB + 32 * sub + 16 * h;
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const bf16x8 pb = pack8(s, 8 * k2);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(vp + 8 * k2), pb, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(vp + 32 * LDTB + 8 * k2), pb, acc1, 0, 0, 0);
+            }
+        }
+    }
+    if (ok) {
+        const float inv = 1.0f / lsum;
+        bf16_t* orow = O + qrow * ldo;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            st4<bf16_t>(orow + 8 * g + 4 * h, make_float4(acc0[4 * g] * inv, acc0[4 * g + 1] * inv, acc0[4 * g + 2] * inv, acc0[4 * g + 3] * inv));
+            st4<bf16_t>(orow + 32 + 8 * g + 4 * h, make_float4(acc1[4 * g] * inv, acc1[4 * g + 1] * inv, acc1[4 * g + 2] * inv, acc1[4 * g + 3] * inv));
+        }
+        if (h == 0) lse[qrow] = (m + log2f(lsum)) * LN2;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_seg_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
+                                                                 const bf16_t* __restrict__ V, int ldv, long long skv,
+                                                                 const bf16_t* __restrict__ dO, int lddo, const float* __restrict__ lse,
+                                                                 const float* __restrict__ delta, bf16_t* __restrict__ dQ, int lddq, Segs sg,
+                                                                 int Nk, float scale) {
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[KB * LDR];
+    __shared__ __attribute__((aligned(16))) bf16_t Vs[KB * LDR];
+    __shared__ __attribute__((aligned(16))) bf16_t Kt[D * LDTB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    int row_base, q0, nq, b;
+    locate_tile(sg, blockIdx.x, row_base, q0, nq, b);
+    const int ql = q0 + wave * 32 + j;
+    const bool ok = ql < nq;
+    const long long qrow = (long long)row_base + ql;
+    bf16x8 qf[4], dof[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const uint4 v = ok ? *reinterpret_cast<const uint4*>(Q + qrow * ldq + 16 * ks + 8 * h) : make_uint4(0u, 0u, 0u, 0u);
+        const uint4 g = ok ? *reinterpret_cast<const uint4*>(dO + qrow * lddo + 16 * ks + 8 * h) : make_uint4(0u, 0u, 0u, 0u);
+        qf[ks] = *reinterpret_cast<const bf16x8*>(&v);
+        dof[ks] = *reinterpret_cast<const bf16x8*>(&g);
+    }
+    const float qs = scale * LOG2E;
+    const float l2 = ok ? lse[qrow] * LOG2E : 0.f;
+    const float dl = ok ? delta[qrow] : 0.f;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    const int krow = pi_row(j);
+    const bf16_t* Kb = K + b * skv;
+    const bf16_t* Vb = V + b * skv;
+    uint4 kr[4], vr[4];
+    auto fetch = [&](int kb0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = tid + i * 256, r = f >> 3, c8 = (f & 7) * 8;
+            kr[i] = ld_row8(Kb, ldk, kb0 + r, Nk, c8);
+            vr[i] = ld_row8(Vb, ldv, kb0 + r, Nk, c8);
+        }
+    };
+    fetch(0);
+    for (int kb0 = 0; kb0 < Nk; kb0 += KB) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = tid + i * 256, r = f >> 3, c8 = (f & 7) * 8;
+            *reinterpret_cast<uint4*>(&Ks[r * LDR + c8]) = kr[i];
+            st_t8(Kt, LDTB, c8, r, kr[i]);
+            *reinterpret_cast<uint4*>(&Vs[r * LDR + c8]) = vr[i];
+        }
+        __syncthreads();
+        if (kb0 + KB < Nk) fetch(kb0 + KB);
+#pragma unroll 1
+        for (int sub = 0; sub < KB / 32; ++sub) {
+            const int kv0 = kb0 + 32 * sub;
+            if (kv0 >= Nk) break;
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+            const bf16_t* kp = Ks + (32 * sub + krow) * LDR + 8 * h;
+            const bf16_t* vp = Vs + (32 * sub + krow) * LDR + 8 * h;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(kp + 16 * ks), qf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(vp + 16 * ks), dof[ks], dp, 0, 0, 0);
+            }
+            const bool tail = kv0 + 32 > Nk;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float p = fast_exp2(fmaf(s[r], qs, -l2));
+                if (tail && kv0 + 16 * h + r >= Nk) p = 0.f;
+                s[r] = p * (dp[r] - dl) * scale;
+            }
+            const bf16_t* kt = Kt + j * LDTB + 32 * sub + 16 * h;
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const bf16x8 db = pack8(s, 8 * k2);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(kt + 8 * k2), db, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(kt + 32 * LDTB + 8 * k2), db, acc1, 0, 0, 0);
+            }
+        }
+    }
+    if (ok) {
+        bf16_t* row = dQ + qrow * lddq;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            st4<bf16_t>(row + 8 * g + 4 * h, make_float4(acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]));
+            st4<bf16_t>(row + 32 + 8 * g + 4 * h, make_float4(acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]));
+        }
+    }
+}
+
+// dK/dV: workgroup = (32-key tile, image); its 4 waves stride over ALL 32-query tiles of that image across the segments.
+__global__ __launch_bounds__(256) void attn_bwd_dkv_seg_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
+                                                               const bf16_t* __restrict__ V, int ldv, long long skv,
+                                                               const bf16_t* __restrict__ dO, int lddo, const float* __restrict__ lse,
+                                                               const float* __restrict__ delta, bf16_t* __restrict__ dK, int lddk,
+                                                               bf16_t* __restrict__ dV, int lddv, long long sdkv, Segs sg, int Nk, float scale) {
+    constexpr int LDQT = 32 + 8;
+    constexpr int PER_WAVE_B = (2 * 32 * LDR + 2 * D * LDQT) * 2 + 256;
+    constexpr int RED_B = 4 * 2 * 64 * 33 * 4;
+    constexpr int SMEM_B = (4 * PER_WAVE_B > RED_B) ? 4 * PER_WAVE_B : RED_B;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_B];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y, kv0 = blockIdx.x * 32;
+    bf16_t* Qs = reinterpret_cast<bf16_t*>(smem + wave * PER_WAVE_B);
+    bf16_t* dOs = Qs + 32 * LDR;
+    bf16_t* Qt = dOs + 32 * LDR;
+    bf16_t* dOt = Qt + D * LDQT;
+    float* lss = reinterpret_cast<float*>(dOt + D * LDQT);
+    float* dls = lss + 32;
+    const int key = kv0 + j;
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const uint4 a = ld_row8(K + b * skv, ldk, key, Nk, 16 * ks + 8 * h);
+        const uint4 c = ld_row8(V + b * skv, ldv, key, Nk, 16 * ks + 8 * h);
+        kf[ks] = *reinterpret_cast<const bf16x8*>(&a);
+        vf[ks] = *reinterpret_cast<const bf16x8*>(&c);
+    }
+    const float qs = scale * LOG2E;
+    f32x16 dk0, dk1, dv0, dv1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk0[r] = dk1[r] = dv0[r] = dv1[r] = 0.f; }
+    const int qrow = pi_row(j);
+    const int ntiles = sg.t32[sg.n];
+    uint4 qr[4], gr[4];
+    float lr = 0.f, dr = 0.f;
+    auto locate = [&](int t, long long& base, int& valid) {       // first row and number of valid rows of 32-query tile t
+        int s = 0;
+#pragma unroll
+        for (int i = 1; i < 4; ++i) if (i < sg.n && t >= sg.t32[i]) s = i;
+        const int q0 = (t - sg.t32[s]) * 32;
+        base = (long long)sg.row0[s] + (long long)b * sg.nq[s] + q0;
+        valid = min(32, sg.nq[s] - q0);
+    };
+    auto fetch = [&](int t) {
+        long long base; int valid;
+        locate(t, base, valid);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = lane + i * 64, r = f >> 3, c8 = (f & 7) * 8;
+            const bool okr = r < valid;
+            qr[i] = okr ? *reinterpret_cast<const uint4*>(Q + (base + r) * ldq + c8) : make_uint4(0u, 0u, 0u, 0u);
+            gr[i] = okr ? *reinterpret_cast<const uint4*>(dO + (base + r) * lddo + c8) : make_uint4(0u, 0u, 0u, 0u);
+        }
+        if (lane < 32) { const bool okr = lane < valid; lr = okr ? lse[base + lane] * LOG2E : 0.f; dr = okr ? delta[base + lane] : 0.f; }
+    };
+    if (wave < ntiles) fetch(wave);
+    for (int t = wave; t < ntiles; t += 4) {
+        long long base; int valid;
+        locate(t, base, valid);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = lane + i * 64, r = f >> 3, c8 = (f & 7) * 8;
+            *reinterpret_cast<uint4*>(&Qs[r * LDR + c8]) = qr[i];
+            *reinterpret_cast<uint4*>(&dOs[r * LDR + c8]) = gr[i];
+            st_t8(Qt, LDQT, c8, r, qr[i]);
+            st_t8(dOt, LDQT, c8, r, gr[i]);
+        }
+        if (lane < 32) { lss[lane] = lr; dls[lane] = dr; }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        if (t + 4 < ntiles) fetch(t + 4);
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+        const bf16_t* qp = Qs + qrow * LDR + 8 * h;
+        const bf16_t* gp = dOs + qrow * LDR + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(qp + 16 * ks), kf[ks], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(gp + 16 * ks), vf[ks], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qi = 16 * h + r;
+            const float p = (qi < valid) ? fast_exp2(fmaf(s[r], qs, -lss[qi])) : 0.f;
+            dp[r] = p * (dp[r] - dls[qi]) * scale;
+            s[r] = p;
+        }
+        const bf16_t* gt = dOt + j * LDQT + 16 * h;
+        const bf16_t* qt = Qt + j * LDQT + 16 * h;
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            const bf16x8 pb = pack8(s, 8 * k2), db = pack8(dp, 8 * k2);
+            dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(gt + 8 * k2), pb, dv0, 0, 0, 0);
+            dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(gt + 32 * LDQT + 8 * k2), pb, dv1, 0, 0, 0);
+            dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(qt + 8 * k2), db, dk0, 0, 0, 0);
+            dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(qt + 32 * LDQT + 8 * k2), db, dk1, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+    constexpr int RW = 2 * 64 * 33;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int d = d_row(r, h);
+        red[wave * RW + (d) * 33 + j] = dk0[r];
+        red[wave * RW + (32 + d) * 33 + j] = dk1[r];
+        red[wave * RW + 64 * 33 + (d) * 33 + j] = dv0[r];
+        red[wave * RW + 64 * 33 + (32 + d) * 33 + j] = dv1[r];
+    }
+    __syncthreads();
+    for (int f = tid; f < 2 * 32 * D; f += 256) {
+        const int which = f / (32 * D), kk = (f % (32 * D)) / D, d = f % D;
+        if (kv0 + kk >= Nk) continue;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) v += red[w * RW + which * 64 * 33 + d * 33 + kk];
+        bf16_t* dst = (which == 0 ? dK + b * sdkv + (long long)(kv0 + kk) * lddk : dV + b * sdkv + (long long)(kv0 + kk) * lddv) + d;
+        *dst = f2bf(v);
+    }
+}
+
+__global__ __launch_bounds__(256) void delta_rows_kernel(const bf16_t* __restrict__ O, int ldo, const bf16_t* __restrict__ dO, int lddo,
+                                                         float* __restrict__ delta, long long rows) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float s = wave_sum(bf2f(O[row * ldo + lane]) * bf2f(dO[row * lddo + lane]));
+    if (lane == 0) delta[row] = s;
+}
+
+bool make_segs(Segs& sg, int B, int nseg, const int* nq, long long& total_rows) {
+    if (nseg < 1 || nseg > 4) return false;
+    sg.n = nseg;
+    int row = 0;
+    sg.tile0[0] = 0;
+    sg.t32[0] = 0;
+    for (int i = 0; i < 4; ++i) {
+        const int n = i < nseg ? nq[i] : 0;
+        if (i < nseg && n <= 0) return false;
+        sg.nq[i] = n;
+        sg.row0[i] = row;
+        row += B * n;
+        sg.tile0[i + 1] = sg.tile0[i] + B * ((n + 127) / 128);
+        sg.t32[i + 1] = sg.t32[i] + (n + 31) / 32;
+    }
+    total_rows = row;
+    return true;
+}
+
+}  // namespace
+
+extern "C" int tc_attn_fwd_seg(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, long long skv, void* O, int ldo,
+                               float* lse, int B, int nseg, const int* nq, int Nk, float scale, int dtype, void* stream) {
+    Segs sg;
+    long long rows;
+    if (!Q || !K || !V || !O || !lse || !nq || B <= 0 || Nk <= 0 || !make_segs(sg, B, nseg, nq, rows)) return TC_ERR_ARG;
+    if (dtype == TC_F32) {                                      // parity path: one fp32 launch per segment
+        for (int i = 0; i < nseg; ++i) {
+            const long long off = sg.row0[i];
+            const int rc = tc_attn_fwd((const float*)Q + off * ldq, ldq, (long long)nq[i] * ldq, K, ldk, V, ldv, skv, (float*)O + off * ldo, ldo,
+                                       (long long)nq[i] * ldo, lse + off, B, nq[i], Nk, scale, dtype, stream);
+            if (rc != TC_OK) return rc;
+        }
+        return TC_OK;
+    }
+    if (dtype != TC_BF16 || ((ldq | ldk | ldv) & 7) || (skv & 7) || (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) || (ldo & 3)) return TC_ERR_ARG;
+    hipLaunchKernelGGL(attn_fwd_seg_kernel, dim3(sg.tile0[nseg]), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk,
+                       (const bf16_t*)V, ldv, skv, (bf16_t*)O, ldo, lse, sg, Nk, scale);
+    return tc_launch_status();
+}
+
+extern "C" int tc_attn_bwd_seg(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, long long skv, const void* O, int ldo,
+                               const void* dO, int lddo, const float* lse, float* delta, void* dQ, int lddq, void* dK, int lddk, void* dV,
+                               int lddv, long long sdkv, int B, int nseg, const int* nq, int Nk, float scale, int dtype, void* stream) {
+    Segs sg;
+    long long rows;
+    if (!Q || !K || !V || !O || !dO || !lse || !delta || !dQ || !dK || !dV || !nq || B <= 0 || Nk <= 0 || !make_segs(sg, B, nseg, nq, rows))
+        return TC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == TC_F32) {
+        for (int i = 0; i < nseg; ++i) {
+            const long long off = sg.row0[i];
+            const int rc = tc_attn_bwd((const float*)Q + off * ldq, ldq, (long long)nq[i] * ldq, K, ldk, V, ldv, skv, (const float*)O + off * ldo, ldo,
+                                       (long long)nq[i] * ldo, (const float*)dO + off * lddo, lddo, (long long)nq[i] * lddo, lse + off, delta + off,
+                                       (float*)dQ + off * lddq, lddq, (long long)nq[i] * lddq, dK, lddk, dV, lddv, sdkv, i > 0, B, nq[i], Nk,
+                                       scale, dtype, stream);
+            if (rc != TC_OK) return rc;
+        }
+        return TC_OK;
+    }
+    if (dtype != TC_BF16 || ((ldq | ldk | ldv | lddo) & 7) || (skv & 7) || (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)dO) & 15) ||
+        ((ldo | lddq) & 3))
+        return TC_ERR_ARG;
+    hipLaunchKernelGGL(delta_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const bf16_t*)O, ldo, (const bf16_t*)dO, lddo, delta, rows);
+    hipLaunchKernelGGL(attn_bwd_dkv_seg_kernel, dim3((Nk + 31) / 32, B), dim3(256), 0, s, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk,
+                       (const bf16_t*)V, ldv, skv, (const bf16_t*)dO, lddo, lse, delta, (bf16_t*)dK, lddk, (bf16_t*)dV, lddv, sdkv, sg, Nk, scale);
+    hipLaunchKernelGGL(attn_bwd_dq_seg_kernel, dim3(sg.tile0[nseg]), dim3(256), 0, s, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk, (const bf16_t*)V,
+                       ldv, skv, (const bf16_t*)dO, lddo, lse, delta, (bf16_t*)dQ, lddq, sg, Nk, scale);
+    return tc_launch_status();
+}

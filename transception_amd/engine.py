@@ -643,6 +643,38 @@ class Graph:
 
     use_fused_attention = False
 
+    def attention_seg(self, q: Var, k: Var, v: Var, B: int, nq: List[int], Nk: int, scale: float, out: Optional[Var] = None) -> Var:
+        """softmax(q k^T * scale) v where q / out are stage-major: segment i = B images x nq[i] query rows, K/V image-major.
+        One launch for all segments on the bf16 path."""
+        rows = B * sum(nq)
+        assert q.rows == rows and q.cols == 64 and q.data.is_contiguous()
+        if out is None:
+            out = self.new(rows, 64)
+        assert out.data.is_contiguous()
+        lse = self.f32(rows)
+        nq_c = (C.c_int * len(nq))(*nq)
+        flops = 4.0 * rows * Nk * 64
+        _timed("attn_fwd", flops, lambda: self.L.tc_attn_fwd_seg(
+            _ptr(q.data), q.ld, _ptr(k.data), k.ld, _ptr(v.data), v.ld, Nk * k.ld, _ptr(out.data), out.ld, _ptr(lse), B, len(nq),
+            nq_c, Nk, scale, self.dt, self.stream))
+
+        def bwd():
+            dO = self.grad_of(out)
+            if dO is None:
+                return
+            assert dO.is_contiguous()
+            gq, aq = self.wgrad(q)
+            gk, ak = self.wgrad(k)
+            gv, av = self.wgrad(v)
+            assert not (aq or ak or av), "attention_seg expects single-use q / k / v"
+            delta = self.f32(rows)
+            _timed("attn_bwd", 10.0 * rows * Nk * 64, lambda: self.L.tc_attn_bwd_seg(
+                _ptr(q.data), q.ld, _ptr(k.data), k.ld, _ptr(v.data), v.ld, Nk * k.ld, _ptr(out.data), out.ld, _ptr(dO),
+                dO.stride(0), _ptr(lse), _ptr(delta), _ptr(gq), gq.stride(0), _ptr(gk), gk.stride(0), _ptr(gv), gv.stride(0),
+                Nk * gk.stride(0), B, len(nq), nq_c, Nk, scale, self.dt, self.stream))
+        self._rec(bwd)
+        return out
+
     def _attention_fused(self, q: Var, k: Var, v: Var, B: int, Nq: int, Nk: int, scale: float, out: Optional[Var] = None) -> Var:
         d = q.cols
         assert d == 64

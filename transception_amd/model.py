@@ -588,8 +588,11 @@ def _self_att(M, G, n: Var, X: Optional[Var], name: str, B: int, sides: List[int
     kv = G.linear(rn, *_lin(M, G, name + ".kv"))
     k, v = kv.colslice(0, Cd), kv.colslice(Cd, 2 * Cd)
     att = G.new(B * N6, Cd)
-    for s in range(4):
-        G.attention(q.rowslice(R[s], R[s + 1]), k, v, B, ntok[s], Nk, Cd ** -0.5, out=att.rowslice(R[s], R[s + 1]))
+    if G.use_fused_attention:
+        G.attention_seg(q, k, v, B, list(ntok), Nk, Cd ** -0.5, out=att)          # all four scales, one launch
+    else:
+        for s in range(4):
+            G.attention(q.rowslice(R[s], R[s + 1]), k, v, B, ntok[s], Nk, Cd ** -0.5, out=att.rowslice(R[s], R[s + 1]))
     return G.linear(att, *_lin(M, G, name + ".proj"), residual=X)
 
 
