@@ -16,7 +16,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
-constexpr int D = 64, KB = 128, LDR = D + 8, LDTB = KB + 8;
+constexpr int D = 64, KB = 128, LDR = D + 8, LDTB = KB + 16;   // LDTB: 288-byte rows = 72 words (8 mod 32), see st_t8
 #define LOG2E 1.4426950408889634f
 #define LN2 0.6931471805599453f
 #define NEG_BIG (-1.0e30f)
@@ -42,11 +42,21 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& v, int o) {
 __device__ __forceinline__ uint4 ld_row8(const bf16_t* base, int ld, int row, int nrows, int c8) {
     return row < nrows ? *reinterpret_cast<const uint4*>(base + (long long)row * ld + c8) : make_uint4(0u, 0u, 0u, 0u);
 }
-__device__ __forceinline__ void st_t8(bf16_t* dst, int ldt, int c8, int col, uint4 v) {
+// Transposed LDS store of one 8-element strip: dst[(c8+i)*ldt + col] = v[i].  A wave stores 16 consecutive `col`s (lanes
+// 0-15) for four strips c8 = 8g (g = lane>>4).  The element order is rotated by g so that the four lane groups hit rows
+// that differ mod 4; with a row stride of 8 (mod 32) words their 8-word spans then fall on disjoint banks.
+__device__ __forceinline__ void st_t8(bf16_t* dst, int ldt, int c8, int col, uint4 v, int g) {
     union { uint4 v; bf16_t e[8]; } u;
     u.v = v;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dst[(c8 + i) * ldt + col] = u.e[i];
+    for (int i = 0; i < 8; ++i) { const int ii = (i + g) & 7; dst[(c8 + ii) * ldt + col] = u.e[ii]; }
+}
+// strip owned by a thread in a 128-key x 64-d fill: wave w, iteration it -> 16 keys x 32 d
+__device__ __forceinline__ void fill_map(int tid, int it, int& r, int& c8, int& g) {
+    const int lane = tid & 63, c = (tid >> 6) * 4 + it;
+    g = lane >> 4;
+    r = 16 * (c >> 1) + (lane & 15);
+    c8 = 32 * (c & 1) + 8 * g;
 }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
@@ -92,7 +102,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_seg_kernel(const bf16_t* __re
     auto fetch = [&](int kb0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int f = tid + i * 256, r = f >> 3, c8 = (f & 7) * 8;
+            int r, c8, g;
+            fill_map(tid, i, r, c8, g);
             kr[i] = ld_row8(Kb, ldk, kb0 + r, Nk, c8);
             vr[i] = ld_row8(Vb, ldv, kb0 + r, Nk, c8);
         }
@@ -102,24 +113,27 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_seg_kernel(const bf16_t* __re
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int f = tid + i * 256, r = f >> 3, c8 = (f & 7) * 8;
+            int r, c8, g;
+            fill_map(tid, i, r, c8, g);
             *reinterpret_cast<uint4*>(&Ks[r * LDR + c8]) = kr[i];
-            st_t8(Vt, LDTB, c8, r, vr[i]);
+            st_t8(Vt, LDTB, c8, r, vr[i], g);
         }
         __syncthreads();
         if (kb0 + KB < Nk) fetch(kb0 + KB);
-#pragma unroll 1
-        for (int sub = 0; sub < KB / 32; ++sub) {
-            const int kv0 = kb0 + 32 * sub;
-            if (kv0 >= Nk) break;
+        // S^T tile of sub-tile `sub`: 4 chained MFMAs, issued asynchronously to the matrix pipe
+        auto qk = [&](int sub) {
             f32x16 s;
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = 0.f;
             const bf16_t* kp = Ks + (32 * sub + krow) * LDR + 8 * h;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(kp + 16 * ks), qf[ks], s, 0, 0, 0);
-            const bool tail = kv0 + 32 > Nk;                    // wave-uniform
-            if (tail) {
+            return s;
+        };
+        // online softmax of a finished S^T tile (register VALU) followed by O^T += V^T P^T
+        auto softmax_pv = [&](f32x16 s, int sub) {
+            const int kv0 = kb0 + 32 * sub;
+            if (kv0 + 32 > Nk) {                                // tail tile (wave-uniform)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) if (kv0 + 16 * h + r >= Nk) s[r] = NEG_BIG;
             }
@@ -147,7 +161,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_seg_kernel(const bf16_t* __re
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(vp + 8 * k2), pb, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(vp + 32 * LDTB + 8 * k2), pb, acc1, 0, 0, 0);
             }
-        }
+        };
+#pragma unroll 1
+        for (int sub = 0; sub < KB / 32 && kb0 + 32 * sub < Nk; ++sub) softmax_pv(qk(sub), sub);
     }
     if (ok) {
         const float inv = 1.0f / lsum;
@@ -196,7 +212,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_seg_kernel(const bf16_t* _
     auto fetch = [&](int kb0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int f = tid + i * 256, r = f >> 3, c8 = (f & 7) * 8;
+            int r, c8, g;
+            fill_map(tid, i, r, c8, g);
             kr[i] = ld_row8(Kb, ldk, kb0 + r, Nk, c8);
             vr[i] = ld_row8(Vb, ldv, kb0 + r, Nk, c8);
         }
@@ -206,9 +223,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_seg_kernel(const bf16_t* _
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int f = tid + i * 256, r = f >> 3, c8 = (f & 7) * 8;
+            int r, c8, g;
+            fill_map(tid, i, r, c8, g);
             *reinterpret_cast<uint4*>(&Ks[r * LDR + c8]) = kr[i];
-            st_t8(Kt, LDTB, c8, r, kr[i]);
+            st_t8(Kt, LDTB, c8, r, kr[i], g);
             *reinterpret_cast<uint4*>(&Vs[r * LDR + c8]) = vr[i];
         }
         __syncthreads();
@@ -259,7 +277,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_seg_kernel(const bf16_t* __r
                                                                const bf16_t* __restrict__ dO, int lddo, const float* __restrict__ lse,
                                                                const float* __restrict__ delta, bf16_t* __restrict__ dK, int lddk,
                                                                bf16_t* __restrict__ dV, int lddv, long long sdkv, Segs sg, int Nk, float scale) {
-    constexpr int LDQT = 32 + 8;
+    constexpr int LDQT = 32 + 16;                  // 96-byte rows = 24 words (8-word spans of rows distinct mod 4 are disjoint)
     constexpr int PER_WAVE_B = (2 * 32 * LDR + 2 * D * LDQT) * 2 + 256;
     constexpr int RED_B = 4 * 2 * 64 * 33 * 4;
     constexpr int SMEM_B = (4 * PER_WAVE_B > RED_B) ? 4 * PER_WAVE_B : RED_B;
@@ -302,7 +320,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_seg_kernel(const bf16_t* __r
         locate(t, base, valid);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int f = lane + i * 64, r = f >> 3, c8 = (f & 7) * 8;
+            const int r = 16 * (i & 1) + (lane & 15), c8 = 32 * (i >> 1) + 8 * (lane >> 4);
             const bool okr = r < valid;
             qr[i] = okr ? *reinterpret_cast<const uint4*>(Q + (base + r) * ldq + c8) : make_uint4(0u, 0u, 0u, 0u);
             gr[i] = okr ? *reinterpret_cast<const uint4*>(dO + (base + r) * lddo + c8) : make_uint4(0u, 0u, 0u, 0u);
@@ -315,11 +333,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_seg_kernel(const bf16_t* __r
         locate(t, base, valid);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int f = lane + i * 64, r = f >> 3, c8 = (f & 7) * 8;
+            const int r = 16 * (i & 1) + (lane & 15), g = lane >> 4, c8 = 32 * (i >> 1) + 8 * g;
             *reinterpret_cast<uint4*>(&Qs[r * LDR + c8]) = qr[i];
             *reinterpret_cast<uint4*>(&dOs[r * LDR + c8]) = gr[i];
-            st_t8(Qt, LDQT, c8, r, qr[i]);
-            st_t8(dOt, LDQT, c8, r, gr[i]);
+            st_t8(Qt, LDQT, c8, r, qr[i], g);
+            st_t8(dOt, LDQT, c8, r, gr[i], g);
         }
         if (lane < 32) { lss[lane] = lr; dls[lane] = dr; }
         __builtin_amdgcn_s_waitcnt(0xc07f);
