@@ -62,6 +62,7 @@ typedef struct TcGemm {
     int c_f32;                   /* C (and the accumulate read) is fp32 whatever dtype is: weight gradients */
     int atomic;                  /* accumulate with fp32 atomics (batches that share one C) */
     float* rowsum;               /* optional fp32 [M]: rowsum[m] += sum_k op(A)[m,k] (bias gradient of a dW GEMM) */
+    long long sBias1, sRow1;     /* level-1 batch strides of bias / rowsum (grouped weights: one weight set per batch) */
 } TcGemm;
 int tc_gemm(const TcGemm* g, void* stream);
 
@@ -76,13 +77,16 @@ int tc_colsum(const void* x, int rows, int cols, int ldx, int nb, long long sb, 
  *   :199,225,1720,2249,2390-2391 and their backward.
  * mean/rstd: fp32 [rows] saved for backward.
  */
+/* groups > 1: `groups` stacked row blocks of `rows` rows each, block g using gamma/beta + g*pstride (the three MB paths). */
 int tc_layernorm_fwd(const void* x, int ldx, const void* gamma, const void* beta, void* y, int ldy,
-                     float* mean, float* rstd, int rows, int C, float eps, int act, int dtype, void* stream);
+                     float* mean, float* rstd, int rows, int C, float eps, int act, int groups, long long pstride,
+                     int dtype, void* stream);
 /* dx = d/dx ; dgamma/dbeta (fp32 [C]) are ACCUMULATED into (caller zeroes or reuses grad buffers).
  * If dres != NULL its rows (stride ldres) are added to dx (fan-in of a residual branch). */
 int tc_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx, const void* gamma, const void* beta,
                      const float* mean, const float* rstd, void* dx, int lddx, const void* dres, int ldres,
-                     float* dgamma, float* dbeta, int rows, int C, int act, int dtype, void* stream);
+                     float* dgamma, float* dbeta, int rows, int C, int act, int groups, long long pstride, int dtype,
+                     void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Depthwise k x k convolution on NHWC maps, k in {3,5,7}, stride 1 or 2, padding (k-1)/2,
@@ -91,15 +95,19 @@ int tc_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx, const voi
  * Replaces: DWConv MSTr.py:21-31 (+ the skip add at :900), ConvPosEnc :744-752, ConvRelPosEnc
  *   depthwise 3/5/7 convs :785-797,814-816, DWConv2d_BN.dwconv :328-336, ResBlock.dwconv :1005-1013.
  */
+/* groups > 1 (stride 1 only): `groups` stacked sets of B images, set g using the filters at w + g*wstride and the bias at
+ * bias + g*wstride (one stride for every parameter: the distance between two MB encoders in the flat arena). */
 int tc_dwconv_fwd(const void* x, int ldx, const void* w, const void* bias, void* y, int ldy,
-                  int B, int H, int W, int C, int k, int stride, int add_input, int dtype, void* stream);
+                  int B, int H, int W, int C, int k, int stride, int add_input, int groups, long long wstride, int dtype,
+                  void* stream);
 /* accumulate=1: dx += result */
 int tc_dwconv_bwd_input(const void* dy, int lddy, const void* w, void* dx, int lddx,
-                        int B, int H, int W, int C, int k, int stride, int add_input, int accumulate, int dtype,
-                        void* stream);
+                        int B, int H, int W, int C, int k, int stride, int add_input, int accumulate, int groups,
+                        long long wstride, int dtype, void* stream);
 /* dw [C,1,k,k] and db [C] (fp32) are ACCUMULATED into. db may be NULL. */
 int tc_dwconv_bwd_weight(const void* dy, int lddy, const void* x, int ldx, float* dw, float* db,
-                         int B, int H, int W, int C, int k, int stride, int dtype, void* stream);
+                         int B, int H, int W, int C, int k, int stride, int groups, long long wstride, int dtype,
+                         void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * BatchNorm2d over token rows ([rows, C], statistics over rows) fused with its activation and an

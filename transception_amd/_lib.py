@@ -25,7 +25,7 @@ class TcGemm(C.Structure):
                 ("transA", i32), ("transB", i32), ("nb1", i32), ("nb2", i32),
                 ("sA1", i64), ("sA2", i64), ("sB1", i64), ("sB2", i64),
                 ("sC1", i64), ("sC2", i64), ("sR1", i64), ("sR2", i64),
-                ("alpha", f32), ("accumulate", i32), ("act", i32), ("splitk", i32), ("dtype", i32), ("c_f32", i32), ("atomic", i32), ("rowsum", vp)]
+                ("alpha", f32), ("accumulate", i32), ("act", i32), ("splitk", i32), ("dtype", i32), ("c_f32", i32), ("atomic", i32), ("rowsum", vp), ("sBias1", i64), ("sRow1", i64)]
 
 
 # name -> argtypes (every function returns int status unless listed in _RET)
@@ -33,11 +33,11 @@ SIGNATURES = {
     "tc_abi_version": [],
     "tc_gemm": [C.POINTER(TcGemm), vp],
     "tc_colsum": [vp, i32, i32, i32, i32, i64, vp, i32, i32, vp],
-    "tc_layernorm_fwd": [vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, f32, i32, i32, vp],
-    "tc_layernorm_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp],
-    "tc_dwconv_fwd": [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
-    "tc_dwconv_bwd_input": [vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
-    "tc_dwconv_bwd_weight": [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "tc_layernorm_fwd": [vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, f32, i32, i32, i64, i32, vp],
+    "tc_layernorm_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i64, i32, vp],
+    "tc_dwconv_fwd": [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i64, i32, vp],
+    "tc_dwconv_bwd_input": [vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i64, i32, vp],
+    "tc_dwconv_bwd_weight": [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i64, i32, vp],
     "tc_bn_scratch_floats": [i32, i32],
     "tc_bn_fwd": [vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, f32, f32, i32, i32, i32, vp],
     "tc_bn_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp],

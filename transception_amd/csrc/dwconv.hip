@@ -129,8 +129,19 @@ template <typename T, int K, int CPT, int MODE>
 __global__ __launch_bounds__(256) void dw_strip_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ w, const T* __restrict__ bias,
                                                        const T* __restrict__ dy, int lddy, T* __restrict__ y, int ldy,
                                                        float* __restrict__ dw, float* __restrict__ db, int B, int H, int W, int C,
-                                                       int add_input, int accumulate, int nseg) {
+                                                       int add_input, int accumulate, int nseg, long long wstride) {
     constexpr int P = (K - 1) / 2, CGB = 64 / CPT, RI = 256 / CGB;
+    {   // group = blockIdx.z: B images each; every parameter / parameter-gradient pointer of group g is wstride elements further on
+        const long long g = blockIdx.z;
+        const long long img = (long long)B * H * W;
+        if (x) x += g * img * ldx;
+        if (dy) dy += g * img * lddy;
+        if (y) y += g * img * ldy;
+        if (w) w += g * wstride;
+        if (bias) bias += g * wstride;
+        if (dw) dw += g * wstride;
+        if (db) db += g * wstride;
+    }
     const int cgl = threadIdx.x % CGB, ri = threadIdx.x / CGB;
     const int c = blockIdx.y * 64 + cgl * CPT;
     const bool cok = c < C;
@@ -251,18 +262,19 @@ __global__ __launch_bounds__(256) void dw_strip_kernel(const T* __restrict__ x, 
 
 template <typename T, int MODE>
 int launch_strip(const void* x, int ldx, const void* w, const void* bias, const void* dy, int lddy, void* y, int ldy, float* dw,
-                 float* db, int B, int H, int W, int C, int k, int add_input, int accumulate, hipStream_t s) {
+                 float* db, int B, int H, int W, int C, int k, int add_input, int accumulate, int groups, long long wstride,
+                 hipStream_t s) {
     const int nrows = B * H;
 #define TC_STRIP(KK, CPT)                                                                                                       \
     {                                                                                                                           \
         constexpr int RI = 256 / (64 / CPT);                                                                                    \
         /* split rows into W-segments until ~64k threads exist (small maps are otherwise a handful of long serial walks) */  \
-        int nseg = (int)(65536LL / ((long long)nrows * ((C + CPT - 1) / CPT)));                                                 \
+        int nseg = (int)(65536LL / ((long long)nrows * groups * ((C + CPT - 1) / CPT)));                                                 \
         const int maxseg = W / (KK + 4) > 0 ? W / (KK + 4) : 1;                                                                 \
         nseg = nseg < 1 ? 1 : (nseg > maxseg ? maxseg : nseg);                                                                  \
-        dim3 grid(tc_blocks((long long)nrows * nseg, RI, MODE == 2 ? 512 : 4096), (C + 63) / 64);                                \
+        dim3 grid(tc_blocks((long long)nrows * nseg, RI, MODE == 2 ? 512 : 4096), (C + 63) / 64, groups);                                \
         hipLaunchKernelGGL((dw_strip_kernel<T, KK, CPT, MODE>), grid, dim3(256), 0, s, (const T*)x, ldx, (const T*)w, (const T*)bias, \
-                           (const T*)dy, lddy, (T*)y, ldy, dw, db, B, H, W, C, add_input, accumulate, nseg);                    \
+                           (const T*)dy, lddy, (T*)y, ldy, dw, db, B, H, W, C, add_input, accumulate, nseg, wstride);                    \
     }
     if (k == 3) TC_STRIP(3, 4) else if (k == 5) TC_STRIP(5, 2) else TC_STRIP(7, 2)
 #undef TC_STRIP
@@ -291,33 +303,37 @@ bool dw_args_ok(int B, int H, int W, int C, int k, int stride, int add_input) {
 }  // namespace
 
 extern "C" int tc_dwconv_fwd(const void* x, int ldx, const void* w, const void* bias, void* y, int ldy, int B, int H, int W,
-                             int C, int k, int stride, int add_input, int dtype, void* stream) {
-    if (!x || !w || !y || (ldx & 3) || (ldy & 3) || !dw_args_ok(B, H, W, C, k, stride, add_input)) return TC_ERR_ARG;
+                             int C, int k, int stride, int add_input, int groups, long long wstride, int dtype, void* stream) {
+    if (!x || !w || !y || (ldx & 3) || (ldy & 3) || groups < 1 || (groups > 1 && stride != 1) || !dw_args_ok(B, H, W, C, k, stride, add_input))
+        return TC_ERR_ARG;
     if (stride == 1)
         TC_DISPATCH_DTYPE(dtype, return (launch_strip<T, 0>(x, ldx, w, bias, nullptr, 0, y, ldy, nullptr, nullptr, B, H, W, C, k,
-                                                            add_input, 0, (hipStream_t)stream)));
+                                                            add_input, 0, groups, wstride, (hipStream_t)stream)));
     TC_DISPATCH_DTYPE(dtype, return (launch_dw<T, false>(x, ldx, w, bias, y, ldy, B, H, W, C, k, stride, add_input, 0,
                                                          (hipStream_t)stream)));
     return TC_ERR_ARG;
 }
 
 extern "C" int tc_dwconv_bwd_input(const void* dy, int lddy, const void* w, void* dx, int lddx, int B, int H, int W, int C,
-                                   int k, int stride, int add_input, int accumulate, int dtype, void* stream) {
-    if (!dy || !w || !dx || (lddy & 3) || (lddx & 3) || !dw_args_ok(B, H, W, C, k, stride, add_input)) return TC_ERR_ARG;
+                                   int k, int stride, int add_input, int accumulate, int groups, long long wstride, int dtype,
+                                   void* stream) {
+    if (!dy || !w || !dx || (lddy & 3) || (lddx & 3) || groups < 1 || (groups > 1 && stride != 1) ||
+        !dw_args_ok(B, H, W, C, k, stride, add_input))
+        return TC_ERR_ARG;
     if (stride == 1)
         TC_DISPATCH_DTYPE(dtype, return (launch_strip<T, 1>(nullptr, 0, w, nullptr, dy, lddy, dx, lddx, nullptr, nullptr, B, H, W, C, k,
-                                                            add_input, accumulate, (hipStream_t)stream)));
+                                                            add_input, accumulate, groups, wstride, (hipStream_t)stream)));
     TC_DISPATCH_DTYPE(dtype, return (launch_dw<T, true>(dy, lddy, w, nullptr, dx, lddx, B, H, W, C, k, stride, add_input, accumulate,
                                                         (hipStream_t)stream)));
     return TC_ERR_ARG;
 }
 
 extern "C" int tc_dwconv_bwd_weight(const void* dy, int lddy, const void* x, int ldx, float* dw, float* db, int B, int H,
-                                    int W, int C, int k, int stride, int dtype, void* stream) {
-    if (!dy || !x || !dw || !dw_args_ok(B, H, W, C, k, stride, 0)) return TC_ERR_ARG;
+                                    int W, int C, int k, int stride, int groups, long long wstride, int dtype, void* stream) {
+    if (!dy || !x || !dw || groups < 1 || (groups > 1 && stride != 1) || !dw_args_ok(B, H, W, C, k, stride, 0)) return TC_ERR_ARG;
     if (stride == 1)
         TC_DISPATCH_DTYPE(dtype, return (launch_strip<T, 2>(x, ldx, nullptr, nullptr, dy, lddy, nullptr, 0, dw, db, B, H, W, C, k, 0, 0,
-                                                            (hipStream_t)stream)));
+                                                            groups, wstride, (hipStream_t)stream)));
     const int P = (k - 1) / 2;
     const int Ho = (H + 2 * P - k) / stride + 1, Wo = (W + 2 * P - k) / stride + 1;
     const long long npix = (long long)B * Ho * Wo;

@@ -23,6 +23,7 @@ struct GemmDev {
     float alpha; int accumulate, act;
     int vecA, vecB, atomic;
     float* rowsum;          // optional: rowsum[m] += sum_k op(A)[m][k]  (fp32, atomics)
+    long long sBias1, sRow1; // batch-level-1 strides of bias / rowsum (grouped weights)
 };
 
 // ---------------------------------------------------------------------------------------------- shared epilogue
@@ -31,7 +32,7 @@ template <typename T, typename TC, int TM, int TN>
 __device__ __forceinline__ void epilogue(const GemmDev& p, f32x16 (&acc)[TM][TN], int b1, int b2, int ks, int mbase, int nbase, int lane) {
     TC* C = reinterpret_cast<TC*>(p.C) + b1 * p.sC1 + b2 * p.sC2;
     const T* R = p.R ? reinterpret_cast<const T*>(p.R) + b1 * p.sR1 + b2 * p.sR2 : nullptr;
-    const T* bias = reinterpret_cast<const T*>(p.bias);
+    const T* bias = p.bias ? reinterpret_cast<const T*>(p.bias) + b1 * p.sBias1 : nullptr;
     const bool first_split = (ks == 0);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev p) {
         }
         __syncthreads();
     }
-    if (do_rowsum && m0 + tid < p.M) atomicAdd(p.rowsum + m0 + tid, rsum);
+    if (do_rowsum && m0 + tid < p.M) atomicAdd(p.rowsum + b1 * p.sRow1 + m0 + tid, rsum);
     epilogue<float, TC, TM, TN>(p, acc, b1, b2, ks, m0 + wr * WM, n0 + wc * WN, lane);
 }
 
@@ -244,13 +245,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmDev p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     uint4 ra[SA], rb[SB];
+    // strip ownership: K-contiguous operands: consecutive threads walk along K (coalesced 16-B loads, vector LDS writes);
+    // transposed operands: lanes 0-31 own the 32 k-rows of the slab for one 8-wide x strip, so that each of the 8 scalar
+    // transposed LDS writes of a wave hits 32 consecutive bf16 of one row (no bank conflicts; the naive mapping strides rows by 8).
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < SA; ++i) {
             const int f = tid + i * 256;
             if (!TA) { const int row = f / (BK / 8), kq = f % (BK / 8);
                 ra[i] = load_strip8(A, p.lda, m0 + row, k0 + kq * 8, p.M, kend, false, p.vecA); }
-            else { const int k = f / (BM / 8), mq = f % (BM / 8);
+            else { const int k = f % BK, mq = f / BK;
                 ra[i] = load_strip8(A, p.lda, m0 + mq * 8, k0 + k, p.M, kend, true, p.vecA); }
         }
 #pragma unroll
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmDev p) {
             const int f = tid + i * 256;
             if (TB) { const int row = f / (BK / 8), kq = f % (BK / 8);
                 rb[i] = load_strip8(B, p.ldb, n0 + row, k0 + kq * 8, p.N, kend, false, p.vecB); }
-            else { const int k = f / (BN / 8), nq = f % (BN / 8);
+            else { const int k = f % BK, nq = f / BK;
                 rb[i] = load_strip8(B, p.ldb, n0 + nq * 8, k0 + k, p.N, kend, true, p.vecB); }
         }
     };
@@ -273,13 +277,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmDev p) {
         for (int i = 0; i < SA; ++i) {
             const int f = tid + i * 256;
             if (!TA) { const int row = f / (BK / 8), kq = f % (BK / 8); *reinterpret_cast<uint4*>(&As[row * LDT + kq * 8]) = ra[i]; }
-            else { const int k = f / (BM / 8), mq = f % (BM / 8); put_t(As, mq * 8, k, ra[i]); }
+            else { const int k = f % BK, mq = f / BK; put_t(As, mq * 8, k, ra[i]); }
         }
 #pragma unroll
         for (int i = 0; i < SB; ++i) {
             const int f = tid + i * 256;
             if (TB) { const int row = f / (BK / 8), kq = f % (BK / 8); *reinterpret_cast<uint4*>(&Bs[row * LDT + kq * 8]) = rb[i]; }
-            else { const int k = f / (BN / 8), nq = f % (BN / 8); put_t(Bs, nq * 8, k, rb[i]); }
+            else { const int k = f % BK, nq = f / BK; put_t(Bs, nq * 8, k, rb[i]); }
         }
     };
 
@@ -311,7 +315,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmDev p) {
         }
         __syncthreads();
     }
-    if (do_rowsum && m0 + tid < p.M) atomicAdd(p.rowsum + m0 + tid, rsum);
+    if (do_rowsum && m0 + tid < p.M) atomicAdd(p.rowsum + b1 * p.sRow1 + m0 + tid, rsum);
     epilogue<bf16_t, TC, TM, TN>(p, acc, b1, b2, ks, m0 + wr * WM, n0 + wc * WN, lane);
 }
 
@@ -342,6 +346,7 @@ int gemm_typed(const TcGemm* g, hipStream_t s) {
     d.alpha = g->alpha; d.accumulate = g->accumulate; d.act = g->act;
     d.atomic = (g->splitk > 1 || g->atomic) ? 1 : 0;
     d.rowsum = g->rowsum;
+    d.sBias1 = g->sBias1; d.sRow1 = g->sRow1;
     constexpr int VEC = 16 / (int)sizeof(T);                         // elements per 16-byte vector
     auto aligned = [&](const void* ptr, int ld, long long s1, long long s2) {
         return ((uintptr_t)ptr % 16 == 0) && (ld % VEC == 0) && (s1 % VEC == 0) && (s2 % VEC == 0);
@@ -374,7 +379,6 @@ extern "C" int tc_gemm(const TcGemm* g, void* stream) {
         g->splitk < 1)
         return TC_ERR_ARG;
     if ((g->splitk > 1 || g->atomic) && (!g->accumulate || (g->dtype != TC_F32 && !g->c_f32) || g->act != TC_ACT_NONE)) return TC_ERR_ARG;
-    if (g->rowsum && (g->nb1 * g->nb2 > 1 && !g->atomic)) return TC_ERR_ARG;
     if (g->act != TC_ACT_NONE && g->act != TC_ACT_SIGMOID) return TC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     TC_DISPATCH_DTYPE(g->dtype, return gemm_typed<T>(g, s));

@@ -22,9 +22,13 @@ template <typename T, int GS, int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ gamma,
                                                      const T* __restrict__ beta, T* __restrict__ y, int ldy,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int rows,
-                                                     int C, float eps, int act) {
+                                                     int C, float eps, int act, long long pstride) {
     constexpr int RPB = 256 / GS;
     const int gl = threadIdx.x % GS, gi = threadIdx.x / GS;
+    {   // group = blockIdx.y: `rows` rows each, parameters pstride apart
+        const long long g = blockIdx.y;
+        x += g * rows * ldx; y += g * rows * ldy; mean += g * rows; rstd += g * rows; gamma += g * pstride; beta += g * pstride;
+    }
     const int nv = C >> 2;
     const float invC = 1.0f / (float)C;
     float4 g[NV], b[NV];
@@ -75,10 +79,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      T* __restrict__ dx, int lddx, const T* __restrict__ dres, int ldres,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int C,
-                                                     int act) {
+                                                     int act, long long pstride) {
     constexpr int RPB = 256 / GS;
     extern __shared__ float red[];           // [RPB][2][C]
     const int gl = threadIdx.x % GS, gi = threadIdx.x / GS;
+    {
+        const long long g = blockIdx.y;
+        dy += g * rows * lddy; x += g * rows * ldx; dx += g * rows * lddx; mean += g * rows; rstd += g * rows;
+        if (dres) dres += g * rows * ldres;
+        gamma += g * pstride; beta += g * pstride; dgamma += g * pstride; dbeta += g * pstride;
+    }
     const int nv = C >> 2;
     float4 g[NV], b[NV], ag[NV], ab[NV];
 #pragma unroll
@@ -289,14 +299,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 }  // namespace
 
 extern "C" int tc_layernorm_fwd(const void* x, int ldx, const void* gamma, const void* beta, void* y, int ldy,
-                                float* mean, float* rstd, int rows, int C, float eps, int act, int dtype, void* stream) {
-    if (!x || !y || !gamma || !beta || !mean || !rstd || rows <= 0 || C <= 0 || (C & 3) || C > LN_MAXC ||
+                                float* mean, float* rstd, int rows, int C, float eps, int act, int groups, long long pstride, int dtype,
+                                void* stream) {
+    if (!x || !y || !gamma || !beta || !mean || !rstd || rows <= 0 || groups < 1 || C <= 0 || (C & 3) || C > LN_MAXC ||
         (ldx & 3) || (ldy & 3) || (act != TC_ACT_NONE && act != TC_ACT_GELU))
         return TC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int quads = C >> 2;
-#define TC_LNF(GS, NV) hipLaunchKernelGGL((ln_fwd_kernel<T, GS, NV>), dim3(tc_blocks(rows, 256 / GS, 2048)), dim3(256), 0, s, (const T*)x, \
-                                          ldx, (const T*)gamma, (const T*)beta, (T*)y, ldy, mean, rstd, rows, C, eps, act)
+#define TC_LNF(GS, NV) hipLaunchKernelGGL((ln_fwd_kernel<T, GS, NV>), dim3(tc_blocks(rows, 256 / GS, 2048), groups), dim3(256), 0, s, (const T*)x, \
+                                          ldx, (const T*)gamma, (const T*)beta, (T*)y, ldy, mean, rstd, rows, C, eps, act, pstride)
     TC_DISPATCH_DTYPE(dtype, { TC_LN_DISPATCH(quads, TC_LNF) });
 #undef TC_LNF
     return tc_launch_status();
@@ -304,16 +315,17 @@ extern "C" int tc_layernorm_fwd(const void* x, int ldx, const void* gamma, const
 
 extern "C" int tc_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx, const void* gamma, const void* beta,
                                 const float* mean, const float* rstd, void* dx, int lddx, const void* dres, int ldres,
-                                float* dgamma, float* dbeta, int rows, int C, int act, int dtype, void* stream) {
-    if (!dy || !x || !gamma || !beta || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0 || C <= 0 || (C & 3) ||
+                                float* dgamma, float* dbeta, int rows, int C, int act, int groups, long long pstride, int dtype,
+                                void* stream) {
+    if (!dy || !x || !gamma || !beta || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0 || groups < 1 || C <= 0 || (C & 3) ||
         C > LN_MAXC || (ldx & 3) || (lddy & 3) || (lddx & 3) || (dres && (ldres & 3)))
         return TC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int quads = C >> 2;
-#define TC_LNB(GS, NV) hipLaunchKernelGGL((ln_bwd_kernel<T, GS, NV>), dim3(tc_blocks(rows, (256 / GS) * 4, 256)), dim3(256),            \
+#define TC_LNB(GS, NV) hipLaunchKernelGGL((ln_bwd_kernel<T, GS, NV>), dim3(tc_blocks(rows, (256 / GS) * 4, 256), groups), dim3(256),    \
                                           (size_t)(256 / GS) * 2 * C * sizeof(float), s, (const T*)dy, lddy, (const T*)x, ldx,            \
                                           (const T*)gamma, (const T*)beta, mean, rstd, (T*)dx, lddx, (const T*)dres, ldres, dgamma,      \
-                                          dbeta, rows, C, act)
+                                          dbeta, rows, C, act, pstride)
     TC_DISPATCH_DTYPE(dtype, { TC_LN_DISPATCH(quads, TC_LNB) });
 #undef TC_LNB
     return tc_launch_status();

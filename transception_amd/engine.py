@@ -40,12 +40,15 @@ def _timed(name: str, flops: float, fn):
 
 
 class P:
-    """Engine-side handle of one parameter: compute-dtype data + fp32 gradient view (or None when frozen)."""
-    __slots__ = ("data", "grad")
+    """Engine-side handle of one parameter: compute-dtype data + fp32 gradient view (or None when frozen).
+    gs = distance (elements) to the same parameter of the next group when an op runs several weight sets at once
+    (the three MB paths: same shapes, different weights, laid out at a constant stride in the flat arenas)."""
+    __slots__ = ("data", "grad", "gs")
 
-    def __init__(self, data: torch.Tensor, grad: Optional[torch.Tensor]):
+    def __init__(self, data: torch.Tensor, grad: Optional[torch.Tensor], gs: int = 0):
         self.data = data
         self.grad = grad
+        self.gs = gs
 
 
 class Var:
@@ -175,8 +178,26 @@ class _Parallel:
             G.tape.append(("fork", G.cur, self.sides, self.shared))   # backward: the branches wait for main
 
 
+class _Grouped:
+    def __init__(self, G, n, pgs):
+        self.G, self.n, self.pgs, self.prev = G, n, pgs, None
+
+    def __enter__(self):
+        self.prev = (self.G.ngroups, self.G.pgs)
+        self.G.ngroups, self.G.pgs = self.n, self.pgs
+        return self
+
+    def __exit__(self, *a):
+        self.G.ngroups, self.G.pgs = self.prev
+
+
 class Graph:
     use_streams = os.environ.get("TC_NO_STREAMS", "0") != "1"
+    ngroups = 1          # ops with parameters run `ngroups` stacked row blocks, block g with the weights at +g*P.gs
+    pgs = 0
+
+    def grouped(self, n: int, pgs: int) -> _Grouped:
+        return _Grouped(self, n, pgs)
 
     def parallel(self, n: int, shared=()) -> _Parallel:
         return _Parallel(self, n, shared)
@@ -296,9 +317,9 @@ class Graph:
 
     # ------------------------------------------------------------------ GEMM plumbing
     def _gemm(self, A, lda, B, ldb, Cm, ldc, M, N, K, tA, tB, bias=None, R=None, ldr=0, alpha=1.0, acc=0, act=ACT_NONE,
-              splitk=1, nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), c_f32=0, atomic=0, rowsum=None):
+              splitk=1, nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), c_f32=0, atomic=0, rowsum=None, sbias=0, srow=0):
         g = TcGemm(A, B, Cm, bias, R, M, N, K, lda, ldb, ldc, ldr, tA, tB, nb1, nb2, sA[0], sA[1], sB[0], sB[1], sC[0], sC[1],
-                   sR[0], sR[1], alpha, acc, act, splitk, self.dt, c_f32, atomic, rowsum)
+                   sR[0], sR[1], alpha, acc, act, splitk, self.dt, c_f32, atomic, rowsum, sbias, srow)
         self.n_launch += 1
         self.L.tc_gemm(C.byref(g), self.stream)
 
@@ -318,16 +339,29 @@ class Graph:
         Wt = W.data if wcols is None else W.data[:, wcols[0]:wcols[1]]
         N, K = Wt.shape
         assert x.cols == K, (x.cols, K)
-        M = x.rows
+        Gn = self.ngroups
+        grouped = Gn > 1
+        M = x.rows // Gn
         if out is None:
             assert batch is None
-            out = self.new(M, N)
-        assert out.rows == M and out.cols == N
-        nb, sx, so, sr = batch if batch is not None else (1, 0, 0, 0)
+            out = self.new(x.rows, N)
+        if grouped:
+            # stacked groups: x / out / residual hold Gn row blocks of M rows; weights of group g at +g*W.gs.
+            # `out` may also be a [M, Gn*N] column range of a wider buffer (group g -> columns g*N..): the IFF concat.
+            assert batch is None and W.gs > 0 and (b is None or b.gs == W.gs)
+            side_by_side = (out.rows == M and out.cols == Gn * N)
+            assert side_by_side or (out.rows == Gn * M and out.cols == N)
+            nb, sx, so, sr = Gn, M * x.ld, (N if side_by_side else M * out.ld), (M * residual.ld if residual is not None else 0)
+            sw = W.gs
+        else:
+            side_by_side = False
+            assert out.rows == M and out.cols == N
+            nb, sx, so, sr = batch if batch is not None else (1, 0, 0, 0)
+            sw = 0
         self._gemm(_ptr(x.data), x.ld, _ptr(Wt), Wt.stride(0), _ptr(out.data), out.ld, M, N, K, 0, 1,
                    bias=_ptr(b.data) if b is not None else None, R=_ptr(residual.data) if residual is not None else None,
                    ldr=residual.ld if residual is not None else 0, acc=int(accumulate), act=act, nb1=nb, sA=(sx, 0),
-                   sC=(so, 0), sR=(sr, 0))
+                   sB=(sw, 0), sC=(so, 0), sR=(sr, 0), sbias=sw)
 
         def bwd():
             dy = self.grad_of(out)
@@ -339,34 +373,41 @@ class Graph:
                 dz = torch.empty_like(dy)
                 self.L.tc_sigmoid_bwd(_ptr(dy), _ptr(out.data), _ptr(dz), dy.numel(), self.dt, self.stream)
             if x.requires_grad:
-                gx, acc = self.wgrad(x, (nb - 1) * sx // x.root.cols if nb > 1 else 0)
+                gx, acc = self.wgrad(x, (nb - 1) * sx // x.root.cols if (nb > 1 and not grouped) else 0)
                 self._gemm(_ptr(dz), dz.stride(0), _ptr(Wt), Wt.stride(0), _ptr(gx), gx.stride(0), M, K, N, 0, 0, acc=acc,
-                           nb1=nb, sA=(so, 0), sC=(sx, 0))
+                           nb1=nb, sA=(so, 0), sB=(sw, 0), sC=(sx, 0))
             want_db = b is not None and b.grad is not None
             if W.grad is not None:
                 gW = W.grad if wcols is None else W.grad[:, wcols[0]:wcols[1]]
                 self._gemm(_ptr(dz), dz.stride(0), _ptr(x.data), x.ld, _ptr(gW), gW.stride(0), N, K, M, 1, 0, acc=1,
-                           splitk=self._splitk(N, K, M), c_f32=1, nb1=nb, sA=(so, 0), sB=(sx, 0), atomic=int(nb > 1),
-                           rowsum=_ptr(b.grad) if want_db else None)       # db = column sums of dz ride along
+                           splitk=self._splitk(N, K, M), c_f32=1, nb1=nb, sA=(so, 0), sB=(sx, 0), sC=(sw, 0),
+                           atomic=int(nb > 1 and not grouped), rowsum=_ptr(b.grad) if want_db else None, srow=sw)
             elif want_db:
+                assert not grouped
                 self.L.tc_colsum(_ptr(dz), M, N, dz.stride(0), nb, so, _ptr(b.grad), 1, self.dt, self.stream)
             if residual is not None:
-                assert nb == 1 or sr == so
-                self.pass_grad(residual, dy) if nb == 1 else self._pass_grad_batched(residual, dy, nb, M, N, so)
+                if nb == 1 or (grouped and not side_by_side):
+                    self.pass_grad(residual, dy)
+                else:
+                    assert grouped or sr == so
+                    self._pass_grad_batched(residual, dy, nb, M, N, so, sr if grouped else so)
         self._rec(bwd)
         return out
 
-    def _pass_grad_batched(self, v: Var, src: torch.Tensor, nb: int, M: int, N: int, sb: int):
-        g, acc = self.wgrad(v, (nb - 1) * sb // v.root.cols)
-        self.L.tc_copy3d(_ptr(src), sb, src.stride(0), _ptr(g), sb, g.stride(0), nb, M, N, acc, self.dt, self.stream)
+    def _pass_grad_batched(self, v: Var, src: torch.Tensor, nb: int, M: int, N: int, sb_src: int, sb_dst: Optional[int] = None):
+        sb_dst = sb_src if sb_dst is None else sb_dst
+        g, acc = self.wgrad(v, 0 if v.rows >= nb * M else (nb - 1) * sb_dst // v.root.cols)
+        self.L.tc_copy3d(_ptr(src), sb_src, src.stride(0), _ptr(g), sb_dst, g.stride(0), nb, M, N, acc, self.dt, self.stream)
 
     def layernorm(self, x: Var, g: P, b: P, eps: float = 1e-5, act: int = ACT_NONE, out: Optional[Var] = None) -> Var:
-        rows, Cc = x.rows, x.cols
+        Gn = self.ngroups
+        rows, Cc = x.rows // Gn, x.cols
+        assert Gn == 1 or (g.gs > 0 and b.gs == g.gs)
         if out is None:
-            out = self.new(rows, Cc)
-        mean, rstd = self.f32(rows), self.f32(rows)
+            out = self.new(x.rows, Cc)
+        mean, rstd = self.f32(x.rows), self.f32(x.rows)
         self.L.tc_layernorm_fwd(_ptr(x.data), x.ld, _ptr(g.data), _ptr(b.data), _ptr(out.data), out.ld, _ptr(mean), _ptr(rstd),
-                                rows, Cc, eps, act, self.dt, self.stream)
+                                rows, Cc, eps, act, Gn, g.gs, self.dt, self.stream)
 
         def bwd():
             dy = self.grad_of(out)
@@ -375,19 +416,20 @@ class Graph:
             gx, acc = self.wgrad(x)
             self.L.tc_layernorm_bwd(_ptr(dy), dy.stride(0), _ptr(x.data), x.ld, _ptr(g.data), _ptr(b.data), _ptr(mean),
                                     _ptr(rstd), _ptr(gx), gx.stride(0), _ptr(gx) if acc else None, gx.stride(0),
-                                    _ptr(g.grad), _ptr(b.grad), rows, Cc, act, self.dt, self.stream)
+                                    _ptr(g.grad), _ptr(b.grad), rows, Cc, act, Gn, g.gs, self.dt, self.stream)
         self._rec(bwd)
         return out
 
     def dwconv(self, x: Var, w: P, b: Optional[P], B: int, H: int, W: int, k: int, stride: int = 1, add_input: bool = False,
                out: Optional[Var] = None) -> Var:
         Cc = x.cols
-        assert x.rows == B * H * W
+        Gn = self.ngroups                                    # B = images per group
+        assert x.rows == Gn * B * H * W and (Gn == 1 or (w.gs > 0 and stride == 1))
         Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
         if out is None:
-            out = self.new(B * Ho * Wo, Cc)
+            out = self.new(Gn * B * Ho * Wo, Cc)
         self.L.tc_dwconv_fwd(_ptr(x.data), x.ld, _ptr(w.data), _ptr(b.data) if b is not None else None, _ptr(out.data), out.ld,
-                             B, H, W, Cc, k, stride, int(add_input), self.dt, self.stream)
+                             B, H, W, Cc, k, stride, int(add_input), Gn, w.gs, self.dt, self.stream)
 
         def bwd():
             dy = self.grad_of(out)
@@ -396,10 +438,11 @@ class Graph:
             if x.requires_grad:
                 gx, acc = self.wgrad(x)
                 self.L.tc_dwconv_bwd_input(_ptr(dy), dy.stride(0), _ptr(w.data), _ptr(gx), gx.stride(0), B, H, W, Cc, k, stride,
-                                           int(add_input), acc, self.dt, self.stream)
+                                           int(add_input), acc, Gn, w.gs, self.dt, self.stream)
             if w.grad is not None:
                 self.L.tc_dwconv_bwd_weight(_ptr(dy), dy.stride(0), _ptr(x.data), x.ld, _ptr(w.grad),
-                                            _ptr(b.grad) if b is not None else None, B, H, W, Cc, k, stride, self.dt, self.stream)
+                                            _ptr(b.grad) if b is not None else None, B, H, W, Cc, k, stride, Gn, w.gs, self.dt,
+                                            self.stream)
         self._rec(bwd)
         return out
 

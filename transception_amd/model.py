@@ -345,7 +345,21 @@ class MSTransception(nn.Module):
         if G.record:
             grad = self._gflat[off:off + n].view(shp)
             self._used_views[self._pid[name]] = (off, shape)
-        return P(data, grad)
+            if G.ngroups > 1:                       # the same parameter of the other MB paths rides along (+g * stride)
+                for g in range(1, G.ngroups):
+                    other = name.replace(".mhca_blks.0.", f".mhca_blks.{g}.")
+                    o2, s2 = self._index[other]
+                    assert o2 == off + g * G.pgs and s2 == shape, (name, other)
+                    self._used_views[self._pid[other]] = (o2, s2)
+        return P(data, grad, G.pgs if G.ngroups > 1 else 0)
+
+    def _path_stride(self, stage: str) -> int:
+        """Distance in the flat arenas between the parameter blocks of two consecutive MB encoders of a stage."""
+        a = self._index[f"{stage}.mhca_blks.0.cpe.proj.weight"][0]
+        b = self._index[f"{stage}.mhca_blks.1.cpe.proj.weight"][0]
+        c = self._index[f"{stage}.mhca_blks.2.cpe.proj.weight"][0]
+        assert b - a == c - b and (b - a) % 8 == 0
+        return b - a
 
     def _run(self, x: torch.Tensor, record: bool):
         dev = x.device
@@ -421,7 +435,7 @@ def _bn(M, G, x, name, act, residual=None, out=None):
 
 def _mixffn(M, G, x, name, B, H, W, residual, out=None):
     """MixFFN_skip, MSTr.py:889-902 (fc1 evaluated once): fc2(GELU(LN(dw3x3(h) + h))) + residual."""
-    h = G.linear(x, *_lin(M, G, name + ".fc1"))
+    h = G.linear(x, *_lin(M, G, name + ".fc1"))                 # B = images per weight group (G.ngroups groups are stacked)
     d = G.dwconv(h, M._P(G, name + ".dwconv.dwconv.weight"), M._P(G, name + ".dwconv.dwconv.bias"), B, H, W, 3, 1, True)
     a = _ln(M, G, d, name + ".norm1", act=ACT_GELU)
     return G.linear(a, *_lin(M, G, name + ".fc2"), out=out, residual=residual)
@@ -451,18 +465,20 @@ def _eff_block(M, G, t: Var, name: str, B: int, H: int, W: int) -> Var:
     return _mixffn(M, G, n2, name + ".mlp", B, H, W, residual=tx)
 
 
-def _ripm(M, G, m: Var, name: str, B: int, side: int) -> Tuple[List[Var], int]:
-    """Patch_Embed_stage of DWConv2d_BN, MSTr.py:725-732, 355-362."""
-    outs, x = [], m
+def _ripm(M, G, m: Var, name: str, B: int, side: int) -> Tuple[Var, int]:
+    """Patch_Embed_stage of DWConv2d_BN, MSTr.py:725-732, 355-362.  Returns the three chained maps stacked [3*rows, C]."""
+    so = (side - 1) // 2 + 1
+    rows = B * so * so
+    stack = G.new(3 * rows, m.cols)
+    x = m
     for i in range(3):
         stride = 2 if i == 0 else 1
         pre = f"{name}.patch_embeds.{i}.patch_conv"
         y = G.dwconv(x, M._P(G, pre + ".dwconv.weight"), None, B, side, side, 3, stride)
         side = (side - 1) // stride + 1
         z = G.linear(y, *_lin(M, G, pre + ".pwconv", bias=False))
-        x = _bn(M, G, z, pre + ".bn", ACT_HSWISH)
-        outs.append(x)
-    return outs, side
+        x = _bn(M, G, z, pre + ".bn", ACT_HSWISH, out=stack.rowslice(i * rows, (i + 1) * rows))
+    return stack, side
 
 
 def _resblock(M, G, x: Var, name: str, B: int, side: int, out: Var) -> Var:
@@ -477,14 +493,15 @@ def _resblock(M, G, x: Var, name: str, B: int, side: int, out: Var) -> Var:
 def _factor_att(M, G, n: Var, blk: str, enc: str, B: int, side: int, residual: Optional[Var] = None) -> Var:
     """FactorAtt_ConvRelPosEnc + ConvRelPosEnc, MSTr.py:852-886, 801-823 (Appendix C.1-2), + residual add."""
     C, N = n.cols, side * side
-    rows, h, Ch = B * N, HEADS, n.cols // HEADS
+    Bt = B * G.ngroups                              # images of all stacked weight groups
+    rows, h, Ch = Bt * N, HEADS, n.cols // HEADS
     qkv = G.linear(n, *_lin(M, G, blk + ".factoratt_crpe.qkv"))
     q, k, v = qkv.colslice(0, C), qkv.colslice(C, 2 * C), qkv.colslice(2 * C, 3 * C)
-    ksm = G.softmax(k, B, 0)
-    ctx = G.new(B * h * Ch, Ch)
-    G.bmm(ksm, v, ctx, Ch, Ch, N, 1, 0, nb1=B, nb2=h, sA=(N * C, Ch), sB=(N * 3 * C, Ch), sC=(h * Ch * Ch, Ch * Ch))
+    ksm = G.softmax(k, Bt, 0)
+    ctx = G.new(Bt * h * Ch, Ch)
+    G.bmm(ksm, v, ctx, Ch, Ch, N, 1, 0, nb1=Bt, nb2=h, sA=(N * C, Ch), sB=(N * 3 * C, Ch), sC=(h * Ch * Ch, Ch * Ch))
     fa = G.new(rows, C)
-    G.bmm(q, ctx, fa, N, Ch, Ch, 0, 0, nb1=B, nb2=h, sA=(N * 3 * C, Ch), sB=(h * Ch * Ch, Ch * Ch), sC=(N * C, Ch))
+    G.bmm(q, ctx, fa, N, Ch, Ch, 0, 0, nb1=Bt, nb2=h, sA=(N * 3 * C, Ch), sB=(h * Ch * Ch, Ch * Ch), sC=(N * C, Ch))
     convv = G.new(rows, C)
     c0 = 0
     for i, (ksz, nh) in enumerate(CRPE_WINDOW):
@@ -517,19 +534,24 @@ def _coord_att(M, G, x: Var, name: str, B: int, side: int, out: Var) -> Var:
     return G.linear(gated, *_lin(M, G, name + ".conv_in_out"), out=out)
 
 
-def _mhca_stage(M, G, maps: List[Var], name: str, layers: int, B: int, side: int, out: Var) -> Var:
-    """MHCA_stage, MSTr.py:1412-1441: the four branch outputs are written into one [rows, 4C] buffer (no cat)."""
-    C = maps[0].cols
-    cat = G.new(B * side * side, 4 * C)
-    with G.parallel(3) as par:                      # the three MB paths (+ InvRes) are independent: one HIP stream each
-        for p in range(3):
-            with par.branch(p):
-                if p == 0:
-                    _resblock(M, G, maps[0], name + ".InvRes", B, side, cat.colslice(0, C))
-                t, enc = maps[p], f"{name}.mhca_blks.{p}"
+def _mhca_stage(M, G, stack: Var, name: str, layers: int, B: int, side: int, out: Var) -> Var:
+    """MHCA_stage, MSTr.py:1412-1441.  `stack` holds the three RIPM maps one after the other ([3*rows, C]); the three MB
+    encoders have identical shapes and their weights sit at a constant stride in the flat arena, so every kernel of the
+    MB blocks runs ONCE for all three paths (grouped weights) instead of three times.  The four branch outputs are written
+    side by side into one [rows, 4C] buffer (no torch.cat)."""
+    C = stack.cols
+    rows = B * side * side
+    cat = G.new(rows, 4 * C)
+    gs = M._path_stride(name)
+    enc = f"{name}.mhca_blks.0"
+    with G.parallel(2) as par:
+        with par.branch(0):
+            with G.grouped(3, gs):
+                t = stack
                 for l in range(layers):
-                    t = _mhca_block(M, G, t, f"{enc}.MHCA_layers.{l}", enc, B, side,
-                                    cat.colslice((p + 1) * C, (p + 2) * C) if l == layers - 1 else None)
+                    t = _mhca_block(M, G, t, f"{enc}.MHCA_layers.{l}", enc, B, side, cat.colslice(C, 4 * C) if l == layers - 1 else None)
+        with par.branch(1):
+            _resblock(M, G, stack.rowslice(0, rows), name + ".InvRes", B, side, cat.colslice(0, C))
     return _coord_att(M, G, cat, name + ".aggregate", B, side, out)
 
 
@@ -661,8 +683,8 @@ def _forward(M: MSTransception, G: Graph, x: torch.Tensor, B: int, in_ch: int, S
     m = _ln(M, G, t, "backbone.norm1", out=stage_map(Xb, 0))
     # stages 2-4 -- RIPM + MB transformer + IFF (MSTr.py:1728-1742)
     for s in (1, 2, 3):
-        maps, side = _ripm(M, G, m, f"backbone.patch_embed_stage{s + 1}", B, sides[s - 1])
-        m = _mhca_stage(M, G, maps, f"backbone.mhca_stage{s + 1}", LAYERS[s - 1], B, side, stage_map(Xb, s))
+        stack, side = _ripm(M, G, m, f"backbone.patch_embed_stage{s + 1}", B, sides[s - 1])
+        m = _mhca_stage(M, G, stack, f"backbone.mhca_stage{s + 1}", LAYERS[s - 1], B, side, stage_map(Xb, s))
     # Dual Transformer Bridge
     X = Xb
     for li in range(1, 5):
