@@ -46,7 +46,7 @@ def test_ctypes_binding_matches_header(built):
     for name, n in fns.items():
         assert len(_lib.SIGNATURES[name]) == n, f"{name}: header has {n} args, ctypes binding {len(_lib.SIGNATURES[name])}"
     assert len(_lib.TcGemm._fields_) == nfields
-    assert _lib.lib().tc_bn_scratch_floats(1000, 64) == 64 * (1 + 2 * 8)
+    assert _lib.lib().tc_bn_scratch_floats(1000, 64) == 64 * (1 + 2 * 16)
 
 
 def test_missing_library_fails_loudly(tmp_path):

@@ -268,11 +268,11 @@ int launch_strip(const void* x, int ldx, const void* w, const void* bias, const 
 #define TC_STRIP(KK, CPT)                                                                                                       \
     {                                                                                                                           \
         constexpr int RI = 256 / (64 / CPT);                                                                                    \
-        /* split rows into W-segments until ~64k threads exist (small maps are otherwise a handful of long serial walks) */  \
-        int nseg = (int)(65536LL / ((long long)nrows * groups * ((C + CPT - 1) / CPT)));                                                 \
-        const int maxseg = W / (KK + 4) > 0 ? W / (KK + 4) : 1;                                                                 \
+        /* split rows into W-segments until ~256k threads exist (few long serial walks leave most of the 256 CUs idle) */      \
+        int nseg = (int)(262144LL / ((long long)nrows * groups * ((C + CPT - 1) / CPT)));                                                 \
+        const int maxseg = W / (KK + 1) > 0 ? W / (KK + 1) : 1;                                                                 \
         nseg = nseg < 1 ? 1 : (nseg > maxseg ? maxseg : nseg);                                                                  \
-        dim3 grid(tc_blocks((long long)nrows * nseg, RI, MODE == 2 ? 512 : 4096), (C + 63) / 64, groups);                                \
+        dim3 grid(tc_blocks((long long)nrows * nseg, RI, MODE == 2 ? 1024 : 8192), (C + 63) / 64, groups);                                \
         hipLaunchKernelGGL((dw_strip_kernel<T, KK, CPT, MODE>), grid, dim3(256), 0, s, (const T*)x, ldx, (const T*)w, (const T*)bias, \
                            (const T*)dy, lddy, (T*)y, ldy, dw, db, B, H, W, C, add_input, accumulate, nseg, wstride);                    \
     }

@@ -2,7 +2,7 @@
 //   C[b] = alpha * op(A[b]) op(B[b]) (+bias) (+R) ; optional sigmoid ; optional accumulate / atomic accumulation.
 // Two matrix-core paths selected by the storage type:
 //   fp32 storage -> v_mfma_f32_32x32x2_f32  (exact fp32 products, the parity path),  K-slab 16
-//   bf16 storage -> v_mfma_f32_32x32x16_bf16 (fp32 accumulate),                       K-slab 32
+//   bf16 storage -> v_mfma_f32_32x32x16_bf16 (fp32 accumulate),                       K-slab 64
 // 256 threads = 4 waves (2 x 2); each wave owns a (BM/2) x (BN/2) sub-tile made of 32x32 MFMA blocks.  Operands are
 // staged through LDS "K-inner" (As[BM][BK+pad], Bs[BN][BK+pad]) whatever their global layout (transposed operands are
 // transposed on the LDS write), with a register prefetch of the next K-slab.  C may be fp32 while A/B are bf16
@@ -217,7 +217,7 @@ __device__ __forceinline__ uint4 load_strip8(const bf16_t* base, int ld, int x, 
 
 template <typename TC, int BM, int BN, bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmDev p) {
-    constexpr int BK = 32, LDT = BK + 8;                       // 80-byte rows: 16-B aligned, conflict-free b128 fragment reads
+    constexpr int BK = 64, LDT = BK + 8;                       // 144-byte rows: 16-B aligned, conflict-free b128 fragment reads
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int SA = BM * BK / 8 / 256, SB = BN * BK / 8 / 256;   // 8-element strips per thread
     static_assert(SA >= 1 && SB >= 1, "tile too small");
@@ -357,7 +357,7 @@ int gemm_typed(const TcGemm* g, hipStream_t s) {
     const long long big = (long long)((g->M + 127) / 128) * ((g->N + 127) / 128) * nb;
     const bool use128 = big >= 192 && g->M >= 96 && g->N >= 96;
     const int BM = use128 ? 128 : 64, BN = use128 ? 128 : 64;
-    constexpr int BK = sizeof(T) == 4 ? 16 : 32;
+    constexpr int BK = sizeof(T) == 4 ? 16 : 64;
     int kchunk = (g->K + g->splitk - 1) / g->splitk;
     kchunk = (kchunk + BK - 1) / BK * BK;
     d.kchunk = kchunk;

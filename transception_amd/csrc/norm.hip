@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
 
 // ---------------------------------------------------------------------------------------------- BatchNorm
 // scratch layout: shift[C] | S1[nchunk][C] | S2[nchunk][C]
-__host__ __device__ inline int bn_nchunk(int rows) { int n = (rows + 127) / 128; return n < 1 ? 1 : (n > 32 ? 32 : n); }
+__host__ __device__ inline int bn_nchunk(int rows) { int n = (rows + 63) / 64; return n < 1 ? 1 : (n > 128 ? 128 : n); }
 
 // mode 0 (forward stats):  S1 = sum(x - shift), S2 = sum((x-shift)^2), shift = x[0, c]
 // mode 1 (backward sums):  S1 = sum(dz), S2 = sum(dz * xhat), dz = dy * act'(z)
@@ -322,7 +322,7 @@ extern "C" int tc_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx
         return TC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int quads = C >> 2;
-#define TC_LNB(GS, NV) hipLaunchKernelGGL((ln_bwd_kernel<T, GS, NV>), dim3(tc_blocks(rows, (256 / GS) * 4, 256), groups), dim3(256),    \
+#define TC_LNB(GS, NV) hipLaunchKernelGGL((ln_bwd_kernel<T, GS, NV>), dim3(tc_blocks(rows, (256 / GS) * 4, 1024), groups), dim3(256),   \
                                           (size_t)(256 / GS) * 2 * C * sizeof(float), s, (const T*)dy, lddy, (const T*)x, ldx,            \
                                           (const T*)gamma, (const T*)beta, mean, rstd, (T*)dx, lddx, (const T*)dres, ldres, dgamma,      \
                                           dbeta, rows, C, act, pstride)
