@@ -134,10 +134,13 @@ int tc_bn_bwd(const void* dy, int lddy, const void* x, int ldx, const void* gamm
  * axis=1: over the contiguous columns; axis=0: over the rows (per column).
  * Replaces F.softmax / .softmax at MSTr.py:118-128 (EfficientAttention: keys over N, queries over C),
  *   :865 (FactorAtt k over N), :2322-2332 (channel attention on the flat re-view), :2283 (scores).
+ * axis=0 is split over row ranges (two passes through caller-provided fp32 scratch of tc_softmax_scratch_floats floats);
+ * scratch may be NULL for axis=1.
  */
-int tc_softmax_fwd(const void* x, void* y, int nb, long long sbx, long long sby, int R, int Ccols,
+long long tc_softmax_scratch_floats(int nb, int R, int Ccols);
+int tc_softmax_fwd(const void* x, void* y, float* scratch, int nb, long long sbx, long long sby, int R, int Ccols,
                    int ldx, int ldy, int axis, int dtype, void* stream);
-int tc_softmax_bwd(const void* dy, const void* y, void* dx, int nb, long long sbdy, long long sby,
+int tc_softmax_bwd(const void* dy, const void* y, void* dx, float* scratch, int nb, long long sbdy, long long sby,
                    long long sbdx, int R, int Ccols, int lddy, int ldy, int lddx, int axis, int accumulate,
                    int dtype, void* stream);
 

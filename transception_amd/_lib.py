@@ -41,8 +41,9 @@ SIGNATURES = {
     "tc_bn_scratch_floats": [i32, i32],
     "tc_bn_fwd": [vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, f32, f32, i32, i32, i32, vp],
     "tc_bn_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp],
-    "tc_softmax_fwd": [vp, vp, i32, i64, i64, i32, i32, i32, i32, i32, i32, vp],
-    "tc_softmax_bwd": [vp, vp, vp, i32, i64, i64, i64, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "tc_softmax_scratch_floats": [i32, i32, i32],
+    "tc_softmax_fwd": [vp, vp, vp, i32, i64, i64, i32, i32, i32, i32, i32, i32, vp],
+    "tc_softmax_bwd": [vp, vp, vp, vp, i32, i64, i64, i64, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "tc_attn_fwd": [vp, i32, i64, vp, i32, vp, i32, i64, vp, i32, i64, vp, i32, i32, i32, f32, i32, vp],
     "tc_attn_bwd": [vp, i32, i64, vp, i32, vp, i32, i64, vp, i32, i64, vp, i32, i64, vp, vp, vp, i32, i64, vp, i32,
                     vp, i32, i64, i32, i32, i32, i32, f32, i32, vp],
@@ -68,8 +69,8 @@ SIGNATURES = {
     "tc_sgd_step": [vp, vp, vp, i64, f32, vp, f32, f32, f32, i32, vp],
     "tc_cast": [vp, vp, i64, i32, i32, vp],
 }
-_RET = {"tc_bn_scratch_floats": i64}
-_RAW = {"tc_abi_version", "tc_bn_scratch_floats"}     # not status-returning
+_RET = {"tc_bn_scratch_floats": i64, "tc_softmax_scratch_floats": i64}
+_RAW = {"tc_abi_version", "tc_bn_scratch_floats", "tc_softmax_scratch_floats"}     # not status-returning
 
 
 class TcError(RuntimeError):

@@ -241,21 +241,29 @@ __global__ __launch_bounds__(256) void dw_strip_kernel(const T* __restrict__ x, 
         }
     }
     if (MODE == 2) {
-        __shared__ float red[RI][64];
+        // reduce over the row items of the block: lanes that hold the same channels are CGB apart inside a wave (xor
+        // shuffles), the four waves meet in LDS for all taps at once (two barriers instead of two per tap), then one
+        // atomic per channel and tap per block.
+        constexpr int NT = K * K + 1;
+        __shared__ float red[4][NT][64];
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
-        for (int t = 0; t <= K * K; ++t) {
+        for (int t = 0; t < NT; ++t) {
 #pragma unroll
-            for (int i = 0; i < CPT; ++i) red[ri][cgl * CPT + i] = (t < K * K) ? acc[t < K * K ? t : 0][i] : accb[i];
-            __syncthreads();
-            if (threadIdx.x < 64 && blockIdx.y * 64 + threadIdx.x < C) {
-                float s_ = 0.f;
+            for (int i = 0; i < CPT; ++i) {
+                float v = (t < K * K) ? acc[t < K * K ? t : 0][i] : accb[i];
 #pragma unroll
-                for (int r = 0; r < RI; ++r) s_ += red[r][threadIdx.x];
-                const int cc = blockIdx.y * 64 + threadIdx.x;
-                if (t < K * K) atomicAdd(dw + (long long)cc * K * K + t, s_);
-                else if (db) atomicAdd(db + cc, s_);
+                for (int o = CGB; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+                if (lane < CGB) red[wave][t][cgl * CPT + i] = v;
             }
-            __syncthreads();
+        }
+        __syncthreads();
+        for (int f = threadIdx.x; f < NT * 64; f += 256) {
+            const int cc = f / NT, t = f - cc * NT, ch = blockIdx.y * 64 + cc;      // taps fastest: neighbouring lanes hit neighbouring dw words
+            if (ch >= C) continue;
+            const float s_ = red[0][t][cc] + red[1][t][cc] + red[2][t][cc] + red[3][t][cc];
+            if (t < K * K) atomicAdd(dw + (long long)ch * K * K + t, s_);
+            else if (db) atomicAdd(db + ch, s_);
         }
     }
 }
@@ -272,7 +280,7 @@ int launch_strip(const void* x, int ldx, const void* w, const void* bias, const 
         int nseg = (int)(262144LL / ((long long)nrows * groups * ((C + CPT - 1) / CPT)));                                                 \
         const int maxseg = W / (KK + 1) > 0 ? W / (KK + 1) : 1;                                                                 \
         nseg = nseg < 1 ? 1 : (nseg > maxseg ? maxseg : nseg);                                                                  \
-        dim3 grid(tc_blocks((long long)nrows * nseg, RI, MODE == 2 ? 1024 : 8192), (C + 63) / 64, groups);                                \
+        dim3 grid(tc_blocks((long long)nrows * nseg, RI, MODE == 2 ? 512 : 8192), (C + 63) / 64, groups);                                \
         hipLaunchKernelGGL((dw_strip_kernel<T, KK, CPT, MODE>), grid, dim3(256), 0, s, (const T*)x, ldx, (const T*)w, (const T*)bias, \
                            (const T*)dy, lddy, (T*)y, ldy, dw, db, B, H, W, C, add_input, accumulate, nseg, wstride);                    \
     }

@@ -21,15 +21,79 @@ struct GemmDev {
     int nb2, splitk, kchunk;
     long long sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2;
     float alpha; int accumulate, act;
-    int vecA, vecB, atomic;
+    int vecA, vecB, vecC, atomic;
     float* rowsum;          // optional: rowsum[m] += sum_k op(A)[m][k]  (fp32, atomics)
     long long sBias1, sRow1; // batch-level-1 strides of bias / rowsum (grouped weights)
 };
 
 // ---------------------------------------------------------------------------------------------- shared epilogue
-// acc[r] of a 32x32 block holds row (r&3) + 8*(r>>2) + 4*(lane>>5), column lane&31
+// The MFMAs are issued with swapped operands (D^T = B^T A^T), so a lane owns ONE output row m = lane&31 of its 32x32
+// block and register r holds column n = (r&3) + 8*(r>>2) + 4*(lane>>5): four consecutive columns per register group,
+// i.e. 8-byte (bf16) / 16-byte (fp32) row-major stores instead of 2-byte ones.
 template <typename T, typename TC, int TM, int TN>
-__device__ __forceinline__ void epilogue(const GemmDev& p, f32x16 (&acc)[TM][TN], int b1, int b2, int ks, int mbase, int nbase, int lane) {
+__device__ __forceinline__ void epilogue_rows(const GemmDev& p, f32x16 (&acc)[TM][TN], int b1, int b2, int ks, int mbase, int nbase, int lane) {
+    TC* C = reinterpret_cast<TC*>(p.C) + b1 * p.sC1 + b2 * p.sC2;
+    const T* R = p.R ? reinterpret_cast<const T*>(p.R) + b1 * p.sR1 + b2 * p.sR2 : nullptr;
+    const T* bias = p.bias ? reinterpret_cast<const T*>(p.bias) + b1 * p.sBias1 : nullptr;
+    const bool first_split = (ks == 0);
+    const int h = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = mbase + i * 32 + (lane & 31);
+        if (row >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = nbase + j * 32 + 8 * g + 4 * h;
+                if (col >= p.N) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = p.alpha * acc[i][j][4 * g + e];
+                TC* c = C + (long long)row * p.ldc + col;
+                if (col + 3 < p.N && p.vecC) {
+                    if (bias && first_split) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += ldf<T>(bias + col + e);
+                    }
+                    if (R && first_split) {
+                        const float4 r4 = ld4<T>(R + (long long)row * p.ldr + col);
+                        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+                    }
+                    if (p.atomic) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) atomicAdd(reinterpret_cast<float*>(c) + e, v[e]);
+                    } else {
+                        if (p.act == TC_ACT_SIGMOID) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = sigmoid_f(v[e]);
+                        }
+                        if (p.accumulate) { const float4 o = ld4<TC>(c); v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
+                        st4<TC>(c, make_float4(v[0], v[1], v[2], v[3]));
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (col + e >= p.N) continue;
+                        float w = v[e];
+                        if (bias && first_split) w += ldf<T>(bias + col + e);
+                        if (R && first_split) w += ldf<T>(R + (long long)row * p.ldr + col + e);
+                        if (p.atomic) atomicAdd(reinterpret_cast<float*>(c) + e, w);
+                        else {
+                            if (p.act == TC_ACT_SIGMOID) w = sigmoid_f(w);
+                            if (p.accumulate) w += ldf<TC>(c + e);
+                            stf<TC>(c + e, w);
+                        }
+                    }
+                }
+            }
+    }
+}
+
+// Un-swapped orientation (fp32 C: weight gradients, fp32 storage): register r holds row (r&3) + 8*(r>>2) + 4*(lane>>5), the
+// 32 lanes of a half-wave hold 32 consecutive columns -> 128-byte coalesced fp32 stores / atomics.
+template <typename T, typename TC, int TM, int TN>
+__device__ __forceinline__ void epilogue_cols(const GemmDev& p, f32x16 (&acc)[TM][TN], int b1, int b2, int ks, int mbase, int nbase, int lane) {
     TC* C = reinterpret_cast<TC*>(p.C) + b1 * p.sC1 + b2 * p.sC2;
     const T* R = p.R ? reinterpret_cast<const T*>(p.R) + b1 * p.sR1 + b2 * p.sR2 : nullptr;
     const T* bias = p.bias ? reinterpret_cast<const T*>(p.bias) + b1 * p.sBias1 : nullptr;
@@ -49,7 +113,7 @@ __device__ __forceinline__ void epilogue(const GemmDev& p, f32x16 (&acc)[TM][TN]
                 if (R && first_split) v += ldf<T>(R + (long long)row * p.ldr + col);
                 TC* c = C + (long long)row * p.ldc + col;
                 if (p.atomic) {
-                    atomicAdd(reinterpret_cast<float*>(c), v);       // fp32 C only (checked on the host)
+                    atomicAdd(reinterpret_cast<float*>(c), v);
                 } else {
                     if (p.act == TC_ACT_SIGMOID) v = sigmoid_f(v);
                     if (p.accumulate) v += ldf<TC>(c);
@@ -185,7 +249,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev p) {
         __syncthreads();
     }
     if (do_rowsum && m0 + tid < p.M) atomicAdd(p.rowsum + b1 * p.sRow1 + m0 + tid, rsum);
-    epilogue<float, TC, TM, TN>(p, acc, b1, b2, ks, m0 + wr * WM, n0 + wc * WN, lane);
+    epilogue_cols<float, TC, TM, TN>(p, acc, b1, b2, ks, m0 + wr * WM, n0 + wc * WN, lane);
 }
 
 // ---------------------------------------------------------------------------------------------- bf16 path
@@ -218,6 +282,7 @@ __device__ __forceinline__ uint4 load_strip8(const bf16_t* base, int ld, int x, 
 template <typename TC, int BM, int BN, bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmDev p) {
     constexpr int BK = 64, LDT = BK + 8;                       // 144-byte rows: 16-B aligned, conflict-free b128 fragment reads
+    constexpr bool SWAP = sizeof(TC) == 2;                     // bf16 output: lane owns a row (8-byte stores); fp32 output: coalesced columns
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int SA = BM * BK / 8 / 256, SB = BN * BK / 8 / 256;   // 8-element strips per thread
     static_assert(SA >= 1 && SB >= 1, "tile too small");
@@ -311,12 +376,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmDev p) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0)      // D^T: lane = output row
+                                     : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
     }
     if (do_rowsum && m0 + tid < p.M) atomicAdd(p.rowsum + b1 * p.sRow1 + m0 + tid, rsum);
-    epilogue<bf16_t, TC, TM, TN>(p, acc, b1, b2, ks, m0 + wr * WM, n0 + wc * WN, lane);
+    if (SWAP) epilogue_rows<bf16_t, TC, TM, TN>(p, acc, b1, b2, ks, m0 + wr * WM, n0 + wc * WN, lane);
+    else epilogue_cols<bf16_t, TC, TM, TN>(p, acc, b1, b2, ks, m0 + wr * WM, n0 + wc * WN, lane);
 }
 
 // ---------------------------------------------------------------------------------------------- host side
@@ -353,6 +420,12 @@ int gemm_typed(const TcGemm* g, hipStream_t s) {
     };
     d.vecA = aligned(g->A, g->lda, g->sA1, g->sA2);
     d.vecB = aligned(g->B, g->ldb, g->sB1, g->sB2);
+    {   // 4-wide epilogue accesses: C (fp32 or T) and R (T) rows must be 4-element aligned
+        const int csz = g->c_f32 ? 4 : (int)sizeof(T);
+        const bool cok = ((uintptr_t)g->C % (4 * csz) == 0) && (g->ldc % 4 == 0) && (g->sC1 % 4 == 0) && (g->sC2 % 4 == 0);
+        const bool rok = !g->R || (((uintptr_t)g->R % (4 * sizeof(T)) == 0) && (g->ldr % 4 == 0) && (g->sR1 % 4 == 0) && (g->sR2 % 4 == 0));
+        d.vecC = cok && rok;
+    }
     const int nb = g->nb1 * g->nb2;
     const long long big = (long long)((g->M + 127) / 128) * ((g->N + 127) / 128) * nb;
     const bool use128 = big >= 192 && g->M >= 96 && g->N >= 96;

@@ -222,24 +222,37 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
                                                        int act) {
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;       // 16 channel quads x 16 row lanes
     const int c = blockIdx.y * 64 + tx * 4;
+    __shared__ float psum[2][4][64];
+    __shared__ float stat[2][64];
+    if (training) {
+        // fold the per-chunk partials once per block: thread (channel = tid % 64, quarter = tid / 64)
+        const int cc = threadIdx.x & 63, part = threadIdx.x >> 6, ch = blockIdx.y * 64 + cc;
+        float s1 = 0.f, s2 = 0.f;
+        if (ch < C)
+            for (int k = part; k < nchunk; k += 4) { s1 += scratch[C + k * C + ch]; s2 += scratch[C + nchunk * C + k * C + ch]; }
+        psum[0][part][cc] = s1; psum[1][part][cc] = s2;
+        __syncthreads();
+        if (threadIdx.x < 64 && ch < C) {
+            s1 = psum[0][0][cc] + psum[0][1][cc] + psum[0][2][cc] + psum[0][3][cc];
+            s2 = psum[1][0][cc] + psum[1][1][cc] + psum[1][2][cc] + psum[1][3][cc];
+            const float m1 = s1 / (float)rows;
+            const float var = fmaxf(s2 / (float)rows - m1 * m1, 0.f);
+            const float mean_ = scratch[ch] + m1, rstd_ = rsqrtf(var + eps);
+            stat[0][cc] = mean_; stat[1][cc] = rstd_;
+            if (blockIdx.x == 0) {
+                save_mean[ch] = mean_; save_rstd[ch] = rstd_;
+                const float unbiased = rows > 1 ? var * (float)rows / (float)(rows - 1) : var;
+                running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * mean_;
+                running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * unbiased;
+            }
+        }
+        __syncthreads();
+    }
     if (c >= C) return;
     float mu[4], rs[4];
     if (training) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float s1 = 0.f, s2 = 0.f;
-            for (int k = 0; k < nchunk; ++k) { s1 += scratch[C + k * C + c + j]; s2 += scratch[C + nchunk * C + k * C + c + j]; }
-            const float m1 = s1 / (float)rows;
-            const float var = fmaxf(s2 / (float)rows - m1 * m1, 0.f);
-            mu[j] = scratch[c + j] + m1;
-            rs[j] = rsqrtf(var + eps);
-            if (blockIdx.x == 0 && ty == 0) {
-                save_mean[c + j] = mu[j]; save_rstd[c + j] = rs[j];
-                const float unbiased = rows > 1 ? var * (float)rows / (float)(rows - 1) : var;
-                running_mean[c + j] = (1.f - momentum) * running_mean[c + j] + momentum * mu[j];
-                running_var[c + j] = (1.f - momentum) * running_var[c + j] + momentum * unbiased;
-            }
-        }
+        for (int j = 0; j < 4; ++j) { mu[j] = stat[0][tx * 4 + j]; rs[j] = stat[1][tx * 4 + j]; }
     } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) { mu[j] = running_mean[c + j]; rs[j] = rsqrtf(running_var[c + j] + eps); }
@@ -265,6 +278,22 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            int act, int accumulate) {
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int c = blockIdx.y * 64 + tx * 4;
+    __shared__ float psum[2][4][64];
+    {
+        const int cc = threadIdx.x & 63, part = threadIdx.x >> 6, ch = blockIdx.y * 64 + cc;
+        float s1 = 0.f, s2 = 0.f;
+        if (ch < C)
+            for (int k = part; k < nchunk; k += 4) { s1 += scratch[C + k * C + ch]; s2 += scratch[C + nchunk * C + k * C + ch]; }
+        psum[0][part][cc] = s1; psum[1][part][cc] = s2;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            s1 = psum[0][0][cc] + psum[0][1][cc] + psum[0][2][cc] + psum[0][3][cc];
+            s2 = psum[1][0][cc] + psum[1][1][cc] + psum[1][2][cc] + psum[1][3][cc];
+            psum[0][0][cc] = s1; psum[1][0][cc] = s2;
+            if (blockIdx.x == 0 && ch < C) { dgamma[ch] += s2; dbeta[ch] += s1; }
+        }
+        __syncthreads();
+    }
     if (c >= C) return;
     float mu[4], rs[4], m1[4], m2[4], gam[4], bet[4];
     const float4 g = ld4<T>(gamma + c), b = ld4<T>(beta + c);
@@ -272,11 +301,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     bet[0] = b.x; bet[1] = b.y; bet[2] = b.z; bet[3] = b.w;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        float s1 = 0.f, s2 = 0.f;
-        for (int k = 0; k < nchunk; ++k) { s1 += scratch[C + k * C + c + j]; s2 += scratch[C + nchunk * C + k * C + c + j]; }
         mu[j] = save_mean[c + j]; rs[j] = save_rstd[c + j];
-        m1[j] = s1 / (float)rows; m2[j] = s2 / (float)rows;
-        if (blockIdx.x == 0 && ty == 0) { dgamma[c + j] += s2; dbeta[c + j] += s1; }
+        m1[j] = psum[0][0][tx * 4 + j] / (float)rows; m2[j] = psum[1][0][tx * 4 + j] / (float)rows;
     }
     for (int r = blockIdx.x * 16 + ty; r < rows; r += gridDim.x * 16) {
         const float4 xv = ld4<T>(x + (long long)r * ldx + c);

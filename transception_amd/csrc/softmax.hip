@@ -58,27 +58,65 @@ __device__ __forceinline__ float4 block_reduce16(float4 v, float4 (*sm)[16], int
     return r;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void softmax_cols_fwd(const T* __restrict__ x, T* __restrict__ y, long long sbx, long long sby,
-                                                        int R, int Cc, int ldx, int ldy) {
+// Column softmax (over the rows of each [R, Ccols] matrix) split over row ranges so that tall-skinny matrices (R = tokens,
+// Ccols = 64) fill the chip: pass 1 writes per-range partial statistics, pass 2 folds them (a few values per column) and
+// normalises its own rows.  scratch: fp32 [nb][RS][2][Ccols].
+//   forward  : partial (max, sum exp(x - max))            backward: partial sum(dy * y)
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void softmax_cols_stats(const T* __restrict__ x, const T* __restrict__ y2, float* __restrict__ scratch,
+                                                          long long sbx, long long sby2, int R, int Cc, int ldx, int ldy2, int rper) {
     __shared__ float4 sm[16][16];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int c = blockIdx.x * 64 + tx * 4;
     const bool ok = c < Cc;
+    const int RS = gridDim.z, rs = blockIdx.z;
+    const int r0 = rs * rper, r1 = min(R, r0 + rper);
     const T* xb = x + blockIdx.y * sbx + (ok ? c : 0);
-    T* yb = y + blockIdx.y * sby + (ok ? c : 0);
-    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-    if (ok) for (int r = ty; r < R; r += 16) m = f4max(m, ld4<T>(xb + (long long)r * ldx));
-    m = block_reduce16<true>(m, sm, tx, ty);
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ok) for (int r = ty; r < R; r += 16) {
-        const float4 v = ld4<T>(xb + (long long)r * ldx);
-        s.x += __expf(v.x - m.x); s.y += __expf(v.y - m.y); s.z += __expf(v.z - m.z); s.w += __expf(v.w - m.w);
+    float* sc = scratch + ((long long)blockIdx.y * RS + rs) * 2 * Cc;
+    if (!BWD) {
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        if (ok) for (int r = r0 + ty; r < r1; r += 16) m = f4max(m, ld4<T>(xb + (long long)r * ldx));
+        m = block_reduce16<true>(m, sm, tx, ty);
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) for (int r = r0 + ty; r < r1; r += 16) {
+            const float4 v = ld4<T>(xb + (long long)r * ldx);
+            s.x += __expf(v.x - m.x); s.y += __expf(v.y - m.y); s.z += __expf(v.z - m.z); s.w += __expf(v.w - m.w);
+        }
+        s = block_reduce16<false>(s, sm, tx, ty);
+        if (ok && ty == 0) { *reinterpret_cast<float4*>(sc + c) = m; *reinterpret_cast<float4*>(sc + Cc + c) = s; }
+    } else {
+        const T* yb = y2 + blockIdx.y * sby2 + (ok ? c : 0);
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) for (int r = r0 + ty; r < r1; r += 16) {
+            const float4 a = ld4<T>(xb + (long long)r * ldx), p = ld4<T>(yb + (long long)r * ldy2);
+            s.x += a.x * p.x; s.y += a.y * p.y; s.z += a.z * p.z; s.w += a.w * p.w;
+        }
+        s = block_reduce16<false>(s, sm, tx, ty);
+        if (ok && ty == 0) *reinterpret_cast<float4*>(sc + c) = s;
     }
-    s = block_reduce16<false>(s, sm, tx, ty);
-    if (!ok) return;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_cols_fwd(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ scratch,
+                                                        long long sbx, long long sby, int R, int Cc, int ldx, int ldy, int rper) {
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + tx * 4;
+    if (c >= Cc) return;
+    const int RS = gridDim.z, rs = blockIdx.z;
+    const float* sc = scratch + (long long)blockIdx.y * RS * 2 * Cc;
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    for (int k = 0; k < RS; ++k) m = f4max(m, *reinterpret_cast<const float4*>(sc + (long long)k * 2 * Cc + c));
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < RS; ++k) {
+        const float4 mk = *reinterpret_cast<const float4*>(sc + (long long)k * 2 * Cc + c);
+        const float4 sk = *reinterpret_cast<const float4*>(sc + (long long)k * 2 * Cc + Cc + c);
+        s.x += sk.x * __expf(mk.x - m.x); s.y += sk.y * __expf(mk.y - m.y); s.z += sk.z * __expf(mk.z - m.z); s.w += sk.w * __expf(mk.w - m.w);
+    }
     s.x = 1.f / s.x; s.y = 1.f / s.y; s.z = 1.f / s.z; s.w = 1.f / s.w;
-    for (int r = ty; r < R; r += 16) {
+    const T* xb = x + blockIdx.y * sbx + c;
+    T* yb = y + blockIdx.y * sby + c;
+    const int r0 = rs * rper, r1 = min(R, r0 + rper);
+    for (int r = r0 + ty; r < r1; r += 16) {
         float4 v = ld4<T>(xb + (long long)r * ldx);
         v.x = __expf(v.x - m.x) * s.x; v.y = __expf(v.y - m.y) * s.y; v.z = __expf(v.z - m.z) * s.z; v.w = __expf(v.w - m.w) * s.w;
         st4<T>(yb + (long long)r * ldy, v);
@@ -87,23 +125,20 @@ __global__ __launch_bounds__(256) void softmax_cols_fwd(const T* __restrict__ x,
 
 template <typename T>
 __global__ __launch_bounds__(256) void softmax_cols_bwd(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx,
-                                                        long long sbdy, long long sby, long long sbdx, int R, int Cc, int lddy,
-                                                        int ldy, int lddx, int accumulate) {
-    __shared__ float4 sm[16][16];
+                                                        const float* __restrict__ scratch, long long sbdy, long long sby, long long sbdx, int R,
+                                                        int Cc, int lddy, int ldy, int lddx, int accumulate, int rper) {
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int c = blockIdx.x * 64 + tx * 4;
-    const bool ok = c < Cc;
-    const T* dyb = dy + blockIdx.y * sbdy + (ok ? c : 0);
-    const T* yb = y + blockIdx.y * sby + (ok ? c : 0);
-    T* dxb = dx + blockIdx.y * sbdx + (ok ? c : 0);
+    if (c >= Cc) return;
+    const int RS = gridDim.z, rs = blockIdx.z;
+    const float* sc = scratch + (long long)blockIdx.y * RS * 2 * Cc;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ok) for (int r = ty; r < R; r += 16) {
-        const float4 a = ld4<T>(dyb + (long long)r * lddy), p = ld4<T>(yb + (long long)r * ldy);
-        s.x += a.x * p.x; s.y += a.y * p.y; s.z += a.z * p.z; s.w += a.w * p.w;
-    }
-    s = block_reduce16<false>(s, sm, tx, ty);
-    if (!ok) return;
-    for (int r = ty; r < R; r += 16) {
+    for (int k = 0; k < RS; ++k) s = f4add(s, *reinterpret_cast<const float4*>(sc + (long long)k * 2 * Cc + c));
+    const T* dyb = dy + blockIdx.y * sbdy + c;
+    const T* yb = y + blockIdx.y * sby + c;
+    T* dxb = dx + blockIdx.y * sbdx + c;
+    const int r0 = rs * rper, r1 = min(R, r0 + rper);
+    for (int r = r0 + ty; r < r1; r += 16) {
         const float4 a = ld4<T>(dyb + (long long)r * lddy), p = ld4<T>(yb + (long long)r * ldy);
         float4 o = make_float4(p.x * (a.x - s.x), p.y * (a.y - s.y), p.z * (a.z - s.z), p.w * (a.w - s.w));
         if (accumulate) { const float4 q = ld4<T>(dxb + (long long)r * lddx); o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w; }
@@ -111,35 +146,61 @@ __global__ __launch_bounds__(256) void softmax_cols_bwd(const T* __restrict__ dy
     }
 }
 
+inline int cols_rsplit(int R, int& rper) {
+    int RS = (R + 127) / 128;
+    if (RS > 64) RS = 64;
+    if (RS < 1) RS = 1;
+    rper = (R + RS - 1) / RS;
+    return (R + rper - 1) / rper;
+}
+
 }  // namespace
 
-extern "C" int tc_softmax_fwd(const void* x, void* y, int nb, long long sbx, long long sby, int R, int Cc, int ldx, int ldy,
+extern "C" long long tc_softmax_scratch_floats(int nb, int R, int Cc) {
+    int rper;
+    return (long long)nb * cols_rsplit(R, rper) * 2 * Cc;
+}
+
+extern "C" int tc_softmax_fwd(const void* x, void* y, float* scratch, int nb, long long sbx, long long sby, int R, int Cc, int ldx, int ldy,
                               int axis, int dtype, void* stream) {
     if (!x || !y || nb <= 0 || R <= 0 || Cc <= 0 || (axis != 0 && axis != 1)) return TC_ERR_ARG;
-    if (axis == 0 && ((Cc & 3) || (ldx & 3) || (ldy & 3) || (sbx & 3) || (sby & 3))) return TC_ERR_ARG;
+    if (axis == 0 && (!scratch || (Cc & 3) || (ldx & 3) || (ldy & 3) || (sbx & 3) || (sby & 3))) return TC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const long long nrows = (long long)nb * R;
     TC_DISPATCH_DTYPE(dtype, {
         if (axis == 1) hipLaunchKernelGGL((softmax_rows_fwd<T>), dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, s, (const T*)x,
                                           (T*)y, sbx, sby, R, Cc, ldx, ldy, nrows);
-        else hipLaunchKernelGGL((softmax_cols_fwd<T>), dim3((Cc + 63) / 64, nb), dim3(256), 0, s, (const T*)x, (T*)y, sbx, sby, R,
-                                Cc, ldx, ldy);
+        else {
+            int rper;
+            const int RS = cols_rsplit(R, rper);
+            dim3 grid((Cc + 63) / 64, nb, RS);
+            hipLaunchKernelGGL((softmax_cols_stats<T, false>), grid, dim3(256), 0, s, (const T*)x, (const T*)nullptr, scratch, sbx, 0LL, R, Cc,
+                               ldx, 0, rper);
+            hipLaunchKernelGGL((softmax_cols_fwd<T>), grid, dim3(256), 0, s, (const T*)x, (T*)y, scratch, sbx, sby, R, Cc, ldx, ldy, rper);
+        }
     });
     return tc_launch_status();
 }
 
-extern "C" int tc_softmax_bwd(const void* dy, const void* y, void* dx, int nb, long long sbdy, long long sby, long long sbdx,
+extern "C" int tc_softmax_bwd(const void* dy, const void* y, void* dx, float* scratch, int nb, long long sbdy, long long sby, long long sbdx,
                               int R, int Cc, int lddy, int ldy, int lddx, int axis, int accumulate, int dtype, void* stream) {
     if (!dy || !y || !dx || nb <= 0 || R <= 0 || Cc <= 0 || (axis != 0 && axis != 1)) return TC_ERR_ARG;
-    if (axis == 0 && ((Cc & 3) || (lddy & 3) || (ldy & 3) || (lddx & 3) || (sbdy & 3) || (sby & 3) || (sbdx & 3)))
+    if (axis == 0 && (!scratch || (Cc & 3) || (lddy & 3) || (ldy & 3) || (lddx & 3) || (sbdy & 3) || (sby & 3) || (sbdx & 3)))
         return TC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const long long nrows = (long long)nb * R;
     TC_DISPATCH_DTYPE(dtype, {
         if (axis == 1) hipLaunchKernelGGL((softmax_rows_bwd<T>), dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, s, (const T*)dy,
                                           (const T*)y, (T*)dx, sbdy, sby, sbdx, R, Cc, lddy, ldy, lddx, nrows, accumulate);
-        else hipLaunchKernelGGL((softmax_cols_bwd<T>), dim3((Cc + 63) / 64, nb), dim3(256), 0, s, (const T*)dy, (const T*)y,
-                                (T*)dx, sbdy, sby, sbdx, R, Cc, lddy, ldy, lddx, accumulate);
+        else {
+            int rper;
+            const int RS = cols_rsplit(R, rper);
+            dim3 grid((Cc + 63) / 64, nb, RS);
+            hipLaunchKernelGGL((softmax_cols_stats<T, true>), grid, dim3(256), 0, s, (const T*)dy, (const T*)y, scratch, sbdy, sby, R, Cc, lddy,
+                               ldy, rper);
+            hipLaunchKernelGGL((softmax_cols_bwd<T>), grid, dim3(256), 0, s, (const T*)dy, (const T*)y, (T*)dx, scratch, sbdy, sby, sbdx, R, Cc,
+                               lddy, ldy, lddx, accumulate, rper);
+        }
     });
     return tc_launch_status();
 }

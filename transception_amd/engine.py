@@ -480,7 +480,8 @@ class Graph:
         R, Cc = x.rows // nb, x.cols
         if out is None:
             out = self.new(x.rows, Cc)
-        self.L.tc_softmax_fwd(_ptr(x.data), _ptr(out.data), nb, R * x.ld, R * out.ld, R, Cc, x.ld, out.ld, axis, self.dt,
+        scr = self.f32(int(self.L.tc_softmax_scratch_floats(nb, R, Cc))) if axis == 0 else None
+        self.L.tc_softmax_fwd(_ptr(x.data), _ptr(out.data), _ptr(scr), nb, R * x.ld, R * out.ld, R, Cc, x.ld, out.ld, axis, self.dt,
                               self.stream)
 
         def bwd():
@@ -488,8 +489,8 @@ class Graph:
             if dy is None:
                 return
             gx, acc = self.wgrad(x)
-            self.L.tc_softmax_bwd(_ptr(dy), _ptr(out.data), _ptr(gx), nb, R * dy.stride(0), R * out.ld, R * gx.stride(0), R, Cc,
-                                  dy.stride(0), out.ld, gx.stride(0), axis, acc, self.dt, self.stream)
+            self.L.tc_softmax_bwd(_ptr(dy), _ptr(out.data), _ptr(gx), _ptr(scr), nb, R * dy.stride(0), R * out.ld, R * gx.stride(0), R,
+                                  Cc, dy.stride(0), out.ld, gx.stride(0), axis, acc, self.dt, self.stream)
         self._rec(bwd)
         return out
 
@@ -497,8 +498,23 @@ class Graph:
             sA=(0, 0), sB=(0, 0), sC=(0, 0), alpha: float = 1.0) -> Var:
         """out[b] = alpha * op(A[b]) op(B[b]); A/B/out are 2-D views whose data pointer is batch (0,0)."""
         assert not (tA and tB)
-        self._gemm(_ptr(A.data), A.ld, _ptr(B.data), B.ld, _ptr(out.data), out.ld, M, N, K, tA, tB, alpha=alpha, nb1=nb1,
-                   nb2=nb2, sA=sA, sB=sB, sC=sC)
+        tiles = ((M + 63) // 64) * ((N + 63) // 64) * nb1 * nb2
+        if tiles < 128 and K >= 1024 and out.data.is_contiguous() and out.is_whole:
+            # a handful of output tiles with a long reduction (token-reduced context matrices): split K over many workgroups,
+            # fp32 atomics into a zeroed buffer, then one cast -- 3 short launches instead of one 100-400 us serial one
+            sk = max(1, min(K // 256, 1024 // tiles))
+            if self.dtype == torch.float32:
+                out.data.zero_()
+                self._gemm(_ptr(A.data), A.ld, _ptr(B.data), B.ld, _ptr(out.data), out.ld, M, N, K, tA, tB, alpha=alpha, nb1=nb1,
+                           nb2=nb2, sA=sA, sB=sB, sC=sC, acc=1, splitk=sk)
+            else:
+                tmp = torch.zeros(out.data.shape, dtype=torch.float32, device=self.dev)
+                self._gemm(_ptr(A.data), A.ld, _ptr(B.data), B.ld, _ptr(tmp), out.ld, M, N, K, tA, tB, alpha=alpha, nb1=nb1,
+                           nb2=nb2, sA=sA, sB=sB, sC=sC, acc=1, splitk=sk, c_f32=1)
+                self.L.tc_cast(_ptr(tmp), _ptr(out.data), tmp.numel(), TC_F32, TC_BF16, self.stream)
+        else:
+            self._gemm(_ptr(A.data), A.ld, _ptr(B.data), B.ld, _ptr(out.data), out.ld, M, N, K, tA, tB, alpha=alpha, nb1=nb1,
+                       nb2=nb2, sA=sA, sB=sB, sC=sC)
 
         def bwd():
             dC = self.grad_of(out)
