@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-attn-events", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying the captured hipGraph")
+    ap.add_argument("--force-split", action="store_true", help="use the 3-graph multi-GPU step structure even on one GPU")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -144,7 +145,7 @@ def main():
     if args.eager:
         step = lambda: train_step(model, loss_fn, opt, x, y, group)
     else:
-        step = GraphedStep(model, loss_fn, opt, x, y, group, warmup=2)      # capture (2 eager steps first), then replay
+        step = GraphedStep(model, loss_fn, opt, x, y, group, warmup=2, force_split=args.force_split)   # capture, then replay
     for i in range(args.warmup):
         step()
         opt.set_lr(cosine_lr(0.05, i + 1, t_max))

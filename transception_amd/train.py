@@ -164,43 +164,84 @@ def train_step(model, loss_fn: SegLoss, opt: FusedSGD, images: torch.Tensor, lab
 
 
 class GraphedStep:
-    """A whole training step (forward, loss, backward, SGD) captured once into a hipGraph and replayed: ~3400 kernel
-    launches per step become one graph launch, removing the host from the loop.  Inputs are copied into static buffers;
-    the learning rate is a device scalar (FusedSGD.set_lr).  For world > 1 the gradient all-reduce stays outside the
-    graphs: graph A = forward+loss+backward, RCCL all-reduce on the flat arena, graph B = SGD."""
+    """A whole training step captured into hipGraphs and replayed: ~1800 kernel launches per step become graph launches,
+    removing the host from the loop.  Inputs are copied into static buffers; the learning rate is a device scalar
+    (FusedSGD.set_lr).
 
-    def __init__(self, model, loss_fn: SegLoss, opt: FusedSGD, images: torch.Tensor, labels: torch.Tensor, group=None, warmup: int = 3):
+    world == 1: ONE graph = zero_grad + forward + loss + backward + SGD (through torch.autograd).
+    world  > 1: no collective is ever captured.  Three graphs with the two RCCL all-reduces between them, driven through
+    the engine directly (no autograd):  A = zero_grad + forward + per-pixel softmax / CE / Dice partial sums;
+    all-reduce(28 floats);  B = loss gradient + backward tape;  all-reduce(flat gradient arena);  C = fused SGD."""
+
+    def __init__(self, model, loss_fn: SegLoss, opt: FusedSGD, images: torch.Tensor, labels: torch.Tensor, group=None, warmup: int = 3,
+                 force_split: bool = False):
         self.model, self.loss_fn, self.opt, self.group = model, loss_fn, opt, group
-        self.x, self.y = images.clone(), labels.clone()
+        self.x, self.y = images.clone(), labels.clone().long().contiguous()
         self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.split = self.distributed or force_split
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                train_step(model, loss_fn, opt, self.x, self.y, group)
+                if self.split:
+                    self._fwd(); self._reduce_sums(); self._bwd(); allreduce_gradients(model, group); opt.step()
+                else:
+                    train_step(model, loss_fn, opt, self.x, self.y, group)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.g_main = torch.cuda.CUDAGraph()
-        if not self.distributed:
+        if not self.split:
             with torch.cuda.graph(self.g_main):
                 self.out = train_step(model, loss_fn, opt, self.x, self.y, None)
-            self.g_opt = None
+            self.g_bwd = self.g_opt = None
         else:
             with torch.cuda.graph(self.g_main):
-                opt.zero_grad()
-                loss, ce, dice = loss_fn(model(self.x), self.y)     # the 28-float Dice all-reduce is captured (RCCL supports it)
-                loss.backward()
-                self.out = (loss, ce, dice)
+                self._fwd()
+            self._reduce_sums()
+            self.g_bwd = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_bwd):
+                self._bwd()
+            allreduce_gradients(model, group)
             self.g_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_opt):
                 opt.step()
+
+    # ---- the three pieces of the split step (engine driven directly; no torch.autograd in between)
+    def _fwd(self):
+        M, L = self.model, lib()
+        self.opt.zero_grad()
+        logits, G, out_var = M._run(self.x, record=True)
+        self._G, self._out_var = G, out_var
+        B, C, H, W = logits.shape
+        stream = torch.cuda.current_stream(logits.device).cuda_stream
+        self._prob = torch.empty((B, C, H, W), dtype=torch.float32, device=logits.device)
+        self._sums = torch.zeros(1 + 3 * C, dtype=torch.float32, device=logits.device)
+        L.tc_seg_loss_fwd(logits.data_ptr(), self.y.data_ptr(), self._prob.data_ptr(), self._sums.data_ptr(), B, C, H * W, TC_F32, stream)
+        self._npix_local = float(B * H * W)
+
+    def _reduce_sums(self):
+        self._sums, self._npix, _ = seg_sums_allreduce(self._sums, self._npix_local, self.group)
+
+    def _bwd(self):
+        M, L = self.model, lib()
+        B, C, H, W = self._prob.shape
+        lf = self.loss_fn
+        self.out = tuple(t.float() for t in loss_from_sums(self._sums, self._npix, lf.w_ce, lf.w_dice))
+        stream = torch.cuda.current_stream(self._prob.device).cuda_stream
+        d = torch.empty((B, C, H, W), dtype=torch.float32, device=self._prob.device)
+        L.tc_seg_loss_bwd(self._prob.data_ptr(), self.y.data_ptr(), self._sums.data_ptr(), d.data_ptr(), B, C, H * W, float(lf.w_ce),
+                          float(lf.w_dice), float(self._npix), 1.0, None, TC_F32, stream)
+        M._backward(self._G, self._out_var, d)
+        self._G = self._out_var = None
 
     def __call__(self, images: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None):
         if images is not None:
             self.x.copy_(images, non_blocking=True)
             self.y.copy_(labels, non_blocking=True)
         self.g_main.replay()
-        if self.g_opt is not None:
-            allreduce_gradients(self.model, self.group)
+        if self.split:
+            self._reduce_sums()                      # C2: in place on the static 28-float buffer
+            self.g_bwd.replay()
+            allreduce_gradients(self.model, self.group)      # C1
             self.g_opt.replay()
         return self.out
