@@ -209,6 +209,7 @@ class GraphedStep:
     # ---- the three pieces of the split step (engine driven directly; no torch.autograd in between)
     def _fwd(self):
         M, L = self.model, lib()
+        M._ensure_flat(self.x.device)
         self.opt.zero_grad()
         logits, G, out_var = M._run(self.x, record=True)
         self._G, self._out_var = G, out_var
