@@ -286,8 +286,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmDev p) {
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int SA = BM * BK / 8 / 256, SB = BN * BK / 8 / 256;   // 8-element strips per thread
     static_assert(SA >= 1 && SB >= 1, "tile too small");
-    __shared__ __attribute__((aligned(16))) bf16_t As[BM * LDT];
-    __shared__ __attribute__((aligned(16))) bf16_t Bs[BN * LDT];
+    // double-buffered LDS + two register sets: the loads of slab i+2 are in flight while slab i is multiplied and slab i+1
+    // is written to the other LDS buffer -- one barrier per slab, two slabs of memory latency covered (small-M GEMMs of this
+    // model run ~1 workgroup per CU, so the K loop is latency-bound, not bandwidth-bound)
+    __shared__ __attribute__((aligned(16))) bf16_t As[2][BM * LDT];
+    __shared__ __attribute__((aligned(16))) bf16_t Bs[2][BN * LDT];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -309,11 +312,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmDev p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    uint4 ra[SA], rb[SB];
     // strip ownership: K-contiguous operands: consecutive threads walk along K (coalesced 16-B loads, vector LDS writes);
-    // transposed operands: lanes 0-31 own the 32 k-rows of the slab for one 8-wide x strip, so that each of the 8 scalar
-    // transposed LDS writes of a wave hits 32 consecutive bf16 of one row (no bank conflicts; the naive mapping strides rows by 8).
-    auto fetch = [&](int k0) {
+    // transposed operands: lanes own consecutive k-rows of the slab for one 8-wide x strip, so that each of the 8 scalar
+    // transposed LDS writes of a wave hits 64 consecutive bf16 of one row (no bank conflicts; the naive mapping strides rows by 8).
+    auto fetch = [&](uint4 (&ra)[SA], uint4 (&rb)[SB], int k0) {
 #pragma unroll
         for (int i = 0; i < SA; ++i) {
             const int f = tid + i * 256;
@@ -337,34 +339,29 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmDev p) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) base[(x0 + i) * LDT + k] = u.e[i];
     };
-    auto stage = [&]() {
+    auto stage = [&](const uint4 (&ra)[SA], const uint4 (&rb)[SB], bf16_t* as, bf16_t* bs) {
 #pragma unroll
         for (int i = 0; i < SA; ++i) {
             const int f = tid + i * 256;
-            if (!TA) { const int row = f / (BK / 8), kq = f % (BK / 8); *reinterpret_cast<uint4*>(&As[row * LDT + kq * 8]) = ra[i]; }
-            else { const int k = f % BK, mq = f / BK; put_t(As, mq * 8, k, ra[i]); }
+            if (!TA) { const int row = f / (BK / 8), kq = f % (BK / 8); *reinterpret_cast<uint4*>(&as[row * LDT + kq * 8]) = ra[i]; }
+            else { const int k = f % BK, mq = f / BK; put_t(as, mq * 8, k, ra[i]); }
         }
 #pragma unroll
         for (int i = 0; i < SB; ++i) {
             const int f = tid + i * 256;
-            if (TB) { const int row = f / (BK / 8), kq = f % (BK / 8); *reinterpret_cast<uint4*>(&Bs[row * LDT + kq * 8]) = rb[i]; }
-            else { const int k = f % BK, nq = f / BK; put_t(Bs, nq * 8, k, rb[i]); }
+            if (TB) { const int row = f / (BK / 8), kq = f % (BK / 8); *reinterpret_cast<uint4*>(&bs[row * LDT + kq * 8]) = rb[i]; }
+            else { const int k = f % BK, nq = f / BK; put_t(bs, nq * 8, k, rb[i]); }
         }
     };
-
     float rsum = 0.f;
     const bool do_rowsum = p.rowsum && blockIdx.x == 0 && tid < BM;
-    if (kbeg < kend) fetch(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        stage();
-        __syncthreads();
-        if (k0 + BK < kend) fetch(k0 + BK);
+    auto compute = [&](const bf16_t* as, const bf16_t* bs) {
         if (do_rowsum) {
 #pragma unroll
-            for (int kk = 0; kk < BK; ++kk) rsum += bf2f(As[tid * LDT + kk]);
+            for (int kk = 0; kk < BK; ++kk) rsum += bf2f(as[tid * LDT + kk]);
         }
-        const bf16_t* ap = &As[(wr * WM + (lane & 31)) * LDT + 8 * (lane >> 5)];
-        const bf16_t* bp = &Bs[(wc * WN + (lane & 31)) * LDT + 8 * (lane >> 5)];
+        const bf16_t* ap = &as[(wr * WM + (lane & 31)) * LDT + 8 * (lane >> 5)];
+        const bf16_t* bp = &bs[(wc * WN + (lane & 31)) * LDT + 8 * (lane >> 5)];
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 16) {
             bf16x8 a[TM], b[TN];
@@ -379,7 +376,30 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmDev p) {
                     acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0)      // D^T: lane = output row
                                      : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+    };
+
+    uint4 ra0[SA], rb0[SB], ra1[SA], rb1[SB];
+    if (kbeg < kend) {
+        fetch(ra0, rb0, kbeg);
+        if (kbeg + BK < kend) fetch(ra1, rb1, kbeg + BK);
+        stage(ra0, rb0, As[0], Bs[0]);
         __syncthreads();
+        if (kbeg + 2 * BK < kend) fetch(ra0, rb0, kbeg + 2 * BK);
+        for (int k0 = kbeg;; k0 += 2 * BK) {
+            // slab k0 sits in LDS buffer 0; slab k0+BK waits in register set 1; slab k0+2BK is arriving in set 0
+            const bool has1 = k0 + BK < kend;
+            if (has1) stage(ra1, rb1, As[1], Bs[1]);
+            compute(As[0], Bs[0]);
+            if (!has1) break;
+            __syncthreads();
+            if (k0 + 3 * BK < kend) fetch(ra1, rb1, k0 + 3 * BK);
+            const bool has2 = k0 + 2 * BK < kend;
+            if (has2) stage(ra0, rb0, As[0], Bs[0]);
+            compute(As[1], Bs[1]);
+            if (!has2) break;
+            __syncthreads();
+            if (k0 + 4 * BK < kend) fetch(ra0, rb0, k0 + 4 * BK);
+        }
     }
     if (do_rowsum && m0 + tid < p.M) atomicAdd(p.rowsum + b1 * p.sRow1 + m0 + tid, rsum);
     if (SWAP) epilogue_rows<bf16_t, TC, TM, TN>(p, acc, b1, b2, ks, m0 + wr * WM, n0 + wc * WN, lane);
