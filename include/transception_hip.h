@@ -167,10 +167,11 @@ int tc_attn_bwd(const void* Q, int ldq, long long sq, const void* K, int ldk, co
  * Replaces the same reference lines (MSTr.py:2281-2287) for all 6076 query tokens of every image at once. */
 int tc_attn_fwd_seg(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, long long skv, void* O, int ldo,
                     float* lse, int B, int nseg, const int* nq, int Nk, float scale, int dtype, void* stream);
+/* dkv32: fp32 scratch [B*Nk*128] (bf16 path: query splits accumulate dK|dV there before one conversion); may be NULL for fp32. */
 int tc_attn_bwd_seg(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, long long skv, const void* O,
-                    int ldo, const void* dO, int lddo, const float* lse, float* delta, void* dQ, int lddq, void* dK,
-                    int lddk, void* dV, int lddv, long long sdkv, int B, int nseg, const int* nq, int Nk, float scale,
-                    int dtype, void* stream);
+                    int ldo, const void* dO, int lddo, const float* lse, float* delta, float* dkv32, void* dQ, int lddq,
+                    void* dK, int lddk, void* dV, int lddv, long long sdkv, int B, int nseg, const int* nq, int Nk,
+                    float scale, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Elementwise / layout kernels.
@@ -241,6 +242,11 @@ int tc_seg_loss_bwd(const float* prob, const long long* labels, const float* sum
  * lr_dev (optional device scalar) overrides lr, so a hipGraph-captured step can follow a per-iteration schedule. */
 int tc_sgd_step(float* p, const float* grad, float* buf, long long n, float lr, const float* lr_dev, float momentum,
                 float wd, float gscale, int first, void* stream);
+/* The same update over nseg contiguous segments of the flat arenas in ONE launch: segs_dev is a DEVICE array of
+ * (offset, length) pairs (elements); max_len = longest segment.  Parameters outside the segments are untouched
+ * (torch.optim.SGD skips parameters whose grad is None -- the reference's 332 grad-less tensors). */
+int tc_sgd_step_multi(float* p, const float* grad, float* buf, const long long* segs_dev, int nseg, long long max_len,
+                      float lr, const float* lr_dev, float momentum, float wd, float gscale, int first, void* stream);
 /* dst(bf16) = src(fp32) and back, for bf16 working copies of fp32 master weights */
 int tc_cast(const void* src, void* dst, long long n, int src_dtype, int dst_dtype, void* stream);
 

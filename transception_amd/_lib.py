@@ -48,7 +48,7 @@ SIGNATURES = {
     "tc_attn_bwd": [vp, i32, i64, vp, i32, vp, i32, i64, vp, i32, i64, vp, i32, i64, vp, vp, vp, i32, i64, vp, i32,
                     vp, i32, i64, i32, i32, i32, i32, f32, i32, vp],
     "tc_attn_fwd_seg": [vp, i32, vp, i32, vp, i32, i64, vp, i32, vp, i32, i32, C.POINTER(i32), i32, f32, i32, vp],
-    "tc_attn_bwd_seg": [vp, i32, vp, i32, vp, i32, i64, vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, vp, i32, i64, i32, i32,
+    "tc_attn_bwd_seg": [vp, i32, vp, i32, vp, i32, i64, vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, i32, vp, i32, i64, i32, i32,
                         C.POINTER(i32), i32, f32, i32, vp],
     "tc_fma3_fwd": [vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, f32, i32, vp],
     "tc_fma3_bwd": [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, vp, i32, i32, i32, f32, i32, vp],
@@ -67,6 +67,7 @@ SIGNATURES = {
     "tc_seg_loss_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "tc_seg_loss_bwd": [vp, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, vp, i32, vp],
     "tc_sgd_step": [vp, vp, vp, i64, f32, vp, f32, f32, f32, i32, vp],
+    "tc_sgd_step_multi": [vp, vp, vp, vp, i32, i64, f32, vp, f32, f32, f32, i32, vp],
     "tc_cast": [vp, vp, i64, i32, i32, vp],
 }
 _RET = {"tc_bn_scratch_floats": i64, "tc_softmax_scratch_floats": i64}

@@ -275,8 +275,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_seg_kernel(const bf16_t* _
 __global__ __launch_bounds__(256) void attn_bwd_dkv_seg_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
                                                                const bf16_t* __restrict__ V, int ldv, long long skv,
                                                                const bf16_t* __restrict__ dO, int lddo, const float* __restrict__ lse,
-                                                               const float* __restrict__ delta, bf16_t* __restrict__ dK, int lddk,
-                                                               bf16_t* __restrict__ dV, int lddv, long long sdkv, Segs sg, int Nk, float scale) {
+                                                               const float* __restrict__ delta, float* __restrict__ dkv32, Segs sg, int Nk,
+                                                               float scale) {
+    // gridDim.z query splits share a (key tile, image): partial dK/dV are added atomically into the fp32 scratch dkv32
+    // [B][Nk][128] (dK | dV), which attn_dkv_store_kernel converts to the bf16 outputs.
     constexpr int LDQT = 32 + 16;                  // 96-byte rows = 24 words (8-word spans of rows distinct mod 4 are disjoint)
     constexpr int PER_WAVE_B = (2 * 32 * LDR + 2 * D * LDQT) * 2 + 256;
     constexpr int RED_B = 4 * 2 * 64 * 33 * 4;
@@ -327,8 +329,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_seg_kernel(const bf16_t* __r
         }
         if (lane < 32) { const bool okr = lane < valid; lr = okr ? lse[base + lane] * LOG2E : 0.f; dr = okr ? delta[base + lane] : 0.f; }
     };
-    if (wave < ntiles) fetch(wave);
-    for (int t = wave; t < ntiles; t += 4) {
+    const int tstep = 4 * gridDim.z, tfirst = blockIdx.z * 4 + wave;
+    if (tfirst < ntiles) fetch(tfirst);
+    for (int t = tfirst; t < ntiles; t += tstep) {
         long long base; int valid;
         locate(t, base, valid);
 #pragma unroll
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_seg_kernel(const bf16_t* __r
         if (lane < 32) { lss[lane] = lr; dls[lane] = dr; }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
-        if (t + 4 < ntiles) fetch(t + 4);
+        if (t + tstep < ntiles) fetch(t + tstep);
         f32x16 s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -390,8 +393,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_seg_kernel(const bf16_t* __r
         float v = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) v += red[w * RW + which * 64 * 33 + d * 33 + kk];
-        bf16_t* dst = (which == 0 ? dK + b * sdkv + (long long)(kv0 + kk) * lddk : dV + b * sdkv + (long long)(kv0 + kk) * lddv) + d;
-        *dst = f2bf(v);
+        atomicAdd(dkv32 + ((long long)b * Nk + kv0 + kk) * 128 + which * 64 + d, v);
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_dkv_store_kernel(const float* __restrict__ dkv32, bf16_t* __restrict__ dK, int lddk,
+                                                             bf16_t* __restrict__ dV, int lddv, long long sdkv, int B, int Nk) {
+    const long long n = (long long)B * Nk * 32;                 // float4 groups
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int q = (int)(i & 31), key = (int)((i >> 5) % Nk), b = (int)((i >> 5) / Nk);
+        const float4 v = *reinterpret_cast<const float4*>(dkv32 + i * 4);
+        bf16_t* dst = (q < 16 ? dK + b * sdkv + (long long)key * lddk + q * 4 : dV + b * sdkv + (long long)key * lddv + (q - 16) * 4);
+        st4<bf16_t>(dst, v);
     }
 }
 
@@ -446,8 +459,9 @@ extern "C" int tc_attn_fwd_seg(const void* Q, int ldq, const void* K, int ldk, c
 }
 
 extern "C" int tc_attn_bwd_seg(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, long long skv, const void* O, int ldo,
-                               const void* dO, int lddo, const float* lse, float* delta, void* dQ, int lddq, void* dK, int lddk, void* dV,
-                               int lddv, long long sdkv, int B, int nseg, const int* nq, int Nk, float scale, int dtype, void* stream) {
+                               const void* dO, int lddo, const float* lse, float* delta, float* dkv32, void* dQ, int lddq, void* dK, int lddk,
+                               void* dV, int lddv, long long sdkv, int B, int nseg, const int* nq, int Nk, float scale, int dtype,
+                               void* stream) {
     Segs sg;
     long long rows;
     if (!Q || !K || !V || !O || !dO || !lse || !delta || !dQ || !dK || !dV || !nq || B <= 0 || Nk <= 0 || !make_segs(sg, B, nseg, nq, rows))
@@ -464,12 +478,15 @@ extern "C" int tc_attn_bwd_seg(const void* Q, int ldq, const void* K, int ldk, c
         }
         return TC_OK;
     }
-    if (dtype != TC_BF16 || ((ldq | ldk | ldv | lddo) & 7) || (skv & 7) || (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)dO) & 15) ||
-        ((ldo | lddq) & 3))
+    if (dtype != TC_BF16 || !dkv32 || ((ldq | ldk | ldv | lddo) & 7) || (skv & 7) ||
+        (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)dO) & 15) || ((ldo | lddq | lddk | lddv) & 3) || (sdkv & 3))
         return TC_ERR_ARG;
+    if (hipMemsetAsync(dkv32, 0, sizeof(float) * (size_t)B * Nk * 128, s) != hipSuccess) return TC_ERR_LAUNCH;
     hipLaunchKernelGGL(delta_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const bf16_t*)O, ldo, (const bf16_t*)dO, lddo, delta, rows);
-    hipLaunchKernelGGL(attn_bwd_dkv_seg_kernel, dim3((Nk + 31) / 32, B), dim3(256), 0, s, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk,
-                       (const bf16_t*)V, ldv, skv, (const bf16_t*)dO, lddo, lse, delta, (bf16_t*)dK, lddk, (bf16_t*)dV, lddv, sdkv, sg, Nk, scale);
+    hipLaunchKernelGGL(attn_bwd_dkv_seg_kernel, dim3((Nk + 31) / 32, B, 4), dim3(256), 0, s, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk,
+                       (const bf16_t*)V, ldv, skv, (const bf16_t*)dO, lddo, lse, delta, dkv32, sg, Nk, scale);
+    hipLaunchKernelGGL(attn_dkv_store_kernel, dim3(tc_blocks((long long)B * Nk * 32, 256, 1024)), dim3(256), 0, s, dkv32, (bf16_t*)dK, lddk,
+                       (bf16_t*)dV, lddv, sdkv, B, Nk);
     hipLaunchKernelGGL(attn_bwd_dq_seg_kernel, dim3(sg.tile0[nseg]), dim3(256), 0, s, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk, (const bf16_t*)V,
                        ldv, skv, (const bf16_t*)dO, lddo, lse, delta, (bf16_t*)dQ, lddq, sg, Nk, scale);
     return tc_launch_status();

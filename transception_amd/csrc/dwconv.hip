@@ -66,7 +66,6 @@ template <typename T, int K>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ x, int ldx,
                                                        float* __restrict__ dw, float* __restrict__ db, int B, int H, int W,
                                                        int Ho, int Wo, int C, int stride) {
-    __shared__ float red[4][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int c = blockIdx.y * 64 + tx;
     constexpr int P = (K - 1) / 2;
@@ -96,16 +95,17 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const T* __restrict__ dy,
             }
         }
     }
+    constexpr int NT = K * K + 1;
+    __shared__ float redall[4][NT][64];
 #pragma unroll
-    for (int i = 0; i <= K * K; ++i) {
-        red[ty][tx] = (i < K * K) ? acc[i < K * K ? i : 0] : accb;
-        __syncthreads();
-        if (ty == 0 && c < C) {
-            const float s = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
-            if (i < K * K) atomicAdd(dw + (long long)c * K * K + i, s);
-            else if (db) atomicAdd(db + c, s);
-        }
-        __syncthreads();
+    for (int i = 0; i < NT; ++i) redall[ty][i][tx] = (i < K * K) ? acc[i < K * K ? i : 0] : accb;
+    __syncthreads();
+    for (int f = threadIdx.x; f < NT * 64; f += 256) {
+        const int cc = f / NT, t = f - cc * NT, ch = blockIdx.y * 64 + cc;      // taps fastest: coalesced atomics
+        if (ch >= C) continue;
+        const float s = redall[0][t][cc] + redall[1][t][cc] + redall[2][t][cc] + redall[3][t][cc];
+        if (t < K * K) atomicAdd(dw + (long long)ch * K * K + t, s);
+        else if (db) atomicAdd(db + ch, s);
     }
 }
 
@@ -345,7 +345,7 @@ extern "C" int tc_dwconv_bwd_weight(const void* dy, int lddy, const void* x, int
     const int P = (k - 1) / 2;
     const int Ho = (H + 2 * P - k) / stride + 1, Wo = (W + 2 * P - k) / stride + 1;
     const long long npix = (long long)B * Ho * Wo;
-    dim3 grid(tc_blocks(npix, 4 * 64, 256), (C + 63) / 64), block(256);
+    dim3 grid(tc_blocks(npix, 4 * 16, 256), (C + 63) / 64), block(256);
     hipStream_t s = (hipStream_t)stream;
 #define TC_DWW(KK) hipLaunchKernelGGL((dw_wgrad_kernel<T, KK>), grid, block, 0, s, (const T*)dy, lddy, (const T*)x, ldx, dw, db, \
                                       B, H, W, Ho, Wo, C, stride)

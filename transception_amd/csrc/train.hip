@@ -107,6 +107,21 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, f
     }
 }
 
+// all contiguous "used" parameter segments in one launch: blockIdx.y = segment, segs[2*i] = offset, segs[2*i+1] = length
+__global__ void sgd_multi_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, const long long* __restrict__ segs,
+                                 float lr, float mom, float wd, float gscale, int first, const float* __restrict__ lr_dev) {
+    if (lr_dev) lr = *lr_dev;
+    const long long off = segs[2 * blockIdx.y], n = segs[2 * blockIdx.y + 1];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const long long j = off + i;
+        const float w = p[j];
+        const float d = g[j] * gscale + wd * w;
+        const float b = first ? d : mom * buf[j] + d;
+        buf[j] = b;
+        p[j] = w - lr * b;
+    }
+}
+
 }  // namespace
 
 extern "C" int tc_colsum(const void* x, int rows, int cols, int ldx, int nb, long long sb, float* out, int accumulate, int dtype,
@@ -142,5 +157,13 @@ extern "C" int tc_sgd_step(float* p, const float* grad, float* buf, long long n,
     if (!p || !grad || !buf || n <= 0) return TC_ERR_ARG;
     hipLaunchKernelGGL(sgd_kernel, dim3(tc_blocks(n, 256 * 4, 4096)), dim3(256), 0, (hipStream_t)stream, p, grad, buf, n, lr, momentum, wd,
                        gscale, first, lr_dev);
+    return tc_launch_status();
+}
+
+extern "C" int tc_sgd_step_multi(float* p, const float* grad, float* buf, const long long* segs_dev, int nseg, long long max_len, float lr,
+                                 const float* lr_dev, float momentum, float wd, float gscale, int first, void* stream) {
+    if (!p || !grad || !buf || !segs_dev || nseg <= 0 || nseg > 65535 || max_len <= 0) return TC_ERR_ARG;
+    hipLaunchKernelGGL(sgd_multi_kernel, dim3(tc_blocks(max_len, 256 * 8, 256), nseg), dim3(256), 0, (hipStream_t)stream, p, grad, buf, segs_dev,
+                       lr, momentum, wd, gscale, first, lr_dev);
     return tc_launch_status();
 }

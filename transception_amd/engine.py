@@ -727,10 +727,11 @@ class Graph:
             gv, av = self.wgrad(v)
             assert not (aq or ak or av), "attention_seg expects single-use q / k / v"
             delta = self.f32(rows)
+            dkv32 = self.f32(B * Nk * 128) if self.dtype != torch.float32 else None
             _timed("attn_bwd", 10.0 * rows * Nk * 64, lambda: self.L.tc_attn_bwd_seg(
                 _ptr(q.data), q.ld, _ptr(k.data), k.ld, _ptr(v.data), v.ld, Nk * k.ld, _ptr(out.data), out.ld, _ptr(dO),
-                dO.stride(0), _ptr(lse), _ptr(delta), _ptr(gq), gq.stride(0), _ptr(gk), gk.stride(0), _ptr(gv), gv.stride(0),
-                Nk * gk.stride(0), B, len(nq), nq_c, Nk, scale, self.dt, self.stream))
+                dO.stride(0), _ptr(lse), _ptr(delta), _ptr(dkv32), _ptr(gq), gq.stride(0), _ptr(gk), gk.stride(0), _ptr(gv),
+                gv.stride(0), Nk * gk.stride(0), B, len(nq), nq_c, Nk, scale, self.dt, self.stream))
         self._rec(bwd)
         return out
 

@@ -104,6 +104,7 @@ class FusedSGD:
         self.buf: Optional[torch.Tensor] = None
         self.steps = 0
         self._segments = None
+        self._segs_dev: Optional[torch.Tensor] = None
         self.lr_dev: Optional[torch.Tensor] = None       # device scalar read by the kernel (hipGraph-friendly schedule)
 
     def set_lr(self, lr: float):
@@ -137,12 +138,13 @@ class FusedSGD:
             self.lr_dev = torch.full((1,), float(self.lr), dtype=torch.float32, device=flat.device)
         L = lib()
         stream = torch.cuda.current_stream(flat.device).cuda_stream
-        es = 4
-        for off, n in self._segs():
-            n = min(n, flat.numel() - off)
-            L.tc_sgd_step(flat.data_ptr() + off * es, g.data_ptr() + off * es, self.buf.data_ptr() + off * es, n, float(self.lr),
-                          self.lr_dev.data_ptr(), float(self.momentum), float(self.wd), float(grad_scale), int(self.steps == 0),
-                          stream)
+        if self._segs_dev is None:
+            segs = [(off, min(n, flat.numel() - off)) for off, n in self._segs()]
+            self._segs_dev = torch.tensor([v for s in segs for v in s], dtype=torch.int64, device=flat.device)
+            self._nseg, self._maxlen = len(segs), max(n for _, n in segs)
+        L.tc_sgd_step_multi(flat.data_ptr(), g.data_ptr(), self.buf.data_ptr(), self._segs_dev.data_ptr(), self._nseg, self._maxlen,
+                            float(self.lr), self.lr_dev.data_ptr(), float(self.momentum), float(self.wd), float(grad_scale),
+                            int(self.steps == 0), stream)
         self.steps += 1
 
 
