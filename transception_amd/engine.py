@@ -193,6 +193,7 @@ class _Grouped:
 
 class Graph:
     use_streams = os.environ.get("TC_NO_STREAMS", "0") != "1"
+    overlap_wgrad = os.environ.get("TC_NO_WGRAD_OVERLAP", "0") != "1"
     ngroups = 1          # ops with parameters run `ngroups` stacked row blocks, block g with the weights at +g*P.gs
     pgs = 0
 
@@ -210,6 +211,9 @@ class Graph:
         self.training = training
         self.record = record
         self.tape: List[Callable[[], None]] = []
+        self._wstream = None          # side stream for weight-gradient kernels (nothing downstream in backward needs them)
+        self._pending: Dict[int, torch.cuda.Event] = {}     # gradient storage -> last weight-gradient kernel still reading it
+        self._keep: list = []
         self.cur = torch.cuda.current_stream(device) if torch.device(device).type == "cuda" else None
         self.stream = self.cur.cuda_stream if self.cur is not None else 0
         self.n_launch = 0
@@ -249,6 +253,10 @@ class Graph:
             r.whole_written = True
         else:
             r.written.append(reg)
+        if self._pending:
+            ev = self._pending.pop(r.grad_t.untyped_storage().data_ptr(), None)
+            if ev is not None:
+                self.cur.wait_event(ev)                  # a weight-gradient kernel on the side stream still reads this buffer
         return v.apply_path(r.grad_t), int(acc)
 
     def _region_grad(self, root: Var, off: int, nelem: int) -> torch.Tensor:
@@ -289,6 +297,25 @@ class Graph:
             self.L.tc_add(_ptr(g), g.stride(0), _ptr(tmp), tmp.stride(0), _ptr(g), g.stride(0), g.shape[0], g.shape[1],
                           self.dt, self.stream)
 
+    def _weight_grad(self, fn: Callable[[], None], reads: Optional[torch.Tensor] = None):
+        """Run a weight-gradient kernel on the side stream: dW / dw / db are only consumed by the optimizer, so they overlap
+        with the activation-gradient chain.  `reads` = the upstream gradient buffer the kernel reads: a later in-place
+        accumulation into that buffer (aliased residual gradients) must wait for this kernel (see wgrad)."""
+        if not (self.overlap_wgrad and self.use_streams and self.cur is not None):
+            fn()
+            return
+        if self._wstream is None:
+            self._wstream = _side_streams(self.dev, 4)[3]
+        ws = self._wstream
+        ws.wait_stream(self.cur)
+        with _Branch(self, ws):
+            fn()
+        if reads is not None:
+            ev = torch.cuda.Event()
+            ev.record(ws)
+            self._pending[reads.untyped_storage().data_ptr()] = ev
+            self._keep.append(reads)
+
     def backward(self):
         main = (self.cur, self.stream)
         for entry in reversed(self.tape):
@@ -309,6 +336,10 @@ class Graph:
                     with _Branch(self, st):
                         fn()
         self.cur, self.stream = main
+        if self._wstream is not None:
+            self.cur.wait_stream(self._wstream)          # all weight gradients are in the arena before anything follows
+        self._pending.clear()
+        self._keep.clear()
         self.tape = []
 
     def _rec(self, fn):
@@ -379,9 +410,10 @@ class Graph:
             want_db = b is not None and b.grad is not None
             if W.grad is not None:
                 gW = W.grad if wcols is None else W.grad[:, wcols[0]:wcols[1]]
-                self._gemm(_ptr(dz), dz.stride(0), _ptr(x.data), x.ld, _ptr(gW), gW.stride(0), N, K, M, 1, 0, acc=1,
-                           splitk=self._splitk(N, K, M), c_f32=1, nb1=nb, sA=(so, 0), sB=(sx, 0), sC=(sw, 0),
-                           atomic=int(nb > 1 and not grouped), rowsum=_ptr(b.grad) if want_db else None, srow=sw)
+                self._weight_grad(lambda: self._gemm(
+                    _ptr(dz), dz.stride(0), _ptr(x.data), x.ld, _ptr(gW), gW.stride(0), N, K, M, 1, 0, acc=1,
+                    splitk=self._splitk(N, K, M), c_f32=1, nb1=nb, sA=(so, 0), sB=(sx, 0), sC=(sw, 0),
+                    atomic=int(nb > 1 and not grouped), rowsum=_ptr(b.grad) if want_db else None, srow=sw), reads=dz)
             elif want_db:
                 assert not grouped
                 self.L.tc_colsum(_ptr(dz), M, N, dz.stride(0), nb, so, _ptr(b.grad), 1, self.dt, self.stream)
@@ -440,9 +472,9 @@ class Graph:
                 self.L.tc_dwconv_bwd_input(_ptr(dy), dy.stride(0), _ptr(w.data), _ptr(gx), gx.stride(0), B, H, W, Cc, k, stride,
                                            int(add_input), acc, Gn, w.gs, self.dt, self.stream)
             if w.grad is not None:
-                self.L.tc_dwconv_bwd_weight(_ptr(dy), dy.stride(0), _ptr(x.data), x.ld, _ptr(w.grad),
-                                            _ptr(b.grad) if b is not None else None, B, H, W, Cc, k, stride, Gn, w.gs, self.dt,
-                                            self.stream)
+                self._weight_grad(lambda: self.L.tc_dwconv_bwd_weight(
+                    _ptr(dy), dy.stride(0), _ptr(x.data), x.ld, _ptr(w.grad), _ptr(b.grad) if b is not None else None, B, H, W, Cc, k,
+                    stride, Gn, w.gs, self.dt, self.stream), reads=dy)
         self._rec(bwd)
         return out
 
