@@ -188,8 +188,13 @@ def main():
             fl = sum(f for _, _, f in ev)
             peak = PEAK_TFLOPS[args.dtype]
             ach = fl / (ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "attn_fwd_kernel (bridge SR-attention forward, QK^T+PV fused)",
-                               "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+            traffic = None                                   # HBM bytes per launch from the committed PMC passes (bf16 kernel only)
+            pmc = os.path.join(ROOT, "profiles", "r1_attn_pmc.json")
+            if args.dtype == "bf16" and args.batch == 16 and args.size == 224 and os.path.exists(pmc):
+                traffic = json.load(open(pmc)).get("attn_fwd_seg_kernel", {}).get("hbm_bytes_corrected")
+            out["roofline"] = {"bound": "mfma", "kernel": "attn_fwd_seg_kernel (bridge SR-attention forward, QK^T + softmax + PV fused, "
+                                                          "all 4 scales x B images in one launch)",
+                               "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                                "launches": len(ev), "avg_launch_us": 1e3 * ms / len(ev),
                                "algorithmic_flops_per_launch": fl / len(ev)}
             if prof.get("attn_bwd"):
