@@ -73,7 +73,7 @@ __device__ __forceinline__ void locate_tile(const Segs& sg, int t, int& row_base
     row_base = sg.row0[s] + b * nq;
 }
 
-__global__ __launch_bounds__(256, 2) void attn_fwd_seg_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
+__global__ __launch_bounds__(256, 4) void attn_fwd_seg_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
                                                               const bf16_t* __restrict__ V, int ldv, long long skv, bf16_t* __restrict__ O,
                                                               int ldo, float* __restrict__ lse, Segs sg, int Nk, float scale) {
     __shared__ __attribute__((aligned(16))) bf16_t Ks[KB * LDR];
@@ -98,14 +98,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_seg_kernel(const bf16_t* __re
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
     float m = NEG_BIG, lsum = 0.f;
     const int krow = pi_row(j);
-    uint4 kr[4], vr[4];
-    auto fetch = [&](int kb0) {
+    uint4 kr[4];                                            // K of the next fill is prefetched; V is fetched at its LDS store (keeps the
+    auto fetch = [&](int kb0) {                            // kernel within 128 VGPRs: 4 workgroups per CU = all 800 tiles resident at once)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int r, c8, g;
             fill_map(tid, i, r, c8, g);
             kr[i] = ld_row8(Kb, ldk, kb0 + r, Nk, c8);
-            vr[i] = ld_row8(Vb, ldv, kb0 + r, Nk, c8);
         }
     };
     fetch(0);
@@ -116,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_seg_kernel(const bf16_t* __re
             int r, c8, g;
             fill_map(tid, i, r, c8, g);
             *reinterpret_cast<uint4*>(&Ks[r * LDR + c8]) = kr[i];
-            st_t8(Vt, LDTB, c8, r, vr[i], g);
+            st_t8(Vt, LDTB, c8, r, ld_row8(Vb, ldv, kb0 + r, Nk, c8), g);
         }
         __syncthreads();
         if (kb0 + KB < Nk) fetch(kb0 + KB);
