@@ -279,7 +279,7 @@ __device__ __forceinline__ uint4 load_strip8(const bf16_t* base, int ld, int x, 
     return u.v;
 }
 
-template <typename TC, int BM, int BN, bool TA, bool TB>
+template <typename TC, int BM, int BN, bool TA, bool TB, bool DB>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmDev p) {
     constexpr int BK = 64, LDT = BK + 8;                       // 144-byte rows: 16-B aligned, conflict-free b128 fragment reads
     constexpr bool SWAP = sizeof(TC) == 2;                     // bf16 output: lane owns a row (8-byte stores); fp32 output: coalesced columns
@@ -289,8 +289,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmDev p) {
     // double-buffered LDS + two register sets: the loads of slab i+2 are in flight while slab i is multiplied and slab i+1
     // is written to the other LDS buffer -- one barrier per slab, two slabs of memory latency covered (small-M GEMMs of this
     // model run ~1 workgroup per CU, so the K loop is latency-bound, not bandwidth-bound)
-    __shared__ __attribute__((aligned(16))) bf16_t As[2][BM * LDT];
-    __shared__ __attribute__((aligned(16))) bf16_t Bs[2][BN * LDT];
+    // (DB = false: K <= 2 slabs -- one LDS buffer, half the footprint, twice the resident workgroups)
+    __shared__ __attribute__((aligned(16))) bf16_t As[DB ? 2 : 1][BM * LDT];
+    __shared__ __attribute__((aligned(16))) bf16_t Bs[DB ? 2 : 1][BN * LDT];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -379,7 +380,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmDev p) {
     };
 
     uint4 ra0[SA], rb0[SB], ra1[SA], rb1[SB];
-    if (kbeg < kend) {
+    if (!DB) {
+        if (kbeg < kend) fetch(ra0, rb0, kbeg);
+        for (int k0 = kbeg; k0 < kend; k0 += BK) {
+            stage(ra0, rb0, As[0], Bs[0]);
+            __syncthreads();
+            if (k0 + BK < kend) fetch(ra0, rb0, k0 + BK);
+            compute(As[0], Bs[0]);
+            __syncthreads();
+        }
+    } else if (kbeg < kend) {
         fetch(ra0, rb0, kbeg);
         if (kbeg + BK < kend) fetch(ra1, rb1, kbeg + BK);
         stage(ra0, rb0, As[0], Bs[0]);
@@ -388,14 +398,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmDev p) {
         for (int k0 = kbeg;; k0 += 2 * BK) {
             // slab k0 sits in LDS buffer 0; slab k0+BK waits in register set 1; slab k0+2BK is arriving in set 0
             const bool has1 = k0 + BK < kend;
-            if (has1) stage(ra1, rb1, As[1], Bs[1]);
+            if (has1) stage(ra1, rb1, As[DB ? 1 : 0], Bs[DB ? 1 : 0]);
             compute(As[0], Bs[0]);
             if (!has1) break;
             __syncthreads();
             if (k0 + 3 * BK < kend) fetch(ra1, rb1, k0 + 3 * BK);
             const bool has2 = k0 + 2 * BK < kend;
             if (has2) stage(ra0, rb0, As[0], Bs[0]);
-            compute(As[1], Bs[1]);
+            compute(As[DB ? 1 : 0], Bs[DB ? 1 : 0]);
             if (!has2) break;
             __syncthreads();
             if (k0 + 4 * BK < kend) fetch(ra0, rb0, k0 + 4 * BK);
@@ -410,7 +420,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmDev p) {
 template <typename T, typename TC, int BM, int BN, bool TA, bool TB>
 void launch_one(const GemmDev& d, dim3 grid, hipStream_t s) {
     if constexpr (sizeof(T) == 4) hipLaunchKernelGGL((gemm_kernel<TC, BM, BN, TA, TB>), grid, dim3(256), 0, s, d);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<TC, BM, BN, TA, TB>), grid, dim3(256), 0, s, d);
+    else if (d.kchunk > 128) hipLaunchKernelGGL((gemm_bf16_kernel<TC, BM, BN, TA, TB, true>), grid, dim3(256), 0, s, d);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<TC, BM, BN, TA, TB, false>), grid, dim3(256), 0, s, d);
 }
 
 template <typename T, typename TC, int BM, int BN>
