@@ -87,6 +87,11 @@ int tc_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx, const voi
                      const float* mean, const float* rstd, void* dx, int lddx, const void* dres, int ldres,
                      float* dgamma, float* dbeta, int rows, int C, int act, int groups, long long pstride, int dtype,
                      void* stream);
+/* dgamma / dbeta may both be NULL above (dx only); this entry then produces them as a row-parallel column reduction, so the
+ * host can run it on a second stream beside the activation-gradient chain. */
+int tc_layernorm_bwd_params(const void* dy, int lddy, const void* x, int ldx, const void* gamma, const void* beta,
+                            const float* mean, const float* rstd, float* dgamma, float* dbeta, int rows, int C, int act,
+                            int groups, long long pstride, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Depthwise k x k convolution on NHWC maps, k in {3,5,7}, stride 1 or 2, padding (k-1)/2,

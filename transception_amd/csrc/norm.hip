@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
         const long long g = blockIdx.y;
         dy += g * rows * lddy; x += g * rows * ldx; dx += g * rows * lddx; mean += g * rows; rstd += g * rows;
         if (dres) dres += g * rows * ldres;
-        gamma += g * pstride; beta += g * pstride; dgamma += g * pstride; dbeta += g * pstride;
+        gamma += g * pstride; beta += g * pstride;
+        if (dgamma) { dgamma += g * pstride; dbeta += g * pstride; }
     }
     const int nv = C >> 2;
     float4 g[NV], b[NV], ag[NV], ab[NV];
@@ -114,8 +115,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
                     d.x *= gelu_grad_f(xv.x * g[i].x + b[i].x); d.y *= gelu_grad_f(xv.y * g[i].y + b[i].y);
                     d.z *= gelu_grad_f(xv.z * g[i].z + b[i].z); d.w *= gelu_grad_f(xv.w * g[i].w + b[i].w);
                 }
-                ag[i].x += d.x * xv.x; ag[i].y += d.y * xv.y; ag[i].z += d.z * xv.z; ag[i].w += d.w * xv.w;
-                ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
+                if (dgamma) {
+                    ag[i].x += d.x * xv.x; ag[i].y += d.y * xv.y; ag[i].z += d.z * xv.z; ag[i].w += d.w * xv.w;
+                    ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
+                }
                 d.x *= g[i].x; d.y *= g[i].y; d.z *= g[i].z; d.w *= g[i].w;
                 s1 += d.x + d.y + d.z + d.w;
                 s2 += d.x * xv.x + d.y * xv.y + d.z * xv.z + d.w * xv.w;
@@ -137,6 +140,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
             }
         }
     }
+    if (!dgamma) return;                     // dx-only launch: parameter gradients come from ln_param_grad_kernel
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int q = gl + i * GS;
@@ -153,6 +157,50 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
         for (int w = 0; w < RPB; ++w) { a += red[(w * 2 + 0) * C + c]; bb += red[(w * 2 + 1) * C + c]; }
         atomicAdd(dgamma + c, a);
         atomicAdd(dbeta + c, bb);
+    }
+}
+
+// dgamma[c] += sum_rows dz * xhat ; dbeta[c] += sum_rows dz   as a column reduction (thread = 4 channels x row lane): fully
+// parallel over rows, a few atomics per block; runs on the weight-gradient stream next to the dx kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void ln_param_grad_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ x, int ldx,
+                                                            const T* __restrict__ gamma, const T* __restrict__ beta,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int C, int act,
+                                                            long long pstride) {
+    __shared__ float4 sg[16][16], sb[16][16];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int c = blockIdx.y * 64 + tx * 4;
+    {
+        const long long g = blockIdx.z;
+        dy += g * rows * lddy; x += g * rows * ldx; mean += g * rows; rstd += g * rows;
+        gamma += g * pstride; beta += g * pstride; dgamma += g * pstride; dbeta += g * pstride;
+    }
+    float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = ag;
+    if (c < C) {
+        const float4 gm = ld4<T>(gamma + c), bt = ld4<T>(beta + c);
+        for (int r = blockIdx.x * 16 + ty; r < rows; r += gridDim.x * 16) {
+            const float mu = mean[r], rs = rstd[r];
+            float4 xv = ld4<T>(x + (long long)r * ldx + c), d = ld4<T>(dy + (long long)r * lddy + c);
+            xv.x = (xv.x - mu) * rs; xv.y = (xv.y - mu) * rs; xv.z = (xv.z - mu) * rs; xv.w = (xv.w - mu) * rs;
+            if (act == TC_ACT_GELU) {
+                d.x *= gelu_grad_f(xv.x * gm.x + bt.x); d.y *= gelu_grad_f(xv.y * gm.y + bt.y);
+                d.z *= gelu_grad_f(xv.z * gm.z + bt.z); d.w *= gelu_grad_f(xv.w * gm.w + bt.w);
+            }
+            ag.x += d.x * xv.x; ag.y += d.y * xv.y; ag.z += d.z * xv.z; ag.w += d.w * xv.w;
+            ab.x += d.x; ab.y += d.y; ab.z += d.z; ab.w += d.w;
+        }
+    }
+    sg[ty][tx] = ag; sb[ty][tx] = ab;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int cc = threadIdx.x & 63, which = threadIdx.x >> 6, q = cc >> 2, e = cc & 3;
+        if (blockIdx.y * 64 + cc < C) {
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float4 t = which ? sb[r][q] : sg[r][q]; v += (e == 0 ? t.x : e == 1 ? t.y : e == 2 ? t.z : t.w); }
+            atomicAdd((which ? dbeta : dgamma) + blockIdx.y * 64 + cc, v);
+        }
     }
 }
 
@@ -343,17 +391,30 @@ extern "C" int tc_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx
                                 const float* mean, const float* rstd, void* dx, int lddx, const void* dres, int ldres,
                                 float* dgamma, float* dbeta, int rows, int C, int act, int groups, long long pstride, int dtype,
                                 void* stream) {
-    if (!dy || !x || !gamma || !beta || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0 || groups < 1 || C <= 0 || (C & 3) ||
+    if (!dy || !x || !gamma || !beta || !mean || !rstd || !dx || (!dgamma != !dbeta) || rows <= 0 || groups < 1 || C <= 0 || (C & 3) ||
         C > LN_MAXC || (ldx & 3) || (lddy & 3) || (lddx & 3) || (dres && (ldres & 3)))
         return TC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int quads = C >> 2;
-#define TC_LNB(GS, NV) hipLaunchKernelGGL((ln_bwd_kernel<T, GS, NV>), dim3(tc_blocks(rows, (256 / GS) * 4, 1024), groups), dim3(256),   \
+#define TC_LNB(GS, NV) hipLaunchKernelGGL((ln_bwd_kernel<T, GS, NV>), dim3(tc_blocks(rows, (256 / GS) * (dgamma ? 4 : 1), dgamma ? 1024 : 8192), groups), dim3(256), \
                                           (size_t)(256 / GS) * 2 * C * sizeof(float), s, (const T*)dy, lddy, (const T*)x, ldx,            \
                                           (const T*)gamma, (const T*)beta, mean, rstd, (T*)dx, lddx, (const T*)dres, ldres, dgamma,      \
                                           dbeta, rows, C, act, pstride)
     TC_DISPATCH_DTYPE(dtype, { TC_LN_DISPATCH(quads, TC_LNB) });
 #undef TC_LNB
+    return tc_launch_status();
+}
+
+extern "C" int tc_layernorm_bwd_params(const void* dy, int lddy, const void* x, int ldx, const void* gamma, const void* beta,
+                                       const float* mean, const float* rstd, float* dgamma, float* dbeta, int rows, int C, int act,
+                                       int groups, long long pstride, int dtype, void* stream) {
+    if (!dy || !x || !gamma || !beta || !mean || !rstd || !dgamma || !dbeta || rows <= 0 || groups < 1 || C <= 0 || (C & 3) || (ldx & 3) ||
+        (lddy & 3))
+        return TC_ERR_ARG;
+    dim3 grid(tc_blocks(rows, 16 * 8, 128), (C + 63) / 64, groups);
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ln_param_grad_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)dy, lddy,
+                                                (const T*)x, ldx, (const T*)gamma, (const T*)beta, mean, rstd, dgamma, dbeta, rows, C, act,
+                                                pstride));
     return tc_launch_status();
 }
 

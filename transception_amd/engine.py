@@ -448,7 +448,11 @@ class Graph:
             gx, acc = self.wgrad(x)
             self.L.tc_layernorm_bwd(_ptr(dy), dy.stride(0), _ptr(x.data), x.ld, _ptr(g.data), _ptr(b.data), _ptr(mean),
                                     _ptr(rstd), _ptr(gx), gx.stride(0), _ptr(gx) if acc else None, gx.stride(0),
-                                    _ptr(g.grad), _ptr(b.grad), rows, Cc, act, Gn, g.gs, self.dt, self.stream)
+                                    None, None, rows, Cc, act, Gn, g.gs, self.dt, self.stream)
+            if g.grad is not None:
+                self._weight_grad(lambda: self.L.tc_layernorm_bwd_params(
+                    _ptr(dy), dy.stride(0), _ptr(x.data), x.ld, _ptr(g.data), _ptr(b.data), _ptr(mean), _ptr(rstd), _ptr(g.grad),
+                    _ptr(b.grad), rows, Cc, act, Gn, g.gs, self.dt, self.stream), reads=dy)
         self._rec(bwd)
         return out
 
