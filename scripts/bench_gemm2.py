@@ -1,0 +1,36 @@
+import sys; sys.argv = sys.argv[:1]
+exec(open("/root/repo/scripts/bench_gemm.py").read().split("run(12544, 256, 64)")[0])
+for cf in (0, 1):
+    run(50176, 256, 64, c_f32=cf); run(50176, 256, 64, tB=0, c_f32=cf); run(50176, 64, 256, c_f32=cf); run(50176, 64, 64, c_f32=cf)
+    run(12544, 512, 128, c_f32=cf); run(3136, 320, 1280, c_f32=cf); run(3136, 1280, 320, c_f32=cf)
+run(3136, 320, 1280, c_f32=1, splitk=2); run(3136, 320, 1280, c_f32=1, splitk=4); run(3136, 320, 1280, c_f32=1, splitk=5)
+run(784, 64, 4096, c_f32=1, splitk=1); run(784, 64, 4096, c_f32=1, splitk=16); run(784, 64, 4096, c_f32=1, splitk=32)
+run(784, 512, 2048, c_f32=1, splitk=1); run(784, 512, 2048, c_f32=1, splitk=4); run(784, 512, 2048, c_f32=1, splitk=8)
+run(64, 64, 3136, tA=1, tB=0, nb=16, c_f32=1, splitk=1); run(64, 64, 3136, tA=1, tB=0, nb=16, c_f32=1, splitk=16)
+print("--- with workspace (fix-up)")
+ws = torch.zeros(16384 + 1024 * 16384, dtype=torch.uint8, device=dev)
+def runw(M, N, K, tA=0, tB=1, c_f32=0, splitk=1, nb=1, iters=50, check=True):
+    a = (torch.randn((K, M) if tA else (M, K), device=dev) * 0.1).bfloat16().repeat(nb, 1)
+    b = (torch.randn((N, K) if tB else (K, N), device=dev) * 0.1).bfloat16().repeat(nb, 1)
+    c = torch.zeros(nb * M, N, device=dev, dtype=torch.float32 if c_f32 else torch.bfloat16)
+    g = TcGemm(a.data_ptr(), b.data_ptr(), c.data_ptr(), None, None, M, N, K, a.stride(0), b.stride(0), N, 0, tA, tB, nb, 1,
+               a.shape[0] // nb * a.stride(0), 0, b.shape[0] // nb * b.stride(0), 0, M * N, 0, 0, 0, 1.0, int(splitk > 1), 0, splitk, TC_BF16, c_f32, 0, None, 0, 0,
+               ws.data_ptr(), ws.numel())
+    c.zero_(); L.tc_gemm(C.byref(g), st); torch.cuda.synchronize()
+    if check:
+        a0 = a[: a.shape[0] // nb].float(); b0 = b[: b.shape[0] // nb].float()
+        ref = (a0.t() if tA else a0) @ (b0.t() if tB else b0)
+        err = (c[:M].float() - ref).abs().max().item() / ref.abs().max().item()
+        assert int(ws[:16384].max()) == 0, "counters not reset"
+    for _ in range(5): L.tc_gemm(C.byref(g), st)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): L.tc_gemm(C.byref(g), st)
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    print(f"M={M:6d} N={N:5d} K={K:6d} tA={tA} tB={tB} nb={nb} splitk={splitk:3d} c_f32={c_f32}: {us:7.1f} us  {2.0*M*N*K*nb/us/1e6:8.1f} TFLOP/s  relerr {err:.1e}")
+runw(3136, 320, 1280); runw(784, 64, 4096); runw(784, 512, 2048); runw(784, 320, 1280, nb=3); runw(784, 128, 2048); runw(64, 64, 3136, tA=1, tB=0, nb=16); runw(64, 64, 6076, nb=16)
+runw(64, 64, 50176, tA=1, tB=0, c_f32=1, splitk=128); runw(64, 64, 50176, tA=1, tB=0, c_f32=1, splitk=256); runw(256, 64, 50176, tA=1, tB=0, c_f32=1, splitk=128); runw(256, 64, 50176, tA=1, tB=0, c_f32=1, splitk=64)
+runw(1280, 320, 3136, tA=1, tB=0, c_f32=1, splitk=5); runw(1280, 320, 3136, tA=1, tB=0, c_f32=1, splitk=2); runw(512, 128, 12544, tA=1, tB=0, c_f32=1, splitk=32)
+runw(128, 128, 784, tA=1, tB=0, nb=16); runw(3136, 320, 320)

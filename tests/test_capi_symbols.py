@@ -36,7 +36,8 @@ def test_library_exports_every_declared_symbol(built):
     dll = ctypes.CDLL(built)
     for name in fns:
         assert hasattr(dll, name), f"{name} declared in the header but not exported by {built}"
-    assert dll.tc_abi_version() == 1
+    from transception_amd import _lib
+    assert dll.tc_abi_version() == _lib.ABI_VERSION == 2
 
 
 def test_ctypes_binding_matches_header(built):

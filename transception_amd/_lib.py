@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(HERE, "libtransception_hip.so")
 
 TC_F32, TC_BF16 = 0, 1
 ACT_NONE, ACT_HSWISH, ACT_COORD, ACT_SIGMOID, ACT_GELU = 0, 1, 2, 3, 4
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_longlong, C.c_float
 
@@ -25,7 +25,8 @@ class TcGemm(C.Structure):
                 ("transA", i32), ("transB", i32), ("nb1", i32), ("nb2", i32),
                 ("sA1", i64), ("sA2", i64), ("sB1", i64), ("sB2", i64),
                 ("sC1", i64), ("sC2", i64), ("sR1", i64), ("sR2", i64),
-                ("alpha", f32), ("accumulate", i32), ("act", i32), ("splitk", i32), ("dtype", i32), ("c_f32", i32), ("atomic", i32), ("rowsum", vp), ("sBias1", i64), ("sRow1", i64)]
+                ("alpha", f32), ("accumulate", i32), ("act", i32), ("splitk", i32), ("dtype", i32), ("c_f32", i32), ("atomic", i32), ("rowsum", vp), ("sBias1", i64), ("sRow1", i64),
+                ("ws", vp), ("ws_bytes", i64)]
 
 
 # name -> argtypes (every function returns int status unless listed in _RET)

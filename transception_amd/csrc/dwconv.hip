@@ -289,6 +289,252 @@ int launch_strip(const void* x, int ldx, const void* w, const void* bias, const 
     return tc_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Stride-1 LDS-tile kernels (the default): a workgroup owns TH x 16 output pixels x (CG * VEC) channels.  The input tile with
+// its (K-1) halo is fetched with 16-byte loads that are ALL issued before the first use (the row-strip walk above keeps only
+// K loads per thread in flight and is latency-bound at ~1/4 of the HBM rate), parked in LDS with a padded pixel pitch, and
+// every thread then produces a run of 4 horizontally adjacent pixels for its VEC channels from LDS.
+//   VEC = channels per 16 bytes (8 bf16 / 4 fp32); CG = 16-byte lanes per pixel (8/4/2: 64/32/16 bf16 channels per workgroup,
+//   picked on the host to waste the fewest lanes on the 16/24/48/80/120-channel maps of the multi-branch stages).
+template <typename T> struct Vec16;
+template <> struct Vec16<float> { static constexpr int N = 4; };
+template <> struct Vec16<bf16_t> { static constexpr int N = 8; };
+template <typename T> __device__ __forceinline__ void unpack16(const uint4& r, float* o);
+template <> __device__ __forceinline__ void unpack16<float>(const uint4& r, float* o) {
+    o[0] = __uint_as_float(r.x); o[1] = __uint_as_float(r.y); o[2] = __uint_as_float(r.z); o[3] = __uint_as_float(r.w);
+}
+template <> __device__ __forceinline__ void unpack16<bf16_t>(const uint4& r, float* o) {
+    o[0] = __uint_as_float(r.x << 16); o[1] = __uint_as_float(r.x & 0xffff0000u);
+    o[2] = __uint_as_float(r.y << 16); o[3] = __uint_as_float(r.y & 0xffff0000u);
+    o[4] = __uint_as_float(r.z << 16); o[5] = __uint_as_float(r.z & 0xffff0000u);
+    o[6] = __uint_as_float(r.w << 16); o[7] = __uint_as_float(r.w & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ uint4 pack16(const float* o);
+template <> __device__ __forceinline__ uint4 pack16<float>(const float* o) {
+    return make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3]));
+}
+template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* o) {
+    return make_uint4((unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16), (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16),
+                      (unsigned)f2bf(o[4]) | ((unsigned)f2bf(o[5]) << 16), (unsigned)f2bf(o[6]) | ((unsigned)f2bf(o[7]) << 16));
+}
+
+template <int K, int CG> struct DwTile {
+    static constexpr int PT = 256 / CG, R = 4, TW = 16, TH = PT / (TW / R), P = (K - 1) / 2;
+    static constexpr int IW = TW + K - 1, IH = TH + K - 1;
+};
+
+// stage rows [h0, h0+NH) x cols [w0, w0+NW) of image b (zero outside the map / past channel C) into LDS, pixel pitch PIXQ uint4
+template <typename T, int CG, int PIXQ>
+__device__ __forceinline__ void dw_stage(uint4* tile, const T* img, int ld, int h0, int w0, int NH, int NW, int H, int W, int crem) {
+    constexpr int VEC = Vec16<T>::N;
+    for (int v = threadIdx.x; v < NH * NW * CG; v += 256) {
+        const int cgi = v % CG, pix = v / CG, ix = pix % NW, iy = pix / NW;
+        const int ih = h0 + iy, iw = w0 + ix;
+        uint4 r = make_uint4(0u, 0u, 0u, 0u);
+        if (ih >= 0 && ih < H && iw >= 0 && iw < W && cgi * VEC < crem)
+            r = *reinterpret_cast<const uint4*>(img + ((long long)ih * W + iw) * ld + cgi * VEC);
+        tile[pix * PIXQ + cgi] = r;
+    }
+}
+
+template <typename T, int K, int CG, int MODE>      // MODE 0: y = conv(x) (+bias) (+x);  MODE 1: dx = conv^T(dy) (+dy) (+dx)
+__global__ __launch_bounds__(256) void dw_tile_kernel(const T* __restrict__ src, int lds_, const T* __restrict__ w,
+                                                      const T* __restrict__ bias, T* __restrict__ y, int ldy, int B, int H, int W,
+                                                      int C, int add_input, int accumulate, long long wstride, int tilesW,
+                                                      int tilesH) {
+    using D = DwTile<K, CG>;
+    constexpr int VEC = Vec16<T>::N, CH = CG * VEC, R = D::R, P = D::P;
+    constexpr int PIXQ = CG + (CG == 8 ? 2 : 1);
+    __shared__ uint4 tile[D::IH * D::IW * PIXQ];
+    __shared__ __attribute__((aligned(16))) float wsm[K * K][CH];
+    {
+        const long long g = blockIdx.z, img = (long long)B * H * W;
+        src += g * img * lds_; y += g * img * ldy; w += g * wstride;
+        if (bias) bias += g * wstride;
+    }
+    const int c0 = blockIdx.y * CH;
+    for (int i = threadIdx.x; i < K * K * CH; i += 256) {
+        const int cc = i / (K * K), t = i - cc * (K * K);
+        wsm[MODE == 1 ? K * K - 1 - t : t][cc] = (c0 + cc < C) ? ldf<T>(w + (long long)(c0 + cc) * K * K + t) : 0.f;
+    }
+    const int tix = blockIdx.x % tilesW, tiy = (blockIdx.x / tilesW) % tilesH, b = blockIdx.x / (tilesW * tilesH);
+    const int oh0 = tiy * D::TH, ow0 = tix * D::TW;
+    dw_stage<T, CG, PIXQ>(tile, src + (long long)b * H * W * lds_ + c0, lds_, oh0 - P, ow0 - P, D::IH, D::IW, H, W, C - c0);
+    __syncthreads();
+    const int cg = threadIdx.x % CG, pt = threadIdx.x / CG, run = pt % (D::TW / R), row = pt / (D::TW / R);
+    const int oh = oh0 + row, owb = ow0 + run * R, c = c0 + cg * VEC;
+    if (c >= C || oh >= H || owb >= W) return;
+    float acc[R][VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        const float bv = (MODE == 0 && bias) ? ldf<T>(bias + c + e) : 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r][e] = bv;
+    }
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+        float in[R + K - 1][VEC];
+#pragma unroll
+        for (int i = 0; i < R + K - 1; ++i) unpack16<T>(tile[((row + ky) * D::IW + run * R + i) * PIXQ + cg], in[i]);
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+            float wr[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; e += 4) {
+                const float4 t4 = *reinterpret_cast<const float4*>(&wsm[ky * K + kx][cg * VEC + e]);
+                wr[e] = t4.x; wr[e + 1] = t4.y; wr[e + 2] = t4.z; wr[e + 3] = t4.w;
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[r][e] += wr[e] * in[r + kx][e];
+        }
+        if (ky == P && add_input) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[r][e] += in[r + P][e];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (owb + r < W) {
+            T* dst = y + (((long long)b * H + oh) * W + owb + r) * ldy + c;
+            if (accumulate) {
+                float q[VEC];
+                unpack16<T>(*reinterpret_cast<const uint4*>(dst), q);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[r][e] += q[e];
+            }
+            *reinterpret_cast<uint4*>(dst) = pack16<T>(acc[r]);
+        }
+    }
+}
+
+// dw[c,ky,kx] += sum_pix dy[pix] * x[pix + (ky-P, kx-P)] ; db[c] += sum_pix dy[pix].  x tile (+halo) and dy tile in LDS; a thread
+// owns (16-byte channel lane, filter row ky) and a share of the tile's (row, 4-pixel run) units, K x VEC sums in registers
+// across all the tiles its workgroup visits; LDS float atomics fold the workgroup, then one global atomic per tap and channel.
+template <typename T, int K, int CG>
+__global__ __launch_bounds__(256) void dw_tile_wgrad_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy,
+                                                            float* __restrict__ dw, float* __restrict__ db, int B, int H, int W, int C,
+                                                            long long wstride, int tilesW, int tilesH) {
+    using D = DwTile<K, CG>;
+    constexpr int VEC = Vec16<T>::N, CH = CG * VEC, R = D::R, P = D::P, PIXQ = CG + 1, NT = K * K + 1;
+    constexpr int RG = D::PT / K, UNITS = D::TH * (D::TW / R);
+    __shared__ uint4 xt[D::IH * D::IW * PIXQ];
+    __shared__ uint4 dt[D::TH * D::TW * PIXQ];
+    __shared__ float lacc[NT][CH];
+    {
+        const long long g = blockIdx.z, img = (long long)B * H * W;
+        x += g * img * ldx; dy += g * img * lddy; dw += g * wstride;
+        if (db) db += g * wstride;
+    }
+    const int c0 = blockIdx.y * CH;
+    for (int i = threadIdx.x; i < NT * CH; i += 256) (&lacc[0][0])[i] = 0.f;
+    const int cg = threadIdx.x % CG, wk = threadIdx.x / CG, ky = wk / RG, rg = wk % RG;
+    const bool active = ky < K && c0 + cg * VEC < C;
+    float acc[K][VEC], accb[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        accb[e] = 0.f;
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) acc[kx][e] = 0.f;
+    }
+    const int ntiles = B * tilesH * tilesW;
+    for (int tidx = blockIdx.x; tidx < ntiles; tidx += gridDim.x) {
+        const int tix = tidx % tilesW, tiy = (tidx / tilesW) % tilesH, b = tidx / (tilesW * tilesH);
+        const int oh0 = tiy * D::TH, ow0 = tix * D::TW;
+        __syncthreads();
+        dw_stage<T, CG, PIXQ>(xt, x + (long long)b * H * W * ldx + c0, ldx, oh0 - P, ow0 - P, D::IH, D::IW, H, W, C - c0);
+        dw_stage<T, CG, PIXQ>(dt, dy + (long long)b * H * W * lddy + c0, lddy, oh0, ow0, D::TH, D::TW, H, W, C - c0);
+        __syncthreads();
+        if (active) {
+            for (int u = rg; u < UNITS; u += RG) {
+                const int row = u / (D::TW / R), run = u % (D::TW / R);
+                float d[R][VEC], in[R + K - 1][VEC];
+#pragma unroll
+                for (int r = 0; r < R; ++r) unpack16<T>(dt[(row * D::TW + run * R + r) * PIXQ + cg], d[r]);
+#pragma unroll
+                for (int i = 0; i < R + K - 1; ++i) unpack16<T>(xt[((row + ky) * D::IW + run * R + i) * PIXQ + cg], in[i]);
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) acc[kx][e] += d[r][e] * in[r + kx][e];
+                if (ky == 0) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) accb[e] += d[r][e];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) atomicAdd(&lacc[ky * K + kx][cg * VEC + e], acc[kx][e]);
+        if (ky == 0) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) atomicAdd(&lacc[K * K][cg * VEC + e], accb[e]);
+        }
+    }
+    __syncthreads();
+    for (int f = threadIdx.x; f < NT * CH; f += 256) {
+        const int cc = f / NT, t = f - cc * NT, ch = c0 + cc;              // taps fastest: neighbouring lanes hit neighbouring dw words
+        if (ch >= C) continue;
+        if (t < K * K) atomicAdd(dw + (long long)ch * K * K + t, lacc[t][cc]);
+        else if (db) atomicAdd(db + ch, lacc[t][cc]);
+    }
+}
+
+// 16-byte lanes per pixel that waste the fewest channels (ties: the widest)
+template <typename T> int dw_pick_cg(int C) {
+    constexpr int VEC = Vec16<T>::N;
+    int best = 8, waste = (C + 8 * VEC - 1) / (8 * VEC) * (8 * VEC) - C;
+    for (int cg = 4; cg >= 2; cg >>= 1) {
+        const int wst = (C + cg * VEC - 1) / (cg * VEC) * (cg * VEC) - C;
+        if (wst < waste) { best = cg; waste = wst; }
+    }
+    return best;
+}
+template <typename T> bool dw_tile_ok(const void* a, int lda, const void* b, int ldb, int C) {
+    constexpr int VEC = Vec16<T>::N;
+    return C % VEC == 0 && lda % VEC == 0 && ldb % VEC == 0 && (uintptr_t)a % 16 == 0 && (uintptr_t)b % 16 == 0;
+}
+
+template <typename T, int MODE>
+int launch_tile(const void* src, int lds_, const void* w, const void* bias, void* y, int ldy, const void* dy, int lddy, float* dw,
+                float* db, int B, int H, int W, int C, int k, int add_input, int accumulate, int groups, long long wstride,
+                hipStream_t s) {
+    constexpr int VEC = Vec16<T>::N;
+    const int cg = dw_pick_cg<T>(C);
+    const int chunks = (C + cg * VEC - 1) / (cg * VEC);
+    const int TH = (256 / cg) / 4, tilesW = (W + 15) / 16, tilesH = (H + TH - 1) / TH;
+    const long long ntiles = (long long)B * tilesW * tilesH;
+    if (ntiles > 0x7fffffffLL) return TC_ERR_ARG;
+#define TC_TILE(KK, CGG)                                                                                                                \
+    if (MODE == 2) {                                                                                                                    \
+        int gx = 512 / (chunks * groups); /* contended fp32 atomics cost ~0.13 us each: few contributors per address */                                                                                           \
+        gx = gx < 1 ? 1 : gx;                                                                                                           \
+        dim3 grid((unsigned)(ntiles < gx ? ntiles : gx), chunks, groups);                                                               \
+        hipLaunchKernelGGL((dw_tile_wgrad_kernel<T, KK, CGG>), grid, dim3(256), 0, s, (const T*)src, lds_, (const T*)dy, lddy, dw, db,  \
+                           B, H, W, C, wstride, tilesW, tilesH);                                                                        \
+    } else {                                                                                                                            \
+        dim3 grid((unsigned)ntiles, chunks, groups);                                                                                    \
+        hipLaunchKernelGGL((dw_tile_kernel<T, KK, CGG, (MODE == 2 ? 0 : MODE)>), grid, dim3(256), 0, s, (const T*)src, lds_,            \
+                           (const T*)w, (const T*)bias, (T*)y, ldy, B, H, W, C, add_input, accumulate, wstride, tilesW, tilesH);        \
+    }
+#define TC_TILE_K(KK) { if (cg == 8) { TC_TILE(KK, 8) } else if (cg == 4) { TC_TILE(KK, 4) } else { TC_TILE(KK, 2) } }
+    if (k == 3) TC_TILE_K(3) else if (k == 5) TC_TILE_K(5) else TC_TILE_K(7)
+#undef TC_TILE_K
+#undef TC_TILE
+    return tc_launch_status();
+}
+
 template <typename T, bool BWD>
 int launch_dw(const void* x, int ldx, const void* w, const void* bias, void* y, int ldy, int B, int H, int W, int C, int k,
               int stride, int add_input, int accumulate, hipStream_t s) {
@@ -315,8 +561,13 @@ extern "C" int tc_dwconv_fwd(const void* x, int ldx, const void* w, const void* 
     if (!x || !w || !y || (ldx & 3) || (ldy & 3) || groups < 1 || (groups > 1 && stride != 1) || !dw_args_ok(B, H, W, C, k, stride, add_input))
         return TC_ERR_ARG;
     if (stride == 1)
-        TC_DISPATCH_DTYPE(dtype, return (launch_strip<T, 0>(x, ldx, w, bias, nullptr, 0, y, ldy, nullptr, nullptr, B, H, W, C, k,
-                                                            add_input, 0, groups, wstride, (hipStream_t)stream)));
+        TC_DISPATCH_DTYPE(dtype, {
+            if (dw_tile_ok<T>(x, ldx, y, ldy, C))
+                return (launch_tile<T, 0>(x, ldx, w, bias, y, ldy, nullptr, 0, nullptr, nullptr, B, H, W, C, k, add_input, 0, groups,
+                                          wstride, (hipStream_t)stream));
+            return (launch_strip<T, 0>(x, ldx, w, bias, nullptr, 0, y, ldy, nullptr, nullptr, B, H, W, C, k, add_input, 0, groups,
+                                       wstride, (hipStream_t)stream));
+        });
     TC_DISPATCH_DTYPE(dtype, return (launch_dw<T, false>(x, ldx, w, bias, y, ldy, B, H, W, C, k, stride, add_input, 0,
                                                          (hipStream_t)stream)));
     return TC_ERR_ARG;
@@ -329,8 +580,13 @@ extern "C" int tc_dwconv_bwd_input(const void* dy, int lddy, const void* w, void
         !dw_args_ok(B, H, W, C, k, stride, add_input))
         return TC_ERR_ARG;
     if (stride == 1)
-        TC_DISPATCH_DTYPE(dtype, return (launch_strip<T, 1>(nullptr, 0, w, nullptr, dy, lddy, dx, lddx, nullptr, nullptr, B, H, W, C, k,
-                                                            add_input, accumulate, groups, wstride, (hipStream_t)stream)));
+        TC_DISPATCH_DTYPE(dtype, {
+            if (dw_tile_ok<T>(dy, lddy, dx, lddx, C))
+                return (launch_tile<T, 1>(dy, lddy, w, nullptr, dx, lddx, nullptr, 0, nullptr, nullptr, B, H, W, C, k, add_input,
+                                          accumulate, groups, wstride, (hipStream_t)stream));
+            return (launch_strip<T, 1>(nullptr, 0, w, nullptr, dy, lddy, dx, lddx, nullptr, nullptr, B, H, W, C, k, add_input,
+                                       accumulate, groups, wstride, (hipStream_t)stream));
+        });
     TC_DISPATCH_DTYPE(dtype, return (launch_dw<T, true>(dy, lddy, w, nullptr, dx, lddx, B, H, W, C, k, stride, add_input, accumulate,
                                                         (hipStream_t)stream)));
     return TC_ERR_ARG;
@@ -340,8 +596,13 @@ extern "C" int tc_dwconv_bwd_weight(const void* dy, int lddy, const void* x, int
                                     int W, int C, int k, int stride, int groups, long long wstride, int dtype, void* stream) {
     if (!dy || !x || !dw || groups < 1 || (groups > 1 && stride != 1) || !dw_args_ok(B, H, W, C, k, stride, 0)) return TC_ERR_ARG;
     if (stride == 1)
-        TC_DISPATCH_DTYPE(dtype, return (launch_strip<T, 2>(x, ldx, nullptr, nullptr, dy, lddy, nullptr, 0, dw, db, B, H, W, C, k, 0, 0,
-                                                            groups, wstride, (hipStream_t)stream)));
+        TC_DISPATCH_DTYPE(dtype, {
+            if (dw_tile_ok<T>(x, ldx, dy, lddy, C))
+                return (launch_tile<T, 2>(x, ldx, nullptr, nullptr, nullptr, 0, dy, lddy, dw, db, B, H, W, C, k, 0, 0, groups, wstride,
+                                          (hipStream_t)stream));
+            return (launch_strip<T, 2>(x, ldx, nullptr, nullptr, dy, lddy, nullptr, 0, dw, db, B, H, W, C, k, 0, 0, groups, wstride,
+                                       (hipStream_t)stream));
+        });
     const int P = (k - 1) / 2;
     const int Ho = (H + 2 * P - k) / stride + 1, Wo = (W + 2 * P - k) / stride + 1;
     const long long npix = (long long)B * Ho * Wo;

@@ -24,18 +24,73 @@ struct GemmDev {
     int vecA, vecB, vecC, atomic;
     float* rowsum;          // optional: rowsum[m] += sum_k op(A)[m][k]  (fp32, atomics)
     long long sBias1, sRow1; // batch-level-1 strides of bias / rowsum (grouped weights)
+    float* ws_part; int* ws_cnt; int fix_group, fix_ngroups;   // split-K fix-up workspace (fix_group > 0: enabled)
 };
+
+// Split-K fix-up without a second launch.  The `splitk` workgroups of an output tile park their fp32 partial tiles in the
+// workspace (plain coalesced stores), groups of `fix_group` consecutive splits share an arrival counter, and the member that
+// arrives last sums its group's partials in split order (deterministic) and runs the normal epilogue: directly when the tile
+// has one group (any output type, bias / residual / activation applied once), with fp32 atomics when it has several (weight
+// gradients with very long K: the same-address atomic chain is then splitk/fix_group long instead of splitk -- contended
+// fp32 atomics cost ~0.13 us EACH on this part, which is what made 128-way atomic split-K slow).
+// Cross-XCD visibility without flushing L2s: partials move with agent-scope (write-through / L2-bypassing) stores and loads,
+// the counter is an agent-scope atomic; an agent-scope fence here would write back and invalidate the whole L2 per workgroup
+// (measured 4x slower than no split at all).
+template <int TM, int TN>
+__device__ __forceinline__ bool splitk_fixup(const GemmDev& p, f32x16 (&acc)[TM][TN], int tile, int ks, int& grp) {
+    const int G = p.fix_group, tid = threadIdx.x;
+    grp = ks / G;
+    const int g0 = grp * G, gm = min(G, p.splitk - g0);
+    if (gm == 1) return true;
+    constexpr int NV = TM * TN * 16;
+    float* part = p.ws_part + ((long long)tile * p.splitk + ks) * (NV * 256) + tid;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                __hip_atomic_store(part + ((i * TN + j) * 16 + r) * 256, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // write-through stores have landed (vmcnt 0); no L2 flush
+    __syncthreads();
+    __shared__ int s_last;
+    if (tid == 0) {
+        int* c = p.ws_cnt + tile * p.fix_ngroups + grp;
+        const int old = atomicAdd(c, 1);
+        s_last = (old == gm - 1);
+        if (s_last) atomicExch(c, 0);                    // the workspace is left clean for the next launch on this stream
+    }
+    __syncthreads();
+    if (!s_last) return false;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const float* q = p.ws_part + ((long long)tile * p.splitk + g0) * (NV * 256) + tid;
+#pragma unroll 4
+    for (int s_ = 0; s_ < gm; ++s_, q += NV * 256) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[i][j][r] += __hip_atomic_load(q + ((i * TN + j) * 16 + r) * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return true;
+}
 
 // ---------------------------------------------------------------------------------------------- shared epilogue
 // The MFMAs are issued with swapped operands (D^T = B^T A^T), so a lane owns ONE output row m = lane&31 of its 32x32
 // block and register r holds column n = (r&3) + 8*(r>>2) + 4*(lane>>5): four consecutive columns per register group,
 // i.e. 8-byte (bf16) / 16-byte (fp32) row-major stores instead of 2-byte ones.
 template <typename T, typename TC, int TM, int TN>
-__device__ __forceinline__ void epilogue_rows(const GemmDev& p, f32x16 (&acc)[TM][TN], int b1, int b2, int ks, int mbase, int nbase, int lane) {
+__device__ __forceinline__ void epilogue_rows(const GemmDev& p, f32x16 (&acc)[TM][TN], int b1, int b2, bool first_split, bool atomic, int mbase, int nbase, int lane) {
     TC* C = reinterpret_cast<TC*>(p.C) + b1 * p.sC1 + b2 * p.sC2;
     const T* R = p.R ? reinterpret_cast<const T*>(p.R) + b1 * p.sR1 + b2 * p.sR2 : nullptr;
     const T* bias = p.bias ? reinterpret_cast<const T*>(p.bias) + b1 * p.sBias1 : nullptr;
-    const bool first_split = (ks == 0);
     const int h = lane >> 5;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -60,7 +115,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmDev& p, f32x16 (&acc)[TM
                         const float4 r4 = ld4<T>(R + (long long)row * p.ldr + col);
                         v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
                     }
-                    if (p.atomic) {
+                    if (atomic) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) atomicAdd(reinterpret_cast<float*>(c) + e, v[e]);
                     } else {
@@ -78,7 +133,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmDev& p, f32x16 (&acc)[TM
                         float w = v[e];
                         if (bias && first_split) w += ldf<T>(bias + col + e);
                         if (R && first_split) w += ldf<T>(R + (long long)row * p.ldr + col + e);
-                        if (p.atomic) atomicAdd(reinterpret_cast<float*>(c) + e, w);
+                        if (atomic) atomicAdd(reinterpret_cast<float*>(c) + e, w);
                         else {
                             if (p.act == TC_ACT_SIGMOID) w = sigmoid_f(w);
                             if (p.accumulate) w += ldf<TC>(c + e);
@@ -93,11 +148,10 @@ __device__ __forceinline__ void epilogue_rows(const GemmDev& p, f32x16 (&acc)[TM
 // Un-swapped orientation (fp32 C: weight gradients, fp32 storage): register r holds row (r&3) + 8*(r>>2) + 4*(lane>>5), the
 // 32 lanes of a half-wave hold 32 consecutive columns -> 128-byte coalesced fp32 stores / atomics.
 template <typename T, typename TC, int TM, int TN>
-__device__ __forceinline__ void epilogue_cols(const GemmDev& p, f32x16 (&acc)[TM][TN], int b1, int b2, int ks, int mbase, int nbase, int lane) {
+__device__ __forceinline__ void epilogue_cols(const GemmDev& p, f32x16 (&acc)[TM][TN], int b1, int b2, bool first_split, bool atomic, int mbase, int nbase, int lane) {
     TC* C = reinterpret_cast<TC*>(p.C) + b1 * p.sC1 + b2 * p.sC2;
     const T* R = p.R ? reinterpret_cast<const T*>(p.R) + b1 * p.sR1 + b2 * p.sR2 : nullptr;
     const T* bias = p.bias ? reinterpret_cast<const T*>(p.bias) + b1 * p.sBias1 : nullptr;
-    const bool first_split = (ks == 0);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -112,7 +166,7 @@ __device__ __forceinline__ void epilogue_cols(const GemmDev& p, f32x16 (&acc)[TM
                 float v = p.alpha * acc[i][j][r] + bv;
                 if (R && first_split) v += ldf<T>(R + (long long)row * p.ldr + col);
                 TC* c = C + (long long)row * p.ldc + col;
-                if (p.atomic) {
+                if (atomic) {
                     atomicAdd(reinterpret_cast<float*>(c), v);
                 } else {
                     if (p.act == TC_ACT_SIGMOID) v = sigmoid_f(v);
@@ -249,7 +303,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev p) {
         __syncthreads();
     }
     if (do_rowsum && m0 + tid < p.M) atomicAdd(p.rowsum + b1 * p.sRow1 + m0 + tid, rsum);
-    epilogue_cols<float, TC, TM, TN>(p, acc, b1, b2, ks, m0 + wr * WM, n0 + wc * WN, lane);
+    bool first = (ks == 0), atomic = p.atomic;
+    if (p.fix_group) {
+        int grp;
+        if (!splitk_fixup<TM, TN>(p, acc, (int)(((blockIdx.z / p.splitk) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x), ks, grp)) return;
+        first = (grp == 0); atomic = p.fix_ngroups > 1;
+    }
+    epilogue_cols<float, TC, TM, TN>(p, acc, b1, b2, first, atomic, m0 + wr * WM, n0 + wc * WN, lane);
 }
 
 // ---------------------------------------------------------------------------------------------- bf16 path
@@ -412,8 +472,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmDev p) {
         }
     }
     if (do_rowsum && m0 + tid < p.M) atomicAdd(p.rowsum + b1 * p.sRow1 + m0 + tid, rsum);
-    if (SWAP) epilogue_rows<bf16_t, TC, TM, TN>(p, acc, b1, b2, ks, m0 + wr * WM, n0 + wc * WN, lane);
-    else epilogue_cols<bf16_t, TC, TM, TN>(p, acc, b1, b2, ks, m0 + wr * WM, n0 + wc * WN, lane);
+    bool first = (ks == 0), atomic = p.atomic;
+    if (p.fix_group) {
+        int grp;
+        if (!splitk_fixup<TM, TN>(p, acc, (int)(((blockIdx.z / p.splitk) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x), ks, grp)) return;
+        first = (grp == 0); atomic = p.fix_ngroups > 1;
+    }
+    if (SWAP) epilogue_rows<bf16_t, TC, TM, TN>(p, acc, b1, b2, first, atomic, m0 + wr * WM, n0 + wc * WN, lane);
+    else epilogue_cols<bf16_t, TC, TM, TN>(p, acc, b1, b2, first, atomic, m0 + wr * WM, n0 + wc * WN, lane);
 }
 
 // ---------------------------------------------------------------------------------------------- host side
@@ -442,7 +508,6 @@ int gemm_typed(const TcGemm* g, hipStream_t s) {
     d.sA1 = g->sA1; d.sA2 = g->sA2; d.sB1 = g->sB1; d.sB2 = g->sB2;
     d.sC1 = g->sC1; d.sC2 = g->sC2; d.sR1 = g->sR1; d.sR2 = g->sR2;
     d.alpha = g->alpha; d.accumulate = g->accumulate; d.act = g->act;
-    d.atomic = (g->splitk > 1 || g->atomic) ? 1 : 0;
     d.rowsum = g->rowsum;
     d.sBias1 = g->sBias1; d.sRow1 = g->sRow1;
     constexpr int VEC = 16 / (int)sizeof(T);                         // elements per 16-byte vector
@@ -462,11 +527,36 @@ int gemm_typed(const TcGemm* g, hipStream_t s) {
     const bool use128 = big >= 192 && g->M >= 96 && g->N >= 96;
     const int BM = use128 ? 128 : 64, BN = use128 ? 128 : 64;
     constexpr int BK = sizeof(T) == 4 ? 16 : 64;
-    int kchunk = (g->K + g->splitk - 1) / g->splitk;
+    // split-K plan: the caller's request (weight gradients), or -- with a workspace -- our own for few-tile / long-K
+    // products whose K loop would otherwise run serially on a handful of CUs
+    constexpr int CNT_BYTES = 16384, PART_BYTES = 64 * 64 * 4, FIX_GROUP = 16;
+    const long long tiles64 = (long long)((g->M + 63) / 64) * ((g->N + 63) / 64) * nb;
+    const long long slots = (g->ws && g->ws_bytes > CNT_BYTES && (uintptr_t)g->ws % 16 == 0) ? (g->ws_bytes - CNT_BYTES) / PART_BYTES : 0;
+    int want = g->splitk;
+    bool fix = false;
+    if (!use128 && slots > 0) {
+        if (want == 1 && !g->atomic && g->K >= 512 && tiles64 <= 384) {
+            long long sk = 1024 / tiles64;
+            if (sk > g->K / 256) sk = g->K / 256;
+            if (sk > FIX_GROUP) sk = FIX_GROUP;
+            if (sk >= 2 && tiles64 * sk <= slots) { want = (int)sk; fix = true; }
+        }
+        // (a caller-requested split -- fp32 weight gradients with K up to 800k -- keeps the atomic epilogue: measured equal or
+        //  better there, the last-arriver's L2-bypassing reads of 16+ partials cost what the atomic chain costs)
+    }
+    int kchunk = (g->K + want - 1) / want;
     kchunk = (kchunk + BK - 1) / BK * BK;
     d.kchunk = kchunk;
     d.splitk = (g->K + kchunk - 1) / kchunk;
     if (d.splitk < 1) d.splitk = 1;
+    d.fix_group = 0; d.fix_ngroups = 1; d.ws_part = nullptr; d.ws_cnt = nullptr;
+    if (fix && d.splitk > 1) {
+        d.fix_group = FIX_GROUP;
+        d.fix_ngroups = (d.splitk + FIX_GROUP - 1) / FIX_GROUP;
+        d.ws_cnt = reinterpret_cast<int*>(g->ws);
+        d.ws_part = reinterpret_cast<float*>(reinterpret_cast<char*>(g->ws) + CNT_BYTES);
+    }
+    d.atomic = ((d.splitk > 1 && !d.fix_group) || g->atomic) ? 1 : 0;
     dim3 grid((g->N + BN - 1) / BN, (g->M + BM - 1) / BM, nb * d.splitk);
     if (grid.y > 65535 || grid.z > 65535) return TC_ERR_ARG;
     if (g->c_f32)

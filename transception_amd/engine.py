@@ -132,6 +132,24 @@ def _side_streams(device, n: int):
     return pool[:n]
 
 
+_WORKSPACES: Dict[Tuple[str, int], torch.Tensor] = {}
+WORKSPACE_BYTES = 16384 + 1024 * 16384             # arrival counters + 1024 fp32 64x64 partial tiles
+
+
+def _workspace(device, stream_ptr: int) -> torch.Tensor:
+    """Split-K fix-up workspace of the kernels launched on `stream_ptr` (include/transception_hip.h, TcGemm.ws): launches on one
+    stream never overlap, so one buffer per stream is enough; zeroed once, every launch leaves its counters zero."""
+    key = (str(device), int(stream_ptr or 0))
+    ws = _WORKSPACES.get(key)
+    if ws is None:
+        ws = _WORKSPACES[key] = torch.zeros(WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+    return ws
+
+
+_N_WSTREAMS = int(os.environ.get("TC_WGRAD_STREAMS", "4"))
+_SKIP_WGRAD = bool(os.environ.get("TC_DEBUG_SKIP_WGRAD"))
+
+
 class _Branch:
     def __init__(self, G, stream):
         self.G, self.stream, self.ctx, self.prev = G, stream, None, None
@@ -211,6 +229,7 @@ class Graph:
         self.training = training
         self.record = record
         self.tape: List[Callable[[], None]] = []
+        self._wnext = 0
         self._wstream = None          # side stream for weight-gradient kernels (nothing downstream in backward needs them)
         self._pending: Dict[int, torch.cuda.Event] = {}     # gradient storage -> last weight-gradient kernel still reading it
         self._keep: list = []
@@ -301,12 +320,15 @@ class Graph:
         """Run a weight-gradient kernel on the side stream: dW / dw / db are only consumed by the optimizer, so they overlap
         with the activation-gradient chain.  `reads` = the upstream gradient buffer the kernel reads: a later in-place
         accumulation into that buffer (aliased residual gradients) must wait for this kernel (see wgrad)."""
+        if _SKIP_WGRAD:                                  # timing what-if only (results are wrong): critical-path analysis
+            return
         if not (self.overlap_wgrad and self.use_streams and self.cur is not None):
             fn()
             return
         if self._wstream is None:
-            self._wstream = _side_streams(self.dev, 4)[3]
-        ws = self._wstream
+            self._wstream = _side_streams(self.dev, 3 + _N_WSTREAMS)[3:]
+        ws = self._wstream[self._wnext % len(self._wstream)]   # independent kernels: round-robin so they also overlap each other
+        self._wnext += 1
         ws.wait_stream(self.cur)
         with _Branch(self, ws):
             fn()
@@ -337,7 +359,8 @@ class Graph:
                         fn()
         self.cur, self.stream = main
         if self._wstream is not None:
-            self.cur.wait_stream(self._wstream)          # all weight gradients are in the arena before anything follows
+            for ws in self._wstream:
+                self.cur.wait_stream(ws)                 # all weight gradients are in the arena before anything follows
         self._pending.clear()
         self._keep.clear()
         self.tape = []
@@ -349,8 +372,9 @@ class Graph:
     # ------------------------------------------------------------------ GEMM plumbing
     def _gemm(self, A, lda, B, ldb, Cm, ldc, M, N, K, tA, tB, bias=None, R=None, ldr=0, alpha=1.0, acc=0, act=ACT_NONE,
               splitk=1, nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), c_f32=0, atomic=0, rowsum=None, sbias=0, srow=0):
+        ws = _workspace(self.dev, self.stream)
         g = TcGemm(A, B, Cm, bias, R, M, N, K, lda, ldb, ldc, ldr, tA, tB, nb1, nb2, sA[0], sA[1], sB[0], sB[1], sC[0], sC[1],
-                   sR[0], sR[1], alpha, acc, act, splitk, self.dt, c_f32, atomic, rowsum, sbias, srow)
+                   sR[0], sR[1], alpha, acc, act, splitk, self.dt, c_f32, atomic, rowsum, sbias, srow, ws.data_ptr(), ws.numel())
         self.n_launch += 1
         self.L.tc_gemm(C.byref(g), self.stream)
 
@@ -534,23 +558,10 @@ class Graph:
             sA=(0, 0), sB=(0, 0), sC=(0, 0), alpha: float = 1.0) -> Var:
         """out[b] = alpha * op(A[b]) op(B[b]); A/B/out are 2-D views whose data pointer is batch (0,0)."""
         assert not (tA and tB)
-        tiles = ((M + 63) // 64) * ((N + 63) // 64) * nb1 * nb2
-        if tiles < 128 and K >= 1024 and out.data.is_contiguous() and out.is_whole:
-            # a handful of output tiles with a long reduction (token-reduced context matrices): split K over many workgroups,
-            # fp32 atomics into a zeroed buffer, then one cast -- 3 short launches instead of one 100-400 us serial one
-            sk = max(1, min(K // 256, 1024 // tiles))
-            if self.dtype == torch.float32:
-                out.data.zero_()
-                self._gemm(_ptr(A.data), A.ld, _ptr(B.data), B.ld, _ptr(out.data), out.ld, M, N, K, tA, tB, alpha=alpha, nb1=nb1,
-                           nb2=nb2, sA=sA, sB=sB, sC=sC, acc=1, splitk=sk)
-            else:
-                tmp = torch.zeros(out.data.shape, dtype=torch.float32, device=self.dev)
-                self._gemm(_ptr(A.data), A.ld, _ptr(B.data), B.ld, _ptr(tmp), out.ld, M, N, K, tA, tB, alpha=alpha, nb1=nb1,
-                           nb2=nb2, sA=sA, sB=sB, sC=sC, acc=1, splitk=sk, c_f32=1)
-                self.L.tc_cast(_ptr(tmp), _ptr(out.data), tmp.numel(), TC_F32, TC_BF16, self.stream)
-        else:
-            self._gemm(_ptr(A.data), A.ld, _ptr(B.data), B.ld, _ptr(out.data), out.ld, M, N, K, tA, tB, alpha=alpha, nb1=nb1,
-                       nb2=nb2, sA=sA, sB=sB, sC=sC)
+        # few output tiles with a long reduction (token-reduced context matrices): tc_gemm splits K itself and folds the
+        # partials in-kernel through the per-stream workspace
+        self._gemm(_ptr(A.data), A.ld, _ptr(B.data), B.ld, _ptr(out.data), out.ld, M, N, K, tA, tB, alpha=alpha, nb1=nb1,
+                   nb2=nb2, sA=sA, sB=sB, sC=sC)
 
         def bwd():
             dC = self.grad_of(out)
