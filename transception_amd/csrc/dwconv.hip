@@ -371,7 +371,9 @@ __global__ __launch_bounds__(256) void dw_tile_kernel(const T* __restrict__ src,
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r][e] = bv;
     }
-#pragma unroll
+    // K = 3: fully unrolled (all 18 LDS reads in flight); K >= 5: one filter row at a time, or the unrolled loads of all K rows
+    // are hoisted and the kernel needs > 256 VGPRs
+#pragma unroll(K == 3 ? 3 : 1)
     for (int ky = 0; ky < K; ++ky) {
         float in[R + K - 1][VEC];
 #pragma unroll

@@ -147,6 +147,7 @@ def _workspace(device, stream_ptr: int) -> torch.Tensor:
 
 
 _N_WSTREAMS = int(os.environ.get("TC_WGRAD_STREAMS", "4"))
+_NO_PENDING = bool(os.environ.get("TC_DEBUG_NO_PENDING"))   # timing what-if only (racy)
 _SKIP_WGRAD = bool(os.environ.get("TC_DEBUG_SKIP_WGRAD"))
 
 
@@ -272,7 +273,7 @@ class Graph:
             r.whole_written = True
         else:
             r.written.append(reg)
-        if self._pending:
+        if self._pending and not _NO_PENDING:
             ev = self._pending.pop(r.grad_t.untyped_storage().data_ptr(), None)
             if ev is not None:
                 self.cur.wait_event(ev)                  # a weight-gradient kernel on the side stream still reads this buffer
