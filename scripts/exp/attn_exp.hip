@@ -9,7 +9,10 @@
 //   * rescales the running output lazily (only when some row maximum grew by more than 2^8),
 //   * allows two workgroups per CU (launch bounds) so one wave's softmax VALU overlaps another's MFMA.
 // fp32 storage falls back to the per-segment fp32 kernels of attention.hip (parity path).
-#include "tc_common.h"
+#include "../../transception_amd/csrc/tc_common.h"
+#ifndef ATT_VAR
+#define ATT_VAR 0
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -33,6 +36,16 @@ struct Segs {
 __device__ __forceinline__ int pi_row(int i) { return 16 * ((i >> 2) & 1) + (i & 3) + 4 * (i >> 3); }
 __device__ __forceinline__ int d_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 __device__ __forceinline__ bf16x8 ld_frag(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+// two hardware transpose reads (ds_read_b64_tr_b16): lane i of a 16-lane group passes the address of row i>>2, columns
+// 4*(i&3).. of a 4 x 16 block and receives column i of it; lo = rows 0-3, hi = rows 4-7 of the lane's 8-deep k-slice
+__device__ __forceinline__ bf16x8 ld_frag_tr(const bf16_t* lo, const bf16_t* hi) {
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(lo));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(hi));
+    const s16x8 c = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, c);
+}
 __device__ __forceinline__ bf16x8 pack8(const f32x16& v, int o) {
     bf16x8 r;
 #pragma unroll
@@ -66,6 +79,11 @@ __device__ __forceinline__ void fill_map(int tid, int it, int& r, int& c8, int& 
     r = 16 * (c >> 1) + (lane & 15);
     c8 = 32 * (c & 1) + 8 * g;
 }
+__device__ __forceinline__ float max3f(float a, float b, float c) {      // no canonicalising v_max in front (MFMA outputs)
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // block -> (segment, image, first query row of the tile, queries valid in the tile's segment-image)
@@ -81,6 +99,169 @@ __device__ __forceinline__ void locate_tile(const Segs& sg, int t, int& row_base
     row_base = sg.row0[s] + b * nq;
 }
 
+#if ATT_VAR >= 5
+// v5: wave tiles flattened per image (768 workgroups = 3 per CU exactly at the bench shape), 64-key double-buffered LDS stages
+// (one barrier per stage, K and V both prefetched a full stage ahead), two independent S chains per iteration.
+__global__ __launch_bounds__(256, 3) void attn_fwd_seg_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
+                                                              const bf16_t* __restrict__ V, int ldv, long long skv, bf16_t* __restrict__ O,
+                                                              int ldo, float* __restrict__ lse, Segs sg, int Nk, float scale) {
+    constexpr int KS = 64, LDK = D + 8, LDV = KS + 16;
+#if ATT_VAR >= 9
+    constexpr int PV = D + 32;                           // 192-byte rows: the 4 rows of a tr-read block land on disjoint 16-bank windows
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[2][KS * LDK];
+    __shared__ __attribute__((aligned(16))) bf16_t Vs[2][KS * PV];
+#else
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[2][KS * LDK];
+    __shared__ __attribute__((aligned(16))) bf16_t Vt[2][D * LDV];
+#endif
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    const int nwt = sg.t32[sg.n], bpi = (nwt + 3) >> 2;
+    const int b = blockIdx.x / bpi, wt = (blockIdx.x - b * bpi) * 4 + wave;
+    int sgi = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) if (i < sg.n && wt >= sg.t32[i]) sgi = i;
+    const int nq = sg.nq[sgi];
+    const int ql = (wt - sg.t32[sgi]) * 32 + j;
+    const bool ok = wt < nwt && ql < nq;
+    const long long qrow = (long long)sg.row0[sgi] + (long long)b * nq + ql;
+    const bf16_t* Kb = K + b * skv;
+    const bf16_t* Vb = V + b * skv;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const uint4 v = ok ? *reinterpret_cast<const uint4*>(Q + qrow * ldq + 16 * ks + 8 * h) : make_uint4(0u, 0u, 0u, 0u);
+        qf[ks] = *reinterpret_cast<const bf16x8*>(&v);
+    }
+    const float qs = scale * LOG2E;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    float m = NEG_BIG, lsum = 0.f;
+    const int krow = pi_row(j);
+    uint4 kr[2], vr[2];
+    auto fmap = [&](int it, int& r, int& c8, int& g) {
+#if ATT_VAR >= 9
+        const int idx = tid + 256 * it;                   // 8 lanes = one 128-byte row: coalesced loads, conflict-free b128 stores
+        g = 0; r = idx >> 3; c8 = (idx & 7) * 8;
+#else
+        const int c = wave * 2 + it;
+        g = lane >> 4; r = 16 * (c >> 1) + (lane & 15); c8 = 32 * (c & 1) + 8 * g;
+#endif
+    };
+    auto fetch = [&](int st) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int r, c8, g; fmap(i, r, c8, g);
+            const int row = min(st * KS + r, Nk - 1);       // rows past Nk: a finite duplicate, masked to P = 0 below (no branch, no wait)
+            kr[i] = *reinterpret_cast<const uint4*>(Kb + (long long)row * ldk + c8);
+            vr[i] = *reinterpret_cast<const uint4*>(Vb + (long long)row * ldv + c8);
+        }
+    };
+    auto put = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int r, c8, g; fmap(i, r, c8, g);
+            *reinterpret_cast<uint4*>(&Ks[buf][r * LDK + c8]) = kr[i];
+#if ATT_VAR >= 9
+            *reinterpret_cast<uint4*>(&Vs[buf][r * PV + c8]) = vr[i];
+#else
+            st_t8(Vt[buf], LDV, c8, r, vr[i], g);
+#endif
+        }
+    };
+    const int nst = (Nk + KS - 1) / KS;
+    fetch(0); put(0);
+    if (nst > 1) fetch(1);
+    __syncthreads();
+    for (int st = 0; st < nst; ++st) {
+        const int buf = st & 1;
+#if ATT_VAR != 7 && ATT_VAR != 8
+        if (st + 1 < nst) put(buf ^ 1);
+        if (st + 2 < nst) fetch(st + 2);
+#endif
+        f32x16 sa, sb;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sa[r] = 0.f; sb[r] = 0.f; }
+        {
+            const bf16_t* kpa = Ks[buf] + krow * LDK + 8 * h;
+            bf16x8 ka[4], kb[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) { ka[ks] = ld_frag(kpa + 16 * ks); kb[ks] = ld_frag(kpa + 32 * LDK + 16 * ks); }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ks], qf[ks], sa, 0, 0, 0);
+                sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb[ks], qf[ks], sb, 0, 0, 0);
+            }
+        }
+        const int kv0 = st * KS;
+        if (kv0 + KS > Nk) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (kv0 + 16 * h + r >= Nk) sa[r] = NEG_BIG;
+                if (kv0 + 32 + 16 * h + r >= Nk) sb[r] = NEG_BIG;
+            }
+        }
+#if ATT_VAR != 6 && ATT_VAR != 8
+        float mx = max3f(sa[0], sb[0], sa[1]);
+        mx = max3f(mx, sb[1], sa[2]);
+#pragma unroll
+        for (int r = 2; r < 15; ++r) mx = max3f(mx, sb[r], sa[r + 1]);
+        mx = fmaxf(mx, sb[15]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * qs;
+        if (__any(mx > m + RESCALE_THR)) {
+            const float mn = fmaxf(m, mx);
+            const float alpha = fast_exp2(m - mn);
+            lsum *= alpha;
+            m = mn;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] *= alpha; acc1[r] *= alpha; }
+        }
+        float rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sa[r] = fast_exp2(fmaf(sa[r], qs, -m)); sb[r] = fast_exp2(fmaf(sb[r], qs, -m));
+            rs += sa[r] + sb[r];
+        }
+        lsum += rs;                                        // the two halves are combined once, after the loop
+#else
+        lsum = 1.f;
+#endif
+#if ATT_VAR >= 9
+        const bf16_t* vp = Vs[buf] + (16 * h + ((lane & 15) >> 2)) * PV + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) {
+            const bf16x8 pb = (k2 < 2) ? pack8(sa, 8 * k2) : pack8(sb, 8 * (k2 - 2));
+            const int roff = (32 * (k2 >> 1) + 8 * (k2 & 1)) * PV;
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag_tr(vp + roff, vp + roff + 4 * PV), pb, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag_tr(vp + roff + 32, vp + roff + 4 * PV + 32), pb, acc1, 0, 0, 0);
+        }
+#else
+        const bf16_t* vp = Vt[buf] + j * LDV + 16 * h;
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) {
+            const bf16x8 pb = (k2 < 2) ? pack8(sa, 8 * k2) : pack8(sb, 8 * (k2 - 2));
+            const int off = 32 * (k2 >> 1) + 8 * (k2 & 1);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(vp + off), pb, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(vp + 32 * LDV + off), pb, acc1, 0, 0, 0);
+        }
+#endif
+#if ATT_VAR != 7 && ATT_VAR != 8
+        __syncthreads();
+#endif
+    }
+    lsum += __shfl_xor(lsum, 32, 64);
+    if (ok) {
+        const float inv = 1.0f / lsum;
+        bf16_t* orow = O + qrow * ldo;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            st4<bf16_t>(orow + 8 * g + 4 * h, make_float4(acc0[4 * g] * inv, acc0[4 * g + 1] * inv, acc0[4 * g + 2] * inv, acc0[4 * g + 3] * inv));
+            st4<bf16_t>(orow + 32 + 8 * g + 4 * h, make_float4(acc1[4 * g] * inv, acc1[4 * g + 1] * inv, acc1[4 * g + 2] * inv, acc1[4 * g + 3] * inv));
+        }
+        if (h == 0) lse[qrow] = (m + log2f(lsum)) * LN2;
+    }
+}
+#else
 __global__ __launch_bounds__(256, 4) void attn_fwd_seg_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
                                                               const bf16_t* __restrict__ V, int ldv, long long skv, bf16_t* __restrict__ O,
                                                               int ldo, float* __restrict__ lse, Segs sg, int Nk, float scale) {
@@ -117,6 +298,9 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_seg_kernel(const bf16_t* __re
     };
     fetch(0);
     for (int kb0 = 0; kb0 < Nk; kb0 += KB) {
+#if ATT_VAR == 2 || ATT_VAR == 3 || ATT_VAR == 4
+        if (kb0 == 0) {
+#endif
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -126,7 +310,11 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_seg_kernel(const bf16_t* __re
             st_t8(Vt, LDTB, c8, r, ld_row8(Vb, ldv, kb0 + r, Nk, c8), g);
         }
         __syncthreads();
+#if ATT_VAR == 2 || ATT_VAR == 3 || ATT_VAR == 4
+        }
+#else
         if (kb0 + KB < Nk) fetch(kb0 + KB);
+#endif
         // S^T tile of sub-tile `sub`: 4 chained MFMAs, issued asynchronously to the matrix pipe
         auto qk = [&](int sub) {
             f32x16 s;
@@ -134,7 +322,11 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_seg_kernel(const bf16_t* __re
             for (int r = 0; r < 16; ++r) s[r] = 0.f;
             const bf16_t* kp = Ks + (32 * sub + krow) * LDR + 8 * h;
 #pragma unroll
+#if ATT_VAR == 4
+            for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[(ks + sub) & 3], qf[ks], s, 0, 0, 0);
+#else
             for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(kp + 16 * ks), qf[ks], s, 0, 0, 0);
+#endif
             return s;
         };
         // online softmax of a finished S^T tile (register VALU) followed by O^T += V^T P^T
@@ -144,6 +336,24 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_seg_kernel(const bf16_t* __re
 #pragma unroll
                 for (int r = 0; r < 16; ++r) if (kv0 + 16 * h + r >= Nk) s[r] = NEG_BIG;
             }
+#if ATT_VAR == 1 || ATT_VAR == 3 || ATT_VAR == 4
+            {
+                const bf16_t* vp = Vt + j * LDTB + 32 * sub + 16 * h;
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    const bf16x8 pb = pack8(s, 8 * k2);
+#if ATT_VAR == 4
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[k2], pb, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[k2 + 2], pb, acc1, 0, 0, 0);
+#else
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(vp + 8 * k2), pb, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(vp + 32 * LDTB + 8 * k2), pb, acc1, 0, 0, 0);
+#endif
+                }
+                lsum = 1.f;
+                return;
+            }
+#endif
             float mx = s[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
@@ -183,6 +393,8 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_seg_kernel(const bf16_t* __re
         if (h == 0) lse[qrow] = (m + log2f(lsum)) * LN2;
     }
 }
+
+#endif
 
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_seg_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
                                                                  const bf16_t* __restrict__ V, int ldv, long long skv,
@@ -460,7 +672,12 @@ extern "C" int tc_attn_fwd_seg(const void* Q, int ldq, const void* K, int ldk, c
         return TC_OK;
     }
     if (dtype != TC_BF16 || ((ldq | ldk | ldv) & 7) || (skv & 7) || (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) || (ldo & 3)) return TC_ERR_ARG;
-    hipLaunchKernelGGL(attn_fwd_seg_kernel, dim3(sg.tile0[nseg]), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk,
+#if ATT_VAR >= 5
+    const unsigned fwd_grid = (unsigned)B * ((sg.t32[nseg] + 3) / 4);
+#else
+    const unsigned fwd_grid = sg.tile0[nseg];
+#endif
+    hipLaunchKernelGGL(attn_fwd_seg_kernel, dim3(fwd_grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk,
                        (const bf16_t*)V, ldv, skv, (bf16_t*)O, ldo, lse, sg, Nk, scale);
     return tc_launch_status();
 }
