@@ -340,7 +340,7 @@ __device__ __forceinline__ uint4 load_strip8(const bf16_t* base, int ld, int x, 
 }
 
 template <typename TC, int BM, int BN, bool TA, bool TB, bool DB>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmDev p) {
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmDev p) {
     constexpr int BK = 64, LDT = BK + 8;                       // 144-byte rows: 16-B aligned, conflict-free b128 fragment reads
     constexpr bool SWAP = sizeof(TC) == 2;                     // bf16 output: lane owns a row (8-byte stores); fp32 output: coalesced columns
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;

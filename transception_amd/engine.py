@@ -146,6 +146,8 @@ def _workspace(device, stream_ptr: int) -> torch.Tensor:
     return ws
 
 
+_SPLITK_CAP = int(os.environ.get("TC_SPLITK_CAP", "128"))
+_SPLITK_BLOCKS = int(os.environ.get("TC_SPLITK_BLOCKS", "512"))
 _N_WSTREAMS = int(os.environ.get("TC_WGRAD_STREAMS", "4"))
 _NO_PENDING = bool(os.environ.get("TC_DEBUG_NO_PENDING"))   # timing what-if only (racy)
 _SKIP_WGRAD = bool(os.environ.get("TC_DEBUG_SKIP_WGRAD"))
@@ -382,7 +384,7 @@ class Graph:
     @staticmethod
     def _splitk(m_out: int, n_out: int, k_red: int) -> int:
         tiles = ((m_out + 63) // 64) * ((n_out + 63) // 64)
-        return max(1, min(512 // max(tiles, 1), k_red // 256, 128))
+        return max(1, min(_SPLITK_BLOCKS // max(tiles, 1), k_red // 256, _SPLITK_CAP))
 
     # ------------------------------------------------------------------ ops
     def linear(self, x: Var, W: P, b: Optional[P] = None, out: Optional[Var] = None, residual: Optional[Var] = None,
