@@ -68,6 +68,9 @@ typedef struct TcGemm {
                                   * stream (launches that may overlap must not share one).  NULL: requested split-K uses atomics. */
 } TcGemm;
 int tc_gemm(const TcGemm* g, void* stream);
+/* The two gradient GEMMs of one Linear in ONE launch when both are small-tile bf16 problems (a: dX = dY W, row-major operands,
+ * bf16 out; b: dW = dY^T X with fp32 accumulate, transA=1): their workgroups share the grid.  Any other pair: a then b. */
+int tc_gemm_pair(const TcGemm* a, const TcGemm* b, void* stream);
 
 /* out[c] (+)= sum_b sum_r x[b*sb + r*ldx + c]   (bias gradients; fp32 output).  Replaces the bias-gradient
  * reductions autograd performs for every Linear/Conv on the path (trainer.py:146). */

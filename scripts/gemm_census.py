@@ -1,8 +1,8 @@
 """Census of the GEMMs of one training step: every tc_gemm call of an eager, single-stream step is replayed alone
 (20 timed repeats on the same pointers, accumulate forced so nothing is clobbered beyond what the step already tolerates)
-and reported by shape class with its achieved TFLOP/s and the HBM-floor time.    TC_NO_STREAMS=1 python scripts/gemm_census.py"""
+and reported by shape class with its achieved TFLOP/s and the HBM-floor time.    python scripts/gemm_census.py"""
 import os, sys, collections, ctypes as C
-os.environ["TC_NO_STREAMS"] = "1"
+os.environ["TC_STREAMS"] = "0"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import transception_amd.engine as engine

@@ -353,3 +353,24 @@ def test_graphed_step_matches_eager(split):
     # capture itself performs steps too (one for the single graph; forward/backward/opt once for the split form)
     pe, pg = me.flat_parameters(), mg.flat_parameters()
     assert torch.isfinite(pg).all()
+
+
+def test_graphed_bf16_replays_track_eager():
+    """The bf16 product path under hipGraph replay: five replays follow the eager bf16 trajectory and every gradient stays
+    finite.  (Regression: a hipMemsetAsync node of the captured single-stream graph ran out of order on ROCm 7.2 and the second
+    replay accumulated dK/dV onto the first replay's scratch -- the fp32 test above never launches that kernel.)"""
+    from transception_amd.train import FusedSGD, GraphedStep, SegLoss, train_step
+    x = torch.from_numpy(seeded_input(2)).to(DEV)
+    lab = torch.from_numpy(seeded_labels(2)).to(DEV)
+    me, mg = _fresh(torch.bfloat16).train(), _fresh(torch.bfloat16).train()
+    oe, og = FusedSGD(me, lr=0.05), FusedSGD(mg, lr=0.05)
+    le, lg = SegLoss(9), SegLoss(9)
+    for _ in range(2):
+        train_step(me, le, oe, x, lab)
+    step = GraphedStep(mg, lg, og, x, lab, None, warmup=2)
+    for _ in range(5):
+        a = train_step(me, le, oe, x, lab)[0].item()
+        b = step()[0].item()
+        assert abs(a - b) < 5e-3, (a, b)                      # bf16 storage + atomic summation order
+        g = mg.flat_gradients()
+        assert torch.isfinite(g).all() and float(g.float().norm()) < 10.0

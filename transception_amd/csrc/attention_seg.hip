@@ -415,6 +415,11 @@ __global__ __launch_bounds__(256) void attn_dkv_store_kernel(const float* __rest
     }
 }
 
+__global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, long long n4) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256)
+        reinterpret_cast<float4*>(p)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 __global__ __launch_bounds__(256) void delta_rows_kernel(const bf16_t* __restrict__ O, int ldo, const bf16_t* __restrict__ dO, int lddo,
                                                          float* __restrict__ delta, long long rows) {
     const int lane = threadIdx.x & 63;
@@ -488,7 +493,8 @@ extern "C" int tc_attn_bwd_seg(const void* Q, int ldq, const void* K, int ldk, c
     if (dtype != TC_BF16 || !dkv32 || ((ldq | ldk | ldv | lddo) & 7) || (skv & 7) ||
         (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)dO) & 15) || ((ldo | lddq | lddk | lddv) & 3) || (sdkv & 3))
         return TC_ERR_ARG;
-    if (hipMemsetAsync(dkv32, 0, sizeof(float) * (size_t)B * Nk * 128, s) != hipSuccess) return TC_ERR_LAUNCH;
+    // zero the fp32 dK/dV scratch with a kernel: a memset NODE in a captured single-stream graph was observed to run out of order
+    hipLaunchKernelGGL(zero_f32_kernel, dim3(tc_blocks((long long)B * Nk * 32, 256, 1024)), dim3(256), 0, s, dkv32, (long long)B * Nk * 32);
     hipLaunchKernelGGL(delta_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const bf16_t*)O, ldo, (const bf16_t*)dO, lddo, delta, rows);
     hipLaunchKernelGGL(attn_bwd_dkv_seg_kernel, dim3((Nk + 31) / 32, B, 4), dim3(256), 0, s, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk,
                        (const bf16_t*)V, ldv, skv, (const bf16_t*)dO, lddo, lse, delta, dkv32, sg, Nk, scale);

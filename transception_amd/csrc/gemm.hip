@@ -339,8 +339,11 @@ __device__ __forceinline__ uint4 load_strip8(const bf16_t* base, int ld, int x, 
     return u.v;
 }
 
+// Body of one workgroup of the bf16 GEMM: (bx, by, bz) of a (gx, gy, *) grid.  The LDS buffers come from the caller so that the
+// two problems of a paired launch (gemm_pair_kernel) share one allocation.
 template <typename TC, int BM, int BN, bool TA, bool TB, bool DB>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmDev p) {
+__device__ __forceinline__ void gemm_bf16_body(const GemmDev& p, const int bx, const int by, const int bz, const int gx, const int gy,
+                                               bf16_t (*As)[BM * (64 + 8)], bf16_t (*Bs)[BN * (64 + 8)]) {
     constexpr int BK = 64, LDT = BK + 8;                       // 144-byte rows: 16-B aligned, conflict-free b128 fragment reads
     constexpr bool SWAP = sizeof(TC) == 2;                     // bf16 output: lane owns a row (8-byte stores); fp32 output: coalesced columns
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
@@ -350,15 +353,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmDev p) {
     // is written to the other LDS buffer -- one barrier per slab, two slabs of memory latency covered (small-M GEMMs of this
     // model run ~1 workgroup per CU, so the K loop is latency-bound, not bandwidth-bound)
     // (DB = false: K <= 2 slabs -- one LDS buffer, half the footprint, twice the resident workgroups)
-    __shared__ __attribute__((aligned(16))) bf16_t As[DB ? 2 : 1][BM * LDT];
-    __shared__ __attribute__((aligned(16))) bf16_t Bs[DB ? 2 : 1][BN * LDT];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    int z = blockIdx.z;
+    int z = bz;
     const int ks = z % p.splitk; z /= p.splitk;
     const int b2 = z % p.nb2, b1 = z / p.nb2;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = by * BM, n0 = bx * BN;
     const int kbeg = ks * p.kchunk;
     const int kend = min(p.K, kbeg + p.kchunk);
 
@@ -415,7 +416,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmDev p) {
         }
     };
     float rsum = 0.f;
-    const bool do_rowsum = p.rowsum && blockIdx.x == 0 && tid < BM;
+    const bool do_rowsum = p.rowsum && bx == 0 && tid < BM;
     auto compute = [&](const bf16_t* as, const bf16_t* bs) {
         if (do_rowsum) {
 #pragma unroll
@@ -475,11 +476,37 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmDev p) {
     bool first = (ks == 0), atomic = p.atomic;
     if (p.fix_group) {
         int grp;
-        if (!splitk_fixup<TM, TN>(p, acc, (int)(((blockIdx.z / p.splitk) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x), ks, grp)) return;
+        if (!splitk_fixup<TM, TN>(p, acc, ((bz / p.splitk) * gy + by) * gx + bx, ks, grp)) return;
         first = (grp == 0); atomic = p.fix_ngroups > 1;
     }
     if (SWAP) epilogue_rows<bf16_t, TC, TM, TN>(p, acc, b1, b2, first, atomic, m0 + wr * WM, n0 + wc * WN, lane);
     else epilogue_cols<bf16_t, TC, TM, TN>(p, acc, b1, b2, first, atomic, m0 + wr * WM, n0 + wc * WN, lane);
+}
+
+template <typename TC, int BM, int BN, bool TA, bool TB, bool DB>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmDev p) {
+    __shared__ __attribute__((aligned(16))) bf16_t As[DB ? 2 : 1][BM * (64 + 8)];
+    __shared__ __attribute__((aligned(16))) bf16_t Bs[DB ? 2 : 1][BN * (64 + 8)];
+    gemm_bf16_body<TC, BM, BN, TA, TB, DB>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y, As, Bs);
+}
+
+// One launch for the two gradient GEMMs of a Linear: problem A = dX = dY W (row-major operands, bf16 out), problem B = dW = dY^T X
+// (+ row sums = db; fp32 accumulate into the gradient arena).  Both are short, low-occupancy grids (64x64 tiles); side by side in
+// one grid they fill the CUs together, where two launches on two streams mostly serialise on this part (measured: kernels from
+// different HW queues overlap only at their tails) and pay two dependency gaps.
+struct GemmPairDev { GemmDev a, b; int nA, gxA, gyA, gxB, gyB; };
+__global__ __launch_bounds__(256, 2) void gemm_pair_kernel(GemmPairDev q) {
+    __shared__ __attribute__((aligned(16))) bf16_t As[2][64 * (64 + 8)];
+    __shared__ __attribute__((aligned(16))) bf16_t Bs[2][64 * (64 + 8)];
+    int lin = blockIdx.x;
+    if (lin < q.nA) {
+        const int bx = lin % q.gxA; lin /= q.gxA;
+        gemm_bf16_body<bf16_t, 64, 64, false, false, true>(q.a, bx, lin % q.gyA, lin / q.gyA, q.gxA, q.gyA, As, Bs);
+    } else {
+        lin -= q.nA;
+        const int bx = lin % q.gxB; lin /= q.gxB;
+        gemm_bf16_body<float, 64, 64, true, false, true>(q.b, bx, lin % q.gyB, lin / q.gyB, q.gxB, q.gyB, As, Bs);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- host side
@@ -499,9 +526,9 @@ int launch(const GemmDev& d, int transA, int transB, dim3 grid, hipStream_t s) {
     return tc_launch_status();
 }
 
+// fills the device-side descriptor and the launch grid; false: bad arguments
 template <typename T>
-int gemm_typed(const TcGemm* g, hipStream_t s) {
-    GemmDev d;
+bool gemm_plan(const TcGemm* g, GemmDev& d, dim3& grid, bool& use128_out) {
     d.A = g->A; d.B = g->B; d.C = g->C; d.bias = g->bias; d.R = g->R;
     d.M = g->M; d.N = g->N; d.K = g->K; d.lda = g->lda; d.ldb = g->ldb; d.ldc = g->ldc; d.ldr = g->ldr;
     d.nb2 = g->nb2; d.splitk = g->splitk;
@@ -557,8 +584,17 @@ int gemm_typed(const TcGemm* g, hipStream_t s) {
         d.ws_part = reinterpret_cast<float*>(reinterpret_cast<char*>(g->ws) + CNT_BYTES);
     }
     d.atomic = ((d.splitk > 1 && !d.fix_group) || g->atomic) ? 1 : 0;
-    dim3 grid((g->N + BN - 1) / BN, (g->M + BM - 1) / BM, nb * d.splitk);
-    if (grid.y > 65535 || grid.z > 65535) return TC_ERR_ARG;
+    grid = dim3((g->N + BN - 1) / BN, (g->M + BM - 1) / BM, nb * d.splitk);
+    use128_out = use128;
+    return grid.y <= 65535 && grid.z <= 65535;
+}
+
+template <typename T>
+int gemm_typed(const TcGemm* g, hipStream_t s) {
+    GemmDev d;
+    dim3 grid;
+    bool use128;
+    if (!gemm_plan<T>(g, d, grid, use128)) return TC_ERR_ARG;
     if (g->c_f32)
         return use128 ? launch<T, float, 128, 128>(d, g->transA, g->transB, grid, s)
                       : launch<T, float, 64, 64>(d, g->transA, g->transB, grid, s);
@@ -566,15 +602,38 @@ int gemm_typed(const TcGemm* g, hipStream_t s) {
                   : launch<T, T, 64, 64>(d, g->transA, g->transB, grid, s);
 }
 
+
 }  // namespace
 
+static bool gemm_args_ok(const TcGemm* g) {
+    if (!g || !g->A || !g->B || !g->C || g->M <= 0 || g->N <= 0 || g->K <= 0 || g->nb1 < 1 || g->nb2 < 1 || g->splitk < 1) return false;
+    if ((g->splitk > 1 || g->atomic) && (!g->accumulate || (g->dtype != TC_F32 && !g->c_f32) || g->act != TC_ACT_NONE)) return false;
+    if (g->act != TC_ACT_NONE && g->act != TC_ACT_SIGMOID) return false;
+    return true;
+}
+
 extern "C" int tc_gemm(const TcGemm* g, void* stream) {
-    if (!g || !g->A || !g->B || !g->C || g->M <= 0 || g->N <= 0 || g->K <= 0 || g->nb1 < 1 || g->nb2 < 1 ||
-        g->splitk < 1)
-        return TC_ERR_ARG;
-    if ((g->splitk > 1 || g->atomic) && (!g->accumulate || (g->dtype != TC_F32 && !g->c_f32) || g->act != TC_ACT_NONE)) return TC_ERR_ARG;
-    if (g->act != TC_ACT_NONE && g->act != TC_ACT_SIGMOID) return TC_ERR_ARG;
+    if (!gemm_args_ok(g)) return TC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     TC_DISPATCH_DTYPE(g->dtype, return gemm_typed<T>(g, s));
     return TC_ERR_ARG;
+}
+
+extern "C" int tc_gemm_pair(const TcGemm* a, const TcGemm* b, void* stream) {
+    if (!gemm_args_ok(a) || !gemm_args_ok(b)) return TC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (a->dtype == TC_BF16 && b->dtype == TC_BF16 && !a->transA && !a->transB && !a->c_f32 && b->transA && !b->transB && b->c_f32) {
+        GemmPairDev q;
+        dim3 ga, gb;
+        bool bigA, bigB;
+        if (!gemm_plan<bf16_t>(a, q.a, ga, bigA) || !gemm_plan<bf16_t>(b, q.b, gb, bigB)) return TC_ERR_ARG;
+        const long long nA = (long long)ga.x * ga.y * ga.z, nB = (long long)gb.x * gb.y * gb.z;
+        if (!bigA && !bigB && nA + nB < 0x7fffffffLL) {
+            q.nA = (int)nA; q.gxA = ga.x; q.gyA = ga.y; q.gxB = gb.x; q.gyB = gb.y;
+            hipLaunchKernelGGL(gemm_pair_kernel, dim3((unsigned)(nA + nB)), dim3(256), 0, s, q);
+            return tc_launch_status();
+        }
+    }
+    const int rc = tc_gemm(a, stream);                       // shapes the paired kernel does not cover: two launches
+    return rc != TC_OK ? rc : tc_gemm(b, stream);
 }

@@ -122,13 +122,19 @@ __global__ void sgd_multi_kernel(float* __restrict__ p, const float* __restrict_
     }
 }
 
+__global__ void zero_floats_kernel(float* __restrict__ p, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0.f;
+}
+
 }  // namespace
 
 extern "C" int tc_colsum(const void* x, int rows, int cols, int ldx, int nb, long long sb, float* out, int accumulate, int dtype,
                          void* stream) {
     if (!x || !out || rows <= 0 || cols <= 0 || nb <= 0) return TC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    if (!accumulate && hipMemsetAsync(out, 0, sizeof(float) * cols, s) != hipSuccess) return TC_ERR_LAUNCH;
+    // (a kernel, not hipMemsetAsync: memset NODES of a captured single-stream graph were observed to run out of order on ROCm 7.2)
+    if (!accumulate) hipLaunchKernelGGL(zero_floats_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, out, cols);
     dim3 grid(tc_blocks((long long)rows * nb, 4 * 32, 256), (cols + 63) / 64);
     TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(256), 0, s, (const T*)x, rows, cols, ldx, out, nb, sb));
     return tc_launch_status();

@@ -148,9 +148,19 @@ def _workspace(device, stream_ptr: int) -> torch.Tensor:
 
 _SPLITK_CAP = int(os.environ.get("TC_SPLITK_CAP", "128"))
 _SPLITK_BLOCKS = int(os.environ.get("TC_SPLITK_BLOCKS", "512"))
+_SPLITK_CAP = int(os.environ.get("TC_SPLITK_CAP", "128"))
+_SPLITK_BLOCKS = int(os.environ.get("TC_SPLITK_BLOCKS", "512"))
+_GEMM_PAIR = os.environ.get("TC_GEMM_PAIR", "1") != "0"
 _N_WSTREAMS = int(os.environ.get("TC_WGRAD_STREAMS", "4"))
 _NO_PENDING = bool(os.environ.get("TC_DEBUG_NO_PENDING"))   # timing what-if only (racy)
 _SKIP_WGRAD = bool(os.environ.get("TC_DEBUG_SKIP_WGRAD"))
+_POISON = bool(os.environ.get("TC_DEBUG_POISON"))         # fill every fresh buffer with NaN: finds reads of memory no kernel wrote
+
+
+def _empty(shape, dtype, device) -> torch.Tensor:
+    if _POISON:
+        return torch.full(tuple(shape), float("nan"), dtype=dtype, device=device)
+    return torch.empty(tuple(shape), dtype=dtype, device=device)
 
 
 class _Branch:
@@ -213,7 +223,11 @@ class _Grouped:
 
 
 class Graph:
-    use_streams = os.environ.get("TC_NO_STREAMS", "0") != "1"
+    # Side streams are OFF by default.  Measured on MI355X (ROCm 7.2): a captured step executes at the SUM of its kernel times
+    # whether its branches are captured on 1 stream or 8 (kernels from different HW queues overlap only at their tails, and a
+    # graph wider than the 4 HW queues shares queues), while the single-stream graph runs every kernel un-contended and
+    # back-to-back -- 671 vs 634-648 img/s -- and avoids the hipStreamEndCapture crashes some multi-stream shapes trigger.
+    use_streams = os.environ.get("TC_STREAMS", "0") == "1"
     overlap_wgrad = os.environ.get("TC_NO_WGRAD_OVERLAP", "0") != "1"
     ngroups = 1          # ops with parameters run `ngroups` stacked row blocks, block g with the weights at +g*P.gs
     pgs = 0
@@ -242,10 +256,10 @@ class Graph:
 
     # ------------------------------------------------------------------ memory
     def new(self, rows: int, cols: int, requires_grad: bool = True) -> Var:
-        return Var(torch.empty((rows, cols), dtype=self.dtype, device=self.dev), requires_grad=requires_grad)
+        return Var(_empty((rows, cols), self.dtype, self.dev), requires_grad=requires_grad)
 
     def f32(self, *shape) -> torch.Tensor:
-        return torch.empty(shape, dtype=torch.float32, device=self.dev)
+        return _empty(shape, torch.float32, self.dev)
 
     # ------------------------------------------------------------------ gradient bookkeeping
     def grad_of(self, v: Var) -> Optional[torch.Tensor]:
@@ -265,7 +279,7 @@ class Graph:
         reg = (v.region[0], v.region[1] + ext_rows, v.region[2], v.region[3])
         if r.grad_t is None:
             if whole:
-                r.grad_t = torch.empty_like(r.data)
+                r.grad_t = _empty(r.data.shape, r.data.dtype, r.data.device)
                 assert r.grad_t.stride() == r.data.stride(), "gradient layout must mirror the data layout"
             else:
                 assert r.data.is_contiguous()
@@ -375,11 +389,23 @@ class Graph:
     # ------------------------------------------------------------------ GEMM plumbing
     def _gemm(self, A, lda, B, ldb, Cm, ldc, M, N, K, tA, tB, bias=None, R=None, ldr=0, alpha=1.0, acc=0, act=ACT_NONE,
               splitk=1, nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), c_f32=0, atomic=0, rowsum=None, sbias=0, srow=0):
-        ws = _workspace(self.dev, self.stream)
-        g = TcGemm(A, B, Cm, bias, R, M, N, K, lda, ldb, ldc, ldr, tA, tB, nb1, nb2, sA[0], sA[1], sB[0], sB[1], sC[0], sC[1],
-                   sR[0], sR[1], alpha, acc, act, splitk, self.dt, c_f32, atomic, rowsum, sbias, srow, ws.data_ptr(), ws.numel())
+        g = self._gemm_desc(A, lda, B, ldb, Cm, ldc, M, N, K, tA, tB, bias, R, ldr, alpha, acc, act, splitk, nb1, nb2, sA, sB, sC, sR,
+                            c_f32, atomic, rowsum, sbias, srow)
         self.n_launch += 1
         self.L.tc_gemm(C.byref(g), self.stream)
+
+    def _gemm_desc(self, A, lda, B, ldb, Cm, ldc, M, N, K, tA, tB, bias=None, R=None, ldr=0, alpha=1.0, acc=0, act=ACT_NONE,
+                   splitk=1, nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), c_f32=0, atomic=0, rowsum=None, sbias=0,
+                   srow=0, use_ws=True) -> TcGemm:
+        ws = _workspace(self.dev, self.stream) if use_ws else None
+        return TcGemm(A, B, Cm, bias, R, M, N, K, lda, ldb, ldc, ldr, tA, tB, nb1, nb2, sA[0], sA[1], sB[0], sB[1], sC[0], sC[1],
+                      sR[0], sR[1], alpha, acc, act, splitk, self.dt, c_f32, atomic, rowsum, sbias, srow,
+                      ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0)
+
+    @staticmethod
+    def _small_tiles(m_out: int, n_out: int, nb: int) -> bool:
+        """tc_gemm's tile choice (gemm.hip, gemm_plan): 64x64 tiles unless >= 192 tiles of 128x128 exist."""
+        return ((m_out + 127) // 128) * ((n_out + 127) // 128) * nb < 192 or m_out < 96 or n_out < 96
 
     @staticmethod
     def _splitk(m_out: int, n_out: int, k_red: int) -> int:
@@ -430,12 +456,28 @@ class Graph:
                 assert dy.is_contiguous() and out.data.is_contiguous() and nb == 1
                 dz = torch.empty_like(dy)
                 self.L.tc_sigmoid_bwd(_ptr(dy), _ptr(out.data), _ptr(dz), dy.numel(), self.dt, self.stream)
-            if x.requires_grad:
+            want_db = b is not None and b.grad is not None
+            paired = (_GEMM_PAIR and x.requires_grad and W.grad is not None and self.dtype == torch.bfloat16
+                      and self._small_tiles(M, K, nb) and self._small_tiles(N, K, nb))
+            if paired:
+                # dX and dW (+db) of this layer share one launch: two short grids fill the CUs together (tc_gemm_pair)
+                gx, acc = self.wgrad(x, (nb - 1) * sx // x.root.cols if (nb > 1 and not grouped) else 0)
+                gW = W.grad if wcols is None else W.grad[:, wcols[0]:wcols[1]]
+                ga = self._gemm_desc(_ptr(dz), dz.stride(0), _ptr(Wt), Wt.stride(0), _ptr(gx), gx.stride(0), M, K, N, 0, 0, acc=acc,
+                                     nb1=nb, sA=(so, 0), sB=(sw, 0), sC=(sx, 0))
+                gb = self._gemm_desc(_ptr(dz), dz.stride(0), _ptr(x.data), x.ld, _ptr(gW), gW.stride(0), N, K, M, 1, 0, acc=1,
+                                     splitk=self._splitk(N, K, M), c_f32=1, nb1=nb, sA=(so, 0), sB=(sx, 0), sC=(sw, 0),
+                                     atomic=int(nb > 1 and not grouped), rowsum=_ptr(b.grad) if want_db else None, srow=sw,
+                                     use_ws=False)
+                self.n_launch += 1
+                self.L.tc_gemm_pair(C.byref(ga), C.byref(gb), self.stream)
+            elif x.requires_grad:
                 gx, acc = self.wgrad(x, (nb - 1) * sx // x.root.cols if (nb > 1 and not grouped) else 0)
                 self._gemm(_ptr(dz), dz.stride(0), _ptr(Wt), Wt.stride(0), _ptr(gx), gx.stride(0), M, K, N, 0, 0, acc=acc,
                            nb1=nb, sA=(so, 0), sB=(sw, 0), sC=(sx, 0))
-            want_db = b is not None and b.grad is not None
-            if W.grad is not None:
+            if paired:
+                pass
+            elif W.grad is not None:
                 gW = W.grad if wcols is None else W.grad[:, wcols[0]:wcols[1]]
                 self._weight_grad(lambda: self._gemm(
                     _ptr(dz), dz.stride(0), _ptr(x.data), x.ld, _ptr(gW), gW.stride(0), N, K, M, 1, 0, acc=1,
