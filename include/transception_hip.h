@@ -91,8 +91,12 @@ int tc_layernorm_fwd(const void* x, int ldx, const void* gamma, const void* beta
  * If dres != NULL its rows (stride ldres) are added to dx (fan-in of a residual branch). */
 int tc_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx, const void* gamma, const void* beta,
                      const float* mean, const float* rstd, void* dx, int lddx, const void* dres, int ldres,
-                     float* dgamma, float* dbeta, int rows, int C, int act, int groups, long long pstride, int dtype,
-                     void* stream);
+                     float* dgamma, float* dbeta, int rows, int C, int act, int groups, long long pstride,
+                     float* scratch, long long scratch_floats, int dtype, void* stream);
+/* scratch (>= tc_layernorm_bwd_scratch_floats() floats, or NULL): with it the parameter gradients are folded from
+ * per-workgroup partials by a second tiny launch instead of ~1000-way contended atomics -- one pass over x / dy for dx,
+ * dgamma and dbeta together. */
+long long tc_layernorm_bwd_scratch_floats(int rows, int C, int groups);
 /* dgamma / dbeta may both be NULL above (dx only); this entry then produces them as a row-parallel column reduction, so the
  * host can run it on a second stream beside the activation-gradient chain. */
 int tc_layernorm_bwd_params(const void* dy, int lddy, const void* x, int ldx, const void* gamma, const void* beta,

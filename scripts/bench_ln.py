@@ -16,8 +16,10 @@ def run(rows, C, act=0):
     g = torch.ones(C, device=dev).bfloat16(); b = torch.zeros(C, device=dev).bfloat16(); dg = torch.zeros(C, device=dev); db = torch.zeros(C, device=dev)
     mean = torch.empty(rows, device=dev); rstd = torch.empty(rows, device=dev)
     f = t(lambda: L.tc_layernorm_fwd(x.data_ptr(), C, g.data_ptr(), b.data_ptr(), y.data_ptr(), C, mean.data_ptr(), rstd.data_ptr(), rows, C, 1e-5, act, 1, 0, TC_BF16, st))
-    d = t(lambda: L.tc_layernorm_bwd(dy.data_ptr(), C, x.data_ptr(), C, g.data_ptr(), b.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), C, None, 0, None, None, rows, C, act, 1, 0, TC_BF16, st))
+    d = t(lambda: L.tc_layernorm_bwd(dy.data_ptr(), C, x.data_ptr(), C, g.data_ptr(), b.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), C, None, 0, None, None, rows, C, act, 1, 0, None, 0, TC_BF16, st))
+    ns = L.tc_layernorm_bwd_scratch_floats(rows, C, 1); sc = torch.empty(ns, device=dev)
+    fz = t(lambda: L.tc_layernorm_bwd(dy.data_ptr(), C, x.data_ptr(), C, g.data_ptr(), b.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), C, None, 0, dg.data_ptr(), db.data_ptr(), rows, C, act, 1, 0, sc.data_ptr(), ns, TC_BF16, st))
     p = t(lambda: L.tc_layernorm_bwd_params(dy.data_ptr(), C, x.data_ptr(), C, g.data_ptr(), b.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dg.data_ptr(), db.data_ptr(), rows, C, act, 1, 0, TC_BF16, st))
     c = t(lambda: y.copy_(x))
-    print(f"rows={rows:6d} C={C:5d} act={act}: fwd {f:6.1f}  dx {d:6.1f}  params {p:6.1f}  copy {c:6.1f} us")
+    print(f"rows={rows:6d} C={C:5d} act={act}: fwd {f:6.1f}  dx {d:6.1f}  params {p:6.1f}  fused {fz:6.1f}  copy {c:6.1f} us")
 run(50176, 64); run(50176, 256, 4); run(12544, 128); run(12544, 512, 4); run(3136, 320); run(3136, 1280, 4); run(784, 512); run(784, 2048, 4); run(97216, 64); run(150528, 64)

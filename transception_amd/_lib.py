@@ -36,7 +36,8 @@ SIGNATURES = {
     "tc_gemm_pair": [C.POINTER(TcGemm), C.POINTER(TcGemm), vp],
     "tc_colsum": [vp, i32, i32, i32, i32, i64, vp, i32, i32, vp],
     "tc_layernorm_fwd": [vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, f32, i32, i32, i64, i32, vp],
-    "tc_layernorm_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i64, i32, vp],
+    "tc_layernorm_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i64, vp, i64, i32, vp],
+    "tc_layernorm_bwd_scratch_floats": [i32, i32, i32],
     "tc_layernorm_bwd_params": [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i32, vp],
     "tc_dwconv_fwd": [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i64, i32, vp],
     "tc_dwconv_bwd_input": [vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i64, i32, vp],
@@ -73,8 +74,8 @@ SIGNATURES = {
     "tc_sgd_step_multi": [vp, vp, vp, vp, i32, i64, f32, vp, f32, f32, f32, i32, vp],
     "tc_cast": [vp, vp, i64, i32, i32, vp],
 }
-_RET = {"tc_bn_scratch_floats": i64, "tc_softmax_scratch_floats": i64}
-_RAW = {"tc_abi_version", "tc_bn_scratch_floats", "tc_softmax_scratch_floats"}     # not status-returning
+_RET = {"tc_bn_scratch_floats": i64, "tc_softmax_scratch_floats": i64, "tc_layernorm_bwd_scratch_floats": i64}
+_RAW = {"tc_abi_version", "tc_bn_scratch_floats", "tc_softmax_scratch_floats", "tc_layernorm_bwd_scratch_floats"}     # not status-returning
 
 
 class TcError(RuntimeError):

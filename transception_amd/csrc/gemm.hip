@@ -567,9 +567,13 @@ bool gemm_plan(const TcGemm* g, GemmDev& d, dim3& grid, bool& use128_out) {
             if (sk > g->K / 256) sk = g->K / 256;
             if (sk > FIX_GROUP) sk = FIX_GROUP;
             if (sk >= 2 && tiles64 * sk <= slots) { want = (int)sk; fix = true; }
+        } else if (want > 128) {
+            // caller-requested split beyond 128 (the classifier's dW: K = 802816): groups of 16 splits fold through the
+            // workspace, only the group leaders touch C atomically -- a 64-long atomic chain instead of a 1024-long one.
+            // (up to 128 the plain atomic epilogue measured equal or better: the leader's L2-bypassing reads of its group's
+            //  partials cost what the shorter chain saves)
+            fix = tiles64 * want <= slots && tiles64 * ((want + FIX_GROUP - 1) / FIX_GROUP) <= CNT_BYTES / 4;
         }
-        // (a caller-requested split -- fp32 weight gradients with K up to 800k -- keeps the atomic epilogue: measured equal or
-        //  better there, the last-arriver's L2-bypassing reads of 16+ partials cost what the atomic chain costs)
     }
     int kchunk = (g->K + want - 1) / want;
     kchunk = (kchunk + BK - 1) / BK * BK;

@@ -6,6 +6,7 @@
 namespace {
 
 constexpr int LN_MAXC = 2048;
+constexpr int LN_BWD_MAX_BLOCKS = 1024, LN_BWD_ROWS_PER_GROUP = 4;   // fused dx + parameter-gradient launch
 
 // ---------------------------------------------------------------------------------------------- LayerNorm
 // A group of GS lanes (16 / 32 / 64) owns one row, each lane NV float4s of it; a 256-thread block therefore works on
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      T* __restrict__ dx, int lddx, const T* __restrict__ dres, int ldres,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int C,
-                                                     int act, long long pstride) {
+                                                     int act, long long pstride, float* __restrict__ partial) {
     constexpr int RPB = 256 / GS;
     extern __shared__ float red[];           // [RPB][2][C]
     const int gl = threadIdx.x % GS, gi = threadIdx.x / GS;
@@ -155,8 +156,37 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
         float a = 0.f, bb = 0.f;
 #pragma unroll
         for (int w = 0; w < RPB; ++w) { a += red[(w * 2 + 0) * C + c]; bb += red[(w * 2 + 1) * C + c]; }
-        atomicAdd(dgamma + c, a);
-        atomicAdd(dbeta + c, bb);
+        if (partial) {                       // no atomics: per-workgroup partials, folded by ln_param_finish_kernel
+            float* pp = partial + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 2 * C;
+            pp[c] = a; pp[C + c] = bb;
+        } else {
+            atomicAdd(dgamma + c, a);
+            atomicAdd(dbeta + c, bb);
+        }
+    }
+}
+
+// dgamma / dbeta += sum over the nblk per-workgroup partials ln_bwd_kernel left in `partial` ([group][nblk][2][C])
+__global__ __launch_bounds__(256) void ln_param_finish_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, long long pstride) {
+    __shared__ float sa[8][32], sb[8][32];
+    const int cl = threadIdx.x & 31, r = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
+    const float* pp = partial + (long long)blockIdx.y * nblk * 2 * C;
+    float a = 0.f, b = 0.f;
+    if (c < C) {
+#pragma unroll 8
+        for (int k = r; k < nblk; k += 8) { a += pp[(long long)k * 2 * C + c]; b += pp[(long long)k * 2 * C + C + c]; }
+    }
+    sa[r][cl] = a; sb[r][cl] = b;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int which = threadIdx.x >> 5, cc = blockIdx.x * 32 + cl;
+        if (cc < C) {
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v += which ? sb[k][cl] : sa[k][cl];
+            atomicAdd((which ? dbeta : dgamma) + blockIdx.y * pstride + cc, v);
+        }
     }
 }
 
@@ -389,20 +419,32 @@ extern "C" int tc_layernorm_fwd(const void* x, int ldx, const void* gamma, const
 
 extern "C" int tc_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx, const void* gamma, const void* beta,
                                 const float* mean, const float* rstd, void* dx, int lddx, const void* dres, int ldres,
-                                float* dgamma, float* dbeta, int rows, int C, int act, int groups, long long pstride, int dtype,
-                                void* stream) {
+                                float* dgamma, float* dbeta, int rows, int C, int act, int groups, long long pstride,
+                                float* scratch, long long scratch_floats, int dtype, void* stream) {
     if (!dy || !x || !gamma || !beta || !mean || !rstd || !dx || (!dgamma != !dbeta) || rows <= 0 || groups < 1 || C <= 0 || (C & 3) ||
         C > LN_MAXC || (ldx & 3) || (lddy & 3) || (lddx & 3) || (dres && (ldres & 3)))
         return TC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int quads = C >> 2;
-#define TC_LNB(GS, NV) hipLaunchKernelGGL((ln_bwd_kernel<T, GS, NV>), dim3(tc_blocks(rows, (256 / GS) * (dgamma ? 4 : 1), dgamma ? 1024 : 8192), groups), dim3(256), \
+    int nblk = 0;
+    float* partial = nullptr;
+#define TC_LNB(GS, NV) {                                                                                                                  \
+        nblk = tc_blocks(rows, (256 / GS) * (dgamma ? LN_BWD_ROWS_PER_GROUP : 1), dgamma ? LN_BWD_MAX_BLOCKS : 8192);                       \
+        partial = (dgamma && scratch && scratch_floats >= (long long)groups * nblk * 2 * C) ? scratch : nullptr;                            \
+        hipLaunchKernelGGL((ln_bwd_kernel<T, GS, NV>), dim3(nblk, groups), dim3(256),                                                       \
                                           (size_t)(256 / GS) * 2 * C * sizeof(float), s, (const T*)dy, lddy, (const T*)x, ldx,            \
                                           (const T*)gamma, (const T*)beta, mean, rstd, (T*)dx, lddx, (const T*)dres, ldres, dgamma,      \
-                                          dbeta, rows, C, act, pstride)
+                                          dbeta, rows, C, act, pstride, partial); }
     TC_DISPATCH_DTYPE(dtype, { TC_LN_DISPATCH(quads, TC_LNB) });
 #undef TC_LNB
+    if (partial)
+        hipLaunchKernelGGL(ln_param_finish_kernel, dim3((C + 31) / 32, groups), dim3(256), 0, s, partial, nblk, C, dgamma, dbeta, pstride);
     return tc_launch_status();
+}
+
+extern "C" long long tc_layernorm_bwd_scratch_floats(int rows, int C, int groups) {
+    if (rows <= 0 || C <= 0 || groups < 1) return 0;
+    return (long long)groups * LN_BWD_MAX_BLOCKS * 2 * C;      // upper bound over the lane-group shapes
 }
 
 extern "C" int tc_layernorm_bwd_params(const void* dy, int lddy, const void* x, int ldx, const void* gamma, const void* beta,

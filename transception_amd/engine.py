@@ -410,7 +410,8 @@ class Graph:
     @staticmethod
     def _splitk(m_out: int, n_out: int, k_red: int) -> int:
         tiles = ((m_out + 63) // 64) * ((n_out + 63) // 64)
-        return max(1, min(_SPLITK_BLOCKS // max(tiles, 1), k_red // 256, _SPLITK_CAP))
+        cap = _SPLITK_CAP if k_red < 262144 else 1024      # > 128: tc_gemm folds groups of 16 splits through the workspace
+        return max(1, min(max(_SPLITK_BLOCKS, cap) // max(tiles, 1), k_red // 256, cap))
 
     # ------------------------------------------------------------------ ops
     def linear(self, x: Var, W: P, b: Optional[P] = None, out: Optional[Var] = None, residual: Optional[Var] = None,
@@ -469,6 +470,8 @@ class Graph:
                                      splitk=self._splitk(N, K, M), c_f32=1, nb1=nb, sA=(so, 0), sB=(sx, 0), sC=(sw, 0),
                                      atomic=int(nb > 1 and not grouped), rowsum=_ptr(b.grad) if want_db else None, srow=sw,
                                      use_ws=False)
+                if gb.splitk > 128:                      # the one workspace of this stream goes to the problem that folds partials
+                    gb.ws, gb.ws_bytes, ga.ws, ga.ws_bytes = ga.ws, ga.ws_bytes, None, 0
                 self.n_launch += 1
                 self.L.tc_gemm_pair(C.byref(ga), C.byref(gb), self.stream)
             elif x.requires_grad:
@@ -515,9 +518,17 @@ class Graph:
             if dy is None or not x.requires_grad:
                 return
             gx, acc = self.wgrad(x)
+            fused = g.grad is not None and not (self.overlap_wgrad and self.use_streams)
+            if fused:                                    # one pass: dx + per-workgroup dgamma/dbeta partials + a tiny folding launch
+                n = self.L.tc_layernorm_bwd_scratch_floats(rows, Cc, Gn)
+                scratch = self.f32(n)
+                self.L.tc_layernorm_bwd(_ptr(dy), dy.stride(0), _ptr(x.data), x.ld, _ptr(g.data), _ptr(b.data), _ptr(mean),
+                                        _ptr(rstd), _ptr(gx), gx.stride(0), _ptr(gx) if acc else None, gx.stride(0),
+                                        _ptr(g.grad), _ptr(b.grad), rows, Cc, act, Gn, g.gs, _ptr(scratch), n, self.dt, self.stream)
+                return
             self.L.tc_layernorm_bwd(_ptr(dy), dy.stride(0), _ptr(x.data), x.ld, _ptr(g.data), _ptr(b.data), _ptr(mean),
                                     _ptr(rstd), _ptr(gx), gx.stride(0), _ptr(gx) if acc else None, gx.stride(0),
-                                    None, None, rows, Cc, act, Gn, g.gs, self.dt, self.stream)
+                                    None, None, rows, Cc, act, Gn, g.gs, None, 0, self.dt, self.stream)
             if g.grad is not None:
                 self._weight_grad(lambda: self.L.tc_layernorm_bwd_params(
                     _ptr(dy), dy.stride(0), _ptr(x.data), x.ld, _ptr(g.data), _ptr(b.data), _ptr(mean), _ptr(rstd), _ptr(g.grad),
