@@ -278,33 +278,36 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_seg_kernel(const bf16_t* _
     }
 }
 
-// dK/dV: workgroup = (32-key tile, image); its 4 waves stride over ALL 32-query tiles of that image across the segments.
-__global__ __launch_bounds__(256) void attn_bwd_dkv_seg_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
-                                                               const bf16_t* __restrict__ V, int ldv, long long skv,
-                                                               const bf16_t* __restrict__ dO, int lddo, const float* __restrict__ lse,
-                                                               const float* __restrict__ delta, float* __restrict__ dkv32, Segs sg, int Nk,
-                                                               float scale) {
-    // gridDim.z query splits share a (key tile, image): partial dK/dV are added atomically into the fp32 scratch dkv32
-    // [B][Nk][128] (dK | dV), which attn_dkv_store_kernel converts to the bf16 outputs.
-    constexpr int LDQT = 32 + 16;                  // 96-byte rows = 24 words (8-word spans of rows distinct mod 4 are disjoint)
-    constexpr int PER_WAVE_B = (2 * 32 * LDR + 2 * D * LDQT) * 2 + 256;
-    constexpr int RED_B = 4 * 2 * 64 * 33 * 4;
-    constexpr int SMEM_B = (4 * PER_WAVE_B > RED_B) ? 4 * PER_WAVE_B : RED_B;
+// dK/dV: workgroup = (NW x 32 keys of one image, one chunk of that image's 32-query tiles).  Every wave keeps the K and V
+// fragments of its own 32 keys in registers and accumulates their dK^T / dV^T tiles; the Q / dO rows of a 64-query stage are
+// staged ONCE per workgroup (row-major for the S and dP products, transposed for the dV^T / dK^T products) and shared by all
+// waves -- the first version staged them per wave (4x the LDS stores and global reads) and needed 288 VGPRs (one wave per SIMD).
+// Query chunks (gridDim.z) add their partial sums atomically into the fp32 scratch dkv32 [B][Nk][128] (dK | dV), which
+// attn_dkv_store_kernel converts to the bf16 outputs.
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
+                                                                    const bf16_t* __restrict__ V, int ldv, long long skv,
+                                                                    const bf16_t* __restrict__ dO, int lddo, const float* __restrict__ lse,
+                                                                    const float* __restrict__ delta, float* __restrict__ dkv32, Segs sg, int Nk,
+                                                                    float scale, int tiles_per_chunk) {
+    constexpr int QS = 64, LDQ = D + 8, LDT = QS + 16;          // LDT: 160-byte rows = 40 words (8 mod 32), see st_t8
+    constexpr int STAGE_B = (2 * QS * LDQ + 2 * D * LDT) * 2 + 2 * QS * 4;
+    constexpr int RED_B = NW * D * 33 * 4;
+    constexpr int SMEM_B = STAGE_B > RED_B ? STAGE_B : RED_B;
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_B];
+    bf16_t* Qs = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* dOs = Qs + QS * LDQ;
+    bf16_t* Qt = dOs + QS * LDQ;
+    bf16_t* dOt = Qt + D * LDT;
+    float* lss = reinterpret_cast<float*>(dOt + D * LDT);
+    float* dls = lss + QS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
-    const int b = blockIdx.y, kv0 = blockIdx.x * 32;
-    bf16_t* Qs = reinterpret_cast<bf16_t*>(smem + wave * PER_WAVE_B);
-    bf16_t* dOs = Qs + 32 * LDR;
-    bf16_t* Qt = dOs + 32 * LDR;
-    bf16_t* dOt = Qt + D * LDQT;
-    float* lss = reinterpret_cast<float*>(dOt + D * LDQT);
-    float* dls = lss + 32;
-    const int key = kv0 + j;
+    const int b = blockIdx.y, kv0 = (blockIdx.x * NW + wave) * 32, key = min(kv0 + j, Nk - 1);
     bf16x8 kf[4], vf[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const uint4 a = ld_row8(K + b * skv, ldk, key, Nk, 16 * ks + 8 * h);
-        const uint4 c = ld_row8(V + b * skv, ldv, key, Nk, 16 * ks + 8 * h);
+    for (int ks = 0; ks < 4; ++ks) {           // keys past Nk: a duplicate row whose results are never stored
+        const uint4 a = *reinterpret_cast<const uint4*>(K + b * skv + (long long)key * ldk + 16 * ks + 8 * h);
+        const uint4 c = *reinterpret_cast<const uint4*>(V + b * skv + (long long)key * ldv + 16 * ks + 8 * h);
         kf[ks] = *reinterpret_cast<const bf16x8*>(&a);
         vf[ks] = *reinterpret_cast<const bf16x8*>(&c);
     }
@@ -314,93 +317,107 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_seg_kernel(const bf16_t* __r
     for (int r = 0; r < 16; ++r) { dk0[r] = dk1[r] = dv0[r] = dv1[r] = 0.f; }
     const int qrow = pi_row(j);
     const int ntiles = sg.t32[sg.n];
-    uint4 qr[4], gr[4];
-    float lr = 0.f, dr = 0.f;
+    const int t_begin = blockIdx.z * tiles_per_chunk, t_end = min(ntiles, t_begin + tiles_per_chunk);
     auto locate = [&](int t, long long& base, int& valid) {       // first row and number of valid rows of 32-query tile t
         int s = 0;
 #pragma unroll
         for (int i = 1; i < 4; ++i) if (i < sg.n && t >= sg.t32[i]) s = i;
         const int q0 = (t - sg.t32[s]) * 32;
         base = (long long)sg.row0[s] + (long long)b * sg.nq[s] + q0;
-        valid = min(32, sg.nq[s] - q0);
+        valid = (t < t_end) ? min(32, sg.nq[s] - q0) : 0;
     };
-    auto fetch = [&](int t) {
-        long long base; int valid;
-        locate(t, base, valid);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = 16 * (i & 1) + (lane & 15), c8 = 32 * (i >> 1) + 8 * (lane >> 4);
-            const bool okr = r < valid;
-            qr[i] = okr ? *reinterpret_cast<const uint4*>(Q + (base + r) * ldq + c8) : make_uint4(0u, 0u, 0u, 0u);
-            gr[i] = okr ? *reinterpret_cast<const uint4*>(dO + (base + r) * lddo + c8) : make_uint4(0u, 0u, 0u, 0u);
-        }
-        if (lane < 32) { const bool okr = lane < valid; lr = okr ? lse[base + lane] * LOG2E : 0.f; dr = okr ? delta[base + lane] : 0.f; }
+    // staging (threads 0..255): strip (row r of the stage, 8 channels from c8); lanes 0-15 take 16 consecutive rows (st_t8)
+    const bool stager = tid < 256;
+    uint4 qr[2], gr[2];
+    float lr = 0.f, dr = 0.f;
+    auto fmap = [&](int it, int& r, int& c8, int& g) {
+        const int c = wave * 2 + it;
+        g = lane >> 4; r = 16 * (c >> 1) + (lane & 15); c8 = 32 * (c & 1) + 8 * g;
     };
-    const int tstep = 4 * gridDim.z, tfirst = blockIdx.z * 4 + wave;
-    if (tfirst < ntiles) fetch(tfirst);
-    for (int t = tfirst; t < ntiles; t += tstep) {
-        long long base; int valid;
-        locate(t, base, valid);
+    auto fetch = [&](int t0) {
+        if (stager) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = 16 * (i & 1) + (lane & 15), g = lane >> 4, c8 = 32 * (i >> 1) + 8 * g;
-            *reinterpret_cast<uint4*>(&Qs[r * LDR + c8]) = qr[i];
-            *reinterpret_cast<uint4*>(&dOs[r * LDR + c8]) = gr[i];
-            st_t8(Qt, LDQT, c8, r, qr[i], g);
-            st_t8(dOt, LDQT, c8, r, gr[i], g);
+            for (int i = 0; i < 2; ++i) {
+                int r, c8, g; fmap(i, r, c8, g);
+                long long base; int valid;
+                locate(t0 + (r >> 5), base, valid);
+                const bool okr = (r & 31) < valid;
+                qr[i] = okr ? *reinterpret_cast<const uint4*>(Q + (base + (r & 31)) * ldq + c8) : make_uint4(0u, 0u, 0u, 0u);
+                gr[i] = okr ? *reinterpret_cast<const uint4*>(dO + (base + (r & 31)) * lddo + c8) : make_uint4(0u, 0u, 0u, 0u);
+            }
         }
-        if (lane < 32) { lss[lane] = lr; dls[lane] = dr; }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        if (t + tstep < ntiles) fetch(t + tstep);
-        f32x16 s, dp;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-        const bf16_t* qp = Qs + qrow * LDR + 8 * h;
-        const bf16_t* gp = dOs + qrow * LDR + 8 * h;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(qp + 16 * ks), kf[ks], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(gp + 16 * ks), vf[ks], dp, 0, 0, 0);
+        if (tid < QS) {
+            long long base; int valid;
+            locate(t0 + (tid >> 5), base, valid);
+            const bool okr = (tid & 31) < valid;
+            lr = okr ? lse[base + (tid & 31)] * LOG2E : 1.0e30f;          // rows past the end: P = exp2(s - 1e30) = 0
+            dr = okr ? delta[base + (tid & 31)] : 0.f;
         }
+    };
+    if (t_begin < t_end) fetch(t_begin);
+    for (int t0 = t_begin; t0 < t_end; t0 += 2) {
+        __syncthreads();
+        if (stager) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int r, c8, g; fmap(i, r, c8, g);
+                *reinterpret_cast<uint4*>(&Qs[r * LDQ + c8]) = qr[i];
+                *reinterpret_cast<uint4*>(&dOs[r * LDQ + c8]) = gr[i];
+                st_t8(Qt, LDT, c8, r, qr[i], g);
+                st_t8(dOt, LDT, c8, r, gr[i], g);
+            }
+        }
+        if (tid < QS) { lss[tid] = lr; dls[tid] = dr; }
+        __syncthreads();
+        if (t0 + 2 < t_end) fetch(t0 + 2);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+            const bf16_t* qp = Qs + (32 * qt + qrow) * LDQ + 8 * h;
+            const bf16_t* gp = dOs + (32 * qt + qrow) * LDQ + 8 * h;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(qp + 16 * ks), kf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(gp + 16 * ks), vf[ks], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qi = 32 * qt + 16 * h + r;
+                const float p = fast_exp2(fmaf(s[r], qs, -lss[qi]));
+                dp[r] = p * (dp[r] - dls[qi]) * scale;
+                s[r] = p;
+            }
+            const bf16_t* gt = dOt + j * LDT + 32 * qt + 16 * h;
+            const bf16_t* qtp = Qt + j * LDT + 32 * qt + 16 * h;
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const bf16x8 pb = pack8(s, 8 * k2), db = pack8(dp, 8 * k2);
+                dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(gt + 8 * k2), pb, dv0, 0, 0, 0);
+                dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(gt + 32 * LDT + 8 * k2), pb, dv1, 0, 0, 0);
+                dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(qtp + 8 * k2), db, dk0, 0, 0, 0);
+                dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(qtp + 32 * LDT + 8 * k2), db, dk1, 0, 0, 0);
+            }
+        }
+    }
+    // each wave owns its keys: transpose its [d][key] accumulators through LDS so that the atomics run along d (coalesced)
+    float* red = reinterpret_cast<float*>(smem) + wave * (D * 33);
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        __syncthreads();
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int qi = 16 * h + r;
-            const float p = (qi < valid) ? fast_exp2(fmaf(s[r], qs, -lss[qi])) : 0.f;
-            dp[r] = p * (dp[r] - dls[qi]) * scale;
-            s[r] = p;
+            const int d = d_row(r, h);
+            red[d * 33 + j] = which ? dv0[r] : dk0[r];
+            red[(32 + d) * 33 + j] = which ? dv1[r] : dk1[r];
         }
-        const bf16_t* gt = dOt + j * LDQT + 16 * h;
-        const bf16_t* qt = Qt + j * LDQT + 16 * h;
-#pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) {
-            const bf16x8 pb = pack8(s, 8 * k2), db = pack8(dp, 8 * k2);
-            dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(gt + 8 * k2), pb, dv0, 0, 0, 0);
-            dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(gt + 32 * LDQT + 8 * k2), pb, dv1, 0, 0, 0);
-            dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(qt + 8 * k2), db, dk0, 0, 0, 0);
-            dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(qt + 32 * LDQT + 8 * k2), db, dk1, 0, 0, 0);
-        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
-    }
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);
-    constexpr int RW = 2 * 64 * 33;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int d = d_row(r, h);
-        red[wave * RW + (d) * 33 + j] = dk0[r];
-        red[wave * RW + (32 + d) * 33 + j] = dk1[r];
-        red[wave * RW + 64 * 33 + (d) * 33 + j] = dv0[r];
-        red[wave * RW + 64 * 33 + (32 + d) * 33 + j] = dv1[r];
-    }
-    __syncthreads();
-    for (int f = tid; f < 2 * 32 * D; f += 256) {
-        const int which = f / (32 * D), kk = (f % (32 * D)) / D, d = f % D;
-        if (kv0 + kk >= Nk) continue;
-        float v = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) v += red[w * RW + which * 64 * 33 + d * 33 + kk];
-        atomicAdd(dkv32 + ((long long)b * Nk + kv0 + kk) * 128 + which * 64 + d, v);
+        for (int f = lane; f < 32 * D; f += 64) {
+            const int kk = f >> 6, d = f & 63;
+            if (kv0 + kk < Nk) atomicAdd(dkv32 + ((long long)b * Nk + kv0 + kk) * 128 + which * 64 + d, red[d * 33 + kk]);
+        }
     }
 }
 
@@ -496,8 +513,23 @@ extern "C" int tc_attn_bwd_seg(const void* Q, int ldq, const void* K, int ldk, c
     // zero the fp32 dK/dV scratch with a kernel: a memset NODE in a captured single-stream graph was observed to run out of order
     hipLaunchKernelGGL(zero_f32_kernel, dim3(tc_blocks((long long)B * Nk * 32, 256, 1024)), dim3(256), 0, s, dkv32, (long long)B * Nk * 32);
     hipLaunchKernelGGL(delta_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const bf16_t*)O, ldo, (const bf16_t*)dO, lddo, delta, rows);
-    hipLaunchKernelGGL(attn_bwd_dkv_seg_kernel, dim3((Nk + 31) / 32, B, 4), dim3(256), 0, s, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk,
-                       (const bf16_t*)V, ldv, skv, (const bf16_t*)dO, lddo, lse, delta, dkv32, sg, Nk, scale);
+    {
+        // workgroups of 4 key waves; query chunks so that ~2 workgroups per CU exist
+        const int kt = (Nk + 31) / 32;
+        const int nw = 4;                                            // measured: 4 waves x 2 workgroups per CU (224 VGPRs) beats 5 x 1
+        const int kb = (kt + nw - 1) / nw, ntiles = sg.t32[nseg];
+        int zs = 512 / (kb * B);
+        zs = zs < 1 ? 1 : (zs > (ntiles + 1) / 2 ? (ntiles + 1) / 2 : zs);
+        int tpc = (ntiles + zs - 1) / zs;
+        tpc = (tpc + 1) & ~1;                                        // whole 64-query stages
+        zs = (ntiles + tpc - 1) / tpc;
+        if (nw == 5)
+            hipLaunchKernelGGL(attn_bwd_dkv_seg_kernel<5>, dim3(kb, B, zs), dim3(320), 0, s, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk,
+                               (const bf16_t*)V, ldv, skv, (const bf16_t*)dO, lddo, lse, delta, dkv32, sg, Nk, scale, tpc);
+        else
+            hipLaunchKernelGGL(attn_bwd_dkv_seg_kernel<4>, dim3(kb, B, zs), dim3(256), 0, s, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk,
+                               (const bf16_t*)V, ldv, skv, (const bf16_t*)dO, lddo, lse, delta, dkv32, sg, Nk, scale, tpc);
+    }
     hipLaunchKernelGGL(attn_dkv_store_kernel, dim3(tc_blocks((long long)B * Nk * 32, 256, 1024)), dim3(256), 0, s, dkv32, (bf16_t*)dK, lddk,
                        (bf16_t*)dV, lddv, sdkv, B, Nk);
     hipLaunchKernelGGL(attn_bwd_dq_seg_kernel, dim3(sg.tile0[nseg]), dim3(256), 0, s, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk, (const bf16_t*)V,
