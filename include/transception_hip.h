@@ -119,10 +119,12 @@ int tc_dwconv_fwd(const void* x, int ldx, const void* w, const void* bias, void*
 int tc_dwconv_bwd_input(const void* dy, int lddy, const void* w, void* dx, int lddx,
                         int B, int H, int W, int C, int k, int stride, int add_input, int accumulate, int groups,
                         long long wstride, int dtype, void* stream);
-/* dw [C,1,k,k] and db [C] (fp32) are ACCUMULATED into. db may be NULL. */
+/* dw [C,1,k,k] and db [C] (fp32) are ACCUMULATED into. db may be NULL.
+ * ws / ws_bytes: optional per-stream workspace with the TcGemm.ws contract (first 16 KiB = zeroed arrival counters): the
+ * workgroups' sums are then folded 16 at a time before anything touches dw / db atomically. */
 int tc_dwconv_bwd_weight(const void* dy, int lddy, const void* x, int ldx, float* dw, float* db,
-                         int B, int H, int W, int C, int k, int stride, int groups, long long wstride, int dtype,
-                         void* stream);
+                         int B, int H, int W, int C, int k, int stride, int groups, long long wstride, void* ws,
+                         long long ws_bytes, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * BatchNorm2d over token rows ([rows, C], statistics over rows) fused with its activation and an

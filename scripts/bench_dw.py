@@ -11,6 +11,7 @@ def t(fn, iters=30):
     for _ in range(iters): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / iters
+wsp = torch.zeros(16384 + 1024 * 16384, dtype=torch.uint8, device=dev)
 def run(B, H, W, C, k, groups=1):
     n = groups * B * H * W
     x = torch.randn(n, C, device=dev).bfloat16(); y = torch.empty_like(x); dy = torch.randn(n, C, device=dev).bfloat16(); dx = torch.empty_like(x)
@@ -19,7 +20,7 @@ def run(B, H, W, C, k, groups=1):
     w, b = par.data_ptr(), par.data_ptr() + 2 * C * k * k
     f = t(lambda: L.tc_dwconv_fwd(x.data_ptr(), C, w, b, y.data_ptr(), C, B, H, W, C, k, 1, 1, groups, ws, TC_BF16, st))
     d = t(lambda: L.tc_dwconv_bwd_input(dy.data_ptr(), C, w, dx.data_ptr(), C, B, H, W, C, k, 1, 1, 0, groups, ws, TC_BF16, st))
-    g = t(lambda: L.tc_dwconv_bwd_weight(dy.data_ptr(), C, x.data_ptr(), C, gpar.data_ptr(), gpar.data_ptr() + 4 * C * k * k, B, H, W, C, k, 1, groups, ws, TC_BF16, st))
+    g = t(lambda: L.tc_dwconv_bwd_weight(dy.data_ptr(), C, x.data_ptr(), C, gpar.data_ptr(), gpar.data_ptr() + 4 * C * k * k, B, H, W, C, k, 1, groups, ws, wsp.data_ptr(), wsp.numel(), TC_BF16, st))
     floor = 2 * n * C * 2 / 8e6
     print(f"B={B} {H}x{W} C={C:4d} k={k} g={groups}: fwd {f:6.1f}  dx {d:6.1f}  dw {g:6.1f} us   (hbm floor {floor:5.1f} us)")
 run(16, 56, 56, 256, 3); run(16, 28, 28, 512, 3); run(16, 14, 14, 1280, 3); run(16, 7, 7, 2048, 3)

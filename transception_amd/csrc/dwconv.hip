@@ -337,6 +337,29 @@ __device__ __forceinline__ void dw_stage(uint4* tile, const T* img, int ld, int 
     }
 }
 
+// the same fill split in two: global -> registers (issued a whole tile ahead), registers -> LDS
+template <typename T, int CG, int NREG>
+__device__ __forceinline__ void dw_fetch(uint4 (&reg)[NREG], const T* img, int ld, int h0, int w0, int NH, int NW, int H, int W, int crem) {
+    constexpr int VEC = Vec16<T>::N;
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) {
+        const int v = threadIdx.x + i * 256;
+        const int cgi = v % CG, pix = v / CG, ix = pix % NW, iy = pix / NW;
+        const int ih = h0 + iy, iw = w0 + ix;
+        reg[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (v < NH * NW * CG && ih >= 0 && ih < H && iw >= 0 && iw < W && cgi * VEC < crem)
+            reg[i] = *reinterpret_cast<const uint4*>(img + ((long long)ih * W + iw) * ld + cgi * VEC);
+    }
+}
+template <int CG, int PIXQ, int NREG>
+__device__ __forceinline__ void dw_put(uint4* tile, const uint4 (&reg)[NREG], int NH, int NW) {
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) {
+        const int v = threadIdx.x + i * 256;
+        if (v < NH * NW * CG) tile[(v / CG) * PIXQ + v % CG] = reg[i];
+    }
+}
+
 template <typename T, int K, int CG, int MODE>      // MODE 0: y = conv(x) (+bias) (+x);  MODE 1: dx = conv^T(dy) (+dy) (+dx)
 __global__ __launch_bounds__(256) void dw_tile_kernel(const T* __restrict__ src, int lds_, const T* __restrict__ w,
                                                       const T* __restrict__ bias, T* __restrict__ y, int ldy, int B, int H, int W,
@@ -419,7 +442,8 @@ __global__ __launch_bounds__(256) void dw_tile_kernel(const T* __restrict__ src,
 template <typename T, int K, int CG>
 __global__ __launch_bounds__(256) void dw_tile_wgrad_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy,
                                                             float* __restrict__ dw, float* __restrict__ db, int B, int H, int W, int C,
-                                                            long long wstride, int tilesW, int tilesH) {
+                                                            long long wstride, int tilesW, int tilesH, float* __restrict__ ws_part,
+                                                            int* __restrict__ ws_cnt) {
     using D = DwTile<K, CG>;
     constexpr int VEC = Vec16<T>::N, CH = CG * VEC, R = D::R, P = D::P, PIXQ = CG + 1, NT = K * K + 1;
     constexpr int RG = D::PT / K, UNITS = D::TH * (D::TW / R);
@@ -443,13 +467,35 @@ __global__ __launch_bounds__(256) void dw_tile_wgrad_kernel(const T* __restrict_
         for (int kx = 0; kx < K; ++kx) acc[kx][e] = 0.f;
     }
     const int ntiles = B * tilesH * tilesW;
+    // K = 3 / 5: the next tile's pixels are fetched into registers while this one is multiplied (a workgroup visits 2-7 tiles and
+    // only 2-3 workgroups fit a CU, so an un-prefetched fill is exposed HBM latency); K = 7 has no registers to spare
+    constexpr bool PF = K <= 5;
+    constexpr int NX = PF ? (D::IH * D::IW * CG + 255) / 256 : 1, ND = PF ? (D::TH * D::TW * CG + 255) / 256 : 1;
+    uint4 xr[NX], dr[ND];
+    auto tile_org = [&](int tidx, int& b, int& oh0, int& ow0) {
+        const int tix = tidx % tilesW, tiy = (tidx / tilesW) % tilesH;
+        b = tidx / (tilesW * tilesH); oh0 = tiy * D::TH; ow0 = tix * D::TW;
+    };
+    auto fetch = [&](int tidx) {
+        int b, oh0, ow0;
+        tile_org(tidx, b, oh0, ow0);
+        dw_fetch<T, CG, NX>(xr, x + (long long)b * H * W * ldx + c0, ldx, oh0 - P, ow0 - P, D::IH, D::IW, H, W, C - c0);
+        dw_fetch<T, CG, ND>(dr, dy + (long long)b * H * W * lddy + c0, lddy, oh0, ow0, D::TH, D::TW, H, W, C - c0);
+    };
+    if (PF && (int)blockIdx.x < ntiles) fetch(blockIdx.x);
     for (int tidx = blockIdx.x; tidx < ntiles; tidx += gridDim.x) {
-        const int tix = tidx % tilesW, tiy = (tidx / tilesW) % tilesH, b = tidx / (tilesW * tilesH);
-        const int oh0 = tiy * D::TH, ow0 = tix * D::TW;
         __syncthreads();
-        dw_stage<T, CG, PIXQ>(xt, x + (long long)b * H * W * ldx + c0, ldx, oh0 - P, ow0 - P, D::IH, D::IW, H, W, C - c0);
-        dw_stage<T, CG, PIXQ>(dt, dy + (long long)b * H * W * lddy + c0, lddy, oh0, ow0, D::TH, D::TW, H, W, C - c0);
+        if (PF) {
+            dw_put<CG, PIXQ, NX>(xt, xr, D::IH, D::IW);
+            dw_put<CG, PIXQ, ND>(dt, dr, D::TH, D::TW);
+        } else {
+            int b, oh0, ow0;
+            tile_org(tidx, b, oh0, ow0);
+            dw_stage<T, CG, PIXQ>(xt, x + (long long)b * H * W * ldx + c0, ldx, oh0 - P, ow0 - P, D::IH, D::IW, H, W, C - c0);
+            dw_stage<T, CG, PIXQ>(dt, dy + (long long)b * H * W * lddy + c0, lddy, oh0, ow0, D::TH, D::TW, H, W, C - c0);
+        }
         __syncthreads();
+        if (PF && tidx + (int)gridDim.x < ntiles) fetch(tidx + gridDim.x);
         if (active) {
             for (int u = rg; u < UNITS; u += RG) {
                 const int row = u / (D::TW / R), run = u % (D::TW / R);
@@ -485,11 +531,50 @@ __global__ __launch_bounds__(256) void dw_tile_wgrad_kernel(const T* __restrict_
         }
     }
     __syncthreads();
+    float* lflat = &lacc[0][0];
+    int gm = 1;
+    const float* pgroup = nullptr;
+    if (ws_part) {
+        // Two-level fold (same protocol as the GEMM split-K fix-up): the workgroups of a (group, channel chunk) park their sums in
+        // the workspace, 16 consecutive ones share an arrival counter, the last to arrive adds the 16 and is the only one that
+        // touches dw / db atomically -- a contended fp32 atomic costs ~0.13 us and 128-170 workgroups used to queue on every word.
+        constexpr int FG = 16;
+        const int chain = (blockIdx.z * gridDim.y + blockIdx.y), grp = blockIdx.x / FG, ngrp = (gridDim.x + FG - 1) / FG;
+        gm = min(FG, (int)gridDim.x - grp * FG);
+        float* part = ws_part + ((long long)chain * gridDim.x + blockIdx.x) * (NT * CH);
+        pgroup = ws_part + ((long long)chain * gridDim.x + grp * FG) * (NT * CH);
+        if (gm > 1) {
+            for (int f = threadIdx.x; f < NT * CH; f += 256) __hip_atomic_store(part + f, lflat[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+            __shared__ int s_last;
+            if (threadIdx.x == 0) {
+                int* c = ws_cnt + chain * ngrp + grp;
+                const int old = atomicAdd(c, 1);
+                s_last = (old == gm - 1);
+                if (s_last) atomicExch(c, 0);
+            }
+            __syncthreads();
+            if (!s_last) return;
+        }
+    }
     for (int f = threadIdx.x; f < NT * CH; f += 256) {
-        const int cc = f / NT, t = f - cc * NT, ch = c0 + cc;              // taps fastest: neighbouring lanes hit neighbouring dw words
+        const int t = f / CH, cc = f - t * CH, ch = c0 + cc;                // lacc is [tap][channel]
         if (ch >= C) continue;
-        if (t < K * K) atomicAdd(dw + (long long)ch * K * K + t, lacc[t][cc]);
-        else if (db) atomicAdd(db + ch, lacc[t][cc]);
+        float v;
+        if (gm > 1) {
+            float tmp[16];                                   // all 16 loads in flight before the first add (they bypass L2: ~2 us each)
+#pragma unroll
+            for (int m = 0; m < 16; ++m)
+                tmp[m] = m < gm ? __hip_atomic_load(pgroup + (long long)m * (NT * CH) + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+            v = 0.f;
+#pragma unroll
+            for (int m = 0; m < 16; ++m) v += tmp[m];
+        } else {
+            v = lflat[f];
+        }
+        if (t < K * K) atomicAdd(dw + (long long)ch * K * K + t, v);
+        else if (db) atomicAdd(db + ch, v);
     }
 }
 
@@ -511,7 +596,7 @@ template <typename T> bool dw_tile_ok(const void* a, int lda, const void* b, int
 template <typename T, int MODE>
 int launch_tile(const void* src, int lds_, const void* w, const void* bias, void* y, int ldy, const void* dy, int lddy, float* dw,
                 float* db, int B, int H, int W, int C, int k, int add_input, int accumulate, int groups, long long wstride,
-                hipStream_t s) {
+                hipStream_t s, void* ws = nullptr, long long ws_bytes = 0) {
     constexpr int VEC = Vec16<T>::N;
     const int cg = dw_pick_cg<T>(C);
     const int chunks = (C + cg * VEC - 1) / (cg * VEC);
@@ -520,11 +605,18 @@ int launch_tile(const void* src, int lds_, const void* w, const void* bias, void
     if (ntiles > 0x7fffffffLL) return TC_ERR_ARG;
 #define TC_TILE(KK, CGG)                                                                                                                \
     if (MODE == 2) {                                                                                                                    \
-        int gx = 512 / (chunks * groups); /* contended fp32 atomics cost ~0.13 us each: few contributors per address */                                                                                           \
+        int gx = 256 / (chunks * groups);   /* measured best with the fold: one workgroup per CU, each visiting ~7 tiles */ /* contended fp32 atomics cost ~0.13 us each: few contributors per word */          \
+        if (gx > ntiles) gx = (int)ntiles;                                                                                              \
+        constexpr int NTC = ((KK) * (KK) + 1) * (CGG) * VEC;                                                                            \
+        float* wp = nullptr; int* wc = nullptr;                                                                                         \
+        if (ws && (uintptr_t)ws % 16 == 0 && ws_bytes >= 16384 + (long long)chunks * groups * (gx < 1 ? 1 : gx) * NTC * 4 &&             \
+            (long long)chunks * groups * (((gx < 1 ? 1 : gx) + 15) / 16) <= 4096) {                                                      \
+            wc = reinterpret_cast<int*>(ws); wp = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + 16384);                         \
+        }                                                                                          \
         gx = gx < 1 ? 1 : gx;                                                                                                           \
         dim3 grid((unsigned)(ntiles < gx ? ntiles : gx), chunks, groups);                                                               \
         hipLaunchKernelGGL((dw_tile_wgrad_kernel<T, KK, CGG>), grid, dim3(256), 0, s, (const T*)src, lds_, (const T*)dy, lddy, dw, db,  \
-                           B, H, W, C, wstride, tilesW, tilesH);                                                                        \
+                           B, H, W, C, wstride, tilesW, tilesH, wp, wc);                                                                        \
     } else {                                                                                                                            \
         dim3 grid((unsigned)ntiles, chunks, groups);                                                                                    \
         hipLaunchKernelGGL((dw_tile_kernel<T, KK, CGG, (MODE == 2 ? 0 : MODE)>), grid, dim3(256), 0, s, (const T*)src, lds_,            \
@@ -595,13 +687,14 @@ extern "C" int tc_dwconv_bwd_input(const void* dy, int lddy, const void* w, void
 }
 
 extern "C" int tc_dwconv_bwd_weight(const void* dy, int lddy, const void* x, int ldx, float* dw, float* db, int B, int H,
-                                    int W, int C, int k, int stride, int groups, long long wstride, int dtype, void* stream) {
+                                    int W, int C, int k, int stride, int groups, long long wstride, void* ws, long long ws_bytes,
+                                    int dtype, void* stream) {
     if (!dy || !x || !dw || groups < 1 || (groups > 1 && stride != 1) || !dw_args_ok(B, H, W, C, k, stride, 0)) return TC_ERR_ARG;
     if (stride == 1)
         TC_DISPATCH_DTYPE(dtype, {
             if (dw_tile_ok<T>(x, ldx, dy, lddy, C))
                 return (launch_tile<T, 2>(x, ldx, nullptr, nullptr, nullptr, 0, dy, lddy, dw, db, B, H, W, C, k, 0, 0, groups, wstride,
-                                          (hipStream_t)stream));
+                                          (hipStream_t)stream, ws, ws_bytes));
             return (launch_strip<T, 2>(x, ldx, nullptr, nullptr, dy, lddy, nullptr, 0, dw, db, B, H, W, C, k, 0, 0, groups, wstride,
                                        (hipStream_t)stream));
         });

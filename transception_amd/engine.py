@@ -556,9 +556,12 @@ class Graph:
                 self.L.tc_dwconv_bwd_input(_ptr(dy), dy.stride(0), _ptr(w.data), _ptr(gx), gx.stride(0), B, H, W, Cc, k, stride,
                                            int(add_input), acc, Gn, w.gs, self.dt, self.stream)
             if w.grad is not None:
-                self._weight_grad(lambda: self.L.tc_dwconv_bwd_weight(
-                    _ptr(dy), dy.stride(0), _ptr(x.data), x.ld, _ptr(w.grad), _ptr(b.grad) if b is not None else None, B, H, W, Cc, k,
-                    stride, Gn, w.gs, self.dt, self.stream), reads=dy)
+                def dwgrad():
+                    ws = _workspace(self.dev, self.stream)           # of the stream this actually runs on
+                    self.L.tc_dwconv_bwd_weight(_ptr(dy), dy.stride(0), _ptr(x.data), x.ld, _ptr(w.grad),
+                                                _ptr(b.grad) if b is not None else None, B, H, W, Cc, k, stride, Gn, w.gs,
+                                                ws.data_ptr(), ws.numel(), self.dt, self.stream)
+                self._weight_grad(dwgrad, reads=dy)
         self._rec(bwd)
         return out
 
