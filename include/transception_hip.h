@@ -93,9 +93,10 @@ int tc_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx, const voi
                      const float* mean, const float* rstd, void* dx, int lddx, const void* dres, int ldres,
                      float* dgamma, float* dbeta, int rows, int C, int act, int groups, long long pstride,
                      float* scratch, long long scratch_floats, int dtype, void* stream);
-/* scratch (>= tc_layernorm_bwd_scratch_floats() floats, or NULL): with it the parameter gradients are folded from
- * per-workgroup partials by a second tiny launch instead of ~1000-way contended atomics -- one pass over x / dy for dx,
- * dgamma and dbeta together. */
+/* scratch (>= tc_layernorm_bwd_scratch_floats() floats, or NULL): a per-stream workspace with the TcGemm.ws contract (its
+ * first 16 KiB are arrival counters: zero before the first use, left zero).  With it the per-workgroup parameter-gradient
+ * partials are folded 16 at a time inside the kernel before anything touches dgamma / dbeta atomically -- one pass over
+ * x / dy for dx, dgamma and dbeta together. */
 long long tc_layernorm_bwd_scratch_floats(int rows, int C, int groups);
 /* dgamma / dbeta may both be NULL above (dx only); this entry then produces them as a row-parallel column reduction, so the
  * host can run it on a second stream beside the activation-gradient chain. */

@@ -17,7 +17,7 @@ def run(rows, C, act=0):
     mean = torch.empty(rows, device=dev); rstd = torch.empty(rows, device=dev)
     f = t(lambda: L.tc_layernorm_fwd(x.data_ptr(), C, g.data_ptr(), b.data_ptr(), y.data_ptr(), C, mean.data_ptr(), rstd.data_ptr(), rows, C, 1e-5, act, 1, 0, TC_BF16, st))
     d = t(lambda: L.tc_layernorm_bwd(dy.data_ptr(), C, x.data_ptr(), C, g.data_ptr(), b.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), C, None, 0, None, None, rows, C, act, 1, 0, None, 0, TC_BF16, st))
-    ns = L.tc_layernorm_bwd_scratch_floats(rows, C, 1); sc = torch.empty(ns, device=dev)
+    ns = L.tc_layernorm_bwd_scratch_floats(rows, C, 1); sc = torch.zeros(ns, device=dev)
     fz = t(lambda: L.tc_layernorm_bwd(dy.data_ptr(), C, x.data_ptr(), C, g.data_ptr(), b.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), C, None, 0, dg.data_ptr(), db.data_ptr(), rows, C, act, 1, 0, sc.data_ptr(), ns, TC_BF16, st))
     p = t(lambda: L.tc_layernorm_bwd_params(dy.data_ptr(), C, x.data_ptr(), C, g.data_ptr(), b.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dg.data_ptr(), db.data_ptr(), rows, C, act, 1, 0, TC_BF16, st))
     c = t(lambda: y.copy_(x))

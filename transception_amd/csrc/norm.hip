@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      T* __restrict__ dx, int lddx, const T* __restrict__ dres, int ldres,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int C,
-                                                     int act, long long pstride, float* __restrict__ partial) {
+                                                     int act, long long pstride, float* __restrict__ partial, int* __restrict__ cnt) {
     constexpr int RPB = 256 / GS;
     extern __shared__ float red[];           // [RPB][2][C]
     const int gl = threadIdx.x % GS, gi = threadIdx.x / GS;
@@ -156,37 +156,41 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
         float a = 0.f, bb = 0.f;
 #pragma unroll
         for (int w = 0; w < RPB; ++w) { a += red[(w * 2 + 0) * C + c]; bb += red[(w * 2 + 1) * C + c]; }
-        if (partial) {                       // no atomics: per-workgroup partials, folded by ln_param_finish_kernel
+        if (partial) {                       // parked for the 16-way fold below
             float* pp = partial + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 2 * C;
-            pp[c] = a; pp[C + c] = bb;
+            __hip_atomic_store(pp + c, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(pp + C + c, bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             atomicAdd(dgamma + c, a);
             atomicAdd(dbeta + c, bb);
         }
     }
-}
-
-// dgamma / dbeta += sum over the nblk per-workgroup partials ln_bwd_kernel left in `partial` ([group][nblk][2][C])
-__global__ __launch_bounds__(256) void ln_param_finish_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta, long long pstride) {
-    __shared__ float sa[8][32], sb[8][32];
-    const int cl = threadIdx.x & 31, r = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
-    const float* pp = partial + (long long)blockIdx.y * nblk * 2 * C;
-    float a = 0.f, b = 0.f;
-    if (c < C) {
-#pragma unroll 8
-        for (int k = r; k < nblk; k += 8) { a += pp[(long long)k * 2 * C + c]; b += pp[(long long)k * 2 * C + C + c]; }
-    }
-    sa[r][cl] = a; sb[r][cl] = b;
+    if (!partial) return;
+    // Two-level fold (the GEMM split-K fix-up protocol): 16 consecutive workgroups share an arrival counter; the last to arrive
+    // adds the 16 partial rows and is the only one that touches dgamma / dbeta atomically (64 contributors per word instead of
+    // 1024, and no second launch).
+    constexpr int FG = 16;
+    const int grp = blockIdx.x / FG, ngrp = (gridDim.x + FG - 1) / FG, gm = min(FG, (int)gridDim.x - grp * FG);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
-    if (threadIdx.x < 64) {
-        const int which = threadIdx.x >> 5, cc = blockIdx.x * 32 + cl;
-        if (cc < C) {
-            float v = 0.f;
+    __shared__ int s_last;
+    if (threadIdx.x == 0) {
+        int* cn = cnt + blockIdx.y * ngrp + grp;
+        const int old = atomicAdd(cn, 1);
+        s_last = (old == gm - 1);
+        if (s_last) atomicExch(cn, 0);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const float* pg = partial + ((long long)blockIdx.y * gridDim.x + grp * FG) * 2 * C;
+    for (int c = threadIdx.x; c < 2 * C; c += 256) {
+        float tmp[FG];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v += which ? sb[k][cl] : sa[k][cl];
-            atomicAdd((which ? dbeta : dgamma) + blockIdx.y * pstride + cc, v);
-        }
+        for (int m = 0; m < FG; ++m) tmp[m] = m < gm ? __hip_atomic_load(pg + (long long)m * 2 * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+        float v = 0.f;
+#pragma unroll
+        for (int m = 0; m < FG; ++m) v += tmp[m];
+        atomicAdd((c < C ? dgamma + c : dbeta + (c - C)), v);
     }
 }
 
@@ -430,21 +434,20 @@ extern "C" int tc_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx
     float* partial = nullptr;
 #define TC_LNB(GS, NV) {                                                                                                                  \
         nblk = tc_blocks(rows, (256 / GS) * (dgamma ? LN_BWD_ROWS_PER_GROUP : 1), dgamma ? LN_BWD_MAX_BLOCKS : 8192);                       \
-        partial = (dgamma && scratch && scratch_floats >= (long long)groups * nblk * 2 * C) ? scratch : nullptr;                            \
+        partial = (dgamma && scratch && (uintptr_t)scratch % 16 == 0 && scratch_floats >= 4096 + (long long)groups * nblk * 2 * C &&      \
+                   (long long)groups * ((nblk + 15) / 16) <= 4096) ? scratch + 4096 : nullptr;                                            \
         hipLaunchKernelGGL((ln_bwd_kernel<T, GS, NV>), dim3(nblk, groups), dim3(256),                                                       \
                                           (size_t)(256 / GS) * 2 * C * sizeof(float), s, (const T*)dy, lddy, (const T*)x, ldx,            \
                                           (const T*)gamma, (const T*)beta, mean, rstd, (T*)dx, lddx, (const T*)dres, ldres, dgamma,      \
-                                          dbeta, rows, C, act, pstride, partial); }
+                                          dbeta, rows, C, act, pstride, partial, reinterpret_cast<int*>(scratch)); }
     TC_DISPATCH_DTYPE(dtype, { TC_LN_DISPATCH(quads, TC_LNB) });
 #undef TC_LNB
-    if (partial)
-        hipLaunchKernelGGL(ln_param_finish_kernel, dim3((C + 31) / 32, groups), dim3(256), 0, s, partial, nblk, C, dgamma, dbeta, pstride);
     return tc_launch_status();
 }
 
 extern "C" long long tc_layernorm_bwd_scratch_floats(int rows, int C, int groups) {
     if (rows <= 0 || C <= 0 || groups < 1) return 0;
-    return (long long)groups * LN_BWD_MAX_BLOCKS * 2 * C;      // upper bound over the lane-group shapes
+    return 4096 + (long long)groups * LN_BWD_MAX_BLOCKS * 2 * C;      // counters + an upper bound over the lane-group shapes
 }
 
 extern "C" int tc_layernorm_bwd_params(const void* dy, int lddy, const void* x, int ldx, const void* gamma, const void* beta,

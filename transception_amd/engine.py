@@ -520,8 +520,8 @@ class Graph:
             gx, acc = self.wgrad(x)
             fused = g.grad is not None and not (self.overlap_wgrad and self.use_streams)
             if fused:                                    # one pass: dx + per-workgroup dgamma/dbeta partials + a tiny folding launch
-                n = self.L.tc_layernorm_bwd_scratch_floats(rows, Cc, Gn)
-                scratch = self.f32(n)
+                ws = _workspace(self.dev, self.stream)
+                scratch, n = ws, ws.numel() // 4
                 self.L.tc_layernorm_bwd(_ptr(dy), dy.stride(0), _ptr(x.data), x.ld, _ptr(g.data), _ptr(b.data), _ptr(mean),
                                         _ptr(rstd), _ptr(gx), gx.stride(0), _ptr(gx) if acc else None, gx.stride(0),
                                         _ptr(g.grad), _ptr(b.grad), rows, Cc, act, Gn, g.gs, _ptr(scratch), n, self.dt, self.stream)
