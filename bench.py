@@ -170,6 +170,32 @@ def main():
             train_step(model, loss_fn, opt, x, y, group)
         torch.cuda.synchronize(dev)
     prof, engine.PROFILE = engine.PROFILE, None
+    extra = {}
+    if rank == 0 and world == 1:
+        # side figures SURVEY.md section 8(d) asks for: C-ABI calls of one step (each is 1-3 kernel launches) and the
+        # forward-only rate (train-mode forward captured alone, 10 replays)
+        from transception_amd._lib import _Lib
+        c0 = _Lib.calls
+        train_step(model, loss_fn, opt, x, y, group)
+        extra["c_abi_calls_per_step"] = _Lib.calls - c0
+        torch.cuda.synchronize(dev)
+        with torch.no_grad():
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                model(x)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize(dev)
+            gf = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gf):
+                model(x)
+            gf.replay()
+            torch.cuda.synchronize(dev)
+            tf = time.perf_counter()
+            for _ in range(10):
+                gf.replay()
+            torch.cuda.synchronize(dev)
+            extra["fwd_only_images_per_sec"] = args.batch * 10 / (time.perf_counter() - tf)
 
     if rank == 0:
         out = {
@@ -180,7 +206,7 @@ def main():
             "config": {"workload": f"TransCeption (MSTransception) {args.size}x{args.size} B={args.batch}/GPU fwd+bwd+SGD, "
                                    "synthetic Synapse slices, name-seeded random-init weights",
                        "global_batch": world * args.batch, "image_size": args.size, "parallelism": f"dp{world}",
-                       "launch_mode": "eager" if args.eager else "hipGraph replay", "final_loss": float(loss.item())},
+                       "launch_mode": "eager" if args.eager else "hipGraph replay", "final_loss": float(loss.item()), **extra},
         }
         if prof and prof.get("attn_fwd"):
             ev = prof["attn_fwd"]

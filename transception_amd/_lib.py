@@ -83,6 +83,8 @@ class TcError(RuntimeError):
 
 
 class _Lib:
+    calls = 0
+
     def __init__(self, path: str = LIB_PATH):
         if not os.path.exists(path):
             raise TcError(f"{path} is missing: build it with `python -m transception_amd.build` "
@@ -101,6 +103,7 @@ class _Lib:
     @staticmethod
     def _checked(name, fn):
         def call(*a):
+            _Lib.calls += 1                      # C-ABI entries since import (bench.py reports the per-step count)
             rc = fn(*a)
             if rc != 0:
                 raise TcError(f"{name} failed with status {rc}")
