@@ -255,6 +255,12 @@ int tc_seg_loss_fwd(const void* logits, const long long* labels, float* prob, fl
 int tc_seg_loss_bwd(const float* prob, const long long* labels, const float* sums, void* dlogits, int B, int ncls,
                     int HW, float w_ce, float w_dice, float n_pix_global, float gscale, const float* gscale_dev, int dtype,
                     void* stream);
+/* Evaluation (utils.py:72-76 argmax(softmax(logits)), :50-60,96-97 per-class Dice): pred[b,p] = argmax_k
+ * logits[b,k,p] as uint8; with labels (int64 [B,HW]) also counts[3k..3k+2] += (|pred==k & gt==k|, |pred==k|, |gt==k|), fp32,
+ * ACCUMULATED.  ncls <= 16. */
+int tc_argmax_counts(const void* logits, const long long* labels, unsigned char* pred, float* counts, int B, int ncls, int HW,
+                     int dtype, void* stream);
+
 /* Fused SGD with momentum and weight decay over flat fp32 buffers (torch.optim.SGD semantics, trainer.py:125):
  *   g = grad*gscale + wd*p ; buf = first ? g : mom*buf + g ; p -= lr*buf.
  * lr_dev (optional device scalar) overrides lr, so a hipGraph-captured step can follow a per-iteration schedule. */

@@ -359,3 +359,23 @@ def load_params(state: Dict[str, Tensor], requires_grad: bool = False) -> Dict[s
         else:
             out[k] = v.detach().clone()
     return out
+
+
+def eval_argmax_counts(logits, labels, ncls: int):
+    """Evaluation oracle (utils.py:72-76,96-97 + calculate_metric_percase :50-60): (pred, counts[ncls,3]) with
+    pred = argmax(softmax(logits, 1), 1) and counts[k] = (|pred==k & gt==k|, |pred==k|, |gt==k|)."""
+    import torch
+    pred = torch.argmax(torch.softmax(logits.float(), dim=1), dim=1)
+    counts = torch.zeros(ncls, 3, dtype=torch.float64)
+    for k in range(ncls):
+        p, g = pred == k, labels == k
+        counts[k, 0], counts[k, 1], counts[k, 2] = (p & g).sum(), p.sum(), g.sum()
+    return pred, counts
+
+
+def eval_dice(counts):
+    """medpy.metric.binary.dc (2|A&B| / (|A|+|B|)) under calculate_metric_percase's empty-set conventions, classes 1.."""
+    out = []
+    for inter, p, g in counts[1:].tolist():
+        out.append(2.0 * inter / (p + g) if (p > 0 and g > 0) else (1.0 if p > 0 else 0.0))
+    return out

@@ -80,3 +80,23 @@ def test_cosine_schedule_matches_torch():
         opt.step()
         sch.step()
         assert math.isclose(opt.param_groups[0]["lr"], cosine_lr(0.05, step, 100), rel_tol=1e-9)
+
+
+def test_eval_dice_conventions():
+    """dice_from_counts (product) == eval_dice (oracle) == the reference's calculate_metric_percase conventions (utils.py:50-60)."""
+    import numpy as np
+    import torch
+    from oracle.transception_oracle import eval_argmax_counts, eval_dice
+    from transception_amd.evaluate import dice_from_counts
+    g = torch.Generator().manual_seed(3)
+    logits = torch.randn(2, 5, 8, 8, generator=g)
+    labels = torch.randint(0, 4, (2, 8, 8), generator=g)           # class 4 never appears in the labels
+    logits[:, 3] = -50.0                                            # class 3 is never predicted
+    pred, counts = eval_argmax_counts(logits, labels, 5)
+    d_oracle = eval_dice(counts)
+    d_prod = dice_from_counts(counts.numpy())
+    assert np.allclose(d_oracle, d_prod)
+    p1, g1 = (pred == 1), (labels == 1)
+    assert abs(d_prod[0] - 2.0 * (p1 & g1).sum().item() / (p1.sum().item() + g1.sum().item())) < 1e-12
+    assert d_prod[2] == 0.0                                          # never predicted -> 0
+    assert d_prod[3] in (0.0, 1.0)                                   # label-free class: 1 if predicted anywhere, else 0

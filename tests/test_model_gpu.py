@@ -374,3 +374,23 @@ def test_graphed_bf16_replays_track_eager():
         assert abs(a - b) < 5e-3, (a, b)                      # bf16 storage + atomic summation order
         g = mg.flat_gradients()
         assert torch.isfinite(g).all() and float(g.float().norm()) < 10.0
+
+
+def test_evaluation_path_matches_oracle():
+    """batched eval-mode inference + tc_argmax_counts reproduce argmax(softmax(.)) of the product logits exactly
+    (bit-exact integer work) and the oracle's Dice counts; the eval-mode forward itself is pinned by the golden tests above."""
+    from oracle.transception_oracle import eval_argmax_counts, eval_dice
+    from transception_amd.evaluate import argmax_counts, dice_from_counts, predict_slices
+    m = _fresh().eval()
+    g = torch.Generator().manual_seed(11)
+    sl = torch.rand(3, 224, 224, generator=g).to(DEV)
+    lab = torch.randint(0, 9, (3, 224, 224), generator=g).to(DEV)
+    with torch.no_grad():
+        logits = m(((sl - 0.5) / 0.5).unsqueeze(1))
+    pred, counts = argmax_counts(logits, lab)
+    ref_pred, ref_counts = eval_argmax_counts(logits.cpu(), lab.cpu(), 9)
+    assert torch.equal(pred.cpu().long(), ref_pred)
+    assert torch.equal(counts.cpu().double(), ref_counts)
+    assert dice_from_counts(counts.cpu().numpy()) == eval_dice(ref_counts)
+    assert torch.equal(predict_slices(m, sl, batch=2).cpu().long(), ref_pred)       # ragged last batch
+    assert not m.training

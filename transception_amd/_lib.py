@@ -69,6 +69,7 @@ SIGNATURES = {
     "tc_sr_deinterleave": [vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp],
     "tc_stem_im2col": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "tc_seg_loss_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "tc_argmax_counts": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "tc_seg_loss_bwd": [vp, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, vp, i32, vp],
     "tc_sgd_step": [vp, vp, vp, i64, f32, vp, f32, f32, f32, i32, vp],
     "tc_sgd_step_multi": [vp, vp, vp, vp, i32, i64, f32, vp, f32, f32, f32, i32, vp],

@@ -122,6 +122,44 @@ __global__ void sgd_multi_kernel(float* __restrict__ p, const float* __restrict_
     }
 }
 
+// Evaluation (utils.py:72-76,96-97): pred = argmax_k logits[b,k,p] (softmax is monotone; first maximum wins like torch.argmax) and,
+// when labels are given, per-class voxel counts  counts[3k..3k+2] += (|pred==k & gt==k|, |pred==k|, |gt==k|)  for the Dice of
+// calculate_metric_percase (utils.py:50-60).  Counts are exact in fp32 up to 2^24 per launch; the host accumulates in float64.
+template <typename T>
+__global__ __launch_bounds__(256) void argmax_counts_kernel(const T* __restrict__ logits, const long long* __restrict__ labels,
+                                                            unsigned char* __restrict__ pred, float* __restrict__ counts, int B, int ncls,
+                                                            int HW) {
+    __shared__ float red[4][3 * MAXCLS];
+    float cnt[3 * MAXCLS];
+#pragma unroll
+    for (int k = 0; k < 3 * MAXCLS; ++k) cnt[k] = 0.f;
+    const long long n = (long long)B * HW;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int b = (int)(i / HW), p = (int)(i % HW);
+        const T* lp = logits + (long long)b * ncls * HW + p;
+        float m = ldf<T>(lp);
+        int arg = 0;
+#pragma unroll
+        for (int k = 1; k < MAXCLS; ++k) if (k < ncls) { const float v = ldf<T>(lp + (long long)k * HW); if (v > m) { m = v; arg = k; } }
+        pred[i] = (unsigned char)arg;
+        if (labels) {
+            const int lab = (int)labels[i];
+#pragma unroll
+            for (int k = 0; k < MAXCLS; ++k) if (k < ncls) {
+                cnt[3 * k] += (arg == k && lab == k) ? 1.f : 0.f;
+                cnt[3 * k + 1] += (arg == k) ? 1.f : 0.f;
+                cnt[3 * k + 2] += (lab == k) ? 1.f : 0.f;
+            }
+        }
+    }
+    if (!labels) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 3 * MAXCLS; ++k) if (k < 3 * ncls) { const float a = wave_sum(cnt[k]); if (lane == 0) red[wave][k] = a; }
+    __syncthreads();
+    if (threadIdx.x < 3 * ncls) atomicAdd(counts + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 __global__ void zero_floats_kernel(float* __restrict__ p, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = 0.f;
@@ -146,6 +184,15 @@ extern "C" int tc_seg_loss_fwd(const void* logits, const long long* labels, floa
     hipStream_t s = (hipStream_t)stream;
     TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((seg_loss_fwd_kernel<T>), dim3(tc_blocks((long long)B * HW, 256, 1024)), dim3(256), 0, s,
                                                 (const T*)logits, labels, prob, sums, B, ncls, HW));
+    return tc_launch_status();
+}
+
+extern "C" int tc_argmax_counts(const void* logits, const long long* labels, unsigned char* pred, float* counts, int B, int ncls, int HW,
+                                int dtype, void* stream) {
+    if (!logits || !pred || (labels && !counts) || B <= 0 || ncls <= 0 || ncls > MAXCLS || HW <= 0) return TC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((argmax_counts_kernel<T>), dim3(tc_blocks((long long)B * HW, 256, 512)), dim3(256), 0, s,
+                                                (const T*)logits, labels, pred, counts, B, ncls, HW));
     return tc_launch_status();
 }
 
