@@ -255,6 +255,18 @@ int tc_seg_loss_fwd(const void* logits, const long long* labels, float* prob, fl
 int tc_seg_loss_bwd(const float* prob, const long long* labels, const float* sums, void* dlogits, int B, int ncls,
                     int HW, float w_ce, float w_dice, float n_pix_global, float gscale, const float* gscale_dev, int dtype,
                     void* stream);
+/* Fused core of FactorAtt_ConvRelPosEnc (MSTr.py:864-877), one workgroup per (image, head):
+ *   o = scale * q (softmax_N(k)^T v) + q (.) convv        q, k, v: column slices (row stride ld) of the [Bt*N, 3C] qkv buffer,
+ * head h owning channels [h*Ch, (h+1)*Ch); convv = crpe(v) (row stride ldc).  stats: tc_factor_att_stats_floats() floats saved for
+ * the backward (column max and 1/sum of the key softmax).  Backward: dq/dk/dv share the row stride ldd (slices of the qkv
+ * gradient; acc_* = add to what is there), dconvv is overwritten.  Replaces 5 forward + 7 backward launches of the unfused form. */
+long long tc_factor_att_stats_floats(int Bt, int heads, int Ch);
+int tc_factor_att_fwd(const void* q, const void* k, const void* v, int ld, const void* convv, int ldc, void* o, int ldo,
+                      float* stats, int Bt, int N, int heads, int Ch, float scale, int dtype, void* stream);
+int tc_factor_att_bwd(const void* q, const void* k, const void* v, int ld, const void* convv, int ldc, const void* go, int ldgo,
+                      const float* stats, void* dq, void* dk, void* dv, int ldd, int acc_q, int acc_k, int acc_v, void* dconvv,
+                      int lddc, int Bt, int N, int heads, int Ch, float scale, int dtype, void* stream);
+
 /* Evaluation (utils.py:72-76 argmax(softmax(logits)), :50-60,96-97 per-class Dice): pred[b,p] = argmax_k
  * logits[b,k,p] as uint8; with labels (int64 [B,HW]) also counts[3k..3k+2] += (|pred==k & gt==k|, |pred==k|, |gt==k|), fp32,
  * ACCUMULATED.  ncls <= 16. */

@@ -484,3 +484,24 @@ def test_attention_segmented(dtype):
     else:
         closeb(Gx.grad_of(qv), qr.grad, 3e-2, "dq bf16")
         closeb(Gx.grad_of(kvv), kvr.grad, 3e-2, "dkv bf16")
+
+
+@pytest.mark.parametrize("Bt,N,heads,Ch", [(3, 784, 8, 8), (2, 196, 8, 16), (2, 49, 8, 40)])
+def test_factor_att_core_fused(G, Bt, N, heads, Ch):
+    """tc_factor_att_fwd/bwd vs a plain PyTorch fp32 restatement of MSTr.py:864-877 (Appendix C.1):
+    o = scale * q (softmax_N(k)^T v) + q * convv per (image, head), q/k/v column slices of one qkv buffer."""
+    C = heads * Ch
+    scale = Ch ** -0.5
+    qkv, cv, gy = T(f"fa.qkv{N}.{Ch}", (Bt * N, 3 * C)), T(f"fa.cv{N}.{Ch}", (Bt * N, C)), T(f"fa.g{N}.{Ch}", (Bt * N, C))
+    qr, cr = qkv.clone().requires_grad_(), cv.clone().requires_grad_()
+    q, k, v = (qr[:, i * C:(i + 1) * C].reshape(Bt, N, heads, Ch).permute(0, 2, 1, 3) for i in range(3))
+    ctx = torch.softmax(k, dim=2).transpose(-1, -2) @ v
+    fa = (q @ ctx).permute(0, 2, 1, 3).reshape(Bt * N, C)
+    ref = scale * fa + qr[:, :C] * cr
+    ref.backward(gy)
+    xv, cvv = mkV(G, qkv), mkV(G, cv)
+    out = G.factor_att_core(xv.colslice(0, C), xv.colslice(C, 2 * C), xv.colslice(2 * C, 3 * C), cvv, Bt, N, heads, scale)
+    close(out.data, ref, 2e-5, 2e-5, "o")
+    run_bwd(G, out, gy)
+    close(G.grad_of(xv), qr.grad, 2e-5, 1e-4, "dqkv")
+    close(G.grad_of(cvv), cr.grad, 2e-6, 2e-5, "dconvv")

@@ -69,14 +69,17 @@ SIGNATURES = {
     "tc_sr_deinterleave": [vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp],
     "tc_stem_im2col": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "tc_seg_loss_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "tc_factor_att_stats_floats": [i32, i32, i32],
+    "tc_factor_att_fwd": [vp, vp, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, f32, i32, vp],
+    "tc_factor_att_bwd": [vp, vp, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, f32, i32, vp],
     "tc_argmax_counts": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "tc_seg_loss_bwd": [vp, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, vp, i32, vp],
     "tc_sgd_step": [vp, vp, vp, i64, f32, vp, f32, f32, f32, i32, vp],
     "tc_sgd_step_multi": [vp, vp, vp, vp, i32, i64, f32, vp, f32, f32, f32, i32, vp],
     "tc_cast": [vp, vp, i64, i32, i32, vp],
 }
-_RET = {"tc_bn_scratch_floats": i64, "tc_softmax_scratch_floats": i64, "tc_layernorm_bwd_scratch_floats": i64}
-_RAW = {"tc_abi_version", "tc_bn_scratch_floats", "tc_softmax_scratch_floats", "tc_layernorm_bwd_scratch_floats"}     # not status-returning
+_RET = {"tc_bn_scratch_floats": i64, "tc_softmax_scratch_floats": i64, "tc_layernorm_bwd_scratch_floats": i64, "tc_factor_att_stats_floats": i64}
+_RAW = {"tc_abi_version", "tc_bn_scratch_floats", "tc_softmax_scratch_floats", "tc_layernorm_bwd_scratch_floats", "tc_factor_att_stats_floats"}     # not status-returning
 
 
 class TcError(RuntimeError):

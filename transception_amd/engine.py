@@ -653,6 +653,32 @@ class Graph:
         self._rec(bwd)
         return out
 
+    def factor_att_core(self, q: Var, k: Var, v: Var, convv: Var, Bt: int, N: int, heads: int, scale: float) -> Var:
+        """o = scale * q (softmax_N(k)^T v) + q (.) convv per (image, head) in one launch (tc_factor_att_fwd); q/k/v are
+        column slices of one qkv buffer."""
+        C_ = q.cols
+        Ch = C_ // heads
+        assert q.ld == k.ld == v.ld and q.rows == Bt * N
+        out = self.new(q.rows, C_)
+        stats = self.f32(int(self.L.tc_factor_att_stats_floats(Bt, heads, Ch)))
+        self.L.tc_factor_att_fwd(_ptr(q.data), _ptr(k.data), _ptr(v.data), q.ld, _ptr(convv.data), convv.ld, _ptr(out.data), out.ld,
+                                 _ptr(stats), Bt, N, heads, Ch, scale, self.dt, self.stream)
+
+        def bwd():
+            go = self.grad_of(out)
+            if go is None:
+                return
+            gq, aq = self.wgrad(q)
+            gk, ak = self.wgrad(k)
+            gv, av = self.wgrad(v)
+            gc, ac = self.wgrad(convv)
+            assert not ac and gq.stride(0) == gk.stride(0) == gv.stride(0)
+            self.L.tc_factor_att_bwd(_ptr(q.data), _ptr(k.data), _ptr(v.data), q.ld, _ptr(convv.data), convv.ld, _ptr(go), go.stride(0),
+                                     _ptr(stats), _ptr(gq), _ptr(gk), _ptr(gv), gq.stride(0), aq, ak, av, _ptr(gc), gc.stride(0), Bt, N,
+                                     heads, Ch, scale, self.dt, self.stream)
+        self._rec(bwd)
+        return out
+
     def fma3(self, a: Var, b: Var, c: Var, alpha: float, out: Optional[Var] = None) -> Var:
         """out = alpha*a + b*c"""
         rows, Cc = a.rows, a.cols

@@ -16,6 +16,7 @@ buffer (no pack/unpack copies), weights and gradients in flat fp32 arenas.
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -490,6 +491,9 @@ def _resblock(M, G, x: Var, name: str, B: int, side: int, out: Var) -> Var:
     return _bn(M, G, f, name + ".conv2.bn", ACT_NONE, residual=x, out=out)
 
 
+FUSED_FACTOR_ATT = os.environ.get("TC_FACTOR_ATT_FUSED", "1") != "0"
+
+
 def _factor_att(M, G, n: Var, blk: str, enc: str, B: int, side: int, residual: Optional[Var] = None) -> Var:
     """FactorAtt_ConvRelPosEnc + ConvRelPosEnc, MSTr.py:852-886, 801-823 (Appendix C.1-2), + residual add."""
     C, N = n.cols, side * side
@@ -497,11 +501,6 @@ def _factor_att(M, G, n: Var, blk: str, enc: str, B: int, side: int, residual: O
     rows, h, Ch = Bt * N, HEADS, n.cols // HEADS
     qkv = G.linear(n, *_lin(M, G, blk + ".factoratt_crpe.qkv"))
     q, k, v = qkv.colslice(0, C), qkv.colslice(C, 2 * C), qkv.colslice(2 * C, 3 * C)
-    ksm = G.softmax(k, Bt, 0)
-    ctx = G.new(Bt * h * Ch, Ch)
-    G.bmm(ksm, v, ctx, Ch, Ch, N, 1, 0, nb1=Bt, nb2=h, sA=(N * C, Ch), sB=(N * 3 * C, Ch), sC=(h * Ch * Ch, Ch * Ch))
-    fa = G.new(rows, C)
-    G.bmm(q, ctx, fa, N, Ch, Ch, 0, 0, nb1=Bt, nb2=h, sA=(N * 3 * C, Ch), sB=(h * Ch * Ch, Ch * Ch), sC=(N * C, Ch))
     convv = G.new(rows, C)
     c0 = 0
     for i, (ksz, nh) in enumerate(CRPE_WINDOW):
@@ -509,7 +508,15 @@ def _factor_att(M, G, n: Var, blk: str, enc: str, B: int, side: int, residual: O
         G.dwconv(v.colslice(c0, c0 + w), M._P(G, f"{enc}.crpe.conv_list.{i}.weight"), M._P(G, f"{enc}.crpe.conv_list.{i}.bias"),
                  B, side, side, ksz, 1, False, out=convv.colslice(c0, c0 + w))
         c0 += w
-    o = G.fma3(fa, q, convv, Ch ** -0.5)
+    if FUSED_FACTOR_ATT and 16 * N * Ch + 8 * Ch * Ch + 1024 <= 150 * 1024:     # a head's q, k, v, do tiles fit LDS in fp32
+        o = G.factor_att_core(q, k, v, convv, Bt, N, h, Ch ** -0.5)
+    else:                                           # unfused composition: larger inputs (384^2: 2304 tokens at stage 2), A/B tests
+        ksm = G.softmax(k, Bt, 0)
+        ctx = G.new(Bt * h * Ch, Ch)
+        G.bmm(ksm, v, ctx, Ch, Ch, N, 1, 0, nb1=Bt, nb2=h, sA=(N * C, Ch), sB=(N * 3 * C, Ch), sC=(h * Ch * Ch, Ch * Ch))
+        fa = G.new(rows, C)
+        G.bmm(q, ctx, fa, N, Ch, Ch, 0, 0, nb1=Bt, nb2=h, sA=(N * 3 * C, Ch), sB=(h * Ch * Ch, Ch * Ch), sC=(N * C, Ch))
+        o = G.fma3(fa, q, convv, Ch ** -0.5)
     return G.linear(o, *_lin(M, G, blk + ".factoratt_crpe.proj"), residual=residual)
 
 
