@@ -22,6 +22,7 @@ struct GemmDev {
     long long sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2;
     float alpha; int accumulate, act;
     int vecA, vecB, vecC, atomic;
+    int vec8C;              // bf16 C rows are 16-byte addressable (LDS-staged, fully coalesced epilogue)
     float* rowsum;          // optional: rowsum[m] += sum_k op(A)[m][k]  (fp32, atomics)
     long long sBias1, sRow1; // batch-level-1 strides of bias / rowsum (grouped weights)
     float* ws_part; int* ws_cnt; int fix_group, fix_ngroups;   // split-K fix-up workspace (fix_group > 0: enabled)
@@ -175,6 +176,58 @@ __device__ __forceinline__ void epilogue_cols(const GemmDev& p, f32x16 (&acc)[TM
                 }
             }
         }
+}
+
+// bf16 C, plain store (no accumulate): values are finished in registers (alpha, bias, residual, activation) exactly as
+// epilogue_rows does, rounded to bf16 once, parked in LDS as the row-major tile and written with 16-byte stores -- 16 consecutive
+// lanes cover one 256-byte row of a 128-wide tile.  (epilogue_rows' direct 8-byte stores touch 32 different lines per
+// instruction; most GEMMs of this model have K <= 512, so the epilogue is a large part of their time.)
+template <int BM, int BN, int TM, int TN>
+__device__ __forceinline__ void epilogue_rows_lds(const GemmDev& p, f32x16 (&acc)[TM][TN], int b1, int b2, int m0, int n0, int wr, int wc,
+                                                  int lane, bf16_t* stage) {
+    constexpr int LDS_ = BN + 8, WM = BM / 2, WN = BN / 2;
+    const bf16_t* R = p.R ? reinterpret_cast<const bf16_t*>(p.R) + b1 * p.sR1 + b2 * p.sR2 : nullptr;
+    const bf16_t* bias = p.bias ? reinterpret_cast<const bf16_t*>(p.bias) + b1 * p.sBias1 : nullptr;
+    const int h = lane >> 5;
+    __syncthreads();                                         // every wave is done with the operand tiles this overwrites
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int lr = wr * WM + i * 32 + (lane & 31), row = m0 + lr;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int lc = wc * WN + j * 32 + 8 * g + 4 * h, col = n0 + lc;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = p.alpha * acc[i][j][4 * g + e];
+                if (row < p.M && col < p.N) {                // N % 8 == 0 on this path: the 4-group is all in or all out
+                    if (bias) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += bf2f(bias[col + e]);
+                    }
+                    if (R) {
+                        const float4 r4 = ld4<bf16_t>(R + (long long)row * p.ldr + col);
+                        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+                    }
+                    if (p.act == TC_ACT_SIGMOID) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = sigmoid_f(v[e]);
+                    }
+                }
+                st4<bf16_t>(stage + lr * LDS_ + lc, make_float4(v[0], v[1], v[2], v[3]));
+            }
+    }
+    __syncthreads();
+    bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + b1 * p.sC1 + b2 * p.sC2;
+    constexpr int CPR = BN / 8;                              // 16-byte chunks per tile row
+#pragma unroll
+    for (int it = 0; it < BM * CPR / 256; ++it) {
+        const int idx = threadIdx.x + it * 256, lr = idx / CPR, lc = (idx - lr * CPR) * 8;
+        const int row = m0 + lr, col = n0 + lc;
+        if (row < p.M && col < p.N)
+            *reinterpret_cast<uint4*>(C + (long long)row * p.ldc + col) = *reinterpret_cast<const uint4*>(stage + lr * LDS_ + lc);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- fp32 path
@@ -479,15 +532,25 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmDev& p, const int bx, c
         if (!splitk_fixup<TM, TN>(p, acc, ((bz / p.splitk) * gy + by) * gx + bx, ks, grp)) return;
         first = (grp == 0); atomic = p.fix_ngroups > 1;
     }
-    if (SWAP) epilogue_rows<bf16_t, TC, TM, TN>(p, acc, b1, b2, first, atomic, m0 + wr * WM, n0 + wc * WN, lane);
-    else epilogue_cols<bf16_t, TC, TM, TN>(p, acc, b1, b2, first, atomic, m0 + wr * WM, n0 + wc * WN, lane);
+    if constexpr (SWAP) {
+        if (p.vec8C && !p.accumulate && !atomic && first) {
+            static_assert((BM * (BN + 8)) <= (DB ? 2 : 1) * (BM + BN) * (64 + 8), "staging tile must fit the operand buffers");
+            epilogue_rows_lds<BM, BN, TM, TN>(p, acc, b1, b2, m0, n0, wr, wc, lane, &As[0][0]);
+        } else {
+            epilogue_rows<bf16_t, TC, TM, TN>(p, acc, b1, b2, first, atomic, m0 + wr * WM, n0 + wc * WN, lane);
+        }
+    } else {
+        epilogue_cols<bf16_t, TC, TM, TN>(p, acc, b1, b2, first, atomic, m0 + wr * WM, n0 + wc * WN, lane);
+    }
 }
 
 template <typename TC, int BM, int BN, bool TA, bool TB, bool DB>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmDev p) {
-    __shared__ __attribute__((aligned(16))) bf16_t As[DB ? 2 : 1][BM * (64 + 8)];
-    __shared__ __attribute__((aligned(16))) bf16_t Bs[DB ? 2 : 1][BN * (64 + 8)];
-    gemm_bf16_body<TC, BM, BN, TA, TB, DB>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y, As, Bs);
+    // ONE buffer: A slabs first, B slabs behind them -- the epilogue reuses it from the start as its C staging tile
+    __shared__ __attribute__((aligned(16))) bf16_t smem[(DB ? 2 : 1) * (BM + BN) * (64 + 8)];
+    gemm_bf16_body<TC, BM, BN, TA, TB, DB>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y,
+                                           reinterpret_cast<bf16_t(*)[BM * (64 + 8)]>(smem),
+                                           reinterpret_cast<bf16_t(*)[BN * (64 + 8)]>(smem + (DB ? 2 : 1) * BM * (64 + 8)));
 }
 
 // One launch for the two gradient GEMMs of a Linear: problem A = dX = dY W (row-major operands, bf16 out), problem B = dW = dY^T X
@@ -496,8 +559,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmDev p) {
 // different HW queues overlap only at their tails) and pay two dependency gaps.
 struct GemmPairDev { GemmDev a, b; int nA, gxA, gyA, gxB, gyB; };
 __global__ __launch_bounds__(256, 2) void gemm_pair_kernel(GemmPairDev q) {
-    __shared__ __attribute__((aligned(16))) bf16_t As[2][64 * (64 + 8)];
-    __shared__ __attribute__((aligned(16))) bf16_t Bs[2][64 * (64 + 8)];
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (64 + 64) * (64 + 8)];
+    bf16_t(*As)[64 * (64 + 8)] = reinterpret_cast<bf16_t(*)[64 * (64 + 8)]>(smem);
+    bf16_t(*Bs)[64 * (64 + 8)] = reinterpret_cast<bf16_t(*)[64 * (64 + 8)]>(smem + 2 * 64 * (64 + 8));
     int lin = blockIdx.x;
     if (lin < q.nA) {
         const int bx = lin % q.gxA; lin /= q.gxA;
@@ -548,6 +612,8 @@ bool gemm_plan(const TcGemm* g, GemmDev& d, dim3& grid, bool& use128_out) {
         const bool cok = ((uintptr_t)g->C % (4 * csz) == 0) && (g->ldc % 4 == 0) && (g->sC1 % 4 == 0) && (g->sC2 % 4 == 0);
         const bool rok = !g->R || (((uintptr_t)g->R % (4 * sizeof(T)) == 0) && (g->ldr % 4 == 0) && (g->sR1 % 4 == 0) && (g->sR2 % 4 == 0));
         d.vecC = cok && rok;
+        d.vec8C = !g->c_f32 && sizeof(T) == 2 && cok && rok && ((uintptr_t)g->C % 16 == 0) && (g->ldc % 8 == 0) && (g->sC1 % 8 == 0) &&
+                  (g->sC2 % 8 == 0) && (g->N % 8 == 0);
     }
     const int nb = g->nb1 * g->nb2;
     const long long big = (long long)((g->M + 127) / 128) * ((g->N + 127) / 128) * nb;
