@@ -67,25 +67,34 @@ __device__ __forceinline__ void fa_softmax_cols(float* e, float* cmax, float* ci
     __syncthreads();
 }
 
-// out[i][j] = sum_n a[n,i] * b[n,j]   (Ch x Ch, accumulated with LDS float atomics from 256 / (Ch*Ch) row lanes when that is > 1)
+// out[i][j] = sum_n a[n,i] * b[n,j]   (Ch x Ch, Ch a multiple of 8).  A thread owns (row i, 8 consecutive j) for the rows
+// n = rl, rl + RL, ...: one read of a[n,i], two 16-byte reads of b[n, j0..j0+7], 8 FMAs; the RL row lanes of an output sit next to
+// each other in a wave and are folded with shuffles.  (One thread per output walking all N rows took ~10 us per product.)
 __device__ __forceinline__ void fa_gram(float* out, const float* a, const float* b, int N, int Ch) {
-    const int P = Ch * Ch, tid = threadIdx.x;
-    for (int i = tid; i < P; i += 256) out[i] = 0.f;
-    __syncthreads();
-    if (P >= 256) {
-        for (int o = tid; o < P; o += 256) {
-            const int i = o / Ch, j = o - i * Ch;
-            float s = 0.f;
-            for (int n = 0; n < N; ++n) s += a[n * Ch + i] * b[n * Ch + j];
-            out[o] = s;
+    const int tid = threadIdx.x, jb = Ch >> 3, combos = Ch * jb;
+    int RL = 256 / combos;                                  // 32 (Ch 8), 8 (Ch 16), 1 (Ch 40)
+    RL = RL >= 32 ? 32 : (RL >= 16 ? 16 : (RL >= 8 ? 8 : (RL >= 4 ? 4 : (RL >= 2 ? 2 : 1))));
+    const int combo = tid / RL, rl = tid - combo * RL;
+    float acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+    for (int cb = combo; cb < combos; cb += 256 / RL) {     // Ch = 40: 200 combos, one pass; generic for larger Ch
+        const int i = cb / jb, j0 = (cb - i * jb) * 8;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+        for (int n = rl; n < N; n += RL) {
+            const float ai = a[n * Ch + i];
+            const float4 b0 = *reinterpret_cast<const float4*>(b + n * Ch + j0), b1 = *reinterpret_cast<const float4*>(b + n * Ch + j0 + 4);
+            acc[0] += ai * b0.x; acc[1] += ai * b0.y; acc[2] += ai * b0.z; acc[3] += ai * b0.w;
+            acc[4] += ai * b1.x; acc[5] += ai * b1.y; acc[6] += ai * b1.z; acc[7] += ai * b1.w;
         }
-    } else {
-        const int L = 256 / P, o = tid % P, l = tid / P;
-        if (l < L) {
-            const int i = o / Ch, j = o - i * Ch;
-            float s = 0.f;
-            for (int n = l; n < N; n += L) s += a[n * Ch + i] * b[n * Ch + j];
-            atomicAdd(&out[o], s);
+        for (int o = RL >> 1; o > 0; o >>= 1) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] += __shfl_xor(acc[u], o, 64);
+        }
+        if (rl == 0) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) out[i * Ch + j0 + u] = acc[u];
         }
     }
     __syncthreads();
@@ -217,7 +226,7 @@ extern "C" int tc_factor_att_fwd(const void* q, const void* k, const void* v, in
                                  float* stats, int Bt, int N, int heads, int Ch, float scale, int dtype, void* stream) {
     if (!q || !k || !v || !convv || !o || !stats || Bt <= 0 || N <= 0 || heads <= 0 || Ch <= 0 || Ch > FA_MAXCH) return TC_ERR_ARG;
     const int vec = dtype == TC_F32 ? 4 : 8;
-    if (Ch % vec || ld % vec || ldc % vec || ldo % vec || (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)convv | (uintptr_t)o) & 15)) return TC_ERR_ARG;
+    if (Ch % 8 || ld % vec || ldc % vec || ldo % vec || (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)convv | (uintptr_t)o) & 15)) return TC_ERR_ARG;
     const size_t smem = sizeof(float) * ((size_t)3 * N * Ch + (size_t)Ch * Ch + 2 * Ch + 256);
     if (smem > 150 * 1024) return TC_ERR_ARG;
     TC_DISPATCH_DTYPE(dtype, {
@@ -235,7 +244,7 @@ extern "C" int tc_factor_att_bwd(const void* q, const void* k, const void* v, in
         Ch > FA_MAXCH)
         return TC_ERR_ARG;
     const int vec = dtype == TC_F32 ? 4 : 8;
-    if (Ch % vec || ld % vec || ldc % vec || ldgo % vec || ldd % vec || lddc % vec ||
+    if (Ch % 8 || ld % vec || ldc % vec || ldgo % vec || ldd % vec || lddc % vec ||
         (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)convv | (uintptr_t)go | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv | (uintptr_t)dconvv) & 15))
         return TC_ERR_ARG;
     const size_t smem = sizeof(float) * ((size_t)4 * N * Ch + (size_t)2 * Ch * Ch + Ch);

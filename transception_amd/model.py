@@ -508,7 +508,7 @@ def _factor_att(M, G, n: Var, blk: str, enc: str, B: int, side: int, residual: O
         G.dwconv(v.colslice(c0, c0 + w), M._P(G, f"{enc}.crpe.conv_list.{i}.weight"), M._P(G, f"{enc}.crpe.conv_list.{i}.bias"),
                  B, side, side, ksz, 1, False, out=convv.colslice(c0, c0 + w))
         c0 += w
-    if FUSED_FACTOR_ATT and 16 * N * Ch + 8 * Ch * Ch + 1024 <= 150 * 1024:     # a head's q, k, v, do tiles fit LDS in fp32
+    if FUSED_FACTOR_ATT and Ch % 8 == 0 and 16 * N * Ch + 8 * Ch * Ch + 1024 <= 150 * 1024:     # a head's q, k, v, do tiles fit LDS in fp32
         o = G.factor_att_core(q, k, v, convv, Bt, N, h, Ch ** -0.5)
     else:                                           # unfused composition: larger inputs (384^2: 2304 tokens at stage 2), A/B tests
         ksm = G.softmax(k, Bt, 0)
