@@ -52,10 +52,26 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// Exact-erf GELU (nn.GELU() default, MSTr.py:894) and its derivative.  erf through Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7,
+// below fp32 resolution of the products it enters): with z = x / sqrt(2),  erf(|z|) = 1 - (a1 t + .. + a5 t^5) exp(-z^2),
+// t = 1 / (1 + p |z|).  exp(-z^2) = exp(-x^2/2) is the Gaussian the derivative needs anyway, so value and gradient cost one
+// exp + one reciprocal + a dozen FMAs -- libm's erff alone was ~25 instructions and made the GELU LayerNorm kernels VALU-bound.
+__device__ __forceinline__ float gelu_cdf_pdf(float x, float& pdf) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float g = __expf(-z * z);                               // exp(-x^2 / 2)
+    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float half_erfc = 0.5f * poly * t * g;                  // 0.5 * erfc(|z|)
+    pdf = 0.39894228040143267794f * g;
+    return x >= 0.f ? 1.0f - half_erfc : half_erfc;               // Phi(x)
+}
+__device__ __forceinline__ float gelu_f(float x) { float pdf; return x * gelu_cdf_pdf(x, pdf); }
 __device__ __forceinline__ float gelu_grad_f(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    float pdf;
+    const float cdf = gelu_cdf_pdf(x, pdf);
     return cdf + x * pdf;
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
