@@ -433,7 +433,9 @@ extern "C" int tc_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx
     int nblk = 0;
     float* partial = nullptr;
 #define TC_LNB(GS, NV) {                                                                                                                  \
-        nblk = tc_blocks(rows, (256 / GS) * (dgamma ? LN_BWD_ROWS_PER_GROUP : 1), dgamma ? LN_BWD_MAX_BLOCKS : 8192);                       \
+        int rpg = dgamma ? rows / ((256 / GS) * 512) : 1;            /* rows per lane group: >= 512 workgroups before rows are stacked */ \
+        rpg = rpg < 1 ? 1 : (rpg > LN_BWD_ROWS_PER_GROUP ? LN_BWD_ROWS_PER_GROUP : rpg);                                                    \
+        nblk = tc_blocks(rows, (256 / GS) * rpg, dgamma ? LN_BWD_MAX_BLOCKS : 8192);                                                        \
         partial = (dgamma && scratch && (uintptr_t)scratch % 16 == 0 && scratch_floats >= 4096 + (long long)groups * nblk * 2 * C &&      \
                    (long long)groups * ((nblk + 15) / 16) <= 4096) ? scratch + 4096 : nullptr;                                            \
         hipLaunchKernelGGL((ln_bwd_kernel<T, GS, NV>), dim3(nblk, groups), dim3(256),                                                       \
