@@ -505,3 +505,77 @@ def test_factor_att_core_fused(G, Bt, N, heads, Ch):
     run_bwd(G, out, gy)
     close(G.grad_of(xv), qr.grad, 2e-5, 1e-4, "dqkv")
     close(G.grad_of(cvv), cr.grad, 2e-6, 2e-5, "dconvv")
+
+
+@pytest.mark.parametrize("Ch,side", [(8, 28), (16, 14), (40, 7)])
+def test_dwconv_multi_matches_torch(G, Ch, side):
+    """tc_dwconv_multi: the three ConvRelPosEnc window sizes (3/5/7 on 2/3/3 heads' channels, MSTr.py:785-816) on column slices
+    of one buffer in one launch each for forward, input gradient and weight gradient, vs F.conv2d."""
+    B, C = 2, 8 * Ch
+    widths, ks = [2 * Ch, 3 * Ch, 3 * Ch], [3, 5, 7]
+    x, gy = T(f"dwm.x{Ch}", (B * side * side, 3 * C)), T(f"dwm.g{Ch}", (B * side * side, C))
+    wts = [T(f"dwm.w{Ch}.{i}", (w, 1, k, k), 0.3) for i, (w, k) in enumerate(zip(widths, ks))]
+    bss = [T(f"dwm.b{Ch}.{i}", (w,), 0.3) for i, w in enumerate(widths)]
+    xr = x.clone().requires_grad_()
+    wr, br = [w.clone().requires_grad_() for w in wts], [b.clone().requires_grad_() for b in bss]
+    v = xr[:, 2 * C:].reshape(B, side, side, C).permute(0, 3, 1, 2)
+    outs, c0 = [], 0
+    for w_, b_, wd, k in zip(wr, br, widths, ks):
+        outs.append(F.conv2d(v[:, c0:c0 + wd], w_, b_, padding=k // 2, groups=wd)); c0 += wd
+    ref = torch.cat(outs, 1).permute(0, 2, 3, 1).reshape(B * side * side, C)
+    ref.backward(gy)
+    xv = mkV(G, x)
+    out = G.new(B * side * side, C)
+    Ws, Bs = [mkP(w.reshape(w.shape[0], -1)) for w in wts], [mkP(b) for b in bss]
+    xs, os_, c0 = [], [], 0
+    for wd in widths:
+        xs.append(xv.colslice(2 * C + c0, 2 * C + c0 + wd)); os_.append(out.colslice(c0, c0 + wd)); c0 += wd
+    G.dwconv_multi(xs, Ws, Bs, B, side, side, ks, os_)
+    close(out.data, ref, 2e-5, 2e-5, "y")
+    run_bwd(G, out, gy)
+    close(G.grad_of(xv), xr.grad, 2e-5, 5e-5, "dx")
+    for i in range(3):
+        close(Ws[i].grad.view_as(wts[i]), wr[i].grad, 5e-5, 1e-4, f"dw{i}")
+        close(Bs[i].grad, br[i].grad, 5e-5, 1e-4, f"db{i}")
+
+
+def test_dwconv_multi_grouped(G):
+    """Same, with three stacked weight groups (the three MB paths of a stage run as one grouped launch)."""
+    from transception_amd.engine import P
+    Ch, side, B, Gn = 8, 14, 2, 3
+    C = 8 * Ch
+    widths, ks = [2 * Ch, 3 * Ch, 3 * Ch], [3, 5, 7]
+    rows = B * side * side
+    x, gy = T("dwmg.x", (Gn * rows, 3 * C)), T("dwmg.g", (Gn * rows, C))
+    per = sum(w * k * k + w for w, k in zip(widths, ks))
+    arena = T("dwmg.p", (Gn * per,), 0.3).to(DEV)
+    garena = torch.zeros_like(arena)
+    offs, o = [], 0
+    for w, k in zip(widths, ks):
+        offs.append((o, o + w * k * k)); o += w * k * k + w
+    xr = x.clone().requires_grad_()
+    ar = arena.cpu().clone().requires_grad_()
+    refs = []
+    for g in range(Gn):
+        v = xr[g * rows:(g + 1) * rows, 2 * C:].reshape(B, side, side, C).permute(0, 3, 1, 2)
+        outs, c0 = [], 0
+        for (ow, ob), wd, k in zip(offs, widths, ks):
+            w_ = ar[g * per + ow:g * per + ow + wd * k * k].view(wd, 1, k, k)
+            b_ = ar[g * per + ob:g * per + ob + wd]
+            outs.append(F.conv2d(v[:, c0:c0 + wd], w_, b_, padding=k // 2, groups=wd)); c0 += wd
+        refs.append(torch.cat(outs, 1).permute(0, 2, 3, 1).reshape(rows, C))
+    ref = torch.cat(refs, 0)
+    ref.backward(gy)
+    xv = mkV(G, x)
+    out = G.new(Gn * rows, C)
+    Ws = [P(arena[ow:ow + wd * k * k].view(wd, k * k), garena[ow:ow + wd * k * k].view(wd, k * k), per) for (ow, _), wd, k in zip(offs, widths, ks)]
+    Bs = [P(arena[ob:ob + wd], garena[ob:ob + wd], per) for (_, ob), wd in zip(offs, widths)]
+    xs, os_, c0 = [], [], 0
+    for wd in widths:
+        xs.append(xv.colslice(2 * C + c0, 2 * C + c0 + wd)); os_.append(out.colslice(c0, c0 + wd)); c0 += wd
+    with G.grouped(Gn, per):
+        G.dwconv_multi(xs, Ws, Bs, B, side, side, ks, os_)
+    close(out.data, ref, 2e-5, 2e-5, "y")
+    run_bwd(G, out, gy)
+    close(G.grad_of(xv), xr.grad, 2e-5, 5e-5, "dx")
+    close(garena, ar.grad, 5e-5, 1e-4, "dw/db of all groups")

@@ -360,27 +360,37 @@ __device__ __forceinline__ void dw_put(uint4* tile, const uint4 (&reg)[NREG], in
     }
 }
 
+// LDS needs of the tile bodies, in uint4 (the multi-segment launches size one dynamic buffer for the largest body they contain)
+template <typename T, int K, int CG> constexpr int dw_tile_smem_q() {
+    return DwTile<K, CG>::IH * DwTile<K, CG>::IW * (CG + (CG == 8 ? 2 : 1)) + (K * K * CG * Vec16<T>::N + 3) / 4;
+}
+template <typename T, int K, int CG> constexpr int dw_wgrad_smem_q() {
+    return DwTile<K, CG>::IH * DwTile<K, CG>::IW * (CG + 1) + DwTile<K, CG>::TH * DwTile<K, CG>::TW * (CG + 1) +
+           ((K * K + 1) * CG * Vec16<T>::N + 3) / 4;
+}
+
+// body of one workgroup (bx = tile, by = channel chunk, bz = weight group); `smem` holds dw_tile_smem_q() uint4
 template <typename T, int K, int CG, int MODE>      // MODE 0: y = conv(x) (+bias) (+x);  MODE 1: dx = conv^T(dy) (+dy) (+dx)
-__global__ __launch_bounds__(256) void dw_tile_kernel(const T* __restrict__ src, int lds_, const T* __restrict__ w,
-                                                      const T* __restrict__ bias, T* __restrict__ y, int ldy, int B, int H, int W,
-                                                      int C, int add_input, int accumulate, long long wstride, int tilesW,
-                                                      int tilesH) {
+__device__ __forceinline__ void dw_tile_body(const T* __restrict__ src, int lds_, const T* __restrict__ w,
+                                             const T* __restrict__ bias, T* __restrict__ y, int ldy, int B, int H, int W,
+                                             int C, int add_input, int accumulate, long long wstride, int tilesW,
+                                             int tilesH, const int bx, const int by, const int bz, uint4* smem) {
     using D = DwTile<K, CG>;
     constexpr int VEC = Vec16<T>::N, CH = CG * VEC, R = D::R, P = D::P;
     constexpr int PIXQ = CG + (CG == 8 ? 2 : 1);
-    __shared__ uint4 tile[D::IH * D::IW * PIXQ];
-    __shared__ __attribute__((aligned(16))) float wsm[K * K][CH];
+    uint4* tile = smem;
+    float (*wsm)[CH] = reinterpret_cast<float (*)[CH]>(smem + D::IH * D::IW * PIXQ);
     {
-        const long long g = blockIdx.z, img = (long long)B * H * W;
+        const long long g = bz, img = (long long)B * H * W;
         src += g * img * lds_; y += g * img * ldy; w += g * wstride;
         if (bias) bias += g * wstride;
     }
-    const int c0 = blockIdx.y * CH;
+    const int c0 = by * CH;
     for (int i = threadIdx.x; i < K * K * CH; i += 256) {
         const int cc = i / (K * K), t = i - cc * (K * K);
         wsm[MODE == 1 ? K * K - 1 - t : t][cc] = (c0 + cc < C) ? ldf<T>(w + (long long)(c0 + cc) * K * K + t) : 0.f;
     }
-    const int tix = blockIdx.x % tilesW, tiy = (blockIdx.x / tilesW) % tilesH, b = blockIdx.x / (tilesW * tilesH);
+    const int tix = bx % tilesW, tiy = (bx / tilesW) % tilesH, b = bx / (tilesW * tilesH);
     const int oh0 = tiy * D::TH, ow0 = tix * D::TW;
     dw_stage<T, CG, PIXQ>(tile, src + (long long)b * H * W * lds_ + c0, lds_, oh0 - P, ow0 - P, D::IH, D::IW, H, W, C - c0);
     __syncthreads();
@@ -436,26 +446,38 @@ __global__ __launch_bounds__(256) void dw_tile_kernel(const T* __restrict__ src,
     }
 }
 
+template <typename T, int K, int CG, int MODE>
+__global__ __launch_bounds__(256) void dw_tile_kernel(const T* __restrict__ src, int lds_, const T* __restrict__ w,
+                                                      const T* __restrict__ bias, T* __restrict__ y, int ldy, int B, int H, int W,
+                                                      int C, int add_input, int accumulate, long long wstride, int tilesW,
+                                                      int tilesH) {
+    __shared__ uint4 smem[dw_tile_smem_q<T, K, CG>()];
+    dw_tile_body<T, K, CG, MODE>(src, lds_, w, bias, y, ldy, B, H, W, C, add_input, accumulate, wstride, tilesW, tilesH, blockIdx.x,
+                                 blockIdx.y, blockIdx.z, smem);
+}
+
 // dw[c,ky,kx] += sum_pix dy[pix] * x[pix + (ky-P, kx-P)] ; db[c] += sum_pix dy[pix].  x tile (+halo) and dy tile in LDS; a thread
 // owns (16-byte channel lane, filter row ky) and a share of the tile's (row, 4-pixel run) units, K x VEC sums in registers
 // across all the tiles its workgroup visits; LDS float atomics fold the workgroup, then one global atomic per tap and channel.
+// body of one workgroup: bx of gx workgroups walk the tiles of channel chunk by (of gy) for weight group bz
 template <typename T, int K, int CG>
-__global__ __launch_bounds__(256) void dw_tile_wgrad_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy,
-                                                            float* __restrict__ dw, float* __restrict__ db, int B, int H, int W, int C,
-                                                            long long wstride, int tilesW, int tilesH, float* __restrict__ ws_part,
-                                                            int* __restrict__ ws_cnt) {
+__device__ __forceinline__ void dw_tile_wgrad_body(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy,
+                                                   float* __restrict__ dw, float* __restrict__ db, int B, int H, int W, int C,
+                                                   long long wstride, int tilesW, int tilesH, float* __restrict__ ws_part,
+                                                   int* __restrict__ ws_cnt, const int bx, const int by, const int bz, const int gx,
+                                                   const int gy, uint4* smem) {
     using D = DwTile<K, CG>;
     constexpr int VEC = Vec16<T>::N, CH = CG * VEC, R = D::R, P = D::P, PIXQ = CG + 1, NT = K * K + 1;
     constexpr int RG = D::PT / K, UNITS = D::TH * (D::TW / R);
-    __shared__ uint4 xt[D::IH * D::IW * PIXQ];
-    __shared__ uint4 dt[D::TH * D::TW * PIXQ];
-    __shared__ float lacc[NT][CH];
+    uint4* xt = smem;
+    uint4* dt = xt + D::IH * D::IW * PIXQ;
+    float (*lacc)[CH] = reinterpret_cast<float (*)[CH]>(dt + D::TH * D::TW * PIXQ);
     {
-        const long long g = blockIdx.z, img = (long long)B * H * W;
+        const long long g = bz, img = (long long)B * H * W;
         x += g * img * ldx; dy += g * img * lddy; dw += g * wstride;
         if (db) db += g * wstride;
     }
-    const int c0 = blockIdx.y * CH;
+    const int c0 = by * CH;
     for (int i = threadIdx.x; i < NT * CH; i += 256) (&lacc[0][0])[i] = 0.f;
     const int cg = threadIdx.x % CG, wk = threadIdx.x / CG, ky = wk / RG, rg = wk % RG;
     const bool active = ky < K && c0 + cg * VEC < C;
@@ -482,8 +504,8 @@ __global__ __launch_bounds__(256) void dw_tile_wgrad_kernel(const T* __restrict_
         dw_fetch<T, CG, NX>(xr, x + (long long)b * H * W * ldx + c0, ldx, oh0 - P, ow0 - P, D::IH, D::IW, H, W, C - c0);
         dw_fetch<T, CG, ND>(dr, dy + (long long)b * H * W * lddy + c0, lddy, oh0, ow0, D::TH, D::TW, H, W, C - c0);
     };
-    if (PF && (int)blockIdx.x < ntiles) fetch(blockIdx.x);
-    for (int tidx = blockIdx.x; tidx < ntiles; tidx += gridDim.x) {
+    if (PF && bx < ntiles) fetch(bx);
+    for (int tidx = bx; tidx < ntiles; tidx += gx) {
         __syncthreads();
         if (PF) {
             dw_put<CG, PIXQ, NX>(xt, xr, D::IH, D::IW);
@@ -495,7 +517,7 @@ __global__ __launch_bounds__(256) void dw_tile_wgrad_kernel(const T* __restrict_
             dw_stage<T, CG, PIXQ>(dt, dy + (long long)b * H * W * lddy + c0, lddy, oh0, ow0, D::TH, D::TW, H, W, C - c0);
         }
         __syncthreads();
-        if (PF && tidx + (int)gridDim.x < ntiles) fetch(tidx + gridDim.x);
+        if (PF && tidx + gx < ntiles) fetch(tidx + gx);
         if (active) {
             for (int u = rg; u < UNITS; u += RG) {
                 const int row = u / (D::TW / R), run = u % (D::TW / R);
@@ -539,13 +561,14 @@ __global__ __launch_bounds__(256) void dw_tile_wgrad_kernel(const T* __restrict_
         // the workspace, 16 consecutive ones share an arrival counter, the last to arrive adds the 16 and is the only one that
         // touches dw / db atomically -- a contended fp32 atomic costs ~0.13 us and 128-170 workgroups used to queue on every word.
         constexpr int FG = 16;
-        const int chain = (blockIdx.z * gridDim.y + blockIdx.y), grp = blockIdx.x / FG, ngrp = (gridDim.x + FG - 1) / FG;
-        gm = min(FG, (int)gridDim.x - grp * FG);
-        float* part = ws_part + ((long long)chain * gridDim.x + blockIdx.x) * (NT * CH);
-        pgroup = ws_part + ((long long)chain * gridDim.x + grp * FG) * (NT * CH);
+        const int chain = bz * gy + by, grp = bx / FG, ngrp = (gx + FG - 1) / FG;
+        gm = min(FG, gx - grp * FG);
+        float* part = ws_part + ((long long)chain * gx + bx) * (NT * CH);
+        pgroup = ws_part + ((long long)chain * gx + grp * FG) * (NT * CH);
         if (gm > 1) {
             for (int f = threadIdx.x; f < NT * CH; f += 256) __hip_atomic_store(part + f, lflat[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0);                          // vmcnt(0): THIS thread's write-through stores have been acknowledged
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (the barrier alone does not wait for stores in flight)
             __syncthreads();
             __shared__ int s_last;
             if (threadIdx.x == 0) {
@@ -576,6 +599,16 @@ __global__ __launch_bounds__(256) void dw_tile_wgrad_kernel(const T* __restrict_
         if (t < K * K) atomicAdd(dw + (long long)ch * K * K + t, v);
         else if (db) atomicAdd(db + ch, v);
     }
+}
+
+template <typename T, int K, int CG>
+__global__ __launch_bounds__(256) void dw_tile_wgrad_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy,
+                                                            float* __restrict__ dw, float* __restrict__ db, int B, int H, int W, int C,
+                                                            long long wstride, int tilesW, int tilesH, float* __restrict__ ws_part,
+                                                            int* __restrict__ ws_cnt) {
+    __shared__ uint4 smem[dw_wgrad_smem_q<T, K, CG>()];
+    dw_tile_wgrad_body<T, K, CG>(x, ldx, dy, lddy, dw, db, B, H, W, C, wstride, tilesW, tilesH, ws_part, ws_cnt, blockIdx.x, blockIdx.y,
+                                 blockIdx.z, gridDim.x, gridDim.y, smem);
 }
 
 // 16-byte lanes per pixel that waste the fewest channels (ties: the widest)
@@ -640,6 +673,117 @@ int launch_dw(const void* x, int ldx, const void* w, const void* bias, void* y, 
                                      (T*)y, ldy, B, H, W, Ho, Wo, C, stride, add_input, accumulate)
     if (k == 3) TC_DW(3); else if (k == 5) TC_DW(5); else TC_DW(7);
 #undef TC_DW
+    return tc_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Multi-segment launches: up to three stride-1 depthwise convolutions with different k / channel counts on column slices of the
+// same maps (ConvRelPosEnc: 3x3 / 5x5 / 7x7 on 2 / 3 / 3 heads' channels, MSTr.py:785-816) in ONE grid.  Each is a 10-30 us
+// latency-bound launch on its own; side by side they cost what the slowest costs.
+struct DwSegDev {
+    const void* src; const void* w; const void* bias; void* y; const void* dy; float* dw; float* db; float* wsp; int* wsc;
+    int C, k, cg, chunks, tilesW, tilesH, gx, blk0;
+};
+struct DwMultiDev { DwSegDev s[3]; int n, lds_, ldy, lddy, B, H, W, add_input, accumulate; long long wstride; };
+
+#define TC_DW_CASES(X) X(3, 2) X(3, 4) X(3, 8) X(5, 2) X(5, 4) X(5, 8) X(7, 2) X(7, 4) X(7, 8)
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void dw_multi_kernel(DwMultiDev a) {
+    extern __shared__ uint4 dsm[];
+    int lin = blockIdx.x, si = 0;
+    if (a.n > 1 && lin >= a.s[1].blk0) si = 1;
+    if (a.n > 2 && lin >= a.s[2].blk0) si = 2;
+    const DwSegDev& g = a.s[si];
+    lin -= g.blk0;
+    const int bx = lin % g.gx, by = lin / g.gx;
+#define TC_CASE(KK, CGG)                                                                                                            \
+    if (g.k == KK && g.cg == CGG) {                                                                                                 \
+        dw_tile_body<T, KK, CGG, MODE>((const T*)g.src, a.lds_, (const T*)g.w, (const T*)g.bias, (T*)g.y, a.ldy, a.B, a.H, a.W, g.C, \
+                                       a.add_input, a.accumulate, a.wstride, g.tilesW, g.tilesH, bx, by, blockIdx.y, dsm);          \
+        return;                                                                                                                     \
+    }
+    TC_DW_CASES(TC_CASE)
+#undef TC_CASE
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dw_multi_wgrad_kernel(DwMultiDev a) {
+    extern __shared__ uint4 dsm[];
+    int lin = blockIdx.x, si = 0;
+    if (a.n > 1 && lin >= a.s[1].blk0) si = 1;
+    if (a.n > 2 && lin >= a.s[2].blk0) si = 2;
+    const DwSegDev& g = a.s[si];
+    lin -= g.blk0;
+    const int bx = lin % g.gx, by = lin / g.gx;
+#define TC_CASE(KK, CGG)                                                                                                            \
+    if (g.k == KK && g.cg == CGG) {                                                                                                 \
+        dw_tile_wgrad_body<T, KK, CGG>((const T*)g.src, a.lds_, (const T*)g.dy, a.lddy, g.dw, g.db, a.B, a.H, a.W, g.C, a.wstride,    \
+                                       g.tilesW, g.tilesH, g.wsp, g.wsc, bx, by, blockIdx.y, g.gx, g.chunks, dsm);                  \
+        return;                                                                                                                     \
+    }
+    TC_DW_CASES(TC_CASE)
+#undef TC_CASE
+}
+
+template <typename T> int dw_smem_q(int k, int cg, bool wgrad) {
+#define TC_CASE(KK, CGG) if (k == KK && cg == CGG) return wgrad ? dw_wgrad_smem_q<T, KK, CGG>() : dw_tile_smem_q<T, KK, CGG>();
+    TC_DW_CASES(TC_CASE)
+#undef TC_CASE
+    return 0;
+}
+
+template <typename T>
+int launch_multi(const TcDwSeg* segs, int nseg, int mode, int ldx, int ldy, int lddy, int B, int H, int W, int add_input, int accumulate,
+                 int groups, long long wstride, void* ws, long long ws_bytes, hipStream_t s) {
+    constexpr int VEC = Vec16<T>::N;
+    DwMultiDev a;
+    a.n = nseg; a.lds_ = ldx; a.ldy = ldy; a.lddy = lddy; a.B = B; a.H = H; a.W = W; a.add_input = add_input; a.accumulate = accumulate;
+    a.wstride = wstride;
+    long long blk = 0, part_floats = 0, cnts = 0;
+    int smem_q = 0;
+    const bool have_ws = mode == 2 && ws && (uintptr_t)ws % 16 == 0 && ws_bytes > 16384;
+    for (int i = 0; i < nseg; ++i) {
+        const TcDwSeg& g = segs[i];
+        DwSegDev& d = a.s[i];
+        d.src = g.x; d.w = g.w; d.bias = g.bias; d.y = g.y; d.dy = g.dy; d.dw = g.dw; d.db = g.db; d.C = g.C; d.k = g.k;
+        d.cg = dw_pick_cg<T>(g.C);
+        d.chunks = (g.C + d.cg * VEC - 1) / (d.cg * VEC);
+        const int TH = (256 / d.cg) / 4;
+        d.tilesW = (W + 15) / 16; d.tilesH = (H + TH - 1) / TH;
+        const long long ntiles = (long long)B * d.tilesW * d.tilesH;
+        if (mode == 2) {
+            long long gx = 256 / ((long long)d.chunks * groups * nseg);
+            gx = gx < 1 ? 1 : (gx > ntiles ? ntiles : gx);
+            d.gx = (int)gx;
+            const long long nt_ch = (long long)(g.k * g.k + 1) * d.cg * VEC;
+            d.wsc = have_ws ? reinterpret_cast<int*>(ws) + cnts : nullptr;
+            d.wsp = have_ws ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + 16384) + part_floats : nullptr;
+            cnts += (long long)d.chunks * groups * ((gx + 15) / 16);
+            part_floats += (long long)d.chunks * groups * gx * nt_ch;
+        } else {
+            d.gx = (int)ntiles; d.wsc = nullptr; d.wsp = nullptr;
+        }
+        d.blk0 = (int)blk;
+        blk += (long long)d.gx * d.chunks;
+        const int q = dw_smem_q<T>(g.k, d.cg, mode == 2);
+        smem_q = q > smem_q ? q : smem_q;
+    }
+    if (blk > 0x7fffffffLL) return TC_ERR_ARG;
+    if (mode == 2 && have_ws && (cnts > 4096 || 16384 + part_floats * 4 > ws_bytes))
+        for (int i = 0; i < nseg; ++i) { a.s[i].wsc = nullptr; a.s[i].wsp = nullptr; }
+    const size_t smem = (size_t)smem_q * 16;
+    dim3 grid((unsigned)blk, groups);
+    if (mode == 0) {
+        if (smem > 64 * 1024) hipFuncSetAttribute((const void*)dw_multi_kernel<T, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL((dw_multi_kernel<T, 0>), grid, dim3(256), smem, s, a);
+    } else if (mode == 1) {
+        if (smem > 64 * 1024) hipFuncSetAttribute((const void*)dw_multi_kernel<T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL((dw_multi_kernel<T, 1>), grid, dim3(256), smem, s, a);
+    } else {
+        if (smem > 64 * 1024) hipFuncSetAttribute((const void*)dw_multi_wgrad_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL((dw_multi_wgrad_kernel<T>), grid, dim3(256), smem, s, a);
+    }
     return tc_launch_status();
 }
 
@@ -708,4 +852,30 @@ extern "C" int tc_dwconv_bwd_weight(const void* dy, int lddy, const void* x, int
     TC_DISPATCH_DTYPE(dtype, { if (k == 3) TC_DWW(3); else if (k == 5) TC_DWW(5); else TC_DWW(7); });
 #undef TC_DWW
     return tc_launch_status();
+}
+
+extern "C" int tc_dwconv_multi(const TcDwSeg* segs, int nseg, int mode, int ldx, int ldy, int lddy, int B, int H, int W, int add_input,
+                               int accumulate, int groups, long long wstride, void* ws, long long ws_bytes, int dtype, void* stream) {
+    if (!segs || nseg < 1 || nseg > 3 || mode < 0 || mode > 2 || groups < 1 || B <= 0 || H <= 0 || W <= 0) return TC_ERR_ARG;
+    bool tile_ok = true;
+    for (int i = 0; i < nseg; ++i) {
+        const TcDwSeg& g = segs[i];
+        if (!g.x || !dw_args_ok(B, H, W, g.C, g.k, 1, add_input) || (mode != 2 && (!g.w || !g.y)) || (mode == 2 && (!g.dy || !g.dw)))
+            return TC_ERR_ARG;
+        const void* second = mode == 2 ? g.dy : g.y;
+        const int ld2 = mode == 2 ? lddy : ldy;
+        if (dtype == TC_F32) tile_ok = tile_ok && dw_tile_ok<float>(g.x, ldx, second, ld2, g.C);
+        else tile_ok = tile_ok && dw_tile_ok<bf16_t>(g.x, ldx, second, ld2, g.C);
+    }
+    if (tile_ok) TC_DISPATCH_DTYPE(dtype, return (launch_multi<T>(segs, nseg, mode, ldx, ldy, lddy, B, H, W, add_input, accumulate, groups,
+                                                                  wstride, ws, ws_bytes, (hipStream_t)stream)));
+    for (int i = 0; i < nseg; ++i) {                          // unaligned views: one launch per segment through the single entries
+        const TcDwSeg& g = segs[i];
+        int rc;
+        if (mode == 0) rc = tc_dwconv_fwd(g.x, ldx, g.w, g.bias, g.y, ldy, B, H, W, g.C, g.k, 1, add_input, groups, wstride, dtype, stream);
+        else if (mode == 1) rc = tc_dwconv_bwd_input(g.x, ldx, g.w, g.y, ldy, B, H, W, g.C, g.k, 1, add_input, accumulate, groups, wstride, dtype, stream);
+        else rc = tc_dwconv_bwd_weight(g.dy, lddy, g.x, ldx, g.dw, g.db, B, H, W, g.C, g.k, 1, groups, wstride, ws, ws_bytes, dtype, stream);
+        if (rc != TC_OK) return rc;
+    }
+    return TC_OK;
 }

@@ -52,7 +52,8 @@ __device__ __forceinline__ bool splitk_fixup(const GemmDev& p, f32x16 (&acc)[TM]
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 __hip_atomic_store(part + ((i * TN + j) * 16 + r) * 256, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // write-through stores have landed (vmcnt 0); no L2 flush
+    __builtin_amdgcn_s_waitcnt(0);                          // vmcnt(0): THIS thread's write-through stores have been acknowledged
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (the barrier alone does not wait for stores in flight)
     __syncthreads();
     __shared__ int s_last;
     if (tid == 0) {

@@ -171,7 +171,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
     // 1024, and no second launch).
     constexpr int FG = 16;
     const int grp = blockIdx.x / FG, ngrp = (gridDim.x + FG - 1) / FG, gm = min(FG, (int)gridDim.x - grp * FG);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);                          // vmcnt(0): THIS thread's write-through stores have been acknowledged
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (the barrier alone does not wait for stores in flight)
     __syncthreads();
     __shared__ int s_last;
     if (threadIdx.x == 0) {

@@ -491,6 +491,7 @@ def _resblock(M, G, x: Var, name: str, B: int, side: int, out: Var) -> Var:
     return _bn(M, G, f, name + ".conv2.bn", ACT_NONE, residual=x, out=out)
 
 
+MULTI_CRPE = os.environ.get("TC_MULTI_CRPE", "1") != "0"
 FUSED_FACTOR_ATT = os.environ.get("TC_FACTOR_ATT_FUSED", "1") != "0"
 
 
@@ -502,12 +503,17 @@ def _factor_att(M, G, n: Var, blk: str, enc: str, B: int, side: int, residual: O
     qkv = G.linear(n, *_lin(M, G, blk + ".factoratt_crpe.qkv"))
     q, k, v = qkv.colslice(0, C), qkv.colslice(C, 2 * C), qkv.colslice(2 * C, 3 * C)
     convv = G.new(rows, C)
-    c0 = 0
+    c0, xs, outs, wts, bss, kss = 0, [], [], [], [], []
     for i, (ksz, nh) in enumerate(CRPE_WINDOW):
         w = nh * Ch
-        G.dwconv(v.colslice(c0, c0 + w), M._P(G, f"{enc}.crpe.conv_list.{i}.weight"), M._P(G, f"{enc}.crpe.conv_list.{i}.bias"),
-                 B, side, side, ksz, 1, False, out=convv.colslice(c0, c0 + w))
+        xs.append(v.colslice(c0, c0 + w)); outs.append(convv.colslice(c0, c0 + w)); kss.append(ksz)
+        wts.append(M._P(G, f"{enc}.crpe.conv_list.{i}.weight")); bss.append(M._P(G, f"{enc}.crpe.conv_list.{i}.bias"))
         c0 += w
+    if MULTI_CRPE:
+        G.dwconv_multi(xs, wts, bss, B, side, side, kss, outs)             # the three window sizes in one launch
+    else:
+        for x_, w_, b_, k_, o_ in zip(xs, wts, bss, kss, outs):
+            G.dwconv(x_, w_, b_, B, side, side, k_, 1, False, out=o_)
     if FUSED_FACTOR_ATT and Ch % 8 == 0 and 16 * N * Ch + 8 * Ch * Ch + 1024 <= 150 * 1024:     # a head's q, k, v, do tiles fit LDS in fp32
         o = G.factor_att_core(q, k, v, convv, Bt, N, h, Ch ** -0.5)
     else:                                           # unfused composition: larger inputs (384^2: 2304 tokens at stage 2), A/B tests
