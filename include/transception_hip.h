@@ -63,6 +63,9 @@ typedef struct TcGemm {
     int atomic;                  /* accumulate with fp32 atomics (batches that share one C) */
     float* rowsum;               /* optional fp32 [M]: rowsum[m] += sum_k op(A)[m,k] (bias gradient of a dW GEMM) */
     long long sBias1, sRow1;     /* level-1 batch strides of bias / rowsum (grouped weights: one weight set per batch) */
+    int bgap_every;              /* > 0 (multiple of 64, transB = 0 only): op(B) is stored [K,N] in blocks of bgap_every rows with */
+    long long bgap;              /* bgap extra elements (multiple of 8) between consecutive blocks -- several [N_i,K] weight matrices
+                                  * separated by their biases in the parameter arena, contracted as one K = sum N_i product */
     void* ws;                    /* optional device workspace (16-byte aligned) for the in-kernel split-K fix-up; its first 16 KiB */
     long long ws_bytes;          /* are arrival counters: zero before the first use, left zero by every launch.  One workspace per
                                   * stream (launches that may overlap must not share one).  NULL: requested split-K uses atomics. */

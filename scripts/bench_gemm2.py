@@ -14,7 +14,7 @@ def runw(M, N, K, tA=0, tB=1, c_f32=0, splitk=1, nb=1, iters=50, check=True):
     b = (torch.randn((N, K) if tB else (K, N), device=dev) * 0.1).bfloat16().repeat(nb, 1)
     c = torch.zeros(nb * M, N, device=dev, dtype=torch.float32 if c_f32 else torch.bfloat16)
     g = TcGemm(a.data_ptr(), b.data_ptr(), c.data_ptr(), None, None, M, N, K, a.stride(0), b.stride(0), N, 0, tA, tB, nb, 1,
-               a.shape[0] // nb * a.stride(0), 0, b.shape[0] // nb * b.stride(0), 0, M * N, 0, 0, 0, 1.0, int(splitk > 1), 0, splitk, TC_BF16, c_f32, 0, None, 0, 0,
+               a.shape[0] // nb * a.stride(0), 0, b.shape[0] // nb * b.stride(0), 0, M * N, 0, 0, 0, 1.0, int(splitk > 1), 0, splitk, TC_BF16, c_f32, 0, None, 0, 0, 0, 0,
                ws.data_ptr(), ws.numel())
     c.zero_(); L.tc_gemm(C.byref(g), st); torch.cuda.synchronize()
     if check:

@@ -27,7 +27,7 @@ def rec(self, *a, **k):
     A, lda, B, ldb, Cm, ldc, M, N, K, tA, tB = a[:11]
     gs = TcGemm(A, B, Cm, k.get('bias'), k.get('R'), M, N, K, lda, ldb, ldc, k.get('ldr', 0), tA, tB, k.get('nb1', 1), k.get('nb2', 1),
                 *k.get('sA', (0, 0)), *k.get('sB', (0, 0)), *k.get('sC', (0, 0)), *k.get('sR', (0, 0)), k.get('alpha', 1.0), k.get('acc', 0),
-                k.get('act', 0), k.get('splitk', 1), self.dt, k.get('c_f32', 0), k.get('atomic', 0), k.get('rowsum'), k.get('sbias', 0), k.get('srow', 0))
+                k.get('act', 0), k.get('splitk', 1), self.dt, k.get('c_f32', 0), k.get('atomic', 0), k.get('rowsum'), k.get('sbias', 0), k.get('srow', 0), 0, 0)
     calls.append((gs, self.stream))
 engine.Graph._gemm = rec
 # keep every temporary alive so the recorded pointers stay valid: hold the graph

@@ -26,7 +26,7 @@ class TcGemm(C.Structure):
                 ("sA1", i64), ("sA2", i64), ("sB1", i64), ("sB2", i64),
                 ("sC1", i64), ("sC2", i64), ("sR1", i64), ("sR2", i64),
                 ("alpha", f32), ("accumulate", i32), ("act", i32), ("splitk", i32), ("dtype", i32), ("c_f32", i32), ("atomic", i32), ("rowsum", vp), ("sBias1", i64), ("sRow1", i64),
-                ("ws", vp), ("ws_bytes", i64)]
+                ("bgap_every", i32), ("bgap", i64), ("ws", vp), ("ws_bytes", i64)]
 
 
 class TcDwSeg(C.Structure):

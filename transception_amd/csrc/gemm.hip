@@ -26,6 +26,7 @@ struct GemmDev {
     float* rowsum;          // optional: rowsum[m] += sum_k op(A)[m][k]  (fp32, atomics)
     long long sBias1, sRow1; // batch-level-1 strides of bias / rowsum (grouped weights)
     float* ws_part; int* ws_cnt; int fix_group, fix_ngroups;   // split-K fix-up workspace (fix_group > 0: enabled)
+    int bgap_every; long long bgap;   // B stored [K,N] in blocks of bgap_every rows with bgap extra elements between blocks
 };
 
 // Split-K fix-up without a second launch.  The `splitk` workgroups of an output tile park their fp32 partial tiles in the
@@ -305,8 +306,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev p) {
             const int f = tid + i * 256;
             if (TB) { const int row = f / (BK / 4), kq = f % (BK / 4);          // stored [N,K]
                 rb[i] = load_strip(B, p.ldb, n0 + row, k0 + kq * 4, p.N, kend, false, p.vecB); }
-            else { const int k = f / (BN / 4), nq = f % (BN / 4);               // stored [K,N]
-                rb[i] = load_strip(B, p.ldb, n0 + nq * 4, k0 + k, p.N, kend, true, p.vecB); }
+            else { const int k = f / (BN / 4), nq = f % (BN / 4);               // stored [K,N] (possibly in gapped row blocks)
+                const float* Bk = p.bgap_every ? B + (long long)(k0 / p.bgap_every) * p.bgap : B;
+                rb[i] = load_strip(Bk, p.ldb, n0 + nq * 4, k0 + k, p.N, kend, true, p.vecB); }
         }
     };
     auto stage = [&]() {
@@ -446,7 +448,8 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmDev& p, const int bx, c
             if (TB) { const int row = f / (BK / 8), kq = f % (BK / 8);
                 rb[i] = load_strip8(B, p.ldb, n0 + row, k0 + kq * 8, p.N, kend, false, p.vecB); }
             else { const int k = f % BK, nq = f / BK;
-                rb[i] = load_strip8(B, p.ldb, n0 + nq * 8, k0 + k, p.N, kend, true, p.vecB); }
+                const bf16_t* Bk = p.bgap_every ? B + (long long)(k0 / p.bgap_every) * p.bgap : B;
+                rb[i] = load_strip8(Bk, p.ldb, n0 + nq * 8, k0 + k, p.N, kend, true, p.vecB); }
         }
     };
     auto put_t = [&](bf16_t* base, int x0, int k, uint4 v) {       // transposed write: 8 rows x0.., column k
@@ -602,6 +605,7 @@ bool gemm_plan(const TcGemm* g, GemmDev& d, dim3& grid, bool& use128_out) {
     d.alpha = g->alpha; d.accumulate = g->accumulate; d.act = g->act;
     d.rowsum = g->rowsum;
     d.sBias1 = g->sBias1; d.sRow1 = g->sRow1;
+    d.bgap_every = g->bgap_every; d.bgap = g->bgap;
     constexpr int VEC = 16 / (int)sizeof(T);                         // elements per 16-byte vector
     auto aligned = [&](const void* ptr, int ld, long long s1, long long s2) {
         return ((uintptr_t)ptr % 16 == 0) && (ld % VEC == 0) && (s1 % VEC == 0) && (s2 % VEC == 0);
@@ -680,6 +684,7 @@ static bool gemm_args_ok(const TcGemm* g) {
     if (!g || !g->A || !g->B || !g->C || g->M <= 0 || g->N <= 0 || g->K <= 0 || g->nb1 < 1 || g->nb2 < 1 || g->splitk < 1) return false;
     if ((g->splitk > 1 || g->atomic) && (!g->accumulate || (g->dtype != TC_F32 && !g->c_f32) || g->act != TC_ACT_NONE)) return false;
     if (g->act != TC_ACT_NONE && g->act != TC_ACT_SIGMOID) return false;
+    if (g->bgap_every < 0 || (g->bgap_every > 0 && (g->transB || g->bgap_every % 64 || (g->bgap % 8)))) return false;
     return true;
 }
 

@@ -396,10 +396,10 @@ class Graph:
 
     def _gemm_desc(self, A, lda, B, ldb, Cm, ldc, M, N, K, tA, tB, bias=None, R=None, ldr=0, alpha=1.0, acc=0, act=ACT_NONE,
                    splitk=1, nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), c_f32=0, atomic=0, rowsum=None, sbias=0,
-                   srow=0, use_ws=True) -> TcGemm:
+                   srow=0, use_ws=True, bgap=(0, 0)) -> TcGemm:
         ws = _workspace(self.dev, self.stream) if use_ws else None
         return TcGemm(A, B, Cm, bias, R, M, N, K, lda, ldb, ldc, ldr, tA, tB, nb1, nb2, sA[0], sA[1], sB[0], sB[1], sC[0], sC[1],
-                      sR[0], sR[1], alpha, acc, act, splitk, self.dt, c_f32, atomic, rowsum, sbias, srow,
+                      sR[0], sR[1], alpha, acc, act, splitk, self.dt, c_f32, atomic, rowsum, sbias, srow, bgap[0], bgap[1],
                       ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0)
 
     @staticmethod
@@ -495,6 +495,49 @@ class Graph:
                 else:
                     assert grouped or sr == so
                     self._pass_grad_batched(residual, dy, nb, M, N, so, sr if grouped else so)
+        self._rec(bwd)
+        return out
+
+    def linear_multi(self, x: Var, Ws: List[P], bs: List[P], out: Var) -> Var:
+        """n Linear layers with the same [N, K] shape on the SAME input, written side by side into out [M, n*N], as ONE batched
+        GEMM (weight i lives a constant stride after weight 0 in the parameter arena) -- EfficientAttention's keys / queries /
+        values (MSTr.py:109-111).  Backward: dX is one K = n*N product over the gapped weight stack (TcGemm.bgap), the n weight
+        gradients one batched GEMM; both share a launch (tc_gemm_pair)."""
+        n = len(Ws)
+        N, K = Ws[0].data.shape
+        M = x.rows
+        es = Ws[0].data.element_size()
+        sw = (Ws[1].data.data_ptr() - Ws[0].data.data_ptr()) // es
+        assert self.ngroups == 1 and out.rows == M and out.cols == n * N and x.cols == K
+        assert all(W.data.shape == (N, K) and W.data.is_contiguous() for W in Ws)
+        assert all((Ws[i].data.data_ptr() - Ws[0].data.data_ptr()) // es == i * sw and
+                   (bs[i].data.data_ptr() - bs[0].data.data_ptr()) // es == i * sw for i in range(n))
+        assert N % 64 == 0 and (sw - N * K) % 8 == 0
+        self._gemm(_ptr(x.data), x.ld, _ptr(Ws[0].data), K, _ptr(out.data), out.ld, M, N, K, 0, 1, bias=_ptr(bs[0].data), nb1=n,
+                   sA=(0, 0), sB=(sw, 0), sC=(N, 0), sbias=sw)
+
+        def bwd():
+            dy = self.grad_of(out)
+            if dy is None:
+                return
+            have_w = Ws[0].grad is not None
+            gsw = (Ws[1].grad.data_ptr() - Ws[0].grad.data_ptr()) // 4 if have_w else 0
+            ga = gb = None
+            if x.requires_grad:
+                gx, acc = self.wgrad(x)
+                ga = self._gemm_desc(_ptr(dy), dy.stride(0), _ptr(Ws[0].data), K, _ptr(gx), gx.stride(0), M, K, n * N, 0, 0, acc=acc,
+                                     bgap=(N, sw - N * K))
+            if have_w:
+                gb = self._gemm_desc(_ptr(dy), dy.stride(0), _ptr(x.data), x.ld, _ptr(Ws[0].grad), K, N, K, M, 1, 0, acc=1,
+                                     splitk=self._splitk(N, K, M), c_f32=1, nb1=n, sA=(N, 0), sB=(0, 0), sC=(gsw, 0),
+                                     rowsum=_ptr(bs[0].grad) if bs[0].grad is not None else None, srow=gsw, use_ws=False)
+            self.n_launch += 1
+            if ga is not None and gb is not None:
+                self.L.tc_gemm_pair(C.byref(ga), C.byref(gb), self.stream)
+            elif ga is not None:
+                self.L.tc_gemm(C.byref(ga), self.stream)
+            elif gb is not None:
+                self.L.tc_gemm(C.byref(gb), self.stream)
         self._rec(bwd)
         return out
 

@@ -447,9 +447,14 @@ def _eff_attention(M, G, n1: Var, name: str, B: int, N: int, residual: Optional[
     C = n1.cols
     rows = B * N
     kqv = G.new(rows, 3 * C)
-    k = G.linear(n1, *_lin(M, G, name + ".keys"), out=kqv.colslice(0, C))
-    q = G.linear(n1, *_lin(M, G, name + ".queries"), out=kqv.colslice(C, 2 * C))
-    v = G.linear(n1, *_lin(M, G, name + ".values"), out=kqv.colslice(2 * C, 3 * C))
+    k, q, v = kqv.colslice(0, C), kqv.colslice(C, 2 * C), kqv.colslice(2 * C, 3 * C)
+    lk, lq, lv = _lin(M, G, name + ".keys"), _lin(M, G, name + ".queries"), _lin(M, G, name + ".values")
+    if MULTI_QKV and C % 64 == 0 and G.ngroups == 1:
+        G.linear_multi(n1, [lk[0], lq[0], lv[0]], [lk[1], lq[1], lv[1]], kqv)       # the three 1x1 convs in one batched GEMM
+    else:
+        G.linear(n1, *lk, out=k)
+        G.linear(n1, *lq, out=q)
+        G.linear(n1, *lv, out=v)
     ksm = G.softmax(k, B, 0)                       # over tokens, per channel
     qsm = G.softmax(q, 1, 1)                       # over channels, per token
     ctx = G.new(B * C, C)
@@ -491,6 +496,7 @@ def _resblock(M, G, x: Var, name: str, B: int, side: int, out: Var) -> Var:
     return _bn(M, G, f, name + ".conv2.bn", ACT_NONE, residual=x, out=out)
 
 
+MULTI_QKV = os.environ.get("TC_MULTI_QKV", "1") != "0"
 MULTI_CRPE = os.environ.get("TC_MULTI_CRPE", "1") != "0"
 FUSED_FACTOR_ATT = os.environ.get("TC_FACTOR_ATT_FUSED", "1") != "0"
 
