@@ -38,6 +38,7 @@ SIGNATURES = {
     "tc_abi_version": [],
     "tc_gemm": [C.POINTER(TcGemm), vp],
     "tc_gemm_pair": [C.POINTER(TcGemm), C.POINTER(TcGemm), vp],
+    "tc_gemm_multi": [C.POINTER(TcGemm), i32, vp],
     "tc_colsum": [vp, i32, i32, i32, i32, i64, vp, i32, i32, vp],
     "tc_layernorm_fwd": [vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, f32, i32, i32, i64, i32, vp],
     "tc_layernorm_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i64, vp, i64, i32, vp],

@@ -577,6 +577,25 @@ __global__ __launch_bounds__(256, 2) void gemm_pair_kernel(GemmPairDev q) {
     }
 }
 
+// Up to 8 independent bf16 GEMMs of the three kinds a Linear produces (y = x W^T: TA=0,TB=1 ; dX = dY W: TA=0,TB=0 ; dW = dY^T X:
+// TA=1,TB=0, fp32 C) in one grid of 64x64 tiles -- the four per-scale MixFFNs of a bridge layer are independent chains of small
+// GEMMs; level by level their workgroups share the CUs instead of queueing as 4 (forward) or 8 (backward) short launches.
+constexpr int GEMM_MULTI_MAX = 8;
+struct GemmMultiDev { GemmDev p[GEMM_MULTI_MAX]; int blk0[GEMM_MULTI_MAX], gx[GEMM_MULTI_MAX], gy[GEMM_MULTI_MAX], kind[GEMM_MULTI_MAX]; int n; };
+__global__ __launch_bounds__(256, 2) void gemm_multi_kernel(GemmMultiDev q) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (64 + 64) * (64 + 8)];
+    bf16_t(*As)[64 * (64 + 8)] = reinterpret_cast<bf16_t(*)[64 * (64 + 8)]>(smem);
+    bf16_t(*Bs)[64 * (64 + 8)] = reinterpret_cast<bf16_t(*)[64 * (64 + 8)]>(smem + 2 * 64 * (64 + 8));
+    int lin = blockIdx.x, i = 0;
+    for (int j = 1; j < q.n; ++j) if (lin >= q.blk0[j]) i = j;
+    lin -= q.blk0[i];
+    const int gx = q.gx[i], gy = q.gy[i], bx = lin % gx, by = (lin / gx) % gy, bz = lin / (gx * gy);
+    const GemmDev& p = q.p[i];
+    if (q.kind[i] == 0) gemm_bf16_body<bf16_t, 64, 64, false, true, true>(p, bx, by, bz, gx, gy, As, Bs);
+    else if (q.kind[i] == 1) gemm_bf16_body<bf16_t, 64, 64, false, false, true>(p, bx, by, bz, gx, gy, As, Bs);
+    else gemm_bf16_body<float, 64, 64, true, false, true>(p, bx, by, bz, gx, gy, As, Bs);
+}
+
 // ---------------------------------------------------------------------------------------------- host side
 template <typename T, typename TC, int BM, int BN, bool TA, bool TB>
 void launch_one(const GemmDev& d, dim3 grid, hipStream_t s) {
@@ -596,7 +615,7 @@ int launch(const GemmDev& d, int transA, int transB, dim3 grid, hipStream_t s) {
 
 // fills the device-side descriptor and the launch grid; false: bad arguments
 template <typename T>
-bool gemm_plan(const TcGemm* g, GemmDev& d, dim3& grid, bool& use128_out) {
+bool gemm_plan(const TcGemm* g, GemmDev& d, dim3& grid, bool& use128_out, bool force64 = false) {
     d.A = g->A; d.B = g->B; d.C = g->C; d.bias = g->bias; d.R = g->R;
     d.M = g->M; d.N = g->N; d.K = g->K; d.lda = g->lda; d.ldb = g->ldb; d.ldc = g->ldc; d.ldr = g->ldr;
     d.nb2 = g->nb2; d.splitk = g->splitk;
@@ -622,7 +641,7 @@ bool gemm_plan(const TcGemm* g, GemmDev& d, dim3& grid, bool& use128_out) {
     }
     const int nb = g->nb1 * g->nb2;
     const long long big = (long long)((g->M + 127) / 128) * ((g->N + 127) / 128) * nb;
-    const bool use128 = big >= 192 && g->M >= 96 && g->N >= 96;
+    const bool use128 = !force64 && big >= 192 && g->M >= 96 && g->N >= 96;
     const int BM = use128 ? 128 : 64, BN = use128 ? 128 : 64;
     constexpr int BK = sizeof(T) == 4 ? 16 : 64;
     // split-K plan: the caller's request (weight gradients), or -- with a workspace -- our own for few-tile / long-K
@@ -712,4 +731,36 @@ extern "C" int tc_gemm_pair(const TcGemm* a, const TcGemm* b, void* stream) {
     }
     const int rc = tc_gemm(a, stream);                       // shapes the paired kernel does not cover: two launches
     return rc != TC_OK ? rc : tc_gemm(b, stream);
+}
+
+extern "C" int tc_gemm_multi(const TcGemm* g, int n, void* stream) {
+    if (!g || n < 1) return TC_ERR_ARG;
+    for (int i = 0; i < n; ++i) if (!gemm_args_ok(g + i)) return TC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    bool ok = n <= GEMM_MULTI_MAX;
+    GemmMultiDev q;
+    long long blk = 0;
+    for (int i = 0; ok && i < n; ++i) {
+        const TcGemm& t = g[i];
+        int kind = -1;
+        if (t.dtype == TC_BF16 && !t.transA && t.transB && !t.c_f32) kind = 0;
+        else if (t.dtype == TC_BF16 && !t.transA && !t.transB && !t.c_f32) kind = 1;
+        else if (t.dtype == TC_BF16 && t.transA && !t.transB && t.c_f32) kind = 2;
+        dim3 grid;
+        bool big;
+        if (kind < 0 || !gemm_plan<bf16_t>(&t, q.p[i], grid, big, true)) { ok = false; break; }
+        q.kind[i] = kind; q.gx[i] = grid.x; q.gy[i] = grid.y; q.blk0[i] = (int)blk;
+        blk += (long long)grid.x * grid.y * grid.z;
+        if (blk > 0x7fffffffLL) ok = false;
+    }
+    if (ok) {
+        q.n = n;
+        hipLaunchKernelGGL(gemm_multi_kernel, dim3((unsigned)blk), dim3(256), 0, s, q);
+        return tc_launch_status();
+    }
+    for (int i = 0; i < n; ++i) {                              // kinds / sizes the merged kernel does not cover: one launch each
+        const int rc = tc_gemm(g + i, stream);
+        if (rc != TC_OK) return rc;
+    }
+    return TC_OK;
 }

@@ -132,14 +132,15 @@ def _side_streams(device, n: int):
     return pool[:n]
 
 
-_WORKSPACES: Dict[Tuple[str, int], torch.Tensor] = {}
+_WORKSPACES: Dict[Tuple[str, int, str], torch.Tensor] = {}
 WORKSPACE_BYTES = 16384 + 1024 * 16384             # arrival counters + 1024 fp32 64x64 partial tiles
 
 
-def _workspace(device, stream_ptr: int) -> torch.Tensor:
+def _workspace(device, stream_ptr: int, tag: str = "") -> torch.Tensor:
     """Split-K fix-up workspace of the kernels launched on `stream_ptr` (include/transception_hip.h, TcGemm.ws): launches on one
-    stream never overlap, so one buffer per stream is enough; zeroed once, every launch leaves its counters zero."""
-    key = (str(device), int(stream_ptr or 0))
+    stream never overlap, so one buffer per stream is enough; zeroed once, every launch leaves its counters zero.  `tag`: a
+    separate buffer for launches that cut it into per-problem slices (their counter areas must never have held partial tiles)."""
+    key = (str(device), int(stream_ptr or 0), tag)
     ws = _WORKSPACES.get(key)
     if ws is None:
         ws = _WORKSPACES[key] = torch.zeros(WORKSPACE_BYTES, dtype=torch.uint8, device=device)
@@ -497,6 +498,53 @@ class Graph:
                     self._pass_grad_batched(residual, dy, nb, M, N, so, sr if grouped else so)
         self._rec(bwd)
         return out
+
+    def linear_many(self, items: List[Tuple[Var, P, Optional[P], Var, Optional[Var]]]) -> List[Var]:
+        """Independent Linear layers (x, W, b, out, residual) of DIFFERENT shapes in one launch (tc_gemm_multi); their 2n gradient
+        GEMMs in one launch too.  out_i = x_i W_i^T + b_i + residual_i."""
+        n = len(items)
+        assert self.ngroups == 1 and 1 <= n <= 4
+        wsb = _workspace(self.dev, self.stream, "many")
+        sl = (wsb.numel() // 8) & ~16383                    # a private workspace slice per problem (fix-up counters + partials)
+
+        def desc(i, *a, **k):
+            g = self._gemm_desc(*a, use_ws=False, **k)
+            g.ws, g.ws_bytes = wsb.data_ptr() + i * sl, sl
+            return g
+        arr = (TcGemm * n)()
+        for i, (x, W, b, out, res) in enumerate(items):
+            N, K = W.data.shape
+            assert x.cols == K and out.rows == x.rows and out.cols == N
+            arr[i] = desc(i, _ptr(x.data), x.ld, _ptr(W.data), W.data.stride(0), _ptr(out.data), out.ld, x.rows, N, K, 0, 1,
+                          bias=_ptr(b.data) if b is not None else None, R=_ptr(res.data) if res is not None else None,
+                          ldr=res.ld if res is not None else 0)
+        self.n_launch += 1
+        self.L.tc_gemm_multi(arr, n, self.stream)
+
+        def bwd():
+            probs = []
+            for i, (x, W, b, out, res) in enumerate(items):
+                dy = self.grad_of(out)
+                if dy is None:
+                    continue
+                N, K = W.data.shape
+                M = x.rows
+                if x.requires_grad:
+                    gx, acc = self.wgrad(x)
+                    probs.append(desc(len(probs), _ptr(dy), dy.stride(0), _ptr(W.data), W.data.stride(0), _ptr(gx), gx.stride(0), M, K, N,
+                                      0, 0, acc=acc))
+                if W.grad is not None:
+                    probs.append(desc(len(probs), _ptr(dy), dy.stride(0), _ptr(x.data), x.ld, _ptr(W.grad), W.grad.stride(0), N, K, M, 1, 0,
+                                      acc=1, splitk=self._splitk(N, K, M), c_f32=1,
+                                      rowsum=_ptr(b.grad) if (b is not None and b.grad is not None) else None))
+                if res is not None:
+                    self.pass_grad(res, dy)
+            if probs:
+                arr2 = (TcGemm * len(probs))(*probs)
+                self.n_launch += 1
+                self.L.tc_gemm_multi(arr2, len(probs), self.stream)
+        self._rec(bwd)
+        return [it[3] for it in items]
 
     def linear_multi(self, x: Var, Ws: List[P], bs: List[P], out: Var) -> Var:
         """n Linear layers with the same [N, K] shape on the SAME input, written side by side into out [M, n*N], as ONE batched

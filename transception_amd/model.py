@@ -496,6 +496,7 @@ def _resblock(M, G, x: Var, name: str, B: int, side: int, out: Var) -> Var:
     return _bn(M, G, f, name + ".conv2.bn", ACT_NONE, residual=x, out=out)
 
 
+MANY_MIXFFN = os.environ.get("TC_MANY_MIXFFN", "1") != "0"
 MULTI_QKV = os.environ.get("TC_MULTI_QKV", "1") != "0"
 MULTI_CRPE = os.environ.get("TC_MULTI_CRPE", "1") != "0"
 FUSED_FACTOR_ATT = os.environ.get("TC_FACTOR_ATT_FUSED", "1") != "0"
@@ -647,12 +648,24 @@ def _bridge_layer(M, G, X: Var, li: int, B: int, sides, ntok, R, N6) -> Var:
         tx1 = _self_att(M, G, n, X, name + ".attn", B, sides, ntok, R, N6)
     tx = _ln(M, G, tx1, name + ".norm2")
     tx2 = G.new(B * N6, 64)
+    geo = [(B * sides[s] * sides[s], 64 * MULT[s]) for s in range(4)]
+    view = lambda v, s: v.rowslice(R[s], R[s + 1]).reshape(*geo[s])
+    if MANY_MIXFFN and not G.use_streams:
+        # the four per-scale MixFFNs level by level: fc1 x4 in one launch, dw x4, LN x4, fc2 x4 in one launch (and the eight
+        # gradient GEMMs of each level in one launch): four independent chains of small kernels share the CUs
+        nm = [f"{name}.mixffn{s + 1}" for s in range(4)]
+        hs = G.linear_many([(view(tx, s), *_lin(M, G, nm[s] + ".fc1"), G.new(geo[s][0], 4 * geo[s][1]), None) for s in range(4)])
+        acts = []
+        for s in range(4):
+            d = G.dwconv(hs[s], M._P(G, nm[s] + ".dwconv.dwconv.weight"), M._P(G, nm[s] + ".dwconv.dwconv.bias"), B, sides[s], sides[s], 3,
+                         1, True)
+            acts.append(_ln(M, G, d, nm[s] + ".norm1", act=ACT_GELU))
+        G.linear_many([(acts[s], *_lin(M, G, nm[s] + ".fc2"), view(tx2, s), view(tx1, s)) for s in range(4)])
+        return tx2
     with G.parallel(4, shared=(tx, tx1)) as par:    # the four per-scale MixFFNs are independent
         for s in range(4):
             with par.branch(s):
-                rows, width = B * sides[s] * sides[s], 64 * MULT[s]
-                view = lambda v: v.rowslice(R[s], R[s + 1]).reshape(rows, width)
-                _mixffn(M, G, view(tx), f"{name}.mixffn{s + 1}", B, sides[s], sides[s], residual=view(tx1), out=view(tx2))
+                _mixffn(M, G, view(tx, s), f"{name}.mixffn{s + 1}", B, sides[s], sides[s], residual=view(tx1, s), out=view(tx2, s))
     return tx2
 
 
