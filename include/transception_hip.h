@@ -134,16 +134,17 @@ int tc_dwconv_bwd_weight(const void* dy, int lddy, const void* x, int ldx, float
                          int B, int H, int W, int C, int k, int stride, int groups, long long wstride, void* ws,
                          long long ws_bytes, int dtype, void* stream);
 
-/* Up to three stride-1 depthwise convolutions on column slices of the same [groups*B, H, W] maps in ONE launch (ConvRelPosEnc's
- * 3x3 / 5x5 / 7x7 branches, MSTr.py:785-816).  mode 0: y = conv(x) (+bias) (+x); mode 1: y (= dx) = conv^T(x (= dy)) (+x)
- * (+y when accumulate); mode 2: dw / db += gradients from x and dy.  Row strides: ldx for x, ldy for y, lddy for dy.
- * All segments share groups / wstride (see tc_dwconv_fwd); ws as in tc_dwconv_bwd_weight. */
+/* Up to four INDEPENDENT stride-1 depthwise convolutions in ONE launch: ConvRelPosEnc's 3x3 / 5x5 / 7x7 branches on column
+ * slices of one map (MSTr.py:785-816), or the four per-scale MixFFN convolutions of a bridge layer (different maps).
+ * mode 0: y = conv(x) (+bias) (+x); mode 1: y (= dx) = conv^T(x (= dy)) (+x) (+y when accumulate); mode 2: dw / db += gradients
+ * from x and dy.  Every segment carries its own geometry and row strides; groups / wstride are common (see tc_dwconv_fwd);
+ * ws as in tc_dwconv_bwd_weight. */
 typedef struct TcDwSeg {
     const void* x; const void* w; const void* bias; void* y; const void* dy; float* dw; float* db;
-    int C; int k;
+    int C; int k; int ldx; int ldy; int lddy; int B; int H; int W;
 } TcDwSeg;
-int tc_dwconv_multi(const TcDwSeg* segs, int nseg, int mode, int ldx, int ldy, int lddy, int B, int H, int W, int add_input,
-                    int accumulate, int groups, long long wstride, void* ws, long long ws_bytes, int dtype, void* stream);
+int tc_dwconv_multi(const TcDwSeg* segs, int nseg, int mode, int add_input, int accumulate, int groups, long long wstride,
+                    void* ws, long long ws_bytes, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * BatchNorm2d over token rows ([rows, C], statistics over rows) fused with its activation and an

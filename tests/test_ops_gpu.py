@@ -530,7 +530,7 @@ def test_dwconv_multi_matches_torch(G, Ch, side):
     xs, os_, c0 = [], [], 0
     for wd in widths:
         xs.append(xv.colslice(2 * C + c0, 2 * C + c0 + wd)); os_.append(out.colslice(c0, c0 + wd)); c0 += wd
-    G.dwconv_multi(xs, Ws, Bs, B, side, side, ks, os_)
+    G.dwconv_multi(xs, Ws, Bs, (B, side, side), ks, os_)
     close(out.data, ref, 2e-5, 2e-5, "y")
     run_bwd(G, out, gy)
     close(G.grad_of(xv), xr.grad, 2e-5, 5e-5, "dx")
@@ -574,7 +574,7 @@ def test_dwconv_multi_grouped(G):
     for wd in widths:
         xs.append(xv.colslice(2 * C + c0, 2 * C + c0 + wd)); os_.append(out.colslice(c0, c0 + wd)); c0 += wd
     with G.grouped(Gn, per):
-        G.dwconv_multi(xs, Ws, Bs, B, side, side, ks, os_)
+        G.dwconv_multi(xs, Ws, Bs, (B, side, side), ks, os_)
     close(out.data, ref, 2e-5, 2e-5, "y")
     run_bwd(G, out, gy)
     close(G.grad_of(xv), xr.grad, 2e-5, 5e-5, "dx")

@@ -30,7 +30,8 @@ class TcGemm(C.Structure):
 
 
 class TcDwSeg(C.Structure):
-    _fields_ = [("x", vp), ("w", vp), ("bias", vp), ("y", vp), ("dy", vp), ("dw", vp), ("db", vp), ("C", i32), ("k", i32)]
+    _fields_ = [("x", vp), ("w", vp), ("bias", vp), ("y", vp), ("dy", vp), ("dw", vp), ("db", vp), ("C", i32), ("k", i32),
+                ("ldx", i32), ("ldy", i32), ("lddy", i32), ("B", i32), ("H", i32), ("W", i32)]
 
 
 # name -> argtypes (every function returns int status unless listed in _RET)
@@ -47,7 +48,7 @@ SIGNATURES = {
     "tc_dwconv_fwd": [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i64, i32, vp],
     "tc_dwconv_bwd_input": [vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i64, i32, vp],
     "tc_dwconv_bwd_weight": [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i64, vp, i64, i32, vp],
-    "tc_dwconv_multi": [C.POINTER(TcDwSeg), i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i64, vp, i64, i32, vp],
+    "tc_dwconv_multi": [C.POINTER(TcDwSeg), i32, i32, i32, i32, i32, i64, vp, i64, i32, vp],
     "tc_bn_scratch_floats": [i32, i32],
     "tc_bn_fwd": [vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, f32, f32, i32, i32, i32, vp],
     "tc_bn_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp],

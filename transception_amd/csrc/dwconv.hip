@@ -682,9 +682,10 @@ int launch_dw(const void* x, int ldx, const void* w, const void* bias, void* y, 
 // latency-bound launch on its own; side by side they cost what the slowest costs.
 struct DwSegDev {
     const void* src; const void* w; const void* bias; void* y; const void* dy; float* dw; float* db; float* wsp; int* wsc;
-    int C, k, cg, chunks, tilesW, tilesH, gx, blk0;
+    int C, k, cg, chunks, tilesW, tilesH, gx, blk0, lds_, ldy, lddy, B, H, W;
 };
-struct DwMultiDev { DwSegDev s[3]; int n, lds_, ldy, lddy, B, H, W, add_input, accumulate; long long wstride; };
+constexpr int DW_MULTI_MAX = 4;
+struct DwMultiDev { DwSegDev s[DW_MULTI_MAX]; int n, add_input, accumulate; long long wstride; };
 
 #define TC_DW_CASES(X) X(3, 2) X(3, 4) X(3, 8) X(5, 2) X(5, 4) X(5, 8) X(7, 2) X(7, 4) X(7, 8)
 
@@ -694,12 +695,13 @@ __global__ __launch_bounds__(256) void dw_multi_kernel(DwMultiDev a) {
     int lin = blockIdx.x, si = 0;
     if (a.n > 1 && lin >= a.s[1].blk0) si = 1;
     if (a.n > 2 && lin >= a.s[2].blk0) si = 2;
+    if (a.n > 3 && lin >= a.s[3].blk0) si = 3;
     const DwSegDev& g = a.s[si];
     lin -= g.blk0;
     const int bx = lin % g.gx, by = lin / g.gx;
 #define TC_CASE(KK, CGG)                                                                                                            \
     if (g.k == KK && g.cg == CGG) {                                                                                                 \
-        dw_tile_body<T, KK, CGG, MODE>((const T*)g.src, a.lds_, (const T*)g.w, (const T*)g.bias, (T*)g.y, a.ldy, a.B, a.H, a.W, g.C, \
+        dw_tile_body<T, KK, CGG, MODE>((const T*)g.src, g.lds_, (const T*)g.w, (const T*)g.bias, (T*)g.y, g.ldy, g.B, g.H, g.W, g.C, \
                                        a.add_input, a.accumulate, a.wstride, g.tilesW, g.tilesH, bx, by, blockIdx.y, dsm);          \
         return;                                                                                                                     \
     }
@@ -713,12 +715,13 @@ __global__ __launch_bounds__(256) void dw_multi_wgrad_kernel(DwMultiDev a) {
     int lin = blockIdx.x, si = 0;
     if (a.n > 1 && lin >= a.s[1].blk0) si = 1;
     if (a.n > 2 && lin >= a.s[2].blk0) si = 2;
+    if (a.n > 3 && lin >= a.s[3].blk0) si = 3;
     const DwSegDev& g = a.s[si];
     lin -= g.blk0;
     const int bx = lin % g.gx, by = lin / g.gx;
 #define TC_CASE(KK, CGG)                                                                                                            \
     if (g.k == KK && g.cg == CGG) {                                                                                                 \
-        dw_tile_wgrad_body<T, KK, CGG>((const T*)g.src, a.lds_, (const T*)g.dy, a.lddy, g.dw, g.db, a.B, a.H, a.W, g.C, a.wstride,    \
+        dw_tile_wgrad_body<T, KK, CGG>((const T*)g.src, g.lds_, (const T*)g.dy, g.lddy, g.dw, g.db, g.B, g.H, g.W, g.C, a.wstride,    \
                                        g.tilesW, g.tilesH, g.wsp, g.wsc, bx, by, blockIdx.y, g.gx, g.chunks, dsm);                  \
         return;                                                                                                                     \
     }
@@ -734,11 +737,11 @@ template <typename T> int dw_smem_q(int k, int cg, bool wgrad) {
 }
 
 template <typename T>
-int launch_multi(const TcDwSeg* segs, int nseg, int mode, int ldx, int ldy, int lddy, int B, int H, int W, int add_input, int accumulate,
-                 int groups, long long wstride, void* ws, long long ws_bytes, hipStream_t s) {
+int launch_multi(const TcDwSeg* segs, int nseg, int mode, int add_input, int accumulate, int groups, long long wstride, void* ws,
+                 long long ws_bytes, hipStream_t s) {
     constexpr int VEC = Vec16<T>::N;
     DwMultiDev a;
-    a.n = nseg; a.lds_ = ldx; a.ldy = ldy; a.lddy = lddy; a.B = B; a.H = H; a.W = W; a.add_input = add_input; a.accumulate = accumulate;
+    a.n = nseg; a.add_input = add_input; a.accumulate = accumulate;
     a.wstride = wstride;
     long long blk = 0, part_floats = 0, cnts = 0;
     int smem_q = 0;
@@ -747,6 +750,8 @@ int launch_multi(const TcDwSeg* segs, int nseg, int mode, int ldx, int ldy, int 
         const TcDwSeg& g = segs[i];
         DwSegDev& d = a.s[i];
         d.src = g.x; d.w = g.w; d.bias = g.bias; d.y = g.y; d.dy = g.dy; d.dw = g.dw; d.db = g.db; d.C = g.C; d.k = g.k;
+        d.lds_ = g.ldx; d.ldy = g.ldy; d.lddy = g.lddy; d.B = g.B; d.H = g.H; d.W = g.W;
+        const int B = g.B, H = g.H, W = g.W;
         d.cg = dw_pick_cg<T>(g.C);
         d.chunks = (g.C + d.cg * VEC - 1) / (d.cg * VEC);
         const int TH = (256 / d.cg) / 4;
@@ -854,27 +859,27 @@ extern "C" int tc_dwconv_bwd_weight(const void* dy, int lddy, const void* x, int
     return tc_launch_status();
 }
 
-extern "C" int tc_dwconv_multi(const TcDwSeg* segs, int nseg, int mode, int ldx, int ldy, int lddy, int B, int H, int W, int add_input,
-                               int accumulate, int groups, long long wstride, void* ws, long long ws_bytes, int dtype, void* stream) {
-    if (!segs || nseg < 1 || nseg > 3 || mode < 0 || mode > 2 || groups < 1 || B <= 0 || H <= 0 || W <= 0) return TC_ERR_ARG;
+extern "C" int tc_dwconv_multi(const TcDwSeg* segs, int nseg, int mode, int add_input, int accumulate, int groups, long long wstride,
+                               void* ws, long long ws_bytes, int dtype, void* stream) {
+    if (!segs || nseg < 1 || nseg > DW_MULTI_MAX || mode < 0 || mode > 2 || groups < 1) return TC_ERR_ARG;
     bool tile_ok = true;
     for (int i = 0; i < nseg; ++i) {
         const TcDwSeg& g = segs[i];
-        if (!g.x || !dw_args_ok(B, H, W, g.C, g.k, 1, add_input) || (mode != 2 && (!g.w || !g.y)) || (mode == 2 && (!g.dy || !g.dw)))
+        if (!g.x || !dw_args_ok(g.B, g.H, g.W, g.C, g.k, 1, add_input) || (mode != 2 && (!g.w || !g.y)) || (mode == 2 && (!g.dy || !g.dw)))
             return TC_ERR_ARG;
         const void* second = mode == 2 ? g.dy : g.y;
-        const int ld2 = mode == 2 ? lddy : ldy;
-        if (dtype == TC_F32) tile_ok = tile_ok && dw_tile_ok<float>(g.x, ldx, second, ld2, g.C);
-        else tile_ok = tile_ok && dw_tile_ok<bf16_t>(g.x, ldx, second, ld2, g.C);
+        const int ld2 = mode == 2 ? g.lddy : g.ldy;
+        if (dtype == TC_F32) tile_ok = tile_ok && dw_tile_ok<float>(g.x, g.ldx, second, ld2, g.C);
+        else tile_ok = tile_ok && dw_tile_ok<bf16_t>(g.x, g.ldx, second, ld2, g.C);
     }
-    if (tile_ok) TC_DISPATCH_DTYPE(dtype, return (launch_multi<T>(segs, nseg, mode, ldx, ldy, lddy, B, H, W, add_input, accumulate, groups,
-                                                                  wstride, ws, ws_bytes, (hipStream_t)stream)));
+    if (tile_ok) TC_DISPATCH_DTYPE(dtype, return (launch_multi<T>(segs, nseg, mode, add_input, accumulate, groups, wstride, ws, ws_bytes,
+                                                                  (hipStream_t)stream)));
     for (int i = 0; i < nseg; ++i) {                          // unaligned views: one launch per segment through the single entries
         const TcDwSeg& g = segs[i];
         int rc;
-        if (mode == 0) rc = tc_dwconv_fwd(g.x, ldx, g.w, g.bias, g.y, ldy, B, H, W, g.C, g.k, 1, add_input, groups, wstride, dtype, stream);
-        else if (mode == 1) rc = tc_dwconv_bwd_input(g.x, ldx, g.w, g.y, ldy, B, H, W, g.C, g.k, 1, add_input, accumulate, groups, wstride, dtype, stream);
-        else rc = tc_dwconv_bwd_weight(g.dy, lddy, g.x, ldx, g.dw, g.db, B, H, W, g.C, g.k, 1, groups, wstride, ws, ws_bytes, dtype, stream);
+        if (mode == 0) rc = tc_dwconv_fwd(g.x, g.ldx, g.w, g.bias, g.y, g.ldy, g.B, g.H, g.W, g.C, g.k, 1, add_input, groups, wstride, dtype, stream);
+        else if (mode == 1) rc = tc_dwconv_bwd_input(g.x, g.ldx, g.w, g.y, g.ldy, g.B, g.H, g.W, g.C, g.k, 1, add_input, accumulate, groups, wstride, dtype, stream);
+        else rc = tc_dwconv_bwd_weight(g.dy, g.lddy, g.x, g.ldx, g.dw, g.db, g.B, g.H, g.W, g.C, g.k, 1, groups, wstride, ws, ws_bytes, dtype, stream);
         if (rc != TC_OK) return rc;
     }
     return TC_OK;

@@ -656,44 +656,51 @@ class Graph:
         self._rec(bwd)
         return out
 
-    def dwconv_multi(self, xs: List[Var], ws: List[P], bs: List[Optional[P]], B: int, H: int, W: int, ks: List[int],
-                     outs: List[Var]) -> None:
-        """Stride-1 depthwise convolutions of different kernel sizes on column slices of ONE buffer, written to column slices of
-        ONE output buffer, in one launch each for forward, input gradient and weight gradient (tc_dwconv_multi)."""
+    def dwconv_multi(self, xs: List[Var], ws: List[P], bs: List[Optional[P]], geo, ks: List[int], outs: List[Optional[Var]],
+                     add_input: bool = False) -> List[Var]:
+        """Up to four independent stride-1 depthwise convolutions in one launch each for forward, input gradient and weight
+        gradient (tc_dwconv_multi): column slices of one map with different kernel sizes (crpe), or different maps (the per-scale
+        MixFFNs of a bridge layer).  geo = (B, H, W) for all, or a list of them per segment; outs[i] None -> a new buffer."""
         n, Gn = len(xs), self.ngroups
-        assert 1 <= n <= 3 and all(x.ld == xs[0].ld for x in xs) and all(o.ld == outs[0].ld for o in outs)
+        assert 1 <= n <= 4
+        geos = [geo] * n if isinstance(geo[0], int) else list(geo)
         gs = ws[0].gs
+        outs = [o if o is not None else self.new(x.rows, x.cols) for o, x in zip(outs, xs)]
 
-        def segs(xp, wp, bp, yp, dyp, dwp, dbp):
+        def segs(xp, wp, bp, yp, dyp, dwp, dbp, ldx, ldy, lddy):
             arr = (TcDwSeg * n)()
             for i in range(n):
-                arr[i] = TcDwSeg(xp[i], wp[i], bp[i], yp[i], dyp[i], dwp[i], dbp[i], xs[i].cols, ks[i])
+                arr[i] = TcDwSeg(xp[i], wp[i], bp[i], yp[i], dyp[i], dwp[i], dbp[i], xs[i].cols, ks[i], ldx[i], ldy[i], lddy[i], *geos[i])
             return arr
-        none = [None] * n
+        none, zero = [None] * n, [0] * n
         wd, bd = [_ptr(w.data) for w in ws], [_ptr(b.data) if b is not None else None for b in bs]
-        self.L.tc_dwconv_multi(segs([_ptr(x.data) for x in xs], wd, bd, [_ptr(o.data) for o in outs], none, none, none), n, 0, xs[0].ld,
-                               outs[0].ld, 0, B, H, W, 0, 0, Gn, gs, None, 0, self.dt, self.stream)
+        self.L.tc_dwconv_multi(segs([_ptr(x.data) for x in xs], wd, bd, [_ptr(o.data) for o in outs], none, none, none,
+                                    [x.ld for x in xs], [o.ld for o in outs], zero), n, 0, int(add_input), 0, Gn, gs, None, 0,
+                               self.dt, self.stream)
 
         def bwd():
             dys = [self.grad_of(o) for o in outs]
             if any(d is None for d in dys):
+                assert all(d is None for d in dys)
                 return
-            ldd = dys[0].stride(0)
-            assert all(d.stride(0) == ldd for d in dys)
+            ldd = [d.stride(0) for d in dys]
             if xs[0].requires_grad:
                 g = [self.wgrad(x) for x in xs]
                 acc = g[0][1]
-                assert all(a == acc for _, a in g) and all(t.stride(0) == g[0][0].stride(0) for t, _ in g)
-                self.L.tc_dwconv_multi(segs([_ptr(d) for d in dys], wd, none, [_ptr(t) for t, _ in g], none, none, none), n, 1, ldd,
-                                       g[0][0].stride(0), 0, B, H, W, 0, acc, Gn, gs, None, 0, self.dt, self.stream)
+                assert all(a == acc for _, a in g)
+                self.L.tc_dwconv_multi(segs([_ptr(d) for d in dys], wd, none, [_ptr(t) for t, _ in g], none, none, none, ldd,
+                                            [t.stride(0) for t, _ in g], zero), n, 1, int(add_input), acc, Gn, gs, None, 0, self.dt,
+                                       self.stream)
             if ws[0].grad is not None:
                 def dwgrad():
                     wk = _workspace(self.dev, self.stream)
                     self.L.tc_dwconv_multi(segs([_ptr(x.data) for x in xs], none, none, none, [_ptr(d) for d in dys],
-                                                [_ptr(w.grad) for w in ws], [_ptr(b.grad) if b is not None else None for b in bs]), n, 2,
-                                           xs[0].ld, 0, ldd, B, H, W, 0, 0, Gn, gs, wk.data_ptr(), wk.numel(), self.dt, self.stream)
+                                                [_ptr(w.grad) for w in ws], [_ptr(b.grad) if b is not None else None for b in bs],
+                                                [x.ld for x in xs], zero, ldd), n, 2, 0, 0, Gn, gs, wk.data_ptr(), wk.numel(), self.dt,
+                                           self.stream)
                 self._weight_grad(dwgrad, reads=dys[0])
         self._rec(bwd)
+        return outs
 
     def batchnorm(self, x: Var, gamma: P, beta: P, running_mean: torch.Tensor, running_var: torch.Tensor, act: int = ACT_NONE,
                   residual: Optional[Var] = None, out: Optional[Var] = None) -> Var:

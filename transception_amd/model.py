@@ -517,7 +517,7 @@ def _factor_att(M, G, n: Var, blk: str, enc: str, B: int, side: int, residual: O
         wts.append(M._P(G, f"{enc}.crpe.conv_list.{i}.weight")); bss.append(M._P(G, f"{enc}.crpe.conv_list.{i}.bias"))
         c0 += w
     if MULTI_CRPE:
-        G.dwconv_multi(xs, wts, bss, B, side, side, kss, outs)             # the three window sizes in one launch
+        G.dwconv_multi(xs, wts, bss, (B, side, side), kss, outs)           # the three window sizes in one launch
     else:
         for x_, w_, b_, k_, o_ in zip(xs, wts, bss, kss, outs):
             G.dwconv(x_, w_, b_, B, side, side, k_, 1, False, out=o_)
@@ -655,11 +655,10 @@ def _bridge_layer(M, G, X: Var, li: int, B: int, sides, ntok, R, N6) -> Var:
         # gradient GEMMs of each level in one launch): four independent chains of small kernels share the CUs
         nm = [f"{name}.mixffn{s + 1}" for s in range(4)]
         hs = G.linear_many([(view(tx, s), *_lin(M, G, nm[s] + ".fc1"), G.new(geo[s][0], 4 * geo[s][1]), None) for s in range(4)])
-        acts = []
-        for s in range(4):
-            d = G.dwconv(hs[s], M._P(G, nm[s] + ".dwconv.dwconv.weight"), M._P(G, nm[s] + ".dwconv.dwconv.bias"), B, sides[s], sides[s], 3,
-                         1, True)
-            acts.append(_ln(M, G, d, nm[s] + ".norm1", act=ACT_GELU))
+        ds = G.dwconv_multi(hs, [M._P(G, nm[s] + ".dwconv.dwconv.weight") for s in range(4)],
+                            [M._P(G, nm[s] + ".dwconv.dwconv.bias") for s in range(4)], [(B, sides[s], sides[s]) for s in range(4)],
+                            [3] * 4, [None] * 4, add_input=True)
+        acts = [_ln(M, G, ds[s], nm[s] + ".norm1", act=ACT_GELU) for s in range(4)]
         G.linear_many([(acts[s], *_lin(M, G, nm[s] + ".fc2"), view(tx2, s), view(tx1, s)) for s in range(4)])
         return tx2
     with G.parallel(4, shared=(tx, tx1)) as par:    # the four per-scale MixFFNs are independent
