@@ -33,6 +33,16 @@ def _worker(rank, world, port, ret):
         _gflat = torch.full((1000,), float(rank + 1))
     allreduce_gradients(Fake)
     ok_grad = bool((Fake._gflat == 3.0).all())
+
+    class Sparse:                                   # live gradients in two far-apart ranges: only those travel
+        _gflat = torch.full((2_000_000,), float(rank + 1))
+        _used_views = {0: (0, (10, 10)), 1: (128, (50,)), 2: (1_500_000, (1000,))}
+    from transception_amd.train import gradient_buckets
+    ok_grad = ok_grad and gradient_buckets(Sparse) == [(0, 178), (1_500_000, 1_501_000)]
+    allreduce_gradients(Sparse)
+    g2 = Sparse._gflat
+    ok_grad = ok_grad and bool((g2[:178] == 3.0).all() and (g2[1_500_000:1_501_000] == 3.0).all() and
+                               (g2[178:1_500_000] == float(rank + 1)).all())
     ret[rank] = (ok_loss, ok_grad)
     dist.destroy_process_group()
 

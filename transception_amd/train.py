@@ -148,10 +148,30 @@ class FusedSGD:
         self.steps += 1
 
 
+def gradient_buckets(model, max_gap: int = 1 << 18):
+    """Contiguous ranges of the flat gradient arena that hold live gradients, merged across gaps of < max_gap elements: the
+    332 grad-less tensors (9.2 M of 47.3 M elements, SURVEY 8e: `conv1_1_s*`, decoder_3's unused blocks, ...) are not worth
+    sending, but neither are dozens of tiny collectives.  Falls back to the whole arena before the first forward."""
+    views = getattr(model, "_used_views", None)
+    n = model._gflat.numel()
+    if not views:
+        return [(0, n)]
+    rng = sorted((off, off + math.prod(shape)) for off, shape in views.values())
+    out = [list(rng[0])]
+    for a, b in rng[1:]:
+        if a - out[-1][1] < max_gap:
+            out[-1][1] = max(out[-1][1], b)
+        else:
+            out.append([a, b])
+    return [(a, min(b, n)) for a, b in out]
+
+
 def allreduce_gradients(model, group=None):
-    """C1: one all-reduce(sum) of the flat gradient arena over RCCL/xGMI (gloo in CPU tests)."""
+    """C1: all-reduce(sum) of the live parts of the flat gradient arena over RCCL/xGMI (gloo in CPU tests): a handful of
+    large buckets, every rank the same ones (the used set is a property of the architecture)."""
     if dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(model._gflat, group=group)
+        for a, b in gradient_buckets(model):
+            dist.all_reduce(model._gflat[a:b], group=group)
 
 
 def train_step(model, loss_fn: SegLoss, opt: FusedSGD, images: torch.Tensor, labels: torch.Tensor, group=None):
