@@ -143,7 +143,7 @@ def _workspace(device, stream_ptr: int, tag: str = "") -> torch.Tensor:
     key = (str(device), int(stream_ptr or 0), tag)
     ws = _WORKSPACES.get(key)
     if ws is None:
-        ws = _WORKSPACES[key] = torch.zeros(WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+        ws = _WORKSPACES[key] = torch.zeros(WORKSPACE_BYTES * (8 if tag == "many" else 1), dtype=torch.uint8, device=device)
     return ws
 
 
@@ -505,7 +505,7 @@ class Graph:
         n = len(items)
         assert self.ngroups == 1 and 1 <= n <= 4
         wsb = _workspace(self.dev, self.stream, "many")
-        sl = (wsb.numel() // 8) & ~16383                    # a private workspace slice per problem (fix-up counters + partials)
+        sl = (wsb.numel() // 8) & ~16383                    # a private, full-size workspace slice per problem (counters + partials)
 
         def desc(i, *a, **k):
             g = self._gemm_desc(*a, use_ws=False, **k)
