@@ -604,29 +604,41 @@ def _channel_att(M, G, n: Var, X: Optional[Var], name: str, B: int, ntok: List[i
     return tx1
 
 
-def _scale_reduce(M, G, n: Var, name: str, B: int, sides: List[int], ntok: List[int], R: List[int]) -> Var:
-    """Scale_reduce, MSTr.py:2225-2249 (Appendix C.4): k=s patchify convs + channel de-interleave + LN -> [B*Nk, 64]."""
+def _scale_reduce(M, G, n: Var, name: str, B: int, sides: List[int], ntok: List[int], R: List[int], extra=None):
+    """Scale_reduce, MSTr.py:2225-2249 (Appendix C.4): k=s patchify convs + channel de-interleave + LN -> [B*Nk, 64].
+    extra = (x, W, b): one more independent Linear (the attention's q projection) that shares the launch of the three
+    patchified convolutions; its output is returned second."""
     Cd = 64
     Pn = sides[3] * sides[3]
     Nk = Pn * 8 + ntok[3]
     red = G.new(B * Nk, Cd)                                     # image-major K/V source
+    cols = [G.patchify(n, R[s] * Cd, sides[s] * sides[s] * Cd * MULT[s], B, sides[s], sides[s], Cd * MULT[s], SR_K[s]) for s in range(3)]
+    lins = [_lin(M, G, f"{name}.sr{s}") for s in range(3)]
+    xo = None
+    if MANY_MIXFFN and not G.use_streams and G.ngroups == 1:
+        items = [(cols[s], lins[s][0], lins[s][1], G.new(cols[s].rows, lins[s][0].data.shape[0]), None) for s in range(3)]
+        if extra is not None:
+            items.append((extra[0], extra[1], extra[2], G.new(extra[0].rows, extra[1].data.shape[0]), None))
+        outs = G.linear_many(items)
+        os_, xo = outs[:3], (outs[3] if extra is not None else None)
+    else:
+        os_ = [G.linear(cols[s], *lins[s]) for s in range(3)]
+        if extra is not None:
+            xo = G.linear(*extra)
     roff = 0
     for s in range(3):
-        Cm = Cd * MULT[s]
-        cols = G.patchify(n, R[s] * Cd, sides[s] * sides[s] * Cm, B, sides[s], sides[s], Cm, SR_K[s])
-        o = G.linear(cols, *_lin(M, G, f"{name}.sr{s}"))
-        G.sr_deinterleave(o, red, roff * Cd, Nk * Cd, B, Pn, Cd, MULT[s])
+        G.sr_deinterleave(os_[s], red, roff * Cd, Nk * Cd, B, Pn, Cd, MULT[s])
         roff += MULT[s] * Pn
     G.copy_rows(n, R[3] * Cd, ntok[3] * Cd, red, roff * Cd, Nk * Cd, B, ntok[3], Cd)
-    return _ln(M, G, red, name + ".norm")
+    rn = _ln(M, G, red, name + ".norm")
+    return rn if extra is None else (rn, xo)
 
 
 def _self_att(M, G, n: Var, X: Optional[Var], name: str, B: int, sides: List[int], ntok: List[int], R: List[int], N6: int) -> Var:
     """M_EfficientSelfAtten, MSTr.py:2267-2292: one head, d = 64, keys/values from the reduced token set."""
     Cd = 64
     Nk = sides[3] * sides[3] * 8 + ntok[3]
-    q = G.linear(n, *_lin(M, G, name + ".q"))
-    rn = _scale_reduce(M, G, n, name + ".scale_reduce", B, sides, ntok, R)
+    rn, q = _scale_reduce(M, G, n, name + ".scale_reduce", B, sides, ntok, R, extra=(n, *_lin(M, G, name + ".q")))
     kv = G.linear(rn, *_lin(M, G, name + ".kv"))
     k, v = kv.colslice(0, Cd), kv.colslice(Cd, 2 * Cd)
     att = G.new(B * N6, Cd)
