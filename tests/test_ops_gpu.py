@@ -579,3 +579,60 @@ def test_dwconv_multi_grouped(G):
     run_bwd(G, out, gy)
     close(G.grad_of(xv), xr.grad, 2e-5, 5e-5, "dx")
     close(garena, ar.grad, 5e-5, 1e-4, "dw/db of all groups")
+
+
+def _flat_params(shapes, tag):
+    """n Linear layers laid out like the model's flat arena: [W0 | b0 | W1 | b1 | ...] with fp32 gradient mirrors."""
+    from transception_amd.engine import P
+    N, K = shapes
+    n = 3
+    arena = T(tag, (n * (N * K + N),), 0.2).to(DEV)
+    garena = torch.zeros_like(arena)
+    Ws = [P(arena[i * (N * K + N):i * (N * K + N) + N * K].view(N, K), garena[i * (N * K + N):i * (N * K + N) + N * K].view(N, K)) for i in range(n)]
+    bs = [P(arena[i * (N * K + N) + N * K:(i + 1) * (N * K + N)], garena[i * (N * K + N) + N * K:(i + 1) * (N * K + N)]) for i in range(n)]
+    return arena, garena, Ws, bs
+
+
+def test_linear_multi_keys_queries_values(G):
+    """linear_multi: three same-shape Linears on one input as ONE batched GEMM; backward = one K=3N product over the gapped weight
+    stack (TcGemm.bgap) + one batched weight-gradient GEMM (EfficientAttention keys/queries/values, MSTr.py:109-111)."""
+    M_, N, K = 392, 64, 64
+    arena, garena, Ws, bs = _flat_params((N, K), "lm.p")
+    x, gy = T("lm.x", (M_, K)), T("lm.g", (M_, 3 * N))
+    xr, ar = x.clone().requires_grad_(), arena.cpu().clone().requires_grad_()
+    per = N * K + N
+    ref = torch.cat([xr @ ar[i * per:i * per + N * K].view(N, K).t() + ar[i * per + N * K:(i + 1) * per] for i in range(3)], 1)
+    ref.backward(gy)
+    xv = mkV(G, x)
+    out = G.new(M_, 3 * N)
+    G.linear_multi(xv, Ws, bs, out)
+    close(out.data, ref, 2e-5, 2e-5, "y")
+    run_bwd(G, out, gy)
+    close(G.grad_of(xv), xr.grad, 2e-5, 1e-4, "dx")
+    close(garena, ar.grad, 5e-5, 1e-4, "dW / db")
+
+
+def test_linear_many_independent_shapes(G):
+    """linear_many: independent Linears of different shapes (+ residual) through tc_gemm_multi, forward and backward."""
+    specs = [(300, 64, 256), (128, 128, 512), (70, 320, 1280)]
+    items, refs, leaves = [], [], []
+    for i, (M_, K, N) in enumerate(specs):
+        x, W, b, r = T(f"lmy.x{i}", (M_, K)), T(f"lmy.w{i}", (N, K), 0.1), T(f"lmy.b{i}", (N,)), T(f"lmy.r{i}", (M_, N))
+        xr, Wr, br, rr = (t.clone().requires_grad_() for t in (x, W, b, r))
+        refs.append(xr @ Wr.t() + br + rr); leaves.append((xr, Wr, br, rr))
+        items.append((mkV(G, x), mkP(W), mkP(b), G.new(M_, N), mkV(G, r)))
+    outs = G.linear_many(items)
+    for i, (o, ref) in enumerate(zip(outs, refs)):
+        close(o.data, ref, 2e-5, 2e-5, f"y{i}")
+    for i, (M_, K, N) in enumerate(specs):
+        gy = T(f"lmy.g{i}", (M_, N))
+        refs[i].backward(gy)
+        outs[i].root.grad_t = gy.to(DEV).contiguous()
+        outs[i].root.whole_written = True
+    G.backward()
+    torch.cuda.synchronize()
+    for i, (xr, Wr, br, rr) in enumerate(leaves):
+        close(G.grad_of(items[i][0]), xr.grad, 2e-5, 1e-4, f"dx{i}")
+        close(items[i][1].grad, Wr.grad, 5e-5, 1e-4, f"dW{i}")
+        close(items[i][2].grad, br.grad, 5e-5, 1e-4, f"db{i}")
+        close(G.grad_of(items[i][4]), rr.grad, 1e-6, 1e-6, f"dres{i}")
