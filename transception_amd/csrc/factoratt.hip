@@ -67,10 +67,31 @@ __device__ __forceinline__ void fa_softmax_cols(float* e, float* cmax, float* ci
     __syncthreads();
 }
 
+// the same head tile kept in its STORAGE type (bf16 operands lose nothing that way and q / v / do take half the LDS: two
+// workgroups per CU at N = 784 instead of one)
+template <typename T>
+__device__ __forceinline__ void fa_load_tile_raw(T* dst, const T* src, int ld, int N, int Ch) {
+    constexpr int VEC = V16<T>::N;
+    const int nv = Ch / VEC, total = N * nv;
+#pragma unroll 4
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int n = i / nv, cv = i - n * nv;
+        *reinterpret_cast<uint4*>(dst + n * Ch + cv * VEC) = *reinterpret_cast<const uint4*>(src + (long long)n * ld + cv * VEC);
+    }
+}
+__device__ __forceinline__ float fa_get(const float* p, int i) { return p[i]; }
+__device__ __forceinline__ float fa_get(const bf16_t* p, int i) { return bf2f(p[i]); }
+__device__ __forceinline__ void fa_get8(const float* p, float* o) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+__device__ __forceinline__ void fa_get8(const bf16_t* p, float* o) { unpack16<bf16_t>(*reinterpret_cast<const uint4*>(p), o); }
+
 // out[i][j] = sum_n a[n,i] * b[n,j]   (Ch x Ch, Ch a multiple of 8).  A thread owns (row i, 8 consecutive j) for the rows
 // n = rl, rl + RL, ...: one read of a[n,i], two 16-byte reads of b[n, j0..j0+7], 8 FMAs; the RL row lanes of an output sit next to
 // each other in a wave and are folded with shuffles.  (One thread per output walking all N rows took ~10 us per product.)
-__device__ __forceinline__ void fa_gram(float* out, const float* a, const float* b, int N, int Ch) {
+template <typename TA, typename TB>
+__device__ __forceinline__ void fa_gram(float* out, const TA* a, const TB* b, int N, int Ch) {
     const int tid = threadIdx.x, jb = Ch >> 3, combos = Ch * jb;
     int RL = 256 / combos;                                  // 32 (Ch 8), 8 (Ch 16), 1 (Ch 40)
     RL = RL >= 32 ? 32 : (RL >= 16 ? 16 : (RL >= 8 ? 8 : (RL >= 4 ? 4 : (RL >= 2 ? 2 : 1))));
@@ -83,10 +104,11 @@ __device__ __forceinline__ void fa_gram(float* out, const float* a, const float*
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc[u] = 0.f;
         for (int n = rl; n < N; n += RL) {
-            const float ai = a[n * Ch + i];
-            const float4 b0 = *reinterpret_cast<const float4*>(b + n * Ch + j0), b1 = *reinterpret_cast<const float4*>(b + n * Ch + j0 + 4);
-            acc[0] += ai * b0.x; acc[1] += ai * b0.y; acc[2] += ai * b0.z; acc[3] += ai * b0.w;
-            acc[4] += ai * b1.x; acc[5] += ai * b1.y; acc[6] += ai * b1.z; acc[7] += ai * b1.w;
+            const float ai = fa_get(a, n * Ch + i);
+            float bv[8];
+            fa_get8(b + n * Ch + j0, bv);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] += ai * bv[u];
         }
         for (int o = RL >> 1; o > 0; o >>= 1) {
 #pragma unroll
@@ -107,18 +129,18 @@ __global__ __launch_bounds__(256) void factor_att_fwd_kernel(const T* __restrict
     constexpr int VEC = V16<T>::N;
     extern __shared__ float sm[];
     float* e = sm;                       // [N][Ch]  k, then exp(k - max)
-    float* vs = e + N * Ch;              // [N][Ch]
-    float* qs = vs + N * Ch;             // [N][Ch]
-    float* ctx = qs + N * Ch;            // [Ch][Ch]
+    float* ctx = e + N * Ch;             // [Ch][Ch]
     float* cmax = ctx + Ch * Ch;
     float* cinv = cmax + Ch;
     float* red = cinv + Ch;              // [256/Ch][Ch] <= 256
+    T* vs = reinterpret_cast<T*>(red + 256);      // [N][Ch] storage type
+    T* qs = vs + N * Ch;
     const int bt = blockIdx.x / heads, hd = blockIdx.x - bt * heads, tid = threadIdx.x;
     const long long row0 = (long long)bt * N;
     const int col0 = hd * Ch;
     fa_load_tile<T>(e, k + row0 * ld + col0, ld, N, Ch);
-    fa_load_tile<T>(vs, v + row0 * ld + col0, ld, N, Ch);
-    fa_load_tile<T>(qs, q + row0 * ld + col0, ld, N, Ch);
+    fa_load_tile_raw<T>(vs, v + row0 * ld + col0, ld, N, Ch);
+    fa_load_tile_raw<T>(qs, q + row0 * ld + col0, ld, N, Ch);
     __syncthreads();
     fa_softmax_cols(e, cmax, cinv, red, N, Ch);
     fa_gram(ctx, e, vs, N, Ch);
@@ -133,14 +155,14 @@ __global__ __launch_bounds__(256) void factor_att_fwd_kernel(const T* __restrict
         unpack16<T>(*reinterpret_cast<const uint4*>(convv + (row0 + n) * ldc + col0 + j0), cv);
 #pragma unroll
         for (int u = 0; u < VEC; ++u) acc[u] = 0.f;
-        const float* qr = qs + n * Ch;
+        const T* qr = qs + n * Ch;
         for (int c = 0; c < Ch; ++c) {
-            const float qc = qr[c];
+            const float qc = fa_get(qr, c);
 #pragma unroll
             for (int u = 0; u < VEC; ++u) acc[u] += qc * ctx[c * Ch + j0 + u];
         }
 #pragma unroll
-        for (int u = 0; u < VEC; ++u) acc[u] = scale * acc[u] + qr[j0 + u] * cv[u];
+        for (int u = 0; u < VEC; ++u) acc[u] = scale * acc[u] + fa_get(qr, j0 + u) * cv[u];
         *reinterpret_cast<uint4*>(o + (row0 + n) * ldo + col0 + j0) = pack16<T>(acc);
     }
 }
@@ -153,22 +175,22 @@ __global__ __launch_bounds__(256) void factor_att_bwd_kernel(const T* __restrict
                                                              T* __restrict__ dconvv, int lddc, int N, int Ch, int heads, float scale) {
     constexpr int VEC = V16<T>::N;
     extern __shared__ float sm[];
-    float* e = sm;                       // softmax(k) (normalised)
-    float* vs = e + N * Ch;
-    float* qs = vs + N * Ch;
-    float* gs = qs + N * Ch;             // do
-    float* ctx = gs + N * Ch;
+    float* e = sm;                       // softmax(k) (normalised), fp32
+    float* ctx = e + N * Ch;
     float* dctx = ctx + Ch * Ch;
-    float* tcol = dctx + Ch * Ch;        // [Ch]
+    float* tcol = dctx + Ch * Ch;        // [Ch] (+ padding to 16 bytes)
+    T* vs = reinterpret_cast<T*>(tcol + ((Ch + 3) & ~3));       // v, q, do tiles in the storage type
+    T* qs = vs + N * Ch;
+    T* gs = qs + N * Ch;
     const int bt = blockIdx.x / heads, hd = blockIdx.x - bt * heads, tid = threadIdx.x;
     const long long row0 = (long long)bt * N;
     const int col0 = hd * Ch;
     const float* cmax = stats + ((long long)blockIdx.x * 2) * Ch;
     const float* cinv = cmax + Ch;
     fa_load_tile<T>(e, k + row0 * ld + col0, ld, N, Ch);
-    fa_load_tile<T>(vs, v + row0 * ld + col0, ld, N, Ch);
-    fa_load_tile<T>(qs, q + row0 * ld + col0, ld, N, Ch);
-    fa_load_tile<T>(gs, go + row0 * ldgo + col0, ldgo, N, Ch);
+    fa_load_tile_raw<T>(vs, v + row0 * ld + col0, ld, N, Ch);
+    fa_load_tile_raw<T>(qs, q + row0 * ld + col0, ld, N, Ch);
+    fa_load_tile_raw<T>(gs, go + row0 * ldgo + col0, ldgo, N, Ch);
     __syncthreads();
     for (int i = tid; i < N * Ch; i += 256) { const int c = i % Ch; e[i] = __expf(e[i] - cmax[c]) * cinv[c]; }
     __syncthreads();
@@ -182,14 +204,14 @@ __global__ __launch_bounds__(256) void factor_att_bwd_kernel(const T* __restrict
     for (int i = tid; i < N * nv; i += 256) {
         const int n = i / nv, c0 = (i - n * nv) * VEC;
         const long long r = row0 + n;
-        const float* gr = gs + n * Ch;
-        const float* vr = vs + n * Ch;
+        const T* gr = gs + n * Ch;
+        const T* vr = vs + n * Ch;
         const float* er = e + n * Ch;
         float a_q[VEC], a_ks[VEC], a_v[VEC], cv[VEC], oc[VEC];
 #pragma unroll
         for (int u = 0; u < VEC; ++u) a_q[u] = a_ks[u] = a_v[u] = 0.f;
         for (int j = 0; j < Ch; ++j) {
-            const float gj = gr[j], vj = vr[j], ej = er[j];
+            const float gj = fa_get(gr, j), vj = fa_get(vr, j), ej = er[j];
 #pragma unroll
             for (int u = 0; u < VEC; ++u) {
                 a_q[u] += gj * ctx[(c0 + u) * Ch + j];        // dq[n,c]  += scale * sum_j do[n,j] ctx[c,j]
@@ -201,7 +223,10 @@ __global__ __launch_bounds__(256) void factor_att_bwd_kernel(const T* __restrict
         T* pq = dq + r * ldd + col0 + c0; T* pk = dk + r * ldd + col0 + c0; T* pv = dv + r * ldd + col0 + c0;
         float old[VEC];
 #pragma unroll
-        for (int u = 0; u < VEC; ++u) { oc[u] = gr[c0 + u] * qs[n * Ch + c0 + u]; a_q[u] = scale * a_q[u] + gr[c0 + u] * cv[u]; a_ks[u] = er[c0 + u] * (a_ks[u] - tcol[c0 + u]); }
+        for (int u = 0; u < VEC; ++u) {
+            const float gc = fa_get(gr, c0 + u);
+            oc[u] = gc * fa_get(qs, n * Ch + c0 + u); a_q[u] = scale * a_q[u] + gc * cv[u]; a_ks[u] = er[c0 + u] * (a_ks[u] - tcol[c0 + u]);
+        }
         if (acc_q) { unpack16<T>(*reinterpret_cast<const uint4*>(pq), old);
 #pragma unroll
             for (int u = 0; u < VEC; ++u) a_q[u] += old[u]; }
@@ -227,7 +252,8 @@ extern "C" int tc_factor_att_fwd(const void* q, const void* k, const void* v, in
     if (!q || !k || !v || !convv || !o || !stats || Bt <= 0 || N <= 0 || heads <= 0 || Ch <= 0 || Ch > FA_MAXCH) return TC_ERR_ARG;
     const int vec = dtype == TC_F32 ? 4 : 8;
     if (Ch % 8 || ld % vec || ldc % vec || ldo % vec || (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)convv | (uintptr_t)o) & 15)) return TC_ERR_ARG;
-    const size_t smem = sizeof(float) * ((size_t)3 * N * Ch + (size_t)Ch * Ch + 2 * Ch + 256);
+    const size_t esz = dtype == TC_F32 ? 4 : 2;
+    const size_t smem = sizeof(float) * ((size_t)N * Ch + (size_t)Ch * Ch + 2 * Ch + 256) + 2 * esz * N * Ch;
     if (smem > 150 * 1024) return TC_ERR_ARG;
     TC_DISPATCH_DTYPE(dtype, {
         if (smem > 64 * 1024) hipFuncSetAttribute((const void*)factor_att_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -247,7 +273,8 @@ extern "C" int tc_factor_att_bwd(const void* q, const void* k, const void* v, in
     if (Ch % 8 || ld % vec || ldc % vec || ldgo % vec || ldd % vec || lddc % vec ||
         (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)convv | (uintptr_t)go | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv | (uintptr_t)dconvv) & 15))
         return TC_ERR_ARG;
-    const size_t smem = sizeof(float) * ((size_t)4 * N * Ch + (size_t)2 * Ch * Ch + Ch);
+    const size_t esz = dtype == TC_F32 ? 4 : 2;
+    const size_t smem = sizeof(float) * ((size_t)N * Ch + (size_t)2 * Ch * Ch + ((Ch + 3) & ~3)) + 3 * esz * N * Ch;
     if (smem > 150 * 1024) return TC_ERR_ARG;
     TC_DISPATCH_DTYPE(dtype, {
         if (smem > 64 * 1024) hipFuncSetAttribute((const void*)factor_att_bwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
