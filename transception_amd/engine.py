@@ -56,7 +56,7 @@ class Var:
 
     Children made by colslice()/rowslice()/reshape() share the root's storage *and* the root's gradient buffer;
     every view knows the rectangle of the root it covers so that gradient writes from overlapping views accumulate."""
-    __slots__ = ("data", "root", "path", "kids", "grad_t", "whole_written", "written", "requires_grad", "region", "reshaped")
+    __slots__ = ("data", "root", "path", "kids", "grad_t", "whole_written", "written", "requires_grad", "region", "reshaped", "covered")
 
     def __init__(self, data: torch.Tensor, root: "Var" = None, path=None, requires_grad: bool = True, region=None,
                  reshaped: bool = False):
@@ -70,6 +70,7 @@ class Var:
         self.written: List[tuple] = []                 # root only: rectangles (r0, r1, c0, c1) that received a gradient
         self.requires_grad = requires_grad
         self.region = region if region is not None else (0, data.shape[0], 0, data.shape[1])   # in root coordinates
+        self.covered = False                           # root only: slice writers are known to cover the whole gradient before any read
         self.reshaped = reshaped
 
     rows = property(lambda s: s.data.shape[0])
@@ -256,8 +257,12 @@ class Graph:
         self.n_launch = 0
 
     # ------------------------------------------------------------------ memory
-    def new(self, rows: int, cols: int, requires_grad: bool = True) -> Var:
-        return Var(_empty((rows, cols), self.dtype, self.dev), requires_grad=requires_grad)
+    def new(self, rows: int, cols: int, requires_grad: bool = True, covered: bool = False) -> Var:
+        """covered=True: every part of this buffer's gradient is written by some slice writer before anything reads it (the
+        q | k | v column split, the per-scale row split of the bridge), so its gradient buffer needs no zero fill."""
+        v = Var(_empty((rows, cols), self.dtype, self.dev), requires_grad=requires_grad)
+        v.covered = covered
+        return v
 
     def f32(self, *shape) -> torch.Tensor:
         return _empty(shape, torch.float32, self.dev)
@@ -284,7 +289,7 @@ class Graph:
                 assert r.grad_t.stride() == r.data.stride(), "gradient layout must mirror the data layout"
             else:
                 assert r.data.is_contiguous()
-                r.grad_t = torch.zeros_like(r.data)        # parts may stay unwritten
+                r.grad_t = _empty(r.data.shape, r.data.dtype, r.data.device) if r.covered else torch.zeros_like(r.data)
         acc = r.whole_written or any(_overlap(reg, w) for w in r.written)
         if whole:
             r.whole_written = True

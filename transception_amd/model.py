@@ -446,7 +446,7 @@ def _eff_attention(M, G, n1: Var, name: str, B: int, N: int, residual: Optional[
     """EfficientAttention with one head, MSTr.py:106-143 (Appendix C.6), + the block's residual add."""
     C = n1.cols
     rows = B * N
-    kqv = G.new(rows, 3 * C)
+    kqv = G.new(rows, 3 * C, covered=True)         # k, q, v gradients (softmax / softmax / bmm backward) cover it
     k, q, v = kqv.colslice(0, C), kqv.colslice(C, 2 * C), kqv.colslice(2 * C, 3 * C)
     lk, lq, lv = _lin(M, G, name + ".keys"), _lin(M, G, name + ".queries"), _lin(M, G, name + ".values")
     if MULTI_QKV and C % 64 == 0 and G.ngroups == 1:
@@ -507,7 +507,7 @@ def _factor_att(M, G, n: Var, blk: str, enc: str, B: int, side: int, residual: O
     C, N = n.cols, side * side
     Bt = B * G.ngroups                              # images of all stacked weight groups
     rows, h, Ch = Bt * N, HEADS, n.cols // HEADS
-    qkv = G.linear(n, *_lin(M, G, blk + ".factoratt_crpe.qkv"))
+    qkv = G.linear(n, *_lin(M, G, blk + ".factoratt_crpe.qkv"), out=G.new(n.rows, 3 * C, covered=FUSED_FACTOR_ATT))
     q, k, v = qkv.colslice(0, C), qkv.colslice(C, 2 * C), qkv.colslice(2 * C, 3 * C)
     convv = G.new(rows, C)
     c0, xs, outs, wts, bss, kss = 0, [], [], [], [], []
