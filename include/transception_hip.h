@@ -74,7 +74,7 @@ int tc_gemm(const TcGemm* g, void* stream);
 /* The two gradient GEMMs of one Linear in ONE launch when both are small-tile bf16 problems (a: dX = dY W, row-major operands,
  * bf16 out; b: dW = dY^T X with fp32 accumulate, transA=1): their workgroups share the grid.  Any other pair: a then b. */
 int tc_gemm_pair(const TcGemm* a, const TcGemm* b, void* stream);
-/* n (<= 8) INDEPENDENT bf16 GEMMs of the kinds a Linear produces (forward transB=1; dX transA=transB=0; dW transA=1 with fp32 C)
+/* n (<= 12) INDEPENDENT bf16 GEMMs of the kinds a Linear produces (forward transB=1; dX transA=transB=0; dW transA=1 with fp32 C)
  * in one grid of 64x64 tiles; each problem that uses the split-K fix-up needs its OWN workspace slice.  Anything else: one launch
  * per problem, in order. */
 int tc_gemm_multi(const TcGemm* g, int n, void* stream);

@@ -577,10 +577,11 @@ __global__ __launch_bounds__(256, 2) void gemm_pair_kernel(GemmPairDev q) {
     }
 }
 
-// Up to 8 independent bf16 GEMMs of the three kinds a Linear produces (y = x W^T: TA=0,TB=1 ; dX = dY W: TA=0,TB=0 ; dW = dY^T X:
+// Up to 12 independent bf16 GEMMs of the three kinds a Linear produces (y = x W^T: TA=0,TB=1 ; dX = dY W: TA=0,TB=0 ; dW = dY^T X:
 // TA=1,TB=0, fp32 C) in one grid of 64x64 tiles -- the four per-scale MixFFNs of a bridge layer are independent chains of small
 // GEMMs; level by level their workgroups share the CUs instead of queueing as 4 (forward) or 8 (backward) short launches.
-constexpr int GEMM_MULTI_MAX = 8;
+constexpr int GEMM_MULTI_MAX = 12;
+static_assert(sizeof(GemmDev) * GEMM_MULTI_MAX + 16 * GEMM_MULTI_MAX + 8 <= 4096, "kernel argument block");
 struct GemmMultiDev { GemmDev p[GEMM_MULTI_MAX]; int blk0[GEMM_MULTI_MAX], gx[GEMM_MULTI_MAX], gy[GEMM_MULTI_MAX], kind[GEMM_MULTI_MAX]; int n; };
 __global__ __launch_bounds__(256, 2) void gemm_multi_kernel(GemmMultiDev q) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (64 + 64) * (64 + 8)];

@@ -504,50 +504,74 @@ class Graph:
         self._rec(bwd)
         return out
 
-    def linear_many(self, items: List[Tuple[Var, P, Optional[P], Var, Optional[Var]]]) -> List[Var]:
-        """Independent Linear layers (x, W, b, out, residual) of DIFFERENT shapes in one launch (tc_gemm_multi); their 2n gradient
-        GEMMs in one launch too.  out_i = x_i W_i^T + b_i + residual_i."""
+    def linear_many(self, items: List[tuple]) -> List[Var]:
+        """Independent Linear layers (x, W, b, out, residual[, batch]) of DIFFERENT shapes in one launch (tc_gemm_multi, at most 12
+        problems per launch); their gradient GEMMs likewise.  out_i = x_i W_i^T + b_i + residual_i.  batch = (nb, sx, so, sr) as in
+        linear(): batch j of x / out / residual lives sx / so / sr elements after batch 0 (row re-layout between buffers)."""
         n = len(items)
-        assert self.ngroups == 1 and 1 <= n <= 4
+        assert self.ngroups == 1 and n >= 1
+        items = [tuple(it) + ((None,) if len(it) == 5 else ()) for it in items]
         wsb = _workspace(self.dev, self.stream, "many")
         sl = (wsb.numel() // 8) & ~16383                    # a private, full-size workspace slice per problem (counters + partials)
 
         def desc(i, *a, **k):
             g = self._gemm_desc(*a, use_ws=False, **k)
-            g.ws, g.ws_bytes = wsb.data_ptr() + i * sl, sl
+            if i < 8:
+                g.ws, g.ws_bytes = wsb.data_ptr() + i * sl, sl
             return g
-        arr = (TcGemm * n)()
-        for i, (x, W, b, out, res) in enumerate(items):
+
+        def launch(probs):
+            for c0 in range(0, len(probs), 12):
+                chunk = probs[c0:c0 + 12]
+                arr = (TcGemm * len(chunk))(*chunk)
+                self.n_launch += 1
+                self.L.tc_gemm_multi(arr, len(chunk), self.stream)
+        fw = []
+        for i, (x, W, b, out, res, batch) in enumerate(items):
             N, K = W.data.shape
+            nb, sx, so, sr = batch if batch is not None else (1, 0, 0, 0)
             assert x.cols == K and out.rows == x.rows and out.cols == N
-            arr[i] = desc(i, _ptr(x.data), x.ld, _ptr(W.data), W.data.stride(0), _ptr(out.data), out.ld, x.rows, N, K, 0, 1,
-                          bias=_ptr(b.data) if b is not None else None, R=_ptr(res.data) if res is not None else None,
-                          ldr=res.ld if res is not None else 0)
-        self.n_launch += 1
-        self.L.tc_gemm_multi(arr, n, self.stream)
+            fw.append(desc(i % 12, _ptr(x.data), x.ld, _ptr(W.data), W.data.stride(0), _ptr(out.data), out.ld, x.rows, N, K, 0, 1,
+                           bias=_ptr(b.data) if b is not None else None, R=_ptr(res.data) if res is not None else None,
+                           ldr=res.ld if res is not None else 0, nb1=nb, sA=(sx, 0), sC=(so, 0), sR=(sr, 0)))
+        launch(fw)
 
         def bwd():
-            probs = []
-            for i, (x, W, b, out, res) in enumerate(items):
+            dxs, dws = [], []
+            waves: List[list] = []                       # dX problems whose outputs overlap must not share a launch
+            for i, (x, W, b, out, res, batch) in enumerate(items):
                 dy = self.grad_of(out)
                 if dy is None:
                     continue
                 N, K = W.data.shape
                 M = x.rows
+                nb, sx, so, sr = batch if batch is not None else (1, 0, 0, 0)
                 if x.requires_grad:
-                    gx, acc = self.wgrad(x)
-                    probs.append(desc(len(probs), _ptr(dy), dy.stride(0), _ptr(W.data), W.data.stride(0), _ptr(gx), gx.stride(0), M, K, N,
-                                      0, 0, acc=acc))
+                    ext = (nb - 1) * sx // x.root.cols if nb > 1 else 0
+                    gx, acc = self.wgrad(x, ext)
+                    reg = (id(x.root), (x.region[0], x.region[1] + ext, x.region[2], x.region[3]))
+                    wi = 0
+                    while wi < len(waves) and any(r[0] == reg[0] and _overlap(r[1], reg[1]) for r, _ in waves[wi]):
+                        wi += 1
+                    if wi == len(waves):
+                        waves.append([])
+                    waves[wi].append((reg, desc(len(waves[wi]) % 8, _ptr(dy), dy.stride(0), _ptr(W.data), W.data.stride(0), _ptr(gx),
+                                                gx.stride(0), M, K, N, 0, 0, acc=acc, nb1=nb, sA=(so, 0), sC=(sx, 0))))
                 if W.grad is not None:
-                    probs.append(desc(len(probs), _ptr(dy), dy.stride(0), _ptr(x.data), x.ld, _ptr(W.grad), W.grad.stride(0), N, K, M, 1, 0,
-                                      acc=1, splitk=self._splitk(N, K, M), c_f32=1,
-                                      rowsum=_ptr(b.grad) if (b is not None and b.grad is not None) else None))
+                    dws.append(self._gemm_desc(_ptr(dy), dy.stride(0), _ptr(x.data), x.ld, _ptr(W.grad), W.grad.stride(0), N, K, M, 1, 0,
+                                               acc=1, splitk=self._splitk(N, K, M), c_f32=1, nb1=nb, sA=(so, 0), sB=(sx, 0),
+                                               atomic=1,      # several problems / batches may share one weight
+                                               rowsum=_ptr(b.grad) if (b is not None and b.grad is not None) else None,
+                                               use_ws=False))
                 if res is not None:
-                    self.pass_grad(res, dy)
-            if probs:
-                arr2 = (TcGemm * len(probs))(*probs)
-                self.n_launch += 1
-                self.L.tc_gemm_multi(arr2, len(probs), self.stream)
+                    if nb == 1:
+                        self.pass_grad(res, dy)
+                    else:
+                        self._pass_grad_batched(res, dy, nb, M, N, so, sr)
+            for wi, wv in enumerate(waves):              # (a later wave accumulates onto what an earlier one stored)
+                launch([d for _, d in wv] + (dws if wi == 0 else []))
+            if not waves:
+                launch(dws)
         self._rec(bwd)
         return [it[3] for it in items]
 

@@ -580,14 +580,19 @@ def _channel_att(M, G, n: Var, X: Optional[Var], name: str, B: int, ntok: List[i
     q/k/v GEMMs scatter their rows from the stage-major buffer into image-major ones, and proj gathers back."""
     Cd = 64
     offs = [sum(ntok[:i]) for i in range(4)]
-    imgs = {}
+    imgs, many = {}, []
     for key in ("k", "q", "v"):
-        buf = G.new(B * N6, Cd)
+        buf = G.new(B * N6, Cd, covered=True)
         Wb = _lin(M, G, f"{name}.{key}")
         for s in range(4):
-            G.linear(n.rowslice(R[s], R[s] + ntok[s]), *Wb, out=buf.rowslice(offs[s], offs[s] + ntok[s]),
-                     batch=(B, ntok[s] * Cd, N6 * Cd, 0))
+            xs_, os_ = n.rowslice(R[s], R[s] + ntok[s]), buf.rowslice(offs[s], offs[s] + ntok[s])
+            if MANY_MIXFFN and not G.use_streams:
+                many.append((xs_, Wb[0], Wb[1], os_, None, (B, ntok[s] * Cd, N6 * Cd, 0)))
+            else:
+                G.linear(xs_, *Wb, out=os_, batch=(B, ntok[s] * Cd, N6 * Cd, 0))
         imgs[key] = buf.reshape(B * Cd, N6)
+    if many:
+        G.linear_many(many)                                     # 3 projections x 4 scales: one launch (and two for the gradients)
     ksm = G.softmax(imgs["k"], 1, 1)
     qsm = G.softmax(imgs["q"], B, 0)
     ctx = G.new(B * Cd, Cd)
@@ -597,10 +602,17 @@ def _channel_att(M, G, n: Var, X: Optional[Var], name: str, B: int, ntok: List[i
     o_img = G.transpose(Op, B)                                  # [B*N6, 64], image-major
     tx1 = G.new(B * N6, Cd)
     Wp = _lin(M, G, name + ".proj")
+    many = []
     for s in range(4):
-        G.linear(o_img.rowslice(offs[s], offs[s] + ntok[s]), *Wp, out=tx1.rowslice(R[s], R[s] + ntok[s]),
-                 residual=X.rowslice(R[s], R[s] + ntok[s]) if X is not None else None,
-                 batch=(B, N6 * Cd, ntok[s] * Cd, ntok[s] * Cd))
+        xs_, os_ = o_img.rowslice(offs[s], offs[s] + ntok[s]), tx1.rowslice(R[s], R[s] + ntok[s])
+        rs_ = X.rowslice(R[s], R[s] + ntok[s]) if X is not None else None
+        bt = (B, N6 * Cd, ntok[s] * Cd, ntok[s] * Cd)
+        if MANY_MIXFFN and not G.use_streams:
+            many.append((xs_, Wp[0], Wp[1], os_, rs_, bt))
+        else:
+            G.linear(xs_, *Wp, out=os_, residual=rs_, batch=bt)
+    if many:
+        G.linear_many(many)
     return tx1
 
 
