@@ -99,7 +99,116 @@ __device__ __forceinline__ void locate_tile(const Segs& sg, int t, int& row_base
     row_base = sg.row0[s] + b * nq;
 }
 
-#if ATT_VAR >= 5
+#if ATT_VAR == 10
+// v10: 6 waves (192 queries) per workgroup over image-flattened 32-query wave tiles: 32 workgroups per image = 512 = 2 per CU
+// exactly (12 waves per CU), K/V staging shared by 192 queries instead of 128, 96-key stages (3 sub-tiles of 32 keys).
+constexpr int NW10 = 6, KB10 = 96, LDT10 = KB10 + 16;     // 224-byte Vt rows = 56 words (24 mod 32) -- see st_t8 note below
+__global__ __launch_bounds__(NW10 * 64, 3) void attn_fwd_seg_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
+                                                                   const bf16_t* __restrict__ V, int ldv, long long skv, bf16_t* __restrict__ O,
+                                                                   int ldo, float* __restrict__ lse, Segs sg, int Nk, float scale) {
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[KB10 * LDR];
+    __shared__ __attribute__((aligned(16))) bf16_t Vt[D * LDT10];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    const int nwt = sg.t32[sg.n], bpi = (nwt + NW10 - 1) / NW10;
+    const int b = blockIdx.x / bpi, wt = (blockIdx.x - b * bpi) * NW10 + wave;
+    int sgi = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) if (i < sg.n && wt >= sg.t32[i]) sgi = i;
+    const int nq = sg.nq[sgi];
+    const int ql = (wt - sg.t32[sgi]) * 32 + j;
+    const bool ok = wt < nwt && ql < nq;
+    const long long qrow = (long long)sg.row0[sgi] + (long long)b * nq + ql;
+    const bf16_t* Kb = K + b * skv;
+    const bf16_t* Vb = V + b * skv;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const uint4 v = ok ? *reinterpret_cast<const uint4*>(Q + qrow * ldq + 16 * ks + 8 * h) : make_uint4(0u, 0u, 0u, 0u);
+        qf[ks] = *reinterpret_cast<const bf16x8*>(&v);
+    }
+    const float qs = scale * LOG2E;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    float m = NEG_BIG, lsum = 0.f;
+    const int krow = pi_row(j);
+    uint4 kr[2], vr[2];
+    auto fmap = [&](int it, int& r, int& c8, int& g) {
+        const int c = wave * 2 + it;                       // 12 chunks of 16 keys x 32 channels
+        g = lane >> 4; r = 16 * (c >> 1) + (lane & 15); c8 = 32 * (c & 1) + 8 * g;
+    };
+    auto fetch = [&](int kb0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int r, c8, g; fmap(i, r, c8, g);
+            const int row = min(kb0 + r, Nk - 1);
+            kr[i] = *reinterpret_cast<const uint4*>(Kb + (long long)row * ldk + c8);
+            vr[i] = *reinterpret_cast<const uint4*>(Vb + (long long)row * ldv + c8);
+        }
+    };
+    fetch(0);
+    for (int kb0 = 0; kb0 < Nk; kb0 += KB10) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int r, c8, g; fmap(i, r, c8, g);
+            *reinterpret_cast<uint4*>(&Ks[r * LDR + c8]) = kr[i];
+            st_t8(Vt, LDT10, c8, r, vr[i], g);
+        }
+        __syncthreads();
+        if (kb0 + KB10 < Nk) fetch(kb0 + KB10);
+#pragma unroll 1
+        for (int sub = 0; sub < KB10 / 32 && kb0 + 32 * sub < Nk; ++sub) {
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            const bf16_t* kp = Ks + (32 * sub + krow) * LDR + 8 * h;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(kp + 16 * ks), qf[ks], s, 0, 0, 0);
+            const int kv0 = kb0 + 32 * sub;
+            if (kv0 + 32 > Nk) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) if (kv0 + 16 * h + r >= Nk) s[r] = NEG_BIG;
+            }
+            float mx = max3f(s[0], s[1], s[2]);
+#pragma unroll
+            for (int r = 3; r < 15; r += 2) mx = max3f(mx, s[r], s[r + 1]);
+            mx = fmaxf(mx, s[15]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * qs;
+            if (__any(mx > m + RESCALE_THR)) {
+                const float mn = fmaxf(m, mx);
+                const float alpha = fast_exp2(m - mn);
+                lsum *= alpha;
+                m = mn;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc0[r] *= alpha; acc1[r] *= alpha; }
+            }
+            float rs = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = fast_exp2(fmaf(s[r], qs, -m)); rs += s[r]; }
+            lsum += rs;
+            const bf16_t* vp = Vt + j * LDT10 + 32 * sub + 16 * h;
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const bf16x8 pb = pack8(s, 8 * k2);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(vp + 8 * k2), pb, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(vp + 32 * LDT10 + 8 * k2), pb, acc1, 0, 0, 0);
+            }
+        }
+    }
+    lsum += __shfl_xor(lsum, 32, 64);
+    if (ok) {
+        const float inv = 1.0f / lsum;
+        bf16_t* orow = O + qrow * ldo;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            st4<bf16_t>(orow + 8 * g + 4 * h, make_float4(acc0[4 * g] * inv, acc0[4 * g + 1] * inv, acc0[4 * g + 2] * inv, acc0[4 * g + 3] * inv));
+            st4<bf16_t>(orow + 32 + 8 * g + 4 * h, make_float4(acc1[4 * g] * inv, acc1[4 * g + 1] * inv, acc1[4 * g + 2] * inv, acc1[4 * g + 3] * inv));
+        }
+        if (h == 0) lse[qrow] = (m + log2f(lsum)) * LN2;
+    }
+}
+#elif ATT_VAR >= 5
 // v5: wave tiles flattened per image (768 workgroups = 3 per CU exactly at the bench shape), 64-key double-buffered LDS stages
 // (one barrier per stage, K and V both prefetched a full stage ahead), two independent S chains per iteration.
 __global__ __launch_bounds__(256, 3) void attn_fwd_seg_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
@@ -672,7 +781,12 @@ extern "C" int tc_attn_fwd_seg(const void* Q, int ldq, const void* K, int ldk, c
         return TC_OK;
     }
     if (dtype != TC_BF16 || ((ldq | ldk | ldv) & 7) || (skv & 7) || (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) || (ldo & 3)) return TC_ERR_ARG;
-#if ATT_VAR >= 5
+#if ATT_VAR == 10
+    const unsigned fwd_grid = (unsigned)B * ((sg.t32[nseg] + 5) / 6);
+    hipLaunchKernelGGL(attn_fwd_seg_kernel, dim3(fwd_grid), dim3(384), 0, (hipStream_t)stream, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk,
+                       (const bf16_t*)V, ldv, skv, (bf16_t*)O, ldo, lse, sg, Nk, scale);
+    return tc_launch_status();
+#elif ATT_VAR >= 5
     const unsigned fwd_grid = (unsigned)B * ((sg.t32[nseg] + 3) / 4);
 #else
     const unsigned fwd_grid = sg.tile0[nseg];
