@@ -746,6 +746,11 @@ int launch_multi(const TcDwSeg* segs, int nseg, int mode, int add_input, int acc
     long long blk = 0, part_floats = 0, cnts = 0;
     int smem_q = 0;
     const bool have_ws = mode == 2 && ws && (uintptr_t)ws % 16 == 0 && ws_bytes > 16384;
+    long long total_work = 0;
+    for (int i = 0; i < nseg; ++i) {
+        const int cg = dw_pick_cg<T>(segs[i].C), TH = (256 / cg) / 4;
+        total_work += (long long)segs[i].B * ((segs[i].W + 15) / 16) * ((segs[i].H + TH - 1) / TH) * ((segs[i].C + cg * VEC - 1) / (cg * VEC));
+    }
     for (int i = 0; i < nseg; ++i) {
         const TcDwSeg& g = segs[i];
         DwSegDev& d = a.s[i];
@@ -758,7 +763,9 @@ int launch_multi(const TcDwSeg* segs, int nseg, int mode, int add_input, int acc
         d.tilesW = (W + 15) / 16; d.tilesH = (H + TH - 1) / TH;
         const long long ntiles = (long long)B * d.tilesW * d.tilesH;
         if (mode == 2) {
-            long long gx = 256 / ((long long)d.chunks * groups * nseg);
+            // ~256 workgroups in total, shared out in proportion to each segment's tiles x chunks (an even split gave the 56x56
+            // map of a bridge layer 16 workgroups of 28 tiles each next to 1-tile workgroups of the 7x7 map)
+            long long gx = (long long)(256.0 * (double)ntiles / (double)(total_work > 0 ? total_work : 1) / groups + 0.5);
             gx = gx < 1 ? 1 : (gx > ntiles ? ntiles : gx);
             d.gx = (int)gx;
             const long long nt_ch = (long long)(g.k * g.k + 1) * d.cg * VEC;
