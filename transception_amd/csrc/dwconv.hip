@@ -749,7 +749,8 @@ int launch_multi(const TcDwSeg* segs, int nseg, int mode, int add_input, int acc
     long long total_work = 0;
     for (int i = 0; i < nseg; ++i) {
         const int cg = dw_pick_cg<T>(segs[i].C), TH = (256 / cg) / 4;
-        total_work += (long long)segs[i].B * ((segs[i].W + 15) / 16) * ((segs[i].H + TH - 1) / TH) * ((segs[i].C + cg * VEC - 1) / (cg * VEC));
+        total_work += (long long)segs[i].B * ((segs[i].W + 15) / 16) * ((segs[i].H + TH - 1) / TH) * ((segs[i].C + cg * VEC - 1) / (cg * VEC)) *
+                      (segs[i].k + 2);                  // cost per tile grows roughly with k (k filter rows per thread, k-wide window)
     }
     for (int i = 0; i < nseg; ++i) {
         const TcDwSeg& g = segs[i];
@@ -765,7 +766,7 @@ int launch_multi(const TcDwSeg* segs, int nseg, int mode, int add_input, int acc
         if (mode == 2) {
             // ~256 workgroups in total, shared out in proportion to each segment's tiles x chunks (an even split gave the 56x56
             // map of a bridge layer 16 workgroups of 28 tiles each next to 1-tile workgroups of the 7x7 map)
-            long long gx = (long long)(256.0 * (double)ntiles / (double)(total_work > 0 ? total_work : 1) / groups + 0.5);
+            long long gx = (long long)(256.0 * (double)ntiles * (g.k + 2) / (double)(total_work > 0 ? total_work : 1) / groups + 0.5);
             gx = gx < 1 ? 1 : (gx > ntiles ? ntiles : gx);
             d.gx = (int)gx;
             const long long nt_ch = (long long)(g.k * g.k + 1) * d.cg * VEC;
