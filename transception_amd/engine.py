@@ -152,6 +152,7 @@ _SPLITK_CAP = int(os.environ.get("TC_SPLITK_CAP", "128"))
 _SPLITK_BLOCKS = int(os.environ.get("TC_SPLITK_BLOCKS", "512"))
 _SPLITK_CAP = int(os.environ.get("TC_SPLITK_CAP", "128"))
 _SPLITK_BLOCKS = int(os.environ.get("TC_SPLITK_BLOCKS", "512"))
+_THR128 = int(os.environ.get("TC_GEMM_THR128", "100000"))     # keep in step with gemm.hip (gemm_plan)
 _GEMM_PAIR = os.environ.get("TC_GEMM_PAIR", "1") != "0"
 _N_WSTREAMS = int(os.environ.get("TC_WGRAD_STREAMS", "4"))
 _NO_PENDING = bool(os.environ.get("TC_DEBUG_NO_PENDING"))   # timing what-if only (racy)
@@ -410,8 +411,8 @@ class Graph:
 
     @staticmethod
     def _small_tiles(m_out: int, n_out: int, nb: int) -> bool:
-        """tc_gemm's tile choice (gemm.hip, gemm_plan): 64x64 tiles unless >= 192 tiles of 128x128 exist."""
-        return ((m_out + 127) // 128) * ((n_out + 127) // 128) * nb < 192 or m_out < 96 or n_out < 96
+        """tc_gemm's tile choice (gemm.hip, gemm_plan): 64x64 tiles unless >= 100000 tiles of 128x128 exist."""
+        return ((m_out + 127) // 128) * ((n_out + 127) // 128) * nb < _THR128 or m_out < 96 or n_out < 96
 
     @staticmethod
     def _splitk(m_out: int, n_out: int, k_red: int) -> int:
