@@ -36,6 +36,20 @@ def synthetic_batch(B: int, size: int, device, seed: int):
     return x.to(device), y.to(device)
 
 
+def _loader_feed(args, dev, rank: int, world: int, n_needed: int):
+    """Generator of (x, y) batches from the device input pipeline over a synthetic Synapse-format training set written to local
+    disk (512x512 npz slices, dataset_synapse.py:103-107)."""
+    import tempfile
+    from transception_amd import data as D
+    tmp = tempfile.mkdtemp(prefix=f"synapse_r{rank}_")
+    D.write_synthetic_synapse(tmp + "/train_npz", tmp + "/lists", n_cases=4, slices_per_case=32, size=512, seed=1234)
+    ds = D.SynapseSlices(tmp + "/train_npz", tmp + "/lists")
+    per_epoch = (len(ds) // (args.batch * world)) * args.batch * world
+    loader = D.DeviceLoader(ds, args.batch, img_size=args.size, device=dev, seed=1234, rank=rank, world=world, augment=True,
+                            epochs=n_needed // per_epoch + 2, readers=8)
+    return iter(loader)
+
+
 def _cpu_baseline_worker(batch: int, size: int):
     """Oracle fwd+bwd+SGD on the host cores.  Bounded sample: the batch is cut to 4 images when a probe says a full step
     would take too long, one warm-up + up to two timed steps (about 10-30 s of CPU work in total)."""
@@ -99,6 +113,9 @@ def main():
     ap.add_argument("--no-attn-events", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying the captured hipGraph")
     ap.add_argument("--force-split", action="store_true", help="use the 3-graph multi-GPU step structure even on one GPU")
+    ap.add_argument("--loader", action="store_true",
+                    help="feed the timed steps from transception_amd.data.DeviceLoader (synthetic Synapse npz files on local disk -> "
+                         "HBM -> device augmentation/resize) instead of one HBM-resident batch; the default keeps BASELINE's definition")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -146,6 +163,11 @@ def main():
         step = lambda: train_step(model, loss_fn, opt, x, y, group)
     else:
         step = GraphedStep(model, loss_fn, opt, x, y, group, warmup=2, force_split=args.force_split)   # capture, then replay
+    feed = None
+    if args.loader and not args.eager:
+        feed = _loader_feed(args, dev, rank, world, (args.steps + args.warmup) * args.batch * world)
+        step_resident = step
+        step = lambda: step_resident(*next(feed))
     for i in range(args.warmup):
         step()
         opt.set_lr(cosine_lr(0.05, i + 1, t_max))
@@ -158,6 +180,9 @@ def main():
         opt.set_lr(cosine_lr(0.05, args.warmup + i + 1, t_max))
     sync()
     elapsed = time.perf_counter() - t0
+    if feed is not None:
+        feed.close()
+        step = step_resident
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -196,6 +221,18 @@ def main():
                 gf.replay()
             torch.cuda.synchronize(dev)
             extra["fwd_only_images_per_sec"] = args.batch * 10 / (time.perf_counter() - tf)
+        if not args.eager and not args.loader and args.size == 224:
+            # SURVEY 8(f)-1 side figure: the same graphed step fed by the device input pipeline (npz -> HBM -> augment/resize)
+            f2 = _loader_feed(args, dev, 0, 1, 24 * args.batch)
+            for _ in range(4):
+                step(*next(f2))
+            torch.cuda.synchronize(dev)
+            tl = time.perf_counter()
+            for _ in range(20):
+                step(*next(f2))
+            torch.cuda.synchronize(dev)
+            extra["loader_fed_images_per_sec"] = args.batch * 20 / (time.perf_counter() - tl)
+            f2.close()
         if args.dtype == "bf16" and args.size % 32 == 0:
             # the roofline kernel again, the way the timed region runs it: back-to-back inside a replayed hipGraph (the
             # instrumented eager pass above separates launches by host gaps, which costs the kernel 10-20 % in clocks / cold caches)
@@ -241,7 +278,7 @@ def main():
             "metric": "images/sec fwd+bwd at 224x224 B=16 per GPU", "value": world * args.batch * args.steps / elapsed,
             "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
+            "dtype": args.dtype, "data": "synthetic" if not args.loader else "synthetic Synapse npz files through DeviceLoader",
             "config": {"workload": f"TransCeption (MSTransception) {args.size}x{args.size} B={args.batch}/GPU fwd+bwd+SGD, "
                                    "synthetic Synapse slices, name-seeded random-init weights",
                        "global_batch": world * args.batch, "image_size": args.size, "parallelism": f"dp{world}",

@@ -292,6 +292,39 @@ int tc_factor_att_bwd(const void* q, const void* k, const void* v, int ld, const
 int tc_argmax_counts(const void* logits, const long long* labels, unsigned char* pred, float* counts, int B, int ncls, int HW,
                      int dtype, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Input pipeline (datasets/dataset_synapse.py:101-112, trainer.py:89-93): a batch of raw slices
+ * [B,H,W] (image fp32 in [0,1], label uint8 0..8) already in HBM -> network input.
+ */
+enum { TC_AUG_WARP = 1, TC_AUG_LINEAR = 2, TC_AUG_BLUR = 4, TC_AUG_PIECEWISE = 8 };
+/* Per-slice augmentation record (DEVICE array of B).  Stage order: warp -> blur -> contrast -> noise.
+ *   warp: source (row, col) = (m[2] + m[0] y' + m[1] x', m[5] + m[3] y' + m[4] x') of output pixel (y, x), where (y', x') = (y, x)
+ *   plus, with TC_AUG_PIECEWISE, the bilinear interpolation of the 4x4 control-point displacements disp[(gy*4+gx)*2 + {0:dy,1:dx}]
+ *   (pixels) spanning the slice; image sampled order 1 (TC_AUG_LINEAR) or order 0, label always order 0, outside -> 0
+ *   (scipy.ndimage mode='constant': dataset_synapse.py:48-52 rotate, :39-46 rot90/flip; imgaug Affine family :90-94).
+ *   blur: Gaussian sigma 1, 9 taps, mirror border (:88).  contrast: center + alpha (v - center) (:89).
+ *   noise: v += noise_sigma * N(0,1), counter-based generator keyed by (noise_seed, pixel) (:87). */
+typedef struct TcSliceAug {
+    double m[6];
+    float disp[32];
+    float alpha, center, noise_sigma;
+    unsigned int noise_seed;
+    int flags;
+    int reserved;
+} TcSliceAug;
+/* img/lab [B,H,W] -> img_out/lab_out (distinct buffers).  H, W >= 9. */
+int tc_slice_augment(const float* img, const unsigned char* lab, const TcSliceAug* aug_dev, float* img_out,
+                     unsigned char* lab_out, int B, int H, int W, void* stream);
+/* Cubic B-spline coefficients (fp64 [B,H,W]) of fp32 slices: the prefilter half of scipy.ndimage.zoom(order=3)
+ * (dataset_synapse.py:111), mirror boundaries, axis 0 then axis 1. */
+int tc_spline_prefilter(const float* img, double* coef, int B, int H, int W, void* stream);
+/* x[b,0,oy,ox] = (zoom3(img)[oy,ox] - mean) / std ; y[b,oy,ox] = zoom0(lab)[oy,ox] (int64) with scipy's grid
+ * (source coordinate o*(in-1)/(out-1) in double; a coordinate that rounds above in-1 yields 0 for image and label -- at 512->224
+ * that is the whole last row and column, as in the reference).  coef = NULL requires OH==H, OW==W and only normalises img
+ * (the reference skips the zoom for equal sizes, dataset_synapse.py:109).  y/lab may be NULL. */
+int tc_zoom_normalize(const double* coef, const float* img, const unsigned char* lab, float* x, long long* y, int B, int H,
+                      int W, int OH, int OW, float mean, float stdv, void* stream);
+
 /* Fused SGD with momentum and weight decay over flat fp32 buffers (torch.optim.SGD semantics, trainer.py:125):
  *   g = grad*gscale + wd*p ; buf = first ? g : mom*buf + g ; p -= lr*buf.
  * lr_dev (optional device scalar) overrides lr, so a hipGraph-captured step can follow a per-iteration schedule. */

@@ -34,6 +34,13 @@ class TcDwSeg(C.Structure):
                 ("ldx", i32), ("ldy", i32), ("lddy", i32), ("B", i32), ("H", i32), ("W", i32)]
 
 
+class TcSliceAug(C.Structure):
+    _fields_ = [("m", C.c_double * 6), ("disp", C.c_float * 32), ("alpha", f32), ("center", f32), ("noise_sigma", f32),
+                ("noise_seed", C.c_uint), ("flags", i32), ("reserved", i32)]
+
+
+TC_AUG_WARP, TC_AUG_LINEAR, TC_AUG_BLUR, TC_AUG_PIECEWISE = 1, 2, 4, 8
+
 # name -> argtypes (every function returns int status unless listed in _RET)
 SIGNATURES = {
     "tc_abi_version": [],
@@ -81,6 +88,9 @@ SIGNATURES = {
     "tc_factor_att_bwd": [vp, vp, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, f32, i32, vp],
     "tc_argmax_counts": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "tc_seg_loss_bwd": [vp, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, vp, i32, vp],
+    "tc_slice_augment": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "tc_spline_prefilter": [vp, vp, i32, i32, i32, vp],
+    "tc_zoom_normalize": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, f32, vp],
     "tc_sgd_step": [vp, vp, vp, i64, f32, vp, f32, f32, f32, i32, vp],
     "tc_sgd_step_multi": [vp, vp, vp, vp, i32, i64, f32, vp, f32, f32, f32, i32, vp],
     "tc_cast": [vp, vp, i64, i32, i32, vp],

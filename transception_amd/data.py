@@ -1,0 +1,437 @@
+"""Input pipeline of the TransCeption path on MI355X: the device side of
+`datasets/dataset_synapse.py::Synapse_dataset.__getitem__` (:101-128) and the trainer's transforms (`trainer.py:89-108`).
+
+The reference prepares every training slice on host cores: `np.load` of `{image,label}` (:104-107), an imgaug `SomeOf((0,4))`
+pipeline of ten augmenters (:84-95), `scipy.ndimage.zoom` order 3 / order 0 from 512x512 to the network size (:108-112), then
+`ToTensor` + `Normalize([0.5],[0.5])` (trainer.py:89-93) -- about 40 ms per slice and core, i.e. ~25 slices/s/core against a GPU
+that consumes ~850 slices/s.  Here the host only reads the npz files and draws the augmentation parameters; the raw slices go
+to HBM as they are (fp32 image, uint8 label: 1.25 MB per slice) and the arithmetic runs there, four launches per batch
+(`csrc/data.hip`): augment -> spline prefilter (columns, rows) -> resize + normalise.  The loader issues that work on its own
+stream while the training step of the previous batch is running.
+
+What is bit-for-bit the reference's arithmetic and what is not is spelled out in `oracle/data_oracle.py`: the resize/normalise
+stage reproduces `scipy.ndimage.zoom` (including its zeroed last row/column at 512 -> 224) and is pinned by a fixture generated
+from the reference's own code; the imgaug stage is a restatement (imgaug is not installable here), with the geometric
+augmenters folded into ONE order-1 warp instead of one resampling per augmenter.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+import queue
+import threading
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+from scipy import special
+
+from ._lib import TC_AUG_BLUR, TC_AUG_LINEAR, TC_AUG_PIECEWISE, TC_AUG_WARP, TcSliceAug, lib
+
+NOISE_SCALE = 0.005 * 255          # AdditiveGaussianNoise(scale=0.005*255), dataset_synapse.py:87 -- applied to [0,1] floats as is
+
+
+# ------------------------------------------------------------------------------------------------ affine maps (output -> source)
+# A map is 6 numbers m: source_row = m[2] + m[0]*y + m[1]*x ; source_col = m[5] + m[3]*y + m[4]*x for output pixel (y, x).
+def _to3(m) -> np.ndarray:
+    return np.array([[m[0], m[1], m[2]], [m[3], m[4], m[5]], [0.0, 0.0, 1.0]], np.float64)
+
+
+def _from3(a: np.ndarray) -> Tuple[float, ...]:
+    return (float(a[0, 0]), float(a[0, 1]), float(a[0, 2]), float(a[1, 0]), float(a[1, 1]), float(a[1, 2]))
+
+
+IDENTITY = (1.0, 0.0, 0.0, 0.0, 1.0, 0.0)
+
+
+def compose(first, then) -> Tuple[float, ...]:
+    """Map of the slice produced by applying augmentation `first` and then `then` (each given as its output->source map)."""
+    return _from3(_to3(first) @ _to3(then))
+
+
+def affine_flip(axis: int, h: int, w: int) -> Tuple[float, ...]:
+    return (-1.0, 0.0, float(h - 1), 0.0, 1.0, 0.0) if axis == 0 else (1.0, 0.0, 0.0, 0.0, -1.0, float(w - 1))
+
+
+def affine_rot90_flip(k: int, axis: int, n: int) -> Tuple[float, ...]:
+    """np.flip(np.rot90(a, k), axis) of a square slice (random_rot_flip, dataset_synapse.py:39-46)."""
+    rot = {0: IDENTITY, 1: (0.0, 1.0, 0.0, -1.0, 0.0, float(n - 1)), 2: (-1.0, 0.0, float(n - 1), 0.0, -1.0, float(n - 1)),
+           3: (0.0, -1.0, float(n - 1), 1.0, 0.0, 0.0)}[k % 4]
+    return compose(rot, affine_flip(axis, n, n))
+
+
+def affine_rotate(angle_deg: float, h: int, w: int) -> Tuple[float, ...]:
+    """scipy.ndimage.rotate(a, angle, reshape=False) (random_rotate, dataset_synapse.py:48-52): matrix [[c, s], [-s, c]] in
+    (row, col), about the slice centre; cos/sin of degrees through scipy.special like scipy itself."""
+    c, s = float(special.cosdg(angle_deg)), float(special.sindg(angle_deg))
+    cy, cx = (h - 1) / 2.0, (w - 1) / 2.0
+    return (c, s, cy - (c * cy + s * cx), -s, c, cx - (-s * cy + c * cx))
+
+
+def _xy_forward_to_map(fwd_xy: np.ndarray, h: int, w: int) -> Tuple[float, ...]:
+    """Forward transform in (x, y) pixel coordinates about the slice centre -> output->source map in (row, col)."""
+    cx, cy = (w - 1) / 2.0, (h - 1) / 2.0
+    t_in = np.array([[1, 0, -cx], [0, 1, -cy], [0, 0, 1]], np.float64)
+    t_out = np.array([[1, 0, cx], [0, 1, cy], [0, 0, 1]], np.float64)
+    inv = np.linalg.inv(t_out @ fwd_xy @ t_in)                     # output (x, y) -> source (x, y)
+    swap = np.array([[0, 1, 0], [1, 0, 0], [0, 0, 1]], np.float64)
+    return _from3(swap @ inv @ swap)
+
+
+def affine_scale(sx: float, sy: float, h: int, w: int):
+    return _xy_forward_to_map(np.diag([sx, sy, 1.0]), h, w)
+
+
+def affine_rotate_xy(deg: float, h: int, w: int):
+    r = math.radians(deg)
+    return _xy_forward_to_map(np.array([[math.cos(r), -math.sin(r), 0], [math.sin(r), math.cos(r), 0], [0, 0, 1]], np.float64), h, w)
+
+
+def affine_shear(deg: float, h: int, w: int):
+    r = math.radians(deg)
+    return _xy_forward_to_map(np.array([[1, -math.sin(r), 0], [0, math.cos(r), 0], [0, 0, 1]], np.float64), h, w)
+
+
+def affine_translate(px: float, py: float, h: int, w: int):
+    return _xy_forward_to_map(np.array([[1, 0, px * w], [0, 1, py * h], [0, 0, 1]], np.float64), h, w)
+
+
+@dataclass
+class SliceAugmentation:
+    """Parameters of one slice's augmentation (one TcSliceAug record)."""
+    m: Tuple[float, ...] = IDENTITY
+    order: int = 1
+    disp: Optional[np.ndarray] = None          # float32 [4,4,2] control-point displacement (dy, dx) in pixels
+    blur: bool = False
+    alpha: float = 1.0
+    center: float = 0.0
+    noise_sigma: float = 0.0
+    noise_seed: int = 0
+    names: List[str] = field(default_factory=list)
+
+    def warps(self) -> bool:
+        return self.disp is not None or tuple(self.m) != IDENTITY
+
+    def record(self) -> TcSliceAug:
+        r = TcSliceAug()
+        for i, v in enumerate(self.m):
+            r.m[i] = v
+        flags = 0
+        if self.warps():
+            flags |= TC_AUG_WARP
+        if self.order == 1:
+            flags |= TC_AUG_LINEAR
+        if self.disp is not None:
+            flags |= TC_AUG_PIECEWISE
+            for i, v in enumerate(np.asarray(self.disp, np.float32).reshape(-1)):
+                r.disp[i] = float(v)
+        if self.blur:
+            flags |= TC_AUG_BLUR
+        r.alpha, r.center, r.noise_sigma, r.noise_seed, r.flags = self.alpha, self.center, self.noise_sigma, self.noise_seed, flags
+        return r
+
+    def as_dict(self) -> dict:
+        """The same parameters in the form oracle/data_oracle.py::augment_slice takes (tests only)."""
+        return {"m": tuple(self.m) if self.warps() else IDENTITY, "order": self.order,
+                "disp": None if self.disp is None else np.asarray(self.disp, np.float32).reshape(-1),
+                "blur": self.blur, "alpha": self.alpha, "center": self.center, "noise_sigma": self.noise_sigma,
+                "noise_seed": self.noise_seed}
+
+
+class AugmentSampler:
+    """Draws what `iaa.SomeOf((0,4), [...ten augmenters...], random_order=True)` draws (dataset_synapse.py:84-95): between 0 and 4 of
+    the ten augmenters, in random order, each with its own parameter ranges.  The geometric ones fold into one output->source map
+    in the drawn order; PiecewiseAffine becomes a 4x4 control-point displacement field applied as the last geometric step."""
+    NAMES = ("Flipud", "Fliplr", "AdditiveGaussianNoise", "GaussianBlur", "LinearContrast", "Affine.scale", "Affine.rotate",
+             "Affine.shear", "PiecewiseAffine", "Affine.translate")
+
+    def __init__(self, seed: int):
+        self.rng = np.random.default_rng(seed)
+
+    def sample(self, h: int, w: int) -> SliceAugmentation:
+        g = self.rng
+        a = SliceAugmentation()
+        k = int(g.integers(0, 5))
+        for idx in g.permutation(10)[:k]:
+            name = self.NAMES[int(idx)]
+            a.names.append(name)
+            if name == "Flipud":
+                if g.random() < 0.5:
+                    a.m = compose(a.m, affine_flip(0, h, w))
+            elif name == "Fliplr":
+                if g.random() < 0.5:
+                    a.m = compose(a.m, affine_flip(1, h, w))
+            elif name == "AdditiveGaussianNoise":
+                a.noise_sigma, a.noise_seed = NOISE_SCALE, int(g.integers(0, 2 ** 31 - 1))
+            elif name == "GaussianBlur":
+                a.blur = True
+            elif name == "LinearContrast":
+                a.alpha = float(g.uniform(0.5, 1.5))
+            elif name == "Affine.scale":
+                a.m = compose(a.m, affine_scale(float(g.uniform(0.5, 2.0)), float(g.uniform(0.5, 2.0)), h, w))
+            elif name == "Affine.rotate":
+                a.m = compose(a.m, affine_rotate_xy(float(g.uniform(-40, 40)), h, w))
+            elif name == "Affine.shear":
+                a.m = compose(a.m, affine_shear(float(g.uniform(-16, 16)), h, w))
+            elif name == "PiecewiseAffine":
+                s = float(g.uniform(0.008, 0.03))
+                a.disp = (g.normal(0.0, 1.0, (4, 4, 2)) * np.array([s * h, s * w])).astype(np.float32)
+            else:
+                a.m = compose(a.m, affine_translate(float(g.uniform(-0.2, 0.2)), float(g.uniform(-0.2, 0.2)), h, w))
+        return a
+
+
+# ------------------------------------------------------------------------------------------------ files
+def write_synthetic_synapse(base_dir: str, list_dir: str, n_cases: int = 2, slices_per_case: int = 8, size: int = 512,
+                            seed: int = 1234) -> List[str]:
+    """Writes a synthetic Synapse training set in the reference's on-disk format: `<base_dir>/caseNNNN_sliceMMM.npz` holding
+    `image` float32 [size,size] in [0,1] and `label` float32 [size,size] in {0..8} (dataset_synapse.py:103-107), names listed in
+    `<list_dir>/train.txt` (:80).  Smooth organ-like blobs, seeded."""
+    os.makedirs(base_dir, exist_ok=True)
+    os.makedirs(list_dir, exist_ok=True)
+    g = np.random.default_rng(seed)
+    yy, xx = np.meshgrid(np.linspace(-1, 1, size, dtype=np.float32), np.linspace(-1, 1, size, dtype=np.float32), indexing="ij")
+    names = []
+    for c in range(n_cases):
+        centres = g.uniform(-0.6, 0.6, (8, 2)).astype(np.float32)
+        radii = g.uniform(0.08, 0.3, (8, 2)).astype(np.float32)
+        for s in range(slices_per_case):
+            grow = np.float32(0.6 + 0.4 * math.sin(math.pi * (s + 0.5) / slices_per_case))
+            image = 0.25 + 0.1 * np.sin(3 * xx + c) * np.cos(2 * yy - s * 0.1)
+            label = np.zeros((size, size), np.float32)
+            for k in range(8):
+                d = ((yy - centres[k, 0]) / (radii[k, 0] * grow)) ** 2 + ((xx - centres[k, 1]) / (radii[k, 1] * grow)) ** 2
+                inside = d < 1.0
+                label[inside] = k + 1
+                image = np.where(inside, 0.35 + 0.07 * k + 0.05 * (1 - d), image)
+            image = np.clip(image + g.normal(0, 0.02, image.shape), 0, 1).astype(np.float32)
+            name = f"case{c:04d}_slice{s:03d}"
+            np.savez(os.path.join(base_dir, name + ".npz"), image=image, label=label)
+            names.append(name)
+    with open(os.path.join(list_dir, "train.txt"), "w") as f:
+        f.write("\n".join(names) + "\n")
+    return names
+
+
+class SynapseSlices:
+    """`Synapse_dataset(split="train")` without the transforms (dataset_synapse.py:75-82,101-107): slice i -> raw `image`
+    (float32 [H,W] in [0,1]) and `label` (uint8 [H,W]; the file stores float32 0..8).  The test split (`.npy.h5` volumes, :114-118)
+    needs h5py, which this image lacks -- volumes are handed to transception_amd.evaluate as arrays instead."""
+
+    def __init__(self, base_dir: str, list_dir: str, split: str = "train"):
+        if split != "train":
+            raise NotImplementedError("only the npz training split is read here; evaluate_volume() takes volumes as arrays")
+        path = os.path.join(list_dir, split + ".txt")
+        with open(path) as f:
+            self.sample_list = [ln.strip("\n") for ln in f.readlines() if ln.strip()]
+        self.data_dir = base_dir
+
+    def __len__(self) -> int:
+        return len(self.sample_list)
+
+    def __getitem__(self, idx: int):
+        name = self.sample_list[idx]
+        data = np.load(os.path.join(self.data_dir, name + ".npz"))
+        image = np.ascontiguousarray(data["image"], np.float32)
+        label = np.ascontiguousarray(data["label"]).astype(np.uint8)
+        return image, label, name
+
+
+# ------------------------------------------------------------------------------------------------ device side
+def preprocess_batch(images: torch.Tensor, labels: torch.Tensor, augs: Optional[Sequence[Optional[SliceAugmentation]]], size: int,
+                     mean: float = 0.5, std: float = 0.5, records: Optional[torch.Tensor] = None, scratch: Optional[dict] = None,
+                     out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Raw slices in HBM -> network input, on the current stream.  images float32 [B,H,W], labels uint8 [B,H,W];
+    `augs` one SliceAugmentation (or None) per slice, or None for no augmentation at all; alternatively `records` = the
+    TcSliceAug array already on the device (uint8 [B, sizeof]).  Returns x float32 [B,1,size,size], y int64 [B,size,size]."""
+    if not images.is_cuda:
+        raise RuntimeError("transception_amd.data preprocesses on MI355X only (no CPU fallback)")
+    B, H, W = images.shape
+    assert images.dtype == torch.float32 and labels.dtype == torch.uint8 and labels.shape == images.shape
+    images, labels = images.contiguous(), labels.contiguous()
+    dev = images.device
+    L = lib()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    scratch = scratch if scratch is not None else {}
+
+    def buf(name, shape, dtype):
+        t = scratch.get(name)
+        if t is None or t.shape != torch.Size(shape) or t.dtype != dtype:
+            t = scratch[name] = torch.empty(shape, dtype=dtype, device=dev)
+        return t
+
+    if records is None and augs is not None and any(a is not None for a in augs):
+        records = torch.from_numpy(pack_records(augs)).to(dev)
+    if records is not None:
+        img2, lab2 = buf("aug_img", (B, H, W), torch.float32), buf("aug_lab", (B, H, W), torch.uint8)
+        L.tc_slice_augment(images.data_ptr(), labels.data_ptr(), records.data_ptr(), img2.data_ptr(), lab2.data_ptr(), B, H, W, stream)
+        images, labels = img2, lab2
+    x, y = out if out is not None else (torch.empty((B, 1, size, size), dtype=torch.float32, device=dev),
+                                        torch.empty((B, size, size), dtype=torch.int64, device=dev))
+    if H != size or W != size:
+        coef = buf("coef", (B, H, W), torch.float64)
+        L.tc_spline_prefilter(images.data_ptr(), coef.data_ptr(), B, H, W, stream)
+        L.tc_zoom_normalize(coef.data_ptr(), images.data_ptr(), labels.data_ptr(), x.data_ptr(), y.data_ptr(), B, H, W, size, size,
+                            float(mean), float(std), stream)
+    else:
+        L.tc_zoom_normalize(None, images.data_ptr(), labels.data_ptr(), x.data_ptr(), y.data_ptr(), B, H, W, size, size,
+                            float(mean), float(std), stream)
+    return x, y
+
+
+def pack_records(augs: Sequence[Optional[SliceAugmentation]]) -> np.ndarray:
+    """TcSliceAug array as bytes, uint8 [B, sizeof(TcSliceAug)]."""
+    arr = (TcSliceAug * len(augs))(*[(a if a is not None else SliceAugmentation()).record() for a in augs])
+    return np.frombuffer(bytes(arr), np.uint8).reshape(len(augs), ctypes.sizeof(TcSliceAug)).copy()
+
+
+def epoch_order(n: int, epoch: int, seed: int, shuffle: bool = True) -> np.ndarray:
+    """Slice order of one epoch -- the same on every rank (the trainer's DataLoader(shuffle=True), trainer.py:104)."""
+    return np.random.default_rng([seed, epoch]).permutation(n) if shuffle else np.arange(n)
+
+
+def rank_batches(order: np.ndarray, batch_size: int, rank: int, world: int) -> List[np.ndarray]:
+    """Global batches of batch_size*world slices (trainer.py:86), rank r taking slices [r*B, (r+1)*B) of each; the ragged tail is
+    dropped on every rank alike so all ranks run the same number of steps."""
+    gb = batch_size * world
+    return [order[i * gb + rank * batch_size: i * gb + (rank + 1) * batch_size] for i in range(len(order) // gb)]
+
+
+class DeviceLoader:
+    """Iterates (x, y) batches resident in HBM.  A host thread reads the npz files and draws the augmentation parameters into
+    pinned staging buffers; the H2D copies and the four preprocessing launches of batch i+1 are issued on the loader's stream
+    when batch i is handed out, so they run under the training step that consumes batch i."""
+
+    def __init__(self, dataset: SynapseSlices, batch_size: int, img_size: int = 224, device="cuda", seed: int = 1234, rank: int = 0,
+                 world: int = 1, augment: bool = True, shuffle: bool = True, epochs: int = 1, prefetch: int = 3, readers: int = 4):
+        self.ds, self.B, self.size, self.device = dataset, batch_size, img_size, torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("DeviceLoader feeds an MI355X; there is no CPU path")
+        self.seed, self.rank, self.world, self.augment, self.shuffle, self.epochs = seed, rank, world, augment, shuffle, epochs
+        self.stream = torch.cuda.Stream(self.device)
+        self.prefetch, self.readers = prefetch, max(1, readers)
+        self.q: "queue.Queue" = queue.Queue(maxsize=prefetch)
+        self.free: "queue.Queue" = queue.Queue()                     # pinned staging sets handed back once their copies ran
+        self._staged = 0
+        self.slots = [dict(scratch={}) for _ in range(2)]
+        self._thread: Optional[threading.Thread] = None
+        self._stop = threading.Event()
+
+    def __len__(self) -> int:
+        return (len(self.ds) // (self.B * self.world)) * self.epochs
+
+    # host side -----------------------------------------------------------------------------------
+    def _staging(self, h: int, w: int):
+        """A pinned (image, label, records) set: at most prefetch + 3 exist (queue + the two device slots + one being filled);
+        page-locking memory per batch would cost more than reading the slices."""
+        while not self._stop.is_set():
+            try:
+                st = self.free.get_nowait() if self._staged >= self.prefetch + 3 else None
+            except queue.Empty:
+                try:
+                    st = self.free.get(timeout=0.1)
+                except queue.Empty:
+                    continue
+            if st is None:
+                self._staged += 1
+                return (torch.empty((self.B, h, w), dtype=torch.float32).pin_memory(), torch.empty((self.B, h, w), dtype=torch.uint8).pin_memory(),
+                        torch.empty((self.B, ctypes.sizeof(TcSliceAug)), dtype=torch.uint8).pin_memory())
+            if st[0].shape[1:] == (h, w):
+                return st
+            self._staged -= 1                                        # slice size changed: drop the set, make a new one
+        return None
+
+    def _produce(self):
+        from concurrent.futures import ThreadPoolExecutor
+        try:
+            with ThreadPoolExecutor(max_workers=self.readers) as pool:
+                for epoch in range(self.epochs):
+                    sampler = AugmentSampler(int(np.random.SeedSequence([self.seed, epoch, self.rank]).generate_state(1)[0]))
+                    for idxs in rank_batches(epoch_order(len(self.ds), epoch, self.seed, self.shuffle), self.B, self.rank, self.world):
+                        first = self.ds[int(idxs[0])]
+                        h, w = first[0].shape
+                        st = self._staging(h, w)
+                        if st is None:
+                            return
+                        img, lab, rec = st
+
+                        def fill(j, item=None):
+                            im, lb, name = item if item is not None else self.ds[int(idxs[j])]
+                            if im.shape != (h, w):
+                                raise ValueError("slices of one batch must have one size")
+                            img[j].copy_(torch.from_numpy(im))
+                            lab[j].copy_(torch.from_numpy(lb))
+                            return name
+                        names = [fill(0, first)] + list(pool.map(fill, range(1, len(idxs))))
+                        augs = [sampler.sample(h, w) for _ in names] if self.augment else None
+                        if augs is not None:
+                            rec.copy_(torch.from_numpy(pack_records(augs)))
+                        while not self._stop.is_set():
+                            try:
+                                self.q.put((st, names, augs), timeout=0.1)
+                                break
+                            except queue.Full:
+                                continue
+                        if self._stop.is_set():
+                            return
+            self.q.put(None)
+        except BaseException as e:                                   # surfaces in the consumer
+            self.q.put(e)
+
+    # device side ---------------------------------------------------------------------------------
+    def _launch(self, slot: dict) -> bool:
+        item = self.q.get()
+        if item is None:
+            return False
+        if isinstance(item, BaseException):
+            raise item
+        st, names, augs = item
+        img, lab, rec = st
+        with torch.cuda.stream(self.stream):
+            if "consumed" in slot:
+                self.stream.wait_event(slot["consumed"])             # the previous batch in this slot has been used
+            if "host" in slot:
+                slot["done"].synchronize()                           # its copies ran two batches ago: hand the staging set back
+                self.free.put(slot.pop("host"))
+            if "out" not in slot:                                    # outputs live as long as the loader: no allocator traffic across streams
+                slot["out"] = (torch.empty((self.B, 1, self.size, self.size), dtype=torch.float32, device=self.device),
+                               torch.empty((self.B, self.size, self.size), dtype=torch.int64, device=self.device))
+            d_img, d_lab = img.to(self.device, non_blocking=True), lab.to(self.device, non_blocking=True)
+            d_rec = rec.to(self.device, non_blocking=True) if augs is not None else None
+            slot["x"], slot["y"] = preprocess_batch(d_img, d_lab, None, self.size, records=d_rec, scratch=slot["scratch"], out=slot["out"])
+            slot["host"] = st                                        # the pinned set stays out of the free list until the copies ran
+            slot["names"], slot["augs"] = names, augs
+            slot["done"] = torch.cuda.Event()
+            slot["done"].record(self.stream)
+        return True
+
+    def __iter__(self):
+        self._stop.clear()
+        self._thread = threading.Thread(target=self._produce, daemon=True)
+        self._thread.start()
+        cur = 0
+        try:
+            live = self._launch(self.slots[cur])
+            while live:
+                slot = self.slots[cur]
+                nxt = 1 - cur
+                live = self._launch(self.slots[nxt])                 # batch i+1 goes out before batch i is consumed
+                main = torch.cuda.current_stream(self.device)
+                main.wait_event(slot["done"])
+                self.last_names, self.last_augs = slot["names"], slot["augs"]      # what the batch being handed out was made from
+                yield slot["x"], slot["y"]
+                slot["consumed"] = torch.cuda.Event()
+                slot["consumed"].record(torch.cuda.current_stream(self.device))
+                cur = nxt
+        finally:
+            self._stop.set()
+            while self._thread.is_alive():                           # unblock a producer waiting on a full queue
+                try:
+                    self.q.get_nowait()
+                except queue.Empty:
+                    pass
+                self._thread.join(timeout=0.05)
+            while not self.q.empty():
+                self.q.get_nowait()
