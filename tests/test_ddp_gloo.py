@@ -43,6 +43,25 @@ def _worker(rank, world, port, ret):
     g2 = Sparse._gflat
     ok_grad = ok_grad and bool((g2[:178] == 3.0).all() and (g2[1_500_000:1_501_000] == 3.0).all() and
                                (g2[178:1_500_000] == float(rank + 1)).all())
+    # the overlapped form: buckets at/above the encoder boundary travel first (asynchronously), the rest afterwards
+    from transception_amd.train import split_buckets
+    assert split_buckets([(0, 100), (200, 400), (500, 600)], 300) == ([(0, 100), (200, 300)], [(300, 400), (500, 600)])
+
+    class Two(Sparse):
+        _gflat = torch.full((2_000_000,), float(rank + 1))
+
+        @staticmethod
+        def late_gradient_offset():
+            return 100
+    works = allreduce_gradients(Two, None, "late", async_op=True)
+    ok_grad = ok_grad and len(works) == 2                      # (100,178) and the far range
+    for w in works:
+        w.wait()
+    g3 = Two._gflat
+    ok_grad = ok_grad and bool((g3[:100] == float(rank + 1)).all() and (g3[100:178] == 3.0).all() and (g3[1_500_000:1_501_000] == 3.0).all())
+    for w in allreduce_gradients(Two, None, "early", async_op=True):
+        w.wait()
+    ok_grad = ok_grad and bool((g3[:178] == 3.0).all() and (g3[178:1_500_000] == float(rank + 1)).all())
     ret[rank] = (ok_loss, ok_grad)
     dist.destroy_process_group()
 

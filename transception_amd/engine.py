@@ -362,10 +362,25 @@ class Graph:
             self._pending[reads.untyped_storage().data_ptr()] = ev
             self._keep.append(reads)
 
-    def backward(self):
+    def mark(self, name: str):
+        """A named cut in the tape: backward(until=name) stops there, so a caller can start exchanging the gradients that are
+        complete (everything recorded after the mark) while the rest of the backward sweep runs."""
+        if self.record:
+            self.tape.append(("mark", name))
+
+    def backward(self, until: Optional[str] = None) -> bool:
+        """Runs the tape in reverse.  With `until`, stops at that mark and returns False (call again to finish)."""
         main = (self.cur, self.stream)
-        for entry in reversed(self.tape):
-            if entry[0] == "join":                       # forward fork point: everything the branches produced flows back to main
+        while self.tape:
+            entry = self.tape.pop()
+            if entry[0] == "mark":
+                if entry[1] == until:
+                    self.cur, self.stream = main
+                    if self._wstream is not None:
+                        for ws in self._wstream:
+                            self.cur.wait_stream(ws)
+                    return False
+            elif entry[0] == "join":                       # forward fork point: everything the branches produced flows back to main
                 for s in entry[2]:
                     entry[1].wait_stream(s)
             elif entry[0] == "fork":                     # forward join point: branch backward starts after main's upstream work
@@ -388,6 +403,7 @@ class Graph:
         self._pending.clear()
         self._keep.clear()
         self.tape = []
+        return True
 
     def _rec(self, fn):
         if self.record:

@@ -395,7 +395,19 @@ class MSTransception(nn.Module):
         self.last_launches = G.n_launch
         return logits, G, out_var
 
-    def _backward(self, G: Graph, out_var: Var, dlogits: torch.Tensor):
+    def late_gradient_offset(self) -> int:
+        """First element of the flat arenas that belongs to the bridge / decoders: parameters are laid out in registration
+        order (backbone, bridge, decoder_3..0), so [offset, end) is complete once backward has passed the "encoder_done" mark."""
+        late = min(off for name, (off, _) in self._index.items() if not name.startswith("backbone."))
+        assert all(off < late for name, (off, _) in self._index.items() if name.startswith("backbone."))
+        return late
+
+    def _backward_finish(self, G: Graph):
+        """Second half of a backward that was stopped at a mark."""
+        G.backward()
+        self._attach_grads()
+
+    def _backward(self, G: Graph, out_var: Var, dlogits: torch.Tensor, until: Optional[str] = None):
         L = lib()
         first = next((p for p in self._uniq_params if id(p) in self._used_views), None)
         if first is not None and first.grad is None:
@@ -407,8 +419,8 @@ class MSTransception(nn.Module):
             d = dl
         out_var.root.grad_t = d.view(out_var.rows, out_var.cols)
         out_var.root.whole_written = True
-        G.backward()
-        self._attach_grads()
+        if G.backward(until):
+            self._attach_grads()
 
 
 TransCeption = MSTransception
@@ -740,7 +752,9 @@ def _forward(M: MSTransception, G: Graph, x: torch.Tensor, B: int, in_ch: int, S
     for s in (1, 2, 3):
         stack, side = _ripm(M, G, m, f"backbone.patch_embed_stage{s + 1}", B, sides[s - 1])
         m = _mhca_stage(M, G, stack, f"backbone.mhca_stage{s + 1}", LAYERS[s - 1], B, side, stage_map(Xb, s))
-    # Dual Transformer Bridge
+    # Dual Transformer Bridge.  The mark lets a multi-GPU step stop its backward sweep here -- bridge and decoder gradients (72 % of
+    # the live gradient bytes) are complete and can travel while the encoder's backward runs.
+    G.mark("encoder_done")
     X = Xb
     for li in range(1, 5):
         X = _bridge_layer(M, G, X, li, B, sides, ntok, R, N6)

@@ -166,12 +166,36 @@ def gradient_buckets(model, max_gap: int = 1 << 18):
     return [(a, min(b, n)) for a, b in out]
 
 
-def allreduce_gradients(model, group=None):
+def split_buckets(buckets, cut: int):
+    """(early, late): the buckets below / at-or-above arena offset `cut`, a bucket that straddles it cut in two."""
+    early, late = [], []
+    for a, b in buckets:
+        if b <= cut:
+            early.append((a, b))
+        elif a >= cut:
+            late.append((a, b))
+        else:
+            early.append((a, cut))
+            late.append((cut, b))
+    return early, late
+
+
+def allreduce_gradients(model, group=None, part: Optional[str] = None, async_op: bool = False):
     """C1: all-reduce(sum) of the live parts of the flat gradient arena over RCCL/xGMI (gloo in CPU tests): a handful of
-    large buckets, every rank the same ones (the used set is a property of the architecture)."""
+    large buckets, every rank the same ones (the used set is a property of the architecture).  part="late" / "early" sends only
+    the buckets at or above / below model.late_gradient_offset() (bridge + decoders / encoder); async_op returns the work
+    handles instead of waiting, so the late part can travel under the encoder's backward."""
+    works = []
     if dist.is_initialized() and dist.get_world_size(group) > 1:
-        for a, b in gradient_buckets(model):
-            dist.all_reduce(model._gflat[a:b], group=group)
+        buckets = gradient_buckets(model)
+        if part is not None:
+            early, late = split_buckets(buckets, model.late_gradient_offset())
+            buckets = late if part == "late" else early
+        for a, b in buckets:
+            w = dist.all_reduce(model._gflat[a:b], group=group, async_op=async_op)
+            if async_op:
+                works.append(w)
+    return works
 
 
 def train_step(model, loss_fn: SegLoss, opt: FusedSGD, images: torch.Tensor, labels: torch.Tensor, group=None):
@@ -193,7 +217,9 @@ class GraphedStep:
     world == 1: ONE graph = zero_grad + forward + loss + backward + SGD (through torch.autograd).
     world  > 1: no collective is ever captured.  Three graphs with the two RCCL all-reduces between them, driven through
     the engine directly (no autograd):  A = zero_grad + forward + per-pixel softmax / CE / Dice partial sums;
-    all-reduce(28 floats);  B = loss gradient + backward tape;  all-reduce(flat gradient arena);  C = fused SGD."""
+    all-reduce(28 floats);  B1 = loss gradient + backward of decoders and bridge;  async all-reduce of their gradient buckets
+    (72 % of the live bytes) on the collective stream while B2 = the encoder's backward runs;  all-reduce of the encoder
+    buckets;  C = fused SGD."""
 
     def __init__(self, model, loss_fn: SegLoss, opt: FusedSGD, images: torch.Tensor, labels: torch.Tensor, group=None, warmup: int = 3,
                  force_split: bool = False):
@@ -206,7 +232,7 @@ class GraphedStep:
         with torch.cuda.stream(side):
             for _ in range(warmup):
                 if self.split:
-                    self._fwd(); self._reduce_sums(); self._bwd(); allreduce_gradients(model, group); opt.step()
+                    self._fwd(); self._reduce_sums(); self._bwd(); self._bwd_rest(); allreduce_gradients(model, group); opt.step()
                 else:
                     train_step(model, loss_fn, opt, self.x, self.y, group)
         torch.cuda.current_stream().wait_stream(side)
@@ -223,6 +249,9 @@ class GraphedStep:
             self.g_bwd = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_bwd):
                 self._bwd()
+            self.g_bwd_rest = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_bwd_rest):
+                self._bwd_rest()
             allreduce_gradients(model, group)
             self.g_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_opt):
@@ -254,7 +283,10 @@ class GraphedStep:
         d = torch.empty((B, C, H, W), dtype=torch.float32, device=self._prob.device)
         L.tc_seg_loss_bwd(self._prob.data_ptr(), self.y.data_ptr(), self._sums.data_ptr(), d.data_ptr(), B, C, H * W, float(lf.w_ce),
                           float(lf.w_dice), float(self._npix), 1.0, None, TC_F32, stream)
-        M._backward(self._G, self._out_var, d)
+        M._backward(self._G, self._out_var, d, until="encoder_done")     # loss gradient, decoders, bridge
+
+    def _bwd_rest(self):
+        self.model._backward_finish(self._G)                            # the encoder
         self._G = self._out_var = None
 
     def __call__(self, images: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None):
@@ -265,6 +297,10 @@ class GraphedStep:
         if self.split:
             self._reduce_sums()                      # C2: in place on the static 28-float buffer
             self.g_bwd.replay()
-            allreduce_gradients(self.model, self.group)      # C1
+            works = allreduce_gradients(self.model, self.group, "late", async_op=True)      # C1, bridge + decoder buckets: the
+            self.g_bwd_rest.replay()                                                        # collective stream waits for g_bwd only
+            works += allreduce_gradients(self.model, self.group, "early", async_op=True)    # C1, encoder buckets
+            for w in works:
+                w.wait()                                     # the compute stream waits for the collectives, the host does not
             self.g_opt.replay()
         return self.out
