@@ -379,3 +379,27 @@ def eval_dice(counts):
     for inter, p, g in counts[1:].tolist():
         out.append(2.0 * inter / (p + g) if (p > 0 and g > 0) else (1.0 if p > 0 else 0.0))
     return out
+
+
+def eval_hd95(pred, gt, spacing=None):
+    """95th-percentile symmetric surface distance by brute force, the definition medpy.metric.binary.hd95 implements (called at
+    utils.py:55): a surface voxel is a mask voxel with at least one face-neighbour (connectivity 1; outside the array counts as
+    background... as in scipy's binary_erosion with border_value 0) outside the mask; distances are Euclidean between voxel
+    centres scaled by `spacing`; both directions pooled, numpy percentile 95.  Small masks only (O(n^2))."""
+    import numpy as np
+    pred, gt = np.asarray(pred) > 0, np.asarray(gt) > 0
+    sp = np.ones(pred.ndim) if spacing is None else np.asarray(spacing, np.float64)
+
+    def surface(m):
+        pad = np.pad(m, 1, constant_values=False)
+        inner = np.ones_like(m)
+        for ax in range(m.ndim):
+            for sh in (-1, 1):
+                sl = [slice(1, -1)] * m.ndim
+                sl[ax] = slice(1 + sh, pad.shape[ax] - 1 + sh)
+                inner &= pad[tuple(sl)]
+        return np.argwhere(m & ~inner) * sp
+
+    a, b = surface(pred), surface(gt)
+    d = np.sqrt(((a[:, None, :] - b[None, :, :]) ** 2).sum(-1))
+    return float(np.percentile(np.hstack((d.min(1), d.min(0))), 95))

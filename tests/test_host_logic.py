@@ -100,3 +100,38 @@ def test_eval_dice_conventions():
     assert abs(d_prod[0] - 2.0 * (p1 & g1).sum().item() / (p1.sum().item() + g1.sum().item())) < 1e-12
     assert d_prod[2] == 0.0                                          # never predicted -> 0
     assert d_prod[3] in (0.0, 1.0)                                   # label-free class: 1 if predicted anywhere, else 0
+
+
+def test_hd95_follows_its_definition():
+    """transception_amd.evaluate.hd95 (scipy restatement of medpy's algorithm, utils.py:55) against the brute-force oracle."""
+    import numpy as np
+    from oracle.transception_oracle import eval_hd95
+    from transception_amd.evaluate import calculate_metric_percase, hd95
+    g = np.random.default_rng(0)
+    yy, xx = np.mgrid[0:40, 0:48]
+    for t in range(6):
+        cy, cx, r = g.uniform(12, 28), g.uniform(12, 36), g.uniform(4, 10)
+        a = (yy - cy) ** 2 + (xx - cx) ** 2 < r * r
+        b = (yy - cy - g.uniform(-4, 4)) ** 2 / 1.5 + (xx - cx - g.uniform(-4, 4)) ** 2 < (r + g.uniform(-2, 2)) ** 2
+        if not b.any():
+            continue
+        assert abs(hd95(a, b) - eval_hd95(a, b)) < 1e-9
+        assert abs(hd95(a, b, voxelspacing=(1.0, 2.5)) - eval_hd95(a, b, (1.0, 2.5))) < 1e-9
+    zz, yy, xx = np.mgrid[0:12, 0:20, 0:20]
+    a = (zz - 6) ** 2 + (yy - 9) ** 2 + (xx - 10) ** 2 < 25
+    b = (zz - 5) ** 2 + (yy - 11) ** 2 + (xx - 9) ** 2 < 30
+    assert abs(hd95(a, b) - eval_hd95(a, b)) < 1e-9
+    assert hd95(a, a) == 0.0
+    # calculate_metric_percase conventions (utils.py:50-60)
+    d, h = calculate_metric_percase(a.astype(np.uint8), b.astype(np.uint8))
+    assert abs(d - 2.0 * (a & b).sum() / (a.sum() + b.sum())) < 1e-12 and abs(h - eval_hd95(a, b)) < 1e-9
+    assert calculate_metric_percase(a.astype(np.uint8), np.zeros_like(a, np.uint8)) == (1.0, 0.0)
+    assert calculate_metric_percase(np.zeros_like(a, np.uint8), b.astype(np.uint8)) == (0.0, 0.0)
+
+
+def test_trainer_schedule_helpers():
+    from transception_amd.trainer import checkpoint_epochs, scaled_base_lr
+    assert checkpoint_epochs(400, 20) == [219, 239, 259, 279, 299, 319, 339, 359, 379, 399]
+    assert checkpoint_epochs(3, 20) == [2] and checkpoint_epochs(150, 50)[-1] == 149 and 99 in checkpoint_epochs(150, 50)
+    assert scaled_base_lr(0.05, 24) == 0.05 and scaled_base_lr(0.05, 16) == 0.05
+    assert abs(scaled_base_lr(0.05, 20) - 0.05 * 20 / 24) < 1e-12

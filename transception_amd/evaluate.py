@@ -6,7 +6,10 @@ normalised and pushed through the eval-mode forward in batches, `argmax(softmax(
 the Dice score are one HIP kernel (`tc_argmax_counts`), and only the uint8 label map returns to the host.
 
 Host-side pieces that stay on the CPU exactly as in the reference: the order-3 `scipy.ndimage.zoom` of a slice to the network
-size and the order-0 zoom of the prediction back (`utils.py:69-70,83-84`), and HD95 (medpy, not available here).
+size and the order-0 zoom of the prediction back (`utils.py:69-70,83-84`), and HD95: `medpy.metric.binary.hd95` (`utils.py:55`;
+medpy is not installable here) restated from its published algorithm on scipy.ndimage -- surface voxels = mask minus its
+erosion (connectivity 1), distances by the Euclidean distance transform of the other mask's surface, 95th percentile of both
+directions pooled.  Parity with medpy itself is unpinned; tests pin it to a brute-force evaluation of that definition.
 """
 from __future__ import annotations
 
@@ -52,6 +55,37 @@ def dice_from_counts(counts: np.ndarray) -> List[float]:
     return out
 
 
+def surface_distances(result: np.ndarray, reference: np.ndarray, voxelspacing=None, connectivity: int = 1) -> np.ndarray:
+    """Distances from every surface voxel of `result` to the nearest surface voxel of `reference` (medpy __surface_distances)."""
+    from scipy.ndimage import binary_erosion, distance_transform_edt, generate_binary_structure
+    result, reference = np.atleast_1d(result.astype(bool)), np.atleast_1d(reference.astype(bool))
+    if not result.any() or not reference.any():
+        raise RuntimeError("surface distances need non-empty masks")
+    footprint = generate_binary_structure(result.ndim, connectivity)
+    result_border = result ^ binary_erosion(result, structure=footprint, iterations=1)
+    reference_border = reference ^ binary_erosion(reference, structure=footprint, iterations=1)
+    dt = distance_transform_edt(~reference_border, sampling=voxelspacing)
+    return dt[result_border]
+
+
+def hd95(result: np.ndarray, reference: np.ndarray, voxelspacing=None, connectivity: int = 1) -> float:
+    """95th percentile of the symmetric surface distances (medpy.metric.binary.hd95, called at utils.py:55)."""
+    a = surface_distances(result, reference, voxelspacing, connectivity)
+    b = surface_distances(reference, result, voxelspacing, connectivity)
+    return float(np.percentile(np.hstack((a, b)), 95))
+
+
+def calculate_metric_percase(pred: np.ndarray, gt: np.ndarray) -> Tuple[float, float]:
+    """(dice, hd95) of one class of one volume with the reference's conventions (utils.py:50-60)."""
+    pred, gt = pred > 0, gt > 0
+    ps, gs = int(pred.sum()), int(gt.sum())
+    if ps > 0 and gs > 0:
+        return float(2.0 * np.logical_and(pred, gt).sum() / (ps + gs)), hd95(pred, gt)
+    if ps > 0:
+        return 1.0, 0.0
+    return 0.0, 0.0
+
+
 @torch.no_grad()
 def predict_slices(model, slices: torch.Tensor, batch: int = 16) -> torch.Tensor:
     """slices: float [N,H,W] in [0,1] at the network size (a multiple of 32); returns uint8 [N,H,W] labels.
@@ -70,8 +104,9 @@ def predict_slices(model, slices: torch.Tensor, batch: int = 16) -> torch.Tensor
 
 @torch.no_grad()
 def evaluate_volume(model, image: np.ndarray, label: np.ndarray, classes: int = 9, patch_size=(224, 224),
-                    batch: int = 16) -> List[float]:
-    """`test_single_volume` for one [D,H,W] volume (utils.py:63-98): per-class Dice for classes 1..classes-1.
+                    batch: int = 16, with_hd95: bool = False):
+    """`test_single_volume` for one [D,H,W] volume (utils.py:63-98): per-class Dice for classes 1..classes-1, or with
+    `with_hd95` the reference's metric_list of (dice, hd95) pairs.
     Slices are zoomed on the host exactly as the reference does; everything between runs on the GPU."""
     from scipy.ndimage import zoom
     dev = next(model.parameters()).device
@@ -81,8 +116,31 @@ def evaluate_volume(model, image: np.ndarray, label: np.ndarray, classes: int = 
     pred = predict_slices(model, torch.from_numpy(sl.astype(np.float32)).to(dev), batch).cpu().numpy()
     if resize:
         pred = np.stack([zoom(pred[d], (X / patch_size[0], Y / patch_size[1]), order=0) for d in range(D)])
+    if with_hd95:
+        return [calculate_metric_percase(pred == k, label == k) for k in range(1, classes)]
     counts = np.zeros((classes, 3), dtype=np.float64)
     for k in range(classes):
         p, g = pred == k, label == k
         counts[k] = (np.logical_and(p, g).sum(), p.sum(), g.sum())
     return dice_from_counts(counts)
+
+
+def inference(model, volumes, classes: int = 9, img_size: int = 224, batch: int = 16, log=None) -> Tuple[float, float]:
+    """trainer.py:25-47: mean Dice and mean HD95 over `volumes` = iterable of (image [D,H,W] in [0,1], label [D,H,W], case name)."""
+    total, n = 0.0, 0
+    for i, (image, label, name) in enumerate(volumes):
+        m = np.array(evaluate_volume(model, np.asarray(image), np.asarray(label), classes, (img_size, img_size), batch, with_hd95=True))
+        total = total + m
+        n += 1
+        if log:
+            log(' idx %d case %s mean_dice %f mean_hd95 %f' % (i, name, m.mean(axis=0)[0], m.mean(axis=0)[1]))
+    if n == 0:
+        raise ValueError("inference() needs at least one volume")
+    total = total / n
+    if log:
+        for k in range(1, classes):
+            log('Mean class %d mean_dice %f mean_hd95 %f' % (k, total[k - 1][0], total[k - 1][1]))
+    performance, mean_hd95 = float(total.mean(axis=0)[0]), float(total.mean(axis=0)[1])
+    if log:
+        log('Testing performance in best val model: mean_dice : %f mean_hd95 : %f' % (performance, mean_hd95))
+    return performance, mean_hd95

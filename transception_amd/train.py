@@ -99,8 +99,9 @@ class FusedSGD:
     Parameters that never receive a gradient (332 tensors in the reference) are left untouched, exactly as
     torch.optim.SGD skips `p.grad is None`: the update runs over the used segments only."""
 
-    def __init__(self, model, lr: float = 0.05, momentum: float = 0.9, weight_decay: float = 1e-4):
+    def __init__(self, model, lr: float = 0.05, momentum: float = 0.9, weight_decay: float = 1e-4, clip_norm: Optional[float] = None):
         self.model, self.lr, self.momentum, self.wd = model, lr, momentum, weight_decay
+        self.clip_norm = clip_norm                       # nn.utils.clip_grad_norm_(max_norm, 2) before the update (trainer.py:147-148)
         self.buf: Optional[torch.Tensor] = None
         self.steps = 0
         self._segments = None
@@ -142,6 +143,8 @@ class FusedSGD:
             segs = [(off, min(n, flat.numel() - off)) for off, n in self._segs()]
             self._segs_dev = torch.tensor([v for s in segs for v in s], dtype=torch.int64, device=flat.device)
             self._nseg, self._maxlen = len(segs), max(n for _, n in segs)
+        if self.clip_norm:                               # grad-less parameters hold zeros, so the arena norm is the model's norm
+            g.mul_(torch.clamp(self.clip_norm / (torch.linalg.vector_norm(g) + 1e-6), max=1.0))
         L.tc_sgd_step_multi(flat.data_ptr(), g.data_ptr(), self.buf.data_ptr(), self._segs_dev.data_ptr(), self._nseg, self._maxlen,
                             float(self.lr), self.lr_dev.data_ptr(), float(self.momentum), float(self.wd), float(grad_scale),
                             int(self.steps == 0), stream)
