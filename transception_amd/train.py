@@ -212,6 +212,11 @@ def train_step(model, loss_fn: SegLoss, opt: FusedSGD, images: torch.Tensor, lab
     return loss, ce, dice
 
 
+# Only the capturing thread is held to the capture rules: the RCCL watchdog thread polls events and the input pipeline's reader
+# thread page-locks staging buffers while a step is being captured.
+_CAPTURE_MODE = "thread_local"
+
+
 class GraphedStep:
     """A whole training step captured into hipGraphs and replayed: ~1800 kernel launches per step become graph launches,
     removing the host from the loop.  Inputs are copied into static buffers; the learning rate is a device scalar
@@ -242,22 +247,22 @@ class GraphedStep:
         torch.cuda.synchronize()
         self.g_main = torch.cuda.CUDAGraph()
         if not self.split:
-            with torch.cuda.graph(self.g_main):
+            with torch.cuda.graph(self.g_main, capture_error_mode=_CAPTURE_MODE):
                 self.out = train_step(model, loss_fn, opt, self.x, self.y, None)
             self.g_bwd = self.g_opt = None
         else:
-            with torch.cuda.graph(self.g_main):
+            with torch.cuda.graph(self.g_main, capture_error_mode=_CAPTURE_MODE):
                 self._fwd()
             self._reduce_sums()
             self.g_bwd = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_bwd):
+            with torch.cuda.graph(self.g_bwd, capture_error_mode=_CAPTURE_MODE):
                 self._bwd()
             self.g_bwd_rest = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_bwd_rest):
+            with torch.cuda.graph(self.g_bwd_rest, capture_error_mode=_CAPTURE_MODE):
                 self._bwd_rest()
             allreduce_gradients(model, group)
             self.g_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_opt):
+            with torch.cuda.graph(self.g_opt, capture_error_mode=_CAPTURE_MODE):
                 opt.step()
 
     # ---- the three pieces of the split step (engine driven directly; no torch.autograd in between)
