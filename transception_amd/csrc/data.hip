@@ -6,7 +6,8 @@
 //                               -> Gaussian blur sigma 1 (9 taps, mirror) -> linear contrast -> additive Gaussian noise,
 //                               one 32x32 output tile (+4 halo when blurring) per workgroup, staged in LDS
 //   spline_prefilter_cols/rows  cubic B-spline coefficients of the slice, mirror boundary, fp64 like scipy (ni_splines.c):
-//                               columns one thread per column (coalesced), rows 64 rows per workgroup through 64x64 LDS tiles
+//                               columns in 32-row segments with a 28-row run-in (lanes along x, coalesced), rows one wavefront
+//                               per row as shuffle scans; simple one-thread-per-line kernels for ragged sizes
 //   zoom_sample_kernel          4x4-tap B-spline evaluation at o*(in-1)/(out-1), nearest label, normalise, int64 labels
 //
 // All of it is HBM-streaming work (16 slices = 16 MB in, 3 MB out); none of it is GEMM-shaped.  Coordinates are computed in
@@ -187,6 +188,62 @@ __global__ __launch_bounds__(256) void spline_prefilter_cols_kernel(const float*
         for (int k = 0; k < U; ++k) {
             if (i0 - k >= 0) { nxt = z * (nxt - v[k]); c[(long long)(i0 - k) * W] = nxt; }
         }
+    }
+}
+
+// Columns of at least 128 rows, a multiple of 32: the pole's impulse response dies out in 28 samples (|z|^28 = 1e-16), so a thread
+// can produce 32 consecutive coefficients of a column from a 28-row run-in above and below them -- 16x the threads of the
+// one-thread-per-column form, each with a short dependency chain.  The first segment starts from the exact mirror sum, the
+// last one ends with the exact anti-causal initial value.
+template <int L, int WU>
+__global__ __launch_bounds__(256) void spline_prefilter_cols_seg_kernel(const float* __restrict__ img, double* __restrict__ coef, int B, int H, int W) {
+    const int nseg = H / L;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)B * W * nseg) return;
+    const int x = (int)(t % W), seg = (int)((t / W) % nseg), b = (int)(t / ((long long)W * nseg));
+    const float* src = img + (long long)b * H * W + x;
+    double* c = coef + (long long)b * H * W + x;
+    const double z = kPole;
+    const int s0 = seg * L, lo = s0 - WU;
+    const bool first = seg == 0, last = seg == nseg - 1;
+    double prev = 0.0;
+    if (first) {                                                       // c0 = sum_{i < 64} z^i 6 s[i]
+        double zi = 1.0;
+#pragma unroll 1
+        for (int i0 = 0; i0 < 64; i0 += 16) {
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = src[(long long)(i0 + i) * W];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { prev += zi * 6.0 * (double)v[i]; zi *= z; }
+        }
+    }
+    double cp[L + WU];                                                 // causal values of rows s0 .. s0 + L + WU - 1
+    constexpr int U = 16;
+#pragma unroll
+    for (int r0 = 0; r0 < L + 2 * WU; r0 += U) {
+        float v[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const int row = lo + r0 + k;
+            v[k] = (r0 + k < L + 2 * WU && row >= 0 && row < H) ? src[(long long)row * W] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const int r = r0 + k, row = lo + r;
+            if (r < L + 2 * WU) {
+                if (row >= 0 && row < H && !(first && row == 0)) prev = 6.0 * (double)v[k] + z * prev;
+                if (r >= WU) cp[r - WU] = prev;                        // (rows beyond H-1 of the last segment are never read back)
+            }
+        }
+    }
+    double nxt = 0.0;
+#pragma unroll
+    for (int r = L + WU - 1; r >= 0; --r) {
+        if (last && r >= L) continue;
+        if (last && r == L - 1) nxt = (z * cp[L - 2] + cp[L - 1]) * z / (z * z - 1.0);
+        else nxt = z * (nxt - cp[r]);
+        if (r < L) c[(long long)(s0 + r) * W] = nxt;
     }
 }
 
@@ -397,7 +454,11 @@ extern "C" int tc_slice_augment(const float* img, const unsigned char* lab, cons
 extern "C" int tc_spline_prefilter(const float* img, double* coef, int B, int H, int W, void* stream) {
     if (!img || !coef || B <= 0 || H <= 0 || W <= 0) return TC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(spline_prefilter_cols_kernel, dim3((unsigned)(((long long)B * W + 255) / 256)), dim3(256), 0, s, img, coef, B, H, W);
+    if (H >= 128 && H % 32 == 0)
+        hipLaunchKernelGGL((spline_prefilter_cols_seg_kernel<32, 28>), dim3((unsigned)(((long long)B * W * (H / 32) + 255) / 256)), dim3(256), 0, s,
+                           img, coef, B, H, W);
+    else
+        hipLaunchKernelGGL(spline_prefilter_cols_kernel, dim3((unsigned)(((long long)B * W + 255) / 256)), dim3(256), 0, s, img, coef, B, H, W);
     const long long rows = (long long)B * H;
     const dim3 wg((unsigned)((rows + 3) / 4));
     switch (W % 64 == 0 ? W / 64 : 0) {
