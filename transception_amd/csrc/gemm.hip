@@ -9,6 +9,7 @@
 // (weight gradients accumulate into the fp32 gradient arena); an optional row-sum of op(A) (the bias gradient that
 // belongs to a dW GEMM) is produced by the blocks of the first N-tile.
 #include "tc_common.h"
+#include <type_traits>
 #include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -371,29 +372,33 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev p) {
 
 // ---------------------------------------------------------------------------------------------- bf16 path
 // Load an 8-wide strip (16 B) of an operand tile as raw bf16 bits.
-__device__ __forceinline__ uint4 load_strip8(const bf16_t* base, int ld, int x, int k, int X, int K, bool trans, bool vec) {
+// Operand strips (8 bf16 along K, or along M/N for a transposed operand).  The common case -- an aligned operand and a strip
+// wholly inside the matrix -- must not sit behind a per-lane branch, and its data must not be touched before it is needed: the
+// compiler closes every divergent region that contains a load with s_waitcnt vmcnt(0), and a select on the loaded value waits
+// for it as well; either turns the strips of one slab into as many sequential memory round trips (measured: 1.2-1.7 us per
+// 64-deep slab).  So strip_raw() issues the 16-byte load unconditionally (strips not wholly inside read the operand's first 16
+// bytes, always valid and aligned) and the zeroing of what lies outside happens when the slab is written to LDS, a slab or two
+// later.  A workgroup with partially covered strips (K / M / N tails not a multiple of 8) or unaligned operands runs the
+// general loop instead, which resolves every strip at fetch time.
+__device__ __forceinline__ bool strip_whole(int x, int k, int X, int K, bool trans) {
+    return trans ? (k < K && x + 7 < X) : (x < X && k + 7 < K);
+}
+__device__ __forceinline__ uint4 strip_raw(const bf16_t* base, const bf16_t* safe, int ld, int x, int k, int X, int K, bool trans) {
+    const long long off = trans ? (long long)k * ld + x : (long long)x * ld + k;
+    return *reinterpret_cast<const uint4*>(strip_whole(x, k, X, K, trans) ? base + off : safe);
+}
+__device__ __forceinline__ uint4 strip_tail(const bf16_t* base, int ld, int x, int k, int X, int K, bool trans) {
     union { uint4 v; bf16_t e[8]; } u;
     u.v = make_uint4(0u, 0u, 0u, 0u);
-    if (!trans) {
-        if (x < X) {
-            const bf16_t* p = base + (long long)x * ld + k;
-            if (vec && k + 7 < K) u.v = *reinterpret_cast<const uint4*>(p);
-            else {
+    const bf16_t* p = base + (trans ? (long long)k * ld + x : (long long)x * ld + k);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) if (k + i < K) u.e[i] = p[i];
-            }
-        }
-    } else {
-        if (k < K) {
-            const bf16_t* p = base + (long long)k * ld + x;
-            if (vec && x + 7 < X) u.v = *reinterpret_cast<const uint4*>(p);
-            else {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) if (x + i < X) u.e[i] = p[i];
-            }
-        }
-    }
+    for (int i = 0; i < 8; ++i) if (trans ? (x + i < X) : (k + i < K)) u.e[i] = p[i];
     return u.v;
+}
+// general path (rare)
+__device__ __forceinline__ uint4 load_strip8(const bf16_t* base, int ld, int x, int k, int X, int K, bool trans) {
+    const bool in = trans ? (k < K) : (x < X);
+    return in ? strip_tail(base, ld, x, k, X, K, trans) : make_uint4(0u, 0u, 0u, 0u);
 }
 
 // Body of one workgroup of the bf16 GEMM: (bx, by, bz) of a (gx, gy, *) grid.  The LDS buffers come from the caller so that the
@@ -434,23 +439,34 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmDev& p, const int bx, c
     // strip ownership: K-contiguous operands: consecutive threads walk along K (coalesced 16-B loads, vector LDS writes);
     // transposed operands: lanes own consecutive k-rows of the slab for one 8-wide x strip, so that each of the 8 scalar
     // transposed LDS writes of a wave hits 64 consecutive bf16 of one row (no bank conflicts; the naive mapping strides rows by 8).
-    auto fetch = [&](uint4 (&ra)[SA], uint4 (&rb)[SB], int k0) {
+    auto a_xy = [&](int i, int k0, int& x, int& k) {
+        const int f = tid + i * 256;
+        if (!TA) { x = m0 + f / (BK / 8); k = k0 + (f % (BK / 8)) * 8; }
+        else { k = k0 + f % BK; x = m0 + (f / BK) * 8; }
+    };
+    auto b_xy = [&](int i, int k0, int& x, int& k) {
+        const int f = tid + i * 256;
+        if (TB) { x = n0 + f / (BK / 8); k = k0 + (f % (BK / 8)) * 8; }
+        else { k = k0 + f % BK; x = n0 + (f / BK) * 8; }
+    };
+    auto b_base = [&](int k0) { return (!TB && p.bgap_every) ? B + (long long)(k0 / p.bgap_every) * p.bgap : B; };
+    // FAST (decided once per workgroup, below): both operands 16-byte aligned and no strip of this workgroup's slabs is partially
+    // covered -- the K loop then contains no branch at all around its loads.  Otherwise: the general loader, everything at fetch time.
+    auto fetch = [&](auto FT, uint4 (&ra)[SA], uint4 (&rb)[SB], int k0) {
+        constexpr bool FAST = decltype(FT)::value;
+        int x, k;
 #pragma unroll
         for (int i = 0; i < SA; ++i) {
-            const int f = tid + i * 256;
-            if (!TA) { const int row = f / (BK / 8), kq = f % (BK / 8);
-                ra[i] = load_strip8(A, p.lda, m0 + row, k0 + kq * 8, p.M, kend, false, p.vecA); }
-            else { const int k = f % BK, mq = f / BK;
-                ra[i] = load_strip8(A, p.lda, m0 + mq * 8, k0 + k, p.M, kend, true, p.vecA); }
+            a_xy(i, k0, x, k);
+            if constexpr (FAST) ra[i] = strip_raw(A, A, p.lda, x, k, p.M, kend, TA);
+            else ra[i] = load_strip8(A, p.lda, x, k, p.M, kend, TA);
         }
+        const bf16_t* Bk = b_base(k0);
 #pragma unroll
         for (int i = 0; i < SB; ++i) {
-            const int f = tid + i * 256;
-            if (TB) { const int row = f / (BK / 8), kq = f % (BK / 8);
-                rb[i] = load_strip8(B, p.ldb, n0 + row, k0 + kq * 8, p.N, kend, false, p.vecB); }
-            else { const int k = f % BK, nq = f / BK;
-                const bf16_t* Bk = p.bgap_every ? B + (long long)(k0 / p.bgap_every) * p.bgap : B;
-                rb[i] = load_strip8(Bk, p.ldb, n0 + nq * 8, k0 + k, p.N, kend, true, p.vecB); }
+            b_xy(i, k0, x, k);
+            if constexpr (FAST) rb[i] = strip_raw(Bk, B, p.ldb, x, k, p.N, kend, !TB);
+            else rb[i] = load_strip8(Bk, p.ldb, x, k, p.N, kend, !TB);
         }
     };
     auto put_t = [&](bf16_t* base, int x0, int k, uint4 v) {       // transposed write: 8 rows x0.., column k
@@ -459,18 +475,27 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmDev& p, const int bx, c
 #pragma unroll
         for (int i = 0; i < 8; ++i) base[(x0 + i) * LDT + k] = u.e[i];
     };
-    auto stage = [&](const uint4 (&ra)[SA], const uint4 (&rb)[SB], bf16_t* as, bf16_t* bs) {
+    auto stage = [&](auto FT, const uint4 (&ra)[SA], const uint4 (&rb)[SB], int k0, bf16_t* as, bf16_t* bs) {
+        constexpr bool FAST = decltype(FT)::value;
+        int x, k;
 #pragma unroll
         for (int i = 0; i < SA; ++i) {
             const int f = tid + i * 256;
-            if (!TA) { const int row = f / (BK / 8), kq = f % (BK / 8); *reinterpret_cast<uint4*>(&as[row * LDT + kq * 8]) = ra[i]; }
-            else { const int k = f % BK, mq = f / BK; put_t(as, mq * 8, k, ra[i]); }
+            a_xy(i, k0, x, k);
+            uint4 v = ra[i];
+            if constexpr (FAST) { if (!strip_whole(x, k, p.M, kend, TA)) v = make_uint4(0u, 0u, 0u, 0u); }
+            if (!TA) { const int row = f / (BK / 8), kq = f % (BK / 8); *reinterpret_cast<uint4*>(&as[row * LDT + kq * 8]) = v; }
+            else { const int kl = f % BK, mq = f / BK; put_t(as, mq * 8, kl, v); }
         }
+        const bf16_t* Bk = b_base(k0);
 #pragma unroll
         for (int i = 0; i < SB; ++i) {
             const int f = tid + i * 256;
-            if (TB) { const int row = f / (BK / 8), kq = f % (BK / 8); *reinterpret_cast<uint4*>(&bs[row * LDT + kq * 8]) = rb[i]; }
-            else { const int k = f % BK, nq = f / BK; put_t(bs, nq * 8, k, rb[i]); }
+            b_xy(i, k0, x, k);
+            uint4 v = rb[i];
+            if constexpr (FAST) { if (!strip_whole(x, k, p.N, kend, !TB)) v = make_uint4(0u, 0u, 0u, 0u); }
+            if (TB) { const int row = f / (BK / 8), kq = f % (BK / 8); *reinterpret_cast<uint4*>(&bs[row * LDT + kq * 8]) = v; }
+            else { const int kl = f % BK, nq = f / BK; put_t(bs, nq * 8, kl, v); }
         }
     };
     float rsum = 0.f;
@@ -498,38 +523,47 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmDev& p, const int bx, c
         }
     };
 
+    auto kloop = [&](auto FT) {
+    // FAST: prefetches are issued unconditionally (a slab beyond kend reads the operands' first bytes and is never used) -- a
+    // conditional prefetch makes the compiler wait for ALL outstanding loads, the new slab's included, before the older slab is used
+    constexpr bool FAST = decltype(FT)::value;
     uint4 ra0[SA], rb0[SB], ra1[SA], rb1[SB];
     if (!DB) {
-        if (kbeg < kend) fetch(ra0, rb0, kbeg);
+        if (kbeg < kend) fetch(FT, ra0, rb0, kbeg);                  // (one register set: a conditional prefetch costs nothing here)
         for (int k0 = kbeg; k0 < kend; k0 += BK) {
-            stage(ra0, rb0, As[0], Bs[0]);
+            stage(FT, ra0, rb0, k0, As[0], Bs[0]);
             __syncthreads();
-            if (k0 + BK < kend) fetch(ra0, rb0, k0 + BK);
+            if (k0 + BK < kend) fetch(FT, ra0, rb0, k0 + BK);
             compute(As[0], Bs[0]);
             __syncthreads();
         }
     } else if (kbeg < kend) {
-        fetch(ra0, rb0, kbeg);
-        if (kbeg + BK < kend) fetch(ra1, rb1, kbeg + BK);
-        stage(ra0, rb0, As[0], Bs[0]);
+        fetch(FT, ra0, rb0, kbeg);
+        if (FAST || kbeg + BK < kend) fetch(FT, ra1, rb1, kbeg + BK);
+        stage(FT, ra0, rb0, kbeg, As[0], Bs[0]);
         __syncthreads();
-        if (kbeg + 2 * BK < kend) fetch(ra0, rb0, kbeg + 2 * BK);
+        if (FAST || kbeg + 2 * BK < kend) fetch(FT, ra0, rb0, kbeg + 2 * BK);
         for (int k0 = kbeg;; k0 += 2 * BK) {
             // slab k0 sits in LDS buffer 0; slab k0+BK waits in register set 1; slab k0+2BK is arriving in set 0
             const bool has1 = k0 + BK < kend;
-            if (has1) stage(ra1, rb1, As[DB ? 1 : 0], Bs[DB ? 1 : 0]);
+            if (has1) stage(FT, ra1, rb1, k0 + BK, As[DB ? 1 : 0], Bs[DB ? 1 : 0]);
             compute(As[0], Bs[0]);
             if (!has1) break;
             __syncthreads();
-            if (k0 + 3 * BK < kend) fetch(ra1, rb1, k0 + 3 * BK);
+            if (FAST || k0 + 3 * BK < kend) fetch(FT, ra1, rb1, k0 + 3 * BK);
             const bool has2 = k0 + 2 * BK < kend;
-            if (has2) stage(ra0, rb0, As[0], Bs[0]);
+            if (has2) stage(FT, ra0, rb0, k0 + 2 * BK, As[0], Bs[0]);
             compute(As[DB ? 1 : 0], Bs[DB ? 1 : 0]);
             if (!has2) break;
             __syncthreads();
-            if (k0 + 4 * BK < kend) fetch(ra0, rb0, k0 + 4 * BK);
+            if (FAST || k0 + 4 * BK < kend) fetch(FT, ra0, rb0, k0 + 4 * BK);
         }
     }
+    };
+    // no partially covered strip anywhere in this workgroup's slabs: K range a multiple of 8 for K-contiguous operands, M / N a
+    // multiple of 8 for operands whose strips run along M / N
+    const bool fast = p.vecA && p.vecB && ((kend - kbeg) % 8 == 0 || (TA && !TB)) && (!TA || p.M % 8 == 0) && (TB || p.N % 8 == 0);
+    if (fast) kloop(std::true_type{}); else kloop(std::false_type{});
     if (do_rowsum && m0 + tid < p.M) atomicAdd(p.rowsum + b1 * p.sRow1 + m0 + tid, rsum);
     bool first = (ks == 0), atomic = p.atomic;
     if (p.fix_group) {
