@@ -323,41 +323,46 @@ template <int K, int CG> struct DwTile {
     static constexpr int IW = TW + K - 1, IH = TH + K - 1;
 };
 
-// stage rows [h0, h0+NH) x cols [w0, w0+NW) of image b (zero outside the map / past channel C) into LDS, pixel pitch PIXQ uint4
-template <typename T, int CG, int PIXQ>
-__device__ __forceinline__ void dw_stage(uint4* tile, const T* img, int ld, int h0, int w0, int NH, int NW, int H, int W, int crem) {
+// Tile fill, global -> registers -> LDS.  The loads are issued unconditionally (a position outside the map or past channel C reads
+// the tile's first valid vector instead) and the zeroing happens when the registers go to LDS: a load inside a per-lane branch, or
+// a select right behind it, makes the compiler wait for each load before issuing the next (s_waitcnt vmcnt(0) per element) and the
+// fill becomes a chain of memory round trips.
+template <typename T, int CG>
+__device__ __forceinline__ bool dw_inside(int v, int h0, int w0, int NH, int NW, int H, int W, int crem, int& off_pix, int& cgi) {
     constexpr int VEC = Vec16<T>::N;
-    for (int v = threadIdx.x; v < NH * NW * CG; v += 256) {
-        const int cgi = v % CG, pix = v / CG, ix = pix % NW, iy = pix / NW;
-        const int ih = h0 + iy, iw = w0 + ix;
-        uint4 r = make_uint4(0u, 0u, 0u, 0u);
-        if (ih >= 0 && ih < H && iw >= 0 && iw < W && cgi * VEC < crem)
-            r = *reinterpret_cast<const uint4*>(img + ((long long)ih * W + iw) * ld + cgi * VEC);
-        tile[pix * PIXQ + cgi] = r;
-    }
+    cgi = v % CG;
+    const int pix = v / CG, ix = pix % NW, iy = pix / NW;
+    const int ih = h0 + iy, iw = w0 + ix;
+    off_pix = ih * W + iw;
+    return v < NH * NW * CG && ih >= 0 && ih < H && iw >= 0 && iw < W && cgi * VEC < crem;
 }
-
-// the same fill split in two: global -> registers (issued a whole tile ahead), registers -> LDS
 template <typename T, int CG, int NREG>
 __device__ __forceinline__ void dw_fetch(uint4 (&reg)[NREG], const T* img, int ld, int h0, int w0, int NH, int NW, int H, int W, int crem) {
     constexpr int VEC = Vec16<T>::N;
 #pragma unroll
     for (int i = 0; i < NREG; ++i) {
-        const int v = threadIdx.x + i * 256;
-        const int cgi = v % CG, pix = v / CG, ix = pix % NW, iy = pix / NW;
-        const int ih = h0 + iy, iw = w0 + ix;
-        reg[i] = make_uint4(0u, 0u, 0u, 0u);
-        if (v < NH * NW * CG && ih >= 0 && ih < H && iw >= 0 && iw < W && cgi * VEC < crem)
-            reg[i] = *reinterpret_cast<const uint4*>(img + ((long long)ih * W + iw) * ld + cgi * VEC);
+        int op, cgi;
+        const bool ok = dw_inside<T, CG>(threadIdx.x + i * 256, h0, w0, NH, NW, H, W, crem, op, cgi);
+        reg[i] = *reinterpret_cast<const uint4*>(ok ? img + (long long)op * ld + cgi * VEC : img);
     }
 }
-template <int CG, int PIXQ, int NREG>
-__device__ __forceinline__ void dw_put(uint4* tile, const uint4 (&reg)[NREG], int NH, int NW) {
+template <typename T, int CG, int PIXQ, int NREG>
+__device__ __forceinline__ void dw_put(uint4* tile, const uint4 (&reg)[NREG], int h0, int w0, int NH, int NW, int H, int W, int crem) {
 #pragma unroll
     for (int i = 0; i < NREG; ++i) {
         const int v = threadIdx.x + i * 256;
-        if (v < NH * NW * CG) tile[(v / CG) * PIXQ + v % CG] = reg[i];
+        int op, cgi;
+        const bool ok = dw_inside<T, CG>(v, h0, w0, NH, NW, H, W, crem, op, cgi);
+        if (v < NH * NW * CG) tile[(v / CG) * PIXQ + cgi] = ok ? reg[i] : make_uint4(0u, 0u, 0u, 0u);
     }
+}
+// stage rows [h0, h0+NH) x cols [w0, w0+NW) of image b (zero outside the map / past channel C) into LDS, pixel pitch PIXQ uint4
+template <typename T, int CG, int PIXQ, int NH, int NW>
+__device__ __forceinline__ void dw_stage(uint4* tile, const T* img, int ld, int h0, int w0, int H, int W, int crem) {
+    constexpr int NREG = (NH * NW * CG + 255) / 256;
+    uint4 reg[NREG];
+    dw_fetch<T, CG, NREG>(reg, img, ld, h0, w0, NH, NW, H, W, crem);
+    dw_put<T, CG, PIXQ, NREG>(tile, reg, h0, w0, NH, NW, H, W, crem);
 }
 
 // LDS needs of the tile bodies, in uint4 (the multi-segment launches size one dynamic buffer for the largest body they contain)
@@ -392,7 +397,7 @@ __device__ __forceinline__ void dw_tile_body(const T* __restrict__ src, int lds_
     }
     const int tix = bx % tilesW, tiy = (bx / tilesW) % tilesH, b = bx / (tilesW * tilesH);
     const int oh0 = tiy * D::TH, ow0 = tix * D::TW;
-    dw_stage<T, CG, PIXQ>(tile, src + (long long)b * H * W * lds_ + c0, lds_, oh0 - P, ow0 - P, D::IH, D::IW, H, W, C - c0);
+    dw_stage<T, CG, PIXQ, D::IH, D::IW>(tile, src + (long long)b * H * W * lds_ + c0, lds_, oh0 - P, ow0 - P, H, W, C - c0);
     __syncthreads();
     const int cg = threadIdx.x % CG, pt = threadIdx.x / CG, run = pt % (D::TW / R), row = pt / (D::TW / R);
     const int oh = oh0 + row, owb = ow0 + run * R, c = c0 + cg * VEC;
@@ -431,19 +436,22 @@ __device__ __forceinline__ void dw_tile_body(const T* __restrict__ src, int lds_
                 for (int e = 0; e < VEC; ++e) acc[r][e] += in[r + P][e];
         }
     }
+    T* dst0 = y + (((long long)b * H + oh) * W + owb) * ldy + c;
+    if (accumulate) {                                         // all R reads in flight at once (columns past W re-read column owb)
+        uint4 old[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        if (owb + r < W) {
-            T* dst = y + (((long long)b * H + oh) * W + owb + r) * ldy + c;
-            if (accumulate) {
-                float q[VEC];
-                unpack16<T>(*reinterpret_cast<const uint4*>(dst), q);
+        for (int r = 0; r < R; ++r) old[r] = *reinterpret_cast<const uint4*>(dst0 + (owb + r < W ? (long long)r * ldy : 0));
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) acc[r][e] += q[e];
-            }
-            *reinterpret_cast<uint4*>(dst) = pack16<T>(acc[r]);
+        for (int r = 0; r < R; ++r) {
+            float q[VEC];
+            unpack16<T>(old[r], q);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[r][e] += q[e];
         }
     }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (owb + r < W) *reinterpret_cast<uint4*>(dst0 + (long long)r * ldy) = pack16<T>(acc[r]);
 }
 
 template <typename T, int K, int CG, int MODE>
@@ -507,14 +515,16 @@ __device__ __forceinline__ void dw_tile_wgrad_body(const T* __restrict__ x, int 
     if (PF && bx < ntiles) fetch(bx);
     for (int tidx = bx; tidx < ntiles; tidx += gx) {
         __syncthreads();
-        if (PF) {
-            dw_put<CG, PIXQ, NX>(xt, xr, D::IH, D::IW);
-            dw_put<CG, PIXQ, ND>(dt, dr, D::TH, D::TW);
-        } else {
+        {
             int b, oh0, ow0;
             tile_org(tidx, b, oh0, ow0);
-            dw_stage<T, CG, PIXQ>(xt, x + (long long)b * H * W * ldx + c0, ldx, oh0 - P, ow0 - P, D::IH, D::IW, H, W, C - c0);
-            dw_stage<T, CG, PIXQ>(dt, dy + (long long)b * H * W * lddy + c0, lddy, oh0, ow0, D::TH, D::TW, H, W, C - c0);
+            if (PF) {
+                dw_put<T, CG, PIXQ, NX>(xt, xr, oh0 - P, ow0 - P, D::IH, D::IW, H, W, C - c0);
+                dw_put<T, CG, PIXQ, ND>(dt, dr, oh0, ow0, D::TH, D::TW, H, W, C - c0);
+            } else {
+                dw_stage<T, CG, PIXQ, D::IH, D::IW>(xt, x + (long long)b * H * W * ldx + c0, ldx, oh0 - P, ow0 - P, H, W, C - c0);
+                dw_stage<T, CG, PIXQ, D::TH, D::TW>(dt, dy + (long long)b * H * W * lddy + c0, lddy, oh0, ow0, H, W, C - c0);
+            }
         }
         __syncthreads();
         if (PF && tidx + gx < ntiles) fetch(tidx + gx);
