@@ -397,9 +397,12 @@ __device__ __forceinline__ uint4 strip_tail(const bf16_t* base, int ld, int x, i
     return u.v;
 }
 // general path (rare)
-__device__ __forceinline__ uint4 load_strip8(const bf16_t* base, int ld, int x, int k, int X, int K, bool trans) {
+__device__ __forceinline__ uint4 load_strip8(const bf16_t* base, int ld, int x, int k, int X, int K, bool trans, bool vec) {
     const bool in = trans ? (k < K) : (x < X);
-    return in ? strip_tail(base, ld, x, k, X, K, trans) : make_uint4(0u, 0u, 0u, 0u);
+    if (!in) return make_uint4(0u, 0u, 0u, 0u);
+    if (vec && strip_whole(x, k, X, K, trans))
+        return *reinterpret_cast<const uint4*>(base + (trans ? (long long)k * ld + x : (long long)x * ld + k));
+    return strip_tail(base, ld, x, k, X, K, trans);
 }
 
 // Body of one workgroup of the bf16 GEMM: (bx, by, bz) of a (gx, gy, *) grid.  The LDS buffers come from the caller so that the
@@ -460,14 +463,14 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmDev& p, const int bx, c
         for (int i = 0; i < SA; ++i) {
             a_xy(i, k0, x, k);
             if constexpr (FAST) ra[i] = strip_raw(A, A, p.lda, x, k, p.M, kend, TA);
-            else ra[i] = load_strip8(A, p.lda, x, k, p.M, kend, TA);
+            else ra[i] = load_strip8(A, p.lda, x, k, p.M, kend, TA, p.vecA);
         }
         const bf16_t* Bk = b_base(k0);
 #pragma unroll
         for (int i = 0; i < SB; ++i) {
             b_xy(i, k0, x, k);
             if constexpr (FAST) rb[i] = strip_raw(Bk, B, p.ldb, x, k, p.N, kend, !TB);
-            else rb[i] = load_strip8(Bk, p.ldb, x, k, p.N, kend, !TB);
+            else rb[i] = load_strip8(Bk, p.ldb, x, k, p.N, kend, !TB, p.vecB);
         }
     };
     auto put_t = [&](bf16_t* base, int x0, int k, uint4 v) {       // transposed write: 8 rows x0.., column k
