@@ -4,8 +4,9 @@
 //   fp32 storage -> v_mfma_f32_32x32x2_f32  (exact fp32 products, the parity path),  K-slab 16
 //   bf16 storage -> v_mfma_f32_32x32x16_bf16 (fp32 accumulate),                       K-slab 64
 // 256 threads = 4 waves (2 x 2); each wave owns a (BM/2) x (BN/2) sub-tile made of 32x32 MFMA blocks.  Operands are
-// staged through LDS "K-inner" (As[BM][BK+pad], Bs[BN][BK+pad]) whatever their global layout (transposed operands are
-// transposed on the LDS write), with a register prefetch of the next K-slab.  C may be fp32 while A/B are bf16
+// staged through LDS with a register prefetch of the next K-slabs: fp32 always "K-inner" (As[BM][BK+pad], transposed on
+// the LDS write); bf16 K-inner for K-contiguous operands and as-is ([BK][X+pad], gathered by ds_read_b64_tr_b16) for
+// operands stored [K][X].  The bf16 K loop keeps its global loads free of per-lane branches (see strip_raw).  C may be fp32 while A/B are bf16
 // (weight gradients accumulate into the fp32 gradient arena); an optional row-sum of op(A) (the bias gradient that
 // belongs to a dW GEMM) is produced by the blocks of the first N-tile.
 #include "tc_common.h"
@@ -405,6 +406,21 @@ __device__ __forceinline__ uint4 load_strip8(const bf16_t* base, int ld, int x, 
     return strip_tail(base, ld, x, k, X, K, trans);
 }
 
+// Operands whose global layout is [K][X] (transposed: A of a weight-gradient product, B of an input-gradient product) are kept in
+// LDS as they come, [64][X+8], one 16-byte store per strip, and their MFMA fragments are gathered with the hardware transpose
+// read (ds_read_b64_tr_b16: lane i of a 16-lane group hands in the address of row i>>2 of a 4-row k block, columns 4(i&3).., and
+// receives column i of the block).  A transpose read touches 4 k-rows x 32 columns per 32 lanes; with 144-byte rows (36 banks)
+// rows p, p+4, p+8, p+12 start 16 banks apart, so the k-rows of every 16-k chunk are stored 4x4-transposed (gemm_krow) and each
+// read is conflict-free at the LDS footprint of the K-contiguous layout.  (Before: eight 2-byte LDS stores per strip.)
+__device__ __forceinline__ int gemm_krow(int k) { return (k & ~15) | ((k & 3) << 2) | ((k >> 2) & 3); }
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 ld_frag_tr(const bf16_t* lo, const bf16_t* hi) {
+    const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(lo));
+    const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(hi));
+    return __builtin_bit_cast(bf16x8, (s16x8_t)__builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
 // Body of one workgroup of the bf16 GEMM: (bx, by, bz) of a (gx, gy, *) grid.  The LDS buffers come from the caller so that the
 // two problems of a paired launch (gemm_pair_kernel) share one allocation.
 template <typename TC, int BM, int BN, bool TA, bool TB, bool DB>
@@ -441,17 +457,16 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmDev& p, const int bx, c
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // strip ownership: K-contiguous operands: consecutive threads walk along K (coalesced 16-B loads, vector LDS writes);
-    // transposed operands: lanes own consecutive k-rows of the slab for one 8-wide x strip, so that each of the 8 scalar
-    // transposed LDS writes of a wave hits 64 consecutive bf16 of one row (no bank conflicts; the naive mapping strides rows by 8).
+    // transposed operands: 8 consecutive threads cover one k-row of the tile (128 contiguous bytes), one 16-B LDS write each
     auto a_xy = [&](int i, int k0, int& x, int& k) {
         const int f = tid + i * 256;
         if (!TA) { x = m0 + f / (BK / 8); k = k0 + (f % (BK / 8)) * 8; }
-        else { k = k0 + f % BK; x = m0 + (f / BK) * 8; }
+        else { k = k0 + f / (BM / 8); x = m0 + (f % (BM / 8)) * 8; }         // 8 lanes = one k-row of the tile: coalesced
     };
     auto b_xy = [&](int i, int k0, int& x, int& k) {
         const int f = tid + i * 256;
         if (TB) { x = n0 + f / (BK / 8); k = k0 + (f % (BK / 8)) * 8; }
-        else { k = k0 + f % BK; x = n0 + (f / BK) * 8; }
+        else { k = k0 + f / (BN / 8); x = n0 + (f % (BN / 8)) * 8; }
     };
     auto b_base = [&](int k0) { return (!TB && p.bgap_every) ? B + (long long)(k0 / p.bgap_every) * p.bgap : B; };
     // FAST (decided once per workgroup, below): both operands 16-byte aligned and no strip of this workgroup's slabs is partially
@@ -473,12 +488,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmDev& p, const int bx, c
             else rb[i] = load_strip8(Bk, p.ldb, x, k, p.N, kend, !TB, p.vecB);
         }
     };
-    auto put_t = [&](bf16_t* base, int x0, int k, uint4 v) {       // transposed write: 8 rows x0.., column k
-        union { uint4 v; bf16_t e[8]; } u;
-        u.v = v;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) base[(x0 + i) * LDT + k] = u.e[i];
-    };
+    constexpr int PA = BM + 8, PB = BN + 8;                    // row pitch of a transposed-layout slab
     auto stage = [&](auto FT, const uint4 (&ra)[SA], const uint4 (&rb)[SB], int k0, bf16_t* as, bf16_t* bs) {
         constexpr bool FAST = decltype(FT)::value;
         int x, k;
@@ -489,7 +499,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmDev& p, const int bx, c
             uint4 v = ra[i];
             if constexpr (FAST) { if (!strip_whole(x, k, p.M, kend, TA)) v = make_uint4(0u, 0u, 0u, 0u); }
             if (!TA) { const int row = f / (BK / 8), kq = f % (BK / 8); *reinterpret_cast<uint4*>(&as[row * LDT + kq * 8]) = v; }
-            else { const int kl = f % BK, mq = f / BK; put_t(as, mq * 8, kl, v); }
+            else { const int kl = f / (BM / 8), mq = f % (BM / 8); *reinterpret_cast<uint4*>(&as[gemm_krow(kl) * PA + mq * 8]) = v; }
         }
         const bf16_t* Bk = b_base(k0);
 #pragma unroll
@@ -499,7 +509,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmDev& p, const int bx, c
             uint4 v = rb[i];
             if constexpr (FAST) { if (!strip_whole(x, k, p.N, kend, !TB)) v = make_uint4(0u, 0u, 0u, 0u); }
             if (TB) { const int row = f / (BK / 8), kq = f % (BK / 8); *reinterpret_cast<uint4*>(&bs[row * LDT + kq * 8]) = v; }
-            else { const int kl = f % BK, nq = f / BK; put_t(bs, nq * 8, kl, v); }
+            else { const int kl = f / (BN / 8), nq = f % (BN / 8); *reinterpret_cast<uint4*>(&bs[gemm_krow(kl) * PB + nq * 8]) = v; }
         }
     };
     float rsum = 0.f;
@@ -507,17 +517,26 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmDev& p, const int bx, c
     auto compute = [&](const bf16_t* as, const bf16_t* bs) {
         if (do_rowsum) {
 #pragma unroll
-            for (int kk = 0; kk < BK; ++kk) rsum += bf2f(as[tid * LDT + kk]);
+            for (int kk = 0; kk < BK; ++kk) rsum += bf2f(TA ? as[kk * PA + tid] : as[tid * LDT + kk]);
         }
-        const bf16_t* ap = &as[(wr * WM + (lane & 31)) * LDT + 8 * (lane >> 5)];
-        const bf16_t* bp = &bs[(wc * WN + (lane & 31)) * LDT + 8 * (lane >> 5)];
+        // K-contiguous slab: lane (row lane&31, k-slice 8*(lane>>5)) reads 16 bytes.  Transposed-layout slab: k block j of a 16-k
+        // chunk lies in rows j, j+4, j+8, j+12 of the chunk; the lane's k-slice 8h..8h+7 is blocks 2h and 2h+1.
+        const int h = lane >> 5, gi = lane & 15, gq = (lane >> 4) & 1;
+        const bf16_t* ap = TA ? &as[(2 * h + 4 * (gi >> 2)) * PA + wr * WM + 16 * gq + 4 * (gi & 3)] : &as[(wr * WM + (lane & 31)) * LDT + 8 * h];
+        const bf16_t* bp = !TB ? &bs[(2 * h + 4 * (gi >> 2)) * PB + wc * WN + 16 * gq + 4 * (gi & 3)] : &bs[(wc * WN + (lane & 31)) * LDT + 8 * h];
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 16) {
             bf16x8 a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(ap + i * 32 * LDT + kk);
+            for (int i = 0; i < TM; ++i) {
+                if constexpr (TA) a[i] = ld_frag_tr(ap + kk * PA + i * 32, ap + (kk + 1) * PA + i * 32);
+                else a[i] = *reinterpret_cast<const bf16x8*>(ap + i * 32 * LDT + kk);
+            }
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8*>(bp + j * 32 * LDT + kk);
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (!TB) b[j] = ld_frag_tr(bp + kk * PB + j * 32, bp + (kk + 1) * PB + j * 32);
+                else b[j] = *reinterpret_cast<const bf16x8*>(bp + j * 32 * LDT + kk);
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
