@@ -714,9 +714,14 @@ bool gemm_plan(const TcGemm* g, GemmDev& d, dim3& grid, bool& use128_out, bool f
     int want = g->splitk;
     bool fix = false;
     if (!use128 && slots > 0) {
-        if (want == 1 && !g->atomic && g->K >= 512 && tiles64 <= 384) {
-            long long sk = 1024 / tiles64;
-            if (sk > g->K / 256) sk = g->K / 256;
+#ifndef GEMM_AS_TILES
+#define GEMM_AS_TILES 384
+#define GEMM_AS_TARGET 512
+#define GEMM_AS_KPER 256
+#endif
+        if (want == 1 && !g->atomic && g->K >= 2 * GEMM_AS_KPER && tiles64 <= GEMM_AS_TILES) {
+            long long sk = GEMM_AS_TARGET / tiles64;
+            if (sk > g->K / GEMM_AS_KPER) sk = g->K / GEMM_AS_KPER;
             if (sk > FIX_GROUP) sk = FIX_GROUP;
             if (sk >= 2 && tiles64 * sk <= slots) { want = (int)sk; fix = true; }
         } else if (want > 128) {
