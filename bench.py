@@ -36,7 +36,7 @@ def synthetic_batch(B: int, size: int, device, seed: int):
     return x.to(device), y.to(device)
 
 
-def _loader_feed(args, dev, rank: int, world: int, n_needed: int):
+def _loader_feed(args, dev, rank: int, world: int, n_needed: int, out=None):
     """Generator of (x, y) batches from the device input pipeline over a synthetic Synapse-format training set written to local
     disk (512x512 npz slices, dataset_synapse.py:103-107)."""
     import tempfile
@@ -46,7 +46,7 @@ def _loader_feed(args, dev, rank: int, world: int, n_needed: int):
     ds = D.SynapseSlices(tmp + "/train_npz", tmp + "/lists")
     per_epoch = (len(ds) // (args.batch * world)) * args.batch * world
     loader = D.DeviceLoader(ds, args.batch, img_size=args.size, device=dev, seed=1234, rank=rank, world=world, augment=True,
-                            epochs=n_needed // per_epoch + 2, readers=8)
+                            epochs=n_needed // per_epoch + 2, readers=8, out=out)
     return iter(loader)
 
 
@@ -165,7 +165,7 @@ def main():
         step = GraphedStep(model, loss_fn, opt, x, y, group, warmup=2, force_split=args.force_split)   # capture, then replay
     feed = None
     if args.loader and not args.eager:
-        feed = _loader_feed(args, dev, rank, world, (args.steps + args.warmup) * args.batch * world)
+        feed = _loader_feed(args, dev, rank, world, (args.steps + args.warmup) * args.batch * world, out=(step.x, step.y))
         step_resident = step
         step = lambda: step_resident(*next(feed))
     for i in range(args.warmup):
@@ -223,7 +223,7 @@ def main():
             extra["fwd_only_images_per_sec"] = args.batch * 10 / (time.perf_counter() - tf)
         if not args.eager and not args.loader and args.size == 224:
             # SURVEY 8(f)-1 side figure: the same graphed step fed by the device input pipeline (npz -> HBM -> augment/resize)
-            f2 = _loader_feed(args, dev, 0, 1, 24 * args.batch)
+            f2 = _loader_feed(args, dev, 0, 1, 24 * args.batch, out=(step.x, step.y))
             for _ in range(4):
                 step(*next(f2))
             torch.cuda.synchronize(dev)

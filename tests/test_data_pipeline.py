@@ -131,3 +131,22 @@ def test_synthetic_set_round_trip_and_sharding(tmp_path):
     for i in range(2):
         merged = np.concatenate([parts[0][i], parts[1][i]])
         np.testing.assert_array_equal(merged, order[i * 4:(i + 1) * 4])
+
+
+def test_direct_npz_reads_match_np_load(tmp_path):
+    """read_slice_into (stored members read straight into caller buffers) against np.load, incl. the compressed fallback."""
+    base, lists = str(tmp_path / "a"), str(tmp_path / "l")
+    D.write_synthetic_synapse(base, lists, n_cases=1, slices_per_case=3, size=48, seed=4)
+    ds = D.SynapseSlices(base, lists)
+    img, lab = np.empty((48, 48), np.float32), np.empty((48, 48), np.uint8)
+    for i in range(3):
+        a, b, name = ds[i]
+        if i == 2:
+            np.savez_compressed(os.path.join(base, name + ".npz"), image=a, label=b.astype(np.float32))
+        img[:] = -1
+        lab[:] = 255
+        assert ds.read_into(i, img, lab) == name
+        np.testing.assert_array_equal(img, a)
+        np.testing.assert_array_equal(lab, b)
+    with pytest.raises(Exception):
+        ds.read_into(0, np.empty((32, 32), np.float32), np.empty((32, 32), np.uint8))

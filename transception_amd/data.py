@@ -215,6 +215,62 @@ def write_synthetic_synapse(base_dir: str, list_dir: str, n_cases: int = 2, slic
     return names
 
 
+def _npz_member(f, zf, name: str):
+    """(dtype, shape, data offset) of an uncompressed C-order .npy member of an open npz, or None (compressed / Fortran / pickled):
+    np.savez stores members uncompressed, so a slice can be read from the file straight into its destination buffer."""
+    import struct
+    import zipfile
+    try:
+        info = zf.getinfo(name + ".npy")
+    except KeyError:
+        return None
+    if info.compress_type != zipfile.ZIP_STORED:
+        return None
+    f.seek(info.header_offset)
+    hdr = f.read(30)
+    if len(hdr) < 30 or hdr[:4] != b"PK\x03\x04":
+        return None
+    nlen, elen = struct.unpack("<HH", hdr[26:30])
+    start = info.header_offset + 30 + nlen + elen
+    f.seek(start)
+    magic = f.read(8)
+    if magic[:6] != b"\x93NUMPY":
+        return None
+    major = magic[6]
+    hlen = struct.unpack("<H", f.read(2))[0] if major == 1 else struct.unpack("<I", f.read(4))[0]
+    import ast
+    meta = ast.literal_eval(f.read(hlen).decode("latin1"))
+    if meta.get("fortran_order") or not isinstance(meta.get("descr"), str):
+        return None
+    return np.dtype(meta["descr"]), tuple(meta["shape"]), start + 8 + (2 if major == 1 else 4) + hlen
+
+
+def read_slice_into(path: str, image_out: np.ndarray, label_out: np.ndarray) -> None:
+    """`np.load(path)['image' | 'label']` (dataset_synapse.py:104-107) written into caller buffers (float32 [H,W] / uint8 [H,W], e.g.
+    views of pinned staging memory): uncompressed members are read from the file straight into place (no intermediate arrays, the
+    GIL is released for the read), anything else goes through np.load."""
+    import zipfile
+    try:
+        with open(path, "rb") as f, zipfile.ZipFile(f) as zf:
+            mi, ml = _npz_member(f, zf, "image"), _npz_member(f, zf, "label")
+            if mi is not None and ml is not None and mi[1] == image_out.shape and ml[1] == label_out.shape:
+                if mi[0] == np.float32 and image_out.flags.c_contiguous:
+                    f.seek(mi[2])
+                    if f.readinto(memoryview(image_out).cast("B")) != image_out.nbytes:
+                        raise IOError("short read")
+                else:
+                    f.seek(mi[2])
+                    image_out[...] = np.fromfile(f, mi[0], image_out.size).reshape(mi[1])
+                f.seek(ml[2])
+                label_out[...] = np.fromfile(f, ml[0], label_out.size).reshape(ml[1])      # float32 0..8 -> uint8
+                return
+    except (zipfile.BadZipFile, ValueError, SyntaxError):
+        pass
+    data = np.load(path)
+    image_out[...] = data["image"]
+    label_out[...] = data["label"]
+
+
 class SynapseSlices:
     """`Synapse_dataset(split="train")` without the transforms (dataset_synapse.py:75-82,101-107): slice i -> raw `image`
     (float32 [H,W] in [0,1]) and `label` (uint8 [H,W]; the file stores float32 0..8).  The test split (`.npy.h5` volumes, :114-118)
@@ -237,6 +293,15 @@ class SynapseSlices:
         image = np.ascontiguousarray(data["image"], np.float32)
         label = np.ascontiguousarray(data["label"]).astype(np.uint8)
         return image, label, name
+
+    def shape(self, idx: int = 0):
+        return self[idx][0].shape
+
+    def read_into(self, idx: int, image_out: np.ndarray, label_out: np.ndarray) -> str:
+        """Slice idx written into caller buffers (see read_slice_into); returns its name."""
+        name = self.sample_list[idx]
+        read_slice_into(os.path.join(self.data_dir, name + ".npz"), image_out, label_out)
+        return name
 
 
 # ------------------------------------------------------------------------------------------------ device side
@@ -300,22 +365,27 @@ def rank_batches(order: np.ndarray, batch_size: int, rank: int, world: int) -> L
 
 
 class DeviceLoader:
-    """Iterates (x, y) batches resident in HBM.  A host thread reads the npz files and draws the augmentation parameters into
-    pinned staging buffers; the H2D copies and the four preprocessing launches of batch i+1 are issued on the loader's stream
-    when batch i is handed out, so they run under the training step that consumes batch i."""
+    """Iterates (x, y) batches resident in HBM.  A host thread (with a pool of readers) fills pinned staging buffers from the npz
+    files and draws the augmentation parameters; host-to-device copies run two batches ahead on the loader's stream; the four
+    preprocessing launches of a batch are issued on the consumer's stream just before the batch is handed out."""
 
     def __init__(self, dataset: SynapseSlices, batch_size: int, img_size: int = 224, device="cuda", seed: int = 1234, rank: int = 0,
-                 world: int = 1, augment: bool = True, shuffle: bool = True, epochs: int = 1, prefetch: int = 3, readers: int = 4):
+                 world: int = 1, augment: bool = True, shuffle: bool = True, epochs: int = 1, prefetch: int = 3, readers: int = 8,
+                 out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
         self.ds, self.B, self.size, self.device = dataset, batch_size, img_size, torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("DeviceLoader feeds an MI355X; there is no CPU path")
         self.seed, self.rank, self.world, self.augment, self.shuffle, self.epochs = seed, rank, world, augment, shuffle, epochs
         self.stream = torch.cuda.Stream(self.device)
         self.prefetch, self.readers = prefetch, max(1, readers)
+        # out = (x float32 [B,1,S,S], y int64 [B,S,S]): every batch is written there (e.g. the static inputs of a captured step: no
+        # device-to-device copy at the step boundary, where it would queue behind the loader's host-to-device transfer)
+        self.out = out
         self.q: "queue.Queue" = queue.Queue(maxsize=prefetch)
         self.free: "queue.Queue" = queue.Queue()                     # pinned staging sets handed back once their copies ran
         self._staged = 0
-        self.slots = [dict(scratch={}) for _ in range(2)]
+        self._hw = None                                              # slice size (one per dataset, as in Synapse)
+        self.slots = [dict(scratch={}) for _ in range(3)]
         self._thread: Optional[threading.Thread] = None
         self._stop = threading.Event()
 
@@ -324,11 +394,11 @@ class DeviceLoader:
 
     # host side -----------------------------------------------------------------------------------
     def _staging(self, h: int, w: int):
-        """A pinned (image, label, records) set: at most prefetch + 3 exist (queue + the two device slots + one being filled);
+        """A pinned (image, label, records) set: at most prefetch + 4 exist (queue + the three device slots + one being filled);
         page-locking memory per batch would cost more than reading the slices."""
         while not self._stop.is_set():
             try:
-                st = self.free.get_nowait() if self._staged >= self.prefetch + 3 else None
+                st = self.free.get_nowait() if self._staged >= self.prefetch + 4 else None
             except queue.Empty:
                 try:
                     st = self.free.get(timeout=0.1)
@@ -350,21 +420,18 @@ class DeviceLoader:
                 for epoch in range(self.epochs):
                     sampler = AugmentSampler(int(np.random.SeedSequence([self.seed, epoch, self.rank]).generate_state(1)[0]))
                     for idxs in rank_batches(epoch_order(len(self.ds), epoch, self.seed, self.shuffle), self.B, self.rank, self.world):
-                        first = self.ds[int(idxs[0])]
-                        h, w = first[0].shape
+                        if self._hw is None:
+                            self._hw = tuple(self.ds.shape(int(idxs[0])))
+                        h, w = self._hw
                         st = self._staging(h, w)
                         if st is None:
                             return
                         img, lab, rec = st
+                        img_np, lab_np = img.numpy(), lab.numpy()           # views of the pinned staging memory
 
-                        def fill(j, item=None):
-                            im, lb, name = item if item is not None else self.ds[int(idxs[j])]
-                            if im.shape != (h, w):
-                                raise ValueError("slices of one batch must have one size")
-                            img[j].copy_(torch.from_numpy(im))
-                            lab[j].copy_(torch.from_numpy(lb))
-                            return name
-                        names = [fill(0, first)] + list(pool.map(fill, range(1, len(idxs))))
+                        def fill(j):
+                            return self.ds.read_into(int(idxs[j]), img_np[j], lab_np[j])   # raises on a slice of another size
+                        names = list(pool.map(fill, range(len(idxs))))
                         augs = [sampler.sample(h, w) for _ in names] if self.augment else None
                         if augs is not None:
                             rec.copy_(torch.from_numpy(pack_records(augs)))
@@ -381,7 +448,8 @@ class DeviceLoader:
             self.q.put(e)
 
     # device side ---------------------------------------------------------------------------------
-    def _launch(self, slot: dict) -> bool:
+    def _copy(self, slot: dict) -> bool:
+        """Next staged batch -> the slot's raw device buffers, on the loader's stream (copy engine, under the running step)."""
         item = self.q.get()
         if item is None:
             return False
@@ -389,42 +457,67 @@ class DeviceLoader:
             raise item
         st, names, augs = item
         img, lab, rec = st
+        if "host" in slot:
+            slot["copied"].synchronize()                             # that copy ran long ago: hand its staging set back
+            self.free.put(slot.pop("host"))
         with torch.cuda.stream(self.stream):
-            if "consumed" in slot:
-                self.stream.wait_event(slot["consumed"])             # the previous batch in this slot has been used
-            if "host" in slot:
-                slot["done"].synchronize()                           # its copies ran two batches ago: hand the staging set back
-                self.free.put(slot.pop("host"))
-            if "out" not in slot:                                    # outputs live as long as the loader: no allocator traffic across streams
-                slot["out"] = (torch.empty((self.B, 1, self.size, self.size), dtype=torch.float32, device=self.device),
-                               torch.empty((self.B, self.size, self.size), dtype=torch.int64, device=self.device))
-            d_img, d_lab = img.to(self.device, non_blocking=True), lab.to(self.device, non_blocking=True)
-            d_rec = rec.to(self.device, non_blocking=True) if augs is not None else None
-            slot["x"], slot["y"] = preprocess_batch(d_img, d_lab, None, self.size, records=d_rec, scratch=slot["scratch"], out=slot["out"])
-            slot["host"] = st                                        # the pinned set stays out of the free list until the copies ran
-            slot["names"], slot["augs"] = names, augs
-            slot["done"] = torch.cuda.Event()
-            slot["done"].record(self.stream)
+            if "raw" not in slot or slot["raw"][0].shape != img.shape or (self.out is not None and slot["out"] is not self.out):
+                slot["raw"] = (torch.empty(img.shape, dtype=torch.float32, device=self.device),
+                               torch.empty(lab.shape, dtype=torch.uint8, device=self.device),
+                               torch.empty(rec.shape, dtype=torch.uint8, device=self.device))
+                slot["out"] = self.out if self.out is not None else (
+                    torch.empty((self.B, 1, self.size, self.size), dtype=torch.float32, device=self.device),
+                    torch.empty((self.B, self.size, self.size), dtype=torch.int64, device=self.device))
+            if "prepped" in slot:
+                self.stream.wait_event(slot["prepped"])              # the kernels that read the previous contents are done
+            slot["raw"][0].copy_(img, non_blocking=True)
+            slot["raw"][1].copy_(lab, non_blocking=True)
+            if augs is not None:
+                slot["raw"][2].copy_(rec, non_blocking=True)
+            slot["copied"] = torch.cuda.Event()
+            slot["copied"].record(self.stream)
+        slot["host"], slot["names"], slot["augs"] = st, names, augs
         return True
 
+    def _prep(self, slot: dict):
+        """The four preprocessing launches on the CONSUMER's stream, right in front of the step that uses the batch (kernels of
+        different streams do not overlap on this GPU anyway -- see DESIGN.md -- and a side stream's launches slowed the step's)."""
+        main = torch.cuda.current_stream(self.device)
+        main.wait_event(slot["copied"])
+        d_img, d_lab, d_rec = slot["raw"]
+        slot["x"], slot["y"] = preprocess_batch(d_img, d_lab, None, self.size, records=d_rec if slot["augs"] is not None else None,
+                                                scratch=slot["scratch"], out=slot["out"])
+        slot["prepped"] = torch.cuda.Event()
+        slot["prepped"].record(main)
+
     def __iter__(self):
+        from collections import deque
         self._stop.clear()
         self._thread = threading.Thread(target=self._produce, daemon=True)
         self._thread.start()
-        cur = 0
+        free, copied = deque(self.slots), deque()
+        eof = False
+
+        def try_copy():
+            nonlocal eof
+            if eof or not free:
+                return
+            slot = free.popleft()
+            if self._copy(slot):
+                copied.append(slot)
+            else:
+                eof = True
+                free.appendleft(slot)
         try:
-            live = self._launch(self.slots[cur])
-            while live:
-                slot = self.slots[cur]
-                nxt = 1 - cur
-                live = self._launch(self.slots[nxt])                 # batch i+1 goes out before batch i is consumed
-                main = torch.cuda.current_stream(self.device)
-                main.wait_event(slot["done"])
+            try_copy()
+            try_copy()                                               # two host-to-device copies ahead of the consumer
+            while copied:
+                slot = copied.popleft()
+                self._prep(slot)
+                try_copy()                                           # goes out now, runs under the step that consumes `slot`
                 self.last_names, self.last_augs = slot["names"], slot["augs"]      # what the batch being handed out was made from
                 yield slot["x"], slot["y"]
-                slot["consumed"] = torch.cuda.Event()
-                slot["consumed"].record(torch.cuda.current_stream(self.device))
-                cur = nxt
+                free.append(slot)                                    # its outputs were consumed in stream order
         finally:
             self._stop.set()
             while self._thread.is_alive():                           # unblock a producer waiting on a full queue

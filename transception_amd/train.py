@@ -298,7 +298,7 @@ class GraphedStep:
         self._G = self._out_var = None
 
     def __call__(self, images: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None):
-        if images is not None:
+        if images is not None and images.data_ptr() != self.x.data_ptr():     # a loader may write straight into self.x / self.y
             self.x.copy_(images, non_blocking=True)
             self.y.copy_(labels, non_blocking=True)
         self.g_main.replay()

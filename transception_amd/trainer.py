@@ -103,6 +103,7 @@ def trainer_synapse(cfg: TrainConfig, model, snapshot_path: str, volumes: Option
         else:
             if step is None:
                 step = GraphedStep(model, loss_fn, opt, x, y, group, warmup=0)
+                loader.out = (step.x, step.y)                     # later batches land in the step's static inputs: no copy per step
             loss, ce, dice = step(x, y)
         iter_num += 1
         if iter_num % cfg.log_every == 0:
