@@ -304,6 +304,13 @@ class MSTransception(nn.Module):
         self._flat, self._gflat = flat, torch.zeros_like(flat)
         self._flat_lp = None
         self._uniq_params = uniq
+        # the 21 BatchNorm step counters live in one int64 vector (each module's buffer is a view of its element), so a training
+        # forward bumps them with one launch instead of 21
+        bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None]
+        nbt = torch.stack([m.num_batches_tracked.detach().to(device=device, dtype=torch.int64).reshape(()) for m in bns]) if bns else None
+        for i, m in enumerate(bns):
+            m._buffers["num_batches_tracked"] = nbt[i]
+        self._nbt_flat, self._nbt_ptrs = nbt, [m.num_batches_tracked.data_ptr() for m in bns]
         off_of = {id(p): o for p, o in zip(uniq, offs)}
         self._index = {n: (off_of[id(p)], tuple(p.shape)) for n, p in self.named_parameters(remove_duplicate=False)}
         self._pid = {n: id(p) for n, p in self.named_parameters(remove_duplicate=False)}
@@ -389,8 +396,12 @@ class MSTransception(nn.Module):
             L.tc_cast(logits.data_ptr(), lf.data_ptr(), logits.numel(), TC_BF16, TC_F32, stream)
             logits = lf
         if self.training:
-            for m in self.modules():
-                if isinstance(m, nn.BatchNorm2d):
+            nbt = getattr(self, "_nbt_flat", None)
+            bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
+            if nbt is not None and [m.num_batches_tracked.data_ptr() for m in bns] == self._nbt_ptrs:
+                nbt += 1                                        # all counters, one launch
+            else:                                               # buffers were replaced since (_apply / load): per module
+                for m in bns:
                     m.num_batches_tracked += 1
         self.last_launches = G.n_launch
         return logits, G, out_var
