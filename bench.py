@@ -127,13 +127,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("TC_TEST_ONE_GPU") == "1":            # drill of the multi-rank step on a 1-GPU box: every rank on cuda:0,
+        local = 0                                           # collectives through TC_DIST_BACKEND=gloo (not a measurement)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     import torch.distributed as dist
     group = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("TC_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         group = dist.group.WORLD
 
     import transception_amd.engine as engine
