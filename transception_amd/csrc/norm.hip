@@ -261,37 +261,54 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ x
                                                          const float* __restrict__ save_mean,
                                                          const float* __restrict__ save_rstd, float* __restrict__ scratch,
                                                          int rows, int C, int act) {
-    __shared__ float r1[4][64], r2[4][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int c = blockIdx.y * 64 + tx;
+    // 16 channel quads x 16 row lanes per workgroup (the layout of the apply kernels): 8/16-byte loads instead of one element per lane
+    __shared__ float r1[16][64], r2[16][64];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int c = blockIdx.y * 64 + tx * 4;
     const int nchunk = gridDim.x, chunk = blockIdx.x;
     const int per = (rows + nchunk - 1) / nchunk;
     const int rbeg = chunk * per, rend = min(rows, rbeg + per);
-    float s1 = 0.f, s2 = 0.f;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     if (c < C) {
         if (MODE == 0) {
-            const float sh = ldf<T>(x + c);
-            if (chunk == 0 && ty == 0) scratch[c] = sh;
-            for (int r = rbeg + ty; r < rend; r += 4) {
-                const float v = ldf<T>(x + (long long)r * ldx + c) - sh;
-                s1 += v; s2 += v * v;
+            const float4 sh = ld4<T>(x + c);
+            if (chunk == 0 && ty == 0) { scratch[c] = sh.x; scratch[c + 1] = sh.y; scratch[c + 2] = sh.z; scratch[c + 3] = sh.w; }
+            for (int r = rbeg + ty; r < rend; r += 16) {
+                const float4 v = ld4<T>(x + (long long)r * ldx + c);
+                const float a0 = v.x - sh.x, a1 = v.y - sh.y, a2 = v.z - sh.z, a3 = v.w - sh.w;
+                s1[0] += a0; s1[1] += a1; s1[2] += a2; s1[3] += a3;
+                s2[0] += a0 * a0; s2[1] += a1 * a1; s2[2] += a2 * a2; s2[3] += a3 * a3;
             }
         } else {
-            const float mu = save_mean[c], rs = save_rstd[c];
-            const float g = ldf<T>(gamma + c), b = ldf<T>(beta + c);
-            for (int r = rbeg + ty; r < rend; r += 4) {
-                const float xh = (ldf<T>(x + (long long)r * ldx + c) - mu) * rs;
-                float d = ldf<T>(dy + (long long)r * lddy + c);
-                if (act != TC_ACT_NONE) d *= act_grad(act, xh * g + b);
-                s1 += d; s2 += d * xh;
+            const float4 mu = *reinterpret_cast<const float4*>(save_mean + c), rs = *reinterpret_cast<const float4*>(save_rstd + c);
+            const float4 g = ld4<T>(gamma + c), b = ld4<T>(beta + c);
+            const float mus[4] = {mu.x, mu.y, mu.z, mu.w}, rss[4] = {rs.x, rs.y, rs.z, rs.w};
+            const float gs[4] = {g.x, g.y, g.z, g.w}, bs[4] = {b.x, b.y, b.z, b.w};
+            for (int r = rbeg + ty; r < rend; r += 16) {
+                const float4 xv = ld4<T>(x + (long long)r * ldx + c), dv = ld4<T>(dy + (long long)r * lddy + c);
+                const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xh = (xs[j] - mus[j]) * rss[j];
+                    float d = ds[j];
+                    if (act != TC_ACT_NONE) d *= act_grad(act, xh * gs[j] + bs[j]);
+                    s1[j] += d; s2[j] += d * xh;
+                }
             }
         }
     }
-    r1[ty][tx] = s1; r2[ty][tx] = s2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { r1[ty][tx * 4 + j] = s1[j]; r2[ty][tx * 4 + j] = s2[j]; }
     __syncthreads();
-    if (ty == 0 && c < C) {
-        scratch[C + chunk * C + c] = r1[0][tx] + r1[1][tx] + r1[2][tx] + r1[3][tx];
-        scratch[C + nchunk * C + chunk * C + c] = r2[0][tx] + r2[1][tx] + r2[2][tx] + r2[3][tx];
+    if (threadIdx.x < 64) {
+        const int cc = threadIdx.x, ch = blockIdx.y * 64 + cc;
+        if (ch < C) {
+            float a = 0.f, b2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) { a += r1[w][cc]; b2 += r2[w][cc]; }
+            scratch[C + chunk * C + ch] = a;
+            scratch[C + nchunk * C + chunk * C + ch] = b2;
+        }
     }
 }
 
