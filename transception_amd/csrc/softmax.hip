@@ -2,6 +2,7 @@
 // axis=1: one wavefront per row, shuffle reductions.  axis=0 (softmax over tokens, per channel): a block owns
 // 64 columns (16 lanes x 4 channels = 256 B per row) and 16 row lanes, reductions through LDS.
 #include "tc_common.h"
+#include <initializer_list>
 
 namespace {
 
@@ -42,6 +43,98 @@ __global__ __launch_bounds__(256) void softmax_rows_bwd(const T* __restrict__ dy
         if (accumulate) v += ldf<T>(dxr + c);
         stf<T>(dxr + c, v);
     }
+}
+
+// Rows of up to 512 channels, a multiple of 4 (the channel softmax of the query in EfficientAttention, MSTr.py:124-128): 16 lanes per
+// row, 4 rows per wavefront, each lane keeps its NV four-channel vectors in registers -- one pass over the row with 8/16-byte
+// accesses instead of three passes of one element per lane and one row per wavefront.
+__device__ __forceinline__ float grp16_max(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 16));
+    return v;
+}
+__device__ __forceinline__ float grp16_sum(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
+    return v;
+}
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void softmax_rows16_fwd(const T* __restrict__ x, T* __restrict__ y, long long sbx, long long sby,
+                                                          int R, int Cc, int ldx, int ldy, long long nrows) {
+    const int l = threadIdx.x & 15;
+    const long long gr = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (gr >= nrows) return;
+    const int b = (int)(gr / R), r = (int)(gr % R), nv = Cc >> 2;
+    const T* xr = x + b * sbx + (long long)r * ldx;
+    T* yr = y + b * sby + (long long)r * ldy;
+    float4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = ld4<T>(xr + min(l + i * 16, nv - 1) * 4);           // all loads first, no per-lane branch
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) if (l + i * 16 < nv) m = fmaxf(fmaxf(m, fmaxf(v[i].x, v[i].y)), fmaxf(v[i].z, v[i].w));
+    m = grp16_max(m);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i].x = __expf(v[i].x - m); v[i].y = __expf(v[i].y - m); v[i].z = __expf(v[i].z - m); v[i].w = __expf(v[i].w - m);
+        if (l + i * 16 < nv) s += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+    s = 1.0f / grp16_sum(s);
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (l + i * 16 < nv) st4<T>(yr + (l + i * 16) * 4, make_float4(v[i].x * s, v[i].y * s, v[i].z * s, v[i].w * s));
+}
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void softmax_rows16_bwd(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx,
+                                                          long long sbdy, long long sby, long long sbdx, int R, int Cc, int lddy,
+                                                          int ldy, int lddx, long long nrows, int accumulate) {
+    const int l = threadIdx.x & 15;
+    const long long gr = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (gr >= nrows) return;
+    const int b = (int)(gr / R), r = (int)(gr % R), nv = Cc >> 2;
+    const T* dyr = dy + b * sbdy + (long long)r * lddy;
+    const T* yr = y + b * sby + (long long)r * ldy;
+    T* dxr = dx + b * sbdx + (long long)r * lddx;
+    float4 yv[NV], dv[NV], ov[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int q = min(l + i * 16, nv - 1) * 4;
+        yv[i] = ld4<T>(yr + q); dv[i] = ld4<T>(dyr + q);
+        ov[i] = accumulate ? ld4<T>(dxr + q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) if (l + i * 16 < nv) s += dv[i].x * yv[i].x + dv[i].y * yv[i].y + dv[i].z * yv[i].z + dv[i].w * yv[i].w;
+    s = grp16_sum(s);
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (l + i * 16 < nv)
+            st4<T>(dxr + (l + i * 16) * 4, make_float4(yv[i].x * (dv[i].x - s) + ov[i].x, yv[i].y * (dv[i].y - s) + ov[i].y,
+                                                       yv[i].z * (dv[i].z - s) + ov[i].z, yv[i].w * (dv[i].w - s) + ov[i].w));
+}
+template <typename T> bool rows16_ok(int Cc, std::initializer_list<long long> strides, std::initializer_list<const void*> ptrs) {
+    constexpr int AL = 4 * (int)sizeof(T);
+    if ((Cc & 3) || Cc > 512) return false;
+    for (long long v : strides) if (v & 3) return false;
+    for (const void* q : ptrs) if ((uintptr_t)q % AL) return false;
+    return true;
+}
+
+template <typename T>
+void launch_rows16_fwd(const T* x, T* y, long long sbx, long long sby, int R, int Cc, int ldx, int ldy, long long nrows, hipStream_t s) {
+    const dim3 g16((unsigned)((nrows + 15) / 16));
+#define TC_SM16(NV) case NV: hipLaunchKernelGGL((softmax_rows16_fwd<T, NV>), g16, dim3(256), 0, s, x, y, sbx, sby, R, Cc, ldx, ldy, nrows); break;
+    switch ((Cc / 4 + 15) / 16) { TC_SM16(1) TC_SM16(2) TC_SM16(3) TC_SM16(4) TC_SM16(5) TC_SM16(6) TC_SM16(7) default: TC_SM16(8) }
+#undef TC_SM16
+}
+template <typename T>
+void launch_rows16_bwd(const T* dy, const T* y, T* dx, long long sbdy, long long sby, long long sbdx, int R, int Cc, int lddy, int ldy,
+                       int lddx, long long nrows, int accumulate, hipStream_t s) {
+    const dim3 g16((unsigned)((nrows + 15) / 16));
+#define TC_SM16(NV) case NV: hipLaunchKernelGGL((softmax_rows16_bwd<T, NV>), g16, dim3(256), 0, s, dy, y, dx, sbdy, sby, sbdx, R, Cc, lddy, ldy, lddx, nrows, accumulate); break;
+    switch ((Cc / 4 + 15) / 16) { TC_SM16(1) TC_SM16(2) TC_SM16(3) TC_SM16(4) TC_SM16(5) TC_SM16(6) TC_SM16(7) default: TC_SM16(8) }
+#undef TC_SM16
 }
 
 __device__ __forceinline__ float4 f4max(float4 a, float4 b) { return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)); }
@@ -168,7 +261,9 @@ extern "C" int tc_softmax_fwd(const void* x, void* y, float* scratch, int nb, lo
     hipStream_t s = (hipStream_t)stream;
     const long long nrows = (long long)nb * R;
     TC_DISPATCH_DTYPE(dtype, {
-        if (axis == 1) hipLaunchKernelGGL((softmax_rows_fwd<T>), dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, s, (const T*)x,
+        if (axis == 1 && rows16_ok<T>(Cc, {sbx, sby, ldx, ldy}, {x, y})) {
+            launch_rows16_fwd<T>((const T*)x, (T*)y, sbx, sby, R, Cc, ldx, ldy, nrows, s);
+        } else if (axis == 1) hipLaunchKernelGGL((softmax_rows_fwd<T>), dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, s, (const T*)x,
                                           (T*)y, sbx, sby, R, Cc, ldx, ldy, nrows);
         else {
             int rper;
@@ -190,7 +285,9 @@ extern "C" int tc_softmax_bwd(const void* dy, const void* y, void* dx, float* sc
     hipStream_t s = (hipStream_t)stream;
     const long long nrows = (long long)nb * R;
     TC_DISPATCH_DTYPE(dtype, {
-        if (axis == 1) hipLaunchKernelGGL((softmax_rows_bwd<T>), dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, s, (const T*)dy,
+        if (axis == 1 && rows16_ok<T>(Cc, {sbdy, sby, sbdx, lddy, ldy, lddx}, {dy, y, dx})) {
+            launch_rows16_bwd<T>((const T*)dy, (const T*)y, (T*)dx, sbdy, sby, sbdx, R, Cc, lddy, ldy, lddx, nrows, accumulate, s);
+        } else if (axis == 1) hipLaunchKernelGGL((softmax_rows_bwd<T>), dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, s, (const T*)dy,
                                           (const T*)y, (T*)dx, sbdy, sby, sbdx, R, Cc, lddy, ldy, lddx, nrows, accumulate);
         else {
             int rper;
