@@ -19,12 +19,16 @@ step = GraphedStep(model, loss_fn, opt, x, y, None, warmup=2)
 tn, ts = [], []
 torch.cuda.synchronize()
 t0 = time.perf_counter()
+evs, ahead = [], []
 for i in range(60):
     a = time.perf_counter(); x, y = next(it); b = time.perf_counter(); step(x, y); c = time.perf_counter()
     tn.append(b - a); ts.append(c - b)
+    e = torch.cuda.Event(); e.record(); evs.append(e)
+    ahead.append(sum(0 if ev.query() else 1 for ev in evs[-12:]))
 torch.cuda.synchronize()
 tot = time.perf_counter() - t0
 import statistics as st
 print(f"60 steps in {tot*1e3:.1f} ms = {tot/60*1e3:.2f} ms/step; host next(): median {st.median(tn)*1e3:.2f} max {max(tn)*1e3:.2f} ms; host step(): median {st.median(ts)*1e3:.2f} max {max(ts)*1e3:.2f} ms")
+print("steps queued ahead of the GPU after each launch:", " ".join(str(v) for v in ahead[:40]))
 print("next() ms:", " ".join(f"{v*1e3:.1f}" for v in tn[:40]))
 print("step() ms:", " ".join(f"{v*1e3:.1f}" for v in ts[:40]))
