@@ -391,13 +391,24 @@ __device__ __forceinline__ void dw_tile_body(const T* __restrict__ src, int lds_
         if (bias) bias += g * wstride;
     }
     const int c0 = by * CH;
-    for (int i = threadIdx.x; i < K * K * CH; i += 256) {
-        const int cc = i / (K * K), t = i - cc * (K * K);
-        wsm[MODE == 1 ? K * K - 1 - t : t][cc] = (c0 + cc < C) ? ldf<T>(w + (long long)(c0 + cc) * K * K + t) : 0.f;
+    // filter taps: requested together and without a per-lane branch (taps of channels past C read tap 0 and are zeroed when they
+    // go to LDS), so that they travel with the tile's pixels instead of costing 3-13 memory round trips before the fill starts
+    constexpr int NWL = (K * K * CH + 255) / 256;
+    float wv[NWL];
+#pragma unroll
+    for (int j = 0; j < NWL; ++j) {
+        const int i = threadIdx.x + j * 256, cc = i / (K * K), t = i - cc * (K * K);
+        const bool ok = i < K * K * CH && c0 + cc < C;
+        wv[j] = ldf<T>(w + (ok ? (long long)(c0 + cc) * K * K + t : 0));
     }
     const int tix = bx % tilesW, tiy = (bx / tilesW) % tilesH, b = bx / (tilesW * tilesH);
     const int oh0 = tiy * D::TH, ow0 = tix * D::TW;
     dw_stage<T, CG, PIXQ, D::IH, D::IW>(tile, src + (long long)b * H * W * lds_ + c0, lds_, oh0 - P, ow0 - P, H, W, C - c0);
+#pragma unroll
+    for (int j = 0; j < NWL; ++j) {
+        const int i = threadIdx.x + j * 256, cc = i / (K * K), t = i - cc * (K * K);
+        if (i < K * K * CH) wsm[MODE == 1 ? K * K - 1 - t : t][cc] = (c0 + cc < C) ? wv[j] : 0.f;
+    }
     __syncthreads();
     const int cg = threadIdx.x % CG, pt = threadIdx.x / CG, run = pt % (D::TW / R), row = pt / (D::TW / R);
     const int oh = oh0 + row, owb = ow0 + run * R, c = c0 + cg * VEC;
