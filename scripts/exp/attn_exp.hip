@@ -99,7 +99,396 @@ __device__ __forceinline__ void locate_tile(const Segs& sg, int t, int& row_base
     row_base = sg.row0[s] + b * nq;
 }
 
-#if ATT_VAR == 10
+#if ATT_VAR == 12
+// v12 = v11 with V kept row-major (4x4 k-row permutation) and gathered by ds_read_b64_tr_b16; V strips loaded together
+// v11: 64 queries per wave (two 32-query sets share every K / V fragment read from LDS), 2 waves = 128 queries per workgroup,
+// 128 threads, up to 4 workgroups per CU (2 waves per SIMD, 256 VGPRs each).
+__global__ __launch_bounds__(128, 2) void attn_fwd_seg_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
+                                                              const bf16_t* __restrict__ V, int ldv, long long skv, bf16_t* __restrict__ O,
+                                                              int ldo, float* __restrict__ lse, Segs sg, int Nk, float scale) {
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[KB * LDR];
+    __shared__ __attribute__((aligned(16))) bf16_t Vs[KB * LDR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    int row_base, q0, nq, b;
+    locate_tile(sg, blockIdx.x, row_base, q0, nq, b);
+    const bf16_t* Kb = K + b * skv;
+    const bf16_t* Vb = V + b * skv;
+    bool ok[2];
+    long long qrow[2];
+    bf16x8 qf[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int ql = q0 + wave * 64 + 32 * t + j;
+        ok[t] = ql < nq;
+        qrow[t] = (long long)row_base + ql;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const uint4 v = ok[t] ? *reinterpret_cast<const uint4*>(Q + qrow[t] * ldq + 16 * ks + 8 * h) : make_uint4(0u, 0u, 0u, 0u);
+            qf[t][ks] = *reinterpret_cast<const bf16x8*>(&v);
+        }
+    }
+    const float qs = scale * LOG2E;
+    f32x16 acc0[2], acc1[2];
+    float m[2], lsum[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        m[t] = NEG_BIG; lsum[t] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[t][r] = 0.f; acc1[t][r] = 0.f; }
+    }
+    const int krow = pi_row(j);
+    auto fmap = [&](int it, int& r, int& c8, int& g) {       // 2 waves x 8 iterations cover the 16 (16 keys x 32 d) chunks of a fill
+        const int c = wave * 8 + it;
+        g = lane >> 4; r = 16 * (c >> 1) + (lane & 15); c8 = 32 * (c & 1) + 8 * g;
+    };
+    uint4 kr[8];
+    auto fetch = [&](int kb0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int r, c8, g; fmap(i, r, c8, g);
+            kr[i] = ld_row8(Kb, ldk, kb0 + r, Nk, c8);
+        }
+    };
+    fetch(0);
+    for (int kb0 = 0; kb0 < Nk; kb0 += KB) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int r, c8, g; fmap(i, r, c8, g);
+            *reinterpret_cast<uint4*>(&Ks[r * LDR + c8]) = kr[i];
+        }
+        {
+            uint4 vr[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                int r, c8, g; fmap(i, r, c8, g);
+                vr[i] = *reinterpret_cast<const uint4*>(Vb + (long long)min(kb0 + r, Nk - 1) * ldv + c8);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                int r, c8, g; fmap(i, r, c8, g);
+                const int pr = (r & ~15) | ((r & 3) << 2) | ((r >> 2) & 3);
+                *reinterpret_cast<uint4*>(&Vs[pr * LDR + c8]) = vr[i];
+            }
+        }
+        __syncthreads();
+        if (kb0 + KB < Nk) fetch(kb0 + KB);
+#pragma unroll 1
+        for (int sub = 0; sub < KB / 32 && kb0 + 32 * sub < Nk; ++sub) {
+            f32x16 s[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+            const bf16_t* kp = Ks + (32 * sub + krow) * LDR + 8 * h;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf = ld_frag(kp + 16 * ks);
+                s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][ks], s[0], 0, 0, 0);
+                s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][ks], s[1], 0, 0, 0);
+            }
+            const int kv0 = kb0 + 32 * sub;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (kv0 + 32 > Nk) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) if (kv0 + 16 * h + r >= Nk) s[t][r] = NEG_BIG;
+                }
+                float mx = s[t][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * qs;
+                if (__any(mx > m[t] + RESCALE_THR)) {
+                    const float mn = fmaxf(m[t], mx);
+                    const float alpha = fast_exp2(m[t] - mn);
+                    lsum[t] *= alpha;
+                    m[t] = mn;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { acc0[t][r] *= alpha; acc1[t][r] *= alpha; }
+                }
+                float rs = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[t][r] = fast_exp2(fmaf(s[t][r], qs, -m[t])); rs += s[t][r]; }
+                lsum[t] += rs;                                   // per-half partial; halves meet after the loop
+            }
+            const int gi = lane & 15, gq = (lane >> 4) & 1;
+            const bf16_t* vp = Vs + (32 * sub + 16 * h + 4 * (gi >> 2)) * LDR + 16 * gq + 4 * (gi & 3);
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const bf16x8 v0 = ld_frag_tr(vp + (2 * k2) * LDR, vp + (2 * k2 + 1) * LDR);
+                const bf16x8 v1 = ld_frag_tr(vp + (2 * k2) * LDR + 32, vp + (2 * k2 + 1) * LDR + 32);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const bf16x8 pb = pack8(s[t], 8 * k2);
+                    acc0[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pb, acc0[t], 0, 0, 0);
+                    acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pb, acc1[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const float tot = lsum[t] + __shfl_xor(lsum[t], 32, 64);
+        if (ok[t]) {
+            const float inv = 1.0f / tot;
+            bf16_t* orow = O + qrow[t] * ldo;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                st4<bf16_t>(orow + 8 * g + 4 * h, make_float4(acc0[t][4 * g] * inv, acc0[t][4 * g + 1] * inv, acc0[t][4 * g + 2] * inv, acc0[t][4 * g + 3] * inv));
+                st4<bf16_t>(orow + 32 + 8 * g + 4 * h, make_float4(acc1[t][4 * g] * inv, acc1[t][4 * g + 1] * inv, acc1[t][4 * g + 2] * inv, acc1[t][4 * g + 3] * inv));
+            }
+            if (h == 0) lse[qrow[t]] = (m[t] + log2f(tot)) * LN2;
+        }
+    }
+}
+#elif ATT_VAR == 11
+// v11: 64 queries per wave (two 32-query sets share every K / V fragment read from LDS), 2 waves = 128 queries per workgroup,
+// 128 threads, up to 4 workgroups per CU (2 waves per SIMD, 256 VGPRs each).
+__global__ __launch_bounds__(128, 2) void attn_fwd_seg_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
+                                                              const bf16_t* __restrict__ V, int ldv, long long skv, bf16_t* __restrict__ O,
+                                                              int ldo, float* __restrict__ lse, Segs sg, int Nk, float scale) {
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[KB * LDR];
+    __shared__ __attribute__((aligned(16))) bf16_t Vt[D * LDTB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    int row_base, q0, nq, b;
+    locate_tile(sg, blockIdx.x, row_base, q0, nq, b);
+    const bf16_t* Kb = K + b * skv;
+    const bf16_t* Vb = V + b * skv;
+    bool ok[2];
+    long long qrow[2];
+    bf16x8 qf[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int ql = q0 + wave * 64 + 32 * t + j;
+        ok[t] = ql < nq;
+        qrow[t] = (long long)row_base + ql;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const uint4 v = ok[t] ? *reinterpret_cast<const uint4*>(Q + qrow[t] * ldq + 16 * ks + 8 * h) : make_uint4(0u, 0u, 0u, 0u);
+            qf[t][ks] = *reinterpret_cast<const bf16x8*>(&v);
+        }
+    }
+    const float qs = scale * LOG2E;
+    f32x16 acc0[2], acc1[2];
+    float m[2], lsum[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        m[t] = NEG_BIG; lsum[t] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[t][r] = 0.f; acc1[t][r] = 0.f; }
+    }
+    const int krow = pi_row(j);
+    auto fmap = [&](int it, int& r, int& c8, int& g) {       // 2 waves x 8 iterations cover the 16 (16 keys x 32 d) chunks of a fill
+        const int c = wave * 8 + it;
+        g = lane >> 4; r = 16 * (c >> 1) + (lane & 15); c8 = 32 * (c & 1) + 8 * g;
+    };
+    uint4 kr[8];
+    auto fetch = [&](int kb0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int r, c8, g; fmap(i, r, c8, g);
+            kr[i] = ld_row8(Kb, ldk, kb0 + r, Nk, c8);
+        }
+    };
+    fetch(0);
+    for (int kb0 = 0; kb0 < Nk; kb0 += KB) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int r, c8, g; fmap(i, r, c8, g);
+            *reinterpret_cast<uint4*>(&Ks[r * LDR + c8]) = kr[i];
+            st_t8(Vt, LDTB, c8, r, ld_row8(Vb, ldv, kb0 + r, Nk, c8), g);
+        }
+        __syncthreads();
+        if (kb0 + KB < Nk) fetch(kb0 + KB);
+#pragma unroll 1
+        for (int sub = 0; sub < KB / 32 && kb0 + 32 * sub < Nk; ++sub) {
+            f32x16 s[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+            const bf16_t* kp = Ks + (32 * sub + krow) * LDR + 8 * h;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf = ld_frag(kp + 16 * ks);
+                s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][ks], s[0], 0, 0, 0);
+                s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][ks], s[1], 0, 0, 0);
+            }
+            const int kv0 = kb0 + 32 * sub;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (kv0 + 32 > Nk) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) if (kv0 + 16 * h + r >= Nk) s[t][r] = NEG_BIG;
+                }
+                float mx = s[t][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * qs;
+                if (__any(mx > m[t] + RESCALE_THR)) {
+                    const float mn = fmaxf(m[t], mx);
+                    const float alpha = fast_exp2(m[t] - mn);
+                    lsum[t] *= alpha;
+                    m[t] = mn;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { acc0[t][r] *= alpha; acc1[t][r] *= alpha; }
+                }
+                float rs = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[t][r] = fast_exp2(fmaf(s[t][r], qs, -m[t])); rs += s[t][r]; }
+                lsum[t] += rs;                                   // per-half partial; halves meet after the loop
+            }
+            const bf16_t* vp = Vt + j * LDTB + 32 * sub + 16 * h;
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const bf16x8 v0 = ld_frag(vp + 8 * k2), v1 = ld_frag(vp + 32 * LDTB + 8 * k2);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const bf16x8 pb = pack8(s[t], 8 * k2);
+                    acc0[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pb, acc0[t], 0, 0, 0);
+                    acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pb, acc1[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const float tot = lsum[t] + __shfl_xor(lsum[t], 32, 64);
+        if (ok[t]) {
+            const float inv = 1.0f / tot;
+            bf16_t* orow = O + qrow[t] * ldo;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                st4<bf16_t>(orow + 8 * g + 4 * h, make_float4(acc0[t][4 * g] * inv, acc0[t][4 * g + 1] * inv, acc0[t][4 * g + 2] * inv, acc0[t][4 * g + 3] * inv));
+                st4<bf16_t>(orow + 32 + 8 * g + 4 * h, make_float4(acc1[t][4 * g] * inv, acc1[t][4 * g + 1] * inv, acc1[t][4 * g + 2] * inv, acc1[t][4 * g + 3] * inv));
+            }
+            if (h == 0) lse[qrow[t]] = (m[t] + log2f(tot)) * LN2;
+        }
+    }
+}
+#elif ATT_VAR == 13
+// v13 = the production kernel with V kept row-major (4x4 k-row permutation), gathered by ds_read_b64_tr_b16, its strips loaded together
+__global__ __launch_bounds__(256, 4) void attn_fwd_seg_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
+                                                              const bf16_t* __restrict__ V, int ldv, long long skv, bf16_t* __restrict__ O,
+                                                              int ldo, float* __restrict__ lse, Segs sg, int Nk, float scale) {
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[KB * LDR];
+    __shared__ __attribute__((aligned(16))) bf16_t Vs[KB * LDR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    int row_base, q0, nq, b;
+    locate_tile(sg, blockIdx.x, row_base, q0, nq, b);
+    const int ql = q0 + wave * 32 + j;                     // query index inside this (segment, image)
+    const bool ok = ql < nq;
+    const long long qrow = (long long)row_base + ql;
+    const bf16_t* Kb = K + b * skv;
+    const bf16_t* Vb = V + b * skv;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const uint4 v = ok ? *reinterpret_cast<const uint4*>(Q + qrow * ldq + 16 * ks + 8 * h) : make_uint4(0u, 0u, 0u, 0u);
+        qf[ks] = *reinterpret_cast<const bf16x8*>(&v);
+    }
+    const float qs = scale * LOG2E;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    float m = NEG_BIG, lsum = 0.f;
+    const int krow = pi_row(j);
+    uint4 kr[4];                                            // K of the next fill is prefetched; V is fetched at its LDS store (keeps the
+    auto fetch = [&](int kb0) {                            // kernel within 128 VGPRs: 4 workgroups per CU = all 800 tiles resident at once)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int r, c8, g;
+            fill_map(tid, i, r, c8, g);
+            kr[i] = ld_row8(Kb, ldk, kb0 + r, Nk, c8);
+        }
+    };
+    fetch(0);
+    for (int kb0 = 0; kb0 < Nk; kb0 += KB) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int r, c8, g;
+            fill_map(tid, i, r, c8, g);
+            *reinterpret_cast<uint4*>(&Ks[r * LDR + c8]) = kr[i];
+        }
+        {
+            uint4 vr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int r, c8, g;
+                fill_map(tid, i, r, c8, g);
+                vr[i] = *reinterpret_cast<const uint4*>(Vb + (long long)min(kb0 + r, Nk - 1) * ldv + c8);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int r, c8, g;
+                fill_map(tid, i, r, c8, g);
+                const int pr = (r & ~15) | ((r & 3) << 2) | ((r >> 2) & 3);
+                *reinterpret_cast<uint4*>(&Vs[pr * LDR + c8]) = vr[i];
+            }
+        }
+        __syncthreads();
+        if (kb0 + KB < Nk) fetch(kb0 + KB);
+        // S^T tile of sub-tile `sub`: 4 chained MFMAs, issued asynchronously to the matrix pipe
+        auto qk = [&](int sub) {
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            const bf16_t* kp = Ks + (32 * sub + krow) * LDR + 8 * h;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(kp + 16 * ks), qf[ks], s, 0, 0, 0);
+            return s;
+        };
+        // online softmax of a finished S^T tile (register VALU) followed by O^T += V^T P^T
+        auto softmax_pv = [&](f32x16 s, int sub) {
+            const int kv0 = kb0 + 32 * sub;
+            if (kv0 + 32 > Nk) {                                // tail tile (wave-uniform)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) if (kv0 + 16 * h + r >= Nk) s[r] = NEG_BIG;
+            }
+            float mx = s[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * qs;        // scaled maximum of this tile
+            if (__any(mx > m + RESCALE_THR)) {                  // lazy rescale: rare once the running maximum has settled
+                const float mn = fmaxf(m, mx);
+                const float alpha = fast_exp2(m - mn);
+                lsum *= alpha;
+                m = mn;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc0[r] *= alpha; acc1[r] *= alpha; }
+            }
+            float rs = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = fast_exp2(fmaf(s[r], qs, -m)); rs += s[r]; }
+            rs += __shfl_xor(rs, 32, 64);
+            lsum += rs;
+            const int gi = lane & 15, gq = (lane >> 4) & 1;
+            const bf16_t* vp = Vs + (32 * sub + 16 * h + 4 * (gi >> 2)) * LDR + 16 * gq + 4 * (gi & 3);
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const bf16x8 pb = pack8(s, 8 * k2);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag_tr(vp + (2 * k2) * LDR, vp + (2 * k2 + 1) * LDR), pb, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag_tr(vp + (2 * k2) * LDR + 32, vp + (2 * k2 + 1) * LDR + 32), pb, acc1, 0, 0, 0);
+            }
+        };
+#pragma unroll 1
+        for (int sub = 0; sub < KB / 32 && kb0 + 32 * sub < Nk; ++sub) softmax_pv(qk(sub), sub);
+    }
+    if (ok) {
+        const float inv = 1.0f / lsum;
+        bf16_t* orow = O + qrow * ldo;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            st4<bf16_t>(orow + 8 * g + 4 * h, make_float4(acc0[4 * g] * inv, acc0[4 * g + 1] * inv, acc0[4 * g + 2] * inv, acc0[4 * g + 3] * inv));
+            st4<bf16_t>(orow + 32 + 8 * g + 4 * h, make_float4(acc1[4 * g] * inv, acc1[4 * g + 1] * inv, acc1[4 * g + 2] * inv, acc1[4 * g + 3] * inv));
+        }
+        if (h == 0) lse[qrow] = (m + log2f(lsum)) * LN2;
+    }
+}
+
+#elif ATT_VAR == 10
 // v10: 6 waves (192 queries) per workgroup over image-flattened 32-query wave tiles: 32 workgroups per image = 512 = 2 per CU
 // exactly (12 waves per CU), K/V staging shared by 192 queries instead of 128, 96-key stages (3 sub-tiles of 32 keys).
 constexpr int NW10 = 6, KB10 = 96, LDT10 = KB10 + 16;     // 224-byte Vt rows = 56 words (24 mod 32) -- see st_t8 note below
@@ -781,19 +1170,25 @@ extern "C" int tc_attn_fwd_seg(const void* Q, int ldq, const void* K, int ldk, c
         return TC_OK;
     }
     if (dtype != TC_BF16 || ((ldq | ldk | ldv) & 7) || (skv & 7) || (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) || (ldo & 3)) return TC_ERR_ARG;
-#if ATT_VAR == 10
+#if ATT_VAR == 11 || ATT_VAR == 12
+    hipLaunchKernelGGL(attn_fwd_seg_kernel, dim3(sg.tile0[nseg]), dim3(128), 0, (hipStream_t)stream, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk,
+                       (const bf16_t*)V, ldv, skv, (bf16_t*)O, ldo, lse, sg, Nk, scale);
+    return tc_launch_status();
+#elif ATT_VAR == 10
     const unsigned fwd_grid = (unsigned)B * ((sg.t32[nseg] + 5) / 6);
     hipLaunchKernelGGL(attn_fwd_seg_kernel, dim3(fwd_grid), dim3(384), 0, (hipStream_t)stream, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk,
                        (const bf16_t*)V, ldv, skv, (bf16_t*)O, ldo, lse, sg, Nk, scale);
     return tc_launch_status();
-#elif ATT_VAR >= 5
+#elif ATT_VAR >= 5 && ATT_VAR != 13
     const unsigned fwd_grid = (unsigned)B * ((sg.t32[nseg] + 3) / 4);
 #else
     const unsigned fwd_grid = sg.tile0[nseg];
 #endif
+#if ATT_VAR != 10 && ATT_VAR != 11 && ATT_VAR != 12
     hipLaunchKernelGGL(attn_fwd_seg_kernel, dim3(fwd_grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk,
                        (const bf16_t*)V, ldv, skv, (bf16_t*)O, ldo, lse, sg, Nk, scale);
     return tc_launch_status();
+#endif
 }
 
 extern "C" int tc_attn_bwd_seg(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, long long skv, const void* O, int ldo,

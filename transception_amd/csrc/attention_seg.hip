@@ -66,6 +66,19 @@ __device__ __forceinline__ void fill_map(int tid, int it, int& r, int& c8, int& 
     r = 16 * (c >> 1) + (lane & 15);
     c8 = 32 * (c & 1) + 8 * g;
 }
+// [keys][d] tiles kept row-major in LDS and consumed as MFMA A-operands with keys as the k index are gathered by the hardware
+// transpose read: lane i of a 16-lane group hands in the address of key row (i >> 2) of a 4-key block, d columns 4 (i & 3).., and
+// receives column i.  With 144-byte rows the 4 rows of a read must lie 4 rows apart to start 16 banks apart, so the keys of every
+// 16-key group are stored 4x4-transposed (row = (key & ~15) | (key & 3) << 2 | (key >> 2) & 3): conflict-free, one 16-byte LDS
+// store per strip instead of eight 2-byte ones (st_t8).
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 ld_frag_tr(const bf16_t* lo, const bf16_t* hi) {
+    const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(lo));
+    const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(hi));
+    return __builtin_bit_cast(bf16x8, (s16x8_t)__builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+__device__ __forceinline__ int key_row(int r) { return (r & ~15) | ((r & 3) << 2) | ((r >> 2) & 3); }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // block -> (segment, image, first query row of the tile, queries valid in the tile's segment-image)
@@ -85,7 +98,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_seg_kernel(const bf16_t* __re
                                                               const bf16_t* __restrict__ V, int ldv, long long skv, bf16_t* __restrict__ O,
                                                               int ldo, float* __restrict__ lse, Segs sg, int Nk, float scale) {
     __shared__ __attribute__((aligned(16))) bf16_t Ks[KB * LDR];
-    __shared__ __attribute__((aligned(16))) bf16_t Vt[D * LDTB];
+    __shared__ __attribute__((aligned(16))) bf16_t Vs[KB * LDR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
     int row_base, q0, nq, b;
     locate_tile(sg, blockIdx.x, row_base, q0, nq, b);
@@ -123,7 +136,21 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_seg_kernel(const bf16_t* __re
             int r, c8, g;
             fill_map(tid, i, r, c8, g);
             *reinterpret_cast<uint4*>(&Ks[r * LDR + c8]) = kr[i];
-            st_t8(Vt, LDTB, c8, r, ld_row8(Vb, ldv, kb0 + r, Nk, c8), g);
+        }
+        {
+            uint4 vr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int r, c8, g;
+                fill_map(tid, i, r, c8, g);
+                vr[i] = *reinterpret_cast<const uint4*>(Vb + (long long)min(kb0 + r, Nk - 1) * ldv + c8);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int r, c8, g;
+                fill_map(tid, i, r, c8, g);
+                *reinterpret_cast<uint4*>(&Vs[key_row(r) * LDR + c8]) = vr[i];
+            }
         }
         __syncthreads();
         if (kb0 + KB < Nk) fetch(kb0 + KB);
@@ -161,12 +188,13 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_seg_kernel(const bf16_t* __re
             for (int r = 0; r < 16; ++r) { s[r] = fast_exp2(fmaf(s[r], qs, -m)); rs += s[r]; }
             rs += __shfl_xor(rs, 32, 64);
             lsum += rs;
-            const bf16_t* vp = Vt + j * LDTB + 32 * sub + 16 * h;
+            const int gi = lane & 15, gq = (lane >> 4) & 1;
+            const bf16_t* vp = Vs + (32 * sub + 16 * h + 4 * (gi >> 2)) * LDR + 16 * gq + 4 * (gi & 3);
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2) {
                 const bf16x8 pb = pack8(s, 8 * k2);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(vp + 8 * k2), pb, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(vp + 32 * LDTB + 8 * k2), pb, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag_tr(vp + (2 * k2) * LDR, vp + (2 * k2 + 1) * LDR), pb, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag_tr(vp + (2 * k2) * LDR + 32, vp + (2 * k2 + 1) * LDR + 32), pb, acc1, 0, 0, 0);
             }
         };
 #pragma unroll 1
