@@ -174,7 +174,12 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_seg_kernel(const bf16_t* __re
             float mx = s[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * qs;        // scaled maximum of this tile
+            {   // both 32-lane halves hold scores of the same query: swapping the upper half of one copy with the lower half of
+                // another leaves x.lo in one register and x.hi in the other in every lane -- a VALU op, no ds_bpermute round trip
+                const unsigned u = __float_as_uint(mx);
+                const auto pr = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+                mx = fmaxf(__uint_as_float(pr[0]), __uint_as_float(pr[1])) * qs;        // scaled maximum of this tile
+            }
             if (__any(mx > m + RESCALE_THR)) {                  // lazy rescale: rare once the running maximum has settled
                 const float mn = fmaxf(m, mx);
                 const float alpha = fast_exp2(m - mn);
@@ -186,8 +191,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_seg_kernel(const bf16_t* __re
             float rs = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = fast_exp2(fmaf(s[r], qs, -m)); rs += s[r]; }
-            rs += __shfl_xor(rs, 32, 64);
-            lsum += rs;
+            lsum += rs;                                         // per-half partial sum: the halves meet once, after the loop
             const int gi = lane & 15, gq = (lane >> 4) & 1;
             const bf16_t* vp = Vs + (32 * sub + 16 * h + 4 * (gi >> 2)) * LDR + 16 * gq + 4 * (gi & 3);
 #pragma unroll
@@ -200,6 +204,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_seg_kernel(const bf16_t* __re
 #pragma unroll 1
         for (int sub = 0; sub < KB / 32 && kb0 + 32 * sub < Nk; ++sub) softmax_pv(qk(sub), sub);
     }
+    lsum += __shfl_xor(lsum, 32, 64);
     if (ok) {
         const float inv = 1.0f / lsum;
         bf16_t* orow = O + qrow * ldo;
