@@ -100,11 +100,17 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_seg_kernel(const bf16_t* __re
     __shared__ __attribute__((aligned(16))) bf16_t Ks[KB * LDR];
     __shared__ __attribute__((aligned(16))) bf16_t Vs[KB * LDR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
-    int row_base, q0, nq, b;
-    locate_tile(sg, blockIdx.x, row_base, q0, nq, b);
-    const int ql = q0 + wave * 32 + j;                     // query index inside this (segment, image)
-    const bool ok = ql < nq;
-    const long long qrow = (long long)row_base + ql;
+    // 32-query wave tiles are numbered through the four scales of an image and dealt four to a workgroup: 48 workgroups per image
+    // at 224^2 = 768 at B = 16 = exactly three per CU (tiles of 128 queries per scale gave 800: the CUs holding four finished last)
+    const int nwt = sg.t32[sg.n], bpi = (nwt + 3) >> 2;
+    const int b = blockIdx.x / bpi, wt = (blockIdx.x - b * bpi) * 4 + wave;
+    int sgi = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) if (i < sg.n && wt >= sg.t32[i]) sgi = i;
+    const int nq = sg.nq[sgi];
+    const int ql = (wt - sg.t32[sgi]) * 32 + j;
+    const bool ok = wt < nwt && ql < nq;
+    const long long qrow = (long long)sg.row0[sgi] + (long long)b * nq + ql;
     const bf16_t* Kb = K + b * skv;
     const bf16_t* Vb = V + b * skv;
     bf16x8 qf[4];
@@ -174,11 +180,10 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_seg_kernel(const bf16_t* __re
             float mx = s[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
-            {   // both 32-lane halves hold scores of the same query: swapping the upper half of one copy with the lower half of
-                // another leaves x.lo in one register and x.hi in the other in every lane -- a VALU op, no ds_bpermute round trip
+            {
                 const unsigned u = __float_as_uint(mx);
                 const auto pr = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-                mx = fmaxf(__uint_as_float(pr[0]), __uint_as_float(pr[1])) * qs;        // scaled maximum of this tile
+                mx = fmaxf(__uint_as_float(pr[0]), __uint_as_float(pr[1])) * qs;
             }
             if (__any(mx > m + RESCALE_THR)) {                  // lazy rescale: rare once the running maximum has settled
                 const float mn = fmaxf(m, mx);
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_seg_kernel(const bf16_t* __re
             float rs = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = fast_exp2(fmaf(s[r], qs, -m)); rs += s[r]; }
-            lsum += rs;                                         // per-half partial sum: the halves meet once, after the loop
+            lsum += rs;
             const int gi = lane & 15, gq = (lane >> 4) & 1;
             const bf16_t* vp = Vs + (32 * sub + 16 * h + 4 * (gi >> 2)) * LDR + 16 * gq + 4 * (gi & 3);
 #pragma unroll
@@ -515,7 +520,7 @@ extern "C" int tc_attn_fwd_seg(const void* Q, int ldq, const void* K, int ldk, c
         return TC_OK;
     }
     if (dtype != TC_BF16 || ((ldq | ldk | ldv) & 7) || (skv & 7) || (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) || (ldo & 3)) return TC_ERR_ARG;
-    hipLaunchKernelGGL(attn_fwd_seg_kernel, dim3(sg.tile0[nseg]), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk,
+    hipLaunchKernelGGL(attn_fwd_seg_kernel, dim3((unsigned)B * ((sg.t32[nseg] + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk,
                        (const bf16_t*)V, ldv, skv, (bf16_t*)O, ldo, lse, sg, Nk, scale);
     return tc_launch_status();
 }
