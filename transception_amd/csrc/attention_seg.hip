@@ -222,20 +222,26 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_seg_kernel(const bf16_t* __re
     }
 }
 
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_seg_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_seg_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
                                                                  const bf16_t* __restrict__ V, int ldv, long long skv,
                                                                  const bf16_t* __restrict__ dO, int lddo, const float* __restrict__ lse,
                                                                  const float* __restrict__ delta, bf16_t* __restrict__ dQ, int lddq, Segs sg,
                                                                  int Nk, float scale) {
     __shared__ __attribute__((aligned(16))) bf16_t Ks[KB * LDR];
     __shared__ __attribute__((aligned(16))) bf16_t Vs[KB * LDR];
-    __shared__ __attribute__((aligned(16))) bf16_t Kt[D * LDTB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
-    int row_base, q0, nq, b;
-    locate_tile(sg, blockIdx.x, row_base, q0, nq, b);
-    const int ql = q0 + wave * 32 + j;
-    const bool ok = ql < nq;
-    const long long qrow = (long long)row_base + ql;
+    // K is stored ONCE, rows in key_row order: conflict-free both for the 16-byte fragment reads of S^T = K Q^T (row
+    // key_row(pi_row(j))) and for the transpose reads of dQ^T += K^T dS^T -- two LDS tiles instead of three, three workgroups per CU,
+    // and the forward kernel's balanced tiling (32-query wave tiles numbered through the scales of an image, 768 workgroups)
+    const int nwt = sg.t32[sg.n], bpi = (nwt + 3) >> 2;
+    const int b = blockIdx.x / bpi, wt = (blockIdx.x - b * bpi) * 4 + wave;
+    int sgi = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) if (i < sg.n && wt >= sg.t32[i]) sgi = i;
+    const int nq = sg.nq[sgi];
+    const int ql = (wt - sg.t32[sgi]) * 32 + j;
+    const bool ok = wt < nwt && ql < nq;
+    const long long qrow = (long long)sg.row0[sgi] + (long long)b * nq + ql;
     bf16x8 qf[4], dof[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -250,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_seg_kernel(const bf16_t* _
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    const int krow = pi_row(j);
+    const int krow = pi_row(j), kprow = key_row(krow);
     const bf16_t* Kb = K + b * skv;
     const bf16_t* Vb = V + b * skv;
     uint4 kr[4], vr[4];
@@ -270,8 +276,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_seg_kernel(const bf16_t* _
         for (int i = 0; i < 4; ++i) {
             int r, c8, g;
             fill_map(tid, i, r, c8, g);
-            *reinterpret_cast<uint4*>(&Ks[r * LDR + c8]) = kr[i];
-            st_t8(Kt, LDTB, c8, r, kr[i], g);
+            *reinterpret_cast<uint4*>(&Ks[key_row(r) * LDR + c8]) = kr[i];
             *reinterpret_cast<uint4*>(&Vs[r * LDR + c8]) = vr[i];
         }
         __syncthreads();
@@ -283,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_seg_kernel(const bf16_t* _
             f32x16 s, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-            const bf16_t* kp = Ks + (32 * sub + krow) * LDR + 8 * h;
+            const bf16_t* kp = Ks + (32 * sub + kprow) * LDR + 8 * h;
             const bf16_t* vp = Vs + (32 * sub + krow) * LDR + 8 * h;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -297,12 +302,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_seg_kernel(const bf16_t* _
                 if (tail && kv0 + 16 * h + r >= Nk) p = 0.f;
                 s[r] = p * (dp[r] - dl) * scale;
             }
-            const bf16_t* kt = Kt + j * LDTB + 32 * sub + 16 * h;
+            const int gi = lane & 15, gq = (lane >> 4) & 1;
+            const bf16_t* kt = Ks + (32 * sub + 16 * h + 4 * (gi >> 2)) * LDR + 16 * gq + 4 * (gi & 3);
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2) {
                 const bf16x8 db = pack8(s, 8 * k2);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(kt + 8 * k2), db, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(kt + 32 * LDTB + 8 * k2), db, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag_tr(kt + (2 * k2) * LDR, kt + (2 * k2 + 1) * LDR), db, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag_tr(kt + (2 * k2) * LDR + 32, kt + (2 * k2 + 1) * LDR + 32), db, acc1, 0, 0, 0);
             }
         }
     }
@@ -570,7 +576,7 @@ extern "C" int tc_attn_bwd_seg(const void* Q, int ldq, const void* K, int ldk, c
     }
     hipLaunchKernelGGL(attn_dkv_store_kernel, dim3(tc_blocks((long long)B * Nk * 32, 256, 1024)), dim3(256), 0, s, dkv32, (bf16_t*)dK, lddk,
                        (bf16_t*)dV, lddv, sdkv, B, Nk);
-    hipLaunchKernelGGL(attn_bwd_dq_seg_kernel, dim3(sg.tile0[nseg]), dim3(256), 0, s, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk, (const bf16_t*)V,
+    hipLaunchKernelGGL(attn_bwd_dq_seg_kernel, dim3((unsigned)B * ((sg.t32[nseg] + 3) / 4)), dim3(256), 0, s, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk, (const bf16_t*)V,
                        ldv, skv, (const bf16_t*)dO, lddo, lse, delta, (bf16_t*)dQ, lddq, sg, Nk, scale);
     return tc_launch_status();
 }
