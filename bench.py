@@ -8,7 +8,8 @@ One "step" = one pass of the hot path over one batch of synthetic Synapse-shaped
 MSTransception forward, 0.4*CE+0.6*Dice loss, backward, (gradient all-reduce over RCCL when N>1), fused SGD update.
 Weak scaling: 16 images per GPU.  Rank 0 prints ONE JSON line (contract in the task description), carrying
   roofline      the bridge SR-attention forward kernel (the MFMA-bound kernel BASELINE.json's north_star names), timed
-                live with HIP events around every one of its launches inside the timed region;
+                live with HIP events: around 30 back-to-back launches in a replayed hipGraph (the way the timed region runs it;
+                agrees with the rocprofv3 average) and, as roofline_eager_events, around each launch of an instrumented eager step;
   cpu_baseline  the CPU oracle (a port of the reference arithmetic; the reference's Python cannot travel) timed on this
                 box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -310,6 +311,14 @@ def main():
                 msb = sum(a.elapsed_time(b) for a, b, _ in evb)
                 flb = sum(f for _, _, f in evb)
                 if world == 1 and extra_roof is not None:
+                    # The timed region replays a hipGraph, where per-launch HIP events cannot be placed: the headline figure is the kernel
+                    # timed with HIP events around 30 back-to-back launches inside a replayed graph (this is what agrees with the
+                    # rocprofv3 average of the same command, profiles/); the per-launch events of the instrumented eager pass, which
+                    # separate the launches by host gaps, are kept beside it.
+                    eager = out["roofline"]
+                    out["roofline"] = dict(eager, achieved=extra_roof["achieved"], frac=extra_roof["frac"], avg_launch_us=extra_roof["avg_launch_us"],
+                                           launches=30, how=extra_roof["how"])
+                    out["roofline_eager_events"] = {k: eager[k] for k in ("achieved", "frac", "launches", "avg_launch_us")}
                     out["roofline_graph_replay"] = extra_roof
                 out["roofline_attn_bwd"] = {"bound": "mfma", "achieved": flb / (msb * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
                                             "frac": flb / (msb * 1e-3) / 1e12 / peak, "launches": len(evb),
