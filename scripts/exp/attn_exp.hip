@@ -867,6 +867,145 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_seg_kernel(const bf16_t* __re
     }
 }
 
+#elif ATT_VAR == 27
+// v27 = v16 with the 4-long dependent QK^T MFMA chain split in two independent halves (3 waves per SIMD budget)
+// v16 = v15 with wave tiles flattened per image: 48 workgroups per image = 768 = 3 per CU exactly
+// v15 = v13 + permlane32 swap for the cross-half max, per-half row sums
+// v13 = the production kernel with V kept row-major (4x4 k-row permutation), gathered by ds_read_b64_tr_b16, its strips loaded together
+__global__ __launch_bounds__(256, 3) void attn_fwd_seg_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
+                                                              const bf16_t* __restrict__ V, int ldv, long long skv, bf16_t* __restrict__ O,
+                                                              int ldo, float* __restrict__ lse, Segs sg, int Nk, float scale) {
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[KB * LDR];
+    __shared__ __attribute__((aligned(16))) bf16_t Vs[KB * LDR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    const int nwt = sg.t32[sg.n], bpi = (nwt + 3) >> 2;
+    const int b = blockIdx.x / bpi, wt = (blockIdx.x - b * bpi) * 4 + wave;
+    int sgi = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) if (i < sg.n && wt >= sg.t32[i]) sgi = i;
+    const int nq = sg.nq[sgi];
+    const int ql = (wt - sg.t32[sgi]) * 32 + j;
+    const bool ok = wt < nwt && ql < nq;
+    const long long qrow = (long long)sg.row0[sgi] + (long long)b * nq + ql;
+    const bf16_t* Kb = K + b * skv;
+    const bf16_t* Vb = V + b * skv;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const uint4 v = ok ? *reinterpret_cast<const uint4*>(Q + qrow * ldq + 16 * ks + 8 * h) : make_uint4(0u, 0u, 0u, 0u);
+        qf[ks] = *reinterpret_cast<const bf16x8*>(&v);
+    }
+    const float qs = scale * LOG2E;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    float m = NEG_BIG, lsum = 0.f;
+    const int krow = pi_row(j);
+    uint4 kr[4];                                            // K of the next fill is prefetched; V is fetched at its LDS store (keeps the
+    auto fetch = [&](int kb0) {                            // kernel within 128 VGPRs: 4 workgroups per CU = all 800 tiles resident at once)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int r, c8, g;
+            fill_map(tid, i, r, c8, g);
+            kr[i] = ld_row8(Kb, ldk, kb0 + r, Nk, c8);
+        }
+    };
+    fetch(0);
+    for (int kb0 = 0; kb0 < Nk; kb0 += KB) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int r, c8, g;
+            fill_map(tid, i, r, c8, g);
+            *reinterpret_cast<uint4*>(&Ks[r * LDR + c8]) = kr[i];
+        }
+        {
+            uint4 vr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int r, c8, g;
+                fill_map(tid, i, r, c8, g);
+                vr[i] = *reinterpret_cast<const uint4*>(Vb + (long long)min(kb0 + r, Nk - 1) * ldv + c8);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int r, c8, g;
+                fill_map(tid, i, r, c8, g);
+                const int pr = (r & ~15) | ((r & 3) << 2) | ((r >> 2) & 3);
+                *reinterpret_cast<uint4*>(&Vs[pr * LDR + c8]) = vr[i];
+            }
+        }
+        __syncthreads();
+        if (kb0 + KB < Nk) fetch(kb0 + KB);
+        // S^T tile of sub-tile `sub`: 4 chained MFMAs, issued asynchronously to the matrix pipe
+        auto qk = [&](int sub) {
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            const bf16_t* kp = Ks + (32 * sub + krow) * LDR + 8 * h;
+            f32x16 s2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s2[r] = 0.f;
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(kp), qf[0], s, 0, 0, 0);
+            s2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(kp + 32), qf[2], s2, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(kp + 16), qf[1], s, 0, 0, 0);
+            s2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(kp + 48), qf[3], s2, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] += s2[r];
+            return s;
+        };
+        // online softmax of a finished S^T tile (register VALU) followed by O^T += V^T P^T
+        auto softmax_pv = [&](f32x16 s, int sub) {
+            const int kv0 = kb0 + 32 * sub;
+            if (kv0 + 32 > Nk) {                                // tail tile (wave-uniform)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) if (kv0 + 16 * h + r >= Nk) s[r] = NEG_BIG;
+            }
+            float mx = s[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+            {
+                const unsigned u = __float_as_uint(mx);
+                const auto pr = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+                mx = fmaxf(__uint_as_float(pr[0]), __uint_as_float(pr[1])) * qs;
+            }
+            if (__any(mx > m + RESCALE_THR)) {                  // lazy rescale: rare once the running maximum has settled
+                const float mn = fmaxf(m, mx);
+                const float alpha = fast_exp2(m - mn);
+                lsum *= alpha;
+                m = mn;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc0[r] *= alpha; acc1[r] *= alpha; }
+            }
+            float rs = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = fast_exp2(fmaf(s[r], qs, -m)); rs += s[r]; }
+            lsum += rs;
+            const int gi = lane & 15, gq = (lane >> 4) & 1;
+            const bf16_t* vp = Vs + (32 * sub + 16 * h + 4 * (gi >> 2)) * LDR + 16 * gq + 4 * (gi & 3);
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const bf16x8 pb = pack8(s, 8 * k2);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag_tr(vp + (2 * k2) * LDR, vp + (2 * k2 + 1) * LDR), pb, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag_tr(vp + (2 * k2) * LDR + 32, vp + (2 * k2 + 1) * LDR + 32), pb, acc1, 0, 0, 0);
+            }
+        };
+#pragma unroll 1
+        for (int sub = 0; sub < KB / 32 && kb0 + 32 * sub < Nk; ++sub) softmax_pv(qk(sub), sub);
+    }
+    lsum += __shfl_xor(lsum, 32, 64);
+    if (ok) {
+        const float inv = 1.0f / lsum;
+        bf16_t* orow = O + qrow * ldo;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            st4<bf16_t>(orow + 8 * g + 4 * h, make_float4(acc0[4 * g] * inv, acc0[4 * g + 1] * inv, acc0[4 * g + 2] * inv, acc0[4 * g + 3] * inv));
+            st4<bf16_t>(orow + 32 + 8 * g + 4 * h, make_float4(acc1[4 * g] * inv, acc1[4 * g + 1] * inv, acc1[4 * g + 2] * inv, acc1[4 * g + 3] * inv));
+        }
+        if (h == 0) lse[qrow] = (m + log2f(lsum)) * LN2;
+    }
+}
+
 #elif ATT_VAR == 25
 // v25 = ablation of v16: no softmax arithmetic (P = raw scores)
 // v16 = v15 with wave tiles flattened per image: 48 workgroups per image = 768 = 3 per CU exactly
@@ -2335,7 +2474,7 @@ extern "C" int tc_attn_fwd_seg(const void* Q, int ldq, const void* K, int ldk, c
     hipLaunchKernelGGL(attn_fwd_seg_kernel, dim3(fwd_grid), dim3(384), 0, (hipStream_t)stream, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk,
                        (const bf16_t*)V, ldv, skv, (bf16_t*)O, ldo, lse, sg, Nk, scale);
     return tc_launch_status();
-#elif (ATT_VAR >= 5 && ATT_VAR < 13) || ATT_VAR == 16 || ATT_VAR == 17 || ATT_VAR == 21 || ATT_VAR == 23 || ATT_VAR == 24 || ATT_VAR == 25 || ATT_VAR == 26
+#elif (ATT_VAR >= 5 && ATT_VAR < 13) || ATT_VAR == 16 || ATT_VAR == 17 || ATT_VAR == 21 || ATT_VAR == 23 || ATT_VAR == 24 || ATT_VAR == 25 || ATT_VAR == 26 || ATT_VAR == 27
     const unsigned fwd_grid = (unsigned)B * ((sg.t32[nseg] + 3) / 4);
 #else
     const unsigned fwd_grid = sg.tile0[nseg];
