@@ -2,22 +2,30 @@
 """bench.py -- images/sec, forward + backward (+ loss + SGD step), TransCeption 224x224, B=16 per GPU.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype f32|bf16] [--batch 16] [--size 224] [--no-cpu]
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
 
-One "step" = one pass of the hot path over one batch of synthetic Synapse-shaped input resident in HBM:
-MSTransception forward, 0.4*CE+0.6*Dice loss, backward, (gradient all-reduce over RCCL when N>1), fused SGD update.
-Weak scaling: 16 images per GPU.  Rank 0 prints ONE JSON line (contract in the task description), carrying
-  roofline      the bridge SR-attention forward kernel (the MFMA-bound kernel BASELINE.json's north_star names), timed
-                live with HIP events: around 30 back-to-back launches in a replayed hipGraph (the way the timed region runs it;
-                agrees with the rocprofv3 average) and, as roofline_eager_events, around each launch of an instrumented eager step;
-  cpu_baseline  the CPU oracle (a port of the reference arithmetic; the reference's Python cannot travel) timed on this
-                box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+N>1: launched by the driver as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...
+bench.py --gpus N ...`; started WITHOUT a rendezvous environment, `--gpus N` re-executes itself through that very launcher, so a
+multi-GPU figure can never be a silent one-GPU run (the world size is asserted and reported as n_gpus / rccl_ranks).
+
+One "step" = one pass of the hot path over one batch of synthetic Synapse-shaped input resident in HBM: MSTransception forward,
+0.4*CE+0.6*Dice loss, backward, (gradient all-reduce over RCCL when N>1), fused SGD update.  Weak scaling: 16 images per GPU.
+`value` = images of the K timed steps / wall time between two barrier+synchronize brackets (max over ranks); the median of the
+per-step HIP-event times is reported beside it (config.median_ms_per_step).  Rank 0 prints ONE JSON line carrying
+  roofline      the bridge SR-attention forward kernel (the MFMA-bound kernel BASELINE.json's north_star names): HIP events
+                around each of its launches inside instrumented steps of the same workload (in-step figure); the same kernel
+                back-to-back inside a replayed hipGraph is kept beside it as roofline_graph_replay;
+  roofline_hbm  the memory-bound family north_star asks an HBM figure for, timed the same way;
+  cpu_baseline  the CPU oracle (a port of the reference arithmetic; the reference's Python cannot travel) timed on this box's
+                host cores on a bounded sample of the same workload (rank 0, N=1 only): median of 3 steps + the config-1 figure.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -27,6 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}        # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
 
 
 def synthetic_batch(B: int, size: int, device, seed: int):
@@ -51,21 +60,28 @@ def _loader_feed(args, dev, rank: int, world: int, n_needed: int, out=None):
     return iter(loader)
 
 
+# ----------------------------------------------------------------------------------------------------------------- CPU baseline
 def _cpu_baseline_worker(batch: int, size: int):
-    """Oracle fwd+bwd+SGD on the host cores.  Bounded sample: the batch is cut to 4 images when a probe says a full step
-    would take too long, one warm-up + up to two timed steps (about 10-30 s of CPU work in total)."""
+    """Oracle on the host cores: config 1 (B=2 train-mode forward) and the benchmarked workload (fwd+bwd+SGD),
+    each the median of 3 repetitions after a warm-up.  Bounded: the batch of the second figure is cut to 4 images when a probe says
+    three full steps would take longer than ~30 s.  Thread count: the faster of 32 / 64 threads on the warm-up probe (more threads
+    than that only add synchronisation cost to this model's many small ops: 256 threads ran several times slower)."""
     from oracle.transception_oracle import TransCeptionOracle, ce_dice_loss, load_params
     from transception_amd.seeded_init import seeded_state_dict
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 32))                      # more threads than that only add synchronisation cost at these sizes
-    torch.set_num_threads(cores)
     P = load_params(seeded_state_dict(), requires_grad=True)
     leaves = list({id(v): v for v in P.values() if v.requires_grad}.values())
     opt = torch.optim.SGD(leaves, lr=0.05, momentum=0.9, weight_decay=1e-4)
     orc = TransCeptionOracle(P, 9, training=True)
+
+    def fwd(x):
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            orc(x)
+        return time.perf_counter() - t0
 
     def step(x, y):
         t0 = time.perf_counter()
@@ -76,21 +92,30 @@ def _cpu_baseline_worker(batch: int, size: int):
         return time.perf_counter() - t0
 
     xp, yp = synthetic_batch(2, size, "cpu", 1)
-    probe = step(xp, yp)                                 # also the warm-up
-    bs = batch if probe * batch / 2 < 12.0 else min(batch, 4)
+    cands = sorted({c for c in (32, 64) if 1 <= c <= avail} or {avail})
+    best, cores = None, cands[0]
+    for c in cands:                                      # doubles as the warm-up
+        torch.set_num_threads(c)
+        fwd(xp)
+        t = fwd(xp)
+        if best is None or t < best:
+            best, cores = t, c
+    torch.set_num_threads(cores)
+    f2 = statistics.median(fwd(xp) for _ in range(3))
+    probe = step(xp, yp)
+    bs = batch if probe * batch / 2 * 3 < 30.0 else min(batch, 4)
     x, y = synthetic_batch(bs, size, "cpu", 1)
-    times = [step(x, y)]
-    if sum(times) < 12.0:
-        times.append(step(x, y))
-    t = min(times)
-    return {"value": bs / t, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"{len(times)} timed fwd+bwd+SGD step(s) of B={bs} {size}x{size} after a B=2 warm-up, fp32 PyTorch-CPU oracle "
-                      f"(port of the reference arithmetic), {cores} threads of {avail} available, best step"}
+    times = [step(x, y) for _ in range(3)]
+    t = statistics.median(times)
+    return {"value": bs / t, "unit": "images/sec", "cores": cores, "cores_available": avail, "kind": "port",
+            "config1_b2_fwd_images_per_sec": 2 / f2,
+            "sample": f"median of 3 fwd+bwd+SGD steps of B={bs} {size}x{size} after warm-up (and median of 3 train-mode forwards of B=2 = "
+                      f"BASELINE config 1), fp32 PyTorch-CPU oracle (port of the reference arithmetic), {cores} threads "
+                      f"(fastest of {cands} on the probe) of {avail} logical cores"}
 
 
-def cpu_baseline(batch: int, size: int, timeout: float = 150.0):
+def cpu_baseline(batch: int, size: int, timeout: float = 240.0):
     """Runs the worker in a child process so a slow host can never stall the GPU measurement."""
-    import subprocess
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--batch", str(batch), "--size", str(size)],
                            capture_output=True, text=True, timeout=timeout)
@@ -102,16 +127,33 @@ def cpu_baseline(batch: int, size: int, timeout: float = 150.0):
         return {"value": None, "unit": "images/sec", "cores": 0, "kind": "port", "sample": f"worker exceeded {timeout:.0f} s"}
 
 
+# ------------------------------------------------------------------------------------------------------------------ launcher
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _self_spawn(n: int) -> int:
+    """`python bench.py --gpus N` without a rendezvous environment: re-run this command line under torch.distributed.run, one rank
+    per GPU (the launch line the driver uses)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+# --------------------------------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16"])
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--size", type=int, default=224)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-attn-events", action="store_true")
+    ap.add_argument("--no-side", action="store_true", help="skip the side figures (forward-only, fp32, loader-fed, roofline passes)")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying the captured hipGraph")
     ap.add_argument("--force-split", action="store_true", help="use the 3-graph multi-GPU step structure even on one GPU")
     ap.add_argument("--loader", action="store_true",
@@ -123,17 +165,21 @@ def main():
         print(json.dumps(_cpu_baseline_worker(args.batch, args.size)))
         return
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(_self_spawn(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if os.environ.get("TC_TEST_ONE_GPU") == "1":            # drill of the multi-rank step on a 1-GPU box: every rank on cuda:0,
-        local = 0                                           # collectives through TC_DIST_BACKEND=gloo (not a measurement)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or drop the rendezvous environment and "
+                         f"let `bench.py --gpus N` spawn its own ranks)")
+    one_gpu_drill = os.environ.get("TC_TEST_ONE_GPU") == "1"    # drill of the multi-rank step on a 1-GPU box: every rank on cuda:0,
+    if one_gpu_drill:                                           # collectives through TC_DIST_BACKEND=gloo (not a measurement)
+        local = 0
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     import torch.distributed as dist
-    group = None
+    group, backend = None, None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("TC_DIST_BACKEND", "nccl")
@@ -142,17 +188,22 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
         group = dist.group.WORLD
+        assert dist.get_world_size() == args.gpus
 
     import transception_amd.engine as engine
     from transception_amd import MSTransception
     from transception_amd.seeded_init import seeded_state_dict
     from transception_amd.train import FusedSGD, GraphedStep, SegLoss, cosine_lr, train_step
 
-    model = MSTransception(num_classes=9)
-    model.load_state_dict(seeded_state_dict(), strict=True)      # random-init weights of the architecture (name-seeded)
-    model.to(dev).train()
-    model.set_compute_dtype(torch.float32 if args.dtype == "f32" else torch.bfloat16)
-    model._ensure_flat(dev)
+    def build_model(dtype: str):
+        m = MSTransception(num_classes=9)
+        m.load_state_dict(seeded_state_dict(), strict=True)      # random-init weights of the architecture (name-seeded)
+        m.to(dev).train()
+        m.set_compute_dtype(torch.float32 if dtype == "f32" else torch.bfloat16)
+        m._ensure_flat(dev)
+        return m
+
+    model = build_model(args.dtype)
     if world > 1:
         dist.broadcast(model.flat_parameters(), src=0)           # C3: identical replicas
     loss_fn = SegLoss(9, group=group)
@@ -179,106 +230,40 @@ def main():
         step()
         opt.set_lr(cosine_lr(0.05, i + 1, t_max))
     sync()
-    if rank == 0 and not args.no_attn_events and args.eager:
-        engine.PROFILE = {}
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         loss, ce, dice = step()
         opt.set_lr(cosine_lr(0.05, args.warmup + i + 1, t_max))
+        marks[i + 1].record()
     sync()
     elapsed = time.perf_counter() - t0
+    per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     if feed is not None:
         feed.close()
         step = step_resident
+    exposed = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    if rank == 0 and not args.no_attn_events and not args.eager:
-        # the attention launches cannot carry HIP events inside a captured graph: time them in an instrumented eager pass
-        # of the same step on the same tensors, right after the timed region
-        engine.PROFILE = {}
-        for _ in range(3):
-            train_step(model, loss_fn, opt, x, y, group)
-        torch.cuda.synchronize(dev)
-    prof, engine.PROFILE = engine.PROFILE, None
-    extra, extra_roof = {}, None
-    if rank == 0 and world == 1:
-        # side figures SURVEY.md section 8(d) asks for: C-ABI calls of one step (each is 1-3 kernel launches) and the
-        # forward-only rate (train-mode forward captured alone, 10 replays)
-        from transception_amd._lib import _Lib
-        c0 = _Lib.calls
-        train_step(model, loss_fn, opt, x, y, group)
-        extra["c_abi_calls_per_step"] = _Lib.calls - c0
-        torch.cuda.synchronize(dev)
-        with torch.no_grad():
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                model(x)
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize(dev)
-            gf = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gf):
-                model(x)
-            gf.replay()
-            torch.cuda.synchronize(dev)
-            tf = time.perf_counter()
-            for _ in range(10):
-                gf.replay()
-            torch.cuda.synchronize(dev)
-            extra["fwd_only_images_per_sec"] = args.batch * 10 / (time.perf_counter() - tf)
-        if not args.eager and not args.loader and args.size == 224:
-            # SURVEY 8(f)-1 side figure: the same graphed step fed by the device input pipeline (npz -> HBM -> augment/resize)
-            f2 = _loader_feed(args, dev, 0, 1, 24 * args.batch, out=(step.x, step.y))
-            for _ in range(4):
-                step(*next(f2))
-            torch.cuda.synchronize(dev)
-            tl = time.perf_counter()
-            for _ in range(20):
-                step(*next(f2))
-            torch.cuda.synchronize(dev)
-            extra["loader_fed_images_per_sec"] = args.batch * 20 / (time.perf_counter() - tl)
-            f2.close()
-        if args.dtype == "bf16" and args.size % 32 == 0:
-            # the roofline kernel again, the way the timed region runs it: back-to-back inside a replayed hipGraph (the
-            # instrumented eager pass above separates launches by host gaps, which costs the kernel 10-20 % in clocks / cold caches)
-            import ctypes as C
-            from transception_amd._lib import TC_BF16, lib
-            Bq, S = args.batch, args.size
-            sides = [S // 4, S // 8, S // 16, S // 32]
-            nq = [sides[i] * sides[i] * m_ for i, m_ in enumerate((1, 2, 5, 8))]
-            Nk = (sides[3] * sides[3]) * (1 + 2 + 5 + 8)
-            rows = Bq * sum(nq)
-            q = torch.randn(rows, 64, device=dev).bfloat16(); kv = torch.randn(Bq * Nk, 128, device=dev).bfloat16()
-            o = torch.empty_like(q); lse = torch.empty(rows, device=dev)
-            nqc = (C.c_int * 4)(*nq)
-            L = lib()
+        if not args.eager:
+            # the same captured step without its collectives: the difference is the all-reduce time the step does not hide
+            k = min(args.steps, 20)
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(k):
+                step(comm=False)
+            sync()
+            t = torch.tensor([(time.perf_counter() - t1) / k], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            exposed = 1e3 * (elapsed / args.steps - float(t.item()))
+            dist.broadcast(model.flat_parameters(), src=0)       # the ranks' un-reduced updates diverged: not used afterwards
 
-            def attn():
-                L.tc_attn_fwd_seg(q.data_ptr(), 64, kv.data_ptr(), 128, kv[:, 64:].data_ptr(), 128, Nk * 128, o.data_ptr(), 64, lse.data_ptr(),
-                                  Bq, 4, nqc, Nk, 0.125, TC_BF16, torch.cuda.current_stream(dev).cuda_stream)
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                attn()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize(dev)
-            ga = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga):
-                for _ in range(30):
-                    attn()
-            ga.replay()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); ga.replay(); e1.record()
-            torch.cuda.synchronize(dev)
-            us = e0.elapsed_time(e1) * 1e3 / 30
-            fl = 4.0 * rows * Nk * 64
-            extra_roof = {"bound": "mfma", "achieved": fl / us / 1e6, "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
-                          "frac": fl / us / 1e6 / PEAK_TFLOPS["bf16"], "avg_launch_us": us,
-                          "how": "30 back-to-back launches of attn_fwd_seg_kernel in one replayed hipGraph, step-shaped random operands"}
-        else:
-            extra_roof = None
+    extra, roofs = {}, {}
+    if rank == 0 and world == 1 and not args.no_side:
+        extra, roofs = side_figures(args, dev, model, loss_fn, opt, step, x, y, build_model, engine, train_step, GraphedStep, FusedSGD, SegLoss)
 
     if rank == 0:
         out = {
@@ -289,45 +274,144 @@ def main():
             "config": {"workload": f"TransCeption (MSTransception) {args.size}x{args.size} B={args.batch}/GPU fwd+bwd+SGD, "
                                    "synthetic Synapse slices, name-seeded random-init weights",
                        "global_batch": world * args.batch, "image_size": args.size, "parallelism": f"dp{world}",
-                       "launch_mode": "eager" if args.eager else "hipGraph replay", "final_loss": float(loss.item()), **extra},
+                       "launch_mode": "eager" if args.eager else "hipGraph replay", "final_loss": float(loss.item()),
+                       "median_ms_per_step": statistics.median(per_step), "min_ms_per_step": min(per_step), **extra},
         }
-        if prof and prof.get("attn_fwd"):
-            ev = prof["attn_fwd"]
-            ms = sum(a.elapsed_time(b) for a, b, _ in ev)
-            fl = sum(f for _, _, f in ev)
-            peak = PEAK_TFLOPS[args.dtype]
-            ach = fl / (ms * 1e-3) / 1e12
-            traffic = None                                   # HBM bytes per launch from the committed PMC passes (bf16 kernel only)
-            pmc = os.path.join(ROOT, "profiles", "r1_attn_pmc.json")
-            if args.dtype == "bf16" and args.batch == 16 and args.size == 224 and os.path.exists(pmc):
-                traffic = json.load(open(pmc)).get("attn_fwd_seg_kernel", {}).get("hbm_bytes_corrected")
-            out["roofline"] = {"bound": "mfma", "kernel": "attn_fwd_seg_kernel (bridge SR-attention forward, QK^T + softmax + PV fused, "
-                                                          "all 4 scales x B images in one launch)",
-                               "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
-                               "launches": len(ev), "avg_launch_us": 1e3 * ms / len(ev),
-                               "algorithmic_flops_per_launch": fl / len(ev)}
-            if prof.get("attn_bwd"):
-                evb = prof["attn_bwd"]
-                msb = sum(a.elapsed_time(b) for a, b, _ in evb)
-                flb = sum(f for _, _, f in evb)
-                if world == 1 and extra_roof is not None:
-                    # The timed region replays a hipGraph, where per-launch HIP events cannot be placed: the headline figure is the kernel
-                    # timed with HIP events around 30 back-to-back launches inside a replayed graph (this is what agrees with the
-                    # rocprofv3 average of the same command, profiles/); the per-launch events of the instrumented eager pass, which
-                    # separate the launches by host gaps, are kept beside it.
-                    eager = out["roofline"]
-                    out["roofline"] = dict(eager, achieved=extra_roof["achieved"], frac=extra_roof["frac"], avg_launch_us=extra_roof["avg_launch_us"],
-                                           launches=30, how=extra_roof["how"])
-                    out["roofline_eager_events"] = {k: eager[k] for k in ("achieved", "frac", "launches", "avg_launch_us")}
-                    out["roofline_graph_replay"] = extra_roof
-                out["roofline_attn_bwd"] = {"bound": "mfma", "achieved": flb / (msb * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
-                                            "frac": flb / (msb * 1e-3) / 1e12 / peak, "launches": len(evb),
-                                            "avg_launch_us": 1e3 * msb / len(evb)}
+        if world > 1:
+            out["rccl_ranks"] = dist.get_world_size()
+            out["config"]["collective_backend"] = backend + (" (all ranks on one GPU: drill, not a measurement)" if one_gpu_drill else "")
+            out["config"]["allreduce_exposed_ms"] = exposed
+        out.update(roofs)
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.batch, args.size)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def _graph_replay_us(fn, n: int, dev) -> float:
+    """Average duration of fn's launches when n of them run back-to-back inside one replayed hipGraph (HIP events on the stream
+    the graph is launched on)."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize(dev)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(n):
+            fn()
+    g.replay()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); g.replay(); e1.record()
+    torch.cuda.synchronize(dev)
+    return e0.elapsed_time(e1) * 1e3 / n
+
+
+def side_figures(args, dev, model, loss_fn, opt, step, x, y, build_model, engine, train_step, GraphedStep, FusedSGD, SegLoss):
+    """Rank 0, one GPU, after the timed region: figures SURVEY.md 8(d) asks for beside the headline."""
+    extra, roofs = {}, {}
+    from transception_amd._lib import _Lib
+    # (1) instrumented steps of the same workload: HIP events around the launches of the named kernels (engine.PROFILE)
+    engine.PROFILE = {}
+    for _ in range(3):
+        train_step(model, loss_fn, opt, x, y, None)
+    torch.cuda.synchronize(dev)
+    prof, engine.PROFILE = engine.PROFILE, None
+    c0 = _Lib.calls
+    train_step(model, loss_fn, opt, x, y, None)
+    extra["c_abi_calls_per_step"] = _Lib.calls - c0
+    torch.cuda.synchronize(dev)
+    peak = PEAK_TFLOPS[args.dtype]
+
+    def mfma_block(ev, kernel):
+        ms = sum(a.elapsed_time(b) for a, b, _ in ev)
+        fl = sum(f for _, _, f in ev)
+        ach = fl / (ms * 1e-3) / 1e12
+        return {"bound": "mfma", "kernel": kernel, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                "launches": len(ev), "avg_launch_us": 1e3 * ms / len(ev), "algorithmic_flops_per_launch": fl / len(ev),
+                "how": "HIP events around each launch inside 3 instrumented training steps of the benchmarked workload (in-step)"}
+    if prof.get("attn_fwd"):
+        r = mfma_block(prof["attn_fwd"], "attn_fwd_seg_kernel (bridge SR-attention forward, QK^T + softmax + PV fused, all 4 scales x B "
+                                         "images in one launch)")
+        r["traffic"], r["traffic_source"] = None, None
+        for name in ("r2_attn_pmc.json", "r1_attn_pmc.json"):   # HBM bytes per launch: a separate rocprofv3 --pmc pass, committed
+            pmc = os.path.join(ROOT, "profiles", name)
+            if args.dtype == "bf16" and args.batch == 16 and args.size == 224 and os.path.exists(pmc):
+                r["traffic"] = json.load(open(pmc)).get("attn_fwd_seg_kernel", {}).get("hbm_bytes_corrected")
+                r["traffic_source"] = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE pass of this workload, not measured in this run)"
+                break
+        roofs["roofline"] = r
+    if prof.get("attn_bwd"):
+        roofs["roofline_attn_bwd"] = mfma_block(prof["attn_bwd"], "attn_bwd (delta + dQ + dK/dV kernels of the bridge SR-attention)")
+    hbm = []
+    for name, ev in prof.items():
+        if name.startswith("hbm:") and ev:
+            ms = sum(a.elapsed_time(b) for a, b, _ in ev)
+            by = sum(f for _, _, f in ev)
+            gbs = by / (ms * 1e-3) / 1e9
+            hbm.append({"bound": "hbm", "kernel": name[4:], "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                        "launches": len(ev), "avg_launch_us": 1e3 * ms / len(ev), "algorithmic_bytes_per_launch": by / len(ev)})
+    if hbm:
+        hbm.sort(key=lambda r: -r["avg_launch_us"] * r["launches"])
+        roofs["roofline_hbm"] = dict(hbm[0], how="HIP events around each launch inside 3 instrumented steps; algorithmic bytes = every "
+                                                "operand read once + every result written once", traffic=None)
+        roofs["roofline_hbm_others"] = hbm[1:6]
+    # (2) forward-only rate (train-mode forward captured alone)
+    with torch.no_grad():
+        us = _graph_replay_us(lambda: model(x), 10, dev)
+        extra["fwd_only_images_per_sec"] = args.batch / (us * 1e-6)
+    # (3) the fp32 parity path on the same workload (the path whose results are pinned to the reference at 1e-4)
+    if args.dtype != "f32" and not args.eager:
+        m32 = build_model("f32")
+        o32 = FusedSGD(m32, lr=0.05, momentum=0.9, weight_decay=1e-4)
+        s32 = GraphedStep(m32, SegLoss(9), o32, x, y, None, warmup=2)
+        for _ in range(3):
+            s32()
+        torch.cuda.synchronize(dev)
+        t = time.perf_counter()
+        for _ in range(10):
+            s32()
+        torch.cuda.synchronize(dev)
+        extra["fp32_images_per_sec"] = args.batch * 10 / (time.perf_counter() - t)
+        del s32, m32, o32
+    # (4) the same graphed step fed by the device input pipeline (npz -> HBM -> augment/resize), SURVEY 8(f)-1
+    if not args.eager and not args.loader and args.size == 224:
+        f2 = _loader_feed(args, dev, 0, 1, 24 * args.batch, out=(step.x, step.y))
+        for _ in range(4):
+            step(*next(f2))
+        torch.cuda.synchronize(dev)
+        tl = time.perf_counter()
+        for _ in range(20):
+            step(*next(f2))
+        torch.cuda.synchronize(dev)
+        extra["loader_fed_images_per_sec"] = args.batch * 20 / (time.perf_counter() - tl)
+        f2.close()
+    # (5) the roofline kernel back-to-back inside a replayed hipGraph on step-shaped operands (the micro-benchmark: warm caches and
+    #     clocks; the rocprofv3 average of this command mixes it with the in-step launches)
+    if args.dtype == "bf16" and args.size % 32 == 0:
+        import ctypes as C
+        from transception_amd._lib import TC_BF16, lib
+        Bq, S = args.batch, args.size
+        sides = [S // 4, S // 8, S // 16, S // 32]
+        nq = [sides[i] * sides[i] * m_ for i, m_ in enumerate((1, 2, 5, 8))]
+        Nk = (sides[3] * sides[3]) * (1 + 2 + 5 + 8)
+        rows = Bq * sum(nq)
+        q = torch.randn(rows, 64, device=dev).bfloat16(); kv = torch.randn(Bq * Nk, 128, device=dev).bfloat16()
+        o = torch.empty_like(q); lse = torch.empty(rows, device=dev)
+        nqc = (C.c_int * 4)(*nq)
+        L = lib()
+
+        def attn():
+            L.tc_attn_fwd_seg(q.data_ptr(), 64, kv.data_ptr(), 128, kv[:, 64:].data_ptr(), 128, Nk * 128, o.data_ptr(), 64, lse.data_ptr(),
+                              Bq, 4, nqc, Nk, 0.125, TC_BF16, torch.cuda.current_stream(dev).cuda_stream)
+        us = _graph_replay_us(attn, 30, dev)
+        fl = 4.0 * rows * Nk * 64
+        roofs["roofline_graph_replay"] = {"bound": "mfma", "achieved": fl / us / 1e6, "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
+                                          "frac": fl / us / 1e6 / PEAK_TFLOPS["bf16"], "avg_launch_us": us,
+                                          "how": "30 back-to-back launches of attn_fwd_seg_kernel in one replayed hipGraph, step-shaped random operands"}
+    return extra, roofs
 
 
 if __name__ == "__main__":

@@ -61,3 +61,32 @@ def test_two_rank_captured_step_follows_eager():
         assert dl < 2e-5, dict(ret)                          # same losses step by step (fp32 compute)
         assert dp < 1e-4, dict(ret)                          # and the same parameters after 5 steps
     assert abs(ret[0][2] - ret[1][2]) < 1e-7                 # both ranks form the loss of the global batch
+
+
+def test_bench_self_spawns_two_ranks_through_the_launcher():
+    """`python bench.py --gpus 2` with no rendezvous environment must start two ranks itself (torch.distributed.run) and say so:
+    n_gpus = rccl_ranks = 2, global batch doubled.  Here both ranks share the one GPU and the collectives go through gloo
+    (TC_TEST_ONE_GPU=1: a drill of the launcher and of the split-graph step, not a measurement)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(TC_TEST_ONE_GPU="1", TC_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "2",
+                        "--no-cpu"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["config"]["global_batch"] == 4
+    assert out["config"]["allreduce_exposed_ms"] is not None and out["value"] > 0
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)

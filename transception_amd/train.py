@@ -297,17 +297,23 @@ class GraphedStep:
         self.model._backward_finish(self._G)                            # the encoder
         self._G = self._out_var = None
 
-    def __call__(self, images: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None):
+    def __call__(self, images: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None, comm: bool = True):
+        """comm=False replays the same graphs without the collectives between them (bench.py: the time the all-reduces add to a
+        step is the difference; the ranks' parameters diverge, so it is a timing aid only)."""
         if images is not None and images.data_ptr() != self.x.data_ptr():     # a loader may write straight into self.x / self.y
             self.x.copy_(images, non_blocking=True)
             self.y.copy_(labels, non_blocking=True)
         self.g_main.replay()
         if self.split:
-            self._reduce_sums()                      # C2: in place on the static 28-float buffer
+            works = []
+            if comm:
+                self._reduce_sums()                  # C2: in place on the static 28-float buffer
             self.g_bwd.replay()
-            works = allreduce_gradients(self.model, self.group, "late", async_op=True)      # C1, bridge + decoder buckets: the
+            if comm:
+                works = allreduce_gradients(self.model, self.group, "late", async_op=True)      # C1, bridge + decoder buckets: the
             self.g_bwd_rest.replay()                                                        # collective stream waits for g_bwd only
-            works += allreduce_gradients(self.model, self.group, "early", async_op=True)    # C1, encoder buckets
+            if comm:
+                works += allreduce_gradients(self.model, self.group, "early", async_op=True)    # C1, encoder buckets
             for w in works:
                 w.wait()                                     # the compute stream waits for the collectives, the host does not
             self.g_opt.replay()
