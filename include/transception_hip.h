@@ -69,7 +69,28 @@ typedef struct TcGemm {
     void* ws;                    /* optional device workspace (16-byte aligned) for the in-kernel split-K fix-up; its first 16 KiB */
     long long ws_bytes;          /* are arrival counters: zero before the first use, left zero by every launch.  One workspace per
                                   * stream (launches that may overlap must not share one).  NULL: requested split-K uses atomics. */
+    /* MixFFN_skip fusion hooks (MSTr.py:889-902, out = fc2(GELU(LayerNorm(d))), d = dw3x3(h) + h): the LayerNorm + GELU between the
+     * depthwise convolution and fc2 never exists as a tensor, it is applied to the operand tiles of the GEMMs that consume it.
+     *   TC_FFN_LN_A (forward fc2; transA = 0, K = LayerNorm width): every row of A goes through GELU(LN(.)) on its way into the
+     *     product.  Row statistics are merged from the chunk partials tc_ffn_dw_fwd left in ffn_part ([rows][ffn_nchunk][2]: sum,
+     *     squared deviations from the chunk mean; ffn_chunk_n channels per chunk) and written to ffn_stat ([rows][2]: mean, rstd).
+     *     ffn_aout (optional, row stride ffn_ldd): the workgroups of the first N tile also store the activated rows GELU(LN(A)) there
+     *     (one extra write of the hidden map, so that the weight-gradient GEMM need not recompute the GELU).
+     *   TC_FFN_LN_B (weight gradient of fc2, dW = dY^T a; transA = 1, transB = 0, N = LayerNorm width): the rows of B (the stored
+     *     d) go through GELU(LN(.)) with the statistics in ffn_stat -- `a` is recomputed, never stored.
+     *   TC_FFN_EP (input gradient of fc2, dY W; transA = transB = 0, N = LayerNorm width, no accumulate / split): the epilogue
+     *     multiplies by GELU'(u), u = xhat gamma + beta from ffn_d (the stored d, row stride ffn_ldd, rows as C) and ffn_stat, stores
+     *     that product gp in C, and leaves per row and 64-column tile (sum gp gamma, sum gp gamma xhat) in ffn_part2
+     *     ([rows][ceil(N/64)][2]) for tc_ffn_mid_bwd.
+     * ffn_gamma / ffn_beta: the LayerNorm parameters (storage dtype).  Level-1 batches (grouped weights): statistics rows of batch b
+     * start at row b * ffn_sRow1, parameters at + b * ffn_sPar1; ffn_d of batch b at + b * ffn_sRow1 * ffn_ldd. */
+    int ffn_mode, ffn_nchunk, ffn_chunk_n, ffn_ldd;
+    float ffn_eps;
+    const float* ffn_part; float* ffn_stat; const void* ffn_gamma; const void* ffn_beta; const void* ffn_d; float* ffn_part2;
+    long long ffn_sRow1, ffn_sPar1;
+    void* ffn_aout;
 } TcGemm;
+enum { TC_FFN_NONE = 0, TC_FFN_LN_A = 1, TC_FFN_LN_B = 2, TC_FFN_EP = 3 };
 int tc_gemm(const TcGemm* g, void* stream);
 /* The two gradient GEMMs of one Linear in ONE launch when both are small-tile bf16 problems (a: dX = dY W, row-major operands,
  * bf16 out; b: dW = dY^T X with fp32 accumulate, transA=1): their workgroups share the grid.  Any other pair: a then b. */
@@ -142,9 +163,34 @@ int tc_dwconv_bwd_weight(const void* dy, int lddy, const void* x, int ldx, float
 typedef struct TcDwSeg {
     const void* x; const void* w; const void* bias; void* y; const void* dy; float* dw; float* db;
     int C; int k; int ldx; int ldy; int lddy; int B; int H; int W;
+    float* stat;                 /* mode 0, k = 3, optional: LayerNorm chunk partials of y as tc_ffn_dw_fwd leaves them */
 } TcDwSeg;
 int tc_dwconv_multi(const TcDwSeg* segs, int nseg, int mode, int add_input, int accumulate, int groups, long long wstride,
                     void* ws, long long ws_bytes, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * MixFFN_skip middle (MSTr.py:889-902 with DWConv :21-31): between fc1 and fc2 the reference runs dw3x3(+bias) + skip, LayerNorm(4C),
+ * GELU as three passes over the hidden map (and their three autograd backward passes + the conv's weight gradient).
+ * Here:  forward  = tc_ffn_dw_fwd (d = dw3x3(h) + bias + h, plus LayerNorm chunk partials) -> fc2 GEMM with TC_FFN_LN_A;
+ *        backward = fc2 input-gradient GEMM with TC_FFN_EP + fc2 weight-gradient GEMM with TC_FFN_LN_B -> tc_ffn_mid_bwd.
+ */
+/* channels per statistics chunk of tc_ffn_dw_fwd for a C-channel map of this dtype (C must be a multiple of it) */
+int tc_ffn_chunk(int C, int dtype);
+/* y = dw3x3(x) + bias + x on `groups` stacked sets of B images (parameters of set g at + g*wstride), and
+ * stat[((g*B + b)*H*W + pixel) * (C / tc_ffn_chunk) + chunk] = float2(sum, squared deviations from the chunk mean) of y's channels. */
+int tc_ffn_dw_fwd(const void* x, int ldx, const void* w, const void* bias, void* y, int ldy, float* stat, int B, int H, int W,
+                  int C, int groups, long long wstride, int dtype, void* stream);
+/* One launch for up to four MixFFN sites (the four scales of a bridge layer):
+ *   dd = LayerNorm backward of gp (x) gamma using stat ([rows][2] mean, rstd) and the row sums in part2 ([rows][nch2][2]),
+ *   dh = dw3x3^T(dd) + dd, and ACCUMULATED into fp32: dw [C,1,3,3], db [C] (conv), dgamma / dbeta [C] (LayerNorm).
+ * gp / d / h / dh: [groups*B*H*W, C] maps with row strides ld*; ws as in tc_dwconv_bwd_weight. */
+typedef struct TcFfnSeg {
+    const void* gp; const void* d; const void* h; void* dh; const float* stat; const float* part2; const void* w; const void* gamma;
+    float* dw; float* db; float* dgamma; float* dbeta;
+    int C, ldg, ldd, ldh, lddh, B, H, W, nch2;
+} TcFfnSeg;
+int tc_ffn_mid_bwd(const TcFfnSeg* segs, int nseg, int groups, long long wstride, void* ws, long long ws_bytes, int dtype,
+                   void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * BatchNorm2d over token rows ([rows, C], statistics over rows) fused with its activation and an

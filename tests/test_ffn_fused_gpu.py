@@ -1,0 +1,166 @@
+"""The fused MixFFN_skip path (engine.Graph.mixffn: LayerNorm + GELU inside the fc2 GEMMs' operand loaders / epilogue, LayerNorm
+backward + depthwise gradients in tc_ffn_mid_bwd) against (a) a plain PyTorch fp32 reference of the same arithmetic
+(MSTr.py:889-902 with DWConv :21-31) and (b) the unfused engine composition it replaces -- forward, input gradient and all eight
+parameter gradients; single sites, stacked weight groups, and the four-site form a bridge layer uses."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _params(C, groups, gen):
+    """One flat fp32 arena holding `groups` parameter sets at a constant stride (what the three MB encoders look like)."""
+    C4 = 4 * C
+    shapes = [("W1", (C4, C)), ("b1", (C4,)), ("wd", (C4, 1, 3, 3)), ("bd", (C4,)), ("lg", (C4,)), ("lb", (C4,)), ("W2", (C, C4)), ("b2", (C,))]
+    offs, tot = {}, 0
+    for k, shp in shapes:
+        offs[k] = tot
+        tot += (int(torch.tensor(shp).prod()) + 7) // 8 * 8
+    flat = torch.zeros(groups * tot)
+    for g in range(groups):
+        for k, shp in shapes:
+            n = int(torch.tensor(shp).prod())
+            fan = shp[1] if k in ("W1", "W2") else (9 if k == "wd" else 1)
+            v = torch.randn(n, generator=gen) * (fan ** -0.5 if k in ("W1", "W2", "wd") else 0.1)
+            if k == "lg":
+                v = 1.0 + 0.2 * torch.randn(n, generator=gen)
+            flat[g * tot + offs[k]: g * tot + offs[k] + n] = v
+    return flat, offs, dict(shapes), tot
+
+
+def _ref(x, flat, offs, shapes, tot, groups, B, H, W, res):
+    """PyTorch fp32 reference per group; x [groups*B*H*W, C] token-major."""
+    C = x.shape[1]
+    outs = []
+    M = B * H * W
+    for g in range(groups):
+        P = {k: flat[g * tot + offs[k]: g * tot + offs[k] + int(torch.tensor(shapes[k]).prod())].view(shapes[k]) for k in offs}
+        xg = x[g * M:(g + 1) * M]
+        h = F.linear(xg, P["W1"], P["b1"])
+        hm = h.view(B, H, W, -1).permute(0, 3, 1, 2)
+        d = (F.conv2d(hm, P["wd"], P["bd"], padding=1, groups=hm.shape[1]) + hm).permute(0, 2, 3, 1).reshape(M, -1)
+        a = F.gelu(F.layer_norm(d, (d.shape[1],), P["lg"], P["lb"], 1e-5))
+        outs.append(F.linear(a, P["W2"], P["b2"]) + res[g * M:(g + 1) * M])
+    return torch.cat(outs, 0)
+
+
+def _engine_run(dtype, fused, x, flat, offs, shapes, tot, groups, B, H, W, res, gout):
+    import transception_amd.model as MM
+    from transception_amd.engine import Graph, P, Var
+    dev = torch.device(DEV)
+    pf = flat.to(dev)
+    pl = pf.to(dtype)
+    gf = torch.zeros_like(pf)
+    G = Graph(dtype, dev, training=True, record=True)
+
+    def mk(k):
+        n = int(torch.tensor(shapes[k]).prod())
+        shp = shapes[k] if k != "wd" else shapes[k]
+        return P(pl[offs[k]:offs[k] + n].view(shp), gf[offs[k]:offs[k] + n].view(shp), tot if groups > 1 else 0)
+    xv, rv = Var(x.to(dev).to(dtype).contiguous()), Var(res.to(dev).to(dtype).contiguous())
+    W1, b1, wd, bd, lg, lb, W2, b2 = (mk(k) for k in ("W1", "b1", "wd", "bd", "lg", "lb", "W2", "b2"))
+    ctx = G.grouped(groups, tot) if groups > 1 else None
+    if ctx:
+        ctx.__enter__()
+    if fused:
+        out = G.mixffn([dict(x=xv, fc1=(W1, b1), dw=(wd, bd), ln=(lg, lb), fc2=(W2, b2), geo=(B, H, W), residual=rv)])[0]
+    else:
+        h = G.linear(xv, W1, b1)
+        d = G.dwconv(h, wd, bd, B, H, W, 3, 1, True)
+        a = G.layernorm(d, lg, lb, 1e-5, MM.ACT_GELU)
+        out = G.linear(a, W2, b2, residual=rv)
+    r = out.root
+    r.grad_t = gout.to(dev).to(dtype).contiguous()
+    r.whole_written = True
+    G.backward()
+    if ctx:
+        ctx.__exit__(None, None, None)
+    torch.cuda.synchronize()
+    return out.data.float().cpu(), G.grad_of(xv).float().cpu(), G.grad_of(rv).float().cpu(), gf.cpu()
+
+
+CASES = [  # C, B, H, W, groups
+    (64, 2, 28, 28, 1),       # stage-2 width, tiles with overhang (28 = 16 + 12)
+    (128, 3, 14, 14, 1),      # stage-3 width
+    (512, 2, 7, 7, 1),        # bridge scale 4: 2048 hidden channels = 32 statistics chunks
+    (320, 2, 7, 7, 1),        # 1280 hidden channels
+    (64, 2, 20, 24, 3),       # three stacked weight groups, non-square map
+    (64, 1, 56, 56, 1),       # stage-1 map: many tiles per workgroup walker
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CASES)
+def test_fused_mixffn_matches_torch_and_unfused(case, dtype):
+    C, B, H, W, groups = case
+    gen = torch.Generator().manual_seed(100 + C + H)
+    flat, offs, shapes, tot = _params(C, groups, gen)
+    rows = groups * B * H * W
+    x = torch.randn(rows, C, generator=gen)
+    res = torch.randn(rows, C, generator=gen)
+    gout = torch.randn(rows, C, generator=gen)
+    # PyTorch reference (fp32, CPU) with autograd
+    xr, fr, rr = x.clone().requires_grad_(True), flat.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    yr = _ref(xr, fr, offs, shapes, tot, groups, B, H, W, rr)
+    yr.backward(gout)
+    y, gx, gr, gp = _engine_run(dtype, True, x, flat, offs, shapes, tot, groups, B, H, W, res, gout)
+    tol = 3e-5 if dtype == torch.float32 else 3e-2
+
+    def close(a, b, what):
+        scale = float(b.abs().max()) + 1e-6
+        err = float((a - b).abs().max()) / scale
+        assert err < tol, f"{what}: rel-to-max error {err:.3e} (case {case}, {dtype})"
+    close(y, yr.detach(), "out")
+    close(gx, xr.grad, "dx")
+    close(gr, rr.grad, "dresidual")
+    for g in range(groups):
+        for k in offs:
+            n = int(torch.tensor(shapes[k]).prod())
+            sl = slice(g * tot + offs[k], g * tot + offs[k] + n)
+            close(gp[sl], fr.grad[sl], f"d{k}[group {g}]")
+    # and the unfused engine composition (same storage type): the two must agree at least as closely
+    yu, gxu, gru, gpu = _engine_run(dtype, False, x, flat, offs, shapes, tot, groups, B, H, W, res, gout)
+    close(y, yu, "out vs unfused")
+    close(gx, gxu, "dx vs unfused")
+    close(gp, gpu, "parameter gradients vs unfused")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_mixffn_four_sites_one_launch_set(dtype):
+    """The bridge form: four independent sites of different widths / map sizes in one fused call (3 + 3 launches)."""
+    from transception_amd.engine import Graph, P, Var
+    dev = torch.device(DEV)
+    gen = torch.Generator().manual_seed(7)
+    B = 2
+    geo = [(64, 56), (128, 28), (320, 14), (512, 7)]
+    G = Graph(dtype, dev, training=True, record=True)
+    sites, refs, keep = [], [], []
+    for C, S in geo:
+        flat, offs, shapes, tot = _params(C, 1, gen)
+        rows = B * S * S
+        x, res, gout = (torch.randn(rows, C, generator=gen) for _ in range(3))
+        pf = flat.to(dev); pl = pf.to(dtype); gf = torch.zeros_like(pf)
+        mk = lambda k: P(pl[offs[k]:offs[k] + int(torch.tensor(shapes[k]).prod())].view(shapes[k]),
+                         gf[offs[k]:offs[k] + int(torch.tensor(shapes[k]).prod())].view(shapes[k]), 0)
+        xv, rv = Var(x.to(dev).to(dtype)), Var(res.to(dev).to(dtype))
+        sites.append(dict(x=xv, fc1=(mk("W1"), mk("b1")), dw=(mk("wd"), mk("bd")), ln=(mk("lg"), mk("lb")), fc2=(mk("W2"), mk("b2")),
+                          geo=(B, S, S), residual=rv))
+        xr, fr = x.clone().requires_grad_(True), flat.clone().requires_grad_(True)
+        yr = _ref(xr, fr, offs, shapes, tot, 1, B, S, S, res)
+        yr.backward(gout)
+        refs.append((yr.detach(), xr.grad, fr.grad))
+        keep.append((xv, gf, gout))
+    n0 = G.n_launch
+    outs = G.mixffn(sites)
+    assert G.n_launch - n0 == 2                                   # fc1 x4 and fc2 x4: one merged grid each (+ one conv launch)
+    for o, (_, _, gout) in zip(outs, keep):
+        o.root.grad_t = gout.to(dev).to(dtype).contiguous()
+        o.root.whole_written = True
+    G.backward()
+    torch.cuda.synchronize()
+    tol = 3e-5 if dtype == torch.float32 else 3e-2
+    for o, (xv, gf, _), (yr, gxr, gpr) in zip(outs, keep, refs):
+        for a, b in ((o.data.float().cpu(), yr), (G.grad_of(xv).float().cpu(), gxr), (gf.cpu(), gpr)):
+            assert float((a - b).abs().max()) / (float(b.abs().max()) + 1e-6) < tol

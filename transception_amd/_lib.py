@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("TC_LIB_PATH") or os.path.join(HERE, "libtransception_
 
 TC_F32, TC_BF16 = 0, 1
 ACT_NONE, ACT_HSWISH, ACT_COORD, ACT_SIGMOID, ACT_GELU = 0, 1, 2, 3, 4
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_longlong, C.c_float
 
@@ -26,12 +26,25 @@ class TcGemm(C.Structure):
                 ("sA1", i64), ("sA2", i64), ("sB1", i64), ("sB2", i64),
                 ("sC1", i64), ("sC2", i64), ("sR1", i64), ("sR2", i64),
                 ("alpha", f32), ("accumulate", i32), ("act", i32), ("splitk", i32), ("dtype", i32), ("c_f32", i32), ("atomic", i32), ("rowsum", vp), ("sBias1", i64), ("sRow1", i64),
-                ("bgap_every", i32), ("bgap", i64), ("ws", vp), ("ws_bytes", i64)]
+                ("bgap_every", i32), ("bgap", i64), ("ws", vp), ("ws_bytes", i64),
+                # MixFFN fusion hooks (include/transception_hip.h): LayerNorm + GELU applied to operand tiles / the epilogue
+                ("ffn_mode", i32), ("ffn_nchunk", i32), ("ffn_chunk_n", i32), ("ffn_ldd", i32), ("ffn_eps", f32),
+                ("ffn_part", vp), ("ffn_stat", vp), ("ffn_gamma", vp), ("ffn_beta", vp), ("ffn_d", vp), ("ffn_part2", vp),
+                ("ffn_sRow1", i64), ("ffn_sPar1", i64), ("ffn_aout", vp)]
+
+
+FFN_NONE, FFN_LN_A, FFN_LN_B, FFN_EP = 0, 1, 2, 3
 
 
 class TcDwSeg(C.Structure):
     _fields_ = [("x", vp), ("w", vp), ("bias", vp), ("y", vp), ("dy", vp), ("dw", vp), ("db", vp), ("C", i32), ("k", i32),
-                ("ldx", i32), ("ldy", i32), ("lddy", i32), ("B", i32), ("H", i32), ("W", i32)]
+                ("ldx", i32), ("ldy", i32), ("lddy", i32), ("B", i32), ("H", i32), ("W", i32), ("stat", vp)]
+
+
+class TcFfnSeg(C.Structure):
+    _fields_ = [("gp", vp), ("d", vp), ("h", vp), ("dh", vp), ("stat", vp), ("part2", vp), ("w", vp), ("gamma", vp),
+                ("dw", vp), ("db", vp), ("dgamma", vp), ("dbeta", vp),
+                ("C", i32), ("ldg", i32), ("ldd", i32), ("ldh", i32), ("lddh", i32), ("B", i32), ("H", i32), ("W", i32), ("nch2", i32)]
 
 
 class TcSliceAug(C.Structure):
@@ -56,6 +69,9 @@ SIGNATURES = {
     "tc_dwconv_bwd_input": [vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i64, i32, vp],
     "tc_dwconv_bwd_weight": [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i64, vp, i64, i32, vp],
     "tc_dwconv_multi": [C.POINTER(TcDwSeg), i32, i32, i32, i32, i32, i64, vp, i64, i32, vp],
+    "tc_ffn_chunk": [i32, i32],
+    "tc_ffn_dw_fwd": [vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i64, i32, vp],
+    "tc_ffn_mid_bwd": [C.POINTER(TcFfnSeg), i32, i32, i64, vp, i64, i32, vp],
     "tc_bn_scratch_floats": [i32, i32],
     "tc_bn_fwd": [vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, f32, f32, i32, i32, i32, vp],
     "tc_bn_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp],
@@ -96,7 +112,7 @@ SIGNATURES = {
     "tc_cast": [vp, vp, i64, i32, i32, vp],
 }
 _RET = {"tc_bn_scratch_floats": i64, "tc_softmax_scratch_floats": i64, "tc_layernorm_bwd_scratch_floats": i64, "tc_factor_att_stats_floats": i64}
-_RAW = {"tc_abi_version", "tc_bn_scratch_floats", "tc_softmax_scratch_floats", "tc_layernorm_bwd_scratch_floats", "tc_factor_att_stats_floats"}     # not status-returning
+_RAW = {"tc_abi_version", "tc_ffn_chunk", "tc_bn_scratch_floats", "tc_softmax_scratch_floats", "tc_layernorm_bwd_scratch_floats", "tc_factor_att_stats_floats"}     # not status-returning
 
 
 class TcError(RuntimeError):

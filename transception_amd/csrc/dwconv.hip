@@ -3,6 +3,7 @@
 // filter slice of the block's 64 channels is staged once in LDS in [tap][channel] order (the PyTorch [C,1,k,k]
 // layout is transposed on the way in), and the k*k window re-reads are served by L1/L2.
 #include "tc_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -123,7 +124,7 @@ template <typename T, int CPT> __device__ __forceinline__ void stv(T* p, const f
 template <> __device__ __forceinline__ void stv<float, 4>(float* p, const float* o) { *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]); }
 template <> __device__ __forceinline__ void stv<float, 2>(float* p, const float* o) { *reinterpret_cast<float2*>(p) = make_float2(o[0], o[1]); }
 template <> __device__ __forceinline__ void stv<bf16_t, 4>(bf16_t* p, const float* o) { st4<bf16_t>(p, make_float4(o[0], o[1], o[2], o[3])); }
-template <> __device__ __forceinline__ void stv<bf16_t, 2>(bf16_t* p, const float* o) { *reinterpret_cast<unsigned*>(p) = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16); }
+template <> __device__ __forceinline__ void stv<bf16_t, 2>(bf16_t* p, const float* o) { *reinterpret_cast<unsigned*>(p) = pack2bf(o[0], o[1]); }
 
 template <typename T, int K, int CPT, int MODE>
 __global__ __launch_bounds__(256) void dw_strip_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ w, const T* __restrict__ bias,
@@ -314,8 +315,26 @@ template <> __device__ __forceinline__ uint4 pack16<float>(const float* o) {
     return make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3]));
 }
 template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* o) {
-    return make_uint4((unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16), (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16),
-                      (unsigned)f2bf(o[4]) | ((unsigned)f2bf(o[5]) << 16), (unsigned)f2bf(o[6]) | ((unsigned)f2bf(o[7]) << 16));
+    return make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
+}
+
+// the same vectors as pairs for the packed fp32 pipe (v_pk_fma_f32: two multiply-adds per issue slot)
+template <typename T> __device__ __forceinline__ void unpack16v(const uint4& r, tc_f32x2* o);
+template <> __device__ __forceinline__ void unpack16v<float>(const uint4& r, tc_f32x2* o) {
+    o[0] = tc_f32x2{__uint_as_float(r.x), __uint_as_float(r.y)}; o[1] = tc_f32x2{__uint_as_float(r.z), __uint_as_float(r.w)};
+}
+template <> __device__ __forceinline__ void unpack16v<bf16_t>(const uint4& r, tc_f32x2* o) {
+    o[0] = tc_f32x2{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u)};
+    o[1] = tc_f32x2{__uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
+    o[2] = tc_f32x2{__uint_as_float(r.z << 16), __uint_as_float(r.z & 0xffff0000u)};
+    o[3] = tc_f32x2{__uint_as_float(r.w << 16), __uint_as_float(r.w & 0xffff0000u)};
+}
+template <typename T> __device__ __forceinline__ uint4 pack16v(const tc_f32x2* o);
+template <> __device__ __forceinline__ uint4 pack16v<float>(const tc_f32x2* o) {
+    return make_uint4(__float_as_uint(o[0].x), __float_as_uint(o[0].y), __float_as_uint(o[1].x), __float_as_uint(o[1].y));
+}
+template <> __device__ __forceinline__ uint4 pack16v<bf16_t>(const tc_f32x2* o) {
+    return make_uint4(pack2bf(o[0].x, o[0].y), pack2bf(o[1].x, o[1].y), pack2bf(o[2].x, o[2].y), pack2bf(o[3].x, o[3].y));
 }
 
 template <int K, int CG> struct DwTile {
@@ -375,11 +394,16 @@ template <typename T, int K, int CG> constexpr int dw_wgrad_smem_q() {
 }
 
 // body of one workgroup (bx = tile, by = channel chunk, bz = weight group); `smem` holds dw_tile_smem_q() uint4
+// stat (MODE 0 only, C a multiple of the chunk width CG * VEC): the kernel also leaves, per output pixel and channel chunk,
+// (sum, sum of squared deviations from the chunk mean) of the values it writes -- float2 stat[(pixel row) * chunks + chunk], pixel
+// rows counted through all images of all weight groups -- so that the LayerNorm that follows (MixFFN_skip, MSTr.py:898-900) never
+// reads the map for its statistics: the consumer merges the chunk partials (Chan's parallel variance formula).
 template <typename T, int K, int CG, int MODE>      // MODE 0: y = conv(x) (+bias) (+x);  MODE 1: dx = conv^T(dy) (+dy) (+dx)
 __device__ __forceinline__ void dw_tile_body(const T* __restrict__ src, int lds_, const T* __restrict__ w,
                                              const T* __restrict__ bias, T* __restrict__ y, int ldy, int B, int H, int W,
                                              int C, int add_input, int accumulate, long long wstride, int tilesW,
-                                             int tilesH, const int bx, const int by, const int bz, uint4* smem) {
+                                             int tilesH, const int bx, const int by, const int bz, uint4* smem,
+                                             float* __restrict__ stat = nullptr, int nchunks = 0) {
     using D = DwTile<K, CG>;
     constexpr int VEC = Vec16<T>::N, CH = CG * VEC, R = D::R, P = D::P;
     constexpr int PIXQ = CG + (CG == 8 ? 2 : 1);
@@ -412,11 +436,12 @@ __device__ __forceinline__ void dw_tile_body(const T* __restrict__ src, int lds_
     __syncthreads();
     const int cg = threadIdx.x % CG, pt = threadIdx.x / CG, run = pt % (D::TW / R), row = pt / (D::TW / R);
     const int oh = oh0 + row, owb = ow0 + run * R, c = c0 + cg * VEC;
-    if (c >= C || oh >= H || owb >= W) return;
+    const bool live = !(c >= C || oh >= H || owb >= W);
+    if (!live && !(MODE == 0 && stat)) return;               // (with statistics every lane stays for the lane-group reductions)
     float acc[R][VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-        const float bv = (MODE == 0 && bias) ? ldf<T>(bias + c + e) : 0.f;
+        const float bv = (MODE == 0 && bias && live) ? ldf<T>(bias + c + e) : 0.f;
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r][e] = bv;
     }
@@ -447,6 +472,33 @@ __device__ __forceinline__ void dw_tile_body(const T* __restrict__ src, int lds_
                 for (int e = 0; e < VEC; ++e) acc[r][e] += in[r + P][e];
         }
     }
+    if (MODE == 0 && stat) {
+        // per pixel: sum over this chunk's CH channels (CG consecutive lanes), then the squared deviations from the chunk mean
+        float sm[R], m2[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float t = 0.f;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) t += acc[r][e];
+#pragma unroll
+            for (int o = 1; o < CG; o <<= 1) t += __shfl_xor(t, o, 64);
+            sm[r] = t;
+            const float mu = t * (1.0f / (float)CH);
+            float q = 0.f;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { const float dlt = acc[r][e] - mu; q += dlt * dlt; }
+#pragma unroll
+            for (int o = 1; o < CG; o <<= 1) q += __shfl_xor(q, o, 64);
+            m2[r] = q;
+        }
+        if (!live) return;
+        if (cg == 0) {
+            const long long prow = (((long long)bz * B + b) * H + oh) * W + owb;
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (owb + r < W) *reinterpret_cast<float2*>(stat + ((prow + r) * nchunks + by) * 2) = make_float2(sm[r], m2[r]);
+        }
+    }
     T* dst0 = y + (((long long)b * H + oh) * W + owb) * ldy + c;
     if (accumulate) {                                         // all R reads in flight at once (columns past W re-read column owb)
         uint4 old[R];
@@ -469,10 +521,10 @@ template <typename T, int K, int CG, int MODE>
 __global__ __launch_bounds__(256) void dw_tile_kernel(const T* __restrict__ src, int lds_, const T* __restrict__ w,
                                                       const T* __restrict__ bias, T* __restrict__ y, int ldy, int B, int H, int W,
                                                       int C, int add_input, int accumulate, long long wstride, int tilesW,
-                                                      int tilesH) {
+                                                      int tilesH, float* __restrict__ stat) {
     __shared__ uint4 smem[dw_tile_smem_q<T, K, CG>()];
     dw_tile_body<T, K, CG, MODE>(src, lds_, w, bias, y, ldy, B, H, W, C, add_input, accumulate, wstride, tilesW, tilesH, blockIdx.x,
-                                 blockIdx.y, blockIdx.z, smem);
+                                 blockIdx.y, blockIdx.z, smem, stat, (int)gridDim.y);
 }
 
 // dw[c,ky,kx] += sum_pix dy[pix] * x[pix + (ky-P, kx-P)] ; db[c] += sum_pix dy[pix].  x tile (+halo) and dy tile in LDS; a thread
@@ -650,9 +702,10 @@ template <typename T> bool dw_tile_ok(const void* a, int lda, const void* b, int
 template <typename T, int MODE>
 int launch_tile(const void* src, int lds_, const void* w, const void* bias, void* y, int ldy, const void* dy, int lddy, float* dw,
                 float* db, int B, int H, int W, int C, int k, int add_input, int accumulate, int groups, long long wstride,
-                hipStream_t s, void* ws = nullptr, long long ws_bytes = 0) {
+                hipStream_t s, void* ws = nullptr, long long ws_bytes = 0, float* stat = nullptr) {
     constexpr int VEC = Vec16<T>::N;
     const int cg = dw_pick_cg<T>(C);
+    if (stat && (MODE != 0 || C % (cg * VEC))) return TC_ERR_ARG;
     const int chunks = (C + cg * VEC - 1) / (cg * VEC);
     const int TH = (256 / cg) / 4, tilesW = (W + 15) / 16, tilesH = (H + TH - 1) / TH;
     const long long ntiles = (long long)B * tilesW * tilesH;
@@ -674,7 +727,7 @@ int launch_tile(const void* src, int lds_, const void* w, const void* bias, void
     } else {                                                                                                                            \
         dim3 grid((unsigned)ntiles, chunks, groups);                                                                                    \
         hipLaunchKernelGGL((dw_tile_kernel<T, KK, CGG, (MODE == 2 ? 0 : MODE)>), grid, dim3(256), 0, s, (const T*)src, lds_,            \
-                           (const T*)w, (const T*)bias, (T*)y, ldy, B, H, W, C, add_input, accumulate, wstride, tilesW, tilesH);        \
+                           (const T*)w, (const T*)bias, (T*)y, ldy, B, H, W, C, add_input, accumulate, wstride, tilesW, tilesH, stat);  \
     }
 #define TC_TILE_K(KK) { if (cg == 8) { TC_TILE(KK, 8) } else if (cg == 4) { TC_TILE(KK, 4) } else { TC_TILE(KK, 2) } }
     if (k == 3) TC_TILE_K(3) else if (k == 5) TC_TILE_K(5) else TC_TILE_K(7)
@@ -702,7 +755,7 @@ int launch_dw(const void* x, int ldx, const void* w, const void* bias, void* y, 
 // same maps (ConvRelPosEnc: 3x3 / 5x5 / 7x7 on 2 / 3 / 3 heads' channels, MSTr.py:785-816) in ONE grid.  Each is a 10-30 us
 // latency-bound launch on its own; side by side they cost what the slowest costs.
 struct DwSegDev {
-    const void* src; const void* w; const void* bias; void* y; const void* dy; float* dw; float* db; float* wsp; int* wsc;
+    const void* src; const void* w; const void* bias; void* y; const void* dy; float* dw; float* db; float* wsp; int* wsc; float* stat;
     int C, k, cg, chunks, tilesW, tilesH, gx, blk0, lds_, ldy, lddy, B, H, W;
 };
 constexpr int DW_MULTI_MAX = 4;
@@ -723,7 +776,8 @@ __global__ __launch_bounds__(256) void dw_multi_kernel(DwMultiDev a) {
 #define TC_CASE(KK, CGG)                                                                                                            \
     if (g.k == KK && g.cg == CGG) {                                                                                                 \
         dw_tile_body<T, KK, CGG, MODE>((const T*)g.src, g.lds_, (const T*)g.w, (const T*)g.bias, (T*)g.y, g.ldy, g.B, g.H, g.W, g.C, \
-                                       a.add_input, a.accumulate, a.wstride, g.tilesW, g.tilesH, bx, by, blockIdx.y, dsm);          \
+                                       a.add_input, a.accumulate, a.wstride, g.tilesW, g.tilesH, bx, by, blockIdx.y, dsm,           \
+                                       MODE == 0 ? g.stat : nullptr, g.chunks);                                                     \
         return;                                                                                                                     \
     }
     TC_DW_CASES(TC_CASE)
@@ -780,6 +834,8 @@ int launch_multi(const TcDwSeg* segs, int nseg, int mode, int add_input, int acc
         d.lds_ = g.ldx; d.ldy = g.ldy; d.lddy = g.lddy; d.B = g.B; d.H = g.H; d.W = g.W;
         const int B = g.B, H = g.H, W = g.W;
         d.cg = dw_pick_cg<T>(g.C);
+        d.stat = mode == 0 ? g.stat : nullptr;
+        if (d.stat && (g.k != 3 || g.C % (d.cg * VEC))) return TC_ERR_ARG;
         d.chunks = (g.C + d.cg * VEC - 1) / (d.cg * VEC);
         const int TH = (256 / d.cg) / 4;
         d.tilesW = (W + 15) / 16; d.tilesH = (H + TH - 1) / TH;
@@ -818,6 +874,328 @@ int launch_multi(const TcDwSeg* segs, int nseg, int mode, int add_input, int acc
         if (smem > 64 * 1024) hipFuncSetAttribute((const void*)dw_multi_wgrad_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipLaunchKernelGGL((dw_multi_wgrad_kernel<T>), grid, dim3(256), smem, s, a);
     }
+    return tc_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// MixFFN_skip middle, backward (MSTr.py:889-902: out = fc2(GELU(LN(d))), d = dw3x3(h) + h, h = fc1(x)) in ONE kernel:
+//   in : gp = dOut W2 (.) GELU'(u)          (the fc2 input-gradient GEMM's epilogue, u = xhat * gamma + beta)
+//        S1[row] = sum_c gp * gamma, S2[row] = sum_c gp * gamma * xhat   (per-row partials left by that epilogue)
+//   dd = rstd * (gp * gamma - S1 / C - xhat * S2 / C)         LayerNorm backward, finished per pixel of the haloed tile
+//   dh = conv3x3^T(dd) + dd                                    depthwise input gradient + the skip
+//   dw[c, tap] += sum dd * h(shifted), db[c] += sum dd, dgamma[c] += sum gp * xhat, dbeta[c] += sum gp
+// i.e. the LayerNorm backward, the depthwise input gradient and the depthwise weight gradient of the unfused form (three launches,
+// seven passes over hidden-width maps) read gp, d and h once and write dh once.  Work decomposition as dw_tile_wgrad_body: a
+// workgroup owns one channel chunk (CG * VEC channels) and walks its share of the TH x 16 pixel tiles with every parameter sum in
+// registers, LDS atomics fold the workgroup, the 16-way workspace fold and one atomic per word finish.
+struct FfnSegDev {
+    const void* gp; const void* d; const void* h; void* dh; const float* stat; const float* part2; const void* w; const void* gamma;
+    float* dw; float* db; float* dgamma; float* dbeta; float* wsp; int* wsc;
+    int C, ldg, ldd, ldh, lddh, B, H, W, nch2, chunks, tilesW, tilesH, gx, blk0;
+};
+constexpr int FFN_MULTI_MAX = 4;
+struct FfnMultiDev { FfnSegDev s[FFN_MULTI_MAX]; int n; long long wstride; };
+
+template <typename T> struct FfnTile {
+    static constexpr int K = 3, CG = 8, VEC = Vec16<T>::N, CH = CG * VEC, R = 4, TW = 16, TH = 8, P = 1, IW = TW + 2, IH = TH + 2;
+    static constexpr int PIXQ = CG + 1, NT = K * K + 3;            // taps, conv bias, dgamma, dbeta
+    static constexpr int smem_q = 2 * IH * IW * PIXQ + IH * IW + (K * K * CH + CH + NT * CH + 3) / 4;
+};
+
+template <typename T, bool PF>
+__device__ __forceinline__ void ffn_mid_bwd_body(const FfnSegDev& a, long long wstride, const int bx, const int by, const int bz,
+                                                 uint4* smem) {
+    using D = FfnTile<T>;
+    constexpr int K = D::K, CG = D::CG, VEC = D::VEC, CH = D::CH, R = D::R, IW = D::IW, IH = D::IH, PIXQ = D::PIXQ, NT = D::NT;
+    constexpr int NPIX = IH * IW, NX = (NPIX * CG + 255) / 256, RG = (256 / CG) / K, UNITS = D::TH * (D::TW / R);
+    uint4* ddt = smem;                                           // dd on the haloed tile, storage type
+    uint4* ht = ddt + NPIX * PIXQ;                               // h on the haloed tile
+    float4* pst = reinterpret_cast<float4*>(ht + NPIX * PIXQ);   // per haloed pixel: mean, rstd, S1 / C, S2 / C
+    float (*wsm)[CH] = reinterpret_cast<float (*)[CH]>(pst + NPIX);      // flipped taps
+    float* gsm = &wsm[K * K][0];
+    float (*lacc)[CH] = reinterpret_cast<float (*)[CH]>(gsm + CH);
+    const int B = a.B, H = a.H, W = a.W, C = a.C;
+    const long long img = (long long)B * H * W, grow = (long long)bz * img;     // first pixel row of this weight group
+    const T* gp = (const T*)a.gp + grow * a.ldg;
+    const T* dm = (const T*)a.d + grow * a.ldd;
+    const T* hm = (const T*)a.h + grow * a.ldh;
+    T* dh = (T*)a.dh + grow * a.lddh;
+    const float* stat = a.stat + grow * 2;
+    const float* part2 = a.part2 + grow * a.nch2 * 2;
+    const T* w = (const T*)a.w + bz * wstride;
+    const T* gamma = (const T*)a.gamma + bz * wstride;
+    const int c0 = by * CH, tid = threadIdx.x;
+    for (int i = tid; i < K * K * CH; i += 256) {
+        const int cc = i / (K * K), t = i - cc * (K * K);
+        wsm[K * K - 1 - t][cc] = (c0 + cc < C) ? ldf<T>(w + (long long)(c0 + cc) * K * K + t) : 0.f;
+    }
+    for (int i = tid; i < CH; i += 256) gsm[i] = (c0 + i < C) ? ldf<T>(gamma + c0 + i) : 0.f;
+    for (int i = tid; i < NT * CH; i += 256) (&lacc[0][0])[i] = 0.f;
+    const int cg = tid % CG, wk = tid / CG;
+    const int ky3 = wk / RG, rg = wk % RG;                        // weight-gradient role: filter row, unit lane
+    const bool wactive = ky3 < K && c0 + cg * VEC < C;
+    const int run = wk % (D::TW / R), row = wk / (D::TW / R);     // input-gradient role: 4-pixel run of tile row `row`
+    constexpr int V2 = VEC / 2;                                   // channel pairs per 16-byte vector (packed fp32 arithmetic)
+    tc_f32x2 acc[K][V2], accb[V2], accg[V2], accbt[V2];
+#pragma unroll
+    for (int e = 0; e < V2; ++e) {
+        accb[e] = accg[e] = accbt[e] = tc_f32x2{0.f, 0.f};
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) acc[kx][e] = tc_f32x2{0.f, 0.f};
+    }
+    const int ntiles = B * a.tilesH * a.tilesW;
+    const float invC = 1.0f / (float)C;
+    // One workgroup per CU (the register file of a single resident wave per SIMD is the budget): the NEXT tile's vectors of the three
+    // maps and its per-pixel LayerNorm quantities are requested before this tile's arithmetic starts and land in registers under it.
+    uint4 gr[NX], dr[NX], hr[NX];
+    float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto tile_org = [&](int tidx, int& b, int& oh0, int& ow0) __attribute__((always_inline)) {
+        const int tix = tidx % a.tilesW, tiy = (tidx / a.tilesW) % a.tilesH;
+        b = tidx / (a.tilesW * a.tilesH); oh0 = tiy * D::TH; ow0 = tix * D::TW;
+    };
+    auto fetch = [&](int tidx) __attribute__((always_inline)) {
+        int b, oh0, ow0;
+        tile_org(tidx, b, oh0, ow0);
+        const long long ibase = (long long)b * H * W;
+        // the row-sum partials first (their sum waits for them; a short, mostly L2-resident read), then the tile vectors, which stay in
+        // flight under the arithmetic of the current tile
+        const int iy = tid / IW, ix = tid - iy * IW, ih = oh0 - 1 + iy, iw = ow0 - 1 + ix;
+        const bool pin = tid < NPIX && ih >= 0 && ih < H && iw >= 0 && iw < W;
+        const long long prow = pin ? ibase + (long long)ih * W + iw : 0;
+        const float2 st = *reinterpret_cast<const float2*>(stat + prow * 2);
+        const float2* pp = reinterpret_cast<const float2*>(part2) + prow * a.nch2;
+        float s1 = 0.f, s2 = 0.f;
+        for (int k = 0; k < a.nch2; ++k) { const float2 q = pp[k]; s1 += q.x; s2 += q.y; }
+        pv = pin ? make_float4(st.x, st.y, s1 * invC, s2 * invC) : make_float4(0.f, 0.f, 0.f, 0.f);
+        dw_fetch<T, CG, NX>(gr, gp + ibase * a.ldg + c0, a.ldg, oh0 - 1, ow0 - 1, IH, IW, H, W, C - c0);
+        dw_fetch<T, CG, NX>(dr, dm + ibase * a.ldd + c0, a.ldd, oh0 - 1, ow0 - 1, IH, IW, H, W, C - c0);
+        dw_fetch<T, CG, NX>(hr, hm + ibase * a.ldh + c0, a.ldh, oh0 - 1, ow0 - 1, IH, IW, H, W, C - c0);
+    };
+    if (PF && bx < ntiles) fetch(bx);
+    __syncthreads();                                              // taps and gamma are in LDS
+    tc_f32x2 gk[V2];                                              // gamma of this thread's channels (its vectors all share cg)
+#pragma unroll
+    for (int e = 0; e < V2; ++e) gk[e] = tc_f32x2{gsm[cg * VEC + 2 * e], gsm[cg * VEC + 2 * e + 1]};
+    for (int tidx = bx; tidx < ntiles; tidx += a.gx) {
+        int b, oh0, ow0;
+        tile_org(tidx, b, oh0, ow0);
+        const long long ibase = (long long)b * H * W;
+        if (!PF) fetch(tidx);                                     // two workgroups per CU cover each other's memory latency instead
+        __syncthreads();                                          // the previous tile's readers are done with the LDS tiles
+        if (tid < NPIX) pst[tid] = pv;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int v = tid + i * 256;
+            int op, cgi;
+            const bool ok = dw_inside<T, CG>(v, oh0 - 1, ow0 - 1, IH, IW, H, W, C - c0, op, cgi);
+            if (v < NPIX * CG) {
+                const int pix = v / CG, iy = pix / IW, ix = pix - iy * IW;
+                const float4 st = pst[pix];
+                tc_f32x2 g8[V2], d8[V2], o8[V2];
+                unpack16v<T>(gr[i], g8);
+                unpack16v<T>(dr[i], d8);
+                const bool inner = ok && iy >= 1 && iy <= D::TH && ix >= 1 && ix <= D::TW;
+                const float rs = ok ? st.y : 0.f, wi = inner ? 1.0f : 0.f;
+#pragma unroll
+                for (int e = 0; e < V2; ++e) {
+                    const tc_f32x2 xh = (d8[e] - st.x) * st.y;
+                    const tc_f32x2 gg = g8[e] * gk[e];
+                    o8[e] = (gg - st.z - xh * st.w) * rs;
+                    const tc_f32x2 gi = g8[e] * wi;
+                    accg[e] += gi * xh; accbt[e] += gi;
+                }
+                ddt[pix * PIXQ + cgi] = pack16v<T>(o8);
+                ht[pix * PIXQ + cgi] = ok ? hr[i] : make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+        __syncthreads();
+        if (PF && tidx + a.gx < ntiles) fetch(tidx + a.gx);
+        {   // dh = conv^T(dd) + dd for this thread's 4-pixel run
+            const int oh = oh0 + row, owb = ow0 + run * R, c = c0 + cg * VEC;
+            if (c < C && oh < H && owb < W) {
+                tc_f32x2 o[R][V2];
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int e = 0; e < V2; ++e) o[r][e] = tc_f32x2{0.f, 0.f};
+#pragma unroll
+                for (int ky = 0; ky < K; ++ky) {
+                    tc_f32x2 in[R + K - 1][V2];
+#pragma unroll
+                    for (int i = 0; i < R + K - 1; ++i) unpack16v<T>(ddt[((row + ky) * IW + run * R + i) * PIXQ + cg], in[i]);
+#pragma unroll
+                    for (int kx = 0; kx < K; ++kx) {
+                        tc_f32x2 wr[V2];
+#pragma unroll
+                        for (int e = 0; e < V2; ++e) wr[e] = *reinterpret_cast<const tc_f32x2*>(&wsm[ky * K + kx][cg * VEC + 2 * e]);
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+#pragma unroll
+                            for (int e = 0; e < V2; ++e) o[r][e] += wr[e] * in[r + kx][e];
+                    }
+                    if (ky == 1) {
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+#pragma unroll
+                            for (int e = 0; e < V2; ++e) o[r][e] += in[r + 1][e];
+                    }
+                }
+                T* dst0 = dh + ((ibase + (long long)oh * W + owb)) * a.lddh + c;
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (owb + r < W) *reinterpret_cast<uint4*>(dst0 + (long long)r * a.lddh) = pack16v<T>(o[r]);
+            }
+        }
+        if (wactive) {   // filter-row ky3 of the weight gradient: sum over the tile of dd[p] * h[p + (ky3 - 1, kx - 1)]
+            for (int u = rg; u < UNITS; u += RG) {
+                const int urow = u / (D::TW / R), urun = u % (D::TW / R);
+                tc_f32x2 d[R][V2], in[R + K - 1][V2];
+#pragma unroll
+                for (int r = 0; r < R; ++r) unpack16v<T>(ddt[((urow + 1) * IW + urun * R + r + 1) * PIXQ + cg], d[r]);
+#pragma unroll
+                for (int i = 0; i < R + K - 1; ++i) unpack16v<T>(ht[((urow + ky3) * IW + urun * R + i) * PIXQ + cg], in[i]);
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+#pragma unroll
+                        for (int e = 0; e < V2; ++e) acc[kx][e] += d[r][e] * in[r + kx][e];
+                if (ky3 == 0) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+#pragma unroll
+                        for (int e = 0; e < V2; ++e) accb[e] += d[r][e];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (c0 + cg * VEC < C) {
+        if (ky3 < K) {
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                for (int e = 0; e < V2; ++e) {
+                    atomicAdd(&lacc[ky3 * K + kx][cg * VEC + 2 * e], acc[kx][e].x);
+                    atomicAdd(&lacc[ky3 * K + kx][cg * VEC + 2 * e + 1], acc[kx][e].y);
+                }
+            if (ky3 == 0) {
+#pragma unroll
+                for (int e = 0; e < V2; ++e) { atomicAdd(&lacc[K * K][cg * VEC + 2 * e], accb[e].x); atomicAdd(&lacc[K * K][cg * VEC + 2 * e + 1], accb[e].y); }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < V2; ++e) {
+            atomicAdd(&lacc[K * K + 1][cg * VEC + 2 * e], accg[e].x); atomicAdd(&lacc[K * K + 1][cg * VEC + 2 * e + 1], accg[e].y);
+            atomicAdd(&lacc[K * K + 2][cg * VEC + 2 * e], accbt[e].x); atomicAdd(&lacc[K * K + 2][cg * VEC + 2 * e + 1], accbt[e].y);
+        }
+    }
+    __syncthreads();
+    float* lflat = &lacc[0][0];
+    int gm = 1;
+    const float* pgroup = nullptr;
+    if (a.wsp) {                                                  // two-level fold, as dw_tile_wgrad_body
+        constexpr int FG = 16;
+        const int chain = bz * a.chunks + by, grp = bx / FG, ngrp = (a.gx + FG - 1) / FG;
+        gm = min(FG, a.gx - grp * FG);
+        float* part = a.wsp + ((long long)chain * a.gx + bx) * (NT * CH);
+        pgroup = a.wsp + ((long long)chain * a.gx + grp * FG) * (NT * CH);
+        if (gm > 1) {
+            for (int f = tid; f < NT * CH; f += 256) __hip_atomic_store(part + f, lflat[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+            __shared__ int s_last;
+            if (tid == 0) {
+                int* cn = a.wsc + chain * ngrp + grp;
+                const int old = atomicAdd(cn, 1);
+                s_last = (old == gm - 1);
+                if (s_last) atomicExch(cn, 0);
+            }
+            __syncthreads();
+            if (!s_last) return;
+        }
+    }
+    float* dwp = a.dw + bz * wstride;
+    float* dbp = a.db ? a.db + bz * wstride : nullptr;
+    float* dgp = a.dgamma ? a.dgamma + bz * wstride : nullptr;
+    float* dbtp = a.dbeta ? a.dbeta + bz * wstride : nullptr;
+    for (int f = tid; f < NT * CH; f += 256) {
+        const int t = f / CH, cc = f - t * CH, ch = c0 + cc;
+        if (ch >= C) continue;
+        float v;
+        if (gm > 1) {
+            float tmp[16];
+#pragma unroll
+            for (int m = 0; m < 16; ++m)
+                tmp[m] = m < gm ? __hip_atomic_load(pgroup + (long long)m * (NT * CH) + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+            v = 0.f;
+#pragma unroll
+            for (int m = 0; m < 16; ++m) v += tmp[m];
+        } else {
+            v = lflat[f];
+        }
+        if (t < K * K) atomicAdd(dwp + (long long)ch * K * K + t, v);
+        else if (t == K * K) { if (dbp) atomicAdd(dbp + ch, v); }
+        else if (t == K * K + 1) { if (dgp) atomicAdd(dgp + ch, v); }
+        else if (dbtp) atomicAdd(dbtp + ch, v);
+    }
+}
+
+template <typename T, bool PF>
+__global__ __launch_bounds__(256, PF ? 1 : 2) void ffn_mid_bwd_kernel(FfnMultiDev q) {
+    extern __shared__ uint4 dsm[];
+    int lin = blockIdx.x, si = 0;
+    if (q.n > 1 && lin >= q.s[1].blk0) si = 1;
+    if (q.n > 2 && lin >= q.s[2].blk0) si = 2;
+    if (q.n > 3 && lin >= q.s[3].blk0) si = 3;
+    const FfnSegDev& g = q.s[si];
+    lin -= g.blk0;
+    ffn_mid_bwd_body<T, PF>(g, q.wstride, lin % g.gx, lin / g.gx, blockIdx.y, dsm);
+}
+
+template <typename T>
+int launch_ffn_mid_bwd(const TcFfnSeg* segs, int nseg, int groups, long long wstride, void* ws, long long ws_bytes, hipStream_t s) {
+    using D = FfnTile<T>;
+    static_assert(D::smem_q * 16 <= 64 * 1024, "static dynamic-LDS limit");
+    static const bool pf = !(getenv("TC_FFN_MID_PF") && atoi(getenv("TC_FFN_MID_PF")) == 0);   // A/B switch: 0 = two workgroups per CU
+    FfnMultiDev q;
+    q.n = nseg; q.wstride = wstride;
+    long long blk = 0, part_floats = 0, cnts = 0, total_work = 0;
+    const bool have_ws = ws && (uintptr_t)ws % 16 == 0 && ws_bytes > 16384;
+    for (int i = 0; i < nseg; ++i)
+        total_work += (long long)segs[i].B * ((segs[i].W + 15) / 16) * ((segs[i].H + D::TH - 1) / D::TH) * ((segs[i].C + D::CH - 1) / D::CH);
+    for (int i = 0; i < nseg; ++i) {
+        const TcFfnSeg& g = segs[i];
+        FfnSegDev& d = q.s[i];
+        if (!g.gp || !g.d || !g.h || !g.dh || !g.stat || !g.part2 || !g.w || !g.gamma || !g.dw || g.C <= 0 || g.C % D::VEC || g.nch2 < 1 ||
+            !dw_tile_ok<T>(g.gp, g.ldg, g.d, g.ldd, g.C) || !dw_tile_ok<T>(g.h, g.ldh, g.dh, g.lddh, g.C))
+            return TC_ERR_ARG;
+        d.gp = g.gp; d.d = g.d; d.h = g.h; d.dh = g.dh; d.stat = g.stat; d.part2 = g.part2; d.w = g.w; d.gamma = g.gamma;
+        d.dw = g.dw; d.db = g.db; d.dgamma = g.dgamma; d.dbeta = g.dbeta;
+        d.C = g.C; d.ldg = g.ldg; d.ldd = g.ldd; d.ldh = g.ldh; d.lddh = g.lddh; d.B = g.B; d.H = g.H; d.W = g.W; d.nch2 = g.nch2;
+        d.chunks = (g.C + D::CH - 1) / D::CH;
+        d.tilesW = (g.W + 15) / 16; d.tilesH = (g.H + D::TH - 1) / D::TH;
+        const long long ntiles = (long long)g.B * d.tilesW * d.tilesH;
+        // ~256 workgroups in total (one per CU; 512 for the two-per-CU variant), shared out by tiles x chunks; every channel chunk
+        // gets gx tile walkers
+        long long gx = (long long)((pf ? 256.0 : 512.0) * (double)ntiles / (double)(total_work > 0 ? total_work : 1) / groups + 0.5);
+        gx = gx < 1 ? 1 : (gx > ntiles ? ntiles : gx);
+        d.gx = (int)gx;
+        d.wsc = have_ws ? reinterpret_cast<int*>(ws) + cnts : nullptr;
+        d.wsp = have_ws ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + 16384) + part_floats : nullptr;
+        cnts += (long long)d.chunks * groups * ((gx + 15) / 16);
+        part_floats += (long long)d.chunks * groups * gx * D::NT * D::CH;
+        d.blk0 = (int)blk;
+        blk += gx * d.chunks;
+    }
+    if (blk > 0x7fffffffLL) return TC_ERR_ARG;
+    if (have_ws && (cnts > 4096 || 16384 + part_floats * 4 > ws_bytes))
+        for (int i = 0; i < nseg; ++i) { q.s[i].wsc = nullptr; q.s[i].wsp = nullptr; }
+    const size_t smem = (size_t)D::smem_q * 16;
+    if (pf) hipLaunchKernelGGL((ffn_mid_bwd_kernel<T, true>), dim3((unsigned)blk, groups), dim3(256), smem, s, q);
+    else hipLaunchKernelGGL((ffn_mid_bwd_kernel<T, false>), dim3((unsigned)blk, groups), dim3(256), smem, s, q);
     return tc_launch_status();
 }
 
@@ -903,6 +1281,7 @@ extern "C" int tc_dwconv_multi(const TcDwSeg* segs, int nseg, int mode, int add_
     }
     if (tile_ok) TC_DISPATCH_DTYPE(dtype, return (launch_multi<T>(segs, nseg, mode, add_input, accumulate, groups, wstride, ws, ws_bytes,
                                                                   (hipStream_t)stream)));
+    for (int i = 0; i < nseg; ++i) if (mode == 0 && segs[i].stat) return TC_ERR_ARG;      // statistics exist on the tile path only
     for (int i = 0; i < nseg; ++i) {                          // unaligned views: one launch per segment through the single entries
         const TcDwSeg& g = segs[i];
         int rc;
@@ -912,4 +1291,30 @@ extern "C" int tc_dwconv_multi(const TcDwSeg* segs, int nseg, int mode, int add_
         if (rc != TC_OK) return rc;
     }
     return TC_OK;
+}
+
+/* see include/transception_hip.h */
+extern "C" int tc_ffn_chunk(int C, int dtype) {
+    if (C <= 0) return TC_ERR_ARG;
+    if (dtype == TC_F32) return dw_pick_cg<float>(C) * Vec16<float>::N;
+    if (dtype == TC_BF16) return dw_pick_cg<bf16_t>(C) * Vec16<bf16_t>::N;
+    return TC_ERR_ARG;
+}
+
+extern "C" int tc_ffn_dw_fwd(const void* x, int ldx, const void* w, const void* bias, void* y, int ldy, float* stat, int B, int H, int W,
+                             int C, int groups, long long wstride, int dtype, void* stream) {
+    if (!x || !w || !y || !stat || (ldx & 3) || (ldy & 3) || groups < 1 || !dw_args_ok(B, H, W, C, 3, 1, 1)) return TC_ERR_ARG;
+    TC_DISPATCH_DTYPE(dtype, {
+        if (!dw_tile_ok<T>(x, ldx, y, ldy, C)) return TC_ERR_ARG;
+        return (launch_tile<T, 0>(x, ldx, w, bias, y, ldy, nullptr, 0, nullptr, nullptr, B, H, W, C, 3, 1, 0, groups, wstride,
+                                  (hipStream_t)stream, nullptr, 0, stat));
+    });
+    return TC_ERR_ARG;
+}
+
+extern "C" int tc_ffn_mid_bwd(const TcFfnSeg* segs, int nseg, int groups, long long wstride, void* ws, long long ws_bytes, int dtype,
+                              void* stream) {
+    if (!segs || nseg < 1 || nseg > FFN_MULTI_MAX || groups < 1) return TC_ERR_ARG;
+    TC_DISPATCH_DTYPE(dtype, return (launch_ffn_mid_bwd<T>(segs, nseg, groups, wstride, ws, ws_bytes, (hipStream_t)stream)));
+    return TC_ERR_ARG;
 }

@@ -30,8 +30,7 @@ template <> __device__ __forceinline__ uint4 pack16<float>(const float* o) {
     return make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3]));
 }
 template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* o) {
-    return make_uint4((unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16), (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16),
-                      (unsigned)f2bf(o[4]) | ((unsigned)f2bf(o[5]) << 16), (unsigned)f2bf(o[6]) | ((unsigned)f2bf(o[7]) << 16));
+    return make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
 }
 // head tile [N][Ch] of a row-strided matrix -> fp32 LDS, 16-byte loads, four in flight per thread (a scalar copy loop keeps ONE
 // load in flight and made the first version of this kernel 50 us for 6272 elements)

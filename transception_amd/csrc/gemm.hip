@@ -31,7 +31,71 @@ struct GemmDev {
     long long sBias1, sRow1; // batch-level-1 strides of bias / rowsum (grouped weights)
     float* ws_part; int* ws_cnt; int fix_group, fix_ngroups;   // split-K fix-up workspace (fix_group > 0: enabled)
     int bgap_every; long long bgap;   // B stored [K,N] in blocks of bgap_every rows with bgap extra elements between blocks
+    struct {                          // MixFFN_skip fusion hooks (TcGemm.ffn_*); mode mirrors the kernels' FFN template parameter
+        int mode, nchunk, chunk_n, ldd, sRow1, sPar1;
+        float eps;
+        const float* part; float* stat; const void* gamma; const void* beta; const void* d; float* part2;
+    } ffn;
 };
+
+// GELU(LayerNorm(.)) on raw 8 x bf16 / 4 x fp32 operand strips (the A rows of fc2's forward, the B rows of its weight gradient)
+__device__ __forceinline__ void bf8_unpack(const uint4& r, float* o) {
+    o[0] = __uint_as_float(r.x << 16); o[1] = __uint_as_float(r.x & 0xffff0000u);
+    o[2] = __uint_as_float(r.y << 16); o[3] = __uint_as_float(r.y & 0xffff0000u);
+    o[4] = __uint_as_float(r.z << 16); o[5] = __uint_as_float(r.z & 0xffff0000u);
+    o[6] = __uint_as_float(r.w << 16); o[7] = __uint_as_float(r.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 bf8_pack(const float* o) {
+    return make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
+}
+__device__ __forceinline__ uint4 ffn_ln_gelu8(const uint4& v, float mean, float rstd, const float* g, const float* b) {
+    float x[8];
+    bf8_unpack(v, x);
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {                          // pairs on the packed fp32 pipe
+        const tc_f32x2 xv = {x[e], x[e + 1]}, gv = {g[e], g[e + 1]}, bv = {b[e], b[e + 1]};
+        const tc_f32x2 u = gelu_f2((xv - mean) * rstd * gv + bv);
+        x[e] = u.x; x[e + 1] = u.y;
+    }
+    return bf8_pack(x);
+}
+__device__ __forceinline__ float4 ffn_ln_gelu4(const float4& v, float mean, float rstd, const float4& g, const float4& b) {
+    return make_float4(gelu_f((v.x - mean) * rstd * g.x + b.x), gelu_f((v.y - mean) * rstd * g.y + b.y),
+                       gelu_f((v.z - mean) * rstd * g.z + b.z), gelu_f((v.w - mean) * rstd * g.w + b.w));
+}
+// TC_FFN_LN_A: merge the chunk partials of the tile's BM rows (Chan's formula), LPR lanes per row; result in LDS (and, from the
+// workgroups of the first N tile / first K split, in ffn.stat for the backward pass)
+template <int BM>
+__device__ __forceinline__ void ffn_finalize_stats(const GemmDev& p, int b1, int m0, bool write_out, float2* s_stat) {
+    constexpr int LPR = 256 / BM;
+    const int tid = threadIdx.x, r = tid / LPR, q = tid % LPR, row = m0 + r;
+    const long long rbase = (long long)b1 * p.ffn.sRow1;
+    const int nch = p.ffn.nchunk;
+    const float cn = (float)p.ffn.chunk_n, inv_cn = 1.0f / cn, invC = 1.0f / (cn * (float)nch);
+    const float2* pp = reinterpret_cast<const float2*>(p.ffn.part) + (rbase + (row < p.M ? row : 0)) * nch;
+    float sm = 0.f;
+    for (int k = q; k < nch; k += LPR) sm += pp[k].x;
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) sm += __shfl_xor(sm, o, 64);
+    const float mean = sm * invC;
+    float m2 = 0.f;
+    for (int k = q; k < nch; k += LPR) { const float2 t = pp[k]; const float dm = t.x * inv_cn - mean; m2 += t.y + cn * dm * dm; }
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) m2 += __shfl_xor(m2, o, 64);
+    const float rstd = rsqrtf(m2 * invC + p.ffn.eps);
+    if (q == 0) {
+        s_stat[r] = make_float2(mean, rstd);
+        if (write_out && row < p.M) reinterpret_cast<float2*>(p.ffn.stat)[rbase + row] = make_float2(mean, rstd);
+    }
+    __syncthreads();
+}
+// TC_FFN_EP on one value: gp = v * GELU'(xhat gamma + beta); accumulates the two LayerNorm-backward row sums
+__device__ __forceinline__ float ffn_ep1(float v, float d, float mean, float rstd, float g, float b, float& s1, float& s2) {
+    const float xh = (d - mean) * rstd;
+    const float gp = v * gelu_grad_f(xh * g + b);
+    s1 += gp * g; s2 += gp * g * xh;
+    return gp;
+}
 
 // Split-K fix-up without a second launch.  The `splitk` workgroups of an output tile park their fp32 partial tiles in the
 // workspace (plain coalesced stores), groups of `fix_group` consecutive splits share an arrival counter, and the member that
@@ -154,24 +218,45 @@ __device__ __forceinline__ void epilogue_rows(const GemmDev& p, f32x16 (&acc)[TM
 
 // Un-swapped orientation (fp32 C: weight gradients, fp32 storage): register r holds row (r&3) + 8*(r>>2) + 4*(lane>>5), the
 // 32 lanes of a half-wave hold 32 consecutive columns -> 128-byte coalesced fp32 stores / atomics.
-template <typename T, typename TC, int TM, int TN>
-__device__ __forceinline__ void epilogue_cols(const GemmDev& p, f32x16 (&acc)[TM][TN], int b1, int b2, bool first_split, bool atomic, int mbase, int nbase, int lane) {
+// EP (fp32 storage only): TC_FFN_EP -- the value becomes gp = v * GELU'(u) and the row sums of gp*gamma, gp*gamma*xhat over this
+// workgroup's 64 columns go to ffn.part2[row][ntile]; srow = LDS float2 [2][64] (the two column halves of the tile), mloc0 = first
+// tile row of this wave.
+template <typename T, typename TC, int TM, int TN, bool EP = false>
+__device__ __forceinline__ void epilogue_cols(const GemmDev& p, f32x16 (&acc)[TM][TN], int b1, int b2, bool first_split, bool atomic, int mbase, int nbase, int lane,
+                                              float2* srow = nullptr, int mloc0 = 0, int wc = 0, int m0 = 0, int ntile = 0, int ntiles = 0) {
     TC* C = reinterpret_cast<TC*>(p.C) + b1 * p.sC1 + b2 * p.sC2;
     const T* R = p.R ? reinterpret_cast<const T*>(p.R) + b1 * p.sR1 + b2 * p.sR2 : nullptr;
     const T* bias = p.bias ? reinterpret_cast<const T*>(p.bias) + b1 * p.sBias1 : nullptr;
+    const long long rbase = EP ? (long long)b1 * p.ffn.sRow1 : 0;
+    const T* dmap = EP ? reinterpret_cast<const T*>(p.ffn.d) + rbase * p.ffn.ldd : nullptr;
+    const float2* stat = EP ? reinterpret_cast<const float2*>(p.ffn.stat) + rbase : nullptr;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i) {
+        float s1[16], s2[16];
+        if constexpr (EP) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s1[r] = s2[r] = 0.f;
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = nbase + j * 32 + (lane & 31);
             if (col >= p.N) continue;
             const float bv = (bias && first_split) ? ldf<T>(bias + col) : 0.f;
+            float gm = 0.f, bt = 0.f;
+            if constexpr (EP) {
+                gm = ldf<T>(reinterpret_cast<const T*>(p.ffn.gamma) + (long long)b1 * p.ffn.sPar1 + col);
+                bt = ldf<T>(reinterpret_cast<const T*>(p.ffn.beta) + (long long)b1 * p.ffn.sPar1 + col);
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (row >= p.M) continue;
                 float v = p.alpha * acc[i][j][r] + bv;
                 if (R && first_split) v += ldf<T>(R + (long long)row * p.ldr + col);
+                if constexpr (EP) {
+                    const float2 st = stat[row];
+                    v = ffn_ep1(v, ldf<T>(dmap + (long long)row * p.ffn.ldd + col), st.x, st.y, gm, bt, s1[r], s2[r]);
+                }
                 TC* c = C + (long long)row * p.ldc + col;
                 if (atomic) {
                     atomicAdd(reinterpret_cast<float*>(c), v);
@@ -182,6 +267,23 @@ __device__ __forceinline__ void epilogue_cols(const GemmDev& p, f32x16 (&acc)[TM
                 }
             }
         }
+        if constexpr (EP) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) { s1[r] += __shfl_xor(s1[r], o, 64); s2[r] += __shfl_xor(s2[r], o, 64); }
+                if ((lane & 31) == 0) srow[wc * 64 + mloc0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)] = make_float2(s1[r], s2[r]);
+            }
+        }
+    }
+    if constexpr (EP) {
+        __syncthreads();
+        const int t = threadIdx.x;
+        if (t < 64 && m0 + t < p.M) {
+            const float2 a = srow[t], b = srow[64 + t];
+            reinterpret_cast<float2*>(p.ffn.part2)[(rbase + m0 + t) * ntiles + ntile] = make_float2(a.x + b.x, a.y + b.y);
+        }
+    }
 }
 
 // bf16 C, plain store (no accumulate): values are finished in registers (alpha, bias, residual, activation) exactly as
@@ -236,6 +338,73 @@ __device__ __forceinline__ void epilogue_rows_lds(const GemmDev& p, f32x16 (&acc
     }
 }
 
+// TC_FFN_EP form of the epilogue above: the d tile (prefetched before the K loop, rd) is parked beside the C staging tile, every
+// value becomes gp = v * GELU'(u) and the row sums for the LayerNorm backward leave through ffn.part2[row][bx].
+template <int BM, int BN, int TM, int TN>
+__device__ __forceinline__ void epilogue_rows_lds_ep(const GemmDev& p, f32x16 (&acc)[TM][TN], int b1, int m0, int n0, int wr, int wc, int lane,
+                                                     bf16_t* stage, const uint4 rd0, const uint4 rd1, int bx, int gx) {
+    constexpr int LDS_ = BN + 8, WM = BM / 2, WN = BN / 2, CPR = BN / 8;
+    bf16_t* dt = stage + BM * LDS_;
+    float2* srow = reinterpret_cast<float2*>(dt + BM * LDS_);          // [2][BM]
+    const long long rbase = (long long)b1 * p.ffn.sRow1;
+    const bf16_t* gam = reinterpret_cast<const bf16_t*>(p.ffn.gamma) + (long long)b1 * p.ffn.sPar1;
+    const bf16_t* bet = reinterpret_cast<const bf16_t*>(p.ffn.beta) + (long long)b1 * p.ffn.sPar1;
+    const float2* stat = reinterpret_cast<const float2*>(p.ffn.stat) + rbase;
+    const int h = lane >> 5;
+    __syncthreads();                                         // every wave is done with the operand tiles this overwrites
+    {
+        const int lr = threadIdx.x / CPR, lc = (threadIdx.x % CPR) * 8;
+        *reinterpret_cast<uint4*>(dt + lr * LDS_ + lc) = rd0;
+        *reinterpret_cast<uint4*>(dt + (lr + 256 / CPR) * LDS_ + lc) = rd1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int lr = wr * WM + i * 32 + (lane & 31), row = m0 + lr;
+        const float2 st = stat[row < p.M ? row : 0];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int lc = wc * WN + j * 32 + 8 * g + 4 * h, col = n0 + lc;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = p.alpha * acc[i][j][4 * g + e];
+                if (row < p.M && col < p.N) {                // N % 8 == 0 on this path: the 4-group is all in or all out
+                    const float4 d4 = ld4<bf16_t>(dt + lr * LDS_ + lc), g4 = ld4<bf16_t>(gam + col), b4 = ld4<bf16_t>(bet + col);
+                    {
+                        const tc_f32x2 va = {v[0], v[1]}, vb = {v[2], v[3]};
+                        const tc_f32x2 ga = {g4.x, g4.y}, gb = {g4.z, g4.w};
+                        const tc_f32x2 xa = (tc_f32x2{d4.x, d4.y} - st.x) * st.y, xb = (tc_f32x2{d4.z, d4.w} - st.x) * st.y;
+                        const tc_f32x2 pa = va * gelu_grad_f2(xa * ga + tc_f32x2{b4.x, b4.y});
+                        const tc_f32x2 pb = vb * gelu_grad_f2(xb * gb + tc_f32x2{b4.z, b4.w});
+                        const tc_f32x2 qa = pa * ga, qb = pb * gb, ra = qa * xa, rb = qb * xb;
+                        s1 += (qa.x + qa.y) + (qb.x + qb.y);
+                        s2 += (ra.x + ra.y) + (rb.x + rb.y);
+                        v[0] = pa.x; v[1] = pa.y; v[2] = pb.x; v[3] = pb.y;
+                    }
+                }
+                st4<bf16_t>(stage + lr * LDS_ + lc, make_float4(v[0], v[1], v[2], v[3]));
+            }
+        s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+        if (h == 0) srow[wc * BM + lr] = make_float2(s1, s2);
+    }
+    __syncthreads();
+    bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + b1 * p.sC1;
+#pragma unroll
+    for (int it = 0; it < BM * CPR / 256; ++it) {
+        const int idx = threadIdx.x + it * 256, lr = idx / CPR, lc = (idx - lr * CPR) * 8;
+        const int row = m0 + lr, col = n0 + lc;
+        if (row < p.M && col < p.N)
+            *reinterpret_cast<uint4*>(C + (long long)row * p.ldc + col) = *reinterpret_cast<const uint4*>(stage + lr * LDS_ + lc);
+    }
+    if (threadIdx.x < BM && m0 + threadIdx.x < p.M) {
+        const float2 a = srow[threadIdx.x], b = srow[BM + threadIdx.x];
+        reinterpret_cast<float2*>(p.ffn.part2)[(rbase + m0 + threadIdx.x) * gx + bx] = make_float2(a.x + b.x, a.y + b.y);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- fp32 path
 // Load a 4-wide strip of an operand tile.  `trans` = the operand is stored [K, X] (X contiguous).
 __device__ __forceinline__ float4 load_strip(const float* base, int ld, int x, int k, int X, int K, bool trans, bool vec) {
@@ -266,14 +435,18 @@ __device__ __forceinline__ float4 load_strip(const float* base, int ld, int x, i
     return v;
 }
 
-template <typename TC, int BM, int BN, bool TA, bool TB>
+template <typename TC, int BM, int BN, bool TA, bool TB, int FFN = 0>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmDev p) {
     constexpr int BK = 16, LDT = BK + 1;
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int SA = BM * BK / 4 / 256, SB = BN * BK / 4 / 256;   // strips per thread
     static_assert(SA >= 1 && SB >= 1, "tile too small");
+    static_assert(FFN == 0 || (BM == 64 && BN == 64), "the MixFFN hooks run on 64x64 tiles");
+    static_assert(FFN != TC_FFN_LN_A || !TA, "LN_A transforms rows of a row-major A");
+    static_assert(FFN != TC_FFN_LN_B || !TB, "LN_B transforms rows of a [K,N] B");
     __shared__ float As[BM * LDT];
     __shared__ float Bs[BN * LDT];
+    __shared__ float2 s_ffn[FFN ? 2 * 64 : 1];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -286,6 +459,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev p) {
 
     const float* A = reinterpret_cast<const float*>(p.A) + b1 * p.sA1 + b2 * p.sA2;
     const float* B = reinterpret_cast<const float*>(p.B) + b1 * p.sB1 + b2 * p.sB2;
+    const float* gam = FFN ? reinterpret_cast<const float*>(p.ffn.gamma) + (long long)b1 * p.ffn.sPar1 : nullptr;
+    const float* bet = FFN ? reinterpret_cast<const float*>(p.ffn.beta) + (long long)b1 * p.ffn.sPar1 : nullptr;
+    const float2* fstat = FFN ? reinterpret_cast<const float2*>(p.ffn.stat) + (long long)b1 * p.ffn.sRow1 : nullptr;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -295,8 +471,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // hook state: LN_A -- this thread's strip row statistics (fixed for the whole K loop), gamma/beta of the slab's k range arrive with
+    // the slab; LN_B -- gamma/beta of the strip's fixed columns, the statistics of the slab's token rows arrive with the slab
+    float a_mean = 0.f, a_rstd = 0.f;
+    float4 hg = make_float4(0.f, 0.f, 0.f, 0.f), hb = hg;     // per slab (LN_A) or fixed (LN_B)
+    float2 hst = make_float2(0.f, 0.f);                        // LN_B: (mean, rstd) of the slab's token row
+    if constexpr (FFN == TC_FFN_LN_A) {
+        ffn_finalize_stats<BM>(p, b1, m0, blockIdx.x == 0 && ks == 0, s_ffn);
+        const float2 st = s_ffn[tid / (BK / 4)];
+        a_mean = st.x; a_rstd = st.y;
+    }
+    if constexpr (FFN == TC_FFN_LN_B) {
+        const int col = n0 + (tid % (BN / 4)) * 4;
+        if (col + 3 < p.N) { hg = *reinterpret_cast<const float4*>(gam + col); hb = *reinterpret_cast<const float4*>(bet + col); }
+    }
+
     float4 ra[SA], rb[SB];
-    auto fetch = [&](int k0) {
+    auto fetch = [&](int k0) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < SA; ++i) {
             const int f = tid + i * 256;
@@ -314,13 +505,30 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev p) {
                 const float* Bk = p.bgap_every ? B + (long long)(k0 / p.bgap_every) * p.bgap : B;
                 rb[i] = load_strip(Bk, p.ldb, n0 + nq * 4, k0 + k, p.N, kend, true, p.vecB); }
         }
+        if constexpr (FFN == TC_FFN_LN_A) {
+            const int k = k0 + (tid % (BK / 4)) * 4;
+            if (k + 3 < kend) { hg = *reinterpret_cast<const float4*>(gam + k); hb = *reinterpret_cast<const float4*>(bet + k); }
+        }
+        if constexpr (FFN == TC_FFN_LN_B) {
+            const int k = k0 + tid / (BN / 4);
+            if (k < kend) hst = fstat[k];
+        }
     };
-    auto stage = [&]() {
+    auto stage = [&](int k0) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < SA; ++i) {
             const int f = tid + i * 256;
             if (!TA) { const int row = f / (BK / 4), kq = f % (BK / 4); float* d = &As[row * LDT + kq * 4];
-                d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w; }
+                float4 v = ra[i];
+                if constexpr (FFN == TC_FFN_LN_A) {          // (K is a multiple of 4 here: a strip is all in or all out)
+                    if (m0 + row < p.M && k0 + kq * 4 + 3 < kend) {
+                        v = ffn_ln_gelu4(v, a_mean, a_rstd, hg, hb);
+                        if (p.ffn.d && blockIdx.x == 0)
+                            *reinterpret_cast<float4*>(reinterpret_cast<float*>(const_cast<void*>(p.ffn.d)) +
+                                                       ((long long)b1 * p.ffn.sRow1 + m0 + row) * p.ffn.ldd + k0 + kq * 4) = v;
+                    }
+                }
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
             else { const int k = f / (BM / 4), mq = f % (BM / 4); float* d = &As[(mq * 4) * LDT + k];
                 d[0] = ra[i].x; d[LDT] = ra[i].y; d[2 * LDT] = ra[i].z; d[3 * LDT] = ra[i].w; }
         }
@@ -330,7 +538,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev p) {
             if (TB) { const int row = f / (BK / 4), kq = f % (BK / 4); float* d = &Bs[row * LDT + kq * 4];
                 d[0] = rb[i].x; d[1] = rb[i].y; d[2] = rb[i].z; d[3] = rb[i].w; }
             else { const int k = f / (BN / 4), nq = f % (BN / 4); float* d = &Bs[(nq * 4) * LDT + k];
-                d[0] = rb[i].x; d[LDT] = rb[i].y; d[2 * LDT] = rb[i].z; d[3 * LDT] = rb[i].w; }
+                float4 v = rb[i];
+                if constexpr (FFN == TC_FFN_LN_B) {
+                    if (k0 + k < kend && n0 + nq * 4 + 3 < p.N) v = ffn_ln_gelu4(v, hst.x, hst.y, hg, hb);
+                }
+                d[0] = v.x; d[LDT] = v.y; d[2 * LDT] = v.z; d[3 * LDT] = v.w; }
         }
     };
 
@@ -338,7 +550,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev p) {
     const bool do_rowsum = p.rowsum && blockIdx.x == 0 && tid < BM;
     if (kbeg < kend) fetch(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        stage();
+        stage(k0);
         __syncthreads();
         if (k0 + BK < kend) fetch(k0 + BK);
         if (do_rowsum) {
@@ -369,7 +581,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev p) {
         if (!splitk_fixup<TM, TN>(p, acc, (int)(((blockIdx.z / p.splitk) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x), ks, grp)) return;
         first = (grp == 0); atomic = p.fix_ngroups > 1;
     }
-    epilogue_cols<float, TC, TM, TN>(p, acc, b1, b2, first, atomic, m0 + wr * WM, n0 + wc * WN, lane);
+    if constexpr (FFN == TC_FFN_EP)
+        epilogue_cols<float, TC, TM, TN, true>(p, acc, b1, b2, first, atomic, m0 + wr * WM, n0 + wc * WN, lane, s_ffn, wr * WM, wc, m0,
+                                               (int)blockIdx.x, (int)gridDim.x);
+    else
+        epilogue_cols<float, TC, TM, TN>(p, acc, b1, b2, first, atomic, m0 + wr * WM, n0 + wc * WN, lane);
 }
 
 // ---------------------------------------------------------------------------------------------- bf16 path
@@ -423,10 +639,14 @@ __device__ __forceinline__ bf16x8 ld_frag_tr(const bf16_t* lo, const bf16_t* hi)
 
 // Body of one workgroup of the bf16 GEMM: (bx, by, bz) of a (gx, gy, *) grid.  The LDS buffers come from the caller so that the
 // two problems of a paired launch (gemm_pair_kernel) share one allocation.
-template <typename TC, int BM, int BN, bool TA, bool TB, bool DB>
+template <typename TC, int BM, int BN, bool TA, bool TB, bool DB, int FFN = 0>
 __device__ __forceinline__ void gemm_bf16_body(const GemmDev& p, const int bx, const int by, const int bz, const int gx, const int gy,
                                                bf16_t (*As)[BM * (64 + 8)], bf16_t (*Bs)[BN * (64 + 8)]) {
     constexpr int BK = 64, LDT = BK + 8;                       // 144-byte rows: 16-B aligned, conflict-free b128 fragment reads
+    static_assert(FFN == 0 || (BM == 64 && BN == 64 && DB), "the MixFFN hooks run on 64x64 tiles with the double-buffered LDS");
+    static_assert(FFN != TC_FFN_LN_A || !TA, "LN_A transforms rows of a row-major A");
+    static_assert(FFN != TC_FFN_LN_B || !TB, "LN_B transforms rows of a [K,N] B");
+    static_assert(FFN != TC_FFN_EP || sizeof(TC) == 2, "EP writes a bf16 C");
     constexpr bool SWAP = sizeof(TC) == 2;                     // bf16 output: lane owns a row (8-byte stores); fp32 output: coalesced columns
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int SA = BM * BK / 8 / 256, SB = BN * BK / 8 / 256;   // 8-element strips per thread
@@ -458,20 +678,51 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmDev& p, const int bx, c
 
     // strip ownership: K-contiguous operands: consecutive threads walk along K (coalesced 16-B loads, vector LDS writes);
     // transposed operands: 8 consecutive threads cover one k-row of the tile (128 contiguous bytes), one 16-B LDS write each
-    auto a_xy = [&](int i, int k0, int& x, int& k) {
+    auto a_xy = [&](int i, int k0, int& x, int& k) __attribute__((always_inline)) {
         const int f = tid + i * 256;
         if (!TA) { x = m0 + f / (BK / 8); k = k0 + (f % (BK / 8)) * 8; }
         else { k = k0 + f / (BM / 8); x = m0 + (f % (BM / 8)) * 8; }         // 8 lanes = one k-row of the tile: coalesced
     };
-    auto b_xy = [&](int i, int k0, int& x, int& k) {
+    auto b_xy = [&](int i, int k0, int& x, int& k) __attribute__((always_inline)) {
         const int f = tid + i * 256;
         if (TB) { x = n0 + f / (BK / 8); k = k0 + (f % (BK / 8)) * 8; }
         else { k = k0 + f / (BN / 8); x = n0 + (f % (BN / 8)) * 8; }
     };
-    auto b_base = [&](int k0) { return (!TB && p.bgap_every) ? B + (long long)(k0 / p.bgap_every) * p.bgap : B; };
+    auto b_base = [&](int k0) __attribute__((always_inline)) { return (!TB && p.bgap_every) ? B + (long long)(k0 / p.bgap_every) * p.bgap : B; };
+    // MixFFN hooks.  LN_A: the statistics of this thread's two strip rows are fixed for the K loop (merged from the chunk partials
+    // here), gamma / beta of a slab's k range travel with the slab (rh = {gamma, beta} raw).  LN_B: gamma / beta of the strip's
+    // fixed columns are loaded once, the statistics of a slab's two token rows travel with the slab (rh[0] = {mean0, rstd0,
+    // mean1, rstd1}).  EP: the d tile under this output tile is requested now and parked in LDS by the epilogue.
+    const bf16_t* gam = FFN ? reinterpret_cast<const bf16_t*>(p.ffn.gamma) + (long long)b1 * p.ffn.sPar1 : nullptr;
+    const bf16_t* bet = FFN ? reinterpret_cast<const bf16_t*>(p.ffn.beta) + (long long)b1 * p.ffn.sPar1 : nullptr;
+    const float2* fstat = FFN ? reinterpret_cast<const float2*>(p.ffn.stat) + (long long)b1 * p.ffn.sRow1 : nullptr;
+    __shared__ float2 s_ffn[FFN == TC_FFN_LN_A ? BM : 1];
+    float a_mean[SA], a_rstd[SA], fg[8], fb[8];
+    bf16_t* aout = (FFN == TC_FFN_LN_A && p.ffn.d && bx == 0) ? reinterpret_cast<bf16_t*>(const_cast<void*>(p.ffn.d)) + (long long)b1 * p.ffn.sRow1 * p.ffn.ldd
+                                                               : nullptr;
+    uint4 rd0 = make_uint4(0u, 0u, 0u, 0u), rd1 = rd0;         // EP: this thread's two 16-byte pieces of the d tile
+    if constexpr (FFN == TC_FFN_LN_A) {
+        ffn_finalize_stats<BM>(p, b1, m0, bx == 0 && ks == 0, s_ffn);
+#pragma unroll
+        for (int i = 0; i < SA; ++i) { const float2 st = s_ffn[(tid + i * 256) / (BK / 8)]; a_mean[i] = st.x; a_rstd[i] = st.y; }
+    }
+    if constexpr (FFN == TC_FFN_LN_B) {
+        const int col = n0 + (tid % (BN / 8)) * 8;
+        const int cc = col + 7 < p.N ? col : 0;
+        bf8_unpack(*reinterpret_cast<const uint4*>(gam + cc), fg);
+        bf8_unpack(*reinterpret_cast<const uint4*>(bet + cc), fb);
+    }
+    if constexpr (FFN == TC_FFN_EP) {
+        const bf16_t* dmap = reinterpret_cast<const bf16_t*>(p.ffn.d) + (long long)b1 * p.ffn.sRow1 * p.ffn.ldd;
+        static_assert(BM * BN / 8 / 256 == 2 || FFN != TC_FFN_EP, "two pieces per thread");
+        const int lr = tid / (BN / 8), lc = (tid % (BN / 8)) * 8;
+        const bool in0 = m0 + lr < p.M && n0 + lc < p.N, in1 = m0 + lr + 256 / (BN / 8) < p.M && n0 + lc < p.N;
+        rd0 = *reinterpret_cast<const uint4*>(in0 ? dmap + (long long)(m0 + lr) * p.ffn.ldd + n0 + lc : dmap);
+        rd1 = *reinterpret_cast<const uint4*>(in1 ? dmap + (long long)(m0 + lr + 256 / (BN / 8)) * p.ffn.ldd + n0 + lc : dmap);
+    }
     // FAST (decided once per workgroup, below): both operands 16-byte aligned and no strip of this workgroup's slabs is partially
     // covered -- the K loop then contains no branch at all around its loads.  Otherwise: the general loader, everything at fetch time.
-    auto fetch = [&](auto FT, uint4 (&ra)[SA], uint4 (&rb)[SB], int k0) {
+    auto fetch = [&](auto FT, uint4 (&ra)[SA], uint4 (&rb)[SB], uint4 (&rh)[2], int k0) __attribute__((always_inline)) {
         constexpr bool FAST = decltype(FT)::value;
         int x, k;
 #pragma unroll
@@ -487,17 +738,34 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmDev& p, const int bx, c
             if constexpr (FAST) rb[i] = strip_raw(Bk, B, p.ldb, x, k, p.N, kend, !TB);
             else rb[i] = load_strip8(Bk, p.ldb, x, k, p.N, kend, !TB, p.vecB);
         }
+        if constexpr (FFN == TC_FFN_LN_A) {
+            const int kk = k0 + (tid % (BK / 8)) * 8, kc = kk + 7 < kend ? kk : 0;
+            rh[0] = *reinterpret_cast<const uint4*>(gam + kc);
+            rh[1] = *reinterpret_cast<const uint4*>(bet + kc);
+        }
+        if constexpr (FFN == TC_FFN_LN_B) {
+            const int t0 = k0 + tid / (BN / 8), t1 = t0 + 256 / (BN / 8);
+            const float2 s0 = fstat[t0 < kend ? t0 : 0], s1 = fstat[t1 < kend ? t1 : 0];
+            rh[0] = make_uint4(__float_as_uint(s0.x), __float_as_uint(s0.y), __float_as_uint(s1.x), __float_as_uint(s1.y));
+        }
     };
     constexpr int PA = BM + 8, PB = BN + 8;                    // row pitch of a transposed-layout slab
-    auto stage = [&](auto FT, const uint4 (&ra)[SA], const uint4 (&rb)[SB], int k0, bf16_t* as, bf16_t* bs) {
+    auto stage = [&](auto FT, const uint4 (&ra)[SA], const uint4 (&rb)[SB], const uint4 (&rh)[2], int k0, bf16_t* as, bf16_t* bs) __attribute__((always_inline)) {
         constexpr bool FAST = decltype(FT)::value;
         int x, k;
+        float hg[8], hb[8];
+        if constexpr (FFN == TC_FFN_LN_A) { bf8_unpack(rh[0], hg); bf8_unpack(rh[1], hb); }
 #pragma unroll
         for (int i = 0; i < SA; ++i) {
             const int f = tid + i * 256;
             a_xy(i, k0, x, k);
             uint4 v = ra[i];
+            if constexpr (FFN == TC_FFN_LN_A) {              // (K % 8 == 0: strips are all in or all out)
+                v = ffn_ln_gelu8(v, a_mean[i], a_rstd[i], hg, hb);
+                if (aout && strip_whole(x, k, p.M, kend, TA)) *reinterpret_cast<uint4*>(aout + (long long)x * p.ffn.ldd + k) = v;
+            }
             if constexpr (FAST) { if (!strip_whole(x, k, p.M, kend, TA)) v = make_uint4(0u, 0u, 0u, 0u); }
+            else if constexpr (FFN == TC_FFN_LN_A) { if (!strip_whole(x, k, p.M, kend, TA)) v = make_uint4(0u, 0u, 0u, 0u); }
             if (!TA) { const int row = f / (BK / 8), kq = f % (BK / 8); *reinterpret_cast<uint4*>(&as[row * LDT + kq * 8]) = v; }
             else { const int kl = f / (BM / 8), mq = f % (BM / 8); *reinterpret_cast<uint4*>(&as[gemm_krow(kl) * PA + mq * 8]) = v; }
         }
@@ -507,14 +775,19 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmDev& p, const int bx, c
             const int f = tid + i * 256;
             b_xy(i, k0, x, k);
             uint4 v = rb[i];
+            if constexpr (FFN == TC_FFN_LN_B) {
+                static_assert(FFN != TC_FFN_LN_B || SB == 2, "two strips per thread");
+                v = ffn_ln_gelu8(v, __uint_as_float(i == 0 ? rh[0].x : rh[0].z), __uint_as_float(i == 0 ? rh[0].y : rh[0].w), fg, fb);
+            }
             if constexpr (FAST) { if (!strip_whole(x, k, p.N, kend, !TB)) v = make_uint4(0u, 0u, 0u, 0u); }
+            else if constexpr (FFN == TC_FFN_LN_B) { if (!strip_whole(x, k, p.N, kend, !TB)) v = make_uint4(0u, 0u, 0u, 0u); }
             if (TB) { const int row = f / (BK / 8), kq = f % (BK / 8); *reinterpret_cast<uint4*>(&bs[row * LDT + kq * 8]) = v; }
             else { const int kl = f / (BN / 8), nq = f % (BN / 8); *reinterpret_cast<uint4*>(&bs[gemm_krow(kl) * PB + nq * 8]) = v; }
         }
     };
     float rsum = 0.f;
     const bool do_rowsum = p.rowsum && bx == 0 && tid < BM;
-    auto compute = [&](const bf16_t* as, const bf16_t* bs) {
+    auto compute = [&](const bf16_t* as, const bf16_t* bs) __attribute__((always_inline)) {
         if (do_rowsum) {
 #pragma unroll
             for (int kk = 0; kk < BK; ++kk) rsum += bf2f(TA ? as[kk * PA + tid] : as[tid * LDT + kk]);
@@ -546,40 +819,40 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmDev& p, const int bx, c
         }
     };
 
-    auto kloop = [&](auto FT) {
+    auto kloop = [&](auto FT) __attribute__((always_inline)) {
     // FAST: prefetches are issued unconditionally (a slab beyond kend reads the operands' first bytes and is never used) -- a
     // conditional prefetch makes the compiler wait for ALL outstanding loads, the new slab's included, before the older slab is used
     constexpr bool FAST = decltype(FT)::value;
-    uint4 ra0[SA], rb0[SB], ra1[SA], rb1[SB];
+    uint4 ra0[SA], rb0[SB], ra1[SA], rb1[SB], rh0[2], rh1[2];
     if (!DB) {
-        if (kbeg < kend) fetch(FT, ra0, rb0, kbeg);                  // (one register set: a conditional prefetch costs nothing here)
+        if (kbeg < kend) fetch(FT, ra0, rb0, rh0, kbeg);             // (one register set: a conditional prefetch costs nothing here)
         for (int k0 = kbeg; k0 < kend; k0 += BK) {
-            stage(FT, ra0, rb0, k0, As[0], Bs[0]);
+            stage(FT, ra0, rb0, rh0, k0, As[0], Bs[0]);
             __syncthreads();
-            if (k0 + BK < kend) fetch(FT, ra0, rb0, k0 + BK);
+            if (k0 + BK < kend) fetch(FT, ra0, rb0, rh0, k0 + BK);
             compute(As[0], Bs[0]);
             __syncthreads();
         }
     } else if (kbeg < kend) {
-        fetch(FT, ra0, rb0, kbeg);
-        if (FAST || kbeg + BK < kend) fetch(FT, ra1, rb1, kbeg + BK);
-        stage(FT, ra0, rb0, kbeg, As[0], Bs[0]);
+        fetch(FT, ra0, rb0, rh0, kbeg);
+        if (FAST || kbeg + BK < kend) fetch(FT, ra1, rb1, rh1, kbeg + BK);
+        stage(FT, ra0, rb0, rh0, kbeg, As[0], Bs[0]);
         __syncthreads();
-        if (FAST || kbeg + 2 * BK < kend) fetch(FT, ra0, rb0, kbeg + 2 * BK);
+        if (FAST || kbeg + 2 * BK < kend) fetch(FT, ra0, rb0, rh0, kbeg + 2 * BK);
         for (int k0 = kbeg;; k0 += 2 * BK) {
             // slab k0 sits in LDS buffer 0; slab k0+BK waits in register set 1; slab k0+2BK is arriving in set 0
             const bool has1 = k0 + BK < kend;
-            if (has1) stage(FT, ra1, rb1, k0 + BK, As[DB ? 1 : 0], Bs[DB ? 1 : 0]);
+            if (has1) stage(FT, ra1, rb1, rh1, k0 + BK, As[DB ? 1 : 0], Bs[DB ? 1 : 0]);
             compute(As[0], Bs[0]);
             if (!has1) break;
             __syncthreads();
-            if (FAST || k0 + 3 * BK < kend) fetch(FT, ra1, rb1, k0 + 3 * BK);
+            if (FAST || k0 + 3 * BK < kend) fetch(FT, ra1, rb1, rh1, k0 + 3 * BK);
             const bool has2 = k0 + 2 * BK < kend;
-            if (has2) stage(FT, ra0, rb0, k0 + 2 * BK, As[0], Bs[0]);
+            if (has2) stage(FT, ra0, rb0, rh0, k0 + 2 * BK, As[0], Bs[0]);
             compute(As[DB ? 1 : 0], Bs[DB ? 1 : 0]);
             if (!has2) break;
             __syncthreads();
-            if (FAST || k0 + 4 * BK < kend) fetch(FT, ra0, rb0, k0 + 4 * BK);
+            if (FAST || k0 + 4 * BK < kend) fetch(FT, ra0, rb0, rh0, k0 + 4 * BK);
         }
     }
     };
@@ -594,7 +867,10 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmDev& p, const int bx, c
         if (!splitk_fixup<TM, TN>(p, acc, ((bz / p.splitk) * gy + by) * gx + bx, ks, grp)) return;
         first = (grp == 0); atomic = p.fix_ngroups > 1;
     }
-    if constexpr (SWAP) {
+    if constexpr (FFN == TC_FFN_EP) {
+        static_assert(FFN != TC_FFN_EP || 2 * BM * (BN + 8) + 2 * BM * 4 <= 2 * (BM + BN) * (64 + 8), "C stage + d tile + row sums must fit");
+        epilogue_rows_lds_ep<BM, BN, TM, TN>(p, acc, b1, m0, n0, wr, wc, lane, &As[0][0], rd0, rd1, bx, gx);
+    } else if constexpr (SWAP) {
         if (p.vec8C && !p.accumulate && !atomic && first) {
             static_assert((BM * (BN + 8)) <= (DB ? 2 : 1) * (BM + BN) * (64 + 8), "staging tile must fit the operand buffers");
             epilogue_rows_lds<BM, BN, TM, TN>(p, acc, b1, b2, m0, n0, wr, wc, lane, &As[0][0]);
@@ -606,13 +882,13 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmDev& p, const int bx, c
     }
 }
 
-template <typename TC, int BM, int BN, bool TA, bool TB, bool DB>
+template <typename TC, int BM, int BN, bool TA, bool TB, bool DB, int FFN = 0>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmDev p) {
     // ONE buffer: A slabs first, B slabs behind them -- the epilogue reuses it from the start as its C staging tile
     __shared__ __attribute__((aligned(16))) bf16_t smem[(DB ? 2 : 1) * (BM + BN) * (64 + 8)];
-    gemm_bf16_body<TC, BM, BN, TA, TB, DB>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y,
-                                           reinterpret_cast<bf16_t(*)[BM * (64 + 8)]>(smem),
-                                           reinterpret_cast<bf16_t(*)[BN * (64 + 8)]>(smem + (DB ? 2 : 1) * BM * (64 + 8)));
+    gemm_bf16_body<TC, BM, BN, TA, TB, DB, FFN>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y,
+                                                reinterpret_cast<bf16_t(*)[BM * (64 + 8)]>(smem),
+                                                reinterpret_cast<bf16_t(*)[BN * (64 + 8)]>(smem + (DB ? 2 : 1) * BM * (64 + 8)));
 }
 
 // One launch for the two gradient GEMMs of a Linear: problem A = dX = dY W (row-major operands, bf16 out), problem B = dW = dY^T X
@@ -627,11 +903,13 @@ __global__ __launch_bounds__(256, 2) void gemm_pair_kernel(GemmPairDev q) {
     int lin = blockIdx.x;
     if (lin < q.nA) {
         const int bx = lin % q.gxA; lin /= q.gxA;
-        gemm_bf16_body<bf16_t, 64, 64, false, false, true>(q.a, bx, lin % q.gyA, lin / q.gyA, q.gxA, q.gyA, As, Bs);
+        if (q.a.ffn.mode == TC_FFN_EP) gemm_bf16_body<bf16_t, 64, 64, false, false, true, TC_FFN_EP>(q.a, bx, lin % q.gyA, lin / q.gyA, q.gxA, q.gyA, As, Bs);
+        else gemm_bf16_body<bf16_t, 64, 64, false, false, true>(q.a, bx, lin % q.gyA, lin / q.gyA, q.gxA, q.gyA, As, Bs);
     } else {
         lin -= q.nA;
         const int bx = lin % q.gxB; lin /= q.gxB;
-        gemm_bf16_body<float, 64, 64, true, false, true>(q.b, bx, lin % q.gyB, lin / q.gyB, q.gxB, q.gyB, As, Bs);
+        if (q.b.ffn.mode == TC_FFN_LN_B) gemm_bf16_body<float, 64, 64, true, false, true, TC_FFN_LN_B>(q.b, bx, lin % q.gyB, lin / q.gyB, q.gxB, q.gyB, As, Bs);
+        else gemm_bf16_body<float, 64, 64, true, false, true>(q.b, bx, lin % q.gyB, lin / q.gyB, q.gxB, q.gyB, As, Bs);
     }
 }
 
@@ -649,10 +927,15 @@ __global__ __launch_bounds__(256, 2) void gemm_multi_kernel(GemmMultiDev q) {
     for (int j = 1; j < q.n; ++j) if (lin >= q.blk0[j]) i = j;
     lin -= q.blk0[i];
     const int gx = q.gx[i], gy = q.gy[i], bx = lin % gx, by = (lin / gx) % gy, bz = lin / (gx * gy);
-    const GemmDev& p = q.p[i];
+    // a private copy of the one descriptor: with six inlined bodies reading fields through a reference into the 4 KB argument block
+    // the compiler stopped forwarding the loads to the kernel-argument segment and copied the whole block to scratch
+    const GemmDev p = q.p[i];
     if (q.kind[i] == 0) gemm_bf16_body<bf16_t, 64, 64, false, true, true>(p, bx, by, bz, gx, gy, As, Bs);
     else if (q.kind[i] == 1) gemm_bf16_body<bf16_t, 64, 64, false, false, true>(p, bx, by, bz, gx, gy, As, Bs);
-    else gemm_bf16_body<float, 64, 64, true, false, true>(p, bx, by, bz, gx, gy, As, Bs);
+    else if (q.kind[i] == 2) gemm_bf16_body<float, 64, 64, true, false, true>(p, bx, by, bz, gx, gy, As, Bs);
+    else if (q.kind[i] == 3) gemm_bf16_body<bf16_t, 64, 64, false, true, true, TC_FFN_LN_A>(p, bx, by, bz, gx, gy, As, Bs);
+    else if (q.kind[i] == 4) gemm_bf16_body<bf16_t, 64, 64, false, false, true, TC_FFN_EP>(p, bx, by, bz, gx, gy, As, Bs);
+    else gemm_bf16_body<float, 64, 64, true, false, true, TC_FFN_LN_B>(p, bx, by, bz, gx, gy, As, Bs);
 }
 
 // ---------------------------------------------------------------------------------------------- host side
@@ -661,6 +944,21 @@ void launch_one(const GemmDev& d, dim3 grid, hipStream_t s) {
     if constexpr (sizeof(T) == 4) hipLaunchKernelGGL((gemm_kernel<TC, BM, BN, TA, TB>), grid, dim3(256), 0, s, d);
     else if (d.kchunk > 128) hipLaunchKernelGGL((gemm_bf16_kernel<TC, BM, BN, TA, TB, true>), grid, dim3(256), 0, s, d);
     else hipLaunchKernelGGL((gemm_bf16_kernel<TC, BM, BN, TA, TB, false>), grid, dim3(256), 0, s, d);
+}
+
+// the three hooked products (64x64 tiles; gemm_plan has checked operand kinds and output types)
+template <typename T>
+int launch_ffn(const GemmDev& d, dim3 grid, hipStream_t s) {
+    if constexpr (sizeof(T) == 4) {
+        if (d.ffn.mode == TC_FFN_LN_A) hipLaunchKernelGGL((gemm_kernel<float, 64, 64, false, true, TC_FFN_LN_A>), grid, dim3(256), 0, s, d);
+        else if (d.ffn.mode == TC_FFN_LN_B) hipLaunchKernelGGL((gemm_kernel<float, 64, 64, true, false, TC_FFN_LN_B>), grid, dim3(256), 0, s, d);
+        else hipLaunchKernelGGL((gemm_kernel<float, 64, 64, false, false, TC_FFN_EP>), grid, dim3(256), 0, s, d);
+    } else {
+        if (d.ffn.mode == TC_FFN_LN_A) hipLaunchKernelGGL((gemm_bf16_kernel<bf16_t, 64, 64, false, true, true, TC_FFN_LN_A>), grid, dim3(256), 0, s, d);
+        else if (d.ffn.mode == TC_FFN_LN_B) hipLaunchKernelGGL((gemm_bf16_kernel<float, 64, 64, true, false, true, TC_FFN_LN_B>), grid, dim3(256), 0, s, d);
+        else hipLaunchKernelGGL((gemm_bf16_kernel<bf16_t, 64, 64, false, false, true, TC_FFN_EP>), grid, dim3(256), 0, s, d);
+    }
+    return tc_launch_status();
 }
 
 template <typename T, typename TC, int BM, int BN>
@@ -684,6 +982,12 @@ bool gemm_plan(const TcGemm* g, GemmDev& d, dim3& grid, bool& use128_out, bool f
     d.rowsum = g->rowsum;
     d.sBias1 = g->sBias1; d.sRow1 = g->sRow1;
     d.bgap_every = g->bgap_every; d.bgap = g->bgap;
+    d.ffn.mode = g->ffn_mode; d.ffn.nchunk = g->ffn_nchunk; d.ffn.chunk_n = g->ffn_chunk_n; d.ffn.ldd = g->ffn_ldd;
+    d.ffn.sRow1 = (int)g->ffn_sRow1; d.ffn.sPar1 = (int)g->ffn_sPar1; d.ffn.eps = g->ffn_eps;
+    d.ffn.part = g->ffn_part; d.ffn.stat = g->ffn_stat; d.ffn.gamma = g->ffn_gamma; d.ffn.beta = g->ffn_beta;
+    d.ffn.d = g->ffn_mode == TC_FFN_LN_A ? g->ffn_aout : g->ffn_d;      // one slot: EP reads d there, LN_A may write the activated rows
+    d.ffn.part2 = g->ffn_part2;
+    if (g->ffn_mode) force64 = true;
     constexpr int VEC = 16 / (int)sizeof(T);                         // elements per 16-byte vector
     auto aligned = [&](const void* ptr, int ld, long long s1, long long s2) {
         return ((uintptr_t)ptr % 16 == 0) && (ld % VEC == 0) && (s1 % VEC == 0) && (s2 % VEC == 0);
@@ -719,7 +1023,7 @@ bool gemm_plan(const TcGemm* g, GemmDev& d, dim3& grid, bool& use128_out, bool f
 #define GEMM_AS_TARGET 512
 #define GEMM_AS_KPER 256
 #endif
-        if (want == 1 && !g->atomic && g->K >= 2 * GEMM_AS_KPER && tiles64 <= GEMM_AS_TILES) {
+        if (want == 1 && !g->atomic && g->ffn_mode != TC_FFN_EP && g->K >= 2 * GEMM_AS_KPER && tiles64 <= GEMM_AS_TILES) {
             long long sk = GEMM_AS_TARGET / tiles64;
             if (sk > g->K / GEMM_AS_KPER) sk = g->K / GEMM_AS_KPER;
             if (sk > FIX_GROUP) sk = FIX_GROUP;
@@ -747,6 +1051,19 @@ bool gemm_plan(const TcGemm* g, GemmDev& d, dim3& grid, bool& use128_out, bool f
     d.atomic = ((d.splitk > 1 && !d.fix_group) || g->atomic) ? 1 : 0;
     grid = dim3((g->N + BN - 1) / BN, (g->M + BM - 1) / BM, nb * d.splitk);
     use128_out = use128;
+    if (g->ffn_mode) {
+        // the hooked kernels assume whole 16-byte strips everywhere and, for EP, the LDS-staged plain-store epilogue
+        if (!d.vecA || !d.vecB || (g->ffn_mode != TC_FFN_LN_B && g->K % VEC) || g->N % VEC || g->nb2 != 1 || (uintptr_t)g->ffn_gamma % 16 || (uintptr_t)g->ffn_beta % 16 ||
+            g->ffn_sPar1 % VEC)
+            return false;
+        if (g->ffn_mode == TC_FFN_LN_A && (g->transA || !g->transB || g->c_f32 || g->K != g->ffn_nchunk * g->ffn_chunk_n ||
+                                           (g->ffn_aout && ((uintptr_t)g->ffn_aout % 16 || g->ffn_ldd % VEC))))
+            return false;
+        if (g->ffn_mode == TC_FFN_LN_B && (!g->transA || g->transB || !(g->c_f32 || sizeof(T) == 4))) return false;
+        if (g->ffn_mode == TC_FFN_EP && (g->transA || g->transB || g->c_f32 || g->accumulate || g->atomic || d.splitk != 1 || g->bias || g->R ||
+                                         g->act != TC_ACT_NONE || (sizeof(T) == 2 && !d.vec8C) || (uintptr_t)g->ffn_d % 16 || g->ffn_ldd % VEC))
+            return false;
+    }
     return grid.y <= 65535 && grid.z <= 65535;
 }
 
@@ -756,6 +1073,7 @@ int gemm_typed(const TcGemm* g, hipStream_t s) {
     dim3 grid;
     bool use128;
     if (!gemm_plan<T>(g, d, grid, use128)) return TC_ERR_ARG;
+    if (g->ffn_mode) return launch_ffn<T>(d, grid, s);
     if (g->c_f32)
         return use128 ? launch<T, float, 128, 128>(d, g->transA, g->transB, grid, s)
                       : launch<T, float, 64, 64>(d, g->transA, g->transB, grid, s);
@@ -771,6 +1089,13 @@ static bool gemm_args_ok(const TcGemm* g) {
     if ((g->splitk > 1 || g->atomic) && (!g->accumulate || (g->dtype != TC_F32 && !g->c_f32) || g->act != TC_ACT_NONE)) return false;
     if (g->act != TC_ACT_NONE && g->act != TC_ACT_SIGMOID) return false;
     if (g->bgap_every < 0 || (g->bgap_every > 0 && (g->transB || g->bgap_every % 64 || (g->bgap % 8)))) return false;
+    if (g->ffn_mode < TC_FFN_NONE || g->ffn_mode > TC_FFN_EP) return false;
+    if (g->ffn_mode != TC_FFN_NONE) {
+        if (!g->ffn_gamma || !g->ffn_beta || !g->ffn_stat || g->bgap_every) return false;
+        if (g->ffn_mode == TC_FFN_LN_A && (!g->ffn_part || g->ffn_nchunk < 1 || g->ffn_chunk_n < 1)) return false;
+        if (g->ffn_mode == TC_FFN_EP && (!g->ffn_d || !g->ffn_part2)) return false;
+        if (g->ffn_sRow1 < 0 || g->ffn_sRow1 > 0x7fffffffLL || g->ffn_sPar1 < 0 || g->ffn_sPar1 > 0x7fffffffLL) return false;
+    }
     return true;
 }
 
@@ -784,7 +1109,8 @@ extern "C" int tc_gemm(const TcGemm* g, void* stream) {
 extern "C" int tc_gemm_pair(const TcGemm* a, const TcGemm* b, void* stream) {
     if (!gemm_args_ok(a) || !gemm_args_ok(b)) return TC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    if (a->dtype == TC_BF16 && b->dtype == TC_BF16 && !a->transA && !a->transB && !a->c_f32 && b->transA && !b->transB && b->c_f32) {
+    if (a->dtype == TC_BF16 && b->dtype == TC_BF16 && !a->transA && !a->transB && !a->c_f32 && b->transA && !b->transB && b->c_f32 &&
+        (a->ffn_mode == TC_FFN_NONE || a->ffn_mode == TC_FFN_EP) && (b->ffn_mode == TC_FFN_NONE || b->ffn_mode == TC_FFN_LN_B)) {
         GemmPairDev q;
         dim3 ga, gb;
         bool bigA, bigB;
@@ -812,9 +1138,9 @@ extern "C" int tc_gemm_multi(const TcGemm* g, int n, void* stream) {
     for (int i = 0; ok && i < n; ++i) {
         const TcGemm& t = g[i];
         int kind = -1;
-        if (t.dtype == TC_BF16 && !t.transA && t.transB && !t.c_f32) kind = 0;
-        else if (t.dtype == TC_BF16 && !t.transA && !t.transB && !t.c_f32) kind = 1;
-        else if (t.dtype == TC_BF16 && t.transA && !t.transB && t.c_f32) kind = 2;
+        if (t.dtype == TC_BF16 && !t.transA && t.transB && !t.c_f32) kind = t.ffn_mode == TC_FFN_LN_A ? 3 : (t.ffn_mode ? -1 : 0);
+        else if (t.dtype == TC_BF16 && !t.transA && !t.transB && !t.c_f32) kind = t.ffn_mode == TC_FFN_EP ? 4 : (t.ffn_mode ? -1 : 1);
+        else if (t.dtype == TC_BF16 && t.transA && !t.transB && t.c_f32) kind = t.ffn_mode == TC_FFN_LN_B ? 5 : (t.ffn_mode ? -1 : 2);
         bool big;
         if (kind < 0 || !gemm_plan<bf16_t>(&t, plan[i], grids[i], big, true)) { ok = false; break; }
         kinds[i] = kind; order[i] = i;

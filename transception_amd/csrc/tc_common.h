@@ -11,11 +11,16 @@ typedef unsigned short bf16_t;
 #define TC_WAVE 64
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    unsigned u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);          // round to nearest even (NaN payloads not preserved)
-    return (bf16_t)(u >> 16);
+// fp32 -> bf16, round to nearest even, through the hardware conversion (v_cvt_pk_bf16_f32 on gfx950: ONE instruction per pair; the
+// integer form -- add 0x7fff + lsb, shift, mask, or -- cost ~5.5 VALU operations per element, a third of the arithmetic of the
+// element-wise kernels that store bf16).
+typedef float tc_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 tc_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+    const tc_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, tc_bf16x2));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, 0.f) & 0xffffu); }
 
 template <typename T> __device__ __forceinline__ float ldf(const T* p);
 template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
@@ -36,8 +41,8 @@ template <typename T> __device__ __forceinline__ void st4(T* p, float4 v);
 template <> __device__ __forceinline__ void st4<float>(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, float4 v) {
     uint2 r;
-    r.x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
-    r.y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
+    r.x = pack2bf(v.x, v.y);
+    r.y = pack2bf(v.z, v.w);
     *reinterpret_cast<uint2*>(p) = r;
 }
 
@@ -69,6 +74,26 @@ __device__ __forceinline__ float gelu_cdf_pdf(float x, float& pdf) {
     return x >= 0.f ? 1.0f - half_erfc : half_erfc;               // Phi(x)
 }
 __device__ __forceinline__ float gelu_f(float x) { float pdf; return x * gelu_cdf_pdf(x, pdf); }
+// Two elements at a time on the packed fp32 pipe (v_pk_mul / v_pk_fma / v_pk_add: two lanes of arithmetic per issue slot; only
+// the two exp and the two reciprocals stay scalar transcendental issues) -- same formula, same rounding per element.
+__device__ __forceinline__ tc_f32x2 gelu_cdf_pdf2(tc_f32x2 x, tc_f32x2& pdf) {
+    const tc_f32x2 ax = {fabsf(x.x), fabsf(x.y)};
+    const tc_f32x2 z = ax * 0.70710678118654752440f;
+    const tc_f32x2 nz2 = -z * z;
+    const tc_f32x2 g = {__expf(nz2.x), __expf(nz2.y)};
+    const tc_f32x2 den = z * 0.3275911f + 1.0f;
+    const tc_f32x2 t = {__frcp_rn(den.x), __frcp_rn(den.y)};
+    tc_f32x2 poly = t * 1.061405429f + (-1.453152027f);
+    poly = poly * t + 1.421413741f;
+    poly = poly * t + (-0.284496736f);
+    poly = poly * t + 0.254829592f;
+    const tc_f32x2 half_erfc = poly * t * g * 0.5f;
+    pdf = g * 0.39894228040143267794f;
+    const tc_f32x2 one_m = 1.0f - half_erfc;
+    return tc_f32x2{x.x >= 0.f ? one_m.x : half_erfc.x, x.y >= 0.f ? one_m.y : half_erfc.y};
+}
+__device__ __forceinline__ tc_f32x2 gelu_f2(tc_f32x2 x) { tc_f32x2 pdf; return x * gelu_cdf_pdf2(x, pdf); }
+__device__ __forceinline__ tc_f32x2 gelu_grad_f2(tc_f32x2 x) { tc_f32x2 pdf; const tc_f32x2 cdf = gelu_cdf_pdf2(x, pdf); return cdf + x * pdf; }
 __device__ __forceinline__ float gelu_grad_f(float x) {
     float pdf;
     const float cdf = gelu_cdf_pdf(x, pdf);

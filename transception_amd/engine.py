@@ -18,7 +18,8 @@ from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
 
-from ._lib import (ACT_COORD, ACT_GELU, ACT_HSWISH, ACT_NONE, ACT_SIGMOID, TC_BF16, TC_F32, TcDwSeg, TcGemm, lib)
+from ._lib import (ACT_COORD, ACT_GELU, ACT_HSWISH, ACT_NONE, ACT_SIGMOID, FFN_EP, FFN_LN_A, FFN_LN_B, TC_BF16, TC_F32, TcDwSeg, TcFfnSeg,
+                   TcGemm, lib)
 
 _DT = {torch.float32: TC_F32, torch.bfloat16: TC_BF16}
 
@@ -157,6 +158,7 @@ _GEMM_PAIR = os.environ.get("TC_GEMM_PAIR", "1") != "0"
 _N_WSTREAMS = int(os.environ.get("TC_WGRAD_STREAMS", "4"))
 _NO_PENDING = bool(os.environ.get("TC_DEBUG_NO_PENDING"))   # timing what-if only (racy)
 _SKIP_WGRAD = bool(os.environ.get("TC_DEBUG_SKIP_WGRAD"))
+_FFN_STORE_ACT = os.environ.get("TC_FFN_STORE_ACT", "1") != "0"   # MixFFN: keep GELU(LN(d)) from the forward pass (0: recompute it in dW2's loader)
 _POISON = bool(os.environ.get("TC_DEBUG_POISON"))         # fill every fresh buffer with NaN: finds reads of memory no kernel wrote
 
 
@@ -634,6 +636,166 @@ class Graph:
                 self.L.tc_gemm(C.byref(gb), self.stream)
         self._rec(bwd)
         return out
+
+    # ------------------------------------------------------------------ MixFFN_skip, fused
+    def _launch_gemms(self, descs: List[TcGemm]):
+        """One launch for a list of GEMM problems: tc_gemm, the dX / dW pair kernel, or the merged grid (<= 12 problems)."""
+        if not descs:
+            return
+        self.n_launch += 1
+        if len(descs) == 1:
+            self.L.tc_gemm(C.byref(descs[0]), self.stream)
+        elif len(descs) == 2 and not descs[0].transA and not descs[0].transB and descs[1].transA and not descs[1].transB:
+            self.L.tc_gemm_pair(C.byref(descs[0]), C.byref(descs[1]), self.stream)
+        else:
+            for c0 in range(0, len(descs), 12):
+                chunk = descs[c0:c0 + 12]
+                self.L.tc_gemm_multi((TcGemm * len(chunk))(*chunk), len(chunk), self.stream)
+
+    def mixffn(self, sites: List[dict]) -> List[Var]:
+        """MixFFN_skip (MSTr.py:889-902, fc1 evaluated once): out = fc2(GELU(LN(dw3x3(h) + h))) + residual, h = fc1(x), for one site
+        (optionally `ngroups` stacked weight groups) or several independent sites (the four scales of a bridge layer) level by level.
+
+        Forward = 3 launches: fc1 GEMM; depthwise conv + skip that also leaves LayerNorm chunk partials (tc_ffn_dw_fwd); fc2 GEMM whose
+        A-operand loader applies LayerNorm + GELU (TC_FFN_LN_A) -- the normalised / activated hidden map never exists.
+        Backward = 3 launches: {fc2 input gradient with GELU' and the LayerNorm row sums in its epilogue (TC_FFN_EP), fc2 weight gradient
+        recomputing GELU(LN(d)) in its B loader (TC_FFN_LN_B)}; tc_ffn_mid_bwd (LayerNorm backward + depthwise input and weight gradients +
+        LayerNorm parameter gradients); {fc1 input gradient, fc1 weight gradient}.  The unfused form takes 4 + 5 launches per site and
+        6 + 10 passes over hidden-width maps; this one 4 + 8.
+        site = dict(x, fc1=(W, b), dw=(w, b), ln=(g, b), fc2=(W, b), geo=(B, H, W), residual=None|Var, out=None|Var)."""
+        n, Gn, L = len(sites), self.ngroups, self.L
+        assert n >= 1 and (Gn == 1 or n == 1)
+        gs = self.pgs if Gn > 1 else 0
+        many = n > 1
+        wsb = _workspace(self.dev, self.stream, "many") if many else None
+        sl = (wsb.numel() // 8) & ~16383 if many else 0
+
+        def desc(i, *a, **k):
+            if not many:
+                return self._gemm_desc(*a, **k)
+            g = self._gemm_desc(*a, use_ws=False, **{kk: vv for kk, vv in k.items() if kk != "use_ws"})
+            if i < 8 and k.get("use_ws", True):
+                g.ws, g.ws_bytes = wsb.data_ptr() + i * sl, sl
+            return g
+
+        st = []
+        for s_ in sites:
+            x = s_["x"]
+            (W1, b1), (wd, bd), (lg, lb), (W2, b2) = s_["fc1"], s_["dw"], s_["ln"], s_["fc2"]
+            B, H, W = s_["geo"]
+            C4, Cin = W1.data.shape
+            M = x.rows // Gn
+            assert x.cols == Cin and M == B * H * W and W2.data.shape == (Cin, C4)
+            cn = int(L.tc_ffn_chunk(C4, self.dt))
+            assert cn > 0 and C4 % cn == 0 and C4 % 8 == 0
+            out = s_.get("out")
+            if out is None:
+                out = self.new(x.rows, Cin)
+            # stacked weight groups write row blocks of `out`, or -- the last MB layer -- column blocks of the IFF concat buffer
+            side = Gn > 1 and out.rows == M and out.cols == Gn * Cin
+            assert side or (out.rows == x.rows and out.cols == Cin)
+            st.append(dict(so=Cin if side else M * out.ld, side=side, x=x, W1=W1, b1=b1, wd=wd, bd=bd, lg=lg, lb=lb, W2=W2, b2=b2, B=B, H=H, W=W, C4=C4, Cin=Cin, M=M, cn=cn,
+                           nch=C4 // cn, nch2=(C4 + 63) // 64, res=s_.get("residual"), out=out,
+                           h=_empty((x.rows, C4), self.dtype, self.dev), d=_empty((x.rows, C4), self.dtype, self.dev),
+                           a=_empty((x.rows, C4), self.dtype, self.dev) if _FFN_STORE_ACT else None,
+                           part=self.f32(x.rows * (C4 // cn) * 2), stat=self.f32(x.rows * 2)))
+
+        def hook(g: TcGemm, t, mode):
+            g.ffn_mode, g.ffn_nchunk, g.ffn_chunk_n, g.ffn_ldd, g.ffn_eps = mode, t["nch"], t["cn"], t["C4"], 1e-5
+            g.ffn_part, g.ffn_stat, g.ffn_gamma, g.ffn_beta = _ptr(t["part"]), _ptr(t["stat"]), _ptr(t["lg"].data), _ptr(t["lb"].data)
+            g.ffn_d = _ptr(t["d"])
+            g.ffn_sRow1, g.ffn_sPar1 = t["M"], gs
+            if mode == FFN_LN_A and t["a"] is not None:
+                g.ffn_aout = _ptr(t["a"])
+            return g
+
+        # fc1
+        self._launch_gemms([desc(i, _ptr(t["x"].data), t["x"].ld, _ptr(t["W1"].data), t["Cin"], _ptr(t["h"]), t["C4"], t["M"], t["C4"], t["Cin"], 0, 1,
+                                 bias=_ptr(t["b1"].data), nb1=Gn, sA=(t["M"] * t["x"].ld, 0), sB=(gs, 0), sC=(t["M"] * t["C4"], 0), sbias=gs)
+                            for i, t in enumerate(st)])
+        # depthwise 3x3 + bias + skip, LayerNorm chunk partials on the side
+        if not many:
+            t = st[0]
+            L.tc_ffn_dw_fwd(_ptr(t["h"]), t["C4"], _ptr(t["wd"].data), _ptr(t["bd"].data), _ptr(t["d"]), t["C4"], _ptr(t["part"]), t["B"], t["H"],
+                            t["W"], t["C4"], Gn, gs, self.dt, self.stream)
+        else:
+            assert n <= 4
+            arr = (TcDwSeg * n)()
+            for i, t in enumerate(st):
+                arr[i] = TcDwSeg(_ptr(t["h"]), _ptr(t["wd"].data), _ptr(t["bd"].data), _ptr(t["d"]), None, None, None, t["C4"], 3, t["C4"], t["C4"], 0,
+                                 t["B"], t["H"], t["W"], _ptr(t["part"]))
+            L.tc_dwconv_multi(arr, n, 0, 1, 0, 1, 0, None, 0, self.dt, self.stream)
+        # fc2 on GELU(LN(d)) (+ bias + residual)
+        fw = []
+        for i, t in enumerate(st):
+            out, res = t["out"], t["res"]
+            fw.append(hook(desc(i, _ptr(t["d"]), t["C4"], _ptr(t["W2"].data), t["C4"], _ptr(out.data), out.ld, t["M"], t["Cin"], t["C4"], 0, 1,
+                                bias=_ptr(t["b2"].data), R=_ptr(res.data) if res is not None else None, ldr=res.ld if res is not None else 0,
+                                nb1=Gn, sA=(t["M"] * t["C4"], 0), sB=(gs, 0), sC=(t["so"], 0),
+                                sR=(t["M"] * res.ld if res is not None else 0, 0), sbias=gs), t, FFN_LN_A))
+        self._launch_gemms(fw)
+
+        def bwd():
+            dys = [self.grad_of(t["out"]) for t in st]
+            if all(d is None for d in dys):
+                return
+            assert all(d is not None for d in dys)
+            # fc2: gp = (dY W2) (.) GELU'(u) with the LayerNorm row sums, and dW2 = dY^T GELU(LN(d)) (+ db2)
+            g1 = []
+            for i, (t, dy) in enumerate(zip(st, dys)):
+                t["gp"] = _empty((t["x"].rows, t["C4"]), self.dtype, self.dev)
+                t["part2"] = self.f32(t["x"].rows * t["nch2"] * 2)
+                ga = hook(desc(i, _ptr(dy), dy.stride(0), _ptr(t["W2"].data), t["C4"], _ptr(t["gp"]), t["C4"], t["M"], t["C4"], t["Cin"], 0, 0,
+                               nb1=Gn, sA=(t["so"], 0), sB=(gs, 0), sC=(t["M"] * t["C4"], 0), use_ws=False), t, FFN_EP)
+                ga.ffn_part2 = _ptr(t["part2"])
+                g1.append(ga)
+            for i, (t, dy) in enumerate(zip(st, dys)):
+                if t["W2"].grad is None:
+                    continue
+                # dW2 = dY^T a: `a` as stored by the forward fc2 kernel, or recomputed from d in the B loader (TC_FFN_LN_B)
+                gb = desc(n + i, _ptr(dy), dy.stride(0), _ptr(t["a"] if t["a"] is not None else t["d"]), t["C4"], _ptr(t["W2"].grad), t["C4"], t["Cin"],
+                          t["C4"], t["M"], 1, 0, acc=1, splitk=self._splitk(t["Cin"], t["C4"], t["M"]), c_f32=1, nb1=Gn, sA=(t["so"], 0),
+                          sB=(t["M"] * t["C4"], 0), sC=(gs, 0), rowsum=_ptr(t["b2"].grad) if t["b2"].grad is not None else None, srow=gs,
+                          use_ws=False)
+                g1.append(gb if t["a"] is not None else hook(gb, t, FFN_LN_B))
+            self._launch_gemms(g1)
+            # LayerNorm backward + depthwise input / weight gradients + LayerNorm parameter gradients
+            segs = (TcFfnSeg * n)()
+            for i, t in enumerate(st):
+                t["dh"] = _empty((t["x"].rows, t["C4"]), self.dtype, self.dev)
+                hg = t["wd"].grad is not None
+                segs[i] = TcFfnSeg(_ptr(t["gp"]), _ptr(t["d"]), _ptr(t["h"]), _ptr(t["dh"]), _ptr(t["stat"]), _ptr(t["part2"]), _ptr(t["wd"].data),
+                                   _ptr(t["lg"].data), _ptr(t["wd"].grad) if hg else None, _ptr(t["bd"].grad) if hg else None,
+                                   _ptr(t["lg"].grad) if hg else None, _ptr(t["lb"].grad) if hg else None,
+                                   t["C4"], t["C4"], t["C4"], t["C4"], t["C4"], t["B"], t["H"], t["W"], t["nch2"])
+            ws = _workspace(self.dev, self.stream)
+            L.tc_ffn_mid_bwd(segs, n, Gn, gs, ws.data_ptr(), ws.numel(), self.dt, self.stream)
+            # fc1: dX = dh W1, dW1 = dh^T x (+ db1)
+            g2 = []
+            for i, t in enumerate(st):
+                x = t["x"]
+                if x.requires_grad:
+                    gx, acc = self.wgrad(x)
+                    g2.append(desc(i, _ptr(t["dh"]), t["C4"], _ptr(t["W1"].data), t["Cin"], _ptr(gx), gx.stride(0), t["M"], t["Cin"], t["C4"], 0, 0,
+                                   acc=acc, nb1=Gn, sA=(t["M"] * t["C4"], 0), sB=(gs, 0), sC=(t["M"] * gx.stride(0), 0)))
+            for i, t in enumerate(st):
+                if t["W1"].grad is not None:
+                    x = t["x"]
+                    g2.append(desc(n + i, _ptr(t["dh"]), t["C4"], _ptr(x.data), x.ld, _ptr(t["W1"].grad), t["Cin"], t["C4"], t["Cin"], t["M"], 1, 0,
+                                   acc=1, splitk=self._splitk(t["C4"], t["Cin"], t["M"]), c_f32=1, nb1=Gn, sA=(t["M"] * t["C4"], 0),
+                                   sB=(t["M"] * x.ld, 0), sC=(gs, 0), rowsum=_ptr(t["b1"].grad) if t["b1"].grad is not None else None, srow=gs,
+                                   use_ws=False))
+            self._launch_gemms(g2)
+            for t, dy in zip(st, dys):
+                if t["res"] is not None:
+                    if t["side"]:
+                        self._pass_grad_batched(t["res"], dy, Gn, t["M"], t["Cin"], t["so"], t["M"] * t["res"].ld)
+                    else:
+                        self.pass_grad(t["res"], dy)
+                for k in ("gp", "part2", "dh"):
+                    t.pop(k, None)
+        self._rec(bwd)
+        return [t["out"] for t in st]
 
     def _pass_grad_batched(self, v: Var, src: torch.Tensor, nb: int, M: int, N: int, sb_src: int, sb_dst: Optional[int] = None):
         sb_dst = sb_src if sb_dst is None else sb_dst

@@ -457,8 +457,19 @@ def _bn(M, G, x, name, act, residual=None, out=None):
                        residual, out)
 
 
+FUSED_MIXFFN = os.environ.get("TC_FUSED_MIXFFN", "1") != "0"
+
+
+def _mixffn_site(M, G, x, name, B, H, W, residual, out=None) -> dict:
+    return dict(x=x, fc1=_lin(M, G, name + ".fc1"), dw=(M._P(G, name + ".dwconv.dwconv.weight"), M._P(G, name + ".dwconv.dwconv.bias")),
+                ln=(M._P(G, name + ".norm1.weight"), M._P(G, name + ".norm1.bias")), fc2=_lin(M, G, name + ".fc2"), geo=(B, H, W),
+                residual=residual, out=out)
+
+
 def _mixffn(M, G, x, name, B, H, W, residual, out=None):
     """MixFFN_skip, MSTr.py:889-902 (fc1 evaluated once): fc2(GELU(LN(dw3x3(h) + h))) + residual."""
+    if FUSED_MIXFFN and not G.use_streams and x.data.is_contiguous():
+        return G.mixffn([_mixffn_site(M, G, x, name, B, H, W, residual, out)])[0]     # 3 + 3 launches (engine.Graph.mixffn)
     h = G.linear(x, *_lin(M, G, name + ".fc1"))                 # B = images per weight group (G.ngroups groups are stacked)
     d = G.dwconv(h, M._P(G, name + ".dwconv.dwconv.weight"), M._P(G, name + ".dwconv.dwconv.bias"), B, H, W, 3, 1, True)
     a = _ln(M, G, d, name + ".norm1", act=ACT_GELU)
@@ -697,6 +708,10 @@ def _bridge_layer(M, G, X: Var, li: int, B: int, sides, ntok, R, N6) -> Var:
     tx2 = G.new(B * N6, 64)
     geo = [(B * sides[s] * sides[s], 64 * MULT[s]) for s in range(4)]
     view = lambda v, s: v.rowslice(R[s], R[s + 1]).reshape(*geo[s])
+    if FUSED_MIXFFN and MANY_MIXFFN and not G.use_streams:
+        # the four per-scale MixFFNs as ONE fused site list: 3 forward + 3 backward launches for all four scales
+        G.mixffn([_mixffn_site(M, G, view(tx, s), f"{name}.mixffn{s + 1}", B, sides[s], sides[s], view(tx1, s), view(tx2, s)) for s in range(4)])
+        return tx2
     if MANY_MIXFFN and not G.use_streams:
         # the four per-scale MixFFNs level by level: fc1 x4 in one launch, dw x4, LN x4, fc2 x4 in one launch (and the eight
         # gradient GEMMs of each level in one launch): four independent chains of small kernels share the CUs
