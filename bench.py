@@ -355,8 +355,18 @@ def side_figures(args, dev, model, loss_fn, opt, step, x, y, build_model, engine
                         "launches": len(ev), "avg_launch_us": 1e3 * ms / len(ev), "algorithmic_bytes_per_launch": by / len(ev)})
     if hbm:
         hbm.sort(key=lambda r: -r["avg_launch_us"] * r["launches"])
-        roofs["roofline_hbm"] = dict(hbm[0], how="HIP events around each launch inside 3 instrumented steps; algorithmic bytes = every "
-                                                "operand read once + every result written once", traffic=None)
+        top = dict(hbm[0], how="HIP events around each launch inside 3 instrumented steps; algorithmic bytes = every operand read once + "
+                               "every result written once (the memory-bound family with the largest share of the step)", traffic=None,
+                   traffic_source=None)
+        pmc = os.path.join(ROOT, "profiles", "r2_hbm_by_kernel.json")       # per-launch memory-side bytes from the committed PMC passes
+        if args.dtype == "bf16" and args.batch == 16 and args.size == 224 and os.path.exists(pmc):
+            doc = json.load(open(pmc)).get("kernels", {})
+            key = next((k for k in doc if k.split("<")[0].split("_kernel")[0] in top["kernel"]), None)
+            if key:
+                top["traffic"] = doc[key]["bytes_per_step"] / max(doc[key]["launches_per_step"], 1)
+                top["traffic_source"] = ("profiles/r2_hbm_by_kernel.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of this workload, "
+                                         "scripts/pmc_step.sh; not measured in this run)")
+        roofs["roofline_hbm"] = top
         roofs["roofline_hbm_others"] = hbm[1:6]
     # (2) forward-only rate (train-mode forward captured alone)
     with torch.no_grad():

@@ -894,7 +894,7 @@ struct FfnSegDev {
     int C, ldg, ldd, ldh, lddh, B, H, W, nch2, chunks, tilesW, tilesH, gx, blk0;
 };
 constexpr int FFN_MULTI_MAX = 4;
-struct FfnMultiDev { FfnSegDev s[FFN_MULTI_MAX]; int n; long long wstride; };
+struct FfnMultiDev { FfnSegDev s[FFN_MULTI_MAX]; int n; int dbg_nofold; long long wstride; };
 
 template <typename T> struct FfnTile {
     static constexpr int K = 3, CG = 8, VEC = Vec16<T>::N, CH = CG * VEC, R = 4, TW = 16, TH = 8, P = 1, IW = TW + 2, IH = TH + 2;
@@ -904,7 +904,7 @@ template <typename T> struct FfnTile {
 
 template <typename T, bool PF>
 __device__ __forceinline__ void ffn_mid_bwd_body(const FfnSegDev& a, long long wstride, const int bx, const int by, const int bz,
-                                                 uint4* smem) {
+                                                 uint4* smem, const int dbg_nofold = 0) {
     using D = FfnTile<T>;
     constexpr int K = D::K, CG = D::CG, VEC = D::VEC, CH = D::CH, R = D::R, IW = D::IW, IH = D::IH, PIXQ = D::PIXQ, NT = D::NT;
     constexpr int NPIX = IH * IW, NX = (NPIX * CG + 255) / 256, RG = (256 / CG) / K, UNITS = D::TH * (D::TW / R);
@@ -948,7 +948,9 @@ __device__ __forceinline__ void ffn_mid_bwd_body(const FfnSegDev& a, long long w
     // One workgroup per CU (the register file of a single resident wave per SIMD is the budget): the NEXT tile's vectors of the three
     // maps and its per-pixel LayerNorm quantities are requested before this tile's arithmetic starts and land in registers under it.
     uint4 gr[NX], dr[NX], hr[NX];
-    float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr int PQ = 8;
+    float2 pq[PQ], pst_raw = make_float2(0.f, 0.f), ps_extra = make_float2(0.f, 0.f);
+    bool pin_next = false;
     auto tile_org = [&](int tidx, int& b, int& oh0, int& ow0) __attribute__((always_inline)) {
         const int tix = tidx % a.tilesW, tiy = (tidx / a.tilesW) % a.tilesH;
         b = tidx / (a.tilesW * a.tilesH); oh0 = tiy * D::TH; ow0 = tix * D::TW;
@@ -962,11 +964,22 @@ __device__ __forceinline__ void ffn_mid_bwd_body(const FfnSegDev& a, long long w
         const int iy = tid / IW, ix = tid - iy * IW, ih = oh0 - 1 + iy, iw = ow0 - 1 + ix;
         const bool pin = tid < NPIX && ih >= 0 && ih < H && iw >= 0 && iw < W;
         const long long prow = pin ? ibase + (long long)ih * W + iw : 0;
-        const float2 st = *reinterpret_cast<const float2*>(stat + prow * 2);
         const float2* pp = reinterpret_cast<const float2*>(part2) + prow * a.nch2;
+        pst_raw = *reinterpret_cast<const float2*>(stat + prow * 2);
+        pin_next = pin;
+        // the first PQ row-sum partials are requested here and added up when the tile is consumed (a load-add-load loop here would
+        // be nch2 dependent memory round trips in front of the tile's own loads); wider LayerNorms finish the sum in the loop below
+#pragma unroll
+        for (int k = 0; k < PQ; ++k) pq[k] = pp[k < a.nch2 ? k : 0];
         float s1 = 0.f, s2 = 0.f;
-        for (int k = 0; k < a.nch2; ++k) { const float2 q = pp[k]; s1 += q.x; s2 += q.y; }
-        pv = pin ? make_float4(st.x, st.y, s1 * invC, s2 * invC) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k0 = PQ; k0 < a.nch2; k0 += 4) {
+            float2 q4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) q4[j] = pp[k0 + j < a.nch2 ? k0 + j : 0];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (k0 + j < a.nch2) { s1 += q4[j].x; s2 += q4[j].y; }
+        }
+        ps_extra = make_float2(s1, s2);
         dw_fetch<T, CG, NX>(gr, gp + ibase * a.ldg + c0, a.ldg, oh0 - 1, ow0 - 1, IH, IW, H, W, C - c0);
         dw_fetch<T, CG, NX>(dr, dm + ibase * a.ldd + c0, a.ldd, oh0 - 1, ow0 - 1, IH, IW, H, W, C - c0);
         dw_fetch<T, CG, NX>(hr, hm + ibase * a.ldh + c0, a.ldh, oh0 - 1, ow0 - 1, IH, IW, H, W, C - c0);
@@ -982,7 +995,12 @@ __device__ __forceinline__ void ffn_mid_bwd_body(const FfnSegDev& a, long long w
         const long long ibase = (long long)b * H * W;
         if (!PF) fetch(tidx);                                     // two workgroups per CU cover each other's memory latency instead
         __syncthreads();                                          // the previous tile's readers are done with the LDS tiles
-        if (tid < NPIX) pst[tid] = pv;
+        if (tid < NPIX) {
+            float s1 = ps_extra.x, s2 = ps_extra.y;
+#pragma unroll
+            for (int k = 0; k < PQ; ++k) if (k < a.nch2) { s1 += pq[k].x; s2 += pq[k].y; }
+            pst[tid] = pin_next ? make_float4(pst_raw.x, pst_raw.y, s1 * invC, s2 * invC) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
@@ -1092,6 +1110,7 @@ __device__ __forceinline__ void ffn_mid_bwd_body(const FfnSegDev& a, long long w
         }
     }
     __syncthreads();
+    if (dbg_nofold) return;                                       // timing what-if only (TC_DEBUG_FFN_NOFOLD=1): parameter gradients are dropped
     float* lflat = &lacc[0][0];
     int gm = 1;
     const float* pgroup = nullptr;
@@ -1152,7 +1171,7 @@ __global__ __launch_bounds__(256, PF ? 1 : 2) void ffn_mid_bwd_kernel(FfnMultiDe
     if (q.n > 3 && lin >= q.s[3].blk0) si = 3;
     const FfnSegDev& g = q.s[si];
     lin -= g.blk0;
-    ffn_mid_bwd_body<T, PF>(g, q.wstride, lin % g.gx, lin / g.gx, blockIdx.y, dsm);
+    ffn_mid_bwd_body<T, PF>(g, q.wstride, lin % g.gx, lin / g.gx, blockIdx.y, dsm, q.dbg_nofold);
 }
 
 template <typename T>
@@ -1160,8 +1179,9 @@ int launch_ffn_mid_bwd(const TcFfnSeg* segs, int nseg, int groups, long long wst
     using D = FfnTile<T>;
     static_assert(D::smem_q * 16 <= 64 * 1024, "static dynamic-LDS limit");
     static const bool pf = !(getenv("TC_FFN_MID_PF") && atoi(getenv("TC_FFN_MID_PF")) == 0);   // A/B switch: 0 = two workgroups per CU
+    static const int nofold = getenv("TC_DEBUG_FFN_NOFOLD") ? atoi(getenv("TC_DEBUG_FFN_NOFOLD")) : 0;
     FfnMultiDev q;
-    q.n = nseg; q.wstride = wstride;
+    q.n = nseg; q.wstride = wstride; q.dbg_nofold = nofold;
     long long blk = 0, part_floats = 0, cnts = 0, total_work = 0;
     const bool have_ws = ws && (uintptr_t)ws % 16 == 0 && ws_bytes > 16384;
     for (int i = 0; i < nseg; ++i)

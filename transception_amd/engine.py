@@ -716,8 +716,9 @@ class Graph:
         # depthwise 3x3 + bias + skip, LayerNorm chunk partials on the side
         if not many:
             t = st[0]
-            L.tc_ffn_dw_fwd(_ptr(t["h"]), t["C4"], _ptr(t["wd"].data), _ptr(t["bd"].data), _ptr(t["d"]), t["C4"], _ptr(t["part"]), t["B"], t["H"],
-                            t["W"], t["C4"], Gn, gs, self.dt, self.stream)
+            _timed("hbm:ffn_dw_fwd (MixFFN dw3x3 + skip + LayerNorm partials)", 2.0 * t["x"].rows * t["C4"] * t["h"].element_size(),
+                   lambda: L.tc_ffn_dw_fwd(_ptr(t["h"]), t["C4"], _ptr(t["wd"].data), _ptr(t["bd"].data), _ptr(t["d"]), t["C4"], _ptr(t["part"]),
+                                           t["B"], t["H"], t["W"], t["C4"], Gn, gs, self.dt, self.stream))
         else:
             assert n <= 4
             arr = (TcDwSeg * n)()
@@ -769,7 +770,9 @@ class Graph:
                                    _ptr(t["lg"].grad) if hg else None, _ptr(t["lb"].grad) if hg else None,
                                    t["C4"], t["C4"], t["C4"], t["C4"], t["C4"], t["B"], t["H"], t["W"], t["nch2"])
             ws = _workspace(self.dev, self.stream)
-            L.tc_ffn_mid_bwd(segs, n, Gn, gs, ws.data_ptr(), ws.numel(), self.dt, self.stream)
+            _timed("hbm:ffn_mid_bwd (MixFFN LayerNorm backward + dw3x3 input/weight gradients)",
+                   sum(4.0 * t["x"].rows * t["C4"] * t["h"].element_size() for t in st),
+                   lambda: L.tc_ffn_mid_bwd(segs, n, Gn, gs, ws.data_ptr(), ws.numel(), self.dt, self.stream))
             # fc1: dX = dh W1, dW1 = dh^T x (+ db1)
             g2 = []
             for i, t in enumerate(st):
@@ -809,8 +812,10 @@ class Graph:
         if out is None:
             out = self.new(x.rows, Cc)
         mean, rstd = self.f32(x.rows), self.f32(x.rows)
-        self.L.tc_layernorm_fwd(_ptr(x.data), x.ld, _ptr(g.data), _ptr(b.data), _ptr(out.data), out.ld, _ptr(mean), _ptr(rstd),
-                                rows, Cc, eps, act, Gn, g.gs, self.dt, self.stream)
+        es = x.data.element_size()
+        _timed("hbm:layernorm_fwd", 2.0 * x.rows * Cc * es, lambda: self.L.tc_layernorm_fwd(
+            _ptr(x.data), x.ld, _ptr(g.data), _ptr(b.data), _ptr(out.data), out.ld, _ptr(mean), _ptr(rstd), rows, Cc, eps, act, Gn, g.gs,
+            self.dt, self.stream))
 
         def bwd():
             dy = self.grad_of(out)
@@ -821,9 +826,10 @@ class Graph:
             if fused:                                    # one pass: dx + per-workgroup dgamma/dbeta partials + a tiny folding launch
                 ws = _workspace(self.dev, self.stream)
                 scratch, n = ws, ws.numel() // 4
-                self.L.tc_layernorm_bwd(_ptr(dy), dy.stride(0), _ptr(x.data), x.ld, _ptr(g.data), _ptr(b.data), _ptr(mean),
-                                        _ptr(rstd), _ptr(gx), gx.stride(0), _ptr(gx) if acc else None, gx.stride(0),
-                                        _ptr(g.grad), _ptr(b.grad), rows, Cc, act, Gn, g.gs, _ptr(scratch), n, self.dt, self.stream)
+                _timed("hbm:layernorm_bwd", (3.0 + acc) * x.rows * Cc * es, lambda: self.L.tc_layernorm_bwd(
+                    _ptr(dy), dy.stride(0), _ptr(x.data), x.ld, _ptr(g.data), _ptr(b.data), _ptr(mean), _ptr(rstd), _ptr(gx), gx.stride(0),
+                    _ptr(gx) if acc else None, gx.stride(0), _ptr(g.grad), _ptr(b.grad), rows, Cc, act, Gn, g.gs, _ptr(scratch), n, self.dt,
+                    self.stream))
                 return
             self.L.tc_layernorm_bwd(_ptr(dy), dy.stride(0), _ptr(x.data), x.ld, _ptr(g.data), _ptr(b.data), _ptr(mean),
                                     _ptr(rstd), _ptr(gx), gx.stride(0), _ptr(gx) if acc else None, gx.stride(0),
@@ -843,8 +849,10 @@ class Graph:
         Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
         if out is None:
             out = self.new(Gn * B * Ho * Wo, Cc)
-        self.L.tc_dwconv_fwd(_ptr(x.data), x.ld, _ptr(w.data), _ptr(b.data) if b is not None else None, _ptr(out.data), out.ld,
-                             B, H, W, Cc, k, stride, int(add_input), Gn, w.gs, self.dt, self.stream)
+        es = x.data.element_size()
+        _timed("hbm:dwconv_fwd", (x.rows + out.rows) * Cc * es, lambda: self.L.tc_dwconv_fwd(
+            _ptr(x.data), x.ld, _ptr(w.data), _ptr(b.data) if b is not None else None, _ptr(out.data), out.ld, B, H, W, Cc, k, stride,
+            int(add_input), Gn, w.gs, self.dt, self.stream))
 
         def bwd():
             dy = self.grad_of(out)
@@ -852,14 +860,15 @@ class Graph:
                 return
             if x.requires_grad:
                 gx, acc = self.wgrad(x)
-                self.L.tc_dwconv_bwd_input(_ptr(dy), dy.stride(0), _ptr(w.data), _ptr(gx), gx.stride(0), B, H, W, Cc, k, stride,
-                                           int(add_input), acc, Gn, w.gs, self.dt, self.stream)
+                _timed("hbm:dwconv_bwd_input", (x.rows * (1 + acc) + out.rows) * Cc * es, lambda: self.L.tc_dwconv_bwd_input(
+                    _ptr(dy), dy.stride(0), _ptr(w.data), _ptr(gx), gx.stride(0), B, H, W, Cc, k, stride, int(add_input), acc, Gn, w.gs,
+                    self.dt, self.stream))
             if w.grad is not None:
                 def dwgrad():
                     ws = _workspace(self.dev, self.stream)           # of the stream this actually runs on
-                    self.L.tc_dwconv_bwd_weight(_ptr(dy), dy.stride(0), _ptr(x.data), x.ld, _ptr(w.grad),
-                                                _ptr(b.grad) if b is not None else None, B, H, W, Cc, k, stride, Gn, w.gs,
-                                                ws.data_ptr(), ws.numel(), self.dt, self.stream)
+                    _timed("hbm:dwconv_bwd_weight", (x.rows + out.rows) * Cc * es, lambda: self.L.tc_dwconv_bwd_weight(
+                        _ptr(dy), dy.stride(0), _ptr(x.data), x.ld, _ptr(w.grad), _ptr(b.grad) if b is not None else None, B, H, W, Cc, k,
+                        stride, Gn, w.gs, ws.data_ptr(), ws.numel(), self.dt, self.stream))
                 self._weight_grad(dwgrad, reads=dy)
         self._rec(bwd)
         return out
@@ -921,19 +930,20 @@ class Graph:
         if self.training:
             smean, srstd = self.f32(Cc), self.f32(Cc)
             part = self.f32(int(self.L.tc_bn_scratch_floats(rows, Cc)))
-        self.L.tc_bn_fwd(_ptr(x.data), x.ld, _ptr(gamma.data), _ptr(beta.data), _ptr(running_mean), _ptr(running_var),
-                         _ptr(residual.data) if residual is not None else None, residual.ld if residual is not None else 0,
-                         _ptr(out.data), out.ld, _ptr(smean), _ptr(srstd), _ptr(part), rows, Cc, 1e-5, 0.1, int(self.training),
-                         act, self.dt, self.stream)
+        es = x.data.element_size()
+        _timed("hbm:batchnorm_fwd", ((3.0 if self.training else 2.0) + (residual is not None)) * rows * Cc * es, lambda: self.L.tc_bn_fwd(
+            _ptr(x.data), x.ld, _ptr(gamma.data), _ptr(beta.data), _ptr(running_mean), _ptr(running_var),
+            _ptr(residual.data) if residual is not None else None, residual.ld if residual is not None else 0, _ptr(out.data), out.ld,
+            _ptr(smean), _ptr(srstd), _ptr(part), rows, Cc, 1e-5, 0.1, int(self.training), act, self.dt, self.stream))
 
         def bwd():
             dy = self.grad_of(out)
             if dy is None:
                 return
             gx, acc = self.wgrad(x)
-            self.L.tc_bn_bwd(_ptr(dy), dy.stride(0), _ptr(x.data), x.ld, _ptr(gamma.data), _ptr(beta.data), _ptr(smean),
-                             _ptr(srstd), _ptr(gx), gx.stride(0), _ptr(gamma.grad), _ptr(beta.grad), _ptr(part), rows, Cc, act,
-                             acc, self.dt, self.stream)
+            _timed("hbm:batchnorm_bwd", (5.0 + acc) * rows * Cc * es, lambda: self.L.tc_bn_bwd(
+                _ptr(dy), dy.stride(0), _ptr(x.data), x.ld, _ptr(gamma.data), _ptr(beta.data), _ptr(smean), _ptr(srstd), _ptr(gx),
+                gx.stride(0), _ptr(gamma.grad), _ptr(beta.grad), _ptr(part), rows, Cc, act, acc, self.dt, self.stream))
             if residual is not None:
                 self.pass_grad(residual, dy)
         self._rec(bwd)
@@ -1049,7 +1059,8 @@ class Graph:
         Cc = x.cols
         assert x.data.is_contiguous()
         out = self.new(B * (H + W), Cc)
-        self.L.tc_coord_pool_fwd(_ptr(x.data), _ptr(out.data), B, H, W, Cc, self.dt, self.stream)
+        _timed("hbm:coord_pool_fwd", (x.rows + out.rows) * Cc * x.data.element_size(),
+               lambda: self.L.tc_coord_pool_fwd(_ptr(x.data), _ptr(out.data), B, H, W, Cc, self.dt, self.stream))
 
         def bwd():
             d = self.grad_of(out)
@@ -1064,7 +1075,8 @@ class Graph:
         Cc = x.cols
         assert x.data.is_contiguous() and att.data.is_contiguous()
         out = self.new(x.rows, Cc)
-        self.L.tc_coord_gate_fwd(_ptr(x.data), _ptr(att.data), _ptr(out.data), B, H, W, Cc, self.dt, self.stream)
+        _timed("hbm:coord_gate_fwd", (2 * x.rows + att.rows) * Cc * x.data.element_size(),
+               lambda: self.L.tc_coord_gate_fwd(_ptr(x.data), _ptr(att.data), _ptr(out.data), B, H, W, Cc, self.dt, self.stream))
 
         def bwd():
             d = self.grad_of(out)
@@ -1082,7 +1094,8 @@ class Graph:
         c = x.cols // (p * p)
         assert x.data.is_contiguous()
         out = self.new(B * H * p * W * p, c)
-        self.L.tc_pixel_shuffle(_ptr(x.data), _ptr(out.data), B, H, W, p, c, 0, self.dt, self.stream)
+        _timed("hbm:pixel_shuffle", 2.0 * x.rows * x.cols * x.data.element_size(),
+               lambda: self.L.tc_pixel_shuffle(_ptr(x.data), _ptr(out.data), B, H, W, p, c, 0, self.dt, self.stream))
 
         def bwd():
             d = self.grad_of(out)
