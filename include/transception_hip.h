@@ -343,7 +343,9 @@ int tc_argmax_counts(const void* logits, const long long* labels, unsigned char*
  * [B,H,W] (image fp32 in [0,1], label uint8 0..8) already in HBM -> network input.
  */
 enum { TC_AUG_WARP = 1, TC_AUG_LINEAR = 2, TC_AUG_BLUR = 4, TC_AUG_PIECEWISE = 8 };
-/* Per-slice augmentation record (DEVICE array of B).  Stage order: warp -> blur -> contrast -> noise.
+/* Per-slice augmentation record (DEVICE array of B).  Stage order: warp first, then the pixel stages in the order `reserved` encodes
+ *   (imgaug's SomeOf(random_order=True) applies its augmenters in the drawn order, dataset_synapse.py:84-95): up to three 2-bit codes,
+ *   first stage in the low bits, 1 = blur, 2 = contrast, 3 = noise; reserved = 0 means blur -> contrast -> noise.
  *   warp: source (row, col) = (m[2] + m[0] y' + m[1] x', m[5] + m[3] y' + m[4] x') of output pixel (y, x), where (y', x') = (y, x)
  *   plus, with TC_AUG_PIECEWISE, the bilinear interpolation of the 4x4 control-point displacements disp[(gy*4+gx)*2 + {0:dy,1:dx}]
  *   (pixels) spanning the slice; image sampled order 1 (TC_AUG_LINEAR) or order 0, label always order 0, outside -> 0
@@ -379,8 +381,16 @@ int tc_sgd_step(float* p, const float* grad, float* buf, long long n, float lr, 
 /* The same update over nseg contiguous segments of the flat arenas in ONE launch: segs_dev is a DEVICE array of
  * (offset, length) pairs (elements); max_len = longest segment.  Parameters outside the segments are untouched
  * (torch.optim.SGD skips parameters whose grad is None -- the reference's 332 grad-less tensors). */
+/* clip_sumsq (optional device scalar = sum of squared gradients, see tc_grad_sumsq): gradients are additionally scaled by
+ * min(1, clip_norm / (sqrt(*clip_sumsq) + 1e-6)) -- nn.utils.clip_grad_norm_(parameters, clip_norm, 2) of trainer.py:147-148 folded
+ * into the update (the stored gradients themselves stay unscaled). */
 int tc_sgd_step_multi(float* p, const float* grad, float* buf, const long long* segs_dev, int nseg, long long max_len,
-                      float lr, const float* lr_dev, float momentum, float wd, float gscale, int first, void* stream);
+                      float lr, const float* lr_dev, float momentum, float wd, float gscale, int first, const float* clip_sumsq,
+                      float clip_norm, void* stream);
+/* *out += sum_i g[i]^2 over a flat fp32 buffer (n a multiple of 4, 16-byte aligned): the squared total gradient norm. */
+int tc_grad_sumsq(const float* g, long long n, float* out, void* stream);
+/* p[0..n) = v (fp32): resets device accumulators inside a captured step */
+int tc_fill_f32(float* p, long long n, float v, void* stream);
 /* dst(bf16) = src(fp32) and back, for bf16 working copies of fp32 master weights */
 int tc_cast(const void* src, void* dst, long long n, int src_dtype, int dst_dtype, void* stream);
 

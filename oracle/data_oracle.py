@@ -197,9 +197,9 @@ def sample_nearest(a: np.ndarray, sy: np.ndarray, sx: np.ndarray) -> np.ndarray:
 
 
 def augment_slice(image: np.ndarray, label: np.ndarray, aug: dict):
-    """One slice through the augmentation stage in its canonical order: geometric warp (affine `m` = 2x3 output->source map in
-    (row, col) coordinates, plus the optional 4x4 control-point displacement) -> Gaussian blur sigma 1 -> linear contrast
-    center + alpha (v - center) -> additive Gaussian noise.  `aug` keys: m (6 floats), order (0|1), disp (32 floats or None),
+    """One slice through the augmentation stage: geometric warp (affine `m` = 2x3 output->source map in (row, col) coordinates,
+    plus the optional 4x4 control-point displacement), then the pixel stages -- Gaussian blur sigma 1, linear contrast
+    center + alpha (v - center), additive Gaussian noise -- in the order `pixel_order` gives (default blur -> contrast -> noise).  `aug` keys: m (6 floats), order (0|1), disp (32 floats or None),
     blur (bool), alpha, center, noise_sigma, noise_seed.  The label is always sampled order 0 and gets no intensity change."""
     h, w = image.shape
     m = np.asarray(aug.get("m", (1, 0, 0, 0, 1, 0)), np.float64)
@@ -217,12 +217,17 @@ def augment_slice(image: np.ndarray, label: np.ndarray, aug: dict):
     order = int(aug.get("order", 1))
     img = (sample_linear(image, sy, sx) if order == 1 else sample_nearest(image, sy, sx)).astype(np.float32)
     lab = sample_nearest(label, sy, sx)
-    if aug.get("blur"):
-        img = ndimage.gaussian_filter(img, 1.0, mode="mirror", truncate=float(BLUR_RADIUS))
     alpha, center = np.float32(aug.get("alpha", 1.0)), np.float32(aug.get("center", 0.0))
-    img = (center + alpha * (img - center)).astype(np.float32)
-    if aug.get("noise_sigma", 0.0) > 0:
-        img = img + noise_field(int(aug["noise_seed"]), h, w, float(aug["noise_sigma"]))
+    # pixel stages in the drawn order (imgaug SomeOf(random_order=True)); stages that were not drawn follow in the canonical order
+    # blur -> contrast -> noise, where they are identities (no blur flag / alpha 1 / sigma 0)
+    stages = list(aug.get("pixel_order", ())) + [s_ for s_ in ("blur", "contrast", "noise") if s_ not in aug.get("pixel_order", ())]
+    for stage in stages:
+        if stage == "blur" and aug.get("blur"):
+            img = ndimage.gaussian_filter(img, 1.0, mode="mirror", truncate=float(BLUR_RADIUS)).astype(np.float32)
+        elif stage == "contrast":
+            img = (center + alpha * (img - center)).astype(np.float32)
+        elif stage == "noise" and aug.get("noise_sigma", 0.0) > 0:
+            img = (img + noise_field(int(aug["noise_seed"]), h, w, float(aug["noise_sigma"]))).astype(np.float32)
     return img.astype(np.float32), lab
 
 

@@ -123,8 +123,16 @@ def test_augmentation_stage_matches_oracle():
         D.SliceAugmentation(m=D.affine_flip(0, H, W), disp=(np.random.default_rng(5).normal(0, 1, (4, 4, 2)) * 2.0).astype(np.float32),
                             blur=True, alpha=1.2, noise_sigma=0.3, noise_seed=2 ** 31 - 2),
     ]
+    # every order of the three pixel stages (imgaug applies its augmenters in the drawn order, dataset_synapse.py:84-95): noise drawn
+    # before the blur is blurred with the slice, noise drawn before the contrast change is scaled by it
+    import itertools
+    for perm in itertools.permutations(("blur", "contrast", "noise")):
+        explicit.append(D.SliceAugmentation(m=D.affine_rotate_xy(-17.0, H, W), blur=True, alpha=1.45, center=0.4, noise_sigma=0.2,
+                                            noise_seed=777, pixel_order=perm))
+    explicit.append(D.SliceAugmentation(alpha=0.55, noise_sigma=0.25, noise_seed=5, pixel_order=("noise", "contrast")))
     sampler = D.AugmentSampler(99)
     augs = explicit + [sampler.sample(H, W) for _ in range(24)]
+    assert any(a.pixel_order[:1] == ("noise",) and len(a.pixel_order) > 1 for a in augs)
     img, lab = _pair(21, H, W, batch=len(augs))
     oi, ol = _augment_on_device(img, lab, augs)
     for b, a in enumerate(augs):

@@ -127,10 +127,13 @@ def test_synthetic_set_round_trip_and_sharding(tmp_path):
     assert sorted(order.tolist()) == list(range(10)) and not np.array_equal(order, D.epoch_order(10, 1, 1234))
     np.testing.assert_array_equal(order, D.epoch_order(10, 0, 1234))
     parts = [D.rank_batches(order, 2, r, 2) for r in range(2)]
-    assert len(parts[0]) == len(parts[1]) == 2                      # 10 // (2*2) global batches, tail of 2 dropped everywhere
+    assert len(parts[0]) == len(parts[1]) == 3                      # ceil(10 / (2*2)) global batches, like DataLoader(drop_last=False)
     for i in range(2):
         merged = np.concatenate([parts[0][i], parts[1][i]])
         np.testing.assert_array_equal(merged, order[i * 4:(i + 1) * 4])
+    last = np.concatenate([parts[0][2], parts[1][2]])               # the short tail is completed from the head of the same permutation
+    np.testing.assert_array_equal(last, np.concatenate([order[8:], order[:2]]))
+    assert len(D.rank_batches(np.arange(2211), 24, 0, 1)) == 93     # Synapse at the reference's batch size (trainer.py:104)
 
 
 def test_direct_npz_reads_match_np_load(tmp_path):

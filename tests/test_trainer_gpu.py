@@ -66,7 +66,9 @@ def test_graphed_and_eager_trainers_agree(tmp_path):
     for a, b in zip(out[0]["loss"], out[1]["loss"]):
         assert abs(a - b) < 5e-4, (out[0]["loss"], out[1]["loss"])
     for i, lr in enumerate(out[0]["lr"]):
-        assert abs(lr - 0.05 * (1.0 - (i + 1) / 8) ** 0.9) < 1e-12               # polynomial decay branch (trainer.py:154-157)
+        # polynomial decay branch (trainer.py:154-159): lr_ is computed from iter_num BEFORE its increment, logged with the incremented
+        # count and used by the NEXT step -- the value logged after iteration i+1 is base (1 - i/max)^0.9
+        assert abs(lr - 0.05 * (1.0 - i / 8) ** 0.9) < 1e-12
 
 
 def test_clip_norm_matches_torch():
@@ -90,3 +92,30 @@ def test_clip_norm_matches_torch():
     want = before - 0.05 * (g * coef + 1e-4 * before)
     live = g != 0
     assert torch.allclose(m.flat_parameters()[live], want[live], atol=1e-7, rtol=1e-5)
+
+
+def test_evaluation_zooms_on_device_match_scipy():
+    """utils.py:69-70,83-84: the order-3 zoom of every slice to the network size and the order-0 zoom of the prediction back run on
+    the GPU; images within 1e-6 of scipy.ndimage.zoom, labels bit-exact, and evaluate_volume agrees with its host-zoom form."""
+    import numpy as np
+    from scipy.ndimage import zoom
+    from transception_amd import MSTransception
+    from transception_amd.evaluate import evaluate_volume, zoom_labels, zoom_volume_to_network
+    from transception_amd.seeded_init import seeded_state_dict
+    g = np.random.default_rng(3)
+    vol = g.random((3, 160, 144)).astype(np.float32)
+    got = zoom_volume_to_network(torch.from_numpy(vol).to(DEV), (64, 96)).cpu().numpy()
+    for d in range(3):
+        np.testing.assert_allclose(got[d], zoom(vol[d], (64 / 160, 96 / 144), order=3), atol=2e-6, rtol=0)
+    lab = g.integers(0, 9, (3, 64, 96)).astype(np.uint8)
+    up = zoom_labels(torch.from_numpy(lab).to(DEV), (160, 144)).cpu().numpy()
+    for d in range(3):
+        np.testing.assert_array_equal(up[d], zoom(lab[d], (160 / 64, 144 / 96), order=0))
+    m = MSTransception(num_classes=9)
+    m.load_state_dict(seeded_state_dict(), strict=True)
+    m.to(DEV).eval()
+    image = g.random((2, 96, 96)).astype(np.float32)
+    label = g.integers(0, 9, (2, 96, 96)).astype(np.uint8)
+    a = evaluate_volume(m, image, label, 9, (64, 64), batch=2)
+    b = evaluate_volume(m, image, label, 9, (64, 64), batch=2, host_zoom=True)
+    np.testing.assert_allclose(np.array(a), np.array(b), atol=2e-3)

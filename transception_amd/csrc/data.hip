@@ -91,6 +91,34 @@ __global__ __launch_bounds__(256) void slice_augment_kernel(const float* __restr
     const unsigned char* lb = lab + (long long)b * H * W;
     const int ty0 = blockIdx.y * kTile, tx0 = blockIdx.x * kTile;
     const bool blur = A.flags & TC_AUG_BLUR;
+    // Pixel stages run in the order the sampler drew them (A.reserved: up to three 2-bit codes, first stage in the low bits;
+    // 1 = blur, 2 = contrast, 3 = noise; 0 = the canonical blur -> contrast -> noise).  Blur is the only non-pointwise stage: the
+    // pointwise stages drawn before it are applied while the haloed tile is filled, the ones after it to the blurred value.
+    int ord = A.reserved & 63;
+    if (ord == 0) ord = 1 | (2 << 2) | (3 << 4);
+    int pre = 0, post = 0, npre = 0, npost = 0;
+    {
+        bool seen_blur = !blur;
+        for (int i = 0; i < 3; ++i) {
+            const int c = (ord >> (2 * i)) & 3;
+            if (c == 1) { seen_blur = true; continue; }
+            if (c == 0) continue;
+            if (seen_blur) { post |= c << (2 * npost); ++npost; } else { pre |= c << (2 * npre); ++npre; }
+        }
+    }
+    auto pointwise = [&](float v, int oy, int ox, int codes, int n) {
+        for (int i = 0; i < n; ++i) {
+            const int c = (codes >> (2 * i)) & 3;
+            if (c == 2) v = A.center + A.alpha * (v - A.center);
+            else if (c == 3 && A.noise_sigma > 0.f) {
+                const unsigned idx = (unsigned)(oy * W + ox), base = A.noise_seed * 0x9E3779B9u;
+                const unsigned ra = mix32(idx * 2u + base), rb = mix32(idx * 2u + 1u + base + 0x85EBCA6Bu);
+                const float u1 = ((float)ra + 1.0f) * 2.3283064365386963e-10f, u2 = (float)rb * 2.3283064365386963e-10f;
+                v += A.noise_sigma * (sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2));
+            }
+        }
+        return v;
+    };
     float g[kBlurR + 1];
     if (blur) {
         double w[kBlurR + 1], s = 1.0;
@@ -100,7 +128,8 @@ __global__ __launch_bounds__(256) void slice_augment_kernel(const float* __restr
         // warped slice over the tile + halo; positions beyond the slice mirror back into it
         for (int p = tid; p < TS * TS; p += 256) {
             const int ly = p / TS, lx = p % TS;
-            t0[p] = aug_image_at(im, A, mirror101(ty0 + ly - kBlurR, H), mirror101(tx0 + lx - kBlurR, W), H, W);
+            const int my = mirror101(ty0 + ly - kBlurR, H), mx = mirror101(tx0 + lx - kBlurR, W);
+            t0[p] = pointwise(aug_image_at(im, A, my, mx, H, W), my, mx, pre, npre);
         }
         __syncthreads();
         for (int p = tid; p < kTile * TS; p += 256) {             // axis 0 first (scipy.ndimage.gaussian_filter order), fp32 intermediate
@@ -122,13 +151,7 @@ __global__ __launch_bounds__(256) void slice_augment_kernel(const float* __restr
         } else {
             v = aug_image_at(im, A, oy, ox, H, W);
         }
-        v = A.center + A.alpha * (v - A.center);
-        if (A.noise_sigma > 0.f) {
-            const unsigned idx = (unsigned)(oy * W + ox), base = A.noise_seed * 0x9E3779B9u;
-            const unsigned ra = mix32(idx * 2u + base), rb = mix32(idx * 2u + 1u + base + 0x85EBCA6Bu);
-            const float u1 = ((float)ra + 1.0f) * 2.3283064365386963e-10f, u2 = (float)rb * 2.3283064365386963e-10f;
-            v += A.noise_sigma * (sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2));
-        }
+        v = pointwise(v, oy, ox, post, npost);
         const long long o = ((long long)b * H + oy) * W + ox;
         oimg[o] = v;
         olab[o] = aug_label_at(lb, A, oy, ox, H, W);

@@ -108,9 +108,26 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, f
 }
 
 // all contiguous "used" parameter segments in one launch: blockIdx.y = segment, segs[2*i] = offset, segs[2*i+1] = length
+// sum of squares of a flat fp32 buffer, accumulated into *out (the total gradient norm of nn.utils.clip_grad_norm_, trainer.py:147-148:
+// parameters without a gradient hold zeros in the arena)
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long long n4, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(g)[i];
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
 __global__ void sgd_multi_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, const long long* __restrict__ segs,
-                                 float lr, float mom, float wd, float gscale, int first, const float* __restrict__ lr_dev) {
+                                 float lr, float mom, float wd, float gscale, int first, const float* __restrict__ lr_dev,
+                                 const float* __restrict__ clip_sumsq, float clip_norm) {
     if (lr_dev) lr = *lr_dev;
+    if (clip_sumsq) gscale *= fminf(clip_norm / (sqrtf(*clip_sumsq) + 1e-6f), 1.0f);      // clip_grad_norm_'s coefficient, clamped to 1
     const long long off = segs[2 * blockIdx.y], n = segs[2 * blockIdx.y + 1];
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const long long j = off + i;
@@ -214,9 +231,25 @@ extern "C" int tc_sgd_step(float* p, const float* grad, float* buf, long long n,
 }
 
 extern "C" int tc_sgd_step_multi(float* p, const float* grad, float* buf, const long long* segs_dev, int nseg, long long max_len, float lr,
-                                 const float* lr_dev, float momentum, float wd, float gscale, int first, void* stream) {
-    if (!p || !grad || !buf || !segs_dev || nseg <= 0 || nseg > 65535 || max_len <= 0) return TC_ERR_ARG;
+                                 const float* lr_dev, float momentum, float wd, float gscale, int first, const float* clip_sumsq,
+                                 float clip_norm, void* stream) {
+    if (!p || !grad || !buf || !segs_dev || nseg <= 0 || nseg > 65535 || max_len <= 0 || (clip_sumsq && !(clip_norm > 0.f))) return TC_ERR_ARG;
     hipLaunchKernelGGL(sgd_multi_kernel, dim3(tc_blocks(max_len, 256 * 8, 256), nseg), dim3(256), 0, (hipStream_t)stream, p, grad, buf, segs_dev,
-                       lr, momentum, wd, gscale, first, lr_dev);
+                       lr, momentum, wd, gscale, first, lr_dev, clip_sumsq, clip_norm);
+    return tc_launch_status();
+}
+
+__global__ void fill_f32_kernel(float* __restrict__ p, long long n, float v) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] = v;
+}
+extern "C" int tc_fill_f32(float* p, long long n, float v, void* stream) {
+    if (!p || n <= 0) return TC_ERR_ARG;
+    hipLaunchKernelGGL(fill_f32_kernel, dim3(tc_blocks(n, 256 * 4, 2048)), dim3(256), 0, (hipStream_t)stream, p, n, v);
+    return tc_launch_status();
+}
+
+extern "C" int tc_grad_sumsq(const float* g, long long n, float* out, void* stream) {
+    if (!g || !out || n <= 0 || (n & 3) || (uintptr_t)g % 16) return TC_ERR_ARG;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(tc_blocks(n / 4, 256 * 8, 1024)), dim3(256), 0, (hipStream_t)stream, g, n / 4, out);
     return tc_launch_status();
 }

@@ -110,6 +110,14 @@ class SliceAugmentation:
     noise_sigma: float = 0.0
     noise_seed: int = 0
     names: List[str] = field(default_factory=list)
+    pixel_order: Tuple[str, ...] = ()          # the pixel stages ("blur" / "contrast" / "noise") in the order they were drawn
+
+    def order_code(self) -> int:
+        """TcSliceAug.reserved: the drawn order of the pixel stages as 2-bit codes (0 = canonical blur -> contrast -> noise)."""
+        code = 0
+        for i, name in enumerate(self.pixel_order[:3]):
+            code |= {"blur": 1, "contrast": 2, "noise": 3}[name] << (2 * i)
+        return code
 
     def warps(self) -> bool:
         return self.disp is not None or tuple(self.m) != IDENTITY
@@ -130,6 +138,7 @@ class SliceAugmentation:
         if self.blur:
             flags |= TC_AUG_BLUR
         r.alpha, r.center, r.noise_sigma, r.noise_seed, r.flags = self.alpha, self.center, self.noise_sigma, self.noise_seed, flags
+        r.reserved = self.order_code()
         return r
 
     def as_dict(self) -> dict:
@@ -137,13 +146,17 @@ class SliceAugmentation:
         return {"m": tuple(self.m) if self.warps() else IDENTITY, "order": self.order,
                 "disp": None if self.disp is None else np.asarray(self.disp, np.float32).reshape(-1),
                 "blur": self.blur, "alpha": self.alpha, "center": self.center, "noise_sigma": self.noise_sigma,
-                "noise_seed": self.noise_seed}
+                "noise_seed": self.noise_seed, "pixel_order": tuple(self.pixel_order)}
 
 
 class AugmentSampler:
     """Draws what `iaa.SomeOf((0,4), [...ten augmenters...], random_order=True)` draws (dataset_synapse.py:84-95): between 0 and 4 of
-    the ten augmenters, in random order, each with its own parameter ranges.  The geometric ones fold into one output->source map
-    in the drawn order; PiecewiseAffine becomes a 4x4 control-point displacement field applied as the last geometric step."""
+    the ten augmenters, in random order, each with its own parameter ranges.  The pixel stages (noise / blur / contrast) are applied
+    in the drawn order (noise before a blur is blurred, noise before a contrast change is scaled).  Deviation kept, and stated: the
+    geometric augmenters fold into ONE output->source map in the drawn order and the slice is resampled once (imgaug resamples once
+    per geometric augmenter with cval=0, so its result is a little softer and loses what an intermediate step moved out of frame);
+    PiecewiseAffine becomes a 4x4 control-point displacement field applied as the last geometric step.  imgaug itself is not
+    importable here, so this stage is parity-unpinned (its arithmetic is defined by oracle/data_oracle.py)."""
     NAMES = ("Flipud", "Fliplr", "AdditiveGaussianNoise", "GaussianBlur", "LinearContrast", "Affine.scale", "Affine.rotate",
              "Affine.shear", "PiecewiseAffine", "Affine.translate")
 
@@ -165,10 +178,13 @@ class AugmentSampler:
                     a.m = compose(a.m, affine_flip(1, h, w))
             elif name == "AdditiveGaussianNoise":
                 a.noise_sigma, a.noise_seed = NOISE_SCALE, int(g.integers(0, 2 ** 31 - 1))
+                a.pixel_order += ("noise",)
             elif name == "GaussianBlur":
                 a.blur = True
+                a.pixel_order += ("blur",)
             elif name == "LinearContrast":
                 a.alpha = float(g.uniform(0.5, 1.5))
+                a.pixel_order += ("contrast",)
             elif name == "Affine.scale":
                 a.m = compose(a.m, affine_scale(float(g.uniform(0.5, 2.0)), float(g.uniform(0.5, 2.0)), h, w))
             elif name == "Affine.rotate":
@@ -358,10 +374,19 @@ def epoch_order(n: int, epoch: int, seed: int, shuffle: bool = True) -> np.ndarr
 
 
 def rank_batches(order: np.ndarray, batch_size: int, rank: int, world: int) -> List[np.ndarray]:
-    """Global batches of batch_size*world slices (trainer.py:86), rank r taking slices [r*B, (r+1)*B) of each; the ragged tail is
-    dropped on every rank alike so all ranks run the same number of steps."""
+    """Global batches of batch_size*world slices (trainer.py:86), rank r taking slices [r*B, (r+1)*B) of each.  ceil(N / global
+    batch) batches per epoch, like the reference's DataLoader (drop_last=False, trainer.py:104: 93 iterations for Synapse's 2211
+    slices at B=24, and a cosine T_max of max_epochs * 93); the captured step needs full batches, so the last one is completed
+    from the head of the same permutation instead of being short."""
     gb = batch_size * world
-    return [order[i * gb + rank * batch_size: i * gb + (rank + 1) * batch_size] for i in range(len(order) // gb)]
+    n = len(order)
+    if n == 0:
+        return []
+    nb = -(-n // gb)
+    padded = np.concatenate([order, order[:nb * gb - n]]) if nb * gb > n else order
+    while len(padded) < nb * gb:                               # data sets smaller than one global batch: keep wrapping
+        padded = np.concatenate([padded, order[:nb * gb - len(padded)]])
+    return [padded[i * gb + rank * batch_size: i * gb + (rank + 1) * batch_size] for i in range(nb)]
 
 
 class DeviceLoader:
@@ -390,7 +415,7 @@ class DeviceLoader:
         self._stop = threading.Event()
 
     def __len__(self) -> int:
-        return (len(self.ds) // (self.B * self.world)) * self.epochs
+        return -(-len(self.ds) // (self.B * self.world)) * self.epochs        # ceil, like DataLoader(drop_last=False): see rank_batches
 
     # host side -----------------------------------------------------------------------------------
     def _staging(self, h: int, w: int):

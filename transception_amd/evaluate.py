@@ -103,19 +103,56 @@ def predict_slices(model, slices: torch.Tensor, batch: int = 16) -> torch.Tensor
 
 
 @torch.no_grad()
+def zoom_volume_to_network(vol: torch.Tensor, size: Tuple[int, int]) -> torch.Tensor:
+    """[D,X,Y] float32 slices on the GPU -> [D,size] : scipy.ndimage.zoom(slice, (size/X, size/Y), order=3) of utils.py:69-70 as the
+    device spline prefilter + 4x4-tap evaluation of the input pipeline (csrc/data.hip; within 1e-6 of scipy, tests/test_data_gpu.py)."""
+    L = lib()
+    D, X, Y = vol.shape
+    stream = torch.cuda.current_stream(vol.device).cuda_stream
+    vol = vol.contiguous()
+    coef = torch.empty((D, X, Y), dtype=torch.float64, device=vol.device)
+    out = torch.empty((D, 1, size[0], size[1]), dtype=torch.float32, device=vol.device)
+    L.tc_spline_prefilter(vol.data_ptr(), coef.data_ptr(), D, X, Y, stream)
+    L.tc_zoom_normalize(coef.data_ptr(), vol.data_ptr(), None, out.data_ptr(), None, D, X, Y, size[0], size[1], 0.0, 1.0, stream)
+    return out[:, 0]
+
+
+@torch.no_grad()
+def zoom_labels(pred: torch.Tensor, size: Tuple[int, int]) -> torch.Tensor:
+    """uint8 [D,h,w] label maps -> [D,size]: scipy.ndimage.zoom(pred, ..., order=0) of utils.py:83-84 (nearest sample at
+    o (in-1)/(out-1); bit-exact integer work) through the label path of the same device kernel."""
+    L = lib()
+    D, h, w = pred.shape
+    dev = pred.device
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    pred = pred.contiguous()
+    coef = torch.zeros(D * h * w, dtype=torch.float64, device=dev)            # the image half of the kernel is unused
+    x = torch.empty((D, 1, size[0], size[1]), dtype=torch.float32, device=dev)
+    y = torch.empty((D, size[0], size[1]), dtype=torch.int64, device=dev)
+    L.tc_zoom_normalize(coef.data_ptr(), None, pred.data_ptr(), x.data_ptr(), y.data_ptr(), D, h, w, size[0], size[1], 0.0, 1.0, stream)
+    return y.to(torch.uint8)
+
+
+@torch.no_grad()
 def evaluate_volume(model, image: np.ndarray, label: np.ndarray, classes: int = 9, patch_size=(224, 224),
-                    batch: int = 16, with_hd95: bool = False):
+                    batch: int = 16, with_hd95: bool = False, host_zoom: bool = False):
     """`test_single_volume` for one [D,H,W] volume (utils.py:63-98): per-class Dice for classes 1..classes-1, or with
-    `with_hd95` the reference's metric_list of (dice, hd95) pairs.
-    Slices are zoomed on the host exactly as the reference does; everything between runs on the GPU."""
-    from scipy.ndimage import zoom
+    `with_hd95` the reference's metric_list of (dice, hd95) pairs.  The volume goes to the GPU once; the order-3 zoom to the network
+    size, inference, argmax and the order-0 zoom back all run there (host_zoom=True: scipy per slice, as the reference does)."""
     dev = next(model.parameters()).device
     D, X, Y = image.shape
     resize = (X, Y) != tuple(patch_size)
-    sl = np.stack([zoom(image[d], (patch_size[0] / X, patch_size[1] / Y), order=3) if resize else image[d] for d in range(D)])
-    pred = predict_slices(model, torch.from_numpy(sl.astype(np.float32)).to(dev), batch).cpu().numpy()
-    if resize:
-        pred = np.stack([zoom(pred[d], (X / patch_size[0], Y / patch_size[1]), order=0) for d in range(D)])
+    if host_zoom:
+        from scipy.ndimage import zoom
+        sl = np.stack([zoom(image[d], (patch_size[0] / X, patch_size[1] / Y), order=3) if resize else image[d] for d in range(D)])
+        pred = predict_slices(model, torch.from_numpy(sl.astype(np.float32)).to(dev), batch).cpu().numpy()
+        if resize:
+            pred = np.stack([zoom(pred[d], (X / patch_size[0], Y / patch_size[1]), order=0) for d in range(D)])
+    else:
+        vol = torch.from_numpy(np.ascontiguousarray(image, np.float32)).to(dev)
+        sl = zoom_volume_to_network(vol, tuple(patch_size)) if resize else vol
+        pred_d = predict_slices(model, sl, batch)
+        pred = (zoom_labels(pred_d, (X, Y)) if resize else pred_d).cpu().numpy()
     if with_hd95:
         return [calculate_metric_percase(pred == k, label == k) for k in range(1, classes)]
     counts = np.zeros((classes, 3), dtype=np.float64)

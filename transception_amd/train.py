@@ -107,6 +107,7 @@ class FusedSGD:
         self._segments = None
         self._segs_dev: Optional[torch.Tensor] = None
         self.lr_dev: Optional[torch.Tensor] = None       # device scalar read by the kernel (hipGraph-friendly schedule)
+        self._sumsq: Optional[torch.Tensor] = None       # squared gradient norm (clip_norm)
 
     def set_lr(self, lr: float):
         self.lr = lr
@@ -143,11 +144,18 @@ class FusedSGD:
             segs = [(off, min(n, flat.numel() - off)) for off, n in self._segs()]
             self._segs_dev = torch.tensor([v for s in segs for v in s], dtype=torch.int64, device=flat.device)
             self._nseg, self._maxlen = len(segs), max(n for _, n in segs)
-        if self.clip_norm:                               # grad-less parameters hold zeros, so the arena norm is the model's norm
-            g.mul_(torch.clamp(self.clip_norm / (torch.linalg.vector_norm(g) + 1e-6), max=1.0))
+        sumsq = None
+        if self.clip_norm:
+            # clip_grad_norm_(max_norm, 2): one reduction kernel for the squared norm (grad-less parameters hold zeros, so the arena's
+            # norm is the model's), the coefficient min(1, max_norm / (norm + 1e-6)) is applied inside the update kernel
+            if self._sumsq is None:
+                self._sumsq = torch.zeros(1, dtype=torch.float32, device=flat.device)
+            L.tc_fill_f32(self._sumsq.data_ptr(), 1, 0.0, stream)
+            L.tc_grad_sumsq(g.data_ptr(), g.numel(), self._sumsq.data_ptr(), stream)
+            sumsq = self._sumsq.data_ptr()
         L.tc_sgd_step_multi(flat.data_ptr(), g.data_ptr(), self.buf.data_ptr(), self._segs_dev.data_ptr(), self._nseg, self._maxlen,
                             float(self.lr), self.lr_dev.data_ptr(), float(self.momentum), float(self.wd), float(grad_scale),
-                            int(self.steps == 0), stream)
+                            int(self.steps == 0), sumsq, float(self.clip_norm or 0.0), stream)
         self.steps += 1
 
 

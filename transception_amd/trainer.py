@@ -86,9 +86,20 @@ def trainer_synapse(cfg: TrainConfig, model, snapshot_path: str, volumes: Option
     opt = FusedSGD(model, lr=cfg.base_lr, momentum=0.9, weight_decay=1e-4, clip_norm=5.0 if cfg.grad_clipping else None)
 
     def lr_at(it: int) -> float:
+        """Learning rate of step `it` (0-based).  Cosine: scheduler.step() follows every optimizer.step() (trainer.py:151-153).
+        Polynomial: the reference computes lr_ from iter_num BEFORE incrementing it and assigns it for the NEXT step (:154-159),
+        so steps 0 and 1 both run at base_lr and step k at base_lr (1 - (k-1)/max)^0.9."""
         if cfg.use_scheduler:
             return cosine_lr(cfg.base_lr, it, max_iterations)
-        return cfg.base_lr * (1.0 - it / max_iterations) ** 0.9
+        return cfg.base_lr * (1.0 - max(it - 1, 0) / max_iterations) ** 0.9
+
+    if distributed:
+        # identical replicas before the first step (the reference's DataParallel re-broadcasts rank 0's weights every forward,
+        # trainer.py:110-111): parameters and BatchNorm statistics come from rank 0
+        model._ensure_flat(dev)
+        dist.broadcast(model.flat_parameters(), src=0, group=group)
+        for buf in model.buffers():
+            dist.broadcast(buf, src=0, group=group)
 
     saves = set(checkpoint_epochs(cfg.max_epochs, cfg.eval_interval))
     hist = {"loss": [], "lr": [], "dice": [], "hd95": [], "checkpoints": []}
@@ -120,10 +131,16 @@ def trainer_synapse(cfg: TrainConfig, model, snapshot_path: str, volumes: Option
                     hist["checkpoints"].append(path)
                     log("save model to {}".format(path))
                 if volumes is not None:
-                    log(f"Running Inference after epoch {epoch_num}")
-                    mean_dice, mean_hd95 = inference(model, volumes(), cfg.num_classes, cfg.img_size, log=log)
-                    hist["dice"].append(mean_dice)
-                    hist["hd95"].append(mean_hd95)
-                    model.train()
+                    # rank 0 evaluates its own replica (the one the checkpoint holds) and shares the two numbers
+                    res = torch.zeros(2, dtype=torch.float64, device=dev)
+                    if rank == 0:
+                        log(f"Running Inference after epoch {epoch_num}")
+                        mean_dice, mean_hd95 = inference(model, volumes(), cfg.num_classes, cfg.img_size, log=log)
+                        res[0], res[1] = mean_dice, mean_hd95
+                        model.train()
+                    if distributed:
+                        dist.broadcast(res, src=0, group=group)
+                    hist["dice"].append(float(res[0]))
+                    hist["hd95"].append(float(res[1]))
     hist["iterations"] = iter_num
     return hist
