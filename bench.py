@@ -34,7 +34,9 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}        # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0}        # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+TORCH_DTYPE = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}
+LOSS_SCALE = {"f32": 1.0, "bf16": 1.0, "f16": 4096.0}     # float16 activations need a loss scale (gradients of order 1e-6)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -149,7 +151,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16"])
+    ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16", "f16"])
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--size", type=int, default=224)
     ap.add_argument("--no-cpu", action="store_true")
@@ -199,14 +201,14 @@ def main():
         m = MSTransception(num_classes=9)
         m.load_state_dict(seeded_state_dict(), strict=True)      # random-init weights of the architecture (name-seeded)
         m.to(dev).train()
-        m.set_compute_dtype(torch.float32 if dtype == "f32" else torch.bfloat16)
+        m.set_compute_dtype(TORCH_DTYPE[dtype])
         m._ensure_flat(dev)
         return m
 
     model = build_model(args.dtype)
     if world > 1:
         dist.broadcast(model.flat_parameters(), src=0)           # C3: identical replicas
-    loss_fn = SegLoss(9, group=group)
+    loss_fn = SegLoss(9, group=group, loss_scale=LOSS_SCALE[args.dtype])
     opt = FusedSGD(model, lr=0.05, momentum=0.9, weight_decay=1e-4)
     x, y = synthetic_batch(args.batch, args.size, dev, 1234 + rank)
     t_max = max(args.steps + args.warmup, 1)
@@ -400,26 +402,27 @@ def side_figures(args, dev, model, loss_fn, opt, step, x, y, build_model, engine
         f2.close()
     # (5) the roofline kernel back-to-back inside a replayed hipGraph on step-shaped operands (the micro-benchmark: warm caches and
     #     clocks; the rocprofv3 average of this command mixes it with the in-step launches)
-    if args.dtype == "bf16" and args.size % 32 == 0:
+    if args.dtype in ("bf16", "f16") and args.size % 32 == 0:
         import ctypes as C
-        from transception_amd._lib import TC_BF16, lib
+        from transception_amd._lib import TC_BF16, TC_F16, lib
+        tcd = TC_BF16 if args.dtype == "bf16" else TC_F16
         Bq, S = args.batch, args.size
         sides = [S // 4, S // 8, S // 16, S // 32]
         nq = [sides[i] * sides[i] * m_ for i, m_ in enumerate((1, 2, 5, 8))]
         Nk = (sides[3] * sides[3]) * (1 + 2 + 5 + 8)
         rows = Bq * sum(nq)
-        q = torch.randn(rows, 64, device=dev).bfloat16(); kv = torch.randn(Bq * Nk, 128, device=dev).bfloat16()
+        q = torch.randn(rows, 64, device=dev).to(TORCH_DTYPE[args.dtype]); kv = torch.randn(Bq * Nk, 128, device=dev).to(TORCH_DTYPE[args.dtype])
         o = torch.empty_like(q); lse = torch.empty(rows, device=dev)
         nqc = (C.c_int * 4)(*nq)
         L = lib()
 
         def attn():
             L.tc_attn_fwd_seg(q.data_ptr(), 64, kv.data_ptr(), 128, kv[:, 64:].data_ptr(), 128, Nk * 128, o.data_ptr(), 64, lse.data_ptr(),
-                              Bq, 4, nqc, Nk, 0.125, TC_BF16, torch.cuda.current_stream(dev).cuda_stream)
+                              Bq, 4, nqc, Nk, 0.125, tcd, torch.cuda.current_stream(dev).cuda_stream)
         us = _graph_replay_us(attn, 30, dev)
         fl = 4.0 * rows * Nk * 64
-        roofs["roofline_graph_replay"] = {"bound": "mfma", "achieved": fl / us / 1e6, "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
-                                          "frac": fl / us / 1e6 / PEAK_TFLOPS["bf16"], "avg_launch_us": us,
+        roofs["roofline_graph_replay"] = {"bound": "mfma", "achieved": fl / us / 1e6, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
+                                          "frac": fl / us / 1e6 / PEAK_TFLOPS[args.dtype], "avg_launch_us": us,
                                           "how": "30 back-to-back launches of attn_fwd_seg_kernel in one replayed hipGraph, step-shaped random operands"}
     return extra, roofs
 

@@ -15,8 +15,9 @@
  *    synchronises; every call is asynchronous on `stream` and capturable in a hipGraph;
  *  - activations are token-major / NHWC: a map [B,H,W,C] is the token matrix [B*H*W, C];
  *    `ld*` arguments are row strides in ELEMENTS so that ops can read/write column slices;
- *  - `dtype` selects the storage type of activations/weights: TC_F32 or TC_BF16; statistics,
- *    accumulators and every `float*` argument are always fp32;
+ *  - `dtype` selects the storage type of activations/weights: TC_F32, TC_BF16 or TC_F16 (IEEE half); statistics,
+ *    accumulators and every `float*` argument are always fp32; the 16-bit types share every kernel (one matrix-core rate),
+ *    they differ in the conversion instructions and the MFMA operand type only;
  *  - return value: TC_OK (0) or a negative TC_ERR_* code; nothing throws across the ABI.
  */
 #ifndef TRANSCEPTION_HIP_H
@@ -27,7 +28,7 @@ extern "C" {
 #endif
 
 enum { TC_OK = 0, TC_ERR_ARG = -1, TC_ERR_LAUNCH = -2, TC_ERR_UNSUPPORTED = -3 };
-enum { TC_F32 = 0, TC_BF16 = 1 };
+enum { TC_F32 = 0, TC_BF16 = 1, TC_F16 = 2 };
 enum { TC_ACT_NONE = 0, TC_ACT_HSWISH = 1, TC_ACT_COORD = 2, TC_ACT_SIGMOID = 3, TC_ACT_GELU = 4 };
 
 /* library identity: returns the ABI version (bumped on any signature change) */

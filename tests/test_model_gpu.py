@@ -194,6 +194,18 @@ def test_modules_bf16_budget_against_reference_goldens(model):
     print("bf16 module errors (abs, worst sample):", {k: f"{v:.2e}" for k, v in sorted(worst.items())})
 
 
+def test_modules_fp16_budget_against_reference_goldens(model):
+    """float16 storage (BASELINE config 5's type; 11-bit mantissa): the same fixtures within 4e-3 (forward) / 1e-2 (input gradient) of
+    the largest reference value -- the 16-bit types share every kernel, only conversions and the MFMA operand type differ."""
+    try:
+        worst = _run_module_cases(model, torch.float16,
+                                  lambda atol: dict(atol=2e-4, scale_rel=4e-3, sum_rtol=4e-3),
+                                  lambda atol: dict(atol=2e-4, scale_rel=1e-2, sum_rtol=1e-2))
+    finally:
+        model.set_compute_dtype(torch.float32)
+    print("fp16 module errors (abs, worst sample):", {k: f"{v:.2e}" for k, v in sorted(worst.items())})
+
+
 def test_ripm_against_reference_golden(model):
     import transception_amd.model as MM
     gold = load("modules.npz")

@@ -358,8 +358,11 @@ def test_seg_loss_and_sgd():
 
 
 # ------------------------------------------------------------------------------------------------ bf16 storage path
+_LP = torch.bfloat16          # the 16-bit storage type under test: the Gb / lp fixtures run every test below for bf16 and fp16
+
+
 def _bf(t):
-    return t.to(torch.bfloat16)
+    return t.to(_LP)
 
 
 def closeb(got, want, rel=1.5e-2, what=""):
@@ -370,10 +373,18 @@ def closeb(got, want, rel=1.5e-2, what=""):
     assert err <= rel * scale + 1e-6, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
 
 
+@pytest.fixture(params=[torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def lp(request):
+    global _LP
+    _LP = request.param
+    yield request.param
+    _LP = torch.bfloat16
+
+
 @pytest.fixture()
-def Gb():
+def Gb(lp):
     from transception_amd.engine import Graph
-    return Graph(torch.bfloat16, torch.device(DEV), training=True, record=True)
+    return Graph(lp, torch.device(DEV), training=True, record=True)
 
 
 def mkPb(t):
@@ -418,7 +429,7 @@ def test_bmm_bf16(Gb, tA, tB):
 
 
 @pytest.mark.parametrize("Nq,Nk", [(200, 98), (392, 784), (130, 784)])
-def test_attention_bf16(Nq, Nk):
+def test_attention_bf16(lp, Nq, Nk):
     from transception_amd.engine import Graph
     B, d = 2, 64
     q, kv, gy = _bf(T(f"ab.q{Nq}", (B * Nq, d))), _bf(T(f"ab.kv{Nk}", (B * Nk, 2 * d))), _bf(T(f"ab.g{Nq}", (B * Nq, d)))
@@ -426,7 +437,7 @@ def test_attention_bf16(Nq, Nk):
     k, v = kvr[:, :d].reshape(B, Nk, d), kvr[:, d:].reshape(B, Nk, d)
     y = (torch.softmax(qr.view(B, Nq, d) @ k.transpose(1, 2) * 0.125, -1) @ v).reshape(B * Nq, d)
     y.backward(gy.float())
-    Gx = Graph(torch.bfloat16, torch.device(DEV), True, True)
+    Gx = Graph(lp, torch.device(DEV), True, True)
     Gx.use_fused_attention = True
     qv, kvv = mkV(Gx, q), mkV(Gx, kv)
     out = Gx.attention(qv, kvv.colslice(0, d), kvv.colslice(d, 2 * d), B, Nq, Nk, 0.125)
@@ -452,13 +463,13 @@ def test_dwconv_layernorm_bf16(Gb):
     closeb(bp.grad, br.grad, what="dw db")
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_attention_segmented(dtype):
     """Stage-major queries (segments of B images each) against image-major K/V: one launch on the bf16 path."""
     from transception_amd.engine import Graph
     B, d, Nk, nq = 2, 64, 210, [150, 64, 33]
     rows = B * sum(nq)
-    cast = (lambda t: t) if dtype == torch.float32 else _bf
+    cast = (lambda t: t.to(dtype))
     q, kv, gy = cast(T("as.q", (rows, d))), cast(T("as.kv", (B * Nk, 2 * d))), cast(T("as.g", (rows, d)))
     qr, kvr = q.float().requires_grad_(), kv.float().requires_grad_()
     k, v = kvr[:, :d].reshape(B, Nk, d), kvr[:, d:].reshape(B, Nk, d)

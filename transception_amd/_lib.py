@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TC_LIB_PATH") or os.path.join(HERE, "libtransception_hip.so")   # override: A/B kernel experiments only
 
-TC_F32, TC_BF16 = 0, 1
+TC_F32, TC_BF16, TC_F16 = 0, 1, 2
 ACT_NONE, ACT_HSWISH, ACT_COORD, ACT_SIGMOID, ACT_GELU = 0, 1, 2, 3, 4
 ABI_VERSION = 3
 

@@ -32,11 +32,11 @@ struct Segs {
 
 __device__ __forceinline__ int pi_row(int i) { return 16 * ((i >> 2) & 1) + (i & 3) + 4 * (i >> 3); }
 __device__ __forceinline__ int d_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-__device__ __forceinline__ bf16x8 ld_frag(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
-__device__ __forceinline__ bf16x8 pack8(const f32x16& v, int o) {
-    bf16x8 r;
+template <typename V8> __device__ __forceinline__ V8 ld_frag(const bf16_t* p) { return *reinterpret_cast<const V8*>(p); }
+template <typename H> __device__ __forceinline__ typename TcHalf<H>::v8 pack8(const f32x16& v, int o) {
+    typename TcHalf<H>::v8 r;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) r[i] = (__bf16)v[o + i];
+    for (int i = 0; i < 8; ++i) r[i] = (typename TcHalf<H>::e)v[o + i];
     return r;
 }
 __device__ __forceinline__ uint4 ld_row8(const bf16_t* base, int ld, int row, int nrows, int c8) {
@@ -73,10 +73,10 @@ __device__ __forceinline__ void fill_map(int tid, int it, int& r, int& c8, int& 
 // store per strip instead of eight 2-byte ones (st_t8).
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef short s16x8_t __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ bf16x8 ld_frag_tr(const bf16_t* lo, const bf16_t* hi) {
+template <typename V8> __device__ __forceinline__ V8 ld_frag_tr(const bf16_t* lo, const bf16_t* hi) {
     const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(lo));
     const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(hi));
-    return __builtin_bit_cast(bf16x8, (s16x8_t)__builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+    return __builtin_bit_cast(V8, (s16x8_t)__builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 __device__ __forceinline__ int key_row(int r) { return (r & ~15) | ((r & 3) << 2) | ((r >> 2) & 3); }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -94,6 +94,7 @@ __device__ __forceinline__ void locate_tile(const Segs& sg, int t, int& row_base
     row_base = sg.row0[s] + b * nq;
 }
 
+template <typename H>
 __global__ __launch_bounds__(256, 4) void attn_fwd_seg_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
                                                               const bf16_t* __restrict__ V, int ldv, long long skv, bf16_t* __restrict__ O,
                                                               int ldo, float* __restrict__ lse, Segs sg, int Nk, float scale) {
@@ -113,11 +114,12 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_seg_kernel(const bf16_t* __re
     const long long qrow = (long long)sg.row0[sgi] + (long long)b * nq + ql;
     const bf16_t* Kb = K + b * skv;
     const bf16_t* Vb = V + b * skv;
-    bf16x8 qf[4];
+    typedef typename TcHalf<H>::v8 V8;
+    V8 qf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
         const uint4 v = ok ? *reinterpret_cast<const uint4*>(Q + qrow * ldq + 16 * ks + 8 * h) : make_uint4(0u, 0u, 0u, 0u);
-        qf[ks] = *reinterpret_cast<const bf16x8*>(&v);
+        qf[ks] = *reinterpret_cast<const V8*>(&v);
     }
     const float qs = scale * LOG2E;
     f32x16 acc0, acc1;
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_seg_kernel(const bf16_t* __re
             for (int r = 0; r < 16; ++r) s[r] = 0.f;
             const bf16_t* kp = Ks + (32 * sub + krow) * LDR + 8 * h;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(kp + 16 * ks), qf[ks], s, 0, 0, 0);
+            for (int ks = 0; ks < 4; ++ks) s = TcHalf<H>::mfma(ld_frag<V8>(kp + 16 * ks), qf[ks], s);
             return s;
         };
         // online softmax of a finished S^T tile (register VALU) followed by O^T += V^T P^T
@@ -201,9 +203,9 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_seg_kernel(const bf16_t* __re
             const bf16_t* vp = Vs + (32 * sub + 16 * h + 4 * (gi >> 2)) * LDR + 16 * gq + 4 * (gi & 3);
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2) {
-                const bf16x8 pb = pack8(s, 8 * k2);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag_tr(vp + (2 * k2) * LDR, vp + (2 * k2 + 1) * LDR), pb, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag_tr(vp + (2 * k2) * LDR + 32, vp + (2 * k2 + 1) * LDR + 32), pb, acc1, 0, 0, 0);
+                const V8 pb = pack8<H>(s, 8 * k2);
+                acc0 = TcHalf<H>::mfma(ld_frag_tr<V8>(vp + (2 * k2) * LDR, vp + (2 * k2 + 1) * LDR), pb, acc0);
+                acc1 = TcHalf<H>::mfma(ld_frag_tr<V8>(vp + (2 * k2) * LDR + 32, vp + (2 * k2 + 1) * LDR + 32), pb, acc1);
             }
         };
 #pragma unroll 1
@@ -215,13 +217,14 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_seg_kernel(const bf16_t* __re
         bf16_t* orow = O + qrow * ldo;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            st4<bf16_t>(orow + 8 * g + 4 * h, make_float4(acc0[4 * g] * inv, acc0[4 * g + 1] * inv, acc0[4 * g + 2] * inv, acc0[4 * g + 3] * inv));
-            st4<bf16_t>(orow + 32 + 8 * g + 4 * h, make_float4(acc1[4 * g] * inv, acc1[4 * g + 1] * inv, acc1[4 * g + 2] * inv, acc1[4 * g + 3] * inv));
+            st4<H>(reinterpret_cast<H*>(orow + 8 * g + 4 * h), make_float4(acc0[4 * g] * inv, acc0[4 * g + 1] * inv, acc0[4 * g + 2] * inv, acc0[4 * g + 3] * inv));
+            st4<H>(reinterpret_cast<H*>(orow + 32 + 8 * g + 4 * h), make_float4(acc1[4 * g] * inv, acc1[4 * g + 1] * inv, acc1[4 * g + 2] * inv, acc1[4 * g + 3] * inv));
         }
         if (h == 0) lse[qrow] = (m + log2f(lsum)) * LN2;
     }
 }
 
+template <typename H>
 __global__ __launch_bounds__(256, 3) void attn_bwd_dq_seg_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
                                                                  const bf16_t* __restrict__ V, int ldv, long long skv,
                                                                  const bf16_t* __restrict__ dO, int lddo, const float* __restrict__ lse,
@@ -242,13 +245,14 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_seg_kernel(const bf16_t* _
     const int ql = (wt - sg.t32[sgi]) * 32 + j;
     const bool ok = wt < nwt && ql < nq;
     const long long qrow = (long long)sg.row0[sgi] + (long long)b * nq + ql;
-    bf16x8 qf[4], dof[4];
+    typedef typename TcHalf<H>::v8 V8;
+    V8 qf[4], dof[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
         const uint4 v = ok ? *reinterpret_cast<const uint4*>(Q + qrow * ldq + 16 * ks + 8 * h) : make_uint4(0u, 0u, 0u, 0u);
         const uint4 g = ok ? *reinterpret_cast<const uint4*>(dO + qrow * lddo + 16 * ks + 8 * h) : make_uint4(0u, 0u, 0u, 0u);
-        qf[ks] = *reinterpret_cast<const bf16x8*>(&v);
-        dof[ks] = *reinterpret_cast<const bf16x8*>(&g);
+        qf[ks] = *reinterpret_cast<const V8*>(&v);
+        dof[ks] = *reinterpret_cast<const V8*>(&g);
     }
     const float qs = scale * LOG2E;
     const float l2 = ok ? lse[qrow] * LOG2E : 0.f;
@@ -292,8 +296,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_seg_kernel(const bf16_t* _
             const bf16_t* vp = Vs + (32 * sub + krow) * LDR + 8 * h;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(kp + 16 * ks), qf[ks], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(vp + 16 * ks), dof[ks], dp, 0, 0, 0);
+                s = TcHalf<H>::mfma(ld_frag<V8>(kp + 16 * ks), qf[ks], s);
+                dp = TcHalf<H>::mfma(ld_frag<V8>(vp + 16 * ks), dof[ks], dp);
             }
             const bool tail = kv0 + 32 > Nk;
 #pragma unroll
@@ -306,9 +310,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_seg_kernel(const bf16_t* _
             const bf16_t* kt = Ks + (32 * sub + 16 * h + 4 * (gi >> 2)) * LDR + 16 * gq + 4 * (gi & 3);
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2) {
-                const bf16x8 db = pack8(s, 8 * k2);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag_tr(kt + (2 * k2) * LDR, kt + (2 * k2 + 1) * LDR), db, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag_tr(kt + (2 * k2) * LDR + 32, kt + (2 * k2 + 1) * LDR + 32), db, acc1, 0, 0, 0);
+                const V8 db = pack8<H>(s, 8 * k2);
+                acc0 = TcHalf<H>::mfma(ld_frag_tr<V8>(kt + (2 * k2) * LDR, kt + (2 * k2 + 1) * LDR), db, acc0);
+                acc1 = TcHalf<H>::mfma(ld_frag_tr<V8>(kt + (2 * k2) * LDR + 32, kt + (2 * k2 + 1) * LDR + 32), db, acc1);
             }
         }
     }
@@ -316,8 +320,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_seg_kernel(const bf16_t* _
         bf16_t* row = dQ + qrow * lddq;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            st4<bf16_t>(row + 8 * g + 4 * h, make_float4(acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]));
-            st4<bf16_t>(row + 32 + 8 * g + 4 * h, make_float4(acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]));
+            st4<H>(reinterpret_cast<H*>(row + 8 * g + 4 * h), make_float4(acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]));
+            st4<H>(reinterpret_cast<H*>(row + 32 + 8 * g + 4 * h), make_float4(acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]));
         }
     }
 }
@@ -328,7 +332,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_seg_kernel(const bf16_t* _
 // waves -- the first version staged them per wave (4x the LDS stores and global reads) and needed 288 VGPRs (one wave per SIMD).
 // Query chunks (gridDim.z) add their partial sums atomically into the fp32 scratch dkv32 [B][Nk][128] (dK | dV), which
 // attn_dkv_store_kernel converts to the bf16 outputs.
-template <int NW>
+template <typename H, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
                                                                     const bf16_t* __restrict__ V, int ldv, long long skv,
                                                                     const bf16_t* __restrict__ dO, int lddo, const float* __restrict__ lse,
@@ -347,13 +351,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16
     float* dls = lss + QS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
     const int b = blockIdx.y, kv0 = (blockIdx.x * NW + wave) * 32, key = min(kv0 + j, Nk - 1);
-    bf16x8 kf[4], vf[4];
+    typedef typename TcHalf<H>::v8 V8;
+    V8 kf[4], vf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {           // keys past Nk: a duplicate row whose results are never stored
         const uint4 a = *reinterpret_cast<const uint4*>(K + b * skv + (long long)key * ldk + 16 * ks + 8 * h);
         const uint4 c = *reinterpret_cast<const uint4*>(V + b * skv + (long long)key * ldv + 16 * ks + 8 * h);
-        kf[ks] = *reinterpret_cast<const bf16x8*>(&a);
-        vf[ks] = *reinterpret_cast<const bf16x8*>(&c);
+        kf[ks] = *reinterpret_cast<const V8*>(&a);
+        vf[ks] = *reinterpret_cast<const V8*>(&c);
     }
     const float qs = scale * LOG2E;
     f32x16 dk0, dk1, dv0, dv1;
@@ -423,8 +428,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16
             const bf16_t* gp = dOs + (32 * qt + qrow) * LDQ + 8 * h;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(qp + 16 * ks), kf[ks], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(gp + 16 * ks), vf[ks], dp, 0, 0, 0);
+                s = TcHalf<H>::mfma(ld_frag<V8>(qp + 16 * ks), kf[ks], s);
+                dp = TcHalf<H>::mfma(ld_frag<V8>(gp + 16 * ks), vf[ks], dp);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -437,11 +442,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16
             const bf16_t* qtp = Qt + j * LDT + 32 * qt + 16 * h;
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2) {
-                const bf16x8 pb = pack8(s, 8 * k2), db = pack8(dp, 8 * k2);
-                dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(gt + 8 * k2), pb, dv0, 0, 0, 0);
-                dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(gt + 32 * LDT + 8 * k2), pb, dv1, 0, 0, 0);
-                dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(qtp + 8 * k2), db, dk0, 0, 0, 0);
-                dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(qtp + 32 * LDT + 8 * k2), db, dk1, 0, 0, 0);
+                const V8 pb = pack8<H>(s, 8 * k2), db = pack8<H>(dp, 8 * k2);
+                dv0 = TcHalf<H>::mfma(ld_frag<V8>(gt + 8 * k2), pb, dv0);
+                dv1 = TcHalf<H>::mfma(ld_frag<V8>(gt + 32 * LDT + 8 * k2), pb, dv1);
+                dk0 = TcHalf<H>::mfma(ld_frag<V8>(qtp + 8 * k2), db, dk0);
+                dk1 = TcHalf<H>::mfma(ld_frag<V8>(qtp + 32 * LDT + 8 * k2), db, dk1);
             }
         }
     }
@@ -465,6 +470,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16
     }
 }
 
+template <typename H>
 __global__ __launch_bounds__(256) void attn_dkv_store_kernel(const float* __restrict__ dkv32, bf16_t* __restrict__ dK, int lddk,
                                                              bf16_t* __restrict__ dV, int lddv, long long sdkv, int B, int Nk) {
     const long long n = (long long)B * Nk * 32;                 // float4 groups
@@ -472,7 +478,7 @@ __global__ __launch_bounds__(256) void attn_dkv_store_kernel(const float* __rest
         const int q = (int)(i & 31), key = (int)((i >> 5) % Nk), b = (int)((i >> 5) / Nk);
         const float4 v = *reinterpret_cast<const float4*>(dkv32 + i * 4);
         bf16_t* dst = (q < 16 ? dK + b * sdkv + (long long)key * lddk + q * 4 : dV + b * sdkv + (long long)key * lddv + (q - 16) * 4);
-        st4<bf16_t>(dst, v);
+        st4<H>(reinterpret_cast<H*>(dst), v);
     }
 }
 
@@ -481,12 +487,13 @@ __global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, lo
         reinterpret_cast<float4*>(p)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+template <typename H>
 __global__ __launch_bounds__(256) void delta_rows_kernel(const bf16_t* __restrict__ O, int ldo, const bf16_t* __restrict__ dO, int lddo,
                                                          float* __restrict__ delta, long long rows) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const float s = wave_sum(bf2f(O[row * ldo + lane]) * bf2f(dO[row * lddo + lane]));
+    const float s = wave_sum(ldf<H>(reinterpret_cast<const H*>(O + row * ldo + lane)) * ldf<H>(reinterpret_cast<const H*>(dO + row * lddo + lane)));
     if (lane == 0) delta[row] = s;
 }
 
@@ -525,9 +532,13 @@ extern "C" int tc_attn_fwd_seg(const void* Q, int ldq, const void* K, int ldk, c
         }
         return TC_OK;
     }
-    if (dtype != TC_BF16 || ((ldq | ldk | ldv) & 7) || (skv & 7) || (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) || (ldo & 3)) return TC_ERR_ARG;
-    hipLaunchKernelGGL(attn_fwd_seg_kernel, dim3((unsigned)B * ((sg.t32[nseg] + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk,
-                       (const bf16_t*)V, ldv, skv, (bf16_t*)O, ldo, lse, sg, Nk, scale);
+    if ((dtype != TC_BF16 && dtype != TC_F16) || ((ldq | ldk | ldv) & 7) || (skv & 7) || (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) || (ldo & 3))
+        return TC_ERR_ARG;
+    const dim3 grid((unsigned)B * ((sg.t32[nseg] + 3) / 4));
+#define TC_FWD(HH) hipLaunchKernelGGL(attn_fwd_seg_kernel<HH>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk, \
+                                      (const bf16_t*)V, ldv, skv, (bf16_t*)O, ldo, lse, sg, Nk, scale)
+    if (dtype == TC_BF16) TC_FWD(bf16_t); else TC_FWD(f16_t);
+#undef TC_FWD
     return tc_launch_status();
 }
 
@@ -551,32 +562,32 @@ extern "C" int tc_attn_bwd_seg(const void* Q, int ldq, const void* K, int ldk, c
         }
         return TC_OK;
     }
-    if (dtype != TC_BF16 || !dkv32 || ((ldq | ldk | ldv | lddo) & 7) || (skv & 7) ||
+    if ((dtype != TC_BF16 && dtype != TC_F16) || !dkv32 || ((ldq | ldk | ldv | lddo) & 7) || (skv & 7) ||
         (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)dO) & 15) || ((ldo | lddq | lddk | lddv) & 3) || (sdkv & 3))
         return TC_ERR_ARG;
     // zero the fp32 dK/dV scratch with a kernel: a memset NODE in a captured single-stream graph was observed to run out of order
     hipLaunchKernelGGL(zero_f32_kernel, dim3(tc_blocks((long long)B * Nk * 32, 256, 1024)), dim3(256), 0, s, dkv32, (long long)B * Nk * 32);
-    hipLaunchKernelGGL(delta_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const bf16_t*)O, ldo, (const bf16_t*)dO, lddo, delta, rows);
-    {
-        // workgroups of 4 key waves; query chunks so that ~2 workgroups per CU exist
-        const int kt = (Nk + 31) / 32;
-        const int nw = 4;                                            // measured: 4 waves x 2 workgroups per CU (224 VGPRs) beats 5 x 1
-        const int kb = (kt + nw - 1) / nw, ntiles = sg.t32[nseg];
-        int zs = 512 / (kb * B);
-        zs = zs < 1 ? 1 : (zs > (ntiles + 1) / 2 ? (ntiles + 1) / 2 : zs);
-        int tpc = (ntiles + zs - 1) / zs;
-        tpc = (tpc + 1) & ~1;                                        // whole 64-query stages
-        zs = (ntiles + tpc - 1) / tpc;
-        if (nw == 5)
-            hipLaunchKernelGGL(attn_bwd_dkv_seg_kernel<5>, dim3(kb, B, zs), dim3(320), 0, s, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk,
-                               (const bf16_t*)V, ldv, skv, (const bf16_t*)dO, lddo, lse, delta, dkv32, sg, Nk, scale, tpc);
-        else
-            hipLaunchKernelGGL(attn_bwd_dkv_seg_kernel<4>, dim3(kb, B, zs), dim3(256), 0, s, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk,
-                               (const bf16_t*)V, ldv, skv, (const bf16_t*)dO, lddo, lse, delta, dkv32, sg, Nk, scale, tpc);
+    // workgroups of 4 key waves (measured: 4 waves x 2 workgroups per CU beats 5 x 1); query chunks so that ~2 workgroups per CU exist
+    const int kt = (Nk + 31) / 32, nw = 4;
+    const int kb = (kt + nw - 1) / nw, ntiles = sg.t32[nseg];
+    int zs = 512 / (kb * B);
+    zs = zs < 1 ? 1 : (zs > (ntiles + 1) / 2 ? (ntiles + 1) / 2 : zs);
+    int tpc = (ntiles + zs - 1) / zs;
+    tpc = (tpc + 1) & ~1;                                            // whole 64-query stages
+    zs = (ntiles + tpc - 1) / tpc;
+#define TC_BWD(HH)                                                                                                                          \
+    {                                                                                                                                       \
+        hipLaunchKernelGGL(delta_rows_kernel<HH>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const bf16_t*)O, ldo, (const bf16_t*)dO, \
+                           lddo, delta, rows);                                                                                              \
+        hipLaunchKernelGGL((attn_bwd_dkv_seg_kernel<HH, 4>), dim3(kb, B, zs), dim3(256), 0, s, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk,    \
+                           (const bf16_t*)V, ldv, skv, (const bf16_t*)dO, lddo, lse, delta, dkv32, sg, Nk, scale, tpc);                     \
+        hipLaunchKernelGGL(attn_dkv_store_kernel<HH>, dim3(tc_blocks((long long)B * Nk * 32, 256, 1024)), dim3(256), 0, s, dkv32,           \
+                           (bf16_t*)dK, lddk, (bf16_t*)dV, lddv, sdkv, B, Nk);                                                              \
+        hipLaunchKernelGGL(attn_bwd_dq_seg_kernel<HH>, dim3((unsigned)B * ((sg.t32[nseg] + 3) / 4)), dim3(256), 0, s, (const bf16_t*)Q, ldq, \
+                           (const bf16_t*)K, ldk, (const bf16_t*)V, ldv, skv, (const bf16_t*)dO, lddo, lse, delta, (bf16_t*)dQ, lddq, sg, Nk, \
+                           scale);                                                                                                          \
     }
-    hipLaunchKernelGGL(attn_dkv_store_kernel, dim3(tc_blocks((long long)B * Nk * 32, 256, 1024)), dim3(256), 0, s, dkv32, (bf16_t*)dK, lddk,
-                       (bf16_t*)dV, lddv, sdkv, B, Nk);
-    hipLaunchKernelGGL(attn_bwd_dq_seg_kernel, dim3((unsigned)B * ((sg.t32[nseg] + 3) / 4)), dim3(256), 0, s, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk, (const bf16_t*)V,
-                       ldv, skv, (const bf16_t*)dO, lddo, lse, delta, (bf16_t*)dQ, lddq, sg, Nk, scale);
+    if (dtype == TC_BF16) TC_BWD(bf16_t) else TC_BWD(f16_t)
+#undef TC_BWD
     return tc_launch_status();
 }

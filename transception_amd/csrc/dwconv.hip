@@ -120,11 +120,16 @@ template <> __device__ __forceinline__ void ldv<float, 4>(const float* p, float*
 template <> __device__ __forceinline__ void ldv<float, 2>(const float* p, float* o) { const float2 v = *reinterpret_cast<const float2*>(p); o[0] = v.x; o[1] = v.y; }
 template <> __device__ __forceinline__ void ldv<bf16_t, 4>(const bf16_t* p, float* o) { const float4 v = ld4<bf16_t>(p); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
 template <> __device__ __forceinline__ void ldv<bf16_t, 2>(const bf16_t* p, float* o) { const unsigned r = *reinterpret_cast<const unsigned*>(p); o[0] = __uint_as_float(r << 16); o[1] = __uint_as_float(r & 0xffff0000u); }
+template <> __device__ __forceinline__ void ldv<f16_t, 4>(const f16_t* p, float* o) { const float4 v = ld4<f16_t>(p); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+template <> __device__ __forceinline__ void ldv<f16_t, 2>(const f16_t* p, float* o) { unpack2<f16_t>(*reinterpret_cast<const unsigned*>(p), o[0], o[1]); }
 template <typename T, int CPT> __device__ __forceinline__ void stv(T* p, const float* o);
 template <> __device__ __forceinline__ void stv<float, 4>(float* p, const float* o) { *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]); }
 template <> __device__ __forceinline__ void stv<float, 2>(float* p, const float* o) { *reinterpret_cast<float2*>(p) = make_float2(o[0], o[1]); }
 template <> __device__ __forceinline__ void stv<bf16_t, 4>(bf16_t* p, const float* o) { st4<bf16_t>(p, make_float4(o[0], o[1], o[2], o[3])); }
 template <> __device__ __forceinline__ void stv<bf16_t, 2>(bf16_t* p, const float* o) { *reinterpret_cast<unsigned*>(p) = pack2bf(o[0], o[1]); }
+
+template <> __device__ __forceinline__ void stv<f16_t, 4>(f16_t* p, const float* o) { st4<f16_t>(p, make_float4(o[0], o[1], o[2], o[3])); }
+template <> __device__ __forceinline__ void stv<f16_t, 2>(f16_t* p, const float* o) { *reinterpret_cast<unsigned*>(p) = pack2h(o[0], o[1]); }
 
 template <typename T, int K, int CPT, int MODE>
 __global__ __launch_bounds__(256) void dw_strip_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ w, const T* __restrict__ bias,
@@ -300,6 +305,7 @@ int launch_strip(const void* x, int ldx, const void* w, const void* bias, const 
 template <typename T> struct Vec16;
 template <> struct Vec16<float> { static constexpr int N = 4; };
 template <> struct Vec16<bf16_t> { static constexpr int N = 8; };
+template <> struct Vec16<f16_t> { static constexpr int N = 8; };
 template <typename T> __device__ __forceinline__ void unpack16(const uint4& r, float* o);
 template <> __device__ __forceinline__ void unpack16<float>(const uint4& r, float* o) {
     o[0] = __uint_as_float(r.x); o[1] = __uint_as_float(r.y); o[2] = __uint_as_float(r.z); o[3] = __uint_as_float(r.w);
@@ -310,6 +316,9 @@ template <> __device__ __forceinline__ void unpack16<bf16_t>(const uint4& r, flo
     o[4] = __uint_as_float(r.z << 16); o[5] = __uint_as_float(r.z & 0xffff0000u);
     o[6] = __uint_as_float(r.w << 16); o[7] = __uint_as_float(r.w & 0xffff0000u);
 }
+template <> __device__ __forceinline__ void unpack16<f16_t>(const uint4& r, float* o) {
+    unpack2<f16_t>(r.x, o[0], o[1]); unpack2<f16_t>(r.y, o[2], o[3]); unpack2<f16_t>(r.z, o[4], o[5]); unpack2<f16_t>(r.w, o[6], o[7]);
+}
 template <typename T> __device__ __forceinline__ uint4 pack16(const float* o);
 template <> __device__ __forceinline__ uint4 pack16<float>(const float* o) {
     return make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3]));
@@ -318,6 +327,9 @@ template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* o) {
     return make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
 }
 
+template <> __device__ __forceinline__ uint4 pack16<f16_t>(const float* o) {
+    return make_uint4(pack2h(o[0], o[1]), pack2h(o[2], o[3]), pack2h(o[4], o[5]), pack2h(o[6], o[7]));
+}
 // the same vectors as pairs for the packed fp32 pipe (v_pk_fma_f32: two multiply-adds per issue slot)
 template <typename T> __device__ __forceinline__ void unpack16v(const uint4& r, tc_f32x2* o);
 template <> __device__ __forceinline__ void unpack16v<float>(const uint4& r, tc_f32x2* o) {
@@ -329,12 +341,23 @@ template <> __device__ __forceinline__ void unpack16v<bf16_t>(const uint4& r, tc
     o[2] = tc_f32x2{__uint_as_float(r.z << 16), __uint_as_float(r.z & 0xffff0000u)};
     o[3] = tc_f32x2{__uint_as_float(r.w << 16), __uint_as_float(r.w & 0xffff0000u)};
 }
+template <> __device__ __forceinline__ void unpack16v<f16_t>(const uint4& r, tc_f32x2* o) {
+    float a, b;
+    unpack2<f16_t>(r.x, a, b); o[0] = tc_f32x2{a, b};
+    unpack2<f16_t>(r.y, a, b); o[1] = tc_f32x2{a, b};
+    unpack2<f16_t>(r.z, a, b); o[2] = tc_f32x2{a, b};
+    unpack2<f16_t>(r.w, a, b); o[3] = tc_f32x2{a, b};
+}
 template <typename T> __device__ __forceinline__ uint4 pack16v(const tc_f32x2* o);
 template <> __device__ __forceinline__ uint4 pack16v<float>(const tc_f32x2* o) {
     return make_uint4(__float_as_uint(o[0].x), __float_as_uint(o[0].y), __float_as_uint(o[1].x), __float_as_uint(o[1].y));
 }
 template <> __device__ __forceinline__ uint4 pack16v<bf16_t>(const tc_f32x2* o) {
     return make_uint4(pack2bf(o[0].x, o[0].y), pack2bf(o[1].x, o[1].y), pack2bf(o[2].x, o[2].y), pack2bf(o[3].x, o[3].y));
+}
+
+template <> __device__ __forceinline__ uint4 pack16v<f16_t>(const tc_f32x2* o) {
+    return make_uint4(pack2h(o[0].x, o[0].y), pack2h(o[1].x, o[1].y), pack2h(o[2].x, o[2].y), pack2h(o[3].x, o[3].y));
 }
 
 template <int K, int CG> struct DwTile {
@@ -1297,7 +1320,7 @@ extern "C" int tc_dwconv_multi(const TcDwSeg* segs, int nseg, int mode, int add_
         const void* second = mode == 2 ? g.dy : g.y;
         const int ld2 = mode == 2 ? g.lddy : g.ldy;
         if (dtype == TC_F32) tile_ok = tile_ok && dw_tile_ok<float>(g.x, g.ldx, second, ld2, g.C);
-        else tile_ok = tile_ok && dw_tile_ok<bf16_t>(g.x, g.ldx, second, ld2, g.C);
+        else tile_ok = tile_ok && dw_tile_ok<bf16_t>(g.x, g.ldx, second, ld2, g.C);           // (either 16-bit type)
     }
     if (tile_ok) TC_DISPATCH_DTYPE(dtype, return (launch_multi<T>(segs, nseg, mode, add_input, accumulate, groups, wstride, ws, ws_bytes,
                                                                   (hipStream_t)stream)));
@@ -1317,7 +1340,7 @@ extern "C" int tc_dwconv_multi(const TcDwSeg* segs, int nseg, int mode, int add_
 extern "C" int tc_ffn_chunk(int C, int dtype) {
     if (C <= 0) return TC_ERR_ARG;
     if (dtype == TC_F32) return dw_pick_cg<float>(C) * Vec16<float>::N;
-    if (dtype == TC_BF16) return dw_pick_cg<bf16_t>(C) * Vec16<bf16_t>::N;
+    if (dtype == TC_BF16 || dtype == TC_F16) return dw_pick_cg<bf16_t>(C) * Vec16<bf16_t>::N;
     return TC_ERR_ARG;
 }
 

@@ -339,6 +339,10 @@ extern "C" int tc_cast(const void* src, void* dst, long long n, int src_dtype, i
         hipLaunchKernelGGL((cast_kernel<float, bf16_t>), g1(n), dim3(256), 0, TC_S, (const float*)src, (bf16_t*)dst, n);
     else if (src_dtype == TC_BF16 && dst_dtype == TC_F32)
         hipLaunchKernelGGL((cast_kernel<bf16_t, float>), g1(n), dim3(256), 0, TC_S, (const bf16_t*)src, (float*)dst, n);
+    else if (src_dtype == TC_F32 && dst_dtype == TC_F16)
+        hipLaunchKernelGGL((cast_kernel<float, f16_t>), g1(n), dim3(256), 0, TC_S, (const float*)src, (f16_t*)dst, n);
+    else if (src_dtype == TC_F16 && dst_dtype == TC_F32)
+        hipLaunchKernelGGL((cast_kernel<f16_t, float>), g1(n), dim3(256), 0, TC_S, (const f16_t*)src, (float*)dst, n);
     else return TC_ERR_ARG;
     return tc_launch_status();
 }

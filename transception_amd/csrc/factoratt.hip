@@ -16,6 +16,7 @@ constexpr int FA_MAXCH = 64;
 template <typename T> struct V16;
 template <> struct V16<float> { static constexpr int N = 4; };
 template <> struct V16<bf16_t> { static constexpr int N = 8; };
+template <> struct V16<f16_t> { static constexpr int N = 8; };
 template <typename T> __device__ __forceinline__ void unpack16(const uint4& r, float* o);
 template <> __device__ __forceinline__ void unpack16<float>(const uint4& r, float* o) {
     o[0] = __uint_as_float(r.x); o[1] = __uint_as_float(r.y); o[2] = __uint_as_float(r.z); o[3] = __uint_as_float(r.w);
@@ -25,12 +26,18 @@ template <> __device__ __forceinline__ void unpack16<bf16_t>(const uint4& r, flo
     o[3] = __uint_as_float(r.y & 0xffff0000u); o[4] = __uint_as_float(r.z << 16); o[5] = __uint_as_float(r.z & 0xffff0000u);
     o[6] = __uint_as_float(r.w << 16); o[7] = __uint_as_float(r.w & 0xffff0000u);
 }
+template <> __device__ __forceinline__ void unpack16<f16_t>(const uint4& r, float* o) {
+    unpack2<f16_t>(r.x, o[0], o[1]); unpack2<f16_t>(r.y, o[2], o[3]); unpack2<f16_t>(r.z, o[4], o[5]); unpack2<f16_t>(r.w, o[6], o[7]);
+}
 template <typename T> __device__ __forceinline__ uint4 pack16(const float* o);
 template <> __device__ __forceinline__ uint4 pack16<float>(const float* o) {
     return make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3]));
 }
 template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* o) {
     return make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
+}
+template <> __device__ __forceinline__ uint4 pack16<f16_t>(const float* o) {
+    return make_uint4(pack2h(o[0], o[1]), pack2h(o[2], o[3]), pack2h(o[4], o[5]), pack2h(o[6], o[7]));
 }
 // head tile [N][Ch] of a row-strided matrix -> fp32 LDS, 16-byte loads, four in flight per thread (a scalar copy loop keeps ONE
 // load in flight and made the first version of this kernel 50 us for 6272 elements)
@@ -80,11 +87,13 @@ __device__ __forceinline__ void fa_load_tile_raw(T* dst, const T* src, int ld, i
 }
 __device__ __forceinline__ float fa_get(const float* p, int i) { return p[i]; }
 __device__ __forceinline__ float fa_get(const bf16_t* p, int i) { return bf2f(p[i]); }
+__device__ __forceinline__ float fa_get(const f16_t* p, int i) { return h2f(p[i]); }
 __device__ __forceinline__ void fa_get8(const float* p, float* o) {
     const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
     o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
 }
 __device__ __forceinline__ void fa_get8(const bf16_t* p, float* o) { unpack16<bf16_t>(*reinterpret_cast<const uint4*>(p), o); }
+__device__ __forceinline__ void fa_get8(const f16_t* p, float* o) { unpack16<f16_t>(*reinterpret_cast<const uint4*>(p), o); }
 
 // out[i][j] = sum_n a[n,i] * b[n,j]   (Ch x Ch, Ch a multiple of 8).  A thread owns (row i, 8 consecutive j) for the rows
 // n = rl, rl + RL, ...: one read of a[n,i], two 16-byte reads of b[n, j0..j0+7], 8 FMAs; the RL row lanes of an output sit next to

@@ -16,6 +16,19 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// The two 16-bit storage types run the same kernels: tiles move as raw 16-bit words, only the MFMA operand type and the
+// conversions differ (H = bf16_t or f16_t).
+template <typename H> struct HalfOps;
+template <> struct HalfOps<bf16_t> {
+    typedef bf16x8 v8;
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct HalfOps<f16_t> {
+    typedef f16x8 v8;
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
 
 namespace {
 
@@ -39,25 +52,22 @@ struct GemmDev {
 };
 
 // GELU(LayerNorm(.)) on raw 8 x bf16 / 4 x fp32 operand strips (the A rows of fc2's forward, the B rows of its weight gradient)
-__device__ __forceinline__ void bf8_unpack(const uint4& r, float* o) {
-    o[0] = __uint_as_float(r.x << 16); o[1] = __uint_as_float(r.x & 0xffff0000u);
-    o[2] = __uint_as_float(r.y << 16); o[3] = __uint_as_float(r.y & 0xffff0000u);
-    o[4] = __uint_as_float(r.z << 16); o[5] = __uint_as_float(r.z & 0xffff0000u);
-    o[6] = __uint_as_float(r.w << 16); o[7] = __uint_as_float(r.w & 0xffff0000u);
+template <typename H> __device__ __forceinline__ void bf8_unpack(const uint4& r, float* o) {
+    unpack2<H>(r.x, o[0], o[1]); unpack2<H>(r.y, o[2], o[3]); unpack2<H>(r.z, o[4], o[5]); unpack2<H>(r.w, o[6], o[7]);
 }
-__device__ __forceinline__ uint4 bf8_pack(const float* o) {
-    return make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
+template <typename H> __device__ __forceinline__ uint4 bf8_pack(const float* o) {
+    return make_uint4(pack2<H>(o[0], o[1]), pack2<H>(o[2], o[3]), pack2<H>(o[4], o[5]), pack2<H>(o[6], o[7]));
 }
-__device__ __forceinline__ uint4 ffn_ln_gelu8(const uint4& v, float mean, float rstd, const float* g, const float* b) {
+template <typename H> __device__ __forceinline__ uint4 ffn_ln_gelu8(const uint4& v, float mean, float rstd, const float* g, const float* b) {
     float x[8];
-    bf8_unpack(v, x);
+    bf8_unpack<H>(v, x);
 #pragma unroll
     for (int e = 0; e < 8; e += 2) {                          // pairs on the packed fp32 pipe
         const tc_f32x2 xv = {x[e], x[e + 1]}, gv = {g[e], g[e + 1]}, bv = {b[e], b[e + 1]};
         const tc_f32x2 u = gelu_f2((xv - mean) * rstd * gv + bv);
         x[e] = u.x; x[e + 1] = u.y;
     }
-    return bf8_pack(x);
+    return bf8_pack<H>(x);
 }
 __device__ __forceinline__ float4 ffn_ln_gelu4(const float4& v, float mean, float rstd, const float4& g, const float4& b) {
     return make_float4(gelu_f((v.x - mean) * rstd * g.x + b.x), gelu_f((v.y - mean) * rstd * g.y + b.y),
@@ -290,12 +300,13 @@ __device__ __forceinline__ void epilogue_cols(const GemmDev& p, f32x16 (&acc)[TM
 // epilogue_rows does, rounded to bf16 once, parked in LDS as the row-major tile and written with 16-byte stores -- 16 consecutive
 // lanes cover one 256-byte row of a 128-wide tile.  (epilogue_rows' direct 8-byte stores touch 32 different lines per
 // instruction; most GEMMs of this model have K <= 512, so the epilogue is a large part of their time.)
-template <int BM, int BN, int TM, int TN>
+template <typename H, int BM, int BN, int TM, int TN>
 __device__ __forceinline__ void epilogue_rows_lds(const GemmDev& p, f32x16 (&acc)[TM][TN], int b1, int b2, int m0, int n0, int wr, int wc,
-                                                  int lane, bf16_t* stage) {
+                                                  int lane, bf16_t* stage_raw) {
+    H* stage = reinterpret_cast<H*>(stage_raw);
     constexpr int LDS_ = BN + 8, WM = BM / 2, WN = BN / 2;
-    const bf16_t* R = p.R ? reinterpret_cast<const bf16_t*>(p.R) + b1 * p.sR1 + b2 * p.sR2 : nullptr;
-    const bf16_t* bias = p.bias ? reinterpret_cast<const bf16_t*>(p.bias) + b1 * p.sBias1 : nullptr;
+    const H* R = p.R ? reinterpret_cast<const H*>(p.R) + b1 * p.sR1 + b2 * p.sR2 : nullptr;
+    const H* bias = p.bias ? reinterpret_cast<const H*>(p.bias) + b1 * p.sBias1 : nullptr;
     const int h = lane >> 5;
     __syncthreads();                                         // every wave is done with the operand tiles this overwrites
 #pragma unroll
@@ -312,10 +323,10 @@ __device__ __forceinline__ void epilogue_rows_lds(const GemmDev& p, f32x16 (&acc
                 if (row < p.M && col < p.N) {                // N % 8 == 0 on this path: the 4-group is all in or all out
                     if (bias) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += bf2f(bias[col + e]);
+                        for (int e = 0; e < 4; ++e) v[e] += ldf<H>(bias + col + e);
                     }
                     if (R) {
-                        const float4 r4 = ld4<bf16_t>(R + (long long)row * p.ldr + col);
+                        const float4 r4 = ld4<H>(R + (long long)row * p.ldr + col);
                         v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
                     }
                     if (p.act == TC_ACT_SIGMOID) {
@@ -323,11 +334,11 @@ __device__ __forceinline__ void epilogue_rows_lds(const GemmDev& p, f32x16 (&acc
                         for (int e = 0; e < 4; ++e) v[e] = sigmoid_f(v[e]);
                     }
                 }
-                st4<bf16_t>(stage + lr * LDS_ + lc, make_float4(v[0], v[1], v[2], v[3]));
+                st4<H>(stage + lr * LDS_ + lc, make_float4(v[0], v[1], v[2], v[3]));
             }
     }
     __syncthreads();
-    bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + b1 * p.sC1 + b2 * p.sC2;
+    H* C = reinterpret_cast<H*>(p.C) + b1 * p.sC1 + b2 * p.sC2;
     constexpr int CPR = BN / 8;                              // 16-byte chunks per tile row
 #pragma unroll
     for (int it = 0; it < BM * CPR / 256; ++it) {
@@ -340,15 +351,16 @@ __device__ __forceinline__ void epilogue_rows_lds(const GemmDev& p, f32x16 (&acc
 
 // TC_FFN_EP form of the epilogue above: the d tile (prefetched before the K loop, rd) is parked beside the C staging tile, every
 // value becomes gp = v * GELU'(u) and the row sums for the LayerNorm backward leave through ffn.part2[row][bx].
-template <int BM, int BN, int TM, int TN>
+template <typename H, int BM, int BN, int TM, int TN>
 __device__ __forceinline__ void epilogue_rows_lds_ep(const GemmDev& p, f32x16 (&acc)[TM][TN], int b1, int m0, int n0, int wr, int wc, int lane,
-                                                     bf16_t* stage, const uint4 rd0, const uint4 rd1, int bx, int gx) {
+                                                     bf16_t* stage_raw, const uint4 rd0, const uint4 rd1, int bx, int gx) {
     constexpr int LDS_ = BN + 8, WM = BM / 2, WN = BN / 2, CPR = BN / 8;
-    bf16_t* dt = stage + BM * LDS_;
+    H* stage = reinterpret_cast<H*>(stage_raw);
+    H* dt = stage + BM * LDS_;
     float2* srow = reinterpret_cast<float2*>(dt + BM * LDS_);          // [2][BM]
     const long long rbase = (long long)b1 * p.ffn.sRow1;
-    const bf16_t* gam = reinterpret_cast<const bf16_t*>(p.ffn.gamma) + (long long)b1 * p.ffn.sPar1;
-    const bf16_t* bet = reinterpret_cast<const bf16_t*>(p.ffn.beta) + (long long)b1 * p.ffn.sPar1;
+    const H* gam = reinterpret_cast<const H*>(p.ffn.gamma) + (long long)b1 * p.ffn.sPar1;
+    const H* bet = reinterpret_cast<const H*>(p.ffn.beta) + (long long)b1 * p.ffn.sPar1;
     const float2* stat = reinterpret_cast<const float2*>(p.ffn.stat) + rbase;
     const int h = lane >> 5;
     __syncthreads();                                         // every wave is done with the operand tiles this overwrites
@@ -372,7 +384,7 @@ __device__ __forceinline__ void epilogue_rows_lds_ep(const GemmDev& p, f32x16 (&
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = p.alpha * acc[i][j][4 * g + e];
                 if (row < p.M && col < p.N) {                // N % 8 == 0 on this path: the 4-group is all in or all out
-                    const float4 d4 = ld4<bf16_t>(dt + lr * LDS_ + lc), g4 = ld4<bf16_t>(gam + col), b4 = ld4<bf16_t>(bet + col);
+                    const float4 d4 = ld4<H>(dt + lr * LDS_ + lc), g4 = ld4<H>(gam + col), b4 = ld4<H>(bet + col);
                     {
                         const tc_f32x2 va = {v[0], v[1]}, vb = {v[2], v[3]};
                         const tc_f32x2 ga = {g4.x, g4.y}, gb = {g4.z, g4.w};
@@ -385,13 +397,13 @@ __device__ __forceinline__ void epilogue_rows_lds_ep(const GemmDev& p, f32x16 (&
                         v[0] = pa.x; v[1] = pa.y; v[2] = pb.x; v[3] = pb.y;
                     }
                 }
-                st4<bf16_t>(stage + lr * LDS_ + lc, make_float4(v[0], v[1], v[2], v[3]));
+                st4<H>(stage + lr * LDS_ + lc, make_float4(v[0], v[1], v[2], v[3]));
             }
         s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
         if (h == 0) srow[wc * BM + lr] = make_float2(s1, s2);
     }
     __syncthreads();
-    bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + b1 * p.sC1;
+    H* C = reinterpret_cast<H*>(p.C) + b1 * p.sC1;
 #pragma unroll
     for (int it = 0; it < BM * CPR / 256; ++it) {
         const int idx = threadIdx.x + it * 256, lr = idx / CPR, lc = (idx - lr * CPR) * 8;
@@ -631,15 +643,15 @@ __device__ __forceinline__ uint4 load_strip8(const bf16_t* base, int ld, int x, 
 __device__ __forceinline__ int gemm_krow(int k) { return (k & ~15) | ((k & 3) << 2) | ((k >> 2) & 3); }
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef short s16x8_t __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ bf16x8 ld_frag_tr(const bf16_t* lo, const bf16_t* hi) {
+template <typename V8> __device__ __forceinline__ V8 ld_frag_tr(const bf16_t* lo, const bf16_t* hi) {
     const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(lo));
     const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(hi));
-    return __builtin_bit_cast(bf16x8, (s16x8_t)__builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+    return __builtin_bit_cast(V8, (s16x8_t)__builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
 // Body of one workgroup of the bf16 GEMM: (bx, by, bz) of a (gx, gy, *) grid.  The LDS buffers come from the caller so that the
 // two problems of a paired launch (gemm_pair_kernel) share one allocation.
-template <typename TC, int BM, int BN, bool TA, bool TB, bool DB, int FFN = 0>
+template <typename H, typename TC, int BM, int BN, bool TA, bool TB, bool DB, int FFN = 0>
 __device__ __forceinline__ void gemm_bf16_body(const GemmDev& p, const int bx, const int by, const int bz, const int gx, const int gy,
                                                bf16_t (*As)[BM * (64 + 8)], bf16_t (*Bs)[BN * (64 + 8)]) {
     constexpr int BK = 64, LDT = BK + 8;                       // 144-byte rows: 16-B aligned, conflict-free b128 fragment reads
@@ -709,8 +721,8 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmDev& p, const int bx, c
     if constexpr (FFN == TC_FFN_LN_B) {
         const int col = n0 + (tid % (BN / 8)) * 8;
         const int cc = col + 7 < p.N ? col : 0;
-        bf8_unpack(*reinterpret_cast<const uint4*>(gam + cc), fg);
-        bf8_unpack(*reinterpret_cast<const uint4*>(bet + cc), fb);
+        bf8_unpack<H>(*reinterpret_cast<const uint4*>(gam + cc), fg);
+        bf8_unpack<H>(*reinterpret_cast<const uint4*>(bet + cc), fb);
     }
     if constexpr (FFN == TC_FFN_EP) {
         const bf16_t* dmap = reinterpret_cast<const bf16_t*>(p.ffn.d) + (long long)b1 * p.ffn.sRow1 * p.ffn.ldd;
@@ -754,14 +766,14 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmDev& p, const int bx, c
         constexpr bool FAST = decltype(FT)::value;
         int x, k;
         float hg[8], hb[8];
-        if constexpr (FFN == TC_FFN_LN_A) { bf8_unpack(rh[0], hg); bf8_unpack(rh[1], hb); }
+        if constexpr (FFN == TC_FFN_LN_A) { bf8_unpack<H>(rh[0], hg); bf8_unpack<H>(rh[1], hb); }
 #pragma unroll
         for (int i = 0; i < SA; ++i) {
             const int f = tid + i * 256;
             a_xy(i, k0, x, k);
             uint4 v = ra[i];
             if constexpr (FFN == TC_FFN_LN_A) {              // (K % 8 == 0: strips are all in or all out)
-                v = ffn_ln_gelu8(v, a_mean[i], a_rstd[i], hg, hb);
+                v = ffn_ln_gelu8<H>(v, a_mean[i], a_rstd[i], hg, hb);
                 if (aout && strip_whole(x, k, p.M, kend, TA)) *reinterpret_cast<uint4*>(aout + (long long)x * p.ffn.ldd + k) = v;
             }
             if constexpr (FAST) { if (!strip_whole(x, k, p.M, kend, TA)) v = make_uint4(0u, 0u, 0u, 0u); }
@@ -777,7 +789,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmDev& p, const int bx, c
             uint4 v = rb[i];
             if constexpr (FFN == TC_FFN_LN_B) {
                 static_assert(FFN != TC_FFN_LN_B || SB == 2, "two strips per thread");
-                v = ffn_ln_gelu8(v, __uint_as_float(i == 0 ? rh[0].x : rh[0].z), __uint_as_float(i == 0 ? rh[0].y : rh[0].w), fg, fb);
+                v = ffn_ln_gelu8<H>(v, __uint_as_float(i == 0 ? rh[0].x : rh[0].z), __uint_as_float(i == 0 ? rh[0].y : rh[0].w), fg, fb);
             }
             if constexpr (FAST) { if (!strip_whole(x, k, p.N, kend, !TB)) v = make_uint4(0u, 0u, 0u, 0u); }
             else if constexpr (FFN == TC_FFN_LN_B) { if (!strip_whole(x, k, p.N, kend, !TB)) v = make_uint4(0u, 0u, 0u, 0u); }
@@ -790,7 +802,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmDev& p, const int bx, c
     auto compute = [&](const bf16_t* as, const bf16_t* bs) __attribute__((always_inline)) {
         if (do_rowsum) {
 #pragma unroll
-            for (int kk = 0; kk < BK; ++kk) rsum += bf2f(TA ? as[kk * PA + tid] : as[tid * LDT + kk]);
+            for (int kk = 0; kk < BK; ++kk) rsum += ldf<H>(reinterpret_cast<const H*>(TA ? as + kk * PA + tid : as + tid * LDT + kk));
         }
         // K-contiguous slab: lane (row lane&31, k-slice 8*(lane>>5)) reads 16 bytes.  Transposed-layout slab: k block j of a 16-k
         // chunk lies in rows j, j+4, j+8, j+12 of the chunk; the lane's k-slice 8h..8h+7 is blocks 2h and 2h+1.
@@ -799,23 +811,24 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmDev& p, const int bx, c
         const bf16_t* bp = !TB ? &bs[(2 * h + 4 * (gi >> 2)) * PB + wc * WN + 16 * gq + 4 * (gi & 3)] : &bs[(wc * WN + (lane & 31)) * LDT + 8 * h];
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 16) {
-            bf16x8 a[TM], b[TN];
+            typedef typename HalfOps<H>::v8 V8;
+            V8 a[TM], b[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                if constexpr (TA) a[i] = ld_frag_tr(ap + kk * PA + i * 32, ap + (kk + 1) * PA + i * 32);
-                else a[i] = *reinterpret_cast<const bf16x8*>(ap + i * 32 * LDT + kk);
+                if constexpr (TA) a[i] = ld_frag_tr<V8>(ap + kk * PA + i * 32, ap + (kk + 1) * PA + i * 32);
+                else a[i] = *reinterpret_cast<const V8*>(ap + i * 32 * LDT + kk);
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                if constexpr (!TB) b[j] = ld_frag_tr(bp + kk * PB + j * 32, bp + (kk + 1) * PB + j * 32);
-                else b[j] = *reinterpret_cast<const bf16x8*>(bp + j * 32 * LDT + kk);
+                if constexpr (!TB) b[j] = ld_frag_tr<V8>(bp + kk * PB + j * 32, bp + (kk + 1) * PB + j * 32);
+                else b[j] = *reinterpret_cast<const V8*>(bp + j * 32 * LDT + kk);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0)      // D^T: lane = output row
-                                     : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = SWAP ? HalfOps<H>::mfma(b[j], a[i], acc[i][j])      // D^T: lane = output row
+                                     : HalfOps<H>::mfma(a[i], b[j], acc[i][j]);
         }
     };
 
@@ -869,24 +882,24 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmDev& p, const int bx, c
     }
     if constexpr (FFN == TC_FFN_EP) {
         static_assert(FFN != TC_FFN_EP || 2 * BM * (BN + 8) + 2 * BM * 4 <= 2 * (BM + BN) * (64 + 8), "C stage + d tile + row sums must fit");
-        epilogue_rows_lds_ep<BM, BN, TM, TN>(p, acc, b1, m0, n0, wr, wc, lane, &As[0][0], rd0, rd1, bx, gx);
+        epilogue_rows_lds_ep<H, BM, BN, TM, TN>(p, acc, b1, m0, n0, wr, wc, lane, &As[0][0], rd0, rd1, bx, gx);
     } else if constexpr (SWAP) {
         if (p.vec8C && !p.accumulate && !atomic && first) {
             static_assert((BM * (BN + 8)) <= (DB ? 2 : 1) * (BM + BN) * (64 + 8), "staging tile must fit the operand buffers");
-            epilogue_rows_lds<BM, BN, TM, TN>(p, acc, b1, b2, m0, n0, wr, wc, lane, &As[0][0]);
+            epilogue_rows_lds<H, BM, BN, TM, TN>(p, acc, b1, b2, m0, n0, wr, wc, lane, &As[0][0]);
         } else {
-            epilogue_rows<bf16_t, TC, TM, TN>(p, acc, b1, b2, first, atomic, m0 + wr * WM, n0 + wc * WN, lane);
+            epilogue_rows<H, TC, TM, TN>(p, acc, b1, b2, first, atomic, m0 + wr * WM, n0 + wc * WN, lane);
         }
     } else {
-        epilogue_cols<bf16_t, TC, TM, TN>(p, acc, b1, b2, first, atomic, m0 + wr * WM, n0 + wc * WN, lane);
+        epilogue_cols<H, TC, TM, TN>(p, acc, b1, b2, first, atomic, m0 + wr * WM, n0 + wc * WN, lane);
     }
 }
 
-template <typename TC, int BM, int BN, bool TA, bool TB, bool DB, int FFN = 0>
+template <typename H, typename TC, int BM, int BN, bool TA, bool TB, bool DB, int FFN = 0>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmDev p) {
     // ONE buffer: A slabs first, B slabs behind them -- the epilogue reuses it from the start as its C staging tile
     __shared__ __attribute__((aligned(16))) bf16_t smem[(DB ? 2 : 1) * (BM + BN) * (64 + 8)];
-    gemm_bf16_body<TC, BM, BN, TA, TB, DB, FFN>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y,
+    gemm_bf16_body<H, TC, BM, BN, TA, TB, DB, FFN>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y,
                                                 reinterpret_cast<bf16_t(*)[BM * (64 + 8)]>(smem),
                                                 reinterpret_cast<bf16_t(*)[BN * (64 + 8)]>(smem + (DB ? 2 : 1) * BM * (64 + 8)));
 }
@@ -896,6 +909,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmDev p) {
 // one grid they fill the CUs together, where two launches on two streams mostly serialise on this part (measured: kernels from
 // different HW queues overlap only at their tails) and pay two dependency gaps.
 struct GemmPairDev { GemmDev a, b; int nA, gxA, gyA, gxB, gyB; };
+template <typename H>
 __global__ __launch_bounds__(256, 2) void gemm_pair_kernel(GemmPairDev q) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (64 + 64) * (64 + 8)];
     bf16_t(*As)[64 * (64 + 8)] = reinterpret_cast<bf16_t(*)[64 * (64 + 8)]>(smem);
@@ -903,13 +917,13 @@ __global__ __launch_bounds__(256, 2) void gemm_pair_kernel(GemmPairDev q) {
     int lin = blockIdx.x;
     if (lin < q.nA) {
         const int bx = lin % q.gxA; lin /= q.gxA;
-        if (q.a.ffn.mode == TC_FFN_EP) gemm_bf16_body<bf16_t, 64, 64, false, false, true, TC_FFN_EP>(q.a, bx, lin % q.gyA, lin / q.gyA, q.gxA, q.gyA, As, Bs);
-        else gemm_bf16_body<bf16_t, 64, 64, false, false, true>(q.a, bx, lin % q.gyA, lin / q.gyA, q.gxA, q.gyA, As, Bs);
+        if (q.a.ffn.mode == TC_FFN_EP) gemm_bf16_body<H, H, 64, 64, false, false, true, TC_FFN_EP>(q.a, bx, lin % q.gyA, lin / q.gyA, q.gxA, q.gyA, As, Bs);
+        else gemm_bf16_body<H, H, 64, 64, false, false, true>(q.a, bx, lin % q.gyA, lin / q.gyA, q.gxA, q.gyA, As, Bs);
     } else {
         lin -= q.nA;
         const int bx = lin % q.gxB; lin /= q.gxB;
-        if (q.b.ffn.mode == TC_FFN_LN_B) gemm_bf16_body<float, 64, 64, true, false, true, TC_FFN_LN_B>(q.b, bx, lin % q.gyB, lin / q.gyB, q.gxB, q.gyB, As, Bs);
-        else gemm_bf16_body<float, 64, 64, true, false, true>(q.b, bx, lin % q.gyB, lin / q.gyB, q.gxB, q.gyB, As, Bs);
+        if (q.b.ffn.mode == TC_FFN_LN_B) gemm_bf16_body<H, float, 64, 64, true, false, true, TC_FFN_LN_B>(q.b, bx, lin % q.gyB, lin / q.gyB, q.gxB, q.gyB, As, Bs);
+        else gemm_bf16_body<H, float, 64, 64, true, false, true>(q.b, bx, lin % q.gyB, lin / q.gyB, q.gxB, q.gyB, As, Bs);
     }
 }
 
@@ -919,6 +933,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pair_kernel(GemmPairDev q) {
 constexpr int GEMM_MULTI_MAX = 12;
 static_assert(sizeof(GemmDev) * GEMM_MULTI_MAX + 16 * GEMM_MULTI_MAX + 8 <= 4096, "kernel argument block");
 struct GemmMultiDev { GemmDev p[GEMM_MULTI_MAX]; int blk0[GEMM_MULTI_MAX], gx[GEMM_MULTI_MAX], gy[GEMM_MULTI_MAX], kind[GEMM_MULTI_MAX]; int n; };
+template <typename H>
 __global__ __launch_bounds__(256, 2) void gemm_multi_kernel(GemmMultiDev q) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (64 + 64) * (64 + 8)];
     bf16_t(*As)[64 * (64 + 8)] = reinterpret_cast<bf16_t(*)[64 * (64 + 8)]>(smem);
@@ -930,20 +945,20 @@ __global__ __launch_bounds__(256, 2) void gemm_multi_kernel(GemmMultiDev q) {
     // a private copy of the one descriptor: with six inlined bodies reading fields through a reference into the 4 KB argument block
     // the compiler stopped forwarding the loads to the kernel-argument segment and copied the whole block to scratch
     const GemmDev p = q.p[i];
-    if (q.kind[i] == 0) gemm_bf16_body<bf16_t, 64, 64, false, true, true>(p, bx, by, bz, gx, gy, As, Bs);
-    else if (q.kind[i] == 1) gemm_bf16_body<bf16_t, 64, 64, false, false, true>(p, bx, by, bz, gx, gy, As, Bs);
-    else if (q.kind[i] == 2) gemm_bf16_body<float, 64, 64, true, false, true>(p, bx, by, bz, gx, gy, As, Bs);
-    else if (q.kind[i] == 3) gemm_bf16_body<bf16_t, 64, 64, false, true, true, TC_FFN_LN_A>(p, bx, by, bz, gx, gy, As, Bs);
-    else if (q.kind[i] == 4) gemm_bf16_body<bf16_t, 64, 64, false, false, true, TC_FFN_EP>(p, bx, by, bz, gx, gy, As, Bs);
-    else gemm_bf16_body<float, 64, 64, true, false, true, TC_FFN_LN_B>(p, bx, by, bz, gx, gy, As, Bs);
+    if (q.kind[i] == 0) gemm_bf16_body<H, H, 64, 64, false, true, true>(p, bx, by, bz, gx, gy, As, Bs);
+    else if (q.kind[i] == 1) gemm_bf16_body<H, H, 64, 64, false, false, true>(p, bx, by, bz, gx, gy, As, Bs);
+    else if (q.kind[i] == 2) gemm_bf16_body<H, float, 64, 64, true, false, true>(p, bx, by, bz, gx, gy, As, Bs);
+    else if (q.kind[i] == 3) gemm_bf16_body<H, H, 64, 64, false, true, true, TC_FFN_LN_A>(p, bx, by, bz, gx, gy, As, Bs);
+    else if (q.kind[i] == 4) gemm_bf16_body<H, H, 64, 64, false, false, true, TC_FFN_EP>(p, bx, by, bz, gx, gy, As, Bs);
+    else gemm_bf16_body<H, float, 64, 64, true, false, true, TC_FFN_LN_B>(p, bx, by, bz, gx, gy, As, Bs);
 }
 
 // ---------------------------------------------------------------------------------------------- host side
 template <typename T, typename TC, int BM, int BN, bool TA, bool TB>
 void launch_one(const GemmDev& d, dim3 grid, hipStream_t s) {
     if constexpr (sizeof(T) == 4) hipLaunchKernelGGL((gemm_kernel<TC, BM, BN, TA, TB>), grid, dim3(256), 0, s, d);
-    else if (d.kchunk > 128) hipLaunchKernelGGL((gemm_bf16_kernel<TC, BM, BN, TA, TB, true>), grid, dim3(256), 0, s, d);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<TC, BM, BN, TA, TB, false>), grid, dim3(256), 0, s, d);
+    else if (d.kchunk > 128) hipLaunchKernelGGL((gemm_bf16_kernel<T, TC, BM, BN, TA, TB, true>), grid, dim3(256), 0, s, d);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<T, TC, BM, BN, TA, TB, false>), grid, dim3(256), 0, s, d);
 }
 
 // the three hooked products (64x64 tiles; gemm_plan has checked operand kinds and output types)
@@ -954,9 +969,9 @@ int launch_ffn(const GemmDev& d, dim3 grid, hipStream_t s) {
         else if (d.ffn.mode == TC_FFN_LN_B) hipLaunchKernelGGL((gemm_kernel<float, 64, 64, true, false, TC_FFN_LN_B>), grid, dim3(256), 0, s, d);
         else hipLaunchKernelGGL((gemm_kernel<float, 64, 64, false, false, TC_FFN_EP>), grid, dim3(256), 0, s, d);
     } else {
-        if (d.ffn.mode == TC_FFN_LN_A) hipLaunchKernelGGL((gemm_bf16_kernel<bf16_t, 64, 64, false, true, true, TC_FFN_LN_A>), grid, dim3(256), 0, s, d);
-        else if (d.ffn.mode == TC_FFN_LN_B) hipLaunchKernelGGL((gemm_bf16_kernel<float, 64, 64, true, false, true, TC_FFN_LN_B>), grid, dim3(256), 0, s, d);
-        else hipLaunchKernelGGL((gemm_bf16_kernel<bf16_t, 64, 64, false, false, true, TC_FFN_EP>), grid, dim3(256), 0, s, d);
+        if (d.ffn.mode == TC_FFN_LN_A) hipLaunchKernelGGL((gemm_bf16_kernel<T, T, 64, 64, false, true, true, TC_FFN_LN_A>), grid, dim3(256), 0, s, d);
+        else if (d.ffn.mode == TC_FFN_LN_B) hipLaunchKernelGGL((gemm_bf16_kernel<T, float, 64, 64, true, false, true, TC_FFN_LN_B>), grid, dim3(256), 0, s, d);
+        else hipLaunchKernelGGL((gemm_bf16_kernel<T, T, 64, 64, false, false, true, TC_FFN_EP>), grid, dim3(256), 0, s, d);
     }
     return tc_launch_status();
 }
@@ -1109,16 +1124,17 @@ extern "C" int tc_gemm(const TcGemm* g, void* stream) {
 extern "C" int tc_gemm_pair(const TcGemm* a, const TcGemm* b, void* stream) {
     if (!gemm_args_ok(a) || !gemm_args_ok(b)) return TC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    if (a->dtype == TC_BF16 && b->dtype == TC_BF16 && !a->transA && !a->transB && !a->c_f32 && b->transA && !b->transB && b->c_f32 &&
+    if ((a->dtype == TC_BF16 || a->dtype == TC_F16) && b->dtype == a->dtype && !a->transA && !a->transB && !a->c_f32 && b->transA && !b->transB && b->c_f32 &&
         (a->ffn_mode == TC_FFN_NONE || a->ffn_mode == TC_FFN_EP) && (b->ffn_mode == TC_FFN_NONE || b->ffn_mode == TC_FFN_LN_B)) {
         GemmPairDev q;
         dim3 ga, gb;
         bool bigA, bigB;
-        if (!gemm_plan<bf16_t>(a, q.a, ga, bigA) || !gemm_plan<bf16_t>(b, q.b, gb, bigB)) return TC_ERR_ARG;
+        if (!gemm_plan<bf16_t>(a, q.a, ga, bigA) || !gemm_plan<bf16_t>(b, q.b, gb, bigB)) return TC_ERR_ARG;     // (sizes only: either 16-bit type)
         const long long nA = (long long)ga.x * ga.y * ga.z, nB = (long long)gb.x * gb.y * gb.z;
         if (!bigA && !bigB && nA + nB < 0x7fffffffLL) {
             q.nA = (int)nA; q.gxA = ga.x; q.gyA = ga.y; q.gxB = gb.x; q.gyB = gb.y;
-            hipLaunchKernelGGL(gemm_pair_kernel, dim3((unsigned)(nA + nB)), dim3(256), 0, s, q);
+            if (a->dtype == TC_BF16) hipLaunchKernelGGL(gemm_pair_kernel<bf16_t>, dim3((unsigned)(nA + nB)), dim3(256), 0, s, q);
+            else hipLaunchKernelGGL(gemm_pair_kernel<f16_t>, dim3((unsigned)(nA + nB)), dim3(256), 0, s, q);
             return tc_launch_status();
         }
     }
@@ -1138,9 +1154,10 @@ extern "C" int tc_gemm_multi(const TcGemm* g, int n, void* stream) {
     for (int i = 0; ok && i < n; ++i) {
         const TcGemm& t = g[i];
         int kind = -1;
-        if (t.dtype == TC_BF16 && !t.transA && t.transB && !t.c_f32) kind = t.ffn_mode == TC_FFN_LN_A ? 3 : (t.ffn_mode ? -1 : 0);
-        else if (t.dtype == TC_BF16 && !t.transA && !t.transB && !t.c_f32) kind = t.ffn_mode == TC_FFN_EP ? 4 : (t.ffn_mode ? -1 : 1);
-        else if (t.dtype == TC_BF16 && t.transA && !t.transB && t.c_f32) kind = t.ffn_mode == TC_FFN_LN_B ? 5 : (t.ffn_mode ? -1 : 2);
+        const bool h16 = (t.dtype == TC_BF16 || t.dtype == TC_F16) && t.dtype == g[0].dtype;     // one 16-bit type per launch
+        if (h16 && !t.transA && t.transB && !t.c_f32) kind = t.ffn_mode == TC_FFN_LN_A ? 3 : (t.ffn_mode ? -1 : 0);
+        else if (h16 && !t.transA && !t.transB && !t.c_f32) kind = t.ffn_mode == TC_FFN_EP ? 4 : (t.ffn_mode ? -1 : 1);
+        else if (h16 && t.transA && !t.transB && t.c_f32) kind = t.ffn_mode == TC_FFN_LN_B ? 5 : (t.ffn_mode ? -1 : 2);
         bool big;
         if (kind < 0 || !gemm_plan<bf16_t>(&t, plan[i], grids[i], big, true)) { ok = false; break; }
         kinds[i] = kind; order[i] = i;
@@ -1159,7 +1176,8 @@ extern "C" int tc_gemm_multi(const TcGemm* g, int n, void* stream) {
     }
     if (ok) {
         q.n = n;
-        hipLaunchKernelGGL(gemm_multi_kernel, dim3((unsigned)blk), dim3(256), 0, s, q);
+        if (g[0].dtype == TC_BF16) hipLaunchKernelGGL(gemm_multi_kernel<bf16_t>, dim3((unsigned)blk), dim3(256), 0, s, q);
+        else hipLaunchKernelGGL(gemm_multi_kernel<f16_t>, dim3((unsigned)blk), dim3(256), 0, s, q);
         return tc_launch_status();
     }
     for (int i = 0; i < n; ++i) {                              // kinds / sizes the merged kernel does not cover: one launch each

@@ -22,12 +22,48 @@ __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
 }
 __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, 0.f) & 0xffffu); }
 
+// IEEE half storage: a distinct 16-bit tag type (bf16_t is `unsigned short`), same raw-bit handling, different conversions
+struct f16_t { unsigned short v; };
+typedef _Float16 tc_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float h2f(f16_t v) { return (float)__builtin_bit_cast(_Float16, v.v); }
+__device__ __forceinline__ unsigned pack2h(float lo, float hi) {
+    const tc_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, tc_f16x2));      // round to nearest even
+}
+__device__ __forceinline__ f16_t f2h(float f) { f16_t r; r.v = __builtin_bit_cast(unsigned short, (_Float16)f); return r; }
+// the two halves of a 32-bit word as floats
+template <typename T> __device__ __forceinline__ void unpack2(unsigned w, float& lo, float& hi);
+template <> __device__ __forceinline__ void unpack2<bf16_t>(unsigned w, float& lo, float& hi) { lo = __uint_as_float(w << 16); hi = __uint_as_float(w & 0xffff0000u); }
+template <> __device__ __forceinline__ void unpack2<f16_t>(unsigned w, float& lo, float& hi) {
+    const tc_f16x2 h = __builtin_bit_cast(tc_f16x2, w);
+    lo = (float)h.x; hi = (float)h.y;
+}
+template <typename T> __device__ __forceinline__ unsigned pack2(float lo, float hi);
+template <> __device__ __forceinline__ unsigned pack2<bf16_t>(float lo, float hi) { return pack2bf(lo, hi); }
+template <> __device__ __forceinline__ unsigned pack2<f16_t>(float lo, float hi) { return pack2h(lo, hi); }
+
+// matrix-core flavour of a 16-bit storage type: MFMA operand vector, its element type and the 32x32x16 instruction
+typedef float tc_f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 tc_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 tc_f16x8 __attribute__((ext_vector_type(8)));
+template <typename H> struct TcHalf;
+template <> struct TcHalf<bf16_t> {
+    typedef tc_bf16x8 v8; typedef __bf16 e;
+    static __device__ __forceinline__ tc_f32x16 mfma(v8 a, v8 b, tc_f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct TcHalf<f16_t> {
+    typedef tc_f16x8 v8; typedef _Float16 e;
+    static __device__ __forceinline__ tc_f32x16 mfma(v8 a, v8 b, tc_f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+
 template <typename T> __device__ __forceinline__ float ldf(const T* p);
 template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+template <> __device__ __forceinline__ float ldf<f16_t>(const f16_t* p) { return h2f(*p); }
 template <typename T> __device__ __forceinline__ void stf(T* p, float v);
 template <> __device__ __forceinline__ void stf<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+template <> __device__ __forceinline__ void stf<f16_t>(f16_t* p, float v) { *p = f2h(v); }
 
 // 4-element vector access (16 B for float, 8 B for bf16); caller guarantees alignment.
 template <typename T> __device__ __forceinline__ float4 ld4(const T* p);
@@ -37,12 +73,25 @@ template <> __device__ __forceinline__ float4 ld4<bf16_t>(const bf16_t* p) {
     return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u),
                        __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
 }
+template <> __device__ __forceinline__ float4 ld4<f16_t>(const f16_t* p) {
+    const uint2 r = *reinterpret_cast<const uint2*>(p);
+    float4 o;
+    unpack2<f16_t>(r.x, o.x, o.y); unpack2<f16_t>(r.y, o.z, o.w);
+    return o;
+}
 template <typename T> __device__ __forceinline__ void st4(T* p, float4 v);
 template <> __device__ __forceinline__ void st4<float>(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, float4 v) {
     uint2 r;
     r.x = pack2bf(v.x, v.y);
     r.y = pack2bf(v.z, v.w);
+    *reinterpret_cast<uint2*>(p) = r;
+}
+
+template <> __device__ __forceinline__ void st4<f16_t>(f16_t* p, float4 v) {
+    uint2 r;
+    r.x = pack2h(v.x, v.y);
+    r.y = pack2h(v.z, v.w);
     *reinterpret_cast<uint2*>(p) = r;
 }
 
@@ -151,5 +200,6 @@ static inline int tc_blocks(long long work, int per_block, int cap = 4096) {
     do {                                                               \
         if ((dtype) == TC_F32) { using T = float; __VA_ARGS__; }       \
         else if ((dtype) == TC_BF16) { using T = bf16_t; __VA_ARGS__; }\
+        else if ((dtype) == TC_F16) { using T = f16_t; __VA_ARGS__; }  \
         else return TC_ERR_ARG;                                        \
     } while (0)

@@ -18,10 +18,10 @@ from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
 
-from ._lib import (ACT_COORD, ACT_GELU, ACT_HSWISH, ACT_NONE, ACT_SIGMOID, FFN_EP, FFN_LN_A, FFN_LN_B, TC_BF16, TC_F32, TcDwSeg, TcFfnSeg,
+from ._lib import (ACT_COORD, ACT_GELU, ACT_HSWISH, ACT_NONE, ACT_SIGMOID, FFN_EP, FFN_LN_A, FFN_LN_B, TC_BF16, TC_F16, TC_F32, TcDwSeg, TcFfnSeg,
                    TcGemm, lib)
 
-_DT = {torch.float32: TC_F32, torch.bfloat16: TC_BF16}
+_DT = {torch.float32: TC_F32, torch.bfloat16: TC_BF16, torch.float16: TC_F16}
 
 # bench.py sets this to a dict {kernel name: [(start_event, stop_event, algorithmic_flops), ...]} to time individual
 # launches with HIP events on the launching stream (the events are recorded on torch's current stream, which is the
@@ -483,7 +483,7 @@ class Graph:
                 dz = torch.empty_like(dy)
                 self.L.tc_sigmoid_bwd(_ptr(dy), _ptr(out.data), _ptr(dz), dy.numel(), self.dt, self.stream)
             want_db = b is not None and b.grad is not None
-            paired = (_GEMM_PAIR and x.requires_grad and W.grad is not None and self.dtype == torch.bfloat16
+            paired = (_GEMM_PAIR and x.requires_grad and W.grad is not None and self.dtype != torch.float32
                       and self._small_tiles(M, K, nb) and self._small_tiles(N, K, nb))
             if paired:
                 # dX and dW (+db) of this layer share one launch: two short grids fill the CUs together (tc_gemm_pair)

@@ -22,7 +22,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 import torch.nn as nn
 
-from ._lib import ACT_COORD, ACT_GELU, ACT_HSWISH, ACT_NONE, ACT_SIGMOID, TC_BF16, TC_F32, lib
+from ._lib import ACT_COORD, ACT_GELU, ACT_HSWISH, ACT_NONE, ACT_SIGMOID, TC_BF16, TC_F16, TC_F32, lib
 from .engine import Graph, P, Var
 
 DIMS = (64, 128, 320, 512)
@@ -282,9 +282,17 @@ class MSTransception(nn.Module):
 
     # ------------------------------------------------------------------ flat parameter / gradient arenas
     def set_compute_dtype(self, dtype: torch.dtype):
-        assert dtype in (torch.float32, torch.bfloat16)
+        """Storage type of activations and of the working copy of the weights: float32 (the parity path), bfloat16, or float16 (IEEE
+        half, BASELINE config 5; train it with a loss scale -- train.SegLoss(loss_scale=...) -- because activation gradients of
+        order 1e-6 underflow in half precision).  Master weights, gradients, statistics and accumulators stay fp32 in every mode."""
+        assert dtype in (torch.float32, torch.bfloat16, torch.float16)
+        if dtype != self.compute_dtype:
+            self._flat_lp = None
         self.compute_dtype = dtype
         return self
+
+    def _tc_dtype(self) -> int:
+        return {torch.float32: TC_F32, torch.bfloat16: TC_BF16, torch.float16: TC_F16}[self.compute_dtype]
 
     def _ensure_flat(self, device):
         uniq = list(self.parameters())
@@ -376,7 +384,7 @@ class MSTransception(nn.Module):
         if self.compute_dtype != torch.float32:
             if self._flat_lp is None:
                 self._flat_lp = torch.empty(self._flat.numel(), dtype=self.compute_dtype, device=dev)
-            L.tc_cast(self._flat.data_ptr(), self._flat_lp.data_ptr(), self._flat.numel(), TC_F32, TC_BF16, stream)
+            L.tc_cast(self._flat.data_ptr(), self._flat_lp.data_ptr(), self._flat.numel(), TC_F32, self._tc_dtype(), stream)
         if record:
             self._used_views = {}
         G = Graph(self.compute_dtype, dev, self.training, record)
@@ -387,13 +395,13 @@ class MSTransception(nn.Module):
         xin = x.contiguous().float()
         if self.compute_dtype != torch.float32:
             xl = torch.empty(xin.shape, dtype=self.compute_dtype, device=dev)
-            L.tc_cast(xin.data_ptr(), xl.data_ptr(), xin.numel(), TC_F32, TC_BF16, stream)
+            L.tc_cast(xin.data_ptr(), xl.data_ptr(), xin.numel(), TC_F32, self._tc_dtype(), stream)
             xin = xl
         out_var = _forward(self, G, xin, B, in_ch, H)
         logits = out_var.data.view(B, self.num_classes, H, W)
         if self.compute_dtype != torch.float32:
             lf = torch.empty(logits.shape, dtype=torch.float32, device=dev)
-            L.tc_cast(logits.data_ptr(), lf.data_ptr(), logits.numel(), TC_BF16, TC_F32, stream)
+            L.tc_cast(logits.data_ptr(), lf.data_ptr(), logits.numel(), self._tc_dtype(), TC_F32, stream)
             logits = lf
         if self.training:
             nbt = getattr(self, "_nbt_flat", None)
@@ -426,7 +434,7 @@ class MSTransception(nn.Module):
         d = dlogits.contiguous()
         if self.compute_dtype != torch.float32:
             dl = torch.empty(d.shape, dtype=self.compute_dtype, device=d.device)
-            L.tc_cast(d.data_ptr(), dl.data_ptr(), d.numel(), TC_F32, TC_BF16, G.stream)
+            L.tc_cast(d.data_ptr(), dl.data_ptr(), d.numel(), TC_F32, self._tc_dtype(), G.stream)
             d = dl
         out_var.root.grad_t = d.view(out_var.rows, out_var.cols)
         out_var.root.whole_written = True

@@ -17,11 +17,11 @@ from typing import Optional
 import torch
 import torch.distributed as dist
 
-from ._lib import TC_BF16, TC_F32, lib
+from ._lib import TC_BF16, TC_F16, TC_F32, lib
 
 
 def _dt(t: torch.Tensor) -> int:
-    return TC_F32 if t.dtype == torch.float32 else TC_BF16
+    return {torch.float32: TC_F32, torch.bfloat16: TC_BF16, torch.float16: TC_F16}[t.dtype]
 
 
 def seg_sums_allreduce(sums: torch.Tensor, n_pix: float, group=None):
@@ -45,7 +45,7 @@ def loss_from_sums(sums: torch.Tensor, n_pix: float, w_ce: float, w_dice: float)
 
 class _SegLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, labels, ncls, w_ce, w_dice, group):
+    def forward(ctx, logits, labels, ncls, w_ce, w_dice, group, loss_scale=1.0):
         L = lib()
         logits = logits.contiguous()
         B, C, H, W = logits.shape
@@ -58,13 +58,13 @@ class _SegLossFn(torch.autograd.Function):
         sums, n_pix, world = seg_sums_allreduce(sums, float(B * H * W), group)
         loss, ce, dice = loss_from_sums(sums, n_pix, w_ce, w_dice)
         ctx.save_for_backward(prob, labels, sums)
-        ctx.meta = (ncls, w_ce, w_dice, n_pix, world, logits.dtype)
+        ctx.meta = (ncls, w_ce, w_dice, n_pix, world, logits.dtype, float(loss_scale))
         return loss.float(), ce.float(), dice.float()
 
     @staticmethod
     def backward(ctx, gloss, gce, gdice):
         prob, labels, sums = ctx.saved_tensors
-        ncls, w_ce, w_dice, n_pix, world, dtype = ctx.meta
+        ncls, w_ce, w_dice, n_pix, world, dtype, loss_scale = ctx.meta
         B, C, H, W = prob.shape
         L = lib()
         stream = torch.cuda.current_stream(prob.device).cuda_stream
@@ -73,19 +73,21 @@ class _SegLossFn(torch.autograd.Function):
         # DDP mean is folded in by the caller (gscale).  gloss is 1 for a plain loss.backward().
         gl = gloss.detach().float().contiguous()             # upstream d(loss) stays on the device: no host sync
         L.tc_seg_loss_bwd(prob.data_ptr(), labels.data_ptr(), sums.data_ptr(), d.data_ptr(), B, ncls, H * W, float(w_ce), float(w_dice),
-                          float(n_pix), 1.0, gl.data_ptr(), _dt(d), stream)
-        return d, None, None, None, None, None
+                          float(n_pix), loss_scale, gl.data_ptr(), _dt(d), stream)
+        return d, None, None, None, None, None, None
 
 
 class SegLoss(torch.nn.Module):
     """0.4*CE + 0.6*Dice over the (global) batch; returns (loss, ce, dice)."""
 
-    def __init__(self, n_classes: int = 9, w_ce: float = 0.4, w_dice: float = 0.6, group=None):
+    def __init__(self, n_classes: int = 9, w_ce: float = 0.4, w_dice: float = 0.6, group=None, loss_scale: float = 1.0):
+        """loss_scale: the gradient that leaves this loss is multiplied by it (the reported loss is not) -- static loss scaling for
+        float16 storage; FusedSGD.step divides it out again (train_step wires the two together)."""
         super().__init__()
-        self.n_classes, self.w_ce, self.w_dice, self.group = n_classes, w_ce, w_dice, group
+        self.n_classes, self.w_ce, self.w_dice, self.group, self.loss_scale = n_classes, w_ce, w_dice, group, float(loss_scale)
 
     def forward(self, logits: torch.Tensor, labels: torch.Tensor):
-        return _SegLossFn.apply(logits, labels.long(), self.n_classes, self.w_ce, self.w_dice, self.group)
+        return _SegLossFn.apply(logits, labels.long(), self.n_classes, self.w_ce, self.w_dice, self.group, self.loss_scale)
 
 
 def cosine_lr(base_lr: float, step: int, t_max: int) -> float:
@@ -108,6 +110,7 @@ class FusedSGD:
         self._segs_dev: Optional[torch.Tensor] = None
         self.lr_dev: Optional[torch.Tensor] = None       # device scalar read by the kernel (hipGraph-friendly schedule)
         self._sumsq: Optional[torch.Tensor] = None       # squared gradient norm (clip_norm)
+        self.grad_scale = 1.0                            # gradients in the arena are this many times too small (1 / loss scale)
 
     def set_lr(self, lr: float):
         self.lr = lr
@@ -131,7 +134,8 @@ class FusedSGD:
         if self.model._gflat is not None:
             self.model._gflat.zero_()
 
-    def step(self, grad_scale: float = 1.0):
+    def step(self, grad_scale: Optional[float] = None):
+        grad_scale = self.grad_scale if grad_scale is None else grad_scale
         M = self.model
         flat, g = M._flat, M._gflat
         if self.buf is None:
@@ -155,7 +159,7 @@ class FusedSGD:
             sumsq = self._sumsq.data_ptr()
         L.tc_sgd_step_multi(flat.data_ptr(), g.data_ptr(), self.buf.data_ptr(), self._segs_dev.data_ptr(), self._nseg, self._maxlen,
                             float(self.lr), self.lr_dev.data_ptr(), float(self.momentum), float(self.wd), float(grad_scale),
-                            int(self.steps == 0), sumsq, float(self.clip_norm or 0.0), stream)
+                            int(self.steps == 0), sumsq, float((self.clip_norm or 0.0) / grad_scale), stream)
         self.steps += 1
 
 
@@ -212,6 +216,7 @@ def allreduce_gradients(model, group=None, part: Optional[str] = None, async_op:
 def train_step(model, loss_fn: SegLoss, opt: FusedSGD, images: torch.Tensor, labels: torch.Tensor, group=None):
     """One step with trainer.py semantics; returns (loss, ce, dice) tensors (no host sync)."""
     opt.zero_grad()
+    opt.grad_scale = 1.0 / getattr(loss_fn, "loss_scale", 1.0)
     logits = model(images)
     loss, ce, dice = loss_fn(logits, labels)
     loss.backward()
@@ -241,6 +246,7 @@ class GraphedStep:
                  force_split: bool = False):
         self.model, self.loss_fn, self.opt, self.group = model, loss_fn, opt, group
         self.x, self.y = images.clone(), labels.clone().long().contiguous()
+        opt.grad_scale = 1.0 / getattr(loss_fn, "loss_scale", 1.0)
         self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         self.split = self.distributed or force_split
         side = torch.cuda.Stream()
@@ -298,7 +304,7 @@ class GraphedStep:
         stream = torch.cuda.current_stream(self._prob.device).cuda_stream
         d = torch.empty((B, C, H, W), dtype=torch.float32, device=self._prob.device)
         L.tc_seg_loss_bwd(self._prob.data_ptr(), self.y.data_ptr(), self._sums.data_ptr(), d.data_ptr(), B, C, H * W, float(lf.w_ce),
-                          float(lf.w_dice), float(self._npix), 1.0, None, TC_F32, stream)
+                          float(lf.w_dice), float(self._npix), float(lf.loss_scale), None, TC_F32, stream)
         M._backward(self._G, self._out_var, d, until="encoder_done")     # loss gradient, decoders, bridge
 
     def _bwd_rest(self):
