@@ -19,7 +19,9 @@ template <int GS> __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
-template <typename T, int GS, int NV>
+// RPT consecutive rows per lane group and iteration: their loads are all issued before the first reduction (narrow rows are
+// 128-256 bytes: one row per group per iteration left a single 8-byte load per lane in flight and ran at ~2 TB/s).
+template <typename T, int GS, int NV, int RPT>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ gamma,
                                                      const T* __restrict__ beta, T* __restrict__ y, int ldy,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int rows,
@@ -38,37 +40,52 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, in
         const int q = gl + i * GS;
         if (q < nv) { g[i] = ld4<T>(gamma + q * 4); b[i] = ld4<T>(beta + q * 4); }
     }
-    for (int row = blockIdx.x * RPB + gi; row < rows; row += gridDim.x * RPB) {
-        const T* xr = x + (long long)row * ldx;
-        float4 v[NV];
-        float s = 0.f;
+    for (int row0 = (blockIdx.x * RPB + gi) * RPT; row0 < rows; row0 += gridDim.x * RPB * RPT) {
+        float4 v[RPT][NV];
+        float mu[RPT], rs[RPT];
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int q = gl + i * GS;
-            if (q < nv) { v[i] = ld4<T>(xr + q * 4); s += v[i].x + v[i].y + v[i].z + v[i].w; }
-        }
-        const float mu = group_sum<GS>(s) * invC;
-        float s2 = 0.f;
+        for (int r = 0; r < RPT; ++r) {
+            const int row = min(row0 + r, rows - 1);              // rows past the end re-read the last row (no divergent loads)
+            const T* xr = x + (long long)row * ldx;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int q = gl + i * GS;
-            if (q < nv) {
-                const float a = v[i].x - mu, bb = v[i].y - mu, c = v[i].z - mu, d = v[i].w - mu;
-                s2 += a * a + bb * bb + c * c + d * d;
+            for (int i = 0; i < NV; ++i) {
+                const int q = gl + i * GS;
+                v[r][i] = q < nv ? ld4<T>(xr + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
-        const float rs = rsqrtf(group_sum<GS>(s2) * invC + eps);
-        if (gl == 0) { mean[row] = mu; rstd[row] = rs; }
-        T* yr = y + (long long)row * ldy;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int q = gl + i * GS;
-            if (q < nv) {
-                float4 o;
-                o.x = (v[i].x - mu) * rs * g[i].x + b[i].x; o.y = (v[i].y - mu) * rs * g[i].y + b[i].y;
-                o.z = (v[i].z - mu) * rs * g[i].z + b[i].z; o.w = (v[i].w - mu) * rs * g[i].w + b[i].w;
-                if (act == TC_ACT_GELU) { o.x = gelu_f(o.x); o.y = gelu_f(o.y); o.z = gelu_f(o.z); o.w = gelu_f(o.w); }
-                st4<T>(yr + q * 4, o);
+        for (int r = 0; r < RPT; ++r) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) s += v[r][i].x + v[r][i].y + v[r][i].z + v[r][i].w;
+            mu[r] = group_sum<GS>(s) * invC;
+            float s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int q = gl + i * GS;
+                if (q < nv) {
+                    const float a = v[r][i].x - mu[r], bb = v[r][i].y - mu[r], c = v[r][i].z - mu[r], d = v[r][i].w - mu[r];
+                    s2 += a * a + bb * bb + c * c + d * d;
+                }
+            }
+            rs[r] = rsqrtf(group_sum<GS>(s2) * invC + eps);
+        }
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const int row = row0 + r;
+            if (row >= rows) break;
+            if (gl == 0) { mean[row] = mu[r]; rstd[row] = rs[r]; }
+            T* yr = y + (long long)row * ldy;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int q = gl + i * GS;
+                if (q < nv) {
+                    float4 o;
+                    o.x = (v[r][i].x - mu[r]) * rs[r] * g[i].x + b[i].x; o.y = (v[r][i].y - mu[r]) * rs[r] * g[i].y + b[i].y;
+                    o.z = (v[r][i].z - mu[r]) * rs[r] * g[i].z + b[i].z; o.w = (v[r][i].w - mu[r]) * rs[r] * g[i].w + b[i].w;
+                    if (act == TC_ACT_GELU) { o.x = gelu_f(o.x); o.y = gelu_f(o.y); o.z = gelu_f(o.z); o.w = gelu_f(o.w); }
+                    st4<T>(yr + q * 4, o);
+                }
             }
         }
     }
@@ -432,8 +449,14 @@ extern "C" int tc_layernorm_fwd(const void* x, int ldx, const void* gamma, const
         return TC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int quads = C >> 2;
-#define TC_LNF(GS, NV) hipLaunchKernelGGL((ln_fwd_kernel<T, GS, NV>), dim3(tc_blocks(rows, 256 / GS, 2048), groups), dim3(256), 0, s, (const T*)x, \
-                                          ldx, (const T*)gamma, (const T*)beta, (T*)y, ldy, mean, rstd, rows, C, eps, act, pstride)
+#define TC_LNF(GS, NV) {                                                                                                                  \
+        constexpr int RPT = NV == 1 ? 4 : (NV == 2 ? 2 : 1);       /* narrow rows: several rows in flight per lane group */                   \
+        if (rows >= 4096)                                                                                                                     \
+            hipLaunchKernelGGL((ln_fwd_kernel<T, GS, NV, RPT>), dim3(tc_blocks(rows, (256 / GS) * RPT, 2048), groups), dim3(256), 0, s,       \
+                               (const T*)x, ldx, (const T*)gamma, (const T*)beta, (T*)y, ldy, mean, rstd, rows, C, eps, act, pstride);       \
+        else                                                                                                                                  \
+            hipLaunchKernelGGL((ln_fwd_kernel<T, GS, NV, 1>), dim3(tc_blocks(rows, 256 / GS, 2048), groups), dim3(256), 0, s, (const T*)x,    \
+                               ldx, (const T*)gamma, (const T*)beta, (T*)y, ldy, mean, rstd, rows, C, eps, act, pstride); }
     TC_DISPATCH_DTYPE(dtype, { TC_LN_DISPATCH(quads, TC_LNF) });
 #undef TC_LNF
     return tc_launch_status();
