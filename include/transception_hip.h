@@ -110,7 +110,8 @@ int tc_colsum(const void* x, int rows, int cols, int ldx, int nb, long long sb, 
  * LayerNorm over the last dim (C <= 4096), optionally followed by exact-erf GELU.
  * Replaces nn.LayerNorm at MSTr.py:165,170,303,898(norm1 of MixFFN_skip)+894 GELU,:932-933 (eps 1e-6),
  *   :199,225,1720,2249,2390-2391 and their backward.
- * mean/rstd: fp32 [rows] saved for backward.
+ * mean/rstd: fp32 [rows] saved for backward (forward only: rstd == mean + 1 selects the interleaved [rows][2] layout that the
+ * TcGemm ffn_stat consumers read).
  */
 /* groups > 1: `groups` stacked row blocks of `rows` rows each, block g using gamma/beta + g*pstride (the three MB paths). */
 int tc_layernorm_fwd(const void* x, int ldx, const void* gamma, const void* beta, void* y, int ldy,

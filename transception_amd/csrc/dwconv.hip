@@ -1346,7 +1346,7 @@ extern "C" int tc_ffn_chunk(int C, int dtype) {
 
 extern "C" int tc_ffn_dw_fwd(const void* x, int ldx, const void* w, const void* bias, void* y, int ldy, float* stat, int B, int H, int W,
                              int C, int groups, long long wstride, int dtype, void* stream) {
-    if (!x || !w || !y || !stat || (ldx & 3) || (ldy & 3) || groups < 1 || !dw_args_ok(B, H, W, C, 3, 1, 1)) return TC_ERR_ARG;
+    if (!x || !w || !y || (ldx & 3) || (ldy & 3) || groups < 1 || !dw_args_ok(B, H, W, C, 3, 1, 1)) return TC_ERR_ARG;     // stat may be NULL
     TC_DISPATCH_DTYPE(dtype, {
         if (!dw_tile_ok<T>(x, ldx, y, ldy, C)) return TC_ERR_ARG;
         return (launch_tile<T, 0>(x, ldx, w, bias, y, ldy, nullptr, 0, nullptr, nullptr, B, H, W, C, 3, 1, 0, groups, wstride,

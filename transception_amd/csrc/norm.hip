@@ -28,9 +28,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, in
                                                      int C, float eps, int act, long long pstride) {
     constexpr int RPB = 256 / GS;
     const int gl = threadIdx.x % GS, gi = threadIdx.x / GS;
+    const int sst = (rstd == mean + 1) ? 2 : 1;                  // interleaved statistics: [rows][2] (mean, rstd) pairs
     {   // group = blockIdx.y: `rows` rows each, parameters pstride apart
         const long long g = blockIdx.y;
-        x += g * rows * ldx; y += g * rows * ldy; mean += g * rows; rstd += g * rows; gamma += g * pstride; beta += g * pstride;
+        x += g * rows * ldx; y += g * rows * ldy; mean += g * rows * sst; rstd += g * rows * sst; gamma += g * pstride; beta += g * pstride;
     }
     const int nv = C >> 2;
     const float invC = 1.0f / (float)C;
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, in
         for (int r = 0; r < RPT; ++r) {
             const int row = row0 + r;
             if (row >= rows) break;
-            if (gl == 0) { mean[row] = mu[r]; rstd[row] = rs[r]; }
+            if (gl == 0) { mean[(long long)row * sst] = mu[r]; rstd[(long long)row * sst] = rs[r]; }
             T* yr = y + (long long)row * ldy;
 #pragma unroll
             for (int i = 0; i < NV; ++i) {

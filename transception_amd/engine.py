@@ -159,6 +159,7 @@ _N_WSTREAMS = int(os.environ.get("TC_WGRAD_STREAMS", "4"))
 _NO_PENDING = bool(os.environ.get("TC_DEBUG_NO_PENDING"))   # timing what-if only (racy)
 _SKIP_WGRAD = bool(os.environ.get("TC_DEBUG_SKIP_WGRAD"))
 _FFN_STORE_ACT = os.environ.get("TC_FFN_STORE_ACT", "1") != "0"   # MixFFN: keep GELU(LN(d)) from the forward pass (0: recompute it in dW2's loader)
+_FFN_LN_GEMM_MAXC = int(os.environ.get("TC_FFN_LN_GEMM_MAXC", "64"))  # widest fc2 output for which LayerNorm + GELU run in its A loader
 _POISON = bool(os.environ.get("TC_DEBUG_POISON"))         # fill every fresh buffer with NaN: finds reads of memory no kernel wrote
 
 
@@ -694,10 +695,14 @@ class Graph:
             # stacked weight groups write row blocks of `out`, or -- the last MB layer -- column blocks of the IFF concat buffer
             side = Gn > 1 and out.rows == M and out.cols == Gn * Cin
             assert side or (out.rows == x.rows and out.cols == Cin)
-            st.append(dict(so=Cin if side else M * out.ld, side=side, x=x, W1=W1, b1=b1, wd=wd, bd=bd, lg=lg, lb=lb, W2=W2, b2=b2, B=B, H=H, W=W, C4=C4, Cin=Cin, M=M, cn=cn,
+            # LayerNorm + GELU inside the fc2 GEMM's A loader pays when the product has ONE 64-column tile (Cin <= 64: every element is
+            # transformed once); with N tiles across Cin the exact-erf GELU would be recomputed N / 64 times, so wider sites run the
+            # LayerNorm kernel on d (it also writes the activated map the weight gradient reads) and a plain fc2 GEMM
+            lng = Cin <= _FFN_LN_GEMM_MAXC
+            st.append(dict(lng=lng, so=Cin if side else M * out.ld, side=side, x=x, W1=W1, b1=b1, wd=wd, bd=bd, lg=lg, lb=lb, W2=W2, b2=b2, B=B, H=H, W=W, C4=C4, Cin=Cin, M=M, cn=cn,
                            nch=C4 // cn, nch2=(C4 + 63) // 64, res=s_.get("residual"), out=out,
                            h=_empty((x.rows, C4), self.dtype, self.dev), d=_empty((x.rows, C4), self.dtype, self.dev),
-                           a=_empty((x.rows, C4), self.dtype, self.dev) if _FFN_STORE_ACT else None,
+                           a=_empty((x.rows, C4), self.dtype, self.dev) if (_FFN_STORE_ACT or not lng) else None,
                            part=self.f32(x.rows * (C4 // cn) * 2), stat=self.f32(x.rows * 2)))
 
         def hook(g: TcGemm, t, mode):
@@ -717,23 +722,26 @@ class Graph:
         if not many:
             t = st[0]
             _timed("hbm:ffn_dw_fwd (MixFFN dw3x3 + skip + LayerNorm partials)", 2.0 * t["x"].rows * t["C4"] * t["h"].element_size(),
-                   lambda: L.tc_ffn_dw_fwd(_ptr(t["h"]), t["C4"], _ptr(t["wd"].data), _ptr(t["bd"].data), _ptr(t["d"]), t["C4"], _ptr(t["part"]),
-                                           t["B"], t["H"], t["W"], t["C4"], Gn, gs, self.dt, self.stream))
+                   lambda: L.tc_ffn_dw_fwd(_ptr(t["h"]), t["C4"], _ptr(t["wd"].data), _ptr(t["bd"].data), _ptr(t["d"]), t["C4"],
+                                           _ptr(t["part"]) if t["lng"] else None, t["B"], t["H"], t["W"], t["C4"], Gn, gs, self.dt, self.stream))
         else:
             assert n <= 4
             arr = (TcDwSeg * n)()
             for i, t in enumerate(st):
                 arr[i] = TcDwSeg(_ptr(t["h"]), _ptr(t["wd"].data), _ptr(t["bd"].data), _ptr(t["d"]), None, None, None, t["C4"], 3, t["C4"], t["C4"], 0,
-                                 t["B"], t["H"], t["W"], _ptr(t["part"]))
+                                 t["B"], t["H"], t["W"], _ptr(t["part"]) if t["lng"] else None)
             L.tc_dwconv_multi(arr, n, 0, 1, 0, 1, 0, None, 0, self.dt, self.stream)
         # fc2 on GELU(LN(d)) (+ bias + residual)
         fw = []
         for i, t in enumerate(st):
             out, res = t["out"], t["res"]
-            fw.append(hook(desc(i, _ptr(t["d"]), t["C4"], _ptr(t["W2"].data), t["C4"], _ptr(out.data), out.ld, t["M"], t["Cin"], t["C4"], 0, 1,
-                                bias=_ptr(t["b2"].data), R=_ptr(res.data) if res is not None else None, ldr=res.ld if res is not None else 0,
-                                nb1=Gn, sA=(t["M"] * t["C4"], 0), sB=(gs, 0), sC=(t["so"], 0),
-                                sR=(t["M"] * res.ld if res is not None else 0, 0), sbias=gs), t, FFN_LN_A))
+            if not t["lng"]:                                 # statistics land interleaved ([rows][2]) where the backward hooks read them
+                L.tc_layernorm_fwd(_ptr(t["d"]), t["C4"], _ptr(t["lg"].data), _ptr(t["lb"].data), _ptr(t["a"]), t["C4"], _ptr(t["stat"]),
+                                   t["stat"].data_ptr() + 4, t["M"], t["C4"], 1e-5, ACT_GELU, Gn, gs, self.dt, self.stream)
+            g = desc(i, _ptr(t["d"] if t["lng"] else t["a"]), t["C4"], _ptr(t["W2"].data), t["C4"], _ptr(out.data), out.ld, t["M"], t["Cin"], t["C4"],
+                     0, 1, bias=_ptr(t["b2"].data), R=_ptr(res.data) if res is not None else None, ldr=res.ld if res is not None else 0,
+                     nb1=Gn, sA=(t["M"] * t["C4"], 0), sB=(gs, 0), sC=(t["so"], 0), sR=(t["M"] * res.ld if res is not None else 0, 0), sbias=gs)
+            fw.append(hook(g, t, FFN_LN_A) if t["lng"] else g)
         self._launch_gemms(fw)
 
         def bwd():
