@@ -169,6 +169,38 @@ def _empty(shape, dtype, device) -> torch.Tensor:
     return torch.empty(tuple(shape), dtype=dtype, device=device)
 
 
+# Gradient buffers that need a zero start (partially written roots, scatter targets) come out of ONE arena per backward sweep that
+# is zeroed by a single launch at the first request: ~30 separate 5 us fill kernels per step otherwise.  The arena's size is what the
+# previous sweep on this (device, dtype) asked for -- shapes are static from step to step -- and anything beyond it falls back to
+# torch.zeros.
+_ZERO_NEED: Dict[Tuple[str, torch.dtype], int] = {}
+
+
+class _ZeroArena:
+    def __init__(self, device, dtype):
+        self.key = (str(device), dtype)
+        self.device, self.dtype = device, dtype
+        self.buf: Optional[torch.Tensor] = None
+        self.used = 0
+        self.asked = 0
+
+    def zeros_like(self, t: torch.Tensor) -> torch.Tensor:
+        n = (t.numel() + 127) // 128 * 128                       # keep 256-byte alignment of every sub-buffer
+        self.asked += n
+        if self.buf is None:
+            need = _ZERO_NEED.get(self.key, 0)
+            if need >= n:
+                self.buf = torch.zeros(need, dtype=self.dtype, device=self.device)
+        if self.buf is not None and self.used + n <= self.buf.numel() and t.is_contiguous():
+            out = self.buf[self.used:self.used + t.numel()].view(t.shape)
+            self.used += n
+            return out
+        return torch.zeros_like(t)
+
+    def close(self):
+        _ZERO_NEED[self.key] = max(self.asked, 0)
+
+
 class _Branch:
     def __init__(self, G, stream):
         self.G, self.stream, self.ctx, self.prev = G, stream, None, None
@@ -259,6 +291,7 @@ class Graph:
         self.cur = torch.cuda.current_stream(device) if torch.device(device).type == "cuda" else None
         self.stream = self.cur.cuda_stream if self.cur is not None else 0
         self.n_launch = 0
+        self._zeros = _ZeroArena(device, dtype)
 
     # ------------------------------------------------------------------ memory
     def new(self, rows: int, cols: int, requires_grad: bool = True, covered: bool = False) -> Var:
@@ -293,7 +326,7 @@ class Graph:
                 assert r.grad_t.stride() == r.data.stride(), "gradient layout must mirror the data layout"
             else:
                 assert r.data.is_contiguous()
-                r.grad_t = _empty(r.data.shape, r.data.dtype, r.data.device) if r.covered else torch.zeros_like(r.data)
+                r.grad_t = _empty(r.data.shape, r.data.dtype, r.data.device) if r.covered else self._zeros.zeros_like(r.data)
         acc = r.whole_written or any(_overlap(reg, w) for w in r.written)
         if whole:
             r.whole_written = True
@@ -311,7 +344,7 @@ class Graph:
         assert root.data.is_contiguous()
         cols = root.data.shape[1]
         if root.grad_t is None:
-            root.grad_t = torch.zeros_like(root.data)
+            root.grad_t = self._zeros.zeros_like(root.data)
         root.written.append((off // cols, (off + nelem + cols - 1) // cols, 0, cols))
         return root.grad_t
 
@@ -389,7 +422,7 @@ class Graph:
             elif entry[0] == "fork":                     # forward join point: branch backward starts after main's upstream work
                 for r in entry[3]:                       # gradient buffers shared by the branches are created (zeroed) on main
                     if r.grad_t is None:                 # first, so no branch's lazy zero-fill can race another branch's write
-                        r.grad_t = torch.zeros_like(r.data)
+                        r.grad_t = self._zeros.zeros_like(r.data)
                 for s in entry[2]:
                     s.wait_stream(entry[1])
             else:
@@ -406,6 +439,7 @@ class Graph:
         self._pending.clear()
         self._keep.clear()
         self.tape = []
+        self._zeros.close()
         return True
 
     def _rec(self, fn):
