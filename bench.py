@@ -262,6 +262,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             exposed = 1e3 * (elapsed / args.steps - float(t.item()))
             dist.broadcast(model.flat_parameters(), src=0)       # the ranks' un-reduced updates diverged: not used afterwards
+            model.invalidate_working_copy()
 
     extra, roofs = {}, {}
     if rank == 0 and world == 1 and not args.no_side:

@@ -386,9 +386,11 @@ int tc_sgd_step(float* p, const float* grad, float* buf, long long n, float lr, 
 /* clip_sumsq (optional device scalar = sum of squared gradients, see tc_grad_sumsq): gradients are additionally scaled by
  * min(1, clip_norm / (sqrt(*clip_sumsq) + 1e-6)) -- nn.utils.clip_grad_norm_(parameters, clip_norm, 2) of trainer.py:147-148 folded
  * into the update (the stored gradients themselves stay unscaled). */
+/* lp (optional, lp_dtype TC_BF16 / TC_F16): the 16-bit working copy of the parameters, same indexing as p -- the updated values are
+ * stored there too, so the next forward needs no cast pass over the arena. */
 int tc_sgd_step_multi(float* p, const float* grad, float* buf, const long long* segs_dev, int nseg, long long max_len,
                       float lr, const float* lr_dev, float momentum, float wd, float gscale, int first, const float* clip_sumsq,
-                      float clip_norm, void* stream);
+                      float clip_norm, void* lp, int lp_dtype, void* stream);
 /* *out += sum_i g[i]^2 over a flat fp32 buffer (n a multiple of 4, 16-byte aligned): the squared total gradient norm. */
 int tc_grad_sumsq(const float* g, long long n, float* out, void* stream);
 /* p[0..n) = v (fp32): resets device accumulators inside a captured step */

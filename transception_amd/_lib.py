@@ -108,7 +108,7 @@ SIGNATURES = {
     "tc_spline_prefilter": [vp, vp, i32, i32, i32, vp],
     "tc_zoom_normalize": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, f32, vp],
     "tc_sgd_step": [vp, vp, vp, i64, f32, vp, f32, f32, f32, i32, vp],
-    "tc_sgd_step_multi": [vp, vp, vp, vp, i32, i64, f32, vp, f32, f32, f32, i32, vp, f32, vp],
+    "tc_sgd_step_multi": [vp, vp, vp, vp, i32, i64, f32, vp, f32, f32, f32, i32, vp, f32, vp, i32, vp],
     "tc_grad_sumsq": [vp, i64, vp, vp],
     "tc_fill_f32": [vp, i64, f32, vp],
     "tc_cast": [vp, vp, i64, i32, i32, vp],

@@ -110,6 +110,60 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const T* __restrict__ dy,
     }
 }
 
+// The same for 3 x 3 filters with 8- / 16-byte loads: a thread owns 4 consecutive channels and one of 16 pixel lanes (the scalar form
+// above moves 2 bytes per lane and load and took 65 us on the 6 MB map of the first RIPM convolution); the 16 lanes of a channel
+// quad fold by two shuffles and one pass through LDS, the grid is capped at 64 workgroups per channel chunk so that at most 64
+// atomics queue on a word.
+template <typename T>
+__global__ __launch_bounds__(256) void dw_wgrad3_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ x, int ldx,
+                                                        float* __restrict__ dw, float* __restrict__ db, int B, int H, int W,
+                                                        int Ho, int Wo, int C, int stride) {
+    constexpr int K = 3, NT = K * K + 1;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int c = blockIdx.y * 64 + tx * 4;
+    float4 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const long long npix = (long long)B * Ho * Wo;
+    if (c < C) {
+        for (long long pix = (long long)blockIdx.x * 16 + ty; pix < npix; pix += (long long)gridDim.x * 16) {
+            const int ow = (int)(pix % Wo), oh = (int)((pix / Wo) % Ho), b = (int)(pix / ((long long)Wo * Ho));
+            const float4 d = ld4<T>(dy + pix * lddy + c);
+            const T* xb = x + (long long)b * H * W * ldx + c;
+            float4 v[K * K];
+#pragma unroll
+            for (int t = 0; t < K * K; ++t) {                      // all nine loads issued before the first use
+                const int ih = oh * stride + t / K - 1, iw = ow * stride + t % K - 1;
+                const bool in = ih >= 0 && ih < H && iw >= 0 && iw < W;
+                v[t] = ld4<T>(xb + (in ? ((long long)ih * W + iw) * ldx : 0));
+                if (!in) v[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int t = 0; t < K * K; ++t) { acc[t].x += d.x * v[t].x; acc[t].y += d.y * v[t].y; acc[t].z += d.z * v[t].z; acc[t].w += d.w * v[t].w; }
+            acc[K * K].x += d.x; acc[K * K].y += d.y; acc[K * K].z += d.z; acc[K * K].w += d.w;
+        }
+    }
+    __shared__ float red[4][NT][64];
+    const int wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        float4 a = acc[t];
+#pragma unroll
+        for (int o = 16; o < 64; o <<= 1) {                         // lanes of one channel quad inside a wave are 16 apart
+            a.x += __shfl_xor(a.x, o, 64); a.y += __shfl_xor(a.y, o, 64); a.z += __shfl_xor(a.z, o, 64); a.w += __shfl_xor(a.w, o, 64);
+        }
+        if ((threadIdx.x & 63) < 16) { float* r = &red[wave][t][tx * 4]; r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; }
+    }
+    __syncthreads();
+    for (int f = threadIdx.x; f < NT * 64; f += 256) {
+        const int cc = f / NT, t = f - cc * NT, ch = blockIdx.y * 64 + cc;      // taps fastest: coalesced atomics
+        if (ch >= C) continue;
+        const float s_ = red[0][t][cc] + red[1][t][cc] + red[2][t][cc] + red[3][t][cc];
+        if (t < K * K) atomicAdd(dw + (long long)ch * K * K + t, s_);
+        else if (db) atomicAdd(db + ch, s_);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Stride-1 "row strip" kernels: a thread owns CPT consecutive channels of one output row (b, oh) and walks along ow with
 // the K x K input window held in registers (K new loads per output instead of K*K; column slots rotate at compile time).
@@ -1302,6 +1356,12 @@ extern "C" int tc_dwconv_bwd_weight(const void* dy, int lddy, const void* x, int
     const long long npix = (long long)B * Ho * Wo;
     dim3 grid(tc_blocks(npix, 4 * 16, 256), (C + 63) / 64), block(256);
     hipStream_t s = (hipStream_t)stream;
+    if (k == 3 && (ldx & 3) == 0 && (lddy & 3) == 0) {
+        const dim3 g3(tc_blocks(npix, 16 * 8, 64), (C + 63) / 64);
+        TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dw_wgrad3_kernel<T>), g3, block, 0, s, (const T*)dy, lddy, (const T*)x, ldx, dw, db, B, H, W,
+                                                    Ho, Wo, C, stride));
+        return tc_launch_status();
+    }
 #define TC_DWW(KK) hipLaunchKernelGGL((dw_wgrad_kernel<T, KK>), grid, block, 0, s, (const T*)dy, lddy, (const T*)x, ldx, dw, db, \
                                       B, H, W, Ho, Wo, C, stride)
     TC_DISPATCH_DTYPE(dtype, { if (k == 3) TC_DWW(3); else if (k == 5) TC_DWW(5); else TC_DWW(7); });

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 
 __global__ void sgd_multi_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, const long long* __restrict__ segs,
                                  float lr, float mom, float wd, float gscale, int first, const float* __restrict__ lr_dev,
-                                 const float* __restrict__ clip_sumsq, float clip_norm) {
+                                 const float* __restrict__ clip_sumsq, float clip_norm, void* __restrict__ lp, int lp_dtype) {
     if (lr_dev) lr = *lr_dev;
     if (clip_sumsq) gscale *= fminf(clip_norm / (sqrtf(*clip_sumsq) + 1e-6f), 1.0f);      // clip_grad_norm_'s coefficient, clamped to 1
     const long long off = segs[2 * blockIdx.y], n = segs[2 * blockIdx.y + 1];
@@ -135,7 +135,11 @@ __global__ void sgd_multi_kernel(float* __restrict__ p, const float* __restrict_
         const float d = g[j] * gscale + wd * w;
         const float b = first ? d : mom * buf[j] + d;
         buf[j] = b;
-        p[j] = w - lr * b;
+        const float wn = w - lr * b;
+        p[j] = wn;
+        // the 16-bit working copy of the weights that the next forward reads (otherwise a separate cast pass over the whole arena)
+        if (lp_dtype == TC_BF16) reinterpret_cast<bf16_t*>(lp)[j] = f2bf(wn);
+        else if (lp_dtype == TC_F16) reinterpret_cast<f16_t*>(lp)[j] = f2h(wn);
     }
 }
 
@@ -232,10 +236,12 @@ extern "C" int tc_sgd_step(float* p, const float* grad, float* buf, long long n,
 
 extern "C" int tc_sgd_step_multi(float* p, const float* grad, float* buf, const long long* segs_dev, int nseg, long long max_len, float lr,
                                  const float* lr_dev, float momentum, float wd, float gscale, int first, const float* clip_sumsq,
-                                 float clip_norm, void* stream) {
-    if (!p || !grad || !buf || !segs_dev || nseg <= 0 || nseg > 65535 || max_len <= 0 || (clip_sumsq && !(clip_norm > 0.f))) return TC_ERR_ARG;
+                                 float clip_norm, void* lp, int lp_dtype, void* stream) {
+    if (!p || !grad || !buf || !segs_dev || nseg <= 0 || nseg > 65535 || max_len <= 0 || (clip_sumsq && !(clip_norm > 0.f)) ||
+        (lp && lp_dtype != TC_BF16 && lp_dtype != TC_F16))
+        return TC_ERR_ARG;
     hipLaunchKernelGGL(sgd_multi_kernel, dim3(tc_blocks(max_len, 256 * 8, 256), nseg), dim3(256), 0, (hipStream_t)stream, p, grad, buf, segs_dev,
-                       lr, momentum, wd, gscale, first, lr_dev, clip_sumsq, clip_norm);
+                       lr, momentum, wd, gscale, first, lr_dev, clip_sumsq, clip_norm, lp, lp ? lp_dtype : -1);
     return tc_launch_status();
 }
 

@@ -275,6 +275,7 @@ class MSTransception(nn.Module):
         self._flat: Optional[torch.Tensor] = None
         self._gflat: Optional[torch.Tensor] = None
         self._flat_lp: Optional[torch.Tensor] = None
+        self._lp_fresh = False                          # FusedSGD wrote the 16-bit copy of the weights with its last update
         self._index: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
         self._uniq_params: List[nn.Parameter] = []
         self._used: set = set()
@@ -323,8 +324,21 @@ class MSTransception(nn.Module):
         self._index = {n: (off_of[id(p)], tuple(p.shape)) for n, p in self.named_parameters(remove_duplicate=False)}
         self._pid = {n: id(p) for n, p in self.named_parameters(remove_duplicate=False)}
 
+    def load_state_dict(self, *args, **kwargs):
+        self._lp_fresh = False                          # weights change under the 16-bit working copy
+        return super().load_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):
+        self._lp_fresh = False
+        return super()._apply(fn, *args, **kwargs)
+
     def flat_parameters(self) -> torch.Tensor:
+        """The fp32 parameter arena.  A caller that writes into it directly (e.g. a broadcast) must do so before the next forward of a
+        step sequence driven by something other than FusedSGD, or call `invalidate_working_copy()`."""
         return self._flat
+
+    def invalidate_working_copy(self):
+        self._lp_fresh = False
 
     def flat_gradients(self) -> torch.Tensor:
         return self._gflat
@@ -382,9 +396,12 @@ class MSTransception(nn.Module):
         L = lib()
         stream = torch.cuda.current_stream(dev).cuda_stream
         if self.compute_dtype != torch.float32:
-            if self._flat_lp is None:
-                self._flat_lp = torch.empty(self._flat.numel(), dtype=self.compute_dtype, device=dev)
-            L.tc_cast(self._flat.data_ptr(), self._flat_lp.data_ptr(), self._flat.numel(), TC_F32, self._tc_dtype(), stream)
+            fresh = self._lp_fresh and self._flat_lp is not None and self._flat_lp.dtype == self.compute_dtype
+            self._lp_fresh = False                      # only the step that FusedSGD just finished vouches for the copy
+            if not fresh:
+                if self._flat_lp is None or self._flat_lp.dtype != self.compute_dtype:
+                    self._flat_lp = torch.empty(self._flat.numel(), dtype=self.compute_dtype, device=dev)
+                L.tc_cast(self._flat.data_ptr(), self._flat_lp.data_ptr(), self._flat.numel(), TC_F32, self._tc_dtype(), stream)
         if record:
             self._used_views = {}
         G = Graph(self.compute_dtype, dev, self.training, record)

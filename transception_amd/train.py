@@ -157,9 +157,13 @@ class FusedSGD:
             L.tc_fill_f32(self._sumsq.data_ptr(), 1, 0.0, stream)
             L.tc_grad_sumsq(g.data_ptr(), g.numel(), self._sumsq.data_ptr(), stream)
             sumsq = self._sumsq.data_ptr()
+        # the 16-bit working copy of the weights is refreshed by the same kernel (the forward then skips its cast pass over the arena)
+        lp = M._flat_lp if (M.compute_dtype != torch.float32 and M._flat_lp is not None and M._flat_lp.dtype == M.compute_dtype) else None
         L.tc_sgd_step_multi(flat.data_ptr(), g.data_ptr(), self.buf.data_ptr(), self._segs_dev.data_ptr(), self._nseg, self._maxlen,
                             float(self.lr), self.lr_dev.data_ptr(), float(self.momentum), float(self.wd), float(grad_scale),
-                            int(self.steps == 0), sumsq, float((self.clip_norm or 0.0) / grad_scale), stream)
+                            int(self.steps == 0), sumsq, float((self.clip_norm or 0.0) / grad_scale),
+                            lp.data_ptr() if lp is not None else None, M._tc_dtype() if lp is not None else 0, stream)
+        M._lp_fresh = lp is not None
         self.steps += 1
 
 

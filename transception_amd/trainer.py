@@ -98,6 +98,7 @@ def trainer_synapse(cfg: TrainConfig, model, snapshot_path: str, volumes: Option
         # trainer.py:110-111): parameters and BatchNorm statistics come from rank 0
         model._ensure_flat(dev)
         dist.broadcast(model.flat_parameters(), src=0, group=group)
+        model.invalidate_working_copy()
         for buf in model.buffers():
             dist.broadcast(buf, src=0, group=group)
 
