@@ -134,6 +134,17 @@ int tc_layernorm_bwd_params(const void* dy, int lddy, const void* x, int ldx, co
                             const float* mean, const float* rstd, float* dgamma, float* dbeta, int rows, int C, int act,
                             int groups, long long pstride, int dtype, void* stream);
 
+/* LayerNorm over the pixels of a pixel-shuffled map without the shuffle copy (PatchExpand / FinalPatchExpand_X4, MSTr.py:196-199,
+ * 222-225: Linear -> rearrange 'b h w (p1 p2 c) -> b (h p1) (w p2) c' -> LayerNorm(c)): x is the UN-shuffled Linear output
+ * [B*H*W, p*p*C] (row stride ldx); output row (b, h*p+p1, w*p+p2) normalises the C-wide chunk (p1*p+p2) of x row (b, h, w); y, mean,
+ * rstd are indexed by output pixel.  Backward writes dx in the un-shuffled layout (row stride lddx), dgamma/dbeta accumulated,
+ * scratch as in tc_layernorm_bwd. */
+int tc_layernorm_ps_fwd(const void* x, int ldx, const void* gamma, const void* beta, void* y, int ldy, float* mean, float* rstd,
+                        int B, int H, int W, int p, int C, float eps, int dtype, void* stream);
+int tc_layernorm_ps_bwd(const void* dy, int lddy, const void* x, int ldx, const void* gamma, const void* beta, const float* mean,
+                        const float* rstd, void* dx, int lddx, float* dgamma, float* dbeta, int B, int H, int W, int p, int C,
+                        float* scratch, long long scratch_floats, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Depthwise k x k convolution on NHWC maps, k in {3,5,7}, stride 1 or 2, padding (k-1)/2,
  * weight in the PyTorch layout [C,1,k,k], optional bias, optional "+ x" (stride 1 only).

@@ -64,6 +64,8 @@ SIGNATURES = {
     "tc_layernorm_fwd": [vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, f32, i32, i32, i64, i32, vp],
     "tc_layernorm_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i64, vp, i64, i32, vp],
     "tc_layernorm_bwd_scratch_floats": [i32, i32, i32],
+    "tc_layernorm_ps_fwd": [vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp],
+    "tc_layernorm_ps_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, i64, i32, vp],
     "tc_layernorm_bwd_params": [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i32, vp],
     "tc_dwconv_fwd": [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i64, i32, vp],
     "tc_dwconv_bwd_input": [vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i64, i32, vp],

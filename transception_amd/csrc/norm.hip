@@ -13,6 +13,17 @@ constexpr int LN_BWD_MAX_BLOCKS = 1024, LN_BWD_ROWS_PER_GROUP = 4;   // fused dx
 // 256/GS rows at a time (C = 64 rows use 16 lanes: 4 rows per wave instead of 48 idle lanes).  Statistics by xor-shuffles
 // inside the group.  The backward keeps per-lane partial dgamma/dbeta over a grid-stride loop of rows, folds the groups
 // of a block through LDS and issues one atomic per channel per block (grid capped so the atomics do not serialise).
+// Optional source addressing of a LayerNorm whose rows are the pixels of a pixel-shuffled map (PatchExpand / FinalPatchExpand_X4,
+// MSTr.py:196-199,222-225): output pixel (b, h p + p1, w p + p2) is the C-wide chunk (p1 p + p2) of row (b, h, w) of the un-shuffled
+// [B H W, p p C] matrix -- the shuffle is an address computation here, not a copy (the X4 copy alone was 206 MB of traffic).
+struct LnMap { int p, H, W; };
+__device__ __forceinline__ long long ln_row_off(int row, const LnMap& m, int ld, int C) {
+    if (m.p == 0) return (long long)row * ld;
+    const int Wp = m.W * m.p, Hp = m.H * m.p;
+    const int ow = row % Wp, t = row / Wp, oh = t % Hp, b = t / Hp;
+    return ((long long)(b * m.H + oh / m.p) * m.W + ow / m.p) * ld + ((oh % m.p) * m.p + ow % m.p) * C;
+}
+
 template <int GS> __device__ __forceinline__ float group_sum(float v) {
 #pragma unroll
     for (int o = GS / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -25,7 +36,7 @@ template <typename T, int GS, int NV, int RPT>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ gamma,
                                                      const T* __restrict__ beta, T* __restrict__ y, int ldy,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int rows,
-                                                     int C, float eps, int act, long long pstride) {
+                                                     int C, float eps, int act, long long pstride, LnMap map) {
     constexpr int RPB = 256 / GS;
     const int gl = threadIdx.x % GS, gi = threadIdx.x / GS;
     const int sst = (rstd == mean + 1) ? 2 : 1;                  // interleaved statistics: [rows][2] (mean, rstd) pairs
@@ -47,7 +58,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, in
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
             const int row = min(row0 + r, rows - 1);              // rows past the end re-read the last row (no divergent loads)
-            const T* xr = x + (long long)row * ldx;
+            const T* xr = x + ln_row_off(row, map, ldx, C);
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const int q = gl + i * GS;
@@ -98,7 +109,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      T* __restrict__ dx, int lddx, const T* __restrict__ dres, int ldres,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int C,
-                                                     int act, long long pstride, float* __restrict__ partial, int* __restrict__ cnt) {
+                                                     int act, long long pstride, float* __restrict__ partial, int* __restrict__ cnt, LnMap map) {
     constexpr int RPB = 256 / GS;
     extern __shared__ float red[];           // [RPB][2][C]
     const int gl = threadIdx.x % GS, gi = threadIdx.x / GS;
@@ -130,9 +141,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
             for (int i = 0; i < NV; ++i) {
                 const int q = gl + i * GS;
                 const bool in = q < nv;
-                xh[r][i] = in ? ld4<T>(x + (long long)row * ldx + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                xh[r][i] = in ? ld4<T>(x + ln_row_off(row, map, ldx, C) + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
                 gg[r][i] = in ? ld4<T>(dy + (long long)row * lddy + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                if (dres) rr[r][i] = in ? ld4<T>(dres + (long long)row * ldres + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (dres) rr[r][i] = in ? ld4<T>(dres + ln_row_off(row, map, ldres, C) + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
 #pragma unroll
@@ -161,7 +172,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
             }
             s1 = group_sum<GS>(s1) * invC; s2 = group_sum<GS>(s2) * invC;
             if (!live) continue;
-            T* dxr = dx + (long long)(row0 + r) * lddx;
+            T* dxr = dx + ln_row_off(row0 + r, map, lddx, C);
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const int q = gl + i * GS;
@@ -458,9 +469,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 
 }  // namespace
 
-extern "C" int tc_layernorm_fwd(const void* x, int ldx, const void* gamma, const void* beta, void* y, int ldy,
-                                float* mean, float* rstd, int rows, int C, float eps, int act, int groups, long long pstride, int dtype,
-                                void* stream) {
+static int ln_fwd_impl(const void* x, int ldx, const void* gamma, const void* beta, void* y, int ldy,
+                       float* mean, float* rstd, int rows, int C, float eps, int act, int groups, long long pstride, int dtype,
+                       void* stream, LnMap map) {
     if (!x || !y || !gamma || !beta || !mean || !rstd || rows <= 0 || groups < 1 || C <= 0 || (C & 3) || C > LN_MAXC ||
         (ldx & 3) || (ldy & 3) || (act != TC_ACT_NONE && act != TC_ACT_GELU))
         return TC_ERR_ARG;
@@ -470,29 +481,41 @@ extern "C" int tc_layernorm_fwd(const void* x, int ldx, const void* gamma, const
         constexpr int RPT = NV == 1 ? 4 : (NV == 2 ? 2 : 1);       /* narrow rows: several rows in flight per lane group */                   \
         if (rows >= 4096)                                                                                                                     \
             hipLaunchKernelGGL((ln_fwd_kernel<T, GS, NV, RPT>), dim3(tc_blocks(rows, (256 / GS) * RPT, 2048), groups), dim3(256), 0, s,       \
-                               (const T*)x, ldx, (const T*)gamma, (const T*)beta, (T*)y, ldy, mean, rstd, rows, C, eps, act, pstride);       \
+                               (const T*)x, ldx, (const T*)gamma, (const T*)beta, (T*)y, ldy, mean, rstd, rows, C, eps, act, pstride, map);  \
         else                                                                                                                                  \
             hipLaunchKernelGGL((ln_fwd_kernel<T, GS, NV, 1>), dim3(tc_blocks(rows, 256 / GS, 2048), groups), dim3(256), 0, s, (const T*)x,    \
-                               ldx, (const T*)gamma, (const T*)beta, (T*)y, ldy, mean, rstd, rows, C, eps, act, pstride); }
+                               ldx, (const T*)gamma, (const T*)beta, (T*)y, ldy, mean, rstd, rows, C, eps, act, pstride, map); }
     TC_DISPATCH_DTYPE(dtype, { TC_LN_DISPATCH(quads, TC_LNF) });
 #undef TC_LNF
     return tc_launch_status();
+}
+
+extern "C" int tc_layernorm_fwd(const void* x, int ldx, const void* gamma, const void* beta, void* y, int ldy,
+                                float* mean, float* rstd, int rows, int C, float eps, int act, int groups, long long pstride, int dtype,
+                                void* stream) {
+    return ln_fwd_impl(x, ldx, gamma, beta, y, ldy, mean, rstd, rows, C, eps, act, groups, pstride, dtype, stream, LnMap{0, 0, 0});
+}
+
+extern "C" int tc_layernorm_ps_fwd(const void* x, int ldx, const void* gamma, const void* beta, void* y, int ldy, float* mean, float* rstd,
+                                   int B, int H, int W, int p, int C, float eps, int dtype, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || p < 1 || ldx < p * p * C) return TC_ERR_ARG;
+    return ln_fwd_impl(x, ldx, gamma, beta, y, ldy, mean, rstd, B * H * p * W * p, C, eps, TC_ACT_NONE, 1, 0, dtype, stream, LnMap{p, H, W});
 }
 
 extern "C" int tc_layernorm_bwd_params(const void* dy, int lddy, const void* x, int ldx, const void* gamma, const void* beta,
                                        const float* mean, const float* rstd, float* dgamma, float* dbeta, int rows, int C, int act,
                                        int groups, long long pstride, int dtype, void* stream);
 
-extern "C" int tc_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx, const void* gamma, const void* beta,
-                                const float* mean, const float* rstd, void* dx, int lddx, const void* dres, int ldres,
-                                float* dgamma, float* dbeta, int rows, int C, int act, int groups, long long pstride,
-                                float* scratch, long long scratch_floats, int dtype, void* stream) {
+static int ln_bwd_impl(const void* dy, int lddy, const void* x, int ldx, const void* gamma, const void* beta,
+                       const float* mean, const float* rstd, void* dx, int lddx, const void* dres, int ldres,
+                       float* dgamma, float* dbeta, int rows, int C, int act, int groups, long long pstride,
+                       float* scratch, long long scratch_floats, int dtype, void* stream, LnMap map) {
     if (!dy || !x || !gamma || !beta || !mean || !rstd || !dx || (!dgamma != !dbeta) || rows <= 0 || groups < 1 || C <= 0 || (C & 3) ||
         C > LN_MAXC || (ldx & 3) || (lddy & 3) || (lddx & 3) || (dres && (ldres & 3)))
         return TC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int quads = C >> 2;
-    if (dgamma && quads > 256) {
+    if (dgamma && quads > 256 && map.p == 0) {
         // wide rows (C = 1280 / 2048: 5-8 float4 per lane): the one-pass kernel would hold ~300 VGPRs; a dx-only launch plus the
         // column-reduction parameter kernel is faster there (measured 18 vs 37 us at 784 x 2048)
         const int rc = tc_layernorm_bwd(dy, lddy, x, ldx, gamma, beta, mean, rstd, dx, lddx, dres, ldres, nullptr, nullptr, rows, C, act,
@@ -506,7 +529,7 @@ extern "C" int tc_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx
         hipLaunchKernelGGL((ln_bwd_kernel<T, GS, NV, RPT>), dim3(nblk, groups), dim3(256),                                                  \
                                           (size_t)(256 / GS) * 2 * C * sizeof(float), s, (const T*)dy, lddy, (const T*)x, ldx,            \
                                           (const T*)gamma, (const T*)beta, mean, rstd, (T*)dx, lddx, (const T*)dres, ldres, dgamma,      \
-                                          dbeta, rows, C, act, pstride, partial, reinterpret_cast<int*>(scratch))
+                                          dbeta, rows, C, act, pstride, partial, reinterpret_cast<int*>(scratch), map)
 #define TC_LNB(GS, NV) {                                                                                                                  \
         constexpr int RPT = 1;   /* two rows in flight measured no faster here (20.5 vs 19.3 us at 97216 x 64): one row per group */      \
         const bool ilp = RPT > 1 && rows >= 8192;                                                                                         \
@@ -521,6 +544,22 @@ extern "C" int tc_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx
 #undef TC_LNB
 #undef TC_LNB_LAUNCH
     return tc_launch_status();
+}
+
+extern "C" int tc_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx, const void* gamma, const void* beta,
+                                const float* mean, const float* rstd, void* dx, int lddx, const void* dres, int ldres,
+                                float* dgamma, float* dbeta, int rows, int C, int act, int groups, long long pstride,
+                                float* scratch, long long scratch_floats, int dtype, void* stream) {
+    return ln_bwd_impl(dy, lddy, x, ldx, gamma, beta, mean, rstd, dx, lddx, dres, ldres, dgamma, dbeta, rows, C, act, groups, pstride, scratch,
+                       scratch_floats, dtype, stream, LnMap{0, 0, 0});
+}
+
+extern "C" int tc_layernorm_ps_bwd(const void* dy, int lddy, const void* x, int ldx, const void* gamma, const void* beta, const float* mean,
+                                   const float* rstd, void* dx, int lddx, float* dgamma, float* dbeta, int B, int H, int W, int p, int C,
+                                   float* scratch, long long scratch_floats, int dtype, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || p < 1 || ldx < p * p * C || lddx < p * p * C || C > 1024) return TC_ERR_ARG;
+    return ln_bwd_impl(dy, lddy, x, ldx, gamma, beta, mean, rstd, dx, lddx, nullptr, 0, dgamma, dbeta, B * H * p * W * p, C, TC_ACT_NONE, 1, 0,
+                       scratch, scratch_floats, dtype, stream, LnMap{p, H, W});
 }
 
 extern "C" long long tc_layernorm_bwd_scratch_floats(int rows, int C, int groups) {

@@ -883,6 +883,32 @@ class Graph:
         self._rec(bwd)
         return out
 
+    def layernorm_shuffled(self, x: Var, g: P, b: P, B: int, H: int, W: int, p: int, eps: float = 1e-5) -> Var:
+        """LayerNorm(c) of the pixel-shuffled map 'b h w (p1 p2 c) -> b (h p1) (w p2) c' of x [B*H*W, p*p*c] (PatchExpand,
+        MSTr.py:196-199,222-225) with the shuffle done by the kernel's addressing: no shuffled copy in either direction."""
+        assert self.ngroups == 1 and x.rows == B * H * W and x.cols % (p * p) == 0
+        c = x.cols // (p * p)
+        rows = B * H * p * W * p
+        out = self.new(rows, c)
+        mean, rstd = self.f32(rows), self.f32(rows)
+        es = x.data.element_size()
+        _timed("hbm:layernorm_fwd", 2.0 * rows * c * es, lambda: self.L.tc_layernorm_ps_fwd(
+            _ptr(x.data), x.ld, _ptr(g.data), _ptr(b.data), _ptr(out.data), out.ld, _ptr(mean), _ptr(rstd), B, H, W, p, c, eps, self.dt,
+            self.stream))
+
+        def bwd():
+            dy = self.grad_of(out)
+            if dy is None or not x.requires_grad:
+                return
+            gx, acc = self.wgrad(x)
+            assert not acc, "the expanded map has one consumer"
+            ws = _workspace(self.dev, self.stream)
+            _timed("hbm:layernorm_bwd", 3.0 * rows * c * es, lambda: self.L.tc_layernorm_ps_bwd(
+                _ptr(dy), dy.stride(0), _ptr(x.data), x.ld, _ptr(g.data), _ptr(b.data), _ptr(mean), _ptr(rstd), _ptr(gx), gx.stride(0),
+                _ptr(g.grad), _ptr(b.grad), B, H, W, p, c, _ptr(ws) if g.grad is not None else None, ws.numel() // 4, self.dt, self.stream))
+        self._rec(bwd)
+        return out
+
     def dwconv(self, x: Var, w: P, b: Optional[P], B: int, H: int, W: int, k: int, stride: int = 1, add_input: bool = False,
                out: Optional[Var] = None) -> Var:
         Cc = x.cols

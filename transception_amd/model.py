@@ -559,6 +559,7 @@ MANY_MIXFFN = os.environ.get("TC_MANY_MIXFFN", "1") != "0"
 MULTI_QKV = os.environ.get("TC_MULTI_QKV", "1") != "0"
 MULTI_CRPE = os.environ.get("TC_MULTI_CRPE", "1") != "0"
 FUSED_FACTOR_ATT = os.environ.get("TC_FACTOR_ATT_FUSED", "1") != "0"
+SHUFFLE_IN_LN = os.environ.get("TC_SHUFFLE_IN_LN", "1") != "0"
 
 
 def _factor_att(M, G, n: Var, blk: str, enc: str, B: int, side: int, residual: Optional[Var] = None) -> Var:
@@ -760,6 +761,8 @@ def _patch_expand(M, G, t: Var, name: str, B: int, side: int, p: int) -> Var:
     if t.rows != B * side * side:
         raise AssertionError("input feature has wrong size")
     y = G.linear(t, *_lin(M, G, name + ".expand", bias=False))
+    if SHUFFLE_IN_LN:                            # the rearrange is an address computation inside the LayerNorm kernels
+        return G.layernorm_shuffled(y, M._P(G, name + ".norm.weight"), M._P(G, name + ".norm.bias"), B, side, side, p)
     return _ln(M, G, G.pixel_shuffle(y, B, side, side, p), name + ".norm")
 
 
