@@ -164,3 +164,15 @@ def test_fused_mixffn_four_sites_one_launch_set(dtype):
     for o, (xv, gf, _), (yr, gxr, gpr) in zip(outs, keep, refs):
         for a, b in ((o.data.float().cpu(), yr), (G.grad_of(xv).float().cpu(), gxr), (gf.cpu(), gpr)):
             assert float((a - b).abs().max()) / (float(b.abs().max()) + 1e-6) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_mixffn_recompute_and_wide_loader_variants(dtype, monkeypatch):
+    """The library paths the default configuration does not take: LayerNorm + GELU in the fc2 loader of a multi-tile product
+    (TC_FFN_LN_A with N > 64) and the weight gradient that recomputes GELU(LN(d)) in its B loader (TC_FFN_LN_B) instead of reading
+    the stored activation."""
+    import transception_amd.engine as E
+    monkeypatch.setattr(E, "_FFN_STORE_ACT", False)
+    monkeypatch.setattr(E, "_FFN_LN_GEMM_MAXC", 4096)
+    for case in ((128, 3, 14, 14, 1), (64, 2, 20, 24, 3), (320, 2, 7, 7, 1)):
+        test_fused_mixffn_matches_torch_and_unfused(case, dtype)
