@@ -10,6 +10,7 @@
 //   * allows two workgroups per CU (launch bounds) so one wave's softmax VALU overlaps another's MFMA.
 // fp32 storage falls back to the per-segment fp32 kernels of attention.hip (parity path).
 #include "../../transception_amd/csrc/tc_common.h"
+#include <type_traits>
 #ifndef ATT_VAR
 #define ATT_VAR 0
 #endif
@@ -864,6 +865,1256 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_seg_kernel(const bf16_t* __re
             st4<bf16_t>(orow + 32 + 8 * g + 4 * h, make_float4(acc1[4 * g] * inv, acc1[4 * g + 1] * inv, acc1[4 * g + 2] * inv, acc1[4 * g + 3] * inv));
         }
         if (h == 0) lse[qrow] = (m + log2f(lsum)) * LN2;
+    }
+}
+
+#elif ATT_VAR >= 30 && ATT_VAR < 40
+// v30: ONE workgroup of NW30 = 12 waves (768 threads) per CU: 16 workgroups per image = 256 at B = 16.  The twelve 32-query wave tiles share
+// one K/V staging (a third of the L2 -> LDS traffic of the 4-wave workgroups); the 128-key K/V tiles are double-buffered in LDS (72 KB)
+// and fetched a whole tile ahead into 3 registers per thread, so a tile costs ONE barrier and no exposed load latency.
+// v31 = v30 + the QK^T MFMAs of the next 32-key sub-tile issued before the softmax of the current one (within a 128-key tile)
+// v32 = v31 + explicit MFMA / VALU interleave (sched_group_barrier)
+#ifndef NW30
+#define NW30 12
+#endif
+#ifndef KB30
+#define KB30 128
+#endif
+#ifdef TIMING
+__device__ long long g_dbg[4 * NW30 * 24];
+#define TSTAMP(k) do { if ((blockIdx.x & 63) == 5 && blockIdx.x < 256 && lane == 0) g_dbg[((blockIdx.x >> 6) * NW30 + wave) * 24 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define TSTAMP(k)
+#endif
+constexpr int NT30 = NW30 * 64, NC30 = KB30 * 8, NF30 = (2 * NC30 + NT30 - 1) / NT30;   // NC30 16-byte chunks per K (or V) tile
+__global__ __launch_bounds__(NT30, 1) void attn_fwd_seg_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
+                                                               const bf16_t* __restrict__ V, int ldv, long long skv, bf16_t* __restrict__ O,
+                                                               int ldo, float* __restrict__ lse, Segs sg, int Nk, float scale) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem30[];      // [2 slots][K tile | V tile][KB][LDR]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    const int nwt = sg.t32[sg.n], bpi = (nwt + NW30 - 1) / NW30;
+    const int b = blockIdx.x / bpi, wt = (blockIdx.x - b * bpi) * NW30 + wave;
+    int sgi = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) if (i < sg.n && wt >= sg.t32[i]) sgi = i;
+    const int nq = sg.nq[sgi];
+    const int ql = (wt - sg.t32[sgi]) * 32 + j;
+    const bool ok = wt < nwt && ql < nq;
+    const long long qrow = (long long)sg.row0[sgi] + (long long)b * nq + ql;
+    const bf16_t* Kb = K + b * skv;
+    const bf16_t* Vb = V + b * skv;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const uint4 v = ok ? *reinterpret_cast<const uint4*>(Q + qrow * ldq + 16 * ks + 8 * h) : make_uint4(0u, 0u, 0u, 0u);
+        qf[ks] = *reinterpret_cast<const bf16x8*>(&v);
+    }
+    const float qs = scale * LOG2E;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    float m = NEG_BIG, lsum = 0.f;
+    const int krow = pi_row(j);
+    // staging: chunk id = tid + i * NT30; ids 0..1023 are K (row = id >> 3, 16-byte chunk id & 7), 1024..2047 V
+    uint4 st[NF30];
+    auto fetch = [&](int kb0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NF30; ++i) {
+            const int id = tid + i * NT30, isv = id >= NC30, r = (id - isv * NC30) >> 3, c8 = (id & 7) * 8;
+            const bf16_t* src = isv ? Vb : Kb;
+            const int ld = isv ? ldv : ldk;
+            st[i] = id < 2 * NC30 ? *reinterpret_cast<const uint4*>(src + (long long)min(kb0 + r, Nk - 1) * ld + c8) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto stash = [&](int slot) __attribute__((always_inline)) {
+        bf16_t* base = smem30 + slot * (2 * KB30 * LDR);
+#pragma unroll
+        for (int i = 0; i < NF30; ++i) {
+            const int id = tid + i * NT30, isv = id >= NC30, r = (id - isv * NC30) >> 3, c8 = (id & 7) * 8;
+            const int pr = isv ? ((r & ~15) | ((r & 3) << 2) | ((r >> 2) & 3)) : r;
+            if (id < 2 * NC30) *reinterpret_cast<uint4*>(base + isv * (KB30 * LDR) + pr * LDR + c8) = st[i];
+        }
+    };
+    const int nt = (Nk + KB30 - 1) / KB30;
+    TSTAMP(0);
+    fetch(0);
+    stash(0);
+    if (nt > 1) fetch(KB30);
+    __syncthreads();
+    TSTAMP(1);
+    for (int t = 0; t < nt; ++t) {
+        const int kb0 = t * KB30;
+#if ATT_VAR != 34 && ATT_VAR != 35 && ATT_VAR != 38 && ATT_VAR != 39
+#ifndef STG_NOSTASH
+        if (t + 1 < nt) stash((t + 1) & 1);
+#endif
+#ifndef STG_NOFETCH
+        if (t + 2 < nt) fetch(kb0 + 2 * KB30);
+#endif
+        const bf16_t* Ks = smem30 + (t & 1) * (2 * KB30 * LDR);
+#else
+        const bf16_t* Ks = smem30;
+#endif
+        const bf16_t* Vs = Ks + KB30 * LDR;
+        auto qk = [&](int sub) __attribute__((always_inline)) {
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            const bf16_t* kp = Ks + (32 * sub + krow) * LDR + 8 * h;
+#pragma unroll
+#if ATT_VAR == 38
+            for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[(ks + sub) & 3], qf[ks], s, 0, 0, 0);
+#else
+            for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(kp + 16 * ks), qf[ks], s, 0, 0, 0);
+#endif
+            return s;
+        };
+        auto softmax_pv = [&](f32x16 s, int sub) __attribute__((always_inline)) {
+            const int kv0 = kb0 + 32 * sub;
+            if (kv0 + 32 > Nk) {                                // tail tile (wave-uniform)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) if (kv0 + 16 * h + r >= Nk) s[r] = NEG_BIG;
+            }
+#if ATT_VAR == 33 || ATT_VAR == 35 || ATT_VAR == 38 || ATT_VAR == 39
+            (void)qs;
+#else
+            float mx = s[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+            {
+                const unsigned u = __float_as_uint(mx);
+                const auto pr = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+                mx = fmaxf(__uint_as_float(pr[0]), __uint_as_float(pr[1])) * qs;
+            }
+            if (__any(mx > m + RESCALE_THR)) {                  // lazy rescale: rare once the running maximum has settled
+                const float mn = fmaxf(m, mx);
+                const float alpha = fast_exp2(m - mn);
+                lsum *= alpha;
+                m = mn;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc0[r] *= alpha; acc1[r] *= alpha; }
+            }
+            float rs = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = fast_exp2(fmaf(s[r], qs, -m)); rs += s[r]; }
+            lsum += rs;
+#endif
+            const int gi = lane & 15, gq = (lane >> 4) & 1;
+            const bf16_t* vp = Vs + (32 * sub + 16 * h + 4 * (gi >> 2)) * LDR + 16 * gq + 4 * (gi & 3);
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const bf16x8 pb = pack8(s, 8 * k2);
+#if ATT_VAR == 38 || ATT_VAR == 39
+                (void)vp;
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[k2], pb, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[2 + k2], pb, acc1, 0, 0, 0);
+#else
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag_tr(vp + (2 * k2) * LDR, vp + (2 * k2 + 1) * LDR), pb, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag_tr(vp + (2 * k2) * LDR + 32, vp + (2 * k2 + 1) * LDR + 32), pb, acc1, 0, 0, 0);
+#endif
+            }
+        };
+        const int nsub = min((KB30 + 31) / 32, (min(Nk, kb0 + KB30) - kb0 + 31) / 32);
+#if ATT_VAR == 30 || (ATT_VAR >= 33 && ATT_VAR <= 39)
+#pragma unroll 1
+        for (int sub = 0; sub < nsub; ++sub) {
+#ifdef ROTPRIO
+            // the three waves of a SIMD (wave, wave + 4, wave + 8) take turns at the top priority, so that none of them lags
+            const int pr = ((wave >> 2) + sub + t) % 3;
+            if (pr == 0) __builtin_amdgcn_s_setprio(ROTPRIO == 1 ? 2 : 0);
+            else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(ROTPRIO == 1 ? 0 : 2);
+#endif
+            softmax_pv(qk(sub), sub);
+        }
+#else
+        f32x16 sc = qk(0);
+#pragma unroll 1
+        for (int sub = 0; sub < nsub; ++sub) {
+            f32x16 sn = sc;
+            if (sub + 1 < nsub) sn = qk(sub + 1);
+            softmax_pv(sc, sub);
+            sc = sn;
+        }
+#endif
+        TSTAMP(2 + 2 * t);
+#if ATT_VAR != 34 && ATT_VAR != 35 && ATT_VAR != 38 && ATT_VAR != 39 && !defined(STG_NOBAR)
+        __syncthreads();
+#endif
+        TSTAMP(3 + 2 * t);
+    }
+    lsum += __shfl_xor(lsum, 32, 64);
+    if (ok) {
+        const float inv = 1.0f / lsum;
+        bf16_t* orow = O + qrow * ldo;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            st4<bf16_t>(orow + 8 * g + 4 * h, make_float4(acc0[4 * g] * inv, acc0[4 * g + 1] * inv, acc0[4 * g + 2] * inv, acc0[4 * g + 3] * inv));
+            st4<bf16_t>(orow + 32 + 8 * g + 4 * h, make_float4(acc1[4 * g] * inv, acc1[4 * g + 1] * inv, acc1[4 * g + 2] * inv, acc1[4 * g + 3] * inv));
+        }
+        if (h == 0) lse[qrow] = (m + log2f(lsum)) * LN2;
+    }
+    TSTAMP(20);
+}
+#ifdef TIMING
+} extern "C" int tc_dbg_read(long long* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_dbg), sizeof(long long) * 4 * NW30 * 24); } namespace {
+#endif
+
+#elif ATT_VAR >= 90 && ATT_VAR < 100
+// v30: ONE workgroup of NW30 = 12 waves (768 threads) per CU: 16 workgroups per image = 256 at B = 16.  The twelve 32-query wave tiles share
+// one K/V staging (a third of the L2 -> LDS traffic of the 4-wave workgroups); the 128-key K/V tiles are double-buffered in LDS (72 KB)
+// and fetched a whole tile ahead into 3 registers per thread, so a tile costs ONE barrier and no exposed load latency.
+// v31 = v30 + the QK^T MFMAs of the next 32-key sub-tile issued before the softmax of the current one (within a 128-key tile)
+// v32 = v31 + explicit MFMA / VALU interleave (sched_group_barrier)
+#ifndef NW30
+#define NW30 12
+#endif
+#ifndef KB30
+#define KB30 128
+#endif
+#ifdef TIMING
+__device__ long long g_dbg[4 * NW30 * 24];
+#define TSTAMP(k) do { if ((blockIdx.x & 63) == 5 && blockIdx.x < 256 && lane == 0) g_dbg[((blockIdx.x >> 6) * NW30 + wave) * 24 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define TSTAMP(k)
+#endif
+constexpr int NT30 = NW30 * 64, NC30 = KB30 * 8, NF30 = (2 * NC30 + NT30 - 1) / NT30;   // NC30 16-byte chunks per K (or V) tile
+__global__ __launch_bounds__(NT30, 1) void attn_fwd_seg_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
+                                                               const bf16_t* __restrict__ V, int ldv, long long skv, bf16_t* __restrict__ O,
+                                                               int ldo, float* __restrict__ lse, Segs sg, int Nk, float scale) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem30[];      // [2 slots][K tile | V tile][KB][LDR]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    TSTAMP(18);
+    const int nwt = sg.t32[sg.n], bpi = (nwt + NW30 - 1) / NW30;
+    const int b = blockIdx.x / bpi, wt = (blockIdx.x - b * bpi) * NW30 + wave;
+    int sgi = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) if (i < sg.n && wt >= sg.t32[i]) sgi = i;
+    const int nq = sg.nq[sgi];
+    const int ql = (wt - sg.t32[sgi]) * 32 + j;
+    const bool ok = wt < nwt && ql < nq;
+    const long long qrow = (long long)sg.row0[sgi] + (long long)b * nq + ql;
+    const bf16_t* Kb = K + b * skv;
+    const bf16_t* Vb = V + b * skv;
+    bf16x8 qf[4];
+#if ATT_VAR >= 91
+    // Q tile of the wave: four coalesced loads (eight lanes per 128-byte row) into a wave-private LDS tile, fragments read back from
+    // there -- a per-lane load of 16 bytes at a row stride touches 32 lines per instruction and queues in the address unit
+    bf16_t* wtile = smem30 + 2 * (2 * KB30 * LDR) + wave * (32 * LDR);
+    {
+        const int tq0 = (wt - sg.t32[sgi]) * 32;                  // first query of the tile within its segment-image
+        const long long trow0 = (long long)sg.row0[sgi] + (long long)b * nq + tq0;
+        uint4 qv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 8 * i + (lane >> 3);
+            qv[i] = (wt < nwt && tq0 + r < nq) ? *reinterpret_cast<const uint4*>(Q + (trow0 + r) * ldq + 8 * (lane & 7)) : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(wtile + (8 * i + (lane >> 3)) * LDR + 8 * (lane & 7)) = qv[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = ld_frag(wtile + j * LDR + 16 * ks + 8 * h);
+    }
+#else
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const uint4 v = ok ? *reinterpret_cast<const uint4*>(Q + qrow * ldq + 16 * ks + 8 * h) : make_uint4(0u, 0u, 0u, 0u);
+        qf[ks] = *reinterpret_cast<const bf16x8*>(&v);
+    }
+#endif
+    const float qs = scale * LOG2E;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    float m = NEG_BIG, lsum = 0.f;
+    const int krow = pi_row(j);
+    // staging: chunk id = tid + i * NT30; ids 0..1023 are K (row = id >> 3, 16-byte chunk id & 7), 1024..2047 V
+    uint4 st[NF30];
+    auto fetch = [&](int kb0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NF30; ++i) {
+            const int id = tid + i * NT30, isv = id >= NC30, r = (id - isv * NC30) >> 3, c8 = (id & 7) * 8;
+            const bf16_t* src = isv ? Vb : Kb;
+            const int ld = isv ? ldv : ldk;
+            st[i] = id < 2 * NC30 ? *reinterpret_cast<const uint4*>(src + (long long)min(kb0 + r, Nk - 1) * ld + c8) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto stash = [&](int slot) __attribute__((always_inline)) {
+        bf16_t* base = smem30 + slot * (2 * KB30 * LDR);
+#pragma unroll
+        for (int i = 0; i < NF30; ++i) {
+            const int id = tid + i * NT30, isv = id >= NC30, r = (id - isv * NC30) >> 3, c8 = (id & 7) * 8;
+            const int pr = isv ? ((r & ~15) | ((r & 3) << 2) | ((r >> 2) & 3)) : r;
+            if (id < 2 * NC30) *reinterpret_cast<uint4*>(base + isv * (KB30 * LDR) + pr * LDR + c8) = st[i];
+        }
+    };
+    const int nt = (Nk + KB30 - 1) / KB30;
+    TSTAMP(0);
+    fetch(0);
+    stash(0);
+    if (nt > 1) fetch(KB30);
+    __syncthreads();
+    TSTAMP(1);
+    for (int t = 0; t < nt; ++t) {
+        const int kb0 = t * KB30;
+#if ATT_VAR != 34 && ATT_VAR != 35 && ATT_VAR != 38 && ATT_VAR != 39
+#ifndef STG_NOSTASH
+        if (t + 1 < nt) stash((t + 1) & 1);
+#endif
+#ifndef STG_NOFETCH
+        if (t + 2 < nt) fetch(kb0 + 2 * KB30);
+#endif
+        const bf16_t* Ks = smem30 + (t & 1) * (2 * KB30 * LDR);
+#else
+        const bf16_t* Ks = smem30;
+#endif
+        const bf16_t* Vs = Ks + KB30 * LDR;
+        auto qk = [&](int sub) __attribute__((always_inline)) {
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            const bf16_t* kp = Ks + (32 * sub + krow) * LDR + 8 * h;
+#pragma unroll
+#if ATT_VAR == 38
+            for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[(ks + sub) & 3], qf[ks], s, 0, 0, 0);
+#else
+            for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(kp + 16 * ks), qf[ks], s, 0, 0, 0);
+#endif
+            return s;
+        };
+        auto softmax_pv = [&](f32x16 s, int sub) __attribute__((always_inline)) {
+            const int kv0 = kb0 + 32 * sub;
+            if (kv0 + 32 > Nk) {                                // tail tile (wave-uniform)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) if (kv0 + 16 * h + r >= Nk) s[r] = NEG_BIG;
+            }
+            // Softmax against a reference exponent m that is NOT the running row maximum: any m within fp32's exponent range of
+            // the true maximum gives the same quotient, so m is set once (integer-valued, from the first sub-tile) and raised only
+            // when a row sum shows that the scores have outgrown it by 2^30 -- one compare per sub-tile instead of a 16-element
+            // maximum, a lane swap and a compare.  Integer m: P differs from the max-referenced P by an exact power of two.
+            if (m == NEG_BIG) {                                 // first sub-tile of the row (wave-uniform: all rows start together)
+                float mx = s[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+                const unsigned u = __float_as_uint(mx);
+                const auto pr = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+                m = ceilf(fmaxf(__uint_as_float(pr[0]), __uint_as_float(pr[1])) * qs);
+            }
+            f32x16 pv;
+            float rs = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { pv[r] = fast_exp2(fmaf(s[r], qs, -m)); rs += pv[r]; }
+            if (__any(!(rs < 1073741824.0f))) {                 // rare: some row grew past 2^30 times its reference; re-reference all rows
+                float mx = s[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+                const unsigned u = __float_as_uint(mx);
+                const auto pr = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+                const float mn = fmaxf(m, ceilf(fmaxf(__uint_as_float(pr[0]), __uint_as_float(pr[1])) * qs));
+                const float alpha = fast_exp2(m - mn);
+                lsum *= alpha;
+                m = mn;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc0[r] *= alpha; acc1[r] *= alpha; }
+                rs = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { pv[r] = fast_exp2(fmaf(s[r], qs, -m)); rs += pv[r]; }
+            }
+            lsum += rs;
+            s = pv;
+            const int gi = lane & 15, gq = (lane >> 4) & 1;
+            const bf16_t* vp = Vs + (32 * sub + 16 * h + 4 * (gi >> 2)) * LDR + 16 * gq + 4 * (gi & 3);
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const bf16x8 pb = pack8(s, 8 * k2);
+#if ATT_VAR == 38 || ATT_VAR == 39
+                (void)vp;
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[k2], pb, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[2 + k2], pb, acc1, 0, 0, 0);
+#else
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag_tr(vp + (2 * k2) * LDR, vp + (2 * k2 + 1) * LDR), pb, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag_tr(vp + (2 * k2) * LDR + 32, vp + (2 * k2 + 1) * LDR + 32), pb, acc1, 0, 0, 0);
+#endif
+            }
+        };
+        const int nsub = min((KB30 + 31) / 32, (min(Nk, kb0 + KB30) - kb0 + 31) / 32);
+#if 1
+#pragma unroll 1
+        for (int sub = 0; sub < nsub; ++sub) {
+#ifdef ROTPRIO
+            // the three waves of a SIMD (wave, wave + 4, wave + 8) take turns at the top priority, so that none of them lags
+            const int pr = ((wave >> 2) + sub + t) % 3;
+            if (pr == 0) __builtin_amdgcn_s_setprio(ROTPRIO == 1 ? 2 : 0);
+            else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(ROTPRIO == 1 ? 0 : 2);
+#endif
+            softmax_pv(qk(sub), sub);
+        }
+#else
+        f32x16 sc = qk(0);
+#pragma unroll 1
+        for (int sub = 0; sub < nsub; ++sub) {
+            f32x16 sn = sc;
+            if (sub + 1 < nsub) sn = qk(sub + 1);
+            softmax_pv(sc, sub);
+            sc = sn;
+        }
+#endif
+        TSTAMP(2 + 2 * t);
+#if ATT_VAR != 34 && ATT_VAR != 35 && ATT_VAR != 38 && ATT_VAR != 39 && !defined(STG_NOBAR)
+        __syncthreads();
+#endif
+        TSTAMP(3 + 2 * t);
+    }
+    TSTAMP(19);
+    lsum += __shfl_xor(lsum, 32, 64);
+#if ATT_VAR >= 91
+    {   // O tile through the wave-private LDS tile: whole 128-byte rows leave with 16-byte stores
+        const float inv = 1.0f / lsum;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            st4<bf16_t>(wtile + j * LDR + 8 * g + 4 * h, make_float4(acc0[4 * g] * inv, acc0[4 * g + 1] * inv, acc0[4 * g + 2] * inv, acc0[4 * g + 3] * inv));
+            st4<bf16_t>(wtile + j * LDR + 32 + 8 * g + 4 * h, make_float4(acc1[4 * g] * inv, acc1[4 * g + 1] * inv, acc1[4 * g + 2] * inv, acc1[4 * g + 3] * inv));
+        }
+        if (ok && h == 0) lse[qrow] = (m + log2f(lsum)) * LN2;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int tq0 = (wt - sg.t32[sgi]) * 32;
+        const long long trow0 = (long long)sg.row0[sgi] + (long long)b * nq + tq0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 8 * i + (lane >> 3);
+            const uint4 v = *reinterpret_cast<const uint4*>(wtile + r * LDR + 8 * (lane & 7));
+            if (wt < nwt && tq0 + r < nq) *reinterpret_cast<uint4*>(O + (trow0 + r) * ldo + 8 * (lane & 7)) = v;
+        }
+    }
+#else
+    if (ok) {
+        const float inv = 1.0f / lsum;
+        bf16_t* orow = O + qrow * ldo;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            st4<bf16_t>(orow + 8 * g + 4 * h, make_float4(acc0[4 * g] * inv, acc0[4 * g + 1] * inv, acc0[4 * g + 2] * inv, acc0[4 * g + 3] * inv));
+            st4<bf16_t>(orow + 32 + 8 * g + 4 * h, make_float4(acc1[4 * g] * inv, acc1[4 * g + 1] * inv, acc1[4 * g + 2] * inv, acc1[4 * g + 3] * inv));
+        }
+        if (h == 0) lse[qrow] = (m + log2f(lsum)) * LN2;
+    }
+#endif
+    TSTAMP(20);
+}
+#ifdef TIMING
+} extern "C" int tc_dbg_read(long long* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_dbg), sizeof(long long) * 4 * NW30 * 24); } namespace {
+#endif
+
+#elif ATT_VAR >= 40 && ATT_VAR < 50
+// v40: v30's one 12-wave workgroup per CU, with the matrix work of a wave re-ordered so that no MFMA follows one it depends on:
+// the four chained QK^T MFMAs of sub-tile i+1 are interleaved one-for-one with the four PV MFMAs of sub-tile i (dependent MFMAs
+// issued back to back are paced by their latency and leave holes in the matrix pipe that no other wave can use).  K/V tiles in a
+// 3-slot LDS ring (108 KB), one barrier per 128-key tile; fragment reads issued before the softmax arithmetic that hides them.
+#ifndef NW30
+#define NW30 12
+#endif
+#define KB30 128
+constexpr int NT30 = NW30 * 64, NC30 = KB30 * 8, NF30 = (2 * NC30 + NT30 - 1) / NT30, SLOT30 = 2 * KB30 * LDR;
+__global__ __launch_bounds__(NT30, 1) void attn_fwd_seg_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
+                                                               const bf16_t* __restrict__ V, int ldv, long long skv, bf16_t* __restrict__ O,
+                                                               int ldo, float* __restrict__ lse, Segs sg, int Nk, float scale) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem30[];      // [3 slots][K tile | V tile][KB30][LDR]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    const int nwt = sg.t32[sg.n], bpi = (nwt + NW30 - 1) / NW30;
+    const int b = blockIdx.x / bpi, wt = (blockIdx.x - b * bpi) * NW30 + wave;
+    int sgi = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) if (i < sg.n && wt >= sg.t32[i]) sgi = i;
+    const int nq = sg.nq[sgi];
+    const int ql = (wt - sg.t32[sgi]) * 32 + j;
+    const bool ok = wt < nwt && ql < nq;
+    const long long qrow = (long long)sg.row0[sgi] + (long long)b * nq + ql;
+    const bf16_t* Kb = K + b * skv;
+    const bf16_t* Vb = V + b * skv;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const uint4 v = ok ? *reinterpret_cast<const uint4*>(Q + qrow * ldq + 16 * ks + 8 * h) : make_uint4(0u, 0u, 0u, 0u);
+        qf[ks] = *reinterpret_cast<const bf16x8*>(&v);
+    }
+    const float qs = scale * LOG2E;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    float m = NEG_BIG, lsum = 0.f;
+    uint4 st[NF30];
+    auto fetch = [&](int kb0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NF30; ++i) {
+            const int id = tid + i * NT30, isv = id >= NC30, r = (id - isv * NC30) >> 3, c8 = (id & 7) * 8;
+            const bf16_t* src = isv ? Vb : Kb;
+            const int ld = isv ? ldv : ldk;
+            st[i] = id < 2 * NC30 ? *reinterpret_cast<const uint4*>(src + (long long)min(kb0 + r, Nk - 1) * ld + c8) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto stash = [&](int slot) __attribute__((always_inline)) {
+        bf16_t* base = smem30 + slot * SLOT30;
+#pragma unroll
+        for (int i = 0; i < NF30; ++i) {
+            const int id = tid + i * NT30, isv = id >= NC30, r = (id - isv * NC30) >> 3, c8 = (id & 7) * 8;
+            const int pr = isv ? ((r & ~15) | ((r & 3) << 2) | ((r >> 2) & 3)) : r;
+            if (id < 2 * NC30) *reinterpret_cast<uint4*>(base + isv * (KB30 * LDR) + pr * LDR + c8) = st[i];
+        }
+    };
+    const int nt = (Nk + KB30 - 1) / KB30, nsubs = (Nk + 31) / 32;
+    const int koff = pi_row(j) * LDR + 8 * h;                                               // K fragment of this lane within a 32-key sub-tile
+    const int voff = (16 * h + 4 * ((lane & 15) >> 2)) * LDR + 16 * ((lane >> 4) & 1) + 4 * (lane & 3) + KB30 * LDR;   // V^T fragment
+    fetch(0);
+    stash(0);
+    if (nt > 1) fetch(KB30);
+    __syncthreads();
+    bf16x8 kf[4], vf[4];
+    f32x16 S;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) S[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(smem30 + koff + 16 * ks), qf[ks], S, 0, 0, 0);
+    int slot = 0, nslot = 1;                                    // ring slot of the current tile / of the next
+#pragma unroll 1
+    for (int i = 0; i < nsubs; ++i) {
+        const int t = i >> 2, sub = i & 3;
+        if (sub == 0) {
+            if (t + 1 < nt) stash(nslot);
+            if (t + 2 < nt) fetch((t + 2) * KB30);
+        }
+        const bf16_t* vp = smem30 + slot * SLOT30 + 32 * sub * LDR + voff;
+#if ATT_VAR == 40
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            vf[2 * k2] = ld_frag_tr(vp + (2 * k2) * LDR, vp + (2 * k2 + 1) * LDR);
+            vf[2 * k2 + 1] = ld_frag_tr(vp + (2 * k2) * LDR + 32, vp + (2 * k2 + 1) * LDR + 32);
+        }
+#endif
+        const bool has_next = i + 1 < nsubs;
+        if (sub == 3 && has_next) __syncthreads();              // the next tile (stored during this one) is complete
+        const bf16_t* kp = smem30 + (sub == 3 ? nslot : slot) * SLOT30 + 32 * ((sub + 1) & 3) * LDR + koff;
+#if ATT_VAR != 42
+        if (has_next) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) kf[ks] = ld_frag(kp + 16 * ks);
+        }
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        // online softmax of S (sub-tile i)
+        const int kv0 = 32 * i;
+        if (kv0 + 32 > Nk) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) if (kv0 + 16 * h + r >= Nk) S[r] = NEG_BIG;
+        }
+        float mx = S[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, S[r]);
+        {
+            const unsigned u = __float_as_uint(mx);
+            const auto pr = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            mx = fmaxf(__uint_as_float(pr[0]), __uint_as_float(pr[1])) * qs;
+        }
+        if (__any(mx > m + RESCALE_THR)) {
+            const float mn = fmaxf(m, mx);
+            const float alpha = fast_exp2(m - mn);
+            lsum *= alpha;
+            m = mn;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] *= alpha; acc1[r] *= alpha; }
+        }
+        float rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { S[r] = fast_exp2(fmaf(S[r], qs, -m)); rs += S[r]; }
+        lsum += rs;
+        const bf16x8 pb0 = pack8(S, 0), pb1 = pack8(S, 8);
+        __builtin_amdgcn_sched_barrier(0);
+#if ATT_VAR != 40
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            vf[2 * k2] = ld_frag_tr(vp + (2 * k2) * LDR, vp + (2 * k2 + 1) * LDR);
+            vf[2 * k2 + 1] = ld_frag_tr(vp + (2 * k2) * LDR + 32, vp + (2 * k2 + 1) * LDR + 32);
+        }
+#endif
+#if ATT_VAR == 42
+        if (has_next) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) kf[ks] = ld_frag(kp + 16 * ks);
+        }
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        if (has_next) {
+            f32x16 Sn;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Sn[r] = 0.f;
+            Sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0], Sn, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pb0, acc0, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            Sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[1], Sn, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pb0, acc1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            Sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2], qf[2], Sn, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[2], pb1, acc0, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            Sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[3], qf[3], Sn, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[3], pb1, acc1, 0, 0, 0);
+            S = Sn;
+        } else {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pb0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pb0, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[2], pb1, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[3], pb1, acc1, 0, 0, 0);
+        }
+        if (sub == 3) { slot = nslot; nslot = nslot == 2 ? 0 : nslot + 1; }
+    }
+    lsum += __shfl_xor(lsum, 32, 64);
+    if (ok) {
+        const float inv = 1.0f / lsum;
+        bf16_t* orow = O + qrow * ldo;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            st4<bf16_t>(orow + 8 * g + 4 * h, make_float4(acc0[4 * g] * inv, acc0[4 * g + 1] * inv, acc0[4 * g + 2] * inv, acc0[4 * g + 3] * inv));
+            st4<bf16_t>(orow + 32 + 8 * g + 4 * h, make_float4(acc1[4 * g] * inv, acc1[4 * g + 1] * inv, acc1[4 * g + 2] * inv, acc1[4 * g + 3] * inv));
+        }
+        if (h == 0) lse[qrow] = (m + log2f(lsum)) * LN2;
+    }
+}
+
+#elif ATT_VAR >= 60 && ATT_VAR < 70
+// v60: ONE wave per SIMD.  A workgroup = 4 waves, each wave owns NQ60 = 3 32-query tiles (96 queries) and the whole 512-register
+// file: the three tiles share every K / V^T fragment read (a third of the LDS read traffic), their independent MFMA and softmax
+// streams interleave inside the wave (no reliance on the arbitration between co-resident waves, which lets the youngest wave of a
+// SIMD lag and makes every barrier wait for it), and the four waves of the workgroup are symmetric, so barriers cost little.
+// Software pipeline: the QK^T MFMAs of key sub-tile i+1 are issued inside the exp / PV phase of sub-tile i.
+// 16 workgroups per image = 256 at B = 16.  K/V tiles of 128 keys in a 3-slot LDS ring, one barrier per tile.
+#ifndef NQ60
+#define NQ60 3
+#endif
+#define KB30 128
+constexpr int NT30 = 256, NC30 = KB30 * 8, NF30 = (2 * NC30 + NT30 - 1) / NT30, SLOT30 = 2 * KB30 * LDR;
+__global__ __launch_bounds__(256, 1) void attn_fwd_seg_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
+                                                              const bf16_t* __restrict__ V, int ldv, long long skv, bf16_t* __restrict__ O,
+                                                              int ldo, float* __restrict__ lse, Segs sg, int Nk, float scale) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem30[];      // [3 slots][K tile | V tile][KB30][LDR]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    const int nwt = sg.t32[sg.n], bpi = (nwt + 4 * NQ60 - 1) / (4 * NQ60);
+    const int b = blockIdx.x / bpi, wt0 = ((blockIdx.x - b * bpi) * 4 + wave) * NQ60;
+    const bf16_t* Kb = K + b * skv;
+    const bf16_t* Vb = V + b * skv;
+    bool ok[NQ60];
+    long long qrow[NQ60];
+    bf16x8 qf[NQ60][4];
+    f32x16 acc0[NQ60], acc1[NQ60], S[NQ60];
+    float m[NQ60], lsum[NQ60];
+#pragma unroll
+    for (int q = 0; q < NQ60; ++q) {
+        const int wt = wt0 + q;
+        int sgi = 0;
+#pragma unroll
+        for (int i = 1; i < 4; ++i) if (i < sg.n && wt >= sg.t32[i]) sgi = i;
+        const int nq = sg.nq[sgi];
+        const int ql = (wt - sg.t32[sgi]) * 32 + j;
+        ok[q] = wt < nwt && ql < nq;
+        qrow[q] = (long long)sg.row0[sgi] + (long long)b * nq + ql;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const uint4 v = ok[q] ? *reinterpret_cast<const uint4*>(Q + qrow[q] * ldq + 16 * ks + 8 * h) : make_uint4(0u, 0u, 0u, 0u);
+            qf[q][ks] = *reinterpret_cast<const bf16x8*>(&v);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[q][r] = 0.f; acc1[q][r] = 0.f; }
+        m[q] = NEG_BIG; lsum[q] = 0.f;
+    }
+    const float qs = scale * LOG2E;
+    uint4 st[NF30];
+    auto fetch = [&](int kb0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NF30; ++i) {
+            const int id = tid + i * NT30, isv = id >= NC30, r = (id - isv * NC30) >> 3, c8 = (id & 7) * 8;
+            const bf16_t* src = isv ? Vb : Kb;
+            const int ld = isv ? ldv : ldk;
+            st[i] = *reinterpret_cast<const uint4*>(src + (long long)min(kb0 + r, Nk - 1) * ld + c8);
+        }
+    };
+    auto stash = [&](int slot) __attribute__((always_inline)) {
+        bf16_t* base = smem30 + slot * SLOT30;
+#pragma unroll
+        for (int i = 0; i < NF30; ++i) {
+            const int id = tid + i * NT30, isv = id >= NC30, r = (id - isv * NC30) >> 3, c8 = (id & 7) * 8;
+            const int pr = isv ? ((r & ~15) | ((r & 3) << 2) | ((r >> 2) & 3)) : r;
+            *reinterpret_cast<uint4*>(base + isv * (KB30 * LDR) + pr * LDR + c8) = st[i];
+        }
+    };
+    const int nt = (Nk + KB30 - 1) / KB30, nsubs = (Nk + 31) / 32;
+    const int koff = pi_row(j) * LDR + 8 * h;
+    const int voff = (16 * h + 4 * ((lane & 15) >> 2)) * LDR + 16 * ((lane >> 4) & 1) + 4 * (lane & 3) + KB30 * LDR;
+    fetch(0);
+    stash(0);
+    if (nt > 1) fetch(KB30);
+    __syncthreads();
+    {
+        bf16x8 kf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) kf[ks] = ld_frag(smem30 + koff + 16 * ks);
+#pragma unroll
+        for (int q = 0; q < NQ60; ++q) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) S[q][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) S[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[q][ks], S[q], 0, 0, 0);
+        }
+    }
+    int slot = 0, nslot = 1;
+    // one key sub-tile: NEXT = the QK^T of sub-tile i + 1 is issued here
+    auto step = [&](int i, auto next_tag) __attribute__((always_inline)) {
+        constexpr bool NEXT = decltype(next_tag)::value;
+        const int t = i >> 2, sub = i & 3;
+        if (sub == 0) {
+            if (t + 1 < nt) stash(nslot);
+            if (t + 2 < nt) fetch((t + 2) * KB30);
+        }
+        if (sub == 3 && NEXT) __syncthreads();                  // the next tile (stored during this one) is complete
+        const int kv0 = 32 * i;
+        if (kv0 + 32 > Nk) {
+#pragma unroll
+            for (int q = 0; q < NQ60; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) if (kv0 + 16 * h + r >= Nk) S[q][r] = NEG_BIG;
+        }
+        float mx[NQ60];
+        bool grow = false;
+#pragma unroll
+        for (int q = 0; q < NQ60; ++q) {
+            float v = S[q][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) v = fmaxf(v, S[q][r]);
+            const unsigned u = __float_as_uint(v);
+            const auto pr = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            mx[q] = fmaxf(__uint_as_float(pr[0]), __uint_as_float(pr[1])) * qs;
+            grow |= mx[q] > m[q] + RESCALE_THR;
+        }
+        if (__any(grow)) {                                      // lazy rescale of all tiles of the wave: rare once the maxima have settled
+#pragma unroll
+            for (int q = 0; q < NQ60; ++q) {
+                const float mn = fmaxf(m[q], mx[q]);
+                const float alpha = fast_exp2(m[q] - mn);
+                lsum[q] *= alpha;
+                m[q] = mn;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc0[q][r] *= alpha; acc1[q][r] *= alpha; }
+            }
+        }
+        const bf16_t* vp = smem30 + slot * SLOT30 + 32 * sub * LDR + voff;
+        bf16x8 vf[4], kf[4];
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            vf[2 * k2] = ld_frag_tr(vp + (2 * k2) * LDR, vp + (2 * k2 + 1) * LDR);
+            vf[2 * k2 + 1] = ld_frag_tr(vp + (2 * k2) * LDR + 32, vp + (2 * k2 + 1) * LDR + 32);
+        }
+        if (NEXT) {
+            const bf16_t* kp = smem30 + (sub == 3 ? nslot : slot) * SLOT30 + 32 * ((sub + 1) & 3) * LDR + koff;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) kf[ks] = ld_frag(kp + 16 * ks);
+        }
+#pragma unroll
+        for (int q = 0; q < NQ60; ++q) {
+            float rs = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { S[q][r] = fast_exp2(fmaf(S[q][r], qs, -m[q])); rs += S[q][r]; }
+            lsum[q] += rs;
+            const bf16x8 pb0 = pack8(S[q], 0), pb1 = pack8(S[q], 8);
+            acc0[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pb0, acc0[q], 0, 0, 0);
+            acc1[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pb0, acc1[q], 0, 0, 0);
+            acc0[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[2], pb1, acc0[q], 0, 0, 0);
+            acc1[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[3], pb1, acc1[q], 0, 0, 0);
+            if (NEXT) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) S[q][r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) S[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[q][ks], S[q], 0, 0, 0);
+            }
+        }
+        if (sub == 3) { slot = nslot; nslot = nslot == 2 ? 0 : nslot + 1; }
+    };
+#pragma unroll 1
+    for (int i = 0; i + 1 < nsubs; ++i) step(i, std::true_type{});
+    step(nsubs - 1, std::false_type{});
+#pragma unroll
+    for (int q = 0; q < NQ60; ++q) {
+        const float ls = lsum[q] + __shfl_xor(lsum[q], 32, 64);
+        if (ok[q]) {
+            const float inv = 1.0f / ls;
+            bf16_t* orow = O + qrow[q] * ldo;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                st4<bf16_t>(orow + 8 * g + 4 * h, make_float4(acc0[q][4 * g] * inv, acc0[q][4 * g + 1] * inv, acc0[q][4 * g + 2] * inv, acc0[q][4 * g + 3] * inv));
+                st4<bf16_t>(orow + 32 + 8 * g + 4 * h, make_float4(acc1[q][4 * g] * inv, acc1[q][4 * g + 1] * inv, acc1[q][4 * g + 2] * inv, acc1[q][4 * g + 3] * inv));
+            }
+            if (h == 0) lse[qrow[q]] = (m[q] + log2f(ls)) * LN2;
+        }
+    }
+}
+
+#elif ATT_VAR >= 70 && ATT_VAR < 80
+// v70: v30's 12-wave workgroup per CU with the matrix and softmax work interleaved INSIDE each wave.  Measured on gfx950
+// (scripts/exp/overlap.hip): MFMAs of one wave and VALU work of another wave on the same SIMD do not overlap (time = sum), while
+// independent VALU instructions placed behind an MFMA in the SAME wave run under it (time = max).  So each loop iteration carries,
+// in program order, the max / exp / sum / pack arithmetic of key sub-tile i interleaved with eight MFMAs that do not depend on it:
+// PV of sub-tile i-1 and QK^T of sub-tile i+1.  3-slot LDS ring of 128-key K/V tiles, one barrier per tile.
+#ifndef NW30
+#define NW30 12
+#endif
+#define KB30 128
+constexpr int NT30 = NW30 * 64, NC30 = KB30 * 8, NF30 = (2 * NC30 + NT30 - 1) / NT30, SLOT30 = 2 * KB30 * LDR;
+__global__ __launch_bounds__(NT30, 1) void attn_fwd_seg_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
+                                                               const bf16_t* __restrict__ V, int ldv, long long skv, bf16_t* __restrict__ O,
+                                                               int ldo, float* __restrict__ lse, Segs sg, int Nk, float scale) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem30[];      // [3 slots][K tile | V tile][KB30][LDR]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    const int nwt = sg.t32[sg.n], bpi = (nwt + NW30 - 1) / NW30;
+    const int b = blockIdx.x / bpi, wt = (blockIdx.x - b * bpi) * NW30 + wave;
+    int sgi = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) if (i < sg.n && wt >= sg.t32[i]) sgi = i;
+    const int nq = sg.nq[sgi];
+    const int ql = (wt - sg.t32[sgi]) * 32 + j;
+    const bool ok = wt < nwt && ql < nq;
+    const long long qrow = (long long)sg.row0[sgi] + (long long)b * nq + ql;
+    const bf16_t* Kb = K + b * skv;
+    const bf16_t* Vb = V + b * skv;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const uint4 v = ok ? *reinterpret_cast<const uint4*>(Q + qrow * ldq + 16 * ks + 8 * h) : make_uint4(0u, 0u, 0u, 0u);
+        qf[ks] = *reinterpret_cast<const bf16x8*>(&v);
+    }
+    const float qs = scale * LOG2E;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    float m = NEG_BIG, lsum = 0.f;
+    uint4 st[NF30];
+    auto fetch = [&](int kb0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NF30; ++i) {
+            const int id = tid + i * NT30, isv = id >= NC30, r = (id - isv * NC30) >> 3, c8 = (id & 7) * 8;
+            const bf16_t* src = isv ? Vb : Kb;
+            const int ld = isv ? ldv : ldk;
+            st[i] = id < 2 * NC30 ? *reinterpret_cast<const uint4*>(src + (long long)min(kb0 + r, Nk - 1) * ld + c8) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto stash = [&](int slot) __attribute__((always_inline)) {
+        bf16_t* base = smem30 + slot * SLOT30;
+#pragma unroll
+        for (int i = 0; i < NF30; ++i) {
+            const int id = tid + i * NT30, isv = id >= NC30, r = (id - isv * NC30) >> 3, c8 = (id & 7) * 8;
+            const int pr = isv ? ((r & ~15) | ((r & 3) << 2) | ((r >> 2) & 3)) : r;
+            if (id < 2 * NC30) *reinterpret_cast<uint4*>(base + isv * (KB30 * LDR) + pr * LDR + c8) = st[i];
+        }
+    };
+    const int nt = (Nk + KB30 - 1) / KB30, nsubs = (Nk + 31) / 32;
+    const int koff = pi_row(j) * LDR + 8 * h;
+    const int voff = (16 * h + 4 * ((lane & 15) >> 2)) * LDR + 16 * ((lane >> 4) & 1) + 4 * (lane & 3) + KB30 * LDR;
+    fetch(0);
+    stash(0);
+    if (nt > 1) fetch(KB30);
+    __syncthreads();
+    bf16x8 vf[4], pb0, pb1;                                     // V^T fragments and packed P of the PREVIOUS sub-tile
+    f32x16 SA, SB;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { pb0[i] = (__bf16)0.f; pb1[i] = (__bf16)0.f; }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) SA[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) SA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(smem30 + koff + 16 * ks), qf[ks], SA, 0, 0, 0);
+    {
+        const bf16_t* vp = smem30 + voff;
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            vf[2 * k2] = ld_frag_tr(vp + (2 * k2) * LDR, vp + (2 * k2 + 1) * LDR);
+            vf[2 * k2 + 1] = ld_frag_tr(vp + (2 * k2) * LDR + 32, vp + (2 * k2 + 1) * LDR + 32);
+        }
+    }
+    int slot = 0, nslot = 1;
+    // iteration i: S = scores of sub-tile i (finished), Sn <- scores of sub-tile i + 1, acc += P(i-1) V(i-1)
+    auto step = [&](f32x16& S, f32x16& Sn, int i, auto last_tag) __attribute__((always_inline)) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        const int t = i >> 2, sub = i & 3;
+        if (sub == 0) {
+            if (t + 1 < nt) stash(nslot);
+            if (t + 2 < nt) fetch((t + 2) * KB30);
+        }
+        if (sub == 3 && !LAST) __syncthreads();                 // the next tile (stored during this one) is complete
+        bf16x8 kf[4];
+        if (!LAST) {
+            const bf16_t* kp = smem30 + (sub == 3 ? nslot : slot) * SLOT30 + 32 * ((sub + 1) & 3) * LDR + koff;
+#pragma unroll
+#if ATT_VAR >= 72
+            for (int ks = 0; ks < 4; ++ks) kf[ks] = *(const volatile bf16x8 __attribute__((address_space(3)))*)(kp + 16 * ks);   // volatile: not sunk behind the branch
+#else
+            for (int ks = 0; ks < 4; ++ks) kf[ks] = ld_frag(kp + 16 * ks);
+#endif
+        }
+        if (LAST) {
+            const int kv0 = 32 * i;
+            if (kv0 + 32 > Nk) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) if (kv0 + 16 * h + r >= Nk) S[r] = NEG_BIG;
+            }
+        }
+        // ---- phase 1: row maxima of S, under the PV MFMAs of the previous sub-tile
+#if ATT_VAR >= 74
+#define FENCE() __builtin_amdgcn_sched_barrier(0)
+        float mx, mxb;
+        FENCE();
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pb0, acc0, 0, 0, 0);
+        FENCE();
+        mx = fmaxf(fmaxf(S[0], S[1]), S[2]); mx = fmaxf(fmaxf(mx, S[3]), S[4]);
+        FENCE();
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pb0, acc1, 0, 0, 0);
+        FENCE();
+        mxb = fmaxf(fmaxf(S[5], S[6]), S[7]); mxb = fmaxf(fmaxf(mxb, S[8]), S[9]); mx = fmaxf(mx, mxb);
+        FENCE();
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[2], pb1, acc0, 0, 0, 0);
+        FENCE();
+        mxb = fmaxf(fmaxf(S[10], S[11]), S[12]); mxb = fmaxf(fmaxf(mxb, S[13]), S[14]); mx = fmaxf(fmaxf(mx, mxb), S[15]);
+        FENCE();
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[3], pb1, acc1, 0, 0, 0);
+        FENCE();
+        {
+            const unsigned u = __float_as_uint(mx);
+            const auto pr = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            mx = fmaxf(__uint_as_float(pr[0]), __uint_as_float(pr[1])) * qs;
+        }
+#else
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pb0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pb0, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[2], pb1, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[3], pb1, acc1, 0, 0, 0);
+        float mx = S[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, S[r]);
+        {
+            const unsigned u = __float_as_uint(mx);
+            const auto pr = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            mx = fmaxf(__uint_as_float(pr[0]), __uint_as_float(pr[1])) * qs;
+        }
+#endif
+#if ATT_VAR == 71 || ATT_VAR == 73
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x2, 5, 0);
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x2, 5, 0);
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x2, 5, 0);
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+#endif
+        if (__any(mx > m + RESCALE_THR)) {                      // lazy rescale: rare once the running maximum has settled
+            const float mn = fmaxf(m, mx);
+            const float alpha = fast_exp2(m - mn);
+            lsum *= alpha;
+            m = mn;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] *= alpha; acc1[r] *= alpha; }
+        }
+        // ---- phase 2: exp / row sum / pack of S, under the QK^T MFMAs of the next sub-tile; V^T fragments of this sub-tile
+        const bf16_t* vp = smem30 + slot * SLOT30 + 32 * sub * LDR + voff;
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            vf[2 * k2] = ld_frag_tr(vp + (2 * k2) * LDR, vp + (2 * k2 + 1) * LDR);
+            vf[2 * k2 + 1] = ld_frag_tr(vp + (2 * k2) * LDR + 32, vp + (2 * k2 + 1) * LDR + 32);
+        }
+#if ATT_VAR >= 74
+        float rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Sn[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            FENCE();
+            if (!LAST) Sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], Sn, 0, 0, 0);
+            FENCE();
+#pragma unroll
+            for (int r = 4 * ks; r < 4 * ks + 4; ++r) { S[r] = fast_exp2(fmaf(S[r], qs, -m)); rs += S[r]; }
+            if (ks == 1) pb0 = pack8(S, 0);
+            if (ks == 3) pb1 = pack8(S, 8);
+        }
+        FENCE();
+        lsum += rs;
+#else
+        if (!LAST) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Sn[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) Sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], Sn, 0, 0, 0);
+        }
+        float rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { S[r] = fast_exp2(fmaf(S[r], qs, -m)); rs += S[r]; }
+        lsum += rs;
+        pb0 = pack8(S, 0);
+        pb1 = pack8(S, 8);
+#endif
+#if ATT_VAR == 71 || ATT_VAR == 73
+        if (!LAST) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x2, 14, 0);
+            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x2, 14, 0);
+            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x2, 14, 0);
+            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+        }
+#endif
+        if (sub == 3) { slot = nslot; nslot = nslot == 2 ? 0 : nslot + 1; }
+    };
+    int i = 0;
+#pragma unroll 1
+    for (; i + 2 < nsubs; i += 2) { step(SA, SB, i, std::false_type{}); step(SB, SA, i + 1, std::false_type{}); }
+    if (i + 2 == nsubs) { step(SA, SB, i, std::false_type{}); step(SB, SA, i + 1, std::true_type{}); }
+    else step(SA, SB, i, std::true_type{});
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pb0, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pb0, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[2], pb1, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[3], pb1, acc1, 0, 0, 0);
+    lsum += __shfl_xor(lsum, 32, 64);
+    if (ok) {
+        const float inv = 1.0f / lsum;
+        bf16_t* orow = O + qrow * ldo;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            st4<bf16_t>(orow + 8 * g + 4 * h, make_float4(acc0[4 * g] * inv, acc0[4 * g + 1] * inv, acc0[4 * g + 2] * inv, acc0[4 * g + 3] * inv));
+            st4<bf16_t>(orow + 32 + 8 * g + 4 * h, make_float4(acc1[4 * g] * inv, acc1[4 * g + 1] * inv, acc1[4 * g + 2] * inv, acc1[4 * g + 3] * inv));
+        }
+        if (h == 0) lse[qrow] = (m + log2f(lsum)) * LN2;
+    }
+}
+
+#elif ATT_VAR >= 80 && ATT_VAR < 90
+// v80: ONE wave per SIMD, three 32-query tiles per wave (as v60), with the register files and the instruction order under control:
+//   * measured on gfx950 (scripts/exp/overlap.hip): an MFMA that finds the matrix pipe busy holds the SIMD's VALU issue, so MFMAs and
+//     VALU work of DIFFERENT waves on one SIMD add up, while independent VALU instructions issued behind an MFMA by the SAME wave run
+//     under it.  Hence one wave per SIMD and >= 32 cycles of softmax arithmetic behind every MFMA, in program order (sched_barrier fences).
+//   * MFMAs are inline asm so that the O accumulators (96 registers) and the Q fragments (48) live in AGPRs and the score tiles in
+//     arch VGPRs (hipcc put every MFMA result in AGPRs and copied 140 registers per iteration, v60).  Hazards of asm MFMAs are not
+//     tracked by the compiler: results are first read >= one loop phase later, behind explicit s_nops.
+//   Per key sub-tile: max of 3 tiles under 8 QK^T MFMAs of the next sub-tile; exp/sum/pack of tile q under the remaining QK^T and
+//   the PV MFMAs of tile q-1.  3-slot LDS ring of 128-key K/V tiles, one barrier per tile, 16 workgroups per image.
+#define NQ60 3
+#define KB30 128
+constexpr int NT30 = 256, NC30 = KB30 * 8, NF30 = (2 * NC30 + NT30 - 1) / NT30, SLOT30 = 2 * KB30 * LDR;
+#define FENCE() __builtin_amdgcn_sched_barrier(0)
+__device__ __forceinline__ void mfma_acc(f32x16& c, const bf16x8& a, const bf16x8& b) {        // c (AGPR) += a b
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_s0(f32x16& c, const bf16x8& a, const bf16x8& b) {         // c (VGPR) = a b, b in AGPR
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "a"(b));
+}
+__device__ __forceinline__ void mfma_s(f32x16& c, const bf16x8& a, const bf16x8& b) {          // c (VGPR) += a b, b in AGPR
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b));
+}
+__global__ __launch_bounds__(256, 1) void attn_fwd_seg_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
+                                                              const bf16_t* __restrict__ V, int ldv, long long skv, bf16_t* __restrict__ O,
+                                                              int ldo, float* __restrict__ lse, Segs sg, int Nk, float scale) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem30[];      // [3 slots][K tile | V tile][KB30][LDR]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    const int nwt = sg.t32[sg.n], bpi = (nwt + 4 * NQ60 - 1) / (4 * NQ60);
+    const int b = blockIdx.x / bpi, wt0 = ((blockIdx.x - b * bpi) * 4 + wave) * NQ60;
+    const bf16_t* Kb = K + b * skv;
+    const bf16_t* Vb = V + b * skv;
+    bool ok[NQ60];
+    long long qrow[NQ60];
+    bf16x8 qf[NQ60][4];
+    f32x16 acc0[NQ60], acc1[NQ60], SA[NQ60], SB[NQ60];
+    float m[NQ60], lsum[NQ60];
+#pragma unroll
+    for (int q = 0; q < NQ60; ++q) {
+        const int wt = wt0 + q;
+        int sgi = 0;
+#pragma unroll
+        for (int i = 1; i < 4; ++i) if (i < sg.n && wt >= sg.t32[i]) sgi = i;
+        const int nq = sg.nq[sgi];
+        const int ql = (wt - sg.t32[sgi]) * 32 + j;
+        ok[q] = wt < nwt && ql < nq;
+        qrow[q] = (long long)sg.row0[sgi] + (long long)b * nq + ql;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const uint4 v = ok[q] ? *reinterpret_cast<const uint4*>(Q + qrow[q] * ldq + 16 * ks + 8 * h) : make_uint4(0u, 0u, 0u, 0u);
+            qf[q][ks] = *reinterpret_cast<const bf16x8*>(&v);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[q][r] = 0.f; acc1[q][r] = 0.f; }
+        m[q] = NEG_BIG; lsum[q] = 0.f;
+    }
+    const float qs = scale * LOG2E;
+    uint4 st[NF30];
+    auto fetch = [&](int kb0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NF30; ++i) {
+            const int id = tid + i * NT30, isv = id >= NC30, r = (id - isv * NC30) >> 3, c8 = (id & 7) * 8;
+            const bf16_t* src = isv ? Vb : Kb;
+            const int ld = isv ? ldv : ldk;
+            st[i] = *reinterpret_cast<const uint4*>(src + (long long)min(kb0 + r, Nk - 1) * ld + c8);
+        }
+    };
+    auto stash = [&](int slot) __attribute__((always_inline)) {
+        bf16_t* base = smem30 + slot * SLOT30;
+#pragma unroll
+        for (int i = 0; i < NF30; ++i) {
+            const int id = tid + i * NT30, isv = id >= NC30, r = (id - isv * NC30) >> 3, c8 = (id & 7) * 8;
+            const int pr = isv ? ((r & ~15) | ((r & 3) << 2) | ((r >> 2) & 3)) : r;
+            *reinterpret_cast<uint4*>(base + isv * (KB30 * LDR) + pr * LDR + c8) = st[i];
+        }
+    };
+    const int nt = (Nk + KB30 - 1) / KB30, nsubs = (Nk + 31) / 32;
+    const int koff = pi_row(j) * LDR + 8 * h;
+    const int voff = (16 * h + 4 * ((lane & 15) >> 2)) * LDR + 16 * ((lane >> 4) & 1) + 4 * (lane & 3) + KB30 * LDR;
+    // fragment loads of key sub-tile i (tile i >> 2, ring slot (i >> 2) % 3)
+    auto kaddr = [&](int i) __attribute__((always_inline)) { return smem30 + ((i >> 2) % 3) * SLOT30 + 32 * (i & 3) * LDR + koff; };
+    auto vaddr = [&](int i) __attribute__((always_inline)) { return smem30 + ((i >> 2) % 3) * SLOT30 + 32 * (i & 3) * LDR + voff; };
+    bf16x8 kf[4], vf[4];
+    auto load_k = [&](int i) __attribute__((always_inline)) {
+        const bf16_t* kp = kaddr(i);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) kf[ks] = ld_frag(kp + 16 * ks);
+    };
+    auto load_v = [&](int i) __attribute__((always_inline)) {
+        const bf16_t* vp = vaddr(i);
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            vf[2 * k2] = ld_frag_tr(vp + (2 * k2) * LDR, vp + (2 * k2 + 1) * LDR);
+            vf[2 * k2 + 1] = ld_frag_tr(vp + (2 * k2) * LDR + 32, vp + (2 * k2 + 1) * LDR + 32);
+        }
+    };
+    fetch(0);
+    stash(0);
+    if (nt > 1) fetch(KB30);
+    __syncthreads();
+    load_k(0);
+#pragma unroll
+    for (int q = 0; q < NQ60; ++q) {
+        mfma_s0(SA[q], kf[0], qf[q][0]);
+#pragma unroll
+        for (int ks = 1; ks < 4; ++ks) mfma_s(SA[q], kf[ks], qf[q][ks]);
+    }
+    if (nsubs > 1) load_k(1);                                   // (sub-tile 1 is in tile 0)
+    // one key sub-tile.  S: finished scores of sub-tile i; Sn: receives the scores of sub-tile i + 1 (kf holds its K fragments)
+    auto step = [&](f32x16 (&S)[NQ60], f32x16 (&Sn)[NQ60], int i, auto last_tag) __attribute__((always_inline)) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        const int t = i >> 2, sub = i & 3;
+        if (sub == 0) {
+            if (t + 1 < nt) stash((t + 1) % 3);
+            if (t + 2 < nt) fetch((t + 2) * KB30);
+        }
+        if (sub == 2 && i + 2 < nsubs) __syncthreads();         // tile t + 1 (stored at sub 0) is complete before its first K fragments are read below
+        load_v(i);
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");        // asm-MFMA results (S) are read by VALU below
+        if (LAST) {
+            const int kv0 = 32 * i;
+            if (kv0 + 32 > Nk) {
+#pragma unroll
+                for (int q = 0; q < NQ60; ++q)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) if (kv0 + 16 * h + r >= Nk) S[q][r] = NEG_BIG;
+            }
+        }
+        // ---- phase M: row maxima of the three tiles, under the QK^T MFMAs (next sub-tile) of tiles 0 and 1
+        float mx[NQ60];
+        bool grow = false;
+#pragma unroll
+        for (int q = 0; q < NQ60; ++q) {
+            float v = S[q][0], w;
+            FENCE();
+            if (!LAST && q < 2) mfma_s0(Sn[q], kf[0], qf[q][0]);
+            FENCE();
+            v = fmaxf(fmaxf(v, S[q][1]), S[q][2]); v = fmaxf(fmaxf(v, S[q][3]), S[q][4]);
+            FENCE();
+            if (!LAST && q < 2) mfma_s(Sn[q], kf[1], qf[q][1]);
+            FENCE();
+            w = fmaxf(fmaxf(S[q][5], S[q][6]), S[q][7]); w = fmaxf(fmaxf(w, S[q][8]), S[q][9]); v = fmaxf(v, w);
+            FENCE();
+            if (!LAST && q < 2) mfma_s(Sn[q], kf[2], qf[q][2]);
+            FENCE();
+            w = fmaxf(fmaxf(S[q][10], S[q][11]), S[q][12]); w = fmaxf(fmaxf(w, S[q][13]), S[q][14]); v = fmaxf(fmaxf(v, w), S[q][15]);
+            FENCE();
+            if (!LAST && q < 2) mfma_s(Sn[q], kf[3], qf[q][3]);
+            FENCE();
+            const unsigned u = __float_as_uint(v);
+            const auto pr = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            mx[q] = fmaxf(__uint_as_float(pr[0]), __uint_as_float(pr[1])) * qs;
+            grow |= mx[q] > m[q] + RESCALE_THR;
+        }
+        if (__any(grow)) {                                      // lazy rescale of all tiles of the wave: rare once the maxima have settled
+            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");
+#pragma unroll
+            for (int q = 0; q < NQ60; ++q) {
+                const float mn = fmaxf(m[q], mx[q]);
+                const float alpha = fast_exp2(m[q] - mn);
+                lsum[q] *= alpha;
+                m[q] = mn;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc0[q][r] *= alpha; acc1[q][r] *= alpha; }
+            }
+        }
+        // ---- phase E: exp / row sum / pack of tile q under 4 MFMAs: QK^T (next) of tile 2 for q = 0, PV of tile q - 1 otherwise
+        bf16x8 pb0, pb1, pp0, pp1;
+#pragma unroll
+        for (int q = 0; q < NQ60; ++q) {
+            float rs = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                FENCE();
+                if (q == 0) {
+                    if (!LAST) { if (g == 0) mfma_s0(Sn[2], kf[0], qf[2][0]); else mfma_s(Sn[2], kf[g], qf[2][g]); }
+                } else {
+                    if (g & 1) mfma_acc(acc1[q - 1], vf[g], g < 2 ? pp0 : pp1); else mfma_acc(acc0[q - 1], vf[g], g < 2 ? pp0 : pp1);
+                }
+                FENCE();
+#pragma unroll
+                for (int r = 4 * g; r < 4 * g + 4; ++r) { S[q][r] = fast_exp2(fmaf(S[q][r], qs, -m[q])); rs += S[q][r]; }
+                if (g == 1) pb0 = pack8(S[q], 0);
+                if (g == 3) pb1 = pack8(S[q], 8);
+            }
+            FENCE();
+            lsum[q] += rs;
+            pp0 = pb0; pp1 = pb1;
+        }
+        // PV of the last tile; the K fragments of sub-tile i + 2 are fetched under it
+        FENCE();
+        asm volatile("s_nop 1" ::: "memory");
+        mfma_acc(acc0[NQ60 - 1], vf[0], pp0);
+        mfma_acc(acc1[NQ60 - 1], vf[1], pp0);
+        if (i + 2 < nsubs) load_k(i + 2);
+        mfma_acc(acc0[NQ60 - 1], vf[2], pp1);
+        mfma_acc(acc1[NQ60 - 1], vf[3], pp1);
+        FENCE();
+    };
+    int i = 0;
+#pragma unroll 1
+    for (; i + 2 < nsubs; i += 2) { step(SA, SB, i, std::false_type{}); step(SB, SA, i + 1, std::false_type{}); }
+    if (i + 2 == nsubs) { step(SA, SB, i, std::false_type{}); step(SB, SA, i + 1, std::true_type{}); }
+    else step(SA, SB, i, std::true_type{});
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < NQ60; ++q) {
+        const float ls = lsum[q] + __shfl_xor(lsum[q], 32, 64);
+        if (ok[q]) {
+            const float inv = 1.0f / ls;
+            bf16_t* orow = O + qrow[q] * ldo;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                st4<bf16_t>(orow + 8 * g + 4 * h, make_float4(acc0[q][4 * g] * inv, acc0[q][4 * g + 1] * inv, acc0[q][4 * g + 2] * inv, acc0[q][4 * g + 3] * inv));
+                st4<bf16_t>(orow + 32 + 8 * g + 4 * h, make_float4(acc1[q][4 * g] * inv, acc1[q][4 * g + 1] * inv, acc1[q][4 * g + 2] * inv, acc1[q][4 * g + 3] * inv));
+            }
+            if (h == 0) lse[qrow[q]] = (m[q] + log2f(ls)) * LN2;
+        }
     }
 }
 
@@ -2465,7 +3716,27 @@ extern "C" int tc_attn_fwd_seg(const void* Q, int ldq, const void* K, int ldk, c
         return TC_OK;
     }
     if (dtype != TC_BF16 || ((ldq | ldk | ldv) & 7) || (skv & 7) || (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) || (ldo & 3)) return TC_ERR_ARG;
-#if ATT_VAR == 11 || ATT_VAR == 12
+#if (ATT_VAR >= 60 && ATT_VAR < 70) || (ATT_VAR >= 80 && ATT_VAR < 90)
+    {
+        const size_t smem = (size_t)3 * SLOT30 * sizeof(bf16_t);
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_seg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; }
+        const unsigned g60 = (unsigned)B * ((sg.t32[nseg] + 4 * NQ60 - 1) / (4 * NQ60));
+        hipLaunchKernelGGL(attn_fwd_seg_kernel, dim3(g60), dim3(256), smem, (hipStream_t)stream, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk,
+                           (const bf16_t*)V, ldv, skv, (bf16_t*)O, ldo, lse, sg, Nk, scale);
+        return tc_launch_status();
+    }
+#elif (ATT_VAR >= 30 && ATT_VAR < 50) || (ATT_VAR >= 70 && ATT_VAR < 80) || (ATT_VAR >= 90 && ATT_VAR < 100)
+    {
+        const size_t smem = ((size_t)((ATT_VAR >= 40 && ATT_VAR < 90) ? 3 : 2) * 2 * KB30 * LDR + (ATT_VAR >= 91 ? NW30 * 32 * LDR : 0)) * sizeof(bf16_t);
+        static bool attr = false;
+        if (!attr) { hipFuncSetAttribute((const void*)attn_fwd_seg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; }
+        const unsigned g30 = (unsigned)B * ((sg.t32[nseg] + NW30 - 1) / NW30);
+        hipLaunchKernelGGL(attn_fwd_seg_kernel, dim3(g30), dim3(NT30), smem, (hipStream_t)stream, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk,
+                           (const bf16_t*)V, ldv, skv, (bf16_t*)O, ldo, lse, sg, Nk, scale);
+        return tc_launch_status();
+    }
+#elif ATT_VAR == 11 || ATT_VAR == 12
     hipLaunchKernelGGL(attn_fwd_seg_kernel, dim3(sg.tile0[nseg]), dim3(128), 0, (hipStream_t)stream, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk,
                        (const bf16_t*)V, ldv, skv, (bf16_t*)O, ldo, lse, sg, Nk, scale);
     return tc_launch_status();
@@ -2479,7 +3750,7 @@ extern "C" int tc_attn_fwd_seg(const void* Q, int ldq, const void* K, int ldk, c
 #else
     const unsigned fwd_grid = sg.tile0[nseg];
 #endif
-#if ATT_VAR != 10 && ATT_VAR != 11 && ATT_VAR != 12
+#if ATT_VAR != 10 && ATT_VAR != 11 && ATT_VAR != 12 && !(ATT_VAR >= 30 && ATT_VAR < 100)
     hipLaunchKernelGGL(attn_fwd_seg_kernel, dim3(fwd_grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk,
                        (const bf16_t*)V, ldv, skv, (bf16_t*)O, ldo, lse, sg, Nk, scale);
     return tc_launch_status();

@@ -414,6 +414,35 @@ template <> __device__ __forceinline__ uint4 pack16v<f16_t>(const tc_f32x2* o) {
     return make_uint4(pack2h(o[0].x, o[0].y), pack2h(o[1].x, o[1].y), pack2h(o[2].x, o[2].y), pack2h(o[3].x, o[3].y));
 }
 
+// SV consecutive channels (a whole 16-byte vector or half of one) from LDS / to global memory, as packed pairs
+template <typename T, int SV> __device__ __forceinline__ void unpack_sv(const void* p, tc_f32x2* o);
+template <> __device__ __forceinline__ void unpack_sv<float, 4>(const void* p, tc_f32x2* o) { unpack16v<float>(*reinterpret_cast<const uint4*>(p), o); }
+template <> __device__ __forceinline__ void unpack_sv<float, 2>(const void* p, tc_f32x2* o) { const float2 v = *reinterpret_cast<const float2*>(p); o[0] = tc_f32x2{v.x, v.y}; }
+template <> __device__ __forceinline__ void unpack_sv<bf16_t, 8>(const void* p, tc_f32x2* o) { unpack16v<bf16_t>(*reinterpret_cast<const uint4*>(p), o); }
+template <> __device__ __forceinline__ void unpack_sv<bf16_t, 4>(const void* p, tc_f32x2* o) {
+    const uint2 r = *reinterpret_cast<const uint2*>(p);
+    o[0] = tc_f32x2{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u)};
+    o[1] = tc_f32x2{__uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
+}
+template <> __device__ __forceinline__ void unpack_sv<f16_t, 8>(const void* p, tc_f32x2* o) { unpack16v<f16_t>(*reinterpret_cast<const uint4*>(p), o); }
+template <> __device__ __forceinline__ void unpack_sv<f16_t, 4>(const void* p, tc_f32x2* o) {
+    const uint2 r = *reinterpret_cast<const uint2*>(p);
+    float a, b;
+    unpack2<f16_t>(r.x, a, b); o[0] = tc_f32x2{a, b};
+    unpack2<f16_t>(r.y, a, b); o[1] = tc_f32x2{a, b};
+}
+template <typename T, int SV> __device__ __forceinline__ void store_sv(T* p, const tc_f32x2* o);
+template <> __device__ __forceinline__ void store_sv<float, 4>(float* p, const tc_f32x2* o) { *reinterpret_cast<uint4*>(p) = pack16v<float>(o); }
+template <> __device__ __forceinline__ void store_sv<float, 2>(float* p, const tc_f32x2* o) { *reinterpret_cast<float2*>(p) = make_float2(o[0].x, o[0].y); }
+template <> __device__ __forceinline__ void store_sv<bf16_t, 8>(bf16_t* p, const tc_f32x2* o) { *reinterpret_cast<uint4*>(p) = pack16v<bf16_t>(o); }
+template <> __device__ __forceinline__ void store_sv<bf16_t, 4>(bf16_t* p, const tc_f32x2* o) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack2bf(o[0].x, o[0].y), pack2bf(o[1].x, o[1].y));
+}
+template <> __device__ __forceinline__ void store_sv<f16_t, 8>(f16_t* p, const tc_f32x2* o) { *reinterpret_cast<uint4*>(p) = pack16v<f16_t>(o); }
+template <> __device__ __forceinline__ void store_sv<f16_t, 4>(f16_t* p, const tc_f32x2* o) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack2h(o[0].x, o[0].y), pack2h(o[1].x, o[1].y));
+}
+
 template <int K, int CG> struct DwTile {
     static constexpr int PT = 256 / CG, R = 4, TW = 16, TH = PT / (TW / R), P = (K - 1) / 2;
     static constexpr int IW = TW + K - 1, IH = TH + K - 1;
@@ -432,13 +461,13 @@ __device__ __forceinline__ bool dw_inside(int v, int h0, int w0, int NH, int NW,
     off_pix = ih * W + iw;
     return v < NH * NW * CG && ih >= 0 && ih < H && iw >= 0 && iw < W && cgi * VEC < crem;
 }
-template <typename T, int CG, int NREG>
+template <typename T, int CG, int NREG, int NTH = 256>
 __device__ __forceinline__ void dw_fetch(uint4 (&reg)[NREG], const T* img, int ld, int h0, int w0, int NH, int NW, int H, int W, int crem) {
     constexpr int VEC = Vec16<T>::N;
 #pragma unroll
     for (int i = 0; i < NREG; ++i) {
         int op, cgi;
-        const bool ok = dw_inside<T, CG>(threadIdx.x + i * 256, h0, w0, NH, NW, H, W, crem, op, cgi);
+        const bool ok = dw_inside<T, CG>(threadIdx.x + i * NTH, h0, w0, NH, NW, H, W, crem, op, cgi);
         reg[i] = *reinterpret_cast<const uint4*>(ok ? img + (long long)op * ld + cgi * VEC : img);
     }
 }
@@ -979,18 +1008,24 @@ template <typename T> struct FfnTile {
     static constexpr int smem_q = 2 * IH * IW * PIXQ + IH * IW + (K * K * CH + CH + NT * CH + 3) / 4;
 };
 
-template <typename T, bool PF>
+// NTH = 256: a thread owns a whole 16-byte channel vector in the convolution / weight-gradient phases (one wave per SIMD).
+// NTH = 512: two threads share a vector (SV = VEC / 2 channels each): half the registers per thread, two waves per SIMD, so that one
+// wave's LDS reads overlap the other's arithmetic -- with a single resident wave the LDS and VALU phases of a tile ran back to back.
+template <typename T, int NTH>
 __device__ __forceinline__ void ffn_mid_bwd_body(const FfnSegDev& a, long long wstride, const int bx, const int by, const int bz,
                                                  uint4* smem, const int dbg_nofold = 0) {
     using D = FfnTile<T>;
     constexpr int K = D::K, CG = D::CG, VEC = D::VEC, CH = D::CH, R = D::R, IW = D::IW, IH = D::IH, PIXQ = D::PIXQ, NT = D::NT;
-    constexpr int NPIX = IH * IW, NX = (NPIX * CG + 255) / 256, RG = (256 / CG) / K, UNITS = D::TH * (D::TW / R);
+    constexpr int HS = NTH / 256, SV = VEC / HS, S2 = SV / 2, V2 = VEC / 2, SVB = 16 / HS;       // sub-vector: SV channels = SVB bytes
+    constexpr int NPIX = IH * IW, NX = (NPIX * CG + NTH - 1) / NTH, RG = (256 / CG) / K, UNITS = D::TH * (D::TW / R);
     uint4* ddt = smem;                                           // dd on the haloed tile, storage type
     uint4* ht = ddt + NPIX * PIXQ;                               // h on the haloed tile
     float4* pst = reinterpret_cast<float4*>(ht + NPIX * PIXQ);   // per haloed pixel: mean, rstd, S1 / C, S2 / C
     float (*wsm)[CH] = reinterpret_cast<float (*)[CH]>(pst + NPIX);      // flipped taps
     float* gsm = &wsm[K * K][0];
     float (*lacc)[CH] = reinterpret_cast<float (*)[CH]>(gsm + CH);
+    const char* ddb = reinterpret_cast<const char*>(ddt);
+    const char* htb = reinterpret_cast<const char*>(ht);
     const int B = a.B, H = a.H, W = a.W, C = a.C;
     const long long img = (long long)B * H * W, grow = (long long)bz * img;     // first pixel row of this weight group
     const T* gp = (const T*)a.gp + grow * a.ldg;
@@ -1002,28 +1037,30 @@ __device__ __forceinline__ void ffn_mid_bwd_body(const FfnSegDev& a, long long w
     const T* w = (const T*)a.w + bz * wstride;
     const T* gamma = (const T*)a.gamma + bz * wstride;
     const int c0 = by * CH, tid = threadIdx.x;
-    for (int i = tid; i < K * K * CH; i += 256) {
+    for (int i = tid; i < K * K * CH; i += NTH) {
         const int cc = i / (K * K), t = i - cc * (K * K);
         wsm[K * K - 1 - t][cc] = (c0 + cc < C) ? ldf<T>(w + (long long)(c0 + cc) * K * K + t) : 0.f;
     }
-    for (int i = tid; i < CH; i += 256) gsm[i] = (c0 + i < C) ? ldf<T>(gamma + c0 + i) : 0.f;
-    for (int i = tid; i < NT * CH; i += 256) (&lacc[0][0])[i] = 0.f;
-    const int cg = tid % CG, wk = tid / CG;
+    for (int i = tid; i < CH; i += NTH) gsm[i] = (c0 + i < C) ? ldf<T>(gamma + c0 + i) : 0.f;
+    for (int i = tid; i < NT * CH; i += NTH) (&lacc[0][0])[i] = 0.f;
+    const int cg = tid % CG, hf = (tid / CG) % HS, wk = tid / (CG * HS);       // channel vector, half of it, one of 32 work lanes
+    const int ch0 = cg * VEC + hf * SV;                           // first of this thread's SV channels within the chunk
     const int ky3 = wk / RG, rg = wk % RG;                        // weight-gradient role: filter row, unit lane
-    const bool wactive = ky3 < K && c0 + cg * VEC < C;
+    const bool wactive = ky3 < K && c0 + ch0 < C;
     const int run = wk % (D::TW / R), row = wk / (D::TW / R);     // input-gradient role: 4-pixel run of tile row `row`
-    constexpr int V2 = VEC / 2;                                   // channel pairs per 16-byte vector (packed fp32 arithmetic)
-    tc_f32x2 acc[K][V2], accb[V2], accg[V2], accbt[V2];
+    tc_f32x2 acc[K][S2], accb[S2], accg[V2], accbt[V2];
 #pragma unroll
-    for (int e = 0; e < V2; ++e) {
-        accb[e] = accg[e] = accbt[e] = tc_f32x2{0.f, 0.f};
+    for (int e = 0; e < S2; ++e) {
+        accb[e] = tc_f32x2{0.f, 0.f};
 #pragma unroll
         for (int kx = 0; kx < K; ++kx) acc[kx][e] = tc_f32x2{0.f, 0.f};
     }
+#pragma unroll
+    for (int e = 0; e < V2; ++e) accg[e] = accbt[e] = tc_f32x2{0.f, 0.f};
     const int ntiles = B * a.tilesH * a.tilesW;
     const float invC = 1.0f / (float)C;
-    // One workgroup per CU (the register file of a single resident wave per SIMD is the budget): the NEXT tile's vectors of the three
-    // maps and its per-pixel LayerNorm quantities are requested before this tile's arithmetic starts and land in registers under it.
+    // One workgroup per CU: the NEXT tile's vectors of the three maps and its per-pixel LayerNorm quantities are requested before this
+    // tile's arithmetic starts and land in registers under it.
     uint4 gr[NX], dr[NX], hr[NX];
     constexpr int PQ = 8;
     float2 pq[PQ], pst_raw = make_float2(0.f, 0.f), ps_extra = make_float2(0.f, 0.f);
@@ -1036,8 +1073,6 @@ __device__ __forceinline__ void ffn_mid_bwd_body(const FfnSegDev& a, long long w
         int b, oh0, ow0;
         tile_org(tidx, b, oh0, ow0);
         const long long ibase = (long long)b * H * W;
-        // the row-sum partials first (their sum waits for them; a short, mostly L2-resident read), then the tile vectors, which stay in
-        // flight under the arithmetic of the current tile
         const int iy = tid / IW, ix = tid - iy * IW, ih = oh0 - 1 + iy, iw = ow0 - 1 + ix;
         const bool pin = tid < NPIX && ih >= 0 && ih < H && iw >= 0 && iw < W;
         const long long prow = pin ? ibase + (long long)ih * W + iw : 0;
@@ -1057,20 +1092,19 @@ __device__ __forceinline__ void ffn_mid_bwd_body(const FfnSegDev& a, long long w
             for (int j = 0; j < 4; ++j) if (k0 + j < a.nch2) { s1 += q4[j].x; s2 += q4[j].y; }
         }
         ps_extra = make_float2(s1, s2);
-        dw_fetch<T, CG, NX>(gr, gp + ibase * a.ldg + c0, a.ldg, oh0 - 1, ow0 - 1, IH, IW, H, W, C - c0);
-        dw_fetch<T, CG, NX>(dr, dm + ibase * a.ldd + c0, a.ldd, oh0 - 1, ow0 - 1, IH, IW, H, W, C - c0);
-        dw_fetch<T, CG, NX>(hr, hm + ibase * a.ldh + c0, a.ldh, oh0 - 1, ow0 - 1, IH, IW, H, W, C - c0);
+        dw_fetch<T, CG, NX, NTH>(gr, gp + ibase * a.ldg + c0, a.ldg, oh0 - 1, ow0 - 1, IH, IW, H, W, C - c0);
+        dw_fetch<T, CG, NX, NTH>(dr, dm + ibase * a.ldd + c0, a.ldd, oh0 - 1, ow0 - 1, IH, IW, H, W, C - c0);
+        dw_fetch<T, CG, NX, NTH>(hr, hm + ibase * a.ldh + c0, a.ldh, oh0 - 1, ow0 - 1, IH, IW, H, W, C - c0);
     };
-    if (PF && bx < ntiles) fetch(bx);
+    if (bx < ntiles) fetch(bx);
     __syncthreads();                                              // taps and gamma are in LDS
-    tc_f32x2 gk[V2];                                              // gamma of this thread's channels (its vectors all share cg)
+    tc_f32x2 gk[V2];                                              // gamma of this thread's channel vector (its vectors all share cg)
 #pragma unroll
     for (int e = 0; e < V2; ++e) gk[e] = tc_f32x2{gsm[cg * VEC + 2 * e], gsm[cg * VEC + 2 * e + 1]};
     for (int tidx = bx; tidx < ntiles; tidx += a.gx) {
         int b, oh0, ow0;
         tile_org(tidx, b, oh0, ow0);
         const long long ibase = (long long)b * H * W;
-        if (!PF) fetch(tidx);                                     // two workgroups per CU cover each other's memory latency instead
         __syncthreads();                                          // the previous tile's readers are done with the LDS tiles
         if (tid < NPIX) {
             float s1 = ps_extra.x, s2 = ps_extra.y;
@@ -1081,7 +1115,7 @@ __device__ __forceinline__ void ffn_mid_bwd_body(const FfnSegDev& a, long long w
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            const int v = tid + i * 256;
+            const int v = tid + i * NTH;
             int op, cgi;
             const bool ok = dw_inside<T, CG>(v, oh0 - 1, ow0 - 1, IH, IW, H, W, C - c0, op, cgi);
             if (v < NPIX * CG) {
@@ -1105,81 +1139,84 @@ __device__ __forceinline__ void ffn_mid_bwd_body(const FfnSegDev& a, long long w
             }
         }
         __syncthreads();
-        if (PF && tidx + a.gx < ntiles) fetch(tidx + a.gx);
-        {   // dh = conv^T(dd) + dd for this thread's 4-pixel run
-            const int oh = oh0 + row, owb = ow0 + run * R, c = c0 + cg * VEC;
+        if (tidx + a.gx < ntiles) fetch(tidx + a.gx);
+        {   // dh = conv^T(dd) + dd for this thread's 4-pixel run and SV channels
+            const int oh = oh0 + row, owb = ow0 + run * R, c = c0 + ch0;
             if (c < C && oh < H && owb < W) {
-                tc_f32x2 o[R][V2];
+                tc_f32x2 o[R][S2];
 #pragma unroll
                 for (int r = 0; r < R; ++r)
 #pragma unroll
-                    for (int e = 0; e < V2; ++e) o[r][e] = tc_f32x2{0.f, 0.f};
+                    for (int e = 0; e < S2; ++e) o[r][e] = tc_f32x2{0.f, 0.f};
 #pragma unroll
                 for (int ky = 0; ky < K; ++ky) {
-                    tc_f32x2 in[R + K - 1][V2];
+                    tc_f32x2 in[R + K - 1][S2];
 #pragma unroll
-                    for (int i = 0; i < R + K - 1; ++i) unpack16v<T>(ddt[((row + ky) * IW + run * R + i) * PIXQ + cg], in[i]);
+                    for (int i = 0; i < R + K - 1; ++i)
+                        unpack_sv<T, SV>(ddb + (((row + ky) * IW + run * R + i) * PIXQ + cg) * 16 + hf * SVB, in[i]);
 #pragma unroll
                     for (int kx = 0; kx < K; ++kx) {
-                        tc_f32x2 wr[V2];
+                        tc_f32x2 wr[S2];
 #pragma unroll
-                        for (int e = 0; e < V2; ++e) wr[e] = *reinterpret_cast<const tc_f32x2*>(&wsm[ky * K + kx][cg * VEC + 2 * e]);
+                        for (int e = 0; e < S2; ++e) wr[e] = *reinterpret_cast<const tc_f32x2*>(&wsm[ky * K + kx][ch0 + 2 * e]);
 #pragma unroll
                         for (int r = 0; r < R; ++r)
 #pragma unroll
-                            for (int e = 0; e < V2; ++e) o[r][e] += wr[e] * in[r + kx][e];
+                            for (int e = 0; e < S2; ++e) o[r][e] += wr[e] * in[r + kx][e];
                     }
                     if (ky == 1) {
 #pragma unroll
                         for (int r = 0; r < R; ++r)
 #pragma unroll
-                            for (int e = 0; e < V2; ++e) o[r][e] += in[r + 1][e];
+                            for (int e = 0; e < S2; ++e) o[r][e] += in[r + 1][e];
                     }
                 }
                 T* dst0 = dh + ((ibase + (long long)oh * W + owb)) * a.lddh + c;
 #pragma unroll
                 for (int r = 0; r < R; ++r)
-                    if (owb + r < W) *reinterpret_cast<uint4*>(dst0 + (long long)r * a.lddh) = pack16v<T>(o[r]);
+                    if (owb + r < W) store_sv<T, SV>(dst0 + (long long)r * a.lddh, o[r]);
             }
         }
         if (wactive) {   // filter-row ky3 of the weight gradient: sum over the tile of dd[p] * h[p + (ky3 - 1, kx - 1)]
             for (int u = rg; u < UNITS; u += RG) {
                 const int urow = u / (D::TW / R), urun = u % (D::TW / R);
-                tc_f32x2 d[R][V2], in[R + K - 1][V2];
+                tc_f32x2 d[R][S2], in[R + K - 1][S2];
 #pragma unroll
-                for (int r = 0; r < R; ++r) unpack16v<T>(ddt[((urow + 1) * IW + urun * R + r + 1) * PIXQ + cg], d[r]);
+                for (int r = 0; r < R; ++r) unpack_sv<T, SV>(ddb + (((urow + 1) * IW + urun * R + r + 1) * PIXQ + cg) * 16 + hf * SVB, d[r]);
 #pragma unroll
-                for (int i = 0; i < R + K - 1; ++i) unpack16v<T>(ht[((urow + ky3) * IW + urun * R + i) * PIXQ + cg], in[i]);
+                for (int i = 0; i < R + K - 1; ++i) unpack_sv<T, SV>(htb + (((urow + ky3) * IW + urun * R + i) * PIXQ + cg) * 16 + hf * SVB, in[i]);
 #pragma unroll
                 for (int kx = 0; kx < K; ++kx)
 #pragma unroll
                     for (int r = 0; r < R; ++r)
 #pragma unroll
-                        for (int e = 0; e < V2; ++e) acc[kx][e] += d[r][e] * in[r + kx][e];
+                        for (int e = 0; e < S2; ++e) acc[kx][e] += d[r][e] * in[r + kx][e];
                 if (ky3 == 0) {
 #pragma unroll
                     for (int r = 0; r < R; ++r)
 #pragma unroll
-                        for (int e = 0; e < V2; ++e) accb[e] += d[r][e];
+                        for (int e = 0; e < S2; ++e) accb[e] += d[r][e];
                 }
             }
         }
     }
     __syncthreads();
-    if (c0 + cg * VEC < C) {
+    if (c0 + ch0 < C) {
         if (ky3 < K) {
 #pragma unroll
             for (int kx = 0; kx < K; ++kx)
 #pragma unroll
-                for (int e = 0; e < V2; ++e) {
-                    atomicAdd(&lacc[ky3 * K + kx][cg * VEC + 2 * e], acc[kx][e].x);
-                    atomicAdd(&lacc[ky3 * K + kx][cg * VEC + 2 * e + 1], acc[kx][e].y);
+                for (int e = 0; e < S2; ++e) {
+                    atomicAdd(&lacc[ky3 * K + kx][ch0 + 2 * e], acc[kx][e].x);
+                    atomicAdd(&lacc[ky3 * K + kx][ch0 + 2 * e + 1], acc[kx][e].y);
                 }
             if (ky3 == 0) {
 #pragma unroll
-                for (int e = 0; e < V2; ++e) { atomicAdd(&lacc[K * K][cg * VEC + 2 * e], accb[e].x); atomicAdd(&lacc[K * K][cg * VEC + 2 * e + 1], accb[e].y); }
+                for (int e = 0; e < S2; ++e) { atomicAdd(&lacc[K * K][ch0 + 2 * e], accb[e].x); atomicAdd(&lacc[K * K][ch0 + 2 * e + 1], accb[e].y); }
             }
         }
+    }
+    if (c0 + cg * VEC < C) {
 #pragma unroll
         for (int e = 0; e < V2; ++e) {
             atomicAdd(&lacc[K * K + 1][cg * VEC + 2 * e], accg[e].x); atomicAdd(&lacc[K * K + 1][cg * VEC + 2 * e + 1], accg[e].y);
@@ -1198,7 +1235,7 @@ __device__ __forceinline__ void ffn_mid_bwd_body(const FfnSegDev& a, long long w
         float* part = a.wsp + ((long long)chain * a.gx + bx) * (NT * CH);
         pgroup = a.wsp + ((long long)chain * a.gx + grp * FG) * (NT * CH);
         if (gm > 1) {
-            for (int f = tid; f < NT * CH; f += 256) __hip_atomic_store(part + f, lflat[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int f = tid; f < NT * CH; f += NTH) __hip_atomic_store(part + f, lflat[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_s_waitcnt(0);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __syncthreads();
@@ -1217,7 +1254,7 @@ __device__ __forceinline__ void ffn_mid_bwd_body(const FfnSegDev& a, long long w
     float* dbp = a.db ? a.db + bz * wstride : nullptr;
     float* dgp = a.dgamma ? a.dgamma + bz * wstride : nullptr;
     float* dbtp = a.dbeta ? a.dbeta + bz * wstride : nullptr;
-    for (int f = tid; f < NT * CH; f += 256) {
+    for (int f = tid; f < NT * CH; f += NTH) {
         const int t = f / CH, cc = f - t * CH, ch = c0 + cc;
         if (ch >= C) continue;
         float v;
@@ -1239,8 +1276,8 @@ __device__ __forceinline__ void ffn_mid_bwd_body(const FfnSegDev& a, long long w
     }
 }
 
-template <typename T, bool PF>
-__global__ __launch_bounds__(256, PF ? 1 : 2) void ffn_mid_bwd_kernel(FfnMultiDev q) {
+template <typename T, int NTH>
+__global__ __launch_bounds__(NTH, 1) void ffn_mid_bwd_kernel(FfnMultiDev q) {
     extern __shared__ uint4 dsm[];
     int lin = blockIdx.x, si = 0;
     if (q.n > 1 && lin >= q.s[1].blk0) si = 1;
@@ -1248,14 +1285,14 @@ __global__ __launch_bounds__(256, PF ? 1 : 2) void ffn_mid_bwd_kernel(FfnMultiDe
     if (q.n > 3 && lin >= q.s[3].blk0) si = 3;
     const FfnSegDev& g = q.s[si];
     lin -= g.blk0;
-    ffn_mid_bwd_body<T, PF>(g, q.wstride, lin % g.gx, lin / g.gx, blockIdx.y, dsm, q.dbg_nofold);
+    ffn_mid_bwd_body<T, NTH>(g, q.wstride, lin % g.gx, lin / g.gx, blockIdx.y, dsm, q.dbg_nofold);
 }
 
 template <typename T>
 int launch_ffn_mid_bwd(const TcFfnSeg* segs, int nseg, int groups, long long wstride, void* ws, long long ws_bytes, hipStream_t s) {
     using D = FfnTile<T>;
     static_assert(D::smem_q * 16 <= 64 * 1024, "static dynamic-LDS limit");
-    static const bool pf = !(getenv("TC_FFN_MID_PF") && atoi(getenv("TC_FFN_MID_PF")) == 0);   // A/B switch: 0 = two workgroups per CU
+    static const int nth = getenv("TC_FFN_MID_THREADS") ? atoi(getenv("TC_FFN_MID_THREADS")) : 256;   // A/B switch: 256 = one wave per SIMD
     static const int nofold = getenv("TC_DEBUG_FFN_NOFOLD") ? atoi(getenv("TC_DEBUG_FFN_NOFOLD")) : 0;
     FfnMultiDev q;
     q.n = nseg; q.wstride = wstride; q.dbg_nofold = nofold;
@@ -1275,9 +1312,8 @@ int launch_ffn_mid_bwd(const TcFfnSeg* segs, int nseg, int groups, long long wst
         d.chunks = (g.C + D::CH - 1) / D::CH;
         d.tilesW = (g.W + 15) / 16; d.tilesH = (g.H + D::TH - 1) / D::TH;
         const long long ntiles = (long long)g.B * d.tilesW * d.tilesH;
-        // ~256 workgroups in total (one per CU; 512 for the two-per-CU variant), shared out by tiles x chunks; every channel chunk
-        // gets gx tile walkers
-        long long gx = (long long)((pf ? 256.0 : 512.0) * (double)ntiles / (double)(total_work > 0 ? total_work : 1) / groups + 0.5);
+        // ~256 workgroups in total (one per CU), shared out by tiles x chunks; every channel chunk gets gx tile walkers
+        long long gx = (long long)(256.0 * (double)ntiles / (double)(total_work > 0 ? total_work : 1) / groups + 0.5);
         gx = gx < 1 ? 1 : (gx > ntiles ? ntiles : gx);
         d.gx = (int)gx;
         d.wsc = have_ws ? reinterpret_cast<int*>(ws) + cnts : nullptr;
@@ -1291,8 +1327,8 @@ int launch_ffn_mid_bwd(const TcFfnSeg* segs, int nseg, int groups, long long wst
     if (have_ws && (cnts > 4096 || 16384 + part_floats * 4 > ws_bytes))
         for (int i = 0; i < nseg; ++i) { q.s[i].wsc = nullptr; q.s[i].wsp = nullptr; }
     const size_t smem = (size_t)D::smem_q * 16;
-    if (pf) hipLaunchKernelGGL((ffn_mid_bwd_kernel<T, true>), dim3((unsigned)blk, groups), dim3(256), smem, s, q);
-    else hipLaunchKernelGGL((ffn_mid_bwd_kernel<T, false>), dim3((unsigned)blk, groups), dim3(256), smem, s, q);
+    if (nth == 256) hipLaunchKernelGGL((ffn_mid_bwd_kernel<T, 256>), dim3((unsigned)blk, groups), dim3(256), smem, s, q);
+    else hipLaunchKernelGGL((ffn_mid_bwd_kernel<T, 512>), dim3((unsigned)blk, groups), dim3(512), smem, s, q);
     return tc_launch_status();
 }
 
