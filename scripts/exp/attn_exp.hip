@@ -1060,7 +1060,7 @@ __global__ __launch_bounds__(NT30, 1) void attn_fwd_seg_kernel(const bf16_t* __r
 } extern "C" int tc_dbg_read(long long* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_dbg), sizeof(long long) * 4 * NW30 * 24); } namespace {
 #endif
 
-#elif ATT_VAR >= 90 && ATT_VAR < 100
+#elif ATT_VAR >= 90 && ATT_VAR < 92
 // v30: ONE workgroup of NW30 = 12 waves (768 threads) per CU: 16 workgroups per image = 256 at B = 16.  The twelve 32-query wave tiles share
 // one K/V staging (a third of the L2 -> LDS traffic of the 4-wave workgroups); the 128-key K/V tiles are double-buffered in LDS (72 KB)
 // and fetched a whole tile ahead into 3 registers per thread, so a tile costs ONE barrier and no exposed load latency.
@@ -2114,6 +2114,219 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_seg_kernel(const bf16_t* __re
                 st4<bf16_t>(orow + 32 + 8 * g + 4 * h, make_float4(acc1[q][4 * g] * inv, acc1[q][4 * g + 1] * inv, acc1[q][4 * g + 2] * inv, acc1[q][4 * g + 3] * inv));
             }
             if (h == 0) lse[qrow[q]] = (m[q] + log2f(ls)) * LN2;
+        }
+    }
+}
+
+#elif ATT_VAR >= 92 && ATT_VAR < 100
+// v92: v91 (12-wave workgroup per CU, reference-exponent softmax, Q/O through LDS) with a software-pipelined, fenced loop body:
+// iteration i carries the exp / sum / pack arithmetic of key sub-tile i in eight groups of 7 VALU instructions, each behind one of
+// eight MFMAs that do not depend on it (PV of sub-tile i-1 alternating with QK^T of sub-tile i+1; no MFMA directly follows one it
+// depends on).  Measured (scripts/exp/overlap.hip, 3 waves per SIMD): this order costs 216 ns per wave-iteration against 283 for MFMA
+// and VALU phases issued apart.  3-slot LDS ring of 128-key K/V tiles, one barrier per tile.
+#ifndef NW30
+#define NW30 12
+#endif
+#ifndef KB30
+#define KB30 96
+#endif
+constexpr int NT30 = NW30 * 64, NC30 = KB30 * 8, NF30 = (2 * NC30 + NT30 - 1) / NT30, SLOT30 = 2 * KB30 * LDR, SPT30 = KB30 / 32;
+#define FENCE() __builtin_amdgcn_sched_barrier(0)
+__global__ __launch_bounds__(NT30, 1) void attn_fwd_seg_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
+                                                               const bf16_t* __restrict__ V, int ldv, long long skv, bf16_t* __restrict__ O,
+                                                               int ldo, float* __restrict__ lse, Segs sg, int Nk, float scale) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem30[];      // [3 slots][K tile | V tile][KB30][LDR], then NW30 wave tiles [32][LDR]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    const int nwt = sg.t32[sg.n], bpi = (nwt + NW30 - 1) / NW30;
+    const int b = blockIdx.x / bpi, wt = (blockIdx.x - b * bpi) * NW30 + wave;
+    int sgi = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) if (i < sg.n && wt >= sg.t32[i]) sgi = i;
+    const int nq = sg.nq[sgi];
+    const int tq0 = (wt - sg.t32[sgi]) * 32;                    // first query of the wave's tile within its segment-image
+    const bool ok = wt < nwt && tq0 + j < nq;
+    const long long trow0 = (long long)sg.row0[sgi] + (long long)b * nq + tq0;
+    const bf16_t* Kb = K + b * skv;
+    const bf16_t* Vb = V + b * skv;
+    bf16_t* wtile = smem30 + 3 * SLOT30 + wave * (32 * LDR);
+    uint4 st[NF30];
+    auto fetch = [&](int kb0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NF30; ++i) {
+            const int id = tid + i * NT30, isv = id >= NC30, r = (id - isv * NC30) >> 3, c8 = (id & 7) * 8;
+            const bf16_t* src = isv ? Vb : Kb;
+            const int ld = isv ? ldv : ldk;
+            st[i] = id < 2 * NC30 ? *reinterpret_cast<const uint4*>(src + (long long)min(kb0 + r, Nk - 1) * ld + c8) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto stash = [&](int slot) __attribute__((always_inline)) {
+        bf16_t* base = smem30 + slot * SLOT30;
+#pragma unroll
+        for (int i = 0; i < NF30; ++i) {
+            const int id = tid + i * NT30, isv = id >= NC30, r = (id - isv * NC30) >> 3, c8 = (id & 7) * 8;
+            const int pr = isv ? ((r & ~15) | ((r & 3) << 2) | ((r >> 2) & 3)) : r;
+            if (id < 2 * NC30) *reinterpret_cast<uint4*>(base + isv * (KB30 * LDR) + pr * LDR + c8) = st[i];
+        }
+    };
+    fetch(0);                                                   // the first K/V tile is requested before the Q tile: every wave waits for it
+    bf16x8 qf[4];
+    {   // Q tile of the wave: coalesced 128-byte rows into the wave-private LDS tile, fragments read back from there
+        uint4 qv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 8 * i + (lane >> 3);
+            qv[i] = (wt < nwt && tq0 + r < nq) ? *reinterpret_cast<const uint4*>(Q + (trow0 + r) * ldq + 8 * (lane & 7)) : make_uint4(0u, 0u, 0u, 0u);
+        }
+        stash(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(wtile + (8 * i + (lane >> 3)) * LDR + 8 * (lane & 7)) = qv[i];
+    }
+    const int nt = (Nk + KB30 - 1) / KB30, nsubs = (Nk + 31) / 32;
+    if (nt > 1) fetch(KB30);
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = ld_frag(wtile + j * LDR + 16 * ks + 8 * h);
+    const float qs = scale * LOG2E;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    float m, lsum = 0.f;
+    const int koff = pi_row(j) * LDR + 8 * h;
+    const int voff = (16 * h + 4 * ((lane & 15) >> 2)) * LDR + 16 * ((lane >> 4) & 1) + 4 * (lane & 3) + KB30 * LDR;
+    auto kaddr = [&](int i) __attribute__((always_inline)) { return smem30 + ((i / SPT30) % 3) * SLOT30 + 32 * (i % SPT30) * LDR + koff; };
+    auto vaddr = [&](int i) __attribute__((always_inline)) { return smem30 + ((i / SPT30) % 3) * SLOT30 + 32 * (i % SPT30) * LDR + voff; };
+    bf16x8 kf[4], vf[4], pb0, pb1;
+    auto load_k = [&](int i) __attribute__((always_inline)) {
+        const bf16_t* kp = kaddr(i);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) kf[ks] = ld_frag(kp + 16 * ks);
+    };
+    auto load_v = [&](int i) __attribute__((always_inline)) {
+        const bf16_t* vp = vaddr(i);
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            vf[2 * k2] = ld_frag_tr(vp + (2 * k2) * LDR, vp + (2 * k2 + 1) * LDR);
+            vf[2 * k2 + 1] = ld_frag_tr(vp + (2 * k2) * LDR + 32, vp + (2 * k2 + 1) * LDR + 32);
+        }
+    };
+    auto qk = [&](f32x16& S) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], S, 0, 0, 0);
+    };
+    auto rowmax = [&](const f32x16& S) __attribute__((always_inline)) {
+        float mx = S[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, S[r]);
+        const unsigned u = __float_as_uint(mx);
+        const auto pr = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        return ceilf(fmaxf(__uint_as_float(pr[0]), __uint_as_float(pr[1])) * qs);
+    };
+    f32x16 SA, SB;
+    load_k(0);
+    qk(SA);
+    m = rowmax(SA);                                             // reference exponent: integer-valued, raised only when a row outgrows it by 2^30
+    load_v(0);                                                  // (placeholder fragments for the empty PV of the first iteration)
+    if (nsubs > 1) load_k(1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { pb0[i] = (__bf16)0.f; pb1[i] = (__bf16)0.f; }
+    // iteration i: S = scores of sub-tile i; kf = K fragments of sub-tile i + 1; vf, pb = V^T fragments and packed P of sub-tile i - 1
+    auto step = [&](f32x16& S, f32x16& Sn, int i, auto last_tag) __attribute__((always_inline)) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        const int t = i / SPT30, sub = i % SPT30;
+        if (sub == 0) {
+            if (t + 1 < nt) stash((t + 1) % 3);
+            if (t + 2 < nt) fetch((t + 2) * KB30);
+        }
+        if (LAST) {
+            const int kv0 = 32 * i;
+            if (kv0 + 32 > Nk) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) if (kv0 + 16 * h + r >= Nk) S[r] = NEG_BIG;
+            }
+        }
+        float rs = 0.f;
+        bf16x8 pn0, pn1;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            FENCE();
+            if (g & 1) {                                        // QK^T of sub-tile i + 1, k-slice g >> 1
+                if (!LAST) {
+                    if (g == 1) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) Sn[r] = 0.f;
+                    }
+                    Sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[g >> 1], qf[g >> 1], Sn, 0, 0, 0);
+                }
+            } else {                                            // PV of sub-tile i - 1
+                const int c = g >> 1;
+                if (c & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[c], c < 2 ? pb0 : pb1, acc1, 0, 0, 0);
+                else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[c], c < 2 ? pb0 : pb1, acc0, 0, 0, 0);
+            }
+            FENCE();
+#pragma unroll
+            for (int r = 2 * g; r < 2 * g + 2; ++r) { S[r] = fast_exp2(fmaf(S[r], qs, -m)); rs += S[r]; }
+            if (g == 3) pn0 = pack8(S, 0);
+            if (g == 7) pn1 = pack8(S, 8);
+        }
+        FENCE();
+        if (__any(!(rs < 1073741824.0f))) {                     // rare: re-reference the rows (scores recomputed from the resident K tile)
+            f32x16 T;
+            const bf16_t* kp = kaddr(i);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(kp + 16 * ks), qf[ks], T, 0, 0, 0);
+            if (LAST) {
+                const int kv0 = 32 * i;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) if (kv0 + 16 * h + r >= Nk) T[r] = NEG_BIG;
+            }
+            const float mn = fmaxf(m, rowmax(T));
+            const float alpha = fast_exp2(m - mn);
+            lsum *= alpha;
+            m = mn;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] *= alpha; acc1[r] *= alpha; }
+            rs = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { S[r] = fast_exp2(fmaf(T[r], qs, -m)); rs += S[r]; }
+            pn0 = pack8(S, 0);
+            pn1 = pack8(S, 8);
+        }
+        lsum += rs;
+        pb0 = pn0; pb1 = pn1;
+        // fragments for the next iteration: V^T of this sub-tile, K of sub-tile i + 2 (its tile was stored >= 2 iterations ago)
+        load_v(i);
+        if (sub == 1 && i + 2 < nsubs) __syncthreads();         // tile t + 1 (stored at sub 0) is complete: sub-tile i + 3 is its first
+        if (i + 2 < nsubs) load_k(i + 2);
+    };
+    int i = 0;
+#pragma unroll 1
+    for (; i + 2 < nsubs; i += 2) { step(SA, SB, i, std::false_type{}); step(SB, SA, i + 1, std::false_type{}); }
+    if (i + 2 == nsubs) { step(SA, SB, i, std::false_type{}); step(SB, SA, i + 1, std::true_type{}); }
+    else step(SA, SB, i, std::true_type{});
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pb0, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pb0, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[2], pb1, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[3], pb1, acc1, 0, 0, 0);
+    lsum += __shfl_xor(lsum, 32, 64);
+    {   // O tile through the wave-private LDS tile: whole 128-byte rows leave with 16-byte stores
+        const float inv = 1.0f / lsum;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            st4<bf16_t>(wtile + j * LDR + 8 * g + 4 * h, make_float4(acc0[4 * g] * inv, acc0[4 * g + 1] * inv, acc0[4 * g + 2] * inv, acc0[4 * g + 3] * inv));
+            st4<bf16_t>(wtile + j * LDR + 32 + 8 * g + 4 * h, make_float4(acc1[4 * g] * inv, acc1[4 * g + 1] * inv, acc1[4 * g + 2] * inv, acc1[4 * g + 3] * inv));
+        }
+        if (ok && h == 0) lse[trow0 + j] = (m + log2f(lsum)) * LN2;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i2 = 0; i2 < 4; ++i2) {
+            const int r = 8 * i2 + (lane >> 3);
+            const uint4 v = *reinterpret_cast<const uint4*>(wtile + r * LDR + 8 * (lane & 7));
+            if (wt < nwt && tq0 + r < nq) *reinterpret_cast<uint4*>(O + (trow0 + r) * ldo + 8 * (lane & 7)) = v;
         }
     }
 }
@@ -3728,7 +3941,8 @@ extern "C" int tc_attn_fwd_seg(const void* Q, int ldq, const void* K, int ldk, c
     }
 #elif (ATT_VAR >= 30 && ATT_VAR < 50) || (ATT_VAR >= 70 && ATT_VAR < 80) || (ATT_VAR >= 90 && ATT_VAR < 100)
     {
-        const size_t smem = ((size_t)((ATT_VAR >= 40 && ATT_VAR < 90) ? 3 : 2) * 2 * KB30 * LDR + (ATT_VAR >= 91 ? NW30 * 32 * LDR : 0)) * sizeof(bf16_t);
+        const size_t smem = ((size_t)(((ATT_VAR >= 40 && ATT_VAR < 90) || ATT_VAR >= 92) ? 3 : 2) * 2 * KB30 * LDR + (ATT_VAR >= 91 ? NW30 * 32 * LDR : 0)) * sizeof(bf16_t);
+        static_assert(ATT_VAR < 92 || (3 * 2 * KB30 * LDR + NW30 * 32 * LDR) * 2 <= 160 * 1024, "LDS");
         static bool attr = false;
         if (!attr) { hipFuncSetAttribute((const void*)attn_fwd_seg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; }
         const unsigned g30 = (unsigned)B * ((sg.t32[nseg] + NW30 - 1) / NW30);

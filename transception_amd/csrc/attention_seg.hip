@@ -2,14 +2,12 @@
 //
 // The bridge's 6076 query tokens per image live in a stage-major buffer (four row segments, one per encoder scale, each
 // holding B images back to back), while the 784 reduced K/V tokens are image-major.  One launch covers every
-// (segment, image, 128-query tile): ~800 workgroups instead of four launches of 50-400, so the chip is filled and the
-// launch boundary is paid once.  Versus attention.hip's first bf16 kernels this version also
-//   * prefetches the next 128-key K/V fill into registers while the current one is being consumed,
-//   * folds the softmax scale into the exp2 argument (one FMA per score), masks keys only in the tail tile,
-//   * rescales the running output lazily (only when some row maximum grew by more than 2^8),
-//   * allows two workgroups per CU (launch bounds) so one wave's softmax VALU overlaps another's MFMA.
+// (segment, image, query tile) instead of four launches of 50-400 workgroups, so the chip is filled and the launch boundary is paid
+// once.  The kernels prefetch the next 128-key K/V fill into registers while the current one is being consumed, fold the softmax
+// scale into the exp2 argument (one FMA per score) and mask keys only in the tail tile; see the comment of each kernel.
 // fp32 storage falls back to the per-segment fp32 kernels of attention.hip (parity path).
 #include "tc_common.h"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -94,32 +92,54 @@ __device__ __forceinline__ void locate_tile(const Segs& sg, int t, int& row_base
     row_base = sg.row0[s] + b * nq;
 }
 
+// Forward.  ONE workgroup of FW_NW = 12 waves per CU; each wave owns a 32-query tile (the tiles are numbered through the four scales of
+// an image: 190 per image at 224^2 = 16 workgroups per image = 256 at B = 16, one per CU).
+//   * The twelve waves share one K/V staging: 128-key tiles, double-buffered in LDS and fetched a whole tile ahead into three
+//     registers per thread -- one barrier and no exposed load per tile (4-wave workgroups staged three times the bytes per CU).
+//   * Softmax against a reference exponent m that is NOT the running row maximum: any m within fp32's exponent range of the true
+//     maximum gives the same quotient, so m is set once (integer-valued, from the row's first sub-tile) and raised only when a row
+//     sum shows that the scores have outgrown it by 2^30 (2^14 for fp16 storage of P) -- one compare per 32-key sub-tile instead of
+//     a 16-element maximum, a lane swap and a compare (-25 % VALU work; on gfx950 the VALU work of one wave does not hide under the
+//     MFMAs of another wave of the same SIMD, scripts/exp/overlap.hip, so every VALU instruction removed is time).  Integer m: P
+//     differs from the maximum-referenced P by an exact power of two.
+//   * Q and O tiles pass through a wave-private LDS tile so that global memory sees whole 128-byte rows (eight lanes x 16 bytes): a
+//     per-lane 16-byte access at a row stride touches 32 lines per instruction and queued in the address unit for ~4 us at each end.
+constexpr int FW_NW = 12, FW_NT = FW_NW * 64, FW_NC = KB * 8, FW_NF = (2 * FW_NC + FW_NT - 1) / FW_NT;
+constexpr int FW_SLOT = 2 * KB * LDR;                           // one ring slot: K tile | V tile
+constexpr size_t FW_SMEM = (size_t)(2 * FW_SLOT + FW_NW * 32 * LDR) * sizeof(bf16_t);
 template <typename H>
-__global__ __launch_bounds__(256, 4) void attn_fwd_seg_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
-                                                              const bf16_t* __restrict__ V, int ldv, long long skv, bf16_t* __restrict__ O,
-                                                              int ldo, float* __restrict__ lse, Segs sg, int Nk, float scale) {
-    __shared__ __attribute__((aligned(16))) bf16_t Ks[KB * LDR];
-    __shared__ __attribute__((aligned(16))) bf16_t Vs[KB * LDR];
+__global__ __launch_bounds__(FW_NT, 1) void attn_fwd_seg_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
+                                                                const bf16_t* __restrict__ V, int ldv, long long skv, bf16_t* __restrict__ O,
+                                                                int ldo, float* __restrict__ lse, Segs sg, int Nk, float scale, int wide_o) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t fw_smem[];      // [2 slots][K tile | V tile][KB][LDR], then FW_NW wave tiles [32][LDR]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
-    // 32-query wave tiles are numbered through the four scales of an image and dealt four to a workgroup: 48 workgroups per image
-    // at 224^2 = 768 at B = 16 = exactly three per CU (tiles of 128 queries per scale gave 800: the CUs holding four finished last)
-    const int nwt = sg.t32[sg.n], bpi = (nwt + 3) >> 2;
-    const int b = blockIdx.x / bpi, wt = (blockIdx.x - b * bpi) * 4 + wave;
+    const int nwt = sg.t32[sg.n], bpi = (nwt + FW_NW - 1) / FW_NW;
+    const int b = blockIdx.x / bpi, wt = (blockIdx.x - b * bpi) * FW_NW + wave;
     int sgi = 0;
 #pragma unroll
     for (int i = 1; i < 4; ++i) if (i < sg.n && wt >= sg.t32[i]) sgi = i;
     const int nq = sg.nq[sgi];
-    const int ql = (wt - sg.t32[sgi]) * 32 + j;
-    const bool ok = wt < nwt && ql < nq;
-    const long long qrow = (long long)sg.row0[sgi] + (long long)b * nq + ql;
+    const int tq0 = (wt - sg.t32[sgi]) * 32;                    // first query of the wave's tile within its segment-image
+    const bool live = wt < nwt, ok = live && tq0 + j < nq;
+    const long long trow0 = (long long)sg.row0[sgi] + (long long)b * nq + tq0;
     const bf16_t* Kb = K + b * skv;
     const bf16_t* Vb = V + b * skv;
     typedef typename TcHalf<H>::v8 V8;
+    bf16_t* wtile = fw_smem + 2 * FW_SLOT + wave * (32 * LDR);
     V8 qf[4];
+    {
+        uint4 qv[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const uint4 v = ok ? *reinterpret_cast<const uint4*>(Q + qrow * ldq + 16 * ks + 8 * h) : make_uint4(0u, 0u, 0u, 0u);
-        qf[ks] = *reinterpret_cast<const V8*>(&v);
+        for (int i = 0; i < 4; ++i) {
+            const int r = 8 * i + (lane >> 3);
+            qv[i] = (live && tq0 + r < nq) ? *reinterpret_cast<const uint4*>(Q + (trow0 + r) * ldq + 8 * (lane & 7)) : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(wtile + (8 * i + (lane >> 3)) * LDR + 8 * (lane & 7)) = qv[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = ld_frag<V8>(wtile + j * LDR + 16 * ks + 8 * h);
     }
     const float qs = scale * LOG2E;
     f32x16 acc0, acc1;
@@ -127,100 +147,113 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_seg_kernel(const bf16_t* __re
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
     float m = NEG_BIG, lsum = 0.f;
     const int krow = pi_row(j);
-    uint4 kr[4];                                            // K of the next fill is prefetched; V is fetched at its LDS store (keeps the
-    auto fetch = [&](int kb0) {                            // kernel within 128 VGPRs: 4 workgroups per CU = all 800 tiles resident at once)
+    // staging: chunk id = tid + i * FW_NT; ids below FW_NC are K (row = id >> 3, 16-byte chunk id & 7), the next FW_NC are V
+    uint4 st[FW_NF];
+    auto fetch = [&](int kb0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int r, c8, g;
-            fill_map(tid, i, r, c8, g);
-            kr[i] = ld_row8(Kb, ldk, kb0 + r, Nk, c8);
+        for (int i = 0; i < FW_NF; ++i) {
+            const int id = tid + i * FW_NT, isv = id >= FW_NC, r = (id - isv * FW_NC) >> 3, c8 = (id & 7) * 8;
+            const bf16_t* src = isv ? Vb : Kb;
+            const int ld = isv ? ldv : ldk;
+            st[i] = id < 2 * FW_NC ? *reinterpret_cast<const uint4*>(src + (long long)min(kb0 + r, Nk - 1) * ld + c8) : make_uint4(0u, 0u, 0u, 0u);
         }
     };
+    auto stash = [&](int slot) __attribute__((always_inline)) {
+        bf16_t* base = fw_smem + slot * FW_SLOT;
+#pragma unroll
+        for (int i = 0; i < FW_NF; ++i) {
+            const int id = tid + i * FW_NT, isv = id >= FW_NC, r = (id - isv * FW_NC) >> 3, c8 = (id & 7) * 8;
+            if (id < 2 * FW_NC) *reinterpret_cast<uint4*>(base + isv * (KB * LDR) + (isv ? key_row(r) : r) * LDR + c8) = st[i];
+        }
+    };
+    const int nt = (Nk + KB - 1) / KB;
     fetch(0);
-    for (int kb0 = 0; kb0 < Nk; kb0 += KB) {
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int r, c8, g;
-            fill_map(tid, i, r, c8, g);
-            *reinterpret_cast<uint4*>(&Ks[r * LDR + c8]) = kr[i];
-        }
-        {
-            uint4 vr[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int r, c8, g;
-                fill_map(tid, i, r, c8, g);
-                vr[i] = *reinterpret_cast<const uint4*>(Vb + (long long)min(kb0 + r, Nk - 1) * ldv + c8);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int r, c8, g;
-                fill_map(tid, i, r, c8, g);
-                *reinterpret_cast<uint4*>(&Vs[key_row(r) * LDR + c8]) = vr[i];
-            }
-        }
-        __syncthreads();
-        if (kb0 + KB < Nk) fetch(kb0 + KB);
-        // S^T tile of sub-tile `sub`: 4 chained MFMAs, issued asynchronously to the matrix pipe
-        auto qk = [&](int sub) {
+    stash(0);
+    if (nt > 1) fetch(KB);
+    __syncthreads();
+    constexpr float REREF = std::is_same<H, f16_t>::value ? 16384.0f : 1073741824.0f;   // P must stay finite in its 16-bit storage type
+    for (int t = 0; t < nt; ++t) {
+        const int kb0 = t * KB;
+        if (t + 1 < nt) stash((t + 1) & 1);                     // (every wave left tile t - 1, the slot's last reader, at the barrier below)
+        if (t + 2 < nt) fetch(kb0 + 2 * KB);
+        const bf16_t* Ks = fw_smem + (t & 1) * FW_SLOT;
+        const bf16_t* Vs = Ks + KB * LDR;
+        const int nsub = min(KB / 32, (Nk - kb0 + 31) / 32);
+#pragma unroll 1
+        for (int sub = 0; sub < nsub; ++sub) {
+            // S^T tile: 4 chained MFMAs
             f32x16 s;
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = 0.f;
             const bf16_t* kp = Ks + (32 * sub + krow) * LDR + 8 * h;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) s = TcHalf<H>::mfma(ld_frag<V8>(kp + 16 * ks), qf[ks], s);
-            return s;
-        };
-        // online softmax of a finished S^T tile (register VALU) followed by O^T += V^T P^T
-        auto softmax_pv = [&](f32x16 s, int sub) {
             const int kv0 = kb0 + 32 * sub;
             if (kv0 + 32 > Nk) {                                // tail tile (wave-uniform)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) if (kv0 + 16 * h + r >= Nk) s[r] = NEG_BIG;
             }
-            float mx = s[0];
+            auto rowmax = [&]() __attribute__((always_inline)) {
+                float mx = s[0];
 #pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
-            {
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
                 const unsigned u = __float_as_uint(mx);
                 const auto pr = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-                mx = fmaxf(__uint_as_float(pr[0]), __uint_as_float(pr[1])) * qs;
-            }
-            if (__any(mx > m + RESCALE_THR)) {                  // lazy rescale: rare once the running maximum has settled
-                const float mn = fmaxf(m, mx);
+                return ceilf(fmaxf(__uint_as_float(pr[0]), __uint_as_float(pr[1])) * qs);
+            };
+            if (kv0 == 0) m = rowmax();                         // the row's first sub-tile sets the reference exponent
+            f32x16 p;
+            float rs = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { p[r] = fast_exp2(fmaf(s[r], qs, -m)); rs += p[r]; }
+            if (__any(!(rs < REREF))) {                         // rare: some row outgrew its reference; re-reference the rows of the wave
+                const float mn = fmaxf(m, rowmax());
                 const float alpha = fast_exp2(m - mn);
                 lsum *= alpha;
                 m = mn;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { acc0[r] *= alpha; acc1[r] *= alpha; }
-            }
-            float rs = 0.f;
+                rs = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = fast_exp2(fmaf(s[r], qs, -m)); rs += s[r]; }
+                for (int r = 0; r < 16; ++r) { p[r] = fast_exp2(fmaf(s[r], qs, -m)); rs += p[r]; }
+            }
             lsum += rs;
+            // O^T += V^T P^T
             const int gi = lane & 15, gq = (lane >> 4) & 1;
             const bf16_t* vp = Vs + (32 * sub + 16 * h + 4 * (gi >> 2)) * LDR + 16 * gq + 4 * (gi & 3);
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2) {
-                const V8 pb = pack8<H>(s, 8 * k2);
+                const V8 pb = pack8<H>(p, 8 * k2);
                 acc0 = TcHalf<H>::mfma(ld_frag_tr<V8>(vp + (2 * k2) * LDR, vp + (2 * k2 + 1) * LDR), pb, acc0);
                 acc1 = TcHalf<H>::mfma(ld_frag_tr<V8>(vp + (2 * k2) * LDR + 32, vp + (2 * k2 + 1) * LDR + 32), pb, acc1);
             }
-        };
-#pragma unroll 1
-        for (int sub = 0; sub < KB / 32 && kb0 + 32 * sub < Nk; ++sub) softmax_pv(qk(sub), sub);
+        }
+        __syncthreads();
     }
     lsum += __shfl_xor(lsum, 32, 64);
-    if (ok) {
-        const float inv = 1.0f / lsum;
-        bf16_t* orow = O + qrow * ldo;
+    const float inv = 1.0f / lsum;
+    if (ok && h == 0) lse[trow0 + j] = (m + log2f(lsum)) * LN2;
+    if (wide_o) {                                               // O tile through the wave's LDS tile: whole rows, 16-byte stores
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            st4<H>(reinterpret_cast<H*>(wtile + j * LDR + 8 * g + 4 * h), make_float4(acc0[4 * g] * inv, acc0[4 * g + 1] * inv, acc0[4 * g + 2] * inv, acc0[4 * g + 3] * inv));
+            st4<H>(reinterpret_cast<H*>(wtile + j * LDR + 32 + 8 * g + 4 * h), make_float4(acc1[4 * g] * inv, acc1[4 * g + 1] * inv, acc1[4 * g + 2] * inv, acc1[4 * g + 3] * inv));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 8 * i + (lane >> 3);
+            const uint4 v = *reinterpret_cast<const uint4*>(wtile + r * LDR + 8 * (lane & 7));
+            if (live && tq0 + r < nq) *reinterpret_cast<uint4*>(O + (trow0 + r) * ldo + 8 * (lane & 7)) = v;
+        }
+    } else if (ok) {                                            // O rows that are not 16-byte aligned: 8-byte stores per lane
+        bf16_t* orow = O + (trow0 + j) * ldo;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             st4<H>(reinterpret_cast<H*>(orow + 8 * g + 4 * h), make_float4(acc0[4 * g] * inv, acc0[4 * g + 1] * inv, acc0[4 * g + 2] * inv, acc0[4 * g + 3] * inv));
             st4<H>(reinterpret_cast<H*>(orow + 32 + 8 * g + 4 * h), make_float4(acc1[4 * g] * inv, acc1[4 * g + 1] * inv, acc1[4 * g + 2] * inv, acc1[4 * g + 3] * inv));
         }
-        if (h == 0) lse[qrow] = (m + log2f(lsum)) * LN2;
     }
 }
 
@@ -534,10 +567,20 @@ extern "C" int tc_attn_fwd_seg(const void* Q, int ldq, const void* K, int ldk, c
     }
     if ((dtype != TC_BF16 && dtype != TC_F16) || ((ldq | ldk | ldv) & 7) || (skv & 7) || (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) || (ldo & 3))
         return TC_ERR_ARG;
-    const dim3 grid((unsigned)B * ((sg.t32[nseg] + 3) / 4));
-#define TC_FWD(HH) hipLaunchKernelGGL(attn_fwd_seg_kernel<HH>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk, \
-                                      (const bf16_t*)V, ldv, skv, (bf16_t*)O, ldo, lse, sg, Nk, scale)
-    if (dtype == TC_BF16) TC_FWD(bf16_t); else TC_FWD(f16_t);
+    const dim3 grid((unsigned)B * ((sg.t32[nseg] + FW_NW - 1) / FW_NW));
+    const int wide_o = !(ldo & 7) && !((uintptr_t)O & 15);
+    static bool lds_ok[2] = {false, false};                     // the kernels use 127 KB of dynamic LDS: raise the per-function limit once
+#define TC_FWD(HH, IDX)                                                                                                                      \
+    {                                                                                                                                       \
+        if (!lds_ok[IDX]) {                                                                                                                 \
+            if (hipFuncSetAttribute((const void*)attn_fwd_seg_kernel<HH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FW_SMEM) != hipSuccess) \
+                return TC_ERR_LAUNCH;                                                                                                       \
+            lds_ok[IDX] = true;                                                                                                             \
+        }                                                                                                                                   \
+        hipLaunchKernelGGL(attn_fwd_seg_kernel<HH>, grid, dim3(FW_NT), FW_SMEM, (hipStream_t)stream, (const bf16_t*)Q, ldq, (const bf16_t*)K, \
+                           ldk, (const bf16_t*)V, ldv, skv, (bf16_t*)O, ldo, lse, sg, Nk, scale, wide_o);                                   \
+    }
+    if (dtype == TC_BF16) TC_FWD(bf16_t, 0) else TC_FWD(f16_t, 1)
 #undef TC_FWD
     return tc_launch_status();
 }
