@@ -2131,7 +2131,12 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_seg_kernel(const bf16_t* __re
 #define KB30 96
 #endif
 constexpr int NT30 = NW30 * 64, NC30 = KB30 * 8, NF30 = (2 * NC30 + NT30 - 1) / NT30, SLOT30 = 2 * KB30 * LDR, SPT30 = KB30 / 32;
+#undef FENCE
+#ifdef NOFENCE
+#define FENCE()
+#else
 #define FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 __global__ __launch_bounds__(NT30, 1) void attn_fwd_seg_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
                                                                const bf16_t* __restrict__ V, int ldv, long long skv, bf16_t* __restrict__ O,
                                                                int ldo, float* __restrict__ lse, Segs sg, int Nk, float scale) {
@@ -2247,7 +2252,6 @@ __global__ __launch_bounds__(NT30, 1) void attn_fwd_seg_kernel(const bf16_t* __r
             }
         }
         float rs = 0.f;
-        bf16x8 pn0, pn1;
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             FENCE();
@@ -2267,10 +2271,11 @@ __global__ __launch_bounds__(NT30, 1) void attn_fwd_seg_kernel(const bf16_t* __r
             FENCE();
 #pragma unroll
             for (int r = 2 * g; r < 2 * g + 2; ++r) { S[r] = fast_exp2(fmaf(S[r], qs, -m)); rs += S[r]; }
-            if (g == 3) pn0 = pack8(S, 0);
-            if (g == 7) pn1 = pack8(S, 8);
+            if (g == 3) pb0 = pack8(S, 0);                      // (the PV MFMAs that read the previous pb0 / pb1 were issued at g = 0, 2 / 4, 6)
+            if (g == 7) pb1 = pack8(S, 8);
         }
         FENCE();
+#ifndef NOSLOW
         if (__any(!(rs < 1073741824.0f))) {                     // rare: re-reference the rows (scores recomputed from the resident K tile)
             f32x16 T;
             const bf16_t* kp = kaddr(i);
@@ -2292,11 +2297,11 @@ __global__ __launch_bounds__(NT30, 1) void attn_fwd_seg_kernel(const bf16_t* __r
             rs = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { S[r] = fast_exp2(fmaf(T[r], qs, -m)); rs += S[r]; }
-            pn0 = pack8(S, 0);
-            pn1 = pack8(S, 8);
+            pb0 = pack8(S, 0);
+            pb1 = pack8(S, 8);
         }
+#endif
         lsum += rs;
-        pb0 = pn0; pb1 = pn1;
         // fragments for the next iteration: V^T of this sub-tile, K of sub-tile i + 2 (its tile was stored >= 2 iterations ago)
         load_v(i);
         if (sub == 1 && i + 2 < nsubs) __syncthreads();         // tile t + 1 (stored at sub 0) is complete: sub-tile i + 3 is its first

@@ -257,71 +257,96 @@ __global__ __launch_bounds__(FW_NT, 1) void attn_fwd_seg_kernel(const bf16_t* __
     }
 }
 
+// dQ.  Same organisation as the forward kernel: one 12-wave workgroup per CU, a 32-query tile per wave, K/V tiles double-buffered in
+// LDS behind one barrier per tile, Q / dO / dQ tiles through the wave's LDS tile as whole 128-byte rows.
+// K is stored ONCE, rows in key_row order: conflict-free both for the 16-byte fragment reads of S^T = K Q^T (row
+// key_row(pi_row(j))) and for the transpose reads of dQ^T += K^T dS^T.
 template <typename H>
-__global__ __launch_bounds__(256, 3) void attn_bwd_dq_seg_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
-                                                                 const bf16_t* __restrict__ V, int ldv, long long skv,
-                                                                 const bf16_t* __restrict__ dO, int lddo, const float* __restrict__ lse,
-                                                                 const float* __restrict__ delta, bf16_t* __restrict__ dQ, int lddq, Segs sg,
-                                                                 int Nk, float scale) {
-    __shared__ __attribute__((aligned(16))) bf16_t Ks[KB * LDR];
-    __shared__ __attribute__((aligned(16))) bf16_t Vs[KB * LDR];
+__global__ __launch_bounds__(FW_NT, 1) void attn_bwd_dq_seg_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
+                                                                   const bf16_t* __restrict__ V, int ldv, long long skv,
+                                                                   const bf16_t* __restrict__ dO, int lddo, const float* __restrict__ lse,
+                                                                   const float* __restrict__ delta, bf16_t* __restrict__ dQ, int lddq, Segs sg,
+                                                                   int Nk, float scale, int wide_o) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t fw_smem[];      // [2 slots][K tile | V tile][KB][LDR], then FW_NW wave tiles [32][LDR]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
-    // K is stored ONCE, rows in key_row order: conflict-free both for the 16-byte fragment reads of S^T = K Q^T (row
-    // key_row(pi_row(j))) and for the transpose reads of dQ^T += K^T dS^T -- two LDS tiles instead of three, three workgroups per CU,
-    // and the forward kernel's balanced tiling (32-query wave tiles numbered through the scales of an image, 768 workgroups)
-    const int nwt = sg.t32[sg.n], bpi = (nwt + 3) >> 2;
-    const int b = blockIdx.x / bpi, wt = (blockIdx.x - b * bpi) * 4 + wave;
+    const int nwt = sg.t32[sg.n], bpi = (nwt + FW_NW - 1) / FW_NW;
+    const int b = blockIdx.x / bpi, wt = (blockIdx.x - b * bpi) * FW_NW + wave;
     int sgi = 0;
 #pragma unroll
     for (int i = 1; i < 4; ++i) if (i < sg.n && wt >= sg.t32[i]) sgi = i;
     const int nq = sg.nq[sgi];
-    const int ql = (wt - sg.t32[sgi]) * 32 + j;
-    const bool ok = wt < nwt && ql < nq;
-    const long long qrow = (long long)sg.row0[sgi] + (long long)b * nq + ql;
+    const int tq0 = (wt - sg.t32[sgi]) * 32;
+    const bool live = wt < nwt, ok = live && tq0 + j < nq;
+    const long long trow0 = (long long)sg.row0[sgi] + (long long)b * nq + tq0;
+    const bf16_t* Kb = K + b * skv;
+    const bf16_t* Vb = V + b * skv;
     typedef typename TcHalf<H>::v8 V8;
+    bf16_t* wtile = fw_smem + 2 * FW_SLOT + wave * (32 * LDR);
     V8 qf[4], dof[4];
+    {   // Q, then dO, through the wave tile (coalesced rows in, fragments out)
+        uint4 qv[4], gv[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const uint4 v = ok ? *reinterpret_cast<const uint4*>(Q + qrow * ldq + 16 * ks + 8 * h) : make_uint4(0u, 0u, 0u, 0u);
-        const uint4 g = ok ? *reinterpret_cast<const uint4*>(dO + qrow * lddo + 16 * ks + 8 * h) : make_uint4(0u, 0u, 0u, 0u);
-        qf[ks] = *reinterpret_cast<const V8*>(&v);
-        dof[ks] = *reinterpret_cast<const V8*>(&g);
+        for (int i = 0; i < 4; ++i) {
+            const int r = 8 * i + (lane >> 3);
+            const bool okr = live && tq0 + r < nq;
+            qv[i] = okr ? *reinterpret_cast<const uint4*>(Q + (trow0 + r) * ldq + 8 * (lane & 7)) : make_uint4(0u, 0u, 0u, 0u);
+            gv[i] = okr ? *reinterpret_cast<const uint4*>(dO + (trow0 + r) * lddo + 8 * (lane & 7)) : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(wtile + (8 * i + (lane >> 3)) * LDR + 8 * (lane & 7)) = qv[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = ld_frag<V8>(wtile + j * LDR + 16 * ks + 8 * h);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(wtile + (8 * i + (lane >> 3)) * LDR + 8 * (lane & 7)) = gv[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) dof[ks] = ld_frag<V8>(wtile + j * LDR + 16 * ks + 8 * h);
     }
     const float qs = scale * LOG2E;
-    const float l2 = ok ? lse[qrow] * LOG2E : 0.f;
-    const float dl = ok ? delta[qrow] : 0.f;
+    const float l2 = ok ? lse[trow0 + j] * LOG2E : 0.f;
+    const float dls = ok ? delta[trow0 + j] * scale : 0.f;      // dS = P (dP scale - delta scale)
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
     const int krow = pi_row(j), kprow = key_row(krow);
-    const bf16_t* Kb = K + b * skv;
-    const bf16_t* Vb = V + b * skv;
-    uint4 kr[4], vr[4];
-    auto fetch = [&](int kb0) {
+    uint4 st[FW_NF];
+    auto fetch = [&](int kb0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int r, c8, g;
-            fill_map(tid, i, r, c8, g);
-            kr[i] = ld_row8(Kb, ldk, kb0 + r, Nk, c8);
-            vr[i] = ld_row8(Vb, ldv, kb0 + r, Nk, c8);
+        for (int i = 0; i < FW_NF; ++i) {
+            const int id = tid + i * FW_NT, isv = id >= FW_NC, r = (id - isv * FW_NC) >> 3, c8 = (id & 7) * 8;
+            const bf16_t* src = isv ? Vb : Kb;
+            const int ld = isv ? ldv : ldk;
+            st[i] = (id < 2 * FW_NC && kb0 + r < Nk) ? *reinterpret_cast<const uint4*>(src + (long long)(kb0 + r) * ld + c8) : make_uint4(0u, 0u, 0u, 0u);
         }
     };
-    fetch(0);
-    for (int kb0 = 0; kb0 < Nk; kb0 += KB) {
-        __syncthreads();
+    auto stash = [&](int slot) __attribute__((always_inline)) {
+        bf16_t* base = fw_smem + slot * FW_SLOT;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int r, c8, g;
-            fill_map(tid, i, r, c8, g);
-            *reinterpret_cast<uint4*>(&Ks[key_row(r) * LDR + c8]) = kr[i];
-            *reinterpret_cast<uint4*>(&Vs[r * LDR + c8]) = vr[i];
+        for (int i = 0; i < FW_NF; ++i) {
+            const int id = tid + i * FW_NT, isv = id >= FW_NC, r = (id - isv * FW_NC) >> 3, c8 = (id & 7) * 8;
+            if (id < 2 * FW_NC) *reinterpret_cast<uint4*>(base + isv * (KB * LDR) + (isv ? r : key_row(r)) * LDR + c8) = st[i];
         }
-        __syncthreads();
-        if (kb0 + KB < Nk) fetch(kb0 + KB);
+    };
+    const int nt = (Nk + KB - 1) / KB;
+    fetch(0);
+    stash(0);
+    if (nt > 1) fetch(KB);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int kb0 = t * KB;
+        if (t + 1 < nt) stash((t + 1) & 1);
+        if (t + 2 < nt) fetch(kb0 + 2 * KB);
+        const bf16_t* Ks = fw_smem + (t & 1) * FW_SLOT;
+        const bf16_t* Vs = Ks + KB * LDR;
+        const int nsub = min(KB / 32, (Nk - kb0 + 31) / 32);
 #pragma unroll 1
-        for (int sub = 0; sub < KB / 32; ++sub) {
+        for (int sub = 0; sub < nsub; ++sub) {
             const int kv0 = kb0 + 32 * sub;
-            if (kv0 >= Nk) break;
             f32x16 s, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -332,12 +357,12 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_seg_kernel(const bf16_t* _
                 s = TcHalf<H>::mfma(ld_frag<V8>(kp + 16 * ks), qf[ks], s);
                 dp = TcHalf<H>::mfma(ld_frag<V8>(vp + 16 * ks), dof[ks], dp);
             }
-            const bool tail = kv0 + 32 > Nk;
+            const bool tail = kv0 + 32 > Nk;                    // keys past Nk were staged as zeros: P is forced to 0 for them
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float p = fast_exp2(fmaf(s[r], qs, -l2));
                 if (tail && kv0 + 16 * h + r >= Nk) p = 0.f;
-                s[r] = p * (dp[r] - dl) * scale;
+                s[r] = p * fmaf(dp[r], scale, -dls);
             }
             const int gi = lane & 15, gq = (lane >> 4) & 1;
             const bf16_t* kt = Ks + (32 * sub + 16 * h + 4 * (gi >> 2)) * LDR + 16 * gq + 4 * (gi & 3);
@@ -348,9 +373,24 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_seg_kernel(const bf16_t* _
                 acc1 = TcHalf<H>::mfma(ld_frag_tr<V8>(kt + (2 * k2) * LDR + 32, kt + (2 * k2 + 1) * LDR + 32), db, acc1);
             }
         }
+        __syncthreads();
     }
-    if (ok) {
-        bf16_t* row = dQ + qrow * lddq;
+    if (wide_o) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            st4<H>(reinterpret_cast<H*>(wtile + j * LDR + 8 * g + 4 * h), make_float4(acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]));
+            st4<H>(reinterpret_cast<H*>(wtile + j * LDR + 32 + 8 * g + 4 * h), make_float4(acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 8 * i + (lane >> 3);
+            const uint4 v = *reinterpret_cast<const uint4*>(wtile + r * LDR + 8 * (lane & 7));
+            if (live && tq0 + r < nq) *reinterpret_cast<uint4*>(dQ + (trow0 + r) * lddq + 8 * (lane & 7)) = v;
+        }
+    } else if (ok) {
+        bf16_t* row = dQ + (trow0 + j) * lddq;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             st4<H>(reinterpret_cast<H*>(row + 8 * g + 4 * h), make_float4(acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]));
@@ -371,16 +411,17 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16
                                                                     const bf16_t* __restrict__ dO, int lddo, const float* __restrict__ lse,
                                                                     const float* __restrict__ delta, float* __restrict__ dkv32, Segs sg, int Nk,
                                                                     float scale, int tiles_per_chunk) {
-    constexpr int QS = 64, LDQ = D + 8, LDT = QS + 16;          // LDT: 160-byte rows = 40 words (8 mod 32), see st_t8
-    constexpr int STAGE_B = (2 * QS * LDQ + 2 * D * LDT) * 2 + 2 * QS * 4;
+    constexpr int QS = 64, LDQ = D + 8;
+    // Q and dO of a stage are stored ONCE, row-major with the rows of every 16-row group 4x4-transposed (key_row): conflict-free both
+    // for the 16-byte fragment reads of S = Q K^T / dP = dO V^T and for the hardware transpose reads (ds_read_b64_tr_b16) that gather
+    // the dO^T / Q^T operands of the dV^T / dK^T products -- the first version kept transposed copies written with 2-byte stores
+    constexpr int STAGE_B = 2 * QS * LDQ * 2 + 2 * QS * 4;
     constexpr int RED_B = NW * D * 33 * 4;
     constexpr int SMEM_B = STAGE_B > RED_B ? STAGE_B : RED_B;
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_B];
     bf16_t* Qs = reinterpret_cast<bf16_t*>(smem);
     bf16_t* dOs = Qs + QS * LDQ;
-    bf16_t* Qt = dOs + QS * LDQ;
-    bf16_t* dOt = Qt + D * LDT;
-    float* lss = reinterpret_cast<float*>(dOt + D * LDT);
+    float* lss = reinterpret_cast<float*>(dOs + QS * LDQ);
     float* dls = lss + QS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
     const int b = blockIdx.y, kv0 = (blockIdx.x * NW + wave) * 32, key = min(kv0 + j, Nk - 1);
@@ -443,10 +484,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 int r, c8, g; fmap(i, r, c8, g);
-                *reinterpret_cast<uint4*>(&Qs[r * LDQ + c8]) = qr[i];
-                *reinterpret_cast<uint4*>(&dOs[r * LDQ + c8]) = gr[i];
-                st_t8(Qt, LDT, c8, r, qr[i], g);
-                st_t8(dOt, LDT, c8, r, gr[i], g);
+                *reinterpret_cast<uint4*>(&Qs[key_row(r) * LDQ + c8]) = qr[i];
+                *reinterpret_cast<uint4*>(&dOs[key_row(r) * LDQ + c8]) = gr[i];
             }
         }
         if (tid < QS) { lss[tid] = lr; dls[tid] = dr; }
@@ -457,8 +496,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16
             f32x16 s, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-            const bf16_t* qp = Qs + (32 * qt + qrow) * LDQ + 8 * h;
-            const bf16_t* gp = dOs + (32 * qt + qrow) * LDQ + 8 * h;
+            const bf16_t* qp = Qs + (32 * qt + key_row(qrow)) * LDQ + 8 * h;
+            const bf16_t* gp = dOs + (32 * qt + key_row(qrow)) * LDQ + 8 * h;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 s = TcHalf<H>::mfma(ld_frag<V8>(qp + 16 * ks), kf[ks], s);
@@ -471,15 +510,16 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16
                 dp[r] = p * (dp[r] - dls[qi]) * scale;
                 s[r] = p;
             }
-            const bf16_t* gt = dOt + j * LDT + 32 * qt + 16 * h;
-            const bf16_t* qtp = Qt + j * LDT + 32 * qt + 16 * h;
+            const int gi = lane & 15, gq = (lane >> 4) & 1, toff = (32 * qt + 16 * h + 4 * (gi >> 2)) * LDQ + 16 * gq + 4 * (gi & 3);
+            const bf16_t* gt = dOs + toff;
+            const bf16_t* qtp = Qs + toff;
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2) {
                 const V8 pb = pack8<H>(s, 8 * k2), db = pack8<H>(dp, 8 * k2);
-                dv0 = TcHalf<H>::mfma(ld_frag<V8>(gt + 8 * k2), pb, dv0);
-                dv1 = TcHalf<H>::mfma(ld_frag<V8>(gt + 32 * LDT + 8 * k2), pb, dv1);
-                dk0 = TcHalf<H>::mfma(ld_frag<V8>(qtp + 8 * k2), db, dk0);
-                dk1 = TcHalf<H>::mfma(ld_frag<V8>(qtp + 32 * LDT + 8 * k2), db, dk1);
+                dv0 = TcHalf<H>::mfma(ld_frag_tr<V8>(gt + (2 * k2) * LDQ, gt + (2 * k2 + 1) * LDQ), pb, dv0);
+                dv1 = TcHalf<H>::mfma(ld_frag_tr<V8>(gt + (2 * k2) * LDQ + 32, gt + (2 * k2 + 1) * LDQ + 32), pb, dv1);
+                dk0 = TcHalf<H>::mfma(ld_frag_tr<V8>(qtp + (2 * k2) * LDQ, qtp + (2 * k2 + 1) * LDQ), db, dk0);
+                dk1 = TcHalf<H>::mfma(ld_frag_tr<V8>(qtp + (2 * k2) * LDQ + 32, qtp + (2 * k2 + 1) * LDQ + 32), db, dk1);
             }
         }
     }
@@ -618,19 +658,26 @@ extern "C" int tc_attn_bwd_seg(const void* Q, int ldq, const void* K, int ldk, c
     int tpc = (ntiles + zs - 1) / zs;
     tpc = (tpc + 1) & ~1;                                            // whole 64-query stages
     zs = (ntiles + tpc - 1) / tpc;
-#define TC_BWD(HH)                                                                                                                          \
+    const int wide_dq = !(lddq & 7) && !((uintptr_t)dQ & 15);
+    static bool lds_ok[2] = {false, false};
+#define TC_BWD(HH, IDX)                                                                                                                     \
     {                                                                                                                                       \
+        if (!lds_ok[IDX]) {                                                                                                                 \
+            if (hipFuncSetAttribute((const void*)attn_bwd_dq_seg_kernel<HH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FW_SMEM) != hipSuccess) \
+                return TC_ERR_LAUNCH;                                                                                                       \
+            lds_ok[IDX] = true;                                                                                                             \
+        }                                                                                                                                   \
         hipLaunchKernelGGL(delta_rows_kernel<HH>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const bf16_t*)O, ldo, (const bf16_t*)dO, \
                            lddo, delta, rows);                                                                                              \
         hipLaunchKernelGGL((attn_bwd_dkv_seg_kernel<HH, 4>), dim3(kb, B, zs), dim3(256), 0, s, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk,    \
                            (const bf16_t*)V, ldv, skv, (const bf16_t*)dO, lddo, lse, delta, dkv32, sg, Nk, scale, tpc);                     \
         hipLaunchKernelGGL(attn_dkv_store_kernel<HH>, dim3(tc_blocks((long long)B * Nk * 32, 256, 1024)), dim3(256), 0, s, dkv32,           \
                            (bf16_t*)dK, lddk, (bf16_t*)dV, lddv, sdkv, B, Nk);                                                              \
-        hipLaunchKernelGGL(attn_bwd_dq_seg_kernel<HH>, dim3((unsigned)B * ((sg.t32[nseg] + 3) / 4)), dim3(256), 0, s, (const bf16_t*)Q, ldq, \
-                           (const bf16_t*)K, ldk, (const bf16_t*)V, ldv, skv, (const bf16_t*)dO, lddo, lse, delta, (bf16_t*)dQ, lddq, sg, Nk, \
-                           scale);                                                                                                          \
+        hipLaunchKernelGGL(attn_bwd_dq_seg_kernel<HH>, dim3((unsigned)B * ((sg.t32[nseg] + FW_NW - 1) / FW_NW)), dim3(FW_NT), FW_SMEM, s,     \
+                           (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk, (const bf16_t*)V, ldv, skv, (const bf16_t*)dO, lddo, lse, delta,    \
+                           (bf16_t*)dQ, lddq, sg, Nk, scale, wide_dq);                                                                      \
     }
-    if (dtype == TC_BF16) TC_BWD(bf16_t) else TC_BWD(f16_t)
+    if (dtype == TC_BF16) TC_BWD(bf16_t, 0) else TC_BWD(f16_t, 1)
 #undef TC_BWD
     return tc_launch_status();
 }
