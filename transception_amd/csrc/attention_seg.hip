@@ -474,7 +474,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16
             locate(t0 + (tid >> 5), base, valid);
             const bool okr = (tid & 31) < valid;
             lr = okr ? lse[base + (tid & 31)] * LOG2E : 1.0e30f;          // rows past the end: P = exp2(s - 1e30) = 0
-            dr = okr ? delta[base + (tid & 31)] : 0.f;
+            dr = okr ? delta[base + (tid & 31)] * scale : 0.f;
         }
     };
     if (t_begin < t_end) fetch(t_begin);
@@ -503,11 +503,19 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16
                 s = TcHalf<H>::mfma(ld_frag<V8>(qp + 16 * ks), kf[ks], s);
                 dp = TcHalf<H>::mfma(ld_frag<V8>(gp + 16 * ks), vf[ks], dp);
             }
+            // the 16 log-sum-exps and (scaled) deltas of this lane's query rows: four 16-byte LDS reads each instead of 16 scalar ones
+            float lq[16], dq[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 a = *reinterpret_cast<const float4*>(lss + 32 * qt + 16 * h + 4 * g);
+                const float4 c = *reinterpret_cast<const float4*>(dls + 32 * qt + 16 * h + 4 * g);
+                lq[4 * g] = a.x; lq[4 * g + 1] = a.y; lq[4 * g + 2] = a.z; lq[4 * g + 3] = a.w;
+                dq[4 * g] = c.x; dq[4 * g + 1] = c.y; dq[4 * g + 2] = c.z; dq[4 * g + 3] = c.w;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int qi = 32 * qt + 16 * h + r;
-                const float p = fast_exp2(fmaf(s[r], qs, -lss[qi]));
-                dp[r] = p * (dp[r] - dls[qi]) * scale;
+                const float p = fast_exp2(fmaf(s[r], qs, -lq[r]));
+                dp[r] = p * fmaf(dp[r], scale, -dq[r]);          // dS = P (dP - delta) scale, delta pre-multiplied by scale at staging
                 s[r] = p;
             }
             const int gi = lane & 15, gq = (lane >> 4) & 1, toff = (32 * qt + 16 * h + 4 * (gi >> 2)) * LDQ + 16 * gq + 4 * (gi & 3);
