@@ -449,13 +449,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16
         base = (long long)sg.row0[s] + (long long)b * sg.nq[s] + q0;
         valid = (t < t_end) ? min(32, sg.nq[s] - q0) : 0;
     };
-    // staging (threads 0..255): strip (row r of the stage, 8 channels from c8); lanes 0-15 take 16 consecutive rows (st_t8)
+    // staging (threads 0..255): 16-byte chunk c8 of row r of the 64-query stage
     const bool stager = tid < 256;
     uint4 qr[2], gr[2];
     float lr = 0.f, dr = 0.f;
-    auto fmap = [&](int it, int& r, int& c8, int& g) {
-        const int c = wave * 2 + it;
-        g = lane >> 4; r = 16 * (c >> 1) + (lane & 15); c8 = 32 * (c & 1) + 8 * g;
+    auto fmap = [&](int it, int& r, int& c8, int& g) {           // eight lanes x 16 bytes cover one 128-byte row: whole lines per request
+        const int idx = it * 256 + tid;
+        g = 0; r = idx >> 3; c8 = (idx & 7) * 8;
     };
     auto fetch = [&](int t0) {
         if (stager) {
