@@ -568,14 +568,38 @@ __global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, lo
         reinterpret_cast<float4*>(p)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// delta[row] = sum_d O[row][d] dO[row][d]: eight lanes x 16 bytes per 128-byte row (the first version read 2 bytes per lane)
 template <typename H>
 __global__ __launch_bounds__(256) void delta_rows_kernel(const bf16_t* __restrict__ O, int ldo, const bf16_t* __restrict__ dO, int lddo,
-                                                         float* __restrict__ delta, long long rows) {
+                                                         float* __restrict__ delta, long long rows, int wide) {
+    if (wide) {
+        const long long row = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
+        const int c8 = (threadIdx.x & 7) * 8;
+        float s = 0.f;
+        if (row < rows) {
+            const uint4 a = *reinterpret_cast<const uint4*>(O + row * ldo + c8), g = *reinterpret_cast<const uint4*>(dO + row * lddo + c8);
+            const unsigned aw[4] = {a.x, a.y, a.z, a.w}, gw[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float a0, a1, g0, g1;
+                unpack2<H>(aw[i], a0, a1);
+                unpack2<H>(gw[i], g0, g1);
+                s = fmaf(a0, g0, fmaf(a1, g1, s));
+            }
+        }
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        if (row < rows && (threadIdx.x & 7) == 0) delta[row] = s;
+        return;
+    }
     const int lane = threadIdx.x & 63;
-    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const float s = wave_sum(ldf<H>(reinterpret_cast<const H*>(O + row * ldo + lane)) * ldf<H>(reinterpret_cast<const H*>(dO + row * lddo + lane)));
-    if (lane == 0) delta[row] = s;
+    for (int w = 0; w < 8; ++w) {
+        const long long row = (long long)blockIdx.x * 32 + (threadIdx.x >> 6) * 8 + w;
+        if (row >= rows) return;
+        const float s = wave_sum(ldf<H>(reinterpret_cast<const H*>(O + row * ldo + lane)) * ldf<H>(reinterpret_cast<const H*>(dO + row * lddo + lane)));
+        if (lane == 0) delta[row] = s;
+    }
 }
 
 bool make_segs(Segs& sg, int B, int nseg, const int* nq, long long& total_rows) {
@@ -667,6 +691,7 @@ extern "C" int tc_attn_bwd_seg(const void* Q, int ldq, const void* K, int ldk, c
     tpc = (tpc + 1) & ~1;                                            // whole 64-query stages
     zs = (ntiles + tpc - 1) / tpc;
     const int wide_dq = !(lddq & 7) && !((uintptr_t)dQ & 15);
+    const int wide_rows = !((ldo | lddo) & 7) && !(((uintptr_t)O | (uintptr_t)dO) & 15);
     static bool lds_ok[2] = {false, false};
 #define TC_BWD(HH, IDX)                                                                                                                     \
     {                                                                                                                                       \
@@ -675,8 +700,8 @@ extern "C" int tc_attn_bwd_seg(const void* Q, int ldq, const void* K, int ldk, c
                 return TC_ERR_LAUNCH;                                                                                                       \
             lds_ok[IDX] = true;                                                                                                             \
         }                                                                                                                                   \
-        hipLaunchKernelGGL(delta_rows_kernel<HH>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const bf16_t*)O, ldo, (const bf16_t*)dO, \
-                           lddo, delta, rows);                                                                                              \
+        hipLaunchKernelGGL(delta_rows_kernel<HH>, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, s, (const bf16_t*)O, ldo, (const bf16_t*)dO, \
+                           lddo, delta, rows, wide_rows);                                                                                   \
         hipLaunchKernelGGL((attn_bwd_dkv_seg_kernel<HH, 4>), dim3(kb, B, zs), dim3(256), 0, s, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk,    \
                            (const bf16_t*)V, ldv, skv, (const bf16_t*)dO, lddo, lse, delta, dkv32, sg, Nk, scale, tpc);                     \
         hipLaunchKernelGGL(attn_dkv_store_kernel<HH>, dim3(tc_blocks((long long)B * Nk * 32, 256, 1024)), dim3(256), 0, s, dkv32,           \
