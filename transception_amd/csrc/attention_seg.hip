@@ -415,14 +415,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16
     // Q and dO of a stage are stored ONCE, row-major with the rows of every 16-row group 4x4-transposed (key_row): conflict-free both
     // for the 16-byte fragment reads of S = Q K^T / dP = dO V^T and for the hardware transpose reads (ds_read_b64_tr_b16) that gather
     // the dO^T / Q^T operands of the dV^T / dK^T products -- the first version kept transposed copies written with 2-byte stores
-    constexpr int STAGE_B = 2 * QS * LDQ * 2 + 2 * QS * 4;
+    // two stage buffers: the next 64-query stage is stored (from registers loaded a stage earlier) while the current one is consumed,
+    // so a stage costs ONE barrier
+    constexpr int STAGE_E = 2 * QS * LDQ + 2 * QS * 2;          // bf16 elements per buffer: Q | dO | lse (fp32) | delta (fp32)
+    constexpr int STAGE_B = 2 * STAGE_E * 2;
     constexpr int RED_B = NW * D * 33 * 4;
     constexpr int SMEM_B = STAGE_B > RED_B ? STAGE_B : RED_B;
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_B];
-    bf16_t* Qs = reinterpret_cast<bf16_t*>(smem);
-    bf16_t* dOs = Qs + QS * LDQ;
-    float* lss = reinterpret_cast<float*>(dOs + QS * LDQ);
-    float* dls = lss + QS;
+    bf16_t* const sbase = reinterpret_cast<bf16_t*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
     const int b = blockIdx.y, kv0 = (blockIdx.x * NW + wave) * 32, key = min(kv0 + j, Nk - 1);
     typedef typename TcHalf<H>::v8 V8;
@@ -477,20 +477,34 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16
             dr = okr ? delta[base + (tid & 31)] * scale : 0.f;
         }
     };
-    if (t_begin < t_end) fetch(t_begin);
-    for (int t0 = t_begin; t0 < t_end; t0 += 2) {
-        __syncthreads();
+    auto stash = [&](int buf) {
+        bf16_t* Qw = sbase + buf * STAGE_E;
+        bf16_t* dOw = Qw + QS * LDQ;
+        float* lw = reinterpret_cast<float*>(dOw + QS * LDQ);
         if (stager) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 int r, c8, g; fmap(i, r, c8, g);
-                *reinterpret_cast<uint4*>(&Qs[key_row(r) * LDQ + c8]) = qr[i];
-                *reinterpret_cast<uint4*>(&dOs[key_row(r) * LDQ + c8]) = gr[i];
+                *reinterpret_cast<uint4*>(&Qw[key_row(r) * LDQ + c8]) = qr[i];
+                *reinterpret_cast<uint4*>(&dOw[key_row(r) * LDQ + c8]) = gr[i];
             }
         }
-        if (tid < QS) { lss[tid] = lr; dls[tid] = dr; }
-        __syncthreads();
-        if (t0 + 2 < t_end) fetch(t0 + 2);
+        if (tid < QS) { lw[tid] = lr; lw[QS + tid] = dr; }
+    };
+    if (t_begin < t_end) {
+        fetch(t_begin);
+        stash(0);
+        if (t_begin + 2 < t_end) fetch(t_begin + 2);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int t0 = t_begin; t0 < t_end; t0 += 2, buf ^= 1) {
+        if (t0 + 2 < t_end) stash(buf ^ 1);                     // (every wave left stage t0 - 2, that buffer's last reader, at the barrier below)
+        if (t0 + 4 < t_end) fetch(t0 + 4);
+        const bf16_t* Qs = sbase + buf * STAGE_E;
+        const bf16_t* dOs = Qs + QS * LDQ;
+        const float* lss = reinterpret_cast<const float*>(dOs + QS * LDQ);
+        const float* dls = lss + QS;
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
             f32x16 s, dp;
@@ -530,6 +544,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16
                 dk1 = TcHalf<H>::mfma(ld_frag_tr<V8>(qtp + (2 * k2) * LDQ + 32, qtp + (2 * k2 + 1) * LDQ + 32), db, dk1);
             }
         }
+        __syncthreads();
     }
     // each wave owns its keys: transpose its [d][key] accumulators through LDS so that the atomics run along d (coalesced)
     float* red = reinterpret_cast<float*>(smem) + wave * (D * 33);
