@@ -6,6 +6,10 @@
 #include <cstdlib>
 
 namespace {
+// workgroups a weight-gradient launch aims for (A/B switches; defaults = one tile walker per CU)
+inline int tc_dw_wg_target() { static const int v = getenv("TC_DW_WG") ? atoi(getenv("TC_DW_WG")) : 256; return v; }
+inline int tc_mid_wg_target() { static const int v = getenv("TC_MID_WG") ? atoi(getenv("TC_MID_WG")) : 256; return v; }
+
 
 template <typename T, int K, bool BWD>
 __global__ __launch_bounds__(256) void dw_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ w,
@@ -818,7 +822,7 @@ int launch_tile(const void* src, int lds_, const void* w, const void* bias, void
     if (ntiles > 0x7fffffffLL) return TC_ERR_ARG;
 #define TC_TILE(KK, CGG)                                                                                                                \
     if (MODE == 2) {                                                                                                                    \
-        int gx = 256 / (chunks * groups);   /* measured best with the fold: one workgroup per CU, each visiting ~7 tiles */ /* contended fp32 atomics cost ~0.13 us each: few contributors per word */          \
+        int gx = tc_dw_wg_target() / (chunks * groups);   /* measured best with the fold: one workgroup per CU, each visiting ~7 tiles */ /* contended fp32 atomics cost ~0.13 us each: few contributors per word */          \
         if (gx > ntiles) gx = (int)ntiles;                                                                                              \
         constexpr int NTC = ((KK) * (KK) + 1) * (CGG) * VEC;                                                                            \
         float* wp = nullptr; int* wc = nullptr;                                                                                         \
@@ -949,7 +953,7 @@ int launch_multi(const TcDwSeg* segs, int nseg, int mode, int add_input, int acc
         if (mode == 2) {
             // ~256 workgroups in total, shared out in proportion to each segment's tiles x chunks (an even split gave the 56x56
             // map of a bridge layer 16 workgroups of 28 tiles each next to 1-tile workgroups of the 7x7 map)
-            long long gx = (long long)(256.0 * (double)ntiles * (g.k + 2) / (double)(total_work > 0 ? total_work : 1) / groups + 0.5);
+            long long gx = (long long)((double)tc_dw_wg_target() * (double)ntiles * (g.k + 2) / (double)(total_work > 0 ? total_work : 1) / groups + 0.5);
             gx = gx < 1 ? 1 : (gx > ntiles ? ntiles : gx);
             d.gx = (int)gx;
             const long long nt_ch = (long long)(g.k * g.k + 1) * d.cg * VEC;
@@ -1313,7 +1317,7 @@ int launch_ffn_mid_bwd(const TcFfnSeg* segs, int nseg, int groups, long long wst
         d.tilesW = (g.W + 15) / 16; d.tilesH = (g.H + D::TH - 1) / D::TH;
         const long long ntiles = (long long)g.B * d.tilesW * d.tilesH;
         // ~256 workgroups in total (one per CU), shared out by tiles x chunks; every channel chunk gets gx tile walkers
-        long long gx = (long long)(256.0 * (double)ntiles / (double)(total_work > 0 ? total_work : 1) / groups + 0.5);
+        long long gx = (long long)((double)tc_mid_wg_target() * (double)ntiles / (double)(total_work > 0 ? total_work : 1) / groups + 0.5);
         gx = gx < 1 ? 1 : (gx > ntiles ? ntiles : gx);
         d.gx = (int)gx;
         d.wsc = have_ws ? reinterpret_cast<int*>(ws) + cnts : nullptr;
