@@ -322,6 +322,20 @@ def side_figures(args, dev, model, loss_fn, opt, step, x, y, build_model, engine
         train_step(model, loss_fn, opt, x, y, None)
     torch.cuda.synchronize(dev)
     prof, engine.PROFILE = engine.PROFILE, None
+    # what an event pair around a launch reports for a kernel that does nothing, on an idle queue (the instrumented steps are eager and
+    # host-bound, so every timed launch starts on an idle GPU): dispatch + event overhead included in every in-step figure below
+    from transception_amd._lib import lib as _libf
+    _L, _one = _libf(), torch.zeros(64, device=dev)
+    _fl = []
+    for _ in range(24):
+        torch.cuda.synchronize(dev)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        _L.tc_fill_f32(_one.data_ptr(), 64, 0.0, torch.cuda.current_stream().cuda_stream)
+        b.record()
+        torch.cuda.synchronize(dev)
+        _fl.append(a.elapsed_time(b) * 1e3)
+    event_floor_us = statistics.median(_fl[4:])
     c0 = _Lib.calls
     train_step(model, loss_fn, opt, x, y, None)
     extra["c_abi_calls_per_step"] = _Lib.calls - c0
@@ -334,7 +348,10 @@ def side_figures(args, dev, model, loss_fn, opt, step, x, y, build_model, engine
         ach = fl / (ms * 1e-3) / 1e12
         return {"bound": "mfma", "kernel": kernel, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                 "launches": len(ev), "avg_launch_us": 1e3 * ms / len(ev), "algorithmic_flops_per_launch": fl / len(ev),
-                "how": "HIP events around each launch inside 3 instrumented training steps of the benchmarked workload (in-step)"}
+                "event_pair_floor_us": event_floor_us,
+                "how": "HIP events around each launch inside 3 instrumented (eager) training steps of the benchmarked workload; an event "
+                       "pair around an empty kernel on the idle queue reads event_pair_floor_us, which every in-step figure includes -- the "
+                       "kernel's own duration is roofline_graph_replay / the rocprofv3 average in profiles/"}
     if prof.get("attn_fwd"):
         r = mfma_block(prof["attn_fwd"], "attn_fwd_seg_kernel (bridge SR-attention forward, QK^T + softmax + PV fused, all 4 scales x B "
                                          "images in one launch)")
