@@ -1240,7 +1240,18 @@ __global__ __launch_bounds__(NT30, 1) void attn_fwd_seg_kernel(const bf16_t* __r
             }
         };
         const int nsub = min((KB30 + 31) / 32, (min(Nk, kb0 + KB30) - kb0 + 31) / 32);
-#if 1
+#ifdef PAIRSUB
+        {   // two sub-tiles' QK^T chains back to back, then their softmax / PV: one MFMA -> VALU drain per pair
+            int sub = 0;
+#pragma unroll 1
+            for (; sub + 1 < nsub; sub += 2) {
+                const f32x16 s0 = qk(sub), s1 = qk(sub + 1);
+                softmax_pv(s0, sub);
+                softmax_pv(s1, sub + 1);
+            }
+            if (sub < nsub) softmax_pv(qk(sub), sub);
+        }
+#elif 1
 #pragma unroll 1
         for (int sub = 0; sub < nsub; ++sub) {
 #ifdef ROTPRIO

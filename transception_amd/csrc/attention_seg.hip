@@ -14,7 +14,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
-constexpr int D = 64, KB = 128, LDR = D + 8, LDTB = KB + 16;   // LDTB: 288-byte rows = 72 words (8 mod 32), see st_t8
+constexpr int D = 64, KB = 128, LDR = D + 8;   // LDR: 144-byte rows = 36 words (4 mod 32)
 #define LOG2E 1.4426950408889634f
 #define LN2 0.6931471805599453f
 #define NEG_BIG (-1.0e30f)
@@ -24,8 +24,7 @@ struct Segs {
     int n;
     int nq[4];        // queries per image in the segment
     int row0[4];      // first row of the segment in the stage-major buffers
-    int tile0[5];     // prefix sums of B * ceil(nq/128)   (forward / dQ tiling)
-    int t32[5];       // prefix sums of ceil(nq/32)        (dK/dV per-image query tiles)
+    int t32[5];       // prefix sums of ceil(nq/32): the 32-query wave tiles of an image, numbered through its segments
 };
 
 __device__ __forceinline__ int pi_row(int i) { return 16 * ((i >> 2) & 1) + (i & 3) + 4 * (i >> 3); }
@@ -37,38 +36,11 @@ template <typename H> __device__ __forceinline__ typename TcHalf<H>::v8 pack8(co
     for (int i = 0; i < 8; ++i) r[i] = (typename TcHalf<H>::e)v[o + i];
     return r;
 }
-__device__ __forceinline__ uint4 ld_row8(const bf16_t* base, int ld, int row, int nrows, int c8) {
-    return row < nrows ? *reinterpret_cast<const uint4*>(base + (long long)row * ld + c8) : make_uint4(0u, 0u, 0u, 0u);
-}
-// Transposed LDS store of one 8-element strip: dst[(c8+i)*ldt + col] = v[i].  A wave stores 16 consecutive `col`s (lanes
-// 0-15) for four strips c8 = 8g (g = lane>>4).  The element order is rotated by g so that the four lane groups hit rows
-// that differ mod 4; with a row stride of 8 (mod 32) words their 8-word spans then fall on disjoint banks.
-__device__ __forceinline__ void st_t8(bf16_t* dst, int ldt, int c8, int col, uint4 v, int g) {
-    // w = v rotated right by g elements (register-only: a dynamically indexed union goes through scratch memory)
-    const bool ds = (g & 2) != 0;
-    const unsigned sh = (g & 1) * 16;
-    const unsigned a0 = ds ? v.y : v.x, a1 = ds ? v.z : v.y, a2 = ds ? v.w : v.z, a3 = ds ? v.x : v.w;
-    unsigned w[4];
-    w[0] = __builtin_amdgcn_alignbit(a1, a0, sh); w[1] = __builtin_amdgcn_alignbit(a2, a1, sh);
-    w[2] = __builtin_amdgcn_alignbit(a3, a2, sh); w[3] = __builtin_amdgcn_alignbit(a0, a3, sh);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int ii = (i + g) & 7;
-        dst[(c8 + ii) * ldt + col] = (bf16_t)((i & 1) ? (w[i >> 1] >> 16) : (w[i >> 1] & 0xffffu));
-    }
-}
-// strip owned by a thread in a 128-key x 64-d fill: wave w, iteration it -> 16 keys x 32 d
-__device__ __forceinline__ void fill_map(int tid, int it, int& r, int& c8, int& g) {
-    const int lane = tid & 63, c = (tid >> 6) * 4 + it;
-    g = lane >> 4;
-    r = 16 * (c >> 1) + (lane & 15);
-    c8 = 32 * (c & 1) + 8 * g;
-}
 // [keys][d] tiles kept row-major in LDS and consumed as MFMA A-operands with keys as the k index are gathered by the hardware
 // transpose read: lane i of a 16-lane group hands in the address of key row (i >> 2) of a 4-key block, d columns 4 (i & 3).., and
 // receives column i.  With 144-byte rows the 4 rows of a read must lie 4 rows apart to start 16 banks apart, so the keys of every
 // 16-key group are stored 4x4-transposed (row = (key & ~15) | (key & 3) << 2 | (key >> 2) & 3): conflict-free, one 16-byte LDS
-// store per strip instead of eight 2-byte ones (st_t8).
+// store per strip instead of eight 2-byte transposed ones.
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef short s16x8_t __attribute__((ext_vector_type(8)));
 template <typename V8> __device__ __forceinline__ V8 ld_frag_tr(const bf16_t* lo, const bf16_t* hi) {
@@ -78,19 +50,6 @@ template <typename V8> __device__ __forceinline__ V8 ld_frag_tr(const bf16_t* lo
 }
 __device__ __forceinline__ int key_row(int r) { return (r & ~15) | ((r & 3) << 2) | ((r >> 2) & 3); }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
-
-// block -> (segment, image, first query row of the tile, queries valid in the tile's segment-image)
-__device__ __forceinline__ void locate_tile(const Segs& sg, int t, int& row_base, int& q_local0, int& nq, int& b) {
-    int s = 0;
-#pragma unroll
-    for (int i = 1; i < 4; ++i) if (i < sg.n && t >= sg.tile0[i]) s = i;
-    const int local = t - sg.tile0[s];
-    nq = sg.nq[s];
-    const int tiles = (nq + 127) >> 7;
-    b = local / tiles;
-    q_local0 = (local - b * tiles) * 128;
-    row_base = sg.row0[s] + b * nq;
-}
 
 // Forward.  ONE workgroup of FW_NW = 12 waves per CU; each wave owns a 32-query tile (the tiles are numbered through the four scales of
 // an image: 190 per image at 224^2 = 16 workgroups per image = 256 at B = 16, one per CU).
@@ -621,7 +580,6 @@ bool make_segs(Segs& sg, int B, int nseg, const int* nq, long long& total_rows) 
     if (nseg < 1 || nseg > 4) return false;
     sg.n = nseg;
     int row = 0;
-    sg.tile0[0] = 0;
     sg.t32[0] = 0;
     for (int i = 0; i < 4; ++i) {
         const int n = i < nseg ? nq[i] : 0;
@@ -629,7 +587,6 @@ bool make_segs(Segs& sg, int B, int nseg, const int* nq, long long& total_rows) 
         sg.nq[i] = n;
         sg.row0[i] = row;
         row += B * n;
-        sg.tile0[i + 1] = sg.tile0[i] + B * ((n + 127) / 128);
         sg.t32[i + 1] = sg.t32[i] + (n + 31) / 32;
     }
     total_rows = row;

@@ -2,11 +2,16 @@
 // HBM-bound kernels: one wavefront per LayerNorm row with the row held in registers (two-pass statistics via
 // wave shuffles); BatchNorm statistics as deterministic per-chunk partials that the apply kernel folds itself.
 #include "tc_common.h"
+#include <cstdlib>
 
 namespace {
 
 constexpr int LN_MAXC = 2048;
 constexpr int LN_BWD_MAX_BLOCKS = 1024, LN_BWD_ROWS_PER_GROUP = 4;   // fused dx + parameter-gradient launch
+inline int ln_bwd_blocks() {   // A/B switch (<= LN_BWD_MAX_BLOCKS, which sizes the scratch)
+    static const int v = getenv("TC_LN_BWD_BLOCKS") ? atoi(getenv("TC_LN_BWD_BLOCKS")) : LN_BWD_MAX_BLOCKS;
+    return v < 16 ? 16 : (v > LN_BWD_MAX_BLOCKS ? LN_BWD_MAX_BLOCKS : v);
+}
 
 // ---------------------------------------------------------------------------------------------- LayerNorm
 // A group of GS lanes (16 / 32 / 64) owns one row, each lane NV float4s of it; a 256-thread block therefore works on
@@ -536,7 +541,7 @@ static int ln_bwd_impl(const void* dy, int lddy, const void* x, int ldx, const v
         int rpg = dgamma ? rows / ((256 / GS) * 512) : 1;            /* rows per lane group: >= 512 workgroups before rows are stacked */ \
         rpg = rpg < 1 ? 1 : (rpg > LN_BWD_ROWS_PER_GROUP ? LN_BWD_ROWS_PER_GROUP : rpg);                                                    \
         if (ilp && rpg < RPT) rpg = RPT;                                                                                                  \
-        nblk = tc_blocks(rows, (256 / GS) * rpg, dgamma ? LN_BWD_MAX_BLOCKS : 8192);                                                        \
+        nblk = tc_blocks(rows, (256 / GS) * rpg, dgamma ? ln_bwd_blocks() : 8192);                                                        \
         partial = (dgamma && scratch && (uintptr_t)scratch % 16 == 0 && scratch_floats >= 4096 + (long long)groups * nblk * 2 * C &&      \
                    (long long)groups * ((nblk + 15) / 16) <= 4096) ? scratch + 4096 : nullptr;                                            \
         if (ilp) TC_LNB_LAUNCH(GS, NV, RPT); else TC_LNB_LAUNCH(GS, NV, 1); }
