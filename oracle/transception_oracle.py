@@ -42,10 +42,15 @@ class TransCeptionOracle:
     HEADS = 8
     CRPE_WINDOW = ((3, 2), (5, 3), (7, 3))   # (kernel, heads)       (MSTr.py:958)
 
-    def __init__(self, params: Dict[str, Tensor], num_classes: int = 9, training: bool = True):
+    def __init__(self, params: Dict[str, Tensor], num_classes: int = 9, training: bool = True, concat: str = "coord",
+                 have_bridge: str = "original", br_ch_att_list=(True, False, False, False)):
         self.P = params
         self.num_classes = num_classes
         self.training = training
+        # ablation switches of the reference constructor (MSTr.py:2760-2823) that this restatement follows: the aggregate of a
+        # stage (:1384-1403), whether the bridge runs (:2840) and which bridge layers use channel attention (:2413-2420)
+        assert concat in ("coord", "normal") and have_bridge not in ("sp", "para") and len(br_ch_att_list) == 4
+        self.concat, self.have_bridge, self.br_ch_att_list = concat, have_bridge, tuple(bool(b) for b in br_ch_att_list)
         # running statistics are buffers: updated in place in training mode
         self.buffers = {k: v.clone() for k, v in params.items()
                         if k.endswith(("running_mean", "running_var", "num_batches_tracked"))}
@@ -195,7 +200,13 @@ class TransCeptionOracle:
             for l in range(layers):
                 t = self.mhca_block(t, f"{enc}.MHCA_layers.{l}", enc, H, W)
             outs.append(t.reshape(B, H, W, C))
-        return self.coord_att(torch.cat(outs, dim=-1), name + ".aggregate")
+        cat = torch.cat(outs, dim=-1)
+        if self.concat == "coord":
+            return self.coord_att(cat, name + ".aggregate")
+        # "normal": Conv2d_BN(4C -> C_out, 1x1, no bias) + BatchNorm + Hardswish, MSTr.py:1384-1390 with Conv2d_BN :364-404
+        B, H, W, C4 = cat.shape
+        y = self.linear(cat.reshape(B, H * W, C4), name + ".aggregate.conv", bias=False)
+        return self.hardswish(self.batchnorm_rows(y, name + ".aggregate.bn")).reshape(B, H, W, -1)
 
     def backbone(self, x: Tensor) -> List[Tensor]:
         """MSViT.forward, MSTr.py:1709-1744.  Returns four NHWC maps."""
@@ -270,7 +281,7 @@ class TransCeptionOracle:
         B = maps[0].shape[0]
         h4 = maps[3].shape[1]
         t = torch.cat([m.reshape(B, -1, 64) for m in maps], dim=1)
-        for i, ch_att in enumerate((True, False, False, False)):
+        for i, ch_att in enumerate(self.br_ch_att_list):
             t = self.bridge_layer(t, f"bridge.bridge_layer{i + 1}", ch_att, h4)
             self.taps[f"bridge{i + 1}"] = t
         outs, off = [], 0
@@ -312,7 +323,7 @@ class TransCeptionOracle:
         enc = self.backbone(x)
         for i, m in enumerate(enc):
             self.taps[f"enc{i}"] = m
-        br = self.bridge(enc)
+        br = self.bridge(enc) if self.have_bridge != "None" else enc          # MSTr.py:2840
         B = x.shape[0]
         t3 = self.decoder_layer(br[3].reshape(B, -1, br[3].shape[-1]), None, "decoder_3", False)
         t2 = self.decoder_layer(t3, br[2], "decoder_2", False)

@@ -13,6 +13,9 @@ fp32 with the name-seeded weights of transception_amd/seeded_init.py loaded stri
                    grad norm, post-step parameter checksums
   modules.npz      per-module forward outputs and input gradients for the sub-modules listed in
                    SURVEY.md section 8(c), driven by seeded inputs / upstream gradients
+  variants.npz     the constructor's ablation switches that the build implements: concat="normal",
+                   have_bridge="None", a non-default br_ch_att_list -- B=1 train-mode logits, loss, gradient probes, eval
+                   logits and the digest of each variant's state_dict schema
 
 Fixtures hold data only (inputs are re-derived from seeds; outputs are sampled at seeded positions
 plus float64 checksums), never reference source.
@@ -29,7 +32,7 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.join(HERE, "..", ".."))
 from ref_shim import import_reference  # noqa: E402
 from transception_amd.seeded_init import (seeded_input, seeded_labels, seeded_state_dict,  # noqa: E402
-                                           seeded_tensor, _stream)
+                                           seeded_tensor, _stream, schema_entries, schema_digest)
 
 NSAMP = 2048
 
@@ -216,16 +219,65 @@ def modules(MST):
     np.savez_compressed(os.path.join(HERE, "modules.npz"), **out)
 
 
+VARIANTS = {   # name -> (constructor kwargs, gradient probes)
+    "concat_normal": (dict(concat="normal"),
+                      ["backbone.patch_embed1.proj.weight", "backbone.mhca_stage2.aggregate.conv.weight",
+                       "backbone.mhca_stage4.aggregate.bn.weight", "bridge.bridge_layer3.attn.kv.weight", "decoder_0.last_layer.weight"]),
+    "no_bridge": (dict(have_bridge="None"),
+                  ["backbone.patch_embed1.proj.weight", "backbone.mhca_stage3.aggregate.conv_w.weight",
+                   "decoder_2.concat_linear.weight", "decoder_0.last_layer.bias"]),
+    "ch_att_1101": (dict(br_ch_att_list=[True, True, False, True]),
+                    ["backbone.mhca_stage4.aggregate.conv_h.weight", "bridge.bridge_layer2.attn.k.weight",
+                     "bridge.bridge_layer3.attn.scale_reduce.sr0.weight", "bridge.bridge_layer4.attn.proj.weight",
+                     "bridge.bridge_layer4.mixffn2.fc1.weight", "decoder_0.last_layer.weight"]),
+}
+
+
+def variants(MST, Dice):
+    out = {}
+    x = torch.from_numpy(seeded_input(1))
+    y_lab = torch.from_numpy(seeded_labels(1))
+    for name, (kw, probes) in VARIANTS.items():
+        ref = MST(num_classes=9, **kw)
+        entries = schema_entries(ref)
+        out[name + "/schema_sha256"] = np.frombuffer(schema_digest(entries).encode(), dtype=np.uint8)
+        out[name + "/n_keys"] = np.array([len(entries), len({c for _, _, c in entries})], dtype=np.int64)
+        sd = seeded_state_dict(entries)
+        ref.load_state_dict(sd, strict=True)
+        ref.train()
+        logits = ref(x)
+        pack(out, name + "/logits", logits)
+        ce = torch.nn.functional.cross_entropy(logits, y_lab)
+        dice = Dice(9)(logits, y_lab, softmax=True)
+        loss = 0.4 * ce + 0.6 * dice
+        loss.backward()
+        out[name + "/loss"] = np.array([loss.item(), ce.item(), dice.item()], dtype=np.float64)
+        named = dict(ref.named_parameters())
+        live = sorted(n for n, p in named.items() if p.grad is not None)
+        out[name + "/n_live"] = np.array([len(live)], dtype=np.int64)
+        for n in probes:
+            pack(out, name + "/grad/" + n, named[n].grad)
+        ref2 = MST(num_classes=9, **kw)
+        ref2.load_state_dict(sd, strict=True)
+        ref2.eval()
+        with torch.no_grad():
+            pack(out, name + "/logits_eval", ref2(x))
+        print(name, "keys", len(entries), "live grads", len(live), "loss", loss.item())
+    np.savez_compressed(os.path.join(HERE, "variants.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     MST, Dice = import_reference()
-    which = sys.argv[1:] or ["model", "trace", "modules"]
+    which = sys.argv[1:] or ["model", "trace", "modules", "variants"]
     if "model" in which:
         whole_model(MST, Dice)
     if "trace" in which:
         train_trace(MST, Dice)
     if "modules" in which:
         modules(MST)
+    if "variants" in which:
+        variants(MST, Dice)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

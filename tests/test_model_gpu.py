@@ -287,6 +287,54 @@ def test_whole_model_train_step_vs_reference_golden_and_oracle():
         assert (got - ref).abs().max().item() <= 2e-6 + 2e-3 * ref.abs().max().item(), key
 
 
+VARIANTS = {   # constructor switches of SURVEY.md 8(f)-4 that the build implements; fixtures tests/golden/variants.npz
+    "concat_normal": dict(concat="normal"),
+    "no_bridge": dict(have_bridge="None"),
+    "ch_att_1101": dict(br_ch_att_list=[True, True, False, True]),
+}
+
+
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+def test_variant_train_step_vs_reference_golden(name):
+    """The HIP path of an ablation variant (fp32 storage) against the reference's own outputs for it: B=1 train-mode logits, loss,
+    gradient probes, the number of live gradients, eval-mode logits; then one bf16 step within the bf16 budget of the fp32 one."""
+    from transception_amd import MSTransception
+    from transception_amd.seeded_init import schema_entries
+    from transception_amd.train import SegLoss
+    g = load("variants.npz")
+    kw = VARIANTS[name]
+    m = MSTransception(num_classes=9, **kw)
+    sd = seeded_state_dict(schema_entries(m))
+    m.load_state_dict(sd, strict=True)
+    m.to(DEV).train()
+    x = torch.from_numpy(seeded_input(1)).to(DEV)
+    lab = torch.from_numpy(seeded_labels(1)).to(DEV)
+    logits = m(x)
+    lc = logits.detach().cpu()
+    check_packed(g, name + "/logits", lc, atol=1e-4)
+    loss, ce, dice = SegLoss(9)(logits, lab)
+    np.testing.assert_allclose([loss.item(), ce.item(), dice.item()], g[name + "/loss"], rtol=0, atol=2e-5)
+    loss.backward()
+    named = dict(m.named_parameters())
+    assert sum(1 for p in m.parameters() if p.grad is not None) == int(g[name + "/n_live"][0])
+    for key in [k[len(name) + 6:-6] for k in g.files if k.startswith(name + "/grad/") and k.endswith("/shape")]:
+        check_packed(g, name + "/grad/" + key, named[key].grad.cpu(), atol=2e-6, rtol=2e-3, sum_rtol=1e-3)
+    m2 = MSTransception(num_classes=9, **kw)
+    m2.load_state_dict(sd, strict=True)
+    m2.to(DEV).eval()
+    with torch.no_grad():
+        check_packed(g, name + "/logits_eval", m2(x).cpu(), atol=1e-4)
+    # bf16 storage on the same variant: the whole-model bf16 budget of test_bf16_storage_budget (max |dlogit| <= 0.15), finite gradients
+    m3 = MSTransception(num_classes=9, **kw)
+    m3.load_state_dict(sd, strict=True)
+    m3.to(DEV).train()
+    m3.set_compute_dtype(torch.bfloat16)
+    lb = m3(x)
+    assert float((lb.detach().cpu() - lc).abs().max()) <= 0.15
+    SegLoss(9)(lb, lab)[0].backward()
+    assert all(torch.isfinite(p.grad).all() for p in m3.parameters() if p.grad is not None)
+
+
 def test_whole_model_eval_and_rgb():
     g = load("model_b2.npz")
     m = _fresh().eval()

@@ -135,11 +135,12 @@ def _mk_coord_att(inp: int, oup: int) -> nn.Module:              # MSTr.py:1304-
     return m
 
 
-def _mk_mhca_stage(dim: int, out_dim: int, layers: int) -> nn.Module:   # MSTr.py:1350-1403
+def _mk_mhca_stage(dim: int, out_dim: int, layers: int, concat: str = "coord") -> nn.Module:   # MSTr.py:1350-1410
     m = nn.Module()
     m.mhca_blks = nn.ModuleList([_mk_mhca_encoder(dim, layers) for _ in range(3)])
     m.InvRes = _mk_resblock(dim)
-    m.aggregate = _mk_coord_att(dim * 4, out_dim)
+    # aggregate of the four branch outputs: CoordAtt (IFF, the default, :1402-1403) or Conv1x1 + BN + Hardswish ("normal", :1384-1390)
+    m.aggregate = _mk_coord_att(dim * 4, out_dim) if concat == "coord" else _mk_conv2d_bn(dim * 4, out_dim)
     return m
 
 
@@ -213,16 +214,16 @@ def _mk_decoder_layer(in_out_chan, n_class: int, is_last: bool) -> nn.Module:   
     return m
 
 
-def _mk_backbone() -> nn.Module:                                 # MSTr.py:1536-1671
+def _mk_backbone(concat: str = "coord") -> nn.Module:             # MSTr.py:1536-1671
     m = nn.Module()
     for i, d in enumerate(DIMS):
         setattr(m, f"conv1_1_s{i + 1}", nn.Conv2d(3 * d, d, 1))     # dead parameters, kept for the schema
     m.patch_embed_stage2 = _mk_patch_embed_stage(DIMS[0])
     m.patch_embed_stage3 = _mk_patch_embed_stage(DIMS[1])
     m.patch_embed_stage4 = _mk_patch_embed_stage(DIMS[2])
-    m.mhca_stage2 = _mk_mhca_stage(DIMS[0], DIMS[1], LAYERS[0])
-    m.mhca_stage3 = _mk_mhca_stage(DIMS[1], DIMS[2], LAYERS[1])
-    m.mhca_stage4 = _mk_mhca_stage(DIMS[2], DIMS[3], LAYERS[2])
+    m.mhca_stage2 = _mk_mhca_stage(DIMS[0], DIMS[1], LAYERS[0], concat)
+    m.mhca_stage3 = _mk_mhca_stage(DIMS[1], DIMS[2], LAYERS[1], concat)
+    m.mhca_stage4 = _mk_mhca_stage(DIMS[2], DIMS[3], LAYERS[2], concat)
     m.patch_embed1 = nn.Module()
     m.patch_embed1.proj = nn.Conv2d(3, DIMS[0], 7, 4, 3)
     m.patch_embed1.norm = nn.LayerNorm(DIMS[0])
@@ -256,14 +257,23 @@ class MSTransception(nn.Module):
                  have_bridge='original', use_sa_config=1, sa_ker=7, Stage_3or4=3, inter='res', num_sp=1,
                  br_ch_att_list=[True, False, False, False]):
         super().__init__()
-        if (token_mlp_mode != "mix_skip" or concat != "coord" or have_bridge not in ("original",) or Stage_3or4 != 3
-                or list(br_ch_att_list) != [True, False, False, False]):
-            raise NotImplementedError("only the default MSTransception configuration (the one train_MSTransception.py:168 "
-                                      "builds) is implemented; ablation switches are out of scope")
+        # Ablation switches of the reference constructor (MSTr.py:2760-2823) that compose from the kernels of the default path:
+        #   concat       "coord" (CoordAtt / IFF, default) | "normal" (Conv1x1 + BN + Hardswish over the concatenation, :1384-1390)
+        #   have_bridge  "original" (default) | "None" (the bridge is built -- its parameters stay in the state_dict -- but skipped, :2840)
+        #   br_ch_att_list  which of the four bridge layers use channel attention instead of SR self-attention (:2413-2420)
+        # use_sa_config / sa_ker / inter / num_sp only reach the "cbam", "sp" and "para" variants and are accepted and ignored, as in
+        # the reference.  Not built: concat in {3d, se, skn, cbam, cam}, have_bridge in {sp, para}, Stage_3or4 != 3,
+        # token_mlp_mode != "mix_skip", and the legacy networks/Transception.py class.
+        br = [bool(b) for b in br_ch_att_list]
+        if (token_mlp_mode != "mix_skip" or concat not in ("coord", "normal") or have_bridge in ("sp", "para") or Stage_3or4 != 3
+                or len(br) != 4):
+            raise NotImplementedError("MSTransception: implemented are concat in {'coord', 'normal'}, have_bridge in {'original', "
+                                      "'None'}, any 4-entry br_ch_att_list, Stage_3or4 = 3, token_mlp_mode = 'mix_skip'")
+        self.concat, self.have_bridge, self.br_ch_att_list = concat, have_bridge, br
         self.num_classes = num_classes
-        self.backbone = _mk_backbone()
+        self.backbone = _mk_backbone(concat)
         self.bridge = nn.Module()
-        for i, ch in enumerate(br_ch_att_list):
+        for i, ch in enumerate(br):
             setattr(self.bridge, f"bridge_layer{i + 1}", _mk_bridge_layer(64, ch))
         ioc = [[32, 64, 64, 64], [144, 128, 128, 128], [288, 320, 320, 320], [512, 512, 512, 512]]
         self.decoder_3 = _mk_decoder_layer(ioc[3], num_classes, False)
@@ -632,7 +642,10 @@ def _mhca_stage(M, G, stack: Var, name: str, layers: int, B: int, side: int, out
                     t = _mhca_block(M, G, t, f"{enc}.MHCA_layers.{l}", enc, B, side, cat.colslice(C, 4 * C) if l == layers - 1 else None)
         with par.branch(1):
             _resblock(M, G, stack.rowslice(0, rows), name + ".InvRes", B, side, cat.colslice(0, C))
-    return _coord_att(M, G, cat, name + ".aggregate", B, side, out)
+    if M.concat == "coord":
+        return _coord_att(M, G, cat, name + ".aggregate", B, side, out)
+    y = G.linear(cat, *_lin(M, G, name + ".aggregate.conv", bias=False))       # "normal": Conv2d_BN with Hardswish, MSTr.py:1384-1390
+    return _bn(M, G, y, name + ".aggregate.bn", ACT_HSWISH, out=out)
 
 
 def _channel_att(M, G, n: Var, X: Optional[Var], name: str, B: int, ntok: List[int], R: List[int], N6: int) -> Var:
@@ -726,7 +739,7 @@ def _bridge_layer(M, G, X: Var, li: int, B: int, sides, ntok, R, N6) -> Var:
     """BridgLayer_4, MSTr.py:2373-2409, on the stage-major token buffer [sum_s B*ntok_s, 64]."""
     name = f"bridge.bridge_layer{li}"
     n = _ln(M, G, X, name + ".norm1")
-    if li == 1:
+    if M.br_ch_att_list[li - 1]:
         tx1 = _channel_att(M, G, n, X, name + ".attn", B, ntok, R, N6)
     else:
         tx1 = _self_att(M, G, n, X, name + ".attn", B, sides, ntok, R, N6)
@@ -810,8 +823,9 @@ def _forward(M: MSTransception, G: Graph, x: torch.Tensor, B: int, in_ch: int, S
     # the live gradient bytes) are complete and can travel while the encoder's backward runs.
     G.mark("encoder_done")
     X = Xb
-    for li in range(1, 5):
-        X = _bridge_layer(M, G, X, li, B, sides, ntok, R, N6)
+    if M.have_bridge != "None":                                   # MSTr.py:2840
+        for li in range(1, 5):
+            X = _bridge_layer(M, G, X, li, B, sides, ntok, R, N6)
     # decoder
     d3 = _patch_expand(M, G, stage_map(X, 3), "decoder_3.layer_up", B, sides[3], 2)
     d2 = _decoder(M, G, d3, stage_map(X, 2), "decoder_2", B, sides[2], False)

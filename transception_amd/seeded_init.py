@@ -108,3 +108,25 @@ def seeded_tensor(tag: str, shape: Tuple[int, ...], scale: float = 1.0, seed: in
     """Generic seeded N(0, scale) array for per-kernel parity inputs / upstream gradients."""
     g = _stream(f"tensor:{tag}", seed)
     return (g.standard_normal(size=tuple(int(s) for s in shape)) * scale).astype(np.float32)
+
+
+def schema_entries(module) -> list:
+    """[(key, shape, canonical_key)] of a torch module's state_dict, in its order: the canonical name of an entry is the first key
+    that shares its storage (shared modules appear under several aliases).  For the default MSTransception this reproduces the
+    committed manifest; the ablation variants (concat / have_bridge / br_ch_att_list) derive their schema this way on both sides --
+    the fixture generator from the imported reference, the tests from the build's module -- and the fixture pins the result."""
+    first = {}
+    out = []
+    for k, t in module.state_dict().items():
+        ptr = (t.data_ptr(), tuple(t.shape), str(t.dtype)) if t.numel() else (id(t),)
+        first.setdefault(ptr, k)
+        out.append((k, tuple(int(v) for v in t.shape), first[ptr]))
+    return out
+
+
+def schema_digest(entries) -> str:
+    """sha256 over 'key|shape|canonical' lines: what a fixture stores to pin a variant's state_dict schema."""
+    h = hashlib.sha256()
+    for k, shp, c in entries:
+        h.update(f"{k}|{','.join(str(v) for v in shp)}|{c}\n".encode())
+    return h.hexdigest()
