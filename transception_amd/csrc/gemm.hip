@@ -39,7 +39,8 @@ struct GemmDev {
     long long sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2;
     float alpha; int accumulate, act;
     int vecA, vecB, vecC, atomic;
-    int vec8C;              // bf16 C rows are 16-byte addressable (LDS-staged, fully coalesced epilogue)
+    short vec8C;            // bf16 C rows are 16-byte addressable (LDS-staged, fully coalesced epilogue)
+    short xcd;              // XCD-aware tile numbering of the plain bf16 kernel (tc_xcd_tile)
     float* rowsum;          // optional: rowsum[m] += sum_k op(A)[m][k]  (fp32, atomics)
     long long sBias1, sRow1; // batch-level-1 strides of bias / rowsum (grouped weights)
     float* ws_part; int* ws_cnt; int fix_group, fix_ngroups;   // split-K fix-up workspace (fix_group > 0: enabled)
@@ -895,11 +896,25 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmDev& p, const int bx, c
     }
 }
 
+// XCD-aware tile numbering.  Workgroups are dealt to the 8 XCDs round-robin in dispatch order (x fastest), so the N-tiles of one
+// M-tile -- which all read the same A rows -- land on different XCDs and every L2 fetches that A tile for itself (N = 1280: twenty
+// times).  Here the l-th workgroup of an XCD takes the l-th tile of that XCD's contiguous share of the (m, n) tile list, n fastest:
+// the readers of an A tile run back to back on one XCD.  A bijection for any tile count (the first T % 8 XCDs get one tile more).
+__device__ __forceinline__ void tc_xcd_tile(int& bx, int& by, const int gx, const int gy) {
+    const int T = gx * gy, L = bx + gx * by;
+    const int xcd = L & 7, slot = L >> 3, q = T >> 3, r = T & 7;
+    const int t = xcd * q + min(xcd, r) + slot;
+    by = t / gx;
+    bx = t - by * gx;
+}
+
 template <typename H, typename TC, int BM, int BN, bool TA, bool TB, bool DB, int FFN = 0>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmDev p) {
     // ONE buffer: A slabs first, B slabs behind them -- the epilogue reuses it from the start as its C staging tile
     __shared__ __attribute__((aligned(16))) bf16_t smem[(DB ? 2 : 1) * (BM + BN) * (64 + 8)];
-    gemm_bf16_body<H, TC, BM, BN, TA, TB, DB, FFN>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y,
+    int tbx = blockIdx.x, tby = blockIdx.y;
+    if (p.xcd) tc_xcd_tile(tbx, tby, gridDim.x, gridDim.y);
+    gemm_bf16_body<H, TC, BM, BN, TA, TB, DB, FFN>(p, tbx, tby, blockIdx.z, gridDim.x, gridDim.y,
                                                 reinterpret_cast<bf16_t(*)[BM * (64 + 8)]>(smem),
                                                 reinterpret_cast<bf16_t(*)[BN * (64 + 8)]>(smem + (DB ? 2 : 1) * BM * (64 + 8)));
 }
@@ -1065,6 +1080,10 @@ bool gemm_plan(const TcGemm* g, GemmDev& d, dim3& grid, bool& use128_out, bool f
     }
     d.atomic = ((d.splitk > 1 && !d.fix_group) || g->atomic) ? 1 : 0;
     grid = dim3((g->N + BN - 1) / BN, (g->M + BM - 1) / BM, nb * d.splitk);
+    {   // XCD-aware tile numbering pays where several N-tiles share an A tile and there are enough tiles to spread (A/B: TC_GEMM_XCD=0)
+        static const int xcd_on = getenv("TC_GEMM_XCD") ? atoi(getenv("TC_GEMM_XCD")) : 1;
+        d.xcd = (xcd_on && grid.x > 1 && (long long)grid.x * grid.y >= 64) ? 1 : 0;
+    }
     use128_out = use128;
     if (g->ffn_mode) {
         // the hooked kernels assume whole 16-byte strips everywhere and, for EP, the LDS-staged plain-store epilogue
