@@ -8,6 +8,7 @@
 // fp32 storage falls back to the per-segment fp32 kernels of attention.hip (parity path).
 #include "tc_common.h"
 #include <type_traits>
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -657,7 +658,8 @@ extern "C" int tc_attn_bwd_seg(const void* Q, int ldq, const void* K, int ldk, c
     // workgroups of 4 key waves (measured: 4 waves x 2 workgroups per CU beats 5 x 1); query chunks so that ~2 workgroups per CU exist
     const int kt = (Nk + 31) / 32, nw = 4;
     const int kb = (kt + nw - 1) / nw, ntiles = sg.t32[nseg];
-    int zs = 512 / (kb * B);
+    static const int dkv_slots = getenv("TC_DKV_SLOTS") ? atoi(getenv("TC_DKV_SLOTS")) : 512;   // resident workgroups aimed for
+    int zs = dkv_slots / (kb * B);
     zs = zs < 1 ? 1 : (zs > (ntiles + 1) / 2 ? (ntiles + 1) / 2 : zs);
     int tpc = (ntiles + zs - 1) / zs;
     tpc = (tpc + 1) & ~1;                                            // whole 64-query stages
