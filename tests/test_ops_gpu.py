@@ -497,6 +497,40 @@ def test_attention_segmented(dtype):
         closeb(Gx.grad_of(kvv), kvr.grad, 3e-2, "dkv bf16")
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_attention_segmented_rereference(dtype):
+    """The forward kernel references its exponents to the first 32-key sub-tile's row maximum and re-references a wave's rows when a
+    row sum passes 2^30 (2^14 for fp16 P).  Here the later keys are 24x larger than the first ones, so their scores outgrow the first
+    reference by far more than that (and by more than fp16's range): output, lse (through the backward) and gradients must still
+    match the fp32 reference; a second case puts the large keys FIRST (the reference starts high and every later P underflows)."""
+    from transception_amd.engine import Graph
+    B, d, Nk, nq = 2, 64, 300, [96, 40]
+    rows = B * sum(nq)
+    for big_first in (False, True):
+        q, kv, gy = T("ar.q", (rows, d)).to(dtype), T("ar.kv", (B * Nk, 2 * d)), T("ar.g", (rows, d)).to(dtype)
+        kv = kv.view(B, Nk, 2 * d).clone()
+        sl = slice(0, 40) if big_first else slice(70, Nk)
+        kv[:, sl, :d] *= 24.0
+        kv = kv.view(B * Nk, 2 * d).to(dtype)
+        qr, kvr = q.float().requires_grad_(), kv.float().requires_grad_()
+        k, v = kvr[:, :d].reshape(B, Nk, d), kvr[:, d:].reshape(B, Nk, d)
+        outs, r0 = [], 0
+        for n in nq:
+            qs = qr[r0:r0 + B * n].view(B, n, d)
+            outs.append((torch.softmax(qs @ k.transpose(1, 2) * 0.125, -1) @ v).reshape(B * n, d))
+            r0 += B * n
+        y = torch.cat(outs, 0)
+        y.backward(gy.float())
+        Gx = Graph(dtype, torch.device(DEV), True, True)
+        qv, kvv = mkV(Gx, q), mkV(Gx, kv)
+        out = Gx.attention_seg(qv, kvv.colslice(0, d), kvv.colslice(d, 2 * d), B, nq, Nk, 0.125)
+        assert torch.isfinite(out.data.float()).all()
+        closeb(out.data, y, 2e-2, f"seg attention, large keys {'first' if big_first else 'late'}")
+        run_bwd(Gx, out, gy)
+        closeb(Gx.grad_of(qv), qr.grad, 3e-2, "dq")
+        closeb(Gx.grad_of(kvv), kvr.grad, 3e-2, "dkv")
+
+
 @pytest.mark.parametrize("Bt,N,heads,Ch", [(3, 784, 8, 8), (2, 196, 8, 16), (2, 49, 8, 40)])
 def test_factor_att_core_fused(G, Bt, N, heads, Ch):
     """tc_factor_att_fwd/bwd vs a plain PyTorch fp32 restatement of MSTr.py:864-877 (Appendix C.1):
