@@ -259,8 +259,12 @@ int tc_attn_bwd(const void* Q, int ldq, long long sq, const void* K, int ldk, co
 
 /* Segmented form used by the bridge: Q / O / dO / dQ / lse are stage-major row blocks -- segment i holds B images of
  * nq[i] queries back to back, segments follow each other -- while K/V stay image-major (batch stride skv).  ONE launch
- * covers all segments (bf16); fp32 storage runs the per-segment kernels above.  nq is a HOST array of nseg (<= 4) ints.
- * Replaces the same reference lines (MSTr.py:2281-2287) for all 6076 query tokens of every image at once. */
+ * covers all segments (bf16 / fp16); fp32 storage runs the per-segment kernels above.  nq is a HOST array of nseg (<= 4) ints.
+ * Replaces the same reference lines (MSTr.py:2281-2287) for all 6076 query tokens of every image at once.
+ * 16-bit path: head dimension 64; Q, K, V (and dO) 16-byte aligned with row strides that are multiples of 8 elements; O / dQ rows
+ * are written with 16-byte stores when their pointer and stride allow it (8-byte stores otherwise).  The forward kernel's softmax
+ * is referenced to an integer exponent per row that is raised only when a row sum outgrows it by 2^30 (2^14 for fp16) -- the
+ * result is the ordinary softmax(QK^T scale)V, lse the ordinary log-sum-exp.  The kernels use 126 KB of dynamic LDS. */
 int tc_attn_fwd_seg(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, long long skv, void* O, int ldo,
                     float* lse, int B, int nseg, const int* nq, int Nk, float scale, int dtype, void* stream);
 /* dkv32: fp32 scratch [B*Nk*128] (bf16 path: query splits accumulate dK|dV there before one conversion); may be NULL for fp32. */
