@@ -931,9 +931,12 @@ __global__ __launch_bounds__(256, 2) void gemm_pair_kernel(GemmPairDev q) {
     bf16_t(*Bs)[64 * (64 + 8)] = reinterpret_cast<bf16_t(*)[64 * (64 + 8)]>(smem + 2 * 64 * (64 + 8));
     int lin = blockIdx.x;
     if (lin < q.nA) {
-        const int bx = lin % q.gxA; lin /= q.gxA;
-        if (q.a.ffn.mode == TC_FFN_EP) gemm_bf16_body<H, H, 64, 64, false, false, true, TC_FFN_EP>(q.a, bx, lin % q.gyA, lin / q.gyA, q.gxA, q.gyA, As, Bs);
-        else gemm_bf16_body<H, H, 64, 64, false, false, true>(q.a, bx, lin % q.gyA, lin / q.gyA, q.gxA, q.gyA, As, Bs);
+        int bx = lin % q.gxA; lin /= q.gxA;
+        int by = lin % q.gyA;
+        const int bz = lin / q.gyA;
+        if (q.a.xcd) tc_xcd_tile(bx, by, q.gxA, q.gyA);
+        if (q.a.ffn.mode == TC_FFN_EP) gemm_bf16_body<H, H, 64, 64, false, false, true, TC_FFN_EP>(q.a, bx, by, bz, q.gxA, q.gyA, As, Bs);
+        else gemm_bf16_body<H, H, 64, 64, false, false, true>(q.a, bx, by, bz, q.gxA, q.gyA, As, Bs);
     } else {
         lin -= q.nA;
         const int bx = lin % q.gxB; lin /= q.gxB;
@@ -956,7 +959,9 @@ __global__ __launch_bounds__(256, 2) void gemm_multi_kernel(GemmMultiDev q) {
     int lin = blockIdx.x, i = 0;
     for (int j = 1; j < q.n; ++j) if (lin >= q.blk0[j]) i = j;
     lin -= q.blk0[i];
-    const int gx = q.gx[i], gy = q.gy[i], bx = lin % gx, by = (lin / gx) % gy, bz = lin / (gx * gy);
+    const int gx = q.gx[i], gy = q.gy[i], bz = lin / (gx * gy);
+    int bx = lin % gx, by = (lin / gx) % gy;
+    if (q.p[i].xcd && q.kind[i] != 2 && q.kind[i] != 5) tc_xcd_tile(bx, by, gx, gy);   // (not the split-K weight gradients)
     // a private copy of the one descriptor: with six inlined bodies reading fields through a reference into the 4 KB argument block
     // the compiler stopped forwarding the loads to the kernel-argument segment and copied the whole block to scratch
     const GemmDev p = q.p[i];
