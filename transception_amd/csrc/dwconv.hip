@@ -1015,6 +1015,14 @@ template <typename T> struct FfnTile {
 // NTH = 256: a thread owns a whole 16-byte channel vector in the convolution / weight-gradient phases (one wave per SIMD).
 // NTH = 512: two threads share a vector (SV = VEC / 2 channels each): half the registers per thread, two waves per SIMD, so that one
 // wave's LDS reads overlap the other's arithmetic -- with a single resident wave the LDS and VALU phases of a tile ran back to back.
+#ifdef TC_MID_TIMING
+__device__ long long g_mid_dbg[64 * 16];
+#define MSTAMP(k) do { if (tid == 0 && by == 0 && bz == 0 && bx < 64) { const long long t_ = __builtin_readcyclecounter(); g_mid_dbg[bx * 16 + (k)] += t_ - mt_; mt_ = t_; } } while (0)
+#define MSTAMP_INIT() long long mt_ = __builtin_readcyclecounter(); if (tid == 0 && by == 0 && bz == 0 && bx < 64) { for (int k_ = 0; k_ < 16; ++k_) g_mid_dbg[bx * 16 + k_] = 0; }
+#else
+#define MSTAMP(k)
+#define MSTAMP_INIT()
+#endif
 template <typename T, int NTH>
 __device__ __forceinline__ void ffn_mid_bwd_body(const FfnSegDev& a, long long wstride, const int bx, const int by, const int bz,
                                                  uint4* smem, const int dbg_nofold = 0) {
@@ -1041,6 +1049,7 @@ __device__ __forceinline__ void ffn_mid_bwd_body(const FfnSegDev& a, long long w
     const T* w = (const T*)a.w + bz * wstride;
     const T* gamma = (const T*)a.gamma + bz * wstride;
     const int c0 = by * CH, tid = threadIdx.x;
+    MSTAMP_INIT();
     for (int i = tid; i < K * K * CH; i += NTH) {
         const int cc = i / (K * K), t = i - cc * (K * K);
         wsm[K * K - 1 - t][cc] = (c0 + cc < C) ? ldf<T>(w + (long long)(c0 + cc) * K * K + t) : 0.f;
@@ -1102,6 +1111,7 @@ __device__ __forceinline__ void ffn_mid_bwd_body(const FfnSegDev& a, long long w
     };
     if (bx < ntiles) fetch(bx);
     __syncthreads();                                              // taps and gamma are in LDS
+    MSTAMP(0);
     tc_f32x2 gk[V2];                                              // gamma of this thread's channel vector (its vectors all share cg)
 #pragma unroll
     for (int e = 0; e < V2; ++e) gk[e] = tc_f32x2{gsm[cg * VEC + 2 * e], gsm[cg * VEC + 2 * e + 1]};
@@ -1110,6 +1120,7 @@ __device__ __forceinline__ void ffn_mid_bwd_body(const FfnSegDev& a, long long w
         tile_org(tidx, b, oh0, ow0);
         const long long ibase = (long long)b * H * W;
         __syncthreads();                                          // the previous tile's readers are done with the LDS tiles
+        MSTAMP(1);
         if (tid < NPIX) {
             float s1 = ps_extra.x, s2 = ps_extra.y;
 #pragma unroll
@@ -1117,6 +1128,7 @@ __device__ __forceinline__ void ffn_mid_bwd_body(const FfnSegDev& a, long long w
             pst[tid] = pin_next ? make_float4(pst_raw.x, pst_raw.y, s1 * invC, s2 * invC) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
+        MSTAMP(2);
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const int v = tid + i * NTH;
@@ -1143,7 +1155,9 @@ __device__ __forceinline__ void ffn_mid_bwd_body(const FfnSegDev& a, long long w
             }
         }
         __syncthreads();
+        MSTAMP(3);
         if (tidx + a.gx < ntiles) fetch(tidx + a.gx);
+        MSTAMP(4);
         {   // dh = conv^T(dd) + dd for this thread's 4-pixel run and SV channels
             const int oh = oh0 + row, owb = ow0 + run * R, c = c0 + ch0;
             if (c < C && oh < H && owb < W) {
@@ -1181,6 +1195,7 @@ __device__ __forceinline__ void ffn_mid_bwd_body(const FfnSegDev& a, long long w
                     if (owb + r < W) store_sv<T, SV>(dst0 + (long long)r * a.lddh, o[r]);
             }
         }
+        MSTAMP(5);
         if (wactive) {   // filter-row ky3 of the weight gradient: sum over the tile of dd[p] * h[p + (ky3 - 1, kx - 1)]
             for (int u = rg; u < UNITS; u += RG) {
                 const int urow = u / (D::TW / R), urun = u % (D::TW / R);
@@ -1203,31 +1218,58 @@ __device__ __forceinline__ void ffn_mid_bwd_body(const FfnSegDev& a, long long w
                 }
             }
         }
+        MSTAMP(10);
+    }
+    MSTAMP(6);
+    __syncthreads();
+    MSTAMP(7);
+    // Workgroup sums of the per-thread accumulators, through the (now free) LDS tiles: every thread parks its values
+    // ([value][thread], conflict-free), then each output word is summed by ONE thread from its RG (taps, bias) or NTH / CG (dgamma,
+    // dbeta) contributors.  The first version added them with LDS atomics: 32 threads per word, 60 atomics per thread -- 31 k of
+    // the kernel's 160 k cycles (scripts/exp/mid_timing.py).
+    float* scr = reinterpret_cast<float*>(smem);
+    static_assert((K * SV + SV) * NTH * 4 <= 2 * NPIX * PIXQ * 16 && 2 * VEC * NTH * 4 <= 2 * NPIX * PIXQ * 16, "scratch fits the dd / h tiles");
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+        for (int e = 0; e < S2; ++e) {
+            scr[(kx * SV + 2 * e) * NTH + tid] = acc[kx][e].x;
+            scr[(kx * SV + 2 * e + 1) * NTH + tid] = acc[kx][e].y;
+        }
+#pragma unroll
+    for (int e = 0; e < S2; ++e) {
+        scr[(K * SV + 2 * e) * NTH + tid] = accb[e].x;
+        scr[(K * SV + 2 * e + 1) * NTH + tid] = accb[e].y;
     }
     __syncthreads();
-    if (c0 + ch0 < C) {
-        if (ky3 < K) {
+    for (int f = tid; f < (K * K + 1) * CH; f += NTH) {           // taps (ky3, kx) and the bias row: RG contributors each
+        const int t = f / CH, c = f - t * CH;
+        const int ky = t < K * K ? t / K : 0, kx = t < K * K ? t - ky * K : K;
+        const int src = (c / VEC) + CG * (((c % VEC) / SV) + HS * (ky * RG));      // thread (cg, hf, wk = ky * RG)
+        const float* col = scr + (kx * SV + (c % SV)) * NTH + src;
+        float v = 0.f;
 #pragma unroll
-            for (int kx = 0; kx < K; ++kx)
-#pragma unroll
-                for (int e = 0; e < S2; ++e) {
-                    atomicAdd(&lacc[ky3 * K + kx][ch0 + 2 * e], acc[kx][e].x);
-                    atomicAdd(&lacc[ky3 * K + kx][ch0 + 2 * e + 1], acc[kx][e].y);
-                }
-            if (ky3 == 0) {
-#pragma unroll
-                for (int e = 0; e < S2; ++e) { atomicAdd(&lacc[K * K][ch0 + 2 * e], accb[e].x); atomicAdd(&lacc[K * K][ch0 + 2 * e + 1], accb[e].y); }
-            }
-        }
-    }
-    if (c0 + cg * VEC < C) {
-#pragma unroll
-        for (int e = 0; e < V2; ++e) {
-            atomicAdd(&lacc[K * K + 1][cg * VEC + 2 * e], accg[e].x); atomicAdd(&lacc[K * K + 1][cg * VEC + 2 * e + 1], accg[e].y);
-            atomicAdd(&lacc[K * K + 2][cg * VEC + 2 * e], accbt[e].x); atomicAdd(&lacc[K * K + 2][cg * VEC + 2 * e + 1], accbt[e].y);
-        }
+        for (int g = 0; g < RG; ++g) v += col[g * CG * HS];
+        lacc[t][c] = v;
     }
     __syncthreads();
+#pragma unroll
+    for (int e = 0; e < V2; ++e) {
+        scr[(2 * e) * NTH + tid] = accg[e].x;
+        scr[(2 * e + 1) * NTH + tid] = accg[e].y;
+        scr[(VEC + 2 * e) * NTH + tid] = accbt[e].x;
+        scr[(VEC + 2 * e + 1) * NTH + tid] = accbt[e].y;
+    }
+    __syncthreads();
+    for (int f = tid; f < 2 * CH; f += NTH) {                     // dgamma and dbeta: every thread of the channel vector contributes
+        const int t = f / CH, c = f - t * CH;
+        const float* col = scr + (t * VEC + (c % VEC)) * NTH + (c / VEC);
+        float v = 0.f;
+        for (int g = 0; g < NTH / CG; ++g) v += col[g * CG];
+        lacc[K * K + 1 + t][c] = v;
+    }
+    __syncthreads();
+    MSTAMP(8);
     if (dbg_nofold) return;                                       // timing what-if only (TC_DEBUG_FFN_NOFOLD=1): parameter gradients are dropped
     float* lflat = &lacc[0][0];
     int gm = 1;
@@ -1278,6 +1320,7 @@ __device__ __forceinline__ void ffn_mid_bwd_body(const FfnSegDev& a, long long w
         else if (t == K * K + 1) { if (dgp) atomicAdd(dgp + ch, v); }
         else if (dbtp) atomicAdd(dbtp + ch, v);
     }
+    MSTAMP(9);
 }
 
 template <typename T, int NTH>
@@ -1455,6 +1498,9 @@ extern "C" int tc_ffn_dw_fwd(const void* x, int ldx, const void* w, const void* 
     return TC_ERR_ARG;
 }
 
+#ifdef TC_MID_TIMING
+extern "C" int tc_mid_dbg_read(long long* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_mid_dbg), sizeof(long long) * 64 * 16); }
+#endif
 extern "C" int tc_ffn_mid_bwd(const TcFfnSeg* segs, int nseg, int groups, long long wstride, void* ws, long long ws_bytes, int dtype,
                               void* stream) {
     if (!segs || nseg < 1 || nseg > FFN_MULTI_MAX || groups < 1) return TC_ERR_ARG;
