@@ -724,15 +724,35 @@ __device__ __forceinline__ void dw_tile_wgrad_body(const T* __restrict__ x, int 
             }
         }
     }
-    __syncthreads();
-    if (active) {
+    // Workgroup sums through the (now free) LDS tiles instead of LDS atomics (RG threads per word, K x VEC + VEC atomics per thread:
+    // a fifth of the MixFFN mid-backward kernel's cycles before the same change there): every thread parks SLOTS filter columns
+    // ([value][thread]), one thread per output word adds its RG contributors.
+    {
+        constexpr int SLOTS_FIT = ((D::IH * D::IW + D::TH * D::TW) * PIXQ * 4) / (256 * VEC);
+        constexpr int SLOTS = SLOTS_FIT > K + 1 ? K + 1 : SLOTS_FIT;
+        static_assert(SLOTS >= 1 && K * RG <= 256 / CG, "scratch / lane roles");
+        float* scr = reinterpret_cast<float*>(smem);
 #pragma unroll
-        for (int kx = 0; kx < K; ++kx)
+        for (int k0 = 0; k0 < K + 1; k0 += SLOTS) {               // column K = the bias sums
+            __syncthreads();
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) atomicAdd(&lacc[ky * K + kx][cg * VEC + e], acc[kx][e]);
-        if (ky == 0) {
+            for (int kk = 0; kk < SLOTS; ++kk) {
+                const int kx = k0 + kk;
+                if (kx <= K) {
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) atomicAdd(&lacc[K * K][cg * VEC + e], accb[e]);
+                    for (int e = 0; e < VEC; ++e) scr[(kk * VEC + e) * 256 + threadIdx.x] = kx < K ? acc[kx < K ? kx : 0][e] : accb[e];
+                }
+            }
+            __syncthreads();
+            for (int f = threadIdx.x; f < SLOTS * K * CH; f += 256) {
+                const int kk = f / (K * CH), rem = f - kk * (K * CH), kyo = rem / CH, c = rem - kyo * CH, kx = k0 + kk;
+                if (kx > K || (kx == K && kyo > 0)) continue;
+                const float* col = scr + (kk * VEC + (c % VEC)) * 256 + (c / VEC) + CG * (kyo * RG);
+                float v = 0.f;
+#pragma unroll
+                for (int g = 0; g < RG; ++g) v += col[g * CG];
+                lacc[kx < K ? kyo * K + kx : K * K][c] = v;
+            }
         }
     }
     __syncthreads();
