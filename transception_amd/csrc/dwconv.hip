@@ -4,6 +4,9 @@
 // layout is transposed on the way in), and the k*k window re-reads are served by L1/L2.
 #include "tc_common.h"
 #include <cstdlib>
+#ifndef DW_FOLD
+#define DW_FOLD 4      // workgroups that share an arrival counter in the two-level folds of the weight-gradient kernels (4 measured best of 1-16)
+#endif
 
 namespace {
 // workgroups a weight-gradient launch aims for (A/B switches; defaults = one tile walker per CU)
@@ -763,7 +766,7 @@ __device__ __forceinline__ void dw_tile_wgrad_body(const T* __restrict__ x, int 
         // Two-level fold (same protocol as the GEMM split-K fix-up): the workgroups of a (group, channel chunk) park their sums in
         // the workspace, 16 consecutive ones share an arrival counter, the last to arrive adds the 16 and is the only one that
         // touches dw / db atomically -- a contended fp32 atomic costs ~0.13 us and 128-170 workgroups used to queue on every word.
-        constexpr int FG = 16;
+        constexpr int FG = DW_FOLD;
         const int chain = bz * gy + by, grp = bx / FG, ngrp = (gx + FG - 1) / FG;
         gm = min(FG, gx - grp * FG);
         float* part = ws_part + ((long long)chain * gx + bx) * (NT * CH);
@@ -789,13 +792,13 @@ __device__ __forceinline__ void dw_tile_wgrad_body(const T* __restrict__ x, int 
         if (ch >= C) continue;
         float v;
         if (gm > 1) {
-            float tmp[16];                                   // all 16 loads in flight before the first add (they bypass L2: ~2 us each)
+            float tmp[DW_FOLD];                                   // all 16 loads in flight before the first add (they bypass L2: ~2 us each)
 #pragma unroll
-            for (int m = 0; m < 16; ++m)
+            for (int m = 0; m < DW_FOLD; ++m)
                 tmp[m] = m < gm ? __hip_atomic_load(pgroup + (long long)m * (NT * CH) + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
             v = 0.f;
 #pragma unroll
-            for (int m = 0; m < 16; ++m) v += tmp[m];
+            for (int m = 0; m < DW_FOLD; ++m) v += tmp[m];
         } else {
             v = lflat[f];
         }
@@ -847,7 +850,7 @@ int launch_tile(const void* src, int lds_, const void* w, const void* bias, void
         constexpr int NTC = ((KK) * (KK) + 1) * (CGG) * VEC;                                                                            \
         float* wp = nullptr; int* wc = nullptr;                                                                                         \
         if (ws && (uintptr_t)ws % 16 == 0 && ws_bytes >= 16384 + (long long)chunks * groups * (gx < 1 ? 1 : gx) * NTC * 4 &&             \
-            (long long)chunks * groups * (((gx < 1 ? 1 : gx) + 15) / 16) <= 4096) {                                                      \
+            (long long)chunks * groups * (((gx < 1 ? 1 : gx) + DW_FOLD - 1) / DW_FOLD) <= 4096) {                                                      \
             wc = reinterpret_cast<int*>(ws); wp = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + 16384);                         \
         }                                                                                          \
         gx = gx < 1 ? 1 : gx;                                                                                                           \
@@ -979,7 +982,7 @@ int launch_multi(const TcDwSeg* segs, int nseg, int mode, int add_input, int acc
             const long long nt_ch = (long long)(g.k * g.k + 1) * d.cg * VEC;
             d.wsc = have_ws ? reinterpret_cast<int*>(ws) + cnts : nullptr;
             d.wsp = have_ws ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + 16384) + part_floats : nullptr;
-            cnts += (long long)d.chunks * groups * ((gx + 15) / 16);
+            cnts += (long long)d.chunks * groups * ((gx + DW_FOLD - 1) / DW_FOLD);
             part_floats += (long long)d.chunks * groups * gx * nt_ch;
         } else {
             d.gx = (int)ntiles; d.wsc = nullptr; d.wsp = nullptr;
@@ -1113,16 +1116,34 @@ __device__ __forceinline__ void ffn_mid_bwd_body(const FfnSegDev& a, long long w
         pst_raw = *reinterpret_cast<const float2*>(stat + prow * 2);
         pin_next = pin;
         // the first PQ row-sum partials are requested here and added up when the tile is consumed (a load-add-load loop here would
-        // be nch2 dependent memory round trips in front of the tile's own loads); wider LayerNorms finish the sum in the loop below
-#pragma unroll
-        for (int k = 0; k < PQ; ++k) pq[k] = pp[k < a.nch2 ? k : 0];
+        // be nch2 dependent memory round trips in front of the tile's own loads); wider LayerNorms finish the sum in the loop below.
+        // An even number of partials per row (every width of this model) is read as 16-byte pairs: half the requests.
         float s1 = 0.f, s2 = 0.f;
-        for (int k0 = PQ; k0 < a.nch2; k0 += 4) {
-            float2 q4[4];
+        if (!(a.nch2 & 1)) {
+            const float4* pp4 = reinterpret_cast<const float4*>(pp);
+            const int n4 = a.nch2 >> 1;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) q4[j] = pp[k0 + j < a.nch2 ? k0 + j : 0];
+            for (int k = 0; k < PQ / 2; ++k) {
+                const float4 v = pp4[k < n4 ? k : 0];
+                pq[2 * k] = make_float2(v.x, v.y); pq[2 * k + 1] = make_float2(v.z, v.w);
+            }
+            for (int k0 = PQ / 2; k0 < n4; k0 += 4) {
+                float4 q4[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (k0 + j < a.nch2) { s1 += q4[j].x; s2 += q4[j].y; }
+                for (int j = 0; j < 4; ++j) q4[j] = pp4[k0 + j < n4 ? k0 + j : 0];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (k0 + j < n4) { s1 += q4[j].x + q4[j].z; s2 += q4[j].y + q4[j].w; }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < PQ; ++k) pq[k] = pp[k < a.nch2 ? k : 0];
+            for (int k0 = PQ; k0 < a.nch2; k0 += 4) {
+                float2 q4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) q4[j] = pp[k0 + j < a.nch2 ? k0 + j : 0];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (k0 + j < a.nch2) { s1 += q4[j].x; s2 += q4[j].y; }
+            }
         }
         ps_extra = make_float2(s1, s2);
         dw_fetch<T, CG, NX, NTH>(gr, gp + ibase * a.ldg + c0, a.ldg, oh0 - 1, ow0 - 1, IH, IW, H, W, C - c0);
@@ -1295,7 +1316,7 @@ __device__ __forceinline__ void ffn_mid_bwd_body(const FfnSegDev& a, long long w
     int gm = 1;
     const float* pgroup = nullptr;
     if (a.wsp) {                                                  // two-level fold, as dw_tile_wgrad_body
-        constexpr int FG = 16;
+        constexpr int FG = DW_FOLD;
         const int chain = bz * a.chunks + by, grp = bx / FG, ngrp = (a.gx + FG - 1) / FG;
         gm = min(FG, a.gx - grp * FG);
         float* part = a.wsp + ((long long)chain * a.gx + bx) * (NT * CH);
@@ -1325,13 +1346,13 @@ __device__ __forceinline__ void ffn_mid_bwd_body(const FfnSegDev& a, long long w
         if (ch >= C) continue;
         float v;
         if (gm > 1) {
-            float tmp[16];
+            float tmp[DW_FOLD];
 #pragma unroll
-            for (int m = 0; m < 16; ++m)
+            for (int m = 0; m < DW_FOLD; ++m)
                 tmp[m] = m < gm ? __hip_atomic_load(pgroup + (long long)m * (NT * CH) + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
             v = 0.f;
 #pragma unroll
-            for (int m = 0; m < 16; ++m) v += tmp[m];
+            for (int m = 0; m < DW_FOLD; ++m) v += tmp[m];
         } else {
             v = lflat[f];
         }
@@ -1371,7 +1392,8 @@ int launch_ffn_mid_bwd(const TcFfnSeg* segs, int nseg, int groups, long long wst
         const TcFfnSeg& g = segs[i];
         FfnSegDev& d = q.s[i];
         if (!g.gp || !g.d || !g.h || !g.dh || !g.stat || !g.part2 || !g.w || !g.gamma || !g.dw || g.C <= 0 || g.C % D::VEC || g.nch2 < 1 ||
-            !dw_tile_ok<T>(g.gp, g.ldg, g.d, g.ldd, g.C) || !dw_tile_ok<T>(g.h, g.ldh, g.dh, g.lddh, g.C))
+            !dw_tile_ok<T>(g.gp, g.ldg, g.d, g.ldd, g.C) || !dw_tile_ok<T>(g.h, g.ldh, g.dh, g.lddh, g.C) ||
+            (!(g.nch2 & 1) && (uintptr_t)g.part2 % 16))              // even partial counts are read as 16-byte pairs
             return TC_ERR_ARG;
         d.gp = g.gp; d.d = g.d; d.h = g.h; d.dh = g.dh; d.stat = g.stat; d.part2 = g.part2; d.w = g.w; d.gamma = g.gamma;
         d.dw = g.dw; d.db = g.db; d.dgamma = g.dgamma; d.dbeta = g.dbeta;
@@ -1385,7 +1407,7 @@ int launch_ffn_mid_bwd(const TcFfnSeg* segs, int nseg, int groups, long long wst
         d.gx = (int)gx;
         d.wsc = have_ws ? reinterpret_cast<int*>(ws) + cnts : nullptr;
         d.wsp = have_ws ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + 16384) + part_floats : nullptr;
-        cnts += (long long)d.chunks * groups * ((gx + 15) / 16);
+        cnts += (long long)d.chunks * groups * ((gx + DW_FOLD - 1) / DW_FOLD);
         part_floats += (long long)d.chunks * groups * gx * D::NT * D::CH;
         d.blk0 = (int)blk;
         blk += gx * d.chunks;

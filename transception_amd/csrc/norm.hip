@@ -7,6 +7,9 @@
 namespace {
 
 constexpr int LN_MAXC = 2048;
+#ifndef LN_FOLD
+#define LN_FOLD 8
+#endif
 constexpr int LN_BWD_MAX_BLOCKS = 1024, LN_BWD_ROWS_PER_GROUP = 4;   // fused dx + parameter-gradient launch
 inline int ln_bwd_blocks() {   // A/B switch (<= LN_BWD_MAX_BLOCKS, which sizes the scratch)
     static const int v = getenv("TC_LN_BWD_BLOCKS") ? atoi(getenv("TC_LN_BWD_BLOCKS")) : LN_BWD_MAX_BLOCKS;
@@ -216,10 +219,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
         }
     }
     if (!partial) return;
-    // Two-level fold (the GEMM split-K fix-up protocol): 16 consecutive workgroups share an arrival counter; the last to arrive
-    // adds the 16 partial rows and is the only one that touches dgamma / dbeta atomically (64 contributors per word instead of
+    // Two-level fold (the GEMM split-K fix-up protocol): LN_FOLD consecutive workgroups share an arrival counter (8 measured best of 2-32: the last arriver reads its group serially); the last to arrive
+    // adds the group's partial rows and is the only one that touches dgamma / dbeta atomically (32 contributors per word instead of
     // 1024, and no second launch).
-    constexpr int FG = 16;
+    constexpr int FG = LN_FOLD;
     const int grp = blockIdx.x / FG, ngrp = (gridDim.x + FG - 1) / FG, gm = min(FG, (int)gridDim.x - grp * FG);
     __builtin_amdgcn_s_waitcnt(0);                          // vmcnt(0): THIS thread's write-through stores have been acknowledged
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (the barrier alone does not wait for stores in flight)
@@ -543,7 +546,7 @@ static int ln_bwd_impl(const void* dy, int lddy, const void* x, int ldx, const v
         if (ilp && rpg < RPT) rpg = RPT;                                                                                                  \
         nblk = tc_blocks(rows, (256 / GS) * rpg, dgamma ? ln_bwd_blocks() : 8192);                                                        \
         partial = (dgamma && scratch && (uintptr_t)scratch % 16 == 0 && scratch_floats >= 4096 + (long long)groups * nblk * 2 * C &&      \
-                   (long long)groups * ((nblk + 15) / 16) <= 4096) ? scratch + 4096 : nullptr;                                            \
+                   (long long)groups * ((nblk + LN_FOLD - 1) / LN_FOLD) <= 4096) ? scratch + 4096 : nullptr;                                            \
         if (ilp) TC_LNB_LAUNCH(GS, NV, RPT); else TC_LNB_LAUNCH(GS, NV, 1); }
     TC_DISPATCH_DTYPE(dtype, { TC_LN_DISPATCH(quads, TC_LNB) });
 #undef TC_LNB
