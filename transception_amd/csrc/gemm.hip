@@ -40,7 +40,7 @@ struct GemmDev {
     float alpha; int accumulate, act;
     int vecA, vecB, vecC, atomic;
     short vec8C;            // bf16 C rows are 16-byte addressable (LDS-staged, fully coalesced epilogue)
-    short xcd;              // XCD-aware tile numbering of the plain bf16 kernel (tc_xcd_tile)
+    short xcd;              // XCD-aware tile numbering (tc_xcd_tile)
     float* rowsum;          // optional: rowsum[m] += sum_k op(A)[m][k]  (fp32, atomics)
     long long sBias1, sRow1; // batch-level-1 strides of bias / rowsum (grouped weights)
     float* ws_part; int* ws_cnt; int fix_group, fix_ngroups;   // split-K fix-up workspace (fix_group > 0: enabled)
@@ -304,6 +304,8 @@ __device__ __forceinline__ void epilogue_cols(const GemmDev& p, f32x16 (&acc)[TM
 template <typename H, int BM, int BN, int TM, int TN>
 __device__ __forceinline__ void epilogue_rows_lds(const GemmDev& p, f32x16 (&acc)[TM][TN], int b1, int b2, int m0, int n0, int wr, int wc,
                                                   int lane, bf16_t* stage_raw) {
+    // (requesting the residual tile and the bias before the K loop and parking them in the staging tile was tried: the sampled
+    //  workgroups' epilogue got shorter, the step did not -- 14.64 ms either way: other resident workgroups already cover the wait)
     H* stage = reinterpret_cast<H*>(stage_raw);
     constexpr int LDS_ = BN + 8, WM = BM / 2, WN = BN / 2;
     const H* R = p.R ? reinterpret_cast<const H*>(p.R) + b1 * p.sR1 + b2 * p.sR2 : nullptr;
@@ -652,6 +654,20 @@ template <typename V8> __device__ __forceinline__ V8 ld_frag_tr(const bf16_t* lo
 
 // Body of one workgroup of the bf16 GEMM: (bx, by, bz) of a (gx, gy, *) grid.  The LDS buffers come from the caller so that the
 // two problems of a paired launch (gemm_pair_kernel) share one allocation.
+#ifdef TC_GEMM_TIMING
+// phase stamps of the bf16 GEMM body (experiment builds only): every 61st workgroup of a launch writes its own row of the table
+// (kind = TA*4 + TB*2 + fp32-out + 8*FFN, cycles of setup / K loop / epilogue) -- plain stores, no atomics (same-address atomics
+// from every workgroup serialise at ~0.13 us each and were what a first version measured)
+__device__ unsigned long long g_gemm_dbg[1024 * 8];
+__device__ unsigned int g_gemm_dbg_n;
+#define GSTAMP(k) do { if (gs_ >= 0) { const long long t_ = __builtin_readcyclecounter(); g_gemm_dbg[gs_ * 8 + 1 + (k)] = (unsigned long long)(t_ - gt_); gt_ = t_; } } while (0)
+#define GSTAMP_INIT() int gs_ = -1; long long gt_ = 0; \
+    if (threadIdx.x == 0 && (blockIdx.x + 7 * blockIdx.y + 13 * blockIdx.z) % 61 == 0) { gs_ = (int)(atomicAdd(&g_gemm_dbg_n, 1u) & 1023u); \
+        g_gemm_dbg[gs_ * 8] = (TA ? 4 : 0) + (TB ? 2 : 0) + (sizeof(TC) == 4 ? 1 : 0) + 8 * FFN + 1000ull * (unsigned long long)((kend_for_stamp)); gt_ = __builtin_readcyclecounter(); }
+#else
+#define GSTAMP(k)
+#define GSTAMP_INIT()
+#endif
 template <typename H, typename TC, int BM, int BN, bool TA, bool TB, bool DB, int FFN = 0>
 __device__ __forceinline__ void gemm_bf16_body(const GemmDev& p, const int bx, const int by, const int bz, const int gx, const int gy,
                                                bf16_t (*As)[BM * (64 + 8)], bf16_t (*Bs)[BN * (64 + 8)]) {
@@ -677,6 +693,8 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmDev& p, const int bx, c
     const int m0 = by * BM, n0 = bx * BN;
     const int kbeg = ks * p.kchunk;
     const int kend = min(p.K, kbeg + p.kchunk);
+    const int kend_for_stamp = kend - kbeg; (void)kend_for_stamp;
+    GSTAMP_INIT();
 
     const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + b1 * p.sA1 + b2 * p.sA2;
     const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B) + b1 * p.sB1 + b2 * p.sB2;
@@ -873,7 +891,9 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmDev& p, const int bx, c
     // no partially covered strip anywhere in this workgroup's slabs: K range a multiple of 8 for K-contiguous operands, M / N a
     // multiple of 8 for operands whose strips run along M / N
     const bool fast = p.vecA && p.vecB && ((kend - kbeg) % 8 == 0 || (TA && !TB)) && (!TA || p.M % 8 == 0) && (TB || p.N % 8 == 0);
+    GSTAMP(0);
     if (fast) kloop(std::true_type{}); else kloop(std::false_type{});
+    GSTAMP(1);
     if (do_rowsum && m0 + tid < p.M) atomicAdd(p.rowsum + b1 * p.sRow1 + m0 + tid, rsum);
     bool first = (ks == 0), atomic = p.atomic;
     if (p.fix_group) {
@@ -894,6 +914,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmDev& p, const int bx, c
     } else {
         epilogue_cols<H, TC, TM, TN>(p, acc, b1, b2, first, atomic, m0 + wr * WM, n0 + wc * WN, lane);
     }
+    GSTAMP(2);
 }
 
 // XCD-aware tile numbering.  Workgroups are dealt to the 8 XCDs round-robin in dispatch order (x fastest), so the N-tiles of one
@@ -913,7 +934,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmDev p) {
     // ONE buffer: A slabs first, B slabs behind them -- the epilogue reuses it from the start as its C staging tile
     __shared__ __attribute__((aligned(16))) bf16_t smem[(DB ? 2 : 1) * (BM + BN) * (64 + 8)];
     int tbx = blockIdx.x, tby = blockIdx.y;
-    if (p.xcd) tc_xcd_tile(tbx, tby, gridDim.x, gridDim.y);
+    if (p.xcd & 1) tc_xcd_tile(tbx, tby, gridDim.x, gridDim.y);
     gemm_bf16_body<H, TC, BM, BN, TA, TB, DB, FFN>(p, tbx, tby, blockIdx.z, gridDim.x, gridDim.y,
                                                 reinterpret_cast<bf16_t(*)[BM * (64 + 8)]>(smem),
                                                 reinterpret_cast<bf16_t(*)[BN * (64 + 8)]>(smem + (DB ? 2 : 1) * BM * (64 + 8)));
@@ -934,7 +955,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pair_kernel(GemmPairDev q) {
         int bx = lin % q.gxA; lin /= q.gxA;
         int by = lin % q.gyA;
         const int bz = lin / q.gyA;
-        if (q.a.xcd) tc_xcd_tile(bx, by, q.gxA, q.gyA);
+        if (q.a.xcd & 1) tc_xcd_tile(bx, by, q.gxA, q.gyA);
         if (q.a.ffn.mode == TC_FFN_EP) gemm_bf16_body<H, H, 64, 64, false, false, true, TC_FFN_EP>(q.a, bx, by, bz, q.gxA, q.gyA, As, Bs);
         else gemm_bf16_body<H, H, 64, 64, false, false, true>(q.a, bx, by, bz, q.gxA, q.gyA, As, Bs);
     } else {
@@ -961,7 +982,7 @@ __global__ __launch_bounds__(256, 2) void gemm_multi_kernel(GemmMultiDev q) {
     lin -= q.blk0[i];
     const int gx = q.gx[i], gy = q.gy[i], bz = lin / (gx * gy);
     int bx = lin % gx, by = (lin / gx) % gy;
-    if (q.p[i].xcd && q.kind[i] != 2 && q.kind[i] != 5) tc_xcd_tile(bx, by, gx, gy);   // (not the split-K weight gradients)
+    if ((q.p[i].xcd & 1) && q.kind[i] != 2 && q.kind[i] != 5) tc_xcd_tile(bx, by, gx, gy);   // (not the split-K weight gradients)
     // a private copy of the one descriptor: with six inlined bodies reading fields through a reference into the 4 KB argument block
     // the compiler stopped forwarding the loads to the kernel-argument segment and copied the whole block to scratch
     const GemmDev p = q.p[i];
@@ -1138,6 +1159,18 @@ static bool gemm_args_ok(const TcGemm* g) {
     return true;
 }
 
+#ifdef TC_GEMM_TIMING
+extern "C" int tc_gemm_dbg_read(unsigned long long* dst, int reset) {
+    int rc = (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_gemm_dbg), sizeof(unsigned long long) * 1024 * 8);
+    if (reset) {
+        static unsigned long long z[1024 * 8];
+        unsigned int zn = 0;
+        rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_dbg), z, sizeof(z));
+        rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_dbg_n), &zn, sizeof(zn));
+    }
+    return rc;
+}
+#endif
 extern "C" int tc_gemm(const TcGemm* g, void* stream) {
     if (!gemm_args_ok(g)) return TC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
