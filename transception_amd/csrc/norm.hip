@@ -111,6 +111,19 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, in
     }
 }
 
+#ifdef TC_LN_TIMING
+// phase stamps of ln_bwd_kernel (experiment builds): every 61st workgroup writes its own row: GS, rows, then cycles of
+// parameter loads / row loop / LDS partials / parked partial + arrival / fold
+__device__ unsigned long long g_ln_dbg[1024 * 8];
+__device__ unsigned int g_ln_dbg_n;
+#define LSTAMP(k) do { if (ls_ >= 0) { const long long t_ = __builtin_readcyclecounter(); g_ln_dbg[ls_ * 8 + 2 + (k)] = (unsigned long long)(t_ - lt_); lt_ = t_; } } while (0)
+#define LSTAMP_INIT() int ls_ = -1; long long lt_ = 0; \
+    if (threadIdx.x == 0 && (blockIdx.x + 17 * blockIdx.y) % 61 == 0) { ls_ = (int)(atomicAdd(&g_ln_dbg_n, 1u) & 1023u); \
+        g_ln_dbg[ls_ * 8] = GS + 1000ull * C; g_ln_dbg[ls_ * 8 + 1] = (unsigned long long)rows; lt_ = __builtin_readcyclecounter(); }
+#else
+#define LSTAMP(k)
+#define LSTAMP_INIT()
+#endif
 template <typename T, int GS, int NV, int RPT>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ x, int ldx,
                                                      const T* __restrict__ gamma, const T* __restrict__ beta,
@@ -128,6 +141,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
         gamma += g * pstride; beta += g * pstride;
         if (dgamma) { dgamma += g * pstride; dbeta += g * pstride; }
     }
+    LSTAMP_INIT();
     const int nv = C >> 2;
     float4 g[NV], b[NV], ag[NV], ab[NV];
 #pragma unroll
@@ -137,6 +151,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
         if (q < nv) { g[i] = ld4<T>(gamma + q * 4); b[i] = ld4<T>(beta + q * 4); }
     }
     const float invC = 1.0f / (float)C;
+    LSTAMP(0);
     // RPT consecutive rows per lane group and iteration, all their loads issued before the first reduction (see ln_fwd_kernel)
     for (int row0 = (blockIdx.x * RPB + gi) * RPT; row0 < rows; row0 += gridDim.x * RPB * RPT) {
         float4 xh[RPT][NV], gg[RPT][NV], rr[RPT][NV];
@@ -194,6 +209,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
             }
         }
     }
+    LSTAMP(1);
     if (!dgamma) return;                     // dx-only launch: parameter gradients come from ln_param_grad_kernel
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -218,6 +234,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
             atomicAdd(dbeta + c, bb);
         }
     }
+    LSTAMP(2);
     if (!partial) return;
     // Two-level fold (the GEMM split-K fix-up protocol): LN_FOLD consecutive workgroups share an arrival counter (8 measured best of 2-32: the last arriver reads its group serially); the last to arrive
     // adds the group's partial rows and is the only one that touches dgamma / dbeta atomically (32 contributors per word instead of
@@ -235,6 +252,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
         if (s_last) atomicExch(cn, 0);
     }
     __syncthreads();
+    LSTAMP(3);
     if (!s_last) return;
     const float* pg = partial + ((long long)blockIdx.y * gridDim.x + grp * FG) * 2 * C;
     for (int c = threadIdx.x; c < 2 * C; c += 256) {
@@ -246,6 +264,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
         for (int m = 0; m < FG; ++m) v += tmp[m];
         atomicAdd((c < C ? dgamma + c : dbeta + (c - C)), v);
     }
+    LSTAMP(4);
 }
 
 // dgamma[c] += sum_rows dz * xhat ; dbeta[c] += sum_rows dz   as a column reduction (thread = 4 channels x row lane): fully
@@ -554,6 +573,18 @@ static int ln_bwd_impl(const void* dy, int lddy, const void* x, int ldx, const v
     return tc_launch_status();
 }
 
+#ifdef TC_LN_TIMING
+extern "C" int tc_ln_dbg_read(unsigned long long* dst, int reset) {
+    int rc = (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_ln_dbg), sizeof(unsigned long long) * 1024 * 8);
+    if (reset) {
+        static unsigned long long z[1024 * 8];
+        unsigned int zn = 0;
+        rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ln_dbg), z, sizeof(z));
+        rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ln_dbg_n), &zn, sizeof(zn));
+    }
+    return rc;
+}
+#endif
 extern "C" int tc_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx, const void* gamma, const void* beta,
                                 const float* mean, const float* rstd, void* dx, int lddx, const void* dres, int ldres,
                                 float* dgamma, float* dbeta, int rows, int C, int act, int groups, long long pstride,
