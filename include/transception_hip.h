@@ -267,7 +267,9 @@ int tc_attn_bwd(const void* Q, int ldq, long long sq, const void* K, int ldk, co
  * result is the ordinary softmax(QK^T scale)V, lse the ordinary log-sum-exp.  The kernels use 126 KB of dynamic LDS. */
 int tc_attn_fwd_seg(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, long long skv, void* O, int ldo,
                     float* lse, int B, int nseg, const int* nq, int Nk, float scale, int dtype, void* stream);
-/* dkv32: fp32 scratch [B*Nk*128] (bf16 path: query splits accumulate dK|dV there before one conversion); may be NULL for fp32. */
+/* dkv32: fp32 scratch of TC_ATTN_DKV_SPLITS * B * Nk * 128 floats (16-bit path: every query chunk of the dK/dV kernel writes its own
+ * partial dK|dV there, one conversion kernel adds them; needs no initialisation); may be NULL for fp32. */
+#define TC_ATTN_DKV_SPLITS 8
 int tc_attn_bwd_seg(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, long long skv, const void* O,
                     int ldo, const void* dO, int lddo, const float* lse, float* delta, float* dkv32, void* dQ, int lddq,
                     void* dK, int lddk, void* dV, int lddv, long long sdkv, int B, int nseg, const int* nq, int Nk,

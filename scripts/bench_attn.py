@@ -11,7 +11,7 @@ dt = TC_BF16 if dtype == torch.bfloat16 else TC_F32
 q = torch.randn(rows, d, device=dev).to(dtype); kv = torch.randn(B * Nk, 2 * d, device=dev).to(dtype)
 o = torch.empty_like(q); do = torch.randn(rows, d, device=dev).to(dtype)
 dq = torch.empty_like(q); dkv = torch.empty_like(kv)
-lse = torch.empty(rows, device=dev); delta = torch.empty(rows, device=dev); dkv32 = torch.empty(B * Nk * 128, device=dev)
+lse = torch.empty(rows, device=dev); delta = torch.empty(rows, device=dev); dkv32 = torch.empty(8 * B * Nk * 128, device=dev)   # TC_ATTN_DKV_SPLITS partial buffers
 nqc = (C.c_int * 4)(*nq)
 st = torch.cuda.current_stream().cuda_stream
 k, v = kv[:, :d], kv[:, d:]

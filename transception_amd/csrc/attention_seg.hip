@@ -365,6 +365,14 @@ __global__ __launch_bounds__(FW_NT, 1) void attn_bwd_dq_seg_kernel(const bf16_t*
 // waves -- the first version staged them per wave (4x the LDS stores and global reads) and needed 288 VGPRs (one wave per SIMD).
 // Query chunks (gridDim.z) add their partial sums atomically into the fp32 scratch dkv32 [B][Nk][128] (dK | dV), which
 // attn_dkv_store_kernel converts to the bf16 outputs.
+#ifdef TC_DKV_TIMING
+__device__ unsigned long long g_dkv_dbg[512 * 4];
+#define DSTAMP(k) do { if (threadIdx.x == 0) { const long long t_ = __builtin_readcyclecounter(); g_dkv_dbg[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) % 512 * 4 + (k)] = (unsigned long long)(t_ - dt_); dt_ = t_; } } while (0)
+#define DSTAMP_INIT() long long dt_ = __builtin_readcyclecounter()
+#else
+#define DSTAMP(k)
+#define DSTAMP_INIT()
+#endif
 template <typename H, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
                                                                     const bf16_t* __restrict__ V, int ldv, long long skv,
@@ -383,6 +391,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16
     constexpr int SMEM_B = STAGE_B > RED_B ? STAGE_B : RED_B;
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_B];
     bf16_t* const sbase = reinterpret_cast<bf16_t*>(smem);
+    DSTAMP_INIT();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
     const int b = blockIdx.y, kv0 = (blockIdx.x * NW + wave) * 32, key = min(kv0 + j, Nk - 1);
     typedef typename TcHalf<H>::v8 V8;
@@ -457,6 +466,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16
         if (t_begin + 2 < t_end) fetch(t_begin + 2);
     }
     __syncthreads();
+    DSTAMP(0);
     int buf = 0;
     for (int t0 = t_begin; t0 < t_end; t0 += 2, buf ^= 1) {
         if (t0 + 2 < t_end) stash(buf ^ 1);                     // (every wave left stage t0 - 2, that buffer's last reader, at the barrier below)
@@ -506,8 +516,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16
         }
         __syncthreads();
     }
-    // each wave owns its keys: transpose its [d][key] accumulators through LDS so that the atomics run along d (coalesced)
+    DSTAMP(1);
+    // each wave owns its keys: its [d][key] accumulators pass through LDS so that the stores run along d (whole 256-byte rows).
+    // Every query chunk (blockIdx.z) writes its own partial [B][Nk][128]; attn_dkv_store_kernel adds the chunks -- fp32 atomics into
+    // one buffer cost this epilogue 20 k of the kernel's 149 k cycles (scripts/exp/dkv_timing.py) plus a zero-fill launch.
     float* red = reinterpret_cast<float*>(smem) + wave * (D * 33);
+    float* dpart = dkv32 + (long long)blockIdx.z * gridDim.y * Nk * 128;
 #pragma unroll
     for (int which = 0; which < 2; ++which) {
         __syncthreads();
@@ -521,26 +535,26 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16
         __builtin_amdgcn_wave_barrier();
         for (int f = lane; f < 32 * D; f += 64) {
             const int kk = f >> 6, d = f & 63;
-            if (kv0 + kk < Nk) atomicAdd(dkv32 + ((long long)b * Nk + kv0 + kk) * 128 + which * 64 + d, red[d * 33 + kk]);
+            if (kv0 + kk < Nk) dpart[((long long)b * Nk + kv0 + kk) * 128 + which * 64 + d] = red[d * 33 + kk];
         }
     }
+    DSTAMP(2);
 }
 
 template <typename H>
 __global__ __launch_bounds__(256) void attn_dkv_store_kernel(const float* __restrict__ dkv32, bf16_t* __restrict__ dK, int lddk,
-                                                             bf16_t* __restrict__ dV, int lddv, long long sdkv, int B, int Nk) {
-    const long long n = (long long)B * Nk * 32;                 // float4 groups
+                                                             bf16_t* __restrict__ dV, int lddv, long long sdkv, int B, int Nk, int zs) {
+    const long long n = (long long)B * Nk * 32;                 // float4 groups per query chunk
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const int q = (int)(i & 31), key = (int)((i >> 5) % Nk), b = (int)((i >> 5) / Nk);
-        const float4 v = *reinterpret_cast<const float4*>(dkv32 + i * 4);
+        float4 v = *reinterpret_cast<const float4*>(dkv32 + i * 4);
+        for (int z = 1; z < zs; ++z) {                          // the query chunks' partial sums
+            const float4 w = *reinterpret_cast<const float4*>(dkv32 + (z * n + i) * 4);
+            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        }
         bf16_t* dst = (q < 16 ? dK + b * sdkv + (long long)key * lddk + q * 4 : dV + b * sdkv + (long long)key * lddv + (q - 16) * 4);
         st4<H>(reinterpret_cast<H*>(dst), v);
     }
-}
-
-__global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, long long n4) {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256)
-        reinterpret_cast<float4*>(p)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // delta[row] = sum_d O[row][d] dO[row][d]: eight lanes x 16 bytes per 128-byte row (the first version read 2 bytes per lane)
@@ -630,6 +644,9 @@ extern "C" int tc_attn_fwd_seg(const void* Q, int ldq, const void* K, int ldk, c
     return tc_launch_status();
 }
 
+#ifdef TC_DKV_TIMING
+extern "C" int tc_dkv_dbg_read(unsigned long long* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_dkv_dbg), sizeof(unsigned long long) * 512 * 4); }
+#endif
 extern "C" int tc_attn_bwd_seg(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, long long skv, const void* O, int ldo,
                                const void* dO, int lddo, const float* lse, float* delta, float* dkv32, void* dQ, int lddq, void* dK, int lddk,
                                void* dV, int lddv, long long sdkv, int B, int nseg, const int* nq, int Nk, float scale, int dtype,
@@ -653,8 +670,6 @@ extern "C" int tc_attn_bwd_seg(const void* Q, int ldq, const void* K, int ldk, c
     if ((dtype != TC_BF16 && dtype != TC_F16) || !dkv32 || ((ldq | ldk | ldv | lddo) & 7) || (skv & 7) ||
         (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)dO) & 15) || ((ldo | lddq | lddk | lddv) & 3) || (sdkv & 3))
         return TC_ERR_ARG;
-    // zero the fp32 dK/dV scratch with a kernel: a memset NODE in a captured single-stream graph was observed to run out of order
-    hipLaunchKernelGGL(zero_f32_kernel, dim3(tc_blocks((long long)B * Nk * 32, 256, 1024)), dim3(256), 0, s, dkv32, (long long)B * Nk * 32);
     // workgroups of 4 key waves (measured: 4 waves x 2 workgroups per CU beats 5 x 1); query chunks so that ~2 workgroups per CU exist
     const int kt = (Nk + 31) / 32, nw = 4;
     const int kb = (kt + nw - 1) / nw, ntiles = sg.t32[nseg];
@@ -664,6 +679,10 @@ extern "C" int tc_attn_bwd_seg(const void* Q, int ldq, const void* K, int ldk, c
     int tpc = (ntiles + zs - 1) / zs;
     tpc = (tpc + 1) & ~1;                                            // whole 64-query stages
     zs = (ntiles + tpc - 1) / tpc;
+    if (zs > TC_ATTN_DKV_SPLITS) {                                    // dkv32 holds TC_ATTN_DKV_SPLITS partial buffers
+        tpc = ((ntiles + TC_ATTN_DKV_SPLITS - 1) / TC_ATTN_DKV_SPLITS + 1) & ~1;
+        zs = (ntiles + tpc - 1) / tpc;
+    }
     const int wide_dq = !(lddq & 7) && !((uintptr_t)dQ & 15);
     const int wide_rows = !((ldo | lddo) & 7) && !(((uintptr_t)O | (uintptr_t)dO) & 15);
     static bool lds_ok[2] = {false, false};
@@ -679,7 +698,7 @@ extern "C" int tc_attn_bwd_seg(const void* Q, int ldq, const void* K, int ldk, c
         hipLaunchKernelGGL((attn_bwd_dkv_seg_kernel<HH, 4>), dim3(kb, B, zs), dim3(256), 0, s, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk,    \
                            (const bf16_t*)V, ldv, skv, (const bf16_t*)dO, lddo, lse, delta, dkv32, sg, Nk, scale, tpc);                     \
         hipLaunchKernelGGL(attn_dkv_store_kernel<HH>, dim3(tc_blocks((long long)B * Nk * 32, 256, 1024)), dim3(256), 0, s, dkv32,           \
-                           (bf16_t*)dK, lddk, (bf16_t*)dV, lddv, sdkv, B, Nk);                                                              \
+                           (bf16_t*)dK, lddk, (bf16_t*)dV, lddv, sdkv, B, Nk, zs);                                                              \
         hipLaunchKernelGGL(attn_bwd_dq_seg_kernel<HH>, dim3((unsigned)B * ((sg.t32[nseg] + FW_NW - 1) / FW_NW)), dim3(FW_NT), FW_SMEM, s,     \
                            (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk, (const bf16_t*)V, ldv, skv, (const bf16_t*)dO, lddo, lse, delta,    \
                            (bf16_t*)dQ, lddq, sg, Nk, scale, wide_dq);                                                                      \

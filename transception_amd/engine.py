@@ -18,7 +18,7 @@ from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
 
-from ._lib import (ACT_COORD, ACT_GELU, ACT_HSWISH, ACT_NONE, ACT_SIGMOID, FFN_EP, FFN_LN_A, FFN_LN_B, TC_BF16, TC_F16, TC_F32, TcDwSeg, TcFfnSeg,
+from ._lib import (ATTN_DKV_SPLITS, ACT_COORD, ACT_GELU, ACT_HSWISH, ACT_NONE, ACT_SIGMOID, FFN_EP, FFN_LN_A, FFN_LN_B, TC_BF16, TC_F16, TC_F32, TcDwSeg, TcFfnSeg,
                    TcGemm, lib)
 
 _DT = {torch.float32: TC_F32, torch.bfloat16: TC_BF16, torch.float16: TC_F16}
@@ -1285,7 +1285,7 @@ class Graph:
             gv, av = self.wgrad(v)
             assert not (aq or ak or av), "attention_seg expects single-use q / k / v"
             delta = self.f32(rows)
-            dkv32 = self.f32(B * Nk * 128) if self.dtype != torch.float32 else None
+            dkv32 = self.f32(ATTN_DKV_SPLITS * B * Nk * 128) if self.dtype != torch.float32 else None
             _timed("attn_bwd", 10.0 * rows * Nk * 64, lambda: self.L.tc_attn_bwd_seg(
                 _ptr(q.data), q.ld, _ptr(k.data), k.ld, _ptr(v.data), v.ld, Nk * k.ld, _ptr(out.data), out.ld, _ptr(dO),
                 dO.stride(0), _ptr(lse), _ptr(delta), _ptr(dkv32), _ptr(gq), gq.stride(0), _ptr(gk), gk.stride(0), _ptr(gv),
