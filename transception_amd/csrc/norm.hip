@@ -11,6 +11,7 @@ constexpr int LN_MAXC = 2048;
 #define LN_FOLD 8
 #endif
 constexpr int LN_BWD_MAX_BLOCKS = 1024, LN_BWD_ROWS_PER_GROUP = 4;   // fused dx + parameter-gradient launch
+inline int ln_bwd_wg_min() { static const int v = getenv("TC_LN_WG_MIN") ? atoi(getenv("TC_LN_WG_MIN")) : 512; return v < 16 ? 16 : v; }
 inline int ln_bwd_blocks() {   // A/B switch (<= LN_BWD_MAX_BLOCKS, which sizes the scratch)
     static const int v = getenv("TC_LN_BWD_BLOCKS") ? atoi(getenv("TC_LN_BWD_BLOCKS")) : LN_BWD_MAX_BLOCKS;
     return v < 16 ? 16 : (v > LN_BWD_MAX_BLOCKS ? LN_BWD_MAX_BLOCKS : v);
@@ -560,7 +561,7 @@ static int ln_bwd_impl(const void* dy, int lddy, const void* x, int ldx, const v
 #define TC_LNB(GS, NV) {                                                                                                                  \
         constexpr int RPT = 1;   /* two rows in flight measured no faster here (20.5 vs 19.3 us at 97216 x 64): one row per group */      \
         const bool ilp = RPT > 1 && rows >= 8192;                                                                                         \
-        int rpg = dgamma ? rows / ((256 / GS) * 512) : 1;            /* rows per lane group: >= 512 workgroups before rows are stacked */ \
+        int rpg = dgamma ? rows / ((256 / GS) * ln_bwd_wg_min()) : 1; /* rows per lane group: >= 512 workgroups before rows are stacked */ \
         rpg = rpg < 1 ? 1 : (rpg > LN_BWD_ROWS_PER_GROUP ? LN_BWD_ROWS_PER_GROUP : rpg);                                                    \
         if (ilp && rpg < RPT) rpg = RPT;                                                                                                  \
         nblk = tc_blocks(rows, (256 / GS) * rpg, dgamma ? ln_bwd_blocks() : 8192);                                                        \
