@@ -475,7 +475,10 @@ __device__ __forceinline__ void dw_fetch(uint4 (&reg)[NREG], const T* img, int l
     for (int i = 0; i < NREG; ++i) {
         int op, cgi;
         const bool ok = dw_inside<T, CG>(threadIdx.x + i * NTH, h0, w0, NH, NW, H, W, crem, op, cgi);
-        reg[i] = *reinterpret_cast<const uint4*>(ok ? img + (long long)op * ld + cgi * VEC : img);
+        // 32-bit byte offset from the (uniform) image base: one multiply-add per load instead of a 64-bit address per lane
+        // (an image's map is far below 4 GB: H * W * ld * sizeof(T))
+        const unsigned boff = ok ? (unsigned)(op * ld + cgi * VEC) * (unsigned)sizeof(T) : 0u;
+        reg[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(img) + boff);
     }
 }
 template <typename T, int CG, int PIXQ, int NREG>
