@@ -187,7 +187,9 @@ __global__ __launch_bounds__(256) void factor_att_bwd_kernel(const T* __restrict
     float* ctx = e + N * Ch;
     float* dctx = ctx + Ch * Ch;
     float* tcol = dctx + Ch * Ch;        // [Ch] (+ padding to 16 bytes)
-    T* vs = reinterpret_cast<T*>(tcol + ((Ch + 3) & ~3));       // v, q, do tiles in the storage type
+    float* ctxT = tcol + ((Ch + 3) & ~3);                      // ctx^T, dctx^T: the per-token loop reads VEC consecutive floats of a row
+    float* dctxT = ctxT + Ch * Ch;
+    T* vs = reinterpret_cast<T*>(dctxT + Ch * Ch);             // v, q, do tiles in the storage type
     T* qs = vs + N * Ch;
     T* gs = qs + N * Ch;
     const int bt = blockIdx.x / heads, hd = blockIdx.x - bt * heads, tid = threadIdx.x;
@@ -207,6 +209,7 @@ __global__ __launch_bounds__(256) void factor_att_bwd_kernel(const T* __restrict
     for (int i = tid; i < Ch * Ch; i += 256) dctx[i] *= scale;
     __syncthreads();
     if (tid < Ch) { float t = 0.f; for (int j = 0; j < Ch; ++j) t += ctx[tid * Ch + j] * dctx[tid * Ch + j]; tcol[tid] = t; }
+    for (int i = tid; i < Ch * Ch; i += 256) { const int c = i / Ch, j = i - c * Ch; ctxT[j * Ch + c] = ctx[i]; dctxT[j * Ch + c] = dctx[i]; }
     __syncthreads();
     const int nv = Ch / VEC;
     for (int i = tid; i < N * nv; i += 256) {
@@ -220,11 +223,18 @@ __global__ __launch_bounds__(256) void factor_att_bwd_kernel(const T* __restrict
         for (int u = 0; u < VEC; ++u) a_q[u] = a_ks[u] = a_v[u] = 0.f;
         for (int j = 0; j < Ch; ++j) {
             const float gj = fa_get(gr, j), vj = fa_get(vr, j), ej = er[j];
+            float cq[VEC], ck[VEC], cw[VEC];                  // 16-byte LDS reads (the first version read 3 x VEC scalars per j, two of them strided)
+#pragma unroll
+            for (int u = 0; u < VEC; u += 4) {
+                *reinterpret_cast<float4*>(cq + u) = *reinterpret_cast<const float4*>(ctxT + j * Ch + c0 + u);
+                *reinterpret_cast<float4*>(ck + u) = *reinterpret_cast<const float4*>(dctxT + j * Ch + c0 + u);
+                *reinterpret_cast<float4*>(cw + u) = *reinterpret_cast<const float4*>(dctx + j * Ch + c0 + u);
+            }
 #pragma unroll
             for (int u = 0; u < VEC; ++u) {
-                a_q[u] += gj * ctx[(c0 + u) * Ch + j];        // dq[n,c]  += scale * sum_j do[n,j] ctx[c,j]
-                a_ks[u] += vj * dctx[(c0 + u) * Ch + j];      // dksm[n,c] = sum_j v[n,j] dctx[c,j]
-                a_v[u] += ej * dctx[j * Ch + c0 + u];         // dv[n,c]   = sum_i ksm[n,i] dctx[i,c]
+                a_q[u] += gj * cq[u];                         // dq[n,c]  += scale * sum_j do[n,j] ctx[c,j]
+                a_ks[u] += vj * ck[u];                        // dksm[n,c] = sum_j v[n,j] dctx[c,j]
+                a_v[u] += ej * cw[u];                         // dv[n,c]   = sum_i ksm[n,i] dctx[i,c]
             }
         }
         unpack16<T>(*reinterpret_cast<const uint4*>(convv + r * ldc + col0 + c0), cv);
@@ -282,7 +292,7 @@ extern "C" int tc_factor_att_bwd(const void* q, const void* k, const void* v, in
         (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)convv | (uintptr_t)go | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv | (uintptr_t)dconvv) & 15))
         return TC_ERR_ARG;
     const size_t esz = dtype == TC_F32 ? 4 : 2;
-    const size_t smem = sizeof(float) * ((size_t)N * Ch + (size_t)2 * Ch * Ch + ((Ch + 3) & ~3)) + 3 * esz * N * Ch;
+    const size_t smem = sizeof(float) * ((size_t)N * Ch + (size_t)4 * Ch * Ch + ((Ch + 3) & ~3)) + 3 * esz * N * Ch;
     if (smem > 150 * 1024) return TC_ERR_ARG;
     TC_DISPATCH_DTYPE(dtype, {
         if (smem > 64 * 1024) hipFuncSetAttribute((const void*)factor_att_bwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
