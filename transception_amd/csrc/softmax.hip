@@ -45,6 +45,84 @@ __global__ __launch_bounds__(256) void softmax_rows_bwd(const T* __restrict__ dy
     }
 }
 
+// Long rows (the N = 6076 key softmax of the bridge's channel attention, MSTr.py:2322-2324: 64 rows per image): ONE workgroup per row,
+// the row in registers as up to 8 four-element vectors per thread, maxima and sums folded through LDS -- one pass of 8/16-byte
+// accesses where softmax_rows_fwd walks the row three times with one element per lane and one wavefront per row (50 / 62 us).
+constexpr int ROWWG_NV = 8;
+__device__ __forceinline__ float block_reduce(float v, bool is_max, float* red) {
+    v = is_max ? wave_max(v) : wave_sum(v);
+    __syncthreads();                                             // (red may still be read by the previous reduction)
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return is_max ? fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) : (red[0] + red[1]) + (red[2] + red[3]);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rowwg_fwd(const T* __restrict__ x, T* __restrict__ y, long long sbx, long long sby,
+                                                         int R, int Cc, int ldx, int ldy) {
+    __shared__ float red[4];
+    const int b = blockIdx.x / R, r = blockIdx.x - b * R, nv = Cc >> 2;
+    const T* xr = x + b * sbx + (long long)r * ldx;
+    T* yr = y + b * sby + (long long)r * ldy;
+    float4 v[ROWWG_NV];
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < ROWWG_NV; ++i) {
+        const int q = threadIdx.x + i * 256;
+        v[i] = q < nv ? ld4<T>(xr + 4 * q) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        m = fmaxf(fmaxf(m, fmaxf(v[i].x, v[i].y)), fmaxf(v[i].z, v[i].w));
+    }
+    m = block_reduce(m, true, red);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < ROWWG_NV; ++i) {
+        v[i].x = __expf(v[i].x - m); v[i].y = __expf(v[i].y - m); v[i].z = __expf(v[i].z - m); v[i].w = __expf(v[i].w - m);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);              // (padding lanes hold exp(-inf) = 0)
+    }
+    s = 1.0f / block_reduce(s, false, red);
+#pragma unroll
+    for (int i = 0; i < ROWWG_NV; ++i) {
+        const int q = threadIdx.x + i * 256;
+        if (q < nv) st4<T>(yr + 4 * q, make_float4(v[i].x * s, v[i].y * s, v[i].z * s, v[i].w * s));
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rowwg_bwd(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx,
+                                                         long long sbdy, long long sby, long long sbdx, int R, int Cc, int lddy,
+                                                         int ldy, int lddx, int accumulate) {
+    __shared__ float red[4];
+    const int b = blockIdx.x / R, r = blockIdx.x - b * R, nv = Cc >> 2;
+    const T* dyr = dy + b * sbdy + (long long)r * lddy;
+    const T* yr = y + b * sby + (long long)r * ldy;
+    T* dxr = dx + b * sbdx + (long long)r * lddx;
+    float4 g[ROWWG_NV], p[ROWWG_NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < ROWWG_NV; ++i) {
+        const int q = threadIdx.x + i * 256;
+        g[i] = q < nv ? ld4<T>(dyr + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        p[i] = q < nv ? ld4<T>(yr + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (g[i].x * p[i].x + g[i].y * p[i].y) + (g[i].z * p[i].z + g[i].w * p[i].w);
+    }
+    s = block_reduce(s, false, red);
+#pragma unroll
+    for (int i = 0; i < ROWWG_NV; ++i) {
+        const int q = threadIdx.x + i * 256;
+        if (q < nv) {
+            float4 o = make_float4(p[i].x * (g[i].x - s), p[i].y * (g[i].y - s), p[i].z * (g[i].z - s), p[i].w * (g[i].w - s));
+            if (accumulate) { const float4 a = ld4<T>(dxr + 4 * q); o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w; }
+            st4<T>(dxr + 4 * q, o);
+        }
+    }
+}
+// long-row form usable: whole 4-element vectors at 4-element-aligned addresses, row within ROWWG_NV x 1024 elements
+template <typename T>
+bool rowwg_ok(int Cc, std::initializer_list<long long> strides, std::initializer_list<const void*> ptrs) {
+    if ((Cc & 3) || Cc <= 512 || Cc > ROWWG_NV * 1024) return false;
+    for (long long v : strides) if (v & 3) return false;
+    for (const void* q : ptrs) if ((uintptr_t)q % (4 * sizeof(T))) return false;
+    return true;
+}
+
 // Rows of up to 512 channels, a multiple of 4 (the channel softmax of the query in EfficientAttention, MSTr.py:124-128): 16 lanes per
 // row, 4 rows per wavefront, each lane keeps its NV four-channel vectors in registers -- one pass over the row with 8/16-byte
 // accesses instead of three passes of one element per lane and one row per wavefront.
@@ -263,6 +341,8 @@ extern "C" int tc_softmax_fwd(const void* x, void* y, float* scratch, int nb, lo
     TC_DISPATCH_DTYPE(dtype, {
         if (axis == 1 && rows16_ok<T>(Cc, {sbx, sby, ldx, ldy}, {x, y})) {
             launch_rows16_fwd<T>((const T*)x, (T*)y, sbx, sby, R, Cc, ldx, ldy, nrows, s);
+        } else if (axis == 1 && rowwg_ok<T>(Cc, {sbx, sby, ldx, ldy}, {x, y})) {
+            hipLaunchKernelGGL((softmax_rowwg_fwd<T>), dim3((unsigned)nrows), dim3(256), 0, s, (const T*)x, (T*)y, sbx, sby, R, Cc, ldx, ldy);
         } else if (axis == 1) hipLaunchKernelGGL((softmax_rows_fwd<T>), dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, s, (const T*)x,
                                           (T*)y, sbx, sby, R, Cc, ldx, ldy, nrows);
         else {
@@ -287,6 +367,9 @@ extern "C" int tc_softmax_bwd(const void* dy, const void* y, void* dx, float* sc
     TC_DISPATCH_DTYPE(dtype, {
         if (axis == 1 && rows16_ok<T>(Cc, {sbdy, sby, sbdx, lddy, ldy, lddx}, {dy, y, dx})) {
             launch_rows16_bwd<T>((const T*)dy, (const T*)y, (T*)dx, sbdy, sby, sbdx, R, Cc, lddy, ldy, lddx, nrows, accumulate, s);
+        } else if (axis == 1 && rowwg_ok<T>(Cc, {sbdy, sby, sbdx, lddy, ldy, lddx}, {dy, y, dx})) {
+            hipLaunchKernelGGL((softmax_rowwg_bwd<T>), dim3((unsigned)nrows), dim3(256), 0, s, (const T*)dy, (const T*)y, (T*)dx, sbdy, sby,
+                               sbdx, R, Cc, lddy, ldy, lddx, accumulate);
         } else if (axis == 1) hipLaunchKernelGGL((softmax_rows_bwd<T>), dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, s, (const T*)dy,
                                           (const T*)y, (T*)dx, sbdy, sby, sbdx, R, Cc, lddy, ldy, lddx, nrows, accumulate);
         else {
