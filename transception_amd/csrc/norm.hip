@@ -559,8 +559,9 @@ static int ln_bwd_impl(const void* dy, int lddy, const void* x, int ldx, const v
                                           (const T*)gamma, (const T*)beta, mean, rstd, (T*)dx, lddx, (const T*)dres, ldres, dgamma,      \
                                           dbeta, rows, C, act, pstride, partial, reinterpret_cast<int*>(scratch), map)
 #define TC_LNB(GS, NV) {                                                                                                                  \
-        constexpr int RPT = 1;   /* two rows in flight measured no faster here (20.5 vs 19.3 us at 97216 x 64): one row per group */      \
-        const bool ilp = RPT > 1 && rows >= 8192;                                                                                         \
+        constexpr int RPT = 2;   /* rows in flight per lane group (narrow rows): 14.16 vs 14.19 ms per step; 4 rows: 14.21 vs 14.22 */                                                         \
+        static const int ilp_on = getenv("TC_LN_BWD_ILP") ? atoi(getenv("TC_LN_BWD_ILP")) : 1;                                             \
+        const bool ilp = ilp_on && NV == 1 && rows >= 8192;                                                                                \
         int rpg = dgamma ? rows / ((256 / GS) * ln_bwd_wg_min()) : 1; /* rows per lane group: >= 512 workgroups before rows are stacked */ \
         rpg = rpg < 1 ? 1 : (rpg > LN_BWD_ROWS_PER_GROUP ? LN_BWD_ROWS_PER_GROUP : rpg);                                                    \
         if (ilp && rpg < RPT) rpg = RPT;                                                                                                  \
