@@ -929,8 +929,13 @@ __device__ __forceinline__ void tc_xcd_tile(int& bx, int& by, const int gx, cons
     bx = t - by * gx;
 }
 
+// resident workgroups per CU the 64x64 kernels are compiled for (89-90 VGPRs without spills; 6: 67-73 VGPRs, equal end to end; 8 spills:
+// 14.54 vs 14.14 ms per step)
+#ifndef GEMM_OCC64
+#define GEMM_OCC64 5
+#endif
 template <typename H, typename TC, int BM, int BN, bool TA, bool TB, bool DB, int FFN = 0>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmDev p) {
+__global__ __launch_bounds__(256, (BM == 64 && BN == 64) ? GEMM_OCC64 : 2) void gemm_bf16_kernel(GemmDev p) {
     // ONE buffer: A slabs first, B slabs behind them -- the epilogue reuses it from the start as its C staging tile
     __shared__ __attribute__((aligned(16))) bf16_t smem[(DB ? 2 : 1) * (BM + BN) * (64 + 8)];
     int tbx = blockIdx.x, tby = blockIdx.y;
