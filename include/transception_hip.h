@@ -309,6 +309,21 @@ int tc_coord_gate_fwd(const void* x, const void* att, void* y, int B, int H, int
 int tc_coord_gate_bwd(const void* dy, const void* x, const void* att, void* dx, int dx_accumulate,
                       void* datt, int B, int H, int W, int C, int dtype, void* stream);
 
+/* Up to TC_EW_MULTI_MAX independent layout moves in one launch (Scale_reduce, MSTr.py:2225-2249: the three patchifies; the three
+ * channel de-interleaves + the stage-4 token copy).  kind / fields (the arguments of the single-op entry points):
+ *   TC_EW_PATCHIFY      a = map, sa = sb_map, lda = ld_map, b = cols, n0..n4 = B, H, W, C, k, flag = inverse      (tc_patchify)
+ *   TC_EW_DEINTERLEAVE  a = in, b = out, sb = sbo, ldb = ldo, n0..n3 = B, P, C, mult, flag = inverse              (tc_sr_deinterleave)
+ *   TC_EW_COPY          a = src, sa = sbs, lda = lds, b = dst, sb = sbd, ldb = ldd, n0..n2 = nb, rows, cols, flag = accumulate (tc_copy3d) */
+#define TC_EW_MULTI_MAX 4
+enum { TC_EW_PATCHIFY = 0, TC_EW_DEINTERLEAVE = 1, TC_EW_COPY = 2 };
+typedef struct TcEwSeg {
+    int kind, flag;
+    const void* a; void* b;
+    long long sa, sb;
+    int lda, ldb, n0, n1, n2, n3, n4, reserved;
+} TcEwSeg;
+int tc_ew_multi(const TcEwSeg* segs, int nseg, int dtype, void* stream);
+
 /* Pixel shuffle of PatchExpand / FinalPatchExpand_X4, MSTr.py:196-197,222-223:
  *   fwd: in [B,H,W,p*p*c] -> out [B,H*p,W*p,c] with channel index (p1*p + p2)*c + cc ; inverse=1 undoes it. */
 int tc_pixel_shuffle(const void* in, void* out, int B, int H, int W, int p, int c, int inverse, int dtype,

@@ -48,6 +48,14 @@ class TcFfnSeg(C.Structure):
                 ("C", i32), ("ldg", i32), ("ldd", i32), ("ldh", i32), ("lddh", i32), ("B", i32), ("H", i32), ("W", i32), ("nch2", i32)]
 
 
+class TcEwSeg(C.Structure):
+    _fields_ = [("kind", i32), ("flag", i32), ("a", vp), ("b", vp), ("sa", i64), ("sb", i64),
+                ("lda", i32), ("ldb", i32), ("n0", i32), ("n1", i32), ("n2", i32), ("n3", i32), ("n4", i32), ("reserved", i32)]
+
+
+EW_PATCHIFY, EW_DEINTERLEAVE, EW_COPY = 0, 1, 2
+
+
 class TcSliceAug(C.Structure):
     _fields_ = [("m", C.c_double * 6), ("disp", C.c_float * 32), ("alpha", f32), ("center", f32), ("noise_sigma", f32),
                 ("noise_seed", C.c_uint), ("flags", i32), ("reserved", i32)]
@@ -59,6 +67,7 @@ TC_AUG_WARP, TC_AUG_LINEAR, TC_AUG_BLUR, TC_AUG_PIECEWISE = 1, 2, 4, 8
 SIGNATURES = {
     "tc_abi_version": [],
     "tc_gemm": [C.POINTER(TcGemm), vp],
+    "tc_ew_multi": [C.POINTER(TcEwSeg), i32, i32, vp],
     "tc_gemm_pair": [C.POINTER(TcGemm), C.POINTER(TcGemm), vp],
     "tc_gemm_multi": [C.POINTER(TcGemm), i32, vp],
     "tc_colsum": [vp, i32, i32, i32, i32, i64, vp, i32, i32, vp],

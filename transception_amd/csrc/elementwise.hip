@@ -45,7 +45,7 @@ __global__ void sigmoid_bwd_kernel(const T* dy, const T* s, T* dz, long long n) 
 }
 
 template <typename T>
-__global__ void copy3d_kernel(const T* src, long long sbs, int lds, T* dst, long long sbd, int ldd, int nb, int rows, int cols, int acc) {
+__device__ __forceinline__ void copy3d_body(const T* src, long long sbs, int lds, T* dst, long long sbd, int ldd, int nb, int rows, int cols, int acc) {
     TC_GRID_STRIDE(i, (long long)nb * rows * cols) {
         const int c = (int)(i % cols); const long long t = i / cols; const int r = (int)(t % rows); const long long b = t / rows;
         T* d = dst + b * sbd + (long long)r * ldd + c;
@@ -53,6 +53,10 @@ __global__ void copy3d_kernel(const T* src, long long sbs, int lds, T* dst, long
         if (acc) v += ldf<T>(d);
         stf<T>(d, v);
     }
+}
+template <typename T>
+__global__ void copy3d_kernel(const T* src, long long sbs, int lds, T* dst, long long sbd, int ldd, int nb, int rows, int cols, int acc) {
+    copy3d_body<T>(src, sbs, lds, dst, sbd, ldd, nb, rows, cols, acc);
 }
 
 template <typename T>
@@ -173,7 +177,7 @@ __global__ void pixel_shuffle_kernel(const T* in, T* out, int B, int H, int W, i
 }
 
 template <typename T>
-__global__ void patchify_kernel(const T* map, long long sb, int ld, T* cols, int B, int H, int W, int C, int k, int inverse) {
+__device__ __forceinline__ void patchify_body(const T* map, long long sb, int ld, T* cols, int B, int H, int W, int C, int k, int inverse) {
     const int cq = C >> 2, Ho = H / k, Wo = W / k;
     const long long n = (long long)B * H * W * cq;
     T* m = const_cast<T*>(map);
@@ -194,9 +198,13 @@ __global__ void patchify_kernel(const T* map, long long sb, int ld, T* cols, int
         }
     }
 }
+template <typename T>
+__global__ void patchify_kernel(const T* map, long long sb, int ld, T* cols, int B, int H, int W, int C, int k, int inverse) {
+    patchify_body<T>(map, sb, ld, cols, B, H, W, C, k, inverse);
+}
 
 template <typename T>
-__global__ void sr_deinterleave_kernel(const T* in, T* out, long long sbo, int ldo, int B, int P, int C, int mult, int inverse) {
+__device__ __forceinline__ void sr_deinterleave_body(const T* in, T* out, long long sbo, int ldo, int B, int P, int C, int mult, int inverse) {
     // out[b, g*P+pos, c] = in[b, pos, c*mult+g]   (in: [B, P, C*mult] contiguous)
     const long long n = (long long)B * P * C * mult;
     T* o = out; T* ii = const_cast<T*>(in);
@@ -207,6 +215,22 @@ __global__ void sr_deinterleave_kernel(const T* in, T* out, long long sbo, int l
         const long long si = ((long long)b * P + pos) * (C * mult) + c * mult + g;
         if (!inverse) o[oi] = ii[si]; else ii[si] = o[oi];
     }
+}
+template <typename T>
+__global__ void sr_deinterleave_kernel(const T* in, T* out, long long sbo, int ldo, int B, int P, int C, int mult, int inverse) {
+    sr_deinterleave_body<T>(in, out, sbo, ldo, B, P, C, mult, inverse);
+}
+
+// Up to TC_EW_MULTI_MAX independent layout moves (patchify / de-interleave / strided copy) in ONE launch: blockIdx.y picks the segment.
+// Scale_reduce (MSTr.py:2225-2249) is three patchifies, three convolutions as GEMMs, three de-interleaves and a copy on maps of a few
+// hundred KB: each of them alone sits at the ~4.5 us floor of a launch.
+struct EwMultiDev { TcEwSeg s[TC_EW_MULTI_MAX]; };
+template <typename T>
+__global__ void ew_multi_kernel(EwMultiDev q) {
+    const TcEwSeg& g = q.s[blockIdx.y];
+    if (g.kind == TC_EW_PATCHIFY) patchify_body<T>((const T*)g.a, g.sa, g.lda, (T*)g.b, g.n0, g.n1, g.n2, g.n3, g.n4, g.flag);
+    else if (g.kind == TC_EW_DEINTERLEAVE) sr_deinterleave_body<T>((const T*)g.a, (T*)g.b, g.sb, g.ldb, g.n0, g.n1, g.n2, g.n3, g.flag);
+    else copy3d_body<T>((const T*)g.a, g.sa, g.lda, (T*)g.b, g.sb, g.ldb, g.n0, g.n1, g.n2, g.flag);
 }
 
 template <typename T>
@@ -324,6 +348,32 @@ extern "C" int tc_sr_deinterleave(const void* in, void* out, long long sbo, int 
     if (!in || !out || B <= 0 || P <= 0 || C <= 0 || mult <= 0) return TC_ERR_ARG;
     TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((sr_deinterleave_kernel<T>), g1((long long)B * P * C * mult), dim3(256), 0, TC_S,
                                                 (const T*)in, (T*)out, sbo, ldo, B, P, C, mult, inverse));
+    return tc_launch_status();
+}
+extern "C" int tc_ew_multi(const TcEwSeg* segs, int nseg, int dtype, void* stream) {
+    if (!segs || nseg < 1 || nseg > TC_EW_MULTI_MAX) return TC_ERR_ARG;
+    EwMultiDev q;
+    long long nmax = 0;
+    for (int i = 0; i < nseg; ++i) {
+        const TcEwSeg& g = segs[i];
+        if (!g.a || !g.b) return TC_ERR_ARG;
+        long long n;
+        if (g.kind == TC_EW_PATCHIFY) {                          // tc_patchify's conditions
+            if (g.n0 <= 0 || g.n1 <= 0 || g.n2 <= 0 || g.n3 <= 0 || (g.n3 & 3) || g.n4 <= 0 || g.n1 % g.n4 || g.n2 % g.n4 || (g.lda & 3) || (g.sa & 3)) return TC_ERR_ARG;
+            n = (long long)g.n0 * g.n1 * g.n2 * g.n3 / 4;
+        } else if (g.kind == TC_EW_DEINTERLEAVE) {
+            if (g.n0 <= 0 || g.n1 <= 0 || g.n2 <= 0 || g.n3 <= 0) return TC_ERR_ARG;
+            n = (long long)g.n0 * g.n1 * g.n2 * g.n3;
+        } else if (g.kind == TC_EW_COPY) {
+            if (g.n0 <= 0 || g.n1 <= 0 || g.n2 <= 0) return TC_ERR_ARG;
+            n = (long long)g.n0 * g.n1 * g.n2;
+        } else return TC_ERR_ARG;
+        nmax = n > nmax ? n : nmax;
+        q.s[i] = g;
+    }
+    dim3 grid = g1(nmax);
+    grid.y = nseg;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ew_multi_kernel<T>), grid, dim3(256), 0, TC_S, q));
     return tc_launch_status();
 }
 extern "C" int tc_stem_im2col(const void* img, void* cols, int ldc, int B, int in_ch, int H, int W, int dtype, void* stream) {

@@ -18,7 +18,7 @@ from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
 
-from ._lib import (ATTN_DKV_SPLITS, ACT_COORD, ACT_GELU, ACT_HSWISH, ACT_NONE, ACT_SIGMOID, FFN_EP, FFN_LN_A, FFN_LN_B, TC_BF16, TC_F16, TC_F32, TcDwSeg, TcFfnSeg,
+from ._lib import (ATTN_DKV_SPLITS, EW_COPY, EW_DEINTERLEAVE, EW_PATCHIFY, TcEwSeg, ACT_COORD, ACT_GELU, ACT_HSWISH, ACT_NONE, ACT_SIGMOID, FFN_EP, FFN_LN_A, FFN_LN_B, TC_BF16, TC_F16, TC_F32, TcDwSeg, TcFfnSeg,
                    TcGemm, lib)
 
 _DT = {torch.float32: TC_F32, torch.bfloat16: TC_BF16, torch.float16: TC_F16}
@@ -1190,6 +1190,64 @@ class Graph:
             self.L.tc_patchify(gbase, sb, Cc, _ptr(d), B, H, W, Cc, k, 2, self.dt, self.stream)
         self._rec(bwd)
         return out
+
+    def _ew_multi(self, segs):
+        arr = (TcEwSeg * len(segs))(*segs)
+        self.L.tc_ew_multi(arr, len(segs), self.dt, self.stream)
+
+    def patchify_many(self, buf: Var, items) -> List[Var]:
+        """patchify of several maps of `buf` in ONE launch (and one launch for their gradients).  items: (off, sb, B, H, W, Cc, k)."""
+        assert buf.data.is_contiguous() and buf.is_whole and len(items) <= 4
+        es = buf.data.element_size()
+        outs = [self.new(B * (H // k) * (W // k), k * k * Cc) for (_, _, B, H, W, Cc, k) in items]
+        self._ew_multi([TcEwSeg(EW_PATCHIFY, 0, buf.data.data_ptr() + off * es, _ptr(o.data), sb, 0, Cc, 0, B, H, W, Cc, k, 0)
+                        for (off, sb, B, H, W, Cc, k), o in zip(items, outs)])
+
+        def bwd():
+            segs = []
+            for (off, sb, B, H, W, Cc, k), o in zip(items, outs):
+                d = self.grad_of(o)
+                if d is None:
+                    continue
+                gt = self._region_grad(buf.root, off, B * sb)
+                segs.append(TcEwSeg(EW_PATCHIFY, 2, gt.data_ptr() + off * gt.element_size(), _ptr(d), sb, 0, Cc, 0, B, H, W, Cc, k, 0))
+            if segs:
+                self._ew_multi(segs)
+        self._rec(bwd)
+        return outs
+
+    def sr_gather(self, parts, copy, dst: Var):
+        """The de-interleaves of Scale_reduce (parts: (x, dst_off, dst_sb, B, Pn, Cc, mult)) and the stage-4 row copy
+        (copy: (src, src_off, src_sb, dst_off, dst_sb, nb, rows, cols)) into `dst` in ONE launch, their gradients in one more."""
+        assert dst.data.is_contiguous() and dst.is_whole and len(parts) <= 3
+        es = dst.data.element_size()
+        src, s_off, s_sb, d_off, d_sb, nb, rows, cols = copy
+        assert src.data.is_contiguous() and src.is_whole
+        segs = [TcEwSeg(EW_DEINTERLEAVE, 0, _ptr(x.data), dst.data.data_ptr() + off * es, 0, sb, 0, dst.ld, B, Pn, Cc, mult, 0, 0)
+                for (x, off, sb, B, Pn, Cc, mult) in parts]
+        segs.append(TcEwSeg(EW_COPY, 0, src.data.data_ptr() + s_off * es, dst.data.data_ptr() + d_off * es, s_sb, d_sb, src.ld, dst.ld,
+                            nb, rows, cols, 0, 0, 0))
+        self._ew_multi(segs)
+
+        def bwd():
+            dg = self.grad_of(dst)
+            if dg is None:
+                return
+            segs, late = [], []
+            for (x, off, sb, B, Pn, Cc, mult) in parts:
+                g, acc = self.wgrad(x)
+                if acc:                                          # (not on the model's path: x is the fresh output of a convolution)
+                    late.append((x, off, sb, B, Pn, Cc, mult))
+                    continue
+                segs.append(TcEwSeg(EW_DEINTERLEAVE, 1, _ptr(g), dg.data_ptr() + off * es, 0, sb, 0, dst.ld, B, Pn, Cc, mult, 0, 0))
+            gt = self._region_grad(src.root, s_off, nb * s_sb)
+            segs.append(TcEwSeg(EW_COPY, 1, dg.data_ptr() + d_off * es, gt.data_ptr() + s_off * es, d_sb, s_sb, dst.ld, src.ld,
+                                nb, rows, cols, 0, 0, 0))
+            self._ew_multi(segs)
+            for (x, off, sb, B, Pn, Cc, mult) in late:
+                self._write_or_add(x, lambda g_: self.L.tc_sr_deinterleave(_ptr(g_), dg.data_ptr() + off * es, sb, dst.ld, B, Pn, Cc, mult,
+                                                                            1, self.dt, self.stream))
+        self._rec(bwd)
 
     def copy_rows(self, src: Var, src_off: int, src_sb: int, dst: Var, dst_off: int, dst_sb: int, nb: int, rows: int, cols: int):
         """dst[b, r, :] = src[b, r, :] for batch-strided row blocks (offsets/strides in elements of the contiguous roots)."""

@@ -697,7 +697,9 @@ def _scale_reduce(M, G, n: Var, name: str, B: int, sides: List[int], ntok: List[
     Pn = sides[3] * sides[3]
     Nk = Pn * 8 + ntok[3]
     red = G.new(B * Nk, Cd)                                     # image-major K/V source
-    cols = [G.patchify(n, R[s] * Cd, sides[s] * sides[s] * Cd * MULT[s], B, sides[s], sides[s], Cd * MULT[s], SR_K[s]) for s in range(3)]
+    pitems = [(R[s] * Cd, sides[s] * sides[s] * Cd * MULT[s], B, sides[s], sides[s], Cd * MULT[s], SR_K[s]) for s in range(3)]
+    merged = MANY_MIXFFN and not G.use_streams and G.ngroups == 1     # the layout moves of the three scales share launches
+    cols = G.patchify_many(n, pitems) if merged else [G.patchify(n, *it) for it in pitems]
     lins = [_lin(M, G, f"{name}.sr{s}") for s in range(3)]
     xo = None
     if MANY_MIXFFN and not G.use_streams and G.ngroups == 1:
@@ -710,11 +712,14 @@ def _scale_reduce(M, G, n: Var, name: str, B: int, sides: List[int], ntok: List[
         os_ = [G.linear(cols[s], *lins[s]) for s in range(3)]
         if extra is not None:
             xo = G.linear(*extra)
-    roff = 0
-    for s in range(3):
-        G.sr_deinterleave(os_[s], red, roff * Cd, Nk * Cd, B, Pn, Cd, MULT[s])
-        roff += MULT[s] * Pn
-    G.copy_rows(n, R[3] * Cd, ntok[3] * Cd, red, roff * Cd, Nk * Cd, B, ntok[3], Cd)
+    roffs = [0, MULT[0] * Pn, (MULT[0] + MULT[1]) * Pn, (MULT[0] + MULT[1] + MULT[2]) * Pn]
+    if merged:
+        G.sr_gather([(os_[s], roffs[s] * Cd, Nk * Cd, B, Pn, Cd, MULT[s]) for s in range(3)],
+                    (n, R[3] * Cd, ntok[3] * Cd, roffs[3] * Cd, Nk * Cd, B, ntok[3], Cd), red)
+    else:
+        for s in range(3):
+            G.sr_deinterleave(os_[s], red, roffs[s] * Cd, Nk * Cd, B, Pn, Cd, MULT[s])
+        G.copy_rows(n, R[3] * Cd, ntok[3] * Cd, red, roffs[3] * Cd, Nk * Cd, B, ntok[3], Cd)
     rn = _ln(M, G, red, name + ".norm")
     return rn if extra is None else (rn, xo)
 
