@@ -955,7 +955,10 @@ __global__ __launch_bounds__(256, 2) void gemm_pair_kernel(GemmPairDev q) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (64 + 64) * (64 + 8)];
     bf16_t(*As)[64 * (64 + 8)] = reinterpret_cast<bf16_t(*)[64 * (64 + 8)]>(smem);
     bf16_t(*Bs)[64 * (64 + 8)] = reinterpret_cast<bf16_t(*)[64 * (64 + 8)]>(smem + 2 * 64 * (64 + 8));
-    int lin = blockIdx.x;
+    // the weight-gradient workgroups (long K ranges: 14-26 k cycles against 7-15 k for a dX tile, scripts/exp/gemm_timing.py) are
+    // dispatched FIRST, the dX tiles fill in behind them -- the other way round the launch ended on late-started long workgroups
+    const int nB = (int)gridDim.x - q.nA;
+    int lin = (int)blockIdx.x < nB ? (int)blockIdx.x + q.nA : (int)blockIdx.x - nB;
     if (lin < q.nA) {
         int bx = lin % q.gxA; lin /= q.gxA;
         int by = lin % q.gyA;
