@@ -981,7 +981,7 @@ constexpr int GEMM_MULTI_MAX = 12;
 static_assert(sizeof(GemmDev) * GEMM_MULTI_MAX + 16 * GEMM_MULTI_MAX + 8 <= 4096, "kernel argument block");
 struct GemmMultiDev { GemmDev p[GEMM_MULTI_MAX]; int blk0[GEMM_MULTI_MAX], gx[GEMM_MULTI_MAX], gy[GEMM_MULTI_MAX], kind[GEMM_MULTI_MAX]; int n; };
 template <typename H>
-__global__ __launch_bounds__(256, 2) void gemm_multi_kernel(GemmMultiDev q) {
+__global__ __launch_bounds__(256, 4) void gemm_multi_kernel(GemmMultiDev q) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (64 + 64) * (64 + 8)];
     bf16_t(*As)[64 * (64 + 8)] = reinterpret_cast<bf16_t(*)[64 * (64 + 8)]>(smem);
     bf16_t(*Bs)[64 * (64 + 8)] = reinterpret_cast<bf16_t(*)[64 * (64 + 8)]>(smem + 2 * 64 * (64 + 8));
