@@ -349,6 +349,10 @@ int tc_stem_im2col(const void* img, void* cols, int ldc, int B, int in_ch, int H
  * logits NCHW [B,ncls,HW] (storage dtype), labels int64 [B,HW]; prob (fp32 [B,ncls,HW]) saved for backward. */
 int tc_seg_loss_fwd(const void* logits, const long long* labels, float* prob, float* sums, int B, int ncls,
                     int HW, int dtype, void* stream);
+/* out3 = {w_ce*CE + w_dice*Dice, CE, Dice} from the (all-reduced) forward sums, evaluated in double on the device
+ * (trainer.py:141-143: loss = 0.4*loss_ce + 0.6*loss_dice; utils.py:34-47: smooth 1e-5, mean over classes).  One launch in
+ * place of the sixteen scalar ones of the host expression. */
+int tc_seg_loss_value(const float* sums, int ncls, double n_pix_global, double w_ce, double w_dice, float* out3, void* stream);
 /* dlogits for loss = w_ce*CE_mean + w_dice*mean_c(1 - (2I+eps)/(Z+Y+eps)); sums are the (all-reduced) forward sums;
  * n_pix_global = global pixel count for the CE mean. */
 int tc_seg_loss_bwd(const float* prob, const long long* labels, const float* sums, void* dlogits, int B, int ncls,

@@ -208,6 +208,29 @@ extern "C" int tc_seg_loss_fwd(const void* logits, const long long* labels, floa
     return tc_launch_status();
 }
 
+// loss, CE and Dice from the (all-reduced) sums, in double like the host expression it replaces (sixteen scalar launches between the
+// forward and the backward of every step).  trainer.py:141-143, utils.py:34-47.
+__global__ void seg_loss_value_kernel(const float* __restrict__ sums, int ncls, double n_pix, double w_ce, double w_dice,
+                                      float* __restrict__ out3) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double ce = (double)sums[0] / n_pix;
+    double acc = 0.0;
+    for (int c = 0; c < ncls; ++c) {
+        const double inter = sums[1 + 3 * c], ysum = sums[2 + 3 * c], zsum = sums[3 + 3 * c];
+        acc += 1.0 - (2.0 * inter + 1e-5) / (zsum + ysum + 1e-5);
+    }
+    const double dice = acc / (double)ncls;
+    out3[0] = (float)(w_ce * ce + w_dice * dice);
+    out3[1] = (float)ce;
+    out3[2] = (float)dice;
+}
+
+extern "C" int tc_seg_loss_value(const float* sums, int ncls, double n_pix, double w_ce, double w_dice, float* out3, void* stream) {
+    if (!sums || !out3 || ncls <= 0 || ncls > MAXCLS || !(n_pix > 0.0)) return TC_ERR_ARG;
+    hipLaunchKernelGGL(seg_loss_value_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, ncls, n_pix, w_ce, w_dice, out3);
+    return tc_launch_status();
+}
+
 extern "C" int tc_argmax_counts(const void* logits, const long long* labels, unsigned char* pred, float* counts, int B, int ncls, int HW,
                                 int dtype, void* stream) {
     if (!logits || !pred || (labels && !counts) || B <= 0 || ncls <= 0 || ncls > MAXCLS || HW <= 0) return TC_ERR_ARG;

@@ -35,7 +35,13 @@ def seg_sums_allreduce(sums: torch.Tensor, n_pix: float, group=None):
 
 
 def loss_from_sums(sums: torch.Tensor, n_pix: float, w_ce: float, w_dice: float):
-    """0.4*CE + 0.6*Dice from the (global) sums: trainer.py:141-143, utils.py:34-47 (smooth 1e-5, mean over classes)."""
+    """0.4*CE + 0.6*Dice from the (global) sums: trainer.py:141-143, utils.py:34-47 (smooth 1e-5, mean over classes).
+    Device sums: one tc_seg_loss_value launch.  Host sums (the gloo tests): the same expression in torch, double."""
+    if sums.is_cuda:
+        out3 = torch.empty(3, dtype=torch.float32, device=sums.device)
+        lib().tc_seg_loss_value(sums.data_ptr(), (sums.numel() - 1) // 3, float(n_pix), float(w_ce), float(w_dice), out3.data_ptr(),
+                                torch.cuda.current_stream(sums.device).cuda_stream)
+        return out3[0], out3[1], out3[2]
     s = sums.double()
     ce = s[0] / n_pix
     inter, ysum, zsum = s[1::3], s[2::3], s[3::3]
