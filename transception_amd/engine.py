@@ -831,20 +831,27 @@ class Graph:
                                    sB=(t["M"] * x.ld, 0), sC=(gs, 0), rowsum=_ptr(t["b1"].grad) if t["b1"].grad is not None else None, srow=gs,
                                    use_ws=False))
             self._launch_gemms(g2)
+            copies = []                                     # the sites' residual gradients leave in one launch (<= 4 per tc_ew_multi)
             for t, dy in zip(st, dys):
                 if t["res"] is not None:
                     if t["side"]:
-                        self._pass_grad_batched(t["res"], dy, Gn, t["M"], t["Cin"], t["so"], t["M"] * t["res"].ld)
+                        copies.append(self._pass_grad_batched(t["res"], dy, Gn, t["M"], t["Cin"], t["so"], t["M"] * t["res"].ld, defer=True))
                     else:
                         self.pass_grad(t["res"], dy)
                 for k in ("gp", "part2", "dh"):
                     t.pop(k, None)
+            for c0 in range(0, len(copies), 4):
+                self._ew_multi(copies[c0:c0 + 4])
         self._rec(bwd)
         return [t["out"] for t in st]
 
-    def _pass_grad_batched(self, v: Var, src: torch.Tensor, nb: int, M: int, N: int, sb_src: int, sb_dst: Optional[int] = None):
+    def _pass_grad_batched(self, v: Var, src: torch.Tensor, nb: int, M: int, N: int, sb_src: int, sb_dst: Optional[int] = None,
+                           defer: bool = False):
+        """v.grad (+)= src for nb batch-strided [M, N] blocks (tc_copy3d); defer: return the copy as a tc_ew_multi segment instead."""
         sb_dst = sb_src if sb_dst is None else sb_dst
         g, acc = self.wgrad(v, 0 if v.rows >= nb * M else (nb - 1) * sb_dst // v.root.cols)
+        if defer:
+            return TcEwSeg(EW_COPY, acc, src.data_ptr(), g.data_ptr(), sb_src, sb_dst, src.stride(0), g.stride(0), nb, M, N, 0, 0, 0)
         self.L.tc_copy3d(_ptr(src), sb_src, src.stride(0), _ptr(g), sb_dst, g.stride(0), nb, M, N, acc, self.dt, self.stream)
 
     def layernorm(self, x: Var, g: P, b: P, eps: float = 1e-5, act: int = ACT_NONE, out: Optional[Var] = None) -> Var:
