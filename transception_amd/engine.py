@@ -348,16 +348,19 @@ class Graph:
         root.written.append((off // cols, (off + nelem + cols - 1) // cols, 0, cols))
         return root.grad_t
 
-    def pass_grad(self, v: Var, src: torch.Tensor):
-        """v.grad (+)= src without a copy when v has no gradient yet (identity / residual branches)."""
+    def pass_grad(self, v: Var, src: torch.Tensor, defer: bool = False):
+        """v.grad (+)= src without a copy when v has no gradient yet (identity / residual branches).  defer: a copy that is needed
+        comes back as a tc_ew_multi segment (None otherwise) for the caller to merge with its neighbours' into one launch."""
         if not v.requires_grad:
-            return
+            return None
         r = v.root
         if v.is_whole and r.grad_t is None and src.stride() == r.data.stride() and src.shape == r.data.shape:
             r.grad_t = src                                   # alias: later contributions accumulate in place
             r.whole_written = True
-            return
+            return None
         g, acc = self.wgrad(v)
+        if defer:
+            return TcEwSeg(EW_COPY, acc, src.data_ptr(), g.data_ptr(), 0, 0, src.stride(0), g.stride(0), 1, g.shape[0], g.shape[1], 0, 0, 0)
         if acc:
             self.L.tc_add(_ptr(g), g.stride(0), _ptr(src), src.stride(0), _ptr(g), g.stride(0), g.shape[0], g.shape[1],
                           self.dt, self.stream)
@@ -837,9 +840,10 @@ class Graph:
                     if t["side"]:
                         copies.append(self._pass_grad_batched(t["res"], dy, Gn, t["M"], t["Cin"], t["so"], t["M"] * t["res"].ld, defer=True))
                     else:
-                        self.pass_grad(t["res"], dy)
+                        copies.append(self.pass_grad(t["res"], dy, defer=True))
                 for k in ("gp", "part2", "dh"):
                     t.pop(k, None)
+            copies = [c for c in copies if c is not None]
             for c0 in range(0, len(copies), 4):
                 self._ew_multi(copies[c0:c0 + 4])
         self._rec(bwd)
