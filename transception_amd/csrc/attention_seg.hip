@@ -64,6 +64,10 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 //     differs from the maximum-referenced P by an exact power of two.
 //   * Q and O tiles pass through a wave-private LDS tile so that global memory sees whole 128-byte rows (eight lanes x 16 bytes): a
 //     per-lane 16-byte access at a row stride touches 32 lines per instruction and queued in the address unit for ~4 us at each end.
+// Workgroups go to the 8 XCDs round-robin by linear index, and each XCD has its own L2.  The workgroups that share operands (the 16
+// query-tile groups of one image read the same K / V; the 7 key blocks of one (image, query chunk) read the same Q / dO) are numbered
+// so that they land on ONE XCD: index l runs on XCD l % 8 and takes the (l / 8)-th unit of that XCD's contiguous share.
+__device__ __forceinline__ int xcd_block(int l, int n) { return (n & 7) ? l : (l & 7) * (n >> 3) + (l >> 3); }
 constexpr int FW_NW = 12, FW_NT = FW_NW * 64, FW_NC = KB * 8, FW_NF = (2 * FW_NC + FW_NT - 1) / FW_NT;
 constexpr int FW_SLOT = 2 * KB * LDR;                           // one ring slot: K tile | V tile
 constexpr size_t FW_SMEM = (size_t)(2 * FW_SLOT + FW_NW * 32 * LDR) * sizeof(bf16_t);
@@ -74,7 +78,8 @@ __global__ __launch_bounds__(FW_NT, 1) void attn_fwd_seg_kernel(const bf16_t* __
     extern __shared__ __attribute__((aligned(16))) bf16_t fw_smem[];      // [2 slots][K tile | V tile][KB][LDR], then FW_NW wave tiles [32][LDR]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
     const int nwt = sg.t32[sg.n], bpi = (nwt + FW_NW - 1) / FW_NW;
-    const int b = blockIdx.x / bpi, wt = (blockIdx.x - b * bpi) * FW_NW + wave;
+    const int bx = xcd_block(blockIdx.x, gridDim.x);
+    const int b = bx / bpi, wt = (bx - b * bpi) * FW_NW + wave;
     int sgi = 0;
 #pragma unroll
     for (int i = 1; i < 4; ++i) if (i < sg.n && wt >= sg.t32[i]) sgi = i;
@@ -230,7 +235,8 @@ __global__ __launch_bounds__(FW_NT, 1) void attn_bwd_dq_seg_kernel(const bf16_t*
     extern __shared__ __attribute__((aligned(16))) bf16_t fw_smem[];      // [2 slots][K tile | V tile][KB][LDR], then FW_NW wave tiles [32][LDR]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
     const int nwt = sg.t32[sg.n], bpi = (nwt + FW_NW - 1) / FW_NW;
-    const int b = blockIdx.x / bpi, wt = (blockIdx.x - b * bpi) * FW_NW + wave;
+    const int bx = xcd_block(blockIdx.x, gridDim.x);
+    const int b = bx / bpi, wt = (bx - b * bpi) * FW_NW + wave;
     int sgi = 0;
 #pragma unroll
     for (int i = 1; i < 4; ++i) if (i < sg.n && wt >= sg.t32[i]) sgi = i;
@@ -393,7 +399,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16
     bf16_t* const sbase = reinterpret_cast<bf16_t*>(smem);
     DSTAMP_INIT();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
-    const int b = blockIdx.y, kv0 = (blockIdx.x * NW + wave) * 32, key = min(kv0 + j, Nk - 1);
+    const int lin = xcd_block((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x * gridDim.y * gridDim.z);
+    const int bkx = lin % gridDim.x, b = (lin / gridDim.x) % gridDim.y, bkz = lin / (gridDim.x * gridDim.y);
+    const int kv0 = (bkx * NW + wave) * 32, key = min(kv0 + j, Nk - 1);
     typedef typename TcHalf<H>::v8 V8;
     V8 kf[4], vf[4];
 #pragma unroll
@@ -409,7 +417,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16
     for (int r = 0; r < 16; ++r) { dk0[r] = dk1[r] = dv0[r] = dv1[r] = 0.f; }
     const int qrow = pi_row(j);
     const int ntiles = sg.t32[sg.n];
-    const int t_begin = blockIdx.z * tiles_per_chunk, t_end = min(ntiles, t_begin + tiles_per_chunk);
+    const int t_begin = bkz * tiles_per_chunk, t_end = min(ntiles, t_begin + tiles_per_chunk);
     auto locate = [&](int t, long long& base, int& valid) {       // first row and number of valid rows of 32-query tile t
         int s = 0;
 #pragma unroll
@@ -521,7 +529,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16
     // Every query chunk (blockIdx.z) writes its own partial [B][Nk][128]; attn_dkv_store_kernel adds the chunks -- fp32 atomics into
     // one buffer cost this epilogue 20 k of the kernel's 149 k cycles (scripts/exp/dkv_timing.py) plus a zero-fill launch.
     float* red = reinterpret_cast<float*>(smem) + wave * (D * 33);
-    float* dpart = dkv32 + (long long)blockIdx.z * gridDim.y * Nk * 128;
+    float* dpart = dkv32 + (long long)bkz * gridDim.y * Nk * 128;
 #pragma unroll
     for (int which = 0; which < 2; ++which) {
         __syncthreads();
