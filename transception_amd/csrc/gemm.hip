@@ -968,6 +968,12 @@ __global__ __launch_bounds__(256, 2) void gemm_pair_kernel(GemmPairDev q) {
         else gemm_bf16_body<H, H, 64, 64, false, false, true>(q.a, bx, by, bz, q.gxA, q.gyA, As, Bs);
     } else {
         lin -= q.nA;
+        if (q.b.xcd & 2) {
+            // the tiles of ONE K split read the same rows of dY and X: the split-major tile list is dealt to the XCDs in contiguous
+            // shares (this workgroup's index IS blockIdx.x, the weight-gradient problem comes first), so a split's tiles share an L2
+            const int xcd = lin & 7, slot = lin >> 3, qq = nB >> 3, r = nB & 7;
+            lin = xcd * qq + min(xcd, r) + slot;
+        }
         const int bx = lin % q.gxB; lin /= q.gxB;
         if (q.b.ffn.mode == TC_FFN_LN_B) gemm_bf16_body<H, float, 64, 64, true, false, true, TC_FFN_LN_B>(q.b, bx, lin % q.gyB, lin / q.gyB, q.gxB, q.gyB, As, Bs);
         else gemm_bf16_body<H, float, 64, 64, true, false, true>(q.b, bx, lin % q.gyB, lin / q.gyB, q.gxB, q.gyB, As, Bs);
@@ -988,6 +994,11 @@ __global__ __launch_bounds__(256, 4) void gemm_multi_kernel(GemmMultiDev q) {
     int lin = blockIdx.x, i = 0;
     for (int j = 1; j < q.n; ++j) if (lin >= q.blk0[j]) i = j;
     lin -= q.blk0[i];
+    if (q.p[i].xcd & 2) {                                    // split-K weight gradients: a split's tiles on one XCD (see gemm_pair_kernel)
+        const int ni = (i + 1 < q.n ? q.blk0[i + 1] : (int)gridDim.x) - q.blk0[i];
+        const int xcd = lin & 7, slot = lin >> 3, qq = ni >> 3, r = ni & 7;    // local indices l, l + 8, ... share an XCD at any offset
+        lin = xcd * qq + min(xcd, r) + slot;
+    }
     const int gx = q.gx[i], gy = q.gy[i], bz = lin / (gx * gy);
     int bx = lin % gx, by = (lin / gx) % gy;
     if ((q.p[i].xcd & 1) && q.kind[i] != 2 && q.kind[i] != 5) tc_xcd_tile(bx, by, gx, gy);   // (not the split-K weight gradients)
@@ -1198,6 +1209,8 @@ extern "C" int tc_gemm_pair(const TcGemm* a, const TcGemm* b, void* stream) {
         const long long nA = (long long)ga.x * ga.y * ga.z, nB = (long long)gb.x * gb.y * gb.z;
         if (!bigA && !bigB && nA + nB < 0x7fffffffLL) {
             q.nA = (int)nA; q.gxA = ga.x; q.gyA = ga.y; q.gxB = gb.x; q.gyB = gb.y;
+            static const int xcd_b = getenv("TC_PAIR_XCD_B") ? atoi(getenv("TC_PAIR_XCD_B")) : 1;   // A/B switch
+            if (xcd_b && gb.x * gb.y > 1) q.b.xcd |= 2;
             if (a->dtype == TC_BF16) hipLaunchKernelGGL(gemm_pair_kernel<bf16_t>, dim3((unsigned)(nA + nB)), dim3(256), 0, s, q);
             else hipLaunchKernelGGL(gemm_pair_kernel<f16_t>, dim3((unsigned)(nA + nB)), dim3(256), 0, s, q);
             return tc_launch_status();
@@ -1232,9 +1245,11 @@ extern "C" int tc_gemm_multi(const TcGemm* g, int n, void* stream) {
         // workgroups are dispatched in index order: the problems whose workgroups run the longest K loops go first, so the launch
         // does not end on a few long-running stragglers (measured 5-12 % on the bridge's four-scale MixFFN launches)
         std::stable_sort(order, order + n, [&](int a, int b) { return plan[a].kchunk > plan[b].kchunk; });
+        static const int xcd_b = getenv("TC_MULTI_XCD_B") ? atoi(getenv("TC_MULTI_XCD_B")) : 1;   // A/B switch
         for (int j = 0; j < n; ++j) {
             const int i = order[j];
             q.p[j] = plan[i]; q.kind[j] = kinds[i]; q.gx[j] = grids[i].x; q.gy[j] = grids[i].y; q.blk0[j] = (int)blk;
+            if (xcd_b && (kinds[i] == 2 || kinds[i] == 5) && grids[i].x * grids[i].y > 1) q.p[j].xcd |= 2;
             blk += (long long)grids[i].x * grids[i].y * grids[i].z;
             if (blk > 0x7fffffffLL) ok = false;
         }
