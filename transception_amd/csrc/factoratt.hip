@@ -143,7 +143,9 @@ __global__ __launch_bounds__(256) void factor_att_fwd_kernel(const T* __restrict
     float* red = cinv + Ch;              // [256/Ch][Ch] <= 256
     T* vs = reinterpret_cast<T*>(red + 256);      // [N][Ch] storage type
     T* qs = vs + N * Ch;
-    const int bt = blockIdx.x / heads, hd = blockIdx.x - bt * heads, tid = threadIdx.x;
+    // the heads of one image read neighbouring 16..128-byte pieces of the same qkv rows: numbered onto ONE XCD (index l runs on XCD l % 8)
+    const int blk = (gridDim.x & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
+    const int bt = blk / heads, hd = blk - bt * heads, tid = threadIdx.x;
     const long long row0 = (long long)bt * N;
     const int col0 = hd * Ch;
     fa_load_tile<T>(e, k + row0 * ld + col0, ld, N, Ch);
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(256) void factor_att_fwd_kernel(const T* __restrict
     fa_softmax_cols(e, cmax, cinv, red, N, Ch);
     fa_gram(ctx, e, vs, N, Ch);
     for (int i = tid; i < Ch * Ch; i += 256) ctx[i] *= cinv[i / Ch];          // rows of ctx carry the softmax normaliser
-    if (tid < Ch) { stats[((long long)blockIdx.x * 2) * Ch + tid] = cmax[tid]; stats[((long long)blockIdx.x * 2 + 1) * Ch + tid] = cinv[tid]; }
+    if (tid < Ch) { stats[((long long)blk * 2) * Ch + tid] = cmax[tid]; stats[((long long)blk * 2 + 1) * Ch + tid] = cinv[tid]; }
     __syncthreads();
     const int nv = Ch / VEC;
 #pragma unroll 2
@@ -192,10 +194,12 @@ __global__ __launch_bounds__(256) void factor_att_bwd_kernel(const T* __restrict
     T* vs = reinterpret_cast<T*>(dctxT + Ch * Ch);             // v, q, do tiles in the storage type
     T* qs = vs + N * Ch;
     T* gs = qs + N * Ch;
-    const int bt = blockIdx.x / heads, hd = blockIdx.x - bt * heads, tid = threadIdx.x;
+    // the heads of one image read neighbouring 16..128-byte pieces of the same qkv rows: numbered onto ONE XCD (index l runs on XCD l % 8)
+    const int blk = (gridDim.x & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
+    const int bt = blk / heads, hd = blk - bt * heads, tid = threadIdx.x;
     const long long row0 = (long long)bt * N;
     const int col0 = hd * Ch;
-    const float* cmax = stats + ((long long)blockIdx.x * 2) * Ch;
+    const float* cmax = stats + ((long long)blk * 2) * Ch;
     const float* cinv = cmax + Ch;
     fa_load_tile<T>(e, k + row0 * ld + col0, ld, N, Ch);
     fa_load_tile_raw<T>(vs, v + row0 * ld + col0, ld, N, Ch);
