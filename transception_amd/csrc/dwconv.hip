@@ -633,14 +633,20 @@ __device__ __forceinline__ void dw_tile_body(const T* __restrict__ src, int lds_
         if (owb + r < W) *reinterpret_cast<uint4*>(dst0 + (long long)r * ldy) = pack16<T>(acc[r]);
 }
 
+// One workgroup per tile: tile indices l, l + 8, ... run on one XCD (whatever the grid offset of the chunk / group), so each XCD takes
+// a CONTIGUOUS share of the tile list and neighbouring tiles find each other's halo rows in its L2 (any n: a bijection).
+__device__ __forceinline__ int dw_xcd_tile(int l, int n) {
+    const int r = l & 7, q = n >> 3, rem = n & 7;
+    return r * q + min(r, rem) + (l >> 3);
+}
 template <typename T, int K, int CG, int MODE>
 __global__ __launch_bounds__(256) void dw_tile_kernel(const T* __restrict__ src, int lds_, const T* __restrict__ w,
                                                       const T* __restrict__ bias, T* __restrict__ y, int ldy, int B, int H, int W,
                                                       int C, int add_input, int accumulate, long long wstride, int tilesW,
                                                       int tilesH, float* __restrict__ stat) {
     __shared__ uint4 smem[dw_tile_smem_q<T, K, CG>()];
-    dw_tile_body<T, K, CG, MODE>(src, lds_, w, bias, y, ldy, B, H, W, C, add_input, accumulate, wstride, tilesW, tilesH, blockIdx.x,
-                                 blockIdx.y, blockIdx.z, smem, stat, (int)gridDim.y);
+    dw_tile_body<T, K, CG, MODE>(src, lds_, w, bias, y, ldy, B, H, W, C, add_input, accumulate, wstride, tilesW, tilesH,
+                                 dw_xcd_tile((int)blockIdx.x, (int)gridDim.x), blockIdx.y, blockIdx.z, smem, stat, (int)gridDim.y);
 }
 
 // dw[c,ky,kx] += sum_pix dy[pix] * x[pix + (ky-P, kx-P)] ; db[c] += sum_pix dy[pix].  x tile (+halo) and dy tile in LDS; a thread
@@ -908,7 +914,7 @@ __global__ __launch_bounds__(256) void dw_multi_kernel(DwMultiDev a) {
     if (a.n > 3 && lin >= a.s[3].blk0) si = 3;
     const DwSegDev& g = a.s[si];
     lin -= g.blk0;
-    const int bx = lin % g.gx, by = lin / g.gx;
+    const int bx = dw_xcd_tile(lin % g.gx, g.gx), by = lin / g.gx;
 #define TC_CASE(KK, CGG)                                                                                                            \
     if (g.k == KK && g.cg == CGG) {                                                                                                 \
         dw_tile_body<T, KK, CGG, MODE>((const T*)g.src, g.lds_, (const T*)g.w, (const T*)g.bias, (T*)g.y, g.ldy, g.B, g.H, g.W, g.C, \
