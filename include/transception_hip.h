@@ -205,6 +205,24 @@ typedef struct TcFfnSeg {
 int tc_ffn_mid_bwd(const TcFfnSeg* segs, int nseg, int groups, long long wstride, void* ws, long long ws_bytes, int dtype,
                    void* stream);
 
+/* MixFFN_skip forward as ONE spatially tiled kernel (16-bit storage types, C = 64 or 128; see csrc/mixffn.hip):
+ *   out = fc2(GELU(LayerNorm_4C(dw3x3(h) + bias + h))) + b2 + res,  h = x W1^T + b1        (MSTr.py:889-902, DWConv :21-31)
+ * x [groups*B*H*W, C] (row stride ldx); parameters of weight group g at + g*wstride elements (PyTorch layouts: w1 [4C,C], wd [4C,1,3,3],
+ * w2 [C,4C]); res / out: pixel row r of group g at g*sres + r*ldr / g*sout + r*ldo (row blocks or column blocks of a wider buffer).
+ * Optional outputs for the backward pass, contiguous [groups*B*H*W, 4C] in the storage type: h (fc1 output), d (dw3x3(h) + bias + h),
+ * a (GELU(LN(d))); stat: fp32 [rows][2] = (mean, rstd) of the LayerNorm.  The hidden maps that are not asked for never leave LDS.
+ * Replaces fc1 GEMM + tc_ffn_dw_fwd + (tc_layernorm_fwd) + fc2 GEMM of the op-by-op form. */
+typedef struct TcFfnFused {
+    const void* x; const void* w1; const void* b1; const void* wd; const void* bd; const void* gamma; const void* beta;
+    const void* w2; const void* b2; const void* res; void* out; void* h; void* d; void* a; float* stat;
+    long long sres, sout, wstride;
+    int ldx, ldr, ldo, C, B, H, W, groups;
+    float eps;
+    int tile_h, tile_w;          /* 0: the library picks the pixel tile; otherwise a forced shape (tests, tuning) */
+} TcFfnFused;
+int tc_ffn_fused_supported(int C, int dtype);
+int tc_ffn_fused_fwd(const TcFfnFused* f, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * BatchNorm2d over token rows ([rows, C], statistics over rows) fused with its activation and an
  * optional residual add:  y = act((x-mean)*rstd*gamma+beta) (+ res).

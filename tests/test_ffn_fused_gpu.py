@@ -88,6 +88,8 @@ CASES = [  # C, B, H, W, groups
     (320, 2, 7, 7, 1),        # 1280 hidden channels
     (64, 2, 20, 24, 3),       # three stacked weight groups, non-square map
     (64, 1, 56, 56, 1),       # stage-1 map: many tiles per workgroup walker
+    (128, 2, 28, 28, 1),      # bridge scale 2 / decoder 1 width
+    (128, 2, 12, 20, 3),      # C = 128 with stacked weight groups, map not a multiple of any tile
 ]
 
 
@@ -154,7 +156,8 @@ def test_fused_mixffn_four_sites_one_launch_set(dtype):
         keep.append((xv, gf, gout))
     n0 = G.n_launch
     outs = G.mixffn(sites)
-    assert G.n_launch - n0 == 2                                   # fc1 x4 and fc2 x4: one merged grid each (+ one conv launch)
+    # fp32: fc1 x4 and fc2 x4, one merged grid each (+ one conv launch); 16-bit: the C = 64 / 128 sites are one tiled kernel each
+    assert G.n_launch - n0 == (2 if dtype == torch.float32 else 4)
     for o, (_, _, gout) in zip(outs, keep):
         o.root.grad_t = gout.to(dev).to(dtype).contiguous()
         o.root.whole_written = True
@@ -176,3 +179,17 @@ def test_fused_mixffn_recompute_and_wide_loader_variants(dtype, monkeypatch):
     monkeypatch.setattr(E, "_FFN_LN_GEMM_MAXC", 4096)
     for case in ((128, 3, 14, 14, 1), (64, 2, 20, 24, 3), (320, 2, 7, 7, 1)):
         test_fused_mixffn_matches_torch_and_unfused(case, dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("tile", [(14, 8), (7, 8), (3, 28), (5, 7), (4, 6), (1, 2), (7, 7), (4, 14), (2, 30)])
+def test_tiled_forward_kernel_tile_shapes(tile, dtype, monkeypatch):
+    """csrc/mixffn.hip with forced pixel tiles: even / odd widths, tiles hanging over the map edge, one-row tiles, tiles wider than the
+    map -- the result must not depend on the tiling."""
+    import transception_amd.engine as E
+    th, tw = tile
+    for C, B, H, W, groups in ((64, 2, 28, 28, 1), (64, 1, 9, 30, 2), (128, 2, 14, 14, 1), (128, 1, 7, 7, 3)):
+        if (th + 2) * (tw + 2) > (160 if C == 64 else 96) or th * tw > (128 if C == 64 else 64):
+            continue
+        monkeypatch.setattr(E, "_FFN_TILE", (th, tw))
+        test_fused_mixffn_matches_torch_and_unfused((C, B, H, W, groups), dtype)

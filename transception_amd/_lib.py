@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("TC_LIB_PATH") or os.path.join(HERE, "libtransception_
 
 TC_F32, TC_BF16, TC_F16 = 0, 1, 2
 ACT_NONE, ACT_HSWISH, ACT_COORD, ACT_SIGMOID, ACT_GELU = 0, 1, 2, 3, 4
-ABI_VERSION = 5
+ABI_VERSION = 6
 ATTN_DKV_SPLITS = 8                # include/transception_hip.h: partial dK|dV buffers in tc_attn_bwd_seg's fp32 scratch
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_longlong, C.c_float
@@ -46,6 +46,14 @@ class TcFfnSeg(C.Structure):
     _fields_ = [("gp", vp), ("d", vp), ("h", vp), ("dh", vp), ("stat", vp), ("part2", vp), ("w", vp), ("gamma", vp),
                 ("dw", vp), ("db", vp), ("dgamma", vp), ("dbeta", vp),
                 ("C", i32), ("ldg", i32), ("ldd", i32), ("ldh", i32), ("lddh", i32), ("B", i32), ("H", i32), ("W", i32), ("nch2", i32)]
+
+
+class TcFfnFused(C.Structure):
+    _fields_ = [("x", vp), ("w1", vp), ("b1", vp), ("wd", vp), ("bd", vp), ("gamma", vp), ("beta", vp), ("w2", vp), ("b2", vp),
+                ("res", vp), ("out", vp), ("h", vp), ("d", vp), ("a", vp), ("stat", vp),
+                ("sres", i64), ("sout", i64), ("wstride", i64),
+                ("ldx", i32), ("ldr", i32), ("ldo", i32), ("C", i32), ("B", i32), ("H", i32), ("W", i32), ("groups", i32), ("eps", f32),
+                ("tile_h", i32), ("tile_w", i32)]
 
 
 class TcEwSeg(C.Structure):
@@ -84,6 +92,8 @@ SIGNATURES = {
     "tc_ffn_chunk": [i32, i32],
     "tc_ffn_dw_fwd": [vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i64, i32, vp],
     "tc_ffn_mid_bwd": [C.POINTER(TcFfnSeg), i32, i32, i64, vp, i64, i32, vp],
+    "tc_ffn_fused_supported": [i32, i32],
+    "tc_ffn_fused_fwd": [C.POINTER(TcFfnFused), i32, vp],
     "tc_bn_scratch_floats": [i32, i32],
     "tc_bn_fwd": [vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, f32, f32, i32, i32, i32, vp],
     "tc_bn_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp],
@@ -127,7 +137,7 @@ SIGNATURES = {
     "tc_cast": [vp, vp, i64, i32, i32, vp],
 }
 _RET = {"tc_bn_scratch_floats": i64, "tc_softmax_scratch_floats": i64, "tc_layernorm_bwd_scratch_floats": i64, "tc_factor_att_stats_floats": i64}
-_RAW = {"tc_abi_version", "tc_ffn_chunk", "tc_bn_scratch_floats", "tc_softmax_scratch_floats", "tc_layernorm_bwd_scratch_floats", "tc_factor_att_stats_floats"}     # not status-returning
+_RAW = {"tc_abi_version", "tc_ffn_chunk", "tc_ffn_fused_supported", "tc_bn_scratch_floats", "tc_softmax_scratch_floats", "tc_layernorm_bwd_scratch_floats", "tc_factor_att_stats_floats"}     # not status-returning
 
 
 class TcError(RuntimeError):

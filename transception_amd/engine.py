@@ -18,7 +18,7 @@ from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
 
-from ._lib import (ATTN_DKV_SPLITS, EW_COPY, EW_DEINTERLEAVE, EW_PATCHIFY, TcEwSeg, ACT_COORD, ACT_GELU, ACT_HSWISH, ACT_NONE, ACT_SIGMOID, FFN_EP, FFN_LN_A, FFN_LN_B, TC_BF16, TC_F16, TC_F32, TcDwSeg, TcFfnSeg,
+from ._lib import (ATTN_DKV_SPLITS, EW_COPY, EW_DEINTERLEAVE, EW_PATCHIFY, TcEwSeg, TcFfnFused, ACT_COORD, ACT_GELU, ACT_HSWISH, ACT_NONE, ACT_SIGMOID, FFN_EP, FFN_LN_A, FFN_LN_B, TC_BF16, TC_F16, TC_F32, TcDwSeg, TcFfnSeg,
                    TcGemm, lib)
 
 _DT = {torch.float32: TC_F32, torch.bfloat16: TC_BF16, torch.float16: TC_F16}
@@ -160,6 +160,8 @@ _NO_PENDING = bool(os.environ.get("TC_DEBUG_NO_PENDING"))   # timing what-if onl
 _SKIP_WGRAD = bool(os.environ.get("TC_DEBUG_SKIP_WGRAD"))
 _FFN_STORE_ACT = os.environ.get("TC_FFN_STORE_ACT", "1") != "0"   # MixFFN: keep GELU(LN(d)) from the forward pass (0: recompute it in dW2's loader)
 _FFN_LN_GEMM_MAXC = int(os.environ.get("TC_FFN_LN_GEMM_MAXC", "64"))  # widest fc2 output for which LayerNorm + GELU run in its A loader
+_FFN_TILED = os.environ.get("TC_FFN_TILED", "1") != "0"        # MixFFN forward as one spatially tiled kernel where the library supports the width (csrc/mixffn.hip)
+_FFN_TILE = (0, 0)                                             # forced pixel tile of the tiled MixFFN kernels (tests); (0, 0): the library's choice
 _POISON = bool(os.environ.get("TC_DEBUG_POISON"))         # fill every fresh buffer with NaN: finds reads of memory no kernel wrote
 
 
@@ -736,11 +738,28 @@ class Graph:
             # transformed once); with N tiles across Cin the exact-erf GELU would be recomputed N / 64 times, so wider sites run the
             # LayerNorm kernel on d (it also writes the activated map the weight gradient reads) and a plain fc2 GEMM
             lng = Cin <= _FFN_LN_GEMM_MAXC
-            st.append(dict(lng=lng, so=Cin if side else M * out.ld, side=side, x=x, W1=W1, b1=b1, wd=wd, bd=bd, lg=lg, lb=lb, W2=W2, b2=b2, B=B, H=H, W=W, C4=C4, Cin=Cin, M=M, cn=cn,
+            # one spatially tiled kernel for the whole forward site (hidden maps in LDS) where the library has it: 16-bit storage, C = 64 / 128
+            fz = (_FFN_TILED and self.dtype != torch.float32 and bool(L.tc_ffn_fused_supported(Cin, self.dt)) and x.ld % 8 == 0 and out.ld % 8 == 0
+                  and (s_.get("residual") is None or s_["residual"].ld % 8 == 0) and gs % 8 == 0)
+            st.append(dict(fz=fz, lng=lng, so=Cin if side else M * out.ld, side=side, x=x, W1=W1, b1=b1, wd=wd, bd=bd, lg=lg, lb=lb, W2=W2, b2=b2, B=B, H=H, W=W, C4=C4, Cin=Cin, M=M, cn=cn,
                            nch=C4 // cn, nch2=(C4 + 63) // 64, res=s_.get("residual"), out=out,
                            h=_empty((x.rows, C4), self.dtype, self.dev), d=_empty((x.rows, C4), self.dtype, self.dev),
-                           a=_empty((x.rows, C4), self.dtype, self.dev) if (_FFN_STORE_ACT or not lng) else None,
-                           part=self.f32(x.rows * (C4 // cn) * 2), stat=self.f32(x.rows * 2)))
+                           a=_empty((x.rows, C4), self.dtype, self.dev) if (_FFN_STORE_ACT or not lng or fz) else None,
+                           part=self.f32(x.rows * (C4 // cn) * 2) if not fz else None, stat=self.f32(x.rows * 2)))
+        for t in st:
+            if t["fz"]:
+                res, out = t["res"], t["out"]
+                f = TcFfnFused(_ptr(t["x"].data), _ptr(t["W1"].data), _ptr(t["b1"].data), _ptr(t["wd"].data), _ptr(t["bd"].data), _ptr(t["lg"].data),
+                               _ptr(t["lb"].data), _ptr(t["W2"].data), _ptr(t["b2"].data), _ptr(res.data) if res is not None else None, _ptr(out.data),
+                               _ptr(t["h"]) if self.record else None, _ptr(t["d"]) if self.record else None, _ptr(t["a"]) if self.record else None,
+                               _ptr(t["stat"]) if self.record else None,
+                               t["M"] * res.ld if res is not None else 0, t["so"], gs, t["x"].ld, res.ld if res is not None else 0, out.ld,
+                               t["Cin"], t["B"], t["H"], t["W"], Gn, 1e-5, *_FFN_TILE)
+                self.n_launch += 1
+                _timed("hbm:ffn_fused_fwd (MixFFN forward, one tiled kernel)", (2.0 * t["Cin"] + (t["Cin"] if res is not None else 0) + t["C4"]) * t["x"].rows * t["h"].element_size(),
+                       lambda f=f: L.tc_ffn_fused_fwd(C.byref(f), self.dt, self.stream))
+        st_all, st = st, [t for t in st if not t["fz"]]
+        nold = len(st)
 
         def hook(g: TcGemm, t, mode):
             g.ffn_mode, g.ffn_nchunk, g.ffn_chunk_n, g.ffn_ldd, g.ffn_eps = mode, t["nch"], t["cn"], t["C4"], 1e-5
@@ -756,18 +775,20 @@ class Graph:
                                  bias=_ptr(t["b1"].data), nb1=Gn, sA=(t["M"] * t["x"].ld, 0), sB=(gs, 0), sC=(t["M"] * t["C4"], 0), sbias=gs)
                             for i, t in enumerate(st)])
         # depthwise 3x3 + bias + skip, LayerNorm chunk partials on the side
-        if not many:
+        if nold == 0:
+            pass
+        elif nold == 1:
             t = st[0]
             _timed("hbm:ffn_dw_fwd (MixFFN dw3x3 + skip + LayerNorm partials)", 2.0 * t["x"].rows * t["C4"] * t["h"].element_size(),
                    lambda: L.tc_ffn_dw_fwd(_ptr(t["h"]), t["C4"], _ptr(t["wd"].data), _ptr(t["bd"].data), _ptr(t["d"]), t["C4"],
                                            _ptr(t["part"]) if t["lng"] else None, t["B"], t["H"], t["W"], t["C4"], Gn, gs, self.dt, self.stream))
         else:
-            assert n <= 4
-            arr = (TcDwSeg * n)()
+            assert nold <= 4
+            arr = (TcDwSeg * nold)()
             for i, t in enumerate(st):
                 arr[i] = TcDwSeg(_ptr(t["h"]), _ptr(t["wd"].data), _ptr(t["bd"].data), _ptr(t["d"]), None, None, None, t["C4"], 3, t["C4"], t["C4"], 0,
                                  t["B"], t["H"], t["W"], _ptr(t["part"]) if t["lng"] else None)
-            L.tc_dwconv_multi(arr, n, 0, 1, 0, 1, 0, None, 0, self.dt, self.stream)
+            L.tc_dwconv_multi(arr, nold, 0, 1, 0, 1, 0, None, 0, self.dt, self.stream)
         # fc2 on GELU(LN(d)) (+ bias + residual)
         fw = []
         for i, t in enumerate(st):
@@ -780,6 +801,7 @@ class Graph:
                      nb1=Gn, sA=(t["M"] * t["C4"], 0), sB=(gs, 0), sC=(t["so"], 0), sR=(t["M"] * res.ld if res is not None else 0, 0), sbias=gs)
             fw.append(hook(g, t, FFN_LN_A) if t["lng"] else g)
         self._launch_gemms(fw)
+        st = st_all                                              # (the backward pass treats every site alike)
 
         def bwd():
             dys = [self.grad_of(t["out"]) for t in st]
