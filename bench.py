@@ -11,10 +11,12 @@ One "step" = one pass of the hot path over one batch of synthetic Synapse-shaped
 0.4*CE+0.6*Dice loss, backward, (gradient all-reduce over RCCL when N>1), fused SGD update.  Weak scaling: 16 images per GPU.
 `value` = images of the K timed steps / wall time between two barrier+synchronize brackets (max over ranks); the median of the
 per-step HIP-event times is reported beside it (config.median_ms_per_step).  Rank 0 prints ONE JSON line carrying
-  roofline      the bridge SR-attention forward kernel (the MFMA-bound kernel BASELINE.json's north_star names): HIP events
-                around each of its launches inside instrumented steps of the same workload (in-step figure); the same kernel
-                back-to-back inside a replayed hipGraph is kept beside it as roofline_graph_replay;
-  roofline_hbm  the memory-bound family north_star asks an HBM figure for, timed the same way;
+  roofline      the bridge SR-attention forward kernel (the MFMA-bound kernel BASELINE.json's north_star names): HIP events around
+                30 back-to-back launches inside a replayed hipGraph (the kernel's own duration; agrees with the rocprofv3 average);
+                the per-launch event figure of instrumented eager steps (it includes the event-pair floor) is
+                roofline_in_step_events;
+  roofline_gemm the time-dominant GEMM family (pair / merged / single launches): algorithmic bytes AND flops per launch;
+  roofline_hbm  the memory-bound family with the largest share of the step, timed the same way, with its PMC traffic;
   cpu_baseline  the CPU oracle (a port of the reference arithmetic; the reference's Python cannot travel) timed on this box's
                 host cores on a bounded sample of the same workload (rank 0, N=1 only): median of 3 steps + the config-1 figure.
 """
@@ -64,10 +66,11 @@ def _loader_feed(args, dev, rank: int, world: int, n_needed: int, out=None):
 
 # ----------------------------------------------------------------------------------------------------------------- CPU baseline
 def _cpu_baseline_worker(batch: int, size: int):
-    """Oracle on the host cores: config 1 (B=2 train-mode forward) and the benchmarked workload (fwd+bwd+SGD),
-    each the median of 3 repetitions after a warm-up.  Bounded: the batch of the second figure is cut to 4 images when a probe says
-    three full steps would take longer than ~30 s.  Thread count: the faster of 32 / 64 threads on the warm-up probe (more threads
-    than that only add synchronisation cost to this model's many small ops: 256 threads ran several times slower)."""
+    """Oracle on the host cores: config 1 (B=2 train-mode forward) and the benchmarked workload (fwd+bwd+SGD at the
+    benchmarked batch: config 2 = B=16), each the median of 3 repetitions after a warm-up.  Bounded: about 4 steps of the full batch
+    (~7 s each on a 2-socket host); only when a probe says they would take longer than ~90 s is the batch cut to 4 images (and the line
+    says so).  Thread count: the faster of 32 / 64 threads on the warm-up probe (more threads than that only add synchronisation cost
+    to this model's many small ops: 256 threads ran several times slower); physical / logical core counts of the host are stated."""
     from oracle.transception_oracle import TransCeptionOracle, ce_dice_loss, load_params
     from transception_amd.seeded_init import seeded_state_dict
     try:
@@ -105,15 +108,45 @@ def _cpu_baseline_worker(batch: int, size: int):
     torch.set_num_threads(cores)
     f2 = statistics.median(fwd(xp) for _ in range(3))
     probe = step(xp, yp)
-    bs = batch if probe * batch / 2 * 3 < 30.0 else min(batch, 4)
+    bs = batch if probe * batch / 2 * 4 < 90.0 else min(batch, 4)
     x, y = synthetic_batch(bs, size, "cpu", 1)
     times = [step(x, y) for _ in range(3)]
     t = statistics.median(times)
-    return {"value": bs / t, "unit": "images/sec", "cores": cores, "cores_available": avail, "kind": "port",
-            "config1_b2_fwd_images_per_sec": 2 / f2,
-            "sample": f"median of 3 fwd+bwd+SGD steps of B={bs} {size}x{size} after warm-up (and median of 3 train-mode forwards of B=2 = "
-                      f"BASELINE config 1), fp32 PyTorch-CPU oracle (port of the reference arithmetic), {cores} threads "
-                      f"(fastest of {cands} on the probe) of {avail} logical cores"}
+    phys = _physical_cores()
+    ratio = _reference_cpu_ratio()
+    out = {"value": bs / t, "unit": "images/sec", "cores": cores, "cores_available": avail, "physical_cores": phys, "kind": "port",
+           "batch": bs, "config1_b2_fwd_images_per_sec": 2 / f2,
+           "sample": f"median of 3 fwd+bwd+SGD steps of B={bs} {size}x{size} after warm-up (and median of 3 train-mode forwards of B=2 = "
+                     f"BASELINE config 1), fp32 PyTorch-CPU oracle (port of the reference arithmetic), {cores} threads "
+                     f"(fastest of {cands} on the probe) of {avail} logical / {phys} physical cores"}
+    if ratio is not None:
+        out["reference_cpu_ratio"] = ratio
+    return out
+
+
+def _physical_cores():
+    """Physical cores of the host: distinct (physical id, core id) pairs of /proc/cpuinfo (None when it cannot be read)."""
+    try:
+        seen, pid = set(), None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                pid = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                seen.add((pid, line.split(":")[1].strip()))
+        return len(seen) or None
+    except OSError:
+        return None
+
+
+def _reference_cpu_ratio():
+    """Oracle-vs-reference CPU timing measured in the build container (the reference's Python cannot travel to the GPU box) by
+    scripts/time_reference_cpu.py and committed as profiles/reference_cpu_ratio.json: the port is FASTER than the reference, so the
+    cpu_baseline above is a conservative (high) stand-in for the reference's own CPU rate."""
+    f = os.path.join(ROOT, "profiles", "reference_cpu_ratio.json")
+    try:
+        return json.load(open(f))
+    except (OSError, ValueError):
+        return None
 
 
 def cpu_baseline(batch: int, size: int, timeout: float = 240.0):
@@ -182,8 +215,13 @@ def main():
     torch.cuda.set_device(dev)
     import torch.distributed as dist
     group, backend = None, None
-    if world > 1:
+    rccl1 = world == 1 and args.force_split and not args.eager     # one GPU: the split step with its collectives on a 1-rank RCCL group
+    if world > 1 or rccl1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if rccl1:
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            import transception_amd.train as _tr
+            _tr.COMM_AT_WORLD_1 = True
         backend = os.environ.get("TC_DIST_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -191,6 +229,7 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
         group = dist.group.WORLD
         assert dist.get_world_size() == args.gpus
+    comm = world > 1 or rccl1
 
     import transception_amd.engine as engine
     from transception_amd import MSTransception
@@ -206,7 +245,7 @@ def main():
         return m
 
     model = build_model(args.dtype)
-    if world > 1:
+    if comm:
         dist.broadcast(model.flat_parameters(), src=0)           # C3: identical replicas
     loss_fn = SegLoss(9, group=group, loss_scale=LOSS_SCALE[args.dtype])
     opt = FusedSGD(model, lr=0.05, momentum=0.9, weight_decay=1e-4)
@@ -215,7 +254,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if comm:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -246,7 +285,7 @@ def main():
         feed.close()
         step = step_resident
     exposed = None
-    if world > 1:
+    if comm:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -264,6 +303,7 @@ def main():
             dist.broadcast(model.flat_parameters(), src=0)       # the ranks' un-reduced updates diverged: not used afterwards
             model.invalidate_working_copy()
 
+    launches = None if args.eager else (step.kernel_nodes() if hasattr(step, "kernel_nodes") else None)
     extra, roofs = {}, {}
     if rank == 0 and world == 1 and not args.no_side:
         extra, roofs = side_figures(args, dev, model, loss_fn, opt, step, x, y, build_model, engine, train_step, GraphedStep, FusedSGD, SegLoss)
@@ -273,22 +313,28 @@ def main():
             "metric": "images/sec fwd+bwd at 224x224 B=16 per GPU", "value": world * args.batch * args.steps / elapsed,
             "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic" if not args.loader else "synthetic Synapse npz files through DeviceLoader",
+            "dtype": args.dtype,
+            "data": "synthetic (one HBM-resident batch of uniform-noise slices in [-1, 1] with random labels; config.loader_fed_images_per_sec "
+                    "is the same step fed from synthetic Synapse npz files)" if not args.loader else
+                    "synthetic Synapse npz files (512x512 smooth-blob slices) through DeviceLoader: read, H2D, augment, resize inside the timed region",
             "config": {"workload": f"TransCeption (MSTransception) {args.size}x{args.size} B={args.batch}/GPU fwd+bwd+SGD, "
-                                   "synthetic Synapse slices, name-seeded random-init weights",
+                                   + ("random-noise batch resident in HBM" if not args.loader else "synthetic Synapse npz slices via the device loader")
+                                   + ", name-seeded random-init weights",
                        "global_batch": world * args.batch, "image_size": args.size, "parallelism": f"dp{world}",
                        "launch_mode": "eager" if args.eager else "hipGraph replay", "final_loss": float(loss.item()),
+                       "launches_per_step": launches,
                        "median_ms_per_step": statistics.median(per_step), "min_ms_per_step": min(per_step), **extra},
         }
-        if world > 1:
+        if comm:
             out["rccl_ranks"] = dist.get_world_size()
-            out["config"]["collective_backend"] = backend + (" (all ranks on one GPU: drill, not a measurement)" if one_gpu_drill else "")
+            out["config"]["collective_backend"] = backend + (" (all ranks on one GPU: drill, not a measurement)" if one_gpu_drill else "") + \
+                (" (one rank: the split step's collectives run on a 1-rank communicator -- the N=1 floor of allreduce_exposed_ms)" if rccl1 else "")
             out["config"]["allreduce_exposed_ms"] = exposed
         out.update(roofs)
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.batch, args.size)
         print(json.dumps(out))
-    if world > 1:
+    if comm:
         dist.destroy_process_group()
 
 
@@ -352,41 +398,78 @@ def side_figures(args, dev, model, loss_fn, opt, step, x, y, build_model, engine
                 "how": "HIP events around each launch inside 3 instrumented (eager) training steps of the benchmarked workload; an event "
                        "pair around an empty kernel on the idle queue reads event_pair_floor_us, which every in-step figure includes -- the "
                        "kernel's own duration is roofline_graph_replay / the rocprofv3 average in profiles/"}
+    prof_file = next((f for f in ("r3_hbm_by_kernel.json", "r2_hbm_by_kernel.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), None)
+    pmc_doc = json.load(open(os.path.join(ROOT, "profiles", prof_file))).get("kernels", {}) if prof_file else {}
+    same_workload = args.dtype == "bf16" and args.batch == 16 and args.size == 224
+
+    def pmc_traffic(prefixes):
+        """Memory-side bytes per launch of the kernels whose names start with one of `prefixes`, from the committed rocprofv3 --pmc
+        passes of this workload (2 x FETCH_SIZE + WRITE_SIZE, scripts/pmc_step.sh); None for another workload."""
+        if not same_workload:
+            return None, None
+        hit = [v for k, v in pmc_doc.items() if any(k.startswith(q) for q in prefixes)]
+        n = sum(v["launches_per_step"] for v in hit)
+        if not n:
+            return None, None
+        return sum(v["bytes_per_step"] for v in hit) / n, (f"profiles/{prof_file} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of this workload, "
+                                                            "scripts/pmc_step.sh; per launch, not measured in this run)")
     if prof.get("attn_fwd"):
         r = mfma_block(prof["attn_fwd"], "attn_fwd_seg_kernel (bridge SR-attention forward, QK^T + softmax + PV fused, all 4 scales x B "
                                          "images in one launch)")
         r["traffic"], r["traffic_source"] = None, None
-        for name in ("r2_attn_pmc.json", "r1_attn_pmc.json"):   # HBM bytes per launch: a separate rocprofv3 --pmc pass, committed
+        for name in ("r3_attn_pmc.json", "r2_attn_pmc.json", "r1_attn_pmc.json"):   # HBM bytes per launch: a separate rocprofv3 --pmc pass, committed
             pmc = os.path.join(ROOT, "profiles", name)
-            if args.dtype == "bf16" and args.batch == 16 and args.size == 224 and os.path.exists(pmc):
+            if same_workload and os.path.exists(pmc):
                 r["traffic"] = json.load(open(pmc)).get("attn_fwd_seg_kernel", {}).get("hbm_bytes_corrected")
                 r["traffic_source"] = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE pass of this workload, not measured in this run)"
                 break
-        roofs["roofline"] = r
+        roofs["roofline_in_step_events"] = r
     if prof.get("attn_bwd"):
         roofs["roofline_attn_bwd"] = mfma_block(prof["attn_bwd"], "attn_bwd (delta + dQ + dK/dV kernels of the bridge SR-attention)")
+    # the GEMM family (the time-dominant one): algorithmic flops AND bytes per launch kind
+    PMC_GEMM = {"single": ("gemm_bf16_kernel", "gemm_kernel"), "pair": ("gemm_pair_kernel",), "multi": ("gemm_multi_kernel",)}
+    gem = []
+    for kind in ("pair", "multi", "single"):
+        ev = prof.get("gemm:" + kind)
+        if not ev:
+            continue
+        ms = sum(a.elapsed_time(b) for a, b, _ in ev)
+        fl = sum(w[0] for _, _, w in ev)
+        by = sum(w[1] for _, _, w in ev)
+        tr, src = pmc_traffic(PMC_GEMM[kind])
+        gem.append({"bound": "hbm", "kernel": {"pair": "gemm_pair_kernel (dX + dW of a Linear in one grid)", "multi": "gemm_multi_kernel (<= 12 independent "
+                    "Linear-type problems in one grid)", "single": "gemm_bf16_kernel / gemm_kernel (one problem per launch)"}[kind],
+                    "achieved": by / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": by / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                    "achieved_tflops": fl / (ms * 1e-3) / 1e12, "frac_of_mfma_peak": fl / (ms * 1e-3) / 1e12 / peak,
+                    "launches": len(ev), "launches_per_step": len(ev) / 3.0, "avg_launch_us": 1e3 * ms / len(ev), "ms_per_step": ms / 3.0,
+                    "algorithmic_bytes_per_launch": by / len(ev), "algorithmic_flops_per_launch": fl / len(ev),
+                    "traffic": tr, "traffic_source": src, "event_pair_floor_us": event_floor_us})
+    if gem:
+        gem.sort(key=lambda r: -r["ms_per_step"])
+        roofs["roofline_gemm"] = dict(gem[0], how="HIP events around each GEMM-family launch inside 3 instrumented (eager) steps; the products are K = 64..2048 "
+                                      "deep, i.e. HBM-bound (bound = hbm: algorithmic operand + result bytes / time), the MFMA figure is given beside it; every "
+                                      "in-step figure includes event_pair_floor_us per launch")
+        roofs["roofline_gemm_others"] = gem[1:]
+    PMC_HBM = {"ffn_mid_bwd": ("ffn_mid_bwd_kernel",), "ffn_fused_fwd": ("ffn_fused_fwd_kernel",), "ffn_fused_bwd": ("ffn_bwd_",), "ffn_dw_fwd": ("dw_tile_kernel", "dw_multi_kernel"),
+               "layernorm_fwd": ("ln_fwd_kernel",), "layernorm_bwd": ("ln_bwd_kernel",), "dwconv_fwd": ("dw_tile_kernel", "dw_multi_kernel<bf16, 0>", "dw_kernel"),
+               "dwconv_bwd_input": ("dw_tile_kernel<bf16, 3, 8, 1>", "dw_multi_kernel<bf16, 1>"), "dwconv_bwd_weight": ("dw_tile_wgrad_kernel", "dw_multi_wgrad_kernel", "dw_wgrad_kernel"),
+               "batchnorm_fwd": ("bn_partial_kernel<bf16, 0>", "bn_apply_kernel"), "batchnorm_bwd": ("bn_partial_kernel<bf16, 1>", "bn_bwd_apply_kernel"),
+               "coord_pool_fwd": ("coord_pool_fwd_kernel",), "coord_gate_fwd": ("coord_gate_fwd_kernel",), "pixel_shuffle": ("pixel_shuffle",)}
     hbm = []
     for name, ev in prof.items():
         if name.startswith("hbm:") and ev:
             ms = sum(a.elapsed_time(b) for a, b, _ in ev)
             by = sum(f for _, _, f in ev)
             gbs = by / (ms * 1e-3) / 1e9
+            tr, src = pmc_traffic(PMC_HBM.get(name[4:].split(" ")[0], ("\0",)))
             hbm.append({"bound": "hbm", "kernel": name[4:], "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                        "launches": len(ev), "avg_launch_us": 1e3 * ms / len(ev), "algorithmic_bytes_per_launch": by / len(ev)})
+                        "launches": len(ev), "avg_launch_us": 1e3 * ms / len(ev), "algorithmic_bytes_per_launch": by / len(ev),
+                        "traffic": tr, "traffic_source": src})
     if hbm:
         hbm.sort(key=lambda r: -r["avg_launch_us"] * r["launches"])
-        top = dict(hbm[0], how="HIP events around each launch inside 3 instrumented steps; algorithmic bytes = every operand read once + "
-                               "every result written once (the memory-bound family with the largest share of the step)", traffic=None,
-                   traffic_source=None)
-        pmc = os.path.join(ROOT, "profiles", "r2_hbm_by_kernel.json")       # per-launch memory-side bytes from the committed PMC passes
-        if args.dtype == "bf16" and args.batch == 16 and args.size == 224 and os.path.exists(pmc):
-            doc = json.load(open(pmc)).get("kernels", {})
-            key = next((k for k in doc if k.split("<")[0].split("_kernel")[0] in top["kernel"]), None)
-            if key:
-                top["traffic"] = doc[key]["bytes_per_step"] / max(doc[key]["launches_per_step"], 1)
-                top["traffic_source"] = ("profiles/r2_hbm_by_kernel.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of this workload, "
-                                         "scripts/pmc_step.sh; not measured in this run)")
-        roofs["roofline_hbm"] = top
+        roofs["roofline_hbm"] = dict(hbm[0], how="HIP events around each launch inside 3 instrumented steps; algorithmic bytes = every operand read once + "
+                                     "every result written once (the memory-bound family with the largest share of the step); traffic = memory-side bytes per "
+                                     "launch of the family's kernels from the committed PMC passes")
         roofs["roofline_hbm_others"] = hbm[1:6]
     # (2) forward-only rate (train-mode forward captured alone)
     with torch.no_grad():
@@ -439,9 +522,17 @@ def side_figures(args, dev, model, loss_fn, opt, step, x, y, build_model, engine
                               Bq, 4, nqc, Nk, 0.125, tcd, torch.cuda.current_stream(dev).cuda_stream)
         us = _graph_replay_us(attn, 30, dev)
         fl = 4.0 * rows * Nk * 64
-        roofs["roofline_graph_replay"] = {"bound": "mfma", "achieved": fl / us / 1e6, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                                          "frac": fl / us / 1e6 / PEAK_TFLOPS[args.dtype], "avg_launch_us": us,
-                                          "how": "30 back-to-back launches of attn_fwd_seg_kernel in one replayed hipGraph, step-shaped random operands"}
+        ins = roofs.get("roofline_in_step_events", {})
+        roofs["roofline"] = {"bound": "mfma", "kernel": "attn_fwd_seg_kernel (bridge SR-attention forward, QK^T + softmax + PV fused, all 4 scales x B images "
+                                                        "in one launch)",
+                             "achieved": fl / us / 1e6, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
+                             "frac": fl / us / 1e6 / PEAK_TFLOPS[args.dtype], "avg_launch_us": us, "algorithmic_flops_per_launch": fl,
+                             "traffic": ins.get("traffic"), "traffic_source": ins.get("traffic_source"),
+                             "how": "HIP events on the launching stream around 30 back-to-back launches of the kernel inside one replayed hipGraph, step-shaped "
+                                    "random operands (no event-pair floor in the figure; agrees with the rocprofv3 average in profiles/); the per-launch "
+                                    "event figure of instrumented eager steps, which includes event_pair_floor_us, is roofline_in_step_events"}
+    elif "roofline_in_step_events" in roofs:
+        roofs["roofline"] = roofs["roofline_in_step_events"]
     return extra, roofs
 
 

@@ -151,3 +151,52 @@ def test_config5_384_train_mode_fwd_bwd_vs_oracle():
         assert dmax <= 0.1 and abs(l_loss - hl) < 1e-2 and cos >= 0.99 and bool(torch.isfinite(gl).all()), name
         if name == "fp16":
             assert dmax <= 0.02 and cos >= 0.9995                 # 11-bit mantissa: an order of magnitude closer than bf16
+
+
+def _lowp_vs_fp32(sd, ncls, dt, name, scale, x, lab, m32, lc, hl, fp16_tight=False):
+    ml = _hip(sd, ncls, dt)
+    ll, l_loss = _hip_step(ml, x, lab, ncls, loss_scale=scale)
+    g32, gl = m32.flat_gradients().double(), ml.flat_gradients().double() / scale
+    cos = float((g32 * gl).sum() / (g32.norm() * gl.norm()))
+    dmax = (ll - lc).abs().max().item()
+    print(f"{name} vs fp32 at B={x.shape[0]} {x.shape[-1]}^2: max|dlogit| {dmax:.3f} loss {l_loss:.5f} vs {hl:.5f} gradient cosine {cos:.5f}")
+    assert dmax <= 0.1 and abs(l_loss - hl) < 1e-2 and cos >= 0.99 and bool(torch.isfinite(gl).all()), name
+    if fp16_tight:
+        assert dmax <= 0.02 and cos >= 0.9995
+
+
+def test_config4_512_binary_full_batch_b8():
+    """BASELINE config 4 at its real per-GPU batch: 512^2, num_classes=2, three-channel input, **B=8** (split-K
+    choices, grouped launches and the attention grid depend on B).  One fp32 HIP step (forward, CE+Dice, backward) against the CPU
+    oracle -- the reference cannot run this size (MSTr.py:2228-2231,2394-2397); the oracle, pinned at 224^2, is the check -- then the
+    bf16 step at the same batch against that fp32 step (stated budget)."""
+    sd = _state(2)
+    x = torch.from_numpy(seeded_input(8, in_ch=3, size=512))
+    lab = torch.from_numpy(seeded_labels(8, num_classes=2, size=512))
+    m = _hip(sd, 2, torch.float32)
+    lc, hl = _hip_step(m, x, lab, 2)
+    assert tuple(lc.shape) == (8, 2, 512, 512)
+    lo, ol, orc = _oracle_step(sd, x, lab, 2)
+    err = _check_against_oracle(m, orc, lo, ol, lc, hl, 2e-4)
+    print(f"512^2 nc=2 B=8: max|dlogit| {err:.2e}")
+    del orc
+    _lowp_vs_fp32(sd, 2, torch.bfloat16, "bf16", 1.0, x, lab, m, lc, hl)
+
+
+def test_config5_384_full_batch_b8_fp16():
+    """BASELINE config 5 at its real per-GPU batch: 384^2, **B=8**, train mode, fp16 storage with the static loss scale; the fp32 step
+    at the same batch against the CPU oracle first (logits, loss, gradient probes, gradient norm, BatchNorm running statistics)."""
+    sd = _state()
+    x = torch.from_numpy(seeded_input(8, size=384))
+    lab = torch.from_numpy(seeded_labels(8, size=384))
+    m = _hip(sd, 9, torch.float32)
+    lc, hl = _hip_step(m, x, lab, 9)
+    lo, ol, orc = _oracle_step(sd, x, lab, 9)
+    err = _check_against_oracle(m, orc, lo, ol, lc, hl, 2e-4)
+    print(f"384^2 train B=8: max|dlogit| {err:.2e}")
+    hsd = m.state_dict()
+    for key in ("backbone.patch_embed_stage3.patch_embeds.1.patch_conv.bn.running_var", "backbone.mhca_stage4.aggregate.bn1.running_mean"):
+        np.testing.assert_allclose(hsd[key].cpu().numpy(), orc.buffers[key].detach().numpy(), rtol=1e-4, atol=1e-5)
+    del orc
+    _lowp_vs_fp32(sd, 9, torch.float16, "fp16", 4096.0, x, lab, m, lc, hl, fp16_tight=True)
+    _lowp_vs_fp32(sd, 9, torch.bfloat16, "bf16", 1.0, x, lab, m, lc, hl)

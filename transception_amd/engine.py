@@ -40,6 +40,27 @@ def _timed(name: str, flops: float, fn):
     PROFILE.setdefault(name, []).append((e0, e1, flops))
 
 
+def _gemm_work(descs):
+    """Algorithmic (flops, bytes) of a list of TcGemm problems: 2MNK per product; every operand read once and the result written
+    once (read + written when it accumulates), in the storage type (fp32 for weight-gradient outputs)."""
+    fl = by = 0.0
+    for g in descs:
+        nb = g.nb1 * g.nb2
+        es = 4 if g.dtype == TC_F32 else 2
+        ec = 4 if g.c_f32 else es
+        fl += 2.0 * g.M * g.N * g.K * nb
+        by += nb * ((g.M * g.K + g.K * g.N) * es + g.M * g.N * ec * (2 if g.accumulate else 1) + (g.M * g.N * es if g.R else 0))
+    return fl, by
+
+
+def _timed_gemm(kind: str, descs, fn):
+    """bench.py: HIP events around a GEMM-family launch (tc_gemm / tc_gemm_pair / tc_gemm_multi) with its algorithmic flops and bytes."""
+    if PROFILE is None:
+        fn()
+        return
+    _timed("gemm:" + kind, _gemm_work(descs), fn)
+
+
 class P:
     """Engine-side handle of one parameter: compute-dtype data + fp32 gradient view (or None when frozen).
     gs = distance (elements) to the same parameter of the next group when an op runs several weight sets at once
@@ -457,7 +478,7 @@ class Graph:
         g = self._gemm_desc(A, lda, B, ldb, Cm, ldc, M, N, K, tA, tB, bias, R, ldr, alpha, acc, act, splitk, nb1, nb2, sA, sB, sC, sR,
                             c_f32, atomic, rowsum, sbias, srow)
         self.n_launch += 1
-        self.L.tc_gemm(C.byref(g), self.stream)
+        _timed_gemm("single", [g], lambda: self.L.tc_gemm(C.byref(g), self.stream))
 
     def _gemm_desc(self, A, lda, B, ldb, Cm, ldc, M, N, K, tA, tB, bias=None, R=None, ldr=0, alpha=1.0, acc=0, act=ACT_NONE,
                    splitk=1, nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), c_f32=0, atomic=0, rowsum=None, sbias=0,
@@ -538,7 +559,7 @@ class Graph:
                 if gb.splitk > 128:                      # the one workspace of this stream goes to the problem that folds partials
                     gb.ws, gb.ws_bytes, ga.ws, ga.ws_bytes = ga.ws, ga.ws_bytes, None, 0
                 self.n_launch += 1
-                self.L.tc_gemm_pair(C.byref(ga), C.byref(gb), self.stream)
+                _timed_gemm("pair", [ga, gb], lambda: self.L.tc_gemm_pair(C.byref(ga), C.byref(gb), self.stream))
             elif x.requires_grad:
                 gx, acc = self.wgrad(x, (nb - 1) * sx // x.root.cols if (nb > 1 and not grouped) else 0)
                 self._gemm(_ptr(dz), dz.stride(0), _ptr(Wt), Wt.stride(0), _ptr(gx), gx.stride(0), M, K, N, 0, 0, acc=acc,
@@ -584,7 +605,7 @@ class Graph:
                 chunk = probs[c0:c0 + 12]
                 arr = (TcGemm * len(chunk))(*chunk)
                 self.n_launch += 1
-                self.L.tc_gemm_multi(arr, len(chunk), self.stream)
+                _timed_gemm("multi", chunk, lambda: self.L.tc_gemm_multi(arr, len(chunk), self.stream))
         fw = []
         for i, (x, W, b, out, res, batch) in enumerate(items):
             N, K = W.data.shape
@@ -669,11 +690,11 @@ class Graph:
                                      rowsum=_ptr(bs[0].grad) if bs[0].grad is not None else None, srow=gsw, use_ws=False)
             self.n_launch += 1
             if ga is not None and gb is not None:
-                self.L.tc_gemm_pair(C.byref(ga), C.byref(gb), self.stream)
+                _timed_gemm("pair", [ga, gb], lambda: self.L.tc_gemm_pair(C.byref(ga), C.byref(gb), self.stream))
             elif ga is not None:
-                self.L.tc_gemm(C.byref(ga), self.stream)
+                _timed_gemm("single", [ga], lambda: self.L.tc_gemm(C.byref(ga), self.stream))
             elif gb is not None:
-                self.L.tc_gemm(C.byref(gb), self.stream)
+                _timed_gemm("single", [gb], lambda: self.L.tc_gemm(C.byref(gb), self.stream))
         self._rec(bwd)
         return out
 
@@ -684,13 +705,13 @@ class Graph:
             return
         self.n_launch += 1
         if len(descs) == 1:
-            self.L.tc_gemm(C.byref(descs[0]), self.stream)
+            _timed_gemm("single", descs, lambda: self.L.tc_gemm(C.byref(descs[0]), self.stream))
         elif len(descs) == 2 and not descs[0].transA and not descs[0].transB and descs[1].transA and not descs[1].transB:
-            self.L.tc_gemm_pair(C.byref(descs[0]), C.byref(descs[1]), self.stream)
+            _timed_gemm("pair", descs, lambda: self.L.tc_gemm_pair(C.byref(descs[0]), C.byref(descs[1]), self.stream))
         else:
             for c0 in range(0, len(descs), 12):
                 chunk = descs[c0:c0 + 12]
-                self.L.tc_gemm_multi((TcGemm * len(chunk))(*chunk), len(chunk), self.stream)
+                _timed_gemm("multi", chunk, lambda: self.L.tc_gemm_multi((TcGemm * len(chunk))(*chunk), len(chunk), self.stream))
 
     def mixffn(self, sites: List[dict]) -> List[Var]:
         """MixFFN_skip (MSTr.py:889-902, fc1 evaluated once): out = fc2(GELU(LN(dw3x3(h) + h))) + residual, h = fc1(x), for one site

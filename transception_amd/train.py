@@ -12,6 +12,7 @@ torch.distributed only.
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
@@ -24,11 +25,24 @@ def _dt(t: torch.Tensor) -> int:
     return {torch.float32: TC_F32, torch.bfloat16: TC_BF16, torch.float16: TC_F16}[t.dtype]
 
 
+COMM_AT_WORLD_1 = os.environ.get("TC_COMM_WORLD1", "0") == "1"
+
+
+def comm_on(group=None) -> bool:
+    """True when the step's collectives are to be issued: a process group of more than one rank -- or of exactly ONE rank when
+    COMM_AT_WORLD_1 is set (TC_COMM_WORLD1=1; bench.py --gpus 1 --force-split and tests/test_rccl_gpu.py): a 1-rank RCCL all-reduce
+    still goes through communicator creation, the collective stream, the async work handles and the no-collective-in-capture rule
+    of the split step, so the structure the driver's 8-GPU run uses is executed on one GPU first."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or COMM_AT_WORLD_1
+
+
 def seg_sums_allreduce(sums: torch.Tensor, n_pix: float, group=None):
     """C2 of SURVEY.md section 8(e): the [1 + 3*classes] vector (sum CE, then intersect/y_sum/z_sum per class) is summed over
     ranks so that every rank forms the loss of the GLOBAL batch (Dice is not linear in the batch, utils.py:24-32)."""
     world = 1
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if comm_on(group):
         world = dist.get_world_size(group)
         dist.all_reduce(sums, group=group)
     return sums, n_pix * world, world
@@ -211,7 +225,7 @@ def allreduce_gradients(model, group=None, part: Optional[str] = None, async_op:
     the buckets at or above / below model.late_gradient_offset() (bridge + decoders / encoder); async_op returns the work
     handles instead of waiting, so the late part can travel under the encoder's backward."""
     works = []
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if comm_on(group):
         buckets = gradient_buckets(model)
         if part is not None:
             early, late = split_buckets(buckets, model.late_gradient_offset())
@@ -240,6 +254,43 @@ def train_step(model, loss_fn: SegLoss, opt: FusedSGD, images: torch.Tensor, lab
 _CAPTURE_MODE = "thread_local"
 
 
+def graph_kernel_nodes(g) -> Optional[int]:
+    """Kernel nodes of a captured hipGraph (hipGraphGetNodes / hipGraphNodeGetType on the raw handle; the graph must have been
+    created with keep_graph=True).  None when the runtime does not expose it."""
+    import ctypes as C
+    try:
+        hip = C.CDLL("libamdhip64.so")
+        raw = C.c_void_p(g.raw_cuda_graph())
+        n = C.c_size_t(0)
+        if hip.hipGraphGetNodes(raw, None, C.byref(n)) != 0:
+            return None
+        arr = (C.c_void_p * max(n.value, 1))()
+        if hip.hipGraphGetNodes(raw, arr, C.byref(n)) != 0:
+            return None
+        k, t = 0, C.c_int(-1)
+        for i in range(n.value):
+            if hip.hipGraphNodeGetType(C.c_void_p(arr[i]), C.byref(t)) == 0 and t.value == 0:       # hipGraphNodeTypeKernel
+                k += 1
+        return k
+    except Exception:
+        return None
+
+
+def _new_graph():
+    try:
+        return torch.cuda.CUDAGraph(keep_graph=True)             # keeps the hipGraph_t so that its nodes can be counted
+    except TypeError:
+        return torch.cuda.CUDAGraph()
+
+
+def _instantiate(g):
+    if hasattr(g, "instantiate"):
+        try:
+            g.instantiate()
+        except Exception:
+            pass
+
+
 class GraphedStep:
     """A whole training step captured into hipGraphs and replayed: ~1800 kernel launches per step become graph launches,
     removing the host from the loop.  Inputs are copied into static buffers; the learning rate is a device scalar
@@ -257,7 +308,7 @@ class GraphedStep:
         self.model, self.loss_fn, self.opt, self.group = model, loss_fn, opt, group
         self.x, self.y = images.clone(), labels.clone().long().contiguous()
         opt.grad_scale = 1.0 / getattr(loss_fn, "loss_scale", 1.0)
-        self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.distributed = comm_on(group)
         self.split = self.distributed or force_split
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -269,25 +320,33 @@ class GraphedStep:
                     train_step(model, loss_fn, opt, self.x, self.y, group)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.g_main = torch.cuda.CUDAGraph()
+        self.g_main = _new_graph()
         if not self.split:
             with torch.cuda.graph(self.g_main, capture_error_mode=_CAPTURE_MODE):
                 self.out = train_step(model, loss_fn, opt, self.x, self.y, None)
-            self.g_bwd = self.g_opt = None
+            self.g_bwd = self.g_bwd_rest = self.g_opt = None
         else:
             with torch.cuda.graph(self.g_main, capture_error_mode=_CAPTURE_MODE):
                 self._fwd()
             self._reduce_sums()
-            self.g_bwd = torch.cuda.CUDAGraph()
+            self.g_bwd = _new_graph()
             with torch.cuda.graph(self.g_bwd, capture_error_mode=_CAPTURE_MODE):
                 self._bwd()
-            self.g_bwd_rest = torch.cuda.CUDAGraph()
+            self.g_bwd_rest = _new_graph()
             with torch.cuda.graph(self.g_bwd_rest, capture_error_mode=_CAPTURE_MODE):
                 self._bwd_rest()
             allreduce_gradients(model, group)
-            self.g_opt = torch.cuda.CUDAGraph()
+            self.g_opt = _new_graph()
             with torch.cuda.graph(self.g_opt, capture_error_mode=_CAPTURE_MODE):
                 opt.step()
+        for g in (self.g_main, self.g_bwd, self.g_bwd_rest, self.g_opt):
+            if g is not None:
+                _instantiate(g)
+
+    def kernel_nodes(self) -> Optional[int]:
+        """Kernel launches of one replayed step = kernel nodes of its captured graph(s)."""
+        ks = [graph_kernel_nodes(g) for g in (self.g_main, self.g_bwd, self.g_bwd_rest, self.g_opt) if g is not None]
+        return None if any(k is None for k in ks) else sum(ks)
 
     # ---- the three pieces of the split step (engine driven directly; no torch.autograd in between)
     def _fwd(self):
