@@ -223,6 +223,32 @@ typedef struct TcFfnFused {
 int tc_ffn_fused_supported(int C, int dtype);
 int tc_ffn_fused_fwd(const TcFfnFused* f, int dtype, void* stream);
 
+/* MixFFN_skip backward with the hidden maps kept on the chip (16-bit storage types; see csrc/mixffn_bwd.hip): the autograd backward of
+ * MSTr.py:889-902 (fc2, GELU, LayerNorm(4C), DWConv :21-31 + skip, fc1) from what tc_ffn_fused_fwd left -- d = dw3x3(h) + bias + h in
+ * the storage type and stat = (mean, rstd) per pixel -- and the site's input x and output gradient dy.  Three launches:
+ *   1. rows of 64 pixels: gp = (dy W2) (.) GELU'(u), u = LN(d);  LayerNorm backward -> gd (the only hidden-width map that is written);
+ *      dW2 += dy^T GELU(u), db2, dgamma, dbeta as per-workgroup fp32 partials (the activation GELU(u) is recomputed, never stored);
+ *   2. pixel tiles with a one-pixel halo: h = fc1(x) recomputed by MFMA, dh = dw3x3^T(gd) + gd, dx (+)= dh W1,
+ *      dW1 += dh^T x, db1, dwd, dbd as per-workgroup fp32 partials (h and dh never leave LDS);
+ *   3. the partials of all workgroups are added into the fp32 gradient arrays.
+ * x / dy / dx rows as in TcFfnFused (x, dx: group g at g*B*H*W rows; dy: pixel row r of group g at g*sdy + r*lddy); parameters and
+ * gradient arrays of weight group g at + g*wstride elements.  gd: [groups*B*H*W, 4C] scratch in the storage type; part: fp32 scratch of
+ * tc_ffn_fused_bwd_scratch_floats(C, groups) floats.  acc_dx = 1 adds to dx.  Replaces {fc2 dX + dW GEMMs, tc_ffn_mid_bwd, fc1 dX + dW
+ * GEMMs} of the op-by-op form, which read or write eight hidden-width maps. */
+typedef struct TcFfnBwd {
+    const void* x; const void* dy; const void* d; const float* stat;
+    const void* w1; const void* b1; const void* wd; const void* gamma; const void* beta; const void* w2;
+    void* dx; void* gd; float* part; long long part_floats;
+    float* dw1; float* db1; float* dwd; float* dbd; float* dgamma; float* dbeta; float* dw2; float* db2;
+    long long sdy, wstride;
+    int ldx, lddy, lddx, C, B, H, W, groups, acc_dx;
+    float eps;
+    int tile_h, tile_w;          /* 0: the library picks the pixel tile of launch 2 */
+} TcFfnBwd;
+int tc_ffn_fused_bwd_supported(int C, int dtype);
+long long tc_ffn_fused_bwd_scratch_floats(int C, int groups);
+int tc_ffn_fused_bwd(const TcFfnBwd* f, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * BatchNorm2d over token rows ([rows, C], statistics over rows) fused with its activation and an
  * optional residual add:  y = act((x-mean)*rstd*gamma+beta) (+ res).

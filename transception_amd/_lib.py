@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("TC_LIB_PATH") or os.path.join(HERE, "libtransception_
 
 TC_F32, TC_BF16, TC_F16 = 0, 1, 2
 ACT_NONE, ACT_HSWISH, ACT_COORD, ACT_SIGMOID, ACT_GELU = 0, 1, 2, 3, 4
-ABI_VERSION = 6
+ABI_VERSION = 7
 ATTN_DKV_SPLITS = 8                # include/transception_hip.h: partial dK|dV buffers in tc_attn_bwd_seg's fp32 scratch
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_longlong, C.c_float
@@ -56,6 +56,16 @@ class TcFfnFused(C.Structure):
                 ("tile_h", i32), ("tile_w", i32)]
 
 
+class TcFfnBwd(C.Structure):
+    _fields_ = [("x", vp), ("dy", vp), ("d", vp), ("stat", vp),
+                ("w1", vp), ("b1", vp), ("wd", vp), ("gamma", vp), ("beta", vp), ("w2", vp),
+                ("dx", vp), ("gd", vp), ("part", vp), ("part_floats", i64),
+                ("dw1", vp), ("db1", vp), ("dwd", vp), ("dbd", vp), ("dgamma", vp), ("dbeta", vp), ("dw2", vp), ("db2", vp),
+                ("sdy", i64), ("wstride", i64),
+                ("ldx", i32), ("lddy", i32), ("lddx", i32), ("C", i32), ("B", i32), ("H", i32), ("W", i32), ("groups", i32), ("acc_dx", i32),
+                ("eps", f32), ("tile_h", i32), ("tile_w", i32)]
+
+
 class TcEwSeg(C.Structure):
     _fields_ = [("kind", i32), ("flag", i32), ("a", vp), ("b", vp), ("sa", i64), ("sb", i64),
                 ("lda", i32), ("ldb", i32), ("n0", i32), ("n1", i32), ("n2", i32), ("n3", i32), ("n4", i32), ("reserved", i32)]
@@ -94,6 +104,9 @@ SIGNATURES = {
     "tc_ffn_mid_bwd": [C.POINTER(TcFfnSeg), i32, i32, i64, vp, i64, i32, vp],
     "tc_ffn_fused_supported": [i32, i32],
     "tc_ffn_fused_fwd": [C.POINTER(TcFfnFused), i32, vp],
+    "tc_ffn_fused_bwd_supported": [i32, i32],
+    "tc_ffn_fused_bwd_scratch_floats": [i32, i32],
+    "tc_ffn_fused_bwd": [C.POINTER(TcFfnBwd), i32, vp],
     "tc_bn_scratch_floats": [i32, i32],
     "tc_bn_fwd": [vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, f32, f32, i32, i32, i32, vp],
     "tc_bn_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp],
@@ -136,8 +149,8 @@ SIGNATURES = {
     "tc_fill_f32": [vp, i64, f32, vp],
     "tc_cast": [vp, vp, i64, i32, i32, vp],
 }
-_RET = {"tc_bn_scratch_floats": i64, "tc_softmax_scratch_floats": i64, "tc_layernorm_bwd_scratch_floats": i64, "tc_factor_att_stats_floats": i64}
-_RAW = {"tc_abi_version", "tc_ffn_chunk", "tc_ffn_fused_supported", "tc_bn_scratch_floats", "tc_softmax_scratch_floats", "tc_layernorm_bwd_scratch_floats", "tc_factor_att_stats_floats"}     # not status-returning
+_RET = {"tc_ffn_fused_bwd_scratch_floats": i64, "tc_bn_scratch_floats": i64, "tc_softmax_scratch_floats": i64, "tc_layernorm_bwd_scratch_floats": i64, "tc_factor_att_stats_floats": i64}
+_RAW = {"tc_abi_version", "tc_ffn_chunk", "tc_ffn_fused_supported", "tc_ffn_fused_bwd_supported", "tc_ffn_fused_bwd_scratch_floats", "tc_bn_scratch_floats", "tc_softmax_scratch_floats", "tc_layernorm_bwd_scratch_floats", "tc_factor_att_stats_floats"}     # not status-returning
 
 
 class TcError(RuntimeError):

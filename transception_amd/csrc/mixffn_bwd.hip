@@ -1,0 +1,729 @@
+// MixFFN_skip backward (autograd of MSTr.py:889-902 with DWConv :21-31) with the hidden maps kept on the chip.
+//   forward (mixffn.hip) left:  d = dw3x3(h) + bias + h  (storage type) and stat = (mean, rstd) of LayerNorm_4C(d) per pixel
+//   launch 1  ffn_bwd_ln_kernel   rows of 64 pixels:  gpre = dy W2 (MFMA), u = LN(d), gp = gpre (.) GELU'(u), LayerNorm backward -> gd,
+//                                 dW2 += dy^T GELU(u) (MFMA, the activation recomputed in registers and staged in LDS only), db2, dgamma, dbeta
+//   launch 2  ffn_bwd_dw_kernel   pixel tiles with a one-pixel halo, 128 hidden channels at a time:  h = fc1(x) recomputed (MFMA) on the
+//                                 haloed tile, dh = dw3x3^T(gd) + gd, dwd / dbd / db1 sums, dx += dh W1 (MFMA), dW1 += dh^T x (MFMA)
+//   launch 3  ffn_bwd_reduce_kernel  the per-workgroup fp32 partial sums of both launches -> the gradient arrays
+// Only gd crosses HBM between the launches (op-by-op: gp, a, d twice, h, dh three times).  Workgroups are persistent (one per CU):
+// weight-gradient accumulators stay in registers / LDS for the whole launch and leave once, as one partial per workgroup.
+// 16-bit storage types (bf16 / fp16), C = 64.
+#include "tc_common.h"
+#include <cstdlib>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+
+// k-row permutation of the LDS tiles whose rows are the reduction index of a transpose-read operand (gemm.hip, gemm_krow)
+__device__ __forceinline__ int krow(int k) { return (k & ~15) | ((k & 3) << 2) | ((k >> 2) & 3); }
+template <typename V8> __device__ __forceinline__ V8 ld_tr(const bf16_t* lo, const bf16_t* hi) {
+    const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(lo));
+    const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(hi));
+    return __builtin_bit_cast(V8, (s16x8_t)__builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+template <typename H> __device__ __forceinline__ void up8(const uint4& r, float* o) {
+    unpack2<H>(r.x, o[0], o[1]); unpack2<H>(r.y, o[2], o[3]); unpack2<H>(r.z, o[4], o[5]); unpack2<H>(r.w, o[6], o[7]);
+}
+template <typename H> __device__ __forceinline__ uint4 pk8(const float* o) {
+    return make_uint4(pack2<H>(o[0], o[1]), pack2<H>(o[2], o[3]), pack2<H>(o[4], o[5]), pack2<H>(o[6], o[7]));
+}
+
+// per-(weight group, workgroup) partial sums, fp32: launch 1 [dW2 C x 4C][db2 C][dgamma 4C][dbeta 4C], launch 2 [dW1 4C x C][db1 4C][dwd 4C x 9][dbd 4C]
+template <int C> struct BwdPart {
+    static constexpr int C4 = 4 * C;
+    static constexpr int oW2 = 0, oB2 = oW2 + C * C4, oG = oB2 + C, oBt = oG + C4, n1 = oBt + C4;
+    static constexpr int oW1 = n1, oB1 = oW1 + C4 * C, oWd = oB1 + C4, oBd = oWd + 9 * C4, n = oBd + C4;
+};
+
+struct FfnBwdDev {
+    const void* x; const void* dy; const void* d; const float* stat;
+    const void* w1; const void* b1; const void* wd; const void* gamma; const void* beta; const void* w2;
+    void* dx; void* gd; float* part;
+    long long sdy, wstride;
+    int ldx, lddy, lddx, B, H, W, M, acc_dx, nblk;
+    int TH, TW, tilesH, tilesW, HW2, HP, MT, IP, MT2, KS, ntiles;
+};
+
+// --------------------------------------------------------------------------------------------------------------------- launch 1
+template <int C> struct LnCfg {
+    static constexpr int C4 = 4 * C, NW = 8, NTH = 512, CW = C4 / NW, NT = CW / 32, KK = C / 16, OB = C / 32, P = 64;
+    static constexpr int PH = C4 + 8, PX = C + 8, HC = C4 / 8, XC = C / 8, ND = P * HC / NTH, NY = (P * XC + NTH - 1) / NTH;
+    static constexpr size_t smem = (size_t)P * PH * 2 + (size_t)P * PX * 2 + (size_t)2 * C4 * 4 + (size_t)NW * P * 8 + (size_t)P * 8;
+    static_assert(NTH % XC == 0 && P * HC % NTH == 0, "strip ownership");
+    static_assert((size_t)NTH * 8 * 4 <= (size_t)P * PH * 2, "db2 fold aliases the hidden tile");
+};
+
+template <typename H, int C>
+__global__ __launch_bounds__(512, 2) void ffn_bwd_ln_kernel(const FfnBwdDev p) {
+    using K = LnCfg<C>;
+    using PT = BwdPart<C>;
+    using V8 = typename TcHalf<H>::v8;
+    constexpr int C4 = K::C4, CW = K::CW, NT = K::NT, KK = K::KK, OB = K::OB, P = K::P, PH = K::PH, PX = K::PX, HC = K::HC, XC = K::XC;
+    constexpr int ND = K::ND, NY = K::NY, NTH = K::NTH, NW = K::NW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* dt = reinterpret_cast<bf16_t*>(smem);                          // [P][PH]  d, then GELU(LN(d)), then gd; rows k-permuted
+    bf16_t* yt = dt + P * PH;                                              // [P][PX]  dy; rows k-permuted
+    float* gbs = reinterpret_cast<float*>(yt + P * PX);                    // gamma[C4], beta[C4]
+    float2* psum = reinterpret_cast<float2*>(gbs + 2 * C4);                // [NW][P] per-wave LayerNorm-backward row sums
+    float2* fst = psum + NW * P;                                           // [P] mean, rstd
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int gi = lane & 15, gq2 = (lane >> 4) & 1;
+    const int g = blockIdx.y, M = p.M;
+    const long long wo = (long long)g * p.wstride;
+    const H* D = reinterpret_cast<const H*>(p.d) + (long long)g * M * C4;
+    H* GD = reinterpret_cast<H*>(p.gd) + (long long)g * M * C4;
+    const H* DY = reinterpret_cast<const H*>(p.dy) + (long long)g * p.sdy;
+    const float2* ST = reinterpret_cast<const float2*>(p.stat) + (long long)g * M;
+    const unsigned short* W2 = reinterpret_cast<const unsigned short*>(p.w2) + wo;
+
+    {
+        const H* gm = reinterpret_cast<const H*>(p.gamma) + wo;
+        const H* bt = reinterpret_cast<const H*>(p.beta) + wo;
+        for (int i = tid; i < C4; i += NTH) { gbs[i] = ldf<H>(gm + i); gbs[C4 + i] = ldf<H>(bt + i); }
+    }
+    // W2^T fragments of this wave's hidden channels (A operand of gpre^T = W2^T dy^T: rows = hidden channel, k = output channel)
+    V8 wf[NT][KK];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            s16x8_t t;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = (short)W2[(long long)(kk * 16 + 8 * hh + j) * C4 + wave * CW + nt * 32 + l31];
+            wf[nt][kk] = __builtin_bit_cast(V8, t);
+        }
+
+    uint4 dr[ND], yr[NY];
+    float2 sr = make_float2(0.f, 0.f);
+    auto fetch = [&](int blk) __attribute__((always_inline)) {
+        const long long r0 = (long long)blk * P;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int s = tid + i * NTH, px = s / HC, cg = s - px * HC;
+            const long long row = r0 + px;
+            dr[i] = *reinterpret_cast<const uint4*>(D + (row < M ? row : 0) * C4 + cg * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < NY; ++i) {
+            const int s = tid + i * NTH, px = s / XC, cg = s - px * XC;
+            const long long row = r0 + px;
+            yr[i] = *reinterpret_cast<const uint4*>(DY + ((row < M && s < P * XC) ? row : 0) * p.lddy + cg * 8);
+        }
+        if (tid < P) { const long long row = r0 + tid; sr = ST[row < M ? row : 0]; }
+    };
+    float b2acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) b2acc[e] = 0.f;
+    auto put = [&](int blk) __attribute__((always_inline)) {
+        const long long r0 = (long long)blk * P;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int s = tid + i * NTH, px = s / HC, cg = s - px * HC;
+            *reinterpret_cast<uint4*>(dt + krow(px) * PH + cg * 8) = (r0 + px < M) ? dr[i] : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int i = 0; i < NY; ++i) {
+            const int s = tid + i * NTH, px = s / XC, cg = s - px * XC;
+            if (s < P * XC) {
+                const uint4 v = (r0 + px < M) ? yr[i] : make_uint4(0u, 0u, 0u, 0u);
+                *reinterpret_cast<uint4*>(yt + krow(px) * PX + cg * 8) = v;
+                float f[8];
+                up8<H>(v, f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) b2acc[e] += f[e];
+            }
+        }
+        if (tid < P) fst[tid] = (r0 + tid < M) ? sr : make_float2(0.f, 0.f);
+    };
+
+    float dgam[NT][16], dbet[NT][16];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dgam[nt][r] = 0.f; dbet[nt][r] = 0.f; }
+    f32x16 acc2[OB][NT];
+#pragma unroll
+    for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[ob][nt][r] = 0.f;
+
+    int blk = blockIdx.x;
+    if (blk < p.nblk) fetch(blk);
+    __syncthreads();                                               // gamma / beta
+    for (; blk < p.nblk; blk += gridDim.x) {
+        put(blk);
+        __syncthreads();
+        const long long r0 = (long long)blk * P;
+        // ---- gpre^T = W2^T dy^T: lane = pixel, registers = 16 of this wave's hidden channels
+        f32x16 acc[2][NT];
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[pb][nt][r] = 0.f;
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+            const bf16_t* yp = yt + krow(pb * 32 + l31) * PX + 8 * hh;
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                const V8 yv = *reinterpret_cast<const V8*>(yp + kk * 16);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[pb][nt] = TcHalf<H>::mfma(wf[nt][kk], yv, acc[pb][nt]);
+            }
+        }
+        // ---- u = LN(d); gp = gpre * GELU'(u); a = GELU(u) -> LDS (over d); gg = gp * gamma and the two row sums; dgamma / dbeta
+        uint2 dk[2][NT][4];
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+            const int px = pb * 32 + l31;
+            bf16_t* rowp = dt + krow(px) * PH;
+            const float2 st = fst[px];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int ch0 = wave * CW + nt * 32 + 8 * gq + 4 * hh;
+                    const uint2 dv = *reinterpret_cast<const uint2*>(rowp + ch0);
+                    dk[pb][nt][gq] = dv;
+                    const float4 g4 = *reinterpret_cast<const float4*>(gbs + ch0), b4 = *reinterpret_cast<const float4*>(gbs + C4 + ch0);
+                    float xv[4], av[4];
+                    unpack2<H>(dv.x, xv[0], xv[1]); unpack2<H>(dv.y, xv[2], xv[3]);
+                    const float gv[4] = {g4.x, g4.y, g4.z, g4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; e += 2) {
+                        const tc_f32x2 x2 = {xv[e], xv[e + 1]}, g2 = {gv[e], gv[e + 1]}, be2 = {bv[e], bv[e + 1]};
+                        const tc_f32x2 xh = (x2 - st.x) * st.y;
+                        const tc_f32x2 u = xh * g2 + be2;
+                        tc_f32x2 pdf;
+                        const tc_f32x2 cdf = gelu_cdf_pdf2(u, pdf);
+                        const tc_f32x2 a2 = u * cdf, gpr = cdf + u * pdf;
+                        const tc_f32x2 gpre = {acc[pb][nt][4 * gq + e], acc[pb][nt][4 * gq + e + 1]};
+                        const tc_f32x2 gp = gpre * gpr;
+                        dbet[nt][4 * gq + e] += gp.x; dbet[nt][4 * gq + e + 1] += gp.y;
+                        const tc_f32x2 gx = gp * xh;
+                        dgam[nt][4 * gq + e] += gx.x; dgam[nt][4 * gq + e + 1] += gx.y;
+                        const tc_f32x2 gg = gp * g2;
+                        s1 += gg.x + gg.y;
+                        const tc_f32x2 gh = gg * xh;
+                        s2 += gh.x + gh.y;
+                        acc[pb][nt][4 * gq + e] = gg.x; acc[pb][nt][4 * gq + e + 1] = gg.y;
+                        av[e] = a2.x; av[e + 1] = a2.y;
+                    }
+                    *reinterpret_cast<uint2*>(rowp + ch0) = make_uint2(pack2<H>(av[0], av[1]), pack2<H>(av[2], av[3]));
+                    __builtin_amdgcn_sched_barrier(0);              // (keeps the next group's loads and temporaries out of this one's live range)
+                }
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (hh == 0) psum[wave * P + px] = make_float2(s1, s2);
+        }
+        __syncthreads();
+        if (blk + (int)gridDim.x < p.nblk) fetch(blk + gridDim.x); // lands under the rest of this block's work
+        // ---- dW2 += dy^T a over the 64 pixels: both operands by transpose reads (k = pixel = LDS row)
+#pragma unroll
+        for (int ks = 0; ks < P / 16; ++ks) {
+            const int rr = 16 * ks + 2 * hh + 4 * (gi >> 2), cc = 16 * gq2 + 4 * (gi & 3);
+            V8 bfr[NT], afr[OB];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bfr[nt] = ld_tr<V8>(dt + rr * PH + wave * CW + nt * 32 + cc, dt + (rr + 1) * PH + wave * CW + nt * 32 + cc);
+#pragma unroll
+            for (int ob = 0; ob < OB; ++ob) afr[ob] = ld_tr<V8>(yt + rr * PX + ob * 32 + cc, yt + (rr + 1) * PX + ob * 32 + cc);
+#pragma unroll
+            for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc2[ob][nt] = TcHalf<H>::mfma(afr[ob], bfr[nt], acc2[ob][nt]);
+        }
+        // ---- LayerNorm backward: gd = rstd * (gg - S1 / 4C - xhat * S2 / 4C), over a in LDS (this wave's columns only)
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+            const int px = pb * 32 + l31;
+            bf16_t* rowp = dt + krow(px) * PH;
+            const float2 st = fst[px];
+            float S1 = 0.f, S2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { const float2 t = psum[w * P + px]; S1 += t.x; S2 += t.y; }
+            const float k1 = S1 * (1.0f / (float)C4), k2 = S2 * (1.0f / (float)C4);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int ch0 = wave * CW + nt * 32 + 8 * gq + 4 * hh;
+                    float xv[4], o[4];
+                    unpack2<H>(dk[pb][nt][gq].x, xv[0], xv[1]); unpack2<H>(dk[pb][nt][gq].y, xv[2], xv[3]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float xh = (xv[e] - st.x) * st.y;
+                        o[e] = st.y * (acc[pb][nt][4 * gq + e] - k1 - xh * k2);
+                    }
+                    *reinterpret_cast<uint2*>(rowp + ch0) = make_uint2(pack2<H>(o[0], o[1]), pack2<H>(o[2], o[3]));
+                }
+        }
+        __syncthreads();
+        // ---- gd leaves as whole pixel rows
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int s = tid + i * NTH, px = s / HC, cg = s - px * HC;
+            if (r0 + px < M) *reinterpret_cast<uint4*>(GD + (r0 + px) * C4 + cg * 8) = *reinterpret_cast<const uint4*>(dt + krow(px) * PH + cg * 8);
+        }
+        __syncthreads();
+    }
+    // ---- this workgroup's partial sums
+    float* PB = p.part + ((long long)g * gridDim.x + blockIdx.x) * PT::n;
+#pragma unroll
+    for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh, ch = wave * CW + nt * 32 + l31;
+                PB[PT::oW2 + o * C4 + ch] = acc2[ob][nt][r];
+            }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float a = dgam[nt][r], b = dbet[nt][r];
+#pragma unroll
+            for (int m = 1; m < 32; m <<= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
+            if (l31 == 0) {
+                const int ch = wave * CW + nt * 32 + 8 * (r >> 2) + 4 * hh + (r & 3);
+                PB[PT::oG + ch] = a; PB[PT::oBt + ch] = b;
+            }
+        }
+    float* fold = reinterpret_cast<float*>(smem);                   // [NTH][8] (the tiles are dead)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) fold[tid * 8 + e] = b2acc[e];
+    __syncthreads();
+    if (tid < C) {
+        const int cg = tid >> 3, e = tid & 7;
+        float s = 0.f;
+        for (int k = 0; k < NTH / XC; ++k) s += fold[(k * XC + cg) * 8 + e];
+        PB[PT::oB2 + tid] = s;
+    }
+}
+
+// --------------------------------------------------------------------------------------------------------------------- launch 2
+template <int C> struct DwCfg {
+    static constexpr int C4 = 4 * C, NW = 8, NTH = 512, CH = 128, NCH = C4 / CH, KK1 = C / 16, KKC = CH / 16, NB = C / 32, XC = C / 8, GC = CH / 8;
+    static constexpr int MPMAX = 144, IPMAX = 128, MT2MAX = IPMAX / 32, TWMAX = 16, THMAX = 8;
+    static constexpr int PX = C + 8, PG = CH + 8, PO = C + 4;
+    static constexpr int NXR = (MPMAX * XC + NTH - 1) / NTH, NGR = (MPMAX * GC + NTH - 1) / NTH;
+    static constexpr size_t o_xs = 0, o_gs = o_xs + (size_t)MPMAX * PX * 2, o_hs = o_gs + (size_t)MPMAX * PG * 2, o_w1 = o_hs + (size_t)(MPMAX + 1) * PG * 2,
+                            o_tap = o_w1 + (size_t)C4 * PX * 2, o_b1 = o_tap + (size_t)9 * C4 * 4, o_acc = o_b1 + (size_t)C4 * 4, smem = o_acc + (size_t)11 * C4 * 4;
+    static_assert(MT2MAX * NB <= NW && (CH / 32) * NB <= NW, "one MFMA block per wave");
+    static_assert((size_t)IPMAX * PO * 4 <= (size_t)MPMAX * PG * 2, "the fp32 dx stage aliases the gd tile");
+    static_assert(smem <= 160 * 1024, "LDS");
+};
+
+template <typename H, int C>
+__global__ __launch_bounds__(512, 2) void ffn_bwd_dw_kernel(const FfnBwdDev p) {
+    using K = DwCfg<C>;
+    using PT = BwdPart<C>;
+    using V8 = typename TcHalf<H>::v8;
+    constexpr int C4 = K::C4, CH = K::CH, NCH = K::NCH, KK1 = K::KK1, KKC = K::KKC, NB = K::NB, XC = K::XC, GC = K::GC, PX = K::PX, PG = K::PG, PO = K::PO;
+    constexpr int NTH = K::NTH, MPMAX = K::MPMAX, NXR = K::NXR, NGR = K::NGR, TWMAX = K::TWMAX;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* xs = reinterpret_cast<bf16_t*>(smem + K::o_xs);               // [MPMAX][PX]      x on the haloed tile
+    bf16_t* gs = reinterpret_cast<bf16_t*>(smem + K::o_gs);               // [MPMAX][PG]      gd, this chunk's channels, haloed tile
+    bf16_t* hs = reinterpret_cast<bf16_t*>(smem + K::o_hs);               // [MPMAX + 1][PG]  h (haloed), then dh (inner pixels); last row = zeros
+    bf16_t* w1s = reinterpret_cast<bf16_t*>(smem + K::o_w1);              // [C4][PX]         W1, rows k-permuted inside each 16-row group
+    float* taps = reinterpret_cast<float*>(smem + K::o_tap);              // [9][C4]
+    float* b1s = reinterpret_cast<float*>(smem + K::o_b1);                // [C4]
+    float* lacc = reinterpret_cast<float*>(smem + K::o_acc);              // [11][C4]: dwd taps 0..8, dbd, db1
+    float* stg = reinterpret_cast<float*>(smem + K::o_gs);                // fp32 dx stage over the gd tile
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int gi = lane & 15, gq2 = (lane >> 4) & 1;
+    const int g = blockIdx.y, M = p.M;
+    const long long wo = (long long)g * p.wstride, imgpix = (long long)p.H * p.W;
+    const H* X = reinterpret_cast<const H*>(p.x) + (long long)g * M * p.ldx;
+    const H* GD = reinterpret_cast<const H*>(p.gd) + (long long)g * M * C4;
+    H* DX = reinterpret_cast<H*>(p.dx) + (long long)g * M * p.lddx;
+    const H* W1 = reinterpret_cast<const H*>(p.w1) + wo;
+    const int TH = p.TH, TW = p.TW, HW2 = p.HW2, HP = p.HP, MT = p.MT, IP = p.IP, Himg = p.H, Wimg = p.W;
+
+    {
+        const H* wd = reinterpret_cast<const H*>(p.wd) + wo;
+        const H* b1 = reinterpret_cast<const H*>(p.b1) + wo;
+        for (int i = tid; i < 9 * C4; i += NTH) { const int ch = i / 9, t = i - ch * 9; taps[t * C4 + ch] = ldf<H>(wd + i); }
+        for (int i = tid; i < C4; i += NTH) b1s[i] = ldf<H>(b1 + i);
+        for (int i = tid; i < 11 * C4; i += NTH) lacc[i] = 0.f;
+        for (int i = tid; i < PG; i += NTH) hs[MPMAX * PG + i] = 0;
+        for (int s = tid; s < C4 * XC; s += NTH) {                 // W1 stays in LDS for the whole launch
+            const int r = s / XC, cg = s - r * XC;
+            *reinterpret_cast<uint4*>(w1s + krow(r) * PX + cg * 8) = *reinterpret_cast<const uint4*>(W1 + (long long)r * C + cg * 8);
+        }
+    }
+
+    auto tile_org = [&](int tidx, int& b, int& oh0, int& ow0) __attribute__((always_inline)) {
+        const int tx = tidx % p.tilesW, ty = (tidx / p.tilesW) % p.tilesH;
+        b = tidx / (p.tilesW * p.tilesH); oh0 = ty * TH; ow0 = tx * TW;
+    };
+    auto halo_in = [&](int pix, int oh0, int ow0, int& ih, int& iw) __attribute__((always_inline)) {
+        const int hy = pix / HW2, hx = pix - hy * HW2;
+        ih = oh0 - 1 + hy; iw = ow0 - 1 + hx;
+        return pix < HP && (unsigned)ih < (unsigned)Himg && (unsigned)iw < (unsigned)Wimg;
+    };
+    uint4 xr[NXR], gr[NGR];
+    auto xfetch = [&](int tidx) __attribute__((always_inline)) {
+        int b, oh0, ow0;
+        tile_org(tidx, b, oh0, ow0);
+        const H* xb = X + (long long)b * imgpix * p.ldx;
+#pragma unroll
+        for (int i = 0; i < NXR; ++i) {
+            const int s = tid + i * NTH, pix = s / XC, cg = s - pix * XC;
+            int ih, iw;
+            const bool ok = halo_in(pix, oh0, ow0, ih, iw);
+            xr[i] = *reinterpret_cast<const uint4*>(xb + (ok ? (long long)(ih * Wimg + iw) * p.ldx + cg * 8 : 0));
+        }
+    };
+    auto xput = [&](int tidx) __attribute__((always_inline)) {
+        int b, oh0, ow0;
+        tile_org(tidx, b, oh0, ow0);
+#pragma unroll
+        for (int i = 0; i < NXR; ++i) {
+            const int s = tid + i * NTH, pix = s / XC, cg = s - pix * XC;
+            int ih, iw;
+            const bool ok = halo_in(pix, oh0, ow0, ih, iw);
+            if (pix < HP) *reinterpret_cast<uint4*>(xs + pix * PX + cg * 8) = ok ? xr[i] : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto gfetch = [&](int tidx, int c) __attribute__((always_inline)) {
+        int b, oh0, ow0;
+        tile_org(tidx, b, oh0, ow0);
+        const H* gb = GD + (long long)b * imgpix * C4 + c * CH;
+#pragma unroll
+        for (int i = 0; i < NGR; ++i) {
+            const int s = tid + i * NTH, pix = s / GC, cg = s - pix * GC;
+            int ih, iw;
+            const bool ok = halo_in(pix, oh0, ow0, ih, iw);
+            gr[i] = *reinterpret_cast<const uint4*>(gb + (ok ? (long long)(ih * Wimg + iw) * C4 + cg * 8 : 0));
+        }
+    };
+    auto gput = [&](int tidx) __attribute__((always_inline)) {
+        int b, oh0, ow0;
+        tile_org(tidx, b, oh0, ow0);
+#pragma unroll
+        for (int i = 0; i < NGR; ++i) {
+            const int s = tid + i * NTH, pix = s / GC, cg = s - pix * GC;
+            int ih, iw;
+            const bool ok = halo_in(pix, oh0, ow0, ih, iw);
+            if (pix < HP) *reinterpret_cast<uint4*>(gs + pix * PG + cg * 8) = ok ? gr[i] : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    // halo-tile row of inner pixel q (row-major over the TH x TW inner pixels)
+    auto hrow = [&](int q) __attribute__((always_inline)) { const int y = q / TW; return (y + 1) * HW2 + (q - y * TW) + 1; };
+
+    f32x16 accw[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accw[c][r] = 0.f;
+    const int cb = wave & 3, nb = wave >> 2;                        // MFMA block of this wave: (hidden block | pixel block, channel block)
+
+    int tidx = blockIdx.x;
+    if (tidx < p.ntiles) { xfetch(tidx); gfetch(tidx, 0); }
+    __syncthreads();                                               // parameters in LDS
+    for (; tidx < p.ntiles; tidx += gridDim.x) {
+        int b, oh0, ow0;
+        tile_org(tidx, b, oh0, ow0);
+        const bool more = tidx + (int)gridDim.x < p.ntiles;
+        xput(tidx);
+        f32x16 accx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accx[r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            gput(tidx);
+            __syncthreads();
+            if (c + 1 < NCH) gfetch(tidx, c + 1);
+            else if (more) { xfetch(tidx + gridDim.x); gfetch(tidx + gridDim.x, 0); }
+            // ---- h = fc1(x) on the haloed tile for this chunk's channels (zero outside the image: the convolution's padding)
+            {
+                V8 af[KK1];
+#pragma unroll
+                for (int kk = 0; kk < KK1; ++kk) af[kk] = *reinterpret_cast<const V8*>(w1s + krow(c * CH + cb * 32 + l31) * PX + kk * 16 + 8 * hh);
+                for (int mi = nb; mi < MT; mi += 2) {
+                    f32x16 acc;
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const float4 bv = *reinterpret_cast<const float4*>(b1s + c * CH + cb * 32 + 8 * gq + 4 * hh);
+                        acc[4 * gq] = bv.x; acc[4 * gq + 1] = bv.y; acc[4 * gq + 2] = bv.z; acc[4 * gq + 3] = bv.w;
+                    }
+                    const int pp = mi * 32 + l31;
+                    const bf16_t* xp = xs + (pp < HP ? pp : 0) * PX + 8 * hh;      // (rows beyond the haloed tile: columns nobody keeps)
+#pragma unroll
+                    for (int kk = 0; kk < KK1; ++kk) acc = TcHalf<H>::mfma(af[kk], *reinterpret_cast<const V8*>(xp + kk * 16), acc);
+                    int ih, iw;
+                    const bool ok = halo_in(pp, oh0, ow0, ih, iw);
+                    if (pp < HP) {
+#pragma unroll
+                        for (int gq = 0; gq < 4; ++gq) {
+                            uint2 v = make_uint2(pack2<H>(acc[4 * gq], acc[4 * gq + 1]), pack2<H>(acc[4 * gq + 2], acc[4 * gq + 3]));
+                            if (!ok) v = make_uint2(0u, 0u);
+                            *reinterpret_cast<uint2*>(hs + pp * PG + cb * 32 + 8 * gq + 4 * hh) = v;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- depthwise stage: wave = inner row, lane = channel pair.  dwd[t] += gd * h(shifted), dbd += gd,
+            //      dh = gd + sum_t w[t] gd(shifted the other way), db1 += dh
+            unsigned dhr[TWMAX];
+            {
+                const int y = wave, chl = 2 * lane, chg = c * CH + chl;
+                const bool active = y < TH;
+                float2 tp[9];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) tp[t] = *reinterpret_cast<const float2*>(taps + t * C4 + chg);
+                float2 aw[9], abd = make_float2(0.f, 0.f), ab1 = make_float2(0.f, 0.f);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) aw[t] = make_float2(0.f, 0.f);
+                if (active) {
+                    float2 gw[3][3], hw[3][3];
+                    const bool rowin = oh0 + y < Himg;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int cx = 1; cx < 3; ++cx) {
+                            const int o = ((y + r) * HW2 + cx - 1) * PG + chl;
+                            unpack2<H>(*reinterpret_cast<const unsigned*>(gs + o), gw[r][cx].x, gw[r][cx].y);
+                            unpack2<H>(*reinterpret_cast<const unsigned*>(hs + o), hw[r][cx].x, hw[r][cx].y);
+                        }
+#pragma unroll
+                    for (int x = 0; x < TWMAX; ++x) {
+                        if (x >= TW) break;
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) {
+                            gw[r][0] = gw[r][1]; gw[r][1] = gw[r][2]; hw[r][0] = hw[r][1]; hw[r][1] = hw[r][2];
+                            const int o = ((y + r) * HW2 + x + 2) * PG + chl;
+                            unpack2<H>(*reinterpret_cast<const unsigned*>(gs + o), gw[r][2].x, gw[r][2].y);
+                            unpack2<H>(*reinterpret_cast<const unsigned*>(hs + o), hw[r][2].x, hw[r][2].y);
+                        }
+                        const float2 gc = gw[1][1];                 // zero for a pixel outside the image
+                        float2 dv = gc;
+#pragma unroll
+                        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                            for (int kx = 0; kx < 3; ++kx) {
+                                aw[ky * 3 + kx].x += gc.x * hw[ky][kx].x; aw[ky * 3 + kx].y += gc.y * hw[ky][kx].y;
+                                dv.x += tp[ky * 3 + kx].x * gw[2 - ky][2 - kx].x; dv.y += tp[ky * 3 + kx].y * gw[2 - ky][2 - kx].y;
+                            }
+                        abd.x += gc.x; abd.y += gc.y;
+                        if (!(rowin && ow0 + x < Wimg)) dv = make_float2(0.f, 0.f);
+                        ab1.x += dv.x; ab1.y += dv.y;
+                        dhr[x] = pack2<H>(dv.x, dv.y);
+                    }
+                }
+                __syncthreads();                                    // every read of h is done: dh takes the inner pixels' slots
+                if (active) {
+#pragma unroll
+                    for (int x = 0; x < TWMAX; ++x)
+                        if (x < TW) *reinterpret_cast<unsigned*>(hs + ((y + 1) * HW2 + x + 1) * PG + chl) = dhr[x];
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) { atomicAdd(lacc + t * C4 + chg, aw[t].x); atomicAdd(lacc + t * C4 + chg + 1, aw[t].y); }
+                    atomicAdd(lacc + 9 * C4 + chg, abd.x); atomicAdd(lacc + 9 * C4 + chg + 1, abd.y);
+                    atomicAdd(lacc + 10 * C4 + chg, ab1.x); atomicAdd(lacc + 10 * C4 + chg + 1, ab1.y);
+                }
+            }
+            __syncthreads();
+            // ---- dx^T += W1^T dh^T  (rows = input channel, columns = inner pixel);  dW1 += dh^T x  (rows = hidden channel, columns = input channel)
+            if (cb < p.MT2) {
+                const int q = cb * 32 + l31;
+                const bf16_t* dp = hs + (q < IP ? hrow(q) : 0) * PG + 8 * hh;
+#pragma unroll
+                for (int kk = 0; kk < KKC; ++kk) {
+                    const bf16_t* wp = w1s + (c * CH + 16 * kk + 2 * hh + 4 * (gi >> 2)) * PX + nb * 32 + 16 * gq2 + 4 * (gi & 3);
+                    accx = TcHalf<H>::mfma(ld_tr<V8>(wp, wp + PX), *reinterpret_cast<const V8*>(dp + kk * 16), accx);
+                }
+            }
+            for (int ks = 0; ks < p.KS; ++ks) {
+                const int qlo = 16 * ks + 8 * hh + (gi >> 2), qhi = qlo + 4, cc = 16 * gq2 + 4 * (gi & 3);
+                const int rlo = qlo < IP ? hrow(qlo) : -1, rhi = qhi < IP ? hrow(qhi) : -1;
+                const V8 av = ld_tr<V8>(hs + (rlo < 0 ? MPMAX : rlo) * PG + cb * 32 + cc, hs + (rhi < 0 ? MPMAX : rhi) * PG + cb * 32 + cc);
+                const V8 bv = ld_tr<V8>(xs + (rlo < 0 ? 0 : rlo) * PX + nb * 32 + cc, xs + (rhi < 0 ? 0 : rhi) * PX + nb * 32 + cc);
+                accw[c] = TcHalf<H>::mfma(av, bv, accw[c]);
+            }
+            __syncthreads();                                        // the tiles of this chunk are dead
+        }
+        // ---- dx leaves as whole pixel rows (through LDS, over the gd tile)
+        if (cb < p.MT2) {
+            float* sp = stg + (cb * 32 + l31) * PO + nb * 32 + 4 * hh;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+                *reinterpret_cast<float4*>(sp + 8 * gq) = make_float4(accx[4 * gq], accx[4 * gq + 1], accx[4 * gq + 2], accx[4 * gq + 3]);
+        }
+        __syncthreads();
+        {
+            H* dxb = DX + (long long)b * imgpix * p.lddx;
+            for (int s = tid; s < IP * XC; s += NTH) {
+                const int q = s / XC, cg = s - q * XC, y = q / TW, x = q - y * TW;
+                if (oh0 + y >= Himg || ow0 + x >= Wimg) continue;
+                const float4 v0 = *reinterpret_cast<const float4*>(stg + q * PO + cg * 8), v1 = *reinterpret_cast<const float4*>(stg + q * PO + cg * 8 + 4);
+                float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                H* dst = dxb + (long long)((oh0 + y) * Wimg + ow0 + x) * p.lddx + cg * 8;
+                if (p.acc_dx) {
+                    float o[8];
+                    up8<H>(*reinterpret_cast<const uint4*>(dst), o);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += o[e];
+                }
+                *reinterpret_cast<uint4*>(dst) = pk8<H>(v);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- this workgroup's partial sums
+    float* PB = p.part + ((long long)g * gridDim.x + blockIdx.x) * PT::n;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ch = c * CH + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            PB[PT::oW1 + ch * C + nb * 32 + l31] = accw[c][r];
+        }
+    for (int i = tid; i < 11 * C4; i += NTH) {
+        const int t = i / C4, ch = i - t * C4;
+        const float v = lacc[i];
+        if (t < 9) PB[PT::oWd + ch * 9 + t] = v;
+        else if (t == 9) PB[PT::oBd + ch] = v;
+        else PB[PT::oB1 + ch] = v;
+    }
+}
+
+// --------------------------------------------------------------------------------------------------------------------- launch 3
+struct RedDev { const float* part; float* dst[8]; int off[9]; int nwg, nper; long long wstride; };
+
+// grid (nper / 64, groups), 256 threads = 16 float4 columns x 16 slices of the workgroup list
+__global__ __launch_bounds__(256) void ffn_bwd_reduce_kernel(const RedDev p) {
+    __shared__ float4 sh[16][17];
+    const int e = threadIdx.x & 15, sl = threadIdx.x >> 4, g = blockIdx.y;
+    const int q = blockIdx.x * 16 + e;                              // float4 index within the partial
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q * 4 < p.nper) {
+        const float* base = p.part + (long long)g * p.nwg * p.nper + (long long)q * 4;
+        for (int w = sl; w < p.nwg; w += 16) {
+            const float4 v = *reinterpret_cast<const float4*>(base + (long long)w * p.nper);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    sh[sl][e] = s;
+    __syncthreads();
+    if (sl == 0 && q * 4 < p.nper) {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) { const float4 v = sh[k][e]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+        const int idx = q * 4;
+        int seg = 0;
+#pragma unroll
+        for (int k = 1; k < 8; ++k) seg += idx >= p.off[k];
+        float* d = p.dst[seg];
+        if (d) {
+            d += (long long)g * p.wstride + (idx - p.off[seg]);
+            d[0] += s.x; d[1] += s.y; d[2] += s.z; d[3] += s.w;
+        }
+    }
+}
+
+int bwd_num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    }
+    return n;
+}
+
+// pixel tile of launch 2: smallest estimated makespan over the CUs (cycles per tile = fixed + haloed pixels of fc1 / fills + inner pixels)
+template <int C>
+void dw_pick_tile(int H, int W, long long images, int gxmax, int fth, int ftw, int& TH, int& TW) {
+    using K = DwCfg<C>;
+    static const int eth = getenv("TC_FFN_BWD_TH") ? atoi(getenv("TC_FFN_BWD_TH")) : 0, etw = getenv("TC_FFN_BWD_TW") ? atoi(getenv("TC_FFN_BWD_TW")) : 0;
+    if (!(fth && ftw)) { fth = eth; ftw = etw; }
+    double best = 1e30;
+    TH = 1; TW = 1;
+    for (int th = 1; th <= K::THMAX && th <= H; ++th)
+        for (int tw = 1; tw <= K::TWMAX && tw <= W; ++tw) {
+            const int hp = (th + 2) * (tw + 2), ip = th * tw;
+            if (hp > K::MPMAX || ip > K::IPMAX) continue;
+            if (fth && ftw && (th != fth || tw != ftw)) continue;
+            const double tiles = (double)images * ((H + th - 1) / th) * ((W + tw - 1) / tw);
+            const double rounds = (double)(long long)((tiles + gxmax - 1) / gxmax);
+            const double cyc = 6000.0 + ((hp + 31) / 32) * 32 * 40.0 + tw * 450.0 + ((ip + 31) / 32) * 32 * 12.0;
+            const double cost = rounds * cyc;
+            if (cost < best) { best = cost; TH = th; TW = tw; }
+        }
+}
+
+bool bwd_args_ok(const TcFfnBwd* f) {
+    if (!f || !f->x || !f->dy || !f->d || !f->stat || !f->w1 || !f->b1 || !f->wd || !f->gamma || !f->beta || !f->w2 || !f->dx || !f->gd || !f->part) return false;
+    if (!f->dw1 || !f->db1 || !f->dwd || !f->dbd || !f->dgamma || !f->dbeta || !f->dw2 || !f->db2) return false;
+    if (f->B < 1 || f->H < 1 || f->W < 1 || f->groups < 1 || f->C != 64) return false;
+    auto al = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    if (!al(f->x) || !al(f->dy) || !al(f->d) || !al(f->dx) || !al(f->gd) || !al(f->w1) || !al(f->part) || ((uintptr_t)f->stat & 7)) return false;
+    if ((f->ldx & 7) || (f->lddy & 7) || (f->lddx & 7) || (f->sdy & 7) || (f->wstride & 7)) return false;
+    const long long mx = f->ldx > f->lddx ? f->ldx : f->lddx;
+    return (long long)f->H * f->W * (mx > 4 * f->C ? mx : 4 * f->C) < 0x7fffffffLL && (long long)f->B * f->H * f->W < 0x7fffffffLL;
+}
+
+template <typename H, int C>
+int ffn_bwd_launch(const TcFfnBwd* f, hipStream_t s) {
+    using PT = BwdPart<C>;
+    using KL = LnCfg<C>;
+    using KD = DwCfg<C>;
+    const int ncu = bwd_num_cus();
+    int gx = ncu / f->groups;                                       // persistent workgroups: never more than the CUs hold at once
+    if (gx < 1) gx = 1;
+    if ((long long)f->groups * gx * PT::n > f->part_floats) return TC_ERR_ARG;
+    FfnBwdDev p;
+    p.x = f->x; p.dy = f->dy; p.d = f->d; p.stat = f->stat; p.w1 = f->w1; p.b1 = f->b1; p.wd = f->wd; p.gamma = f->gamma; p.beta = f->beta; p.w2 = f->w2;
+    p.dx = f->dx; p.gd = f->gd; p.part = f->part; p.sdy = f->sdy; p.wstride = f->wstride; p.ldx = f->ldx; p.lddy = f->lddy; p.lddx = f->lddx;
+    p.B = f->B; p.H = f->H; p.W = f->W; p.M = f->B * f->H * f->W; p.acc_dx = f->acc_dx;
+    p.nblk = (p.M + KL::P - 1) / KL::P;
+    dw_pick_tile<C>(f->H, f->W, f->B, gx, f->tile_h, f->tile_w, p.TH, p.TW);
+    if ((p.TH + 2) * (p.TW + 2) > KD::MPMAX || p.TH * p.TW > KD::IPMAX || p.TH > KD::THMAX || p.TW > KD::TWMAX) return TC_ERR_ARG;
+    p.tilesH = (f->H + p.TH - 1) / p.TH; p.tilesW = (f->W + p.TW - 1) / p.TW;
+    p.HW2 = p.TW + 2; p.HP = (p.TH + 2) * p.HW2; p.MT = (p.HP + 31) / 32; p.IP = p.TH * p.TW; p.MT2 = (p.IP + 31) / 32; p.KS = (p.IP + 15) / 16;
+    p.ntiles = f->B * p.tilesH * p.tilesW;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)ffn_bwd_ln_kernel<H, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KL::smem) != hipSuccess) return TC_ERR_LAUNCH;
+        if (hipFuncSetAttribute((const void*)ffn_bwd_dw_kernel<H, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KD::smem) != hipSuccess) return TC_ERR_LAUNCH;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((ffn_bwd_ln_kernel<H, C>), dim3(gx, f->groups), dim3(KL::NTH), KL::smem, s, p);
+    if (tc_launch_status() != TC_OK) return TC_ERR_LAUNCH;
+    hipLaunchKernelGGL((ffn_bwd_dw_kernel<H, C>), dim3(gx, f->groups), dim3(KD::NTH), KD::smem, s, p);
+    if (tc_launch_status() != TC_OK) return TC_ERR_LAUNCH;
+    RedDev r;
+    r.part = f->part; r.nwg = gx; r.nper = PT::n; r.wstride = f->wstride;
+    float* dsts[8] = {f->dw2, f->db2, f->dgamma, f->dbeta, f->dw1, f->db1, f->dwd, f->dbd};
+    const int offs[9] = {PT::oW2, PT::oB2, PT::oG, PT::oBt, PT::oW1, PT::oB1, PT::oWd, PT::oBd, PT::n};
+    for (int i = 0; i < 8; ++i) r.dst[i] = dsts[i];
+    for (int i = 0; i < 9; ++i) r.off[i] = offs[i];
+    hipLaunchKernelGGL(ffn_bwd_reduce_kernel, dim3((PT::n / 4 + 15) / 16, f->groups), dim3(256), 0, s, r);
+    return tc_launch_status();
+}
+
+}  // namespace
+
+extern "C" int tc_ffn_fused_bwd_supported(int C, int dtype) { return C == 64 && (dtype == TC_BF16 || dtype == TC_F16); }
+
+extern "C" long long tc_ffn_fused_bwd_scratch_floats(int C, int groups) {
+    if (C != 64 || groups < 1) return 0;
+    const int ncu = bwd_num_cus();
+    const int gx = ncu / groups < 1 ? 1 : ncu / groups;
+    return (long long)groups * gx * BwdPart<64>::n;
+}
+
+extern "C" int tc_ffn_fused_bwd(const TcFfnBwd* f, int dtype, void* stream) {
+    if (!bwd_args_ok(f) || !tc_ffn_fused_bwd_supported(f->C, dtype)) return TC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    return dtype == TC_BF16 ? ffn_bwd_launch<bf16_t, 64>(f, s) : ffn_bwd_launch<f16_t, 64>(f, s);
+}

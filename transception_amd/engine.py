@@ -18,7 +18,7 @@ from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
 
-from ._lib import (ATTN_DKV_SPLITS, EW_COPY, EW_DEINTERLEAVE, EW_PATCHIFY, TcEwSeg, TcFfnFused, ACT_COORD, ACT_GELU, ACT_HSWISH, ACT_NONE, ACT_SIGMOID, FFN_EP, FFN_LN_A, FFN_LN_B, TC_BF16, TC_F16, TC_F32, TcDwSeg, TcFfnSeg,
+from ._lib import (ATTN_DKV_SPLITS, EW_COPY, EW_DEINTERLEAVE, EW_PATCHIFY, TcEwSeg, TcFfnBwd, TcFfnFused, ACT_COORD, ACT_GELU, ACT_HSWISH, ACT_NONE, ACT_SIGMOID, FFN_EP, FFN_LN_A, FFN_LN_B, TC_BF16, TC_F16, TC_F32, TcDwSeg, TcFfnSeg,
                    TcGemm, lib)
 
 _DT = {torch.float32: TC_F32, torch.bfloat16: TC_BF16, torch.float16: TC_F16}
@@ -182,6 +182,8 @@ _SKIP_WGRAD = bool(os.environ.get("TC_DEBUG_SKIP_WGRAD"))
 _FFN_STORE_ACT = os.environ.get("TC_FFN_STORE_ACT", "1") != "0"   # MixFFN: keep GELU(LN(d)) from the forward pass (0: recompute it in dW2's loader)
 _FFN_LN_GEMM_MAXC = int(os.environ.get("TC_FFN_LN_GEMM_MAXC", "64"))  # widest fc2 output for which LayerNorm + GELU run in its A loader
 _FFN_TILED = os.environ.get("TC_FFN_TILED", "1") != "0"        # MixFFN forward as one spatially tiled kernel where the library supports the width (csrc/mixffn.hip)
+_FFN_TILED_BWD = os.environ.get("TC_FFN_TILED_BWD", "1") != "0"   # MixFFN backward on the chip (csrc/mixffn_bwd.hip) where the library supports the width
+_FFN_TILE_BWD = (0, 0)                                         # forced pixel tile of the tiled backward's second launch (tests)
 _FFN_TILE = (0, 0)                                             # forced pixel tile of the tiled MixFFN kernels (tests); (0, 0): the library's choice
 _POISON = bool(os.environ.get("TC_DEBUG_POISON"))         # fill every fresh buffer with NaN: finds reads of memory no kernel wrote
 
@@ -762,22 +764,26 @@ class Graph:
             # one spatially tiled kernel for the whole forward site (hidden maps in LDS) where the library has it: 16-bit storage, C = 64 / 128
             fz = (_FFN_TILED and self.dtype != torch.float32 and bool(L.tc_ffn_fused_supported(Cin, self.dt)) and x.ld % 8 == 0 and out.ld % 8 == 0
                   and (s_.get("residual") is None or s_["residual"].ld % 8 == 0) and gs % 8 == 0)
-            st.append(dict(fz=fz, lng=lng, so=Cin if side else M * out.ld, side=side, x=x, W1=W1, b1=b1, wd=wd, bd=bd, lg=lg, lb=lb, W2=W2, b2=b2, B=B, H=H, W=W, C4=C4, Cin=Cin, M=M, cn=cn,
+            # ... and its backward from d + the row statistics alone (h, a, gp, dh never exist in HBM)
+            fzb = (fz and _FFN_TILED_BWD and self.record and bool(L.tc_ffn_fused_bwd_supported(Cin, self.dt)) and x.requires_grad
+                   and all(q.grad is not None for q in (W1, b1, wd, bd, lg, lb, W2, b2)))
+            st.append(dict(fz=fz, fzb=fzb, lng=lng, so=Cin if side else M * out.ld, side=side, x=x, W1=W1, b1=b1, wd=wd, bd=bd, lg=lg, lb=lb, W2=W2, b2=b2, B=B, H=H, W=W, C4=C4, Cin=Cin, M=M, cn=cn,
                            nch=C4 // cn, nch2=(C4 + 63) // 64, res=s_.get("residual"), out=out,
-                           h=_empty((x.rows, C4), self.dtype, self.dev), d=_empty((x.rows, C4), self.dtype, self.dev),
-                           a=_empty((x.rows, C4), self.dtype, self.dev) if (_FFN_STORE_ACT or not lng or fz) else None,
+                           h=_empty((x.rows, C4), self.dtype, self.dev) if not fzb else None, d=_empty((x.rows, C4), self.dtype, self.dev),
+                           a=_empty((x.rows, C4), self.dtype, self.dev) if ((_FFN_STORE_ACT or not lng or fz) and not fzb) else None,
                            part=self.f32(x.rows * (C4 // cn) * 2) if not fz else None, stat=self.f32(x.rows * 2)))
         for t in st:
             if t["fz"]:
                 res, out = t["res"], t["out"]
                 f = TcFfnFused(_ptr(t["x"].data), _ptr(t["W1"].data), _ptr(t["b1"].data), _ptr(t["wd"].data), _ptr(t["bd"].data), _ptr(t["lg"].data),
                                _ptr(t["lb"].data), _ptr(t["W2"].data), _ptr(t["b2"].data), _ptr(res.data) if res is not None else None, _ptr(out.data),
-                               _ptr(t["h"]) if self.record else None, _ptr(t["d"]) if self.record else None, _ptr(t["a"]) if self.record else None,
+                               _ptr(t["h"]) if (self.record and t["h"] is not None) else None, _ptr(t["d"]) if self.record else None,
+                               _ptr(t["a"]) if (self.record and t["a"] is not None) else None,
                                _ptr(t["stat"]) if self.record else None,
                                t["M"] * res.ld if res is not None else 0, t["so"], gs, t["x"].ld, res.ld if res is not None else 0, out.ld,
                                t["Cin"], t["B"], t["H"], t["W"], Gn, 1e-5, *_FFN_TILE)
                 self.n_launch += 1
-                _timed("hbm:ffn_fused_fwd (MixFFN forward, one tiled kernel)", (2.0 * t["Cin"] + (t["Cin"] if res is not None else 0) + t["C4"]) * t["x"].rows * t["h"].element_size(),
+                _timed("hbm:ffn_fused_fwd (MixFFN forward, one tiled kernel)", (2.0 * t["Cin"] + (t["Cin"] if res is not None else 0) + t["C4"]) * t["x"].rows * t["d"].element_size(),
                        lambda f=f: L.tc_ffn_fused_fwd(C.byref(f), self.dt, self.stream))
         st_all, st = st, [t for t in st if not t["fz"]]
         nold = len(st)
@@ -822,13 +828,49 @@ class Graph:
                      nb1=Gn, sA=(t["M"] * t["C4"], 0), sB=(gs, 0), sC=(t["so"], 0), sR=(t["M"] * res.ld if res is not None else 0, 0), sbias=gs)
             fw.append(hook(g, t, FFN_LN_A) if t["lng"] else g)
         self._launch_gemms(fw)
-        st = st_all                                              # (the backward pass treats every site alike)
+
+        def bwd_tiled(t, dy):
+            """One site through csrc/mixffn_bwd.hip: three launches, gd the only hidden-width map in HBM."""
+            x = t["x"]
+            gx, acc = self.wgrad(x)
+            gd = _empty((x.rows, t["C4"]), self.dtype, self.dev)
+            nf = int(L.tc_ffn_fused_bwd_scratch_floats(t["Cin"], Gn))
+            part = self.f32(nf)
+            f = TcFfnBwd(_ptr(x.data), _ptr(dy), _ptr(t["d"]), _ptr(t["stat"]), _ptr(t["W1"].data), _ptr(t["b1"].data), _ptr(t["wd"].data),
+                         _ptr(t["lg"].data), _ptr(t["lb"].data), _ptr(t["W2"].data), _ptr(gx), _ptr(gd), _ptr(part), nf,
+                         _ptr(t["W1"].grad), _ptr(t["b1"].grad), _ptr(t["wd"].grad), _ptr(t["bd"].grad), _ptr(t["lg"].grad), _ptr(t["lb"].grad),
+                         _ptr(t["W2"].grad), _ptr(t["b2"].grad), t["so"], gs, x.ld, dy.stride(0), gx.stride(0), t["Cin"], t["B"], t["H"], t["W"], Gn,
+                         acc, 1e-5, *_FFN_TILE_BWD)
+            self.n_launch += 3
+            es = t["d"].element_size()
+            _timed("hbm:ffn_fused_bwd (MixFFN backward on the chip: LayerNorm/GELU backward + fc2 gradients, dw3x3/fc1 gradients, partial fold)",
+                   (3.0 * t["Cin"] + 3.0 * t["C4"]) * x.rows * es, lambda: L.tc_ffn_fused_bwd(C.byref(f), self.dt, self.stream))
 
         def bwd():
-            dys = [self.grad_of(t["out"]) for t in st]
-            if all(d is None for d in dys):
+            dys_all = [self.grad_of(t["out"]) for t in st_all]
+            if all(d is None for d in dys_all):
                 return
-            assert all(d is not None for d in dys)
+            assert all(d is not None for d in dys_all)
+            for t, dy in zip(st_all, dys_all):
+                if t["fzb"]:
+                    bwd_tiled(t, dy)
+            pairs = [(t, dy) for t, dy in zip(st_all, dys_all) if not t["fzb"]]
+            st, dys = [t for t, _ in pairs], [dy for _, dy in pairs]
+            n = len(st)
+            if n:
+                bwd_opbyop(st, dys, n)
+            copies = []                                     # the sites' residual gradients leave in one launch (<= 4 per tc_ew_multi)
+            for t, dy in zip(st_all, dys_all):
+                if t["res"] is not None:
+                    if t["side"]:
+                        copies.append(self._pass_grad_batched(t["res"], dy, Gn, t["M"], t["Cin"], t["so"], t["M"] * t["res"].ld, defer=True))
+                    else:
+                        copies.append(self.pass_grad(t["res"], dy, defer=True))
+            copies = [c for c in copies if c is not None]
+            for c0 in range(0, len(copies), 4):
+                self._ew_multi(copies[c0:c0 + 4])
+
+        def bwd_opbyop(st, dys, n):
             # fc2: gp = (dY W2) (.) GELU'(u) with the LayerNorm row sums, and dW2 = dY^T GELU(LN(d)) (+ db2)
             g1 = []
             for i, (t, dy) in enumerate(zip(st, dys)):
@@ -877,20 +919,11 @@ class Graph:
                                    sB=(t["M"] * x.ld, 0), sC=(gs, 0), rowsum=_ptr(t["b1"].grad) if t["b1"].grad is not None else None, srow=gs,
                                    use_ws=False))
             self._launch_gemms(g2)
-            copies = []                                     # the sites' residual gradients leave in one launch (<= 4 per tc_ew_multi)
-            for t, dy in zip(st, dys):
-                if t["res"] is not None:
-                    if t["side"]:
-                        copies.append(self._pass_grad_batched(t["res"], dy, Gn, t["M"], t["Cin"], t["so"], t["M"] * t["res"].ld, defer=True))
-                    else:
-                        copies.append(self.pass_grad(t["res"], dy, defer=True))
+            for t in st:
                 for k in ("gp", "part2", "dh"):
                     t.pop(k, None)
-            copies = [c for c in copies if c is not None]
-            for c0 in range(0, len(copies), 4):
-                self._ew_multi(copies[c0:c0 + 4])
         self._rec(bwd)
-        return [t["out"] for t in st]
+        return [t["out"] for t in st_all]
 
     def _pass_grad_batched(self, v: Var, src: torch.Tensor, nb: int, M: int, N: int, sb_src: int, sb_dst: Optional[int] = None,
                            defer: bool = False):
