@@ -30,8 +30,9 @@ template <int C> struct FfnCfg {
     static constexpr int MPMAX = C == 64 ? 160 : 96, IPMAX = C == 64 ? 128 : 64;    // halo / inner pixels of a tile
     static constexpr int MT2MAX = IPMAX / 32;
     static constexpr int NXR = (MPMAX * (C / 8) + NTH - 1) / NTH;                   // 16-byte x strips per thread
+    static constexpr bool W2LDS = C == 64;                                           // fc2's weights resident in LDS (33 KB at C = 64; 133 KB at C = 128: streamed from L2)
     static constexpr size_t smem = (size_t)MPMAX * PH * 2 + (size_t)MPMAX * PX * 2 + (size_t)10 * C4 * 4 + (size_t)3 * C4 * 4 +
-                                   (size_t)NW * IPMAX * 8 + (size_t)IPMAX * 8;
+                                   (size_t)NW * IPMAX * 8 + (size_t)IPMAX * 8 + (W2LDS ? (size_t)C * PH * 2 : 0);
     static_assert(NW == MT2MAX * NT2, "one fc2 block per wave");
     static_assert((size_t)IPMAX * PO * 4 <= (size_t)MPMAX * PH * 2, "the fp32 output stage aliases the hidden tile");
     static_assert(smem <= 160 * 1024, "LDS");
@@ -43,6 +44,18 @@ template <typename H> __device__ __forceinline__ void up8(const uint4& r, float*
 template <typename H> __device__ __forceinline__ uint4 pk8(const float* o) {
     return make_uint4(pack2<H>(o[0], o[1]), pack2<H>(o[2], o[3]), pack2<H>(o[4], o[5]), pack2<H>(o[6], o[7]));
 }
+
+#ifdef TC_FFNF_TIMING
+// phase stamps (experiment builds only, scripts/exp/ffnb_timing.py --fwd): thread 0 of the first 16 workgroups of weight group 0
+__device__ long long g_ffnf_dbg[16 * 16];
+#define FSTAMP(k) do { if (fs_) { const long long t_ = __builtin_readcyclecounter(); fs_[k] += t_ - ft_; ft_ = t_; } } while (0)
+#define FSTAMP_INIT() long long ft_ = __builtin_readcyclecounter(); \
+    long long* fs_ = (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 16) ? g_ffnf_dbg + blockIdx.x * 16 : nullptr; \
+    if (fs_) for (int k_ = 0; k_ < 16; ++k_) fs_[k_] = 0;
+#else
+#define FSTAMP(k)
+#define FSTAMP_INIT()
+#endif
 
 template <typename H, int C>
 __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p) {
@@ -57,10 +70,12 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p
     float* gbs = wtap + 10 * C4;                                           // gamma[C4], beta[C4], fc1 bias[C4]
     float2* pst = reinterpret_cast<float2*>(gbs + 3 * C4);                 // [8][IPMAX] per-wave (sum, squared deviations)
     float2* fst = pst + 8 * IPMAX;                                         // [IPMAX] mean, rstd
+    bf16_t* w2s = reinterpret_cast<bf16_t*>(fst + IPMAX);                  // [C][PH] fc2 weights (W2LDS)
     float* stg = reinterpret_cast<float*>(smem);                           // fp32 out stage over the (then dead) hidden tile
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     const int g = blockIdx.y;
+    FSTAMP_INIT();
     const long long wo = (long long)g * p.wstride, imgpix = (long long)p.H * p.W, grow = (long long)g * p.B * imgpix;
     const H* X = reinterpret_cast<const H*>(p.x) + grow * p.ldx;
     const H* W1 = reinterpret_cast<const H*>(p.w1) + wo;
@@ -81,6 +96,12 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p
         for (int i = tid; i < 9 * C4; i += NTH) { const int ch = i / 9, t = i - ch * 9; wtap[t * C4 + ch] = ldf<H>(wd + i); }
         const H* b1 = reinterpret_cast<const H*>(p.b1) + wo;
         for (int i = tid; i < C4; i += NTH) { wtap[9 * C4 + i] = ldf<H>(bd + i); gbs[i] = ldf<H>(gm + i); gbs[C4 + i] = ldf<H>(bt + i); gbs[2 * C4 + i] = ldf<H>(b1 + i); }
+    }
+    if constexpr (K::W2LDS) {
+        for (int i = tid; i < C * HC; i += NTH) {
+            const int o = i / HC, cg = i - o * HC;
+            *reinterpret_cast<uint4*>(w2s + o * PH + cg * 8) = *reinterpret_cast<const uint4*>(W2 + (long long)o * C4 + cg * 8);
+        }
     }
     // fc1 weights of this wave's channels: MFMA operand fragments, resident for the whole launch
     V8 wf1[NT1][KK1];
@@ -137,6 +158,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p
     int tidx = blockIdx.x;
     if (tidx < p.ntiles) { xfetch(tidx); xput(tidx); }
     __syncthreads();                                             // parameters and the first x tile are in LDS
+    FSTAMP(0);
     for (; tidx < p.ntiles; tidx += gridDim.x) {
         int b, oh0, ow0;
         tile_org(tidx, b, oh0, ow0);
@@ -174,63 +196,91 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p
                     if (HO && inner) *reinterpret_cast<uint2*>(HO + (ibase + (long long)ih * Wimg + iw) * C4 + col) = v;
                 }
         }
+        FSTAMP(1);
         // ---- d = dw3x3(h) + bias + h on the inner pixels, in place: the result of pixel (y, x) goes to halo slot (y, x), which no
         // later pixel of the row-major walk reads (a wave's LDS accesses execute in order; every load of a round precedes its stores)
         {
+            // item = (inner row y, pixel pair x0 / x0 + 1, 8-channel group) of this wave's channels, 64 items per round, all rounds in
+            // registers at once: a filter row's taps are read from LDS once per tile (not once per item), and every load of the walk
+            // precedes its first store
+            constexpr int NRD = 4;
             const int sg = lane % SG, chw = wave * CW + sg * 8, RW = (TW + 1) >> 1, nitems = TH * RW * SG;
-            for (int it0 = 0; it0 < nitems; it0 += 64) {
-                const int it = it0 + lane;
-                const bool live = it < nitems;
-                const int run = live ? it / SG : 0, y = run / RW, x0 = (run - y * RW) * 2;
-                float o[2][8];
-                {
-                    const float4 ba = *reinterpret_cast<const float4*>(wtap + 9 * C4 + chw), bb = *reinterpret_cast<const float4*>(wtap + 9 * C4 + chw + 4);
+            int yq[NRD], xq[NRD];
+            tc_f32x2 o[NRD][2][4];                               // packed fp32 pairs: two channels per issue slot
+            auto up8p = [&](const uint4& r, tc_f32x2* v) __attribute__((always_inline)) {
+                float a, b;
+                unpack2<H>(r.x, a, b); v[0] = tc_f32x2{a, b}; unpack2<H>(r.y, a, b); v[1] = tc_f32x2{a, b};
+                unpack2<H>(r.z, a, b); v[2] = tc_f32x2{a, b}; unpack2<H>(r.w, a, b); v[3] = tc_f32x2{a, b};
+            };
+            {
+                const float4 ba = *reinterpret_cast<const float4*>(wtap + 9 * C4 + chw), bb = *reinterpret_cast<const float4*>(wtap + 9 * C4 + chw + 4);
 #pragma unroll
-                    for (int r = 0; r < 2; ++r) { o[r][0] = ba.x; o[r][1] = ba.y; o[r][2] = ba.z; o[r][3] = ba.w; o[r][4] = bb.x; o[r][5] = bb.y; o[r][6] = bb.z; o[r][7] = bb.w; }
+                for (int q = 0; q < NRD; ++q) {
+                    const int it = q * 64 + lane, run = it < nitems ? it / SG : 0;
+                    yq[q] = run / RW; xq[q] = (run - yq[q] * RW) * 2;
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) { o[q][r][0] = tc_f32x2{ba.x, ba.y}; o[q][r][1] = tc_f32x2{ba.z, ba.w}; o[q][r][2] = tc_f32x2{bb.x, bb.y}; o[q][r][3] = tc_f32x2{bb.z, bb.w}; }
+                }
+            }
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                tc_f32x2 tw[3][4];
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const float* tp = wtap + (dy * 3 + dx) * C4 + chw;
+                    const float4 ta = *reinterpret_cast<const float4*>(tp), tb = *reinterpret_cast<const float4*>(tp + 4);
+                    tw[dx][0] = tc_f32x2{ta.x, ta.y}; tw[dx][1] = tc_f32x2{ta.z, ta.w}; tw[dx][2] = tc_f32x2{tb.x, tb.y}; tw[dx][3] = tc_f32x2{tb.z, tb.w};
                 }
 #pragma unroll
-                for (int dy = 0; dy < 3; ++dy) {
-                    float in[4][8];
+                for (int q = 0; q < NRD; ++q) {
+                    if (q * 64 >= nitems) break;
+                    tc_f32x2 in[4][4];
 #pragma unroll
-                    for (int dx = 0; dx < 4; ++dx) up8<H>(*reinterpret_cast<const uint4*>(hs + ((y + dy) * HW2 + x0 + dx) * PH + chw), in[dx]);
+                    for (int dx = 0; dx < 4; ++dx) up8p(*reinterpret_cast<const uint4*>(hs + ((yq[q] + dy) * HW2 + xq[q] + dx) * PH + chw), in[dx]);
 #pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) {
-                        const float* tp = wtap + (dy * 3 + dx) * C4 + chw;
-                        const float4 ta = *reinterpret_cast<const float4*>(tp), tb = *reinterpret_cast<const float4*>(tp + 4);
-                        const float tw[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
+                    for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
                         for (int r = 0; r < 2; ++r)
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) o[r][e] += tw[e] * in[r + dx][e];
-                    }
+                            for (int e = 0; e < 4; ++e) o[q][r][e] += tw[dx][e] * in[r + dx][e];
                     if (dy == 1) {
 #pragma unroll
                         for (int r = 0; r < 2; ++r)
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) o[r][e] += in[r + 1][e];
+                            for (int e = 0; e < 4; ++e) o[q][r][e] += in[r + 1][e];
                     }
                 }
+            }
+#pragma unroll
+            for (int q = 0; q < NRD; ++q) {
+                if (q * 64 >= nitems) break;
+                const bool live = q * 64 + lane < nitems;
+                const int y = yq[q], x0 = xq[q];
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {                    // LayerNorm partials over this wave's CW channels (Chan-mergeable)
-                    float s = 0.f;
+                    const tc_f32x2 s4 = (o[q][r][0] + o[q][r][1]) + (o[q][r][2] + o[q][r][3]);
+                    float sm = s4.x + s4.y;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) s += o[r][e];
+                    for (int m = 1; m < SG; m <<= 1) sm += __shfl_xor(sm, m, 64);
+                    const float mu = sm * (1.0f / (float)CW);
+                    tc_f32x2 q2 = {0.f, 0.f};
 #pragma unroll
-                    for (int m = 1; m < SG; m <<= 1) s += __shfl_xor(s, m, 64);
-                    const float mu = s * (1.0f / (float)CW);
-                    float q = 0.f;
+                    for (int e = 0; e < 4; ++e) { const tc_f32x2 dl = o[q][r][e] - mu; q2 += dl * dl; }
+                    float sq = q2.x + q2.y;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { const float dl = o[r][e] - mu; q += dl * dl; }
-#pragma unroll
-                    for (int m = 1; m < SG; m <<= 1) q += __shfl_xor(q, m, 64);
-                    if (live && sg == 0 && x0 + r < TW) pst[wave * IPMAX + y * TW + x0 + r] = make_float2(s, q);
+                    for (int m = 1; m < SG; m <<= 1) sq += __shfl_xor(sq, m, 64);
+                    if (live && sg == 0 && x0 + r < TW) pst[wave * IPMAX + y * TW + x0 + r] = make_float2(sm, sq);
                 }
 #pragma unroll
                 for (int r = 0; r < 2; ++r)
-                    if (live && x0 + r < TW) *reinterpret_cast<uint4*>(hs + (y * HW2 + x0 + r) * PH + chw) = pk8<H>(o[r]);
+                    if (live && x0 + r < TW)
+                        *reinterpret_cast<uint4*>(hs + (y * HW2 + x0 + r) * PH + chw) =
+                            make_uint4(pack2<H>(o[q][r][0].x, o[q][r][0].y), pack2<H>(o[q][r][1].x, o[q][r][1].y), pack2<H>(o[q][r][2].x, o[q][r][2].y), pack2<H>(o[q][r][3].x, o[q][r][3].y));
             }
         }
+        FSTAMP(2);
         __syncthreads();
+        FSTAMP(3);
         // ---- row statistics
         if (tid < IP) {
             float s = 0.f;
@@ -246,6 +296,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p
             if (ST && oh0 + y < Himg && ow0 + x < Wimg) ST[ibase + (long long)(oh0 + y) * Wimg + ow0 + x] = make_float2(mean, rstd);
         }
         __syncthreads();
+        FSTAMP(4);
         // ---- a = GELU(LN(d)) in place; d (and a, when asked for) leave for the backward pass as whole pixel rows
         {
             const int cgx = tid % HC;
@@ -266,7 +317,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
                     const tc_f32x2 xv = {v[e], v[e + 1]}, gv = {gm[e], gm[e + 1]}, bv = {bt[e], bt[e + 1]};
-                    const tc_f32x2 u = gelu_f2((xv - st.x) * st.y * gv + bv);
+                    const tc_f32x2 u = gelu_f2_fast((xv - st.x) * st.y * gv + bv);
                     v[e] = u.x; v[e + 1] = u.y;
                 }
                 const uint4 av = pk8<H>(v);
@@ -278,7 +329,9 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p
                 }
             }
         }
+        FSTAMP(5);
         __syncthreads();
+        FSTAMP(6);
         // ---- fc2: this wave's 32 pixels x 32 output channels over K = 4C
         f32x16 oacc;
 #pragma unroll
@@ -286,7 +339,12 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p
         if (mt2 < p.MT2) {
             const int q = min(mt2 * 32 + l31, IP - 1), y = q / TW, x = q - y * TW;
             const bf16_t* ap = hs + (y * HW2 + x) * PH + 8 * hh;
-            {
+            if constexpr (K::W2LDS) {
+                const bf16_t* wp = w2s + (nt2 * 32 + l31) * PH + 8 * hh;
+#pragma unroll
+                for (int kk = 0; kk < KK2; ++kk)
+                    oacc = TcHalf<H>::mfma(*reinterpret_cast<const V8*>(wp + kk * 16), *reinterpret_cast<const V8*>(ap + kk * 16), oacc);
+            } else {
                 // W2 fragments stream from L2 (shared by every workgroup), four k-steps ahead of their use
                 const H* wp = W2 + (long long)(nt2 * 32 + l31) * C4 + 8 * hh;
                 V8 bq[4];
@@ -303,7 +361,9 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p
                 }
             }
         }
+        FSTAMP(7);
         __syncthreads();                                         // every fragment read of the hidden tile is done: it becomes the out stage
+        FSTAMP(8);
         if (mt2 < p.MT2) {
             float* sp = stg + (mt2 * 32 + l31) * PO + nt2 * 32 + 4 * hh;
 #pragma unroll
@@ -311,6 +371,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p
                 *reinterpret_cast<float4*>(sp + 8 * gq) = make_float4(oacc[4 * gq], oacc[4 * gq + 1], oacc[4 * gq + 2], oacc[4 * gq + 3]);
         }
         __syncthreads();
+        FSTAMP(9);
         {   // + bias + residual, rounded once, whole 16-byte pieces of pixel rows
             const int cg = tid % XC;
             for (int s = tid; s < IP * XC; s += NTH) {
@@ -328,8 +389,10 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p
                 *reinterpret_cast<uint4*>(OUT + rg * p.ldo + cg * 8) = pk8<H>(v);
             }
         }
+        FSTAMP(10);
         if (more) xput(tidx + gridDim.x);                        // (the x tile's last reader was this tile's fc1)
         __syncthreads();
+        FSTAMP(11);
     }
 }
 
@@ -357,7 +420,7 @@ void ffn_pick_tile(int H, int W, long long images, int fth, int ftw, int& TH, in
             if (tw > W && tw != ((W + 1) & ~1)) continue;
             if ((tw & 1) && tw != W && !(fth && ftw)) continue;
             const int hp = (th + 2) * (tw + 2), ip = th * tw;
-            if (hp > K::MPMAX || ip > K::IPMAX) continue;
+            if (hp > K::MPMAX || ip > K::IPMAX || th * ((tw + 1) / 2) * K::SG > 256) continue;
             if (fth && ftw && (th != fth || tw != ftw)) continue;
             const double tiles = (double)images * ((H + th - 1) / th) * ((W + tw - 1) / tw);
             const double rounds = (double)(long long)((tiles + ncu - 1) / ncu);
@@ -376,7 +439,7 @@ int ffn_fused_fwd_launch(const TcFfnFused* f, hipStream_t s) {
     p.sres = f->sres; p.sout = f->sout; p.wstride = f->wstride; p.ldx = f->ldx; p.ldr = f->ldr; p.ldo = f->ldo;
     p.B = f->B; p.H = f->H; p.W = f->W; p.eps = f->eps;
     ffn_pick_tile<C>(f->H, f->W, (long long)f->B * f->groups, f->tile_h, f->tile_w, p.TH, p.TW);
-    if ((p.TH + 2) * (p.TW + 2) > K::MPMAX || p.TH * p.TW > K::IPMAX) return TC_ERR_ARG;
+    if ((p.TH + 2) * (p.TW + 2) > K::MPMAX || p.TH * p.TW > K::IPMAX || p.TH * ((p.TW + 1) / 2) * K::SG > 256) return TC_ERR_ARG;
     p.tilesH = (f->H + p.TH - 1) / p.TH; p.tilesW = (f->W + p.TW - 1) / p.TW;
     p.HW2 = p.TW + 2; p.HP = (p.TH + 2) * p.HW2; p.MT = (p.HP + 31) / 32; p.IP = p.TH * p.TW; p.MT2 = (p.IP + 31) / 32;
     const long long nt = (long long)f->B * p.tilesH * p.tilesW;
@@ -404,6 +467,10 @@ bool ffn_fused_args_ok(const TcFfnFused* f) {
 }
 
 }  // namespace
+
+#ifdef TC_FFNF_TIMING
+extern "C" int tc_ffnf_dbg_read(long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ffnf_dbg), sizeof(long long) * 16 * 16); }
+#endif
 
 extern "C" int tc_ffn_fused_supported(int C, int dtype) { return (C == 64 || C == 128) && (dtype == TC_BF16 || dtype == TC_F16); }
 

@@ -47,13 +47,27 @@ struct FfnBwdDev {
     int TH, TW, tilesH, tilesW, HW2, HP, MT, IP, MT2, KS, ntiles;
 };
 
+#ifdef TC_FFNB_TIMING
+// phase stamps (experiment builds only, scripts/exp/ffnb_timing.py): thread 0 of the first 16 workgroups of weight group 0 adds the
+// cycles between consecutive stamps to its row of the table
+__device__ long long g_ffnb_dbg[2 * 16 * 16];
+#define BSTAMP(k) do { if (bs_) { const long long t_ = __builtin_readcyclecounter(); bs_[k] += t_ - bt_; bt_ = t_; } } while (0)
+#define BSTAMP_INIT(kern) long long bt_ = __builtin_readcyclecounter(); \
+    long long* bs_ = (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 16) ? g_ffnb_dbg + ((kern) * 16 + blockIdx.x) * 16 : nullptr; \
+    if (bs_) for (int k_ = 0; k_ < 16; ++k_) bs_[k_] = 0;
+#else
+#define BSTAMP(k)
+#define BSTAMP_INIT(kern)
+#endif
+
 // --------------------------------------------------------------------------------------------------------------------- launch 1
 template <int C> struct LnCfg {
-    static constexpr int C4 = 4 * C, NW = 8, NTH = 512, CW = C4 / NW, NT = CW / 32, KK = C / 16, OB = C / 32, P = 64;
+    static constexpr int C4 = 4 * C, NW = 8, NTH = 512, CW = C4 / NW, NT = CW / 32, KK = C / 16, OB = C / 32, P = 32;   // P = 64 needs ~290 registers (spills, and a spill reload after the prefetch waits for it)
     static constexpr int PH = C4 + 8, PX = C + 8, HC = C4 / 8, XC = C / 8, ND = P * HC / NTH, NY = (P * XC + NTH - 1) / NTH;
-    static constexpr size_t smem = (size_t)P * PH * 2 + (size_t)P * PX * 2 + (size_t)2 * C4 * 4 + (size_t)NW * P * 8 + (size_t)P * 8;
+    static constexpr int PGG = C4 + 4;                               // fp32 row pitch of the parked gg tile
+    static constexpr size_t smem = (size_t)P * PH * 2 + (size_t)P * PX * 2 + (size_t)2 * C4 * 4 + (size_t)NW * P * 8 + (size_t)P * 8 + (size_t)P * PGG * 4 + (size_t)C4 * PX * 2;
     static_assert(NTH % XC == 0 && P * HC % NTH == 0, "strip ownership");
-    static_assert((size_t)NTH * 8 * 4 <= (size_t)P * PH * 2, "db2 fold aliases the hidden tile");
+    static_assert(smem <= 160 * 1024, "LDS");
 };
 
 template <typename H, int C>
@@ -62,17 +76,20 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_ln_kernel(const FfnBwdDev p) {
     using PT = BwdPart<C>;
     using V8 = typename TcHalf<H>::v8;
     constexpr int C4 = K::C4, CW = K::CW, NT = K::NT, KK = K::KK, OB = K::OB, P = K::P, PH = K::PH, PX = K::PX, HC = K::HC, XC = K::XC;
-    constexpr int ND = K::ND, NY = K::NY, NTH = K::NTH, NW = K::NW;
+    constexpr int ND = K::ND, NY = K::NY, NTH = K::NTH, NW = K::NW, PGG = K::PGG;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* dt = reinterpret_cast<bf16_t*>(smem);                          // [P][PH]  d, then GELU(LN(d)), then gd; rows k-permuted
     bf16_t* yt = dt + P * PH;                                              // [P][PX]  dy; rows k-permuted
     float* gbs = reinterpret_cast<float*>(yt + P * PX);                    // gamma[C4], beta[C4]
     float2* psum = reinterpret_cast<float2*>(gbs + 2 * C4);                // [NW][P] per-wave LayerNorm-backward row sums
     float2* fst = psum + NW * P;                                           // [P] mean, rstd
+    float* ggs = reinterpret_cast<float*>(fst + P);                        // [P][PGG] gp * gamma, parked between the two LayerNorm-backward phases
+    bf16_t* w2t = reinterpret_cast<bf16_t*>(ggs + P * PGG);                // [C4][PX] W2^T (rows = hidden channel): A operand of gpre^T = W2^T dy^T
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     const int gi = lane & 15, gq2 = (lane >> 4) & 1;
     const int g = blockIdx.y, M = p.M;
+    BSTAMP_INIT(0);
     const long long wo = (long long)g * p.wstride;
     const H* D = reinterpret_cast<const H*>(p.d) + (long long)g * M * C4;
     H* GD = reinterpret_cast<H*>(p.gd) + (long long)g * M * C4;
@@ -85,17 +102,14 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_ln_kernel(const FfnBwdDev p) {
         const H* bt = reinterpret_cast<const H*>(p.beta) + wo;
         for (int i = tid; i < C4; i += NTH) { gbs[i] = ldf<H>(gm + i); gbs[C4 + i] = ldf<H>(bt + i); }
     }
-    // W2^T fragments of this wave's hidden channels (A operand of gpre^T = W2^T dy^T: rows = hidden channel, k = output channel)
-    V8 wf[NT][KK];
+    for (int i = tid; i < C4 * XC; i += NTH) {                      // W2 [C][C4] -> W2^T in LDS, once per launch: lanes walk the hidden
+        const int og = i / C4, ch = i - og * C4;                    // channels (coalesced 2-byte reads), eight output channels per 16-byte store
+        unsigned w[4];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int kk = 0; kk < KK; ++kk) {
-            s16x8_t t;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) t[j] = (short)W2[(long long)(kk * 16 + 8 * hh + j) * C4 + wave * CW + nt * 32 + l31];
-            wf[nt][kk] = __builtin_bit_cast(V8, t);
-        }
+        for (int e = 0; e < 4; ++e)
+            w[e] = (unsigned)W2[(long long)(og * 8 + 2 * e) * C4 + ch] | ((unsigned)W2[(long long)(og * 8 + 2 * e + 1) * C4 + ch] << 16);
+        *reinterpret_cast<uint4*>(w2t + ch * PX + og * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
 
     uint4 dr[ND], yr[NY];
     float2 sr = make_float2(0.f, 0.f);
@@ -115,9 +129,9 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_ln_kernel(const FfnBwdDev p) {
         }
         if (tid < P) { const long long row = r0 + tid; sr = ST[row < M ? row : 0]; }
     };
-    float b2acc[8];
+    float db2p[OB];                                                 // (wave 0) column sums of dy, from the dW2 operand fragments
 #pragma unroll
-    for (int e = 0; e < 8; ++e) b2acc[e] = 0.f;
+    for (int ob = 0; ob < OB; ++ob) db2p[ob] = 0.f;
     auto put = [&](int blk) __attribute__((always_inline)) {
         const long long r0 = (long long)blk * P;
 #pragma unroll
@@ -131,10 +145,6 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_ln_kernel(const FfnBwdDev p) {
             if (s < P * XC) {
                 const uint4 v = (r0 + px < M) ? yr[i] : make_uint4(0u, 0u, 0u, 0u);
                 *reinterpret_cast<uint4*>(yt + krow(px) * PX + cg * 8) = v;
-                float f[8];
-                up8<H>(v, f);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) b2acc[e] += f[e];
             }
         }
         if (tid < P) fst[tid] = (r0 + tid < M) ? sr : make_float2(0.f, 0.f);
@@ -156,34 +166,37 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_ln_kernel(const FfnBwdDev p) {
     int blk = blockIdx.x;
     if (blk < p.nblk) fetch(blk);
     __syncthreads();                                               // gamma / beta
+    BSTAMP(0);
     for (; blk < p.nblk; blk += gridDim.x) {
         put(blk);
+        BSTAMP(1);
         __syncthreads();
+        BSTAMP(2);
+        if (blk + (int)gridDim.x < p.nblk) fetch(blk + gridDim.x); // lands under this block's arithmetic
         const long long r0 = (long long)blk * P;
-        // ---- gpre^T = W2^T dy^T: lane = pixel, registers = 16 of this wave's hidden channels
-        f32x16 acc[2][NT];
+        // ---- per 32-pixel half: gpre^T = W2^T dy^T (lane = pixel, registers = 16 of this wave's hidden channels); u = LN(d);
+        //      gp = gpre * GELU'(u); a = GELU(u) -> LDS (over d); gg = gp * gamma -> LDS (fp32) and its two row sums; dgamma / dbeta
+        uint2 dk[P / 32][NT][4];
 #pragma unroll
-        for (int pb = 0; pb < 2; ++pb)
+        for (int pb = 0; pb < P / 32; ++pb) {
+            const int px = pb * 32 + l31;
+            f32x16 acc[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[pb][nt][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+            {
+                const bf16_t* yp = yt + krow(px) * PX + 8 * hh;
 #pragma unroll
-        for (int pb = 0; pb < 2; ++pb) {
-            const bf16_t* yp = yt + krow(pb * 32 + l31) * PX + 8 * hh;
+                for (int kk = 0; kk < KK; ++kk) {
+                    const V8 yv = *reinterpret_cast<const V8*>(yp + kk * 16);
 #pragma unroll
-            for (int kk = 0; kk < KK; ++kk) {
-                const V8 yv = *reinterpret_cast<const V8*>(yp + kk * 16);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[pb][nt] = TcHalf<H>::mfma(wf[nt][kk], yv, acc[pb][nt]);
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[nt] = TcHalf<H>::mfma(*reinterpret_cast<const V8*>(w2t + (wave * CW + nt * 32 + l31) * PX + kk * 16 + 8 * hh), yv, acc[nt]);
+                }
             }
-        }
-        // ---- u = LN(d); gp = gpre * GELU'(u); a = GELU(u) -> LDS (over d); gg = gp * gamma and the two row sums; dgamma / dbeta
-        uint2 dk[2][NT][4];
-#pragma unroll
-        for (int pb = 0; pb < 2; ++pb) {
-            const int px = pb * 32 + l31;
             bf16_t* rowp = dt + krow(px) * PH;
+            float* ggp = ggs + px * PGG;
             const float2 st = fst[px];
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -194,7 +207,7 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_ln_kernel(const FfnBwdDev p) {
                     const uint2 dv = *reinterpret_cast<const uint2*>(rowp + ch0);
                     dk[pb][nt][gq] = dv;
                     const float4 g4 = *reinterpret_cast<const float4*>(gbs + ch0), b4 = *reinterpret_cast<const float4*>(gbs + C4 + ch0);
-                    float xv[4], av[4];
+                    float xv[4], av[4], gv4[4];
                     unpack2<H>(dv.x, xv[0], xv[1]); unpack2<H>(dv.y, xv[2], xv[3]);
                     const float gv[4] = {g4.x, g4.y, g4.z, g4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
@@ -203,9 +216,9 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_ln_kernel(const FfnBwdDev p) {
                         const tc_f32x2 xh = (x2 - st.x) * st.y;
                         const tc_f32x2 u = xh * g2 + be2;
                         tc_f32x2 pdf;
-                        const tc_f32x2 cdf = gelu_cdf_pdf2(u, pdf);
+                        const tc_f32x2 cdf = gelu_cdf_pdf2_fast(u, pdf);
                         const tc_f32x2 a2 = u * cdf, gpr = cdf + u * pdf;
-                        const tc_f32x2 gpre = {acc[pb][nt][4 * gq + e], acc[pb][nt][4 * gq + e + 1]};
+                        const tc_f32x2 gpre = {acc[nt][4 * gq + e], acc[nt][4 * gq + e + 1]};
                         const tc_f32x2 gp = gpre * gpr;
                         dbet[nt][4 * gq + e] += gp.x; dbet[nt][4 * gq + e + 1] += gp.y;
                         const tc_f32x2 gx = gp * xh;
@@ -214,18 +227,19 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_ln_kernel(const FfnBwdDev p) {
                         s1 += gg.x + gg.y;
                         const tc_f32x2 gh = gg * xh;
                         s2 += gh.x + gh.y;
-                        acc[pb][nt][4 * gq + e] = gg.x; acc[pb][nt][4 * gq + e + 1] = gg.y;
+                        gv4[e] = gg.x; gv4[e + 1] = gg.y;
                         av[e] = a2.x; av[e + 1] = a2.y;
                     }
                     *reinterpret_cast<uint2*>(rowp + ch0) = make_uint2(pack2<H>(av[0], av[1]), pack2<H>(av[2], av[3]));
-                    __builtin_amdgcn_sched_barrier(0);              // (keeps the next group's loads and temporaries out of this one's live range)
+                    *reinterpret_cast<float4*>(ggp + ch0) = make_float4(gv4[0], gv4[1], gv4[2], gv4[3]);
                 }
             s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 32, 64);
             if (hh == 0) psum[wave * P + px] = make_float2(s1, s2);
         }
+        BSTAMP(4);
         __syncthreads();
-        if (blk + (int)gridDim.x < p.nblk) fetch(blk + gridDim.x); // lands under the rest of this block's work
+        BSTAMP(5);
         // ---- dW2 += dy^T a over the 64 pixels: both operands by transpose reads (k = pixel = LDS row)
 #pragma unroll
         for (int ks = 0; ks < P / 16; ++ks) {
@@ -235,14 +249,24 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_ln_kernel(const FfnBwdDev p) {
             for (int nt = 0; nt < NT; ++nt) bfr[nt] = ld_tr<V8>(dt + rr * PH + wave * CW + nt * 32 + cc, dt + (rr + 1) * PH + wave * CW + nt * 32 + cc);
 #pragma unroll
             for (int ob = 0; ob < OB; ++ob) afr[ob] = ld_tr<V8>(yt + rr * PX + ob * 32 + cc, yt + (rr + 1) * PX + ob * 32 + cc);
+            if (wave == 0) {
+#pragma unroll
+                for (int ob = 0; ob < OB; ++ob) {
+                    const uint4 q = __builtin_bit_cast(uint4, afr[ob]);
+                    float f[8];
+                    up8<H>(q, f);
+                    db2p[ob] += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
+                }
+            }
 #pragma unroll
             for (int ob = 0; ob < OB; ++ob)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc2[ob][nt] = TcHalf<H>::mfma(afr[ob], bfr[nt], acc2[ob][nt]);
         }
+        BSTAMP(6);
         // ---- LayerNorm backward: gd = rstd * (gg - S1 / 4C - xhat * S2 / 4C), over a in LDS (this wave's columns only)
 #pragma unroll
-        for (int pb = 0; pb < 2; ++pb) {
+        for (int pb = 0; pb < P / 32; ++pb) {
             const int px = pb * 32 + l31;
             bf16_t* rowp = dt + krow(px) * PH;
             const float2 st = fst[px];
@@ -257,22 +281,28 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_ln_kernel(const FfnBwdDev p) {
                     const int ch0 = wave * CW + nt * 32 + 8 * gq + 4 * hh;
                     float xv[4], o[4];
                     unpack2<H>(dk[pb][nt][gq].x, xv[0], xv[1]); unpack2<H>(dk[pb][nt][gq].y, xv[2], xv[3]);
+                    const float4 g4 = *reinterpret_cast<const float4*>(ggs + px * PGG + ch0);
+                    const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float xh = (xv[e] - st.x) * st.y;
-                        o[e] = st.y * (acc[pb][nt][4 * gq + e] - k1 - xh * k2);
+                        o[e] = st.y * (gg[e] - k1 - xh * k2);
                     }
                     *reinterpret_cast<uint2*>(rowp + ch0) = make_uint2(pack2<H>(o[0], o[1]), pack2<H>(o[2], o[3]));
                 }
         }
+        BSTAMP(7);
         __syncthreads();
+        BSTAMP(8);
         // ---- gd leaves as whole pixel rows
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
             const int s = tid + i * NTH, px = s / HC, cg = s - px * HC;
             if (r0 + px < M) *reinterpret_cast<uint4*>(GD + (r0 + px) * C4 + cg * 8) = *reinterpret_cast<const uint4*>(dt + krow(px) * PH + cg * 8);
         }
+        BSTAMP(9);
         __syncthreads();
+        BSTAMP(10);
     }
     // ---- this workgroup's partial sums
     float* PB = p.part + ((long long)g * gridDim.x + blockIdx.x) * PT::n;
@@ -285,28 +315,38 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_ln_kernel(const FfnBwdDev p) {
                 const int o = ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh, ch = wave * CW + nt * 32 + l31;
                 PB[PT::oW2 + o * C4 + ch] = acc2[ob][nt][r];
             }
+    // dgamma / dbeta: sums over the 32 pixel lanes of a half-wave, as a transposing butterfly (31 shuffles per 16 values instead of 80):
+    // afterwards lane l holds the total of register l & 15
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float a = dgam[nt][r], b = dbet[nt][r];
+        for (int which = 0; which < 2; ++which) {
+            float v[16];
 #pragma unroll
-            for (int m = 1; m < 32; m <<= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
-            if (l31 == 0) {
-                const int ch = wave * CW + nt * 32 + 8 * (r >> 2) + 4 * hh + (r & 3);
-                PB[PT::oG + ch] = a; PB[PT::oBt + ch] = b;
+            for (int r = 0; r < 16; ++r) { const float t = which ? dbet[nt][r] : dgam[nt][r]; v[r] = t + __shfl_xor(t, 16, 64); }
+#pragma unroll
+            for (int m = 8, n = 16; m >= 1; m >>= 1, n >>= 1) {
+                const bool up = (lane & m) != 0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (j < n / 2) {
+                        const float keep = up ? v[j + n / 2] : v[j], send = up ? v[j] : v[j + n / 2];
+                        v[j] = keep + __shfl_xor(send, m, 64);
+                    }
+            }
+            if (l31 < 16) {
+                const int r = l31, ch = wave * CW + nt * 32 + 8 * (r >> 2) + 4 * hh + (r & 3);
+                PB[(which ? PT::oBt : PT::oG) + ch] = v[0];
             }
         }
-    float* fold = reinterpret_cast<float*>(smem);                   // [NTH][8] (the tiles are dead)
+    if (wave == 0) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) fold[tid * 8 + e] = b2acc[e];
-    __syncthreads();
-    if (tid < C) {
-        const int cg = tid >> 3, e = tid & 7;
-        float s = 0.f;
-        for (int k = 0; k < NTH / XC; ++k) s += fold[(k * XC + cg) * 8 + e];
-        PB[PT::oB2 + tid] = s;
+        for (int ob = 0; ob < OB; ++ob) {
+            const float v = db2p[ob] + __shfl_xor(db2p[ob], 32, 64);
+            if (hh == 0) PB[PT::oB2 + ob * 32 + l31] = v;
+        }
     }
+    BSTAMP(11);
 }
 
 // --------------------------------------------------------------------------------------------------------------------- launch 2
@@ -316,7 +356,8 @@ template <int C> struct DwCfg {
     static constexpr int PX = C + 8, PG = CH + 8, PO = C + 4;
     static constexpr int NXR = (MPMAX * XC + NTH - 1) / NTH, NGR = (MPMAX * GC + NTH - 1) / NTH;
     static constexpr size_t o_xs = 0, o_gs = o_xs + (size_t)MPMAX * PX * 2, o_hs = o_gs + (size_t)MPMAX * PG * 2, o_w1 = o_hs + (size_t)(MPMAX + 1) * PG * 2,
-                            o_tap = o_w1 + (size_t)C4 * PX * 2, o_b1 = o_tap + (size_t)9 * C4 * 4, o_acc = o_b1 + (size_t)C4 * 4, smem = o_acc + (size_t)11 * C4 * 4;
+                            o_tap = o_w1 + (size_t)C4 * PX * 2, o_b1 = o_tap + (size_t)9 * C4 * 4, smem = o_b1 + (size_t)C4 * 4;
+    static_assert((size_t)NW * NCH * 22 * 64 * 4 <= o_w1, "the final fold of the depthwise sums aliases the tiles");
     static_assert(MT2MAX * NB <= NW && (CH / 32) * NB <= NW, "one MFMA block per wave");
     static_assert((size_t)IPMAX * PO * 4 <= (size_t)MPMAX * PG * 2, "the fp32 dx stage aliases the gd tile");
     static_assert(smem <= 160 * 1024, "LDS");
@@ -336,12 +377,12 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dw_kernel(const FfnBwdDev p) {
     bf16_t* w1s = reinterpret_cast<bf16_t*>(smem + K::o_w1);              // [C4][PX]         W1, rows k-permuted inside each 16-row group
     float* taps = reinterpret_cast<float*>(smem + K::o_tap);              // [9][C4]
     float* b1s = reinterpret_cast<float*>(smem + K::o_b1);                // [C4]
-    float* lacc = reinterpret_cast<float*>(smem + K::o_acc);              // [11][C4]: dwd taps 0..8, dbd, db1
     float* stg = reinterpret_cast<float*>(smem + K::o_gs);                // fp32 dx stage over the gd tile
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     const int gi = lane & 15, gq2 = (lane >> 4) & 1;
     const int g = blockIdx.y, M = p.M;
+    BSTAMP_INIT(1);
     const long long wo = (long long)g * p.wstride, imgpix = (long long)p.H * p.W;
     const H* X = reinterpret_cast<const H*>(p.x) + (long long)g * M * p.ldx;
     const H* GD = reinterpret_cast<const H*>(p.gd) + (long long)g * M * C4;
@@ -349,18 +390,17 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dw_kernel(const FfnBwdDev p) {
     const H* W1 = reinterpret_cast<const H*>(p.w1) + wo;
     const int TH = p.TH, TW = p.TW, HW2 = p.HW2, HP = p.HP, MT = p.MT, IP = p.IP, Himg = p.H, Wimg = p.W;
 
-    {
+    auto stage_params = [&]() __attribute__((always_inline)) {
         const H* wd = reinterpret_cast<const H*>(p.wd) + wo;
         const H* b1 = reinterpret_cast<const H*>(p.b1) + wo;
         for (int i = tid; i < 9 * C4; i += NTH) { const int ch = i / 9, t = i - ch * 9; taps[t * C4 + ch] = ldf<H>(wd + i); }
         for (int i = tid; i < C4; i += NTH) b1s[i] = ldf<H>(b1 + i);
-        for (int i = tid; i < 11 * C4; i += NTH) lacc[i] = 0.f;
         for (int i = tid; i < PG; i += NTH) hs[MPMAX * PG + i] = 0;
         for (int s = tid; s < C4 * XC; s += NTH) {                 // W1 stays in LDS for the whole launch
             const int r = s / XC, cg = s - r * XC;
             *reinterpret_cast<uint4*>(w1s + krow(r) * PX + cg * 8) = *reinterpret_cast<const uint4*>(W1 + (long long)r * C + cg * 8);
         }
-    }
+    };
 
     auto tile_org = [&](int tidx, int& b, int& oh0, int& ow0) __attribute__((always_inline)) {
         const int tx = tidx % p.tilesW, ty = (tidx / p.tilesW) % p.tilesH;
@@ -422,15 +462,21 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dw_kernel(const FfnBwdDev p) {
     auto hrow = [&](int q) __attribute__((always_inline)) { const int y = q / TW; return (y + 1) * HW2 + (q - y * TW) + 1; };
 
     f32x16 accw[NCH];
+    tc_f32x2 aw[NCH][11];                                            // this thread's sums over (its row of every tile) x (its channel pair of chunk c): dwd taps, dbd, db1
 #pragma unroll
-    for (int c = 0; c < NCH; ++c)
+    for (int c = 0; c < NCH; ++c) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) accw[c][r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 11; ++t) aw[c][t] = tc_f32x2{0.f, 0.f};
+    }
     const int cb = wave & 3, nb = wave >> 2;                        // MFMA block of this wave: (hidden block | pixel block, channel block)
 
     int tidx = blockIdx.x;
-    if (tidx < p.ntiles) { xfetch(tidx); gfetch(tidx, 0); }
+    if (tidx < p.ntiles) { xfetch(tidx); gfetch(tidx, 0); }        // (in flight under the parameter staging)
+    stage_params();
     __syncthreads();                                               // parameters in LDS
+    BSTAMP(0);
     for (; tidx < p.ntiles; tidx += gridDim.x) {
         int b, oh0, ow0;
         tile_org(tidx, b, oh0, ow0);
@@ -442,15 +488,16 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dw_kernel(const FfnBwdDev p) {
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             gput(tidx);
+            BSTAMP(1);
             __syncthreads();
+            BSTAMP(2);
             if (c + 1 < NCH) gfetch(tidx, c + 1);
-            else if (more) { xfetch(tidx + gridDim.x); gfetch(tidx + gridDim.x, 0); }
             // ---- h = fc1(x) on the haloed tile for this chunk's channels (zero outside the image: the convolution's padding)
             {
                 V8 af[KK1];
 #pragma unroll
                 for (int kk = 0; kk < KK1; ++kk) af[kk] = *reinterpret_cast<const V8*>(w1s + krow(c * CH + cb * 32 + l31) * PX + kk * 16 + 8 * hh);
-                for (int mi = nb; mi < MT; mi += 2) {
+                for (int mi = nb; mi < MT; mi += 2) {               // (one block at a time: three interleaved chains cost 36 spilled registers)
                     f32x16 acc;
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq) {
@@ -473,67 +520,79 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dw_kernel(const FfnBwdDev p) {
                     }
                 }
             }
+            BSTAMP(3);
             __syncthreads();
-            // ---- depthwise stage: wave = inner row, lane = channel pair.  dwd[t] += gd * h(shifted), dbd += gd,
-            //      dh = gd + sum_t w[t] gd(shifted the other way), db1 += dh
-            unsigned dhr[TWMAX];
+            BSTAMP(4);
+            // ---- depthwise stage: wave = inner row, lane = channel pair (packed fp32 math on the pair).
+            //      Pass 1: dwd[t] += gd * h(shifted), dbd += gd.  (barrier: every read of h is done.)
+            //      Pass 2: dh = gd + sum_t w[t] gd(shifted the other way) -> the inner pixels' slots of the h tile, db1 += dh.
+            //      Both walk the row with the next column's LDS reads in flight under the current column's arithmetic.
             {
                 const int y = wave, chl = 2 * lane, chg = c * CH + chl;
                 const bool active = y < TH;
-                float2 tp[9];
-#pragma unroll
-                for (int t = 0; t < 9; ++t) tp[t] = *reinterpret_cast<const float2*>(taps + t * C4 + chg);
-                float2 aw[9], abd = make_float2(0.f, 0.f), ab1 = make_float2(0.f, 0.f);
-#pragma unroll
-                for (int t = 0; t < 9; ++t) aw[t] = make_float2(0.f, 0.f);
+                auto ld2 = [&](const bf16_t* q) __attribute__((always_inline)) { tc_f32x2 v; float a, b; unpack2<H>(*reinterpret_cast<const unsigned*>(q), a, b); v.x = a; v.y = b; return v; };
                 if (active) {
-                    float2 gw[3][3], hw[3][3];
-                    const bool rowin = oh0 + y < Himg;
+                    const bf16_t* hb = hs + (y * HW2) * PG + chl;
+                    const bf16_t* gcp = gs + ((y + 1) * HW2 + 1) * PG + chl;
+                    tc_f32x2 c0[3], c1[3], c2[3];
 #pragma unroll
-                    for (int r = 0; r < 3; ++r)
+                    for (int r = 0; r < 3; ++r) { c1[r] = ld2(hb + (r * HW2) * PG); c2[r] = ld2(hb + (r * HW2 + 1) * PG); }
+                    unsigned nh[3], ng = *reinterpret_cast<const unsigned*>(gcp);
 #pragma unroll
-                        for (int cx = 1; cx < 3; ++cx) {
-                            const int o = ((y + r) * HW2 + cx - 1) * PG + chl;
-                            unpack2<H>(*reinterpret_cast<const unsigned*>(gs + o), gw[r][cx].x, gw[r][cx].y);
-                            unpack2<H>(*reinterpret_cast<const unsigned*>(hs + o), hw[r][cx].x, hw[r][cx].y);
+                    for (int r = 0; r < 3; ++r) nh[r] = *reinterpret_cast<const unsigned*>(hb + (r * HW2 + 2) * PG);
+                    for (int x = 0; x < TW; ++x) {
+                        tc_f32x2 gc;
+                        { float a, b; unpack2<H>(ng, a, b); gc.x = a; gc.y = b; }          // zero for a pixel outside the image
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) { c0[r] = c1[r]; c1[r] = c2[r]; float a, b; unpack2<H>(nh[r], a, b); c2[r].x = a; c2[r].y = b; }
+                        const int xn = x + 1 < TW ? x + 1 : x;                               // (the last step re-reads its own column)
+                        ng = *reinterpret_cast<const unsigned*>(gcp + xn * PG);
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) nh[r] = *reinterpret_cast<const unsigned*>(hb + (r * HW2 + xn + 2) * PG);
+#pragma unroll
+                        for (int ky = 0; ky < 3; ++ky) {
+                            aw[c][ky * 3] += gc * c0[ky]; aw[c][ky * 3 + 1] += gc * c1[ky]; aw[c][ky * 3 + 2] += gc * c2[ky];
                         }
-#pragma unroll
-                    for (int x = 0; x < TWMAX; ++x) {
-                        if (x >= TW) break;
-#pragma unroll
-                        for (int r = 0; r < 3; ++r) {
-                            gw[r][0] = gw[r][1]; gw[r][1] = gw[r][2]; hw[r][0] = hw[r][1]; hw[r][1] = hw[r][2];
-                            const int o = ((y + r) * HW2 + x + 2) * PG + chl;
-                            unpack2<H>(*reinterpret_cast<const unsigned*>(gs + o), gw[r][2].x, gw[r][2].y);
-                            unpack2<H>(*reinterpret_cast<const unsigned*>(hs + o), hw[r][2].x, hw[r][2].y);
-                        }
-                        const float2 gc = gw[1][1];                 // zero for a pixel outside the image
-                        float2 dv = gc;
-#pragma unroll
-                        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                            for (int kx = 0; kx < 3; ++kx) {
-                                aw[ky * 3 + kx].x += gc.x * hw[ky][kx].x; aw[ky * 3 + kx].y += gc.y * hw[ky][kx].y;
-                                dv.x += tp[ky * 3 + kx].x * gw[2 - ky][2 - kx].x; dv.y += tp[ky * 3 + kx].y * gw[2 - ky][2 - kx].y;
-                            }
-                        abd.x += gc.x; abd.y += gc.y;
-                        if (!(rowin && ow0 + x < Wimg)) dv = make_float2(0.f, 0.f);
-                        ab1.x += dv.x; ab1.y += dv.y;
-                        dhr[x] = pack2<H>(dv.x, dv.y);
+                        aw[c][9] += gc;
                     }
                 }
-                __syncthreads();                                    // every read of h is done: dh takes the inner pixels' slots
+                BSTAMP(5);
+                __syncthreads();
+                BSTAMP(6);
                 if (active) {
+                    const bool rowin = oh0 + y < Himg;
+                    tc_f32x2 tp[9];
 #pragma unroll
-                    for (int x = 0; x < TWMAX; ++x)
-                        if (x < TW) *reinterpret_cast<unsigned*>(hs + ((y + 1) * HW2 + x + 1) * PG + chl) = dhr[x];
+                    for (int t = 0; t < 9; ++t) { const float2 q = *reinterpret_cast<const float2*>(taps + t * C4 + chg); tp[t].x = q.x; tp[t].y = q.y; }
+                    const bf16_t* gb = gs + (y * HW2) * PG + chl;
+                    bf16_t* dhp = hs + ((y + 1) * HW2 + 1) * PG + chl;
+                    tc_f32x2 c0[3], c1[3], c2[3];
 #pragma unroll
-                    for (int t = 0; t < 9; ++t) { atomicAdd(lacc + t * C4 + chg, aw[t].x); atomicAdd(lacc + t * C4 + chg + 1, aw[t].y); }
-                    atomicAdd(lacc + 9 * C4 + chg, abd.x); atomicAdd(lacc + 9 * C4 + chg + 1, abd.y);
-                    atomicAdd(lacc + 10 * C4 + chg, ab1.x); atomicAdd(lacc + 10 * C4 + chg + 1, ab1.y);
+                    for (int r = 0; r < 3; ++r) { c1[r] = ld2(gb + (r * HW2) * PG); c2[r] = ld2(gb + (r * HW2 + 1) * PG); }
+                    unsigned nh[3];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) nh[r] = *reinterpret_cast<const unsigned*>(gb + (r * HW2 + 2) * PG);
+                    for (int x = 0; x < TW; ++x) {
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) { c0[r] = c1[r]; c1[r] = c2[r]; float a, b; unpack2<H>(nh[r], a, b); c2[r].x = a; c2[r].y = b; }
+                        const int xn = x + 1 < TW ? x + 1 : x;
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) nh[r] = *reinterpret_cast<const unsigned*>(gb + (r * HW2 + xn + 2) * PG);
+                        tc_f32x2 dv = c1[1];
+#pragma unroll
+                        for (int ky = 0; ky < 3; ++ky) {            // gd at (row 2 - ky, column 2 - kx) of the window meets tap (ky, kx)
+                            dv += tp[ky * 3] * c2[2 - ky]; dv += tp[ky * 3 + 1] * c1[2 - ky]; dv += tp[ky * 3 + 2] * c0[2 - ky];
+                        }
+                        if (!(rowin && ow0 + x < Wimg)) dv = tc_f32x2{0.f, 0.f};
+                        aw[c][10] += dv;
+                        *reinterpret_cast<unsigned*>(dhp + x * PG) = pack2<H>(dv.x, dv.y);
+                    }
                 }
             }
+            if (c + 1 == NCH && more) { xfetch(tidx + gridDim.x); gfetch(tidx + gridDim.x, 0); }     // (after the register-hungry stage)
+            BSTAMP(7);
             __syncthreads();
+            BSTAMP(8);
             // ---- dx^T += W1^T dh^T  (rows = input channel, columns = inner pixel);  dW1 += dh^T x  (rows = hidden channel, columns = input channel)
             if (cb < p.MT2) {
                 const int q = cb * 32 + l31;
@@ -544,14 +603,17 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dw_kernel(const FfnBwdDev p) {
                     accx = TcHalf<H>::mfma(ld_tr<V8>(wp, wp + PX), *reinterpret_cast<const V8*>(dp + kk * 16), accx);
                 }
             }
-            for (int ks = 0; ks < p.KS; ++ks) {
+#pragma unroll
+            for (int ks = 0; ks < K::IPMAX / 16; ++ks) {                // (steps beyond the tile's pixels multiply the zero row)
                 const int qlo = 16 * ks + 8 * hh + (gi >> 2), qhi = qlo + 4, cc = 16 * gq2 + 4 * (gi & 3);
                 const int rlo = qlo < IP ? hrow(qlo) : -1, rhi = qhi < IP ? hrow(qhi) : -1;
                 const V8 av = ld_tr<V8>(hs + (rlo < 0 ? MPMAX : rlo) * PG + cb * 32 + cc, hs + (rhi < 0 ? MPMAX : rhi) * PG + cb * 32 + cc);
                 const V8 bv = ld_tr<V8>(xs + (rlo < 0 ? 0 : rlo) * PX + nb * 32 + cc, xs + (rhi < 0 ? 0 : rhi) * PX + nb * 32 + cc);
                 accw[c] = TcHalf<H>::mfma(av, bv, accw[c]);
             }
+            BSTAMP(9);
             __syncthreads();                                        // the tiles of this chunk are dead
+            BSTAMP(10);
         }
         // ---- dx leaves as whole pixel rows (through LDS, over the gd tile)
         if (cb < p.MT2) {
@@ -579,6 +641,7 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dw_kernel(const FfnBwdDev p) {
             }
         }
         __syncthreads();
+        BSTAMP(11);
     }
     // ---- this workgroup's partial sums
     float* PB = p.part + ((long long)g * gridDim.x + blockIdx.x) * PT::n;
@@ -589,13 +652,28 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dw_kernel(const FfnBwdDev p) {
             const int ch = c * CH + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
             PB[PT::oW1 + ch * C + nb * 32 + l31] = accw[c][r];
         }
-    for (int i = tid; i < 11 * C4; i += NTH) {
-        const int t = i / C4, ch = i - t * C4;
-        const float v = lacc[i];
-        if (t < 9) PB[PT::oWd + ch * 9 + t] = v;
-        else if (t == 9) PB[PT::oBd + ch] = v;
-        else PB[PT::oB1 + ch] = v;
+    {   // depthwise sums: the eight waves (rows) of the workgroup fold through LDS (the tiles are dead)
+        float* red = reinterpret_cast<float*>(smem);               // [NW][NCH * 22][64]
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int t = 0; t < 11; ++t) {
+                red[(wave * (NCH * 22) + c * 22 + 2 * t) * 64 + lane] = aw[c][t].x;
+                red[(wave * (NCH * 22) + c * 22 + 2 * t + 1) * 64 + lane] = aw[c][t].y;
+            }
+        __syncthreads();
+        for (int i = tid; i < NCH * 22 * 64; i += NTH) {
+            const int v = i >> 6, l = i & 63, c = v / 22, t = (v - c * 22) >> 1, ch = c * CH + 2 * l + (v & 1);
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < K::NW; ++w) sum += red[(w * (NCH * 22) + v) * 64 + l];
+            if (t < 9) PB[PT::oWd + ch * 9 + t] = sum;
+            else if (t == 9) PB[PT::oBd + ch] = sum;
+            else PB[PT::oB1 + ch] = sum;
+        }
     }
+    BSTAMP(12);
 }
 
 // --------------------------------------------------------------------------------------------------------------------- launch 3
@@ -712,6 +790,10 @@ int ffn_bwd_launch(const TcFfnBwd* f, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef TC_FFNB_TIMING
+extern "C" int tc_ffnb_dbg_read(long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ffnb_dbg), sizeof(long long) * 2 * 16 * 16); }
+#endif
 
 extern "C" int tc_ffn_fused_bwd_supported(int C, int dtype) { return C == 64 && (dtype == TC_BF16 || dtype == TC_F16); }
 

@@ -141,6 +141,25 @@ __device__ __forceinline__ tc_f32x2 gelu_cdf_pdf2(tc_f32x2 x, tc_f32x2& pdf) {
     const tc_f32x2 one_m = 1.0f - half_erfc;
     return tc_f32x2{x.x >= 0.f ? one_m.x : half_erfc.x, x.y >= 0.f ? one_m.y : half_erfc.y};
 }
+// The same with the hardware reciprocal (v_rcp_f32, 1 ulp) instead of the correctly rounded one (__frcp_rn expands to the IEEE division
+// sequence, ~10 instructions per element): for the 16-bit storage kernels, where the difference is far below the storage rounding.
+__device__ __forceinline__ tc_f32x2 gelu_cdf_pdf2_fast(tc_f32x2 x, tc_f32x2& pdf) {
+    const tc_f32x2 ax = {fabsf(x.x), fabsf(x.y)};
+    const tc_f32x2 z = ax * 0.70710678118654752440f;
+    const tc_f32x2 nz2 = -z * z;
+    const tc_f32x2 g = {__expf(nz2.x), __expf(nz2.y)};
+    const tc_f32x2 den = z * 0.3275911f + 1.0f;
+    const tc_f32x2 t = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+    tc_f32x2 poly = t * 1.061405429f + (-1.453152027f);
+    poly = poly * t + 1.421413741f;
+    poly = poly * t + (-0.284496736f);
+    poly = poly * t + 0.254829592f;
+    const tc_f32x2 half_erfc = poly * t * g * 0.5f;
+    pdf = g * 0.39894228040143267794f;
+    const tc_f32x2 one_m = 1.0f - half_erfc;
+    return tc_f32x2{x.x >= 0.f ? one_m.x : half_erfc.x, x.y >= 0.f ? one_m.y : half_erfc.y};
+}
+__device__ __forceinline__ tc_f32x2 gelu_f2_fast(tc_f32x2 x) { tc_f32x2 pdf; return x * gelu_cdf_pdf2_fast(x, pdf); }
 __device__ __forceinline__ tc_f32x2 gelu_f2(tc_f32x2 x) { tc_f32x2 pdf; return x * gelu_cdf_pdf2(x, pdf); }
 __device__ __forceinline__ tc_f32x2 gelu_grad_f2(tc_f32x2 x) { tc_f32x2 pdf; const tc_f32x2 cdf = gelu_cdf_pdf2(x, pdf); return cdf + x * pdf; }
 __device__ __forceinline__ float gelu_grad_f(float x) {
