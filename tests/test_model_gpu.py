@@ -478,3 +478,46 @@ def test_evaluation_path_matches_oracle():
     assert dice_from_counts(counts.cpu().numpy()) == eval_dice(ref_counts)
     assert torch.equal(predict_slices(m, sl, batch=2).cpu().long(), ref_pred)       # ragged last batch
     assert not m.training
+
+
+TAPS = ("patch_embed1", "enc0", "enc1", "enc2", "enc3", "bridge1", "bridge2", "bridge3", "bridge4", "dec1")
+
+
+def test_stage_outputs_vs_reference_golden():
+    """Stage-level GPU goldens (SURVEY 8(a) rows a8 `MHCA_stage` and a14 `BridgeBlock_4`): the outputs of the patch
+    embedding, the four encoder stages (MSTr.py:1721,1729,1735,1741), the four bridge layers (:2430, in the reference's per-image
+    [B, 6076, 64] order) and decoder_1 (:2849) of the fp32 HIP path against the reference's own tensors (`tap/*` of model_b2.npz, train
+    mode, B=2).  When whole-model logit parity breaks, this localises the failing stage."""
+    g = load("model_b2.npz")
+    m = _fresh().train()
+    m.capture_taps = True
+    m(torch.from_numpy(seeded_input(2)).to(DEV))
+    torch.cuda.synchronize()
+    assert set(m.taps) == set(TAPS)
+    for k in TAPS:
+        check_packed(g, "tap/" + k, m.taps[k].cpu(), atol=5e-5, scale_rel=2e-5)
+
+
+def test_bf16_error_by_stage_is_reported_and_bounded():
+    """Where the 16-bit path's logit error comes from: bf16 stage outputs against the fp32 HIP path's, as a fraction
+    of each stage's largest value.  The relative error must not jump at any single stage (it grows gradually through the depth of the
+    network -- the logits' 0.08 is the accumulated error of ~200 bf16 layers, not one bad kernel); printed for DESIGN.md section 2."""
+    x = torch.from_numpy(seeded_input(2)).to(DEV)
+    taps = {}
+    for dt in (torch.float32, torch.bfloat16):
+        m = _fresh(dt).train()
+        m.capture_taps = True
+        lg = m(x)
+        torch.cuda.synchronize()
+        taps[dt] = dict(m.taps, logits=lg.float())
+    rel = {}
+    for k in TAPS + ("logits",):
+        a, b = taps[torch.float32][k], taps[torch.bfloat16][k]
+        rel[k] = float((a - b).abs().max() / a.abs().max())
+    print("bf16 vs fp32, max |d| / max |x| per stage: " + ", ".join(f"{k} {v:.4f}" for k, v in rel.items()))
+    prev = None
+    for k in TAPS + ("logits",):
+        assert rel[k] < 0.05, (k, rel)
+        if prev is not None:
+            assert rel[k] < 6.0 * max(rel[prev], 2e-3), (prev, k, rel)       # no single stage multiplies the error
+        prev = k

@@ -282,6 +282,8 @@ class MSTransception(nn.Module):
         self.decoder_0 = _mk_decoder_layer(ioc[0], num_classes, True)
         self.compute_dtype = torch.float32
         self.use_fused_attention = True
+        self.capture_taps = False          # tests: keep copies of the stage outputs of the next forward in self.taps (fp32, reference layouts)
+        self.taps = {}
         self._flat: Optional[torch.Tensor] = None
         self._gflat: Optional[torch.Tensor] = None
         self._flat_lp: Optional[torch.Tensor] = None
@@ -817,6 +819,9 @@ def _forward(M: MSTransception, G: Graph, x: torch.Tensor, B: int, in_ch: int, S
     W, b = _lin(M, G, "backbone.patch_embed1.proj")
     t = G.linear(cols.colslice(0, 147), W, b)
     t = _ln(M, G, t, "backbone.patch_embed1.norm")
+    tap = getattr(M, "capture_taps", False)
+    if tap:
+        M.taps = {"patch_embed1": t.data.float().view(B, sides[0] * sides[0], 64).clone()}
     for i in range(2):
         t = _eff_block(M, G, t, f"backbone.block1.{i}", B, sides[0], sides[0])
     m = _ln(M, G, t, "backbone.norm1", out=stage_map(Xb, 0))
@@ -828,11 +833,21 @@ def _forward(M: MSTransception, G: Graph, x: torch.Tensor, B: int, in_ch: int, S
     # the live gradient bytes) are complete and can travel while the encoder's backward runs.
     G.mark("encoder_done")
     X = Xb
+
+    def image_major(buf: Var) -> torch.Tensor:                     # stage-major [stage][B][tokens][64] -> the reference's [B, 6076, 64]
+        return torch.cat([buf.data[R[s]:R[s + 1]].float().view(B, ntok[s], 64) for s in range(4)], dim=1)
+    if tap:
+        for s in range(4):
+            M.taps[f"enc{s}"] = stage_map(Xb, s).data.float().view(B, sides[s], sides[s], 64 * MULT[s]).clone()
     if M.have_bridge != "None":                                   # MSTr.py:2840
         for li in range(1, 5):
             X = _bridge_layer(M, G, X, li, B, sides, ntok, R, N6)
+            if tap:
+                M.taps[f"bridge{li}"] = image_major(X)
     # decoder
     d3 = _patch_expand(M, G, stage_map(X, 3), "decoder_3.layer_up", B, sides[3], 2)
     d2 = _decoder(M, G, d3, stage_map(X, 2), "decoder_2", B, sides[2], False)
     d1 = _decoder(M, G, d2, stage_map(X, 1), "decoder_1", B, sides[1], False)
+    if tap:
+        M.taps["dec1"] = d1.data.float().view(B, sides[0] * sides[0], d1.cols).clone()
     return _decoder(M, G, d1, stage_map(X, 0), "decoder_0", B, sides[0], True)
