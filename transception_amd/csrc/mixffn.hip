@@ -203,8 +203,10 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p
             // item = (inner row y, pixel pair x0 / x0 + 1, 8-channel group) of this wave's channels, 64 items per round, all rounds in
             // registers at once: a filter row's taps are read from LDS once per tile (not once per item), and every load of the walk
             // precedes its first store
-            constexpr int NRD = 4;
-            const int sg = lane % SG, chw = wave * CW + sg * 8, RW = (TW + 1) >> 1, nitems = TH * RW * SG;
+            constexpr int NRD = 2;                 // rounds held in registers at once (C = 128: two passes of two, or the fc1 fragments spill)
+            const int sg = lane % SG, chw = wave * CW + sg * 8, RW = (TW + 1) >> 1, nitems_all = TH * RW * SG;
+            for (int it00 = 0; it00 < nitems_all; it00 += NRD * 64) {
+            const int nitems = min(nitems_all - it00, NRD * 64);
             int yq[NRD], xq[NRD];
             tc_f32x2 o[NRD][2][4];                               // packed fp32 pairs: two channels per issue slot
             auto up8p = [&](const uint4& r, tc_f32x2* v) __attribute__((always_inline)) {
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p
                 const float4 ba = *reinterpret_cast<const float4*>(wtap + 9 * C4 + chw), bb = *reinterpret_cast<const float4*>(wtap + 9 * C4 + chw + 4);
 #pragma unroll
                 for (int q = 0; q < NRD; ++q) {
-                    const int it = q * 64 + lane, run = it < nitems ? it / SG : 0;
+                    const int it = q * 64 + lane, run = it < nitems ? (it00 + it) / SG : 0;
                     yq[q] = run / RW; xq[q] = (run - yq[q] * RW) * 2;
 #pragma unroll
                     for (int r = 0; r < 2; ++r) { o[q][r][0] = tc_f32x2{ba.x, ba.y}; o[q][r][1] = tc_f32x2{ba.z, ba.w}; o[q][r][2] = tc_f32x2{bb.x, bb.y}; o[q][r][3] = tc_f32x2{bb.z, bb.w}; }
@@ -276,6 +278,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p
                     if (live && x0 + r < TW)
                         *reinterpret_cast<uint4*>(hs + (y * HW2 + x0 + r) * PH + chw) =
                             make_uint4(pack2<H>(o[q][r][0].x, o[q][r][0].y), pack2<H>(o[q][r][1].x, o[q][r][1].y), pack2<H>(o[q][r][2].x, o[q][r][2].y), pack2<H>(o[q][r][3].x, o[q][r][3].y));
+            }
             }
         }
         FSTAMP(2);
