@@ -20,9 +20,16 @@ Pinning:
     row and column of image and label are zero) -- tests check the restatement against scipy and against
     tests/golden/data_pipeline.npz, which was produced by running the reference's own RandomGenerator.
   * rot90/flip and order-0 rotate: pinned by the same fixture.
-  * the imgaug family (Flipud/Fliplr/AdditiveGaussianNoise/GaussianBlur/LinearContrast/Affine x4/PiecewiseAffine): imgaug is
-    NOT in this image and cannot be imported, so that stage is "parity unpinned": `augment_slice` below defines the arithmetic
-    the HIP kernel has to match (scipy-style order-1 sampling, cval 0), it is not checked against imgaug.
+  * the imgaug family (Flipud/Fliplr/AdditiveGaussianNoise/GaussianBlur/LinearContrast/Affine x4/PiecewiseAffine): imgaug
+    (requirements: imgaug 0.4.0) is NOT in this image and cannot be imported, so that stage is "parity unpinned": `augment_slice`
+    below defines the arithmetic the HIP kernel has to match, it is not checked against imgaug.  What follows imgaug 0.4's
+    published algorithm: the drawn augmenters are applied ONE AFTER THE OTHER in the drawn order (`SomeOf(random_order=True)`),
+    every geometric one with its own order-1 resampling of the image (order 0 for the segmentation map) and cval 0
+    (`Affine(order=1, cval=0, mode="constant")` defaults -> cv2.warpAffine INTER_LINEAR / BORDER_CONSTANT); transforms are taken
+    about the pixel-centre midpoint ((w - 1) / 2, (h - 1) / 2) (imgaug's `_AffineMatrixGenerator`: shift = size / 2 - 0.5); the
+    flips are array flips (exact).  What is NOT restated: cv2.warpAffine's fixed-point source coordinates (interpolation tables
+    of 1/32 pixel) and skimage's per-triangle `PiecewiseAffineTransform` (here: bilinear interpolation of the 4x4 control-point
+    displacements).
 """
 import math
 
@@ -201,6 +208,10 @@ def augment_slice(image: np.ndarray, label: np.ndarray, aug: dict):
     plus the optional 4x4 control-point displacement), then the pixel stages -- Gaussian blur sigma 1, linear contrast
     center + alpha (v - center), additive Gaussian noise -- in the order `pixel_order` gives (default blur -> contrast -> noise).  `aug` keys: m (6 floats), order (0|1), disp (32 floats or None),
     blur (bool), alpha, center, noise_sigma, noise_seed.  The label is always sampled order 0 and gets no intensity change."""
+    if "stages" in aug:                          # a chain of single-augmenter stages, each resampling the previous one's result:
+        for st in aug["stages"]:                 # what imgaug's SomeOf(random_order=True) does (dataset_synapse.py:84-95)
+            image, label = augment_slice(image, label, st)
+        return image.astype(np.float32), label
     h, w = image.shape
     m = np.asarray(aug.get("m", (1, 0, 0, 0, 1, 0)), np.float64)
     yy, xx = np.meshgrid(np.arange(h, dtype=np.float64), np.arange(w, dtype=np.float64), indexing="ij")

@@ -102,12 +102,15 @@ def test_reference_fixture_through_the_device():
 def _augment_on_device(img, lab, augs):
     B, H, W = img.shape
     d_img, d_lab = _dev(img, lab)
-    rec = torch.from_numpy(D.pack_records(augs)).to(DEV)
-    oi, ol = torch.empty_like(d_img), torch.empty_like(d_lab)
-    lib().tc_slice_augment(d_img.data_ptr(), d_lab.data_ptr(), rec.data_ptr(), oi.data_ptr(), ol.data_ptr(), B, H, W,
-                           torch.cuda.current_stream().cuda_stream)
+    rec_np, n = D.pack_rounds(augs)                                  # one launch per round of the slices' stage chains
+    rec = torch.from_numpy(rec_np).to(DEV)
+    for r in range(max(n, 1)):
+        oi, ol = torch.empty_like(d_img), torch.empty_like(d_lab)
+        lib().tc_slice_augment(d_img.data_ptr(), d_lab.data_ptr(), rec[r].data_ptr(), oi.data_ptr(), ol.data_ptr(), B, H, W,
+                               torch.cuda.current_stream().cuda_stream)
+        d_img, d_lab = oi, ol
     torch.cuda.synchronize()
-    return oi.cpu().numpy(), ol.cpu().numpy()
+    return d_img.cpu().numpy(), d_lab.cpu().numpy()
 
 
 def test_augmentation_stage_matches_oracle():
@@ -133,6 +136,7 @@ def test_augmentation_stage_matches_oracle():
     sampler = D.AugmentSampler(99)
     augs = explicit + [sampler.sample(H, W) for _ in range(24)]
     assert any(a.pixel_order[:1] == ("noise",) and len(a.pixel_order) > 1 for a in augs)
+    assert any(a.stages is not None and sum(st.warps() for st in a.stages) >= 2 for a in augs)     # chains with two resamplings
     img, lab = _pair(21, H, W, batch=len(augs))
     oi, ol = _augment_on_device(img, lab, augs)
     for b, a in enumerate(augs):

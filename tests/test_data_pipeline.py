@@ -103,14 +103,18 @@ def test_sampler_is_seeded_and_in_range():
     seen = set()
     for _ in range(300):
         x, y = s1.sample(512, 512), s2.sample(512, 512)
-        assert x.names == y.names and x.m == y.m and x.alpha == y.alpha and x.noise_seed == y.noise_seed
-        assert len(x.names) <= 4 and len(set(x.names)) == len(x.names)
-        assert 0.5 <= x.alpha <= 1.5 and x.noise_sigma in (0.0, D.NOISE_SCALE)
+        assert x.names == y.names and len(x.stages) == len(y.stages) <= len(x.names) <= 4 and len(set(x.names)) == len(x.names)
+        for sx, sy in zip(x.stages, y.stages):                       # one stage per drawn augmenter, in the drawn order
+            assert sx.m == sy.m and sx.alpha == sy.alpha and sx.noise_seed == sy.noise_seed and sx.stages is None
+            assert 0.5 <= sx.alpha <= 1.5 and sx.noise_sigma in (0.0, D.NOISE_SCALE)
+            assert sum([sx.warps(), sx.blur, sx.alpha != 1.0, sx.noise_sigma > 0]) == 1      # exactly one operation per stage
+            r = sx.record()
+            assert bool(r.flags & D.TC_AUG_WARP) == sx.warps() and bool(r.flags & D.TC_AUG_BLUR) == sx.blur
         seen.update(x.names)
-        r = x.record()
-        assert bool(r.flags & D.TC_AUG_WARP) == x.warps() and bool(r.flags & D.TC_AUG_BLUR) == x.blur
     assert seen == set(D.AugmentSampler.NAMES)
-    assert D.pack_records([a[0], None]).shape == (2, 200)
+    rec, n = D.pack_rounds([a[0], None])
+    assert rec.shape == (D.MAX_ROUNDS, 2, 200) and n == len(a[0].stages)
+    assert D.pack_records([D.SliceAugmentation(blur=True), None]).shape == (2, 200)
 
 
 def test_synthetic_set_round_trip_and_sharding(tmp_path):

@@ -521,3 +521,32 @@ def test_bf16_error_by_stage_is_reported_and_bounded():
         if prev is not None:
             assert rel[k] < 6.0 * max(rel[prev], 2e-3), (prev, k, rel)       # no single stage multiplies the error
         prev = k
+
+
+def test_fp16_overflow_skips_the_update_and_load_state_dict_refreshes_the_working_copy():
+    """(a) float16 storage runs with a static loss scale; one non-finite gradient must not reach the fp32 master weights,
+    the momentum buffer or the 16-bit working copy -- FusedSGD skips that update (tc_grad_sumsq + the finite test inside the update
+    kernel).  (b) load_state_dict / invalidate_working_copy re-cast the 16-bit working copy in place, so a step captured without its
+    cast launch never reads stale weights."""
+    from transception_amd.train import FusedSGD, SegLoss, train_step
+    m = _fresh(torch.float16).train()
+    opt = FusedSGD(m, lr=0.05)
+    x, y = torch.from_numpy(seeded_input(2)).to(DEV), torch.from_numpy(seeded_labels(2)).to(DEV)
+    train_step(m, SegLoss(9, loss_scale=4096.0), opt, x, y)
+    torch.cuda.synchronize()
+    w0, b0, lp0 = m.flat_parameters().clone(), opt.buf.clone(), m._flat_lp.clone()
+    m.flat_gradients()[12345] = float("inf")
+    opt.step()
+    torch.cuda.synchronize()
+    assert torch.equal(m.flat_parameters(), w0) and torch.equal(opt.buf, b0) and torch.equal(m._flat_lp, lp0)
+    m.flat_gradients()[12345] = 0.0
+    opt.step()
+    torch.cuda.synchronize()
+    assert not torch.equal(m.flat_parameters(), w0) and bool(torch.isfinite(m.flat_parameters()).all())
+    # (b)
+    ptr = m._flat_lp.data_ptr()
+    sd = {k: v + 0.25 if v.dtype.is_floating_point and "running" not in k else v for k, v in m.state_dict().items()}
+    m.load_state_dict(sd, strict=True)
+    torch.cuda.synchronize()
+    assert m._flat_lp.data_ptr() == ptr
+    assert float((m._flat_lp.float() - m.flat_parameters()).abs().max()) < 2e-2        # the copy follows the new master weights

@@ -127,7 +127,11 @@ __global__ void sgd_multi_kernel(float* __restrict__ p, const float* __restrict_
                                  float lr, float mom, float wd, float gscale, int first, const float* __restrict__ lr_dev,
                                  const float* __restrict__ clip_sumsq, float clip_norm, void* __restrict__ lp, int lp_dtype) {
     if (lr_dev) lr = *lr_dev;
-    if (clip_sumsq) gscale *= fminf(clip_norm / (sqrtf(*clip_sumsq) + 1e-6f), 1.0f);      // clip_grad_norm_'s coefficient, clamped to 1
+    if (clip_sumsq) {
+        const float ss = *clip_sumsq;
+        if (!(ss < __builtin_inff())) return;                     // a non-finite gradient (float16 overflow under a static loss scale): skip the
+        gscale *= fminf(clip_norm / (sqrtf(ss) + 1e-6f), 1.0f);   // update -- weights, momentum and the 16-bit copy stay as they were.  Otherwise
+    }                                                             // clip_grad_norm_'s coefficient, clamped to 1 (clip_norm = inf: no clipping)
     const long long off = segs[2 * blockIdx.y], n = segs[2 * blockIdx.y + 1];
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const long long j = off + i;

@@ -98,9 +98,14 @@ def affine_translate(px: float, py: float, h: int, w: int):
     return _xy_forward_to_map(np.array([[1, 0, px * w], [0, 1, py * h], [0, 0, 1]], np.float64), h, w)
 
 
+MAX_ROUNDS = 4                             # SomeOf((0, 4), ...): at most four augmenters per slice (dataset_synapse.py:84)
+
+
 @dataclass
 class SliceAugmentation:
-    """Parameters of one slice's augmentation (one TcSliceAug record)."""
+    """Parameters of one slice's augmentation.  Either ONE stage (one TcSliceAug record: an output->source warp and / or pixel
+    operations), or -- what AugmentSampler draws -- a chain of stages applied one after the other, each with its own resampling
+    (`stages`: one single-stage SliceAugmentation per drawn augmenter, in the drawn order; imgaug resamples once per augmenter)."""
     m: Tuple[float, ...] = IDENTITY
     order: int = 1
     disp: Optional[np.ndarray] = None          # float32 [4,4,2] control-point displacement (dy, dx) in pixels
@@ -111,6 +116,11 @@ class SliceAugmentation:
     noise_seed: int = 0
     names: List[str] = field(default_factory=list)
     pixel_order: Tuple[str, ...] = ()          # the pixel stages ("blur" / "contrast" / "noise") in the order they were drawn
+    stages: Optional[List["SliceAugmentation"]] = None
+
+    def rounds(self) -> List["SliceAugmentation"]:
+        """The launches this slice needs: its chain, or itself as a single stage."""
+        return list(self.stages) if self.stages is not None else [self]
 
     def order_code(self) -> int:
         """TcSliceAug.reserved: the drawn order of the pixel stages as 2-bit codes (0 = canonical blur -> contrast -> noise)."""
@@ -143,6 +153,8 @@ class SliceAugmentation:
 
     def as_dict(self) -> dict:
         """The same parameters in the form oracle/data_oracle.py::augment_slice takes (tests only)."""
+        if self.stages is not None:
+            return {"stages": [st.as_dict() for st in self.stages]}
         return {"m": tuple(self.m) if self.warps() else IDENTITY, "order": self.order,
                 "disp": None if self.disp is None else np.asarray(self.disp, np.float32).reshape(-1),
                 "blur": self.blur, "alpha": self.alpha, "center": self.center, "noise_sigma": self.noise_sigma,
@@ -151,12 +163,14 @@ class SliceAugmentation:
 
 class AugmentSampler:
     """Draws what `iaa.SomeOf((0,4), [...ten augmenters...], random_order=True)` draws (dataset_synapse.py:84-95): between 0 and 4 of
-    the ten augmenters, in random order, each with its own parameter ranges.  The pixel stages (noise / blur / contrast) are applied
-    in the drawn order (noise before a blur is blurred, noise before a contrast change is scaled).  Deviation kept, and stated: the
-    geometric augmenters fold into ONE output->source map in the drawn order and the slice is resampled once (imgaug resamples once
-    per geometric augmenter with cval=0, so its result is a little softer and loses what an intermediate step moved out of frame);
-    PiecewiseAffine becomes a 4x4 control-point displacement field applied as the last geometric step.  imgaug itself is not
-    importable here, so this stage is parity-unpinned (its arithmetic is defined by oracle/data_oracle.py)."""
+    the ten augmenters, in random order, each with its own parameter ranges.  Every drawn augmenter is its own stage, applied in the
+    drawn order with its own resampling (order 1 for the image, order 0 for the label, cval 0), as imgaug does: a later geometric
+    augmenter sees what an earlier one moved out of frame as zeros, and every resampling softens the slice a little; the flips are
+    exact copies.  Coordinates follow imgaug 0.4's pixel-centre convention (transforms about ((w - 1) / 2, (h - 1) / 2), its
+    `_AffineMatrixGenerator` shift of size / 2 - 0.5).  Not restated: cv2.warpAffine's fixed-point coordinates (1/32-pixel
+    interpolation tables) and skimage's per-triangle PiecewiseAffineTransform -- PiecewiseAffine is a 4x4 control-point displacement
+    field interpolated bilinearly.  imgaug itself is not importable here, so this stage stays parity-unpinned (its arithmetic is
+    defined by oracle/data_oracle.py)."""
     NAMES = ("Flipud", "Fliplr", "AdditiveGaussianNoise", "GaussianBlur", "LinearContrast", "Affine.scale", "Affine.rotate",
              "Affine.shear", "PiecewiseAffine", "Affine.translate")
 
@@ -165,37 +179,37 @@ class AugmentSampler:
 
     def sample(self, h: int, w: int) -> SliceAugmentation:
         g = self.rng
-        a = SliceAugmentation()
+        a = SliceAugmentation(stages=[])
         k = int(g.integers(0, 5))
         for idx in g.permutation(10)[:k]:
             name = self.NAMES[int(idx)]
             a.names.append(name)
+            st = SliceAugmentation()
             if name == "Flipud":
                 if g.random() < 0.5:
-                    a.m = compose(a.m, affine_flip(0, h, w))
+                    st.m = affine_flip(0, h, w)                  # (integer source coordinates: an exact copy, as imgaug's array flip)
             elif name == "Fliplr":
                 if g.random() < 0.5:
-                    a.m = compose(a.m, affine_flip(1, h, w))
+                    st.m = affine_flip(1, h, w)
             elif name == "AdditiveGaussianNoise":
-                a.noise_sigma, a.noise_seed = NOISE_SCALE, int(g.integers(0, 2 ** 31 - 1))
-                a.pixel_order += ("noise",)
+                st.noise_sigma, st.noise_seed = NOISE_SCALE, int(g.integers(0, 2 ** 31 - 1))
             elif name == "GaussianBlur":
-                a.blur = True
-                a.pixel_order += ("blur",)
+                st.blur = True
             elif name == "LinearContrast":
-                a.alpha = float(g.uniform(0.5, 1.5))
-                a.pixel_order += ("contrast",)
+                st.alpha = float(g.uniform(0.5, 1.5))
             elif name == "Affine.scale":
-                a.m = compose(a.m, affine_scale(float(g.uniform(0.5, 2.0)), float(g.uniform(0.5, 2.0)), h, w))
+                st.m = affine_scale(float(g.uniform(0.5, 2.0)), float(g.uniform(0.5, 2.0)), h, w)
             elif name == "Affine.rotate":
-                a.m = compose(a.m, affine_rotate_xy(float(g.uniform(-40, 40)), h, w))
+                st.m = affine_rotate_xy(float(g.uniform(-40, 40)), h, w)
             elif name == "Affine.shear":
-                a.m = compose(a.m, affine_shear(float(g.uniform(-16, 16)), h, w))
+                st.m = affine_shear(float(g.uniform(-16, 16)), h, w)
             elif name == "PiecewiseAffine":
-                s = float(g.uniform(0.008, 0.03))
-                a.disp = (g.normal(0.0, 1.0, (4, 4, 2)) * np.array([s * h, s * w])).astype(np.float32)
+                sc = float(g.uniform(0.008, 0.03))
+                st.disp = (g.normal(0.0, 1.0, (4, 4, 2)) * np.array([sc * h, sc * w])).astype(np.float32)
             else:
-                a.m = compose(a.m, affine_translate(float(g.uniform(-0.2, 0.2)), float(g.uniform(-0.2, 0.2)), h, w))
+                st.m = affine_translate(float(g.uniform(-0.2, 0.2)), float(g.uniform(-0.2, 0.2)), h, w)
+            if st.warps() or st.blur or st.alpha != 1.0 or st.noise_sigma > 0.0:
+                a.stages.append(st)
         return a
 
 
@@ -323,10 +337,12 @@ class SynapseSlices:
 # ------------------------------------------------------------------------------------------------ device side
 def preprocess_batch(images: torch.Tensor, labels: torch.Tensor, augs: Optional[Sequence[Optional[SliceAugmentation]]], size: int,
                      mean: float = 0.5, std: float = 0.5, records: Optional[torch.Tensor] = None, scratch: Optional[dict] = None,
-                     out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                     out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, rounds: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Raw slices in HBM -> network input, on the current stream.  images float32 [B,H,W], labels uint8 [B,H,W];
     `augs` one SliceAugmentation (or None) per slice, or None for no augmentation at all; alternatively `records` = the
-    TcSliceAug array already on the device (uint8 [B, sizeof]).  Returns x float32 [B,1,size,size], y int64 [B,size,size]."""
+    TcSliceAug array already on the device (uint8 [B, sizeof], or [MAX_ROUNDS, B, sizeof] with `rounds` of them in use: one
+    tc_slice_augment launch per round, each resampling the previous round's result).  Returns x float32 [B,1,size,size], y int64
+    [B,size,size]."""
     if not images.is_cuda:
         raise RuntimeError("transception_amd.data preprocesses on MI355X only (no CPU fallback)")
     B, H, W = images.shape
@@ -344,11 +360,15 @@ def preprocess_batch(images: torch.Tensor, labels: torch.Tensor, augs: Optional[
         return t
 
     if records is None and augs is not None and any(a is not None for a in augs):
-        records = torch.from_numpy(pack_records(augs)).to(dev)
+        rec_np, rounds = pack_rounds(augs)
+        records = torch.from_numpy(rec_np).to(dev)
     if records is not None:
-        img2, lab2 = buf("aug_img", (B, H, W), torch.float32), buf("aug_lab", (B, H, W), torch.uint8)
-        L.tc_slice_augment(images.data_ptr(), labels.data_ptr(), records.data_ptr(), img2.data_ptr(), lab2.data_ptr(), B, H, W, stream)
-        images, labels = img2, lab2
+        if records.dim() == 2:
+            records, rounds = records.unsqueeze(0), 1
+        for r in range(int(rounds if rounds is not None else records.shape[0])):
+            img2, lab2 = buf(f"aug_img{r & 1}", (B, H, W), torch.float32), buf(f"aug_lab{r & 1}", (B, H, W), torch.uint8)
+            L.tc_slice_augment(images.data_ptr(), labels.data_ptr(), records[r].data_ptr(), img2.data_ptr(), lab2.data_ptr(), B, H, W, stream)
+            images, labels = img2, lab2
     x, y = out if out is not None else (torch.empty((B, 1, size, size), dtype=torch.float32, device=dev),
                                         torch.empty((B, size, size), dtype=torch.int64, device=dev))
     if H != size or W != size:
@@ -363,9 +383,22 @@ def preprocess_batch(images: torch.Tensor, labels: torch.Tensor, augs: Optional[
 
 
 def pack_records(augs: Sequence[Optional[SliceAugmentation]]) -> np.ndarray:
-    """TcSliceAug array as bytes, uint8 [B, sizeof(TcSliceAug)]."""
+    """TcSliceAug array as bytes, uint8 [B, sizeof(TcSliceAug)] (single-stage augmentations)."""
+    assert all(a is None or a.stages is None for a in augs), "chains of stages go through pack_rounds"
     arr = (TcSliceAug * len(augs))(*[(a if a is not None else SliceAugmentation()).record() for a in augs])
     return np.frombuffer(bytes(arr), np.uint8).reshape(len(augs), ctypes.sizeof(TcSliceAug)).copy()
+
+
+def pack_rounds(augs: Sequence[Optional[SliceAugmentation]]) -> Tuple[np.ndarray, int]:
+    """(uint8 [MAX_ROUNDS, B, sizeof(TcSliceAug)], rounds in use): round r holds stage r of every slice's chain (the identity record
+    for a slice with fewer stages: flags 0 copies the slice exactly)."""
+    chains = [(a.rounds() if a is not None else []) for a in augs]
+    n = max([len(c) for c in chains] + [0])
+    assert n <= MAX_ROUNDS
+    out = np.zeros((MAX_ROUNDS, len(augs), ctypes.sizeof(TcSliceAug)), np.uint8)
+    for r in range(n):
+        out[r] = pack_records([c[r] if r < len(c) else None for c in chains])
+    return out, n
 
 
 def epoch_order(n: int, epoch: int, seed: int, shuffle: bool = True) -> np.ndarray:
@@ -377,7 +410,9 @@ def rank_batches(order: np.ndarray, batch_size: int, rank: int, world: int) -> L
     """Global batches of batch_size*world slices (trainer.py:86), rank r taking slices [r*B, (r+1)*B) of each.  ceil(N / global
     batch) batches per epoch, like the reference's DataLoader (drop_last=False, trainer.py:104: 93 iterations for Synapse's 2211
     slices at B=24, and a cosine T_max of max_epochs * 93); the captured step needs full batches, so the last one is completed
-    from the head of the same permutation instead of being short."""
+    from the head of the same permutation instead of being short.  Stated deviation: the reference's last batch of an epoch holds
+    N mod global-batch slices (3 of 24 for Synapse) whose loss is a mean over 3; here those slices share a full batch with
+    global-batch - 3 slices that the epoch has already seen (each of them weighs 1/24, and 21 slices are seen twice per epoch)."""
     gb = batch_size * world
     n = len(order)
     if n == 0:
@@ -432,7 +467,7 @@ class DeviceLoader:
             if st is None:
                 self._staged += 1
                 return (torch.empty((self.B, h, w), dtype=torch.float32).pin_memory(), torch.empty((self.B, h, w), dtype=torch.uint8).pin_memory(),
-                        torch.empty((self.B, ctypes.sizeof(TcSliceAug)), dtype=torch.uint8).pin_memory())
+                        torch.empty((MAX_ROUNDS, self.B, ctypes.sizeof(TcSliceAug)), dtype=torch.uint8).pin_memory())
             if st[0].shape[1:] == (h, w):
                 return st
             self._staged -= 1                                        # slice size changed: drop the set, make a new one
@@ -458,11 +493,13 @@ class DeviceLoader:
                             return self.ds.read_into(int(idxs[j]), img_np[j], lab_np[j])   # raises on a slice of another size
                         names = list(pool.map(fill, range(len(idxs))))
                         augs = [sampler.sample(h, w) for _ in names] if self.augment else None
+                        nr = 0
                         if augs is not None:
-                            rec.copy_(torch.from_numpy(pack_records(augs)))
+                            rec_np, nr = pack_rounds(augs)
+                            rec.copy_(torch.from_numpy(rec_np))
                         while not self._stop.is_set():
                             try:
-                                self.q.put((st, names, augs), timeout=0.1)
+                                self.q.put((st, names, augs, nr), timeout=0.1)
                                 break
                             except queue.Full:
                                 continue
@@ -480,7 +517,7 @@ class DeviceLoader:
             return False
         if isinstance(item, BaseException):
             raise item
-        st, names, augs = item
+        st, names, augs, nr = item
         img, lab, rec = st
         if "host" in slot:
             slot["copied"].synchronize()                             # that copy ran long ago: hand its staging set back
@@ -501,7 +538,7 @@ class DeviceLoader:
                 slot["raw"][2].copy_(rec, non_blocking=True)
             slot["copied"] = torch.cuda.Event()
             slot["copied"].record(self.stream)
-        slot["host"], slot["names"], slot["augs"] = st, names, augs
+        slot["host"], slot["names"], slot["augs"], slot["rounds"] = st, names, augs, nr
         return True
 
     def _prep(self, slot: dict):
@@ -510,8 +547,8 @@ class DeviceLoader:
         main = torch.cuda.current_stream(self.device)
         main.wait_event(slot["copied"])
         d_img, d_lab, d_rec = slot["raw"]
-        slot["x"], slot["y"] = preprocess_batch(d_img, d_lab, None, self.size, records=d_rec if slot["augs"] is not None else None,
-                                                scratch=slot["scratch"], out=slot["out"])
+        slot["x"], slot["y"] = preprocess_batch(d_img, d_lab, None, self.size, records=d_rec if (slot["augs"] is not None and slot["rounds"]) else None,
+                                                scratch=slot["scratch"], out=slot["out"], rounds=slot["rounds"])
         slot["prepped"] = torch.cuda.Event()
         slot["prepped"].record(main)
 

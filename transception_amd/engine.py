@@ -202,8 +202,12 @@ _ZERO_NEED: Dict[Tuple[str, torch.dtype], int] = {}
 
 
 class _ZeroArena:
-    def __init__(self, device, dtype):
+    def __init__(self, device, dtype, shared: bool = True):
+        """shared=False (the TC_STREAMS=1 mode): every request gets its own torch.zeros storage -- Graph._pending keys the events of
+        side-stream weight-gradient kernels by gradient STORAGE, and one arena storage under several gradient buffers would let one
+        buffer's event overwrite another's; the single zero fill would also run on whichever branch stream asked first."""
         self.key = (str(device), dtype)
+        self.shared = shared
         self.device, self.dtype = device, dtype
         self.buf: Optional[torch.Tensor] = None
         self.used = 0
@@ -211,6 +215,8 @@ class _ZeroArena:
 
     def zeros_like(self, t: torch.Tensor) -> torch.Tensor:
         n = (t.numel() + 127) // 128 * 128                       # keep 256-byte alignment of every sub-buffer
+        if not self.shared:
+            return torch.zeros_like(t)
         self.asked += n
         if self.buf is None:
             need = _ZERO_NEED.get(self.key, 0)
@@ -316,7 +322,7 @@ class Graph:
         self.cur = torch.cuda.current_stream(device) if torch.device(device).type == "cuda" else None
         self.stream = self.cur.cuda_stream if self.cur is not None else 0
         self.n_launch = 0
-        self._zeros = _ZeroArena(device, dtype)
+        self._zeros = _ZeroArena(device, dtype, shared=not self.use_streams)
 
     # ------------------------------------------------------------------ memory
     def new(self, rows: int, cols: int, requires_grad: bool = True, covered: bool = False) -> Var:

@@ -338,7 +338,19 @@ class MSTransception(nn.Module):
 
     def load_state_dict(self, *args, **kwargs):
         self._lp_fresh = False                          # weights change under the 16-bit working copy
-        return super().load_state_dict(*args, **kwargs)
+        r = super().load_state_dict(*args, **kwargs)
+        self._recast_working_copy()
+        return r
+
+    def _recast_working_copy(self):
+        """Refresh the 16-bit working copy IN PLACE (same buffer) from the fp32 master weights.  A captured training step (GraphedStep)
+        may have been captured right after a FusedSGD update, i.e. without the cast launch: it reads whatever this buffer holds, so
+        every path that changes the master weights behind the optimiser's back re-casts eagerly instead of relying on the next eager
+        forward."""
+        lp, flat = getattr(self, "_flat_lp", None), getattr(self, "_flat", None)
+        if lp is None or flat is None or not flat.is_cuda or lp.dtype != self.compute_dtype or lp.numel() != flat.numel():
+            return
+        lib().tc_cast(flat.data_ptr(), lp.data_ptr(), flat.numel(), TC_F32, self._tc_dtype(), torch.cuda.current_stream(flat.device).cuda_stream)
 
     def _apply(self, fn, *args, **kwargs):
         self._lp_fresh = False
@@ -351,6 +363,7 @@ class MSTransception(nn.Module):
 
     def invalidate_working_copy(self):
         self._lp_fresh = False
+        self._recast_working_copy()
 
     def flat_gradients(self) -> torch.Tensor:
         return self._gflat

@@ -131,6 +131,7 @@ class FusedSGD:
         self.lr_dev: Optional[torch.Tensor] = None       # device scalar read by the kernel (hipGraph-friendly schedule)
         self._sumsq: Optional[torch.Tensor] = None       # squared gradient norm (clip_norm)
         self.grad_scale = 1.0                            # gradients in the arena are this many times too small (1 / loss scale)
+        self.guard_overflow: Optional[bool] = None       # skip the update when the gradient norm is not finite; None: on for float16 storage
 
     def set_lr(self, lr: float):
         self.lr = lr
@@ -169,7 +170,8 @@ class FusedSGD:
             self._segs_dev = torch.tensor([v for s in segs for v in s], dtype=torch.int64, device=flat.device)
             self._nseg, self._maxlen = len(segs), max(n for _, n in segs)
         sumsq = None
-        if self.clip_norm:
+        guard = self.guard_overflow if self.guard_overflow is not None else M.compute_dtype == torch.float16
+        if self.clip_norm or guard:
             # clip_grad_norm_(max_norm, 2): one reduction kernel for the squared norm (grad-less parameters hold zeros, so the arena's
             # norm is the model's), the coefficient min(1, max_norm / (norm + 1e-6)) is applied inside the update kernel
             if self._sumsq is None:
@@ -181,7 +183,7 @@ class FusedSGD:
         lp = M._flat_lp if (M.compute_dtype != torch.float32 and M._flat_lp is not None and M._flat_lp.dtype == M.compute_dtype) else None
         L.tc_sgd_step_multi(flat.data_ptr(), g.data_ptr(), self.buf.data_ptr(), self._segs_dev.data_ptr(), self._nseg, self._maxlen,
                             float(self.lr), self.lr_dev.data_ptr(), float(self.momentum), float(self.wd), float(grad_scale),
-                            int(self.steps == 0), sumsq, float((self.clip_norm or 0.0) / grad_scale),
+                            int(self.steps == 0), sumsq, float((self.clip_norm or math.inf) / grad_scale),
                             lp.data_ptr() if lp is not None else None, M._tc_dtype() if lp is not None else 0, stream)
         M._lp_fresh = lp is not None
         self.steps += 1
@@ -307,6 +309,7 @@ class GraphedStep:
                  force_split: bool = False):
         self.model, self.loss_fn, self.opt, self.group = model, loss_fn, opt, group
         self.x, self.y = images.clone(), labels.clone().long().contiguous()
+        self._dtype = model.compute_dtype                # the captured launches hold pointers into this storage type's working copy
         opt.grad_scale = 1.0 / getattr(loss_fn, "loss_scale", 1.0)
         self.distributed = comm_on(group)
         self.split = self.distributed or force_split
@@ -383,6 +386,8 @@ class GraphedStep:
     def __call__(self, images: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None, comm: bool = True):
         """comm=False replays the same graphs without the collectives between them (bench.py: the time the all-reduces add to a
         step is the difference; the ranks' parameters diverge, so it is a timing aid only)."""
+        if self.model.compute_dtype != self._dtype:
+            raise RuntimeError("the model's compute dtype changed after this step was captured: capture a new GraphedStep")
         if images is not None and images.data_ptr() != self.x.data_ptr():     # a loader may write straight into self.x / self.y
             self.x.copy_(images, non_blocking=True)
             self.y.copy_(labels, non_blocking=True)

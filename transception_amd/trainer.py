@@ -75,9 +75,7 @@ def trainer_synapse(cfg: TrainConfig, model, snapshot_path: str, volumes: Option
     ds = SynapseSlices(cfg.root_path, cfg.list_dir, split="train")
     loader = DeviceLoader(ds, cfg.batch_size, img_size=cfg.img_size, device=dev, seed=cfg.seed, rank=rank, world=world,
                           augment=cfg.augment, epochs=cfg.max_epochs)
-    per_epoch = len(loader) // cfg.max_epochs
-    if per_epoch == 0:
-        raise ValueError(f"{len(ds)} slices do not fill one global batch of {cfg.batch_size * world}")
+    per_epoch = len(loader) // cfg.max_epochs            # >= 1 for a non-empty set: data.rank_batches completes the last global batch
     max_iterations = cfg.max_epochs * per_epoch
     log("The length of train set is: {}".format(len(ds)))
     log("{} iterations per epoch. {} max iterations ".format(per_epoch, max_iterations))
@@ -132,16 +130,24 @@ def trainer_synapse(cfg: TrainConfig, model, snapshot_path: str, volumes: Option
                     hist["checkpoints"].append(path)
                     log("save model to {}".format(path))
                 if volumes is not None:
-                    # rank 0 evaluates its own replica (the one the checkpoint holds) and shares the two numbers
-                    res = torch.zeros(2, dtype=torch.float64, device=dev)
-                    if rank == 0:
-                        log(f"Running Inference after epoch {epoch_num}")
-                        mean_dice, mean_hd95 = inference(model, volumes(), cfg.num_classes, cfg.img_size, log=log)
-                        res[0], res[1] = mean_dice, mean_hd95
+                    # Every rank evaluates its share of the volumes with the replica the checkpoint holds (rank 0's BatchNorm statistics
+                    # are broadcast first; the weights are identical already) and the per-case sums are all-reduced: no rank sits in a
+                    # collective while another spends minutes in host-side HD95 (a process-group timeout would abort the job).
+                    vols = list(volumes())
+                    if distributed:
+                        for buf in model.buffers():
+                            dist.broadcast(buf, src=0, group=group)
+                        vols = vols[rank::world]
+                    res = torch.zeros(3, dtype=torch.float64, device=dev)
+                    if vols:
+                        if rank == 0:
+                            log(f"Running Inference after epoch {epoch_num}")
+                        mean_dice, mean_hd95 = inference(model, vols, cfg.num_classes, cfg.img_size, log=log)
+                        res[0], res[1], res[2] = mean_dice * len(vols), mean_hd95 * len(vols), len(vols)
                         model.train()
                     if distributed:
-                        dist.broadcast(res, src=0, group=group)
-                    hist["dice"].append(float(res[0]))
-                    hist["hd95"].append(float(res[1]))
+                        dist.all_reduce(res, group=group)
+                    hist["dice"].append(float(res[0] / res[2].clamp(min=1)))
+                    hist["hd95"].append(float(res[1] / res[2].clamp(min=1)))
     hist["iterations"] = iter_num
     return hist
