@@ -336,6 +336,11 @@ def main():
         print(json.dumps(out))
     if comm:
         dist.destroy_process_group()
+        # RCCL writes a version banner through C stdio, which would be flushed to stdout AFTER the JSON line at interpreter exit:
+        # leave without the C-level flush so that stdout holds the one line the driver parses
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 def _graph_replay_us(fn, n: int, dev) -> float:

@@ -1,5 +1,5 @@
 cd /root/repo
-O=gpurun_out/r3_d; rm -rf $O; mkdir -p $O
+O=gpurun_out/ffn_sites; rm -rf $O; mkdir -p $O
 timeout 600 python -m pytest tests/test_ffn_fused_gpu.py -x -q -m gpu 2>&1 | tail -5 > $O/pytest.log
 for cfg in "64 16 56 56 1" "128 16 28 28 1" "128 16 14 14 3"; do
   TC_LIB_PATH=transception_amd/libtc_ffnb.so python scripts/exp/ffnb_timing.py $cfg >> $O/timing.log 2>&1
