@@ -119,3 +119,46 @@ def test_evaluation_zooms_on_device_match_scipy():
     a = evaluate_volume(m, image, label, 9, (64, 64), batch=2)
     b = evaluate_volume(m, image, label, 9, (64, 64), batch=2, host_zoom=True)
     np.testing.assert_allclose(np.array(a), np.array(b), atol=2e-3)
+
+
+def test_inference_dice_and_hd95_vs_the_oracle_pipeline_on_non_224_volumes():
+    """End to end, the path `test.py` exercises (test.py:60-86, utils.py:63-98): multi-slice volumes whose slices are NOT the network
+    size -> order-3 zoom to 224 -> eval-mode forward -> argmax -> order-0 zoom back -> per-class Dice / HD95 -> means over cases.
+    `evaluate.inference` on the MI355X (device zooms, batched slices, tc_argmax_counts) against the same pipeline restated on the CPU:
+    scipy.ndimage.zoom per slice, the oracle's eval-mode forward, numpy argmax, `calculate_metric_percase` with the reference's
+    conventions.  The two forwards differ by ~4e-6 in the logits, so single pixels on class boundaries may flip: Dice within 2e-3,
+    HD95 (a percentile of surface distances) within half a pixel."""
+    from scipy.ndimage import zoom
+    from oracle.transception_oracle import TransCeptionOracle, load_params
+    from transception_amd.evaluate import calculate_metric_percase, inference
+    from transception_amd.seeded_init import seeded_state_dict
+    g = np.random.default_rng(11)
+    vols = []
+    yy, xx = np.meshgrid(np.linspace(-1, 1, 192), np.linspace(-1, 1, 160), indexing="ij")
+    for c in range(2):
+        D = 3 + c
+        image = np.clip(0.4 + 0.3 * np.sin(3 * xx[None] + c) * np.cos(2 * yy[None] - np.arange(D)[:, None, None] * 0.3)
+                        + g.normal(0, 0.05, (D, 192, 160)), 0, 1).astype(np.float32)
+        label = np.zeros((D, 192, 160), np.uint8)
+        for k in range(1, 9):
+            cy, cx, r = g.uniform(-0.6, 0.6), g.uniform(-0.6, 0.6), g.uniform(0.1, 0.3)
+            label[:, ((yy - cy) ** 2 + (xx - cx) ** 2) < r * r] = k
+        vols.append((image, label, f"case{c}"))
+    m = _model().eval()
+    dice_hip, hd_hip = inference(m, vols, 9, 224, batch=4)
+    orc = TransCeptionOracle(load_params(seeded_state_dict(), requires_grad=False), 9, training=False)
+    per_case = []
+    for image, label, _ in vols:
+        pred = np.zeros_like(label)
+        for d in range(image.shape[0]):
+            sl = zoom(image[d], (224 / 192, 224 / 160), order=3)                                   # utils.py:69-70
+            x = torch.from_numpy(((sl.astype(np.float32) - 0.5) / 0.5)[None, None])                # Normalize([0.5], [0.5]), utils.py:71-75
+            with torch.no_grad():
+                out = orc(x)
+            p = out.argmax(1)[0].numpy().astype(np.uint8)                                          # argmax(softmax(.)), utils.py:82
+            pred[d] = zoom(p, (192 / 224, 160 / 224), order=0)                                     # utils.py:83-84
+        per_case.append(np.array([calculate_metric_percase(pred == k, label == k) for k in range(1, 9)]))
+    mean = np.mean(per_case, axis=0).mean(axis=0)                                                  # trainer.py:36-46
+    assert abs(dice_hip - mean[0]) < 2e-3, (dice_hip, mean)
+    assert abs(hd_hip - mean[1]) < 0.5, (hd_hip, mean)
+    assert 0.0 <= dice_hip <= 1.0 and hd_hip >= 0.0
