@@ -335,9 +335,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.batch, args.size)
         print(json.dumps(out))
     if comm:
-        dist.destroy_process_group()
-        # RCCL writes a version banner through C stdio, which would be flushed to stdout AFTER the JSON line at interpreter exit:
-        # leave without the C-level flush so that stdout holds the one line the driver parses
+        # Every rank is done (barrier + device sync), then the process leaves WITHOUT the C++ / C-stdio teardown: RCCL writes a version
+        # banner through C stdio that would be flushed to stdout after the JSON line, and tearing the communicator down while its
+        # watchdog thread is alive has aborted the process once (SIGABRT after a complete, correct run).
+        sync()
         sys.stdout.flush()
         sys.stderr.flush()
         os._exit(0)

@@ -163,7 +163,10 @@ def _workspace(device, stream_ptr: int, tag: str = "") -> torch.Tensor:
     """Split-K fix-up workspace of the kernels launched on `stream_ptr` (include/transception_hip.h, TcGemm.ws): launches on one
     stream never overlap, so one buffer per stream is enough; zeroed once, every launch leaves its counters zero.  `tag`: a
     separate buffer for launches that cut it into per-problem slices (their counter areas must never have held partial tiles)."""
-    key = (str(device), int(stream_ptr or 0), tag)
+    # Single-stream mode (the default): warm-up stream, capture stream and replay stream take turns and never run launches
+    # concurrently, so they share ONE workspace -- a workspace per stream pointer was created (and zero-filled: 134 MB for the
+    # "many" one) INSIDE the capture of a step, whose stream is new, and the fill was replayed with every step.
+    key = (str(device), int(stream_ptr or 0) if Graph.use_streams else 0, tag)
     ws = _WORKSPACES.get(key)
     if ws is None:
         ws = _WORKSPACES[key] = torch.zeros(WORKSPACE_BYTES * (8 if tag == "many" else 1), dtype=torch.uint8, device=device)

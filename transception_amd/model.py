@@ -688,7 +688,7 @@ def _channel_att(M, G, n: Var, X: Optional[Var], name: str, B: int, ntok: List[i
     Op = G.new(B * Cd, N6)
     G.bmm(ctx, qsm, Op, Cd, N6, Cd, 1, 0, nb1=B, sA=(Cd * Cd, 0), sB=(Cd * N6, 0), sC=(Cd * N6, 0))
     o_img = G.transpose(Op, B)                                  # [B*N6, 64], image-major
-    tx1 = G.new(B * N6, Cd)
+    tx1 = G.new(B * N6, Cd, covered=True)                      # (see _self_att)
     Wp = _lin(M, G, name + ".proj")
     many = []
     for s in range(4):
@@ -752,7 +752,8 @@ def _self_att(M, G, n: Var, X: Optional[Var], name: str, B: int, sides: List[int
     else:
         for s in range(4):
             G.attention(q.rowslice(R[s], R[s + 1]), k, v, B, ntok[s], Nk, Cd ** -0.5, out=att.rowslice(R[s], R[s + 1]))
-    return G.linear(att, *_lin(M, G, name + ".proj"), residual=X)
+    # (tx1's gradient is covered: the four per-scale MixFFN residuals write its four row groups before LayerNorm 2's backward adds to it)
+    return G.linear(att, *_lin(M, G, name + ".proj"), residual=X, out=G.new(B * N6, Cd, covered=True))
 
 
 def _bridge_layer(M, G, X: Var, li: int, B: int, sides, ntok, R, N6) -> Var:
@@ -763,7 +764,7 @@ def _bridge_layer(M, G, X: Var, li: int, B: int, sides, ntok, R, N6) -> Var:
         tx1 = _channel_att(M, G, n, X, name + ".attn", B, ntok, R, N6)
     else:
         tx1 = _self_att(M, G, n, X, name + ".attn", B, sides, ntok, R, N6)
-    tx = _ln(M, G, tx1, name + ".norm2")
+    tx = _ln(M, G, tx1, name + ".norm2", out=G.new(B * N6, 64, covered=True))    # gradient = the four MixFFN input gradients, row group by row group
     tx2 = G.new(B * N6, 64)
     geo = [(B * sides[s] * sides[s], 64 * MULT[s]) for s in range(4)]
     view = lambda v, s: v.rowslice(R[s], R[s + 1]).reshape(*geo[s])
