@@ -249,6 +249,29 @@ int tc_ffn_fused_bwd_supported(int C, int dtype);
 long long tc_ffn_fused_bwd_scratch_floats(int C, int groups);
 int tc_ffn_fused_bwd(const TcFfnBwd* f, int dtype, void* stream);
 
+/* ---- EfficientAttention block: out = t + reproj(softmax_c(Q) . (softmax_n(K)^T V)) with K | Q | V = LayerNorm(t) W^T + b ----
+ * Replaces, for C = 64 and one head, MSTr.py:80-143 (EfficientAttention.forward: keys / queries / values 1x1 convolutions,
+ * softmax over the tokens for the keys, over the channels for the queries, context = key @ value^T, attended = context^T @ query,
+ * reprojection) together with its caller's LayerNorm and residual (MSTr.py:166-167: tx = x + attn(norm1(x))), forward and backward.
+ * t / out / dout / dt: [B * N, C] token maps of the storage type with leading dimensions ldt / ldo / lddo / lddt (elements).
+ * ctx [B][C][C] and kstat [B][2][C] (column maximum and sum of the keys' softmax) are fp32 outputs of the forward that the backward
+ * reads; part is fp32 scratch of tc_effatt_scratch_floats(C, B, N) floats; g1 a [B * N, C] scratch map of the storage type.
+ * The backward ADDS into the fp32 gradient arrays (dw* [C][C], db* / dgamma / dbeta [C]); dt is overwritten, or added to when acc_dt.
+ * Seven launches in all (3 forward, 4 backward) on `stream`.  TC_ERR_ARG for anything unsupported (use tc_effatt_supported). */
+typedef struct TcEffAtt {
+    const void* t; const void* gamma; const void* beta;
+    const void* wk; const void* bk; const void* wq; const void* bq; const void* wv; const void* bv; const void* wr; const void* br;
+    void* out; float* ctx; float* kstat; float* part; long long part_floats;
+    const void* dout; void* dt; void* g1;
+    float* dgamma; float* dbeta; float* dwk; float* dbk; float* dwq; float* dbq; float* dwv; float* dbv; float* dwr; float* dbr;
+    int ldt, ldo, lddo, lddt, acc_dt, C, B, N;
+    float eps;
+} TcEffAtt;
+int tc_effatt_supported(int C, int dtype);
+long long tc_effatt_scratch_floats(int C, int B, int N);
+int tc_effatt_fwd(const TcEffAtt* f, int dtype, void* stream);
+int tc_effatt_bwd(const TcEffAtt* f, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * BatchNorm2d over token rows ([rows, C], statistics over rows) fused with its activation and an
  * optional residual add:  y = act((x-mean)*rstd*gamma+beta) (+ res).

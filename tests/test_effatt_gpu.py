@@ -1,0 +1,98 @@
+"""Fused EfficientAttention block (tc_effatt_fwd / tc_effatt_bwd) against a plain torch fp32 statement of
+MSTr.py:80-143 + :166-167  (tx = x + attn(norm1(x)), one head).  Tolerances: the maps are stored in bf16 / fp16
+(2^-8 / 2^-11 relative) and pass through five chained 64-deep products; 2 % (bf16) and 0.5 % (fp16) of the
+reference's maximum per tensor, stated per assert."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(t, P, B, N, eps=1e-5):
+    c = t.shape[1]
+    n1 = torch.nn.functional.layer_norm(t, (c,), P["gamma"], P["beta"], eps)
+    k = (n1 @ P["wk"].t() + P["bk"]).view(B, N, c)
+    q = (n1 @ P["wq"].t() + P["bq"]).view(B, N, c)
+    v = (n1 @ P["wv"].t() + P["bv"]).view(B, N, c)
+    ksm = torch.softmax(k, dim=1)            # over the tokens (MSTr.py:117 softmax(dim=2) of [B, C, N])
+    qsm = torch.softmax(q, dim=2)            # over the channels (MSTr.py:119 softmax(dim=1) of [B, C, N])
+    ctx = ksm.transpose(1, 2) @ v            # [B, C, C]   (MSTr.py:122 key @ value^T)
+    att = qsm @ ctx                          # [B, N, C]   (MSTr.py:123 context^T @ query)
+    out = att.reshape(B * N, c) @ P["wr"].t() + P["br"] + t
+    return out, ctx
+
+
+NAMES = ["gamma", "beta", "wk", "bk", "wq", "bq", "wv", "bv", "wr", "br"]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,N", [(2, 3136), (3, 200), (1, 32), (2, 257)])
+def test_effatt_fused_forward_and_backward_vs_torch_fp32(dtype, B, N):
+    from transception_amd import _lib
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    c = 64
+    g = torch.Generator(device="cpu").manual_seed(5 + N)
+    P32 = {}
+    for n in NAMES:
+        shape = (c, c) if n.startswith("w") else (c,)
+        scale = 0.25 if n.startswith("w") else 0.3
+        P32[n] = (torch.randn(shape, generator=g) * scale + (1.0 if n == "gamma" else 0.0))
+    t32 = torch.randn(B * N, c, generator=g) * 1.5
+    dy32 = torch.randn(B * N, c, generator=g)
+    Pl = {n: P32[n].to(dev, dtype).contiguous() for n in NAMES}
+    tl, dyl = t32.to(dev, dtype).contiguous(), dy32.to(dev, dtype).contiguous()
+    # the reference sees exactly the stored (rounded) inputs, in fp32
+    Pr = {n: Pl[n].float().requires_grad_(True) for n in NAMES}
+    tr = tl.float().requires_grad_(True)
+    out_r, ctx_r = _ref(tr, Pr, B, N)
+    out_r.backward(dyl.float())
+
+    nfl = L.tc_effatt_scratch_floats(c, B, N)
+    part = torch.empty(nfl, device=dev, dtype=torch.float32)
+    out = torch.empty_like(tl)
+    ctx = torch.empty(B, c, c, device=dev, dtype=torch.float32)
+    kstat = torch.empty(B, 2, c, device=dev, dtype=torch.float32)
+    dt = torch.empty_like(tl)
+    g1 = torch.empty_like(tl)
+    G = {n: torch.zeros_like(P32[n], device=dev, dtype=torch.float32) for n in NAMES}
+    f = _lib.TcEffAtt()
+    f.t = tl.data_ptr(); f.gamma = Pl["gamma"].data_ptr(); f.beta = Pl["beta"].data_ptr()
+    for n in ("wk", "bk", "wq", "bq", "wv", "bv", "wr", "br"):
+        setattr(f, n, Pl[n].data_ptr())
+    f.out = out.data_ptr(); f.ctx = ctx.data_ptr(); f.kstat = kstat.data_ptr(); f.part = part.data_ptr(); f.part_floats = nfl
+    f.dout = dyl.data_ptr(); f.dt = dt.data_ptr(); f.g1 = g1.data_ptr()
+    f.dgamma = G["gamma"].data_ptr(); f.dbeta = G["beta"].data_ptr()
+    for n in ("wk", "bk", "wq", "bq", "wv", "bv", "wr", "br"):
+        setattr(f, "d" + n, G[n].data_ptr())
+    f.ldt = f.ldo = f.lddo = f.lddt = c
+    f.acc_dt = 0; f.C = c; f.B = B; f.N = N; f.eps = 1e-5
+    dt_code = _lib.dtype_code(dtype) if hasattr(_lib, "dtype_code") else {torch.bfloat16: 1, torch.float16: 2}[dtype]
+    s = torch.cuda.current_stream().cuda_stream
+    L.tc_effatt_fwd(C.byref(f), dt_code, s)
+    torch.cuda.synchronize()
+    tol = 0.02 if dtype == torch.bfloat16 else 0.005
+
+    def close(a, b, name, k=1.0, scale=None):
+        err = float((a.float() - b.float()).abs().max()) / max(float(b.float().abs().max()) if scale is None else scale, 1e-6)
+        assert err < tol * k, f"{name}: {err:.4f} (budget {tol * k})"
+
+    close(ctx, ctx_r.detach(), "ctx")
+    close(out, out_r.detach(), "out")
+    L.tc_effatt_bwd(C.byref(f), dt_code, s)
+    torch.cuda.synchronize()
+    close(dt, tr.grad, "dt")
+    for n in NAMES:
+        # d(bk) is zero in exact arithmetic (the softmax over the tokens ignores a per-channel shift of the keys): what is left is
+        # the rounding of sum_n dK, measured on the scale of the same sum weighted by the O(1) tokens, dWk
+        close(G[n], Pr[n].grad, "d" + n, 1.5, float(Pr["wk"].grad.abs().max()) if n == "bk" else None)
+    # accumulate form: dt += ...
+    f.acc_dt = 1
+    before = dt.clone()
+    for n in NAMES:
+        G[n].zero_()
+    L.tc_effatt_bwd(C.byref(f), dt_code, s)
+    torch.cuda.synchronize()
+    close(dt, 2 * tr.grad, "dt (accumulated)", 1.5)

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("TC_LIB_PATH") or os.path.join(HERE, "libtransception_
 
 TC_F32, TC_BF16, TC_F16 = 0, 1, 2
 ACT_NONE, ACT_HSWISH, ACT_COORD, ACT_SIGMOID, ACT_GELU = 0, 1, 2, 3, 4
-ABI_VERSION = 7
+ABI_VERSION = 8
 ATTN_DKV_SPLITS = 8                # include/transception_hip.h: partial dK|dV buffers in tc_attn_bwd_seg's fp32 scratch
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_longlong, C.c_float
@@ -66,6 +66,16 @@ class TcFfnBwd(C.Structure):
                 ("eps", f32), ("tile_h", i32), ("tile_w", i32)]
 
 
+class TcEffAtt(C.Structure):
+    _fields_ = [("t", vp), ("gamma", vp), ("beta", vp),
+                ("wk", vp), ("bk", vp), ("wq", vp), ("bq", vp), ("wv", vp), ("bv", vp), ("wr", vp), ("br", vp),
+                ("out", vp), ("ctx", vp), ("kstat", vp), ("part", vp), ("part_floats", i64),
+                ("dout", vp), ("dt", vp), ("g1", vp),
+                ("dgamma", vp), ("dbeta", vp), ("dwk", vp), ("dbk", vp), ("dwq", vp), ("dbq", vp), ("dwv", vp), ("dbv", vp), ("dwr", vp), ("dbr", vp),
+                ("ldt", i32), ("ldo", i32), ("lddo", i32), ("lddt", i32), ("acc_dt", i32), ("C", i32), ("B", i32), ("N", i32),
+                ("eps", f32)]
+
+
 class TcEwSeg(C.Structure):
     _fields_ = [("kind", i32), ("flag", i32), ("a", vp), ("b", vp), ("sa", i64), ("sb", i64),
                 ("lda", i32), ("ldb", i32), ("n0", i32), ("n1", i32), ("n2", i32), ("n3", i32), ("n4", i32), ("reserved", i32)]
@@ -107,6 +117,10 @@ SIGNATURES = {
     "tc_ffn_fused_bwd_supported": [i32, i32],
     "tc_ffn_fused_bwd_scratch_floats": [i32, i32],
     "tc_ffn_fused_bwd": [C.POINTER(TcFfnBwd), i32, vp],
+    "tc_effatt_supported": [i32, i32],
+    "tc_effatt_scratch_floats": [i32, i32, i32],
+    "tc_effatt_fwd": [C.POINTER(TcEffAtt), i32, vp],
+    "tc_effatt_bwd": [C.POINTER(TcEffAtt), i32, vp],
     "tc_bn_scratch_floats": [i32, i32],
     "tc_bn_fwd": [vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, f32, f32, i32, i32, i32, vp],
     "tc_bn_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp],
@@ -149,8 +163,8 @@ SIGNATURES = {
     "tc_fill_f32": [vp, i64, f32, vp],
     "tc_cast": [vp, vp, i64, i32, i32, vp],
 }
-_RET = {"tc_ffn_fused_bwd_scratch_floats": i64, "tc_bn_scratch_floats": i64, "tc_softmax_scratch_floats": i64, "tc_layernorm_bwd_scratch_floats": i64, "tc_factor_att_stats_floats": i64}
-_RAW = {"tc_abi_version", "tc_ffn_chunk", "tc_ffn_fused_supported", "tc_ffn_fused_bwd_supported", "tc_ffn_fused_bwd_scratch_floats", "tc_bn_scratch_floats", "tc_softmax_scratch_floats", "tc_layernorm_bwd_scratch_floats", "tc_factor_att_stats_floats"}     # not status-returning
+_RET = {"tc_ffn_fused_bwd_scratch_floats": i64, "tc_effatt_scratch_floats": i64, "tc_bn_scratch_floats": i64, "tc_softmax_scratch_floats": i64, "tc_layernorm_bwd_scratch_floats": i64, "tc_factor_att_stats_floats": i64}
+_RAW = {"tc_abi_version", "tc_effatt_supported", "tc_effatt_scratch_floats", "tc_ffn_chunk", "tc_ffn_fused_supported", "tc_ffn_fused_bwd_supported", "tc_ffn_fused_bwd_scratch_floats", "tc_bn_scratch_floats", "tc_softmax_scratch_floats", "tc_layernorm_bwd_scratch_floats", "tc_factor_att_stats_floats"}     # not status-returning
 
 
 class TcError(RuntimeError):
