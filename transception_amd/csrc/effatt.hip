@@ -27,10 +27,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef short s16x8_t __attribute__((ext_vector_type(8)));
 
-constexpr int C = 64, PT = C + 8, TPW = 256, NBLK = TPW / 32;      // channels, LDS row pitch (elements), tokens per wave, 32-token blocks
-constexpr int F_M = 0, F_S = C, F_P = 2 * C, F_N = 2 * C + C * C;                       // forward partial of a wave
+constexpr int C = 64, PT = C + 8, TPW = 256, NW = 4, RT = 32 * NW, NRD = TPW / RT;     // channels, LDS row pitch, tokens per workgroup, waves, tokens per round, rounds
+constexpr int TOUT = RT;                                                                    // tokens per workgroup of the forward's output launch
+constexpr int F_M = 0, F_S = C, F_P = 2 * C, F_N = 2 * C + C * C;                       // forward partial of a workgroup
 constexpr int B1_DCTX = 0, B1_DWR = C * C, B1_DWQ = 2 * C * C, B1_DBR = 3 * C * C, B1_DBQ = B1_DBR + C, B1_N = B1_DBQ + C;
 constexpr int B2_DWK = 0, B2_DWV = C * C, B2_DBK = 2 * C * C, B2_DBV = B2_DBK + C, B2_DG = B2_DBV + C, B2_DB = B2_DG + C, B2_N = B2_DB + C;
+constexpr int SCW = 64 * 33;                                                                // a wave's column-reduction scratch (floats)
 
 struct EffDev {
     const void* t; const void* gamma; const void* beta;
@@ -46,21 +48,23 @@ template <typename V8> __device__ __forceinline__ V8 ld_tr(const bf16_t* lo, con
     const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(hi));
     return __builtin_bit_cast(V8, (s16x8_t)__builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
 }
-
 template <typename H> __device__ __forceinline__ void up8s(const uint4& r, float* o) {
     unpack2<H>(r.x, o[0], o[1]); unpack2<H>(r.y, o[2], o[3]); unpack2<H>(r.z, o[4], o[5]); unpack2<H>(r.w, o[6], o[7]);
 }
 // Lane geometry of a wave: D^T tiles put token l31 on the lane and channels cb * 32 + 8 gq + 4 hh + j in register 4 gq + j of acc[cb].
-struct Lane { int lane, l31, hh, gi, gq2; };
-__device__ __forceinline__ Lane lane_of() { Lane L; L.lane = threadIdx.x & 63; L.l31 = L.lane & 31; L.hh = L.lane >> 5; L.gi = L.lane & 15; L.gq2 = (L.lane >> 4) & 1; return L; }
+struct Lane { int lane, l31, hh, gi, gq2, wv; };
+__device__ __forceinline__ Lane lane_of() {
+    Lane L; L.lane = threadIdx.x & 63; L.wv = threadIdx.x >> 6; L.l31 = L.lane & 31; L.hh = L.lane >> 5; L.gi = L.lane & 15; L.gq2 = (L.lane >> 4) & 1;
+    return L;
+}
 
-template <typename H> __device__ __forceinline__ void zero2(f32x16 (&a)[2]) {
+__device__ __forceinline__ void zero2(f32x16 (&a)[2]) {
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) a[cb][r] = 0.f;
 }
-// acc^T[o][tok] += sum_k W[o][k] X[tok][k]:  W rows = output channel (k contiguous), X rows = tokens; both 16-byte fragment reads
+// acc^T[o][tok] += sum_k W[o][k] X[tok][k]:  W rows = output channel (k contiguous), X rows = this wave's 32 tokens; 16-byte fragment reads
 template <typename H> __device__ __forceinline__ void mm_w(const bf16_t* W, const bf16_t* X, const Lane& L, f32x16 (&acc)[2]) {
     using V8 = typename TcHalf<H>::v8;
 #pragma unroll
@@ -81,25 +85,19 @@ template <typename H> __device__ __forceinline__ void mm_wt(const bf16_t* W, con
         for (int cb = 0; cb < 2; ++cb) acc[cb] = TcHalf<H>::mfma(ld_tr<V8>(wp + cb * 32, wp + 4 * PT + cb * 32), xv, acc[cb]);
     }
 }
-// out[i][j] += sum_tok X[tok][i] Y[tok][j] over the 32 tokens of a block (both tiles in LDS, rows = tokens): 2 x 2 tiles of 32 x 32
-template <typename H> __device__ __forceinline__ void mm_tok(const bf16_t* X, const bf16_t* Y, const Lane& L, f32x16 (&acc)[2][2]) {
+// acc[i][j] += sum_tok X[tok][32 ib + i] Y[tok][32 jb + j] over the RT tokens of a round (both tiles in LDS, rows = tokens)
+template <typename H> __device__ __forceinline__ void mm_tok(const bf16_t* X, const bf16_t* Y, int ib, int jb, const Lane& L, f32x16& acc) {
     using V8 = typename TcHalf<H>::v8;
+    const int col = 16 * L.gq2 + 4 * (L.gi & 3);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        const int row = 16 * ks + 8 * L.hh + (L.gi >> 2), col = 16 * L.gq2 + 4 * (L.gi & 3);
-        V8 a[2], b[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            a[q] = ld_tr<V8>(X + row * PT + q * 32 + col, X + (row + 4) * PT + q * 32 + col);
-            b[q] = ld_tr<V8>(Y + row * PT + q * 32 + col, Y + (row + 4) * PT + q * 32 + col);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = TcHalf<H>::mfma(a[i], b[j], acc[i][j]);
+    for (int ks = 0; ks < RT / 16; ++ks) {
+        const int row = 16 * ks + 8 * L.hh + (L.gi >> 2);
+        const V8 a = ld_tr<V8>(X + row * PT + ib * 32 + col, X + (row + 4) * PT + ib * 32 + col);
+        const V8 b = ld_tr<V8>(Y + row * PT + jb * 32 + col, Y + (row + 4) * PT + jb * 32 + col);
+        acc = TcHalf<H>::mfma(a, b, acc);
     }
 }
-// a D^T pair of tiles -> the wave's LDS tile [32 tokens][PT] in the storage type
+// a D^T pair of tiles -> the wave's 32 rows of an LDS tile in the storage type
 template <typename H> __device__ __forceinline__ void put_T(bf16_t* X, const Lane& L, const f32x16 (&acc)[2]) {
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
@@ -108,7 +106,19 @@ template <typename H> __device__ __forceinline__ void put_T(bf16_t* X, const Lan
             *reinterpret_cast<uint2*>(X + L.l31 * PT + cb * 32 + 8 * gq + 4 * L.hh) =
                 make_uint2(pack2<H>(acc[cb][4 * gq], acc[cb][4 * gq + 1]), pack2<H>(acc[cb][4 * gq + 2], acc[cb][4 * gq + 3]));
 }
-// per-channel vector (bias, gamma, ...) in the D^T register order, from an fp32 LDS array
+// the wave's 32 rows of an LDS tile, added to a D^T pair of tiles
+template <typename H> __device__ __forceinline__ void add_T(const bf16_t* X, const Lane& L, f32x16 (&acc)[2]) {
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const uint2 tv = *reinterpret_cast<const uint2*>(X + L.l31 * PT + cb * 32 + 8 * gq + 4 * L.hh);
+            float t0, t1, t2, t3;
+            unpack2<H>(tv.x, t0, t1); unpack2<H>(tv.y, t2, t3);
+            acc[cb][4 * gq] += t0; acc[cb][4 * gq + 1] += t1; acc[cb][4 * gq + 2] += t2; acc[cb][4 * gq + 3] += t3;
+        }
+}
+// per-channel vector (bias, ...) in the D^T register order, from an fp32 LDS array
 __device__ __forceinline__ void get_vecT(const float* v, const Lane& L, f32x16 (&o)[2]) {
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
@@ -118,40 +128,40 @@ __device__ __forceinline__ void get_vecT(const float* v, const Lane& L, f32x16 (
             o[cb][4 * gq] = q.x; o[cb][4 * gq + 1] = q.y; o[cb][4 * gq + 2] = q.z; o[cb][4 * gq + 3] = q.w;
         }
 }
-__device__ __forceinline__ int chan_of(int cb, int r, int hh) { return cb * 32 + 8 * (r >> 2) + 4 * hh + (r & 3); }
-// sum over the 32 token lanes of a half-wave of the 16 registers of one tile: afterwards lane l holds the total of register l & 15
-__device__ __forceinline__ float fold16(const f32x16& t, int lane) {
-    float v[16];
+// Column reductions over the 32 token lanes through the wave's scratch: every lane parks its 32 per-channel values, then lane j
+// gathers channel j.  D^T order: value e = 16 cb + r of lane (l31, hh) is channel cb * 32 + 8 (r >> 2) + 4 hh + (r & 3).
+template <bool MAX> __device__ __forceinline__ float colred_T(float* sc, const f32x16 (&a)[2], const Lane& L) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = t[r] + __shfl_xor(t[r], 16, 64);
+    for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-    for (int m = 8, n = 16; m >= 1; m >>= 1, n >>= 1) {
-        const bool up = (lane & m) != 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (j < n / 2) { const float keep = up ? v[j + n / 2] : v[j], send = up ? v[j] : v[j + n / 2]; v[j] = keep + __shfl_xor(send, m, 64); }
-    }
-    return v[0];
+        for (int r = 0; r < 16; ++r) sc[L.lane * 33 + cb * 16 + r] = a[cb][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    const int cb = L.lane >> 5, c5 = L.lane & 31, hh = (c5 >> 2) & 1, e = cb * 16 + 4 * (c5 >> 3) + (c5 & 3);
+    float s = MAX ? -3.0e38f : 0.f;
+#pragma unroll 8
+    for (int l = 0; l < 32; ++l) { const float v = sc[(hh * 32 + l) * 33 + e]; s = MAX ? fmaxf(s, v) : s + v; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    return s;
 }
-// the column sums of a D^T pair of tiles -> part[chan] (one writer per channel)
-__device__ __forceinline__ void put_colsum(float* dst, const f32x16 (&a)[2], const Lane& L) {
+// row order: value e of lane (l31, hh) is channel hh * 32 + e
+__device__ __forceinline__ float colsum_row(float* sc, const float* v, const Lane& L) {
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        const float s = fold16(a[cb], L.lane);
-        if (L.l31 < 16) dst[chan_of(cb, L.l31, L.hh)] = s;
-    }
+    for (int e = 0; e < 32; ++e) sc[L.lane * 33 + e] = v[e];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    const int hh = L.lane >> 5, e = L.lane & 31;
+    float s = 0.f;
+#pragma unroll 8
+    for (int l = 0; l < 32; ++l) s += sc[(hh * 32 + l) * 33 + e];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    return s;
 }
-// a 2 x 2 set of D tiles (rows i, columns j) -> part[i * C + j]
-__device__ __forceinline__ void put_mat(float* dst, const f32x16 (&a)[2][2], const Lane& L) {
+// one D tile (rows i, columns j) -> dst[i * C + j]
+__device__ __forceinline__ void put_tile(float* dst, int ib, int jb, const f32x16& a, const Lane& L) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dst[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * L.hh) * C + j * 32 + L.l31] = a[i][j][r];
+    for (int r = 0; r < 16; ++r) dst[(ib * 32 + (r & 3) + 8 * (r >> 2) + 4 * L.hh) * C + jb * 32 + L.l31] = a[r];
 }
 
-// 32 token rows of a [rows, ld] map -> LDS tile (zero rows beyond the image's tokens)
+// 32 token rows of a [rows, ld] map -> the wave's rows of an LDS tile (zero rows beyond the image's tokens)
 template <typename H> __device__ __forceinline__ void load_tile(bf16_t* X, const H* src, long long row0, int ld, int nvalid, int lane) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -167,26 +177,31 @@ template <typename H> __device__ __forceinline__ void store_tile(const bf16_t* X
         if (r < nvalid) *reinterpret_cast<uint4*>(dst + (row0 + r) * ld + cg * 8) = *reinterpret_cast<const uint4*>(X + r * PT + cg * 8);
     }
 }
-// weights [C][C] (storage type) -> LDS [C][PT]; vectors -> fp32 LDS
-template <typename H> __device__ __forceinline__ void load_w(bf16_t* W, const void* src, int lane) {
+// weights [C][C] (storage type) -> LDS [C][PT]; vectors -> fp32 LDS (whole workgroup)
+template <typename H> __device__ __forceinline__ void load_w(bf16_t* W, const void* src) {
     const H* s = reinterpret_cast<const H*>(src);
-    for (int i = lane; i < C * (C / 8); i += 64) { const int r = i >> 3, cg = i & 7; *reinterpret_cast<uint4*>(W + r * PT + cg * 8) = *reinterpret_cast<const uint4*>(s + r * C + cg * 8); }
+    for (int i = threadIdx.x; i < C * (C / 8); i += 64 * NW) { const int r = i >> 3, cg = i & 7; *reinterpret_cast<uint4*>(W + r * PT + cg * 8) = *reinterpret_cast<const uint4*>(s + r * C + cg * 8); }
 }
-template <typename H> __device__ __forceinline__ void load_v(float* v, const void* src, int lane) { v[lane] = ldf<H>(reinterpret_cast<const H*>(src) + lane); }
+template <typename H> __device__ __forceinline__ void load_v(float* v, const void* src) { if (threadIdx.x < C) v[threadIdx.x] = ldf<H>(reinterpret_cast<const H*>(src) + threadIdx.x); }
+// a [C][C] fp32 matrix -> LDS in the storage type
+template <typename H> __device__ __forceinline__ void load_ctx(bf16_t* W, const float* src) {
+    for (int i = threadIdx.x; i < C * (C / 4); i += 64 * NW) {
+        const int r = i >> 4, c4 = (i & 15) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(src + r * C + c4);
+        *reinterpret_cast<uint2*>(W + r * PT + c4) = make_uint2(pack2<H>(v.x, v.y), pack2<H>(v.z, v.w));
+    }
+}
 
-// LayerNorm of the 32 token rows of an LDS tile, in place (lane = token, hh = channel half); returns xhat in registers when asked for
-template <typename H, bool KEEP> __device__ __forceinline__ void ln_tile(bf16_t* X, const float* gam, const float* bet, float eps, const Lane& L, float& mean, float& rstd, float* xh) {
+// LayerNorm of the wave's 32 token rows of an LDS tile, in place (lane = token, hh = channel half); xhat kept in registers when asked for
+template <typename H, bool KEEP> __device__ __forceinline__ void ln_tile(bf16_t* X, const float* gam, const float* bet, float eps, const Lane& L, float& rstd, float* xh) {
     float v[32];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const uint4 u = *reinterpret_cast<const uint4*>(X + L.l31 * PT + L.hh * 32 + q * 8);
-        unpack2<H>(u.x, v[8 * q], v[8 * q + 1]); unpack2<H>(u.y, v[8 * q + 2], v[8 * q + 3]); unpack2<H>(u.z, v[8 * q + 4], v[8 * q + 5]); unpack2<H>(u.w, v[8 * q + 6], v[8 * q + 7]);
-    }
+    for (int q = 0; q < 4; ++q) up8s<H>(*reinterpret_cast<const uint4*>(X + L.l31 * PT + L.hh * 32 + q * 8), v + 8 * q);
     float s = 0.f;
 #pragma unroll
     for (int e = 0; e < 32; ++e) s += v[e];
     s += __shfl_xor(s, 32, 64);
-    mean = s * (1.0f / C);
+    const float mean = s * (1.0f / C);
     float q2 = 0.f;
 #pragma unroll
     for (int e = 0; e < 32; ++e) { const float d = v[e] - mean; q2 += d * d; }
@@ -205,115 +220,8 @@ template <typename H, bool KEEP> __device__ __forceinline__ void ln_tile(bf16_t*
         *reinterpret_cast<uint4*>(X + L.l31 * PT + L.hh * 32 + q * 8) = make_uint4(pack2<H>(o[0], o[1]), pack2<H>(o[2], o[3]), pack2<H>(o[4], o[5]), pack2<H>(o[6], o[7]));
     }
 }
-// (the wave's LDS accesses execute in order; the compiler must not move them across each other: one fence where a tile changes hands)
+// (a wave's LDS accesses execute in order; the compiler must not move them across each other: one fence where rows change hands)
 __device__ __forceinline__ void lds_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
-
-struct Where { int b, w; long long row0; int ntok; };
-__device__ __forceinline__ Where where_am_i(const EffDev& p) {
-    Where q;
-    q.b = blockIdx.x / p.wpi; q.w = blockIdx.x - q.b * p.wpi;
-    q.row0 = (long long)q.b * p.N + (long long)q.w * TPW;
-    q.ntok = min(TPW, p.N - q.w * TPW);
-    return q;
-}
-
-// ---------------------------------------------------------------------------------------------------------------- forward 1
-template <typename H>
-__global__ __launch_bounds__(64, 1) void effatt_kv_kernel(const EffDev p) {
-    __shared__ __attribute__((aligned(16))) bf16_t wk[C * PT], wv[C * PT], xt[TPW * PT], et[32 * PT], vt[32 * PT];
-    __shared__ float vec[4 * C];                                   // gamma, beta, bk, bv
-    const Lane L = lane_of();
-    const Where q = where_am_i(p);
-    load_w<H>(wk, p.wk, L.lane); load_w<H>(wv, p.wv, L.lane);
-    load_v<H>(vec, p.gamma, L.lane); load_v<H>(vec + C, p.beta, L.lane); load_v<H>(vec + 2 * C, p.bk, L.lane); load_v<H>(vec + 3 * C, p.bv, L.lane);
-    const H* T = reinterpret_cast<const H*>(p.t);
-    lds_fence();
-    f32x16 bkv[2], bvv[2];
-    get_vecT(vec + 2 * C, L, bkv); get_vecT(vec + 3 * C, L, bvv);
-    // pass 1: LN of every block (kept in LDS), K^T of every block (kept in registers), the running column maximum
-    f32x16 kk[NBLK][2];
-    f32x16 mx[2];
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx[cb][r] = -3.0e38f;
-#pragma unroll
-    for (int blk = 0; blk < NBLK; ++blk) {
-        bf16_t* X = xt + blk * 32 * PT;
-        const int nv = q.ntok - blk * 32;
-        load_tile<H>(X, T, q.row0 + blk * 32, p.ldt, nv, L.lane);
-        lds_fence();
-        float mean, rstd;
-        ln_tile<H, false>(X, vec, vec + C, p.eps, L, mean, rstd, nullptr);
-        lds_fence();
-        kk[blk][0] = bkv[0]; kk[blk][1] = bkv[1];
-        mm_w<H>(wk, X, L, kk[blk]);
-        const bool ok = L.l31 < nv;
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { if (!ok) kk[blk][cb][r] = -3.0e38f; mx[cb][r] = fmaxf(mx[cb][r], kk[blk][cb][r]); }
-    }
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-#pragma unroll
-            for (int m = 1; m < 32; m <<= 1) mx[cb][r] = fmaxf(mx[cb][r], __shfl_xor(mx[cb][r], m, 64));
-    // pass 2: E = exp(K - m), S += E, P += E^T V
-    f32x16 ss[2], pp[2][2];
-    zero2<H>(ss);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) zero2<H>(pp[i]);
-#pragma unroll
-    for (int blk = 0; blk < NBLK; ++blk) {
-        const bf16_t* X = xt + blk * 32 * PT;
-        const int nv = q.ntok - blk * 32;
-        const bool ok = L.l31 < nv;
-        f32x16 vv[2];
-        vv[0] = bvv[0]; vv[1] = bvv[1];
-        mm_w<H>(wv, X, L, vv);
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = ok ? __expf(kk[blk][cb][r] - mx[cb][r]) : 0.f;
-                kk[blk][cb][r] = e; ss[cb][r] += e;
-                if (!ok) vv[cb][r] = 0.f;
-            }
-        put_T<H>(et, L, kk[blk]);
-        put_T<H>(vt, L, vv);
-        lds_fence();
-        mm_tok<H>(et, vt, L, pp);
-        lds_fence();
-    }
-    float* PB = p.part + (long long)blockIdx.x * F_N;
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        const float s = fold16(ss[cb], L.lane);
-        if (L.l31 < 16) { const int ch = chan_of(cb, L.l31, L.hh); PB[F_S + ch] = s; }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) if (L.l31 == 0) PB[F_M + chan_of(cb, r, L.hh)] = mx[cb][r];
-    }
-    put_mat(PB + F_P, pp, L);
-}
-
-// ---------------------------------------------------------------------------------------------------------------- forward 2
-// grid (B, C): thread = (channel c = blockIdx.y, column c'); ctx[b][c][c'], kstat[b] = (M[C], Z[C])
-__global__ __launch_bounds__(64) void effatt_ctx_kernel(const EffDev p) {
-    const int b = blockIdx.x, c = blockIdx.y, cc = threadIdx.x;
-    const float* PB = p.part + (long long)b * p.wpi * F_N;
-    float M = -3.0e38f;
-    for (int w = 0; w < p.wpi; ++w) M = fmaxf(M, PB[(long long)w * F_N + F_M + c]);
-    float Z = 0.f, acc = 0.f;
-    for (int w = 0; w < p.wpi; ++w) {
-        const float f = __expf(PB[(long long)w * F_N + F_M + c] - M);
-        Z += f * PB[(long long)w * F_N + F_S + c];
-        acc += f * PB[(long long)w * F_N + F_P + c * C + cc];
-    }
-    p.ctx[((long long)b * C + c) * C + cc] = acc / Z;
-    if (cc == 0) { p.kstat[(long long)b * 2 * C + c] = M; p.kstat[(long long)b * 2 * C + C + c] = Z; }
-}
 
 // row softmax of a D^T pair of tiles over the 64 channels of each token (in lane + the partner half-wave)
 __device__ __forceinline__ void row_softmax(f32x16 (&a)[2]) {
@@ -335,115 +243,210 @@ __device__ __forceinline__ void row_softmax(f32x16 (&a)[2]) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) a[cb][r] *= inv;
 }
-// ctx[b] (fp32 [C][C]) -> LDS in the storage type
-template <typename H> __device__ __forceinline__ void load_ctx(bf16_t* W, const float* src, int lane) {
-    for (int i = lane; i < C * (C / 4); i += 64) {
-        const int r = i >> 4, c4 = (i & 15) * 4;
-        const float4 v = *reinterpret_cast<const float4*>(src + r * C + c4);
-        *reinterpret_cast<uint2*>(W + r * PT + c4) = make_uint2(pack2<H>(v.x, v.y), pack2<H>(v.z, v.w));
-    }
+
+struct Where { int b, w; long long row0; int ntok; };
+__device__ __forceinline__ Where where_am_i(int wpi, int N, int tpw) {
+    Where q;
+    q.b = blockIdx.x / wpi; q.w = blockIdx.x - q.b * wpi;
+    q.row0 = (long long)q.b * N + (long long)q.w * tpw;
+    q.ntok = min(tpw, N - q.w * tpw);
+    return q;
 }
 
+// ---------------------------------------------------------------------------------------------------------------- forward 1
 template <typename H>
-__global__ __launch_bounds__(64, 1) void effatt_out_kernel(const EffDev p) {
-    __shared__ __attribute__((aligned(16))) bf16_t wq[C * PT], wr[C * PT], cx[C * PT], xt[32 * PT], nt[32 * PT], st[32 * PT];
-    __shared__ float vec[4 * C];                                   // gamma, beta, bq, br
+__global__ __launch_bounds__(64 * NW) void effatt_kv_kernel(const EffDev p) {
+    __shared__ __attribute__((aligned(16))) bf16_t wk[C * PT], wv[C * PT], xt[TPW * PT], ev[2 * RT * PT];
+    __shared__ float vec[4 * C], mxs[NW][C], mall[C];              // gamma, beta, bk, bv
+    bf16_t* et = ev; bf16_t* vt = ev + RT * PT;
+    float* sc = reinterpret_cast<float*>(ev);                      // column-reduction scratch over et | vt, between their uses
+    static_assert(NW * SCW * 4 <= 2 * RT * PT * 2, "scratch");
     const Lane L = lane_of();
-    const Where q = where_am_i(p);
-    load_w<H>(wq, p.wq, L.lane); load_w<H>(wr, p.wr, L.lane); load_ctx<H>(cx, p.ctx + (long long)q.b * C * C, L.lane);
-    load_v<H>(vec, p.gamma, L.lane); load_v<H>(vec + C, p.beta, L.lane); load_v<H>(vec + 2 * C, p.bq, L.lane); load_v<H>(vec + 3 * C, p.br, L.lane);
+    const Where q = where_am_i(p.wpi, p.N, TPW);
+    load_w<H>(wk, p.wk); load_w<H>(wv, p.wv);
+    load_v<H>(vec, p.gamma); load_v<H>(vec + C, p.beta); load_v<H>(vec + 2 * C, p.bk); load_v<H>(vec + 3 * C, p.bv);
     const H* T = reinterpret_cast<const H*>(p.t);
-    H* O = reinterpret_cast<H*>(p.out);
-    lds_fence();
-    f32x16 bqv[2], brv[2];
-    get_vecT(vec + 2 * C, L, bqv); get_vecT(vec + 3 * C, L, brv);
-    for (int blk = 0; blk < NBLK; ++blk) {
-        const int nv = q.ntok - blk * 32;
-        if (nv <= 0) break;
-        load_tile<H>(xt, T, q.row0 + blk * 32, p.ldt, nv, L.lane);
-        lds_fence();
+    __syncthreads();
+    // pass 1: LN of the wave's blocks (kept in LDS), their K^T (kept in registers), the column maximum
+    f32x16 kk[NRD][2], mx[2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {                              // n1 = LN(t) in its own tile: t itself is the residual
-            const int r = 8 * i + (L.lane >> 3), cg = L.lane & 7;
-            *reinterpret_cast<uint4*>(nt + r * PT + cg * 8) = *reinterpret_cast<const uint4*>(xt + r * PT + cg * 8);
-        }
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx[cb][r] = -3.0e38f;
+#pragma unroll
+    for (int rd = 0; rd < NRD; ++rd) {
+        const int blk = rd * NW + L.wv, nv = q.ntok - blk * 32;
+        bf16_t* X = xt + blk * 32 * PT;
+        load_tile<H>(X, T, q.row0 + blk * 32, p.ldt, nv, L.lane);
         lds_fence();
-        float mean, rstd;
-        ln_tile<H, false>(nt, vec, vec + C, p.eps, L, mean, rstd, nullptr);
+        float rstd;
+        ln_tile<H, false>(X, vec, vec + C, p.eps, L, rstd, nullptr);
         lds_fence();
-        f32x16 a[2];
-        a[0] = bqv[0]; a[1] = bqv[1];
-        mm_w<H>(wq, nt, L, a);
-        row_softmax(a);
-        put_T<H>(st, L, a);                                        // Qsm
-        lds_fence();
-        zero2<H>(a);
-        mm_wt<H>(cx, st, L, a);                                    // att^T[c'][tok] = sum_c ctx[c][c'] Qsm[tok][c]
-        lds_fence();
-        put_T<H>(st, L, a);                                        // att (every read of Qsm is done)
-        lds_fence();
-        a[0] = brv[0]; a[1] = brv[1];
-        mm_w<H>(wr, st, L, a);                                     // out^T[o][tok] = sum_c' Wr[o][c'] att[tok][c']
+        get_vecT(vec + 2 * C, L, kk[rd]);
+        mm_w<H>(wk, X, L, kk[rd]);
+        const bool ok = L.l31 < nv;
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const uint2 tv = *reinterpret_cast<const uint2*>(xt + L.l31 * PT + cb * 32 + 8 * gq + 4 * L.hh);
-                float t0, t1, t2, t3;
-                unpack2<H>(tv.x, t0, t1); unpack2<H>(tv.y, t2, t3);
-                a[cb][4 * gq] += t0; a[cb][4 * gq + 1] += t1; a[cb][4 * gq + 2] += t2; a[cb][4 * gq + 3] += t3;
-            }
-        lds_fence();
-        put_T<H>(st, L, a);
-        lds_fence();
-        store_tile<H>(st, O, q.row0 + blk * 32, p.ldo, nv, L.lane);
-        lds_fence();
+            for (int r = 0; r < 16; ++r) { if (!ok) kk[rd][cb][r] = -3.0e38f; mx[cb][r] = fmaxf(mx[cb][r], kk[rd][cb][r]); }
     }
+    mxs[L.wv][L.lane] = colred_T<true>(sc + L.wv * SCW, mx, L);
+    __syncthreads();
+    if (threadIdx.x < C) mall[threadIdx.x] = fmaxf(fmaxf(mxs[0][threadIdx.x], mxs[1][threadIdx.x]), fmaxf(mxs[2][threadIdx.x], mxs[3][threadIdx.x]));
+    __syncthreads();
+    get_vecT(mall, L, mx);
+    // pass 2: E = exp(K - m), S += E, P += E^T V (wave = one 32 x 32 tile of P over the round's tokens)
+    f32x16 ss[2], pp;
+    zero2(ss);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pp[r] = 0.f;
+    const int ib = L.wv >> 1, jb = L.wv & 1;
+#pragma unroll
+    for (int rd = 0; rd < NRD; ++rd) {
+        const int blk = rd * NW + L.wv, nv = q.ntok - blk * 32;
+        const bf16_t* X = xt + blk * 32 * PT;
+        const bool ok = L.l31 < nv;
+        f32x16 vv[2];
+        get_vecT(vec + 3 * C, L, vv);
+        mm_w<H>(wv, X, L, vv);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = ok ? __expf(kk[rd][cb][r] - mx[cb][r]) : 0.f;
+                kk[rd][cb][r] = e; ss[cb][r] += e;
+                if (!ok) vv[cb][r] = 0.f;
+            }
+        put_T<H>(et + L.wv * 32 * PT, L, kk[rd]);
+        put_T<H>(vt + L.wv * 32 * PT, L, vv);
+        __syncthreads();
+        mm_tok<H>(et, vt, ib, jb, L, pp);
+        __syncthreads();
+    }
+    float* PB = p.part + (long long)blockIdx.x * F_N;
+    put_tile(PB + F_P, ib, jb, pp, L);
+    mxs[L.wv][L.lane] = colred_T<false>(sc + L.wv * SCW, ss, L);
+    __syncthreads();
+    if (threadIdx.x < C) {
+        PB[F_S + threadIdx.x] = mxs[0][threadIdx.x] + mxs[1][threadIdx.x] + mxs[2][threadIdx.x] + mxs[3][threadIdx.x];
+        PB[F_M + threadIdx.x] = mall[threadIdx.x];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- forward 2
+// grid (B, C): thread = (channel c = blockIdx.y, column c'); ctx[b][c][c'], kstat[b] = (M[C], Z[C])
+__global__ __launch_bounds__(64) void effatt_ctx_kernel(const EffDev p) {
+    const int b = blockIdx.x, c = blockIdx.y, cc = threadIdx.x;
+    const float* PB = p.part + (long long)b * p.wpi * F_N;
+    float M = -3.0e38f;
+    for (int w = 0; w < p.wpi; ++w) M = fmaxf(M, PB[(long long)w * F_N + F_M + c]);
+    float Z = 0.f, acc = 0.f;
+    for (int w = 0; w < p.wpi; ++w) {
+        const float f = __expf(PB[(long long)w * F_N + F_M + c] - M);
+        Z += f * PB[(long long)w * F_N + F_S + c];
+        acc += f * PB[(long long)w * F_N + F_P + c * C + cc];
+    }
+    p.ctx[((long long)b * C + c) * C + cc] = acc / Z;
+    if (cc == 0) { p.kstat[(long long)b * 2 * C + c] = M; p.kstat[(long long)b * 2 * C + C + c] = Z; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- forward 3
+// workgroup = TOUT tokens, wave = 32 of them, nothing shared but the weights
+template <typename H>
+__global__ __launch_bounds__(64 * NW) void effatt_out_kernel(const EffDev p) {
+    __shared__ __attribute__((aligned(16))) bf16_t wq[C * PT], wr[C * PT], cx[C * PT], xts[TOUT * PT], nts[TOUT * PT], sts[TOUT * PT];
+    __shared__ float vec[4 * C];                                   // gamma, beta, bq, br
+    const Lane L = lane_of();
+    const int wpo = (p.N + TOUT - 1) / TOUT;
+    const Where q = where_am_i(wpo, p.N, TOUT);
+    load_w<H>(wq, p.wq); load_w<H>(wr, p.wr); load_ctx<H>(cx, p.ctx + (long long)q.b * C * C);
+    load_v<H>(vec, p.gamma); load_v<H>(vec + C, p.beta); load_v<H>(vec + 2 * C, p.bq); load_v<H>(vec + 3 * C, p.br);
+    const H* T = reinterpret_cast<const H*>(p.t);
+    H* O = reinterpret_cast<H*>(p.out);
+    bf16_t* xt = xts + L.wv * 32 * PT; bf16_t* nt = nts + L.wv * 32 * PT; bf16_t* st = sts + L.wv * 32 * PT;
+    const int nv = q.ntok - L.wv * 32;
+    const long long row = q.row0 + L.wv * 32;
+    if (nv > 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                              // t twice: itself (the residual) and the copy that becomes n1 = LN(t)
+            const int r = 8 * i + (L.lane >> 3), cg = L.lane & 7;
+            const uint4 v = r < nv ? *reinterpret_cast<const uint4*>(T + (row + r) * p.ldt + cg * 8) : make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4*>(xt + r * PT + cg * 8) = v;
+            *reinterpret_cast<uint4*>(nt + r * PT + cg * 8) = v;
+        }
+    }
+    __syncthreads();
+    if (nv <= 0) return;
+    float rstd;
+    ln_tile<H, false>(nt, vec, vec + C, p.eps, L, rstd, nullptr);
+    lds_fence();
+    f32x16 a[2];
+    get_vecT(vec + 2 * C, L, a);
+    mm_w<H>(wq, nt, L, a);
+    row_softmax(a);
+    put_T<H>(st, L, a);                                            // Qsm
+    lds_fence();
+    zero2(a);
+    mm_wt<H>(cx, st, L, a);                                        // att^T[c'][tok] = sum_c ctx[c][c'] Qsm[tok][c]
+    lds_fence();
+    put_T<H>(st, L, a);                                            // att (every read of Qsm is done)
+    lds_fence();
+    get_vecT(vec + 3 * C, L, a);
+    mm_w<H>(wr, st, L, a);                                         // out^T[o][tok] = sum_c' Wr[o][c'] att[tok][c']
+    add_T<H>(xt, L, a);
+    lds_fence();
+    put_T<H>(st, L, a);
+    lds_fence();
+    store_tile<H>(st, O, row, p.ldo, nv, L.lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- backward 1
 template <typename H>
-__global__ __launch_bounds__(64, 1) void effatt_bq_kernel(const EffDev p) {
+__global__ __launch_bounds__(64 * NW) void effatt_bq_kernel(const EffDev p) {
     __shared__ __attribute__((aligned(16))) bf16_t wq[C * PT], wr[C * PT], cx[C * PT];
-    __shared__ __attribute__((aligned(16))) bf16_t nt[32 * PT], qt[32 * PT], at[32 * PT], yt[32 * PT], dat[32 * PT], dqt[32 * PT];   // n1, Qsm, att, dout, d_att, dQ
-    __shared__ float vec[3 * C];                                   // gamma, beta, bq
+    __shared__ __attribute__((aligned(16))) bf16_t tl[6 * RT * PT];                    // n1, Qsm, att, dout, d_att, dQ: [RT tokens][PT] each
+    __shared__ float vec[3 * C], vs[NW][2][C];                     // gamma, beta, bq
+    bf16_t* nts = tl; bf16_t* qts = tl + RT * PT; bf16_t* ats = tl + 2 * RT * PT; bf16_t* yts = tl + 3 * RT * PT; bf16_t* dats = tl + 4 * RT * PT; bf16_t* dqts = tl + 5 * RT * PT;
+    float* sc = reinterpret_cast<float*>(tl);
     const Lane L = lane_of();
-    const Where q = where_am_i(p);
-    load_w<H>(wq, p.wq, L.lane); load_w<H>(wr, p.wr, L.lane); load_ctx<H>(cx, p.ctx + (long long)q.b * C * C, L.lane);
-    load_v<H>(vec, p.gamma, L.lane); load_v<H>(vec + C, p.beta, L.lane); load_v<H>(vec + 2 * C, p.bq, L.lane);
+    const Where q = where_am_i(p.wpi, p.N, TPW);
+    load_w<H>(wq, p.wq); load_w<H>(wr, p.wr); load_ctx<H>(cx, p.ctx + (long long)q.b * C * C);
+    load_v<H>(vec, p.gamma); load_v<H>(vec + C, p.beta); load_v<H>(vec + 2 * C, p.bq);
     const H* T = reinterpret_cast<const H*>(p.t);
     const H* DY = reinterpret_cast<const H*>(p.dout);
     H* G1 = reinterpret_cast<H*>(p.g1);
-    lds_fence();
-    f32x16 bqv[2];
-    get_vecT(vec + 2 * C, L, bqv);
-    f32x16 dctx[2][2], dwr[2][2], dwq[2][2], dbr[2], dbq[2];
+    const int wo = L.wv * 32 * PT;
+    bf16_t* nt = nts + wo; bf16_t* qt = qts + wo; bf16_t* at = ats + wo; bf16_t* yt = yts + wo; bf16_t* dat = dats + wo; bf16_t* dqt = dqts + wo;
+    __syncthreads();
+    f32x16 dctx, dwr, dwq, dbr[2], dbq[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { zero2<H>(dctx[i]); zero2<H>(dwr[i]); zero2<H>(dwq[i]); }
-    zero2<H>(dbr); zero2<H>(dbq);
-    for (int blk = 0; blk < NBLK; ++blk) {
-        const int nv = q.ntok - blk * 32;
-        if (nv <= 0) break;
-        load_tile<H>(nt, T, q.row0 + blk * 32, p.ldt, nv, L.lane);
-        load_tile<H>(yt, DY, q.row0 + blk * 32, p.lddo, nv, L.lane);          // (rows beyond the image: zeros -> no contribution)
+    for (int r = 0; r < 16; ++r) { dctx[r] = 0.f; dwr[r] = 0.f; dwq[r] = 0.f; }
+    zero2(dbr); zero2(dbq);
+    const int ib = L.wv >> 1, jb = L.wv & 1;
+    for (int rd = 0; rd < NRD; ++rd) {
+        const int blk = rd * NW + L.wv, nv = q.ntok - blk * 32;
+        const long long row = q.row0 + blk * 32;
+        const bool ok = L.l31 < nv;
+        load_tile<H>(nt, T, row, p.ldt, nv, L.lane);
+        load_tile<H>(yt, DY, row, p.lddo, nv, L.lane);             // (rows beyond the image: zeros -> no contribution)
         lds_fence();
-        float mean, rstd;
-        ln_tile<H, false>(nt, vec, vec + C, p.eps, L, mean, rstd, nullptr);
+        float rstd;
+        ln_tile<H, false>(nt, vec, vec + C, p.eps, L, rstd, nullptr);
         lds_fence();
         f32x16 qs[2], a[2];
-        qs[0] = bqv[0]; qs[1] = bqv[1];
+        get_vecT(vec + 2 * C, L, qs);
         mm_w<H>(wq, nt, L, qs);
         row_softmax(qs);
         put_T<H>(qt, L, qs);                                       // Qsm
         lds_fence();
-        zero2<H>(a);
+        zero2(a);
         mm_wt<H>(cx, qt, L, a);
         put_T<H>(at, L, a);                                        // att = Qsm ctx (recomputed for dWr)
-        zero2<H>(a);
+        zero2(a);
         mm_wt<H>(wr, yt, L, a);                                    // d_att^T[c'][tok] = sum_o Wr[o][c'] dout[tok][o]
         put_T<H>(dat, L, a);
         lds_fence();
-        zero2<H>(a);
+        zero2(a);
         mm_w<H>(cx, dat, L, a);                                    // dQsm^T[c][tok] = sum_c' ctx[c][c'] d_att[tok][c']
         float dot = 0.f;
 #pragma unroll
@@ -451,39 +454,38 @@ __global__ __launch_bounds__(64, 1) void effatt_bq_kernel(const EffDev p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) dot += qs[cb][r] * a[cb][r];
         dot += __shfl_xor(dot, 32, 64);
-        const bool ok = L.l31 < nv;
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { a[cb][r] = ok ? qs[cb][r] * (a[cb][r] - dot) : 0.f; dbq[cb][r] += a[cb][r]; }       // dQ
         put_T<H>(dqt, L, a);
         lds_fence();
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {                       // dbr: column sums of dout
-                const uint2 tv = *reinterpret_cast<const uint2*>(yt + L.l31 * PT + cb * 32 + 8 * gq + 4 * L.hh);
-                float t0, t1, t2, t3;
-                unpack2<H>(tv.x, t0, t1); unpack2<H>(tv.y, t2, t3);
-                dbr[cb][4 * gq] += t0; dbr[cb][4 * gq + 1] += t1; dbr[cb][4 * gq + 2] += t2; dbr[cb][4 * gq + 3] += t3;
-            }
-        mm_tok<H>(qt, dat, L, dctx);                               // d_ctx[c][c'] += sum_tok Qsm[tok][c] d_att[tok][c']
-        mm_tok<H>(yt, at, L, dwr);                                 // dWr[o][c']   += sum_tok dout[tok][o] att[tok][c']
-        mm_tok<H>(dqt, nt, L, dwq);                                // dWq[c][cin]  += sum_tok dQ[tok][c] n1[tok][cin]
-        zero2<H>(a);
+        add_T<H>(yt, L, dbr);                                      // dbr: column sums of dout
+        zero2(a);
         mm_wt<H>(wq, dqt, L, a);                                   // g1^T[cin][tok] = sum_c Wq[c][cin] dQ[tok][c]
+        __syncthreads();
+        mm_tok<H>(qts, dats, ib, jb, L, dctx);                     // d_ctx[c][c'] += sum_tok Qsm[tok][c] d_att[tok][c']
+        mm_tok<H>(yts, ats, ib, jb, L, dwr);                       // dWr[o][c']   += sum_tok dout[tok][o] att[tok][c']
+        mm_tok<H>(dqts, nts, ib, jb, L, dwq);                      // dWq[c][cin]  += sum_tok dQ[tok][c] n1[tok][cin]
+        __syncthreads();
+        put_T<H>(at, L, a);
         lds_fence();
-        put_T<H>(at, L, a);                                        // (att's readers are done)
-        lds_fence();
-        store_tile<H>(at, G1, q.row0 + blk * 32, C, nv, L.lane);
+        store_tile<H>(at, G1, row, C, nv, L.lane);
         lds_fence();
     }
     float* PB = p.part + (long long)blockIdx.x * (B1_N + B2_N);
-    put_mat(PB + B1_DCTX, dctx, L); put_mat(PB + B1_DWR, dwr, L); put_mat(PB + B1_DWQ, dwq, L);
-    put_colsum(PB + B1_DBR, dbr, L); put_colsum(PB + B1_DBQ, dbq, L);
+    put_tile(PB + B1_DCTX, ib, jb, dctx, L); put_tile(PB + B1_DWR, ib, jb, dwr, L); put_tile(PB + B1_DWQ, ib, jb, dwq, L);
+    __syncthreads();
+    vs[L.wv][0][L.lane] = colred_T<false>(sc + L.wv * SCW, dbr, L);
+    vs[L.wv][1][L.lane] = colred_T<false>(sc + L.wv * SCW, dbq, L);
+    __syncthreads();
+    if (threadIdx.x < 2 * C) {
+        const int k = threadIdx.x >> 6, ch = threadIdx.x & 63;
+        PB[(k ? B1_DBQ : B1_DBR) + ch] = vs[0][k][ch] + vs[1][k][ch] + vs[2][k][ch] + vs[3][k][ch];
+    }
 }
 
-// grid (B, C): d_ctx[b][c][c'] = sum over the image's waves; r[b][c] = sum_c' d_ctx ctx
+// grid (B, C): d_ctx[b][c][c'] = sum over the image's workgroups; r[b][c] = sum_c' d_ctx ctx
 __global__ __launch_bounds__(64) void effatt_dctx_kernel(const EffDev p) {
     const int b = blockIdx.x, c = blockIdx.y, cc = threadIdx.x;
     const float* PB = p.part + (long long)b * p.wpi * (B1_N + B2_N);
@@ -498,90 +500,98 @@ __global__ __launch_bounds__(64) void effatt_dctx_kernel(const EffDev p) {
 
 // ---------------------------------------------------------------------------------------------------------------- backward 2
 template <typename H>
-__global__ __launch_bounds__(64, 1) void effatt_bkv_kernel(const EffDev p) {
+__global__ __launch_bounds__(64 * NW) void effatt_bkv_kernel(const EffDev p) {
     __shared__ __attribute__((aligned(16))) bf16_t wk[C * PT], wv[C * PT], dcx[C * PT];
-    __shared__ __attribute__((aligned(16))) bf16_t nt[32 * PT], kt[32 * PT], vt[32 * PT], dkt[32 * PT], dvt[32 * PT], gt[32 * PT];  // n1, Ksm, V, dK, dV, g1 / dt
-    __shared__ float vec[7 * C];                                   // gamma, beta, bk, bv, M, 1 / Z, r
+    __shared__ __attribute__((aligned(16))) bf16_t tl[6 * RT * PT];                    // n1, Ksm, V, dK, dV, g1: [RT tokens][PT] each
+    __shared__ float vec[7 * C], vs[NW][4][C];                     // gamma, beta, bk, bv, M, 1 / Z, r
+    bf16_t* nts = tl; bf16_t* dkts = tl + 3 * RT * PT; bf16_t* dvts = tl + 4 * RT * PT;
+    float* sc = reinterpret_cast<float*>(tl);
     const Lane L = lane_of();
-    const Where q = where_am_i(p);
-    load_w<H>(wk, p.wk, L.lane); load_w<H>(wv, p.wv, L.lane); load_ctx<H>(dcx, p.dctx + (long long)q.b * C * C, L.lane);
-    load_v<H>(vec, p.gamma, L.lane); load_v<H>(vec + C, p.beta, L.lane); load_v<H>(vec + 2 * C, p.bk, L.lane); load_v<H>(vec + 3 * C, p.bv, L.lane);
-    vec[4 * C + L.lane] = p.kstat[(long long)q.b * 2 * C + L.lane];
-    vec[5 * C + L.lane] = 1.0f / p.kstat[(long long)q.b * 2 * C + C + L.lane];
-    vec[6 * C + L.lane] = p.rsum[(long long)q.b * C + L.lane];
+    const Where q = where_am_i(p.wpi, p.N, TPW);
+    load_w<H>(wk, p.wk); load_w<H>(wv, p.wv); load_ctx<H>(dcx, p.dctx + (long long)q.b * C * C);
+    load_v<H>(vec, p.gamma); load_v<H>(vec + C, p.beta); load_v<H>(vec + 2 * C, p.bk); load_v<H>(vec + 3 * C, p.bv);
+    if (threadIdx.x < C) {
+        vec[4 * C + threadIdx.x] = p.kstat[(long long)q.b * 2 * C + threadIdx.x];
+        vec[5 * C + threadIdx.x] = 1.0f / p.kstat[(long long)q.b * 2 * C + C + threadIdx.x];
+        vec[6 * C + threadIdx.x] = p.rsum[(long long)q.b * C + threadIdx.x];
+    }
     const H* T = reinterpret_cast<const H*>(p.t);
     const H* DY = reinterpret_cast<const H*>(p.dout);
     const H* G1 = reinterpret_cast<const H*>(p.g1);
     H* DT = reinterpret_cast<H*>(p.dt);
-    lds_fence();
-    f32x16 bkv[2], bvv[2], Mv[2], iZ[2], rv[2];
-    get_vecT(vec + 2 * C, L, bkv); get_vecT(vec + 3 * C, L, bvv); get_vecT(vec + 4 * C, L, Mv); get_vecT(vec + 5 * C, L, iZ); get_vecT(vec + 6 * C, L, rv);
-    f32x16 dwk[2][2], dwv[2][2], dbk[2], dbv[2], dgm[2], dbt[2];
+    const int wo = L.wv * 32 * PT;
+    bf16_t* nt = tl + wo; bf16_t* kt = tl + RT * PT + wo; bf16_t* vt = tl + 2 * RT * PT + wo; bf16_t* dkt = dkts + wo; bf16_t* dvt = dvts + wo; bf16_t* gt = tl + 5 * RT * PT + wo;
+    __syncthreads();
+    f32x16 dwk, dwv, dbk[2], dbv[2];
+    float dgr[32], dbr[32];                                        // dgamma / dbeta of the lane's token, row order (channels hh * 32 + e)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { zero2<H>(dwk[i]); zero2<H>(dwv[i]); }
-    zero2<H>(dbk); zero2<H>(dbv); zero2<H>(dgm); zero2<H>(dbt);
-    for (int blk = 0; blk < NBLK; ++blk) {
-        const int nv = q.ntok - blk * 32;
-        if (nv <= 0) break;
+    for (int r = 0; r < 16; ++r) { dwk[r] = 0.f; dwv[r] = 0.f; }
+    zero2(dbk); zero2(dbv);
+#pragma unroll
+    for (int e = 0; e < 32; ++e) { dgr[e] = 0.f; dbr[e] = 0.f; }
+    const int ib = L.wv >> 1, jb = L.wv & 1;
+    for (int rd = 0; rd < NRD; ++rd) {
+        const int blk = rd * NW + L.wv, nv = q.ntok - blk * 32;
+        const long long row = q.row0 + blk * 32;
         const bool ok = L.l31 < nv;
-        load_tile<H>(nt, T, q.row0 + blk * 32, p.ldt, nv, L.lane);
-        load_tile<H>(gt, G1, q.row0 + blk * 32, C, nv, L.lane);
+        load_tile<H>(nt, T, row, p.ldt, nv, L.lane);
+        load_tile<H>(gt, G1, row, C, nv, L.lane);
         lds_fence();
-        float mean, rstd, xh[32];
-        ln_tile<H, true>(nt, vec, vec + C, p.eps, L, mean, rstd, xh);        // xh: this lane's 32 channels hh * 32 + 0..31 (row order)
+        float rstd, xh[32];
+        ln_tile<H, true>(nt, vec, vec + C, p.eps, L, rstd, xh);
         lds_fence();
-        f32x16 ks[2], vv[2], a[2], b2[2];
-        ks[0] = bkv[0]; ks[1] = bkv[1];
+        f32x16 ks[2], a[2], b2[2];
+        get_vecT(vec + 2 * C, L, ks);
         mm_w<H>(wk, nt, L, ks);
-        vv[0] = bvv[0]; vv[1] = bvv[1];
-        mm_w<H>(wv, nt, L, vv);
+        get_vecT(vec + 3 * C, L, a);
+        mm_w<H>(wv, nt, L, a);
+        put_T<H>(vt, L, a);                                        // V
+        get_vecT(vec + 4 * C, L, a); get_vecT(vec + 5 * C, L, b2);
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) ks[cb][r] = __expf(ks[cb][r] - Mv[cb][r]) * iZ[cb][r];                                   // Ksm
+            for (int r = 0; r < 16; ++r) ks[cb][r] = __expf(ks[cb][r] - a[cb][r]) * b2[cb][r];                                    // Ksm
         put_T<H>(kt, L, ks);
-        put_T<H>(vt, L, vv);
         lds_fence();
-        zero2<H>(a);
+        zero2(a);
         mm_wt<H>(dcx, kt, L, a);                                   // dV^T[c'][tok]  = sum_c d_ctx[c][c'] Ksm[tok][c]
-        zero2<H>(b2);
+        zero2(b2);
         mm_w<H>(dcx, vt, L, b2);                                   // dKsm^T[c][tok] = sum_c' d_ctx[c][c'] V[tok][c']
+        {
+            f32x16 rv[2];
+            get_vecT(vec + 6 * C, L, rv);
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+            for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                b2[cb][r] = ok ? ks[cb][r] * (b2[cb][r] - rv[cb][r]) : 0.f;                                                       // dK
-                if (!ok) a[cb][r] = 0.f;
-                dbk[cb][r] += b2[cb][r]; dbv[cb][r] += a[cb][r];
-            }
+                for (int r = 0; r < 16; ++r) {
+                    b2[cb][r] = ok ? ks[cb][r] * (b2[cb][r] - rv[cb][r]) : 0.f;                                                   // dK
+                    if (!ok) a[cb][r] = 0.f;
+                    dbk[cb][r] += b2[cb][r]; dbv[cb][r] += a[cb][r];
+                }
+        }
         put_T<H>(dkt, L, b2);
         put_T<H>(dvt, L, a);
         lds_fence();
-        mm_tok<H>(dkt, nt, L, dwk);                                // dWk[c][cin] += sum_tok dK[tok][c] n1[tok][cin]
-        mm_tok<H>(dvt, nt, L, dwv);
-        zero2<H>(a);
+        zero2(a);
         mm_wt<H>(wk, dkt, L, a);                                   // d_n1^T[cin][tok] = g1 + sum_c Wk[c][cin] dK[tok][c] + sum_c' Wv[c'][cin] dV[tok][c']
         mm_wt<H>(wv, dvt, L, a);
         lds_fence();
-        put_T<H>(kt, L, a);                                        // (Ksm's readers are done): the two GEMM terms, token rows
+        put_T<H>(kt, L, a);                                        // (Ksm's readers are done): the two GEMM terms, by token rows
         lds_fence();
         // LayerNorm backward in row order: lane = token, its channels hh * 32 + 0..31
         float dn[32], s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
-            const uint4 u = *reinterpret_cast<const uint4*>(kt + L.l31 * PT + L.hh * 32 + qq * 8);
-            const uint4 g = *reinterpret_cast<const uint4*>(gt + L.l31 * PT + L.hh * 32 + qq * 8);
             float x[8], y[8];
-            unpack2<H>(u.x, x[0], x[1]); unpack2<H>(u.y, x[2], x[3]); unpack2<H>(u.z, x[4], x[5]); unpack2<H>(u.w, x[6], x[7]);
-            unpack2<H>(g.x, y[0], y[1]); unpack2<H>(g.y, y[2], y[3]); unpack2<H>(g.z, y[4], y[5]); unpack2<H>(g.w, y[6], y[7]);
+            up8s<H>(*reinterpret_cast<const uint4*>(kt + L.l31 * PT + L.hh * 32 + qq * 8), x);
+            up8s<H>(*reinterpret_cast<const uint4*>(gt + L.l31 * PT + L.hh * 32 + qq * 8), y);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const int ch = L.hh * 32 + qq * 8 + e;
                 const float d = ok ? x[e] + y[e] : 0.f;             // d_n1
-                const float dg = d * vec[ch];
+                dgr[qq * 8 + e] += d * xh[qq * 8 + e]; dbr[qq * 8 + e] += d;
+                const float dg = d * vec[L.hh * 32 + qq * 8 + e];
                 dn[qq * 8 + e] = dg;
                 s1 += dg; s2 += dg * xh[qq * 8 + e];
-                // (dgamma / dbeta need column sums: gathered below in the D^T register order from a tile)
             }
         }
         s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
@@ -589,38 +599,14 @@ __global__ __launch_bounds__(64, 1) void effatt_bkv_kernel(const EffDev p) {
         lds_fence();
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
-            // dgamma += d_n1 xhat, dbeta += d_n1: park (d_n1 xhat) in dkt and d_n1 in dvt (their readers are done), summed by columns below
-            const uint4 u = *reinterpret_cast<const uint4*>(kt + L.l31 * PT + L.hh * 32 + qq * 8);
-            const uint4 g = *reinterpret_cast<const uint4*>(gt + L.l31 * PT + L.hh * 32 + qq * 8);
-            float x[8], y[8], o[8], w1[8], w2[8];
-            unpack2<H>(u.x, x[0], x[1]); unpack2<H>(u.y, x[2], x[3]); unpack2<H>(u.z, x[4], x[5]); unpack2<H>(u.w, x[6], x[7]);
-            unpack2<H>(g.x, y[0], y[1]); unpack2<H>(g.y, y[2], y[3]); unpack2<H>(g.z, y[4], y[5]); unpack2<H>(g.w, y[6], y[7]);
+            float o[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float d = ok ? x[e] + y[e] : 0.f;
-                w1[e] = d * xh[qq * 8 + e]; w2[e] = d;
-                o[e] = ok ? rstd * (dn[qq * 8 + e] - k1 - xh[qq * 8 + e] * k2) : 0.f;
-            }
-            *reinterpret_cast<uint4*>(dkt + L.l31 * PT + L.hh * 32 + qq * 8) = make_uint4(pack2<H>(w1[0], w1[1]), pack2<H>(w1[2], w1[3]), pack2<H>(w1[4], w1[5]), pack2<H>(w1[6], w1[7]));
-            *reinterpret_cast<uint4*>(dvt + L.l31 * PT + L.hh * 32 + qq * 8) = make_uint4(pack2<H>(w2[0], w2[1]), pack2<H>(w2[2], w2[3]), pack2<H>(w2[4], w2[5]), pack2<H>(w2[6], w2[7]));
+            for (int e = 0; e < 8; ++e) o[e] = rstd * (dn[qq * 8 + e] - k1 - xh[qq * 8 + e] * k2);
             *reinterpret_cast<uint4*>(vt + L.l31 * PT + L.hh * 32 + qq * 8) = make_uint4(pack2<H>(o[0], o[1]), pack2<H>(o[2], o[3]), pack2<H>(o[4], o[5]), pack2<H>(o[6], o[7]));
         }
-        lds_fence();
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const uint2 u1 = *reinterpret_cast<const uint2*>(dkt + L.l31 * PT + cb * 32 + 8 * gq + 4 * L.hh);
-                const uint2 u2 = *reinterpret_cast<const uint2*>(dvt + L.l31 * PT + cb * 32 + 8 * gq + 4 * L.hh);
-                float t0, t1, t2, t3;
-                unpack2<H>(u1.x, t0, t1); unpack2<H>(u1.y, t2, t3);
-                dgm[cb][4 * gq] += t0; dgm[cb][4 * gq + 1] += t1; dgm[cb][4 * gq + 2] += t2; dgm[cb][4 * gq + 3] += t3;
-                unpack2<H>(u2.x, t0, t1); unpack2<H>(u2.y, t2, t3);
-                dbt[cb][4 * gq] += t0; dbt[cb][4 * gq + 1] += t1; dbt[cb][4 * gq + 2] += t2; dbt[cb][4 * gq + 3] += t3;
-            }
         // dt = LayerNorm backward + the residual's gradient (dout) [+ what dt holds]
-        load_tile<H>(kt, DY, q.row0 + blk * 32, p.lddo, nv, L.lane);
-        if (p.acc_dt) load_tile<H>(gt, DT, q.row0 + blk * 32, p.lddt, nv, L.lane);
+        load_tile<H>(kt, DY, row, p.lddo, nv, L.lane);
+        if (p.acc_dt) load_tile<H>(gt, DT, row, p.lddt, nv, L.lane);
         lds_fence();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -635,19 +621,31 @@ __global__ __launch_bounds__(64, 1) void effatt_bkv_kernel(const EffDev p) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) x[e] += y[e];
             }
-            if (r < nv) *reinterpret_cast<uint4*>(DT + (q.row0 + blk * 32 + r) * p.lddt + cg * 8) =
+            if (r < nv) *reinterpret_cast<uint4*>(DT + (row + r) * p.lddt + cg * 8) =
                 make_uint4(pack2<H>(x[0], x[1]), pack2<H>(x[2], x[3]), pack2<H>(x[4], x[5]), pack2<H>(x[6], x[7]));
         }
-        lds_fence();
+        __syncthreads();
+        mm_tok<H>(dkts, nts, ib, jb, L, dwk);                      // dWk[c][cin] += sum_tok dK[tok][c] n1[tok][cin]
+        mm_tok<H>(dvts, nts, ib, jb, L, dwv);
+        __syncthreads();
     }
     float* PB = p.part + (long long)blockIdx.x * (B1_N + B2_N) + B1_N;
-    put_mat(PB + B2_DWK, dwk, L); put_mat(PB + B2_DWV, dwv, L);
-    put_colsum(PB + B2_DBK, dbk, L); put_colsum(PB + B2_DBV, dbv, L); put_colsum(PB + B2_DG, dgm, L); put_colsum(PB + B2_DB, dbt, L);
+    put_tile(PB + B2_DWK, ib, jb, dwk, L); put_tile(PB + B2_DWV, ib, jb, dwv, L);
+    vs[L.wv][0][L.lane] = colred_T<false>(sc + L.wv * SCW, dbk, L);
+    vs[L.wv][1][L.lane] = colred_T<false>(sc + L.wv * SCW, dbv, L);
+    vs[L.wv][2][L.lane] = colsum_row(sc + L.wv * SCW, dgr, L);
+    vs[L.wv][3][L.lane] = colsum_row(sc + L.wv * SCW, dbr, L);
+    __syncthreads();
+    {
+        const int k = threadIdx.x >> 6, ch = threadIdx.x & 63;
+        const int off = k == 0 ? B2_DBK : k == 1 ? B2_DBV : k == 2 ? B2_DG : B2_DB;
+        PB[off + ch] = vs[0][k][ch] + vs[1][k][ch] + vs[2][k][ch] + vs[3][k][ch];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------- fold
 struct FoldDev { const float* part; float* dst[12]; int off[13]; int nwv, nper; };
-// grid (nper / 64), 256 threads = 16 float4 columns x 16 slices of the wave list
+// grid (nper / 64), 256 threads = 16 float4 columns x 16 slices of the workgroup list
 __global__ __launch_bounds__(256) void effatt_fold_kernel(const FoldDev p) {
     __shared__ float4 sh[16][17];
     const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
@@ -702,21 +700,21 @@ EffDev eff_dev(const TcEffAtt* f) {
 template <typename H> int eff_fwd(const TcEffAtt* f, hipStream_t s) {
     const EffDev p = eff_dev(f);
     const int nwv = f->B * p.wpi;
-    hipLaunchKernelGGL((effatt_kv_kernel<H>), dim3(nwv), dim3(64), 0, s, p);
+    hipLaunchKernelGGL((effatt_kv_kernel<H>), dim3(nwv), dim3(64 * NW), 0, s, p);
     if (tc_launch_status() != TC_OK) return TC_ERR_LAUNCH;
     hipLaunchKernelGGL(effatt_ctx_kernel, dim3(f->B, C), dim3(64), 0, s, p);
     if (tc_launch_status() != TC_OK) return TC_ERR_LAUNCH;
-    hipLaunchKernelGGL((effatt_out_kernel<H>), dim3(nwv), dim3(64), 0, s, p);
+    hipLaunchKernelGGL((effatt_out_kernel<H>), dim3(f->B * ((f->N + TOUT - 1) / TOUT)), dim3(64 * NW), 0, s, p);
     return tc_launch_status();
 }
 template <typename H> int eff_bwd(const TcEffAtt* f, hipStream_t s) {
     const EffDev p = eff_dev(f);
     const int nwv = f->B * p.wpi;
-    hipLaunchKernelGGL((effatt_bq_kernel<H>), dim3(nwv), dim3(64), 0, s, p);
+    hipLaunchKernelGGL((effatt_bq_kernel<H>), dim3(nwv), dim3(64 * NW), 0, s, p);
     if (tc_launch_status() != TC_OK) return TC_ERR_LAUNCH;
     hipLaunchKernelGGL(effatt_dctx_kernel, dim3(f->B, C), dim3(64), 0, s, p);
     if (tc_launch_status() != TC_OK) return TC_ERR_LAUNCH;
-    hipLaunchKernelGGL((effatt_bkv_kernel<H>), dim3(nwv), dim3(64), 0, s, p);
+    hipLaunchKernelGGL((effatt_bkv_kernel<H>), dim3(nwv), dim3(64 * NW), 0, s, p);
     if (tc_launch_status() != TC_OK) return TC_ERR_LAUNCH;
     FoldDev r;
     r.part = f->part; r.nwv = nwv; r.nper = B1_N + B2_N;

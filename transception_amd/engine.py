@@ -18,7 +18,7 @@ from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
 
-from ._lib import (ATTN_DKV_SPLITS, EW_COPY, EW_DEINTERLEAVE, EW_PATCHIFY, TcEwSeg, TcFfnBwd, TcFfnFused, ACT_COORD, ACT_GELU, ACT_HSWISH, ACT_NONE, ACT_SIGMOID, FFN_EP, FFN_LN_A, FFN_LN_B, TC_BF16, TC_F16, TC_F32, TcDwSeg, TcFfnSeg,
+from ._lib import (ATTN_DKV_SPLITS, EW_COPY, EW_DEINTERLEAVE, EW_PATCHIFY, TcEffAtt, TcEwSeg, TcFfnBwd, TcFfnFused, ACT_COORD, ACT_GELU, ACT_HSWISH, ACT_NONE, ACT_SIGMOID, FFN_EP, FFN_LN_A, FFN_LN_B, TC_BF16, TC_F16, TC_F32, TcDwSeg, TcFfnSeg,
                    TcGemm, lib)
 
 _DT = {torch.float32: TC_F32, torch.bfloat16: TC_BF16, torch.float16: TC_F16}
@@ -185,6 +185,7 @@ _SKIP_WGRAD = bool(os.environ.get("TC_DEBUG_SKIP_WGRAD"))
 _FFN_STORE_ACT = os.environ.get("TC_FFN_STORE_ACT", "1") != "0"   # MixFFN: keep GELU(LN(d)) from the forward pass (0: recompute it in dW2's loader)
 _FFN_LN_GEMM_MAXC = int(os.environ.get("TC_FFN_LN_GEMM_MAXC", "64"))  # widest fc2 output for which LayerNorm + GELU run in its A loader
 _FFN_TILED = os.environ.get("TC_FFN_TILED", "1") != "0"        # MixFFN forward as one spatially tiled kernel where the library supports the width (csrc/mixffn.hip)
+_EFFATT_FUSED = os.environ.get("TC_EFFATT_FUSED", "1") != "0"        # EfficientAttention blocks through csrc/effatt.hip where the library supports the width
 _FFN_TILED_BWD = os.environ.get("TC_FFN_TILED_BWD", "1") != "0"   # MixFFN backward on the chip (csrc/mixffn_bwd.hip) where the library supports the width
 _FFN_TILE_BWD = (0, 0)                                         # forced pixel tile of the tiled backward's second launch (tests)
 _FFN_TILE = (0, 0)                                             # forced pixel tile of the tiled MixFFN kernels (tests); (0, 0): the library's choice
@@ -942,6 +943,58 @@ class Graph:
         if defer:
             return TcEwSeg(EW_COPY, acc, src.data_ptr(), g.data_ptr(), sb_src, sb_dst, src.stride(0), g.stride(0), nb, M, N, 0, 0, 0)
         self.L.tc_copy3d(_ptr(src), sb_src, src.stride(0), _ptr(g), sb_dst, g.stride(0), nb, M, N, acc, self.dt, self.stream)
+
+    def effatt_supported(self, t: Var) -> bool:
+        return (_EFFATT_FUSED and self.ngroups == 1 and not self.use_streams and self.dt != TC_F32
+                and bool(self.L.tc_effatt_supported(t.cols, self.dt)) and t.data.is_contiguous())
+
+    def eff_attention_block(self, t: Var, ln: Tuple[P, P], keys: Tuple[P, P], queries: Tuple[P, P], values: Tuple[P, P],
+                            reproj: Tuple[P, P], B: int, N: int, eps: float = 1e-5) -> Var:
+        """t + EfficientAttention(LayerNorm(t)) (MSTr.py:166-167 around :106-143, one head) through csrc/effatt.hip: 3 launches forward,
+        4 backward, nothing N-sized in HBM but t, the result and one C-wide gradient scratch (op by op: 10 + 12 launches and the
+        K | Q | V maps, both softmaxes and the attended map, each twice)."""
+        L, Cc = self.L, t.cols
+        assert t.rows == B * N and self.effatt_supported(t)
+        out = self.new(t.rows, Cc)
+        nf = int(L.tc_effatt_scratch_floats(Cc, B, N))
+        ctx, kstat = self.f32(B, Cc, Cc), self.f32(B, 2, Cc)
+        es = t.data.element_size()
+
+        def desc(part, dout=None, dt=None, g1=None, acc=0, grads=False):
+            f = TcEffAtt()
+            f.t, f.gamma, f.beta = _ptr(t.data), _ptr(ln[0].data), _ptr(ln[1].data)
+            for nm, (W, b) in (("k", keys), ("q", queries), ("v", values), ("r", reproj)):
+                setattr(f, "w" + nm, _ptr(W.data)); setattr(f, "b" + nm, _ptr(b.data))
+                if grads:
+                    setattr(f, "dw" + nm, _ptr(W.grad)); setattr(f, "db" + nm, _ptr(b.grad))
+            if grads:
+                f.dgamma, f.dbeta = _ptr(ln[0].grad), _ptr(ln[1].grad)
+            f.out, f.ctx, f.kstat, f.part, f.part_floats = _ptr(out.data), _ptr(ctx), _ptr(kstat), _ptr(part), nf
+            f.ldt, f.ldo, f.C, f.B, f.N, f.eps = t.ld, out.ld, Cc, B, N, eps
+            if dout is not None:
+                f.dout, f.lddo, f.dt, f.lddt, f.g1, f.acc_dt = _ptr(dout), dout.stride(0), _ptr(dt), dt.stride(0), _ptr(g1), acc
+            return f
+
+        part = self.f32(nf)
+        f = desc(part)
+        self.n_launch += 3
+        _timed("hbm:effatt_fwd (LayerNorm + EfficientAttention + residual: token statistics, context fold, output)",
+               3.0 * t.rows * Cc * es, lambda: L.tc_effatt_fwd(C.byref(f), self.dt, self.stream))
+        del part
+
+        def bwd():
+            dy = self.grad_of(out)
+            if dy is None or not t.requires_grad:
+                return
+            gx, acc = self.wgrad(t)
+            part = self.f32(nf)
+            g1 = _empty((t.rows, Cc), self.dtype, self.dev)
+            fb = desc(part, dy, gx, g1, acc, grads=True)
+            self.n_launch += 4
+            _timed("hbm:effatt_bwd (query side + d_ctx partials, d_ctx fold, key/value side + LayerNorm backward, parameter fold)",
+                   (6.0 + acc) * t.rows * Cc * es, lambda: L.tc_effatt_bwd(C.byref(fb), self.dt, self.stream))
+        self._rec(bwd)
+        return out
 
     def layernorm(self, x: Var, g: P, b: P, eps: float = 1e-5, act: int = ACT_NONE, out: Optional[Var] = None) -> Var:
         Gn = self.ngroups

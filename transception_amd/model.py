@@ -550,7 +550,12 @@ def _eff_attention(M, G, n1: Var, name: str, B: int, N: int, residual: Optional[
 
 def _eff_block(M, G, t: Var, name: str, B: int, H: int, W: int) -> Var:
     """EfficientTransformerBlock, MSTr.py:164-173."""
-    tx = _eff_attention(M, G, _ln(M, G, t, name + ".norm1"), name + ".attn", B, H * W, residual=t)
+    if G.effatt_supported(t):
+        a = name + ".attn"
+        tx = G.eff_attention_block(t, (M._P(G, name + ".norm1.weight"), M._P(G, name + ".norm1.bias")), _lin(M, G, a + ".keys"),
+                                   _lin(M, G, a + ".queries"), _lin(M, G, a + ".values"), _lin(M, G, a + ".reprojection"), B, H * W)
+    else:
+        tx = _eff_attention(M, G, _ln(M, G, t, name + ".norm1"), name + ".attn", B, H * W, residual=t)
     n2 = _ln(M, G, tx, name + ".norm2")
     return _mixffn(M, G, n2, name + ".mlp", B, H, W, residual=tx)
 
