@@ -219,6 +219,9 @@ typedef struct TcFfnFused {
     int ldx, ldr, ldo, C, B, H, W, groups;
     float eps;
     int tile_h, tile_w;          /* 0: the library picks the pixel tile; otherwise a forced shape (tests, tuning) */
+    const void* pre_gamma; const void* pre_beta; float pre_eps;   /* optional LayerNorm(C) of x ahead of fc1 (the block's norm2, MSTr.py:168 /
+                                                                    :906-907), applied as the tile is loaded; null: x is used as it is.  Same
+                                                                    per-group stride (wstride) as the other parameters */
 } TcFfnFused;
 int tc_ffn_fused_supported(int C, int dtype);
 int tc_ffn_fused_fwd(const TcFfnFused* f, int dtype, void* stream);
@@ -244,6 +247,10 @@ typedef struct TcFfnBwd {
     int ldx, lddy, lddx, C, B, H, W, groups, acc_dx;
     float eps;
     int tile_h, tile_w;          /* 0: the library picks the pixel tile of launch 2 */
+    const void* pre_gamma; const void* pre_beta; float* dpre_gamma; float* dpre_beta; float pre_eps;
+                                 /* the forward's optional LayerNorm(C) of x (TcFfnFused.pre_gamma): x is normalised again as it is loaded, dx
+                                    becomes the gradient of the RAW x (LayerNorm backward applied where dx leaves launch 2) and the fp32
+                                    dpre_* receive (+=) the LayerNorm's parameter gradients; null: no LayerNorm */
 } TcFfnBwd;
 int tc_ffn_fused_bwd_supported(int C, int dtype);
 long long tc_ffn_fused_bwd_scratch_floats(int C, int groups);

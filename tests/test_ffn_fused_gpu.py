@@ -10,10 +10,12 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _params(C, groups, gen):
+def _params(C, groups, gen, pre=False):
     """One flat fp32 arena holding `groups` parameter sets at a constant stride (what the three MB encoders look like)."""
     C4 = 4 * C
     shapes = [("W1", (C4, C)), ("b1", (C4,)), ("wd", (C4, 1, 3, 3)), ("bd", (C4,)), ("lg", (C4,)), ("lb", (C4,)), ("W2", (C, C4)), ("b2", (C,))]
+    if pre:
+        shapes += [("pg", (C,)), ("pb", (C,))]              # the block's norm2 ahead of the site
     offs, tot = {}, 0
     for k, shp in shapes:
         offs[k] = tot
@@ -24,13 +26,13 @@ def _params(C, groups, gen):
             n = int(torch.tensor(shp).prod())
             fan = shp[1] if k in ("W1", "W2") else (9 if k == "wd" else 1)
             v = torch.randn(n, generator=gen) * (fan ** -0.5 if k in ("W1", "W2", "wd") else 0.1)
-            if k == "lg":
+            if k in ("lg", "pg"):
                 v = 1.0 + 0.2 * torch.randn(n, generator=gen)
             flat[g * tot + offs[k]: g * tot + offs[k] + n] = v
     return flat, offs, dict(shapes), tot
 
 
-def _ref(x, flat, offs, shapes, tot, groups, B, H, W, res):
+def _ref(x, flat, offs, shapes, tot, groups, B, H, W, res, pre_eps=None):
     """PyTorch fp32 reference per group; x [groups*B*H*W, C] token-major."""
     C = x.shape[1]
     outs = []
@@ -38,6 +40,8 @@ def _ref(x, flat, offs, shapes, tot, groups, B, H, W, res):
     for g in range(groups):
         P = {k: flat[g * tot + offs[k]: g * tot + offs[k] + int(torch.tensor(shapes[k]).prod())].view(shapes[k]) for k in offs}
         xg = x[g * M:(g + 1) * M]
+        if pre_eps is not None:
+            xg = F.layer_norm(xg, (C,), P["pg"], P["pb"], pre_eps)
         h = F.linear(xg, P["W1"], P["b1"])
         hm = h.view(B, H, W, -1).permute(0, 3, 1, 2)
         d = (F.conv2d(hm, P["wd"], P["bd"], padding=1, groups=hm.shape[1]) + hm).permute(0, 2, 3, 1).reshape(M, -1)
@@ -46,7 +50,7 @@ def _ref(x, flat, offs, shapes, tot, groups, B, H, W, res):
     return torch.cat(outs, 0)
 
 
-def _engine_run(dtype, fused, x, flat, offs, shapes, tot, groups, B, H, W, res, gout):
+def _engine_run(dtype, fused, x, flat, offs, shapes, tot, groups, B, H, W, res, gout, pre_eps=None):
     import transception_amd.model as MM
     from transception_amd.engine import Graph, P, Var
     dev = torch.device(DEV)
@@ -54,20 +58,24 @@ def _engine_run(dtype, fused, x, flat, offs, shapes, tot, groups, B, H, W, res, 
     pl = pf.to(dtype)
     gf = torch.zeros_like(pf)
     G = Graph(dtype, dev, training=True, record=True)
+    from transception_amd import _lib
+    calls0 = _lib._Lib.calls
 
     def mk(k):
         n = int(torch.tensor(shapes[k]).prod())
         shp = shapes[k] if k != "wd" else shapes[k]
         return P(pl[offs[k]:offs[k] + n].view(shp), gf[offs[k]:offs[k] + n].view(shp), tot if groups > 1 else 0)
-    xv, rv = Var(x.to(dev).to(dtype).contiguous()), Var(res.to(dev).to(dtype).contiguous())
+    xv = Var(x.to(dev).to(dtype).contiguous())
+    rv = xv if res is None else Var(res.to(dev).to(dtype).contiguous())       # res None: the block form, residual = the site's raw input
     W1, b1, wd, bd, lg, lb, W2, b2 = (mk(k) for k in ("W1", "b1", "wd", "bd", "lg", "lb", "W2", "b2"))
+    pre = (mk("pg"), mk("pb"), pre_eps) if pre_eps is not None else None
     ctx = G.grouped(groups, tot) if groups > 1 else None
     if ctx:
         ctx.__enter__()
     if fused:
-        out = G.mixffn([dict(x=xv, fc1=(W1, b1), dw=(wd, bd), ln=(lg, lb), fc2=(W2, b2), geo=(B, H, W), residual=rv)])[0]
+        out = G.mixffn([dict(x=xv, fc1=(W1, b1), dw=(wd, bd), ln=(lg, lb), fc2=(W2, b2), geo=(B, H, W), residual=rv, pre_ln=pre)])[0]
     else:
-        h = G.linear(xv, W1, b1)
+        h = G.linear(xv if pre is None else G.layernorm(xv, *pre), W1, b1)
         d = G.dwconv(h, wd, bd, B, H, W, 3, 1, True)
         a = G.layernorm(d, lg, lb, 1e-5, MM.ACT_GELU)
         out = G.linear(a, W2, b2, residual=rv)
@@ -78,7 +86,50 @@ def _engine_run(dtype, fused, x, flat, offs, shapes, tot, groups, B, H, W, res, 
     if ctx:
         ctx.__exit__(None, None, None)
     torch.cuda.synchronize()
-    return out.data.float().cpu(), G.grad_of(xv).float().cpu(), G.grad_of(rv).float().cpu(), gf.cpu()
+    return out.data.float().cpu(), G.grad_of(xv).float().cpu(), G.grad_of(rv).float().cpu(), gf.cpu(), _lib._Lib.calls - calls0
+
+
+PRE_CASES = [(64, 2, 28, 28, 1, 1e-5), (64, 2, 20, 24, 3, 1e-6), (64, 1, 56, 56, 1, 1e-5), (64, 2, 7, 9, 1, 1e-6), (128, 3, 14, 14, 1, 1e-6)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", PRE_CASES)
+def test_mixffn_with_the_blocks_norm2_inside_the_tiled_kernels(case, dtype, monkeypatch):
+    """out = MixFFN(LayerNorm(x)) + x (MSTr.py:168 / :945): the LayerNorm applied as the tiled kernels load x (C = 64, 16-bit types; a
+    launch of its own otherwise), its backward where dx leaves -- against torch fp32 and against the engine with the fusion switched off."""
+    C, B, H, W, groups, eps = case
+    gen = torch.Generator().manual_seed(300 + C + H)
+    flat, offs, shapes, tot = _params(C, groups, gen, pre=True)
+    rows = groups * B * H * W
+    x = torch.randn(rows, C, generator=gen) * 1.3 + 0.2
+    gout = torch.randn(rows, C, generator=gen)
+    xr, fr = x.clone().requires_grad_(True), flat.clone().requires_grad_(True)
+    yr = _ref(xr, fr, offs, shapes, tot, groups, B, H, W, xr, eps)
+    yr.backward(gout)
+    import transception_amd.engine as E
+    monkeypatch.setattr(E, "_FFN_PRE_LN", True)             # (off by default: a wash in time; kept as a switch and kept correct)
+    y, gx, _, gp, nl = _engine_run(dtype, True, x, flat, offs, shapes, tot, groups, B, H, W, None, gout, eps)
+    monkeypatch.setattr(E, "_FFN_PRE_LN", False)
+    yu, gxu, _, gpu, nlu = _engine_run(dtype, True, x, flat, offs, shapes, tot, groups, B, H, W, None, gout, eps)
+    if C == 64 and dtype != torch.float32:
+        assert nl < nlu, (nl, nlu)                          # fewer C-ABI calls: the LayerNorm launches are gone
+    else:
+        assert nl == nlu
+    tol = {torch.float32: 3e-5, torch.bfloat16: 3e-2, torch.float16: 6e-3}[dtype]
+
+    def close(a, b, what):
+        err = float((a - b).abs().max()) / (float(b.abs().max()) + 1e-6)
+        assert err < tol, f"{what}: rel-to-max error {err:.3e} (case {case}, {dtype})"
+    close(y, yr.detach(), "out")
+    close(gx, xr.grad, "dx")
+    close(y, yu, "out vs separate LayerNorm")
+    close(gx, gxu, "dx vs separate LayerNorm")
+    for g in range(groups):
+        for k in offs:
+            n = int(torch.tensor(shapes[k]).prod())
+            sl = slice(g * tot + offs[k], g * tot + offs[k] + n)
+            close(gp[sl], fr.grad[sl], f"d{k}[group {g}]")
+            close(gp[sl], gpu[sl], f"d{k}[group {g}] vs separate LayerNorm")
 
 
 CASES = [  # C, B, H, W, groups
@@ -107,7 +158,7 @@ def test_fused_mixffn_matches_torch_and_unfused(case, dtype):
     xr, fr, rr = x.clone().requires_grad_(True), flat.clone().requires_grad_(True), res.clone().requires_grad_(True)
     yr = _ref(xr, fr, offs, shapes, tot, groups, B, H, W, rr)
     yr.backward(gout)
-    y, gx, gr, gp = _engine_run(dtype, True, x, flat, offs, shapes, tot, groups, B, H, W, res, gout)
+    y, gx, gr, gp, _ = _engine_run(dtype, True, x, flat, offs, shapes, tot, groups, B, H, W, res, gout)
     tol = {torch.float32: 3e-5, torch.bfloat16: 3e-2, torch.float16: 6e-3}[dtype]
 
     def close(a, b, what):
@@ -123,7 +174,7 @@ def test_fused_mixffn_matches_torch_and_unfused(case, dtype):
             sl = slice(g * tot + offs[k], g * tot + offs[k] + n)
             close(gp[sl], fr.grad[sl], f"d{k}[group {g}]")
     # and the unfused engine composition (same storage type): the two must agree at least as closely
-    yu, gxu, gru, gpu = _engine_run(dtype, False, x, flat, offs, shapes, tot, groups, B, H, W, res, gout)
+    yu, gxu, gru, gpu, _ = _engine_run(dtype, False, x, flat, offs, shapes, tot, groups, B, H, W, res, gout)
     close(y, yu, "out vs unfused")
     close(gx, gxu, "dx vs unfused")
     close(gp, gpu, "parameter gradients vs unfused")

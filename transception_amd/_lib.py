@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("TC_LIB_PATH") or os.path.join(HERE, "libtransception_
 
 TC_F32, TC_BF16, TC_F16 = 0, 1, 2
 ACT_NONE, ACT_HSWISH, ACT_COORD, ACT_SIGMOID, ACT_GELU = 0, 1, 2, 3, 4
-ABI_VERSION = 8
+ABI_VERSION = 9
 ATTN_DKV_SPLITS = 8                # include/transception_hip.h: partial dK|dV buffers in tc_attn_bwd_seg's fp32 scratch
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_longlong, C.c_float
@@ -53,7 +53,7 @@ class TcFfnFused(C.Structure):
                 ("res", vp), ("out", vp), ("h", vp), ("d", vp), ("a", vp), ("stat", vp),
                 ("sres", i64), ("sout", i64), ("wstride", i64),
                 ("ldx", i32), ("ldr", i32), ("ldo", i32), ("C", i32), ("B", i32), ("H", i32), ("W", i32), ("groups", i32), ("eps", f32),
-                ("tile_h", i32), ("tile_w", i32)]
+                ("tile_h", i32), ("tile_w", i32), ("pre_gamma", vp), ("pre_beta", vp), ("pre_eps", f32)]
 
 
 class TcFfnBwd(C.Structure):
@@ -63,7 +63,8 @@ class TcFfnBwd(C.Structure):
                 ("dw1", vp), ("db1", vp), ("dwd", vp), ("dbd", vp), ("dgamma", vp), ("dbeta", vp), ("dw2", vp), ("db2", vp),
                 ("sdy", i64), ("wstride", i64),
                 ("ldx", i32), ("lddy", i32), ("lddx", i32), ("C", i32), ("B", i32), ("H", i32), ("W", i32), ("groups", i32), ("acc_dx", i32),
-                ("eps", f32), ("tile_h", i32), ("tile_w", i32)]
+                ("eps", f32), ("tile_h", i32), ("tile_w", i32),
+                ("pre_gamma", vp), ("pre_beta", vp), ("dpre_gamma", vp), ("dpre_beta", vp), ("pre_eps", f32)]
 
 
 class TcEffAtt(C.Structure):

@@ -22,6 +22,7 @@ struct FfnFwdDev {
     int B, H, W;
     int TH, TW, tilesH, tilesW, HW2, HP, MT, IP, MT2, ntiles;
     float eps;
+    const void* pre_g; const void* pre_b; float pre_eps;           // LayerNorm(C) applied to x on its way into LDS (the block's norm2), or null
 };
 
 template <int C> struct FfnCfg {
@@ -57,7 +58,7 @@ __device__ long long g_ffnf_dbg[16 * 16];
 #define FSTAMP_INIT()
 #endif
 
-template <typename H, int C>
+template <typename H, int C, bool PRE>
 __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p) {
     using K = FfnCfg<C>;
     using V8 = typename TcHalf<H>::v8;
@@ -151,7 +152,32 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p
             int pix, cg, off;
             const int s = tid + i * NTH;
             const bool ok = xin(s, oh0, ow0, pix, cg, off);
-            if (s < MT * 32 * XC) *reinterpret_cast<uint4*>(xs + pix * PX + cg * 8) = ok ? xr[i] : make_uint4(0u, 0u, 0u, 0u);
+            uint4 v = ok ? xr[i] : make_uint4(0u, 0u, 0u, 0u);
+            if constexpr (PRE) {                                   // LayerNorm over the pixel's C channels: XC consecutive lanes hold one pixel
+                float f[8], gm[8], bt[8];
+                up8<H>(v, f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {                      // (parameter vectors sit at any 2-byte offset of the flat buffer)
+                    gm[e] = ldf<H>(reinterpret_cast<const H*>(p.pre_g) + wo + cg * 8 + e);
+                    bt[e] = ldf<H>(reinterpret_cast<const H*>(p.pre_b) + wo + cg * 8 + e);
+                }
+                float sm = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sm += f[e];
+#pragma unroll
+                for (int m = 1; m < XC; m <<= 1) sm += __shfl_xor(sm, m, 64);
+                const float mean = sm * (1.0f / C);
+                float q2 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { f[e] -= mean; q2 += f[e] * f[e]; }
+#pragma unroll
+                for (int m = 1; m < XC; m <<= 1) q2 += __shfl_xor(q2, m, 64);
+                const float rstd = rsqrtf(q2 * (1.0f / C) + p.pre_eps);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = f[e] * rstd * gm[e] + bt[e];
+                v = pk8<H>(f);
+            }
+            if (s < MT * 32 * XC) *reinterpret_cast<uint4*>(xs + pix * PX + cg * 8) = v;
         }
     };
 
@@ -433,7 +459,7 @@ void ffn_pick_tile(int H, int W, long long images, int fth, int ftw, int& TH, in
         }
 }
 
-template <typename H, int C>
+template <typename H, int C, bool PRE>
 int ffn_fused_fwd_launch(const TcFfnFused* f, hipStream_t s) {
     using K = FfnCfg<C>;
     FfnFwdDev p;
@@ -441,6 +467,7 @@ int ffn_fused_fwd_launch(const TcFfnFused* f, hipStream_t s) {
     p.res = f->res; p.out = f->out; p.h = f->h; p.d = f->d; p.a = f->a; p.stat = f->stat;
     p.sres = f->sres; p.sout = f->sout; p.wstride = f->wstride; p.ldx = f->ldx; p.ldr = f->ldr; p.ldo = f->ldo;
     p.B = f->B; p.H = f->H; p.W = f->W; p.eps = f->eps;
+    p.pre_g = f->pre_gamma; p.pre_b = f->pre_beta; p.pre_eps = f->pre_eps;
     ffn_pick_tile<C>(f->H, f->W, (long long)f->B * f->groups, f->tile_h, f->tile_w, p.TH, p.TW);
     if ((p.TH + 2) * (p.TW + 2) > K::MPMAX || p.TH * p.TW > K::IPMAX || p.TH * ((p.TW + 1) / 2) * K::SG > 256) return TC_ERR_ARG;
     p.tilesH = (f->H + p.TH - 1) / p.TH; p.tilesW = (f->W + p.TW - 1) / p.TW;
@@ -453,10 +480,10 @@ int ffn_fused_fwd_launch(const TcFfnFused* f, hipStream_t s) {
     if (f->groups > 1) { gx = (ncu + f->groups - 1) / f->groups; if (gx > nt) gx = (int)nt; if (gx < 1) gx = 1; }
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)ffn_fused_fwd_kernel<H, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::smem) != hipSuccess) return TC_ERR_LAUNCH;
+        if (hipFuncSetAttribute((const void*)ffn_fused_fwd_kernel<H, C, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::smem) != hipSuccess) return TC_ERR_LAUNCH;
         attr_done = true;
     }
-    hipLaunchKernelGGL((ffn_fused_fwd_kernel<H, C>), dim3(gx, f->groups), dim3(K::NTH), K::smem, s, p);
+    hipLaunchKernelGGL((ffn_fused_fwd_kernel<H, C, PRE>), dim3(gx, f->groups), dim3(K::NTH), K::smem, s, p);
     return tc_launch_status();
 }
 
@@ -480,6 +507,9 @@ extern "C" int tc_ffn_fused_supported(int C, int dtype) { return (C == 64 || C =
 extern "C" int tc_ffn_fused_fwd(const TcFfnFused* f, int dtype, void* stream) {
     if (!ffn_fused_args_ok(f) || !tc_ffn_fused_supported(f->C, dtype)) return TC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == TC_BF16) return f->C == 64 ? ffn_fused_fwd_launch<bf16_t, 64>(f, s) : ffn_fused_fwd_launch<bf16_t, 128>(f, s);
-    return f->C == 64 ? ffn_fused_fwd_launch<f16_t, 64>(f, s) : ffn_fused_fwd_launch<f16_t, 128>(f, s);
+    const bool pre = f->pre_gamma != nullptr;
+    if (pre && (!f->pre_beta || f->C != 64)) return TC_ERR_ARG;      // the fused LayerNorm(C) exists for the width whose backward is tiled as well
+    if (dtype == TC_BF16)
+        return f->C == 128 ? ffn_fused_fwd_launch<bf16_t, 128, false>(f, s) : pre ? ffn_fused_fwd_launch<bf16_t, 64, true>(f, s) : ffn_fused_fwd_launch<bf16_t, 64, false>(f, s);
+    return f->C == 128 ? ffn_fused_fwd_launch<f16_t, 128, false>(f, s) : pre ? ffn_fused_fwd_launch<f16_t, 64, true>(f, s) : ffn_fused_fwd_launch<f16_t, 64, false>(f, s);
 }

@@ -35,7 +35,7 @@ template <typename H> __device__ __forceinline__ uint4 pk8(const float* o) {
 template <int C> struct BwdPart {
     static constexpr int C4 = 4 * C;
     static constexpr int oW2 = 0, oB2 = oW2 + C * C4, oG = oB2 + C, oBt = oG + C4, n1 = oBt + C4;
-    static constexpr int oW1 = n1, oB1 = oW1 + C4 * C, oWd = oB1 + C4, oBd = oWd + 9 * C4, n = oBd + C4;
+    static constexpr int oW1 = n1, oB1 = oW1 + C4 * C, oWd = oB1 + C4, oBd = oWd + 9 * C4, oPG = oBd + C4, oPB = oPG + C, n = oPB + C;   // (+ the fused norm2's dgamma, dbeta)
 };
 
 struct FfnBwdDev {
@@ -45,6 +45,7 @@ struct FfnBwdDev {
     long long sdy, wstride;
     int ldx, lddy, lddx, B, H, W, M, acc_dx, nblk;
     int TH, TW, tilesH, tilesW, HW2, HP, MT, IP, MT2, KS, ntiles;
+    const void* pre_g; const void* pre_b; float pre_eps;           // LayerNorm(C) ahead of fc1 (applied to x as it is loaded, differentiated where dx leaves), or null
 };
 
 #ifdef TC_FFNB_TIMING
@@ -356,14 +357,14 @@ template <int C> struct DwCfg {
     static constexpr int PX = C + 8, PG = CH + 8, PO = C + 4;
     static constexpr int NXR = (MPMAX * XC + NTH - 1) / NTH, NGR = (MPMAX * GC + NTH - 1) / NTH;
     static constexpr size_t o_xs = 0, o_gs = o_xs + (size_t)MPMAX * PX * 2, o_hs = o_gs + (size_t)MPMAX * PG * 2, o_w1 = o_hs + (size_t)(MPMAX + 1) * PG * 2,
-                            o_tap = o_w1 + (size_t)C4 * PX * 2, o_b1 = o_tap + (size_t)9 * C4 * 4, smem = o_b1 + (size_t)C4 * 4;
+                            o_tap = o_w1 + (size_t)C4 * PX * 2, o_b1 = o_tap + (size_t)9 * C4 * 4, o_pre = o_b1 + (size_t)C4 * 4, smem = o_pre + (size_t)4 * C * 4;
     static_assert((size_t)NW * NCH * 22 * 64 * 4 <= o_w1, "the final fold of the depthwise sums aliases the tiles");
     static_assert(MT2MAX * NB <= NW && (CH / 32) * NB <= NW, "one MFMA block per wave");
     static_assert((size_t)IPMAX * PO * 4 <= (size_t)MPMAX * PG * 2, "the fp32 dx stage aliases the gd tile");
     static_assert(smem <= 160 * 1024, "LDS");
 };
 
-template <typename H, int C>
+template <typename H, int C, bool PRE>
 __global__ __launch_bounds__(512, 2) void ffn_bwd_dw_kernel(const FfnBwdDev p) {
     using K = DwCfg<C>;
     using PT = BwdPart<C>;
@@ -378,6 +379,7 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dw_kernel(const FfnBwdDev p) {
     float* taps = reinterpret_cast<float*>(smem + K::o_tap);              // [9][C4]
     float* b1s = reinterpret_cast<float*>(smem + K::o_b1);                // [C4]
     float* stg = reinterpret_cast<float*>(smem + K::o_gs);                // fp32 dx stage over the gd tile
+    float* pre = reinterpret_cast<float*>(smem + K::o_pre);               // fused norm2: gamma[C], beta[C], then this workgroup's dgamma[C], dbeta[C]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     const int gi = lane & 15, gq2 = (lane >> 4) & 1;
@@ -396,6 +398,12 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dw_kernel(const FfnBwdDev p) {
         for (int i = tid; i < 9 * C4; i += NTH) { const int ch = i / 9, t = i - ch * 9; taps[t * C4 + ch] = ldf<H>(wd + i); }
         for (int i = tid; i < C4; i += NTH) b1s[i] = ldf<H>(b1 + i);
         for (int i = tid; i < PG; i += NTH) hs[MPMAX * PG + i] = 0;
+        if constexpr (PRE) {
+            for (int i = tid; i < C; i += NTH) {
+                pre[i] = ldf<H>(reinterpret_cast<const H*>(p.pre_g) + wo + i); pre[C + i] = ldf<H>(reinterpret_cast<const H*>(p.pre_b) + wo + i);
+                pre[2 * C + i] = 0.f; pre[3 * C + i] = 0.f;
+            }
+        }
         for (int s = tid; s < C4 * XC; s += NTH) {                 // W1 stays in LDS for the whole launch
             const int r = s / XC, cg = s - r * XC;
             *reinterpret_cast<uint4*>(w1s + krow(r) * PX + cg * 8) = *reinterpret_cast<const uint4*>(W1 + (long long)r * C + cg * 8);
@@ -432,7 +440,27 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dw_kernel(const FfnBwdDev p) {
             const int s = tid + i * NTH, pix = s / XC, cg = s - pix * XC;
             int ih, iw;
             const bool ok = halo_in(pix, oh0, ow0, ih, iw);
-            if (pix < HP) *reinterpret_cast<uint4*>(xs + pix * PX + cg * 8) = ok ? xr[i] : make_uint4(0u, 0u, 0u, 0u);
+            uint4 v = ok ? xr[i] : make_uint4(0u, 0u, 0u, 0u);
+            if constexpr (PRE) {                                    // n2 = LayerNorm(x): XC consecutive lanes hold one pixel
+                float f[8];
+                up8<H>(v, f);
+                float sm = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sm += f[e];
+#pragma unroll
+                for (int m = 1; m < XC; m <<= 1) sm += __shfl_xor(sm, m, 64);
+                const float mean = sm * (1.0f / C);
+                float q2 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { f[e] -= mean; q2 += f[e] * f[e]; }
+#pragma unroll
+                for (int m = 1; m < XC; m <<= 1) q2 += __shfl_xor(q2, m, 64);
+                const float rstd = rsqrtf(q2 * (1.0f / C) + p.pre_eps);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = f[e] * rstd * pre[cg * 8 + e] + pre[C + cg * 8 + e];
+                v = pk8<H>(f);
+            }
+            if (pix < HP) *reinterpret_cast<uint4*>(xs + pix * PX + cg * 8) = v;
         }
     };
     auto gfetch = [&](int tidx, int c) __attribute__((always_inline)) {
@@ -616,6 +644,17 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dw_kernel(const FfnBwdDev p) {
             BSTAMP(10);
         }
         // ---- dx leaves as whole pixel rows (through LDS, over the gd tile)
+        constexpr int NEP = (K::IPMAX * XC + NTH - 1) / NTH;          // trips of the leaving loop
+        uint4 xraw[NEP];
+        if constexpr (PRE) {                                         // the raw rows the LayerNorm backward needs: in flight under the staging
+            const H* xb = X + (long long)b * imgpix * p.ldx;
+#pragma unroll
+            for (int k = 0; k < NEP; ++k) {
+                const int s = k * NTH + tid, q = s < IP * XC ? s / XC : 0, y = q / TW, x = q - y * TW;
+                const bool valid = s < IP * XC && oh0 + y < Himg && ow0 + x < Wimg;
+                xraw[k] = *reinterpret_cast<const uint4*>(xb + (valid ? (long long)(oh0 + y) * Wimg + ow0 + x : 0) * p.ldx + (tid % XC) * 8);
+            }
+        }
         if (cb < p.MT2) {
             float* sp = stg + (cb * 32 + l31) * PO + nb * 32 + 4 * hh;
 #pragma unroll
@@ -623,7 +662,7 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dw_kernel(const FfnBwdDev p) {
                 *reinterpret_cast<float4*>(sp + 8 * gq) = make_float4(accx[4 * gq], accx[4 * gq + 1], accx[4 * gq + 2], accx[4 * gq + 3]);
         }
         __syncthreads();
-        {
+        if constexpr (!PRE) {
             H* dxb = DX + (long long)b * imgpix * p.lddx;
             for (int s = tid; s < IP * XC; s += NTH) {
                 const int q = s / XC, cg = s - q * XC, y = q / TW, x = q - y * TW;
@@ -638,6 +677,70 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dw_kernel(const FfnBwdDev p) {
                     for (int e = 0; e < 8; ++e) v[e] += o[e];
                 }
                 *reinterpret_cast<uint4*>(dst) = pk8<H>(v);
+            }
+        } else {
+            H* dxb = DX + (long long)b * imgpix * p.lddx;
+            const int cg = tid % XC;
+            float dgl[8], dbl[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { dgl[e] = 0.f; dbl[e] = 0.f; }
+#pragma unroll
+            for (int k = 0; k < NEP; ++k) {                         // (whole pixels per lane group, every lane makes every trip)
+                const int s = k * NTH + tid, q = s < IP * XC ? s / XC : 0, y = q / TW, x = q - y * TW;
+                const bool valid = s < IP * XC && oh0 + y < Himg && ow0 + x < Wimg;
+                const long long pix = valid ? (long long)(oh0 + y) * Wimg + ow0 + x : 0;
+                const float4 v0 = *reinterpret_cast<const float4*>(stg + q * PO + cg * 8), v1 = *reinterpret_cast<const float4*>(stg + q * PO + cg * 8 + 4);
+                float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                if constexpr (PRE) {
+                    // v = d(n2); the gradient of x = LayerNorm backward of it, from the raw row (still in L2) -- statistics recomputed
+                    float f[8];
+                    up8<H>(xraw[k], f);
+                    float sm = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) sm += f[e];
+#pragma unroll
+                    for (int m = 1; m < XC; m <<= 1) sm += __shfl_xor(sm, m, 64);
+                    const float mean = sm * (1.0f / C);
+                    float q2 = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { f[e] -= mean; q2 += f[e] * f[e]; }
+#pragma unroll
+                    for (int m = 1; m < XC; m <<= 1) q2 += __shfl_xor(q2, m, 64);
+                    const float rstd = rsqrtf(q2 * (1.0f / C) + p.pre_eps);
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        f[e] *= rstd;                               // xhat
+                        if (valid) { dgl[e] += v[e] * f[e]; dbl[e] += v[e]; }
+                        v[e] *= pre[cg * 8 + e];
+                        s1 += v[e]; s2 += v[e] * f[e];
+                    }
+#pragma unroll
+                    for (int m = 1; m < XC; m <<= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
+                    s1 *= 1.0f / C; s2 *= 1.0f / C;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = rstd * (v[e] - s1 - f[e] * s2);
+                }
+                if (valid) {
+                    H* dst = dxb + pix * p.lddx + cg * 8;
+                    if (p.acc_dx) {
+                        float o[8];
+                        up8<H>(*reinterpret_cast<const uint4*>(dst), o);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += o[e];
+                    }
+                    *reinterpret_cast<uint4*>(dst) = pk8<H>(v);
+                }
+            }
+            if constexpr (PRE) {                                    // lanes of one channel group (stride XC) fold, then one LDS add per wave and channel
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+#pragma unroll
+                    for (int m = XC; m < 64; m <<= 1) { dgl[e] += __shfl_xor(dgl[e], m, 64); dbl[e] += __shfl_xor(dbl[e], m, 64); }
+                if (lane < XC) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { atomicAdd(pre + 2 * C + cg * 8 + e, dgl[e]); atomicAdd(pre + 3 * C + cg * 8 + e, dbl[e]); }
+                }
             }
         }
         __syncthreads();
@@ -655,6 +758,7 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dw_kernel(const FfnBwdDev p) {
     {   // depthwise sums: the eight waves (rows) of the workgroup fold through LDS (the tiles are dead)
         float* red = reinterpret_cast<float*>(smem);               // [NW][NCH * 22][64]
         __syncthreads();
+        if constexpr (PRE) { if (tid < 2 * C) PB[PT::oPG + tid] = pre[2 * C + tid]; }
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
 #pragma unroll
@@ -677,7 +781,7 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dw_kernel(const FfnBwdDev p) {
 }
 
 // --------------------------------------------------------------------------------------------------------------------- launch 3
-struct RedDev { const float* part; float* dst[8]; int off[9]; int nwg, nper; long long wstride; };
+struct RedDev { const float* part; float* dst[10]; int off[11]; int nwg, nper; long long wstride; };
 
 // grid (nper / 64, groups), 256 threads = 16 float4 columns x 16 slices of the workgroup list
 __global__ __launch_bounds__(256) void ffn_bwd_reduce_kernel(const RedDev p) {
@@ -700,7 +804,7 @@ __global__ __launch_bounds__(256) void ffn_bwd_reduce_kernel(const RedDev p) {
         const int idx = q * 4;
         int seg = 0;
 #pragma unroll
-        for (int k = 1; k < 8; ++k) seg += idx >= p.off[k];
+        for (int k = 1; k < 10; ++k) seg += idx >= p.off[k];
         float* d = p.dst[seg];
         if (d) {
             d += (long long)g * p.wstride + (idx - p.off[seg]);
@@ -750,7 +854,7 @@ bool bwd_args_ok(const TcFfnBwd* f) {
     return (long long)f->H * f->W * (mx > 4 * f->C ? mx : 4 * f->C) < 0x7fffffffLL && (long long)f->B * f->H * f->W < 0x7fffffffLL;
 }
 
-template <typename H, int C>
+template <typename H, int C, bool PRE>
 int ffn_bwd_launch(const TcFfnBwd* f, hipStream_t s) {
     using PT = BwdPart<C>;
     using KL = LnCfg<C>;
@@ -763,6 +867,7 @@ int ffn_bwd_launch(const TcFfnBwd* f, hipStream_t s) {
     p.x = f->x; p.dy = f->dy; p.d = f->d; p.stat = f->stat; p.w1 = f->w1; p.b1 = f->b1; p.wd = f->wd; p.gamma = f->gamma; p.beta = f->beta; p.w2 = f->w2;
     p.dx = f->dx; p.gd = f->gd; p.part = f->part; p.sdy = f->sdy; p.wstride = f->wstride; p.ldx = f->ldx; p.lddy = f->lddy; p.lddx = f->lddx;
     p.B = f->B; p.H = f->H; p.W = f->W; p.M = f->B * f->H * f->W; p.acc_dx = f->acc_dx;
+    p.pre_g = f->pre_gamma; p.pre_b = f->pre_beta; p.pre_eps = f->pre_eps;
     p.nblk = (p.M + KL::P - 1) / KL::P;
     dw_pick_tile<C>(f->H, f->W, f->B, gx, f->tile_h, f->tile_w, p.TH, p.TW);
     if ((p.TH + 2) * (p.TW + 2) > KD::MPMAX || p.TH * p.TW > KD::IPMAX || p.TH > KD::THMAX || p.TW > KD::TWMAX) return TC_ERR_ARG;
@@ -772,19 +877,19 @@ int ffn_bwd_launch(const TcFfnBwd* f, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)ffn_bwd_ln_kernel<H, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KL::smem) != hipSuccess) return TC_ERR_LAUNCH;
-        if (hipFuncSetAttribute((const void*)ffn_bwd_dw_kernel<H, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KD::smem) != hipSuccess) return TC_ERR_LAUNCH;
+        if (hipFuncSetAttribute((const void*)ffn_bwd_dw_kernel<H, C, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KD::smem) != hipSuccess) return TC_ERR_LAUNCH;
         attr_done = true;
     }
     hipLaunchKernelGGL((ffn_bwd_ln_kernel<H, C>), dim3(gx, f->groups), dim3(KL::NTH), KL::smem, s, p);
     if (tc_launch_status() != TC_OK) return TC_ERR_LAUNCH;
-    hipLaunchKernelGGL((ffn_bwd_dw_kernel<H, C>), dim3(gx, f->groups), dim3(KD::NTH), KD::smem, s, p);
+    hipLaunchKernelGGL((ffn_bwd_dw_kernel<H, C, PRE>), dim3(gx, f->groups), dim3(KD::NTH), KD::smem, s, p);
     if (tc_launch_status() != TC_OK) return TC_ERR_LAUNCH;
     RedDev r;
     r.part = f->part; r.nwg = gx; r.nper = PT::n; r.wstride = f->wstride;
-    float* dsts[8] = {f->dw2, f->db2, f->dgamma, f->dbeta, f->dw1, f->db1, f->dwd, f->dbd};
-    const int offs[9] = {PT::oW2, PT::oB2, PT::oG, PT::oBt, PT::oW1, PT::oB1, PT::oWd, PT::oBd, PT::n};
-    for (int i = 0; i < 8; ++i) r.dst[i] = dsts[i];
-    for (int i = 0; i < 9; ++i) r.off[i] = offs[i];
+    float* dsts[10] = {f->dw2, f->db2, f->dgamma, f->dbeta, f->dw1, f->db1, f->dwd, f->dbd, PRE ? f->dpre_gamma : nullptr, PRE ? f->dpre_beta : nullptr};
+    const int offs[11] = {PT::oW2, PT::oB2, PT::oG, PT::oBt, PT::oW1, PT::oB1, PT::oWd, PT::oBd, PT::oPG, PT::oPB, PT::n};
+    for (int i = 0; i < 10; ++i) r.dst[i] = dsts[i];
+    for (int i = 0; i < 11; ++i) r.off[i] = offs[i];
     hipLaunchKernelGGL(ffn_bwd_reduce_kernel, dim3((PT::n / 4 + 15) / 16, f->groups), dim3(256), 0, s, r);
     return tc_launch_status();
 }
@@ -807,5 +912,8 @@ extern "C" long long tc_ffn_fused_bwd_scratch_floats(int C, int groups) {
 extern "C" int tc_ffn_fused_bwd(const TcFfnBwd* f, int dtype, void* stream) {
     if (!bwd_args_ok(f) || !tc_ffn_fused_bwd_supported(f->C, dtype)) return TC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    return dtype == TC_BF16 ? ffn_bwd_launch<bf16_t, 64>(f, s) : ffn_bwd_launch<f16_t, 64>(f, s);
+    const bool pre = f->pre_gamma != nullptr;
+    if (pre && (!f->pre_beta || !f->dpre_gamma || !f->dpre_beta)) return TC_ERR_ARG;
+    if (dtype == TC_BF16) return pre ? ffn_bwd_launch<bf16_t, 64, true>(f, s) : ffn_bwd_launch<bf16_t, 64, false>(f, s);
+    return pre ? ffn_bwd_launch<f16_t, 64, true>(f, s) : ffn_bwd_launch<f16_t, 64, false>(f, s);
 }

@@ -186,6 +186,10 @@ _FFN_STORE_ACT = os.environ.get("TC_FFN_STORE_ACT", "1") != "0"   # MixFFN: keep
 _FFN_LN_GEMM_MAXC = int(os.environ.get("TC_FFN_LN_GEMM_MAXC", "64"))  # widest fc2 output for which LayerNorm + GELU run in its A loader
 _FFN_TILED = os.environ.get("TC_FFN_TILED", "1") != "0"        # MixFFN forward as one spatially tiled kernel where the library supports the width (csrc/mixffn.hip)
 _EFFATT_FUSED = os.environ.get("TC_EFFATT_FUSED", "1") != "0"        # EfficientAttention blocks through csrc/effatt.hip where the library supports the width
+# The LayerNorm ahead of a MixFFN site (the block's norm2) inside the tiled kernels (both directions tiled: C = 64).  OFF by default:
+# measured a wash -- 13.12 vs 13.08 ms per step with it on: the tiled kernels are VALU-bound, so the +17 us (backward) / +2 us (forward)
+# the in-kernel LayerNorm costs per site cancel the two memory-bound launches it removes (negative results).
+_FFN_PRE_LN = os.environ.get("TC_FFN_PRE_LN", "0") != "0"
 _FFN_TILED_BWD = os.environ.get("TC_FFN_TILED_BWD", "1") != "0"   # MixFFN backward on the chip (csrc/mixffn_bwd.hip) where the library supports the width
 _FFN_TILE_BWD = (0, 0)                                         # forced pixel tile of the tiled backward's second launch (tests)
 _FFN_TILE = (0, 0)                                             # forced pixel tile of the tiled MixFFN kernels (tests); (0, 0): the library's choice
@@ -777,7 +781,12 @@ class Graph:
             # ... and its backward from d + the row statistics alone (h, a, gp, dh never exist in HBM)
             fzb = (fz and _FFN_TILED_BWD and self.record and bool(L.tc_ffn_fused_bwd_supported(Cin, self.dt)) and x.requires_grad
                    and all(q.grad is not None for q in (W1, b1, wd, bd, lg, lb, W2, b2)))
-            st.append(dict(fz=fz, fzb=fzb, lng=lng, so=Cin if side else M * out.ld, side=side, x=x, W1=W1, b1=b1, wd=wd, bd=bd, lg=lg, lb=lb, W2=W2, b2=b2, B=B, H=H, W=W, C4=C4, Cin=Cin, M=M, cn=cn,
+            # the block's LayerNorm ahead of the site (norm2): inside the tiled kernels where both directions are tiled, a launch of its own otherwise
+            pre = s_.get("pre_ln")
+            if pre is not None and not (_FFN_PRE_LN and fz and (fzb or not self.record) and Cin == 64 and (not self.record or pre[0].grad is not None)):
+                x = self.layernorm(x, pre[0], pre[1], pre[2])
+                pre = None
+            st.append(dict(pre=pre, fz=fz, fzb=fzb, lng=lng, so=Cin if side else M * out.ld, side=side, x=x, W1=W1, b1=b1, wd=wd, bd=bd, lg=lg, lb=lb, W2=W2, b2=b2, B=B, H=H, W=W, C4=C4, Cin=Cin, M=M, cn=cn,
                            nch=C4 // cn, nch2=(C4 + 63) // 64, res=s_.get("residual"), out=out,
                            h=_empty((x.rows, C4), self.dtype, self.dev) if not fzb else None, d=_empty((x.rows, C4), self.dtype, self.dev),
                            a=_empty((x.rows, C4), self.dtype, self.dev) if ((_FFN_STORE_ACT or not lng or fz) and not fzb) else None,
@@ -791,7 +800,8 @@ class Graph:
                                _ptr(t["a"]) if (self.record and t["a"] is not None) else None,
                                _ptr(t["stat"]) if self.record else None,
                                t["M"] * res.ld if res is not None else 0, t["so"], gs, t["x"].ld, res.ld if res is not None else 0, out.ld,
-                               t["Cin"], t["B"], t["H"], t["W"], Gn, 1e-5, *_FFN_TILE)
+                               t["Cin"], t["B"], t["H"], t["W"], Gn, 1e-5, *_FFN_TILE,
+                               *((_ptr(t["pre"][0].data), _ptr(t["pre"][1].data), t["pre"][2]) if t["pre"] is not None else (None, None, 0.0)))
                 self.n_launch += 1
                 _timed("hbm:ffn_fused_fwd (MixFFN forward, one tiled kernel)", (2.0 * t["Cin"] + (t["Cin"] if res is not None else 0) + t["C4"]) * t["x"].rows * t["d"].element_size(),
                        lambda f=f: L.tc_ffn_fused_fwd(C.byref(f), self.dt, self.stream))
@@ -850,7 +860,9 @@ class Graph:
                          _ptr(t["lg"].data), _ptr(t["lb"].data), _ptr(t["W2"].data), _ptr(gx), _ptr(gd), _ptr(part), nf,
                          _ptr(t["W1"].grad), _ptr(t["b1"].grad), _ptr(t["wd"].grad), _ptr(t["bd"].grad), _ptr(t["lg"].grad), _ptr(t["lb"].grad),
                          _ptr(t["W2"].grad), _ptr(t["b2"].grad), t["so"], gs, x.ld, dy.stride(0), gx.stride(0), t["Cin"], t["B"], t["H"], t["W"], Gn,
-                         acc, 1e-5, *_FFN_TILE_BWD)
+                         acc, 1e-5, *_FFN_TILE_BWD,
+                         *((_ptr(t["pre"][0].data), _ptr(t["pre"][1].data), _ptr(t["pre"][0].grad), _ptr(t["pre"][1].grad), t["pre"][2]) if t["pre"] is not None
+                           else (None, None, None, None, 0.0)))
             self.n_launch += 3
             es = t["d"].element_size()
             _timed("hbm:ffn_fused_bwd (MixFFN backward on the chip: LayerNorm/GELU backward + fc2 gradients, dw3x3/fc1 gradients, partial fold)",

@@ -510,16 +510,20 @@ def _bn(M, G, x, name, act, residual=None, out=None):
 FUSED_MIXFFN = os.environ.get("TC_FUSED_MIXFFN", "1") != "0"
 
 
-def _mixffn_site(M, G, x, name, B, H, W, residual, out=None) -> dict:
-    return dict(x=x, fc1=_lin(M, G, name + ".fc1"), dw=(M._P(G, name + ".dwconv.dwconv.weight"), M._P(G, name + ".dwconv.dwconv.bias")),
+def _mixffn_site(M, G, x, name, B, H, W, residual, out=None, pre_ln=None) -> dict:
+    return dict(pre_ln=pre_ln, x=x, fc1=_lin(M, G, name + ".fc1"), dw=(M._P(G, name + ".dwconv.dwconv.weight"), M._P(G, name + ".dwconv.dwconv.bias")),
                 ln=(M._P(G, name + ".norm1.weight"), M._P(G, name + ".norm1.bias")), fc2=_lin(M, G, name + ".fc2"), geo=(B, H, W),
                 residual=residual, out=out)
 
 
-def _mixffn(M, G, x, name, B, H, W, residual, out=None):
-    """MixFFN_skip, MSTr.py:889-902 (fc1 evaluated once): fc2(GELU(LN(dw3x3(h) + h))) + residual."""
+def _mixffn(M, G, x, name, B, H, W, residual, out=None, pre_ln=None):
+    """MixFFN_skip, MSTr.py:889-902 (fc1 evaluated once): fc2(GELU(LN(dw3x3(h) + h))) + residual.
+    pre_ln = (norm name, eps): the site's input is LayerNorm(x) -- the block's norm2 -- which the tiled kernels apply themselves."""
+    pl = (M._P(G, pre_ln[0] + ".weight"), M._P(G, pre_ln[0] + ".bias"), pre_ln[1]) if pre_ln is not None else None
     if FUSED_MIXFFN and not G.use_streams and x.data.is_contiguous():
-        return G.mixffn([_mixffn_site(M, G, x, name, B, H, W, residual, out)])[0]     # 3 + 3 launches (engine.Graph.mixffn)
+        return G.mixffn([_mixffn_site(M, G, x, name, B, H, W, residual, out, pl)])[0]     # 3 + 3 launches (engine.Graph.mixffn)
+    if pl is not None:
+        x = G.layernorm(x, *pl)
     h = G.linear(x, *_lin(M, G, name + ".fc1"))                 # B = images per weight group (G.ngroups groups are stacked)
     d = G.dwconv(h, M._P(G, name + ".dwconv.dwconv.weight"), M._P(G, name + ".dwconv.dwconv.bias"), B, H, W, 3, 1, True)
     a = _ln(M, G, d, name + ".norm1", act=ACT_GELU)
@@ -556,8 +560,7 @@ def _eff_block(M, G, t: Var, name: str, B: int, H: int, W: int) -> Var:
                                    _lin(M, G, a + ".queries"), _lin(M, G, a + ".values"), _lin(M, G, a + ".reprojection"), B, H * W)
     else:
         tx = _eff_attention(M, G, _ln(M, G, t, name + ".norm1"), name + ".attn", B, H * W, residual=t)
-    n2 = _ln(M, G, tx, name + ".norm2")
-    return _mixffn(M, G, n2, name + ".mlp", B, H, W, residual=tx)
+    return _mixffn(M, G, tx, name + ".mlp", B, H, W, residual=tx, pre_ln=(name + ".norm2", 1e-5))
 
 
 def _ripm(M, G, m: Var, name: str, B: int, side: int) -> Tuple[Var, int]:
@@ -627,8 +630,7 @@ def _mhca_block(M, G, t: Var, blk: str, enc: str, B: int, side: int, out: Option
     """MHCABlock, MSTr.py:935-946: shared cpe (dw3x3 + identity) in every block, LN eps 1e-6."""
     t1 = G.dwconv(t, M._P(G, enc + ".cpe.proj.weight"), M._P(G, enc + ".cpe.proj.bias"), B, side, side, 3, 1, True)
     t2 = _factor_att(M, G, _ln(M, G, t1, blk + ".norm1", 1e-6), blk, enc, B, side, residual=t1)
-    n2 = _ln(M, G, t2, blk + ".norm2", 1e-6)
-    return _mixffn(M, G, n2, blk + ".mlp", B, side, side, residual=t2, out=out)
+    return _mixffn(M, G, t2, blk + ".mlp", B, side, side, residual=t2, out=out, pre_ln=(blk + ".norm2", 1e-6))
 
 
 def _coord_att(M, G, x: Var, name: str, B: int, side: int, out: Var) -> Var:
