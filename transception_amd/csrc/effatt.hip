@@ -170,6 +170,18 @@ template <typename H> __device__ __forceinline__ void load_tile(bf16_t* X, const
         *reinterpret_cast<uint4*>(X + r * PT + cg * 8) = v;
     }
 }
+// the same in two halves: the global loads into registers (issued a round early), the registers into LDS
+template <typename H> __device__ __forceinline__ void fetch_tile(uint4 (&v)[4], const H* src, long long row0, int ld, int nvalid, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 8 * i + (lane >> 3), cg = lane & 7;
+        v[i] = r < nvalid ? *reinterpret_cast<const uint4*>(src + (row0 + r) * ld + cg * 8) : make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+__device__ __forceinline__ void stash_tile(bf16_t* X, const uint4 (&v)[4], int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(X + (8 * i + (lane >> 3)) * PT + (lane & 7) * 8) = v[i];
+}
 template <typename H> __device__ __forceinline__ void store_tile(const bf16_t* X, H* dst, long long row0, int ld, int nvalid, int lane) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -263,9 +275,12 @@ __global__ __launch_bounds__(64 * NW) void effatt_kv_kernel(const EffDev p) {
     static_assert(NW * SCW * 4 <= 2 * RT * PT * 2, "scratch");
     const Lane L = lane_of();
     const Where q = where_am_i(p.wpi, p.N, TPW);
+    const H* T = reinterpret_cast<const H*>(p.t);
+    uint4 tf[NRD][4];                                              // the wave's token rows of both rounds: in flight under the parameter staging
+#pragma unroll
+    for (int rd = 0; rd < NRD; ++rd) fetch_tile<H>(tf[rd], T, q.row0 + (rd * NW + L.wv) * 32, p.ldt, q.ntok - (rd * NW + L.wv) * 32, L.lane);
     load_w<H>(wk, p.wk); load_w<H>(wv, p.wv);
     load_v<H>(vec, p.gamma); load_v<H>(vec + C, p.beta); load_v<H>(vec + 2 * C, p.bk); load_v<H>(vec + 3 * C, p.bv);
-    const H* T = reinterpret_cast<const H*>(p.t);
     __syncthreads();
     // pass 1: LN of the wave's blocks (kept in LDS), their K^T (kept in registers), the column maximum
     f32x16 kk[NRD][2], mx[2];
@@ -277,7 +292,7 @@ __global__ __launch_bounds__(64 * NW) void effatt_kv_kernel(const EffDev p) {
     for (int rd = 0; rd < NRD; ++rd) {
         const int blk = rd * NW + L.wv, nv = q.ntok - blk * 32;
         bf16_t* X = xt + blk * 32 * PT;
-        load_tile<H>(X, T, q.row0 + blk * 32, p.ldt, nv, L.lane);
+        stash_tile(X, tf[rd], L.lane);
         lds_fence();
         float rstd;
         ln_tile<H, false>(X, vec, vec + C, p.eps, L, rstd, nullptr);
@@ -334,17 +349,30 @@ __global__ __launch_bounds__(64 * NW) void effatt_kv_kernel(const EffDev p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------- forward 2
-// grid (B, C): thread = (channel c = blockIdx.y, column c'); ctx[b][c][c'], kstat[b] = (M[C], Z[C])
+// grid (B, C): thread = (channel c = blockIdx.y, column c'); ctx[b][c][c'], kstat[b] = (M[C], Z[C]).  The partials of an image are read
+// sixteen at a time with every load of a batch issued before the first use (a loop over a run-time count issues them one by one).
 __global__ __launch_bounds__(64) void effatt_ctx_kernel(const EffDev p) {
     const int b = blockIdx.x, c = blockIdx.y, cc = threadIdx.x;
     const float* PB = p.part + (long long)b * p.wpi * F_N;
     float M = -3.0e38f;
-    for (int w = 0; w < p.wpi; ++w) M = fmaxf(M, PB[(long long)w * F_N + F_M + c]);
+    for (int w0 = 0; w0 < p.wpi; w0 += 16) {
+        float mv[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) mv[k] = w0 + k < p.wpi ? PB[(long long)(w0 + k) * F_N + F_M + c] : -3.0e38f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) M = fmaxf(M, mv[k]);
+    }
     float Z = 0.f, acc = 0.f;
-    for (int w = 0; w < p.wpi; ++w) {
-        const float f = __expf(PB[(long long)w * F_N + F_M + c] - M);
-        Z += f * PB[(long long)w * F_N + F_S + c];
-        acc += f * PB[(long long)w * F_N + F_P + c * C + cc];
+    for (int w0 = 0; w0 < p.wpi; w0 += 16) {
+        float mv[16], sv[16], pv[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const bool in = w0 + k < p.wpi;
+            const float* q = PB + (long long)(in ? w0 + k : 0) * F_N;
+            mv[k] = in ? q[F_M + c] : -3.0e38f; sv[k] = in ? q[F_S + c] : 0.f; pv[k] = in ? q[F_P + c * C + cc] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const float f = __expf(mv[k] - M); Z += f * sv[k]; acc += f * pv[k]; }
     }
     p.ctx[((long long)b * C + c) * C + cc] = acc / Z;
     if (cc == 0) { p.kstat[(long long)b * 2 * C + c] = M; p.kstat[(long long)b * 2 * C + C + c] = Z; }
@@ -354,7 +382,7 @@ __global__ __launch_bounds__(64) void effatt_ctx_kernel(const EffDev p) {
 // workgroup = TOUT tokens, wave = 32 of them, nothing shared but the weights
 template <typename H>
 __global__ __launch_bounds__(64 * NW) void effatt_out_kernel(const EffDev p) {
-    __shared__ __attribute__((aligned(16))) bf16_t wq[C * PT], wr[C * PT], cx[C * PT], xts[TOUT * PT], nts[TOUT * PT], sts[TOUT * PT];
+    __shared__ __attribute__((aligned(16))) bf16_t wq[C * PT], wr[C * PT], cx[C * PT], nts[TOUT * PT], sts[TOUT * PT];      // 66 KB: two workgroups per CU
     __shared__ float vec[4 * C];                                   // gamma, beta, bq, br
     const Lane L = lane_of();
     const int wpo = (p.N + TOUT - 1) / TOUT;
@@ -363,18 +391,12 @@ __global__ __launch_bounds__(64 * NW) void effatt_out_kernel(const EffDev p) {
     load_v<H>(vec, p.gamma); load_v<H>(vec + C, p.beta); load_v<H>(vec + 2 * C, p.bq); load_v<H>(vec + 3 * C, p.br);
     const H* T = reinterpret_cast<const H*>(p.t);
     H* O = reinterpret_cast<H*>(p.out);
-    bf16_t* xt = xts + L.wv * 32 * PT; bf16_t* nt = nts + L.wv * 32 * PT; bf16_t* st = sts + L.wv * 32 * PT;
+    bf16_t* nt = nts + L.wv * 32 * PT; bf16_t* st = sts + L.wv * 32 * PT;
     const int nv = q.ntok - L.wv * 32;
     const long long row = q.row0 + L.wv * 32;
-    if (nv > 0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {                              // t twice: itself (the residual) and the copy that becomes n1 = LN(t)
-            const int r = 8 * i + (L.lane >> 3), cg = L.lane & 7;
-            const uint4 v = r < nv ? *reinterpret_cast<const uint4*>(T + (row + r) * p.ldt + cg * 8) : make_uint4(0u, 0u, 0u, 0u);
-            *reinterpret_cast<uint4*>(xt + r * PT + cg * 8) = v;
-            *reinterpret_cast<uint4*>(nt + r * PT + cg * 8) = v;
-        }
-    }
+    uint4 tf[4];                                                   // t: normalised in LDS, and kept as it is for the residual
+    fetch_tile<H>(tf, T, row, p.ldt, nv, L.lane);
+    stash_tile(nt, tf, L.lane);
     __syncthreads();
     if (nv <= 0) return;
     float rstd;
@@ -393,11 +415,27 @@ __global__ __launch_bounds__(64 * NW) void effatt_out_kernel(const EffDev p) {
     lds_fence();
     get_vecT(vec + 3 * C, L, a);
     mm_w<H>(wr, st, L, a);                                         // out^T[o][tok] = sum_c' Wr[o][c'] att[tok][c']
-    add_T<H>(xt, L, a);
     lds_fence();
-    put_T<H>(st, L, a);
+    // fp32 on the way out (one rounding, after the residual): channels 0..31 over the wave's att rows, 32..63 over its n1 rows (a row of
+    // PT 16-bit elements holds 36 floats)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(cb ? nt : st) + L.l31 * (PT / 2) + 8 * gq + 4 * L.hh) =
+                make_float4(a[cb][4 * gq], a[cb][4 * gq + 1], a[cb][4 * gq + 2], a[cb][4 * gq + 3]);
     lds_fence();
-    store_tile<H>(st, O, row, p.ldo, nv, L.lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                                  // + t, row-wise
+        const int r = 8 * i + (L.lane >> 3), cg = L.lane & 7;
+        const float* src = reinterpret_cast<const float*>((cg >> 2) ? nt : st) + r * (PT / 2) + (cg & 3) * 8;
+        const float4 o0 = *reinterpret_cast<const float4*>(src), o1 = *reinterpret_cast<const float4*>(src + 4);
+        float o[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w}, x[8];
+        up8s<H>(tf[i], x);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += x[e];
+        if (r < nv) *reinterpret_cast<uint4*>(O + (row + r) * p.ldo + cg * 8) = make_uint4(pack2<H>(o[0], o[1]), pack2<H>(o[2], o[3]), pack2<H>(o[4], o[5]), pack2<H>(o[6], o[7]));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------- backward 1
@@ -410,11 +448,14 @@ __global__ __launch_bounds__(64 * NW) void effatt_bq_kernel(const EffDev p) {
     float* sc = reinterpret_cast<float*>(tl);
     const Lane L = lane_of();
     const Where q = where_am_i(p.wpi, p.N, TPW);
-    load_w<H>(wq, p.wq); load_w<H>(wr, p.wr); load_ctx<H>(cx, p.ctx + (long long)q.b * C * C);
-    load_v<H>(vec, p.gamma); load_v<H>(vec + C, p.beta); load_v<H>(vec + 2 * C, p.bq);
     const H* T = reinterpret_cast<const H*>(p.t);
     const H* DY = reinterpret_cast<const H*>(p.dout);
     H* G1 = reinterpret_cast<H*>(p.g1);
+    uint4 tf[4], yf[4];                                            // next round's token / gradient rows, a round ahead
+    fetch_tile<H>(tf, T, q.row0 + L.wv * 32, p.ldt, q.ntok - L.wv * 32, L.lane);
+    fetch_tile<H>(yf, DY, q.row0 + L.wv * 32, p.lddo, q.ntok - L.wv * 32, L.lane);
+    load_w<H>(wq, p.wq); load_w<H>(wr, p.wr); load_ctx<H>(cx, p.ctx + (long long)q.b * C * C);
+    load_v<H>(vec, p.gamma); load_v<H>(vec + C, p.beta); load_v<H>(vec + 2 * C, p.bq);
     const int wo = L.wv * 32 * PT;
     bf16_t* nt = nts + wo; bf16_t* qt = qts + wo; bf16_t* at = ats + wo; bf16_t* yt = yts + wo; bf16_t* dat = dats + wo; bf16_t* dqt = dqts + wo;
     __syncthreads();
@@ -427,8 +468,12 @@ __global__ __launch_bounds__(64 * NW) void effatt_bq_kernel(const EffDev p) {
         const int blk = rd * NW + L.wv, nv = q.ntok - blk * 32;
         const long long row = q.row0 + blk * 32;
         const bool ok = L.l31 < nv;
-        load_tile<H>(nt, T, row, p.ldt, nv, L.lane);
-        load_tile<H>(yt, DY, row, p.lddo, nv, L.lane);             // (rows beyond the image: zeros -> no contribution)
+        stash_tile(nt, tf, L.lane);
+        stash_tile(yt, yf, L.lane);                                // (rows beyond the image: zeros -> no contribution)
+        if (rd + 1 < NRD) {
+            fetch_tile<H>(tf, T, row + NW * 32, p.ldt, nv - NW * 32, L.lane);
+            fetch_tile<H>(yf, DY, row + NW * 32, p.lddo, nv - NW * 32, L.lane);
+        }
         lds_fence();
         float rstd;
         ln_tile<H, false>(nt, vec, vec + C, p.eps, L, rstd, nullptr);
@@ -490,7 +535,13 @@ __global__ __launch_bounds__(64) void effatt_dctx_kernel(const EffDev p) {
     const int b = blockIdx.x, c = blockIdx.y, cc = threadIdx.x;
     const float* PB = p.part + (long long)b * p.wpi * (B1_N + B2_N);
     float acc = 0.f;
-    for (int w = 0; w < p.wpi; ++w) acc += PB[(long long)w * (B1_N + B2_N) + B1_DCTX + c * C + cc];
+    for (int w0 = 0; w0 < p.wpi; w0 += 16) {
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = w0 + k < p.wpi ? PB[(long long)(w0 + k) * (B1_N + B2_N) + B1_DCTX + c * C + cc] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc += v[k];
+    }
     p.dctx[((long long)b * C + c) * C + cc] = acc;
     float r = acc * p.ctx[((long long)b * C + c) * C + cc];
 #pragma unroll
@@ -519,6 +570,8 @@ __global__ __launch_bounds__(64 * NW) void effatt_bkv_kernel(const EffDev p) {
     const H* DY = reinterpret_cast<const H*>(p.dout);
     const H* G1 = reinterpret_cast<const H*>(p.g1);
     H* DT = reinterpret_cast<H*>(p.dt);
+    uint4 tf[4], gf[4];                                            // next round's token / g1 rows, a round ahead
+    fetch_tile<H>(tf, T, q.row0 + L.wv * 32, p.ldt, q.ntok - L.wv * 32, L.lane);
     const int wo = L.wv * 32 * PT;
     bf16_t* nt = tl + wo; bf16_t* kt = tl + RT * PT + wo; bf16_t* vt = tl + 2 * RT * PT + wo; bf16_t* dkt = dkts + wo; bf16_t* dvt = dvts + wo; bf16_t* gt = tl + 5 * RT * PT + wo;
     __syncthreads();
@@ -534,8 +587,12 @@ __global__ __launch_bounds__(64 * NW) void effatt_bkv_kernel(const EffDev p) {
         const int blk = rd * NW + L.wv, nv = q.ntok - blk * 32;
         const long long row = q.row0 + blk * 32;
         const bool ok = L.l31 < nv;
-        load_tile<H>(nt, T, row, p.ldt, nv, L.lane);
-        load_tile<H>(gt, G1, row, C, nv, L.lane);
+        stash_tile(nt, tf, L.lane);
+        uint4 yf[4], df[4];
+        fetch_tile<H>(gf, G1, row, C, nv, L.lane);                 // g1, dout and (accumulating) dt: used late in the round, requested now
+        fetch_tile<H>(yf, DY, row, p.lddo, nv, L.lane);
+        if (p.acc_dt) fetch_tile<H>(df, DT, row, p.lddt, nv, L.lane);
+        if (rd + 1 < NRD) fetch_tile<H>(tf, T, row + NW * 32, p.ldt, nv - NW * 32, L.lane);
         lds_fence();
         float rstd, xh[32];
         ln_tile<H, true>(nt, vec, vec + C, p.eps, L, rstd, xh);
@@ -577,6 +634,7 @@ __global__ __launch_bounds__(64 * NW) void effatt_bkv_kernel(const EffDev p) {
         mm_wt<H>(wv, dvt, L, a);
         lds_fence();
         put_T<H>(kt, L, a);                                        // (Ksm's readers are done): the two GEMM terms, by token rows
+        stash_tile(gt, gf, L.lane);
         lds_fence();
         // LayerNorm backward in row order: lane = token, its channels hh * 32 + 0..31
         float dn[32], s1 = 0.f, s2 = 0.f;
@@ -605,8 +663,8 @@ __global__ __launch_bounds__(64 * NW) void effatt_bkv_kernel(const EffDev p) {
             *reinterpret_cast<uint4*>(vt + L.l31 * PT + L.hh * 32 + qq * 8) = make_uint4(pack2<H>(o[0], o[1]), pack2<H>(o[2], o[3]), pack2<H>(o[4], o[5]), pack2<H>(o[6], o[7]));
         }
         // dt = LayerNorm backward + the residual's gradient (dout) [+ what dt holds]
-        load_tile<H>(kt, DY, row, p.lddo, nv, L.lane);
-        if (p.acc_dt) load_tile<H>(gt, DT, row, p.lddt, nv, L.lane);
+        stash_tile(kt, yf, L.lane);
+        if (p.acc_dt) stash_tile(gt, df, L.lane);
         lds_fence();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -653,9 +711,12 @@ __global__ __launch_bounds__(256) void effatt_fold_kernel(const FoldDev p) {
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (q * 4 < p.nper) {
         const float* base = p.part + (long long)q * 4;
-        for (int w = sl; w < p.nwv; w += 16) {
-            const float4 v = *reinterpret_cast<const float4*>(base + (long long)w * p.nper);
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        for (int w0 = sl; w0 < p.nwv; w0 += 16 * 8) {             // eight loads in flight per thread
+            float4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = w0 + 16 * k < p.nwv ? *reinterpret_cast<const float4*>(base + (long long)(w0 + 16 * k) * p.nper) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { s.x += v[k].x; s.y += v[k].y; s.z += v[k].z; s.w += v[k].w; }
         }
     }
     sh[sl][e] = s;
