@@ -460,6 +460,7 @@ def side_figures(args, dev, model, loss_fn, opt, step, x, y, build_model, engine
                "layernorm_fwd": ("ln_fwd_kernel",), "layernorm_bwd": ("ln_bwd_kernel",), "dwconv_fwd": ("dw_tile_kernel", "dw_multi_kernel<bf16, 0>", "dw_kernel"),
                "dwconv_bwd_input": ("dw_tile_kernel<bf16, 3, 8, 1>", "dw_multi_kernel<bf16, 1>"), "dwconv_bwd_weight": ("dw_tile_wgrad_kernel", "dw_multi_wgrad_kernel", "dw_wgrad_kernel"),
                "batchnorm_fwd": ("bn_partial_kernel<bf16, 0>", "bn_apply_kernel"), "batchnorm_bwd": ("bn_partial_kernel<bf16, 1>", "bn_bwd_apply_kernel"),
+               "effatt_fwd": ("effatt_kv_kernel", "effatt_ctx_kernel", "effatt_out_kernel"), "effatt_bwd": ("effatt_bq_kernel", "effatt_dctx_kernel", "effatt_bkv_kernel", "effatt_fold_kernel"),
                "coord_pool_fwd": ("coord_pool_fwd_kernel",), "coord_gate_fwd": ("coord_gate_fwd_kernel",), "pixel_shuffle": ("pixel_shuffle",)}
     hbm = []
     for name, ev in prof.items():
