@@ -28,8 +28,9 @@ NAMES = ["gamma", "beta", "wk", "bk", "wq", "bq", "wv", "bv", "wr", "br"]
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("B,N", [(2, 3136), (3, 200), (1, 32), (2, 257)])
-def test_effatt_fused_forward_and_backward_vs_torch_fp32(dtype, B, N):
+@pytest.mark.parametrize("B,N,pad", [(2, 3136, 0), (3, 200, 0), (1, 32, 0), (2, 257, 8), (1, 5, 0), (2, 784, 24)])
+def test_effatt_fused_forward_and_backward_vs_torch_fp32(dtype, B, N, pad):
+    """pad > 0: the token maps are column slices of wider buffers (row pitch C + pad), as the engine's views can be."""
     from transception_amd import _lib
     L = _lib.lib()
     dev = torch.device("cuda:0")
@@ -43,7 +44,11 @@ def test_effatt_fused_forward_and_backward_vs_torch_fp32(dtype, B, N):
     t32 = torch.randn(B * N, c, generator=g) * 1.5
     dy32 = torch.randn(B * N, c, generator=g)
     Pl = {n: P32[n].to(dev, dtype).contiguous() for n in NAMES}
-    tl, dyl = t32.to(dev, dtype).contiguous(), dy32.to(dev, dtype).contiguous()
+    def wide(v):                                             # [rows, C] view of a [rows, C + pad] buffer
+        buf = torch.full((v.shape[0], c + pad), 7.0, device=dev, dtype=dtype)
+        buf[:, :c] = v.to(dev, dtype)
+        return buf[:, :c]
+    tl, dyl = wide(t32), wide(dy32)
     # the reference sees exactly the stored (rounded) inputs, in fp32
     Pr = {n: Pl[n].float().requires_grad_(True) for n in NAMES}
     tr = tl.float().requires_grad_(True)
@@ -52,11 +57,11 @@ def test_effatt_fused_forward_and_backward_vs_torch_fp32(dtype, B, N):
 
     nfl = L.tc_effatt_scratch_floats(c, B, N)
     part = torch.empty(nfl, device=dev, dtype=torch.float32)
-    out = torch.empty_like(tl)
+    out = wide(torch.zeros(B * N, c))
     ctx = torch.empty(B, c, c, device=dev, dtype=torch.float32)
     kstat = torch.empty(B, 2, c, device=dev, dtype=torch.float32)
-    dt = torch.empty_like(tl)
-    g1 = torch.empty_like(tl)
+    dt = wide(torch.zeros(B * N, c))
+    g1 = torch.empty(B * N, c, device=dev, dtype=dtype)
     G = {n: torch.zeros_like(P32[n], device=dev, dtype=torch.float32) for n in NAMES}
     f = _lib.TcEffAtt()
     f.t = tl.data_ptr(); f.gamma = Pl["gamma"].data_ptr(); f.beta = Pl["beta"].data_ptr()
@@ -67,7 +72,7 @@ def test_effatt_fused_forward_and_backward_vs_torch_fp32(dtype, B, N):
     f.dgamma = G["gamma"].data_ptr(); f.dbeta = G["beta"].data_ptr()
     for n in ("wk", "bk", "wq", "bq", "wv", "bv", "wr", "br"):
         setattr(f, "d" + n, G[n].data_ptr())
-    f.ldt = f.ldo = f.lddo = f.lddt = c
+    f.ldt = f.ldo = f.lddo = f.lddt = c + pad
     f.acc_dt = 0; f.C = c; f.B = B; f.N = N; f.eps = 1e-5
     dt_code = _lib.dtype_code(dtype) if hasattr(_lib, "dtype_code") else {torch.bfloat16: 1, torch.float16: 2}[dtype]
     s = torch.cuda.current_stream().cuda_stream
@@ -90,7 +95,6 @@ def test_effatt_fused_forward_and_backward_vs_torch_fp32(dtype, B, N):
         close(G[n], Pr[n].grad, "d" + n, 1.5, float(Pr["wk"].grad.abs().max()) if n == "bk" else None)
     # accumulate form: dt += ...
     f.acc_dt = 1
-    before = dt.clone()
     for n in NAMES:
         G[n].zero_()
     L.tc_effatt_bwd(C.byref(f), dt_code, s)
