@@ -264,7 +264,8 @@ int tc_ffn_fused_bwd(const TcFfnBwd* f, int dtype, void* stream);
  * ctx [B][C][C] and kstat [B][2][C] (column maximum and sum of the keys' softmax) are fp32 outputs of the forward that the backward
  * reads; part is fp32 scratch of tc_effatt_scratch_floats(C, B, N) floats; g1 a [B * N, C] scratch map of the storage type.
  * The backward ADDS into the fp32 gradient arrays (dw* [C][C], db* / dgamma / dbeta [C]); dt is overwritten, or added to when acc_dt.
- * Seven launches in all (3 forward, 4 backward) on `stream`.  TC_ERR_ARG for anything unsupported (use tc_effatt_supported). */
+ * Seven launches in all (3 forward, 4 backward) on `stream`.  TC_ERR_ARG for anything unsupported (use tc_effatt_supported): C != 64,
+ * fp32 storage, token maps or weight matrices not 16-byte aligned, leading dimensions not multiples of 8 elements. */
 typedef struct TcEffAtt {
     const void* t; const void* gamma; const void* beta;
     const void* wk; const void* bk; const void* wq; const void* bq; const void* wv; const void* bv; const void* wr; const void* br;

@@ -736,6 +736,8 @@ __global__ __launch_bounds__(256) void effatt_fold_kernel(const FoldDev p) {
 bool eff_ok(const TcEffAtt* f, bool bwd) {
     if (!f || !f->t || !f->gamma || !f->beta || !f->wk || !f->bk || !f->wq || !f->bq || !f->wv || !f->bv || !f->wr || !f->br || !f->ctx || !f->kstat || !f->part) return false;
     if (f->C != C || f->B < 1 || f->N < 1 || (f->ldt & 7) || ((uintptr_t)f->t & 15) || ((uintptr_t)f->part & 15) || ((uintptr_t)f->ctx & 15)) return false;
+    if (((uintptr_t)f->wk | (uintptr_t)f->wq | (uintptr_t)f->wv | (uintptr_t)f->wr) & 15) return false;      // weight rows are fetched 16 bytes at a time
+    if ((long long)f->B * f->N >= 0x7fffffffLL / (f->ldt > C ? f->ldt : C)) return false;
     if (!bwd) return f->out && !(f->ldo & 7) && !((uintptr_t)f->out & 15);
     if (!f->dout || !f->dt || !f->g1 || (f->lddo & 7) || (f->lddt & 7) || ((uintptr_t)f->dout & 15) || ((uintptr_t)f->dt & 15) || ((uintptr_t)f->g1 & 15)) return false;
     return f->dgamma && f->dbeta && f->dwk && f->dbk && f->dwq && f->dbq && f->dwv && f->dbv && f->dwr && f->dbr;
