@@ -10,9 +10,12 @@ args = sys.argv[1:6] or ["64", "16", "56", "56", "1"]
 sys.argv = [sys.argv[0]] + args + ["--reps", "2", "--only", "fused"]
 exec(open(os.path.join(ROOT, "scripts", "bench_ffn.py")).read().replace('if __name__ == "__main__":', "if True:"))
 buf = np.zeros(2 * 16 * 16, dtype=np.int64)
-f = C.CDLL(os.environ["TC_LIB_PATH"]).tc_ffnb_dbg_read
-f.argtypes = [C.c_void_p]
-print("rc", f(buf.ctypes.data))
+try:                                                   # (a forward-only timing build has no backward table)
+    f = C.CDLL(os.environ["TC_LIB_PATH"]).tc_ffnb_dbg_read
+    f.argtypes = [C.c_void_p]
+    print("rc", f(buf.ctypes.data))
+except AttributeError:
+    pass
 t = buf.reshape(2, 16, 16)
 N1 = ["0 prologue (W2 fragments, gamma/beta, first fetch)", "1 put (waits on the fetch)", "2 barrier", "3 gpre MFMA", "4 epilogue (LN, GELU, GELU', sums, a -> LDS)", "5 barrier",
       "6 next fetch issue + dW2 MFMA", "7 LayerNorm backward -> LDS", "8 barrier", "9 gd store", "10 barrier", "11 tail (partials)"]

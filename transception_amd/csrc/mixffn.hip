@@ -89,19 +89,30 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p
     float2* ST = p.stat ? reinterpret_cast<float2*>(p.stat) + grow : nullptr;
     const int TH = p.TH, TW = p.TW, HW2 = p.HW2, HP = p.HP, MT = p.MT, IP = p.IP, Himg = p.H, Wimg = p.W;
 
-    {   // parameters of this weight group: taps transposed to [tap][channel], fp32
+    // Parameters of this weight group.  Every global load of the prologue is issued before the first LDS store waits for one (the
+    // staging loops used to pay one memory round trip per iteration: 10 - 17 k cycles of a 25 - 80 k-cycle launch).
+    constexpr int NTAP = (9 * C4 + NTH - 1) / NTH, NPAR = (C4 + NTH - 1) / NTH, NW2 = K::W2LDS ? (C * HC + NTH - 1) / NTH : 1;
+    float tv[NTAP], pv[NPAR][4];
+    uint4 w2v[NW2];
+    {
         const H* wd = reinterpret_cast<const H*>(p.wd) + wo;
         const H* bd = reinterpret_cast<const H*>(p.bd) + wo;
         const H* gm = reinterpret_cast<const H*>(p.gamma) + wo;
         const H* bt = reinterpret_cast<const H*>(p.beta) + wo;
-        for (int i = tid; i < 9 * C4; i += NTH) { const int ch = i / 9, t = i - ch * 9; wtap[t * C4 + ch] = ldf<H>(wd + i); }
         const H* b1 = reinterpret_cast<const H*>(p.b1) + wo;
-        for (int i = tid; i < C4; i += NTH) { wtap[9 * C4 + i] = ldf<H>(bd + i); gbs[i] = ldf<H>(gm + i); gbs[C4 + i] = ldf<H>(bt + i); gbs[2 * C4 + i] = ldf<H>(b1 + i); }
-    }
-    if constexpr (K::W2LDS) {
-        for (int i = tid; i < C * HC; i += NTH) {
-            const int o = i / HC, cg = i - o * HC;
-            *reinterpret_cast<uint4*>(w2s + o * PH + cg * 8) = *reinterpret_cast<const uint4*>(W2 + (long long)o * C4 + cg * 8);
+#pragma unroll
+        for (int k = 0; k < NTAP; ++k) { const int i = tid + k * NTH; tv[k] = ldf<H>(wd + (i < 9 * C4 ? i : 0)); }
+#pragma unroll
+        for (int k = 0; k < NPAR; ++k) {
+            const int i = min(tid + k * NTH, C4 - 1);
+            pv[k][0] = ldf<H>(bd + i); pv[k][1] = ldf<H>(gm + i); pv[k][2] = ldf<H>(bt + i); pv[k][3] = ldf<H>(b1 + i);
+        }
+        if constexpr (K::W2LDS) {
+#pragma unroll
+            for (int k = 0; k < NW2; ++k) {
+                const int i = min(tid + k * NTH, C * HC - 1), o = i / HC, cg = i - o * HC;
+                w2v[k] = *reinterpret_cast<const uint4*>(W2 + (long long)o * C4 + cg * 8);
+            }
         }
     }
     // fc1 weights of this wave's channels: MFMA operand fragments, resident for the whole launch
@@ -111,14 +122,14 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p
 #pragma unroll
         for (int kk = 0; kk < KK1; ++kk)
             wf1[nt][kk] = *reinterpret_cast<const V8*>(W1 + (long long)(wave * CW + nt * 32 + l31) * C + kk * 16 + 8 * hh);
-    // fc2: wave -> (pixel block mt2, output-channel block nt2)
-    const int mt2 = wave % K::MT2MAX, nt2 = wave / K::MT2MAX;
     float b2v[8];
     {
         const H* b2 = reinterpret_cast<const H*>(p.b2) + wo;
 #pragma unroll
         for (int e = 0; e < 8; ++e) b2v[e] = ldf<H>(b2 + (tid % XC) * 8 + e);
     }
+    // fc2: wave -> (pixel block mt2, output-channel block nt2)
+    const int mt2 = wave % K::MT2MAX, nt2 = wave / K::MT2MAX;
 
     auto tile_org = [&](int tidx, int& b, int& oh0, int& ow0) __attribute__((always_inline)) {
         const int tx = tidx % p.tilesW, ty = (tidx / p.tilesW) % p.tilesH;
@@ -182,7 +193,24 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p
     };
 
     int tidx = blockIdx.x;
-    if (tidx < p.ntiles) { xfetch(tidx); xput(tidx); }
+    if (tidx < p.ntiles) xfetch(tidx);                           // (in flight with the parameter loads)
+    {   // taps transposed to [tap][channel], fp32; conv bias, gamma, beta, fc1 bias; fc2 weights (W2LDS)
+#pragma unroll
+        for (int k = 0; k < NTAP; ++k) { const int i = tid + k * NTH, ch = i / 9, t = i - ch * 9; if (i < 9 * C4) wtap[t * C4 + ch] = tv[k]; }
+#pragma unroll
+        for (int k = 0; k < NPAR; ++k) {
+            const int i = tid + k * NTH;
+            if (i < C4) { wtap[9 * C4 + i] = pv[k][0]; gbs[i] = pv[k][1]; gbs[C4 + i] = pv[k][2]; gbs[2 * C4 + i] = pv[k][3]; }
+        }
+        if constexpr (K::W2LDS) {
+#pragma unroll
+            for (int k = 0; k < NW2; ++k) {
+                const int i = tid + k * NTH, o = i / HC, cg = i - o * HC;
+                if (i < C * HC) *reinterpret_cast<uint4*>(w2s + o * PH + cg * 8) = w2v[k];
+            }
+        }
+    }
+    if (tidx < p.ntiles) xput(tidx);
     __syncthreads();                                             // parameters and the first x tile are in LDS
     FSTAMP(0);
     for (; tidx < p.ntiles; tidx += gridDim.x) {

@@ -103,13 +103,23 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_ln_kernel(const FfnBwdDev p) {
         const H* bt = reinterpret_cast<const H*>(p.beta) + wo;
         for (int i = tid; i < C4; i += NTH) { gbs[i] = ldf<H>(gm + i); gbs[C4 + i] = ldf<H>(bt + i); }
     }
-    for (int i = tid; i < C4 * XC; i += NTH) {                      // W2 [C][C4] -> W2^T in LDS, once per launch: lanes walk the hidden
-        const int og = i / C4, ch = i - og * C4;                    // channels (coalesced 2-byte reads), eight output channels per 16-byte store
-        unsigned w[4];
+    {   // W2 [C][C4] -> W2^T in LDS, once per launch: lanes walk the hidden channels (coalesced 2-byte reads), eight output channels per
+        // 16-byte store; every load of the staging is issued before the first store waits for one
+        constexpr int NWT = (C4 * XC + NTH - 1) / NTH;
+        unsigned short wv[NWT][8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            w[e] = (unsigned)W2[(long long)(og * 8 + 2 * e) * C4 + ch] | ((unsigned)W2[(long long)(og * 8 + 2 * e + 1) * C4 + ch] << 16);
-        *reinterpret_cast<uint4*>(w2t + ch * PX + og * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+        for (int k = 0; k < NWT; ++k) {
+            const int i = min(tid + k * NTH, C4 * XC - 1), og = i / C4, ch = i - og * C4;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) wv[k][e] = W2[(long long)(og * 8 + e) * C4 + ch];
+        }
+#pragma unroll
+        for (int k = 0; k < NWT; ++k) {
+            const int i = tid + k * NTH, og = i / C4, ch = i - og * C4;
+            if (i < C4 * XC)
+                *reinterpret_cast<uint4*>(w2t + ch * PX + og * 8) = make_uint4((unsigned)wv[k][0] | ((unsigned)wv[k][1] << 16), (unsigned)wv[k][2] | ((unsigned)wv[k][3] << 16),
+                                                                                 (unsigned)wv[k][4] | ((unsigned)wv[k][5] << 16), (unsigned)wv[k][6] | ((unsigned)wv[k][7] << 16));
+        }
     }
 
     uint4 dr[ND], yr[NY];
@@ -395,7 +405,19 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dw_kernel(const FfnBwdDev p) {
     auto stage_params = [&]() __attribute__((always_inline)) {
         const H* wd = reinterpret_cast<const H*>(p.wd) + wo;
         const H* b1 = reinterpret_cast<const H*>(p.b1) + wo;
-        for (int i = tid; i < 9 * C4; i += NTH) { const int ch = i / 9, t = i - ch * 9; taps[t * C4 + ch] = ldf<H>(wd + i); }
+        // (every global load of the staging in flight before the first LDS store waits for one)
+        constexpr int NTAP = (9 * C4 + NTH - 1) / NTH, NW1 = (C4 * XC + NTH - 1) / NTH;
+        float tv[NTAP];
+        uint4 w1v[NW1];
+#pragma unroll
+        for (int k = 0; k < NTAP; ++k) { const int i = tid + k * NTH; tv[k] = ldf<H>(wd + (i < 9 * C4 ? i : 0)); }
+#pragma unroll
+        for (int k = 0; k < NW1; ++k) {
+            const int s = min(tid + k * NTH, C4 * XC - 1), r = s / XC, cg = s - r * XC;
+            w1v[k] = *reinterpret_cast<const uint4*>(W1 + (long long)r * C + cg * 8);
+        }
+#pragma unroll
+        for (int k = 0; k < NTAP; ++k) { const int i = tid + k * NTH, ch = i / 9, t = i - ch * 9; if (i < 9 * C4) taps[t * C4 + ch] = tv[k]; }
         for (int i = tid; i < C4; i += NTH) b1s[i] = ldf<H>(b1 + i);
         for (int i = tid; i < PG; i += NTH) hs[MPMAX * PG + i] = 0;
         if constexpr (PRE) {
@@ -404,9 +426,10 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dw_kernel(const FfnBwdDev p) {
                 pre[2 * C + i] = 0.f; pre[3 * C + i] = 0.f;
             }
         }
-        for (int s = tid; s < C4 * XC; s += NTH) {                 // W1 stays in LDS for the whole launch
-            const int r = s / XC, cg = s - r * XC;
-            *reinterpret_cast<uint4*>(w1s + krow(r) * PX + cg * 8) = *reinterpret_cast<const uint4*>(W1 + (long long)r * C + cg * 8);
+#pragma unroll
+        for (int k = 0; k < NW1; ++k) {                            // W1 stays in LDS for the whole launch
+            const int s = tid + k * NTH, r = s / XC, cg = s - r * XC;
+            if (s < C4 * XC) *reinterpret_cast<uint4*>(w1s + krow(r) * PX + cg * 8) = w1v[k];
         }
     };
 
