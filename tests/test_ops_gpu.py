@@ -357,6 +357,39 @@ def test_seg_loss_and_sgd():
     close(ld.grad, lr_.grad, 1e-8, 1e-4, "dlogits")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_seg_loss_on_token_major_logits_equals_the_nchw_kernels(dtype):
+    """tc_seg_loss_fwd_tok / _bwd_tok (the captured step's path: logits [B*HW, ld] in the storage type) against tc_seg_loss_fwd / _bwd on the
+    NCHW fp32 copy of the same values: probabilities and gradients bit for bit (the gradient after the same round to the storage type),
+    the atomically accumulated sums to 1e-6 relative."""
+    from transception_amd import _lib
+    L = _lib.lib()
+    B, ncls, H, ld = 3, 9, 24, 16
+    HW = H * H
+    g = torch.Generator().manual_seed(11)
+    code = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[dtype]
+    buf = (torch.randn(B * HW, ld, generator=g) * 2.0).to(DEV).to(dtype)
+    tok = buf[:, :ncls]                                           # a column slice: row pitch ld
+    lab = torch.randint(0, ncls, (B, HW), generator=g).to(DEV)
+    nchw = tok.float().view(B, HW, ncls).permute(0, 2, 1).contiguous()
+    st = torch.cuda.current_stream().cuda_stream
+    pa, pb = torch.empty(B, ncls, HW, device=DEV), torch.empty(B, ncls, HW, device=DEV)
+    sa, sb = torch.zeros(1 + 3 * ncls, device=DEV), torch.zeros(1 + 3 * ncls, device=DEV)
+    L.tc_seg_loss_fwd(nchw.data_ptr(), lab.data_ptr(), pa.data_ptr(), sa.data_ptr(), B, ncls, HW, 0, st)
+    L.tc_seg_loss_fwd_tok(tok.data_ptr(), ld, lab.data_ptr(), pb.data_ptr(), sb.data_ptr(), B, ncls, HW, code, st)
+    torch.cuda.synchronize()
+    assert torch.equal(pa, pb)
+    assert float(((sa - sb).abs() / (sa.abs() + 1e-6)).max()) < 1e-5
+    da = torch.empty(B, ncls, HW, device=DEV)
+    db = torch.full((B * HW, ld), 3.0, device=DEV, dtype=dtype)
+    L.tc_seg_loss_bwd(pa.data_ptr(), lab.data_ptr(), sa.data_ptr(), da.data_ptr(), B, ncls, HW, 0.4, 0.6, float(B * HW), 128.0, None, 0, st)
+    L.tc_seg_loss_bwd_tok(pa.data_ptr(), lab.data_ptr(), sa.data_ptr(), db.data_ptr(), ld, B, ncls, HW, 0.4, 0.6, float(B * HW), 128.0, None, code, st)
+    torch.cuda.synchronize()
+    want = da.view(B, ncls, HW).permute(0, 2, 1).reshape(B * HW, ncls).to(dtype)
+    assert torch.equal(db[:, :ncls], want)
+    assert bool((db[:, ncls:] == 3.0).all())                      # the padding columns are not touched
+
+
 # ------------------------------------------------------------------------------------------------ bf16 storage path
 _LP = torch.bfloat16          # the 16-bit storage type under test: the Gb / lp fixtures run every test below for bf16 and fp16
 

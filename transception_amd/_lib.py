@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("TC_LIB_PATH") or os.path.join(HERE, "libtransception_
 
 TC_F32, TC_BF16, TC_F16 = 0, 1, 2
 ACT_NONE, ACT_HSWISH, ACT_COORD, ACT_SIGMOID, ACT_GELU = 0, 1, 2, 3, 4
-ABI_VERSION = 9
+ABI_VERSION = 10
 ATTN_DKV_SPLITS = 8                # include/transception_hip.h: partial dK|dV buffers in tc_attn_bwd_seg's fp32 scratch
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_longlong, C.c_float
@@ -154,6 +154,8 @@ SIGNATURES = {
     "tc_factor_att_bwd": [vp, vp, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, f32, i32, vp],
     "tc_argmax_counts": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "tc_seg_loss_bwd": [vp, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, vp, i32, vp],
+    "tc_seg_loss_fwd_tok": [vp, i32, vp, vp, vp, i32, i32, i32, i32, vp],
+    "tc_seg_loss_bwd_tok": [vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, f32, f32, vp, i32, vp],
     "tc_seg_loss_value": [vp, i32, C.c_double, C.c_double, C.c_double, vp, vp],
     "tc_slice_augment": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "tc_spline_prefilter": [vp, vp, i32, i32, i32, vp],

@@ -21,9 +21,11 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
 
 constexpr int MAXCLS = 16;
 
+// ld = 0: logits / dlogits are [B, ncls, HW] (the module's NCHW output); ld > 0: token-major [B * HW, ld] rows as the last Linear leaves
+// them (the captured training step hands them over without the transpose and the fp32 copy); prob is [B, ncls, HW] either way
 template <typename T>
 __global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const T* __restrict__ logits, const long long* __restrict__ labels,
-                                                           float* __restrict__ prob, float* __restrict__ sums, int B, int ncls, int HW) {
+                                                           float* __restrict__ prob, float* __restrict__ sums, int B, int ncls, int HW, int ld) {
     __shared__ float red[4][1 + 3 * MAXCLS];
     float ce = 0.f, I[MAXCLS], Y[MAXCLS], Z[MAXCLS];
 #pragma unroll
@@ -31,10 +33,11 @@ __global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const T* __restrict__
     const long long n = (long long)B * HW;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const int b = (int)(i / HW); const int p = (int)(i % HW);
-        const T* lp = logits + (long long)b * ncls * HW + p;
+        const T* lp = ld ? logits + i * ld : logits + (long long)b * ncls * HW + p;
+        const long long ks = ld ? 1 : HW;
         float v[MAXCLS], m = -INFINITY;
 #pragma unroll
-        for (int k = 0; k < MAXCLS; ++k) if (k < ncls) { v[k] = ldf<T>(lp + (long long)k * HW); m = fmaxf(m, v[k]); }
+        for (int k = 0; k < MAXCLS; ++k) if (k < ncls) { v[k] = ldf<T>(lp + k * ks); m = fmaxf(m, v[k]); }
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < MAXCLS; ++k) if (k < ncls) { v[k] = expf(v[k] - m); s += v[k]; }
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const T* __restrict__
 template <typename T>
 __global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float* __restrict__ prob, const long long* __restrict__ labels,
                                                            const float* __restrict__ sums, T* __restrict__ dlogits, int B, int ncls,
-                                                           int HW, float w_ce, float w_dice, float n_pix, float gscale, const float* __restrict__ gscale_dev) {
+                                                           int HW, float w_ce, float w_dice, float n_pix, float gscale, const float* __restrict__ gscale_dev, int ld) {
     if (gscale_dev) gscale *= *gscale_dev;
     __shared__ float ca[MAXCLS], cb[MAXCLS];          // dDice/dp_c = ca[c]*onehot_c + cb[c]*p_c
     if (threadIdx.x < ncls) {
@@ -88,10 +91,11 @@ __global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float* __restri
             g[k] = (k == lab ? ca[k] : 0.f) + cb[k] * pk[k];
             dot += g[k] * pk[k];
         }
-        T* dp = dlogits + (long long)b * ncls * HW + p;
+        T* dp = ld ? dlogits + i * ld : dlogits + (long long)b * ncls * HW + p;
+        const long long ks = ld ? 1 : HW;
 #pragma unroll
         for (int k = 0; k < MAXCLS; ++k) if (k < ncls)
-            stf<T>(dp + (long long)k * HW, gscale * (cew * (pk[k] - (k == lab ? 1.f : 0.f)) + pk[k] * (g[k] - dot)));
+            stf<T>(dp + k * ks, gscale * (cew * (pk[k] - (k == lab ? 1.f : 0.f)) + pk[k] * (g[k] - dot)));
     }
 }
 
@@ -208,7 +212,16 @@ extern "C" int tc_seg_loss_fwd(const void* logits, const long long* labels, floa
     if (!logits || !labels || !prob || !sums || B <= 0 || ncls <= 0 || ncls > MAXCLS || HW <= 0) return TC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((seg_loss_fwd_kernel<T>), dim3(tc_blocks((long long)B * HW, 256, 1024)), dim3(256), 0, s,
-                                                (const T*)logits, labels, prob, sums, B, ncls, HW));
+                                                (const T*)logits, labels, prob, sums, B, ncls, HW, 0));
+    return tc_launch_status();
+}
+
+extern "C" int tc_seg_loss_fwd_tok(const void* logits, int ld, const long long* labels, float* prob, float* sums, int B, int ncls, int HW,
+                                   int dtype, void* stream) {
+    if (!logits || !labels || !prob || !sums || B <= 0 || ncls <= 0 || ncls > MAXCLS || HW <= 0 || ld < ncls) return TC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((seg_loss_fwd_kernel<T>), dim3(tc_blocks((long long)B * HW, 256, 1024)), dim3(256), 0, s,
+                                                (const T*)logits, labels, prob, sums, B, ncls, HW, ld));
     return tc_launch_status();
 }
 
@@ -249,7 +262,16 @@ extern "C" int tc_seg_loss_bwd(const float* prob, const long long* labels, const
     if (!prob || !labels || !sums || !dlogits || B <= 0 || ncls <= 0 || ncls > MAXCLS || HW <= 0) return TC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((seg_loss_bwd_kernel<T>), dim3(tc_blocks((long long)B * HW, 256, 2048)), dim3(256), 0, s,
-                                                prob, labels, sums, (T*)dlogits, B, ncls, HW, w_ce, w_dice, n_pix_global, gscale, gscale_dev));
+                                                prob, labels, sums, (T*)dlogits, B, ncls, HW, w_ce, w_dice, n_pix_global, gscale, gscale_dev, 0));
+    return tc_launch_status();
+}
+
+extern "C" int tc_seg_loss_bwd_tok(const float* prob, const long long* labels, const float* sums, void* dlogits, int ld, int B, int ncls, int HW,
+                                   float w_ce, float w_dice, float n_pix_global, float gscale, const float* gscale_dev, int dtype, void* stream) {
+    if (!prob || !labels || !sums || !dlogits || B <= 0 || ncls <= 0 || ncls > MAXCLS || HW <= 0 || ld < ncls) return TC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((seg_loss_bwd_kernel<T>), dim3(tc_blocks((long long)B * HW, 256, 2048)), dim3(256), 0, s,
+                                                prob, labels, sums, (T*)dlogits, B, ncls, HW, w_ce, w_dice, n_pix_global, gscale, gscale_dev, ld));
     return tc_launch_status();
 }
 

@@ -416,7 +416,9 @@ class MSTransception(nn.Module):
         assert b - a == c - b and (b - a) % 8 == 0
         return b - a
 
-    def _run(self, x: torch.Tensor, record: bool):
+    def _run(self, x: torch.Tensor, record: bool, token_logits: bool = False):
+        """token_logits: hand the logits over as the classifier Linear leaves them -- token-major [B*H*W, classes] in the storage type
+        (train.GraphedStep: tc_seg_loss_*_tok read / write that layout) -- instead of the module's fp32 NCHW output."""
         dev = x.device
         L = lib()
         stream = torch.cuda.current_stream(dev).cuda_stream
@@ -439,9 +441,11 @@ class MSTransception(nn.Module):
             xl = torch.empty(xin.shape, dtype=self.compute_dtype, device=dev)
             L.tc_cast(xin.data_ptr(), xl.data_ptr(), xin.numel(), TC_F32, self._tc_dtype(), stream)
             xin = xl
+        self._tok_logits = token_logits
         out_var = _forward(self, G, xin, B, in_ch, H)
-        logits = out_var.data.view(B, self.num_classes, H, W)
-        if self.compute_dtype != torch.float32:
+        self._tok_logits = False
+        logits = out_var.data if token_logits else out_var.data.view(B, self.num_classes, H, W)
+        if self.compute_dtype != torch.float32 and not token_logits:
             lf = torch.empty(logits.shape, dtype=torch.float32, device=dev)
             L.tc_cast(logits.data_ptr(), lf.data_ptr(), logits.numel(), self._tc_dtype(), TC_F32, stream)
             logits = lf
@@ -474,7 +478,7 @@ class MSTransception(nn.Module):
         if first is not None and first.grad is None:
             self._gflat.zero_()                     # zero_grad(set_to_none=True) semantics: start from zero
         d = dlogits.contiguous()
-        if self.compute_dtype != torch.float32:
+        if d.dtype != self.compute_dtype:
             dl = torch.empty(d.shape, dtype=self.compute_dtype, device=d.device)
             L.tc_cast(d.data_ptr(), dl.data_ptr(), d.numel(), TC_F32, self._tc_dtype(), G.stream)
             d = dl
@@ -819,6 +823,8 @@ def _decoder(M, G, x1: Var, skip: Var, name: str, B: int, side: int, last: bool)
         return _patch_expand(M, G, t, name + ".layer_up", B, side, 2)
     y = _patch_expand(M, G, t, name + ".layer_up", B, side, 4)
     lg = G.linear(y, *_lin(M, G, name + ".last_layer"))         # [B*16*side^2, classes]
+    if getattr(M, "_tok_logits", False):
+        return lg                                               # token-major for the captured step's loss kernels
     return G.transpose(lg, B)                                   # NCHW logits [B*classes, H*W]
 
 

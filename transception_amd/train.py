@@ -320,13 +320,13 @@ class GraphedStep:
                 if self.split:
                     self._fwd(); self._reduce_sums(); self._bwd(); self._bwd_rest(); allreduce_gradients(model, group); opt.step()
                 else:
-                    train_step(model, loss_fn, opt, self.x, self.y, group)
+                    self._whole_step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.g_main = _new_graph()
         if not self.split:
             with torch.cuda.graph(self.g_main, capture_error_mode=_CAPTURE_MODE):
-                self.out = train_step(model, loss_fn, opt, self.x, self.y, None)
+                self._whole_step()
             self.g_bwd = self.g_bwd_rest = self.g_opt = None
         else:
             with torch.cuda.graph(self.g_main, capture_error_mode=_CAPTURE_MODE):
@@ -351,18 +351,30 @@ class GraphedStep:
         ks = [graph_kernel_nodes(g) for g in (self.g_main, self.g_bwd, self.g_bwd_rest, self.g_opt) if g is not None]
         return None if any(k is None for k in ks) else sum(ks)
 
+    def _whole_step(self):
+        """One process, no exchange: the same engine-driven pieces back to back in one graph (the loss kernels read the token-major
+        logits of the classifier directly; train_step's nn.Module boundary would add the NCHW transpose and fp32 copies both ways)."""
+        self._fwd()
+        self._npix = self._npix_local
+        self._bwd()
+        self._bwd_rest()
+        self.opt.step()
+
     # ---- the three pieces of the split step (engine driven directly; no torch.autograd in between)
     def _fwd(self):
         M, L = self.model, lib()
         M._ensure_flat(self.x.device)
         self.opt.zero_grad()
-        logits, G, out_var = M._run(self.x, record=True)
+        logits, G, out_var = M._run(self.x, record=True, token_logits=True)     # [B*H*W, classes], storage type: no transpose, no fp32 copy
         self._G, self._out_var = G, out_var
-        B, C, H, W = logits.shape
+        B, H, W = self.x.shape[0], self.x.shape[2], self.x.shape[3]
+        C = logits.shape[1]
+        assert logits.shape[0] == B * H * W and logits.stride(1) == 1
         stream = torch.cuda.current_stream(logits.device).cuda_stream
         self._prob = torch.empty((B, C, H, W), dtype=torch.float32, device=logits.device)
         self._sums = torch.zeros(1 + 3 * C, dtype=torch.float32, device=logits.device)
-        L.tc_seg_loss_fwd(logits.data_ptr(), self.y.data_ptr(), self._prob.data_ptr(), self._sums.data_ptr(), B, C, H * W, TC_F32, stream)
+        L.tc_seg_loss_fwd_tok(logits.data_ptr(), logits.stride(0), self.y.data_ptr(), self._prob.data_ptr(), self._sums.data_ptr(), B, C, H * W,
+                              _dt(logits), stream)
         self._npix_local = float(B * H * W)
 
     def _reduce_sums(self):
@@ -374,9 +386,9 @@ class GraphedStep:
         lf = self.loss_fn
         self.out = tuple(t.float() for t in loss_from_sums(self._sums, self._npix, lf.w_ce, lf.w_dice))
         stream = torch.cuda.current_stream(self._prob.device).cuda_stream
-        d = torch.empty((B, C, H, W), dtype=torch.float32, device=self._prob.device)
-        L.tc_seg_loss_bwd(self._prob.data_ptr(), self.y.data_ptr(), self._sums.data_ptr(), d.data_ptr(), B, C, H * W, float(lf.w_ce),
-                          float(lf.w_dice), float(self._npix), float(lf.loss_scale), None, TC_F32, stream)
+        d = torch.empty((B * H * W, C), dtype=self.model.compute_dtype, device=self._prob.device)        # the gradient of the token-major logits
+        L.tc_seg_loss_bwd_tok(self._prob.data_ptr(), self.y.data_ptr(), self._sums.data_ptr(), d.data_ptr(), d.stride(0), B, C, H * W,
+                              float(lf.w_ce), float(lf.w_dice), float(self._npix), float(lf.loss_scale), None, _dt(d), stream)
         M._backward(self._G, self._out_var, d, until="encoder_done")     # loss gradient, decoders, bridge
 
     def _bwd_rest(self):
