@@ -467,6 +467,36 @@ class MSTransception(nn.Module):
         assert all(off < late for name, (off, _) in self._index.items() if name.startswith("backbone."))
         return late
 
+    def gradient_pieces(self):
+        """The stops of a split backward sweep and the arena ranges whose gradients are complete at each, in the order they are reached:
+        bridge + decoders at "encoder_done", then stage 4 (63 % of the encoder's parameters), stage 3, and the rest at the end (None).
+        A multi-GPU step sends each piece while the sweep continues (train.GraphedStep); only the small last piece is exposed."""
+        late, pieces, taken = self.late_gradient_offset(), [], []          # (the flat arenas exist: called after a first step)
+        pieces.append(("encoder_done", [(late, self._gflat.numel())]))
+        for stage in (4, 3):
+            rs = []
+            for pre in (f"backbone.patch_embed_stage{stage}.", f"backbone.mhca_stage{stage}."):
+                offs = [(o, o + (math.prod(sh) + 7) // 8 * 8) for n, (o, sh) in self._index.items() if n.startswith(pre)]
+                lo, hi = min(a for a, _ in offs), max(b for _, b in offs)
+                assert all(n.startswith(pre) for n, (o, sh) in self._index.items() if lo <= o < hi), pre      # one module, one contiguous range
+                rs.append((lo, hi))
+            pieces.append((f"stage{stage}_done", rs))
+            taken += rs
+        rest, at = [], 0
+        for lo, hi in sorted(taken):
+            if lo > at:
+                rest.append((at, lo))
+            at = hi
+        if at < late:
+            rest.append((at, late))
+        pieces.append((None, rest))
+        return pieces
+
+    def _backward_continue(self, G: Graph, until: Optional[str]):
+        """Next leg of a backward that was stopped at a mark: to the mark `until`, or (None) to the end."""
+        if G.backward(until):
+            self._attach_grads()
+
     def _backward_finish(self, G: Graph):
         """Second half of a backward that was stopped at a mark."""
         G.backward()
@@ -854,6 +884,8 @@ def _forward(M: MSTransception, G: Graph, x: torch.Tensor, B: int, in_ch: int, S
     m = _ln(M, G, t, "backbone.norm1", out=stage_map(Xb, 0))
     # stages 2-4 -- RIPM + MB transformer + IFF (MSTr.py:1728-1742)
     for s in (1, 2, 3):
+        if s >= 2:
+            G.mark(f"stage{s + 1}_done")                          # a backward sweep that stops here has finished stage s + 1 (its RIPM included)
         stack, side = _ripm(M, G, m, f"backbone.patch_embed_stage{s + 1}", B, sides[s - 1])
         m = _mhca_stage(M, G, stack, f"backbone.mhca_stage{s + 1}", LAYERS[s - 1], B, side, stage_map(Xb, s))
     # Dual Transformer Bridge.  The mark lets a multi-GPU step stop its backward sweep here -- bridge and decoder gradients (72 % of

@@ -221,7 +221,18 @@ def split_buckets(buckets, cut: int):
     return early, late
 
 
-def allreduce_gradients(model, group=None, part: Optional[str] = None, async_op: bool = False):
+def clip_buckets(buckets, ranges):
+    """The parts of `buckets` inside the arena `ranges` (both lists of half-open element ranges)."""
+    out = []
+    for lo, hi in ranges:
+        for a, b in buckets:
+            a2, b2 = max(a, lo), min(b, hi)
+            if a2 < b2:
+                out.append((a2, b2))
+    return sorted(out)
+
+
+def allreduce_gradients(model, group=None, part: Optional[str] = None, async_op: bool = False, ranges=None):
     """C1: all-reduce(sum) of the live parts of the flat gradient arena over RCCL/xGMI (gloo in CPU tests): a handful of
     large buckets, every rank the same ones (the used set is a property of the architecture).  part="late" / "early" sends only
     the buckets at or above / below model.late_gradient_offset() (bridge + decoders / encoder); async_op returns the work
@@ -232,6 +243,8 @@ def allreduce_gradients(model, group=None, part: Optional[str] = None, async_op:
         if part is not None:
             early, late = split_buckets(buckets, model.late_gradient_offset())
             buckets = late if part == "late" else early
+        if ranges is not None:                           # one piece of a split backward sweep (model.gradient_pieces)
+            buckets = clip_buckets(buckets, ranges)
         for a, b in buckets:
             w = dist.all_reduce(model._gflat[a:b], group=group, async_op=async_op)
             if async_op:
@@ -335,20 +348,26 @@ class GraphedStep:
             self.g_bwd = _new_graph()
             with torch.cuda.graph(self.g_bwd, capture_error_mode=_CAPTURE_MODE):
                 self._bwd()
-            self.g_bwd_rest = _new_graph()
-            with torch.cuda.graph(self.g_bwd_rest, capture_error_mode=_CAPTURE_MODE):
-                self._bwd_rest()
+            # the encoder's sweep in legs (stage 4, stage 3, the rest): each leg's gradients travel while the next leg runs
+            self._pieces = model.gradient_pieces()
+            self.g_bwd_legs = []
+            for until, _ in self._pieces[1:]:
+                g = _new_graph()
+                with torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
+                    self._bwd_leg(until)
+                self.g_bwd_legs.append(g)
+            self.g_bwd_rest = self.g_bwd_legs[-1]
             allreduce_gradients(model, group)
             self.g_opt = _new_graph()
             with torch.cuda.graph(self.g_opt, capture_error_mode=_CAPTURE_MODE):
                 opt.step()
-        for g in (self.g_main, self.g_bwd, self.g_bwd_rest, self.g_opt):
+        for g in [self.g_main, self.g_bwd, self.g_opt] + (self.g_bwd_legs if self.split else []):
             if g is not None:
                 _instantiate(g)
 
     def kernel_nodes(self) -> Optional[int]:
         """Kernel launches of one replayed step = kernel nodes of its captured graph(s)."""
-        ks = [graph_kernel_nodes(g) for g in (self.g_main, self.g_bwd, self.g_bwd_rest, self.g_opt) if g is not None]
+        ks = [graph_kernel_nodes(g) for g in [self.g_main, self.g_bwd, self.g_opt] + (self.g_bwd_legs if self.split else []) if g is not None]
         return None if any(k is None for k in ks) else sum(ks)
 
     def _whole_step(self):
@@ -391,9 +410,13 @@ class GraphedStep:
                               float(lf.w_ce), float(lf.w_dice), float(self._npix), float(lf.loss_scale), None, _dt(d), stream)
         M._backward(self._G, self._out_var, d, until="encoder_done")     # loss gradient, decoders, bridge
 
+    def _bwd_leg(self, until: Optional[str]):
+        self.model._backward_continue(self._G, until)                   # one leg of the encoder's sweep (None: to the end)
+        if until is None:
+            self._G = self._out_var = None
+
     def _bwd_rest(self):
-        self.model._backward_finish(self._G)                            # the encoder
-        self._G = self._out_var = None
+        self._bwd_leg(None)                                             # the whole encoder in one go
 
     def __call__(self, images: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None, comm: bool = True):
         """comm=False replays the same graphs without the collectives between them (bench.py: the time the all-reduces add to a
@@ -409,11 +432,12 @@ class GraphedStep:
             if comm:
                 self._reduce_sums()                  # C2: in place on the static 28-float buffer
             self.g_bwd.replay()
-            if comm:
-                works = allreduce_gradients(self.model, self.group, "late", async_op=True)      # C1, bridge + decoder buckets: the
-            self.g_bwd_rest.replay()                                                        # collective stream waits for g_bwd only
-            if comm:
-                works += allreduce_gradients(self.model, self.group, "early", async_op=True)    # C1, encoder buckets
+            if comm:                                 # C1, bridge + decoder buckets: the collective stream waits for g_bwd only
+                works = allreduce_gradients(self.model, self.group, async_op=True, ranges=self._pieces[0][1])
+            for g, (_, rng) in zip(self.g_bwd_legs, self._pieces[1:]):
+                g.replay()                           # stage 4, stage 3, rest of the encoder: each leg's buckets leave under the next leg
+                if comm:
+                    works += allreduce_gradients(self.model, self.group, async_op=True, ranges=rng)
             for w in works:
                 w.wait()                                     # the compute stream waits for the collectives, the host does not
             self.g_opt.replay()
