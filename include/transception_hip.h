@@ -435,11 +435,14 @@ int tc_seg_loss_bwd(const float* prob, const long long* labels, const float* sum
                     void* stream);
 /* The same two kernels on TOKEN-MAJOR logits / dlogits [B*HW, ld] (rows = pixels, ld >= ncls elements of the storage type), the layout
  * the classifier Linear (MSTr.py:281 last_layer) leaves: the captured training step skips the NHWC -> NCHW transpose and the fp32 copy
- * of the logits, and their counterparts on the way back (trainer.py:139-143 see the same values).  prob stays [B, ncls, HW] fp32. */
+ * of the logits, and their counterparts on the way back (trainer.py:139-143 see the same values).  prob, when given, is [B, ncls, HW] fp32. */
 int tc_seg_loss_fwd_tok(const void* logits, int ld, const long long* labels, float* prob, float* sums, int B, int ncls, int HW, int dtype,
                         void* stream);
-int tc_seg_loss_bwd_tok(const float* prob, const long long* labels, const float* sums, void* dlogits, int ld, int B, int ncls, int HW,
-                        float w_ce, float w_dice, float n_pix_global, float gscale, const float* gscale_dev, int dtype, void* stream);
+int tc_seg_loss_bwd_tok(const float* prob, const void* logits, int ldl, const long long* labels, const float* sums, void* dlogits, int ld,
+                        int B, int ncls, int HW, float w_ce, float w_dice, float n_pix_global, float gscale, const float* gscale_dev,
+                        int dtype, void* stream);
+/* prob may be NULL in both: the forward then only accumulates the sums, the backward recomputes the softmax from `logits` (row pitch ldl)
+ * with the forward's operations in the forward's order -- 29 MB of fp32 probabilities less to write and read at B = 16, 224 x 224. */
 /* Fused core of FactorAtt_ConvRelPosEnc (MSTr.py:864-877), one workgroup per (image, head):
  *   o = scale * q (softmax_N(k)^T v) + q (.) convv        q, k, v: column slices (row stride ld) of the [Bt*N, 3C] qkv buffer,
  * head h owning channels [h*Ch, (h+1)*Ch); convv = crpe(v) (row stride ldc).  stats: tc_factor_att_stats_floats() floats saved for

@@ -383,11 +383,18 @@ def test_seg_loss_on_token_major_logits_equals_the_nchw_kernels(dtype):
     da = torch.empty(B, ncls, HW, device=DEV)
     db = torch.full((B * HW, ld), 3.0, device=DEV, dtype=dtype)
     L.tc_seg_loss_bwd(pa.data_ptr(), lab.data_ptr(), sa.data_ptr(), da.data_ptr(), B, ncls, HW, 0.4, 0.6, float(B * HW), 128.0, None, 0, st)
-    L.tc_seg_loss_bwd_tok(pa.data_ptr(), lab.data_ptr(), sa.data_ptr(), db.data_ptr(), ld, B, ncls, HW, 0.4, 0.6, float(B * HW), 128.0, None, code, st)
+    L.tc_seg_loss_bwd_tok(pa.data_ptr(), None, 0, lab.data_ptr(), sa.data_ptr(), db.data_ptr(), ld, B, ncls, HW, 0.4, 0.6, float(B * HW), 128.0, None, code, st)
     torch.cuda.synchronize()
     want = da.view(B, ncls, HW).permute(0, 2, 1).reshape(B * HW, ncls).to(dtype)
     assert torch.equal(db[:, :ncls], want)
     assert bool((db[:, ncls:] == 3.0).all())                      # the padding columns are not touched
+    # without a probability map: sums only in the forward, the softmax recomputed in the backward -- the same bits
+    sc, dc = torch.zeros(1 + 3 * ncls, device=DEV), torch.full((B * HW, ld), 3.0, device=DEV, dtype=dtype)
+    L.tc_seg_loss_fwd_tok(tok.data_ptr(), ld, lab.data_ptr(), None, sc.data_ptr(), B, ncls, HW, code, st)
+    L.tc_seg_loss_bwd_tok(None, tok.data_ptr(), ld, lab.data_ptr(), sa.data_ptr(), dc.data_ptr(), ld, B, ncls, HW, 0.4, 0.6, float(B * HW), 128.0, None, code, st)
+    torch.cuda.synchronize()
+    assert float(((sc - sb).abs() / (sb.abs() + 1e-6)).max()) < 1e-5
+    assert torch.equal(dc, db)
 
 
 # ------------------------------------------------------------------------------------------------ bf16 storage path

@@ -155,7 +155,7 @@ SIGNATURES = {
     "tc_argmax_counts": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "tc_seg_loss_bwd": [vp, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, vp, i32, vp],
     "tc_seg_loss_fwd_tok": [vp, i32, vp, vp, vp, i32, i32, i32, i32, vp],
-    "tc_seg_loss_bwd_tok": [vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, f32, f32, vp, i32, vp],
+    "tc_seg_loss_bwd_tok": [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, f32, f32, f32, f32, vp, i32, vp],
     "tc_seg_loss_value": [vp, i32, C.c_double, C.c_double, C.c_double, vp, vp],
     "tc_slice_augment": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "tc_spline_prefilter": [vp, vp, i32, i32, i32, vp],

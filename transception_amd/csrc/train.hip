@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const T* __restrict__
 #pragma unroll
         for (int k = 0; k < MAXCLS; ++k) if (k < ncls) {
             const float pk = v[k] * inv;
-            pp[(long long)k * HW] = pk;
+            if (prob) pp[(long long)k * HW] = pk;                  // (null: the backward recomputes the softmax from the logits)
             Z[k] += pk * pk;
             if (k == lab) { I[k] += pk; Y[k] += 1.f; ce -= logf(fmaxf(pk, 1e-38f)); }
         }
@@ -68,7 +68,8 @@ __global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const T* __restrict__
 template <typename T>
 __global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float* __restrict__ prob, const long long* __restrict__ labels,
                                                            const float* __restrict__ sums, T* __restrict__ dlogits, int B, int ncls,
-                                                           int HW, float w_ce, float w_dice, float n_pix, float gscale, const float* __restrict__ gscale_dev, int ld) {
+                                                           int HW, float w_ce, float w_dice, float n_pix, float gscale, const float* __restrict__ gscale_dev, int ld,
+                                                           const T* __restrict__ logits, int ldl) {
     if (gscale_dev) gscale *= *gscale_dev;
     __shared__ float ca[MAXCLS], cb[MAXCLS];          // dDice/dp_c = ca[c]*onehot_c + cb[c]*p_c
     if (threadIdx.x < ncls) {
@@ -85,9 +86,22 @@ __global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float* __restri
         const float* pp = prob + (long long)b * ncls * HW + p;
         const int lab = (int)labels[i];
         float pk[MAXCLS], g[MAXCLS], dot = 0.f;
+        if (prob) {
+#pragma unroll
+            for (int k = 0; k < MAXCLS; ++k) if (k < ncls) pk[k] = pp[(long long)k * HW];
+        } else {                                                // the forward's arithmetic again (same operations, same order: same bits)
+            const T* lp = logits + i * ldl;
+            float m = -INFINITY, ssum = 0.f;
+#pragma unroll
+            for (int k = 0; k < MAXCLS; ++k) if (k < ncls) { pk[k] = ldf<T>(lp + k); m = fmaxf(m, pk[k]); }
+#pragma unroll
+            for (int k = 0; k < MAXCLS; ++k) if (k < ncls) { pk[k] = expf(pk[k] - m); ssum += pk[k]; }
+            const float inv = 1.f / ssum;
+#pragma unroll
+            for (int k = 0; k < MAXCLS; ++k) if (k < ncls) pk[k] *= inv;
+        }
 #pragma unroll
         for (int k = 0; k < MAXCLS; ++k) if (k < ncls) {
-            pk[k] = pp[(long long)k * HW];
             g[k] = (k == lab ? ca[k] : 0.f) + cb[k] * pk[k];
             dot += g[k] * pk[k];
         }
@@ -218,7 +232,7 @@ extern "C" int tc_seg_loss_fwd(const void* logits, const long long* labels, floa
 
 extern "C" int tc_seg_loss_fwd_tok(const void* logits, int ld, const long long* labels, float* prob, float* sums, int B, int ncls, int HW,
                                    int dtype, void* stream) {
-    if (!logits || !labels || !prob || !sums || B <= 0 || ncls <= 0 || ncls > MAXCLS || HW <= 0 || ld < ncls) return TC_ERR_ARG;
+    if (!logits || !labels || !sums || B <= 0 || ncls <= 0 || ncls > MAXCLS || HW <= 0 || ld < ncls) return TC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((seg_loss_fwd_kernel<T>), dim3(tc_blocks((long long)B * HW, 256, 1024)), dim3(256), 0, s,
                                                 (const T*)logits, labels, prob, sums, B, ncls, HW, ld));
@@ -262,16 +276,17 @@ extern "C" int tc_seg_loss_bwd(const float* prob, const long long* labels, const
     if (!prob || !labels || !sums || !dlogits || B <= 0 || ncls <= 0 || ncls > MAXCLS || HW <= 0) return TC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((seg_loss_bwd_kernel<T>), dim3(tc_blocks((long long)B * HW, 256, 2048)), dim3(256), 0, s,
-                                                prob, labels, sums, (T*)dlogits, B, ncls, HW, w_ce, w_dice, n_pix_global, gscale, gscale_dev, 0));
+                                                prob, labels, sums, (T*)dlogits, B, ncls, HW, w_ce, w_dice, n_pix_global, gscale, gscale_dev, 0, (const T*)nullptr, 0));
     return tc_launch_status();
 }
 
-extern "C" int tc_seg_loss_bwd_tok(const float* prob, const long long* labels, const float* sums, void* dlogits, int ld, int B, int ncls, int HW,
-                                   float w_ce, float w_dice, float n_pix_global, float gscale, const float* gscale_dev, int dtype, void* stream) {
-    if (!prob || !labels || !sums || !dlogits || B <= 0 || ncls <= 0 || ncls > MAXCLS || HW <= 0 || ld < ncls) return TC_ERR_ARG;
+extern "C" int tc_seg_loss_bwd_tok(const float* prob, const void* logits, int ldl, const long long* labels, const float* sums, void* dlogits, int ld,
+                                   int B, int ncls, int HW, float w_ce, float w_dice, float n_pix_global, float gscale, const float* gscale_dev,
+                                   int dtype, void* stream) {
+    if ((!prob && (!logits || ldl < ncls)) || !labels || !sums || !dlogits || B <= 0 || ncls <= 0 || ncls > MAXCLS || HW <= 0 || ld < ncls) return TC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((seg_loss_bwd_kernel<T>), dim3(tc_blocks((long long)B * HW, 256, 2048)), dim3(256), 0, s,
-                                                prob, labels, sums, (T*)dlogits, B, ncls, HW, w_ce, w_dice, n_pix_global, gscale, gscale_dev, ld));
+                                                prob, labels, sums, (T*)dlogits, B, ncls, HW, w_ce, w_dice, n_pix_global, gscale, gscale_dev, ld, (const T*)logits, ldl));
     return tc_launch_status();
 }
 

@@ -390,9 +390,9 @@ class GraphedStep:
         C = logits.shape[1]
         assert logits.shape[0] == B * H * W and logits.stride(1) == 1
         stream = torch.cuda.current_stream(logits.device).cuda_stream
-        self._prob = torch.empty((B, C, H, W), dtype=torch.float32, device=logits.device)
+        self._logits, self._shape = logits, (B, C, H, W)           # (no probability map: the backward recomputes the softmax)
         self._sums = torch.zeros(1 + 3 * C, dtype=torch.float32, device=logits.device)
-        L.tc_seg_loss_fwd_tok(logits.data_ptr(), logits.stride(0), self.y.data_ptr(), self._prob.data_ptr(), self._sums.data_ptr(), B, C, H * W,
+        L.tc_seg_loss_fwd_tok(logits.data_ptr(), logits.stride(0), self.y.data_ptr(), None, self._sums.data_ptr(), B, C, H * W,
                               _dt(logits), stream)
         self._npix_local = float(B * H * W)
 
@@ -401,12 +401,12 @@ class GraphedStep:
 
     def _bwd(self):
         M, L = self.model, lib()
-        B, C, H, W = self._prob.shape
-        lf = self.loss_fn
+        B, C, H, W = self._shape
+        lf, lg = self.loss_fn, self._logits
         self.out = tuple(t.float() for t in loss_from_sums(self._sums, self._npix, lf.w_ce, lf.w_dice))
-        stream = torch.cuda.current_stream(self._prob.device).cuda_stream
-        d = torch.empty((B * H * W, C), dtype=self.model.compute_dtype, device=self._prob.device)        # the gradient of the token-major logits
-        L.tc_seg_loss_bwd_tok(self._prob.data_ptr(), self.y.data_ptr(), self._sums.data_ptr(), d.data_ptr(), d.stride(0), B, C, H * W,
+        stream = torch.cuda.current_stream(lg.device).cuda_stream
+        d = torch.empty((B * H * W, C), dtype=self.model.compute_dtype, device=lg.device)        # the gradient of the token-major logits
+        L.tc_seg_loss_bwd_tok(None, lg.data_ptr(), lg.stride(0), self.y.data_ptr(), self._sums.data_ptr(), d.data_ptr(), d.stride(0), B, C, H * W,
                               float(lf.w_ce), float(lf.w_dice), float(self._npix), float(lf.loss_scale), None, _dt(d), stream)
         M._backward(self._G, self._out_var, d, until="encoder_done")     # loss gradient, decoders, bridge
 
