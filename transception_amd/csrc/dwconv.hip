@@ -596,15 +596,13 @@ __device__ __forceinline__ void dw_tile_body(const T* __restrict__ src, int lds_
             float t = 0.f;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) t += acc[r][e];
-#pragma unroll
-            for (int o = 1; o < CG; o <<= 1) t += __shfl_xor(t, o, 64);
+            t = tc_group_sum<CG>(t);
             sm[r] = t;
             const float mu = t * (1.0f / (float)CH);
             float q = 0.f;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) { const float dlt = acc[r][e] - mu; q += dlt * dlt; }
-#pragma unroll
-            for (int o = 1; o < CG; o <<= 1) q += __shfl_xor(q, o, 64);
+            q = tc_group_sum<CG>(q);
             m2[r] = q;
         }
         if (!live) return;

@@ -86,13 +86,11 @@ __device__ __forceinline__ void ffn_finalize_stats(const GemmDev& p, int b1, int
     const float2* pp = reinterpret_cast<const float2*>(p.ffn.part) + (rbase + (row < p.M ? row : 0)) * nch;
     float sm = 0.f;
     for (int k = q; k < nch; k += LPR) sm += pp[k].x;
-#pragma unroll
-    for (int o = 1; o < LPR; o <<= 1) sm += __shfl_xor(sm, o, 64);
+    sm = tc_group_sum<LPR>(sm);
     const float mean = sm * invC;
     float m2 = 0.f;
     for (int k = q; k < nch; k += LPR) { const float2 t = pp[k]; const float dm = t.x * inv_cn - mean; m2 += t.y + cn * dm * dm; }
-#pragma unroll
-    for (int o = 1; o < LPR; o <<= 1) m2 += __shfl_xor(m2, o, 64);
+    m2 = tc_group_sum<LPR>(m2);
     const float rstd = rsqrtf(m2 * invC + p.ffn.eps);
     if (q == 0) {
         s_stat[r] = make_float2(mean, rstd);

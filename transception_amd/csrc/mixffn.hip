@@ -175,14 +175,12 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p
                 float sm = 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) sm += f[e];
-#pragma unroll
-                for (int m = 1; m < XC; m <<= 1) sm += __shfl_xor(sm, m, 64);
+                sm = tc_group_sum<XC>(sm);
                 const float mean = sm * (1.0f / C);
                 float q2 = 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { f[e] -= mean; q2 += f[e] * f[e]; }
-#pragma unroll
-                for (int m = 1; m < XC; m <<= 1) q2 += __shfl_xor(q2, m, 64);
+                q2 = tc_group_sum<XC>(q2);
                 const float rstd = rsqrtf(q2 * (1.0f / C) + p.pre_eps);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) f[e] = f[e] * rstd * gm[e] + bt[e];
@@ -316,15 +314,13 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p
                 for (int r = 0; r < 2; ++r) {                    // LayerNorm partials over this wave's CW channels (Chan-mergeable)
                     const tc_f32x2 s4 = (o[q][r][0] + o[q][r][1]) + (o[q][r][2] + o[q][r][3]);
                     float sm = s4.x + s4.y;
-#pragma unroll
-                    for (int m = 1; m < SG; m <<= 1) sm += __shfl_xor(sm, m, 64);
+                    sm = tc_group_sum<SG>(sm);
                     const float mu = sm * (1.0f / (float)CW);
                     tc_f32x2 q2 = {0.f, 0.f};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { const tc_f32x2 dl = o[q][r][e] - mu; q2 += dl * dl; }
                     float sq = q2.x + q2.y;
-#pragma unroll
-                    for (int m = 1; m < SG; m <<= 1) sq += __shfl_xor(sq, m, 64);
+                    sq = tc_group_sum<SG>(sq);
                     if (live && sg == 0 && x0 + r < TW) pst[wave * IPMAX + y * TW + x0 + r] = make_float2(sm, sq);
                 }
 #pragma unroll

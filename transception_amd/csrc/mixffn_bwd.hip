@@ -470,14 +470,12 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dw_kernel(const FfnBwdDev p) {
                 float sm = 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) sm += f[e];
-#pragma unroll
-                for (int m = 1; m < XC; m <<= 1) sm += __shfl_xor(sm, m, 64);
+                sm = tc_group_sum<XC>(sm);
                 const float mean = sm * (1.0f / C);
                 float q2 = 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { f[e] -= mean; q2 += f[e] * f[e]; }
-#pragma unroll
-                for (int m = 1; m < XC; m <<= 1) q2 += __shfl_xor(q2, m, 64);
+                q2 = tc_group_sum<XC>(q2);
                 const float rstd = rsqrtf(q2 * (1.0f / C) + p.pre_eps);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) f[e] = f[e] * rstd * pre[cg * 8 + e] + pre[C + cg * 8 + e];
@@ -721,14 +719,12 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dw_kernel(const FfnBwdDev p) {
                     float sm = 0.f;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) sm += f[e];
-#pragma unroll
-                    for (int m = 1; m < XC; m <<= 1) sm += __shfl_xor(sm, m, 64);
+                    sm = tc_group_sum<XC>(sm);
                     const float mean = sm * (1.0f / C);
                     float q2 = 0.f;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { f[e] -= mean; q2 += f[e] * f[e]; }
-#pragma unroll
-                    for (int m = 1; m < XC; m <<= 1) q2 += __shfl_xor(q2, m, 64);
+                    q2 = tc_group_sum<XC>(q2);
                     const float rstd = rsqrtf(q2 * (1.0f / C) + p.pre_eps);
                     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -738,8 +734,7 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dw_kernel(const FfnBwdDev p) {
                         v[e] *= pre[cg * 8 + e];
                         s1 += v[e]; s2 += v[e] * f[e];
                     }
-#pragma unroll
-                    for (int m = 1; m < XC; m <<= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
+                    s1 = tc_group_sum<XC>(s1); s2 = tc_group_sum<XC>(s2);
                     s1 *= 1.0f / C; s2 *= 1.0f / C;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = rstd * (v[e] - s1 - f[e] * s2);

@@ -33,11 +33,7 @@ __device__ __forceinline__ long long ln_row_off(int row, const LnMap& m, int ld,
     return ((long long)(b * m.H + oh / m.p) * m.W + ow / m.p) * ld + ((oh % m.p) * m.p + ow % m.p) * C;
 }
 
-template <int GS> __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-    for (int o = GS / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+template <int GS> __device__ __forceinline__ float group_sum(float v) { return tc_group_sum<GS>(v); }
 
 // RPT consecutive rows per lane group and iteration: their loads are all issued before the first reduction (narrow rows are
 // 128-256 bytes: one row per group per iteration left a single 8-byte load per lane in flight and ran at ~2 TB/s).

@@ -127,13 +127,11 @@ bool rowwg_ok(int Cc, std::initializer_list<long long> strides, std::initializer
 // row, 4 rows per wavefront, each lane keeps its NV four-channel vectors in registers -- one pass over the row with 8/16-byte
 // accesses instead of three passes of one element per lane and one row per wavefront.
 __device__ __forceinline__ float grp16_max(float v) {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 16));
+    v = tc_group_max<16>(v);
     return v;
 }
 __device__ __forceinline__ float grp16_sum(float v) {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
+    v = tc_group_sum<16>(v);
     return v;
 }
 template <typename T, int NV>

@@ -95,16 +95,33 @@ template <> __device__ __forceinline__ void st4<f16_t>(f16_t* p, float4 v) {
     *reinterpret_cast<uint2*>(p) = r;
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Sums / maxima over aligned groups of G = 2 .. 64 lanes, every lane of the group receiving the result.  Inside a 16-lane row the
+// partner comes through DPP (quad_perm, row_half_mirror, row_mirror: a VALU operand modifier); __shfl_xor compiles to ds_bpermute_b32,
+// an LDS-crossbar instruction with ~100 cycles of latency per dependent step -- four of those per LayerNorm row reduction.
+template <int CTRL> __device__ __forceinline__ float tc_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int G> __device__ __forceinline__ float tc_group_sum(float v) {
+    if (G >= 2) v += tc_dpp<0xB1>(v);                  // quad_perm [1,0,3,2]
+    if (G >= 4) v += tc_dpp<0x4E>(v);                  // quad_perm [2,3,0,1]
+    if (G >= 8) v += tc_dpp<0x141>(v);                 // row_half_mirror: lane i <-> 7 - i of its half row (both quads hold their sum)
+    if (G >= 16) v += tc_dpp<0x140>(v);                // row_mirror: lane i <-> 15 - i of its row
+    if (G >= 32) v += __shfl_xor(v, 16, 64);
+    if (G >= 64) v += __shfl_xor(v, 32, 64);
     return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+template <int G> __device__ __forceinline__ float tc_group_max(float v) {
+    if (G >= 2) v = fmaxf(v, tc_dpp<0xB1>(v));
+    if (G >= 4) v = fmaxf(v, tc_dpp<0x4E>(v));
+    if (G >= 8) v = fmaxf(v, tc_dpp<0x141>(v));
+    if (G >= 16) v = fmaxf(v, tc_dpp<0x140>(v));
+    if (G >= 32) v = fmaxf(v, __shfl_xor(v, 16, 64));
+    if (G >= 64) v = fmaxf(v, __shfl_xor(v, 32, 64));
     return v;
 }
+
+__device__ __forceinline__ float wave_sum(float v) { return tc_group_sum<64>(v); }
+__device__ __forceinline__ float wave_max(float v) { return tc_group_max<64>(v); }
 
 // Exact-erf GELU (nn.GELU() default, MSTr.py:894) and its derivative.  erf through Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7,
 // below fp32 resolution of the products it enters): with z = x / sqrt(2),  erf(|z|) = 1 - (a1 t + .. + a5 t^5) exp(-z^2),
