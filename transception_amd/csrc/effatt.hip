@@ -544,8 +544,7 @@ __global__ __launch_bounds__(64) void effatt_dctx_kernel(const EffDev p) {
     }
     p.dctx[((long long)b * C + c) * C + cc] = acc;
     float r = acc * p.ctx[((long long)b * C + c) * C + cc];
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) r += __shfl_xor(r, m, 64);
+    r = wave_sum(r);
     if (cc == 0) p.rsum[(long long)b * C + c] = r;
 }
 

@@ -118,9 +118,15 @@ __device__ __forceinline__ void fa_gram(float* out, const TA* a, const TB* b, in
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc[u] += ai * bv[u];
         }
-        for (int o = RL >> 1; o > 0; o >>= 1) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc[u] += __shfl_xor(acc[u], o, 64);
+        for (int u = 0; u < 8; ++u) {                           // (RL is 1 .. 32, wave-uniform: the in-row steps through DPP)
+            float v = acc[u];
+            if (RL >= 2) v += tc_dpp<0xB1>(v);
+            if (RL >= 4) v += tc_dpp<0x4E>(v);
+            if (RL >= 8) v += tc_dpp<0x141>(v);
+            if (RL >= 16) v += tc_dpp<0x140>(v);
+            if (RL >= 32) v += __shfl_xor(v, 16, 64);
+            acc[u] = v;
         }
         if (rl == 0) {
 #pragma unroll

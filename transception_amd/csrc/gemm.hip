@@ -279,8 +279,7 @@ __device__ __forceinline__ void epilogue_cols(const GemmDev& p, f32x16 (&acc)[TM
         if constexpr (EP) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-#pragma unroll
-                for (int o = 1; o < 32; o <<= 1) { s1[r] += __shfl_xor(s1[r], o, 64); s2[r] += __shfl_xor(s2[r], o, 64); }
+                s1[r] = tc_group_sum<32>(s1[r]); s2[r] = tc_group_sum<32>(s2[r]);
                 if ((lane & 31) == 0) srow[wc * 64 + mloc0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)] = make_float2(s1[r], s2[r]);
             }
         }
