@@ -3,7 +3,11 @@
 
 namespace {
 
-#define TC_GRID_STRIDE(i, n) for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long long)gridDim.x * blockDim.x)
+// Element index of a grid-stride loop.  32-bit: the kernels below split it with run-time divisors (row / column, pixel / channel quad),
+// and a 64-bit division is ~100 instructions on this ISA -- the layout moves were integer-ALU-bound.  g1() refuses n >= 2^31 (the launch
+// then fails and the entry point reports it); the two kernels without a division keep the 64-bit form.
+#define TC_GRID_STRIDE(i, n) for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)(n); i += gridDim.x * blockDim.x)
+#define TC_GRID_STRIDE64(i, n) for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long long)gridDim.x * blockDim.x)
 
 template <typename T>
 __global__ void fma3_fwd_kernel(const T* a, int lda, const T* b, int ldb, const T* c, int ldc, T* o, int ldo, int rows, int cq,
@@ -41,13 +45,36 @@ __global__ void add_kernel(const T* a, int lda, const T* b, int ldb, T* y, int l
 
 template <typename T>
 __global__ void sigmoid_bwd_kernel(const T* dy, const T* s, T* dz, long long n) {
-    TC_GRID_STRIDE(i, n) { const float v = ldf<T>(s + i); stf<T>(dz + i, ldf<T>(dy + i) * v * (1.f - v)); }
+    TC_GRID_STRIDE64(i, n) { const float v = ldf<T>(s + i); stf<T>(dz + i, ldf<T>(dy + i) * v * (1.f - v)); }
 }
 
 template <typename T>
 __device__ __forceinline__ void copy3d_body(const T* src, long long sbs, int lds, T* dst, long long sbd, int ldd, int nb, int rows, int cols, int acc) {
+    constexpr int V = 16 / (int)sizeof(T);                      // elements of a 16-byte piece
+    const bool wide = !((cols | lds | ldd) % V) && !(sbs % V) && !(sbd % V) && !(((uintptr_t)src | (uintptr_t)dst) & 15);
+    if (wide) {                                                 // whole 16-byte pieces per thread (the residual-gradient copies: 8 elements at a time)
+        const int cv = cols / V;
+        TC_GRID_STRIDE(i, (long long)nb * rows * cv) {
+            const int c = (int)(i % cv) * V; const unsigned t = i / cv; const int r = (int)(t % rows); const long long b = t / rows;
+            T* d = dst + b * sbd + (long long)r * ldd + c;
+            const uint4 sv = *reinterpret_cast<const uint4*>(src + b * sbs + (long long)r * lds + c);
+            if (!acc) { *reinterpret_cast<uint4*>(d) = sv; continue; }
+            const uint4 dv = *reinterpret_cast<const uint4*>(d);
+            if constexpr (sizeof(T) == 4) {
+                const float4 a = __builtin_bit_cast(float4, sv), o = __builtin_bit_cast(float4, dv);
+                *reinterpret_cast<float4*>(d) = make_float4(a.x + o.x, a.y + o.y, a.z + o.z, a.w + o.w);
+            } else {
+                const unsigned sw[4] = {sv.x, sv.y, sv.z, sv.w}, dw[4] = {dv.x, dv.y, dv.z, dv.w};
+                unsigned ow[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { float a0, a1, o0, o1; unpack2<T>(sw[e], a0, a1); unpack2<T>(dw[e], o0, o1); ow[e] = pack2<T>(a0 + o0, a1 + o1); }
+                *reinterpret_cast<uint4*>(d) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+            }
+        }
+        return;
+    }
     TC_GRID_STRIDE(i, (long long)nb * rows * cols) {
-        const int c = (int)(i % cols); const long long t = i / cols; const int r = (int)(t % rows); const long long b = t / rows;
+        const int c = (int)(i % cols); const unsigned t = i / cols; const int r = (int)(t % rows); const long long b = t / rows;
         T* d = dst + b * sbd + (long long)r * ldd + c;
         float v = ldf<T>(src + b * sbs + (long long)r * lds + c);
         if (acc) v += ldf<T>(d);
@@ -77,7 +104,7 @@ template <typename T>
 __global__ void coord_pool_fwd_kernel(const T* x, T* pooled, int B, int H, int W, int C) {
     const int cq = C >> 2;
     TC_GRID_STRIDE(i, (long long)B * (H + W) * cq) {
-        const int q = (int)(i % cq) * 4; const int j = (int)((i / cq) % (H + W)); const int b = (int)(i / ((long long)cq * (H + W)));
+        const int q = (int)(i % cq) * 4; const int j = (int)((i / cq) % (H + W)); const int b = (int)(i / (unsigned)(cq * (H + W)));
         const T* xb = x + (long long)b * H * W * C + q;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         if (j < H) { for (int w = 0; w < W; ++w) { const float4 v = ld4<T>(xb + ((long long)j * W + w) * C); s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
@@ -92,8 +119,9 @@ template <typename T>
 __global__ void coord_pool_bwd_kernel(const T* dp, T* dx, int B, int H, int W, int C, int acc) {
     const int cq = C >> 2;
     TC_GRID_STRIDE(i, (long long)B * H * W * cq) {
-        const int q = (int)(i % cq) * 4; const long long pix = i / cq;
-        const int w = (int)(pix % W), h = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
+        const int q = (int)(i % cq) * 4; const unsigned pix32 = i / cq;
+        const int w = (int)(pix32 % W), h = (int)((pix32 / W) % H), b = (int)(pix32 / (unsigned)(W * H));
+        const long long pix = pix32;
         const float4 gh = ld4<T>(dp + ((long long)b * H + h) * C + q), gw = ld4<T>(dp + ((long long)B * H + (long long)b * W + w) * C + q);
         const float ih = 1.f / W, iw = 1.f / H;
         float4 g = make_float4(gh.x * ih + gw.x * iw, gh.y * ih + gw.y * iw, gh.z * ih + gw.z * iw, gh.w * ih + gw.w * iw);
@@ -107,8 +135,9 @@ template <typename T>
 __global__ void coord_gate_fwd_kernel(const T* x, const T* att, T* y, int B, int H, int W, int C) {
     const int cq = C >> 2;
     TC_GRID_STRIDE(i, (long long)B * H * W * cq) {
-        const int q = (int)(i % cq) * 4; const long long pix = i / cq;
-        const int w = (int)(pix % W), h = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
+        const int q = (int)(i % cq) * 4; const unsigned pix32 = i / cq;
+        const int w = (int)(pix32 % W), h = (int)((pix32 / W) % H), b = (int)(pix32 / (unsigned)(W * H));
+        const long long pix = pix32;
         const float4 ah = ld4<T>(att + ((long long)b * H + h) * C + q), aw = ld4<T>(att + ((long long)B * H + (long long)b * W + w) * C + q);
         const float4 v = ld4<T>(x + pix * C + q);
         st4<T>(y + pix * C + q, make_float4(v.x * aw.x * ah.x, v.y * aw.y * ah.y, v.z * aw.z * ah.z, v.w * aw.w * ah.w));
@@ -120,8 +149,9 @@ template <typename T>
 __global__ void coord_gate_bwd_dx_kernel(const T* dy, const T* att, T* dx, int acc, int B, int H, int W, int C) {
     const int cq = C >> 2;
     TC_GRID_STRIDE(i, (long long)B * H * W * cq) {
-        const int q = (int)(i % cq) * 4; const long long pix = i / cq;
-        const int w = (int)(pix % W), h = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
+        const int q = (int)(i % cq) * 4; const unsigned pix32 = i / cq;
+        const int w = (int)(pix32 % W), h = (int)((pix32 / W) % H), b = (int)(pix32 / (unsigned)(W * H));
+        const long long pix = pix32;
         const float4 ah = ld4<T>(att + ((long long)b * H + h) * C + q), aw = ld4<T>(att + ((long long)B * H + (long long)b * W + w) * C + q);
         const float4 d = ld4<T>(dy + pix * C + q);
         float4 g = make_float4(d.x * aw.x * ah.x, d.y * aw.y * ah.y, d.z * aw.z * ah.z, d.w * aw.w * ah.w);
@@ -136,7 +166,7 @@ template <typename T>
 __global__ void coord_gate_bwd_att_kernel(const T* dy, const T* x, const T* att, T* datt, int B, int H, int W, int C) {
     const int cq = C >> 2;
     TC_GRID_STRIDE(i, (long long)B * (H + W) * cq) {
-        const int q = (int)(i % cq) * 4; const int j = (int)((i / cq) % (H + W)); const int b = (int)(i / ((long long)cq * (H + W)));
+        const int q = (int)(i % cq) * 4; const int j = (int)((i / cq) % (H + W)); const int b = (int)(i / (unsigned)(cq * (H + W)));
         const T* ah_b = att + (long long)b * H * C + q;
         const T* aw_b = att + ((long long)B * H + (long long)b * W) * C + q;
         const long long base = (long long)b * H * W;
@@ -166,9 +196,9 @@ __global__ void pixel_shuffle_kernel(const T* in, T* out, int B, int H, int W, i
     const int cq = c >> 2;
     const long long n = (long long)B * H * p * W * p * cq;
     TC_GRID_STRIDE(i, n) {
-        const int q = (int)(i % cq) * 4; long long t = i / cq;
-        const int ow = (int)(t % (W * p)); t /= (W * p);
-        const int oh = (int)(t % (H * p)); const int b = (int)(t / (H * p));
+        const int q = (int)(i % cq) * 4; unsigned t = i / cq;
+        const int ow = (int)(t % (unsigned)(W * p)); t /= (unsigned)(W * p);
+        const int oh = (int)(t % (unsigned)(H * p)); const int b = (int)(t / (unsigned)(H * p));
         const int h = oh / p, p1 = oh % p, w = ow / p, p2 = ow % p;
         const long long fine = (((long long)b * H * p + oh) * W * p + ow) * c + q;
         const long long coarse = (((long long)b * H + h) * W + w) * (long long)(p * p * c) + (p1 * p + p2) * c + q;
@@ -182,7 +212,7 @@ __device__ __forceinline__ void patchify_body(const T* map, long long sb, int ld
     const long long n = (long long)B * H * W * cq;
     T* m = const_cast<T*>(map);
     TC_GRID_STRIDE(i, n) {
-        const int q = (int)(i % cq) * 4; long long t = i / cq;
+        const int q = (int)(i % cq) * 4; unsigned t = i / cq;
         const int w = (int)(t % W); t /= W; const int h = (int)(t % H); const int b = (int)(t / H);
         const long long src = b * sb + ((long long)h * W + w) * ld + q;
         const long long row = ((long long)b * Ho + h / k) * Wo + w / k;
@@ -209,7 +239,7 @@ __device__ __forceinline__ void sr_deinterleave_body(const T* in, T* out, long l
     const long long n = (long long)B * P * C * mult;
     T* o = out; T* ii = const_cast<T*>(in);
     TC_GRID_STRIDE(i, n) {
-        const int c = (int)(i % C); long long t = i / C;
+        const int c = (int)(i % C); unsigned t = i / C;
         const int pos = (int)(t % P); t /= P; const int g = (int)(t % mult); const int b = (int)(t / mult);
         const long long oi = b * sbo + ((long long)g * P + pos) * ldo + c;
         const long long si = ((long long)b * P + pos) * (C * mult) + c * mult + g;
@@ -237,7 +267,7 @@ template <typename T>
 __global__ void stem_im2col_kernel(const T* img, T* cols, int ldc, int B, int in_ch, int H, int W, int Ho, int Wo) {
     const long long n = (long long)B * Ho * Wo * ldc;
     TC_GRID_STRIDE(i, n) {
-        const int col = (int)(i % ldc); long long t = i / ldc;
+        const int col = (int)(i % ldc); unsigned t = i / ldc;
         const int ow = (int)(t % Wo); t /= Wo; const int oh = (int)(t % Ho); const int b = (int)(t / Ho);
         float v = 0.f;
         if (col < 147) {
@@ -251,9 +281,9 @@ __global__ void stem_im2col_kernel(const T* img, T* cols, int ldc, int B, int in
 }
 
 template <typename TS, typename TD>
-__global__ void cast_kernel(const TS* s, TD* d, long long n) { TC_GRID_STRIDE(i, n) stf<TD>(d + i, ldf<TS>(s + i)); }
+__global__ void cast_kernel(const TS* s, TD* d, long long n) { TC_GRID_STRIDE64(i, n) stf<TD>(d + i, ldf<TS>(s + i)); }
 
-inline dim3 g1(long long n) { return dim3(tc_blocks(n, 256, 8192)); }
+inline dim3 g1(long long n) { return n < 0x7fffffffLL ? dim3(tc_blocks(n, 256, 8192)) : dim3(0); }     // (an empty grid is a launch error: reported)
 
 }  // namespace
 

@@ -32,7 +32,8 @@ __global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const T* __restrict__
     for (int k = 0; k < MAXCLS; ++k) I[k] = Y[k] = Z[k] = 0.f;
     const long long n = (long long)B * HW;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const int b = (int)(i / HW); const int p = (int)(i % HW);
+        const int b = (ld && !prob) ? 0 : (int)((unsigned)i / (unsigned)HW), p = (int)i - b * HW;     // (B * HW < 2^31: checked by the entry points;
+                                                                                                    //  token-major without a probability map needs neither)
         const T* lp = ld ? logits + i * ld : logits + (long long)b * ncls * HW + p;
         const long long ks = ld ? 1 : HW;
         float v[MAXCLS], m = -INFINITY;
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float* __restri
     const long long n = (long long)B * HW;
     const float cew = w_ce / n_pix;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const int b = (int)(i / HW); const int p = (int)(i % HW);
+        const int b = (ld && !prob) ? 0 : (int)((unsigned)i / (unsigned)HW), p = (int)i - b * HW;
         const float* pp = prob + (long long)b * ncls * HW + p;
         const int lab = (int)labels[i];
         float pk[MAXCLS], g[MAXCLS], dot = 0.f;
@@ -223,7 +224,7 @@ extern "C" int tc_colsum(const void* x, int rows, int cols, int ldx, int nb, lon
 
 extern "C" int tc_seg_loss_fwd(const void* logits, const long long* labels, float* prob, float* sums, int B, int ncls, int HW,
                                int dtype, void* stream) {
-    if (!logits || !labels || !prob || !sums || B <= 0 || ncls <= 0 || ncls > MAXCLS || HW <= 0) return TC_ERR_ARG;
+    if (!logits || !labels || !prob || !sums || B <= 0 || ncls <= 0 || ncls > MAXCLS || HW <= 0 || (long long)B * HW >= 0x7fffffffLL) return TC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((seg_loss_fwd_kernel<T>), dim3(tc_blocks((long long)B * HW, 256, 1024)), dim3(256), 0, s,
                                                 (const T*)logits, labels, prob, sums, B, ncls, HW, 0));
@@ -232,7 +233,7 @@ extern "C" int tc_seg_loss_fwd(const void* logits, const long long* labels, floa
 
 extern "C" int tc_seg_loss_fwd_tok(const void* logits, int ld, const long long* labels, float* prob, float* sums, int B, int ncls, int HW,
                                    int dtype, void* stream) {
-    if (!logits || !labels || !sums || B <= 0 || ncls <= 0 || ncls > MAXCLS || HW <= 0 || ld < ncls) return TC_ERR_ARG;
+    if (!logits || !labels || !sums || B <= 0 || ncls <= 0 || ncls > MAXCLS || HW <= 0 || ld < ncls || (long long)B * HW >= 0x7fffffffLL) return TC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((seg_loss_fwd_kernel<T>), dim3(tc_blocks((long long)B * HW, 256, 1024)), dim3(256), 0, s,
                                                 (const T*)logits, labels, prob, sums, B, ncls, HW, ld));
@@ -273,7 +274,7 @@ extern "C" int tc_argmax_counts(const void* logits, const long long* labels, uns
 
 extern "C" int tc_seg_loss_bwd(const float* prob, const long long* labels, const float* sums, void* dlogits, int B, int ncls, int HW,
                                float w_ce, float w_dice, float n_pix_global, float gscale, const float* gscale_dev, int dtype, void* stream) {
-    if (!prob || !labels || !sums || !dlogits || B <= 0 || ncls <= 0 || ncls > MAXCLS || HW <= 0) return TC_ERR_ARG;
+    if (!prob || !labels || !sums || !dlogits || B <= 0 || ncls <= 0 || ncls > MAXCLS || HW <= 0 || (long long)B * HW >= 0x7fffffffLL) return TC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((seg_loss_bwd_kernel<T>), dim3(tc_blocks((long long)B * HW, 256, 2048)), dim3(256), 0, s,
                                                 prob, labels, sums, (T*)dlogits, B, ncls, HW, w_ce, w_dice, n_pix_global, gscale, gscale_dev, 0, (const T*)nullptr, 0));
@@ -283,7 +284,9 @@ extern "C" int tc_seg_loss_bwd(const float* prob, const long long* labels, const
 extern "C" int tc_seg_loss_bwd_tok(const float* prob, const void* logits, int ldl, const long long* labels, const float* sums, void* dlogits, int ld,
                                    int B, int ncls, int HW, float w_ce, float w_dice, float n_pix_global, float gscale, const float* gscale_dev,
                                    int dtype, void* stream) {
-    if ((!prob && (!logits || ldl < ncls)) || !labels || !sums || !dlogits || B <= 0 || ncls <= 0 || ncls > MAXCLS || HW <= 0 || ld < ncls) return TC_ERR_ARG;
+    if ((!prob && (!logits || ldl < ncls)) || !labels || !sums || !dlogits || B <= 0 || ncls <= 0 || ncls > MAXCLS || HW <= 0 || ld < ncls ||
+        (long long)B * HW >= 0x7fffffffLL)
+        return TC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((seg_loss_bwd_kernel<T>), dim3(tc_blocks((long long)B * HW, 256, 2048)), dim3(256), 0, s,
                                                 prob, labels, sums, (T*)dlogits, B, ncls, HW, w_ce, w_dice, n_pix_global, gscale, gscale_dev, ld, (const T*)logits, ldl));
