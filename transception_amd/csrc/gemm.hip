@@ -65,7 +65,7 @@ template <typename H> __device__ __forceinline__ uint4 ffn_ln_gelu8(const uint4&
 #pragma unroll
     for (int e = 0; e < 8; e += 2) {                          // pairs on the packed fp32 pipe
         const tc_f32x2 xv = {x[e], x[e + 1]}, gv = {g[e], g[e + 1]}, bv = {b[e], b[e + 1]};
-        const tc_f32x2 u = gelu_f2((xv - mean) * rstd * gv + bv);
+        const tc_f32x2 u = gelu_f2_fast((xv - mean) * rstd * gv + bv);           // (16-bit storage: hardware reciprocal)
         x[e] = u.x; x[e + 1] = u.y;
     }
     return bf8_pack<H>(x);
@@ -99,9 +99,9 @@ __device__ __forceinline__ void ffn_finalize_stats(const GemmDev& p, int b1, int
     __syncthreads();
 }
 // TC_FFN_EP on one value: gp = v * GELU'(xhat gamma + beta); accumulates the two LayerNorm-backward row sums
-__device__ __forceinline__ float ffn_ep1(float v, float d, float mean, float rstd, float g, float b, float& s1, float& s2) {
+template <typename T> __device__ __forceinline__ float ffn_ep1(float v, float d, float mean, float rstd, float g, float b, float& s1, float& s2) {
     const float xh = (d - mean) * rstd;
-    const float gp = v * gelu_grad_f(xh * g + b);
+    const float gp = v * gelu_grad_fT<T>(xh * g + b);
     s1 += gp * g; s2 += gp * g * xh;
     return gp;
 }
@@ -264,7 +264,7 @@ __device__ __forceinline__ void epilogue_cols(const GemmDev& p, f32x16 (&acc)[TM
                 if (R && first_split) v += ldf<T>(R + (long long)row * p.ldr + col);
                 if constexpr (EP) {
                     const float2 st = stat[row];
-                    v = ffn_ep1(v, ldf<T>(dmap + (long long)row * p.ffn.ldd + col), st.x, st.y, gm, bt, s1[r], s2[r]);
+                    v = ffn_ep1<T>(v, ldf<T>(dmap + (long long)row * p.ffn.ldd + col), st.x, st.y, gm, bt, s1[r], s2[r]);
                 }
                 TC* c = C + (long long)row * p.ldc + col;
                 if (atomic) {
@@ -389,8 +389,8 @@ __device__ __forceinline__ void epilogue_rows_lds_ep(const GemmDev& p, f32x16 (&
                         const tc_f32x2 va = {v[0], v[1]}, vb = {v[2], v[3]};
                         const tc_f32x2 ga = {g4.x, g4.y}, gb = {g4.z, g4.w};
                         const tc_f32x2 xa = (tc_f32x2{d4.x, d4.y} - st.x) * st.y, xb = (tc_f32x2{d4.z, d4.w} - st.x) * st.y;
-                        const tc_f32x2 pa = va * gelu_grad_f2(xa * ga + tc_f32x2{b4.x, b4.y});
-                        const tc_f32x2 pb = vb * gelu_grad_f2(xb * gb + tc_f32x2{b4.z, b4.w});
+                        const tc_f32x2 pa = va * gelu_grad_f2_fast(xa * ga + tc_f32x2{b4.x, b4.y});      // (the 16-bit kernel)
+                        const tc_f32x2 pb = vb * gelu_grad_f2_fast(xb * gb + tc_f32x2{b4.z, b4.w});
                         const tc_f32x2 qa = pa * ga, qb = pb * gb, ra = qa * xa, rb = qb * xb;
                         s1 += (qa.x + qa.y) + (qb.x + qb.y);
                         s2 += (ra.x + ra.y) + (rb.x + rb.y);

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, in
                     float4 o;
                     o.x = (v[r][i].x - mu[r]) * rs[r] * g[i].x + b[i].x; o.y = (v[r][i].y - mu[r]) * rs[r] * g[i].y + b[i].y;
                     o.z = (v[r][i].z - mu[r]) * rs[r] * g[i].z + b[i].z; o.w = (v[r][i].w - mu[r]) * rs[r] * g[i].w + b[i].w;
-                    if (act == TC_ACT_GELU) { o.x = gelu_f(o.x); o.y = gelu_f(o.y); o.z = gelu_f(o.z); o.w = gelu_f(o.w); }
+                    if (act == TC_ACT_GELU) { o.x = gelu_fT<T>(o.x); o.y = gelu_fT<T>(o.y); o.z = gelu_fT<T>(o.z); o.w = gelu_fT<T>(o.w); }
                     st4<T>(yr + q * 4, o);
                 }
             }
@@ -177,8 +177,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
                     float4 xv = xh[r][i], d = gg[r][i];
                     xv.x = (xv.x - mu[r]) * rs[r]; xv.y = (xv.y - mu[r]) * rs[r]; xv.z = (xv.z - mu[r]) * rs[r]; xv.w = (xv.w - mu[r]) * rs[r];
                     if (act == TC_ACT_GELU) {
-                        d.x *= gelu_grad_f(xv.x * g[i].x + b[i].x); d.y *= gelu_grad_f(xv.y * g[i].y + b[i].y);
-                        d.z *= gelu_grad_f(xv.z * g[i].z + b[i].z); d.w *= gelu_grad_f(xv.w * g[i].w + b[i].w);
+                        d.x *= gelu_grad_fT<T>(xv.x * g[i].x + b[i].x); d.y *= gelu_grad_fT<T>(xv.y * g[i].y + b[i].y);
+                        d.z *= gelu_grad_fT<T>(xv.z * g[i].z + b[i].z); d.w *= gelu_grad_fT<T>(xv.w * g[i].w + b[i].w);
                     }
                     if (dgamma && live) {
                         ag[i].x += d.x * xv.x; ag[i].y += d.y * xv.y; ag[i].z += d.z * xv.z; ag[i].w += d.w * xv.w;
@@ -288,8 +288,8 @@ __global__ __launch_bounds__(256) void ln_param_grad_kernel(const T* __restrict_
             float4 xv = ld4<T>(x + (long long)r * ldx + c), d = ld4<T>(dy + (long long)r * lddy + c);
             xv.x = (xv.x - mu) * rs; xv.y = (xv.y - mu) * rs; xv.z = (xv.z - mu) * rs; xv.w = (xv.w - mu) * rs;
             if (act == TC_ACT_GELU) {
-                d.x *= gelu_grad_f(xv.x * gm.x + bt.x); d.y *= gelu_grad_f(xv.y * gm.y + bt.y);
-                d.z *= gelu_grad_f(xv.z * gm.z + bt.z); d.w *= gelu_grad_f(xv.w * gm.w + bt.w);
+                d.x *= gelu_grad_fT<T>(xv.x * gm.x + bt.x); d.y *= gelu_grad_fT<T>(xv.y * gm.y + bt.y);
+                d.z *= gelu_grad_fT<T>(xv.z * gm.z + bt.z); d.w *= gelu_grad_fT<T>(xv.w * gm.w + bt.w);
             }
             ag.x += d.x * xv.x; ag.y += d.y * xv.y; ag.z += d.z * xv.z; ag.w += d.w * xv.w;
             ab.x += d.x; ab.y += d.y; ab.z += d.z; ab.w += d.w;

@@ -2,6 +2,7 @@
 // One storage type parameter T per kernel: float (parity path) or bf16_t (raw 16-bit storage, fp32 math).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 #include "../../include/transception_hip.h"
@@ -127,10 +128,14 @@ __device__ __forceinline__ float wave_max(float v) { return tc_group_max<64>(v);
 // below fp32 resolution of the products it enters): with z = x / sqrt(2),  erf(|z|) = 1 - (a1 t + .. + a5 t^5) exp(-z^2),
 // t = 1 / (1 + p |z|).  exp(-z^2) = exp(-x^2/2) is the Gaussian the derivative needs anyway, so value and gradient cost one
 // exp + one reciprocal + a dozen FMAs -- libm's erff alone was ~25 instructions and made the GELU LayerNorm kernels VALU-bound.
-__device__ __forceinline__ float gelu_cdf_pdf(float x, float& pdf) {
+// FAST: the hardware reciprocal (v_rcp_f32, 1 ulp) instead of the correctly rounded one -- __frcp_rn and `1.0f / x` expand to the IEEE
+// division sequence (v_div_scale x 2, v_rcp, four FMAs, v_div_fmas, v_div_fixup: ~10 instructions); the 16-bit storage kernels take
+// FAST (the difference is far below their storage rounding), the fp32 parity path keeps the exact form.
+template <bool FAST> __device__ __forceinline__ float tc_rcp(float x) { return FAST ? __builtin_amdgcn_rcpf(x) : __frcp_rn(x); }
+template <bool FAST = false> __device__ __forceinline__ float gelu_cdf_pdf(float x, float& pdf) {
     const float z = fabsf(x) * 0.70710678118654752440f;
     const float g = __expf(-z * z);                               // exp(-x^2 / 2)
-    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+    const float t = tc_rcp<FAST>(fmaf(0.3275911f, z, 1.0f));
     float poly = fmaf(1.061405429f, t, -1.453152027f);
     poly = fmaf(poly, t, 1.421413741f);
     poly = fmaf(poly, t, -0.284496736f);
@@ -140,6 +145,14 @@ __device__ __forceinline__ float gelu_cdf_pdf(float x, float& pdf) {
     return x >= 0.f ? 1.0f - half_erfc : half_erfc;               // Phi(x)
 }
 __device__ __forceinline__ float gelu_f(float x) { float pdf; return x * gelu_cdf_pdf(x, pdf); }
+// by storage type: exact for fp32, FAST for the 16-bit types
+template <typename T> __device__ __forceinline__ float gelu_fT(float x) { float pdf; return x * gelu_cdf_pdf<!std::is_same<T, float>::value>(x, pdf); }
+template <typename T> __device__ __forceinline__ float gelu_grad_fT(float x) {
+    float pdf;
+    const float cdf = gelu_cdf_pdf<!std::is_same<T, float>::value>(x, pdf);
+    return cdf + x * pdf;
+}
+template <typename T> __device__ __forceinline__ float sigmoid_fT(float x) { return tc_rcp<!std::is_same<T, float>::value>(1.0f + __expf(-x)); }
 // Two elements at a time on the packed fp32 pipe (v_pk_mul / v_pk_fma / v_pk_add: two lanes of arithmetic per issue slot; only
 // the two exp and the two reciprocals stay scalar transcendental issues) -- same formula, same rounding per element.
 __device__ __forceinline__ tc_f32x2 gelu_cdf_pdf2(tc_f32x2 x, tc_f32x2& pdf) {
@@ -179,6 +192,7 @@ __device__ __forceinline__ tc_f32x2 gelu_cdf_pdf2_fast(tc_f32x2 x, tc_f32x2& pdf
 __device__ __forceinline__ tc_f32x2 gelu_f2_fast(tc_f32x2 x) { tc_f32x2 pdf; return x * gelu_cdf_pdf2_fast(x, pdf); }
 __device__ __forceinline__ tc_f32x2 gelu_f2(tc_f32x2 x) { tc_f32x2 pdf; return x * gelu_cdf_pdf2(x, pdf); }
 __device__ __forceinline__ tc_f32x2 gelu_grad_f2(tc_f32x2 x) { tc_f32x2 pdf; const tc_f32x2 cdf = gelu_cdf_pdf2(x, pdf); return cdf + x * pdf; }
+__device__ __forceinline__ tc_f32x2 gelu_grad_f2_fast(tc_f32x2 x) { tc_f32x2 pdf; const tc_f32x2 cdf = gelu_cdf_pdf2_fast(x, pdf); return cdf + x * pdf; }
 __device__ __forceinline__ float gelu_grad_f(float x) {
     float pdf;
     const float cdf = gelu_cdf_pdf(x, pdf);
