@@ -167,6 +167,11 @@ int tc_dwconv_bwd_input(const void* dy, int lddy, const void* w, void* dx, int l
 int tc_dwconv_bwd_weight(const void* dy, int lddy, const void* x, int ldx, float* dw, float* db,
                          int B, int H, int W, int C, int k, int stride, int groups, long long wstride, void* ws,
                          long long ws_bytes, int dtype, void* stream);
+/* Both gradients of a stride-1 convolution in ONE launch (same arguments and semantics as the two entries above; falls back to them when
+ * the operands do not allow the 16-byte tile kernels): the two launches read the same dy and do not depend on each other. */
+int tc_dwconv_bwd(const void* dy, int lddy, const void* x, int ldx, const void* w, void* dx, int lddx, float* dw, float* db, int B, int H,
+                  int W, int C, int k, int add_input, int accumulate, int groups, long long wstride, void* ws, long long ws_bytes,
+                  int dtype, void* stream);
 
 /* Up to four INDEPENDENT stride-1 depthwise convolutions in ONE launch: ConvRelPosEnc's 3x3 / 5x5 / 7x7 branches on column
  * slices of one map (MSTr.py:785-816), or the four per-scale MixFFN convolutions of a bridge layer (different maps).

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("TC_LIB_PATH") or os.path.join(HERE, "libtransception_
 
 TC_F32, TC_BF16, TC_F16 = 0, 1, 2
 ACT_NONE, ACT_HSWISH, ACT_COORD, ACT_SIGMOID, ACT_GELU = 0, 1, 2, 3, 4
-ABI_VERSION = 10
+ABI_VERSION = 11
 ATTN_DKV_SPLITS = 8                # include/transception_hip.h: partial dK|dV buffers in tc_attn_bwd_seg's fp32 scratch
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_longlong, C.c_float
@@ -109,6 +109,7 @@ SIGNATURES = {
     "tc_dwconv_fwd": [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i64, i32, vp],
     "tc_dwconv_bwd_input": [vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i64, i32, vp],
     "tc_dwconv_bwd_weight": [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i64, vp, i64, i32, vp],
+    "tc_dwconv_bwd": [vp, i32, vp, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i64, vp, i64, i32, vp],
     "tc_dwconv_multi": [C.POINTER(TcDwSeg), i32, i32, i32, i32, i32, i64, vp, i64, i32, vp],
     "tc_ffn_chunk": [i32, i32],
     "tc_ffn_dw_fwd": [vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i64, i32, vp],

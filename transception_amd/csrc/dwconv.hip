@@ -824,6 +824,24 @@ __global__ __launch_bounds__(256) void dw_tile_wgrad_kernel(const T* __restrict_
                                  blockIdx.z, gridDim.x, gridDim.y, smem);
 }
 
+// Input gradient and weight gradient of one stride-1 convolution in ONE grid: the first n_wg workgroups of a row are the (long-running)
+// weight-gradient walkers, the rest the input-gradient tiles -- both read dy, neither reads the other's result, and as two launches each
+// paid its own ramp and drain (5 + 11 us at the cpe shapes).
+template <typename T, int K, int CG>
+__global__ __launch_bounds__(256) void dw_tile_bwd_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ w, T* __restrict__ dx, int lddx,
+                                                          const T* __restrict__ x, int ldx, float* __restrict__ dw, float* __restrict__ db,
+                                                          int B, int H, int W, int C, int add_input, int accumulate, long long wstride, int tilesW,
+                                                          int tilesH, float* __restrict__ ws_part, int* __restrict__ ws_cnt, int n_wg, int n_in) {
+    constexpr int SQ = dw_tile_smem_q<T, K, CG>() > dw_wgrad_smem_q<T, K, CG>() ? dw_tile_smem_q<T, K, CG>() : dw_wgrad_smem_q<T, K, CG>();
+    __shared__ uint4 smem[SQ];
+    if ((int)blockIdx.x < n_wg)
+        dw_tile_wgrad_body<T, K, CG>(x, ldx, dy, lddy, dw, db, B, H, W, C, wstride, tilesW, tilesH, ws_part, ws_cnt, blockIdx.x, blockIdx.y, blockIdx.z,
+                                     n_wg, gridDim.y, smem);
+    else
+        dw_tile_body<T, K, CG, 1>(dy, lddy, w, nullptr, dx, lddx, B, H, W, C, add_input, accumulate, wstride, tilesW, tilesH,
+                                  dw_xcd_tile((int)blockIdx.x - n_wg, n_in), blockIdx.y, blockIdx.z, smem, nullptr, (int)gridDim.y);
+}
+
 // 16-byte lanes per pixel that waste the fewest channels (ties: the widest)
 template <typename T> int dw_pick_cg(int C) {
     constexpr int VEC = Vec16<T>::N;
@@ -870,6 +888,35 @@ int launch_tile(const void* src, int lds_, const void* w, const void* bias, void
                            (const T*)w, (const T*)bias, (T*)y, ldy, B, H, W, C, add_input, accumulate, wstride, tilesW, tilesH, stat);  \
     }
 #define TC_TILE_K(KK) { if (cg == 8) { TC_TILE(KK, 8) } else if (cg == 4) { TC_TILE(KK, 4) } else { TC_TILE(KK, 2) } }
+    if (k == 3) TC_TILE_K(3) else if (k == 5) TC_TILE_K(5) else TC_TILE_K(7)
+#undef TC_TILE_K
+#undef TC_TILE
+    return tc_launch_status();
+}
+
+template <typename T>
+int launch_tile_bwd(const void* dy, int lddy, const void* w, void* dx, int lddx, const void* x, int ldx, float* dw, float* db, int B, int H, int W,
+                    int C, int k, int add_input, int accumulate, int groups, long long wstride, hipStream_t s, void* ws, long long ws_bytes) {
+    constexpr int VEC = Vec16<T>::N;
+    const int cg = dw_pick_cg<T>(C);
+    const int chunks = (C + cg * VEC - 1) / (cg * VEC);
+    const int TH = (256 / cg) / 4, tilesW = (W + 15) / 16, tilesH = (H + TH - 1) / TH;
+    const long long ntiles = (long long)B * tilesW * tilesH;
+    if (ntiles > 0x3fffffffLL) return TC_ERR_ARG;
+#define TC_TILE(KK, CGG) {                                                                                                              \
+        int gx = tc_dw_wg_target() / (chunks * groups);                                                                                 \
+        if (gx > ntiles) gx = (int)ntiles;                                                                                              \
+        gx = gx < 1 ? 1 : gx;                                                                                                           \
+        constexpr int NTC = ((KK) * (KK) + 1) * (CGG) * VEC;                                                                            \
+        float* wp = nullptr; int* wc = nullptr;                                                                                         \
+        if (ws && (uintptr_t)ws % 16 == 0 && ws_bytes >= 16384 + (long long)chunks * groups * gx * NTC * 4 &&                            \
+            (long long)chunks * groups * ((gx + DW_FOLD - 1) / DW_FOLD) <= 4096) {                                                      \
+            wc = reinterpret_cast<int*>(ws); wp = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + 16384);                         \
+        }                                                                                                                               \
+        dim3 grid((unsigned)(gx + ntiles), chunks, groups);                                                                             \
+        hipLaunchKernelGGL((dw_tile_bwd_kernel<T, KK, CGG>), grid, dim3(256), 0, s, (const T*)dy, lddy, (const T*)w, (T*)dx, lddx,       \
+                           (const T*)x, ldx, dw, db, B, H, W, C, add_input, accumulate, wstride, tilesW, tilesH, wp, wc, gx, (int)ntiles); }
+#define TC_TILE_K(KK) { if (cg == 8) TC_TILE(KK, 8) else if (cg == 4) TC_TILE(KK, 4) else TC_TILE(KK, 2) }
     if (k == 3) TC_TILE_K(3) else if (k == 5) TC_TILE_K(5) else TC_TILE_K(7)
 #undef TC_TILE_K
 #undef TC_TILE
@@ -1469,6 +1516,22 @@ extern "C" int tc_dwconv_bwd_input(const void* dy, int lddy, const void* w, void
     TC_DISPATCH_DTYPE(dtype, return (launch_dw<T, true>(dy, lddy, w, nullptr, dx, lddx, B, H, W, C, k, stride, add_input, accumulate,
                                                         (hipStream_t)stream)));
     return TC_ERR_ARG;
+}
+
+extern "C" int tc_dwconv_bwd_weight(const void* dy, int lddy, const void* x, int ldx, float* dw, float* db, int B, int H, int W, int C,
+                                    int k, int stride, int groups, long long wstride, void* ws, long long ws_bytes, int dtype, void* stream);
+/* see include/transception_hip.h */
+extern "C" int tc_dwconv_bwd(const void* dy, int lddy, const void* x, int ldx, const void* w, void* dx, int lddx, float* dw, float* db, int B, int H,
+                             int W, int C, int k, int add_input, int accumulate, int groups, long long wstride, void* ws, long long ws_bytes,
+                             int dtype, void* stream) {
+    if (!dy || !x || !w || !dx || !dw || (lddy & 3) || (lddx & 3) || groups < 1 || !dw_args_ok(B, H, W, C, k, 1, add_input)) return TC_ERR_ARG;
+    TC_DISPATCH_DTYPE(dtype, {
+        if (dw_tile_ok<T>(dy, lddy, dx, lddx, C) && dw_tile_ok<T>(x, ldx, dy, lddy, C))
+            return (launch_tile_bwd<T>(dy, lddy, w, dx, lddx, x, ldx, dw, db, B, H, W, C, k, add_input, accumulate, groups, wstride, (hipStream_t)stream,
+                                       ws, ws_bytes));
+    });
+    const int rc = tc_dwconv_bwd_input(dy, lddy, w, dx, lddx, B, H, W, C, k, 1, add_input, accumulate, groups, wstride, dtype, stream);
+    return rc != TC_OK ? rc : tc_dwconv_bwd_weight(dy, lddy, x, ldx, dw, db, B, H, W, C, k, 1, groups, wstride, ws, ws_bytes, dtype, stream);
 }
 
 extern "C" int tc_dwconv_bwd_weight(const void* dy, int lddy, const void* x, int ldx, float* dw, float* db, int B, int H,

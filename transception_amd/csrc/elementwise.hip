@@ -426,4 +426,4 @@ extern "C" int tc_cast(const void* src, void* dst, long long n, int src_dtype, i
     else return TC_ERR_ARG;
     return tc_launch_status();
 }
-extern "C" int tc_abi_version(void) { return 10; }
+extern "C" int tc_abi_version(void) { return 11; }

@@ -190,6 +190,7 @@ _EFFATT_FUSED = os.environ.get("TC_EFFATT_FUSED", "1") != "0"        # Efficient
 # measured a wash -- 13.12 vs 13.08 ms per step with it on: the tiled kernels are VALU-bound, so the +17 us (backward) / +2 us (forward)
 # the in-kernel LayerNorm costs per site cancel the two memory-bound launches it removes (negative results).
 _FFN_PRE_LN = os.environ.get("TC_FFN_PRE_LN", "0") != "0"
+_DW_BWD_ONE = os.environ.get("TC_DW_BWD_ONE", "1") != "0"          # input + weight gradient of a stride-1 depthwise conv in one launch
 _FFN_TILED_BWD = os.environ.get("TC_FFN_TILED_BWD", "1") != "0"   # MixFFN backward on the chip (csrc/mixffn_bwd.hip) where the library supports the width
 _FFN_TILE_BWD = (0, 0)                                         # forced pixel tile of the tiled backward's second launch (tests)
 _FFN_TILE = (0, 0)                                             # forced pixel tile of the tiled MixFFN kernels (tests); (0, 0): the library's choice
@@ -1086,6 +1087,14 @@ class Graph:
         def bwd():
             dy = self.grad_of(out)
             if dy is None:
+                return
+            if x.requires_grad and w.grad is not None and stride == 1 and _DW_BWD_ONE and not (self.overlap_wgrad and self.use_streams):
+                gx, acc = self.wgrad(x)                       # both gradients in one launch (they share dy and nothing else)
+                ws = _workspace(self.dev, self.stream)
+                _timed("hbm:dwconv_bwd (input + weight gradient, one launch)", (2.0 * x.rows * (1 + acc) + 2.0 * out.rows) * Cc * es,
+                       lambda: self.L.tc_dwconv_bwd(_ptr(dy), dy.stride(0), _ptr(x.data), x.ld, _ptr(w.data), _ptr(gx), gx.stride(0), _ptr(w.grad),
+                                                    _ptr(b.grad) if b is not None else None, B, H, W, Cc, k, int(add_input), acc, Gn, w.gs,
+                                                    ws.data_ptr(), ws.numel(), self.dt, self.stream))
                 return
             if x.requires_grad:
                 gx, acc = self.wgrad(x)
