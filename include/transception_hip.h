@@ -176,7 +176,8 @@ int tc_dwconv_bwd(const void* dy, int lddy, const void* x, int ldx, const void* 
 /* Up to four INDEPENDENT stride-1 depthwise convolutions in ONE launch: ConvRelPosEnc's 3x3 / 5x5 / 7x7 branches on column
  * slices of one map (MSTr.py:785-816), or the four per-scale MixFFN convolutions of a bridge layer (different maps).
  * mode 0: y = conv(x) (+bias) (+x); mode 1: y (= dx) = conv^T(x (= dy)) (+x) (+y when accumulate); mode 2: dw / db += gradients
- * from x and dy.  Every segment carries its own geometry and row strides; groups / wstride are common (see tc_dwconv_fwd);
+ * from x and dy; mode 3: both gradients in the one launch -- y (= dx) = conv^T(dy) (+dy) (+y when accumulate) and dw / db += gradients
+ * from x and dy (tc_dwconv_bwd per segment).  Every segment carries its own geometry and row strides; groups / wstride are common (see tc_dwconv_fwd);
  * ws as in tc_dwconv_bwd_weight. */
 typedef struct TcDwSeg {
     const void* x; const void* w; const void* bias; void* y; const void* dy; float* dw; float* db;

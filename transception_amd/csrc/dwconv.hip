@@ -944,6 +944,7 @@ int launch_dw(const void* x, int ldx, const void* w, const void* bias, void* y, 
 struct DwSegDev {
     const void* src; const void* w; const void* bias; void* y; const void* dy; float* dw; float* db; float* wsp; int* wsc; float* stat;
     int C, k, cg, chunks, tilesW, tilesH, gx, blk0, lds_, ldy, lddy, B, H, W;
+    int nt;           // mode 3: input-gradient tiles per chunk row, after the gx weight-gradient walkers
 };
 constexpr int DW_MULTI_MAX = 4;
 struct DwMultiDev { DwSegDev s[DW_MULTI_MAX]; int n, add_input, accumulate; long long wstride; };
@@ -991,6 +992,35 @@ __global__ __launch_bounds__(256) void dw_multi_wgrad_kernel(DwMultiDev a) {
 #undef TC_CASE
 }
 
+// mode 3: both gradients of every segment in one grid -- per segment the weight-gradient walkers (src = x, dy -> dw, db) first, then the
+// input-gradient tiles (dy, w -> y = dx)
+template <typename T>
+__global__ __launch_bounds__(256) void dw_multi_bwd_kernel(DwMultiDev a) {
+    extern __shared__ uint4 dsm[];
+    int lin = blockIdx.x, si = 0;
+    if (a.n > 1 && lin >= a.s[1].blk0) si = 1;
+    if (a.n > 2 && lin >= a.s[2].blk0) si = 2;
+    if (a.n > 3 && lin >= a.s[3].blk0) si = 3;
+    const DwSegDev& g = a.s[si];
+    lin -= g.blk0;
+    const int nw = g.gx * g.chunks;
+    const bool wg = lin < nw;
+    if (!wg) lin -= nw;
+    const int per = wg ? g.gx : g.nt;
+    const int bx = wg ? lin % per : dw_xcd_tile(lin % per, per), by = lin / per;
+#define TC_CASE(KK, CGG)                                                                                                            \
+    if (g.k == KK && g.cg == CGG) {                                                                                                 \
+        if (wg) dw_tile_wgrad_body<T, KK, CGG>((const T*)g.src, g.lds_, (const T*)g.dy, g.lddy, g.dw, g.db, g.B, g.H, g.W, g.C, a.wstride, \
+                                               g.tilesW, g.tilesH, g.wsp, g.wsc, bx, by, blockIdx.y, g.gx, g.chunks, dsm);          \
+        else dw_tile_body<T, KK, CGG, 1>((const T*)g.dy, g.lddy, (const T*)g.w, nullptr, (T*)g.y, g.ldy, g.B, g.H, g.W, g.C,        \
+                                         a.add_input, a.accumulate, a.wstride, g.tilesW, g.tilesH, bx, by, blockIdx.y, dsm, nullptr,   \
+                                         g.chunks);                                                                                 \
+        return;                                                                                                                     \
+    }
+    TC_DW_CASES(TC_CASE)
+#undef TC_CASE
+}
+
 template <typename T> int dw_smem_q(int k, int cg, bool wgrad) {
 #define TC_CASE(KK, CGG) if (k == KK && cg == CGG) return wgrad ? dw_wgrad_smem_q<T, KK, CGG>() : dw_tile_smem_q<T, KK, CGG>();
     TC_DW_CASES(TC_CASE)
@@ -1007,7 +1037,8 @@ int launch_multi(const TcDwSeg* segs, int nseg, int mode, int add_input, int acc
     a.wstride = wstride;
     long long blk = 0, part_floats = 0, cnts = 0;
     int smem_q = 0;
-    const bool have_ws = mode == 2 && ws && (uintptr_t)ws % 16 == 0 && ws_bytes > 16384;
+    const bool wgm = mode >= 2;                                  // weight-gradient walkers in the grid (mode 3: followed by the input-gradient tiles)
+    const bool have_ws = wgm && ws && (uintptr_t)ws % 16 == 0 && ws_bytes > 16384;
     long long total_work = 0;
     for (int i = 0; i < nseg; ++i) {
         const int cg = dw_pick_cg<T>(segs[i].C), TH = (256 / cg) / 4;
@@ -1027,7 +1058,8 @@ int launch_multi(const TcDwSeg* segs, int nseg, int mode, int add_input, int acc
         const int TH = (256 / d.cg) / 4;
         d.tilesW = (W + 15) / 16; d.tilesH = (H + TH - 1) / TH;
         const long long ntiles = (long long)B * d.tilesW * d.tilesH;
-        if (mode == 2) {
+        d.nt = (int)ntiles;
+        if (wgm) {
             // ~256 workgroups in total, shared out in proportion to each segment's tiles x chunks (an even split gave the 56x56
             // map of a bridge layer 16 workgroups of 28 tiles each next to 1-tile workgroups of the 7x7 map)
             long long gx = (long long)((double)tc_dw_wg_target() * (double)ntiles * (g.k + 2) / (double)(total_work > 0 ? total_work : 1) / groups + 0.5);
@@ -1042,12 +1074,13 @@ int launch_multi(const TcDwSeg* segs, int nseg, int mode, int add_input, int acc
             d.gx = (int)ntiles; d.wsc = nullptr; d.wsp = nullptr;
         }
         d.blk0 = (int)blk;
-        blk += (long long)d.gx * d.chunks;
-        const int q = dw_smem_q<T>(g.k, d.cg, mode == 2);
+        blk += ((long long)d.gx + (mode == 3 ? ntiles : 0)) * d.chunks;
+        const int q = dw_smem_q<T>(g.k, d.cg, wgm), q2 = mode == 3 ? dw_smem_q<T>(g.k, d.cg, false) : 0;
         smem_q = q > smem_q ? q : smem_q;
+        smem_q = q2 > smem_q ? q2 : smem_q;
     }
     if (blk > 0x7fffffffLL) return TC_ERR_ARG;
-    if (mode == 2 && have_ws && (cnts > 4096 || 16384 + part_floats * 4 > ws_bytes))
+    if (wgm && have_ws && (cnts > 4096 || 16384 + part_floats * 4 > ws_bytes))
         for (int i = 0; i < nseg; ++i) { a.s[i].wsc = nullptr; a.s[i].wsp = nullptr; }
     const size_t smem = (size_t)smem_q * 16;
     dim3 grid((unsigned)blk, groups);
@@ -1057,9 +1090,12 @@ int launch_multi(const TcDwSeg* segs, int nseg, int mode, int add_input, int acc
     } else if (mode == 1) {
         if (smem > 64 * 1024) hipFuncSetAttribute((const void*)dw_multi_kernel<T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipLaunchKernelGGL((dw_multi_kernel<T, 1>), grid, dim3(256), smem, s, a);
-    } else {
+    } else if (mode == 2) {
         if (smem > 64 * 1024) hipFuncSetAttribute((const void*)dw_multi_wgrad_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipLaunchKernelGGL((dw_multi_wgrad_kernel<T>), grid, dim3(256), smem, s, a);
+    } else {
+        if (smem > 64 * 1024) hipFuncSetAttribute((const void*)dw_multi_bwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL((dw_multi_bwd_kernel<T>), grid, dim3(256), smem, s, a);
     }
     return tc_launch_status();
 }
@@ -1566,16 +1602,29 @@ extern "C" int tc_dwconv_bwd_weight(const void* dy, int lddy, const void* x, int
 
 extern "C" int tc_dwconv_multi(const TcDwSeg* segs, int nseg, int mode, int add_input, int accumulate, int groups, long long wstride,
                                void* ws, long long ws_bytes, int dtype, void* stream) {
-    if (!segs || nseg < 1 || nseg > DW_MULTI_MAX || mode < 0 || mode > 2 || groups < 1) return TC_ERR_ARG;
+    if (!segs || nseg < 1 || nseg > DW_MULTI_MAX || mode < 0 || mode > 3 || groups < 1) return TC_ERR_ARG;
     bool tile_ok = true;
     for (int i = 0; i < nseg; ++i) {
         const TcDwSeg& g = segs[i];
-        if (!g.x || !dw_args_ok(g.B, g.H, g.W, g.C, g.k, 1, add_input) || (mode != 2 && (!g.w || !g.y)) || (mode == 2 && (!g.dy || !g.dw)))
+        if (!g.x || !dw_args_ok(g.B, g.H, g.W, g.C, g.k, 1, add_input) || (mode != 2 && (!g.w || !g.y)) || (mode >= 2 && (!g.dy || !g.dw)))
             return TC_ERR_ARG;
-        const void* second = mode == 2 ? g.dy : g.y;
-        const int ld2 = mode == 2 ? g.lddy : g.ldy;
+        const void* second = mode >= 2 ? g.dy : g.y;
+        const int ld2 = mode >= 2 ? g.lddy : g.ldy;
         if (dtype == TC_F32) tile_ok = tile_ok && dw_tile_ok<float>(g.x, g.ldx, second, ld2, g.C);
         else tile_ok = tile_ok && dw_tile_ok<bf16_t>(g.x, g.ldx, second, ld2, g.C);           // (either 16-bit type)
+        if (mode == 3) {                                       // mode 3 also writes y = dx from dy
+            if (dtype == TC_F32) tile_ok = tile_ok && dw_tile_ok<float>(g.dy, g.lddy, g.y, g.ldy, g.C);
+            else tile_ok = tile_ok && dw_tile_ok<bf16_t>(g.dy, g.lddy, g.y, g.ldy, g.C);
+        }
+    }
+    if (mode == 3 && !tile_ok) {                               // both gradients, one segment at a time through the single entry
+        for (int i = 0; i < nseg; ++i) {
+            const TcDwSeg& g = segs[i];
+            const int rc = tc_dwconv_bwd(g.dy, g.lddy, g.x, g.ldx, g.w, g.y, g.ldy, g.dw, g.db, g.B, g.H, g.W, g.C, g.k, add_input, accumulate, groups,
+                                         wstride, ws, ws_bytes, dtype, stream);
+            if (rc != TC_OK) return rc;
+        }
+        return TC_OK;
     }
     if (tile_ok) TC_DISPATCH_DTYPE(dtype, return (launch_multi<T>(segs, nseg, mode, add_input, accumulate, groups, wstride, ws, ws_bytes,
                                                                   (hipStream_t)stream)));

@@ -1139,6 +1139,16 @@ class Graph:
                 assert all(d is None for d in dys)
                 return
             ldd = [d.stride(0) for d in dys]
+            if xs[0].requires_grad and ws[0].grad is not None and _DW_BWD_ONE and not (self.overlap_wgrad and self.use_streams):
+                g = [self.wgrad(x) for x in xs]                   # input and weight gradients of all segments in one launch
+                acc = g[0][1]
+                assert all(a == acc for _, a in g)
+                wk = _workspace(self.dev, self.stream)
+                self.L.tc_dwconv_multi(segs([_ptr(x.data) for x in xs], wd, none, [_ptr(t) for t, _ in g], [_ptr(d) for d in dys],
+                                            [_ptr(w.grad) for w in ws], [_ptr(b.grad) if b is not None else None for b in bs],
+                                            [x.ld for x in xs], [t.stride(0) for t, _ in g], ldd), n, 3, int(add_input), acc, Gn, gs,
+                                       wk.data_ptr(), wk.numel(), self.dt, self.stream)
+                return
             if xs[0].requires_grad:
                 g = [self.wgrad(x) for x in xs]
                 acc = g[0][1]
