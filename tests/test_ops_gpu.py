@@ -592,6 +592,15 @@ def test_factor_att_core_fused(G, Bt, N, heads, Ch):
     close(G.grad_of(cvv), cr.grad, 2e-6, 2e-5, "dconvv")
 
 
+def test_dwconv_backward_as_two_launches(G, monkeypatch):
+    """The default backward of a stride-1 depthwise convolution is ONE launch for both gradients (tc_dwconv_bwd, tc_dwconv_multi mode 3);
+    the two-launch form stays for the side-stream mode: same checks against torch with the merge switched off."""
+    import transception_amd.engine as E
+    monkeypatch.setattr(E, "_DW_BWD_ONE", False)
+    test_dwconv(G, 64, 14, 3, 1, True, True)
+    test_dwconv_multi_matches_torch(G, 16, 14)
+
+
 @pytest.mark.parametrize("Ch,side", [(8, 28), (16, 14), (40, 7)])
 def test_dwconv_multi_matches_torch(G, Ch, side):
     """tc_dwconv_multi: the three ConvRelPosEnc window sizes (3/5/7 on 2/3/3 heads' channels, MSTr.py:785-816) on column slices
