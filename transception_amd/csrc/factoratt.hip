@@ -172,10 +172,18 @@ __global__ __launch_bounds__(256) void factor_att_fwd_kernel(const T* __restrict
 #pragma unroll
         for (int u = 0; u < VEC; ++u) acc[u] = 0.f;
         const T* qr = qs + n * Ch;
-        for (int c = 0; c < Ch; ++c) {
-            const float qc = fa_get(qr, c);
+        for (int c8 = 0; c8 < Ch; c8 += 8) {                    // the row's q values eight at a time (one or two 16-byte LDS reads instead of eight scalar ones)
+            float q8[8];
+            fa_get8(qr + c8, q8);
 #pragma unroll
-            for (int u = 0; u < VEC; ++u) acc[u] += qc * ctx[c * Ch + j0 + u];
+            for (int cc = 0; cc < 8; ++cc) {
+                const float* cr = ctx + (c8 + cc) * Ch + j0;
+                float cx[VEC];
+#pragma unroll
+                for (int u = 0; u < VEC; u += 4) *reinterpret_cast<float4*>(cx + u) = *reinterpret_cast<const float4*>(cr + u);
+#pragma unroll
+                for (int u = 0; u < VEC; ++u) acc[u] += q8[cc] * cx[u];
+            }
         }
 #pragma unroll
         for (int u = 0; u < VEC; ++u) acc[u] = scale * acc[u] + fa_get(qr, j0 + u) * cv[u];
@@ -212,7 +220,13 @@ __global__ __launch_bounds__(256) void factor_att_bwd_kernel(const T* __restrict
     fa_load_tile_raw<T>(qs, q + row0 * ld + col0, ld, N, Ch);
     fa_load_tile_raw<T>(gs, go + row0 * ldgo + col0, ldgo, N, Ch);
     __syncthreads();
-    for (int i = tid; i < N * Ch; i += 256) { const int c = i % Ch; e[i] = __expf(e[i] - cmax[c]) * cinv[c]; }
+    if (256 % Ch == 0) {                                        // (Ch = 8, 16, 32, 64: a thread stays in its column -- no division per element)
+        const int c = tid % Ch;
+        const float mc = cmax[c], ic = cinv[c];
+        for (int i = tid; i < N * Ch; i += 256) e[i] = __expf(e[i] - mc) * ic;
+    } else {
+        for (int i = tid; i < N * Ch; i += 256) { const int c = i % Ch; e[i] = __expf(e[i] - cmax[c]) * cinv[c]; }
+    }
     __syncthreads();
     fa_gram(ctx, e, vs, N, Ch);
     fa_gram(dctx, qs, gs, N, Ch);
@@ -231,20 +245,25 @@ __global__ __launch_bounds__(256) void factor_att_bwd_kernel(const T* __restrict
         float a_q[VEC], a_ks[VEC], a_v[VEC], cv[VEC], oc[VEC];
 #pragma unroll
         for (int u = 0; u < VEC; ++u) a_q[u] = a_ks[u] = a_v[u] = 0.f;
-        for (int j = 0; j < Ch; ++j) {
-            const float gj = fa_get(gr, j), vj = fa_get(vr, j), ej = er[j];
-            float cq[VEC], ck[VEC], cw[VEC];                  // 16-byte LDS reads (the first version read 3 x VEC scalars per j, two of them strided)
+        for (int j8 = 0; j8 < Ch; j8 += 8) {                    // the row's do / v / ksm values eight at a time (16-byte LDS reads; Ch % 8 == 0)
+            float g8[8], v8[8], e8[8];
+            fa_get8(gr + j8, g8); fa_get8(vr + j8, v8); fa_get8(er + j8, e8);
 #pragma unroll
-            for (int u = 0; u < VEC; u += 4) {
-                *reinterpret_cast<float4*>(cq + u) = *reinterpret_cast<const float4*>(ctxT + j * Ch + c0 + u);
-                *reinterpret_cast<float4*>(ck + u) = *reinterpret_cast<const float4*>(dctxT + j * Ch + c0 + u);
-                *reinterpret_cast<float4*>(cw + u) = *reinterpret_cast<const float4*>(dctx + j * Ch + c0 + u);
-            }
+            for (int jj = 0; jj < 8; ++jj) {
+                const int j = j8 + jj;
+                float cq[VEC], ck[VEC], cw[VEC];              // 16-byte LDS reads (the first version read 3 x VEC scalars per j, two of them strided)
 #pragma unroll
-            for (int u = 0; u < VEC; ++u) {
-                a_q[u] += gj * cq[u];                         // dq[n,c]  += scale * sum_j do[n,j] ctx[c,j]
-                a_ks[u] += vj * ck[u];                        // dksm[n,c] = sum_j v[n,j] dctx[c,j]
-                a_v[u] += ej * cw[u];                         // dv[n,c]   = sum_i ksm[n,i] dctx[i,c]
+                for (int u = 0; u < VEC; u += 4) {
+                    *reinterpret_cast<float4*>(cq + u) = *reinterpret_cast<const float4*>(ctxT + j * Ch + c0 + u);
+                    *reinterpret_cast<float4*>(ck + u) = *reinterpret_cast<const float4*>(dctxT + j * Ch + c0 + u);
+                    *reinterpret_cast<float4*>(cw + u) = *reinterpret_cast<const float4*>(dctx + j * Ch + c0 + u);
+                }
+#pragma unroll
+                for (int u = 0; u < VEC; ++u) {
+                    a_q[u] += g8[jj] * cq[u];                 // dq[n,c]  += scale * sum_j do[n,j] ctx[c,j]
+                    a_ks[u] += v8[jj] * ck[u];                // dksm[n,c] = sum_j v[n,j] dctx[c,j]
+                    a_v[u] += e8[jj] * cw[u];                 // dv[n,c]   = sum_i ksm[n,i] dctx[i,c]
+                }
             }
         }
         unpack16<T>(*reinterpret_cast<const uint4*>(convv + r * ldc + col0 + c0), cv);
