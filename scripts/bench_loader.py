@@ -25,15 +25,18 @@ for name, augs in (("no augmentation", None), ("sampled augmentation", [sampler.
                    ("worst case (warp+piecewise+blur+noise on every slice)",
                     [D.SliceAugmentation(m=D.affine_rotate_xy(20, 512, 512), disp=np.ones((4, 4, 2), np.float32), blur=True, alpha=1.1,
                                          noise_sigma=1.0, noise_seed=i) for i in range(B)])):
-    rec = torch.from_numpy(D.pack_records(augs)).to(dev) if augs is not None else None
+    rec, nr = None, None
+    if augs is not None:                                         # chains of imgaug stages: one record array per round
+        packed, nr = D.pack_rounds(augs)
+        rec = torch.from_numpy(packed).to(dev)
     scratch = {}
     for _ in range(3):
-        D.preprocess_batch(img, lab, None, 224, records=rec, scratch=scratch)
+        D.preprocess_batch(img, lab, None, 224, records=rec, scratch=scratch, rounds=nr)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(20):
-        D.preprocess_batch(img, lab, None, 224, records=rec, scratch=scratch)
+        D.preprocess_batch(img, lab, None, 224, records=rec, scratch=scratch, rounds=nr)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 20
     print(f"device preprocess, B={B}, 512->224, {name}: {ms:.3f} ms/batch = {B / ms * 1e3:.0f} slices/s")
