@@ -222,6 +222,124 @@ __global__ __launch_bounds__(FW_NT, 1) void attn_fwd_seg_kernel(const bf16_t* __
     }
 }
 
+// Forward, hand-scheduled (the default for 16-bit storage; the kernel above stays as the generic fallback and the A/B baseline).
+// ONE wave per SIMD: a workgroup is 4 waves, each wave owns THREE 32-query tiles (12 tiles per workgroup as above), and the whole
+// key loop is one instruction stream emitted by gen_attn_asm.py (attn_fwd_asm.inc) -- per 32-key sub-tile, three groups of eight
+// MFMAs (QK^T of one tile alternating with PV of another) each carrying the exp / row-sum / pack arithmetic of the third tile and
+// the LDS fragment reads in program order, because on gfx950 VALU work hides only under MFMAs issued by the SAME wave.  Scores are
+// produced directly as s * scale * log2(e) - m: Q is scaled when it is staged and -m is the C operand of the first QK^T MFMA, so
+// the softmax is exp2 + add + pack per score.  K / V sub-tiles of 32 keys go through a 4-slot LDS ring (buffer loads three
+// sub-tiles ahead, one barrier per sub-tile).  This function stages Q and the first three sub-tiles, hands the addresses to the
+// stream and stores the O tiles / lse the stream leaves in the wave's LDS tiles.
+#include "attn_fwd_asm.inc"
+typedef int tc_i32x4 __attribute__((ext_vector_type(4)));
+constexpr int AS_TPW = 3, AS_NW = 4, AS_TPB = AS_TPW * AS_NW;
+constexpr int AS_SLOT = 16384, AS_VOFF = 32 * LDR * 2, AS_WT = 32 * LDR * 2, AS_WT0 = 4 * AS_SLOT, AS_LSE0 = AS_WT0 + AS_NW * AS_TPW * AS_WT;
+#ifdef TC_ATTN_ASM_TIMING
+constexpr size_t AS_SMEM = AS_LSE0 + AS_NW * AS_TPW * 32 * sizeof(float) + 8192;
+__device__ unsigned long long g_attn_dbg[1024 * 16];
+#else
+constexpr size_t AS_SMEM = AS_LSE0 + AS_NW * AS_TPW * 32 * sizeof(float);
+#endif
+template <typename H>
+__global__ __launch_bounds__(AS_NW * 64, 1) void attn_fwd_asm_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
+                                                                     const bf16_t* __restrict__ V, int ldv, long long skv, bf16_t* __restrict__ O,
+                                                                     int ldo, float* __restrict__ lse, Segs sg, int Nk, float scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char as_smem[];
+#ifdef TC_ATTN_ASM_TIMING
+    const unsigned long long dbg_t0 = __builtin_readcyclecounter();
+#endif
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    const int nwt = sg.t32[sg.n], bpi = (nwt + AS_TPB - 1) / AS_TPB;
+    const int bx = xcd_block(blockIdx.x, gridDim.x);
+    const int b = bx / bpi, wt0 = (bx - b * bpi) * AS_TPB + wave * AS_TPW;
+    const bf16_t* Kb = K + b * skv;
+    const bf16_t* Vb = V + b * skv;
+    unsigned char* wtile = as_smem + AS_WT0 + wave * (AS_TPW * AS_WT);
+    const float qs = scale * LOG2E;
+    int nq_t[AS_TPW], tq0_t[AS_TPW];
+    long long trow0_t[AS_TPW];
+    bool live_t[AS_TPW];
+#pragma unroll
+    for (int t = 0; t < AS_TPW; ++t) {
+        const int wt = wt0 + t;
+        int sgi = 0;
+#pragma unroll
+        for (int i = 1; i < 4; ++i) if (i < sg.n && wt >= sg.t32[i]) sgi = i;
+        nq_t[t] = sg.nq[sgi];
+        tq0_t[t] = (wt - sg.t32[sgi]) * 32;
+        live_t[t] = wt < nwt;
+        trow0_t[t] = (long long)sg.row0[sgi] + (long long)b * nq_t[t] + tq0_t[t];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                           // Q rows, scaled by scale * log2(e), whole 128-byte rows in
+            const int r = 8 * i + (lane >> 3);
+            uint4 v = (live_t[t] && tq0_t[t] + r < nq_t[t]) ? *reinterpret_cast<const uint4*>(Q + (trow0_t[t] + r) * ldq + 8 * (lane & 7)) : make_uint4(0u, 0u, 0u, 0u);
+            unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float lo, hi;
+                unpack2<H>(w[e], lo, hi);
+                w[e] = pack2<H>(lo * qs, hi * qs);
+            }
+            *reinterpret_cast<uint4*>(wtile + t * AS_WT + r * (LDR * 2) + 16 * (lane & 7)) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+    const int sr = tid >> 3, sc = tid & 7;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {                               // sub-tiles 0..2 into ring slots 0..2 (rows past Nk: a duplicate, masked later)
+        const int row = min(32 * s + sr, Nk - 1);
+        const uint4 kk = *reinterpret_cast<const uint4*>(Kb + (long long)row * ldk + 8 * sc);
+        const uint4 vv = *reinterpret_cast<const uint4*>(Vb + (long long)row * ldv + 8 * sc);
+        *reinterpret_cast<uint4*>(as_smem + s * AS_SLOT + sr * (LDR * 2) + 16 * sc) = kk;
+        *reinterpret_cast<uint4*>(as_smem + s * AS_SLOT + AS_VOFF + key_row(sr) * (LDR * 2) + 16 * sc) = vv;
+    }
+    __syncthreads();
+    {
+        const unsigned lds0 = (unsigned)(uintptr_t)as_smem;     // LDS offset = low half of the flat address
+        const int gi = lane & 15, gq = (lane >> 4) & 1, nsub = (Nk + 31) / 32, nv = Nk - 32 * (nsub - 1);
+        const unsigned kaddr = lds0 + pi_row(j) * (LDR * 2) + 16 * h;
+        const unsigned vaddr = lds0 + AS_VOFF + (16 * h + 4 * (gi >> 2)) * (LDR * 2) + 32 * gq + 8 * (gi & 3);
+        const unsigned wk = lds0 + sr * (LDR * 2) + 16 * sc, wv = lds0 + AS_VOFF + key_row(sr) * (LDR * 2) + 16 * sc;
+        const unsigned gk = (unsigned)(((96 + sr) * ldk + 8 * sc) * 2), gv = (unsigned)(((96 + sr) * ldv + 8 * sc) * 2);
+        const unsigned wbase = lds0 + AS_WT0 + wave * (AS_TPW * AS_WT);
+        const unsigned qaddr = wbase + j * (LDR * 2) + 16 * h, oaddr = wbase + j * (LDR * 2) + 8 * h;
+        const unsigned lseaddr = lds0 + AS_LSE0 + (wave * AS_TPW * 32 + j) * 4;
+        unsigned mask = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mask |= (16 * h + r >= nv) ? (1u << r) : 0u;
+        const unsigned long long pk = (unsigned long long)(uintptr_t)Kb, pv = (unsigned long long)(uintptr_t)Vb;
+        const tc_i32x4 rk = {(int)(unsigned)pk, (int)(unsigned)(pk >> 32), (int)(((Nk - 1) * ldk + D) * 2), 0x00020000};
+        const tc_i32x4 rv = {(int)(unsigned)pv, (int)(unsigned)(pv >> 32), (int)(((Nk - 1) * ldv + D) * 2), 0x00020000};
+        const int stepk = 32 * ldk * 2, stepv = 32 * ldv * 2;
+        if (std::is_same<H, f16_t>::value)
+            asm volatile(TC_ATTN_FWD_ASM_F16 : : "v"(kaddr), "v"(vaddr), "v"(wk), "v"(wv), "v"(gk), "v"(gv), "v"(qaddr), "v"(oaddr), "v"(lseaddr), "v"(mask),
+                         "s"(rk), "s"(rv), "s"(nsub), "s"(stepk), "s"(stepv) : TC_ATTN_FWD_ASM_CLOBBERS);
+        else
+            asm volatile(TC_ATTN_FWD_ASM_BF16 : : "v"(kaddr), "v"(vaddr), "v"(wk), "v"(wv), "v"(gk), "v"(gv), "v"(qaddr), "v"(oaddr), "v"(lseaddr), "v"(mask),
+                         "s"(rk), "s"(rv), "s"(nsub), "s"(stepk), "s"(stepv) : TC_ATTN_FWD_ASM_CLOBBERS);
+    }
+    const float* lsel = reinterpret_cast<const float*>(as_smem + AS_LSE0) + wave * (AS_TPW * 32);
+#pragma unroll
+    for (int t = 0; t < AS_TPW; ++t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 8 * i + (lane >> 3);
+            const uint4 v = *reinterpret_cast<const uint4*>(wtile + t * AS_WT + r * (LDR * 2) + 16 * (lane & 7));
+            if (live_t[t] && tq0_t[t] + r < nq_t[t]) *reinterpret_cast<uint4*>(O + (trow0_t[t] + r) * ldo + 8 * (lane & 7)) = v;
+        }
+        if (h == 0 && live_t[t] && tq0_t[t] + j < nq_t[t]) lse[trow0_t[t] + j] = lsel[t * 32 + j];
+    }
+#ifdef TC_ATTN_ASM_TIMING
+    if (lane == 0 && blockIdx.x < 256) {
+        unsigned long long* dst = g_attn_dbg + (blockIdx.x * 4 + wave) * 16;
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(as_smem + AS_LSE0 + wave * (AS_TPW * 32 * 4) + 4096);
+        dst[0] = dbg_t0;
+        for (int k = 0; k < TC_ATTN_ASM_TIMING; ++k) dst[1 + k] = src[k];
+        dst[1 + TC_ATTN_ASM_TIMING] = __builtin_readcyclecounter();
+    }
+#endif
+}
+
 // dQ.  Same organisation as the forward kernel: one 12-wave workgroup per CU, a 32-query tile per wave, K/V tiles double-buffered in
 // LDS behind one barrier per tile, Q / dO / dQ tiles through the wave's LDS tile as whole 128-byte rows.
 // K is stored ONCE, rows in key_row order: conflict-free both for the 16-byte fragment reads of S^T = K Q^T (row
@@ -636,6 +754,24 @@ extern "C" int tc_attn_fwd_seg(const void* Q, int ldq, const void* K, int ldk, c
         return TC_ERR_ARG;
     const dim3 grid((unsigned)B * ((sg.t32[nseg] + FW_NW - 1) / FW_NW));
     const int wide_o = !(ldo & 7) && !((uintptr_t)O & 15);
+    static const bool use_asm = !(getenv("TC_ATTN_FWD_ASM") && atoi(getenv("TC_ATTN_FWD_ASM")) == 0);
+    if (use_asm && wide_o && Nk >= 64 && (long long)Nk * (ldk > ldv ? ldk : ldv) * 2 < (1ll << 31)) {   // the hand-scheduled stream (needs >= 2 key sub-tiles)
+        static bool as_ok[2] = {false, false};
+#define TC_FWD_ASM(HH, IDX)                                                                                                                  \
+    {                                                                                                                                       \
+        if (!as_ok[IDX]) {                                                                                                                  \
+            if (hipFuncSetAttribute((const void*)attn_fwd_asm_kernel<HH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AS_SMEM) != hipSuccess) \
+                return TC_ERR_LAUNCH;                                                                                                       \
+            as_ok[IDX] = true;                                                                                                              \
+        }                                                                                                                                   \
+        hipLaunchKernelGGL(attn_fwd_asm_kernel<HH>, dim3((unsigned)B * ((sg.t32[nseg] + AS_TPB - 1) / AS_TPB)), dim3(AS_NW * 64), AS_SMEM,    \
+                           (hipStream_t)stream, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk, (const bf16_t*)V, ldv, skv, (bf16_t*)O, ldo,  \
+                           lse, sg, Nk, scale);                                                                                             \
+    }
+        if (dtype == TC_BF16) TC_FWD_ASM(bf16_t, 0) else TC_FWD_ASM(f16_t, 1)
+#undef TC_FWD_ASM
+        return tc_launch_status();
+    }
     static bool lds_ok[2] = {false, false};                     // the kernels use 127 KB of dynamic LDS: raise the per-function limit once
 #define TC_FWD(HH, IDX)                                                                                                                      \
     {                                                                                                                                       \
@@ -652,6 +788,9 @@ extern "C" int tc_attn_fwd_seg(const void* Q, int ldq, const void* K, int ldk, c
     return tc_launch_status();
 }
 
+#ifdef TC_ATTN_ASM_TIMING
+extern "C" int tc_attn_dbg_read(unsigned long long* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_attn_dbg), sizeof(unsigned long long) * 1024 * 16); }
+#endif
 #ifdef TC_DKV_TIMING
 extern "C" int tc_dkv_dbg_read(unsigned long long* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_dkv_dbg), sizeof(unsigned long long) * 512 * 4); }
 #endif
