@@ -526,7 +526,7 @@ def side_figures(args, dev, model, loss_fn, opt, step, x, y, build_model, engine
 
         def attn():
             L.tc_attn_fwd_seg(q.data_ptr(), 64, kv.data_ptr(), 128, kv[:, 64:].data_ptr(), 128, Nk * 128, o.data_ptr(), 64, lse.data_ptr(),
-                              Bq, 4, nqc, Nk, 0.125, tcd, torch.cuda.current_stream(dev).cuda_stream)
+                              Bq, 4, nqc, Nk, 0.125, 1, tcd, torch.cuda.current_stream(dev).cuda_stream)   # qscaled = 1: as the model calls it
         us = _graph_replay_us(attn, 30, dev)
         fl = 4.0 * rows * Nk * 64
         ins = roofs.get("roofline_in_step_events", {})

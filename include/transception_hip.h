@@ -29,7 +29,8 @@ extern "C" {
 
 enum { TC_OK = 0, TC_ERR_ARG = -1, TC_ERR_LAUNCH = -2, TC_ERR_UNSUPPORTED = -3 };
 enum { TC_F32 = 0, TC_BF16 = 1, TC_F16 = 2 };
-enum { TC_ACT_NONE = 0, TC_ACT_HSWISH = 1, TC_ACT_COORD = 2, TC_ACT_SIGMOID = 3, TC_ACT_GELU = 4 };
+enum { TC_ACT_NONE = 0, TC_ACT_HSWISH = 1, TC_ACT_COORD = 2, TC_ACT_SIGMOID = 3, TC_ACT_GELU = 4,
+       TC_ACT_SCALE = 5 /* tc_gemm only: C = alpha * (op(A) op(B) + bias + R), i.e. alpha applied AFTER bias and residual */ };
 
 /* library identity: returns the ABI version (bumped on any signature change) */
 int tc_abi_version(void);
@@ -57,7 +58,7 @@ typedef struct TcGemm {
     long long sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2;
     float alpha;
     int accumulate;              /* C += result */
-    int act;                     /* TC_ACT_NONE or TC_ACT_SIGMOID */
+    int act;                     /* TC_ACT_NONE, TC_ACT_SIGMOID or TC_ACT_SCALE */
     int splitk;                  /* >=1 */
     int dtype;
     int c_f32;                   /* C (and the accumulate read) is fp32 whatever dtype is: weight gradients */
@@ -345,16 +346,19 @@ int tc_attn_bwd(const void* Q, int ldq, long long sq, const void* K, int ldk, co
  * 16-bit path: head dimension 64; Q, K, V (and dO) 16-byte aligned with row strides that are multiples of 8 elements; O / dQ rows
  * are written with 16-byte stores when their pointer and stride allow it (8-byte stores otherwise).  The forward kernel's softmax
  * is referenced to an integer exponent per row that is raised only when a row sum outgrows it by 2^30 (2^14 for fp16) -- the
- * result is the ordinary softmax(QK^T scale)V, lse the ordinary log-sum-exp.  The kernels use 126 KB of dynamic LDS. */
+ * result is the ordinary softmax(QK^T scale)V, lse the ordinary log-sum-exp.  The kernels use 126 KB of dynamic LDS.
+ * qscaled (16-bit paths only): Q already holds q * scale * log2(e), rounded ONCE from the fp32 accumulator of the projection that
+ * produced it (tc_gemm with TC_ACT_SCALE): the scores then need no multiply per element, and no second rounding of Q.  The
+ * backward then takes the same scaled Q and still returns dQ = dL/dq of the UNSCALED projection output (and dK, dV as ever). */
 int tc_attn_fwd_seg(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, long long skv, void* O, int ldo,
-                    float* lse, int B, int nseg, const int* nq, int Nk, float scale, int dtype, void* stream);
+                    float* lse, int B, int nseg, const int* nq, int Nk, float scale, int qscaled, int dtype, void* stream);
 /* dkv32: fp32 scratch of TC_ATTN_DKV_SPLITS * B * Nk * 128 floats (16-bit path: every query chunk of the dK/dV kernel writes its own
  * partial dK|dV there, one conversion kernel adds them; needs no initialisation); may be NULL for fp32. */
 #define TC_ATTN_DKV_SPLITS 8
 int tc_attn_bwd_seg(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, long long skv, const void* O,
                     int ldo, const void* dO, int lddo, const float* lse, float* delta, float* dkv32, void* dQ, int lddq,
                     void* dK, int lddk, void* dV, int lddv, long long sdkv, int B, int nseg, const int* nq, int Nk,
-                    float scale, int dtype, void* stream);
+                    float scale, int qscaled, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Elementwise / layout kernels.

@@ -8,11 +8,16 @@ dev = torch.device("cuda:0")
 st = torch.cuda.current_stream().cuda_stream
 d = 64
 
+QSCALED = int(os.environ.get("QSCALED", "1"))   # 1: Q handed over as q * scale * log2(e), rounded once (what the model does)
+LOG2E = 1.4426950408889634
+
+
 def run(B, nq, Nk, dtype, scale=0.125, spike=False, seed=0, time_it=False):
     g = torch.Generator(device=dev).manual_seed(seed)
     rows = B * sum(nq)
     tdt = torch.bfloat16 if dtype == TC_BF16 else torch.float16
-    q = torch.randn(rows, d, device=dev, generator=g).to(tdt)
+    qf = torch.randn(rows, d, device=dev, generator=g)
+    q = (qf * (scale * LOG2E)).to(tdt) if QSCALED else qf.to(tdt)
     kv = torch.randn(B * Nk, 2 * d, device=dev, generator=g).to(tdt)
     if spike:                                     # late keys that outgrow the first sub-tile's reference exponent by far more than 2^30
         kvf = kv.float().view(B, Nk, 2 * d)
@@ -23,7 +28,7 @@ def run(B, nq, Nk, dtype, scale=0.125, spike=False, seed=0, time_it=False):
     o = torch.full((rows, d), float("nan"), device=dev).to(tdt)
     lse = torch.full((rows,), float("nan"), device=dev)
     nqc = (C.c_int * 4)(*(list(nq) + [0] * (4 - len(nq))))
-    def f(): return L.tc_attn_fwd_seg(q.data_ptr(), d, k.data_ptr(), 2 * d, v.data_ptr(), 2 * d, Nk * 2 * d, o.data_ptr(), d, lse.data_ptr(), B, len(nq), nqc, Nk, scale, dtype, st)
+    def f(): return L.tc_attn_fwd_seg(q.data_ptr(), d, k.data_ptr(), 2 * d, v.data_ptr(), 2 * d, Nk * 2 * d, o.data_ptr(), d, lse.data_ptr(), B, len(nq), nqc, Nk, scale, QSCALED, dtype, st)
     rc = f(); torch.cuda.synchronize()
     # reference (stage-major query rows: segment s holds B images of nq[s] rows)
     ref_o = torch.empty(rows, d, dtype=torch.float64, device=dev); ref_l = torch.empty(rows, dtype=torch.float64, device=dev)
@@ -31,7 +36,7 @@ def run(B, nq, Nk, dtype, scale=0.125, spike=False, seed=0, time_it=False):
     kd, vd = k.double().view(B, Nk, d), v.double().view(B, Nk, d)
     for n in nq:
         qq = q[off: off + B * n].double().view(B, n, d)
-        s = torch.einsum("bqd,bkd->bqk", qq, kd) * scale
+        s = torch.einsum("bqd,bkd->bqk", qq, kd) * (1.0 / LOG2E if QSCALED else scale)   # the reference starts from the STORED operands
         ref_l[off: off + B * n] = torch.logsumexp(s, -1).reshape(-1)
         ref_o[off: off + B * n] = torch.einsum("bqk,bkd->bqd", torch.softmax(s, -1), vd).reshape(-1, d)
         off += B * n
@@ -50,7 +55,7 @@ def run(B, nq, Nk, dtype, scale=0.125, spike=False, seed=0, time_it=False):
     print(msg, flush=True)
     return eo, el
 
-print("TC_ATTN_FWD_ASM =", os.environ.get("TC_ATTN_FWD_ASM", "(default 1)"))
+print("TC_ATTN_FWD_ASM =", os.environ.get("TC_ATTN_FWD_ASM", "(default 1)"), " QSCALED =", QSCALED)
 run(1, [64], 64, TC_BF16)
 run(1, [33], 100, TC_BF16)
 run(2, [100, 37], 64, TC_BF16)

@@ -15,9 +15,9 @@ lse = torch.empty(rows, device=dev); delta = torch.empty(rows, device=dev); dkv3
 nqc = (C.c_int * 4)(*nq)
 st = torch.cuda.current_stream().cuda_stream
 k, v = kv[:, :d], kv[:, d:]
-def fwd(): L.tc_attn_fwd_seg(q.data_ptr(), d, k.data_ptr(), 2 * d, v.data_ptr(), 2 * d, Nk * 2 * d, o.data_ptr(), d, lse.data_ptr(), B, 4, nqc, Nk, 0.125, dt, st)
+def fwd(): L.tc_attn_fwd_seg(q.data_ptr(), d, k.data_ptr(), 2 * d, v.data_ptr(), 2 * d, Nk * 2 * d, o.data_ptr(), d, lse.data_ptr(), B, 4, nqc, Nk, 0.125, 0, dt, st)
 def bwd(): L.tc_attn_bwd_seg(q.data_ptr(), d, k.data_ptr(), 2 * d, v.data_ptr(), 2 * d, Nk * 2 * d, o.data_ptr(), d, do.data_ptr(), d, lse.data_ptr(), delta.data_ptr(), dkv32.data_ptr(),
-                             dq.data_ptr(), d, dkv.data_ptr(), 2 * d, dkv[:, d:].data_ptr(), 2 * d, Nk * 2 * d, B, 4, nqc, Nk, 0.125, dt, st)
+                             dq.data_ptr(), d, dkv.data_ptr(), 2 * d, dkv[:, d:].data_ptr(), 2 * d, Nk * 2 * d, B, 4, nqc, Nk, 0.125, 0, dt, st)
 for name, fn, fl in (("fwd", fwd, 4.0 * rows * Nk * d), ("bwd", bwd, 10.0 * rows * Nk * d)):
     for _ in range(5): fn()
     torch.cuda.synchronize()

@@ -10,38 +10,44 @@ q = torch.randn(rows, d, device=dev).bfloat16(); kv = torch.randn(B * Nk, 2 * d,
 o = torch.empty_like(q); lse = torch.empty(rows, device=dev)
 nqc = (C.c_int * 4)(*nq); st = torch.cuda.current_stream().cuda_stream
 k, v = kv[:, :d], kv[:, d:]
-names = ["stage Q,K,V + barrier", "asm prologue (Q frags, zero acc, QK_0(0))", "first body", "loop (nsub-2 bodies)", "last body + drain", "epilogue (O -> LDS)", "stores"]
+names = ["stage Q,K,V + barrier", "asm prologue (Q frags, zero acc, QK(0))", "first iteration", "loop (nsub-2 iterations)", "last + drain", "epilogue (O -> LDS)", "stores"]
 for so in sorted(glob.glob(os.path.join(here, "libattn_timing_*.so"))):
   L = C.CDLL(so)
   f = L.tc_attn_fwd_seg
-  f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_longlong, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]
+  f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_longlong, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p]
   for _ in range(3):
-    f(q.data_ptr(), d, k.data_ptr(), 2 * d, v.data_ptr(), 2 * d, Nk * 2 * d, o.data_ptr(), d, lse.data_ptr(), B, 4, nqc, Nk, 0.125, 1, st)
+    f(q.data_ptr(), d, k.data_ptr(), 2 * d, v.data_ptr(), 2 * d, Nk * 2 * d, o.data_ptr(), d, lse.data_ptr(), B, 4, nqc, Nk, 0.125, 1, 1, st)
   torch.cuda.synchronize()
-  buf = np.zeros(1024 * 16, dtype=np.uint64)
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  e0.record()
+  for _ in range(20): f(q.data_ptr(), d, k.data_ptr(), 2 * d, v.data_ptr(), 2 * d, Nk * 2 * d, o.data_ptr(), d, lse.data_ptr(), B, 4, nqc, Nk, 0.125, 1, 1, st)
+  e1.record(); torch.cuda.synchronize()
+  us = e0.elapsed_time(e1) * 1e3 / 20
+  buf = np.zeros(256 * 12 * 8, dtype=np.uint64)
   L.tc_attn_dbg_read.argtypes = [C.c_void_p]
   L.tc_attn_dbg_read(buf.ctypes.data)
-  t = buf.reshape(1024, 16)[:, :8].astype(np.int64)
+  t = buf.reshape(256 * 12, 8).astype(np.int64)
   t[:, 1:7] &= 0xffffffff                      # (neighbouring lanes overlap the high word: the low words are the stamps)
   t[:, 0] &= 0xffffffff; t[:, 7] &= 0xffffffff
   dt = np.diff(t, axis=1) & 0xffffffff
-  print(os.path.basename(so))
+  print(os.path.basename(so), f"{us:.1f} us per launch (events, back to back)")
   for i, n in enumerate(names):
     print(f"  {n:45s} {np.median(dt[:, i]):9.0f} {dt[:, i].min():9d} {dt[:, i].max():9d}")
-  print(f"  per loop body: {np.median(dt[:, 3]) / 23:.0f} cycles = {np.median(dt[:, 3]) / 69:.0f} per group of 8 MFMAs")
+  tot = (t[:, 7] - t[:, 0]) & 0xffffffff
+  print(f"  per loop iteration (one 32-key sub-tile of one wave): {np.median(dt[:, 3]) / 23:.0f} cycles; whole wave {np.median(tot):.0f}")
 sys.exit(0)
 f = L.tc_attn_fwd_seg
-f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_longlong, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]
+f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_longlong, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p]
 k, v = kv[:, :d], kv[:, d:]
 for _ in range(3):
-    f(q.data_ptr(), d, k.data_ptr(), 2 * d, v.data_ptr(), 2 * d, Nk * 2 * d, o.data_ptr(), d, lse.data_ptr(), B, 4, nqc, Nk, 0.125, 1, st)
+    f(q.data_ptr(), d, k.data_ptr(), 2 * d, v.data_ptr(), 2 * d, Nk * 2 * d, o.data_ptr(), d, lse.data_ptr(), B, 4, nqc, Nk, 0.125, 1, 1, st)
 torch.cuda.synchronize()
-buf = np.zeros(1024 * 16, dtype=np.uint64)
+buf = np.zeros(256 * 12 * 8, dtype=np.uint64)
 L.tc_attn_dbg_read.argtypes = [C.c_void_p]
 L.tc_attn_dbg_read(buf.ctypes.data)
-t = buf.reshape(1024, 16)[:, :8].astype(np.int64)
+t = buf.reshape(256 * 12, 8).astype(np.int64)
 dt = np.diff(t, axis=1)
-names = ["stage Q,K,V + barrier", "asm prologue (Q frags, zero acc, QK_0(0))", "first body", "loop (nsub-2 bodies)", "last body + drain", "epilogue (O -> LDS)", "stores"]
+names = ["stage Q,K,V + barrier", "asm prologue (Q frags, zero acc, QK(0))", "first iteration", "loop (nsub-2 iterations)", "last + drain", "epilogue (O -> LDS)", "stores"]
 print("cycles per phase: median / min / max over 1024 waves (s_memtime ticks; 100 MHz?? see total)")
 for i, n in enumerate(names):
     print(f"  {n:45s} {np.median(dt[:, i]):9.0f} {dt[:, i].min():9d} {dt[:, i].max():9d}")

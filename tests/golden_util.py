@@ -35,3 +35,61 @@ def check_packed(store, tag: str, t: torch.Tensor, atol: float, rtol: float = 0.
     gsa = np.abs(a.astype(np.float64)).sum()
     assert abs(gsa - sa) <= sum_rtol * max(sa, 1e-12) + atol * a.size * 0.01, f"{tag}: |x| checksum {gsa} vs {sa}"
     return float(err.max())
+
+
+def check_all_grads(named, ref_grads, atol: float = 2e-6, rtol: float = 2e-3, what: str = ""):
+    """EVERY parameter gradient of the HIP model against a reference gradient (the CPU oracle's, evaluated in the calling test):
+    per tensor |got - ref|_inf <= atol + rtol |ref|_inf.  `named`: dict(model.named_parameters()); `ref_grads`: name -> tensor or
+    None.  A parameter without a HIP gradient must have none (or an all-zero one) in the reference.  Returns the number of live
+    tensors checked and the worst (error / bound, name); fails listing every tensor out of bound."""
+    bad, worst, n = [], (0.0, ""), 0
+    for key, p in named.items():
+        ref = ref_grads.get(key)
+        if p.grad is None:
+            if ref is not None and float(ref.abs().max()) != 0.0:
+                bad.append(f"{key}: no HIP gradient, reference max {float(ref.abs().max()):.3e}")
+            continue
+        if ref is None:
+            if float(p.grad.abs().max()) != 0.0:
+                bad.append(f"{key}: HIP gradient max {float(p.grad.abs().max()):.3e}, none in the reference")
+            continue
+        n += 1
+        got = p.grad.detach().float().cpu()
+        ref = ref.detach().float().cpu().reshape(got.shape)
+        err, bound = float((got - ref).abs().max()), atol + rtol * float(ref.abs().max())
+        if not (err <= bound):
+            bad.append(f"{key}: err {err:.3e} > {bound:.3e} (|ref|max {float(ref.abs().max()):.3e})")
+        if err / bound > worst[0]:
+            worst = (err / bound, key)
+    assert not bad, f"{what}{len(bad)} of {n} gradient tensors out of bound:\n  " + "\n  ".join(bad[:20])
+    return n, worst
+
+
+def check_all_grads_lowp(named_lp, named_ref, rel_l2: float, cos_min: float, what: str = "", zero_rel: float = 1e-6, zero_abs: float = 1e-5):
+    """16-bit storage path against the fp32 HIP path, EVERY gradient tensor: relative L2 error <= rel_l2 and cosine >= cos_min.
+    Tensors whose fp32 gradient is numerically zero (norm below zero_rel x the global gradient norm: biases in front of a softmax
+    over their own axis or of a BatchNorm, whose exact gradient is 0) are held to |diff| <= zero_abs x the global norm instead."""
+    gn = float(sum(float((q.grad.double() ** 2).sum()) for q in named_ref.values() if q.grad is not None) ** 0.5)
+    bad, worst, n, nz = [], (0.0, ""), 0, 0
+    for key, p in named_lp.items():
+        q = named_ref[key]
+        assert (p.grad is None) == (q.grad is None), key
+        if p.grad is None:
+            continue
+        n += 1
+        a, b = p.grad.detach().double().flatten(), q.grad.detach().double().flatten()
+        nb = float(b.norm())
+        d = float((a - b).norm())
+        if nb < zero_rel * gn:
+            nz += 1
+            if d > zero_abs * gn:
+                bad.append(f"{key}: |ref| {nb:.2e} (numerically zero), |diff| {d:.2e} > {zero_abs * gn:.2e}")
+            continue
+        rel = d / nb
+        cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-300))
+        if not (rel <= rel_l2 and cos >= cos_min):
+            bad.append(f"{key}: rel L2 {rel:.3e}, cosine {cos:.5f}")
+        if rel > worst[0]:
+            worst = (rel, key)
+    assert not bad, f"{what}{len(bad)} of {n} gradient tensors out of bound:\n  " + "\n  ".join(bad[:20])
+    return n, worst

@@ -16,7 +16,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from golden_util import check_packed, load  # noqa: E402
+from golden_util import check_all_grads, check_packed, load  # noqa: E402
 from transception_amd.seeded_init import seeded_input, seeded_labels, seeded_state_dict, seeded_tensor  # noqa: E402
 
 DEV = "cuda:0"
@@ -280,11 +280,10 @@ def test_whole_model_train_step_vs_reference_golden_and_oracle():
     assert (lo.detach() - lc).abs().max().item() < 1e-4
     ol, _, _ = ce_dice_loss(lo, lab, 9)
     ol.backward()
-    for key in ("bridge.bridge_layer2.attn.kv.weight", "backbone.mhca_stage3.mhca_blks.0.crpe.conv_list.1.weight",
-                "decoder_0.layer_up.expand.weight", "backbone.patch_embed1.proj.bias"):
-        ref = orc.P[key].grad
-        got = named[key].grad.cpu()
-        assert (got - ref).abs().max().item() <= 2e-6 + 2e-3 * ref.abs().max().item(), key
+    # every parameter gradient (1217 live tensors), not probes: |got - ref|_inf <= 2e-6 + 2e-3 |ref|_inf per tensor
+    n, worst = check_all_grads(named, {k: orc.P[k].grad for k in named}, atol=2e-6, rtol=2e-3, what="B=2 fp32 vs oracle: ")
+    assert n == len(named) - 332
+    print(f"all {n} gradient tensors within bound; worst {worst[0]:.3f} of its bound ({worst[1]})")
 
 
 VARIANTS = {   # constructor switches of SURVEY.md 8(f)-4 that the build implements; fixtures tests/golden/variants.npz

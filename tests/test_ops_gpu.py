@@ -532,9 +532,47 @@ def test_attention_segmented(dtype):
     if tol:
         close(Gx.grad_of(qv), qr.grad, 5e-5, 5e-5, "dq")
         close(Gx.grad_of(kvv), kvr.grad, 5e-5, 5e-5, "dkv")
-    else:
-        closeb(Gx.grad_of(qv), qr.grad, 3e-2, "dq bf16")
-        closeb(Gx.grad_of(kvv), kvr.grad, 3e-2, "dkv bf16")
+        return
+    closeb(Gx.grad_of(qv), qr.grad, 3e-2, "dq bf16")
+    closeb(Gx.grad_of(kvv), kvr.grad, 3e-2, "dkv bf16")
+    _seg_prescaled_cases(dtype, q, kv, gy, B, nq, Nk, y, qr.grad, kvr.grad)
+
+
+def _seg_prescaled_cases(dtype, q, kv, gy, B, nq, Nk, y, dq_ref, dkv_ref, tol_o=2e-2, tol_g=3e-2):
+    """The form the model uses: Q handed over as q * scale * log2(e) rounded once from fp32 (here from the test's fp32 q), the
+    gradient returned for the UNSCALED q -- through the hand-scheduled forward stream (default) and the compiler-scheduled kernel
+    (TC_ATTN_FWD_ASM=0), which must agree with each other to rounding of P."""
+    import os
+    from transception_amd.engine import Graph
+    d = 64
+    qp = (q.float() * (0.125 * 1.4426950408889634)).to(dtype)
+    # reference for the stored operand: q_eff = stored / (scale log2 e)
+    qe = (qp.float() / (0.125 * 1.4426950408889634)).requires_grad_()
+    kvr = kv.float().requires_grad_()
+    k, v = kvr[:, :d].reshape(B, Nk, d), kvr[:, d:].reshape(B, Nk, d)
+    outs, r0 = [], 0
+    for n in nq:
+        qs = qe[r0:r0 + B * n].view(B, n, d)
+        outs.append((torch.softmax(qs @ k.transpose(1, 2) * 0.125, -1) @ v).reshape(B * n, d))
+        r0 += B * n
+    yr = torch.cat(outs, 0)
+    yr.backward(gy.float())
+    res = {}
+    for impl in ("1", "0"):
+        os.environ["TC_ATTN_FWD_ASM"] = impl
+        try:
+            Gx = Graph(dtype, torch.device(DEV), True, True)
+            qv, kvv = mkV(Gx, qp), mkV(Gx, kv)
+            out = Gx.attention_seg(qv, kvv.colslice(0, d), kvv.colslice(d, 2 * d), B, nq, Nk, 0.125, q_prescaled=True)
+            assert torch.isfinite(out.data.float()).all()
+            closeb(out.data, yr, tol_o, f"seg attention, prescaled q, impl {impl}")
+            run_bwd(Gx, out, gy)
+            closeb(Gx.grad_of(qv), qe.grad, tol_g, f"dq, prescaled q, impl {impl}")
+            closeb(Gx.grad_of(kvv), kvr.grad, tol_g, f"dkv, prescaled q, impl {impl}")
+            res[impl] = out.data.float().clone()
+        finally:
+            os.environ.pop("TC_ATTN_FWD_ASM", None)
+    closeb(res["1"], res["0"].cpu(), 1e-2, "hand-scheduled vs compiler-scheduled forward")
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -569,6 +607,7 @@ def test_attention_segmented_rereference(dtype):
         run_bwd(Gx, out, gy)
         closeb(Gx.grad_of(qv), qr.grad, 3e-2, "dq")
         closeb(Gx.grad_of(kvv), kvr.grad, 3e-2, "dkv")
+        _seg_prescaled_cases(dtype, q, kv, gy, B, nq, Nk, y, qr.grad, kvr.grad)     # the rare re-reference path of the hand-scheduled stream
 
 
 @pytest.mark.parametrize("Bt,N,heads,Ch", [(3, 784, 8, 8), (2, 196, 8, 16), (2, 49, 8, 40)])

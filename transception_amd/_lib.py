@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TC_LIB_PATH") or os.path.join(HERE, "libtransception_hip.so")   # override: A/B kernel experiments only
 
 TC_F32, TC_BF16, TC_F16 = 0, 1, 2
-ACT_NONE, ACT_HSWISH, ACT_COORD, ACT_SIGMOID, ACT_GELU = 0, 1, 2, 3, 4
+ACT_NONE, ACT_HSWISH, ACT_COORD, ACT_SIGMOID, ACT_GELU, ACT_SCALE = 0, 1, 2, 3, 4, 5
 ABI_VERSION = 11
 ATTN_DKV_SPLITS = 8                # include/transception_hip.h: partial dK|dV buffers in tc_attn_bwd_seg's fp32 scratch
 
@@ -132,9 +132,9 @@ SIGNATURES = {
     "tc_attn_fwd": [vp, i32, i64, vp, i32, vp, i32, i64, vp, i32, i64, vp, i32, i32, i32, f32, i32, vp],
     "tc_attn_bwd": [vp, i32, i64, vp, i32, vp, i32, i64, vp, i32, i64, vp, i32, i64, vp, vp, vp, i32, i64, vp, i32,
                     vp, i32, i64, i32, i32, i32, i32, f32, i32, vp],
-    "tc_attn_fwd_seg": [vp, i32, vp, i32, vp, i32, i64, vp, i32, vp, i32, i32, C.POINTER(i32), i32, f32, i32, vp],
+    "tc_attn_fwd_seg": [vp, i32, vp, i32, vp, i32, i64, vp, i32, vp, i32, i32, C.POINTER(i32), i32, f32, i32, i32, vp],
     "tc_attn_bwd_seg": [vp, i32, vp, i32, vp, i32, i64, vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, i32, vp, i32, i64, i32, i32,
-                        C.POINTER(i32), i32, f32, i32, vp],
+                        C.POINTER(i32), i32, f32, i32, i32, vp],
     "tc_fma3_fwd": [vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, f32, i32, vp],
     "tc_fma3_bwd": [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, vp, i32, i32, i32, f32, i32, vp],
     "tc_add": [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp],

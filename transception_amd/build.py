@@ -32,14 +32,19 @@ def _stale(target: str, deps) -> bool:
 
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = _hipcc()
+    # the hand-scheduled attention stream is generated source: refresh attn_fwd_asm.inc (rewritten only when its text changes)
+    r = subprocess.run([sys.executable, os.path.join(CSRC, "gen_attn_asm.py")], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"gen_attn_asm.py failed:\n{r.stderr}")
     headers = [os.path.join(CSRC, "tc_common.h"), os.path.join(HERE, "..", "include", "transception_hip.h")]
+    extra = {"attention_seg.hip": [os.path.join(CSRC, "attn_fwd_asm.inc")]}
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
-        if force or _stale(o, [s] + headers):
+        if force or _stale(o, [s] + headers + extra.get(src, [])):
             jobs.append((s, o))
 
     def compile_one(job):

@@ -74,7 +74,7 @@ constexpr size_t FW_SMEM = (size_t)(2 * FW_SLOT + FW_NW * 32 * LDR) * sizeof(bf1
 template <typename H>
 __global__ __launch_bounds__(FW_NT, 1) void attn_fwd_seg_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
                                                                 const bf16_t* __restrict__ V, int ldv, long long skv, bf16_t* __restrict__ O,
-                                                                int ldo, float* __restrict__ lse, Segs sg, int Nk, float scale, int wide_o) {
+                                                                int ldo, float* __restrict__ lse, Segs sg, int Nk, float qs, int wide_o) {
     extern __shared__ __attribute__((aligned(16))) bf16_t fw_smem[];      // [2 slots][K tile | V tile][KB][LDR], then FW_NW wave tiles [32][LDR]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
     const int nwt = sg.t32[sg.n], bpi = (nwt + FW_NW - 1) / FW_NW;
@@ -106,8 +106,7 @@ __global__ __launch_bounds__(FW_NT, 1) void attn_fwd_seg_kernel(const bf16_t* __
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qf[ks] = ld_frag<V8>(wtile + j * LDR + 16 * ks + 8 * h);
     }
-    const float qs = scale * LOG2E;
-    f32x16 acc0, acc1;
+    f32x16 acc0, acc1;                                           // (qs = scale * log2(e), or 1 when Q arrives scaled)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
     float m = NEG_BIG, lsum = 0.f;
@@ -223,116 +222,113 @@ __global__ __launch_bounds__(FW_NT, 1) void attn_fwd_seg_kernel(const bf16_t* __
 }
 
 // Forward, hand-scheduled (the default for 16-bit storage; the kernel above stays as the generic fallback and the A/B baseline).
-// ONE wave per SIMD: a workgroup is 4 waves, each wave owns THREE 32-query tiles (12 tiles per workgroup as above), and the whole
-// key loop is one instruction stream emitted by gen_attn_asm.py (attn_fwd_asm.inc) -- per 32-key sub-tile, three groups of eight
-// MFMAs (QK^T of one tile alternating with PV of another) each carrying the exp / row-sum / pack arithmetic of the third tile and
-// the LDS fragment reads in program order, because on gfx950 VALU work hides only under MFMAs issued by the SAME wave.  Scores are
-// produced directly as s * scale * log2(e) - m: Q is scaled when it is staged and -m is the C operand of the first QK^T MFMA, so
-// the softmax is exp2 + add + pack per score.  K / V sub-tiles of 32 keys go through a 4-slot LDS ring (buffer loads three
-// sub-tiles ahead, one barrier per sub-tile).  This function stages Q and the first three sub-tiles, hands the addresses to the
-// stream and stores the O tiles / lse the stream leaves in the wave's LDS tiles.
+// Same decomposition -- one 12-wave workgroup per CU, a 32-query tile per wave -- but the whole key loop of a wave is one
+// instruction stream emitted by gen_attn_asm.py (attn_fwd_asm.inc; the reasons and the measurements are in that file's header):
+// software-pipelined so that every group of four MFMAs carries softmax arithmetic or fragment reads of another sub-tile, which
+// keeps the twelve waves from running their matrix and VALU phases in lock step.  Scores are produced directly as
+// s * scale * log2(e) - m: Q is scaled when it is staged and -m is the C operand of the first QK^T MFMA, so the softmax is
+// max3 tree + exp2 + add + pack per score.  K / V sub-tiles of 32 keys go through a 12-slot LDS ring (buffer loads six
+// sub-tiles ahead: waves 0-3 stage K, waves 4-7 V, one 16-byte chunk per thread; one barrier per FOUR sub-tiles).  This function stages
+// Q and the first five sub-tiles, hands the addresses to the stream and stores the O tile / lse the stream leaves in the wave's LDS tile.
 #include "attn_fwd_asm.inc"
 typedef int tc_i32x4 __attribute__((ext_vector_type(4)));
-constexpr int AS_TPW = 3, AS_NW = 4, AS_TPB = AS_TPW * AS_NW;
-constexpr int AS_SLOT = 16384, AS_VOFF = 32 * LDR * 2, AS_WT = 32 * LDR * 2, AS_WT0 = 4 * AS_SLOT, AS_LSE0 = AS_WT0 + AS_NW * AS_TPW * AS_WT;
+// LDS: 12 ring slots of one 32-key K | V sub-tile; the twelve 32-query wave tiles (Q in, O out) alias slots 6-11, which the stream
+// does not store to before every wave has read its Q fragments and does not read after the barrier in front of the O tiles.
+constexpr int AS_NW = 12, AS_VOFF = 32 * LDR * 2, AS_SLOT = 2 * AS_VOFF, AS_NSLOT = 12, AS_AHEAD = 6, AS_WT = 32 * LDR * 2, AS_WT0 = 6 * AS_SLOT,
+              AS_LSE0 = AS_NSLOT * AS_SLOT;
+static_assert(AS_WT0 + AS_NW * AS_WT <= AS_LSE0, "wave tiles must fit in the ring");
 #ifdef TC_ATTN_ASM_TIMING
-constexpr size_t AS_SMEM = AS_LSE0 + AS_NW * AS_TPW * 32 * sizeof(float) + 8192;
-__device__ unsigned long long g_attn_dbg[1024 * 16];
+constexpr size_t AS_SMEM = AS_LSE0 + AS_NW * 32 * sizeof(float) + 8192;
+__device__ unsigned long long g_attn_dbg[256 * 12 * 8];
 #else
-constexpr size_t AS_SMEM = AS_LSE0 + AS_NW * AS_TPW * 32 * sizeof(float);
+constexpr size_t AS_SMEM = AS_LSE0 + AS_NW * 32 * sizeof(float);
 #endif
 template <typename H>
 __global__ __launch_bounds__(AS_NW * 64, 1) void attn_fwd_asm_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
                                                                      const bf16_t* __restrict__ V, int ldv, long long skv, bf16_t* __restrict__ O,
-                                                                     int ldo, float* __restrict__ lse, Segs sg, int Nk, float scale) {
+                                                                     int ldo, float* __restrict__ lse, Segs sg, int Nk, float qs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char as_smem[];
 #ifdef TC_ATTN_ASM_TIMING
     const unsigned long long dbg_t0 = __builtin_readcyclecounter();
 #endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
-    const int nwt = sg.t32[sg.n], bpi = (nwt + AS_TPB - 1) / AS_TPB;
+    const int nwt = sg.t32[sg.n], bpi = (nwt + AS_NW - 1) / AS_NW;
     const int bx = xcd_block(blockIdx.x, gridDim.x);
-    const int b = bx / bpi, wt0 = (bx - b * bpi) * AS_TPB + wave * AS_TPW;
+    const int b = bx / bpi, wt = (bx - b * bpi) * AS_NW + wave;
+    int sgi = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) if (i < sg.n && wt >= sg.t32[i]) sgi = i;
+    const int nq = sg.nq[sgi];
+    const int tq0 = (wt - sg.t32[sgi]) * 32;
+    const bool live = wt < nwt;
+    const long long trow0 = (long long)sg.row0[sgi] + (long long)b * nq + tq0;
     const bf16_t* Kb = K + b * skv;
     const bf16_t* Vb = V + b * skv;
-    unsigned char* wtile = as_smem + AS_WT0 + wave * (AS_TPW * AS_WT);
-    const float qs = scale * LOG2E;
-    int nq_t[AS_TPW], tq0_t[AS_TPW];
-    long long trow0_t[AS_TPW];
-    bool live_t[AS_TPW];
+    unsigned char* wtile = as_smem + AS_WT0 + wave * AS_WT;
 #pragma unroll
-    for (int t = 0; t < AS_TPW; ++t) {
-        const int wt = wt0 + t;
-        int sgi = 0;
-#pragma unroll
-        for (int i = 1; i < 4; ++i) if (i < sg.n && wt >= sg.t32[i]) sgi = i;
-        nq_t[t] = sg.nq[sgi];
-        tq0_t[t] = (wt - sg.t32[sgi]) * 32;
-        live_t[t] = wt < nwt;
-        trow0_t[t] = (long long)sg.row0[sgi] + (long long)b * nq_t[t] + tq0_t[t];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {                           // Q rows, scaled by scale * log2(e), whole 128-byte rows in
-            const int r = 8 * i + (lane >> 3);
-            uint4 v = (live_t[t] && tq0_t[t] + r < nq_t[t]) ? *reinterpret_cast<const uint4*>(Q + (trow0_t[t] + r) * ldq + 8 * (lane & 7)) : make_uint4(0u, 0u, 0u, 0u);
-            unsigned w[4] = {v.x, v.y, v.z, v.w};
+    for (int i = 0; i < 4; ++i) {                               // Q rows (scaled by qs = scale * log2(e) here unless the producer did: qs = 1), whole 128-byte rows in
+        const int r = 8 * i + (lane >> 3);
+        const uint4 v = (live && tq0 + r < nq) ? *reinterpret_cast<const uint4*>(Q + (trow0 + r) * ldq + 8 * (lane & 7)) : make_uint4(0u, 0u, 0u, 0u);
+        unsigned w[4] = {v.x, v.y, v.z, v.w};
+        if (qs != 1.0f) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float lo, hi;
                 unpack2<H>(w[e], lo, hi);
                 w[e] = pack2<H>(lo * qs, hi * qs);
             }
-            *reinterpret_cast<uint4*>(wtile + t * AS_WT + r * (LDR * 2) + 16 * (lane & 7)) = make_uint4(w[0], w[1], w[2], w[3]);
         }
+        *reinterpret_cast<uint4*>(wtile + r * (LDR * 2) + 16 * (lane & 7)) = make_uint4(w[0], w[1], w[2], w[3]);
     }
-    const int sr = tid >> 3, sc = tid & 7;
+    // staging roles: thread (tid & 255) of waves 0-3 owns the K chunk (row sr, 16-byte column sc) of every sub-tile, of waves 4-7 the V chunk
+    const int role = wave >> 2, sr = (tid & 255) >> 3, sc = tid & 7;
+    if (role < 2) {
+        const bf16_t* src = role ? Vb : Kb;
+        const int ld = role ? ldv : ldk;
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {                               // sub-tiles 0..2 into ring slots 0..2 (rows past Nk: a duplicate, masked later)
-        const int row = min(32 * s + sr, Nk - 1);
-        const uint4 kk = *reinterpret_cast<const uint4*>(Kb + (long long)row * ldk + 8 * sc);
-        const uint4 vv = *reinterpret_cast<const uint4*>(Vb + (long long)row * ldv + 8 * sc);
-        *reinterpret_cast<uint4*>(as_smem + s * AS_SLOT + sr * (LDR * 2) + 16 * sc) = kk;
-        *reinterpret_cast<uint4*>(as_smem + s * AS_SLOT + AS_VOFF + key_row(sr) * (LDR * 2) + 16 * sc) = vv;
+        for (int s = 0; s < AS_AHEAD - 1; ++s) {                // sub-tiles 0..4 into ring slots 0..4 (rows past Nk: a duplicate, masked later)
+            const uint4 x = *reinterpret_cast<const uint4*>(src + (long long)min(32 * s + sr, Nk - 1) * ld + 8 * sc);
+            *reinterpret_cast<uint4*>(as_smem + s * AS_SLOT + (role ? AS_VOFF + key_row(sr) * (LDR * 2) : sr * (LDR * 2)) + 16 * sc) = x;
+        }
     }
     __syncthreads();
     {
         const unsigned lds0 = (unsigned)(uintptr_t)as_smem;     // LDS offset = low half of the flat address
         const int gi = lane & 15, gq = (lane >> 4) & 1, nsub = (Nk + 31) / 32, nv = Nk - 32 * (nsub - 1);
-        const unsigned kaddr = lds0 + pi_row(j) * (LDR * 2) + 16 * h;
-        const unsigned vaddr = lds0 + AS_VOFF + (16 * h + 4 * (gi >> 2)) * (LDR * 2) + 32 * gq + 8 * (gi & 3);
-        const unsigned wk = lds0 + sr * (LDR * 2) + 16 * sc, wv = lds0 + AS_VOFF + key_row(sr) * (LDR * 2) + 16 * sc;
-        const unsigned gk = (unsigned)(((96 + sr) * ldk + 8 * sc) * 2), gv = (unsigned)(((96 + sr) * ldv + 8 * sc) * 2);
-        const unsigned wbase = lds0 + AS_WT0 + wave * (AS_TPW * AS_WT);
-        const unsigned qaddr = wbase + j * (LDR * 2) + 16 * h, oaddr = wbase + j * (LDR * 2) + 8 * h;
-        const unsigned lseaddr = lds0 + AS_LSE0 + (wave * AS_TPW * 32 + j) * 4;
+        const unsigned kbase = lds0 + pi_row(j) * (LDR * 2) + 16 * h;
+        const unsigned vbase = lds0 + AS_VOFF + (16 * h + 4 * (gi >> 2)) * (LDR * 2) + 32 * gq + 8 * (gi & 3);
+        const unsigned wbase = lds0 + (role == 1 ? AS_VOFF + key_row(sr) * (LDR * 2) : sr * (LDR * 2)) + 16 * sc;
+        const int ld = role == 1 ? ldv : ldk;
+        unsigned goff = (unsigned)(((32 * (AS_AHEAD - 1) + sr) * ld + 8 * sc) * 2);           // sub-tile 5 is the first one the stream loads
+        const unsigned qaddr = lds0 + AS_WT0 + wave * AS_WT + j * (LDR * 2) + 16 * h, oaddr = qaddr - 8 * h;
+        const unsigned lseaddr = lds0 + AS_LSE0 + (wave * 32 + j) * 4;
         unsigned mask = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) mask |= (16 * h + r >= nv) ? (1u << r) : 0u;
-        const unsigned long long pk = (unsigned long long)(uintptr_t)Kb, pv = (unsigned long long)(uintptr_t)Vb;
-        const tc_i32x4 rk = {(int)(unsigned)pk, (int)(unsigned)(pk >> 32), (int)(((Nk - 1) * ldk + D) * 2), 0x00020000};
-        const tc_i32x4 rv = {(int)(unsigned)pv, (int)(unsigned)(pv >> 32), (int)(((Nk - 1) * ldv + D) * 2), 0x00020000};
-        const int stepk = 32 * ldk * 2, stepv = 32 * ldv * 2;
+        const unsigned long long pb = (unsigned long long)(uintptr_t)(role == 1 ? Vb : Kb);
+        const tc_i32x4 rsrc = {__builtin_amdgcn_readfirstlane((int)(unsigned)pb), __builtin_amdgcn_readfirstlane((int)(unsigned)(pb >> 32)),
+                               __builtin_amdgcn_readfirstlane(((Nk - 1) * ld + D) * 2), 0x00020000};
+        const int step = __builtin_amdgcn_readfirstlane(32 * ld * 2);
+        const int wex = __builtin_amdgcn_readfirstlane(role < 2 ? -1 : 0);
+        const long long wexec = ((long long)wex << 32) | (unsigned)wex;
         if (std::is_same<H, f16_t>::value)
-            asm volatile(TC_ATTN_FWD_ASM_F16 : : "v"(kaddr), "v"(vaddr), "v"(wk), "v"(wv), "v"(gk), "v"(gv), "v"(qaddr), "v"(oaddr), "v"(lseaddr), "v"(mask),
-                         "s"(rk), "s"(rv), "s"(nsub), "s"(stepk), "s"(stepv) : TC_ATTN_FWD_ASM_CLOBBERS);
+            asm volatile(TC_ATTN_FWD_ASM_F16 : "+v"(goff) : "v"(kbase), "v"(vbase), "v"(wbase), "v"(qaddr), "v"(oaddr), "v"(lseaddr), "v"(mask),
+                         "s"(rsrc), "s"(nsub), "s"(step), "s"(wexec) : TC_ATTN_FWD_ASM_CLOBBERS);
         else
-            asm volatile(TC_ATTN_FWD_ASM_BF16 : : "v"(kaddr), "v"(vaddr), "v"(wk), "v"(wv), "v"(gk), "v"(gv), "v"(qaddr), "v"(oaddr), "v"(lseaddr), "v"(mask),
-                         "s"(rk), "s"(rv), "s"(nsub), "s"(stepk), "s"(stepv) : TC_ATTN_FWD_ASM_CLOBBERS);
+            asm volatile(TC_ATTN_FWD_ASM_BF16 : "+v"(goff) : "v"(kbase), "v"(vbase), "v"(wbase), "v"(qaddr), "v"(oaddr), "v"(lseaddr), "v"(mask),
+                         "s"(rsrc), "s"(nsub), "s"(step), "s"(wexec) : TC_ATTN_FWD_ASM_CLOBBERS);
     }
-    const float* lsel = reinterpret_cast<const float*>(as_smem + AS_LSE0) + wave * (AS_TPW * 32);
 #pragma unroll
-    for (int t = 0; t < AS_TPW; ++t) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = 8 * i + (lane >> 3);
-            const uint4 v = *reinterpret_cast<const uint4*>(wtile + t * AS_WT + r * (LDR * 2) + 16 * (lane & 7));
-            if (live_t[t] && tq0_t[t] + r < nq_t[t]) *reinterpret_cast<uint4*>(O + (trow0_t[t] + r) * ldo + 8 * (lane & 7)) = v;
-        }
-        if (h == 0 && live_t[t] && tq0_t[t] + j < nq_t[t]) lse[trow0_t[t] + j] = lsel[t * 32 + j];
+    for (int i = 0; i < 4; ++i) {
+        const int r = 8 * i + (lane >> 3);
+        const uint4 v = *reinterpret_cast<const uint4*>(wtile + r * (LDR * 2) + 16 * (lane & 7));
+        if (live && tq0 + r < nq) *reinterpret_cast<uint4*>(O + (trow0 + r) * ldo + 8 * (lane & 7)) = v;
     }
+    if (h == 0 && live && tq0 + j < nq) lse[trow0 + j] = reinterpret_cast<const float*>(as_smem + AS_LSE0)[wave * 32 + j];
 #ifdef TC_ATTN_ASM_TIMING
     if (lane == 0 && blockIdx.x < 256) {
-        unsigned long long* dst = g_attn_dbg + (blockIdx.x * 4 + wave) * 16;
-        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(as_smem + AS_LSE0 + wave * (AS_TPW * 32 * 4) + 4096);
+        unsigned long long* dst = g_attn_dbg + (blockIdx.x * 12 + wave) * 8;
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(as_smem + AS_LSE0 + wave * 128 + 4096);
         dst[0] = dbg_t0;
         for (int k = 0; k < TC_ATTN_ASM_TIMING; ++k) dst[1 + k] = src[k];
         dst[1 + TC_ATTN_ASM_TIMING] = __builtin_readcyclecounter();
@@ -349,7 +345,7 @@ __global__ __launch_bounds__(FW_NT, 1) void attn_bwd_dq_seg_kernel(const bf16_t*
                                                                    const bf16_t* __restrict__ V, int ldv, long long skv,
                                                                    const bf16_t* __restrict__ dO, int lddo, const float* __restrict__ lse,
                                                                    const float* __restrict__ delta, bf16_t* __restrict__ dQ, int lddq, Segs sg,
-                                                                   int Nk, float scale, int wide_o) {
+                                                                   int Nk, float scale, float qs, int wide_o) {
     extern __shared__ __attribute__((aligned(16))) bf16_t fw_smem[];      // [2 slots][K tile | V tile][KB][LDR], then FW_NW wave tiles [32][LDR]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
     const int nwt = sg.t32[sg.n], bpi = (nwt + FW_NW - 1) / FW_NW;
@@ -391,8 +387,7 @@ __global__ __launch_bounds__(FW_NT, 1) void attn_bwd_dq_seg_kernel(const bf16_t*
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) dof[ks] = ld_frag<V8>(wtile + j * LDR + 16 * ks + 8 * h);
     }
-    const float qs = scale * LOG2E;
-    const float l2 = ok ? lse[trow0 + j] * LOG2E : 0.f;
+    const float l2 = ok ? lse[trow0 + j] * LOG2E : 0.f;         // qs = scale * log2(e), or 1 when Q arrives scaled
     const float dls = ok ? delta[trow0 + j] * scale : 0.f;      // dS = P (dP scale - delta scale)
     f32x16 acc0, acc1;
 #pragma unroll
@@ -502,7 +497,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16
                                                                     const bf16_t* __restrict__ V, int ldv, long long skv,
                                                                     const bf16_t* __restrict__ dO, int lddo, const float* __restrict__ lse,
                                                                     const float* __restrict__ delta, float* __restrict__ dkv32, Segs sg, int Nk,
-                                                                    float scale, int tiles_per_chunk) {
+                                                                    float scale, float qs, int tiles_per_chunk) {
     constexpr int QS = 64, LDQ = D + 8;
     // Q and dO of a stage are stored ONCE, row-major with the rows of every 16-row group 4x4-transposed (key_row): conflict-free both
     // for the 16-byte fragment reads of S = Q K^T / dP = dO V^T and for the hardware transpose reads (ds_read_b64_tr_b16) that gather
@@ -529,7 +524,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16
         kf[ks] = *reinterpret_cast<const V8*>(&a);
         vf[ks] = *reinterpret_cast<const V8*>(&c);
     }
-    const float qs = scale * LOG2E;
+    // qs = scale * log2(e) and dS = P (dP - delta) scale multiplies the UNSCALED Q into dK; with Q stored as q * qs (qs passed as 1)
+    // the factor of dS is ln 2 = scale / (scale * log2(e)) instead (`scale` is passed as ln 2 by the host in that case)
     f32x16 dk0, dk1, dv0, dv1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk0[r] = dk1[r] = dv0[r] = dv1[r] = 0.f; }
@@ -737,11 +733,12 @@ bool make_segs(Segs& sg, int B, int nseg, const int* nq, long long& total_rows) 
 }  // namespace
 
 extern "C" int tc_attn_fwd_seg(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, long long skv, void* O, int ldo,
-                               float* lse, int B, int nseg, const int* nq, int Nk, float scale, int dtype, void* stream) {
+                               float* lse, int B, int nseg, const int* nq, int Nk, float scale, int qscaled, int dtype, void* stream) {
     Segs sg;
     long long rows;
     if (!Q || !K || !V || !O || !lse || !nq || B <= 0 || Nk <= 0 || !make_segs(sg, B, nseg, nq, rows)) return TC_ERR_ARG;
     if (dtype == TC_F32) {                                      // parity path: one fp32 launch per segment
+        if (qscaled) return TC_ERR_ARG;
         for (int i = 0; i < nseg; ++i) {
             const long long off = sg.row0[i];
             const int rc = tc_attn_fwd((const float*)Q + off * ldq, ldq, (long long)nq[i] * ldq, K, ldk, V, ldv, skv, (float*)O + off * ldo, ldo,
@@ -754,8 +751,11 @@ extern "C" int tc_attn_fwd_seg(const void* Q, int ldq, const void* K, int ldk, c
         return TC_ERR_ARG;
     const dim3 grid((unsigned)B * ((sg.t32[nseg] + FW_NW - 1) / FW_NW));
     const int wide_o = !(ldo & 7) && !((uintptr_t)O & 15);
-    static const bool use_asm = !(getenv("TC_ATTN_FWD_ASM") && atoi(getenv("TC_ATTN_FWD_ASM")) == 0);
-    if (use_asm && wide_o && Nk >= 64 && (long long)Nk * (ldk > ldv ? ldk : ldv) * 2 < (1ll << 31)) {   // the hand-scheduled stream (needs >= 2 key sub-tiles)
+    const float qs = qscaled ? 1.0f : scale * LOG2E;
+    const char* asm_env = getenv("TC_ATTN_FWD_ASM");               // read per call: the tests run both kernels in one process
+    const bool use_asm = !(asm_env && atoi(asm_env) == 0);
+    // the stream takes Q already scaled (an in-kernel scale would round Q a second time: 2^-9 relative on every score)
+    if (use_asm && qscaled && wide_o && Nk >= 64 && (long long)Nk * (ldk > ldv ? ldk : ldv) * 2 < (1ll << 31)) {   // the hand-scheduled stream (needs >= 2 key sub-tiles)
         static bool as_ok[2] = {false, false};
 #define TC_FWD_ASM(HH, IDX)                                                                                                                  \
     {                                                                                                                                       \
@@ -764,9 +764,9 @@ extern "C" int tc_attn_fwd_seg(const void* Q, int ldq, const void* K, int ldk, c
                 return TC_ERR_LAUNCH;                                                                                                       \
             as_ok[IDX] = true;                                                                                                              \
         }                                                                                                                                   \
-        hipLaunchKernelGGL(attn_fwd_asm_kernel<HH>, dim3((unsigned)B * ((sg.t32[nseg] + AS_TPB - 1) / AS_TPB)), dim3(AS_NW * 64), AS_SMEM,    \
+        hipLaunchKernelGGL(attn_fwd_asm_kernel<HH>, dim3((unsigned)B * ((sg.t32[nseg] + AS_NW - 1) / AS_NW)), dim3(AS_NW * 64), AS_SMEM,    \
                            (hipStream_t)stream, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk, (const bf16_t*)V, ldv, skv, (bf16_t*)O, ldo,  \
-                           lse, sg, Nk, scale);                                                                                             \
+                           lse, sg, Nk, qs);                                                                                                \
     }
         if (dtype == TC_BF16) TC_FWD_ASM(bf16_t, 0) else TC_FWD_ASM(f16_t, 1)
 #undef TC_FWD_ASM
@@ -781,7 +781,7 @@ extern "C" int tc_attn_fwd_seg(const void* Q, int ldq, const void* K, int ldk, c
             lds_ok[IDX] = true;                                                                                                             \
         }                                                                                                                                   \
         hipLaunchKernelGGL(attn_fwd_seg_kernel<HH>, grid, dim3(FW_NT), FW_SMEM, (hipStream_t)stream, (const bf16_t*)Q, ldq, (const bf16_t*)K, \
-                           ldk, (const bf16_t*)V, ldv, skv, (bf16_t*)O, ldo, lse, sg, Nk, scale, wide_o);                                   \
+                           ldk, (const bf16_t*)V, ldv, skv, (bf16_t*)O, ldo, lse, sg, Nk, qs, wide_o);                                      \
     }
     if (dtype == TC_BF16) TC_FWD(bf16_t, 0) else TC_FWD(f16_t, 1)
 #undef TC_FWD
@@ -789,21 +789,22 @@ extern "C" int tc_attn_fwd_seg(const void* Q, int ldq, const void* K, int ldk, c
 }
 
 #ifdef TC_ATTN_ASM_TIMING
-extern "C" int tc_attn_dbg_read(unsigned long long* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_attn_dbg), sizeof(unsigned long long) * 1024 * 16); }
+extern "C" int tc_attn_dbg_read(unsigned long long* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_attn_dbg), sizeof(unsigned long long) * 256 * 12 * 8); }
 #endif
 #ifdef TC_DKV_TIMING
 extern "C" int tc_dkv_dbg_read(unsigned long long* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_dkv_dbg), sizeof(unsigned long long) * 512 * 4); }
 #endif
 extern "C" int tc_attn_bwd_seg(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, long long skv, const void* O, int ldo,
                                const void* dO, int lddo, const float* lse, float* delta, float* dkv32, void* dQ, int lddq, void* dK, int lddk,
-                               void* dV, int lddv, long long sdkv, int B, int nseg, const int* nq, int Nk, float scale, int dtype,
-                               void* stream) {
+                               void* dV, int lddv, long long sdkv, int B, int nseg, const int* nq, int Nk, float scale, int qscaled,
+                               int dtype, void* stream) {
     Segs sg;
     long long rows;
     if (!Q || !K || !V || !O || !dO || !lse || !delta || !dQ || !dK || !dV || !nq || B <= 0 || Nk <= 0 || !make_segs(sg, B, nseg, nq, rows))
         return TC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == TC_F32) {
+        if (qscaled) return TC_ERR_ARG;
         for (int i = 0; i < nseg; ++i) {
             const long long off = sg.row0[i];
             const int rc = tc_attn_bwd((const float*)Q + off * ldq, ldq, (long long)nq[i] * ldq, K, ldk, V, ldv, skv, (const float*)O + off * ldo, ldo,
@@ -830,6 +831,7 @@ extern "C" int tc_attn_bwd_seg(const void* Q, int ldq, const void* K, int ldk, c
         tpc = ((ntiles + TC_ATTN_DKV_SPLITS - 1) / TC_ATTN_DKV_SPLITS + 1) & ~1;
         zs = (ntiles + tpc - 1) / tpc;
     }
+    const float qs = qscaled ? 1.0f : scale * LOG2E, kscale = qscaled ? LN2 : scale;    // dK = dS^T Q: ln 2 when Q is stored as q * scale * log2(e)
     const int wide_dq = !(lddq & 7) && !((uintptr_t)dQ & 15);
     const int wide_rows = !((ldo | lddo) & 7) && !(((uintptr_t)O | (uintptr_t)dO) & 15);
     static bool lds_ok[2] = {false, false};
@@ -843,12 +845,12 @@ extern "C" int tc_attn_bwd_seg(const void* Q, int ldq, const void* K, int ldk, c
         hipLaunchKernelGGL(delta_rows_kernel<HH>, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, s, (const bf16_t*)O, ldo, (const bf16_t*)dO, \
                            lddo, delta, rows, wide_rows);                                                                                   \
         hipLaunchKernelGGL((attn_bwd_dkv_seg_kernel<HH, 4>), dim3(kb, B, zs), dim3(256), 0, s, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk,    \
-                           (const bf16_t*)V, ldv, skv, (const bf16_t*)dO, lddo, lse, delta, dkv32, sg, Nk, scale, tpc);                     \
+                           (const bf16_t*)V, ldv, skv, (const bf16_t*)dO, lddo, lse, delta, dkv32, sg, Nk, kscale, qs, tpc);                \
         hipLaunchKernelGGL(attn_dkv_store_kernel<HH>, dim3(tc_blocks((long long)B * Nk * 32, 256, 1024)), dim3(256), 0, s, dkv32,           \
                            (bf16_t*)dK, lddk, (bf16_t*)dV, lddv, sdkv, B, Nk, zs);                                                              \
         hipLaunchKernelGGL(attn_bwd_dq_seg_kernel<HH>, dim3((unsigned)B * ((sg.t32[nseg] + FW_NW - 1) / FW_NW)), dim3(FW_NT), FW_SMEM, s,     \
                            (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk, (const bf16_t*)V, ldv, skv, (const bf16_t*)dO, lddo, lse, delta,    \
-                           (bf16_t*)dQ, lddq, sg, Nk, scale, wide_dq);                                                                      \
+                           (bf16_t*)dQ, lddq, sg, Nk, scale, qs, wide_dq);                                                                  \
     }
     if (dtype == TC_BF16) TC_BWD(bf16_t, 0) else TC_BWD(f16_t, 1)
 #undef TC_BWD

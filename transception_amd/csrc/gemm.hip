@@ -184,7 +184,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmDev& p, f32x16 (&acc)[TM
                 if (col >= p.N) continue;
                 float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = p.alpha * acc[i][j][4 * g + e];
+                for (int e = 0; e < 4; ++e) v[e] = (p.act == TC_ACT_SCALE ? 1.0f : p.alpha) * acc[i][j][4 * g + e];
                 TC* c = C + (long long)row * p.ldc + col;
                 if (col + 3 < p.N && p.vecC) {
                     if (bias && first_split) {
@@ -202,6 +202,9 @@ __device__ __forceinline__ void epilogue_rows(const GemmDev& p, f32x16 (&acc)[TM
                         if (p.act == TC_ACT_SIGMOID) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = sigmoid_f(v[e]);
+                        } else if (p.act == TC_ACT_SCALE) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
                         }
                         if (p.accumulate) { const float4 o = ld4<TC>(c); v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
                         st4<TC>(c, make_float4(v[0], v[1], v[2], v[3]));
@@ -216,6 +219,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmDev& p, f32x16 (&acc)[TM
                         if (atomic) atomicAdd(reinterpret_cast<float*>(c) + e, w);
                         else {
                             if (p.act == TC_ACT_SIGMOID) w = sigmoid_f(w);
+                            else if (p.act == TC_ACT_SCALE) w *= p.alpha;
                             if (p.accumulate) w += ldf<TC>(c + e);
                             stf<TC>(c + e, w);
                         }
@@ -260,7 +264,7 @@ __device__ __forceinline__ void epilogue_cols(const GemmDev& p, f32x16 (&acc)[TM
             for (int r = 0; r < 16; ++r) {
                 const int row = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (row >= p.M) continue;
-                float v = p.alpha * acc[i][j][r] + bv;
+                float v = (p.act == TC_ACT_SCALE ? 1.0f : p.alpha) * acc[i][j][r] + bv;
                 if (R && first_split) v += ldf<T>(R + (long long)row * p.ldr + col);
                 if constexpr (EP) {
                     const float2 st = stat[row];
@@ -271,6 +275,7 @@ __device__ __forceinline__ void epilogue_cols(const GemmDev& p, f32x16 (&acc)[TM
                     atomicAdd(reinterpret_cast<float*>(c), v);
                 } else {
                     if (p.act == TC_ACT_SIGMOID) v = sigmoid_f(v);
+                    else if (p.act == TC_ACT_SCALE) v *= p.alpha;
                     if (p.accumulate) v += ldf<TC>(c);
                     stf<TC>(c, v);
                 }
@@ -319,7 +324,7 @@ __device__ __forceinline__ void epilogue_rows_lds(const GemmDev& p, f32x16 (&acc
                 const int lc = wc * WN + j * 32 + 8 * g + 4 * h, col = n0 + lc;
                 float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = p.alpha * acc[i][j][4 * g + e];
+                for (int e = 0; e < 4; ++e) v[e] = (p.act == TC_ACT_SCALE ? 1.0f : p.alpha) * acc[i][j][4 * g + e];
                 if (row < p.M && col < p.N) {                // N % 8 == 0 on this path: the 4-group is all in or all out
                     if (bias) {
 #pragma unroll
@@ -332,6 +337,9 @@ __device__ __forceinline__ void epilogue_rows_lds(const GemmDev& p, f32x16 (&acc
                     if (p.act == TC_ACT_SIGMOID) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = sigmoid_f(v[e]);
+                    } else if (p.act == TC_ACT_SCALE) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
                     }
                 }
                 st4<H>(stage + lr * LDS_ + lc, make_float4(v[0], v[1], v[2], v[3]));
@@ -1163,7 +1171,8 @@ int gemm_typed(const TcGemm* g, hipStream_t s) {
 static bool gemm_args_ok(const TcGemm* g) {
     if (!g || !g->A || !g->B || !g->C || g->M <= 0 || g->N <= 0 || g->K <= 0 || g->nb1 < 1 || g->nb2 < 1 || g->splitk < 1) return false;
     if ((g->splitk > 1 || g->atomic) && (!g->accumulate || (g->dtype != TC_F32 && !g->c_f32) || g->act != TC_ACT_NONE)) return false;
-    if (g->act != TC_ACT_NONE && g->act != TC_ACT_SIGMOID) return false;
+    if (g->act != TC_ACT_NONE && g->act != TC_ACT_SIGMOID && g->act != TC_ACT_SCALE) return false;
+    if (g->act == TC_ACT_SCALE && g->ffn_mode != TC_FFN_NONE) return false;
     if (g->bgap_every < 0 || (g->bgap_every > 0 && (g->transB || g->bgap_every % 64 || (g->bgap % 8)))) return false;
     if (g->ffn_mode < TC_FFN_NONE || g->ffn_mode > TC_FFN_EP) return false;
     if (g->ffn_mode != TC_FFN_NONE) {

@@ -18,7 +18,7 @@ from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
 
-from ._lib import (ATTN_DKV_SPLITS, EW_COPY, EW_DEINTERLEAVE, EW_PATCHIFY, TcEffAtt, TcEwSeg, TcFfnBwd, TcFfnFused, ACT_COORD, ACT_GELU, ACT_HSWISH, ACT_NONE, ACT_SIGMOID, FFN_EP, FFN_LN_A, FFN_LN_B, TC_BF16, TC_F16, TC_F32, TcDwSeg, TcFfnSeg,
+from ._lib import (ATTN_DKV_SPLITS, EW_COPY, EW_DEINTERLEAVE, EW_PATCHIFY, TcEffAtt, TcEwSeg, TcFfnBwd, TcFfnFused, ACT_COORD, ACT_GELU, ACT_HSWISH, ACT_NONE, ACT_SCALE, ACT_SIGMOID, FFN_EP, FFN_LN_A, FFN_LN_B, TC_BF16, TC_F16, TC_F32, TcDwSeg, TcFfnSeg,
                    TcGemm, lib)
 
 _DT = {torch.float32: TC_F32, torch.bfloat16: TC_BF16, torch.float16: TC_F16}
@@ -519,8 +519,12 @@ class Graph:
     # ------------------------------------------------------------------ ops
     def linear(self, x: Var, W: P, b: Optional[P] = None, out: Optional[Var] = None, residual: Optional[Var] = None,
                act: int = ACT_NONE, wcols: Optional[Tuple[int, int]] = None, accumulate: bool = False,
-               batch: Optional[Tuple[int, int, int, int]] = None) -> Var:
+               batch: Optional[Tuple[int, int, int, int]] = None, post_scale: Optional[float] = None) -> Var:
         """out = act(x @ W[:, wcols]^T + b + residual)  (or out += ... when accumulate).  W is [N, K] (nn.Linear).
+
+        post_scale c: out = c * (x W^T + b + residual), rounded once from the fp32 accumulator (TC_ACT_SCALE) -- the bridge's q
+        projection hands the attention kernels q * scale * log2(e).  The consumer must hand back d loss / d(x W^T + b) as
+        grad_of(out), i.e. the scale belongs to the consumer's backward, not to this layer's (attention_seg(q_prescaled=True) does).
 
         batch=(nb, sx, so, sr): x / out / residual are the views of batch 0 ([M, K] / [M, N]); batch i lives
         sx / so / sr ELEMENTS further on in the same buffers (used to re-lay-out rows between buffers)."""
@@ -546,10 +550,12 @@ class Graph:
             assert out.rows == M and out.cols == N
             nb, sx, so, sr = batch if batch is not None else (1, 0, 0, 0)
             sw = 0
+        if post_scale is not None:
+            assert act == ACT_NONE and not accumulate
         self._gemm(_ptr(x.data), x.ld, _ptr(Wt), Wt.stride(0), _ptr(out.data), out.ld, M, N, K, 0, 1,
                    bias=_ptr(b.data) if b is not None else None, R=_ptr(residual.data) if residual is not None else None,
-                   ldr=residual.ld if residual is not None else 0, acc=int(accumulate), act=act, nb1=nb, sA=(sx, 0),
-                   sB=(sw, 0), sC=(so, 0), sR=(sr, 0), sbias=sw)
+                   ldr=residual.ld if residual is not None else 0, acc=int(accumulate), act=act if post_scale is None else ACT_SCALE,
+                   alpha=1.0 if post_scale is None else post_scale, nb1=nb, sA=(sx, 0), sB=(sw, 0), sC=(so, 0), sR=(sr, 0), sbias=sw)
 
         def bwd():
             dy = self.grad_of(out)
@@ -602,12 +608,13 @@ class Graph:
         return out
 
     def linear_many(self, items: List[tuple]) -> List[Var]:
-        """Independent Linear layers (x, W, b, out, residual[, batch]) of DIFFERENT shapes in one launch (tc_gemm_multi, at most 12
-        problems per launch); their gradient GEMMs likewise.  out_i = x_i W_i^T + b_i + residual_i.  batch = (nb, sx, so, sr) as in
-        linear(): batch j of x / out / residual lives sx / so / sr elements after batch 0 (row re-layout between buffers)."""
+        """Independent Linear layers (x, W, b, out, residual[, batch[, post_scale]]) of DIFFERENT shapes in one launch (tc_gemm_multi,
+        at most 12 problems per launch); their gradient GEMMs likewise.  out_i = x_i W_i^T + b_i + residual_i (times post_scale, see
+        linear()).  batch = (nb, sx, so, sr) as in linear(): batch j of x / out / residual lives sx / so / sr elements after batch 0
+        (row re-layout between buffers)."""
         n = len(items)
         assert self.ngroups == 1 and n >= 1
-        items = [tuple(it) + ((None,) if len(it) == 5 else ()) for it in items]
+        items = [tuple(it) + (None,) * (7 - len(it)) for it in items]
         wsb = _workspace(self.dev, self.stream, "many")
         sl = (wsb.numel() // 8) & ~16383                    # a private, full-size workspace slice per problem (counters + partials)
 
@@ -624,19 +631,20 @@ class Graph:
                 self.n_launch += 1
                 _timed_gemm("multi", chunk, lambda: self.L.tc_gemm_multi(arr, len(chunk), self.stream))
         fw = []
-        for i, (x, W, b, out, res, batch) in enumerate(items):
+        for i, (x, W, b, out, res, batch, ps) in enumerate(items):
             N, K = W.data.shape
             nb, sx, so, sr = batch if batch is not None else (1, 0, 0, 0)
             assert x.cols == K and out.rows == x.rows and out.cols == N
             fw.append(desc(i % 12, _ptr(x.data), x.ld, _ptr(W.data), W.data.stride(0), _ptr(out.data), out.ld, x.rows, N, K, 0, 1,
                            bias=_ptr(b.data) if b is not None else None, R=_ptr(res.data) if res is not None else None,
-                           ldr=res.ld if res is not None else 0, nb1=nb, sA=(sx, 0), sC=(so, 0), sR=(sr, 0)))
+                           ldr=res.ld if res is not None else 0, nb1=nb, sA=(sx, 0), sC=(so, 0), sR=(sr, 0),
+                           alpha=1.0 if ps is None else ps, act=ACT_NONE if ps is None else ACT_SCALE))
         launch(fw)
 
         def bwd():
             dxs, dws = [], []
             waves: List[list] = []                       # dX problems whose outputs overlap must not share a launch
-            for i, (x, W, b, out, res, batch) in enumerate(items):
+            for i, (x, W, b, out, res, batch, _ps) in enumerate(items):
                 dy = self.grad_of(out)
                 if dy is None:
                     continue
@@ -1498,9 +1506,12 @@ class Graph:
 
     use_fused_attention = False
 
-    def attention_seg(self, q: Var, k: Var, v: Var, B: int, nq: List[int], Nk: int, scale: float, out: Optional[Var] = None) -> Var:
+    def attention_seg(self, q: Var, k: Var, v: Var, B: int, nq: List[int], Nk: int, scale: float, out: Optional[Var] = None,
+                      q_prescaled: bool = False) -> Var:
         """softmax(q k^T * scale) v where q / out are stage-major: segment i = B images x nq[i] query rows, K/V image-major.
-        One launch for all segments on the bf16 path."""
+        One launch for all segments on the bf16 path.  q_prescaled: q holds (projection output) * scale * log2(e) (linear(...,
+        post_scale=...)); the gradient written for q is then the one of the unscaled projection output."""
+        assert not (q_prescaled and self.dtype == torch.float32)
         rows = B * sum(nq)
         assert q.rows == rows and q.cols == 64 and q.data.is_contiguous()
         if out is None:
@@ -1511,7 +1522,7 @@ class Graph:
         flops = 4.0 * rows * Nk * 64
         _timed("attn_fwd", flops, lambda: self.L.tc_attn_fwd_seg(
             _ptr(q.data), q.ld, _ptr(k.data), k.ld, _ptr(v.data), v.ld, Nk * k.ld, _ptr(out.data), out.ld, _ptr(lse), B, len(nq),
-            nq_c, Nk, scale, self.dt, self.stream))
+            nq_c, Nk, scale, int(q_prescaled), self.dt, self.stream))
 
         def bwd():
             dO = self.grad_of(out)
@@ -1527,7 +1538,7 @@ class Graph:
             _timed("attn_bwd", 10.0 * rows * Nk * 64, lambda: self.L.tc_attn_bwd_seg(
                 _ptr(q.data), q.ld, _ptr(k.data), k.ld, _ptr(v.data), v.ld, Nk * k.ld, _ptr(out.data), out.ld, _ptr(dO),
                 dO.stride(0), _ptr(lse), _ptr(delta), _ptr(dkv32), _ptr(gq), gq.stride(0), _ptr(gk), gk.stride(0), _ptr(gv),
-                gv.stride(0), Nk * gk.stride(0), B, len(nq), nq_c, Nk, scale, self.dt, self.stream))
+                gv.stride(0), Nk * gk.stride(0), B, len(nq), nq_c, Nk, scale, int(q_prescaled), self.dt, self.stream))
         self._rec(bwd)
         return out
 

@@ -747,7 +747,7 @@ def _channel_att(M, G, n: Var, X: Optional[Var], name: str, B: int, ntok: List[i
 
 def _scale_reduce(M, G, n: Var, name: str, B: int, sides: List[int], ntok: List[int], R: List[int], extra=None):
     """Scale_reduce, MSTr.py:2225-2249 (Appendix C.4): k=s patchify convs + channel de-interleave + LN -> [B*Nk, 64].
-    extra = (x, W, b): one more independent Linear (the attention's q projection) that shares the launch of the three
+    extra = (x, W, b, post_scale): one more independent Linear (the attention's q projection) that shares the launch of the three
     patchified convolutions; its output is returned second."""
     Cd = 64
     Pn = sides[3] * sides[3]
@@ -761,13 +761,13 @@ def _scale_reduce(M, G, n: Var, name: str, B: int, sides: List[int], ntok: List[
     if MANY_MIXFFN and not G.use_streams and G.ngroups == 1:
         items = [(cols[s], lins[s][0], lins[s][1], G.new(cols[s].rows, lins[s][0].data.shape[0]), None) for s in range(3)]
         if extra is not None:
-            items.append((extra[0], extra[1], extra[2], G.new(extra[0].rows, extra[1].data.shape[0]), None))
+            items.append((extra[0], extra[1], extra[2], G.new(extra[0].rows, extra[1].data.shape[0]), None, None, extra[3]))
         outs = G.linear_many(items)
         os_, xo = outs[:3], (outs[3] if extra is not None else None)
     else:
         os_ = [G.linear(cols[s], *lins[s]) for s in range(3)]
         if extra is not None:
-            xo = G.linear(*extra)
+            xo = G.linear(extra[0], extra[1], extra[2], post_scale=extra[3])
     roffs = [0, MULT[0] * Pn, (MULT[0] + MULT[1]) * Pn, (MULT[0] + MULT[1] + MULT[2]) * Pn]
     if merged:
         G.sr_gather([(os_[s], roffs[s] * Cd, Nk * Cd, B, Pn, Cd, MULT[s]) for s in range(3)],
@@ -780,16 +780,23 @@ def _scale_reduce(M, G, n: Var, name: str, B: int, sides: List[int], ntok: List[
     return rn if extra is None else (rn, xo)
 
 
+LOG2E = 1.4426950408889634
+
+
 def _self_att(M, G, n: Var, X: Optional[Var], name: str, B: int, sides: List[int], ntok: List[int], R: List[int], N6: int) -> Var:
     """M_EfficientSelfAtten, MSTr.py:2267-2292: one head, d = 64, keys/values from the reduced token set."""
     Cd = 64
     Nk = sides[3] * sides[3] * 8 + ntok[3]
-    rn, q = _scale_reduce(M, G, n, name + ".scale_reduce", B, sides, ntok, R, extra=(n, *_lin(M, G, name + ".q")))
+    # 16-bit fused path: the q projection stores q * scale * log2(e), rounded once from its fp32 accumulator (the attention kernels then
+    # spend no multiply per score and Q is not rounded a second time)
+    pre = G.use_fused_attention and G.dtype != torch.float32
+    rn, q = _scale_reduce(M, G, n, name + ".scale_reduce", B, sides, ntok, R,
+                          extra=(n, *_lin(M, G, name + ".q"), (Cd ** -0.5) * LOG2E if pre else None))
     kv = G.linear(rn, *_lin(M, G, name + ".kv"))
     k, v = kv.colslice(0, Cd), kv.colslice(Cd, 2 * Cd)
     att = G.new(B * N6, Cd)
     if G.use_fused_attention:
-        G.attention_seg(q, k, v, B, list(ntok), Nk, Cd ** -0.5, out=att)          # all four scales, one launch
+        G.attention_seg(q, k, v, B, list(ntok), Nk, Cd ** -0.5, out=att, q_prescaled=pre)      # all four scales, one launch
     else:
         for s in range(4):
             G.attention(q.rowslice(R[s], R[s + 1]), k, v, B, ntok[s], Nk, Cd ** -0.5, out=att.rowslice(R[s], R[s + 1]))
