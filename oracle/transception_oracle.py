@@ -105,6 +105,7 @@ class TransCeptionOracle:
         ksm = torch.softmax(k, dim=1)                       # over tokens, per channel
         qsm = torch.softmax(q, dim=2)                       # over channels, per token
         ctx = ksm.transpose(1, 2) @ v                       # [B, C, C']
+        self.taps[name + ".ctx"] = ctx                      # (the fused kernels keep this context matrix: tests compare it)
         att = qsm @ ctx                                     # [B, N, C']
         return self.linear(att, name + ".reprojection")
 

@@ -176,7 +176,8 @@ def train_trace(MST, Dice):
 
 
 def modules(MST):
-    """Per-module goldens: y = m(x); gx = d(sum(y*g))/dx, on seeded x, g (B=2)."""
+    """Per-module goldens: y = m(x); gx = d(sum(y*g))/dx and gw/<parameter> = d(sum(y*g))/dw for every parameter of the module,
+    on seeded x, g (B=2)."""
     out = {}
     ref = MST(num_classes=9)
     ref.load_state_dict(seeded_state_dict(), strict=True)
@@ -185,13 +186,19 @@ def modules(MST):
 
     def run(tag, fn, shapes, scale=1.0):
         xs = [torch.from_numpy(seeded_tensor(f"{tag}/x{i}", s, scale)).requires_grad_(True) for i, s in enumerate(shapes)]
+        ref.zero_grad(set_to_none=True)
         y = fn(*xs)
         g = torch.from_numpy(seeded_tensor(f"{tag}/g", tuple(y.shape)))
         (y * g).sum().backward()
         pack(out, f"{tag}/y", y)
         for i, xi in enumerate(xs):
             pack(out, f"{tag}/gx{i}", xi.grad)
-        print(tag, tuple(y.shape))
+        nw = 0
+        for name, p in ref.named_parameters():       # a sampled grad_weight per kernel golden -- every parameter the module touched
+            if p.grad is not None:
+                pack(out, f"{tag}/gw/{name}", p.grad)
+                nw += 1
+        print(tag, tuple(y.shape), f"{nw} weight gradients")
 
     B = 2
     run("patch_embed1", lambda x: bb.patch_embed1(x)[0], [(B, 3, 224, 224)])

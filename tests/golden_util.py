@@ -37,6 +37,20 @@ def check_packed(store, tag: str, t: torch.Tensor, atol: float, rtol: float = 0.
     return float(err.max())
 
 
+def check_packed_l2(store, tag: str, t: torch.Tensor, rel_l2: float, floor: float):
+    """16-bit paths: the sampled entries of `t` against the stored samples in relative L2 (rounding noise of a long bf16 sum is a few
+    per cent of the tensor's norm and lands anywhere, so a per-entry bound relative to the largest sample is the wrong shape);
+    tensors whose samples have a norm below `floor` are held to an absolute L2 of floor * rel_l2 ... floor instead."""
+    a = t.detach().contiguous().float().cpu().reshape(-1).numpy()
+    shape = tuple(int(s) for s in store[tag + "/shape"])
+    assert tuple(t.shape) == shape, f"{tag}: shape {tuple(t.shape)} != golden {shape}"
+    want = store[tag + "/samples"].astype(np.float64)
+    got = a[sample_idx(tag, a.size)].astype(np.float64)
+    d, nw = float(np.linalg.norm(got - want)), float(np.linalg.norm(want))
+    assert d <= rel_l2 * max(nw, floor), f"{tag}: sampled rel L2 {d / max(nw, 1e-300):.3e} (|want| {nw:.3e}, floor {floor:.3e}, budget {rel_l2})"
+    return d / max(nw, floor)
+
+
 def check_all_grads(named, ref_grads, atol: float = 2e-6, rtol: float = 2e-3, what: str = ""):
     """EVERY parameter gradient of the HIP model against a reference gradient (the CPU oracle's, evaluated in the calling test):
     per tensor |got - ref|_inf <= atol + rtol |ref|_inf.  `named`: dict(model.named_parameters()); `ref_grads`: name -> tensor or

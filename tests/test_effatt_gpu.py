@@ -1,5 +1,5 @@
-"""Fused EfficientAttention block (tc_effatt_fwd / tc_effatt_bwd) against a plain torch fp32 statement of
-MSTr.py:80-143 + :166-167  (tx = x + attn(norm1(x)), one head).  Tolerances: the maps are stored in bf16 / fp16
+"""Fused EfficientAttention block (tc_effatt_fwd / tc_effatt_bwd) against the pinned CPU oracle's statement of
+MSTr.py:80-143 + :166-167  (tx = x + attn(norm1(x)), one head), evaluated on the stored (rounded) inputs in fp32.  Tolerances: the maps are stored in bf16 / fp16
 (2^-8 / 2^-11 relative) and pass through five chained 64-deep products; 2 % (bf16) and 0.5 % (fp16) of the
 reference's maximum per tensor, stated per assert."""
 import ctypes as C
@@ -11,17 +11,17 @@ pytestmark = pytest.mark.gpu
 
 
 def _ref(t, P, B, N, eps=1e-5):
+    """tx = x + attn(norm1(x)) through the pinned CPU oracle (oracle/transception_oracle.py: layernorm + efficient_attention, the
+    restatement of MSTr.py:80-143 that tests/test_oracle_golden.py holds to the reference's own outputs) -- one source of truth."""
+    from oracle.transception_oracle import TransCeptionOracle
     c = t.shape[1]
-    n1 = torch.nn.functional.layer_norm(t, (c,), P["gamma"], P["beta"], eps)
-    k = (n1 @ P["wk"].t() + P["bk"]).view(B, N, c)
-    q = (n1 @ P["wq"].t() + P["bq"]).view(B, N, c)
-    v = (n1 @ P["wv"].t() + P["bv"]).view(B, N, c)
-    ksm = torch.softmax(k, dim=1)            # over the tokens (MSTr.py:117 softmax(dim=2) of [B, C, N])
-    qsm = torch.softmax(q, dim=2)            # over the channels (MSTr.py:119 softmax(dim=1) of [B, C, N])
-    ctx = ksm.transpose(1, 2) @ v            # [B, C, C]   (MSTr.py:122 key @ value^T)
-    att = qsm @ ctx                          # [B, N, C]   (MSTr.py:123 context^T @ query)
-    out = att.reshape(B * N, c) @ P["wr"].t() + P["br"] + t
-    return out, ctx
+    names = {"gamma": "blk.norm1.weight", "beta": "blk.norm1.bias", "wk": "blk.attn.keys.weight", "bk": "blk.attn.keys.bias",
+             "wq": "blk.attn.queries.weight", "bq": "blk.attn.queries.bias", "wv": "blk.attn.values.weight", "bv": "blk.attn.values.bias",
+             "wr": "blk.attn.reprojection.weight", "br": "blk.attn.reprojection.bias"}
+    orc = TransCeptionOracle({names[k]: v for k, v in P.items()}, 9, training=True)
+    t3 = t.view(B, N, c)
+    out = t3 + orc.efficient_attention(orc.layernorm(t3, "blk.norm1", eps), "blk.attn")
+    return out.reshape(B * N, c), orc.taps["blk.attn.ctx"]
 
 
 NAMES = ["gamma", "beta", "wk", "bk", "wq", "bq", "wv", "bv", "wr", "br"]

@@ -179,6 +179,9 @@ def _lowp_vs_fp32(sd, ncls, dt, name, scale, x, lab, m32, lc, hl, fp16_tight=Fal
     assert dmax <= 0.1 and abs(l_loss - hl) < 1e-2 and cos >= 0.99 and bool(torch.isfinite(gl).all()), name
     if fp16_tight:
         assert dmax <= 0.02 and cos >= 0.9995
+    if scale == 1.0:                                      # per tensor as well (the fp16 arena holds loss-scaled values: global check only)
+        n, w = check_all_grads_lowp(dict(ml.named_parameters()), dict(m32.named_parameters()), rel_l2=BF16_REL_L2, cos_min=BF16_COS, what=f"{name} vs fp32 HIP: ")
+        print(f"{name} vs fp32: all {n} gradient tensors within rel L2 {BF16_REL_L2} / cosine {BF16_COS}; worst rel L2 {w[0]:.4f} ({w[1]})")
 
 
 def test_config4_512_binary_full_batch_b8():
