@@ -13,11 +13,12 @@ o = torch.empty_like(q); do = torch.randn(rows, d, device=dev).to(dtype)
 dq = torch.empty_like(q); dkv = torch.empty_like(kv)
 lse = torch.empty(rows, device=dev); delta = torch.empty(rows, device=dev); dkv32 = torch.empty(8 * B * Nk * 128, device=dev)   # TC_ATTN_DKV_SPLITS partial buffers
 nqc = (C.c_int * 4)(*nq)
+QS = 0 if ("--unscaled" in sys.argv or dtype == torch.float32) else 1   # 1: Q handed over as q * scale * log2(e) (what the model does: the hand-scheduled forward)
 st = torch.cuda.current_stream().cuda_stream
 k, v = kv[:, :d], kv[:, d:]
-def fwd(): L.tc_attn_fwd_seg(q.data_ptr(), d, k.data_ptr(), 2 * d, v.data_ptr(), 2 * d, Nk * 2 * d, o.data_ptr(), d, lse.data_ptr(), B, 4, nqc, Nk, 0.125, 0, dt, st)
+def fwd(): L.tc_attn_fwd_seg(q.data_ptr(), d, k.data_ptr(), 2 * d, v.data_ptr(), 2 * d, Nk * 2 * d, o.data_ptr(), d, lse.data_ptr(), B, 4, nqc, Nk, 0.125, QS, dt, st)
 def bwd(): L.tc_attn_bwd_seg(q.data_ptr(), d, k.data_ptr(), 2 * d, v.data_ptr(), 2 * d, Nk * 2 * d, o.data_ptr(), d, do.data_ptr(), d, lse.data_ptr(), delta.data_ptr(), dkv32.data_ptr(),
-                             dq.data_ptr(), d, dkv.data_ptr(), 2 * d, dkv[:, d:].data_ptr(), 2 * d, Nk * 2 * d, B, 4, nqc, Nk, 0.125, 0, dt, st)
+                             dq.data_ptr(), d, dkv.data_ptr(), 2 * d, dkv[:, d:].data_ptr(), 2 * d, Nk * 2 * d, B, 4, nqc, Nk, 0.125, QS, dt, st)
 for name, fn, fl in (("fwd", fwd, 4.0 * rows * Nk * d), ("bwd", bwd, 10.0 * rows * Nk * d)):
     for _ in range(5): fn()
     torch.cuda.synchronize()

@@ -492,7 +492,10 @@ __device__ unsigned long long g_dkv_dbg[512 * 4];
 #define DSTAMP(k)
 #define DSTAMP_INIT()
 #endif
-template <typename H, int NW>
+// QSC (Q stored as q * scale * log2(e), `qs` = 1): the stage keeps -lse * log2(e) and -delta, and they are the INITIAL values of
+// the S and dP accumulators -- P = exp2(S), dS = P dP' with no multiply-add per score (a third of the kernel's VALU work, which
+// shares the SIMD's issue slots with the MFMAs); the factor ln 2 of dK (`scale`) is applied once to the accumulators at the end.
+template <typename H, int NW, bool QSC>
 __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
                                                                     const bf16_t* __restrict__ V, int ldv, long long skv,
                                                                     const bf16_t* __restrict__ dO, int lddo, const float* __restrict__ lse,
@@ -565,7 +568,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16
             locate(t0 + (tid >> 5), base, valid);
             const bool okr = (tid & 31) < valid;
             lr = okr ? lse[base + (tid & 31)] * LOG2E : 1.0e30f;          // rows past the end: P = exp2(s - 1e30) = 0
-            dr = okr ? delta[base + (tid & 31)] * scale : 0.f;
+            dr = okr ? delta[base + (tid & 31)] * (QSC ? 1.0f : scale) : 0.f;
+            if (QSC) { lr = -lr; dr = -dr; }
         }
     };
     auto stash = [&](int buf) {
@@ -599,18 +603,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16
         const float* dls = lss + QS;
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-            f32x16 s, dp;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-            const bf16_t* qp = Qs + (32 * qt + key_row(qrow)) * LDQ + 8 * h;
-            const bf16_t* gp = dOs + (32 * qt + key_row(qrow)) * LDQ + 8 * h;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                s = TcHalf<H>::mfma(ld_frag<V8>(qp + 16 * ks), kf[ks], s);
-                dp = TcHalf<H>::mfma(ld_frag<V8>(gp + 16 * ks), vf[ks], dp);
-            }
             // the 16 log-sum-exps and (scaled) deltas of this lane's query rows: four 16-byte LDS reads each instead of 16 scalar ones
-            float lq[16], dq[16];
+            f32x16 lq, dq;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 a = *reinterpret_cast<const float4*>(lss + 32 * qt + 16 * h + 4 * g);
@@ -618,11 +612,30 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16
                 lq[4 * g] = a.x; lq[4 * g + 1] = a.y; lq[4 * g + 2] = a.z; lq[4 * g + 3] = a.w;
                 dq[4 * g] = c.x; dq[4 * g + 1] = c.y; dq[4 * g + 2] = c.z; dq[4 * g + 3] = c.w;
             }
+            f32x16 s, dp;
+            if (QSC) { s = lq; dp = dq; }                        // accumulators start at -lse log2(e) and -delta
+            else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+            }
+            const bf16_t* qp = Qs + (32 * qt + key_row(qrow)) * LDQ + 8 * h;
+            const bf16_t* gp = dOs + (32 * qt + key_row(qrow)) * LDQ + 8 * h;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                s = TcHalf<H>::mfma(ld_frag<V8>(qp + 16 * ks), kf[ks], s);
+                dp = TcHalf<H>::mfma(ld_frag<V8>(gp + 16 * ks), vf[ks], dp);
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = fast_exp2(fmaf(s[r], qs, -lq[r]));
-                dp[r] = p * fmaf(dp[r], scale, -dq[r]);          // dS = P (dP - delta) scale, delta pre-multiplied by scale at staging
-                s[r] = p;
+                if (QSC) {
+                    const float p = fast_exp2(s[r]);
+                    dp[r] *= p;                                  // dS / ln 2 = P (dP - delta)
+                    s[r] = p;
+                } else {
+                    const float p = fast_exp2(fmaf(s[r], qs, -lq[r]));
+                    dp[r] = p * fmaf(dp[r], scale, -dq[r]);      // dS = P (dP - delta) scale, delta pre-multiplied by scale at staging
+                    s[r] = p;
+                }
             }
             const int gi = lane & 15, gq = (lane >> 4) & 1, toff = (32 * qt + 16 * h + 4 * (gi >> 2)) * LDQ + 16 * gq + 4 * (gi & 3);
             const bf16_t* gt = dOs + toff;
@@ -650,8 +663,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int d = d_row(r, h);
-            red[d * 33 + j] = which ? dv0[r] : dk0[r];
-            red[(32 + d) * 33 + j] = which ? dv1[r] : dk1[r];
+            red[d * 33 + j] = which ? dv0[r] : dk0[r] * (QSC ? scale : 1.0f);
+            red[(32 + d) * 33 + j] = which ? dv1[r] : dk1[r] * (QSC ? scale : 1.0f);
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
@@ -844,8 +857,12 @@ extern "C" int tc_attn_bwd_seg(const void* Q, int ldq, const void* K, int ldk, c
         }                                                                                                                                   \
         hipLaunchKernelGGL(delta_rows_kernel<HH>, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, s, (const bf16_t*)O, ldo, (const bf16_t*)dO, \
                            lddo, delta, rows, wide_rows);                                                                                   \
-        hipLaunchKernelGGL((attn_bwd_dkv_seg_kernel<HH, 4>), dim3(kb, B, zs), dim3(256), 0, s, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk,    \
-                           (const bf16_t*)V, ldv, skv, (const bf16_t*)dO, lddo, lse, delta, dkv32, sg, Nk, kscale, qs, tpc);                \
+        if (qscaled)                                                                                                                        \
+            hipLaunchKernelGGL((attn_bwd_dkv_seg_kernel<HH, 4, true>), dim3(kb, B, zs), dim3(256), 0, s, (const bf16_t*)Q, ldq, (const bf16_t*)K, \
+                               ldk, (const bf16_t*)V, ldv, skv, (const bf16_t*)dO, lddo, lse, delta, dkv32, sg, Nk, kscale, qs, tpc);             \
+        else                                                                                                                                \
+            hipLaunchKernelGGL((attn_bwd_dkv_seg_kernel<HH, 4, false>), dim3(kb, B, zs), dim3(256), 0, s, (const bf16_t*)Q, ldq, (const bf16_t*)K, \
+                               ldk, (const bf16_t*)V, ldv, skv, (const bf16_t*)dO, lddo, lse, delta, dkv32, sg, Nk, kscale, qs, tpc);             \
         hipLaunchKernelGGL(attn_dkv_store_kernel<HH>, dim3(tc_blocks((long long)B * Nk * 32, 256, 1024)), dim3(256), 0, s, dkv32,           \
                            (bf16_t*)dK, lddk, (bf16_t*)dV, lddv, sdkv, B, Nk, zs);                                                              \
         hipLaunchKernelGGL(attn_bwd_dq_seg_kernel<HH>, dim3((unsigned)B * ((sg.t32[nseg] + FW_NW - 1) / FW_NW)), dim3(FW_NT), FW_SMEM, s,     \
