@@ -16,6 +16,10 @@ per-step HIP-event times is reported beside it (config.median_ms_per_step).  Ran
                 the per-launch event figure of instrumented eager steps (it includes the event-pair floor) is
                 roofline_in_step_events;
   roofline_gemm the time-dominant GEMM family (pair / merged / single launches): algorithmic bytes AND flops per launch;
+  roofline_step_dominant  the kernel with the largest share of the step (gemm_pair_kernel), same algorithmic work per launch over the
+                duration rocprofv3 reports for it inside the replayed step (profiles/r4_step_timeline.json);
+  step          the whole step: algorithmic TFLOP/s and fraction of the MFMA peak, memory-side GB/s from the committed PMC passes of
+                one replayed step and traffic_over_algorithmic;
   roofline_hbm  the memory-bound family with the largest share of the step, timed the same way, with its PMC traffic;
   cpu_baseline  the CPU oracle (a port of the reference arithmetic; the reference's Python cannot travel) timed on this box's
                 host cores on a bounded sample of the same workload (rank 0, N=1 only): median of 3 steps + the config-1 figure.
@@ -306,7 +310,8 @@ def main():
     launches = None if args.eager else (step.kernel_nodes() if hasattr(step, "kernel_nodes") else None)
     extra, roofs = {}, {}
     if rank == 0 and world == 1 and not args.no_side:
-        extra, roofs = side_figures(args, dev, model, loss_fn, opt, step, x, y, build_model, engine, train_step, GraphedStep, FusedSGD, SegLoss)
+        extra, roofs = side_figures(args, dev, model, loss_fn, opt, step, x, y, build_model, engine, train_step, GraphedStep, FusedSGD, SegLoss,
+                                     extra_step_seconds=(elapsed / args.steps,))
 
     if rank == 0:
         out = {
@@ -344,6 +349,10 @@ def main():
         os._exit(0)
 
 
+ATTN_KERNEL = ("attn_fwd_asm_kernel (bridge SR-attention forward, QK^T + softmax + PV fused, all 4 scales x B images in one launch; the "
+               "hand-scheduled gfx950 stream of csrc/gen_attn_asm.py -- TC_ATTN_FWD_ASM=0 selects the compiler-scheduled attn_fwd_seg_kernel)")
+
+
 def _graph_replay_us(fn, n: int, dev) -> float:
     """Average duration of fn's launches when n of them run back-to-back inside one replayed hipGraph (HIP events on the stream
     the graph is launched on)."""
@@ -364,7 +373,7 @@ def _graph_replay_us(fn, n: int, dev) -> float:
     return e0.elapsed_time(e1) * 1e3 / n
 
 
-def side_figures(args, dev, model, loss_fn, opt, step, x, y, build_model, engine, train_step, GraphedStep, FusedSGD, SegLoss):
+def side_figures(args, dev, model, loss_fn, opt, step, x, y, build_model, engine, train_step, GraphedStep, FusedSGD, SegLoss, extra_step_seconds=()):
     """Rank 0, one GPU, after the timed region: figures SURVEY.md 8(d) asks for beside the headline."""
     extra, roofs = {}, {}
     from transception_amd._lib import _Lib
@@ -404,8 +413,11 @@ def side_figures(args, dev, model, loss_fn, opt, step, x, y, build_model, engine
                 "how": "HIP events around each launch inside 3 instrumented (eager) training steps of the benchmarked workload; an event "
                        "pair around an empty kernel on the idle queue reads event_pair_floor_us, which every in-step figure includes -- the "
                        "kernel's own duration is roofline_graph_replay / the rocprofv3 average in profiles/"}
-    prof_file = next((f for f in ("r3_hbm_by_kernel.json", "r2_hbm_by_kernel.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), None)
-    pmc_doc = json.load(open(os.path.join(ROOT, "profiles", prof_file))).get("kernels", {}) if prof_file else {}
+    prof_file = next((f for f in ("r4_hbm_by_kernel.json", "r3_hbm_by_kernel.json", "r2_hbm_by_kernel.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), None)
+    pmc_all = json.load(open(os.path.join(ROOT, "profiles", prof_file))) if prof_file else {}
+    pmc_doc = pmc_all.get("kernels", {})
+    tl_file = next((f for f in ("r4_step_timeline.json", "r3_step_timeline.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), None)
+    tl_doc = json.load(open(os.path.join(ROOT, "profiles", tl_file))).get("kernels", {}) if tl_file else {}
     same_workload = args.dtype == "bf16" and args.batch == 16 and args.size == 224
 
     def pmc_traffic(prefixes):
@@ -420,13 +432,14 @@ def side_figures(args, dev, model, loss_fn, opt, step, x, y, build_model, engine
         return sum(v["bytes_per_step"] for v in hit) / n, (f"profiles/{prof_file} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of this workload, "
                                                             "scripts/pmc_step.sh; per launch, not measured in this run)")
     if prof.get("attn_fwd"):
-        r = mfma_block(prof["attn_fwd"], "attn_fwd_seg_kernel (bridge SR-attention forward, QK^T + softmax + PV fused, all 4 scales x B "
-                                         "images in one launch)")
+        r = mfma_block(prof["attn_fwd"], ATTN_KERNEL)
         r["traffic"], r["traffic_source"] = None, None
-        for name in ("r3_attn_pmc.json", "r2_attn_pmc.json", "r1_attn_pmc.json"):   # HBM bytes per launch: a separate rocprofv3 --pmc pass, committed
+        for name in ("r4_attn_pmc.json", "r2_attn_pmc.json", "r1_attn_pmc.json"):   # HBM bytes per launch: a separate rocprofv3 --pmc pass, committed
             pmc = os.path.join(ROOT, "profiles", name)
             if same_workload and os.path.exists(pmc):
-                r["traffic"] = json.load(open(pmc)).get("attn_fwd_seg_kernel", {}).get("hbm_bytes_corrected")
+                doc = json.load(open(pmc))
+                ent = doc.get("attn_fwd_asm_kernel") or doc.get("attn_fwd_seg_kernel") or {}
+                r["traffic"] = ent.get("hbm_bytes_corrected")
                 r["traffic_source"] = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE pass of this workload, not measured in this run)"
                 break
         roofs["roofline_in_step_events"] = r
@@ -456,6 +469,23 @@ def side_figures(args, dev, model, loss_fn, opt, step, x, y, build_model, engine
                                       "deep, i.e. HBM-bound (bound = hbm: algorithmic operand + result bytes / time), the MFMA figure is given beside it; every "
                                       "in-step figure includes event_pair_floor_us per launch")
         roofs["roofline_gemm_others"] = gem[1:]
+        # the step-dominant kernel beside the named (attention) one: the same algorithmic work per launch over the launch duration
+        # rocprofv3 reports for it inside the replayed step (no event-pair floor), from the committed timeline of this workload
+        dom = dict(gem[0])
+        names = PMC_GEMM[{"gemm_pair_kernel": "pair", "gemm_multi_kernel": "multi"}.get(dom["kernel"].split(" ")[0], "single")]
+        hit = [v for k, v in tl_doc.items() if any(k.startswith(q) for q in names)] if same_workload else []
+        if hit:
+            n_l, ms_l = sum(v["launches"] for v in hit), sum(v["ms"] for v in hit)
+            us = 1e3 * ms_l / n_l
+            dom.update(avg_launch_us=us, launches_per_step=n_l, ms_per_step=ms_l, share_of_step=ms_l / max(1e-9, sum(v["ms"] for v in tl_doc.values())),
+                       achieved=dom["algorithmic_bytes_per_launch"] / (us * 1e-6) / 1e9, duration_source=f"profiles/{tl_file} (rocprofv3 --kernel-trace of one replayed step)")
+            dom["frac"] = dom["achieved"] / PEAK_HBM_GBS
+            dom["achieved_tflops"] = dom["algorithmic_flops_per_launch"] / (us * 1e-6) / 1e12
+            dom["frac_of_mfma_peak"] = dom["achieved_tflops"] / peak
+            if dom.get("traffic"):
+                dom["traffic_over_algorithmic"] = dom["traffic"] / dom["algorithmic_bytes_per_launch"]
+        dom.pop("event_pair_floor_us", None)
+        roofs["roofline_step_dominant"] = dom
     PMC_HBM = {"ffn_mid_bwd": ("ffn_mid_bwd_kernel",), "ffn_fused_fwd": ("ffn_fused_fwd_kernel",), "ffn_fused_bwd": ("ffn_bwd_",), "ffn_dw_fwd": ("dw_tile_kernel", "dw_multi_kernel"),
                "layernorm_fwd": ("ln_fwd_kernel",), "layernorm_bwd": ("ln_bwd_kernel",), "dwconv_fwd": ("dw_tile_kernel", "dw_multi_kernel<bf16, 0>", "dw_kernel"),
                "dwconv_bwd_input": ("dw_tile_kernel<bf16, 3, 8, 1>", "dw_multi_kernel<bf16, 1>"), "dwconv_bwd_weight": ("dw_tile_wgrad_kernel", "dw_multi_wgrad_kernel", "dw_wgrad_kernel"),
@@ -478,6 +508,21 @@ def side_figures(args, dev, model, loss_fn, opt, step, x, y, build_model, engine
                                      "every result written once (the memory-bound family with the largest share of the step); traffic = memory-side bytes per "
                                      "launch of the family's kernels from the committed PMC passes")
         roofs["roofline_hbm_others"] = hbm[1:6]
+    # whole step: algorithmic work (16.88 GFLOP forward per 224^2 image, backward = 2x; fused-unit bytes 19.6 MB of bf16
+    # activations per image and 92.7 MB of weights per step, x3 for forward + backward) over the measured step, and the memory-side
+    # traffic of one replayed step from the committed PMC passes
+    if args.size == 224 and args.dtype in ("bf16", "f16"):
+        step_s = extra_step_seconds[0] if extra_step_seconds else None
+        if step_s:
+            fl = 3 * 16.88e9 * args.batch
+            alg_b = 3 * (19.6e6 * args.batch + 92.7e6)
+            st = {"algorithmic_flops_per_step": fl, "achieved_tflops": fl / step_s / 1e12, "frac_of_mfma_peak": fl / step_s / 1e12 / peak,
+                  "algorithmic_bytes_per_step": alg_b}
+            if same_workload and pmc_all.get("step_hbm_GB"):
+                tb = 1e9 * pmc_all["step_hbm_GB"]
+                st.update(traffic_bytes_per_step=tb, achieved_GBps=tb / step_s / 1e9, frac_of_hbm_peak=tb / step_s / 1e9 / PEAK_HBM_GBS,
+                          traffic_over_algorithmic=tb / alg_b, traffic_source=f"profiles/{prof_file} (2 x FETCH_SIZE + WRITE_SIZE over one replayed step)")
+            roofs["step"] = st
     # (2) forward-only rate (train-mode forward captured alone)
     with torch.no_grad():
         us = _graph_replay_us(lambda: model(x), 10, dev)
@@ -530,8 +575,7 @@ def side_figures(args, dev, model, loss_fn, opt, step, x, y, build_model, engine
         us = _graph_replay_us(attn, 30, dev)
         fl = 4.0 * rows * Nk * 64
         ins = roofs.get("roofline_in_step_events", {})
-        roofs["roofline"] = {"bound": "mfma", "kernel": "attn_fwd_seg_kernel (bridge SR-attention forward, QK^T + softmax + PV fused, all 4 scales x B images "
-                                                        "in one launch)",
+        roofs["roofline"] = {"bound": "mfma", "kernel": ATTN_KERNEL,
                              "achieved": fl / us / 1e6, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                              "frac": fl / us / 1e6 / PEAK_TFLOPS[args.dtype], "avg_launch_us": us, "algorithmic_flops_per_launch": fl,
                              "traffic": ins.get("traffic"), "traffic_source": ins.get("traffic_source"),
