@@ -49,7 +49,7 @@ class TransCeptionOracle:
         self.training = training
         # ablation switches of the reference constructor (MSTr.py:2760-2823) that this restatement follows: the aggregate of a
         # stage (:1384-1403), whether the bridge runs (:2840) and which bridge layers use channel attention (:2413-2420)
-        assert concat in ("coord", "normal") and have_bridge not in ("sp", "para") and len(br_ch_att_list) == 4
+        assert concat in ("coord", "normal") and have_bridge != "sp" and len(br_ch_att_list) == 4
         self.concat, self.have_bridge, self.br_ch_att_list = concat, have_bridge, tuple(bool(b) for b in br_ch_att_list)
         # running statistics are buffers: updated in place in training mode
         self.buffers = {k: v.clone() for k, v in params.items()
@@ -282,9 +282,16 @@ class TransCeptionOracle:
         B = maps[0].shape[0]
         h4 = maps[3].shape[1]
         t = torch.cat([m.reshape(B, -1, 64) for m in maps], dim=1)
-        for i, ch_att in enumerate(self.br_ch_att_list):
-            t = self.bridge_layer(t, f"bridge.bridge_layer{i + 1}", ch_att, h4)
-            self.taps[f"bridge{i + 1}"] = t
+        if self.have_bridge == "para":                      # BridgeBlock_para, MSTr.py:2500-2524 (BridgLayer_para = BridgLayer_4's arithmetic)
+            b1 = self.bridge_layer(t, "bridge.bridge_layer1", True, h4)
+            b2 = self.bridge_layer(t, "bridge.bridge_layer2", False, h4)
+            d = F.gelu(self.layernorm(self.linear(torch.cat([b1, b2], dim=2), "bridge.proj_act.0"), "bridge.proj_act.1"))
+            t = self.bridge_layer(self.bridge_layer(d, "bridge.bridge_layer3", False, h4), "bridge.bridge_layer4", False, h4)
+            self.taps["bridge4"] = t
+        else:
+            for i, ch_att in enumerate(self.br_ch_att_list):
+                t = self.bridge_layer(t, f"bridge.bridge_layer{i + 1}", ch_att, h4)
+                self.taps[f"bridge{i + 1}"] = t
         outs, off = [], 0
         for side, mult, ntok in self.stage_tokens(h4):
             outs.append(t[:, off:off + ntok].reshape(B, side, side, 64 * mult))

@@ -4,7 +4,7 @@ import csv, glob, json, sys, collections
 out, dirs = sys.argv[1], sys.argv[2:]
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for d in dirs:
-    for f in glob.glob(d + '/*/*counter_collection.csv'):
+    for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
         for r in csv.DictReader(open(f)):
             n = r['Kernel_Name']
             import re

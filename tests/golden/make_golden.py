@@ -237,6 +237,10 @@ VARIANTS = {   # name -> (constructor kwargs, gradient probes)
                     ["backbone.mhca_stage4.aggregate.conv_h.weight", "bridge.bridge_layer2.attn.k.weight",
                      "bridge.bridge_layer3.attn.scale_reduce.sr0.weight", "bridge.bridge_layer4.attn.proj.weight",
                      "bridge.bridge_layer4.mixffn2.fc1.weight", "decoder_0.last_layer.weight"]),
+    "bridge_para": (dict(have_bridge="para"),
+                    ["backbone.mhca_stage3.aggregate.conv1.weight", "bridge.bridge_layer1.attn.q.weight", "bridge.bridge_layer2.attn.kv.weight",
+                     "bridge.proj_act.0.weight", "bridge.proj_act.0.bias", "bridge.proj_act.1.weight", "bridge.bridge_layer3.mixffn4.fc2.weight",
+                     "bridge.bridge_layer4.attn.proj.bias", "decoder_0.last_layer.weight"]),
 }
 
 

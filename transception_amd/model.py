@@ -262,19 +262,30 @@ class MSTransception(nn.Module):
         #   have_bridge  "original" (default) | "None" (the bridge is built -- its parameters stay in the state_dict -- but skipped, :2840)
         #   br_ch_att_list  which of the four bridge layers use channel attention instead of SR self-attention (:2413-2420)
         # use_sa_config / sa_ker / inter / num_sp only reach the "cbam", "sp" and "para" variants and are accepted and ignored, as in
-        # the reference.  Not built: concat in {3d, se, skn, cbam, cam}, have_bridge in {sp, para}, Stage_3or4 != 3,
+        #                | "para" (BridgeBlock_para, :2500-2538: channel and spatial layer side by side, Linear(128->64)+LN+GELU, two
+        #                  more spatial layers)
+        # the reference.  Not built: concat in {3d, se, skn, cbam, cam}, have_bridge = sp, Stage_3or4 != 3,
         # token_mlp_mode != "mix_skip", and the legacy networks/Transception.py class.
         br = [bool(b) for b in br_ch_att_list]
-        if (token_mlp_mode != "mix_skip" or concat not in ("coord", "normal") or have_bridge in ("sp", "para") or Stage_3or4 != 3
+        if (token_mlp_mode != "mix_skip" or concat not in ("coord", "normal") or have_bridge == "sp" or Stage_3or4 != 3
                 or len(br) != 4):
             raise NotImplementedError("MSTransception: implemented are concat in {'coord', 'normal'}, have_bridge in {'original', "
-                                      "'None'}, any 4-entry br_ch_att_list, Stage_3or4 = 3, token_mlp_mode = 'mix_skip'")
+                                      "'None', 'para'}, any 4-entry br_ch_att_list, Stage_3or4 = 3, token_mlp_mode = 'mix_skip'")
+        if have_bridge == "para":                       # BridgeBlock_para ignores br_ch_att_list (it receives num_sp, MSTr.py:2806-2807):
+            br = [True, False, False, False]            # layer 1 channel, layers 2-4 spatial (MSTr.py:2504-2512)
         self.concat, self.have_bridge, self.br_ch_att_list = concat, have_bridge, br
         self.num_classes = num_classes
         self.backbone = _mk_backbone(concat)
         self.bridge = nn.Module()
-        for i, ch in enumerate(br):
-            setattr(self.bridge, f"bridge_layer{i + 1}", _mk_bridge_layer(64, ch))
+        if have_bridge == "para":                       # constructor order of BridgeBlock_para: layers 1, 2, proj_act, layers 3, 4
+            self.bridge.bridge_layer1 = _mk_bridge_layer(64, True)
+            self.bridge.bridge_layer2 = _mk_bridge_layer(64, False)
+            self.bridge.proj_act = nn.Sequential(nn.Linear(128, 64), nn.LayerNorm(64), nn.GELU())
+            self.bridge.bridge_layer3 = _mk_bridge_layer(64, False)
+            self.bridge.bridge_layer4 = _mk_bridge_layer(64, False)
+        else:
+            for i, ch in enumerate(br):
+                setattr(self.bridge, f"bridge_layer{i + 1}", _mk_bridge_layer(64, ch))
         ioc = [[32, 64, 64, 64], [144, 128, 128, 128], [288, 320, 320, 320], [512, 512, 512, 512]]
         self.decoder_3 = _mk_decoder_layer(ioc[3], num_classes, False)
         self.decoder_2 = _mk_decoder_layer(ioc[2], num_classes, False)
@@ -905,7 +916,18 @@ def _forward(M: MSTransception, G: Graph, x: torch.Tensor, B: int, in_ch: int, S
     if tap:
         for s in range(4):
             M.taps[f"enc{s}"] = stage_map(Xb, s).data.float().view(B, sides[s], sides[s], 64 * MULT[s]).clone()
-    if M.have_bridge != "None":                                   # MSTr.py:2840
+    if M.have_bridge == "para":                                   # BridgeBlock_para.forward, MSTr.py:2514-2524
+        b1 = _bridge_layer(M, G, X, 1, B, sides, ntok, R, N6)      # channel attention and ...
+        b2 = _bridge_layer(M, G, X, 2, B, sides, ntok, R, N6)      # ... spatial attention on the same input
+        Wp, bp = _lin(M, G, "bridge.proj_act.0")                   # Linear over cat([b1, b2], channels) = two accumulating products
+        y = G.linear(b1, Wp, bp, wcols=(0, 64))
+        G.linear(b2, Wp, None, wcols=(64, 128), out=y, accumulate=True)
+        X = _ln(M, G, y, "bridge.proj_act.1", act=ACT_GELU)
+        for li in (3, 4):
+            X = _bridge_layer(M, G, X, li, B, sides, ntok, R, N6)
+        if tap:
+            M.taps["bridge4"] = image_major(X)
+    elif M.have_bridge != "None":                                 # MSTr.py:2840
         for li in range(1, 5):
             X = _bridge_layer(M, G, X, li, B, sides, ntok, R, N6)
             if tap:
