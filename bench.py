@@ -198,6 +198,9 @@ def main():
     ap.add_argument("--loader", action="store_true",
                     help="feed the timed steps from transception_amd.data.DeviceLoader (synthetic Synapse npz files on local disk -> "
                          "HBM -> device augmentation/resize) instead of one HBM-resident batch; the default keeps BASELINE's definition")
+    ap.add_argument("--comm-plan", type=int, default=8, metavar="N",
+                    help="attach config.comm_plan: what a data-parallel step of N GPUs would send (pieces, buckets, expected xGMI ring time) -- "
+                         "computed on this rank, nothing is sent")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -335,6 +338,9 @@ def main():
             out["config"]["collective_backend"] = backend + (" (all ranks on one GPU: drill, not a measurement)" if one_gpu_drill else "") + \
                 (" (one rank: the split step's collectives run on a 1-rank communicator -- the N=1 floor of allreduce_exposed_ms)" if rccl1 else "")
             out["config"]["allreduce_exposed_ms"] = exposed
+        if args.comm_plan > 1:
+            from transception_amd.train import comm_plan
+            out["config"]["comm_plan"] = comm_plan(model, max(world, args.comm_plan) if world == 1 else world)
         out.update(roofs)
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.batch, args.size)

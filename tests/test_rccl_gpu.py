@@ -84,3 +84,25 @@ def test_bench_force_split_runs_on_a_one_rank_rccl_group():
     assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1 and out["config"]["collective_backend"].startswith("nccl")
     assert out["config"]["allreduce_exposed_ms"] is not None and out["value"] > 0
     assert out["config"]["launches_per_step"] is None or out["config"]["launches_per_step"] > 100
+
+
+def test_comm_plan_covers_every_live_gradient_once():
+    """train.comm_plan (the dry description of what an N-GPU step sends): its pieces partition the live part of the gradient arena --
+    every bucket element of gradient_buckets() appears in exactly one piece -- and the expected ring times follow from the bytes."""
+    from transception_amd import MSTransception
+    from transception_amd.seeded_init import seeded_input, seeded_labels, seeded_state_dict
+    from transception_amd.train import SegLoss, comm_plan, gradient_buckets
+    m = MSTransception(num_classes=9)
+    m.load_state_dict(seeded_state_dict(), strict=True)
+    m.to("cuda:0").train()
+    loss, _, _ = SegLoss(9)(m(torch.from_numpy(seeded_input(1)).to("cuda:0")), torch.from_numpy(seeded_labels(1)).to("cuda:0"))
+    loss.backward()
+    plan = comm_plan(m, 8)
+    live = sum(b - a for a, b in gradient_buckets(m))
+    sent = sorted((a, b) for p in plan["pieces"] for a, b in p["buckets_elements"])
+    assert sum(b - a for a, b in sent) == live and all(sent[i][1] <= sent[i + 1][0] for i in range(len(sent) - 1))
+    assert abs(plan["gradient_megabytes_per_step"] - 4 * live / 1e6) < 1e-9 and plan["ranks"] == 8
+    assert plan["pieces"][0]["sent_when_backward_reaches"] == "encoder_done" and plan["pieces"][-1]["sent_when_backward_reaches"].startswith("end")
+    assert plan["total_ring_ms_one_link"] > plan["total_ring_ms_seven_links"] > 0
+    live_params = sum(p.numel() for p in m.parameters() if p.grad is not None)
+    assert live >= live_params                                    # buckets merge small gaps; nothing live is left out

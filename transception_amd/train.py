@@ -232,6 +232,34 @@ def clip_buckets(buckets, ranges):
     return sorted(out)
 
 
+XGMI_LINK_GBS, XGMI_LINKS, RING_HOP_US = 153.0, 7, 6.0     # MI355X: 7 point-to-point links per GPU; per-hop latency of a ring step (assumed)
+
+
+def comm_plan(model, n_ranks: int):
+    """What a data-parallel step of `n_ranks` GPUs sends, without sending it: the pieces of the split backward sweep
+    (model.gradient_pieces), the all-reduce buckets inside each (fp32 elements of the flat gradient arena, the grad-less tensors left
+    out), and the time a ring all-reduce of each would take over xGMI -- a ring moves 2 (N-1)/N of the bytes through every GPU and is
+    bound by ONE link per direction (153 GB/s) unless RCCL runs one ring per link (7), so both bounds are given, plus 2 (N-1) hops of
+    latency per collective.  Lets the first multi-GPU run be read against an expectation."""
+    buckets = gradient_buckets(model)
+    out, tot = [], 0
+    f = 2.0 * (n_ranks - 1) / max(n_ranks, 1)
+    for stop, ranges in model.gradient_pieces():
+        bs = clip_buckets(buckets, ranges)
+        nbytes = 4 * sum(b - a for a, b in bs)
+        tot += nbytes
+        lat = 2 * (n_ranks - 1) * RING_HOP_US * 1e-3 * len(bs)
+        out.append({"sent_when_backward_reaches": stop or "end of backward (exposed)", "collectives": len(bs),
+                    "buckets_elements": [[int(a), int(b)] for a, b in bs], "megabytes": nbytes / 1e6,
+                    "ring_ms_one_link": f * nbytes / (XGMI_LINK_GBS * 1e9) * 1e3 + lat,
+                    "ring_ms_seven_links": f * nbytes / (XGMI_LINK_GBS * XGMI_LINKS * 1e9) * 1e3 + lat})
+    return {"ranks": n_ranks, "pieces": out, "gradient_megabytes_per_step": tot / 1e6, "loss_sums_bytes": 28 * 4,
+            "total_ring_ms_one_link": sum(p["ring_ms_one_link"] for p in out), "total_ring_ms_seven_links": sum(p["ring_ms_seven_links"] for p in out),
+            "exposed_ring_ms_one_link": out[-1]["ring_ms_one_link"], "exposed_ring_ms_seven_links": out[-1]["ring_ms_seven_links"],
+            "model": "ring all-reduce: 2 (N-1)/N x bytes per GPU over 153 GB/s per xGMI link (one ring) or 7 links (one ring per link), + 2 (N-1) "
+                     "hops x 6 us per collective; every piece but the last travels under the rest of the backward sweep"}
+
+
 def allreduce_gradients(model, group=None, part: Optional[str] = None, async_op: bool = False, ranges=None):
     """C1: all-reduce(sum) of the live parts of the flat gradient arena over RCCL/xGMI (gloo in CPU tests): a handful of
     large buckets, every rank the same ones (the used set is a property of the architecture).  part="late" / "early" sends only
