@@ -284,6 +284,7 @@ template <typename TS, typename TD>
 __global__ void cast_kernel(const TS* s, TD* d, long long n) { TC_GRID_STRIDE64(i, n) stf<TD>(d + i, ldf<TS>(s + i)); }
 
 inline dim3 g1(long long n) { return n < 0x7fffffffLL ? dim3(tc_blocks(n, 256, 8192)) : dim3(0); }     // (an empty grid is a launch error: reported)
+inline dim3 g1_64(long long n) { return dim3(tc_blocks(n, 256, 8192)); }                                // kernels on the 64-bit TC_GRID_STRIDE64 loop (cast, sigmoid')
 
 }  // namespace
 
@@ -313,7 +314,7 @@ extern "C" int tc_add(const void* a, int lda, const void* b, int ldb, void* y, i
 }
 extern "C" int tc_sigmoid_bwd(const void* dy, const void* s, void* dz, long long n, int dtype, void* stream) {
     if (!dy || !s || !dz || n <= 0) return TC_ERR_ARG;
-    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((sigmoid_bwd_kernel<T>), g1(n), dim3(256), 0, TC_S, (const T*)dy, (const T*)s, (T*)dz, n));
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((sigmoid_bwd_kernel<T>), g1_64(n), dim3(256), 0, TC_S, (const T*)dy, (const T*)s, (T*)dz, n));
     return tc_launch_status();
 }
 extern "C" int tc_copy3d(const void* src, long long sbs, int lds, void* dst, long long sbd, int ldd, int nb, int rows, int cols,
@@ -416,13 +417,13 @@ extern "C" int tc_stem_im2col(const void* img, void* cols, int ldc, int B, int i
 extern "C" int tc_cast(const void* src, void* dst, long long n, int src_dtype, int dst_dtype, void* stream) {
     if (!src || !dst || n <= 0) return TC_ERR_ARG;
     if (src_dtype == TC_F32 && dst_dtype == TC_BF16)
-        hipLaunchKernelGGL((cast_kernel<float, bf16_t>), g1(n), dim3(256), 0, TC_S, (const float*)src, (bf16_t*)dst, n);
+        hipLaunchKernelGGL((cast_kernel<float, bf16_t>), g1_64(n), dim3(256), 0, TC_S, (const float*)src, (bf16_t*)dst, n);
     else if (src_dtype == TC_BF16 && dst_dtype == TC_F32)
-        hipLaunchKernelGGL((cast_kernel<bf16_t, float>), g1(n), dim3(256), 0, TC_S, (const bf16_t*)src, (float*)dst, n);
+        hipLaunchKernelGGL((cast_kernel<bf16_t, float>), g1_64(n), dim3(256), 0, TC_S, (const bf16_t*)src, (float*)dst, n);
     else if (src_dtype == TC_F32 && dst_dtype == TC_F16)
-        hipLaunchKernelGGL((cast_kernel<float, f16_t>), g1(n), dim3(256), 0, TC_S, (const float*)src, (f16_t*)dst, n);
+        hipLaunchKernelGGL((cast_kernel<float, f16_t>), g1_64(n), dim3(256), 0, TC_S, (const float*)src, (f16_t*)dst, n);
     else if (src_dtype == TC_F16 && dst_dtype == TC_F32)
-        hipLaunchKernelGGL((cast_kernel<f16_t, float>), g1(n), dim3(256), 0, TC_S, (const f16_t*)src, (float*)dst, n);
+        hipLaunchKernelGGL((cast_kernel<f16_t, float>), g1_64(n), dim3(256), 0, TC_S, (const f16_t*)src, (float*)dst, n);
     else return TC_ERR_ARG;
     return tc_launch_status();
 }

@@ -167,6 +167,10 @@ def _workspace(device, stream_ptr: int, tag: str = "") -> torch.Tensor:
     # concurrently, so they share ONE workspace -- a workspace per stream pointer was created (and zero-filled: 134 MB for the
     # "many" one) INSIDE the capture of a step, whose stream is new, and the fill was replayed with every step.
     key = (str(device), int(stream_ptr or 0) if Graph.use_streams else 0, tag)
+    # CONSTRAINT: this holds only while the engine launches of a device are serialized -- one training / evaluation loop at a
+    # time.  Two loops driving the engine concurrently on one device (an evaluation thread beside the training thread, two models on two
+    # streams) would share split-K counters and partial tiles; run them with TC_STREAMS=1 (a workspace per stream) or one after the
+    # other.  (Not asserted here: autograd runs the backward of a step on its own worker thread, so thread identity says nothing.)
     ws = _WORKSPACES.get(key)
     if ws is None:
         ws = _WORKSPACES[key] = torch.zeros(WORKSPACE_BYTES * (8 if tag == "many" else 1), dtype=torch.uint8, device=device)
@@ -965,7 +969,12 @@ class Graph:
             return TcEwSeg(EW_COPY, acc, src.data_ptr(), g.data_ptr(), sb_src, sb_dst, src.stride(0), g.stride(0), nb, M, N, 0, 0, 0)
         self.L.tc_copy3d(_ptr(src), sb_src, src.stride(0), _ptr(g), sb_dst, g.stride(0), nb, M, N, acc, self.dt, self.stream)
 
-    def effatt_supported(self, t: Var) -> bool:
+    def effatt_supported(self, t: Var, params: Optional[Tuple[P, ...]] = None) -> bool:
+        """params: the ten parameters of the block.  The fused backward writes the input gradient and all ten parameter gradients in its
+        launches, so when recording a backward every one of them (and t) must take a gradient -- a frozen norm / projection falls back to
+        the op-by-op path, which handles any subset."""
+        if self.record and (not t.requires_grad or (params is not None and any(p.grad is None for p in params))):
+            return False
         return (_EFFATT_FUSED and self.ngroups == 1 and not self.use_streams and self.dt != TC_F32
                 and bool(self.L.tc_effatt_supported(t.cols, self.dt)) and t.data.is_contiguous())
 

@@ -599,10 +599,11 @@ def _eff_attention(M, G, n1: Var, name: str, B: int, N: int, residual: Optional[
 
 def _eff_block(M, G, t: Var, name: str, B: int, H: int, W: int) -> Var:
     """EfficientTransformerBlock, MSTr.py:164-173."""
-    if G.effatt_supported(t):
-        a = name + ".attn"
-        tx = G.eff_attention_block(t, (M._P(G, name + ".norm1.weight"), M._P(G, name + ".norm1.bias")), _lin(M, G, a + ".keys"),
-                                   _lin(M, G, a + ".queries"), _lin(M, G, a + ".values"), _lin(M, G, a + ".reprojection"), B, H * W)
+    a = name + ".attn"
+    blk = ((M._P(G, name + ".norm1.weight"), M._P(G, name + ".norm1.bias")), _lin(M, G, a + ".keys"), _lin(M, G, a + ".queries"),
+           _lin(M, G, a + ".values"), _lin(M, G, a + ".reprojection"))
+    if G.effatt_supported(t, tuple(p for pair in blk for p in pair)):
+        tx = G.eff_attention_block(t, *blk, B, H * W)
     else:
         tx = _eff_attention(M, G, _ln(M, G, t, name + ".norm1"), name + ".attn", B, H * W, residual=t)
     return _mixffn(M, G, tx, name + ".mlp", B, H, W, residual=tx, pre_ln=(name + ".norm2", 1e-5))

@@ -133,6 +133,18 @@ class FusedSGD:
         self.grad_scale = 1.0                            # gradients in the arena are this many times too small (1 / loss scale)
         self.guard_overflow: Optional[bool] = None       # skip the update when the gradient norm is not finite; None: on for float16 storage
 
+        self.skipped_steps = 0                           # updates found skipped by last_step_skipped() (read back at the caller's log cadence)
+
+    def last_step_skipped(self) -> bool:
+        """True when the last update was skipped because the gradient norm was not finite (float16 overflow under a static loss scale:
+        sgd_multi_kernel returns without touching the weights).  Reads one float back (a host sync): call it where the loop already
+        reads its loss scalars; a run whose every step overflows would otherwise look like a plateau."""
+        if self._sumsq is None:
+            return False
+        skipped = not math.isfinite(float(self._sumsq.item()))
+        self.skipped_steps += int(skipped)
+        return skipped
+
     def set_lr(self, lr: float):
         self.lr = lr
         if self.lr_dev is not None:

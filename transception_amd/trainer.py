@@ -121,6 +121,9 @@ def trainer_synapse(cfg: TrainConfig, model, snapshot_path: str, volumes: Option
             hist["loss"].append(lv)
             hist["lr"].append(lr_at(iter_num))
             log('iteration %d : lr: %f, loss : %f, loss_ce: %f, loss_dice: %f' % (iter_num, lr_at(iter_num), lv, cv, dv))
+            if opt.last_step_skipped():                           # float16: a non-finite gradient norm skips the update (no weights were touched)
+                log('iteration %d : update SKIPPED, gradient norm not finite (%d skipped so far; lower the loss scale if this persists)'
+                    % (iter_num, opt.skipped_steps))
         if iter_num % per_epoch == 0:
             epoch_num = iter_num // per_epoch - 1
             if epoch_num in saves:
