@@ -54,9 +54,10 @@ def synthetic_batch(B: int, size: int, device, seed: int):
     return x.to(device), y.to(device)
 
 
-def _loader_feed(args, dev, rank: int, world: int, n_needed: int, out=None):
+def _loader_feed(args, dev, rank: int, world: int, n_needed: int, out=None, raw=False):
     """Generator of (x, y) batches from the device input pipeline over a synthetic Synapse-format training set written to local
-    disk (512x512 npz slices, dataset_synapse.py:103-107)."""
+    disk (512x512 npz slices, dataset_synapse.py:103-107).  raw: (loader, generator of raw batch slots) instead -- the consumer
+    captures the preprocessing launches at the head of its step graph (_loader_fed_step)."""
     import tempfile
     from transception_amd import data as D
     tmp = tempfile.mkdtemp(prefix=f"synapse_r{rank}_")
@@ -64,8 +65,24 @@ def _loader_feed(args, dev, rank: int, world: int, n_needed: int, out=None):
     ds = D.SynapseSlices(tmp + "/train_npz", tmp + "/lists")
     per_epoch = (len(ds) // (args.batch * world)) * args.batch * world
     loader = D.DeviceLoader(ds, args.batch, img_size=args.size, device=dev, seed=1234, rank=rank, world=world, augment=True,
-                            epochs=n_needed // per_epoch + 2, readers=8, out=out)
-    return iter(loader)
+                            epochs=n_needed // per_epoch + 2, readers=8, out=None if raw else out)
+    return (loader, loader.iter_raw(int(os.environ.get("TC_BENCH_LOADER_SLOTS", "3")))) if raw else iter(loader)
+
+
+def _loader_fed_step(args, dev, rank, world, n_needed, make_step):
+    """A step() fed by the device input pipeline with NOTHING eager between two step graphs: the raw batch (fp32 slices, uint8 labels,
+    augmentation records) lands in one of three static device slots under the previous step, and the augmentation / spline / zoom
+    launches are captured at the head of the step graph of that slot (one captured step per slot; make_step(pre) builds it)."""
+    loader, it = _loader_feed(args, dev, rank, world, n_needed, raw=True)
+    steps = {}
+
+    def step():
+        slot = next(it)
+        st = steps.get(slot["index"])
+        if st is None:
+            st = steps[slot["index"]] = make_step(loader.slot_preprocess(slot))
+        return st()
+    return step, steps, it
 
 
 # ----------------------------------------------------------------------------------------------------------------- CPU baseline
@@ -271,9 +288,11 @@ def main():
         step = GraphedStep(model, loss_fn, opt, x, y, group, warmup=2, force_split=args.force_split)   # capture, then replay
     feed = None
     if args.loader and not args.eager:
-        feed = _loader_feed(args, dev, rank, world, (args.steps + args.warmup) * args.batch * world, out=(step.x, step.y))
         step_resident = step
-        step = lambda: step_resident(*next(feed))
+        step, fed_steps, feed = _loader_fed_step(args, dev, rank, world, (args.steps + args.warmup + 4) * args.batch * world,
+                                                 lambda pre: GraphedStep(model, loss_fn, opt, x, y, group, warmup=1, force_split=args.force_split, pre=pre))
+        for _ in range(3):                                       # every slot's step graph is captured before the warm-up / timed steps
+            step()
     for i in range(args.warmup):
         step()
         opt.set_lr(cosine_lr(0.05, i + 1, t_max))
@@ -288,8 +307,10 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    fed_launches = None
     if feed is not None:
         feed.close()
+        fed_launches = next(iter(fed_steps.values())).kernel_nodes()
         step = step_resident
     exposed = None
     if comm:
@@ -310,7 +331,7 @@ def main():
             dist.broadcast(model.flat_parameters(), src=0)       # the ranks' un-reduced updates diverged: not used afterwards
             model.invalidate_working_copy()
 
-    launches = None if args.eager else (step.kernel_nodes() if hasattr(step, "kernel_nodes") else None)
+    launches = None if args.eager else (fed_launches or (step.kernel_nodes() if hasattr(step, "kernel_nodes") else None))
     extra, roofs = {}, {}
     if rank == 0 and world == 1 and not args.no_side:
         extra, roofs = side_figures(args, dev, model, loss_fn, opt, step, x, y, build_model, engine, train_step, GraphedStep, FusedSGD, SegLoss,
@@ -549,16 +570,19 @@ def side_figures(args, dev, model, loss_fn, opt, step, x, y, build_model, engine
         del s32, m32, o32
     # (4) the same graphed step fed by the device input pipeline (npz -> HBM -> augment/resize), SURVEY 8(f)-1
     if not args.eager and not args.loader and args.size == 224:
-        f2 = _loader_feed(args, dev, 0, 1, 24 * args.batch, out=(step.x, step.y))
+        fstep, fsteps, f2 = _loader_fed_step(args, dev, 0, 1, 28 * args.batch,
+                                              lambda pre: GraphedStep(model, loss_fn, opt, x, y, None, warmup=1, pre=pre))
         for _ in range(4):
-            step(*next(f2))
+            fstep()
         torch.cuda.synchronize(dev)
         tl = time.perf_counter()
         for _ in range(20):
-            step(*next(f2))
+            fstep()
         torch.cuda.synchronize(dev)
         extra["loader_fed_images_per_sec"] = args.batch * 20 / (time.perf_counter() - tl)
+        extra["loader_fed_launches_per_step"] = next(iter(fsteps.values())).kernel_nodes()
         f2.close()
+        del fsteps, fstep
     # (5) the roofline kernel back-to-back inside a replayed hipGraph on step-shaped operands (the micro-benchmark: warm caches and
     #     clocks; the rocprofv3 average of this command mixes it with the in-step launches)
     if args.dtype in ("bf16", "f16") and args.size % 32 == 0:

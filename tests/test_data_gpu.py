@@ -173,6 +173,33 @@ def test_loader_batches_match_oracle(tmp_path):
         assert list(names) == want
 
 
+def test_loader_raw_slots_with_consumer_side_preprocessing_match_oracle(tmp_path):
+    """DeviceLoader.iter_raw + slot_preprocess (the form a captured step uses: the preprocessing launches belong to the consumer and
+    always run MAX_ROUNDS augmentation rounds, identity records in the unused ones): same batches, same results as the oracle, the
+    three static slots in rotation, their buffers at the same addresses throughout."""
+    base, lists = str(tmp_path / "train_npz"), str(tmp_path / "lists")
+    D.write_synthetic_synapse(base, lists, n_cases=2, slices_per_case=6, size=512, seed=5)
+    ds = D.SynapseSlices(base, lists)
+    loader = D.DeviceLoader(ds, batch_size=3, img_size=224, device=DEV, seed=77, rank=0, world=1, augment=True, epochs=1)
+    x = torch.empty((3, 1, 224, 224), dtype=torch.float32, device=DEV)
+    y = torch.empty((3, 224, 224), dtype=torch.int64, device=DEV)
+    ptrs, n = {}, 0
+    for slot in loader.iter_raw(3):
+        assert slot["index"] == n % 3
+        assert ptrs.setdefault(slot["index"], slot["raw"][0].data_ptr()) == slot["raw"][0].data_ptr()
+        names, augs = loader.last_names, loader.last_augs
+        loader.slot_preprocess(slot)(x, y)
+        torch.cuda.synchronize()
+        xs, ys = x.cpu().numpy(), y.cpu().numpy()
+        for j, name in enumerate(names):
+            img, lab, _ = ds[ds.sample_list.index(name)]
+            wx, wy = O.preprocess_slice(img, lab, augs[j].as_dict(), 224)
+            np.testing.assert_array_equal(ys[j], wy, err_msg=f"{name} {augs[j].names}")
+            np.testing.assert_allclose(xs[j], wx, atol=1e-4, rtol=0, err_msg=f"{name} {augs[j].names}")
+        n += 1
+    assert n == 4 and not loader._thread.is_alive()
+
+
 def test_loader_without_augmentation_and_early_exit(tmp_path):
     base, lists = str(tmp_path / "train_npz"), str(tmp_path / "lists")
     D.write_synthetic_synapse(base, lists, n_cases=1, slices_per_case=8, size=128, seed=6)

@@ -395,9 +395,15 @@ def pack_rounds(augs: Sequence[Optional[SliceAugmentation]]) -> Tuple[np.ndarray
     chains = [(a.rounds() if a is not None else []) for a in augs]
     n = max([len(c) for c in chains] + [0])
     assert n <= MAX_ROUNDS
-    out = np.zeros((MAX_ROUNDS, len(augs), ctypes.sizeof(TcSliceAug)), np.uint8)
-    for r in range(n):
-        out[r] = pack_records([c[r] if r < len(c) else None for c in chains])
+    out = np.empty((MAX_ROUNDS, len(augs), ctypes.sizeof(TcSliceAug)), np.uint8)
+    ident = None
+    for r in range(MAX_ROUNDS):                                   # rounds past n hold identity records too: a captured step runs all of them
+        if r < n:
+            out[r] = pack_records([c[r] if r < len(c) else None for c in chains])
+        else:
+            if ident is None:
+                ident = pack_records([None] * len(augs))
+            out[r] = ident
     return out, n
 
 
@@ -422,6 +428,11 @@ def rank_batches(order: np.ndarray, batch_size: int, rank: int, world: int) -> L
     while len(padded) < nb * gb:                               # data sets smaller than one global batch: keep wrapping
         padded = np.concatenate([padded, order[:nb * gb - len(padded)]])
     return [padded[i * gb + rank * batch_size: i * gb + (rank + 1) * batch_size] for i in range(nb)]
+
+
+_DEBUG_SKIP_H2D = bool(os.environ.get("TC_LOADER_SKIP_H2D"))
+_DEBUG_NO_EVENTS = bool(os.environ.get("TC_LOADER_NO_EVENTS"))      # timing what-if only (racy)
+_HOST_WAITS_FOR_COPY = os.environ.get("TC_LOADER_HOST_WAIT", "1") != "0"
 
 
 class DeviceLoader:
@@ -475,6 +486,18 @@ class DeviceLoader:
 
     def _produce(self):
         from concurrent.futures import ThreadPoolExecutor
+        # CPython hands the GIL over every 5 ms by default: while this thread packs augmentation records, the consumer's next graph
+        # launch would wait up to that long (measured: 0.3-1.7 ms idle gaps at step boundaries of a 12.6 ms step).  A short switch
+        # interval lets the launching thread in at once; restored when the producer ends.
+        import sys as _sys
+        old_iv = _sys.getswitchinterval()
+        _sys.setswitchinterval(min(old_iv, float(os.environ.get("TC_LOADER_SWITCH_INTERVAL", "2e-5"))))
+        try:
+            self._produce_body(ThreadPoolExecutor)
+        finally:
+            _sys.setswitchinterval(old_iv)
+
+    def _produce_body(self, ThreadPoolExecutor):
         try:
             with ThreadPoolExecutor(max_workers=self.readers) as pool:
                 for epoch in range(self.epochs):
@@ -530,27 +553,114 @@ class DeviceLoader:
                 slot["out"] = self.out if self.out is not None else (
                     torch.empty((self.B, 1, self.size, self.size), dtype=torch.float32, device=self.device),
                     torch.empty((self.B, self.size, self.size), dtype=torch.int64, device=self.device))
-            if "prepped" in slot:
-                self.stream.wait_event(slot["prepped"])              # the kernels that read the previous contents are done
-            slot["raw"][0].copy_(img, non_blocking=True)
-            slot["raw"][1].copy_(lab, non_blocking=True)
-            if augs is not None:
-                slot["raw"][2].copy_(rec, non_blocking=True)
+            if "prepped" in slot and not os.environ.get("TC_LOADER_NO_STREAM_WAIT"):
+                # The kernels that read the slot's previous contents are done.  The HOST waits (the callers arrange that this event
+                # is at least one step old, so the wait ends while the GPU still has a queued step to run); letting the loader's
+                # stream wait for it on the device costs the CONSUMER's stream ~0.55 ms of idle time per step on this runtime when the
+                # event sits behind a graph launch (13.34 vs 12.79 ms per loader-fed step, copies disabled in both).
+                if _HOST_WAITS_FOR_COPY:
+                    slot["prepped"].synchronize()
+                else:
+                    self.stream.wait_event(slot["prepped"])
+            if not _DEBUG_SKIP_H2D or "h2d_once" not in slot:        # (timing what-if: TC_LOADER_SKIP_H2D=1 reuses the slot's first batch)
+                slot["raw"][0].copy_(img, non_blocking=True)
+                slot["raw"][1].copy_(lab, non_blocking=True)
+                if augs is not None:
+                    slot["raw"][2].copy_(rec, non_blocking=True)
+                slot["h2d_once"] = True
             slot["copied"] = torch.cuda.Event()
             slot["copied"].record(self.stream)
         slot["host"], slot["names"], slot["augs"], slot["rounds"] = st, names, augs, nr
         return True
 
+    def _wait_copied(self, slot: dict, main):
+        """The batch in `slot` is on the device before anything the consumer launches reads it.  The HOST waits for the copy's event
+        (issued one or two steps ago on the loader's stream: it has long completed) instead of making the consumer's stream wait for
+        it: a cross-stream wait in front of a graph launch costs ~0.55 ms of idle GPU per step on this runtime (measured: 13.36 vs
+        12.80 ms per loader-fed step), an event record behind it does not."""
+        if _HOST_WAITS_FOR_COPY:
+            slot["copied"].synchronize()
+        else:
+            main.wait_event(slot["copied"])
+
     def _prep(self, slot: dict):
         """The four preprocessing launches on the CONSUMER's stream, right in front of the step that uses the batch (kernels of
         different streams do not overlap on this GPU anyway -- see DESIGN.md -- and a side stream's launches slowed the step's)."""
         main = torch.cuda.current_stream(self.device)
-        main.wait_event(slot["copied"])
+        self._wait_copied(slot, main)
         d_img, d_lab, d_rec = slot["raw"]
         slot["x"], slot["y"] = preprocess_batch(d_img, d_lab, None, self.size, records=d_rec if (slot["augs"] is not None and slot["rounds"]) else None,
                                                 scratch=slot["scratch"], out=slot["out"], rounds=slot["rounds"])
         slot["prepped"] = torch.cuda.Event()
         slot["prepped"].record(main)
+
+    def iter_raw(self, nslots: int = 3):
+        """Yields device slots holding one RAW batch each -- {"index", "raw": (float32 [B,H,W], uint8 [B,H,W], TcSliceAug records uint8
+        [MAX_ROUNDS,B,sizeof] or None)} -- for a consumer that runs the preprocessing itself, e.g. captured at the head of its step
+        graph (`slot_preprocess(slot)` below gives the callable; train.GraphedStep(pre=...)): one captured step per slot, `nslots`
+        of them, the host-to-device copy of the batch after next running under the current step.  The slot's buffers are static (same
+        addresses for the whole iteration).  The consumer must have issued everything that reads the slot on the current stream
+        before it asks for the next one.  A slot is refilled one step AFTER the step that read it was issued (the host then waits
+        for that step's event while the next step is already queued), hence three slots for an uninterrupted GPU."""
+        from collections import deque
+        assert 1 <= nslots <= len(self.slots)
+        self._stop.clear()
+        self._thread = threading.Thread(target=self._produce, daemon=True)
+        self._thread.start()
+        slots = self.slots[:nslots]
+        for i, sl in enumerate(slots):
+            sl["index"] = i
+        free, copied, busy = deque(slots), deque(), deque()
+        eof = False
+
+        def try_copy():
+            nonlocal eof
+            if eof or not free:
+                return
+            slot = free.popleft()
+            if self._copy(slot):
+                copied.append(slot)
+            else:
+                eof = True
+                free.appendleft(slot)
+        try:
+            for _ in range(max(1, nslots - 1)):
+                try_copy()
+            while copied:
+                slot = copied.popleft()
+                main = torch.cuda.current_stream(self.device)
+                if not _DEBUG_NO_EVENTS:
+                    self._wait_copied(slot, main)
+                self.last_names, self.last_augs = slot["names"], slot["augs"]
+                yield slot
+                if not _DEBUG_NO_EVENTS:
+                    slot["prepped"] = torch.cuda.Event()             # everything the consumer issued that reads the slot is in front of this
+                    slot["prepped"].record(torch.cuda.current_stream(self.device))
+                busy.append(slot)
+                while len(busy) > (1 if nslots > 2 else 0):          # the slot of the step BEFORE the one just issued is refilled now
+                    free.append(busy.popleft())
+                try_copy()
+        finally:
+            self._stop.set()
+            while self._thread.is_alive():
+                try:
+                    self.q.get_nowait()
+                except queue.Empty:
+                    pass
+                self._thread.join(timeout=0.05)
+            while not self.q.empty():
+                self.q.get_nowait()
+
+    def slot_preprocess(self, slot: dict):
+        """pre(x, y) for train.GraphedStep: the preprocessing launches of the batch in `slot` (always MAX_ROUNDS augmentation rounds --
+        the count must not depend on the batch inside a captured graph; unused rounds hold identity records, which copy), writing the
+        network input into x / y."""
+        d_img, d_lab, d_rec = slot["raw"]
+        scratch, size, aug = slot["scratch"], self.size, self.augment
+
+        def pre(x, y):
+            preprocess_batch(d_img, d_lab, None, size, records=d_rec if aug else None, scratch=scratch, out=(x, y), rounds=MAX_ROUNDS if aug else None)
+        return pre
 
     def __iter__(self):
         from collections import deque

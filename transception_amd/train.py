@@ -359,8 +359,12 @@ class GraphedStep:
     buckets;  C = fused SGD."""
 
     def __init__(self, model, loss_fn: SegLoss, opt: FusedSGD, images: torch.Tensor, labels: torch.Tensor, group=None, warmup: int = 3,
-                 force_split: bool = False):
+                 force_split: bool = False, pre=None):
+        """pre(x, y): launches (on the current stream) that FILL the step's static inputs, captured at the head of the step's first graph
+        -- the device input pipeline's augmentation / resize kernels reading one raw batch slot (data.DeviceLoader.iter_raw): a
+        loader-fed loop is then graph launch after graph launch, with no eager launch in between."""
         self.model, self.loss_fn, self.opt, self.group = model, loss_fn, opt, group
+        self._pre = pre
         self.x, self.y = images.clone(), labels.clone().long().contiguous()
         self._dtype = model.compute_dtype                # the captured launches hold pointers into this storage type's working copy
         opt.grad_scale = 1.0 / getattr(loss_fn, "loss_scale", 1.0)
@@ -423,6 +427,8 @@ class GraphedStep:
     def _fwd(self):
         M, L = self.model, lib()
         M._ensure_flat(self.x.device)
+        if self._pre is not None:
+            self._pre(self.x, self.y)
         self.opt.zero_grad()
         logits, G, out_var = M._run(self.x, record=True, token_logits=True)     # [B*H*W, classes], storage type: no transpose, no fp32 copy
         self._G, self._out_var = G, out_var
