@@ -59,8 +59,8 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 //   * Softmax against a reference exponent m that is NOT the running row maximum: any m within fp32's exponent range of the true
 //     maximum gives the same quotient, so m is set once (integer-valued, from the row's first sub-tile) and raised only when a row
 //     sum shows that the scores have outgrown it by 2^30 (2^14 for fp16 storage of P) -- one compare per 32-key sub-tile instead of
-//     a 16-element maximum, a lane swap and a compare (-25 % VALU work; on gfx950 the VALU work of one wave does not hide under the
-//     MFMAs of another wave of the same SIMD, scripts/exp/overlap.hip, so every VALU instruction removed is time).  Integer m: P
+//     a 16-element maximum, a lane swap and a compare (-25 % VALU work: the SIMD issues one vector instruction per 4 cycles whoever it
+//     comes from, so every VALU instruction removed is time -- scripts/exp/overlap2.hip, DESIGN.md section 5 "Round 4").  Integer m: P
 //     differs from the maximum-referenced P by an exact power of two.
 //   * Q and O tiles pass through a wave-private LDS tile so that global memory sees whole 128-byte rows (eight lanes x 16 bytes): a
 //     per-lane 16-byte access at a row stride touches 32 lines per instruction and queued in the address unit for ~4 us at each end.

@@ -3,8 +3,8 @@
 
 Why a generator.  The compiler-scheduled kernel (attn_fwd_seg_kernel) runs its twelve waves per CU in lock step -- QK^T MFMAs,
 then softmax VALU, then PV MFMAs, re-aligned by a barrier every 128 keys -- so the matrix pipe idles while the VALU works and
-vice versa (0.265 of the bf16 MFMA peak in rounds 2-3, and hipcc would not keep a software-pipelined order: v60/v74/v80/v92 of
-scripts/exp/attn_exp.hip).  Measured on gfx950 this round (scripts/exp/overlap2.hip, profiles/r4_overlap2.txt): one wave issues
+vice versa (0.265 of the bf16 MFMA peak in rounds 2-3, and hipcc would not keep a software-pipelined order: variants v60/v74/v80/v92 of
+rounds 2-3, `git show 970a2e3:scripts/exp/attn_exp.hip`).  Measured on gfx950 this round (scripts/exp/overlap2.hip, profiles/r4_overlap2.txt): one wave issues
 about one instruction per 5.4 cycles whatever its type, so a single wave per SIMD is issue-bound (the first version of this file:
 3 query tiles per wave, 486 cycles per 8 MFMAs); but the VALU stream of one wave DOES run under the MFMAs of another wave of the same
 SIMD (8 MFMAs 256 -> 269 cycles next to a VALU wave that loses 15 %).  Hence: twelve waves per CU, ONE 32-query tile per wave, and
