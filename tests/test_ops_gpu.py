@@ -610,6 +610,58 @@ def test_attention_segmented_rereference(dtype):
         _seg_prescaled_cases(dtype, q, kv, gy, B, nq, Nk, y, qr.grad, kvr.grad)     # the rare re-reference path of the hand-scheduled stream
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_attention_stream_vs_compiler_kernel_and_fp64_over_shapes(dtype):
+    """The hand-scheduled forward stream (tc_attn_fwd_seg with qscaled = 1, the model's form) over the shapes that exercise its edges:
+    the minimum of two key sub-tiles, every tail length class (Nk mod 32 in {0, 1, 16, 31}), one / few / many loop iterations, ring
+    wrap-around (> 12 sub-tiles), one to four segments with partial and single-row tiles, dead wave tiles, B = 1 -- O and lse against
+    an fp64 statement on the stored operands, and against the compiler-scheduled kernel (TC_ATTN_FWD_ASM=0) on the same operands."""
+    import ctypes as C
+    import os
+    from transception_amd._lib import TC_BF16, TC_F16, lib
+    L = lib()
+    d, scale, l2e = 64, 0.125, 1.4426950408889634
+    dt = TC_BF16 if dtype == torch.bfloat16 else TC_F16
+    st = torch.cuda.current_stream().cuda_stream
+    cases = [(1, [64], 64), (1, [33], 65), (2, [100, 37], 80), (2, [1, 32, 31], 95), (1, [384], 96), (3, [70, 5, 129, 12], 127), (2, [64, 200], 128),
+             (1, [95], 161), (2, [392, 40], 400), (2, [150, 64, 33], 784), (1, [257], 1023)]
+    for ci, (B, nq, Nk) in enumerate(cases):
+        rows = B * sum(nq)
+        qf = T(f"sv.q{ci}", (rows, d)).to(DEV)
+        q = (qf * (scale * l2e)).to(dtype)
+        kv = T(f"sv.kv{ci}", (B * Nk, 2 * d)).to(DEV).to(dtype)
+        k, v = kv[:, :d], kv[:, d:]
+        nqc = (C.c_int * 4)(*(list(nq) + [0] * (4 - len(nq))))
+        outs = {}
+        for impl in ("1", "0"):
+            os.environ["TC_ATTN_FWD_ASM"] = impl
+            try:
+                o = torch.full((rows, d), float("nan"), device=DEV).to(dtype)
+                lse = torch.full((rows,), float("nan"), device=DEV)
+                rc = L.tc_attn_fwd_seg(q.data_ptr(), d, k.data_ptr(), 2 * d, v.data_ptr(), 2 * d, Nk * 2 * d, o.data_ptr(), d, lse.data_ptr(), B, len(nq),
+                                       nqc, Nk, scale, 1, dt, st)
+                torch.cuda.synchronize()
+                assert rc in (0, None)
+                outs[impl] = (o.double(), lse.double())
+            finally:
+                os.environ.pop("TC_ATTN_FWD_ASM", None)
+        ref_o = torch.empty(rows, d, dtype=torch.float64, device=DEV)
+        ref_l = torch.empty(rows, dtype=torch.float64, device=DEV)
+        off, kd, vd = 0, k.double().view(B, Nk, d), v.double().view(B, Nk, d)
+        for n in nq:
+            s_ = torch.einsum("bqd,bkd->bqk", q[off:off + B * n].double().view(B, n, d), kd) / l2e
+            ref_l[off:off + B * n] = torch.logsumexp(s_, -1).reshape(-1)
+            ref_o[off:off + B * n] = torch.einsum("bqk,bkd->bqd", torch.softmax(s_, -1), vd).reshape(-1, d)
+            off += B * n
+        tol_o = 8e-3 if dtype == torch.bfloat16 else 1.5e-3          # P and O are rounded to the storage type
+        for impl, (o, lse) in outs.items():
+            assert torch.isfinite(o).all() and torch.isfinite(lse).all(), (impl, B, nq, Nk)
+            assert (o - ref_o).abs().max().item() <= tol_o * max(1.0, ref_o.abs().max().item()), (impl, B, nq, Nk, (o - ref_o).abs().max().item())
+            assert (lse - ref_l).abs().max().item() <= 2e-5, (impl, B, nq, Nk, (lse - ref_l).abs().max().item())
+        assert (outs["1"][0] - outs["0"][0]).abs().max().item() <= tol_o, (B, nq, Nk)
+        assert (outs["1"][1] - outs["0"][1]).abs().max().item() <= 2e-5, (B, nq, Nk)
+
+
 @pytest.mark.parametrize("Bt,N,heads,Ch", [(3, 784, 8, 8), (2, 196, 8, 16), (2, 49, 8, 40)])
 def test_factor_att_core_fused(G, Bt, N, heads, Ch):
     """tc_factor_att_fwd/bwd vs a plain PyTorch fp32 restatement of MSTr.py:864-877 (Appendix C.1):
