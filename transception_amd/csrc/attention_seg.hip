@@ -340,11 +340,17 @@ __global__ __launch_bounds__(AS_NW * 64, 1) void attn_fwd_asm_kernel(const bf16_
 // LDS behind one barrier per tile, Q / dO / dQ tiles through the wave's LDS tile as whole 128-byte rows.
 // K is stored ONCE, rows in key_row order: conflict-free both for the 16-byte fragment reads of S^T = K Q^T (row
 // key_row(pi_row(j))) and for the transpose reads of dQ^T += K^T dS^T.
-template <typename H>
+// O != nullptr: delta = rowsum(O dO) of the wave's 32 rows is computed HERE from the dO rows the wave loads anyway (+ the O rows) and
+// written to `delta` for the dK/dV kernel, which is launched behind this one -- no separate delta pass over O and dO.
+// QM = 1 (Q stored as q * scale * log2(e)): -lse * log2(e) is the INITIAL value of the S accumulator (P = exp2(S) directly), dS is
+// P (dP - delta) and `scale` is applied once to the dQ accumulators.  (-delta as the initial value of dP as well -- bit 1 -- keeps a
+// second 16-register tuple alive through the key loop: 23 spilled registers at the 168 of a 12-wave workgroup, 139 vs 132 us.)
+template <typename H, int QM>
 __global__ __launch_bounds__(FW_NT, 1) void attn_bwd_dq_seg_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
                                                                    const bf16_t* __restrict__ V, int ldv, long long skv,
+                                                                   const bf16_t* __restrict__ O, int ldo,
                                                                    const bf16_t* __restrict__ dO, int lddo, const float* __restrict__ lse,
-                                                                   const float* __restrict__ delta, bf16_t* __restrict__ dQ, int lddq, Segs sg,
+                                                                   float* __restrict__ delta, bf16_t* __restrict__ dQ, int lddq, Segs sg,
                                                                    int Nk, float scale, float qs, int wide_o) {
     extern __shared__ __attribute__((aligned(16))) bf16_t fw_smem[];      // [2 slots][K tile | V tile][KB][LDR], then FW_NW wave tiles [32][LDR]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
@@ -363,6 +369,7 @@ __global__ __launch_bounds__(FW_NT, 1) void attn_bwd_dq_seg_kernel(const bf16_t*
     typedef typename TcHalf<H>::v8 V8;
     bf16_t* wtile = fw_smem + 2 * FW_SLOT + wave * (32 * LDR);
     V8 qf[4], dof[4];
+    float dsum[4] = {0.f, 0.f, 0.f, 0.f};                      // O != nullptr: delta of row 8 i + (lane >> 3), complete in every lane of the row
     {   // Q, then dO, through the wave tile (coalesced rows in, fragments out)
         uint4 qv[4], gv[4];
 #pragma unroll
@@ -371,6 +378,23 @@ __global__ __launch_bounds__(FW_NT, 1) void attn_bwd_dq_seg_kernel(const bf16_t*
             const bool okr = live && tq0 + r < nq;
             qv[i] = okr ? *reinterpret_cast<const uint4*>(Q + (trow0 + r) * ldq + 8 * (lane & 7)) : make_uint4(0u, 0u, 0u, 0u);
             gv[i] = okr ? *reinterpret_cast<const uint4*>(dO + (trow0 + r) * lddo + 8 * (lane & 7)) : make_uint4(0u, 0u, 0u, 0u);
+            if (O) {
+                const uint4 ov = okr ? *reinterpret_cast<const uint4*>(O + (trow0 + r) * ldo + 8 * (lane & 7)) : make_uint4(0u, 0u, 0u, 0u);
+                const unsigned aw[4] = {ov.x, ov.y, ov.z, ov.w}, gw[4] = {gv[i].x, gv[i].y, gv[i].z, gv[i].w};
+                float sd = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float a0, a1, g0, g1;
+                    unpack2<H>(aw[e], a0, a1);
+                    unpack2<H>(gw[e], g0, g1);
+                    sd = fmaf(a0, g0, fmaf(a1, g1, sd));
+                }
+                sd += __shfl_xor(sd, 1, 64);
+                sd += __shfl_xor(sd, 2, 64);
+                sd += __shfl_xor(sd, 4, 64);
+                dsum[i] = sd;
+                if (okr && (lane & 7) == 0) delta[trow0 + r] = sd;
+            }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(wtile + (8 * i + (lane >> 3)) * LDR + 8 * (lane & 7)) = qv[i];
@@ -386,9 +410,22 @@ __global__ __launch_bounds__(FW_NT, 1) void attn_bwd_dq_seg_kernel(const bf16_t*
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) dof[ks] = ld_frag<V8>(wtile + j * LDR + 16 * ks + 8 * h);
+        if (O) {                                                // row deltas -> lane j through the wave tile (behind the fragment reads)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if ((lane & 7) == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) reinterpret_cast<float*>(wtile)[8 * i + (lane >> 3)] = dsum[i];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
     }
     const float l2 = ok ? lse[trow0 + j] * LOG2E : 0.f;         // qs = scale * log2(e), or 1 when Q arrives scaled
-    const float dls = ok ? delta[trow0 + j] * scale : 0.f;      // dS = P (dP scale - delta scale)
+    const float dlt = O ? reinterpret_cast<const float*>(wtile)[j] : (ok ? delta[trow0 + j] : 0.f);
+    const float dls = ok ? dlt * scale : 0.f;                   // dS = P (dP scale - delta scale)
+    const float dl0 = ok ? dlt : 0.f;
+    constexpr bool QSC = QM != 0;                               // QM bit 0: -l2 is the C operand of S; bit 1: -delta the C operand of dP
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
@@ -423,12 +460,15 @@ __global__ __launch_bounds__(FW_NT, 1) void attn_bwd_dq_seg_kernel(const bf16_t*
         const bf16_t* Ks = fw_smem + (t & 1) * FW_SLOT;
         const bf16_t* Vs = Ks + KB * LDR;
         const int nsub = min(KB / 32, (Nk - kb0 + 31) / 32);
+        // (issuing the S / dP products of sub-tile sub+1 before the softmax arithmetic of sub-tile sub -- a source-level software
+        // pipeline -- needs 32-64 more live accumulator registers than the 168 of a 12-wave workgroup: the compiler spills 28-62
+        // registers and the kernel runs 63 us instead of 44)
 #pragma unroll 1
         for (int sub = 0; sub < nsub; ++sub) {
             const int kv0 = kb0 + 32 * sub;
             f32x16 s, dp;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { s[r] = (QM & 1) ? -l2 : 0.f; dp[r] = (QM & 2) ? -dl0 : 0.f; }
             const bf16_t* kp = Ks + (32 * sub + kprow) * LDR + 8 * h;
             const bf16_t* vp = Vs + (32 * sub + krow) * LDR + 8 * h;
 #pragma unroll
@@ -439,9 +479,9 @@ __global__ __launch_bounds__(FW_NT, 1) void attn_bwd_dq_seg_kernel(const bf16_t*
             const bool tail = kv0 + 32 > Nk;                    // keys past Nk were staged as zeros: P is forced to 0 for them
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float p = fast_exp2(fmaf(s[r], qs, -l2));
+                float p = (QM & 1) ? fast_exp2(s[r]) : (QSC ? fast_exp2(s[r] - l2) : fast_exp2(fmaf(s[r], qs, -l2)));
                 if (tail && kv0 + 16 * h + r >= Nk) p = 0.f;
-                s[r] = p * fmaf(dp[r], scale, -dls);
+                s[r] = (QM & 2) ? p * dp[r] : (QSC ? p * (dp[r] - dl0) : p * fmaf(dp[r], scale, -dls));
             }
             const int gi = lane & 15, gq = (lane >> 4) & 1;
             const bf16_t* kt = Ks + (32 * sub + 16 * h + 4 * (gi >> 2)) * LDR + 16 * gq + 4 * (gi & 3);
@@ -453,6 +493,10 @@ __global__ __launch_bounds__(FW_NT, 1) void attn_bwd_dq_seg_kernel(const bf16_t*
             }
         }
         __syncthreads();
+    }
+    if (QSC) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] *= scale; acc1[r] *= scale; }
     }
     if (wide_o) {
 #pragma unroll
@@ -495,23 +539,26 @@ __device__ unsigned long long g_dkv_dbg[512 * 4];
 // QSC (Q stored as q * scale * log2(e), `qs` = 1): the stage keeps -lse * log2(e) and -delta, and they are the INITIAL values of
 // the S and dP accumulators -- P = exp2(S), dS = P dP' with no multiply-add per score (a third of the kernel's VALU work, which
 // shares the SIMD's issue slots with the MFMAs); the factor ln 2 of dK (`scale`) is applied once to the accumulators at the end.
+#ifndef DKV_QS
+#define DKV_QS 64                                               // queries per stage of the dK/dV kernel (whole 32-query tiles)
+#endif
+constexpr int DKV_STAGE_B = 2 * (2 * DKV_QS * (D + 8) + 2 * DKV_QS * 2) * 2;
+constexpr int DKV_SMEM_B = DKV_STAGE_B > 4 * D * 33 * 4 ? DKV_STAGE_B : 4 * D * 33 * 4;
 template <typename H, int NW, bool QSC>
 __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
                                                                     const bf16_t* __restrict__ V, int ldv, long long skv,
                                                                     const bf16_t* __restrict__ dO, int lddo, const float* __restrict__ lse,
                                                                     const float* __restrict__ delta, float* __restrict__ dkv32, Segs sg, int Nk,
                                                                     float scale, float qs, int tiles_per_chunk) {
-    constexpr int QS = 64, LDQ = D + 8;
+    constexpr int QS = DKV_QS, NT = QS / 32, NI = QS * 8 / 256, LDQ = D + 8;
     // Q and dO of a stage are stored ONCE, row-major with the rows of every 16-row group 4x4-transposed (key_row): conflict-free both
     // for the 16-byte fragment reads of S = Q K^T / dP = dO V^T and for the hardware transpose reads (ds_read_b64_tr_b16) that gather
     // the dO^T / Q^T operands of the dV^T / dK^T products -- the first version kept transposed copies written with 2-byte stores
     // two stage buffers: the next 64-query stage is stored (from registers loaded a stage earlier) while the current one is consumed,
     // so a stage costs ONE barrier
     constexpr int STAGE_E = 2 * QS * LDQ + 2 * QS * 2;          // bf16 elements per buffer: Q | dO | lse (fp32) | delta (fp32)
-    constexpr int STAGE_B = 2 * STAGE_E * 2;
-    constexpr int RED_B = NW * D * 33 * 4;
-    constexpr int SMEM_B = STAGE_B > RED_B ? STAGE_B : RED_B;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_B];
+    static_assert(2 * STAGE_E * 2 == DKV_STAGE_B && NW * D * 33 * 4 <= DKV_SMEM_B, "host-side LDS size");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* const sbase = reinterpret_cast<bf16_t*>(smem);
     DSTAMP_INIT();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
@@ -545,7 +592,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16
     };
     // staging (threads 0..255): 16-byte chunk c8 of row r of the 64-query stage
     const bool stager = tid < 256;
-    uint4 qr[2], gr[2];
+    uint4 qr[NI], gr[NI];
     float lr = 0.f, dr = 0.f;
     auto fmap = [&](int it, int& r, int& c8, int& g) {           // eight lanes x 16 bytes cover one 128-byte row: whole lines per request
         const int idx = it * 256 + tid;
@@ -554,7 +601,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16
     auto fetch = [&](int t0) {
         if (stager) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < NI; ++i) {
                 int r, c8, g; fmap(i, r, c8, g);
                 long long base; int valid;
                 locate(t0 + (r >> 5), base, valid);
@@ -578,7 +625,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16
         float* lw = reinterpret_cast<float*>(dOw + QS * LDQ);
         if (stager) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < NI; ++i) {
                 int r, c8, g; fmap(i, r, c8, g);
                 *reinterpret_cast<uint4*>(&Qw[key_row(r) * LDQ + c8]) = qr[i];
                 *reinterpret_cast<uint4*>(&dOw[key_row(r) * LDQ + c8]) = gr[i];
@@ -589,20 +636,20 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16
     if (t_begin < t_end) {
         fetch(t_begin);
         stash(0);
-        if (t_begin + 2 < t_end) fetch(t_begin + 2);
+        if (t_begin + NT < t_end) fetch(t_begin + NT);
     }
     __syncthreads();
     DSTAMP(0);
     int buf = 0;
-    for (int t0 = t_begin; t0 < t_end; t0 += 2, buf ^= 1) {
-        if (t0 + 2 < t_end) stash(buf ^ 1);                     // (every wave left stage t0 - 2, that buffer's last reader, at the barrier below)
-        if (t0 + 4 < t_end) fetch(t0 + 4);
+    for (int t0 = t_begin; t0 < t_end; t0 += NT, buf ^= 1) {
+        if (t0 + NT < t_end) stash(buf ^ 1);                    // (every wave left the stage before, that buffer's last reader, at the barrier below)
+        if (t0 + 2 * NT < t_end) fetch(t0 + 2 * NT);
         const bf16_t* Qs = sbase + buf * STAGE_E;
         const bf16_t* dOs = Qs + QS * LDQ;
         const float* lss = reinterpret_cast<const float*>(dOs + QS * LDQ);
         const float* dls = lss + QS;
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
+        for (int qt = 0; qt < NT; ++qt) {
             // the 16 log-sum-exps and (scaled) deltas of this lane's query rows: four 16-byte LDS reads each instead of 16 scalar ones
             f32x16 lq, dq;
 #pragma unroll
@@ -838,38 +885,49 @@ extern "C" int tc_attn_bwd_seg(const void* Q, int ldq, const void* K, int ldk, c
     int zs = dkv_slots / (kb * B);
     zs = zs < 1 ? 1 : (zs > (ntiles + 1) / 2 ? (ntiles + 1) / 2 : zs);
     int tpc = (ntiles + zs - 1) / zs;
-    tpc = (tpc + 1) & ~1;                                            // whole 64-query stages
+    constexpr int dkv_nt = DKV_QS / 32;
+    tpc = (tpc + dkv_nt - 1) / dkv_nt * dkv_nt;                      // whole stages
     zs = (ntiles + tpc - 1) / tpc;
     if (zs > TC_ATTN_DKV_SPLITS) {                                    // dkv32 holds TC_ATTN_DKV_SPLITS partial buffers
-        tpc = ((ntiles + TC_ATTN_DKV_SPLITS - 1) / TC_ATTN_DKV_SPLITS + 1) & ~1;
+        tpc = ((ntiles + TC_ATTN_DKV_SPLITS - 1) / TC_ATTN_DKV_SPLITS + dkv_nt - 1) / dkv_nt * dkv_nt;
         zs = (ntiles + tpc - 1) / tpc;
     }
     const float qs = qscaled ? 1.0f : scale * LOG2E, kscale = qscaled ? LN2 : scale;    // dK = dS^T Q: ln 2 when Q is stored as q * scale * log2(e)
     const int wide_dq = !(lddq & 7) && !((uintptr_t)dQ & 15);
     const int wide_rows = !((ldo | lddo) & 7) && !(((uintptr_t)O | (uintptr_t)dO) & 15);
+    static const int fuse_env = getenv("TC_ATTN_FUSE_DELTA") ? atoi(getenv("TC_ATTN_FUSE_DELTA")) : 1;
+    const bool fuse_delta = wide_rows && fuse_env;
     static bool lds_ok[2] = {false, false};
+    // dQ first: it computes delta = rowsum(O dO) on the way (when O / dO rows are 16-byte accessible) and the dK/dV kernel reads it
+#define TC_BWD_DQ(HH, QMV)                                                                                                                 \
+        hipLaunchKernelGGL((attn_bwd_dq_seg_kernel<HH, QMV>), dim3((unsigned)B * ((sg.t32[nseg] + FW_NW - 1) / FW_NW)), dim3(FW_NT), FW_SMEM, s, \
+                           (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk, (const bf16_t*)V, ldv, skv, fuse_delta ? (const bf16_t*)O : nullptr, ldo, \
+                           (const bf16_t*)dO, lddo, lse, delta, (bf16_t*)dQ, lddq, sg, Nk, scale, qs, wide_dq)
 #define TC_BWD(HH, IDX)                                                                                                                     \
     {                                                                                                                                       \
         if (!lds_ok[IDX]) {                                                                                                                 \
-            if (hipFuncSetAttribute((const void*)attn_bwd_dq_seg_kernel<HH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FW_SMEM) != hipSuccess) \
+            if (hipFuncSetAttribute((const void*)attn_bwd_dq_seg_kernel<HH, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FW_SMEM) != hipSuccess || \
+                hipFuncSetAttribute((const void*)attn_bwd_dq_seg_kernel<HH, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FW_SMEM) != hipSuccess || \
+                hipFuncSetAttribute((const void*)attn_bwd_dkv_seg_kernel<HH, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_SMEM_B) != hipSuccess || \
+                hipFuncSetAttribute((const void*)attn_bwd_dkv_seg_kernel<HH, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_SMEM_B) != hipSuccess) \
                 return TC_ERR_LAUNCH;                                                                                                       \
             lds_ok[IDX] = true;                                                                                                             \
         }                                                                                                                                   \
-        hipLaunchKernelGGL(delta_rows_kernel<HH>, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, s, (const bf16_t*)O, ldo, (const bf16_t*)dO, \
-                           lddo, delta, rows, wide_rows);                                                                                   \
+        if (!fuse_delta)                                                                                                                    \
+            hipLaunchKernelGGL(delta_rows_kernel<HH>, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, s, (const bf16_t*)O, ldo,             \
+                               (const bf16_t*)dO, lddo, delta, rows, wide_rows);                                                            \
+        if (qscaled) TC_BWD_DQ(HH, 1); else TC_BWD_DQ(HH, 0);                                                                               \
         if (qscaled)                                                                                                                        \
-            hipLaunchKernelGGL((attn_bwd_dkv_seg_kernel<HH, 4, true>), dim3(kb, B, zs), dim3(256), 0, s, (const bf16_t*)Q, ldq, (const bf16_t*)K, \
+            hipLaunchKernelGGL((attn_bwd_dkv_seg_kernel<HH, 4, true>), dim3(kb, B, zs), dim3(256), DKV_SMEM_B, s, (const bf16_t*)Q, ldq, (const bf16_t*)K, \
                                ldk, (const bf16_t*)V, ldv, skv, (const bf16_t*)dO, lddo, lse, delta, dkv32, sg, Nk, kscale, qs, tpc);             \
         else                                                                                                                                \
-            hipLaunchKernelGGL((attn_bwd_dkv_seg_kernel<HH, 4, false>), dim3(kb, B, zs), dim3(256), 0, s, (const bf16_t*)Q, ldq, (const bf16_t*)K, \
+            hipLaunchKernelGGL((attn_bwd_dkv_seg_kernel<HH, 4, false>), dim3(kb, B, zs), dim3(256), DKV_SMEM_B, s, (const bf16_t*)Q, ldq, (const bf16_t*)K, \
                                ldk, (const bf16_t*)V, ldv, skv, (const bf16_t*)dO, lddo, lse, delta, dkv32, sg, Nk, kscale, qs, tpc);             \
         hipLaunchKernelGGL(attn_dkv_store_kernel<HH>, dim3(tc_blocks((long long)B * Nk * 32, 256, 1024)), dim3(256), 0, s, dkv32,           \
                            (bf16_t*)dK, lddk, (bf16_t*)dV, lddv, sdkv, B, Nk, zs);                                                              \
-        hipLaunchKernelGGL(attn_bwd_dq_seg_kernel<HH>, dim3((unsigned)B * ((sg.t32[nseg] + FW_NW - 1) / FW_NW)), dim3(FW_NT), FW_SMEM, s,     \
-                           (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk, (const bf16_t*)V, ldv, skv, (const bf16_t*)dO, lddo, lse, delta,    \
-                           (bf16_t*)dQ, lddq, sg, Nk, scale, qs, wide_dq);                                                                  \
     }
     if (dtype == TC_BF16) TC_BWD(bf16_t, 0) else TC_BWD(f16_t, 1)
 #undef TC_BWD
+#undef TC_BWD_DQ
     return tc_launch_status();
 }
