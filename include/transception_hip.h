@@ -91,6 +91,14 @@ typedef struct TcGemm {
     const float* ffn_part; float* ffn_stat; const void* ffn_gamma; const void* ffn_beta; const void* ffn_d; float* ffn_part2;
     long long ffn_sRow1, ffn_sPar1;
     void* ffn_aout;
+    /* BatchNorm statistics of the OUTPUT in the epilogue (DWConv2d_BN / Conv2d_BN, MSTr.py:338-339, 394-400: a 1x1 convolution whose
+     * result goes straight into a training-mode BatchNorm2d).  bn_part != NULL (16-bit storage, plain store: no batches, no split-K,
+     * no accumulate, 16-byte addressable C rows, N % 8 == 0 -- anything else is TC_ERR_ARG): every 64-row tile t of C leaves
+     *   bn_part[N + t*N + n]            = sum over its rows of (c[m][n] - shift[n])
+     *   bn_part[N + (T + t)*N + n]      = sum over its rows of (c[m][n] - shift[n])^2        (T = ceil(M / 64) tiles)
+     * computed from the ROUNDED values it stores, and bn_part[n] = shift[n] = bn_shift[n] (fp32 [N], e.g. the running mean; NULL: 0).
+     * That is tc_bn_fwd's scratch layout with T chunks: pass stats_chunks = T there and the separate statistics pass is skipped. */
+    float* bn_part; const float* bn_shift;
 } TcGemm;
 enum { TC_FFN_NONE = 0, TC_FFN_LN_A = 1, TC_FFN_LN_B = 2, TC_FFN_EP = 3 };
 int tc_gemm(const TcGemm* g, void* stream);
@@ -295,12 +303,14 @@ int tc_effatt_bwd(const TcEffAtt* f, int dtype, void* stream);
  * training=1: batch statistics (biased var), running stats updated with momentum 0.1 and the unbiased
  *   variance, save_mean/save_rstd [C] written for backward.  training=0: running statistics.
  * `partial` is caller-provided fp32 scratch of at least tc_bn_scratch_floats(rows, C) floats.
+ * stats_chunks > 0 (training only): `partial` ALREADY holds the shifted sums of x in stats_chunks row chunks, left there by the
+ *   GEMM that produced x (TcGemm.bn_part; C * (1 + 2 * stats_chunks) floats) -- no statistics pass is launched.  0: computed here.
  */
 long long tc_bn_scratch_floats(int rows, int C);
 int tc_bn_fwd(const void* x, int ldx, const void* gamma, const void* beta, float* running_mean,
               float* running_var, const void* res, int ldres, void* y, int ldy, float* save_mean,
               float* save_rstd, float* partial, int rows, int C, float eps, float momentum, int training,
-              int act, int dtype, void* stream);
+              int stats_chunks, int act, int dtype, void* stream);
 /* dgamma/dbeta ACCUMULATED into; dx written (or accumulated into when accumulate=1).
  * (The residual gradient is dy itself.) */
 int tc_bn_bwd(const void* dy, int lddy, const void* x, int ldx, const void* gamma, const void* beta,

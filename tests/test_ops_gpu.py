@@ -197,6 +197,48 @@ def test_batchnorm_train(G, rows, C, act, res):
         close(G.grad_of(resv), rr.grad, what="dres")
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K,bias", [(12544, 64, 64, False), (3136, 128, 128, False), (784, 320, 320, False), (896, 16, 256, True),
+                                         (224, 80, 1280, True), (100, 24, 72, False)])
+def test_linear_leaves_batchnorm_statistics(M, N, K, bias, dtype):
+    """TcGemm.bn_part: the 1x1 convolution's epilogue makes the statistics pass of the BatchNorm behind it (DWConv2d_BN / Conv2d_BN /
+    CoordAtt conv1 + bn1, MSTr.py:338-339, 394-400, 1333-1335).  The partial sums are those of the ROUNDED stored values about the
+    given shift; BatchNorm with them equals BatchNorm with its own statistics pass (same mean / rstd / running buffers / output)."""
+    from transception_amd.engine import Graph
+    Gh = Graph(dtype, torch.device(DEV), training=True, record=True)
+    x, w = T(f"bnl.x{M}.{K}", (M, K)).to(dtype), (T(f"bnl.w{N}.{K}", (N, K), 1 / math.sqrt(K)) + 0.02).to(dtype)
+    b = T(f"bnl.b{N}", (N,), 0.3).to(dtype) if bias else None
+    g, be = (T(f"bnl.g{N}", (N,)) * 0.2 + 1).to(dtype), T(f"bnl.be{N}", (N,), 0.3).to(dtype)
+    rm, rv = T(f"bnl.rm{N}", (N,), 0.3), T(f"bnl.rv{N}", (N,)).abs() + 0.5
+    res = {}
+    for fused in (True, False):
+        rmd, rvd = rm.to(DEV), rv.to(DEV)
+        xv = mkV(Gh, x)
+        y = Gh.linear(xv, mkP(w), mkP(b) if bias else None, bn_shift=rmd if fused else None)
+        assert (getattr(y, "bn_part", None) is not None) == fused
+        if fused:
+            part, tiles = y.bn_part
+            assert tiles == (M + 63) // 64
+            torch.cuda.synchronize()
+            yf = y.data.float() - rmd                                      # what the kernel summed: stored values minus the shift
+            pc = part.cpu()
+            assert torch.equal(pc[:N], rm)
+            s1 = pc[N:N + tiles * N].view(tiles, N).double().sum(0)
+            s2 = pc[N + tiles * N:N + 2 * tiles * N].view(tiles, N).double().sum(0)
+            close(s1.float(), yf.double().sum(0).float().cpu(), 2e-3, 2e-5, "sum")
+            close(s2.float(), (yf.double() ** 2).sum(0).float().cpu(), 2e-3, 2e-5, "squared sum")
+            t0 = pc[N:2 * N]                                               # first row tile alone
+            close(t0, yf[:min(64, M)].double().sum(0).float().cpu(), 1e-3, 1e-5, "tile 0")
+        gp, bp = mkP(g), mkP(be)
+        out = Gh.batchnorm(y, gp, bp, rmd, rvd, ACT_HSWISH)
+        run_bwd(Gh, out, T(f"bnl.gy{M}.{N}", (M, N)).to(dtype))
+        res[fused] = (out.data.float().cpu(), rmd.cpu(), rvd.cpu(), Gh.grad_of(xv).float().cpu(), gp.grad.cpu(), bp.grad.cpu())
+    names = ("y", "running_mean", "running_var", "dx", "dgamma", "dbeta")
+    for a, c, nm in zip(res[True], res[False], names):
+        tol = 2e-2 if nm in ("y", "dx") else 1e-4                          # y / dx are 16-bit: one rounding step where mean / rstd differ in the last bits
+        close(a, c, tol * max(1.0, float(c.abs().max())), 0.0, nm)
+
+
 def test_batchnorm_eval():
     from transception_amd.engine import Graph
     Ge = Graph(torch.float32, torch.device(DEV), training=False, record=False)

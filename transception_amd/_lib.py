@@ -31,7 +31,9 @@ class TcGemm(C.Structure):
                 # MixFFN fusion hooks (include/transception_hip.h): LayerNorm + GELU applied to operand tiles / the epilogue
                 ("ffn_mode", i32), ("ffn_nchunk", i32), ("ffn_chunk_n", i32), ("ffn_ldd", i32), ("ffn_eps", f32),
                 ("ffn_part", vp), ("ffn_stat", vp), ("ffn_gamma", vp), ("ffn_beta", vp), ("ffn_d", vp), ("ffn_part2", vp),
-                ("ffn_sRow1", i64), ("ffn_sPar1", i64), ("ffn_aout", vp)]
+                ("ffn_sRow1", i64), ("ffn_sPar1", i64), ("ffn_aout", vp),
+                # BatchNorm statistics of the output left by the epilogue (tc_bn_fwd(stats_chunks=...))
+                ("bn_part", vp), ("bn_shift", vp)]
 
 
 FFN_NONE, FFN_LN_A, FFN_LN_B, FFN_EP = 0, 1, 2, 3
@@ -124,7 +126,7 @@ SIGNATURES = {
     "tc_effatt_fwd": [C.POINTER(TcEffAtt), i32, vp],
     "tc_effatt_bwd": [C.POINTER(TcEffAtt), i32, vp],
     "tc_bn_scratch_floats": [i32, i32],
-    "tc_bn_fwd": [vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, f32, f32, i32, i32, i32, vp],
+    "tc_bn_fwd": [vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, f32, f32, i32, i32, i32, i32, vp],
     "tc_bn_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "tc_softmax_scratch_floats": [i32, i32, i32],
     "tc_softmax_fwd": [vp, vp, vp, i32, i64, i64, i32, i32, i32, i32, i32, i32, vp],

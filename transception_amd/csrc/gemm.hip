@@ -50,7 +50,12 @@ struct GemmDev {
         float eps;
         const float* part; float* stat; const void* gamma; const void* beta; const void* d; float* part2;
     } ffn;
+    // BatchNorm statistics of the stored tile (TcGemm.bn_part / bn_shift; plain products only, so they share the slots of the MixFFN
+    // hooks -- the argument block of gemm_multi_kernel holds twelve of these structs in 4 KiB): ffn.mode == GEMM_BN_STATS
+    __device__ __host__ float* bn_part() const { return ffn.mode == 4 ? ffn.part2 : nullptr; }
+    __device__ __host__ const float* bn_shift() const { return ffn.part; }
 };
+constexpr int GEMM_BN_STATS = 4;
 
 // GELU(LayerNorm(.)) on raw 8 x bf16 / 4 x fp32 operand strips (the A rows of fc2's forward, the B rows of its weight gradient)
 template <typename H> __device__ __forceinline__ void bf8_unpack(const uint4& r, float* o) {
@@ -354,6 +359,32 @@ __device__ __forceinline__ void epilogue_rows_lds(const GemmDev& p, f32x16 (&acc
         const int row = m0 + lr, col = n0 + lc;
         if (row < p.M && col < p.N)
             *reinterpret_cast<uint4*>(C + (long long)row * p.ldc + col) = *reinterpret_cast<const uint4*>(stage + lr * LDS_ + lc);
+    }
+    if constexpr (BM == 64 && BN == 64) {
+        if (float* const bnp = p.bn_part()) {
+            // the statistics pass of the BatchNorm that follows, on the ROUNDED tile as it lies in LDS: thread (column, row quarter)
+            // adds 16 rows, the quarters meet behind the staging tile, one thread per column writes this row tile's two sums
+            float* red = reinterpret_cast<float*>(stage_raw + BM * LDS_);      // [2][4][64] floats behind the 64 x 72 tile
+            const int cc = threadIdx.x & 63, part = threadIdx.x >> 6, col = n0 + cc;
+            const float sh = (p.bn_shift() && col < p.N) ? p.bn_shift()[col] : 0.f;
+            float s1 = 0.f, s2 = 0.f;
+            if (col < p.N) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int lr = part * 16 + r;
+                    const float v = (m0 + lr < p.M) ? ldf<H>(stage + lr * LDS_ + cc) - sh : 0.f;
+                    s1 += v; s2 += v * v;
+                }
+            }
+            red[part * 64 + cc] = s1; red[256 + part * 64 + cc] = s2;
+            __syncthreads();
+            if (threadIdx.x < 64 && col < p.N) {
+                const int T = (p.M + BM - 1) / BM, t = m0 / BM;
+                bnp[p.N + (long long)t * p.N + col] = red[cc] + red[64 + cc] + red[128 + cc] + red[192 + cc];
+                bnp[p.N + (long long)(T + t) * p.N + col] = red[256 + cc] + red[320 + cc] + red[384 + cc] + red[448 + cc];
+                if (t == 0) bnp[col] = sh;
+            }
+        }
     }
 }
 
@@ -1067,7 +1098,8 @@ bool gemm_plan(const TcGemm* g, GemmDev& d, dim3& grid, bool& use128_out, bool f
     d.ffn.part = g->ffn_part; d.ffn.stat = g->ffn_stat; d.ffn.gamma = g->ffn_gamma; d.ffn.beta = g->ffn_beta;
     d.ffn.d = g->ffn_mode == TC_FFN_LN_A ? g->ffn_aout : g->ffn_d;      // one slot: EP reads d there, LN_A may write the activated rows
     d.ffn.part2 = g->ffn_part2;
-    if (g->ffn_mode) force64 = true;
+    if (g->bn_part && !g->ffn_mode) { d.ffn.mode = GEMM_BN_STATS; d.ffn.part2 = g->bn_part; d.ffn.part = g->bn_shift; }
+    if (g->ffn_mode || g->bn_part) force64 = true;
     constexpr int VEC = 16 / (int)sizeof(T);                         // elements per 16-byte vector
     auto aligned = [&](const void* ptr, int ld, long long s1, long long s2) {
         return ((uintptr_t)ptr % 16 == 0) && (ld % VEC == 0) && (s1 % VEC == 0) && (s2 % VEC == 0);
@@ -1103,7 +1135,7 @@ bool gemm_plan(const TcGemm* g, GemmDev& d, dim3& grid, bool& use128_out, bool f
 #define GEMM_AS_TARGET 512
 #define GEMM_AS_KPER 256
 #endif
-        if (want == 1 && !g->atomic && g->ffn_mode != TC_FFN_EP && g->K >= 2 * GEMM_AS_KPER && tiles64 <= GEMM_AS_TILES) {
+        if (want == 1 && !g->atomic && g->ffn_mode != TC_FFN_EP && !g->bn_part && g->K >= 2 * GEMM_AS_KPER && tiles64 <= GEMM_AS_TILES) {
             long long sk = GEMM_AS_TARGET / tiles64;
             if (sk > g->K / GEMM_AS_KPER) sk = g->K / GEMM_AS_KPER;
             if (sk > FIX_GROUP) sk = FIX_GROUP;
@@ -1135,6 +1167,10 @@ bool gemm_plan(const TcGemm* g, GemmDev& d, dim3& grid, bool& use128_out, bool f
         d.xcd = (xcd_on && grid.x > 1 && (long long)grid.x * grid.y >= 64) ? 1 : 0;
     }
     use128_out = use128;
+    if (g->bn_part) {                                               // statistics come from the LDS-staged plain-store epilogue of ONE product
+        if (sizeof(T) != 2 || g->c_f32 || g->accumulate || g->atomic || d.splitk != 1 || nb != 1 || !d.vec8C || g->ffn_mode || g->act != TC_ACT_NONE)
+            return false;
+    }
     if (g->ffn_mode) {
         // the hooked kernels assume whole 16-byte strips everywhere and, for EP, the LDS-staged plain-store epilogue
         if (!d.vecA || !d.vecB || (g->ffn_mode != TC_FFN_LN_B && g->K % VEC) || g->N % VEC || g->nb2 != 1 || (uintptr_t)g->ffn_gamma % 16 || (uintptr_t)g->ffn_beta % 16 ||
@@ -1204,7 +1240,7 @@ extern "C" int tc_gemm(const TcGemm* g, void* stream) {
 }
 
 extern "C" int tc_gemm_pair(const TcGemm* a, const TcGemm* b, void* stream) {
-    if (!gemm_args_ok(a) || !gemm_args_ok(b)) return TC_ERR_ARG;
+    if (!gemm_args_ok(a) || !gemm_args_ok(b) || a->bn_part || b->bn_part) return TC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     if ((a->dtype == TC_BF16 || a->dtype == TC_F16) && b->dtype == a->dtype && !a->transA && !a->transB && !a->c_f32 && b->transA && !b->transB && b->c_f32 &&
         (a->ffn_mode == TC_FFN_NONE || a->ffn_mode == TC_FFN_EP) && (b->ffn_mode == TC_FFN_NONE || b->ffn_mode == TC_FFN_LN_B)) {
@@ -1228,7 +1264,7 @@ extern "C" int tc_gemm_pair(const TcGemm* a, const TcGemm* b, void* stream) {
 
 extern "C" int tc_gemm_multi(const TcGemm* g, int n, void* stream) {
     if (!g || n < 1) return TC_ERR_ARG;
-    for (int i = 0; i < n; ++i) if (!gemm_args_ok(g + i)) return TC_ERR_ARG;
+    for (int i = 0; i < n; ++i) if (!gemm_args_ok(g + i) || g[i].bn_part) return TC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     bool ok = n <= GEMM_MULTI_MAX;
     GemmMultiDev q;

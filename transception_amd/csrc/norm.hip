@@ -320,7 +320,13 @@ __global__ __launch_bounds__(256) void ln_param_grad_kernel(const T* __restrict_
 
 // ---------------------------------------------------------------------------------------------- BatchNorm
 // scratch layout: shift[C] | S1[nchunk][C] | S2[nchunk][C]
-__host__ __device__ inline int bn_nchunk(int rows) { int n = (rows + 63) / 64; return n < 1 ? 1 : (n > 128 ? 128 : n); }
+// Row chunks of the statistics pass.  EVERY workgroup of the apply kernels folds all chunks of its 64 channels, so the chunk count is
+// a per-workgroup read of nchunk x 512 bytes: at 128 chunks the apply pass of a [12544, 64] map (1.6 MB) read 12.5 MB of partials.
+#ifndef BN_MAX_CHUNKS
+#define BN_MAX_CHUNKS 128
+#endif
+inline int bn_chunk_cap() { static const int v = getenv("TC_BN_CHUNKS") ? atoi(getenv("TC_BN_CHUNKS")) : BN_MAX_CHUNKS; return v < 1 ? 1 : (v > 128 ? 128 : v); }
+inline int bn_nchunk(int rows) { int n = (rows + 63) / 64; const int cap = bn_chunk_cap(); return n < 1 ? 1 : (n > cap ? cap : n); }
 
 // mode 0 (forward stats):  S1 = sum(x - shift), S2 = sum((x-shift)^2), shift = x[0, c]
 // mode 1 (backward sums):  S1 = sum(dz), S2 = sum(dz * xhat), dz = dy * act'(z)
@@ -617,20 +623,21 @@ extern "C" int tc_layernorm_bwd_params(const void* dy, int lddy, const void* x, 
     return tc_launch_status();
 }
 
-extern "C" long long tc_bn_scratch_floats(int rows, int C) { return (long long)C * (1 + 2 * bn_nchunk(rows)); }
+extern "C" long long tc_bn_scratch_floats(int rows, int C) { int n = (rows + 63) / 64; n = n < 1 ? 1 : (n > 128 ? 128 : n); return (long long)C * (1 + 2 * n); }
 
 extern "C" int tc_bn_fwd(const void* x, int ldx, const void* gamma, const void* beta, float* running_mean,
                          float* running_var, const void* res, int ldres, void* y, int ldy, float* save_mean,
                          float* save_rstd, float* partial, int rows, int C, float eps, float momentum, int training,
-                         int act, int dtype, void* stream) {
+                         int stats_chunks, int act, int dtype, void* stream) {
     if (!x || !gamma || !beta || !running_mean || !running_var || !y || rows <= 0 || C <= 0 || (C & 3) || (ldx & 3) ||
-        (ldy & 3) || (res && (ldres & 3)) || (training && (!save_mean || !save_rstd || !partial)))
+        (ldy & 3) || (res && (ldres & 3)) || (training && (!save_mean || !save_rstd || !partial)) || stats_chunks < 0 ||
+        (stats_chunks > 0 && !training))
         return TC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    const int nchunk = bn_nchunk(rows);
+    const int nchunk = stats_chunks > 0 ? stats_chunks : bn_nchunk(rows);
     const int cb = (C + 63) / 64;
     TC_DISPATCH_DTYPE(dtype, {
-        if (training) {
+        if (training && stats_chunks == 0) {
             hipLaunchKernelGGL((bn_partial_kernel<T, 0>), dim3(nchunk, cb), dim3(256), 0, s, (const T*)x, ldx, (const T*)nullptr,
                                0, (const T*)gamma, (const T*)beta, (const float*)nullptr, (const float*)nullptr, partial, rows,
                                C, act);

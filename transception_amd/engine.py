@@ -27,6 +27,7 @@ _DT = {torch.float32: TC_F32, torch.bfloat16: TC_BF16, torch.float16: TC_F16}
 # launches with HIP events on the launching stream (the events are recorded on torch's current stream, which is the
 # stream every kernel here is launched on).
 PROFILE: Optional[dict] = None
+BN_STATS_IN_GEMM = os.environ.get("TC_BN_STATS_IN_GEMM", "1") != "0"     # A/B switch: BatchNorm statistics in the producing GEMM's epilogue
 
 
 def _timed(name: str, flops: float, fn):
@@ -78,7 +79,7 @@ class Var:
 
     Children made by colslice()/rowslice()/reshape() share the root's storage *and* the root's gradient buffer;
     every view knows the rectangle of the root it covers so that gradient writes from overlapping views accumulate."""
-    __slots__ = ("data", "root", "path", "kids", "grad_t", "whole_written", "written", "requires_grad", "region", "reshaped", "covered")
+    __slots__ = ("data", "root", "path", "kids", "grad_t", "whole_written", "written", "requires_grad", "region", "reshaped", "covered", "bn_part")
 
     def __init__(self, data: torch.Tensor, root: "Var" = None, path=None, requires_grad: bool = True, region=None,
                  reshaped: bool = False):
@@ -495,9 +496,12 @@ class Graph:
 
     # ------------------------------------------------------------------ GEMM plumbing
     def _gemm(self, A, lda, B, ldb, Cm, ldc, M, N, K, tA, tB, bias=None, R=None, ldr=0, alpha=1.0, acc=0, act=ACT_NONE,
-              splitk=1, nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), c_f32=0, atomic=0, rowsum=None, sbias=0, srow=0):
+              splitk=1, nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), c_f32=0, atomic=0, rowsum=None, sbias=0, srow=0,
+              bn_part=None, bn_shift=None):
         g = self._gemm_desc(A, lda, B, ldb, Cm, ldc, M, N, K, tA, tB, bias, R, ldr, alpha, acc, act, splitk, nb1, nb2, sA, sB, sC, sR,
                             c_f32, atomic, rowsum, sbias, srow)
+        if bn_part is not None:
+            g.bn_part, g.bn_shift = bn_part, bn_shift
         self.n_launch += 1
         _timed_gemm("single", [g], lambda: self.L.tc_gemm(C.byref(g), self.stream))
 
@@ -523,8 +527,12 @@ class Graph:
     # ------------------------------------------------------------------ ops
     def linear(self, x: Var, W: P, b: Optional[P] = None, out: Optional[Var] = None, residual: Optional[Var] = None,
                act: int = ACT_NONE, wcols: Optional[Tuple[int, int]] = None, accumulate: bool = False,
-               batch: Optional[Tuple[int, int, int, int]] = None, post_scale: Optional[float] = None) -> Var:
+               batch: Optional[Tuple[int, int, int, int]] = None, post_scale: Optional[float] = None,
+               bn_shift: Optional[torch.Tensor] = None) -> Var:
         """out = act(x @ W[:, wcols]^T + b + residual)  (or out += ... when accumulate).  W is [N, K] (nn.Linear).
+
+        bn_shift (fp32 [N], the running mean of the BatchNorm this output feeds in training mode): on 16-bit storage the GEMM's
+        epilogue leaves the statistics pass of that BatchNorm behind (TcGemm.bn_part) and batchnorm(out, ...) skips its own.
 
         post_scale c: out = c * (x W^T + b + residual), rounded once from the fp32 accumulator (TC_ACT_SCALE) -- the bridge's q
         projection hands the attention kernels q * scale * log2(e).  The consumer must hand back d loss / d(x W^T + b) as
@@ -556,10 +564,17 @@ class Graph:
             sw = 0
         if post_scale is not None:
             assert act == ACT_NONE and not accumulate
+        bn_part = None
+        if (bn_shift is not None and BN_STATS_IN_GEMM and self.training and self.dtype != torch.float32 and nb == 1 and not accumulate
+                and act == ACT_NONE and post_scale is None and N % 8 == 0 and out.ld % 8 == 0 and out.data.data_ptr() % 16 == 0):
+            tiles = (M + 63) // 64
+            bn_part = self.f32(N * (1 + 2 * max(tiles, 128)))        # (also the scratch of the BatchNorm's backward sums)
+            out.bn_part = (bn_part, tiles)
         self._gemm(_ptr(x.data), x.ld, _ptr(Wt), Wt.stride(0), _ptr(out.data), out.ld, M, N, K, 0, 1,
                    bias=_ptr(b.data) if b is not None else None, R=_ptr(residual.data) if residual is not None else None,
                    ldr=residual.ld if residual is not None else 0, acc=int(accumulate), act=act if post_scale is None else ACT_SCALE,
-                   alpha=1.0 if post_scale is None else post_scale, nb1=nb, sA=(sx, 0), sB=(sw, 0), sC=(so, 0), sR=(sr, 0), sbias=sw)
+                   alpha=1.0 if post_scale is None else post_scale, nb1=nb, sA=(sx, 0), sB=(sw, 0), sC=(so, 0), sR=(sr, 0), sbias=sw,
+                   bn_part=_ptr(bn_part) if bn_part is not None else None, bn_shift=_ptr(bn_shift) if bn_part is not None else None)
 
         def bwd():
             dy = self.grad_of(out)
@@ -1192,14 +1207,19 @@ class Graph:
         if self.record and not self.training:
             raise NotImplementedError("backward through BatchNorm in eval mode is not part of the reference path")
         smean = srstd = part = None
+        chunks = 0
         if self.training:
             smean, srstd = self.f32(Cc), self.f32(Cc)
-            part = self.f32(int(self.L.tc_bn_scratch_floats(rows, Cc)))
+            pre = getattr(x, "bn_part", None)                     # the producing GEMM's epilogue already made the statistics pass
+            if pre is not None:
+                part, chunks = pre
+            else:
+                part = self.f32(int(self.L.tc_bn_scratch_floats(rows, Cc)))
         es = x.data.element_size()
-        _timed("hbm:batchnorm_fwd", ((3.0 if self.training else 2.0) + (residual is not None)) * rows * Cc * es, lambda: self.L.tc_bn_fwd(
+        _timed("hbm:batchnorm_fwd", ((3.0 if self.training and not chunks else 2.0) + (residual is not None)) * rows * Cc * es, lambda: self.L.tc_bn_fwd(
             _ptr(x.data), x.ld, _ptr(gamma.data), _ptr(beta.data), _ptr(running_mean), _ptr(running_var),
             _ptr(residual.data) if residual is not None else None, residual.ld if residual is not None else 0, _ptr(out.data), out.ld,
-            _ptr(smean), _ptr(srstd), _ptr(part), rows, Cc, 1e-5, 0.1, int(self.training), act, self.dt, self.stream))
+            _ptr(smean), _ptr(srstd), _ptr(part), rows, Cc, 1e-5, 0.1, int(self.training), chunks, act, self.dt, self.stream))
 
         def bwd():
             dy = self.grad_of(out)

@@ -546,6 +546,12 @@ def _ln(M, G, x, name, eps=1e-5, act=ACT_NONE, out=None):
     return G.layernorm(x, M._P(G, name + ".weight"), M._P(G, name + ".bias"), eps, act, out)
 
 
+def _bn_shift(M, name):
+    """Shift of the BatchNorm statistics the producing GEMM leaves behind (engine.Graph.linear(bn_shift=...)): the layer's running
+    mean -- any per-channel constant gives the same mean / variance, one near the batch mean keeps the squared sums small."""
+    return M.get_submodule(name).running_mean
+
+
 def _bn(M, G, x, name, act, residual=None, out=None):
     holder = M.get_submodule(name)
     return G.batchnorm(x, M._P(G, name + ".weight"), M._P(G, name + ".bias"), holder.running_mean, holder.running_var, act,
@@ -620,17 +626,17 @@ def _ripm(M, G, m: Var, name: str, B: int, side: int) -> Tuple[Var, int]:
         pre = f"{name}.patch_embeds.{i}.patch_conv"
         y = G.dwconv(x, M._P(G, pre + ".dwconv.weight"), None, B, side, side, 3, stride)
         side = (side - 1) // stride + 1
-        z = G.linear(y, *_lin(M, G, pre + ".pwconv", bias=False))
+        z = G.linear(y, *_lin(M, G, pre + ".pwconv", bias=False), bn_shift=_bn_shift(M, pre + ".bn"))
         x = _bn(M, G, z, pre + ".bn", ACT_HSWISH, out=stack.rowslice(i * rows, (i + 1) * rows))
     return stack, side
 
 
 def _resblock(M, G, x: Var, name: str, B: int, side: int, out: Var) -> Var:
     """ResBlock, MSTr.py:1042-1050."""
-    f = _bn(M, G, G.linear(x, *_lin(M, G, name + ".conv1.conv", bias=False)), name + ".conv1.bn", ACT_HSWISH)
+    f = _bn(M, G, G.linear(x, *_lin(M, G, name + ".conv1.conv", bias=False), bn_shift=_bn_shift(M, name + ".conv1.bn")), name + ".conv1.bn", ACT_HSWISH)
     f = G.dwconv(f, M._P(G, name + ".dwconv.weight"), None, B, side, side, 3, 1)
     f = _bn(M, G, f, name + ".norm", ACT_HSWISH)
-    f = G.linear(f, *_lin(M, G, name + ".conv2.conv", bias=False))
+    f = G.linear(f, *_lin(M, G, name + ".conv2.conv", bias=False), bn_shift=_bn_shift(M, name + ".conv2.bn"))
     return _bn(M, G, f, name + ".conv2.bn", ACT_NONE, residual=x, out=out)
 
 
@@ -682,7 +688,7 @@ def _mhca_block(M, G, t: Var, blk: str, enc: str, B: int, side: int, out: Option
 def _coord_att(M, G, x: Var, name: str, B: int, side: int, out: Var) -> Var:
     """CoordAtt (IFF), MSTr.py:1322-1348."""
     pooled = G.coord_pool(x, B, side, side)
-    y = G.linear(pooled, *_lin(M, G, name + ".conv1"))
+    y = G.linear(pooled, *_lin(M, G, name + ".conv1"), bn_shift=_bn_shift(M, name + ".bn1"))
     y = _bn(M, G, y, name + ".bn1", ACT_COORD)
     att = G.new(2 * B * side, x.cols)
     half = B * side
@@ -712,7 +718,7 @@ def _mhca_stage(M, G, stack: Var, name: str, layers: int, B: int, side: int, out
             _resblock(M, G, stack.rowslice(0, rows), name + ".InvRes", B, side, cat.colslice(0, C))
     if M.concat == "coord":
         return _coord_att(M, G, cat, name + ".aggregate", B, side, out)
-    y = G.linear(cat, *_lin(M, G, name + ".aggregate.conv", bias=False))       # "normal": Conv2d_BN with Hardswish, MSTr.py:1384-1390
+    y = G.linear(cat, *_lin(M, G, name + ".aggregate.conv", bias=False), bn_shift=_bn_shift(M, name + ".aggregate.bn"))   # "normal": Conv2d_BN with Hardswish, MSTr.py:1384-1390
     return _bn(M, G, y, name + ".aggregate.bn", ACT_HSWISH, out=out)
 
 
