@@ -30,7 +30,8 @@ extern "C" {
 enum { TC_OK = 0, TC_ERR_ARG = -1, TC_ERR_LAUNCH = -2, TC_ERR_UNSUPPORTED = -3 };
 enum { TC_F32 = 0, TC_BF16 = 1, TC_F16 = 2 };
 enum { TC_ACT_NONE = 0, TC_ACT_HSWISH = 1, TC_ACT_COORD = 2, TC_ACT_SIGMOID = 3, TC_ACT_GELU = 4,
-       TC_ACT_SCALE = 5 /* tc_gemm only: C = alpha * (op(A) op(B) + bias + R), i.e. alpha applied AFTER bias and residual */ };
+       TC_ACT_SCALE = 5 /* tc_gemm only: C = alpha * (op(A) op(B) + bias + R), i.e. alpha applied AFTER bias and residual */,
+       TC_ACT_RELU = 6  /* tc_bn_fwd / tc_bn_bwd only (SE_Block's act(bn(.)), MSTr.py:590) */ };
 
 /* library identity: returns the ABI version (bumped on any signature change) */
 int tc_abi_version(void);
@@ -391,6 +392,19 @@ int tc_copy3d(const void* src, long long sbs, int lds, void* dst, long long sbd,
               int accumulate, int dtype, void* stream);
 /* batched transpose: dst[b, c, r] = src[b, r, c]  (logits NHWC -> NCHW, MSTr.py:281 permute) */
 int tc_transpose(const void* src, void* dst, int nb, int R, int Ccols, int dtype, void* stream);
+
+/* SE_Block (MSTr.py:571-594, the concat = "se" aggregate of MHCA_stage :1396-1397): x is [B*N, C] token rows (row stride ldx).
+ *   squeeze     pooled[b, c] = mean over the image's N rows of x                      (AdaptiveAvgPool2d(1), :586)
+ *   gate        y[b, n, c]   = x[b, n, c] * gate[b, c]                                (x * y.expand_as(x), :588)
+ * and their gradients: dx (+)= dpooled / N;  dx (+)= dy * gate, dgate[b, c] = sum_n dy * x.  pooled / gate / dgate are [B, C], storage dtype. */
+int tc_chan_pool_fwd(const void* x, int ldx, void* pooled, int B, int N, int C, int dtype, void* stream);
+int tc_chan_pool_bwd(const void* dpooled, void* dx, int lddx, int B, int N, int C, int accumulate, int dtype, void* stream);
+int tc_chan_gate_fwd(const void* x, int ldx, const void* gate, void* y, int ldy, int B, int N, int C, int dtype, void* stream);
+int tc_chan_gate_bwd(const void* dy, int lddy, const void* x, int ldx, const void* gate, void* dx, int lddx, int dx_accumulate,
+                     void* dgate, int B, int N, int C, int dtype, void* stream);
+/* y = max(x, 0) and dz = dy where y > 0 (nn.ReLU of SE_Block's excitation, MSTr.py:577; after its BatchNorm the ReLU is TC_ACT_RELU) */
+int tc_relu_fwd(const void* x, void* y, long long n, int dtype, void* stream);
+int tc_relu_bwd(const void* dy, const void* y, void* dz, long long n, int dtype, void* stream);
 
 /* CoordAtt pooling MSTr.py:1327-1332.  pooled/att rows: first B*H rows (b,h) = mean over w, then B*W rows (b,w) = mean over h
  * (a row permutation of the reference's per-image cat; BatchNorm statistics over rows are unaffected). */

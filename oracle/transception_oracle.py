@@ -49,7 +49,7 @@ class TransCeptionOracle:
         self.training = training
         # ablation switches of the reference constructor (MSTr.py:2760-2823) that this restatement follows: the aggregate of a
         # stage (:1384-1403), whether the bridge runs (:2840) and which bridge layers use channel attention (:2413-2420)
-        assert concat in ("coord", "normal") and have_bridge != "sp" and len(br_ch_att_list) == 4
+        assert concat in ("coord", "normal", "se") and have_bridge != "sp" and len(br_ch_att_list) == 4
         self.concat, self.have_bridge, self.br_ch_att_list = concat, have_bridge, tuple(bool(b) for b in br_ch_att_list)
         # running statistics are buffers: updated in place in training mode
         self.buffers = {k: v.clone() for k, v in params.items()
@@ -204,6 +204,16 @@ class TransCeptionOracle:
         cat = torch.cat(outs, dim=-1)
         if self.concat == "coord":
             return self.coord_att(cat, name + ".aggregate")
+        if self.concat == "se":
+            # SE_Block, MSTr.py:571-594: squeeze (mean over the map) -> Linear(4C, 4C/16, no bias) -> ReLU -> Linear(4C/16, 4C, no bias)
+            # -> sigmoid gates the channels; then conv1x1 (with bias) -> BatchNorm -> ReLU
+            B, H, W, C4 = cat.shape
+            agg = name + ".aggregate"
+            y = cat.mean(dim=(1, 2))
+            y = torch.relu(self.linear(y, agg + ".excitation.0", bias=False))
+            y = torch.sigmoid(self.linear(y, agg + ".excitation.2", bias=False))
+            z = self.linear((cat * y[:, None, None, :]).reshape(B, H * W, C4), agg + ".conv")
+            return torch.relu(self.batchnorm_rows(z, agg + ".bn")).reshape(B, H, W, -1)
         # "normal": Conv2d_BN(4C -> C_out, 1x1, no bias) + BatchNorm + Hardswish, MSTr.py:1384-1390 with Conv2d_BN :364-404
         B, H, W, C4 = cat.shape
         y = self.linear(cat.reshape(B, H * W, C4), name + ".aggregate.conv", bias=False)

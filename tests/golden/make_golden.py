@@ -237,6 +237,10 @@ VARIANTS = {   # name -> (constructor kwargs, gradient probes)
                     ["backbone.mhca_stage4.aggregate.conv_h.weight", "bridge.bridge_layer2.attn.k.weight",
                      "bridge.bridge_layer3.attn.scale_reduce.sr0.weight", "bridge.bridge_layer4.attn.proj.weight",
                      "bridge.bridge_layer4.mixffn2.fc1.weight", "decoder_0.last_layer.weight"]),
+    "concat_se": (dict(concat="se"),
+                  ["backbone.mhca_stage2.aggregate.excitation.0.weight", "backbone.mhca_stage3.aggregate.excitation.2.weight",
+                   "backbone.mhca_stage4.aggregate.conv.weight", "backbone.mhca_stage4.aggregate.conv.bias", "backbone.mhca_stage3.aggregate.bn.weight",
+                   "backbone.mhca_stage2.mhca_blks.1.MHCA_layers.0.mlp.fc1.weight", "decoder_0.last_layer.weight"]),
     "bridge_para": (dict(have_bridge="para"),
                     ["backbone.mhca_stage3.aggregate.conv1.weight", "bridge.bridge_layer1.attn.q.weight", "bridge.bridge_layer2.attn.kv.weight",
                      "bridge.proj_act.0.weight", "bridge.proj_act.0.bias", "bridge.proj_act.1.weight", "bridge.bridge_layer3.mixffn4.fc2.weight",

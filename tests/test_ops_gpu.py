@@ -239,6 +239,58 @@ def test_linear_leaves_batchnorm_statistics(M, N, K, bias, dtype):
         close(a, c, tol * max(1.0, float(c.abs().max())), 0.0, nm)
 
 
+@pytest.mark.parametrize("B,N,C", [(2, 784, 256), (3, 49, 1280), (1, 196, 512), (2, 37, 24)])
+def test_se_block_pieces(G, B, N, C):
+    """SE_Block (MSTr.py:584-593) op by op: squeeze, ReLU, channel gate, BatchNorm + ReLU -- forward and gradients against torch."""
+    from transception_amd._lib import ACT_RELU
+    x, gate = T(f"se.x{B}.{N}.{C}", (B * N, C)), torch.sigmoid(T(f"se.g{B}.{C}", (B, C)))
+    gy, gp = T(f"se.gy{B}.{N}.{C}", (B * N, C)), T(f"se.gp{B}.{C}", (B, C))
+    xr, gr = x.clone().requires_grad_(), gate.clone().requires_grad_()
+    pooled = xr.view(B, N, C).mean(1)
+    hid = torch.relu(pooled - 0.1)
+    out = (xr.view(B, N, C) * gr[:, None, :]).reshape(B * N, C)
+    (out * gy).sum().backward(retain_graph=True)
+    (hid * gp).sum().backward()
+    xv, gv = mkV(G, x), mkV(G, gate)
+    po = G.chan_pool(xv, B, N)
+    close(po.data, pooled, 1e-6, 1e-5, "squeeze")
+    sh = mkV(G, (pooled.detach() - 0.1))
+    rl = G.relu(sh)
+    close(rl.data, hid, 0, 0, "relu")
+    o = G.chan_gate(xv, gv, B, N)
+    close(o.data, out, 1e-6, 1e-5, "gate")
+    for v, g_ in ((o, gy), (po, gp)):
+        v.root.grad_t = g_.to(DEV).contiguous(); v.root.whole_written = True
+    rl.root.grad_t = gp.to(DEV).contiguous(); rl.root.whole_written = True
+    G.backward()
+    torch.cuda.synchronize()
+    want_dx = xr.grad                                             # gate path + pooled path (through relu(pooled - 0.1) in the torch graph)
+    got_dx = G.grad_of(xv).cpu() 
+    # the engine's pooled gradient is gp itself (po is a leaf output here), torch's went through the ReLU: rebuild torch's from the mask
+    mask = (pooled.detach() - 0.1 > 0).float()
+    want = (gy * gate[:, None, :].expand(B, N, C).reshape(B * N, C)) + ((gp / N)[:, None, :].expand(B, N, C).reshape(B * N, C))
+    close(got_dx, want, 1e-6, 1e-5, "dx = gate path + squeeze path")
+    close(want_dx, (gy * gate[:, None, :].expand(B, N, C).reshape(B * N, C)) + ((gp * mask / N)[:, None, :].expand(B, N, C).reshape(B * N, C)), 1e-6, 1e-5, "torch cross-check")
+    close(G.grad_of(gv), gr.grad, 2e-5, 2e-5, "dgate")
+    close(G.grad_of(sh), gp * mask, 0, 0, "relu gradient")
+    # BatchNorm + ReLU
+    rows = B * N
+    g, b = T(f"se.bg{C}", (C,)) * 0.2 + 1, T(f"se.bb{C}", (C,), 0.3)
+    rm, rv = T(f"se.rm{C}", (C,), 0.1), T(f"se.rv{C}", (C,)).abs() + 0.5
+    xr2, gr2, br2 = x.clone().requires_grad_(), g.clone().requires_grad_(), b.clone().requires_grad_()
+    y = torch.relu(F.batch_norm(xr2, rm.clone(), rv.clone(), gr2, br2, True, 0.1, 1e-5))
+    y.backward(gy)
+    from transception_amd.engine import Graph
+    G2 = Graph(torch.float32, torch.device(DEV), training=True, record=True)
+    xv2, gP, bP = mkV(G2, x), mkP(g), mkP(b)
+    ob = G2.batchnorm(xv2, gP, bP, rm.to(DEV), rv.to(DEV), ACT_RELU)
+    close(ob.data, y, 3e-5, 3e-5, "relu(bn)")
+    run_bwd(G2, ob, gy)
+    close(G2.grad_of(xv2), xr2.grad, 1e-4, 1e-4, "bn dx")
+    close(gP.grad, gr2.grad, 3e-4, 3e-4, "bn dgamma")
+    close(bP.grad, br2.grad, 3e-4, 3e-4, "bn dbeta")
+
+
 def test_batchnorm_eval():
     from transception_amd.engine import Graph
     Ge = Graph(torch.float32, torch.device(DEV), training=False, record=False)

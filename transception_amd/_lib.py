@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TC_LIB_PATH") or os.path.join(HERE, "libtransception_hip.so")   # override: A/B kernel experiments only
 
 TC_F32, TC_BF16, TC_F16 = 0, 1, 2
-ACT_NONE, ACT_HSWISH, ACT_COORD, ACT_SIGMOID, ACT_GELU, ACT_SCALE = 0, 1, 2, 3, 4, 5
+ACT_NONE, ACT_HSWISH, ACT_COORD, ACT_SIGMOID, ACT_GELU, ACT_SCALE, ACT_RELU = 0, 1, 2, 3, 4, 5, 6
 ABI_VERSION = 11
 ATTN_DKV_SPLITS = 8                # include/transception_hip.h: partial dK|dV buffers in tc_attn_bwd_seg's fp32 scratch
 
@@ -143,6 +143,12 @@ SIGNATURES = {
     "tc_sigmoid_bwd": [vp, vp, vp, i64, i32, vp],
     "tc_copy3d": [vp, i64, i32, vp, i64, i32, i32, i32, i32, i32, i32, vp],
     "tc_transpose": [vp, vp, i32, i32, i32, i32, vp],
+    "tc_chan_pool_fwd": [vp, i32, vp, i32, i32, i32, i32, vp],
+    "tc_chan_pool_bwd": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "tc_chan_gate_fwd": [vp, i32, vp, vp, i32, i32, i32, i32, i32, vp],
+    "tc_chan_gate_bwd": [vp, i32, vp, i32, vp, vp, i32, i32, vp, i32, i32, i32, i32, vp],
+    "tc_relu_fwd": [vp, vp, i64, i32, vp],
+    "tc_relu_bwd": [vp, vp, vp, i64, i32, vp],
     "tc_coord_pool_fwd": [vp, vp, i32, i32, i32, i32, i32, vp],
     "tc_coord_pool_bwd": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "tc_coord_gate_fwd": [vp, vp, vp, i32, i32, i32, i32, i32, vp],

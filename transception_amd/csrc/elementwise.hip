@@ -99,6 +99,89 @@ __global__ void transpose_kernel(const T* src, T* dst, int R, int Cc) {
     for (int j = ty; j < 32; j += 8) if (c0 + j < Cc && r0 + tx < R) stf<T>(d + (long long)(c0 + j) * R + r0 + tx, tile[tx][j]);
 }
 
+// ---------------------------------------------------------------- SE_Block (concat = "se"): squeeze, gate, ReLU
+// One workgroup = (image b, 64 channels): 16 channel quads x 16 row lanes walk the image's N token rows; the 16 row lanes meet in LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void chan_pool_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ pooled, int N, int C) {
+    __shared__ float4 red[16][16];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4, c = blockIdx.y * 64 + tx * 4, b = blockIdx.x;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < C)
+        for (int r = ty; r < N; r += 16) { const float4 v = ld4<T>(x + ((long long)b * N + r) * ldx + c); s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        float4 t = red[0][tx];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) { const float4 v = red[k][tx]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        const float inv = 1.f / (float)N;
+        st4<T>(pooled + (long long)b * C + c, make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv));
+    }
+}
+
+template <typename T>
+__global__ void chan_pool_bwd_kernel(const T* dp, T* dx, int lddx, int B, int N, int C, int acc) {
+    const int cq = C >> 2;
+    const float inv = 1.f / (float)N;
+    TC_GRID_STRIDE(i, (long long)B * N * cq) {
+        const int q = (int)(i % cq) * 4; const unsigned row = i / cq; const int b = (int)(row / (unsigned)N);
+        const float4 g = ld4<T>(dp + (long long)b * C + q);
+        float4 o = make_float4(g.x * inv, g.y * inv, g.z * inv, g.w * inv);
+        T* d = dx + (long long)row * lddx + q;
+        if (acc) { const float4 v = ld4<T>(d); o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w; }
+        st4<T>(d, o);
+    }
+}
+
+template <typename T>
+__global__ void chan_gate_fwd_kernel(const T* x, int ldx, const T* g, T* y, int ldy, int B, int N, int C) {
+    const int cq = C >> 2;
+    TC_GRID_STRIDE(i, (long long)B * N * cq) {
+        const int q = (int)(i % cq) * 4; const unsigned row = i / cq; const int b = (int)(row / (unsigned)N);
+        const float4 v = ld4<T>(x + (long long)row * ldx + q), a = ld4<T>(g + (long long)b * C + q);
+        st4<T>(y + (long long)row * ldy + q, make_float4(v.x * a.x, v.y * a.y, v.z * a.z, v.w * a.w));
+    }
+}
+
+// dx (+)= dy * g[b]; dg[b][c] = sum over the image's rows of dy * x
+template <typename T>
+__global__ __launch_bounds__(256) void chan_gate_bwd_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ x, int ldx,
+                                                            const T* __restrict__ g, T* __restrict__ dx, int lddx, int acc,
+                                                            T* __restrict__ dg, int N, int C) {
+    __shared__ float4 red[16][16];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4, c = blockIdx.y * 64 + tx * 4, b = blockIdx.x;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < C) {
+        const float4 a = ld4<T>(g + (long long)b * C + c);
+        for (int r = ty; r < N; r += 16) {
+            const long long row = (long long)b * N + r;
+            const float4 d = ld4<T>(dy + row * lddy + c), v = ld4<T>(x + row * ldx + c);
+            s.x += d.x * v.x; s.y += d.y * v.y; s.z += d.z * v.z; s.w += d.w * v.w;
+            float4 o = make_float4(d.x * a.x, d.y * a.y, d.z * a.z, d.w * a.w);
+            T* dst = dx + row * lddx + c;
+            if (acc) { const float4 w = ld4<T>(dst); o.x += w.x; o.y += w.y; o.z += w.z; o.w += w.w; }
+            st4<T>(dst, o);
+        }
+    }
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        float4 t = red[0][tx];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) { const float4 v = red[k][tx]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        st4<T>(dg + (long long)b * C + c, t);
+    }
+}
+
+template <typename T>
+__global__ void relu_fwd_kernel(const T* x, T* y, long long n) {
+    TC_GRID_STRIDE64(i, n) { stf<T>(y + i, fmaxf(ldf<T>(x + i), 0.f)); }
+}
+template <typename T>
+__global__ void relu_bwd_kernel(const T* dy, const T* y, T* dz, long long n) {
+    TC_GRID_STRIDE64(i, n) { stf<T>(dz + i, ldf<T>(y + i) > 0.f ? ldf<T>(dy + i) : 0.f); }
+}
+
 // ---------------------------------------------------------------- CoordAtt (IFF) pooling and gating
 template <typename T>
 __global__ void coord_pool_fwd_kernel(const T* x, T* pooled, int B, int H, int W, int C) {
@@ -329,6 +412,40 @@ extern "C" int tc_transpose(const void* src, void* dst, int nb, int R, int Cc, i
     dim3 grid((Cc + 31) / 32, (R + 31) / 32, nb);
     if (grid.y > 65535) return TC_ERR_ARG;
     TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((transpose_kernel<T>), grid, dim3(256), 0, TC_S, (const T*)src, (T*)dst, R, Cc));
+    return tc_launch_status();
+}
+extern "C" int tc_chan_pool_fwd(const void* x, int ldx, void* pooled, int B, int N, int C, int dtype, void* stream) {
+    if (!x || !pooled || B <= 0 || N <= 0 || C <= 0 || ((C | ldx) & 3)) return TC_ERR_ARG;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((chan_pool_fwd_kernel<T>), dim3(B, (C + 63) / 64), dim3(256), 0, TC_S, (const T*)x, ldx, (T*)pooled, N, C));
+    return tc_launch_status();
+}
+extern "C" int tc_chan_pool_bwd(const void* dpooled, void* dx, int lddx, int B, int N, int C, int accumulate, int dtype, void* stream) {
+    if (!dpooled || !dx || B <= 0 || N <= 0 || C <= 0 || ((C | lddx) & 3)) return TC_ERR_ARG;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((chan_pool_bwd_kernel<T>), g1((long long)B * N * C / 4), dim3(256), 0, TC_S, (const T*)dpooled,
+                                                (T*)dx, lddx, B, N, C, accumulate));
+    return tc_launch_status();
+}
+extern "C" int tc_chan_gate_fwd(const void* x, int ldx, const void* gate, void* y, int ldy, int B, int N, int C, int dtype, void* stream) {
+    if (!x || !gate || !y || B <= 0 || N <= 0 || C <= 0 || ((C | ldx | ldy) & 3)) return TC_ERR_ARG;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((chan_gate_fwd_kernel<T>), g1((long long)B * N * C / 4), dim3(256), 0, TC_S, (const T*)x, ldx,
+                                                (const T*)gate, (T*)y, ldy, B, N, C));
+    return tc_launch_status();
+}
+extern "C" int tc_chan_gate_bwd(const void* dy, int lddy, const void* x, int ldx, const void* gate, void* dx, int lddx, int dx_accumulate,
+                                void* dgate, int B, int N, int C, int dtype, void* stream) {
+    if (!dy || !x || !gate || !dx || !dgate || B <= 0 || N <= 0 || C <= 0 || ((C | lddy | ldx | lddx) & 3)) return TC_ERR_ARG;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((chan_gate_bwd_kernel<T>), dim3(B, (C + 63) / 64), dim3(256), 0, TC_S, (const T*)dy, lddy,
+                                                (const T*)x, ldx, (const T*)gate, (T*)dx, lddx, dx_accumulate, (T*)dgate, N, C));
+    return tc_launch_status();
+}
+extern "C" int tc_relu_fwd(const void* x, void* y, long long n, int dtype, void* stream) {
+    if (!x || !y || n <= 0) return TC_ERR_ARG;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((relu_fwd_kernel<T>), g1_64(n), dim3(256), 0, TC_S, (const T*)x, (T*)y, n));
+    return tc_launch_status();
+}
+extern "C" int tc_relu_bwd(const void* dy, const void* y, void* dz, long long n, int dtype, void* stream) {
+    if (!dy || !y || !dz || n <= 0) return TC_ERR_ARG;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((relu_bwd_kernel<T>), g1_64(n), dim3(256), 0, TC_S, (const T*)dy, (const T*)y, (T*)dz, n));
     return tc_launch_status();
 }
 extern "C" int tc_coord_pool_fwd(const void* x, void* pooled, int B, int H, int W, int C, int dtype, void* stream) {

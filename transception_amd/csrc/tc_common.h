@@ -223,6 +223,7 @@ __device__ __forceinline__ float apply_act(int act, float v) {
         case TC_ACT_COORD: return coordact_f(v);
         case TC_ACT_SIGMOID: return sigmoid_f(v);
         case TC_ACT_GELU: return gelu_f(v);
+        case TC_ACT_RELU: return fmaxf(v, 0.f);
         default: return v;
     }
 }
@@ -232,6 +233,7 @@ __device__ __forceinline__ float act_grad(int act, float z) {
         case TC_ACT_COORD: return coordact_grad_f(z);
         case TC_ACT_SIGMOID: { const float s = sigmoid_f(z); return s * (1.0f - s); }
         case TC_ACT_GELU: return gelu_grad_f(z);
+        case TC_ACT_RELU: return z > 0.f ? 1.0f : 0.f;
         default: return 1.0f;
     }
 }

@@ -1375,6 +1375,53 @@ class Graph:
         self._rec(bwd)
         return out
 
+    def chan_pool(self, x: Var, B: int, N: int) -> Var:
+        """SE_Block squeeze (MSTr.py:586): [B, C] means over each image's N token rows."""
+        out = self.new(B, x.cols)
+        self.L.tc_chan_pool_fwd(_ptr(x.data), x.ld, _ptr(out.data), B, N, x.cols, self.dt, self.stream)
+
+        def bwd():
+            d = self.grad_of(out)
+            if d is None:
+                return
+            assert d.is_contiguous()
+            gx, acc = self.wgrad(x)
+            self.L.tc_chan_pool_bwd(_ptr(d), _ptr(gx), gx.stride(0), B, N, x.cols, acc, self.dt, self.stream)
+        self._rec(bwd)
+        return out
+
+    def chan_gate(self, x: Var, gate: Var, B: int, N: int) -> Var:
+        """SE_Block gating (MSTr.py:588): out[b, n, :] = x[b, n, :] * gate[b, :]."""
+        assert gate.data.is_contiguous() and gate.rows == B and gate.cols == x.cols
+        out = self.new(x.rows, x.cols)
+        self.L.tc_chan_gate_fwd(_ptr(x.data), x.ld, _ptr(gate.data), _ptr(out.data), out.ld, B, N, x.cols, self.dt, self.stream)
+
+        def bwd():
+            d = self.grad_of(out)
+            if d is None:
+                return
+            gx, acc = self.wgrad(x)
+            gg, accg = self.wgrad(gate)
+            assert not accg and gg.is_contiguous()
+            self.L.tc_chan_gate_bwd(_ptr(d), d.stride(0), _ptr(x.data), x.ld, _ptr(gate.data), _ptr(gx), gx.stride(0), acc, _ptr(gg), B, N,
+                                    x.cols, self.dt, self.stream)
+        self._rec(bwd)
+        return out
+
+    def relu(self, x: Var) -> Var:
+        assert x.data.is_contiguous()
+        out = self.new(x.rows, x.cols)
+        self.L.tc_relu_fwd(_ptr(x.data), _ptr(out.data), x.data.numel(), self.dt, self.stream)
+
+        def bwd():
+            d = self.grad_of(out)
+            if d is None:
+                return
+            assert d.is_contiguous()
+            self._write_or_add(x, lambda g: self.L.tc_relu_bwd(_ptr(d), _ptr(out.data), _ptr(g), d.numel(), self.dt, self.stream))
+        self._rec(bwd)
+        return out
+
     def pixel_shuffle(self, x: Var, B: int, H: int, W: int, p: int) -> Var:
         c = x.cols // (p * p)
         assert x.data.is_contiguous()

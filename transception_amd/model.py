@@ -22,7 +22,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 import torch.nn as nn
 
-from ._lib import ACT_COORD, ACT_GELU, ACT_HSWISH, ACT_NONE, ACT_SIGMOID, TC_BF16, TC_F16, TC_F32, lib
+from ._lib import ACT_COORD, ACT_GELU, ACT_HSWISH, ACT_NONE, ACT_RELU, ACT_SIGMOID, TC_BF16, TC_F16, TC_F32, lib
 from .engine import Graph, P, Var
 
 DIMS = (64, 128, 320, 512)
@@ -139,8 +139,19 @@ def _mk_mhca_stage(dim: int, out_dim: int, layers: int, concat: str = "coord") -
     m = nn.Module()
     m.mhca_blks = nn.ModuleList([_mk_mhca_encoder(dim, layers) for _ in range(3)])
     m.InvRes = _mk_resblock(dim)
-    # aggregate of the four branch outputs: CoordAtt (IFF, the default, :1402-1403) or Conv1x1 + BN + Hardswish ("normal", :1384-1390)
-    m.aggregate = _mk_coord_att(dim * 4, out_dim) if concat == "coord" else _mk_conv2d_bn(dim * 4, out_dim)
+    # aggregate of the four branch outputs: CoordAtt (IFF, the default, :1402-1403), Conv1x1 + BN + Hardswish ("normal", :1384-1390)
+    # or SE_Block ("se", :1396-1397, 571-583)
+    if concat == "coord":
+        m.aggregate = _mk_coord_att(dim * 4, out_dim)
+    elif concat == "se":
+        a = nn.Module()
+        a.excitation = nn.Sequential(nn.Linear(dim * 4, dim * 4 // 16, bias=False), nn.ReLU(inplace=True),
+                                     nn.Linear(dim * 4 // 16, dim * 4, bias=False), nn.Sigmoid())
+        a.conv = nn.Conv2d(dim * 4, out_dim, 1)
+        a.bn = nn.BatchNorm2d(out_dim)
+        m.aggregate = a
+    else:
+        m.aggregate = _mk_conv2d_bn(dim * 4, out_dim)
     return m
 
 
@@ -259,17 +270,18 @@ class MSTransception(nn.Module):
         super().__init__()
         # Ablation switches of the reference constructor (MSTr.py:2760-2823) that compose from the kernels of the default path:
         #   concat       "coord" (CoordAtt / IFF, default) | "normal" (Conv1x1 + BN + Hardswish over the concatenation, :1384-1390)
+        #                | "se" (SE_Block over the concatenation, :571-594: squeeze / excitation gate, Conv1x1 + BN + ReLU)
         #   have_bridge  "original" (default) | "None" (the bridge is built -- its parameters stay in the state_dict -- but skipped, :2840)
         #   br_ch_att_list  which of the four bridge layers use channel attention instead of SR self-attention (:2413-2420)
         # use_sa_config / sa_ker / inter / num_sp only reach the "cbam", "sp" and "para" variants and are accepted and ignored, as in
         #                | "para" (BridgeBlock_para, :2500-2538: channel and spatial layer side by side, Linear(128->64)+LN+GELU, two
         #                  more spatial layers)
-        # the reference.  Not built: concat in {3d, se, skn, cbam, cam}, have_bridge = sp, Stage_3or4 != 3,
+        # the reference.  Not built: concat in {3d, skn, cbam, cam}, have_bridge = sp, Stage_3or4 != 3,
         # token_mlp_mode != "mix_skip", and the legacy networks/Transception.py class.
         br = [bool(b) for b in br_ch_att_list]
-        if (token_mlp_mode != "mix_skip" or concat not in ("coord", "normal") or have_bridge == "sp" or Stage_3or4 != 3
+        if (token_mlp_mode != "mix_skip" or concat not in ("coord", "normal", "se") or have_bridge == "sp" or Stage_3or4 != 3
                 or len(br) != 4):
-            raise NotImplementedError("MSTransception: implemented are concat in {'coord', 'normal'}, have_bridge in {'original', "
+            raise NotImplementedError("MSTransception: implemented are concat in {'coord', 'normal', 'se'}, have_bridge in {'original', "
                                       "'None', 'para'}, any 4-entry br_ch_att_list, Stage_3or4 = 3, token_mlp_mode = 'mix_skip'")
         if have_bridge == "para":                       # BridgeBlock_para ignores br_ch_att_list (it receives num_sp, MSTr.py:2806-2807):
             br = [True, False, False, False]            # layer 1 channel, layers 2-4 spatial (MSTr.py:2504-2512)
@@ -718,6 +730,12 @@ def _mhca_stage(M, G, stack: Var, name: str, layers: int, B: int, side: int, out
             _resblock(M, G, stack.rowslice(0, rows), name + ".InvRes", B, side, cat.colslice(0, C))
     if M.concat == "coord":
         return _coord_att(M, G, cat, name + ".aggregate", B, side, out)
+    if M.concat == "se":                                                         # SE_Block, MSTr.py:584-593
+        agg = name + ".aggregate"
+        y = G.relu(G.linear(G.chan_pool(cat, B, side * side), *_lin(M, G, agg + ".excitation.0", bias=False)))
+        y = G.linear(y, *_lin(M, G, agg + ".excitation.2", bias=False), act=ACT_SIGMOID)
+        z = G.linear(G.chan_gate(cat, y, B, side * side), *_lin(M, G, agg + ".conv"), bn_shift=_bn_shift(M, agg + ".bn"))
+        return _bn(M, G, z, agg + ".bn", ACT_RELU, out=out)
     y = G.linear(cat, *_lin(M, G, name + ".aggregate.conv", bias=False), bn_shift=_bn_shift(M, name + ".aggregate.bn"))   # "normal": Conv2d_BN with Hardswish, MSTr.py:1384-1390
     return _bn(M, G, y, name + ".aggregate.bn", ACT_HSWISH, out=out)
 
