@@ -351,7 +351,7 @@ __global__ __launch_bounds__(FW_NT, 1) void attn_bwd_dq_seg_kernel(const bf16_t*
                                                                    const bf16_t* __restrict__ O, int ldo,
                                                                    const bf16_t* __restrict__ dO, int lddo, const float* __restrict__ lse,
                                                                    float* __restrict__ delta, bf16_t* __restrict__ dQ, int lddq, Segs sg,
-                                                                   int Nk, float scale, float qs, int wide_o) {
+                                                                   int Nk, float scale, float qs, int wide_o, float* __restrict__ nstat) {
     extern __shared__ __attribute__((aligned(16))) bf16_t fw_smem[];      // [2 slots][K tile | V tile][KB][LDR], then FW_NW wave tiles [32][LDR]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
     const int nwt = sg.t32[sg.n], bpi = (nwt + FW_NW - 1) / FW_NW;
@@ -425,6 +425,13 @@ __global__ __launch_bounds__(FW_NT, 1) void attn_bwd_dq_seg_kernel(const bf16_t*
     const float dlt = O ? reinterpret_cast<const float*>(wtile)[j] : (ok ? delta[trow0 + j] : 0.f);
     const float dls = ok ? dlt * scale : 0.f;                   // dS = P (dP scale - delta scale)
     const float dl0 = ok ? dlt : 0.f;
+    // the hand-scheduled dK/dV stream reads the row statistics per 32-query TILE: [image][tile][-lse log2(e) x 32 | -delta x 32], rows past
+    // the end of a segment as (-1e30, 0) so that their P is exactly 0
+    if (nstat && live && h == 0) {
+        float* st = nstat + ((long long)b * nwt + wt) * 64;
+        st[j] = ok ? -l2 : NEG_BIG;
+        st[32 + j] = -dl0;
+    }
     constexpr bool QSC = QM != 0;                               // QM bit 0: -l2 is the C operand of S; bit 1: -delta the C operand of dP
     f32x16 acc0, acc1;
 #pragma unroll
@@ -539,6 +546,9 @@ __device__ unsigned long long g_dkv_dbg[512 * 4];
 // QSC (Q stored as q * scale * log2(e), `qs` = 1): the stage keeps -lse * log2(e) and -delta, and they are the INITIAL values of
 // the S and dP accumulators -- P = exp2(S), dS = P dP' with no multiply-add per score (a third of the kernel's VALU work, which
 // shares the SIMD's issue slots with the MFMAs); the factor ln 2 of dK (`scale`) is applied once to the accumulators at the end.
+#ifndef DKV_PIPE
+#define DKV_PIPE 0
+#endif
 #ifndef DKV_QS
 #define DKV_QS 64                                               // queries per stage of the dK/dV kernel (whole 32-query tiles)
 #endif
@@ -648,10 +658,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16
         const bf16_t* dOs = Qs + QS * LDQ;
         const float* lss = reinterpret_cast<const float*>(dOs + QS * LDQ);
         const float* dls = lss + QS;
-#pragma unroll
-        for (int qt = 0; qt < NT; ++qt) {
+        // S / dP of 32-query tile qt + 1 are issued BEFORE the exp2 / multiply / pack / dV^T / dK^T work of tile qt (DKV_PIPE, within a
+        // stage): two waves per SIMD do not cover each other's dependent chains, the wave's own next tile does
+        auto sdp = [&](int qt, f32x16& s, f32x16& dp, f32x16& lq, f32x16& dq) __attribute__((always_inline)) {
             // the 16 log-sum-exps and (scaled) deltas of this lane's query rows: four 16-byte LDS reads each instead of 16 scalar ones
-            f32x16 lq, dq;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 a = *reinterpret_cast<const float4*>(lss + 32 * qt + 16 * h + 4 * g);
@@ -659,7 +669,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16
                 lq[4 * g] = a.x; lq[4 * g + 1] = a.y; lq[4 * g + 2] = a.z; lq[4 * g + 3] = a.w;
                 dq[4 * g] = c.x; dq[4 * g + 1] = c.y; dq[4 * g + 2] = c.z; dq[4 * g + 3] = c.w;
             }
-            f32x16 s, dp;
             if (QSC) { s = lq; dp = dq; }                        // accumulators start at -lse log2(e) and -delta
             else {
 #pragma unroll
@@ -672,6 +681,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16
                 s = TcHalf<H>::mfma(ld_frag<V8>(qp + 16 * ks), kf[ks], s);
                 dp = TcHalf<H>::mfma(ld_frag<V8>(gp + 16 * ks), vf[ks], dp);
             }
+        };
+        auto fold = [&](int qt, f32x16& s, f32x16& dp, const f32x16& lq, const f32x16& dq) __attribute__((always_inline)) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 if (QSC) {
@@ -695,7 +706,23 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16
                 dk0 = TcHalf<H>::mfma(ld_frag_tr<V8>(qtp + (2 * k2) * LDQ, qtp + (2 * k2 + 1) * LDQ), db, dk0);
                 dk1 = TcHalf<H>::mfma(ld_frag_tr<V8>(qtp + (2 * k2) * LDQ + 32, qtp + (2 * k2 + 1) * LDQ + 32), db, dk1);
             }
+        };
+#if DKV_PIPE
+        f32x16 sv[2], dpv[2], lqv[2], dqv[2];
+        sdp(0, sv[0], dpv[0], lqv[0], dqv[0]);
+#pragma unroll
+        for (int qt = 0; qt < NT; ++qt) {
+            if (qt + 1 < NT) sdp(qt + 1, sv[(qt + 1) & 1], dpv[(qt + 1) & 1], lqv[(qt + 1) & 1], dqv[(qt + 1) & 1]);
+            fold(qt, sv[qt & 1], dpv[qt & 1], lqv[qt & 1], dqv[qt & 1]);
         }
+#else
+#pragma unroll
+        for (int qt = 0; qt < NT; ++qt) {
+            f32x16 s, dp, lq, dq;
+            sdp(qt, s, dp, lq, dq);
+            fold(qt, s, dp, lq, dq);
+        }
+#endif
         __syncthreads();
     }
     DSTAMP(1);
@@ -721,6 +748,112 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16
         }
     }
     DSTAMP(2);
+}
+
+// dK/dV, hand-scheduled (gen_dkv_asm.py; Q stored scaled, 16-byte addressable rows): the decomposition of attn_bwd_dkv_seg_kernel -- workgroup =
+// (4 x 32 keys of one image, one chunk of that image's 32-query tiles), every wave owns 32 keys -- with the 32-query sub-tiles of
+// Q | dO | statistics streaming through an 8-slot LDS ring (buffer loads six sub-tiles ahead, one barrier per two sub-tiles).  This
+// function stages sub-tiles 0..4 and the parameter block, runs the stream and stores the [d][key] fp32 tiles it leaves in LDS.
+#include "attn_dkv_asm.inc"
+constexpr int DA_TILE = 32 * LDR * 2, DA_SLOT = 2 * DA_TILE + 256, DA_NSLOT = 8, DA_AHEAD = 6, DA_PRM0 = DA_NSLOT * DA_SLOT, DA_SMEM = DA_PRM0 + 64;
+constexpr int DA_RED = D * 33 * 4;
+static_assert(4 * 2 * DA_RED <= DA_NSLOT * DA_SLOT, "the accumulator tiles of the four waves fit the ring");
+template <typename H>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_asm_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
+                                                                    const bf16_t* __restrict__ V, int ldv, long long skv,
+                                                                    const bf16_t* __restrict__ dO, int lddo, const float* __restrict__ nstat,
+                                                                    float* __restrict__ dkv32, Segs sg, int Nk, float kscale, int tiles_per_chunk,
+                                                                    long long rows) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char da_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    const int lin = xcd_block((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x * gridDim.y * gridDim.z);
+    const int bkx = lin % gridDim.x, b = (lin / gridDim.x) % gridDim.y, bkz = lin / (gridDim.x * gridDim.y);
+    const int kv0 = (bkx * 4 + wave) * 32, key = min(kv0 + j, Nk - 1);
+    const int ntiles = sg.t32[sg.n];
+    const int t_begin = bkz * tiles_per_chunk, nsub = min(ntiles, t_begin + tiles_per_chunk) - t_begin;
+    // first row of tile t of this image = A_s + 32 t, s = the segment of t
+    int As[4], Ts[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        As[i] = i < sg.n ? sg.row0[i] + b * sg.nq[i] - 32 * sg.t32[i] : 0;
+        Ts[i] = i < sg.n ? sg.t32[i] : 0x7fffffff;
+    }
+    const int sr = tid >> 3, sc = tid & 7;
+#pragma unroll
+    for (int s = 0; s < DA_AHEAD - 1; ++s) {                    // sub-tiles 0..4 into ring slots 0..4
+        const int t = t_begin + s;
+        int a = As[0];
+#pragma unroll
+        for (int i = 1; i < 4; ++i) if (t >= Ts[i]) a = As[i];
+        const long long row = (long long)a + 32LL * t + sr;
+        const bool in = row >= 0 && row < rows;
+        const uint4 qv = in ? *reinterpret_cast<const uint4*>(Q + row * ldq + 8 * sc) : make_uint4(0u, 0u, 0u, 0u);
+        const uint4 gv = in ? *reinterpret_cast<const uint4*>(dO + row * lddo + 8 * sc) : make_uint4(0u, 0u, 0u, 0u);
+        unsigned char* slot = da_smem + s * DA_SLOT;
+        *reinterpret_cast<uint4*>(slot + key_row(sr) * (LDR * 2) + 16 * sc) = qv;
+        *reinterpret_cast<uint4*>(slot + DA_TILE + key_row(sr) * (LDR * 2) + 16 * sc) = gv;
+        if (tid < 16)
+            *reinterpret_cast<uint4*>(slot + 2 * DA_TILE + 16 * tid) =
+                t < ntiles ? *reinterpret_cast<const uint4*>(nstat + ((long long)b * ntiles + t) * 64 + 4 * tid) : make_uint4(0u, 0u, 0u, 0u);
+    }
+    if (tid < 16) {
+        int v = 0;
+        switch (tid) {
+            case 0: v = nsub; break;
+            case 1: v = t_begin + DA_AHEAD - 1; break;
+            case 2: v = (b * ntiles + t_begin + DA_AHEAD - 1) * 256; break;
+            case 3: v = Ts[1]; break;
+            case 4: v = Ts[2]; break;
+            case 5: v = Ts[3]; break;
+            case 6: v = As[0]; break;
+            case 7: v = As[1]; break;
+            case 8: v = As[2]; break;
+            case 9: v = As[3]; break;
+            case 10: v = ldq * 2; break;
+            case 11: v = lddo * 2; break;
+            case 12: v = __float_as_int(kscale); break;
+            default: break;
+        }
+        reinterpret_cast<int*>(da_smem + DA_PRM0)[tid] = v;
+    }
+    __syncthreads();
+    {
+        const unsigned lds0 = (unsigned)(uintptr_t)da_smem;
+        const int gi = lane & 15, gq = (lane >> 4) & 1;
+        const unsigned vq = (unsigned)((sr * ldq + 8 * sc) * 2), vg = (unsigned)((sr * lddo + 8 * sc) * 2), vs = (unsigned)(16 * (tid & 15));
+        const unsigned wq = lds0 + key_row(sr) * (LDR * 2) + 16 * sc, ws = lds0 + 2 * DA_TILE + 16 * (tid & 15);
+        const unsigned rb = lds0 + key_row(pi_row(j)) * (LDR * 2) + 16 * h;
+        const unsigned tb = lds0 + (16 * h + 4 * (gi >> 2)) * (LDR * 2) + 32 * gq + 8 * (gi & 3);
+        const unsigned sb = lds0 + 2 * DA_TILE + 64 * h;
+        const unsigned ko = (unsigned)((key * ldk + 8 * h) * 2), vo = (unsigned)((key * ldv + 8 * h) * 2);
+        const unsigned red = lds0 + wave * (2 * DA_RED) + (4 * h * 33 + j) * 4;
+        const unsigned prm = lds0 + DA_PRM0;
+        auto mk = [](const void* p, long long bytes) {
+            const unsigned long long a = (unsigned long long)(uintptr_t)p;
+            return tc_i32x4{__builtin_amdgcn_readfirstlane((int)(unsigned)a), __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32)),
+                            __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000};
+        };
+        const tc_i32x4 rq = mk(Q, ((rows - 1) * ldq + D) * 2), rg = mk(dO, ((rows - 1) * lddo + D) * 2);
+        const tc_i32x4 rs = mk(nstat, (long long)gridDim.y * ntiles * 256);
+        const tc_i32x4 rk = mk(K + b * skv, ((long long)(Nk - 1) * ldk + D) * 2), rv = mk(V + b * skv, ((long long)(Nk - 1) * ldv + D) * 2);
+        const int smlo = __builtin_amdgcn_readfirstlane(wave == 0 ? 0xffff : 0);
+        const long long smask = (long long)(unsigned)smlo;
+        if (std::is_same<H, f16_t>::value)
+            asm volatile(TC_ATTN_DKV_ASM_F16 : : "v"(vq), "v"(vg), "v"(vs), "v"(wq), "v"(ws), "v"(rb), "v"(tb), "v"(sb), "v"(ko), "v"(vo), "v"(red), "v"(prm),
+                         "s"(rq), "s"(rg), "s"(rs), "s"(rk), "s"(rv), "s"(smask) : TC_ATTN_DKV_ASM_CLOBBERS);
+        else
+            asm volatile(TC_ATTN_DKV_ASM_BF16 : : "v"(vq), "v"(vg), "v"(vs), "v"(wq), "v"(ws), "v"(rb), "v"(tb), "v"(sb), "v"(ko), "v"(vo), "v"(red), "v"(prm),
+                         "s"(rq), "s"(rg), "s"(rs), "s"(rk), "s"(rv), "s"(smask) : TC_ATTN_DKV_ASM_CLOBBERS);
+    }
+    // each wave owns its keys: whole 256-byte rows of its [key][d] partial out of the [d][key] tiles the stream left in LDS
+    const float* redw = reinterpret_cast<const float*>(da_smem + wave * (2 * DA_RED));
+    float* dpart = dkv32 + (long long)bkz * gridDim.y * Nk * 128;
+#pragma unroll
+    for (int which = 0; which < 2; ++which)
+        for (int f = lane; f < 32 * D; f += 64) {
+            const int kk = f >> 6, d = f & 63;
+            if (kv0 + kk < Nk) dpart[((long long)b * Nk + kv0 + kk) * 128 + which * 64 + d] = redw[which * (D * 33) + d * 33 + kk];
+        }
 }
 
 template <typename H>
@@ -897,17 +1030,24 @@ extern "C" int tc_attn_bwd_seg(const void* Q, int ldq, const void* K, int ldk, c
     const int wide_rows = !((ldo | lddo) & 7) && !(((uintptr_t)O | (uintptr_t)dO) & 15);
     static const int fuse_env = getenv("TC_ATTN_FUSE_DELTA") ? atoi(getenv("TC_ATTN_FUSE_DELTA")) : 1;
     const bool fuse_delta = wide_rows && fuse_env;
+    // the hand-scheduled dK/dV stream: Q stored scaled, 16-byte rows, every query chunk at least two tiles long, and room for the per-tile
+    // statistics (B x tiles x 64 floats) in the LAST of the TC_ATTN_DKV_SPLITS partial buffers
+    const int dkv_asm_env = getenv("TC_ATTN_DKV_ASM") ? atoi(getenv("TC_ATTN_DKV_ASM")) : 1;
+    const bool dkv_asm = dkv_asm_env && qscaled && wide_rows && zs < TC_ATTN_DKV_SPLITS && (long long)ntiles * 64 <= (long long)Nk * 128 &&
+                         ntiles - (zs - 1) * tpc >= 2 && tpc >= 2 && rows * (long long)(ldq > lddo ? ldq : lddo) * 2 < 0x7fffffffLL;
+    float* const nstat = dkv_asm ? dkv32 + (long long)(TC_ATTN_DKV_SPLITS - 1) * B * Nk * 128 : nullptr;
     static bool lds_ok[2] = {false, false};
     // dQ first: it computes delta = rowsum(O dO) on the way (when O / dO rows are 16-byte accessible) and the dK/dV kernel reads it
 #define TC_BWD_DQ(HH, QMV)                                                                                                                 \
         hipLaunchKernelGGL((attn_bwd_dq_seg_kernel<HH, QMV>), dim3((unsigned)B * ((sg.t32[nseg] + FW_NW - 1) / FW_NW)), dim3(FW_NT), FW_SMEM, s, \
                            (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk, (const bf16_t*)V, ldv, skv, fuse_delta ? (const bf16_t*)O : nullptr, ldo, \
-                           (const bf16_t*)dO, lddo, lse, delta, (bf16_t*)dQ, lddq, sg, Nk, scale, qs, wide_dq)
+                           (const bf16_t*)dO, lddo, lse, delta, (bf16_t*)dQ, lddq, sg, Nk, scale, qs, wide_dq, nstat)
 #define TC_BWD(HH, IDX)                                                                                                                     \
     {                                                                                                                                       \
         if (!lds_ok[IDX]) {                                                                                                                 \
             if (hipFuncSetAttribute((const void*)attn_bwd_dq_seg_kernel<HH, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FW_SMEM) != hipSuccess || \
                 hipFuncSetAttribute((const void*)attn_bwd_dq_seg_kernel<HH, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FW_SMEM) != hipSuccess || \
+                hipFuncSetAttribute((const void*)attn_bwd_dkv_asm_kernel<HH>, hipFuncAttributeMaxDynamicSharedMemorySize, DA_SMEM) != hipSuccess || \
                 hipFuncSetAttribute((const void*)attn_bwd_dkv_seg_kernel<HH, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_SMEM_B) != hipSuccess || \
                 hipFuncSetAttribute((const void*)attn_bwd_dkv_seg_kernel<HH, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_SMEM_B) != hipSuccess) \
                 return TC_ERR_LAUNCH;                                                                                                       \
@@ -917,7 +1057,10 @@ extern "C" int tc_attn_bwd_seg(const void* Q, int ldq, const void* K, int ldk, c
             hipLaunchKernelGGL(delta_rows_kernel<HH>, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, s, (const bf16_t*)O, ldo,             \
                                (const bf16_t*)dO, lddo, delta, rows, wide_rows);                                                            \
         if (qscaled) TC_BWD_DQ(HH, 1); else TC_BWD_DQ(HH, 0);                                                                               \
-        if (qscaled)                                                                                                                        \
+        if (dkv_asm)                                                                                                                        \
+            hipLaunchKernelGGL((attn_bwd_dkv_asm_kernel<HH>), dim3(kb, B, zs), dim3(256), DA_SMEM, s, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk, \
+                               (const bf16_t*)V, ldv, skv, (const bf16_t*)dO, lddo, nstat, dkv32, sg, Nk, kscale, tpc, rows);                    \
+        else if (qscaled)                                                                                                                   \
             hipLaunchKernelGGL((attn_bwd_dkv_seg_kernel<HH, 4, true>), dim3(kb, B, zs), dim3(256), DKV_SMEM_B, s, (const bf16_t*)Q, ldq, (const bf16_t*)K, \
                                ldk, (const bf16_t*)V, ldv, skv, (const bf16_t*)dO, lddo, lse, delta, dkv32, sg, Nk, kscale, qs, tpc);             \
         else                                                                                                                                \

@@ -108,11 +108,12 @@ class Gen:
             if any(r in touched for r in wr):
                 idx = i
         if idx >= 0:
-            n = len(q) - idx - 1
+            n = min(len(q) - idx - 1, 15 if name == "lgkmcnt" else 63)     # the counters are 4 / 6 bits wide: a smaller count waits for more
             self._push(Ins(f"s_waitcnt {name}({n})", "wait"))
-            del q[: idx + 1]
+            del q[: len(q) - n]
 
     def wait_lgkm(self, n):
+        n = min(n, 15)
         if len(self.lgkm) > n:
             self._push(Ins(f"s_waitcnt lgkmcnt({n})", "wait"))
             del self.lgkm[: len(self.lgkm) - n]
