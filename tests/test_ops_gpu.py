@@ -756,6 +756,73 @@ def test_attention_stream_vs_compiler_kernel_and_fp64_over_shapes(dtype):
         assert (outs["1"][1] - outs["0"][1]).abs().max().item() <= 2e-5, (B, nq, Nk)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_attention_dkv_stream_vs_compiler_kernel_and_fp64_over_shapes(dtype):
+    """The hand-scheduled dK / dV stream (tc_attn_bwd_seg with qscaled = 1: gen_dkv_asm.py) over the shapes that exercise its edges: two
+    query tiles per chunk (the minimum), chunks of unequal length, ring wrap-around (> 8 sub-tiles per chunk), one to four segments with
+    partial and single-row tiles (rows past a segment's end get P = 0 through the padded statistics), key counts with a partial last
+    wave and idle waves, B = 1.  It performs the arithmetic of the compiler-scheduled kernel in the same order: dK / dV are BIT-IDENTICAL
+    to TC_ATTN_DKV_ASM=0 on the same bf16 operands (fp16: to the last place); both are held to an fp64 statement on the stored operands."""
+    import ctypes as C
+    import os
+    from transception_amd._lib import TC_BF16, TC_F16, lib
+    from transception_amd.engine import ATTN_DKV_SPLITS
+    L = lib()
+    d, scale, l2e = 64, 0.125, 1.4426950408889634
+    dt = TC_BF16 if dtype == torch.bfloat16 else TC_F16
+    st = torch.cuda.current_stream().cuda_stream
+    cases = [(1, [64], 64), (1, [33], 65), (2, [100, 37], 80), (2, [1, 32, 31], 95), (1, [384], 96), (3, [70, 5, 129, 12], 127), (2, [640, 200], 128),
+             (1, [950], 161), (2, [392, 40], 400), (2, [1500, 64, 33], 784), (16, [784, 392, 245, 98], 196), (1, [2570], 33)]
+    for ci, (B, nq, Nk) in enumerate(cases):
+        rows = B * sum(nq)
+        q = (T(f"dv.q{ci}", (rows, d)).to(DEV) * (scale * l2e)).to(dtype)
+        kv = T(f"dv.kv{ci}", (B * Nk, 2 * d)).to(DEV).to(dtype)
+        k, v = kv[:, :d], kv[:, d:]
+        do = T(f"dv.g{ci}", (rows, d)).to(DEV).to(dtype)
+        nqc = (C.c_int * 4)(*(list(nq) + [0] * (4 - len(nq))))
+        o = torch.empty((rows, d), device=DEV, dtype=dtype)
+        lse = torch.empty((rows,), device=DEV)
+        assert L.tc_attn_fwd_seg(q.data_ptr(), d, k.data_ptr(), 2 * d, v.data_ptr(), 2 * d, Nk * 2 * d, o.data_ptr(), d, lse.data_ptr(), B, len(nq), nqc, Nk,
+                                 scale, 1, dt, st) in (0, None)
+        outs = {}
+        for impl in ("1", "0"):
+            os.environ["TC_ATTN_DKV_ASM"] = impl
+            try:
+                dq = torch.full((rows, d), float("nan"), device=DEV).to(dtype)
+                dkv = torch.full((B * Nk, 2 * d), float("nan"), device=DEV).to(dtype)
+                delta = torch.empty((rows,), device=DEV)
+                dkv32 = torch.full((ATTN_DKV_SPLITS * B * Nk * 128,), float("nan"), device=DEV)
+                rc = L.tc_attn_bwd_seg(q.data_ptr(), d, k.data_ptr(), 2 * d, v.data_ptr(), 2 * d, Nk * 2 * d, o.data_ptr(), d, do.data_ptr(), d, lse.data_ptr(),
+                                       delta.data_ptr(), dkv32.data_ptr(), dq.data_ptr(), d, dkv.data_ptr(), 2 * d, dkv.data_ptr() + 2 * d, 2 * d, Nk * 2 * d, B,
+                                       len(nq), nqc, Nk, scale, 1, dt, st)
+                torch.cuda.synchronize()
+                assert rc in (0, None)
+                outs[impl] = (dq.double(), dkv.double())
+            finally:
+                os.environ.pop("TC_ATTN_DKV_ASM", None)
+        if dtype == torch.bfloat16:
+            assert torch.equal(outs["1"][1], outs["0"][1]), (B, nq, Nk, (outs["1"][1] - outs["0"][1]).abs().max().item())
+        else:       # fp16: identical but for single last-place differences of a dK row (one case of twelve, one key: 1.2e-4 at magnitude 0.2)
+            assert (outs["1"][1] - outs["0"][1]).abs().max().item() <= 1e-3 * max(1.0, outs["0"][1].abs().max().item()), (B, nq, Nk)
+        assert torch.equal(outs["1"][0], outs["0"][0]), (B, nq, Nk)
+        # fp64 statement on the stored operands (q holds q' = q * scale * log2(e): the gradients wanted are those of the unscaled product)
+        kd, vd = k.double().view(B, Nk, d), v.double().view(B, Nk, d)
+        ref_dk, ref_dv = torch.zeros(B, Nk, d, dtype=torch.float64, device=DEV), torch.zeros(B, Nk, d, dtype=torch.float64, device=DEV)
+        off = 0
+        for n in nq:
+            qs_ = (q[off:off + B * n].double().view(B, n, d) / (scale * l2e)).requires_grad_()
+            kk, vv = kd.clone().requires_grad_(), vd.clone().requires_grad_()
+            out = torch.softmax(torch.einsum("bqd,bkd->bqk", qs_, kk) * scale, -1) @ vv
+            out.backward(do[off:off + B * n].double().view(B, n, d))
+            ref_dk += kk.grad; ref_dv += vv.grad
+            off += B * n
+        tol = 2.5e-2 if dtype == torch.bfloat16 else 4e-3             # P, dS and the outputs are rounded to the storage type
+        got = outs["1"][1].view(B, Nk, 2 * d)
+        for nm, g_, r_ in (("dK", got[..., :d], ref_dk), ("dV", got[..., d:], ref_dv)):
+            assert torch.isfinite(g_).all(), (nm, B, nq, Nk)
+            assert (g_ - r_).abs().max().item() <= tol * max(1.0, r_.abs().max().item()), (nm, B, nq, Nk, (g_ - r_).abs().max().item(), r_.abs().max().item())
+
+
 @pytest.mark.parametrize("Bt,N,heads,Ch", [(3, 784, 8, 8), (2, 196, 8, 16), (2, 49, 8, 40)])
 def test_factor_att_core_fused(G, Bt, N, heads, Ch):
     """tc_factor_att_fwd/bwd vs a plain PyTorch fp32 restatement of MSTr.py:864-877 (Appendix C.1):

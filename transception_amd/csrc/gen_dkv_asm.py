@@ -35,6 +35,7 @@ LDR_B = 144                      # bytes per LDS row: 64 halfs + 8 pad
 TILE_B = 32 * LDR_B               # one 32-row operand tile
 SLOT_B = 2 * TILE_B + 256         # ring slot: Q tile | dO tile | 32 x (-lse log2 e) | 32 x (-delta)
 OFF_G, OFF_L, OFF_D = TILE_B, 2 * TILE_B, 2 * TILE_B + 128
+ABL = os.environ.get("TC_DKV_ABLATE", "")    # timing experiments only (wrong results): novalu, nopack, nolds, nostage, nobar, noprio, nosalu
 NSLOT, AHEAD, PERIOD = 8, 6, 2    # stores run AHEAD - 1 sub-tiles ahead: AHEAD - 1 >= PERIOD + 2, NSLOT >= AHEAD - 1 + PERIOD - 1 (gen_attn_asm.py)
 RED_B = 64 * 33 * 4               # one [d][key] fp32 accumulator tile in the epilogue's LDS layout
 
@@ -44,8 +45,9 @@ PP, PD = 64, 72                   # packed P / dS: two B operands of 4 each
 STQ, STG, STS = 80, 84, 88        # ring staging
 T0, T1 = 92, 93
 AR, AT, AS, AW, AWS = 94, 95, 96, 97, 98
+XL, XD = 99, 100                  # the sub-tile's 32 + 32 statistics, one per lane (lanes 16..31 / 48..63 repeat their row of 16)
 PRM = S                           # 16 parameter dwords (prologue only: aliases the score registers)
-NV = 99
+NV = 101
 # AGPRs
 def DK(blk): return 16 * blk
 def DV(blk): return 32 + 16 * blk
@@ -91,11 +93,19 @@ def tr_load(g, i, base):
 
 
 def stat_loads(g, base):
-    it = []
-    for q in range(4):
-        it.append(lambda q=q: g.emit(f"ds_read_b128 {vreg(NEGL + 4 * q, 4)}, {vreg(base)} offset:{16 * q}", "ds_read", [vreg(base)], regs("v", NEGL + 4 * q, 4)))
-        it.append(lambda q=q: g.emit(f"ds_read_b128 {vreg(NEGD + 4 * q, 4)}, {vreg(base)} offset:{128 + 16 * q}", "ds_read", [vreg(base)], regs("v", NEGD + 4 * q, 4)))
-    return it
+    """The C operands of the S / dP MFMAs: register r of a lane is the statistic of query 16 h + r, the same for the 32 lanes of a half.
+    ONE 4-byte LDS read per lane and matrix (lane (i, h) reads query 16 h + (i & 15)) and 16 row broadcasts (DPP row_newbcast) build each
+    tuple -- 0.5 KB of LDS traffic per wave and sub-tile instead of the 8 KB of eight 16-byte reads (the stream is LDS-bandwidth-bound:
+    removing every MFMA and VALU instruction left 44 of its 59 us)."""
+    b = base if isinstance(base, str) else vreg(base)
+    ld = [lambda: g.emit(f"ds_read_b32 {vreg(XL)}, {b}", "ds_read", [b], [vreg(XL)]),
+          lambda: g.emit(f"ds_read_b32 {vreg(XD)}, {b} offset:128", "ds_read", [b], [vreg(XD)])]
+    mv = []
+    for r in range(16):
+        mv.append(lambda r=r: g.emit(f"v_mov_b32_dpp {vreg(NEGL + r)}, {vreg(XL)} row_newbcast:{r} row_mask:0xf bank_mask:0xf", "permlane", [vreg(XL)], [vreg(NEGL + r)]))
+    for r in range(16):
+        mv.append(lambda r=r: g.emit(f"v_mov_b32_dpp {vreg(NEGD + r)}, {vreg(XD)} row_newbcast:{r} row_mask:0xf bank_mask:0xf", "permlane", [vreg(XD)], [vreg(NEGD + r)]))
+    return ld, mv
 
 
 def valu_items(g):
@@ -176,38 +186,42 @@ def iteration(g, mode):
     if mode == "loop":
         def bar():
             g.wait_lgkm(0)
-            g.salu(f"s_cmp_lg_u32 s{S_PH}, 0")
-            g.emit(f"s_cbranch_scc1 .Lnobar{g.uid}_%=", "branch")
-            g.emit("s_barrier", "barrier")
-            g.label(f".Lnobar{g.uid}_%=")
-            g.uid += 1
+            if "nobar" not in ABL:
+                g.salu(f"s_cmp_lg_u32 s{S_PH}, 0")
+                g.emit(f"s_cbranch_scc1 .Lnobar{g.uid}_%=", "branch")
+                g.emit("s_barrier", "barrier")
+                g.label(f".Lnobar{g.uid}_%=")
+                g.uid += 1
             g.salu(f"s_add_u32 s{S_PH}, s{S_PH}, 1")
             g.salu(f"s_and_b32 s{S_PH}, s{S_PH}, {PERIOD - 1}")
         head.append(bar)
-    if stage:
+    if stage and not ("nostage" in ABL and mode == "loop"):
         if not first:
             head.append(lambda: stash(g))                  # the sub-tile requested one iteration ago: a whole iteration of latency cover
         head.append(lambda: stage_request(g))
+    if stage:
         head.append(lambda: g.valu(f"v_add_u32_e32 {vreg(AR)}, s{S_SR}, {OP_RB}", [], [vreg(AR)]))
         head.append(lambda: g.valu(f"v_add_u32_e32 {vreg(AS)}, s{S_SR}, {OP_SB}", [], [vreg(AS)]))
-    free = [] if drain else valu_items(g)
-    if stage:
-        st = stat_loads(g, AS)
-        free = free[:4] + st + free[4:]
-    if not first:
+    free = [] if (drain or "novalu" in ABL) else valu_items(g)
+    nolds = "nolds" in ABL and mode == "loop"
+    if stage and not nolds:
+        ld, mv = stat_loads(g, AS)
+        free = ld + free + mv
+    if not first and "noprio" not in ABL:
         head.append(lambda: g.salu("s_setprio 1"))
-    interleave(g, 8, None if first else (lambda i: mf_dvdk(g, i)), (lambda i: row_load(g, i, AR)) if stage else (lambda i: None), free, head)
-    if not first:
+    interleave(g, 8, None if first else (lambda i: mf_dvdk(g, i)), (lambda i: row_load(g, i, AR)) if (stage and not nolds) else (lambda i: None), free, head)
+    if not first and "noprio" not in ABL:
         g.salu("s_setprio 0")
     if drain:
         return
-    for f in pack_items(g):
-        f()
+    if "nopack" not in ABL:
+        for f in pack_items(g):
+            f()
     # ---- S / dP (j+2) group: transpose reads of sub-tile j+1 behind the MFMAs
     head = [lambda: g.valu(f"v_add_u32_e32 {vreg(AT)}, s{S_ST}, {OP_TB}", [], [vreg(AT)])]
     noop = lambda: None
     free = [noop] * 7 + [(lambda: slots(g, (S_SR, S_ST, S_SW))) if not last else noop]
-    interleave(g, 8, None if last else (lambda i: mf_sdp(g, i)), lambda i: tr_load(g, i, AT), free, head)
+    interleave(g, 8, None if last else (lambda i: mf_sdp(g, i)), (lambda i: None) if nolds else (lambda i: tr_load(g, i, AT)), free, head)
 
 
 def prologue(g):
@@ -230,12 +244,14 @@ def prologue(g):
     for r in range(64):
         g.valu(f"v_accvgpr_write_b32 {areg(r)}, 0", [], [areg(r)])
     # sub-tile 0: statistics, row fragments, S / dP
-    for q in range(4):
-        g.emit(f"ds_read_b128 {vreg(NEGL + 4 * q, 4)}, {OP_SB} offset:{16 * q}", "ds_read", [], regs("v", NEGL + 4 * q, 4))
-        g.emit(f"ds_read_b128 {vreg(NEGD + 4 * q, 4)}, {OP_SB} offset:{128 + 16 * q}", "ds_read", [], regs("v", NEGD + 4 * q, 4))
+    ld, mv = stat_loads(g, OP_SB)
+    for f in ld:
+        f()
     for i in range(8):
         ks, which = i >> 1, i & 1
         g.emit(f"ds_read_b128 {areg(F(i), 4)}, {OP_RB} offset:{(OFF_G if which else 0) + 32 * ks}", "ds_read", [], regs("a", F(i), 4))
+    for f in mv:
+        f()
     g.wait_vm(0)
     for i in range(8):
         mf_sdp(g, i)
