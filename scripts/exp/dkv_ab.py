@@ -21,7 +21,7 @@ for shape in ([16, 0, 784], [3, 100, 70], [2, 6076, 33], [1, 64, 64], [5, 97, 50
     res = {}
     for asm in ("1", "0"):
         out = f"/tmp/dkv_ab_{asm}.npz"
-        subprocess.run([sys.executable, __file__, "worker", *map(str, shape), out], check=True, env=dict(os.environ, TC_ATTN_DKV_ASM=asm), timeout=120)
+        subprocess.run([sys.executable, __file__, "worker", *map(str, shape), out], check=True, env=dict(os.environ, TC_ATTN_DKV_ASM=asm, TC_ATTN_DQ_ASM=asm), timeout=120)
         res[asm] = np.load(out)
     line = []
     for kname in ("dq", "dk", "dv"):

@@ -33,12 +33,12 @@ def _stale(target: str, deps) -> bool:
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = _hipcc()
     # the hand-scheduled attention stream is generated source: refresh attn_fwd_asm.inc (rewritten only when its text changes)
-    for gen in ("gen_attn_asm.py", "gen_dkv_asm.py"):
+    for gen in ("gen_attn_asm.py", "gen_dkv_asm.py", "gen_dq_asm.py"):
         r = subprocess.run([sys.executable, os.path.join(CSRC, gen)], capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"{gen} failed:\n{r.stderr}")
     headers = [os.path.join(CSRC, "tc_common.h"), os.path.join(HERE, "..", "include", "transception_hip.h")]
-    extra = {"attention_seg.hip": [os.path.join(CSRC, "attn_fwd_asm.inc"), os.path.join(CSRC, "attn_dkv_asm.inc")]}
+    extra = {"attention_seg.hip": [os.path.join(CSRC, "attn_fwd_asm.inc"), os.path.join(CSRC, "attn_dkv_asm.inc"), os.path.join(CSRC, "attn_dq_asm.inc")]}
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     jobs = []

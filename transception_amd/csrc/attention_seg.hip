@@ -750,6 +750,116 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_seg_kernel(const bf16
     DSTAMP(2);
 }
 
+// dQ, hand-scheduled (gen_dq_asm.py; Q stored scaled, 16-byte addressable rows, at least two key sub-tiles): the forward stream's workgroup
+// and ring (attn_fwd_asm_kernel), K rows in key_row order and V rows in natural order.  This function computes the row deltas (and the
+// per-tile statistics of the dK/dV stream), stages sub-tiles 0..4, runs the stream and stores the dQ tile it leaves in the wave's LDS tile.
+#include "attn_dq_asm.inc"
+template <typename H>
+__global__ __launch_bounds__(AS_NW * 64, 1) void attn_bwd_dq_asm_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
+                                                                        const bf16_t* __restrict__ V, int ldv, long long skv,
+                                                                        const bf16_t* __restrict__ O, int ldo, const bf16_t* __restrict__ dO, int lddo,
+                                                                        const float* __restrict__ lse, float* __restrict__ delta,
+                                                                        bf16_t* __restrict__ dQ, int lddq, Segs sg, int Nk, float scale,
+                                                                        float* __restrict__ nstat, long long rows) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char as_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    const int nwt = sg.t32[sg.n], bpi = (nwt + AS_NW - 1) / AS_NW;
+    const int bx = xcd_block(blockIdx.x, gridDim.x);
+    const int b = bx / bpi, wt = (bx - b * bpi) * AS_NW + wave;
+    int sgi = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) if (i < sg.n && wt >= sg.t32[i]) sgi = i;
+    const int nq = sg.nq[sgi];
+    const int tq0 = (wt - sg.t32[sgi]) * 32;
+    const bool live = wt < nwt, ok = live && tq0 + j < nq;
+    const long long trow0 = (long long)sg.row0[sgi] + (long long)b * nq + tq0;
+    const bf16_t* Kb = K + b * skv;
+    const bf16_t* Vb = V + b * skv;
+    unsigned char* wtile = as_smem + AS_WT0 + wave * AS_WT;
+    {   // delta = rowsum(O dO) of the wave's rows: eight lanes x 16 bytes per row, the sums meet in the wave tile
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 8 * i + (lane >> 3);
+            const bool okr = live && tq0 + r < nq;
+            const uint4 gv = okr ? *reinterpret_cast<const uint4*>(dO + (trow0 + r) * lddo + 8 * (lane & 7)) : make_uint4(0u, 0u, 0u, 0u);
+            const uint4 ov = okr ? *reinterpret_cast<const uint4*>(O + (trow0 + r) * ldo + 8 * (lane & 7)) : make_uint4(0u, 0u, 0u, 0u);
+            const unsigned aw[4] = {ov.x, ov.y, ov.z, ov.w}, gw[4] = {gv.x, gv.y, gv.z, gv.w};
+            float sd = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a0, a1, g0, g1;
+                unpack2<H>(aw[e], a0, a1);
+                unpack2<H>(gw[e], g0, g1);
+                sd = fmaf(a0, g0, fmaf(a1, g1, sd));
+            }
+            sd += __shfl_xor(sd, 1, 64);
+            sd += __shfl_xor(sd, 2, 64);
+            sd += __shfl_xor(sd, 4, 64);
+            if (okr && (lane & 7) == 0) delta[trow0 + r] = sd;
+            if ((lane & 7) == 0) reinterpret_cast<float*>(wtile)[r] = sd;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    const float dl0 = ok ? reinterpret_cast<const float*>(wtile)[j] : 0.f;
+    const float nl2 = ok ? -(lse[trow0 + j] * LOG2E) : 0.f;
+    if (nstat && live && h == 0) {
+        float* st = nstat + ((long long)b * nwt + wt) * 64;
+        st[j] = ok ? nl2 : NEG_BIG;
+        st[32 + j] = -dl0;
+    }
+    const int role = wave >> 2, sr = (tid & 255) >> 3, sc = tid & 7;
+    if (role < 2) {
+        const bf16_t* src = role ? Vb : Kb;
+        const int ld = role ? ldv : ldk;
+#pragma unroll
+        for (int s = 0; s < AS_AHEAD - 1; ++s) {                // sub-tiles 0..4 into ring slots 0..4 (rows past Nk: a duplicate, masked by the stream)
+            const uint4 x = *reinterpret_cast<const uint4*>(src + (long long)min(32 * s + sr, Nk - 1) * ld + 8 * sc);
+            *reinterpret_cast<uint4*>(as_smem + s * AS_SLOT + (role ? AS_VOFF + sr * (LDR * 2) : key_row(sr) * (LDR * 2)) + 16 * sc) = x;
+        }
+    }
+    __syncthreads();
+    {
+        const unsigned lds0 = (unsigned)(uintptr_t)as_smem;
+        const int gi = lane & 15, gq = (lane >> 4) & 1, nsub = (Nk + 31) / 32, nv = Nk - 32 * (nsub - 1);
+        const unsigned kbase = lds0 + key_row(pi_row(j)) * (LDR * 2) + 16 * h;
+        const unsigned vbase = lds0 + AS_VOFF + pi_row(j) * (LDR * 2) + 16 * h;
+        const unsigned tbase = lds0 + (16 * h + 4 * (gi >> 2)) * (LDR * 2) + 32 * gq + 8 * (gi & 3);
+        const unsigned wbase = lds0 + (role == 1 ? AS_VOFF + sr * (LDR * 2) : key_row(sr) * (LDR * 2)) + 16 * sc;
+        const int ld = role == 1 ? ldv : ldk;
+        unsigned goff = (unsigned)(((32 * (AS_AHEAD - 1) + sr) * ld + 8 * sc) * 2);
+        const long long qrow = live ? trow0 + min(j, max(0, min(32, nq - tq0) - 1)) : 0;     // rows past the tile's end: a valid row whose column is never stored
+        const unsigned qoff = (unsigned)((qrow * ldq + 8 * h) * 2), gooff = (unsigned)((qrow * lddo + 8 * h) * 2);
+        const unsigned oaddr = lds0 + AS_WT0 + wave * AS_WT + j * (LDR * 2) + 8 * h;
+        unsigned mask = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mask |= (16 * h + r >= nv) ? (1u << r) : 0u;
+        auto mk = [](const void* p, long long bytes) {
+            const unsigned long long a = (unsigned long long)(uintptr_t)p;
+            return tc_i32x4{__builtin_amdgcn_readfirstlane((int)(unsigned)a), __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32)),
+                            __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000};
+        };
+        const tc_i32x4 rsrc = mk(role == 1 ? Vb : Kb, ((long long)(Nk - 1) * ld + D) * 2);
+        const tc_i32x4 rq = mk(Q, ((rows - 1) * ldq + D) * 2), rg = mk(dO, ((rows - 1) * lddo + D) * 2);
+        const int step = __builtin_amdgcn_readfirstlane(32 * ld * 2);
+        const int wex = __builtin_amdgcn_readfirstlane(role < 2 ? -1 : 0);
+        const long long wexec = ((long long)wex << 32) | (unsigned)wex;
+        const int scl = __builtin_amdgcn_readfirstlane(__float_as_int(scale));
+        if (std::is_same<H, f16_t>::value)
+            asm volatile(TC_ATTN_DQ_ASM_F16 : "+v"(goff) : "v"(kbase), "v"(vbase), "v"(tbase), "v"(wbase), "v"(qoff), "v"(gooff), "v"(oaddr), "v"(nl2), "v"(dl0),
+                         "v"(mask), "s"(rsrc), "s"(rq), "s"(rg), "s"(nsub), "s"(step), "s"(wexec), "s"(scl) : TC_ATTN_DQ_ASM_CLOBBERS);
+        else
+            asm volatile(TC_ATTN_DQ_ASM_BF16 : "+v"(goff) : "v"(kbase), "v"(vbase), "v"(tbase), "v"(wbase), "v"(qoff), "v"(gooff), "v"(oaddr), "v"(nl2), "v"(dl0),
+                         "v"(mask), "s"(rsrc), "s"(rq), "s"(rg), "s"(nsub), "s"(step), "s"(wexec), "s"(scl) : TC_ATTN_DQ_ASM_CLOBBERS);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 8 * i + (lane >> 3);
+        const uint4 v = *reinterpret_cast<const uint4*>(wtile + r * (LDR * 2) + 16 * (lane & 7));
+        if (live && tq0 + r < nq) *reinterpret_cast<uint4*>(dQ + (trow0 + r) * lddq + 8 * (lane & 7)) = v;
+    }
+}
+
 // dK/dV, hand-scheduled (gen_dkv_asm.py; Q stored scaled, 16-byte addressable rows): the decomposition of attn_bwd_dkv_seg_kernel -- workgroup =
 // (4 x 32 keys of one image, one chunk of that image's 32-query tiles), every wave owns 32 keys -- with the 32-query sub-tiles of
 // Q | dO | statistics streaming through an 8-slot LDS ring (buffer loads six sub-tiles ahead, one barrier per two sub-tiles).  This
@@ -1036,6 +1146,8 @@ extern "C" int tc_attn_bwd_seg(const void* Q, int ldq, const void* K, int ldk, c
     const bool dkv_asm = dkv_asm_env && qscaled && wide_rows && zs < TC_ATTN_DKV_SPLITS && (long long)ntiles * 64 <= (long long)Nk * 128 &&
                          ntiles - (zs - 1) * tpc >= 2 && tpc >= 2 && rows * (long long)(ldq > lddo ? ldq : lddo) * 2 < 0x7fffffffLL;
     float* const nstat = dkv_asm ? dkv32 + (long long)(TC_ATTN_DKV_SPLITS - 1) * B * Nk * 128 : nullptr;
+    const int dq_asm_env = getenv("TC_ATTN_DQ_ASM") ? atoi(getenv("TC_ATTN_DQ_ASM")) : 1;
+    const bool dq_asm = dq_asm_env && qscaled && fuse_delta && wide_dq && Nk >= 33 && rows * (long long)(ldq > lddo ? ldq : lddo) * 2 < 0x7fffffffLL;
     static bool lds_ok[2] = {false, false};
     // dQ first: it computes delta = rowsum(O dO) on the way (when O / dO rows are 16-byte accessible) and the dK/dV kernel reads it
 #define TC_BWD_DQ(HH, QMV)                                                                                                                 \
@@ -1048,6 +1160,7 @@ extern "C" int tc_attn_bwd_seg(const void* Q, int ldq, const void* K, int ldk, c
             if (hipFuncSetAttribute((const void*)attn_bwd_dq_seg_kernel<HH, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FW_SMEM) != hipSuccess || \
                 hipFuncSetAttribute((const void*)attn_bwd_dq_seg_kernel<HH, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FW_SMEM) != hipSuccess || \
                 hipFuncSetAttribute((const void*)attn_bwd_dkv_asm_kernel<HH>, hipFuncAttributeMaxDynamicSharedMemorySize, DA_SMEM) != hipSuccess || \
+                hipFuncSetAttribute((const void*)attn_bwd_dq_asm_kernel<HH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AS_SMEM) != hipSuccess || \
                 hipFuncSetAttribute((const void*)attn_bwd_dkv_seg_kernel<HH, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_SMEM_B) != hipSuccess || \
                 hipFuncSetAttribute((const void*)attn_bwd_dkv_seg_kernel<HH, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_SMEM_B) != hipSuccess) \
                 return TC_ERR_LAUNCH;                                                                                                       \
@@ -1056,7 +1169,11 @@ extern "C" int tc_attn_bwd_seg(const void* Q, int ldq, const void* K, int ldk, c
         if (!fuse_delta)                                                                                                                    \
             hipLaunchKernelGGL(delta_rows_kernel<HH>, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, s, (const bf16_t*)O, ldo,             \
                                (const bf16_t*)dO, lddo, delta, rows, wide_rows);                                                            \
-        if (qscaled) TC_BWD_DQ(HH, 1); else TC_BWD_DQ(HH, 0);                                                                               \
+        if (dq_asm)                                                                                                                         \
+            hipLaunchKernelGGL((attn_bwd_dq_asm_kernel<HH>), dim3((unsigned)B * ((sg.t32[nseg] + AS_NW - 1) / AS_NW)), dim3(AS_NW * 64), AS_SMEM, s, \
+                               (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk, (const bf16_t*)V, ldv, skv, (const bf16_t*)O, ldo, (const bf16_t*)dO, lddo, \
+                               lse, delta, (bf16_t*)dQ, lddq, sg, Nk, scale, nstat, rows);                                                     \
+        else if (qscaled) TC_BWD_DQ(HH, 1); else TC_BWD_DQ(HH, 0);                                                                          \
         if (dkv_asm)                                                                                                                        \
             hipLaunchKernelGGL((attn_bwd_dkv_asm_kernel<HH>), dim3(kb, B, zs), dim3(256), DA_SMEM, s, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk, \
                                (const bf16_t*)V, ldv, skv, (const bf16_t*)dO, lddo, nstat, dkv32, sg, Nk, kscale, tpc, rows);                    \
