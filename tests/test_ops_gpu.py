@@ -757,12 +757,14 @@ def test_attention_stream_vs_compiler_kernel_and_fp64_over_shapes(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_attention_dkv_stream_vs_compiler_kernel_and_fp64_over_shapes(dtype):
-    """The hand-scheduled dK / dV stream (tc_attn_bwd_seg with qscaled = 1: gen_dkv_asm.py) over the shapes that exercise its edges: two
+def test_attention_backward_streams_vs_compiler_kernels_and_fp64_over_shapes(dtype):
+    """The hand-scheduled dQ and dK / dV streams (tc_attn_bwd_seg with qscaled = 1: gen_dq_asm.py, gen_dkv_asm.py) over the shapes that
+    exercise their edges: every key tail class (Nk mod 32), two key sub-tiles (the dQ stream's minimum) up to ring wrap-around, two
     query tiles per chunk (the minimum), chunks of unequal length, ring wrap-around (> 8 sub-tiles per chunk), one to four segments with
     partial and single-row tiles (rows past a segment's end get P = 0 through the padded statistics), key counts with a partial last
-    wave and idle waves, B = 1.  It performs the arithmetic of the compiler-scheduled kernel in the same order: dK / dV are BIT-IDENTICAL
-    to TC_ATTN_DKV_ASM=0 on the same bf16 operands (fp16: to the last place); both are held to an fp64 statement on the stored operands."""
+    wave and idle waves, B = 1.  They perform the arithmetic of the compiler-scheduled kernels in the same order: dQ / dK / dV are
+    BIT-IDENTICAL to TC_ATTN_DQ_ASM=0 TC_ATTN_DKV_ASM=0 on the same bf16 operands (fp16 dK / dV: to the last place); both are held to an
+    fp64 statement on the stored operands."""
     import ctypes as C
     import os
     from transception_amd._lib import TC_BF16, TC_F16, lib
@@ -786,7 +788,7 @@ def test_attention_dkv_stream_vs_compiler_kernel_and_fp64_over_shapes(dtype):
                                  scale, 1, dt, st) in (0, None)
         outs = {}
         for impl in ("1", "0"):
-            os.environ["TC_ATTN_DKV_ASM"] = impl
+            os.environ["TC_ATTN_DKV_ASM"] = os.environ["TC_ATTN_DQ_ASM"] = impl
             try:
                 dq = torch.full((rows, d), float("nan"), device=DEV).to(dtype)
                 dkv = torch.full((B * Nk, 2 * d), float("nan"), device=DEV).to(dtype)
@@ -800,6 +802,7 @@ def test_attention_dkv_stream_vs_compiler_kernel_and_fp64_over_shapes(dtype):
                 outs[impl] = (dq.double(), dkv.double())
             finally:
                 os.environ.pop("TC_ATTN_DKV_ASM", None)
+                os.environ.pop("TC_ATTN_DQ_ASM", None)
         if dtype == torch.bfloat16:
             assert torch.equal(outs["1"][1], outs["0"][1]), (B, nq, Nk, (outs["1"][1] - outs["0"][1]).abs().max().item())
         else:       # fp16: identical but for single last-place differences of a dK row (one case of twelve, one key: 1.2e-4 at magnitude 0.2)
@@ -808,6 +811,7 @@ def test_attention_dkv_stream_vs_compiler_kernel_and_fp64_over_shapes(dtype):
         # fp64 statement on the stored operands (q holds q' = q * scale * log2(e): the gradients wanted are those of the unscaled product)
         kd, vd = k.double().view(B, Nk, d), v.double().view(B, Nk, d)
         ref_dk, ref_dv = torch.zeros(B, Nk, d, dtype=torch.float64, device=DEV), torch.zeros(B, Nk, d, dtype=torch.float64, device=DEV)
+        ref_dq = torch.empty(rows, d, dtype=torch.float64, device=DEV)
         off = 0
         for n in nq:
             qs_ = (q[off:off + B * n].double().view(B, n, d) / (scale * l2e)).requires_grad_()
@@ -815,10 +819,11 @@ def test_attention_dkv_stream_vs_compiler_kernel_and_fp64_over_shapes(dtype):
             out = torch.softmax(torch.einsum("bqd,bkd->bqk", qs_, kk) * scale, -1) @ vv
             out.backward(do[off:off + B * n].double().view(B, n, d))
             ref_dk += kk.grad; ref_dv += vv.grad
+            ref_dq[off:off + B * n] = qs_.grad.reshape(-1, d)      # gradient of the UNSCALED projection output (include/transception_hip.h, qscaled)
             off += B * n
         tol = 2.5e-2 if dtype == torch.bfloat16 else 4e-3             # P, dS and the outputs are rounded to the storage type
         got = outs["1"][1].view(B, Nk, 2 * d)
-        for nm, g_, r_ in (("dK", got[..., :d], ref_dk), ("dV", got[..., d:], ref_dv)):
+        for nm, g_, r_ in (("dK", got[..., :d], ref_dk), ("dV", got[..., d:], ref_dv), ("dQ", outs["1"][0], ref_dq)):
             assert torch.isfinite(g_).all(), (nm, B, nq, Nk)
             assert (g_ - r_).abs().max().item() <= tol * max(1.0, r_.abs().max().item()), (nm, B, nq, Nk, (g_ - r_).abs().max().item(), r_.abs().max().item())
 

@@ -934,7 +934,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_asm_kernel(const bf16_t* 
         const unsigned wq = lds0 + key_row(sr) * (LDR * 2) + 16 * sc, ws = lds0 + 2 * DA_TILE + 16 * (tid & 15);
         const unsigned rb = lds0 + key_row(pi_row(j)) * (LDR * 2) + 16 * h;
         const unsigned tb = lds0 + (16 * h + 4 * (gi >> 2)) * (LDR * 2) + 32 * gq + 8 * (gi & 3);
+#ifdef TC_DKV_B128STATS
+        const unsigned sb = lds0 + 2 * DA_TILE + 64 * h;
+#else
         const unsigned sb = lds0 + 2 * DA_TILE + 4 * (16 * h + (lane & 15));
+#endif
         const unsigned ko = (unsigned)((key * ldk + 8 * h) * 2), vo = (unsigned)((key * ldv + 8 * h) * 2);
         const unsigned red = lds0 + wave * (2 * DA_RED) + (4 * h * 33 + j) * 4;
         const unsigned prm = lds0 + DA_PRM0;

@@ -98,6 +98,12 @@ def stat_loads(g, base):
     tuple -- 0.5 KB of LDS traffic per wave and sub-tile instead of the 8 KB of eight 16-byte reads (the stream is LDS-bandwidth-bound:
     removing every MFMA and VALU instruction left 44 of its 59 us)."""
     b = base if isinstance(base, str) else vreg(base)
+    if "b128stats" in ABL:        # the first version: eight 16-byte reads (needs the statistics base at + 64 h instead of + 4 (16 h + lane & 15))
+        ld = []
+        for q in range(4):
+            ld.append(lambda q=q: g.emit(f"ds_read_b128 {vreg(NEGL + 4 * q, 4)}, {b} offset:{16 * q}", "ds_read", [b], regs("v", NEGL + 4 * q, 4)))
+            ld.append(lambda q=q: g.emit(f"ds_read_b128 {vreg(NEGD + 4 * q, 4)}, {b} offset:{128 + 16 * q}", "ds_read", [b], regs("v", NEGD + 4 * q, 4)))
+        return ld, []
     ld = [lambda: g.emit(f"ds_read_b32 {vreg(XL)}, {b}", "ds_read", [b], [vreg(XL)]),
           lambda: g.emit(f"ds_read_b32 {vreg(XD)}, {b} offset:128", "ds_read", [b], [vreg(XD)])]
     mv = []
