@@ -471,7 +471,7 @@ def side_figures(args, dev, model, loss_fn, opt, step, x, y, build_model, engine
                 break
         roofs["roofline_in_step_events"] = r
     if prof.get("attn_bwd"):
-        roofs["roofline_attn_bwd"] = mfma_block(prof["attn_bwd"], "attn_bwd (delta + dQ + dK/dV kernels of the bridge SR-attention)")
+        roofs["roofline_attn_bwd"] = mfma_block(prof["attn_bwd"], "attn_bwd (dQ stream incl. the row deltas + dK/dV stream + partial fold of the bridge SR-attention)")
     # the GEMM family (the time-dominant one): algorithmic flops AND bytes per launch kind
     PMC_GEMM = {"single": ("gemm_bf16_kernel", "gemm_kernel"), "pair": ("gemm_pair_kernel",), "multi": ("gemm_multi_kernel",)}
     gem = []
@@ -616,6 +616,27 @@ def side_figures(args, dev, model, loss_fn, opt, step, x, y, build_model, engine
                              "how": "HIP events on the launching stream around 30 back-to-back launches of the kernel inside one replayed hipGraph, step-shaped "
                                     "random operands (no event-pair floor in the figure; agrees with the rocprofv3 average in profiles/); the per-launch "
                                     "event figure of instrumented eager steps, which includes event_pair_floor_us, is roofline_in_step_events"}
+        # the backward of the same call, the same way (dQ stream -- it also makes the row deltas -- dK/dV stream, partial fold)
+        from transception_amd.engine import ATTN_DKV_SPLITS
+        do = torch.randn(rows, 64, device=dev).to(TORCH_DTYPE[args.dtype])
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        delta = torch.empty(rows, device=dev); dkv32 = torch.empty(ATTN_DKV_SPLITS * Bq * Nk * 128, device=dev)
+
+        def attn_bwd():
+            L.tc_attn_bwd_seg(q.data_ptr(), 64, kv.data_ptr(), 128, kv[:, 64:].data_ptr(), 128, Nk * 128, o.data_ptr(), 64, do.data_ptr(), 64, lse.data_ptr(),
+                              delta.data_ptr(), dkv32.data_ptr(), dq.data_ptr(), 64, dkv.data_ptr(), 128, dkv[:, 64:].data_ptr(), 128, Nk * 128, Bq, 4, nqc, Nk,
+                              0.125, 1, tcd, torch.cuda.current_stream(dev).cuda_stream)
+        usb = _graph_replay_us(attn_bwd, 20, dev)
+        flb = 10.0 * rows * Nk * 64
+        roofs["roofline_attn_bwd_graph_replay"] = {
+            "bound": "mfma", "kernel": "tc_attn_bwd_seg: attn_bwd_dq_asm_kernel (S, dP, dQ products + the row deltas) + attn_bwd_dkv_asm_kernel (S, dP, dV, dK "
+                                       "products) + attn_dkv_store_kernel; hand-scheduled streams of csrc/gen_dq_asm.py / gen_dkv_asm.py",
+            "achieved": flb / usb / 1e6, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s", "frac": flb / usb / 1e6 / PEAK_TFLOPS[args.dtype],
+            "avg_launch_us": usb, "algorithmic_flops_per_launch": flb,
+            "frac_counting_4_products": 0.8 * flb / usb / 1e6 / PEAK_TFLOPS[args.dtype],
+            "how": "as roofline: 20 back-to-back calls inside one replayed hipGraph; flops = the five products a backward without stored "
+                   "probabilities needs (S, dP, dV, dQ, dK; frac_counting_4_products leaves S out); 7 products are executed (each stream "
+                   "recomputes S and dP)"}
     elif "roofline_in_step_events" in roofs:
         roofs["roofline"] = roofs["roofline_in_step_events"]
     return extra, roofs
