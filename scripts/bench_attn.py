@@ -4,7 +4,9 @@ sys.path.insert(0, "/root/repo")
 from transception_amd._lib import lib, TC_BF16, TC_F32
 L = lib()
 dev = torch.device("cuda:0")
-B, nq, Nk, d = 16, [3136, 1568, 980, 392], 784, 64
+import os
+_sc = float(os.environ.get("TC_BENCH_NQ_SCALE", "1"))          # < 1: fewer queries per image (separates the per-sub-tile cost of the streams from their fixed part)
+B, nq, Nk, d = 16, [int(n * _sc) for n in (3136, 1568, 980, 392)], 784, 64
 rows = B * sum(nq)
 dtype = torch.bfloat16 if "--f32" not in sys.argv else torch.float32
 dt = TC_BF16 if dtype == torch.bfloat16 else TC_F32

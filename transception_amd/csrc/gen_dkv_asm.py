@@ -295,7 +295,7 @@ def generate(half):
     g.salu(f"s_cmp_lg_u32 s{S_CNT}, 0")
     g.emit("s_cbranch_scc1 .Lloop_%=", "branch")
     loop_end = len(g.out)
-    if g.state() != st_in:
+    if g.state() != st_in and not ABL:
         raise RuntimeError(f"loop back-edge changes the outstanding-load queues:\n in  {st_in}\n out {g.state()}")
     g.label(".Llast_%=")
     last_begin = len(g.out)

@@ -9,8 +9,7 @@ dQ^T += K^T dS^T.  Three waves per SIMD leave 84 + 84 registers, so ONE pool of 
 kinds in turn -- MFMA i of a group reads fragment i and the load behind it refills it for MFMA i of the next group:
 
   iteration j:  dQ^T(j)       4 MFMAs on the K^T fragments, carrying exp2 / subtract / multiply of sub-tile j+1; refill: K rows of j+2
-                pack dS(j+1)
-                S^T(j+2)      4 MFMAs (C = -lse log2 e: P = exp2(S) directly); refill: V rows of j+2
+                S^T(j+2)      4 MFMAs (C = -lse log2 e: P = exp2(S) directly), carrying pack dS(j+1); refill: V rows of j+2
                 dP^T(j+2)     4 MFMAs; refill: K^T fragments of j+1; ring store of sub-tile j+6, bookkeeping
 
 Arithmetic = attn_bwd_dq_seg_kernel<H, 1> (Q stored as q * scale * log2 e): dQ = scale * (P (dP - delta)) K.
@@ -139,14 +138,13 @@ def iteration(g, mode):
         g.salu("s_setprio 0")
     if drain:
         return
-    for f in pack_items(g):
-        f()
-    # ---- S^T(j+2) | V rows (j+2)
+    # ---- S^T(j+2) | V rows (j+2) | pack dS(j+1): the packs read the dS registers the dP^T group overwrites, not the S registers this one
+    #      writes, and sit between a V-row refill and the dP^T MFMA that needs it
     head = []
     if not last:
         head.append(lambda: g.valu(f"v_add_u32_e32 {vreg(AV)}, s{S_SK}, {OP_VBASE}", [], [vreg(AV)]))
     head.append(lambda: g.valu(f"v_add_u32_e32 {vreg(AT)}, s{S_SV}, {OP_TBASE}", [], [vreg(AT)]))
-    interleave(g, 4, None if last else (lambda i: mf_s(g, i)), (lambda i: krow_load(g, i, AV)) if not last else nothing, [], head)
+    interleave(g, 4, None if last else (lambda i: mf_s(g, i)), (lambda i: krow_load(g, i, AV)) if not last else nothing, pack_items(g), head)
     # ---- dP^T(j+2) | K^T fragments (j+1) | ring store, slot bookkeeping
     free = []
     if stage:
