@@ -616,6 +616,8 @@ def side_figures(args, dev, model, loss_fn, opt, step, x, y, build_model, engine
                              "how": "HIP events on the launching stream around 30 back-to-back launches of the kernel inside one replayed hipGraph, step-shaped "
                                     "random operands (no event-pair floor in the figure; agrees with the rocprofv3 average in profiles/); the per-launch "
                                     "event figure of instrumented eager steps, which includes event_pair_floor_us, is roofline_in_step_events"}
+        roofs["roofline_graph_replay"] = dict(roofs["roofline"], note="the same figure as `roofline` under a name that says how it is taken (the key `roofline` "
+                                              "carried the in-step event figure until round 2; that one is roofline_in_step_events)")
         # the backward of the same call, the same way (dQ stream -- it also makes the row deltas -- dK/dV stream, partial fold)
         from transception_amd.engine import ATTN_DKV_SPLITS
         do = torch.randn(rows, 64, device=dev).to(TORCH_DTYPE[args.dtype])

@@ -364,7 +364,11 @@ int tc_attn_bwd(const void* Q, int ldq, long long sq, const void* K, int ldk, co
 int tc_attn_fwd_seg(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, long long skv, void* O, int ldo,
                     float* lse, int B, int nseg, const int* nq, int Nk, float scale, int qscaled, int dtype, void* stream);
 /* dkv32: fp32 scratch of TC_ATTN_DKV_SPLITS * B * Nk * 128 floats (16-bit path: every query chunk of the dK/dV kernel writes its own
- * partial dK|dV there, one conversion kernel adds them; needs no initialisation); may be NULL for fp32. */
+ * partial dK|dV there, one conversion kernel adds them; needs no initialisation); may be NULL for fp32.
+ * delta: fp32 [rows], written (row sums of O dO; computed inside the dQ kernel when O / dO rows are 16-byte addressable).
+ * With qscaled = 1 and 16-byte addressable rows the two kernels are the hand-scheduled streams of csrc/gen_dq_asm.py / gen_dkv_asm.py
+ * (same arithmetic in the same order as the compiler-scheduled kernels, which remain for every other case and as
+ * TC_ATTN_DQ_ASM=0 / TC_ATTN_DKV_ASM=0); the dK/dV stream keeps its per-tile row statistics in the LAST of the dkv32 partial buffers. */
 #define TC_ATTN_DKV_SPLITS 8
 int tc_attn_bwd_seg(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, long long skv, const void* O,
                     int ldo, const void* dO, int lddo, const float* lse, float* delta, float* dkv32, void* dQ, int lddq,
