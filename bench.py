@@ -641,6 +641,28 @@ def side_figures(args, dev, model, loss_fn, opt, step, x, y, build_model, engine
                    "recomputes S and dP)"}
     elif "roofline_in_step_events" in roofs:
         roofs["roofline"] = roofs["roofline_in_step_events"]
+    # (6) the memory-bound stages north_star names, alone: RIPM (Patch_Embed_stage) and IFF (CoordAtt), forward + backward of the three
+    #     encoder stages of each in one replayed graph (scripts/bench_stage.py); memory-side bytes from the committed PMC passes of the same command
+    if args.dtype == "bf16" and args.size == 224 and not args.eager:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("bench_stage", os.path.join(ROOT, "scripts", "bench_stage.py"))
+        bs = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bs)
+        pf = os.path.join(ROOT, "profiles", "r4_ripm_iff_hbm.json")
+        pmc = json.load(open(pf)) if os.path.exists(pf) and args.batch == 16 else {}
+        for which, key in (("ripm", "roofline_ripm"), ("iff", "roofline_iff")):
+            _, one_pass = bs.build(which, args.batch, dev)
+            us = _graph_replay_us(one_pass, 4, dev)
+            by = 3.0 * bs.ELEMS[which] * args.batch * 2
+            tr = pmc.get(which, {}).get("traffic_bytes_per_pass")
+            roofs[key] = {"bound": "hbm", "kernel": {"ripm": "RIPM: Patch_Embed_stage x 3 encoder stages (dw3x3 + pw1x1 + BatchNorm + Hardswish, x 3 per stage), forward + backward",
+                                                      "iff": "IFF: CoordAtt x 3 encoder stages (pool, conv1 + BatchNorm + act, conv_h / conv_w + sigmoid, gate, conv_in_out), forward + backward"}[which],
+                          "achieved": by / us / 1e3, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": by / us / 1e3 / PEAK_HBM_GBS, "us_per_pass": us,
+                          "algorithmic_bytes_per_pass": by, "traffic": tr, "traffic_GBps": tr / us / 1e3 if tr else None,
+                          "launches_per_pass": pmc.get(which, {}).get("launches_per_pass"),
+                          "traffic_source": "profiles/r4_ripm_iff_hbm.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of scripts/bench_stage.py, scripts/pmc_stage.sh)" if tr else None,
+                          "how": "the stage functions of the model on random maps of the step's shapes, captured once and replayed (HIP events on the launching "
+                                 "stream); algorithmic bytes = SURVEY.md 8(d): every activation of the fused unit read / written once, backward = 2 x forward"}
     return extra, roofs
 
 
