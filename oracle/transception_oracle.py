@@ -49,7 +49,7 @@ class TransCeptionOracle:
         self.training = training
         # ablation switches of the reference constructor (MSTr.py:2760-2823) that this restatement follows: the aggregate of a
         # stage (:1384-1403), whether the bridge runs (:2840) and which bridge layers use channel attention (:2413-2420)
-        assert concat in ("coord", "normal", "se") and have_bridge != "sp" and len(br_ch_att_list) == 4
+        assert concat in ("coord", "normal", "se", "3d") and have_bridge != "sp" and len(br_ch_att_list) == 4
         self.concat, self.have_bridge, self.br_ch_att_list = concat, have_bridge, tuple(bool(b) for b in br_ch_att_list)
         # running statistics are buffers: updated in place in training mode
         self.buffers = {k: v.clone() for k, v in params.items()
@@ -204,6 +204,14 @@ class TransCeptionOracle:
         cat = torch.cat(outs, dim=-1)
         if self.concat == "coord":
             return self.coord_att(cat, name + ".aggregate")
+        if self.concat == "3d":
+            # Conv3d_BN_concat, MSTr.py:447-462: the branch maps stacked on a depth axis, Conv3d(C, out, kernel (4, 1, 1)) = a sum over the
+            # four paths and the channels, ReLU, then BatchNorm
+            agg = name + ".aggregate"
+            w = self.P[agg + ".interact_concat.0.weight"][:, :, :, 0, 0]          # [O, C, 4]
+            z = sum(torch.einsum("bhwc,oc->bhwo", outs[p], w[:, :, p]) for p in range(4)) + self.P[agg + ".interact_concat.0.bias"]
+            B, H, W, O = z.shape
+            return self.batchnorm_rows(torch.relu(z).reshape(B, H * W, O), agg + ".bn").reshape(B, H, W, O)
         if self.concat == "se":
             # SE_Block, MSTr.py:571-594: squeeze (mean over the map) -> Linear(4C, 4C/16, no bias) -> ReLU -> Linear(4C/16, 4C, no bias)
             # -> sigmoid gates the channels; then conv1x1 (with bias) -> BatchNorm -> ReLU

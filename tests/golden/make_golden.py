@@ -241,6 +241,10 @@ VARIANTS = {   # name -> (constructor kwargs, gradient probes)
                   ["backbone.mhca_stage2.aggregate.excitation.0.weight", "backbone.mhca_stage3.aggregate.excitation.2.weight",
                    "backbone.mhca_stage4.aggregate.conv.weight", "backbone.mhca_stage4.aggregate.conv.bias", "backbone.mhca_stage3.aggregate.bn.weight",
                    "backbone.mhca_stage2.mhca_blks.1.MHCA_layers.0.mlp.fc1.weight", "decoder_0.last_layer.weight"]),
+    "concat_3d": (dict(concat="3d"),
+                  ["backbone.mhca_stage2.aggregate.interact_concat.0.weight", "backbone.mhca_stage3.aggregate.interact_concat.0.bias",
+                   "backbone.mhca_stage4.aggregate.interact_concat.0.weight", "backbone.mhca_stage4.aggregate.bn.weight",
+                   "backbone.mhca_stage3.mhca_blks.2.MHCA_layers.1.factoratt_crpe.qkv.weight", "decoder_0.last_layer.weight"]),
     "bridge_para": (dict(have_bridge="para"),
                     ["backbone.mhca_stage3.aggregate.conv1.weight", "bridge.bridge_layer1.attn.q.weight", "bridge.bridge_layer2.attn.kv.weight",
                      "bridge.proj_act.0.weight", "bridge.proj_act.0.bias", "bridge.proj_act.1.weight", "bridge.bridge_layer3.mixffn4.fc2.weight",

@@ -306,6 +306,7 @@ def test_whole_model_train_step_vs_reference_golden_and_oracle():
 VARIANTS = {   # constructor switches of SURVEY.md 8(f)-4 that the build implements; fixtures tests/golden/variants.npz
     "concat_normal": dict(concat="normal"),
     "concat_se": dict(concat="se"),
+    "concat_3d": dict(concat="3d"),
     "no_bridge": dict(have_bridge="None"),
     "ch_att_1101": dict(br_ch_att_list=[True, True, False, True]),
     "bridge_para": dict(have_bridge="para"),

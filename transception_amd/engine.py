@@ -1375,6 +1375,25 @@ class Graph:
         self._rec(bwd)
         return out
 
+    def permuted_weight(self, W: P, nb: int, R: int, Cc: int) -> P:
+        """A weight stored [nb, R, Cc] handed out as [nb, Cc * R] with the two inner axes swapped (Conv3d(kernel (4, 1, 1)) over the stacked
+        branch maps = a Linear over their concatenation, MSTr.py:441-462: the weight is stored [O][C][path], the concatenation runs
+        [path][C]).  The copy is made per pass (it is a few KB); its gradient is swapped back into W.grad."""
+        assert W.data.is_contiguous() and W.data.numel() == nb * R * Cc
+        data = torch.empty((nb, Cc * R), dtype=W.data.dtype, device=self.dev)
+        self.L.tc_transpose(_ptr(W.data), _ptr(data), nb, R, Cc, self.dt, self.stream)
+        if W.grad is None or not self.record:
+            return P(data, None)
+        grad = torch.zeros((nb, Cc * R), dtype=torch.float32, device=self.dev)
+
+        def bwd():
+            tmp = torch.empty((nb, R * Cc), dtype=torch.float32, device=self.dev)
+            self.L.tc_transpose(_ptr(grad), _ptr(tmp), nb, Cc, R, TC_F32, self.stream)
+            g = W.grad.view(nb, R * Cc)
+            self.L.tc_add(_ptr(g), g.stride(0), _ptr(tmp), tmp.stride(0), _ptr(g), g.stride(0), nb, R * Cc, TC_F32, self.stream)
+        self._rec(bwd)
+        return P(data, grad)
+
     def chan_pool(self, x: Var, B: int, N: int) -> Var:
         """SE_Block squeeze (MSTr.py:586): [B, C] means over each image's N token rows."""
         out = self.new(B, x.cols)

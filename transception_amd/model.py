@@ -143,6 +143,11 @@ def _mk_mhca_stage(dim: int, out_dim: int, layers: int, concat: str = "coord") -
     # or SE_Block ("se", :1396-1397, 571-583)
     if concat == "coord":
         m.aggregate = _mk_coord_att(dim * 4, out_dim)
+    elif concat == "3d":                                        # Conv3d_BN_concat, MSTr.py:406-462: Conv3d(C, out, (4, 1, 1)) + ReLU over the stacked maps, BatchNorm
+        a = nn.Module()
+        a.bn = nn.BatchNorm2d(out_dim)
+        a.interact_concat = nn.Sequential(nn.Conv3d(dim, out_dim, kernel_size=(4, 1, 1)), nn.ReLU())
+        m.aggregate = a
     elif concat == "se":
         a = nn.Module()
         a.excitation = nn.Sequential(nn.Linear(dim * 4, dim * 4 // 16, bias=False), nn.ReLU(inplace=True),
@@ -271,17 +276,18 @@ class MSTransception(nn.Module):
         # Ablation switches of the reference constructor (MSTr.py:2760-2823) that compose from the kernels of the default path:
         #   concat       "coord" (CoordAtt / IFF, default) | "normal" (Conv1x1 + BN + Hardswish over the concatenation, :1384-1390)
         #                | "se" (SE_Block over the concatenation, :571-594: squeeze / excitation gate, Conv1x1 + BN + ReLU)
+        #                | "3d" (Conv3d_BN_concat, :406-462: Conv3d(kernel (4, 1, 1)) over the stacked branch maps + ReLU, BatchNorm)
         #   have_bridge  "original" (default) | "None" (the bridge is built -- its parameters stay in the state_dict -- but skipped, :2840)
         #   br_ch_att_list  which of the four bridge layers use channel attention instead of SR self-attention (:2413-2420)
         # use_sa_config / sa_ker / inter / num_sp only reach the "cbam", "sp" and "para" variants and are accepted and ignored, as in
         #                | "para" (BridgeBlock_para, :2500-2538: channel and spatial layer side by side, Linear(128->64)+LN+GELU, two
         #                  more spatial layers)
-        # the reference.  Not built: concat in {3d, skn, cbam, cam}, have_bridge = sp, Stage_3or4 != 3,
+        # the reference.  Not built: concat in {skn, cbam, cam}, have_bridge = sp, Stage_3or4 != 3,
         # token_mlp_mode != "mix_skip", and the legacy networks/Transception.py class.
         br = [bool(b) for b in br_ch_att_list]
-        if (token_mlp_mode != "mix_skip" or concat not in ("coord", "normal", "se") or have_bridge == "sp" or Stage_3or4 != 3
+        if (token_mlp_mode != "mix_skip" or concat not in ("coord", "normal", "se", "3d") or have_bridge == "sp" or Stage_3or4 != 3
                 or len(br) != 4):
-            raise NotImplementedError("MSTransception: implemented are concat in {'coord', 'normal', 'se'}, have_bridge in {'original', "
+            raise NotImplementedError("MSTransception: implemented are concat in {'coord', 'normal', 'se', '3d'}, have_bridge in {'original', "
                                       "'None', 'para'}, any 4-entry br_ch_att_list, Stage_3or4 = 3, token_mlp_mode = 'mix_skip'")
         if have_bridge == "para":                       # BridgeBlock_para ignores br_ch_att_list (it receives num_sp, MSTr.py:2806-2807):
             br = [True, False, False, False]            # layer 1 channel, layers 2-4 spatial (MSTr.py:2504-2512)
@@ -730,6 +736,12 @@ def _mhca_stage(M, G, stack: Var, name: str, layers: int, B: int, side: int, out
             _resblock(M, G, stack.rowslice(0, rows), name + ".InvRes", B, side, cat.colslice(0, C))
     if M.concat == "coord":
         return _coord_att(M, G, cat, name + ".aggregate", B, side, out)
+    if M.concat == "3d":                                                         # Conv3d_BN_concat, MSTr.py:447-462
+        agg = name + ".aggregate"
+        off, shape = M._index[agg + ".interact_concat.0.weight"]                 # [O, C, 4, 1, 1]
+        Wp = G.permuted_weight(M._P(G, agg + ".interact_concat.0.weight", (shape[0], C * 4)), shape[0], C, 4)
+        z = G.relu(G.linear(cat, Wp, M._P(G, agg + ".interact_concat.0.bias")))
+        return _bn(M, G, z, agg + ".bn", ACT_NONE, out=out)
     if M.concat == "se":                                                         # SE_Block, MSTr.py:584-593
         agg = name + ".aggregate"
         y = G.relu(G.linear(G.chan_pool(cat, B, side * side), *_lin(M, G, agg + ".excitation.0", bias=False)))
