@@ -49,7 +49,7 @@ class TransCeptionOracle:
         self.training = training
         # ablation switches of the reference constructor (MSTr.py:2760-2823) that this restatement follows: the aggregate of a
         # stage (:1384-1403), whether the bridge runs (:2840) and which bridge layers use channel attention (:2413-2420)
-        assert concat in ("coord", "normal", "se", "3d") and have_bridge != "sp" and len(br_ch_att_list) == 4
+        assert concat in ("coord", "normal", "se", "3d", "skn") and have_bridge != "sp" and len(br_ch_att_list) == 4
         self.concat, self.have_bridge, self.br_ch_att_list = concat, have_bridge, tuple(bool(b) for b in br_ch_att_list)
         # running statistics are buffers: updated in place in training mode
         self.buffers = {k: v.clone() for k, v in params.items()
@@ -212,6 +212,17 @@ class TransCeptionOracle:
             z = sum(torch.einsum("bhwc,oc->bhwo", outs[p], w[:, :, p]) for p in range(4)) + self.P[agg + ".interact_concat.0.bias"]
             B, H, W, O = z.shape
             return self.batchnorm_rows(torch.relu(z).reshape(B, H * W, O), agg + ".bn").reshape(B, H, W, O)
+        if self.concat == "skn":
+            # SK_Block, MSTr.py:1076-1107: U = sum of the branch maps, S = its spatial mean, Z = fc(S), one Linear(d, C) per branch, softmax over
+            # the branches, V = sum_k a_k x_k, then Conv1x1 (bias) -> ReLU -> BatchNorm
+            agg = name + ".aggregate"
+            S = sum(outs).mean(dim=(1, 2))
+            Z = self.linear(S, agg + ".fc")
+            a = torch.softmax(torch.stack([self.linear(Z, f"{agg}.fcs.{k}") for k in range(4)], 0), dim=0)      # [4, B, C]
+            V = sum(a[k][:, None, None, :] * outs[k] for k in range(4))
+            B, H, W, C = V.shape
+            z = torch.relu(self.linear(V.reshape(B, H * W, C), agg + ".conv_bn_ac.0"))
+            return self.batchnorm_rows(z, agg + ".conv_bn_ac.2").reshape(B, H, W, -1)
         if self.concat == "se":
             # SE_Block, MSTr.py:571-594: squeeze (mean over the map) -> Linear(4C, 4C/16, no bias) -> ReLU -> Linear(4C/16, 4C, no bias)
             # -> sigmoid gates the channels; then conv1x1 (with bias) -> BatchNorm -> ReLU

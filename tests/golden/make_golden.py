@@ -245,6 +245,10 @@ VARIANTS = {   # name -> (constructor kwargs, gradient probes)
                   ["backbone.mhca_stage2.aggregate.interact_concat.0.weight", "backbone.mhca_stage3.aggregate.interact_concat.0.bias",
                    "backbone.mhca_stage4.aggregate.interact_concat.0.weight", "backbone.mhca_stage4.aggregate.bn.weight",
                    "backbone.mhca_stage3.mhca_blks.2.MHCA_layers.1.factoratt_crpe.qkv.weight", "decoder_0.last_layer.weight"]),
+    "concat_skn": (dict(concat="skn"),
+                   ["backbone.mhca_stage2.aggregate.fc.weight", "backbone.mhca_stage2.aggregate.fc.bias", "backbone.mhca_stage3.aggregate.fcs.0.weight",
+                    "backbone.mhca_stage3.aggregate.fcs.3.bias", "backbone.mhca_stage4.aggregate.conv_bn_ac.0.weight",
+                    "backbone.mhca_stage4.aggregate.conv_bn_ac.0.bias", "backbone.mhca_stage2.aggregate.conv_bn_ac.2.weight", "decoder_0.last_layer.weight"]),
     "bridge_para": (dict(have_bridge="para"),
                     ["backbone.mhca_stage3.aggregate.conv1.weight", "bridge.bridge_layer1.attn.q.weight", "bridge.bridge_layer2.attn.kv.weight",
                      "bridge.proj_act.0.weight", "bridge.proj_act.0.bias", "bridge.proj_act.1.weight", "bridge.bridge_layer3.mixffn4.fc2.weight",

@@ -307,6 +307,7 @@ VARIANTS = {   # constructor switches of SURVEY.md 8(f)-4 that the build impleme
     "concat_normal": dict(concat="normal"),
     "concat_se": dict(concat="se"),
     "concat_3d": dict(concat="3d"),
+    "concat_skn": dict(concat="skn"),
     "no_bridge": dict(have_bridge="None"),
     "ch_att_1101": dict(br_ch_att_list=[True, True, False, True]),
     "bridge_para": dict(have_bridge="para"),

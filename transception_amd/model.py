@@ -148,6 +148,14 @@ def _mk_mhca_stage(dim: int, out_dim: int, layers: int, concat: str = "coord") -
         a.bn = nn.BatchNorm2d(out_dim)
         a.interact_concat = nn.Sequential(nn.Conv3d(dim, out_dim, kernel_size=(4, 1, 1)), nn.ReLU())
         m.aggregate = a
+    elif concat == "skn":                                       # SK_Block(in_ch = C, num_path = 4, reduction = 8, L = 32), MSTr.py:1054-1107, 1398-1399
+        a = nn.Module()
+        dd = max(32, dim // 8)
+        a.fc = nn.Linear(dim, dd)
+        a.fcs = nn.ModuleList([nn.Linear(dd, dim) for _ in range(4)])
+        a.softmax = nn.Softmax(dim=0)
+        a.conv_bn_ac = nn.Sequential(nn.Conv2d(dim, out_dim, kernel_size=(1, 1)), nn.ReLU(inplace=True), nn.BatchNorm2d(out_dim))
+        m.aggregate = a
     elif concat == "se":
         a = nn.Module()
         a.excitation = nn.Sequential(nn.Linear(dim * 4, dim * 4 // 16, bias=False), nn.ReLU(inplace=True),
@@ -277,17 +285,18 @@ class MSTransception(nn.Module):
         #   concat       "coord" (CoordAtt / IFF, default) | "normal" (Conv1x1 + BN + Hardswish over the concatenation, :1384-1390)
         #                | "se" (SE_Block over the concatenation, :571-594: squeeze / excitation gate, Conv1x1 + BN + ReLU)
         #                | "3d" (Conv3d_BN_concat, :406-462: Conv3d(kernel (4, 1, 1)) over the stacked branch maps + ReLU, BatchNorm)
+        #                | "skn" (SK_Block, :1054-1107: per-channel softmax over the four branches from their pooled sum, Conv1x1 + ReLU + BN)
         #   have_bridge  "original" (default) | "None" (the bridge is built -- its parameters stay in the state_dict -- but skipped, :2840)
         #   br_ch_att_list  which of the four bridge layers use channel attention instead of SR self-attention (:2413-2420)
         # use_sa_config / sa_ker / inter / num_sp only reach the "cbam", "sp" and "para" variants and are accepted and ignored, as in
         #                | "para" (BridgeBlock_para, :2500-2538: channel and spatial layer side by side, Linear(128->64)+LN+GELU, two
         #                  more spatial layers)
-        # the reference.  Not built: concat in {skn, cbam, cam}, have_bridge = sp, Stage_3or4 != 3,
+        # the reference.  Not built: concat in {cbam, cam}, have_bridge = sp, Stage_3or4 != 3,
         # token_mlp_mode != "mix_skip", and the legacy networks/Transception.py class.
         br = [bool(b) for b in br_ch_att_list]
-        if (token_mlp_mode != "mix_skip" or concat not in ("coord", "normal", "se", "3d") or have_bridge == "sp" or Stage_3or4 != 3
+        if (token_mlp_mode != "mix_skip" or concat not in ("coord", "normal", "se", "3d", "skn") or have_bridge == "sp" or Stage_3or4 != 3
                 or len(br) != 4):
-            raise NotImplementedError("MSTransception: implemented are concat in {'coord', 'normal', 'se', '3d'}, have_bridge in {'original', "
+            raise NotImplementedError("MSTransception: implemented are concat in {'coord', 'normal', 'se', '3d', 'skn'}, have_bridge in {'original', "
                                       "'None', 'para'}, any 4-entry br_ch_att_list, Stage_3or4 = 3, token_mlp_mode = 'mix_skip'")
         if have_bridge == "para":                       # BridgeBlock_para ignores br_ch_att_list (it receives num_sp, MSTr.py:2806-2807):
             br = [True, False, False, False]            # layer 1 channel, layers 2-4 spatial (MSTr.py:2504-2512)
@@ -742,6 +751,24 @@ def _mhca_stage(M, G, stack: Var, name: str, layers: int, B: int, side: int, out
         Wp = G.permuted_weight(M._P(G, agg + ".interact_concat.0.weight", (shape[0], C * 4)), shape[0], C, 4)
         z = G.relu(G.linear(cat, Wp, M._P(G, agg + ".interact_concat.0.bias")))
         return _bn(M, G, z, agg + ".bn", ACT_NONE, out=out)
+    if M.concat == "skn":                                                        # SK_Block, MSTr.py:1076-1107
+        agg = name + ".aggregate"
+        N = side * side
+        pooled = G.chan_pool(cat, B, N)                                          # [B, 4C]: S = mean(sum_k x_k) = sum_k mean(x_k)
+        Wf, bf = _lin(M, G, agg + ".fc")
+        Z = G.new(B, Wf.data.shape[0])
+        for k in range(4):                                                       # fc(S): the same weight on the four column blocks, accumulated
+            G.linear(pooled.colslice(k * C, (k + 1) * C), Wf, bf if k == 0 else None, out=Z, accumulate=k > 0)
+        A = G.new(B, 4 * C)
+        for k in range(4):
+            G.linear(Z, *_lin(M, G, f"{agg}.fcs.{k}"), out=A.colslice(k * C, (k + 1) * C))
+        att = G.softmax(A.reshape(B * 4, C), B, 0).reshape(B, 4 * C)             # softmax over the four paths, per image and channel
+        gated = G.chan_gate(cat, att, B, N)
+        Wc, bc = _lin(M, G, agg + ".conv_bn_ac.0")
+        z = G.new(rows, Wc.data.shape[0])
+        for k in range(4):                                                       # conv(sum_k a_k x_k)
+            G.linear(gated.colslice(k * C, (k + 1) * C), Wc, bc if k == 0 else None, out=z, accumulate=k > 0)
+        return _bn(M, G, G.relu(z), agg + ".conv_bn_ac.2", ACT_NONE, out=out)
     if M.concat == "se":                                                         # SE_Block, MSTr.py:584-593
         agg = name + ".aggregate"
         y = G.relu(G.linear(G.chan_pool(cat, B, side * side), *_lin(M, G, agg + ".excitation.0", bias=False)))
