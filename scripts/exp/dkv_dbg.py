@@ -15,7 +15,7 @@ for ci, (B, nq, Nk) in enumerate([(1, [64], 64), (1, [33], 65), (2, [100, 37], 8
     q = (T(f"dv.q{ci}", (rows, d)).to(DEV) * (scale * l2e)).to(dtype)
     kv = T(f"dv.kv{ci}", (B * Nk, 2 * d)).to(DEV).to(dtype)
     k, v = kv[:, :d], kv[:, d:]
-    do = T(f"dv.g{ci}", (rows, d)).to(DEV).to(dtype)
+    do = (T(f"dv.g{ci}", (rows, d)).to(DEV) * float(os.environ.get("DO_SCALE", "1"))).to(dtype)
     nqc = (C.c_int * 4)(*(list(nq) + [0] * (4 - len(nq))))
     o = torch.empty((rows, d), device=DEV, dtype=dtype); lse = torch.empty((rows,), device=DEV)
     L.tc_attn_fwd_seg(q.data_ptr(), d, k.data_ptr(), 2 * d, v.data_ptr(), 2 * d, Nk * 2 * d, o.data_ptr(), d, lse.data_ptr(), B, len(nq), nqc, Nk, scale, 1, dt, st)

@@ -14,10 +14,14 @@ inline int tc_dw_wg_target() { static const int v = getenv("TC_DW_WG") ? atoi(ge
 inline int tc_mid_wg_target() { static const int v = getenv("TC_MID_WG") ? atoi(getenv("TC_MID_WG")) : 256; return v; }
 
 
-template <typename T, int K, bool BWD>
+// STRIDE is a template parameter (the strided form serves the first depthwise convolution of every RIPM stage, stride 2): with a run-time
+// stride the input-gradient form spends ~40 instructions per tap on `t % stride` / `t / stride`, and the pixel index is split with
+// 32-bit arithmetic (a 64-bit division is ~100 instructions on this machine) -- 15 -> see DESIGN.md section 5 us per launch at [16, 56, 56, 64].
+template <typename T, int K, bool BWD, int STRIDE>
 __global__ __launch_bounds__(256) void dw_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ w,
                                                  const T* __restrict__ bias, T* __restrict__ y, int ldy, int B, int H, int W,
-                                                 int Ho, int Wo, int C, int stride, int add_input, int accumulate) {
+                                                 int Ho, int Wo, int C, int add_input, int accumulate) {
+    constexpr int stride = STRIDE;
     // forward:  x is the [B,H,W] input, y the [B,Ho,Wo] output.
     // BWD    :  x is dy on [B,Ho,Wo], y is dx on [B,H,W]  (transposed convolution with the same taps).
     __shared__ float wsm[K * K][64];
@@ -35,11 +39,12 @@ __global__ __launch_bounds__(256) void dw_kernel(const T* __restrict__ x, int ld
     constexpr int P = (K - 1) / 2;
     const int OH = BWD ? H : Ho, OW = BWD ? W : Wo;          // extent of the tensor being written
     const int IH = BWD ? Ho : H, IW = BWD ? Wo : W;          // extent of the tensor being read
-    const long long npix = (long long)B * OH * OW;
-    for (long long pix = (long long)blockIdx.x * 16 + ty; pix < npix; pix += (long long)gridDim.x * 16) {
-        const int ow = (int)(pix % OW);
-        const int oh = (int)((pix / OW) % OH);
-        const int b = (int)(pix / ((long long)OW * OH));
+    const unsigned npix = (unsigned)B * OH * OW;                // (< 2^31: checked by the host)
+    for (unsigned pix = blockIdx.x * 16 + ty; pix < npix; pix += gridDim.x * 16) {
+        const int ow = (int)(pix % (unsigned)OW);
+        const unsigned prow = pix / (unsigned)OW;
+        const int oh = (int)(prow % (unsigned)OH);
+        const int b = (int)(prow / (unsigned)OH);
         float4 acc = BWD ? make_float4(0.f, 0.f, 0.f, 0.f)
                          : make_float4(bsm[tx * 4], bsm[tx * 4 + 1], bsm[tx * 4 + 2], bsm[tx * 4 + 3]);
         const T* xb = x + (long long)b * IH * IW * ldx + c;
@@ -64,8 +69,8 @@ __global__ __launch_bounds__(256) void dw_kernel(const T* __restrict__ x, int ld
             const float4 v = ld4<T>(xb + ((long long)oh * IW + ow) * ldx);
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
-        if (accumulate) { const float4 o = ld4<T>(y + pix * ldy + c); acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
-        st4<T>(y + pix * ldy + c, acc);
+        if (accumulate) { const float4 o = ld4<T>(y + (long long)pix * ldy + c); acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
+        st4<T>(y + (long long)pix * ldy + c, acc);
     }
 }
 
@@ -131,11 +136,12 @@ __global__ __launch_bounds__(256) void dw_wgrad3_kernel(const T* __restrict__ dy
     float4 acc[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const long long npix = (long long)B * Ho * Wo;
+    const unsigned npix = (unsigned)B * Ho * Wo;                // (< 2^31: checked by the host; 32-bit index arithmetic, see dw_kernel)
     if (c < C) {
-        for (long long pix = (long long)blockIdx.x * 16 + ty; pix < npix; pix += (long long)gridDim.x * 16) {
-            const int ow = (int)(pix % Wo), oh = (int)((pix / Wo) % Ho), b = (int)(pix / ((long long)Wo * Ho));
-            const float4 d = ld4<T>(dy + pix * lddy + c);
+        for (unsigned pix = blockIdx.x * 16 + ty; pix < npix; pix += gridDim.x * 16) {
+            const unsigned prow = pix / (unsigned)Wo;
+            const int ow = (int)(pix - prow * (unsigned)Wo), oh = (int)(prow % (unsigned)Ho), b = (int)(prow / (unsigned)Ho);
+            const float4 d = ld4<T>(dy + (long long)pix * lddy + c);
             const T* xb = x + (long long)b * H * W * ldx + c;
             float4 v[K * K];
 #pragma unroll
@@ -929,11 +935,14 @@ int launch_dw(const void* x, int ldx, const void* w, const void* bias, void* y, 
     const int P = (k - 1) / 2;
     const int Ho = (H + 2 * P - k) / stride + 1, Wo = (W + 2 * P - k) / stride + 1;
     const long long npix = (long long)B * (BWD ? H * W : Ho * Wo);
-    dim3 grid(tc_blocks(npix, 16 * 4, 2048), (C + 63) / 64), block(256);
-#define TC_DW(KK) hipLaunchKernelGGL((dw_kernel<T, KK, BWD>), grid, block, 0, s, (const T*)x, ldx, (const T*)w, (const T*)bias, \
-                                     (T*)y, ldy, B, H, W, Ho, Wo, C, stride, add_input, accumulate)
-    if (k == 3) TC_DW(3); else if (k == 5) TC_DW(5); else TC_DW(7);
+    if (npix >= 0x7fffffffLL || (stride != 1 && stride != 2)) return TC_ERR_ARG;
+    dim3 grid(tc_blocks(npix, 16, 4096), (C + 63) / 64), block(256);       // one pixel row of 16 per workgroup pass: maps of 12.5 k pixels fill the chip
+#define TC_DW2(KK, SS) hipLaunchKernelGGL((dw_kernel<T, KK, BWD, SS>), grid, block, 0, s, (const T*)x, ldx, (const T*)w, (const T*)bias, \
+                                          (T*)y, ldy, B, H, W, Ho, Wo, C, add_input, accumulate)
+#define TC_DW(KK) { if (stride == 1) TC_DW2(KK, 1); else TC_DW2(KK, 2); }
+    if (k == 3) TC_DW(3) else if (k == 5) TC_DW(5) else TC_DW(7)
 #undef TC_DW
+#undef TC_DW2
     return tc_launch_status();
 }
 
@@ -1587,8 +1596,9 @@ extern "C" int tc_dwconv_bwd_weight(const void* dy, int lddy, const void* x, int
     const long long npix = (long long)B * Ho * Wo;
     dim3 grid(tc_blocks(npix, 4 * 16, 256), (C + 63) / 64), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (k == 3 && (ldx & 3) == 0 && (lddy & 3) == 0) {
-        const dim3 g3(tc_blocks(npix, 16 * 8, 64), (C + 63) / 64);
+    if (k == 3 && (ldx & 3) == 0 && (lddy & 3) == 0 && npix < 0x7fffffffLL) {
+        static const int wg3 = getenv("TC_DW_WGRAD3_WG") ? atoi(getenv("TC_DW_WGRAD3_WG")) : 64;
+        const dim3 g3(tc_blocks(npix, 16 * 8, wg3), (C + 63) / 64);
         TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dw_wgrad3_kernel<T>), g3, block, 0, s, (const T*)dy, lddy, (const T*)x, ldx, dw, db, B, H, W,
                                                     Ho, Wo, C, stride));
         return tc_launch_status();

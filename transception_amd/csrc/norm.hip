@@ -642,7 +642,10 @@ extern "C" int tc_bn_fwd(const void* x, int ldx, const void* gamma, const void* 
                                0, (const T*)gamma, (const T*)beta, (const float*)nullptr, (const float*)nullptr, partial, rows,
                                C, act);
         }
-        const int rb = tc_blocks(rows, 64, 512);
+        // rows per workgroup of the apply pass: these maps are a few MB, the pass is bound by its round trips, not by bytes -- more, shorter
+        // workgroups win although each folds the chunk partials again (RIPM stages alone: 536 us at 64 rows, 527 at 32, 523 at 16, 594 at 256)
+        static const int rpw = getenv("TC_BN_ROWS_PER_WG") ? atoi(getenv("TC_BN_ROWS_PER_WG")) : 16;
+        const int rb = tc_blocks(rows, rpw, 2048);
         hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(rb, cb), dim3(256), 0, s, (const T*)x, ldx, (const T*)gamma,
                            (const T*)beta, running_mean, running_var, (const T*)res, ldres, (T*)y, ldy, save_mean, save_rstd,
                            partial, nchunk, rows, C, eps, momentum, training, act);
@@ -662,7 +665,8 @@ extern "C" int tc_bn_bwd(const void* dy, int lddy, const void* x, int ldx, const
     TC_DISPATCH_DTYPE(dtype, {
         hipLaunchKernelGGL((bn_partial_kernel<T, 1>), dim3(nchunk, cb), dim3(256), 0, s, (const T*)x, ldx, (const T*)dy, lddy,
                            (const T*)gamma, (const T*)beta, save_mean, save_rstd, partial, rows, C, act);
-        const int rb = tc_blocks(rows, 64, 512);
+        static const int rpwb = getenv("TC_BN_BWD_ROWS_PER_WG") ? atoi(getenv("TC_BN_BWD_ROWS_PER_WG")) : 16;
+        const int rb = tc_blocks(rows, rpwb, 2048);
         hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(rb, cb), dim3(256), 0, s, (const T*)dy, lddy, (const T*)x, ldx,
                            (const T*)gamma, (const T*)beta, save_mean, save_rstd, (T*)dx, lddx, dgamma, dbeta, partial, nchunk,
                            rows, C, act, accumulate);
