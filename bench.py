@@ -373,7 +373,8 @@ def main():
         sync()
         sys.stdout.flush()
         sys.stderr.flush()
-        os._exit(0)
+        if os.environ.get("TC_BENCH_SOFT_EXIT", "0") != "1":         # (a tracer needs the ordinary teardown to write its files)
+            os._exit(0)
 
 
 ATTN_KERNEL = ("attn_fwd_asm_kernel (bridge SR-attention forward, QK^T + softmax + PV fused, all 4 scales x B images in one launch; the "

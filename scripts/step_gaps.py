@@ -1,10 +1,10 @@
 """Wall time vs kernel time of the last few replayed steps in a rocprofv3 kernel trace: python scripts/step_gaps.py <dir>"""
 import csv, glob, sys
-f = glob.glob(sys.argv[1] + '/*/*kernel_trace.csv')[0]
+f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
 ev = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) for r in rows]
 starts = [i for i, e in enumerate(ev) if 'stem_im2col_kernel' in e[2]]
-segs = [(a, b) for a, b in zip(starts, starts[1:]) if b - a > 1000]
+segs = [(a, b) for a, b in zip(starts, starts[1:]) if b - a > 500]
 for a, b in segs[-8:]:
     seg = ev[a:b]
     wall = (ev[b][0] - seg[0][0]) / 1e6

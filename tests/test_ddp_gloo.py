@@ -62,6 +62,22 @@ def _worker(rank, world, port, ret):
     for w in allreduce_gradients(Two, None, "early", async_op=True):
         w.wait()
     ok_grad = ok_grad and bool((g3[:178] == 3.0).all() and (g3[178:1_500_000] == float(rank + 1)).all())
+    # a piece of several small non-adjacent buckets as ONE collective (the exposed last piece of the split backward sweep)
+
+    class Three(Sparse):
+        _gflat = torch.arange(2_000_000, dtype=torch.float32) * float(rank + 1)
+        _used_views = {0: (0, (10, 10)), 1: (500_000, (64,)), 2: (1_500_000, (1000,))}
+    want = torch.arange(2_000_000, dtype=torch.float32) * 3.0
+    for async_op in (True, False):
+        Three._gflat = torch.arange(2_000_000, dtype=torch.float32) * float(rank + 1)
+        works = allreduce_gradients(Three, None, async_op=async_op, ranges=[(0, 600_000), (1_400_000, 2_000_000)], coalesce=True)
+        ok_grad = ok_grad and len(works) == (1 if async_op else 0)                 # three buckets, one collective
+        for w in works:
+            w.wait()
+        g4 = Three._gflat
+        for a, b in ((0, 100), (500_000, 500_064), (1_500_000, 1_501_000)):
+            ok_grad = ok_grad and bool((g4[a:b] == want[a:b]).all())
+        ok_grad = ok_grad and bool((g4[100:500_000] == want[100:500_000] / 3.0 * (rank + 1)).all())    # everything else untouched
     ret[rank] = (ok_loss, ok_grad)
     dist.destroy_process_group()
 

@@ -137,15 +137,18 @@ def test_trainer_schedule_helpers():
     assert abs(scaled_base_lr(0.05, 20) - 0.05 * 20 / 24) < 1e-12
 
 
-def test_gradient_pieces_partition_the_arena_and_follow_the_backward_order(model):
-    """model.gradient_pieces(): what a multi-GPU step sends after each leg of its backward sweep (bridge + decoders, stage 4, stage 3,
-    the rest) -- disjoint ranges that cover the whole flat gradient arena, each made of whole modules."""
+@pytest.mark.parametrize("legs", ["merged", "split"])
+def test_gradient_pieces_partition_the_arena_and_follow_the_backward_order(model, legs, monkeypatch):
+    """model.gradient_pieces(): what a multi-GPU step sends after each leg of its backward sweep (bridge + decoders, stages 4 + 3 -- one
+    piece by default, one each with TC_GRAD_LEGS=split -- the rest) -- disjoint ranges that cover the whole flat gradient arena, each
+    made of whole modules."""
     import math
     import torch
     from transception_amd.train import clip_buckets
+    monkeypatch.setenv("TC_GRAD_LEGS", legs)
     model._ensure_flat(torch.device("cpu"))
     pieces = model.gradient_pieces()
-    assert [u for u, _ in pieces] == ["encoder_done", "stage4_done", "stage3_done", None]
+    assert [u for u, _ in pieces] == (["encoder_done", "stage4_done", "stage3_done", None] if legs == "split" else ["encoder_done", "stage3_done", None])
     flat = sorted(r for _, rs in pieces for r in rs)
     assert flat[0][0] == 0 and flat[-1][1] == model._gflat.numel()
     assert all(a[1] == b[0] for a, b in zip(flat, flat[1:]))                 # no hole, no overlap
@@ -156,10 +159,11 @@ def test_gradient_pieces_partition_the_arena_and_follow_the_backward_order(model
                 if lo <= off < hi:
                     assert off + math.prod(shape) <= hi                      # no tensor straddles a cut
                     owner[name] = until
-    assert all(owner[n] == "stage4_done" for n in owner if n.startswith(("backbone.mhca_stage4.", "backbone.patch_embed_stage4.")))
+    assert all(owner[n] == ("stage4_done" if legs == "split" else "stage3_done") for n in owner
+               if n.startswith(("backbone.mhca_stage4.", "backbone.patch_embed_stage4.")))
     assert all(owner[n] == "stage3_done" for n in owner if n.startswith(("backbone.mhca_stage3.", "backbone.patch_embed_stage3.")))
     assert all(owner[n] == "encoder_done" for n in owner if not n.startswith("backbone."))
     assert all(owner[n] is None for n in owner if n.startswith(("backbone.block1.", "backbone.patch_embed1.", "backbone.mhca_stage2.")))
     s4 = sum(hi - lo for lo, hi in pieces[1][1]) / model.late_gradient_offset()
-    assert 0.6 < s4 < 0.7                                                     # stage 4 is ~64 % of the encoder's arena
+    assert (0.6 < s4 < 0.7) if legs == "split" else (0.85 < s4 < 0.95)        # stage 4 is ~64 % of the encoder's arena, stages 4 + 3 ~90 %
     assert clip_buckets([(0, 100), (200, 400), (500, 600)], [(50, 250), (550, 900)]) == [(50, 100), (200, 250), (550, 600)]

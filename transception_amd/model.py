@@ -511,6 +511,11 @@ class MSTransception(nn.Module):
         A multi-GPU step sends each piece while the sweep continues (train.GraphedStep); only the small last piece is exposed."""
         late, pieces, taken = self.late_gradient_offset(), [], []          # (the flat arenas exist: called after a first step)
         pieces.append(("encoder_done", [(late, self._gflat.numel())]))
+        # stages 4 and 3 leave TOGETHER at "stage3_done" by default: their 72 MB travel under the sweep through stages 2 and 1 either way
+        # (~2.5 ms against 0.5-1.2 ms of ring time), and every stop is one more graph launch per step (+0.13 ms at N = 1).
+        # TC_GRAD_LEGS=split: one piece per stage, as in round 3.
+        split = os.environ.get("TC_GRAD_LEGS", "merged") == "split"
+        acc = []
         for stage in (4, 3):
             rs = []
             for pre in (f"backbone.patch_embed_stage{stage}.", f"backbone.mhca_stage{stage}."):
@@ -518,8 +523,11 @@ class MSTransception(nn.Module):
                 lo, hi = min(a for a, _ in offs), max(b for _, b in offs)
                 assert all(n.startswith(pre) for n, (o, sh) in self._index.items() if lo <= o < hi), pre      # one module, one contiguous range
                 rs.append((lo, hi))
-            pieces.append((f"stage{stage}_done", rs))
             taken += rs
+            acc += rs
+            if split or stage == 3:
+                pieces.append((f"stage{stage}_done", acc))
+                acc = []
         rest, at = [], 0
         for lo, hi in sorted(taken):
             if lo > at:

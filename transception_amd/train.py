@@ -260,8 +260,9 @@ def comm_plan(model, n_ranks: int):
         bs = clip_buckets(buckets, ranges)
         nbytes = 4 * sum(b - a for a, b in bs)
         tot += nbytes
-        lat = 2 * (n_ranks - 1) * RING_HOP_US * 1e-3 * len(bs)
-        out.append({"sent_when_backward_reaches": stop or "end of backward (exposed)", "collectives": len(bs),
+        ncoll = 1 if (stop is None and len(bs) > 1 and nbytes // 4 <= COALESCE_MAX) else len(bs)      # the last piece travels packed (allreduce_gradients(coalesce=True))
+        lat = 2 * (n_ranks - 1) * RING_HOP_US * 1e-3 * ncoll
+        out.append({"sent_when_backward_reaches": stop or "end of backward (exposed)", "collectives": ncoll,
                     "buckets_elements": [[int(a), int(b)] for a, b in bs], "megabytes": nbytes / 1e6,
                     "ring_ms_one_link": f * nbytes / (XGMI_LINK_GBS * 1e9) * 1e3 + lat,
                     "ring_ms_seven_links": f * nbytes / (XGMI_LINK_GBS * XGMI_LINKS * 1e9) * 1e3 + lat})
@@ -272,11 +273,38 @@ def comm_plan(model, n_ranks: int):
                      "hops x 6 us per collective; every piece but the last travels under the rest of the backward sweep"}
 
 
-def allreduce_gradients(model, group=None, part: Optional[str] = None, async_op: bool = False, ranges=None):
+class _PackedWork:
+    """Several small, non-adjacent buckets sent as ONE collective: packed into a staging buffer, all-reduced, unpacked on wait()."""
+
+    def __init__(self, grads, buckets, group, async_op):
+        self.grads, self.buckets = grads, buckets
+        self.flat = torch.cat([grads[a:b] for a, b in buckets])
+        self.work = dist.all_reduce(self.flat, group=group, async_op=async_op)
+        if not async_op:
+            self._unpack()
+
+    def _unpack(self):
+        at = 0
+        for a, b in self.buckets:
+            self.grads[a:b].copy_(self.flat[at:at + b - a])
+            at += b - a
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+        self._unpack()
+
+
+COALESCE_MAX = int(os.environ.get("TC_DDP_COALESCE_MAX", str(4 << 20)))     # elements: pieces up to this size travel as one collective
+
+
+def allreduce_gradients(model, group=None, part: Optional[str] = None, async_op: bool = False, ranges=None, coalesce: bool = False):
     """C1: all-reduce(sum) of the live parts of the flat gradient arena over RCCL/xGMI (gloo in CPU tests): a handful of
     large buckets, every rank the same ones (the used set is a property of the architecture).  part="late" / "early" sends only
     the buckets at or above / below model.late_gradient_offset() (bridge + decoders / encoder); async_op returns the work
-    handles instead of waiting, so the late part can travel under the encoder's backward."""
+    handles instead of waiting, so the late part can travel under the encoder's backward.
+    coalesce: a piece of several small non-adjacent buckets (the LAST piece of the split sweep: three ranges, 2.7 MB, nothing left to
+    hide it under) goes as one collective through a packed staging buffer -- every collective costs 2 (N-1) ring hops of latency."""
     works = []
     if comm_on(group):
         buckets = gradient_buckets(model)
@@ -285,6 +313,9 @@ def allreduce_gradients(model, group=None, part: Optional[str] = None, async_op:
             buckets = late if part == "late" else early
         if ranges is not None:                           # one piece of a split backward sweep (model.gradient_pieces)
             buckets = clip_buckets(buckets, ranges)
+        if coalesce and len(buckets) > 1 and sum(b - a for a, b in buckets) <= COALESCE_MAX:
+            w = _PackedWork(model._gflat, buckets, group, async_op)
+            return [w] if async_op else []
         for a, b in buckets:
             w = dist.all_reduce(model._gflat[a:b], group=group, async_op=async_op)
             if async_op:
@@ -480,10 +511,10 @@ class GraphedStep:
             self.g_bwd.replay()
             if comm:                                 # C1, bridge + decoder buckets: the collective stream waits for g_bwd only
                 works = allreduce_gradients(self.model, self.group, async_op=True, ranges=self._pieces[0][1])
-            for g, (_, rng) in zip(self.g_bwd_legs, self._pieces[1:]):
-                g.replay()                           # stage 4, stage 3, rest of the encoder: each leg's buckets leave under the next leg
-                if comm:
-                    works += allreduce_gradients(self.model, self.group, async_op=True, ranges=rng)
+            for g, (until, rng) in zip(self.g_bwd_legs, self._pieces[1:]):
+                g.replay()                           # stages 4 + 3, rest of the encoder: each leg's buckets leave under the next leg
+                if comm:                             # (the last piece has nothing to hide under: its small buckets go as ONE collective)
+                    works += allreduce_gradients(self.model, self.group, async_op=True, ranges=rng, coalesce=until is None)
             for w in works:
                 w.wait()                                     # the compute stream waits for the collectives, the host does not
             self.g_opt.replay()
