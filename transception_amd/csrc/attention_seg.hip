@@ -234,7 +234,10 @@ __global__ __launch_bounds__(FW_NT, 1) void attn_fwd_seg_kernel(const bf16_t* __
 typedef int tc_i32x4 __attribute__((ext_vector_type(4)));
 // LDS: 12 ring slots of one 32-key K | V sub-tile; the twelve 32-query wave tiles (Q in, O out) alias slots 6-11, which the stream
 // does not store to before every wave has read its Q fragments and does not read after the barrier in front of the O tiles.
-constexpr int AS_NW = 12, AS_VOFF = 32 * LDR * 2, AS_SLOT = 2 * AS_VOFF, AS_NSLOT = 12, AS_AHEAD = 6, AS_WT = 32 * LDR * 2, AS_WT0 = 6 * AS_SLOT,
+#ifndef TC_AS_AHEAD
+#define TC_AS_AHEAD 6                                            // keep in sync with AHEAD of gen_attn_asm.py (TC_ATTN_AHEAD)
+#endif
+constexpr int AS_NW = 12, AS_VOFF = 32 * LDR * 2, AS_SLOT = 2 * AS_VOFF, AS_NSLOT = 12, AS_AHEAD = TC_AS_AHEAD, AS_WT = 32 * LDR * 2, AS_WT0 = 6 * AS_SLOT,
               AS_LSE0 = AS_NSLOT * AS_SLOT;
 static_assert(AS_WT0 + AS_NW * AS_WT <= AS_LSE0, "wave tiles must fit in the ring");
 #ifdef TC_ATTN_ASM_TIMING

@@ -39,9 +39,12 @@ import sys
 LDR_B = 144                     # bytes per LDS row: 64 halfs + 8 pad
 SLOT_B = 2 * 32 * LDR_B          # ring slot: K sub-tile | V sub-tile of 32 keys
 NSLOT = 12                      # slots; sub-tile j+AHEAD is stored during iteration j, and the workgroup barrier comes every PERIOD iterations:
-AHEAD = 6                       #   a store must be separated from the first read of its slot (2 iterations before its PV) and from the last
+AHEAD = int(os.environ.get("TC_ATTN_AHEAD", "6"))   #   a store must be separated from the first read of its slot (2 iterations before its PV) and from the last
 PERIOD = 4                      #   read of the slot's previous occupant by a barrier: AHEAD >= PERIOD + 2, NSLOT >= AHEAD + PERIOD - 1 (+ slack)
 NEG_BIG = 0xF149F2CA            # -1.0e30f
+DEFER = bool(int(os.environ.get("TC_ATTN_DEFER", "0")))   # experiment: ring store of the sub-tile requested ONE iteration ago, at the head of the
+#   iteration (stores run AHEAD - 1 ahead; with TC_ATTN_AHEAD=7 and -DTC_AS_AHEAD=7, scripts/exp/build_fwd_variant.sh): 25.6 vs 25.7 us -- the
+#   wait for the global load is not what an iteration waits for
 
 TIMING = bool(int(os.environ.get("TC_ATTN_TIMING", "0")))       # experiment builds: s_memtime stamps at section boundaries
 NSTAMP = 6
@@ -342,7 +345,15 @@ def iteration(g, mode):
             g.salu(f"s_add_u32 s{S_PH}, s{S_PH}, 1")
             g.salu(f"s_and_b32 s{S_PH}, s{S_PH}, {PERIOD - 1}")
         head.append(bar)
+    def stash():
+        g.wait_vm(0)
+        g.valu(f"v_add_u32_e32 {vreg(AW)}, s{S_SW}, {OP_WBASE}", [], [vreg(AW)])
+        g.salu(f"s_mov_b64 exec, {OP_WEXEC}")
+        g.emit(f"ds_write_b128 {vreg(AW)}, {vreg(ST, 4)}", "ds_write", [vreg(AW)] + regs("v", ST, 4))
+        g.salu("s_mov_b64 exec, -1")
     if stage:
+        if DEFER and not first:
+            head.append(stash)
         head.append(lambda: g.salu(f"s_mov_b64 exec, {OP_WEXEC}"))
         head.append(lambda: g.emit(f"buffer_load_dwordx4 {vreg(ST, 4)}, {OP_GOFF}, {OP_RSRC}, 0 offen", "vmem_load", [], regs("v", ST, 4)))
         head.append(lambda: g.salu("s_mov_b64 exec, -1"))
@@ -369,13 +380,7 @@ def iteration(g, mode):
     head = [lambda: g.valu(f"v_add_u32_e32 {vreg(AV)}, s{S_SV}, {OP_VBASE}", [], [vreg(AV)])]
     mf = [] if last else [lambda ks=ks: mf_qk(g, ks) for ks in range(4)]
     free = [lambda f=f: vf_load(g, f, AV) for f in range(4)]      # V(j+1) fragments: free since PV(j) issued above
-    if stage:
-        def stash():
-            g.wait_vm(0)
-            g.valu(f"v_add_u32_e32 {vreg(AW)}, s{S_SW}, {OP_WBASE}", [], [vreg(AW)])
-            g.salu(f"s_mov_b64 exec, {OP_WEXEC}")
-            g.emit(f"ds_write_b128 {vreg(AW)}, {vreg(ST, 4)}", "ds_write", [vreg(AW)] + regs("v", ST, 4))
-            g.salu("s_mov_b64 exec, -1")
+    if stage and not DEFER:
         free.append(stash)
     if not last:
         def slots():
@@ -455,7 +460,7 @@ def prologue(g):
     g.salu(f"s_mov_b32 s{S_LN2}, 0x3f317218")
     g.salu(f"s_mov_b32 s{S_SV}, 0")                                                       # V(0)
     g.salu(f"s_mov_b32 s{S_SK}, {SLOT_B}")                                                # K(1)
-    g.salu(f"s_mov_b32 s{S_SW}, {(AHEAD - 1) * SLOT_B}")                                  # sub-tile AHEAD-1 is stored by iteration -1
+    g.salu(f"s_mov_b32 s{S_SW}, {(AHEAD - (2 if DEFER else 1)) * SLOT_B}")               # sub-tile AHEAD-1 is stored by iteration -1 (DEFER: by iteration 0)
     g.salu(f"s_mov_b32 s{S_PH}, {2 % PERIOD}")                                            # (j + 2) mod PERIOD of iteration 0
     g.salu(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 2")                                            # steady iterations j = 0 .. nsub - 3
     for ks in range(4):
