@@ -410,6 +410,23 @@ int tc_chan_gate_bwd(const void* dy, int lddy, const void* x, int ldx, const voi
 int tc_relu_fwd(const void* x, void* y, long long n, int dtype, void* stream);
 int tc_relu_bwd(const void* dy, const void* y, void* dz, long long n, int dtype, void* stream);
 
+/* CBAMBlock pieces (the concat = "cbam" aggregate, MSTr.py:1128-1211): x is [B*N, C] token rows.
+ *   tc_chan_pool2: pooled rows 0..B-1 = max over the image's N rows (idx[b, c] = the first maximal row), rows B..2B-1 = mean    (:1141-1142)
+ *   tc_pix_stats:  st[row] = (max over the C channels, mean over them), idx[row] = the first maximal channel                   (:1156-1158)
+ *   tc_sa_conv:    g = sigmoid(Conv2d(2 -> 1, k x k, padding k/2)(st))  over the [B, H, W] token grid, k = 3 or 7               (:1151,1161-1163)
+ *                  backward: dst, dw (fp32 [2*k*k], ACCUMULATED), db (fp32 [1], ACCUMULATED) from dg and the stored g
+ *   tc_pix_gate:   y[row, c] = x[row, c] * g[row]; backward dx (+)= dy g, dg[row] = sum_c dy x                                  (:1206) */
+int tc_chan_pool2_fwd(const void* x, int ldx, void* pooled, int* idx, int B, int N, int C, int dtype, void* stream);
+int tc_chan_pool2_bwd(const void* dpooled, const int* idx, void* dx, int lddx, int B, int N, int C, int accumulate, int dtype, void* stream);
+int tc_pix_stats_fwd(const void* x, int ldx, void* st, int* idx, int rows, int C, int dtype, void* stream);
+int tc_pix_stats_bwd(const void* dst, const int* idx, void* dx, int lddx, int rows, int C, int accumulate, int dtype, void* stream);
+int tc_sa_conv_fwd(const void* st, const void* w, const void* bias, void* g, int B, int H, int W, int k, int dtype, void* stream);
+int tc_sa_conv_bwd(const void* dg, const void* g, const void* st, const void* w, void* dst, float* dw, float* db, int B, int H, int W, int k,
+                   int dtype, void* stream);
+int tc_pix_gate_fwd(const void* x, int ldx, const void* g, void* y, int ldy, int rows, int C, int dtype, void* stream);
+int tc_pix_gate_bwd(const void* dy, int lddy, const void* x, int ldx, const void* g, void* dx, int lddx, int dx_accumulate, void* dg, int rows, int C,
+                    int dtype, void* stream);
+
 /* CoordAtt pooling MSTr.py:1327-1332.  pooled/att rows: first B*H rows (b,h) = mean over w, then B*W rows (b,w) = mean over h
  * (a row permutation of the reference's per-image cat; BatchNorm statistics over rows are unaffected). */
 int tc_coord_pool_fwd(const void* x, void* pooled, int B, int H, int W, int C, int dtype, void* stream);

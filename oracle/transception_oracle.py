@@ -43,14 +43,16 @@ class TransCeptionOracle:
     CRPE_WINDOW = ((3, 2), (5, 3), (7, 3))   # (kernel, heads)       (MSTr.py:958)
 
     def __init__(self, params: Dict[str, Tensor], num_classes: int = 9, training: bool = True, concat: str = "coord",
-                 have_bridge: str = "original", br_ch_att_list=(True, False, False, False)):
+                 have_bridge: str = "original", br_ch_att_list=(True, False, False, False), use_sa_config: int = 1, sa_ker: int = 7):
         self.P = params
         self.num_classes = num_classes
         self.training = training
         # ablation switches of the reference constructor (MSTr.py:2760-2823) that this restatement follows: the aggregate of a
         # stage (:1384-1403), whether the bridge runs (:2840) and which bridge layers use channel attention (:2413-2420)
-        assert concat in ("coord", "normal", "se", "3d", "skn") and have_bridge != "sp" and len(br_ch_att_list) == 4
+        assert concat in ("coord", "normal", "se", "3d", "skn", "cbam") and have_bridge != "sp" and len(br_ch_att_list) == 4
         self.concat, self.have_bridge, self.br_ch_att_list = concat, have_bridge, tuple(bool(b) for b in br_ch_att_list)
+        # which stages' CBAM blocks apply the spatial attention (MSTr.py:2766-2775)
+        self.use_sa_list = {1: (True, True, False), 2: (True, False, False), 3: (False, False, False), 4: (True, True, True)}.get(use_sa_config, (True, True, True))
         # running statistics are buffers: updated in place in training mode
         self.buffers = {k: v.clone() for k, v in params.items()
                         if k.endswith(("running_mean", "running_var", "num_batches_tracked"))}
@@ -212,6 +214,23 @@ class TransCeptionOracle:
             z = sum(torch.einsum("bhwc,oc->bhwo", outs[p], w[:, :, p]) for p in range(4)) + self.P[agg + ".interact_concat.0.bias"]
             B, H, W, O = z.shape
             return self.batchnorm_rows(torch.relu(z).reshape(B, H * W, O), agg + ".bn").reshape(B, H, W, O)
+        if self.concat == "cbam":
+            # CBAMBlock, MSTr.py:1198-1211 with ChannelAttention :1141-1146 and SpatialAttention :1155-1165: out = x * sigmoid(se(max) + se(avg));
+            # (stages with use_sa) out = out * sigmoid(conv_kxk([max_c out, mean_c out])); then Conv1x1(out + x) -> BatchNorm -> ReLU
+            agg = name + ".aggregate"
+            B, H, W, C4 = cat.shape
+            flat = cat.reshape(B, H * W, C4)
+            se = lambda t: self.linear(torch.relu(self.linear(t, agg + ".ca.se.0", bias=False)), agg + ".ca.se.2", bias=False)
+            ca = torch.sigmoid(se(flat.max(dim=1).values) + se(flat.mean(dim=1)))
+            o = cat * ca[:, None, None, :]
+            stage = int(name[-1])
+            if self.use_sa_list[stage - 2]:
+                st = torch.stack([o.max(dim=-1).values, o.mean(dim=-1)], dim=1)                         # [B, 2, H, W]
+                k = self.P[agg + ".sa.conv.weight"].shape[-1]
+                sa = torch.sigmoid(F.conv2d(st, self.P[agg + ".sa.conv.weight"], self.P[agg + ".sa.conv.bias"], padding=k // 2))
+                o = o * sa.permute(0, 2, 3, 1)
+            z = self.linear((o + cat).reshape(B, H * W, C4), agg + ".conv2d_bn_act.0", bias=False)
+            return torch.relu(self.batchnorm_rows(z, agg + ".conv2d_bn_act.1")).reshape(B, H, W, -1)
         if self.concat == "skn":
             # SK_Block, MSTr.py:1076-1107: U = sum of the branch maps, S = its spatial mean, Z = fc(S), one Linear(d, C) per branch, softmax over
             # the branches, V = sum_k a_k x_k, then Conv1x1 (bias) -> ReLU -> BatchNorm

@@ -249,6 +249,13 @@ VARIANTS = {   # name -> (constructor kwargs, gradient probes)
                    ["backbone.mhca_stage2.aggregate.fc.weight", "backbone.mhca_stage2.aggregate.fc.bias", "backbone.mhca_stage3.aggregate.fcs.0.weight",
                     "backbone.mhca_stage3.aggregate.fcs.3.bias", "backbone.mhca_stage4.aggregate.conv_bn_ac.0.weight",
                     "backbone.mhca_stage4.aggregate.conv_bn_ac.0.bias", "backbone.mhca_stage2.aggregate.conv_bn_ac.2.weight", "decoder_0.last_layer.weight"]),
+    "concat_cbam": (dict(concat="cbam"),
+                    ["backbone.mhca_stage2.aggregate.ca.se.0.weight", "backbone.mhca_stage3.aggregate.ca.se.2.weight", "backbone.mhca_stage2.aggregate.sa.conv.weight",
+                     "backbone.mhca_stage3.aggregate.sa.conv.bias", "backbone.mhca_stage4.aggregate.conv2d_bn_act.0.weight",
+                     "backbone.mhca_stage2.aggregate.conv2d_bn_act.1.weight", "backbone.mhca_stage2.mhca_blks.0.MHCA_layers.2.mlp.fc2.weight",
+                     "decoder_0.last_layer.weight"]),
+    "concat_cbam_sa4_k3": (dict(concat="cbam", use_sa_config=4, sa_ker=3),
+                           ["backbone.mhca_stage4.aggregate.sa.conv.weight", "backbone.mhca_stage4.aggregate.ca.se.0.weight", "decoder_0.last_layer.weight"]),
     "bridge_para": (dict(have_bridge="para"),
                     ["backbone.mhca_stage3.aggregate.conv1.weight", "bridge.bridge_layer1.attn.q.weight", "bridge.bridge_layer2.attn.kv.weight",
                      "bridge.proj_act.0.weight", "bridge.proj_act.0.bias", "bridge.proj_act.1.weight", "bridge.bridge_layer3.mixffn4.fc2.weight",

@@ -308,6 +308,8 @@ VARIANTS = {   # constructor switches of SURVEY.md 8(f)-4 that the build impleme
     "concat_se": dict(concat="se"),
     "concat_3d": dict(concat="3d"),
     "concat_skn": dict(concat="skn"),
+    "concat_cbam": dict(concat="cbam"),
+    "concat_cbam_sa4_k3": dict(concat="cbam", use_sa_config=4, sa_ker=3),
     "no_bridge": dict(have_bridge="None"),
     "ch_att_1101": dict(br_ch_att_list=[True, True, False, True]),
     "bridge_para": dict(have_bridge="para"),
@@ -337,8 +339,9 @@ def test_variant_train_step_vs_reference_golden(name):
     loss.backward()
     named = dict(m.named_parameters())
     assert sum(1 for p in m.parameters() if p.grad is not None) == int(g[name + "/n_live"][0])
+    extra = dict(scale_rel=1e-2, sum_rtol=1e-2) if "cbam" in name else {}      # maxima: near-ties move gradient between neighbours (test_oracle_golden.py)
     for key in [k[len(name) + 6:-6] for k in g.files if k.startswith(name + "/grad/") and k.endswith("/shape")]:
-        check_packed(g, name + "/grad/" + key, named[key].grad.cpu(), atol=2e-6, rtol=2e-3, sum_rtol=1e-3)
+        check_packed(g, name + "/grad/" + key, named[key].grad.cpu(), **dict(dict(atol=2e-6, rtol=2e-3, sum_rtol=1e-3), **extra))
     m2 = MSTransception(num_classes=9, **kw)
     m2.load_state_dict(sd, strict=True)
     m2.to(DEV).eval()

@@ -291,6 +291,46 @@ def test_se_block_pieces(G, B, N, C):
     close(bP.grad, br2.grad, 3e-4, 3e-4, "bn dbeta")
 
 
+@pytest.mark.parametrize("B,H,W,C,k", [(2, 28, 28, 256, 7), (3, 7, 7, 1280, 3), (1, 14, 14, 512, 7), (2, 5, 9, 24, 3)])
+def test_cbam_pieces(G, B, H, W, C, k):
+    """CBAMBlock's own kernels (MSTr.py:1128-1211) op by op against torch: max + mean pooling over the tokens (gradient to the first maximal
+    token), max + mean over the channels per token, Conv2d(2 -> 1, k x k) + sigmoid on the token grid, the per-token gate."""
+    N, rows = H * W, B * H * W
+    x = T(f"cb.x{B}.{N}.{C}", (rows, C))
+    xr = x.clone().requires_grad_()
+    x4 = xr.view(B, H, W, C).permute(0, 3, 1, 2)
+    mx, av = F.adaptive_max_pool2d(x4, 1).view(B, C), F.adaptive_avg_pool2d(x4, 1).view(B, C)
+    gp = T(f"cb.gp{B}.{C}", (2 * B, C))
+    (torch.cat([mx, av], 0) * gp).sum().backward()
+    xv = mkV(G, x)
+    po = G.chan_pool2(xv, B, N)
+    close(po.data, torch.cat([mx, av], 0), 1e-6, 1e-5, "max | mean pooling")
+    run_bwd(G, po, gp)
+    close(G.grad_of(xv), xr.grad, 1e-6, 1e-5, "pooling gradient")
+    # spatial attention: statistics -> conv -> sigmoid -> gate
+    from transception_amd.engine import Graph
+    G2 = Graph(torch.float32, torch.device(DEV), training=True, record=True)
+    w, b = T(f"cb.w{k}", (1, 2, k, k), 0.3), T(f"cb.b{k}", (1,), 0.1)
+    gy = T(f"cb.gy{B}.{N}.{C}", (rows, C))
+    xr2, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    x42 = xr2.view(B, H, W, C).permute(0, 3, 1, 2)
+    st = torch.cat([x42.max(dim=1, keepdim=True)[0], x42.mean(dim=1, keepdim=True)], 1)
+    sa = torch.sigmoid(F.conv2d(st, wr, br, padding=k // 2))
+    y = (x42 * sa).permute(0, 2, 3, 1).reshape(rows, C)
+    y.backward(gy)
+    xv2, W_, b_ = mkV(G2, x), mkP(w), mkP(b)
+    stv = G2.pix_stats(xv2)
+    close(stv.data, st.permute(0, 2, 3, 1).reshape(rows, 2), 1e-6, 1e-5, "channel max | mean per token")
+    gate = G2.sa_conv(stv, W_, b_, B, H, W, k)
+    close(gate.data.view(-1), sa.reshape(-1), 2e-6, 1e-5, "spatial attention")
+    out = G2.pix_gate(xv2, gate)
+    close(out.data, y, 2e-6, 1e-5, "gated map")
+    run_bwd(G2, out, gy)
+    close(G2.grad_of(xv2), xr2.grad, 1e-5, 1e-4, "dx through gate, statistics and convolution")
+    close(W_.grad.view(-1), wr.grad.view(-1), 1e-4 * max(1.0, float(wr.grad.abs().max())), 1e-4, "d conv weight")
+    close(b_.grad, br.grad, 1e-4 * max(1.0, float(br.grad.abs().max())), 1e-4, "d conv bias")
+
+
 def test_batchnorm_eval():
     from transception_amd.engine import Graph
     Ge = Graph(torch.float32, torch.device(DEV), training=False, record=False)

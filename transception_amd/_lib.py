@@ -149,6 +149,14 @@ SIGNATURES = {
     "tc_chan_gate_bwd": [vp, i32, vp, i32, vp, vp, i32, i32, vp, i32, i32, i32, i32, vp],
     "tc_relu_fwd": [vp, vp, i64, i32, vp],
     "tc_relu_bwd": [vp, vp, vp, i64, i32, vp],
+    "tc_chan_pool2_fwd": [vp, i32, vp, vp, i32, i32, i32, i32, vp],
+    "tc_chan_pool2_bwd": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "tc_pix_stats_fwd": [vp, i32, vp, vp, i32, i32, i32, vp],
+    "tc_pix_stats_bwd": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "tc_sa_conv_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "tc_sa_conv_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "tc_pix_gate_fwd": [vp, i32, vp, vp, i32, i32, i32, i32, vp],
+    "tc_pix_gate_bwd": [vp, i32, vp, i32, vp, vp, i32, i32, vp, i32, i32, i32, vp],
     "tc_coord_pool_fwd": [vp, vp, i32, i32, i32, i32, i32, vp],
     "tc_coord_pool_bwd": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "tc_coord_gate_fwd": [vp, vp, vp, i32, i32, i32, i32, i32, vp],

@@ -1,0 +1,277 @@
+// CBAMBlock pieces (the concat = "cbam" aggregate of MHCA_stage, MSTr.py:1128-1211, 1400-1401) that the rest of the library does not have:
+//   ChannelAttention: global max AND average pooling of the token map per image and channel (:1141-1142)
+//   SpatialAttention: per-token maximum and mean over the channels (:1156-1158), Conv2d(2 -> 1, k x k, padding k/2) + sigmoid (:1151,1161-1163)
+//   the per-token gate out = x * sa (:1206)
+// Maps are [B * N, C] token rows (row stride ld), storage dtype T; small index arrays are int32.  All of it is memory-bound glue on maps of
+// a few MB; the kernels follow the pooling / gating kernels of elementwise.hip (16 channel quads x 16 row lanes per workgroup).
+#include "tc_common.h"
+
+namespace {
+
+#define TC_S ((hipStream_t)stream)
+
+// pooled rows 0..B-1 = max over the image's N rows (first maximal row in idx), rows B..2B-1 = mean
+template <typename T>
+__global__ __launch_bounds__(256) void chan_pool2_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ pooled, int* __restrict__ idx, int B, int N, int C) {
+    __shared__ float4 rs[16][16], rm[16][16];
+    __shared__ int ri[16][16][4];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4, c = blockIdx.y * 64 + tx * 4, b = blockIdx.x;
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int mi[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+    if (c < C)
+        for (int r = ty; r < N; r += 16) {
+            const float4 v = ld4<T>(x + ((long long)b * N + r) * ldx + c);
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s[e] += vv[e]; if (vv[e] > m[e]) { m[e] = vv[e]; mi[e] = r; } }
+        }
+    rs[ty][tx] = make_float4(s[0], s[1], s[2], s[3]);
+    rm[ty][tx] = make_float4(m[0], m[1], m[2], m[3]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ri[ty][tx][e] = mi[e];
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        float ts[4] = {0.f, 0.f, 0.f, 0.f}, tm[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int ti[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+        for (int k = 0; k < 16; ++k) {
+            const float4 a = rs[k][tx], mm = rm[k][tx];
+            const float av[4] = {a.x, a.y, a.z, a.w}, mv[4] = {mm.x, mm.y, mm.z, mm.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ts[e] += av[e];
+                const int i2 = ri[k][tx][e];
+                if (mv[e] > tm[e] || (mv[e] == tm[e] && i2 < ti[e])) { tm[e] = mv[e]; ti[e] = i2; }      // the FIRST maximal row, as torch
+            }
+        }
+        const float inv = 1.f / (float)N;
+        st4<T>(pooled + (long long)b * C + c, make_float4(tm[0], tm[1], tm[2], tm[3]));
+        st4<T>(pooled + ((long long)B + b) * C + c, make_float4(ts[0] * inv, ts[1] * inv, ts[2] * inv, ts[3] * inv));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) idx[(long long)b * C + c + e] = ti[e];
+    }
+}
+
+// dx[b, n, c] (+)= (n == idx[b, c] ? dpooled[b, c] : 0) + dpooled[B + b, c] / N
+template <typename T>
+__global__ void chan_pool2_bwd_kernel(const T* dp, const int* idx, T* dx, int lddx, int B, int N, int C, int acc) {
+    const int cq = C >> 2;
+    const float inv = 1.f / (float)N;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)B * N * cq; i += gridDim.x * blockDim.x) {
+        const int q = (int)(i % cq) * 4; const unsigned row = i / cq; const int b = (int)(row / (unsigned)N), n = (int)(row - (unsigned)b * N);
+        const float4 gm = ld4<T>(dp + (long long)b * C + q), ga = ld4<T>(dp + ((long long)B + b) * C + q);
+        const int4 ix = *reinterpret_cast<const int4*>(idx + (long long)b * C + q);
+        float4 o = make_float4(ga.x * inv + (ix.x == n ? gm.x : 0.f), ga.y * inv + (ix.y == n ? gm.y : 0.f), ga.z * inv + (ix.z == n ? gm.z : 0.f),
+                               ga.w * inv + (ix.w == n ? gm.w : 0.f));
+        T* d = dx + (long long)row * lddx + q;
+        if (acc) { const float4 v = ld4<T>(d); o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w; }
+        st4<T>(d, o);
+    }
+}
+
+// per token row: st[row] = (max over the C channels, mean over them), idx[row] = the first maximal channel.  16 lanes per row.
+template <typename T>
+__global__ __launch_bounds__(256) void pix_stats_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ st, int* __restrict__ idx, int rows, int C) {
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    for (int r = blockIdx.x * 16 + ty; r < rows; r += gridDim.x * 16) {
+        float s = 0.f, m = -INFINITY;
+        int mi = 0x7fffffff;
+        for (int c = tx * 4; c < C; c += 64) {
+            const float4 v = ld4<T>(x + (long long)r * ldx + c);
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s += vv[e]; if (vv[e] > m) { m = vv[e]; mi = c + e; } }
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            s += __shfl_xor(s, o, 64);
+            const float m2 = __shfl_xor(m, o, 64);
+            const int i2 = __shfl_xor(mi, o, 64);
+            if (m2 > m || (m2 == m && i2 < mi)) { m = m2; mi = i2; }
+        }
+        if (tx == 0) { stf<T>(st + (long long)r * 2, m); stf<T>(st + (long long)r * 2 + 1, s / (float)C); idx[r] = mi; }
+    }
+}
+
+// dx[r, c] (+)= dst[r, 1] / C + (c == idx[r] ? dst[r, 0] : 0)
+template <typename T>
+__global__ void pix_stats_bwd_kernel(const T* dst, const int* idx, T* dx, int lddx, int rows, int C, int acc) {
+    const int cq = C >> 2;
+    const float inv = 1.f / (float)C;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)rows * cq; i += gridDim.x * blockDim.x) {
+        const int q = (int)(i % cq) * 4; const unsigned r = i / cq;
+        const float gm = ldf<T>(dst + (long long)r * 2), ga = ldf<T>(dst + (long long)r * 2 + 1) * inv;
+        const int ix = idx[r];
+        float4 o = make_float4(ga + (ix == q ? gm : 0.f), ga + (ix == q + 1 ? gm : 0.f), ga + (ix == q + 2 ? gm : 0.f), ga + (ix == q + 3 ? gm : 0.f));
+        T* d = dx + (long long)r * lddx + q;
+        if (acc) { const float4 v = ld4<T>(d); o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w; }
+        st4<T>(d, o);
+    }
+}
+
+// g[b, h, w] = sigmoid(bias + sum_{ch, ky, kx} w[ch][ky][kx] st[b, h + ky - P, w + kx - P, ch])   (zero padding), one thread per token
+template <typename T, int K>
+__global__ __launch_bounds__(256) void sa_conv_fwd_kernel(const T* __restrict__ st, const T* __restrict__ w, const T* __restrict__ bias, T* __restrict__ g,
+                                                          int B, int H, int W) {
+    __shared__ float ws[2 * K * K + 1];
+    for (int i = threadIdx.x; i < 2 * K * K; i += 256) ws[i] = ldf<T>(w + i);
+    if (threadIdx.x == 0) ws[2 * K * K] = ldf<T>(bias);
+    __syncthreads();
+    constexpr int P = K / 2;
+    const unsigned n = (unsigned)B * H * W;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int x0 = (int)(i % (unsigned)W); const unsigned t = i / (unsigned)W; const int y0 = (int)(t % (unsigned)H), b = (int)(t / (unsigned)H);
+        float acc = ws[2 * K * K];
+        for (int ky = 0; ky < K; ++ky) {
+            const int yy = y0 + ky - P;
+            if (yy < 0 || yy >= H) continue;
+            for (int kx = 0; kx < K; ++kx) {
+                const int xx = x0 + kx - P;
+                if (xx < 0 || xx >= W) continue;
+                const T* p = st + (((long long)b * H + yy) * W + xx) * 2;
+                acc += ws[ky * K + kx] * ldf<T>(p) + ws[K * K + ky * K + kx] * ldf<T>(p + 1);
+            }
+        }
+        stf<T>(g + i, sigmoid_f(acc));
+    }
+}
+
+// dz = dg * g (1 - g);  dst[b, y, x, ch] = sum_taps w[ch][ky][kx] dz[b, y - ky + P, x - kx + P];  dw[ch][ky][kx] += sum dz[p] st[p + tap];  db += sum dz
+template <typename T, int K>
+__global__ __launch_bounds__(256) void sa_conv_bwd_kernel(const T* __restrict__ dg, const T* __restrict__ g, const T* __restrict__ st, const T* __restrict__ w,
+                                                          T* __restrict__ dst, float* __restrict__ dw, float* __restrict__ db, int B, int H, int W) {
+    __shared__ float ws[2 * K * K];
+    __shared__ float red[2 * K * K + 1];
+    for (int i = threadIdx.x; i < 2 * K * K; i += 256) ws[i] = ldf<T>(w + i);
+    for (int i = threadIdx.x; i < 2 * K * K + 1; i += 256) red[i] = 0.f;
+    __syncthreads();
+    constexpr int P = K / 2;
+    const unsigned n = (unsigned)B * H * W;
+    auto dz_at = [&](int b, int yy, int xx) -> float {
+        if (yy < 0 || yy >= H || xx < 0 || xx >= W) return 0.f;
+        const long long p = ((long long)b * H + yy) * W + xx;
+        const float s = ldf<T>(g + p);
+        return ldf<T>(dg + p) * s * (1.f - s);
+    };
+    for (unsigned i0 = blockIdx.x * 256; i0 < n; i0 += gridDim.x * 256) {
+        const unsigned i = i0 + threadIdx.x;
+        const bool in = i < n;
+        const int x0 = (int)(i % (unsigned)W); const unsigned t = i / (unsigned)W; const int y0 = (int)(t % (unsigned)H), b = (int)(t / (unsigned)H);
+        float a0 = 0.f, a1 = 0.f;
+        const float dz = in ? dz_at(b, y0, x0) : 0.f;
+        for (int ky = 0; ky < K; ++ky)
+            for (int kx = 0; kx < K; ++kx) {
+                if (in) {                                           // input gradient: the transposed convolution
+                    const float d2 = dz_at(b, y0 - ky + P, x0 - kx + P);
+                    a0 += ws[ky * K + kx] * d2; a1 += ws[K * K + ky * K + kx] * d2;
+                }
+                // weight gradient of this tap: dz[p] * st[p + (ky - P, kx - P)], summed over the workgroup's tokens
+                float w0 = 0.f, w1 = 0.f;
+                const int yy = y0 + ky - P, xx = x0 + kx - P;
+                if (in && yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                    const T* p = st + (((long long)b * H + yy) * W + xx) * 2;
+                    w0 = dz * ldf<T>(p); w1 = dz * ldf<T>(p + 1);
+                }
+                w0 = wave_sum(w0); w1 = wave_sum(w1);
+                if ((threadIdx.x & 63) == 0) { atomicAdd(&red[ky * K + kx], w0); atomicAdd(&red[K * K + ky * K + kx], w1); }
+            }
+        const float dzs = wave_sum(dz);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&red[2 * K * K], dzs);
+        if (in) { stf<T>(dst + (long long)i * 2, a0); stf<T>(dst + (long long)i * 2 + 1, a1); }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * K * K; i += 256) atomicAdd(dw + i, red[i]);
+    if (threadIdx.x == 0) atomicAdd(db, red[2 * K * K]);
+}
+
+// y[r, c] = x[r, c] * g[r]
+template <typename T>
+__global__ void pix_gate_fwd_kernel(const T* x, int ldx, const T* g, T* y, int ldy, int rows, int C) {
+    const int cq = C >> 2;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)rows * cq; i += gridDim.x * blockDim.x) {
+        const int q = (int)(i % cq) * 4; const unsigned r = i / cq;
+        const float a = ldf<T>(g + r);
+        const float4 v = ld4<T>(x + (long long)r * ldx + q);
+        st4<T>(y + (long long)r * ldy + q, make_float4(v.x * a, v.y * a, v.z * a, v.w * a));
+    }
+}
+
+// dx (+)= dy * g[r];  dg[r] = sum_c dy * x.  16 lanes per row.
+template <typename T>
+__global__ __launch_bounds__(256) void pix_gate_bwd_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ x, int ldx, const T* __restrict__ g,
+                                                           T* __restrict__ dx, int lddx, int acc, T* __restrict__ dg, int rows, int C) {
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    for (int r = blockIdx.x * 16 + ty; r < rows; r += gridDim.x * 16) {
+        const float a = ldf<T>(g + r);
+        float s = 0.f;
+        for (int c = tx * 4; c < C; c += 64) {
+            const float4 d = ld4<T>(dy + (long long)r * lddy + c), v = ld4<T>(x + (long long)r * ldx + c);
+            s += d.x * v.x + d.y * v.y + d.z * v.z + d.w * v.w;
+            float4 o = make_float4(d.x * a, d.y * a, d.z * a, d.w * a);
+            T* dst = dx + (long long)r * lddx + c;
+            if (acc) { const float4 w = ld4<T>(dst); o.x += w.x; o.y += w.y; o.z += w.z; o.w += w.w; }
+            st4<T>(dst, o);
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
+        if (tx == 0) stf<T>(dg + r, s);
+    }
+}
+
+inline dim3 gq(long long n) { return dim3(tc_blocks(n, 256, 8192)); }
+
+}  // namespace
+
+extern "C" int tc_chan_pool2_fwd(const void* x, int ldx, void* pooled, int* idx, int B, int N, int C, int dtype, void* stream) {
+    if (!x || !pooled || !idx || B <= 0 || N <= 0 || C <= 0 || ((C | ldx) & 3) || (long long)B * N * (C / 4) >= 0x7fffffffLL) return TC_ERR_ARG;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((chan_pool2_fwd_kernel<T>), dim3(B, (C + 63) / 64), dim3(256), 0, TC_S, (const T*)x, ldx, (T*)pooled, idx, B, N, C));
+    return tc_launch_status();
+}
+extern "C" int tc_chan_pool2_bwd(const void* dpooled, const int* idx, void* dx, int lddx, int B, int N, int C, int accumulate, int dtype, void* stream) {
+    if (!dpooled || !idx || !dx || B <= 0 || N <= 0 || C <= 0 || ((C | lddx) & 3) || (long long)B * N * (C / 4) >= 0x7fffffffLL) return TC_ERR_ARG;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((chan_pool2_bwd_kernel<T>), gq((long long)B * N * C / 4), dim3(256), 0, TC_S, (const T*)dpooled, idx, (T*)dx, lddx,
+                                                B, N, C, accumulate));
+    return tc_launch_status();
+}
+extern "C" int tc_pix_stats_fwd(const void* x, int ldx, void* st, int* idx, int rows, int C, int dtype, void* stream) {
+    if (!x || !st || !idx || rows <= 0 || C <= 0 || ((C | ldx) & 3)) return TC_ERR_ARG;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((pix_stats_fwd_kernel<T>), dim3(tc_blocks(rows, 16, 4096)), dim3(256), 0, TC_S, (const T*)x, ldx, (T*)st, idx, rows, C));
+    return tc_launch_status();
+}
+extern "C" int tc_pix_stats_bwd(const void* dst, const int* idx, void* dx, int lddx, int rows, int C, int accumulate, int dtype, void* stream) {
+    if (!dst || !idx || !dx || rows <= 0 || C <= 0 || ((C | lddx) & 3) || (long long)rows * (C / 4) >= 0x7fffffffLL) return TC_ERR_ARG;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((pix_stats_bwd_kernel<T>), gq((long long)rows * C / 4), dim3(256), 0, TC_S, (const T*)dst, idx, (T*)dx, lddx, rows, C,
+                                                accumulate));
+    return tc_launch_status();
+}
+extern "C" int tc_sa_conv_fwd(const void* st, const void* w, const void* bias, void* g, int B, int H, int W, int k, int dtype, void* stream) {
+    if (!st || !w || !bias || !g || B <= 0 || H <= 0 || W <= 0 || (k != 3 && k != 7) || (long long)B * H * W >= 0x7fffffffLL) return TC_ERR_ARG;
+    const dim3 grid(tc_blocks((long long)B * H * W, 256, 4096));
+    TC_DISPATCH_DTYPE(dtype, {
+        if (k == 7) hipLaunchKernelGGL((sa_conv_fwd_kernel<T, 7>), grid, dim3(256), 0, TC_S, (const T*)st, (const T*)w, (const T*)bias, (T*)g, B, H, W);
+        else hipLaunchKernelGGL((sa_conv_fwd_kernel<T, 3>), grid, dim3(256), 0, TC_S, (const T*)st, (const T*)w, (const T*)bias, (T*)g, B, H, W);
+    });
+    return tc_launch_status();
+}
+extern "C" int tc_sa_conv_bwd(const void* dg, const void* g, const void* st, const void* w, void* dst, float* dw, float* db, int B, int H, int W, int k, int dtype,
+                              void* stream) {
+    if (!dg || !g || !st || !w || !dst || !dw || !db || B <= 0 || H <= 0 || W <= 0 || (k != 3 && k != 7) || (long long)B * H * W >= 0x7fffffffLL) return TC_ERR_ARG;
+    const dim3 grid(tc_blocks((long long)B * H * W, 256, 256));
+    TC_DISPATCH_DTYPE(dtype, {
+        if (k == 7) hipLaunchKernelGGL((sa_conv_bwd_kernel<T, 7>), grid, dim3(256), 0, TC_S, (const T*)dg, (const T*)g, (const T*)st, (const T*)w, (T*)dst, dw, db, B, H, W);
+        else hipLaunchKernelGGL((sa_conv_bwd_kernel<T, 3>), grid, dim3(256), 0, TC_S, (const T*)dg, (const T*)g, (const T*)st, (const T*)w, (T*)dst, dw, db, B, H, W);
+    });
+    return tc_launch_status();
+}
+extern "C" int tc_pix_gate_fwd(const void* x, int ldx, const void* g, void* y, int ldy, int rows, int C, int dtype, void* stream) {
+    if (!x || !g || !y || rows <= 0 || C <= 0 || ((C | ldx | ldy) & 3) || (long long)rows * (C / 4) >= 0x7fffffffLL) return TC_ERR_ARG;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((pix_gate_fwd_kernel<T>), gq((long long)rows * C / 4), dim3(256), 0, TC_S, (const T*)x, ldx, (const T*)g, (T*)y, ldy,
+                                                rows, C));
+    return tc_launch_status();
+}
+extern "C" int tc_pix_gate_bwd(const void* dy, int lddy, const void* x, int ldx, const void* g, void* dx, int lddx, int dx_accumulate, void* dg, int rows, int C,
+                               int dtype, void* stream) {
+    if (!dy || !x || !g || !dx || !dg || rows <= 0 || C <= 0 || ((C | lddy | ldx | lddx) & 3)) return TC_ERR_ARG;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((pix_gate_bwd_kernel<T>), dim3(tc_blocks(rows, 16, 4096)), dim3(256), 0, TC_S, (const T*)dy, lddy, (const T*)x, ldx,
+                                                (const T*)g, (T*)dx, lddx, dx_accumulate, (T*)dg, rows, C));
+    return tc_launch_status();
+}

@@ -1427,6 +1427,88 @@ class Graph:
         self._rec(bwd)
         return out
 
+    def add(self, a: Var, b: Var) -> Var:
+        """a + b (same shape)."""
+        assert a.rows == b.rows and a.cols == b.cols and a.cols % 4 == 0
+        out = self.new(a.rows, a.cols)
+        self.L.tc_add(_ptr(a.data), a.ld, _ptr(b.data), b.ld, _ptr(out.data), out.ld, a.rows, a.cols, self.dt, self.stream)
+
+        def bwd():
+            d = self.grad_of(out)
+            if d is None:
+                return
+            self.pass_grad(a, d)
+            self.pass_grad(b, d)
+        self._rec(bwd)
+        return out
+
+    def chan_pool2(self, x: Var, B: int, N: int) -> Var:
+        """CBAM ChannelAttention pooling (MSTr.py:1141-1142): [2B, C] -- rows 0..B-1 the per-image channel maxima, rows B..2B-1 the means."""
+        out = self.new(2 * B, x.cols)
+        idx = torch.empty((B, x.cols), dtype=torch.int32, device=self.dev)
+        self.L.tc_chan_pool2_fwd(_ptr(x.data), x.ld, _ptr(out.data), _ptr(idx), B, N, x.cols, self.dt, self.stream)
+
+        def bwd():
+            d = self.grad_of(out)
+            if d is None:
+                return
+            assert d.is_contiguous()
+            gx, acc = self.wgrad(x)
+            self.L.tc_chan_pool2_bwd(_ptr(d), _ptr(idx), _ptr(gx), gx.stride(0), B, N, x.cols, acc, self.dt, self.stream)
+        self._rec(bwd)
+        return out
+
+    def pix_stats(self, x: Var) -> Var:
+        """CBAM SpatialAttention statistics (MSTr.py:1156-1158): [rows, 2] = (max over the channels, mean over them) per token."""
+        out = self.new(x.rows, 2)
+        idx = torch.empty((x.rows,), dtype=torch.int32, device=self.dev)
+        self.L.tc_pix_stats_fwd(_ptr(x.data), x.ld, _ptr(out.data), _ptr(idx), x.rows, x.cols, self.dt, self.stream)
+
+        def bwd():
+            d = self.grad_of(out)
+            if d is None:
+                return
+            assert d.is_contiguous()
+            gx, acc = self.wgrad(x)
+            self.L.tc_pix_stats_bwd(_ptr(d), _ptr(idx), _ptr(gx), gx.stride(0), x.rows, x.cols, acc, self.dt, self.stream)
+        self._rec(bwd)
+        return out
+
+    def sa_conv(self, st: Var, W: P, b: P, B: int, H: int, Wd: int, k: int) -> Var:
+        """sigmoid(Conv2d(2 -> 1, k x k, padding k / 2)(st)) over the token grid (MSTr.py:1151, 1161-1163): [rows, 1]."""
+        assert st.cols == 2 and st.data.is_contiguous() and st.rows == B * H * Wd
+        out = self.new(st.rows, 1)
+        self.L.tc_sa_conv_fwd(_ptr(st.data), _ptr(W.data), _ptr(b.data), _ptr(out.data), B, H, Wd, k, self.dt, self.stream)
+
+        def bwd():
+            d = self.grad_of(out)
+            if d is None:
+                return
+            assert d.is_contiguous() and W.grad is not None and b.grad is not None
+            tmp = torch.empty((st.rows, 2), dtype=st.data.dtype, device=self.dev)
+            self.L.tc_sa_conv_bwd(_ptr(d), _ptr(out.data), _ptr(st.data), _ptr(W.data), _ptr(tmp), _ptr(W.grad), _ptr(b.grad), B, H, Wd, k, self.dt, self.stream)
+            self.pass_grad(st, tmp)
+        self._rec(bwd)
+        return out
+
+    def pix_gate(self, x: Var, g: Var) -> Var:
+        """out[row, :] = x[row, :] * g[row] (MSTr.py:1206)."""
+        assert g.cols == 1 and g.rows == x.rows and g.data.is_contiguous()
+        out = self.new(x.rows, x.cols)
+        self.L.tc_pix_gate_fwd(_ptr(x.data), x.ld, _ptr(g.data), _ptr(out.data), out.ld, x.rows, x.cols, self.dt, self.stream)
+
+        def bwd():
+            d = self.grad_of(out)
+            if d is None:
+                return
+            gx, acc = self.wgrad(x)
+            gg, accg = self.wgrad(g)
+            assert not accg and gg.is_contiguous()
+            self.L.tc_pix_gate_bwd(_ptr(d), d.stride(0), _ptr(x.data), x.ld, _ptr(g.data), _ptr(gx), gx.stride(0), acc, _ptr(gg), x.rows, x.cols,
+                                   self.dt, self.stream)
+        self._rec(bwd)
+        return out
+
     def relu(self, x: Var) -> Var:
         assert x.data.is_contiguous()
         out = self.new(x.rows, x.cols)

@@ -135,7 +135,7 @@ def _mk_coord_att(inp: int, oup: int) -> nn.Module:              # MSTr.py:1304-
     return m
 
 
-def _mk_mhca_stage(dim: int, out_dim: int, layers: int, concat: str = "coord") -> nn.Module:   # MSTr.py:1350-1410
+def _mk_mhca_stage(dim: int, out_dim: int, layers: int, concat: str = "coord", use_sa: bool = True, sa_ker: int = 7) -> nn.Module:   # MSTr.py:1350-1410
     m = nn.Module()
     m.mhca_blks = nn.ModuleList([_mk_mhca_encoder(dim, layers) for _ in range(3)])
     m.InvRes = _mk_resblock(dim)
@@ -147,6 +147,16 @@ def _mk_mhca_stage(dim: int, out_dim: int, layers: int, concat: str = "coord") -
         a = nn.Module()
         a.bn = nn.BatchNorm2d(out_dim)
         a.interact_concat = nn.Sequential(nn.Conv3d(dim, out_dim, kernel_size=(4, 1, 1)), nn.ReLU())
+        m.aggregate = a
+    elif concat == "cbam":                                      # CBAMBlock(channel = 4C, reduction = 16, kernel_size = sa_ker), MSTr.py:1169-1211, 1400-1401
+        a = nn.Module()
+        a.ca = nn.Module()
+        a.ca.se = nn.Sequential(nn.Conv2d(dim * 4, dim * 4 // 16, 1, bias=False), nn.ReLU(), nn.Conv2d(dim * 4 // 16, dim * 4, 1, bias=False))
+        a.sa = nn.Module()
+        a.sa.conv = nn.Conv2d(2, 1, kernel_size=sa_ker, stride=1, padding=sa_ker // 2)
+        a.conv2d_bn_act = nn.Sequential(nn.Conv2d(dim * 4, out_dim, 1, bias=False), nn.BatchNorm2d(out_dim), nn.ReLU())
+        a.use_sa = use_sa
+        a.sa_ker = sa_ker
         m.aggregate = a
     elif concat == "skn":                                       # SK_Block(in_ch = C, num_path = 4, reduction = 8, L = 32), MSTr.py:1054-1107, 1398-1399
         a = nn.Module()
@@ -238,16 +248,16 @@ def _mk_decoder_layer(in_out_chan, n_class: int, is_last: bool) -> nn.Module:   
     return m
 
 
-def _mk_backbone(concat: str = "coord") -> nn.Module:             # MSTr.py:1536-1671
+def _mk_backbone(concat: str = "coord", use_sa_list=(True, True, False), sa_ker: int = 7) -> nn.Module:             # MSTr.py:1536-1671
     m = nn.Module()
     for i, d in enumerate(DIMS):
         setattr(m, f"conv1_1_s{i + 1}", nn.Conv2d(3 * d, d, 1))     # dead parameters, kept for the schema
     m.patch_embed_stage2 = _mk_patch_embed_stage(DIMS[0])
     m.patch_embed_stage3 = _mk_patch_embed_stage(DIMS[1])
     m.patch_embed_stage4 = _mk_patch_embed_stage(DIMS[2])
-    m.mhca_stage2 = _mk_mhca_stage(DIMS[0], DIMS[1], LAYERS[0], concat)
-    m.mhca_stage3 = _mk_mhca_stage(DIMS[1], DIMS[2], LAYERS[1], concat)
-    m.mhca_stage4 = _mk_mhca_stage(DIMS[2], DIMS[3], LAYERS[2], concat)
+    m.mhca_stage2 = _mk_mhca_stage(DIMS[0], DIMS[1], LAYERS[0], concat, use_sa_list[0], sa_ker)
+    m.mhca_stage3 = _mk_mhca_stage(DIMS[1], DIMS[2], LAYERS[1], concat, use_sa_list[1], sa_ker)
+    m.mhca_stage4 = _mk_mhca_stage(DIMS[2], DIMS[3], LAYERS[2], concat, use_sa_list[2], sa_ker)
     m.patch_embed1 = nn.Module()
     m.patch_embed1.proj = nn.Conv2d(3, DIMS[0], 7, 4, 3)
     m.patch_embed1.norm = nn.LayerNorm(DIMS[0])
@@ -286,23 +296,29 @@ class MSTransception(nn.Module):
         #                | "se" (SE_Block over the concatenation, :571-594: squeeze / excitation gate, Conv1x1 + BN + ReLU)
         #                | "3d" (Conv3d_BN_concat, :406-462: Conv3d(kernel (4, 1, 1)) over the stacked branch maps + ReLU, BatchNorm)
         #                | "skn" (SK_Block, :1054-1107: per-channel softmax over the four branches from their pooled sum, Conv1x1 + ReLU + BN)
+        #                | "cbam" (CBAMBlock, :1128-1211: channel attention from max + mean pooling, spatial attention per use_sa_config / sa_ker,
+        #                  Conv1x1 + BN + ReLU over out + input)
         #   have_bridge  "original" (default) | "None" (the bridge is built -- its parameters stay in the state_dict -- but skipped, :2840)
         #   br_ch_att_list  which of the four bridge layers use channel attention instead of SR self-attention (:2413-2420)
         # use_sa_config / sa_ker / inter / num_sp only reach the "cbam", "sp" and "para" variants and are accepted and ignored, as in
         #                | "para" (BridgeBlock_para, :2500-2538: channel and spatial layer side by side, Linear(128->64)+LN+GELU, two
         #                  more spatial layers)
-        # the reference.  Not built: concat in {cbam, cam}, have_bridge = sp, Stage_3or4 != 3,
+        # the reference.  Not built: concat = cam / cam_fact, have_bridge = sp, Stage_3or4 != 3,
         # token_mlp_mode != "mix_skip", and the legacy networks/Transception.py class.
         br = [bool(b) for b in br_ch_att_list]
-        if (token_mlp_mode != "mix_skip" or concat not in ("coord", "normal", "se", "3d", "skn") or have_bridge == "sp" or Stage_3or4 != 3
+        if (token_mlp_mode != "mix_skip" or concat not in ("coord", "normal", "se", "3d", "skn", "cbam") or have_bridge == "sp" or Stage_3or4 != 3
                 or len(br) != 4):
-            raise NotImplementedError("MSTransception: implemented are concat in {'coord', 'normal', 'se', '3d', 'skn'}, have_bridge in {'original', "
+            raise NotImplementedError("MSTransception: implemented are concat in {'coord', 'normal', 'se', '3d', 'skn', 'cbam'}, have_bridge in {'original', "
                                       "'None', 'para'}, any 4-entry br_ch_att_list, Stage_3or4 = 3, token_mlp_mode = 'mix_skip'")
         if have_bridge == "para":                       # BridgeBlock_para ignores br_ch_att_list (it receives num_sp, MSTr.py:2806-2807):
             br = [True, False, False, False]            # layer 1 channel, layers 2-4 spatial (MSTr.py:2504-2512)
         self.concat, self.have_bridge, self.br_ch_att_list = concat, have_bridge, br
         self.num_classes = num_classes
-        self.backbone = _mk_backbone(concat)
+        # use_sa_config (MSTr.py:2766-2775): which of the three stages' CBAM blocks apply the spatial attention; sa_ker its kernel size (3 or 7 here)
+        use_sa_list = {1: (True, True, False), 2: (True, False, False), 3: (False, False, False), 4: (True, True, True)}.get(use_sa_config, (True, True, True))
+        if concat == "cbam" and sa_ker not in (3, 7):
+            raise NotImplementedError("MSTransception(concat='cbam'): sa_ker must be 3 or 7")
+        self.backbone = _mk_backbone(concat, use_sa_list, sa_ker)
         self.bridge = nn.Module()
         if have_bridge == "para":                       # constructor order of BridgeBlock_para: layers 1, 2, proj_act, layers 3, 4
             self.bridge.bridge_layer1 = _mk_bridge_layer(64, True)
@@ -759,6 +775,23 @@ def _mhca_stage(M, G, stack: Var, name: str, layers: int, B: int, side: int, out
         Wp = G.permuted_weight(M._P(G, agg + ".interact_concat.0.weight", (shape[0], C * 4)), shape[0], C, 4)
         z = G.relu(G.linear(cat, Wp, M._P(G, agg + ".interact_concat.0.bias")))
         return _bn(M, G, z, agg + ".bn", ACT_NONE, out=out)
+    if M.concat == "cbam":                                                       # CBAMBlock, MSTr.py:1198-1211
+        agg = name + ".aggregate"
+        holder = M.get_submodule(agg)
+        N = side * side
+        pooled = G.chan_pool2(cat, B, N)                                         # [2B, 4C]: max rows, then mean rows -- the shared MLP runs on both at once
+        hid = G.relu(G.linear(pooled, *_lin(M, G, agg + ".ca.se.0", bias=False)))
+        ca = G.linear(G.add(hid.rowslice(0, B), hid.rowslice(B, 2 * B)), *_lin(M, G, agg + ".ca.se.2", bias=False), act=ACT_SIGMOID)   # se(max) + se(avg): the last layer is linear
+        o = G.chan_gate(cat, ca, B, N)
+        if holder.use_sa:
+            k = holder.sa_ker
+            g = G.sa_conv(G.pix_stats(o), M._P(G, agg + ".sa.conv.weight"), M._P(G, agg + ".sa.conv.bias"), B, side, side, k)
+            o = G.pix_gate(o, g)
+        Wc, _ = _lin(M, G, agg + ".conv2d_bn_act.0", bias=False)
+        z = G.new(rows, Wc.data.shape[0])
+        G.linear(o, Wc, None, out=z)                                             # conv(out + residual) = conv(out) + conv(x)
+        G.linear(cat, Wc, None, out=z, accumulate=True)
+        return _bn(M, G, z, agg + ".conv2d_bn_act.1", ACT_RELU, out=out)
     if M.concat == "skn":                                                        # SK_Block, MSTr.py:1076-1107
         agg = name + ".aggregate"
         N = side * side
