@@ -427,6 +427,18 @@ int tc_pix_gate_fwd(const void* x, int ldx, const void* g, void* y, int ldy, int
 int tc_pix_gate_bwd(const void* dy, int lddy, const void* x, int ldx, const void* g, void* dx, int lddx, int dx_accumulate, void* dg, int rows, int C,
                     int dtype, void* stream);
 
+/* CAM_Module (the concat = "cam" aggregate, MSTr.py:464-509): x is [B*N, 4*C], the four branch maps side by side (column p*C + c).  Per image and
+ * channel the 4 x 4 path energy E = x^T x over the tokens, A = softmax(rowmax(E) - E) (att: fp32 [B][C][16]), y = gamma (A x) + x.
+ * tc_cam_bwd: dx (+)= the gradient through the residual, the attention-weighted sum and the energy; dgamma (fp32 [1]) ACCUMULATED; att2 is
+ * fp32 scratch [B][C][16]. */
+int tc_cam_att_fwd(const void* x, int ldx, float* att, int B, int N, int C, int dtype, void* stream);
+int tc_cam_apply_fwd(const void* x, int ldx, const float* att, const float* gamma, void* y, int ldy, int B, int N, int C, int dtype, void* stream);
+int tc_cam_bwd(const void* x, int ldx, const void* dy, int lddy, const float* att, const float* gamma, float* att2, float* dgamma, void* dx, int lddx,
+               int dx_accumulate, int B, int N, int C, int dtype, void* stream);
+/* y = GELU(x) (exact erf form, nn.GELU()) and dz = dy * GELU'(x), elementwise (Conv3d + GELU of the "cam" aggregate, MSTr.py:625-628) */
+int tc_gelu_fwd(const void* x, void* y, long long n, int dtype, void* stream);
+int tc_gelu_bwd(const void* dy, const void* x, void* dz, long long n, int dtype, void* stream);
+
 /* CoordAtt pooling MSTr.py:1327-1332.  pooled/att rows: first B*H rows (b,h) = mean over w, then B*W rows (b,w) = mean over h
  * (a row permutation of the reference's per-image cat; BatchNorm statistics over rows are unaffected). */
 int tc_coord_pool_fwd(const void* x, void* pooled, int B, int H, int W, int C, int dtype, void* stream);

@@ -256,6 +256,10 @@ VARIANTS = {   # name -> (constructor kwargs, gradient probes)
                      "decoder_0.last_layer.weight"]),
     "concat_cbam_sa4_k3": (dict(concat="cbam", use_sa_config=4, sa_ker=3),
                            ["backbone.mhca_stage4.aggregate.sa.conv.weight", "backbone.mhca_stage4.aggregate.ca.se.0.weight", "decoder_0.last_layer.weight"]),
+    "concat_cam": (dict(concat="cam"),
+                   ["backbone.mhca_stage2.aggregate.channelAttention.gamma", "backbone.mhca_stage3.aggregate.channelAttention.gamma",
+                    "backbone.mhca_stage2.aggregate.bn3d.weight", "backbone.mhca_stage4.aggregate.bn3d.bias", "backbone.mhca_stage3.aggregate.interact_concat.0.weight",
+                    "backbone.mhca_stage2.aggregate.bn.weight", "backbone.mhca_stage2.mhca_blks.1.MHCA_layers.2.mlp.fc1.weight", "decoder_0.last_layer.weight"]),
     "bridge_para": (dict(have_bridge="para"),
                     ["backbone.mhca_stage3.aggregate.conv1.weight", "bridge.bridge_layer1.attn.q.weight", "bridge.bridge_layer2.attn.kv.weight",
                      "bridge.proj_act.0.weight", "bridge.proj_act.0.bias", "bridge.proj_act.1.weight", "bridge.bridge_layer3.mixffn4.fc2.weight",

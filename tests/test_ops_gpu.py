@@ -331,6 +331,37 @@ def test_cbam_pieces(G, B, H, W, C, k):
     close(b_.grad, br.grad, 1e-4 * max(1.0, float(br.grad.abs().max())), 1e-4, "d conv bias")
 
 
+@pytest.mark.parametrize("B,N,C", [(2, 784, 64), (3, 49, 320), (1, 196, 128), (2, 37, 24)])
+def test_cam_module_and_gelu(G, B, N, C):
+    """CAM_Module (MSTr.py:478-509) on the four branch maps side by side, and the elementwise GELU behind its Conv3d: forward and gradients
+    (input, gamma) against torch."""
+    rows = B * N
+    x, gy = T(f"cam.x{B}.{N}.{C}", (rows, 4 * C), 0.5), T(f"cam.g{B}.{N}.{C}", (rows, 4 * C))
+    gamma = torch.tensor([0.45])
+    xr, gr = x.clone().requires_grad_(), gamma.clone().requires_grad_()
+    x5 = xr.view(B, N, 4, C).permute(0, 3, 2, 1)                         # [B, C, 4, N]
+    energy = x5 @ x5.transpose(-1, -2)
+    att = torch.softmax(energy.max(-1, keepdim=True)[0] - energy, -1)
+    y = (gr * (att @ x5) + x5).permute(0, 3, 2, 1).reshape(rows, 4 * C)
+    y.backward(gy)
+    xv, gp = mkV(G, x), mkP(gamma)
+    out = G.cam(xv, gp, B, N)
+    close(out.data, y, 2e-5, 2e-5, "y")
+    run_bwd(G, out, gy)
+    close(G.grad_of(xv), xr.grad, 2e-4 * max(1.0, float(xr.grad.abs().max())), 1e-4, "dx")
+    close(gp.grad, gr.grad, 1e-4 * max(1.0, float(gr.grad.abs().max())), 1e-4, "dgamma")
+    from transception_amd.engine import Graph
+    G2 = Graph(torch.float32, torch.device(DEV), training=True, record=True)
+    xr2 = x.clone().requires_grad_()
+    z = F.gelu(xr2)
+    z.backward(gy)
+    xv2 = mkV(G2, x)
+    o2 = G2.gelu(xv2)
+    close(o2.data, z, 2e-6, 2e-6, "gelu")
+    run_bwd(G2, o2, gy)
+    close(G2.grad_of(xv2), xr2.grad, 5e-6, 5e-6, "gelu gradient")
+
+
 def test_batchnorm_eval():
     from transception_amd.engine import Graph
     Ge = Graph(torch.float32, torch.device(DEV), training=False, record=False)

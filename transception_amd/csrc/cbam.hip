@@ -217,9 +217,214 @@ __global__ __launch_bounds__(256) void pix_gate_bwd_kernel(const T* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- CAM_Module
+// (the concat = "cam" aggregate, MSTr.py:464-509).  x is [B * N, 4 * C]: the four branch maps side by side, column p * C + c.  Per image
+// and channel: E[p][q] = sum_n x[n,p] x[n,q], A = softmax_q(max_q E[p,:] - E[p,q]), y[n,p] = gamma * sum_q A[p][q] x[n,q] + x[n,p].
+// att holds A as [B][C][16] fp32.  Backward (softmax is shift invariant, so the row maximum carries no gradient):
+//   dA[p][q] = gamma sum_n dy[n,p] x[n,q];  dEn = A (.) (dA - rowsum(A (.) dA));  dE = -dEn;  G = dE + dE^T;
+//   dx[n,p] = dy[n,p] + gamma sum_q A[q][p] dy[n,q] + sum_q G[p][q] x[n,q];   dgamma = sum dy (.) (A x).
+template <typename T>
+__global__ __launch_bounds__(256) void cam_att_fwd_kernel(const T* __restrict__ x, int ldx, float* __restrict__ att, int N, int C) {
+    __shared__ float red[16][64][10];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4, c = blockIdx.y * 64 + tx * 4, b = blockIdx.x;
+    float e[4][10];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < 10; ++i) e[k][i] = 0.f;
+    if (c < C)
+        for (int r = ty; r < N; r += 16) {
+            const T* row = x + ((long long)b * N + r) * ldx + c;
+            float v[4][4];                                              // [path][channel of the quad]
+#pragma unroll
+            for (int p = 0; p < 4; ++p) { const float4 t = ld4<T>(row + p * C); v[p][0] = t.x; v[p][1] = t.y; v[p][2] = t.z; v[p][3] = t.w; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int i = 0;
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int q = p; q < 4; ++q) e[k][i++] += v[p][k] * v[q][k];
+            }
+        }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < 10; ++i) red[ty][tx * 4 + k][i] = e[k][i];
+    __syncthreads();
+    if (threadIdx.x < 64 && blockIdx.y * 64 + threadIdx.x < C) {
+        const int cc = threadIdx.x;
+        float E[4][4];
+        int i = 0;
+        for (int p = 0; p < 4; ++p)
+            for (int q = p; q < 4; ++q, ++i) {
+                float t = 0.f;
+                for (int w = 0; w < 16; ++w) t += red[w][cc][i];
+                E[p][q] = E[q][p] = t;
+            }
+        float* a = att + ((long long)b * C + blockIdx.y * 64 + cc) * 16;
+        for (int p = 0; p < 4; ++p) {
+            const float m = fmaxf(fmaxf(E[p][0], E[p][1]), fmaxf(E[p][2], E[p][3]));
+            float en[4], mx = -INFINITY, sum = 0.f;
+            for (int q = 0; q < 4; ++q) { en[q] = m - E[p][q]; mx = fmaxf(mx, en[q]); }
+            for (int q = 0; q < 4; ++q) { en[q] = __expf(en[q] - mx); sum += en[q]; }
+            for (int q = 0; q < 4; ++q) a[p * 4 + q] = en[q] / sum;
+        }
+    }
+}
+
+// MODE 0: y = gamma (A x) + x.   MODE 1 (backward): dx (+)= dy + gamma A^T dy + G x   (G in `att2`)
+template <typename T, int MODE>
+__global__ void cam_apply_kernel(const T* x, int ldx, const T* dy, int lddy, const float* att, const float* att2, const float* gamma, T* y, int ldy, int acc,
+                                 int B, int N, int C) {
+    const int cq = C >> 2;
+    const float gm = *gamma;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)B * N * cq; i += gridDim.x * blockDim.x) {
+        const int q4 = (int)(i % cq) * 4; const unsigned row = i / cq; const int b = (int)(row / (unsigned)N);
+        float v[4][4], d[4][4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const float4 t = ld4<T>(x + (long long)row * ldx + p * C + q4); v[p][0] = t.x; v[p][1] = t.y; v[p][2] = t.z; v[p][3] = t.w;
+            if (MODE == 1) { const float4 u = ld4<T>(dy + (long long)row * lddy + p * C + q4); d[p][0] = u.x; d[p][1] = u.y; d[p][2] = u.z; d[p][3] = u.w; }
+        }
+        float o[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float* a = att + ((long long)b * C + q4 + k) * 16;
+            if (MODE == 0) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) o[p][k] = gm * (a[p * 4] * v[0][k] + a[p * 4 + 1] * v[1][k] + a[p * 4 + 2] * v[2][k] + a[p * 4 + 3] * v[3][k]) + v[p][k];
+            } else {
+                const float* g = att2 + ((long long)b * C + q4 + k) * 16;
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    o[p][k] = d[p][k] + gm * (a[p] * d[0][k] + a[4 + p] * d[1][k] + a[8 + p] * d[2][k] + a[12 + p] * d[3][k]) +
+                              g[p * 4] * v[0][k] + g[p * 4 + 1] * v[1][k] + g[p * 4 + 2] * v[2][k] + g[p * 4 + 3] * v[3][k];
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            T* dst = y + (long long)row * ldy + p * C + q4;
+            float4 w = make_float4(o[p][0], o[p][1], o[p][2], o[p][3]);
+            if (acc) { const float4 u = ld4<T>(dst); w.x += u.x; w.y += u.y; w.z += u.z; w.w += u.w; }
+            st4<T>(dst, w);
+        }
+    }
+}
+
+// per (image, channel): dA = gamma sum_n dy x^T (16 sums) -> G = dE + dE^T into att2;  dgamma += sum dy (.) (A x)
+template <typename T>
+__global__ __launch_bounds__(256) void cam_bwd_reduce_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy, const float* __restrict__ att,
+                                                             const float* __restrict__ gamma, float* __restrict__ att2, float* __restrict__ dgamma, int N, int C) {
+    __shared__ float red[16][64][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4, c = blockIdx.y * 64 + tx * 4, b = blockIdx.x;
+    float s[4][17];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < 17; ++i) s[k][i] = 0.f;
+    if (c < C) {
+        float a[4][16];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) a[k][i] = att[((long long)b * C + c + k) * 16 + i];
+        for (int r = ty; r < N; r += 16) {
+            const long long off = ((long long)b * N + r);
+            float v[4][4], d[4][4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const float4 t = ld4<T>(x + off * ldx + p * C + c); v[p][0] = t.x; v[p][1] = t.y; v[p][2] = t.z; v[p][3] = t.w;
+                const float4 u = ld4<T>(dy + off * lddy + p * C + c); d[p][0] = u.x; d[p][1] = u.y; d[p][2] = u.z; d[p][3] = u.w;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    float ax = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { s[k][p * 4 + q] += d[p][k] * v[q][k]; ax += a[k][p * 4 + q] * v[q][k]; }
+                    s[k][16] += d[p][k] * ax;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < 17; ++i) red[ty][tx * 4 + k][i] = s[k][i];
+    __syncthreads();
+    float dgl = 0.f;
+    if (threadIdx.x < 64 && blockIdx.y * 64 + threadIdx.x < C) {
+        const int cc = threadIdx.x;
+        const float gm = *gamma;
+        float dA[16], dg = 0.f;
+        for (int i = 0; i < 16; ++i) { float t = 0.f; for (int w = 0; w < 16; ++w) t += red[w][cc][i]; dA[i] = gm * t; }
+        for (int w = 0; w < 16; ++w) dg += red[w][cc][16];
+        dgl = dg;
+        const float* a = att + ((long long)b * C + blockIdx.y * 64 + cc) * 16;
+        float dE[16];
+        for (int p = 0; p < 4; ++p) {
+            float rs = 0.f;
+            for (int q = 0; q < 4; ++q) rs += a[p * 4 + q] * dA[p * 4 + q];
+            for (int q = 0; q < 4; ++q) dE[p * 4 + q] = -a[p * 4 + q] * (dA[p * 4 + q] - rs);
+        }
+        float* g = att2 + ((long long)b * C + blockIdx.y * 64 + cc) * 16;
+        for (int p = 0; p < 4; ++p)
+            for (int q = 0; q < 4; ++q) g[p * 4 + q] = dE[p * 4 + q] + dE[q * 4 + p];
+    }
+    if (threadIdx.x < 64) {
+        dgl = wave_sum(dgl);
+        if (threadIdx.x == 0) atomicAdd(dgamma, dgl);
+    }
+}
+
+template <typename T>
+__global__ void gelu_fwd_kernel(const T* x, T* y, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) stf<T>(y + i, gelu_f(ldf<T>(x + i)));
+}
+template <typename T>
+__global__ void gelu_bwd_kernel(const T* dy, const T* x, T* dz, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) stf<T>(dz + i, ldf<T>(dy + i) * gelu_grad_f(ldf<T>(x + i)));
+}
+
 inline dim3 gq(long long n) { return dim3(tc_blocks(n, 256, 8192)); }
 
 }  // namespace
+
+extern "C" int tc_cam_att_fwd(const void* x, int ldx, float* att, int B, int N, int C, int dtype, void* stream) {
+    if (!x || !att || B <= 0 || N <= 0 || C <= 0 || ((C | ldx) & 3)) return TC_ERR_ARG;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((cam_att_fwd_kernel<T>), dim3(B, (C + 63) / 64), dim3(256), 0, TC_S, (const T*)x, ldx, att, N, C));
+    return tc_launch_status();
+}
+extern "C" int tc_cam_apply_fwd(const void* x, int ldx, const float* att, const float* gamma, void* y, int ldy, int B, int N, int C, int dtype, void* stream) {
+    if (!x || !att || !gamma || !y || B <= 0 || N <= 0 || C <= 0 || ((C | ldx | ldy) & 3) || (long long)B * N * (C / 4) >= 0x7fffffffLL) return TC_ERR_ARG;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((cam_apply_kernel<T, 0>), gq((long long)B * N * C / 4), dim3(256), 0, TC_S, (const T*)x, ldx, (const T*)nullptr, 0, att,
+                                                (const float*)nullptr, gamma, (T*)y, ldy, 0, B, N, C));
+    return tc_launch_status();
+}
+extern "C" int tc_cam_bwd(const void* x, int ldx, const void* dy, int lddy, const float* att, const float* gamma, float* att2, float* dgamma, void* dx, int lddx,
+                          int dx_accumulate, int B, int N, int C, int dtype, void* stream) {
+    if (!x || !dy || !att || !gamma || !att2 || !dgamma || !dx || B <= 0 || N <= 0 || C <= 0 || ((C | ldx | lddy | lddx) & 3) ||
+        (long long)B * N * (C / 4) >= 0x7fffffffLL)
+        return TC_ERR_ARG;
+    TC_DISPATCH_DTYPE(dtype, {
+        hipLaunchKernelGGL((cam_bwd_reduce_kernel<T>), dim3(B, (C + 63) / 64), dim3(256), 0, TC_S, (const T*)x, ldx, (const T*)dy, lddy, att, gamma, att2, dgamma, N, C);
+        hipLaunchKernelGGL((cam_apply_kernel<T, 1>), gq((long long)B * N * C / 4), dim3(256), 0, TC_S, (const T*)x, ldx, (const T*)dy, lddy, att, att2, gamma, (T*)dx, lddx,
+                           dx_accumulate, B, N, C);
+    });
+    return tc_launch_status();
+}
+extern "C" int tc_gelu_fwd(const void* x, void* y, long long n, int dtype, void* stream) {
+    if (!x || !y || n <= 0) return TC_ERR_ARG;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gelu_fwd_kernel<T>), gq(n), dim3(256), 0, TC_S, (const T*)x, (T*)y, n));
+    return tc_launch_status();
+}
+extern "C" int tc_gelu_bwd(const void* dy, const void* x, void* dz, long long n, int dtype, void* stream) {
+    if (!dy || !x || !dz || n <= 0) return TC_ERR_ARG;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gelu_bwd_kernel<T>), gq(n), dim3(256), 0, TC_S, (const T*)dy, (const T*)x, (T*)dz, n));
+    return tc_launch_status();
+}
 
 extern "C" int tc_chan_pool2_fwd(const void* x, int ldx, void* pooled, int* idx, int B, int N, int C, int dtype, void* stream) {
     if (!x || !pooled || !idx || B <= 0 || N <= 0 || C <= 0 || ((C | ldx) & 3) || (long long)B * N * (C / 4) >= 0x7fffffffLL) return TC_ERR_ARG;

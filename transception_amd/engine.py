@@ -1509,6 +1509,41 @@ class Graph:
         self._rec(bwd)
         return out
 
+    def cam(self, x: Var, gamma: P, B: int, N: int) -> Var:
+        """CAM_Module (MSTr.py:478-509) over the four branch maps side by side in x [B*N, 4C]: gamma * (path attention applied) + x."""
+        Cc = x.cols // 4
+        out = self.new(x.rows, x.cols)
+        att = self.f32(B * Cc * 16)
+        g32 = gamma.data.float() if gamma.data.dtype != torch.float32 else gamma.data       # the kernels read gamma as one fp32 scalar
+        self.L.tc_cam_att_fwd(_ptr(x.data), x.ld, _ptr(att), B, N, Cc, self.dt, self.stream)
+        self.L.tc_cam_apply_fwd(_ptr(x.data), x.ld, _ptr(att), _ptr(g32), _ptr(out.data), out.ld, B, N, Cc, self.dt, self.stream)
+
+        def bwd():
+            d = self.grad_of(out)
+            if d is None:
+                return
+            gx, acc = self.wgrad(x)
+            att2 = self.f32(B * Cc * 16)
+            dg = gamma.grad if gamma.grad is not None else self.f32(1)
+            self.L.tc_cam_bwd(_ptr(x.data), x.ld, _ptr(d), d.stride(0), _ptr(att), _ptr(g32), _ptr(att2), _ptr(dg), _ptr(gx), gx.stride(0), acc, B, N, Cc,
+                              self.dt, self.stream)
+        self._rec(bwd)
+        return out
+
+    def gelu(self, x: Var) -> Var:
+        assert x.data.is_contiguous()
+        out = self.new(x.rows, x.cols)
+        self.L.tc_gelu_fwd(_ptr(x.data), _ptr(out.data), x.data.numel(), self.dt, self.stream)
+
+        def bwd():
+            d = self.grad_of(out)
+            if d is None:
+                return
+            assert d.is_contiguous()
+            self._write_or_add(x, lambda g: self.L.tc_gelu_bwd(_ptr(d), _ptr(x.data), _ptr(g), d.numel(), self.dt, self.stream))
+        self._rec(bwd)
+        return out
+
     def relu(self, x: Var) -> Var:
         assert x.data.is_contiguous()
         out = self.new(x.rows, x.cols)

@@ -148,6 +148,14 @@ def _mk_mhca_stage(dim: int, out_dim: int, layers: int, concat: str = "coord", u
         a.bn = nn.BatchNorm2d(out_dim)
         a.interact_concat = nn.Sequential(nn.Conv3d(dim, out_dim, kernel_size=(4, 1, 1)), nn.ReLU())
         m.aggregate = a
+    elif concat == "cam":                                       # Conv3d_BN_channel_attention_concat(cam="cam"), MSTr.py:596-668 (constructor order kept)
+        a = nn.Module()
+        a.bn = nn.BatchNorm2d(out_dim)
+        a.interact_concat = nn.Sequential(nn.Conv3d(dim, out_dim, kernel_size=(4, 1, 1)), nn.GELU())
+        a.channelAttention = nn.Module()
+        a.channelAttention.gamma = nn.Parameter(torch.zeros(1))
+        a.bn3d = nn.BatchNorm3d(dim)
+        m.aggregate = a
     elif concat == "cbam":                                      # CBAMBlock(channel = 4C, reduction = 16, kernel_size = sa_ker), MSTr.py:1169-1211, 1400-1401
         a = nn.Module()
         a.ca = nn.Module()
@@ -303,12 +311,12 @@ class MSTransception(nn.Module):
         # use_sa_config / sa_ker / inter / num_sp only reach the "cbam", "sp" and "para" variants and are accepted and ignored, as in
         #                | "para" (BridgeBlock_para, :2500-2538: channel and spatial layer side by side, Linear(128->64)+LN+GELU, two
         #                  more spatial layers)
-        # the reference.  Not built: concat = cam / cam_fact, have_bridge = sp, Stage_3or4 != 3,
+        # the reference.  Not built: concat = cam_fact, have_bridge = sp, Stage_3or4 != 3,
         # token_mlp_mode != "mix_skip", and the legacy networks/Transception.py class.
         br = [bool(b) for b in br_ch_att_list]
-        if (token_mlp_mode != "mix_skip" or concat not in ("coord", "normal", "se", "3d", "skn", "cbam") or have_bridge == "sp" or Stage_3or4 != 3
+        if (token_mlp_mode != "mix_skip" or concat not in ("coord", "normal", "se", "3d", "skn", "cbam", "cam") or have_bridge == "sp" or Stage_3or4 != 3
                 or len(br) != 4):
-            raise NotImplementedError("MSTransception: implemented are concat in {'coord', 'normal', 'se', '3d', 'skn', 'cbam'}, have_bridge in {'original', "
+            raise NotImplementedError("MSTransception: implemented are concat in {'coord', 'normal', 'se', '3d', 'skn', 'cbam', 'cam'}, have_bridge in {'original', "
                                       "'None', 'para'}, any 4-entry br_ch_att_list, Stage_3or4 = 3, token_mlp_mode = 'mix_skip'")
         if have_bridge == "para":                       # BridgeBlock_para ignores br_ch_att_list (it receives num_sp, MSTr.py:2806-2807):
             br = [True, False, False, False]            # layer 1 channel, layers 2-4 spatial (MSTr.py:2504-2512)
@@ -774,6 +782,19 @@ def _mhca_stage(M, G, stack: Var, name: str, layers: int, B: int, side: int, out
         off, shape = M._index[agg + ".interact_concat.0.weight"]                 # [O, C, 4, 1, 1]
         Wp = G.permuted_weight(M._P(G, agg + ".interact_concat.0.weight", (shape[0], C * 4)), shape[0], C, 4)
         z = G.relu(G.linear(cat, Wp, M._P(G, agg + ".interact_concat.0.bias")))
+        return _bn(M, G, z, agg + ".bn", ACT_NONE, out=out)
+    if M.concat == "cam":                                                        # Conv3d_BN_channel_attention_concat, MSTr.py:642-668
+        agg = name + ".aggregate"
+        N = side * side
+        # BatchNorm3d over (image, path, token) per channel = BatchNorm over the rows of the [4 * rows, C] view of the concatenation (a row of the
+        # concatenation is path-major).  The reference also runs bn3d on the partial stacks of 1, 2, 3 paths and discards the results (:651-655):
+        # only its running statistics see those passes; they are not reproduced.
+        x3 = _bn(M, G, cat.reshape(4 * rows, C), agg + ".bn3d", ACT_NONE).reshape(rows, 4 * C)
+        x3 = G.cam(x3, M._P(G, agg + ".channelAttention.gamma"), B, N)
+        x3 = _bn(M, G, x3.reshape(4 * rows, C), agg + ".bn3d", ACT_NONE).reshape(rows, 4 * C)
+        off, shape = M._index[agg + ".interact_concat.0.weight"]                 # [O, C, 4, 1, 1]
+        Wp = G.permuted_weight(M._P(G, agg + ".interact_concat.0.weight", (shape[0], C * 4)), shape[0], C, 4)
+        z = G.gelu(G.linear(x3, Wp, M._P(G, agg + ".interact_concat.0.bias")))
         return _bn(M, G, z, agg + ".bn", ACT_NONE, out=out)
     if M.concat == "cbam":                                                       # CBAMBlock, MSTr.py:1198-1211
         agg = name + ".aggregate"

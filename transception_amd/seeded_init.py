@@ -56,6 +56,8 @@ def seeded_array(name: str, shape: Tuple[int, ...], salt: int = 0) -> np.ndarray
         fan_in = int(np.prod(shape[1:]))
         bound = 1.0 / np.sqrt(max(fan_in, 1))
         return g.uniform(-bound, bound, size=shape).astype(np.float32)
+    if leaf == "gamma":                               # CAM_Module's residual scale (a zero-initialised scalar in the reference: a nonzero value exercises the path)
+        return g.uniform(0.3, 0.7, size=shape).astype(np.float32)
     raise ValueError(f"seeded_init: do not know how to fill '{name}'")
 
 
