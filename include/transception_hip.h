@@ -435,6 +435,11 @@ int tc_cam_att_fwd(const void* x, int ldx, float* att, int B, int N, int C, int 
 int tc_cam_apply_fwd(const void* x, int ldx, const float* att, const float* gamma, void* y, int ldy, int B, int N, int C, int dtype, void* stream);
 int tc_cam_bwd(const void* x, int ldx, const void* dy, int lddy, const float* att, const float* gamma, float* att2, float* dgamma, void* dx, int lddx,
                int dx_accumulate, int B, int N, int C, int dtype, void* stream);
+/* y = gamma * a + x with gamma an fp32 device scalar (the residual scale of CAM_Module / CAM_Factorized_Module, MSTr.py:508, 566);
+ * backward: da = gamma dy, dx (+)= dy, dgamma (fp32 [1]) += sum dy (.) a */
+int tc_gamma_res_fwd(const void* a, int lda, const void* x, int ldx, const float* gamma, void* y, int ldy, int rows, int C, int dtype, void* stream);
+int tc_gamma_res_bwd(const void* dy, int lddy, const void* a, int lda, const float* gamma, void* da, int ldda, void* dx, int lddx, int dx_accumulate,
+                     float* dgamma, int rows, int C, int dtype, void* stream);
 /* y = GELU(x) (exact erf form, nn.GELU()) and dz = dy * GELU'(x), elementwise (Conv3d + GELU of the "cam" aggregate, MSTr.py:625-628) */
 int tc_gelu_fwd(const void* x, void* y, long long n, int dtype, void* stream);
 int tc_gelu_bwd(const void* dy, const void* x, void* dz, long long n, int dtype, void* stream);

@@ -49,7 +49,7 @@ class TransCeptionOracle:
         self.training = training
         # ablation switches of the reference constructor (MSTr.py:2760-2823) that this restatement follows: the aggregate of a
         # stage (:1384-1403), whether the bridge runs (:2840) and which bridge layers use channel attention (:2413-2420)
-        assert concat in ("coord", "normal", "se", "3d", "skn", "cbam", "cam") and have_bridge != "sp" and len(br_ch_att_list) == 4
+        assert concat in ("coord", "normal", "se", "3d", "skn", "cbam", "cam", "cam_fact") and have_bridge != "sp" and len(br_ch_att_list) == 4
         self.concat, self.have_bridge, self.br_ch_att_list = concat, have_bridge, tuple(bool(b) for b in br_ch_att_list)
         # which stages' CBAM blocks apply the spatial attention (MSTr.py:2766-2775)
         self.use_sa_list = {1: (True, True, False), 2: (True, False, False), 3: (False, False, False), 4: (True, True, True)}.get(use_sa_config, (True, True, True))
@@ -214,7 +214,7 @@ class TransCeptionOracle:
             z = sum(torch.einsum("bhwc,oc->bhwo", outs[p], w[:, :, p]) for p in range(4)) + self.P[agg + ".interact_concat.0.bias"]
             B, H, W, O = z.shape
             return self.batchnorm_rows(torch.relu(z).reshape(B, H * W, O), agg + ".bn").reshape(B, H, W, O)
-        if self.concat == "cam":
+        if self.concat in ("cam", "cam_fact"):
             # Conv3d_BN_channel_attention_concat with CAM_Module, MSTr.py:642-668, 478-509: BatchNorm3d of the stacked maps, the 4 x 4 path attention
             # per image and channel, BatchNorm3d again, Conv3d(kernel (4, 1, 1)) + GELU, BatchNorm2d.  (bn3d's passes over the partial stacks, whose
             # results the reference discards, only touch its running statistics and are not restated.)
@@ -222,9 +222,19 @@ class TransCeptionOracle:
             B, H, W, C = outs[0].shape
             x = torch.stack(outs, dim=3).reshape(B, H * W * 4, C)                 # rows (token, path)
             x = self.batchnorm_rows(x, agg + ".bn3d").reshape(B, H * W, 4, C)
-            e = torch.einsum("bnpc,bnqc->bcpq", x, x)
-            att = torch.softmax(e.max(dim=-1, keepdim=True)[0] - e, dim=-1)
-            x = self.P[agg + ".channelAttention.gamma"] * torch.einsum("bcpq,bnqc->bnpc", att, x) + x
+            if self.concat == "cam":
+                e = torch.einsum("bnpc,bnqc->bcpq", x, x)
+                att = torch.softmax(e.max(dim=-1, keepdim=True)[0] - e, dim=-1)
+                x = self.P[agg + ".channelAttention.gamma"] * torch.einsum("bcpq,bnqc->bnpc", att, x) + x
+            else:
+                # CAM_Factorized_Module, MSTr.py:528-568: all 4 N tokens of an image through one factorized attention (no position term)
+                ca, h = agg + ".channelAttention", self.HEADS
+                t = x.reshape(B, H * W * 4, C)
+                qkv = self.linear(t, ca + ".qkv")
+                q, k, v = (qkv[..., i * C:(i + 1) * C].reshape(B, -1, h, C // h) for i in range(3))
+                ctx = torch.einsum("bnhi,bnhj->bhij", torch.softmax(k, dim=1), v)
+                fa = (C // h) ** -0.5 * torch.einsum("bnhi,bhij->bnhj", q, ctx).reshape(B, -1, C)
+                x = (self.P[ca + ".gamma"] * self.linear(fa, ca + ".proj") + t).reshape(B, H * W, 4, C)
             x = self.batchnorm_rows(x.reshape(B, H * W * 4, C), agg + ".bn3d").reshape(B, H * W, 4, C)
             w = self.P[agg + ".interact_concat.0.weight"][:, :, :, 0, 0]          # [O, C, 4]
             z = torch.einsum("bnpc,ocp->bno", x, w) + self.P[agg + ".interact_concat.0.bias"]

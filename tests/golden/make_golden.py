@@ -260,6 +260,10 @@ VARIANTS = {   # name -> (constructor kwargs, gradient probes)
                    ["backbone.mhca_stage2.aggregate.channelAttention.gamma", "backbone.mhca_stage3.aggregate.channelAttention.gamma",
                     "backbone.mhca_stage2.aggregate.bn3d.weight", "backbone.mhca_stage4.aggregate.bn3d.bias", "backbone.mhca_stage3.aggregate.interact_concat.0.weight",
                     "backbone.mhca_stage2.aggregate.bn.weight", "backbone.mhca_stage2.mhca_blks.1.MHCA_layers.2.mlp.fc1.weight", "decoder_0.last_layer.weight"]),
+    "concat_cam_fact": (dict(concat="cam_fact"),
+                        ["backbone.mhca_stage2.aggregate.channelAttention.gamma", "backbone.mhca_stage3.aggregate.channelAttention.qkv.weight",
+                         "backbone.mhca_stage4.aggregate.channelAttention.qkv.bias", "backbone.mhca_stage2.aggregate.channelAttention.proj.weight",
+                         "backbone.mhca_stage3.aggregate.bn3d.weight", "backbone.mhca_stage4.aggregate.interact_concat.0.weight", "decoder_0.last_layer.weight"]),
     "bridge_para": (dict(have_bridge="para"),
                     ["backbone.mhca_stage3.aggregate.conv1.weight", "bridge.bridge_layer1.attn.q.weight", "bridge.bridge_layer2.attn.kv.weight",
                      "bridge.proj_act.0.weight", "bridge.proj_act.0.bias", "bridge.proj_act.1.weight", "bridge.bridge_layer3.mixffn4.fc2.weight",
@@ -267,37 +271,63 @@ VARIANTS = {   # name -> (constructor kwargs, gradient probes)
 }
 
 
+class dense_batchnorm3d_input:
+    """Works around a host-framework defect while the cam_fact vectors are made, without touching the reference's arithmetic.
+
+    CAM_Factorized_Module (MSTr.py:559-567) hands BatchNorm3d a tensor whose strides are channels-last-3d.  torch 2.10's CPU batch-norm backward
+    returns a wrong input gradient for that layout when the incoming gradient is dense (it differs from the same call on a dense copy of the input by
+    more than the gradient's own norm; forward is unaffected; scripts/exp/bn3d_cl_backward.py reproduces it in ten lines).  The vectors must pin the
+    reference's algorithm, not this build's CPU kernel, so BatchNorm3d sees a dense copy of its input while this variant runs."""
+
+    def __enter__(self):
+        self.orig = orig = torch.nn.BatchNorm3d.forward
+        torch.nn.BatchNorm3d.forward = lambda m, x: orig(m, x.contiguous())
+
+    def __exit__(self, *a):
+        torch.nn.BatchNorm3d.forward = self.orig
+
+
+class _nothing:
+    def __enter__(self): pass
+    def __exit__(self, *a): pass
+
+
 def variants(MST, Dice):
     out = {}
+    for name, (kw, probes) in VARIANTS.items():
+        with (dense_batchnorm3d_input() if kw.get("concat") == "cam_fact" else _nothing()):
+            _variant(out, name, kw, probes, MST, Dice)
+    np.savez_compressed(os.path.join(HERE, "variants.npz"), **out)
+
+
+def _variant(out, name, kw, probes, MST, Dice):
     x = torch.from_numpy(seeded_input(1))
     y_lab = torch.from_numpy(seeded_labels(1))
-    for name, (kw, probes) in VARIANTS.items():
-        ref = MST(num_classes=9, **kw)
-        entries = schema_entries(ref)
-        out[name + "/schema_sha256"] = np.frombuffer(schema_digest(entries).encode(), dtype=np.uint8)
-        out[name + "/n_keys"] = np.array([len(entries), len({c for _, _, c in entries})], dtype=np.int64)
-        sd = seeded_state_dict(entries)
-        ref.load_state_dict(sd, strict=True)
-        ref.train()
-        logits = ref(x)
-        pack(out, name + "/logits", logits)
-        ce = torch.nn.functional.cross_entropy(logits, y_lab)
-        dice = Dice(9)(logits, y_lab, softmax=True)
-        loss = 0.4 * ce + 0.6 * dice
-        loss.backward()
-        out[name + "/loss"] = np.array([loss.item(), ce.item(), dice.item()], dtype=np.float64)
-        named = dict(ref.named_parameters())
-        live = sorted(n for n, p in named.items() if p.grad is not None)
-        out[name + "/n_live"] = np.array([len(live)], dtype=np.int64)
-        for n in probes:
-            pack(out, name + "/grad/" + n, named[n].grad)
-        ref2 = MST(num_classes=9, **kw)
-        ref2.load_state_dict(sd, strict=True)
-        ref2.eval()
-        with torch.no_grad():
-            pack(out, name + "/logits_eval", ref2(x))
-        print(name, "keys", len(entries), "live grads", len(live), "loss", loss.item())
-    np.savez_compressed(os.path.join(HERE, "variants.npz"), **out)
+    ref = MST(num_classes=9, **kw)
+    entries = schema_entries(ref)
+    out[name + "/schema_sha256"] = np.frombuffer(schema_digest(entries).encode(), dtype=np.uint8)
+    out[name + "/n_keys"] = np.array([len(entries), len({c for _, _, c in entries})], dtype=np.int64)
+    sd = seeded_state_dict(entries)
+    ref.load_state_dict(sd, strict=True)
+    ref.train()
+    logits = ref(x)
+    pack(out, name + "/logits", logits)
+    ce = torch.nn.functional.cross_entropy(logits, y_lab)
+    dice = Dice(9)(logits, y_lab, softmax=True)
+    loss = 0.4 * ce + 0.6 * dice
+    loss.backward()
+    out[name + "/loss"] = np.array([loss.item(), ce.item(), dice.item()], dtype=np.float64)
+    named = dict(ref.named_parameters())
+    live = sorted(n for n, p in named.items() if p.grad is not None)
+    out[name + "/n_live"] = np.array([len(live)], dtype=np.int64)
+    for n in probes:
+        pack(out, name + "/grad/" + n, named[n].grad)
+    ref2 = MST(num_classes=9, **kw)
+    ref2.load_state_dict(sd, strict=True)
+    ref2.eval()
+    with torch.no_grad():
+        pack(out, name + "/logits_eval", ref2(x))
+    print(name, "keys", len(entries), "live grads", len(live), "loss", loss.item())
 
 
 if __name__ == "__main__":

@@ -309,6 +309,7 @@ VARIANTS = {   # constructor switches of SURVEY.md 8(f)-4 that the build impleme
     "concat_3d": dict(concat="3d"),
     "concat_skn": dict(concat="skn"),
     "concat_cam": dict(concat="cam"),
+    "concat_cam_fact": dict(concat="cam_fact"),
     "concat_cbam": dict(concat="cbam"),
     "concat_cbam_sa4_k3": dict(concat="cbam", use_sa_config=4, sa_ker=3),
     "no_bridge": dict(have_bridge="None"),

@@ -362,6 +362,23 @@ def test_cam_module_and_gelu(G, B, N, C):
     close(G2.grad_of(xv2), xr2.grad, 5e-6, 5e-6, "gelu gradient")
 
 
+@pytest.mark.parametrize("rows,C", [(196, 320), (4 * 784, 128), (37, 64)])
+def test_gamma_residual(G, rows, C):
+    """gamma * a + x with a one-element gamma (the tail of CAM_Factorized_Module, MSTr.py:565-567): forward, both input gradients, dgamma."""
+    a, x, gy = T(f"gr.a{rows}", (rows, C)), T(f"gr.x{rows}", (rows, C)), T(f"gr.g{rows}", (rows, C))
+    gamma = torch.tensor([0.55])
+    ar, xr, gr = a.clone().requires_grad_(), x.clone().requires_grad_(), gamma.clone().requires_grad_()
+    y = gr * ar + xr
+    y.backward(gy)
+    av, xv, gp = mkV(G, a), mkV(G, x), mkP(gamma)
+    out = G.gamma_residual(av, xv, gp)
+    close(out.data, y, 1e-6, 1e-6, "y")
+    run_bwd(G, out, gy)
+    close(G.grad_of(av), ar.grad, 1e-6, 1e-6, "da")
+    close(G.grad_of(xv), xr.grad, 1e-6, 1e-6, "dx")
+    close(gp.grad, gr.grad, 1e-4 * max(1.0, float(gr.grad.abs().max())), 1e-5, "dgamma")
+
+
 def test_batchnorm_eval():
     from transception_amd.engine import Graph
     Ge = Graph(torch.float32, torch.device(DEV), training=False, record=False)

@@ -160,6 +160,8 @@ SIGNATURES = {
     "tc_cam_att_fwd": [vp, i32, vp, i32, i32, i32, i32, vp],
     "tc_cam_apply_fwd": [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "tc_cam_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "tc_gamma_res_fwd": [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp],
+    "tc_gamma_res_bwd": [vp, i32, vp, i32, vp, vp, i32, vp, i32, i32, vp, i32, i32, i32, vp],
     "tc_gelu_fwd": [vp, vp, i64, i32, vp],
     "tc_gelu_bwd": [vp, vp, vp, i64, i32, vp],
     "tc_coord_pool_fwd": [vp, vp, i32, i32, i32, i32, i32, vp],

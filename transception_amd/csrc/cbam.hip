@@ -379,6 +379,40 @@ __global__ __launch_bounds__(256) void cam_bwd_reduce_kernel(const T* __restrict
     }
 }
 
+// y = gamma * a + x (the residual scale of the CAM modules, MSTr.py:508, 566);  backward: da = gamma dy, dx (+)= dy, dgamma += sum dy (.) a
+template <typename T>
+__global__ void gamma_res_fwd_kernel(const T* a, int lda, const T* x, int ldx, const float* gamma, T* y, int ldy, int rows, int C) {
+    const int cq = C >> 2;
+    const float gm = *gamma;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)rows * cq; i += gridDim.x * blockDim.x) {
+        const int q = (int)(i % cq) * 4; const unsigned r = i / cq;
+        const float4 u = ld4<T>(a + (long long)r * lda + q), v = ld4<T>(x + (long long)r * ldx + q);
+        st4<T>(y + (long long)r * ldy + q, make_float4(gm * u.x + v.x, gm * u.y + v.y, gm * u.z + v.z, gm * u.w + v.w));
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gamma_res_bwd_kernel(const T* dy, int lddy, const T* a, int lda, const float* gamma, T* da, int ldda, T* dx, int lddx,
+                                                            int acc, float* dgamma, int rows, int C) {
+    const int cq = C >> 2;
+    const float gm = *gamma;
+    float s = 0.f;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)rows * cq; i += gridDim.x * blockDim.x) {
+        const int q = (int)(i % cq) * 4; const unsigned r = i / cq;
+        const float4 d = ld4<T>(dy + (long long)r * lddy + q), u = ld4<T>(a + (long long)r * lda + q);
+        s += d.x * u.x + d.y * u.y + d.z * u.z + d.w * u.w;
+        st4<T>(da + (long long)r * ldda + q, make_float4(gm * d.x, gm * d.y, gm * d.z, gm * d.w));
+        T* p = dx + (long long)r * lddx + q;
+        float4 o = d;
+        if (acc) { const float4 w = ld4<T>(p); o.x += w.x; o.y += w.y; o.z += w.z; o.w += w.w; }
+        st4<T>(p, o);
+    }
+    __shared__ float red[4];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(dgamma, red[0] + red[1] + red[2] + red[3]);
+}
+
 template <typename T>
 __global__ void gelu_fwd_kernel(const T* x, T* y, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) stf<T>(y + i, gelu_f(ldf<T>(x + i)));
@@ -413,6 +447,20 @@ extern "C" int tc_cam_bwd(const void* x, int ldx, const void* dy, int lddy, cons
         hipLaunchKernelGGL((cam_apply_kernel<T, 1>), gq((long long)B * N * C / 4), dim3(256), 0, TC_S, (const T*)x, ldx, (const T*)dy, lddy, att, att2, gamma, (T*)dx, lddx,
                            dx_accumulate, B, N, C);
     });
+    return tc_launch_status();
+}
+extern "C" int tc_gamma_res_fwd(const void* a, int lda, const void* x, int ldx, const float* gamma, void* y, int ldy, int rows, int C, int dtype, void* stream) {
+    if (!a || !x || !gamma || !y || rows <= 0 || C <= 0 || ((C | lda | ldx | ldy) & 3) || (long long)rows * (C / 4) >= 0x7fffffffLL) return TC_ERR_ARG;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gamma_res_fwd_kernel<T>), gq((long long)rows * C / 4), dim3(256), 0, TC_S, (const T*)a, lda, (const T*)x, ldx, gamma,
+                                                (T*)y, ldy, rows, C));
+    return tc_launch_status();
+}
+extern "C" int tc_gamma_res_bwd(const void* dy, int lddy, const void* a, int lda, const float* gamma, void* da, int ldda, void* dx, int lddx, int dx_accumulate,
+                                float* dgamma, int rows, int C, int dtype, void* stream) {
+    if (!dy || !a || !gamma || !da || !dx || !dgamma || rows <= 0 || C <= 0 || ((C | lddy | lda | ldda | lddx) & 3) || (long long)rows * (C / 4) >= 0x7fffffffLL)
+        return TC_ERR_ARG;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gamma_res_bwd_kernel<T>), dim3(tc_blocks((long long)rows * C / 4, 256, 1024)), dim3(256), 0, TC_S, (const T*)dy, lddy,
+                                                (const T*)a, lda, gamma, (T*)da, ldda, (T*)dx, lddx, dx_accumulate, dgamma, rows, C));
     return tc_launch_status();
 }
 extern "C" int tc_gelu_fwd(const void* x, void* y, long long n, int dtype, void* stream) {

@@ -1530,6 +1530,26 @@ class Graph:
         self._rec(bwd)
         return out
 
+    def gamma_residual(self, a: Var, x: Var, gamma: P) -> Var:
+        """gamma * a + x, gamma a one-element parameter (MSTr.py:508, 566)."""
+        assert a.rows == x.rows and a.cols == x.cols
+        out = self.new(x.rows, x.cols)
+        g32 = gamma.data.float() if gamma.data.dtype != torch.float32 else gamma.data
+        self.L.tc_gamma_res_fwd(_ptr(a.data), a.ld, _ptr(x.data), x.ld, _ptr(g32), _ptr(out.data), out.ld, x.rows, x.cols, self.dt, self.stream)
+
+        def bwd():
+            d = self.grad_of(out)
+            if d is None:
+                return
+            ga, acca = self.wgrad(a)
+            assert not acca
+            gx, acc = self.wgrad(x)
+            dg = gamma.grad if gamma.grad is not None else self.f32(1)
+            self.L.tc_gamma_res_bwd(_ptr(d), d.stride(0), _ptr(a.data), a.ld, _ptr(g32), _ptr(ga), ga.stride(0), _ptr(gx), gx.stride(0), acc, _ptr(dg),
+                                    x.rows, x.cols, self.dt, self.stream)
+        self._rec(bwd)
+        return out
+
     def gelu(self, x: Var) -> Var:
         assert x.data.is_contiguous()
         out = self.new(x.rows, x.cols)

@@ -148,6 +148,20 @@ def _mk_mhca_stage(dim: int, out_dim: int, layers: int, concat: str = "coord", u
         a.bn = nn.BatchNorm2d(out_dim)
         a.interact_concat = nn.Sequential(nn.Conv3d(dim, out_dim, kernel_size=(4, 1, 1)), nn.ReLU())
         m.aggregate = a
+    elif concat == "cam_fact":                                  # Conv3d_BN_channel_attention_concat(cam="cam_fact") with CAM_Factorized_Module, MSTr.py:512-568
+        a = nn.Module()
+        a.bn = nn.BatchNorm2d(out_dim)
+        a.interact_concat = nn.Sequential(nn.Conv3d(dim, out_dim, kernel_size=(4, 1, 1)), nn.GELU())
+        ca = nn.Module()
+        ca.gamma = nn.Parameter(torch.zeros(1))
+        ca.qkv = nn.Linear(dim, dim * 3)
+        ca.proj = nn.Linear(dim, dim)
+        ch = dim // HEADS
+        ca.crpe = nn.Module()                                   # built, never used by its forward (:551-554): its parameters stay without gradient
+        ca.crpe.conv_list = nn.ModuleList([nn.Conv2d(nh * ch, nh * ch, k, padding=k // 2, groups=nh * ch) for k, nh in CRPE_WINDOW])
+        a.channelAttention = ca
+        a.bn3d = nn.BatchNorm3d(dim)
+        m.aggregate = a
     elif concat == "cam":                                       # Conv3d_BN_channel_attention_concat(cam="cam"), MSTr.py:596-668 (constructor order kept)
         a = nn.Module()
         a.bn = nn.BatchNorm2d(out_dim)
@@ -311,12 +325,12 @@ class MSTransception(nn.Module):
         # use_sa_config / sa_ker / inter / num_sp only reach the "cbam", "sp" and "para" variants and are accepted and ignored, as in
         #                | "para" (BridgeBlock_para, :2500-2538: channel and spatial layer side by side, Linear(128->64)+LN+GELU, two
         #                  more spatial layers)
-        # the reference.  Not built: concat = cam_fact, have_bridge = sp, Stage_3or4 != 3,
+        # the reference.  Not built: have_bridge = sp, Stage_3or4 != 3,
         # token_mlp_mode != "mix_skip", and the legacy networks/Transception.py class.
         br = [bool(b) for b in br_ch_att_list]
-        if (token_mlp_mode != "mix_skip" or concat not in ("coord", "normal", "se", "3d", "skn", "cbam", "cam") or have_bridge == "sp" or Stage_3or4 != 3
+        if (token_mlp_mode != "mix_skip" or concat not in ("coord", "normal", "se", "3d", "skn", "cbam", "cam", "cam_fact") or have_bridge == "sp" or Stage_3or4 != 3
                 or len(br) != 4):
-            raise NotImplementedError("MSTransception: implemented are concat in {'coord', 'normal', 'se', '3d', 'skn', 'cbam', 'cam'}, have_bridge in {'original', "
+            raise NotImplementedError("MSTransception: implemented are every concat of the reference ('coord', 'normal', 'se', '3d', 'skn', 'cbam', 'cam', 'cam_fact'), have_bridge in {'original', "
                                       "'None', 'para'}, any 4-entry br_ch_att_list, Stage_3or4 = 3, token_mlp_mode = 'mix_skip'")
         if have_bridge == "para":                       # BridgeBlock_para ignores br_ch_att_list (it receives num_sp, MSTr.py:2806-2807):
             br = [True, False, False, False]            # layer 1 channel, layers 2-4 spatial (MSTr.py:2504-2512)
@@ -783,14 +797,31 @@ def _mhca_stage(M, G, stack: Var, name: str, layers: int, B: int, side: int, out
         Wp = G.permuted_weight(M._P(G, agg + ".interact_concat.0.weight", (shape[0], C * 4)), shape[0], C, 4)
         z = G.relu(G.linear(cat, Wp, M._P(G, agg + ".interact_concat.0.bias")))
         return _bn(M, G, z, agg + ".bn", ACT_NONE, out=out)
-    if M.concat == "cam":                                                        # Conv3d_BN_channel_attention_concat, MSTr.py:642-668
+    if M.concat in ("cam", "cam_fact"):                                          # Conv3d_BN_channel_attention_concat, MSTr.py:642-668
         agg = name + ".aggregate"
         N = side * side
         # BatchNorm3d over (image, path, token) per channel = BatchNorm over the rows of the [4 * rows, C] view of the concatenation (a row of the
         # concatenation is path-major).  The reference also runs bn3d on the partial stacks of 1, 2, 3 paths and discards the results (:651-655):
         # only its running statistics see those passes; they are not reproduced.
         x3 = _bn(M, G, cat.reshape(4 * rows, C), agg + ".bn3d", ACT_NONE).reshape(rows, 4 * C)
-        x3 = G.cam(x3, M._P(G, agg + ".channelAttention.gamma"), B, N)
+        if M.concat == "cam":
+            x3 = G.cam(x3, M._P(G, agg + ".channelAttention.gamma"), B, N)
+        else:
+            # CAM_Factorized_Module, MSTr.py:528-568: the 4 N tokens of an image (every path's) through one factorized attention -- softmax of k
+            # over the tokens, k^T v per head, q times that, scaled -- then proj and gamma * out + x.  Sums over tokens do not care about their
+            # order, so the (token, path) rows of the concatenation's [4 rows, C] view stand for the reference's (path, token) ones.
+            ca = agg + ".channelAttention"
+            t = x3.reshape(4 * rows, C)
+            N4, Ch = 4 * N, C // HEADS
+            qkv = G.linear(t, *_lin(M, G, ca + ".qkv"))
+            q, k, v = qkv.colslice(0, C), qkv.colslice(C, 2 * C), qkv.colslice(2 * C, 3 * C)
+            ksm = G.softmax(k, B, 0)
+            ctx = G.new(B * HEADS * Ch, Ch)
+            G.bmm(ksm, v, ctx, Ch, Ch, N4, 1, 0, nb1=B, nb2=HEADS, sA=(N4 * C, Ch), sB=(N4 * 3 * C, Ch), sC=(HEADS * Ch * Ch, Ch * Ch))
+            fa = G.new(4 * rows, C)
+            G.bmm(q, ctx, fa, N4, Ch, Ch, 0, 0, nb1=B, nb2=HEADS, sA=(N4 * 3 * C, Ch), sB=(HEADS * Ch * Ch, Ch * Ch), sC=(N4 * C, Ch), alpha=Ch ** -0.5)
+            o = G.linear(fa, *_lin(M, G, ca + ".proj"))
+            x3 = G.gamma_residual(o, t, M._P(G, ca + ".gamma")).reshape(rows, 4 * C)
         x3 = _bn(M, G, x3.reshape(4 * rows, C), agg + ".bn3d", ACT_NONE).reshape(rows, 4 * C)
         off, shape = M._index[agg + ".interact_concat.0.weight"]                 # [O, C, 4, 1, 1]
         Wp = G.permuted_weight(M._P(G, agg + ".interact_concat.0.weight", (shape[0], C * 4)), shape[0], C, 4)
