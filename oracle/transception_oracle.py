@@ -43,13 +43,23 @@ class TransCeptionOracle:
     CRPE_WINDOW = ((3, 2), (5, 3), (7, 3))   # (kernel, heads)       (MSTr.py:958)
 
     def __init__(self, params: Dict[str, Tensor], num_classes: int = 9, training: bool = True, concat: str = "coord",
-                 have_bridge: str = "original", br_ch_att_list=(True, False, False, False), use_sa_config: int = 1, sa_ker: int = 7):
+                 have_bridge: str = "original", br_ch_att_list=(True, False, False, False), use_sa_config: int = 1, sa_ker: int = 7,
+                 Stage_3or4: int = 3, inter: str = "res"):
         self.P = params
         self.num_classes = num_classes
         self.training = training
         # ablation switches of the reference constructor (MSTr.py:2760-2823) that this restatement follows: the aggregate of a
         # stage (:1384-1403), whether the bridge runs (:2840) and which bridge layers use channel attention (:2413-2420)
         assert concat in ("coord", "normal", "se", "3d", "skn", "cbam", "cam", "cam_fact") and have_bridge != "sp" and len(br_ch_att_list) == 4
+        assert Stage_3or4 != 4
+        self.inter = "out"                      # CBAMBlock: the spatial attention reads the gated concatenation
+        if Stage_3or4 != 3:
+            # MSViT_casa (MSTr.py:2788-2791, 1990-2207): MSViT with MHCA_stage_casa (:1443-1534), which has no CoordAtt branch -- "coord" (any name it
+            # does not know) falls through to Conv3d_BN_channel_attention_concat with CAM_Factorized_Module (:1497-1502, 631-635) -- and whose "cbam"
+            # is CBAMBlock_casa (:1213-1257): spatial attention from the ResBlock branch (inter "res"), from the gated concatenation ("out"), or none
+            if concat not in ("normal", "3d", "se", "skn", "cbam", "cam"):
+                concat = "cam_fact"
+            self.inter = inter
         self.concat, self.have_bridge, self.br_ch_att_list = concat, have_bridge, tuple(bool(b) for b in br_ch_att_list)
         # which stages' CBAM blocks apply the spatial attention (MSTr.py:2766-2775)
         self.use_sa_list = {1: (True, True, False), 2: (True, False, False), 3: (False, False, False), 4: (True, True, True)}.get(use_sa_config, (True, True, True))
@@ -249,8 +259,9 @@ class TransCeptionOracle:
             ca = torch.sigmoid(se(flat.max(dim=1).values) + se(flat.mean(dim=1)))
             o = cat * ca[:, None, None, :]
             stage = int(name[-1])
-            if self.use_sa_list[stage - 2]:
-                st = torch.stack([o.max(dim=-1).values, o.mean(dim=-1)], dim=1)                         # [B, 2, H, W]
+            if self.use_sa_list[stage - 2] and self.inter in ("res", "out"):
+                src = o if self.inter == "out" else outs[0]                                             # CBAMBlock_casa :1243-1251: x[0], the ResBlock branch
+                st = torch.stack([src.max(dim=-1).values, src.mean(dim=-1)], dim=1)                     # [B, 2, H, W]
                 k = self.P[agg + ".sa.conv.weight"].shape[-1]
                 sa = torch.sigmoid(F.conv2d(st, self.P[agg + ".sa.conv.weight"], self.P[agg + ".sa.conv.bias"], padding=k // 2))
                 o = o * sa.permute(0, 2, 3, 1)

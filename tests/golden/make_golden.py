@@ -264,6 +264,14 @@ VARIANTS = {   # name -> (constructor kwargs, gradient probes)
                         ["backbone.mhca_stage2.aggregate.channelAttention.gamma", "backbone.mhca_stage3.aggregate.channelAttention.qkv.weight",
                          "backbone.mhca_stage4.aggregate.channelAttention.qkv.bias", "backbone.mhca_stage2.aggregate.channelAttention.proj.weight",
                          "backbone.mhca_stage3.aggregate.bn3d.weight", "backbone.mhca_stage4.aggregate.interact_concat.0.weight", "decoder_0.last_layer.weight"]),
+    # Stage_3or4 = 5 builds MSViT_casa: "coord" falls through to the factorized path attention; "cbam" is CBAMBlock_casa (inter)
+    "stage5_coord": (dict(Stage_3or4=5),
+                     ["backbone.mhca_stage2.aggregate.channelAttention.gamma", "backbone.mhca_stage4.aggregate.channelAttention.qkv.weight",
+                      "backbone.mhca_stage3.aggregate.bn3d.weight", "backbone.mhca_stage2.aggregate.interact_concat.0.weight",
+                      "backbone.mhca_stage3.InvRes.conv2.conv.weight", "decoder_0.last_layer.weight"]),
+    "stage5_cbam_res": (dict(Stage_3or4=5, concat="cbam", inter="res"),
+                        ["backbone.mhca_stage2.aggregate.sa.conv.weight", "backbone.mhca_stage3.aggregate.sa.conv.bias", "backbone.mhca_stage3.aggregate.ca.se.0.weight",
+                         "backbone.mhca_stage2.InvRes.conv2.conv.weight", "backbone.mhca_stage2.aggregate.conv2d_bn_act.1.weight", "decoder_0.last_layer.weight"]),
     "bridge_para": (dict(have_bridge="para"),
                     ["backbone.mhca_stage3.aggregate.conv1.weight", "bridge.bridge_layer1.attn.q.weight", "bridge.bridge_layer2.attn.kv.weight",
                      "bridge.proj_act.0.weight", "bridge.proj_act.0.bias", "bridge.proj_act.1.weight", "bridge.bridge_layer3.mixffn4.fc2.weight",
@@ -295,7 +303,8 @@ class _nothing:
 def variants(MST, Dice):
     out = {}
     for name, (kw, probes) in VARIANTS.items():
-        with (dense_batchnorm3d_input() if kw.get("concat") == "cam_fact" else _nothing()):
+        factorized = kw.get("concat") == "cam_fact" or (kw.get("Stage_3or4", 3) == 5 and kw.get("concat", "coord") not in ("normal", "3d", "se", "skn", "cbam", "cam"))
+        with (dense_batchnorm3d_input() if factorized else _nothing()):
             _variant(out, name, kw, probes, MST, Dice)
     np.savez_compressed(os.path.join(HERE, "variants.npz"), **out)
 

@@ -325,13 +325,23 @@ class MSTransception(nn.Module):
         # use_sa_config / sa_ker / inter / num_sp only reach the "cbam", "sp" and "para" variants and are accepted and ignored, as in
         #                | "para" (BridgeBlock_para, :2500-2538: channel and spatial layer side by side, Linear(128->64)+LN+GELU, two
         #                  more spatial layers)
-        # the reference.  Not built: have_bridge = sp, Stage_3or4 != 3,
+        #   Stage_3or4   3 (MSViT, default) | 5 (anything but 3 and 4: MSViT_casa, :1990-2207 = MSViT with MHCA_stage_casa, :1443-1534, which has no
+        #                  CoordAtt branch: concat = "coord" -- or any string it does not know -- builds Conv3d_BN_channel_attention_concat with
+        #                  CAM_Factorized_Module, i.e. what concat = "cam_fact" builds; concat = "cbam" builds CBAMBlock_casa, :1213-1257, whose
+        #                  spatial attention reads the ResBlock branch alone when inter = "res", the gated concatenation when inter = "out", and is
+        #                  skipped for any other inter)
+        # the reference.  Not built: have_bridge = sp, Stage_3or4 = 4 (MSViT_4Stages),
         # token_mlp_mode != "mix_skip", and the legacy networks/Transception.py class.
         br = [bool(b) for b in br_ch_att_list]
-        if (token_mlp_mode != "mix_skip" or concat not in ("coord", "normal", "se", "3d", "skn", "cbam", "cam", "cam_fact") or have_bridge == "sp" or Stage_3or4 != 3
+        if (token_mlp_mode != "mix_skip" or concat not in ("coord", "normal", "se", "3d", "skn", "cbam", "cam", "cam_fact") or have_bridge == "sp" or Stage_3or4 == 4
                 or len(br) != 4):
             raise NotImplementedError("MSTransception: implemented are every concat of the reference ('coord', 'normal', 'se', '3d', 'skn', 'cbam', 'cam', 'cam_fact'), have_bridge in {'original', "
-                                      "'None', 'para'}, any 4-entry br_ch_att_list, Stage_3or4 = 3, token_mlp_mode = 'mix_skip'")
+                                      "'None', 'para'}, any 4-entry br_ch_att_list, Stage_3or4 in {3, 5}, token_mlp_mode = 'mix_skip'")
+        self.inter = "out"                              # CBAMBlock (Stage_3or4 = 3) gates with the statistics of the gated concatenation
+        if Stage_3or4 != 3:                             # MSViT_casa (MSTr.py:2788-2791: the else branch of 4 / 3)
+            if concat not in ("normal", "3d", "se", "skn", "cbam", "cam"):
+                concat = "cam_fact"
+            self.inter = inter
         if have_bridge == "para":                       # BridgeBlock_para ignores br_ch_att_list (it receives num_sp, MSTr.py:2806-2807):
             br = [True, False, False, False]            # layer 1 channel, layers 2-4 spatial (MSTr.py:2504-2512)
         self.concat, self.have_bridge, self.br_ch_att_list = concat, have_bridge, br
@@ -341,6 +351,7 @@ class MSTransception(nn.Module):
         if concat == "cbam" and sa_ker not in (3, 7):
             raise NotImplementedError("MSTransception(concat='cbam'): sa_ker must be 3 or 7")
         self.backbone = _mk_backbone(concat, use_sa_list, sa_ker)
+        self.Stage_3or4 = Stage_3or4
         self.bridge = nn.Module()
         if have_bridge == "para":                       # constructor order of BridgeBlock_para: layers 1, 2, proj_act, layers 3, 4
             self.bridge.bridge_layer1 = _mk_bridge_layer(64, True)
@@ -835,9 +846,10 @@ def _mhca_stage(M, G, stack: Var, name: str, layers: int, B: int, side: int, out
         hid = G.relu(G.linear(pooled, *_lin(M, G, agg + ".ca.se.0", bias=False)))
         ca = G.linear(G.add(hid.rowslice(0, B), hid.rowslice(B, 2 * B)), *_lin(M, G, agg + ".ca.se.2", bias=False), act=ACT_SIGMOID)   # se(max) + se(avg): the last layer is linear
         o = G.chan_gate(cat, ca, B, N)
-        if holder.use_sa:
+        if holder.use_sa and M.inter in ("res", "out"):                           # CBAMBlock_casa, MSTr.py:1243-1251: "res" reads the ResBlock branch (x[0])
             k = holder.sa_ker
-            g = G.sa_conv(G.pix_stats(o), M._P(G, agg + ".sa.conv.weight"), M._P(G, agg + ".sa.conv.bias"), B, side, side, k)
+            src = o if M.inter == "out" else cat.colslice(0, C)
+            g = G.sa_conv(G.pix_stats(src), M._P(G, agg + ".sa.conv.weight"), M._P(G, agg + ".sa.conv.bias"), B, side, side, k)
             o = G.pix_gate(o, g)
         Wc, _ = _lin(M, G, agg + ".conv2d_bn_act.0", bias=False)
         z = G.new(rows, Wc.data.shape[0])
