@@ -9,7 +9,7 @@ fp32 with the name-seeded weights of transception_amd/seeded_init.py loaded stri
   model_b2.npz     whole model, B=2, train mode: sampled stage activations, sampled logits, the packed
                    argmax mask, the top-2 margin, loss / ce / dice, sampled parameter gradients,
                    updated BatchNorm running statistics; eval-mode logits sample as well
-  train_trace.npz  two SGD steps (lr 0.05, m 0.9, wd 1e-4, cosine T_max=100): loss, ce, dice, lr,
+  train_trace.npz  six SGD steps (lr 0.05, m 0.9, wd 1e-4, cosine T_max=100): loss, ce, dice, lr,
                    grad norm, post-step parameter checksums
   modules.npz      per-module forward outputs and input gradients for the sub-modules listed in
                    SURVEY.md section 8(c), driven by seeded inputs / upstream gradients
@@ -144,6 +144,9 @@ TRACE_PROBES = ["backbone.patch_embed1.proj.weight", "backbone.mhca_stage2.mhca_
                 "decoder_0.last_layer.weight", "backbone.mhca_stage4.InvRes.conv1.bn.weight"]
 
 
+TRACE_STEPS = 6          # rounds 1-3 pinned two steps; six show that the trajectories stay together once momentum and the running statistics feed back
+
+
 def train_trace(MST, Dice):
     out = {}
     ref = MST(num_classes=9)
@@ -153,7 +156,7 @@ def train_trace(MST, Dice):
     sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=100)
     dice_fn = Dice(9)
     rows = []
-    for step in range(2):
+    for step in range(TRACE_STEPS):
         x = torch.from_numpy(seeded_input(2, seed=7 + step))
         lab = torch.from_numpy(seeded_labels(2, seed=7 + step))
         logits = ref(x)

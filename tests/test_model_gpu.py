@@ -4,7 +4,7 @@
    produced by the reference itself) on the same seeded inputs;
  * whole model (B=2, 224^2, fp32 path): logits / loss / gradients / BatchNorm buffers against tests/golden/model_b2.npz,
    and against the CPU oracle run in the same process; eval mode; 3-channel input;
- * two SGD steps against the reference's train trace (tests/golden/train_trace.npz);
+ * six SGD steps against the reference's train trace (tests/golden/train_trace.npz);
  * sizes the reference cannot run (384^2) against the CPU oracle; bf16 storage path with its own stated budget.
 Tolerance for the fp32 path: 1e-3 abs on logits is the contract (BASELINE.json); the tests assert 1e-4.
 """
@@ -379,22 +379,25 @@ def test_whole_model_eval_and_rgb():
         assert torch.equal(sd[k].cpu(), ref[k])
 
 
-def test_train_trace_two_sgd_steps():
+def test_train_trace_sgd_steps():
+    """Six SGD steps against the reference's own trace.  fp32 rounding differences between the HIP kernels and torch's CPU kernels (1e-7 in the
+    first loss) are fed back through momentum and the running statistics: measured growth of the worst probe (|w| sum of the classifier
+    weight) 3e-10, 1e-6, 6e-6, 2e-5, 5e-5, 1e-4 and of the loss 8e-8 ... 2e-5 (scripts/exp/trace_dev.py), so the bounds widen per step."""
     from transception_amd.train import FusedSGD, SegLoss, cosine_lr, train_step
     g = load("train_trace.npz")
     m = _fresh().train()
     opt = FusedSGD(m, lr=0.05, momentum=0.9, weight_decay=1e-4)
     loss_fn = SegLoss(9)
-    for step in range(2):
+    for step in range(len(g["trace"])):
         x = torch.from_numpy(seeded_input(2, seed=7 + step)).to(DEV)
         lab = torch.from_numpy(seeded_labels(2, seed=7 + step)).to(DEV)
         loss, ce, dice = train_step(m, loss_fn, opt, x, lab)
         opt.lr = cosine_lr(0.05, step + 1, 100)
-        np.testing.assert_allclose([loss.item(), ce.item(), dice.item(), opt.lr], g["trace"][step][:4], rtol=5e-5, atol=2e-5)
+        np.testing.assert_allclose([loss.item(), ce.item(), dice.item(), opt.lr], g["trace"][step][:4], rtol=max(5e-5, 1e-5 * 2 ** step), atol=2e-5)
         named = dict(m.named_parameters())
         for key in [k.split("/", 1)[1] for k in g.files if k.startswith(f"step{step}/")]:
             a = named[key].detach().double().cpu()
-            np.testing.assert_allclose([a.sum().item(), a.abs().sum().item()], g[f"step{step}/{key}"], rtol=2e-5, atol=2e-4)
+            np.testing.assert_allclose([a.sum().item(), a.abs().sum().item()], g[f"step{step}/{key}"], rtol=max(2e-5, 4e-6 * 3 ** step), atol=2e-4)
 
 
 def test_size_384_against_oracle():
