@@ -1077,3 +1077,13 @@ def test_linear_many_independent_shapes(G):
         close(items[i][1].grad, Wr.grad, 5e-5, 1e-4, f"dW{i}")
         close(items[i][2].grad, br.grad, 5e-5, 1e-4, f"db{i}")
         close(G.grad_of(items[i][4]), rr.grad, 1e-6, 1e-6, f"dres{i}")
+
+
+def test_attention_streams_run_to_run_bit_identical():
+    """scripts/attn_stress.py (short form): the three hand-scheduled streams involve no atomics, so repeated runs on the same operands must
+    agree bit for bit whatever the timing (a side stream perturbs it); 30,000 runs of the long form: profiles/r4_attn_race_hunt.txt."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "attn_stress.py"), "--iters", "120", "--reseed", "30"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "RACE HUNT clean" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
