@@ -580,3 +580,15 @@ def test_fp16_overflow_skips_the_update_and_load_state_dict_refreshes_the_workin
     torch.cuda.synchronize()
     assert m._flat_lp.data_ptr() == ptr
     assert float((m._flat_lp.float() - m.flat_parameters()).abs().max()) < 2e-2        # the copy follows the new master weights
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_step_is_stable_run_to_run(dtype):
+    """scripts/step_stress.py (short form): repeated steps on fixed weights, inputs and BatchNorm buffers give bit-identical logits and a
+    gradient arena within the bound fp32 atomics allow -- a race anywhere in the step would be an outlier."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "step_stress.py"), "--iters", "40", "--dtype", dtype, "--batch", "2"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "STEP STRESS clean" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "bit-identical to the first run in 39 of 39" in r.stdout, r.stdout[-600:]
