@@ -871,19 +871,30 @@ __global__ __launch_bounds__(AS_NW * 64, 1) void attn_bwd_dq_asm_kernel(const bf
 constexpr int DA_TILE = 32 * LDR * 2, DA_SLOT = 2 * DA_TILE + 256, DA_NSLOT = 8, DA_AHEAD = 6, DA_PRM0 = DA_NSLOT * DA_SLOT, DA_SMEM = DA_PRM0 + 64;
 constexpr int DA_RED = D * 33 * 4;
 static_assert(4 * 2 * DA_RED <= DA_NSLOT * DA_SLOT, "the accumulator tiles of the four waves fit the ring");
-template <typename H>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_asm_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
+// PAIR = 2: an 8-wave workgroup whose two halves take two query chunks of the same 128 keys -- each half with its own ring and parameter
+// block, the barriers of the stream shared (the chunks are equally long by construction: see the host) -- and add their accumulator tiles
+// through LDS before the store: half the fp32 partial traffic.
+constexpr int DA_HALF = (DA_SMEM + 15) / 16 * 16;
+template <typename H, int PAIR>
+__global__ __launch_bounds__(256 * PAIR, 3 - PAIR) void attn_bwd_dkv_asm_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ K, int ldk,
                                                                     const bf16_t* __restrict__ V, int ldv, long long skv,
                                                                     const bf16_t* __restrict__ dO, int lddo, const float* __restrict__ nstat,
                                                                     float* __restrict__ dkv32, Segs sg, int Nk, float kscale, int tiles_per_chunk,
                                                                     long long rows) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char da_smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    extern __shared__ __attribute__((aligned(16))) unsigned char da_smem_all[];
+    const int half = PAIR == 2 ? (int)(threadIdx.x >> 8) : 0;
+    unsigned char* const da_smem = da_smem_all + half * DA_HALF;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
     const int lin = xcd_block((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x * gridDim.y * gridDim.z);
     const int bkx = lin % gridDim.x, b = (lin / gridDim.x) % gridDim.y, bkz = lin / (gridDim.x * gridDim.y);
     const int kv0 = (bkx * 4 + wave) * 32, key = min(kv0 + j, Nk - 1);
     const int ntiles = sg.t32[sg.n];
-    const int t_begin = bkz * tiles_per_chunk, nsub = min(ntiles, t_begin + tiles_per_chunk) - t_begin;
+    // PAIR: every chunk is tiles_per_chunk long; the last one starts early and its first t_mask tiles -- the previous chunk's -- count for
+    // nothing: their statistics are staged as the padding (-1e30, 0), so P = exp2(S - 1e30) = 0 exactly (the host keeps t_mask below the 5 staged here)
+    const int chunk = PAIR * bkz + half;
+    const int t_begin = PAIR == 2 ? min(chunk * tiles_per_chunk, ntiles - tiles_per_chunk) : bkz * tiles_per_chunk;
+    const int t_mask = PAIR == 2 ? chunk * tiles_per_chunk - t_begin : 0;
+    const int nsub = PAIR == 2 ? tiles_per_chunk : min(ntiles, t_begin + tiles_per_chunk) - t_begin;
     // first row of tile t of this image = A_s + 32 t, s = the segment of t
     int As[4], Ts[4];
 #pragma unroll
@@ -905,9 +916,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_asm_kernel(const bf16_t* 
         unsigned char* slot = da_smem + s * DA_SLOT;
         *reinterpret_cast<uint4*>(slot + key_row(sr) * (LDR * 2) + 16 * sc) = qv;
         *reinterpret_cast<uint4*>(slot + DA_TILE + key_row(sr) * (LDR * 2) + 16 * sc) = gv;
-        if (tid < 16)
-            *reinterpret_cast<uint4*>(slot + 2 * DA_TILE + 16 * tid) =
-                t < ntiles ? *reinterpret_cast<const uint4*>(nstat + ((long long)b * ntiles + t) * 64 + 4 * tid) : make_uint4(0u, 0u, 0u, 0u);
+        if (tid < 16) {
+            uint4 sv = t < ntiles ? *reinterpret_cast<const uint4*>(nstat + ((long long)b * ntiles + t) * 64 + 4 * tid) : make_uint4(0u, 0u, 0u, 0u);
+            if (s < t_mask) {                                    // [-lse log2e x 32 | -delta x 32] of a tile that counts for nothing
+                const unsigned pad = tid < 8 ? __float_as_uint(-1e30f) : 0u;
+                sv = make_uint4(pad, pad, pad, pad);
+            }
+            *reinterpret_cast<uint4*>(slot + 2 * DA_TILE + 16 * tid) = sv;
+        }
     }
     if (tid < 16) {
         int v = 0;
@@ -965,6 +981,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_asm_kernel(const bf16_t* 
     // each wave owns its keys: whole 256-byte rows of its [key][d] partial out of the [d][key] tiles the stream left in LDS
     const float* redw = reinterpret_cast<const float*>(da_smem + wave * (2 * DA_RED));
     float* dpart = dkv32 + (long long)bkz * gridDim.y * Nk * 128;
+    if (PAIR == 2) {                                            // the two halves' tiles added; half 0 stores dK, half 1 dV
+        __syncthreads();
+        const float* red0 = reinterpret_cast<const float*>(da_smem_all + wave * (2 * DA_RED));
+        const float* red1 = reinterpret_cast<const float*>(da_smem_all + DA_HALF + wave * (2 * DA_RED));
+        const int which = half;
+        for (int f = lane; f < 32 * D; f += 64) {
+            const int kk = f >> 6, d = f & 63, o = which * (D * 33) + d * 33 + kk;
+            if (kv0 + kk < Nk) dpart[((long long)b * Nk + kv0 + kk) * 128 + which * 64 + d] = red0[o] + red1[o];
+        }
+        return;
+    }
 #pragma unroll
     for (int which = 0; which < 2; ++which)
         for (int f = lane; f < 32 * D; f += 64) {
@@ -979,11 +1006,16 @@ __global__ __launch_bounds__(256) void attn_dkv_store_kernel(const float* __rest
     const long long n = (long long)B * Nk * 32;                 // float4 groups per query chunk
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const int q = (int)(i & 31), key = (int)((i >> 5) % Nk), b = (int)((i >> 5) / Nk);
-        float4 v = *reinterpret_cast<const float4*>(dkv32 + i * 4);
-        for (int z = 1; z < zs; ++z) {                          // the query chunks' partial sums
-            const float4 w = *reinterpret_cast<const float4*>(dkv32 + (z * n + i) * 4);
-            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
-        }
+        // the query chunks' partial sums, added as a fixed binary tree over (up to) TC_ATTN_DKV_SPLITS = 8 leaves, absent ones zero: the paired
+        // dK/dV kernel hands over leaves already added two by two and must land on the same bits
+        float4 t[8];
+#pragma unroll
+        for (int z = 0; z < 8; ++z) t[z] = z < zs ? *reinterpret_cast<const float4*>(dkv32 + (z * n + i) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int w = 1; w < 8; w *= 2)
+#pragma unroll
+            for (int z = 0; z < 8; z += 2 * w) { t[z].x += t[z + w].x; t[z].y += t[z + w].y; t[z].z += t[z + w].z; t[z].w += t[z + w].w; }
+        const float4 v = t[0];
         bf16_t* dst = (q < 16 ? dK + b * sdkv + (long long)key * lddk + q * 4 : dV + b * sdkv + (long long)key * lddv + (q - 16) * 4);
         st4<H>(reinterpret_cast<H*>(dst), v);
     }
@@ -1153,6 +1185,10 @@ extern "C" int tc_attn_bwd_seg(const void* Q, int ldq, const void* K, int ldk, c
     const bool dkv_asm = dkv_asm_env && qscaled && wide_rows && zs < TC_ATTN_DKV_SPLITS && (long long)ntiles * 64 <= (long long)Nk * 128 &&
                          ntiles - (zs - 1) * tpc >= 2 && tpc >= 2 && rows * (long long)(ldq > lddo ? ldq : lddo) * 2 < 0x7fffffffLL;
     float* const nstat = dkv_asm ? dkv32 + (long long)(TC_ATTN_DKV_SPLITS - 1) * B * Nk * 128 : nullptr;
+    // paired query chunks (8-wave workgroups): an even number of equally long chunks, the last one overlapping its predecessor by fewer tiles
+    // than the kernel stages itself
+    static const int pair_env = getenv("TC_ATTN_DKV_PAIR") ? atoi(getenv("TC_ATTN_DKV_PAIR")) : 1;
+    const bool dkv_pair = pair_env && dkv_asm && zs >= 2 && !(zs & 1) && tpc <= ntiles && zs * tpc - ntiles < DA_AHEAD - 1 && (zs - 1) * tpc < ntiles;
     const int dq_asm_env = getenv("TC_ATTN_DQ_ASM") ? atoi(getenv("TC_ATTN_DQ_ASM")) : 1;
     const bool dq_asm = dq_asm_env && qscaled && fuse_delta && wide_dq && Nk >= 33 && rows * (long long)(ldq > lddo ? ldq : lddo) * 2 < 0x7fffffffLL;
     static bool lds_ok[2] = {false, false};
@@ -1166,7 +1202,8 @@ extern "C" int tc_attn_bwd_seg(const void* Q, int ldq, const void* K, int ldk, c
         if (!lds_ok[IDX]) {                                                                                                                 \
             if (hipFuncSetAttribute((const void*)attn_bwd_dq_seg_kernel<HH, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FW_SMEM) != hipSuccess || \
                 hipFuncSetAttribute((const void*)attn_bwd_dq_seg_kernel<HH, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FW_SMEM) != hipSuccess || \
-                hipFuncSetAttribute((const void*)attn_bwd_dkv_asm_kernel<HH>, hipFuncAttributeMaxDynamicSharedMemorySize, DA_SMEM) != hipSuccess || \
+                hipFuncSetAttribute((const void*)attn_bwd_dkv_asm_kernel<HH, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, DA_SMEM) != hipSuccess || \
+                hipFuncSetAttribute((const void*)attn_bwd_dkv_asm_kernel<HH, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DA_HALF) != hipSuccess || \
                 hipFuncSetAttribute((const void*)attn_bwd_dq_asm_kernel<HH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AS_SMEM) != hipSuccess || \
                 hipFuncSetAttribute((const void*)attn_bwd_dkv_seg_kernel<HH, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_SMEM_B) != hipSuccess || \
                 hipFuncSetAttribute((const void*)attn_bwd_dkv_seg_kernel<HH, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_SMEM_B) != hipSuccess) \
@@ -1181,8 +1218,11 @@ extern "C" int tc_attn_bwd_seg(const void* Q, int ldq, const void* K, int ldk, c
                                (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk, (const bf16_t*)V, ldv, skv, (const bf16_t*)O, ldo, (const bf16_t*)dO, lddo, \
                                lse, delta, (bf16_t*)dQ, lddq, sg, Nk, scale, nstat, rows);                                                     \
         else if (qscaled) TC_BWD_DQ(HH, 1); else TC_BWD_DQ(HH, 0);                                                                          \
-        if (dkv_asm)                                                                                                                        \
-            hipLaunchKernelGGL((attn_bwd_dkv_asm_kernel<HH>), dim3(kb, B, zs), dim3(256), DA_SMEM, s, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk, \
+        if (dkv_pair)                                                                                                                       \
+            hipLaunchKernelGGL((attn_bwd_dkv_asm_kernel<HH, 2>), dim3(kb, B, zs / 2), dim3(512), 2 * DA_HALF, s, (const bf16_t*)Q, ldq,           \
+                               (const bf16_t*)K, ldk, (const bf16_t*)V, ldv, skv, (const bf16_t*)dO, lddo, nstat, dkv32, sg, Nk, kscale, tpc, rows); \
+        else if (dkv_asm)                                                                                                                   \
+            hipLaunchKernelGGL((attn_bwd_dkv_asm_kernel<HH, 1>), dim3(kb, B, zs), dim3(256), DA_SMEM, s, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk, \
                                (const bf16_t*)V, ldv, skv, (const bf16_t*)dO, lddo, nstat, dkv32, sg, Nk, kscale, tpc, rows);                    \
         else if (qscaled)                                                                                                                   \
             hipLaunchKernelGGL((attn_bwd_dkv_seg_kernel<HH, 4, true>), dim3(kb, B, zs), dim3(256), DKV_SMEM_B, s, (const bf16_t*)Q, ldq, (const bf16_t*)K, \
@@ -1191,7 +1231,7 @@ extern "C" int tc_attn_bwd_seg(const void* Q, int ldq, const void* K, int ldk, c
             hipLaunchKernelGGL((attn_bwd_dkv_seg_kernel<HH, 4, false>), dim3(kb, B, zs), dim3(256), DKV_SMEM_B, s, (const bf16_t*)Q, ldq, (const bf16_t*)K, \
                                ldk, (const bf16_t*)V, ldv, skv, (const bf16_t*)dO, lddo, lse, delta, dkv32, sg, Nk, kscale, qs, tpc);             \
         hipLaunchKernelGGL(attn_dkv_store_kernel<HH>, dim3(tc_blocks((long long)B * Nk * 32, 256, 1024)), dim3(256), 0, s, dkv32,           \
-                           (bf16_t*)dK, lddk, (bf16_t*)dV, lddv, sdkv, B, Nk, zs);                                                              \
+                           (bf16_t*)dK, lddk, (bf16_t*)dV, lddv, sdkv, B, Nk, dkv_pair ? zs / 2 : zs);                                          \
     }
     if (dtype == TC_BF16) TC_BWD(bf16_t, 0) else TC_BWD(f16_t, 1)
 #undef TC_BWD
