@@ -875,8 +875,9 @@ def test_attention_backward_streams_vs_compiler_kernels_and_fp64_over_shapes(dty
         assert L.tc_attn_fwd_seg(q.data_ptr(), d, k.data_ptr(), 2 * d, v.data_ptr(), 2 * d, Nk * 2 * d, o.data_ptr(), d, lse.data_ptr(), B, len(nq), nqc, Nk,
                                  scale, 1, dt, st) in (0, None)
         outs = {}
-        for impl in ("1", "0"):
-            os.environ["TC_ATTN_DKV_ASM"] = os.environ["TC_ATTN_DQ_ASM"] = impl
+        for impl in ("1", "1u", "0"):                  # streams (query chunks paired where the plan allows), streams unpaired, compiler-scheduled
+            os.environ["TC_ATTN_DKV_ASM"] = os.environ["TC_ATTN_DQ_ASM"] = impl[0]
+            os.environ["TC_ATTN_DKV_PAIR"] = "0" if impl == "1u" else "1"
             try:
                 dq = torch.full((rows, d), float("nan"), device=DEV).to(dtype)
                 dkv = torch.full((B * Nk, 2 * d), float("nan"), device=DEV).to(dtype)
@@ -891,6 +892,9 @@ def test_attention_backward_streams_vs_compiler_kernels_and_fp64_over_shapes(dty
             finally:
                 os.environ.pop("TC_ATTN_DKV_ASM", None)
                 os.environ.pop("TC_ATTN_DQ_ASM", None)
+                os.environ.pop("TC_ATTN_DKV_PAIR", None)
+        # paired and unpaired chunks run the same stream and the fold is a fixed tree: the same bits for both storage types
+        assert torch.equal(outs["1"][1], outs["1u"][1]) and torch.equal(outs["1"][0], outs["1u"][0]), (B, nq, Nk)
         if dtype == torch.bfloat16:
             assert torch.equal(outs["1"][1], outs["0"][1]), (B, nq, Nk, (outs["1"][1] - outs["0"][1]).abs().max().item())
         else:       # fp16: identical but for single last-place differences of a dK row (one case of twelve, one key: 1.2e-4 at magnitude 0.2):

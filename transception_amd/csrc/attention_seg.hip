@@ -1187,7 +1187,7 @@ extern "C" int tc_attn_bwd_seg(const void* Q, int ldq, const void* K, int ldk, c
     float* const nstat = dkv_asm ? dkv32 + (long long)(TC_ATTN_DKV_SPLITS - 1) * B * Nk * 128 : nullptr;
     // paired query chunks (8-wave workgroups): an even number of equally long chunks, the last one overlapping its predecessor by fewer tiles
     // than the kernel stages itself
-    static const int pair_env = getenv("TC_ATTN_DKV_PAIR") ? atoi(getenv("TC_ATTN_DKV_PAIR")) : 1;
+    const int pair_env = getenv("TC_ATTN_DKV_PAIR") ? atoi(getenv("TC_ATTN_DKV_PAIR")) : 1;     // read per call: the tests run both forms in one process
     const bool dkv_pair = pair_env && dkv_asm && zs >= 2 && !(zs & 1) && tpc <= ntiles && zs * tpc - ntiles < DA_AHEAD - 1 && (zs - 1) * tpc < ntiles;
     const int dq_asm_env = getenv("TC_ATTN_DQ_ASM") ? atoi(getenv("TC_ATTN_DQ_ASM")) : 1;
     const bool dq_asm = dq_asm_env && qscaled && fuse_delta && wide_dq && Nk >= 33 && rows * (long long)(ldq > lddo ? ldq : lddo) * 2 < 0x7fffffffLL;
