@@ -138,6 +138,23 @@ int tc_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx, const voi
  * partials are folded 16 at a time inside the kernel before anything touches dgamma / dbeta atomically -- one pass over
  * x / dy for dx, dgamma and dbeta together. */
 long long tc_layernorm_bwd_scratch_floats(int rows, int C, int groups);
+/* Deferred parameter gradients (the backward of nn.LayerNorm's weight / bias at the same reference lines): tc_layernorm_bwd_defer is
+ * tc_layernorm_bwd, but instead of folding its per-workgroup column sums at its tail it leaves them in `part`
+ * ([groups][tc_layernorm_bwd_nblk(rows, C)][dgamma C | dbeta C] floats, a buffer of this launch's own, kept until the fold) and returns;
+ * tc_layernorm_fold adds the partials of up to 64 such launches to their dgamma / dbeta in ONE launch (the host calls it when a backward
+ * sweep stops or ends).  tc_layernorm_bwd_nblk returns 0 for shapes that are not deferred (C > 1024: they fold in launches of their own). */
+typedef struct {
+    const float* part;            /* what tc_layernorm_bwd_defer left */
+    float* dgamma; float* dbeta;  /* accumulated into (group g at + g * pstride) */
+    long long pstride;
+    int nblk, C, groups;
+} TcLnFold;
+int tc_layernorm_bwd_nblk(int rows, int C);
+int tc_layernorm_bwd_defer(const void* dy, int lddy, const void* x, int ldx, const void* gamma, const void* beta,
+                           const float* mean, const float* rstd, void* dx, int lddx, const void* dres, int ldres,
+                           float* dgamma, float* dbeta, int rows, int C, int act, int groups, long long pstride,
+                           float* part, long long part_floats, int dtype, void* stream);
+int tc_layernorm_fold(const TcLnFold* sites, int n, void* stream);
 /* dgamma / dbeta may both be NULL above (dx only); this entry then produces them as a row-parallel column reduction, so the
  * host can run it on a second stream beside the activation-gradient chain. */
 int tc_layernorm_bwd_params(const void* dy, int lddy, const void* x, int ldx, const void* gamma, const void* beta,

@@ -138,6 +138,33 @@ def test_layernorm(G, rows, C, eps, act):
     close(bp.grad, br.grad, 2e-4, 2e-4, "dbeta")
 
 
+@pytest.mark.parametrize("rows,C", [(3136, 128), (50176, 64), (784, 320), (37, 64)])
+def test_layernorm_deferred_parameter_fold(rows, C, monkeypatch):
+    """tc_layernorm_bwd_defer + tc_layernorm_fold (the default: partials parked per launch, one fold per backward leg) against the launch
+    that folds at its own tail (TC_LN_DEFER=0): the same dx bit for bit, dgamma / dbeta to summation order; two LayerNorms sharing one
+    parameter pair accumulate both contributions."""
+    from transception_amd import engine
+    from transception_amd.engine import Graph
+    x, g, b, gy = T(f"lnd.x{rows}", (rows, C), 2.0), T(f"lnd.g{C}", (C,)) * 0.2 + 1, T(f"lnd.b{C}", (C,), 0.3), T(f"lnd.gy{rows}", (rows, C))
+    res = {}
+    for defer in (True, False):
+        monkeypatch.setattr(engine, "_LN_DEFER", defer)
+        G = Graph(torch.float32, torch.device(DEV), training=True, record=True)
+        xv, gp, bp = mkV(G, x), mkP(g), mkP(b)
+        o1 = G.layernorm(xv, gp, bp)
+        o2 = G.layernorm(o1, gp, bp)                      # the same parameters a second time
+        n0 = G.n_launch
+        run_bwd(G, o2, gy)
+        res[defer] = (G.grad_of(xv).clone(), gp.grad.clone(), bp.grad.clone(), G.n_launch - n0)
+    assert torch.equal(res[True][0], res[False][0])
+    for i, what in ((1, "dgamma"), (2, "dbeta")):
+        close(res[True][i], res[False][i].cpu(), 1e-5 * max(1.0, float(res[False][i].abs().max())), 1e-5, what)
+    xr, gr, br = x.clone().requires_grad_(), g.clone().requires_grad_(), b.clone().requires_grad_()
+    F.layer_norm(F.layer_norm(xr, (C,), gr, br), (C,), gr, br).backward(gy)
+    close(res[True][1], gr.grad, 3e-4 * max(1.0, float(gr.grad.abs().max())), 3e-4, "dgamma vs torch")
+    close(res[True][2], br.grad, 3e-4 * max(1.0, float(br.grad.abs().max())), 3e-4, "dbeta vs torch")
+
+
 @pytest.mark.parametrize("C,H,k,stride,bias,add", [(64, 12, 3, 1, True, True), (64, 12, 3, 2, False, False), (24, 9, 5, 1, True, False),
                                                     (120, 7, 7, 1, True, False), (256, 14, 3, 1, True, True), (16, 28, 3, 1, True, False)])
 def test_dwconv(G, C, H, k, stride, bias, add):

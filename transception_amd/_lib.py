@@ -44,6 +44,10 @@ class TcDwSeg(C.Structure):
                 ("ldx", i32), ("ldy", i32), ("lddy", i32), ("B", i32), ("H", i32), ("W", i32), ("stat", vp)]
 
 
+class TcLnFold(C.Structure):
+    _fields_ = [("part", vp), ("dgamma", vp), ("dbeta", vp), ("pstride", i64), ("nblk", i32), ("C", i32), ("groups", i32)]
+
+
 class TcFfnSeg(C.Structure):
     _fields_ = [("gp", vp), ("d", vp), ("h", vp), ("dh", vp), ("stat", vp), ("part2", vp), ("w", vp), ("gamma", vp),
                 ("dw", vp), ("db", vp), ("dgamma", vp), ("dbeta", vp),
@@ -105,6 +109,9 @@ SIGNATURES = {
     "tc_layernorm_fwd": [vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, f32, i32, i32, i64, i32, vp],
     "tc_layernorm_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i64, vp, i64, i32, vp],
     "tc_layernorm_bwd_scratch_floats": [i32, i32, i32],
+    "tc_layernorm_bwd_nblk": [i32, i32],
+    "tc_layernorm_bwd_defer": [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i64, vp, i64, i32, vp],
+    "tc_layernorm_fold": [vp, i32, vp],
     "tc_layernorm_ps_fwd": [vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp],
     "tc_layernorm_ps_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, i64, i32, vp],
     "tc_layernorm_bwd_params": [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i32, vp],
@@ -191,7 +198,7 @@ SIGNATURES = {
     "tc_cast": [vp, vp, i64, i32, i32, vp],
 }
 _RET = {"tc_ffn_fused_bwd_scratch_floats": i64, "tc_effatt_scratch_floats": i64, "tc_bn_scratch_floats": i64, "tc_softmax_scratch_floats": i64, "tc_layernorm_bwd_scratch_floats": i64, "tc_factor_att_stats_floats": i64}
-_RAW = {"tc_abi_version", "tc_effatt_supported", "tc_effatt_scratch_floats", "tc_ffn_chunk", "tc_ffn_fused_supported", "tc_ffn_fused_bwd_supported", "tc_ffn_fused_bwd_scratch_floats", "tc_bn_scratch_floats", "tc_softmax_scratch_floats", "tc_layernorm_bwd_scratch_floats", "tc_factor_att_stats_floats"}     # not status-returning
+_RAW = {"tc_abi_version", "tc_effatt_supported", "tc_effatt_scratch_floats", "tc_ffn_chunk", "tc_ffn_fused_supported", "tc_ffn_fused_bwd_supported", "tc_ffn_fused_bwd_scratch_floats", "tc_bn_scratch_floats", "tc_softmax_scratch_floats", "tc_layernorm_bwd_scratch_floats", "tc_layernorm_bwd_nblk", "tc_factor_att_stats_floats"}     # not status-returning
 
 
 class TcError(RuntimeError):

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      T* __restrict__ dx, int lddx, const T* __restrict__ dres, int ldres,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int C,
-                                                     int act, long long pstride, float* __restrict__ partial, int* __restrict__ cnt, LnMap map) {
+                                                     int act, long long pstride, float* __restrict__ partial, int* __restrict__ cnt, LnMap map, int defer) {
     constexpr int RPB = 256 / GS;
     extern __shared__ float red[];           // [RPB][2][C]
     const int gl = threadIdx.x % GS, gi = threadIdx.x / GS;
@@ -222,17 +222,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
         float a = 0.f, bb = 0.f;
 #pragma unroll
         for (int w = 0; w < RPB; ++w) { a += red[(w * 2 + 0) * C + c]; bb += red[(w * 2 + 1) * C + c]; }
-        if (partial) {                       // parked for the 16-way fold below
+        if (partial) {                       // parked for the 16-way fold below, or (defer) for ln_fold_kernel: one launch per backward leg
             float* pp = partial + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 2 * C;
-            __hip_atomic_store(pp + c, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(pp + C + c, bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (defer) { pp[c] = a; pp[C + c] = bb; }
+            else {
+                __hip_atomic_store(pp + c, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(pp + C + c, bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         } else {
             atomicAdd(dgamma + c, a);
             atomicAdd(dbeta + c, bb);
         }
     }
     LSTAMP(2);
-    if (!partial) return;
+    if (!partial || defer) return;
     // Two-level fold (the GEMM split-K fix-up protocol): LN_FOLD consecutive workgroups share an arrival counter (8 measured best of 2-32: the last arriver reads its group serially); the last to arrive
     // adds the group's partial rows and is the only one that touches dgamma / dbeta atomically (32 contributors per word instead of
     // 1024, and no second launch).
@@ -497,6 +500,53 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     }
 }
 
+// Deferred parameter gradients of the LayerNorms (tc_layernorm_bwd_defer): every backward launch leaves its per-workgroup column sums
+// [groups][nblk][dgamma C | dbeta C] in a buffer of its own and returns -- no arrival counter, no last-arriver fold at its tail (3-5 us of a
+// 6-11 us launch on the small maps) -- and ONE launch per backward leg adds them up for all sites.  Workgroup = (site, group, 64 columns of
+// the 2C): 64 columns x 4 row slices, every load of a slice's batch issued before the first add.
+constexpr int LN_FOLD_SITES = 64;
+struct LnFoldSite { const float* part; float* dgamma; float* dbeta; long long pstride; int nblk, C, groups, blk0; };
+struct LnFoldDev { LnFoldSite s[LN_FOLD_SITES]; int n; };
+__global__ __launch_bounds__(256) void ln_fold_kernel(const LnFoldDev q) {
+    __shared__ float red[4][64];
+    int si = 0;
+    for (int i = 1; i < q.n; ++i) if ((int)blockIdx.x >= q.s[i].blk0) si = i;
+    const LnFoldSite& t = q.s[si];
+    const int cchunks = (2 * t.C + 63) / 64;
+    const int lin = blockIdx.x - t.blk0, g = lin / cchunks, c = (lin - g * cchunks) * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+    float v = 0.f;
+    if (c < 2 * t.C) {
+        const float* p = t.part + (long long)g * t.nblk * 2 * t.C + c;
+        int r = sl;
+        for (; r + 28 < t.nblk; r += 32) {
+            float tmp[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) tmp[m] = p[(long long)(r + 4 * m) * 2 * t.C];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) v += tmp[m];
+        }
+        for (; r < t.nblk; r += 4) v += p[(long long)r * 2 * t.C];
+    }
+    red[sl][threadIdx.x & 63] = v;
+    __syncthreads();
+    if (sl == 0 && c < 2 * t.C) {
+        v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        atomicAdd(c < t.C ? t.dgamma + g * t.pstride + c : t.dbeta + g * t.pstride + (c - t.C), v);     // (a parameter used at two sites has two writers)
+    }
+}
+
+// workgroups of the fused dx + parameter-gradient launch (one place: the launch and the size of a deferred partial buffer)
+inline int ln_bwd_nblk(int rows, int C, bool with_params) {
+    const int quads = C >> 2;
+    const int GS = quads <= 16 ? 16 : (quads <= 32 ? 32 : 64);
+    static const int ilp_on = getenv("TC_LN_BWD_ILP") ? atoi(getenv("TC_LN_BWD_ILP")) : 1;
+    const bool ilp = ilp_on && quads <= 64 && rows >= 8192;
+    int rpg = with_params ? rows / ((256 / GS) * ln_bwd_wg_min()) : 1;   // rows per lane group: >= 512 workgroups before rows are stacked
+    rpg = rpg < 1 ? 1 : (rpg > LN_BWD_ROWS_PER_GROUP ? LN_BWD_ROWS_PER_GROUP : rpg);
+    if (ilp && rpg < 2) rpg = 2;
+    return tc_blocks(rows, (256 / GS) * rpg, with_params ? ln_bwd_blocks() : 8192);
+}
+
 }  // namespace
 
 static int ln_fwd_impl(const void* x, int ldx, const void* gamma, const void* beta, void* y, int ldy,
@@ -539,7 +589,7 @@ extern "C" int tc_layernorm_bwd_params(const void* dy, int lddy, const void* x, 
 static int ln_bwd_impl(const void* dy, int lddy, const void* x, int ldx, const void* gamma, const void* beta,
                        const float* mean, const float* rstd, void* dx, int lddx, const void* dres, int ldres,
                        float* dgamma, float* dbeta, int rows, int C, int act, int groups, long long pstride,
-                       float* scratch, long long scratch_floats, int dtype, void* stream, LnMap map) {
+                       float* scratch, long long scratch_floats, int dtype, void* stream, LnMap map, float* defer_part = nullptr) {
     if (!dy || !x || !gamma || !beta || !mean || !rstd || !dx || (!dgamma != !dbeta) || rows <= 0 || groups < 1 || C <= 0 || (C & 3) ||
         C > LN_MAXC || (ldx & 3) || (lddy & 3) || (lddx & 3) || (dres && (ldres & 3)))
         return TC_ERR_ARG;
@@ -559,16 +609,14 @@ static int ln_bwd_impl(const void* dy, int lddy, const void* x, int ldx, const v
         hipLaunchKernelGGL((ln_bwd_kernel<T, GS, NV, RPT>), dim3(nblk, groups), dim3(256),                                                  \
                                           (size_t)(256 / GS) * 2 * C * sizeof(float), s, (const T*)dy, lddy, (const T*)x, ldx,            \
                                           (const T*)gamma, (const T*)beta, mean, rstd, (T*)dx, lddx, (const T*)dres, ldres, dgamma,      \
-                                          dbeta, rows, C, act, pstride, partial, reinterpret_cast<int*>(scratch), map)
+                                          dbeta, rows, C, act, pstride, partial, reinterpret_cast<int*>(scratch), map, defer_part ? 1 : 0)
 #define TC_LNB(GS, NV) {                                                                                                                  \
         constexpr int RPT = 2;   /* rows in flight per lane group (narrow rows): 14.16 vs 14.19 ms per step; 4 rows: 14.21 vs 14.22 */                                                         \
         static const int ilp_on = getenv("TC_LN_BWD_ILP") ? atoi(getenv("TC_LN_BWD_ILP")) : 1;                                             \
         const bool ilp = ilp_on && NV == 1 && rows >= 8192;                                                                                \
-        int rpg = dgamma ? rows / ((256 / GS) * ln_bwd_wg_min()) : 1; /* rows per lane group: >= 512 workgroups before rows are stacked */ \
-        rpg = rpg < 1 ? 1 : (rpg > LN_BWD_ROWS_PER_GROUP ? LN_BWD_ROWS_PER_GROUP : rpg);                                                    \
-        if (ilp && rpg < RPT) rpg = RPT;                                                                                                  \
-        nblk = tc_blocks(rows, (256 / GS) * rpg, dgamma ? ln_bwd_blocks() : 8192);                                                        \
-        partial = (dgamma && scratch && (uintptr_t)scratch % 16 == 0 && scratch_floats >= 4096 + (long long)groups * nblk * 2 * C &&      \
+        nblk = ln_bwd_nblk(rows, C, dgamma != nullptr);                                                                                    \
+        partial = defer_part ? defer_part :                                                                                               \
+                  (dgamma && scratch && (uintptr_t)scratch % 16 == 0 && scratch_floats >= 4096 + (long long)groups * nblk * 2 * C &&      \
                    (long long)groups * ((nblk + LN_FOLD - 1) / LN_FOLD) <= 4096) ? scratch + 4096 : nullptr;                                            \
         if (ilp) TC_LNB_LAUNCH(GS, NV, RPT); else TC_LNB_LAUNCH(GS, NV, 1); }
     TC_DISPATCH_DTYPE(dtype, { TC_LN_DISPATCH(quads, TC_LNB) });
@@ -603,6 +651,36 @@ extern "C" int tc_layernorm_ps_bwd(const void* dy, int lddy, const void* x, int 
     if (B <= 0 || H <= 0 || W <= 0 || p < 1 || ldx < p * p * C || lddx < p * p * C || C > 1024) return TC_ERR_ARG;
     return ln_bwd_impl(dy, lddy, x, ldx, gamma, beta, mean, rstd, dx, lddx, nullptr, 0, dgamma, dbeta, B * H * p * W * p, C, TC_ACT_NONE, 1, 0,
                        scratch, scratch_floats, dtype, stream, LnMap{p, H, W});
+}
+
+extern "C" int tc_layernorm_bwd_nblk(int rows, int C) {
+    if (rows <= 0 || C <= 0 || (C & 3) || C > LN_MAXC || (C >> 2) > 256) return 0;     // wide rows fold in launches of their own
+    return ln_bwd_nblk(rows, C, true);
+}
+
+extern "C" int tc_layernorm_bwd_defer(const void* dy, int lddy, const void* x, int ldx, const void* gamma, const void* beta,
+                                      const float* mean, const float* rstd, void* dx, int lddx, const void* dres, int ldres,
+                                      float* dgamma, float* dbeta, int rows, int C, int act, int groups, long long pstride,
+                                      float* part, long long part_floats, int dtype, void* stream) {
+    const int nblk = tc_layernorm_bwd_nblk(rows, C);
+    if (!part || !dgamma || nblk <= 0 || groups < 1 || part_floats < (long long)groups * nblk * 2 * C) return TC_ERR_ARG;
+    return ln_bwd_impl(dy, lddy, x, ldx, gamma, beta, mean, rstd, dx, lddx, dres, ldres, dgamma, dbeta, rows, C, act, groups, pstride, nullptr, 0,
+                       dtype, stream, LnMap{0, 0, 0}, part);
+}
+
+extern "C" int tc_layernorm_fold(const TcLnFold* sites, int n, void* stream) {
+    if (!sites || n < 1 || n > LN_FOLD_SITES) return TC_ERR_ARG;
+    LnFoldDev q;
+    q.n = n;
+    int blk = 0;
+    for (int i = 0; i < n; ++i) {
+        const TcLnFold& t = sites[i];
+        if (!t.part || !t.dgamma || !t.dbeta || t.nblk < 1 || t.C <= 0 || t.groups < 1) return TC_ERR_ARG;
+        q.s[i] = LnFoldSite{t.part, t.dgamma, t.dbeta, t.pstride, t.nblk, t.C, t.groups, blk};
+        blk += t.groups * ((2 * t.C + 63) / 64);
+    }
+    hipLaunchKernelGGL(ln_fold_kernel, dim3(blk), dim3(256), 0, (hipStream_t)stream, q);
+    return tc_launch_status();
 }
 
 extern "C" long long tc_layernorm_bwd_scratch_floats(int rows, int C, int groups) {

@@ -190,6 +190,7 @@ _SKIP_WGRAD = bool(os.environ.get("TC_DEBUG_SKIP_WGRAD"))
 _FFN_STORE_ACT = os.environ.get("TC_FFN_STORE_ACT", "1") != "0"   # MixFFN: keep GELU(LN(d)) from the forward pass (0: recompute it in dW2's loader)
 _FFN_LN_GEMM_MAXC = int(os.environ.get("TC_FFN_LN_GEMM_MAXC", "64"))  # widest fc2 output for which LayerNorm + GELU run in its A loader
 _FFN_TILED = os.environ.get("TC_FFN_TILED", "1") != "0"        # MixFFN forward as one spatially tiled kernel where the library supports the width (csrc/mixffn.hip)
+_LN_DEFER = os.environ.get("TC_LN_DEFER", "1") != "0"                  # LayerNorm dgamma / dbeta partials folded once per backward leg (tc_layernorm_fold) instead of at every launch's tail
 _EFFATT_FUSED = os.environ.get("TC_EFFATT_FUSED", "1") != "0"        # EfficientAttention blocks through csrc/effatt.hip where the library supports the width
 # The LayerNorm ahead of a MixFFN site (the block's norm2) inside the tiled kernels (both directions tiled: C = 64).  OFF by default:
 # measured a wash -- 13.12 vs 13.08 ms per step with it on: the tiled kernels are VALU-bound, so the +17 us (backward) / +2 us (forward)
@@ -333,6 +334,7 @@ class Graph:
         self._wstream = None          # side stream for weight-gradient kernels (nothing downstream in backward needs them)
         self._pending: Dict[int, torch.cuda.Event] = {}     # gradient storage -> last weight-gradient kernel still reading it
         self._keep: list = []
+        self._ln_pending: list = []                          # LayerNorm backward launches whose dgamma / dbeta partials wait for the leg's fold
         self.cur = torch.cuda.current_stream(device) if torch.device(device).type == "cuda" else None
         self.stream = self.cur.cuda_stream if self.cur is not None else 0
         self.n_launch = 0
@@ -460,6 +462,7 @@ class Graph:
             if entry[0] == "mark":
                 if entry[1] == until:
                     self.cur, self.stream = main
+                    self._flush_ln_folds()
                     if self._wstream is not None:
                         for ws in self._wstream:
                             self.cur.wait_stream(ws)
@@ -481,6 +484,7 @@ class Graph:
                     with _Branch(self, st):
                         fn()
         self.cur, self.stream = main
+        self._flush_ln_folds()
         if self._wstream is not None:
             for ws in self._wstream:
                 self.cur.wait_stream(ws)                 # all weight gradients are in the arena before anything follows
@@ -489,6 +493,19 @@ class Graph:
         self.tape = []
         self._zeros.close()
         return True
+
+    def _flush_ln_folds(self):
+        """One launch adds the parked dgamma / dbeta partials of every LayerNorm backward since the last flush (tc_layernorm_fold)."""
+        if not self._ln_pending:
+            return
+        from ._lib import TcLnFold
+        arr = (TcLnFold * len(self._ln_pending))()
+        for i, (part, dg, db, gs, nblk, Cc, Gn) in enumerate(self._ln_pending):
+            arr[i].part, arr[i].dgamma, arr[i].dbeta, arr[i].pstride = _ptr(part), _ptr(dg), _ptr(db), gs
+            arr[i].nblk, arr[i].C, arr[i].groups = nblk, Cc, Gn
+        self.n_launch += 1
+        self.L.tc_layernorm_fold(arr, len(self._ln_pending), self.stream)
+        self._ln_pending = []                    # (the buffers may go back to the allocator now: whatever reuses them runs after this launch)
 
     def _rec(self, fn):
         if self.record:
@@ -1059,6 +1076,18 @@ class Graph:
                 return
             gx, acc = self.wgrad(x)
             fused = g.grad is not None and not (self.overlap_wgrad and self.use_streams)
+            nblk = int(self.L.tc_layernorm_bwd_nblk(rows, Cc)) if (fused and _LN_DEFER) else 0
+            if nblk > 0:                                 # dx + per-workgroup dgamma / dbeta partials; the partials of ALL LayerNorms of a backward
+                nf = Gn * nblk * 2 * Cc                  # leg are added up by one launch when the leg ends (_flush_ln_folds)
+                part = self.f32(nf)
+                _timed("hbm:layernorm_bwd", (3.0 + acc) * x.rows * Cc * es, lambda: self.L.tc_layernorm_bwd_defer(
+                    _ptr(dy), dy.stride(0), _ptr(x.data), x.ld, _ptr(g.data), _ptr(b.data), _ptr(mean), _ptr(rstd), _ptr(gx), gx.stride(0),
+                    _ptr(gx) if acc else None, gx.stride(0), _ptr(g.grad), _ptr(b.grad), rows, Cc, act, Gn, g.gs, _ptr(part), nf, self.dt,
+                    self.stream))
+                self._ln_pending.append((part, g.grad, b.grad, g.gs, nblk, Cc, Gn))
+                if len(self._ln_pending) == 64:
+                    self._flush_ln_folds()
+                return
             if fused:                                    # one pass: dx + per-workgroup dgamma/dbeta partials + a tiny folding launch
                 ws = _workspace(self.dev, self.stream)
                 scratch, n = ws, ws.numel() // 4
