@@ -277,7 +277,9 @@ __device__ __forceinline__ void epilogue_cols(const GemmDev& p, f32x16 (&acc)[TM
                 }
                 TC* c = C + (long long)row * p.ldc + col;
                 if (atomic) {
+#ifndef TC_DBG_GEMM_NOATOMIC                                       // what-if build (scripts/exp): the weight-gradient atomics dropped, timing only
                     atomicAdd(reinterpret_cast<float*>(c), v);
+#endif
                 } else {
                     if (p.act == TC_ACT_SIGMOID) v = sigmoid_f(v);
                     else if (p.act == TC_ACT_SCALE) v *= p.alpha;
