@@ -196,6 +196,18 @@ int tc_dwconv_bwd_weight(const void* dy, int lddy, const void* x, int ldx, float
                          long long ws_bytes, int dtype, void* stream);
 /* Both gradients of a stride-1 convolution in ONE launch (same arguments and semantics as the two entries above; falls back to them when
  * the operands do not allow the 16-byte tile kernels): the two launches read the same dy and do not depend on each other. */
+/* Deferred weight gradients: with ws_bytes < 0, ws is a buffer of the caller's own (>= tc_dwconv_bwd_part_floats() floats, -ws_bytes bytes;
+ * 0 floats: this shape cannot defer) in which tc_dwconv_bwd leaves the per-workgroup sums instead of folding them at its tail; tc_dw_fold adds
+ * the sums of up to 64 such launches to their dw / db in ONE launch (the host calls it when a backward sweep stops or ends). */
+typedef struct {
+    const float* part; float* dw; float* db;   /* the launch's sums; its dw / db (db may be NULL), group g at + g * wstride */
+    long long wstride;
+    int C, k, groups;
+    int ch, chunks, gx;                        /* geometry of the sums ([group * chunks + chunk][gx walkers][k*k + 1 taps][ch channels]): filled by the plans */
+} TcDwFold;
+/* floats the launch will leave (0: this shape cannot defer); fill *site's geometry */
+long long tc_dwconv_bwd_plan(int B, int H, int W, int C, int k, int groups, int dtype, TcDwFold* site);
+int tc_dw_fold(const TcDwFold* sites, int n, void* stream);
 int tc_dwconv_bwd(const void* dy, int lddy, const void* x, int ldx, const void* w, void* dx, int lddx, float* dw, float* db, int B, int H,
                   int W, int C, int k, int add_input, int accumulate, int groups, long long wstride, void* ws, long long ws_bytes,
                   int dtype, void* stream);
@@ -213,6 +225,9 @@ typedef struct TcDwSeg {
 } TcDwSeg;
 int tc_dwconv_multi(const TcDwSeg* segs, int nseg, int mode, int add_input, int accumulate, int groups, long long wstride,
                     void* ws, long long ws_bytes, int dtype, void* stream);
+/* Deferred weight gradients of a mode 2 / 3 launch (ws_bytes < 0, as tc_dwconv_bwd): total floats the launch will leave (0: cannot defer);
+ * sites[i] gets segment i's geometry and offs[i] its offset (floats) into the one buffer -- the caller sets part / dw / db / wstride. */
+long long tc_dwconv_multi_plan(const TcDwSeg* segs, int nseg, int groups, int dtype, TcDwFold* sites, long long* offs);
 
 /* ------------------------------------------------------------------------------------------
  * MixFFN_skip middle (MSTr.py:889-902 with DWConv :21-31): between fc1 and fc2 the reference runs dw3x3(+bias) + skip, LayerNorm(4C),

@@ -165,6 +165,36 @@ def test_layernorm_deferred_parameter_fold(rows, C, monkeypatch):
     close(res[True][2], br.grad, 3e-4 * max(1.0, float(br.grad.abs().max())), 3e-4, "dbeta vs torch")
 
 
+@pytest.mark.parametrize("C,H,k,bias", [(64, 28, 3, True), (128, 14, 3, False), (320, 7, 3, True), (48, 14, 5, True)])
+def test_dwconv_deferred_weight_gradient_fold(C, H, k, bias, monkeypatch):
+    """tc_dwconv_bwd with its walkers' sums parked (ws_bytes < 0) + tc_dw_fold (the default) against the launch that folds at its own tail
+    (TC_DW_DEFER=0): the same dx bit for bit, dw / db to summation order; a convolution used twice accumulates both contributions."""
+    from transception_amd import engine
+    from transception_amd.engine import Graph
+    B = 4
+    x, w, gy = T(f"dwd.x{C}.{H}", (B * H * H, C)), T(f"dwd.w{C}.{k}", (C, 1, k, k), 0.3), T(f"dwd.g{C}.{H}", (B * H * H, C))
+    b = T(f"dwd.b{C}", (C,), 0.1) if bias else None
+    res = {}
+    for defer in (True, False):
+        monkeypatch.setattr(engine, "_DW_DEFER", defer)
+        G = Graph(torch.float32, torch.device(DEV), training=True, record=True)
+        xv, wp = mkV(G, x), mkP(w)
+        bp = mkP(b) if bias else None
+        o1 = G.dwconv(xv, wp, bp, B, H, H, k, 1, False)
+        o2 = G.dwconv(o1, wp, bp, B, H, H, k, 1, False)      # the same weights a second time
+        run_bwd(G, o2, gy)
+        res[defer] = (G.grad_of(xv).clone(), wp.grad.clone(), bp.grad.clone() if bias else None)
+    assert torch.equal(res[True][0], res[False][0])
+    close(res[True][1], res[False][1].cpu(), 1e-5 * max(1.0, float(res[False][1].abs().max())), 1e-5, "dw")
+    if bias:
+        close(res[True][2], res[False][2].cpu(), 1e-5 * max(1.0, float(res[False][2].abs().max())), 1e-5, "db")
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    br = b.clone().requires_grad_() if bias else None
+    conv = lambda t: F.conv2d(t.view(B, H, H, C).permute(0, 3, 1, 2), wr, br, padding=k // 2, groups=C).permute(0, 2, 3, 1).reshape(B * H * H, C)
+    conv(conv(xr)).backward(gy)
+    close(res[True][1], wr.grad, 3e-4 * max(1.0, float(wr.grad.abs().max())), 3e-4, "dw vs torch")
+
+
 @pytest.mark.parametrize("C,H,k,stride,bias,add", [(64, 12, 3, 1, True, True), (64, 12, 3, 2, False, False), (24, 9, 5, 1, True, False),
                                                     (120, 7, 7, 1, True, False), (256, 14, 3, 1, True, True), (16, 28, 3, 1, True, False)])
 def test_dwconv(G, C, H, k, stride, bias, add):

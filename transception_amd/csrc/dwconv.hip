@@ -772,9 +772,20 @@ __device__ __forceinline__ void dw_tile_wgrad_body(const T* __restrict__ x, int 
         }
     }
     __syncthreads();
+#ifdef TC_DBG_DW_NOFOLD                                            // what-if build (scripts/exp): weight gradients dropped, timing only
+    return;
+#endif
     float* lflat = &lacc[0][0];
     int gm = 1;
     const float* pgroup = nullptr;
+    if (ws_part && !ws_cnt) {
+        // Deferred (tc_dwconv_bwd with ws_bytes < 0): the sums go, plainly, to a buffer of this launch's own -- [group * chunks + chunk][walker]
+        // [tap][channel] -- and tc_dw_fold adds the walkers of every such launch of a backward leg in one launch: no write-through stores, no
+        // arrival counter, no last-arriver fold and no contended atomics at the tail of every launch (0.19 ms of a 12.2 ms step).
+        float* part = ws_part + ((long long)(bz * gy + by) * gx + bx) * (NT * CH);
+        for (int f = threadIdx.x; f < NT * CH; f += 256) part[f] = lflat[f];
+        return;
+    }
     if (ws_part) {
         // Two-level fold (same protocol as the GEMM split-K fix-up): the workgroups of a (group, channel chunk) park their sums in
         // the workspace, 16 consecutive ones share an arrival counter, the last to arrive adds the 16 and is the only one that
@@ -915,7 +926,10 @@ int launch_tile_bwd(const void* dy, int lddy, const void* w, void* dx, int lddx,
         gx = gx < 1 ? 1 : gx;                                                                                                           \
         constexpr int NTC = ((KK) * (KK) + 1) * (CGG) * VEC;                                                                            \
         float* wp = nullptr; int* wc = nullptr;                                                                                         \
-        if (ws && (uintptr_t)ws % 16 == 0 && ws_bytes >= 16384 + (long long)chunks * groups * gx * NTC * 4 &&                            \
+        if (ws && ws_bytes < 0) {                                  /* deferred: the caller's own buffer, folded later by tc_dw_fold */   \
+            if (-ws_bytes < (long long)chunks * groups * gx * NTC * 4 || (uintptr_t)ws % 16) return TC_ERR_ARG;                          \
+            wp = reinterpret_cast<float*>(ws);                                                                                          \
+        } else if (ws && (uintptr_t)ws % 16 == 0 && ws_bytes >= 16384 + (long long)chunks * groups * gx * NTC * 4 &&                     \
             (long long)chunks * groups * ((gx + DW_FOLD - 1) / DW_FOLD) <= 4096) {                                                      \
             wc = reinterpret_cast<int*>(ws); wp = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + 16384);                         \
         }                                                                                                                               \
@@ -1047,7 +1061,9 @@ int launch_multi(const TcDwSeg* segs, int nseg, int mode, int add_input, int acc
     long long blk = 0, part_floats = 0, cnts = 0;
     int smem_q = 0;
     const bool wgm = mode >= 2;                                  // weight-gradient walkers in the grid (mode 3: followed by the input-gradient tiles)
-    const bool have_ws = wgm && ws && (uintptr_t)ws % 16 == 0 && ws_bytes > 16384;
+    const bool defer = wgm && ws && ws_bytes < 0;                // the walkers' sums go to the caller's own buffer (tc_dw_fold adds them later)
+    if (defer && (uintptr_t)ws % 16) return TC_ERR_ARG;
+    const bool have_ws = !defer && wgm && ws && (uintptr_t)ws % 16 == 0 && ws_bytes > 16384;
     long long total_work = 0;
     for (int i = 0; i < nseg; ++i) {
         const int cg = dw_pick_cg<T>(segs[i].C), TH = (256 / cg) / 4;
@@ -1077,6 +1093,7 @@ int launch_multi(const TcDwSeg* segs, int nseg, int mode, int add_input, int acc
             const long long nt_ch = (long long)(g.k * g.k + 1) * d.cg * VEC;
             d.wsc = have_ws ? reinterpret_cast<int*>(ws) + cnts : nullptr;
             d.wsp = have_ws ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + 16384) + part_floats : nullptr;
+            if (defer) d.wsp = reinterpret_cast<float*>(ws) + part_floats;
             cnts += (long long)d.chunks * groups * ((gx + DW_FOLD - 1) / DW_FOLD);
             part_floats += (long long)d.chunks * groups * gx * nt_ch;
         } else {
@@ -1089,6 +1106,7 @@ int launch_multi(const TcDwSeg* segs, int nseg, int mode, int add_input, int acc
         smem_q = q2 > smem_q ? q2 : smem_q;
     }
     if (blk > 0x7fffffffLL) return TC_ERR_ARG;
+    if (defer && part_floats * 4 > -ws_bytes) return TC_ERR_ARG;
     if (wgm && have_ws && (cnts > 4096 || 16384 + part_floats * 4 > ws_bytes))
         for (int i = 0; i < nseg; ++i) { a.s[i].wsc = nullptr; a.s[i].wsp = nullptr; }
     const size_t smem = (size_t)smem_q * 16;
@@ -1566,6 +1584,105 @@ extern "C" int tc_dwconv_bwd_input(const void* dy, int lddy, const void* w, void
 extern "C" int tc_dwconv_bwd_weight(const void* dy, int lddy, const void* x, int ldx, float* dw, float* db, int B, int H, int W, int C,
                                     int k, int stride, int groups, long long wstride, void* ws, long long ws_bytes, int dtype, void* stream);
 /* see include/transception_hip.h */
+// ---- deferred weight-gradient fold of tc_dwconv_bwd (ws_bytes < 0) --------------------------------------------------------------------
+namespace {
+struct DwGeom { int cg, ch, chunks, gx, nt; };
+template <typename T> DwGeom dw_bwd_geom(int B, int H, int W, int C, int k, int groups) {     // launch_tile_bwd's numbers
+    constexpr int VEC = Vec16<T>::N;
+    DwGeom g;
+    g.cg = dw_pick_cg<T>(C); g.ch = g.cg * VEC; g.chunks = (C + g.ch - 1) / g.ch;
+    const int TH = (256 / g.cg) / 4, tilesW = (W + 15) / 16, tilesH = (H + TH - 1) / TH;
+    const long long ntiles = (long long)B * tilesW * tilesH;
+    long long gx = tc_dw_wg_target() / (g.chunks * groups);
+    if (gx > ntiles) gx = ntiles;
+    g.gx = (int)(gx < 1 ? 1 : gx); g.nt = k * k + 1;
+    return g;
+}
+constexpr int DWF_SITES = 64;
+struct DwFoldSite { const float* part; float* dw; float* db; long long wstride; int C, kk, ch, chunks, gx, nt, groups, blk0; };
+struct DwFoldDev { DwFoldSite s[DWF_SITES]; int n; };
+// workgroup = one (site, group, channel chunk): thread f = (tap, channel) adds its walkers' sums
+__global__ __launch_bounds__(256) void dw_fold_kernel(const DwFoldDev q) {
+    int si = 0;
+    for (int i = 1; i < q.n; ++i) if ((int)blockIdx.x >= q.s[i].blk0) si = i;
+    const DwFoldSite& t = q.s[si];
+    const int chain = blockIdx.x - t.blk0, g = chain / t.chunks, c0 = (chain - g * t.chunks) * t.ch, ntc = t.nt * t.ch;
+    const float* p = t.part + (long long)chain * t.gx * ntc;
+    for (int f = threadIdx.x; f < ntc; f += 256) {
+        const int tap = f / t.ch, ch = c0 + (f - tap * t.ch);
+        if (ch >= t.C) continue;
+        float v = 0.f;
+        int m = 0;
+        for (; m + 8 <= t.gx; m += 8) {
+            float tmp[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) tmp[e] = p[(long long)(m + e) * ntc + f];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v += tmp[e];
+        }
+        for (; m < t.gx; ++m) v += p[(long long)m * ntc + f];
+        if (tap < t.kk) atomicAdd(t.dw + g * t.wstride + (long long)ch * t.kk + tap, v);      // (shared modules: a weight may have two writers)
+        else if (t.db) atomicAdd(t.db + g * t.wstride + ch, v);
+    }
+}
+}  // namespace
+
+extern "C" long long tc_dwconv_bwd_plan(int B, int H, int W, int C, int k, int groups, int dtype, TcDwFold* site) {
+    if (!site || groups < 1 || !dw_args_ok(B, H, W, C, k, 1, 0)) return 0;
+    TC_DISPATCH_DTYPE(dtype, {
+        constexpr int VEC = Vec16<T>::N;
+        if (C % VEC) return 0;
+        const DwGeom g = dw_bwd_geom<T>(B, H, W, C, k, groups);
+        site->C = C; site->k = k; site->groups = groups; site->ch = g.ch; site->chunks = g.chunks; site->gx = g.gx;
+        return (long long)g.chunks * groups * g.gx * g.nt * g.ch;
+    });
+    return 0;
+}
+
+// the same for the weight-gradient walkers of a tc_dwconv_multi launch (mode 2 or 3): sites[i] / offs[i] (floats into the one buffer) per segment
+extern "C" long long tc_dwconv_multi_plan(const TcDwSeg* segs, int nseg, int groups, int dtype, TcDwFold* sites, long long* offs) {
+    if (!segs || !sites || !offs || nseg < 1 || nseg > DW_MULTI_MAX || groups < 1) return 0;
+    long long total = 0;
+    TC_DISPATCH_DTYPE(dtype, {
+        constexpr int VEC = Vec16<T>::N;
+        long long total_work = 0;
+        for (int i = 0; i < nseg; ++i) {
+            if (segs[i].C % VEC || !dw_args_ok(segs[i].B, segs[i].H, segs[i].W, segs[i].C, segs[i].k, 1, 0)) return 0;
+            const int cg = dw_pick_cg<T>(segs[i].C), TH = (256 / cg) / 4;
+            total_work += (long long)segs[i].B * ((segs[i].W + 15) / 16) * ((segs[i].H + TH - 1) / TH) * ((segs[i].C + cg * VEC - 1) / (cg * VEC)) *
+                          (segs[i].k + 2);
+        }
+        for (int i = 0; i < nseg; ++i) {                         // launch_multi's numbers
+            const TcDwSeg& g = segs[i];
+            const int cg = dw_pick_cg<T>(g.C), ch = cg * VEC, chunks = (g.C + ch - 1) / ch, TH = (256 / cg) / 4;
+            const long long ntiles = (long long)g.B * ((g.W + 15) / 16) * ((g.H + TH - 1) / TH);
+            long long gx = (long long)((double)tc_dw_wg_target() * (double)ntiles * (g.k + 2) / (double)(total_work > 0 ? total_work : 1) / groups + 0.5);
+            gx = gx < 1 ? 1 : (gx > ntiles ? ntiles : gx);
+            sites[i].C = g.C; sites[i].k = g.k; sites[i].groups = groups; sites[i].ch = ch; sites[i].chunks = chunks; sites[i].gx = (int)gx;
+            offs[i] = total;
+            total += (long long)chunks * groups * gx * (g.k * g.k + 1) * ch;
+        }
+        return total;
+    });
+    return 0;
+}
+
+extern "C" int tc_dw_fold(const TcDwFold* sites, int n, void* stream) {
+    if (!sites || n < 1 || n > DWF_SITES) return TC_ERR_ARG;
+    DwFoldDev q;
+    q.n = n;
+    int blk = 0;
+    for (int i = 0; i < n; ++i) {
+        const TcDwFold& t = sites[i];
+        if (!t.part || !t.dw || t.groups < 1 || t.C < 1 || (t.k != 3 && t.k != 5 && t.k != 7)) return TC_ERR_ARG;
+        if (t.gx < 1 || t.ch < 1 || t.chunks != (t.C + t.ch - 1) / t.ch) return TC_ERR_ARG;
+        q.s[i] = DwFoldSite{t.part, t.dw, t.db, t.wstride, t.C, t.k * t.k, t.ch, t.chunks, t.gx, t.k * t.k + 1, t.groups, blk};
+        blk += t.chunks * t.groups;
+    }
+    hipLaunchKernelGGL(dw_fold_kernel, dim3(blk), dim3(256), 0, (hipStream_t)stream, q);
+    return tc_launch_status();
+}
+
 extern "C" int tc_dwconv_bwd(const void* dy, int lddy, const void* x, int ldx, const void* w, void* dx, int lddx, float* dw, float* db, int B, int H,
                              int W, int C, int k, int add_input, int accumulate, int groups, long long wstride, void* ws, long long ws_bytes,
                              int dtype, void* stream) {
@@ -1575,6 +1692,7 @@ extern "C" int tc_dwconv_bwd(const void* dy, int lddy, const void* x, int ldx, c
             return (launch_tile_bwd<T>(dy, lddy, w, dx, lddx, x, ldx, dw, db, B, H, W, C, k, add_input, accumulate, groups, wstride, (hipStream_t)stream,
                                        ws, ws_bytes));
     });
+    if (ws_bytes < 0) return TC_ERR_ARG;                        // deferred sums exist only in the tile kernels (16-byte addressable operands)
     const int rc = tc_dwconv_bwd_input(dy, lddy, w, dx, lddx, B, H, W, C, k, 1, add_input, accumulate, groups, wstride, dtype, stream);
     return rc != TC_OK ? rc : tc_dwconv_bwd_weight(dy, lddy, x, ldx, dw, db, B, H, W, C, k, 1, groups, wstride, ws, ws_bytes, dtype, stream);
 }

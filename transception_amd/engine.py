@@ -190,6 +190,7 @@ _SKIP_WGRAD = bool(os.environ.get("TC_DEBUG_SKIP_WGRAD"))
 _FFN_STORE_ACT = os.environ.get("TC_FFN_STORE_ACT", "1") != "0"   # MixFFN: keep GELU(LN(d)) from the forward pass (0: recompute it in dW2's loader)
 _FFN_LN_GEMM_MAXC = int(os.environ.get("TC_FFN_LN_GEMM_MAXC", "64"))  # widest fc2 output for which LayerNorm + GELU run in its A loader
 _FFN_TILED = os.environ.get("TC_FFN_TILED", "1") != "0"        # MixFFN forward as one spatially tiled kernel where the library supports the width (csrc/mixffn.hip)
+_DW_DEFER = os.environ.get("TC_DW_DEFER", "1") != "0"                  # depthwise weight-gradient sums folded once per backward leg (tc_dw_fold)
 _LN_DEFER = os.environ.get("TC_LN_DEFER", "1") != "0"                  # LayerNorm dgamma / dbeta partials folded once per backward leg (tc_layernorm_fold) instead of at every launch's tail
 _EFFATT_FUSED = os.environ.get("TC_EFFATT_FUSED", "1") != "0"        # EfficientAttention blocks through csrc/effatt.hip where the library supports the width
 # The LayerNorm ahead of a MixFFN site (the block's norm2) inside the tiled kernels (both directions tiled: C = 64).  OFF by default:
@@ -335,6 +336,7 @@ class Graph:
         self._pending: Dict[int, torch.cuda.Event] = {}     # gradient storage -> last weight-gradient kernel still reading it
         self._keep: list = []
         self._ln_pending: list = []                          # LayerNorm backward launches whose dgamma / dbeta partials wait for the leg's fold
+        self._dw_pending: list = []                          # depthwise backward launches whose weight-gradient sums wait for the leg's fold
         self.cur = torch.cuda.current_stream(device) if torch.device(device).type == "cuda" else None
         self.stream = self.cur.cuda_stream if self.cur is not None else 0
         self.n_launch = 0
@@ -494,8 +496,19 @@ class Graph:
         self._zeros.close()
         return True
 
+    def _flush_dw_folds(self):
+        """One launch adds the parked walker sums of every depthwise weight gradient since the last flush (tc_dw_fold)."""
+        from ._lib import TcDwFold
+        for c0 in range(0, len(self._dw_pending), 64):
+            chunk = self._dw_pending[c0:c0 + 64]
+            arr = (TcDwFold * len(chunk))(*[site for site, _ in chunk])
+            self.n_launch += 1
+            self.L.tc_dw_fold(arr, len(chunk), self.stream)
+        self._dw_pending = []
+
     def _flush_ln_folds(self):
         """One launch adds the parked dgamma / dbeta partials of every LayerNorm backward since the last flush (tc_layernorm_fold)."""
+        self._flush_dw_folds()
         if not self._ln_pending:
             return
         from ._lib import TcLnFold
@@ -1151,6 +1164,21 @@ class Graph:
                 return
             if x.requires_grad and w.grad is not None and stride == 1 and _DW_BWD_ONE and not (self.overlap_wgrad and self.use_streams):
                 gx, acc = self.wgrad(x)                       # both gradients in one launch (they share dy and nothing else)
+                vec = 16 // es
+                from ._lib import TcDwFold
+                site = TcDwFold()
+                nf = (int(self.L.tc_dwconv_bwd_plan(B, H, W, Cc, k, Gn, self.dt, C.byref(site)))
+                      if (_DW_DEFER and not (x.ld % vec or dy.stride(0) % vec or gx.stride(0) % vec or _ptr(dy) % 16 or _ptr(x.data) % 16 or _ptr(gx) % 16))
+                      else 0)
+                if nf > 0:                                    # the walkers' sums parked in a buffer of this launch's own; one tc_dw_fold per backward leg
+                    part = self.f32(nf)
+                    _timed("hbm:dwconv_bwd (input + weight gradient, one launch)", (2.0 * x.rows * (1 + acc) + 2.0 * out.rows) * Cc * es,
+                           lambda: self.L.tc_dwconv_bwd(_ptr(dy), dy.stride(0), _ptr(x.data), x.ld, _ptr(w.data), _ptr(gx), gx.stride(0), _ptr(w.grad),
+                                                        _ptr(b.grad) if b is not None else None, B, H, W, Cc, k, int(add_input), acc, Gn, w.gs,
+                                                        _ptr(part), -4 * nf, self.dt, self.stream))
+                    site.part, site.dw, site.db, site.wstride = _ptr(part), _ptr(w.grad), _ptr(b.grad) if b is not None else None, w.gs
+                    self._dw_pending.append((site, part))
+                    return
                 ws = _workspace(self.dev, self.stream)
                 _timed("hbm:dwconv_bwd (input + weight gradient, one launch)", (2.0 * x.rows * (1 + acc) + 2.0 * out.rows) * Cc * es,
                        lambda: self.L.tc_dwconv_bwd(_ptr(dy), dy.stride(0), _ptr(x.data), x.ld, _ptr(w.data), _ptr(gx), gx.stride(0), _ptr(w.grad),
@@ -1204,11 +1232,25 @@ class Graph:
                 g = [self.wgrad(x) for x in xs]                   # input and weight gradients of all segments in one launch
                 acc = g[0][1]
                 assert all(a == acc for _, a in g)
+                sg = segs([_ptr(x.data) for x in xs], wd, none, [_ptr(t) for t, _ in g], [_ptr(d) for d in dys],
+                          [_ptr(w.grad) for w in ws], [_ptr(b.grad) if b is not None else None for b in bs],
+                          [x.ld for x in xs], [t.stride(0) for t, _ in g], ldd)
+                if _DW_DEFER:                                  # the walkers' sums parked; one tc_dw_fold per backward leg
+                    from ._lib import TcDwFold
+                    sites, offs = (TcDwFold * n)(), (C.c_longlong * n)()
+                    nf = int(self.L.tc_dwconv_multi_plan(sg, n, Gn, self.dt, sites, offs))
+                    if nf > 0:
+                        part = self.f32(nf)
+                        self.L.tc_dwconv_multi(sg, n, 3, int(add_input), acc, Gn, gs, _ptr(part), -4 * nf, self.dt, self.stream)
+                        for i in range(n):
+                            st = TcDwFold()
+                            C.memmove(C.byref(st), C.byref(sites[i]), C.sizeof(TcDwFold))
+                            st.part, st.dw, st.wstride = _ptr(part) + 4 * offs[i], _ptr(ws[i].grad), gs
+                            st.db = _ptr(bs[i].grad) if bs[i] is not None else None
+                            self._dw_pending.append((st, part))
+                        return
                 wk = _workspace(self.dev, self.stream)
-                self.L.tc_dwconv_multi(segs([_ptr(x.data) for x in xs], wd, none, [_ptr(t) for t, _ in g], [_ptr(d) for d in dys],
-                                            [_ptr(w.grad) for w in ws], [_ptr(b.grad) if b is not None else None for b in bs],
-                                            [x.ld for x in xs], [t.stride(0) for t, _ in g], ldd), n, 3, int(add_input), acc, Gn, gs,
-                                       wk.data_ptr(), wk.numel(), self.dt, self.stream)
+                self.L.tc_dwconv_multi(sg, n, 3, int(add_input), acc, Gn, gs, wk.data_ptr(), wk.numel(), self.dt, self.stream)
                 return
             if xs[0].requires_grad:
                 g = [self.wgrad(x) for x in xs]
