@@ -10,8 +10,8 @@
 
 namespace {
 // workgroups a weight-gradient launch aims for (A/B switches; defaults = one tile walker per CU)
-inline int tc_dw_wg_target() { static const int v = getenv("TC_DW_WG") ? atoi(getenv("TC_DW_WG")) : 256; return v; }
-inline int tc_mid_wg_target() { static const int v = getenv("TC_MID_WG") ? atoi(getenv("TC_MID_WG")) : 256; return v; }
+inline int tc_dw_wg_target() { static const int v = getenv("TC_DW_WG") ? atoi(getenv("TC_DW_WG")) : 512; return v; }   // 256 while every launch folded at its tail; with the deferred fold: 12.07 / 12.03 / 12.01 / 12.03 ms at 256 / 384 / 512 / 768
+inline int tc_mid_wg_target() { static const int v = getenv("TC_MID_WG") ? atoi(getenv("TC_MID_WG")) : 384; return v; }   // (re-swept with the other two: 256 / 384 / 512 -> 12.07 / 12.03 / 12.06 ms)
 
 
 // STRIDE is a template parameter (the strided form serves the first depthwise convolution of every RIPM stage, stride 2): with a run-time

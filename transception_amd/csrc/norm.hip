@@ -11,7 +11,7 @@ constexpr int LN_MAXC = 2048;
 #define LN_FOLD 8
 #endif
 constexpr int LN_BWD_MAX_BLOCKS = 1024, LN_BWD_ROWS_PER_GROUP = 4;   // fused dx + parameter-gradient launch
-inline int ln_bwd_wg_min() { static const int v = getenv("TC_LN_WG_MIN") ? atoi(getenv("TC_LN_WG_MIN")) : 512; return v < 16 ? 16 : v; }
+inline int ln_bwd_wg_min() { static const int v = getenv("TC_LN_WG_MIN") ? atoi(getenv("TC_LN_WG_MIN")) : 1024; return v < 16 ? 16 : v; }   // 512 with the fold at the tail; deferred: 256 / 512 / 1024 -> 12.11 / 12.07 / 12.04 ms
 inline int ln_bwd_blocks() {   // A/B switch (<= LN_BWD_MAX_BLOCKS, which sizes the scratch)
     static const int v = getenv("TC_LN_BWD_BLOCKS") ? atoi(getenv("TC_LN_BWD_BLOCKS")) : LN_BWD_MAX_BLOCKS;
     return v < 16 ? 16 : (v > LN_BWD_MAX_BLOCKS ? LN_BWD_MAX_BLOCKS : v);
