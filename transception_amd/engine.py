@@ -180,8 +180,7 @@ def _workspace(device, stream_ptr: int, tag: str = "") -> torch.Tensor:
 
 _SPLITK_CAP = int(os.environ.get("TC_SPLITK_CAP", "128"))
 _SPLITK_BLOCKS = int(os.environ.get("TC_SPLITK_BLOCKS", "512"))
-_SPLITK_CAP = int(os.environ.get("TC_SPLITK_CAP", "128"))
-_SPLITK_BLOCKS = int(os.environ.get("TC_SPLITK_BLOCKS", "512"))
+_SPLITK_KMIN = int(os.environ.get("TC_SPLITK_KMIN", "384"))              # shortest K range of a split of a weight-gradient product: 256 / 320 / 384 / 448 / 512 -> 12.00 / 11.94 / 11.95 / 12.11 / 12.20 ms (fewer fp32 atomics against longer serial K loops)
 _THR128 = int(os.environ.get("TC_GEMM_THR128", "100000"))     # keep in step with gemm.hip (gemm_plan)
 _GEMM_PAIR = os.environ.get("TC_GEMM_PAIR", "1") != "0"
 _N_WSTREAMS = int(os.environ.get("TC_WGRAD_STREAMS", "4"))
@@ -552,7 +551,7 @@ class Graph:
     def _splitk(m_out: int, n_out: int, k_red: int) -> int:
         tiles = ((m_out + 63) // 64) * ((n_out + 63) // 64)
         cap = _SPLITK_CAP if k_red < 262144 else 1024      # > 128: tc_gemm folds groups of 16 splits through the workspace
-        return max(1, min(max(_SPLITK_BLOCKS, cap) // max(tiles, 1), k_red // 256, cap))
+        return max(1, min(max(_SPLITK_BLOCKS, cap) // max(tiles, 1), k_red // _SPLITK_KMIN, cap))
 
     # ------------------------------------------------------------------ ops
     def linear(self, x: Var, W: P, b: Optional[P] = None, out: Optional[Var] = None, residual: Optional[Var] = None,
