@@ -201,9 +201,10 @@ int tc_dwconv_bwd_weight(const void* dy, int lddy, const void* x, int ldx, float
  * the sums of up to 64 such launches to their dw / db in ONE launch (the host calls it when a backward sweep stops or ends). */
 typedef struct {
     const float* part; float* dw; float* db;   /* the launch's sums; its dw / db (db may be NULL), group g at + g * wstride */
+    float* dgamma; float* dbeta;               /* tc_ffn_mid_bwd only (nt = k*k + 3), else NULL */
     long long wstride;
     int C, k, groups;
-    int ch, chunks, gx;                        /* geometry of the sums ([group * chunks + chunk][gx walkers][k*k + 1 taps][ch channels]): filled by the plans */
+    int ch, chunks, gx, nt;                    /* geometry of the sums ([group * chunks + chunk][gx walkers][nt taps][ch channels]): filled by the plans */
 } TcDwFold;
 /* floats the launch will leave (0: this shape cannot defer); fill *site's geometry */
 long long tc_dwconv_bwd_plan(int B, int H, int W, int C, int k, int groups, int dtype, TcDwFold* site);
@@ -252,6 +253,9 @@ typedef struct TcFfnSeg {
 } TcFfnSeg;
 int tc_ffn_mid_bwd(const TcFfnSeg* segs, int nseg, int groups, long long wstride, void* ws, long long ws_bytes, int dtype,
                    void* stream);
+/* Deferred parameter gradients of a tc_ffn_mid_bwd launch (ws_bytes < 0, as tc_dwconv_bwd): total floats it will leave (0: cannot defer);
+ * sites[i] / offs[i] as tc_dwconv_multi_plan -- the caller sets part, dw, db, dgamma, dbeta and wstride, tc_dw_fold adds them. */
+long long tc_ffn_mid_plan(const TcFfnSeg* segs, int nseg, int groups, int dtype, TcDwFold* sites, long long* offs);
 
 /* MixFFN_skip forward as ONE spatially tiled kernel (16-bit storage types, C = 64 or 128; see csrc/mixffn.hip):
  *   out = fc2(GELU(LayerNorm_4C(dw3x3(h) + bias + h))) + b2 + res,  h = x W1^T + b1        (MSTr.py:889-902, DWConv :21-31)

@@ -45,8 +45,8 @@ class TcDwSeg(C.Structure):
 
 
 class TcDwFold(C.Structure):
-    _fields_ = [("part", vp), ("dw", vp), ("db", vp), ("wstride", i64), ("C", i32), ("k", i32), ("groups", i32),
-                ("ch", i32), ("chunks", i32), ("gx", i32)]
+    _fields_ = [("part", vp), ("dw", vp), ("db", vp), ("dgamma", vp), ("dbeta", vp), ("wstride", i64), ("C", i32), ("k", i32), ("groups", i32),
+                ("ch", i32), ("chunks", i32), ("gx", i32), ("nt", i32)]
 
 
 class TcLnFold(C.Structure):
@@ -117,6 +117,7 @@ SIGNATURES = {
     "tc_layernorm_bwd_nblk": [i32, i32],
     "tc_dwconv_bwd_plan": [i32, i32, i32, i32, i32, i32, i32, vp],
     "tc_dwconv_multi_plan": [vp, i32, i32, i32, vp, vp],
+    "tc_ffn_mid_plan": [vp, i32, i32, i32, vp, vp],
     "tc_dw_fold": [vp, i32, vp],
     "tc_layernorm_bwd_defer": [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i64, vp, i64, i32, vp],
     "tc_layernorm_fold": [vp, i32, vp],
@@ -205,8 +206,8 @@ SIGNATURES = {
     "tc_fill_f32": [vp, i64, f32, vp],
     "tc_cast": [vp, vp, i64, i32, i32, vp],
 }
-_RET = {"tc_ffn_fused_bwd_scratch_floats": i64, "tc_effatt_scratch_floats": i64, "tc_bn_scratch_floats": i64, "tc_softmax_scratch_floats": i64, "tc_layernorm_bwd_scratch_floats": i64, "tc_dwconv_bwd_plan": i64, "tc_dwconv_multi_plan": i64, "tc_factor_att_stats_floats": i64}
-_RAW = {"tc_abi_version", "tc_effatt_supported", "tc_effatt_scratch_floats", "tc_ffn_chunk", "tc_ffn_fused_supported", "tc_ffn_fused_bwd_supported", "tc_ffn_fused_bwd_scratch_floats", "tc_bn_scratch_floats", "tc_softmax_scratch_floats", "tc_layernorm_bwd_scratch_floats", "tc_layernorm_bwd_nblk", "tc_dwconv_bwd_plan", "tc_dwconv_multi_plan", "tc_factor_att_stats_floats"}     # not status-returning
+_RET = {"tc_ffn_fused_bwd_scratch_floats": i64, "tc_effatt_scratch_floats": i64, "tc_bn_scratch_floats": i64, "tc_softmax_scratch_floats": i64, "tc_layernorm_bwd_scratch_floats": i64, "tc_dwconv_bwd_plan": i64, "tc_dwconv_multi_plan": i64, "tc_ffn_mid_plan": i64, "tc_factor_att_stats_floats": i64}
+_RAW = {"tc_abi_version", "tc_effatt_supported", "tc_effatt_scratch_floats", "tc_ffn_chunk", "tc_ffn_fused_supported", "tc_ffn_fused_bwd_supported", "tc_ffn_fused_bwd_scratch_floats", "tc_bn_scratch_floats", "tc_softmax_scratch_floats", "tc_layernorm_bwd_scratch_floats", "tc_layernorm_bwd_nblk", "tc_dwconv_bwd_plan", "tc_dwconv_multi_plan", "tc_ffn_mid_plan", "tc_factor_att_stats_floats"}     # not status-returning
 
 
 class TcError(RuntimeError):

@@ -1432,6 +1432,11 @@ __device__ __forceinline__ void ffn_mid_bwd_body(const FfnSegDev& a, long long w
     float* lflat = &lacc[0][0];
     int gm = 1;
     const float* pgroup = nullptr;
+    if (a.wsp && !a.wsc) {                                        // deferred (ws_bytes < 0): sums parked for tc_dw_fold, as dw_tile_wgrad_body
+        float* part = a.wsp + ((long long)(bz * a.chunks + by) * a.gx + bx) * (NT * CH);
+        for (int f = tid; f < NT * CH; f += NTH) part[f] = lflat[f];
+        return;
+    }
     if (a.wsp) {                                                  // two-level fold, as dw_tile_wgrad_body
         constexpr int FG = DW_FOLD;
         const int chain = bz * a.chunks + by, grp = bx / FG, ngrp = (a.gx + FG - 1) / FG;
@@ -1502,7 +1507,9 @@ int launch_ffn_mid_bwd(const TcFfnSeg* segs, int nseg, int groups, long long wst
     FfnMultiDev q;
     q.n = nseg; q.wstride = wstride; q.dbg_nofold = nofold;
     long long blk = 0, part_floats = 0, cnts = 0, total_work = 0;
-    const bool have_ws = ws && (uintptr_t)ws % 16 == 0 && ws_bytes > 16384;
+    const bool defer = ws && ws_bytes < 0;                       // the walkers' sums go to the caller's own buffer (tc_dw_fold adds them later)
+    if (defer && (uintptr_t)ws % 16) return TC_ERR_ARG;
+    const bool have_ws = !defer && ws && (uintptr_t)ws % 16 == 0 && ws_bytes > 16384;
     for (int i = 0; i < nseg; ++i)
         total_work += (long long)segs[i].B * ((segs[i].W + 15) / 16) * ((segs[i].H + D::TH - 1) / D::TH) * ((segs[i].C + D::CH - 1) / D::CH);
     for (int i = 0; i < nseg; ++i) {
@@ -1524,12 +1531,14 @@ int launch_ffn_mid_bwd(const TcFfnSeg* segs, int nseg, int groups, long long wst
         d.gx = (int)gx;
         d.wsc = have_ws ? reinterpret_cast<int*>(ws) + cnts : nullptr;
         d.wsp = have_ws ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + 16384) + part_floats : nullptr;
+        if (defer) d.wsp = reinterpret_cast<float*>(ws) + part_floats;
         cnts += (long long)d.chunks * groups * ((gx + DW_FOLD - 1) / DW_FOLD);
         part_floats += (long long)d.chunks * groups * gx * D::NT * D::CH;
         d.blk0 = (int)blk;
         blk += gx * d.chunks;
     }
     if (blk > 0x7fffffffLL) return TC_ERR_ARG;
+    if (defer && part_floats * 4 > -ws_bytes) return TC_ERR_ARG;
     if (have_ws && (cnts > 4096 || 16384 + part_floats * 4 > ws_bytes))
         for (int i = 0; i < nseg; ++i) { q.s[i].wsc = nullptr; q.s[i].wsp = nullptr; }
     const size_t smem = (size_t)D::smem_q * 16;
@@ -1599,7 +1608,7 @@ template <typename T> DwGeom dw_bwd_geom(int B, int H, int W, int C, int k, int 
     return g;
 }
 constexpr int DWF_SITES = 64;
-struct DwFoldSite { const float* part; float* dw; float* db; long long wstride; int C, kk, ch, chunks, gx, nt, groups, blk0; };
+struct DwFoldSite { const float* part; float* dw; float* db; float* dgamma; float* dbeta; long long wstride; int C, kk, ch, chunks, gx, nt, groups, blk0; };
 struct DwFoldDev { DwFoldSite s[DWF_SITES]; int n; };
 // workgroup = one (site, group, channel chunk): thread f = (tap, channel) adds its walkers' sums
 __global__ __launch_bounds__(256) void dw_fold_kernel(const DwFoldDev q) {
@@ -1622,7 +1631,9 @@ __global__ __launch_bounds__(256) void dw_fold_kernel(const DwFoldDev q) {
         }
         for (; m < t.gx; ++m) v += p[(long long)m * ntc + f];
         if (tap < t.kk) atomicAdd(t.dw + g * t.wstride + (long long)ch * t.kk + tap, v);      // (shared modules: a weight may have two writers)
-        else if (t.db) atomicAdd(t.db + g * t.wstride + ch, v);
+        else if (tap == t.kk) { if (t.db) atomicAdd(t.db + g * t.wstride + ch, v); }
+        else if (tap == t.kk + 1) { if (t.dgamma) atomicAdd(t.dgamma + g * t.wstride + ch, v); }   // tc_ffn_mid_bwd: the LayerNorm behind the convolution
+        else if (t.dbeta) atomicAdd(t.dbeta + g * t.wstride + ch, v);
     }
 }
 }  // namespace
@@ -1633,7 +1644,7 @@ extern "C" long long tc_dwconv_bwd_plan(int B, int H, int W, int C, int k, int g
         constexpr int VEC = Vec16<T>::N;
         if (C % VEC) return 0;
         const DwGeom g = dw_bwd_geom<T>(B, H, W, C, k, groups);
-        site->C = C; site->k = k; site->groups = groups; site->ch = g.ch; site->chunks = g.chunks; site->gx = g.gx;
+        site->C = C; site->k = k; site->groups = groups; site->ch = g.ch; site->chunks = g.chunks; site->gx = g.gx; site->nt = g.nt;
         return (long long)g.chunks * groups * g.gx * g.nt * g.ch;
     });
     return 0;
@@ -1659,6 +1670,7 @@ extern "C" long long tc_dwconv_multi_plan(const TcDwSeg* segs, int nseg, int gro
             long long gx = (long long)((double)tc_dw_wg_target() * (double)ntiles * (g.k + 2) / (double)(total_work > 0 ? total_work : 1) / groups + 0.5);
             gx = gx < 1 ? 1 : (gx > ntiles ? ntiles : gx);
             sites[i].C = g.C; sites[i].k = g.k; sites[i].groups = groups; sites[i].ch = ch; sites[i].chunks = chunks; sites[i].gx = (int)gx;
+            sites[i].nt = g.k * g.k + 1;
             offs[i] = total;
             total += (long long)chunks * groups * gx * (g.k * g.k + 1) * ch;
         }
@@ -1676,7 +1688,8 @@ extern "C" int tc_dw_fold(const TcDwFold* sites, int n, void* stream) {
         const TcDwFold& t = sites[i];
         if (!t.part || !t.dw || t.groups < 1 || t.C < 1 || (t.k != 3 && t.k != 5 && t.k != 7)) return TC_ERR_ARG;
         if (t.gx < 1 || t.ch < 1 || t.chunks != (t.C + t.ch - 1) / t.ch) return TC_ERR_ARG;
-        q.s[i] = DwFoldSite{t.part, t.dw, t.db, t.wstride, t.C, t.k * t.k, t.ch, t.chunks, t.gx, t.k * t.k + 1, t.groups, blk};
+        if (t.nt != t.k * t.k + 1 && t.nt != t.k * t.k + 3) return TC_ERR_ARG;
+        q.s[i] = DwFoldSite{t.part, t.dw, t.db, t.dgamma, t.dbeta, t.wstride, t.C, t.k * t.k, t.ch, t.chunks, t.gx, t.nt, t.groups, blk};
         blk += t.chunks * t.groups;
     }
     hipLaunchKernelGGL(dw_fold_kernel, dim3(blk), dim3(256), 0, (hipStream_t)stream, q);
@@ -1790,6 +1803,31 @@ extern "C" int tc_ffn_dw_fwd(const void* x, int ldx, const void* w, const void* 
 #ifdef TC_MID_TIMING
 extern "C" int tc_mid_dbg_read(long long* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_mid_dbg), sizeof(long long) * 64 * 16); }
 #endif
+// the same for tc_ffn_mid_bwd (ws_bytes < 0): per segment the walkers' geometry (taps: 9 + conv bias + dgamma + dbeta) and its offset
+extern "C" long long tc_ffn_mid_plan(const TcFfnSeg* segs, int nseg, int groups, int dtype, TcDwFold* sites, long long* offs) {
+    if (!segs || !sites || !offs || nseg < 1 || nseg > FFN_MULTI_MAX || groups < 1) return 0;
+    TC_DISPATCH_DTYPE(dtype, {
+        using D = FfnTile<T>;
+        long long total_work = 0, total = 0;
+        for (int i = 0; i < nseg; ++i)
+            total_work += (long long)segs[i].B * ((segs[i].W + 15) / 16) * ((segs[i].H + D::TH - 1) / D::TH) * ((segs[i].C + D::CH - 1) / D::CH);
+        for (int i = 0; i < nseg; ++i) {                         // launch_ffn_mid_bwd's numbers
+            const TcFfnSeg& g = segs[i];
+            if (g.C <= 0 || g.C % D::VEC) return 0;
+            const int chunks = (g.C + D::CH - 1) / D::CH;
+            const long long ntiles = (long long)g.B * ((g.W + 15) / 16) * ((g.H + D::TH - 1) / D::TH);
+            long long gx = (long long)((double)tc_mid_wg_target() * (double)ntiles / (double)(total_work > 0 ? total_work : 1) / groups + 0.5);
+            gx = gx < 1 ? 1 : (gx > ntiles ? ntiles : gx);
+            sites[i].C = g.C; sites[i].k = 3; sites[i].groups = groups; sites[i].ch = D::CH; sites[i].chunks = chunks; sites[i].gx = (int)gx;
+            sites[i].nt = D::NT;
+            offs[i] = total;
+            total += (long long)chunks * groups * gx * D::NT * D::CH;
+        }
+        return total;
+    });
+    return 0;
+}
+
 extern "C" int tc_ffn_mid_bwd(const TcFfnSeg* segs, int nseg, int groups, long long wstride, void* ws, long long ws_bytes, int dtype,
                               void* stream) {
     if (!segs || nseg < 1 || nseg > FFN_MULTI_MAX || groups < 1) return TC_ERR_ARG;

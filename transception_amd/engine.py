@@ -978,10 +978,27 @@ class Graph:
                                    _ptr(t["lg"].data), _ptr(t["wd"].grad) if hg else None, _ptr(t["bd"].grad) if hg else None,
                                    _ptr(t["lg"].grad) if hg else None, _ptr(t["lb"].grad) if hg else None,
                                    t["C4"], t["C4"], t["C4"], t["C4"], t["C4"], t["B"], t["H"], t["W"], t["nch2"])
-            ws = _workspace(self.dev, self.stream)
-            _timed("hbm:ffn_mid_bwd (MixFFN LayerNorm backward + dw3x3 input/weight gradients)",
-                   sum(4.0 * t["x"].rows * t["C4"] * t["h"].element_size() for t in st),
-                   lambda: L.tc_ffn_mid_bwd(segs, n, Gn, gs, ws.data_ptr(), ws.numel(), self.dt, self.stream))
+            nf = 0
+            if _DW_DEFER and all(t["wd"].grad is not None for t in st):     # the walkers' sums parked; one tc_dw_fold per backward leg
+                from ._lib import TcDwFold
+                sites, offs = (TcDwFold * n)(), (C.c_longlong * n)()
+                nf = int(L.tc_ffn_mid_plan(segs, n, Gn, self.dt, sites, offs))
+            if nf > 0:
+                part = self.f32(nf)
+                _timed("hbm:ffn_mid_bwd (MixFFN LayerNorm backward + dw3x3 input/weight gradients)",
+                       sum(4.0 * t["x"].rows * t["C4"] * t["h"].element_size() for t in st),
+                       lambda: L.tc_ffn_mid_bwd(segs, n, Gn, gs, _ptr(part), -4 * nf, self.dt, self.stream))
+                for i, t in enumerate(st):
+                    sf = TcDwFold()
+                    C.memmove(C.byref(sf), C.byref(sites[i]), C.sizeof(TcDwFold))
+                    sf.part, sf.wstride = _ptr(part) + 4 * offs[i], gs
+                    sf.dw, sf.db, sf.dgamma, sf.dbeta = _ptr(t["wd"].grad), _ptr(t["bd"].grad), _ptr(t["lg"].grad), _ptr(t["lb"].grad)
+                    self._dw_pending.append((sf, part))
+            else:
+                ws = _workspace(self.dev, self.stream)
+                _timed("hbm:ffn_mid_bwd (MixFFN LayerNorm backward + dw3x3 input/weight gradients)",
+                       sum(4.0 * t["x"].rows * t["C4"] * t["h"].element_size() for t in st),
+                       lambda: L.tc_ffn_mid_bwd(segs, n, Gn, gs, ws.data_ptr(), ws.numel(), self.dt, self.stream))
             # fc1: dX = dh W1, dW1 = dh^T x (+ db1)
             g2 = []
             for i, t in enumerate(st):
