@@ -198,7 +198,7 @@ int tc_dwconv_bwd_weight(const void* dy, int lddy, const void* x, int ldx, float
  * the operands do not allow the 16-byte tile kernels): the two launches read the same dy and do not depend on each other. */
 /* Deferred weight gradients: with ws_bytes < 0, ws is a buffer of the caller's own (>= tc_dwconv_bwd_part_floats() floats, -ws_bytes bytes;
  * 0 floats: this shape cannot defer) in which tc_dwconv_bwd leaves the per-workgroup sums instead of folding them at its tail; tc_dw_fold adds
- * the sums of up to 64 such launches to their dw / db in ONE launch (the host calls it when a backward sweep stops or ends). */
+ * the sums of up to 48 such launches to their dw / db in ONE launch (the host calls it when a backward sweep stops or ends). */
 typedef struct {
     const float* part; float* dw; float* db;   /* the launch's sums; its dw / db (db may be NULL), group g at + g * wstride */
     float* dgamma; float* dbeta;               /* tc_ffn_mid_bwd only (nt = k*k + 3), else NULL */

@@ -1607,9 +1607,10 @@ template <typename T> DwGeom dw_bwd_geom(int B, int H, int W, int C, int k, int 
     g.gx = (int)(gx < 1 ? 1 : gx); g.nt = k * k + 1;
     return g;
 }
-constexpr int DWF_SITES = 64;
+constexpr int DWF_SITES = 48;                                  // (48 sites x 80 bytes: the argument block stays below 4 KiB)
 struct DwFoldSite { const float* part; float* dw; float* db; float* dgamma; float* dbeta; long long wstride; int C, kk, ch, chunks, gx, nt, groups, blk0; };
 struct DwFoldDev { DwFoldSite s[DWF_SITES]; int n; };
+static_assert(sizeof(DwFoldDev) <= 4096, "kernel argument block");
 // workgroup = one (site, group, channel chunk): thread f = (tap, channel) adds its walkers' sums
 __global__ __launch_bounds__(256) void dw_fold_kernel(const DwFoldDev q) {
     int si = 0;

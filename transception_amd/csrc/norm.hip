@@ -507,6 +507,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 constexpr int LN_FOLD_SITES = 64;
 struct LnFoldSite { const float* part; float* dgamma; float* dbeta; long long pstride; int nblk, C, groups, blk0; };
 struct LnFoldDev { LnFoldSite s[LN_FOLD_SITES]; int n; };
+static_assert(sizeof(LnFoldDev) <= 4096, "kernel argument block");
 __global__ __launch_bounds__(256) void ln_fold_kernel(const LnFoldDev q) {
     __shared__ float red[4][64];
     int si = 0;

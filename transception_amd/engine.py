@@ -498,8 +498,8 @@ class Graph:
     def _flush_dw_folds(self):
         """One launch adds the parked walker sums of every depthwise weight gradient since the last flush (tc_dw_fold)."""
         from ._lib import TcDwFold
-        for c0 in range(0, len(self._dw_pending), 64):
-            chunk = self._dw_pending[c0:c0 + 64]
+        for c0 in range(0, len(self._dw_pending), 48):                # (tc_dw_fold takes up to 48 sites: its argument block stays below 4 KiB)
+            chunk = self._dw_pending[c0:c0 + 48]
             arr = (TcDwFold * len(chunk))(*[site for site, _ in chunk])
             self.n_launch += 1
             self.L.tc_dw_fold(arr, len(chunk), self.stream)
