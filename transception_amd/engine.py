@@ -463,7 +463,7 @@ class Graph:
             if entry[0] == "mark":
                 if entry[1] == until:
                     self.cur, self.stream = main
-                    self._flush_ln_folds()
+                    self._flush_param_folds()
                     if self._wstream is not None:
                         for ws in self._wstream:
                             self.cur.wait_stream(ws)
@@ -485,7 +485,7 @@ class Graph:
                     with _Branch(self, st):
                         fn()
         self.cur, self.stream = main
-        self._flush_ln_folds()
+        self._flush_param_folds()
         if self._wstream is not None:
             for ws in self._wstream:
                 self.cur.wait_stream(ws)                 # all weight gradients are in the arena before anything follows
@@ -505,8 +505,9 @@ class Graph:
             self.L.tc_dw_fold(arr, len(chunk), self.stream)
         self._dw_pending = []
 
-    def _flush_ln_folds(self):
-        """One launch adds the parked dgamma / dbeta partials of every LayerNorm backward since the last flush (tc_layernorm_fold)."""
+    def _flush_param_folds(self):
+        """End of a backward leg: the parked parameter-gradient partials of the leg's launches are added up -- depthwise / mid-backward walkers
+        (tc_dw_fold), then the LayerNorms' dgamma / dbeta (tc_layernorm_fold: one launch for every LayerNorm backward since the last flush)."""
         self._flush_dw_folds()
         if not self._ln_pending:
             return
@@ -1107,7 +1108,7 @@ class Graph:
             fused = g.grad is not None and not (self.overlap_wgrad and self.use_streams)
             nblk = int(self.L.tc_layernorm_bwd_nblk(rows, Cc)) if (fused and _LN_DEFER) else 0
             if nblk > 0:                                 # dx + per-workgroup dgamma / dbeta partials; the partials of ALL LayerNorms of a backward
-                nf = Gn * nblk * 2 * Cc                  # leg are added up by one launch when the leg ends (_flush_ln_folds)
+                nf = Gn * nblk * 2 * Cc                  # leg are added up by one launch when the leg ends (_flush_param_folds)
                 part = self.f32(nf)
                 _timed("hbm:layernorm_bwd", (3.0 + acc) * x.rows * Cc * es, lambda: self.L.tc_layernorm_bwd_defer(
                     _ptr(dy), dy.stride(0), _ptr(x.data), x.ld, _ptr(g.data), _ptr(b.data), _ptr(mean), _ptr(rstd), _ptr(gx), gx.stride(0),
@@ -1115,7 +1116,7 @@ class Graph:
                     self.stream))
                 self._ln_pending.append((part, g.grad, b.grad, g.gs, nblk, Cc, Gn))
                 if len(self._ln_pending) == 64:
-                    self._flush_ln_folds()
+                    self._flush_param_folds()
                 return
             if fused:                                    # one pass: dx + per-workgroup dgamma/dbeta partials + a tiny folding launch
                 ws = _workspace(self.dev, self.stream)
