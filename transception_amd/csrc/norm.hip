@@ -10,11 +10,14 @@ constexpr int LN_MAXC = 2048;
 #ifndef LN_FOLD
 #define LN_FOLD 8
 #endif
-constexpr int LN_BWD_MAX_BLOCKS = 1024, LN_BWD_ROWS_PER_GROUP = 4;   // fused dx + parameter-gradient launch
+constexpr int LN_BWD_MAX_BLOCKS = 4096, LN_BWD_ROWS_PER_GROUP = 4;   // fused dx + parameter-gradient launch
 inline int ln_bwd_wg_min() { static const int v = getenv("TC_LN_WG_MIN") ? atoi(getenv("TC_LN_WG_MIN")) : 1024; return v < 16 ? 16 : v; }   // 512 with the fold at the tail; deferred: 256 / 512 / 1024 -> 12.11 / 12.07 / 12.04 ms
-inline int ln_bwd_blocks() {   // A/B switch (<= LN_BWD_MAX_BLOCKS, which sizes the scratch)
-    static const int v = getenv("TC_LN_BWD_BLOCKS") ? atoi(getenv("TC_LN_BWD_BLOCKS")) : LN_BWD_MAX_BLOCKS;
-    return v < 16 ? 16 : (v > LN_BWD_MAX_BLOCKS ? LN_BWD_MAX_BLOCKS : v);
+inline int ln_bwd_blocks(bool deferred) {   // A/B switch (<= LN_BWD_MAX_BLOCKS, which sizes the scratch)
+    // launches that fold at their own tail: 1024 (every block is one more partial to park and fold in-kernel); deferred fold: 4096
+    // (1024 / 2048 / 4096 -> 11.87 / 11.85 / 11.84 ms per step)
+    static const int v = getenv("TC_LN_BWD_BLOCKS") ? atoi(getenv("TC_LN_BWD_BLOCKS")) : 0;
+    const int w = v > 0 ? v : (deferred ? LN_BWD_MAX_BLOCKS : 1024);
+    return w < 16 ? 16 : (w > LN_BWD_MAX_BLOCKS ? LN_BWD_MAX_BLOCKS : w);
 }
 
 // ---------------------------------------------------------------------------------------------- LayerNorm
@@ -537,7 +540,7 @@ __global__ __launch_bounds__(256) void ln_fold_kernel(const LnFoldDev q) {
 }
 
 // workgroups of the fused dx + parameter-gradient launch (one place: the launch and the size of a deferred partial buffer)
-inline int ln_bwd_nblk(int rows, int C, bool with_params) {
+inline int ln_bwd_nblk(int rows, int C, bool with_params, bool deferred) {
     const int quads = C >> 2;
     const int GS = quads <= 16 ? 16 : (quads <= 32 ? 32 : 64);
     static const int ilp_on = getenv("TC_LN_BWD_ILP") ? atoi(getenv("TC_LN_BWD_ILP")) : 1;
@@ -545,7 +548,7 @@ inline int ln_bwd_nblk(int rows, int C, bool with_params) {
     int rpg = with_params ? rows / ((256 / GS) * ln_bwd_wg_min()) : 1;   // rows per lane group: >= 512 workgroups before rows are stacked
     rpg = rpg < 1 ? 1 : (rpg > LN_BWD_ROWS_PER_GROUP ? LN_BWD_ROWS_PER_GROUP : rpg);
     if (ilp && rpg < 2) rpg = 2;
-    return tc_blocks(rows, (256 / GS) * rpg, with_params ? ln_bwd_blocks() : 8192);
+    return tc_blocks(rows, (256 / GS) * rpg, with_params ? ln_bwd_blocks(deferred) : 8192);
 }
 
 }  // namespace
@@ -615,7 +618,7 @@ static int ln_bwd_impl(const void* dy, int lddy, const void* x, int ldx, const v
         constexpr int RPT = 2;   /* rows in flight per lane group (narrow rows): 14.16 vs 14.19 ms per step; 4 rows: 14.21 vs 14.22 */                                                         \
         static const int ilp_on = getenv("TC_LN_BWD_ILP") ? atoi(getenv("TC_LN_BWD_ILP")) : 1;                                             \
         const bool ilp = ilp_on && NV == 1 && rows >= 8192;                                                                                \
-        nblk = ln_bwd_nblk(rows, C, dgamma != nullptr);                                                                                    \
+        nblk = ln_bwd_nblk(rows, C, dgamma != nullptr, defer_part != nullptr);                                                             \
         partial = defer_part ? defer_part :                                                                                               \
                   (dgamma && scratch && (uintptr_t)scratch % 16 == 0 && scratch_floats >= 4096 + (long long)groups * nblk * 2 * C &&      \
                    (long long)groups * ((nblk + LN_FOLD - 1) / LN_FOLD) <= 4096) ? scratch + 4096 : nullptr;                                            \
@@ -656,7 +659,7 @@ extern "C" int tc_layernorm_ps_bwd(const void* dy, int lddy, const void* x, int 
 
 extern "C" int tc_layernorm_bwd_nblk(int rows, int C) {
     if (rows <= 0 || C <= 0 || (C & 3) || C > LN_MAXC || (C >> 2) > 256) return 0;     // wide rows fold in launches of their own
-    return ln_bwd_nblk(rows, C, true);
+    return ln_bwd_nblk(rows, C, true, true);
 }
 
 extern "C" int tc_layernorm_bwd_defer(const void* dy, int lddy, const void* x, int ldx, const void* gamma, const void* beta,
@@ -686,7 +689,7 @@ extern "C" int tc_layernorm_fold(const TcLnFold* sites, int n, void* stream) {
 
 extern "C" long long tc_layernorm_bwd_scratch_floats(int rows, int C, int groups) {
     if (rows <= 0 || C <= 0 || groups < 1) return 0;
-    return 4096 + (long long)groups * LN_BWD_MAX_BLOCKS * 2 * C;      // counters + an upper bound over the lane-group shapes
+    return 4096 + (long long)groups * 1024 * 2 * C;      // counters + an upper bound over the lane-group shapes (launches that fold at their tail use <= 1024 workgroups)
 }
 
 extern "C" int tc_layernorm_bwd_params(const void* dy, int lddy, const void* x, int ldx, const void* gamma, const void* beta,
