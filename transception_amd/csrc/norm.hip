@@ -393,6 +393,23 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ x
     }
 }
 
+// A quarter (part = 0..3) of the chunk partials of one channel: every workgroup of the apply kernels starts with this fold, and as a loop
+// of dependent loads over a run-time count it was a chain of ~nchunk / 4 L2 round trips at the head of each of them (the GEMM epilogue leaves
+// one partial per 64-row tile: 196 for a 12544-row map).  Eight loads per array in flight before the first add.
+__device__ __forceinline__ void bn_fold_partials(const float* __restrict__ scratch, int nchunk, int C, int ch, int part, float& s1, float& s2) {
+    const float* p1 = scratch + C + ch;
+    const float* p2 = scratch + C + (long long)nchunk * C + ch;
+    int k = part;
+    for (; k + 28 < nchunk; k += 32) {
+        float a[8], b[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) { a[m] = p1[(long long)(k + 4 * m) * C]; b[m] = p2[(long long)(k + 4 * m) * C]; }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) { s1 += a[m]; s2 += b[m]; }
+    }
+    for (; k < nchunk; k += 4) { s1 += p1[(long long)k * C]; s2 += p2[(long long)k * C]; }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ gamma,
                                                        const T* __restrict__ beta, float* __restrict__ running_mean,
@@ -409,8 +426,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
         // fold the per-chunk partials once per block: thread (channel = tid % 64, quarter = tid / 64)
         const int cc = threadIdx.x & 63, part = threadIdx.x >> 6, ch = blockIdx.y * 64 + cc;
         float s1 = 0.f, s2 = 0.f;
-        if (ch < C)
-            for (int k = part; k < nchunk; k += 4) { s1 += scratch[C + k * C + ch]; s2 += scratch[C + nchunk * C + k * C + ch]; }
+        if (ch < C) bn_fold_partials(scratch, nchunk, C, ch, part, s1, s2);
         psum[0][part][cc] = s1; psum[1][part][cc] = s2;
         __syncthreads();
         if (threadIdx.x < 64 && ch < C) {
@@ -463,8 +479,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     {
         const int cc = threadIdx.x & 63, part = threadIdx.x >> 6, ch = blockIdx.y * 64 + cc;
         float s1 = 0.f, s2 = 0.f;
-        if (ch < C)
-            for (int k = part; k < nchunk; k += 4) { s1 += scratch[C + k * C + ch]; s2 += scratch[C + nchunk * C + k * C + ch]; }
+        if (ch < C) bn_fold_partials(scratch, nchunk, C, ch, part, s1, s2);
         psum[0][part][cc] = s1; psum[1][part][cc] = s2;
         __syncthreads();
         if (threadIdx.x < 64) {
