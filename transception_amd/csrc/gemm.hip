@@ -89,12 +89,27 @@ __device__ __forceinline__ void ffn_finalize_stats(const GemmDev& p, int b1, int
     const int nch = p.ffn.nchunk;
     const float cn = (float)p.ffn.chunk_n, inv_cn = 1.0f / cn, invC = 1.0f / (cn * (float)nch);
     const float2* pp = reinterpret_cast<const float2*>(p.ffn.part) + (rbase + (row < p.M ? row : 0)) * nch;
-    float sm = 0.f;
-    for (int k = q; k < nch; k += LPR) sm += pp[k].x;
-    sm = tc_group_sum<LPR>(sm);
+    // this lane's partials are read ONCE, all loads in flight before the first use (two loops of dependent loads over a run-time count were
+    // up to 2 x 16 L2 round trips at the head of every workgroup); more than 16 per lane (nch > 16 LPR): the plain loops
+    float sm = 0.f, m2 = 0.f;
+    constexpr int PMAX = 16;
+    if (nch <= PMAX * LPR) {
+        float2 t[PMAX];
+#pragma unroll
+        for (int e = 0; e < PMAX; ++e) t[e] = pp[min(q + e * LPR, nch - 1)];
+#pragma unroll
+        for (int e = 0; e < PMAX; ++e) if (q + e * LPR < nch) sm += t[e].x;
+        sm = tc_group_sum<LPR>(sm);
+        const float mean_ = sm * invC;
+#pragma unroll
+        for (int e = 0; e < PMAX; ++e) if (q + e * LPR < nch) { const float dm = t[e].x * inv_cn - mean_; m2 += t[e].y + cn * dm * dm; }
+    } else {
+        for (int k = q; k < nch; k += LPR) sm += pp[k].x;
+        sm = tc_group_sum<LPR>(sm);
+        const float mean_ = sm * invC;
+        for (int k = q; k < nch; k += LPR) { const float2 t = pp[k]; const float dm = t.x * inv_cn - mean_; m2 += t.y + cn * dm * dm; }
+    }
     const float mean = sm * invC;
-    float m2 = 0.f;
-    for (int k = q; k < nch; k += LPR) { const float2 t = pp[k]; const float dm = t.x * inv_cn - mean; m2 += t.y + cn * dm * dm; }
     m2 = tc_group_sum<LPR>(m2);
     const float rstd = rsqrtf(m2 * invC + p.ffn.eps);
     if (q == 0) {
