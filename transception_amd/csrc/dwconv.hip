@@ -1611,31 +1611,39 @@ constexpr int DWF_SITES = 48;                                  // (48 sites x 80
 struct DwFoldSite { const float* part; float* dw; float* db; float* dgamma; float* dbeta; long long wstride; int C, kk, ch, chunks, gx, nt, groups, blk0; };
 struct DwFoldDev { DwFoldSite s[DWF_SITES]; int n; };
 static_assert(sizeof(DwFoldDev) <= 4096, "kernel argument block");
-// workgroup = one (site, group, channel chunk): thread f = (tap, channel) adds its walkers' sums
+// workgroup = 64 consecutive (tap, channel) words of one (site, group, channel chunk) x 4 slices of its walkers (a first version gave a whole
+// chain to one workgroup, every thread adding all walkers of its words: ~300 workgroups and 33 us per launch)
 __global__ __launch_bounds__(256) void dw_fold_kernel(const DwFoldDev q) {
+    __shared__ float red[4][64];
     int si = 0;
     for (int i = 1; i < q.n; ++i) if ((int)blockIdx.x >= q.s[i].blk0) si = i;
     const DwFoldSite& t = q.s[si];
-    const int chain = blockIdx.x - t.blk0, g = chain / t.chunks, c0 = (chain - g * t.chunks) * t.ch, ntc = t.nt * t.ch;
-    const float* p = t.part + (long long)chain * t.gx * ntc;
-    for (int f = threadIdx.x; f < ntc; f += 256) {
-        const int tap = f / t.ch, ch = c0 + (f - tap * t.ch);
-        if (ch >= t.C) continue;
-        float v = 0.f;
-        int m = 0;
-        for (; m + 8 <= t.gx; m += 8) {
+    const int ntc = t.nt * t.ch, per = (ntc + 63) / 64;
+    const int lin = blockIdx.x - t.blk0, chain = lin / per, f = (lin - chain * per) * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+    const int g = chain / t.chunks, c0 = (chain - g * t.chunks) * t.ch;
+    float v = 0.f;
+    if (f < ntc) {
+        const float* p = t.part + (long long)chain * t.gx * ntc + f;
+        int m = sl;
+        for (; m + 28 < t.gx; m += 32) {
             float tmp[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) tmp[e] = p[(long long)(m + e) * ntc + f];
+            for (int e = 0; e < 8; ++e) tmp[e] = p[(long long)(m + 4 * e) * ntc];
 #pragma unroll
             for (int e = 0; e < 8; ++e) v += tmp[e];
         }
-        for (; m < t.gx; ++m) v += p[(long long)m * ntc + f];
-        if (tap < t.kk) atomicAdd(t.dw + g * t.wstride + (long long)ch * t.kk + tap, v);      // (shared modules: a weight may have two writers)
-        else if (tap == t.kk) { if (t.db) atomicAdd(t.db + g * t.wstride + ch, v); }
-        else if (tap == t.kk + 1) { if (t.dgamma) atomicAdd(t.dgamma + g * t.wstride + ch, v); }   // tc_ffn_mid_bwd: the LayerNorm behind the convolution
-        else if (t.dbeta) atomicAdd(t.dbeta + g * t.wstride + ch, v);
+        for (; m < t.gx; m += 4) v += p[(long long)m * ntc];
     }
+    red[sl][threadIdx.x & 63] = v;
+    __syncthreads();
+    if (sl != 0 || f >= ntc) return;
+    v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    const int tap = f / t.ch, ch = c0 + (f - tap * t.ch);
+    if (ch >= t.C) return;
+    if (tap < t.kk) atomicAdd(t.dw + g * t.wstride + (long long)ch * t.kk + tap, v);      // (shared modules: a weight may have two writers)
+    else if (tap == t.kk) { if (t.db) atomicAdd(t.db + g * t.wstride + ch, v); }
+    else if (tap == t.kk + 1) { if (t.dgamma) atomicAdd(t.dgamma + g * t.wstride + ch, v); }   // tc_ffn_mid_bwd: the LayerNorm behind the convolution
+    else if (t.dbeta) atomicAdd(t.dbeta + g * t.wstride + ch, v);
 }
 }  // namespace
 
@@ -1691,7 +1699,7 @@ extern "C" int tc_dw_fold(const TcDwFold* sites, int n, void* stream) {
         if (t.gx < 1 || t.ch < 1 || t.chunks != (t.C + t.ch - 1) / t.ch) return TC_ERR_ARG;
         if (t.nt != t.k * t.k + 1 && t.nt != t.k * t.k + 3) return TC_ERR_ARG;
         q.s[i] = DwFoldSite{t.part, t.dw, t.db, t.dgamma, t.dbeta, t.wstride, t.C, t.k * t.k, t.ch, t.chunks, t.gx, t.nt, t.groups, blk};
-        blk += t.chunks * t.groups;
+        blk += t.chunks * t.groups * ((t.nt * t.ch + 63) / 64);
     }
     hipLaunchKernelGGL(dw_fold_kernel, dim3(blk), dim3(256), 0, (hipStream_t)stream, q);
     return tc_launch_status();
