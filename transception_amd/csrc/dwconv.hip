@@ -1609,6 +1609,7 @@ template <typename T> DwGeom dw_bwd_geom(int B, int H, int W, int C, int k, int 
 }
 constexpr int DWF_SITES = 48;                                  // (48 sites x 80 bytes: the argument block stays below 4 KiB)
 struct DwFoldSite { const float* part; float* dw; float* db; float* dgamma; float* dbeta; long long wstride; int C, kk, ch, chunks, gx, nt, groups, blk0; };
+constexpr int DWF_WALKERS = 32;                                 // walkers per fold workgroup: one batch of eight loads per thread
 struct DwFoldDev { DwFoldSite s[DWF_SITES]; int n; };
 static_assert(sizeof(DwFoldDev) <= 4096, "kernel argument block");
 // workgroup = 64 consecutive (tap, channel) words of one (site, group, channel chunk) x 4 slices of its walkers (a first version gave a whole
@@ -1618,21 +1619,24 @@ __global__ __launch_bounds__(256) void dw_fold_kernel(const DwFoldDev q) {
     int si = 0;
     for (int i = 1; i < q.n; ++i) if ((int)blockIdx.x >= q.s[i].blk0) si = i;
     const DwFoldSite& t = q.s[si];
-    const int ntc = t.nt * t.ch, per = (ntc + 63) / 64;
-    const int lin = blockIdx.x - t.blk0, chain = lin / per, f = (lin - chain * per) * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+    const int ntc = t.nt * t.ch, per = (ntc + 63) / 64, wsplit = (t.gx + DWF_WALKERS - 1) / DWF_WALKERS;
+    int lin = blockIdx.x - t.blk0;
+    const int ws = lin % wsplit; lin /= wsplit;
+    const int chain = lin / per, f = (lin - chain * per) * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
     const int g = chain / t.chunks, c0 = (chain - g * t.chunks) * t.ch;
+    const int mend = min(t.gx, (ws + 1) * DWF_WALKERS);
     float v = 0.f;
     if (f < ntc) {
         const float* p = t.part + (long long)chain * t.gx * ntc + f;
-        int m = sl;
-        for (; m + 28 < t.gx; m += 32) {
+        int m = ws * DWF_WALKERS + sl;
+        for (; m + 28 < mend; m += 32) {
             float tmp[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) tmp[e] = p[(long long)(m + 4 * e) * ntc];
 #pragma unroll
             for (int e = 0; e < 8; ++e) v += tmp[e];
         }
-        for (; m < t.gx; m += 4) v += p[(long long)m * ntc];
+        for (; m < mend; m += 4) v += p[(long long)m * ntc];
     }
     red[sl][threadIdx.x & 63] = v;
     __syncthreads();
@@ -1699,7 +1703,7 @@ extern "C" int tc_dw_fold(const TcDwFold* sites, int n, void* stream) {
         if (t.gx < 1 || t.ch < 1 || t.chunks != (t.C + t.ch - 1) / t.ch) return TC_ERR_ARG;
         if (t.nt != t.k * t.k + 1 && t.nt != t.k * t.k + 3) return TC_ERR_ARG;
         q.s[i] = DwFoldSite{t.part, t.dw, t.db, t.dgamma, t.dbeta, t.wstride, t.C, t.k * t.k, t.ch, t.chunks, t.gx, t.nt, t.groups, blk};
-        blk += t.chunks * t.groups * ((t.nt * t.ch + 63) / 64);
+        blk += t.chunks * t.groups * ((t.nt * t.ch + 63) / 64) * ((t.gx + DWF_WALKERS - 1) / DWF_WALKERS);
     }
     hipLaunchKernelGGL(dw_fold_kernel, dim3(blk), dim3(256), 0, (hipStream_t)stream, q);
     return tc_launch_status();

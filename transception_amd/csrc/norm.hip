@@ -522,8 +522,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 // [groups][nblk][dgamma C | dbeta C] in a buffer of its own and returns -- no arrival counter, no last-arriver fold at its tail (3-5 us of a
 // 6-11 us launch on the small maps) -- and ONE launch per backward leg adds them up for all sites.  Workgroup = (site, group, 64 columns of
 // the 2C): 64 columns x 4 row slices, every load of a slice's batch issued before the first add.
-constexpr int LN_FOLD_SITES = 64;
-struct LnFoldSite { const float* part; float* dgamma; float* dbeta; long long pstride; int nblk, C, groups, blk0; };
+constexpr int LN_FOLD_SITES = 64, LN_FOLD_ROWS = 128;
+struct LnFoldSite { const float* part; float* dgamma; float* dbeta; long long pstride; int nblk, C, groups, blk0, rsplit; };
 struct LnFoldDev { LnFoldSite s[LN_FOLD_SITES]; int n; };
 static_assert(sizeof(LnFoldDev) <= 4096, "kernel argument block");
 __global__ __launch_bounds__(256) void ln_fold_kernel(const LnFoldDev q) {
@@ -532,19 +532,23 @@ __global__ __launch_bounds__(256) void ln_fold_kernel(const LnFoldDev q) {
     for (int i = 1; i < q.n; ++i) if ((int)blockIdx.x >= q.s[i].blk0) si = i;
     const LnFoldSite& t = q.s[si];
     const int cchunks = (2 * t.C + 63) / 64;
-    const int lin = blockIdx.x - t.blk0, g = lin / cchunks, c = (lin - g * cchunks) * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+    // (site, group, 64 columns, LN_FOLD_ROWS-row range): with up to 4096 partial rows per site one workgroup per column chunk was 30 us of serial adds
+    int lin = blockIdx.x - t.blk0;
+    const int rs = lin % t.rsplit; lin /= t.rsplit;
+    const int g = lin / cchunks, c = (lin - g * cchunks) * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+    const int rend = min(t.nblk, (rs + 1) * LN_FOLD_ROWS);
     float v = 0.f;
     if (c < 2 * t.C) {
         const float* p = t.part + (long long)g * t.nblk * 2 * t.C + c;
-        int r = sl;
-        for (; r + 28 < t.nblk; r += 32) {
+        int r = rs * LN_FOLD_ROWS + sl;
+        for (; r + 28 < rend; r += 32) {
             float tmp[8];
 #pragma unroll
             for (int m = 0; m < 8; ++m) tmp[m] = p[(long long)(r + 4 * m) * 2 * t.C];
 #pragma unroll
             for (int m = 0; m < 8; ++m) v += tmp[m];
         }
-        for (; r < t.nblk; r += 4) v += p[(long long)r * 2 * t.C];
+        for (; r < rend; r += 4) v += p[(long long)r * 2 * t.C];
     }
     red[sl][threadIdx.x & 63] = v;
     __syncthreads();
@@ -695,8 +699,9 @@ extern "C" int tc_layernorm_fold(const TcLnFold* sites, int n, void* stream) {
     for (int i = 0; i < n; ++i) {
         const TcLnFold& t = sites[i];
         if (!t.part || !t.dgamma || !t.dbeta || t.nblk < 1 || t.C <= 0 || t.groups < 1) return TC_ERR_ARG;
-        q.s[i] = LnFoldSite{t.part, t.dgamma, t.dbeta, t.pstride, t.nblk, t.C, t.groups, blk};
-        blk += t.groups * ((2 * t.C + 63) / 64);
+        const int rsplit = (t.nblk + LN_FOLD_ROWS - 1) / LN_FOLD_ROWS;
+        q.s[i] = LnFoldSite{t.part, t.dgamma, t.dbeta, t.pstride, t.nblk, t.C, t.groups, blk, rsplit};
+        blk += t.groups * ((2 * t.C + 63) / 64) * rsplit;
     }
     hipLaunchKernelGGL(ln_fold_kernel, dim3(blk), dim3(256), 0, (hipStream_t)stream, q);
     return tc_launch_status();
