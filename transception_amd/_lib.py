@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("TC_LIB_PATH") or os.path.join(HERE, "libtransception_
 
 TC_F32, TC_BF16, TC_F16 = 0, 1, 2
 ACT_NONE, ACT_HSWISH, ACT_COORD, ACT_SIGMOID, ACT_GELU, ACT_SCALE, ACT_RELU = 0, 1, 2, 3, 4, 5, 6
-ABI_VERSION = 11
+ABI_VERSION = 12
 ATTN_DKV_SPLITS = 8                # include/transception_hip.h: partial dK|dV buffers in tc_attn_bwd_seg's fp32 scratch
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_longlong, C.c_float
@@ -205,6 +205,7 @@ SIGNATURES = {
     "tc_grad_sumsq": [vp, i64, vp, vp],
     "tc_fill_f32": [vp, i64, f32, vp],
     "tc_cast": [vp, vp, i64, i32, i32, vp],
+    "tc_seg_marker": [i32, vp],
 }
 _RET = {"tc_ffn_fused_bwd_scratch_floats": i64, "tc_effatt_scratch_floats": i64, "tc_bn_scratch_floats": i64, "tc_softmax_scratch_floats": i64, "tc_layernorm_bwd_scratch_floats": i64, "tc_dwconv_bwd_plan": i64, "tc_dwconv_multi_plan": i64, "tc_ffn_mid_plan": i64, "tc_factor_att_stats_floats": i64}
 _RAW = {"tc_abi_version", "tc_effatt_supported", "tc_effatt_scratch_floats", "tc_ffn_chunk", "tc_ffn_fused_supported", "tc_ffn_fused_bwd_supported", "tc_ffn_fused_bwd_scratch_floats", "tc_bn_scratch_floats", "tc_softmax_scratch_floats", "tc_layernorm_bwd_scratch_floats", "tc_layernorm_bwd_nblk", "tc_dwconv_bwd_plan", "tc_dwconv_multi_plan", "tc_ffn_mid_plan", "tc_factor_att_stats_floats"}     # not status-returning

@@ -544,4 +544,12 @@ extern "C" int tc_cast(const void* src, void* dst, long long n, int src_dtype, i
     else return TC_ERR_ARG;
     return tc_launch_status();
 }
-extern "C" int tc_abi_version(void) { return 11; }
+// A named cut in a kernel trace: an empty one-wave launch whose only purpose is to show up (with its id as the grid's x extent) between the
+// launches of two sections of a step (engine.Graph.segment, scripts/seg_timeline.py).  Never launched unless TC_SEG_MARKS=1.
+__global__ void seg_marker_kernel(int id) { (void)id; }
+extern "C" int tc_seg_marker(int id, void* stream) {
+    if (id < 0) return TC_ERR_ARG;
+    hipLaunchKernelGGL(seg_marker_kernel, dim3(id + 1), dim3(64), 0, TC_S, id);
+    return tc_launch_status();
+}
+extern "C" int tc_abi_version(void) { return 12; }

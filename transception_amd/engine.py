@@ -30,6 +30,10 @@ PROFILE: Optional[dict] = None
 BN_STATS_IN_GEMM = os.environ.get("TC_BN_STATS_IN_GEMM", "1") != "0"     # A/B switch: BatchNorm statistics in the producing GEMM's epilogue
 
 
+SEG_MARKS = os.environ.get("TC_SEG_MARKS", "")      # json path: section markers on (Graph.segment)
+SEG_LABELS: List[str] = []
+
+
 def _timed(name: str, flops: float, fn):
     if PROFILE is None:
         fn()
@@ -339,6 +343,9 @@ class Graph:
         self.cur = torch.cuda.current_stream(device) if torch.device(device).type == "cuda" else None
         self.stream = self.cur.cuda_stream if self.cur is not None else 0
         self.n_launch = 0
+        self._seg_prev = None
+        if SEG_MARKS:
+            del SEG_LABELS[:]
         self._zeros = _ZeroArena(device, dtype, shared=not self.use_streams)
 
     # ------------------------------------------------------------------ memory
@@ -455,6 +462,23 @@ class Graph:
         if self.record:
             self.tape.append(("mark", name))
 
+    def segment(self, name: str):
+        """Profiling aid (TC_SEG_MARKS=<json path>, off by default): an empty marker launch at the start of section `name` of the forward
+        sweep and -- through the tape -- at the start of the backward of the section that ends here, so that a kernel trace of a replayed
+        step can be cut into sections (scripts/seg_timeline.py).  The marker's id is its grid size; the id -> label table is written to
+        the path when the backward sweep ends."""
+        if not SEG_MARKS:
+            return
+        prev = self._seg_prev
+        self._seg_prev = name
+        SEG_LABELS.append("F:" + name)
+        self.L.tc_seg_marker(len(SEG_LABELS) - 1, self.stream)
+
+        def bwd():
+            SEG_LABELS.append("B:" + (prev or "head"))
+            self.L.tc_seg_marker(len(SEG_LABELS) - 1, self.stream)
+        self._rec(bwd)
+
     def backward(self, until: Optional[str] = None) -> bool:
         """Runs the tape in reverse.  With `until`, stops at that mark and returns False (call again to finish)."""
         main = (self.cur, self.stream)
@@ -493,6 +517,10 @@ class Graph:
         self._keep.clear()
         self.tape = []
         self._zeros.close()
+        if SEG_MARKS:
+            import json
+            with open(SEG_MARKS, "w") as f:
+                json.dump(SEG_LABELS, f)
         return True
 
     def _flush_dw_folds(self):

@@ -792,14 +792,18 @@ def _mhca_stage(M, G, stack: Var, name: str, layers: int, B: int, side: int, out
     cat = G.new(rows, 4 * C)
     gs = M._path_stride(name)
     enc = f"{name}.mhca_blks.0"
+    stg = name[-1]
     with G.parallel(2) as par:
         with par.branch(0):
+            G.segment("mb" + stg)
             with G.grouped(3, gs):
                 t = stack
                 for l in range(layers):
                     t = _mhca_block(M, G, t, f"{enc}.MHCA_layers.{l}", enc, B, side, cat.colslice(C, 4 * C) if l == layers - 1 else None)
         with par.branch(1):
+            G.segment("res" + stg)
             _resblock(M, G, stack.rowslice(0, rows), name + ".InvRes", B, side, cat.colslice(0, C))
+    G.segment("iff" + stg)
     if M.concat == "coord":
         return _coord_att(M, G, cat, name + ".aggregate", B, side, out)
     if M.concat == "3d":                                                         # Conv3d_BN_concat, MSTr.py:447-462
@@ -1059,6 +1063,7 @@ def _forward(M: MSTransception, G: Graph, x: torch.Tensor, B: int, in_ch: int, S
         return buf.rowslice(R[s], R[s + 1]).reshape(B * sides[s] * sides[s], 64 * MULT[s])
 
     # stage 1 -- OverlapPatchEmbeddings + 2 EfficientTransformerBlocks (MSTr.py:1714-1721)
+    G.segment("stage1")
     cols = G.stem_im2col(x, B, in_ch, S, S)
     W, b = _lin(M, G, "backbone.patch_embed1.proj")
     t = G.linear(cols.colslice(0, 147), W, b)
@@ -1073,6 +1078,7 @@ def _forward(M: MSTransception, G: Graph, x: torch.Tensor, B: int, in_ch: int, S
     for s in (1, 2, 3):
         if s >= 2:
             G.mark(f"stage{s + 1}_done")                          # a backward sweep that stops here has finished stage s + 1 (its RIPM included)
+        G.segment(f"ripm{s + 1}")
         stack, side = _ripm(M, G, m, f"backbone.patch_embed_stage{s + 1}", B, sides[s - 1])
         m = _mhca_stage(M, G, stack, f"backbone.mhca_stage{s + 1}", LAYERS[s - 1], B, side, stage_map(Xb, s))
     # Dual Transformer Bridge.  The mark lets a multi-GPU step stop its backward sweep here -- bridge and decoder gradients (72 % of
@@ -1098,13 +1104,20 @@ def _forward(M: MSTransception, G: Graph, x: torch.Tensor, B: int, in_ch: int, S
             M.taps["bridge4"] = image_major(X)
     elif M.have_bridge != "None":                                 # MSTr.py:2840
         for li in range(1, 5):
+            G.segment(f"bridge{li}")
             X = _bridge_layer(M, G, X, li, B, sides, ntok, R, N6)
             if tap:
                 M.taps[f"bridge{li}"] = image_major(X)
     # decoder
+    G.segment("dec3")
     d3 = _patch_expand(M, G, stage_map(X, 3), "decoder_3.layer_up", B, sides[3], 2)
+    G.segment("dec2")
     d2 = _decoder(M, G, d3, stage_map(X, 2), "decoder_2", B, sides[2], False)
+    G.segment("dec1")
     d1 = _decoder(M, G, d2, stage_map(X, 1), "decoder_1", B, sides[1], False)
     if tap:
         M.taps["dec1"] = d1.data.float().view(B, sides[0] * sides[0], d1.cols).clone()
-    return _decoder(M, G, d1, stage_map(X, 0), "decoder_0", B, sides[0], True)
+    G.segment("dec0")
+    out = _decoder(M, G, d1, stage_map(X, 0), "decoder_0", B, sides[0], True)
+    G.segment("loss")
+    return out
