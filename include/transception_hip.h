@@ -557,6 +557,17 @@ int tc_seg_loss_bwd_tok(const float* prob, const void* logits, int ldl, const lo
  * the backward (column max and 1/sum of the key softmax).  Backward: dq/dk/dv share the row stride ldd (slices of the qkv
  * gradient; acc_* = add to what is there), dconvv is overwritten.  Replaces 5 forward + 7 backward launches of the unfused form. */
 long long tc_factor_att_stats_floats(int Bt, int heads, int Ch);
+/* The attention half of an MHCABlock after norm1 in one launch (16-bit storage; C = 64 / 128 / 320 with 8 heads; N = H * W tokens per
+ * image small enough for one head's tiles to sit in LDS -- ask tc_mhca_att_supported): per (image, head)
+ *   q | k | v = xn Wqkv_h^T + b_h (nn.Linear(C, 3C), MSTr.py:856-862), convv = crpe_h(v) (ConvRelPosEnc, :801-823: heads 0-1 3x3, 2-4 5x5,
+ *   5-7 7x7 depthwise windows, weights w3 / w5 / w7 [nh*Ch, 1, k, k] + biases), o = scale q (softmax_N(k)^T v) + q (.) convv (:864-877).
+ * xn [groups*B*N, C] (row stride ldx); qkv [.., 3C], convv, o [.., C] and stats (tc_factor_att_stats_floats(groups*B, 8, C/8) floats) are
+ * written as tc_gemm + tc_dwconv_multi + tc_factor_att_fwd would leave them (their backward entries apply unchanged).  Parameters of
+ * weight group g (the three MB paths) at +g*gs elements. */
+int tc_mhca_att_supported(int C, int N, int dtype);
+int tc_mhca_att_fwd(const void* xn, int ldx, const void* Wqkv, const void* bqkv, const void* w3, const void* b3, const void* w5,
+                    const void* b5, const void* w7, const void* b7, long long gs, void* qkv, int ldq, void* convv, int ldc,
+                    void* o, int ldo, float* stats, int groups, int B, int H, int W, int C, float scale, int dtype, void* stream);
 int tc_factor_att_fwd(const void* q, const void* k, const void* v, int ld, const void* convv, int ldc, void* o, int ldo,
                       float* stats, int Bt, int N, int heads, int Ch, float scale, int dtype, void* stream);
 int tc_factor_att_bwd(const void* q, const void* k, const void* v, int ld, const void* convv, int ldc, const void* go, int ldgo,

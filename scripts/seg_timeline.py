@@ -17,8 +17,9 @@ import sys
 
 
 def short(n):
-    n = re.sub(r"\(.*$", "", n)
+    n = n.replace("(anonymous namespace)::", "").replace("unsigned short", "bf16")
     n = re.sub(r"^void ", "", n)
+    n = re.sub(r"\([^()]*\)$", "", n)
     return n[:70]
 
 

@@ -1,0 +1,133 @@
+"""Fused pieces of the MHCABlock (MSTr.py:826-946) against plain PyTorch fp32 restatements and against the op-by-op launches they
+replace.  16-bit storage only (the fp32 parity path keeps the op-by-op form)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from transception_amd.seeded_init import seeded_tensor  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+WINDOWS = [(3, 2), (5, 3), (7, 3)]
+
+
+def T(tag, shape, scale=1.0):
+    return torch.from_numpy(seeded_tensor("mhca/" + tag, shape, scale))
+
+
+def rel(got, want):
+    got, want = got.detach().float().cpu(), want.detach().float().cpu()
+    assert got.shape == want.shape, (got.shape, want.shape)
+    return (got - want).abs().max().item() / (want.abs().max().item() + 1e-12)
+
+
+def _arena(C, Gn, dtype, tag):
+    """The parameters of Gn weight groups laid out at a constant stride, as in the model's flat arenas: Wqkv | bqkv | w3 | b3 | w5 | b5 | w7 | b7."""
+    from transception_amd.engine import P
+    Ch = C // 8
+    shapes = [(3 * C, C), (3 * C,)]
+    for k, nh in WINDOWS:
+        shapes += [(nh * Ch, k * k), (nh * Ch,)]
+    sizes = [(int(torch.tensor(s).prod()) + 7) // 8 * 8 for s in shapes]
+    per = sum(sizes)
+    flat = T(tag, (Gn * per,), 0.15)
+    lp = flat.to(dtype).to(DEV)
+    master = lp.float().cpu()                                     # the reference sees the rounded parameters
+    gflat = torch.zeros(Gn * per, dtype=torch.float32, device=DEV)
+    Ps, off = [], 0
+    for s, n in zip(shapes, sizes):
+        ne = int(torch.tensor(s).prod())
+        Ps.append(P(lp[off:off + ne].view(s), gflat[off:off + ne].view(s), per if Gn > 1 else 0))
+        off += n
+    return Ps, master, gflat, per, shapes, sizes
+
+
+def _reference(x, master, per, shapes, sizes, Gn, B, side, C):
+    Ch, N = C // 8, side * side
+    pr = master.clone().requires_grad_()
+    xr = x.clone().requires_grad_()
+    outs = []
+    for g in range(Gn):
+        ps, off = [], g * per
+        for s, n in zip(shapes, sizes):
+            ne = int(torch.tensor(s).prod())
+            ps.append(pr[off:off + ne].view(s)); off += n
+        xg = xr[g * B * N:(g + 1) * B * N]
+        qkv = xg @ ps[0].t() + ps[1]
+        q, k, v = (qkv[:, i * C:(i + 1) * C] for i in range(3))
+        vim = v.reshape(B, side, side, C).permute(0, 3, 1, 2)
+        cs, c0 = [], 0
+        for i, (ks, nh) in enumerate(WINDOWS):
+            wd = nh * Ch
+            cs.append(F.conv2d(vim[:, c0:c0 + wd], ps[2 + 2 * i].view(wd, 1, ks, ks), ps[3 + 2 * i], padding=ks // 2, groups=wd)); c0 += wd
+        convv = torch.cat(cs, 1).permute(0, 2, 3, 1).reshape(B * N, C)
+        qh, kh, vh = (t.reshape(B, N, 8, Ch).permute(0, 2, 1, 3) for t in (q, k, v))
+        ctx = torch.softmax(kh, dim=2).transpose(-1, -2) @ vh
+        fa = (qh @ ctx).permute(0, 2, 1, 3).reshape(B * N, C)
+        outs.append(Ch ** -0.5 * fa + q * convv)
+    return torch.cat(outs, 0), xr, pr
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("C,side,B,Gn", [(64, 28, 2, 3), (128, 14, 2, 3), (320, 7, 3, 3), (128, 14, 1, 1), (64, 12, 2, 1), (320, 5, 2, 1)])
+def test_mhca_attention_one_launch(dtype, C, side, B, Gn):
+    """engine.Graph.mhca_attention (tc_mhca_att_fwd: qkv projection + ConvRelPosEnc + factorised attention per (image, head)) against the
+    fp32 torch statement of MSTr.py:852-886, forward and -- through the recorded closures of the ops it replaces -- backward; and against
+    the three launches it replaces on the same operands."""
+    import transception_amd.engine as E
+    from transception_amd.engine import Graph, Var
+    N, Ch = side * side, C // 8
+    rows = Gn * B * N
+    x16 = T(f"x{C}.{side}", (rows, C)).to(dtype)
+    gy16 = T(f"g{C}.{side}", (rows, C)).to(dtype)
+    Ps, master, gflat, per, shapes, sizes = _arena(C, Gn, dtype, f"p{C}.{Gn}")
+    ref, xr, pr = _reference(x16.float(), master, per, shapes, sizes, Gn, B, side, C)
+    ref.backward(gy16.float())
+
+    def run(fused):
+        E._MHCA_ATT_FUSED = fused
+        gflat.zero_()
+        G = Graph(dtype, torch.device(DEV), training=True, record=True)
+        xv = Var(x16.to(DEV).contiguous())
+        assert G.mhca_att_supported(xv, N) == fused
+        ctxm = G.grouped(Gn, per) if Gn > 1 else None
+        if ctxm is not None:
+            ctxm.__enter__()
+        if fused:
+            o = G.mhca_attention(xv, Ps[0], Ps[1], [Ps[2], Ps[4], Ps[6]], [Ps[3], Ps[5], Ps[7]], B, side, 8, Ch ** -0.5, WINDOWS)
+        else:
+            qkv = G.linear(xv, Ps[0], Ps[1], out=G.new(rows, 3 * C, covered=True))
+            q, k, v = qkv.colslice(0, C), qkv.colslice(C, 2 * C), qkv.colslice(2 * C, 3 * C)
+            convv = G.new(rows, C)
+            c0, xs, outs = 0, [], []
+            for ks, nh in WINDOWS:
+                xs.append(v.colslice(c0, c0 + nh * Ch)); outs.append(convv.colslice(c0, c0 + nh * Ch)); c0 += nh * Ch
+            G.dwconv_multi(xs, [Ps[2], Ps[4], Ps[6]], [Ps[3], Ps[5], Ps[7]], (B, side, side), [3, 5, 7], outs)
+            o = G.factor_att_core(q, k, v, convv, Gn * B, N, 8, Ch ** -0.5)
+        nl = G.n_launch
+        o.root.grad_t = gy16.to(DEV).contiguous()
+        o.root.whole_written = True
+        G.backward()
+        if ctxm is not None:
+            ctxm.__exit__(None, None, None)
+        torch.cuda.synchronize()
+        return o.data.float().cpu(), G.grad_of(xv).float().cpu(), gflat.cpu().clone(), nl
+
+    try:
+        of, dxf, gpf, nlf = run(True)
+        ou, dxu, gpu_, nlu = run(False)
+    finally:
+        E._MHCA_ATT_FUSED = True
+    tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
+    assert rel(of, ref) < tol, ("o vs torch", rel(of, ref))
+    assert rel(dxf, xr.grad) < 2 * tol, ("dx vs torch", rel(dxf, xr.grad))
+    assert rel(gpf, pr.grad) < 2 * tol, ("parameter gradients vs torch", rel(gpf, pr.grad))
+    # against the op-by-op launches: the same roundings at the same places, only the summation order of the projection differs
+    assert rel(of, ou) < tol / 2, ("o fused vs unfused", rel(of, ou))
+    assert rel(dxf, dxu) < tol, ("dx fused vs unfused", rel(dxf, dxu))
+    assert rel(gpf, gpu_) < tol, ("parameter gradients fused vs unfused", rel(gpf, gpu_))
+    assert nlf == 1 and nlu >= 1

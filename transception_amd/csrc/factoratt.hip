@@ -290,6 +290,386 @@ __global__ __launch_bounds__(256) void factor_att_bwd_kernel(const T* __restrict
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The attention half of an MHCABlock in ONE launch (MSTr.py:852-886 + 801-823; 16-bit storage): for one (image, head) per workgroup
+//   q | k | v = xn Wqkv_h^T + b_h          by MFMA (D^T tiles: lane = token, registers = 16 of the head's 3 Ch output channels; the
+//                                          xn rows and the head's 3 Ch weight rows go from global memory straight into operand registers)
+//   convv     = crpe_h(v)                  the head's 3x3 / 5x5 / 7x7 depthwise window over the token grid, from the v tile in LDS
+//   o         = scale q (softmax_N(k)^T v) + q (.) convv      exactly as factor_att_fwd_kernel
+// replacing the qkv GEMM, the three-window depthwise launch and the factor-attention launch (33-43 us of 5-20 us launches per block)
+// by one, with q, k, v, convv never read back from memory in the forward pass.  q | k | v, convv and the softmax statistics are still
+// stored (the backward kernels read them), in the storage type and rounded BEFORE they are used, so that the forward consumes the
+// same values the backward will see.
+// a 16-bit element as a zero-extended 32-bit load (two 16-bit loads into the halves of ONE register order the second behind the first:
+// a wait between loads that were meant to be in flight together), converted when it is used
+template <typename T> __device__ __forceinline__ unsigned ld_raw16(const T* p) { return (unsigned)*reinterpret_cast<const unsigned short*>(p); }
+template <typename T> __device__ __forceinline__ float cvt_raw16(unsigned r);
+template <> __device__ __forceinline__ float cvt_raw16<bf16_t>(unsigned r) { return __uint_as_float(r << 16); }
+template <> __device__ __forceinline__ float cvt_raw16<f16_t>(unsigned r) { f16_t h; h.v = (unsigned short)r; return h2f(h); }
+
+struct MhcaAttDev {
+    const void *xn, *Wqkv, *bqkv, *cw[3], *cb[3];
+    void *qkv, *convv, *o;
+    float* stats;
+    long long gs;
+    int ldx, ldq, ldc, ldo, B, N, H, W;
+    float scale;
+};
+
+// One head's depthwise K x K window over the token grid, v tile [N][CH] (storage type) -> convv tile.  A thread owns XB neighbouring
+// pixels of a row and 8 channels: per filter row it reads XB + K - 1 input vectors and the K tap vectors once and feeds XB * K * 8
+// FMAs from them (one vector per tap and pixel cost 3 LDS reads per 8 FMAs and made the 7 x 7 heads the launch's critical path);
+// out-of-range taps read a clamped address and are zeroed by a select, so the loop body has no branches.
+template <int K, int CH, int XB, typename T>
+__device__ __forceinline__ void mhca_conv_tile(T* cvs, const T* vs, const float* wcv, const float* bcv, int H, int W) {
+    constexpr int P = K / 2, NV = CH / 8, NIN = XB + K - 1;
+    const int nxb = (W + XB - 1) / XB, items = H * nxb * NV;
+    for (int i = threadIdx.x; i < items; i += 256) {
+        const int cvi = i % NV, t = i / NV, xb = t % nxb, y = t / nxb, x0 = xb * XB, c0 = cvi * 8;
+        float acc[XB][8];
+#pragma unroll
+        for (int o = 0; o < XB; ++o)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[o][u] = bcv[c0 + u];
+#pragma unroll 1
+        for (int ky = 0; ky < K; ++ky) {
+            const int yy = y + ky - P;
+            const bool rv = (unsigned)yy < (unsigned)H;
+            const int yc = rv ? yy : y;
+            float vin[NIN][8];
+#pragma unroll
+            for (int j = 0; j < NIN; ++j) {
+                const int xx = x0 + j - P;
+                const bool ok = rv && (unsigned)xx < (unsigned)W;
+                const int xc = (unsigned)xx < (unsigned)W ? xx : x0;
+                uint4 r = *reinterpret_cast<const uint4*>(vs + (yc * W + xc) * CH + c0);
+                if (!ok) r = make_uint4(0u, 0u, 0u, 0u);
+                unpack16<T>(r, vin[j]);
+            }
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                float w8[8];
+                fa_get8(wcv + (ky * K + kx) * CH + c0, w8);
+#pragma unroll
+                for (int o = 0; o < XB; ++o)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc[o][u] = fmaf(vin[o + kx][u], w8[u], acc[o][u]);
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < XB; ++o)
+            if (x0 + o < W) *reinterpret_cast<uint4*>(cvs + (y * W + x0 + o) * CH + c0) = pack16<T>(acc[o]);
+    }
+}
+template <int K, int CH, typename T>
+__device__ __forceinline__ void mhca_conv_pick(T* cvs, const T* vs, const float* wcv, const float* bcv, int H, int W) {
+    if (W >= 24) mhca_conv_tile<K, CH, 4, T>(cvs, vs, wcv, bcv, H, W);
+    else if (W >= 12) mhca_conv_tile<K, CH, 2, T>(cvs, vs, wcv, bcv, H, W);
+    else mhca_conv_tile<K, CH, 1, T>(cvs, vs, wcv, bcv, H, W);
+}
+
+template <typename T, int C>
+__global__ __launch_bounds__(256, 2) void mhca_att_fwd_kernel(MhcaAttDev p) {
+    constexpr int CH = C / 8, KS = C / 16, NQ = 3 * CH, NCOL = (NQ + 31) / 32, RSTEP = 4 / NCOL, NV = CH / 8;
+    constexpr bool STAGE_X = C >= 320;
+    constexpr int XLD = C + 8;
+    static_assert(NCOL == 1 || NCOL == 2 || NCOL == 4, "column tiles of a head must divide the four waves");
+    typedef typename TcHalf<T>::v8 v8;
+    extern __shared__ float sm[];
+    const int N = p.N, tid = threadIdx.x;
+#ifdef TC_MHCA_TIMING
+    long long tstamp[16];
+#define MHCA_STAMP(i) tstamp[i] = clock64()
+    MHCA_STAMP(0);
+#else
+#define MHCA_STAMP(i)
+#endif
+    float* e = sm;                        // [N][CH]  k (rounded to the storage type), then exp(k - max)
+    float* ctx = e + N * CH;              // [CH][CH]
+    float* cmax = ctx + CH * CH;
+    float* cinv = cmax + CH;
+    float* red = cinv + CH;               // 256
+    float* wcv = red + 256;               // [49][CH] window taps of this head, channel fastest
+    float* bcv = wcv + 49 * CH;           // [CH]
+    T* vs = reinterpret_cast<T*>(bcv + CH);
+    T* qs = vs + N * CH;
+    T* cvs = qs + N * CH;                 // convv tile; until the projection is done the same bytes hold the xn staging tiles
+    T* xs = STAGE_X ? cvs + N * CH : cvs; // STAGE_X: [N][XLD] xn rows of the image; else 4 wave-private [32][XLD] tiles (aliasing cvs)
+    // Workgroup -> (image, head).  Index l runs on XCD l % 8 (each XCD has its own L2): the eight heads of an image, which read the same xn rows,
+    // share an XCD; inside an XCD's share the 7 x 7 heads are dispatched first, then the 5 x 5, then the 3 x 3 ones -- the window makes a
+    // 7 x 7 head ~10 k cycles longer than a 3 x 3 one, and the CUs that take a second workgroup then pair a long one with a short one.
+    int bt, hd;
+    if (((gridDim.x >> 3) & 7) == 0) {                 // images a multiple of 8
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, nu = gridDim.x >> 6;       // nu images per XCD
+        const int hs = j / nu;
+        hd = hs < 3 ? 5 + hs : (hs < 6 ? hs - 1 : hs - 6);
+        bt = xcd * nu + (j - hs * nu);
+    } else {
+        const int blk0 = (gridDim.x & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
+        bt = blk0 >> 3; hd = blk0 & 7;
+    }
+    const int blk = bt * 8 + hd, g = bt / p.B;
+    const long long row0 = (long long)bt * N;
+    const T* xn = reinterpret_cast<const T*>(p.xn);
+    const T* Wg = reinterpret_cast<const T*>(p.Wqkv) + g * p.gs;
+    const T* bg = reinterpret_cast<const T*>(p.bqkv) + g * p.gs;
+    // window of this head (MSTr.py:785-799: heads 0-1 3x3, 2-4 5x5, 5-7 7x7), taps transposed into LDS
+    const int wi = hd < 2 ? 0 : (hd < 5 ? 1 : 2), K = 3 + 2 * wi, hoff = hd - (wi == 0 ? 0 : (wi == 1 ? 2 : 5));
+    // Every global load of the projection phase is issued before the first wait: the window taps (<= 8 per thread), the weight fragments and
+    // biases, the xn rows of ALL of the wave's tiles.  (Taps staged by a loop of load -> LDS store, then the weights, then a tile at a time
+    // were four to nine dependent memory round trips of ~3.5 k cycles each: two thirds of the launch.)
+    const int KK = K * K, ntap = KK * CH;
+    // (no lambdas and no "memory"-clobbering barriers in this phase: an array captured by a lambda, or live across such a barrier, is
+    // kept in scratch memory, and a scratch store of a loaded value is a wait.  The xn rows are fetched by `asm volatile` loads -- which
+    // the compiler can neither sink to their uses nor reorder -- followed by one explicit wait; its own waits for the compiler-visible
+    // loads issued before them stay conservative because the memory counter retires in order.)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#define MHCA_GLOAD128(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr))
+#define MHCA_KEEP128(r) asm volatile("" : "+v"(r))
+    unsigned tapv[8];                     // (raw until they are parked: a conversion right behind a load is a wait)
+    unsigned bcv_v;
+#define MHCA_LOAD_TAPS()                                                                                                               \
+    {                                                                                                                                  \
+        const T* cw = reinterpret_cast<const T*>(p.cw[wi]) + g * p.gs + (long long)hoff * CH * KK;                                     \
+        const T* cb = reinterpret_cast<const T*>(p.cb[wi]) + g * p.gs + hoff * CH;                                                     \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) { const int i = tid + 256 * j; tapv[j] = ld_raw16<T>(cw + (i < ntap ? i : 0)); } \
+        bcv_v = ld_raw16<T>(cb + (tid < CH ? tid : 0));                                                                                \
+    }
+#define MHCA_STASH_TAPS()                                                                                                              \
+    {                                                                                                                                  \
+        const float rkk = 1.0f / (float)KK;                                                                                            \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                                                \
+            const int i = tid + 256 * j;                                                                                               \
+            if (i < ntap) { const int ch = (int)(((float)i + 0.5f) * rkk), tap = i - ch * KK; wcv[tap * CH + ch] = cvt_raw16<T>(tapv[j]); } \
+        }                                                                                                                              \
+        if (tid < CH) bcv[tid] = cvt_raw16<T>(bcv_v);                                                                                  \
+    }
+    // operand fragments / raw biases / destinations of column tile CT (32 of the head's 3 CH output channels): lane l31 supplies weight row
+    // j = CT * 32 + l31; register group gq of a D^T tile holds 4 consecutive channels of q, k or v: which tile (0 q, 1 k, 2 v) * 65536 + channel, or -1
+#define MHCA_LOAD_W(CT, AF, BIAS, DSTI)                                                                                                \
+    {                                                                                                                                  \
+        const int j_ = (CT) * 32 + l31, jj_ = j_ < NQ ? j_ : NQ - 1;                                                                   \
+        const int wrow_ = (jj_ / CH) * C + hd * CH + (jj_ % CH);                                                                       \
+        _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) AF[ks] = *reinterpret_cast<const v8*>(Wg + (long long)wrow_ * C + ks * 16 + hh * 8); \
+        _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                                                             \
+            const int j0_ = (CT) * 32 + 8 * gq + 4 * hh;                                                                               \
+            DSTI[gq] = j0_ < NQ ? ((j0_ / CH) << 16) + (j0_ % CH) : -1;                                                                \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                                            \
+                const int ju_ = j0_ + u < NQ ? j0_ + u : NQ - 1;                                                                       \
+                BIAS[4 * gq + u] = ld_raw16<T>(bg + (ju_ / CH) * C + hd * CH + (ju_ % CH));                                            \
+            }                                                                                                                          \
+        }                                                                                                                              \
+    }
+#define MHCA_PUT(ACC, DSTI, TOK)                                                                                                       \
+    if ((TOK) < N) {                                                                                                                   \
+        _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                                                             \
+            if (DSTI[gq] >= 0) {                                                                                                       \
+                const int which = DSTI[gq] >> 16, ch = DSTI[gq] & 0xffff;                                                              \
+                const unsigned lo = pack2<T>(ACC[4 * gq], ACC[4 * gq + 1]), hi = pack2<T>(ACC[4 * gq + 2], ACC[4 * gq + 3]);           \
+                if (which == 1) {                                                                                                      \
+                    float4 f;                                                                                                          \
+                    unpack2<T>(lo, f.x, f.y); unpack2<T>(hi, f.z, f.w);                                                                \
+                    *reinterpret_cast<float4*>(e + (TOK) * CH + ch) = f;                                                               \
+                } else {                                                                                                               \
+                    *reinterpret_cast<uint2*>((which == 0 ? qs : vs) + (TOK) * CH + ch) = make_uint2(lo, hi);                          \
+                }                                                                                                                      \
+            }                                                                                                                          \
+        }                                                                                                                              \
+    }
+    MHCA_STAMP(8);
+    // ---- q | k | v of this head for all N tokens
+    {
+        const int w = tid >> 6, l = tid & 63, l31 = l & 31, hh = l >> 5;
+        const int nrt = (N + 31) >> 5;
+        if constexpr (STAGE_X) {
+            // wide rows (C = 320): wave = column tile; the image's xn rows go through LDS once, fetched by the whole workgroup with every
+            // load in flight, rows padded by 16 bytes against bank conflicts
+            v8 af[KS];
+            unsigned bias[16];
+            int dsti[4];
+            constexpr int CV = C / 8, XPT = 8;                  // 16-byte pieces per row; pieces per thread in flight at once (8 x 256 threads = 51 rows of C = 320)
+            u32x4 xr[XPT];
+#define MHCA_FETCH_X(I0)                                                                                                               \
+    _Pragma("unroll") for (int j = 0; j < XPT; ++j) {                                                                                  \
+        const int i = (I0) + tid + 256 * j, ic = i < N * CV ? i : 0, n = ic / CV, c8 = ic - n * CV;                                    \
+        const T* src = xn + (row0 + n) * p.ldx + c8 * 8;                                                                               \
+        MHCA_GLOAD128(xr[j], src);                                                                                                     \
+    }
+            MHCA_FETCH_X(0);                                    // (the asm loads first: what the compiler hoists out of the loop below -- bias conversions -- then waits behind them, not before them)
+            MHCA_LOAD_TAPS();
+            MHCA_LOAD_W(w % NCOL, af, bias, dsti);
+            for (int i0 = 0;;) {
+                asm volatile("s_waitcnt vmcnt(0)");
+#pragma unroll
+                for (int j = 0; j < XPT; ++j) MHCA_KEEP128(xr[j]);
+                if (i0 == 0) MHCA_STASH_TAPS();
+#pragma unroll
+                for (int j = 0; j < XPT; ++j) {
+                    const int i = i0 + tid + 256 * j, n = i / CV, c8 = i - n * CV;
+                    if (i < N * CV) *reinterpret_cast<u32x4*>(xs + n * XLD + c8 * 8) = xr[j];
+                }
+                i0 += 256 * XPT;
+                if (i0 >= N * CV) break;
+                MHCA_FETCH_X(i0);
+            }
+            MHCA_STAMP(9);
+            __syncthreads();
+            for (int rt = w / NCOL; rt < nrt; rt += RSTEP) {
+                const int tok = rt * 32 + l31, tc = tok < N ? tok : N - 1;
+                const T* xr = xs + tc * XLD + hh * 8;
+                tc_f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = cvt_raw16<T>(bias[r]);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) acc = TcHalf<T>::mfma(af[ks], *reinterpret_cast<const v8*>(xr + ks * 16), acc);
+                MHCA_PUT(acc, dsti, tok);
+            }
+        } else {
+            // wave = row tiles w, w + 4, ... against ALL column tiles of the head.  A tile's 32 xn rows are fetched as whole rows (16 bytes
+            // per lane, consecutive lanes consecutive bytes -- per-lane row-strided fragment loads touch 32 cache lines per instruction),
+            // parked in a wave-private LDS tile (no barrier: a wave reads what it wrote) and read back as operand fragments.  MAXT tiles
+            // of a wave are in flight at once: all of them at the 224^2 shapes (25 / 7 row tiles over 4 waves).
+            constexpr int LPT = 32 * C / (64 * 8);             // 16-byte loads per lane and tile
+            constexpr int MAXT = C <= 64 ? 7 : 2;
+            v8 af[NCOL][KS];
+            unsigned bias[NCOL][16];
+            int dsti[NCOL][4];
+            T* xw = xs + w * 32 * XLD;
+            const int mine = nrt > w ? (nrt - w + 3) >> 2 : 0;
+            u32x4 xr[MAXT][LPT];
+#define MHCA_FETCH_T(T0)                                                                                                               \
+    _Pragma("unroll") for (int u = 0; u < MAXT; ++u)                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < LPT; ++i) {            /* (rows past the image: a clamped row, dropped in MHCA_PUT) */   \
+            const int flat = (i * 64 + l) * 8, row = flat / C, col = flat - row * C;                                                   \
+            const int tok = (w + 4 * ((T0) + u)) * 32 + row, tc = tok < N ? tok : N - 1;                                               \
+            const T* src = xn + (row0 + tc) * p.ldx + col;                                                                             \
+            MHCA_GLOAD128(xr[u][i], src);                                                                                              \
+        }
+            MHCA_FETCH_T(0);                                    // (the asm loads first: what the compiler hoists out of the loop below -- bias conversions -- then waits behind them, not before them)
+            MHCA_LOAD_TAPS();
+#pragma unroll
+            for (int ct = 0; ct < NCOL; ++ct) MHCA_LOAD_W(ct, af[ct], bias[ct], dsti[ct]);
+            for (int t0 = 0;;) {
+                asm volatile("s_waitcnt vmcnt(0)");
+#pragma unroll
+                for (int u = 0; u < MAXT; ++u)
+#pragma unroll
+                    for (int i = 0; i < LPT; ++i) MHCA_KEEP128(xr[u][i]);
+                if (t0 == 0) { MHCA_STASH_TAPS(); MHCA_STAMP(9); }
+#pragma unroll
+                for (int u = 0; u < MAXT; ++u) {
+#pragma unroll
+                    for (int i = 0; i < LPT; ++i) {
+                        const int flat = (i * 64 + l) * 8, row = flat / C, col = flat - row * C;
+                        *reinterpret_cast<u32x4*>(xw + row * XLD + col) = xr[u][i];
+                    }
+                    const int tok = t0 + u < mine ? (w + 4 * (t0 + u)) * 32 + l31 : N;
+                    tc_f32x16 acc[NCOL];
+#pragma unroll
+                    for (int ct = 0; ct < NCOL; ++ct)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[ct][r] = cvt_raw16<T>(bias[ct][r]);
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        const v8 bfr = *reinterpret_cast<const v8*>(xw + l31 * XLD + ks * 16 + hh * 8);
+#pragma unroll
+                        for (int ct = 0; ct < NCOL; ++ct) acc[ct] = TcHalf<T>::mfma(af[ct][ks], bfr, acc[ct]);
+                    }
+#pragma unroll
+                    for (int ct = 0; ct < NCOL; ++ct) MHCA_PUT(acc[ct], dsti[ct], tok);
+                }
+                t0 += MAXT;
+                if (t0 >= mine) break;
+                MHCA_FETCH_T(t0);
+            }
+        }
+    }
+    __syncthreads();
+    MHCA_STAMP(1);
+    // ---- q | k | v out for the backward (16-byte rows pieces), the window over v
+    {
+        T* qo = reinterpret_cast<T*>(p.qkv) + row0 * p.ldq + hd * CH;
+        for (int i = tid; i < N * NV; i += 256) {
+            const int n = i / NV, c0 = (i - n * NV) * 8;
+            T* dst = qo + (long long)n * p.ldq + c0;
+            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(qs + n * CH + c0);
+            *reinterpret_cast<uint4*>(dst + C) = pack16<T>(e + n * CH + c0);
+            *reinterpret_cast<uint4*>(dst + 2 * C) = *reinterpret_cast<const uint4*>(vs + n * CH + c0);
+        }
+    }
+    MHCA_STAMP(2);
+    if (K == 3) mhca_conv_pick<3, CH, T>(cvs, vs, wcv, bcv, p.H, p.W);
+    else if (K == 5) mhca_conv_pick<5, CH, T>(cvs, vs, wcv, bcv, p.H, p.W);
+    else mhca_conv_pick<7, CH, T>(cvs, vs, wcv, bcv, p.H, p.W);
+    __syncthreads();
+    MHCA_STAMP(3);
+    fa_softmax_cols(e, cmax, cinv, red, N, CH);
+    MHCA_STAMP(4);
+    fa_gram(ctx, e, vs, N, CH);
+    MHCA_STAMP(5);
+    for (int i = tid; i < CH * CH; i += 256) ctx[i] *= cinv[i / CH];
+    if (tid < CH) { p.stats[((long long)blk * 2) * CH + tid] = cmax[tid]; p.stats[((long long)blk * 2 + 1) * CH + tid] = cinv[tid]; }
+    __syncthreads();
+    {
+        T* oo = reinterpret_cast<T*>(p.o) + row0 * p.ldo + hd * CH;
+        T* co = reinterpret_cast<T*>(p.convv) + row0 * p.ldc + hd * CH;
+        const float scale = p.scale;
+#pragma unroll 2
+        for (int i = tid; i < N * NV; i += 256) {
+            const int n = i / NV, j0 = (i - n * NV) * 8;
+            float cv[8], acc[8];
+            const uint4 craw = *reinterpret_cast<const uint4*>(cvs + n * CH + j0);
+            *reinterpret_cast<uint4*>(co + (long long)n * p.ldc + j0) = craw;
+            unpack16<T>(craw, cv);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+            const T* qr = qs + n * CH;
+#pragma unroll
+            for (int c8 = 0; c8 < CH; c8 += 8) {
+                float q8[8];
+                fa_get8(qr + c8, q8);
+#pragma unroll
+                for (int cc = 0; cc < 8; ++cc) {
+                    const float* cr = ctx + (c8 + cc) * CH + j0;
+                    const float4 c0 = *reinterpret_cast<const float4*>(cr), c1 = *reinterpret_cast<const float4*>(cr + 4);
+                    acc[0] += q8[cc] * c0.x; acc[1] += q8[cc] * c0.y; acc[2] += q8[cc] * c0.z; acc[3] += q8[cc] * c0.w;
+                    acc[4] += q8[cc] * c1.x; acc[5] += q8[cc] * c1.y; acc[6] += q8[cc] * c1.z; acc[7] += q8[cc] * c1.w;
+                }
+            }
+            float qj[8];
+            fa_get8(qr + j0, qj);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] = scale * acc[u] + qj[u] * cv[u];
+            *reinterpret_cast<uint4*>(oo + (long long)n * p.ldo + j0) = pack16<T>(acc);
+        }
+    }
+#ifdef TC_MHCA_TIMING
+    MHCA_STAMP(6);
+    if (tid == 0) {                       // (experiment builds only: the caller's stats buffer has room for 8 stamps per workgroup behind the statistics)
+        long long* dbg = reinterpret_cast<long long*>(p.stats + (long long)gridDim.x * 2 * CH) + (long long)blk * 16;
+        for (int i = 0; i < 7; ++i) dbg[i] = tstamp[i];
+        dbg[7] = hd;
+        for (int i = 8; i < 10; ++i) dbg[i] = tstamp[i];
+        dbg[10] = tstamp[9];
+    }
+#endif
+}
+
+template <int C> __host__ size_t mhca_att_smem(int N) {
+    constexpr int CH = C / 8;
+    const size_t cvs = 2 * (size_t)N * CH, stage = 2 * (size_t)4 * 32 * (C + 8);           // convv tile / the four xn staging tiles share their bytes
+    return sizeof(float) * ((size_t)N * CH + (size_t)CH * CH + 3 * CH + 256 + 49 * CH) + 2 * 2 * (size_t)N * CH +
+           (C >= 320 ? cvs + 2 * (size_t)N * (C + 8) : (cvs > stage ? cvs : stage));
+}
+
+template <typename T, int C> int mhca_att_launch(const MhcaAttDev& p, int Bt, hipStream_t s) {
+    const size_t smem = mhca_att_smem<C>(p.N);
+    if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)mhca_att_fwd_kernel<T, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL((mhca_att_fwd_kernel<T, C>), dim3(Bt * 8), dim3(256), smem, s, p);
+    return tc_launch_status();
+}
+
 }  // namespace
 
 extern "C" long long tc_factor_att_stats_floats(int Bt, int heads, int Ch) { return (long long)Bt * heads * 2 * Ch; }
@@ -303,7 +683,7 @@ extern "C" int tc_factor_att_fwd(const void* q, const void* k, const void* v, in
     const size_t smem = sizeof(float) * ((size_t)N * Ch + (size_t)Ch * Ch + 2 * Ch + 256) + 2 * esz * N * Ch;
     if (smem > 150 * 1024) return TC_ERR_ARG;
     TC_DISPATCH_DTYPE(dtype, {
-        if (smem > 64 * 1024) hipFuncSetAttribute((const void*)factor_att_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)factor_att_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipLaunchKernelGGL((factor_att_fwd_kernel<T>), dim3(Bt * heads), dim3(256), smem, (hipStream_t)stream, (const T*)q, (const T*)k,
                            (const T*)v, ld, (const T*)convv, ldc, (T*)o, ldo, stats, N, Ch, heads, scale);
     });
@@ -324,10 +704,44 @@ extern "C" int tc_factor_att_bwd(const void* q, const void* k, const void* v, in
     const size_t smem = sizeof(float) * ((size_t)N * Ch + (size_t)4 * Ch * Ch + ((Ch + 3) & ~3)) + 3 * esz * N * Ch;
     if (smem > 150 * 1024) return TC_ERR_ARG;
     TC_DISPATCH_DTYPE(dtype, {
-        if (smem > 64 * 1024) hipFuncSetAttribute((const void*)factor_att_bwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)factor_att_bwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipLaunchKernelGGL((factor_att_bwd_kernel<T>), dim3(Bt * heads), dim3(256), smem, (hipStream_t)stream, (const T*)q, (const T*)k,
                            (const T*)v, ld, (const T*)convv, ldc, (const T*)go, ldgo, stats, (T*)dq, (T*)dk, (T*)dv, ldd, acc_q, acc_k,
                            acc_v, (T*)dconvv, lddc, N, Ch, heads, scale);
     });
     return tc_launch_status();
+}
+
+// LDS bytes of the fused attention half for width C and N tokens per image (0: unsupported width)
+static size_t mhca_att_smem_of(int C, int N) {
+    return C == 64 ? mhca_att_smem<64>(N) : C == 128 ? mhca_att_smem<128>(N) : C == 320 ? mhca_att_smem<320>(N) : 0;
+}
+extern "C" int tc_mhca_att_supported(int C, int N, int dtype) {
+    if (dtype != TC_BF16 && dtype != TC_F16) return 0;
+    const size_t sm = mhca_att_smem_of(C, N);
+    return sm > 0 && sm <= 150 * 1024 && N > 0;
+}
+extern "C" int tc_mhca_att_fwd(const void* xn, int ldx, const void* Wqkv, const void* bqkv, const void* w3, const void* b3, const void* w5,
+                               const void* b5, const void* w7, const void* b7, long long gs, void* qkv, int ldq, void* convv, int ldc,
+                               void* o, int ldo, float* stats, int groups, int B, int H, int W, int C, float scale, int dtype, void* stream) {
+    if (!xn || !Wqkv || !bqkv || !w3 || !b3 || !w5 || !b5 || !w7 || !b7 || !qkv || !convv || !o || !stats || groups <= 0 || B <= 0 || H <= 0 || W <= 0)
+        return TC_ERR_ARG;
+    if (!tc_mhca_att_supported(C, H * W, dtype)) return TC_ERR_UNSUPPORTED;
+    if (ldx % 8 || ldq % 8 || ldc % 8 || ldo % 8 || gs % 8 ||
+        (((uintptr_t)xn | (uintptr_t)Wqkv | (uintptr_t)qkv | (uintptr_t)convv | (uintptr_t)o) & 15))
+        return TC_ERR_ARG;
+    MhcaAttDev p;
+    p.xn = xn; p.Wqkv = Wqkv; p.bqkv = bqkv; p.cw[0] = w3; p.cw[1] = w5; p.cw[2] = w7; p.cb[0] = b3; p.cb[1] = b5; p.cb[2] = b7;
+    p.qkv = qkv; p.convv = convv; p.o = o; p.stats = stats; p.gs = gs; p.ldx = ldx; p.ldq = ldq; p.ldc = ldc; p.ldo = ldo;
+    p.B = B; p.N = H * W; p.H = H; p.W = W; p.scale = scale;
+    const int Bt = groups * B;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == TC_BF16) {
+        if (C == 64) return mhca_att_launch<bf16_t, 64>(p, Bt, s);
+        if (C == 128) return mhca_att_launch<bf16_t, 128>(p, Bt, s);
+        return mhca_att_launch<bf16_t, 320>(p, Bt, s);
+    }
+    if (C == 64) return mhca_att_launch<f16_t, 64>(p, Bt, s);
+    if (C == 128) return mhca_att_launch<f16_t, 128>(p, Bt, s);
+    return mhca_att_launch<f16_t, 320>(p, Bt, s);
 }

@@ -200,6 +200,7 @@ _EFFATT_FUSED = os.environ.get("TC_EFFATT_FUSED", "1") != "0"        # Efficient
 # measured a wash -- 13.12 vs 13.08 ms per step with it on: the tiled kernels are VALU-bound, so the +17 us (backward) / +2 us (forward)
 # the in-kernel LayerNorm costs per site cancel the two memory-bound launches it removes (negative results).
 _FFN_PRE_LN = os.environ.get("TC_FFN_PRE_LN", "0") != "0"
+_MHCA_ATT_FUSED = os.environ.get("TC_MHCA_ATT_FUSED", "1") != "0"  # qkv + crpe + factorised attention of an MHCABlock as one forward launch (csrc/factoratt.hip)
 _DW_BWD_ONE = os.environ.get("TC_DW_BWD_ONE", "1") != "0"          # input + weight gradient of a stride-1 depthwise conv in one launch
 _FFN_TILED_BWD = os.environ.get("TC_FFN_TILED_BWD", "1") != "0"   # MixFFN backward on the chip (csrc/mixffn_bwd.hip) where the library supports the width
 _FFN_TILE_BWD = (0, 0)                                         # forced pixel tile of the tiled backward's second launch (tests)
@@ -586,7 +587,7 @@ class Graph:
     def linear(self, x: Var, W: P, b: Optional[P] = None, out: Optional[Var] = None, residual: Optional[Var] = None,
                act: int = ACT_NONE, wcols: Optional[Tuple[int, int]] = None, accumulate: bool = False,
                batch: Optional[Tuple[int, int, int, int]] = None, post_scale: Optional[float] = None,
-               bn_shift: Optional[torch.Tensor] = None) -> Var:
+               bn_shift: Optional[torch.Tensor] = None, launch: bool = True) -> Var:
         """out = act(x @ W[:, wcols]^T + b + residual)  (or out += ... when accumulate).  W is [N, K] (nn.Linear).
 
         bn_shift (fp32 [N], the running mean of the BatchNorm this output feeds in training mode): on 16-bit storage the GEMM's
@@ -628,11 +629,12 @@ class Graph:
             tiles = (M + 63) // 64
             bn_part = self.f32(N * (1 + 2 * max(tiles, 128)))        # (also the scratch of the BatchNorm's backward sums)
             out.bn_part = (bn_part, tiles)
-        self._gemm(_ptr(x.data), x.ld, _ptr(Wt), Wt.stride(0), _ptr(out.data), out.ld, M, N, K, 0, 1,
-                   bias=_ptr(b.data) if b is not None else None, R=_ptr(residual.data) if residual is not None else None,
-                   ldr=residual.ld if residual is not None else 0, acc=int(accumulate), act=act if post_scale is None else ACT_SCALE,
-                   alpha=1.0 if post_scale is None else post_scale, nb1=nb, sA=(sx, 0), sB=(sw, 0), sC=(so, 0), sR=(sr, 0), sbias=sw,
-                   bn_part=_ptr(bn_part) if bn_part is not None else None, bn_shift=_ptr(bn_shift) if bn_part is not None else None)
+        if launch:          # (False: a fused kernel of the caller computes `out`; only the backward closure is recorded)
+            self._gemm(_ptr(x.data), x.ld, _ptr(Wt), Wt.stride(0), _ptr(out.data), out.ld, M, N, K, 0, 1,
+                       bias=_ptr(b.data) if b is not None else None, R=_ptr(residual.data) if residual is not None else None,
+                       ldr=residual.ld if residual is not None else 0, acc=int(accumulate), act=act if post_scale is None else ACT_SCALE,
+                       alpha=1.0 if post_scale is None else post_scale, nb1=nb, sA=(sx, 0), sB=(sw, 0), sC=(so, 0), sR=(sr, 0), sbias=sw,
+                       bn_part=_ptr(bn_part) if bn_part is not None else None, bn_shift=_ptr(bn_shift) if bn_part is not None else None)
 
         def bwd():
             dy = self.grad_of(out)
@@ -1246,7 +1248,7 @@ class Graph:
         return out
 
     def dwconv_multi(self, xs: List[Var], ws: List[P], bs: List[Optional[P]], geo, ks: List[int], outs: List[Optional[Var]],
-                     add_input: bool = False) -> List[Var]:
+                     add_input: bool = False, launch: bool = True) -> List[Var]:
         """Up to four independent stride-1 depthwise convolutions in one launch each for forward, input gradient and weight
         gradient (tc_dwconv_multi): column slices of one map with different kernel sizes (crpe), or different maps (the per-scale
         MixFFNs of a bridge layer).  geo = (B, H, W) for all, or a list of them per segment; outs[i] None -> a new buffer."""
@@ -1263,9 +1265,10 @@ class Graph:
             return arr
         none, zero = [None] * n, [0] * n
         wd, bd = [_ptr(w.data) for w in ws], [_ptr(b.data) if b is not None else None for b in bs]
-        self.L.tc_dwconv_multi(segs([_ptr(x.data) for x in xs], wd, bd, [_ptr(o.data) for o in outs], none, none, none,
-                                    [x.ld for x in xs], [o.ld for o in outs], zero), n, 0, int(add_input), 0, Gn, gs, None, 0,
-                               self.dt, self.stream)
+        if launch:
+            self.L.tc_dwconv_multi(segs([_ptr(x.data) for x in xs], wd, bd, [_ptr(o.data) for o in outs], none, none, none,
+                                        [x.ld for x in xs], [o.ld for o in outs], zero), n, 0, int(add_input), 0, Gn, gs, None, 0,
+                                   self.dt, self.stream)
 
         def bwd():
             dys = [self.grad_of(o) for o in outs]
@@ -1409,16 +1412,52 @@ class Graph:
         self._rec(bwd)
         return out
 
-    def factor_att_core(self, q: Var, k: Var, v: Var, convv: Var, Bt: int, N: int, heads: int, scale: float) -> Var:
+    def mhca_att_supported(self, n: Var, N: int) -> bool:
+        return (_MHCA_ATT_FUSED and self.dt != TC_F32 and not self.use_streams and n.ld % 8 == 0 and n.data.data_ptr() % 16 == 0
+                and (self.pgs % 8 == 0 or self.ngroups == 1) and bool(self.L.tc_mhca_att_supported(n.cols, N, self.dt)))
+
+    def mhca_attention(self, n: Var, Wqkv: P, bqkv: P, cws: List[P], cbs: List[P], B: int, side: int, heads: int, scale: float,
+                       windows: List[Tuple[int, int]]) -> Var:
+        """The attention half of an MHCABlock after norm1 -- qkv projection, ConvRelPosEnc over v, factorised attention
+        (MSTr.py:852-886, 801-823) -- as ONE forward launch per (image, head) (tc_mhca_att_fwd) instead of three.  q | k | v, crpe(v)
+        and the key-softmax statistics are stored as before, and the backward is the three ops' own (their closures are recorded
+        without their forward launches)."""
+        C_, N = n.cols, side * side
+        Ch = C_ // heads
+        Bt = B * self.ngroups
+        qkv = self.linear(n, Wqkv, bqkv, out=self.new(n.rows, 3 * C_, covered=True), launch=False)
+        q, k, v = qkv.colslice(0, C_), qkv.colslice(C_, 2 * C_), qkv.colslice(2 * C_, 3 * C_)
+        convv = self.new(n.rows, C_)
+        c0, xs, outs, kss = 0, [], [], []
+        for ksz, nh in windows:
+            w = nh * Ch
+            xs.append(v.colslice(c0, c0 + w)); outs.append(convv.colslice(c0, c0 + w)); kss.append(ksz)
+            c0 += w
+        self.dwconv_multi(xs, cws, cbs, (B, side, side), kss, outs, launch=False)
+        stats = self.f32(int(self.L.tc_factor_att_stats_floats(Bt, heads, Ch)))
+        o = self.factor_att_core(q, k, v, convv, Bt, N, heads, scale, stats=stats, launch=False)
+        gs = Wqkv.gs if self.ngroups > 1 else 0
+        self.n_launch += 1
+        _timed("hbm:mhca_att_fwd (qkv projection + crpe + factorised attention, one launch)", (1.0 + 3.0 + 1.0 + 1.0) * n.rows * C_ * n.data.element_size(),
+               lambda: self.L.tc_mhca_att_fwd(_ptr(n.data), n.ld, _ptr(Wqkv.data), _ptr(bqkv.data), _ptr(cws[0].data), _ptr(cbs[0].data),
+                                              _ptr(cws[1].data), _ptr(cbs[1].data), _ptr(cws[2].data), _ptr(cbs[2].data), gs, _ptr(qkv.data), qkv.ld,
+                                              _ptr(convv.data), convv.ld, _ptr(o.data), o.ld, _ptr(stats), self.ngroups, B, side, side, C_, scale,
+                                              self.dt, self.stream))
+        return o
+
+    def factor_att_core(self, q: Var, k: Var, v: Var, convv: Var, Bt: int, N: int, heads: int, scale: float,
+                        stats: Optional[torch.Tensor] = None, launch: bool = True) -> Var:
         """o = scale * q (softmax_N(k)^T v) + q (.) convv per (image, head) in one launch (tc_factor_att_fwd); q/k/v are
         column slices of one qkv buffer."""
         C_ = q.cols
         Ch = C_ // heads
         assert q.ld == k.ld == v.ld and q.rows == Bt * N
         out = self.new(q.rows, C_)
-        stats = self.f32(int(self.L.tc_factor_att_stats_floats(Bt, heads, Ch)))
-        self.L.tc_factor_att_fwd(_ptr(q.data), _ptr(k.data), _ptr(v.data), q.ld, _ptr(convv.data), convv.ld, _ptr(out.data), out.ld,
-                                 _ptr(stats), Bt, N, heads, Ch, scale, self.dt, self.stream)
+        if stats is None:
+            stats = self.f32(int(self.L.tc_factor_att_stats_floats(Bt, heads, Ch)))
+        if launch:
+            self.L.tc_factor_att_fwd(_ptr(q.data), _ptr(k.data), _ptr(v.data), q.ld, _ptr(convv.data), convv.ld, _ptr(out.data), out.ld,
+                                     _ptr(stats), Bt, N, heads, Ch, scale, self.dt, self.stream)
 
         def bwd():
             go = self.grad_of(out)

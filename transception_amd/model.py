@@ -736,6 +736,10 @@ def _factor_att(M, G, n: Var, blk: str, enc: str, B: int, side: int, residual: O
     C, N = n.cols, side * side
     Bt = B * G.ngroups                              # images of all stacked weight groups
     rows, h, Ch = Bt * N, HEADS, n.cols // HEADS
+    if FUSED_FACTOR_ATT and MULTI_CRPE and Ch % 8 == 0 and G.mhca_att_supported(n, N):     # qkv + crpe + attention core: one launch
+        o = G.mhca_attention(n, *_lin(M, G, blk + ".factoratt_crpe.qkv"), [M._P(G, f"{enc}.crpe.conv_list.{i}.weight") for i in range(3)],
+                             [M._P(G, f"{enc}.crpe.conv_list.{i}.bias") for i in range(3)], B, side, h, Ch ** -0.5, list(CRPE_WINDOW))
+        return G.linear(o, *_lin(M, G, blk + ".factoratt_crpe.proj"), residual=residual)
     qkv = G.linear(n, *_lin(M, G, blk + ".factoratt_crpe.qkv"), out=G.new(n.rows, 3 * C, covered=FUSED_FACTOR_ATT))
     q, k, v = qkv.colslice(0, C), qkv.colslice(C, 2 * C), qkv.colslice(2 * C, 3 * C)
     convv = G.new(rows, C)
