@@ -564,7 +564,16 @@ long long tc_factor_att_stats_floats(int Bt, int heads, int Ch);
  * xn [groups*B*N, C] (row stride ldx); qkv [.., 3C], convv, o [.., C] and stats (tc_factor_att_stats_floats(groups*B, 8, C/8) floats) are
  * written as tc_gemm + tc_dwconv_multi + tc_factor_att_fwd would leave them (their backward entries apply unchanged).  Parameters of
  * weight group g (the three MB paths) at +g*gs elements. */
+/* tc_mhca_att_bwd: the backward of the crpe window and the attention core for the same layout in one launch per (image, head) -- what
+ * tc_factor_att_bwd followed by tc_dwconv_multi (mode 3) compute: dq | dk | dv into dqkv [.., 3C] (row stride ldd; acc_* = add to what is
+ * there), the window's weight / bias gradients ADDED to dw3 / db3 / dw5 / db5 / dw7 / db7 (fp32, laid out like the weights, group g at
+ * +g*gs).  go = d loss / d o.  dconvv is not materialised. */
 int tc_mhca_att_supported(int C, int N, int dtype);
+int tc_mhca_att_bwd_supported(int C, int N, int dtype);
+int tc_mhca_att_bwd(const void* qkv, int ldq, const void* convv, int ldc, const void* go, int ldgo, const float* stats, void* dqkv,
+                    int ldd, int acc_q, int acc_k, int acc_v, const void* w3, const void* w5, const void* w7, float* dw3, float* db3,
+                    float* dw5, float* db5, float* dw7, float* db7, long long gs, int groups, int B, int H, int W, int C, float scale,
+                    int dtype, void* stream);
 int tc_mhca_att_fwd(const void* xn, int ldx, const void* Wqkv, const void* bqkv, const void* w3, const void* b3, const void* w5,
                     const void* b5, const void* w7, const void* b7, long long gs, void* qkv, int ldq, void* convv, int ldc,
                     void* o, int ldo, float* stats, int groups, int B, int H, int W, int C, float scale, int dtype, void* stream);

@@ -88,8 +88,9 @@ def test_mhca_attention_one_launch(dtype, C, side, B, Gn):
     ref, xr, pr = _reference(x16.float(), master, per, shapes, sizes, Gn, B, side, C)
     ref.backward(gy16.float())
 
-    def run(fused):
+    def run(fused, fused_bwd=True):
         E._MHCA_ATT_FUSED = fused
+        E._MHCA_ATT_BWD_FUSED = fused_bwd
         gflat.zero_()
         G = Graph(dtype, torch.device(DEV), training=True, record=True)
         xv = Var(x16.to(DEV).contiguous())
@@ -108,10 +109,10 @@ def test_mhca_attention_one_launch(dtype, C, side, B, Gn):
                 xs.append(v.colslice(c0, c0 + nh * Ch)); outs.append(convv.colslice(c0, c0 + nh * Ch)); c0 += nh * Ch
             G.dwconv_multi(xs, [Ps[2], Ps[4], Ps[6]], [Ps[3], Ps[5], Ps[7]], (B, side, side), [3, 5, 7], outs)
             o = G.factor_att_core(q, k, v, convv, Gn * B, N, 8, Ch ** -0.5)
-        nl = G.n_launch
         o.root.grad_t = gy16.to(DEV).contiguous()
         o.root.whole_written = True
         G.backward()
+        nl = G.n_launch
         if ctxm is not None:
             ctxm.__exit__(None, None, None)
         torch.cuda.synchronize()
@@ -119,9 +120,10 @@ def test_mhca_attention_one_launch(dtype, C, side, B, Gn):
 
     try:
         of, dxf, gpf, nlf = run(True)
+        o2, dx2, gp2, _ = run(True, fused_bwd=False)
         ou, dxu, gpu_, nlu = run(False)
     finally:
-        E._MHCA_ATT_FUSED = True
+        E._MHCA_ATT_FUSED = E._MHCA_ATT_BWD_FUSED = True
     tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
     assert rel(of, ref) < tol, ("o vs torch", rel(of, ref))
     assert rel(dxf, xr.grad) < 2 * tol, ("dx vs torch", rel(dxf, xr.grad))
@@ -130,4 +132,7 @@ def test_mhca_attention_one_launch(dtype, C, side, B, Gn):
     assert rel(of, ou) < tol / 2, ("o fused vs unfused", rel(of, ou))
     assert rel(dxf, dxu) < tol, ("dx fused vs unfused", rel(dxf, dxu))
     assert rel(gpf, gpu_) < tol, ("parameter gradients fused vs unfused", rel(gpf, gpu_))
-    assert nlf == 1 and nlu >= 1
+    # the one-launch backward against the two launches it replaces (same forward)
+    assert rel(dxf, dx2) < tol / 2, ("dx, fused backward vs factor_att_bwd + dwconv_multi", rel(dxf, dx2))
+    assert rel(gpf, gp2) < tol / 2, ("parameter gradients, fused backward vs factor_att_bwd + dwconv_multi", rel(gpf, gp2))
+    assert nlf == 3 and nlu >= 1                      # forward, fused backward, the projection's gradient pair

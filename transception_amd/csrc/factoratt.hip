@@ -656,6 +656,350 @@ __global__ __launch_bounds__(256, 2) void mhca_att_fwd_kernel(MhcaAttDev p) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Backward of the same half, one launch per (image, head): factor_att_bwd_kernel's arithmetic + the window's backward, which used to be
+// a launch of its own (tc_dwconv_multi mode 3) reading dconvv back from memory:
+//   dconvv = do (.) q  stays in LDS;  dv += crpe^T(dconvv) (the window flipped);  dw[c][tap] += sum_n dconvv[n, c] v[n + tap, c],
+//   db[c] += sum_n dconvv[n, c]  -- per-head sums over the image, added to the fp32 gradients with one atomic per word and workgroup.
+struct MhcaAttBwdDev {
+    const void *qkv, *convv, *go, *cw[3];
+    const float* stats;
+    void* dqkv;
+    float *dcw[3], *dcb[3];
+    long long gs;
+    int ldq, ldc, ldgo, ldd, acc_q, acc_k, acc_v, B, N, H, W;
+    float scale;
+};
+
+// dw / db of one head's K x K window.  Work item = (filter row ky, 8-channel group, image row y): it walks the W pixels of its row with
+// K x 8 accumulators (one filter row), G = 8 / 16 / 32 / 64 lanes (the image rows, padded to a power of two) then fold by DPP / shuffles
+// and lane 0 of a group adds the K x 8 (+ 8 for the bias, ky == 0) sums to the gradient arrays.
+#ifdef TC_MHCA_TIMING
+__device__ long long g_wg_stamps[4096 * 4];
+#define WG_STAMP(i) if (threadIdx.x == 0 && it0 == 0) g_wg_stamps[blockIdx.x * 4 + (i)] = clock64()
+#else
+#define WG_STAMP(i)
+#endif
+// dw / db of one head's K x K window.  Work item = (filter row ky, 8-channel group, image row y): it walks the W pixels of its row with
+// K x 8 accumulators (one filter row) and a K-wide window of v in registers -- the walk is unrolled K pixels at a time so that the
+// window's slots are compile-time names: one new v vector and one dconvv vector are read per pixel (reading the K window vectors per
+// pixel cost ~230 instructions per pixel for a lone wave per SIMD: the phase was half of the launch).  G = 8 / 16 / 32 / 64 lanes
+// (the image rows, padded to a power of two) then fold by DPP / shuffles; lane 0 of a group leaves the K x 8 (+ 8 for the bias,
+// ky == 0) sums in the LDS array `dwl` ([CH][K*K] then [CH]), which the caller adds to the gradient arrays with full-width atomics.
+template <int K, int CH, int G, typename T>
+__device__ __forceinline__ void mhca_conv_wgrad(const T* dc, const T* vs, float* dwl, int H, int W) {
+    constexpr int P = K / 2, NV = CH / 8, KK = K * K;
+    const int items = K * NV * G;
+    for (int it0 = 0; it0 < items; it0 += 256) {
+        const int it = it0 + threadIdx.x;
+        const int y = it & (G - 1), r = it / G, cvi = r % NV, ky = r / NV, c0 = cvi * 8;
+        const bool live = it < items && y < H;
+        const int yy = y + ky - P;
+        const bool rv = live && (unsigned)yy < (unsigned)H;
+        float acc[K][8], accb[8], win[K][8];
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[kx][u] = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) accb[u] = 0.f;
+        WG_STAMP(0);
+        const T* dr = dc + ((live ? y : 0) * W) * CH + c0;
+        const T* vr = vs + ((rv ? yy : 0) * W) * CH + c0;
+        // window slots: at pixel x = xb + j slot (j + i) % K holds v[x - P + i]; before the walk: v[-P .. P-1] (zeros left of the row)
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const int xx = i - P;
+            uint4 raw = *reinterpret_cast<const uint4*>(vr + (xx > 0 && xx < W ? xx : 0) * CH);
+            if (!(rv && xx >= 0 && xx < W)) raw = make_uint4(0u, 0u, 0u, 0u);
+            unpack16<T>(raw, win[i]);
+        }
+        for (int xb = 0; xb < W; xb += K) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const int x = xb + j;
+                // the newest element v[x + P] replaces v[x - P - 1] in slot (j + K - 1) % K ... which at step j is the slot of window index K - 1
+                {
+                    const int xx = x + P;
+                    uint4 raw = *reinterpret_cast<const uint4*>(vr + (xx < W ? xx : 0) * CH);
+                    if (!(rv && xx < W)) raw = make_uint4(0u, 0u, 0u, 0u);
+                    unpack16<T>(raw, win[(j + K - 1) % K]);
+                }
+                uint4 draw = *reinterpret_cast<const uint4*>(dr + (x < W ? x : 0) * CH);
+                if (!(live && x < W)) draw = make_uint4(0u, 0u, 0u, 0u);
+                float d8[8];
+                unpack16<T>(draw, d8);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) accb[u] += d8[u];
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc[kx][u] = fmaf(d8[u], win[(j + kx) % K][u], acc[kx][u]);
+            }
+        }
+        WG_STAMP(1);
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[kx][u] = tc_group_sum<G>(acc[kx][u]);
+        WG_STAMP(2);
+        if (it < items && y == 0) {
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) dwl[(c0 + u) * KK + ky * K + kx] = acc[kx][u];
+        }
+        if (ky == 0) {                                           // (uniform per G-lane group)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) accb[u] = tc_group_sum<G>(accb[u]);
+            if (it < items && y == 0) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) dwl[CH * KK + c0 + u] = accb[u];
+            }
+        }
+        WG_STAMP(3);
+    }
+}
+#ifdef TC_MHCA_TIMING
+extern "C" int tc_dbg_wg_stamps(long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wg_stamps), sizeof(long long) * n); }
+#endif
+template <int K, int CH, typename T>
+__device__ __forceinline__ void mhca_conv_wgrad_pick(const T* dc, const T* vs, float* dwl, int H, int W) {
+    if (H <= 8) mhca_conv_wgrad<K, CH, 8, T>(dc, vs, dwl, H, W);
+    else if (H <= 16) mhca_conv_wgrad<K, CH, 16, T>(dc, vs, dwl, H, W);
+    else if (H <= 32) mhca_conv_wgrad<K, CH, 32, T>(dc, vs, dwl, H, W);
+    else mhca_conv_wgrad<K, CH, 64, T>(dc, vs, dwl, H, W);
+}
+
+template <typename T, int C>
+__global__ __launch_bounds__(256, 2) void mhca_att_bwd_kernel(MhcaAttBwdDev p) {
+    constexpr int CH = C / 8, NV = CH / 8, VEC = 8;
+    extern __shared__ float sm[];
+    const int N = p.N, tid = threadIdx.x;
+#ifdef TC_MHCA_TIMING
+    long long tstamp[8];
+    MHCA_STAMP(0);
+#endif
+    float* e = sm;                        // softmax(k) (normalised), fp32
+    float* ctx = e + N * CH;
+    float* dctx = ctx + CH * CH;
+    float* tcol = dctx + CH * CH;         // [CH] (+ padding to 16 bytes)
+    float* ctxT = tcol + ((CH + 3) & ~3);
+    float* dctxT = ctxT + CH * CH;
+    float* wcv = dctxT + CH * CH;         // [49][CH] the window's taps FLIPPED (the input gradient of a correlation is the correlation with the flipped window)
+    float* bz = wcv + 49 * CH;            // [CH] zeros (the window routine adds a bias)
+    T* vs = reinterpret_cast<T*>(bz + CH);
+    T* qs = vs + N * CH;                  // q, then dconvv = do (.) q in place
+    T* gs_ = qs + N * CH;                 // do
+    T* dvc = gs_ + N * CH;                // crpe^T(dconvv)
+    int bt, hd;
+    if (((gridDim.x >> 3) & 7) == 0) {                 // (as in the forward kernel: heads of an image on one XCD, long windows first)
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, nu = gridDim.x >> 6;
+        const int hs = j / nu;
+        hd = hs < 3 ? 5 + hs : (hs < 6 ? hs - 1 : hs - 6);
+        bt = xcd * nu + (j - hs * nu);
+    } else {
+        const int blk0 = (gridDim.x & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
+        bt = blk0 >> 3; hd = blk0 & 7;
+    }
+    const int blk = bt * 8 + hd, g = bt / p.B;
+    const long long row0 = (long long)bt * N;
+    const int col0 = hd * CH;
+    const int wi = hd < 2 ? 0 : (hd < 5 ? 1 : 2), K = 3 + 2 * wi, hoff = hd - (wi == 0 ? 0 : (wi == 1 ? 2 : 5)), KK = K * K, ntap = KK * CH;
+    const T* qg = reinterpret_cast<const T*>(p.qkv) + row0 * p.ldq + col0;
+    const T* gg = reinterpret_cast<const T*>(p.go) + row0 * p.ldgo + col0;
+    const T* cg = reinterpret_cast<const T*>(p.convv) + row0 * p.ldc + col0;
+    // ---- every tile of the head in flight at once: q | k | v | do pieces of up to 4 x 256 (token, 8-channel) items, this thread's convv pieces, the taps
+    const int nitem = N * NV;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 cvr[4];
+    {
+        // (asm volatile loads, one explicit wait: see the forward kernel -- the compiler otherwise sinks every piece's loads to its LDS store,
+        // one memory round trip per piece)
+        u32x4 rq[4], rk[4], rv[4], rg[4];
+#define MHCA_FETCH_B(I0)                                                                                                               \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                                    \
+        const int i = (I0) + tid + 256 * j, ic = i < nitem ? i : 0, n = ic / NV, c8 = (ic - n * NV) * 8;                               \
+        const T* src = qg + (long long)n * p.ldq + c8;                                                                                 \
+        const T* srk = src + C;                                                                                                        \
+        const T* srv = src + 2 * C;                                                                                                    \
+        const T* srg = gg + (long long)n * p.ldgo + c8;                                                                                \
+        MHCA_GLOAD128(rq[j], src); MHCA_GLOAD128(rk[j], srk); MHCA_GLOAD128(rv[j], srv); MHCA_GLOAD128(rg[j], srg);                    \
+    }
+        MHCA_FETCH_B(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = tid + 256 * j, ic = i < nitem ? i : 0, n = ic / NV, c8 = (ic - n * NV) * 8;
+            const T* src = cg + (long long)n * p.ldc + c8;
+            MHCA_GLOAD128(cvr[j], src);
+        }
+        unsigned tapv[8];
+        const T* cw = reinterpret_cast<const T*>(p.cw[wi]) + g * p.gs + (long long)hoff * CH * KK;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int i = tid + 256 * j; tapv[j] = ld_raw16<T>(cw + (i < ntap ? i : 0)); }
+        const float stv = p.stats[((long long)blk * 2) * CH + (tid < 2 * CH ? tid : 0)];      // cmax[CH] | cinv[CH] of this head, through LDS (tcol / ctxT are free until the grams are done)
+        float* cmaxp = ctxT;
+        for (int i0 = 0;;) {
+            asm volatile("s_waitcnt vmcnt(0)");
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { MHCA_KEEP128(rq[j]); MHCA_KEEP128(rk[j]); MHCA_KEEP128(rv[j]); MHCA_KEEP128(rg[j]); }
+            if (i0 == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) MHCA_KEEP128(cvr[j]);
+                const float rkk = 1.0f / (float)KK;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int i = tid + 256 * j;
+                    if (i < ntap) { const int ch = (int)(((float)i + 0.5f) * rkk), tap = i - ch * KK; wcv[(KK - 1 - tap) * CH + ch] = cvt_raw16<T>(tapv[j]); }
+                }
+                if (tid < CH) bz[tid] = 0.f;
+                if (tid < 2 * CH) cmaxp[tid] = stv;
+                __syncthreads();
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = i0 + tid + 256 * j;
+                if (i < nitem) {
+                    const int n = i / NV, c8 = (i - n * NV) * 8;
+                    *reinterpret_cast<u32x4*>(qs + n * CH + c8) = rq[j];
+                    *reinterpret_cast<u32x4*>(vs + n * CH + c8) = rv[j];
+                    *reinterpret_cast<u32x4*>(gs_ + n * CH + c8) = rg[j];
+                    float k8[8];
+                    unpack16<T>(make_uint4(rk[j].x, rk[j].y, rk[j].z, rk[j].w), k8);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) k8[u] = __expf(k8[u] - cmaxp[c8 + u]) * cmaxp[CH + c8 + u];
+                    *reinterpret_cast<float4*>(e + n * CH + c8) = make_float4(k8[0], k8[1], k8[2], k8[3]);
+                    *reinterpret_cast<float4*>(e + n * CH + c8 + 4) = make_float4(k8[4], k8[5], k8[6], k8[7]);
+                }
+            }
+            i0 += 1024;
+            if (i0 >= nitem) break;
+            MHCA_FETCH_B(i0);
+        }
+    }
+    __syncthreads();
+    MHCA_STAMP(1);
+    fa_gram(ctx, e, vs, N, CH);
+    fa_gram(dctx, qs, gs_, N, CH);
+    for (int i = tid; i < CH * CH; i += 256) dctx[i] *= p.scale;
+    // dconvv = do (.) q, in place of q (q is not read again: dq's q-term is do (.) convv)
+    for (int i = tid; i < nitem; i += 256) {
+        float a[8], b[8];
+        fa_get8(qs + i * 8, a); fa_get8(gs_ + i * 8, b);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] *= b[u];
+        *reinterpret_cast<uint4*>(qs + i * 8) = pack16<T>(a);
+    }
+    __syncthreads();
+    if (tid < CH) { float t = 0.f; for (int j = 0; j < CH; ++j) t += ctx[tid * CH + j] * dctx[tid * CH + j]; tcol[tid] = t; }
+    for (int i = tid; i < CH * CH; i += 256) { const int c = i / CH, j = i - c * CH; ctxT[j * CH + c] = ctx[i]; dctxT[j * CH + c] = dctx[i]; }
+    MHCA_STAMP(2);
+    // the window's backward on the dconvv tile: input gradient (-> dvc), then the head's weight / bias gradient sums -- parked in the taps' LDS
+    // array (the taps are not read again) and added to the fp32 gradients by the whole workgroup: one atomic per word, consecutive lanes
+    // consecutive words (lane 0 of every row group issuing its 64 atomics one lane at a time took ~180 cycles per instruction)
+    if (K == 3) mhca_conv_pick<3, CH, T>(dvc, qs, wcv, bz, p.H, p.W);
+    else if (K == 5) mhca_conv_pick<5, CH, T>(dvc, qs, wcv, bz, p.H, p.W);
+    else mhca_conv_pick<7, CH, T>(dvc, qs, wcv, bz, p.H, p.W);
+    MHCA_STAMP(3);
+    __syncthreads();
+    if (K == 3) mhca_conv_wgrad_pick<3, CH, T>(qs, vs, wcv, p.H, p.W);
+    else if (K == 5) mhca_conv_wgrad_pick<5, CH, T>(qs, vs, wcv, p.H, p.W);
+    else mhca_conv_wgrad_pick<7, CH, T>(qs, vs, wcv, p.H, p.W);
+    __syncthreads();
+    {
+        float* dwg = p.dcw[wi] + g * p.gs + (long long)hoff * CH * KK;
+        float* dbg = p.dcb[wi] + g * p.gs + hoff * CH;
+        for (int i = tid; i < ntap + CH; i += 256) atomicAdd(i < ntap ? dwg + i : dbg + (i - ntap), wcv[i]);
+    }
+    __syncthreads();
+    MHCA_STAMP(4);
+    T* dq0 = reinterpret_cast<T*>(p.dqkv) + row0 * p.ldd + col0;
+    auto token = [&](int i, const uint4 cvraw) __attribute__((always_inline)) {
+        const int n = i / NV, c0 = (i - n * NV) * VEC;
+        const T* gr = gs_ + n * CH;
+        const T* vr = vs + n * CH;
+        const float* er = e + n * CH;
+        float a_q[VEC], a_ks[VEC], a_v[VEC], cv[VEC];
+#pragma unroll
+        for (int u = 0; u < VEC; ++u) a_q[u] = a_ks[u] = a_v[u] = 0.f;
+#pragma unroll 1
+        for (int j8 = 0; j8 < CH; j8 += 8) {
+            float g8[8], v8[8], e8[8];
+            fa_get8(gr + j8, g8); fa_get8(vr + j8, v8); fa_get8(er + j8, e8);
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int j = j8 + jj;
+                float cq[VEC], ck[VEC], cw8[VEC];
+#pragma unroll
+                for (int u = 0; u < VEC; u += 4) {
+                    *reinterpret_cast<float4*>(cq + u) = *reinterpret_cast<const float4*>(ctxT + j * CH + c0 + u);
+                    *reinterpret_cast<float4*>(ck + u) = *reinterpret_cast<const float4*>(dctxT + j * CH + c0 + u);
+                    *reinterpret_cast<float4*>(cw8 + u) = *reinterpret_cast<const float4*>(dctx + j * CH + c0 + u);
+                }
+#pragma unroll
+                for (int u = 0; u < VEC; ++u) {
+                    a_q[u] += g8[jj] * cq[u];                 // dq[n,c]  += scale * sum_j do[n,j] ctx[c,j]   (dctx carries the scale; ctx does not:)
+                    a_ks[u] += v8[jj] * ck[u];                // dksm[n,c] = sum_j v[n,j] dctx[c,j]
+                    a_v[u] += e8[jj] * cw8[u];                // dv[n,c]   = sum_i ksm[n,i] dctx[i,c]
+                }
+            }
+        }
+        unpack16<T>(cvraw, cv);
+        float dvc8[8], g0[8];
+        fa_get8(dvc + n * CH + c0, dvc8);
+        fa_get8(gr + c0, g0);
+        T* pq = dq0 + (long long)n * p.ldd + c0;
+        float old[VEC];
+#pragma unroll
+        for (int u = 0; u < VEC; ++u) {
+            a_q[u] = p.scale * a_q[u] + g0[u] * cv[u];
+            a_ks[u] = er[c0 + u] * (a_ks[u] - tcol[c0 + u]);
+            a_v[u] += dvc8[u];
+        }
+        if (p.acc_q) { unpack16<T>(*reinterpret_cast<const uint4*>(pq), old);
+#pragma unroll
+            for (int u = 0; u < VEC; ++u) a_q[u] += old[u]; }
+        if (p.acc_k) { unpack16<T>(*reinterpret_cast<const uint4*>(pq + C), old);
+#pragma unroll
+            for (int u = 0; u < VEC; ++u) a_ks[u] += old[u]; }
+        if (p.acc_v) { unpack16<T>(*reinterpret_cast<const uint4*>(pq + 2 * C), old);
+#pragma unroll
+            for (int u = 0; u < VEC; ++u) a_v[u] += old[u]; }
+        *reinterpret_cast<uint4*>(pq) = pack16<T>(a_q);
+        *reinterpret_cast<uint4*>(pq + C) = pack16<T>(a_ks);
+        *reinterpret_cast<uint4*>(pq + 2 * C) = pack16<T>(a_v);
+    };
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+        const int i = tid + 256 * jt;
+        const uint4 c = make_uint4(cvr[jt].x, cvr[jt].y, cvr[jt].z, cvr[jt].w);
+        if (i < nitem) token(i, c);
+    }
+    for (int i = tid + 1024; i < nitem; i += 256) {
+        const int n = i / NV, c0 = (i - n * NV) * VEC;
+        token(i, *reinterpret_cast<const uint4*>(cg + (long long)n * p.ldc + c0));
+    }
+#ifdef TC_MHCA_TIMING
+    MHCA_STAMP(5);
+    if (tid == 0) {                       // (experiment builds only: the caller's dqkv buffer is followed by room for 8 stamps per workgroup -- passed through p.stats' tail)
+        long long* dbg = reinterpret_cast<long long*>(const_cast<float*>(p.stats) + (long long)gridDim.x * 2 * CH) + (long long)blk * 8;
+        for (int i = 0; i < 6; ++i) dbg[i] = tstamp[i];
+        dbg[7] = hd;
+    }
+#endif
+}
+
+template <int C> __host__ size_t mhca_att_bwd_smem(int N) {
+    constexpr int CH = C / 8;
+    return sizeof(float) * ((size_t)N * CH + (size_t)4 * CH * CH + ((CH + 3) & ~3) + 49 * CH + CH) + 4 * 2 * (size_t)N * CH;
+}
+template <typename T, int C> int mhca_att_bwd_launch(const MhcaAttBwdDev& p, int Bt, hipStream_t s) {
+    const size_t smem = mhca_att_bwd_smem<C>(p.N);
+    if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)mhca_att_bwd_kernel<T, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL((mhca_att_bwd_kernel<T, C>), dim3(Bt * 8), dim3(256), smem, s, p);
+    return tc_launch_status();
+}
+
 template <int C> __host__ size_t mhca_att_smem(int N) {
     constexpr int CH = C / 8;
     const size_t cvs = 2 * (size_t)N * CH, stage = 2 * (size_t)4 * 32 * (C + 8);           // convv tile / the four xn staging tiles share their bytes
@@ -744,4 +1088,38 @@ extern "C" int tc_mhca_att_fwd(const void* xn, int ldx, const void* Wqkv, const 
     if (C == 64) return mhca_att_launch<f16_t, 64>(p, Bt, s);
     if (C == 128) return mhca_att_launch<f16_t, 128>(p, Bt, s);
     return mhca_att_launch<f16_t, 320>(p, Bt, s);
+}
+
+static size_t mhca_att_bwd_smem_of(int C, int N) {
+    return C == 64 ? mhca_att_bwd_smem<64>(N) : C == 128 ? mhca_att_bwd_smem<128>(N) : C == 320 ? mhca_att_bwd_smem<320>(N) : 0;
+}
+extern "C" int tc_mhca_att_bwd_supported(int C, int N, int dtype) {
+    if (dtype != TC_BF16 && dtype != TC_F16) return 0;
+    const size_t sm = mhca_att_bwd_smem_of(C, N);
+    return sm > 0 && sm <= 79 * 1024 && N > 0;          // (two workgroups per CU: a launch of 3 x 16 images x 8 heads stays one wave of workgroups)
+}
+extern "C" int tc_mhca_att_bwd(const void* qkv, int ldq, const void* convv, int ldc, const void* go, int ldgo, const float* stats, void* dqkv,
+                               int ldd, int acc_q, int acc_k, int acc_v, const void* w3, const void* w5, const void* w7, float* dw3, float* db3,
+                               float* dw5, float* db5, float* dw7, float* db7, long long gs, int groups, int B, int H, int W, int C, float scale,
+                               int dtype, void* stream) {
+    if (!qkv || !convv || !go || !stats || !dqkv || !w3 || !w5 || !w7 || !dw3 || !db3 || !dw5 || !db5 || !dw7 || !db7 || groups <= 0 || B <= 0 ||
+        H <= 0 || W <= 0)
+        return TC_ERR_ARG;
+    if (!tc_mhca_att_bwd_supported(C, H * W, dtype)) return TC_ERR_UNSUPPORTED;
+    if (ldq % 8 || ldc % 8 || ldgo % 8 || ldd % 8 || (((uintptr_t)qkv | (uintptr_t)convv | (uintptr_t)go | (uintptr_t)dqkv) & 15)) return TC_ERR_ARG;
+    MhcaAttBwdDev p;
+    p.qkv = qkv; p.convv = convv; p.go = go; p.cw[0] = w3; p.cw[1] = w5; p.cw[2] = w7; p.stats = stats; p.dqkv = dqkv;
+    p.dcw[0] = dw3; p.dcw[1] = dw5; p.dcw[2] = dw7; p.dcb[0] = db3; p.dcb[1] = db5; p.dcb[2] = db7; p.gs = gs;
+    p.ldq = ldq; p.ldc = ldc; p.ldgo = ldgo; p.ldd = ldd; p.acc_q = acc_q; p.acc_k = acc_k; p.acc_v = acc_v;
+    p.B = B; p.N = H * W; p.H = H; p.W = W; p.scale = scale;
+    const int Bt = groups * B;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == TC_BF16) {
+        if (C == 64) return mhca_att_bwd_launch<bf16_t, 64>(p, Bt, s);
+        if (C == 128) return mhca_att_bwd_launch<bf16_t, 128>(p, Bt, s);
+        return mhca_att_bwd_launch<bf16_t, 320>(p, Bt, s);
+    }
+    if (C == 64) return mhca_att_bwd_launch<f16_t, 64>(p, Bt, s);
+    if (C == 128) return mhca_att_bwd_launch<f16_t, 128>(p, Bt, s);
+    return mhca_att_bwd_launch<f16_t, 320>(p, Bt, s);
 }

@@ -200,6 +200,7 @@ _EFFATT_FUSED = os.environ.get("TC_EFFATT_FUSED", "1") != "0"        # Efficient
 # measured a wash -- 13.12 vs 13.08 ms per step with it on: the tiled kernels are VALU-bound, so the +17 us (backward) / +2 us (forward)
 # the in-kernel LayerNorm costs per site cancel the two memory-bound launches it removes (negative results).
 _FFN_PRE_LN = os.environ.get("TC_FFN_PRE_LN", "0") != "0"
+_MHCA_ATT_BWD_FUSED = os.environ.get("TC_MHCA_ATT_BWD_FUSED", "1") != "0"  # ... and the backward of crpe + attention core as one launch
 _MHCA_ATT_FUSED = os.environ.get("TC_MHCA_ATT_FUSED", "1") != "0"  # qkv + crpe + factorised attention of an MHCABlock as one forward launch (csrc/factoratt.hip)
 _DW_BWD_ONE = os.environ.get("TC_DW_BWD_ONE", "1") != "0"          # input + weight gradient of a stride-1 depthwise conv in one launch
 _FFN_TILED_BWD = os.environ.get("TC_FFN_TILED_BWD", "1") != "0"   # MixFFN backward on the chip (csrc/mixffn_bwd.hip) where the library supports the width
@@ -1433,10 +1434,34 @@ class Graph:
             w = nh * Ch
             xs.append(v.colslice(c0, c0 + w)); outs.append(convv.colslice(c0, c0 + w)); kss.append(ksz)
             c0 += w
-        self.dwconv_multi(xs, cws, cbs, (B, side, side), kss, outs, launch=False)
         stats = self.f32(int(self.L.tc_factor_att_stats_floats(Bt, heads, Ch)))
-        o = self.factor_att_core(q, k, v, convv, Bt, N, heads, scale, stats=stats, launch=False)
         gs = Wqkv.gs if self.ngroups > 1 else 0
+        fused_bwd = (_MHCA_ATT_BWD_FUSED and self.record and heads == 8 and [k_ for k_, _ in windows] == [3, 5, 7]
+                     and all(w_.grad is not None for w_ in cws) and all(b_ is not None and b_.grad is not None for b_ in cbs)
+                     and bool(self.L.tc_mhca_att_bwd_supported(C_, N, self.dt)))
+        if fused_bwd:
+            # backward of crpe + attention core as ONE launch per (image, head) (tc_mhca_att_bwd): dconvv never leaves the chip
+            o = self.new(n.rows, C_)
+            Gn = self.ngroups
+
+            def bwd():
+                go = self.grad_of(o)
+                if go is None:
+                    return
+                gq, aq = self.wgrad(q)
+                gk, ak = self.wgrad(k)
+                gv, av = self.wgrad(v)
+                assert gq.stride(0) == gk.stride(0) == gv.stride(0) and gk.data_ptr() - gq.data_ptr() == C_ * gq.element_size()
+                self.n_launch += 1
+                _timed("hbm:mhca_att_bwd (factorised attention + crpe backward, one launch)", (3.0 + 1.0 + 1.0 + 3.0) * n.rows * C_ * n.data.element_size(),
+                       lambda: self.L.tc_mhca_att_bwd(_ptr(qkv.data), qkv.ld, _ptr(convv.data), convv.ld, _ptr(go), go.stride(0), _ptr(stats), _ptr(gq),
+                                                      gq.stride(0), aq, ak, av, _ptr(cws[0].data), _ptr(cws[1].data), _ptr(cws[2].data),
+                                                      _ptr(cws[0].grad), _ptr(cbs[0].grad), _ptr(cws[1].grad), _ptr(cbs[1].grad), _ptr(cws[2].grad),
+                                                      _ptr(cbs[2].grad), gs, Gn, B, side, side, C_, scale, self.dt, self.stream))
+            self._rec(bwd)
+        else:
+            self.dwconv_multi(xs, cws, cbs, (B, side, side), kss, outs, launch=False)
+            o = self.factor_att_core(q, k, v, convv, Bt, N, heads, scale, stats=stats, launch=False)
         self.n_launch += 1
         _timed("hbm:mhca_att_fwd (qkv projection + crpe + factorised attention, one launch)", (1.0 + 3.0 + 1.0 + 1.0) * n.rows * C_ * n.data.element_size(),
                lambda: self.L.tc_mhca_att_fwd(_ptr(n.data), n.ld, _ptr(Wqkv.data), _ptr(bqkv.data), _ptr(cws[0].data), _ptr(cbs[0].data),
