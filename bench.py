@@ -46,6 +46,25 @@ LOSS_SCALE = {"f32": 1.0, "bf16": 1.0, "f16": 4096.0}     # float16 activations 
 PEAK_HBM_GBS = 8000.0
 
 
+def _profile(*names):
+    """The newest committed profile summary among `names` (profiles/<name>) -> (doc, file name, fresh).  fresh: its provenance stamp
+    (scripts/provenance.py: sha256 of the kernel sources + host package it was collected from) equals the sources this run executes;
+    a stale or unstamped profile still names its file, but bench reports its traffic as null with traffic_stale = true."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("provenance", os.path.join(ROOT, "scripts", "provenance.py"))
+    prov = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(prov)
+    for n in names:
+        f = os.path.join(ROOT, "profiles", n)
+        if os.path.exists(f):
+            try:
+                doc = json.load(open(f))
+            except ValueError:
+                continue
+            return doc, n, prov.matches(doc, ROOT)
+    return {}, None, False
+
+
 def synthetic_batch(B: int, size: int, device, seed: int):
     """Synapse-shaped input: one-channel slice normalised to [-1, 1] (trainer.py:89-92) + integer labels in 0..8."""
     g = torch.Generator(device="cpu").manual_seed(seed)
@@ -135,7 +154,17 @@ def _cpu_baseline_worker(batch: int, size: int):
     t = statistics.median(times)
     phys = _physical_cores()
     ratio = _reference_cpu_ratio()
+    # SURVEY.md 8(d) words the baseline as "n = all physical host cores": that figure beside the fastest thread count (one step after one
+    # warm-up step: the oversubscribed pool is several times slower, and the whole baseline has to stay inside its time budget)
+    allp = None
+    if phys and phys != cores and phys <= avail:
+        torch.set_num_threads(phys)
+        step(xp, yp)
+        ta = step(x, y)
+        allp = {"cores": phys, "value": bs / ta, "unit": "images/sec", "sample": f"one fwd+bwd+SGD step of B={bs} after a B=2 warm-up step"}
+        torch.set_num_threads(cores)
     out = {"value": bs / t, "unit": "images/sec", "cores": cores, "cores_available": avail, "physical_cores": phys, "kind": "port",
+           "all_physical_cores": allp,
            "batch": bs, "config1_b2_fwd_images_per_sec": 2 / f2,
            "sample": f"median of 3 fwd+bwd+SGD steps of B={bs} {size}x{size} after warm-up (and median of 3 train-mode forwards of B=2 = "
                      f"BASELINE config 1), fp32 PyTorch-CPU oracle (port of the reference arithmetic), {cores} threads "
@@ -170,7 +199,7 @@ def _reference_cpu_ratio():
         return None
 
 
-def cpu_baseline(batch: int, size: int, timeout: float = 240.0):
+def cpu_baseline(batch: int, size: int, timeout: float = 300.0):
     """Runs the worker in a child process so a slow host can never stall the GPU measurement."""
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--batch", str(batch), "--size", str(size)],
@@ -212,6 +241,8 @@ def main():
     ap.add_argument("--no-side", action="store_true", help="skip the side figures (forward-only, fp32, loader-fed, roofline passes)")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying the captured hipGraph")
     ap.add_argument("--force-split", action="store_true", help="use the 3-graph multi-GPU step structure even on one GPU")
+    ap.add_argument("--resident", action="store_true", help="time the step on ONE HBM-resident noise batch (the headline of rounds 1-4) instead of the "
+                    "loader-fed step; the other figure is reported beside the headline either way")
     ap.add_argument("--loader", action="store_true",
                     help="feed the timed steps from transception_amd.data.DeviceLoader (synthetic Synapse npz files on local disk -> "
                          "HBM -> device augmentation/resize) instead of one HBM-resident batch; the default keeps BASELINE's definition")
@@ -287,12 +318,24 @@ def main():
     else:
         step = GraphedStep(model, loss_fn, opt, x, y, group, warmup=2, force_split=args.force_split)   # capture, then replay
     feed = None
+    # BASELINE config 2 words the workload as "synthetic Synapse npz": the timed region is the LOADER-FED step by default (npz slices on local
+    # disk -> pinned staging -> HBM -> device augmentation / spline zoom captured at the head of the step graph); --resident times the step
+    # on one HBM-resident batch instead (rounds 1-4's headline), and the other figure is reported beside the headline either way.
+    if not args.resident and not args.eager:
+        args.loader = True
+    loader_note = None
     if args.loader and not args.eager:
         step_resident = step
-        step, fed_steps, feed = _loader_fed_step(args, dev, rank, world, (args.steps + args.warmup + 4) * args.batch * world,
-                                                 lambda pre: GraphedStep(model, loss_fn, opt, x, y, group, warmup=1, force_split=args.force_split, pre=pre))
-        for _ in range(3):                                       # every slot's step graph is captured before the warm-up / timed steps
-            step()
+        try:
+            step, fed_steps, feed = _loader_fed_step(args, dev, rank, world, (args.steps + args.warmup + 4) * args.batch * world,
+                                                     lambda pre: GraphedStep(model, loss_fn, opt, x, y, group, warmup=1, force_split=args.force_split, pre=pre))
+            for _ in range(3):                                   # every slot's step graph is captured before the warm-up / timed steps
+                step()
+        except Exception as e:                                   # (a box without a writable temp dir, ...): say so and time the resident batch
+            if world > 1:
+                raise
+            loader_note = f"loader-fed step unavailable ({type(e).__name__}: {e}); resident batch timed instead"
+            step, feed, args.loader = step_resident, None, False
     for i in range(args.warmup):
         step()
         opt.set_lr(cosine_lr(0.05, i + 1, t_max))
@@ -343,9 +386,10 @@ def main():
             "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype,
-            "data": "synthetic (one HBM-resident batch of uniform-noise slices in [-1, 1] with random labels; config.loader_fed_images_per_sec "
-                    "is the same step fed from synthetic Synapse npz files)" if not args.loader else
-                    "synthetic Synapse npz files (512x512 smooth-blob slices) through DeviceLoader: read, H2D, augment, resize inside the timed region",
+            "data": ("synthetic (one HBM-resident batch of uniform-noise slices in [-1, 1] with random labels; config.loader_fed_images_per_sec "
+                     "is the same step fed from synthetic Synapse npz files)" if not args.loader else
+                     "synthetic Synapse npz files (512x512 smooth-blob slices) through DeviceLoader: read, H2D, augment, resize inside the timed region; "
+                     "config.resident_batch_images_per_sec is the same step on one HBM-resident batch") + (f" [{loader_note}]" if loader_note else ""),
             "config": {"workload": f"TransCeption (MSTransception) {args.size}x{args.size} B={args.batch}/GPU fwd+bwd+SGD, "
                                    + ("random-noise batch resident in HBM" if not args.loader else "synthetic Synapse npz slices via the device loader")
                                    + ", name-seeded random-init weights",
@@ -441,35 +485,38 @@ def side_figures(args, dev, model, loss_fn, opt, step, x, y, build_model, engine
                 "how": "HIP events around each launch inside 3 instrumented (eager) training steps of the benchmarked workload; an event "
                        "pair around an empty kernel on the idle queue reads event_pair_floor_us, which every in-step figure includes -- the "
                        "kernel's own duration is roofline_graph_replay / the rocprofv3 average in profiles/"}
-    prof_file = next((f for f in ("r4_hbm_by_kernel.json", "r3_hbm_by_kernel.json", "r2_hbm_by_kernel.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), None)
-    pmc_all = json.load(open(os.path.join(ROOT, "profiles", prof_file))) if prof_file else {}
+    # committed profile summaries of this workload; a summary counts only when its provenance stamp matches the sources this run executes
+    pmc_all, prof_file, pmc_fresh = _profile("r5_hbm_by_kernel.json", "r4_hbm_by_kernel.json", "r3_hbm_by_kernel.json", "r2_hbm_by_kernel.json")
     pmc_doc = pmc_all.get("kernels", {})
-    tl_file = next((f for f in ("r4_step_timeline.json", "r3_step_timeline.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), None)
-    tl_doc = json.load(open(os.path.join(ROOT, "profiles", tl_file))).get("kernels", {}) if tl_file else {}
+    tl_all, tl_file, tl_fresh = _profile("r5_step_timeline.json", "r4_step_timeline.json", "r3_step_timeline.json")
+    tl_doc = tl_all.get("kernels", {})
     same_workload = args.dtype == "bf16" and args.batch == 16 and args.size == 224
+    STALE = "stale: the kernel sources changed since this profile was collected (scripts/provenance.py); re-run scripts/profile_round5.sh"
 
     def pmc_traffic(prefixes):
         """Memory-side bytes per launch of the kernels whose names start with one of `prefixes`, from the committed rocprofv3 --pmc
         passes of this workload (2 x FETCH_SIZE + WRITE_SIZE, scripts/pmc_step.sh); None for another workload."""
         if not same_workload:
             return None, None
+        if not pmc_fresh:
+            return None, f"profiles/{prof_file}: {STALE}" if prof_file else None
         hit = [v for k, v in pmc_doc.items() if any(k.startswith(q) for q in prefixes)]
         n = sum(v["launches_per_step"] for v in hit)
         if not n:
             return None, None
         return sum(v["bytes_per_step"] for v in hit) / n, (f"profiles/{prof_file} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of this workload, "
-                                                            "scripts/pmc_step.sh; per launch, not measured in this run)")
+                                                            "scripts/pmc_step.sh; per launch; collected from the sources this run executes)")
     if prof.get("attn_fwd"):
         r = mfma_block(prof["attn_fwd"], ATTN_KERNEL)
         r["traffic"], r["traffic_source"] = None, None
-        for name in ("r4_attn_pmc.json", "r2_attn_pmc.json", "r1_attn_pmc.json"):   # HBM bytes per launch: a separate rocprofv3 --pmc pass, committed
-            pmc = os.path.join(ROOT, "profiles", name)
-            if same_workload and os.path.exists(pmc):
-                doc = json.load(open(pmc))
-                ent = doc.get("attn_fwd_asm_kernel") or doc.get("attn_fwd_seg_kernel") or {}
+        adoc, aname, afresh = _profile("r5_attn_pmc.json", "r4_attn_pmc.json", "r2_attn_pmc.json", "r1_attn_pmc.json")   # HBM bytes per launch: a separate rocprofv3 --pmc pass, committed
+        if same_workload and aname:
+            ent = adoc.get("attn_fwd_asm_kernel") or adoc.get("attn_fwd_seg_kernel") or {}
+            if afresh:
                 r["traffic"] = ent.get("hbm_bytes_corrected")
-                r["traffic_source"] = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE pass of this workload, not measured in this run)"
-                break
+                r["traffic_source"] = f"profiles/{aname} (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE pass of this workload; collected from the sources this run executes)"
+            else:
+                r["traffic_stale"], r["traffic_source"] = True, f"profiles/{aname}: {STALE}"
         roofs["roofline_in_step_events"] = r
     if prof.get("attn_bwd"):
         roofs["roofline_attn_bwd"] = mfma_block(prof["attn_bwd"], "attn_bwd (dQ stream incl. the row deltas + dK/dV stream + partial fold of the bridge SR-attention)")
@@ -490,7 +537,7 @@ def side_figures(args, dev, model, loss_fn, opt, step, x, y, build_model, engine
                     "achieved_tflops": fl / (ms * 1e-3) / 1e12, "frac_of_mfma_peak": fl / (ms * 1e-3) / 1e12 / peak,
                     "launches": len(ev), "launches_per_step": len(ev) / 3.0, "avg_launch_us": 1e3 * ms / len(ev), "ms_per_step": ms / 3.0,
                     "algorithmic_bytes_per_launch": by / len(ev), "algorithmic_flops_per_launch": fl / len(ev),
-                    "traffic": tr, "traffic_source": src, "event_pair_floor_us": event_floor_us})
+                    "traffic": tr, "traffic_source": src, "traffic_stale": bool(same_workload and prof_file and not pmc_fresh), "event_pair_floor_us": event_floor_us})
     if gem:
         gem.sort(key=lambda r: -r["ms_per_step"])
         roofs["roofline_gemm"] = dict(gem[0], how="HIP events around each GEMM-family launch inside 3 instrumented (eager) steps; the products are K = 64..2048 "
@@ -501,7 +548,9 @@ def side_figures(args, dev, model, loss_fn, opt, step, x, y, build_model, engine
         # rocprofv3 reports for it inside the replayed step (no event-pair floor), from the committed timeline of this workload
         dom = dict(gem[0])
         names = PMC_GEMM[{"gemm_pair_kernel": "pair", "gemm_multi_kernel": "multi"}.get(dom["kernel"].split(" ")[0], "single")]
-        hit = [v for k, v in tl_doc.items() if any(k.startswith(q) for q in names)] if same_workload else []
+        hit = [v for k, v in tl_doc.items() if any(k.startswith(q) for q in names)] if (same_workload and tl_fresh) else []
+        if same_workload and tl_file and not tl_fresh:
+            dom["duration_stale"], dom["duration_source"] = True, f"profiles/{tl_file}: {STALE} (the in-step event figure above stands in)"
         if hit:
             n_l, ms_l = sum(v["launches"] for v in hit), sum(v["ms"] for v in hit)
             us = 1e3 * ms_l / n_l
@@ -529,7 +578,7 @@ def side_figures(args, dev, model, loss_fn, opt, step, x, y, build_model, engine
             tr, src = pmc_traffic(PMC_HBM.get(name[4:].split(" ")[0], ("\0",)))
             hbm.append({"bound": "hbm", "kernel": name[4:], "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
                         "launches": len(ev), "avg_launch_us": 1e3 * ms / len(ev), "algorithmic_bytes_per_launch": by / len(ev),
-                        "traffic": tr, "traffic_source": src})
+                        "traffic": tr, "traffic_source": src, "traffic_stale": bool(same_workload and prof_file and not pmc_fresh)})
     if hbm:
         hbm.sort(key=lambda r: -r["avg_launch_us"] * r["launches"])
         roofs["roofline_hbm"] = dict(hbm[0], how="HIP events around each launch inside 3 instrumented steps; algorithmic bytes = every operand read once + "
@@ -546,10 +595,23 @@ def side_figures(args, dev, model, loss_fn, opt, step, x, y, build_model, engine
             alg_b = 3 * (19.6e6 * args.batch + 92.7e6)
             st = {"algorithmic_flops_per_step": fl, "achieved_tflops": fl / step_s / 1e12, "frac_of_mfma_peak": fl / step_s / 1e12 / peak,
                   "algorithmic_bytes_per_step": alg_b}
-            if same_workload and pmc_all.get("step_hbm_GB"):
+            if same_workload and prof_file and not pmc_fresh:
+                st.update(traffic_bytes_per_step=None, traffic_stale=True, traffic_source=f"profiles/{prof_file}: {STALE}")
+            if same_workload and pmc_fresh and pmc_all.get("step_hbm_GB"):
                 tb = 1e9 * pmc_all["step_hbm_GB"]
                 st.update(traffic_bytes_per_step=tb, achieved_GBps=tb / step_s / 1e9, frac_of_hbm_peak=tb / step_s / 1e9 / PEAK_HBM_GBS,
                           traffic_over_algorithmic=tb / alg_b, traffic_source=f"profiles/{prof_file} (2 x FETCH_SIZE + WRITE_SIZE over one replayed step)")
+            # the launch-bound share as a number: what a step of this many launches costs when every launch is an EMPTY kernel -- the
+            # per-boundary cost measured here (200 empty one-wave kernels back to back in one replayed hipGraph) times the step's launches
+            try:
+                from transception_amd._lib import lib as _lf
+                _Lm = _lf()
+                bus = _graph_replay_us(lambda: _Lm.tc_seg_marker(0, torch.cuda.current_stream(dev).cuda_stream), 200, dev)
+                nl = step.kernel_nodes() if hasattr(step, "kernel_nodes") else None
+                if nl:
+                    st.update(launch_boundary_us=bus, launches=nl, launch_floor_ms=bus * nl * 1e-3, launch_floor_share_of_step=bus * nl * 1e-6 / step_s)
+            except Exception as e:                               # (never let a side figure take the headline down)
+                st["launch_floor_error"] = repr(e)
             roofs["step"] = st
     # (2) forward-only rate (train-mode forward captured alone)
     with torch.no_grad():
@@ -570,6 +632,21 @@ def side_figures(args, dev, model, loss_fn, opt, step, x, y, build_model, engine
         extra["fp32_images_per_sec"] = args.batch * 10 / (time.perf_counter() - t)
         del s32, m32, o32
     # (4) the same graphed step fed by the device input pipeline (npz -> HBM -> augment/resize), SURVEY 8(f)-1
+    if not args.eager and args.loader:
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize(dev)
+        wins = []
+        for _ in range(3):                               # the captured step on ONE HBM-resident batch (rounds 1-4's headline): three windows of 20 steps
+            tl = time.perf_counter()
+            for _ in range(20):
+                step()
+            torch.cuda.synchronize(dev)
+            wins.append(args.batch * 20 / (time.perf_counter() - tl))
+        extra["resident_batch_images_per_sec"] = statistics.median(wins)
+        extra["resident_batch_ms_per_step"] = 1e3 * args.batch / statistics.median(wins)
+        extra["resident_batch_windows_images_per_sec"] = wins
+        extra["resident_batch_launches_per_step"] = step.kernel_nodes() if hasattr(step, "kernel_nodes") else None
     if not args.eager and not args.loader and args.size == 224:
         fstep, fsteps, f2 = _loader_fed_step(args, dev, 0, 1, 70 * args.batch,
                                               lambda pre: GraphedStep(model, loss_fn, opt, x, y, None, warmup=1, pre=pre))
@@ -613,7 +690,7 @@ def side_figures(args, dev, model, loss_fn, opt, step, x, y, build_model, engine
         roofs["roofline"] = {"bound": "mfma", "kernel": ATTN_KERNEL,
                              "achieved": fl / us / 1e6, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                              "frac": fl / us / 1e6 / PEAK_TFLOPS[args.dtype], "avg_launch_us": us, "algorithmic_flops_per_launch": fl,
-                             "traffic": ins.get("traffic"), "traffic_source": ins.get("traffic_source"),
+                             "traffic": ins.get("traffic"), "traffic_source": ins.get("traffic_source"), "traffic_stale": bool(ins.get("traffic_stale")),
                              "how": "HIP events on the launching stream around 30 back-to-back launches of the kernel inside one replayed hipGraph, step-shaped "
                                     "random operands (no event-pair floor in the figure; agrees with the rocprofv3 average in profiles/); the per-launch "
                                     "event figure of instrumented eager steps, which includes event_pair_floor_us, is roofline_in_step_events"}
@@ -649,19 +726,22 @@ def side_figures(args, dev, model, loss_fn, opt, step, x, y, build_model, engine
         spec = importlib.util.spec_from_file_location("bench_stage", os.path.join(ROOT, "scripts", "bench_stage.py"))
         bs = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(bs)
-        pf = os.path.join(ROOT, "profiles", "r4_ripm_iff_hbm.json")
-        pmc = json.load(open(pf)) if os.path.exists(pf) and args.batch == 16 else {}
+        pmc, pname, pfresh = _profile("r5_ripm_iff_hbm.json", "r4_ripm_iff_hbm.json")
+        if args.batch != 16:
+            pmc, pname = {}, None
         for which, key in (("ripm", "roofline_ripm"), ("iff", "roofline_iff")):
             _, one_pass = bs.build(which, args.batch, dev)
             us = _graph_replay_us(one_pass, 4, dev)
             by = 3.0 * bs.ELEMS[which] * args.batch * 2
-            tr = pmc.get(which, {}).get("traffic_bytes_per_pass")
+            tr = pmc.get(which, {}).get("traffic_bytes_per_pass") if pfresh else None
             roofs[key] = {"bound": "hbm", "kernel": {"ripm": "RIPM: Patch_Embed_stage x 3 encoder stages (dw3x3 + pw1x1 + BatchNorm + Hardswish, x 3 per stage), forward + backward",
                                                       "iff": "IFF: CoordAtt x 3 encoder stages (pool, conv1 + BatchNorm + act, conv_h / conv_w + sigmoid, gate, conv_in_out), forward + backward"}[which],
                           "achieved": by / us / 1e3, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": by / us / 1e3 / PEAK_HBM_GBS, "us_per_pass": us,
                           "algorithmic_bytes_per_pass": by, "traffic": tr, "traffic_GBps": tr / us / 1e3 if tr else None,
-                          "launches_per_pass": pmc.get(which, {}).get("launches_per_pass"),
-                          "traffic_source": "profiles/r4_ripm_iff_hbm.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of scripts/bench_stage.py, scripts/pmc_stage.sh)" if tr else None,
+                          "launches_per_pass": pmc.get(which, {}).get("launches_per_pass") if pfresh else None,
+                          "traffic_stale": bool(pname and not pfresh),
+                          "traffic_source": (f"profiles/{pname} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of scripts/bench_stage.py, scripts/pmc_stage.sh; collected "
+                                             "from the sources this run executes)" if tr else (f"profiles/{pname}: {STALE}" if pname else None)),
                           "how": "the stage functions of the model on random maps of the step's shapes, captured once and replayed (HIP events on the launching "
                                  "stream); algorithmic bytes = SURVEY.md 8(d): every activation of the fused unit read / written once, backward = 2 x forward"}
     return extra, roofs

@@ -504,5 +504,19 @@ def eval_hd95(pred, gt, spacing=None):
         return np.argwhere(m & ~inner) * sp
 
     a, b = surface(pred), surface(gt)
-    d = np.sqrt(((a[:, None, :] - b[None, :, :]) ** 2).sum(-1))
-    return float(np.percentile(np.hstack((d.min(1), d.min(0))), 95))
+    dab, dba = np.empty(len(a)), np.full(len(b), np.inf)
+    for i0 in range(0, len(a), 256):                                   # (row blocks: the full distance matrix of two 5 k-voxel surfaces is 0.6 GB)
+        d = np.sqrt(((a[i0:i0 + 256, None, :] - b[None, :, :]) ** 2).sum(-1))
+        dab[i0:i0 + 256] = d.min(1)
+        dba = np.minimum(dba, d.min(0))
+    return float(np.percentile(np.hstack((dab, dba)), 95))
+
+
+def eval_metric_percase(pred, gt):
+    """(dice, hd95) of one class of one volume under utils.py:50-60's conventions, from the definitions (no code shared with the product)."""
+    import numpy as np
+    pred, gt = np.asarray(pred) > 0, np.asarray(gt) > 0
+    ps, gs = int(pred.sum()), int(gt.sum())
+    if ps > 0 and gs > 0:
+        return 2.0 * float((pred & gt).sum()) / (ps + gs), eval_hd95(pred, gt)
+    return (1.0, 0.0) if ps > 0 else (0.0, 0.0)

@@ -4,7 +4,7 @@
 # refuses --pmc together with the API trace domains).  Output under gpurun_out/$1; fold with scripts/hbm_by_kernel.py.
 set -u
 OUT=gpurun_out/${1:-pmc_step}
-CMD="python bench.py --no-cpu --no-side --steps 3 --warmup 1 ${BENCH_ARGS:-}"
+CMD="python bench.py --resident --no-cpu --no-side --steps 3 --warmup 1 ${BENCH_ARGS:-}"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p $OUT
 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o t -- $CMD > $OUT/trace.log 2>&1

@@ -10,6 +10,8 @@ Tolerance for the fp32 path: 1e-3 abs on logits is the contract (BASELINE.json);
 """
 import math
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -209,6 +211,13 @@ def test_modules_bf16_budget_against_reference_goldens(model):
     finally:
         model.set_compute_dtype(torch.float32)
     print("bf16 module errors (abs, worst sample):", {k: f"{v:.2e}" for k, v in sorted(worst.items())})
+    # The hand-scheduled attention streams (csrc/gen_attn_asm.py, gen_dq_asm.py, gen_dkv_asm.py) run only on 16-bit storage, so the fp32
+    # goldens never see them: the `self_att` case -- bridge_layer3.attn = Scale_reduce + q / kv projections + the SR attention + proj,
+    # MSTr.py:2267-2292 -- in bf16 against the REFERENCE's fixture, at 1.5 x the error measured on MI355X (forward 8.4e-4 and input
+    # gradient 9.1e-4 on tensors whose largest reference samples are 0.23 / 0.14: 0.4-0.7 %, i.e. bf16 rounding of the stored q / k / v / o;
+    # weight gradients 5.9e-3 in sampled relative L2) instead of the generic 2e-2 / 5e-2 module budget.
+    assert os.environ.get("TC_ATTN_FWD_ASM", "1") != "0" and os.environ.get("TC_ATTN_DKV_ASM", "1") != "0"
+    assert worst["self_att/y"] <= 1.3e-3 and worst["self_att/gx0"] <= 1.4e-3 and worst["self_att/gw"] <= 9e-3, {k: v for k, v in worst.items() if k.startswith("self_att")}
 
 
 def test_modules_fp16_budget_against_reference_goldens(model):
