@@ -78,6 +78,30 @@ def _worker(rank, world, port, ret):
         for a, b in ((0, 100), (500_000, 500_064), (1_500_000, 1_501_000)):
             ok_grad = ok_grad and bool((g4[a:b] == want[a:b]).all())
         ok_grad = ok_grad and bool((g4[100:500_000] == want[100:500_000] / 3.0 * (rank + 1)).all())    # everything else untouched
+    # one collective per stop of the split backward sweep (train.comm_schedule / allreduce_scheduled): dead-only gaps are spanned, a
+    # piece's stragglers are deferred to the packed last piece, words of a later piece are never touched early
+    from transception_amd.train import allreduce_scheduled, comm_schedule
+
+    class Pieces(Sparse):
+        _used_views = {0: (0, (1000,)), 1: (10_000, (390_000,)), 2: (400_000, (800_000,)), 3: (1_250_000, (10_000,)),
+                       4: (1_600_000, (800_000,)), 5: (2_700_000, (300_000,))}
+
+        @staticmethod
+        def gradient_pieces():
+            return [("enc", [(1_500_000, 3_000_000)]), ("s3", [(5_000, 1_230_000)]), (None, [(0, 5_000), (1_230_000, 1_500_000)])]
+    base = torch.arange(3_000_000, dtype=torch.float32) % 977 + 1.0
+    Pieces._gflat = base * float(rank + 1)
+    sched = comm_schedule(Pieces)
+    ok_grad = ok_grad and [len(e) for _, e in sched] == [1, 1, 1] and [e[0][0] for _, e in sched] == ["span", "span", "pack"]
+    ok_grad = ok_grad and sched[0][1][0][1:] == (1_600_000, 3_000_000) and sched[1][1][0][1:] == (5_000, 1_230_000)
+    seen = Pieces._gflat.clone()
+    for stop, entries in sched:
+        for w in allreduce_scheduled(Pieces, entries, None, async_op=True):
+            w.wait()
+        if stop == "enc":                                      # nothing below the encoder piece has moved yet
+            ok_grad = ok_grad and bool((Pieces._gflat[:1_500_000] == seen[:1_500_000]).all())
+    for off, shape in Pieces._used_views.values():
+        ok_grad = ok_grad and bool((Pieces._gflat[off:off + shape[0]] == 3.0 * base[off:off + shape[0]]).all())
     ret[rank] = (ok_loss, ok_grad)
     dist.destroy_process_group()
 

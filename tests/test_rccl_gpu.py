@@ -98,10 +98,25 @@ def test_comm_plan_covers_every_live_gradient_once():
     loss, _, _ = SegLoss(9)(m(torch.from_numpy(seeded_input(1)).to("cuda:0")), torch.from_numpy(seeded_labels(1)).to("cuda:0"))
     loss.backward()
     plan = comm_plan(m, 8)
-    live = sum(b - a for a, b in gradient_buckets(m))
+    lb = gradient_buckets(m)
+    live = sum(b - a for a, b in lb)
     sent = sorted((a, b) for p in plan["pieces"] for a, b in p["buckets_elements"])
-    assert sum(b - a for a, b in sent) == live and all(sent[i][1] <= sent[i + 1][0] for i in range(len(sent) - 1))
-    assert abs(plan["gradient_megabytes_per_step"] - 4 * live / 1e6) < 1e-9 and plan["ranks"] == 8
+    # the sent ranges are disjoint, cover every live word exactly once, and whatever else they span is grad-less (zeros): dead words of
+    # gaps the schedule sends along instead of opening another collective (train.comm_schedule)
+    assert all(sent[i][1] <= sent[i + 1][0] for i in range(len(sent) - 1))
+    covered = sum(max(0, min(b, y) - max(a, x)) for a, b in sent for x, y in lb)
+    assert covered == live and abs(plan["live_gradient_megabytes_per_step"] - 4 * live / 1e6) < 1e-9
+    g = m.flat_gradients()
+    for a, b in sent:
+        for x, y in [(a, b)]:
+            dead = torch.ones(b - a, dtype=torch.bool, device=g.device)
+            for u, v in lb:
+                lo, hi = max(a, u), min(b, v)
+                if lo < hi:
+                    dead[lo - a:hi - a] = False
+            assert float(g[a:b][dead].abs().max()) == 0.0 if bool(dead.any()) else True
+    assert plan["gradient_megabytes_per_step"] >= 4 * live / 1e6 and plan["ranks"] == 8
+    assert plan["collectives_per_step"] <= 4, plan["collectives_per_step"]          # one per stop of the backward sweep + the 28 loss sums
     assert plan["pieces"][0]["sent_when_backward_reaches"] == "encoder_done" and plan["pieces"][-1]["sent_when_backward_reaches"].startswith("end")
     assert plan["total_ring_ms_one_link"] > plan["total_ring_ms_seven_links"] > 0
     live_params = sum(p.numel() for p in m.parameters() if p.grad is not None)

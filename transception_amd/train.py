@@ -244,6 +244,73 @@ def clip_buckets(buckets, ranges):
     return sorted(out)
 
 
+SPAN_GAP_MAX = int(os.environ.get("TC_DDP_SPAN_GAP_MAX", str(8 << 20)))     # elements: a gap of dead (grad-less, zero) words up to this size is sent along rather than starting a new collective
+
+
+def comm_schedule(model):
+    """ONE collective per stop of the split backward sweep (the nine bucket collectives of round 4 cost ~75 us each
+    even on a 1-rank communicator and 2 (N-1) ring hops each on N ranks).  For every piece of model.gradient_pieces(), in order:
+      * its live buckets are merged across gaps that hold only grad-less words (zeros in every rank's arena: sending them is harmless)
+        up to SPAN_GAP_MAX elements -- never across words that belong to a LATER piece (they are not final yet and would be reduced twice);
+      * the largest merged run is the piece's collective ("span"); smaller stragglers of at most COALESCE_MAX elements in all are
+        deferred to the last piece;
+      * the last piece (nothing left to hide it under) travels packed through a staging buffer ("pack"), stragglers included.
+    Returns [(stop, [("span", a, b) | ("pack", [(a, b), ...]), ...]), ...]; every live word appears in exactly one entry."""
+    live = gradient_buckets(model)
+    pieces = model.gradient_pieces()
+
+    def dead_only(x, y):
+        return not any(a < y and x < b for a, b in live)
+
+    sched, deferred = [], []
+    for pi, (stop, ranges) in enumerate(pieces):
+        bs = clip_buckets(live, ranges)
+        runs = []
+        for a, b in bs:
+            if runs and (a == runs[-1][1] or (a - runs[-1][1] <= SPAN_GAP_MAX and dead_only(runs[-1][1], a))):
+                runs[-1][1] = b
+            else:
+                runs.append([a, b])
+        runs = [(a, b) for a, b in runs]
+        if pi == len(pieces) - 1:
+            allr = sorted(runs + deferred)
+            if len(allr) == 1:
+                sched.append((stop, [("span",) + allr[0]]))
+            elif sum(b - a for a, b in allr) <= COALESCE_MAX:
+                sched.append((stop, [("pack", allr)]))
+            else:
+                sched.append((stop, [("span", a, b) for a, b in allr]))
+            continue
+        if not runs:
+            sched.append((stop, []))
+            continue
+        big = max(runs, key=lambda r: r[1] - r[0])
+        small = [r for r in runs if r != big]
+        if sum(b - a for a, b in small) <= COALESCE_MAX // 2:
+            deferred += small
+            sched.append((stop, [("span",) + big]))
+        else:
+            sched.append((stop, [("span", a, b) for a, b in runs]))
+    return sched
+
+
+def allreduce_scheduled(model, entries, group=None, async_op: bool = False):
+    """Issues the collectives of one stop of comm_schedule(); returns the work handles (async_op) -- _PackedWork for a packed entry."""
+    works = []
+    if not comm_on(group):
+        return works
+    for e in entries:
+        if e[0] == "span":
+            w = dist.all_reduce(model._gflat[e[1]:e[2]], group=group, async_op=async_op)
+            if async_op:
+                works.append(w)
+        else:
+            w = _PackedWork(model._gflat, e[1], group, async_op)
+            if async_op:
+                works.append(w)
+    return works
+
+
 XGMI_LINK_GBS, XGMI_LINKS, RING_HOP_US = 153.0, 7, 6.0     # MI355X: 7 point-to-point links per GPU; per-hop latency of a ring step (assumed)
 
 
@@ -253,20 +320,24 @@ def comm_plan(model, n_ranks: int):
     out), and the time a ring all-reduce of each would take over xGMI -- a ring moves 2 (N-1)/N of the bytes through every GPU and is
     bound by ONE link per direction (153 GB/s) unless RCCL runs one ring per link (7), so both bounds are given, plus 2 (N-1) hops of
     latency per collective.  Lets the first multi-GPU run be read against an expectation."""
-    buckets = gradient_buckets(model)
-    out, tot = [], 0
+    out, tot, live = [], 0, 0
     f = 2.0 * (n_ranks - 1) / max(n_ranks, 1)
-    for stop, ranges in model.gradient_pieces():
-        bs = clip_buckets(buckets, ranges)
-        nbytes = 4 * sum(b - a for a, b in bs)
+    lb = gradient_buckets(model)
+    for stop, entries in comm_schedule(model):
+        spans = [(e[1], e[2]) for e in entries if e[0] == "span"] + [r for e in entries if e[0] == "pack" for r in e[1]]
+        nbytes = 4 * sum(b - a for a, b in spans)
+        nlive = 4 * sum(max(0, min(b, y) - max(a, x)) for a, b in spans for x, y in lb)
         tot += nbytes
-        ncoll = 1 if (stop is None and len(bs) > 1 and nbytes // 4 <= COALESCE_MAX) else len(bs)      # the last piece travels packed (allreduce_gradients(coalesce=True))
+        live += nlive
+        ncoll = len(entries)
         lat = 2 * (n_ranks - 1) * RING_HOP_US * 1e-3 * ncoll
         out.append({"sent_when_backward_reaches": stop or "end of backward (exposed)", "collectives": ncoll,
-                    "buckets_elements": [[int(a), int(b)] for a, b in bs], "megabytes": nbytes / 1e6,
+                    "how": [e[0] for e in entries],
+                    "buckets_elements": [[int(a), int(b)] for a, b in spans], "megabytes": nbytes / 1e6, "live_megabytes": nlive / 1e6,
                     "ring_ms_one_link": f * nbytes / (XGMI_LINK_GBS * 1e9) * 1e3 + lat,
                     "ring_ms_seven_links": f * nbytes / (XGMI_LINK_GBS * XGMI_LINKS * 1e9) * 1e3 + lat})
-    return {"ranks": n_ranks, "pieces": out, "gradient_megabytes_per_step": tot / 1e6, "loss_sums_bytes": 28 * 4,
+    return {"ranks": n_ranks, "pieces": out, "gradient_megabytes_per_step": tot / 1e6, "live_gradient_megabytes_per_step": live / 1e6,
+            "collectives_per_step": sum(p["collectives"] for p in out) + 1, "loss_sums_bytes": 28 * 4,
             "total_ring_ms_one_link": sum(p["ring_ms_one_link"] for p in out), "total_ring_ms_seven_links": sum(p["ring_ms_seven_links"] for p in out),
             "exposed_ring_ms_one_link": out[-1]["ring_ms_one_link"], "exposed_ring_ms_seven_links": out[-1]["ring_ms_seven_links"],
             "model": "ring all-reduce: 2 (N-1)/N x bytes per GPU over 153 GB/s per xGMI link (one ring) or 7 links (one ring per link), + 2 (N-1) "
@@ -432,6 +503,8 @@ class GraphedStep:
                     self._bwd_leg(until)
                 self.g_bwd_legs.append(g)
             self.g_bwd_rest = self.g_bwd_legs[-1]
+            self._sched = comm_schedule(model)
+            assert [st for st, _ in self._sched] == [st for st, _ in self._pieces]
             allreduce_gradients(model, group)
             self.g_opt = _new_graph()
             with torch.cuda.graph(self.g_opt, capture_error_mode=_CAPTURE_MODE):
@@ -509,12 +582,12 @@ class GraphedStep:
             if comm:
                 self._reduce_sums()                  # C2: in place on the static 28-float buffer
             self.g_bwd.replay()
-            if comm:                                 # C1, bridge + decoder buckets: the collective stream waits for g_bwd only
-                works = allreduce_gradients(self.model, self.group, async_op=True, ranges=self._pieces[0][1])
-            for g, (until, rng) in zip(self.g_bwd_legs, self._pieces[1:]):
-                g.replay()                           # stages 4 + 3, rest of the encoder: each leg's buckets leave under the next leg
-                if comm:                             # (the last piece has nothing to hide under: its small buckets go as ONE collective)
-                    works += allreduce_gradients(self.model, self.group, async_op=True, ranges=rng, coalesce=until is None)
+            if comm:                                 # C1, bridge + decoders: ONE collective (comm_schedule); the collective stream waits for g_bwd only
+                works = allreduce_scheduled(self.model, self._sched[0][1], self.group, async_op=True)
+            for g, (until, entries) in zip(self.g_bwd_legs, self._sched[1:]):
+                g.replay()                           # stages 4 + 3, rest of the encoder: each leg's collective leaves under the next leg
+                if comm:                             # (the last piece has nothing to hide under: everything left goes packed as ONE collective)
+                    works += allreduce_scheduled(self.model, entries, self.group, async_op=True)
             for w in works:
                 w.wait()                                     # the compute stream waits for the collectives, the host does not
             self.g_opt.replay()
