@@ -569,6 +569,13 @@ long long tc_factor_att_stats_floats(int Bt, int heads, int Ch);
  * there), the window's weight / bias gradients ADDED to dw3 / db3 / dw5 / db5 / dw7 / db7 (fp32, laid out like the weights, group g at
  * +g*gs).  go = d loss / d o.  dconvv is not materialised. */
 int tc_mhca_att_supported(int C, int N, int dtype);
+/* tc_dw_ln_fwd: the head of an MHCABlock in one launch (16-bit storage, C = 64 / 128 / 320): t1 = x + dw3x3(x) + bias (ConvPosEnc,
+ * MSTr.py:744-752), xn = LayerNorm_C(t1) (norm1, :932, 937), mean / rstd [groups*B*H*W] as tc_layernorm_fwd leaves them.  Parameters of
+ * weight group g at +g*wstride (conv) / +g*gstride (norm).  Backward: tc_layernorm_bwd*, then tc_dwconv_bwd -- unchanged. */
+int tc_dw_ln_supported(int C, int dtype);
+int tc_dw_ln_fwd(const void* x, int ldx, const void* w, const void* b, long long wstride, const void* gamma, const void* beta,
+                 long long gstride, void* t1, int ldt, void* xn, int ldn, float* mean, float* rstd, int groups, int B, int H, int W,
+                 int C, float eps, int dtype, void* stream);
 int tc_mhca_att_bwd_supported(int C, int N, int dtype);
 int tc_mhca_att_bwd(const void* qkv, int ldq, const void* convv, int ldc, const void* go, int ldgo, const float* stats, void* dqkv,
                     int ldd, int acc_q, int acc_k, int acc_v, const void* w3, const void* w5, const void* w7, float* dw3, float* db3,

@@ -136,3 +136,60 @@ def test_mhca_attention_one_launch(dtype, C, side, B, Gn):
     assert rel(dxf, dx2) < tol / 2, ("dx, fused backward vs factor_att_bwd + dwconv_multi", rel(dxf, dx2))
     assert rel(gpf, gp2) < tol / 2, ("parameter gradients, fused backward vs factor_att_bwd + dwconv_multi", rel(gpf, gp2))
     assert nlf == 3 and nlu >= 1                      # forward, fused backward, the projection's gradient pair
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("C,side,B,Gn", [(64, 28, 2, 3), (128, 14, 2, 3), (320, 7, 3, 3), (128, 9, 1, 1)])
+def test_dw_ln_one_launch(dtype, C, side, B, Gn):
+    """engine.Graph.dw_ln (tc_dw_ln_fwd: ConvPosEnc dw3x3 + skip and norm1 of an MHCABlock in one launch) against torch fp32 and against the
+    two launches it replaces (forward identical up to the summation order; backward is theirs)."""
+    import transception_amd.engine as E
+    from transception_amd.engine import Graph, P, Var
+    rows = Gn * B * side * side
+    x16, g1, g2 = T(f"dl.x{C}", (rows, C)).to(dtype), T(f"dl.g1{C}", (rows, C)).to(dtype), T(f"dl.g2{C}", (rows, C)).to(dtype)
+    per = (9 * C + C + C + C + 7) // 8 * 8
+    flat = T(f"dl.p{C}", (Gn * per,), 0.3)
+    flat.view(Gn, per)[:, 10 * C:11 * C] += 1.0                                   # gamma around 1
+    lp = flat.to(dtype).to(DEV)
+    master = lp.float().cpu().clone().requires_grad_()
+    gflat = torch.zeros(Gn * per, dtype=torch.float32, device=DEV)
+    mk = lambda a, n, shp: P(lp[a:a + n].view(shp), gflat[a:a + n].view(shp), per if Gn > 1 else 0)
+    w, b, ga, be = mk(0, 9 * C, (C, 9)), mk(9 * C, C, (C,)), mk(10 * C, C, (C,)), mk(11 * C, C, (C,))
+    xr = x16.float().requires_grad_()
+    outs_t, outs_n = [], []
+    for g in range(Gn):
+        m = master[g * per:(g + 1) * per]
+        xi = xr[g * B * side * side:(g + 1) * B * side * side].reshape(B, side, side, C).permute(0, 3, 1, 2)
+        t1 = (F.conv2d(xi, m[:9 * C].view(C, 1, 3, 3), m[9 * C:10 * C], padding=1, groups=C) + xi).permute(0, 2, 3, 1).reshape(-1, C)
+        outs_t.append(t1); outs_n.append(F.layer_norm(t1, (C,), m[10 * C:11 * C], m[11 * C:12 * C], 1e-6))
+    rt, rn = torch.cat(outs_t), torch.cat(outs_n)
+    (rt * g1.float()).sum().backward(retain_graph=True)
+    (rn * g2.float()).sum().backward()
+
+    def run(fused):
+        E._DW_LN_FUSED = fused
+        gflat.zero_()
+        G = Graph(dtype, torch.device(DEV), training=True, record=True)
+        xv = Var(x16.to(DEV).contiguous())
+        with (G.grouped(Gn, per) if Gn > 1 else G.grouped(1, 0)):
+            assert G.dw_ln_supported(xv) == fused
+            if fused:
+                t1, xn = G.dw_ln(xv, w, b, ga, be, B, side, side, 1e-6)
+            else:
+                t1 = G.dwconv(xv, w, b, B, side, side, 3, 1, True)
+                xn = G.layernorm(t1, ga, be, 1e-6)
+            xn.root.grad_t = g2.to(DEV).contiguous(); xn.root.whole_written = True
+            t1.root.grad_t = g1.to(DEV).contiguous(); t1.root.whole_written = True       # (the residual branch's gradient of t1: LayerNorm's backward adds to it)
+            G.backward()
+        torch.cuda.synchronize()
+        return t1.data.float().cpu(), xn.data.float().cpu(), G.grad_of(xv).float().cpu(), gflat.cpu().clone()
+    try:
+        tf, nf, dxf, gpf = run(True)
+        tu, nu, dxu, gpu_ = run(False)
+    finally:
+        E._DW_LN_FUSED = True
+    tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
+    assert rel(tf, rt) < tol and rel(nf, rn) < tol, (rel(tf, rt), rel(nf, rn))
+    assert rel(tf, tu) < tol / 4 and rel(nf, nu) < tol / 2, (rel(tf, tu), rel(nf, nu))
+    assert rel(dxf, xr.grad) < 2 * tol and rel(gpf, master.grad) < 2 * tol, (rel(dxf, xr.grad), rel(gpf, master.grad))
+    assert rel(dxf, dxu) < tol and rel(gpf, gpu_) < tol

@@ -33,8 +33,11 @@ def _stale(target: str, deps) -> bool:
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = _hipcc()
     # the hand-scheduled attention stream is generated source: refresh attn_fwd_asm.inc (rewritten only when its text changes)
+    # (the generators read TC_ATTN_* knobs -- ablation modes that change results among them -- for the experiment builds under scripts/exp;
+    # a product build must not pick them up from the caller's environment and overwrite the committed streams: ADVICE r4)
+    genv = {k: v for k, v in os.environ.items() if not k.startswith(("TC_ATTN_", "TC_AS_", "TC_DKV_", "TC_DQ_"))}
     for gen in ("gen_attn_asm.py", "gen_dkv_asm.py", "gen_dq_asm.py"):
-        r = subprocess.run([sys.executable, os.path.join(CSRC, gen)], capture_output=True, text=True)
+        r = subprocess.run([sys.executable, os.path.join(CSRC, gen)], capture_output=True, text=True, env=genv)
         if r.returncode != 0:
             raise RuntimeError(f"{gen} failed:\n{r.stderr}")
     headers = [os.path.join(CSRC, "tc_common.h"), os.path.join(HERE, "..", "include", "transception_hip.h")]

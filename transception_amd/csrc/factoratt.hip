@@ -1056,6 +1056,103 @@ extern "C" int tc_factor_att_bwd(const void* q, const void* k, const void* v, in
     return tc_launch_status();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Head of an MHCABlock (MSTr.py:935-940): t1 = t + cpe(t) (ConvPosEnc: depthwise 3x3 + bias, :744-752), xn = LayerNorm(t1) (norm1, eps 1e-6)
+// in ONE launch (16-bit storage): the depthwise launch wrote t1, the LayerNorm launch read it back -- a 5 us launch and a memory round
+// trip per block for a map that is read once.  Eight lanes own a token (C / 64 vectors of 8 channels each); the 9 taps are read straight
+// from global memory (the neighbouring tokens of a workgroup's 32 overlap in the L1), the taps' weights sit transposed in LDS; both
+// results, the mean and the reciprocal standard deviation leave exactly as tc_dwconv_fwd + tc_layernorm_fwd leave them (their backward
+// entries apply unchanged): t1 is rounded to the storage type before the statistics are taken.
+struct DwLnDev {
+    const void *x, *w, *b, *gamma, *beta;
+    void *t1, *xn;
+    float *mean, *rstd;
+    long long wstride, gstride;
+    int ldx, ldt, ldn, B, H, W, rows_per_group;
+    float eps;
+};
+template <typename T, int C>
+__global__ __launch_bounds__(256) void dw_ln_fwd_kernel(DwLnDev p) {
+    constexpr int NVL = C / 64;                                  // 8-channel vectors per lane
+    __shared__ float wt[9 * C], bs[C], gm[C], bt[C];
+    const int tid = threadIdx.x, sub = tid & 7;
+    const long long row = (long long)blockIdx.x * 32 + (tid >> 3);
+    const long long total = (long long)gridDim.y * 0 + (long long)p.rows_per_group * gridDim.y;
+    const int g = blockIdx.y;
+    {
+        const T* w = reinterpret_cast<const T*>(p.w) + g * p.wstride;
+        const T* b = reinterpret_cast<const T*>(p.b) + g * p.wstride;
+        const T* ga = reinterpret_cast<const T*>(p.gamma) + g * p.gstride;
+        const T* be = reinterpret_cast<const T*>(p.beta) + g * p.gstride;
+        for (int i = tid; i < 9 * C; i += 256) { const int ch = i / 9, tap = i - ch * 9; wt[tap * C + ch] = ldf<T>(w + i); }
+        for (int i = tid; i < C; i += 256) { bs[i] = ldf<T>(b + i); gm[i] = ldf<T>(ga + i); bt[i] = ldf<T>(be + i); }
+    }
+    (void)total;
+    const bool live = row < p.rows_per_group;
+    const long long r = live ? row : 0;
+    const int hw = p.H * p.W, img = (int)(r / hw), pix = (int)(r - (long long)img * hw), y = pix / p.W, x = pix - y * p.W;
+    const long long grow = (long long)g * p.rows_per_group;
+    const T* xb = reinterpret_cast<const T*>(p.x) + (grow + (long long)img * hw) * p.ldx;
+    uint4 raw[9][NVL];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int yy = y + ky - 1, xx = x + kx - 1;
+            const bool ok = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+            const T* src = xb + (long long)((ok ? yy : y) * p.W + (ok ? xx : x)) * p.ldx + sub * 8;
+#pragma unroll
+            for (int v = 0; v < NVL; ++v) {
+                raw[ky * 3 + kx][v] = *reinterpret_cast<const uint4*>(src + v * 64);
+                if (!ok) raw[ky * 3 + kx][v] = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+    __syncthreads();
+    float t1v[NVL][8];
+    float s1 = 0.f;
+#pragma unroll
+    for (int v = 0; v < NVL; ++v) {
+        const int c0 = v * 64 + sub * 8;
+        float acc[8], ctr[8];
+        unpack16<T>(raw[4][v], ctr);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] = bs[c0 + u];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            float xv[8], w8[8];
+            unpack16<T>(raw[tap][v], xv);
+            fa_get8(wt + tap * C + c0, w8);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] = fmaf(xv[u], w8[u], acc[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] += ctr[u];
+        const uint4 pk = pack16<T>(acc);
+        if (live) *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.t1) + (grow + r) * p.ldt + c0) = pk;
+        unpack16<T>(pk, t1v[v]);                                 // (the statistics see what the next reader of t1 will see)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s1 += t1v[v][u];
+    }
+    const float mean = tc_group_sum<8>(s1) * (1.0f / C);
+    float s2 = 0.f;
+#pragma unroll
+    for (int v = 0; v < NVL; ++v)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const float d = t1v[v][u] - mean; s2 += d * d; }
+    const float rstd = rsqrtf(tc_group_sum<8>(s2) * (1.0f / C) + p.eps);
+    if (live) {
+#pragma unroll
+        for (int v = 0; v < NVL; ++v) {
+            const int c0 = v * 64 + sub * 8;
+            float o[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) o[u] = (t1v[v][u] - mean) * rstd * gm[c0 + u] + bt[c0 + u];
+            *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.xn) + (grow + r) * p.ldn + c0) = pack16<T>(o);
+        }
+        if (sub == 0) { p.mean[grow + r] = mean; p.rstd[grow + r] = rstd; }
+    }
+}
+
 // LDS bytes of the fused attention half for width C and N tokens per image (0: unsupported width)
 static size_t mhca_att_smem_of(int C, int N) {
     return C == 64 ? mhca_att_smem<64>(N) : C == 128 ? mhca_att_smem<128>(N) : C == 320 ? mhca_att_smem<320>(N) : 0;
@@ -1122,4 +1219,24 @@ extern "C" int tc_mhca_att_bwd(const void* qkv, int ldq, const void* convv, int 
     if (C == 64) return mhca_att_bwd_launch<f16_t, 64>(p, Bt, s);
     if (C == 128) return mhca_att_bwd_launch<f16_t, 128>(p, Bt, s);
     return mhca_att_bwd_launch<f16_t, 320>(p, Bt, s);
+}
+
+extern "C" int tc_dw_ln_supported(int C, int dtype) { return (dtype == TC_BF16 || dtype == TC_F16) && (C == 64 || C == 128 || C == 320); }
+extern "C" int tc_dw_ln_fwd(const void* x, int ldx, const void* w, const void* b, long long wstride, const void* gamma, const void* beta,
+                            long long gstride, void* t1, int ldt, void* xn, int ldn, float* mean, float* rstd, int groups, int B, int H, int W,
+                            int C, float eps, int dtype, void* stream) {
+    if (!x || !w || !b || !gamma || !beta || !t1 || !xn || !mean || !rstd || groups <= 0 || B <= 0 || H <= 0 || W <= 0) return TC_ERR_ARG;
+    if (!tc_dw_ln_supported(C, dtype)) return TC_ERR_UNSUPPORTED;
+    if (ldx % 8 || ldt % 8 || ldn % 8 || (((uintptr_t)x | (uintptr_t)t1 | (uintptr_t)xn) & 15)) return TC_ERR_ARG;
+    DwLnDev p;
+    p.x = x; p.w = w; p.b = b; p.gamma = gamma; p.beta = beta; p.t1 = t1; p.xn = xn; p.mean = mean; p.rstd = rstd;
+    p.wstride = wstride; p.gstride = gstride; p.ldx = ldx; p.ldt = ldt; p.ldn = ldn; p.B = B; p.H = H; p.W = W;
+    p.rows_per_group = B * H * W; p.eps = eps;
+    const dim3 grid((p.rows_per_group + 31) / 32, groups);
+    hipStream_t s = (hipStream_t)stream;
+#define DWLN(TT, CC) hipLaunchKernelGGL((dw_ln_fwd_kernel<TT, CC>), grid, dim3(256), 0, s, p)
+    if (dtype == TC_BF16) { if (C == 64) DWLN(bf16_t, 64); else if (C == 128) DWLN(bf16_t, 128); else DWLN(bf16_t, 320); }
+    else { if (C == 64) DWLN(f16_t, 64); else if (C == 128) DWLN(f16_t, 128); else DWLN(f16_t, 320); }
+#undef DWLN
+    return tc_launch_status();
 }

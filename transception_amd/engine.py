@@ -200,6 +200,7 @@ _EFFATT_FUSED = os.environ.get("TC_EFFATT_FUSED", "1") != "0"        # Efficient
 # measured a wash -- 13.12 vs 13.08 ms per step with it on: the tiled kernels are VALU-bound, so the +17 us (backward) / +2 us (forward)
 # the in-kernel LayerNorm costs per site cancel the two memory-bound launches it removes (negative results).
 _FFN_PRE_LN = os.environ.get("TC_FFN_PRE_LN", "0") != "0"
+_DW_LN_FUSED = os.environ.get("TC_DW_LN_FUSED", "1") != "0"          # cpe (dw3x3 + skip) + norm1 of an MHCABlock as one forward launch
 _MHCA_ATT_BWD_FUSED = os.environ.get("TC_MHCA_ATT_BWD_FUSED", "1") != "0"  # ... and the backward of crpe + attention core as one launch
 _MHCA_ATT_FUSED = os.environ.get("TC_MHCA_ATT_FUSED", "1") != "0"  # qkv + crpe + factorised attention of an MHCABlock as one forward launch (csrc/factoratt.hip)
 _DW_BWD_ONE = os.environ.get("TC_DW_BWD_ONE", "1") != "0"          # input + weight gradient of a stride-1 depthwise conv in one launch
@@ -1119,17 +1120,20 @@ class Graph:
         self._rec(bwd)
         return out
 
-    def layernorm(self, x: Var, g: P, b: P, eps: float = 1e-5, act: int = ACT_NONE, out: Optional[Var] = None) -> Var:
+    def layernorm(self, x: Var, g: P, b: P, eps: float = 1e-5, act: int = ACT_NONE, out: Optional[Var] = None,
+                  stats: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, launch: bool = True) -> Var:
+        """launch=False: a fused kernel of the caller writes `out` and stats = (mean, rstd); only the backward closure is recorded."""
         Gn = self.ngroups
         rows, Cc = x.rows // Gn, x.cols
         assert Gn == 1 or (g.gs > 0 and b.gs == g.gs)
         if out is None:
             out = self.new(x.rows, Cc)
-        mean, rstd = self.f32(x.rows), self.f32(x.rows)
+        mean, rstd = stats if stats is not None else (self.f32(x.rows), self.f32(x.rows))
         es = x.data.element_size()
-        _timed("hbm:layernorm_fwd", 2.0 * x.rows * Cc * es, lambda: self.L.tc_layernorm_fwd(
-            _ptr(x.data), x.ld, _ptr(g.data), _ptr(b.data), _ptr(out.data), out.ld, _ptr(mean), _ptr(rstd), rows, Cc, eps, act, Gn, g.gs,
-            self.dt, self.stream))
+        if launch:
+            _timed("hbm:layernorm_fwd", 2.0 * x.rows * Cc * es, lambda: self.L.tc_layernorm_fwd(
+                _ptr(x.data), x.ld, _ptr(g.data), _ptr(b.data), _ptr(out.data), out.ld, _ptr(mean), _ptr(rstd), rows, Cc, eps, act, Gn, g.gs,
+                self.dt, self.stream))
 
         def bwd():
             dy = self.grad_of(out)
@@ -1193,8 +1197,26 @@ class Graph:
         self._rec(bwd)
         return out
 
+    def dw_ln_supported(self, x: Var) -> bool:
+        return (_DW_LN_FUSED and self.dt != TC_F32 and not self.use_streams and x.ld % 8 == 0 and x.data.data_ptr() % 16 == 0
+                and (self.pgs % 8 == 0 or self.ngroups == 1) and bool(self.L.tc_dw_ln_supported(x.cols, self.dt)))
+
+    def dw_ln(self, x: Var, w: P, b: P, g: P, beta: P, B: int, H: int, W: int, eps: float) -> Tuple[Var, Var]:
+        """(t1, LayerNorm(t1)) with t1 = x + dw3x3(x) + bias -- the head of an MHCABlock (cpe + norm1, MSTr.py:744-752, 935-940) -- as ONE forward
+        launch (tc_dw_ln_fwd); the backward is the two ops' own (their closures are recorded without their forward launches)."""
+        Gn = self.ngroups
+        t1 = self.dwconv(x, w, b, B, H, W, 3, 1, True, launch=False)
+        mean, rstd = self.f32(x.rows), self.f32(x.rows)
+        xn = self.layernorm(t1, g, beta, eps, stats=(mean, rstd), launch=False)
+        self.n_launch += 1
+        es = x.data.element_size()
+        _timed("hbm:dw_ln_fwd (cpe dw3x3 + skip + LayerNorm, one launch)", 3.0 * x.rows * x.cols * es, lambda: self.L.tc_dw_ln_fwd(
+            _ptr(x.data), x.ld, _ptr(w.data), _ptr(b.data), w.gs if Gn > 1 else 0, _ptr(g.data), _ptr(beta.data), g.gs if Gn > 1 else 0,
+            _ptr(t1.data), t1.ld, _ptr(xn.data), xn.ld, _ptr(mean), _ptr(rstd), Gn, B, H, W, x.cols, eps, self.dt, self.stream))
+        return t1, xn
+
     def dwconv(self, x: Var, w: P, b: Optional[P], B: int, H: int, W: int, k: int, stride: int = 1, add_input: bool = False,
-               out: Optional[Var] = None) -> Var:
+               out: Optional[Var] = None, launch: bool = True) -> Var:
         Cc = x.cols
         Gn = self.ngroups                                    # B = images per group
         assert x.rows == Gn * B * H * W and (Gn == 1 or (w.gs > 0 and stride == 1))
@@ -1202,9 +1224,10 @@ class Graph:
         if out is None:
             out = self.new(Gn * B * Ho * Wo, Cc)
         es = x.data.element_size()
-        _timed("hbm:dwconv_fwd", (x.rows + out.rows) * Cc * es, lambda: self.L.tc_dwconv_fwd(
-            _ptr(x.data), x.ld, _ptr(w.data), _ptr(b.data) if b is not None else None, _ptr(out.data), out.ld, B, H, W, Cc, k, stride,
-            int(add_input), Gn, w.gs, self.dt, self.stream))
+        if launch:
+            _timed("hbm:dwconv_fwd", (x.rows + out.rows) * Cc * es, lambda: self.L.tc_dwconv_fwd(
+                _ptr(x.data), x.ld, _ptr(w.data), _ptr(b.data) if b is not None else None, _ptr(out.data), out.ld, B, H, W, Cc, k, stride,
+                int(add_input), Gn, w.gs, self.dt, self.stream))
 
         def bwd():
             dy = self.grad_of(out)

@@ -768,8 +768,13 @@ def _factor_att(M, G, n: Var, blk: str, enc: str, B: int, side: int, residual: O
 
 def _mhca_block(M, G, t: Var, blk: str, enc: str, B: int, side: int, out: Optional[Var] = None) -> Var:
     """MHCABlock, MSTr.py:935-946: shared cpe (dw3x3 + identity) in every block, LN eps 1e-6."""
-    t1 = G.dwconv(t, M._P(G, enc + ".cpe.proj.weight"), M._P(G, enc + ".cpe.proj.bias"), B, side, side, 3, 1, True)
-    t2 = _factor_att(M, G, _ln(M, G, t1, blk + ".norm1", 1e-6), blk, enc, B, side, residual=t1)
+    if G.dw_ln_supported(t):                                     # cpe + norm1: one launch
+        t1, n1 = G.dw_ln(t, M._P(G, enc + ".cpe.proj.weight"), M._P(G, enc + ".cpe.proj.bias"), M._P(G, blk + ".norm1.weight"),
+                         M._P(G, blk + ".norm1.bias"), B, side, side, 1e-6)
+    else:
+        t1 = G.dwconv(t, M._P(G, enc + ".cpe.proj.weight"), M._P(G, enc + ".cpe.proj.bias"), B, side, side, 3, 1, True)
+        n1 = _ln(M, G, t1, blk + ".norm1", 1e-6)
+    t2 = _factor_att(M, G, n1, blk, enc, B, side, residual=t1)
     return _mixffn(M, G, t2, blk + ".mlp", B, side, side, residual=t2, out=out, pre_ln=(blk + ".norm2", 1e-6))
 
 
