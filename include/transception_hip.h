@@ -654,6 +654,24 @@ int tc_fill_f32(float* p, long long n, float v, void* stream);
 /* dst(bf16) = src(fp32) and back, for bf16 working copies of fp32 master weights */
 int tc_cast(const void* src, void* dst, long long n, int src_dtype, int dst_dtype, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * RIPM (Patch_Embed_stage of DWConv2d_BN, MSTr.py:704-732 / 309-362): one DWConv2d_BN step per launch (16-bit storage, C = 64 / 128 / 320).
+ *   bn_in = 0:  x = xin                                   (step 0: the previous stage's map, stride 2)
+ *   bn_in = 1:  x = Hardswish(BatchNorm(xin))             (xin = the raw 1x1 output of the previous step; training: batch statistics folded
+ *               from part_in -- tc_bn_fwd's scratch with chunks_in row chunks, as left by the previous call -- save_mean / save_rstd [C]
+ *               written and running_mean / running_var updated (momentum) as tc_bn_fwd does; eval: the running statistics) and x is ALSO
+ *               written to xnorm [B*Hi*Wi, C] (row stride ldn): the map the step's other consumers read;
+ *   y = dw3x3(x, stride, pad 1, no bias) [B*Ho*Wo, C]   z = y wp^T [.., C] (wp = nn.Conv2d(C, C, 1) weight [C, C], no bias)
+ *   part_out = shift[C] | S1[T][C] | S2[T][C], T = tc_ripm_tiles(B, Ho, Wo): sums of (z - shift) and (z - shift)^2 per 8 x 8-pixel tile
+ *   (shift = shift_out[C] or 0) -- pass it to tc_bn_fwd(stats_chunks = T) / the next tc_ripm_fwd(part_in, chunks_in = T).
+ * Backward: tc_bn_bwd, tc_gemm_pair, tc_dwconv_bwd* on the tensors left here -- unchanged. */
+int tc_ripm_supported(int C, int dtype);
+int tc_ripm_tiles(int B, int Ho, int Wo);
+int tc_ripm_fwd(const void* xin, int ldx, int bn_in, const float* part_in, int chunks_in, const void* gamma, const void* beta,
+                float* running_mean, float* running_var, float* save_mean, float* save_rstd, float eps, float momentum,
+                int training, void* xnorm, int ldn, const void* wd, const void* wp, void* y, int ldy, void* z, int ldz,
+                float* part_out, const float* shift_out, int B, int Hi, int Wi, int C, int stride, int dtype, void* stream);
+
 /* profiling aid: an empty launch of id + 1 workgroups that marks a section boundary in a kernel trace (no reference counterpart) */
 int tc_seg_marker(int id, void* stream);
 

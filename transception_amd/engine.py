@@ -200,6 +200,7 @@ _EFFATT_FUSED = os.environ.get("TC_EFFATT_FUSED", "1") != "0"        # Efficient
 # measured a wash -- 13.12 vs 13.08 ms per step with it on: the tiled kernels are VALU-bound, so the +17 us (backward) / +2 us (forward)
 # the in-kernel LayerNorm costs per site cancel the two memory-bound launches it removes (negative results).
 _FFN_PRE_LN = os.environ.get("TC_FFN_PRE_LN", "0") != "0"
+_RIPM_FUSED = os.environ.get("TC_RIPM_FUSED", "1") != "0"            # a DWConv2d_BN step of the RIPM stages per launch, BatchNorm applied by the consumer (csrc/ripm.hip)
 _DW_LN_FUSED = os.environ.get("TC_DW_LN_FUSED", "1") != "0"          # cpe (dw3x3 + skip) + norm1 of an MHCABlock as one forward launch
 _MHCA_ATT_BWD_FUSED = os.environ.get("TC_MHCA_ATT_BWD_FUSED", "1") != "0"  # ... and the backward of crpe + attention core as one launch
 _MHCA_ATT_FUSED = os.environ.get("TC_MHCA_ATT_FUSED", "1") != "0"  # qkv + crpe + factorised attention of an MHCABlock as one forward launch (csrc/factoratt.hip)
@@ -1343,7 +1344,10 @@ class Graph:
         return outs
 
     def batchnorm(self, x: Var, gamma: P, beta: P, running_mean: torch.Tensor, running_var: torch.Tensor, act: int = ACT_NONE,
-                  residual: Optional[Var] = None, out: Optional[Var] = None) -> Var:
+                  residual: Optional[Var] = None, out: Optional[Var] = None, saved: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+                  launch: bool = True) -> Var:
+        """saved = (save_mean, save_rstd) buffers to use; launch=False: a fused kernel of the caller applies this BatchNorm (writes `out`,
+        the saved statistics and the running statistics); only the backward closure is recorded."""
         rows, Cc = x.rows, x.cols
         if out is None:
             out = self.new(rows, Cc)
@@ -1352,17 +1356,18 @@ class Graph:
         smean = srstd = part = None
         chunks = 0
         if self.training:
-            smean, srstd = self.f32(Cc), self.f32(Cc)
+            smean, srstd = saved if saved is not None else (self.f32(Cc), self.f32(Cc))
             pre = getattr(x, "bn_part", None)                     # the producing GEMM's epilogue already made the statistics pass
             if pre is not None:
                 part, chunks = pre
             else:
                 part = self.f32(int(self.L.tc_bn_scratch_floats(rows, Cc)))
         es = x.data.element_size()
-        _timed("hbm:batchnorm_fwd", ((3.0 if self.training and not chunks else 2.0) + (residual is not None)) * rows * Cc * es, lambda: self.L.tc_bn_fwd(
-            _ptr(x.data), x.ld, _ptr(gamma.data), _ptr(beta.data), _ptr(running_mean), _ptr(running_var),
-            _ptr(residual.data) if residual is not None else None, residual.ld if residual is not None else 0, _ptr(out.data), out.ld,
-            _ptr(smean), _ptr(srstd), _ptr(part), rows, Cc, 1e-5, 0.1, int(self.training), chunks, act, self.dt, self.stream))
+        if launch:
+            _timed("hbm:batchnorm_fwd", ((3.0 if self.training and not chunks else 2.0) + (residual is not None)) * rows * Cc * es, lambda: self.L.tc_bn_fwd(
+                _ptr(x.data), x.ld, _ptr(gamma.data), _ptr(beta.data), _ptr(running_mean), _ptr(running_var),
+                _ptr(residual.data) if residual is not None else None, residual.ld if residual is not None else 0, _ptr(out.data), out.ld,
+                _ptr(smean), _ptr(srstd), _ptr(part), rows, Cc, 1e-5, 0.1, int(self.training), chunks, act, self.dt, self.stream))
 
         def bwd():
             dy = self.grad_of(out)
@@ -1376,6 +1381,47 @@ class Graph:
                 self.pass_grad(residual, dy)
         self._rec(bwd)
         return out
+
+    def ripm_supported(self, m: Var) -> bool:
+        return (_RIPM_FUSED and self.dt != TC_F32 and not self.use_streams and self.ngroups == 1 and m.ld % 8 == 0
+                and m.data.data_ptr() % 16 == 0 and bool(self.L.tc_ripm_supported(m.cols, self.dt)))
+
+    def ripm_stage(self, m: Var, steps: List[dict], B: int, side: int, stack: Var) -> int:
+        """Patch_Embed_stage (MSTr.py:725-732): three DWConv2d_BN steps -- dw3x3 (stride 2, 1, 1), pw1x1, BatchNorm, Hardswish -- as
+        3 + 1 forward launches instead of 9 (tc_ripm_fwd: a step per launch; the BatchNorm + Hardswish of a step is applied by the NEXT step
+        on the way in, which also writes the normalised map into `stack`; the last step's by tc_bn_fwd from the sums the kernel left).
+        steps[i] = dict(dw=P, pw=P, gamma=P, beta=P, rmean=tensor, rvar=tensor).  The backward is the nine ops' own.  Returns the output side."""
+        Cc, L = m.cols, self.L
+        xin, prev = m, None
+        for i, st in enumerate(steps):
+            stride = 2 if i == 0 else 1
+            so = (side - 1) // stride + 1
+            rows = B * so * so
+            y = self.dwconv(xin, st["dw"], None, B, side, side, 3, stride, launch=False)
+            z = self.new(rows, Cc)
+            T = int(L.tc_ripm_tiles(B, so, so))
+            part = self.f32(Cc * (1 + 2 * max(T, 128)))              # (also the scratch of the BatchNorm's backward sums)
+            if self.training:
+                z.bn_part = (part, T)
+            self.linear(y, st["pw"], None, out=z, launch=False)
+            saved = (self.f32(Cc), self.f32(Cc))
+            self.n_launch += 1
+            pp = prev
+            _timed("hbm:ripm_fwd (BatchNorm + Hardswish of the input, dw3x3, pw1x1, statistics: one launch)", (2.0 * xin.rows + 2.0 * rows) * Cc * m.data.element_size(),
+                   lambda: L.tc_ripm_fwd(_ptr(pp["z"].data if pp else m.data), (pp["z"].ld if pp else m.ld), int(pp is not None),
+                                         _ptr(pp["part"]) if pp else None, pp["T"] if pp else 0,
+                                         _ptr(pp["st"]["gamma"].data) if pp else None, _ptr(pp["st"]["beta"].data) if pp else None,
+                                         _ptr(pp["st"]["rmean"]) if pp else None, _ptr(pp["st"]["rvar"]) if pp else None,
+                                         _ptr(pp["saved"][0]) if pp else None, _ptr(pp["saved"][1]) if pp else None, 1e-5, 0.1, int(self.training),
+                                         _ptr(xin.data) if pp else None, xin.ld if pp else 0, _ptr(st["dw"].data), _ptr(st["pw"].data), _ptr(y.data), y.ld,
+                                         _ptr(z.data), z.ld, _ptr(part), _ptr(st["rmean"]) if self.training else None, B, side, side, Cc, stride, self.dt,
+                                         self.stream))
+            last = i == len(steps) - 1
+            xout = self.batchnorm(z, st["gamma"], st["beta"], st["rmean"], st["rvar"], ACT_HSWISH, out=stack.rowslice(i * rows, (i + 1) * rows),
+                                  saved=saved, launch=last)
+            prev = dict(z=z, part=part, T=T, st=st, saved=saved)
+            xin, side = xout, so
+        return side
 
     def softmax(self, x: Var, nb: int, axis: int, out: Optional[Var] = None) -> Var:
         """Softmax over axis (0 = rows, 1 = cols) of each of the nb stacked [rows/nb, cols] matrices."""

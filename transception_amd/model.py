@@ -704,6 +704,14 @@ def _ripm(M, G, m: Var, name: str, B: int, side: int) -> Tuple[Var, int]:
     so = (side - 1) // 2 + 1
     rows = B * so * so
     stack = G.new(3 * rows, m.cols)
+    if G.ripm_supported(m):                                      # a step per launch, BatchNorm + Hardswish applied by the consumer
+        steps = []
+        for i in range(3):
+            pre = f"{name}.patch_embeds.{i}.patch_conv"
+            holder = M.get_submodule(pre + ".bn")
+            steps.append(dict(dw=M._P(G, pre + ".dwconv.weight"), pw=_lin(M, G, pre + ".pwconv", bias=False)[0], gamma=M._P(G, pre + ".bn.weight"),
+                              beta=M._P(G, pre + ".bn.bias"), rmean=holder.running_mean, rvar=holder.running_var))
+        return stack, G.ripm_stage(m, steps, B, side, stack)
     x = m
     for i in range(3):
         stride = 2 if i == 0 else 1
