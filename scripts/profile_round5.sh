@@ -32,3 +32,9 @@ for d in stats stats_c5 stats_c4; do cp $(find $O/$d -name "*kernel_stats.csv" |
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete
 python bench.py --gpus 1 --force-split --steps 20 --warmup 5 --no-cpu --no-side > $O/bench_split.json 2> $O/bench_split.err
 ls -R $O | head -40
+# round-5 evidence that is not rocprofv3 output: per-phase cycles of the fused MHCA kernels (a -DTC_MHCA_TIMING library built in the container:
+# bash scripts/exp/build_variant.sh mhcatiming factoratt.hip -DTC_MHCA_TIMING), fused vs op-by-op launch times, the grid-barrier probe
+python scripts/bench_mhca.py --bwd > $O/r5_mhca_fused_vs_opbyop.txt 2>/dev/null
+if [ -f scripts/exp/lib_mhcatiming.so ]; then TC_LIB_PATH=scripts/exp/lib_mhcatiming.so python scripts/bench_mhca.py --timing --timing-bwd 2>/dev/null | grep -v "fused " > $O/r5_mhca_phase_cycles.txt; fi
+if [ -x scripts/exp/gridbar ]; then timeout 120 scripts/exp/gridbar > $O/r5_gridbar.txt 2>&1; fi
+ls $O
