@@ -672,6 +672,17 @@ int tc_ripm_fwd(const void* xin, int ldx, int bn_in, const float* part_in, int c
                 int training, void* xnorm, int ldn, const void* wd, const void* wp, void* y, int ldy, void* z, int ldz,
                 float* part_out, const float* shift_out, int B, int Hi, int Wi, int C, int stride, int dtype, void* stream);
 
+/* Square Linear + residual + LayerNorm in one launch (16-bit storage, C = 64 / 128 / 320): t = x W^T + b + res (res may be NULL),
+ * xn = LayerNorm_C(t) with mean / rstd [groups*rows] as tc_layernorm_fwd leaves them -- nn.Linear(C, C) `proj` + skip + norm2 of an MHCABlock
+ * (MSTr.py:883, 940-942) and of a bridge layer (:2288, 2404-2406), `reprojection` + skip + norm2 of an EfficientTransformerBlock (:141,
+ * 167-170).  `groups` row blocks of `rows` rows, group g's parameters at +g*wstride (W, b) / +g*gstride (gamma, beta).  Every pointer
+ * 16-byte aligned, ld* and both strides multiples of 8 elements (TC_ERR_ARG otherwise).  Backward: tc_layernorm_bwd*, then tc_gemm_pair --
+ * unchanged. */
+int tc_linear_ln_supported(int C, int dtype);
+int tc_linear_ln_fwd(const void* x, int ldx, const void* w, const void* b, long long wstride, const void* res, int ldr, const void* gamma,
+                     const void* beta, long long gstride, void* t, int ldt, void* xn, int ldn, float* mean, float* rstd, int groups,
+                     int rows, int C, float eps, int dtype, void* stream);
+
 /* profiling aid: an empty launch of id + 1 workgroups that marks a section boundary in a kernel trace (no reference counterpart) */
 int tc_seg_marker(int id, void* stream);
 

@@ -26,7 +26,7 @@ gout = torch.randn(B * N, C, generator=g).to(dev).to(dtype)
 def run():
     G = Graph(dtype, dev, training=True, record=True)
     t = Var(x)
-    out = MM._eff_attention(M, G, MM._ln(M, G, t, BLK + ".norm1"), BLK + ".attn", B, N, residual=t)
+    out = MM._eff_attention(M, G, MM._ln(M, G, t, BLK + ".norm1"), BLK + ".attn", B, N, residual=t)[0]
     out.root.grad_t = gout
     out.root.whole_written = True
     G.backward()

@@ -193,3 +193,69 @@ def test_dw_ln_one_launch(dtype, C, side, B, Gn):
     assert rel(tf, tu) < tol / 4 and rel(nf, nu) < tol / 2, (rel(tf, tu), rel(nf, nu))
     assert rel(dxf, xr.grad) < 2 * tol and rel(gpf, master.grad) < 2 * tol, (rel(dxf, xr.grad), rel(gpf, master.grad))
     assert rel(dxf, dxu) < tol and rel(gpf, gpu_) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("C,rows_g,Gn,res", [(64, 2 * 784, 3, True), (128, 2 * 196, 3, True), (320, 3 * 49, 3, True), (64, 1029, 1, True),
+                                             (128, 81, 1, False), (320, 200, 1, True)])
+def test_linear_ln_one_launch(dtype, C, rows_g, Gn, res):
+    """engine.Graph.linear_ln (tc_linear_ln_fwd: square Linear + bias + skip and the LayerNorm after it in one launch -- proj + norm2 of an
+    MHCABlock / bridge layer, reprojection + norm2 of an EfficientTransformerBlock) against torch fp32 and against the two launches it
+    replaces (forward: same roundings at the same places; backward is theirs).  Row counts include a partial last 64-row tile per group."""
+    import transception_amd.engine as E
+    from transception_amd.engine import Graph, P, Var
+    rows = Gn * rows_g
+    x16, r16 = T(f"ll.x{C}", (rows, C)).to(dtype), T(f"ll.r{C}", (rows, C)).to(dtype)
+    g1, g2 = T(f"ll.g1{C}", (rows, C)).to(dtype), T(f"ll.g2{C}", (rows, C)).to(dtype)
+    per = (C * C + 3 * C + 7) // 8 * 8
+    flat = T(f"ll.p{C}", (Gn * per,), C ** -0.5)
+    flat.view(Gn, per)[:, C * C + C:C * C + 2 * C] += 1.0                          # gamma around 1
+    lp = flat.to(dtype).to(DEV)
+    master = lp.float().cpu().clone().requires_grad_()
+    gflat = torch.zeros(Gn * per, dtype=torch.float32, device=DEV)
+    mk = lambda a, n, shp: P(lp[a:a + n].view(shp), gflat[a:a + n].view(shp), per if Gn > 1 else 0)
+    W, b, ga, be = mk(0, C * C, (C, C)), mk(C * C, C, (C,)), mk(C * C + C, C, (C,)), mk(C * C + 2 * C, C, (C,))
+    xr, rr = x16.float().requires_grad_(), r16.float().requires_grad_()
+    outs_t, outs_n = [], []
+    for g in range(Gn):
+        m = master[g * per:(g + 1) * per]
+        t = F.linear(xr[g * rows_g:(g + 1) * rows_g], m[:C * C].view(C, C), m[C * C:C * C + C])
+        if res:
+            t = t + rr[g * rows_g:(g + 1) * rows_g]
+        outs_t.append(t); outs_n.append(F.layer_norm(t, (C,), m[C * C + C:C * C + 2 * C], m[C * C + 2 * C:C * C + 3 * C], 1e-6))
+    rt, rn = torch.cat(outs_t), torch.cat(outs_n)
+    (rt * g1.float()).sum().backward(retain_graph=True)
+    (rn * g2.float()).sum().backward()
+
+    def run(fused):
+        E._LIN_LN_FUSED = fused
+        gflat.zero_()
+        G = Graph(dtype, torch.device(DEV), training=True, record=True)
+        xv, rv = Var(x16.to(DEV).contiguous()), (Var(r16.to(DEV).contiguous()) if res else None)
+        with (G.grouped(Gn, per) if Gn > 1 else G.grouped(1, 0)):
+            assert G.linear_ln_supported(xv, W, rv) == fused
+            n0 = G.n_launch
+            if fused:
+                t, xn = G.linear_ln(xv, W, b, rv, ga, be, 1e-6)
+                assert G.n_launch - n0 == 1
+            else:
+                t = G.linear(xv, W, b, residual=rv)
+                xn = G.layernorm(t, ga, be, 1e-6)
+            xn.root.grad_t = g2.to(DEV).contiguous(); xn.root.whole_written = True
+            t.root.grad_t = g1.to(DEV).contiguous(); t.root.whole_written = True       # (the skip branch's gradient of t: LayerNorm's backward adds to it)
+            G.backward()
+        torch.cuda.synchronize()
+        dr = G.grad_of(rv).float().cpu() if res else None
+        return t.data.float().cpu(), xn.data.float().cpu(), G.grad_of(xv).float().cpu(), dr, gflat.cpu().clone()
+    try:
+        tf, nf, dxf, drf, gpf = run(True)
+        tu, nu, dxu, dru, gpu_ = run(False)
+    finally:
+        E._LIN_LN_FUSED = True
+    tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
+    assert rel(tf, rt) < tol and rel(nf, rn) < tol, (rel(tf, rt), rel(nf, rn))
+    assert rel(tf, tu) < tol / 4 and rel(nf, nu) < tol / 2, (rel(tf, tu), rel(nf, nu))
+    assert rel(dxf, xr.grad) < 2 * tol and rel(gpf, master.grad) < 2 * tol, (rel(dxf, xr.grad), rel(gpf, master.grad))
+    assert rel(dxf, dxu) < tol and rel(gpf, gpu_) < tol
+    if res:
+        assert rel(drf, rr.grad) < 2 * tol and rel(drf, dru) < tol

@@ -139,9 +139,9 @@ def _run_module_cases(model, dtype, y_tol, gx_tol, gw_l2=0.0):
     ident = lambda t: t
     tok3 = lambda t: t.reshape(-1, t.shape[-1])
     # EfficientAttention / EfficientTransformerBlock / MixFFN
-    run("eff_attn_s1", [(B, 64, 56, 56)], [_tok], lambda G, x: MM._eff_attention(model, G, x, f"{bb}.block1.0.attn", B, 3136),
+    run("eff_attn_s1", [(B, 64, 56, 56)], [_tok], lambda G, x: MM._eff_attention(model, G, x, f"{bb}.block1.0.attn", B, 3136)[0],
         lambda o: _untok(o, B, 56, 56), _tok, [lambda g: _untok(g, B, 56, 56)])
-    run("eff_attn_d2", [(B, 320, 14, 14)], [_tok], lambda G, x: MM._eff_attention(model, G, x, "decoder_2.layer_former_1.attn", B, 196),
+    run("eff_attn_d2", [(B, 320, 14, 14)], [_tok], lambda G, x: MM._eff_attention(model, G, x, "decoder_2.layer_former_1.attn", B, 196)[0],
         lambda o: _untok(o, B, 14, 14), _tok, [lambda g: _untok(g, B, 14, 14)])
     run("eff_block_s1", [(B, 3136, 64)], [tok3], lambda G, x: MM._eff_block(model, G, x, f"{bb}.block1.1", B, 56, 56),
         lambda o: o.reshape(B, 3136, 64), tok3, [lambda g: g.reshape(B, 3136, 64)])
@@ -160,7 +160,7 @@ def _run_module_cases(model, dtype, y_tol, gx_tol, gw_l2=0.0):
             lambda G, x, st=st, hw=hw: MM._mhca_block(model, G, x, f"{st}.mhca_blks.1.MHCA_layers.1", f"{st}.mhca_blks.1", B, hw),
             lambda o, hw=hw, C=C: o.reshape(B, hw * hw, C), tok3, [lambda g, hw=hw, C=C: g.reshape(B, hw * hw, C)])
         run(f"factoratt_s{s}", [(B, hw * hw, C)], [tok3],
-            lambda G, x, st=st, hw=hw: MM._factor_att(model, G, x, f"{st}.mhca_blks.2.MHCA_layers.0", f"{st}.mhca_blks.2", B, hw),
+            lambda G, x, st=st, hw=hw: MM._factor_att(model, G, x, f"{st}.mhca_blks.2.MHCA_layers.0", f"{st}.mhca_blks.2", B, hw)[0],
             lambda o, hw=hw, C=C: o.reshape(B, hw * hw, C), tok3, [lambda g, hw=hw, C=C: g.reshape(B, hw * hw, C)])
         run(f"coordatt_s{s}", [(B, 4 * C, hw, hw)], [_tok],
             lambda G, x, st=st, hw=hw: MM._coord_att(model, G, x, f"{st}.aggregate", B, hw, G.new(B * hw * hw, model._index[
@@ -178,7 +178,7 @@ def _run_module_cases(model, dtype, y_tol, gx_tol, gw_l2=0.0):
 
         def self_att(G, x):
             G.use_fused_attention = fused
-            return MM._self_att(model, G, x, None, "bridge.bridge_layer3.attn", B, SIDES, NTOK, R, N6)
+            return MM._self_att(model, G, x, None, "bridge.bridge_layer3.attn", B, SIDES, NTOK, R, N6)[0]
         run("self_att", [(B, N6, 64)], [sm], self_att, im, sm, [im], atol=1e-4)
     for li in (1, 4):
         def layer(G, x, li=li):

@@ -206,6 +206,8 @@ SIGNATURES = {
     "tc_fill_f32": [vp, i64, f32, vp],
     "tc_cast": [vp, vp, i64, i32, i32, vp],
     "tc_seg_marker": [i32, vp],
+    "tc_linear_ln_supported": [i32, i32],
+    "tc_linear_ln_fwd": [vp, i32, vp, vp, i64, vp, i32, vp, vp, i64, vp, i32, vp, i32, vp, vp, i32, i32, i32, f32, i32, vp],
     "tc_ripm_supported": [i32, i32],
     "tc_ripm_tiles": [i32, i32, i32],
     "tc_ripm_fwd": [vp, i32, i32, vp, i32, vp, vp, vp, vp, vp, vp, f32, f32, i32, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp],
@@ -217,7 +219,7 @@ SIGNATURES = {
     "tc_mhca_att_fwd": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, f32, i32, vp],
 }
 _RET = {"tc_ffn_fused_bwd_scratch_floats": i64, "tc_effatt_scratch_floats": i64, "tc_bn_scratch_floats": i64, "tc_softmax_scratch_floats": i64, "tc_layernorm_bwd_scratch_floats": i64, "tc_dwconv_bwd_plan": i64, "tc_dwconv_multi_plan": i64, "tc_ffn_mid_plan": i64, "tc_factor_att_stats_floats": i64}
-_RAW = {"tc_abi_version", "tc_ripm_supported", "tc_ripm_tiles", "tc_mhca_att_supported", "tc_dw_ln_supported", "tc_mhca_att_bwd_supported", "tc_effatt_supported", "tc_effatt_scratch_floats", "tc_ffn_chunk", "tc_ffn_fused_supported", "tc_ffn_fused_bwd_supported", "tc_ffn_fused_bwd_scratch_floats", "tc_bn_scratch_floats", "tc_softmax_scratch_floats", "tc_layernorm_bwd_scratch_floats", "tc_layernorm_bwd_nblk", "tc_dwconv_bwd_plan", "tc_dwconv_multi_plan", "tc_ffn_mid_plan", "tc_factor_att_stats_floats"}     # not status-returning
+_RAW = {"tc_abi_version", "tc_linear_ln_supported", "tc_ripm_supported", "tc_ripm_tiles", "tc_mhca_att_supported", "tc_dw_ln_supported", "tc_mhca_att_bwd_supported", "tc_effatt_supported", "tc_effatt_scratch_floats", "tc_ffn_chunk", "tc_ffn_fused_supported", "tc_ffn_fused_bwd_supported", "tc_ffn_fused_bwd_scratch_floats", "tc_bn_scratch_floats", "tc_softmax_scratch_floats", "tc_layernorm_bwd_scratch_floats", "tc_layernorm_bwd_nblk", "tc_dwconv_bwd_plan", "tc_dwconv_multi_plan", "tc_ffn_mid_plan", "tc_factor_att_stats_floats"}     # not status-returning
 
 
 class TcError(RuntimeError):

@@ -200,6 +200,7 @@ _EFFATT_FUSED = os.environ.get("TC_EFFATT_FUSED", "1") != "0"        # Efficient
 # measured a wash -- 13.12 vs 13.08 ms per step with it on: the tiled kernels are VALU-bound, so the +17 us (backward) / +2 us (forward)
 # the in-kernel LayerNorm costs per site cancel the two memory-bound launches it removes (negative results).
 _FFN_PRE_LN = os.environ.get("TC_FFN_PRE_LN", "0") != "0"
+_LIN_LN_FUSED = os.environ.get("TC_LIN_LN_FUSED", "1") != "0"       # square Linear + residual + LayerNorm (proj / reprojection + skip + norm2) as one forward launch (csrc/linln.hip)
 _RIPM_FUSED = os.environ.get("TC_RIPM_FUSED", "1") != "0"            # a DWConv2d_BN step of the RIPM stages per launch, BatchNorm applied by the consumer (csrc/ripm.hip)
 _DW_LN_FUSED = os.environ.get("TC_DW_LN_FUSED", "1") != "0"          # cpe (dw3x3 + skip) + norm1 of an MHCABlock as one forward launch
 _MHCA_ATT_BWD_FUSED = os.environ.get("TC_MHCA_ATT_BWD_FUSED", "1") != "0"  # ... and the backward of crpe + attention core as one launch
@@ -1197,6 +1198,32 @@ class Graph:
                 _ptr(g.grad), _ptr(b.grad), B, H, W, p, c, _ptr(ws) if g.grad is not None else None, ws.numel() // 4, self.dt, self.stream))
         self._rec(bwd)
         return out
+
+    def linear_ln_supported(self, x: Var, W: P, residual: Optional[Var], *params: P) -> bool:
+        """params: the bias / gamma / beta the call will pass (their 16-byte alignment is the kernel's: it loads them as whole 8-element pieces)"""
+        Cc = x.cols
+        return (all(q.data.data_ptr() % 16 == 0 for q in params) and _LIN_LN_FUSED and self.dt != TC_F32 and not self.use_streams and tuple(W.data.shape) == (Cc, Cc) and W.data.is_contiguous()
+                and x.ld % 8 == 0 and x.data.data_ptr() % 16 == 0 and (residual is None or (residual.ld % 8 == 0 and residual.data.data_ptr() % 16 == 0))
+                and (self.ngroups == 1 or self.pgs % 8 == 0) and bool(self.L.tc_linear_ln_supported(Cc, self.dt)))
+
+    def linear_ln(self, x: Var, W: P, b: P, residual: Optional[Var], g: P, beta: P, eps: float, out: Optional[Var] = None,
+                  ln_out: Optional[Var] = None) -> Tuple[Var, Var]:
+        """(t, LayerNorm(t)) with t = x W^T + b + residual for a square Linear -- `proj` + skip + norm2 of an MHCABlock / bridge layer,
+        `reprojection` + skip + norm2 of an EfficientTransformerBlock -- as ONE forward launch (tc_linear_ln_fwd); the backward is the two
+        ops' own (their closures are recorded without their forward launches)."""
+        Gn = self.ngroups
+        t = self.linear(x, W, b, out=out, residual=residual, launch=False)
+        mean, rstd = self.f32(x.rows), self.f32(x.rows)
+        xn = self.layernorm(t, g, beta, eps, out=ln_out, stats=(mean, rstd), launch=False)
+        assert t.rows == x.rows and t.cols == x.cols, "row-stacked groups only"
+        self.n_launch += 1
+        es = x.data.element_size()
+        _timed("hbm:linear_ln_fwd (Linear + residual + LayerNorm, one launch)", (4.0 if residual is not None else 3.0) * x.rows * x.cols * es,
+               lambda: self.L.tc_linear_ln_fwd(_ptr(x.data), x.ld, _ptr(W.data), _ptr(b.data), W.gs if Gn > 1 else 0,
+                                               _ptr(residual.data) if residual is not None else None, residual.ld if residual is not None else 0,
+                                               _ptr(g.data), _ptr(beta.data), g.gs if Gn > 1 else 0, _ptr(t.data), t.ld, _ptr(xn.data), xn.ld,
+                                               _ptr(mean), _ptr(rstd), Gn, x.rows // Gn, x.cols, eps, self.dt, self.stream))
+        return t, xn
 
     def dw_ln_supported(self, x: Var) -> bool:
         return (_DW_LN_FUSED and self.dt != TC_F32 and not self.use_streams and x.ld % 8 == 0 and x.data.data_ptr() % 16 == 0

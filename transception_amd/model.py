@@ -665,8 +665,9 @@ def _mixffn(M, G, x, name, B, H, W, residual, out=None, pre_ln=None):
     return G.linear(a, *_lin(M, G, name + ".fc2"), out=out, residual=residual)
 
 
-def _eff_attention(M, G, n1: Var, name: str, B: int, N: int, residual: Optional[Var] = None) -> Var:
-    """EfficientAttention with one head, MSTr.py:106-143 (Appendix C.6), + the block's residual add."""
+def _eff_attention(M, G, n1: Var, name: str, B: int, N: int, residual: Optional[Var] = None, ln=None):
+    """EfficientAttention with one head, MSTr.py:106-143 (Appendix C.6), + the block's residual add.  Returns (tx, LayerNorm(tx) | None):
+    ln = (norm name, eps) asks for the block's norm2 from the same launch as `reprojection` (_proj_ln)."""
     C = n1.cols
     rows = B * N
     kqv = G.new(rows, 3 * C, covered=True)         # k, q, v gradients (softmax / softmax / bmm backward) cover it
@@ -684,7 +685,7 @@ def _eff_attention(M, G, n1: Var, name: str, B: int, N: int, residual: Optional[
     G.bmm(ksm, v, ctx, C, C, N, 1, 0, nb1=B, sA=(N * ksm.ld, 0), sB=(N * v.ld, 0), sC=(C * C, 0))
     att = G.new(rows, C)
     G.bmm(qsm, ctx, att, N, C, C, 0, 0, nb1=B, sA=(N * qsm.ld, 0), sB=(C * C, 0), sC=(N * C, 0))
-    return G.linear(att, *_lin(M, G, name + ".reprojection"), residual=residual)
+    return _proj_ln(M, G, att, name + ".reprojection", residual, ln)
 
 
 def _eff_block(M, G, t: Var, name: str, B: int, H: int, W: int) -> Var:
@@ -694,9 +695,9 @@ def _eff_block(M, G, t: Var, name: str, B: int, H: int, W: int) -> Var:
            _lin(M, G, a + ".values"), _lin(M, G, a + ".reprojection"))
     if G.effatt_supported(t, tuple(p for pair in blk for p in pair)):
         tx = G.eff_attention_block(t, *blk, B, H * W)
-    else:
-        tx = _eff_attention(M, G, _ln(M, G, t, name + ".norm1"), name + ".attn", B, H * W, residual=t)
-    return _mixffn(M, G, tx, name + ".mlp", B, H, W, residual=tx, pre_ln=(name + ".norm2", 1e-5))
+        return _mixffn(M, G, tx, name + ".mlp", B, H, W, residual=tx, pre_ln=(name + ".norm2", 1e-5))
+    tx, n2 = _eff_attention(M, G, _ln(M, G, t, name + ".norm1"), name + ".attn", B, H * W, residual=t, ln=(name + ".norm2", 1e-5))
+    return _mixffn(M, G, n2, name + ".mlp", B, H, W, residual=tx)
 
 
 def _ripm(M, G, m: Var, name: str, B: int, side: int) -> Tuple[Var, int]:
@@ -739,15 +740,17 @@ FUSED_FACTOR_ATT = os.environ.get("TC_FACTOR_ATT_FUSED", "1") != "0"
 SHUFFLE_IN_LN = os.environ.get("TC_SHUFFLE_IN_LN", "1") != "0"
 
 
-def _factor_att(M, G, n: Var, blk: str, enc: str, B: int, side: int, residual: Optional[Var] = None) -> Var:
-    """FactorAtt_ConvRelPosEnc + ConvRelPosEnc, MSTr.py:852-886, 801-823 (Appendix C.1-2), + residual add."""
+def _factor_att(M, G, n: Var, blk: str, enc: str, B: int, side: int, residual: Optional[Var] = None, ln=None):
+    """FactorAtt_ConvRelPosEnc + ConvRelPosEnc, MSTr.py:852-886, 801-823 (Appendix C.1-2), + residual add.
+    ln = (norm name, eps): also return LayerNorm(result) -- the block's norm2 -- from the same launch as `proj` where the library has it
+    (engine.Graph.linear_ln); returns (t2, LayerNorm(t2) or None)."""
     C, N = n.cols, side * side
     Bt = B * G.ngroups                              # images of all stacked weight groups
     rows, h, Ch = Bt * N, HEADS, n.cols // HEADS
     if FUSED_FACTOR_ATT and MULTI_CRPE and Ch % 8 == 0 and G.mhca_att_supported(n, N):     # qkv + crpe + attention core: one launch
         o = G.mhca_attention(n, *_lin(M, G, blk + ".factoratt_crpe.qkv"), [M._P(G, f"{enc}.crpe.conv_list.{i}.weight") for i in range(3)],
                              [M._P(G, f"{enc}.crpe.conv_list.{i}.bias") for i in range(3)], B, side, h, Ch ** -0.5, list(CRPE_WINDOW))
-        return G.linear(o, *_lin(M, G, blk + ".factoratt_crpe.proj"), residual=residual)
+        return _proj_ln(M, G, o, blk + ".factoratt_crpe.proj", residual, ln)
     qkv = G.linear(n, *_lin(M, G, blk + ".factoratt_crpe.qkv"), out=G.new(n.rows, 3 * C, covered=FUSED_FACTOR_ATT))
     q, k, v = qkv.colslice(0, C), qkv.colslice(C, 2 * C), qkv.colslice(2 * C, 3 * C)
     convv = G.new(rows, C)
@@ -771,7 +774,18 @@ def _factor_att(M, G, n: Var, blk: str, enc: str, B: int, side: int, residual: O
         fa = G.new(rows, C)
         G.bmm(q, ctx, fa, N, Ch, Ch, 0, 0, nb1=Bt, nb2=h, sA=(N * 3 * C, Ch), sB=(h * Ch * Ch, Ch * Ch), sC=(N * C, Ch))
         o = G.fma3(fa, q, convv, Ch ** -0.5)
-    return G.linear(o, *_lin(M, G, blk + ".factoratt_crpe.proj"), residual=residual)
+    return _proj_ln(M, G, o, blk + ".factoratt_crpe.proj", residual, ln)
+
+
+def _proj_ln(M, G, o: Var, proj: str, residual: Optional[Var], ln, out: Optional[Var] = None, ln_out: Optional[Var] = None):
+    """(t, LayerNorm(t) | None) with t = proj(o) + residual: one launch for both where the library supports the width (tc_linear_ln_fwd)."""
+    W, b = _lin(M, G, proj)
+    if ln is not None and b is not None:
+        g, beta = M._P(G, ln[0] + ".weight"), M._P(G, ln[0] + ".bias")
+        if G.linear_ln_supported(o, W, residual, b, g, beta):
+            return G.linear_ln(o, W, b, residual, g, beta, ln[1], out=out, ln_out=ln_out)
+    t = G.linear(o, W, b, residual=residual, out=out)
+    return t, (_ln(M, G, t, ln[0], ln[1], out=ln_out) if ln is not None else None)
 
 
 def _mhca_block(M, G, t: Var, blk: str, enc: str, B: int, side: int, out: Optional[Var] = None) -> Var:
@@ -782,8 +796,8 @@ def _mhca_block(M, G, t: Var, blk: str, enc: str, B: int, side: int, out: Option
     else:
         t1 = G.dwconv(t, M._P(G, enc + ".cpe.proj.weight"), M._P(G, enc + ".cpe.proj.bias"), B, side, side, 3, 1, True)
         n1 = _ln(M, G, t1, blk + ".norm1", 1e-6)
-    t2 = _factor_att(M, G, n1, blk, enc, B, side, residual=t1)
-    return _mixffn(M, G, t2, blk + ".mlp", B, side, side, residual=t2, out=out, pre_ln=(blk + ".norm2", 1e-6))
+    t2, n2 = _factor_att(M, G, n1, blk, enc, B, side, residual=t1, ln=(blk + ".norm2", 1e-6))     # proj + skip + norm2: one launch
+    return _mixffn(M, G, n2, blk + ".mlp", B, side, side, residual=t2, out=out)
 
 
 def _coord_att(M, G, x: Var, name: str, B: int, side: int, out: Var) -> Var:
@@ -984,8 +998,9 @@ def _scale_reduce(M, G, n: Var, name: str, B: int, sides: List[int], ntok: List[
 LOG2E = 1.4426950408889634
 
 
-def _self_att(M, G, n: Var, X: Optional[Var], name: str, B: int, sides: List[int], ntok: List[int], R: List[int], N6: int) -> Var:
-    """M_EfficientSelfAtten, MSTr.py:2267-2292: one head, d = 64, keys/values from the reduced token set."""
+def _self_att(M, G, n: Var, X: Optional[Var], name: str, B: int, sides: List[int], ntok: List[int], R: List[int], N6: int, ln=None):
+    """M_EfficientSelfAtten, MSTr.py:2267-2292: one head, d = 64, keys/values from the reduced token set.  Returns (tx1, LayerNorm(tx1) | None):
+    ln = (norm name, eps) asks for the layer's norm2 from the same launch as `proj` (_proj_ln)."""
     Cd = 64
     Nk = sides[3] * sides[3] * 8 + ntok[3]
     # 16-bit fused path: the q projection stores q * scale * log2(e), rounded once from its fp32 accumulator (the attention kernels then
@@ -1001,8 +1016,9 @@ def _self_att(M, G, n: Var, X: Optional[Var], name: str, B: int, sides: List[int
     else:
         for s in range(4):
             G.attention(q.rowslice(R[s], R[s + 1]), k, v, B, ntok[s], Nk, Cd ** -0.5, out=att.rowslice(R[s], R[s + 1]))
-    # (tx1's gradient is covered: the four per-scale MixFFN residuals write its four row groups before LayerNorm 2's backward adds to it)
-    return G.linear(att, *_lin(M, G, name + ".proj"), residual=X, out=G.new(B * N6, Cd, covered=True))
+    # (tx1's gradient is covered: the four per-scale MixFFN residuals write its four row groups before LayerNorm 2's backward adds to it;
+    # tx = norm2(tx1) likewise: its gradient = the four MixFFN input gradients, row group by row group)
+    return _proj_ln(M, G, att, name + ".proj", X, ln, out=G.new(B * N6, Cd, covered=True), ln_out=G.new(B * N6, Cd, covered=True) if ln is not None else None)
 
 
 def _bridge_layer(M, G, X: Var, li: int, B: int, sides, ntok, R, N6) -> Var:
@@ -1011,9 +1027,9 @@ def _bridge_layer(M, G, X: Var, li: int, B: int, sides, ntok, R, N6) -> Var:
     n = _ln(M, G, X, name + ".norm1")
     if M.br_ch_att_list[li - 1]:
         tx1 = _channel_att(M, G, n, X, name + ".attn", B, ntok, R, N6)
+        tx = _ln(M, G, tx1, name + ".norm2", out=G.new(B * N6, 64, covered=True))    # gradient = the four MixFFN input gradients, row group by row group
     else:
-        tx1 = _self_att(M, G, n, X, name + ".attn", B, sides, ntok, R, N6)
-    tx = _ln(M, G, tx1, name + ".norm2", out=G.new(B * N6, 64, covered=True))    # gradient = the four MixFFN input gradients, row group by row group
+        tx1, tx = _self_att(M, G, n, X, name + ".attn", B, sides, ntok, R, N6, ln=(name + ".norm2", 1e-5))
     tx2 = G.new(B * N6, 64)
     geo = [(B * sides[s] * sides[s], 64 * MULT[s]) for s in range(4)]
     view = lambda v, s: v.rowslice(R[s], R[s + 1]).reshape(*geo[s])
