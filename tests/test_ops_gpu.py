@@ -742,6 +742,30 @@ def test_dwconv_layernorm_bf16(Gb):
     closeb(bp.grad, br.grad, what="dw db")
 
 
+@pytest.mark.parametrize("rows,C,residual", [(37, 64, False), (3136, 128, True), (50176, 64, True), (150001, 64, False), (6000, 256, True),
+                                             (1111, 512, False), (784, 320, True)])
+def test_layernorm_16bit(Gb, rows, C, residual):
+    """LayerNorm forward / backward on 16-bit storage against torch fp32 on the rounded operands: C = 64 / 128 / 256 / 512 take the
+    eight-channels-per-lane backward (ln_bwd_v8_kernel: 1, 2 or 4 rows per lane group in flight by size, ragged tails), C = 320 the 4-wide one;
+    `residual`: the normalised tensor also feeds a skip branch whose gradient the backward adds on top of (in-place accumulation)."""
+    x, g, b = _bf(T(f"l16.x{rows}", (rows, C), 2.0)), _bf(T(f"l16.g{C}", (C,)) * 0.2 + 1), _bf(T(f"l16.b{C}", (C,), 0.3))
+    gy, gr_ = _bf(T(f"l16.gy{rows}", (rows, C))), _bf(T(f"l16.gr{rows}", (rows, C)))
+    xr, gr, br = x.float().requires_grad_(), g.float().requires_grad_(), b.float().requires_grad_()
+    y = F.layer_norm(xr, (C,), gr, br, 1e-5)
+    y.backward(gy.float())
+    want_dx = xr.grad + (gr_.float() if residual else 0)
+    xv, gp, bp = mkV(Gb, x), mkPb(g.float()), mkPb(b.float())
+    out = Gb.layernorm(xv, gp, bp, 1e-5)
+    closeb(out.data, y, what="y")
+    if residual:                                           # the skip branch arrived first: LayerNorm's backward accumulates
+        xv.root.grad_t = gr_.to(DEV).contiguous()
+        xv.root.whole_written = True
+    run_bwd(Gb, out, gy)
+    closeb(Gb.grad_of(xv), want_dx, what="dx")
+    closeb(gp.grad, gr.grad, 2e-2, "dgamma")
+    closeb(bp.grad, br.grad, 2e-2, "dbeta")
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_attention_segmented(dtype):
     """Stage-major queries (segments of B images each) against image-major K/V: one launch on the bf16 path."""

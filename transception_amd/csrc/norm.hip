@@ -111,6 +111,62 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, in
     }
 }
 
+// The parameter-gradient tail of the LayerNorm backward kernels: the workgroup's per-lane-group column sums (red[RPB][2][C], filled by the
+// caller) are added up and leave as atomics, as a parked partial row (defer: ln_fold_kernel adds them, one launch per backward leg), or
+// through the two-level fold below.
+template <int RPB>
+__device__ __forceinline__ void ln_bwd_param_tail(const float* red, const int C, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                  float* __restrict__ partial, int* __restrict__ cnt, const int defer) {
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a = 0.f, bb = 0.f;
+#pragma unroll
+        for (int w = 0; w < RPB; ++w) { a += red[(w * 2 + 0) * C + c]; bb += red[(w * 2 + 1) * C + c]; }
+        if (partial) {                       // parked for the 16-way fold below, or (defer) for ln_fold_kernel: one launch per backward leg
+            float* pp = partial + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 2 * C;
+            if (defer) { pp[c] = a; pp[C + c] = bb; }
+            else {
+                __hip_atomic_store(pp + c, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(pp + C + c, bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+            atomicAdd(dgamma + c, a);
+            atomicAdd(dbeta + c, bb);
+        }
+    }
+    
+    if (!partial || defer) return;
+    // Two-level fold (the GEMM split-K fix-up protocol): LN_FOLD consecutive workgroups share an arrival counter (8 measured best of 2-32: the last arriver reads its group serially); the last to arrive
+    // adds the group's partial rows and is the only one that touches dgamma / dbeta atomically (32 contributors per word instead of
+    // 1024, and no second launch).
+    constexpr int FG = LN_FOLD;
+    const int grp = blockIdx.x / FG, ngrp = (gridDim.x + FG - 1) / FG, gm = min(FG, (int)gridDim.x - grp * FG);
+    __builtin_amdgcn_s_waitcnt(0);                          // vmcnt(0): THIS thread's write-through stores have been acknowledged
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (the barrier alone does not wait for stores in flight)
+    __syncthreads();
+    __shared__ int s_last;
+    if (threadIdx.x == 0) {
+        int* cn = cnt + blockIdx.y * ngrp + grp;
+        const int old = atomicAdd(cn, 1);
+        s_last = (old == gm - 1);
+        if (s_last) atomicExch(cn, 0);
+    }
+    __syncthreads();
+    
+    if (!s_last) return;
+    const float* pg = partial + ((long long)blockIdx.y * gridDim.x + grp * FG) * 2 * C;
+    for (int c = threadIdx.x; c < 2 * C; c += 256) {
+        float tmp[FG];
+#pragma unroll
+        for (int m = 0; m < FG; ++m) tmp[m] = m < gm ? __hip_atomic_load(pg + (long long)m * 2 * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+        float v = 0.f;
+#pragma unroll
+        for (int m = 0; m < FG; ++m) v += tmp[m];
+        atomicAdd((c < C ? dgamma + c : dbeta + (c - C)), v);
+    }
+    
+}
+
 #ifdef TC_LN_TIMING
 // phase stamps of ln_bwd_kernel (experiment builds): every 61st workgroup writes its own row: GS, rows, then cycles of
 // parameter loads / row loop / LDS partials / parked partial + arrival / fold
@@ -220,54 +276,91 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
             r1[0] = ab[i].x; r1[1] = ab[i].y; r1[2] = ab[i].z; r1[3] = ab[i].w;
         }
     }
-    __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float a = 0.f, bb = 0.f;
+    ln_bwd_param_tail<RPB>(red, C, dgamma, dbeta, partial, cnt, defer);
+}
+
+// 16-bit rows of 64 / 128 / 256 / 512 channels: a lane owns EIGHT channels (one 16-byte piece) of a row, GS = C / 8 lanes a row, RPT rows per
+// lane group in flight -- ln_bwd_kernel's 8-byte pieces left 16-32 bytes per lane in flight and ran the 25 MB maps of the last decoder
+// stage at 1.4 TB/s (56 us a launch).  The raw pieces of all RPT rows are requested before the first one is unpacked.  Same arithmetic in the
+// same order per row as ln_bwd_kernel (statistics over the group by the same shuffles), same parameter-gradient tail.
+typedef unsigned lnu4 __attribute__((ext_vector_type(4)));
+template <typename T> __device__ __forceinline__ void ln_unpack8(const lnu4& r, float* o) {
+    unpack2<T>(r.x, o[0], o[1]); unpack2<T>(r.y, o[2], o[3]); unpack2<T>(r.z, o[4], o[5]); unpack2<T>(r.w, o[6], o[7]);
+}
+template <typename T, int GS, int RPT>
+__global__ __launch_bounds__(256) void ln_bwd_v8_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ x, int ldx,
+                                                        const T* __restrict__ gamma, const T* __restrict__ beta,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        T* __restrict__ dx, int lddx, const T* __restrict__ dres, int ldres,
+                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int rows,
+                                                        long long pstride, float* __restrict__ partial, int* __restrict__ cnt, LnMap map, int defer) {
+    constexpr int RPB = 256 / GS, C = GS * 8;
+    extern __shared__ float red[];           // [RPB][2][C]
+    const int gl = threadIdx.x % GS, gi = threadIdx.x / GS;
+    {
+        const long long g = blockIdx.y;
+        dy += g * rows * lddy; x += g * rows * ldx; dx += g * rows * lddx; mean += g * rows; rstd += g * rows;
+        if (dres) dres += g * rows * ldres;
+        gamma += g * pstride; beta += g * pstride;
+        if (dgamma) { dgamma += g * pstride; dbeta += g * pstride; }
+    }
+    float g[8], ag[8], ab[8];
+    ln_unpack8<T>(*reinterpret_cast<const lnu4*>(gamma + gl * 8), g);
 #pragma unroll
-        for (int w = 0; w < RPB; ++w) { a += red[(w * 2 + 0) * C + c]; bb += red[(w * 2 + 1) * C + c]; }
-        if (partial) {                       // parked for the 16-way fold below, or (defer) for ln_fold_kernel: one launch per backward leg
-            float* pp = partial + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 2 * C;
-            if (defer) { pp[c] = a; pp[C + c] = bb; }
-            else {
-                __hip_atomic_store(pp + c, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(pp + C + c, bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int j = 0; j < 8; ++j) ag[j] = ab[j] = 0.f;
+    constexpr float invC = 1.0f / (float)C;
+    const bool has_res = dres != nullptr;
+    for (int row0 = (blockIdx.x * RPB + gi) * RPT; row0 < rows; row0 += gridDim.x * RPB * RPT) {
+        lnu4 rx[RPT], rd[RPT], rr[RPT];
+        float mu[RPT], rs[RPT];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const int row = min(row0 + r, rows - 1);
+            rx[r] = *reinterpret_cast<const lnu4*>(x + ln_row_off(row, map, ldx, C) + gl * 8);
+            rd[r] = *reinterpret_cast<const lnu4*>(dy + (long long)row * lddy + gl * 8);
+            if (has_res) rr[r] = *reinterpret_cast<const lnu4*>(dres + ln_row_off(row, map, ldres, C) + gl * 8);
+            mu[r] = mean[row]; rs[r] = rstd[row];
+        }
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const bool live = row0 + r < rows;
+            float xv[8], d[8];
+            ln_unpack8<T>(rx[r], xv); ln_unpack8<T>(rd[r], d);
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xv[j] = (xv[j] - mu[r]) * rs[r];
+            if (dgamma && live) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { ag[j] += d[j] * xv[j]; ab[j] += d[j]; }
             }
-        } else {
-            atomicAdd(dgamma + c, a);
-            atomicAdd(dbeta + c, bb);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[j] *= g[j];
+            // (the 4-wide kernel's order: a lane adds its four values of a piece, pieces in turn)
+            s1 = ((d[0] + d[1]) + d[2]) + d[3]; s1 += ((d[4] + d[5]) + d[6]) + d[7];
+            s2 = ((d[0] * xv[0] + d[1] * xv[1]) + d[2] * xv[2]) + d[3] * xv[3]; s2 += ((d[4] * xv[4] + d[5] * xv[5]) + d[6] * xv[6]) + d[7] * xv[7];
+            s1 = group_sum<GS>(s1) * invC; s2 = group_sum<GS>(s2) * invC;
+            if (!live) continue;
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = rs[r] * (d[j] - s1 - xv[j] * s2);
+            if (has_res) {
+                float q[8];
+                ln_unpack8<T>(rr[r], q);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] += q[j];
+            }
+            lnu4 w;
+            w.x = pack2<T>(o[0], o[1]); w.y = pack2<T>(o[2], o[3]); w.z = pack2<T>(o[4], o[5]); w.w = pack2<T>(o[6], o[7]);
+            *reinterpret_cast<lnu4*>(dx + ln_row_off(row0 + r, map, lddx, C) + gl * 8) = w;
         }
     }
-    LSTAMP(2);
-    if (!partial || defer) return;
-    // Two-level fold (the GEMM split-K fix-up protocol): LN_FOLD consecutive workgroups share an arrival counter (8 measured best of 2-32: the last arriver reads its group serially); the last to arrive
-    // adds the group's partial rows and is the only one that touches dgamma / dbeta atomically (32 contributors per word instead of
-    // 1024, and no second launch).
-    constexpr int FG = LN_FOLD;
-    const int grp = blockIdx.x / FG, ngrp = (gridDim.x + FG - 1) / FG, gm = min(FG, (int)gridDim.x - grp * FG);
-    __builtin_amdgcn_s_waitcnt(0);                          // vmcnt(0): THIS thread's write-through stores have been acknowledged
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (the barrier alone does not wait for stores in flight)
-    __syncthreads();
-    __shared__ int s_last;
-    if (threadIdx.x == 0) {
-        int* cn = cnt + blockIdx.y * ngrp + grp;
-        const int old = atomicAdd(cn, 1);
-        s_last = (old == gm - 1);
-        if (s_last) atomicExch(cn, 0);
-    }
-    __syncthreads();
-    LSTAMP(3);
-    if (!s_last) return;
-    const float* pg = partial + ((long long)blockIdx.y * gridDim.x + grp * FG) * 2 * C;
-    for (int c = threadIdx.x; c < 2 * C; c += 256) {
-        float tmp[FG];
+    if (!dgamma) return;
 #pragma unroll
-        for (int m = 0; m < FG; ++m) tmp[m] = m < gm ? __hip_atomic_load(pg + (long long)m * 2 * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
-        float v = 0.f;
-#pragma unroll
-        for (int m = 0; m < FG; ++m) v += tmp[m];
-        atomicAdd((c < C ? dgamma + c : dbeta + (c - C)), v);
+    for (int j = 0; j < 8; ++j) {
+        red[(gi * 2 + 0) * C + gl * 8 + j] = ag[j];
+        red[(gi * 2 + 1) * C + gl * 8 + j] = ab[j];
     }
-    LSTAMP(4);
+    ln_bwd_param_tail<RPB>(red, C, dgamma, dbeta, partial, cnt, defer);
 }
 
 // dgamma[c] += sum_rows dz * xhat ; dbeta[c] += sum_rows dz   as a column reduction (thread = 4 channels x row lane): fully
@@ -628,6 +721,30 @@ static int ln_bwd_impl(const void* dy, int lddy, const void* x, int ldx, const v
     }
     int nblk = 0;
     float* partial = nullptr;
+    {   // 16-bit rows of 64 / 128 / 256 / 512 channels, every row piece 16-byte aligned: eight channels per lane (ln_bwd_v8_kernel)
+        static const int v8_on = getenv("TC_LN_BWD_V8") ? atoi(getenv("TC_LN_BWD_V8")) : 1;
+        const bool al = !((lddy | ldx | lddx | (dres ? ldres : 0)) & 7) && !(pstride & 7) &&
+                        !(((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)gamma | (dres ? (uintptr_t)dres : 0)) & 15);
+        if (v8_on && (dtype == TC_BF16 || dtype == TC_F16) && act == TC_ACT_NONE && al && (C == 64 || C == 128 || C == 256 || C == 512)) {
+            nblk = ln_bwd_nblk(rows, C, dgamma != nullptr, defer_part != nullptr);
+            partial = defer_part ? defer_part :
+                      (dgamma && scratch && (uintptr_t)scratch % 16 == 0 && scratch_floats >= 4096 + (long long)groups * nblk * 2 * C &&
+                       (long long)groups * ((nblk + LN_FOLD - 1) / LN_FOLD) <= 4096) ? scratch + 4096 : nullptr;
+            const long long rpi = (long long)nblk * (2048 / C);           // rows the grid takes per iteration with one row per lane group
+            const int rpt = rows >= 4 * rpi ? 4 : (rows >= 2 * rpi ? 2 : 1);
+#define TC_LNB8(T_, GS_, RPT_)                                                                                                             \
+            hipLaunchKernelGGL((ln_bwd_v8_kernel<T_, GS_, RPT_>), dim3(nblk, groups), dim3(256), (size_t)(256 / GS_) * 2 * C * sizeof(float), s,   \
+                               (const T_*)dy, lddy, (const T_*)x, ldx, (const T_*)gamma, (const T_*)beta, mean, rstd, (T_*)dx, lddx,            \
+                               (const T_*)dres, ldres, dgamma, dbeta, rows, pstride, partial, reinterpret_cast<int*>(scratch), map, defer_part ? 1 : 0)
+#define TC_LNB8_R(T_, GS_) { if (rpt == 4) TC_LNB8(T_, GS_, 4); else if (rpt == 2) TC_LNB8(T_, GS_, 2); else TC_LNB8(T_, GS_, 1); }
+#define TC_LNB8_C(T_) { if (C == 64) TC_LNB8_R(T_, 8) else if (C == 128) TC_LNB8_R(T_, 16) else if (C == 256) TC_LNB8_R(T_, 32) else TC_LNB8_R(T_, 64) }
+            if (dtype == TC_BF16) TC_LNB8_C(bf16_t) else TC_LNB8_C(f16_t)
+#undef TC_LNB8_C
+#undef TC_LNB8_R
+#undef TC_LNB8
+            return tc_launch_status();
+        }
+    }
 #define TC_LNB_LAUNCH(GS, NV, RPT)                                                                                                        \
         hipLaunchKernelGGL((ln_bwd_kernel<T, GS, NV, RPT>), dim3(nblk, groups), dim3(256),                                                  \
                                           (size_t)(256 / GS) * 2 * C * sizeof(float), s, (const T*)dy, lddy, (const T*)x, ldx,            \
