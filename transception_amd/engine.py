@@ -646,7 +646,7 @@ class Graph:
                 return
             dz = dy
             if act == ACT_SIGMOID:
-                assert dy.is_contiguous() and out.data.is_contiguous() and nb == 1
+                assert dy.is_contiguous() and out.data.is_contiguous() and (nb == 1 or (grouped and not side_by_side))
                 dz = torch.empty_like(dy)
                 self.L.tc_sigmoid_bwd(_ptr(dy), _ptr(out.data), _ptr(dz), dy.numel(), self.dt, self.stream)
             want_db = b is not None and b.grad is not None

@@ -626,6 +626,24 @@ def _lin(M: MSTransception, G: Graph, name: str, bias: bool = True):
     return W, b
 
 
+_PAIR_GROUPED = os.environ.get("TC_PAIR_GROUPED", "1") != "0"       # A/B switch of _lin_pair
+
+
+def _lin_pair(M: MSTransception, G: Graph, a: str, b: str):
+    """(W, bias, stride) of two same-shaped Linear / 1x1 layers as TWO WEIGHT GROUPS of one launch (Graph.grouped(2, stride)) -- or None when
+    their parameters do not sit at one constant, 16-byte-aligned distance in the flat arenas."""
+    (oa, sa), (ob, sb) = M._index[a + ".weight"], M._index[b + ".weight"]
+    (ba, sba), (bb, sbb) = M._index[a + ".bias"], M._index[b + ".bias"]
+    stride = ob - oa
+    if sa != sb or sba != sbb or bb - ba != stride or stride <= 0 or stride % 8 or oa % 8 or ba % 8 or not _PAIR_GROUPED:
+        return None
+    W, bias = _lin(M, G, a)
+    if G.record:
+        for nm in (b + ".weight", b + ".bias"):
+            M._used_views[M._pid[nm]] = M._index[nm]
+    return P(W.data, W.grad, stride), P(bias.data, bias.grad, stride), stride
+
+
 def _ln(M, G, x, name, eps=1e-5, act=ACT_NONE, out=None):
     return G.layernorm(x, M._P(G, name + ".weight"), M._P(G, name + ".bias"), eps, act, out)
 
@@ -807,8 +825,13 @@ def _coord_att(M, G, x: Var, name: str, B: int, side: int, out: Var) -> Var:
     y = _bn(M, G, y, name + ".bn1", ACT_COORD)
     att = G.new(2 * B * side, x.cols)
     half = B * side
-    G.linear(y.rowslice(0, half), *_lin(M, G, name + ".conv_h"), out=att.rowslice(0, half), act=ACT_SIGMOID)
-    G.linear(y.rowslice(half, 2 * half), *_lin(M, G, name + ".conv_w"), out=att.rowslice(half, 2 * half), act=ACT_SIGMOID)
+    pair = _lin_pair(M, G, name + ".conv_h", name + ".conv_w")
+    if pair is not None:                                  # the two gate convolutions: one launch, two weight groups (rows [0, half) / [half, 2 half))
+        with G.grouped(2, pair[2]):
+            G.linear(y, pair[0], pair[1], out=att, act=ACT_SIGMOID)
+    else:
+        G.linear(y.rowslice(0, half), *_lin(M, G, name + ".conv_h"), out=att.rowslice(0, half), act=ACT_SIGMOID)
+        G.linear(y.rowslice(half, 2 * half), *_lin(M, G, name + ".conv_w"), out=att.rowslice(half, 2 * half), act=ACT_SIGMOID)
     gated = G.coord_gate(x, att, B, side, side)
     return G.linear(gated, *_lin(M, G, name + ".conv_in_out"), out=out)
 
