@@ -44,7 +44,7 @@ class TransCeptionOracle:
 
     def __init__(self, params: Dict[str, Tensor], num_classes: int = 9, training: bool = True, concat: str = "coord",
                  have_bridge: str = "original", br_ch_att_list=(True, False, False, False), use_sa_config: int = 1, sa_ker: int = 7,
-                 Stage_3or4: int = 3, inter: str = "res"):
+                 Stage_3or4: int = 3, inter: str = "res", token_mlp_mode: str = "mix_skip"):
         self.P = params
         self.num_classes = num_classes
         self.training = training
@@ -52,6 +52,10 @@ class TransCeptionOracle:
         # stage (:1384-1403), whether the bridge runs (:2840) and which bridge layers use channel attention (:2413-2420)
         assert concat in ("coord", "normal", "se", "3d", "skn", "cbam", "cam", "cam_fact") and have_bridge != "sp" and len(br_ch_att_list) == 4
         assert Stage_3or4 != 4
+        # token_mlp of the EfficientTransformerBlocks (stage 1 and the decoder, MSTr.py:157-162): "mix_skip" (default) | "mix" (MixFFN, :35-46).  Any
+        # other value builds MLP_FFN (:63-77), whose forward(x) the block calls with (x, H, W): the reference raises there, nothing to follow.
+        assert token_mlp_mode in ("mix_skip", "mix")
+        self.token_mlp_mode = token_mlp_mode
         self.inter = "out"                      # CBAMBlock: the spatial attention reads the gated concatenation
         if Stage_3or4 != 3:
             # MSViT_casa (MSTr.py:2788-2791, 1990-2207): MSViT with MHCA_stage_casa (:1443-1534), which has no CoordAtt branch -- "coord" (any name it
@@ -130,10 +134,19 @@ class TransCeptionOracle:
         a = F.gelu(self.layernorm(d, name + ".norm1"))
         return self.linear(a, name + ".fc2")
 
+    def mixffn(self, t: Tensor, name: str, H: int, W: int) -> Tensor:
+        """MixFFN, MSTr.py:35-46: fc2(GELU(dw3x3(fc1(x)))) -- no skip around the convolution, no LayerNorm."""
+        B, N, _ = t.shape
+        h = self.linear(t, name + ".fc1")
+        C4 = h.shape[-1]
+        d = self.dwconv_map(h.reshape(B, H, W, C4), name + ".dwconv.dwconv", 3).reshape(B, N, C4)
+        return self.linear(F.gelu(d), name + ".fc2")
+
     def efficient_block(self, t: Tensor, name: str, H: int, W: int) -> Tensor:
         """EfficientTransformerBlock, MSTr.py:164-173."""
         tx = t + self.efficient_attention(self.layernorm(t, name + ".norm1"), name + ".attn")
-        return tx + self.mixffn_skip(self.layernorm(tx, name + ".norm2"), name + ".mlp", H, W)
+        mlp = self.mixffn_skip if self.token_mlp_mode == "mix_skip" else self.mixffn
+        return tx + mlp(self.layernorm(tx, name + ".norm2"), name + ".mlp", H, W)
 
     # ------------------------------------------------------------------ RIPM
     def dwconv2d_bn(self, x: Tensor, name: str, stride: int) -> Tensor:

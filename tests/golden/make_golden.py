@@ -275,6 +275,10 @@ VARIANTS = {   # name -> (constructor kwargs, gradient probes)
     "stage5_cbam_res": (dict(Stage_3or4=5, concat="cbam", inter="res"),
                         ["backbone.mhca_stage2.aggregate.sa.conv.weight", "backbone.mhca_stage3.aggregate.sa.conv.bias", "backbone.mhca_stage3.aggregate.ca.se.0.weight",
                          "backbone.mhca_stage2.InvRes.conv2.conv.weight", "backbone.mhca_stage2.aggregate.conv2d_bn_act.1.weight", "decoder_0.last_layer.weight"]),
+    "token_mlp_mix": (dict(token_mlp_mode="mix"),
+                      ["backbone.block1.0.mlp.fc1.weight", "backbone.block1.1.mlp.dwconv.dwconv.weight", "backbone.block1.1.mlp.dwconv.dwconv.bias",
+                       "decoder_2.layer_former_1.mlp.fc2.weight", "decoder_1.layer_former_2.mlp.dwconv.dwconv.weight", "decoder_0.layer_former_1.mlp.fc1.bias",
+                       "backbone.mhca_stage3.mhca_blks.0.MHCA_layers.0.mlp.norm1.weight", "decoder_0.last_layer.weight"]),
     "bridge_para": (dict(have_bridge="para"),
                     ["backbone.mhca_stage3.aggregate.conv1.weight", "bridge.bridge_layer1.attn.q.weight", "bridge.bridge_layer2.attn.kv.weight",
                      "bridge.proj_act.0.weight", "bridge.proj_act.0.bias", "bridge.proj_act.1.weight", "bridge.bridge_layer3.mixffn4.fc2.weight",
@@ -303,9 +307,15 @@ class _nothing:
     def __exit__(self, *a): pass
 
 
-def variants(MST, Dice):
+def variants(MST, Dice, only=()):
+    """only: names to (re)generate -- the other entries of the committed file are kept as they are."""
     out = {}
+    if only:
+        with np.load(os.path.join(HERE, "variants.npz")) as old:
+            out = {k: old[k] for k in old.files if k.split("/")[0] not in only}
     for name, (kw, probes) in VARIANTS.items():
+        if only and name not in only:
+            continue
         factorized = kw.get("concat") == "cam_fact" or (kw.get("Stage_3or4", 3) == 5 and kw.get("concat", "coord") not in ("normal", "3d", "se", "skn", "cbam", "cam"))
         with (dense_batchnorm3d_input() if factorized else _nothing()):
             _variant(out, name, kw, probes, MST, Dice)
@@ -345,7 +355,8 @@ def _variant(out, name, kw, probes, MST, Dice):
 if __name__ == "__main__":
     torch.set_num_threads(8)
     MST, Dice = import_reference()
-    which = sys.argv[1:] or ["model", "trace", "modules", "variants"]
+    which = [a for a in sys.argv[1:] if not a.startswith("variant=")] or ["model", "trace", "modules", "variants"]
+    only_variants = tuple(a[len("variant="):] for a in sys.argv[1:] if a.startswith("variant="))      # e.g.  variants variant=token_mlp_mix
     if "model" in which:
         whole_model(MST, Dice)
     if "trace" in which:
@@ -353,7 +364,7 @@ if __name__ == "__main__":
     if "modules" in which:
         modules(MST)
     if "variants" in which:
-        variants(MST, Dice)
+        variants(MST, Dice, only_variants)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -89,6 +89,15 @@ def _mk_mixffn_skip(c1: int, c2: int) -> nn.Module:              # MSTr.py:889-8
     return m
 
 
+def _mk_mixffn(c1: int, c2: int) -> nn.Module:                   # MSTr.py:35-41
+    m = nn.Module()
+    m.fc1 = nn.Linear(c1, c2)
+    m.dwconv = nn.Module()
+    m.dwconv.dwconv = nn.Conv2d(c2, c2, 3, 1, 1, groups=c2)
+    m.fc2 = nn.Linear(c2, c1)
+    return m
+
+
 def _mk_mhca_encoder(dim: int, layers: int) -> nn.Module:        # MSTr.py:949-978
     m = nn.Module()
     m.cpe = nn.Module()
@@ -200,7 +209,7 @@ def _mk_mhca_stage(dim: int, out_dim: int, layers: int, concat: str = "coord", u
     return m
 
 
-def _mk_eff_block(dim: int) -> nn.Module:                        # MSTr.py:146-162, 95-103
+def _mk_eff_block(dim: int, token_mlp: str = "mix_skip") -> nn.Module:                        # MSTr.py:146-162, 95-103
     m = nn.Module()
     m.norm1 = nn.LayerNorm(dim)
     m.attn = nn.Module()
@@ -209,7 +218,7 @@ def _mk_eff_block(dim: int) -> nn.Module:                        # MSTr.py:146-1
     m.attn.values = nn.Conv2d(dim, dim, 1)
     m.attn.reprojection = nn.Conv2d(dim, dim, 1)
     m.norm2 = nn.LayerNorm(dim)
-    m.mlp = _mk_mixffn_skip(dim, dim * 4)
+    m.mlp = _mk_mixffn_skip(dim, dim * 4) if token_mlp == "mix_skip" else _mk_mixffn(dim, dim * 4)
     return m
 
 
@@ -245,7 +254,7 @@ def _mk_bridge_layer(dim: int, ch_att: bool) -> nn.Module:       # MSTr.py:2356-
     return m
 
 
-def _mk_decoder_layer(in_out_chan, n_class: int, is_last: bool) -> nn.Module:   # MSTr.py:230-269
+def _mk_decoder_layer(in_out_chan, n_class: int, is_last: bool, token_mlp: str = "mix_skip") -> nn.Module:   # MSTr.py:230-269
     dims, out_dim = in_out_chan[0], in_out_chan[1]
     m = nn.Module()
     m.concat_linear = nn.Linear(dims * (4 if is_last else 2), out_dim)
@@ -257,8 +266,8 @@ def _mk_decoder_layer(in_out_chan, n_class: int, is_last: bool) -> nn.Module:   
         m.layer_up.expand = nn.Linear(out_dim, 16 * out_dim, bias=False)
         m.layer_up.norm = nn.LayerNorm(out_dim)
         m.last_layer = nn.Conv2d(out_dim, n_class, 1)
-    m.layer_former_1 = _mk_eff_block(out_dim)
-    m.layer_former_2 = _mk_eff_block(out_dim)
+    m.layer_former_1 = _mk_eff_block(out_dim, token_mlp)
+    m.layer_former_2 = _mk_eff_block(out_dim, token_mlp)
     for sub in m.modules():                 # MSTr.py:255-269
         if isinstance(sub, (nn.Linear, nn.Conv2d)):
             nn.init.xavier_uniform_(sub.weight)
@@ -270,7 +279,7 @@ def _mk_decoder_layer(in_out_chan, n_class: int, is_last: bool) -> nn.Module:   
     return m
 
 
-def _mk_backbone(concat: str = "coord", use_sa_list=(True, True, False), sa_ker: int = 7) -> nn.Module:             # MSTr.py:1536-1671
+def _mk_backbone(concat: str = "coord", use_sa_list=(True, True, False), sa_ker: int = 7, token_mlp: str = "mix_skip") -> nn.Module:   # MSTr.py:1536-1671
     m = nn.Module()
     for i, d in enumerate(DIMS):
         setattr(m, f"conv1_1_s{i + 1}", nn.Conv2d(3 * d, d, 1))     # dead parameters, kept for the schema
@@ -285,7 +294,7 @@ def _mk_backbone(concat: str = "coord", use_sa_list=(True, True, False), sa_ker:
     m.patch_embed1.norm = nn.LayerNorm(DIMS[0])
     m.cpe = nn.Module()
     m.cpe.proj = nn.Conv2d(DIMS[0], DIMS[0], 3, 1, 1, groups=DIMS[0])   # dead
-    m.block1 = nn.ModuleList([_mk_eff_block(DIMS[0]) for _ in range(2)])
+    m.block1 = nn.ModuleList([_mk_eff_block(DIMS[0], token_mlp) for _ in range(2)])
     m.norm1 = nn.LayerNorm(DIMS[0])
     return m
 
@@ -330,13 +339,15 @@ class MSTransception(nn.Module):
         #                  CAM_Factorized_Module, i.e. what concat = "cam_fact" builds; concat = "cbam" builds CBAMBlock_casa, :1213-1257, whose
         #                  spatial attention reads the ResBlock branch alone when inter = "res", the gated concatenation when inter = "out", and is
         #                  skipped for any other inter)
-        # the reference.  Not built: have_bridge = sp, Stage_3or4 = 4 (MSViT_4Stages),
-        # token_mlp_mode != "mix_skip", and the legacy networks/Transception.py class.
+        #   token_mlp_mode  "mix_skip" (default) | "mix": the EfficientTransformerBlocks of stage 1 and of the decoder use MixFFN (MSTr.py:35-46: no skip
+        #                  around the depthwise convolution, no LayerNorm) instead of MixFFN_skip; the MB blocks and the bridge keep MixFFN_skip.  Any other
+        #                  value builds MLP_FFN (:63-77), whose forward(x) the block calls with (x, H, W): the reference raises a TypeError there.
+        # the reference.  Not built: have_bridge = sp, Stage_3or4 = 4 (MSViT_4Stages), and the legacy networks/Transception.py class.
         br = [bool(b) for b in br_ch_att_list]
-        if (token_mlp_mode != "mix_skip" or concat not in ("coord", "normal", "se", "3d", "skn", "cbam", "cam", "cam_fact") or have_bridge == "sp" or Stage_3or4 == 4
+        if (token_mlp_mode not in ("mix_skip", "mix") or concat not in ("coord", "normal", "se", "3d", "skn", "cbam", "cam", "cam_fact") or have_bridge == "sp" or Stage_3or4 == 4
                 or len(br) != 4):
             raise NotImplementedError("MSTransception: implemented are every concat of the reference ('coord', 'normal', 'se', '3d', 'skn', 'cbam', 'cam', 'cam_fact'), have_bridge in {'original', "
-                                      "'None', 'para'}, any 4-entry br_ch_att_list, Stage_3or4 in {3, 5}, token_mlp_mode = 'mix_skip'")
+                                      "'None', 'para'}, any 4-entry br_ch_att_list, Stage_3or4 in {3, 5}, token_mlp_mode in {'mix_skip', 'mix'}")
         self.inter = "out"                              # CBAMBlock (Stage_3or4 = 3) gates with the statistics of the gated concatenation
         if Stage_3or4 != 3:                             # MSViT_casa (MSTr.py:2788-2791: the else branch of 4 / 3)
             if concat not in ("normal", "3d", "se", "skn", "cbam", "cam"):
@@ -350,7 +361,8 @@ class MSTransception(nn.Module):
         use_sa_list = {1: (True, True, False), 2: (True, False, False), 3: (False, False, False), 4: (True, True, True)}.get(use_sa_config, (True, True, True))
         if concat == "cbam" and sa_ker not in (3, 7):
             raise NotImplementedError("MSTransception(concat='cbam'): sa_ker must be 3 or 7")
-        self.backbone = _mk_backbone(concat, use_sa_list, sa_ker)
+        self.token_mlp_mode = token_mlp_mode
+        self.backbone = _mk_backbone(concat, use_sa_list, sa_ker, token_mlp_mode)
         self.Stage_3or4 = Stage_3or4
         self.bridge = nn.Module()
         if have_bridge == "para":                       # constructor order of BridgeBlock_para: layers 1, 2, proj_act, layers 3, 4
@@ -363,10 +375,10 @@ class MSTransception(nn.Module):
             for i, ch in enumerate(br):
                 setattr(self.bridge, f"bridge_layer{i + 1}", _mk_bridge_layer(64, ch))
         ioc = [[32, 64, 64, 64], [144, 128, 128, 128], [288, 320, 320, 320], [512, 512, 512, 512]]
-        self.decoder_3 = _mk_decoder_layer(ioc[3], num_classes, False)
-        self.decoder_2 = _mk_decoder_layer(ioc[2], num_classes, False)
-        self.decoder_1 = _mk_decoder_layer(ioc[1], num_classes, False)
-        self.decoder_0 = _mk_decoder_layer(ioc[0], num_classes, True)
+        self.decoder_3 = _mk_decoder_layer(ioc[3], num_classes, False, token_mlp_mode)
+        self.decoder_2 = _mk_decoder_layer(ioc[2], num_classes, False, token_mlp_mode)
+        self.decoder_1 = _mk_decoder_layer(ioc[1], num_classes, False, token_mlp_mode)
+        self.decoder_0 = _mk_decoder_layer(ioc[0], num_classes, True, token_mlp_mode)
         self.compute_dtype = torch.float32
         self.use_fused_attention = True
         self.capture_taps = False          # tests: keep copies of the stage outputs of the next forward in self.taps (fp32, reference layouts)
@@ -683,6 +695,13 @@ def _mixffn(M, G, x, name, B, H, W, residual, out=None, pre_ln=None):
     return G.linear(a, *_lin(M, G, name + ".fc2"), out=out, residual=residual)
 
 
+def _mixffn_plain(M, G, x, name, B, H, W, residual):
+    """MixFFN (token_mlp_mode = "mix"), MSTr.py:35-46: fc2(GELU(dw3x3(fc1(x)))) + residual -- an ablation variant, run op by op."""
+    h = G.linear(x, *_lin(M, G, name + ".fc1"))
+    d = G.dwconv(h, M._P(G, name + ".dwconv.dwconv.weight"), M._P(G, name + ".dwconv.dwconv.bias"), B, H, W, 3, 1, False)
+    return G.linear(G.gelu(d), *_lin(M, G, name + ".fc2"), residual=residual)
+
+
 def _eff_attention(M, G, n1: Var, name: str, B: int, N: int, residual: Optional[Var] = None, ln=None):
     """EfficientAttention with one head, MSTr.py:106-143 (Appendix C.6), + the block's residual add.  Returns (tx, LayerNorm(tx) | None):
     ln = (norm name, eps) asks for the block's norm2 from the same launch as `reprojection` (_proj_ln)."""
@@ -713,8 +732,12 @@ def _eff_block(M, G, t: Var, name: str, B: int, H: int, W: int) -> Var:
            _lin(M, G, a + ".values"), _lin(M, G, a + ".reprojection"))
     if G.effatt_supported(t, tuple(p for pair in blk for p in pair)):
         tx = G.eff_attention_block(t, *blk, B, H * W)
+        if M.token_mlp_mode == "mix":
+            return _mixffn_plain(M, G, _ln(M, G, tx, name + ".norm2"), name + ".mlp", B, H, W, residual=tx)
         return _mixffn(M, G, tx, name + ".mlp", B, H, W, residual=tx, pre_ln=(name + ".norm2", 1e-5))
     tx, n2 = _eff_attention(M, G, _ln(M, G, t, name + ".norm1"), name + ".attn", B, H * W, residual=t, ln=(name + ".norm2", 1e-5))
+    if M.token_mlp_mode == "mix":
+        return _mixffn_plain(M, G, n2, name + ".mlp", B, H, W, residual=tx)
     return _mixffn(M, G, n2, name + ".mlp", B, H, W, residual=tx)
 
 
