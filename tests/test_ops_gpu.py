@@ -742,6 +742,35 @@ def test_dwconv_layernorm_bf16(Gb):
     closeb(bp.grad, br.grad, what="dw db")
 
 
+@pytest.mark.parametrize("rows,C,act,prior", [(224, 40, ACT_COORD, False), (896, 8, ACT_COORD, False), (1568, 128, ACT_HSWISH, True), (3136, 128, ACT_HSWISH, False),
+                                              (784, 320, ACT_NONE, True), (8000, 64, ACT_HSWISH, False), (12544, 64, ACT_HSWISH, True),
+                                              (12544, 60, ACT_NONE, False), (20000, 64, ACT_HSWISH, True)])
+def test_batchnorm_train_16bit(Gb, rows, C, act, prior):
+    """Training-mode BatchNorm (+ Hardswish / the CoordAtt activation) on 16-bit storage against torch fp32 on the rounded operands, at the map
+    sizes of the RIPM / ResBlock / IFF chains; `prior`: the input already carries a gradient the backward adds to."""
+    x = _bf(T(f"bn16.x{rows}.{C}", (rows, C), 1.5) + 0.7)
+    g, b = _bf(T(f"bn16.g{C}", (C,)) * 0.2 + 1), _bf(T(f"bn16.b{C}", (C,), 0.3))
+    rm, rv = T(f"bn16.rm{C}", (C,), 0.1), T(f"bn16.rv{C}", (C,)).abs() + 0.5
+    gy, g0 = _bf(T(f"bn16.gy{rows}.{C}", (rows, C))), _bf(T(f"bn16.g0{rows}.{C}", (rows, C)))
+    xr, gr, br = x.float().requires_grad_(), g.float().requires_grad_(), b.float().requires_grad_()
+    y = F.batch_norm(xr, rm.clone(), rv.clone(), gr, br, True, 0.1, 1e-5)
+    if act == ACT_HSWISH:
+        y = F.hardswish(y)
+    elif act == ACT_COORD:
+        y = y * torch.clamp(F.silu(y + 3) / 6, max=1.0)
+    y.backward(gy.float())
+    xv, gp, bp = mkV(Gb, x), mkPb(g.float()), mkPb(b.float())
+    out = Gb.batchnorm(xv, gp, bp, rm.to(DEV), rv.to(DEV), act)
+    closeb(out.data, y, what="y")
+    if prior:
+        xv.root.grad_t = g0.to(DEV).contiguous()
+        xv.root.whole_written = True
+    run_bwd(Gb, out, gy)
+    closeb(Gb.grad_of(xv), xr.grad + (g0.float() if prior else 0), 2e-2, what="dx")
+    closeb(gp.grad, gr.grad, 2e-2, "dgamma")
+    closeb(bp.grad, br.grad, 2e-2, "dbeta")
+
+
 @pytest.mark.parametrize("rows,C,residual", [(37, 64, False), (3136, 128, True), (50176, 64, True), (150001, 64, False), (6000, 256, True),
                                              (1111, 512, False), (784, 320, True)])
 def test_layernorm_16bit(Gb, rows, C, residual):
