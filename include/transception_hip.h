@@ -605,8 +605,12 @@ enum { TC_AUG_WARP = 1, TC_AUG_LINEAR = 2, TC_AUG_BLUR = 4, TC_AUG_PIECEWISE = 8
  *   (imgaug's SomeOf(random_order=True) applies its augmenters in the drawn order, dataset_synapse.py:84-95): up to three 2-bit codes,
  *   first stage in the low bits, 1 = blur, 2 = contrast, 3 = noise; reserved = 0 means blur -> contrast -> noise.
  *   warp: source (row, col) = (m[2] + m[0] y' + m[1] x', m[5] + m[3] y' + m[4] x') of output pixel (y, x), where (y', x') = (y, x)
- *   plus, with TC_AUG_PIECEWISE, the bilinear interpolation of the 4x4 control-point displacements disp[(gy*4+gx)*2 + {0:dy,1:dx}]
- *   (pixels) spanning the slice; image sampled order 1 (TC_AUG_LINEAR) or order 0, label always order 0, outside -> 0
+ *   plus, with TC_AUG_PIECEWISE, the piecewise-affine displacement of imgaug's PiecewiseAffine = skimage's PiecewiseAffineTransform
+ *   (dataset_synapse.py:93): control points linspace(0, H, 4) x linspace(0, W, 4) moved by disp[(gy*4+gx)*2 + {0:dy,1:dx}] (pixels,
+ *   already clipped into the image as imgaug clips them); every cell of the grid is two triangles -- bit 8 + gy*3 + gx of `flags` set:
+ *   split along the top-right / bottom-left diagonal, clear: top-left / bottom-right (the host takes this from the Delaunay
+ *   triangulation of the grid, as skimage does) -- and a pixel moves by the barycentric mix of its triangle's three corner displacements;
+ *   image sampled order 1 (TC_AUG_LINEAR) or order 0, label always order 0, outside -> 0
  *   (scipy.ndimage mode='constant': dataset_synapse.py:48-52 rotate, :39-46 rot90/flip; imgaug Affine family :90-94).
  *   blur: Gaussian sigma 1, 9 taps, mirror border (:88).  contrast: center + alpha (v - center) (:89).
  *   noise: v += noise_sigma * N(0,1), counter-based generator keyed by (noise_seed, pixel) (:87). */

@@ -27,9 +27,10 @@ Pinning:
     every geometric one with its own order-1 resampling of the image (order 0 for the segmentation map) and cval 0
     (`Affine(order=1, cval=0, mode="constant")` defaults -> cv2.warpAffine INTER_LINEAR / BORDER_CONSTANT); transforms are taken
     about the pixel-centre midpoint ((w - 1) / 2, (h - 1) / 2) (imgaug's `_AffineMatrixGenerator`: shift = size / 2 - 0.5); the
-    flips are array flips (exact).  What is NOT restated: cv2.warpAffine's fixed-point source coordinates (interpolation tables
-    of 1/32 pixel) and skimage's per-triangle `PiecewiseAffineTransform` (here: bilinear interpolation of the 4x4 control-point
-    displacements).
+    flips are array flips (exact); PiecewiseAffine is skimage's per-triangle `PiecewiseAffineTransform` over the Delaunay triangulation
+    of imgaug's control grid (`piecewise_source`).  What is NOT restated: cv2.warpAffine's fixed-point source coordinates
+    (interpolation tables of 1/32 pixel); and which diagonal Qhull picks in the (co-circular) cells of the regular grid is whatever
+    THIS image's scipy picks -- the pinned scipy 1.5.4 may pick differently.
 """
 import math
 
@@ -164,20 +165,50 @@ def noise_field(seed: int, h: int, w: int, sigma: float) -> np.ndarray:
     return (np.float32(sigma) * n).reshape(h, w).astype(np.float32)
 
 
-def control_displacement(disp: np.ndarray, h: int, w: int):
-    """Piecewise warp: a 4x4 grid of control-point displacements (pixels) spanning the slice, interpolated bilinearly."""
-    gy = np.arange(h, dtype=np.float64) * (3.0 / (h - 1))
-    gx = np.arange(w, dtype=np.float64) * (3.0 / (w - 1))
-    y0 = np.minimum(np.floor(gy).astype(np.int64), 2)
-    x0 = np.minimum(np.floor(gx).astype(np.int64), 2)
-    fy, fx = (gy - y0)[:, None], (gx - x0)[None, :]
-    d = disp.astype(np.float64).reshape(4, 4, 2)
-    out = []
-    for k in range(2):
-        g = d[..., k]
-        out.append((1 - fy) * (1 - fx) * g[y0][:, x0] + (1 - fy) * fx * g[y0][:, x0 + 1]
-                   + fy * (1 - fx) * g[y0 + 1][:, x0] + fy * fx * g[y0 + 1][:, x0 + 1])
-    return out[0], out[1]
+def piecewise_grid(h: int, w: int, nb_rows: int = 4, nb_cols: int = 4) -> np.ndarray:
+    """Control points of imgaug 0.4.0's PiecewiseAffine (`_get_transformer`): np.linspace(0, h, nb_rows) x np.linspace(0, w, nb_cols), as
+    (row, col) pairs in row-major order -- the grid spans [0, h] x [0, w], one step past the last pixel."""
+    y, x = np.linspace(0, h, nb_rows), np.linspace(0, w, nb_cols)
+    xx, yy = np.meshgrid(x, y)
+    return np.dstack([yy.flat, xx.flat])[0]
+
+
+def piecewise_clip(jitter: np.ndarray, h: int, w: int) -> np.ndarray:
+    """Control-point displacements (row, col) after imgaug's restriction of the moved points to the image plane
+    (`points_dest = clip(points_src + jitter, 0, size - 1)`): what the augmentation records carry."""
+    src = piecewise_grid(h, w)
+    dst = src + np.asarray(jitter, np.float64).reshape(-1, 2)
+    dst[:, 0] = np.clip(dst[:, 0], 0, h - 1)
+    dst[:, 1] = np.clip(dst[:, 1], 0, w - 1)
+    return (dst - src).astype(np.float32)
+
+
+def piecewise_source(disp: np.ndarray, h: int, w: int):
+    """Source coordinates (row, col) of every output pixel under imgaug's PiecewiseAffine with control-point displacements `disp`
+    ([16, 2] (row, col), already clipped): skimage's `PiecewiseAffineTransform.estimate(src, dst)` -- Delaunay triangulation of the SOURCE
+    grid (scipy.spatial, as skimage calls it), one affine map per triangle taking its source corners to its moved corners -- evaluated at
+    the output pixel coordinates as `skimage.transform.warp` does (a pixel outside every triangle maps to -1, i.e. to cval; none is:
+    the grid spans the slice).  Restated from the published algorithm: skimage cannot be imported here."""
+    from scipy import spatial
+    src = piecewise_grid(h, w)
+    dst = src + np.asarray(disp, np.float64).reshape(-1, 2)
+    sxy, dxy = src[:, ::-1], dst[:, ::-1]                             # skimage works in (x, y)
+    tri = spatial.Delaunay(sxy)
+    cols, rows = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+    coords = np.stack([cols.ravel(), rows.ravel()], 1)
+    simplex = tri.find_simplex(coords)
+    out = np.full_like(coords, -1.0)
+    for i, verts in enumerate(tri.simplices):
+        mask = simplex == i
+        if not mask.any():
+            continue
+        M = np.linalg.solve(np.hstack([sxy[verts], np.ones((3, 1))]), dxy[verts])        # [x y 1] M = (x', y') at the three corners
+        out[mask] = np.hstack([coords[mask], np.ones((int(mask.sum()), 1))]) @ M
+    # a map solved from three corners carries ~1e-15 of rounding: on the grid's outer edges (row 0, column 0: the unmoved, clipped corners)
+    # that noise alone would decide between the slice's first row and cval.  Coordinates within 1e-9 of an integer are that integer.
+    near = np.abs(out - np.round(out)) < 1e-9
+    out = np.where(near, np.round(out), out)
+    return out[:, 1].reshape(h, w), out[:, 0].reshape(h, w)
 
 
 def sample_linear(a: np.ndarray, sy: np.ndarray, sx: np.ndarray) -> np.ndarray:
@@ -205,7 +236,7 @@ def sample_nearest(a: np.ndarray, sy: np.ndarray, sx: np.ndarray) -> np.ndarray:
 
 def augment_slice(image: np.ndarray, label: np.ndarray, aug: dict):
     """One slice through the augmentation stage: geometric warp (affine `m` = 2x3 output->source map in (row, col) coordinates,
-    plus the optional 4x4 control-point displacement), then the pixel stages -- Gaussian blur sigma 1, linear contrast
+    plus the optional piecewise-affine warp of a 4x4 control grid, `piecewise_source`), then the pixel stages -- Gaussian blur sigma 1, linear contrast
     center + alpha (v - center), additive Gaussian noise -- in the order `pixel_order` gives (default blur -> contrast -> noise).  `aug` keys: m (6 floats), order (0|1), disp (32 floats or None),
     blur (bool), alpha, center, noise_sigma, noise_seed.  The label is always sampled order 0 and gets no intensity change."""
     if "stages" in aug:                          # a chain of single-augmenter stages, each resampling the previous one's result:
@@ -219,9 +250,7 @@ def augment_slice(image: np.ndarray, label: np.ndarray, aug: dict):
     def source(py, px):
         qy, qx = py, px
         if aug.get("disp") is not None:
-            dy, dx = control_displacement(np.asarray(aug["disp"], np.float32), h, w)
-            iy, ix = py.astype(np.int64), px.astype(np.int64)
-            qy, qx = py + dy[iy, ix], px + dx[iy, ix]
+            qy, qx = piecewise_source(np.asarray(aug["disp"], np.float32), h, w)
         return (m[2] + m[0] * qy) + m[1] * qx, (m[5] + m[3] * qy) + m[4] * qx      # scipy's order: shift first
 
     sy, sx = source(yy, xx)

@@ -122,9 +122,10 @@ def test_augmentation_stage_matches_oracle():
         D.SliceAugmentation(m=D.affine_rotate_xy(33.0, H, W), blur=True, alpha=0.6),
         D.SliceAugmentation(m=D.compose(D.affine_scale(0.7, 1.6, H, W), D.affine_shear(-12.0, H, W))),
         D.SliceAugmentation(m=D.affine_translate(0.15, -0.1, H, W), order=0),
-        D.SliceAugmentation(disp=(np.random.default_rng(4).normal(0, 1, (4, 4, 2)) * 3.0).astype(np.float32)),
-        D.SliceAugmentation(m=D.affine_flip(0, H, W), disp=(np.random.default_rng(5).normal(0, 1, (4, 4, 2)) * 2.0).astype(np.float32),
-                            blur=True, alpha=1.2, noise_sigma=0.3, noise_seed=2 ** 31 - 2),
+        D.SliceAugmentation(disp=D.piecewise_disp(np.random.default_rng(4).normal(0, 1, (4, 4, 2)) * 3.0, H, W), shape=(H, W)),
+        D.SliceAugmentation(disp=D.piecewise_disp(np.random.default_rng(6).normal(0, 1, (4, 4, 2)) * 9.0, H, W), shape=(H, W), order=0),
+        D.SliceAugmentation(m=D.affine_flip(0, H, W), disp=D.piecewise_disp(np.random.default_rng(5).normal(0, 1, (4, 4, 2)) * 2.0, H, W),
+                            shape=(H, W), blur=True, alpha=1.2, noise_sigma=0.3, noise_seed=2 ** 31 - 2),
     ]
     # every order of the three pixel stages (imgaug applies its augmenters in the drawn order, dataset_synapse.py:84-95): noise drawn
     # before the blur is blurred with the slice, noise drawn before the contrast change is scaled by it

@@ -167,3 +167,41 @@ def test_gradient_pieces_partition_the_arena_and_follow_the_backward_order(model
     s4 = sum(hi - lo for lo, hi in pieces[1][1]) / model.late_gradient_offset()
     assert (0.6 < s4 < 0.7) if legs == "split" else (0.85 < s4 < 0.95)        # stage 4 is ~64 % of the encoder's arena, stages 4 + 3 ~90 %
     assert clip_buckets([(0, 100), (200, 400), (500, 600)], [(50, 250), (550, 900)]) == [(50, 100), (200, 250), (550, 600)]
+
+
+@pytest.mark.parametrize("h,w", [(512, 512), (100, 136), (224, 224)])
+def test_piecewise_affine_triangles_follow_the_delaunay_statement(h, w):
+    """PiecewiseAffine (dataset_synapse.py:93): the record the HIP kernel reads -- clipped control-point displacements + one diagonal bit per
+    cell of imgaug's 4x4 grid (transception_amd.data) and the barycentric mix inside the pixel's triangle (csrc/data.hip: restated here in
+    numpy) -- gives the source coordinates of oracle.data_oracle.piecewise_source, which builds skimage's PiecewiseAffineTransform from the
+    published algorithm (Delaunay triangulation of the source grid, one affine map per triangle)."""
+    import numpy as np
+    from oracle import data_oracle as O
+    from transception_amd import data as D
+    g = np.random.default_rng(h + w)
+    jitter = g.normal(0.0, 1.0, (4, 4, 2)) * np.array([0.03 * h, 0.03 * w])
+    disp = D.piecewise_disp(jitter, h, w)
+    np.testing.assert_array_equal(disp.reshape(-1, 2), O.piecewise_clip(jitter, h, w))
+    np.testing.assert_array_equal(D.piecewise_grid(h, w), O.piecewise_grid(h, w))
+    bits = D.piecewise_diagonals(h, w)
+    yy, xx = np.meshgrid(np.arange(h, dtype=np.float64), np.arange(w, dtype=np.float64), indexing="ij")
+    gy, gx = yy * (3.0 / h), xx * (3.0 / w)
+    y0, x0 = np.minimum(np.floor(gy).astype(int), 2), np.minimum(np.floor(gx).astype(int), 2)
+    fy, fx = gy - y0, gx - x0
+    d = disp.astype(np.float64)
+    tl, tr, bl, br = d[y0, x0], d[y0, x0 + 1], d[y0 + 1, x0], d[y0 + 1, x0 + 1]
+    diag_b = ((bits >> (y0 * 3 + x0)) & 1).astype(bool)
+    z = np.zeros_like(fx)
+    upper, left = fx >= fy, fx + fy <= 1.0
+    l00 = np.where(diag_b, np.where(left, 1 - fx - fy, z), np.where(upper, 1 - fx, 1 - fy))
+    l01 = np.where(diag_b, np.where(left, fx, 1 - fy), np.where(upper, fx - fy, z))
+    l10 = np.where(diag_b, np.where(left, fy, 1 - fx), np.where(upper, z, fy - fx))
+    l11 = np.where(diag_b, np.where(left, z, fx + fy - 1), np.where(upper, fy, fx))
+    mix = l00[..., None] * tl + l01[..., None] * tr + l10[..., None] * bl + l11[..., None] * br
+    sy, sx = O.piecewise_source(disp, h, w)
+    np.testing.assert_allclose(yy + mix[..., 0], sy, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(xx + mix[..., 1], sx, rtol=0, atol=1e-9)
+    # nothing drawn: the far edge of the grid lies one step outside the slice and is clipped onto its last row / column, nothing else moves
+    sy0, sx0 = O.piecewise_source(D.piecewise_disp(np.zeros((4, 4, 2)), h, w), h, w)
+    assert np.abs(sy0 - yy)[: h // 3].max() < 1e-9 and np.abs(sx0 - xx)[:, : w // 3].max() < 1e-9
+    assert -1.0 <= (sy0 - yy).min() and (sy0 - yy).max() <= 1e-9

@@ -36,13 +36,23 @@ __device__ __forceinline__ unsigned mix32(unsigned v) {
 __device__ __forceinline__ void aug_source(const TcSliceAug& A, int oy, int ox, int H, int W, double& sy, double& sx) {
     double qy = (double)oy, qx = (double)ox;
     if (A.flags & TC_AUG_PIECEWISE) {
-        const double gy = qy * (3.0 / (double)(H - 1)), gx = qx * (3.0 / (double)(W - 1));
+        // imgaug PiecewiseAffine = skimage PiecewiseAffineTransform: the control grid spans [0, H] x [0, W] (linspace(0, size, 4)), every cell is
+        // two triangles (which diagonal: bit 8 + cell of flags, from the host's Delaunay triangulation), and inside a triangle the map is
+        // affine: the pixel moves by the barycentric mix of its three corners' displacements
+        const double gy = qy * (3.0 / (double)H), gx = qx * (3.0 / (double)W);
         const int y0 = min((int)floor(gy), 2), x0 = min((int)floor(gx), 2);
         const double fy = gy - (double)y0, fx = gx - (double)x0;
-        const float* d = A.disp + (y0 * 4 + x0) * 2;
-        const double w00 = (1.0 - fy) * (1.0 - fx), w01 = (1.0 - fy) * fx, w10 = fy * (1.0 - fx), w11 = fy * fx;
-        const double dy = ((w00 * (double)d[0] + w01 * (double)d[2]) + w10 * (double)d[8]) + w11 * (double)d[10];
-        const double dx = ((w00 * (double)d[1] + w01 * (double)d[3]) + w10 * (double)d[9]) + w11 * (double)d[11];
+        const float* d = A.disp + (y0 * 4 + x0) * 2;                       // TL d[0..1], TR d[2..3], BL d[8..9], BR d[10..11]
+        double l00 = 0.0, l01 = 0.0, l10 = 0.0, l11 = 0.0;                 // weights of TL, TR, BL, BR
+        if (!((A.flags >> (8 + y0 * 3 + x0)) & 1)) {                      // diagonal TL - BR
+            if (fx >= fy) { l00 = 1.0 - fx; l01 = fx - fy; l11 = fy; }
+            else { l00 = 1.0 - fy; l10 = fy - fx; l11 = fx; }
+        } else {                                                          // diagonal TR - BL
+            if (fx + fy <= 1.0) { l00 = (1.0 - fx) - fy; l01 = fx; l10 = fy; }
+            else { l11 = (fx + fy) - 1.0; l01 = 1.0 - fy; l10 = 1.0 - fx; }
+        }
+        const double dy = ((l00 * (double)d[0] + l01 * (double)d[2]) + l10 * (double)d[8]) + l11 * (double)d[10];
+        const double dx = ((l00 * (double)d[1] + l01 * (double)d[3]) + l10 * (double)d[9]) + l11 * (double)d[11];
         qy = qy + dy; qx = qx + dx;
     }
     sy = (A.m[2] + A.m[0] * qy) + A.m[1] * qx;

@@ -552,4 +552,4 @@ extern "C" int tc_seg_marker(int id, void* stream) {
     hipLaunchKernelGGL(seg_marker_kernel, dim3(id + 1), dim3(64), 0, TC_S, id);
     return tc_launch_status();
 }
-extern "C" int tc_abi_version(void) { return 12; }
+extern "C" int tc_abi_version(void) { return 13; }

@@ -101,6 +101,44 @@ def affine_translate(px: float, py: float, h: int, w: int):
 MAX_ROUNDS = 4                             # SomeOf((0, 4), ...): at most four augmenters per slice (dataset_synapse.py:84)
 
 
+_PW_DIAG: dict = {}
+
+
+def piecewise_grid(h: int, w: int) -> np.ndarray:
+    """imgaug 0.4.0 PiecewiseAffine control points: linspace(0, h, 4) x linspace(0, w, 4), (row, col), row-major."""
+    xx, yy = np.meshgrid(np.linspace(0, w, 4), np.linspace(0, h, 4))
+    return np.dstack([yy.flat, xx.flat])[0]
+
+
+def piecewise_disp(jitter: np.ndarray, h: int, w: int) -> np.ndarray:
+    """Control-point displacements [4,4,2] (dy, dx) of a drawn jitter: imgaug clips the moved points into the image plane."""
+    src = piecewise_grid(h, w)
+    dst = src + np.asarray(jitter, np.float64).reshape(-1, 2)
+    dst[:, 0], dst[:, 1] = np.clip(dst[:, 0], 0, h - 1), np.clip(dst[:, 1], 0, w - 1)
+    return (dst - src).astype(np.float32).reshape(4, 4, 2)
+
+
+def piecewise_diagonals(h: int, w: int) -> int:
+    """Nine bits, one per cell (gy * 3 + gx) of the 4x4 control grid: set when the Delaunay triangulation of the grid -- what skimage's
+    PiecewiseAffineTransform builds from the source points (scipy.spatial.Delaunay) -- splits the cell along its top-right / bottom-left
+    diagonal, clear for top-left / bottom-right.  The grid is regular, every cell's corners are co-circular, the choice is Qhull's."""
+    key = (h, w)
+    if key not in _PW_DIAG:
+        from scipy import spatial
+        tri = spatial.Delaunay(piecewise_grid(h, w)[:, ::-1])
+        edges = {frozenset((int(a), int(b))) for t in tri.simplices for a, b in ((t[0], t[1]), (t[1], t[2]), (t[0], t[2]))}
+        bits = 0
+        for gy in range(3):
+            for gx in range(3):
+                tl = gy * 4 + gx
+                a, b = frozenset((tl, tl + 5)) in edges, frozenset((tl + 1, tl + 4)) in edges
+                assert a != b, "every cell of the control grid is split by exactly one diagonal"
+                if b:
+                    bits |= 1 << (gy * 3 + gx)
+        _PW_DIAG[key] = bits
+    return _PW_DIAG[key]
+
+
 @dataclass
 class SliceAugmentation:
     """Parameters of one slice's augmentation.  Either ONE stage (one TcSliceAug record: an output->source warp and / or pixel
@@ -108,7 +146,9 @@ class SliceAugmentation:
     (`stages`: one single-stage SliceAugmentation per drawn augmenter, in the drawn order; imgaug resamples once per augmenter)."""
     m: Tuple[float, ...] = IDENTITY
     order: int = 1
-    disp: Optional[np.ndarray] = None          # float32 [4,4,2] control-point displacement (dy, dx) in pixels
+    disp: Optional[np.ndarray] = None          # float32 [4,4,2] control-point displacement (dy, dx) in pixels (PiecewiseAffine: moved - source
+    #                                            point of imgaug's 4x4 grid over [0, h] x [0, w], after its clip into the image: piecewise_disp)
+    shape: Optional[Tuple[int, int]] = None    # (h, w) of the slices the record is for: required with `disp` (the grid's triangulation)
     blur: bool = False
     alpha: float = 1.0
     center: float = 0.0
@@ -142,7 +182,8 @@ class SliceAugmentation:
         if self.order == 1:
             flags |= TC_AUG_LINEAR
         if self.disp is not None:
-            flags |= TC_AUG_PIECEWISE
+            assert self.shape is not None, "a piecewise warp needs the slice shape (the control grid's triangulation depends on it)"
+            flags |= TC_AUG_PIECEWISE | (piecewise_diagonals(*self.shape) << 8)
             for i, v in enumerate(np.asarray(self.disp, np.float32).reshape(-1)):
                 r.disp[i] = float(v)
         if self.blur:
@@ -168,9 +209,9 @@ class AugmentSampler:
     augmenter sees what an earlier one moved out of frame as zeros, and every resampling softens the slice a little; the flips are
     exact copies.  Coordinates follow imgaug 0.4's pixel-centre convention (transforms about ((w - 1) / 2, (h - 1) / 2), its
     `_AffineMatrixGenerator` shift of size / 2 - 0.5).  Not restated: cv2.warpAffine's fixed-point coordinates (1/32-pixel
-    interpolation tables) and skimage's per-triangle PiecewiseAffineTransform -- PiecewiseAffine is a 4x4 control-point displacement
-    field interpolated bilinearly.  imgaug itself is not importable here, so this stage stays parity-unpinned (its arithmetic is
-    defined by oracle/data_oracle.py)."""
+    interpolation tables).  PiecewiseAffine follows skimage's per-triangle PiecewiseAffineTransform over the Delaunay triangulation of
+    imgaug's 4x4 control grid (piecewise_grid / piecewise_disp / piecewise_diagonals).  imgaug itself is not importable here, so this
+    stage stays parity-unpinned (its arithmetic is defined by oracle/data_oracle.py)."""
     NAMES = ("Flipud", "Fliplr", "AdditiveGaussianNoise", "GaussianBlur", "LinearContrast", "Affine.scale", "Affine.rotate",
              "Affine.shear", "PiecewiseAffine", "Affine.translate")
 
@@ -205,7 +246,7 @@ class AugmentSampler:
                 st.m = affine_shear(float(g.uniform(-16, 16)), h, w)
             elif name == "PiecewiseAffine":
                 sc = float(g.uniform(0.008, 0.03))
-                st.disp = (g.normal(0.0, 1.0, (4, 4, 2)) * np.array([sc * h, sc * w])).astype(np.float32)
+                st.disp, st.shape = piecewise_disp(g.normal(0.0, 1.0, (4, 4, 2)) * np.array([sc * h, sc * w]), h, w), (h, w)
             else:
                 st.m = affine_translate(float(g.uniform(-0.2, 0.2)), float(g.uniform(-0.2, 0.2)), h, w)
             if st.warps() or st.blur or st.alpha != 1.0 or st.noise_sigma > 0.0:
