@@ -911,19 +911,30 @@ int launch_tile(const void* src, int lds_, const void* w, const void* bias, void
     return tc_launch_status();
 }
 
+struct DwGeom { int cg, ch, chunks, gx, nt; };
+template <typename T> DwGeom dw_bwd_geom(int B, int H, int W, int C, int k, int groups) {     // ONE statement of the one-launch backward's geometry: launch_tile_bwd launches it, tc_dwconv_bwd_plan hands it to the fold
+    constexpr int VEC = Vec16<T>::N;
+    DwGeom g;
+    g.cg = dw_pick_cg<T>(C); g.ch = g.cg * VEC; g.chunks = (C + g.ch - 1) / g.ch;
+    const int TH = (256 / g.cg) / 4, tilesW = (W + 15) / 16, tilesH = (H + TH - 1) / TH;
+    const long long ntiles = (long long)B * tilesW * tilesH;
+    long long gx = tc_dw_wg_target() / (g.chunks * groups);
+    if (gx > ntiles) gx = ntiles;
+    g.gx = (int)(gx < 1 ? 1 : gx); g.nt = k * k + 1;
+    return g;
+}
+
 template <typename T>
 int launch_tile_bwd(const void* dy, int lddy, const void* w, void* dx, int lddx, const void* x, int ldx, float* dw, float* db, int B, int H, int W,
                     int C, int k, int add_input, int accumulate, int groups, long long wstride, hipStream_t s, void* ws, long long ws_bytes) {
     constexpr int VEC = Vec16<T>::N;
-    const int cg = dw_pick_cg<T>(C);
-    const int chunks = (C + cg * VEC - 1) / (cg * VEC);
+    const DwGeom geo = dw_bwd_geom<T>(B, H, W, C, k, groups);      // (the plan the caller sized and described its deferred sums with)
+    const int cg = geo.cg, chunks = geo.chunks;
     const int TH = (256 / cg) / 4, tilesW = (W + 15) / 16, tilesH = (H + TH - 1) / TH;
     const long long ntiles = (long long)B * tilesW * tilesH;
     if (ntiles > 0x3fffffffLL) return TC_ERR_ARG;
 #define TC_TILE(KK, CGG) {                                                                                                              \
-        int gx = tc_dw_wg_target() / (chunks * groups);                                                                                 \
-        if (gx > ntiles) gx = (int)ntiles;                                                                                              \
-        gx = gx < 1 ? 1 : gx;                                                                                                           \
+        const int gx = geo.gx;                                                                                                          \
         constexpr int NTC = ((KK) * (KK) + 1) * (CGG) * VEC;                                                                            \
         float* wp = nullptr; int* wc = nullptr;                                                                                         \
         if (ws && ws_bytes < 0) {                                  /* deferred: the caller's own buffer, folded later by tc_dw_fold */   \
@@ -1051,6 +1062,24 @@ template <typename T> int dw_smem_q(int k, int cg, bool wgrad) {
     return 0;
 }
 
+// Weight-gradient walkers of segment i of a multi-segment launch: ~tc_dw_wg_target() workgroups in total, shared out in proportion to each
+// segment's tiles x chunks x (k + 2) (an even split gave the 56x56 map of a bridge layer 16 workgroups of 28 tiles each next to 1-tile
+// workgroups of the 7x7 map).  ONE statement: launch_multi launches it, tc_dwconv_multi_plan describes the deferred sums with it.
+template <typename T> long long dw_multi_work(const TcDwSeg* segs, int nseg) {
+    constexpr int VEC = Vec16<T>::N;
+    long long total_work = 0;
+    for (int i = 0; i < nseg; ++i) {
+        const int cg = dw_pick_cg<T>(segs[i].C), TH = (256 / cg) / 4;
+        total_work += (long long)segs[i].B * ((segs[i].W + 15) / 16) * ((segs[i].H + TH - 1) / TH) * ((segs[i].C + cg * VEC - 1) / (cg * VEC)) *
+                      (segs[i].k + 2);                  // cost per tile grows roughly with k (k filter rows per thread, k-wide window)
+    }
+    return total_work;
+}
+inline long long dw_multi_gx(long long ntiles, int k, long long total_work, int groups) {
+    long long gx = (long long)((double)tc_dw_wg_target() * (double)ntiles * (k + 2) / (double)(total_work > 0 ? total_work : 1) / groups + 0.5);
+    return gx < 1 ? 1 : (gx > ntiles ? ntiles : gx);
+}
+
 template <typename T>
 int launch_multi(const TcDwSeg* segs, int nseg, int mode, int add_input, int accumulate, int groups, long long wstride, void* ws,
                  long long ws_bytes, hipStream_t s) {
@@ -1064,12 +1093,7 @@ int launch_multi(const TcDwSeg* segs, int nseg, int mode, int add_input, int acc
     const bool defer = wgm && ws && ws_bytes < 0;                // the walkers' sums go to the caller's own buffer (tc_dw_fold adds them later)
     if (defer && (uintptr_t)ws % 16) return TC_ERR_ARG;
     const bool have_ws = !defer && wgm && ws && (uintptr_t)ws % 16 == 0 && ws_bytes > 16384;
-    long long total_work = 0;
-    for (int i = 0; i < nseg; ++i) {
-        const int cg = dw_pick_cg<T>(segs[i].C), TH = (256 / cg) / 4;
-        total_work += (long long)segs[i].B * ((segs[i].W + 15) / 16) * ((segs[i].H + TH - 1) / TH) * ((segs[i].C + cg * VEC - 1) / (cg * VEC)) *
-                      (segs[i].k + 2);                  // cost per tile grows roughly with k (k filter rows per thread, k-wide window)
-    }
+    const long long total_work = dw_multi_work<T>(segs, nseg);
     for (int i = 0; i < nseg; ++i) {
         const TcDwSeg& g = segs[i];
         DwSegDev& d = a.s[i];
@@ -1087,8 +1111,7 @@ int launch_multi(const TcDwSeg* segs, int nseg, int mode, int add_input, int acc
         if (wgm) {
             // ~256 workgroups in total, shared out in proportion to each segment's tiles x chunks (an even split gave the 56x56
             // map of a bridge layer 16 workgroups of 28 tiles each next to 1-tile workgroups of the 7x7 map)
-            long long gx = (long long)((double)tc_dw_wg_target() * (double)ntiles * (g.k + 2) / (double)(total_work > 0 ? total_work : 1) / groups + 0.5);
-            gx = gx < 1 ? 1 : (gx > ntiles ? ntiles : gx);
+            const long long gx = dw_multi_gx(ntiles, g.k, total_work, groups);
             d.gx = (int)gx;
             const long long nt_ch = (long long)(g.k * g.k + 1) * d.cg * VEC;
             d.wsc = have_ws ? reinterpret_cast<int*>(ws) + cnts : nullptr;
@@ -1498,6 +1521,20 @@ __global__ __launch_bounds__(NTH, 1) void ffn_mid_bwd_kernel(FfnMultiDev q) {
     ffn_mid_bwd_body<T, NTH>(g, q.wstride, lin % g.gx, lin / g.gx, blockIdx.y, dsm, q.dbg_nofold);
 }
 
+// Tile walkers of segment i of a tc_ffn_mid_bwd launch: ~tc_mid_wg_target() workgroups in total, shared out by tiles x chunks.  ONE statement
+// for launch_ffn_mid_bwd and tc_ffn_mid_plan (the deferred sums are laid out by it).
+template <typename T> long long ffn_mid_work(const TcFfnSeg* segs, int nseg) {
+    using D = FfnTile<T>;
+    long long total_work = 0;
+    for (int i = 0; i < nseg; ++i)
+        total_work += (long long)segs[i].B * ((segs[i].W + 15) / 16) * ((segs[i].H + D::TH - 1) / D::TH) * ((segs[i].C + D::CH - 1) / D::CH);
+    return total_work;
+}
+inline long long ffn_mid_gx(long long ntiles, long long total_work, int groups) {
+    long long gx = (long long)((double)tc_mid_wg_target() * (double)ntiles / (double)(total_work > 0 ? total_work : 1) / groups + 0.5);
+    return gx < 1 ? 1 : (gx > ntiles ? ntiles : gx);
+}
+
 template <typename T>
 int launch_ffn_mid_bwd(const TcFfnSeg* segs, int nseg, int groups, long long wstride, void* ws, long long ws_bytes, hipStream_t s) {
     using D = FfnTile<T>;
@@ -1506,12 +1543,11 @@ int launch_ffn_mid_bwd(const TcFfnSeg* segs, int nseg, int groups, long long wst
     static const int nofold = getenv("TC_DEBUG_FFN_NOFOLD") ? atoi(getenv("TC_DEBUG_FFN_NOFOLD")) : 0;
     FfnMultiDev q;
     q.n = nseg; q.wstride = wstride; q.dbg_nofold = nofold;
-    long long blk = 0, part_floats = 0, cnts = 0, total_work = 0;
+    long long blk = 0, part_floats = 0, cnts = 0;
     const bool defer = ws && ws_bytes < 0;                       // the walkers' sums go to the caller's own buffer (tc_dw_fold adds them later)
     if (defer && (uintptr_t)ws % 16) return TC_ERR_ARG;
     const bool have_ws = !defer && ws && (uintptr_t)ws % 16 == 0 && ws_bytes > 16384;
-    for (int i = 0; i < nseg; ++i)
-        total_work += (long long)segs[i].B * ((segs[i].W + 15) / 16) * ((segs[i].H + D::TH - 1) / D::TH) * ((segs[i].C + D::CH - 1) / D::CH);
+    const long long total_work = ffn_mid_work<T>(segs, nseg);
     for (int i = 0; i < nseg; ++i) {
         const TcFfnSeg& g = segs[i];
         FfnSegDev& d = q.s[i];
@@ -1526,8 +1562,7 @@ int launch_ffn_mid_bwd(const TcFfnSeg* segs, int nseg, int groups, long long wst
         d.tilesW = (g.W + 15) / 16; d.tilesH = (g.H + D::TH - 1) / D::TH;
         const long long ntiles = (long long)g.B * d.tilesW * d.tilesH;
         // ~256 workgroups in total (one per CU), shared out by tiles x chunks; every channel chunk gets gx tile walkers
-        long long gx = (long long)((double)tc_mid_wg_target() * (double)ntiles / (double)(total_work > 0 ? total_work : 1) / groups + 0.5);
-        gx = gx < 1 ? 1 : (gx > ntiles ? ntiles : gx);
+        const long long gx = ffn_mid_gx(ntiles, total_work, groups);
         d.gx = (int)gx;
         d.wsc = have_ws ? reinterpret_cast<int*>(ws) + cnts : nullptr;
         d.wsp = have_ws ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + 16384) + part_floats : nullptr;
@@ -1595,18 +1630,6 @@ extern "C" int tc_dwconv_bwd_weight(const void* dy, int lddy, const void* x, int
 /* see include/transception_hip.h */
 // ---- deferred weight-gradient fold of tc_dwconv_bwd (ws_bytes < 0) --------------------------------------------------------------------
 namespace {
-struct DwGeom { int cg, ch, chunks, gx, nt; };
-template <typename T> DwGeom dw_bwd_geom(int B, int H, int W, int C, int k, int groups) {     // launch_tile_bwd's numbers
-    constexpr int VEC = Vec16<T>::N;
-    DwGeom g;
-    g.cg = dw_pick_cg<T>(C); g.ch = g.cg * VEC; g.chunks = (C + g.ch - 1) / g.ch;
-    const int TH = (256 / g.cg) / 4, tilesW = (W + 15) / 16, tilesH = (H + TH - 1) / TH;
-    const long long ntiles = (long long)B * tilesW * tilesH;
-    long long gx = tc_dw_wg_target() / (g.chunks * groups);
-    if (gx > ntiles) gx = ntiles;
-    g.gx = (int)(gx < 1 ? 1 : gx); g.nt = k * k + 1;
-    return g;
-}
 constexpr int DWF_SITES = 48;                                  // (48 sites x 80 bytes: the argument block stays below 4 KiB)
 struct DwFoldSite { const float* part; float* dw; float* db; float* dgamma; float* dbeta; long long wstride; int C, kk, ch, chunks, gx, nt, groups, blk0; };
 constexpr int DWF_WALKERS = 32;                                 // walkers per fold workgroup: one batch of eight loads per thread
@@ -1669,19 +1692,14 @@ extern "C" long long tc_dwconv_multi_plan(const TcDwSeg* segs, int nseg, int gro
     long long total = 0;
     TC_DISPATCH_DTYPE(dtype, {
         constexpr int VEC = Vec16<T>::N;
-        long long total_work = 0;
-        for (int i = 0; i < nseg; ++i) {
+        for (int i = 0; i < nseg; ++i)
             if (segs[i].C % VEC || !dw_args_ok(segs[i].B, segs[i].H, segs[i].W, segs[i].C, segs[i].k, 1, 0)) return 0;
-            const int cg = dw_pick_cg<T>(segs[i].C), TH = (256 / cg) / 4;
-            total_work += (long long)segs[i].B * ((segs[i].W + 15) / 16) * ((segs[i].H + TH - 1) / TH) * ((segs[i].C + cg * VEC - 1) / (cg * VEC)) *
-                          (segs[i].k + 2);
-        }
+        const long long total_work = dw_multi_work<T>(segs, nseg);
         for (int i = 0; i < nseg; ++i) {                         // launch_multi's numbers
             const TcDwSeg& g = segs[i];
             const int cg = dw_pick_cg<T>(g.C), ch = cg * VEC, chunks = (g.C + ch - 1) / ch, TH = (256 / cg) / 4;
             const long long ntiles = (long long)g.B * ((g.W + 15) / 16) * ((g.H + TH - 1) / TH);
-            long long gx = (long long)((double)tc_dw_wg_target() * (double)ntiles * (g.k + 2) / (double)(total_work > 0 ? total_work : 1) / groups + 0.5);
-            gx = gx < 1 ? 1 : (gx > ntiles ? ntiles : gx);
+            const long long gx = dw_multi_gx(ntiles, g.k, total_work, groups);
             sites[i].C = g.C; sites[i].k = g.k; sites[i].groups = groups; sites[i].ch = ch; sites[i].chunks = chunks; sites[i].gx = (int)gx;
             sites[i].nt = g.k * g.k + 1;
             offs[i] = total;
@@ -1821,16 +1839,14 @@ extern "C" long long tc_ffn_mid_plan(const TcFfnSeg* segs, int nseg, int groups,
     if (!segs || !sites || !offs || nseg < 1 || nseg > FFN_MULTI_MAX || groups < 1) return 0;
     TC_DISPATCH_DTYPE(dtype, {
         using D = FfnTile<T>;
-        long long total_work = 0, total = 0;
-        for (int i = 0; i < nseg; ++i)
-            total_work += (long long)segs[i].B * ((segs[i].W + 15) / 16) * ((segs[i].H + D::TH - 1) / D::TH) * ((segs[i].C + D::CH - 1) / D::CH);
+        long long total = 0;
+        const long long total_work = ffn_mid_work<T>(segs, nseg);
         for (int i = 0; i < nseg; ++i) {                         // launch_ffn_mid_bwd's numbers
             const TcFfnSeg& g = segs[i];
             if (g.C <= 0 || g.C % D::VEC) return 0;
             const int chunks = (g.C + D::CH - 1) / D::CH;
             const long long ntiles = (long long)g.B * ((g.W + 15) / 16) * ((g.H + D::TH - 1) / D::TH);
-            long long gx = (long long)((double)tc_mid_wg_target() * (double)ntiles / (double)(total_work > 0 ? total_work : 1) / groups + 0.5);
-            gx = gx < 1 ? 1 : (gx > ntiles ? ntiles : gx);
+            const long long gx = ffn_mid_gx(ntiles, total_work, groups);
             sites[i].C = g.C; sites[i].k = 3; sites[i].groups = groups; sites[i].ch = D::CH; sites[i].chunks = chunks; sites[i].gx = (int)gx;
             sites[i].nt = D::NT;
             offs[i] = total;

@@ -1014,7 +1014,7 @@ class Graph:
                                    _ptr(t["lg"].grad) if hg else None, _ptr(t["lb"].grad) if hg else None,
                                    t["C4"], t["C4"], t["C4"], t["C4"], t["C4"], t["B"], t["H"], t["W"], t["nch2"])
             nf = 0
-            if _DW_DEFER and all(t["wd"].grad is not None for t in st):     # the walkers' sums parked; one tc_dw_fold per backward leg
+            if _DW_DEFER and not self.use_streams and all(t["wd"].grad is not None for t in st):     # the walkers' sums parked; one tc_dw_fold per backward leg
                 from ._lib import TcDwFold
                 sites, offs = (TcDwFold * n)(), (C.c_longlong * n)()
                 nf = int(L.tc_ffn_mid_plan(segs, n, Gn, self.dt, sites, offs))
@@ -1143,7 +1143,7 @@ class Graph:
                 return
             gx, acc = self.wgrad(x)
             fused = g.grad is not None and not (self.overlap_wgrad and self.use_streams)
-            nblk = int(self.L.tc_layernorm_bwd_nblk(rows, Cc)) if (fused and _LN_DEFER) else 0
+            nblk = int(self.L.tc_layernorm_bwd_nblk(rows, Cc)) if (fused and _LN_DEFER and not self.use_streams) else 0
             if nblk > 0:                                 # dx + per-workgroup dgamma / dbeta partials; the partials of ALL LayerNorms of a backward
                 nf = Gn * nblk * 2 * Cc                  # leg are added up by one launch when the leg ends (_flush_param_folds)
                 part = self.f32(nf)
@@ -1267,7 +1267,7 @@ class Graph:
                 from ._lib import TcDwFold
                 site = TcDwFold()
                 nf = (int(self.L.tc_dwconv_bwd_plan(B, H, W, Cc, k, Gn, self.dt, C.byref(site)))
-                      if (_DW_DEFER and not (x.ld % vec or dy.stride(0) % vec or gx.stride(0) % vec or _ptr(dy) % 16 or _ptr(x.data) % 16 or _ptr(gx) % 16))
+                      if (_DW_DEFER and not self.use_streams and not (x.ld % vec or dy.stride(0) % vec or gx.stride(0) % vec or _ptr(dy) % 16 or _ptr(x.data) % 16 or _ptr(gx) % 16))
                       else 0)
                 if nf > 0:                                    # the walkers' sums parked in a buffer of this launch's own; one tc_dw_fold per backward leg
                     part = self.f32(nf)
@@ -1335,7 +1335,8 @@ class Graph:
                 sg = segs([_ptr(x.data) for x in xs], wd, none, [_ptr(t) for t, _ in g], [_ptr(d) for d in dys],
                           [_ptr(w.grad) for w in ws], [_ptr(b.grad) if b is not None else None for b in bs],
                           [x.ld for x in xs], [t.stride(0) for t, _ in g], ldd)
-                if _DW_DEFER:                                  # the walkers' sums parked; one tc_dw_fold per backward leg
+                if _DW_DEFER and not self.use_streams:         # the walkers' sums parked; one tc_dw_fold per backward leg (single-stream sweeps only:
+                    #                                            a fold issued on one branch stream must not read a sibling branch's unfinished sums)
                     from ._lib import TcDwFold
                     sites, offs = (TcDwFold * n)(), (C.c_longlong * n)()
                     nf = int(self.L.tc_dwconv_multi_plan(sg, n, Gn, self.dt, sites, offs))
