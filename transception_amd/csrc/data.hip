@@ -100,6 +100,18 @@ __global__ __launch_bounds__(256) void slice_augment_kernel(const float* __restr
     const float* im = img + (long long)b * H * W;
     const unsigned char* lb = lab + (long long)b * H * W;
     const int ty0 = blockIdx.y * kTile, tx0 = blockIdx.x * kTile;
+    // A slice this round does nothing to (the identity record of a slice with fewer stages than the batch's longest chain: about half of all
+    // (slice, round) pairs) is copied in 16-byte pieces: the general path below moves a pixel per thread and step and made an identity round
+    // cost what a warp costs.  (alpha 1 about center 0 and sigma 0 leave every value bit for bit.)
+    if (!(A.flags & (TC_AUG_WARP | TC_AUG_BLUR)) && A.alpha == 1.0f && A.center == 0.0f && !(A.noise_sigma > 0.0f) && !(W & 3) && tx0 + kTile <= W) {
+        const int ly = tid >> 3, lx = (tid & 7) * 4, oy = ty0 + ly;
+        if (oy < H) {
+            const long long o = ((long long)b * H + oy) * W + tx0 + lx;
+            *reinterpret_cast<float4*>(oimg + o) = *reinterpret_cast<const float4*>(img + o);
+            *reinterpret_cast<uchar4*>(olab + o) = *reinterpret_cast<const uchar4*>(lab + o);
+        }
+        return;
+    }
     const bool blur = A.flags & TC_AUG_BLUR;
     // Pixel stages run in the order the sampler drew them (A.reserved: up to three 2-bit codes, first stage in the low bits;
     // 1 = blur, 2 = contrast, 3 = noise; 0 = the canonical blur -> contrast -> noise).  Blur is the only non-pointwise stage: the
