@@ -363,6 +363,51 @@ __global__ __launch_bounds__(256) void ln_bwd_v8_kernel(const T* __restrict__ dy
     ln_bwd_param_tail<RPB>(red, C, dgamma, dbeta, partial, cnt, defer);
 }
 
+// The forward on the same rows (16-bit, C = 64 / 128 / 256 / 512, no activation): eight channels per lane, RPT rows per lane group in flight
+// (ln_fwd_kernel's 8-byte pieces stream the 100 MB FinalPatchExpand map at 3.5 TB/s).  Same two-pass statistics, same order per row.
+template <typename T, int GS, int RPT>
+__global__ __launch_bounds__(256) void ln_fwd_v8_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ gamma, const T* __restrict__ beta,
+                                                        T* __restrict__ y, int ldy, float* __restrict__ mean, float* __restrict__ rstd, int rows,
+                                                        float eps, long long pstride, LnMap map) {
+    constexpr int RPB = 256 / GS, C = GS * 8;
+    const int gl = threadIdx.x % GS, gi = threadIdx.x / GS;
+    const int sst = (rstd == mean + 1) ? 2 : 1;
+    {
+        const long long g = blockIdx.y;
+        x += g * rows * ldx; y += g * rows * ldy; mean += g * rows * sst; rstd += g * rows * sst; gamma += g * pstride; beta += g * pstride;
+    }
+    float gm[8], bt[8];
+    ln_unpack8<T>(*reinterpret_cast<const lnu4*>(gamma + gl * 8), gm);
+    ln_unpack8<T>(*reinterpret_cast<const lnu4*>(beta + gl * 8), bt);
+    constexpr float invC = 1.0f / (float)C;
+    for (int row0 = (blockIdx.x * RPB + gi) * RPT; row0 < rows; row0 += gridDim.x * RPB * RPT) {
+        lnu4 raw[RPT];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) raw[r] = *reinterpret_cast<const lnu4*>(x + ln_row_off(min(row0 + r, rows - 1), map, ldx, C) + gl * 8);
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            float v[8];
+            ln_unpack8<T>(raw[r], v);
+            float s = ((v[0] + v[1]) + v[2]) + v[3];
+            s += ((v[4] + v[5]) + v[6]) + v[7];
+            const float mu = group_sum<GS>(s) * invC;
+            float s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[j] - mu; s2 += d * d; }
+            const float rs = rsqrtf(group_sum<GS>(s2) * invC + eps);
+            const int row = row0 + r;
+            if (row >= rows) continue;
+            if (gl == 0) { mean[(long long)row * sst] = mu; rstd[(long long)row * sst] = rs; }
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (v[j] - mu) * rs * gm[j] + bt[j];
+            lnu4 w;
+            w.x = pack2<T>(o[0], o[1]); w.y = pack2<T>(o[2], o[3]); w.z = pack2<T>(o[4], o[5]); w.w = pack2<T>(o[6], o[7]);
+            *reinterpret_cast<lnu4*>(y + (long long)row * ldy + gl * 8) = w;
+        }
+    }
+}
+
 // dgamma[c] += sum_rows dz * xhat ; dbeta[c] += sum_rows dz   as a column reduction (thread = 4 channels x row lane): fully
 // parallel over rows, a few atomics per block; runs on the weight-gradient stream next to the dx kernel.
 template <typename T>
@@ -672,6 +717,20 @@ static int ln_fwd_impl(const void* x, int ldx, const void* gamma, const void* be
         (ldx & 3) || (ldy & 3) || (act != TC_ACT_NONE && act != TC_ACT_GELU))
         return TC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
+    {   // 16-bit rows of 64 / 128 / 256 / 512 channels, every row piece 16-byte aligned, large maps: eight channels per lane (ln_fwd_v8_kernel)
+        static const int v8_on = getenv("TC_LN_FWD_V8") ? atoi(getenv("TC_LN_FWD_V8")) : 1;
+        const bool al = !((ldx | ldy) & 7) && !(pstride & 7) && !(((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15);
+        if (v8_on && (dtype == TC_BF16 || dtype == TC_F16) && act == TC_ACT_NONE && al && rows >= 65536 && (C == 64 || C == 128 || C == 256 || C == 512)) {
+            const dim3 grid(tc_blocks(rows, (2048 / C) * 4, 2048), groups);
+#define TC_LNF8(T_, GS_) hipLaunchKernelGGL((ln_fwd_v8_kernel<T_, GS_, 4>), grid, dim3(256), 0, s, (const T_*)x, ldx, (const T_*)gamma, (const T_*)beta,   \
+                                            (T_*)y, ldy, mean, rstd, rows, eps, pstride, map)
+#define TC_LNF8_C(T_) { if (C == 64) TC_LNF8(T_, 8); else if (C == 128) TC_LNF8(T_, 16); else if (C == 256) TC_LNF8(T_, 32); else TC_LNF8(T_, 64); }
+            if (dtype == TC_BF16) TC_LNF8_C(bf16_t) else TC_LNF8_C(f16_t)
+#undef TC_LNF8_C
+#undef TC_LNF8
+            return tc_launch_status();
+        }
+    }
     const int quads = C >> 2;
 #define TC_LNF(GS, NV) {                                                                                                                  \
         constexpr int RPT = NV == 1 ? 4 : (NV == 2 ? 2 : 1);       /* narrow rows: several rows in flight per lane group */                   \
