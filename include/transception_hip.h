@@ -524,6 +524,12 @@ int tc_sr_deinterleave(const void* in, void* out, long long sbo, int ldo, int B,
  * channels (1 => the reference's x.repeat(1,3,1,1), MSTr.py:2828-2829, is folded in):
  *   cols [B*Ho*Wo, ldc] with column (ci*49 + ky*7 + kx), ci in 0..2, zero padded up to ldc. */
 int tc_stem_im2col(const void* img, void* cols, int ldc, int B, int in_ch, int H, int W, int dtype, void* stream);
+/* im2col / col2im of a 3x3 stride-2 pad-1 convolution -- the Conv2d_BN stem of MSViT_4Stages (Stage_3or4 = 4, MSTr.py:1793-1810; the product
+ * is a tc_gemm with the [Cout, Cin*9] weight): cols [B*Ho*Wo, ldc], column c*9 + ky*3 + kx = x(b, 2 oy + ky - 1, 2 ox + kx - 1, c), zero
+ * outside the map and up to ldc.  nchw != 0: x is an image [B, src_ch, H, W] (src_ch = 1 feeds every channel, MSTr.py:2828-2829), else
+ * token-major rows [B*H*W, Cin] with row stride ldx.  tc_col2im3s2: dx (+)= the transposed gather of the column gradients. */
+int tc_im2col3s2(const void* x, int ldx, int nchw, int src_ch, void* cols, int ldc, int B, int Cin, int H, int W, int dtype, void* stream);
+int tc_col2im3s2(const void* dcols, int ldc, void* dx, int lddx, int B, int Cin, int H, int W, int accumulate, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Training-step kernels (trainer.py:123-153, utils.py:11-47).

@@ -51,13 +51,16 @@ class TransCeptionOracle:
         # ablation switches of the reference constructor (MSTr.py:2760-2823) that this restatement follows: the aggregate of a
         # stage (:1384-1403), whether the bridge runs (:2840) and which bridge layers use channel attention (:2413-2420)
         assert concat in ("coord", "normal", "se", "3d", "skn", "cbam", "cam", "cam_fact") and have_bridge != "sp" and len(br_ch_att_list) == 4
-        assert Stage_3or4 != 4
+        # Stage_3or4 = 4: MSViT_4Stages (MSTr.py:1746-1988) -- a Conv2d_BN stem and a first MHCA stage with two paths in place of the
+        # OverlapPatchEmbeddings + EfficientTransformerBlocks of MSViT; restated for the default aggregate ("coord") only
+        assert Stage_3or4 != 4 or concat == "coord"
+        self.four_stages = Stage_3or4 == 4
         # token_mlp of the EfficientTransformerBlocks (stage 1 and the decoder, MSTr.py:157-162): "mix_skip" (default) | "mix" (MixFFN, :35-46).  Any
         # other value builds MLP_FFN (:63-77), whose forward(x) the block calls with (x, H, W): the reference raises there, nothing to follow.
         assert token_mlp_mode in ("mix_skip", "mix")
         self.token_mlp_mode = token_mlp_mode
         self.inter = "out"                      # CBAMBlock: the spatial attention reads the gated concatenation
-        if Stage_3or4 != 3:
+        if Stage_3or4 not in (3, 4):
             # MSViT_casa (MSTr.py:2788-2791, 1990-2207): MSViT with MHCA_stage_casa (:1443-1534), which has no CoordAtt branch -- "coord" (any name it
             # does not know) falls through to Conv3d_BN_channel_attention_concat with CAM_Factorized_Module (:1497-1502, 631-635) -- and whose "cbam"
             # is CBAMBlock_casa (:1213-1257): spatial attention from the ResBlock branch (inter "res"), from the gated concatenation ("out"), or none
@@ -155,13 +158,18 @@ class TransCeptionOracle:
         y = self.linear(y, name + ".pwconv", bias=False)
         return self.hardswish(self.batchnorm_rows(y, name + ".bn"))
 
-    def patch_embed_stage(self, x: Tensor, name: str) -> List[Tensor]:
-        """Patch_Embed_stage, MSTr.py:704-732: chained, first one stride 2."""
+    def patch_embed_stage(self, x: Tensor, name: str, num_path: int = 3, pool: bool = True) -> List[Tensor]:
+        """Patch_Embed_stage, MSTr.py:704-732: chained, first one stride 2 (isPool)."""
         outs = []
-        for i in range(3):
-            x = self.dwconv2d_bn(x, f"{name}.patch_embeds.{i}.patch_conv", 2 if i == 0 else 1)
+        for i in range(num_path):
+            x = self.dwconv2d_bn(x, f"{name}.patch_embeds.{i}.patch_conv", 2 if (i == 0 and pool) else 1)
             outs.append(x)
         return outs
+
+    def conv2d_bn_hswish(self, x: Tensor, name: str, stride: int, pad: int) -> Tensor:
+        """Conv2d_BN(act_layer = Hardswish), MSTr.py:364-404: conv (no bias) -> BatchNorm -> Hardswish, NCHW in, NHWC out."""
+        y = F.conv2d(x, self.P[name + ".conv.weight"], None, stride=stride, padding=pad).permute(0, 2, 3, 1)
+        return self.hardswish(self.batchnorm_rows(y, name + ".bn"))
 
     def resblock(self, x: Tensor, name: str) -> Tensor:
         """ResBlock ('InvRes'), MSTr.py:1042-1050."""
@@ -306,8 +314,22 @@ class TransCeptionOracle:
         y = self.linear(cat.reshape(B, H * W, C4), name + ".aggregate.conv", bias=False)
         return self.hardswish(self.batchnorm_rows(y, name + ".aggregate.bn")).reshape(B, H, W, -1)
 
+    def backbone4(self, x: Tensor) -> List[Tensor]:
+        """MSViT_4Stages.forward, MSTr.py:1956-1988: stem (two 3x3 stride-2 Conv2d_BN + Hardswish, :1793-1810), then four RIPM + MHCA stages --
+        the first with two paths, one layer and no pooling (:1747-1790: num_path [2,3,3,3], num_layers [1,3,8,3])."""
+        m = self.conv2d_bn_hswish(x, "backbone.stem.0", 2, 1)
+        m = self.conv2d_bn_hswish(m.permute(0, 3, 1, 2), "backbone.stem.1", 2, 1)
+        outs = []
+        for s, layers, npath in zip((1, 2, 3, 4), (1,) + tuple(self.LAYERS), (2, 3, 3, 3)):
+            maps = self.patch_embed_stage(m, f"backbone.patch_embed_stage{s}", npath, pool=s > 1)
+            m = self.mhca_stage(maps, f"backbone.mhca_stage{s}", layers)
+            outs.append(m)
+        return outs
+
     def backbone(self, x: Tensor) -> List[Tensor]:
         """MSViT.forward, MSTr.py:1709-1744.  Returns four NHWC maps."""
+        if self.four_stages:
+            return self.backbone4(x)
         t, H, W = self.patch_embed1(x)
         self.taps["patch_embed1"] = t
         for i in range(2):

@@ -279,6 +279,13 @@ VARIANTS = {   # name -> (constructor kwargs, gradient probes)
                       ["backbone.block1.0.mlp.fc1.weight", "backbone.block1.1.mlp.dwconv.dwconv.weight", "backbone.block1.1.mlp.dwconv.dwconv.bias",
                        "decoder_2.layer_former_1.mlp.fc2.weight", "decoder_1.layer_former_2.mlp.dwconv.dwconv.weight", "decoder_0.layer_former_1.mlp.fc1.bias",
                        "backbone.mhca_stage3.mhca_blks.0.MHCA_layers.0.mlp.norm1.weight", "decoder_0.last_layer.weight"]),
+    # Stage_3or4 = 4 builds MSViT_4Stages: Conv2d_BN stem + a first MHCA stage of two paths
+    "stage4_coord": (dict(Stage_3or4=4),
+                     ["backbone.stem.0.conv.weight", "backbone.stem.0.bn.weight", "backbone.stem.1.conv.weight", "backbone.stem.1.bn.bias",
+                      "backbone.patch_embed_stage1.patch_embeds.1.patch_conv.dwconv.weight", "backbone.mhca_stage1.mhca_blks.1.MHCA_layers.0.factoratt_crpe.qkv.weight",
+                      "backbone.mhca_stage1.mhca_blks.0.crpe.conv_list.2.weight", "backbone.mhca_stage1.InvRes.conv1.conv.weight",
+                      "backbone.mhca_stage1.aggregate.conv1.weight", "backbone.mhca_stage1.aggregate.conv_in_out.weight",
+                      "backbone.mhca_stage3.mhca_blks.2.MHCA_layers.7.mlp.fc2.weight", "decoder_0.last_layer.weight"]),
     "bridge_para": (dict(have_bridge="para"),
                     ["backbone.mhca_stage3.aggregate.conv1.weight", "bridge.bridge_layer1.attn.q.weight", "bridge.bridge_layer2.attn.kv.weight",
                      "bridge.proj_act.0.weight", "bridge.proj_act.0.bias", "bridge.proj_act.1.weight", "bridge.bridge_layer3.mixffn4.fc2.weight",

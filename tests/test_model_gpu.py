@@ -386,6 +386,7 @@ VARIANTS = {   # constructor switches of SURVEY.md 8(f)-4 that the build impleme
     "no_bridge": dict(have_bridge="None"),
     "ch_att_1101": dict(br_ch_att_list=[True, True, False, True]),
     "bridge_para": dict(have_bridge="para"),
+    "stage4_coord": dict(Stage_3or4=4),                                 # MSViT_4Stages: Conv2d_BN stem + a two-path first MHCA stage
     "token_mlp_mix": dict(token_mlp_mode="mix"),                        # MixFFN instead of MixFFN_skip in the EfficientTransformerBlocks
     "stage5_coord": dict(Stage_3or4=5),                                 # MSViT_casa: "coord" builds the factorized path attention
     "stage5_cbam_res": dict(Stage_3or4=5, concat="cbam", inter="res"),  # CBAMBlock_casa

@@ -363,6 +363,50 @@ __global__ void stem_im2col_kernel(const T* img, T* cols, int ldc, int B, int in
     }
 }
 
+// im2col / col2im of a 3x3, stride-2, pad-1 convolution (the Conv2d_BN stem of MSViT_4Stages, MSTr.py:1793-1810): column c * 9 + ky * 3 + kx of
+// row (b, oy, ox) is x(b, 2 oy + ky - 1, 2 ox + kx - 1, c), zero outside the map -- the order of a [Cout, Cin, 3, 3] weight's rows.
+// nchw: x is an image [B, src_ch, H, W] (src_ch = 1 feeds all Cin channels: the reference's x.repeat(1, 3, 1, 1)); else token-major rows.
+template <typename T>
+__global__ void im2col3s2_kernel(const T* x, int ldx, int nchw, int src_ch, T* cols, int ldc, int B, int Cin, int H, int W, int Ho, int Wo) {
+    const long long n = (long long)B * Ho * Wo * ldc;
+    TC_GRID_STRIDE(i, n) {
+        const int col = (int)(i % ldc); unsigned t = i / ldc;
+        const int ox = (int)(t % Wo); t /= Wo; const int oy = (int)(t % Ho); const int b = (int)(t / Ho);
+        float v = 0.f;
+        if (col < 9 * Cin) {
+            const int c = col / 9, ky = (col % 9) / 3, kx = col % 3;
+            const int iy = 2 * oy + ky - 1, ix = 2 * ox + kx - 1;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W)
+                v = nchw ? ldf<T>(x + (((long long)b * src_ch + (src_ch == 1 ? 0 : c)) * H + iy) * W + ix)
+                         : ldf<T>(x + ((long long)(b * H + iy) * W + ix) * ldx + c);
+        }
+        stf<T>(cols + i, v);
+    }
+}
+// dx(b, y, x, c) (+)= the sum of the column gradients of every (output pixel, tap) that read it
+template <typename T>
+__global__ void col2im3s2_kernel(const T* dcols, int ldc, T* dx, int lddx, int B, int Cin, int H, int W, int Ho, int Wo, int accumulate) {
+    const long long n = (long long)B * H * W * Cin;
+    TC_GRID_STRIDE(i, n) {
+        const int c = (int)(i % Cin); unsigned t = i / Cin;
+        const int x_ = (int)(t % W); t /= W; const int y = (int)(t % H); const int b = (int)(t / H);
+        float a = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int sy = y + 1 - ky;
+            if (sy < 0 || (sy & 1) || (sy >> 1) >= Ho) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int sx = x_ + 1 - kx;
+                if (sx < 0 || (sx & 1) || (sx >> 1) >= Wo) continue;
+                a += ldf<T>(dcols + ((long long)(b * Ho + (sy >> 1)) * Wo + (sx >> 1)) * ldc + c * 9 + ky * 3 + kx);
+            }
+        }
+        T* d = dx + ((long long)(b * H + y) * W + x_) * lddx + c;
+        stf<T>(d, accumulate ? ldf<T>(d) + a : a);
+    }
+}
+
 template <typename TS, typename TD>
 __global__ void cast_kernel(const TS* s, TD* d, long long n) { TC_GRID_STRIDE64(i, n) stf<TD>(d + i, ldf<TS>(s + i)); }
 
@@ -529,6 +573,20 @@ extern "C" int tc_stem_im2col(const void* img, void* cols, int ldc, int B, int i
     const int Ho = (H + 6 - 7) / 4 + 1, Wo = (W + 6 - 7) / 4 + 1;
     TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((stem_im2col_kernel<T>), g1((long long)B * Ho * Wo * ldc), dim3(256), 0, TC_S, (const T*)img,
                                                 (T*)cols, ldc, B, in_ch, H, W, Ho, Wo));
+    return tc_launch_status();
+}
+extern "C" int tc_im2col3s2(const void* x, int ldx, int nchw, int src_ch, void* cols, int ldc, int B, int Cin, int H, int W, int dtype, void* stream) {
+    if (!x || !cols || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || ldc < 9 * Cin || (nchw ? (src_ch != 1 && src_ch != Cin) : ldx < Cin)) return TC_ERR_ARG;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((im2col3s2_kernel<T>), g1((long long)B * Ho * Wo * ldc), dim3(256), 0, TC_S, (const T*)x, ldx, nchw,
+                                                src_ch, (T*)cols, ldc, B, Cin, H, W, Ho, Wo));
+    return tc_launch_status();
+}
+extern "C" int tc_col2im3s2(const void* dcols, int ldc, void* dx, int lddx, int B, int Cin, int H, int W, int accumulate, int dtype, void* stream) {
+    if (!dcols || !dx || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || ldc < 9 * Cin || lddx < Cin) return TC_ERR_ARG;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((col2im3s2_kernel<T>), g1((long long)B * H * W * Cin), dim3(256), 0, TC_S, (const T*)dcols, ldc,
+                                                (T*)dx, lddx, B, Cin, H, W, Ho, Wo, accumulate));
     return tc_launch_status();
 }
 extern "C" int tc_cast(const void* src, void* dst, long long n, int src_dtype, int dst_dtype, void* stream) {

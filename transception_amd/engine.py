@@ -2000,6 +2000,31 @@ class Graph:
         self.L.tc_stem_im2col(_ptr(img), _ptr(out.data), 148, B, in_ch, H, W, self.dt, self.stream)
         return out
 
+    def im2col3s2(self, x, B: int, Cin: int, H: int, W: int, src_ch: int = 0) -> Var:
+        """Patches of a 3x3 stride-2 pad-1 convolution (the Conv2d_BN stem of MSViT_4Stages): [B*Ho*Wo, 9*Cin] (row pitch rounded up to 8), column
+        c*9 + ky*3 + kx -- the rows of the [Cout, Cin, 3, 3] weight.  x: a token-major Var [B*H*W, Cin] (its gradient comes back through
+        tc_col2im3s2), or -- src_ch 1 | Cin -- the NCHW network input (a tensor: no gradient)."""
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        image = not isinstance(x, Var)
+        ldc = (9 * Cin + 7) // 8 * 8
+        buf = self.new(B * Ho * Wo, ldc, requires_grad=not image)
+        self.n_launch += 1
+        self.L.tc_im2col3s2(_ptr(x) if image else _ptr(x.data), 0 if image else x.ld, int(image), src_ch if image else 0, _ptr(buf.data), ldc, B, Cin, H, W,
+                            self.dt, self.stream)
+        cols = buf.colslice(0, 9 * Cin)
+        if image:
+            return cols
+
+        def bwd():
+            d = self.grad_of(cols)
+            if d is None or not x.requires_grad:
+                return
+            gx, acc = self.wgrad(x)
+            self.n_launch += 1
+            self.L.tc_col2im3s2(_ptr(d), d.stride(0), _ptr(gx), gx.stride(0), B, Cin, H, W, acc, self.dt, self.stream)
+        self._rec(bwd)
+        return cols
+
     def attention(self, q: Var, k: Var, v: Var, B: int, Nq: int, Nk: int, scale: float, out: Optional[Var] = None) -> Var:
         """softmax(q k^T * scale) v per batch (single head, d = q.cols)."""
         d = q.cols

@@ -56,12 +56,12 @@ def _mk_dwconv2d_bn(ch: int, stride: int) -> nn.Module:          # MSTr.py:309-3
     return m
 
 
-def _mk_patch_embed_stage(ch: int) -> nn.Module:                 # MSTr.py:704-722
+def _mk_patch_embed_stage(ch: int, npath: int = 3, pool: bool = True) -> nn.Module:                 # MSTr.py:704-722
     m = nn.Module()
     pes = []
-    for idx in range(3):
+    for idx in range(npath):
         pe = nn.Module()
-        pe.patch_conv = _mk_dwconv2d_bn(ch, 2 if idx == 0 else 1)
+        pe.patch_conv = _mk_dwconv2d_bn(ch, 2 if (idx == 0 and pool) else 1)
         pes.append(pe)
     m.patch_embeds = nn.ModuleList(pes)
     return m
@@ -144,10 +144,14 @@ def _mk_coord_att(inp: int, oup: int) -> nn.Module:              # MSTr.py:1304-
     return m
 
 
-def _mk_mhca_stage(dim: int, out_dim: int, layers: int, concat: str = "coord", use_sa: bool = True, sa_ker: int = 7) -> nn.Module:   # MSTr.py:1350-1410
+def _mk_mhca_stage(dim: int, out_dim: int, layers: int, concat: str = "coord", use_sa: bool = True, sa_ker: int = 7, npath: int = 3) -> nn.Module:   # MSTr.py:1350-1410
     m = nn.Module()
-    m.mhca_blks = nn.ModuleList([_mk_mhca_encoder(dim, layers) for _ in range(3)])
+    m.mhca_blks = nn.ModuleList([_mk_mhca_encoder(dim, layers) for _ in range(npath)])
     m.InvRes = _mk_resblock(dim)
+    if npath != 3:                                              # (MSViT_4Stages' first stage: built for the default aggregate only)
+        assert concat == "coord"
+        m.aggregate = _mk_coord_att(dim * (npath + 1), out_dim)
+        return m
     # aggregate of the four branch outputs: CoordAtt (IFF, the default, :1402-1403), Conv1x1 + BN + Hardswish ("normal", :1384-1390)
     # or SE_Block ("se", :1396-1397, 571-583)
     if concat == "coord":
@@ -279,6 +283,29 @@ def _mk_decoder_layer(in_out_chan, n_class: int, is_last: bool, token_mlp: str =
     return m
 
 
+def _mk_backbone4(concat: str = "coord", sa_ker: int = 7) -> nn.Module:                                             # MSViT_4Stages, MSTr.py:1746-1920
+    m = nn.Module()
+    for i, d in enumerate(DIMS):
+        setattr(m, f"conv1_1_s{i + 1}", nn.Conv2d(3 * d, d, 1))     # dead parameters, kept for the schema
+    stem = []
+    for cin, cout in ((3, DIMS[0] // 2), (DIMS[0] // 2, DIMS[0])):                                                   # Conv2d_BN(k3, s2, p1, Hardswish) x 2, :1793-1810
+        c = nn.Module()
+        c.conv = nn.Conv2d(cin, cout, 3, 2, 1, bias=False)
+        c.bn = nn.BatchNorm2d(cout)
+        nn.init.xavier_uniform_(c.conv.weight)
+        stem.append(c)
+    m.stem = nn.Sequential(*stem)
+    npath, layers = (2, 3, 3, 3), (1,) + tuple(LAYERS)
+    for i in range(4):
+        setattr(m, f"patch_embed_stage{i + 1}", _mk_patch_embed_stage(DIMS[max(i - 1, 0)], npath[i], pool=i > 0))
+    for i in range(4):
+        setattr(m, f"mhca_stage{i + 1}", _mk_mhca_stage(DIMS[max(i - 1, 0)], DIMS[i], layers[i], concat, True, sa_ker, npath[i]))
+    m.cpe = nn.Module()
+    m.cpe.proj = nn.Conv2d(DIMS[0], DIMS[0], 3, 1, 1, groups=DIMS[0])   # dead
+    m.norm1 = nn.LayerNorm(DIMS[0])                                      # dead
+    return m
+
+
 def _mk_backbone(concat: str = "coord", use_sa_list=(True, True, False), sa_ker: int = 7, token_mlp: str = "mix_skip") -> nn.Module:   # MSTr.py:1536-1671
     m = nn.Module()
     for i, d in enumerate(DIMS):
@@ -342,14 +369,16 @@ class MSTransception(nn.Module):
         #   token_mlp_mode  "mix_skip" (default) | "mix": the EfficientTransformerBlocks of stage 1 and of the decoder use MixFFN (MSTr.py:35-46: no skip
         #                  around the depthwise convolution, no LayerNorm) instead of MixFFN_skip; the MB blocks and the bridge keep MixFFN_skip.  Any other
         #                  value builds MLP_FFN (:63-77), whose forward(x) the block calls with (x, H, W): the reference raises a TypeError there.
-        # the reference.  Not built: have_bridge = sp, Stage_3or4 = 4 (MSViT_4Stages), and the legacy networks/Transception.py class.
+        #   Stage_3or4   ... | 4: MSViT_4Stages with concat = "coord" (the other aggregates of a two-path first stage are not built)
+        # the reference.  Not built: have_bridge = sp, Stage_3or4 = 4 with a non-default aggregate, and the legacy
+        # networks/Transception.py class.
         br = [bool(b) for b in br_ch_att_list]
-        if (token_mlp_mode not in ("mix_skip", "mix") or concat not in ("coord", "normal", "se", "3d", "skn", "cbam", "cam", "cam_fact") or have_bridge == "sp" or Stage_3or4 == 4
-                or len(br) != 4):
+        if (token_mlp_mode not in ("mix_skip", "mix") or concat not in ("coord", "normal", "se", "3d", "skn", "cbam", "cam", "cam_fact") or have_bridge == "sp"
+                or (Stage_3or4 == 4 and concat != "coord") or len(br) != 4):
             raise NotImplementedError("MSTransception: implemented are every concat of the reference ('coord', 'normal', 'se', '3d', 'skn', 'cbam', 'cam', 'cam_fact'), have_bridge in {'original', "
-                                      "'None', 'para'}, any 4-entry br_ch_att_list, Stage_3or4 in {3, 5}, token_mlp_mode in {'mix_skip', 'mix'}")
+                                      "'None', 'para'}, any 4-entry br_ch_att_list, Stage_3or4 in {3, 5} (and 4 with concat = 'coord'), token_mlp_mode in {'mix_skip', 'mix'}")
         self.inter = "out"                              # CBAMBlock (Stage_3or4 = 3) gates with the statistics of the gated concatenation
-        if Stage_3or4 != 3:                             # MSViT_casa (MSTr.py:2788-2791: the else branch of 4 / 3)
+        if Stage_3or4 not in (3, 4):                    # MSViT_casa (MSTr.py:2788-2791: the else branch of 4 / 3)
             if concat not in ("normal", "3d", "se", "skn", "cbam", "cam"):
                 concat = "cam_fact"
             self.inter = inter
@@ -362,7 +391,9 @@ class MSTransception(nn.Module):
         if concat == "cbam" and sa_ker not in (3, 7):
             raise NotImplementedError("MSTransception(concat='cbam'): sa_ker must be 3 or 7")
         self.token_mlp_mode = token_mlp_mode
-        self.backbone = _mk_backbone(concat, use_sa_list, sa_ker, token_mlp_mode)
+        # Stage_3or4 = 4: MSViT_4Stages (MSTr.py:1746-1988) -- a Conv2d_BN stem and a first MHCA stage (two paths, one layer) instead of the
+        # OverlapPatchEmbeddings + EfficientTransformerBlocks; built for the default aggregate
+        self.backbone = _mk_backbone4(concat, sa_ker) if Stage_3or4 == 4 else _mk_backbone(concat, use_sa_list, sa_ker, token_mlp_mode)
         self.Stage_3or4 = Stage_3or4
         self.bridge = nn.Module()
         if have_bridge == "para":                       # constructor order of BridgeBlock_para: layers 1, 2, proj_act, layers 3, 4
@@ -507,13 +538,12 @@ class MSTransception(nn.Module):
                     self._used_views[self._pid[other]] = (o2, s2)
         return P(data, grad, G.pgs if G.ngroups > 1 else 0)
 
-    def _path_stride(self, stage: str) -> int:
+    def _path_stride(self, stage: str, npath: int = 3) -> int:
         """Distance in the flat arenas between the parameter blocks of two consecutive MB encoders of a stage."""
-        a = self._index[f"{stage}.mhca_blks.0.cpe.proj.weight"][0]
-        b = self._index[f"{stage}.mhca_blks.1.cpe.proj.weight"][0]
-        c = self._index[f"{stage}.mhca_blks.2.cpe.proj.weight"][0]
-        assert b - a == c - b and (b - a) % 8 == 0
-        return b - a
+        offs = [self._index[f"{stage}.mhca_blks.{g}.cpe.proj.weight"][0] for g in range(npath)]
+        d = offs[1] - offs[0]
+        assert all(offs[g + 1] - offs[g] == d for g in range(npath - 1)) and d % 8 == 0
+        return d
 
     def _run(self, x: torch.Tensor, record: bool, token_logits: bool = False):
         """token_logits: hand the logits over as the classifier Linear leaves them -- token-major [B*H*W, classes] in the storage type
@@ -741,12 +771,13 @@ def _eff_block(M, G, t: Var, name: str, B: int, H: int, W: int) -> Var:
     return _mixffn(M, G, n2, name + ".mlp", B, H, W, residual=tx)
 
 
-def _ripm(M, G, m: Var, name: str, B: int, side: int) -> Tuple[Var, int]:
-    """Patch_Embed_stage of DWConv2d_BN, MSTr.py:725-732, 355-362.  Returns the three chained maps stacked [3*rows, C]."""
-    so = (side - 1) // 2 + 1
+def _ripm(M, G, m: Var, name: str, B: int, side: int, npath: int = 3, pool: bool = True) -> Tuple[Var, int]:
+    """Patch_Embed_stage of DWConv2d_BN, MSTr.py:725-732, 355-362.  Returns the npath chained maps stacked [npath*rows, C] (npath = 3 and a pooling
+    first step everywhere but in the first stage of MSViT_4Stages: two paths, no pooling)."""
+    so = (side - 1) // 2 + 1 if pool else side
     rows = B * so * so
-    stack = G.new(3 * rows, m.cols)
-    if G.ripm_supported(m):                                      # a step per launch, BatchNorm + Hardswish applied by the consumer
+    stack = G.new(npath * rows, m.cols)
+    if npath == 3 and pool and G.ripm_supported(m):              # a step per launch, BatchNorm + Hardswish applied by the consumer
         steps = []
         for i in range(3):
             pre = f"{name}.patch_embeds.{i}.patch_conv"
@@ -755,8 +786,8 @@ def _ripm(M, G, m: Var, name: str, B: int, side: int) -> Tuple[Var, int]:
                               beta=M._P(G, pre + ".bn.bias"), rmean=holder.running_mean, rvar=holder.running_var))
         return stack, G.ripm_stage(m, steps, B, side, stack)
     x = m
-    for i in range(3):
-        stride = 2 if i == 0 else 1
+    for i in range(npath):
+        stride = 2 if (i == 0 and pool) else 1
         pre = f"{name}.patch_embeds.{i}.patch_conv"
         y = G.dwconv(x, M._P(G, pre + ".dwconv.weight"), None, B, side, side, 3, stride)
         side = (side - 1) // stride + 1
@@ -859,24 +890,24 @@ def _coord_att(M, G, x: Var, name: str, B: int, side: int, out: Var) -> Var:
     return G.linear(gated, *_lin(M, G, name + ".conv_in_out"), out=out)
 
 
-def _mhca_stage(M, G, stack: Var, name: str, layers: int, B: int, side: int, out: Var) -> Var:
+def _mhca_stage(M, G, stack: Var, name: str, layers: int, B: int, side: int, out: Var, npath: int = 3) -> Var:
     """MHCA_stage, MSTr.py:1412-1441.  `stack` holds the three RIPM maps one after the other ([3*rows, C]); the three MB
     encoders have identical shapes and their weights sit at a constant stride in the flat arena, so every kernel of the
     MB blocks runs ONCE for all three paths (grouped weights) instead of three times.  The four branch outputs are written
     side by side into one [rows, 4C] buffer (no torch.cat)."""
     C = stack.cols
     rows = B * side * side
-    cat = G.new(rows, 4 * C)
-    gs = M._path_stride(name)
+    cat = G.new(rows, (npath + 1) * C)
+    gs = M._path_stride(name, npath)
     enc = f"{name}.mhca_blks.0"
     stg = name[-1]
     with G.parallel(2) as par:
         with par.branch(0):
             G.segment("mb" + stg)
-            with G.grouped(3, gs):
+            with G.grouped(npath, gs):
                 t = stack
                 for l in range(layers):
-                    t = _mhca_block(M, G, t, f"{enc}.MHCA_layers.{l}", enc, B, side, cat.colslice(C, 4 * C) if l == layers - 1 else None)
+                    t = _mhca_block(M, G, t, f"{enc}.MHCA_layers.{l}", enc, B, side, cat.colslice(C, (npath + 1) * C) if l == layers - 1 else None)
         with par.branch(1):
             G.segment("res" + stg)
             _resblock(M, G, stack.rowslice(0, rows), name + ".InvRes", B, side, cat.colslice(0, C))
@@ -1141,13 +1172,32 @@ def _forward(M: MSTransception, G: Graph, x: torch.Tensor, B: int, in_ch: int, S
     def stage_map(buf: Var, s: int) -> Var:
         return buf.rowslice(R[s], R[s + 1]).reshape(B * sides[s] * sides[s], 64 * MULT[s])
 
+    tap = getattr(M, "capture_taps", False)
+    if M.Stage_3or4 == 4:
+        # MSViT_4Stages.forward, MSTr.py:1956-1988: Conv2d_BN stem (3x3 stride 2 + BatchNorm + Hardswish, twice: im2col + GEMM), then FOUR
+        # RIPM + MHCA stages -- the first with two paths, one layer and no pooling
+        G.segment("stage1")
+        m = x
+        for i, (cin, hw) in enumerate(((3, S), (DIMS[0] // 2, S // 2))):
+            cols = G.im2col3s2(m, B, cin, hw, hw, src_ch=in_ch if i == 0 else 0)
+            z = G.linear(cols, *_lin(M, G, f"backbone.stem.{i}.conv", bias=False), bn_shift=_bn_shift(M, f"backbone.stem.{i}.bn"))
+            m = _bn(M, G, z, f"backbone.stem.{i}.bn", ACT_HSWISH)
+        if tap:
+            M.taps = {}
+        side = sides[0]
+        for s4, (layers, npath) in enumerate(zip((1,) + tuple(LAYERS), (2, 3, 3, 3))):
+            if s4 >= 2:
+                G.mark(f"stage{s4 + 1}_done")
+            G.segment(f"ripm{s4 + 1}")
+            stack, side = _ripm(M, G, m, f"backbone.patch_embed_stage{s4 + 1}", B, side, npath, pool=s4 > 0)
+            m = _mhca_stage(M, G, stack, f"backbone.mhca_stage{s4 + 1}", layers, B, side, stage_map(Xb, s4), npath)
+        return _bridge_and_decoder(M, G, Xb, B, S, sides, ntok, R, N6, tap)
     # stage 1 -- OverlapPatchEmbeddings + 2 EfficientTransformerBlocks (MSTr.py:1714-1721)
     G.segment("stage1")
     cols = G.stem_im2col(x, B, in_ch, S, S)
     W, b = _lin(M, G, "backbone.patch_embed1.proj")
     t = G.linear(cols.colslice(0, 147), W, b)
     t = _ln(M, G, t, "backbone.patch_embed1.norm")
-    tap = getattr(M, "capture_taps", False)
     if tap:
         M.taps = {"patch_embed1": t.data.float().view(B, sides[0] * sides[0], 64).clone()}
     for i in range(2):
@@ -1160,6 +1210,14 @@ def _forward(M: MSTransception, G: Graph, x: torch.Tensor, B: int, in_ch: int, S
         G.segment(f"ripm{s + 1}")
         stack, side = _ripm(M, G, m, f"backbone.patch_embed_stage{s + 1}", B, sides[s - 1])
         m = _mhca_stage(M, G, stack, f"backbone.mhca_stage{s + 1}", LAYERS[s - 1], B, side, stage_map(Xb, s))
+    return _bridge_and_decoder(M, G, Xb, B, S, sides, ntok, R, N6, tap)
+
+
+def _bridge_and_decoder(M: MSTransception, G: Graph, Xb: Var, B: int, S: int, sides, ntok, R, N6: int, tap: bool) -> Var:
+    """BridgeBlock_4 (MSTr.py:2422-2442) and the four decoder layers (:2843-2850) over the stage-major encoder buffer."""
+    def stage_map(buf: Var, s: int) -> Var:
+        return buf.rowslice(R[s], R[s + 1]).reshape(B * sides[s] * sides[s], 64 * MULT[s])
+
     # Dual Transformer Bridge.  The mark lets a multi-GPU step stop its backward sweep here -- bridge and decoder gradients (72 % of
     # the live gradient bytes) are complete and can travel while the encoder's backward runs.
     G.mark("encoder_done")
