@@ -528,6 +528,15 @@ int tc_stem_im2col(const void* img, void* cols, int ldc, int B, int in_ch, int H
  * is a tc_gemm with the [Cout, Cin*9] weight): cols [B*Ho*Wo, ldc], column c*9 + ky*3 + kx = x(b, 2 oy + ky - 1, 2 ox + kx - 1, c), zero
  * outside the map and up to ldc.  nchw != 0: x is an image [B, src_ch, H, W] (src_ch = 1 feeds every channel, MSTr.py:2828-2829), else
  * token-major rows [B*H*W, Cin] with row stride ldx.  tc_col2im3s2: dx (+)= the transposed gather of the column gradients. */
+/* have_bridge = "sp" (BridgeBlock_sp, MSTr.py:2586-2757).  tc_window_rows: the window partition of SpatialAwareTrans (:2627-2640) and its
+ * reverse (:2649-2658) as a row permutation between a token map [B*H*W, C] (row stride: lds / ldd) and the window-token matrix
+ * [B*(H/ws)*(W/ws)*ntw, C]: pixel (b, wy ws + iy, wx ws + ix) <-> token off + iy ws + ix of window (b, wy, wx); dir 0: windows <- map,
+ * dir 1: map (+)= windows.  C a multiple of 8.  tc_dropout: nn.Dropout of its MLP_FFN (:70, 75-77) in training mode, y = x keep / (1 - p) with
+ * keep drawn from a counter-based generator keyed by (*seed_dev + salt, element index); the backward applies the same call to the gradient.
+ * (The mask bits have no reference counterpart: torch draws them from its own generator.) */
+int tc_window_rows(const void* src, int lds, void* dst, int ldd, int B, int H, int W, int ws, int ntw, int off, int C, int dir, int accumulate,
+                   int dtype, void* stream);
+int tc_dropout(const void* x, void* y, long long n, float p, const long long* seed_dev, unsigned salt, int dtype, void* stream);
 int tc_im2col3s2(const void* x, int ldx, int nchw, int src_ch, void* cols, int ldc, int B, int Cin, int H, int W, int dtype, void* stream);
 int tc_col2im3s2(const void* dcols, int ldc, void* dx, int lddx, int B, int Cin, int H, int W, int accumulate, int dtype, void* stream);
 

@@ -44,13 +44,18 @@ class TransCeptionOracle:
 
     def __init__(self, params: Dict[str, Tensor], num_classes: int = 9, training: bool = True, concat: str = "coord",
                  have_bridge: str = "original", br_ch_att_list=(True, False, False, False), use_sa_config: int = 1, sa_ker: int = 7,
-                 Stage_3or4: int = 3, inter: str = "res", token_mlp_mode: str = "mix_skip"):
+                 Stage_3or4: int = 3, inter: str = "res", token_mlp_mode: str = "mix_skip", num_sp: int = 1, sp_dropout: float = 0.1):
         self.P = params
         self.num_classes = num_classes
         self.training = training
         # ablation switches of the reference constructor (MSTr.py:2760-2823) that this restatement follows: the aggregate of a
         # stage (:1384-1403), whether the bridge runs (:2840) and which bridge layers use channel attention (:2413-2420)
-        assert concat in ("coord", "normal", "se", "3d", "skn", "cbam", "cam", "cam_fact") and have_bridge != "sp" and len(br_ch_att_list) == 4
+        assert concat in ("coord", "normal", "se", "3d", "skn", "cbam", "cam", "cam_fact") and len(br_ch_att_list) == 4
+        # have_bridge = "sp": BridgeBlock_sp (MSTr.py:2728-2757) -- SpatialAwareTrans ahead of the first of four all-spatial bridge layers.  Its
+        # MLP_FFN carries a live Dropout(0.1) (:63-77): sp_dropout = 0 restates the arithmetic without the random mask (what the fixtures pin)
+        self.num_sp, self.sp_dropout = int(num_sp), float(sp_dropout)
+        if have_bridge == "sp":
+            br_ch_att_list = (False, False, False, False)
         # Stage_3or4 = 4: MSViT_4Stages (MSTr.py:1746-1988) -- a Conv2d_BN stem and a first MHCA stage with two paths in place of the
         # OverlapPatchEmbeddings + EfficientTransformerBlocks of MSViT; restated for the default aggregate ("coord") only
         assert Stage_3or4 != 4 or concat == "coord"
@@ -396,10 +401,50 @@ class TransCeptionOracle:
             off += ntok
         return tx1 + torch.cat(outs, dim=1)
 
+    def multi_scale_atten(self, x: Tensor, name: str) -> Tensor:
+        """MultiScaleAtten, MSTr.py:2542-2559: eight heads over the N tokens of a window, UNSCALED scores (self.scale is never used)."""
+        B, nb, _, N, C = x.shape
+        h = 8
+        qkv = self.linear(x, name + ".qkv_linear").reshape(B, nb, nb, N, 3, h, C // h).permute(4, 0, 1, 2, 5, 3, 6)
+        q, k, v = qkv[0], qkv[1], qkv[2]
+        att = torch.softmax(q @ k.transpose(-1, -2), dim=-1)
+        return self.linear((att @ v).transpose(-2, -3).reshape(B, nb, nb, N, C), name + ".proj")
+
+    def inter_trans_block(self, x: Tensor, name: str) -> Tensor:
+        """InterTransBlock, MSTr.py:2562-2583 with MLP_FFN :63-77 (fc1, GELU, Dropout, fc2, Dropout)."""
+        x = x + self.multi_scale_atten(self.layernorm(x, name + ".SlayerNorm_1", 1e-6), name + ".Attention")
+        y = F.gelu(self.linear(self.layernorm(x, name + ".SlayerNorm_2", 1e-6), name + ".mlp.fc1"))
+        y = F.dropout(y, self.sp_dropout, self.training)
+        y = F.dropout(self.linear(y, name + ".mlp.fc2"), self.sp_dropout, self.training)
+        return x + y
+
+    def spatial_aware_trans(self, maps: List[Tensor], name: str) -> List[Tensor]:
+        """SpatialAwareTrans, MSTr.py:2586-2664: every scale projected to 64 channels, cut into windows of 8 / 4 / 2 / 1 pixels a side (the same
+        H/8 x W/8 grid of windows at every scale: 64 + 16 + 4 + 1 = 85 tokens each), num_sp InterTransBlocks over the window tokens, windows
+        put back and projected to their scale's width (fc_back; fc1_back .. fc4_back exist and are never used)."""
+        wins, xs = (8, 4, 2, 1), []
+        for j, m in enumerate(maps):
+            t = self.linear(m, f"{name}.fc{j + 1}")
+            B, H, W, C = t.shape
+            ws = wins[j]
+            xs.append(t.reshape(B, H // ws, ws, W // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H // ws, W // ws, ws * ws, C))
+        x = torch.cat(xs, dim=-2)
+        for i in range(self.num_sp):
+            x = self.inter_trans_block(x, f"{name}.group_attention.{i}")
+        outs = []
+        for j, item in enumerate(torch.split(x, [w * w for w in wins], dim=-2)):
+            B, nb, _, N, C = item.shape
+            ws = wins[j]
+            item = item.reshape(B, nb, nb, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, nb * ws, nb * ws, C)
+            outs.append(self.linear(item, f"{name}.fc_back.{j}"))
+        return outs
+
     def bridge(self, maps: List[Tensor]) -> List[Tensor]:
         """BridgeBlock_4, MSTr.py:2422-2442 (NHWC maps are already the packed token layout, Appendix C.5)."""
         B = maps[0].shape[0]
         h4 = maps[3].shape[1]
+        if self.have_bridge == "sp" and self.num_sp > 0:    # BridgeLayer_new, MSTr.py:2686-2704: only the first layer is handed the list of maps
+            maps = self.spatial_aware_trans(maps, "bridge.bridge_layer1.scale_fuse_att")
         t = torch.cat([m.reshape(B, -1, 64) for m in maps], dim=1)
         if self.have_bridge == "para":                      # BridgeBlock_para, MSTr.py:2500-2524 (BridgLayer_para = BridgLayer_4's arithmetic)
             b1 = self.bridge_layer(t, "bridge.bridge_layer1", True, h4)

@@ -279,6 +279,14 @@ VARIANTS = {   # name -> (constructor kwargs, gradient probes)
                       ["backbone.block1.0.mlp.fc1.weight", "backbone.block1.1.mlp.dwconv.dwconv.weight", "backbone.block1.1.mlp.dwconv.dwconv.bias",
                        "decoder_2.layer_former_1.mlp.fc2.weight", "decoder_1.layer_former_2.mlp.dwconv.dwconv.weight", "decoder_0.layer_former_1.mlp.fc1.bias",
                        "backbone.mhca_stage3.mhca_blks.0.MHCA_layers.0.mlp.norm1.weight", "decoder_0.last_layer.weight"]),
+    # have_bridge = "sp": BridgeBlock_sp.  Its MLP_FFN holds a live nn.Dropout(0.1): the vectors are made with p = 0 on those modules (set on the
+    # constructed reference model, _variant below) -- the arithmetic of every other operation is pinned, the random mask cannot be
+    "bridge_sp": (dict(have_bridge="sp"),
+                  ["bridge.bridge_layer1.scale_fuse_att.fc1.weight", "bridge.bridge_layer1.scale_fuse_att.fc3.bias", "bridge.bridge_layer1.scale_fuse_att.fc_back.2.weight",
+                   "bridge.bridge_layer1.scale_fuse_att.group_attention.0.Attention.qkv_linear.weight", "bridge.bridge_layer1.scale_fuse_att.group_attention.0.Attention.proj.bias",
+                   "bridge.bridge_layer1.scale_fuse_att.group_attention.0.mlp.fc1.weight", "bridge.bridge_layer1.scale_fuse_att.group_attention.0.SlayerNorm_2.weight",
+                   "bridge.bridge_layer1.attn.kv.weight", "bridge.bridge_layer4.mixffn3.fc2.weight", "backbone.mhca_stage4.aggregate.conv1.weight",
+                   "decoder_0.last_layer.weight"]),
     # Stage_3or4 = 4 builds MSViT_4Stages: Conv2d_BN stem + a first MHCA stage of two paths
     "stage4_coord": (dict(Stage_3or4=4),
                      ["backbone.stem.0.conv.weight", "backbone.stem.0.bn.weight", "backbone.stem.1.conv.weight", "backbone.stem.1.bn.bias",
@@ -338,6 +346,10 @@ def _variant(out, name, kw, probes, MST, Dice):
     out[name + "/n_keys"] = np.array([len(entries), len({c for _, _, c in entries})], dtype=np.int64)
     sd = seeded_state_dict(entries)
     ref.load_state_dict(sd, strict=True)
+    if kw.get("have_bridge") == "sp":
+        for mod in ref.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
     ref.train()
     logits = ref(x)
     pack(out, name + "/logits", logits)

@@ -386,6 +386,7 @@ VARIANTS = {   # constructor switches of SURVEY.md 8(f)-4 that the build impleme
     "no_bridge": dict(have_bridge="None"),
     "ch_att_1101": dict(br_ch_att_list=[True, True, False, True]),
     "bridge_para": dict(have_bridge="para"),
+    "bridge_sp": dict(have_bridge="sp"),                               # BridgeBlock_sp; the fixture was made with its Dropout(0.1) at p = 0
     "stage4_coord": dict(Stage_3or4=4),                                 # MSViT_4Stages: Conv2d_BN stem + a two-path first MHCA stage
     "token_mlp_mix": dict(token_mlp_mode="mix"),                        # MixFFN instead of MixFFN_skip in the EfficientTransformerBlocks
     "stage5_coord": dict(Stage_3or4=5),                                 # MSViT_casa: "coord" builds the factorized path attention
@@ -406,6 +407,7 @@ def test_variant_train_step_vs_reference_golden(name):
     sd = seeded_state_dict(schema_entries(m))
     m.load_state_dict(sd, strict=True)
     m.to(DEV).train()
+    m.sp_dropout = 0.0                                    # (only have_bridge = "sp" has a dropout: its fixture pins the arithmetic without the mask)
     x = torch.from_numpy(seeded_input(1)).to(DEV)
     lab = torch.from_numpy(seeded_labels(1)).to(DEV)
     logits = m(x)
@@ -428,6 +430,7 @@ def test_variant_train_step_vs_reference_golden(name):
     m3 = MSTransception(num_classes=9, **kw)
     m3.load_state_dict(sd, strict=True)
     m3.to(DEV).train()
+    m3.sp_dropout = 0.0
     m3.set_compute_dtype(torch.bfloat16)
     lb = m3(x)
     assert float((lb.detach().cpu() - lc).abs().max()) <= 0.15

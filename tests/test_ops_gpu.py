@@ -1201,3 +1201,56 @@ def test_attention_streams_run_to_run_bit_identical():
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "attn_stress.py"), "--iters", "120", "--reseed", "30"], capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0 and "RACE HUNT clean" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dropout_mask_properties(dtype):
+    """engine.Graph.dropout (tc_dropout: the Dropout(0.1) of the "sp" bridge's MLP_FFN, MSTr.py:70-77).  The mask bits cannot be pinned to torch's
+    generator; what is checked: kept elements are x / (1 - p) exactly, the dropped fraction is p within sampling error, the backward applies the
+    SAME mask to the gradient, another seed or salt gives another mask, and outside training mode the op is the identity."""
+    from transception_amd.engine import Graph, Var
+    n, p = (4096, 256), 0.1
+    x = (torch.rand(n, generator=torch.Generator().manual_seed(1)) + 0.5).to(dtype).to(DEV)
+    gy = (torch.rand(n, generator=torch.Generator().manual_seed(2)) + 0.5).to(dtype).to(DEV)
+    seed = torch.tensor([5], dtype=torch.int64, device=DEV)
+
+    def run(seed_t, salt, training=True):
+        G = Graph(dtype, torch.device(DEV), training=training, record=True)
+        xv = Var(x.clone())
+        out = G.dropout(xv, p, seed_t, salt)
+        if out is xv:
+            return None, None
+        run_bwd(G, out, gy)
+        return out.data.float().cpu(), G.grad_of(xv).float().cpu()
+    y, dx = run(seed, 0)
+    keep = y != 0
+    frac = 1.0 - keep.float().mean().item()
+    assert abs(frac - p) < 4 * (p * (1 - p) / keep.numel()) ** 0.5 + 1e-3, frac
+    scale = torch.tensor(1.0 / (1.0 - p), dtype=torch.float32)
+    want = (x.float().cpu() * scale).to(dtype).float()
+    assert torch.equal(y[keep], want[keep])
+    assert torch.equal(dx != 0, keep) and torch.equal(dx[keep], (gy.float().cpu() * scale).to(dtype).float()[keep])
+    y2, _ = run(torch.tensor([6], dtype=torch.int64, device=DEV), 0)
+    y3, _ = run(seed, 1)
+    assert not torch.equal(y2 != 0, keep) and not torch.equal(y3 != 0, keep)
+    assert run(seed, 0, training=False) == (None, None)
+
+
+def test_sp_bridge_trains_with_dropout():
+    """have_bridge = "sp" with its Dropout(0.1) live: two training forwards of the same input differ (the mask counter advances), gradients are finite,
+    and the eval-mode forward is deterministic."""
+    from transception_amd import MSTransception
+    from transception_amd.seeded_init import schema_entries, seeded_input, seeded_labels, seeded_state_dict
+    from transception_amd.train import SegLoss
+    m = MSTransception(num_classes=9, have_bridge="sp")
+    m.load_state_dict(seeded_state_dict(schema_entries(m)), strict=True)
+    m.to(DEV).train()
+    x, lab = torch.from_numpy(seeded_input(1)).to(DEV), torch.from_numpy(seeded_labels(1)).to(DEV)
+    a = m(x)
+    SegLoss(9)(a, lab)[0].backward()
+    assert all(torch.isfinite(q.grad).all() for q in m.parameters() if q.grad is not None)
+    b = m(x).detach()
+    assert not torch.equal(a.detach(), b)
+    m.eval()
+    with torch.no_grad():
+        assert torch.equal(m(x), m(x))

@@ -188,6 +188,8 @@ SIGNATURES = {
     "tc_patchify": [vp, i64, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "tc_sr_deinterleave": [vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp],
     "tc_stem_im2col": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "tc_window_rows": [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "tc_dropout": [vp, vp, i64, f32, vp, C.c_uint, i32, vp],
     "tc_im2col3s2": [vp, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp],
     "tc_col2im3s2": [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "tc_seg_loss_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, vp],

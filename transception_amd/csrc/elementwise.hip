@@ -407,6 +407,38 @@ __global__ void col2im3s2_kernel(const T* dcols, int ldc, T* dx, int lddx, int B
     }
 }
 
+// Window partition of SpatialAwareTrans (have_bridge = "sp", MSTr.py:2627-2640, 2649-2658): pixel (b, wy ws + iy, wx ws + ix) of a [B, H, W, C]
+// token map is token off + iy ws + ix of window (b, wy, wx) in a [B (H/ws) (W/ws), ntw, C] window-token matrix.  dir 0: windows <- map;
+// dir 1: map (+)= windows (the reverse step, and each direction's gradient).  Eight channels per thread.
+template <typename T>
+__global__ void window_rows_kernel(const T* src, int lds, T* dst, int ldd, int B, int H, int W, int ws, int ntw, int off, int C8, int dir, int accumulate) {
+    const long long n = (long long)B * H * W * C8;
+    const int nbx = W / ws, nby = H / ws;
+    TC_GRID_STRIDE(i, n) {
+        const int c8 = (int)(i % C8); unsigned t = i / C8;
+        const int x_ = (int)(t % W); t /= W; const int y = (int)(t % H); const int b = (int)(t / H);
+        const long long rmap = ((long long)b * H + y) * W + x_;
+        const long long rwin = (((long long)b * nby + y / ws) * nbx + x_ / ws) * ntw + off + (y % ws) * ws + x_ % ws;
+        const T* s_ = src + (dir ? rwin : rmap) * lds + c8 * 8;
+        T* d_ = dst + (dir ? rmap : rwin) * ldd + c8 * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) stf<T>(d_ + e, accumulate ? ldf<T>(d_ + e) + ldf<T>(s_ + e) : ldf<T>(s_ + e));
+    }
+}
+// Dropout (MLP_FFN of the "sp" bridge, MSTr.py:70,75-77): y = x * keep / (1 - p), keep from a counter-based generator keyed by (*seed + salt,
+// element index) -- the backward calls it on the gradient with the same key.  No reference counterpart for the bits (torch's CPU generator).
+template <typename T>
+__global__ void dropout_kernel(const T* x, T* y, long long n, float p, const long long* seed, unsigned salt) {
+    const unsigned key = (unsigned)(*seed) * 0x9E3779B9u + salt * 0x85EBCA6Bu;
+    const float scale = 1.0f / (1.0f - p);
+    TC_GRID_STRIDE64(i, n) {
+        unsigned v = (unsigned)i ^ ((unsigned)(i >> 32) * 0xC2B2AE35u) ^ key;
+        v ^= v >> 16; v *= 0x7FEB352Du; v ^= v >> 15; v *= 0x846CA68Bu; v ^= v >> 16;
+        const bool keep = (float)v * 2.3283064365386963e-10f >= p;
+        stf<T>(y + i, keep ? ldf<T>(x + i) * scale : 0.f);
+    }
+}
+
 template <typename TS, typename TD>
 __global__ void cast_kernel(const TS* s, TD* d, long long n) { TC_GRID_STRIDE64(i, n) stf<TD>(d + i, ldf<TS>(s + i)); }
 
@@ -573,6 +605,19 @@ extern "C" int tc_stem_im2col(const void* img, void* cols, int ldc, int B, int i
     const int Ho = (H + 6 - 7) / 4 + 1, Wo = (W + 6 - 7) / 4 + 1;
     TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((stem_im2col_kernel<T>), g1((long long)B * Ho * Wo * ldc), dim3(256), 0, TC_S, (const T*)img,
                                                 (T*)cols, ldc, B, in_ch, H, W, Ho, Wo));
+    return tc_launch_status();
+}
+extern "C" int tc_window_rows(const void* src, int lds, void* dst, int ldd, int B, int H, int W, int ws, int ntw, int off, int C, int dir,
+                              int accumulate, int dtype, void* stream) {
+    if (!src || !dst || B <= 0 || H <= 0 || W <= 0 || ws <= 0 || H % ws || W % ws || C <= 0 || (C & 7) || off < 0 || off + ws * ws > ntw || lds < C || ldd < C)
+        return TC_ERR_ARG;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((window_rows_kernel<T>), g1((long long)B * H * W * (C / 8)), dim3(256), 0, TC_S, (const T*)src, lds,
+                                                (T*)dst, ldd, B, H, W, ws, ntw, off, C / 8, dir, accumulate));
+    return tc_launch_status();
+}
+extern "C" int tc_dropout(const void* x, void* y, long long n, float p, const long long* seed_dev, unsigned salt, int dtype, void* stream) {
+    if (!x || !y || n <= 0 || !(p >= 0.f && p < 1.f) || !seed_dev) return TC_ERR_ARG;
+    TC_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dropout_kernel<T>), g1(n), dim3(256), 0, TC_S, (const T*)x, (T*)y, n, p, seed_dev, salt));
     return tc_launch_status();
 }
 extern "C" int tc_im2col3s2(const void* x, int ldx, int nchw, int src_ch, void* cols, int ldc, int B, int Cin, int H, int W, int dtype, void* stream) {

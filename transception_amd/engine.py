@@ -2000,6 +2000,55 @@ class Graph:
         self.L.tc_stem_im2col(_ptr(img), _ptr(out.data), 148, B, in_ch, H, W, self.dt, self.stream)
         return out
 
+    def window_rows(self, src: Var, dst: Var, B: int, H: int, W: int, ws: int, ntw: int, off: int, to_map: bool):
+        """SpatialAwareTrans' window partition (to_map False: dst = window-token matrix [B*(H/ws)*(W/ws)*ntw, C] <- src = token map [B*H*W, C]) or
+        its reverse (to_map True: dst = map <- src = windows): a row permutation (tc_window_rows); the gradient takes the same road back."""
+        Cc = src.cols
+        assert dst.cols == Cc and Cc % 8 == 0
+        self.n_launch += 1
+        self.L.tc_window_rows(_ptr(src.data), src.ld, _ptr(dst.data), dst.ld, B, H, W, ws, ntw, off, Cc, int(to_map), 0, self.dt, self.stream)
+
+        def bwd():
+            d = self.grad_of(dst)
+            if d is None or not src.requires_grad:
+                return
+            if to_map:
+                # the reverse step reads ONE scale's tokens of every window: its gradient covers those rows of the window matrix only (the four
+                # scales' launches together cover it) -- a zero-filled buffer, always added to
+                r = src.root
+                assert src.is_whole
+                if r.grad_t is None:
+                    r.grad_t = self._zeros.zeros_like(r.data)
+                r.whole_written = True
+                g, acc = src.apply_path(r.grad_t), 1
+            else:
+                g, acc = self.wgrad(src)
+            self.n_launch += 1
+            self.L.tc_window_rows(_ptr(d), d.stride(0), _ptr(g), g.stride(0), B, H, W, ws, ntw, off, Cc, int(not to_map), acc, self.dt, self.stream)
+        self._rec(bwd)
+
+    def dropout(self, x: Var, p: float, seed: torch.Tensor, salt: int) -> Var:
+        """nn.Dropout(p) in training mode (identity otherwise): the keep mask comes from a counter-based generator keyed by (*seed + salt, element);
+        the backward applies the same mask to the gradient (tc_dropout)."""
+        if not self.training or p <= 0.0:
+            return x
+        assert x.data.is_contiguous()
+        out = self.new(x.rows, x.cols)
+        n = x.rows * x.cols
+        self.n_launch += 1
+        self.L.tc_dropout(_ptr(x.data), _ptr(out.data), n, float(p), _ptr(seed), salt, self.dt, self.stream)
+
+        def bwd():
+            d = self.grad_of(out)
+            if d is None or not x.requires_grad:
+                return
+            assert d.is_contiguous()
+            tmp = torch.empty_like(d)
+            self.L.tc_dropout(_ptr(d), _ptr(tmp), n, float(p), _ptr(seed), salt, self.dt, self.stream)
+            self.pass_grad(x, tmp)
+        self._rec(bwd)
+        return out
+
     def im2col3s2(self, x, B: int, Cin: int, H: int, W: int, src_ch: int = 0) -> Var:
         """Patches of a 3x3 stride-2 pad-1 convolution (the Conv2d_BN stem of MSViT_4Stages): [B*Ho*Wo, 9*Cin] (row pitch rounded up to 8), column
         c*9 + ky*3 + kx -- the rows of the [Cout, Cin, 3, 3] weight.  x: a token-major Var [B*H*W, Cin] (its gradient comes back through

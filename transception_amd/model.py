@@ -258,6 +258,36 @@ def _mk_bridge_layer(dim: int, ch_att: bool) -> nn.Module:       # MSTr.py:2356-
     return m
 
 
+def _mk_spatial_aware_trans(dim: int, num_sp: int) -> nn.Module:             # SpatialAwareTrans, MSTr.py:2586-2615 (constructor order kept)
+    m = nn.Module()
+    chans = [dim * k for k in MULT]
+    for j, c in enumerate(chans):
+        setattr(m, f"fc{j + 1}", nn.Linear(c, dim))
+    for j, c in enumerate(chans):
+        setattr(m, f"fc{j + 1}_back", nn.Linear(dim, c))            # built, never used by its forward (:2658 takes fc_back)
+    m.fc_back = nn.ModuleList([nn.Linear(dim, c) for c in chans])
+    blocks = []
+    for _ in range(num_sp):                                         # InterTransBlock, :2562-2568; MultiScaleAtten :2542-2549; MLP_FFN :63-70
+        b = nn.Module()
+        b.SlayerNorm_1 = nn.LayerNorm(dim, eps=1e-6)
+        b.SlayerNorm_2 = nn.LayerNorm(dim, eps=1e-6)
+        b.Attention = nn.Module()
+        b.Attention.qkv_linear = nn.Linear(dim, dim * 3)
+        b.Attention.proj = nn.Linear(dim, dim)
+        b.mlp = nn.Module()
+        b.mlp.fc1 = nn.Linear(dim, 4 * dim)
+        b.mlp.fc2 = nn.Linear(4 * dim, dim)
+        blocks.append(b)
+    m.group_attention = nn.Sequential(*blocks)
+    return m
+
+
+def _mk_bridge_layer_sp(dim: int, num_sp: int) -> nn.Module:       # BridgeLayer_new, MSTr.py:2668-2684
+    m = _mk_bridge_layer(dim, False)
+    m.scale_fuse_att = _mk_spatial_aware_trans(dim, num_sp)
+    return m
+
+
 def _mk_decoder_layer(in_out_chan, n_class: int, is_last: bool, token_mlp: str = "mix_skip") -> nn.Module:   # MSTr.py:230-269
     dims, out_dim = in_out_chan[0], in_out_chan[1]
     m = nn.Module()
@@ -370,13 +400,15 @@ class MSTransception(nn.Module):
         #                  around the depthwise convolution, no LayerNorm) instead of MixFFN_skip; the MB blocks and the bridge keep MixFFN_skip.  Any other
         #                  value builds MLP_FFN (:63-77), whose forward(x) the block calls with (x, H, W): the reference raises a TypeError there.
         #   Stage_3or4   ... | 4: MSViT_4Stages with concat = "coord" (the other aggregates of a two-path first stage are not built)
-        # the reference.  Not built: have_bridge = sp, Stage_3or4 = 4 with a non-default aggregate, and the legacy
-        # networks/Transception.py class.
+        #   have_bridge  ... | "sp" (BridgeBlock_sp, :2728-2757: SpatialAwareTrans -- per-scale Linear to 64 channels, windows of 8 / 4 / 2 / 1 pixels,
+        #                  num_sp InterTransBlocks of 8-head attention over the 85 tokens of a window + MLP_FFN with Dropout(0.1), windows back, Linear
+        #                  to the scale's width -- ahead of four all-spatial bridge layers)
+        # the reference.  Not built: Stage_3or4 = 4 with a non-default aggregate, and the legacy networks/Transception.py class.
         br = [bool(b) for b in br_ch_att_list]
-        if (token_mlp_mode not in ("mix_skip", "mix") or concat not in ("coord", "normal", "se", "3d", "skn", "cbam", "cam", "cam_fact") or have_bridge == "sp"
-                or (Stage_3or4 == 4 and concat != "coord") or len(br) != 4):
+        if (token_mlp_mode not in ("mix_skip", "mix") or concat not in ("coord", "normal", "se", "3d", "skn", "cbam", "cam", "cam_fact")
+                or (Stage_3or4 == 4 and concat != "coord") or len(br) != 4 or (have_bridge == "sp" and int(num_sp) < 0)):
             raise NotImplementedError("MSTransception: implemented are every concat of the reference ('coord', 'normal', 'se', '3d', 'skn', 'cbam', 'cam', 'cam_fact'), have_bridge in {'original', "
-                                      "'None', 'para'}, any 4-entry br_ch_att_list, Stage_3or4 in {3, 5} (and 4 with concat = 'coord'), token_mlp_mode in {'mix_skip', 'mix'}")
+                                      "'None', 'para', 'sp'}, any 4-entry br_ch_att_list, Stage_3or4 in {3, 5} (and 4 with concat = 'coord'), token_mlp_mode in {'mix_skip', 'mix'}")
         self.inter = "out"                              # CBAMBlock (Stage_3or4 = 3) gates with the statistics of the gated concatenation
         if Stage_3or4 not in (3, 4):                    # MSViT_casa (MSTr.py:2788-2791: the else branch of 4 / 3)
             if concat not in ("normal", "3d", "se", "skn", "cbam", "cam"):
@@ -384,6 +416,10 @@ class MSTransception(nn.Module):
             self.inter = inter
         if have_bridge == "para":                       # BridgeBlock_para ignores br_ch_att_list (it receives num_sp, MSTr.py:2806-2807):
             br = [True, False, False, False]            # layer 1 channel, layers 2-4 spatial (MSTr.py:2504-2512)
+        if have_bridge == "sp":                         # BridgeBlock_sp (MSTr.py:2728-2757): four BridgeLayer_new, all with spatial attention;
+            br = [False, False, False, False]           # SpatialAwareTrans (num_sp InterTransBlocks) runs ahead of the first layer only
+        self.num_sp = int(num_sp)
+        self.sp_dropout = 0.1                           # nn.Dropout(0.1) of the InterTransBlocks' MLP_FFN (MSTr.py:70); training mode only
         self.concat, self.have_bridge, self.br_ch_att_list = concat, have_bridge, br
         self.num_classes = num_classes
         # use_sa_config (MSTr.py:2766-2775): which of the three stages' CBAM blocks apply the spatial attention; sa_ker its kernel size (3 or 7 here)
@@ -402,6 +438,9 @@ class MSTransception(nn.Module):
             self.bridge.proj_act = nn.Sequential(nn.Linear(128, 64), nn.LayerNorm(64), nn.GELU())
             self.bridge.bridge_layer3 = _mk_bridge_layer(64, False)
             self.bridge.bridge_layer4 = _mk_bridge_layer(64, False)
+        elif have_bridge == "sp":
+            for i in range(4):
+                setattr(self.bridge, f"bridge_layer{i + 1}", _mk_bridge_layer_sp(64, self.num_sp))
         else:
             for i, ch in enumerate(br):
                 setattr(self.bridge, f"bridge_layer{i + 1}", _mk_bridge_layer(64, ch))
@@ -537,6 +576,16 @@ class MSTransception(nn.Module):
                     assert o2 == off + g * G.pgs and s2 == shape, (name, other)
                     self._used_views[self._pid[other]] = (o2, s2)
         return P(data, grad, G.pgs if G.ngroups > 1 else 0)
+
+    def _dropout_seed(self, G: Graph) -> torch.Tensor:
+        """Device counter that keys the dropout masks of a forward pass (have_bridge = "sp"); advanced once per training forward, inside a captured
+        step too (the increment is a captured launch -- the counter itself must exist before the capture: train.GraphedStep's eager warm-up
+        steps create it)."""
+        if getattr(self, "_drop_ctr", None) is None or self._drop_ctr.device != G.dev:
+            self._drop_ctr = torch.zeros(1, dtype=torch.int64, device=G.dev)
+        if G.training:
+            self._drop_ctr += 1
+        return self._drop_ctr
 
     def _path_stride(self, stage: str, npath: int = 3) -> int:
         """Distance in the flat arenas between the parameter blocks of two consecutive MB encoders of a stage."""
@@ -1213,6 +1262,46 @@ def _forward(M: MSTransception, G: Graph, x: torch.Tensor, B: int, in_ch: int, S
     return _bridge_and_decoder(M, G, Xb, B, S, sides, ntok, R, N6, tap)
 
 
+def _spatial_aware_trans(M, G, Xb: Var, name: str, B: int, sides, R, stage_map) -> Var:
+    """SpatialAwareTrans, MSTr.py:2617-2664 (an ablation variant, run op by op): per scale a Linear to 64 channels, the window partition (windows of
+    8 / 4 / 2 / 1 pixels: 64 + 16 + 4 + 1 = 85 tokens per window of the common H/8 x W/8 grid), num_sp InterTransBlocks (:2562-2583) -- LayerNorm,
+    8-head attention over a window's tokens with UNSCALED scores (:2555), proj, skip; LayerNorm, MLP_FFN with Dropout(0.1) after GELU and after
+    fc2 (:63-77), skip -- the windows put back and a Linear to the scale's width (fc_back), written as the bridge's stage-major buffer."""
+    wins, ntw, nb = (8, 4, 2, 1), 85, sides[3]
+    assert all(sides[j] == nb * wins[j] for j in range(4)), "SpatialAwareTrans needs the four scales on a common window grid"
+    nw, d, h = B * nb * nb, 64, 8
+    win = G.new(nw * ntw, d)
+    off = 0
+    for j in range(4):
+        t = G.linear(stage_map(Xb, j), *_lin(M, G, f"{name}.fc{j + 1}"))
+        G.window_rows(t, win, B, sides[j], sides[j], wins[j], ntw, off, to_map=False)
+        off += wins[j] * wins[j]
+    x = win
+    seed = M._dropout_seed(G)
+    for i in range(M.num_sp):
+        blk = f"{name}.group_attention.{i}"
+        qkv = G.linear(_ln(M, G, x, blk + ".SlayerNorm_1", 1e-6), *_lin(M, G, blk + ".Attention.qkv_linear"))
+        q, k, v = qkv.colslice(0, d), qkv.colslice(d, 2 * d), qkv.colslice(2 * d, 3 * d)
+        sc = G.new(nw * h * ntw, ntw)                             # scores per (window, head): [85, 85]
+        G.bmm(q, k, sc, ntw, ntw, d // h, 0, 1, nb1=nw, nb2=h, sA=(ntw * qkv.ld, d // h), sB=(ntw * qkv.ld, d // h), sC=(h * ntw * ntw, ntw * ntw))
+        p = G.softmax(sc, 1, 1)
+        o = G.new(nw * ntw, d)
+        G.bmm(p, v, o, ntw, d // h, ntw, 0, 0, nb1=nw, nb2=h, sA=(h * ntw * ntw, ntw * ntw), sB=(ntw * qkv.ld, d // h), sC=(ntw * d, d // h))
+        x = G.linear(o, *_lin(M, G, blk + ".Attention.proj"), residual=x)
+        y = G.gelu(G.linear(_ln(M, G, x, blk + ".SlayerNorm_2", 1e-6), *_lin(M, G, blk + ".mlp.fc1")))
+        y = G.dropout(y, M.sp_dropout, seed, 2 * i)
+        y = G.dropout(G.linear(y, *_lin(M, G, blk + ".mlp.fc2")), M.sp_dropout, seed, 2 * i + 1)
+        x = G.add(x, y)
+    X = G.new(Xb.rows, Xb.cols)
+    off = 0
+    for j in range(4):
+        t = G.new(B * sides[j] * sides[j], d)
+        G.window_rows(x, t, B, sides[j], sides[j], wins[j], ntw, off, to_map=True)
+        off += wins[j] * wins[j]
+        G.linear(t, *_lin(M, G, f"{name}.fc_back.{j}"), out=stage_map(X, j))
+    return X
+
+
 def _bridge_and_decoder(M: MSTransception, G: Graph, Xb: Var, B: int, S: int, sides, ntok, R, N6: int, tap: bool) -> Var:
     """BridgeBlock_4 (MSTr.py:2422-2442) and the four decoder layers (:2843-2850) over the stage-major encoder buffer."""
     def stage_map(buf: Var, s: int) -> Var:
@@ -1240,6 +1329,8 @@ def _bridge_and_decoder(M: MSTransception, G: Graph, Xb: Var, B: int, S: int, si
         if tap:
             M.taps["bridge4"] = image_major(X)
     elif M.have_bridge != "None":                                 # MSTr.py:2840
+        if M.have_bridge == "sp" and M.num_sp > 0:                # BridgeLayer_new, MSTr.py:2686-2704: only the first layer is handed the maps
+            X = _spatial_aware_trans(M, G, Xb, "bridge.bridge_layer1.scale_fuse_att", B, sides, R, stage_map)
         for li in range(1, 5):
             G.segment(f"bridge{li}")
             X = _bridge_layer(M, G, X, li, B, sides, ntok, R, N6)
