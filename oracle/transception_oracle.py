@@ -58,7 +58,7 @@ class TransCeptionOracle:
             br_ch_att_list = (False, False, False, False)
         # Stage_3or4 = 4: MSViT_4Stages (MSTr.py:1746-1988) -- a Conv2d_BN stem and a first MHCA stage with two paths in place of the
         # OverlapPatchEmbeddings + EfficientTransformerBlocks of MSViT; restated for the default aggregate ("coord") only
-        assert Stage_3or4 != 4 or concat == "coord"
+        assert Stage_3or4 != 4 or concat in ("coord", "normal", "se", "cbam", "skn")     # ("3d" / "cam" / "cam_fact" hard-code four maps: the reference fails on the three of a two-path stage)
         self.four_stages = Stage_3or4 == 4
         # token_mlp of the EfficientTransformerBlocks (stage 1 and the decoder, MSTr.py:157-162): "mix_skip" (default) | "mix" (MixFFN, :35-46).  Any
         # other value builds MLP_FFN (:63-77), whose forward(x) the block calls with (x, H, W): the reference raises there, nothing to follow.
@@ -285,7 +285,9 @@ class TransCeptionOracle:
             ca = torch.sigmoid(se(flat.max(dim=1).values) + se(flat.mean(dim=1)))
             o = cat * ca[:, None, None, :]
             stage = int(name[-1])
-            if self.use_sa_list[stage - 2] and self.inter in ("res", "out"):
+            # MSViT_4Stages (MSTr.py:2778-2779): use_sa_list = [True, True, True, False] for its stages 1..4 whatever use_sa_config says
+            use_sa = (True, True, True, False)[stage - 1] if self.four_stages else self.use_sa_list[stage - 2]
+            if use_sa and self.inter in ("res", "out"):
                 src = o if self.inter == "out" else outs[0]                                             # CBAMBlock_casa :1243-1251: x[0], the ResBlock branch
                 st = torch.stack([src.max(dim=-1).values, src.mean(dim=-1)], dim=1)                     # [B, 2, H, W]
                 k = self.P[agg + ".sa.conv.weight"].shape[-1]
@@ -299,8 +301,8 @@ class TransCeptionOracle:
             agg = name + ".aggregate"
             S = sum(outs).mean(dim=(1, 2))
             Z = self.linear(S, agg + ".fc")
-            a = torch.softmax(torch.stack([self.linear(Z, f"{agg}.fcs.{k}") for k in range(4)], 0), dim=0)      # [4, B, C]
-            V = sum(a[k][:, None, None, :] * outs[k] for k in range(4))
+            a = torch.softmax(torch.stack([self.linear(Z, f"{agg}.fcs.{k}") for k in range(len(outs))], 0), dim=0)      # [branches, B, C]
+            V = sum(a[k][:, None, None, :] * outs[k] for k in range(len(outs)))
             B, H, W, C = V.shape
             z = torch.relu(self.linear(V.reshape(B, H * W, C), agg + ".conv_bn_ac.0"))
             return self.batchnorm_rows(z, agg + ".conv_bn_ac.2").reshape(B, H, W, -1)

@@ -294,6 +294,19 @@ VARIANTS = {   # name -> (constructor kwargs, gradient probes)
                       "backbone.mhca_stage1.mhca_blks.0.crpe.conv_list.2.weight", "backbone.mhca_stage1.InvRes.conv1.conv.weight",
                       "backbone.mhca_stage1.aggregate.conv1.weight", "backbone.mhca_stage1.aggregate.conv_in_out.weight",
                       "backbone.mhca_stage3.mhca_blks.2.MHCA_layers.7.mlp.fc2.weight", "decoder_0.last_layer.weight"]),
+    "stage4_normal": (dict(Stage_3or4=4, concat="normal"),
+                      ["backbone.mhca_stage1.aggregate.conv.weight", "backbone.mhca_stage1.aggregate.bn.weight", "backbone.stem.1.conv.weight",
+                       "backbone.mhca_stage1.mhca_blks.1.MHCA_layers.0.mlp.fc1.weight", "decoder_0.last_layer.weight"]),
+    "stage4_se": (dict(Stage_3or4=4, concat="se"),
+                  ["backbone.mhca_stage1.aggregate.excitation.0.weight", "backbone.mhca_stage1.aggregate.excitation.2.weight", "backbone.mhca_stage1.aggregate.conv.weight",
+                   "backbone.mhca_stage1.aggregate.conv.bias", "backbone.stem.0.conv.weight", "decoder_0.last_layer.weight"]),
+    # (with four stages the spatial attention runs in stages 1-3 whatever use_sa_config says, MSTr.py:2778-2779)
+    "stage4_cbam_k3": (dict(Stage_3or4=4, concat="cbam", use_sa_config=3, sa_ker=3),
+                       ["backbone.mhca_stage1.aggregate.ca.se.0.weight", "backbone.mhca_stage1.aggregate.sa.conv.weight", "backbone.mhca_stage3.aggregate.sa.conv.weight",
+                        "backbone.mhca_stage1.aggregate.conv2d_bn_act.0.weight", "backbone.stem.1.bn.weight", "decoder_0.last_layer.weight"]),
+    "stage4_skn": (dict(Stage_3or4=4, concat="skn"),
+                   ["backbone.mhca_stage1.aggregate.fc.weight", "backbone.mhca_stage1.aggregate.fcs.2.weight", "backbone.mhca_stage1.aggregate.conv_bn_ac.0.weight",
+                    "backbone.mhca_stage2.aggregate.fcs.3.bias", "backbone.stem.0.bn.weight", "decoder_0.last_layer.weight"]),
     "bridge_para": (dict(have_bridge="para"),
                     ["backbone.mhca_stage3.aggregate.conv1.weight", "bridge.bridge_layer1.attn.q.weight", "bridge.bridge_layer2.attn.kv.weight",
                      "bridge.proj_act.0.weight", "bridge.proj_act.0.bias", "bridge.proj_act.1.weight", "bridge.bridge_layer3.mixffn4.fc2.weight",

@@ -37,7 +37,7 @@ def test_constructor_contract():
     MSTransception(num_classes=2, head_count=8, dil_conv=1, token_mlp_mode="mix_skip", MSViT_config=2, concat="coord",
                    have_bridge="original", use_sa_config=1, sa_ker=7, Stage_3or4=3, inter="res", num_sp=1,
                    br_ch_att_list=[True, False, False, False])
-    for kw in (dict(concat="nonsense"), dict(have_bridge="sp", num_sp=-1), dict(Stage_3or4=4, concat="normal"), dict(token_mlp_mode="mlp")):
+    for kw in (dict(concat="nonsense"), dict(have_bridge="sp", num_sp=-1), dict(Stage_3or4=4, concat="3d"), dict(token_mlp_mode="mlp")):
         with pytest.raises(NotImplementedError):
             MSTransception(**kw)
 

@@ -387,7 +387,11 @@ VARIANTS = {   # constructor switches of SURVEY.md 8(f)-4 that the build impleme
     "ch_att_1101": dict(br_ch_att_list=[True, True, False, True]),
     "bridge_para": dict(have_bridge="para"),
     "bridge_sp": dict(have_bridge="sp"),                               # BridgeBlock_sp; the fixture was made with its Dropout(0.1) at p = 0
-    "stage4_coord": dict(Stage_3or4=4),                                 # MSViT_4Stages: Conv2d_BN stem + a two-path first MHCA stage
+    "stage4_coord": dict(Stage_3or4=4),
+    "stage4_normal": dict(Stage_3or4=4, concat="normal"),
+    "stage4_se": dict(Stage_3or4=4, concat="se"),
+    "stage4_cbam_k3": dict(Stage_3or4=4, concat="cbam", use_sa_config=3, sa_ker=3),
+    "stage4_skn": dict(Stage_3or4=4, concat="skn"),                                 # MSViT_4Stages: Conv2d_BN stem + a two-path first MHCA stage
     "token_mlp_mix": dict(token_mlp_mode="mix"),                        # MixFFN instead of MixFFN_skip in the EfficientTransformerBlocks
     "stage5_coord": dict(Stage_3or4=5),                                 # MSViT_casa: "coord" builds the factorized path attention
     "stage5_cbam_res": dict(Stage_3or4=5, concat="cbam", inter="res"),  # CBAMBlock_casa

@@ -148,14 +148,14 @@ def _mk_mhca_stage(dim: int, out_dim: int, layers: int, concat: str = "coord", u
     m = nn.Module()
     m.mhca_blks = nn.ModuleList([_mk_mhca_encoder(dim, layers) for _ in range(npath)])
     m.InvRes = _mk_resblock(dim)
-    if npath != 3:                                              # (MSViT_4Stages' first stage: built for the default aggregate only)
-        assert concat == "coord"
-        m.aggregate = _mk_coord_att(dim * (npath + 1), out_dim)
-        return m
+    nb = npath + 1                                              # branch maps the aggregate sees (MSViT_4Stages' first stage: two paths + ResBlock)
+    if nb != 4 and concat not in ("coord", "normal", "se", "cbam", "skn"):
+        raise NotImplementedError("a two-path MHCA stage exists for concat in {'coord', 'normal', 'se', 'cbam', 'skn'}: the reference's '3d' / 'cam' / 'cam_fact' "
+                                  "aggregates hard-code four maps and fail on three")
     # aggregate of the four branch outputs: CoordAtt (IFF, the default, :1402-1403), Conv1x1 + BN + Hardswish ("normal", :1384-1390)
     # or SE_Block ("se", :1396-1397, 571-583)
     if concat == "coord":
-        m.aggregate = _mk_coord_att(dim * 4, out_dim)
+        m.aggregate = _mk_coord_att(dim * nb, out_dim)
     elif concat == "3d":                                        # Conv3d_BN_concat, MSTr.py:406-462: Conv3d(C, out, (4, 1, 1)) + ReLU over the stacked maps, BatchNorm
         a = nn.Module()
         a.bn = nn.BatchNorm2d(out_dim)
@@ -186,10 +186,10 @@ def _mk_mhca_stage(dim: int, out_dim: int, layers: int, concat: str = "coord", u
     elif concat == "cbam":                                      # CBAMBlock(channel = 4C, reduction = 16, kernel_size = sa_ker), MSTr.py:1169-1211, 1400-1401
         a = nn.Module()
         a.ca = nn.Module()
-        a.ca.se = nn.Sequential(nn.Conv2d(dim * 4, dim * 4 // 16, 1, bias=False), nn.ReLU(), nn.Conv2d(dim * 4 // 16, dim * 4, 1, bias=False))
+        a.ca.se = nn.Sequential(nn.Conv2d(dim * nb, dim * nb // 16, 1, bias=False), nn.ReLU(), nn.Conv2d(dim * nb // 16, dim * nb, 1, bias=False))
         a.sa = nn.Module()
         a.sa.conv = nn.Conv2d(2, 1, kernel_size=sa_ker, stride=1, padding=sa_ker // 2)
-        a.conv2d_bn_act = nn.Sequential(nn.Conv2d(dim * 4, out_dim, 1, bias=False), nn.BatchNorm2d(out_dim), nn.ReLU())
+        a.conv2d_bn_act = nn.Sequential(nn.Conv2d(dim * nb, out_dim, 1, bias=False), nn.BatchNorm2d(out_dim), nn.ReLU())
         a.use_sa = use_sa
         a.sa_ker = sa_ker
         m.aggregate = a
@@ -197,19 +197,19 @@ def _mk_mhca_stage(dim: int, out_dim: int, layers: int, concat: str = "coord", u
         a = nn.Module()
         dd = max(32, dim // 8)
         a.fc = nn.Linear(dim, dd)
-        a.fcs = nn.ModuleList([nn.Linear(dd, dim) for _ in range(4)])
+        a.fcs = nn.ModuleList([nn.Linear(dd, dim) for _ in range(nb)])
         a.softmax = nn.Softmax(dim=0)
         a.conv_bn_ac = nn.Sequential(nn.Conv2d(dim, out_dim, kernel_size=(1, 1)), nn.ReLU(inplace=True), nn.BatchNorm2d(out_dim))
         m.aggregate = a
     elif concat == "se":
         a = nn.Module()
-        a.excitation = nn.Sequential(nn.Linear(dim * 4, dim * 4 // 16, bias=False), nn.ReLU(inplace=True),
-                                     nn.Linear(dim * 4 // 16, dim * 4, bias=False), nn.Sigmoid())
-        a.conv = nn.Conv2d(dim * 4, out_dim, 1)
+        a.excitation = nn.Sequential(nn.Linear(dim * nb, dim * nb // 16, bias=False), nn.ReLU(inplace=True),
+                                     nn.Linear(dim * nb // 16, dim * nb, bias=False), nn.Sigmoid())
+        a.conv = nn.Conv2d(dim * nb, out_dim, 1)
         a.bn = nn.BatchNorm2d(out_dim)
         m.aggregate = a
     else:
-        m.aggregate = _mk_conv2d_bn(dim * 4, out_dim)
+        m.aggregate = _mk_conv2d_bn(dim * nb, out_dim)
     return m
 
 
@@ -328,8 +328,9 @@ def _mk_backbone4(concat: str = "coord", sa_ker: int = 7) -> nn.Module:         
     npath, layers = (2, 3, 3, 3), (1,) + tuple(LAYERS)
     for i in range(4):
         setattr(m, f"patch_embed_stage{i + 1}", _mk_patch_embed_stage(DIMS[max(i - 1, 0)], npath[i], pool=i > 0))
+    use_sa = (True, True, True, False)                              # MSTr.py:2778-2779: this list whatever use_sa_config says
     for i in range(4):
-        setattr(m, f"mhca_stage{i + 1}", _mk_mhca_stage(DIMS[max(i - 1, 0)], DIMS[i], layers[i], concat, True, sa_ker, npath[i]))
+        setattr(m, f"mhca_stage{i + 1}", _mk_mhca_stage(DIMS[max(i - 1, 0)], DIMS[i], layers[i], concat, use_sa[i], sa_ker, npath[i]))
     m.cpe = nn.Module()
     m.cpe.proj = nn.Conv2d(DIMS[0], DIMS[0], 3, 1, 1, groups=DIMS[0])   # dead
     m.norm1 = nn.LayerNorm(DIMS[0])                                      # dead
@@ -399,16 +400,17 @@ class MSTransception(nn.Module):
         #   token_mlp_mode  "mix_skip" (default) | "mix": the EfficientTransformerBlocks of stage 1 and of the decoder use MixFFN (MSTr.py:35-46: no skip
         #                  around the depthwise convolution, no LayerNorm) instead of MixFFN_skip; the MB blocks and the bridge keep MixFFN_skip.  Any other
         #                  value builds MLP_FFN (:63-77), whose forward(x) the block calls with (x, H, W): the reference raises a TypeError there.
-        #   Stage_3or4   ... | 4: MSViT_4Stages with concat = "coord" (the other aggregates of a two-path first stage are not built)
+        #   Stage_3or4   ... | 4: MSViT_4Stages with concat in {"coord", "normal", "se", "cbam", "skn"} ("3d" / "cam" / "cam_fact" hard-code four maps
+        #                  and fail in the reference itself on the three of its two-path first stage)
         #   have_bridge  ... | "sp" (BridgeBlock_sp, :2728-2757: SpatialAwareTrans -- per-scale Linear to 64 channels, windows of 8 / 4 / 2 / 1 pixels,
         #                  num_sp InterTransBlocks of 8-head attention over the 85 tokens of a window + MLP_FFN with Dropout(0.1), windows back, Linear
         #                  to the scale's width -- ahead of four all-spatial bridge layers)
-        # the reference.  Not built: Stage_3or4 = 4 with a non-default aggregate, and the legacy networks/Transception.py class.
+        # the reference.  Not built: the legacy networks/Transception.py class.
         br = [bool(b) for b in br_ch_att_list]
         if (token_mlp_mode not in ("mix_skip", "mix") or concat not in ("coord", "normal", "se", "3d", "skn", "cbam", "cam", "cam_fact")
-                or (Stage_3or4 == 4 and concat != "coord") or len(br) != 4 or (have_bridge == "sp" and int(num_sp) < 0)):
+                or (Stage_3or4 == 4 and concat not in ("coord", "normal", "se", "cbam", "skn")) or len(br) != 4 or (have_bridge == "sp" and int(num_sp) < 0)):
             raise NotImplementedError("MSTransception: implemented are every concat of the reference ('coord', 'normal', 'se', '3d', 'skn', 'cbam', 'cam', 'cam_fact'), have_bridge in {'original', "
-                                      "'None', 'para', 'sp'}, any 4-entry br_ch_att_list, Stage_3or4 in {3, 5} (and 4 with concat = 'coord'), token_mlp_mode in {'mix_skip', 'mix'}")
+                                      "'None', 'para', 'sp'}, any 4-entry br_ch_att_list, Stage_3or4 in {3, 5} (and 4 with concat in {'coord', 'normal', 'se', 'cbam', 'skn'}), token_mlp_mode in {'mix_skip', 'mix'}")
         self.inter = "out"                              # CBAMBlock (Stage_3or4 = 3) gates with the statistics of the gated concatenation
         if Stage_3or4 not in (3, 4):                    # MSViT_casa (MSTr.py:2788-2791: the else branch of 4 / 3)
             if concat not in ("normal", "3d", "se", "skn", "cbam", "cam"):
@@ -428,7 +430,7 @@ class MSTransception(nn.Module):
             raise NotImplementedError("MSTransception(concat='cbam'): sa_ker must be 3 or 7")
         self.token_mlp_mode = token_mlp_mode
         # Stage_3or4 = 4: MSViT_4Stages (MSTr.py:1746-1988) -- a Conv2d_BN stem and a first MHCA stage (two paths, one layer) instead of the
-        # OverlapPatchEmbeddings + EfficientTransformerBlocks; built for the default aggregate
+        # OverlapPatchEmbeddings + EfficientTransformerBlocks
         self.backbone = _mk_backbone4(concat, sa_ker) if Stage_3or4 == 4 else _mk_backbone(concat, use_sa_list, sa_ker, token_mlp_mode)
         self.Stage_3or4 = Stage_3or4
         self.bridge = nn.Module()
@@ -1023,16 +1025,17 @@ def _mhca_stage(M, G, stack: Var, name: str, layers: int, B: int, side: int, out
         pooled = G.chan_pool(cat, B, N)                                          # [B, 4C]: S = mean(sum_k x_k) = sum_k mean(x_k)
         Wf, bf = _lin(M, G, agg + ".fc")
         Z = G.new(B, Wf.data.shape[0])
-        for k in range(4):                                                       # fc(S): the same weight on the four column blocks, accumulated
+        nbr = cat.cols // C                                                      # branch maps: four (three in the first stage of MSViT_4Stages)
+        for k in range(nbr):                                                     # fc(S): the same weight on the column blocks, accumulated
             G.linear(pooled.colslice(k * C, (k + 1) * C), Wf, bf if k == 0 else None, out=Z, accumulate=k > 0)
-        A = G.new(B, 4 * C)
-        for k in range(4):
+        A = G.new(B, nbr * C)
+        for k in range(nbr):
             G.linear(Z, *_lin(M, G, f"{agg}.fcs.{k}"), out=A.colslice(k * C, (k + 1) * C))
-        att = G.softmax(A.reshape(B * 4, C), B, 0).reshape(B, 4 * C)             # softmax over the four paths, per image and channel
+        att = G.softmax(A.reshape(B * nbr, C), B, 0).reshape(B, nbr * C)         # softmax over the paths, per image and channel
         gated = G.chan_gate(cat, att, B, N)
         Wc, bc = _lin(M, G, agg + ".conv_bn_ac.0")
         z = G.new(rows, Wc.data.shape[0])
-        for k in range(4):                                                       # conv(sum_k a_k x_k)
+        for k in range(nbr):                                                     # conv(sum_k a_k x_k)
             G.linear(gated.colslice(k * C, (k + 1) * C), Wc, bc if k == 0 else None, out=z, accumulate=k > 0)
         return _bn(M, G, G.relu(z), agg + ".conv_bn_ac.2", ACT_NONE, out=out)
     if M.concat == "se":                                                         # SE_Block, MSTr.py:584-593
