@@ -615,7 +615,8 @@ int tc_argmax_counts(const void* logits, const long long* labels, unsigned char*
  * Input pipeline (datasets/dataset_synapse.py:101-112, trainer.py:89-93): a batch of raw slices
  * [B,H,W] (image fp32 in [0,1], label uint8 0..8) already in HBM -> network input.
  */
-enum { TC_AUG_WARP = 1, TC_AUG_LINEAR = 2, TC_AUG_BLUR = 4, TC_AUG_PIECEWISE = 8 };
+enum { TC_AUG_WARP = 1, TC_AUG_LINEAR = 2, TC_AUG_BLUR = 4, TC_AUG_PIECEWISE = 8,
+       TC_AUG_SKIP = 1 << 20, TC_AUG_FROM_RAW = 1 << 21 };      /* (rounds of a chain only, see tc_slice_augment_chain) */
 /* Per-slice augmentation record (DEVICE array of B).  Stage order: warp first, then the pixel stages in the order `reserved` encodes
  *   (imgaug's SomeOf(random_order=True) applies its augmenters in the drawn order, dataset_synapse.py:84-95): up to three 2-bit codes,
  *   first stage in the low bits, 1 = blur, 2 = contrast, 3 = noise; reserved = 0 means blur -> contrast -> noise.
@@ -640,6 +641,13 @@ typedef struct TcSliceAug {
 /* img/lab [B,H,W] -> img_out/lab_out (distinct buffers).  H, W >= 9. */
 int tc_slice_augment(const float* img, const unsigned char* lab, const TcSliceAug* aug_dev, float* img_out,
                      unsigned char* lab_out, int B, int H, int W, void* stream);
+/* The stage chains of a batch (imgaug's SomeOf((0, 4), ..., random_order=True), dataset_synapse.py:84-95: every drawn augmenter resamples the
+ * previous one's result) as rounds [first_round, rounds) of launches: aug_dev [rounds][B]; round r writes buffer a (r even) or b (r odd) and
+ * reads the other one, or the raw slice where the record says TC_AUG_FROM_RAW (the first stage of a slice's chain); a record with TC_AUG_SKIP
+ * does nothing (the slice's chain has not started: chains END in the last round, so that the result of every slice lies in the buffer of
+ * round rounds - 1 and no identity copy is needed in between; a slice without stages is copied there once, by a plain FROM_RAW record). */
+int tc_slice_augment_chain(const float* raw_img, const unsigned char* raw_lab, const TcSliceAug* aug_dev, int first_round, int rounds,
+                           float* img_a, unsigned char* lab_a, float* img_b, unsigned char* lab_b, int B, int H, int W, void* stream);
 /* Cubic B-spline coefficients (fp64 [B,H,W]) of fp32 slices: the prefilter half of scipy.ndimage.zoom(order=3)
  * (dataset_synapse.py:111), mirror boundaries, axis 0 then axis 1. */
 int tc_spline_prefilter(const float* img, double* coef, int B, int H, int W, void* stream);

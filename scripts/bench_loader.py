@@ -23,7 +23,7 @@ lab = torch.from_numpy(np.stack([it[1] for it in items[:B]])).to(dev)
 sampler = D.AugmentSampler(1)
 for name, augs in (("no augmentation", None), ("sampled augmentation", [sampler.sample(512, 512) for _ in range(B)]),
                    ("worst case (warp+piecewise+blur+noise on every slice)",
-                    [D.SliceAugmentation(m=D.affine_rotate_xy(20, 512, 512), disp=np.ones((4, 4, 2), np.float32), blur=True, alpha=1.1,
+                    [D.SliceAugmentation(m=D.affine_rotate_xy(20, 512, 512), disp=np.ones((4, 4, 2), np.float32), shape=(512, 512), blur=True, alpha=1.1,
                                          noise_sigma=1.0, noise_seed=i) for i in range(B)])):
     rec, nr = None, None
     if augs is not None:                                         # chains of imgaug stages: one record array per round
@@ -40,6 +40,16 @@ for name, augs in (("no augmentation", None), ("sampled augmentation", [sampler.
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 20
     print(f"device preprocess, B={B}, 512->224, {name}: {ms:.3f} ms/batch = {B / ms * 1e3:.0f} slices/s")
+    if rec is not None:                                          # what a captured step launches: all MAX_ROUNDS rounds, inside a replayed graph
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            D.preprocess_batch(img, lab, None, 224, records=rec, scratch=scratch, rounds=D.MAX_ROUNDS)
+        g.replay(); torch.cuda.synchronize()
+        e0.record()
+        for _ in range(50):
+            g.replay()
+        e1.record(); torch.cuda.synchronize()
+        print(f"    all {D.MAX_ROUNDS} rounds in a replayed graph: {e0.elapsed_time(e1) / 50 * 1e3:.1f} us/batch")
 
 for aug in (False, True):
     loader = D.DeviceLoader(ds, batch_size=B, img_size=224, device=dev, augment=aug, epochs=4)

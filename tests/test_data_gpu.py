@@ -99,18 +99,19 @@ def test_reference_fixture_through_the_device():
             np.testing.assert_array_equal(ol[0].cpu().numpy(), G[f"{tag}/{s}/label"])
 
 
-def _augment_on_device(img, lab, augs):
+def _augment_on_device(img, lab, augs, all_rounds=False):
+    """The slices' stage chains through tc_slice_augment_chain: the rounds the longest chain needs, or (a captured step) all MAX_ROUNDS."""
     B, H, W = img.shape
     d_img, d_lab = _dev(img, lab)
-    rec_np, n = D.pack_rounds(augs)                                  # one launch per round of the slices' stage chains
+    rec_np, n = D.pack_rounds(augs)
     rec = torch.from_numpy(rec_np).to(DEV)
-    for r in range(max(n, 1)):
-        oi, ol = torch.empty_like(d_img), torch.empty_like(d_lab)
-        lib().tc_slice_augment(d_img.data_ptr(), d_lab.data_ptr(), rec[r].data_ptr(), oi.data_ptr(), ol.data_ptr(), B, H, W,
-                               torch.cuda.current_stream().cuda_stream)
-        d_img, d_lab = oi, ol
+    R = D.MAX_ROUNDS
+    n = R if all_rounds else max(n, 1)
+    bufs = [torch.full_like(d_img, float("nan")) for _ in range(2)] + [torch.full_like(d_lab, 255) for _ in range(2)]
+    lib().tc_slice_augment_chain(d_img.data_ptr(), d_lab.data_ptr(), rec.data_ptr(), R - n, R, bufs[0].data_ptr(), bufs[2].data_ptr(),
+                                 bufs[1].data_ptr(), bufs[3].data_ptr(), B, H, W, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    return d_img.cpu().numpy(), d_lab.cpu().numpy()
+    return bufs[(R - 1) & 1].cpu().numpy(), bufs[2 + ((R - 1) & 1)].cpu().numpy()
 
 
 def test_augmentation_stage_matches_oracle():
@@ -144,6 +145,14 @@ def test_augmentation_stage_matches_oracle():
         wi, wl = O.augment_slice(img[b], lab[b].astype(np.uint8), a.as_dict())
         np.testing.assert_array_equal(ol[b], wl, err_msg=f"label of slice {b} ({a.names})")
         np.testing.assert_allclose(oi[b], wi, atol=2e-5, rtol=0, err_msg=f"image of slice {b} ({a.names})")
+    # all MAX_ROUNDS rounds (what a captured step launches whatever the batch holds): the skipped rounds change nothing, bit for bit
+    oi4, ol4 = _augment_on_device(img, lab, augs, all_rounds=True)
+    np.testing.assert_array_equal(oi4, oi)
+    np.testing.assert_array_equal(ol4, ol)
+    # a batch without any stage: one copy per slice, in the last round
+    oi0, ol0 = _augment_on_device(img[:3], lab[:3], [None, D.SliceAugmentation(stages=[]), None], all_rounds=True)
+    np.testing.assert_array_equal(oi0, img[:3])
+    np.testing.assert_array_equal(ol0, lab[:3].astype(np.uint8))
 
 
 def test_loader_batches_match_oracle(tmp_path):

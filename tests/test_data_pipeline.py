@@ -114,6 +114,18 @@ def test_sampler_is_seeded_and_in_range():
     assert seen == set(D.AugmentSampler.NAMES)
     rec, n = D.pack_rounds([a[0], None])
     assert rec.shape == (D.MAX_ROUNDS, 2, 200) and n == len(a[0].stages)
+    # chains end in the last round: skip records before a chain starts, its first stage reads the raw slice, a slice without stages is
+    # copied once in the last round
+    import ctypes
+    from transception_amd._lib import TcSliceAug
+    three = D.SliceAugmentation(stages=[D.SliceAugmentation(blur=True), D.SliceAugmentation(alpha=1.2), D.SliceAugmentation(m=D.affine_flip(0, 64, 64))])
+    rec, n = D.pack_rounds([three, None, D.SliceAugmentation(blur=True)])
+    assert n == 3
+    flags = [[TcSliceAug.from_buffer_copy(rec[r, b].tobytes()).flags for b in range(3)] for r in range(D.MAX_ROUNDS)]
+    S, F = D.TC_AUG_SKIP, D.TC_AUG_FROM_RAW
+    assert [f[0] & (S | F) for f in flags] == [S, F, 0, 0] and flags[1][0] & D.TC_AUG_BLUR and flags[3][0] & D.TC_AUG_WARP
+    assert [f[1] & (S | F | D.TC_AUG_WARP | D.TC_AUG_BLUR) for f in flags] == [S, S, S, F]
+    assert [f[2] & (S | F) for f in flags] == [S, S, S, F] and flags[3][2] & D.TC_AUG_BLUR
     assert D.pack_records([D.SliceAugmentation(blur=True), None]).shape == (2, 200)
 
 

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("TC_LIB_PATH") or os.path.join(HERE, "libtransception_
 
 TC_F32, TC_BF16, TC_F16 = 0, 1, 2
 ACT_NONE, ACT_HSWISH, ACT_COORD, ACT_SIGMOID, ACT_GELU, ACT_SCALE, ACT_RELU = 0, 1, 2, 3, 4, 5, 6
-ABI_VERSION = 13
+ABI_VERSION = 14
 ATTN_DKV_SPLITS = 8                # include/transception_hip.h: partial dK|dV buffers in tc_attn_bwd_seg's fp32 scratch
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_longlong, C.c_float
@@ -102,6 +102,7 @@ class TcSliceAug(C.Structure):
 
 
 TC_AUG_WARP, TC_AUG_LINEAR, TC_AUG_BLUR, TC_AUG_PIECEWISE = 1, 2, 4, 8
+TC_AUG_SKIP, TC_AUG_FROM_RAW = 1 << 20, 1 << 21
 
 # name -> argtypes (every function returns int status unless listed in _RET)
 SIGNATURES = {
@@ -202,6 +203,7 @@ SIGNATURES = {
     "tc_seg_loss_bwd_tok": [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, f32, f32, f32, f32, vp, i32, vp],
     "tc_seg_loss_value": [vp, i32, C.c_double, C.c_double, C.c_double, vp, vp],
     "tc_slice_augment": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "tc_slice_augment_chain": [vp, vp, vp, i32, i32, vp, vp, vp, vp, i32, i32, i32, vp],
     "tc_spline_prefilter": [vp, vp, i32, i32, i32, vp],
     "tc_zoom_normalize": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, f32, vp],
     "tc_sgd_step": [vp, vp, vp, i64, f32, vp, f32, f32, f32, i32, vp],

@@ -6,7 +6,7 @@
 //                               -> Gaussian blur sigma 1 (9 taps, mirror) -> linear contrast -> additive Gaussian noise,
 //                               one 32x32 output tile (+4 halo when blurring) per workgroup, staged in LDS
 //   spline_prefilter_cols/rows  cubic B-spline coefficients of the slice, mirror boundary, fp64 like scipy (ni_splines.c):
-//                               columns in 32-row segments with a 28-row run-in (lanes along x, coalesced), rows one wavefront
+//                               columns in 32-row segments with a 16-row run-in (lanes along x, coalesced), rows one wavefront
 //                               per row as shuffle scans; simple one-thread-per-line kernels for ragged sizes
 //   zoom_sample_kernel          4x4-tap B-spline evaluation at o*(in-1)/(out-1), nearest label, normalise, int64 labels
 //
@@ -20,6 +20,10 @@ namespace {
 constexpr double kPole = -0.26794919243112270647;            // sqrt(3) - 2
 constexpr int kBlurR = 4;
 constexpr int kTile = 32;
+#ifndef TC_AUG_THREADS
+#define TC_AUG_THREADS 256
+#endif
+constexpr int kAugThreads = TC_AUG_THREADS;     // (1024 = a thread per pixel of the tile measured no faster: 163 against 158 us for the four rounds + zoom of a sampled batch)
 
 __device__ __forceinline__ int mirror101(int i, int n) {       // scipy 'mirror' / cv2 BORDER_REFLECT_101
     if (i < 0) i = -i;
@@ -87,7 +91,8 @@ __device__ __forceinline__ unsigned char aug_label_at(const unsigned char* lab, 
     return lab[(long long)iy * W + ix];
 }
 
-__global__ __launch_bounds__(256) void slice_augment_kernel(const float* __restrict__ img, const unsigned char* __restrict__ lab,
+__global__ __launch_bounds__(kAugThreads) void slice_augment_kernel(const float* __restrict__ img, const unsigned char* __restrict__ lab,
+                                                            const float* __restrict__ raw_img, const unsigned char* __restrict__ raw_lab,
                                                             const TcSliceAug* __restrict__ aug, float* __restrict__ oimg,
                                                             unsigned char* __restrict__ olab, int H, int W) {
     constexpr int TS = kTile + 2 * kBlurR;
@@ -95,20 +100,24 @@ __global__ __launch_bounds__(256) void slice_augment_kernel(const float* __restr
     __shared__ float t1[kTile * TS];
     __shared__ TcSliceAug A;
     const int b = blockIdx.z, tid = threadIdx.x;
-    for (int i = tid; i < (int)(sizeof(TcSliceAug) / 4); i += 256) reinterpret_cast<unsigned*>(&A)[i] = reinterpret_cast<const unsigned*>(aug + b)[i];
+    for (int i = tid; i < (int)(sizeof(TcSliceAug) / 4); i += kAugThreads) reinterpret_cast<unsigned*>(&A)[i] = reinterpret_cast<const unsigned*>(aug + b)[i];
     __syncthreads();
-    const float* im = img + (long long)b * H * W;
-    const unsigned char* lb = lab + (long long)b * H * W;
+    // rounds of a chain (tc_slice_augment_chain): a slice with nothing to do this round and nothing to deliver leaves at once; the first
+    // stage of a slice's chain reads the raw slice, later ones the previous round's buffer
+    if (A.flags & TC_AUG_SKIP) return;
+    const bool from_raw = A.flags & TC_AUG_FROM_RAW;
+    const float* im = (from_raw ? raw_img : img) + (long long)b * H * W;
+    const unsigned char* lb = (from_raw ? raw_lab : lab) + (long long)b * H * W;
     const int ty0 = blockIdx.y * kTile, tx0 = blockIdx.x * kTile;
-    // A slice this round does nothing to (the identity record of a slice with fewer stages than the batch's longest chain: about half of all
-    // (slice, round) pairs) is copied in 16-byte pieces: the general path below moves a pixel per thread and step and made an identity round
-    // cost what a warp costs.  (alpha 1 about center 0 and sigma 0 leave every value bit for bit.)
+    // An identity record (a slice without stages on its way to the result buffer, or the plain tc_slice_augment entry given one) is copied in
+    // 16-byte pieces: the general path below moves a pixel per thread and step and made a copy cost what a warp costs.  (alpha 1 about
+    // center 0 and sigma 0 leave every value bit for bit.)
     if (!(A.flags & (TC_AUG_WARP | TC_AUG_BLUR)) && A.alpha == 1.0f && A.center == 0.0f && !(A.noise_sigma > 0.0f) && !(W & 3) && tx0 + kTile <= W) {
         const int ly = tid >> 3, lx = (tid & 7) * 4, oy = ty0 + ly;
-        if (oy < H) {
-            const long long o = ((long long)b * H + oy) * W + tx0 + lx;
-            *reinterpret_cast<float4*>(oimg + o) = *reinterpret_cast<const float4*>(img + o);
-            *reinterpret_cast<uchar4*>(olab + o) = *reinterpret_cast<const uchar4*>(lab + o);
+        if (tid < 256 && oy < H) {
+            const long long o = ((long long)b * H + oy) * W + tx0 + lx, oi = (long long)oy * W + tx0 + lx;
+            *reinterpret_cast<float4*>(oimg + o) = *reinterpret_cast<const float4*>(im + oi);
+            *reinterpret_cast<uchar4*>(olab + o) = *reinterpret_cast<const uchar4*>(lb + oi);
         }
         return;
     }
@@ -148,13 +157,13 @@ __global__ __launch_bounds__(256) void slice_augment_kernel(const float* __restr
         for (int k = 1; k <= kBlurR; ++k) { w[k] = exp(-0.5 * (double)(k * k)); s += 2.0 * w[k]; }
         for (int k = 0; k <= kBlurR; ++k) g[k] = (float)(w[k] / s);
         // warped slice over the tile + halo; positions beyond the slice mirror back into it
-        for (int p = tid; p < TS * TS; p += 256) {
+        for (int p = tid; p < TS * TS; p += kAugThreads) {
             const int ly = p / TS, lx = p % TS;
             const int my = mirror101(ty0 + ly - kBlurR, H), mx = mirror101(tx0 + lx - kBlurR, W);
             t0[p] = pointwise(aug_image_at(im, A, my, mx, H, W), my, mx, pre, npre);
         }
         __syncthreads();
-        for (int p = tid; p < kTile * TS; p += 256) {             // axis 0 first (scipy.ndimage.gaussian_filter order), fp32 intermediate
+        for (int p = tid; p < kTile * TS; p += kAugThreads) {             // axis 0 first (scipy.ndimage.gaussian_filter order), fp32 intermediate
             const int ly = p / TS, lx = p % TS;
             double a = (double)g[0] * (double)t0[(ly + kBlurR) * TS + lx];
             for (int k = 1; k <= kBlurR; ++k) a += (double)g[k] * ((double)t0[(ly + kBlurR + k) * TS + lx] + (double)t0[(ly + kBlurR - k) * TS + lx]);
@@ -162,7 +171,7 @@ __global__ __launch_bounds__(256) void slice_augment_kernel(const float* __restr
         }
         __syncthreads();
     }
-    for (int p = tid; p < kTile * kTile; p += 256) {
+    for (int p = tid; p < kTile * kTile; p += kAugThreads) {
         const int ly = p / kTile, lx = p % kTile, oy = ty0 + ly, ox = tx0 + lx;
         if (oy >= H || ox >= W) continue;
         float v;
@@ -236,9 +245,10 @@ __global__ __launch_bounds__(256) void spline_prefilter_cols_kernel(const float*
     }
 }
 
-// Columns of at least 128 rows, a multiple of 32: the pole's impulse response dies out in 28 samples (|z|^28 = 1e-16), so a thread
-// can produce 32 consecutive coefficients of a column from a 28-row run-in above and below them -- 16x the threads of the
-// one-thread-per-column form, each with a short dependency chain.  The first segment starts from the exact mirror sum, the
+// Columns of at least 128 rows, a multiple of 32: the pole's impulse response is down to |z|^16 = 7e-10 after 16 samples -- a hundredth of
+// the float32 resolution of the zoomed slice these coefficients are for -- so a thread can produce 32 consecutive coefficients of a column
+// from a 16-row run-in above and below them (with a 28-row run-in, 1e-16, it read 2.75 instead of 2 rows per row written: prefilter + zoom
+// of sixteen 512 x 512 slices 98 -> 71 us) -- 16x the threads of the one-thread-per-column form, each with a short dependency chain.  The first segment starts from the exact mirror sum, the
 // last one ends with the exact anti-causal initial value.
 template <int L, int WU>
 __global__ __launch_bounds__(256) void spline_prefilter_cols_seg_kernel(const float* __restrict__ img, double* __restrict__ coef, int B, int H, int W) {
@@ -491,16 +501,32 @@ extern "C" int tc_slice_augment(const float* img, const unsigned char* lab, cons
                                 unsigned char* lab_out, int B, int H, int W, void* stream) {
     if (!img || !lab || !aug_dev || !img_out || !lab_out || B <= 0 || H < 2 * kBlurR + 1 || W < 2 * kBlurR + 1) return TC_ERR_ARG;
     if (img == img_out || lab == lab_out) return TC_ERR_ARG;        // the warp gathers: not in place
-    hipLaunchKernelGGL(slice_augment_kernel, dim3((W + kTile - 1) / kTile, (H + kTile - 1) / kTile, B), dim3(256), 0, (hipStream_t)stream,
-                       img, lab, aug_dev, img_out, lab_out, H, W);
+    hipLaunchKernelGGL(slice_augment_kernel, dim3((W + kTile - 1) / kTile, (H + kTile - 1) / kTile, B), dim3(kAugThreads), 0, (hipStream_t)stream,
+                       img, lab, img, lab, aug_dev, img_out, lab_out, H, W);
     return tc_launch_status();
+}
+
+extern "C" int tc_slice_augment_chain(const float* raw_img, const unsigned char* raw_lab, const TcSliceAug* aug_dev, int first_round,
+                                      int rounds, float* img_a, unsigned char* lab_a, float* img_b, unsigned char* lab_b, int B, int H,
+                                      int W, void* stream) {
+    if (!raw_img || !raw_lab || !aug_dev || !img_a || !lab_a || !img_b || !lab_b || B <= 0 || H < 2 * kBlurR + 1 || W < 2 * kBlurR + 1) return TC_ERR_ARG;
+    if (first_round < 0 || rounds < first_round || img_a == img_b || lab_a == lab_b || raw_img == img_a || raw_img == img_b || raw_lab == lab_a || raw_lab == lab_b)
+        return TC_ERR_ARG;
+    for (int r = first_round; r < rounds; ++r) {                    // round r: reads the buffer round r - 1 wrote (or the raw slice), writes the other
+        const bool odd = r & 1;
+        hipLaunchKernelGGL(slice_augment_kernel, dim3((W + kTile - 1) / kTile, (H + kTile - 1) / kTile, B), dim3(kAugThreads), 0, (hipStream_t)stream,
+                           odd ? img_a : img_b, odd ? lab_a : lab_b, raw_img, raw_lab, aug_dev + (long long)r * B, odd ? img_b : img_a,
+                           odd ? lab_b : lab_a, H, W);
+        if (tc_launch_status() != TC_OK) return TC_ERR_LAUNCH;
+    }
+    return TC_OK;
 }
 
 extern "C" int tc_spline_prefilter(const float* img, double* coef, int B, int H, int W, void* stream) {
     if (!img || !coef || B <= 0 || H <= 0 || W <= 0) return TC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (H >= 128 && H % 32 == 0)
-        hipLaunchKernelGGL((spline_prefilter_cols_seg_kernel<32, 28>), dim3((unsigned)(((long long)B * W * (H / 32) + 255) / 256)), dim3(256), 0, s,
+        hipLaunchKernelGGL((spline_prefilter_cols_seg_kernel<32, 16>), dim3((unsigned)(((long long)B * W * (H / 32) + 255) / 256)), dim3(256), 0, s,
                            img, coef, B, H, W);
     else
         hipLaunchKernelGGL(spline_prefilter_cols_kernel, dim3((unsigned)(((long long)B * W + 255) / 256)), dim3(256), 0, s, img, coef, B, H, W);

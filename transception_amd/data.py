@@ -28,7 +28,7 @@ import numpy as np
 import torch
 from scipy import special
 
-from ._lib import TC_AUG_BLUR, TC_AUG_LINEAR, TC_AUG_PIECEWISE, TC_AUG_WARP, TcSliceAug, lib
+from ._lib import TC_AUG_BLUR, TC_AUG_FROM_RAW, TC_AUG_LINEAR, TC_AUG_PIECEWISE, TC_AUG_SKIP, TC_AUG_WARP, TcSliceAug, lib
 
 NOISE_SCALE = 0.005 * 255          # AdditiveGaussianNoise(scale=0.005*255), dataset_synapse.py:87 -- applied to [0,1] floats as is
 
@@ -381,8 +381,8 @@ def preprocess_batch(images: torch.Tensor, labels: torch.Tensor, augs: Optional[
                      out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, rounds: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Raw slices in HBM -> network input, on the current stream.  images float32 [B,H,W], labels uint8 [B,H,W];
     `augs` one SliceAugmentation (or None) per slice, or None for no augmentation at all; alternatively `records` = the
-    TcSliceAug array already on the device (uint8 [B, sizeof], or [MAX_ROUNDS, B, sizeof] with `rounds` of them in use: one
-    tc_slice_augment launch per round, each resampling the previous round's result).  Returns x float32 [B,1,size,size], y int64
+    TcSliceAug array already on the device (uint8 [B, sizeof], or pack_rounds' [MAX_ROUNDS, B, sizeof] of which the LAST `rounds` are
+    launched: one launch per round, each slice's stage resampling its previous stage's result -- tc_slice_augment_chain).  Returns x float32 [B,1,size,size], y int64
     [B,size,size]."""
     if not images.is_cuda:
         raise RuntimeError("transception_amd.data preprocesses on MI355X only (no CPU fallback)")
@@ -403,13 +403,18 @@ def preprocess_batch(images: torch.Tensor, labels: torch.Tensor, augs: Optional[
     if records is None and augs is not None and any(a is not None for a in augs):
         rec_np, rounds = pack_rounds(augs)
         records = torch.from_numpy(rec_np).to(dev)
-    if records is not None:
-        if records.dim() == 2:
-            records, rounds = records.unsqueeze(0), 1
-        for r in range(int(rounds if rounds is not None else records.shape[0])):
-            img2, lab2 = buf(f"aug_img{r & 1}", (B, H, W), torch.float32), buf(f"aug_lab{r & 1}", (B, H, W), torch.uint8)
-            L.tc_slice_augment(images.data_ptr(), labels.data_ptr(), records[r].data_ptr(), img2.data_ptr(), lab2.data_ptr(), B, H, W, stream)
-            images, labels = img2, lab2
+    if records is not None and records.dim() == 2:                # one single-stage record per slice
+        img2, lab2 = buf("aug_img1", (B, H, W), torch.float32), buf("aug_lab1", (B, H, W), torch.uint8)
+        L.tc_slice_augment(images.data_ptr(), labels.data_ptr(), records.data_ptr(), img2.data_ptr(), lab2.data_ptr(), B, H, W, stream)
+        images, labels = img2, lab2
+    elif records is not None:                                     # chains (pack_rounds): the last `rounds` of the MAX_ROUNDS rounds
+        R = int(records.shape[0])
+        n = R if rounds is None else int(rounds)
+        if n > 0:
+            bufs = [buf(f"aug_img{i}", (B, H, W), torch.float32) for i in (0, 1)] + [buf(f"aug_lab{i}", (B, H, W), torch.uint8) for i in (0, 1)]
+            L.tc_slice_augment_chain(images.data_ptr(), labels.data_ptr(), records.data_ptr(), R - n, R, bufs[0].data_ptr(), bufs[2].data_ptr(),
+                                     bufs[1].data_ptr(), bufs[3].data_ptr(), B, H, W, stream)
+            images, labels = bufs[(R - 1) & 1], bufs[2 + ((R - 1) & 1)]
     x, y = out if out is not None else (torch.empty((B, 1, size, size), dtype=torch.float32, device=dev),
                                         torch.empty((B, size, size), dtype=torch.int64, device=dev))
     if H != size or W != size:
@@ -431,21 +436,29 @@ def pack_records(augs: Sequence[Optional[SliceAugmentation]]) -> np.ndarray:
 
 
 def pack_rounds(augs: Sequence[Optional[SliceAugmentation]]) -> Tuple[np.ndarray, int]:
-    """(uint8 [MAX_ROUNDS, B, sizeof(TcSliceAug)], rounds in use): round r holds stage r of every slice's chain (the identity record
-    for a slice with fewer stages: flags 0 copies the slice exactly)."""
+    """(uint8 [MAX_ROUNDS, B, sizeof(TcSliceAug)], n = the longest chain) for tc_slice_augment_chain.  Chains END in the last round: stage
+    j of a chain of k stages sits in round MAX_ROUNDS - k + j, its first stage marked TC_AUG_FROM_RAW (it reads the raw slice); the rounds
+    before a chain starts hold TC_AUG_SKIP records (nothing is read or written: no identity copies between the ping-pong buffers), and a
+    slice without stages is copied once, in the last round (identity record | TC_AUG_FROM_RAW).  Every slice's result is then in the
+    buffer the last round writes, whichever of rounds [MAX_ROUNDS - n, MAX_ROUNDS) -- or all of them, in a captured step -- are launched."""
     chains = [(a.rounds() if a is not None else []) for a in augs]
     n = max([len(c) for c in chains] + [0])
     assert n <= MAX_ROUNDS
-    out = np.empty((MAX_ROUNDS, len(augs), ctypes.sizeof(TcSliceAug)), np.uint8)
-    ident = None
-    for r in range(MAX_ROUNDS):                                   # rounds past n hold identity records too: a captured step runs all of them
-        if r < n:
-            out[r] = pack_records([c[r] if r < len(c) else None for c in chains])
-        else:
-            if ident is None:
-                ident = pack_records([None] * len(augs))
-            out[r] = ident
-    return out, n
+    sz = ctypes.sizeof(TcSliceAug)
+    arr = ((TcSliceAug * len(augs)) * MAX_ROUNDS)()
+    for b, c in enumerate(chains):
+        k = len(c)
+        for r in range(MAX_ROUNDS):
+            j = r - (MAX_ROUNDS - k)
+            if j >= 0:
+                rec = c[j].record()
+                if j == 0:
+                    rec.flags |= TC_AUG_FROM_RAW
+            else:
+                rec = SliceAugmentation().record()
+                rec.flags |= (TC_AUG_FROM_RAW if (k == 0 and r == MAX_ROUNDS - 1) else TC_AUG_SKIP)
+            arr[r][b] = rec
+    return np.frombuffer(bytes(arr), np.uint8).reshape(MAX_ROUNDS, len(augs), sz).copy(), n
 
 
 def epoch_order(n: int, epoch: int, seed: int, shuffle: bool = True) -> np.ndarray:
@@ -694,8 +707,8 @@ class DeviceLoader:
 
     def slot_preprocess(self, slot: dict):
         """pre(x, y) for train.GraphedStep: the preprocessing launches of the batch in `slot` (always MAX_ROUNDS augmentation rounds --
-        the count must not depend on the batch inside a captured graph; unused rounds hold identity records, which copy), writing the
-        network input into x / y."""
+        the count must not depend on the batch inside a captured graph; a slice's chain ends in the last round and the rounds before it
+        starts hold skip records: pack_rounds), writing the network input into x / y."""
         d_img, d_lab, d_rec = slot["raw"]
         scratch, size, aug = slot["scratch"], self.size, self.augment
 
