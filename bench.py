@@ -425,9 +425,13 @@ ATTN_KERNEL = ("attn_fwd_asm_kernel (bridge SR-attention forward, QK^T + softmax
                "hand-scheduled gfx950 stream of csrc/gen_attn_asm.py -- TC_ATTN_FWD_ASM=0 selects the compiler-scheduled attn_fwd_seg_kernel)")
 
 
-def _graph_replay_us(fn, n: int, dev) -> float:
+def _graph_replay_us(fn, n: int, dev, settle_s: float = 0.3, timed_s: float = 0.1, burst: dict | None = None) -> float:
     """Average duration of fn's launches when n of them run back-to-back inside one replayed hipGraph (HIP events on the stream
-    the graph is launched on)."""
+    the graph is launched on), in the STEADY state: the graph is replayed for `settle_s` seconds first and then timed over
+    enough replays to fill `timed_s`.  Round 6 measured why (scripts/exp/attn_power.py, profiles/r6_attn_fwd_sustained_power.txt):
+    the MFMA streams run against the package power limit (~1300 W, sclk ~2.1 GHz on random operands), and a single 30-launch
+    replay after an idle gap (what rounds 2-5 timed) is over before the clock has settled -- it read 25.6 us for a kernel that
+    sustains 22.6-24.2 us.  The single-replay figure is still taken and returned through `burst` for continuity."""
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -442,7 +446,24 @@ def _graph_replay_us(fn, n: int, dev) -> float:
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); g.replay(); e1.record()
     torch.cuda.synchronize(dev)
-    return e0.elapsed_time(e1) * 1e3 / n
+    one = e0.elapsed_time(e1) * 1e-3                      # seconds per replay, cold clocks
+    if burst is not None:
+        burst["single_replay_us"] = one * 1e6 / n
+    if settle_s <= 0:
+        return one * 1e6 / n
+    chunk = max(1, int(0.02 / max(one, 1e-6)))            # ~20 ms of replays between host synchronisations
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < settle_s:
+        for _ in range(chunk):
+            g.replay()
+        torch.cuda.synchronize(dev)
+    reps = max(1, int(timed_s / max(one, 1e-6)))
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return e0.elapsed_time(e1) * 1e3 / (n * reps)
 
 
 def side_figures(args, dev, model, loss_fn, opt, step, x, y, build_model, engine, train_step, GraphedStep, FusedSGD, SegLoss, extra_step_seconds=()):
@@ -684,16 +705,20 @@ def side_figures(args, dev, model, loss_fn, opt, step, x, y, build_model, engine
         def attn():
             L.tc_attn_fwd_seg(q.data_ptr(), 64, kv.data_ptr(), 128, kv[:, 64:].data_ptr(), 128, Nk * 128, o.data_ptr(), 64, lse.data_ptr(),
                               Bq, 4, nqc, Nk, 0.125, 1, tcd, torch.cuda.current_stream(dev).cuda_stream)   # qscaled = 1: as the model calls it
-        us = _graph_replay_us(attn, 30, dev)
+        burst_f = {}
+        us = _graph_replay_us(attn, 30, dev, burst=burst_f)
         fl = 4.0 * rows * Nk * 64
         ins = roofs.get("roofline_in_step_events", {})
         roofs["roofline"] = {"bound": "mfma", "kernel": ATTN_KERNEL,
                              "achieved": fl / us / 1e6, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                              "frac": fl / us / 1e6 / PEAK_TFLOPS[args.dtype], "avg_launch_us": us, "algorithmic_flops_per_launch": fl,
+                             "single_cold_replay_us": burst_f.get("single_replay_us"),
                              "traffic": ins.get("traffic"), "traffic_source": ins.get("traffic_source"), "traffic_stale": bool(ins.get("traffic_stale")),
-                             "how": "HIP events on the launching stream around 30 back-to-back launches of the kernel inside one replayed hipGraph, step-shaped "
-                                    "random operands (no event-pair floor in the figure; agrees with the rocprofv3 average in profiles/); the per-launch "
-                                    "event figure of instrumented eager steps, which includes event_pair_floor_us, is roofline_in_step_events"}
+                             "how": "HIP events on the launching stream around back-to-back launches of the kernel (30 per replayed hipGraph), step-shaped "
+                                    "RANDOM operands, steady state: 0.3 s of replays first, then 0.1 s timed (the stream runs against the package power "
+                                    "limit, ~2.1 GHz at ~1300 W; single_cold_replay_us is the one replay after an idle gap that rounds 2-5 reported; on "
+                                    "all-zero operands the same kernel holds 2.4 GHz at ~990 W and takes ~19.8 us: profiles/r6_attn_fwd_sustained_power.txt). "
+                                    "The per-launch event figure of instrumented eager steps, which includes event_pair_floor_us, is roofline_in_step_events"}
         roofs["roofline_graph_replay"] = dict(roofs["roofline"], note="the same figure as `roofline` under a name that says how it is taken (the key `roofline` "
                                               "carried the in-step event figure until round 2; that one is roofline_in_step_events)")
         # the backward of the same call, the same way (dQ stream -- it also makes the row deltas -- dK/dV stream, partial fold)
@@ -706,13 +731,14 @@ def side_figures(args, dev, model, loss_fn, opt, step, x, y, build_model, engine
             L.tc_attn_bwd_seg(q.data_ptr(), 64, kv.data_ptr(), 128, kv[:, 64:].data_ptr(), 128, Nk * 128, o.data_ptr(), 64, do.data_ptr(), 64, lse.data_ptr(),
                               delta.data_ptr(), dkv32.data_ptr(), dq.data_ptr(), 64, dkv.data_ptr(), 128, dkv[:, 64:].data_ptr(), 128, Nk * 128, Bq, 4, nqc, Nk,
                               0.125, 1, tcd, torch.cuda.current_stream(dev).cuda_stream)
-        usb = _graph_replay_us(attn_bwd, 20, dev)
+        burst_b = {}
+        usb = _graph_replay_us(attn_bwd, 20, dev, burst=burst_b)
         flb = 10.0 * rows * Nk * 64
         roofs["roofline_attn_bwd_graph_replay"] = {
             "bound": "mfma", "kernel": "tc_attn_bwd_seg: attn_bwd_dq_asm_kernel (S, dP, dQ products + the row deltas) + attn_bwd_dkv_asm_kernel (S, dP, dV, dK "
                                        "products) + attn_dkv_store_kernel; hand-scheduled streams of csrc/gen_dq_asm.py / gen_dkv_asm.py",
             "achieved": flb / usb / 1e6, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s", "frac": flb / usb / 1e6 / PEAK_TFLOPS[args.dtype],
-            "avg_launch_us": usb, "algorithmic_flops_per_launch": flb,
+            "avg_launch_us": usb, "algorithmic_flops_per_launch": flb, "single_cold_replay_us": burst_b.get("single_replay_us"),
             "frac_counting_4_products": 0.8 * flb / usb / 1e6 / PEAK_TFLOPS[args.dtype],
             "how": "as roofline: 20 back-to-back calls inside one replayed hipGraph; flops = the five products a backward without stored "
                    "probabilities needs (S, dP, dV, dQ, dK; frac_counting_4_products leaves S out); 7 products are executed (each stream "

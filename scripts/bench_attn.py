@@ -1,4 +1,6 @@
-"""Micro-benchmark of the bridge SR-attention launches at the bench shape (B=16, 224^2): HIP-event timing, 30 iterations."""
+"""Micro-benchmark of the bridge SR-attention launches at the bench shape (B=16, 224^2): HIP-event timing in the steady state (round 6:
+the streams run against the package power limit, a 30-launch burst after an idle gap is over before the clock settles -- TC_BENCH_ITERS launches
+back to back, default 2000 forward / 600 backward after a quarter of that as warm-up; TC_BENCH_ITERS=30 restores the burst of rounds 2-5)."""
 import ctypes as C, sys, torch
 sys.path.insert(0, "/root/repo")
 from transception_amd._lib import lib, TC_BF16, TC_F32
@@ -22,11 +24,12 @@ def fwd(): L.tc_attn_fwd_seg(q.data_ptr(), d, k.data_ptr(), 2 * d, v.data_ptr(),
 def bwd(): L.tc_attn_bwd_seg(q.data_ptr(), d, k.data_ptr(), 2 * d, v.data_ptr(), 2 * d, Nk * 2 * d, o.data_ptr(), d, do.data_ptr(), d, lse.data_ptr(), delta.data_ptr(), dkv32.data_ptr(),
                              dq.data_ptr(), d, dkv.data_ptr(), 2 * d, dkv[:, d:].data_ptr(), 2 * d, Nk * 2 * d, B, 4, nqc, Nk, 0.125, QS, dt, st)
 for name, fn, fl in (("fwd", fwd, 4.0 * rows * Nk * d), ("bwd", bwd, 10.0 * rows * Nk * d)):
-    for _ in range(5): fn()
+    it = int(os.environ.get("TC_BENCH_ITERS", "2000" if name == "fwd" else "600"))
+    for _ in range(max(5, it // 4)): fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(30): fn()
+    for _ in range(it): fn()
     e1.record(); torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / 30
+    us = e0.elapsed_time(e1) * 1e3 / it
     print(f"attn {name} {dtype}: {us:8.1f} us/launch  {fl / us / 1e6:8.1f} TFLOP/s")

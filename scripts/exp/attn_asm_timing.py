@@ -34,6 +34,10 @@ for so in sorted(glob.glob(os.path.join(here, "libattn_timing_*.so"))):
   for i, n in enumerate(names):
     print(f"  {n:45s} {np.median(dt[:, i]):9.0f} {dt[:, i].min():9d} {dt[:, i].max():9d}")
   tot = (t[:, 7] - t[:, 0]) & 0xffffffff
+  if "--by-wave" in sys.argv:                 # loop cycles by wave index (mean over the 256 workgroups): which waves of a SIMD run ahead
+    lw = dt[:, 3].reshape(256, 12)
+    print("  loop cycles by wave (mean over workgroups):", " ".join(f"{x:.0f}" for x in lw.mean(axis=0)))
+    print("  start of the loop relative to the workgroup's first wave, by wave:", " ".join(f"{x:.0f}" for x in ((t[:, 3].reshape(256, 12) - t[:, 3].reshape(256, 12).min(axis=1, keepdims=True)) & 0xffffffff).mean(axis=0)))
   print(f"  per loop iteration (one 32-key sub-tile of one wave): {np.median(dt[:, 3]) / 23:.0f} cycles; whole wave {np.median(tot):.0f}")
 sys.exit(0)
 f = L.tc_attn_fwd_seg

@@ -314,16 +314,12 @@ __global__ __launch_bounds__(AS_NW * 64, 1) void attn_fwd_asm_kernel(const bf16_
         const int step = __builtin_amdgcn_readfirstlane(32 * ld * 2);
         const int wex = __builtin_amdgcn_readfirstlane(role < 2 ? -1 : 0);
         const long long wexec = ((long long)wex << 32) | (unsigned)wex;
-        // selector operand of the row-sum MFMAs (gen_attn_asm.py::mfma_rowsum): A[m][k group g] of a 16x16x32 product, lane = 16 g + m -- ones where
-        // (m % 4 == 0 and g even) or (m % 4 == 1 and g odd), so D rows 4 g' hold the sums of query lane % 16 and rows 4 g' + 1 those of lane % 16 + 16
-        const unsigned one2 = std::is_same<H, f16_t>::value ? 0x3C003C00u : 0x3F803F80u;
-        const unsigned sel = ((lane & 3) == ((lane >> 4) & 1)) ? one2 : 0u;
         if (std::is_same<H, f16_t>::value)
             asm volatile(TC_ATTN_FWD_ASM_F16 : "+v"(goff) : "v"(kbase), "v"(vbase), "v"(wbase), "v"(qaddr), "v"(oaddr), "v"(lseaddr), "v"(mask),
-                         "s"(rsrc), "s"(nsub), "s"(step), "s"(wexec), "v"(sel) : TC_ATTN_FWD_ASM_CLOBBERS);
+                         "s"(rsrc), "s"(nsub), "s"(step), "s"(wexec) : TC_ATTN_FWD_ASM_CLOBBERS);
         else
             asm volatile(TC_ATTN_FWD_ASM_BF16 : "+v"(goff) : "v"(kbase), "v"(vbase), "v"(wbase), "v"(qaddr), "v"(oaddr), "v"(lseaddr), "v"(mask),
-                         "s"(rsrc), "s"(nsub), "s"(step), "s"(wexec), "v"(sel) : TC_ATTN_FWD_ASM_CLOBBERS);
+                         "s"(rsrc), "s"(nsub), "s"(step), "s"(wexec) : TC_ATTN_FWD_ASM_CLOBBERS);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

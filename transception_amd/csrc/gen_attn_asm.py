@@ -46,10 +46,6 @@ DEFER = bool(int(os.environ.get("TC_ATTN_DEFER", "0")))   # experiment: ring sto
 #   iteration (stores run AHEAD - 1 ahead; with TC_ATTN_AHEAD=7 and -DTC_AS_AHEAD=7, scripts/exp/build_fwd_variant.sh): 25.6 vs 25.7 us -- the
 #   wait for the global load is not what an iteration waits for
 
-ROWSUM_MFMA = bool(int(os.environ.get("TC_ATTN_ROWSUM_MFMA", "1")))   # row sums of P by two 16x16x32 MFMAs per sub-tile against a 0 / 1 selector operand
-#   (round 6): the 16 v_add_f32 per sub-tile leave the VALU stream -- see rowsum_items().  0 restores the VALU row sum (the round-4 stream).
-PHASE = bool(int(os.environ.get("TC_ATTN_PHASE", "1"))) and ROWSUM_MFMA   # phase-split iterations (round 6, iteration_ps()): a VALU / LDS phase, then all ten
-#   MFMAs of the sub-tile back to back -- see iteration_ps().  0: the round-4 stream (every MFMA group carries another sub-tile's softmax).
 TIMING = bool(int(os.environ.get("TC_ATTN_TIMING", "0")))       # experiment builds: s_memtime stamps at section boundaries
 NSTAMP = 6
 ABLATE = os.environ.get("TC_ATTN_ABLATE", "")                    # timing experiments only (wrong results): noexp, novalu, nomfma, nostage, nobar
@@ -74,19 +70,17 @@ P = 32                                       # packed P: two B operands of 4    
 ST = 40                                      # ring staging (one 16-byte chunk per thread of waves 0-7)       4
 L, M, RS, T0, T1, T2, T3, T4 = 44, 45, 46, 47, 48, 49, 50, 51
 AK, AV, AW, MSK = 52, 53, 54, 55             # LDS addresses of the current ring slots (the subroutines own T0..T4); tail mask
-L1, TS = RS, T1                              # ROWSUM_MFMA: L = row sum of queries lane % 16, L1 = of queries lane % 16 + 16 (in RS's place); TS = the sub-tile's
-NV = 56                                      #   sums, a 16x16 D tile in T1..T4 (dead between the pack and the next softmax; the rare path is done with them before its own sums)
+NV = 56
 # AGPRs (at three waves per SIMD hipcc splits the 168 registers of a wave 84 / 84, so the MFMA-only operands live here)
 def O(blk): return 16 * blk                  # O^T accumulators                                              32
 def QF(ks): return 32 + 4 * ks               # Q fragments                                                   16
 def KF(ks): return 48 + 4 * ks               # K fragments of the next sub-tile                              16
 def VF(f): return 64 + 4 * f                 # V^T fragments, f = 2 * k2 + blk                                16
-SEL = 80                                     # ROWSUM_MFMA: the selector A operand of the row-sum MFMAs            4
-NA = 84 if ROWSUM_MFMA else 80
+NA = 80
 # operands of the asm statement: %0 is the only output ("+v": the global offset of this thread's staging chunk, advanced per iteration)
-OP_GOFF, OP_KBASE, OP_VBASE, OP_WBASE, OP_QADDR, OP_OADDR, OP_LSEADDR, OP_MASK, OP_RSRC, OP_NSUB, OP_STEP, OP_WEXEC, OP_SEL = (f"%{i}" for i in range(13))
-S_CNT, S_THR, S_SV, S_SK, S_SW, S_PH, S_RA, S_LN2, S_STEP, S_CC = 60, 61, 62, 63, 64, 65, 66, 68, 69, 70
-SGPRS = list(range(60, 72))
+OP_GOFF, OP_KBASE, OP_VBASE, OP_WBASE, OP_QADDR, OP_OADDR, OP_LSEADDR, OP_MASK, OP_RSRC, OP_NSUB, OP_STEP, OP_WEXEC = (f"%{i}" for i in range(12))
+S_CNT, S_THR, S_SV, S_SK, S_SW, S_PH, S_RA, S_LN2, S_STEP = 60, 61, 62, 63, 64, 65, 66, 68, 69
+SGPRS = list(range(60, 70))
 if TIMING:
     SGPRS = list(range(60, 72 + 2 * NSTAMP))
 
@@ -202,19 +196,6 @@ class Gen:
         self.emit(f"v_mfma_f32_32x32x16_{self.half} {(areg if acc_d else vreg)(d, 16)}, {areg(a, 4)}, {(areg if b_acc else vreg)(b, 4)}, "
                   f"{(areg if acc_d else vreg)(c, 16)}", "mfma", an + bn + cn, dn)
 
-    def mfma_rowsum(self, k2):
-        """TS (+)= SEL x P[k2]: v_mfma_f32_16x16x32 reads the four P registers of key half k2 as its B operand -- lane l as column l % 16,
-        k group l / 16 -- so a column collects the lanes l % 16 + {0, 32} (query l % 16) and + {16, 48} (query l % 16 + 16); the
-        selector A operand keeps the even groups in rows 4 g and the odd ones in rows 4 g + 1: TS+0 = sum over the 16 keys of query
-        lane % 16, TS+1 = of query lane % 16 + 16, in every lane."""
-        if "nomfma" in ABLATE:
-            return
-        b = regs("v", P + 4 * k2, 4)
-        d = regs("v", TS, 4)
-        c = "0" if k2 == 0 else vreg(TS, 4)
-        self.emit(f"v_mfma_f32_16x16x32_{self.half} {vreg(TS, 4)}, {areg(SEL, 4)}, {vreg(P + 4 * k2, 4)}, {c}", "mfma",
-                  regs("a", SEL, 4) + b + (d if k2 else []), d)
-
     def valu(self, text, rd=(), wr=(), trans=False):
         if trans and "noexp" in ABLATE:
             text, trans = text.replace("v_exp_f32_e32", "v_mov_b32_e32"), False
@@ -283,8 +264,6 @@ def mask_items(g, src):
 def exp_sum_items(g):
     """exp2 in place and the 16-key row sum into RS: 16 + 15 instructions, each sum two instructions behind its exp."""
     def ex(r): return lambda: g.valu(f"v_exp_f32_e32 {vreg(S + r)}, {vreg(S + r)}", [vreg(S + r)], [vreg(S + r)], trans=True)
-    if ROWSUM_MFMA:
-        return [ex(r) for r in range(16)]
     def ad(r): return lambda: g.valu(f"v_add_f32_e32 {vreg(RS)}, {vreg(RS)}, {vreg(S + r)}", [vreg(RS), vreg(S + r)], [vreg(RS)])
     it = [ex(0), ex(1), ex(2), lambda: g.valu(f"v_add_f32_e32 {vreg(RS)}, {vreg(S)}, {vreg(S + 1)}", regs("v", S, 2), [vreg(RS)])]
     for r in range(3, 16):
@@ -306,8 +285,6 @@ def sm_items(g, mode):
     if mode == "first":
         it.append(lambda: g.emit(f"s_call_b64 s[{S_RA}:{S_RA + 1}], .Lfirst_%=", "call"))
     it += exp_sum_items(g)
-    if ROWSUM_MFMA:
-        return it                              # the row sums and the overflow check follow the pack: rowsum_items()
     if mode != "first":
         def check():                           # one unit: nothing may be scheduled between the branch and its target
             g.valu(f"v_cmp_ngt_f32_e32 vcc, s{S_THR}, {vreg(RS)}", [vreg(RS)], ["vcc"])
@@ -320,28 +297,6 @@ def sm_items(g, mode):
     return it
 
 
-def rowsum_items(g, mode):
-    """ROWSUM_MFMA: after the pack of P(j+1) -- (the two row-sum MFMAs, the closures that follow them).  The check compares the
-    sub-tile's two sums per lane with REREF exactly as the VALU form compares its one: a sum that large (or inf / NaN) means a score
-    outgrew the reference exponent; PV(j+1) has not been issued, so O is intact, and the rare path redoes the whole sub-tile
-    (scores, reference, exp2, pack, sums) and the QK(j+2) MFMAs issued since.  Then L += TS."""
-    mf = [lambda k2=k2: g.mfma_rowsum(k2) for k2 in range(2)]
-    it = []
-    if mode != "first" and "novalu" not in ABLATE:
-        def check():                           # one unit: nothing may be scheduled between the branch and its target
-            g.valu(f"v_cmp_ngt_f32_e64 s[{S_CC}:{S_CC + 1}], s{S_THR}, {vreg(TS)}", [vreg(TS)], ["scc_pair"])
-            g.valu(f"v_cmp_ngt_f32_e32 vcc, s{S_THR}, {vreg(TS + 1)}", [vreg(TS + 1)], ["vcc"])
-            g.salu(f"s_or_b64 vcc, vcc, s[{S_CC}:{S_CC + 1}]")
-            g.emit(f"s_cbranch_vccz .Lskip{g.uid}_%=", "branch", ["vcc"])
-            g.emit(f"s_call_b64 s[{S_RA}:{S_RA + 1}], .Lslow_%=", "call")
-            g.label(f".Lskip{g.uid}_%=")
-            g.uid += 1
-        it.append(check)
-    it.append(lambda: g.valu(f"v_add_f32_e32 {vreg(L)}, {vreg(L)}, {vreg(TS)}", [vreg(L), vreg(TS)], [vreg(L)]))
-    it.append(lambda: g.valu(f"v_add_f32_e32 {vreg(L1)}, {vreg(L1)}, {vreg(TS + 1)}", [vreg(L1), vreg(TS + 1)], [vreg(L1)]))
-    return mf, it
-
-
 def pack_items(g):
     if "dot2" in ABLATE:
         d2 = "v_dot2c_f32_bf16" if "dot2c" in ABLATE else "v_dot2_f32_bf16"
@@ -352,14 +307,13 @@ def pack_items(g):
             for q in range(8)]
 
 
-def group(g, mfmas, free, head=(), tail=()):
-    """head: closures before the first MFMA; mfmas: closures; free: ordered closures spread evenly over the gaps after the MFMAs;
-    tail: closures behind everything else."""
+def group(g, mfmas, free, head=()):
+    """head: closures before the first MFMA; mfmas: closures; free: ordered closures spread evenly over the gaps after the MFMAs."""
     for f in head:
         f()
     n = len(mfmas)
     if n == 0:
-        for f in list(free) + list(tail):
+        for f in free:
             f()
         return
     per = [len(free) // n + (1 if k < len(free) % n else 0) for k in range(n)]
@@ -369,8 +323,6 @@ def group(g, mfmas, free, head=(), tail=()):
         for f in free[pos: pos + per[k]]:
             f()
         pos += per[k]
-    for f in tail:
-        f()
 
 
 def iteration(g, mode):
@@ -414,8 +366,6 @@ def iteration(g, mode):
     free = [] if drain else sm_items(g, mode)
     if not (last or drain):                    # K(j+2) fragments: free since QK(j+1) issued in the previous iteration
         kl = [lambda ks=ks: kf_load(g, ks, AK) for ks in range(4)]
-        if "nolds" in ABLATE and mode == "loop":
-            kl = []
         free = free[:4] + kl + free[4:] if len(free) > 8 else kl + free
     if mf and "noprio" not in ABLATE:          # the group that carries this wave's VALU work runs at raised priority (measured -3 % loop time)
         head.append(lambda: g.salu("s_setprio 1"))
@@ -430,13 +380,8 @@ def iteration(g, mode):
     head = [lambda: g.valu(f"v_add_u32_e32 {vreg(AV)}, s{S_SV}, {OP_VBASE}", [], [vreg(AV)])]
     mf = [] if last else [lambda ks=ks: mf_qk(g, ks) for ks in range(4)]
     free = [lambda f=f: vf_load(g, f, AV) for f in range(4)]      # V(j+1) fragments: free since PV(j) issued above
-    if "nolds" in ABLATE and mode == "loop":
-        free = []
     if stage and not DEFER:
         free.append(stash)
-    if ROWSUM_MFMA:                            # row sums of P(j+1): behind the first QK^T MFMA (the packs need two wait states), the check behind the last
-        rs, tail = rowsum_items(g, mode)
-        mf = mf[:1] + rs[:1] + mf[1:2] + rs[1:] + mf[2:]
     if not last:
         def slots():
             for s in (S_SV, S_SK, S_SW):      # ring slot offsets of the next iteration
@@ -446,88 +391,10 @@ def iteration(g, mode):
         free.append(slots)
     if "prioQ" in ABLATE and mf:
         head.append(lambda: g.salu("s_setprio 1"))
-    if ROWSUM_MFMA:                            # the check and L += TS go behind the last MFMA, the slot bookkeeping behind them (the rare path reads the slot registers)
-        if not last:
-            free.pop()
-            tail = tail + [slots]
-        group(g, mf, free, head, tail)
-    else:
-        group(g, mf, free, head)
+    group(g, mf, free, head)
     if "prioQ" in ABLATE and mf:
         g.salu("s_setprio 0")
 
-
-
-def iteration_ps(g, mode):
-    """Phase-split iteration i (round 6):
-         V phase   exp2 of S = QK(i) in place, the K(i+1) fragment reads, pack P(i)            -- no MFMA
-         M phase   row sums of P(i) | QK(i+1) carrying the V(i) fragment reads | check | PV(i)   -- ten MFMAs, nothing else of weight
-       then the ring store of sub-tile i+5 and the slot bookkeeping.
-    Why: measured (scripts/exp/attn_asm_timing.py, round 6) the round-4 stream is bound neither by the SIMD's VALU issue nor by the matrix
-    pipe -- taking the 17 row-sum adds out of it moved the loop by 1.5 %, taking ALL its MFMAs out by 22 % -- but by each wave's own
-    in-order issue: every one of its MFMAs queues behind the other two waves' (the pipe is 0.7 busy), and while it queues the wave
-    issues nothing.  Here a wave asks for the pipe once per sub-tile, for ten MFMAs in a row, and the other two waves of the SIMD run
-    their V phases under them.
-    mode 'first' (i = 0: the softmax sets the reference exponent, no check), 'loop', 'last' (i = nsub-1: keys past Nk masked, no QK)."""
-    first, last = mode == "first", mode == "last"
-    stage = not last and not ("nostage" in ABLATE and mode == "loop")
-    # ---- V phase
-    if mode == "loop":                         # every PERIOD-th iteration: the stores of the last PERIOD iterations become visible, their slots' previous occupants are dead
-        g.wait_lgkm(0)
-        if "nobar" not in ABLATE:
-            g.salu(f"s_cmp_lg_u32 s{S_PH}, 0")
-            g.emit(f"s_cbranch_scc1 .Lnobar{g.uid}_%=", "branch")
-            g.emit("s_barrier", "barrier")
-            g.label(f".Lnobar{g.uid}_%=")
-            g.uid += 1
-        g.salu(f"s_add_u32 s{S_PH}, s{S_PH}, 1")
-        g.salu(f"s_and_b32 s{S_PH}, s{S_PH}, {PERIOD - 1}")
-    if stage:
-        g.salu(f"s_mov_b64 exec, {OP_WEXEC}")
-        g.emit(f"buffer_load_dwordx4 {vreg(ST, 4)}, {OP_GOFF}, {OP_RSRC}, 0 offen", "vmem_load", [], regs("v", ST, 4))
-        g.salu("s_mov_b64 exec, -1")
-        g.valu(f"v_add_u32_e32 {OP_GOFF}, s{S_STEP}, {OP_GOFF}", [], [])
-    if last:
-        g.valu(f"v_mov_b32_e32 {vreg(MSK)}, {OP_MASK}", [], [vreg(MSK)])
-    else:
-        g.valu(f"v_add_u32_e32 {vreg(AK)}, s{S_SK}, {OP_KBASE}", [], [vreg(AK)])
-    sm = sm_items(g, mode)                     # (mask) | (reference) | 16 x exp2
-    kl = [] if last or ("nolds" in ABLATE and mode == "loop") else [lambda ks=ks: kf_load(g, ks, AK) for ks in range(4)]
-    nhead = len(sm) - 16                       # the K(i+1) reads go behind the first exp2s (KF is free: QK(i) has been issued long ago)
-    for f in sm[:nhead + 2] + kl + sm[nhead + 2:]:
-        f()
-    for f in pack_items(g):
-        f()
-    # ---- M phase
-    g.valu(f"v_add_u32_e32 {vreg(AV)}, s{S_SV}, {OP_VBASE}", [], [vreg(AV)])
-    rs, tail = rowsum_items(g, mode)
-    qk = [] if last else [lambda ks=ks: mf_qk(g, ks) for ks in range(4)]
-    vl = [] if ("nolds" in ABLATE and mode == "loop") else [lambda f=f: vf_load(g, f, AV) for f in range(4)]
-    if "noprio" not in ABLATE:
-        g.salu("s_setprio 1")
-    group(g, rs + qk, vl)
-    check, adds = (tail[:-2], tail[-2:])
-    for f in check:
-        f()
-    def stash():
-        g.wait_vm(0)
-        g.valu(f"v_add_u32_e32 {vreg(AW)}, s{S_SW}, {OP_WBASE}", [], [vreg(AW)])
-        g.salu(f"s_mov_b64 exec, {OP_WEXEC}")
-        g.emit(f"ds_write_b128 {vreg(AW)}, {vreg(ST, 4)}", "ds_write", [vreg(AW)] + regs("v", ST, 4))
-        g.salu("s_mov_b64 exec, -1")
-    def slots():
-        for s_ in (S_SV, S_SK, S_SW):          # ring slot offsets of the next iteration
-            g.salu(f"s_add_u32 s{s_}, s{s_}, {SLOT_B}")
-            g.salu(f"s_cmp_eq_u32 s{s_}, {SLOT_B * NSLOT}")
-            g.salu(f"s_cselect_b32 s{s_}, 0, s{s_}")
-    pv = [lambda f=f: mf_pv(g, f) for f in range(4)]
-    group(g, pv, adds)
-    if "noprio" not in ABLATE:
-        g.salu("s_setprio 0")
-    if stage:
-        stash()
-    if not last:
-        slots()
 
 def rereference(g, first):
     """S holds s * qs - m_old: m_delta = ceil(row max over both lane halves) (first) / max(that, 0); rescale L and O by 2^-m_delta
@@ -543,8 +410,6 @@ def rereference(g, first):
         g.valu(f"v_sub_f32_e32 {vreg(T1)}, 0, {vreg(T2)}", [vreg(T2)], [vreg(T1)])
         g.valu(f"v_exp_f32_e32 {vreg(T3)}, {vreg(T1)}", [vreg(T1)], [vreg(T3)], trans=True)  # T3 = 2^-m_delta
         g.valu(f"v_mul_f32_e32 {vreg(L)}, {vreg(L)}, {vreg(T3)}", [vreg(L), vreg(T3)], [vreg(L)])
-        if ROWSUM_MFMA:
-            g.valu(f"v_mul_f32_e32 {vreg(L1)}, {vreg(L1)}, {vreg(T3)}", [vreg(L1), vreg(T3)], [vreg(L1)])
         for a in range(32):
             g.valu(f"v_accvgpr_read_b32 {vreg(T1)}, {areg(a)}", [areg(a)], [vreg(T1)])
             g.valu(f"v_mul_f32_e32 {vreg(T1)}, {vreg(T1)}, {vreg(T3)}", [vreg(T1), vreg(T3)], [vreg(T1)])
@@ -580,19 +445,9 @@ def subroutine(g, first):
     if not first:
         for f in exp_sum_items(g0):
             f()
-        if ROWSUM_MFMA:                        # called behind the pack, the row-sum MFMAs and QK(j+2): redo all three
-            for f in pack_items(g0):
-                f()
-            for k2 in range(2):
-                g0.mfma_rowsum(k2)
         g0.valu(f"v_add_u32_e32 {vreg(T0)}, s{S_SK}, {OP_KBASE}", [], [vreg(T0)])
         for ks in range(4):
             kf_load(g0, ks, T0)
-        if ROWSUM_MFMA:
-            for ks in range(4):                # QK(j+2) against the raised reference (in the last iteration: scores nobody reads)
-                mf_qk(g0, ks)
-            g0.wait_lgkm(0)
-            g0.nop(32)
     g0.nop(4)
     g0.emit(f"s_setpc_b64 s[{S_RA}:{S_RA + 1}]", "ret")
     g.out += g0.out
@@ -606,7 +461,7 @@ def prologue(g):
     g.salu(f"s_mov_b32 s{S_SV}, 0")                                                       # V(0)
     g.salu(f"s_mov_b32 s{S_SK}, {SLOT_B}")                                                # K(1)
     g.salu(f"s_mov_b32 s{S_SW}, {(AHEAD - (2 if DEFER else 1)) * SLOT_B}")               # sub-tile AHEAD-1 is stored by iteration -1 (DEFER: by iteration 0)
-    g.salu(f"s_mov_b32 s{S_PH}, {1 if PHASE else 2 % PERIOD}")                            # (j + 2) mod PERIOD of iteration 0 (PHASE: i mod PERIOD of iteration 1)
+    g.salu(f"s_mov_b32 s{S_PH}, {2 % PERIOD}")                                            # (j + 2) mod PERIOD of iteration 0
     g.salu(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 2")                                            # steady iterations j = 0 .. nsub - 3
     for ks in range(4):
         g.emit(f"ds_read_b128 {areg(QF(ks), 4)}, {OP_QADDR} offset:{32 * ks}", "ds_read", [], regs("a", QF(ks), 4))
@@ -615,10 +470,6 @@ def prologue(g):
     g.valu(f"v_mov_b32_e32 {vreg(L)}, 0", [], [vreg(L)])
     g.valu(f"v_mov_b32_e32 {vreg(M)}, 0", [], [vreg(M)])
     g.valu(f"v_mov_b32_e32 {vreg(MSK)}, 0", [], [vreg(MSK)])
-    if ROWSUM_MFMA:
-        g.valu(f"v_mov_b32_e32 {vreg(L1)}, 0", [], [vreg(L1)])
-        for r in range(4):
-            g.valu(f"v_accvgpr_write_b32 {areg(SEL + r)}, {OP_SEL}", [], [areg(SEL + r)])
     for r in range(16):
         g.valu(f"v_mov_b32_e32 {vreg(NEGM + r)}, 0", [], [vreg(NEGM + r)])
     for r in range(32):
@@ -629,15 +480,10 @@ def prologue(g):
 
 def epilogue(g):
     g.nop(32)
-    if ROWSUM_MFMA:                            # the MFMA sums are complete in every lane: query j = lane % 32 takes L (j < 16) or L1
-        g.salu(f"s_mov_b32 s{S_CC}, 0xffff0000")
-        g.salu(f"s_mov_b32 s{S_CC + 1}, 0xffff0000")
-        g.valu(f"v_cndmask_b32_e64 {vreg(T0)}, {vreg(L)}, {vreg(L1)}, s[{S_CC}:{S_CC + 1}]", [vreg(L), vreg(L1)], [vreg(T0)])
-    else:
-        g.valu(f"v_mov_b32_e32 {vreg(T0)}, {vreg(L)}", [vreg(L)], [vreg(T0)])
-        g.valu(f"v_mov_b32_e32 {vreg(T1)}, {vreg(L)}", [vreg(L)], [vreg(T1)])
-        g.emit(f"v_permlane32_swap_b32_e32 {vreg(T0)}, {vreg(T1)}", "permlane", [vreg(T0), vreg(T1)], [vreg(T0), vreg(T1)])
-        g.valu(f"v_add_f32_e32 {vreg(T0)}, {vreg(T0)}, {vreg(T1)}", [vreg(T0), vreg(T1)], [vreg(T0)])      # T0 = row sum over both halves
+    g.valu(f"v_mov_b32_e32 {vreg(T0)}, {vreg(L)}", [vreg(L)], [vreg(T0)])
+    g.valu(f"v_mov_b32_e32 {vreg(T1)}, {vreg(L)}", [vreg(L)], [vreg(T1)])
+    g.emit(f"v_permlane32_swap_b32_e32 {vreg(T0)}, {vreg(T1)}", "permlane", [vreg(T0), vreg(T1)], [vreg(T0), vreg(T1)])
+    g.valu(f"v_add_f32_e32 {vreg(T0)}, {vreg(T0)}, {vreg(T1)}", [vreg(T0), vreg(T1)], [vreg(T0)])          # T0 = row sum over both halves
     g.valu(f"v_rcp_f32_e32 {vreg(T4)}, {vreg(T0)}", [vreg(T0)], [vreg(T4)], trans=True)
     g.valu(f"v_log_f32_e32 {vreg(T1)}, {vreg(T0)}", [vreg(T0)], [vreg(T1)], trans=True)
     g.valu(f"v_add_f32_e32 {vreg(T1)}, {vreg(T1)}, {vreg(M)}", [vreg(T1), vreg(M)], [vreg(T1)])
@@ -709,8 +555,7 @@ def generate(half):
     g.wait_lgkm(0)
     g.emit("s_barrier", "barrier")                       # the Q tiles (read by now) lie in ring slots that the stores of iteration 0.. reuse
     g.stamp(1)
-    it_ = iteration_ps if PHASE else iteration
-    it_(g, "first")
+    iteration(g, "first")
     g.stamp(2)
     first_end = len(g.out)
     st_in = g.state()
@@ -718,7 +563,7 @@ def generate(half):
     g.emit("s_cbranch_scc1 .Llast_%=", "branch")
     g.label(".Lloop_%=")
     loop_begin = len(g.out)
-    it_(g, "loop")
+    iteration(g, "loop")
     if TIMING:
         g.wait_lgkm(0)                                   # (the stamp before the loop drained the queue)
     g.salu(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
@@ -731,9 +576,8 @@ def generate(half):
     last_begin = len(g.out)
     g.stamp(3)
     g.nop(11)                                            # entered from the loop or straight from the first iteration (nsub = 2)
-    it_(g, "last")
-    if not PHASE:
-        iteration(g, "drain")
+    iteration(g, "last")
+    iteration(g, "drain")
     g.wait_lgkm(0)
     g.emit("s_barrier", "barrier")                       # the O tiles written below lie in ring slots other waves may still be reading
     g.stamp(4)
