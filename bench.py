@@ -394,6 +394,9 @@ def main():
                                    + ("random-noise batch resident in HBM" if not args.loader else "synthetic Synapse npz slices via the device loader")
                                    + ", name-seeded random-init weights",
                        "global_batch": world * args.batch, "image_size": args.size, "parallelism": f"dp{world}",
+                       #  which workload `value` timed, machine-readable: "loader" (the default since round 5), "resident"
+                       # (--resident / --eager; rounds 1-4's headline), and degraded = the loader-fed step was asked for and could not run
+                       "headline_mode": "loader" if args.loader else "resident", "headline_degraded": bool(loader_note),
                        "launch_mode": "eager" if args.eager else "hipGraph replay", "final_loss": float(loss.item()),
                        "launches_per_step": launches,
                        "median_ms_per_step": statistics.median(per_step), "min_ms_per_step": min(per_step), **extra},

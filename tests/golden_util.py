@@ -153,6 +153,9 @@ def check_all_grads_lowp(named_lp, named_ref, rel_l2: float, cos_min: float, wha
         tab[config] = old
         with open(wb, "w") as f:
             json.dump(tab, f, indent=0, sort_keys=True)
+        #  write mode is not a free pass: the measured errors it records must still sit inside the global bounds
+        over = [f"{fam}: rel L2 {v[0]:.3e} / cosine {v[1]:.5f}" for fam, v in measured.items() if not (v[0] <= rel_l2 and v[1] >= cos_min)]
+        assert not over, f"{what}TC_WRITE_BUDGET run: families outside the global bound ({rel_l2}, {cos_min}):\n  " + "\n  ".join(over[:20])
         return n, worst
     assert not bad, f"{what}{len(bad)} of {n} gradient tensors out of bound:\n  " + "\n  ".join(bad[:20])
     return n, worst

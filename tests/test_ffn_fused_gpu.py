@@ -144,6 +144,49 @@ CASES = [  # C, B, H, W, groups
 ]
 
 
+def _ref_rounding_model(x, flat, offs, shapes, tot, groups, B, H, W, res, dtype, pre_eps=None, stats_of_unrounded=True):
+    """fp64 model of the tiled kernels' own arithmetic on storage-grid operands: h, d and a live in LDS / HBM in the storage type (rounded
+    there), the LayerNorm statistics are those of the rounded d, the result is rounded once."""
+    rq = lambda t: t.to(dtype).double()
+    x, flat, res = rq(x), rq(flat), rq(res)
+    C, M, outs = x.shape[1], B * H * W, []
+    for g in range(groups):
+        P = {k: flat[g * tot + offs[k]: g * tot + offs[k] + int(torch.tensor(shapes[k]).prod())].view(shapes[k]) for k in offs}
+        xg = x[g * M:(g + 1) * M]
+        if pre_eps is not None:
+            xg = rq(F.layer_norm(xg, (C,), P["pg"], P["pb"], pre_eps))
+        h = rq(F.linear(xg, P["W1"], P["b1"]))
+        hm = h.view(B, H, W, -1).permute(0, 3, 1, 2)
+        du = (F.conv2d(hm, P["wd"], P["bd"], padding=1, groups=hm.shape[1]) + hm).permute(0, 2, 3, 1).reshape(M, -1)
+        d = rq(du)
+        if stats_of_unrounded:                     # the tiled forward takes the row statistics from the fp32 values before they are rounded into LDS
+            mu, var = du.mean(1, keepdim=True), du.var(1, unbiased=False, keepdim=True)
+            a = rq(F.gelu((d - mu) * torch.rsqrt(var + 1e-5) * P["lg"] + P["lb"]))
+        else:
+            a = rq(F.gelu(F.layer_norm(d, (d.shape[1],), P["lg"], P["lb"], 1e-5)))
+        outs.append(rq(F.linear(a, P["W2"], P["b2"]) + res[g * M:(g + 1) * M]))
+    return torch.cat(outs, 0)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [(64, 2, 28, 28, 1), (64, 1, 56, 56, 1), (64, 2, 7, 9, 1), (128, 3, 14, 14, 1), (128, 2, 28, 28, 3)])
+def test_fused_mixffn_forward_within_one_rounding_of_its_fp64_model(case, dtype):
+    """ffn_fused_fwd_kernel on storage-grid operands against the fp64 model of its own arithmetic, <= 3e-3 (bf16) /
+    4e-4 (fp16) of the result's largest value -- the 3e-2 of the fp32 comparison below would let a wrong tap or bias through."""
+    C, B, H, W, groups = case
+    gen = torch.Generator().manual_seed(300 + C + H)
+    flat, offs, shapes, tot = _params(C, groups, gen)
+    rows = groups * B * H * W
+    x, res, gout = (torch.randn(rows, C, generator=gen) for _ in range(3))
+    y, *_ = _engine_run(dtype, True, x, flat, offs, shapes, tot, groups, B, H, W, res, gout)
+    ym = _ref_rounding_model(x, flat, offs, shapes, tot, groups, B, H, W, res, dtype)
+    err = float((y.double() - ym).abs().max() / ym.abs().max())
+    ym2 = _ref_rounding_model(x, flat, offs, shapes, tot, groups, B, H, W, res, dtype, stats_of_unrounded=False)
+    err2 = float((y.double() - ym2).abs().max() / ym2.abs().max())
+    print(f"ffn_fused_fwd {case} {dtype}: out vs the fp64 rounding model {err:.2e} (statistics of the rounded d: {err2:.2e})")
+    assert err < {torch.bfloat16: 3e-3, torch.float16: 4e-4}[dtype], err
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("case", CASES)
 def test_fused_mixffn_matches_torch_and_unfused(case, dtype):

@@ -25,6 +25,18 @@ def rel(got, want):
     return (got - want).abs().max().item() / (want.abs().max().item() + 1e-12)
 
 
+# the fused 16-bit kernels against an fp64 model of their OWN arithmetic -- operands on the storage grid, every value the
+# kernel stores rounded where the kernel rounds it -- within about one rounding of the result's largest value: half an ulp of the top
+# binade is 2^-9 = 2.0e-3 (bf16) / 2^-12 = 2.4e-4 (fp16), and an intermediate that rounds the other way than the model's (fp32 against
+# fp64 sums near a tie) moves a result by one more; measured on MI355X: <= 1.8e-3 / 5.1e-4.  A wrong halo row, tap or bias moves an output by >= 1e-2.
+TIGHT = {torch.bfloat16: 3e-3, torch.float16: 8e-4}
+
+
+def rq(t, dtype):
+    """Round to the storage type, continue in fp64."""
+    return t.to(dtype).double()
+
+
 def _arena(C, Gn, dtype, tag):
     """The parameters of Gn weight groups laid out at a constant stride, as in the model's flat arenas: Wqkv | bqkv | w3 | b3 | w5 | b5 | w7 | b7."""
     from transception_amd.engine import P
@@ -46,10 +58,15 @@ def _arena(C, Gn, dtype, tag):
     return Ps, master, gflat, per, shapes, sizes
 
 
-def _reference(x, master, per, shapes, sizes, Gn, B, side, C):
+def _reference(x, master, per, shapes, sizes, Gn, B, side, C, rnd=None):
+    """rnd: the rounding model (fp64 in, storage-grid fp64 out) applied where tc_mhca_att_fwd stores -- q | k | v, crpe(v), the result;
+    None: the plain fp32 statement with autograd."""
     Ch, N = C // 8, side * side
-    pr = master.clone().requires_grad_()
-    xr = x.clone().requires_grad_()
+    if rnd is not None:
+        x, master = x.double(), master.double()
+    pr = master.clone().requires_grad_(rnd is None)
+    xr = x.clone().requires_grad_(rnd is None)
+    rnd = rnd or (lambda t: t)
     outs = []
     for g in range(Gn):
         ps, off = [], g * per
@@ -57,18 +74,18 @@ def _reference(x, master, per, shapes, sizes, Gn, B, side, C):
             ne = int(torch.tensor(s).prod())
             ps.append(pr[off:off + ne].view(s)); off += n
         xg = xr[g * B * N:(g + 1) * B * N]
-        qkv = xg @ ps[0].t() + ps[1]
+        qkv = rnd(xg @ ps[0].t() + ps[1])
         q, k, v = (qkv[:, i * C:(i + 1) * C] for i in range(3))
         vim = v.reshape(B, side, side, C).permute(0, 3, 1, 2)
         cs, c0 = [], 0
         for i, (ks, nh) in enumerate(WINDOWS):
             wd = nh * Ch
             cs.append(F.conv2d(vim[:, c0:c0 + wd], ps[2 + 2 * i].view(wd, 1, ks, ks), ps[3 + 2 * i], padding=ks // 2, groups=wd)); c0 += wd
-        convv = torch.cat(cs, 1).permute(0, 2, 3, 1).reshape(B * N, C)
+        convv = rnd(torch.cat(cs, 1).permute(0, 2, 3, 1).reshape(B * N, C))
         qh, kh, vh = (t.reshape(B, N, 8, Ch).permute(0, 2, 1, 3) for t in (q, k, v))
         ctx = torch.softmax(kh, dim=2).transpose(-1, -2) @ vh
         fa = (qh @ ctx).permute(0, 2, 1, 3).reshape(B * N, C)
-        outs.append(Ch ** -0.5 * fa + q * convv)
+        outs.append(rnd(Ch ** -0.5 * fa + q * convv))
     return torch.cat(outs, 0), xr, pr
 
 
@@ -126,6 +143,10 @@ def test_mhca_attention_one_launch(dtype, C, side, B, Gn):
         E._MHCA_ATT_FUSED = E._MHCA_ATT_BWD_FUSED = True
     tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
     assert rel(of, ref) < tol, ("o vs torch", rel(of, ref))
+    with torch.no_grad():
+        ref_m = _reference(x16.float(), master, per, shapes, sizes, Gn, B, side, C, rnd=lambda t: rq(t, dtype))[0]
+    print(f"mhca_att_fwd C={C} {dtype}: o vs the fp64 rounding model {rel(of, ref_m):.2e} (vs plain fp32 {rel(of, ref):.2e})")
+    assert rel(of, ref_m) < TIGHT[dtype], ("o vs the fp64 rounding model", rel(of, ref_m))
     assert rel(dxf, xr.grad) < 2 * tol, ("dx vs torch", rel(dxf, xr.grad))
     assert rel(gpf, pr.grad) < 2 * tol, ("parameter gradients vs torch", rel(gpf, pr.grad))
     # against the op-by-op launches: the same roundings at the same places, only the summation order of the projection differs
@@ -190,6 +211,17 @@ def test_dw_ln_one_launch(dtype, C, side, B, Gn):
         E._DW_LN_FUSED = True
     tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
     assert rel(tf, rt) < tol and rel(nf, rn) < tol, (rel(tf, rt), rel(nf, rn))
+    with torch.no_grad():                                                          # fp64 rounding model: t1 rounded, norm1 of the ROUNDED t1, rounded
+        mt, mn = [], []
+        md = master.detach().double()
+        for g in range(Gn):
+            m = md[g * per:(g + 1) * per]
+            xi = x16.double()[g * B * side * side:(g + 1) * B * side * side].reshape(B, side, side, C).permute(0, 3, 1, 2)
+            t1 = rq((F.conv2d(xi, m[:9 * C].view(C, 1, 3, 3), m[9 * C:10 * C], padding=1, groups=C) + xi).permute(0, 2, 3, 1).reshape(-1, C), dtype)
+            mt.append(t1); mn.append(rq(F.layer_norm(t1, (C,), m[10 * C:11 * C], m[11 * C:12 * C], 1e-6), dtype))
+        mt, mn = torch.cat(mt), torch.cat(mn)
+    print(f"dw_ln_fwd C={C} {dtype}: t1 / norm1 vs the fp64 rounding model {rel(tf, mt):.2e} / {rel(nf, mn):.2e}")
+    assert rel(tf, mt) < TIGHT[dtype] and rel(nf, mn) < TIGHT[dtype], (rel(tf, mt), rel(nf, mn))
     assert rel(tf, tu) < tol / 4 and rel(nf, nu) < tol / 2, (rel(tf, tu), rel(nf, nu))
     assert rel(dxf, xr.grad) < 2 * tol and rel(gpf, master.grad) < 2 * tol, (rel(dxf, xr.grad), rel(gpf, master.grad))
     assert rel(dxf, dxu) < tol and rel(gpf, gpu_) < tol
@@ -254,6 +286,19 @@ def test_linear_ln_one_launch(dtype, C, rows_g, Gn, res):
         E._LIN_LN_FUSED = True
     tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
     assert rel(tf, rt) < tol and rel(nf, rn) < tol, (rel(tf, rt), rel(nf, rn))
+    with torch.no_grad():                                                          # fp64 rounding model: t rounded before the statistics (what the backward reads)
+        mt, mn = [], []
+        md = master.detach().double()
+        for g in range(Gn):
+            m = md[g * per:(g + 1) * per]
+            t = F.linear(x16.double()[g * rows_g:(g + 1) * rows_g], m[:C * C].view(C, C), m[C * C:C * C + C])
+            if res:
+                t = t + r16.double()[g * rows_g:(g + 1) * rows_g]
+            t = rq(t, dtype)
+            mt.append(t); mn.append(rq(F.layer_norm(t, (C,), m[C * C + C:C * C + 2 * C], m[C * C + 2 * C:C * C + 3 * C], 1e-6), dtype))
+        mt, mn = torch.cat(mt), torch.cat(mn)
+    print(f"lin_res_ln C={C} {dtype}: t / LayerNorm(t) vs the fp64 rounding model {rel(tf, mt):.2e} / {rel(nf, mn):.2e}")
+    assert rel(tf, mt) < TIGHT[dtype] and rel(nf, mn) < TIGHT[dtype], (rel(tf, mt), rel(nf, mn))
     assert rel(tf, tu) < tol / 4 and rel(nf, nu) < tol / 2, (rel(tf, tu), rel(nf, nu))
     assert rel(dxf, xr.grad) < 2 * tol and rel(gpf, master.grad) < 2 * tol, (rel(dxf, xr.grad), rel(gpf, master.grad))
     assert rel(dxf, dxu) < tol and rel(gpf, gpu_) < tol

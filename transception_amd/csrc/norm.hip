@@ -548,6 +548,25 @@ __device__ __forceinline__ void bn_fold_partials(const float* __restrict__ scrat
     for (; k < nchunk; k += 4) { s1 += p1[(long long)k * C]; s2 += p2[(long long)k * C]; }
 }
 
+// The forward statistics: the producers' shift is the running mean (GEMM / RIPM epilogues) or the map's first row (bn_partial_kernel), which
+// a distribution shift can leave many standard deviations off the batch mean -- and var = S2 / n - (S1 / n)^2 then cancels.  The per-chunk
+// sums are exact to their own fp32 rounding (independent between chunks), so folding them and taking the difference in fp64 keeps the
+// relative error of the variance at (mean - shift)^2 / var x 1e-8 instead of x 1e-6 x sqrt(chunks)  (round 6; tests/test_ops_gpu.py::
+// test_batchnorm_statistics_far_from_the_shift: batch mean = 50 standard deviations).
+__device__ __forceinline__ void bn_fold_partials(const float* __restrict__ scratch, int nchunk, int C, int ch, int part, double& s1, double& s2) {
+    const float* p1 = scratch + C + ch;
+    const float* p2 = scratch + C + (long long)nchunk * C + ch;
+    int k = part;
+    for (; k + 28 < nchunk; k += 32) {
+        float a[8], b[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) { a[m] = p1[(long long)(k + 4 * m) * C]; b[m] = p2[(long long)(k + 4 * m) * C]; }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) { s1 += (double)a[m]; s2 += (double)b[m]; }
+    }
+    for (; k < nchunk; k += 4) { s1 += (double)p1[(long long)k * C]; s2 += (double)p2[(long long)k * C]; }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ gamma,
                                                        const T* __restrict__ beta, float* __restrict__ running_mean,
@@ -558,21 +577,21 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
                                                        int act) {
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;       // 16 channel quads x 16 row lanes
     const int c = blockIdx.y * 64 + tx * 4;
-    __shared__ float psum[2][4][64];
+    __shared__ double psum[2][4][64];
     __shared__ float stat[2][64];
     if (training) {
-        // fold the per-chunk partials once per block: thread (channel = tid % 64, quarter = tid / 64)
+        // fold the per-chunk partials once per block: thread (channel = tid % 64, quarter = tid / 64); fp64 sums and difference (see above)
         const int cc = threadIdx.x & 63, part = threadIdx.x >> 6, ch = blockIdx.y * 64 + cc;
-        float s1 = 0.f, s2 = 0.f;
+        double s1 = 0.0, s2 = 0.0;
         if (ch < C) bn_fold_partials(scratch, nchunk, C, ch, part, s1, s2);
         psum[0][part][cc] = s1; psum[1][part][cc] = s2;
         __syncthreads();
         if (threadIdx.x < 64 && ch < C) {
-            s1 = psum[0][0][cc] + psum[0][1][cc] + psum[0][2][cc] + psum[0][3][cc];
-            s2 = psum[1][0][cc] + psum[1][1][cc] + psum[1][2][cc] + psum[1][3][cc];
-            const float m1 = s1 / (float)rows;
-            const float var = fmaxf(s2 / (float)rows - m1 * m1, 0.f);
-            const float mean_ = scratch[ch] + m1, rstd_ = rsqrtf(var + eps);
+            s1 = (psum[0][0][cc] + psum[0][1][cc]) + (psum[0][2][cc] + psum[0][3][cc]);
+            s2 = (psum[1][0][cc] + psum[1][1][cc]) + (psum[1][2][cc] + psum[1][3][cc]);
+            const double m1 = s1 / (double)rows;
+            const float var = (float)fmax(s2 / (double)rows - m1 * m1, 0.0);
+            const float mean_ = (float)((double)scratch[ch] + m1), rstd_ = rsqrtf(var + eps);
             stat[0][cc] = mean_; stat[1][cc] = rstd_;
             if (blockIdx.x == 0) {
                 save_mean[ch] = mean_; save_rstd[ch] = rstd_;

@@ -93,7 +93,11 @@ __global__ __launch_bounds__(256) void ripm_fwd_kernel(RipmFwdDev p) {
         if (p.training) {
             constexpr int NQ = C / 4, L = 256 / NQ;          // channel quads; chunk lanes per quad
             const int q = tid % NQ, ln = tid / NQ;
-            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+            // fp64 sums and difference: the producer's shift (its running mean) may lie many standard deviations off the batch mean
+            // (norm.hip, bn_fold_partials).  The fold's scratch is 2 * L * C doubles: `red` and the head of in_t, which nobody writes
+            // before the barrier behind this block.
+            double* redd = reinterpret_cast<double*>(red);
+            double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
             if (ln < L) {
                 const float* p1 = p.part_in + C + 4 * q;
                 const float* p2 = p1 + (long long)p.chunks_in * C;
@@ -108,20 +112,21 @@ __global__ __launch_bounds__(256) void ripm_fwd_kernel(RipmFwdDev p) {
                     }
 #pragma unroll
                     for (int m = 0; m < 8; ++m) {
-                        s1[0] += a[m].x; s1[1] += a[m].y; s1[2] += a[m].z; s1[3] += a[m].w;
-                        s2[0] += c[m].x; s2[1] += c[m].y; s2[2] += c[m].z; s2[3] += c[m].w;
+                        s1[0] += (double)a[m].x; s1[1] += (double)a[m].y; s1[2] += (double)a[m].z; s1[3] += (double)a[m].w;
+                        s2[0] += (double)c[m].x; s2[1] += (double)c[m].y; s2[2] += (double)c[m].z; s2[3] += (double)c[m].w;
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { red[ln * C + 4 * q + u] = s1[u]; red[L * C + ln * C + 4 * q + u] = s2[u]; }
+                for (int u = 0; u < 4; ++u) { redd[ln * C + 4 * q + u] = s1[u]; redd[L * C + ln * C + 4 * q + u] = s2[u]; }
             }
             __syncthreads();
             for (int c = tid; c < C; c += 256) {
-                float a = 0.f, d = 0.f;
+                double a = 0.0, d = 0.0;
 #pragma unroll
-                for (int m = 0; m < L; ++m) { a += red[m * C + c]; d += red[L * C + m * C + c]; }
-                const float n = (float)p.rows_in, m1 = a / n, var = fmaxf(d / n - m1 * m1, 0.f);
-                const float mean = p.part_in[c] + m1, rstd = rsqrtf(var + p.eps);
+                for (int m = 0; m < L; ++m) { a += redd[m * C + c]; d += redd[L * C + m * C + c]; }
+                const double nd = (double)p.rows_in, m1d = a / nd;
+                const float n = (float)p.rows_in, m1 = (float)m1d, var = (float)fmax(d / nd - m1d * m1d, 0.0);
+                const float mean = (float)((double)p.part_in[c] + m1d), rstd = rsqrtf(var + p.eps);
                 const float g = ldf<T>(gm + c);
                 sc[c] = rstd * g; sh[c] = ldf<T>(bt + c) - mean * rstd * g;
                 if (tile == 0 && js == 0) {

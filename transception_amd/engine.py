@@ -1510,7 +1510,11 @@ class Graph:
         self._rec(bwd)
         return out
 
-    def mhca_att_supported(self, n: Var, N: int) -> bool:
+    def mhca_att_supported(self, n: Var, N: int, heads: int = 8, windows: Optional[List[Tuple[int, int]]] = None) -> bool:
+        """tc_mhca_att_fwd / _bwd hard-code the reference's head layout (8 heads; 3x3 / 5x5 / 7x7 windows over 2 / 3 / 3 of them,
+        MSTr.py:1404 crpe_window): anything else takes the op-by-op form."""
+        if heads != 8 or (windows is not None and [tuple(w_) for w_ in windows] != [(3, 2), (5, 3), (7, 3)]):
+            return False
         return (_MHCA_ATT_FUSED and self.dt != TC_F32 and not self.use_streams and n.ld % 8 == 0 and n.data.data_ptr() % 16 == 0
                 and (self.pgs % 8 == 0 or self.ngroups == 1) and bool(self.L.tc_mhca_att_supported(n.cols, N, self.dt)))
 
@@ -1533,6 +1537,7 @@ class Graph:
             c0 += w
         stats = self.f32(int(self.L.tc_factor_att_stats_floats(Bt, heads, Ch)))
         gs = Wqkv.gs if self.ngroups > 1 else 0
+        assert heads == 8 and [tuple(w_) for w_ in windows] == [(3, 2), (5, 3), (7, 3)], "tc_mhca_att_* hard-code this head layout: ask mhca_att_supported first"
         fused_bwd = (_MHCA_ATT_BWD_FUSED and self.record and heads == 8 and [k_ for k_, _ in windows] == [3, 5, 7]
                      and all(w_.grad is not None for w_ in cws) and all(b_ is not None and b_.grad is not None for b_ in cbs)
                      and bool(self.L.tc_mhca_att_bwd_supported(C_, N, self.dt)))

@@ -584,10 +584,29 @@ class MSTransception(nn.Module):
         step too (the increment is a captured launch -- the counter itself must exist before the capture: train.GraphedStep's eager warm-up
         steps create it)."""
         if getattr(self, "_drop_ctr", None) is None or self._drop_ctr.device != G.dev:
-            self._drop_ctr = torch.zeros(1, dtype=torch.int64, device=G.dev)
+            # (ADVICE r5) the key starts at ((seed * world + rank) mod 128) << 24: ranks of a DDP job draw different masks, a user seed
+            # (TC_DROPOUT_SEED, default torch's initial seed) moves the sequence, and the low 24 bits count forwards (the kernel keys on
+            # 32 bits).  Like the reference -- whose masks come from torch's global generator, which trainer.py:49-237 never saves -- a
+            # resumed run restarts the sequence; `dropout_counter` / `set_dropout_counter` let a caller carry it across a checkpoint
+            # without touching the state_dict schema (2200 keys, strict-loadable both ways).
+            import torch.distributed as dist
+            rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+            base = int(os.environ.get("TC_DROPOUT_SEED", torch.initial_seed() & 0x7FFF))
+            start = getattr(self, "_drop_ctr_restore", None)
+            v0 = start if start is not None else (((base * world + rank) & 0x7F) << 24)
+            self._drop_ctr = torch.full((1,), v0, dtype=torch.int64, device=G.dev)
+            self._drop_ctr_restore = None
         if G.training:
             self._drop_ctr += 1
         return self._drop_ctr
+
+    def dropout_counter(self) -> Optional[int]:
+        c = getattr(self, "_drop_ctr", None)
+        return int(c.item()) if c is not None else None
+
+    def set_dropout_counter(self, value: int) -> None:
+        self._drop_ctr_restore, self._drop_ctr = int(value), None
+
 
     def _path_stride(self, stage: str, npath: int = 3) -> int:
         """Distance in the flat arenas between the parameter blocks of two consecutive MB encoders of a stage."""
@@ -870,7 +889,7 @@ def _factor_att(M, G, n: Var, blk: str, enc: str, B: int, side: int, residual: O
     C, N = n.cols, side * side
     Bt = B * G.ngroups                              # images of all stacked weight groups
     rows, h, Ch = Bt * N, HEADS, n.cols // HEADS
-    if FUSED_FACTOR_ATT and MULTI_CRPE and Ch % 8 == 0 and G.mhca_att_supported(n, N):     # qkv + crpe + attention core: one launch
+    if FUSED_FACTOR_ATT and MULTI_CRPE and Ch % 8 == 0 and G.mhca_att_supported(n, N, h, list(CRPE_WINDOW)):     # qkv + crpe + attention core: one launch
         o = G.mhca_attention(n, *_lin(M, G, blk + ".factoratt_crpe.qkv"), [M._P(G, f"{enc}.crpe.conv_list.{i}.weight") for i in range(3)],
                              [M._P(G, f"{enc}.crpe.conv_list.{i}.bias") for i in range(3)], B, side, h, Ch ** -0.5, list(CRPE_WINDOW))
         return _proj_ln(M, G, o, blk + ".factoratt_crpe.proj", residual, ln)

@@ -244,7 +244,7 @@ def clip_buckets(buckets, ranges):
     return sorted(out)
 
 
-SPAN_GAP_MAX = int(os.environ.get("TC_DDP_SPAN_GAP_MAX", str(8 << 20)))     # elements: a gap of dead (grad-less, zero) words up to this size is sent along rather than starting a new collective
+SPAN_GAP_MAX = int(os.environ.get("TC_DDP_SPAN_GAP_MAX", str(2 << 20)))     # elements: a gap of dead (grad-less, zero) words up to this size is sent along rather than starting a new collective.  8 MB of zeros cost a one-link ring about what a collective's own latency does (2 (N-1) hops x 6 us at N = 8 = 84 us x 153 GB/s / 1.75); the 8 M elements of round 5 put 32 MB of zeros on the wire to save one
 
 
 def comm_schedule(model):
@@ -274,7 +274,9 @@ def comm_schedule(model):
         runs = [(a, b) for a, b in runs]
         if pi == len(pieces) - 1:
             allr = sorted(runs + deferred)
-            if len(allr) == 1:
+            if not allr:                                   #  nothing live in the last piece and nothing deferred: no collective, not an empty pack
+                sched.append((stop, []))
+            elif len(allr) == 1:
                 sched.append((stop, [("span",) + allr[0]]))
             elif sum(b - a for a, b in allr) <= COALESCE_MAX:
                 sched.append((stop, [("pack", allr)]))
