@@ -306,6 +306,11 @@ def test_ripm_one_launch_per_step_16bit(model, stage, dtype):
     tol = 2e-2 if bf else 4e-3
     print(f"stage {stage} {dtype}: fused vs op-by-op: y {rel(yf, yu):.2e} gx {rel(gxf, gxu):.2e} gw {rel(gpf, gpu_):.2e} running stats {rel(stf, stu):.2e}; launches {nlf} vs {nlu}")
     assert rel(yf, yu) < tol and rel(gxf, gxu) < 2 * tol and rel(gpf, gpu_) < 2 * tol, (rel(yf, yu), rel(gxf, gxu), rel(gpf, gpu_))
+    # the one-launch form makes the op-by-op form's roundings at the same places, so the A/B holds far inside the 16-bit
+    # module budget (measured on MI355X: y 7e-7 / 7e-4, gx 3.6e-3 / 9e-4, gw 1.6e-4 / 3.8e-4 for bf16 / fp16) -- a wrong halo row or
+    # BatchNorm fold moves y by >= 1e-2
+    ty, tg, tw = (2e-3, 8e-3, 1e-3) if bf else (1.5e-3, 2e-3, 1e-3)
+    assert rel(yf, yu) < ty and rel(gxf, gxu) < tg and rel(gpf, gpu_) < tw, (rel(yf, yu), rel(gxf, gxu), rel(gpf, gpu_))
     if stage == 2:
         # against the reference's fixture: the three chained BatchNorms amplify 16-bit rounding in the input gradient (the op-by-op path sits
         # at the same distance: both are printed), so its budget is 0.15 of the largest reference sample instead of the modules' 5e-2
