@@ -173,6 +173,29 @@ int tc_layernorm_ps_bwd(const void* dy, int lddy, const void* x, int ldx, const 
                         float* scratch, long long scratch_floats, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The tail of the last decoder stage in one forward and one backward call (ABI 15, round 6):
+ *   logits = last_layer(LayerNorm(rearrange 'b h w (p1 p2 c) -> b (h p1) (w p2) c' (x)))
+ * Replaces the rearrange + self.norm of FinalPatchExpand_X4.forward (MSTr.py:222-225) and self.last_layer (Conv2d(c, n_class, 1),
+ * MSTr.py:258, called at :281) -- tc_layernorm_ps_fwd + tc_gemm, and tc_gemm_pair + tc_layernorm_ps_bwd on the way back -- without
+ * the normalised [B * (H p) * (W p), c] map (or its gradient) ever reaching memory.
+ *   x       [B*H*W, p*p*c] the expand Linear's output (row stride ldx, un-shuffled); p = 0: x is [B*H*W, c] itself (no rearrange)
+ *   Wc, bc  [ncls, c], [ncls] (the 1x1 convolution's weight / bias); gamma, beta [c]
+ *   logits  [B*(H p)*(W p), ldl] token-major, ldl >= ncls; mean / rstd [rows] fp32 saved for the backward
+ *   dl      the gradient of logits [rows, lddl]; read in 16-byte pieces when its rows are 16-byte aligned (lddl a multiple of 8 elements
+ *           >= ncls rounded up to 8: the captured training step pads the logits' rows to that), element by element otherwise
+ *   dx      written in x's layout (row stride lddx); dgamma / dbeta / dWc / dbc fp32, ADDED to
+ *   scratch fp32, tc_ln_cls_scratch_floats(rows, ncls) floats (per-workgroup partial sums; folded by the call's second launch)
+ * 16-bit storage, c = 64, ncls in {2, 9}: tc_ln_cls_supported; TC_ERR_ARG otherwise (callers keep the op-by-op form).
+ * xn is kept in fp32 between the LayerNorm and the product (the op-by-op form rounds it to the storage type). */
+int tc_ln_cls_supported(int C, int ncls, int dtype);
+long long tc_ln_cls_scratch_floats(int rows, int ncls);
+int tc_ln_cls_fwd(const void* x, int ldx, const void* gamma, const void* beta, const void* Wc, const void* bc, void* logits, int ldl,
+                  float* mean, float* rstd, int B, int H, int W, int p, int C, int ncls, float eps, int dtype, void* stream);
+int tc_ln_cls_bwd(const void* dl, int lddl, const void* x, int ldx, const void* gamma, const void* beta, const void* Wc, const float* mean,
+                  const float* rstd, void* dx, int lddx, float* dgamma, float* dbeta, float* dWc, float* dbc, float* scratch,
+                  long long scratch_floats, int B, int H, int W, int p, int C, int ncls, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Depthwise k x k convolution on NHWC maps, k in {3,5,7}, stride 1 or 2, padding (k-1)/2,
  * weight in the PyTorch layout [C,1,k,k], optional bias, optional "+ x" (stride 1 only).
  * x rows (pixels) have stride ldx elements, y rows ldy, so channel slices of wider buffers work.

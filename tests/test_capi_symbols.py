@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol(built):
     for name in fns:
         assert hasattr(dll, name), f"{name} declared in the header but not exported by {built}"
     from transception_amd import _lib
-    assert dll.tc_abi_version() == _lib.ABI_VERSION == 14
+    assert dll.tc_abi_version() == _lib.ABI_VERSION == 15
 
 
 def test_ctypes_binding_matches_header(built):

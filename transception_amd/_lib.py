@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("TC_LIB_PATH") or os.path.join(HERE, "libtransception_
 
 TC_F32, TC_BF16, TC_F16 = 0, 1, 2
 ACT_NONE, ACT_HSWISH, ACT_COORD, ACT_SIGMOID, ACT_GELU, ACT_SCALE, ACT_RELU = 0, 1, 2, 3, 4, 5, 6
-ABI_VERSION = 14
+ABI_VERSION = 15
 ATTN_DKV_SPLITS = 8                # include/transception_hip.h: partial dK|dV buffers in tc_attn_bwd_seg's fp32 scratch
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_longlong, C.c_float
@@ -124,6 +124,10 @@ SIGNATURES = {
     "tc_layernorm_fold": [vp, i32, vp],
     "tc_layernorm_ps_fwd": [vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp],
     "tc_layernorm_ps_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, i64, i32, vp],
+    "tc_ln_cls_supported": [i32, i32, i32],
+    "tc_ln_cls_scratch_floats": [i32, i32],
+    "tc_ln_cls_fwd": [vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, f32, i32, vp],
+    "tc_ln_cls_bwd": [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp],
     "tc_layernorm_bwd_params": [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i32, vp],
     "tc_dwconv_fwd": [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i64, i32, vp],
     "tc_dwconv_bwd_input": [vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i64, i32, vp],
@@ -224,8 +228,8 @@ SIGNATURES = {
     "tc_mhca_att_bwd": [vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, f32, i32, vp],
     "tc_mhca_att_fwd": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, f32, i32, vp],
 }
-_RET = {"tc_ffn_fused_bwd_scratch_floats": i64, "tc_effatt_scratch_floats": i64, "tc_bn_scratch_floats": i64, "tc_softmax_scratch_floats": i64, "tc_layernorm_bwd_scratch_floats": i64, "tc_dwconv_bwd_plan": i64, "tc_dwconv_multi_plan": i64, "tc_ffn_mid_plan": i64, "tc_factor_att_stats_floats": i64}
-_RAW = {"tc_abi_version", "tc_linear_ln_supported", "tc_ripm_supported", "tc_ripm_tiles", "tc_mhca_att_supported", "tc_dw_ln_supported", "tc_mhca_att_bwd_supported", "tc_effatt_supported", "tc_effatt_scratch_floats", "tc_ffn_chunk", "tc_ffn_fused_supported", "tc_ffn_fused_bwd_supported", "tc_ffn_fused_bwd_scratch_floats", "tc_bn_scratch_floats", "tc_softmax_scratch_floats", "tc_layernorm_bwd_scratch_floats", "tc_layernorm_bwd_nblk", "tc_dwconv_bwd_plan", "tc_dwconv_multi_plan", "tc_ffn_mid_plan", "tc_factor_att_stats_floats"}     # not status-returning
+_RET = {"tc_ln_cls_scratch_floats": i64, "tc_ffn_fused_bwd_scratch_floats": i64, "tc_effatt_scratch_floats": i64, "tc_bn_scratch_floats": i64, "tc_softmax_scratch_floats": i64, "tc_layernorm_bwd_scratch_floats": i64, "tc_dwconv_bwd_plan": i64, "tc_dwconv_multi_plan": i64, "tc_ffn_mid_plan": i64, "tc_factor_att_stats_floats": i64}
+_RAW = {"tc_abi_version", "tc_ln_cls_supported", "tc_ln_cls_scratch_floats", "tc_linear_ln_supported", "tc_ripm_supported", "tc_ripm_tiles", "tc_mhca_att_supported", "tc_dw_ln_supported", "tc_mhca_att_bwd_supported", "tc_effatt_supported", "tc_effatt_scratch_floats", "tc_ffn_chunk", "tc_ffn_fused_supported", "tc_ffn_fused_bwd_supported", "tc_ffn_fused_bwd_scratch_floats", "tc_bn_scratch_floats", "tc_softmax_scratch_floats", "tc_layernorm_bwd_scratch_floats", "tc_layernorm_bwd_nblk", "tc_dwconv_bwd_plan", "tc_dwconv_multi_plan", "tc_ffn_mid_plan", "tc_factor_att_stats_floats"}     # not status-returning
 
 
 class TcError(RuntimeError):

@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtransception_hip.so")
-SOURCES = ["gemm.hip", "norm.hip", "dwconv.hip", "softmax.hip", "attention.hip", "attention_seg.hip", "elementwise.hip", "train.hip", "factoratt.hip", "data.hip", "mixffn.hip", "mixffn_bwd.hip", "effatt.hip", "cbam.hip", "ripm.hip", "linln.hip"]
+SOURCES = ["gemm.hip", "norm.hip", "dwconv.hip", "softmax.hip", "attention.hip", "attention_seg.hip", "elementwise.hip", "train.hip", "factoratt.hip", "data.hip", "mixffn.hip", "mixffn_bwd.hip", "effatt.hip", "cbam.hip", "ripm.hip", "linln.hip", "lncls.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-munsafe-fp-atomics"]
 
 

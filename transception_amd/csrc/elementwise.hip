@@ -655,4 +655,4 @@ extern "C" int tc_seg_marker(int id, void* stream) {
     hipLaunchKernelGGL(seg_marker_kernel, dim3(id + 1), dim3(64), 0, TC_S, id);
     return tc_launch_status();
 }
-extern "C" int tc_abi_version(void) { return 14; }
+extern "C" int tc_abi_version(void) { return 15; }

@@ -202,6 +202,7 @@ _EFFATT_FUSED = os.environ.get("TC_EFFATT_FUSED", "1") != "0"        # Efficient
 _FFN_PRE_LN = os.environ.get("TC_FFN_PRE_LN", "0") != "0"
 _LIN_LN_FUSED = os.environ.get("TC_LIN_LN_FUSED", "1") != "0"       # square Linear + residual + LayerNorm (proj / reprojection + skip + norm2) as one forward launch (csrc/linln.hip)
 _RIPM_FUSED = os.environ.get("TC_RIPM_FUSED", "1") != "0"            # a DWConv2d_BN step of the RIPM stages per launch, BatchNorm applied by the consumer (csrc/ripm.hip)
+_LN_CLS_FUSED = os.environ.get("TC_LN_CLS_FUSED", "1") != "0"        # FinalPatchExpand_X4's rearrange + LayerNorm and the classifier as one forward / one backward launch (csrc/lncls.hip, round 6)
 _DW_LN_FUSED = os.environ.get("TC_DW_LN_FUSED", "1") != "0"          # cpe (dw3x3 + skip) + norm1 of an MHCABlock as one forward launch
 _MHCA_ATT_BWD_FUSED = os.environ.get("TC_MHCA_ATT_BWD_FUSED", "1") != "0"  # ... and the backward of crpe + attention core as one launch
 _MHCA_ATT_FUSED = os.environ.get("TC_MHCA_ATT_FUSED", "1") != "0"  # qkv + crpe + factorised attention of an MHCABlock as one forward launch (csrc/factoratt.hip)
@@ -1196,6 +1197,43 @@ class Graph:
             _timed("hbm:layernorm_bwd", 3.0 * rows * c * es, lambda: self.L.tc_layernorm_ps_bwd(
                 _ptr(dy), dy.stride(0), _ptr(x.data), x.ld, _ptr(g.data), _ptr(b.data), _ptr(mean), _ptr(rstd), _ptr(gx), gx.stride(0),
                 _ptr(g.grad), _ptr(b.grad), B, H, W, p, c, _ptr(ws) if g.grad is not None else None, ws.numel() // 4, self.dt, self.stream))
+        self._rec(bwd)
+        return out
+
+    def ln_cls_supported(self, x: Var, p: int, g: P, b: P, Wc: P, bc: Optional[P]) -> bool:
+        c = x.cols // max(p * p, 1)
+        return (_LN_CLS_FUSED and self.dt != TC_F32 and self.ngroups == 1 and not self.use_streams and bc is not None and x.ld % 8 == 0
+                and all(q.data.data_ptr() % 16 == 0 for q in (x, g, b, Wc)) and Wc.data.is_contiguous() and Wc.data.shape[1] == c
+                and bool(self.L.tc_ln_cls_supported(c, Wc.data.shape[0], self.dt)))
+
+    def ln_cls(self, x: Var, g: P, b: P, Wc: P, bc: P, B: int, H: int, W: int, p: int, eps: float = 1e-5, pad_rows: bool = False) -> Var:
+        """logits = classifier(LayerNorm(pixel-shuffled x)) -- FinalPatchExpand_X4's rearrange + norm and last_layer (MSTr.py:222-225, 281) -- as
+        ONE forward launch and one backward call (tc_ln_cls_fwd / _bwd): the normalised [B (H p) (W p), c] map and its gradient never reach
+        memory.  pad_rows: the logits (and so their gradient) get 16-byte-aligned rows (row stride ncls rounded up to 8); the returned Var is
+        the [rows, ncls] column slice of that buffer."""
+        assert self.ngroups == 1 and x.rows == B * H * W and x.cols % max(p * p, 1) == 0
+        c = x.cols // max(p * p, 1)
+        ncls = Wc.data.shape[0]
+        rows = B * H * p * W * p if p else x.rows
+        out = self.new(rows, (ncls + 7) // 8 * 8).colslice(0, ncls) if pad_rows else self.new(rows, ncls)
+        mean, rstd = self.f32(rows), self.f32(rows)
+        es = x.data.element_size()
+        self.n_launch += 1
+        _timed("hbm:ln_cls_fwd (pixel shuffle + LayerNorm + classifier, one launch)", 1.0 * rows * (c + ncls) * es, lambda: self.L.tc_ln_cls_fwd(
+            _ptr(x.data), x.ld, _ptr(g.data), _ptr(b.data), _ptr(Wc.data), _ptr(bc.data), _ptr(out.data), out.ld, _ptr(mean), _ptr(rstd),
+            B, H, W, p, c, ncls, eps, self.dt, self.stream))
+
+        def bwd():
+            dl = self.grad_of(out)
+            if dl is None or not x.requires_grad:
+                return
+            gx, acc = self.wgrad(x)
+            assert not acc, "the expanded map has one consumer"
+            n = int(self.L.tc_ln_cls_scratch_floats(rows, ncls))
+            scratch = self.f32(n)
+            _timed("hbm:ln_cls_bwd", 1.0 * rows * (2 * c + ncls) * es, lambda: self.L.tc_ln_cls_bwd(
+                _ptr(dl), dl.stride(0), _ptr(x.data), x.ld, _ptr(g.data), _ptr(b.data), _ptr(Wc.data), _ptr(mean), _ptr(rstd), _ptr(gx), gx.stride(0),
+                _ptr(g.grad), _ptr(b.grad), _ptr(Wc.grad), _ptr(bc.grad), _ptr(scratch), n, B, H, W, p, c, ncls, self.dt, self.stream))
         self._rec(bwd)
         return out
 

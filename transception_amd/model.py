@@ -714,6 +714,21 @@ class MSTransception(nn.Module):
         first = next((p for p in self._uniq_params if id(p) in self._used_views), None)
         if first is not None and first.grad is None:
             self._gflat.zero_()                     # zero_grad(set_to_none=True) semantics: start from zero
+        root = out_var.root
+        if not out_var.is_whole:
+            # token-major logits with padded rows (Graph.ln_cls(pad_rows=True)): the gradient mirrors that layout.  A caller that allocated
+            # dlogits as the column slice of such a buffer (train.GraphedStep does) hands it over as it is; anything else is copied in.
+            es = root.data.element_size()
+            if (dlogits.dtype == self.compute_dtype and dlogits.dim() == 2 and dlogits.stride() == out_var.data.stride() and dlogits.storage_offset() == 0
+                    and dlogits.untyped_storage().nbytes() >= root.data.numel() * es):
+                full = torch.as_strided(dlogits, root.data.shape, root.data.stride())
+            else:
+                full = torch.empty_like(root.data)
+                out_var.apply_path(full).copy_(dlogits.view(out_var.rows, out_var.cols))
+            root.grad_t, root.whole_written = full, True
+            if G.backward(until):
+                self._attach_grads()
+            return
         d = dlogits.contiguous()
         if d.dtype != self.compute_dtype:
             dl = torch.empty(d.shape, dtype=self.compute_dtype, device=d.device)
@@ -1223,9 +1238,20 @@ def _decoder(M, G, x1: Var, skip: Var, name: str, B: int, side: int, last: bool)
     t = _eff_block(M, G, t, name + ".layer_former_2", B, side, side)
     if not last:
         return _patch_expand(M, G, t, name + ".layer_up", B, side, 2)
-    y = _patch_expand(M, G, t, name + ".layer_up", B, side, 4)
-    lg = G.linear(y, *_lin(M, G, name + ".last_layer"))         # [B*16*side^2, classes]
-    if getattr(M, "_tok_logits", False):
+    tok = bool(getattr(M, "_tok_logits", False))
+    up = name + ".layer_up"
+    if t.rows != B * side * side:
+        raise AssertionError("input feature has wrong size")
+    Wc, bc = _lin(M, G, name + ".last_layer")
+    gn, bn = M._P(G, up + ".norm.weight"), M._P(G, up + ".norm.bias")
+    ye = G.linear(t, *_lin(M, G, up + ".expand", bias=False))       # FinalPatchExpand_X4.expand, MSTr.py:219-221
+    if SHUFFLE_IN_LN and G.ln_cls_supported(ye, 4, gn, bn, Wc, bc):
+        # rearrange + norm of FinalPatchExpand_X4 and last_layer in one launch each way (csrc/lncls.hip): the normalised 224^2 x 64 map is never stored
+        lg = G.ln_cls(ye, gn, bn, Wc, bc, B, side, side, 4, pad_rows=tok)
+    else:
+        y = G.layernorm_shuffled(ye, gn, bn, B, side, side, 4) if SHUFFLE_IN_LN else _ln(M, G, G.pixel_shuffle(ye, B, side, side, 4), up + ".norm")
+        lg = G.linear(y, Wc, bc)                                # [B*16*side^2, classes]
+    if tok:
         return lg                                               # token-major for the captured step's loss kernels
     return G.transpose(lg, B)                                   # NCHW logits [B*classes, H*W]
 

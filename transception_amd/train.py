@@ -557,7 +557,9 @@ class GraphedStep:
         lf, lg = self.loss_fn, self._logits
         self.out = tuple(t.float() for t in loss_from_sums(self._sums, self._npix, lf.w_ce, lf.w_dice))
         stream = torch.cuda.current_stream(lg.device).cuda_stream
-        d = torch.empty((B * H * W, C), dtype=self.model.compute_dtype, device=lg.device)        # the gradient of the token-major logits
+        # the gradient of the token-major logits, in the logits' own layout (their rows are padded to 16 bytes when the fused LayerNorm +
+        # classifier produced them: Graph.ln_cls)
+        d = torch.empty((B * H * W, lg.stride(0)), dtype=self.model.compute_dtype, device=lg.device)[:, :C]
         L.tc_seg_loss_bwd_tok(None, lg.data_ptr(), lg.stride(0), self.y.data_ptr(), self._sums.data_ptr(), d.data_ptr(), d.stride(0), B, C, H * W,
                               float(lf.w_ce), float(lf.w_dice), float(self._npix), float(lf.loss_scale), None, _dt(d), stream)
         M._backward(self._G, self._out_var, d, until="encoder_done")     # loss gradient, decoders, bridge
