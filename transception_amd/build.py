@@ -51,9 +51,13 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if force or _stale(o, [s] + headers + extra.get(src, [])):
             jobs.append((s, o))
 
+    # per-file flags.  lncls.hip: hipcc's SLP vectoriser packs the classifier's fp32 multiply-adds into v_pk_fma_f32 / v_pk_add_f32 and pays
+    # for it in v_mov_b32 (305 of the forward kernel's 1412 instructions; packed fp32 issues at half rate anyway): 8 % fewer instructions without
+    extra_flags = {"lncls.hip": ["-fno-slp-vectorize"]}
+
     def compile_one(job):
         s, o = job
-        cmd = [hipcc, *FLAGS, "-c", s, "-o", o]
+        cmd = [hipcc, *FLAGS, *extra_flags.get(os.path.basename(s), []), "-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {s}:\n{r.stderr}")

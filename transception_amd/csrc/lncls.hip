@@ -17,12 +17,25 @@
 
 namespace {
 
-struct PsMap { int p, H, W; };
+// Output pixel -> element offset of its c channels in the un-shuffled map.  The three divisions (by W p, H p and p) are multiplications by
+// M = floor(2^32 / d) + 1 (exact for n * d < 2^32; the host checks): as run-time integer divisions they were ~100 of the ~250 instructions
+// a row costs these kernels.
+struct PsMap { int p, H, W; unsigned mWp, mHp, mp; };
 __device__ __forceinline__ long long ps_row_off(int row, const PsMap& m, int ld, int C) {
     if (m.p == 0) return (long long)row * ld;
-    const int Wp = m.W * m.p, Hp = m.H * m.p;
-    const int ow = row % Wp, t = row / Wp, oh = t % Hp, b = t / Hp;
-    return ((long long)(b * m.H + oh / m.p) * m.W + ow / m.p) * ld + ((oh % m.p) * m.p + ow % m.p) * C;
+    const unsigned Wp = m.W * m.p, Hp = m.H * m.p, r = (unsigned)row;
+    const unsigned t = __umulhi(r, m.mWp), ow = r - t * Wp, b = __umulhi(t, m.mHp), oh = t - b * Hp;
+    const unsigned ih = __umulhi(oh, m.mp), iw = __umulhi(ow, m.mp), p1 = oh - ih * m.p, p2 = ow - iw * m.p;
+    return ((long long)(b * m.H + ih) * m.W + iw) * ld + (p1 * m.p + p2) * C;
+}
+inline bool ps_map(PsMap& m, int p, int H, int W, long long rows) {
+    m.p = p; m.H = H; m.W = W; m.mWp = m.mHp = m.mp = 0;
+    if (p == 0) return true;
+    if (p < 2) return false;                                        // (M of d = 1 does not fit 32 bits; p = 1 is p = 0 to the callers)
+    const unsigned long long Wp = (unsigned long long)W * p, Hp = (unsigned long long)H * p;
+    if ((unsigned long long)rows * (Wp > Hp ? Wp : Hp) >= (1ull << 32)) return false;
+    m.mWp = (unsigned)((1ull << 32) / Wp + 1); m.mHp = (unsigned)((1ull << 32) / Hp + 1); m.mp = (unsigned)((1ull << 32) / (unsigned)p + 1);
+    return true;
 }
 
 template <typename T> __device__ __forceinline__ void up8(const uint4& r, float* o) {
@@ -32,25 +45,31 @@ template <typename T> __device__ __forceinline__ void up8(const uint4& r, float*
 constexpr int LC_C = 64, LC_GS = 8, LC_RPB = 256 / LC_GS;      // channels; lanes per row; rows per workgroup pass
 
 // One pass = 32 consecutive output rows per workgroup; RP passes' loads are issued before the first reduction.
-template <typename T, int NC, int RP>
+// PL: the logits rows are 16-byte aligned and padded to a multiple of 8 elements (Graph.ln_cls(pad_rows=True)): lane q of the row stores
+// the 16-byte piece q (classes 8 q .. 8 q + 7, zeros past NC); otherwise lane j stores class j as a 2-byte element (nine partial-line
+// writes per row: measured 56 us for the 224^2 B = 16 map against 3x less with whole pieces).
+template <typename T, int NC, int RP, bool PL>
 __global__ __launch_bounds__(256) void ln_cls_fwd_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ gamma, const T* __restrict__ beta,
                                                          const T* __restrict__ Wc, const T* __restrict__ bc, T* __restrict__ logits, int ldl,
                                                          float* __restrict__ mean, float* __restrict__ rstd, int rows, float eps, PsMap map) {
     const int gl = threadIdx.x % LC_GS, gi = threadIdx.x / LC_GS;
-    float g[8], b[8], w[NC][8], bias[NC];
+    // the lane's slice of Wc is read from LDS per row (fp32; the same address across a wave's rows: broadcast) -- in registers it cost 72 VGPRs
+    // and a wave per SIMD
+    __shared__ float4 wsh4[NC * LC_C / 4];
+    float* wsh = reinterpret_cast<float*>(wsh4);
+    for (int i = threadIdx.x; i < NC * LC_C; i += 256) wsh[i] = ldf<T>(Wc + i);
+    float g[8], b[8], bias[NC];
     up8<T>(*reinterpret_cast<const uint4*>(gamma + gl * 8), g);
     up8<T>(*reinterpret_cast<const uint4*>(beta + gl * 8), b);
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        up8<T>(*reinterpret_cast<const uint4*>(Wc + c * LC_C + gl * 8), w[c]);
-        bias[c] = ldf<T>(bc + c);
-    }
+    for (int c = 0; c < NC; ++c) bias[c] = ldf<T>(bc + c);
+    __syncthreads();
     for (long long r0 = (long long)blockIdx.x * LC_RPB * RP; r0 < rows; r0 += (long long)gridDim.x * LC_RPB * RP) {
         uint4 raw[RP];
 #pragma unroll
         for (int q = 0; q < RP; ++q) {
             const long long r = r0 + q * LC_RPB + gi;
-            raw[q] = r < rows ? *reinterpret_cast<const uint4*>(x + ps_row_off((int)r, map, ldx, LC_C) + gl * 8) : make_uint4(0u, 0u, 0u, 0u);
+            raw[q] = *reinterpret_cast<const uint4*>(x + ps_row_off((int)(r < rows ? r : rows - 1), map, ldx, LC_C) + gl * 8);   // (branch-free: rows past the end re-read the last one)
         }
 #pragma unroll
         for (int q = 0; q < RP; ++q) {
@@ -68,20 +87,35 @@ __global__ __launch_bounds__(256) void ln_cls_fwd_kernel(const T* __restrict__ x
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e] * rs, g[e], b[e]);
             float acc[NC];
+            int woff = gl * 2;
+            asm volatile("" : "+v"(woff));                          // (keeps the loop-invariant LDS reads inside the loop)
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                float a = 0.f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) a = fmaf(v[e], w[c][e], a);
+                const float4 w0 = wsh4[c * (LC_C / 4) + woff], w1 = wsh4[c * (LC_C / 4) + woff + 1];
+                float a = v[0] * w0.x;
+                a = fmaf(v[1], w0.y, a); a = fmaf(v[2], w0.z, a); a = fmaf(v[3], w0.w, a);
+                a = fmaf(v[4], w1.x, a); a = fmaf(v[5], w1.y, a); a = fmaf(v[6], w1.z, a); a = fmaf(v[7], w1.w, a);
                 acc[c] = tc_group_sum<LC_GS>(a) + bias[c];
             }
             if (r < rows) {
                 if (gl == 0) { mean[r] = mu; rstd[r] = rs; }
                 T* lp = logits + r * ldl;
-                // lane j of the row stores class j (+ 8 j' for NC > 8): every lane of the group holds every sum after the butterflies
+                // every lane of the group holds every sum after the butterflies
+                if constexpr (PL) {
+                    constexpr int NQ = (NC + 7) / 8;
 #pragma unroll
-                for (int c = 0; c < NC; ++c)
-                    if ((c & 7) == gl) stf<T>(lp + c, acc[c]);
+                    for (int q = 0; q < NQ; ++q)
+                        if (gl == q) {
+                            float o[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) o[e] = 8 * q + e < NC ? acc[(8 * q + e) < NC ? 8 * q + e : 0] : 0.f;
+                            *reinterpret_cast<uint4*>(lp + 8 * q) = make_uint4(pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]), pack2<T>(o[4], o[5]), pack2<T>(o[6], o[7]));
+                        }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c)
+                        if ((c & 7) == gl) stf<T>(lp + c, acc[c]);
+                }
             }
         }
     }
@@ -102,7 +136,8 @@ __global__ __launch_bounds__(256, 2) void ln_cls_bwd_kernel(const T* __restrict_
                                                             int lddx, float* __restrict__ part, int rows, PsMap map) {
     using PT = LcPart<NC>;
     __shared__ float red[4][PT::n];
-    __shared__ __attribute__((aligned(16))) float wsh[NC * LC_C];
+    __shared__ float4 wsh4[NC * LC_C / 4];
+    float* wsh = reinterpret_cast<float*>(wsh4);
     const int gl = threadIdx.x % LC_GS, gi = threadIdx.x / LC_GS, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < NC * LC_C; i += 256) wsh[i] = ldf<T>(Wc + i);
     float g[8], b[8];
@@ -120,47 +155,50 @@ __global__ __launch_bounds__(256, 2) void ln_cls_bwd_kernel(const T* __restrict_
     __syncthreads();
     constexpr int NQ = (NC + 7) / 8;                                // 16-byte pieces of a dlogits row (rows are 16-byte aligned: lddl % 8 == 0)
     const long long step = (long long)gridDim.x * LC_RPB;
-    uint4 raw, dq[NQ];
-    float du[AL ? 1 : NC];
-    float mu, rs;
-    auto fetch = [&](long long r) __attribute__((always_inline)) {
-        const bool ok = r < rows;
-        raw = *reinterpret_cast<const uint4*>(x + (ok ? ps_row_off((int)r, map, ldx, LC_C) + gl * 8 : 0));
+    // two rows of this lane group are in flight ahead of the one being worked on (at two waves per SIMD one row ahead left ~24 KB per CU
+    // outstanding: 106 us for the 224^2 B = 16 map, latency-bound)
+    struct Row { uint4 raw, dq[NQ]; float du[AL ? 1 : NC]; float mu, rs; };
+    Row nx0, nx1;
+    auto fetch = [&](Row& w, long long r) __attribute__((always_inline)) {
+        const long long rc = r < rows ? r : rows - 1;               // (branch-free: rows past the end re-read the last one and are dropped)
+        w.raw = *reinterpret_cast<const uint4*>(x + ps_row_off((int)rc, map, ldx, LC_C) + gl * 8);
         if constexpr (AL) {
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) dq[q] = *reinterpret_cast<const uint4*>(dl + (ok ? r : 0) * lddl + q * 8);
+            for (int q = 0; q < NQ; ++q) w.dq[q] = *reinterpret_cast<const uint4*>(dl + rc * lddl + q * 8);
         } else {
 #pragma unroll
-            for (int c = 0; c < NC; ++c) du[c] = ldf<T>(dl + (ok ? r : 0) * lddl + c);
+            for (int c = 0; c < NC; ++c) w.du[c] = ldf<T>(dl + rc * lddl + c);
         }
-        mu = mean[ok ? r : 0]; rs = rstd[ok ? r : 0];
+        w.mu = mean[rc]; w.rs = rstd[rc];
     };
     long long r = (long long)blockIdx.x * LC_RPB + gi;
-    fetch(r);
+    fetch(nx0, r);
+    fetch(nx1, r + step);
     for (; r - gi < rows; r += step) {
         const bool ok = r < rows;
         float v[8], d[NC];
-        const float mu_ = mu, rs_ = rs;
-        up8<T>(raw, v);
+        const float mu_ = nx0.mu, rs_ = nx0.rs;
+        up8<T>(nx0.raw, v);
         if constexpr (AL) {
             float t8[8 * NQ];
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) up8<T>(dq[q], t8 + 8 * q);
+            for (int q = 0; q < NQ; ++q) up8<T>(nx0.dq[q], t8 + 8 * q);
 #pragma unroll
             for (int c = 0; c < NC; ++c) d[c] = ok ? t8[c] : 0.f;
         } else {
 #pragma unroll
-            for (int c = 0; c < NC; ++c) d[c] = ok ? du[c] : 0.f;
+            for (int c = 0; c < NC; ++c) d[c] = ok ? nx0.du[c] : 0.f;
         }
-        fetch(r + step);                                            // the next row of this lane group: in flight under the arithmetic below
+        nx0 = nx1;
+        fetch(nx1, r + 2 * step);                                   // two rows ahead: in flight under the arithmetic of this row and the next
         float xh[8], xn[8], dxn[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { xh[e] = (v[e] - mu_) * rs_; xn[e] = fmaf(xh[e], g[e], b[e]); dxn[e] = 0.f; }
-        int woff = gl * 8;
+        int woff = gl * 2;
         asm volatile("" : "+v"(woff));                              // (loop-invariant LDS reads would be hoisted: 72 more live registers)
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            const float4 w0 = *reinterpret_cast<const float4*>(wsh + c * LC_C + woff), w1 = *reinterpret_cast<const float4*>(wsh + c * LC_C + woff + 4);
+            const float4 w0 = wsh4[c * (LC_C / 4) + woff], w1 = wsh4[c * (LC_C / 4) + woff + 1];
             const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
             dc[c] += d[c];
 #pragma unroll
@@ -212,15 +250,17 @@ __global__ __launch_bounds__(256, 2) void ln_cls_bwd_kernel(const T* __restrict_
     for (int i = threadIdx.x; i < PT::n; i += 256) po[i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
 }
 
-// sums the per-workgroup partials and ADDS them to the gradient arrays: one thread per entry, eight partials in flight
+// sums the per-workgroup partials and ADDS them to the gradient arrays: thread = (entry, one of gridDim.y slices of the partials), eight
+// partials in flight, one fp32 atomic per thread (one thread per entry walking all 512 partials took 26 us: a chain of 64 round trips)
 template <int NC>
-__global__ __launch_bounds__(256) void ln_cls_fold_kernel(const float* __restrict__ part, int nblk, float* __restrict__ dgamma, float* __restrict__ dbeta,
+__global__ __launch_bounds__(256) void ln_cls_fold_kernel(const float* __restrict__ part, int nblk_all, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                           float* __restrict__ dWc, float* __restrict__ dbc) {
     using PT = LcPart<NC>;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= PT::n) return;
+    const int per = (nblk_all + (int)gridDim.y - 1) / (int)gridDim.y, k0 = blockIdx.y * per, nblk = min(nblk_all, k0 + per);
     float s = 0.f;
-    int k = 0;
+    int k = k0;
     for (; k + 8 <= nblk; k += 8) {
         float a[8];
 #pragma unroll
@@ -228,10 +268,9 @@ __global__ __launch_bounds__(256) void ln_cls_fold_kernel(const float* __restric
         s += ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     }
     for (; k < nblk; ++k) s += part[(long long)k * PT::n + i];
-    if (i < PT::oB) dgamma[i] += s;
-    else if (i < PT::oW) dbeta[i - PT::oB] += s;
-    else if (i < PT::oC) dWc[i - PT::oW] += s;
-    else dbc[i - PT::oC] += s;
+    if (k0 >= nblk_all) return;
+    float* dst = i < PT::oB ? dgamma + i : i < PT::oW ? dbeta + (i - PT::oB) : i < PT::oC ? dWc + (i - PT::oW) : dbc + (i - PT::oC);
+    atomicAdd(dst, s);
 }
 
 inline int lc_nblk(int rows) {
@@ -253,18 +292,24 @@ extern "C" long long tc_ln_cls_scratch_floats(int rows, int ncls) {
 extern "C" int tc_ln_cls_fwd(const void* x, int ldx, const void* gamma, const void* beta, const void* Wc, const void* bc, void* logits, int ldl,
                              float* mean, float* rstd, int B, int H, int W, int p, int C, int ncls, float eps, int dtype, void* stream) {
     if (!tc_ln_cls_supported(C, ncls, dtype) || !x || !gamma || !beta || !Wc || !bc || !logits || !mean || !rstd || B <= 0 || H <= 0 || W <= 0 || p < 0 ||
-        ldx < (p ? p * p : 1) * C || (ldx & 7) || ldl < ncls || !lc_aligned(x) || !lc_aligned(gamma) || !lc_aligned(beta) || !lc_aligned(Wc))
+        ldx < (p ? p * p : 1) * C || (ldx & 7) || ldl < ncls || !lc_aligned(x) || !lc_aligned(gamma) || !lc_aligned(beta))
         return TC_ERR_ARG;
     const long long rows = p ? (long long)B * H * p * W * p : (long long)B * H * W;
     if (rows > 0x7fffffffLL) return TC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    const PsMap map{p, H, W};
-    const int nblk = (int)((rows + 2 * LC_RPB - 1) / (2 * LC_RPB) < 2048 ? (rows + 2 * LC_RPB - 1) / (2 * LC_RPB) : 2048);
-#define TC_LCF(T_, NC_) hipLaunchKernelGGL((ln_cls_fwd_kernel<T_, NC_, 2>), dim3(nblk), dim3(256), 0, s, (const T_*)x, ldx, (const T_*)gamma, (const T_*)beta, \
-                                           (const T_*)Wc, (const T_*)bc, (T_*)logits, ldl, mean, rstd, (int)rows, eps, map)
-    if (dtype == TC_BF16) { if (ncls == 9) TC_LCF(bf16_t, 9); else TC_LCF(bf16_t, 2); }
-    else { if (ncls == 9) TC_LCF(f16_t, 9); else TC_LCF(f16_t, 2); }
+    PsMap map;
+    if (!ps_map(map, p, H, W, rows)) return TC_ERR_ARG;
+    constexpr int RP = 4;                                           // rows of a lane group in flight
+    const long long passes = (rows + RP * LC_RPB - 1) / (RP * LC_RPB);
+    const int nblk = (int)(passes < 1024 ? passes : 1024);          // 4 workgroups per CU (~100 VGPRs)
+    const bool pl = !(ldl & 7) && ldl >= ((ncls + 7) & ~7) && lc_aligned(logits);
+#define TC_LCF1(T_, NC_, PL_) hipLaunchKernelGGL((ln_cls_fwd_kernel<T_, NC_, RP, PL_>), dim3(nblk), dim3(256), 0, s, (const T_*)x, ldx, (const T_*)gamma, (const T_*)beta, \
+                                                 (const T_*)Wc, (const T_*)bc, (T_*)logits, ldl, mean, rstd, (int)rows, eps, map)
+#define TC_LCF(T_, NC_) { if (pl) TC_LCF1(T_, NC_, true); else TC_LCF1(T_, NC_, false); }
+    if (dtype == TC_BF16) { if (ncls == 9) TC_LCF(bf16_t, 9) else TC_LCF(bf16_t, 2) }
+    else { if (ncls == 9) TC_LCF(f16_t, 9) else TC_LCF(f16_t, 2) }
 #undef TC_LCF
+#undef TC_LCF1
     return tc_launch_status();
 }
 
@@ -279,12 +324,13 @@ extern "C" int tc_ln_cls_bwd(const void* dl, int lddl, const void* x, int ldx, c
     const long long rows = p ? (long long)B * H * p * W * p : (long long)B * H * W;
     if (rows > 0x7fffffffLL || scratch_floats < tc_ln_cls_scratch_floats((int)rows, ncls)) return TC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    const PsMap map{p, H, W};
+    PsMap map;
+    if (!ps_map(map, p, H, W, rows)) return TC_ERR_ARG;
     const int nblk = lc_nblk((int)rows);
 #define TC_LCB1(T_, NC_, AL_) hipLaunchKernelGGL((ln_cls_bwd_kernel<T_, NC_, AL_>), dim3(nblk), dim3(256), 0, s, (const T_*)dl, lddl, (const T_*)x, ldx, (const T_*)gamma, \
                                                  (const T_*)beta, (const T_*)Wc, mean, rstd, (T_*)dx, lddx, scratch, (int)rows, map)
 #define TC_LCB(T_, NC_) { if (al) TC_LCB1(T_, NC_, true); else TC_LCB1(T_, NC_, false);                                                                          \
-                          hipLaunchKernelGGL((ln_cls_fold_kernel<NC_>), dim3((LcPart<NC_>::n + 255) / 256), dim3(256), 0, s, scratch, nblk, dgamma, dbeta, dWc, dbc); }
+                          hipLaunchKernelGGL((ln_cls_fold_kernel<NC_>), dim3((LcPart<NC_>::n + 255) / 256, 32), dim3(256), 0, s, scratch, nblk, dgamma, dbeta, dWc, dbc); }
     if (dtype == TC_BF16) { if (ncls == 9) TC_LCB(bf16_t, 9) else TC_LCB(bf16_t, 2) }
     else { if (ncls == 9) TC_LCB(f16_t, 9) else TC_LCB(f16_t, 2) }
 #undef TC_LCB

@@ -1200,8 +1200,10 @@ class Graph:
         self._rec(bwd)
         return out
 
-    def ln_cls_supported(self, x: Var, p: int, g: P, b: P, Wc: P, bc: Optional[P]) -> bool:
+    def ln_cls_supported(self, x: Var, p: int, g: P, b: P, Wc: P, bc: Optional[P], B: int = 0, H: int = 0, W: int = 0) -> bool:
         c = x.cols // max(p * p, 1)
+        if p >= 2 and B * H * p * W * p * max(H, W) * p >= 1 << 32:        # the kernels' pixel-shuffle addressing divides by multiplication (csrc/lncls.hip, ps_map)
+            return False
         return (_LN_CLS_FUSED and self.dt != TC_F32 and self.ngroups == 1 and not self.use_streams and bc is not None and x.ld % 8 == 0
                 and all(q.data.data_ptr() % 16 == 0 for q in (x, g, b, Wc)) and Wc.data.is_contiguous() and Wc.data.shape[1] == c
                 and bool(self.L.tc_ln_cls_supported(c, Wc.data.shape[0], self.dt)))

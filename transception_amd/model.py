@@ -1245,7 +1245,7 @@ def _decoder(M, G, x1: Var, skip: Var, name: str, B: int, side: int, last: bool)
     Wc, bc = _lin(M, G, name + ".last_layer")
     gn, bn = M._P(G, up + ".norm.weight"), M._P(G, up + ".norm.bias")
     ye = G.linear(t, *_lin(M, G, up + ".expand", bias=False))       # FinalPatchExpand_X4.expand, MSTr.py:219-221
-    if SHUFFLE_IN_LN and G.ln_cls_supported(ye, 4, gn, bn, Wc, bc):
+    if SHUFFLE_IN_LN and G.ln_cls_supported(ye, 4, gn, bn, Wc, bc, B, side, side):
         # rearrange + norm of FinalPatchExpand_X4 and last_layer in one launch each way (csrc/lncls.hip): the normalised 224^2 x 64 map is never stored
         lg = G.ln_cls(ye, gn, bn, Wc, bc, B, side, side, 4, pad_rows=tok)
     else:
