@@ -116,7 +116,9 @@ def test_comm_plan_covers_every_live_gradient_once():
                     dead[lo - a:hi - a] = False
             assert float(g[a:b][dead].abs().max()) == 0.0 if bool(dead.any()) else True
     assert plan["gradient_megabytes_per_step"] >= 4 * live / 1e6 and plan["ranks"] == 8
-    assert plan["collectives_per_step"] <= 4, plan["collectives_per_step"]          # one per stop of the backward sweep + the 28 loss sums
+    # one per stop of the backward sweep + the 28 loss sums, + one where a stop's live words are split by a dead gap larger than
+    # train.SPAN_GAP_MAX (round 6, ADVICE r5: 31 MB of grad-less zeros inside the first piece are no longer sent along to save a collective)
+    assert plan["collectives_per_step"] <= 5, plan["collectives_per_step"]
     assert plan["pieces"][0]["sent_when_backward_reaches"] == "encoder_done" and plan["pieces"][-1]["sent_when_backward_reaches"].startswith("end")
     assert plan["total_ring_ms_one_link"] > plan["total_ring_ms_seven_links"] > 0
     live_params = sum(p.numel() for p in m.parameters() if p.grad is not None)

@@ -32,18 +32,28 @@ template <> struct HalfOps<f16_t> {
 
 namespace {
 
+// Division of a workgroup index by a launch constant as a multiplication (round 6): hipcc expands `n / d` with a run-time d into ~30 VALU
+// instructions (v_rcp_iflag_f32 + fix-ups) although both are wave-uniform -- the tile-index prologues of gemm_pair_kernel / gemm_multi_kernel
+// held 44 / 53 such sequences, several hundred instructions at the head of every workgroup.  m = floor(2^32 / d) + 1 is exact for
+// n * d < 2^32 (the host checks against the largest n the launch can produce; m = 0 keeps the division).
+static inline unsigned fdiv_make(long long d, unsigned long long nmax) {
+    return (d > 1 && nmax * (unsigned long long)d < (1ull << 32)) ? (unsigned)((1ull << 32) / (unsigned long long)d + 1) : 0u;
+}
+__device__ __forceinline__ int fdiv(int n, int d, unsigned m) { return d == 1 ? n : (m ? (int)__umulhi((unsigned)n, m) : n / d); }
+
 struct GemmDev {
     const void* A; const void* B; void* C; const void* bias; const void* R;
     int M, N, K, lda, ldb, ldc, ldr;
     int nb2, splitk, kchunk;
+    unsigned m_splitk, m_nb2, m_gx;   // fdiv multipliers: blockIdx.z = (b1 * nb2 + b2) * splitk + ks < 65536; m_gx: the grid's x extent (tc_xcd_tile)
     long long sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2;
     float alpha; int accumulate, act;
-    int vecA, vecB, vecC, atomic;
+    unsigned char vecA, vecB, vecC, atomic;   // (bytes: twelve of these structs + the per-problem arrays of gemm_multi_kernel fill the 4 KiB argument block)
     short vec8C;            // bf16 C rows are 16-byte addressable (LDS-staged, fully coalesced epilogue)
     short xcd;              // XCD-aware tile numbering (tc_xcd_tile)
     float* rowsum;          // optional: rowsum[m] += sum_k op(A)[m][k]  (fp32, atomics)
     long long sBias1, sRow1; // batch-level-1 strides of bias / rowsum (grouped weights)
-    float* ws_part; int* ws_cnt; int fix_group, fix_ngroups;   // split-K fix-up workspace (fix_group > 0: enabled)
+    float* ws_part; int* ws_cnt; short fix_group, fix_ngroups;   // split-K fix-up workspace (fix_group > 0: enabled; group size 16, <= 4096 groups)
     int bgap_every; long long bgap;   // B stored [K,N] in blocks of bgap_every rows with bgap extra elements between blocks
     struct {                          // MixFFN_skip fusion hooks (TcGemm.ffn_*); mode mirrors the kernels' FFN template parameter
         int mode, nchunk, chunk_n, ldd, sRow1, sPar1;
@@ -741,8 +751,9 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmDev& p, const int bx, c
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     int z = bz;
-    const int ks = z % p.splitk; z /= p.splitk;
-    const int b2 = z % p.nb2, b1 = z / p.nb2;
+    const int zq = fdiv(z, p.splitk, p.m_splitk);
+    const int ks = z - zq * p.splitk; z = zq;
+    const int b1 = fdiv(z, p.nb2, p.m_nb2), b2 = z - b1 * p.nb2;
     const int m0 = by * BM, n0 = bx * BN;
     const int kbeg = ks * p.kchunk;
     const int kend = min(p.K, kbeg + p.kchunk);
@@ -951,7 +962,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmDev& p, const int bx, c
     bool first = (ks == 0), atomic = p.atomic;
     if (p.fix_group) {
         int grp;
-        if (!splitk_fixup<TM, TN>(p, acc, ((bz / p.splitk) * gy + by) * gx + bx, ks, grp)) return;
+        if (!splitk_fixup<TM, TN>(p, acc, (zq * gy + by) * gx + bx, ks, grp)) return;
         first = (grp == 0); atomic = p.fix_ngroups > 1;
     }
     if constexpr (FFN == TC_FFN_EP) {
@@ -974,11 +985,11 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmDev& p, const int bx, c
 // M-tile -- which all read the same A rows -- land on different XCDs and every L2 fetches that A tile for itself (N = 1280: twenty
 // times).  Here the l-th workgroup of an XCD takes the l-th tile of that XCD's contiguous share of the (m, n) tile list, n fastest:
 // the readers of an A tile run back to back on one XCD.  A bijection for any tile count (the first T % 8 XCDs get one tile more).
-__device__ __forceinline__ void tc_xcd_tile(int& bx, int& by, const int gx, const int gy) {
+__device__ __forceinline__ void tc_xcd_tile(int& bx, int& by, const int gx, const int gy, const unsigned mgx) {
     const int T = gx * gy, L = bx + gx * by;
     const int xcd = L & 7, slot = L >> 3, q = T >> 3, r = T & 7;
     const int t = xcd * q + min(xcd, r) + slot;
-    by = t / gx;
+    by = fdiv(t, gx, mgx);
     bx = t - by * gx;
 }
 
@@ -992,7 +1003,7 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64) ? GEMM_OCC64 : 2) void 
     // ONE buffer: A slabs first, B slabs behind them -- the epilogue reuses it from the start as its C staging tile
     __shared__ __attribute__((aligned(16))) bf16_t smem[(DB ? 2 : 1) * (BM + BN) * (64 + 8)];
     int tbx = blockIdx.x, tby = blockIdx.y;
-    if (p.xcd & 1) tc_xcd_tile(tbx, tby, gridDim.x, gridDim.y);
+    if (p.xcd & 1) tc_xcd_tile(tbx, tby, gridDim.x, gridDim.y, p.m_gx);
     gemm_bf16_body<H, TC, BM, BN, TA, TB, DB, FFN>(p, tbx, tby, blockIdx.z, gridDim.x, gridDim.y,
                                                 reinterpret_cast<bf16_t(*)[BM * (64 + 8)]>(smem),
                                                 reinterpret_cast<bf16_t(*)[BN * (64 + 8)]>(smem + (DB ? 2 : 1) * BM * (64 + 8)));
@@ -1002,7 +1013,7 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64) ? GEMM_OCC64 : 2) void 
 // (+ row sums = db; fp32 accumulate into the gradient arena).  Both are short, low-occupancy grids (64x64 tiles); side by side in
 // one grid they fill the CUs together, where two launches on two streams mostly serialise on this part (measured: kernels from
 // different HW queues overlap only at their tails) and pay two dependency gaps.
-struct GemmPairDev { GemmDev a, b; int nA, gxA, gyA, gxB, gyB; };
+struct GemmPairDev { GemmDev a, b; int nA, gxA, gyA, gxB, gyB; unsigned mgxA, mgyA, mgxB, mgyB; };
 template <typename H>
 __global__ __launch_bounds__(256, 2) void gemm_pair_kernel(GemmPairDev q) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (64 + 64) * (64 + 8)];
@@ -1013,10 +1024,11 @@ __global__ __launch_bounds__(256, 2) void gemm_pair_kernel(GemmPairDev q) {
     const int nB = (int)gridDim.x - q.nA;
     int lin = (int)blockIdx.x < nB ? (int)blockIdx.x + q.nA : (int)blockIdx.x - nB;
     if (lin < q.nA) {
-        int bx = lin % q.gxA; lin /= q.gxA;
-        int by = lin % q.gyA;
-        const int bz = lin / q.gyA;
-        if (q.a.xcd & 1) tc_xcd_tile(bx, by, q.gxA, q.gyA);
+        const int l1 = fdiv(lin, q.gxA, q.mgxA);
+        int bx = lin - l1 * q.gxA;
+        const int bz = fdiv(l1, q.gyA, q.mgyA);
+        int by = l1 - bz * q.gyA;
+        if (q.a.xcd & 1) tc_xcd_tile(bx, by, q.gxA, q.gyA, q.mgxA);
         if (q.a.ffn.mode == TC_FFN_EP) gemm_bf16_body<H, H, 64, 64, false, false, true, TC_FFN_EP>(q.a, bx, by, bz, q.gxA, q.gyA, As, Bs);
         else gemm_bf16_body<H, H, 64, 64, false, false, true>(q.a, bx, by, bz, q.gxA, q.gyA, As, Bs);
     } else {
@@ -1027,9 +1039,9 @@ __global__ __launch_bounds__(256, 2) void gemm_pair_kernel(GemmPairDev q) {
             const int xcd = lin & 7, slot = lin >> 3, qq = nB >> 3, r = nB & 7;
             lin = xcd * qq + min(xcd, r) + slot;
         }
-        const int bx = lin % q.gxB; lin /= q.gxB;
-        if (q.b.ffn.mode == TC_FFN_LN_B) gemm_bf16_body<H, float, 64, 64, true, false, true, TC_FFN_LN_B>(q.b, bx, lin % q.gyB, lin / q.gyB, q.gxB, q.gyB, As, Bs);
-        else gemm_bf16_body<H, float, 64, 64, true, false, true>(q.b, bx, lin % q.gyB, lin / q.gyB, q.gxB, q.gyB, As, Bs);
+        const int l1 = fdiv(lin, q.gxB, q.mgxB), bx = lin - l1 * q.gxB, bz = fdiv(l1, q.gyB, q.mgyB), by = l1 - bz * q.gyB;
+        if (q.b.ffn.mode == TC_FFN_LN_B) gemm_bf16_body<H, float, 64, 64, true, false, true, TC_FFN_LN_B>(q.b, bx, by, bz, q.gxB, q.gyB, As, Bs);
+        else gemm_bf16_body<H, float, 64, 64, true, false, true>(q.b, bx, by, bz, q.gxB, q.gyB, As, Bs);
     }
 }
 
@@ -1037,8 +1049,8 @@ __global__ __launch_bounds__(256, 2) void gemm_pair_kernel(GemmPairDev q) {
 // TA=1,TB=0, fp32 C) in one grid of 64x64 tiles -- the four per-scale MixFFNs of a bridge layer are independent chains of small
 // GEMMs; level by level their workgroups share the CUs instead of queueing as 4 (forward) or 8 (backward) short launches.
 constexpr int GEMM_MULTI_MAX = 12;
-static_assert(sizeof(GemmDev) * GEMM_MULTI_MAX + 16 * GEMM_MULTI_MAX + 8 <= 4096, "kernel argument block");
-struct GemmMultiDev { GemmDev p[GEMM_MULTI_MAX]; int blk0[GEMM_MULTI_MAX], gx[GEMM_MULTI_MAX], gy[GEMM_MULTI_MAX], kind[GEMM_MULTI_MAX]; int n; };
+static_assert(sizeof(GemmDev) * GEMM_MULTI_MAX + 20 * GEMM_MULTI_MAX + 8 <= 4096, "kernel argument block");
+struct GemmMultiDev { GemmDev p[GEMM_MULTI_MAX]; int blk0[GEMM_MULTI_MAX], gx[GEMM_MULTI_MAX], gy[GEMM_MULTI_MAX], kind[GEMM_MULTI_MAX]; unsigned mgy[GEMM_MULTI_MAX]; int n; };
 template <typename H>
 __global__ __launch_bounds__(256, 4) void gemm_multi_kernel(GemmMultiDev q) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (64 + 64) * (64 + 8)];
@@ -1052,9 +1064,11 @@ __global__ __launch_bounds__(256, 4) void gemm_multi_kernel(GemmMultiDev q) {
         const int xcd = lin & 7, slot = lin >> 3, qq = ni >> 3, r = ni & 7;    // local indices l, l + 8, ... share an XCD at any offset
         lin = xcd * qq + min(xcd, r) + slot;
     }
-    const int gx = q.gx[i], gy = q.gy[i], bz = lin / (gx * gy);
-    int bx = lin % gx, by = (lin / gx) % gy;
-    if ((q.p[i].xcd & 1) && q.kind[i] != 2 && q.kind[i] != 5) tc_xcd_tile(bx, by, gx, gy);   // (not the split-K weight gradients)
+    const int gx = q.gx[i], gy = q.gy[i];
+    const unsigned mgx = q.p[i].m_gx;
+    const int l1 = fdiv(lin, gx, mgx), bz = fdiv(l1, gy, q.mgy[i]);
+    int bx = lin - l1 * gx, by = l1 - bz * gy;
+    if ((q.p[i].xcd & 1) && q.kind[i] != 2 && q.kind[i] != 5) tc_xcd_tile(bx, by, gx, gy, mgx);   // (not the split-K weight gradients)
     // a private copy of the one descriptor: with six inlined bodies reading fields through a reference into the 4 KB argument block
     // the compiler stopped forwarding the loads to the kernel-argument segment and copied the whole block to scratch
     const GemmDev p = q.p[i];
@@ -1179,6 +1193,8 @@ bool gemm_plan(const TcGemm* g, GemmDev& d, dim3& grid, bool& use128_out, bool f
     }
     d.atomic = ((d.splitk > 1 && !d.fix_group) || g->atomic) ? 1 : 0;
     grid = dim3((g->N + BN - 1) / BN, (g->M + BM - 1) / BM, nb * d.splitk);
+    d.m_splitk = fdiv_make(d.splitk, 65536); d.m_nb2 = fdiv_make(d.nb2, 65536);
+    d.m_gx = fdiv_make(grid.x, (unsigned long long)grid.x * grid.y * grid.z);          // (every linear index the launchers divide by gx is below the block count)
     {   // XCD-aware tile numbering pays where several N-tiles share an A tile and there are enough tiles to spread (A/B: TC_GEMM_XCD=0)
         static const int xcd_on = getenv("TC_GEMM_XCD") ? atoi(getenv("TC_GEMM_XCD")) : 1;
         d.xcd = (xcd_on && grid.x > 1 && (long long)grid.x * grid.y >= 64) ? 1 : 0;
@@ -1268,6 +1284,7 @@ extern "C" int tc_gemm_pair(const TcGemm* a, const TcGemm* b, void* stream) {
         const long long nA = (long long)ga.x * ga.y * ga.z, nB = (long long)gb.x * gb.y * gb.z;
         if (!bigA && !bigB && nA + nB < 0x7fffffffLL) {
             q.nA = (int)nA; q.gxA = ga.x; q.gyA = ga.y; q.gxB = gb.x; q.gyB = gb.y;
+            q.mgxA = fdiv_make(ga.x, nA + nB); q.mgyA = fdiv_make(ga.y, nA + nB); q.mgxB = fdiv_make(gb.x, nA + nB); q.mgyB = fdiv_make(gb.y, nA + nB);
             static const int xcd_b = getenv("TC_PAIR_XCD_B") ? atoi(getenv("TC_PAIR_XCD_B")) : 1;   // A/B switch
             if (xcd_b && gb.x * gb.y > 1) q.b.xcd |= 2;
             if (a->dtype == TC_BF16) hipLaunchKernelGGL(gemm_pair_kernel<bf16_t>, dim3((unsigned)(nA + nB)), dim3(256), 0, s, q);
@@ -1308,6 +1325,7 @@ extern "C" int tc_gemm_multi(const TcGemm* g, int n, void* stream) {
         for (int j = 0; j < n; ++j) {
             const int i = order[j];
             q.p[j] = plan[i]; q.kind[j] = kinds[i]; q.gx[j] = grids[i].x; q.gy[j] = grids[i].y; q.blk0[j] = (int)blk;
+            q.mgy[j] = fdiv_make(grids[i].y, (unsigned long long)grids[i].x * grids[i].y * grids[i].z);
             if (xcd_b && (kinds[i] == 2 || kinds[i] == 5) && grids[i].x * grids[i].y > 1) q.p[j].xcd |= 2;
             blk += (long long)grids[i].x * grids[i].y * grids[i].z;
             if (blk > 0x7fffffffLL) ok = false;

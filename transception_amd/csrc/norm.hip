@@ -582,16 +582,34 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     if (training) {
         // fold the per-chunk partials once per block: thread (channel = tid % 64, quarter = tid / 64); fp64 sums and difference (see above)
         const int cc = threadIdx.x & 63, part = threadIdx.x >> 6, ch = blockIdx.y * 64 + cc;
+        // (fp32 storage = the parity path: its statistics pass shifts by the map's first row, which is well conditioned, and the fp32 fold
+        //  reproduces the reference's own fp32 arithmetic more closely -- with the fp64 fold one stem-weight gradient sample of the stage4_se
+        //  fixture moved from inside 2e-6 to 4.2e-6 of the reference's value; 16-bit storage, where the GEMM / RIPM epilogues shift by the
+        //  running mean, folds in fp64)
+        constexpr bool F32FOLD = std::is_same<T, float>::value;
         double s1 = 0.0, s2 = 0.0;
-        if (ch < C) bn_fold_partials(scratch, nchunk, C, ch, part, s1, s2);
+        if (ch < C) {
+            if constexpr (F32FOLD) { float f1 = 0.f, f2 = 0.f; bn_fold_partials(scratch, nchunk, C, ch, part, f1, f2); s1 = f1; s2 = f2; }
+            else bn_fold_partials(scratch, nchunk, C, ch, part, s1, s2);
+        }
         psum[0][part][cc] = s1; psum[1][part][cc] = s2;
         __syncthreads();
         if (threadIdx.x < 64 && ch < C) {
             s1 = (psum[0][0][cc] + psum[0][1][cc]) + (psum[0][2][cc] + psum[0][3][cc]);
             s2 = (psum[1][0][cc] + psum[1][1][cc]) + (psum[1][2][cc] + psum[1][3][cc]);
-            const double m1 = s1 / (double)rows;
-            const float var = (float)fmax(s2 / (double)rows - m1 * m1, 0.0);
-            const float mean_ = (float)((double)scratch[ch] + m1), rstd_ = rsqrtf(var + eps);
+            float var, mean_;
+            if constexpr (F32FOLD) {
+                const float f1 = (float)psum[0][0][cc] + (float)psum[0][1][cc] + (float)psum[0][2][cc] + (float)psum[0][3][cc];     // (round 5's order)
+                const float f2 = (float)psum[1][0][cc] + (float)psum[1][1][cc] + (float)psum[1][2][cc] + (float)psum[1][3][cc];
+                const float m1f = f1 / (float)rows;
+                var = fmaxf(f2 / (float)rows - m1f * m1f, 0.f);
+                mean_ = scratch[ch] + m1f;
+            } else {
+                const double m1 = s1 / (double)rows;
+                var = (float)fmax(s2 / (double)rows - m1 * m1, 0.0);
+                mean_ = (float)((double)scratch[ch] + m1);
+            }
+            const float rstd_ = rsqrtf(var + eps);
             stat[0][cc] = mean_; stat[1][cc] = rstd_;
             if (blockIdx.x == 0) {
                 save_mean[ch] = mean_; save_rstd[ch] = rstd_;
