@@ -510,9 +510,9 @@ def side_figures(args, dev, model, loss_fn, opt, step, x, y, build_model, engine
                        "pair around an empty kernel on the idle queue reads event_pair_floor_us, which every in-step figure includes -- the "
                        "kernel's own duration is roofline_graph_replay / the rocprofv3 average in profiles/"}
     # committed profile summaries of this workload; a summary counts only when its provenance stamp matches the sources this run executes
-    pmc_all, prof_file, pmc_fresh = _profile("r5_hbm_by_kernel.json", "r4_hbm_by_kernel.json", "r3_hbm_by_kernel.json", "r2_hbm_by_kernel.json")
+    pmc_all, prof_file, pmc_fresh = _profile("r6_hbm_by_kernel.json", "r5_hbm_by_kernel.json", "r4_hbm_by_kernel.json", "r3_hbm_by_kernel.json", "r2_hbm_by_kernel.json")
     pmc_doc = pmc_all.get("kernels", {})
-    tl_all, tl_file, tl_fresh = _profile("r5_step_timeline.json", "r4_step_timeline.json", "r3_step_timeline.json")
+    tl_all, tl_file, tl_fresh = _profile("r6_step_timeline.json", "r5_step_timeline.json", "r4_step_timeline.json", "r3_step_timeline.json")
     tl_doc = tl_all.get("kernels", {})
     same_workload = args.dtype == "bf16" and args.batch == 16 and args.size == 224
     STALE = "stale: the kernel sources changed since this profile was collected (scripts/provenance.py); re-run scripts/profile_round5.sh"
@@ -533,7 +533,7 @@ def side_figures(args, dev, model, loss_fn, opt, step, x, y, build_model, engine
     if prof.get("attn_fwd"):
         r = mfma_block(prof["attn_fwd"], ATTN_KERNEL)
         r["traffic"], r["traffic_source"] = None, None
-        adoc, aname, afresh = _profile("r5_attn_pmc.json", "r4_attn_pmc.json", "r2_attn_pmc.json", "r1_attn_pmc.json")   # HBM bytes per launch: a separate rocprofv3 --pmc pass, committed
+        adoc, aname, afresh = _profile("r6_attn_pmc.json", "r5_attn_pmc.json", "r4_attn_pmc.json", "r2_attn_pmc.json", "r1_attn_pmc.json")   # HBM bytes per launch: a separate rocprofv3 --pmc pass, committed
         if same_workload and aname:
             ent = adoc.get("attn_fwd_asm_kernel") or adoc.get("attn_fwd_seg_kernel") or {}
             if afresh:
@@ -755,7 +755,7 @@ def side_figures(args, dev, model, loss_fn, opt, step, x, y, build_model, engine
         spec = importlib.util.spec_from_file_location("bench_stage", os.path.join(ROOT, "scripts", "bench_stage.py"))
         bs = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(bs)
-        pmc, pname, pfresh = _profile("r5_ripm_iff_hbm.json", "r4_ripm_iff_hbm.json")
+        pmc, pname, pfresh = _profile("r6_ripm_iff_hbm.json", "r5_ripm_iff_hbm.json", "r4_ripm_iff_hbm.json")
         if args.batch != 16:
             pmc, pname = {}, None
         for which, key in (("ripm", "roofline_ripm"), ("iff", "roofline_iff")):
