@@ -21,12 +21,31 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
 
 constexpr int MAXCLS = 16;
 
+// a token row of up to 16 classes whose storage is 16-byte aligned and padded to a multiple of 8 elements: one or two 16-byte pieces
+template <typename T> __device__ __forceinline__ void tok_row_load(const T* lp, int ncls, float* v) {
+    if constexpr (sizeof(T) == 2) {
+        const uint4 a = *reinterpret_cast<const uint4*>(lp);
+        unpack2<T>(a.x, v[0], v[1]); unpack2<T>(a.y, v[2], v[3]); unpack2<T>(a.z, v[4], v[5]); unpack2<T>(a.w, v[6], v[7]);
+        if (ncls > 8) {
+            const uint4 b = *reinterpret_cast<const uint4*>(lp + 8);
+            unpack2<T>(b.x, v[8], v[9]); unpack2<T>(b.y, v[10], v[11]); unpack2<T>(b.z, v[12], v[13]); unpack2<T>(b.w, v[14], v[15]);
+        }
+    }
+}
+template <typename T> __device__ __forceinline__ void tok_row_store(T* dp, int ncls, const float* v) {
+    if constexpr (sizeof(T) == 2) {
+        *reinterpret_cast<uint4*>(dp) = make_uint4(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7]));
+        if (ncls > 8) *reinterpret_cast<uint4*>(dp + 8) = make_uint4(pack2<T>(v[8], v[9]), pack2<T>(v[10], v[11]), pack2<T>(v[12], v[13]), pack2<T>(v[14], v[15]));
+    }
+}
+
 // ld = 0: logits / dlogits are [B, ncls, HW] (the module's NCHW output); ld > 0: token-major [B * HW, ld] rows as the last Linear leaves
 // them (the captured training step hands them over without the transpose and the fp32 copy); prob is [B, ncls, HW] either way
 template <typename T>
 __global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const T* __restrict__ logits, const long long* __restrict__ labels,
                                                            float* __restrict__ prob, float* __restrict__ sums, int B, int ncls, int HW, int ld) {
     __shared__ float red[4][1 + 3 * MAXCLS];
+    const bool vec16 = ld > 0 && !(ld & 7) && ld >= ((ncls + 7) & ~7) && !((uintptr_t)logits & 15);
     float ce = 0.f, I[MAXCLS], Y[MAXCLS], Z[MAXCLS];
 #pragma unroll
     for (int k = 0; k < MAXCLS; ++k) I[k] = Y[k] = Z[k] = 0.f;
@@ -37,8 +56,14 @@ __global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const T* __restrict__
         const T* lp = ld ? logits + i * ld : logits + (long long)b * ncls * HW + p;
         const long long ks = ld ? 1 : HW;
         float v[MAXCLS], m = -INFINITY;
+        if (sizeof(T) == 2 && vec16) {                          // padded token rows (Graph.ln_cls(pad_rows)): whole 16-byte pieces instead of ncls 2-byte loads
+            tok_row_load<T>(lp, ncls, v);
 #pragma unroll
-        for (int k = 0; k < MAXCLS; ++k) if (k < ncls) { v[k] = ldf<T>(lp + k * ks); m = fmaxf(m, v[k]); }
+            for (int k = 0; k < MAXCLS; ++k) if (k < ncls) m = fmaxf(m, v[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < MAXCLS; ++k) if (k < ncls) { v[k] = ldf<T>(lp + k * ks); m = fmaxf(m, v[k]); }
+        }
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < MAXCLS; ++k) if (k < ncls) { v[k] = expf(v[k] - m); s += v[k]; }
@@ -72,6 +97,8 @@ __global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float* __restri
                                                            int HW, float w_ce, float w_dice, float n_pix, float gscale, const float* __restrict__ gscale_dev, int ld,
                                                            const T* __restrict__ logits, int ldl) {
     if (gscale_dev) gscale *= *gscale_dev;
+    const bool vin = !prob && !(ldl & 7) && ldl >= ((ncls + 7) & ~7) && !((uintptr_t)logits & 15);
+    const bool vout = ld > 0 && !(ld & 7) && ld >= ((ncls + 7) & ~7) && !((uintptr_t)dlogits & 15);
     __shared__ float ca[MAXCLS], cb[MAXCLS];          // dDice/dp_c = ca[c]*onehot_c + cb[c]*p_c
     if (threadIdx.x < ncls) {
         const float I = sums[1 + 3 * threadIdx.x], Y = sums[2 + 3 * threadIdx.x], Z = sums[3 + 3 * threadIdx.x];
@@ -93,8 +120,14 @@ __global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float* __restri
         } else {                                                // the forward's arithmetic again (same operations, same order: same bits)
             const T* lp = logits + i * ldl;
             float m = -INFINITY, ssum = 0.f;
+            if (sizeof(T) == 2 && vin) {
+                tok_row_load<T>(lp, ncls, pk);
 #pragma unroll
-            for (int k = 0; k < MAXCLS; ++k) if (k < ncls) { pk[k] = ldf<T>(lp + k); m = fmaxf(m, pk[k]); }
+                for (int k = 0; k < MAXCLS; ++k) if (k < ncls) m = fmaxf(m, pk[k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < MAXCLS; ++k) if (k < ncls) { pk[k] = ldf<T>(lp + k); m = fmaxf(m, pk[k]); }
+            }
 #pragma unroll
             for (int k = 0; k < MAXCLS; ++k) if (k < ncls) { pk[k] = expf(pk[k] - m); ssum += pk[k]; }
             const float inv = 1.f / ssum;
@@ -108,9 +141,16 @@ __global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float* __restri
         }
         T* dp = ld ? dlogits + i * ld : dlogits + (long long)b * ncls * HW + p;
         const long long ks = ld ? 1 : HW;
+        if (sizeof(T) == 2 && vout) {                           // padded rows: the pad elements are written as zeros
+            float o[MAXCLS];
 #pragma unroll
-        for (int k = 0; k < MAXCLS; ++k) if (k < ncls)
-            stf<T>(dp + k * ks, gscale * (cew * (pk[k] - (k == lab ? 1.f : 0.f)) + pk[k] * (g[k] - dot)));
+            for (int k = 0; k < MAXCLS; ++k) o[k] = k < ncls ? gscale * (cew * (pk[k] - (k == lab ? 1.f : 0.f)) + pk[k] * (g[k] - dot)) : 0.f;
+            tok_row_store<T>(dp, ncls, o);
+        } else {
+#pragma unroll
+            for (int k = 0; k < MAXCLS; ++k) if (k < ncls)
+                stf<T>(dp + k * ks, gscale * (cew * (pk[k] - (k == lab ? 1.f : 0.f)) + pk[k] * (g[k] - dot)));
+        }
     }
 }
 
