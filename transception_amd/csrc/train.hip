@@ -192,6 +192,28 @@ __global__ void sgd_multi_kernel(float* __restrict__ p, const float* __restrict_
         gscale *= fminf(clip_norm / (sqrtf(ss) + 1e-6f), 1.0f);   // update -- weights, momentum and the 16-bit copy stay as they were.  Otherwise
     }                                                             // clip_grad_norm_'s coefficient, clamped to 1 (clip_norm = inf: no clipping)
     const long long off = segs[2 * blockIdx.y], n = segs[2 * blockIdx.y + 1];
+    if (!((off | n) & 3) && !(((uintptr_t)p | (uintptr_t)g | (uintptr_t)buf) & 15) && !((uintptr_t)lp & 7)) {
+        // four elements per thread in 16-byte pieces (the arena's segments start and end on multiples of 8 elements): the scalar form
+        // ran at 4.1 TB/s for the 22 bytes per weight it moves
+        const long long n4 = n >> 2;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+            const long long j = off + 4 * i;
+            const float4 w = *reinterpret_cast<const float4*>(p + j), gv = *reinterpret_cast<const float4*>(g + j);
+            float4 b;
+            if (first) b = make_float4(gv.x * gscale + wd * w.x, gv.y * gscale + wd * w.y, gv.z * gscale + wd * w.z, gv.w * gscale + wd * w.w);
+            else {
+                const float4 m = *reinterpret_cast<const float4*>(buf + j);
+                b = make_float4(mom * m.x + (gv.x * gscale + wd * w.x), mom * m.y + (gv.y * gscale + wd * w.y), mom * m.z + (gv.z * gscale + wd * w.z),
+                                mom * m.w + (gv.w * gscale + wd * w.w));
+            }
+            *reinterpret_cast<float4*>(buf + j) = b;
+            const float4 wn = make_float4(w.x - lr * b.x, w.y - lr * b.y, w.z - lr * b.z, w.w - lr * b.w);
+            *reinterpret_cast<float4*>(p + j) = wn;
+            if (lp_dtype == TC_BF16) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(lp) + j) = make_uint2(pack2<bf16_t>(wn.x, wn.y), pack2<bf16_t>(wn.z, wn.w));
+            else if (lp_dtype == TC_F16) *reinterpret_cast<uint2*>(reinterpret_cast<f16_t*>(lp) + j) = make_uint2(pack2<f16_t>(wn.x, wn.y), pack2<f16_t>(wn.z, wn.w));
+        }
+        return;
+    }
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const long long j = off + i;
         const float w = p[j];
