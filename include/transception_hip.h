@@ -581,7 +581,9 @@ int tc_seg_loss_bwd(const float* prob, const long long* labels, const float* sum
                     void* stream);
 /* The same two kernels on TOKEN-MAJOR logits / dlogits [B*HW, ld] (rows = pixels, ld >= ncls elements of the storage type), the layout
  * the classifier Linear (MSTr.py:281 last_layer) leaves: the captured training step skips the NHWC -> NCHW transpose and the fp32 copy
- * of the logits, and their counterparts on the way back (trainer.py:139-143 see the same values).  prob, when given, is [B, ncls, HW] fp32. */
+ * of the logits, and their counterparts on the way back (trainer.py:139-143 see the same values).  prob, when given, is [B, ncls, HW] fp32.
+ * 16-bit rows that are 16-byte aligned and padded to a multiple of 8 elements (tc_ln_cls_fwd's padded logits) are read and written as whole
+ * 16-byte pieces: the pad elements of dlogits are then written as zeros; any other row pitch is accessed element by element, padding untouched. */
 int tc_seg_loss_fwd_tok(const void* logits, int ld, const long long* labels, float* prob, float* sums, int B, int ncls, int HW, int dtype,
                         void* stream);
 int tc_seg_loss_bwd_tok(const float* prob, const void* logits, int ldl, const long long* labels, const float* sums, void* dlogits, int ld,
