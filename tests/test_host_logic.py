@@ -205,3 +205,45 @@ def test_piecewise_affine_triangles_follow_the_delaunay_statement(h, w):
     sy0, sx0 = O.piecewise_source(D.piecewise_disp(np.zeros((4, 4, 2)), h, w), h, w)
     assert np.abs(sy0 - yy)[: h // 3].max() < 1e-9 and np.abs(sx0 - xx)[:, : w // 3].max() < 1e-9
     assert -1.0 <= (sy0 - yy).min() and (sy0 - yy).max() <= 1e-9
+
+
+def test_comm_schedule_empty_last_piece_and_capped_dead_gaps():
+    """ADVICE r5 (train.comm_schedule): (1) a last piece with no live run and nothing deferred yields NO collective (it used to emit an empty
+    pack, and torch.cat([]) raised); (2) a dead gap above SPAN_GAP_MAX elements is not sent along to save a collective -- the stop's two
+    live runs travel separately; a gap below it still is."""
+    import torch
+    from transception_amd import train
+
+    class M1:                                       # every live word sits in the first piece
+        _gflat = torch.zeros(1_000_000)
+        _used_views = {0: (600_000, (100_000,)), 1: (800_000, (50_000,))}
+
+        @staticmethod
+        def gradient_pieces():
+            return [("enc", [(500_000, 1_000_000)]), (None, [(0, 500_000)])]
+    sched = train.comm_schedule(M1)
+    assert [stop for stop, _ in sched] == ["enc", None]
+    assert sched[1][1] == [] and train.allreduce_scheduled(M1, sched[1][1], None) == []
+    assert sum(b - a for e in sched[0][1] for a, b in ([(e[1], e[2])] if e[0] == "span" else e[1])) >= 150_000
+
+    big = train.SPAN_GAP_MAX + 500_000
+
+    class M2:                                       # two live runs in one piece, a dead gap larger than SPAN_GAP_MAX between them
+        _gflat = torch.zeros(3_000_000 + big)
+        _used_views = {0: (0, (1_000_000,)), 1: (1_000_000 + big, (2_000_000,))}
+
+        @staticmethod
+        def gradient_pieces():
+            return [("enc", [(0, 3_000_000 + big)]), (None, [])]
+    spans = [e for _, ent in train.comm_schedule(M2) for e in ent if e[0] == "span"]
+    assert sorted((e[1], e[2]) for e in spans) == [(0, 1_000_000), (1_000_000 + big, 3_000_000 + big)]
+
+    class M3(M2):                                   # the same with a gap just below the limit: one collective, the zeros ride along
+        _gflat = torch.zeros(3_000_000 + train.SPAN_GAP_MAX - 8)
+        _used_views = {0: (0, (1_000_000,)), 1: (1_000_000 + train.SPAN_GAP_MAX - 8, (2_000_000,))}
+
+        @staticmethod
+        def gradient_pieces():
+            return [("enc", [(0, 3_000_000 + train.SPAN_GAP_MAX - 8)]), (None, [])]
+    spans = [e for _, ent in train.comm_schedule(M3) for e in ent if e[0] == "span"]
+    assert [(e[1], e[2]) for e in spans] == [(0, 3_000_000 + train.SPAN_GAP_MAX - 8)]
