@@ -159,3 +159,21 @@ def check_all_grads_lowp(named_lp, named_ref, rel_l2: float, cos_min: float, wha
         return n, worst
     assert not bad, f"{what}{len(bad)} of {n} gradient tensors out of bound:\n  " + "\n  ".join(bad[:20])
     return n, worst
+
+
+def gelu_model(u: torch.Tensor, dtype) -> torch.Tensor:
+    """GELU as the kernels of storage type `dtype` evaluate it, in the precision of `u`: exact erf for fp32; for bf16 / fp16 the forward kernels
+    take Phi(x) ~ 0.5 + t P(t^2), t = clamp(x, -X0, X0) (csrc/tc_common.h TC_PHI_*: within 1.02e-5 of the normal CDF, pinned by
+    tests/test_ops_gpu.py::test_gelu_16bit_polynomial_against_erf) -- the fp64 rounding models use the same polynomial, read from the header."""
+    if dtype == torch.float32:
+        return torch.nn.functional.gelu(u)
+    import re
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "transception_amd", "csrc", "tc_common.h")).read()
+    val = lambda name: float(re.search(r"#define %s\s+(-?[0-9.eE+-]+)f" % name, hdr).group(1))
+    x0, c = val("TC_PHI_X0"), [val("TC_PHI_C%d" % k) for k in range(9)]
+    t = u.clamp(-x0, x0)
+    s2 = t * t
+    pl = torch.full_like(u, c[8])
+    for k in range(7, -1, -1):
+        pl = pl * s2 + c[k]
+    return u * (t * pl + 0.5)

@@ -6,6 +6,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from golden_util import gelu_model
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
@@ -146,7 +148,8 @@ CASES = [  # C, B, H, W, groups
 
 def _ref_rounding_model(x, flat, offs, shapes, tot, groups, B, H, W, res, dtype, pre_eps=None, stats_of_unrounded=True):
     """fp64 model of the tiled kernels' own arithmetic on storage-grid operands: h, d and a live in LDS / HBM in the storage type (rounded
-    there), the LayerNorm statistics are those of the rounded d, the result is rounded once."""
+    there), the LayerNorm statistics are those of the rounded d, GELU through the polynomial CDF of the 16-bit kernels (golden_util.gelu_model),
+    the result is rounded once."""
     rq = lambda t: t.to(dtype).double()
     x, flat, res = rq(x), rq(flat), rq(res)
     C, M, outs = x.shape[1], B * H * W, []
@@ -161,9 +164,9 @@ def _ref_rounding_model(x, flat, offs, shapes, tot, groups, B, H, W, res, dtype,
         d = rq(du)
         if stats_of_unrounded:                     # the tiled forward takes the row statistics from the fp32 values before they are rounded into LDS
             mu, var = du.mean(1, keepdim=True), du.var(1, unbiased=False, keepdim=True)
-            a = rq(F.gelu((d - mu) * torch.rsqrt(var + 1e-5) * P["lg"] + P["lb"]))
+            a = rq(gelu_model((d - mu) * torch.rsqrt(var + 1e-5) * P["lg"] + P["lb"], dtype))
         else:
-            a = rq(F.gelu(F.layer_norm(d, (d.shape[1],), P["lg"], P["lb"], 1e-5)))
+            a = rq(gelu_model(F.layer_norm(d, (d.shape[1],), P["lg"], P["lb"], 1e-5), dtype))
         outs.append(rq(F.linear(a, P["W2"], P["b2"]) + res[g * M:(g + 1) * M]))
     return torch.cat(outs, 0)
 
@@ -172,7 +175,7 @@ def _ref_rounding_model(x, flat, offs, shapes, tot, groups, B, H, W, res, dtype,
 @pytest.mark.parametrize("case", [(64, 2, 28, 28, 1), (64, 1, 56, 56, 1), (64, 2, 7, 9, 1), (128, 3, 14, 14, 1), (128, 2, 28, 28, 3)])
 def test_fused_mixffn_forward_within_one_rounding_of_its_fp64_model(case, dtype):
     """ffn_fused_fwd_kernel on storage-grid operands against the fp64 model of its own arithmetic, <= 3e-3 (bf16) /
-    4e-4 (fp16) of the result's largest value -- the 3e-2 of the fp32 comparison below would let a wrong tap or bias through."""
+    1e-3 (fp16) of the result's largest value -- the 3e-2 of the fp32 comparison below would let a wrong tap or bias through."""
     C, B, H, W, groups = case
     gen = torch.Generator().manual_seed(300 + C + H)
     flat, offs, shapes, tot = _params(C, groups, gen)
@@ -184,7 +187,9 @@ def test_fused_mixffn_forward_within_one_rounding_of_its_fp64_model(case, dtype)
     ym2 = _ref_rounding_model(x, flat, offs, shapes, tot, groups, B, H, W, res, dtype, stats_of_unrounded=False)
     err2 = float((y.double() - ym2).abs().max() / ym2.abs().max())
     print(f"ffn_fused_fwd {case} {dtype}: out vs the fp64 rounding model {err:.2e} (statistics of the rounded d: {err2:.2e})")
-    assert err < {torch.bfloat16: 3e-3, torch.float16: 4e-4}[dtype], err
+    # fp16: one spacing of the largest results (2^-10 of their binade): the kernel's fp32 value and the model's fp64 value of an element can sit on
+    # either side of a rounding boundary (about one element in 4000 does), which costs a whole spacing, not half of one
+    assert err < {torch.bfloat16: 3e-3, torch.float16: 1e-3}[dtype], err
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])

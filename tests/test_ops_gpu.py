@@ -449,6 +449,35 @@ def test_cam_module_and_gelu(G, B, N, C):
     close(G2.grad_of(xv2), xr2.grad, 5e-6, 5e-6, "gelu gradient")
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gelu_16bit_polynomial_against_erf(dtype):
+    """The forward GELU of the 16-bit kernels (csrc/tc_common.h gelu_poly: Phi as a clamped odd polynomial, no exp / reciprocal) on EVERY
+    storage value of [-8, 8] against fp64 erf: within half a storage spacing of the exact value plus 1.05e-5 |x| (the polynomial's absolute
+    error in Phi), i.e. the same rounded result as exact arithmetic (give or take a rounding boundary) wherever |GELU(x)| >= 4e-3, and within 1.05e-5 |x|
+    absolutely in the negative tail below that.
+    The test-side model of the polynomial (golden_util.gelu_model, which the fp64 rounding models use) is checked against the kernel here too."""
+    from golden_util import gelu_model
+    from transception_amd.engine import Graph
+    bits = torch.arange(0, 65536, dtype=torch.int32).to(torch.int16)
+    x = bits.view(dtype).float()
+    x = x[torch.isfinite(x) & (x.abs() <= 8.0)]
+    G2 = Graph(dtype, torch.device(DEV), training=False, record=False)
+    y = G2.gelu(mkV(G2, x.to(dtype).view(-1, 1).contiguous(), requires_grad=False)).data.float().cpu().view(-1).double()
+    xd = x.double()
+    exact = 0.5 * xd * (1.0 + torch.erf(xd / 2.0 ** 0.5))
+    mant, emin = (7, -126) if dtype == torch.bfloat16 else (10, -14)
+    spacing = lambda v: torch.exp2(torch.floor(torch.log2(v.abs().clamp_min(2.0 ** emin))) - mant)      # storage spacing at v (subnormals included)
+    err = (y - exact).abs()
+    slack = err - 0.5 * spacing(exact) * 1.001 - 1.05e-5 * xd.abs()
+    assert float(slack.max()) <= 1e-12, (float(slack.max()), float(xd[slack.argmax()]))
+    assert float(err[exact.abs() < 4e-3].max()) < 1.05e-5 * 8.0                      # the tail: absolute, not relative (5e-5 at x = -8)
+    model = gelu_model(xd, dtype)
+    assert float((model - exact).abs().max()) <= 1.05e-5 * 8.0
+    # kernel (fp32 Horner) == its fp64 model to one storage rounding wherever the value is not a cancellation residue of the clamp's tail
+    body = exact.abs() >= 4e-3
+    assert bool(((y - model)[body].abs() <= 0.5 * spacing(model)[body] * 1.001 + 2e-7 * xd.abs()[body]).all())
+
+
 @pytest.mark.parametrize("rows,C", [(196, 320), (4 * 784, 128), (37, 64)])
 def test_gamma_residual(G, rows, C):
     """gamma * a + x with a one-element gamma (the tail of CAM_Factorized_Module, MSTr.py:565-567): forward, both input gradients, dgamma."""
@@ -584,6 +613,43 @@ def test_patchify_deinterleave(G):
     dst.data.zero_()
     G.sr_deinterleave(ov, dst, 2 * Cd, 12 * Cd, B, Pn, Cd, mult)
     close(dst.data.view(B, 12, Cd)[:, 2:2 + mult * Pn], want, 0, 0, "deinterleave")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_patchify_16bit_pieces(dtype):
+    """The 16-bit patchify body (whole 4 / 8 / 16-byte pieces, byte permutes; k = 8 / 4 / 2 = Scale_reduce's three maps, MSTr.py:2225-2249)
+    against F.unfold: the forward moves storage values bit for bit, the backward ACCUMULATES into the map's gradient (one rounding of the sum);
+    single launches and the merged three-map launch."""
+    from transception_amd.engine import Graph
+    B = 2
+    items, off = [], 0
+    for (H, C, k) in [(16, 64, 8), (8, 128, 4), (6, 40, 2)]:
+        items.append((off, H * H * C, B, H, H, C, k)); off += B * H * H * C
+    rows = (off + 63) // 64 + 3
+    buf = (T("pf16.x", (rows, 64)).to(dtype)).float()
+    pre = (T("pf16.p", (rows, 64), 0.5).to(dtype)).float()            # a gradient already sitting in the map's buffer
+    for merged in (False, True):
+        G = Graph(dtype, torch.device(DEV), training=True, record=True)
+        bv = mkV(G, buf.to(dtype))
+        cols = G.patchify_many(bv, items) if merged else [G.patchify(bv, *it) for it in items]
+        gys = []
+        for (o, sb, _, H, _, C, k), cv in zip(items, cols):
+            ref = F.unfold(buf.view(-1)[o:o + B * sb].view(B, H, H, C).permute(0, 3, 1, 2), k, stride=k).transpose(1, 2).reshape(-1, C * k * k)
+            assert torch.equal(cv.data.float().cpu(), ref), (merged, k)
+            gys.append(T(f"pf16.g{k}", tuple(ref.shape)).to(dtype))
+        for cv, gy in zip(cols, gys):
+            cv.root.grad_t = gy.to(DEV).contiguous()
+            cv.root.whole_written = True
+        bv.root.grad_t = pre.to(dtype).to(DEV).contiguous()
+        bv.root.whole_written = True
+        G.backward()
+        torch.cuda.synchronize()
+        got = G.grad_of(bv).float().cpu().view(-1)
+        want = pre.view(-1).clone()
+        for (o, sb, _, H, _, C, k), gy in zip(items, gys):
+            g = F.fold(gy.float().view(B, -1, C * k * k).transpose(1, 2), (H, H), k, stride=k).permute(0, 2, 3, 1).reshape(-1)
+            want[o:o + B * sb] = (want[o:o + B * sb] + g).to(dtype).float()
+        assert torch.equal(got, want), (merged, float((got - want).abs().max()))
 
 
 def test_attention_paths_agree_with_reference(G):

@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void gamma_res_bwd_kernel(const T* dy, int ldd
 
 template <typename T>
 __global__ void gelu_fwd_kernel(const T* x, T* y, long long n) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) stf<T>(y + i, gelu_f(ldf<T>(x + i)));
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) stf<T>(y + i, gelu_fT<T>(ldf<T>(x + i)));
 }
 template <typename T>
 __global__ void gelu_bwd_kernel(const T* dy, const T* x, T* dz, long long n) {

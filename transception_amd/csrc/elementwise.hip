@@ -289,11 +289,92 @@ __global__ void pixel_shuffle_kernel(const T* in, T* out, int B, int H, int W, i
     }
 }
 
+// 16-bit storage, k = 2 / 4 / 8 (Scale_reduce's three convolutions, MSTr.py:2225-2249): a thread owns one filter row ky of one patch and four
+// channels -- k pixels x 8 bytes on the map side, four runs of k consecutive columns (c, ky, 0..k-1) on the matrix side -- and moves whole
+// 4 / 8 / 16-byte pieces between them with byte permutes, no conversion.  The element-wise walk below wrote (or read) the matrix two bytes at a
+// time at a stride of k k elements: 20 us for the 23 MB of a bridge layer's three maps.  Lane order by direction, so that the side being WRITTEN
+// is contiguous across adjacent lanes: ky fastest towards the matrix (eight lanes fill a channel's 128-byte run at k = 8), the channel group
+// fastest towards the map.  Indices through sdiv (tc_common.h): the caller checks n + divisors < 2^22 and that every offset fits 31 bits.
+template <typename T, int K>
+__device__ __forceinline__ void patchify16_body(T* m, long long sb, int ld, T* cols, int B, int H, int W, int C, int inverse) {
+    static_assert(sizeof(T) == 2 && (K == 2 || K == 4 || K == 8), "16-bit storage, power-of-two patch");
+    constexpr int KK = K * K, LK = K == 2 ? 1 : (K == 4 ? 2 : 3), NW = K / 2;
+    const int cqn = C >> 2, Ho = H / K, Wo = W / K;
+    const unsigned n = (unsigned)B * Ho * Wo * K * cqn;
+    const SDiv dcq = sdiv_make(cqn), dWo = sdiv_make(Wo), dHo = sdiv_make(Ho);
+    TC_GRID_STRIDE(i, n) {
+        int ky, cq, t;
+        if (!inverse) { ky = i & (K - 1); const int t0 = (int)(i >> LK); t = sdiv(t0, dcq); cq = smod(t0, t, dcq); }
+        else { const int t0 = sdiv((int)i, dcq); cq = smod((int)i, t0, dcq); ky = t0 & (K - 1); t = t0 >> LK; }
+        const int t1 = sdiv(t, dWo), wo = smod(t, t1, dWo), b = sdiv(t1, dHo), ho = smod(t1, b, dHo);
+        T* mp = m + b * sb + (long long)(((ho * K + ky) * W + wo * K) * ld + cq * 4);
+        T* cp = cols + (long long)(((b * Ho + ho) * Wo + wo) * (KK * C) + cq * 4 * KK + ky * K);
+        unsigned w[4][NW];                                          // channel j, pixels (2 m, 2 m + 1)
+        if (!inverse) {
+            uint2 px[K];
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) px[kx] = *reinterpret_cast<const uint2*>(mp + kx * ld);
+#pragma unroll
+            for (int mw = 0; mw < NW; ++mw) {
+                w[0][mw] = __byte_perm(px[2 * mw].x, px[2 * mw + 1].x, 0x5410); w[1][mw] = __byte_perm(px[2 * mw].x, px[2 * mw + 1].x, 0x7632);
+                w[2][mw] = __byte_perm(px[2 * mw].y, px[2 * mw + 1].y, 0x5410); w[3][mw] = __byte_perm(px[2 * mw].y, px[2 * mw + 1].y, 0x7632);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (K == 8) *reinterpret_cast<uint4*>(cp + j * KK) = make_uint4(w[j][0], w[j][1], w[j][2], w[j][3]);
+                else if constexpr (K == 4) *reinterpret_cast<uint2*>(cp + j * KK) = make_uint2(w[j][0], w[j][1]);
+                else *reinterpret_cast<unsigned*>(cp + j * KK) = w[j][0];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (K == 8) { const uint4 v = *reinterpret_cast<const uint4*>(cp + j * KK); w[j][0] = v.x; w[j][1] = v.y; w[j][2] = v.z; w[j][3] = v.w; }
+                else if constexpr (K == 4) { const uint2 v = *reinterpret_cast<const uint2*>(cp + j * KK); w[j][0] = v.x; w[j][1] = v.y; }
+                else w[j][0] = *reinterpret_cast<const unsigned*>(cp + j * KK);
+            }
+            uint2 old[K];
+            if (inverse == 2) {
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) old[kx] = *reinterpret_cast<const uint2*>(mp + kx * ld);
+            }
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const int mw = kx >> 1;
+                uint2 v;
+                if (kx & 1) { v.x = __byte_perm(w[0][mw], w[1][mw], 0x7632); v.y = __byte_perm(w[2][mw], w[3][mw], 0x7632); }
+                else { v.x = __byte_perm(w[0][mw], w[1][mw], 0x5410); v.y = __byte_perm(w[2][mw], w[3][mw], 0x5410); }
+                if (inverse == 2) {
+                    float a0, a1, a2, a3, o0, o1, o2, o3;
+                    unpack2<T>(v.x, a0, a1); unpack2<T>(v.y, a2, a3); unpack2<T>(old[kx].x, o0, o1); unpack2<T>(old[kx].y, o2, o3);
+                    v.x = pack2<T>(a0 + o0, a1 + o1); v.y = pack2<T>(a2 + o2, a3 + o3);
+                }
+                *reinterpret_cast<uint2*>(mp + kx * ld) = v;
+            }
+        }
+    }
+}
+// whether patchify16_body may run: 16-byte pieces aligned, every index below 2^22 and every element offset below 2^31
+template <typename T>
+__device__ __forceinline__ bool patchify16_ok(const T* map, long long sb, int ld, const T* cols, int B, int H, int W, int C, int k) {
+    if (sizeof(T) != 2 || (k != 2 && k != 4 && k != 8)) return false;
+    const long long n = (long long)B * (H / k) * (W / k) * k * (C >> 2);
+    return n + H + W + C < (1LL << 22) && (long long)B * sb < (1LL << 31) && (long long)H * W * ld < (1LL << 31) && (long long)B * H * W * C < (1LL << 31) &&
+           !(((uintptr_t)map | (uintptr_t)cols) & 15) && !(ld & 3) && !(sb & 3);
+}
+
 template <typename T>
 __device__ __forceinline__ void patchify_body(const T* map, long long sb, int ld, T* cols, int B, int H, int W, int C, int k, int inverse) {
     const int cq = C >> 2, Ho = H / k, Wo = W / k;
     const long long n = (long long)B * H * W * cq;
     T* m = const_cast<T*>(map);
+    if constexpr (sizeof(T) == 2) {
+        if (patchify16_ok<T>(map, sb, ld, cols, B, H, W, C, k)) {
+            if (k == 8) patchify16_body<T, 8>(m, sb, ld, cols, B, H, W, C, inverse);
+            else if (k == 4) patchify16_body<T, 4>(m, sb, ld, cols, B, H, W, C, inverse);
+            else patchify16_body<T, 2>(m, sb, ld, cols, B, H, W, C, inverse);
+            return;
+        }
+    }
     TC_GRID_STRIDE(i, n) {
         const int q = (int)(i % cq) * 4; unsigned t = i / cq;
         const int w = (int)(t % W); t /= W; const int h = (int)(t % H); const int b = (int)(t / H);

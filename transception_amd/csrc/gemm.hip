@@ -80,7 +80,7 @@ template <typename H> __device__ __forceinline__ uint4 ffn_ln_gelu8(const uint4&
 #pragma unroll
     for (int e = 0; e < 8; e += 2) {                          // pairs on the packed fp32 pipe
         const tc_f32x2 xv = {x[e], x[e + 1]}, gv = {g[e], g[e + 1]}, bv = {b[e], b[e + 1]};
-        const tc_f32x2 u = gelu_f2_fast((xv - mean) * rstd * gv + bv);           // (16-bit storage: hardware reciprocal)
+        const tc_f32x2 u = gelu_poly2((xv - mean) * rstd * gv + bv);             // (16-bit storage: the polynomial CDF, tc_common.h)
         x[e] = u.x; x[e + 1] = u.y;
     }
     return bf8_pack<H>(x);

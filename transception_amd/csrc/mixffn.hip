@@ -88,6 +88,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p
     H* AO = p.a ? reinterpret_cast<H*>(p.a) + grow * C4 : nullptr;
     float2* ST = p.stat ? reinterpret_cast<float2*>(p.stat) + grow : nullptr;
     const int TH = p.TH, TW = p.TW, HW2 = p.HW2, HP = p.HP, MT = p.MT, IP = p.IP, Himg = p.H, Wimg = p.W;
+    const SDiv dHW2 = sdiv_make(HW2), dTW = sdiv_make(TW), dRW = sdiv_make((TW + 1) >> 1), dTLW = sdiv_make(p.tilesW), dTLH = sdiv_make(p.tilesH);   // (tc_common.h: run-time divisors)
 
     // Parameters of this weight group.  Every global load of the prologue is issued before the first LDS store waits for one (the
     // staging loops used to pay one memory round trip per iteration: 10 - 17 k cycles of a 25 - 80 k-cycle launch).
@@ -132,14 +133,16 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p
     const int mt2 = wave % K::MT2MAX, nt2 = wave / K::MT2MAX;
 
     auto tile_org = [&](int tidx, int& b, int& oh0, int& ow0) __attribute__((always_inline)) {
-        const int tx = tidx % p.tilesW, ty = (tidx / p.tilesW) % p.tilesH;
-        b = tidx / (p.tilesW * p.tilesH); oh0 = ty * TH; ow0 = tx * TW;
+        const int t1 = sdiv(tidx, dTLW), tx = smod(tidx, t1, dTLW);
+        b = sdiv(t1, dTLH);
+        const int ty = smod(t1, b, dTLH);
+        b = __builtin_amdgcn_readfirstlane(b); oh0 = __builtin_amdgcn_readfirstlane(ty * TH); ow0 = __builtin_amdgcn_readfirstlane(tx * TW);
     };
     // x on the haloed tile: loads issued branch-free (positions outside read the map's first bytes), zeroed on the way into LDS
     uint4 xr[K::NXR];
     auto xin = [&](int s, int oh0, int ow0, int& pix, int& cg, int& off) __attribute__((always_inline)) {
         pix = s / XC; cg = s - pix * XC;
-        const int hy = pix / HW2, hx = pix - hy * HW2, ih = oh0 - 1 + hy, iw = ow0 - 1 + hx;
+        const int hy = sdiv(pix, dHW2), hx = smod(pix, hy, dHW2), ih = oh0 - 1 + hy, iw = ow0 - 1 + hx;
         const bool ok = pix < HP && (unsigned)ih < (unsigned)Himg && (unsigned)iw < (unsigned)Wimg;
         off = (ih * Wimg + iw) * p.ldx + cg * 8;
         return ok;
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p
 #pragma unroll
                 for (int nt = 0; nt < NT1; ++nt) acc[nt] = TcHalf<H>::mfma(wf1[nt][kk], av, acc[nt]);     // D^T: lane = pixel row
             }
-            const int pp = mi * 32 + l31, hy = pp / HW2, hx = pp - hy * HW2, ih = oh0 - 1 + hy, iw = ow0 - 1 + hx;
+            const int pp = mi * 32 + l31, hy = sdiv(pp, dHW2), hx = smod(pp, hy, dHW2), ih = oh0 - 1 + hy, iw = ow0 - 1 + hx;
             const bool ok = pp < HP && (unsigned)ih < (unsigned)Himg && (unsigned)iw < (unsigned)Wimg;
             const bool inner = ok && hy >= 1 && hy <= TH && hx >= 1 && hx <= TW;
 #pragma unroll
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p
 #pragma unroll
                 for (int q = 0; q < NRD; ++q) {
                     const int it = q * 64 + lane, run = it < nitems ? (it00 + it) / SG : 0;
-                    yq[q] = run / RW; xq[q] = (run - yq[q] * RW) * 2;
+                    yq[q] = sdiv(run, dRW); xq[q] = smod(run, yq[q], dRW) * 2;
 #pragma unroll
                     for (int r = 0; r < 2; ++r) { o[q][r][0] = tc_f32x2{ba.x, ba.y}; o[q][r][1] = tc_f32x2{ba.z, ba.w}; o[q][r][2] = tc_f32x2{bb.x, bb.y}; o[q][r][3] = tc_f32x2{bb.z, bb.w}; }
                 }
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p
             for (int w = 0; w < 8; ++w) { const float2 t = pst[w * IPMAX + tid]; const float dm = t.x * (1.0f / (float)CW) - mean; m2 += t.y + (float)CW * dm * dm; }
             const float rstd = rsqrtf(m2 * (1.0f / (float)C4) + p.eps);
             fst[tid] = make_float2(mean, rstd);
-            const int y = tid / TW, x = tid - y * TW;
+            const int y = sdiv(tid, dTW), x = smod(tid, y, dTW);
             if (ST && oh0 + y < Himg && ow0 + x < Wimg) ST[ibase + (long long)(oh0 + y) * Wimg + ow0 + x] = make_float2(mean, rstd);
         }
         __syncthreads();
@@ -361,7 +364,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p
                 bt[0] = c0.x; bt[1] = c0.y; bt[2] = c0.z; bt[3] = c0.w; bt[4] = c1.x; bt[5] = c1.y; bt[6] = c1.z; bt[7] = c1.w;
             }
             for (int s = tid; s < IP * HC; s += NTH) {
-                const int q = s / HC, y = q / TW, x = q - y * TW;
+                const int q = s / HC, y = sdiv(q, dTW), x = smod(q, y, dTW);
                 bf16_t* cell = hs + (y * HW2 + x) * PH + cgx * 8;
                 const uint4 dv = *reinterpret_cast<const uint4*>(cell);
                 const float2 st = fst[q];
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
                     const tc_f32x2 xv = {v[e], v[e + 1]}, gv = {gm[e], gm[e + 1]}, bv = {bt[e], bt[e + 1]};
-                    const tc_f32x2 u = gelu_f2_fast((xv - st.x) * st.y * gv + bv);
+                    const tc_f32x2 u = gelu_poly2((xv - st.x) * st.y * gv + bv);
                     v[e] = u.x; v[e + 1] = u.y;
                 }
                 const uint4 av = pk8<H>(v);
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
         if (mt2 < p.MT2) {
-            const int q = min(mt2 * 32 + l31, IP - 1), y = q / TW, x = q - y * TW;
+            const int q = min(mt2 * 32 + l31, IP - 1), y = sdiv(q, dTW), x = smod(q, y, dTW);
             const bf16_t* ap = hs + (y * HW2 + x) * PH + 8 * hh;
             if constexpr (K::W2LDS) {
                 const bf16_t* wp = w2s + (nt2 * 32 + l31) * PH + 8 * hh;
@@ -428,7 +431,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p
         {   // + bias + residual, rounded once, whole 16-byte pieces of pixel rows
             const int cg = tid % XC;
             for (int s = tid; s < IP * XC; s += NTH) {
-                const int q = s / XC, y = q / TW, x = q - y * TW;
+                const int q = s / XC, y = sdiv(q, dTW), x = smod(q, y, dTW);
                 if (oh0 + y >= Himg || ow0 + x >= Wimg) continue;
                 const long long rg = ibase + (long long)(oh0 + y) * Wimg + ow0 + x;
                 const float4 v0 = *reinterpret_cast<const float4*>(stg + q * PO + cg * 8), v1 = *reinterpret_cast<const float4*>(stg + q * PO + cg * 8 + 4);

@@ -401,6 +401,7 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dw_kernel(const FfnBwdDev p) {
     H* DX = reinterpret_cast<H*>(p.dx) + (long long)g * M * p.lddx;
     const H* W1 = reinterpret_cast<const H*>(p.w1) + wo;
     const int TH = p.TH, TW = p.TW, HW2 = p.HW2, HP = p.HP, MT = p.MT, IP = p.IP, Himg = p.H, Wimg = p.W;
+    const SDiv dHW2 = sdiv_make(HW2), dTW = sdiv_make(TW), dTLW = sdiv_make(p.tilesW), dTLH = sdiv_make(p.tilesH);      // (tc_common.h: run-time divisors)
 
     auto stage_params = [&]() __attribute__((always_inline)) {
         const H* wd = reinterpret_cast<const H*>(p.wd) + wo;
@@ -434,11 +435,14 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dw_kernel(const FfnBwdDev p) {
     };
 
     auto tile_org = [&](int tidx, int& b, int& oh0, int& ow0) __attribute__((always_inline)) {
-        const int tx = tidx % p.tilesW, ty = (tidx / p.tilesW) % p.tilesH;
-        b = tidx / (p.tilesW * p.tilesH); oh0 = ty * TH; ow0 = tx * TW;
+        const int t1 = sdiv(tidx, dTLW), tx = smod(tidx, t1, dTLW);
+        b = sdiv(t1, dTLH);
+        const int ty = smod(t1, b, dTLH);
+        b = __builtin_amdgcn_readfirstlane(b); oh0 = __builtin_amdgcn_readfirstlane(ty * TH); ow0 = __builtin_amdgcn_readfirstlane(tx * TW);
     };
     auto halo_in = [&](int pix, int oh0, int ow0, int& ih, int& iw) __attribute__((always_inline)) {
-        const int hy = pix / HW2, hx = pix - hy * HW2;
+        pix = tc_opaque(pix);
+        const int hy = sdiv(pix, dHW2), hx = smod(pix, hy, dHW2);
         ih = oh0 - 1 + hy; iw = ow0 - 1 + hx;
         return pix < HP && (unsigned)ih < (unsigned)Himg && (unsigned)iw < (unsigned)Wimg;
     };
@@ -508,7 +512,7 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dw_kernel(const FfnBwdDev p) {
         }
     };
     // halo-tile row of inner pixel q (row-major over the TH x TW inner pixels)
-    auto hrow = [&](int q) __attribute__((always_inline)) { const int y = q / TW; return (y + 1) * HW2 + (q - y * TW) + 1; };
+    auto hrow = [&](int q) __attribute__((always_inline)) { q = tc_opaque(q); const int y = sdiv(q, dTW); return (y + 1) * HW2 + smod(q, y, dTW) + 1; };
 
     f32x16 accw[NCH];
     tc_f32x2 aw[NCH][11];                                            // this thread's sums over (its row of every tile) x (its channel pair of chunk c): dwd taps, dbd, db1
@@ -671,7 +675,7 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dw_kernel(const FfnBwdDev p) {
             const H* xb = X + (long long)b * imgpix * p.ldx;
 #pragma unroll
             for (int k = 0; k < NEP; ++k) {
-                const int s = k * NTH + tid, q = s < IP * XC ? s / XC : 0, y = q / TW, x = q - y * TW;
+                const int s = k * NTH + tid, q = s < IP * XC ? s / XC : 0, y = sdiv(q, dTW), x = smod(q, y, dTW);
                 const bool valid = s < IP * XC && oh0 + y < Himg && ow0 + x < Wimg;
                 xraw[k] = *reinterpret_cast<const uint4*>(xb + (valid ? (long long)(oh0 + y) * Wimg + ow0 + x : 0) * p.ldx + (tid % XC) * 8);
             }
@@ -686,7 +690,7 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dw_kernel(const FfnBwdDev p) {
         if constexpr (!PRE) {
             H* dxb = DX + (long long)b * imgpix * p.lddx;
             for (int s = tid; s < IP * XC; s += NTH) {
-                const int q = s / XC, cg = s - q * XC, y = q / TW, x = q - y * TW;
+                const int q = s / XC, cg = s - q * XC, y = sdiv(q, dTW), x = smod(q, y, dTW);
                 if (oh0 + y >= Himg || ow0 + x >= Wimg) continue;
                 const float4 v0 = *reinterpret_cast<const float4*>(stg + q * PO + cg * 8), v1 = *reinterpret_cast<const float4*>(stg + q * PO + cg * 8 + 4);
                 float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
@@ -707,7 +711,7 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dw_kernel(const FfnBwdDev p) {
             for (int e = 0; e < 8; ++e) { dgl[e] = 0.f; dbl[e] = 0.f; }
 #pragma unroll
             for (int k = 0; k < NEP; ++k) {                         // (whole pixels per lane group, every lane makes every trip)
-                const int s = k * NTH + tid, q = s < IP * XC ? s / XC : 0, y = q / TW, x = q - y * TW;
+                const int s = k * NTH + tid, q = s < IP * XC ? s / XC : 0, y = sdiv(q, dTW), x = smod(q, y, dTW);
                 const bool valid = s < IP * XC && oh0 + y < Himg && ow0 + x < Wimg;
                 const long long pix = valid ? (long long)(oh0 + y) * Wimg + ow0 + x : 0;
                 const float4 v0 = *reinterpret_cast<const float4*>(stg + q * PO + cg * 8), v1 = *reinterpret_cast<const float4*>(stg + q * PO + cg * 8 + 4);

@@ -121,6 +121,18 @@ template <int G> __device__ __forceinline__ float tc_group_max(float v) {
     return v;
 }
 
+// n / d for small non-negative n and a RUN-TIME d (pixel / tile indices; n + d < 2^22): hipcc expands an unsigned division into a hoisted
+// reciprocal, a v_mul_hi_u32, two v_mul_lo_u32 (32-bit integer multiplies issue at a quarter of the VALU rate) and eight corrections per
+// quotient -- round 6 found a fifth of the tiled MixFFN kernels' vector instructions there.  floor((n + 0.5) / d) in fp32 is exact on that
+// range ((n + 0.5) / d is at least 0.5 / d away from an integer, the two roundings move it by < (n / d + 1) 2^-23) and costs a convert, an FMA
+// and a convert, all full rate; the remainder takes a 24-bit multiply-add.
+struct SDiv { float inv, half; int d; };
+__device__ __forceinline__ SDiv sdiv_make(int d) { SDiv s; s.inv = 1.0f / (float)d; s.half = 0.5f * s.inv; s.d = d; return s; }
+__device__ __forceinline__ int sdiv(int n, const SDiv& s) { return (int)fmaf((float)n, s.inv, s.half); }
+__device__ __forceinline__ int smod(int n, int q, const SDiv& s) { return n - __mul24(q, s.d); }
+// An index the compiler must treat as new at every use: with divisions this cheap it hoists every loop-invariant quotient out of the tile loop and
+// spills it (ffn_bwd_dw_kernel: 22 more scratch words, +12 % time) -- three instructions recomputed beat a scratch reload.
+__device__ __forceinline__ int tc_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 __device__ __forceinline__ float wave_sum(float v) { return tc_group_sum<64>(v); }
 __device__ __forceinline__ float wave_max(float v) { return tc_group_max<64>(v); }
 
@@ -145,8 +157,7 @@ template <bool FAST = false> __device__ __forceinline__ float gelu_cdf_pdf(float
     return x >= 0.f ? 1.0f - half_erfc : half_erfc;               // Phi(x)
 }
 __device__ __forceinline__ float gelu_f(float x) { float pdf; return x * gelu_cdf_pdf(x, pdf); }
-// by storage type: exact for fp32, FAST for the 16-bit types
-template <typename T> __device__ __forceinline__ float gelu_fT(float x) { float pdf; return x * gelu_cdf_pdf<!std::is_same<T, float>::value>(x, pdf); }
+// by storage type (gradient): exact reciprocal for fp32, the hardware one for the 16-bit types
 template <typename T> __device__ __forceinline__ float gelu_grad_fT(float x) {
     float pdf;
     const float cdf = gelu_cdf_pdf<!std::is_same<T, float>::value>(x, pdf);
@@ -190,6 +201,38 @@ __device__ __forceinline__ tc_f32x2 gelu_cdf_pdf2_fast(tc_f32x2 x, tc_f32x2& pdf
     return tc_f32x2{x.x >= 0.f ? one_m.x : half_erfc.x, x.y >= 0.f ? one_m.y : half_erfc.y};
 }
 __device__ __forceinline__ tc_f32x2 gelu_f2_fast(tc_f32x2 x) { tc_f32x2 pdf; return x * gelu_cdf_pdf2_fast(x, pdf); }
+// Forward-only GELU of the 16-bit storage kernels (round 6).  Where only the VALUE is needed the Gaussian is not, and the normal CDF is smooth
+// enough for a polynomial:  Phi(x) ~ 0.5 + t P(t^2), t = clamp(x, -4.2, 4.2), P of degree 8 in t^2 fitted for the smallest maximum ABSOLUTE error
+// (scripts/exp/fit_phi_poly.py: 1.02e-5 over the whole line in fp32 Horner arithmetic; Phi(-4.2) = 1.3e-5 is the clamp's share).  Twelve full-rate
+// instructions per element against sixteen + v_exp_f32 + v_rcp_f32 (quarter rate): 30 against 58 SIMD-cycles per 64 elements
+// (scripts/exp/valu_rate.hip).  The error is absolute, not relative: x Phi(x) is off by <= 1.02e-5 |x|, under 0.3 % of a bf16 / 2 % of an fp16
+// spacing wherever |GELU| >= 4e-3 -- below that (x < -2.8) the value is within 1.02e-5 |x| of the exact one instead of within an ulp of it.  The
+// backward kernels keep the A-S form: they need exp(-x^2 / 2) anyway and get Phi from it for three more instructions.
+#define TC_PHI_X0 4.2f
+#define TC_PHI_C0 3.9890743800e-01f
+#define TC_PHI_C1 -6.6360416413e-02f
+#define TC_PHI_C2 9.8301434219e-03f
+#define TC_PHI_C3 -1.1141502210e-03f
+#define TC_PHI_C4 9.4574729576e-05f
+#define TC_PHI_C5 -5.7608060352e-06f
+#define TC_PHI_C6 2.3436991163e-07f
+#define TC_PHI_C7 -5.6334089611e-09f
+#define TC_PHI_C8 5.9982045543e-11f
+__device__ __forceinline__ float gelu_poly(float x) {
+    const float t = __builtin_amdgcn_fmed3f(x, -TC_PHI_X0, TC_PHI_X0), s = t * t;
+    float p = fmaf(TC_PHI_C8, s, TC_PHI_C7);
+    p = fmaf(p, s, TC_PHI_C6); p = fmaf(p, s, TC_PHI_C5); p = fmaf(p, s, TC_PHI_C4); p = fmaf(p, s, TC_PHI_C3);
+    p = fmaf(p, s, TC_PHI_C2); p = fmaf(p, s, TC_PHI_C1); p = fmaf(p, s, TC_PHI_C0);
+    return x * fmaf(t, p, 0.5f);
+}
+__device__ __forceinline__ tc_f32x2 gelu_poly2(tc_f32x2 x) {
+    const tc_f32x2 t = {__builtin_amdgcn_fmed3f(x.x, -TC_PHI_X0, TC_PHI_X0), __builtin_amdgcn_fmed3f(x.y, -TC_PHI_X0, TC_PHI_X0)};
+    const tc_f32x2 s = t * t;
+    tc_f32x2 p = s * TC_PHI_C8 + TC_PHI_C7;
+    p = p * s + TC_PHI_C6; p = p * s + TC_PHI_C5; p = p * s + TC_PHI_C4; p = p * s + TC_PHI_C3;
+    p = p * s + TC_PHI_C2; p = p * s + TC_PHI_C1; p = p * s + TC_PHI_C0;
+    return x * (t * p + 0.5f);
+}
 __device__ __forceinline__ tc_f32x2 gelu_f2(tc_f32x2 x) { tc_f32x2 pdf; return x * gelu_cdf_pdf2(x, pdf); }
 __device__ __forceinline__ tc_f32x2 gelu_grad_f2(tc_f32x2 x) { tc_f32x2 pdf; const tc_f32x2 cdf = gelu_cdf_pdf2(x, pdf); return cdf + x * pdf; }
 __device__ __forceinline__ tc_f32x2 gelu_grad_f2_fast(tc_f32x2 x) { tc_f32x2 pdf; const tc_f32x2 cdf = gelu_cdf_pdf2_fast(x, pdf); return cdf + x * pdf; }
@@ -197,6 +240,10 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     float pdf;
     const float cdf = gelu_cdf_pdf(x, pdf);
     return cdf + x * pdf;
+}
+// by storage type: the exact form for fp32, the polynomial for the 16-bit types
+template <typename T> __device__ __forceinline__ float gelu_fT(float x) {
+    if constexpr (std::is_same<T, float>::value) return gelu_f(x); else return gelu_poly(x);
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float hswish_f(float x) { return x * fminf(fmaxf(x + 3.0f, 0.0f), 6.0f) * (1.0f / 6.0f); }
