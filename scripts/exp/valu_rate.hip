@@ -59,6 +59,29 @@ template <int MODE> __global__ __launch_bounds__(256) void rate_kernel(float* ou
         } else if constexpr (MODE == 6) {                          // A-S value + gradient (the backward's pair), packed
 #pragma unroll
             for (int e = 0; e < 8; e += 2) { tc_f32x2 pdf; const tc_f32x2 x = {v[e], v[e + 1]}; const tc_f32x2 cdf = gelu_cdf_pdf2_fast(x, pdf); const tc_f32x2 u = x * cdf + (cdf + x * pdf) * 0.1f; v[e] = u.x - 0.3f; v[e + 1] = u.y + 0.2f; }
+        } else if constexpr (MODE == 8) {                          // 8 x v_dot2_f32_bf16 (two bf16 products into an fp32 accumulator)
+            const unsigned w = __float_as_uint(seed) | 0x3f803f80u;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) asm volatile("v_dot2_f32_bf16 %0, %1, %2, %0" : "+v"(v[e]) : "v"(w), "v"(0x3e803e80u));
+        } else if constexpr (MODE == 9) {                          // 8 x v_perm_b32
+            unsigned* u = reinterpret_cast<unsigned*>(v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(u[e]) : "v"(0x12345678u), "v"(0x05040100u));
+        } else if constexpr (MODE == 10) {                         // 8 x v_mul_lo_u32
+            unsigned* u = reinterpret_cast<unsigned*>(v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(u[e]) : "v"(0x9e3779b1u));
+        } else if constexpr (MODE == 11) {                         // 8 x v_mul_i32_i24
+            int* u = reinterpret_cast<int*>(v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) asm volatile("v_mul_i32_i24 %0, %0, %1" : "+v"(u[e]) : "v"(3));
+        } else if constexpr (MODE == 12) {                         // 8 x v_exp_f32
+#pragma unroll
+            for (int e = 0; e < 8; ++e) asm volatile("v_exp_f32 %0, %0" : "+v"(v[e]));
+        } else if constexpr (MODE == 13) {                         // 4 x v_cvt_pk_bf16_f32 (8 elements)
+            unsigned* u = reinterpret_cast<unsigned*>(v);
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u[e]) : "v"(v[e]), "v"(v[e + 1]));
         } else {                                                   // polynomial value + exp for the density, scalar
 #pragma unroll
             for (int e = 0; e < 8; ++e) { const float x = v[e], cdf = phi_poly(x), pdf = 0.39894228f * __expf(-0.5f * x * x); v[e] = x * cdf + (cdf + x * pdf) * 0.1f - 0.3f; }
@@ -97,5 +120,11 @@ int main() {
     run<5>("GELU clamped polynomial CDF, packed", out);
     run<6>("GELU + GELU' A-S, packed (today's backward)", out);
     run<7>("GELU + GELU' polynomial CDF + exp density, scalar", out);
+    run<8>("8 x v_dot2_f32_bf16", out);
+    run<9>("8 x v_perm_b32", out);
+    run<10>("8 x v_mul_lo_u32", out);
+    run<11>("8 x v_mul_i32_i24", out);
+    run<12>("8 x v_exp_f32", out);
+    run<13>("4 x v_cvt_pk_bf16_f32 (8 elements)", out);
     return 0;
 }

@@ -52,7 +52,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             jobs.append((s, o))
 
     # per-file flags.  lncls.hip: hipcc's SLP vectoriser packs the classifier's fp32 multiply-adds into v_pk_fma_f32 / v_pk_add_f32 and pays
-    # for it in v_mov_b32 (305 of the forward kernel's 1412 instructions; packed fp32 issues at half rate anyway): 8 % fewer instructions without
+    # for it in v_mov_b32 (305 of the forward kernel's 1412 instructions; a v_pk_fma_f32 takes 5.0 SIMD-cycles against 3.0 for a v_fma_f32, scripts/exp/valu_rate.hip): 8 % fewer instructions without
     extra_flags = {"lncls.hip": ["-fno-slp-vectorize"]}
 
     def compile_one(job):

@@ -325,8 +325,9 @@ template <int K, int CH, int XB, typename T>
 __device__ __forceinline__ void mhca_conv_tile(T* cvs, const T* vs, const float* wcv, const float* bcv, int H, int W) {
     constexpr int P = K / 2, NV = CH / 8, NIN = XB + K - 1;
     const int nxb = (W + XB - 1) / XB, items = H * nxb * NV;
+    const SDiv dnxb = sdiv_make(nxb);                                 // (tc_common.h: a run-time divisor of small indices)
     for (int i = threadIdx.x; i < items; i += 256) {
-        const int cvi = i % NV, t = i / NV, xb = t % nxb, y = t / nxb, x0 = xb * XB, c0 = cvi * 8;
+        const int cvi = i % NV, t = i / NV, y = sdiv(t, dnxb), xb = smod(t, y, dnxb), x0 = xb * XB, c0 = cvi * 8;
         float acc[XB][8];
 #pragma unroll
         for (int o = 0; o < XB; ++o)
@@ -343,7 +344,7 @@ __device__ __forceinline__ void mhca_conv_tile(T* cvs, const T* vs, const float*
                 const int xx = x0 + j - P;
                 const bool ok = rv && (unsigned)xx < (unsigned)W;
                 const int xc = (unsigned)xx < (unsigned)W ? xx : x0;
-                uint4 r = *reinterpret_cast<const uint4*>(vs + (yc * W + xc) * CH + c0);
+                uint4 r = *reinterpret_cast<const uint4*>(vs + tc_mul24(tc_mad24(yc, W, xc), CH) + c0);
                 if (!ok) r = make_uint4(0u, 0u, 0u, 0u);
                 unpack16<T>(r, vin[j]);
             }
@@ -359,7 +360,7 @@ __device__ __forceinline__ void mhca_conv_tile(T* cvs, const T* vs, const float*
         }
 #pragma unroll
         for (int o = 0; o < XB; ++o)
-            if (x0 + o < W) *reinterpret_cast<uint4*>(cvs + (y * W + x0 + o) * CH + c0) = pack16<T>(acc[o]);
+            if (x0 + o < W) *reinterpret_cast<uint4*>(cvs + tc_mul24(tc_mad24(y, W, x0 + o), CH) + c0) = pack16<T>(acc[o]);
     }
 }
 template <int K, int CH, typename T>
@@ -412,6 +413,7 @@ __global__ __launch_bounds__(256, 2) void mhca_att_fwd_kernel(MhcaAttDev p) {
     const int blk = bt * 8 + hd, g = bt / p.B;
     const long long row0 = (long long)bt * N;
     const T* xn = reinterpret_cast<const T*>(p.xn);
+    const T* xn_img = xn + row0 * p.ldx;            // this image's first row (uniform); a token's offset below it fits 32 bits
     const T* Wg = reinterpret_cast<const T*>(p.Wqkv) + g * p.gs;
     const T* bg = reinterpret_cast<const T*>(p.bqkv) + g * p.gs;
     // window of this head (MSTr.py:785-799: heads 0-1 3x3, 2-4 5x5, 5-7 7x7), taps transposed into LDS
@@ -493,7 +495,7 @@ __global__ __launch_bounds__(256, 2) void mhca_att_fwd_kernel(MhcaAttDev p) {
 #define MHCA_FETCH_X(I0)                                                                                                               \
     _Pragma("unroll") for (int j = 0; j < XPT; ++j) {                                                                                  \
         const int i = (I0) + tid + 256 * j, ic = i < N * CV ? i : 0, n = ic / CV, c8 = ic - n * CV;                                    \
-        const T* src = xn + (row0 + n) * p.ldx + c8 * 8;                                                                               \
+        const T* src = xn_img + tc_mul24(n, p.ldx) + c8 * 8;                                                                            \
         MHCA_GLOAD128(xr[j], src);                                                                                                     \
     }
             MHCA_FETCH_X(0);                                    // (the asm loads first: what the compiler hoists out of the loop below -- bias conversions -- then waits behind them, not before them)
@@ -543,7 +545,7 @@ __global__ __launch_bounds__(256, 2) void mhca_att_fwd_kernel(MhcaAttDev p) {
         _Pragma("unroll") for (int i = 0; i < LPT; ++i) {            /* (rows past the image: a clamped row, dropped in MHCA_PUT) */   \
             const int flat = (i * 64 + l) * 8, row = flat / C, col = flat - row * C;                                                   \
             const int tok = (w + 4 * ((T0) + u)) * 32 + row, tc = tok < N ? tok : N - 1;                                               \
-            const T* src = xn + (row0 + tc) * p.ldx + col;                                                                             \
+            const T* src = xn_img + tc_mul24(tc, p.ldx) + col;                                                                          \
             MHCA_GLOAD128(xr[u][i], src);                                                                                              \
         }
             MHCA_FETCH_T(0);                                    // (the asm loads first: what the compiler hoists out of the loop below -- bias conversions -- then waits behind them, not before them)
@@ -592,7 +594,7 @@ __global__ __launch_bounds__(256, 2) void mhca_att_fwd_kernel(MhcaAttDev p) {
         T* qo = reinterpret_cast<T*>(p.qkv) + row0 * p.ldq + hd * CH;
         for (int i = tid; i < N * NV; i += 256) {
             const int n = i / NV, c0 = (i - n * NV) * 8;
-            T* dst = qo + (long long)n * p.ldq + c0;
+            T* dst = qo + tc_mul24(n, p.ldq) + c0;
             *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(qs + n * CH + c0);
             *reinterpret_cast<uint4*>(dst + C) = pack16<T>(e + n * CH + c0);
             *reinterpret_cast<uint4*>(dst + 2 * C) = *reinterpret_cast<const uint4*>(vs + n * CH + c0);
@@ -620,7 +622,7 @@ __global__ __launch_bounds__(256, 2) void mhca_att_fwd_kernel(MhcaAttDev p) {
             const int n = i / NV, j0 = (i - n * NV) * 8;
             float cv[8], acc[8];
             const uint4 craw = *reinterpret_cast<const uint4*>(cvs + n * CH + j0);
-            *reinterpret_cast<uint4*>(co + (long long)n * p.ldc + j0) = craw;
+            *reinterpret_cast<uint4*>(co + tc_mul24(n, p.ldc) + j0) = craw;
             unpack16<T>(craw, cv);
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc[u] = 0.f;
@@ -641,7 +643,7 @@ __global__ __launch_bounds__(256, 2) void mhca_att_fwd_kernel(MhcaAttDev p) {
             fa_get8(qr + j0, qj);
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc[u] = scale * acc[u] + qj[u] * cv[u];
-            *reinterpret_cast<uint4*>(oo + (long long)n * p.ldo + j0) = pack16<T>(acc);
+            *reinterpret_cast<uint4*>(oo + tc_mul24(n, p.ldo) + j0) = pack16<T>(acc);
         }
     }
 #ifdef TC_MHCA_TIMING
@@ -820,17 +822,17 @@ __global__ __launch_bounds__(256, 2) void mhca_att_bwd_kernel(MhcaAttBwdDev p) {
 #define MHCA_FETCH_B(I0)                                                                                                               \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                                    \
         const int i = (I0) + tid + 256 * j, ic = i < nitem ? i : 0, n = ic / NV, c8 = (ic - n * NV) * 8;                               \
-        const T* src = qg + (long long)n * p.ldq + c8;                                                                                 \
+        const T* src = qg + tc_mul24(n, p.ldq) + c8;                                                                                 \
         const T* srk = src + C;                                                                                                        \
         const T* srv = src + 2 * C;                                                                                                    \
-        const T* srg = gg + (long long)n * p.ldgo + c8;                                                                                \
+        const T* srg = gg + tc_mul24(n, p.ldgo) + c8;                                                                                \
         MHCA_GLOAD128(rq[j], src); MHCA_GLOAD128(rk[j], srk); MHCA_GLOAD128(rv[j], srv); MHCA_GLOAD128(rg[j], srg);                    \
     }
         MHCA_FETCH_B(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int i = tid + 256 * j, ic = i < nitem ? i : 0, n = ic / NV, c8 = (ic - n * NV) * 8;
-            const T* src = cg + (long long)n * p.ldc + c8;
+            const T* src = cg + tc_mul24(n, p.ldc) + c8;
             MHCA_GLOAD128(cvr[j], src);
         }
         unsigned tapv[8];
@@ -948,7 +950,7 @@ __global__ __launch_bounds__(256, 2) void mhca_att_bwd_kernel(MhcaAttBwdDev p) {
         float dvc8[8], g0[8];
         fa_get8(dvc + n * CH + c0, dvc8);
         fa_get8(gr + c0, g0);
-        T* pq = dq0 + (long long)n * p.ldd + c0;
+        T* pq = dq0 + tc_mul24(n, p.ldd) + c0;
         float old[VEC];
 #pragma unroll
         for (int u = 0; u < VEC; ++u) {
@@ -977,7 +979,7 @@ __global__ __launch_bounds__(256, 2) void mhca_att_bwd_kernel(MhcaAttBwdDev p) {
     }
     for (int i = tid + 1024; i < nitem; i += 256) {
         const int n = i / NV, c0 = (i - n * NV) * VEC;
-        token(i, *reinterpret_cast<const uint4*>(cg + (long long)n * p.ldc + c0));
+        token(i, *reinterpret_cast<const uint4*>(cg + tc_mul24(n, p.ldc) + c0));
     }
 #ifdef TC_MHCA_TIMING
     MHCA_STAMP(5);
@@ -1168,6 +1170,10 @@ extern "C" int tc_mhca_att_fwd(const void* xn, int ldx, const void* Wqkv, const 
     if (!xn || !Wqkv || !bqkv || !w3 || !b3 || !w5 || !b5 || !w7 || !b7 || !qkv || !convv || !o || !stats || groups <= 0 || B <= 0 || H <= 0 || W <= 0)
         return TC_ERR_ARG;
     if (!tc_mhca_att_supported(C, H * W, dtype)) return TC_ERR_UNSUPPORTED;
+    {   // token offsets inside an image are formed in 32 bits
+        const long long n = (long long)H * W, lmax = ldx > ldq ? (ldx > ldc ? ldx : ldc) : (ldq > ldc ? ldq : ldc);
+        if (n * (lmax > ldo ? lmax : ldo) >= (1LL << 31) || lmax >= (1 << 23) || ldo >= (1 << 23)) return TC_ERR_ARG;
+    }
     if (ldx % 8 || ldq % 8 || ldc % 8 || ldo % 8 || gs % 8 ||
         (((uintptr_t)xn | (uintptr_t)Wqkv | (uintptr_t)qkv | (uintptr_t)convv | (uintptr_t)o) & 15))
         return TC_ERR_ARG;
@@ -1203,6 +1209,10 @@ extern "C" int tc_mhca_att_bwd(const void* qkv, int ldq, const void* convv, int 
         H <= 0 || W <= 0)
         return TC_ERR_ARG;
     if (!tc_mhca_att_bwd_supported(C, H * W, dtype)) return TC_ERR_UNSUPPORTED;
+    {
+        const long long n = (long long)H * W, l1 = ldq > ldc ? ldq : ldc, l2 = ldgo > ldd ? ldgo : ldd, lmax = l1 > l2 ? l1 : l2;
+        if (n * lmax >= (1LL << 31) || lmax >= (1 << 23)) return TC_ERR_ARG;
+    }
     if (ldq % 8 || ldc % 8 || ldgo % 8 || ldd % 8 || (((uintptr_t)qkv | (uintptr_t)convv | (uintptr_t)go | (uintptr_t)dqkv) & 15)) return TC_ERR_ARG;
     MhcaAttBwdDev p;
     p.qkv = qkv; p.convv = convv; p.go = go; p.cw[0] = w3; p.cw[1] = w5; p.cw[2] = w7; p.stats = stats; p.dqkv = dqkv;

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p
         const int t1 = sdiv(tidx, dTLW), tx = smod(tidx, t1, dTLW);
         b = sdiv(t1, dTLH);
         const int ty = smod(t1, b, dTLH);
-        b = __builtin_amdgcn_readfirstlane(b); oh0 = __builtin_amdgcn_readfirstlane(ty * TH); ow0 = __builtin_amdgcn_readfirstlane(tx * TW);
+        b = __builtin_amdgcn_readfirstlane(b); oh0 = __builtin_amdgcn_readfirstlane(tc_mul24(ty, TH)); ow0 = __builtin_amdgcn_readfirstlane(tc_mul24(tx, TW));
     };
     // x on the haloed tile: loads issued branch-free (positions outside read the map's first bytes), zeroed on the way into LDS
     uint4 xr[K::NXR];
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p
         pix = s / XC; cg = s - pix * XC;
         const int hy = sdiv(pix, dHW2), hx = smod(pix, hy, dHW2), ih = oh0 - 1 + hy, iw = ow0 - 1 + hx;
         const bool ok = pix < HP && (unsigned)ih < (unsigned)Himg && (unsigned)iw < (unsigned)Wimg;
-        off = (ih * Wimg + iw) * p.ldx + cg * 8;
+        off = tc_mad24(tc_mad24(ih, Wimg, iw), p.ldx, cg * 8);
         return ok;
     };
     auto xfetch = [&](int tidx) __attribute__((always_inline)) {
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p
                 for (int e = 0; e < 8; ++e) f[e] = f[e] * rstd * gm[e] + bt[e];
                 v = pk8<H>(f);
             }
-            if (s < MT * 32 * XC) *reinterpret_cast<uint4*>(xs + pix * PX + cg * 8) = v;
+            if (s < MT * 32 * XC) *reinterpret_cast<uint4*>(xs + tc_mul24(pix, PX) + cg * 8) = v;
         }
     };
 
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p
                     const float4 bv = *reinterpret_cast<const float4*>(gbs + 2 * C4 + wave * CW + nt * 32 + 8 * gq + 4 * hh);
                     acc[nt][4 * gq] = bv.x; acc[nt][4 * gq + 1] = bv.y; acc[nt][4 * gq + 2] = bv.z; acc[nt][4 * gq + 3] = bv.w;
                 }
-            const bf16_t* ap = xs + (mi * 32 + l31) * PX + 8 * hh;
+            const bf16_t* ap = xs + tc_mul24(mi * 32 + l31, PX) + 8 * hh;
 #pragma unroll
             for (int kk = 0; kk < KK1; ++kk) {
                 const V8 av = *reinterpret_cast<const V8*>(ap + kk * 16);
@@ -240,6 +240,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p
             const int pp = mi * 32 + l31, hy = sdiv(pp, dHW2), hx = smod(pp, hy, dHW2), ih = oh0 - 1 + hy, iw = ow0 - 1 + hx;
             const bool ok = pp < HP && (unsigned)ih < (unsigned)Himg && (unsigned)iw < (unsigned)Wimg;
             const bool inner = ok && hy >= 1 && hy <= TH && hx >= 1 && hx <= TW;
+            const int ppH = tc_mul24(pp, PH);
 #pragma unroll
             for (int nt = 0; nt < NT1; ++nt)
 #pragma unroll
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p
                     const int col = wave * CW + nt * 32 + 8 * gq + 4 * hh;
                     uint2 v = make_uint2(pack2<H>(acc[nt][4 * gq], acc[nt][4 * gq + 1]), pack2<H>(acc[nt][4 * gq + 2], acc[nt][4 * gq + 3]));
                     if (!ok) v = make_uint2(0u, 0u);
-                    *reinterpret_cast<uint2*>(hs + pp * PH + col) = v;
+                    *reinterpret_cast<uint2*>(hs + ppH + col) = v;
                     if (HO && inner) *reinterpret_cast<uint2*>(HO + (ibase + (long long)ih * Wimg + iw) * C4 + col) = v;
                 }
         }
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p
                     if (q * 64 >= nitems) break;
                     tc_f32x2 in[4][4];
 #pragma unroll
-                    for (int dx = 0; dx < 4; ++dx) up8p(*reinterpret_cast<const uint4*>(hs + ((yq[q] + dy) * HW2 + xq[q] + dx) * PH + chw), in[dx]);
+                    for (int dx = 0; dx < 4; ++dx) up8p(*reinterpret_cast<const uint4*>(hs + tc_mul24(tc_mad24(yq[q] + dy, HW2, xq[q] + dx), PH) + chw), in[dx]);
 #pragma unroll
                     for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p
 #pragma unroll
                 for (int r = 0; r < 2; ++r)
                     if (live && x0 + r < TW)
-                        *reinterpret_cast<uint4*>(hs + (y * HW2 + x0 + r) * PH + chw) =
+                        *reinterpret_cast<uint4*>(hs + tc_mul24(tc_mad24(y, HW2, x0 + r), PH) + chw) =
                             make_uint4(pack2<H>(o[q][r][0].x, o[q][r][0].y), pack2<H>(o[q][r][1].x, o[q][r][1].y), pack2<H>(o[q][r][2].x, o[q][r][2].y), pack2<H>(o[q][r][3].x, o[q][r][3].y));
             }
             }
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p
             }
             for (int s = tid; s < IP * HC; s += NTH) {
                 const int q = s / HC, y = sdiv(q, dTW), x = smod(q, y, dTW);
-                bf16_t* cell = hs + (y * HW2 + x) * PH + cgx * 8;
+                bf16_t* cell = hs + tc_mul24(tc_mad24(y, HW2, x), PH) + cgx * 8;
                 const uint4 dv = *reinterpret_cast<const uint4*>(cell);
                 const float2 st = fst[q];
                 float v[8];
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p
         for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
         if (mt2 < p.MT2) {
             const int q = min(mt2 * 32 + l31, IP - 1), y = sdiv(q, dTW), x = smod(q, y, dTW);
-            const bf16_t* ap = hs + (y * HW2 + x) * PH + 8 * hh;
+            const bf16_t* ap = hs + tc_mul24(tc_mad24(y, HW2, x), PH) + 8 * hh;
             if constexpr (K::W2LDS) {
                 const bf16_t* wp = w2s + (nt2 * 32 + l31) * PH + 8 * hh;
 #pragma unroll
@@ -421,7 +422,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p
         __syncthreads();                                         // every fragment read of the hidden tile is done: it becomes the out stage
         FSTAMP(8);
         if (mt2 < p.MT2) {
-            float* sp = stg + (mt2 * 32 + l31) * PO + nt2 * 32 + 4 * hh;
+            float* sp = stg + tc_mul24(mt2 * 32 + l31, PO) + nt2 * 32 + 4 * hh;
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq)
                 *reinterpret_cast<float4*>(sp + 8 * gq) = make_float4(oacc[4 * gq], oacc[4 * gq + 1], oacc[4 * gq + 2], oacc[4 * gq + 3]);
@@ -434,7 +435,8 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnFwdDev p
                 const int q = s / XC, y = sdiv(q, dTW), x = smod(q, y, dTW);
                 if (oh0 + y >= Himg || ow0 + x >= Wimg) continue;
                 const long long rg = ibase + (long long)(oh0 + y) * Wimg + ow0 + x;
-                const float4 v0 = *reinterpret_cast<const float4*>(stg + q * PO + cg * 8), v1 = *reinterpret_cast<const float4*>(stg + q * PO + cg * 8 + 4);
+                const float* sq = stg + tc_mul24(q, PO) + cg * 8;
+                const float4 v0 = *reinterpret_cast<const float4*>(sq), v1 = *reinterpret_cast<const float4*>(sq + 4);
                 float v[8] = {v0.x + b2v[0], v0.y + b2v[1], v0.z + b2v[2], v0.w + b2v[3], v1.x + b2v[4], v1.y + b2v[5], v1.z + b2v[6], v1.w + b2v[7]};
                 if (RES) {
                     float rv[8];
@@ -500,7 +502,8 @@ int ffn_fused_fwd_launch(const TcFfnFused* f, hipStream_t s) {
     p.tilesH = (f->H + p.TH - 1) / p.TH; p.tilesW = (f->W + p.TW - 1) / p.TW;
     p.HW2 = p.TW + 2; p.HP = (p.TH + 2) * p.HW2; p.MT = (p.HP + 31) / 32; p.IP = p.TH * p.TW; p.MT2 = (p.IP + 31) / 32;
     const long long nt = (long long)f->B * p.tilesH * p.tilesW;
-    if (nt > 0x7fffffffLL) return TC_ERR_ARG;
+    // the kernels form tile / pixel indices in fp32 (sdiv: < 2^22) and per-image element offsets in 32 bits (< 2^31)
+    if (nt >= (1LL << 22) || (long long)f->H * f->W >= (1LL << 23) || f->ldx >= (1 << 23) || (long long)f->H * f->W * f->ldx >= (1LL << 31)) return TC_ERR_ARG;
     p.ntiles = (int)nt;
     const int ncu = ffn_num_cus();
     int gx = (int)(nt < ncu ? nt : ncu);

@@ -438,7 +438,7 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dw_kernel(const FfnBwdDev p) {
         const int t1 = sdiv(tidx, dTLW), tx = smod(tidx, t1, dTLW);
         b = sdiv(t1, dTLH);
         const int ty = smod(t1, b, dTLH);
-        b = __builtin_amdgcn_readfirstlane(b); oh0 = __builtin_amdgcn_readfirstlane(ty * TH); ow0 = __builtin_amdgcn_readfirstlane(tx * TW);
+        b = __builtin_amdgcn_readfirstlane(b); oh0 = __builtin_amdgcn_readfirstlane(tc_mul24(ty, TH)); ow0 = __builtin_amdgcn_readfirstlane(tc_mul24(tx, TW));
     };
     auto halo_in = [&](int pix, int oh0, int ow0, int& ih, int& iw) __attribute__((always_inline)) {
         pix = tc_opaque(pix);
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dw_kernel(const FfnBwdDev p) {
             const int s = tid + i * NTH, pix = s / XC, cg = s - pix * XC;
             int ih, iw;
             const bool ok = halo_in(pix, oh0, ow0, ih, iw);
-            xr[i] = *reinterpret_cast<const uint4*>(xb + (ok ? (long long)(ih * Wimg + iw) * p.ldx + cg * 8 : 0));
+            xr[i] = *reinterpret_cast<const uint4*>(xb + (ok ? tc_mad24(tc_mad24(ih, Wimg, iw), p.ldx, cg * 8) : 0));
         }
     };
     auto xput = [&](int tidx) __attribute__((always_inline)) {
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dw_kernel(const FfnBwdDev p) {
                 for (int e = 0; e < 8; ++e) f[e] = f[e] * rstd * pre[cg * 8 + e] + pre[C + cg * 8 + e];
                 v = pk8<H>(f);
             }
-            if (pix < HP) *reinterpret_cast<uint4*>(xs + pix * PX + cg * 8) = v;
+            if (pix < HP) *reinterpret_cast<uint4*>(xs + tc_mul24(pix, PX) + cg * 8) = v;
         }
     };
     auto gfetch = [&](int tidx, int c) __attribute__((always_inline)) {
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dw_kernel(const FfnBwdDev p) {
             const int s = tid + i * NTH, pix = s / GC, cg = s - pix * GC;
             int ih, iw;
             const bool ok = halo_in(pix, oh0, ow0, ih, iw);
-            gr[i] = *reinterpret_cast<const uint4*>(gb + (ok ? (long long)(ih * Wimg + iw) * C4 + cg * 8 : 0));
+            gr[i] = *reinterpret_cast<const uint4*>(gb + (ok ? tc_mad24(ih, Wimg, iw) * C4 + cg * 8 : 0));
         }
     };
     auto gput = [&](int tidx) __attribute__((always_inline)) {
@@ -508,11 +508,11 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dw_kernel(const FfnBwdDev p) {
             const int s = tid + i * NTH, pix = s / GC, cg = s - pix * GC;
             int ih, iw;
             const bool ok = halo_in(pix, oh0, ow0, ih, iw);
-            if (pix < HP) *reinterpret_cast<uint4*>(gs + pix * PG + cg * 8) = ok ? gr[i] : make_uint4(0u, 0u, 0u, 0u);
+            if (pix < HP) *reinterpret_cast<uint4*>(gs + tc_mul24(pix, PG) + cg * 8) = ok ? gr[i] : make_uint4(0u, 0u, 0u, 0u);
         }
     };
     // halo-tile row of inner pixel q (row-major over the TH x TW inner pixels)
-    auto hrow = [&](int q) __attribute__((always_inline)) { q = tc_opaque(q); const int y = sdiv(q, dTW); return (y + 1) * HW2 + smod(q, y, dTW) + 1; };
+    auto hrow = [&](int q) __attribute__((always_inline)) { q = tc_opaque(q); const int y = sdiv(q, dTW); return tc_mad24(y + 1, HW2, smod(q, y, dTW) + 1); };
 
     f32x16 accw[NCH];
     tc_f32x2 aw[NCH][11];                                            // this thread's sums over (its row of every tile) x (its channel pair of chunk c): dwd taps, dbd, db1
@@ -558,17 +558,18 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dw_kernel(const FfnBwdDev p) {
                         acc[4 * gq] = bv.x; acc[4 * gq + 1] = bv.y; acc[4 * gq + 2] = bv.z; acc[4 * gq + 3] = bv.w;
                     }
                     const int pp = mi * 32 + l31;
-                    const bf16_t* xp = xs + (pp < HP ? pp : 0) * PX + 8 * hh;      // (rows beyond the haloed tile: columns nobody keeps)
+                    const bf16_t* xp = xs + tc_mul24(pp < HP ? pp : 0, PX) + 8 * hh;      // (rows beyond the haloed tile: columns nobody keeps)
 #pragma unroll
                     for (int kk = 0; kk < KK1; ++kk) acc = TcHalf<H>::mfma(af[kk], *reinterpret_cast<const V8*>(xp + kk * 16), acc);
                     int ih, iw;
                     const bool ok = halo_in(pp, oh0, ow0, ih, iw);
+                    const int ppG = tc_mul24(pp, PG);
                     if (pp < HP) {
 #pragma unroll
                         for (int gq = 0; gq < 4; ++gq) {
                             uint2 v = make_uint2(pack2<H>(acc[4 * gq], acc[4 * gq + 1]), pack2<H>(acc[4 * gq + 2], acc[4 * gq + 3]));
                             if (!ok) v = make_uint2(0u, 0u);
-                            *reinterpret_cast<uint2*>(hs + pp * PG + cb * 32 + 8 * gq + 4 * hh) = v;
+                            *reinterpret_cast<uint2*>(hs + ppG + cb * 32 + 8 * gq + 4 * hh) = v;
                         }
                     }
                 }
@@ -649,7 +650,7 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dw_kernel(const FfnBwdDev p) {
             // ---- dx^T += W1^T dh^T  (rows = input channel, columns = inner pixel);  dW1 += dh^T x  (rows = hidden channel, columns = input channel)
             if (cb < p.MT2) {
                 const int q = cb * 32 + l31;
-                const bf16_t* dp = hs + (q < IP ? hrow(q) : 0) * PG + 8 * hh;
+                const bf16_t* dp = hs + tc_mul24(q < IP ? hrow(q) : 0, PG) + 8 * hh;
 #pragma unroll
                 for (int kk = 0; kk < KKC; ++kk) {
                     const bf16_t* wp = w1s + (c * CH + 16 * kk + 2 * hh + 4 * (gi >> 2)) * PX + nb * 32 + 16 * gq2 + 4 * (gi & 3);
@@ -660,8 +661,8 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dw_kernel(const FfnBwdDev p) {
             for (int ks = 0; ks < K::IPMAX / 16; ++ks) {                // (steps beyond the tile's pixels multiply the zero row)
                 const int qlo = 16 * ks + 8 * hh + (gi >> 2), qhi = qlo + 4, cc = 16 * gq2 + 4 * (gi & 3);
                 const int rlo = qlo < IP ? hrow(qlo) : -1, rhi = qhi < IP ? hrow(qhi) : -1;
-                const V8 av = ld_tr<V8>(hs + (rlo < 0 ? MPMAX : rlo) * PG + cb * 32 + cc, hs + (rhi < 0 ? MPMAX : rhi) * PG + cb * 32 + cc);
-                const V8 bv = ld_tr<V8>(xs + (rlo < 0 ? 0 : rlo) * PX + nb * 32 + cc, xs + (rhi < 0 ? 0 : rhi) * PX + nb * 32 + cc);
+                const V8 av = ld_tr<V8>(hs + tc_mul24(rlo < 0 ? MPMAX : rlo, PG) + cb * 32 + cc, hs + tc_mul24(rhi < 0 ? MPMAX : rhi, PG) + cb * 32 + cc);
+                const V8 bv = ld_tr<V8>(xs + tc_mul24(rlo < 0 ? 0 : rlo, PX) + nb * 32 + cc, xs + tc_mul24(rhi < 0 ? 0 : rhi, PX) + nb * 32 + cc);
                 accw[c] = TcHalf<H>::mfma(av, bv, accw[c]);
             }
             BSTAMP(9);
@@ -681,7 +682,7 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dw_kernel(const FfnBwdDev p) {
             }
         }
         if (cb < p.MT2) {
-            float* sp = stg + (cb * 32 + l31) * PO + nb * 32 + 4 * hh;
+            float* sp = stg + tc_mul24(cb * 32 + l31, PO) + nb * 32 + 4 * hh;
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq)
                 *reinterpret_cast<float4*>(sp + 8 * gq) = make_float4(accx[4 * gq], accx[4 * gq + 1], accx[4 * gq + 2], accx[4 * gq + 3]);
@@ -692,7 +693,8 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dw_kernel(const FfnBwdDev p) {
             for (int s = tid; s < IP * XC; s += NTH) {
                 const int q = s / XC, cg = s - q * XC, y = sdiv(q, dTW), x = smod(q, y, dTW);
                 if (oh0 + y >= Himg || ow0 + x >= Wimg) continue;
-                const float4 v0 = *reinterpret_cast<const float4*>(stg + q * PO + cg * 8), v1 = *reinterpret_cast<const float4*>(stg + q * PO + cg * 8 + 4);
+                const float* sq = stg + tc_mul24(q, PO) + cg * 8;
+                const float4 v0 = *reinterpret_cast<const float4*>(sq), v1 = *reinterpret_cast<const float4*>(sq + 4);
                 float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
                 H* dst = dxb + (long long)((oh0 + y) * Wimg + ow0 + x) * p.lddx + cg * 8;
                 if (p.acc_dx) {
@@ -714,7 +716,8 @@ __global__ __launch_bounds__(512, 2) void ffn_bwd_dw_kernel(const FfnBwdDev p) {
                 const int s = k * NTH + tid, q = s < IP * XC ? s / XC : 0, y = sdiv(q, dTW), x = smod(q, y, dTW);
                 const bool valid = s < IP * XC && oh0 + y < Himg && ow0 + x < Wimg;
                 const long long pix = valid ? (long long)(oh0 + y) * Wimg + ow0 + x : 0;
-                const float4 v0 = *reinterpret_cast<const float4*>(stg + q * PO + cg * 8), v1 = *reinterpret_cast<const float4*>(stg + q * PO + cg * 8 + 4);
+                const float* sq = stg + tc_mul24(q, PO) + cg * 8;
+                const float4 v0 = *reinterpret_cast<const float4*>(sq), v1 = *reinterpret_cast<const float4*>(sq + 4);
                 float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
                 if constexpr (PRE) {
                     // v = d(n2); the gradient of x = LayerNorm backward of it, from the raw row (still in L2) -- statistics recomputed
@@ -895,6 +898,9 @@ int ffn_bwd_launch(const TcFfnBwd* f, hipStream_t s) {
     if ((p.TH + 2) * (p.TW + 2) > KD::MPMAX || p.TH * p.TW > KD::IPMAX || p.TH > KD::THMAX || p.TW > KD::TWMAX) return TC_ERR_ARG;
     p.tilesH = (f->H + p.TH - 1) / p.TH; p.tilesW = (f->W + p.TW - 1) / p.TW;
     p.HW2 = p.TW + 2; p.HP = (p.TH + 2) * p.HW2; p.MT = (p.HP + 31) / 32; p.IP = p.TH * p.TW; p.MT2 = (p.IP + 31) / 32; p.KS = (p.IP + 15) / 16;
+    // tile / pixel indices in fp32 (sdiv: < 2^22), per-image element offsets in 32 bits (< 2^31)
+    if ((long long)f->B * p.tilesH * p.tilesW >= (1LL << 22) || (long long)f->H * f->W >= (1LL << 23) || f->ldx >= (1 << 23) ||
+        (long long)f->H * f->W * (f->ldx > 4 * C ? f->ldx : 4 * C) >= (1LL << 31)) return TC_ERR_ARG;
     p.ntiles = f->B * p.tilesH * p.tilesW;
     static bool attr_done = false;
     if (!attr_done) {

@@ -122,14 +122,18 @@ template <int G> __device__ __forceinline__ float tc_group_max(float v) {
 }
 
 // n / d for small non-negative n and a RUN-TIME d (pixel / tile indices; n + d < 2^22): hipcc expands an unsigned division into a hoisted
-// reciprocal, a v_mul_hi_u32, two v_mul_lo_u32 (32-bit integer multiplies issue at a quarter of the VALU rate) and eight corrections per
-// quotient -- round 6 found a fifth of the tiled MixFFN kernels' vector instructions there.  floor((n + 0.5) / d) in fp32 is exact on that
-// range ((n + 0.5) / d is at least 0.5 / d away from an integer, the two roundings move it by < (n / d + 1) 2^-23) and costs a convert, an FMA
-// and a convert, all full rate; the remainder takes a 24-bit multiply-add.
+// reciprocal and, per quotient, a v_mul_hi_u32, two v_mul_lo_u32 and eight compare / select / subtract corrections -- round 6 found a fifth of
+// the tiled MixFFN kernels' vector instructions there.  floor((n + 0.5) / d) in fp32 is exact on that range ((n + 0.5) / d is at least 0.5 / d
+// away from an integer, the two roundings move it by < (n / d + 1) 2^-23) and costs a convert, an FMA and a convert; the remainder one
+// multiply-add.  (It is the instruction COUNT that matters: scripts/exp/valu_rate.hip measures v_mul_lo_u32, v_mul_i32_i24, v_perm_b32 and
+// v_dot2_f32_bf16 all at 4.3 SIMD-cycles per wave instruction against 3.0 for v_fma_f32 and 8.8 for v_exp_f32 -- 32-bit integer multiplies
+// are not quarter-rate on this chip, and replacing them by 24-bit ones changed nothing.)
+__device__ __forceinline__ int tc_mul24(int a, int b) { return a * b; }                 // index products of small operands (named for the reader)
+__device__ __forceinline__ int tc_mad24(int a, int b, int c) { return a * b + c; }
 struct SDiv { float inv, half; int d; };
 __device__ __forceinline__ SDiv sdiv_make(int d) { SDiv s; s.inv = 1.0f / (float)d; s.half = 0.5f * s.inv; s.d = d; return s; }
 __device__ __forceinline__ int sdiv(int n, const SDiv& s) { return (int)fmaf((float)n, s.inv, s.half); }
-__device__ __forceinline__ int smod(int n, int q, const SDiv& s) { return n - __mul24(q, s.d); }
+__device__ __forceinline__ int smod(int n, int q, const SDiv& s) { return n - q * s.d; }
 // An index the compiler must treat as new at every use: with divisions this cheap it hoists every loop-invariant quotient out of the tile loop and
 // spills it (ffn_bwd_dw_kernel: 22 more scratch words, +12 % time) -- three instructions recomputed beat a scratch reload.
 __device__ __forceinline__ int tc_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
@@ -204,7 +208,7 @@ __device__ __forceinline__ tc_f32x2 gelu_f2_fast(tc_f32x2 x) { tc_f32x2 pdf; ret
 // Forward-only GELU of the 16-bit storage kernels (round 6).  Where only the VALUE is needed the Gaussian is not, and the normal CDF is smooth
 // enough for a polynomial:  Phi(x) ~ 0.5 + t P(t^2), t = clamp(x, -4.2, 4.2), P of degree 8 in t^2 fitted for the smallest maximum ABSOLUTE error
 // (scripts/exp/fit_phi_poly.py: 1.02e-5 over the whole line in fp32 Horner arithmetic; Phi(-4.2) = 1.3e-5 is the clamp's share).  Twelve full-rate
-// instructions per element against sixteen + v_exp_f32 + v_rcp_f32 (quarter rate): 30 against 58 SIMD-cycles per 64 elements
+// instructions per element against sixteen + v_exp_f32 + v_rcp_f32 (8.8 cycles each): 30 against 58 SIMD-cycles per 64 elements
 // (scripts/exp/valu_rate.hip).  The error is absolute, not relative: x Phi(x) is off by <= 1.02e-5 |x|, under 0.3 % of a bf16 / 2 % of an fp16
 // spacing wherever |GELU| >= 4e-3 -- below that (x < -2.8) the value is within 1.02e-5 |x| of the exact one instead of within an ulp of it.  The
 // backward kernels keep the A-S form: they need exp(-x^2 / 2) anyway and get Phi from it for three more instructions.
