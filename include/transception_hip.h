@@ -286,7 +286,11 @@ long long tc_ffn_mid_plan(const TcFfnSeg* segs, int nseg, int groups, int dtype,
  * w2 [C,4C]); res / out: pixel row r of group g at g*sres + r*ldr / g*sout + r*ldo (row blocks or column blocks of a wider buffer).
  * Optional outputs for the backward pass, contiguous [groups*B*H*W, 4C] in the storage type: h (fc1 output), d (dw3x3(h) + bias + h),
  * a (GELU(LN(d))); stat: fp32 [rows][2] = (mean, rstd) of the LayerNorm.  The hidden maps that are not asked for never leave LDS.
- * Replaces fc1 GEMM + tc_ffn_dw_fwd + (tc_layernorm_fwd) + fc2 GEMM of the op-by-op form. */
+ * Replaces fc1 GEMM + tc_ffn_dw_fwd + (tc_layernorm_fwd) + fc2 GEMM of the op-by-op form.
+ * GELU: the 16-bit kernels evaluate the normal CDF as a clamped odd polynomial (|error| <= 1.02e-5 absolute, csrc/tc_common.h gelu_poly) in
+ * every FORWARD use (here, the op-by-op LayerNorm + GELU, tc_gelu_fwd); the backward kernels and the fp32 path use the erf form.
+ * Ranges (TC_ERR_ARG beyond them; both tiled directions): B * tiles per image < 2^22, H * W < 2^23, H * W * ld < 2^31 -- the kernels form
+ * tile / pixel indices by fp32 floor((n + 0.5) / d) and per-image element offsets in 32 bits. */
 typedef struct TcFfnFused {
     const void* x; const void* w1; const void* b1; const void* wd; const void* bd; const void* gamma; const void* beta;
     const void* w2; const void* b2; const void* res; void* out; void* h; void* d; void* a; float* stat;
@@ -499,7 +503,8 @@ int tc_cam_bwd(const void* x, int ldx, const void* dy, int lddy, const float* at
 int tc_gamma_res_fwd(const void* a, int lda, const void* x, int ldx, const float* gamma, void* y, int ldy, int rows, int C, int dtype, void* stream);
 int tc_gamma_res_bwd(const void* dy, int lddy, const void* a, int lda, const float* gamma, void* da, int ldda, void* dx, int lddx, int dx_accumulate,
                      float* dgamma, int rows, int C, int dtype, void* stream);
-/* y = GELU(x) (exact erf form, nn.GELU()) and dz = dy * GELU'(x), elementwise (Conv3d + GELU of the "cam" aggregate, MSTr.py:625-628) */
+/* y = GELU(x) (nn.GELU(): exact erf form in fp32; bf16 / fp16 storage takes the polynomial CDF described at TcFfnFused, within 1.02e-5 |x| of
+ * it) and dz = dy * GELU'(x) (erf form), elementwise (Conv3d + GELU of the "cam" aggregate, MSTr.py:625-628) */
 int tc_gelu_fwd(const void* x, void* y, long long n, int dtype, void* stream);
 int tc_gelu_bwd(const void* dy, const void* x, void* dz, long long n, int dtype, void* stream);
 
@@ -536,7 +541,8 @@ int tc_pixel_shuffle(const void* in, void* out, int B, int H, int W, int p, int 
                      void* stream);
 /* Non-overlapping patch gather for the k=s patchify convs of Scale_reduce, MSTr.py:2215-2217,2233-2235:
  *   fwd: map [B,H,W,C] (batch stride sb_map, pixel stride ld_map) -> cols [B*(H/k)*(W/k), k*k*C] ordered (c,ky,kx) = the conv weight's [O, I*k*k] view;
- *   inverse=1 scatters cols back (the input gradient); inverse=2 adds them onto the map. */
+ *   inverse=1 scatters cols back (the input gradient); inverse=2 adds them onto the map.
+ *   16-bit storage with k = 2 / 4 / 8 and 16-byte aligned buffers moves whole 4 / 8 / 16-byte pieces (one filter row of a patch x four channels per thread). */
 int tc_patchify(const void* map, long long sb_map, int ld_map, void* cols, int B, int H, int W, int C, int k,
                 int inverse, int dtype, void* stream);
 /* Channel de-interleave of Scale_reduce (Appendix C.4): out[b, g*P+pos, c] = in[b, pos, c*mult+g];
